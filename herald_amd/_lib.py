@@ -1,0 +1,118 @@
+"""ctypes binding of libherald_amd.so (the C-ABI of include/herald_amd.h).
+
+The library is the product: if it is missing or a symbol is absent this module raises -- there is
+no CPU or PyTorch fallback anywhere in herald_amd.
+"""
+import ctypes
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libherald_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "herald_amd.h")
+
+_lib = None
+
+
+class HeraldAmdError(RuntimeError):
+    pass
+
+
+class DLContext(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int), ("device_type", ctypes.c_int)]
+
+
+class DLArray(ctypes.Structure):
+    """Mirror of the reference's DLArray (src/common/dlarray.h:40-55; python/hetu/ndarray.py:54-60)."""
+    _fields_ = [("data", ctypes.c_void_p), ("ctx", DLContext), ("ndim", ctypes.c_int),
+                ("shape", ctypes.POINTER(ctypes.c_int64)), ("stride", ctypes.POINTER(ctypes.c_int64))]
+
+
+class DLStream(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int), ("handle", ctypes.c_void_p)]
+
+
+class PlanView(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int64), ("n_unique", ctypes.c_void_p), ("keys", ctypes.c_void_p),
+                ("sorted", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("inverse", ctypes.c_void_p),
+                ("uniq", ctypes.c_void_p), ("counts", ctypes.c_void_p), ("seg", ctypes.c_void_p),
+                ("upos", ctypes.c_void_p)]
+
+
+def declared_symbols():
+    """Names of every function include/herald_amd.h declares."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def load(build_if_missing=True):
+    """Load libherald_amd.so; torch is imported first so both share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64.so.7 before ours is resolved)
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise HeraldAmdError("libherald_amd.so is not built (%s)" % LIB_PATH)
+        from . import _build
+        _build.build_lib()
+    try:
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:
+        raise HeraldAmdError("cannot load %s: %s" % (LIB_PATH, e))
+    _declare(L)
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ha_last_error().decode("utf-8", "replace")
+        raise HeraldAmdError("%s failed: %s" % (what or "herald_amd call", msg))
+
+
+def _declare(L):
+    c = ctypes
+    vp, i64, f32, sz = c.c_void_p, c.c_int64, c.c_float, c.c_size_t
+    L.ha_version.restype = c.c_char_p
+    L.ha_last_error.restype = c.c_char_p
+    L.ha_device_count.restype = c.c_int
+    L.ha_plan_bytes.restype = sz
+    L.ha_plan_bytes.argtypes = [i64]
+    L.ha_plan_view_of.argtypes = [vp, i64, c.POINTER(PlanView)]
+    sigs = {
+        "ha_gather_f32ids": [vp, i64, i64, vp, i64, vp, vp],
+        "ha_gather_u64ids": [vp, i64, i64, vp, i64, vp, vp],
+        "ha_gather_u32keys": [vp, i64, i64, vp, i64, vp, vp],
+        "ha_scatter_rows_f32ids": [vp, vp, i64, i64, vp, i64, vp],
+        "ha_plan_build_f32ids": [vp, i64, vp, vp],
+        "ha_plan_build_u64ids": [vp, i64, vp, vp],
+        "ha_plan_build_u32keys": [vp, i64, vp, c.c_int, vp],
+        "ha_plan_export_f32": [vp, i64, vp, vp, vp],
+        "ha_dedup_reduce": [vp, i64, vp, i64, vp, vp],
+        "ha_sgd_apply": [vp, i64, i64, vp, i64, vp, f32, vp],
+        "ha_push_apply": [vp, i64, i64, vp, i64, vp, vp],
+        "ha_sgd_sparse_update_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = c.c_int
+    A, S = c.POINTER(DLArray), c.POINTER(DLStream)
+    dl = {
+        "DLGpuEmbeddingLookUp": [A, A, A, S],
+        "DLGpuEmbeddingLookUp_Gradient": [A, A, A, S],
+        "IndexedSlicesOneSideAdd": [A, A, A, S],
+        "DeduplicateIndexedSlices": [A, A, A, S],
+        "IndexedSlices2Dense": [A, A, A, S],
+        "SGDOptimizerSparseUpdate": [A, A, A, f32, S],
+    }
+    for name, args in dl.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = c.c_int

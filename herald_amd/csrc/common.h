@@ -1,0 +1,91 @@
+// Shared host/device helpers for the herald_amd HIP sources (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/herald_amd.h"
+
+namespace ha {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define HA_CHECK_HIP(expr)                                                     \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) {                                                \
+            ::ha::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,      \
+                            hipGetErrorString(_e));                            \
+            return -1;                                                         \
+        }                                                                      \
+    } while (0)
+
+#define HA_REQUIRE(cond, ...)                                                  \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            ::ha::set_error(__VA_ARGS__);                                      \
+            return -1;                                                         \
+        }                                                                      \
+    } while (0)
+
+#define HA_LAUNCH_CHECK() HA_CHECK_HIP(hipGetLastError())
+
+static inline hipStream_t as_stream(ha_stream_t s) {
+    return reinterpret_cast<hipStream_t>(s);
+}
+static inline hipStream_t dl_stream(DLStreamHandle h) {
+    // reference: *(cudaStream_t *)stream_handle->handle (src/ops/EmbeddingLookup.cu:46)
+    if (h == nullptr || h->handle == nullptr)
+        return nullptr;
+    return *reinterpret_cast<hipStream_t *>(h->handle);
+}
+static inline int64_t dl_numel(const DLArray *a) {
+    int64_t n = 1;
+    for (int i = 0; i < a->ndim; ++i)
+        n *= a->shape[i];
+    return n;
+}
+
+static inline size_t align_up(size_t x, size_t a) {
+    return (x + a - 1) / a * a;
+}
+
+// ---- device helpers -------------------------------------------------------
+// (size_t)f of the reference (src/dnnl_ops/EmbeddingLookup.cpp:31) for the ids a
+// table can hold: truncation toward zero, ids < 2^32.
+__device__ __forceinline__ uint32_t f32_to_key(float f) {
+    return static_cast<uint32_t>(f);
+}
+
+__device__ __forceinline__ int lane_id() {
+    return threadIdx.x & (kWave - 1);
+}
+
+// Wave-uniform value -> SGPR.
+__device__ __forceinline__ int uniform(int v) {
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ uint32_t uniform(uint32_t v) {
+    return static_cast<uint32_t>(
+        __builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+}
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4v ld4(const float *p) {
+    return *reinterpret_cast<const float4v *>(p);
+}
+__device__ __forceinline__ void st4(float *p, float4v v) {
+    *reinterpret_cast<float4v *>(p) = v;
+}
+__device__ __forceinline__ void st4_nt(float *p, float4v v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(p));
+}
+
+}  // namespace ha

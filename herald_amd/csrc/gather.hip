@@ -1,0 +1,188 @@
+// Forward sparse gather: out[i,:] = table[(size_t)ids[i],:].
+//
+// Replaces cpu_EmbeddingLookup (reference src/dnnl_ops/EmbeddingLookup.cpp:16-35: OpenMP
+// memcpy per id) and embedding_lookup_kernel (src/ops/EmbeddingLookup.cu:3-14: one
+// thread per id looping over the row, i.e. lanes stride `width` floats apart).
+//
+// MI355X layout: the output is viewed as a flat array of 16-byte vectors; lane e copies
+// vector e, so a wavefront moves 1 KiB of one (or two adjacent) output row(s) per
+// instruction, and the matching table reads are 1 KiB contiguous pieces of the source
+// row(s).  Every thread keeps UNROLL independent 16-byte loads in flight before its
+// first store.  Output stores are non-temporal: the gathered rows are consumed by a
+// different kernel (the dense network) and should not evict table rows from L2.
+//
+// Algorithmic bytes per id: 4 (id) + 4*width (row read) + 4*width (row write).
+#include "common.h"
+
+namespace ha {
+
+template <typename IdT>
+__device__ __forceinline__ uint64_t id_to_row(IdT v);
+template <>
+__device__ __forceinline__ uint64_t id_to_row<float>(float v) {
+    return static_cast<uint64_t>(f32_to_key(v));
+}
+template <>
+__device__ __forceinline__ uint64_t id_to_row<uint64_t>(uint64_t v) {
+    return v;
+}
+template <>
+__device__ __forceinline__ uint64_t id_to_row<uint32_t>(uint32_t v) {
+    return v;
+}
+
+// NV_SHIFT >= 0: vectors per row is 1 << NV_SHIFT (shift/mask instead of div/mod).
+template <typename IdT, int UNROLL, int NV_SHIFT>
+__global__ __launch_bounds__(256) void gather_vec4_kernel(
+    const float *__restrict__ table, uint64_t rows, uint32_t nv,
+    const IdT *__restrict__ ids, uint64_t total_vec, float *__restrict__ out) {
+    const uint64_t base =
+        static_cast<uint64_t>(blockIdx.x) * (256u * UNROLL) + threadIdx.x;
+    float4v v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint64_t e = base + static_cast<uint64_t>(u) * 256u;
+        v[u] = float4v{0.f, 0.f, 0.f, 0.f};
+        if (e < total_vec) {
+            uint64_t i, c;
+            if (NV_SHIFT >= 0) {
+                i = e >> NV_SHIFT;
+                c = e & ((1u << NV_SHIFT) - 1u);
+            } else {
+                i = e / nv;
+                c = e - i * nv;
+            }
+            const uint64_t r = id_to_row<IdT>(ids[i]);
+            if (r < rows)
+                v[u] = ld4(table + (r * nv + c) * 4u);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint64_t e = base + static_cast<uint64_t>(u) * 256u;
+        if (e < total_vec)
+            st4_nt(out + e * 4u, v[u]);
+    }
+}
+
+// Any width (not a multiple of 4, or unaligned buffers): one float per lane.
+template <typename IdT>
+__global__ __launch_bounds__(256) void gather_scalar_kernel(
+    const float *__restrict__ table, uint64_t rows, uint32_t width,
+    const IdT *__restrict__ ids, uint64_t total, float *__restrict__ out) {
+    uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
+    for (; e < total; e += stride) {
+        const uint64_t i = e / width;
+        const uint64_t c = e - i * width;
+        const uint64_t r = id_to_row<IdT>(ids[i]);
+        out[e] = r < rows ? table[r * width + c] : 0.f;
+    }
+}
+
+template <typename IdT>
+static int gather_launch(const float *table, int64_t rows, int64_t width,
+                         const IdT *ids, int64_t n, float *out,
+                         hipStream_t stream) {
+    HA_REQUIRE(rows >= 0 && width >= 1 && n >= 0,
+               "gather: bad sizes rows=%ld width=%ld n=%ld", (long)rows,
+               (long)width, (long)n);
+    if (n == 0)
+        return 0;
+    HA_REQUIRE(table && ids && out, "gather: null pointer");
+    const bool vec_ok = (width % 4 == 0) &&
+                        (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    if (!vec_ok) {
+        const uint64_t total = static_cast<uint64_t>(n) * width;
+        uint64_t blocks = (total + 255) / 256;
+        if (blocks > 16384)
+            blocks = 16384;
+        hipLaunchKernelGGL(gather_scalar_kernel<IdT>, dim3((unsigned)blocks),
+                           dim3(256), 0, stream, table, (uint64_t)rows,
+                           (uint32_t)width, ids, total, out);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
+    const uint32_t nv = static_cast<uint32_t>(width / 4);
+    const uint64_t total_vec = static_cast<uint64_t>(n) * nv;
+    constexpr int UNROLL = 4;
+    const uint64_t blocks64 = (total_vec + 256 * UNROLL - 1) / (256 * UNROLL);
+    HA_REQUIRE(blocks64 < (1ull << 31), "gather: batch too large");
+    const dim3 grid(static_cast<unsigned>(blocks64)), block(256);
+#define HA_GATHER_CASE(S)                                                      \
+    hipLaunchKernelGGL((gather_vec4_kernel<IdT, UNROLL, S>), grid, block, 0,   \
+                       stream, table, (uint64_t)rows, nv, ids, total_vec, out)
+    switch (nv) {
+    case 4: HA_GATHER_CASE(2); break;     // width 16
+    case 8: HA_GATHER_CASE(3); break;     // width 32
+    case 16: HA_GATHER_CASE(4); break;    // width 64
+    case 32: HA_GATHER_CASE(5); break;    // width 128
+    case 64: HA_GATHER_CASE(6); break;    // width 256
+    case 128: HA_GATHER_CASE(7); break;   // width 512
+    case 256: HA_GATHER_CASE(8); break;   // width 1024
+    default: HA_GATHER_CASE(-1); break;
+    }
+#undef HA_GATHER_CASE
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// new_values[(int)ids[i], :] = values[i, :]  (indexedslices2dense_kernel,
+// reference src/ops/OptimizersSparse.cu:233-246; ids are deduplicated by the caller)
+template <typename IdT>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(
+    const float *__restrict__ values, const IdT *__restrict__ ids,
+    uint64_t total, uint32_t width, uint64_t rows, float *__restrict__ dst) {
+    uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
+    for (; e < total; e += stride) {
+        const uint64_t i = e / width;
+        const uint64_t c = e - i * width;
+        const uint64_t r = id_to_row<IdT>(ids[i]);
+        if (r < rows)
+            dst[r * width + c] = values[e];
+    }
+}
+
+}  // namespace ha
+
+extern "C" int ha_scatter_rows_f32ids(const float *values, const float *ids,
+                                      int64_t n, int64_t width, float *dst,
+                                      int64_t rows, ha_stream_t stream) {
+    HA_REQUIRE(n >= 0 && width >= 1 && rows >= 0, "scatter_rows: bad sizes");
+    if (n == 0)
+        return 0;
+    HA_REQUIRE(values && ids && dst, "scatter_rows: null pointer");
+    const uint64_t total = static_cast<uint64_t>(n) * width;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 16384)
+        blocks = 16384;
+    hipLaunchKernelGGL(ha::scatter_rows_kernel<float>, dim3((unsigned)blocks),
+                       dim3(256), 0, ha::as_stream(stream), values, ids, total,
+                       (uint32_t)width, (uint64_t)rows, dst);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ha_gather_f32ids(const float *table, int64_t rows, int64_t width,
+                                const float *ids, int64_t n, float *out,
+                                ha_stream_t stream) {
+    return ha::gather_launch<float>(table, rows, width, ids, n, out,
+                                    ha::as_stream(stream));
+}
+
+extern "C" int ha_gather_u64ids(const float *table, int64_t rows, int64_t width,
+                                const uint64_t *ids, int64_t n, float *out,
+                                ha_stream_t stream) {
+    return ha::gather_launch<uint64_t>(table, rows, width, ids, n, out,
+                                       ha::as_stream(stream));
+}
+
+extern "C" int ha_gather_u32keys(const float *table, int64_t rows,
+                                 int64_t width, const uint32_t *keys, int64_t n,
+                                 float *out, ha_stream_t stream) {
+    return ha::gather_launch<uint32_t>(table, rows, width, keys, n, out,
+                                       ha::as_stream(stream));
+}

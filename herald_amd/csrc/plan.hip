@@ -1,0 +1,631 @@
+// Index plan: per-batch sorted-unique / inverse / counts / occurrence lists of the ids.
+//
+// Reference semantics reproduced bit-exactly (integer work):
+//   * np.unique(ids, return_inverse=True)      python/hetu/ndarray.py:534,559
+//   * hetu::Unique<T> (argsort + map)           src/hetu_cache/include/unqiue_tools.h:9-48
+//   * std::map<idx, vector<pos>> dedup          ps-lite/include/ps/worker/PSAgent.h:124-183
+// All three produce ASCENDING distinct keys, an inverse map, and (implicitly) the list of
+// occurrence positions of each key in ascending position order.  The plan materialises
+// exactly that:  sorted keys, a STABLE argsort `perm`, segment offsets `seg`, `uniq`,
+// `counts`, `inverse`, and `upos` (unique index of every sorted position).
+//
+// Two sort engines:
+//   n <= kSmallMax : rank-by-counting.  Every 1024-thread workgroup stages all keys in LDS and
+//                    computes the final stable rank of 64 elements by comparing them against all
+//                    n keys (16 waves split the j-range, partial ranks are summed through LDS).
+//                    One launch, no inter-workgroup communication, O(n^2/64) VALU wave-instructions
+//                    spread over ceil(n/64) CUs: ~2 us for the 6,656-id wdl_criteo batch, where a
+//                    multi-pass radix sort would pay >= 12 dependent kernel boundaries.
+//   larger n       : LSD radix sort, 8-bit digits, wave-ballot multisplit ranking (stable).
+#include "common.h"
+
+namespace ha {
+
+constexpr int kSmallMax = 15360;     // rank-by-counting up to here (keys + partial ranks = 64 KiB LDS)
+constexpr uint32_t kPadKey = 0xFFFFFFFFu;
+
+struct PlanHeader {
+    int64_t n_unique;
+    int64_t reserved[31];
+};
+static_assert(sizeof(PlanHeader) == 256, "plan header is one 256-byte line");
+
+struct PlanPtrs {
+    PlanHeader *hdr;
+    uint32_t *keys, *sorted, *uniq;
+    int32_t *perm, *inverse, *counts, *seg, *upos;
+    // radix scratch
+    uint32_t *keys_alt;
+    int32_t *perm_alt;
+    uint32_t *hist;        // [256 * nblocks]
+    uint32_t *block_sums;  // finish scan scratch
+    size_t bytes;
+};
+
+constexpr int kRadixTile = 4096;  // keys per workgroup per radix pass
+constexpr int kFinishTile = 8192; // sorted positions per workgroup in the finish pass
+
+static PlanPtrs plan_layout(void *ws, int64_t n) {
+    PlanPtrs p;
+    char *b = static_cast<char *>(ws);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *r = b ? b + off : nullptr;
+        off += align_up(bytes, 256);
+        return r;
+    };
+    const size_t n4 = static_cast<size_t>(n) * 4;
+    p.hdr = reinterpret_cast<PlanHeader *>(take(sizeof(PlanHeader)));
+    p.keys = reinterpret_cast<uint32_t *>(take(n4));
+    p.sorted = reinterpret_cast<uint32_t *>(take(n4));
+    p.uniq = reinterpret_cast<uint32_t *>(take(n4));
+    p.perm = reinterpret_cast<int32_t *>(take(n4));
+    p.inverse = reinterpret_cast<int32_t *>(take(n4));
+    p.counts = reinterpret_cast<int32_t *>(take(n4));
+    p.seg = reinterpret_cast<int32_t *>(take(n4 + 4));
+    p.upos = reinterpret_cast<int32_t *>(take(n4));
+    p.keys_alt = reinterpret_cast<uint32_t *>(take(n4));
+    p.perm_alt = reinterpret_cast<int32_t *>(take(n4));
+    const size_t nblk = (static_cast<size_t>(n) + kRadixTile - 1) / kRadixTile;
+    p.hist = reinterpret_cast<uint32_t *>(take((nblk * 256 + 1) * 4));
+    const size_t nfin = (static_cast<size_t>(n) + kFinishTile - 1) / kFinishTile;
+    p.block_sums = reinterpret_cast<uint32_t *>(take((nfin + 1) * 4));
+    p.bytes = off;
+    return p;
+}
+
+template <typename IdT>
+__device__ __forceinline__ uint32_t to_key(IdT v);
+template <>
+__device__ __forceinline__ uint32_t to_key<float>(float v) {
+    const uint32_t k = f32_to_key(v);
+    return k == kPadKey ? 0xFFFFFFFEu : k;  // keep the pad value out of the key space
+}
+template <>
+__device__ __forceinline__ uint32_t to_key<uint64_t>(uint64_t v) {
+    return v > 0xFFFFFFFEull ? 0xFFFFFFFEu : static_cast<uint32_t>(v);
+}
+template <>
+__device__ __forceinline__ uint32_t to_key<uint32_t>(uint32_t v) {
+    return v;
+}
+
+// ===========================================================================
+// Small path: stable rank by counting.
+// ===========================================================================
+template <typename IdT>
+__global__ __launch_bounds__(1024) void plan_rank_small_kernel(
+    const IdT *__restrict__ ids, int n, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ sorted, int32_t *__restrict__ perm) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    const int npad = (n + 63) & ~63;
+    uint32_t *s_keys = s_mem;            // [npad]
+    uint32_t *s_part = s_mem + npad;     // [16][64]
+
+    for (int j = threadIdx.x; j < npad; j += 1024)
+        s_keys[j] = j < n ? to_key<IdT>(ids[j]) : kPadKey;
+    __syncthreads();
+
+    const int lane = lane_id();
+    const int w = uniform(static_cast<int>(threadIdx.x >> 6));
+    const int i0 = blockIdx.x * 64;
+    const int i = i0 + lane;
+    const uint32_t ki = s_keys[i];  // i < npad always (grid = npad/64)
+
+    // j-range of this wave, in units of 4 keys (one ds_read_b128 broadcast)
+    const int chunks = npad >> 2;
+    const int cpw = (chunks + 15) >> 4;
+    const int jbeg = min(npad, w * cpw * 4);
+    const int jend = min(npad, jbeg + cpw * 4);
+
+    uint32_t rank = 0;
+    // (a) j entirely before the i-tile: equal keys at smaller positions sort first -> "<="
+    {
+        const int e = min(jend, i0);
+        for (int j = jbeg; j < e; j += 4) {
+            const uint4 k = *reinterpret_cast<const uint4 *>(s_keys + j);
+            rank += (k.x <= ki);
+            rank += (k.y <= ki);
+            rank += (k.z <= ki);
+            rank += (k.w <= ki);
+        }
+    }
+    // (b) the diagonal: j inside the i-tile
+    {
+        const int b = max(jbeg, i0), e = min(jend, i0 + 64);
+        for (int j = b; j < e; j += 4) {
+            const uint4 k = *reinterpret_cast<const uint4 *>(s_keys + j);
+            rank += (k.x < ki) || (k.x == ki && (j + 0) < i);
+            rank += (k.y < ki) || (k.y == ki && (j + 1) < i);
+            rank += (k.z < ki) || (k.z == ki && (j + 2) < i);
+            rank += (k.w < ki) || (k.w == ki && (j + 3) < i);
+        }
+    }
+    // (c) j entirely after the i-tile -> "<"
+    {
+        const int b = max(jbeg, i0 + 64);
+        for (int j = b; j < jend; j += 4) {
+            const uint4 k = *reinterpret_cast<const uint4 *>(s_keys + j);
+            rank += (k.x < ki);
+            rank += (k.y < ki);
+            rank += (k.z < ki);
+            rank += (k.w < ki);
+        }
+    }
+    s_part[w * 64 + lane] = rank;
+    __syncthreads();
+    if (w == 0 && i < n) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            r += s_part[k * 64 + lane];
+        sorted[r] = ki;
+        perm[r] = i;
+        keys[i] = ki;
+    }
+}
+
+// ===========================================================================
+// General path: LSD radix sort (8-bit digits), stable.
+// ===========================================================================
+template <typename IdT>
+__global__ __launch_bounds__(256) void plan_convert_kernel(
+    const IdT *__restrict__ ids, int n, uint32_t *__restrict__ keys) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int stride = gridDim.x * 256;
+    for (; i < n; i += stride)
+        keys[i] = to_key<IdT>(ids[i]);
+}
+
+// per-block digit histogram; hist[d * nblk + blk]
+__global__ __launch_bounds__(256) void radix_hist_kernel(
+    const uint32_t *__restrict__ keys, int n, int shift, int nblk,
+    uint32_t *__restrict__ hist) {
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kRadixTile;
+    const int end = min(n, base + kRadixTile);
+    for (int j = base + threadIdx.x; j < end; j += 256)
+        atomicAdd(&s_h[(keys[j] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist[threadIdx.x * nblk + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// exclusive scan of `m` uint32 values in place, single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void scan_exclusive_kernel(
+    uint32_t *__restrict__ data, int m, uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0)
+        s_carry = 0;
+    __syncthreads();
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (int base = 0; base < m; base += 1024) {
+        const int j = base + threadIdx.x;
+        const uint32_t v = j < m ? data[j] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o)
+                x += y;
+        }
+        if (lane == 63)
+            s_w[w] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k)
+            woff += s_w[k];
+        const uint32_t carry = s_carry;
+        if (j < m)
+            data[j] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            s_carry = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out)
+        *total_out = s_carry;
+}
+
+// stable scatter of one digit pass.  Each of the 4 waves owns a contiguous quarter of the tile
+// and walks it in rows of 64 keys; within a row, lanes with equal digits are ranked by a
+// ballot match (8 ballots), the per-wave running digit counters live in LDS.
+__global__ __launch_bounds__(256) void radix_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ perm_in,
+    int n, int shift, int nblk, const uint32_t *__restrict__ hist,
+    uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out) {
+    constexpr int kRows = kRadixTile / 256;  // rows of 64 keys per wave
+    __shared__ uint32_t s_cnt[4][256];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < 4 * 256; k += 256)
+        (&s_cnt[0][0])[k] = 0;
+    __syncthreads();
+
+    const int wbase = blockIdx.x * kRadixTile + w * (kRows * 64);
+    uint32_t key[kRows];
+    int32_t val[kRows];
+    uint32_t lrank[kRows];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int j = wbase + r * 64 + lane;
+        const bool ok = j < n;
+        key[r] = ok ? keys_in[j] : 0u;
+        val[r] = ok ? (perm_in ? perm_in[j] : j) : 0;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long m = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        // m: valid lanes with my digit
+        const uint32_t before = __popcll(m & lt_mask);
+        const uint32_t cnt = __popcll(m);
+        uint32_t basec = 0;
+        if (ok) {
+            basec = s_cnt[w][d];
+        }
+        lrank[r] = basec + before;
+        // all lanes of the group have read basec before the leader bumps it
+        __builtin_amdgcn_wave_barrier();
+        if (ok && before == 0)
+            s_cnt[w][d] = basec + cnt;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // digit d = threadIdx.x: exclusive prefix over the 4 waves + global base
+    {
+        const int d = threadIdx.x;
+        uint32_t run = hist[d * nblk + blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = s_cnt[k][d];
+            s_cnt[k][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int j = wbase + r * 64 + lane;
+        if (j < n) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t pos = s_cnt[w][d] + lrank[r];
+            keys_out[pos] = key[r];
+            perm_out[pos] = val[r];
+        }
+    }
+}
+
+// ===========================================================================
+// Finish: head flags -> scan -> uniq / seg / counts / inverse / upos.
+// ===========================================================================
+// Phase 1 (multi-block): number of heads per tile of kFinishTile sorted positions.
+__global__ __launch_bounds__(1024) void finish_count_kernel(
+    const uint32_t *__restrict__ sorted, int n,
+    uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t s_w[16];
+    const int base = blockIdx.x * kFinishTile;
+    uint32_t c = 0;
+    for (int k = 0; k < kFinishTile / 1024; ++k) {
+        const int p = base + k * 1024 + threadIdx.x;
+        if (p < n)
+            c += (p == 0 || sorted[p] != sorted[p - 1]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        c += __shfl_down(c, o, 64);
+    if (lane_id() == 0)
+        s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < 16; ++k)
+            t += s_w[k];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// Phase 2 (multi-block): block_sums has been exclusively scanned; block_sums[nblocks] = U.
+// Each thread owns 8 CONSECUTIVE sorted positions.
+__global__ __launch_bounds__(1024) void finish_write_kernel(
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    int n, const uint32_t *__restrict__ block_sums, int nblocks,
+    PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
+    int32_t *__restrict__ seg, int32_t *__restrict__ inverse,
+    int32_t *__restrict__ upos) {
+    constexpr int kItems = kFinishTile / 1024;
+    __shared__ uint32_t s_w[16];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int p0 = blockIdx.x * kFinishTile + threadIdx.x * kItems;
+    uint32_t key[kItems];
+    bool head[kItems];
+    uint32_t prev = (p0 > 0 && p0 - 1 < n) ? sorted[p0 - 1] : 0u;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int p = p0 + k;
+        key[k] = p < n ? sorted[p] : 0u;
+        head[k] = p < n && (p == 0 || key[k] != prev);
+        prev = key[k];
+        c += head[k];
+    }
+    uint32_t x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o)
+            x += y;
+    }
+    if (lane == 63)
+        s_w[w] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; ++k)
+        woff += s_w[k];
+    uint32_t u = block_sums[blockIdx.x] + woff + x - c;  // heads before my first item
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int p = p0 + k;
+        if (p < n) {
+            if (head[k]) {
+                uniq[u] = key[k];
+                seg[u] = p;
+                ++u;
+            }
+            const int32_t ui = static_cast<int32_t>(u) - 1;
+            upos[p] = ui;
+            inverse[perm[p]] = ui;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t U = block_sums[nblocks];
+        hdr->n_unique = U;
+        seg[U] = n;
+    }
+}
+
+// Phase 3: counts[u] = seg[u+1] - seg[u]
+__global__ __launch_bounds__(256) void finish_counts_kernel(
+    const PlanHeader *__restrict__ hdr, const int32_t *__restrict__ seg,
+    int32_t *__restrict__ counts, int n) {
+    const int U = static_cast<int>(hdr->n_unique);
+    int u = blockIdx.x * 256 + threadIdx.x;
+    const int stride = gridDim.x * 256;
+    for (; u < U; u += stride)
+        counts[u] = seg[u + 1] - seg[u];
+}
+
+// Small-n fused finish: one workgroup does phases 1-3 (n <= kSmallMax).
+__global__ __launch_bounds__(1024) void finish_small_kernel(
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    int n, PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
+    int32_t *__restrict__ seg, int32_t *__restrict__ counts,
+    int32_t *__restrict__ inverse, int32_t *__restrict__ upos) {
+    constexpr int kItems = kSmallMax / 1024;  // 15
+    __shared__ uint32_t s_w[16];
+    __shared__ uint16_t s_seg[kSmallMax + 2];  // positions <= 15360 fit 16 bits
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int p0 = threadIdx.x * kItems;
+    uint32_t key[kItems];
+    bool head[kItems];
+    uint32_t prev = (p0 > 0 && p0 - 1 < n) ? sorted[p0 - 1] : 0u;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int p = p0 + k;
+        key[k] = p < n ? sorted[p] : 0u;
+        head[k] = p < n && (p == 0 || key[k] != prev);
+        prev = key[k];
+        c += head[k];
+    }
+    uint32_t x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o)
+            x += y;
+    }
+    if (lane == 63)
+        s_w[w] = x;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < w)
+            woff += s_w[k];
+        total += s_w[k];
+    }
+    uint32_t u = woff + x - c;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int p = p0 + k;
+        if (p < n) {
+            if (head[k]) {
+                uniq[u] = key[k];
+                seg[u] = p;
+                s_seg[u] = static_cast<uint16_t>(p);
+                ++u;
+            }
+            const int32_t ui = static_cast<int32_t>(u) - 1;
+            upos[p] = ui;
+            inverse[perm[p]] = ui;
+        }
+    }
+    if (threadIdx.x == 0) {
+        hdr->n_unique = total;
+        seg[total] = n;
+        s_seg[total] = static_cast<uint16_t>(n);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < static_cast<int>(total); k += 1024)
+        counts[k] = static_cast<int32_t>(s_seg[k + 1]) - static_cast<int32_t>(s_seg[k]);
+}
+
+__global__ void plan_empty_kernel(PlanHeader *hdr, int32_t *seg) {
+    hdr->n_unique = 0;
+    seg[0] = 0;
+}
+
+template <typename IdT>
+static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
+                      hipStream_t stream) {
+    HA_REQUIRE(n >= 0 && n < (1ll << 31), "plan: bad n=%ld", (long)n);
+    HA_REQUIRE(ws != nullptr, "plan: null workspace");
+    PlanPtrs p = plan_layout(ws, n);
+    if (n == 0) {
+        hipLaunchKernelGGL(plan_empty_kernel, dim3(1), dim3(1), 0, stream,
+                           p.hdr, p.seg);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
+    HA_REQUIRE(ids != nullptr, "plan: null ids");
+    const int ni = static_cast<int>(n);
+    if (n <= kSmallMax) {
+        const int npad = (ni + 63) & ~63;
+        const size_t lds = (static_cast<size_t>(npad) + 16 * 64) * 4;
+        hipLaunchKernelGGL(plan_rank_small_kernel<IdT>, dim3(npad / 64),
+                           dim3(1024), lds, stream, ids, ni, p.keys, p.sorted,
+                           p.perm);
+        HA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(finish_small_kernel, dim3(1), dim3(1024), 0, stream,
+                           p.sorted, p.perm, ni, p.hdr, p.uniq, p.seg,
+                           p.counts, p.inverse, p.upos);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
+    // ---- radix path
+    {
+        int blocks = (ni + 255) / 256;
+        if (blocks > 4096)
+            blocks = 4096;
+        hipLaunchKernelGGL(plan_convert_kernel<IdT>, dim3(blocks), dim3(256),
+                           0, stream, ids, ni, p.keys);
+        HA_LAUNCH_CHECK();
+    }
+    const int nblk = (ni + kRadixTile - 1) / kRadixTile;
+    int passes = (key_bits + 7) / 8;
+    if (passes < 1)
+        passes = 1;
+    if (passes > 4)
+        passes = 4;
+    // Pass 0 reads `keys` (kept intact) with the identity permutation; pass k writes buffer
+    // B = (sorted, perm) when (passes-1-k) is even and A = (keys_alt, perm_alt) otherwise, so the
+    // last pass lands in B and consecutive passes never alias.
+    const uint32_t *kin = p.keys;
+    const int32_t *vin = nullptr;
+    for (int pass = 0; pass < passes; ++pass) {
+        const bool toB = ((passes - 1 - pass) & 1) == 0;
+        uint32_t *kout = toB ? p.sorted : p.keys_alt;
+        int32_t *vout = toB ? p.perm : p.perm_alt;
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, stream,
+                           kin, ni, shift, nblk, p.hist);
+        HA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0,
+                           stream, p.hist, 256 * nblk,
+                           static_cast<uint32_t *>(nullptr));
+        HA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0,
+                           stream, kin, vin, ni, shift, nblk, p.hist, kout,
+                           vout);
+        HA_LAUNCH_CHECK();
+        kin = kout;
+        vin = vout;
+    }
+    // ---- finish
+    const int nfin = (ni + kFinishTile - 1) / kFinishTile;
+    hipLaunchKernelGGL(finish_count_kernel, dim3(nfin), dim3(1024), 0, stream,
+                       p.sorted, ni, p.block_sums);
+    HA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream,
+                       p.block_sums, nfin, p.block_sums + nfin);
+    HA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_write_kernel, dim3(nfin), dim3(1024), 0, stream,
+                       p.sorted, p.perm, ni, p.block_sums, nfin, p.hdr, p.uniq,
+                       p.seg, p.inverse, p.upos);
+    HA_LAUNCH_CHECK();
+    {
+        int blocks = (ni + 255) / 256;
+        if (blocks > 2048)
+            blocks = 2048;
+        hipLaunchKernelGGL(finish_counts_kernel, dim3(blocks), dim3(256), 0,
+                           stream, p.hdr, p.seg, p.counts, ni);
+        HA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void plan_export_f32_kernel(
+    const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq,
+    const int32_t *__restrict__ inverse, int n, float *__restrict__ uniq_f32,
+    float *__restrict__ inverse_f32) {
+    const int U = static_cast<int>(hdr->n_unique);
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int stride = gridDim.x * 256;
+    for (; i < n; i += stride) {
+        if (uniq_f32 && i < U)
+            uniq_f32[i] = static_cast<float>(uniq[i]);
+        if (inverse_f32)
+            inverse_f32[i] = static_cast<float>(inverse[i]);
+    }
+}
+
+}  // namespace ha
+
+using namespace ha;
+
+extern "C" size_t ha_plan_bytes(int64_t n) {
+    if (n < 0)
+        n = 0;
+    return plan_layout(nullptr, n).bytes;
+}
+
+extern "C" int ha_plan_view_of(void *ws, int64_t n, ha_plan_view *view) {
+    HA_REQUIRE(ws && view && n >= 0, "plan_view_of: bad arguments");
+    PlanPtrs p = plan_layout(ws, n);
+    view->n = n;
+    view->n_unique = &p.hdr->n_unique;
+    view->keys = p.keys;
+    view->sorted = p.sorted;
+    view->perm = p.perm;
+    view->inverse = p.inverse;
+    view->uniq = p.uniq;
+    view->counts = p.counts;
+    view->seg = p.seg;
+    view->upos = p.upos;
+    return 0;
+}
+
+extern "C" int ha_plan_build_f32ids(const float *ids, int64_t n, void *ws,
+                                    ha_stream_t stream) {
+    return plan_build<float>(ids, n, ws, 32, as_stream(stream));
+}
+
+extern "C" int ha_plan_build_u64ids(const uint64_t *ids, int64_t n, void *ws,
+                                    ha_stream_t stream) {
+    return plan_build<uint64_t>(ids, n, ws, 32, as_stream(stream));
+}
+
+extern "C" int ha_plan_build_u32keys(const uint32_t *keys, int64_t n, void *ws,
+                                     int key_bits, ha_stream_t stream) {
+    return plan_build<uint32_t>(keys, n, ws, key_bits, as_stream(stream));
+}
+
+extern "C" int ha_plan_export_f32(const void *ws, int64_t n, float *uniq_f32,
+                                  float *inverse_f32, ha_stream_t stream) {
+    HA_REQUIRE(ws && n >= 0, "plan_export: bad arguments");
+    if (n == 0 || (!uniq_f32 && !inverse_f32))
+        return 0;
+    PlanPtrs p = plan_layout(const_cast<void *>(ws), n);
+    int blocks = static_cast<int>((n + 255) / 256);
+    if (blocks > 2048)
+        blocks = 2048;
+    hipLaunchKernelGGL(plan_export_f32_kernel, dim3(blocks), dim3(256), 0,
+                       as_stream(stream), p.hdr, p.uniq, p.inverse,
+                       static_cast<int>(n), uniq_f32, inverse_f32);
+    HA_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference's embedding operators, on torch-allocated device memory.
+
+Mirrors (reference paths relative to /root/reference):
+  embedding_lookup            python/hetu/gpu_links/EmbeddingLookUpLink.py:8-13 -> DLGpuEmbeddingLookUp
+  sgd_sparse_update           python/hetu/gpu_links/OptimizerLink.py:23-33      -> SGDOptimizerSparseUpdate
+  indexedslices_oneside_add   python/hetu/gpu_links/IndexedSlicesLink.py         -> IndexedSlicesOneSideAdd
+  IndexedSlices               python/hetu/ndarray.py:503-611 (deduplicate on the GPU instead of a
+                              host np.unique round trip)
+  IndexPlan                   the per-batch sorted-unique/inverse/counts plan (np.unique /
+                              hetu::Unique<T> semantics) that gather, dedup-reduce and apply share
+
+torch is plumbing only: it owns the device allocations and the stream; every computation below is a
+call into libherald_amd.so.  There is no fallback: a missing library raises HeraldAmdError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import DLArray, DLContext, DLStream, PlanView, check
+
+
+def _stream_ptr(stream=None):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    if isinstance(stream, int):
+        return ctypes.c_void_p(stream)
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _require(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/HIP torch tensor" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+# ---- DLArray plumbing (for the reference-named symbols) ------------------------------------------
+class DLHolder:
+    """Keeps the ctypes shape buffer alive next to the DLArray struct."""
+
+    def __init__(self, t):
+        self.tensor = t
+        self.shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+        self.arr = DLArray(ctypes.c_void_p(t.data_ptr()),
+                           DLContext(t.device.index or 0, 2 if t.is_cuda else 1), t.dim(),
+                           ctypes.cast(self.shape, ctypes.POINTER(ctypes.c_int64)), None)
+
+    @property
+    def handle(self):
+        return ctypes.byref(self.arr)
+
+
+class DLStreamHolder:
+    """DLStream whose handle points AT a hipStream_t, as the reference expects
+    (`*(cudaStream_t *)stream_handle->handle`, src/ops/EmbeddingLookup.cu:46)."""
+
+    def __init__(self, stream=None):
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        self._raw = ctypes.c_void_p(stream.cuda_stream)
+        self.s = DLStream(stream.device.index or 0, ctypes.cast(ctypes.pointer(self._raw), ctypes.c_void_p))
+
+    @property
+    def handle(self):
+        return ctypes.byref(self.s)
+
+
+# ---- forward gather ----------------------------------------------------------------------------------
+def embedding_lookup(table, ids, out=None, stream=None):
+    """out[..., :] = table[(size_t)ids[...], :]; ids float32 (operator boundary) or int64/uint64 keys."""
+    L = _lib.load()
+    _require(table, torch.float32, "table")
+    if table.dim() != 2:
+        raise ValueError("table must be 2-D")
+    if not ids.is_cuda or not ids.is_contiguous():
+        raise ValueError("ids must be a contiguous device tensor")
+    width = table.shape[1]
+    if out is None:
+        out = torch.empty(tuple(ids.shape) + (width,), dtype=torch.float32, device=table.device)
+    _require(out, torch.float32, "out")
+    if out.numel() != ids.numel() * width:
+        raise ValueError("out has the wrong size")
+    if ids.dtype == torch.float32:
+        fn = L.ha_gather_f32ids
+    elif ids.dtype in (torch.int64, torch.uint64):
+        fn = L.ha_gather_u64ids
+    else:
+        raise TypeError("ids must be float32 or (u)int64")
+    check(fn(_ptr(table), table.shape[0], width, _ptr(ids), ids.numel(), _ptr(out), _stream_ptr(stream)),
+          "ha_gather")
+    return out
+
+
+# ---- index plan ----------------------------------------------------------------------------------------
+class IndexPlan:
+    """Device-resident np.unique(return_inverse, return_counts) + occurrence lists of one id batch."""
+
+    def __init__(self, capacity, device=None):
+        L = _lib.load()
+        self.capacity = int(capacity)
+        self.device = torch.device(device if device is not None else "cuda")
+        self.nbytes = L.ha_plan_bytes(self.capacity)
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.n = 0
+        self._view = None
+
+    def build(self, ids, stream=None):
+        L = _lib.load()
+        n = ids.numel()
+        if n > self.capacity:
+            raise ValueError("plan capacity %d < %d ids" % (self.capacity, n))
+        if not ids.is_cuda or not ids.is_contiguous():
+            raise ValueError("ids must be a contiguous device tensor")
+        # the workspace layout depends on n, so a view is per build
+        if ids.dtype == torch.float32:
+            rc = L.ha_plan_build_f32ids(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
+        elif ids.dtype in (torch.int64, torch.uint64):
+            rc = L.ha_plan_build_u64ids(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
+        else:
+            raise TypeError("ids must be float32 or (u)int64")
+        check(rc, "ha_plan_build")
+        self.n = n
+        self._view = None
+        return self
+
+    # -- typed views into the workspace (no copies) --
+    def view(self):
+        if self._view is None:
+            v = PlanView()
+            check(_lib.load().ha_plan_view_of(_ptr(self.ws), self.n, ctypes.byref(v)), "ha_plan_view_of")
+            self._view = v
+        return self._view
+
+    def _slice(self, addr, count, dtype):
+        itemsize = torch.empty(0, dtype=dtype).element_size()
+        off = addr - self.ws.data_ptr()
+        return self.ws[off:off + count * itemsize].view(dtype)
+
+    def n_unique(self):
+        """Host int (synchronises the current stream)."""
+        return int(self._slice(self.view().n_unique, 1, torch.int64).item())
+
+    def n_unique_dev(self):
+        return self._slice(self.view().n_unique, 1, torch.int64)
+
+    def keys(self):
+        return self._slice(self.view().keys, self.n, torch.int32)
+
+    def sorted_keys(self):
+        return self._slice(self.view().sorted, self.n, torch.int32)
+
+    def perm(self):
+        return self._slice(self.view().perm, self.n, torch.int32)
+
+    def inverse(self):
+        return self._slice(self.view().inverse, self.n, torch.int32)
+
+    def uniq(self, u=None):
+        u = self.n_unique() if u is None else u
+        return self._slice(self.view().uniq, u, torch.int32)
+
+    def counts(self, u=None):
+        u = self.n_unique() if u is None else u
+        return self._slice(self.view().counts, u, torch.int32)
+
+    def seg(self, u=None):
+        u = self.n_unique() if u is None else u
+        return self._slice(self.view().seg, u + 1, torch.int32)
+
+    def export_f32(self, stream=None):
+        """(uniq_f32[U], inverse_f32[n]) as IndexedSlices.deduplicate hands them on (ndarray.py:534-545)."""
+        u = self.n_unique()
+        uniq = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        inv = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        check(_lib.load().ha_plan_export_f32(_ptr(self.ws), self.n, _ptr(uniq), _ptr(inv),
+                                             _stream_ptr(stream)), "ha_plan_export_f32")
+        return uniq[:u], inv
+
+
+# ---- backward ---------------------------------------------------------------------------------------------
+def dedup_reduce(plan, grads, out=None, stream=None):
+    """reduced[u,:] = sum of grads rows of unique key u in occurrence order (cpu_deduplicate order)."""
+    _require(grads, torch.float32, "grads")
+    n = plan.n
+    width = grads.numel() // max(n, 1) if n else (grads.shape[-1] if grads.dim() else 1)
+    if out is None:
+        out = torch.empty((max(n, 1), width), dtype=torch.float32, device=grads.device)
+    check(_lib.load().ha_dedup_reduce(_ptr(plan.ws), n, _ptr(grads), width, _ptr(out), _stream_ptr(stream)),
+          "ha_dedup_reduce")
+    return out
+
+
+def sgd_apply(table, plan, grads, lr, stream=None):
+    """table[key,:] -= lr*grads[i,:] per occurrence, occurrence order (bit-exact cpu_SGDOptimizerSparseUpdate)."""
+    _require(table, torch.float32, "table")
+    _require(grads, torch.float32, "grads")
+    check(_lib.load().ha_sgd_apply(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws), plan.n,
+                                   _ptr(grads), ctypes.c_float(lr), _stream_ptr(stream)), "ha_sgd_apply")
+    return table
+
+
+def push_apply(table, plan, grads, stream=None):
+    """table[key,:] += (0 + g_i0 + g_i1 ...)  -- worker-side reduce + server-side `+=` of a sparse push."""
+    _require(table, torch.float32, "table")
+    _require(grads, torch.float32, "grads")
+    check(_lib.load().ha_push_apply(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws), plan.n,
+                                    _ptr(grads), _stream_ptr(stream)), "ha_push_apply")
+    return table
+
+
+def sgd_sparse_update(table, ids, grads, lr, stream=None):
+    """One call: plan + apply (reference SGDOptimizerSparseUpdate / cpu_SGDOptimizerSparseUpdate)."""
+    _require(table, torch.float32, "table")
+    _require(ids, torch.float32, "ids")
+    _require(grads, torch.float32, "grads")
+    check(_lib.load().ha_sgd_sparse_update_f32ids(_ptr(table), table.shape[0], table.shape[1], _ptr(ids),
+                                                  ids.numel(), _ptr(grads), ctypes.c_float(lr),
+                                                  _stream_ptr(stream)), "ha_sgd_sparse_update")
+    return table
+
+
+# ---- reference-named symbols through the DLArray ABI ---------------------------------------------
+def dl_call(name, arrays, scalars=(), stream=None):
+    """Call a reference-named symbol: arrays -> DLArray*, then scalars, then DLStream*."""
+    L = _lib.load()
+    holders = [DLHolder(a) for a in arrays]
+    sh = DLStreamHolder(stream)
+    args = [h.handle for h in holders] + list(scalars) + [sh.handle]
+    check(getattr(L, name)(*args), name)
+
+
+class IndexedSlices:
+    """Mirror of python/hetu/ndarray.py:503-611 with device-side dedup.
+
+    indices: float32 device tensor (any shape), values: float32 [..., width].
+    deduplicate() replaces (indices, values) by (sorted unique indices, occurrence-order row sums),
+    exactly what the reference computes with np.unique + DeduplicateIndexedSlices / cpu_deduplicate.
+    """
+
+    def __init__(self, indices=None, values=None, dense_shape=None, push_indices=None):
+        self.indices = indices
+        self.values = values
+        self.dense_shape = dense_shape
+        self.push_indices = push_indices
+        self.deduplicated = False
+
+    def get_dense_shape(self):
+        assert self.dense_shape is not None
+        return self.dense_shape
+
+    def get_sparse_shape(self):
+        return tuple(self.values.shape)
+
+    def update(self, indices, values, dense_shape, push_indices=None):
+        self.indices = indices
+        self.push_indices = push_indices
+        self.values = values
+        if self.dense_shape is not None:
+            assert tuple(self.dense_shape) == tuple(dense_shape)
+        else:
+            self.dense_shape = dense_shape
+        self.deduplicated = False
+
+    def deduplicate(self, stream=None):
+        ids = self.indices.reshape(-1)
+        n = ids.numel()
+        width = self.values.shape[-1]
+        plan = IndexPlan(max(n, 1), device=ids.device).build(ids, stream)
+        reduced = dedup_reduce(plan, self.values.reshape(n, width), stream=stream)
+        uniq_f32, _ = plan.export_f32(stream)
+        u = uniq_f32.numel()
+        self.indices = uniq_f32
+        self.values = reduced[:u]
+        if self.push_indices is not None:
+            pids = self.push_indices.reshape(-1)
+            pplan = IndexPlan(max(pids.numel(), 1), device=pids.device).build(pids, stream)
+            self.push_indices, _ = pplan.export_f32(stream)
+        self.deduplicated = True
+        return self
+
+    def to_dense(self, stream=None):
+        dense = torch.zeros(tuple(self.get_dense_shape()), dtype=torch.float32, device=self.values.device)
+        dl_call("IndexedSlices2Dense", [self.values.contiguous(), self.indices.contiguous(), dense],
+                stream=stream)
+        return dense

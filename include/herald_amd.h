@@ -1,0 +1,212 @@
+/*
+ * herald_amd.h -- C-ABI of the MI355X-native embedding-access engine.
+ *
+ * This is the drop-in boundary for Herald/Hetu's embedding hot path.  Two groups
+ * of entry points are exported by libherald_amd.so:
+ *
+ *  (1) Reference-named operator symbols, with the reference's DLArray/DLStream
+ *      calling convention, so the ctypes wrappers in python/hetu/gpu_links (ctypes) binds them
+ *      unchanged.  Each declaration cites the reference prototype it replaces.
+ *
+ *  (2) `ha_*` plain-pointer entry points (device pointers, sizes, a hipStream_t
+ *      passed as void*) that the reference-named symbols, the hetu_cache /
+ *      laia_cache plugin mirrors and the sharded store are built from.
+ *
+ * Conventions (same as the reference, src/common/c_runtime_api.h + runtime_base.h):
+ *   - return 0 on success, -1 on error (ha_last_error() holds the message);
+ *   - caller owns every buffer; the callee borrows it for the call;
+ *   - GPU work is asynchronous on the given stream; the caller synchronises;
+ *   - indices at the operator boundary are float32 (python/hetu/dataloader.py:14),
+ *     converted with (size_t)ids[i] semantics (src/dnnl_ops/EmbeddingLookup.cpp:31);
+ *   - all embedding values are float32, row-major [rows, width].
+ *
+ * No torch types appear here; PyTorch is only used by the Python host side to
+ * allocate device memory and provide streams.
+ */
+#ifndef HERALD_AMD_H_
+#define HERALD_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference ABI structs (src/common/dlarray.h:18-60) ------------------ */
+typedef enum { kCPU = 1, kGPU = 2 } DLDeviceType;
+typedef struct {
+    int device_id;
+    DLDeviceType device_type;
+} DLContext;
+typedef struct {
+    void *data;
+    DLContext ctx;
+    int ndim;
+    int64_t *shape;
+    int64_t *stride;
+} DLArray;
+typedef struct {
+    int device_id;
+    void *handle; /* points at a hipStream_t (reference: cudaStream_t*), may be NULL */
+} DLStream;
+typedef DLArray *DLArrayHandle;
+typedef DLStream *DLStreamHandle;
+
+typedef void *ha_stream_t; /* hipStream_t */
+
+/* ---- library / error handling ------------------------------------------- */
+const char *ha_version(void);
+const char *ha_last_error(void);
+/* Free the internal per-stream scratch used by the one-call reference-named ops. */
+int ha_scratch_release(void);
+/* Number of visible HIP devices (does not initialise a context beyond hipGetDeviceCount). */
+int ha_device_count(void);
+
+/* ========================================================================= *
+ * (1) Reference-named operator symbols
+ * ========================================================================= */
+
+/* src/common/c_runtime_api.h:308-310, src/ops/EmbeddingLookup.cu:16-52
+ * output[..., :] = input[(size_t)ids[...], :]                                */
+int DLGpuEmbeddingLookUp(const DLArrayHandle input, const DLArrayHandle ids,
+                         DLArrayHandle output, DLStreamHandle stream_handle);
+
+/* src/common/c_runtime_api.h:312-314, src/ops/EmbeddingLookup.cu:75-132
+ * input_grad = 0; input_grad[ids[i], :] += output_grad[i, :]  (dense result) */
+int DLGpuEmbeddingLookUp_Gradient(const DLArrayHandle output_grad,
+                                  const DLArrayHandle ids,
+                                  DLArrayHandle input_grad,
+                                  DLStreamHandle stream_handle);
+
+/* src/common/c_runtime_api.h:569-571, src/ops/IndexedSlices.cu:17-48
+ * output[indices[i], :] += values[i, :]                                      */
+int IndexedSlicesOneSideAdd(const DLArrayHandle indices,
+                            const DLArrayHandle values, DLArrayHandle output,
+                            DLStreamHandle stream_handle);
+
+/* src/common/c_runtime_api.h:700-702, src/ops/OptimizersSparse.cu:282-329
+ * compressed[(int)inverse[i], :] += origin[i, :]   (compressed pre-zeroed by caller) */
+int DeduplicateIndexedSlices(const DLArrayHandle origin,
+                             const DLArrayHandle inverse,
+                             DLArrayHandle compressed,
+                             DLStreamHandle stream_handle);
+
+/* src/common/c_runtime_api.h:704-706, src/ops/OptimizersSparse.cu:233-280
+ * new_values[(int)indices[i], :] = values[i, :]   (new_values pre-zeroed by caller) */
+int IndexedSlices2Dense(const DLArrayHandle values, const DLArrayHandle indices,
+                        DLArrayHandle new_values, DLStreamHandle stream_handle);
+
+/* src/common/c_runtime_api.h:645-648, src/ops/OptimizersSparse.cu:53-99
+ * param[indices[i], :] -= lr * values[i, :]; duplicates applied in occurrence
+ * order per row (bit-identical to cpu_SGDOptimizerSparseUpdate,
+ * src/dnnl_ops/Optimizers.cpp:51-74).                                         */
+int SGDOptimizerSparseUpdate(DLArrayHandle param,
+                             const DLArrayHandle grad_indices,
+                             const DLArrayHandle grad_values, float lr,
+                             DLStreamHandle stream_handle);
+
+/* ========================================================================= *
+ * (2) Plain-pointer engine entry points.  All pointers are DEVICE pointers
+ *     unless a parameter name ends in _host.
+ * ========================================================================= */
+
+/* ---- forward gather (replaces cpu_EmbeddingLookup / embedding_lookup_kernel) */
+/* out[i,:] = table[(size_t)ids[i],:], ids float32.  width % 4 == 0 takes the
+ * 16-byte vector path; any width >= 1 is supported.                          */
+int ha_gather_f32ids(const float *table, int64_t rows, int64_t width,
+                     const float *ids, int64_t n, float *out,
+                     ha_stream_t stream);
+/* Same with 64-bit keys (hetu_cache numpy-uint64 entry points, cache.cc:37-47). */
+int ha_gather_u64ids(const float *table, int64_t rows, int64_t width,
+                     const uint64_t *ids, int64_t n, float *out,
+                     ha_stream_t stream);
+int ha_gather_u32keys(const float *table, int64_t rows, int64_t width,
+                      const uint32_t *keys, int64_t n, float *out,
+                      ha_stream_t stream);
+
+/* dst[(size_t)ids[i],:] = values[i,:] (ids deduplicated by the caller; the body of
+ * IndexedSlices2Dense, src/ops/OptimizersSparse.cu:233-280). */
+int ha_scatter_rows_f32ids(const float *values, const float *ids, int64_t n,
+                           int64_t width, float *dst, int64_t rows,
+                           ha_stream_t stream);
+
+/* ---- index plan: sorted-unique + inverse + counts + occurrence lists ------
+ * Semantics of np.unique(ids, return_inverse=True, return_counts=True)
+ * (python/hetu/ndarray.py:534,559) == hetu::Unique<T> (unqiue_tools.h:27-48)
+ * == the std::map dedup of PSAgent::vecPushSparse (PSAgent.h:124-183):
+ *   uniq   : ascending distinct keys
+ *   inverse: inverse[i] = position of ids[i] in uniq
+ *   counts : occurrences of each unique key
+ *   perm   : stable argsort of ids (occurrence order inside a run of equal keys)
+ *   seg    : seg[u] = first sorted position of unique key u; seg[U] = n
+ * Keys are held as uint32 (tables up to 2^32-2 rows).
+ *
+ * A plan lives in a caller-provided device workspace of ha_plan_bytes(n) bytes
+ * laid out as struct ha_plan_view describes; it is valid until the workspace is
+ * reused.  n_unique is produced on the device (plan header) so that no host
+ * sync is needed between plan and the kernels that consume it.               */
+typedef struct {
+    int64_t n;           /* number of ids */
+    int64_t *n_unique;   /* device scalar (first word of the workspace) */
+    uint32_t *keys;      /* [n] ids converted to integer keys, original order */
+    uint32_t *sorted;    /* [n] keys ascending */
+    int32_t *perm;       /* [n] stable argsort: sorted[p] == keys[perm[p]] */
+    int32_t *inverse;    /* [n] */
+    uint32_t *uniq;      /* [n] first *n_unique valid */
+    int32_t *counts;     /* [n] first *n_unique valid */
+    int32_t *seg;        /* [n+1] first *n_unique+1 valid */
+    int32_t *upos;       /* [n] upos[p] = unique index of sorted position p */
+} ha_plan_view;
+
+size_t ha_plan_bytes(int64_t n);
+/* Fill `view` with the addresses of the sub-arrays of workspace `ws` (host-side
+ * pointer arithmetic only; no device access). */
+int ha_plan_view_of(void *ws, int64_t n, ha_plan_view *view);
+/* Build the plan from float32 ids / uint64 keys. */
+int ha_plan_build_f32ids(const float *ids, int64_t n, void *ws,
+                         ha_stream_t stream);
+int ha_plan_build_u64ids(const uint64_t *ids, int64_t n, void *ws,
+                         ha_stream_t stream);
+/* keys already integer; key_bits = number of significant key bits (radix passes). */
+int ha_plan_build_u32keys(const uint32_t *keys, int64_t n, void *ws,
+                          int key_bits, ha_stream_t stream);
+/* Export np.unique-style float32 results (what IndexedSlices.deduplicate hands to
+ * DeduplicateIndexedSlices): uniq_f32[U], inverse_f32[n].  Either may be NULL. */
+int ha_plan_export_f32(const void *ws, int64_t n, float *uniq_f32,
+                       float *inverse_f32, ha_stream_t stream);
+
+/* ---- backward: dedup-reduce and fused apply -------------------------------*/
+/* reduced[u,:] = sum over occurrences i of key u, in occurrence order, starting
+ * from 0.0f (IndexedSlices.cpu_deduplicate, python/hetu/ndarray.py:556-576;
+ * PSAgent::vecPushSparse; Line::accumulate).  reduced must hold n rows; the
+ * first *n_unique are written.  Deterministic, no atomics.                    */
+int ha_dedup_reduce(const void *plan_ws, int64_t n, const float *grads,
+                    int64_t width, float *reduced, ha_stream_t stream);
+
+/* table[key,:] -= lr * grads[i,:] for every occurrence i, applied per row in
+ * occurrence order with separate multiply and subtract roundings: the result is
+ * bit-identical to the serial loop of cpu_SGDOptimizerSparseUpdate
+ * (src/dnnl_ops/Optimizers.cpp:65-72).  Each unique row is read and written once. */
+int ha_sgd_apply(float *table, int64_t rows, int64_t width,
+                 const void *plan_ws, int64_t n, const float *grads, float lr,
+                 ha_stream_t stream);
+
+/* table[key,:] += scale * reduced_in_occurrence_order (PS push semantics:
+ * worker pre-multiplies by -lr, server does +=;
+ * ParameterServerCommunicate.py:58-59, PSFHandle.h:130-164).                  */
+int ha_push_apply(float *table, int64_t rows, int64_t width,
+                  const void *plan_ws, int64_t n, const float *grads,
+                  ha_stream_t stream);
+
+/* One-call convenience used by the reference-named SGDOptimizerSparseUpdate:
+ * plan + apply using an internal per-stream workspace. */
+int ha_sgd_sparse_update_f32ids(float *table, int64_t rows, int64_t width,
+                                const float *ids, int64_t n,
+                                const float *grads, float lr,
+                                ha_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HERALD_AMD_H_ */

@@ -1,0 +1,133 @@
+"""ctypes front-end of oracle/oracle.c plus numpy restatements of the reference's Python steps.
+
+TEST INFRASTRUCTURE ONLY (see oracle/oracle.c header).  Reference citations are relative to
+/root/reference.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "_build", "liboracle.so")
+        if not os.path.exists(path):
+            import sys
+            sys.path.insert(0, os.path.dirname(_HERE))
+            from herald_amd import _build
+            _build.build_oracle()
+        L = ctypes.CDLL(path)
+        c = ctypes
+        L.oracle_embedding_lookup.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_void_p]
+        L.oracle_sgd_sparse_update.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t,
+                                               c.c_void_p, c.c_float]
+        L.oracle_unique_u64.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p]
+        L.oracle_unique_u64.restype = c.c_size_t
+        L.oracle_ids_to_keys.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p]
+        L.oracle_dedup_reduce.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_size_t,
+                                          c.c_void_p]
+        L.oracle_push_apply.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_void_p]
+        L.oracle_partition.argtypes = [c.c_size_t, c.c_size_t, c.c_void_p]
+        L.oracle_num_threads.restype = c.c_int
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def embedding_lookup(table, ids):
+    """cpu_EmbeddingLookup (src/dnnl_ops/EmbeddingLookup.cpp:16-35)."""
+    table = _f32(table)
+    ids = _f32(ids)
+    out = np.empty(ids.shape + (table.shape[1],), dtype=np.float32)
+    lib().oracle_embedding_lookup(_p(table), table.shape[1], _p(ids), ids.size, _p(out))
+    return out
+
+
+def sgd_sparse_update(table, ids, grads, lr):
+    """cpu_SGDOptimizerSparseUpdate (src/dnnl_ops/Optimizers.cpp:51-74); updates `table` in place."""
+    assert table.dtype == np.float32 and table.flags.c_contiguous
+    ids = _f32(ids)
+    grads = _f32(grads)
+    lib().oracle_sgd_sparse_update(_p(table), table.shape[1], _p(ids), ids.size, _p(grads),
+                                   ctypes.c_float(lr))
+    return table
+
+
+def ids_to_keys(ids):
+    ids = _f32(ids).reshape(-1)
+    keys = np.empty(ids.size, dtype=np.uint64)
+    lib().oracle_ids_to_keys(_p(ids), ids.size, _p(keys))
+    return keys
+
+
+def unique(keys):
+    """hetu::Unique<T> / np.unique(return_inverse, return_counts): (uniq, inverse, counts)."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1)
+    n = keys.size
+    uniq = np.empty(n, dtype=np.uint64)
+    inverse = np.empty(n, dtype=np.int64)
+    counts = np.empty(n, dtype=np.int64)
+    u = lib().oracle_unique_u64(_p(keys), n, _p(uniq), _p(inverse), _p(counts))
+    return uniq[:u].copy(), inverse, counts[:u].copy()
+
+
+def dedup_reduce(ids, grads):
+    """IndexedSlices.cpu_deduplicate (python/hetu/ndarray.py:556-576): (uniq_keys, reduced)."""
+    keys = ids_to_keys(ids)
+    grads = _f32(grads).reshape(keys.size, -1)
+    uniq, inverse, _ = unique(keys)
+    reduced = np.empty((uniq.size, grads.shape[1]), dtype=np.float32)
+    lib().oracle_dedup_reduce(_p(inverse), keys.size, _p(grads), grads.shape[1], uniq.size,
+                              _p(reduced))
+    return uniq, inverse, reduced
+
+
+def push_apply(table, uniq, reduced):
+    """Server `+=` of SparsePush (ps-lite/include/ps/server/PSFHandle.h:130-164)."""
+    uniq = np.ascontiguousarray(uniq, dtype=np.uint64)
+    reduced = _f32(reduced)
+    lib().oracle_push_apply(_p(table), table.shape[1], _p(uniq), uniq.size, _p(reduced))
+    return table
+
+
+def partition(length, nshard):
+    """AveragePartitioner::partitionDense (ps-lite/include/ps/partitioner.h:46-57)."""
+    starts = np.empty(nshard + 1, dtype=np.uint64)
+    lib().oracle_partition(length, nshard, _p(starts))
+    return starts.astype(np.int64)
+
+
+def num_threads():
+    return lib().oracle_num_threads()
+
+
+# ---- numpy restatements of Python-level reference steps ---------------------------------------
+def np_unique(ids):
+    """IndexedSlices.deduplicate's host step (python/hetu/ndarray.py:534): np.unique on the float ids."""
+    return np.unique(np.asarray(ids), return_inverse=True)
+
+
+def np_cpu_deduplicate(ids, values):
+    """Literal restatement of IndexedSlices.cpu_deduplicate (ndarray.py:556-576), Python loop included.
+    Small inputs only."""
+    np_indices = np.asarray(ids)
+    unique_indices, inverse = np.unique(np_indices, return_inverse=True)
+    last_dim = values.shape[-1]
+    new_values = np.zeros((unique_indices.shape[0], last_dim)).astype(np.float32)
+    flatten = np.asarray(values).reshape((-1, last_dim))
+    for i, ind in enumerate(np.asarray(inverse).reshape(-1)):
+        new_values[ind] += flatten[i]
+    return unique_indices, new_values

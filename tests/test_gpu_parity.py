@@ -1,0 +1,219 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from herald_amd import ops, synth
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _u32(t):
+    return (t.cpu().numpy().astype(np.int64) & 0xFFFFFFFF).astype(np.uint64)
+
+
+@pytest.mark.parametrize("width", [1, 3, 4, 16, 64, 128, 200, 512, 1024])
+@pytest.mark.parametrize("n", [1, 63, 6656])
+def test_gather_bit_exact(dev, width, n):
+    rng = np.random.default_rng(width * 7 + n)
+    rows = 5000
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = rng.integers(0, rows, size=n).astype(np.float32)
+    want = cpu.embedding_lookup(table, ids)
+    got = ops.embedding_lookup(_dev(table, dev), _dev(ids, dev))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_gather_shapes_and_empty(dev):
+    table = _dev(np.arange(25, dtype=np.float32).reshape(5, 5), dev)
+    ids = _dev(np.array([[0, 1], [0, 1]], dtype=np.float32), dev)   # tests/test_dnnl_op.py:1120-1135
+    out = ops.embedding_lookup(table, ids)
+    assert tuple(out.shape) == (2, 2, 5)
+    np.testing.assert_array_equal(out.cpu().numpy(), table.cpu().numpy()[[[0, 1], [0, 1]]])
+    empty = ops.embedding_lookup(table, torch.empty(0, dtype=torch.float32, device=dev))
+    assert tuple(empty.shape) == (0, 5)
+
+
+def test_gather_u64_ids(dev):
+    rng = np.random.default_rng(5)
+    table = rng.standard_normal((3000, 64), dtype=np.float32)
+    ids = rng.integers(0, 3000, size=(40, 26)).astype(np.int64)
+    got = ops.embedding_lookup(_dev(table, dev), _dev(ids, dev))
+    np.testing.assert_array_equal(got.cpu().numpy(), table[ids])
+
+
+def test_gather_through_reference_named_symbol(dev):
+    rng = np.random.default_rng(6)
+    table = _dev(rng.standard_normal((777, 128), dtype=np.float32), dev)
+    ids = _dev(rng.integers(0, 777, size=(256, 26)).astype(np.float32), dev)
+    out = torch.empty((256, 26, 128), dtype=torch.float32, device=dev)
+    ops.dl_call("DLGpuEmbeddingLookUp", [table, ids, out])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(),
+                                  cpu.embedding_lookup(table.cpu().numpy(), ids.cpu().numpy()))
+
+
+def _check_plan(ids_f32, dev):
+    n = ids_f32.size
+    plan = ops.IndexPlan(max(n, 1), dev).build(_dev(ids_f32, dev))
+    torch.cuda.synchronize()
+    keys = cpu.ids_to_keys(ids_f32)
+    uniq, inv, cnt = cpu.unique(keys)
+    u = plan.n_unique()
+    assert u == uniq.size
+    if n == 0:
+        return plan
+    np.testing.assert_array_equal(_u32(plan.keys()), keys)
+    np.testing.assert_array_equal(_u32(plan.uniq(u)), uniq)
+    np.testing.assert_array_equal(plan.inverse().cpu().numpy().astype(np.int64), inv)
+    np.testing.assert_array_equal(plan.counts(u).cpu().numpy().astype(np.int64), cnt)
+    # stable argsort: occurrence order inside every run
+    perm = plan.perm().cpu().numpy()
+    np.testing.assert_array_equal(perm, np.argsort(keys, kind="stable"))
+    np.testing.assert_array_equal(_u32(plan.sorted_keys()), keys[perm])
+    seg = plan.seg(u).cpu().numpy()
+    np.testing.assert_array_equal(seg, np.concatenate([[0], np.cumsum(cnt)]))
+    # float32 export == np.unique on the float ids (python/hetu/ndarray.py:534)
+    uf, invf = plan.export_f32()
+    ru, rinv = np.unique(ids_f32, return_inverse=True)
+    np.testing.assert_array_equal(uf.cpu().numpy(), ru)
+    np.testing.assert_array_equal(invf.cpu().numpy(), rinv.astype(np.float32))
+    return plan
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1000, 6656, 15360])
+def test_plan_small_path(dev, n):
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, max(2, n // 2 + 1), size=n).astype(np.float32)
+    _check_plan(ids, dev)
+
+
+@pytest.mark.parametrize("n", [15361, 26624, 106496, 300000])
+def test_plan_radix_path(dev, n):
+    rng = np.random.default_rng(n)
+    ids = synth.as_f32_ids(rng.integers(0, synth.CRITEO_ROWS, size=n))
+    ids[: n // 4] = ids[n // 2: n // 2 + n // 4]        # force duplicates
+    _check_plan(ids, dev)
+
+
+def test_plan_all_equal_and_all_distinct(dev):
+    _check_plan(np.full(6656, 12345.0, dtype=np.float32), dev)
+    _check_plan(np.arange(6656, dtype=np.float32)[::-1].copy(), dev)
+    _check_plan(np.full(20000, 7.0, dtype=np.float32), dev)
+
+
+def test_plan_criteo_batches(dev):
+    for step in range(3):
+        ids = synth.as_f32_ids(synth.criteo_batch(256, step)).reshape(-1)
+        _check_plan(ids, dev)
+
+
+@pytest.mark.parametrize("width", [1, 4, 6, 64, 128, 512])
+@pytest.mark.parametrize("n", [1, 200, 6656])
+def test_sgd_apply_bit_exact(dev, width, n):
+    rng = np.random.default_rng(n + width)
+    rows = 3000
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = rng.integers(0, max(2, n // 3), size=n).astype(np.float32)
+    if n >= 200:
+        ids[:150] = 3.0                                  # a hot row with >=150 occurrences
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    lr = 0.01
+    want = cpu.sgd_sparse_update(table.copy(), ids, grads, lr)
+    t = _dev(table, dev)
+    ops.sgd_sparse_update(t, _dev(ids, dev), _dev(grads, dev), lr)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("width", [4, 128, 512])
+def test_dedup_reduce_bit_exact(dev, width):
+    rng = np.random.default_rng(width)
+    n = 6656
+    ids = synth.as_f32_ids(synth.criteo_batch(256, 1)).reshape(-1)
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    uniq, inv, want = cpu.dedup_reduce(ids, grads)
+    plan = ops.IndexPlan(n, dev).build(_dev(ids, dev))
+    red = ops.dedup_reduce(plan, _dev(grads, dev))
+    torch.cuda.synchronize()
+    u = plan.n_unique()
+    assert u == uniq.size
+    np.testing.assert_array_equal(red[:u].cpu().numpy(), want)
+
+
+def test_indexed_slices_deduplicate_matches_cpu_deduplicate(dev):
+    # scenario of tests/test_optimizer.py:117-198: 500x400 table, 100 random duplicated ids
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, 500, size=100).astype(np.float32)
+    vals = rng.standard_normal((100, 400), dtype=np.float32)
+    s = ops.IndexedSlices(_dev(ids, dev), _dev(vals, dev), dense_shape=(500, 400)).deduplicate()
+    ru, rvals = cpu.np_cpu_deduplicate(ids, vals)
+    np.testing.assert_array_equal(s.indices.cpu().numpy(), ru)
+    np.testing.assert_array_equal(s.values.cpu().numpy(), rvals)
+    dense = s.to_dense()
+    want = np.zeros((500, 400), dtype=np.float32)
+    want[ru.astype(np.int64)] = rvals
+    np.testing.assert_array_equal(dense.cpu().numpy(), want)
+
+
+def test_push_apply_and_reference_named_scatter_ops(dev):
+    rng = np.random.default_rng(4)
+    rows, width, n = 2000, 128, 1200                     # tests/pstests/test_apis.py:105-157 shape family
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = rng.integers(0, rows, size=n).astype(np.float32)
+    vals = rng.standard_normal((n, width), dtype=np.float32)
+    uniq, inv, red = cpu.dedup_reduce(ids, vals)
+    want = cpu.push_apply(table.copy(), uniq, red)
+    t = _dev(table, dev)
+    ops.dl_call("IndexedSlicesOneSideAdd", [_dev(ids, dev), _dev(vals, dev), t])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t.cpu().numpy(), want)
+    # DLGpuEmbeddingLookUp_Gradient: dense grad = scatter-add into zeros
+    g = torch.full((rows, width), 7.0, dtype=torch.float32, device=dev)
+    ops.dl_call("DLGpuEmbeddingLookUp_Gradient", [_dev(vals, dev), _dev(ids, dev), g])
+    want_g = cpu.push_apply(np.zeros((rows, width), dtype=np.float32), uniq, red)
+    np.testing.assert_array_equal(g.cpu().numpy(), want_g)
+    # SGDOptimizerSparseUpdate through the DLArray ABI
+    import ctypes
+    t2 = _dev(table, dev)
+    ops.dl_call("SGDOptimizerSparseUpdate", [t2, _dev(ids, dev), _dev(vals, dev)],
+                scalars=[ctypes.c_float(0.05)])
+    want2 = cpu.sgd_sparse_update(table.copy(), ids, vals, 0.05)
+    np.testing.assert_array_equal(t2.cpu().numpy(), want2)
+    # DeduplicateIndexedSlices with a host-computed inverse, as the reference calls it
+    ru, rinv = np.unique(ids, return_inverse=True)
+    comp = torch.zeros((ru.size, width), dtype=torch.float32, device=dev)
+    ops.dl_call("DeduplicateIndexedSlices", [_dev(vals, dev), _dev(rinv.astype(np.float32), dev), comp])
+    np.testing.assert_array_equal(comp.cpu().numpy(), red)
+
+
+def test_full_size_step_properties(dev):
+    """BASELINE config A at full width on a table slice: lookup -> apply round trip and linearity."""
+    rows, width, n = 200000, 512, 6656
+    rng = np.random.default_rng(9)
+    table = torch.from_numpy(rng.standard_normal((rows, width), dtype=np.float32)).to(dev)
+    ids_np = (synth.criteo_batch(256, 0).reshape(-1) % rows).astype(np.float32)
+    ids = _dev(ids_np, dev)
+    before = ops.embedding_lookup(table, ids).clone()
+    grads = torch.from_numpy(rng.standard_normal((n, width), dtype=np.float32)).to(dev)
+    plan = ops.IndexPlan(n, dev).build(ids)
+    t0 = table.clone()
+    ops.sgd_apply(table, plan, grads, 0.5)
+    # rows not in the batch are untouched
+    mask = torch.ones(rows, dtype=torch.bool, device=dev)
+    mask[ids.long()] = False
+    assert torch.equal(table[mask], t0[mask])
+    # a zero gradient is the identity, bit for bit
+    t1 = table.clone()
+    ops.sgd_apply(table, plan, torch.zeros_like(grads), 0.5)
+    assert torch.equal(table, t1)
+    # against the oracle on the touched rows only
+    want = cpu.sgd_sparse_update(t0.cpu().numpy(), ids_np, grads.cpu().numpy(), 0.5)
+    np.testing.assert_array_equal(table.cpu().numpy(), want)
+    assert torch.equal(before, ops.embedding_lookup(t0, ids))
