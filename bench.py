@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- embedding rows/s (lookup + grad) of the hot path on MI355X.
+
+One "step" = one pass of the hot path over one synthetic Criteo-shaped batch:
+    forward : out[i,:] = table[ids[i],:]                         (ha_gather_f32ids)
+    plan    : sorted-unique / inverse / counts of the batch ids  (ha_plan_build_f32ids)
+    backward: table[id,:] -= lr * grad[i,:] per occurrence, occurrence order per row,
+              every unique row read and written once             (ha_sgd_apply)
+Inputs (ids of >= 1024 distinct batches, gradient rows, the table) are resident in HBM before the
+timed region.  N=1 workload: BASELINE.json configs[1], wdl_criteo bs=256 d=512, full 33,762,577-row
+table in HBM.  N>1: the table is row-range sharded over the ranks (AveragePartitioner ranges) and
+ids / rows / reduced gradients cross ranks with RCCL all-to-all (herald_amd.sharded).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+LR = 1e-6              # examples/ctr/models/wdl_criteo.py:12
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2000)
+    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--batch", type=int, default=256)
+    p.add_argument("--width", type=int, default=512)
+    p.add_argument("--rows", type=int, default=33762577)
+    p.add_argument("--fields", type=int, default=26)
+    p.add_argument("--distinct-batches", type=int, default=1024)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-pass", action="store_true")
+    return p.parse_args()
+
+
+def algorithmic_bytes(n, u, width):
+    """fwd n*(8d+4); bwd n*(4d+4) + U*8d."""
+    fwd = n * (8 * width + 4)
+    bwd = n * (4 * width + 4) + u * 8 * width
+    return fwd, bwd
+
+
+def init_table(rows, width, dev, seed=123):
+    t = torch.empty((rows, width), dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    chunk = 1 << 20
+    for s in range(0, rows, chunk):
+        t[s:s + chunk].normal_(0.0, 0.01, generator=g)   # init.random_normal(stddev=0.01)
+    return t
+
+
+def make_batches(args, rank, world):
+    from herald_amd import synth
+    nb = args.distinct_batches
+    ids = np.empty((nb, args.batch * args.fields), dtype=np.float32)
+    uniq = np.empty(nb, dtype=np.int64)
+    for b in range(nb):
+        raw = synth.criteo_batch(args.batch, step=b * world + rank, rows=args.rows, nfields=args.fields)
+        f = synth.as_f32_ids(raw).reshape(-1)
+        # float32 rounding above 2^24 can land on `rows` itself; the reference would read out of
+        # bounds there, the synthetic stream keeps ids inside the table
+        np.minimum(f, np.float32(args.rows - 1), out=f)
+        ids[b] = f
+        uniq[b] = np.unique(f).size
+    return ids, uniq
+
+
+def cpu_baseline(args, ids_host):
+    """Reference CPU path restated (oracle/oracle.c), timed on this box's host cores on a bounded
+    sample: a 1M-row slice of the table, ids folded into it, gather (OpenMP) + serial sparse SGD."""
+    from oracle import cpu
+    rows_cpu = min(args.rows, 1_000_000)
+    rng = np.random.default_rng(7)
+    table = (rng.standard_normal((rows_cpu, args.width), dtype=np.float32) * np.float32(0.01))
+    n = ids_host.shape[1]
+    grads = rng.standard_normal((n, args.width), dtype=np.float32)
+    steps = 0
+    t_budget = 12.0
+    # warm-up
+    idf = np.mod(ids_host[0], rows_cpu).astype(np.float32)
+    cpu.embedding_lookup(table, idf)
+    cpu.sgd_sparse_update(table, idf, grads, LR)
+    t0 = time.perf_counter()
+    while True:
+        idf = np.mod(ids_host[steps % ids_host.shape[0]], rows_cpu).astype(np.float32)
+        cpu.embedding_lookup(table, idf)
+        cpu.sgd_sparse_update(table, idf, grads, LR)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > t_budget or steps >= 400:
+            break
+    return {
+        "value": n * steps / el, "unit": "rows/s", "cores": cpu.num_threads(), "kind": "port",
+        "sample": "%d steps of bs=%d d=%d on a %d-row table slice: OpenMP gather (%d threads) + serial "
+                  "sparse SGD (1 thread, as cpu_SGDOptimizerSparseUpdate mandates), %.1f ms/step"
+                  % (steps, args.batch, args.width, rows_cpu, cpu.num_threads(), 1e3 * el / steps),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from herald_amd import ops
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        from herald_amd import sharded_bench
+        return sharded_bench.run(args, rank, world, dev)
+
+    n = args.batch * args.fields
+    ids_host, uniq_counts = make_batches(args, rank, world)
+    ids_dev = torch.from_numpy(ids_host).to(dev)
+    table = init_table(args.rows, args.width, dev)
+    out = torch.empty((n, args.width), dtype=torch.float32, device=dev)
+    ngrad = 4
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(456)
+    grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(ngrad)]
+    plan = ops.IndexPlan(n, dev)
+    nb = ids_dev.shape[0]
+
+    def step(k):
+        ids = ids_dev[k % nb]
+        ops.embedding_lookup(table, ids, out=out)
+        plan.sort(ids)
+        ops.sgd_apply(table, plan, grads[k % ngrad], LR)
+        plan.finish()
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    total_ms = max(dev_ms, wall * 1e3)      # host-bound launches count as well
+    ms_per_step = total_ms / args.steps
+    rows_per_s = n * args.steps / (total_ms * 1e-3)
+
+    used = [(args.warmup + k) % nb for k in range(args.steps)]
+    u_mean = float(np.mean(uniq_counts[used]))
+    fwd_b, bwd_b = algorithmic_bytes(n, u_mean, args.width)
+
+    # ---- per-kernel pass: HIP events (torch events on the launch stream) around every kernel
+    kernels = {}
+    if not args.no_kernel_pass:
+        ksteps = min(args.steps, 500)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(ksteps)]
+        for k in range(ksteps):
+            ids = ids_dev[(args.warmup + k) % nb]
+            evs[k][0].record()
+            ops.embedding_lookup(table, ids, out=out)
+            evs[k][1].record()
+            plan.sort(ids)
+            evs[k][2].record()
+            ops.sgd_apply(table, plan, grads[k % ngrad], LR)
+            evs[k][3].record()
+            plan.finish()
+            evs[k][4].record()
+        torch.cuda.synchronize()
+        f_ms = np.mean([e[3].elapsed_time(e[4]) for e in evs])
+        g_ms = np.mean([e[0].elapsed_time(e[1]) for e in evs])
+        p_ms = np.mean([e[1].elapsed_time(e[2]) for e in evs])
+        a_ms = np.mean([e[2].elapsed_time(e[3]) for e in evs])
+        kernels = {
+            "gather_vec4_kernel": {"avg_us": g_ms * 1e3, "algorithmic_bytes": fwd_b,
+                                   "GBps": fwd_b / (g_ms * 1e-3) / 1e9},
+            "plan_rank_small_kernel": {"avg_us": p_ms * 1e3, "algorithmic_bytes": 0},
+            "finish_small_kernel": {"avg_us": f_ms * 1e3, "algorithmic_bytes": 0},
+            "apply_kernel<sgd>": {"avg_us": a_ms * 1e3, "algorithmic_bytes": bwd_b,
+                                  "GBps": bwd_b / (a_ms * 1e-3) / 1e9},
+        }
+        dom = "apply_kernel<sgd>" if a_ms >= g_ms else "gather_vec4_kernel"
+        dom_bytes = bwd_b if a_ms >= g_ms else fwd_b
+        dom_ms = max(a_ms, g_ms)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_us": dom_ms * 1e3, "algorithmic_bytes_per_launch": dom_bytes}
+    else:
+        roofline = None
+
+    step_gbs = (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9
+    result = {
+        "metric": "embedding rows/s (lookup+grad)", "value": rows_per_s, "unit": "rows/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "wdl_criteo bs=%d d=%d, %d fields, full %d-row fp32 table in HBM (%.1f GB), "
+                               "gather + dedup plan + fused SGD scatter-apply per step; the LRU "
+                               "cache-limit-0.1 tier is not part of this line"
+                               % (args.batch, args.width, args.fields, args.rows,
+                                  args.rows * args.width * 4 / 1e9),
+                   "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,
+                   "parallelism": "1 GPU"},
+        "step_algorithmic_bytes": fwd_b + bwd_b,
+        "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,
+        "device_ms": dev_ms, "wall_ms": wall * 1e3,
+        "roofline": roofline, "kernels": kernels,
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, ids_host)
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -124,7 +124,7 @@ static int scatter_add_rows(float *dst, int64_t rows, int64_t width,
     void *ws = nullptr;
     if (scratch_get(stream, ha_plan_bytes(n), &ws))
         return -1;
-    if (ha_plan_build_f32ids(ids, n, ws, stream))
+    if (ha_plan_sort_f32ids(ids, n, ws, stream))
         return -1;
     return ha_push_apply(dst, rows, width, ws, n, vals, stream);
 }
@@ -245,7 +245,7 @@ extern "C" int ha_sgd_sparse_update_f32ids(float *table, int64_t rows,
     void *ws = nullptr;
     if (scratch_get(as_stream(stream), ha_plan_bytes(n), &ws))
         return -1;
-    if (ha_plan_build_f32ids(ids, n, ws, stream))
+    if (ha_plan_sort_f32ids(ids, n, ws, stream))
         return -1;
     return ha_sgd_apply(table, rows, width, ws, n, grads, lr, stream);
 }

@@ -92,73 +92,89 @@ __device__ __forceinline__ uint32_t to_key<uint32_t>(uint32_t v) {
 
 // ===========================================================================
 // Small path: stable rank by counting.
+//
+// Workgroup = 1024 threads = 16 waves, owns the 32 elements i in [32*b, 32*b+32).  Lane l works for
+// element i0 + (l & 31); the two half-waves (h = l >> 5) of wave w interleave the 16-byte key chunks
+// of the wave's j-range, so one ds_read_b128 serves two broadcast addresses and the before / diagonal
+// / after regions stay wave-uniform.  rank(i) = #{j : key_j < key_i} + #{j < i : key_j == key_i}.
 // ===========================================================================
+constexpr int kRankTile = 32;
+
 template <typename IdT>
 __global__ __launch_bounds__(1024) void plan_rank_small_kernel(
     const IdT *__restrict__ ids, int n, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ sorted, int32_t *__restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
-    const int npad = (n + 63) & ~63;
-    uint32_t *s_keys = s_mem;            // [npad]
-    uint32_t *s_part = s_mem + npad;     // [16][64]
+    const int npad = (n + 127) & ~127;      // 32 j-splits x 4 keys
+    uint32_t *s_keys = s_mem;               // [npad]
+    uint32_t *s_part = s_mem + npad;        // [32 splits][32 elements]
 
-    for (int j = threadIdx.x; j < npad; j += 1024)
-        s_keys[j] = j < n ? to_key<IdT>(ids[j]) : kPadKey;
+    // stage all keys: every thread issues a batch of 8 loads before the matching LDS writes
+    for (int base = 0; base < npad; base += 8192) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = base + threadIdx.x + k * 1024;
+            v[k] = kPadKey;
+            if (j < n)
+                v[k] = to_key<IdT>(ids[j]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = base + threadIdx.x + k * 1024;
+            if (j < npad)
+                s_keys[j] = v[k];
+        }
+    }
     __syncthreads();
 
     const int lane = lane_id();
+    const int il = lane & 31, h = lane >> 5;
     const int w = uniform(static_cast<int>(threadIdx.x >> 6));
-    const int i0 = blockIdx.x * 64;
-    const int i = i0 + lane;
-    const uint32_t ki = s_keys[i];  // i < npad always (grid = npad/64)
+    const int i0 = blockIdx.x * kRankTile;
+    const int i = i0 + il;
+    const uint32_t ki = s_keys[min(i, npad - 1)];
 
-    // j-range of this wave, in units of 4 keys (one ds_read_b128 broadcast)
-    const int chunks = npad >> 2;
-    const int cpw = (chunks + 15) >> 4;
-    const int jbeg = min(npad, w * cpw * 4);
-    const int jend = min(npad, jbeg + cpw * 4);
+    // wave w owns chunk pairs [pb, pe); a pair = 8 consecutive keys, half h takes keys 4h..4h+3
+    const int pairs = npad >> 3;
+    const int ppw = pairs >> 4;  // npad % 128 == 0
+    const int pb = w * ppw, pe = pb + ppw;
+    const int tile_pb = i0 >> 3, tile_pe = (i0 + kRankTile) >> 3;
 
     uint32_t rank = 0;
-    // (a) j entirely before the i-tile: equal keys at smaller positions sort first -> "<="
-    {
-        const int e = min(jend, i0);
-        for (int j = jbeg; j < e; j += 4) {
-            const uint4 k = *reinterpret_cast<const uint4 *>(s_keys + j);
-            rank += (k.x <= ki);
-            rank += (k.y <= ki);
-            rank += (k.z <= ki);
-            rank += (k.w <= ki);
-        }
+    const uint32_t *kp = s_keys + 4 * h;
+    // (a) before the tile: equal keys at smaller positions come first -> "<="
+    for (int p = pb; p < min(pe, tile_pb); ++p) {
+        const uint4 k = *reinterpret_cast<const uint4 *>(kp + 8 * p);
+        rank += (k.x <= ki);
+        rank += (k.y <= ki);
+        rank += (k.z <= ki);
+        rank += (k.w <= ki);
     }
-    // (b) the diagonal: j inside the i-tile
-    {
-        const int b = max(jbeg, i0), e = min(jend, i0 + 64);
-        for (int j = b; j < e; j += 4) {
-            const uint4 k = *reinterpret_cast<const uint4 *>(s_keys + j);
-            rank += (k.x < ki) || (k.x == ki && (j + 0) < i);
-            rank += (k.y < ki) || (k.y == ki && (j + 1) < i);
-            rank += (k.z < ki) || (k.z == ki && (j + 2) < i);
-            rank += (k.w < ki) || (k.w == ki && (j + 3) < i);
-        }
+    // (b) inside the tile
+    for (int p = max(pb, tile_pb); p < min(pe, tile_pe); ++p) {
+        const uint4 k = *reinterpret_cast<const uint4 *>(kp + 8 * p);
+        const int j = 8 * p + 4 * h;
+        rank += (k.x < ki) || (k.x == ki && (j + 0) < i);
+        rank += (k.y < ki) || (k.y == ki && (j + 1) < i);
+        rank += (k.z < ki) || (k.z == ki && (j + 2) < i);
+        rank += (k.w < ki) || (k.w == ki && (j + 3) < i);
     }
-    // (c) j entirely after the i-tile -> "<"
-    {
-        const int b = max(jbeg, i0 + 64);
-        for (int j = b; j < jend; j += 4) {
-            const uint4 k = *reinterpret_cast<const uint4 *>(s_keys + j);
-            rank += (k.x < ki);
-            rank += (k.y < ki);
-            rank += (k.z < ki);
-            rank += (k.w < ki);
-        }
+    // (c) after the tile -> "<"
+    for (int p = max(pb, tile_pe); p < pe; ++p) {
+        const uint4 k = *reinterpret_cast<const uint4 *>(kp + 8 * p);
+        rank += (k.x < ki);
+        rank += (k.y < ki);
+        rank += (k.z < ki);
+        rank += (k.w < ki);
     }
-    s_part[w * 64 + lane] = rank;
+    s_part[(w * 2 + h) * 32 + il] = rank;
     __syncthreads();
-    if (w == 0 && i < n) {
+    if (threadIdx.x < 32 && i < n) {
         uint32_t r = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            r += s_part[k * 64 + lane];
+        for (int k = 0; k < 32; ++k)
+            r += s_part[k * 32 + il];
         sorted[r] = ki;
         perm[r] = i;
         keys[i] = ki;
@@ -400,6 +416,10 @@ __global__ __launch_bounds__(256) void finish_counts_kernel(
 }
 
 // Small-n fused finish: one workgroup does phases 1-3 (n <= kSmallMax).
+//   pass A (coalesced): head flag of every sorted position -> LDS
+//   pass B (blocked)  : thread t owns positions t*15.., local count + wave/block scan -> unique index
+//   pass C (coalesced): uniq / seg / counts / upos / inverse written out
+// LDS: upos|head<<15 as u16[n] + seg as u16[n+2] (positions and unique indices are <= 15360 < 2^15).
 __global__ __launch_bounds__(1024) void finish_small_kernel(
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     int n, PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
@@ -407,20 +427,37 @@ __global__ __launch_bounds__(1024) void finish_small_kernel(
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos) {
     constexpr int kItems = kSmallMax / 1024;  // 15
     __shared__ uint32_t s_w[16];
-    __shared__ uint16_t s_seg[kSmallMax + 2];  // positions <= 15360 fit 16 bits
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    uint16_t *s_upos = reinterpret_cast<uint16_t *>(s_dyn);   // [n rounded up to 8]
+    uint16_t *s_seg = s_upos + ((n + 7) & ~7);                // [n+2]
     const int lane = lane_id(), w = threadIdx.x >> 6;
+    // ---- pass A
+    {
+        uint32_t a[kItems], b[kItems];
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int p = threadIdx.x + k * 1024;
+            a[k] = p < n ? sorted[p] : 0u;
+            b[k] = (p < n && p > 0) ? sorted[p - 1] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int p = threadIdx.x + k * 1024;
+            if (p < n)
+                s_upos[p] = (p == 0 || a[k] != b[k]) ? 0x8000u : 0u;
+        }
+    }
+    __syncthreads();
+    // ---- pass B
     const int p0 = threadIdx.x * kItems;
-    uint32_t key[kItems];
-    bool head[kItems];
-    uint32_t prev = (p0 > 0 && p0 - 1 < n) ? sorted[p0 - 1] : 0u;
     uint32_t c = 0;
+    uint32_t flags = 0;
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int p = p0 + k;
-        key[k] = p < n ? sorted[p] : 0u;
-        head[k] = p < n && (p == 0 || key[k] != prev);
-        prev = key[k];
-        c += head[k];
+        const uint32_t hd = (p < n) ? (s_upos[p] >> 15) : 0u;
+        flags |= hd << k;
+        c += hd;
     }
     uint32_t x = c;
 #pragma unroll
@@ -443,25 +480,48 @@ __global__ __launch_bounds__(1024) void finish_small_kernel(
     for (int k = 0; k < kItems; ++k) {
         const int p = p0 + k;
         if (p < n) {
-            if (head[k]) {
-                uniq[u] = key[k];
-                seg[u] = p;
+            const uint32_t hd = (flags >> k) & 1u;
+            if (hd) {
                 s_seg[u] = static_cast<uint16_t>(p);
                 ++u;
             }
-            const int32_t ui = static_cast<int32_t>(u) - 1;
-            upos[p] = ui;
-            inverse[perm[p]] = ui;
+            s_upos[p] = static_cast<uint16_t>((u - 1) | (hd << 15));
         }
     }
     if (threadIdx.x == 0) {
         hdr->n_unique = total;
-        seg[total] = n;
         s_seg[total] = static_cast<uint16_t>(n);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < static_cast<int>(total); k += 1024)
-        counts[k] = static_cast<int32_t>(s_seg[k + 1]) - static_cast<int32_t>(s_seg[k]);
+    // ---- pass C
+    for (int k = threadIdx.x; k <= static_cast<int>(total); k += 1024) {
+        const int32_t a = s_seg[k];
+        seg[k] = a;
+        if (k < static_cast<int>(total))
+            counts[k] = static_cast<int32_t>(s_seg[k + 1]) - a;
+    }
+    {
+        int32_t pv[kItems];
+        uint32_t sv[kItems];
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int p = threadIdx.x + k * 1024;
+            pv[k] = p < n ? perm[p] : 0;
+            sv[k] = p < n ? sorted[p] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int p = threadIdx.x + k * 1024;
+            if (p < n) {
+                const uint32_t v = s_upos[p];
+                const int32_t ui = static_cast<int32_t>(v & 0x7FFFu);
+                upos[p] = ui;
+                inverse[pv[k]] = ui;
+                if (v >> 15)
+                    uniq[ui] = sv[k];
+            }
+        }
+    }
 }
 
 __global__ void plan_empty_kernel(PlanHeader *hdr, int32_t *seg) {
@@ -469,9 +529,11 @@ __global__ void plan_empty_kernel(PlanHeader *hdr, int32_t *seg) {
     seg[0] = 0;
 }
 
+static int plan_finish(void *ws, int64_t n, hipStream_t stream);
+
 template <typename IdT>
 static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
-                      hipStream_t stream) {
+                      bool sort_only, hipStream_t stream) {
     HA_REQUIRE(n >= 0 && n < (1ll << 31), "plan: bad n=%ld", (long)n);
     HA_REQUIRE(ws != nullptr, "plan: null workspace");
     PlanPtrs p = plan_layout(ws, n);
@@ -484,16 +546,16 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
     HA_REQUIRE(ids != nullptr, "plan: null ids");
     const int ni = static_cast<int>(n);
     if (n <= kSmallMax) {
-        const int npad = (ni + 63) & ~63;
-        const size_t lds = (static_cast<size_t>(npad) + 16 * 64) * 4;
-        hipLaunchKernelGGL(plan_rank_small_kernel<IdT>, dim3(npad / 64),
-                           dim3(1024), lds, stream, ids, ni, p.keys, p.sorted,
-                           p.perm);
+        const int npad = (ni + 127) & ~127;
+        const size_t lds = (static_cast<size_t>(npad) + 32 * 32) * 4;
+        hipLaunchKernelGGL(plan_rank_small_kernel<IdT>,
+                           dim3((ni + kRankTile - 1) / kRankTile), dim3(1024),
+                           lds, stream, ids, ni, p.keys, p.sorted, p.perm);
         HA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(finish_small_kernel, dim3(1), dim3(1024), 0, stream,
-                           p.sorted, p.perm, ni, p.hdr, p.uniq, p.seg,
-                           p.counts, p.inverse, p.upos);
-        HA_LAUNCH_CHECK();
+        if (!sort_only) {
+            if (plan_finish(ws, n, stream))
+                return -1;
+        }
         return 0;
     }
     // ---- radix path
@@ -535,7 +597,29 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
         kin = kout;
         vin = vout;
     }
-    // ---- finish
+    if (sort_only)
+        return 0;
+    return plan_finish(ws, n, stream);
+}
+
+static int plan_finish(void *ws, int64_t n, hipStream_t stream) {
+    HA_REQUIRE(ws != nullptr && n >= 0, "plan_finish: bad arguments");
+    PlanPtrs p = plan_layout(ws, n);
+    if (n == 0) {
+        hipLaunchKernelGGL(plan_empty_kernel, dim3(1), dim3(1), 0, stream,
+                           p.hdr, p.seg);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
+    const int ni = static_cast<int>(n);
+    if (n <= kSmallMax) {
+        const size_t lds = (((static_cast<size_t>(ni) + 7) & ~size_t(7)) + ni + 2) * 2 + 16;
+        hipLaunchKernelGGL(finish_small_kernel, dim3(1), dim3(1024), lds, stream,
+                           p.sorted, p.perm, ni, p.hdr, p.uniq, p.seg,
+                           p.counts, p.inverse, p.upos);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
     const int nfin = (ni + kFinishTile - 1) / kFinishTile;
     hipLaunchKernelGGL(finish_count_kernel, dim3(nfin), dim3(1024), 0, stream,
                        p.sorted, ni, p.block_sums);
@@ -601,17 +685,31 @@ extern "C" int ha_plan_view_of(void *ws, int64_t n, ha_plan_view *view) {
 
 extern "C" int ha_plan_build_f32ids(const float *ids, int64_t n, void *ws,
                                     ha_stream_t stream) {
-    return plan_build<float>(ids, n, ws, 32, as_stream(stream));
+    return plan_build<float>(ids, n, ws, 32, false, as_stream(stream));
 }
 
 extern "C" int ha_plan_build_u64ids(const uint64_t *ids, int64_t n, void *ws,
                                     ha_stream_t stream) {
-    return plan_build<uint64_t>(ids, n, ws, 32, as_stream(stream));
+    return plan_build<uint64_t>(ids, n, ws, 32, false, as_stream(stream));
 }
 
 extern "C" int ha_plan_build_u32keys(const uint32_t *keys, int64_t n, void *ws,
                                      int key_bits, ha_stream_t stream) {
-    return plan_build<uint32_t>(keys, n, ws, key_bits, as_stream(stream));
+    return plan_build<uint32_t>(keys, n, ws, key_bits, false, as_stream(stream));
+}
+
+extern "C" int ha_plan_sort_f32ids(const float *ids, int64_t n, void *ws,
+                                   ha_stream_t stream) {
+    return plan_build<float>(ids, n, ws, 32, true, as_stream(stream));
+}
+
+extern "C" int ha_plan_sort_u64ids(const uint64_t *ids, int64_t n, void *ws,
+                                   ha_stream_t stream) {
+    return plan_build<uint64_t>(ids, n, ws, 32, true, as_stream(stream));
+}
+
+extern "C" int ha_plan_finish(void *ws, int64_t n, ha_stream_t stream) {
+    return plan_finish(ws, n, as_stream(stream));
 }
 
 extern "C" int ha_plan_export_f32(const void *ws, int64_t n, float *uniq_f32,

@@ -1,4 +1,4 @@
-// Backward of the embedding lookup: dedup-reduce and fused sparse apply, driven by an index plan.
+// Backward of the embedding lookup: dedup-reduce and fused sparse apply, driven by the sorted plan.
 //
 // Reference semantics (all fp32, all deterministic here; no atomics):
 //   ha_sgd_apply    : cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:51-74 -- serial loop
@@ -15,19 +15,20 @@
 // 282-295); here every unique row is read once, updated in registers and written once:
 // algorithmic bytes per batch = n*(4*width + 4) + U*8*width.
 //
-// Work mapping: one wavefront per SORTED POSITION p.  u = upos[p] is its unique row, o = p - seg[u]
-// its offset in the run of `len` equal keys.  A run of length 1 (the common case) is handled by its
-// single wave with 16-byte loads over the whole row.  Longer runs are column-split over
-// min(len, S) of their own waves so that hot rows (hundreds of occurrences in one batch) do not
-// serialise on one wave; every wave keeps kDepth occurrence loads in flight.
+// Work mapping.  Input is the stable sort of the batch keys (`sorted`, `perm`).  A 1024-thread
+// workgroup owns 16 consecutive sorted positions, one wave each.  A wave whose position starts a run
+// of equal keys ("head") owns that unique row:
+//   * short run (< kHotLen occurrences, the common case): the wave alone loads the table row and all
+//     occurrence rows with 16-byte loads (up to kDepth occurrence rows in flight) and applies them in
+//     order;
+//   * long run (hot row: a low-cardinality Criteo field repeats one id hundreds of times per batch):
+//     the whole workgroup streams the occurrence rows through LDS -- all 16 waves load (flat,
+//     coalesced, kStages rounds of loads in flight), then one thread per column applies the staged
+//     rows in occurrence order.  The serial chain per column is the only ordered part.
+// Waves at non-head positions exit (their occurrence is consumed by the head's wave/workgroup).
 #include "common.h"
 
 namespace ha {
-
-struct PlanHeader {
-    int64_t n_unique;
-    int64_t reserved[31];
-};
 
 enum ApplyMode {
     kModeSgd = 0,     // row = row - lr*g  (two roundings per occurrence)
@@ -35,8 +36,12 @@ enum ApplyMode {
     kModeReduce = 2,  // out[u] = 0 + g0 + g1 ...
 };
 
-constexpr int kDepth = 8;       // occurrence rows in flight per wave
-constexpr int kFineRunLen = 4;  // runs at least this long use 64-column slices
+constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per workgroup
+constexpr int kHotLen = 16;        // runs at least this long take the workgroup-cooperative path
+constexpr int kDepth = 8;          // cold path: occurrence rows in flight per wave
+constexpr int kStages = 4;         // hot path: rounds of global loads in flight
+constexpr int kBufFloats = 8192;   // hot path: LDS staging buffer (32 KiB)
+constexpr int kPermChunk = 1024;   // hot path: occurrence indices staged per super-round
 
 template <int MODE>
 __device__ __forceinline__ float step(float acc, float g, float lr) {
@@ -46,128 +51,268 @@ __device__ __forceinline__ float step(float acc, float g, float lr) {
 }
 
 template <int VEC>
-__device__ __forceinline__ void load_vec(const float *p, float (&o)[VEC]) {
-    if constexpr (VEC == 4) {
-        const float4v v = ld4(p);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k)
-            o[k] = p[k];
-    }
-}
-template <int VEC>
-__device__ __forceinline__ void store_vec(float *p, const float (&o)[VEC]) {
-    if constexpr (VEC == 4) {
-        st4(p, float4v{o[0], o[1], o[2], o[3]});
-    } else {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k)
-            p[k] = o[k];
-    }
-}
+struct Vec;
+template <>
+struct Vec<4> {
+    float4v v;
+    __device__ __forceinline__ void load(const float *p) { v = ld4(p); }
+    __device__ __forceinline__ void store(float *p) const { st4(p, v); }
+    __device__ __forceinline__ void zero() { v = float4v{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ float get(int k) const { return v[k]; }
+    __device__ __forceinline__ void set(int k, float x) { v[k] = x; }
+};
+template <>
+struct Vec<1> {
+    float v;
+    __device__ __forceinline__ void load(const float *p) { v = *p; }
+    __device__ __forceinline__ void store(float *p) const { *p = v; }
+    __device__ __forceinline__ void zero() { v = 0.f; }
+    __device__ __forceinline__ float get(int) const { return v; }
+    __device__ __forceinline__ void set(int, float x) { v = x; }
+};
 
-// Process columns [c0, c1) (in floats, both multiples of VEC) of unique row `u`.
-template <int MODE, int VEC>
-__device__ __forceinline__ void apply_slice(
-    float *__restrict__ dst_row, const float *__restrict__ grads,
-    const int32_t *__restrict__ occ, int len, int width, int c0, int c1,
-    float lr) {
+// ---- cold path: one wave, whole row, columns [cbase, cbase + VB*64*VEC) per call ---------------
+template <int MODE, int VEC, int VB>
+__device__ __forceinline__ void cold_block(float *__restrict__ dst_row,
+                                           const float *__restrict__ grads,
+                                           int width, int cbase, int permv,
+                                           int len, float lr) {
     const int lane = lane_id();
-    for (int c = c0 + lane * VEC; c < c1; c += kWave * VEC) {
-        float acc[VEC];
-        if (MODE == kModeSgd) {
-            load_vec<VEC>(dst_row + c, acc);
-        } else {
+    Vec<VEC> acc[VB];
+    int col[VB];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k)
-                acc[k] = 0.f;
-        }
-        for (int q0 = 0; q0 < len; q0 += kDepth) {
-            float g[kDepth][VEC];
+    for (int b = 0; b < VB; ++b) {
+        col[b] = cbase + (b * kWave + lane) * VEC;
+        acc[b].zero();
+        if (MODE == kModeSgd && col[b] < width)
+            acc[b].load(dst_row + col[b]);
+    }
+    for (int q0 = 0; q0 < len; q0 += kDepth) {
+        Vec<VEC> g[kDepth][VB];
 #pragma unroll
-            for (int t = 0; t < kDepth; ++t) {
-                if (q0 + t < len) {
-                    const float *src =
-                        grads + static_cast<size_t>(occ[q0 + t]) * width + c;
-                    load_vec<VEC>(src, g[t]);
-                }
+        for (int t = 0; t < kDepth; ++t) {
+            if (q0 + t < len) {
+                const int idx = __builtin_amdgcn_readlane(permv, q0 + t);
+                const float *src = grads + static_cast<size_t>(idx) * width;
+#pragma unroll
+                for (int b = 0; b < VB; ++b)
+                    if (col[b] < width)
+                        g[t][b].load(src + col[b]);
             }
+        }
 #pragma unroll
-            for (int t = 0; t < kDepth; ++t) {
-                if (q0 + t < len) {
+        for (int t = 0; t < kDepth; ++t) {
+            if (q0 + t < len) {
+#pragma unroll
+                for (int b = 0; b < VB; ++b)
 #pragma unroll
                     for (int k = 0; k < VEC; ++k)
-                        acc[k] = step<MODE>(acc[k], g[t][k], lr);
-                }
+                        acc[b].set(k, step<MODE>(acc[b].get(k), g[t][b].get(k), lr));
             }
         }
-        if (MODE == kModePush) {
-            float cur[VEC];
-            load_vec<VEC>(dst_row + c, cur);
+    }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k)
-                acc[k] = __fadd_rn(cur[k], acc[k]);
+    for (int b = 0; b < VB; ++b) {
+        if (col[b] < width) {
+            if (MODE == kModePush) {
+                Vec<VEC> cur;
+                cur.load(dst_row + col[b]);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    acc[b].set(k, __fadd_rn(cur.get(k), acc[b].get(k)));
+            }
+            acc[b].store(dst_row + col[b]);
         }
-        store_vec<VEC>(dst_row + c, acc);
     }
 }
 
 template <int MODE, int VEC>
-__global__ __launch_bounds__(256) void apply_kernel(
-    float *__restrict__ dst, uint64_t dst_rows, int width,
-    const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq,
-    const int32_t *__restrict__ seg, const int32_t *__restrict__ upos,
-    const int32_t *__restrict__ perm, int n, const float *__restrict__ grads,
-    float lr) {
-    const int p = uniform(static_cast<int>(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (p >= n)
-        return;
-    const int u = uniform(upos[p]);
-    const int start = uniform(seg[u]);
-    const int len = uniform(seg[u + 1]) - start;
-    const int o = p - start;
-    uint64_t row;
-    if (MODE == kModeReduce) {
-        row = static_cast<uint64_t>(u);
-    } else {
-        row = uniq[u];
-        if (row >= dst_rows)
-            return;  // out-of-range id: ignored (the reference has undefined behaviour here)
-    }
-    float *dst_row = dst + row * static_cast<uint64_t>(width);
-    const int32_t *occ = perm + start;
-    // Column slices: a run of `len` occurrences owns `len` waves; up to max_slices of them each take
-    // a contiguous column range.  Short runs use 256-column (16 B/lane) slices, long runs switch to
-    // 64-column (4 B/lane, 256 B per wave access) slices to spread the serial chain over more waves.
-    if (VEC == 4 && len < kFineRunLen) {
-        const int slice_cols = kWave * 4;
-        const int max_slices = (width + slice_cols - 1) / slice_cols;
-        const int nslice = min(len, max_slices);
-        if (o >= nslice)
-            return;
-        const int per = (max_slices + nslice - 1) / nslice;
-        const int c0 = min(width, o * per * slice_cols);
-        const int c1 = min(width, (o + 1) * per * slice_cols);
-        apply_slice<MODE, 4>(dst_row, grads, occ, len, width, c0, c1, lr);
-    } else {
-        const int slice_cols = kWave;
-        const int max_slices = (width + slice_cols - 1) / slice_cols;
-        const int nslice = min(len, max_slices);
-        if (o >= nslice)
-            return;
-        const int per = (max_slices + nslice - 1) / nslice;
-        const int c0 = min(width, o * per * slice_cols);
-        const int c1 = min(width, (o + 1) * per * slice_cols);
-        apply_slice<MODE, 1>(dst_row, grads, occ, len, width, c0, c1, lr);
+__device__ __forceinline__ void cold_row(float *__restrict__ dst_row,
+                                         const float *__restrict__ grads,
+                                         int width, int permv, int len,
+                                         float lr) {
+    constexpr int kCols1 = kWave * VEC;
+    int c = 0;
+    for (; width - c > kCols1; c += 2 * kCols1)
+        cold_block<MODE, VEC, 2>(dst_row, grads, width, c, permv, len, lr);
+    for (; c < width; c += kCols1)
+        cold_block<MODE, VEC, 1>(dst_row, grads, width, c, permv, len, lr);
+}
+
+// ---- hot path: the whole workgroup streams one long run through LDS -------------------------------
+// Columns [cb, cb+CB) of every occurrence row are staged round by round: a round is R = kBufFloats/CB
+// occurrence rows = kBufFloats/VEC vector units, loaded flat (unit f -> occurrence f / (CB/VEC),
+// column (f % (CB/VEC))*VEC), i.e. kBufFloats/VEC/1024 units per thread.
+template <int MODE, int VEC>
+__device__ __forceinline__ void hot_run(float *__restrict__ dst_row,
+                                        const float *__restrict__ grads,
+                                        const int32_t *__restrict__ perm_run,
+                                        int len, int width, float lr,
+                                        float *s_buf, int32_t *s_perm) {
+    constexpr int kUnits = kBufFloats / VEC / 1024;  // units per thread per round: 2 (VEC=4), 8 (VEC=1)
+    const int tid = threadIdx.x;
+    // column block: power of two in [64*VEC, 1024] (one combiner thread per column)
+    int CB = 64 * VEC;
+    while (CB < width && CB < 1024)
+        CB <<= 1;
+    const int upr = CB / VEC;       // units per occurrence-row slice
+    const int R = kBufFloats / CB;  // occurrence rows per round
+
+    for (int cb = 0; cb < width; cb += CB) {
+        const int mycol = cb + tid;
+        const bool combiner = tid < CB && mycol < width;
+        float acc = 0.f;
+        if (MODE == kModeSgd && combiner)
+            acc = dst_row[mycol];
+        for (int s0 = 0; s0 < len; s0 += kPermChunk) {
+            const int slen = min(kPermChunk, len - s0);
+            __syncthreads();  // previous users of s_perm / s_buf are done
+            s_perm[tid] = tid < slen ? perm_run[s0 + tid] : 0;
+            __syncthreads();
+            const int nr = (slen + R - 1) / R;
+            Vec<VEC> rg[kStages][kUnits];
+
+            auto issue = [&](int r, Vec<VEC>(&dstv)[kUnits]) {
+#pragma unroll
+                for (int k = 0; k < kUnits; ++k) {
+                    const int f = tid + k * 1024;
+                    const int m = f / upr;
+                    const int c = cb + (f - m * upr) * VEC;
+                    const int q = r * R + m;
+                    dstv[k].zero();
+                    if (q < slen && c < width)
+                        dstv[k].load(grads + static_cast<size_t>(s_perm[q]) * width + c);
+                }
+            };
+            auto stage_and_combine = [&](int r, Vec<VEC>(&srcv)[kUnits]) {
+#pragma unroll
+                for (int k = 0; k < kUnits; ++k) {
+                    const int f = tid + k * 1024;
+                    srcv[k].store(s_buf + f * VEC);
+                }
+                __syncthreads();
+                const int cnt = min(R, slen - r * R);
+                if (combiner) {
+                    for (int m = 0; m < cnt; ++m)
+                        acc = step<MODE>(acc, s_buf[m * CB + tid], lr);
+                }
+                __syncthreads();
+            };
+
+#pragma unroll
+            for (int d = 0; d < kStages - 1; ++d)
+                if (d < nr)
+                    issue(d, rg[d]);
+            for (int r0 = 0; r0 < nr; r0 += kStages) {
+#pragma unroll
+                for (int j = 0; j < kStages; ++j) {
+                    const int r = r0 + j;
+                    if (r < nr) {
+                        if (r + kStages - 1 < nr)
+                            issue(r + kStages - 1, rg[(j + kStages - 1) % kStages]);
+                        stage_and_combine(r, rg[j]);
+                    }
+                }
+            }
+        }
+        if (combiner) {
+            if (MODE == kModePush)
+                acc = __fadd_rn(dst_row[mycol], acc);
+            dst_row[mycol] = acc;
+        }
     }
 }
 
-struct PlanArrays {
-    const PlanHeader *hdr;
-    const uint32_t *uniq;
-    const int32_t *seg, *upos, *perm;
-};
+template <int MODE, int VEC>
+__global__ __launch_bounds__(1024) void apply_kernel(
+    float *__restrict__ dst, uint64_t dst_rows, int width,
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
+    float lr) {
+    __shared__ __attribute__((aligned(16))) float s_buf[kBufFloats];
+    __shared__ int32_t s_perm[kPermChunk];
+    __shared__ int s_hot_p;
+    __shared__ int s_scan[kPosPerBlock];
+    const int lane = lane_id();
+    const int w = uniform(static_cast<int>(threadIdx.x >> 6));
+    const int p = blockIdx.x * kPosPerBlock + w;
+    if (threadIdx.x == 0)
+        s_hot_p = -1;
+    __syncthreads();
+
+    // ---- phase A: classify my sorted position
+    const bool in_range = p < n;
+    const int pos = p + lane;
+    uint32_t ks = 0;
+    int permv = 0;
+    if (pos < n) {
+        ks = sorted[pos];
+        permv = perm[pos];
+    }
+    uint32_t prevk = 0;
+    if (in_range && p > 0)
+        prevk = sorted[p - 1];
+    const uint32_t key = uniform(ks);
+    const unsigned long long same = __ballot(pos < n && ks == key);
+    const int len64 = (~same == 0ull) ? 64 : __builtin_ctzll(~same);
+    const bool head = in_range && (p == 0 || prevk != key);
+    const bool hot = head && len64 >= kHotLen;
+    if (hot && lane == 0)
+        s_hot_p = p;
+    __syncthreads();
+
+    // ---- phase B: the (at most one) hot run whose head lies in this block
+    const int hp = s_hot_p;
+    if (hp >= 0) {
+        const uint32_t hkey = sorted[hp];
+        // run length: every wave scans 64 positions per step until a different key shows up
+        int len = 0;
+        for (int base = hp;; base += kPosPerBlock * kWave) {
+            const int q = base + w * kWave + lane;
+            const unsigned long long m = __ballot(q < n && sorted[min(q, n - 1)] == hkey);
+            const int c = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
+            if (lane == 0)
+                s_scan[w] = c;
+            __syncthreads();
+            int add = 0;
+            bool full = true;
+            for (int k = 0; k < kPosPerBlock; ++k) {
+                if (full)
+                    add += s_scan[k];
+                full = full && s_scan[k] == 64;
+            }
+            len += add;
+            __syncthreads();
+            if (!full)
+                break;
+        }
+        uint64_t row;
+        bool ok = true;
+        if (MODE == kModeReduce) {
+            row = static_cast<uint64_t>(upos[hp]);
+        } else {
+            row = hkey;
+            ok = row < dst_rows;
+        }
+        if (ok)
+            hot_run<MODE, VEC>(dst + row * static_cast<uint64_t>(width), grads,
+                               perm + hp, len, width, lr, s_buf, s_perm);
+    }
+
+    // ---- phase C: short runs, one wave each
+    if (head && !hot) {
+        uint64_t row;
+        if (MODE == kModeReduce) {
+            row = static_cast<uint64_t>(upos[p]);
+        } else {
+            row = key;
+            if (row >= dst_rows)
+                return;  // out-of-range id: ignored (undefined behaviour in the reference)
+        }
+        cold_row<MODE, VEC>(dst + row * static_cast<uint64_t>(width), grads,
+                            width, permv, len64, lr);
+    }
+}
 
 }  // namespace ha
 
@@ -187,19 +332,19 @@ static int apply_launch(float *dst, int64_t dst_rows, int64_t width,
     ha_plan_view v;
     if (ha_plan_view_of(const_cast<void *>(plan_ws), n, &v) != 0)
         return -1;
-    const PlanHeader *hdr = reinterpret_cast<const PlanHeader *>(v.n_unique);
-    const unsigned blocks = static_cast<unsigned>((n + 3) / 4);
+    const unsigned blocks =
+        static_cast<unsigned>((n + kPosPerBlock - 1) / kPosPerBlock);
     const bool vec_ok = (width % 4 == 0) &&
                         (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
                         (reinterpret_cast<uintptr_t>(grads) % 16 == 0);
     if (vec_ok) {
-        hipLaunchKernelGGL((apply_kernel<MODE, 4>), dim3(blocks), dim3(256), 0,
-                           stream, dst, (uint64_t)dst_rows, (int)width, hdr,
-                           v.uniq, v.seg, v.upos, v.perm, (int)n, grads, lr);
+        hipLaunchKernelGGL((apply_kernel<MODE, 4>), dim3(blocks), dim3(1024), 0,
+                           stream, dst, (uint64_t)dst_rows, (int)width,
+                           v.sorted, v.perm, v.upos, (int)n, grads, lr);
     } else {
-        hipLaunchKernelGGL((apply_kernel<MODE, 1>), dim3(blocks), dim3(256), 0,
-                           stream, dst, (uint64_t)dst_rows, (int)width, hdr,
-                           v.uniq, v.seg, v.upos, v.perm, (int)n, grads, lr);
+        hipLaunchKernelGGL((apply_kernel<MODE, 1>), dim3(blocks), dim3(1024), 0,
+                           stream, dst, (uint64_t)dst_rows, (int)width,
+                           v.sorted, v.perm, v.upos, (int)n, grads, lr);
     }
     HA_LAUNCH_CHECK();
     return 0;

@@ -111,7 +111,16 @@ class IndexPlan:
         self.n = 0
         self._view = None
 
-    def build(self, ids, stream=None):
+    def sort(self, ids, stream=None):
+        """Stable sort only (keys / sorted / perm): all that sgd_apply and push_apply consume."""
+        return self.build(ids, stream, sort_only=True)
+
+    def finish(self, stream=None):
+        """Second phase after sort(): n_unique, uniq, counts, seg, inverse, upos."""
+        check(_lib.load().ha_plan_finish(_ptr(self.ws), self.n, _stream_ptr(stream)), "ha_plan_finish")
+        return self
+
+    def build(self, ids, stream=None, sort_only=False):
         L = _lib.load()
         n = ids.numel()
         if n > self.capacity:
@@ -120,9 +129,11 @@ class IndexPlan:
             raise ValueError("ids must be a contiguous device tensor")
         # the workspace layout depends on n, so a view is per build
         if ids.dtype == torch.float32:
-            rc = L.ha_plan_build_f32ids(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
+            fn = L.ha_plan_sort_f32ids if sort_only else L.ha_plan_build_f32ids
+            rc = fn(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
         elif ids.dtype in (torch.int64, torch.uint64):
-            rc = L.ha_plan_build_u64ids(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
+            fn = L.ha_plan_sort_u64ids if sort_only else L.ha_plan_build_u64ids
+            rc = fn(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
         else:
             raise TypeError("ids must be float32 or (u)int64")
         check(rc, "ha_plan_build")
