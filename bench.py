@@ -33,8 +33,8 @@ LR = 1e-6              # examples/ctr/models/wdl_criteo.py:12
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2000)
-    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--steps", type=int, default=2048)
+    p.add_argument("--warmup", type=int, default=256)
     p.add_argument("--batch", type=int, default=256)
     p.add_argument("--width", type=int, default=512)
     p.add_argument("--rows", type=int, default=33762577)
@@ -42,6 +42,8 @@ def parse_args():
     p.add_argument("--distinct-batches", type=int, default=1024)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true")
+    p.add_argument("--graph-steps", type=int, default=32,
+                   help="steps captured per hipGraph (1 = eager launches)")
     return p.parse_args()
 
 
@@ -137,26 +139,82 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(456)
     grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(ngrad)]
-    plan = ops.IndexPlan(n, dev)
     nb = ids_dev.shape[0]
+    G = max(1, args.graph_steps)
+    nplan = 4
+    plans = [ops.IndexPlan(n, dev) for _ in range(nplan)]
+    main_s = torch.cuda.Stream(device=dev)
+    side_s = torch.cuda.Stream(device=dev)
+
+    # One step.  The table dependency gather(k) -> apply(k) -> gather(k+1) stays on the main stream;
+    # the index plan of a batch only depends on its ids (known ahead, like the reference's prefetching
+    # dataloader), so sort/finish run on a side stream and join before the apply that consumes them.
+    ev_sorted = [None] * nplan
+    ev_applied = [None] * nplan
 
     def step(k):
         ids = ids_dev[k % nb]
-        ops.embedding_lookup(table, ids, out=out)
-        plan.sort(ids)
-        ops.sgd_apply(table, plan, grads[k % ngrad], LR)
-        plan.finish()
+        pl = plans[k % nplan]
+        if ev_applied[k % nplan] is not None:
+            side_s.wait_event(ev_applied[k % nplan])      # plan buffer free again
+        pl.sort(ids, stream=side_s)
+        ev_sorted[k % nplan] = side_s.record_event()
+        ops.embedding_lookup(table, ids, out=out, stream=main_s)
+        main_s.wait_event(ev_sorted[k % nplan])
+        ops.sgd_apply(table, pl, grads[k % ngrad], LR, stream=main_s)
+        ev_applied[k % nplan] = main_s.record_event()
+        pl.finish(stream=side_s)
 
-    for k in range(args.warmup):
-        step(k)
+    def run_eager(k0, count):
+        for k in range(k0, k0 + count):
+            step(k)
+
+    graphs = {}
+
+    def capture(k0):
+        """Graph of G consecutive steps starting at batch k0 (k0 % G == 0)."""
+        for i in range(nplan):
+            ev_sorted[i] = ev_applied[i] = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=main_s):
+            side_s.wait_stream(main_s)
+            run_eager(k0, G)
+            main_s.wait_stream(side_s)
+        for i in range(nplan):
+            ev_sorted[i] = ev_applied[i] = None
+        return g
+
+    use_graph = G > 1
+    ngraphs = max(1, nb // G) if use_graph else 0
+    if use_graph:
+        torch.cuda.synchronize()
+        for gi in range(ngraphs):
+            graphs[gi] = capture(gi * G)
+        torch.cuda.synchronize()
+
+    def run(k0, count):
+        """Exactly `count` steps starting at step index k0."""
+        k = k0
+        endk = k0 + count
+        with torch.cuda.stream(main_s):
+            while k < endk:
+                if use_graph and k % G == 0 and k + G <= endk:
+                    graphs[(k // G) % ngraphs].replay()
+                    k += G
+                else:
+                    step(k)
+                    k += 1
+            main_s.wait_stream(side_s)
+
+    wu = ((args.warmup + G - 1) // G) * G if use_graph else args.warmup
+    run(0, wu)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    e1.record()
+    e0.record(main_s)
+    run(wu, args.steps)
+    e1.record(main_s)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
@@ -164,38 +222,47 @@ def main():
     ms_per_step = total_ms / args.steps
     rows_per_s = n * args.steps / (total_ms * 1e-3)
 
-    used = [(args.warmup + k) % nb for k in range(args.steps)]
+    used = [(wu + k) % nb for k in range(args.steps)]
     u_mean = float(np.mean(uniq_counts[used]))
     fwd_b, bwd_b = algorithmic_bytes(n, u_mean, args.width)
 
-    # ---- per-kernel pass: HIP events (torch events on the launch stream) around every kernel
+    # ---- per-kernel pass: for every kernel a graph of KL back-to-back launches over KL distinct
+    # batches, bracketed by HIP events on the launch stream -> average launch duration (boundary
+    # to the next launch included)
     kernels = {}
+    roofline = None
     if not args.no_kernel_pass:
-        ksteps = min(args.steps, 500)
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(ksteps)]
-        for k in range(ksteps):
-            ids = ids_dev[(args.warmup + k) % nb]
-            evs[k][0].record()
-            ops.embedding_lookup(table, ids, out=out)
-            evs[k][1].record()
-            plan.sort(ids)
-            evs[k][2].record()
-            ops.sgd_apply(table, plan, grads[k % ngrad], LR)
-            evs[k][3].record()
-            plan.finish()
-            evs[k][4].record()
-        torch.cuda.synchronize()
-        f_ms = np.mean([e[3].elapsed_time(e[4]) for e in evs])
-        g_ms = np.mean([e[0].elapsed_time(e[1]) for e in evs])
-        p_ms = np.mean([e[1].elapsed_time(e[2]) for e in evs])
-        a_ms = np.mean([e[2].elapsed_time(e[3]) for e in evs])
+        KL = 64
+        kplans = [ops.IndexPlan(n, dev).sort(ids_dev[(wu + i) % nb], stream=main_s) for i in range(KL)]
+        main_s.synchronize()
+
+        def timed_graph(fn, reps=5):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=main_s):
+                for i in range(KL):
+                    fn(i)
+            with torch.cuda.stream(main_s):
+                g.replay()
+                main_s.synchronize()
+                a, bq = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(main_s)
+                for _ in range(reps):
+                    g.replay()
+                bq.record(main_s)
+                main_s.synchronize()
+            return a.elapsed_time(bq) / (reps * KL)
+
+        g_ms = timed_graph(lambda i: ops.embedding_lookup(table, ids_dev[(wu + i) % nb], out=out, stream=main_s))
+        s_ms = timed_graph(lambda i: kplans[i].sort(ids_dev[(wu + i) % nb], stream=main_s))
+        a_ms = timed_graph(lambda i: ops.sgd_apply(table, kplans[i], grads[i % ngrad], LR, stream=main_s))
+        f_ms = timed_graph(lambda i: kplans[i].finish(stream=main_s))
         kernels = {
             "gather_vec4_kernel": {"avg_us": g_ms * 1e3, "algorithmic_bytes": fwd_b,
                                    "GBps": fwd_b / (g_ms * 1e-3) / 1e9},
-            "plan_rank_small_kernel": {"avg_us": p_ms * 1e3, "algorithmic_bytes": 0},
-            "finish_small_kernel": {"avg_us": f_ms * 1e3, "algorithmic_bytes": 0},
+            "plan_rank_small_kernel": {"avg_us": s_ms * 1e3, "algorithmic_bytes": 0},
             "apply_kernel<sgd>": {"avg_us": a_ms * 1e3, "algorithmic_bytes": bwd_b,
                                   "GBps": bwd_b / (a_ms * 1e-3) / 1e9},
+            "finish_small_kernel": {"avg_us": f_ms * 1e3, "algorithmic_bytes": 0},
         }
         dom = "apply_kernel<sgd>" if a_ms >= g_ms else "gather_vec4_kernel"
         dom_bytes = bwd_b if a_ms >= g_ms else fwd_b
@@ -204,13 +271,11 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_us": dom_ms * 1e3, "algorithmic_bytes_per_launch": dom_bytes}
-    else:
-        roofline = None
 
     step_gbs = (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9
     result = {
         "metric": "embedding rows/s (lookup+grad)", "value": rows_per_s, "unit": "rows/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": 1, "steps": args.steps, "warmup": wu, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "wdl_criteo bs=%d d=%d, %d fields, full %d-row fp32 table in HBM (%.1f GB), "
@@ -219,6 +284,7 @@ def main():
                                % (args.batch, args.width, args.fields, args.rows,
                                   args.rows * args.width * 4 / 1e9),
                    "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,
+                   "launch": ("hipGraph of %d steps" % G) if use_graph else "eager",
                    "parallelism": "1 GPU"},
         "step_algorithmic_bytes": fwd_b + bwd_b,
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,

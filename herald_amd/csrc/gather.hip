@@ -38,30 +38,39 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(
     const IdT *__restrict__ ids, uint64_t total_vec, float *__restrict__ out) {
     const uint64_t base =
         static_cast<uint64_t>(blockIdx.x) * (256u * UNROLL) + threadIdx.x;
-    float4v v[UNROLL];
+    // Loads are branch-free (clamped addresses): hipcc puts an s_waitcnt vmcnt(0) behind every load
+    // that sits in its own exec-masked branch, which would serialise the UNROLL row reads.
+    const uint64_t last = total_vec - 1;
+    uint64_t row[UNROLL], col[UNROLL];
+    IdT idv[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-        const uint64_t e = base + static_cast<uint64_t>(u) * 256u;
-        v[u] = float4v{0.f, 0.f, 0.f, 0.f};
-        if (e < total_vec) {
-            uint64_t i, c;
-            if (NV_SHIFT >= 0) {
-                i = e >> NV_SHIFT;
-                c = e & ((1u << NV_SHIFT) - 1u);
-            } else {
-                i = e / nv;
-                c = e - i * nv;
-            }
-            const uint64_t r = id_to_row<IdT>(ids[i]);
-            if (r < rows)
-                v[u] = ld4(table + (r * nv + c) * 4u);
+        uint64_t e = base + static_cast<uint64_t>(u) * 256u;
+        e = e < last ? e : last;
+        uint64_t i;
+        if (NV_SHIFT >= 0) {
+            i = e >> NV_SHIFT;
+            col[u] = e & ((1u << NV_SHIFT) - 1u);
+        } else {
+            i = e / nv;
+            col[u] = e - i * nv;
         }
+        idv[u] = ids[i];
+    }
+    float4v v[UNROLL];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint64_t r = id_to_row<IdT>(idv[u]);
+        ok[u] = r < rows;
+        row[u] = ok[u] ? r : 0;
+        v[u] = ld4(table + (row[u] * nv + col[u]) * 4u);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
         const uint64_t e = base + static_cast<uint64_t>(u) * 256u;
         if (e < total_vec)
-            st4_nt(out + e * 4u, v[u]);
+            st4_nt(out + e * 4u, ok[u] ? v[u] : float4v{0.f, 0.f, 0.f, 0.f});
     }
 }
 

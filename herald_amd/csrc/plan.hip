@@ -115,9 +115,8 @@ __global__ __launch_bounds__(1024) void plan_rank_small_kernel(
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int j = base + threadIdx.x + k * 1024;
-            v[k] = kPadKey;
-            if (j < n)
-                v[k] = to_key<IdT>(ids[j]);
+            const uint32_t kv = to_key<IdT>(ids[min(j, n - 1)]);  // branch-free load
+            v[k] = j < n ? kv : kPadKey;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -437,8 +436,8 @@ __global__ __launch_bounds__(1024) void finish_small_kernel(
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             const int p = threadIdx.x + k * 1024;
-            a[k] = p < n ? sorted[p] : 0u;
-            b[k] = (p < n && p > 0) ? sorted[p - 1] : 0u;
+            a[k] = sorted[min(p, n - 1)];              // branch-free loads
+            b[k] = sorted[max(min(p, n - 1) - 1, 0)];
         }
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
@@ -506,8 +505,8 @@ __global__ __launch_bounds__(1024) void finish_small_kernel(
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             const int p = threadIdx.x + k * 1024;
-            pv[k] = p < n ? perm[p] : 0;
-            sv[k] = p < n ? sorted[p] : 0u;
+            pv[k] = perm[min(p, n - 1)];
+            sv[k] = sorted[min(p, n - 1)];
         }
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {

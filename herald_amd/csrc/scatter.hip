@@ -22,9 +22,9 @@
 //     occurrence rows with 16-byte loads (up to kDepth occurrence rows in flight) and applies them in
 //     order;
 //   * long run (hot row: a low-cardinality Criteo field repeats one id hundreds of times per batch):
-//     the whole workgroup streams the occurrence rows through LDS -- all 16 waves load (flat,
-//     coalesced, kStages rounds of loads in flight), then one thread per column applies the staged
-//     rows in occurrence order.  The serial chain per column is the only ordered part.
+//     the run is column-split over the waves of the head's workgroup, 64 columns per wave, each
+//     wave streaming the occurrence rows of its slice in order with 2x32 loads in flight.  The
+//     two-instruction chain per occurrence and column is the only ordered part.
 // Waves at non-head positions exit (their occurrence is consumed by the head's wave/workgroup).
 #include "common.h"
 
@@ -39,9 +39,6 @@ enum ApplyMode {
 constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per workgroup
 constexpr int kHotLen = 16;        // runs at least this long take the workgroup-cooperative path
 constexpr int kDepth = 8;          // cold path: occurrence rows in flight per wave
-constexpr int kStages = 4;         // hot path: rounds of global loads in flight
-constexpr int kBufFloats = 8192;   // hot path: LDS staging buffer (32 KiB)
-constexpr int kPermChunk = 1024;   // hot path: occurrence indices staged per super-round
 
 template <int MODE>
 __device__ __forceinline__ float step(float acc, float g, float lr) {
@@ -80,24 +77,25 @@ __device__ __forceinline__ void cold_block(float *__restrict__ dst_row,
     const int lane = lane_id();
     Vec<VEC> acc[VB];
     int col[VB];
+    int lcol[VB];  // clamped column: loads are branch-free, stores are guarded
 #pragma unroll
     for (int b = 0; b < VB; ++b) {
         col[b] = cbase + (b * kWave + lane) * VEC;
+        lcol[b] = col[b] < width ? col[b] : 0;
         acc[b].zero();
-        if (MODE == kModeSgd && col[b] < width)
-            acc[b].load(dst_row + col[b]);
+        if (MODE == kModeSgd)
+            acc[b].load(dst_row + lcol[b]);
     }
     for (int q0 = 0; q0 < len; q0 += kDepth) {
         Vec<VEC> g[kDepth][VB];
 #pragma unroll
         for (int t = 0; t < kDepth; ++t) {
-            if (q0 + t < len) {
+            if (q0 + t < len) {  // wave-uniform
                 const int idx = __builtin_amdgcn_readlane(permv, q0 + t);
                 const float *src = grads + static_cast<size_t>(idx) * width;
 #pragma unroll
                 for (int b = 0; b < VB; ++b)
-                    if (col[b] < width)
-                        g[t][b].load(src + col[b]);
+                    g[t][b].load(src + lcol[b]);
             }
         }
 #pragma unroll
@@ -116,7 +114,7 @@ __device__ __forceinline__ void cold_block(float *__restrict__ dst_row,
         if (col[b] < width) {
             if (MODE == kModePush) {
                 Vec<VEC> cur;
-                cur.load(dst_row + col[b]);
+                cur.load(dst_row + lcol[b]);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
                     acc[b].set(k, __fadd_rn(cur.get(k), acc[b].get(k)));
@@ -139,87 +137,56 @@ __device__ __forceinline__ void cold_row(float *__restrict__ dst_row,
         cold_block<MODE, VEC, 1>(dst_row, grads, width, c, permv, len, lr);
 }
 
-// ---- hot path: the whole workgroup streams one long run through LDS -------------------------------
-// Columns [cb, cb+CB) of every occurrence row are staged round by round: a round is R = kBufFloats/CB
-// occurrence rows = kBufFloats/VEC vector units, loaded flat (unit f -> occurrence f / (CB/VEC),
-// column (f % (CB/VEC))*VEC), i.e. kBufFloats/VEC/1024 units per thread.
-template <int MODE, int VEC>
-__device__ __forceinline__ void hot_run(float *__restrict__ dst_row,
-                                        const float *__restrict__ grads,
-                                        const int32_t *__restrict__ perm_run,
-                                        int len, int width, float lr,
-                                        float *s_buf, int32_t *s_perm) {
-    constexpr int kUnits = kBufFloats / VEC / 1024;  // units per thread per round: 2 (VEC=4), 8 (VEC=1)
-    const int tid = threadIdx.x;
-    // column block: power of two in [64*VEC, 1024] (one combiner thread per column)
-    int CB = 64 * VEC;
-    while (CB < width && CB < 1024)
-        CB <<= 1;
-    const int upr = CB / VEC;       // units per occurrence-row slice
-    const int R = kBufFloats / CB;  // occurrence rows per round
+// ---- hot path: a long run is column-split over the waves of the head's workgroup ------------------
+// Wave s owns the 64 columns [64*s, 64*s+64) (one dword per lane, 256 contiguous bytes per occurrence
+// row) and walks the run's occurrences in order with kHotDepth loads in flight in each of two
+// register half-rings, so the only serial part is the two-instruction chain per occurrence.  All
+// loads are branch-free (occurrence index and column clamped) so that hipcc counts vmcnt across the
+// ring instead of draining it.
+constexpr int kHotDepth = 32;
 
-    for (int cb = 0; cb < width; cb += CB) {
-        const int mycol = cb + tid;
-        const bool combiner = tid < CB && mycol < width;
-        float acc = 0.f;
-        if (MODE == kModeSgd && combiner)
-            acc = dst_row[mycol];
-        for (int s0 = 0; s0 < len; s0 += kPermChunk) {
-            const int slen = min(kPermChunk, len - s0);
-            __syncthreads();  // previous users of s_perm / s_buf are done
-            s_perm[tid] = tid < slen ? perm_run[s0 + tid] : 0;
-            __syncthreads();
-            const int nr = (slen + R - 1) / R;
-            Vec<VEC> rg[kStages][kUnits];
+template <int MODE>
+__device__ __forceinline__ void hot_slice(float *__restrict__ dst_row,
+                                          const float *__restrict__ grads,
+                                          const int32_t *__restrict__ perm_run,
+                                          int len, int width, int col, float lr) {
+    const int lane = lane_id();
+    const bool live = col < width;
+    const int lcol = live ? col : 0;
+    float acc = 0.f;
+    if (MODE == kModeSgd)
+        acc = dst_row[lcol];
+    const float *gcol = grads + lcol;
 
-            auto issue = [&](int r, Vec<VEC>(&dstv)[kUnits]) {
+    auto load_chunk = [&](float(&g)[kHotDepth], int q0) {
+        // occurrence indices come through the scalar cache (wave-uniform addresses): SMEM loads
+        // count on lgkmcnt, so fetching them never drains the vector-memory ring (vmcnt)
 #pragma unroll
-                for (int k = 0; k < kUnits; ++k) {
-                    const int f = tid + k * 1024;
-                    const int m = f / upr;
-                    const int c = cb + (f - m * upr) * VEC;
-                    const int q = r * R + m;
-                    dstv[k].zero();
-                    if (q < slen && c < width)
-                        dstv[k].load(grads + static_cast<size_t>(s_perm[q]) * width + c);
-                }
-            };
-            auto stage_and_combine = [&](int r, Vec<VEC>(&srcv)[kUnits]) {
-#pragma unroll
-                for (int k = 0; k < kUnits; ++k) {
-                    const int f = tid + k * 1024;
-                    srcv[k].store(s_buf + f * VEC);
-                }
-                __syncthreads();
-                const int cnt = min(R, slen - r * R);
-                if (combiner) {
-                    for (int m = 0; m < cnt; ++m)
-                        acc = step<MODE>(acc, s_buf[m * CB + tid], lr);
-                }
-                __syncthreads();
-            };
-
-#pragma unroll
-            for (int d = 0; d < kStages - 1; ++d)
-                if (d < nr)
-                    issue(d, rg[d]);
-            for (int r0 = 0; r0 < nr; r0 += kStages) {
-#pragma unroll
-                for (int j = 0; j < kStages; ++j) {
-                    const int r = r0 + j;
-                    if (r < nr) {
-                        if (r + kStages - 1 < nr)
-                            issue(r + kStages - 1, rg[(j + kStages - 1) % kStages]);
-                        stage_and_combine(r, rg[j]);
-                    }
-                }
-            }
+        for (int t = 0; t < kHotDepth; ++t) {
+            const int idx = perm_run[uniform(min(q0 + t, len - 1))];
+            g[t] = gcol[static_cast<size_t>(idx) * width];
         }
-        if (combiner) {
-            if (MODE == kModePush)
-                acc = __fadd_rn(dst_row[mycol], acc);
-            dst_row[mycol] = acc;
+    };
+    auto consume = [&](const float(&g)[kHotDepth], int q0) {
+#pragma unroll
+        for (int t = 0; t < kHotDepth; ++t) {
+            const float nx = step<MODE>(acc, g[t], lr);
+            acc = (q0 + t < len) ? nx : acc;
         }
+    };
+
+    float ga[kHotDepth], gb[kHotDepth];
+    load_chunk(ga, 0);
+    for (int q0 = 0; q0 < len; q0 += 2 * kHotDepth) {
+        load_chunk(gb, q0 + kHotDepth);
+        consume(ga, q0);
+        load_chunk(ga, q0 + 2 * kHotDepth);
+        consume(gb, q0 + kHotDepth);
+    }
+    if (live) {
+        if (MODE == kModePush)
+            acc = __fadd_rn(dst_row[col], acc);
+        dst_row[col] = acc;
     }
 }
 
@@ -229,8 +196,6 @@ __global__ __launch_bounds__(1024) void apply_kernel(
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr) {
-    __shared__ __attribute__((aligned(16))) float s_buf[kBufFloats];
-    __shared__ int32_t s_perm[kPermChunk];
     __shared__ int s_hot_p;
     __shared__ int s_scan[kPosPerBlock];
     const int lane = lane_id();
@@ -243,15 +208,10 @@ __global__ __launch_bounds__(1024) void apply_kernel(
     // ---- phase A: classify my sorted position
     const bool in_range = p < n;
     const int pos = p + lane;
-    uint32_t ks = 0;
-    int permv = 0;
-    if (pos < n) {
-        ks = sorted[pos];
-        permv = perm[pos];
-    }
-    uint32_t prevk = 0;
-    if (in_range && p > 0)
-        prevk = sorted[p - 1];
+    const int cpos = min(pos, n - 1);
+    const uint32_t ks = sorted[cpos];
+    const int permv = perm[cpos];
+    const uint32_t prevk = sorted[max(min(p, n - 1) - 1, 0)];
     const uint32_t key = uniform(ks);
     const unsigned long long same = __ballot(pos < n && ks == key);
     const int len64 = (~same == 0ull) ? 64 : __builtin_ctzll(~same);
@@ -294,9 +254,11 @@ __global__ __launch_bounds__(1024) void apply_kernel(
             row = hkey;
             ok = row < dst_rows;
         }
-        if (ok)
-            hot_run<MODE, VEC>(dst + row * static_cast<uint64_t>(width), grads,
-                               perm + hp, len, width, lr, s_buf, s_perm);
+        if (ok) {
+            for (int col = w * kWave + lane; col - lane < width; col += kPosPerBlock * kWave)
+                hot_slice<MODE>(dst + row * static_cast<uint64_t>(width), grads,
+                                perm + hp, len, width, col, lr);
+        }
     }
 
     // ---- phase C: short runs, one wave each
