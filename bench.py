@@ -141,47 +141,26 @@ def main():
     grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(ngrad)]
     nb = ids_dev.shape[0]
     G = max(1, args.graph_steps)
-    nplan = 4
-    plans = [ops.IndexPlan(n, dev) for _ in range(nplan)]
+    plan = ops.IndexPlan(n, dev)
     main_s = torch.cuda.Stream(device=dev)
-    side_s = torch.cuda.Stream(device=dev)
 
-    # One step.  The table dependency gather(k) -> apply(k) -> gather(k+1) stays on the main stream;
-    # the index plan of a batch only depends on its ids (known ahead, like the reference's prefetching
-    # dataloader), so sort/finish run on a side stream and join before the apply that consumes them.
-    ev_sorted = [None] * nplan
-    ev_applied = [None] * nplan
-
+    # One step = two launches on one stream:
+    #   forward : gather(ids) + stable sort of ids            (ha_lookup_sort_f32ids)
+    #   backward: fused SGD apply + plan finish (uniq/counts) (ha_sgd_apply_finish)
+    # The table dependency gather(k) -> apply(k) -> gather(k+1) is the stream order.
     def step(k):
         ids = ids_dev[k % nb]
-        pl = plans[k % nplan]
-        if ev_applied[k % nplan] is not None:
-            side_s.wait_event(ev_applied[k % nplan])      # plan buffer free again
-        pl.sort(ids, stream=side_s)
-        ev_sorted[k % nplan] = side_s.record_event()
-        ops.embedding_lookup(table, ids, out=out, stream=main_s)
-        main_s.wait_event(ev_sorted[k % nplan])
-        ops.sgd_apply(table, pl, grads[k % ngrad], LR, stream=main_s)
-        ev_applied[k % nplan] = main_s.record_event()
-        pl.finish(stream=side_s)
-
-    def run_eager(k0, count):
-        for k in range(k0, k0 + count):
-            step(k)
+        ops.lookup_sort(table, ids, plan, out=out, stream=main_s)
+        ops.sgd_apply_finish(table, plan, grads[k % ngrad], LR, stream=main_s)
 
     graphs = {}
 
     def capture(k0):
         """Graph of G consecutive steps starting at batch k0 (k0 % G == 0)."""
-        for i in range(nplan):
-            ev_sorted[i] = ev_applied[i] = None
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=main_s):
-            side_s.wait_stream(main_s)
-            run_eager(k0, G)
-            main_s.wait_stream(side_s)
-        for i in range(nplan):
-            ev_sorted[i] = ev_applied[i] = None
+            for k in range(k0, k0 + G):
+                step(k)
         return g
 
     use_graph = G > 1
@@ -204,7 +183,6 @@ def main():
                 else:
                     step(k)
                     k += 1
-            main_s.wait_stream(side_s)
 
     wu = ((args.warmup + G - 1) // G) * G if use_graph else args.warmup
     run(0, wu)
@@ -252,19 +230,17 @@ def main():
                 main_s.synchronize()
             return a.elapsed_time(bq) / (reps * KL)
 
-        g_ms = timed_graph(lambda i: ops.embedding_lookup(table, ids_dev[(wu + i) % nb], out=out, stream=main_s))
-        s_ms = timed_graph(lambda i: kplans[i].sort(ids_dev[(wu + i) % nb], stream=main_s))
-        a_ms = timed_graph(lambda i: ops.sgd_apply(table, kplans[i], grads[i % ngrad], LR, stream=main_s))
-        f_ms = timed_graph(lambda i: kplans[i].finish(stream=main_s))
+        g_ms = timed_graph(lambda i: ops.lookup_sort(table, ids_dev[(wu + i) % nb], kplans[i], out=out,
+                                                     stream=main_s))
+        a_ms = timed_graph(lambda i: ops.sgd_apply_finish(table, kplans[i], grads[i % ngrad], LR,
+                                                          stream=main_s))
         kernels = {
-            "gather_vec4_kernel": {"avg_us": g_ms * 1e3, "algorithmic_bytes": fwd_b,
-                                   "GBps": fwd_b / (g_ms * 1e-3) / 1e9},
-            "plan_rank_small_kernel": {"avg_us": s_ms * 1e3, "algorithmic_bytes": 0},
-            "apply_kernel<sgd>": {"avg_us": a_ms * 1e3, "algorithmic_bytes": bwd_b,
-                                  "GBps": bwd_b / (a_ms * 1e-3) / 1e9},
-            "finish_small_kernel": {"avg_us": f_ms * 1e3, "algorithmic_bytes": 0},
+            "fwd_fused_kernel(gather+rank)": {"avg_us": g_ms * 1e3, "algorithmic_bytes": fwd_b,
+                                              "GBps": fwd_b / (g_ms * 1e-3) / 1e9},
+            "bwd_fused_kernel(sgd apply+finish)": {"avg_us": a_ms * 1e3, "algorithmic_bytes": bwd_b,
+                                                   "GBps": bwd_b / (a_ms * 1e-3) / 1e9},
         }
-        dom = "apply_kernel<sgd>" if a_ms >= g_ms else "gather_vec4_kernel"
+        dom = "bwd_fused_kernel(sgd apply+finish)" if a_ms >= g_ms else "fwd_fused_kernel(gather+rank)"
         dom_bytes = bwd_b if a_ms >= g_ms else fwd_b
         dom_ms = max(a_ms, g_ms)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9,

@@ -101,6 +101,10 @@ def _declare(L):
         "ha_sgd_apply": [vp, i64, i64, vp, i64, vp, f32, vp],
         "ha_push_apply": [vp, i64, i64, vp, i64, vp, vp],
         "ha_sgd_sparse_update_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp],
+        "ha_lookup_sort_f32ids": [vp, i64, i64, vp, i64, vp, vp, vp],
+        "ha_lookup_sort_u64ids": [vp, i64, i64, vp, i64, vp, vp, vp],
+        "ha_sgd_apply_finish": [vp, i64, i64, vp, i64, vp, f32, vp],
+        "ha_push_apply_finish": [vp, i64, i64, vp, i64, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

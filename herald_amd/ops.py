@@ -237,6 +237,49 @@ def sgd_sparse_update(table, ids, grads, lr, stream=None):
     return table
 
 
+# ---- fused launches: two per training step --------------------------------------------------------
+def lookup_sort(table, ids, plan, out=None, stream=None):
+    """Forward of one batch in ONE launch: out = table[ids] and plan.sort(ids)."""
+    L = _lib.load()
+    _require(table, torch.float32, "table")
+    n = ids.numel()
+    width = table.shape[1]
+    if n > plan.capacity:
+        raise ValueError("plan capacity %d < %d ids" % (plan.capacity, n))
+    if out is None:
+        out = torch.empty(tuple(ids.shape) + (width,), dtype=torch.float32, device=table.device)
+    if ids.dtype == torch.float32:
+        fn = L.ha_lookup_sort_f32ids
+    elif ids.dtype in (torch.int64, torch.uint64):
+        fn = L.ha_lookup_sort_u64ids
+    else:
+        raise TypeError("ids must be float32 or (u)int64")
+    check(fn(_ptr(table), table.shape[0], width, _ptr(ids), n, _ptr(out), _ptr(plan.ws),
+             _stream_ptr(stream)), "ha_lookup_sort")
+    plan.n = n
+    plan._view = None
+    return out
+
+
+def sgd_apply_finish(table, plan, grads, lr, stream=None):
+    """Backward of one batch in ONE launch: sgd_apply + plan.finish()."""
+    _require(table, torch.float32, "table")
+    _require(grads, torch.float32, "grads")
+    check(_lib.load().ha_sgd_apply_finish(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws),
+                                          plan.n, _ptr(grads), ctypes.c_float(lr), _stream_ptr(stream)),
+          "ha_sgd_apply_finish")
+    return table
+
+
+def push_apply_finish(table, plan, grads, stream=None):
+    _require(table, torch.float32, "table")
+    _require(grads, torch.float32, "grads")
+    check(_lib.load().ha_push_apply_finish(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws),
+                                           plan.n, _ptr(grads), _stream_ptr(stream)),
+          "ha_push_apply_finish")
+    return table
+
+
 # ---- reference-named symbols through the DLArray ABI ---------------------------------------------
 def dl_call(name, arrays, scalars=(), stream=None):
     """Call a reference-named symbol: arrays -> DLArray*, then scalars, then DLStream*."""

@@ -207,6 +207,25 @@ int ha_push_apply(float *table, int64_t rows, int64_t width,
                   const void *plan_ws, int64_t n, const float *grads,
                   ha_stream_t stream);
 
+/* ---- fused launches (two per training step) --------------------------------
+ * ha_lookup_sort_*    == ha_gather_* + ha_plan_sort_*   in ONE launch (forward: the lookup of a
+ *                        batch and the index plan its backward will need);
+ * ha_sgd_apply_finish == ha_sgd_apply + ha_plan_finish  in ONE launch (backward);
+ * ha_push_apply_finish likewise for the PS push semantics.  Bit-identical to the unfused calls;
+ * batches larger than the single-launch sort limit fall back to the unfused sequence. */
+int ha_lookup_sort_f32ids(const float *table, int64_t rows, int64_t width,
+                          const float *ids, int64_t n, float *out,
+                          void *plan_ws, ha_stream_t stream);
+int ha_lookup_sort_u64ids(const float *table, int64_t rows, int64_t width,
+                          const uint64_t *ids, int64_t n, float *out,
+                          void *plan_ws, ha_stream_t stream);
+int ha_sgd_apply_finish(float *table, int64_t rows, int64_t width,
+                        void *plan_ws, int64_t n, const float *grads, float lr,
+                        ha_stream_t stream);
+int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
+                         void *plan_ws, int64_t n, const float *grads,
+                         ha_stream_t stream);
+
 /* One-call convenience used by the reference-named SGDOptimizerSparseUpdate:
  * plan + apply using an internal per-stream workspace. */
 int ha_sgd_sparse_update_f32ids(float *table, int64_t rows, int64_t width,

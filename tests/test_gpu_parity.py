@@ -217,3 +217,36 @@ def test_full_size_step_properties(dev):
     want = cpu.sgd_sparse_update(t0.cpu().numpy(), ids_np, grads.cpu().numpy(), 0.5)
     np.testing.assert_array_equal(table.cpu().numpy(), want)
     assert torch.equal(before, ops.embedding_lookup(t0, ids))
+
+
+@pytest.mark.parametrize("width,n", [(512, 6656), (128, 6656), (64, 100), (512, 15360), (200, 300), (512, 20000)])
+def test_fused_step_matches_oracle_and_unfused(dev, width, n):
+    """ha_lookup_sort_* + ha_sgd_apply_finish (two launches) == oracle == the unfused four calls."""
+    rng = np.random.default_rng(width + n)
+    rows = 40000
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = (synth.criteo_batch(max(1, (n + 25) // 26), 3).reshape(-1)[:n] % rows).astype(np.float32)
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    lr = 0.05
+    want_out = cpu.embedding_lookup(table, ids)
+    uniq, inv, cnt = cpu.unique(cpu.ids_to_keys(ids))
+    want_t = cpu.sgd_sparse_update(table.copy(), ids, grads, lr)
+    t = _dev(table, dev)
+    d_ids = _dev(ids, dev)
+    plan = ops.IndexPlan(n, dev)
+    out = ops.lookup_sort(t, d_ids, plan)
+    ops.sgd_apply_finish(t, plan, _dev(grads, dev), lr)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), want_out)
+    np.testing.assert_array_equal(t.cpu().numpy(), want_t)
+    u = plan.n_unique()
+    assert u == uniq.size
+    np.testing.assert_array_equal(_u32(plan.uniq(u)), uniq)
+    np.testing.assert_array_equal(plan.inverse().cpu().numpy().astype(np.int64), inv)
+    np.testing.assert_array_equal(plan.counts(u).cpu().numpy().astype(np.int64), cnt)
+    # push flavour
+    t2 = _dev(table, dev)
+    ops.lookup_sort(t2, d_ids, plan)
+    ops.push_apply_finish(t2, plan, _dev(grads, dev))
+    _, _, red = cpu.dedup_reduce(ids, grads)
+    np.testing.assert_array_equal(t2.cpu().numpy(), cpu.push_apply(table.copy(), uniq, red))
