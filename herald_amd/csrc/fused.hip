@@ -32,7 +32,7 @@ __global__ __launch_bounds__(1024) void fwd_fused_kernel(
 }
 
 template <int MODE, int VEC>
-__global__ __launch_bounds__(1024, 8) void bwd_fused_kernel(
+__global__ __launch_bounds__(1024) void bwd_fused_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     int n, const float *__restrict__ grads, float lr,

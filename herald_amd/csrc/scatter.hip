@@ -15,28 +15,35 @@
 // 282-295); here every unique row is read once, updated in registers and written once:
 // algorithmic bytes per batch = n*(4*width + 4) + U*8*width.
 //
-// Work mapping.  Input is the stable sort of the batch keys (`sorted`, `perm`).  A 1024-thread
-// workgroup owns 16 consecutive sorted positions, one wave each.  A wave whose position starts a run
-// of equal keys ("head") owns that unique row:
-//   * short run (< kHotLen occurrences, the common case): the wave alone loads the table row and all
-//     occurrence rows with 16-byte loads (up to kDepth occurrence rows in flight) and applies them in
-//     order;
-//   * long run (hot row: a low-cardinality Criteo field repeats one id hundreds of times per batch):
-//     the run is column-split over the waves of the head's workgroup, 64 columns per wave, each
-//     wave streaming the occurrence rows of its slice in order with 2x32 loads in flight.  The
-//     two-instruction chain per occurrence and column is the only ordered part.
-// Waves at non-head positions exit (their occurrence is consumed by the head's wave/workgroup).
+// Work mapping.  Input is the stable sort of the batch keys (`sorted`, `perm`).  One wavefront per
+// SORTED POSITION p, no workgroup-level synchronisation.  A wave reads the window of sorted keys
+// p-16..p+47 and finds its offset o in its run of equal keys:
+//   * run of 1..3 occurrences (the common case): the wave at o == 0 loads the table row and all
+//     occurrence rows with 16-byte loads in one batch and applies them in order;
+//   * longer run (a low-cardinality Criteo field repeats one id hundreds of times per batch): the
+//     first min(L,16) waves of the run each take 64-column slices and stream ALL occurrences of
+//     the run for their slice in order, 2x16 loads in flight (split_slice in scatter_dev.h).  The
+//     two-instruction chain per occurrence and column is the only ordered part;
+//   * every other wave of a run exits.
 #include "scatter_dev.h"
 
 namespace ha {
 
 template <int MODE, int VEC>
-__global__ __launch_bounds__(1024, 8) void apply_kernel(
+__global__ __launch_bounds__(1024) void apply_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr) {
     apply_body<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, blockIdx.x);
+}
+
+// diagnostic twin of apply_kernel<kModeSgd,4>: same body plus per-wave time stamps
+__global__ __launch_bounds__(1024) void apply_timeline_kernel(
+    float *__restrict__ dst, uint64_t dst_rows, int width,
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    int n, const float *__restrict__ grads, float lr, unsigned long long *dbg) {
+    apply_body<kModeSgd, 4>(dst, dst_rows, width, sorted, perm, nullptr, n, grads, lr, blockIdx.x, dbg);
 }
 
 }  // namespace ha
@@ -96,4 +103,21 @@ extern "C" int ha_dedup_reduce(const void *plan_ws, int64_t n,
                                float *reduced, ha_stream_t stream) {
     return ha::apply_launch<ha::kModeReduce>(reduced, n, width, plan_ws, n,
                                              grads, 0.f, ha::as_stream(stream));
+}
+
+// Development aid (tools/timeline.py): SGD apply with per-wave {start, end, role, cycles} stamps
+// written to dbg[4*n] (s_memrealtime ticks are 10 ns).  Not part of the product path.
+extern "C" int ha_debug_apply_timeline(float *table, int64_t rows, int64_t width,
+                                       const void *plan_ws, int64_t n,
+                                       const float *grads, float lr,
+                                       unsigned long long *dbg, ha_stream_t stream) {
+    HA_REQUIRE(table && plan_ws && grads && dbg && n > 0 && width % 4 == 0, "timeline: bad arguments");
+    ha_plan_view v;
+    if (ha_plan_view_of(const_cast<void *>(plan_ws), n, &v) != 0)
+        return -1;
+    const unsigned blocks = static_cast<unsigned>((n + ha::kPosPerBlock - 1) / ha::kPosPerBlock);
+    hipLaunchKernelGGL(ha::apply_timeline_kernel, dim3(blocks), dim3(1024), 0, ha::as_stream(stream),
+                       table, (uint64_t)rows, (int)width, v.sorted, v.perm, (int)n, grads, lr, dbg);
+    HA_LAUNCH_CHECK();
+    return 0;
 }

@@ -11,9 +11,10 @@ enum ApplyMode {
     kModeReduce = 2,  // out[u] = 0 + g0 + g1 ...
 };
 
-constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per workgroup
-constexpr int kHotLen = 16;        // runs at least this long take the workgroup-cooperative path
-constexpr int kDepth = 4;          // cold path: occurrence rows in flight per wave
+constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per 1024-thread workgroup
+constexpr int kLookBack = 16;      // positions a wave looks back to find its offset in its run
+constexpr int kShortRun = 3;       // runs up to this long: one wave, whole row, 16-byte accesses
+constexpr int kHotDepth = 16;      // split mode: loads per chunk (a 64-block is 4 chunks)
 
 template <int MODE>
 __device__ __forceinline__ float step(float acc, float g, float lr) {
@@ -43,16 +44,17 @@ struct Vec<1> {
     __device__ __forceinline__ void set(int, float x) { v = x; }
 };
 
-// ---- cold path: one wave, whole row, columns [cbase, cbase + VB*64*VEC) per call ---------------
+// ---- short runs (1..kShortRun occurrences): one wave, whole row --------------------------------
+// Columns [cbase, cbase + VB*64*VEC); the table row and every occurrence row are requested in one
+// batch (branch-free, clamped), then applied in occurrence order.
 template <int MODE, int VEC, int VB>
-__device__ __forceinline__ void cold_block(float *__restrict__ dst_row,
-                                           const float *__restrict__ grads,
-                                           int width, int cbase, int permv,
-                                           int len, float lr) {
+__device__ __forceinline__ void short_block(float *__restrict__ dst_row,
+                                            const float *__restrict__ grads,
+                                            int width, int cbase, int pv,
+                                            int lane0, int len, float lr) {
     const int lane = lane_id();
-    Vec<VEC> acc[VB];
-    int col[VB];
-    int lcol[VB];  // clamped column: loads are branch-free, stores are guarded
+    Vec<VEC> acc[VB], g[kShortRun][VB];
+    int col[VB], lcol[VB];
 #pragma unroll
     for (int b = 0; b < VB; ++b) {
         col[b] = cbase + (b * kWave + lane) * VEC;
@@ -61,27 +63,22 @@ __device__ __forceinline__ void cold_block(float *__restrict__ dst_row,
         if (MODE == kModeSgd)
             acc[b].load(dst_row + lcol[b]);
     }
-    for (int q0 = 0; q0 < len; q0 += kDepth) {
-        Vec<VEC> g[kDepth][VB];
 #pragma unroll
-        for (int t = 0; t < kDepth; ++t) {
-            if (q0 + t < len) {  // wave-uniform
-                const int idx = __builtin_amdgcn_readlane(permv, q0 + t);
-                const float *src = grads + static_cast<size_t>(idx) * width;
+    for (int t = 0; t < kShortRun; ++t) {
+        const int idx = __builtin_amdgcn_readlane(pv, lane0 + (t < len ? t : 0));
+        const float *src = grads + static_cast<size_t>(idx) * width;
 #pragma unroll
-                for (int b = 0; b < VB; ++b)
-                    g[t][b].load(src + lcol[b]);
-            }
-        }
+        for (int b = 0; b < VB; ++b)
+            g[t][b].load(src + lcol[b]);
+    }
 #pragma unroll
-        for (int t = 0; t < kDepth; ++t) {
-            if (q0 + t < len) {
+    for (int t = 0; t < kShortRun; ++t) {
+        if (t < len) {  // wave-uniform
 #pragma unroll
-                for (int b = 0; b < VB; ++b)
+            for (int b = 0; b < VB; ++b)
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k)
-                        acc[b].set(k, step<MODE>(acc[b].get(k), g[t][b].get(k), lr));
-            }
+                for (int k = 0; k < VEC; ++k)
+                    acc[b].set(k, step<MODE>(acc[b].get(k), g[t][b].get(k), lr));
         }
     }
 #pragma unroll
@@ -100,34 +97,34 @@ __device__ __forceinline__ void cold_block(float *__restrict__ dst_row,
 }
 
 template <int MODE, int VEC>
-__device__ __forceinline__ void cold_row(float *__restrict__ dst_row,
-                                         const float *__restrict__ grads,
-                                         int width, int permv, int len,
-                                         float lr) {
+__device__ __forceinline__ void short_row(float *__restrict__ dst_row,
+                                          const float *__restrict__ grads,
+                                          int width, int pv, int lane0, int len,
+                                          float lr) {
     constexpr int kCols1 = kWave * VEC;
     int c = 0;
     for (; width - c > kCols1; c += 2 * kCols1)
-        cold_block<MODE, VEC, 2>(dst_row, grads, width, c, permv, len, lr);
+        short_block<MODE, VEC, 2>(dst_row, grads, width, c, pv, lane0, len, lr);
     for (; c < width; c += kCols1)
-        cold_block<MODE, VEC, 1>(dst_row, grads, width, c, permv, len, lr);
+        short_block<MODE, VEC, 1>(dst_row, grads, width, c, pv, lane0, len, lr);
 }
 
-// ---- hot path: a long run is column-split over the waves of the head's workgroup ------------------
-// Wave s owns the 64 columns [64*s, 64*s+64) (one dword per lane, 256 contiguous bytes per occurrence
-// row) and walks the run's occurrences in order.  One wave can issue roughly one instruction every
-// four cycles, so the loop is written for the fewest instructions per occurrence:
-//   v_readlane (row byte offset, computed 64 occurrences at a time by one vector multiply)
-//   v_add (+ column offset), global_load_dword (SGPR base + 32-bit VGPR offset), v_mul, v_sub
-// with two register half-rings of kHotDepth loads in flight.  The index vector of the NEXT 64
-// occurrences is requested before the row loads that must stay in flight, so waiting for it
-// (in-order vmcnt) never drains the ring; all loads are branch-free (clamped).
-constexpr int kHotDepth = 16;
-
+// ---- longer runs: column-split over the run's own waves ------------------------------------------
+// The wave at offset o of a run owns the 64-column slice(s) o, o+W, ... (W = min(run length, 16)
+// workers) and walks ALL occurrences of the run in order: one dword per lane = 256 contiguous bytes
+// per occurrence row.  One wave issues roughly one instruction every four cycles, so the loop is
+// written for the fewest instructions per occurrence (v_readlane of a byte offset computed 64
+// occurrences at a time, v_add, global_load_dword, v_mul, v_sub), with two register half-rings of
+// kHotDepth loads in flight.  The run's end is found on the fly: every block of 64 occurrence
+// indices is loaded together with the 64 sorted keys of those positions, one block ahead of the
+// row loads that must stay in flight (so the in-order vmcnt wait never drains the ring).
 template <int MODE, bool OFF32>
-__device__ __forceinline__ void hot_slice(float *__restrict__ dst_row,
-                                          const float *__restrict__ grads,
-                                          const int32_t *__restrict__ perm_run,
-                                          int len, int width, int col, float lr) {
+__device__ __forceinline__ void split_slice(float *__restrict__ dst_row,
+                                            const float *__restrict__ grads,
+                                            const uint32_t *__restrict__ sorted,
+                                            const int32_t *__restrict__ perm,
+                                            int start, int n, uint32_t key,
+                                            int width, int col, float lr) {
     const int lane = lane_id();
     const bool live = col < width;
     const int lcol = live ? col : 0;
@@ -138,10 +135,15 @@ __device__ __forceinline__ void hot_slice(float *__restrict__ dst_row,
     const uint32_t col4 = static_cast<uint32_t>(lcol) * 4u;
     const uint32_t rowbytes = static_cast<uint32_t>(width) * 4u;
 
-    // lane l: byte offset of occurrence base+l's gradient row (OFF32) or its row index (!OFF32)
-    auto load_idx = [&](int base) -> uint32_t {
-        const uint32_t idx = static_cast<uint32_t>(perm_run[min(base + lane, len - 1)]);
-        return OFF32 ? idx * rowbytes : idx;
+    // block b = occurrences [64b, 64b+64) of the run = sorted positions start+64b+lane
+    auto load_block = [&](int b, uint32_t &pv, int &cnt) {
+        const int q = start + 64 * b + lane;
+        const int cq = min(q, n - 1);
+        const uint32_t ks = sorted[cq];
+        const uint32_t idx = static_cast<uint32_t>(perm[cq]);
+        pv = OFF32 ? idx * rowbytes : idx;
+        const unsigned long long m = __ballot(q < n && ks == key);
+        cnt = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
     };
     auto load_chunk = [&](float(&g)[kHotDepth], uint32_t pv, int lane0) {
 #pragma unroll
@@ -155,39 +157,70 @@ __device__ __forceinline__ void hot_slice(float *__restrict__ dst_row,
                     gbase + static_cast<size_t>(s) * rowbytes + col4);
         }
     };
-    auto consume_full = [&](const float(&g)[kHotDepth]) {
+    auto consume = [&](const float(&g)[kHotDepth], int cnt) {  // cnt = valid entries (may be >= depth)
+        if (cnt >= kHotDepth) {
 #pragma unroll
-        for (int t = 0; t < kHotDepth; ++t)
-            acc = step<MODE>(acc, g[t], lr);
-    };
-    auto consume_tail = [&](const float(&g)[kHotDepth], int cnt) {
+            for (int t = 0; t < kHotDepth; ++t)
+                acc = step<MODE>(acc, g[t], lr);
+        } else {
 #pragma unroll
-        for (int t = 0; t < kHotDepth; ++t) {
-            const float nx = step<MODE>(acc, g[t], lr);
-            acc = (t < cnt) ? nx : acc;
+            for (int t = 0; t < kHotDepth; ++t) {
+                const float nx = step<MODE>(acc, g[t], lr);
+                acc = (t < cnt) ? nx : acc;
+            }
         }
     };
-    auto consume = [&](const float(&g)[kHotDepth], int q0) {
-        if (q0 + kHotDepth <= len)
-            consume_full(g);
-        else if (q0 < len)
-            consume_tail(g, len - q0);
-    };
 
-    float ga[kHotDepth], gb[kHotDepth];
-    uint32_t pv_cur = load_idx(0);
+    // three register chunks rotate: while chunk c is consumed, chunks c+1 and c+2 are in flight
+    // (up to 48 row loads per wave; vmcnt counts 63 at most)
+    float ga[kHotDepth], gb[kHotDepth], gc[kHotDepth];
+    uint32_t pv_cur, pv_nxt;
+    int cnt_cur, cnt_nxt;
+    load_block(0, pv_cur, cnt_cur);
     load_chunk(ga, pv_cur, 0);
-    for (int q0 = 0; q0 < len; q0 += 64) {
-        const uint32_t pv_nxt = load_idx(q0 + 64);
+    if (cnt_cur > 16)
         load_chunk(gb, pv_cur, 16);
-        consume(ga, q0);
-        load_chunk(ga, pv_cur, 32);
-        consume(gb, q0 + 16);
-        load_chunk(gb, pv_cur, 48);
-        consume(ga, q0 + 32);
-        load_chunk(ga, pv_nxt, 0);
-        consume(gb, q0 + 48);
-        pv_cur = pv_nxt;
+    // invariant at loop top: chunks 0 (ga) and 1 (gb) of the current block are in flight
+    for (int b = 0;; b += 3) {
+        // ---- block b: ga=c0 gb=c1 ; stream c2->gc c3->ga ; next block c0->gb c1->gc
+        load_block(b + 1, pv_nxt, cnt_nxt);
+        if (cnt_cur < 64) cnt_nxt = 0;
+        if (cnt_cur > 32) load_chunk(gc, pv_cur, 32);
+        consume(ga, cnt_cur);
+        if (cnt_cur > 48) load_chunk(ga, pv_cur, 48);
+        if (cnt_cur > 16) consume(gb, cnt_cur - 16);
+        if (cnt_nxt > 0) load_chunk(gb, pv_nxt, 0);
+        if (cnt_cur > 32) consume(gc, cnt_cur - 32);
+        if (cnt_nxt > 16) load_chunk(gc, pv_nxt, 16);
+        if (cnt_cur > 48) consume(ga, cnt_cur - 48);
+        if (cnt_nxt == 0) break;
+        pv_cur = pv_nxt; cnt_cur = cnt_nxt;
+        // ---- block b+1: gb=c0 gc=c1 ; c2->ga c3->gb ; next block c0->gc c1->ga
+        load_block(b + 2, pv_nxt, cnt_nxt);
+        if (cnt_cur < 64) cnt_nxt = 0;
+        if (cnt_cur > 32) load_chunk(ga, pv_cur, 32);
+        consume(gb, cnt_cur);
+        if (cnt_cur > 48) load_chunk(gb, pv_cur, 48);
+        if (cnt_cur > 16) consume(gc, cnt_cur - 16);
+        if (cnt_nxt > 0) load_chunk(gc, pv_nxt, 0);
+        if (cnt_cur > 32) consume(ga, cnt_cur - 32);
+        if (cnt_nxt > 16) load_chunk(ga, pv_nxt, 16);
+        if (cnt_cur > 48) consume(gb, cnt_cur - 48);
+        if (cnt_nxt == 0) break;
+        pv_cur = pv_nxt; cnt_cur = cnt_nxt;
+        // ---- block b+2: gc=c0 ga=c1 ; c2->gb c3->gc ; next block c0->ga c1->gb
+        load_block(b + 3, pv_nxt, cnt_nxt);
+        if (cnt_cur < 64) cnt_nxt = 0;
+        if (cnt_cur > 32) load_chunk(gb, pv_cur, 32);
+        consume(gc, cnt_cur);
+        if (cnt_cur > 48) load_chunk(gc, pv_cur, 48);
+        if (cnt_cur > 16) consume(ga, cnt_cur - 16);
+        if (cnt_nxt > 0) load_chunk(ga, pv_nxt, 0);
+        if (cnt_cur > 32) consume(gb, cnt_cur - 32);
+        if (cnt_nxt > 16) load_chunk(gb, pv_nxt, 16);
+        if (cnt_cur > 48) consume(gc, cnt_cur - 48);
+        if (cnt_nxt == 0) break;
+        pv_cur = pv_nxt; cnt_cur = cnt_nxt;
     }
     if (live) {
         if (MODE == kModePush)
@@ -196,96 +229,98 @@ __device__ __forceinline__ void hot_slice(float *__restrict__ dst_row,
     }
 }
 
+// One wave per sorted position p (wave-uniform p; no workgroup-level synchronisation).
+template <int MODE, int VEC>
+__device__ __forceinline__ void apply_body_impl(
+    float *__restrict__ dst, uint64_t dst_rows, int width,
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
+    float lr, int p, int *dbg_info);
+
+// One wave per sorted position p.  `dbg` (diagnostic builds of the timeline tool only) receives
+// {realtime start, realtime end, role/len, shader cycles} per position.
 template <int MODE, int VEC>
 __device__ __forceinline__ void apply_body(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int vblock) {
-    // gradient rows addressable with 32-bit byte offsets (the usual case: n*width*4 < 4 GiB)
-    const bool off32 = static_cast<uint64_t>(n) * static_cast<uint64_t>(width) * 4ull < (1ull << 32);
-    __shared__ int s_hot_p;
-    __shared__ int s_scan[kPosPerBlock];
-    const int lane = lane_id();
+    float lr, int vblock, unsigned long long *dbg = nullptr) {
     const int w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int p = vblock * kPosPerBlock + w;
-    if (threadIdx.x == 0)
-        s_hot_p = -1;
-    __syncthreads();
-
-    // ---- phase A: classify my sorted position
-    const bool in_range = p < n;
-    const int pos = p + lane;
-    const int cpos = min(pos, n - 1);
-    const uint32_t ks = sorted[cpos];
-    const int permv = perm[cpos];
-    const uint32_t prevk = sorted[max(min(p, n - 1) - 1, 0)];
-    const uint32_t key = uniform(ks);
-    const unsigned long long same = __ballot(pos < n && ks == key);
-    const int len64 = (~same == 0ull) ? 64 : __builtin_ctzll(~same);
-    const bool head = in_range && (p == 0 || prevk != key);
-    const bool hot = head && len64 >= kHotLen;
-    if (hot && lane == 0)
-        s_hot_p = p;
-    __syncthreads();
-
-    // ---- phase B: the (at most one) hot run whose head lies in this block
-    const int hp = s_hot_p;
-    if (hp >= 0) {
-        const uint32_t hkey = sorted[hp];
-        // run length: every wave scans 64 positions per step until a different key shows up
-        int len = 0;
-        for (int base = hp;; base += kPosPerBlock * kWave) {
-            const int q = base + w * kWave + lane;
-            const unsigned long long m = __ballot(q < n && sorted[min(q, n - 1)] == hkey);
-            const int c = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
-            if (lane == 0)
-                s_scan[w] = c;
-            __syncthreads();
-            int add = 0;
-            bool full = true;
-            for (int k = 0; k < kPosPerBlock; ++k) {
-                if (full)
-                    add += s_scan[k];
-                full = full && s_scan[k] == 64;
-            }
-            len += add;
-            __syncthreads();
-            if (!full)
-                break;
-        }
-        uint64_t row;
-        bool ok = true;
-        if (MODE == kModeReduce) {
-            row = static_cast<uint64_t>(upos[hp]);
-        } else {
-            row = hkey;
-            ok = row < dst_rows;
-        }
-        if (ok) {
-            for (int col = w * kWave + lane; col - lane < width; col += kPosPerBlock * kWave) {
-                if (off32)
-                    hot_slice<MODE, true>(dst + row * static_cast<uint64_t>(width), grads,
-                                          perm + hp, len, width, col, lr);
-                else
-                    hot_slice<MODE, false>(dst + row * static_cast<uint64_t>(width), grads,
-                                           perm + hp, len, width, col, lr);
-            }
-        }
+    if (p >= n)
+        return;
+    if (dbg == nullptr) {
+        apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, nullptr);
+        return;
     }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    int info = 0;
+    apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, &info);
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (lane_id() == 0) {
+        dbg[p * 4 + 0] = t0;
+        dbg[p * 4 + 1] = t1;
+        dbg[p * 4 + 2] = static_cast<unsigned long long>(info);
+        dbg[p * 4 + 3] = c1 - c0;
+    }
+}
 
-    // ---- phase C: short runs, one wave each
-    if (head && !hot) {
-        uint64_t row;
-        if (MODE == kModeReduce) {
-            row = static_cast<uint64_t>(upos[p]);
-        } else {
-            row = key;
-            if (row >= dst_rows)
-                return;  // out-of-range id: ignored (undefined behaviour in the reference)
-        }
-        cold_row<MODE, VEC>(dst + row * static_cast<uint64_t>(width), grads,
-                            width, permv, len64, lr);
+template <int MODE, int VEC>
+__device__ __forceinline__ void apply_body_impl(
+    float *__restrict__ dst, uint64_t dst_rows, int width,
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
+    float lr, int p, int *dbg_info) {
+    const int lane = lane_id();
+    // window of sorted positions p-16 .. p+47 (branch-free loads)
+    const int q = p - kLookBack + lane;
+    const int cq = max(0, min(q, n - 1));
+    const uint32_t ks = sorted[cq];
+    const int pv = perm[cq];
+    const uint32_t key = static_cast<uint32_t>(
+        __builtin_amdgcn_readlane(static_cast<int>(ks), kLookBack));
+    const unsigned long long eq = __ballot(q >= 0 && q < n && ks == key);
+    const uint32_t inv_lo = static_cast<uint32_t>(~eq) & 0xFFFFu;
+    const int back = inv_lo == 0 ? kLookBack : (__builtin_clz(inv_lo) - 16);
+    const unsigned long long inv_hi = (~eq) >> kLookBack;  // bit t <-> position p+t, 48 valid bits
+    const int fwd = __builtin_ctzll(inv_hi | (1ull << 48));  // 1..48
+    const int o = back;
+    if (o >= kLookBack)
+        return;  // deep inside a long run: the first 16 waves of the run do the work
+    const bool exact = fwd < 48;
+    const int len_known = o + fwd;  // exact run length when `exact`
+    if (dbg_info)
+        *dbg_info = (o << 16) | len_known | (exact ? 0 : 0x8000);
+
+    uint64_t row;
+    if (MODE == kModeReduce) {
+        row = static_cast<uint64_t>(upos[p]);
+    } else {
+        row = key;
+        if (row >= dst_rows)
+            return;  // out-of-range id: ignored (undefined behaviour in the reference)
+    }
+    float *dst_row = dst + row * static_cast<uint64_t>(width);
+
+    if (exact && len_known <= kShortRun) {
+        if (o == 0)
+            short_row<MODE, VEC>(dst_row, grads, width, pv, kLookBack, len_known, lr);
+        return;
+    }
+    // split mode: W workers, worker o takes slices o, o+W, ...
+    const int workers = exact ? min(len_known, kLookBack) : kLookBack;
+    if (o >= workers)
+        return;
+    const bool off32 = static_cast<uint64_t>(n) * static_cast<uint64_t>(width) * 4ull < (1ull << 32);
+    const int start = p - o;
+    for (int c0 = o * kWave; c0 < width; c0 += workers * kWave) {
+        if (off32)
+            split_slice<MODE, true>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr);
+        else
+            split_slice<MODE, false>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr);
     }
 }
 

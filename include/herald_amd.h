@@ -226,6 +226,13 @@ int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
                          void *plan_ws, int64_t n, const float *grads,
                          ha_stream_t stream);
 
+/* Development aid: ha_sgd_apply with per-wave time stamps, dbg[4*n] u64 =
+ * {s_memrealtime start, end (10 ns ticks), role/len, shader cycles} per sorted position. */
+int ha_debug_apply_timeline(float *table, int64_t rows, int64_t width,
+                            const void *plan_ws, int64_t n, const float *grads,
+                            float lr, unsigned long long *dbg,
+                            ha_stream_t stream);
+
 /* One-call convenience used by the reference-named SGDOptimizerSparseUpdate:
  * plan + apply using an internal per-stream workspace. */
 int ha_sgd_sparse_update_f32ids(float *table, int64_t rows, int64_t width,
