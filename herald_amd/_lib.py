@@ -98,6 +98,9 @@ def _declare(L):
         "ha_plan_finish": [vp, i64, vp],
         "ha_plan_export_f32": [vp, i64, vp, vp, vp],
         "ha_dedup_reduce": [vp, i64, vp, i64, vp, vp],
+        "ha_shard_bucket": [vp, i64, vp, c.c_int, vp, vp, vp],
+        "ha_dedup_reduce_scaled": [vp, i64, vp, i64, f32, vp, vp],
+        "ha_debug_apply_timeline": [vp, i64, i64, vp, i64, vp, f32, vp, vp],
         "ha_sgd_apply": [vp, i64, i64, vp, i64, vp, f32, vp],
         "ha_push_apply": [vp, i64, i64, vp, i64, vp, vp],
         "ha_sgd_sparse_update_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp],

@@ -171,6 +171,6 @@ extern "C" int ha_sgd_apply_finish(float *table, int64_t rows, int64_t width,
 extern "C" int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
                                     void *plan_ws, int64_t n, const float *grads,
                                     ha_stream_t stream) {
-    return apply_finish<kModePush>(table, rows, width, plan_ws, n, grads, 0.f,
+    return apply_finish<kModePush>(table, rows, width, plan_ws, n, grads, 1.f,
                                    as_stream(stream));
 }

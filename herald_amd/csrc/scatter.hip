@@ -95,14 +95,22 @@ extern "C" int ha_push_apply(float *table, int64_t rows, int64_t width,
                              const void *plan_ws, int64_t n, const float *grads,
                              ha_stream_t stream) {
     return ha::apply_launch<ha::kModePush>(table, rows, width, plan_ws, n,
-                                           grads, 0.f, ha::as_stream(stream));
+                                           grads, 1.f, ha::as_stream(stream));
 }
 
 extern "C" int ha_dedup_reduce(const void *plan_ws, int64_t n,
                                const float *grads, int64_t width,
                                float *reduced, ha_stream_t stream) {
     return ha::apply_launch<ha::kModeReduce>(reduced, n, width, plan_ws, n,
-                                             grads, 0.f, ha::as_stream(stream));
+                                             grads, 1.f, ha::as_stream(stream));
+}
+
+extern "C" int ha_dedup_reduce_scaled(const void *plan_ws, int64_t n,
+                                      const float *grads, int64_t width,
+                                      float scale, float *reduced,
+                                      ha_stream_t stream) {
+    return ha::apply_launch<ha::kModeReduce>(reduced, n, width, plan_ws, n,
+                                             grads, scale, ha::as_stream(stream));
 }
 
 // Development aid (tools/timeline.py): SGD apply with per-wave {start, end, role, cycles} stamps

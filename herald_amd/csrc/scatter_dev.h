@@ -20,7 +20,10 @@ template <int MODE>
 __device__ __forceinline__ float step(float acc, float g, float lr) {
     if (MODE == kModeSgd)
         return __fsub_rn(acc, __fmul_rn(lr, g));
-    return __fadd_rn(acc, g);
+    // push / reduce: `lr` is the scale applied to every value before it is summed (the reference
+    // multiplies the whole value array by -lr first, ParameterServerCommunicate.py:58-59);
+    // scale 1.0f is exact, so the unscaled ops use the same code.
+    return __fadd_rn(acc, __fmul_rn(lr, g));
 }
 
 template <int VEC>

@@ -196,15 +196,20 @@ class IndexPlan:
 
 
 # ---- backward ---------------------------------------------------------------------------------------------
-def dedup_reduce(plan, grads, out=None, stream=None):
-    """reduced[u,:] = sum of grads rows of unique key u in occurrence order (cpu_deduplicate order)."""
+def dedup_reduce(plan, grads, out=None, stream=None, scale=None):
+    """reduced[u,:] = sum of (scale *) grads rows of unique key u in occurrence order (cpu_deduplicate
+    order; with scale = -lr this is the worker side of a PS sparse push)."""
     _require(grads, torch.float32, "grads")
     n = plan.n
     width = grads.numel() // max(n, 1) if n else (grads.shape[-1] if grads.dim() else 1)
     if out is None:
         out = torch.empty((max(n, 1), width), dtype=torch.float32, device=grads.device)
-    check(_lib.load().ha_dedup_reduce(_ptr(plan.ws), n, _ptr(grads), width, _ptr(out), _stream_ptr(stream)),
-          "ha_dedup_reduce")
+    if scale is None:
+        check(_lib.load().ha_dedup_reduce(_ptr(plan.ws), n, _ptr(grads), width, _ptr(out),
+                                          _stream_ptr(stream)), "ha_dedup_reduce")
+    else:
+        check(_lib.load().ha_dedup_reduce_scaled(_ptr(plan.ws), n, _ptr(grads), width, ctypes.c_float(scale),
+                                                 _ptr(out), _stream_ptr(stream)), "ha_dedup_reduce_scaled")
     return out
 
 

@@ -1,0 +1,77 @@
+"""bench.py's N>1 leg: the same per-GPU workload as N=1 (weak scaling), with the table row-range
+sharded over the ranks and the sparse pull / push carried by RCCL all-to-all (herald_amd.sharded)."""
+import json
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+XGMI_LINK_GBS = 153.0   # per link, 7 links per GPU (MI355X_MICROARCH / task statement)
+HBM_PEAK_GBS = 8000.0
+
+
+def run(args, rank, world, dev):
+    from herald_amd import synth
+    from herald_amd.sharded import ShardedEmbedding
+
+    n = args.batch * args.fields
+    nb = min(args.distinct_batches, 256)
+    ids_host = np.empty((nb, n), dtype=np.float32)
+    for b in range(nb):
+        f = synth.as_f32_ids(synth.criteo_batch(args.batch, step=b * world + rank, rows=args.rows,
+                                                nfields=args.fields)).reshape(-1)
+        np.minimum(f, np.float32(args.rows - 1), out=f)
+        ids_host[b] = f
+    ids_dev = torch.from_numpy(ids_host).to(dev)
+    emb = ShardedEmbedding(args.rows, args.width, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(123 + rank)
+    chunk = 1 << 20
+    for s in range(0, emb.local_rows, chunk):
+        emb.table[s:s + chunk].normal_(0.0, 0.01, generator=g)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(456 + rank)
+    grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(2)]
+    lr = 1e-6
+
+    def step(k):
+        ids = ids_dev[k % nb]
+        out, plan = emb.pull(ids, return_plan=True)      # forward lookup
+        emb.push(ids, grads[k % 2], lr, plan=plan)       # backward: -lr scale, dedup-reduce, exchange, apply
+        return out
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    dist.barrier()
+    emb.stats = {"xgmi_bytes_out": 0, "xgmi_bytes_in": 0}
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    xg = torch.tensor([emb.stats["xgmi_bytes_out"], emb.stats["xgmi_bytes_in"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(xg, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        rows_per_s = world * n * args.steps / el
+        xgmi_gbs = float(xg[0].item()) / el / 1e9
+        links = min(world - 1, 7)
+        print(json.dumps({
+            "metric": "embedding rows/s (lookup+grad)", "value": rows_per_s, "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "wdl_criteo bs=%d d=%d per GPU, %d fields, %d-row fp32 table row-range "
+                                   "sharded over %d GPUs (AveragePartitioner), sparse pull/push by RCCL "
+                                   "all-to-all" % (args.batch, args.width, args.fields, args.rows, world),
+                       "ids_per_step_per_gpu": n, "parallelism": "row-sharded x%d" % world},
+            "xgmi": {"egress_GBps_per_gpu_max": xgmi_gbs, "peak_GBps_per_gpu": links * XGMI_LINK_GBS,
+                     "frac": xgmi_gbs / (links * XGMI_LINK_GBS)},
+            "roofline": None, "cpu_baseline": None,
+        }))
+    dist.destroy_process_group()

@@ -192,10 +192,20 @@ int ha_plan_export_f32(const void *ws, int64_t n, float *uniq_f32,
 int ha_dedup_reduce(const void *plan_ws, int64_t n, const float *grads,
                     int64_t width, float *reduced, ha_stream_t stream);
 
+/* Same with every value multiplied by `scale` before it is summed: reduced[u,:] = sum(scale*g_i).
+ * This is the worker side of a PS sparse push: `values *= -lr` (python/hetu/gpu_ops/
+ * ParameterServerCommunicate.py:58-59) followed by the occurrence-order reduce of
+ * PSAgent::vecPushSparse (PSAgent.h:146-160). */
+int ha_dedup_reduce_scaled(const void *plan_ws, int64_t n, const float *grads,
+                           int64_t width, float scale, float *reduced,
+                           ha_stream_t stream);
+
 /* table[key,:] -= lr * grads[i,:] for every occurrence i, applied per row in
  * occurrence order with separate multiply and subtract roundings: the result is
  * bit-identical to the serial loop of cpu_SGDOptimizerSparseUpdate
- * (src/dnnl_ops/Optimizers.cpp:65-72).  Each unique row is read and written once. */
+ * (src/dnnl_ops/Optimizers.cpp:65-72).  Each unique row is read and written once.
+ * With lr = -1 this is the server side of sparse pushes applied one after the other in
+ * occurrence order: table[key,:] = (table[key,:] + v_i0) + v_i1 ...  (PSFHandle.h:130-164). */
 int ha_sgd_apply(float *table, int64_t rows, int64_t width,
                  const void *plan_ws, int64_t n, const float *grads, float lr,
                  ha_stream_t stream);
@@ -225,6 +235,16 @@ int ha_sgd_apply_finish(float *table, int64_t rows, int64_t width,
 int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
                          void *plan_ws, int64_t n, const float *grads,
                          ha_stream_t stream);
+
+/* ---- row-range sharding (in-node replacement of the PS/worker split) -------
+ * For the plan's sorted unique keys: offsets[g] = index of the first unique key owned by shard g
+ * (offsets[nshard] = n_unique) and local_keys[u] = uniq[u] - starts[owner(u)], where shard g owns
+ * rows [starts[g], starts[g+1]) -- AveragePartitioner ranges (ps-lite/include/ps/partitioner.h:46-57)
+ * routed like PSAgent (PSAgent.h:537-560).  starts_host[nshard+1] is a HOST array; offsets
+ * (int32[nshard+1]) and local_keys (uint32[n]) are device arrays. */
+int ha_shard_bucket(const void *plan_ws, int64_t n, const int64_t *starts_host,
+                    int nshard, int32_t *offsets, uint32_t *local_keys,
+                    ha_stream_t stream);
 
 /* Development aid: ha_sgd_apply with per-wave time stamps, dbg[4*n] u64 =
  * {s_memrealtime start, end (10 ns ticks), role/len, shader cycles} per sorted position. */

@@ -131,3 +131,23 @@ def np_cpu_deduplicate(ids, values):
     for i, ind in enumerate(np.asarray(inverse).reshape(-1)):
         new_values[ind] += flatten[i]
     return unique_indices, new_values
+
+
+# ---- sharded store (PS semantics) ----------------------------------------------------------------
+def scale_values(values, lr):
+    """`values *= -lr` of ParameterServerCommunicateOp (gpu_ops/ParameterServerCommunicate.py:24,58-59):
+    numpy float32 array times a Python float -> float32 product, one rounding."""
+    return (np.asarray(values, dtype=np.float32) * np.float32(-lr)).astype(np.float32)
+
+
+def sparse_pull(table, ids):
+    """PSAgent::vecPullSparse + serve(SparsePull): every position receives its row (PSAgent.h:185-237)."""
+    return embedding_lookup(table, ids)
+
+
+def sparse_push(table, ids, values, lr=None):
+    """One worker's SparsePush on a global table: scale by -lr, reduce equal ids in position order from 0
+    (PSAgent::vecPushSparse, PSAgent.h:124-183), server `+=` (PSFHandle.h:130-164).  In place."""
+    vals = scale_values(values, lr) if lr is not None else _f32(values)
+    uniq, _, red = dedup_reduce(ids, vals.reshape(np.asarray(ids).size, -1))
+    return push_apply(table, uniq, red)

@@ -250,3 +250,46 @@ def test_fused_step_matches_oracle_and_unfused(dev, width, n):
     ops.push_apply_finish(t2, plan, _dev(grads, dev))
     _, _, red = cpu.dedup_reduce(ids, grads)
     np.testing.assert_array_equal(t2.cpu().numpy(), cpu.push_apply(table.copy(), uniq, red))
+
+
+def test_sharded_single_rank_hip_engine(dev):
+    """herald_amd.sharded with the HIP engine at world_size 1: SparsePull / SparsePush semantics."""
+    from herald_amd.sharded import ShardedEmbedding
+    rng = np.random.default_rng(11)
+    rows, width, n = 5000, 128, 2000
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = rng.integers(0, rows, size=n).astype(np.float32)
+    ids[:500] = ids[0]
+    vals = rng.standard_normal((n, width), dtype=np.float32)
+    emb = ShardedEmbedding(rows, width, dev, table=_dev(table, dev))
+    out, plan = emb.pull(_dev(ids, dev), return_plan=True)
+    np.testing.assert_array_equal(out.cpu().numpy(), cpu.sparse_pull(table, ids))
+    emb.push(_dev(ids, dev), _dev(vals, dev), 0.01, plan=plan)
+    want = cpu.sparse_push(table.copy(), ids, vals, 0.01)
+    np.testing.assert_array_equal(emb.table.cpu().numpy(), want)
+    # a second push without lr scaling (IndexedSlices add semantics)
+    emb.push(_dev(ids, dev), _dev(vals, dev))
+    want = cpu.sparse_push(want, ids, vals, None)
+    np.testing.assert_array_equal(emb.table.cpu().numpy(), want)
+
+
+def test_shard_bucket_matches_partitioner(dev, lib):
+    import ctypes
+    rng = np.random.default_rng(12)
+    rows, nshard, n = 33762577, 8, 6656
+    ids = synth.as_f32_ids(synth.criteo_batch(256, 5)).reshape(-1)
+    plan = ops.IndexPlan(n, dev).build(_dev(ids, dev))
+    starts = cpu.partition(rows, nshard)
+    offsets = torch.empty(nshard + 1, dtype=torch.int32, device=dev)
+    local = torch.empty(n, dtype=torch.int32, device=dev)
+    st = (ctypes.c_int64 * (nshard + 1))(*[int(x) for x in starts])
+    assert lib.ha_shard_bucket(ctypes.c_void_p(plan.ws.data_ptr()), n, st, nshard,
+                               ctypes.c_void_p(offsets.data_ptr()), ctypes.c_void_p(local.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    uniq = np.unique(cpu.ids_to_keys(ids))
+    want_off = np.searchsorted(uniq, starts.astype(np.uint64), side="left")
+    want_off[-1] = uniq.size
+    np.testing.assert_array_equal(offsets.cpu().numpy(), want_off)
+    owner = np.searchsorted(starts, uniq.astype(np.int64), side="right") - 1
+    np.testing.assert_array_equal(local.cpu().numpy()[:uniq.size].astype(np.int64),
+                                  uniq.astype(np.int64) - starts[owner])

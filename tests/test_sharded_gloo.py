@@ -1,0 +1,85 @@
+"""Multi-rank exchange logic of herald_amd.sharded under gloo (CPU, world_size 2 and 3).
+
+The arithmetic is done by tests/cpu_engine.py (oracle-backed test double); what is under test is the
+routing: AveragePartitioner ranges, counts / keys / rows all-to-alls, rank-ordered application."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, rows, width, n, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_engine import CpuEngine
+    from herald_amd.sharded import ShardedEmbedding, partition
+    from oracle import cpu
+
+    rng = np.random.default_rng(1234)              # same stream on every rank
+    table_g = rng.standard_normal((rows, width), dtype=np.float32)
+    all_ids = [rng.integers(0, rows, size=n).astype(np.float32) for _ in range(world)]
+    for r in range(world):
+        all_ids[r][: n // 3] = all_ids[0][: n // 3]          # keys shared between ranks
+        all_ids[r][n // 3: n // 2] = all_ids[r][0]           # duplicates inside a rank
+    all_vals = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(world)]
+    starts = partition(rows, world)
+    assert starts == list(cpu.partition(rows, world))
+    shard = torch.from_numpy(table_g[starts[rank]:starts[rank + 1]].copy())
+    emb = ShardedEmbedding(rows, width, "cpu", engine=CpuEngine(), table=shard)
+
+    ids = torch.from_numpy(all_ids[rank])
+    out = emb.pull(ids)
+    np.testing.assert_array_equal(out.numpy(), cpu.sparse_pull(table_g, all_ids[rank]))
+
+    lr = 0.05
+    emb.push(ids, torch.from_numpy(all_vals[rank]), lr)
+    dist.barrier()
+    want = table_g.copy()
+    for r in range(world):                                   # rank order
+        cpu.sparse_push(want, all_ids[r], all_vals[r], lr)
+    np.testing.assert_array_equal(emb.table.numpy(), want[starts[rank]:starts[rank + 1]])
+
+    out2 = emb.pull(ids)                                     # pull after push sees every rank's update
+    np.testing.assert_array_equal(out2.numpy(), want[all_ids[rank].astype(np.int64)])
+
+    # 2-D id batches and the checkpoint format round trip
+    ids2 = ids[: (n // 4) * 4].reshape(-1, 4)
+    assert tuple(emb.pull(ids2).shape) == (ids2.shape[0], 4, width)
+    emb.save(os.path.join(out_dir, "emb"))
+    before = emb.table.clone()
+    emb.table.zero_()
+    emb.load(os.path.join(out_dir, "emb"))
+    assert torch.equal(before, emb.table)
+    assert emb.stats["xgmi_bytes_out"] > 0 or world == 1
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,rows,width,n", [(2, 1001, 8, 300), (3, 50, 4, 64)])
+def test_sharded_pull_push_gloo(tmp_path, world, rows, width, n):
+    mp.spawn(_worker, args=(world, _free_port(), rows, width, n, str(tmp_path)), nprocs=world, join=True)
+
+
+def test_partition_is_average_partitioner():
+    from herald_amd.sharded import partition
+    s = partition(33762577, 8)
+    assert s[1] - s[0] == 4220323 and all(s[i + 1] - s[i] == 4220322 for i in range(1, 8)) and s[-1] == 33762577
+    assert partition(10, 3) == [0, 4, 7, 10]
