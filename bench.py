@@ -124,7 +124,7 @@ def main():
 
     from herald_amd import ops
 
-    if world > 1:
+    if world > 1 or os.environ.get("HA_FORCE_SHARDED") == "1":
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         from herald_amd import sharded_bench

@@ -98,6 +98,7 @@ def _declare(L):
         "ha_plan_finish": [vp, i64, vp],
         "ha_plan_export_f32": [vp, i64, vp, vp, vp],
         "ha_dedup_reduce": [vp, i64, vp, i64, vp, vp],
+        "ha_apply_mapped": [vp, i64, i64, vp, i64, vp, f32, vp, vp, vp, vp],
         "ha_shard_bucket": [vp, i64, vp, c.c_int, vp, vp, vp],
         "ha_dedup_reduce_scaled": [vp, i64, vp, i64, f32, vp, vp],
         "ha_debug_apply_timeline": [vp, i64, i64, vp, i64, vp, f32, vp, vp],
@@ -110,6 +111,31 @@ def _declare(L):
         "ha_push_apply_finish": [vp, i64, i64, vp, i64, vp, vp],
     }
     for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = c.c_int
+    L.ha_cache_create.restype = vp
+    L.ha_cache_create.argtypes = [c.c_int, i64, i64, i64, i64]
+    L.ha_cache_destroy.restype = None
+    L.ha_cache_destroy.argtypes = [vp]
+    for name in ("ha_cache_data", "ha_cache_grad"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
+    for name in ("ha_cache_limit", "ha_cache_width"):
+        getattr(L, name).restype = i64
+        getattr(L, name).argtypes = [vp]
+    cache_sigs = {
+        "ha_cache_set_bounds": [vp, i64, i64],
+        "ha_cache_set_bypass": [vp, c.c_int],
+        "ha_cache_bind_store": [vp, vp, vp, i64, i64],
+        "ha_cache_lookup": [vp, vp, c.c_int, i64, vp, vp],
+        "ha_cache_update": [vp, vp, c.c_int, i64, vp, vp],
+        "ha_cache_update_with_push_keys": [vp, vp, c.c_int, i64, vp, c.c_int, i64, vp, vp],
+        "ha_cache_perf": [vp, vp, vp],
+        "ha_cache_state": [vp, vp, vp],
+        "ha_cache_snapshot": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
+    }
+    for name, args in cache_sigs.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = c.c_int

@@ -1,0 +1,392 @@
+"""Host-side mirror of the `hetu_cache` plugin and of `CacheSparseTable`, on the device-resident cache.
+
+Reference surfaces mirrored (paths relative to /root/reference):
+  hetu_cache.LRUCache / LFUCache / LFUOptCache(limit, len, width, node_id)
+        src/hetu_cache/src/python_api.cc:12-79 -- properties limit, width, perf, pull_bound, push_bound,
+        perf_enabled; methods bypass, undo_bypass, embedding_lookup, embedding_update,
+        embedding_update_with_push_keys, *_raw variants, count, size, keys, lookup, __repr__;
+        every batch method returns a wait handle with .wait().
+  CacheSparseTable(limit, length, width, node_id, policy, bound)   python/hetu/cstable.py:20-36
+
+Differences that the boundary makes explicit:
+  * the server is not reached through libps: `bind_store(table, versions)` hands the cache the table
+    shard (device tensor) and its per-row version array, or pass `node_id` of a table registered with
+    `herald_amd.cache.register_table` (the role InitTensor plays in the reference);
+  * keys / dest / grads may be device tensors (no copy) or host numpy arrays (staged over PCIe);
+  * calls are asynchronous on a HIP stream; the returned handle's wait() synchronises it.
+All computation is in libherald_amd.so (csrc/cache.hip); this file only marshals arguments.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+_TABLES = {}
+
+
+def register_table(node_id, table, versions=None, row_start=0):
+    """The in-node equivalent of InitTensor(node_id, ptype=CacheTable, ...) (python/hetu/initializers.py:28-38):
+    associates a device table shard (and its row versions) with a node id."""
+    if versions is None:
+        versions = torch.zeros(table.shape[0], dtype=torch.int64, device=table.device)
+    _TABLES[int(node_id)] = (table, versions, int(row_start))
+    return versions
+
+
+class Wait:
+    """The `_waittype` of the reference (a shared_future): wait() blocks until the call is done."""
+
+    def __init__(self, stream, keep=()):
+        self._event = torch.cuda.Event()
+        self._event.record(stream)
+        self._keep = keep
+        self._after = None
+
+    def wait(self):
+        self._event.synchronize()
+        if self._after is not None:
+            self._after()
+            self._after = None
+        self._keep = ()
+
+
+class Embedding:
+    """The `Embedding` view of one cache line (python_api.cc:60-75)."""
+
+    def __init__(self, key, version, data, grad=None, updates=0):
+        self.key, self.version, self.updates = int(key), int(version), int(updates)
+        self.data, self.grad = data, grad
+
+    def mean(self):
+        return float(np.mean(self.data.astype(np.float64)))
+
+    def var(self):
+        return float(np.var(self.data.astype(np.float64)))
+
+    def __repr__(self):
+        return "<hetu.Embedding : key:%d, len:%d, version:%d, mean:%g, var:%g>" % (
+            self.key, self.data.size, self.version, self.mean(), self.var())
+
+
+class _CacheBase:
+    POLICY = None
+    NAME = None
+
+    def __init__(self, limit, length, width, node_id=0, max_batch=None, device=None, stream=None):
+        self._L = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda")
+        self._limit, self._length, self._width, self.node_id = int(limit), int(length), int(width), int(node_id)
+        self._max_batch = int(max_batch) if max_batch else 1 << 17
+        with torch.cuda.device(self.device):
+            self._h = self._L.ha_cache_create(self.POLICY, self._limit, self._length, self._width,
+                                              self._max_batch)
+        if not self._h:
+            raise _lib.HeraldAmdError("ha_cache_create failed: %s" % self._L.ha_last_error().decode())
+        self._pull_bound = self._push_bound = 5
+        self.perf_enabled = False
+        self._perf = []
+        self._store = None
+        self.stream = stream
+        if self.node_id in _TABLES:
+            self.bind_store(*_TABLES[self.node_id])
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.ha_cache_destroy(h)
+
+    # ---- store ---------------------------------------------------------------------------------------
+    def bind_store(self, table, versions, row_start=0):
+        assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
+        assert versions.is_cuda and versions.dtype == torch.int64 and versions.numel() == table.shape[0]
+        assert table.shape[1] == self._width
+        self._store = (table, versions)
+        check(self._L.ha_cache_bind_store(self._h, ctypes.c_void_p(table.data_ptr()),
+                                          ctypes.c_void_p(versions.data_ptr()), table.shape[0], int(row_start)),
+              "ha_cache_bind_store")
+
+    # ---- properties of the reference ----------------------------------------------------------------------
+    @property
+    def limit(self):
+        return self._limit
+
+    @property
+    def width(self):
+        return self._width
+
+    @property
+    def pull_bound(self):
+        return self._pull_bound
+
+    @pull_bound.setter
+    def pull_bound(self, v):
+        self._pull_bound = int(v)
+        check(self._L.ha_cache_set_bounds(self._h, self._pull_bound, self._push_bound), "set_bounds")
+
+    @property
+    def push_bound(self):
+        return self._push_bound
+
+    @push_bound.setter
+    def push_bound(self, v):
+        self._push_bound = int(v)
+        check(self._L.ha_cache_set_bounds(self._h, self._pull_bound, self._push_bound), "set_bounds")
+
+    @property
+    def perf(self):
+        return self._perf
+
+    def bypass(self):
+        check(self._L.ha_cache_set_bypass(self._h, 1), "bypass")
+
+    def undo_bypass(self):
+        check(self._L.ha_cache_set_bypass(self._h, 0), "undo_bypass")
+
+    # ---- argument marshalling ----------------------------------------------------------------------------------
+    def _stream(self):
+        return self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+
+    def _keys(self, keys, keep):
+        """-> (device tensor, key_kind).  float32 -> kind 0 (raw entry points), (u)int64 -> kind 1."""
+        if isinstance(keys, np.ndarray):
+            if not keys.flags.c_contiguous:
+                raise RuntimeError("Numpy Array is not contiguous")          # binding.h:51-57
+            if keys.dtype == np.uint64:
+                keys = keys.view(np.int64)
+            t = torch.from_numpy(keys).to(self.device, non_blocking=False)
+            keep.append(t)
+            keys = t
+        if keys.dtype == torch.float32:
+            kind = 0
+        elif keys.dtype in (torch.int64, torch.uint64):
+            kind = 1
+        else:
+            raise TypeError("keys must be float32 or (u)int64, got %s" % keys.dtype)
+        if not keys.is_contiguous():
+            raise RuntimeError("keys are not contiguous")
+        return keys, kind
+
+    def _perf_record(self, kind):
+        out = (ctypes.c_int64 * 8)()
+        check(self._L.ha_cache_perf(self._h, out, ctypes.c_void_p(self._stream().cuda_stream)), "ha_cache_perf")
+        d = {"type": "Pull" if out[0] == 0 else "Push", "num_all": out[1], "num_unique": out[2],
+             "num_miss": out[3], "num_transfered": out[4], "is_full": bool(out[6])}
+        if out[0] == 1:
+            d["num_evict"] = out[5]
+        self._perf.append(d)
+
+    # ---- batch API ---------------------------------------------------------------------------------------------------
+    def embedding_lookup(self, keys, dest):
+        """dest[i,:] = line(keys[i]).data after the staleness-bounded pull (cache.cc:60-107)."""
+        keep = []
+        s = self._stream()
+        with torch.cuda.stream(s):
+            k, kind = self._keys(keys, keep)
+            host_dest = None
+            if isinstance(dest, np.ndarray):
+                if not dest.flags.c_contiguous:
+                    raise RuntimeError("Numpy Array is not contiguous")
+                host_dest = dest
+                dest = torch.empty((k.numel(), self._width), dtype=torch.float32, device=self.device)
+            assert dest.numel() == k.numel() * self._width and dest.dtype == torch.float32
+            check(self._L.ha_cache_lookup(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
+                                          ctypes.c_void_p(dest.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
+                  "ha_cache_lookup")
+            if self.perf_enabled:
+                self._perf_record(0)
+            w = Wait(s, keep + [k, dest])
+            if host_dest is not None:
+                w._after = (lambda hd=host_dest, dd=dest: np.copyto(hd.reshape(dd.shape), dd.cpu().numpy()))
+        return w
+
+    def _grads(self, grads, keep):
+        if isinstance(grads, np.ndarray):
+            if not grads.flags.c_contiguous:
+                raise RuntimeError("Numpy Array is not contiguous")
+            grads = torch.from_numpy(grads).to(self.device)
+            keep.append(grads)
+        assert grads.dtype == torch.float32 and grads.is_contiguous()
+        return grads
+
+    def embedding_update(self, keys, grads):
+        """Line::accumulate per occurrence + bounded push (cache.cc:132-197)."""
+        keep = []
+        s = self._stream()
+        with torch.cuda.stream(s):
+            k, kind = self._keys(keys, keep)
+            g = self._grads(grads, keep)
+            assert g.numel() == k.numel() * self._width
+            check(self._L.ha_cache_update(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
+                                          ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
+                  "ha_cache_update")
+            if self.perf_enabled:
+                self._perf_record(1)
+            return Wait(s, keep + [k, g])
+
+    def embedding_update_with_push_keys(self, keys, push_keys, grads):
+        """As embedding_update, the push set being the lines listed in the (sorted) push keys (cache.cc:248-335)."""
+        keep = []
+        s = self._stream()
+        with torch.cuda.stream(s):
+            k, kind = self._keys(keys, keep)
+            pk, pkind = self._keys(push_keys, keep)
+            g = self._grads(grads, keep)
+            check(self._L.ha_cache_update_with_push_keys(
+                self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(), ctypes.c_void_p(pk.data_ptr()), pkind,
+                pk.numel(), ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
+                "ha_cache_update_with_push_keys")
+            if self.perf_enabled:
+                self._perf_record(1)
+            return Wait(s, keep + [k, pk, g])
+
+    # the *_raw spellings of the reference take addresses; here they take the tensors themselves
+    embedding_lookup_raw = embedding_lookup
+    embedding_update_raw = embedding_update
+    embedding_update_with_push_keys_raw = embedding_update_with_push_keys
+    embedding_update_with_push_keys_np_raw = embedding_update_with_push_keys
+
+    # ---- inspection (debug API of the reference: count / size / keys / lookup) ----------------------------------------------
+    def _snapshot(self):
+        cap = self._limit + 8
+        dev = self.device
+        keys = torch.empty(cap, dtype=torch.int32, device=dev)
+        ver = torch.empty(cap, dtype=torch.int64, device=dev)
+        upd = torch.empty(cap, dtype=torch.int32, device=dev)
+        stamp = torch.empty(cap, dtype=torch.int64, device=dev)
+        slots = torch.empty(cap, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        s = self._stream()
+        with torch.cuda.stream(s):
+            check(self._L.ha_cache_snapshot(self._h, cap, *[ctypes.c_void_p(t.data_ptr()) for t in
+                                                            (keys, ver, upd, stamp, slots, cnt)],
+                                            ctypes.c_void_p(s.cuda_stream)), "ha_cache_snapshot")
+            s.synchronize()
+        n = int(cnt.item())
+        k = (keys[:n].cpu().numpy().astype(np.int64) & 0xFFFFFFFF)
+        order = np.argsort(k, kind="stable")
+        return {"keys": k[order], "version": ver[:n].cpu().numpy()[order], "updates": upd[:n].cpu().numpy()[order],
+                "stamp": stamp[:n].cpu().numpy()[order], "slots": slots[:n].cpu().numpy()[order]}
+
+    def _rows(self, which, slots):
+        """Rows of the cache's data / grad arrays (device -> host copies; inspection only)."""
+        fn = self._L.ha_cache_data if which == "data" else self._L.ha_cache_grad
+        base = fn(self._h)
+        out = np.empty((len(slots), self._width), dtype=np.float32)
+        torch.cuda.synchronize(self.device)
+        hip = _hip()
+        for i, sl in enumerate(slots):
+            rc = hip.hipMemcpy(ctypes.c_void_p(out[i].ctypes.data), ctypes.c_void_p(base + int(sl) * self._width * 4),
+                               ctypes.c_size_t(self._width * 4), ctypes.c_int(2))   # hipMemcpyDeviceToHost
+            if rc != 0:
+                raise _lib.HeraldAmdError("hipMemcpy failed: %d" % rc)
+        return out
+
+    def size(self):
+        out = (ctypes.c_int64 * 8)()
+        check(self._L.ha_cache_state(self._h, out, ctypes.c_void_p(self._stream().cuda_stream)), "ha_cache_state")
+        return int(out[0])
+
+    def state(self):
+        out = (ctypes.c_int64 * 8)()
+        check(self._L.ha_cache_state(self._h, out, ctypes.c_void_p(self._stream().cuda_stream)), "ha_cache_state")
+        return dict(zip(("size", "pending_evictions", "free_slots", "log_head", "log_tail", "clock", "slots",
+                         "log_cap"), [int(x) for x in out]))
+
+    def keys(self):
+        return self._snapshot()["keys"].astype(np.uint64)
+
+    def count(self, k):
+        return int(int(k) in set(self._snapshot()["keys"].tolist()))
+
+    def lookup(self, k):
+        snap = self._snapshot()
+        idx = np.nonzero(snap["keys"] == int(k))[0]
+        if idx.size == 0:
+            return None
+        i = int(idx[0])
+        data = self._rows("data", [snap["slots"][i]])[0]
+        grad = self._rows("grad", [snap["slots"][i]])[0]
+        return Embedding(k, snap["version"][i], data, grad, snap["updates"][i])
+
+    def lines(self):
+        """All resident lines as {key: Embedding} (test helper)."""
+        snap = self._snapshot()
+        data = self._rows("data", snap["slots"])
+        grad = self._rows("grad", snap["slots"])
+        return {int(k): Embedding(k, snap["version"][i], data[i], grad[i], snap["updates"][i])
+                for i, k in enumerate(snap["keys"])}
+
+    def __repr__(self):
+        return "<Cache : %d/%d , id:%d , width:%d , bound:%d %d>" % (
+            self.size(), self._limit, self.node_id, self._width, self._pull_bound, self._push_bound)
+
+
+_HIP = None
+
+
+def _hip():
+    global _HIP
+    if _HIP is None:
+        import os
+        _HIP = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        _HIP.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _HIP.hipMemcpy.restype = ctypes.c_int
+    return _HIP
+
+
+class LRUCache(_CacheBase):
+    POLICY, NAME = 0, "LRU"
+
+
+class LFUCache(_CacheBase):
+    POLICY, NAME = 1, "LFU"
+
+
+class LFUOptCache(_CacheBase):
+    POLICY, NAME = 2, "LFUOpt"
+
+
+class CacheSparseTable:
+    """Mirror of python/hetu/cstable.py:20-150."""
+
+    def __init__(self, limit, length, width, node_id, policy="LRU", bound=100, max_batch=None, device=None):
+        policy = policy.lower()
+        cls = {"lru": LRUCache, "lfu": LFUCache, "lfuopt": LFUOptCache}.get(policy)
+        if cls is None:
+            raise NotImplementedError(policy)
+        self.cache = cls(limit, length, width, node_id, max_batch=max_batch, device=device)
+        self.cache.pull_bound = bound
+        self.cache.push_bound = bound
+
+    def _finish(self, wait, sync):
+        if sync:
+            wait.wait()
+        return wait
+
+    def embedding_lookup(self, keys, dest, sync=False):
+        if isinstance(keys, tuple):
+            keys = keys[0]
+        return self._finish(self.cache.embedding_lookup(keys, dest), sync)
+
+    def embedding_update(self, keys, grads, sync=False):
+        return self._finish(self.cache.embedding_update(keys, grads), sync)
+
+    def embedding_update_with_push_keys(self, keys, push_keys, grads, sync=False):
+        return self._finish(self.cache.embedding_update_with_push_keys(keys, push_keys, grads), sync)
+
+    @property
+    def width(self):
+        return self.cache.width
+
+    @property
+    def limit(self):
+        return self.cache.limit
+
+    def perf_enabled(self, enable=True):
+        self.cache.perf_enabled = enable
+
+    def perf(self):
+        return self.cache.perf

@@ -1,0 +1,858 @@
+// HET embedding cache on the GPU (reference: src/hetu_cache).
+//
+// Reference model.  A worker-side cache of `limit` embedding lines in front of the parameter server.
+// A line (Line<T>, include/embedding.h:18-149) has data[width], a lazily created grad[width], a
+// `version` (-1 until first pulled) and an `updates` counter.  Per batch (src/cache.cc):
+//   lookup (60-107):  Unique(keys) -> policy lookup of every unique key IN SORTED ORDER (hit = touch)
+//       -> new empty lines for misses -> syncEmbedding: the server returns a row when the line's
+//       version is -1 or lags by more than pull_bound; the client stores version and row and re-adds
+//       its un-pushed gradient (hetu_client.cc:25-30, Line::addup) -> copy the line to every
+//       occurrence -> policy insert of the misses (sorted order), evicting when size > limit;
+//       evicted lines with updates != 0 wait in `evict_` for the next push.
+//   update (132-197): Unique -> policy lookup (touch) -> per occurrence, in order: grad += g;
+//       data += g; updates++ -> push = lines with updates > push_bound (or without data), merged with
+//       the pending evictions -> server: ver[row] += updates, row += grad (PSFhandle_embedding.cc:5-28)
+//       -> pushed lines: version += updates, zeroGrad.
+// LRUCache (src/lru_cache.cc): insert/lookup move to the list front, evict the back.
+//
+// MI355X layout.  Everything lives in HBM and every step is a kernel over the batch's unique keys;
+// no host round trip is needed between the kernels of one call (counts stay on the device):
+//   slot_of[length]     direct map row id -> slot (-1 absent): one load per probe, no hashing
+//   key/version/updates/stamp/state/hasgrad [S], data[S,width], grad[S,width]   S = limit + slack
+//   free_list[S]        stack of free slots
+//   LRU order = (stamp).  Every touch stamps the line with a monotone counter and appends
+//       (slot, stamp) to a ring log; the log is ordered by stamp, an entry is stale when the line was
+//       touched again (stamp mismatch) or left the cache.  Evicting E lines = taking the first E
+//       valid entries from the log head -- exactly the list-back order of the reference, found with
+//       a block scan instead of a pointer chase.  The log is compacted in place when it fills.
+// The batch index plan (plan.hip) supplies sorted unique keys / inverse / counts; occurrence-order
+// accumulation and the ordered server `+=` reuse the apply kernels (scatter_dev.h, ha_apply_mapped).
+#include "plan_dev.h"
+
+#include <vector>
+
+extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
+                               const void *plan_ws, int64_t n, const float *src,
+                               float lr, const int32_t *rowmap,
+                               const int32_t *valmap, const uint8_t *dst_init,
+                               ha_stream_t stream);
+
+namespace ha {
+
+enum LineState : uint8_t { kFree = 0, kResident = 1, kEvictedDirty = 2, kTransient = 3, kPending = 4 };
+
+struct CacheCtl {
+    long long size;       // resident lines
+    long long free_top;   // entries in free_list
+    long long log_head, log_tail;
+    long long evict_n;    // lines waiting in the evict list
+    long long clock;      // next stamp
+    // per-call scratch
+    long long U, M, nhit, E, pulled, C, dropped;
+    // last op report: type(0 pull,1 push), num_all, num_unique, num_miss, num_transfered, num_evict, is_full
+    long long perf[8];
+};
+
+struct Cache {
+    int policy;
+    int64_t limit, length, width, nmax, S, Lcap;
+    int64_t pull_bound, push_bound;
+    bool bypass;
+    CacheCtl *ctl;
+    int32_t *slot_of;
+    uint32_t *key;
+    long long *version;
+    int32_t *updates;
+    uint8_t *hasgrad, *state;
+    unsigned long long *stamp;
+    float *data, *grad;
+    int32_t *free_list;
+    uint32_t *log_slot;
+    unsigned long long *log_stamp;
+    int32_t *evict_slots;
+    // per-call scratch, sized nmax
+    void *plan_ws, *plan2_ws;
+    int32_t *uslot, *data_row;
+    uint32_t *flag, *rank;
+    uint8_t *pushflag;
+    uint32_t *pushkeys_u32;
+    // store (the "server"): rows [row_start, row_start + store_rows) of the global table
+    float *table;
+    long long *srv_ver;
+    int64_t store_rows, row_start;
+};
+
+#define CACHE_GRID(n) dim3(static_cast<unsigned>(((n) + 255) / 256 > 2048 ? 2048 : ((n) + 255) / 256 < 1 ? 1 : ((n) + 255) / 256))
+
+// ---- block-wide exclusive scan helper (1024 threads) ----------------------------------------------
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *s_w, uint32_t *total) {
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o)
+            x += y;
+    }
+    __syncthreads();
+    if (lane == 63)
+        s_w[w] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < w)
+            woff += s_w[k];
+        tot += s_w[k];
+    }
+    *total = tot;
+    return woff + x - v;
+}
+
+// ---- probe: slot of every unique key --------------------------------------------------------------
+__global__ __launch_bounds__(256) void cache_probe_kernel(
+    CacheCtl *ctl, const PlanHeader *hdr, const uint32_t *uniq,
+    const int32_t *slot_of, long long length, int bypass, int32_t *uslot,
+    uint32_t *flag) {
+    const int U = static_cast<int>(hdr->n_unique);
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
+        const uint32_t k = uniq[u];
+        int s = -1;
+        if (!bypass && k < static_cast<unsigned long long>(length))
+            s = slot_of[k];
+        uslot[u] = s;
+        flag[u] = s < 0 ? 1u : 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        ctl->U = U;
+}
+
+// exclusive scan of flag[0..U) -> rank, total -> *total_out.  Single workgroup.
+__global__ __launch_bounds__(1024) void cache_scan_kernel(
+    const PlanHeader *hdr, const uint32_t *flag, uint32_t *rank, long long *total_out,
+    long long *nhit_out) {
+    __shared__ uint32_t s_w[16];
+    const int U = static_cast<int>(hdr->n_unique);
+    uint32_t carry = 0;
+    for (int base = 0; base < U; base += 1024) {
+        const int u = base + threadIdx.x;
+        const uint32_t v = u < U ? flag[u] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan_1024(v, s_w, &tot);
+        if (u < U)
+            rank[u] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (nhit_out)
+            *nhit_out = U - static_cast<long long>(carry);
+    }
+}
+
+// hits: LRU touch (stamp + log append).  misses: take a slot from the free stack, new line.
+__global__ __launch_bounds__(256) void cache_assign_kernel(
+    const CacheCtl *ctl, Cache c, const uint32_t *uniq, const uint32_t *flag,
+    const uint32_t *rank, int miss_state) {
+    const int U = static_cast<int>(ctl->U);
+    const long long clock = ctl->clock, tail = ctl->log_tail, ftop = ctl->free_top;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
+        if (!flag[u]) {
+            const int s = c.uslot[u];
+            const unsigned long long st = static_cast<unsigned long long>(clock + u);
+            c.stamp[s] = st;
+            const long long pos = (tail + (u - static_cast<long long>(rank[u]))) % c.Lcap;
+            c.log_slot[pos] = static_cast<uint32_t>(s);
+            c.log_stamp[pos] = st;
+        } else {
+            const long long idx = ftop - 1 - static_cast<long long>(rank[u]);
+            // running out of slots is a sizing error reported by the host wrapper (nmax)
+            const int s = idx >= 0 ? c.free_list[idx] : 0;
+            c.uslot[u] = s;
+            c.key[s] = uniq[u];
+            c.version[s] = -1;
+            c.updates[s] = 0;
+            c.hasgrad[s] = 0;
+            c.state[s] = static_cast<uint8_t>(miss_state);
+        }
+    }
+}
+
+// syncEmbedding: pull rows whose cached version is -1 or lags by more than pull_bound.
+// One wave per unique key.
+__global__ __launch_bounds__(256) void cache_sync_kernel(CacheCtl *ctl, Cache c,
+                                                         const uint32_t *uniq) {
+    const int U = static_cast<int>(ctl->U);
+    const int lane = lane_id();
+    const int wpb = 4;
+    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < U; u += gridDim.x * wpb) {
+        const int s = c.uslot[u];
+        const uint32_t k = uniq[u];
+        const long long lk = static_cast<long long>(k) - c.row_start;
+        if (lk < 0 || lk >= c.store_rows)
+            continue;
+        const long long v = c.version[s];
+        const long long sv = c.srv_ver[lk];
+        if (!(v == -1 || sv - v > c.pull_bound))
+            continue;
+        const bool hg = c.hasgrad[s] != 0;
+        const float *src = c.table + lk * c.width;
+        float *dst = c.data + static_cast<long long>(s) * c.width;
+        const float *g = c.grad + static_cast<long long>(s) * c.width;
+        for (long long j = lane; j < c.width; j += kWave) {
+            float x = src[j];
+            if (hg)
+                x = __fadd_rn(x, g[j]);  // Line::addup(): data += grad
+            dst[j] = x;
+        }
+        if (lane == 0) {
+            c.version[s] = sv;
+            atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->pulled), 1ull);
+        }
+    }
+}
+
+// dest[i,:] = data[uslot[inverse[i]],:]
+__global__ __launch_bounds__(256) void cache_dest_kernel(Cache c, const int32_t *inverse,
+                                                         long long n, float *dest) {
+    const long long total = n * c.width;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        const long long i = e / c.width, j = e - i * c.width;
+        dest[e] = c.data[static_cast<long long>(c.uslot[inverse[i]]) * c.width + j];
+    }
+}
+
+// batchedInsert of the misses (sorted order) + LRU eviction + log compaction.  Single workgroup.
+__global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
+    CacheCtl *ctl, Cache c, const uint32_t *uniq, const uint32_t *flag,
+    const uint32_t *rank, int do_insert) {
+    __shared__ uint32_t s_w[16];
+    __shared__ long long s_head, s_need, s_clean, s_dirty;
+    const int U = static_cast<int>(ctl->U);
+    const long long M = do_insert ? ctl->M : 0;
+    const long long nhit = ctl->nhit;
+    const long long clock = ctl->clock, tail0 = ctl->log_tail;
+    if (do_insert) {
+        for (int u = threadIdx.x; u < U; u += 1024) {
+            if (flag[u]) {
+                const int s = c.uslot[u];
+                const unsigned long long st = static_cast<unsigned long long>(clock + U + rank[u]);
+                c.slot_of[uniq[u]] = s;
+                c.stamp[s] = st;
+                c.state[s] = kResident;
+                const long long pos = (tail0 + nhit + rank[u]) % c.Lcap;
+                c.log_slot[pos] = static_cast<uint32_t>(s);
+                c.log_stamp[pos] = st;
+            }
+        }
+    }
+    __syncthreads();
+    const long long tail = tail0 + nhit + M;
+    long long size = ctl->size + M;
+    long long need = size > c.limit ? size - c.limit : 0;
+    if (threadIdx.x == 0) {
+        s_head = ctl->log_head;
+        s_need = need;
+        s_clean = 0;
+        s_dirty = 0;
+    }
+    __syncthreads();
+    const long long E = need;
+    // ---- evict the `need` oldest valid log entries
+    while (true) {
+        const long long head = s_head, left = s_need;
+        if (left <= 0 || head >= tail)
+            break;
+        const long long pos = head + threadIdx.x;
+        int s = -1;
+        bool valid = false;
+        if (pos < tail) {
+            s = static_cast<int>(c.log_slot[pos % c.Lcap]);
+            valid = c.state[s] == kResident && c.stamp[s] == c.log_stamp[pos % c.Lcap];
+        }
+        uint32_t tot;
+        const uint32_t r = block_scan_1024(valid ? 1u : 0u, s_w, &tot);
+        const bool take = valid && static_cast<long long>(r) < left;
+        const bool dirty = take && c.updates[s] != 0;
+        uint32_t tot_d, tot_c;
+        const uint32_t rd = block_scan_1024(dirty ? 1u : 0u, s_w, &tot_d);
+        const uint32_t rc = block_scan_1024((take && !dirty) ? 1u : 0u, s_w, &tot_c);
+        if (take) {
+            c.slot_of[c.key[s]] = -1;
+            if (dirty) {
+                c.state[s] = kEvictedDirty;
+                c.evict_slots[ctl->evict_n + s_dirty + rd] = s;
+            } else {
+                c.state[s] = kFree;
+                // freed slots go on top of the stack AFTER this call's allocations are retired
+                c.free_list[ctl->free_top - M + s_clean + rc] = s;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const long long taken = static_cast<long long>(tot) < left ? tot : left;
+            s_need = left - taken;
+            s_clean += tot_c;
+            s_dirty += tot_d;
+            s_head = head + 1024 < tail ? head + 1024 : tail;
+        }
+        __syncthreads();
+        // entries past the last victim of a chunk that satisfied `need` are skipped too; they are
+        // either stale or still valid-and-resident -- the latter must stay reachable, so rewind
+        if (s_need == 0) {
+            // find the position right after the last taken entry
+            __shared__ long long s_last;
+            if (threadIdx.x == 0)
+                s_last = head;
+            __syncthreads();
+            if (take)
+                atomicMax(reinterpret_cast<unsigned long long *>(&s_last),
+                          static_cast<unsigned long long>(pos + 1));
+            __syncthreads();
+            if (threadIdx.x == 0)
+                s_head = s_last;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    long long head = s_head;
+    long long new_tail = tail;
+    // ---- compact the log in place when it is nearly full (valid entries keep their order)
+    if (tail - head > c.Lcap - 4 * c.nmax - 2048) {
+        __shared__ long long s_wr;
+        if (threadIdx.x == 0)
+            s_wr = head;
+        __syncthreads();
+        for (long long base = head; base < tail; base += 1024) {
+            const long long pos = base + threadIdx.x;
+            int s = -1;
+            unsigned long long st = 0;
+            bool valid = false;
+            if (pos < tail) {
+                s = static_cast<int>(c.log_slot[pos % c.Lcap]);
+                st = c.log_stamp[pos % c.Lcap];
+                valid = c.state[s] == kResident && c.stamp[s] == st;
+            }
+            uint32_t tot;
+            const uint32_t r = block_scan_1024(valid ? 1u : 0u, s_w, &tot);
+            const long long wr = s_wr;
+            __syncthreads();
+            if (valid) {
+                c.log_slot[(wr + r) % c.Lcap] = static_cast<uint32_t>(s);
+                c.log_stamp[(wr + r) % c.Lcap] = st;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0)
+                s_wr = wr + tot;
+            __syncthreads();
+        }
+        new_tail = s_wr;
+    }
+    if (threadIdx.x == 0) {
+        const long long evicted = E - s_need;
+        ctl->log_head = head;
+        ctl->log_tail = new_tail;
+        ctl->free_top = ctl->free_top - M + s_clean;
+        ctl->evict_n += s_dirty;
+        ctl->size = size - evicted;
+        ctl->clock = clock + U + M;
+        ctl->E = evicted;
+    }
+}
+
+// after a lookup: report (type 0)
+__global__ void cache_report_pull_kernel(CacheCtl *ctl, Cache c, long long n) {
+    ctl->perf[0] = 0;
+    ctl->perf[1] = n;
+    ctl->perf[2] = ctl->U;
+    ctl->perf[3] = ctl->M;
+    ctl->perf[4] = ctl->pulled;
+    ctl->perf[5] = 0;
+    ctl->perf[6] = ctl->size == c.limit;
+    ctl->pulled = 0;
+}
+
+// ---- update ----------------------------------------------------------------------------------------
+// rows for the two accumulate passes: grad row = slot (every line), data row = slot for lines with data
+__global__ __launch_bounds__(256) void cache_update_rows_kernel(const CacheCtl *ctl, Cache c) {
+    const int U = static_cast<int>(ctl->U);
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
+        const int s = c.uslot[u];
+        c.data_row[u] = c.state[s] == kTransient ? -1 : s;
+    }
+}
+
+// bookkeeping after the accumulate: updates += count, push decision
+__global__ __launch_bounds__(256) void cache_update_flags_kernel(
+    const CacheCtl *ctl, Cache c, const uint32_t *uniq, const int32_t *counts,
+    const uint32_t *push_keys, long long n_push_keys, int with_push_keys) {
+    const int U = static_cast<int>(ctl->U);
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
+        const int s = c.uslot[u];
+        c.hasgrad[s] = 1;
+        const int upd = c.updates[s] + counts[u];
+        c.updates[s] = upd;
+        const bool has_data = c.state[s] != kTransient;
+        bool push;
+        if (!with_push_keys) {
+            push = upd > c.push_bound || !has_data;  // cache.cc:159
+        } else {
+            // lines whose key is listed in the (sorted) push keys and that hold data (cache.cc:295-299)
+            const uint32_t k = uniq[u];
+            long long lo = 0, hi = n_push_keys;
+            while (lo < hi) {
+                const long long mid = (lo + hi) >> 1;
+                if (push_keys[mid] < k)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            push = has_data && lo < n_push_keys && push_keys[lo] == k;
+        }
+        c.pushflag[u] = push ? 1 : 0;
+        c.flag[u] = push ? 1u : 0u;
+    }
+}
+
+// server side of pushEmbedding for the batch's own lines (unique keys: no conflicts):
+//   ver[row] += updates;  row += grad      (PSFhandle_embedding.cc:23-27).  One wave per unique key.
+__global__ __launch_bounds__(256) void cache_push_lines_kernel(const CacheCtl *ctl, Cache c,
+                                                               const uint32_t *uniq) {
+    const int U = static_cast<int>(ctl->U);
+    const int lane = lane_id();
+    for (int u = blockIdx.x * 4 + (threadIdx.x >> 6); u < U; u += gridDim.x * 4) {
+        if (!c.pushflag[u])
+            continue;
+        const int s = c.uslot[u];
+        const long long lk = static_cast<long long>(uniq[u]) - c.row_start;
+        if (lk < 0 || lk >= c.store_rows)
+            continue;
+        float *row = c.table + lk * c.width;
+        const float *g = c.grad + static_cast<long long>(s) * c.width;
+        for (long long j = lane; j < c.width; j += kWave)
+            row[j] = __fadd_rn(row[j], g[j]);
+        if (lane == 0)
+            c.srv_ver[lk] += c.updates[s];
+    }
+}
+
+// pending evicted lines, pushed after the batch's lines (same-key order of the reference's merge:
+// the current line first, then the older evicted ones in eviction order).  Entry j is applied by the
+// wave of the FIRST entry with its key, which then walks the later duplicates in order.
+__global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl *ctl, Cache c) {
+    const int En = static_cast<int>(ctl->evict_n);
+    const int lane = lane_id();
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < En; j += gridDim.x * 4) {
+        const int s = c.evict_slots[j];
+        const uint32_t k = c.key[s];
+        bool earlier = false;
+        for (int b = 0; b < j && !earlier; b += kWave) {
+            const int t = b + lane;
+            const bool m = t < j && c.key[c.evict_slots[t]] == k;
+            earlier = __ballot(m) != 0ull;
+        }
+        if (earlier)
+            continue;
+        const long long lk = static_cast<long long>(k) - c.row_start;
+        if (lk < 0 || lk >= c.store_rows)
+            continue;
+        float *row = c.table + lk * c.width;
+        long long vadd = 0;
+        for (int t = j; t < En; ++t) {
+            const int st = c.evict_slots[t];
+            if (c.key[st] != k)
+                continue;
+            const float *g = c.grad + static_cast<long long>(st) * c.width;
+            for (long long q = lane; q < c.width; q += kWave)
+                row[q] = __fadd_rn(row[q], g[q]);
+            vadd += c.updates[st];
+        }
+        if (lane == 0)
+            c.srv_ver[lk] += vadd;
+    }
+}
+
+// after the push: version bump, zeroGrad, transient lines dropped, evicted slots freed.
+__global__ __launch_bounds__(256) void cache_update_cleanup_kernel(const CacheCtl *ctl, Cache c,
+                                                                   int with_push_keys) {
+    const int U = static_cast<int>(ctl->U);
+    const int lane = lane_id();
+    for (int u = blockIdx.x * 4 + (threadIdx.x >> 6); u < U; u += gridDim.x * 4) {
+        const int s = c.uslot[u];
+        const bool has_data = c.state[s] != kTransient;
+        const bool pushed = c.pushflag[u] != 0;
+        bool zero;
+        if (!with_push_keys) {
+            zero = pushed && has_data;                    // cache.cc:171-177
+            if (zero && lane == 0)
+                c.version[s] += c.updates[s];
+        } else {
+            if (lane == 0)
+                c.version[s] += c.updates[s];             // every touched line (cache.cc:308-310)
+            zero = pushed;
+        }
+        if (zero) {
+            float *g = c.grad + static_cast<long long>(s) * c.width;
+            for (long long j = lane; j < c.width; j += kWave)
+                g[j] = 0.f;
+            if (lane == 0)
+                c.updates[s] = 0;
+        }
+        if (!has_data && lane == 0)
+            c.state[s] = kFree;  // its stack entry was never retired (free_top unchanged)
+    }
+}
+
+__global__ __launch_bounds__(1024) void cache_update_commit_kernel(CacheCtl *ctl, Cache c,
+                                                                   long long n) {
+    __shared__ uint32_t s_w[16];
+    const int U = static_cast<int>(ctl->U);
+    const long long En = ctl->evict_n;
+    const long long ftop = ctl->free_top;
+    for (long long j = threadIdx.x; j < En; j += 1024) {
+        const int s = c.evict_slots[j];
+        c.state[s] = kFree;
+        c.free_list[ftop + j] = s;
+    }
+    // number of pushed lines of the batch
+    uint32_t cnt = 0;
+    for (int u = threadIdx.x; u < U; u += 1024)
+        cnt += c.pushflag[u];
+    uint32_t tot;
+    block_scan_1024(cnt, s_w, &tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl->perf[0] = 1;
+        ctl->perf[1] = n;
+        ctl->perf[2] = U;
+        ctl->perf[3] = ctl->M;       // lines not in the cache
+        ctl->perf[4] = tot + En;     // num_transfered
+        ctl->perf[5] = En;           // num_evict
+        ctl->perf[6] = ctl->size == c.limit;
+        ctl->free_top = ftop + En;
+        ctl->evict_n = 0;
+        ctl->clock += U;             // the touches of this call
+        ctl->log_tail += ctl->nhit;
+    }
+}
+
+__global__ __launch_bounds__(256) void cache_f32_to_u32_kernel(const float *in, long long n,
+                                                               uint32_t *out) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+        out[i] = f32_to_key(in[i]);
+}
+__global__ __launch_bounds__(256) void cache_u64_to_u32_kernel(const uint64_t *in, long long n,
+                                                               uint32_t *out) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+        out[i] = in[i] > 0xFFFFFFFEull ? 0xFFFFFFFEu : static_cast<uint32_t>(in[i]);
+}
+
+__global__ __launch_bounds__(256) void cache_init_kernel(Cache c) {
+    const long long tid = blockIdx.x * 256ll + threadIdx.x, stride = gridDim.x * 256ll;
+    for (long long i = tid; i < c.length; i += stride)
+        c.slot_of[i] = -1;
+    for (long long i = tid; i < c.S; i += stride) {
+        c.free_list[i] = static_cast<int32_t>(c.S - 1 - i);  // slot 0 is handed out first
+        c.state[i] = kFree;
+        c.updates[i] = 0;
+        c.hasgrad[i] = 0;
+        c.version[i] = -1;
+        c.stamp[i] = 0;
+    }
+    if (tid == 0) {
+        memset(c.ctl, 0, sizeof(CacheCtl));
+        c.ctl->free_top = c.S;
+        c.ctl->clock = 1;
+    }
+}
+
+// snapshot of the resident lines (unordered) for tests / keys() / debugging
+__global__ __launch_bounds__(256) void cache_snapshot_kernel(Cache c, long long cap, uint32_t *keys,
+                                                             long long *version, int32_t *updates,
+                                                             unsigned long long *stamp,
+                                                             int32_t *slots,
+                                                             unsigned long long *count) {
+    for (long long s = blockIdx.x * 256ll + threadIdx.x; s < c.S; s += gridDim.x * 256ll) {
+        if (c.state[s] != kResident)
+            continue;
+        const unsigned long long i = atomicAdd(count, 1ull);
+        if (static_cast<long long>(i) < cap) {
+            keys[i] = c.key[s];
+            version[i] = c.version[s];
+            updates[i] = c.updates[s];
+            stamp[i] = c.stamp[s];
+            slots[i] = static_cast<int32_t>(s);
+        }
+    }
+}
+
+template <typename T>
+static int dmalloc(T **p, size_t count) {
+    HA_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 256));
+    return 0;
+}
+
+}  // namespace ha
+
+using namespace ha;
+
+struct ha_cache {
+    Cache c;
+    std::vector<void *> allocs;
+};
+
+extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
+                                     int64_t width, int64_t max_batch) {
+    if (policy != 0) {
+        set_error("ha_cache_create: only the LRU policy (0) is implemented on the GPU so far");
+        return nullptr;
+    }
+    if (limit < 0 || length <= 0 || length > 0xFFFFFFFEll || width <= 0 || max_batch <= 0) {
+        set_error("ha_cache_create: bad arguments");
+        return nullptr;
+    }
+    ha_cache *h = new ha_cache();
+    Cache &c = h->c;
+    memset(&c, 0, sizeof(c));
+    c.policy = policy;
+    c.limit = limit;
+    c.length = length;
+    c.width = width;
+    c.nmax = max_batch;
+    c.S = limit + 4 * max_batch + 64;
+    c.Lcap = 2 * c.S + 8 * max_batch + 4096;
+    c.pull_bound = 5;   // include/cache.h:27-28
+    c.push_bound = 5;
+    const size_t plan_bytes = ha_plan_bytes(max_batch);
+    bool ok = true;
+#define CACHE_ALLOC(field, count)                                                   \
+    do {                                                                            \
+        if (ok && dmalloc(&c.field, static_cast<size_t>(count)) != 0)               \
+            ok = false;                                                             \
+        else if (ok)                                                                \
+            h->allocs.push_back(c.field);                                           \
+    } while (0)
+    CACHE_ALLOC(ctl, 1);
+    CACHE_ALLOC(slot_of, length);
+    CACHE_ALLOC(key, c.S);
+    CACHE_ALLOC(version, c.S);
+    CACHE_ALLOC(updates, c.S);
+    CACHE_ALLOC(hasgrad, c.S);
+    CACHE_ALLOC(state, c.S);
+    CACHE_ALLOC(stamp, c.S);
+    CACHE_ALLOC(data, c.S * width);
+    CACHE_ALLOC(grad, c.S * width);
+    CACHE_ALLOC(free_list, c.S);
+    CACHE_ALLOC(log_slot, c.Lcap);
+    CACHE_ALLOC(log_stamp, c.Lcap);
+    CACHE_ALLOC(evict_slots, c.S);
+    CACHE_ALLOC(uslot, max_batch);
+    CACHE_ALLOC(data_row, max_batch);
+    CACHE_ALLOC(flag, max_batch);
+    CACHE_ALLOC(rank, max_batch);
+    CACHE_ALLOC(pushflag, max_batch);
+    CACHE_ALLOC(pushkeys_u32, max_batch);
+    if (ok) {
+        char *p = nullptr;
+        if (dmalloc(&p, plan_bytes) == 0) {
+            c.plan_ws = p;
+            h->allocs.push_back(p);
+        } else {
+            ok = false;
+        }
+    }
+#undef CACHE_ALLOC
+    if (!ok) {
+        for (void *p : h->allocs)
+            (void)hipFree(p);
+        delete h;
+        return nullptr;
+    }
+    hipLaunchKernelGGL(cache_init_kernel, dim3(2048), dim3(256), 0, nullptr, c);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_error("ha_cache_create: init kernel failed");
+        for (void *p : h->allocs)
+            (void)hipFree(p);
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" void ha_cache_destroy(ha_cache *h) {
+    if (!h)
+        return;
+    (void)hipDeviceSynchronize();
+    for (void *p : h->allocs)
+        (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int ha_cache_set_bounds(ha_cache *h, int64_t pull_bound, int64_t push_bound) {
+    HA_REQUIRE(h, "cache: null handle");
+    h->c.pull_bound = pull_bound;
+    h->c.push_bound = push_bound;
+    return 0;
+}
+
+extern "C" int ha_cache_set_bypass(ha_cache *h, int bypass) {
+    HA_REQUIRE(h, "cache: null handle");
+    h->c.bypass = bypass != 0;
+    return 0;
+}
+
+extern "C" int ha_cache_bind_store(ha_cache *h, float *table, int64_t *versions,
+                                   int64_t store_rows, int64_t row_start) {
+    HA_REQUIRE(h && table && versions && store_rows >= 0 && row_start >= 0, "cache_bind_store: bad arguments");
+    h->c.table = table;
+    h->c.srv_ver = reinterpret_cast<long long *>(versions);
+    h->c.store_rows = store_rows;
+    h->c.row_start = row_start;
+    return 0;
+}
+
+// key_kind: 0 = float32 ids (the *_raw entry points, cache.cc:49-58), 1 = uint64 keys
+static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hipStream_t s) {
+    HA_REQUIRE(n <= h->c.nmax, "cache: batch of %ld keys exceeds max_batch %ld", (long)n, (long)h->c.nmax);
+    if (key_kind == 0)
+        return ha_plan_build_f32ids(static_cast<const float *>(keys), n, h->c.plan_ws, s);
+    return ha_plan_build_u64ids(static_cast<const uint64_t *>(keys), n, h->c.plan_ws, s);
+}
+
+extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int64_t n,
+                               float *dest, ha_stream_t stream) {
+    HA_REQUIRE(h && h->c.table, "cache_lookup: no store bound");
+    HA_REQUIRE(n >= 0 && (n == 0 || (keys && dest)), "cache_lookup: bad arguments");
+    Cache &c = h->c;
+    hipStream_t s = as_stream(stream);
+    if (cache_plan(h, keys, key_kind, n, s))
+        return -1;
+    PlanPtrs p = plan_layout(c.plan_ws, n);
+    const dim3 g = CACHE_GRID(n), b(256);
+    hipLaunchKernelGGL(cache_probe_kernel, g, b, 0, s, c.ctl, p.hdr, p.uniq, c.slot_of,
+                       (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
+    hipLaunchKernelGGL(cache_scan_kernel, dim3(1), dim3(1024), 0, s, p.hdr, c.flag, c.rank,
+                       &c.ctl->M, &c.ctl->nhit);
+    hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c, p.uniq, c.flag, c.rank,
+                       static_cast<int>(kPending));
+    hipLaunchKernelGGL(cache_sync_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq);
+    if (n > 0)
+        hipLaunchKernelGGL(cache_dest_kernel, CACHE_GRID(n * c.width), b, 0, s, c, p.inverse,
+                           (long long)n, dest);
+    hipLaunchKernelGGL(cache_insert_evict_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, p.uniq,
+                       c.flag, c.rank, c.bypass ? 0 : 1);
+    hipLaunchKernelGGL(cache_report_pull_kernel, dim3(1), dim3(1), 0, s, c.ctl, c, (long long)n);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_t n,
+                             const float *grads, const void *push_keys, int push_kind,
+                             int64_t n_push, int with_push_keys, hipStream_t s) {
+    HA_REQUIRE(h && h->c.table, "cache_update: no store bound");
+    HA_REQUIRE(n >= 0 && (n == 0 || (keys && grads)), "cache_update: bad arguments");
+    Cache &c = h->c;
+    if (cache_plan(h, keys, key_kind, n, s))
+        return -1;
+    PlanPtrs p = plan_layout(c.plan_ws, n);
+    const dim3 g = CACHE_GRID(n), b(256);
+    const uint32_t *pk = nullptr;
+    if (with_push_keys) {
+        HA_REQUIRE(n_push <= c.nmax, "cache_update: too many push keys");
+        if (n_push > 0) {
+            if (push_kind == 0)
+                hipLaunchKernelGGL(cache_f32_to_u32_kernel, CACHE_GRID(n_push), b, 0, s,
+                                   static_cast<const float *>(push_keys), (long long)n_push, c.pushkeys_u32);
+            else
+                hipLaunchKernelGGL(cache_u64_to_u32_kernel, CACHE_GRID(n_push), b, 0, s,
+                                   static_cast<const uint64_t *>(push_keys), (long long)n_push, c.pushkeys_u32);
+        }
+        pk = c.pushkeys_u32;
+    }
+    hipLaunchKernelGGL(cache_probe_kernel, g, b, 0, s, c.ctl, p.hdr, p.uniq, c.slot_of,
+                       (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
+    hipLaunchKernelGGL(cache_scan_kernel, dim3(1), dim3(1024), 0, s, p.hdr, c.flag, c.rank,
+                       &c.ctl->M, &c.ctl->nhit);
+    hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c, p.uniq, c.flag, c.rank,
+                       static_cast<int>(kTransient));
+    hipLaunchKernelGGL(cache_update_rows_kernel, g, b, 0, s, c.ctl, c);
+    HA_LAUNCH_CHECK();
+    // Line::accumulate per occurrence, occurrence order: grad += g (every line), data += g (lines
+    // with data).  lr = -1 turns the SGD chain `acc - lr*g` into `acc + g` bit for bit.
+    if (n > 0) {
+        if (ha_apply_mapped(c.grad, c.S, c.width, c.plan_ws, n, grads, -1.0f, c.uslot, nullptr,
+                            c.hasgrad, s))
+            return -1;
+        if (ha_apply_mapped(c.data, c.S, c.width, c.plan_ws, n, grads, -1.0f, c.data_row, nullptr,
+                            nullptr, s))
+            return -1;
+    }
+    hipLaunchKernelGGL(cache_update_flags_kernel, g, b, 0, s, c.ctl, c, p.uniq, p.counts, pk,
+                       (long long)n_push, with_push_keys);
+    hipLaunchKernelGGL(cache_push_lines_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq);
+    hipLaunchKernelGGL(cache_push_evicted_kernel, CACHE_GRID(c.nmax * 64), b, 0, s, c.ctl, c);
+    hipLaunchKernelGGL(cache_update_cleanup_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, with_push_keys);
+    hipLaunchKernelGGL(cache_update_commit_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, (long long)n);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ha_cache_update(ha_cache *h, const void *keys, int key_kind, int64_t n,
+                               const float *grads, ha_stream_t stream) {
+    return cache_update_impl(h, keys, key_kind, n, grads, nullptr, 0, 0, 0, as_stream(stream));
+}
+
+extern "C" int ha_cache_update_with_push_keys(ha_cache *h, const void *keys, int key_kind,
+                                              int64_t n, const void *push_keys, int push_kind,
+                                              int64_t n_push, const float *grads,
+                                              ha_stream_t stream) {
+    return cache_update_impl(h, keys, key_kind, n, grads, push_keys, push_kind, n_push, 1,
+                             as_stream(stream));
+}
+
+// out[8]: last op report {type, num_all, num_unique, num_miss, num_transfered, num_evict, is_full, size}
+extern "C" int ha_cache_perf(ha_cache *h, int64_t *out_host, ha_stream_t stream) {
+    HA_REQUIRE(h && out_host, "cache_perf: bad arguments");
+    CacheCtl ctl;
+    HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
+    HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    for (int i = 0; i < 7; ++i)
+        out_host[i] = ctl.perf[i];
+    out_host[7] = ctl.size;
+    return 0;
+}
+
+// out[8]: {size, evict_n, free_top, log_head, log_tail, clock, S, Lcap}
+extern "C" int ha_cache_state(ha_cache *h, int64_t *out_host, ha_stream_t stream) {
+    HA_REQUIRE(h && out_host, "cache_state: bad arguments");
+    CacheCtl ctl;
+    HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
+    HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    out_host[0] = ctl.size;
+    out_host[1] = ctl.evict_n;
+    out_host[2] = ctl.free_top;
+    out_host[3] = ctl.log_head;
+    out_host[4] = ctl.log_tail;
+    out_host[5] = ctl.clock;
+    out_host[6] = h->c.S;
+    out_host[7] = h->c.Lcap;
+    return 0;
+}
+
+// Resident lines, unordered: device arrays of capacity cap; returns the count through *count_dev
+// (device u64, zeroed by the caller).  slots[i] indexes ha_cache_data / ha_cache_grad rows.
+extern "C" int ha_cache_snapshot(ha_cache *h, int64_t cap, uint32_t *keys, int64_t *version,
+                                 int32_t *updates, uint64_t *stamp, int32_t *slots,
+                                 uint64_t *count_dev, ha_stream_t stream) {
+    HA_REQUIRE(h && keys && version && updates && stamp && slots && count_dev, "cache_snapshot: null pointer");
+    hipLaunchKernelGGL(cache_snapshot_kernel, dim3(1024), dim3(256), 0, as_stream(stream), h->c,
+                       (long long)cap, keys, reinterpret_cast<long long *>(version), updates,
+                       reinterpret_cast<unsigned long long *>(stamp), slots,
+                       reinterpret_cast<unsigned long long *>(count_dev));
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" float *ha_cache_data(ha_cache *h) { return h ? h->c.data : nullptr; }
+extern "C" float *ha_cache_grad(ha_cache *h) { return h ? h->c.grad : nullptr; }
+extern "C" int64_t ha_cache_limit(ha_cache *h) { return h ? h->c.limit : -1; }
+extern "C" int64_t ha_cache_width(ha_cache *h) { return h ? h->c.width : -1; }

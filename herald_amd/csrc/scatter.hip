@@ -38,6 +38,16 @@ __global__ __launch_bounds__(1024) void apply_kernel(
     apply_body<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, blockIdx.x);
 }
 
+// cache flavour: destination / source rows through index maps (see ApplyMaps)
+template <int VEC>
+__global__ __launch_bounds__(1024) void apply_mapped_kernel(
+    float *__restrict__ dst, uint64_t dst_rows, int width,
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ upos, int n, const float *__restrict__ src,
+    float lr, ApplyMaps maps) {
+    apply_body<kModeSgd, VEC>(dst, dst_rows, width, sorted, perm, upos, n, src, lr, blockIdx.x, nullptr, maps);
+}
+
 // diagnostic twin of apply_kernel<kModeSgd,4>: same body plus per-wave time stamps
 __global__ __launch_bounds__(1024) void apply_timeline_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
@@ -126,6 +136,35 @@ extern "C" int ha_debug_apply_timeline(float *table, int64_t rows, int64_t width
     const unsigned blocks = static_cast<unsigned>((n + ha::kPosPerBlock - 1) / ha::kPosPerBlock);
     hipLaunchKernelGGL(ha::apply_timeline_kernel, dim3(blocks), dim3(1024), 0, ha::as_stream(stream),
                        table, (uint64_t)rows, (int)width, v.sorted, v.perm, (int)n, grads, lr, dbg);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst[rowmap[u],:] = (init ? dst[rowmap[u],:] : 0) - lr*src[valmap[i0],:] - lr*src[valmap[i1],:] ...
+// over the occurrences i0 < i1 < ... of unique key u of a FINISHED plan.  rowmap / valmap / dst_init
+// may each be NULL (identity / identity / always init).  Used by the embedding cache.
+extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
+                               const void *plan_ws, int64_t n, const float *src,
+                               float lr, const int32_t *rowmap,
+                               const int32_t *valmap, const uint8_t *dst_init,
+                               ha_stream_t stream) {
+    HA_REQUIRE(n >= 0 && width >= 1 && width < (1 << 30), "apply_mapped: bad sizes");
+    if (n == 0)
+        return 0;
+    HA_REQUIRE(dst && plan_ws && src, "apply_mapped: null pointer");
+    ha_plan_view v;
+    if (ha_plan_view_of(const_cast<void *>(plan_ws), n, &v) != 0)
+        return -1;
+    const unsigned blocks = static_cast<unsigned>((n + ha::kPosPerBlock - 1) / ha::kPosPerBlock);
+    const bool vec_ok = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+    const ha::ApplyMaps maps{rowmap, valmap, dst_init};
+    if (vec_ok)
+        hipLaunchKernelGGL((ha::apply_mapped_kernel<4>), dim3(blocks), dim3(1024), 0, ha::as_stream(stream),
+                           dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos, (int)n, src, lr, maps);
+    else
+        hipLaunchKernelGGL((ha::apply_mapped_kernel<1>), dim3(blocks), dim3(1024), 0, ha::as_stream(stream),
+                           dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos, (int)n, src, lr, maps);
     HA_LAUNCH_CHECK();
     return 0;
 }

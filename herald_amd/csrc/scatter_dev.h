@@ -11,6 +11,16 @@ enum ApplyMode {
     kModeReduce = 2,  // out[u] = 0 + g0 + g1 ...
 };
 
+// Optional indirections used by the embedding cache (cache.hip): the destination row of unique key u
+// is rowmap[u] (-1 = skip), the source row of occurrence i is valmap[i], and a destination row whose
+// dst_init flag is 0 starts from 0.0f instead of its stored value (a cache line without a gradient
+// buffer yet, Line::_maybeInitGrad, src/hetu_cache/include/embedding.h:131-134).
+struct ApplyMaps {
+    const int32_t *rowmap;
+    const int32_t *valmap;
+    const uint8_t *dst_init;
+};
+
 constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per 1024-thread workgroup
 constexpr int kLookBack = 16;      // positions a wave looks back to find its offset in its run
 constexpr int kShortRun = 3;       // runs up to this long: one wave, whole row, 16-byte accesses
@@ -54,7 +64,8 @@ template <int MODE, int VEC, int VB>
 __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                                             const float *__restrict__ grads,
                                             int width, int cbase, int pv,
-                                            int lane0, int len, float lr) {
+                                            int lane0, int len, float lr,
+                                            bool init) {
     const int lane = lane_id();
     Vec<VEC> acc[VB], g[kShortRun][VB];
     int col[VB], lcol[VB];
@@ -63,7 +74,7 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
         col[b] = cbase + (b * kWave + lane) * VEC;
         lcol[b] = col[b] < width ? col[b] : 0;
         acc[b].zero();
-        if (MODE == kModeSgd)
+        if (MODE == kModeSgd && init)  // wave-uniform
             acc[b].load(dst_row + lcol[b]);
     }
 #pragma unroll
@@ -103,13 +114,13 @@ template <int MODE, int VEC>
 __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
                                           const float *__restrict__ grads,
                                           int width, int pv, int lane0, int len,
-                                          float lr) {
+                                          float lr, bool init) {
     constexpr int kCols1 = kWave * VEC;
     int c = 0;
     for (; width - c > kCols1; c += 2 * kCols1)
-        short_block<MODE, VEC, 2>(dst_row, grads, width, c, pv, lane0, len, lr);
+        short_block<MODE, VEC, 2>(dst_row, grads, width, c, pv, lane0, len, lr, init);
     for (; c < width; c += kCols1)
-        short_block<MODE, VEC, 1>(dst_row, grads, width, c, pv, lane0, len, lr);
+        short_block<MODE, VEC, 1>(dst_row, grads, width, c, pv, lane0, len, lr, init);
 }
 
 // ---- longer runs: column-split over the run's own waves ------------------------------------------
@@ -127,12 +138,14 @@ __device__ __forceinline__ void split_slice(float *__restrict__ dst_row,
                                             const uint32_t *__restrict__ sorted,
                                             const int32_t *__restrict__ perm,
                                             int start, int n, uint32_t key,
-                                            int width, int col, float lr) {
+                                            int width, int col, float lr,
+                                            const int32_t *__restrict__ valmap,
+                                            bool init) {
     const int lane = lane_id();
     const bool live = col < width;
     const int lcol = live ? col : 0;
     float acc = 0.f;
-    if (MODE == kModeSgd)
+    if (MODE == kModeSgd && init)
         acc = dst_row[lcol];
     const char *gbase = reinterpret_cast<const char *>(grads);
     const uint32_t col4 = static_cast<uint32_t>(lcol) * 4u;
@@ -143,7 +156,9 @@ __device__ __forceinline__ void split_slice(float *__restrict__ dst_row,
         const int q = start + 64 * b + lane;
         const int cq = min(q, n - 1);
         const uint32_t ks = sorted[cq];
-        const uint32_t idx = static_cast<uint32_t>(perm[cq]);
+        uint32_t idx = static_cast<uint32_t>(perm[cq]);
+        if (valmap)  // wave-uniform
+            idx = static_cast<uint32_t>(valmap[idx]);
         pv = OFF32 ? idx * rowbytes : idx;
         const unsigned long long m = __ballot(q < n && ks == key);
         cnt = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
@@ -238,7 +253,7 @@ __device__ __forceinline__ void apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int p, int *dbg_info);
+    float lr, int p, int *dbg_info, ApplyMaps maps);
 
 // One wave per sorted position p.  `dbg` (diagnostic builds of the timeline tool only) receives
 // {realtime start, realtime end, role/len, shader cycles} per position.
@@ -247,19 +262,20 @@ __device__ __forceinline__ void apply_body(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int vblock, unsigned long long *dbg = nullptr) {
+    float lr, int vblock, unsigned long long *dbg = nullptr,
+    ApplyMaps maps = ApplyMaps{nullptr, nullptr, nullptr}) {
     const int w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int p = vblock * kPosPerBlock + w;
     if (p >= n)
         return;
     if (dbg == nullptr) {
-        apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, nullptr);
+        apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, nullptr, maps);
         return;
     }
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     int info = 0;
-    apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, &info);
+    apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, &info, maps);
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -276,13 +292,15 @@ __device__ __forceinline__ void apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int p, int *dbg_info) {
+    float lr, int p, int *dbg_info, ApplyMaps maps) {
     const int lane = lane_id();
     // window of sorted positions p-16 .. p+47 (branch-free loads)
     const int q = p - kLookBack + lane;
     const int cq = max(0, min(q, n - 1));
     const uint32_t ks = sorted[cq];
-    const int pv = perm[cq];
+    int pv = perm[cq];
+    if (maps.valmap)  // wave-uniform
+        pv = maps.valmap[pv];
     const uint32_t key = static_cast<uint32_t>(
         __builtin_amdgcn_readlane(static_cast<int>(ks), kLookBack));
     const unsigned long long eq = __ballot(q >= 0 && q < n && ks == key);
@@ -299,18 +317,26 @@ __device__ __forceinline__ void apply_body_impl(
         *dbg_info = (o << 16) | len_known | (exact ? 0 : 0x8000);
 
     uint64_t row;
-    if (MODE == kModeReduce) {
+    bool init = true;
+    if (maps.rowmap) {
+        const int r = maps.rowmap[upos[p]];
+        if (r < 0)
+            return;  // unique key without a destination
+        row = static_cast<uint64_t>(r);
+        if (maps.dst_init)
+            init = maps.dst_init[r] != 0;
+    } else if (MODE == kModeReduce) {
         row = static_cast<uint64_t>(upos[p]);
     } else {
         row = key;
-        if (row >= dst_rows)
-            return;  // out-of-range id: ignored (undefined behaviour in the reference)
     }
+    if (row >= dst_rows)
+        return;  // out-of-range id: ignored (undefined behaviour in the reference)
     float *dst_row = dst + row * static_cast<uint64_t>(width);
 
     if (exact && len_known <= kShortRun) {
         if (o == 0)
-            short_row<MODE, VEC>(dst_row, grads, width, pv, kLookBack, len_known, lr);
+            short_row<MODE, VEC>(dst_row, grads, width, pv, kLookBack, len_known, lr, init);
         return;
     }
     // split mode: W workers, worker o takes slices o, o+W, ...
@@ -321,9 +347,9 @@ __device__ __forceinline__ void apply_body_impl(
     const int start = p - o;
     for (int c0 = o * kWave; c0 < width; c0 += workers * kWave) {
         if (off32)
-            split_slice<MODE, true>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr);
+            split_slice<MODE, true>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr, maps.valmap, init);
         else
-            split_slice<MODE, false>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr);
+            split_slice<MODE, false>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr, maps.valmap, init);
     }
 }
 

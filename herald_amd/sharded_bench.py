@@ -71,7 +71,7 @@ def run(args, rank, world, dev):
                                    "all-to-all" % (args.batch, args.width, args.fields, args.rows, world),
                        "ids_per_step_per_gpu": n, "parallelism": "row-sharded x%d" % world},
             "xgmi": {"egress_GBps_per_gpu_max": xgmi_gbs, "peak_GBps_per_gpu": links * XGMI_LINK_GBS,
-                     "frac": xgmi_gbs / (links * XGMI_LINK_GBS)},
+                     "frac": xgmi_gbs / (max(links, 1) * XGMI_LINK_GBS)},
             "roofline": None, "cpu_baseline": None,
         }))
     dist.destroy_process_group()

@@ -217,6 +217,15 @@ int ha_push_apply(float *table, int64_t rows, int64_t width,
                   const void *plan_ws, int64_t n, const float *grads,
                   ha_stream_t stream);
 
+/* Mapped flavour used by the embedding cache: for every unique key u of a FINISHED plan
+ *   dst[rowmap[u],:] = (dst_init[rowmap[u]] ? dst[rowmap[u],:] : 0) - lr*src[valmap[i0],:] - lr*src[valmap[i1],:] ...
+ * over its occurrences i0 < i1 < ... (rowmap[u] < 0 skips u; NULL maps are identities).  With
+ * lr = -1 this is Line::accumulate (src/hetu_cache/include/embedding.h:78-91) for a whole batch. */
+int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
+                    const void *plan_ws, int64_t n, const float *src, float lr,
+                    const int32_t *rowmap, const int32_t *valmap,
+                    const uint8_t *dst_init, ha_stream_t stream);
+
 /* ---- fused launches (two per training step) --------------------------------
  * ha_lookup_sort_*    == ha_gather_* + ha_plan_sort_*   in ONE launch (forward: the lookup of a
  *                        batch and the index plan its backward will need);
@@ -245,6 +254,48 @@ int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
 int ha_shard_bucket(const void *plan_ws, int64_t n, const int64_t *starts_host,
                     int nshard, int32_t *offsets, uint32_t *local_keys,
                     ha_stream_t stream);
+
+/* ---- HET embedding cache (replaces the hetu_cache plugin, src/hetu_cache) ----
+ * An opaque device-resident cache of `limit` lines in front of a store (the "server": a table shard
+ * plus one int64 version per row, ps-lite/include/ps/server/param.h:119-138).  Semantics of
+ * CacheBase::_embeddingLookup / _embeddingUpdate / _embeddingUpdateWithPushKeys
+ * (src/hetu_cache/src/cache.cc:60-107, 132-197, 248-335) with LRUCache eviction
+ * (src/hetu_cache/src/lru_cache.cc).  policy: 0 = LRU.  max_batch bounds the keys of one call.
+ * key_kind: 0 = float32 ids (the *_raw entry points, cache.cc:49-58), 1 = uint64 keys.
+ * dest / grads / keys are DEVICE pointers; all calls are asynchronous on `stream`. */
+typedef struct ha_cache ha_cache;
+ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
+                          int64_t width, int64_t max_batch);
+void ha_cache_destroy(ha_cache *cache);
+int ha_cache_set_bounds(ha_cache *cache, int64_t pull_bound, int64_t push_bound);
+int ha_cache_set_bypass(ha_cache *cache, int bypass);
+/* store rows [row_start, row_start+store_rows) of the global table live at `table`;
+ * versions[store_rows] are the server-side row versions (zero-initialised by the caller). */
+int ha_cache_bind_store(ha_cache *cache, float *table, int64_t *versions,
+                        int64_t store_rows, int64_t row_start);
+int ha_cache_lookup(ha_cache *cache, const void *keys, int key_kind, int64_t n,
+                    float *dest, ha_stream_t stream);
+int ha_cache_update(ha_cache *cache, const void *keys, int key_kind, int64_t n,
+                    const float *grads, ha_stream_t stream);
+int ha_cache_update_with_push_keys(ha_cache *cache, const void *keys,
+                                   int key_kind, int64_t n,
+                                   const void *push_keys, int push_kind,
+                                   int64_t n_push, const float *grads,
+                                   ha_stream_t stream);
+/* Synchronising inspectors.  perf out[8] = {type(0 pull / 1 push), num_all, num_unique, num_miss,
+ * num_transfered, num_evict, is_full, size} of the last call (the perf dict of cache.cc:89-106).
+ * state out[8] = {size, pending evictions, free slots, log head, log tail, clock, slots, log cap}. */
+int ha_cache_perf(ha_cache *cache, int64_t *out_host, ha_stream_t stream);
+int ha_cache_state(ha_cache *cache, int64_t *out_host, ha_stream_t stream);
+/* Resident lines, unordered, into device arrays of capacity cap; *count_dev (zeroed by the
+ * caller) receives the number of resident lines; slots[] index the rows of ha_cache_data/grad. */
+int ha_cache_snapshot(ha_cache *cache, int64_t cap, uint32_t *keys,
+                      int64_t *version, int32_t *updates, uint64_t *stamp,
+                      int32_t *slots, uint64_t *count_dev, ha_stream_t stream);
+float *ha_cache_data(ha_cache *cache);
+float *ha_cache_grad(ha_cache *cache);
+int64_t ha_cache_limit(ha_cache *cache);
+int64_t ha_cache_width(ha_cache *cache);
 
 /* Development aid: ha_sgd_apply with per-wave time stamps, dbg[4*n] u64 =
  * {s_memrealtime start, end (10 ns ticks), role/len, shader cycles} per sorted position. */

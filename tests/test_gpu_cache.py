@@ -1,0 +1,120 @@
+"""GPU parity of the device-resident HET cache against oracle/cache_model.py (bit-exact rows,
+identical hit/miss/evict/transfer counts, versions and resident sets, step by step)."""
+import numpy as np
+import pytest
+import torch
+
+from herald_amd import cache as hcache
+from oracle import cache_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_state(gpu, model, step):
+    res = model.resident()
+    lines = gpu.lines()
+    assert sorted(lines.keys()) == sorted(res.keys()), "resident set differs at step %d" % step
+    for k, ln in res.items():
+        g = lines[k]
+        assert g.version == ln.version, (step, k, g.version, ln.version)
+        assert g.updates == ln.updates, (step, k)
+        np.testing.assert_array_equal(g.data, ln.data, err_msg="data of key %d at step %d" % (k, step))
+        if ln.grad is not None:
+            np.testing.assert_array_equal(g.grad, ln.grad, err_msg="grad of key %d at step %d" % (k, step))
+
+
+def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_keys_mode=False, seed=0,
+               zipf=True, check_every=1):
+    rng = np.random.default_rng(seed)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    server = cache_model.Server(table0)
+    model = cache_model.CacheModel("lru", limit, width, server, pull_bound, push_bound)
+    table = torch.from_numpy(table0.copy()).to(dev)
+    versions = torch.zeros(rows, dtype=torch.int64, device=dev)
+    gpu = hcache.LRUCache(limit, rows, width, node_id=0, max_batch=max(n, 64), device=dev)
+    gpu.bind_store(table, versions)
+    gpu.pull_bound, gpu.push_bound = pull_bound, push_bound
+    gpu.perf_enabled = True
+    for step in range(steps):
+        if zipf:
+            keys = np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1).astype(np.int64)
+            keys = (keys * 7919) % rows
+        else:
+            keys = rng.integers(0, rows, size=n)
+        fk = keys.astype(np.float32)                      # the *_raw entry points take float32 ids
+        want = model.lookup(fk.astype(np.uint64))
+        dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+        gpu.embedding_lookup(torch.from_numpy(fk).to(dev), dest).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % step)
+        grads = (rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01))
+        if push_keys_mode:
+            pk = np.unique(rng.choice(keys, size=max(1, n // 3)))
+            model.update_with_push_keys(fk.astype(np.uint64), pk.astype(np.uint64), grads)
+            gpu.embedding_update_with_push_keys(torch.from_numpy(fk).to(dev),
+                                                torch.from_numpy(pk.astype(np.int64)).to(dev),
+                                                torch.from_numpy(grads).to(dev)).wait()
+        else:
+            model.update(fk.astype(np.uint64), grads)
+            gpu.embedding_update(torch.from_numpy(fk).to(dev), torch.from_numpy(grads).to(dev)).wait()
+        # perf dicts (cache.cc:89-106,179-196)
+        for got, exp in zip(gpu.perf[-2:], model.perf[-2:]):
+            for f in ("type", "num_all", "num_unique", "num_miss", "num_transfered", "is_full"):
+                assert got[f] == exp[f], (step, f, got, exp)
+            if exp["type"] == "Push":
+                assert got["num_evict"] == exp["num_evict"], (step, got, exp)
+        np.testing.assert_array_equal(versions.cpu().numpy(), server.ver, err_msg="server versions step %d" % step)
+        if step % check_every == 0 or step == steps - 1:
+            np.testing.assert_array_equal(table.cpu().numpy(), server.table, err_msg="server table step %d" % step)
+            _compare_state(gpu, model, step)
+    assert gpu.size() == model.policy.size()
+    np.testing.assert_array_equal(gpu.keys(), np.array(model.policy.keys(), dtype=np.uint64))
+    return gpu, model
+
+
+@pytest.mark.parametrize("pull_bound,push_bound", [(0, 0), (3, 3), (100, 100)])
+def test_lru_trace_small(dev, pull_bound, push_bound):
+    _run_trace(dev, limit=40, rows=400, width=8, n=64, steps=60, pull_bound=pull_bound, push_bound=push_bound)
+
+
+def test_lru_trace_uniform_heavy_eviction(dev):
+    _run_trace(dev, limit=16, rows=1000, width=4, n=48, steps=40, pull_bound=2, push_bound=2, zipf=False, seed=3)
+
+
+def test_lru_limit_smaller_than_batch(dev):
+    _run_trace(dev, limit=5, rows=200, width=4, n=40, steps=25, pull_bound=1, push_bound=1, zipf=False, seed=4)
+
+
+def test_lru_trace_with_push_keys(dev):
+    _run_trace(dev, limit=50, rows=500, width=8, n=80, steps=40, pull_bound=3, push_bound=3, push_keys_mode=True,
+               seed=5)
+
+
+def test_lru_trace_criteo_width(dev):
+    _run_trace(dev, limit=300, rows=5000, width=128, n=416, steps=12, pull_bound=2, push_bound=2, seed=6,
+               check_every=4)
+
+
+def test_log_compaction_keeps_lru_order(dev):
+    # a tiny cache driven for many steps forces the stamp log to wrap and compact
+    gpu, _ = _run_trace(dev, limit=8, rows=64, width=4, n=16, steps=400, pull_bound=0, push_bound=0, seed=7,
+                        check_every=50)
+    st = gpu.state()
+    assert st["log_tail"] - st["log_head"] <= st["log_cap"]
+
+
+def test_cache_sparse_table_numpy_and_bounds(dev):
+    rows, width = 300, 16
+    rng = np.random.default_rng(8)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    table = torch.from_numpy(table0.copy()).to(dev)
+    hcache.register_table(7, table)
+    t = hcache.CacheSparseTable(limit=32, length=rows, width=width, node_id=7, policy="LRU", bound=0,
+                                max_batch=128, device=dev)
+    keys = rng.integers(0, rows, size=50).astype(np.uint64)
+    dest = np.empty((50, width), dtype=np.float32)
+    t.embedding_lookup(keys, dest, sync=True)
+    np.testing.assert_array_equal(dest, table0[keys.astype(np.int64)])
+    assert t.width == width and t.limit == 32
+    with pytest.raises(NotImplementedError):
+        hcache.CacheSparseTable(10, rows, width, 7, policy="fifo")
+    assert "Cache" in repr(t.cache)
