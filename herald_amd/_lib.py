@@ -139,6 +139,14 @@ def _declare(L):
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = c.c_int
+    L.ha_laia_create.restype = vp
+    L.ha_laia_create.argtypes = [vp, i64, i64, i64, i64, i64, i64]
+    L.ha_laia_destroy.restype = None
+    L.ha_laia_destroy.argtypes = [vp]
+    L.ha_laia_next.restype = c.c_int
+    L.ha_laia_next.argtypes = [vp, i64, i64, vp, vp, i64, vp]
+    L.ha_laia_snapshot_keys.restype = i64
+    L.ha_laia_snapshot_keys.argtypes = [vp, i64, vp, i64]
     A, S = c.POINTER(DLArray), c.POINTER(DLStream)
     dl = {
         "DLGpuEmbeddingLookUp": [A, A, A, S],

@@ -21,6 +21,10 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+bool g_err_is_empty() {
+    return g_err[0] == 0;
+}
+
 // Per-(device, stream) scratch that the one-call reference-named ops use for their index plan.
 // It only grows; a stream serialises its own users, so reuse across calls on one stream is safe.
 struct Scratch {

@@ -15,6 +15,7 @@ constexpr int kWave = 64;  // CDNA wavefront
 
 // ---- error plumbing -------------------------------------------------------
 void set_error(const char *fmt, ...);
+bool g_err_is_empty();
 
 #define HA_CHECK_HIP(expr)                                                     \
     do {                                                                       \

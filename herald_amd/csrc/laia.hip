@@ -1,0 +1,411 @@
+// laia embedding scheduler (reference laia/): per global batch, score every
+// sample against per-worker cache snapshots, assign samples to workers, and emit each worker's
+// communication plan (rows it holds that another worker will touch).
+//
+// Reference: LaiaScheduler::get_dist / launch (laia/src/laia_scheduler.cc:115-271) with
+// MiniLRUCache snapshots (laia/include/mini_lru_cache.h:14-137).
+//
+// Split between the GPU and the host thread that drives it:
+//   GPU  * probing: for every (sample, table) of the batch, the set of workers whose snapshot holds
+//          the row VALID (one byte per (worker,row) in HBM, B*T*W probes per batch) -> per-sample
+//          scores and per-(sample,table) worker masks;
+//        * plan extraction: rows valid at w that occur in samples NOT assigned to w, and each
+//          worker's touched rows, as composite keys w*R+row, sorted-unique by the index-plan sort;
+//        * applying the snapshot deltas to the validity bytes.
+//   host * the greedy capacity-bounded assignment (sequential by definition, laia_scheduler.cc:231-249);
+//        * the exact MiniLRUCache bookkeeping (get / outdate in sorted-key order with interleaved
+//          evictions, mini_lru_cache.h:69-128) -- a pointer-chasing recurrence with no parallel form
+//          that keeps the reference's eviction order.
+// The emitted (plan, dist) sequence is bit-identical to the reference's.
+#include "plan_dev.h"
+
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+
+namespace ha {
+
+// ---- host-side snapshot: the semantics of MiniLRUCache (hash mode) ---------------------------------
+struct Snapshot {
+    int cap = 0;
+    std::unordered_map<int32_t, int> node_of;
+    std::vector<int> prev, next;
+    std::vector<int32_t> key;
+    std::vector<uint8_t> valid;
+    std::vector<int> free_nodes;
+    int front = -1, back = -1;
+
+    void init(int capacity) {
+        cap = capacity;
+        const int n = capacity + 2;
+        prev.assign(n, -1);
+        next.assign(n, -1);
+        key.assign(n, 0);
+        valid.assign(n, 0);
+        free_nodes.clear();
+        for (int i = n - 1; i >= 0; --i)
+            free_nodes.push_back(i);
+        node_of.clear();
+        node_of.reserve(static_cast<size_t>(capacity) * 3);  // set_cap, mini_lru_cache.h:49-52
+        front = back = -1;
+    }
+    void unlink(int x) {
+        if (prev[x] >= 0) next[prev[x]] = next[x]; else front = next[x];
+        if (next[x] >= 0) prev[next[x]] = prev[x]; else back = prev[x];
+    }
+    void push_front(int x) {
+        prev[x] = -1;
+        next[x] = front;
+        if (front >= 0) prev[front] = x;
+        front = x;
+        if (back < 0) back = x;
+    }
+    // delta: (key, new validity byte) pairs to mirror on the device
+    void outdate(int32_t k, std::vector<std::pair<int32_t, uint8_t>> &delta) {
+        auto it = node_of.find(k);
+        if (it != node_of.end() && valid[it->second]) {
+            valid[it->second] = 0;
+            delta.emplace_back(k, 0);
+        }
+    }
+    int get(int32_t k, std::vector<std::pair<int32_t, uint8_t>> &delta) {
+        auto it = node_of.find(k);
+        if (it != node_of.end()) {
+            const int x = it->second;
+            const int res = valid[x] ? -1 : -2;
+            unlink(x);
+            push_front(x);
+            if (!valid[x]) {
+                valid[x] = 1;
+                delta.emplace_back(k, 1);
+            }
+            return res;
+        }
+        const int x = free_nodes.back();
+        free_nodes.pop_back();
+        key[x] = k;
+        valid[x] = 1;
+        push_front(x);
+        node_of[k] = x;
+        delta.emplace_back(k, 1);
+        if (static_cast<int>(node_of.size()) > cap) {
+            const int e = back;
+            const bool flag = valid[e] != 0;
+            unlink(e);
+            node_of.erase(key[e]);
+            if (flag)
+                delta.emplace_back(key[e], 0);
+            free_nodes.push_back(e);
+            return flag ? 1 : 0;
+        }
+        return 0;
+    }
+};
+
+// ---- kernels -------------------------------------------------------------------------------------------
+// mask[i*T+j] = set of workers whose snapshot holds row samples[(start+i)%S][j] valid
+__global__ __launch_bounds__(256) void laia_probe_kernel(
+    const uint32_t *__restrict__ samples, long long S, int T, long long start, int B, int W,
+    const uint8_t *__restrict__ valid, long long R, unsigned long long *__restrict__ mask) {
+    const long long total = static_cast<long long>(B) * T;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        const long long i = e / T;
+        const int j = static_cast<int>(e - i * T);
+        const uint32_t emb = samples[((start + i) % S) * T + j];
+        unsigned long long m = 0;
+        if (emb < R) {
+            for (int w = 0; w < W; ++w)
+                if (valid[static_cast<long long>(w) * R + emb])
+                    m |= 1ull << w;
+        }
+        mask[e] = m;
+    }
+}
+
+// scores[i*W+w] = number of tables j with bit w set
+__global__ __launch_bounds__(256) void laia_score_kernel(
+    const unsigned long long *__restrict__ mask, int B, int T, int W, int32_t *__restrict__ scores) {
+    const int total = B * W;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int i = e / W, w = e - i * W;
+        int s = 0;
+        for (int j = 0; j < T; ++j)
+            s += static_cast<int>((mask[static_cast<long long>(i) * T + j] >> w) & 1ull);
+        scores[e] = s;
+    }
+}
+
+// plan pairs: (w, row) for rows valid at w in samples not assigned to w; touched pairs: (owner, row)
+__global__ __launch_bounds__(256) void laia_pairs_kernel(
+    const uint32_t *__restrict__ samples, long long S, int T, long long start, int B, int W,
+    const unsigned long long *__restrict__ mask, const int32_t *__restrict__ owner, long long R,
+    uint32_t *__restrict__ plan_pairs, unsigned long long *__restrict__ plan_count,
+    uint32_t *__restrict__ touch_pairs) {
+    const long long total = static_cast<long long>(B) * T;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        const long long i = e / T;
+        const int j = static_cast<int>(e - i * T);
+        const uint32_t emb = samples[((start + i) % S) * T + j];
+        const int ow = owner[i];
+        touch_pairs[e] = static_cast<uint32_t>(ow * R + emb);
+        unsigned long long m = mask[e] & ~(1ull << ow);
+        while (m) {
+            const int w = __builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned long long pos = atomicAdd(plan_count, 1ull);
+            plan_pairs[pos] = static_cast<uint32_t>(w * R + emb);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void laia_delta_kernel(const uint32_t *__restrict__ dkeys,
+                                                         const uint8_t *__restrict__ dvals,
+                                                         long long n, uint8_t *__restrict__ valid) {
+    // deltas of one batch are applied in list order per key; duplicates of a key are rare (a row
+    // revalidated and then evicted) -- the host keeps only the LAST value per (worker,row)
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll)
+        valid[dkeys[e]] = dvals[e];
+}
+
+struct Laia {
+    long long S = 0, R = 0;
+    int T = 0, W = 0, cache_size = 0;
+    std::vector<uint64_t> samples_host;
+    std::vector<Snapshot> snaps;
+    hipStream_t stream = nullptr;
+    uint32_t *d_samples = nullptr;
+    uint8_t *d_valid = nullptr;
+    unsigned long long *d_mask = nullptr, *d_count = nullptr;
+    int32_t *d_scores = nullptr, *d_owner = nullptr;
+    uint32_t *d_plan_pairs = nullptr, *d_touch_pairs = nullptr, *d_dkeys = nullptr;
+    uint8_t *d_dvals = nullptr;
+    void *d_plan_ws = nullptr;
+    size_t plan_cap = 0, delta_cap = 0;
+    int Bcap = 0;
+    std::vector<void *> allocs;
+};
+
+}  // namespace ha
+
+using namespace ha;
+
+struct ha_laia {
+    Laia l;
+};
+
+static int laia_alloc(Laia &l, void **p, size_t bytes) {
+    HA_CHECK_HIP(hipMalloc(p, bytes + 256));
+    l.allocs.push_back(*p);
+    return 0;
+}
+
+extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sample, int64_t num_table,
+                                   int64_t nrank, int64_t cache_size, int64_t key_limit,
+                                   int64_t max_batch) {
+    if (!samples_host || num_sample <= 0 || num_table <= 0 || nrank <= 0 || nrank > 64 || cache_size < 0 ||
+        key_limit <= 0 || max_batch <= 0 || static_cast<unsigned long long>(nrank) * key_limit > 0xFFFFFFFEull) {
+        set_error("ha_laia_create: bad arguments (need nrank <= 64 and nrank*key_limit < 2^32)");
+        return nullptr;
+    }
+    ha_laia *h = new ha_laia();
+    Laia &l = h->l;
+    l.S = num_sample;
+    l.T = static_cast<int>(num_table);
+    l.W = static_cast<int>(nrank);
+    l.R = key_limit;
+    l.cache_size = static_cast<int>(cache_size);
+    l.Bcap = static_cast<int>(max_batch);
+    l.samples_host.assign(samples_host, samples_host + num_sample * num_table);
+    l.snaps.resize(l.W);
+    for (auto &s : l.snaps)
+        s.init(l.cache_size);
+    const size_t BT = static_cast<size_t>(l.Bcap) * l.T;
+    l.plan_cap = BT * (l.W > 1 ? l.W - 1 : 1);
+    if (l.plan_cap < BT)
+        l.plan_cap = BT;
+    l.delta_cap = BT * 2 + static_cast<size_t>(l.W) * 16;
+    bool ok = hipStreamCreate(&l.stream) == hipSuccess;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_samples), num_sample * num_table * 4) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_valid), static_cast<size_t>(l.W) * l.R) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_mask), BT * 8) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_count), 8) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_scores), static_cast<size_t>(l.Bcap) * l.W * 4) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_owner), static_cast<size_t>(l.Bcap) * 4) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_plan_pairs), l.plan_cap * 4) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_touch_pairs), BT * 4) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_dkeys), l.delta_cap * 4) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_dvals), l.delta_cap) == 0;
+    ok = ok && laia_alloc(l, &l.d_plan_ws, ha_plan_bytes(static_cast<int64_t>(l.plan_cap))) == 0;
+    if (ok) {
+        std::vector<uint32_t> s32(l.samples_host.size());
+        for (size_t i = 0; i < s32.size(); ++i)
+            s32[i] = l.samples_host[i] > 0xFFFFFFFEull ? 0xFFFFFFFEu : static_cast<uint32_t>(l.samples_host[i]);
+        ok = hipMemcpy(l.d_samples, s32.data(), s32.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemset(l.d_valid, 0, static_cast<size_t>(l.W) * l.R) == hipSuccess;
+    }
+    if (!ok) {
+        if (g_err_is_empty())
+            set_error("ha_laia_create: device allocation failed");
+        for (void *p : l.allocs)
+            (void)hipFree(p);
+        if (l.stream)
+            (void)hipStreamDestroy(l.stream);
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" void ha_laia_destroy(ha_laia *h) {
+    if (!h)
+        return;
+    (void)hipStreamSynchronize(h->l.stream);
+    for (void *p : h->l.allocs)
+        (void)hipFree(p);
+    (void)hipStreamDestroy(h->l.stream);
+    delete h;
+}
+
+// sorted-unique of n composite keys (device) -> host vector
+static int sorted_unique_to_host(Laia &l, const uint32_t *d_keys, size_t n, std::vector<uint32_t> &out) {
+    out.clear();
+    if (n == 0)
+        return 0;
+    int bits = 1;
+    while ((static_cast<unsigned long long>(l.W) * l.R) >> bits)
+        ++bits;
+    if (ha_plan_build_u32keys(d_keys, static_cast<int64_t>(n), l.d_plan_ws, bits, l.stream))
+        return -1;
+    PlanPtrs p = plan_layout(l.d_plan_ws, static_cast<int64_t>(n));
+    long long U = 0;
+    HA_CHECK_HIP(hipMemcpyAsync(&U, &p.hdr->n_unique, 8, hipMemcpyDeviceToHost, l.stream));
+    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    out.resize(static_cast<size_t>(U));
+    if (U > 0) {
+        HA_CHECK_HIP(hipMemcpyAsync(out.data(), p.uniq, static_cast<size_t>(U) * 4, hipMemcpyDeviceToHost, l.stream));
+        HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    }
+    return 0;
+}
+
+// One global batch: get_dist(batch_id) followed by the snapshot update of launch().
+//   dist_out   [W * mini_bs]   global sample indices per worker (laia_scheduler.cc:245)
+//   plan_out   concatenated sorted plans of workers 0..W-1, plan_off[W+1] their offsets;
+//              plan_cap_elems bounds plan_out.
+extern "C" int ha_laia_next(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out,
+                            uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off) {
+    HA_REQUIRE(h && dist_out && plan_out && plan_off && mini_bs > 0, "laia_next: bad arguments");
+    Laia &l = h->l;
+    const int W = l.W, T = l.T;
+    const long long B = mini_bs * W;
+    HA_REQUIRE(B <= l.Bcap, "laia_next: global batch %lld exceeds max_batch %d", B, l.Bcap);
+    const long long start = (batch_id * B) % l.S;  // laia_scheduler.cc:182
+    const long long BT = B * T;
+    int blocks = static_cast<int>((BT + 255) / 256);
+    if (blocks > 4096)
+        blocks = 4096;
+    // ---- score
+    hipLaunchKernelGGL(laia_probe_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T,
+                       start, (int)B, W, l.d_valid, l.R, l.d_mask);
+    hipLaunchKernelGGL(laia_score_kernel, dim3((int)((B * W + 255) / 256)), dim3(256), 0, l.stream,
+                       l.d_mask, (int)B, T, W, l.d_scores);
+    HA_LAUNCH_CHECK();
+    std::vector<int32_t> scores(static_cast<size_t>(B) * W);
+    HA_CHECK_HIP(hipMemcpyAsync(scores.data(), l.d_scores, scores.size() * 4, hipMemcpyDeviceToHost, l.stream));
+    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    // ---- assign (laia_scheduler.cc:226-249): sequential, capacity mini_bs per worker, workers visited
+    // in the order (j + batch_id) % W, strictly greater score wins
+    std::vector<int32_t> owner(static_cast<size_t>(B));
+    std::vector<long long> workload(W, 0);
+    for (long long i = 0; i < B; ++i) {
+        int max_score = -1, max_worker = -1;
+        for (int j = 0; j < W; ++j) {
+            const int w = static_cast<int>((j + batch_id) % W);
+            const int sc = scores[static_cast<size_t>(i) * W + w];
+            if (workload[w] < mini_bs && max_score < sc) {
+                max_score = sc;
+                max_worker = w;
+            }
+        }
+        dist_out[static_cast<size_t>(max_worker) * mini_bs + workload[max_worker]] = (i + start) % l.S;
+        workload[max_worker] += 1;
+        owner[static_cast<size_t>(i)] = max_worker;
+    }
+    // ---- plan + touched rows
+    HA_CHECK_HIP(hipMemcpyAsync(l.d_owner, owner.data(), owner.size() * 4, hipMemcpyHostToDevice, l.stream));
+    HA_CHECK_HIP(hipMemsetAsync(l.d_count, 0, 8, l.stream));
+    hipLaunchKernelGGL(laia_pairs_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start,
+                       (int)B, W, l.d_mask, l.d_owner, l.R, l.d_plan_pairs, l.d_count, l.d_touch_pairs);
+    HA_LAUNCH_CHECK();
+    unsigned long long npairs = 0;
+    HA_CHECK_HIP(hipMemcpyAsync(&npairs, l.d_count, 8, hipMemcpyDeviceToHost, l.stream));
+    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    std::vector<uint32_t> plan_keys, touch_keys;
+    if (sorted_unique_to_host(l, l.d_plan_pairs, static_cast<size_t>(npairs), plan_keys))
+        return -1;
+    if (sorted_unique_to_host(l, l.d_touch_pairs, static_cast<size_t>(BT), touch_keys))
+        return -1;
+    // ---- emit plans (composite keys are sorted by worker, then row)
+    HA_REQUIRE(static_cast<long long>(plan_keys.size()) <= plan_cap_elems, "laia_next: plan buffer too small");
+    {
+        size_t k = 0;
+        for (int w = 0; w < W; ++w) {
+            plan_off[w] = static_cast<int64_t>(k);
+            while (k < plan_keys.size() && plan_keys[k] / l.R == static_cast<unsigned long long>(w)) {
+                plan_out[k] = plan_keys[k] - static_cast<unsigned long long>(w) * l.R;
+                ++k;
+            }
+        }
+        plan_off[W] = static_cast<int64_t>(plan_keys.size());
+    }
+    // ---- snapshot update (laia_scheduler.cc:146-162): outdate the plan keys, then get() every unique
+    // touched key in ascending order
+    std::vector<uint32_t> dkeys;
+    std::vector<uint8_t> dvals;
+    {
+        size_t pk = 0, tk = 0;
+        std::vector<std::pair<int32_t, uint8_t>> delta;
+        for (int w = 0; w < W; ++w) {
+            delta.clear();
+            const unsigned long long base = static_cast<unsigned long long>(w) * l.R;
+            for (; pk < plan_keys.size() && plan_keys[pk] / l.R == static_cast<unsigned long long>(w); ++pk)
+                l.snaps[w].outdate(static_cast<int32_t>(plan_keys[pk] - base), delta);
+            for (; tk < touch_keys.size() && touch_keys[tk] / l.R == static_cast<unsigned long long>(w); ++tk)
+                l.snaps[w].get(static_cast<int32_t>(touch_keys[tk] - base), delta);
+            // keep the last value per row
+            std::unordered_map<int32_t, uint8_t> last;
+            last.reserve(delta.size() * 2);
+            for (auto &d : delta)
+                last[d.first] = d.second;
+            for (auto &kv : last) {
+                dkeys.push_back(static_cast<uint32_t>(base + static_cast<uint32_t>(kv.first)));
+                dvals.push_back(kv.second);
+            }
+        }
+    }
+    if (!dkeys.empty()) {
+        HA_REQUIRE(dkeys.size() <= l.delta_cap, "laia_next: delta buffer too small");
+        HA_CHECK_HIP(hipMemcpyAsync(l.d_dkeys, dkeys.data(), dkeys.size() * 4, hipMemcpyHostToDevice, l.stream));
+        HA_CHECK_HIP(hipMemcpyAsync(l.d_dvals, dvals.data(), dvals.size(), hipMemcpyHostToDevice, l.stream));
+        hipLaunchKernelGGL(laia_delta_kernel, dim3((int)((dkeys.size() + 255) / 256)), dim3(256), 0, l.stream,
+                           l.d_dkeys, l.d_dvals, (long long)dkeys.size(), l.d_valid);
+        HA_LAUNCH_CHECK();
+        HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    }
+    return 0;
+}
+
+// valid keys of worker w's snapshot, ascending (MiniLRUCache::get_keys); returns the count
+extern "C" int64_t ha_laia_snapshot_keys(ha_laia *h, int64_t w, int32_t *out, int64_t cap) {
+    if (!h || w < 0 || w >= h->l.W)
+        return -1;
+    Snapshot &s = h->l.snaps[static_cast<size_t>(w)];
+    std::vector<int32_t> keys;
+    for (auto &kv : s.node_of)
+        if (s.valid[kv.second])
+            keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    for (size_t i = 0; i < keys.size() && static_cast<int64_t>(i) < cap; ++i)
+        out[i] = keys[i];
+    return static_cast<int64_t>(keys.size());
+}

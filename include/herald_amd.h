@@ -297,6 +297,25 @@ float *ha_cache_grad(ha_cache *cache);
 int64_t ha_cache_limit(ha_cache *cache);
 int64_t ha_cache_width(ha_cache *cache);
 
+/* ---- laia embedding scheduler (replaces the laia_cache plugin, laia/) --------
+ * LaiaScheduler::get_dist + the snapshot update of launch() (laia/src/laia_scheduler.cc:115-271) for
+ * one global batch of nrank*mini_bs samples: probing / plan extraction on the GPU, the greedy
+ * assignment and the MiniLRUCache bookkeeping (laia/include/mini_lru_cache.h) on the calling host
+ * thread.  samples_host[num_sample*num_table] are the embedding keys (all < key_limit,
+ * nrank*key_limit < 2^32).  ha_laia_next writes dist_out[nrank*mini_bs] (global sample indices per
+ * worker) and the workers' sorted communication plans concatenated into plan_out with
+ * plan_off[nrank+1].  All pointers are HOST pointers; the call synchronises its private stream. */
+typedef struct ha_laia ha_laia;
+ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sample,
+                        int64_t num_table, int64_t nrank, int64_t cache_size,
+                        int64_t key_limit, int64_t max_batch);
+void ha_laia_destroy(ha_laia *sched);
+int ha_laia_next(ha_laia *sched, int64_t batch_id, int64_t mini_bs,
+                 int64_t *dist_out, uint64_t *plan_out, int64_t plan_cap_elems,
+                 int64_t *plan_off);
+int64_t ha_laia_snapshot_keys(ha_laia *sched, int64_t worker, int32_t *out,
+                              int64_t cap);
+
 /* Development aid: ha_sgd_apply with per-wave time stamps, dbg[4*n] u64 =
  * {s_memrealtime start, end (10 ns ticks), role/len, shader cycles} per sorted position. */
 int ha_debug_apply_timeline(float *table, int64_t rows, int64_t width,
