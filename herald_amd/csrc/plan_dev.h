@@ -188,14 +188,19 @@ __device__ __forceinline__ void finish_small_body(
     uint16_t *s_upos = reinterpret_cast<uint16_t *>(s_dyn);   // [n rounded up to 8]
     uint16_t *s_seg = s_upos + ((n + 7) & ~7);                // [n+2]
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    // ---- pass A
+    // ---- pass A.  The only global-load round trip: sorted key, its left neighbour and the permutation
+    // entry of the kItems positions this thread covers in the coalesced mapping stay in registers for
+    // pass C.
+    uint32_t a[kItems];
+    int32_t pv[kItems];
     {
-        uint32_t a[kItems], b[kItems];
+        uint32_t b[kItems];
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             const int p = threadIdx.x + k * 1024;
             a[k] = sorted[min(p, n - 1)];              // branch-free loads
             b[k] = sorted[max(min(p, n - 1) - 1, 0)];
+            pv[k] = perm[min(p, n - 1)];
         }
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
@@ -257,26 +262,16 @@ __device__ __forceinline__ void finish_small_body(
         if (k < static_cast<int>(total))
             counts[k] = static_cast<int32_t>(s_seg[k + 1]) - a;
     }
-    {
-        int32_t pv[kItems];
-        uint32_t sv[kItems];
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const int p = threadIdx.x + k * 1024;
-            pv[k] = perm[min(p, n - 1)];
-            sv[k] = sorted[min(p, n - 1)];
-        }
-#pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const int p = threadIdx.x + k * 1024;
-            if (p < n) {
-                const uint32_t v = s_upos[p];
-                const int32_t ui = static_cast<int32_t>(v & 0x7FFFu);
-                upos[p] = ui;
-                inverse[pv[k]] = ui;
-                if (v >> 15)
-                    uniq[ui] = sv[k];
-            }
+    for (int k = 0; k < kItems; ++k) {
+        const int p = threadIdx.x + k * 1024;
+        if (p < n) {
+            const uint32_t v = s_upos[p];
+            const int32_t ui = static_cast<int32_t>(v & 0x7FFFu);
+            upos[p] = ui;
+            inverse[pv[k]] = ui;
+            if (v >> 15)
+                uniq[ui] = a[k];
         }
     }
 }

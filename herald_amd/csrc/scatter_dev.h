@@ -23,6 +23,7 @@ struct ApplyMaps {
 
 constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per 1024-thread workgroup
 constexpr int kLookBack = 16;      // positions a wave looks back to find its offset in its run
+constexpr int kLongRun = 48;       // runs at least this long are split over waves of different workgroups
 constexpr int kShortRun = 3;       // runs up to this long: one wave, whole row, 16-byte accesses
 constexpr int kHotDepth = 16;      // split mode: loads per chunk (a 64-block is 4 chunks)
 
@@ -255,7 +256,7 @@ __device__ __forceinline__ void apply_body_impl(
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr, int p, int *dbg_info, ApplyMaps maps);
 
-// One wave per sorted position p.  `dbg` (diagnostic builds of the timeline tool only) receives
+// One wave per sorted position p.  `dbg` (tools/timeline.py only) receives
 // {realtime start, realtime end, role/len, shader cycles} per position.
 template <int MODE, int VEC>
 __device__ __forceinline__ void apply_body(
@@ -308,13 +309,62 @@ __device__ __forceinline__ void apply_body_impl(
     const int back = inv_lo == 0 ? kLookBack : (__builtin_clz(inv_lo) - 16);
     const unsigned long long inv_hi = (~eq) >> kLookBack;  // bit t <-> position p+t, 48 valid bits
     const int fwd = __builtin_ctzll(inv_hi | (1ull << 48));  // 1..48
-    const int o = back;
-    if (o >= kLookBack)
-        return;  // deep inside a long run: the first 16 waves of the run do the work
-    const bool exact = fwd < 48;
+    // A compute unit pulls only ~25 GB/s from HBM (66 GB/s from L2), so a long run (hundreds of
+    // occurrence rows) must not be streamed by the waves of ONE workgroup.  Runs of >= kLongRun
+    // occurrences are therefore column-split over waves of DIFFERENT workgroups: the designated worker
+    // of slice group k is the wave at run offset 16*k (positions 16 apart sit in consecutive
+    // workgroups, which the dispatcher spreads over compute units and XCDs).
+    int o = back;
+    bool long_worker = false;   // designated worker of a long run
+    int long_workers = 0, long_k = 0;
+    const int nslice = (width + kWave - 1) / kWave;
+    if (back >= kLookBack) {
+        // deep inside a run: exact offset up to 16*nslice by an extended look-back
+        const int maxo = kLookBack * nslice;
+        int cnt = kLookBack;
+        for (int base = p - kLookBack; cnt < maxo; base -= kWave) {
+            const int qq = base - 1 - lane;                 // positions base-1, base-2, ...
+            const unsigned long long m = __ballot(qq >= 0 && sorted[max(qq, 0)] == key);
+            const int c = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
+            cnt += c;
+            if (c < 64)
+                break;
+        }
+        o = cnt;
+        if (o >= maxo || (o % kLookBack) != 0 || o + fwd < kLongRun)
+            return;  // not a designated offset, or the run is not a long one
+        long_worker = true;
+    } else if (o + fwd >= kLongRun) {
+        // a long run (every wave of the run reaches the same verdict: o + fwd is the exact length
+        // unless fwd == 48, and then it is >= 48 anyway): only offsets 0, 16, 32, ... work
+        if (o != 0)
+            return;
+        long_worker = true;
+    }
+    if (long_worker) {
+        // run length capped at 16*nslice decides how many designated workers exist
+        const int cap = kLookBack * nslice;
+        int lcap = o + fwd;
+        if (fwd >= 48) {
+            for (int base = p + 48; lcap < cap; base += kWave) {
+                const int qq = base + lane;
+                const unsigned long long m = __ballot(qq < n && sorted[min(qq, n - 1)] == key);
+                const int c = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
+                lcap += c;
+                if (c < 64)
+                    break;
+            }
+        }
+        lcap = min(lcap, cap);
+        long_workers = min(nslice, lcap / kLookBack);
+        long_k = o / kLookBack;
+        if (long_k >= long_workers)
+            return;
+    }
+    const bool exact = fwd < 48 && !long_worker;
     const int len_known = o + fwd;  // exact run length when `exact`
     if (dbg_info)
-        *dbg_info = (o << 16) | len_known | (exact ? 0 : 0x8000);
+        *dbg_info = (o << 16) | (len_known & 0x7FFF) | (exact ? 0 : 0x8000);
 
     uint64_t row;
     bool init = true;
@@ -339,13 +389,15 @@ __device__ __forceinline__ void apply_body_impl(
             short_row<MODE, VEC>(dst_row, grads, width, pv, kLookBack, len_known, lr, init);
         return;
     }
-    // split mode: W workers, worker o takes slices o, o+W, ...
-    const int workers = exact ? min(len_known, kLookBack) : kLookBack;
-    if (o >= workers)
+    // split mode.  Medium runs (4..47): the first min(L,16) waves of the run (same workgroup), worker o
+    // takes slices o, o+W, ...  Long runs: designated worker k of long_workers takes slices k, k+W, ...
+    const int workers = long_worker ? long_workers : min(len_known, kLookBack);
+    const int me = long_worker ? long_k : o;
+    if (me >= workers)
         return;
     const bool off32 = static_cast<uint64_t>(n) * static_cast<uint64_t>(width) * 4ull < (1ull << 32);
     const int start = p - o;
-    for (int c0 = o * kWave; c0 < width; c0 += workers * kWave) {
+    for (int c0 = me * kWave; c0 < width; c0 += workers * kWave) {
         if (off32)
             split_slice<MODE, true>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr, maps.valmap, init);
         else

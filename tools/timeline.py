@@ -40,7 +40,7 @@ for case in ("criteo", "distinct"):
     print("== %s: waves stamped %d, kernel span %.2f us" % (case, live.sum(), e[live].max()))
     print("   start times: p50 %.2f p90 %.2f max %.2f us" % tuple(np.percentile(s[live], [50, 90, 100])))
     worker = live & (dur > 0.3)
-    for lo, hi in ((1, 1), (2, 3), (4, 15), (16, 63), (64, 10000)):
+    for lo, hi in ((1, 1), (2, 3), (4, 15), (16, 47), (48, 10000)):
         m = live & (ln >= lo) & (ln <= hi) & (o == 0)
         if m.any():
             print("   run len %4d-%-5d heads %4d: dur p50 %.2f max %.2f us, end max %.2f" %
