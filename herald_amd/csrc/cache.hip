@@ -25,6 +25,13 @@
 //       touched again (stamp mismatch) or left the cache.  Evicting E lines = taking the first E
 //       valid entries from the log head -- exactly the list-back order of the reference, found with
 //       a block scan instead of a pointer chase.  The log is compacted in place when it fills.
+// LFUCache (src/lfu_cache.cc) and LFUOptCache (src/lfuopt_cache.cc) evict the oldest line of the lowest
+// use bucket BEFORE each insert once size == limit.  New lines enter the lowest bucket with the newest
+// stamps, so within one batch the victims are (exactly, see cache_insert_evict_kernel): the old lines of
+// the lowest bucket in arrival order, then -- once those are gone -- the batch's own first inserts; a
+// line of a higher bucket is taken at most once per batch, when the cache is full and the lowest
+// bucket empty.  The lowest bucket therefore gets the same stamp log as LRU (an entry is stale once the
+// line was promoted or evicted) and the rare higher-bucket victim is found by one scan over the slots.
 // The batch index plan (plan.hip) supplies sorted unique keys / inverse / counts; occurrence-order
 // accumulation and the ordered server `+=` reuse the apply kernels (scatter_dev.h, ha_apply_mapped).
 #include "plan_dev.h"
@@ -39,7 +46,10 @@ extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
 
 namespace ha {
 
-enum LineState : uint8_t { kFree = 0, kResident = 1, kEvictedDirty = 2, kTransient = 3, kPending = 4 };
+enum LineState : uint8_t { kFree = 0, kResident = 1, kEvictedDirty = 2, kTransient = 3, kPending = 4,
+                           kStored = 5 /* LFUOpt permanent store */ };
+enum Policy { kLRU = 0, kLFU = 1, kLFUOpt = 2 };
+constexpr int kUseCntMax = 10;  // lfuopt_cache.h:26
 
 struct CacheCtl {
     long long size;       // resident lines
@@ -49,6 +59,9 @@ struct CacheCtl {
     long long clock;      // next stamp
     // per-call scratch
     long long U, M, nhit, E, pulled, C, dropped;
+    long long n_base;      // LFU/LFUOpt: resident lines in the lowest use bucket
+    long long n_hash;      // LFUOpt: resident lines outside the permanent store
+    long long scan_victim; // slot of the lowest (use, stamp) line outside the lowest bucket, or -1
     // last op report: type(0 pull,1 push), num_all, num_unique, num_miss, num_transfered, num_evict, is_full
     long long perf[8];
 };
@@ -63,6 +76,7 @@ struct Cache {
     uint32_t *key;
     long long *version;
     int32_t *updates;
+    int32_t *freq;
     uint8_t *hasgrad, *state;
     unsigned long long *stamp;
     float *data, *grad;
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(1024) void cache_scan_kernel(
 
 // hits: LRU touch (stamp + log append).  misses: take a slot from the free stack, new line.
 __global__ __launch_bounds__(256) void cache_assign_kernel(
-    const CacheCtl *ctl, Cache c, const uint32_t *uniq, const uint32_t *flag,
+    const CacheCtl *ctl, CacheCtl *ctl_mut, Cache c, const uint32_t *uniq, const uint32_t *flag,
     const uint32_t *rank, int miss_state) {
     const int U = static_cast<int>(ctl->U);
     const long long clock = ctl->clock, tail = ctl->log_tail, ftop = ctl->free_top;
@@ -159,10 +173,32 @@ __global__ __launch_bounds__(256) void cache_assign_kernel(
         if (!flag[u]) {
             const int s = c.uslot[u];
             const unsigned long long st = static_cast<unsigned long long>(clock + u);
-            c.stamp[s] = st;
-            const long long pos = (tail + (u - static_cast<long long>(rank[u]))) % c.Lcap;
-            c.log_slot[pos] = static_cast<uint32_t>(s);
-            c.log_stamp[pos] = st;
+            if (c.policy == kLRU) {
+                // lru_cache.cc:27-39: move to the list front
+                c.stamp[s] = st;
+                const long long pos = (tail + (u - static_cast<long long>(rank[u]))) % c.Lcap;
+                c.log_slot[pos] = static_cast<uint32_t>(s);
+                c.log_stamp[pos] = st;
+            } else if (c.policy == kLFU) {
+                // lfu_cache.cc:22-29,51-68: use+1, front of the next bucket
+                const int f = c.freq[s];
+                if (f == 1)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_base), ~0ull);
+                c.freq[s] = f + 1;
+                c.stamp[s] = st;
+            } else if (c.state[s] == kResident) {
+                // lfuopt_cache.cc:26-41: use+1 or promotion to the never-evicted store
+                const int f = c.freq[s];
+                if (f == 0)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_base), ~0ull);
+                if (f + 1 < kUseCntMax) {
+                    c.freq[s] = f + 1;
+                    c.stamp[s] = st;
+                } else {
+                    c.state[s] = kStored;
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_hash), ~0ull);
+                }
+            }
         } else {
             const long long idx = ftop - 1 - static_cast<long long>(rank[u]);
             // running out of slots is a sizing error reported by the host wrapper (nmax)
@@ -221,6 +257,53 @@ __global__ __launch_bounds__(256) void cache_dest_kernel(Cache c, const int32_t 
     }
 }
 
+// LFU / LFUOpt, rare path: the cache is full and its lowest use bucket is empty, so the first insert of
+// this batch evicts the oldest line of the lowest non-empty bucket (lfu_cache.cc:31-42,
+// lfuopt_cache.cc:48-60): argmin (use, stamp) over the resident, non-stored lines.  Single workgroup;
+// exits immediately when the situation does not arise.
+__global__ __launch_bounds__(1024) void cache_scan_victim_kernel(CacheCtl *ctl, Cache c) {
+    __shared__ unsigned long long s_best[16];
+    __shared__ int s_slot[16];
+    if (threadIdx.x == 0)
+        ctl->scan_victim = -1;
+    const bool needed = c.policy != kLRU && ctl->M > 0 && ctl->n_base == 0 && ctl->size >= c.limit;
+    if (!needed)
+        return;
+    unsigned long long best = ~0ull;
+    int slot = -1;
+    for (long long s = threadIdx.x; s < c.S; s += 1024) {
+        if (c.state[s] != kResident)
+            continue;
+        // stamps stay far below 2^48
+        const unsigned long long k = (static_cast<unsigned long long>(c.freq[s]) << 48) | c.stamp[s];
+        if (k < best) {
+            best = k;
+            slot = static_cast<int>(s);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_down(best, o, 64);
+        const int os = __shfl_down(slot, o, 64);
+        if (ob < best) {
+            best = ob;
+            slot = os;
+        }
+    }
+    if (lane_id() == 0) {
+        s_best[threadIdx.x >> 6] = best;
+        s_slot[threadIdx.x >> 6] = slot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k)
+            if (s_best[k] < s_best[0]) {
+                s_best[0] = s_best[k];
+                s_slot[0] = s_slot[k];
+            }
+        ctl->scan_victim = s_slot[0];
+    }
+}
+
 // batchedInsert of the misses (sorted order) + LRU eviction + log compaction.  Single workgroup.
 __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
     CacheCtl *ctl, Cache c, const uint32_t *uniq, const uint32_t *flag,
@@ -229,34 +312,83 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
     __shared__ long long s_head, s_need, s_clean, s_dirty;
     const int U = static_cast<int>(ctl->U);
     const long long M = do_insert ? ctl->M : 0;
-    const long long nhit = ctl->nhit;
+    const long long nhit = c.policy == kLRU ? ctl->nhit : 0;  // only LRU logs its touches
     const long long clock = ctl->clock, tail0 = ctl->log_tail;
+    const long long size0 = ctl->size;
+    // Number of evictions and how many of the batch's own first inserts they consume (v_new), see the
+    // file header: LRU evicts after an insert while size > limit, LFU/LFUOpt before it while
+    // size == limit, and prefer old lines of the lowest bucket, then their own new lines.
+    long long need, v_new = 0, drop_all = 0, scan_take = 0;
+    if (c.policy == kLRU) {
+        need = size0 + M > c.limit ? size0 + M - c.limit : 0;
+    } else {
+        const long long free0 = c.limit > size0 ? c.limit - size0 : 0;
+        long long ev = M > free0 ? M - free0 : 0;
+        if (c.policy == kLFUOpt && ev > 0 && free0 == 0 && ctl->n_hash == 0)
+            drop_all = 1;  // only the permanent store is left: new lines are dropped (lfuopt_cache.cc:18-24)
+        if (drop_all) {
+            ev = 0;
+            v_new = M;
+        } else if (ev > 0 && ctl->n_base == 0 && free0 == 0) {
+            scan_take = ctl->scan_victim >= 0 ? 1 : 0;
+            v_new = ev - scan_take;
+            ev = 0;
+        } else {
+            const long long from_old = ev < ctl->n_base ? ev : ctl->n_base;
+            v_new = ev - from_old;
+            ev = from_old;
+        }
+        need = ev;
+    }
+    const int base_use = c.policy == kLFU ? 1 : 0;
     if (do_insert) {
         for (int u = threadIdx.x; u < U; u += 1024) {
             if (flag[u]) {
                 const int s = c.uslot[u];
-                const unsigned long long st = static_cast<unsigned long long>(clock + U + rank[u]);
+                const long long q = rank[u];
+                if (q < v_new) {
+                    // inserted and evicted again inside this batch (or dropped): never becomes resident;
+                    // a fresh line has updates == 0, so it does not enter evict_
+                    c.state[s] = kFree;
+                    continue;
+                }
+                const unsigned long long st = static_cast<unsigned long long>(clock + U + q);
                 c.slot_of[uniq[u]] = s;
                 c.stamp[s] = st;
+                c.freq[s] = base_use;
                 c.state[s] = kResident;
-                const long long pos = (tail0 + nhit + rank[u]) % c.Lcap;
+                const long long pos = (tail0 + nhit + (q - v_new)) % c.Lcap;
                 c.log_slot[pos] = static_cast<uint32_t>(s);
                 c.log_stamp[pos] = st;
             }
         }
     }
     __syncthreads();
-    const long long tail = tail0 + nhit + M;
-    long long size = ctl->size + M;
-    long long need = size > c.limit ? size - c.limit : 0;
+    const long long inserted = M - v_new;
+    const long long tail = tail0 + nhit + inserted;
+    long long size = size0 + inserted;
     if (threadIdx.x == 0) {
         s_head = ctl->log_head;
         s_need = need;
         s_clean = 0;
         s_dirty = 0;
+        if (scan_take) {
+            // the one victim outside the lowest bucket
+            const int vs = static_cast<int>(ctl->scan_victim);
+            c.slot_of[c.key[vs]] = -1;
+            if (c.updates[vs] != 0) {
+                c.state[vs] = kEvictedDirty;
+                c.evict_slots[ctl->evict_n] = vs;
+                s_dirty = 1;
+            } else {
+                c.state[vs] = kFree;
+                c.free_list[ctl->free_top - M] = vs;
+                s_clean = 1;
+            }
+        }
     }
     __syncthreads();
-    const long long E = need;
+    const long long E = need + scan_take;
     // ---- evict the `need` oldest valid log entries
     while (true) {
         const long long head = s_head, left = s_need;
@@ -267,7 +399,8 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
         bool valid = false;
         if (pos < tail) {
             s = static_cast<int>(c.log_slot[pos % c.Lcap]);
-            valid = c.state[s] == kResident && c.stamp[s] == c.log_stamp[pos % c.Lcap];
+            valid = c.state[s] == kResident && c.stamp[s] == c.log_stamp[pos % c.Lcap] &&
+                    (c.policy == kLRU || c.freq[s] == base_use);
         }
         uint32_t tot;
         const uint32_t r = block_scan_1024(valid ? 1u : 0u, s_w, &tot);
@@ -330,7 +463,8 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
             if (pos < tail) {
                 s = static_cast<int>(c.log_slot[pos % c.Lcap]);
                 st = c.log_stamp[pos % c.Lcap];
-                valid = c.state[s] == kResident && c.stamp[s] == st;
+                valid = c.state[s] == kResident && c.stamp[s] == st &&
+                        (c.policy == kLRU || c.freq[s] == base_use);
             }
             uint32_t tot;
             const uint32_t r = block_scan_1024(valid ? 1u : 0u, s_w, &tot);
@@ -347,15 +481,28 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
         }
         new_tail = s_wr;
     }
+    // the slots of the batch's dropped inserts go back on the stack right above the freed victims
+    if (do_insert && v_new > 0) {
+        const long long base = ctl->free_top - M + s_clean;
+        for (int u = threadIdx.x; u < U; u += 1024)
+            if (flag[u] && static_cast<long long>(rank[u]) < v_new)
+                c.free_list[base + rank[u]] = c.uslot[u];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         const long long evicted = E - s_need;
         ctl->log_head = head;
         ctl->log_tail = new_tail;
-        ctl->free_top = ctl->free_top - M + s_clean;
+        // slots of the batch's dropped inserts return to the stack as well
+        ctl->free_top = ctl->free_top - M + s_clean + v_new;
         ctl->evict_n += s_dirty;
         ctl->size = size - evicted;
         ctl->clock = clock + U + M;
         ctl->E = evicted;
+        if (c.policy != kLRU) {
+            ctl->n_base += inserted - (evicted - scan_take);
+            ctl->n_hash += inserted - evicted;
+        }
     }
 }
 
@@ -531,7 +678,8 @@ __global__ __launch_bounds__(1024) void cache_update_commit_kernel(CacheCtl *ctl
         ctl->free_top = ftop + En;
         ctl->evict_n = 0;
         ctl->clock += U;             // the touches of this call
-        ctl->log_tail += ctl->nhit;
+        if (c.policy == kLRU)
+            ctl->log_tail += ctl->nhit;  // the touches were logged by cache_assign_kernel
     }
 }
 
@@ -554,6 +702,7 @@ __global__ __launch_bounds__(256) void cache_init_kernel(Cache c) {
         c.free_list[i] = static_cast<int32_t>(c.S - 1 - i);  // slot 0 is handed out first
         c.state[i] = kFree;
         c.updates[i] = 0;
+        c.freq[i] = 0;
         c.hasgrad[i] = 0;
         c.version[i] = -1;
         c.stamp[i] = 0;
@@ -572,7 +721,7 @@ __global__ __launch_bounds__(256) void cache_snapshot_kernel(Cache c, long long 
                                                              int32_t *slots,
                                                              unsigned long long *count) {
     for (long long s = blockIdx.x * 256ll + threadIdx.x; s < c.S; s += gridDim.x * 256ll) {
-        if (c.state[s] != kResident)
+        if (c.state[s] != kResident && c.state[s] != kStored)
             continue;
         const unsigned long long i = atomicAdd(count, 1ull);
         if (static_cast<long long>(i) < cap) {
@@ -602,8 +751,8 @@ struct ha_cache {
 
 extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
                                      int64_t width, int64_t max_batch) {
-    if (policy != 0) {
-        set_error("ha_cache_create: only the LRU policy (0) is implemented on the GPU so far");
+    if (policy < 0 || policy > 2) {
+        set_error("ha_cache_create: policy must be 0 (LRU), 1 (LFU) or 2 (LFUOpt)");
         return nullptr;
     }
     if (limit < 0 || length <= 0 || length > 0xFFFFFFFEll || width <= 0 || max_batch <= 0) {
@@ -636,6 +785,7 @@ extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
     CACHE_ALLOC(key, c.S);
     CACHE_ALLOC(version, c.S);
     CACHE_ALLOC(updates, c.S);
+    CACHE_ALLOC(freq, c.S);
     CACHE_ALLOC(hasgrad, c.S);
     CACHE_ALLOC(state, c.S);
     CACHE_ALLOC(stamp, c.S);
@@ -732,12 +882,14 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
                        (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
     hipLaunchKernelGGL(cache_scan_kernel, dim3(1), dim3(1024), 0, s, p.hdr, c.flag, c.rank,
                        &c.ctl->M, &c.ctl->nhit);
-    hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c, p.uniq, c.flag, c.rank,
+    hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c.ctl, c, p.uniq, c.flag, c.rank,
                        static_cast<int>(kPending));
     hipLaunchKernelGGL(cache_sync_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq);
     if (n > 0)
         hipLaunchKernelGGL(cache_dest_kernel, CACHE_GRID(n * c.width), b, 0, s, c, p.inverse,
                            (long long)n, dest);
+    if (c.policy != kLRU)
+        hipLaunchKernelGGL(cache_scan_victim_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c);
     hipLaunchKernelGGL(cache_insert_evict_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, p.uniq,
                        c.flag, c.rank, c.bypass ? 0 : 1);
     hipLaunchKernelGGL(cache_report_pull_kernel, dim3(1), dim3(1), 0, s, c.ctl, c, (long long)n);
@@ -772,7 +924,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
                        (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
     hipLaunchKernelGGL(cache_scan_kernel, dim3(1), dim3(1024), 0, s, p.hdr, c.flag, c.rank,
                        &c.ctl->M, &c.ctl->nhit);
-    hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c, p.uniq, c.flag, c.rank,
+    hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c.ctl, c, p.uniq, c.flag, c.rank,
                        static_cast<int>(kTransient));
     hipLaunchKernelGGL(cache_update_rows_kernel, g, b, 0, s, c.ctl, c);
     HA_LAUNCH_CHECK();

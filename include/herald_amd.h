@@ -260,7 +260,8 @@ int ha_shard_bucket(const void *plan_ws, int64_t n, const int64_t *starts_host,
  * plus one int64 version per row, ps-lite/include/ps/server/param.h:119-138).  Semantics of
  * CacheBase::_embeddingLookup / _embeddingUpdate / _embeddingUpdateWithPushKeys
  * (src/hetu_cache/src/cache.cc:60-107, 132-197, 248-335) with LRUCache eviction
- * (src/hetu_cache/src/lru_cache.cc).  policy: 0 = LRU.  max_batch bounds the keys of one call.
+ * (lru_cache.cc), LFUCache (lfu_cache.cc) or LFUOptCache (lfuopt_cache.cc) eviction.
+ * policy: 0 = LRU, 1 = LFU, 2 = LFUOpt.  max_batch bounds the keys of one call.
  * key_kind: 0 = float32 ids (the *_raw entry points, cache.cc:49-58), 1 = uint64 keys.
  * dest / grads / keys are DEVICE pointers; all calls are asynchronous on `stream`. */
 typedef struct ha_cache ha_cache;

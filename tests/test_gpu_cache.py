@@ -24,14 +24,15 @@ def _compare_state(gpu, model, step):
 
 
 def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_keys_mode=False, seed=0,
-               zipf=True, check_every=1):
+               zipf=True, check_every=1, policy="lru"):
     rng = np.random.default_rng(seed)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
     server = cache_model.Server(table0)
-    model = cache_model.CacheModel("lru", limit, width, server, pull_bound, push_bound)
+    model = cache_model.CacheModel(policy, limit, width, server, pull_bound, push_bound)
     table = torch.from_numpy(table0.copy()).to(dev)
     versions = torch.zeros(rows, dtype=torch.int64, device=dev)
-    gpu = hcache.LRUCache(limit, rows, width, node_id=0, max_batch=max(n, 64), device=dev)
+    cls = {"lru": hcache.LRUCache, "lfu": hcache.LFUCache, "lfuopt": hcache.LFUOptCache}[policy]
+    gpu = cls(limit, rows, width, node_id=0, max_batch=max(n, 64), device=dev)
     gpu.bind_store(table, versions)
     gpu.pull_bound, gpu.push_bound = pull_bound, push_bound
     gpu.perf_enabled = True
@@ -118,3 +119,31 @@ def test_cache_sparse_table_numpy_and_bounds(dev):
     with pytest.raises(NotImplementedError):
         hcache.CacheSparseTable(10, rows, width, 7, policy="fifo")
     assert "Cache" in repr(t.cache)
+
+
+@pytest.mark.parametrize("policy", ["lfu", "lfuopt"])
+@pytest.mark.parametrize("pull_bound,push_bound", [(0, 0), (3, 3)])
+def test_lfu_policies_trace(dev, policy, pull_bound, push_bound):
+    _run_trace(dev, limit=40, rows=400, width=8, n=64, steps=60, pull_bound=pull_bound, push_bound=push_bound,
+               policy=policy, seed=11)
+
+
+@pytest.mark.parametrize("policy", ["lfu", "lfuopt"])
+def test_lfu_policies_heavy_eviction_and_small_limit(dev, policy):
+    _run_trace(dev, limit=16, rows=1000, width=4, n=48, steps=40, pull_bound=2, push_bound=2, zipf=False, seed=12,
+               policy=policy)
+    _run_trace(dev, limit=5, rows=200, width=4, n=40, steps=25, pull_bound=1, push_bound=1, zipf=False, seed=13,
+               policy=policy)
+
+
+def test_lfuopt_store_fills_up(dev):
+    # a hot working set smaller than the limit gets promoted to the never-evicted store; once the store
+    # holds `limit` lines new keys are dropped (lfuopt_cache.cc:18-24)
+    _run_trace(dev, limit=12, rows=60, width=4, n=40, steps=80, pull_bound=0, push_bound=0, zipf=True, seed=14,
+               policy="lfuopt")
+
+
+@pytest.mark.parametrize("policy", ["lfu", "lfuopt"])
+def test_lfu_with_push_keys(dev, policy):
+    _run_trace(dev, limit=50, rows=500, width=8, n=80, steps=30, pull_bound=3, push_bound=3, push_keys_mode=True,
+               seed=15, policy=policy)
