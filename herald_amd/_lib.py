@@ -131,6 +131,7 @@ def _declare(L):
         "ha_cache_lookup": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_update": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_update_with_push_keys": [vp, vp, c.c_int, i64, vp, c.c_int, i64, vp, vp],
+        "ha_cache_push_pull": [vp, vp, c.c_int, i64, vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_perf": [vp, vp, vp],
         "ha_cache_state": [vp, vp, vp],
         "ha_cache_snapshot": [vp, i64, vp, vp, vp, vp, vp, vp, vp],

@@ -242,6 +242,23 @@ class _CacheBase:
                 self._perf_record(1)
             return Wait(s, keep + [k, pk, g])
 
+    def embedding_push_pull(self, pullkeys, dest, pushkeys, grads):
+        """Push the gradients of pushkeys, then pull pullkeys into dest (cache.cc:356-422)."""
+        keep = []
+        s = self._stream()
+        with torch.cuda.stream(s):
+            pk, pkind = self._keys(pullkeys, keep)
+            sk, skind = self._keys(pushkeys, keep)
+            g = self._grads(grads, keep)
+            assert dest.is_cuda and dest.dtype == torch.float32 and dest.numel() == pk.numel() * self._width
+            check(self._L.ha_cache_push_pull(self._h, ctypes.c_void_p(pk.data_ptr()), pkind, pk.numel(),
+                                             ctypes.c_void_p(dest.data_ptr()), ctypes.c_void_p(sk.data_ptr()), skind,
+                                             sk.numel(), ctypes.c_void_p(g.data_ptr()),
+                                             ctypes.c_void_p(s.cuda_stream)), "ha_cache_push_pull")
+            return Wait(s, keep + [pk, sk, g, dest])
+
+    embedding_push_pull_raw = embedding_push_pull
+
     # the *_raw spellings of the reference take addresses; here they take the tensors themselves
     embedding_lookup_raw = embedding_lookup
     embedding_update_raw = embedding_update
@@ -376,6 +393,9 @@ class CacheSparseTable:
 
     def embedding_update_with_push_keys(self, keys, push_keys, grads, sync=False):
         return self._finish(self.cache.embedding_update_with_push_keys(keys, push_keys, grads), sync)
+
+    def embedding_push_pull(self, pullkeys, dest, pushkeys, grads, sync=False):
+        return self._finish(self.cache.embedding_push_pull(pullkeys, dest, pushkeys, grads), sync)
 
     @property
     def width(self):

@@ -61,6 +61,7 @@ struct CacheCtl {
     long long U, M, nhit, E, pulled, C, dropped;
     long long n_base;      // LFU/LFUOpt: resident lines in the lowest use bucket
     long long n_hash;      // LFUOpt: resident lines outside the permanent store
+    long long parked[4];   // push_pull: U, M, nhit of the parked pull phase; U of the push phase
     long long scan_victim; // slot of the lowest (use, stamp) line outside the lowest bucket, or -1
     // last op report: type(0 pull,1 push), num_all, num_unique, num_miss, num_transfered, num_evict, is_full
     long long perf[8];
@@ -90,6 +91,11 @@ struct Cache {
     uint32_t *flag, *rank;
     uint8_t *pushflag;
     uint32_t *pushkeys_u32;
+    // second scratch set (the pull phase of push_pull)
+    void *plan_ws_b;
+    int32_t *uslot_b, *data_row_b;
+    uint32_t *flag_b, *rank_b;
+    uint8_t *pushflag_b;
     // store (the "server"): rows [row_start, row_start + store_rows) of the global table
     float *table;
     long long *srv_ver;
@@ -213,6 +219,38 @@ __global__ __launch_bounds__(256) void cache_assign_kernel(
     }
 }
 
+// Makes the touches of cache_assign_kernel permanent: the stamps clock .. clock+U-1 are used, the LRU
+// log grew by one entry per hit.
+__global__ void cache_commit_touch_kernel(CacheCtl *ctl, Cache c) {
+    if (c.policy == kLRU)
+        ctl->log_tail += ctl->nhit;
+    ctl->clock += ctl->U;
+}
+// push_pull: the pull phase's new lines keep their stack entries out of reach of the push phase
+__global__ void cache_retire_kernel(CacheCtl *ctl, int retire) {
+    if (retire)
+        ctl->free_top -= ctl->parked[1];
+    else
+        ctl->free_top += ctl->parked[1];
+}
+// embedding_push_pull runs a pull phase and a push phase over two scratch sets; the pull phase's
+// counters are parked while the push phase uses the control block.
+__global__ void cache_park_kernel(CacheCtl *ctl, int op) {
+    if (op == 0) {          // park the pull phase
+        ctl->parked[0] = ctl->U;
+        ctl->parked[1] = ctl->M;
+        ctl->parked[2] = ctl->nhit;
+    } else if (op == 1) {   // resume the pull phase
+        ctl->U = ctl->parked[0];
+        ctl->M = ctl->parked[1];
+        ctl->nhit = ctl->parked[2];
+    } else if (op == 2) {   // park the push phase's unique count
+        ctl->parked[3] = ctl->U;
+    } else {                // resume it for the deferred clean-up
+        ctl->U = ctl->parked[3];
+    }
+}
+
 // syncEmbedding: pull rows whose cached version is -1 or lags by more than pull_bound.
 // One wave per unique key.
 __global__ __launch_bounds__(256) void cache_sync_kernel(CacheCtl *ctl, Cache c,
@@ -312,7 +350,8 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
     __shared__ long long s_head, s_need, s_clean, s_dirty;
     const int U = static_cast<int>(ctl->U);
     const long long M = do_insert ? ctl->M : 0;
-    const long long nhit = c.policy == kLRU ? ctl->nhit : 0;  // only LRU logs its touches
+    // the touches of this call (stamps clock-U .. clock-1, LRU log entries) were committed by
+    // cache_commit_touch_kernel: misses are stamped clock + rank and logged from the current tail
     const long long clock = ctl->clock, tail0 = ctl->log_tail;
     const long long size0 = ctl->size;
     // Number of evictions and how many of the batch's own first inserts they consume (v_new), see the
@@ -352,12 +391,12 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
                     c.state[s] = kFree;
                     continue;
                 }
-                const unsigned long long st = static_cast<unsigned long long>(clock + U + q);
+                const unsigned long long st = static_cast<unsigned long long>(clock + q);
                 c.slot_of[uniq[u]] = s;
                 c.stamp[s] = st;
                 c.freq[s] = base_use;
                 c.state[s] = kResident;
-                const long long pos = (tail0 + nhit + (q - v_new)) % c.Lcap;
+                const long long pos = (tail0 + (q - v_new)) % c.Lcap;
                 c.log_slot[pos] = static_cast<uint32_t>(s);
                 c.log_stamp[pos] = st;
             }
@@ -365,7 +404,7 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
     }
     __syncthreads();
     const long long inserted = M - v_new;
-    const long long tail = tail0 + nhit + inserted;
+    const long long tail = tail0 + inserted;
     long long size = size0 + inserted;
     if (threadIdx.x == 0) {
         s_head = ctl->log_head;
@@ -497,7 +536,7 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
         ctl->free_top = ctl->free_top - M + s_clean + v_new;
         ctl->evict_n += s_dirty;
         ctl->size = size - evicted;
-        ctl->clock = clock + U + M;
+        ctl->clock = clock + M;
         ctl->E = evicted;
         if (c.policy != kLRU) {
             ctl->n_base += inserted - (evicted - scan_take);
@@ -677,9 +716,6 @@ __global__ __launch_bounds__(1024) void cache_update_commit_kernel(CacheCtl *ctl
         ctl->perf[6] = ctl->size == c.limit;
         ctl->free_top = ftop + En;
         ctl->evict_n = 0;
-        ctl->clock += U;             // the touches of this call
-        if (c.policy == kLRU)
-            ctl->log_tail += ctl->nhit;  // the touches were logged by cache_assign_kernel
     }
 }
 
@@ -801,11 +837,23 @@ extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
     CACHE_ALLOC(rank, max_batch);
     CACHE_ALLOC(pushflag, max_batch);
     CACHE_ALLOC(pushkeys_u32, max_batch);
+    CACHE_ALLOC(uslot_b, max_batch);
+    CACHE_ALLOC(data_row_b, max_batch);
+    CACHE_ALLOC(flag_b, max_batch);
+    CACHE_ALLOC(rank_b, max_batch);
+    CACHE_ALLOC(pushflag_b, max_batch);
     if (ok) {
         char *p = nullptr;
         if (dmalloc(&p, plan_bytes) == 0) {
             c.plan_ws = p;
             h->allocs.push_back(p);
+        } else {
+            ok = false;
+        }
+        char *p2 = nullptr;
+        if (ok && dmalloc(&p2, plan_bytes) == 0) {
+            c.plan_ws_b = p2;
+            h->allocs.push_back(p2);
         } else {
             ok = false;
         }
@@ -884,6 +932,7 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
                        &c.ctl->M, &c.ctl->nhit);
     hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c.ctl, c, p.uniq, c.flag, c.rank,
                        static_cast<int>(kPending));
+    hipLaunchKernelGGL(cache_commit_touch_kernel, dim3(1), dim3(1), 0, s, c.ctl, c);
     hipLaunchKernelGGL(cache_sync_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq);
     if (n > 0)
         hipLaunchKernelGGL(cache_dest_kernel, CACHE_GRID(n * c.width), b, 0, s, c, p.inverse,
@@ -897,9 +946,12 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     return 0;
 }
 
+// defer_cleanup: embedding_push_pull runs the version bump / zeroGrad of the pushed lines only after
+// its pull phase, as the reference does (cache.cc:413-421 after 398-411).
 static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_t n,
                              const float *grads, const void *push_keys, int push_kind,
-                             int64_t n_push, int with_push_keys, hipStream_t s) {
+                             int64_t n_push, int with_push_keys, hipStream_t s,
+                             bool defer_cleanup = false) {
     HA_REQUIRE(h && h->c.table, "cache_update: no store bound");
     HA_REQUIRE(n >= 0 && (n == 0 || (keys && grads)), "cache_update: bad arguments");
     Cache &c = h->c;
@@ -926,6 +978,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
                        &c.ctl->M, &c.ctl->nhit);
     hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c.ctl, c, p.uniq, c.flag, c.rank,
                        static_cast<int>(kTransient));
+    hipLaunchKernelGGL(cache_commit_touch_kernel, dim3(1), dim3(1), 0, s, c.ctl, c);
     hipLaunchKernelGGL(cache_update_rows_kernel, g, b, 0, s, c.ctl, c);
     HA_LAUNCH_CHECK();
     // Line::accumulate per occurrence, occurrence order: grad += g (every line), data += g (lines
@@ -942,8 +995,10 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
                        (long long)n_push, with_push_keys);
     hipLaunchKernelGGL(cache_push_lines_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq);
     hipLaunchKernelGGL(cache_push_evicted_kernel, CACHE_GRID(c.nmax * 64), b, 0, s, c.ctl, c);
-    hipLaunchKernelGGL(cache_update_cleanup_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, with_push_keys);
+    // the evicted lines that were pending before this call are pushed now: their slots are free again
     hipLaunchKernelGGL(cache_update_commit_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, (long long)n);
+    if (!defer_cleanup)
+        hipLaunchKernelGGL(cache_update_cleanup_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, with_push_keys);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -959,6 +1014,68 @@ extern "C" int ha_cache_update_with_push_keys(ha_cache *h, const void *keys, int
                                               ha_stream_t stream) {
     return cache_update_impl(h, keys, key_kind, n, grads, push_keys, push_kind, n_push, 1,
                              as_stream(stream));
+}
+
+// embedding_push_pull (cache.cc:356-422): pull phase (touch + new lines) on scratch set B, push phase
+// (touch, accumulate, push incl. pending evictions) on scratch set A, then -- as
+// PSHandler::serve(kPushSyncEmbedding) pushes before it syncs (PSFhandle_embedding.cc:66-79) -- the
+// staleness-bounded pull, the copy to dest and the insert of the pull misses.
+extern "C" int ha_cache_push_pull(ha_cache *h, const void *pull_keys, int pull_kind, int64_t n_pull,
+                                  float *dest, const void *push_keys, int push_kind, int64_t n_push,
+                                  const float *grads, ha_stream_t stream) {
+    HA_REQUIRE(h && h->c.table, "cache_push_pull: no store bound");
+    HA_REQUIRE(n_pull >= 0 && n_push >= 0 && n_pull <= h->c.nmax && n_push <= h->c.nmax,
+               "cache_push_pull: bad sizes");
+    HA_REQUIRE((n_pull == 0 || (pull_keys && dest)) && (n_push == 0 || (push_keys && grads)),
+               "cache_push_pull: null pointer");
+    Cache &c = h->c;
+    hipStream_t s = as_stream(stream);
+    Cache cb = c;  // view with the B scratch set
+    cb.plan_ws = c.plan_ws_b;
+    cb.uslot = c.uslot_b;
+    cb.data_row = c.data_row_b;
+    cb.flag = c.flag_b;
+    cb.rank = c.rank_b;
+    cb.pushflag = c.pushflag_b;
+    const dim3 b(256);
+    // ---- pull phase, part 1
+    if (pull_kind == 0 ? ha_plan_build_f32ids(static_cast<const float *>(pull_keys), n_pull, cb.plan_ws, s)
+                       : ha_plan_build_u64ids(static_cast<const uint64_t *>(pull_keys), n_pull, cb.plan_ws, s))
+        return -1;
+    PlanPtrs pp = plan_layout(cb.plan_ws, n_pull);
+    hipLaunchKernelGGL(cache_probe_kernel, CACHE_GRID(n_pull), b, 0, s, c.ctl, pp.hdr, pp.uniq, c.slot_of,
+                       (long long)c.length, c.bypass ? 1 : 0, cb.uslot, cb.flag);
+    hipLaunchKernelGGL(cache_scan_kernel, dim3(1), dim3(1024), 0, s, pp.hdr, cb.flag, cb.rank, &c.ctl->M,
+                       &c.ctl->nhit);
+    hipLaunchKernelGGL(cache_assign_kernel, CACHE_GRID(n_pull), b, 0, s, c.ctl, c.ctl, cb, pp.uniq, cb.flag,
+                       cb.rank, static_cast<int>(kPending));
+    hipLaunchKernelGGL(cache_commit_touch_kernel, dim3(1), dim3(1), 0, s, c.ctl, c);
+    // the pull misses hold stack entries until they are inserted: retire them now so that the push
+    // phase's transient lines take different slots
+    hipLaunchKernelGGL(cache_park_kernel, dim3(1), dim3(1), 0, s, c.ctl, 0);
+    hipLaunchKernelGGL(cache_retire_kernel, dim3(1), dim3(1), 0, s, c.ctl, 1);
+    HA_LAUNCH_CHECK();
+    // ---- push phase (a complete embedding_update on scratch set A)
+    if (cache_update_impl(h, push_keys, push_kind, n_push, grads, nullptr, 0, 0, 0, s, true))
+        return -1;
+    // ---- pull phase, part 2
+    hipLaunchKernelGGL(cache_park_kernel, dim3(1), dim3(1), 0, s, c.ctl, 2);  // park the push phase's U
+    hipLaunchKernelGGL(cache_retire_kernel, dim3(1), dim3(1), 0, s, c.ctl, 0);
+    hipLaunchKernelGGL(cache_park_kernel, dim3(1), dim3(1), 0, s, c.ctl, 1);
+    hipLaunchKernelGGL(cache_sync_kernel, CACHE_GRID(n_pull * 64), b, 0, s, c.ctl, cb, pp.uniq);
+    if (n_pull > 0)
+        hipLaunchKernelGGL(cache_dest_kernel, CACHE_GRID(n_pull * c.width), b, 0, s, cb, pp.inverse,
+                           (long long)n_pull, dest);
+    if (c.policy != kLRU)
+        hipLaunchKernelGGL(cache_scan_victim_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c);
+    hipLaunchKernelGGL(cache_insert_evict_kernel, dim3(1), dim3(1024), 0, s, c.ctl, cb, pp.uniq, cb.flag,
+                       cb.rank, c.bypass ? 0 : 1);
+    hipLaunchKernelGGL(cache_report_pull_kernel, dim3(1), dim3(1), 0, s, c.ctl, c, (long long)n_pull);
+    // ---- deferred clean-up of the push phase (its unique count was parked before the pull phase resumed)
+    hipLaunchKernelGGL(cache_park_kernel, dim3(1), dim3(1), 0, s, c.ctl, 3);
+    hipLaunchKernelGGL(cache_update_cleanup_kernel, CACHE_GRID(n_push * 64), b, 0, s, c.ctl, c, 0);
+    HA_LAUNCH_CHECK();
+    return 0;
 }
 
 // out[8]: last op report {type, num_all, num_unique, num_miss, num_transfered, num_evict, is_full, size}

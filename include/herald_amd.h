@@ -283,6 +283,13 @@ int ha_cache_update_with_push_keys(ha_cache *cache, const void *keys,
                                    const void *push_keys, int push_kind,
                                    int64_t n_push, const float *grads,
                                    ha_stream_t stream);
+/* CacheBase::_embeddingPushPull (cache.cc:356-422): push the gradients of `push_keys`, then pull the
+ * rows of `pull_keys` (the server pushes before it syncs) -- the ASP-prefetch call of
+ * ParameterServerCommunicateOp (python/hetu/gpu_ops/ParameterServerCommunicate.py:37-40,68-72). */
+int ha_cache_push_pull(ha_cache *cache, const void *pull_keys, int pull_kind,
+                       int64_t n_pull, float *dest, const void *push_keys,
+                       int push_kind, int64_t n_push, const float *grads,
+                       ha_stream_t stream);
 /* Synchronising inspectors.  perf out[8] = {type(0 pull / 1 push), num_all, num_unique, num_miss,
  * num_transfered, num_evict, is_full, size} of the last call (the perf dict of cache.cc:89-106).
  * state out[8] = {size, pending evictions, free slots, log head, log tail, clock, slots, log cap}. */

@@ -333,6 +333,39 @@ class CacheModel:
                           "num_unique": len(ukeys), "num_evict": len(evict), "num_miss": miss,
                           "num_transfered": len(should_push)})
 
+    def push_pull(self, pull_keys, push_keys, grads):                          # _embeddingPushPull :356-422
+        pull_keys = np.asarray(pull_keys, dtype=np.uint64).reshape(-1)
+        push_keys = np.asarray(push_keys, dtype=np.uint64).reshape(-1)
+        grads = np.asarray(grads, dtype=np.float32).reshape(push_keys.size, self.width)
+        ukeys, inv = unique_sorted(pull_keys)
+        embeds = self._batched_lookup(ukeys)
+        should_insert = []
+        for i, k in enumerate(ukeys):
+            if embeds[i] is None:
+                embeds[i] = Line(k, self.width)
+                should_insert.append(embeds[i])
+        pkeys, pembeds, miss, evict = self._accumulate(push_keys, grads)
+        should_push = []
+        it = 0
+        for i in range(len(pkeys)):
+            if pembeds[i].updates > self.push_bound or pembeds[i].data is None:
+                while it < len(evict) and evict[it].key < pembeds[i].key:
+                    should_push.append(evict[it])
+                    it += 1
+                should_push.append(pembeds[i])
+        should_push.extend(evict[it:])
+        self.server.push_embedding(should_push)                                 # server: push, then sync
+        self.server.sync_embedding(embeds, self.pull_bound)                     # (PSFhandle_embedding.cc:66-79)
+        dest = np.empty((pull_keys.size, self.width), dtype=np.float32)
+        for j in range(pull_keys.size):
+            dest[j] = embeds[inv[j]].data
+        self._batched_insert(should_insert)
+        for i in range(len(pkeys)):
+            if pembeds[i].updates > self.push_bound and pembeds[i].data is not None:
+                pembeds[i].version += pembeds[i].updates
+                pembeds[i].zero_grad()
+        return dest
+
     # -- inspection helpers for the tests
     def resident(self):
         pol = self.policy

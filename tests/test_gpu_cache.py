@@ -147,3 +147,33 @@ def test_lfuopt_store_fills_up(dev):
 def test_lfu_with_push_keys(dev, policy):
     _run_trace(dev, limit=50, rows=500, width=8, n=80, steps=30, pull_bound=3, push_bound=3, push_keys_mode=True,
                seed=15, policy=policy)
+
+
+@pytest.mark.parametrize("policy", ["lru", "lfu", "lfuopt"])
+def test_push_pull_trace(dev, policy):
+    """embedding_push_pull (ASP prefetch): push batch k while pulling batch k+1, step by step."""
+    rng = np.random.default_rng(21)
+    rows, width, n, limit = 300, 8, 48, 30
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    server = cache_model.Server(table0)
+    model = cache_model.CacheModel(policy, limit, width, server, 2, 2)
+    table = torch.from_numpy(table0.copy()).to(dev)
+    versions = torch.zeros(rows, dtype=torch.int64, device=dev)
+    cls = {"lru": hcache.LRUCache, "lfu": hcache.LFUCache, "lfuopt": hcache.LFUOptCache}[policy]
+    gpu = cls(limit, rows, width, node_id=0, max_batch=64, device=dev)
+    gpu.bind_store(table, versions)
+    gpu.pull_bound = gpu.push_bound = 2
+    batches = [((np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1) * 31) % rows).astype(np.float32) for _ in range(40)]
+    want = model.lookup(batches[0].astype(np.uint64))
+    dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+    gpu.embedding_lookup(torch.from_numpy(batches[0]).to(dev), dest).wait()
+    np.testing.assert_array_equal(dest.cpu().numpy(), want)
+    for k in range(len(batches) - 1):
+        grads = rng.standard_normal((n, width), dtype=np.float32) * np.float32(0.01)
+        want = model.push_pull(batches[k + 1].astype(np.uint64), batches[k].astype(np.uint64), grads)
+        gpu.embedding_push_pull(torch.from_numpy(batches[k + 1]).to(dev), dest, torch.from_numpy(batches[k]).to(dev),
+                                torch.from_numpy(grads).to(dev)).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="push_pull rows at step %d" % k)
+        np.testing.assert_array_equal(versions.cpu().numpy(), server.ver)
+        np.testing.assert_array_equal(table.cpu().numpy(), server.table)
+        _compare_state(gpu, model, k)
