@@ -72,6 +72,33 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_plugins(force=False):
+    """pybind11 modules `hetu_cache` and `laia_cache` (host C++ over the C-ABI) -> herald_amd/plugins/."""
+    import sysconfig
+    import pybind11
+    out_dir = os.path.join(PKG, "plugins")
+    os.makedirs(out_dir, exist_ok=True)
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    inc = ["-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"], "-I", "/opt/rocm/include"]
+    outs = []
+    procs = []
+    for name in ("hetu_cache", "laia_cache"):
+        src = os.path.join(CSRC, "py_%s.cpp" % name)
+        out = os.path.join(out_dir, name + suffix)
+        outs.append(out)
+        if force or _newer([src, os.path.join(ROOT, "include", "herald_amd.h"), LIB], out):
+            cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-D__HIP_PLATFORM_AMD__"] + inc + \
+                  [src, "-o", out, "-L", PKG, "-lherald_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+                   "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-pthread"]
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        o, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(" ".join(cmd) + "\n" + o + "\n")
+            raise RuntimeError("plugin build failed")
+    return outs
+
+
 def build_oracle(force=False):
     """gcc build of the CPU restatement (oracle/oracle.c)."""
     src = os.path.join(ROOT, "oracle", "oracle.c")
@@ -97,6 +124,7 @@ def build_ref(force=False):
 
 def build_all(force=False, verbose=False):
     lib = build_lib(force=force, verbose=verbose)
+    build_plugins(force=force)
     build_oracle(force=force)
     build_ref(force=force)
     return lib
