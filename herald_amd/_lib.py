@@ -156,6 +156,9 @@ def _declare(L):
         "DeduplicateIndexedSlices": [A, A, A, S],
         "IndexedSlices2Dense": [A, A, A, S],
         "SGDOptimizerSparseUpdate": [A, A, A, f32, S],
+        "AdaGradOptimizerSparseUpdate": [A, A, A, A, f32, f32, S],
+        "AdamOptimizerSparseUpdate": [A, A, A, A, A, f32, f32, f32, f32, f32, f32, S],
+        "AdamWOptimizerSparseUpdate": [A, A, A, A, A, f32, f32, f32, f32, f32, f32, f32, S],
     }
     for name, args in dl.items():
         fn = getattr(L, name)

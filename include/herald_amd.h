@@ -106,6 +106,32 @@ int SGDOptimizerSparseUpdate(DLArrayHandle param,
                              const DLArrayHandle grad_values, float lr,
                              DLStreamHandle stream_handle);
 
+/* Sparse optimizers on DEDUPLICATED indices (callers run IndexedSlices.deduplicate first,
+ * python/hetu/gpu_links/OptimizerLink.py:60,78,95):
+ * src/common/c_runtime_api.h:661-664 / src/ops/OptimizersSparse.cu:331-389 */
+int AdaGradOptimizerSparseUpdate(DLArrayHandle param,
+                                 const DLArrayHandle grad_indices,
+                                 const DLArrayHandle grad_values,
+                                 DLArrayHandle acc, float lr, float eps,
+                                 DLStreamHandle stream_handle);
+/* src/common/c_runtime_api.h:670-674 / src/ops/OptimizersSparse.cu:391-455 */
+int AdamOptimizerSparseUpdate(DLArrayHandle param,
+                              const DLArrayHandle grad_indices,
+                              const DLArrayHandle grad_values,
+                              DLArrayHandle expavg, DLArrayHandle expavgsq,
+                              float lr, float beta1, float beta2, float beta1t,
+                              float beta2t, float eps,
+                              DLStreamHandle stream_handle);
+/* src/common/c_runtime_api.h:681-686 / src/ops/OptimizersSparse.cu:457-522 */
+int AdamWOptimizerSparseUpdate(DLArrayHandle param,
+                               const DLArrayHandle grad_indices,
+                               const DLArrayHandle grad_values,
+                               DLArrayHandle expavg, DLArrayHandle expavgsq,
+                               float lr, float beta1, float beta2,
+                               float beta1t, float beta2t, float eps,
+                               float weight_decay,
+                               DLStreamHandle stream_handle);
+
 /* ========================================================================= *
  * (2) Plain-pointer engine entry points.  All pointers are DEVICE pointers
  *     unless a parameter name ends in _host.

@@ -151,3 +151,32 @@ def sparse_push(table, ids, values, lr=None):
     vals = scale_values(values, lr) if lr is not None else _f32(values)
     uniq, _, red = dedup_reduce(ids, vals.reshape(np.asarray(ids).size, -1))
     return push_apply(table, uniq, red)
+
+
+# ---- sparse optimizers on deduplicated rows (numpy, the oracle style of tests/test_optimizer.py:117-198) ----
+def adagrad_sparse(param, acc, ids, grads, lr, eps):
+    """adagrad_sparse_update, src/ops/OptimizersSparse.cu:331-349 (ids unique).  In place, float32."""
+    f = np.float32
+    idx = np.asarray(ids).astype(np.int64)
+    g = np.asarray(grads, dtype=f)
+    a = (acc[idx] + g * g).astype(f)
+    acc[idx] = a
+    param[idx] = (param[idx] - f(lr) * g / (np.sqrt(a, dtype=f) + f(eps))).astype(f)
+
+
+def adam_sparse(param, m, v, ids, grads, lr, beta1, beta2, beta1t, beta2t, eps, weight_decay=None):
+    """adam_sparse_update / adamw_sparse_update, OptimizersSparse.cu:391-416, 457-484.  In place."""
+    f = np.float32
+    idx = np.asarray(ids).astype(np.int64)
+    g = np.asarray(grads, dtype=f)
+    cm = (f(beta1) * m[idx] + (f(1) - f(beta1)) * g).astype(f)
+    cv = (f(beta2) * v[idx] + (f(1) - f(beta2)) * g * g).astype(f)
+    m[idx] = cm
+    v[idx] = cv
+    cm = (cm / (f(1) - f(beta1t))).astype(f)
+    cv = (cv / (f(1) - f(beta2t))).astype(f)
+    if weight_decay is None:
+        param[idx] = (param[idx] - f(lr) * cm / (np.sqrt(cv, dtype=f) + f(eps))).astype(f)
+    else:
+        upd = (cm / (np.sqrt(cv, dtype=f) + f(eps))).astype(f)
+        param[idx] = (param[idx] - f(lr) * (upd + f(weight_decay) * param[idx])).astype(f)
