@@ -90,6 +90,7 @@ def _declare(L):
         "ha_gather_u64ids": [vp, i64, i64, vp, i64, vp, vp],
         "ha_gather_u32keys": [vp, i64, i64, vp, i64, vp, vp],
         "ha_scatter_rows_f32ids": [vp, vp, i64, i64, vp, i64, vp],
+        "ha_scale_f32": [vp, i64, f32, vp],
         "ha_plan_build_f32ids": [vp, i64, vp, vp],
         "ha_plan_build_u64ids": [vp, i64, vp, vp],
         "ha_plan_build_u32keys": [vp, i64, vp, c.c_int, vp],

@@ -128,6 +128,30 @@ extern "C" int ha_scatter_rows_f32ids(const float *values, const float *ids,
     return 0;
 }
 
+namespace ha {
+__global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ x, uint64_t n, float s) {
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
+    for (; i < n; i += stride)
+        x[i] = __fmul_rn(x[i], s);
+}
+}  // namespace ha
+
+// values[:] = values * scale -- `input_val.values[:] = input_val.values.asnumpy() * self.learning_rate`
+// of ParameterServerCommunicateOp._mult_lr_sparse_cpu (python/hetu/gpu_ops/ParameterServerCommunicate.py:58-59)
+extern "C" int ha_scale_f32(float *values, int64_t n, float scale, ha_stream_t stream) {
+    HA_REQUIRE(n >= 0 && (n == 0 || values), "scale: bad arguments");
+    if (n == 0)
+        return 0;
+    uint64_t blocks = (static_cast<uint64_t>(n) + 255) / 256;
+    if (blocks > 16384)
+        blocks = 16384;
+    hipLaunchKernelGGL(ha::scale_kernel, dim3((unsigned)blocks), dim3(256), 0, ha::as_stream(stream), values,
+                       (uint64_t)n, scale);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ha_gather_f32ids(const float *table, int64_t rows, int64_t width,
                                 const float *ids, int64_t n, float *out,
                                 ha_stream_t stream) {

@@ -157,6 +157,10 @@ int ha_scatter_rows_f32ids(const float *values, const float *ids, int64_t n,
                            int64_t width, float *dst, int64_t rows,
                            ha_stream_t stream);
 
+/* values[i] *= scale (one float32 rounding): the `values *= -lr` step of
+ * ParameterServerCommunicateOp (python/hetu/gpu_ops/ParameterServerCommunicate.py:24,58-59). */
+int ha_scale_f32(float *values, int64_t n, float scale, ha_stream_t stream);
+
 /* ---- index plan: sorted-unique + inverse + counts + occurrence lists ------
  * Semantics of np.unique(ids, return_inverse=True, return_counts=True)
  * (python/hetu/ndarray.py:534,559) == hetu::Unique<T> (unqiue_tools.h:27-48)

@@ -1,0 +1,86 @@
+"""Operator-level harness (herald_amd/hetu_ops.py): the op sequence of a training step as the reference's
+executor issues it, against a numpy restatement of the same sequence."""
+import numpy as np
+import pytest
+import torch
+
+from herald_amd import hetu_ops, synth
+from herald_amd.sharded import ShardedEmbedding
+from oracle import cache_model, cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(nb, bs, rows, seed):
+    return [(synth.criteo_batch(bs, b, seed=seed).reshape(bs, 26) % rows).astype(np.float32) for b in range(nb)]
+
+
+def test_gpu_table_sgd_step_sequence(dev):
+    """comm None: EmbeddingLookUp._compute_gpu -> dense part -> EmbeddingLookUp_Gradient -> sparse SGD."""
+    rows, width, bs, lr = 20000, 32, 16, 0.05
+    rng = np.random.default_rng(1)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    emb = hetu_ops.EmbeddingParameter(table=torch.from_numpy(table0.copy()).to(dev))
+    look = hetu_ops.EmbeddingLookUp(emb)
+    look.forward_hook(hetu_ops.Config(comm_mode=None, prefetch=False, use_sparse_pull=False))
+    gradop = hetu_ops.EmbeddingLookUp_Gradient(emb.shape)
+    ref = table0.copy()
+    for ids in _batches(6, bs, rows, 5):
+        d_ids = torch.from_numpy(ids).to(dev)
+        out = torch.empty((bs, 26, width), dtype=torch.float32, device=dev)
+        look.compute(d_ids, out)
+        np.testing.assert_array_equal(out.cpu().numpy(), cpu.embedding_lookup(ref, ids))
+        gout = (out * 0.5 + 1.0).contiguous()                      # stands in for the dense network's backward
+        grad = gradop.compute(gout, d_ids)
+        hetu_ops.sgd_update_sparse(emb, grad, lr)
+        cpu.sgd_sparse_update(ref, ids, gout.cpu().numpy().reshape(-1, width), lr)
+        np.testing.assert_array_equal(emb.table.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("mode", ["bsp_prefetch", "asp_prefetch", "no_prefetch"])
+def test_hybrid_cache_step_sequence(dev, mode):
+    """comm Hybrid + cache: ParameterServerCommunicateOp in its three schedules (cache.cc flows underneath)."""
+    rows, width, bs, lr, limit, bound = 3000, 16, 8, 0.1, 200, 1
+    rng = np.random.default_rng(2)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    store = ShardedEmbedding(rows, width, dev, table=torch.from_numpy(table0.copy()).to(dev))
+    emb = hetu_ops.EmbeddingParameter(store=store)
+    batches = _batches(8, bs, rows, 9)
+    state = {"k": 0}
+
+    def next_ids():
+        return torch.from_numpy(batches[(state["k"] + 1) % len(batches)]).to(dev)
+
+    prefetch = mode != "no_prefetch"
+    cfg = hetu_ops.Config(comm_mode="Hybrid", bsp=0 if mode != "asp_prefetch" else -1, prefetch=prefetch,
+                          cstable_policy="LRU", cache_bound=bound, cache_limit=limit)
+    comm = hetu_ops.ParameterServerCommunicateOp(emb, lr, next_ids)
+    comm.forward_hook(cfg, first_ids=torch.from_numpy(batches[0]).to(dev))
+    look = hetu_ops.EmbeddingLookUp(emb)
+    look.forward_hook(cfg)
+    gradop = hetu_ops.EmbeddingLookUp_Gradient(emb.shape)
+
+    server = cache_model.Server(table0)
+    model = cache_model.CacheModel("lru", limit, width, server, bound, bound)
+    pending = model.lookup(batches[0].reshape(-1).astype(np.uint64)) if prefetch else None
+    for k in range(len(batches) - 1):
+        state["k"] = k
+        ids = batches[k]
+        d_ids = torch.from_numpy(ids).to(dev)
+        out = torch.empty((bs, 26, width), dtype=torch.float32, device=dev)
+        look.compute(d_ids, out)
+        want = pending if prefetch else model.lookup(ids.reshape(-1).astype(np.uint64))
+        np.testing.assert_array_equal(out.cpu().numpy().reshape(-1, width), want, err_msg="lookup step %d" % k)
+        gout = (out * 0.25 - 0.5).contiguous()
+        g_np = cpu.scale_values(gout.cpu().numpy().reshape(-1, width), lr)   # values *= -lr
+        grad = gradop.compute(gout, d_ids)
+        comm.compute(grad)
+        nxt = batches[k + 1].reshape(-1).astype(np.uint64)
+        if mode == "asp_prefetch":
+            pending = model.push_pull(nxt, ids.reshape(-1).astype(np.uint64), g_np)
+        else:
+            model.update(ids.reshape(-1).astype(np.uint64), g_np)
+            if prefetch:
+                pending = model.lookup(nxt)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(store.table.cpu().numpy(), server.table, err_msg="server table step %d" % k)
