@@ -188,26 +188,26 @@ __device__ __forceinline__ void finish_small_body(
     uint16_t *s_upos = reinterpret_cast<uint16_t *>(s_dyn);   // [n rounded up to 8]
     uint16_t *s_seg = s_upos + ((n + 7) & ~7);                // [n+2]
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    // ---- pass A.  The only global-load round trip: sorted key, its left neighbour and the permutation
-    // entry of the kItems positions this thread covers in the coalesced mapping stay in registers for
-    // pass C.
-    uint32_t a[kItems];
-    int32_t pv[kItems];
-    {
-        uint32_t b[kItems];
+    // ---- pass A (coalesced, batches of kBatch positions per thread to stay light on registers: this
+    // body shares a kernel with the apply blocks and must not raise their register budget)
+    constexpr int kBatch = 5;
+    static_assert(kItems % kBatch == 0, "kItems must be a multiple of kBatch");
+    for (int k0 = 0; k0 < kItems; k0 += kBatch) {
+        uint32_t a[kBatch], b[kBatch];
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const int p = threadIdx.x + k * 1024;
+        for (int k = 0; k < kBatch; ++k) {
+            const int p = threadIdx.x + (k0 + k) * 1024;
             a[k] = sorted[min(p, n - 1)];              // branch-free loads
             b[k] = sorted[max(min(p, n - 1) - 1, 0)];
-            pv[k] = perm[min(p, n - 1)];
         }
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const int p = threadIdx.x + k * 1024;
+        for (int k = 0; k < kBatch; ++k) {
+            const int p = threadIdx.x + (k0 + k) * 1024;
             if (p < n)
                 s_upos[p] = (p == 0 || a[k] != b[k]) ? 0x8000u : 0u;
         }
+        if ((k0 + kBatch) * 1024 >= n)
+            break;
     }
     __syncthreads();
     // ---- pass B
@@ -262,17 +262,29 @@ __device__ __forceinline__ void finish_small_body(
         if (k < static_cast<int>(total))
             counts[k] = static_cast<int32_t>(s_seg[k + 1]) - a;
     }
+    for (int k0 = 0; k0 < kItems; k0 += kBatch) {
+        uint32_t a[kBatch];
+        int32_t pv[kBatch];
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const int p = threadIdx.x + k * 1024;
-        if (p < n) {
-            const uint32_t v = s_upos[p];
-            const int32_t ui = static_cast<int32_t>(v & 0x7FFFu);
-            upos[p] = ui;
-            inverse[pv[k]] = ui;
-            if (v >> 15)
-                uniq[ui] = a[k];
+        for (int k = 0; k < kBatch; ++k) {
+            const int p = threadIdx.x + (k0 + k) * 1024;
+            a[k] = sorted[min(p, n - 1)];
+            pv[k] = perm[min(p, n - 1)];
         }
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const int p = threadIdx.x + (k0 + k) * 1024;
+            if (p < n) {
+                const uint32_t v = s_upos[p];
+                const int32_t ui = static_cast<int32_t>(v & 0x7FFFu);
+                upos[p] = ui;
+                inverse[pv[k]] = ui;
+                if (v >> 15)
+                    uniq[ui] = a[k];
+            }
+        }
+        if ((k0 + kBatch) * 1024 >= n)
+            break;
     }
 }
 
