@@ -110,6 +110,7 @@ class IndexPlan:
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
         self.n = 0
         self._view = None
+        self._route_cache = None
 
     def sort(self, ids, stream=None):
         """Stable sort only (keys / sorted / perm): all that sgd_apply and push_apply consume."""
@@ -139,6 +140,7 @@ class IndexPlan:
         check(rc, "ha_plan_build")
         self.n = n
         self._view = None
+        self._route_cache = None
         return self
 
     # -- typed views into the workspace (no copies) --

@@ -147,14 +147,31 @@ class ShardedEmbedding:
         return out
 
     def _route(self, plan):
-        """Counts all-to-all.  -> (U, send_counts, recv_counts, local_keys) with host-side counts."""
+        """Counts all-to-all.  -> (U, send_counts, recv_counts, local_keys) with host-side counts.
+        The routing of a plan is cached on the plan object: pull and push of the same batch (the
+        training step) pay for one counts exchange and one host synchronisation."""
+        cached = getattr(plan, "_route_cache", None)
+        if cached is not None and cached[0] is self:
+            return cached[1]
+        r = self._route_uncached(plan)
+        try:
+            plan._route_cache = (self, r)
+        except AttributeError:
+            pass
+        return r
+
+    def _route_uncached(self, plan):
         eng = self.engine
         offsets, local = eng.bucket(plan, self.starts)
         send_cnt_dev = (offsets[1:] - offsets[:-1]).to(torch.int64)
         recv_cnt_dev = torch.empty_like(send_cnt_dev)
         self._a2a(recv_cnt_dev, send_cnt_dev, None, None)
         u, (send_cnt, recv_cnt) = eng.n_unique_and(plan, send_cnt_dev, recv_cnt_dev)
-        return u, send_cnt, recv_cnt, local
+        # the shard-local keys every owner will be asked for (pull) / handed rows for (push)
+        keys_send = local[:u].contiguous()
+        keys_recv = torch.empty(sum(recv_cnt), dtype=keys_send.dtype, device=self.device)
+        self._a2a(keys_recv, keys_send, recv_cnt, send_cnt)
+        return u, send_cnt, recv_cnt, keys_recv
 
     def _account(self, send_cnt, recv_cnt, bytes_per_key_out, bytes_per_key_in):
         r = self.rank
@@ -169,11 +186,7 @@ class ShardedEmbedding:
         eng = self.engine
         if plan is None:
             plan = eng.plan(ids)
-        u, send_cnt, recv_cnt, local = self._route(plan)
-        nrecv = sum(recv_cnt)
-        keys_send = local[:u].contiguous()
-        keys_recv = torch.empty(nrecv, dtype=keys_send.dtype, device=self.device)
-        self._a2a(keys_recv, keys_send, recv_cnt, send_cnt)
+        u, send_cnt, recv_cnt, keys_recv = self._route(plan)
         rows_send = eng.gather_keys(self.table, keys_recv)
         rows_recv = torch.empty((u, self.width), dtype=torch.float32, device=self.device)
         self._a2a(rows_recv, rows_send, send_cnt, recv_cnt)
@@ -191,16 +204,13 @@ class ShardedEmbedding:
             plan = eng.plan(ids)
         scale = 1.0 if lr is None else -float(lr)
         reduced = eng.reduce_scaled(plan, values.reshape(-1, self.width), scale)
-        u, send_cnt, recv_cnt, local = self._route(plan)
+        u, send_cnt, recv_cnt, keys_recv = self._route(plan)
         nrecv = sum(recv_cnt)
-        keys_send = local[:u].contiguous()
-        keys_recv = torch.empty(nrecv, dtype=keys_send.dtype, device=self.device)
-        self._a2a(keys_recv, keys_send, recv_cnt, send_cnt)
         rows_send = reduced[:u].contiguous()
         rows_recv = torch.empty((nrecv, self.width), dtype=torch.float32, device=self.device)
         self._a2a(rows_recv, rows_send, recv_cnt, send_cnt)
         eng.acc_apply(self.table, keys_recv, rows_recv)
-        self._account(send_cnt, recv_cnt, 4 + 4 * self.width, 0)
+        self._account(send_cnt, recv_cnt, 4 * self.width, 0)
 
     # -- SSPushPull (push this batch, pull the next one): ParameterServerCommunicate.py:74-76 ------------
     def push_pull(self, push_ids, values, lr, pull_ids):
