@@ -32,19 +32,20 @@ __global__ __launch_bounds__(1024) void fwd_fused_kernel(
 }
 
 template <int MODE, int VEC>
-__global__ __launch_bounds__(1024) void bwd_fused_kernel(
+__global__ __launch_bounds__(1024, 8) void bwd_fused_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     int n, const float *__restrict__ grads, float lr,
     PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
-    int32_t *__restrict__ inverse, int32_t *__restrict__ upos) {
+    int32_t *__restrict__ inverse, int32_t *__restrict__ upos, int n_finish_blocks) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    if (blockIdx.x == 0)
-        finish_small_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, s_dyn);
+    const int b = blockIdx.x;
+    if (b < n_finish_blocks)
+        finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, b, s_dyn);
     else
         apply_body<MODE, VEC>(dst, dst_rows, width, sorted, perm, nullptr, n,
-                              grads, lr, blockIdx.x - 1);
+                              grads, lr, b - n_finish_blocks, s_dyn);
 }
 
 static int nv_shift_of(uint32_t nv) {
@@ -124,19 +125,20 @@ static int apply_finish(float *dst, int64_t rows, int64_t width, void *plan_ws,
     HA_REQUIRE(dst && grads, "apply_finish: null pointer");
     PlanPtrs p = plan_layout(plan_ws, n);
     const int ni = static_cast<int>(n);
-    const unsigned blocks = 1u + static_cast<unsigned>((n + kPosPerBlock - 1) / kPosPerBlock);
-    const size_t lds = finish_small_lds_bytes(ni);
+    const int fblocks = finish_blocks(ni);
+    const unsigned blocks = static_cast<unsigned>(fblocks) + static_cast<unsigned>((n + kPosPerBlock - 1) / kPosPerBlock);
+    const size_t lds = kApplyLdsBytes;
     const bool vec_ok = (width % 4 == 0) &&
                         (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
                         (reinterpret_cast<uintptr_t>(grads) % 16 == 0);
     if (vec_ok)
         hipLaunchKernelGGL((bwd_fused_kernel<MODE, 4>), dim3(blocks), dim3(1024), lds,
                            stream, dst, (uint64_t)rows, (int)width, p.sorted, p.perm,
-                           ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos);
+                           ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, fblocks);
     else
         hipLaunchKernelGGL((bwd_fused_kernel<MODE, 1>), dim3(blocks), dim3(1024), lds,
                            stream, dst, (uint64_t)rows, (int)width, p.sorted, p.perm,
-                           ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos);
+                           ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, fblocks);
     HA_LAUNCH_CHECK();
     return 0;
 }

@@ -268,8 +268,8 @@ __global__ __launch_bounds__(1024) void finish_small_kernel(
     int n, PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    finish_small_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, s_dyn);
+    __shared__ uint32_t s_w[kFinishLdsWords];
+    finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, blockIdx.x, s_w);
 }
 
 __global__ void plan_empty_kernel(PlanHeader *hdr, int32_t *seg) {
@@ -360,8 +360,7 @@ static int plan_finish(void *ws, int64_t n, hipStream_t stream) {
     }
     const int ni = static_cast<int>(n);
     if (n <= kSmallMax) {
-        const size_t lds = finish_small_lds_bytes(ni);
-        hipLaunchKernelGGL(finish_small_kernel, dim3(1), dim3(1024), lds, stream,
+        hipLaunchKernelGGL(finish_small_kernel, dim3(finish_blocks(ni)), dim3(1024), 0, stream,
                            p.sorted, p.perm, ni, p.hdr, p.uniq, p.seg,
                            p.counts, p.inverse, p.upos);
         HA_LAUNCH_CHECK();

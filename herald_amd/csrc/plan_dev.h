@@ -78,9 +78,6 @@ inline size_t rank_small_lds_bytes(int n) {
     const int npad = (n + 127) & ~127;
     return (static_cast<size_t>(npad) + 32 * 32) * 4;
 }
-inline size_t finish_small_lds_bytes(int n) {
-    return (((static_cast<size_t>(n) + 7) & ~size_t(7)) + n + 2) * 2 + 16;
-}
 
 // ===========================================================================
 // Small path: stable rank by counting.
@@ -172,119 +169,118 @@ __device__ __forceinline__ void rank_tile_body(
     }
 }
 
-// Small-n fused finish: one workgroup does phases 1-3 (n <= kSmallMax).
-//   pass A (coalesced): head flag of every sorted position -> LDS
-//   pass B (blocked)  : thread t owns positions t*15.., local count + wave/block scan -> unique index
-//   pass C (coalesced): uniq / seg / counts / upos / inverse written out
-// LDS: upos|head<<15 as u16[n] + seg as u16[n+2] (positions and unique indices are <= 15360 < 2^15).
-__device__ __forceinline__ void finish_small_body(
+// Small-n finish (n <= kSmallMax): ceil(n/1024) independent workgroups, one sorted position per
+// thread, no inter-workgroup communication.  Block b
+//   * counts the heads (first position of every run) before its chunk by re-reading the sorted keys of
+//     chunks 0..b-1 -- at most 14 x 2 L2-resident loads per thread, all independent, instead of a
+//     dependent scan across workgroups;
+//   * ranks its own heads with a ballot per wave + 16 wave totals in LDS, and writes
+//     upos / inverse / uniq / seg for its positions;
+//   * writes counts[u] = next head - this head for its heads; only the last run of the chunk can end
+//     outside it, and its end is found by probing the following chunks (the first probe is requested
+//     together with everything else, so the common case costs no extra round trip).
+// Registers: a handful per thread -- this body shares a kernel with the apply blocks and must not
+// raise their budget.  LDS: 64 words.
+constexpr int kFinishLdsWords = 64;
+inline int finish_blocks(int n) { return (n + 1023) / 1024; }
+
+__device__ __forceinline__ void finish_block_body(
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     int n, PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
-    uint32_t *s_dyn) {
-    constexpr int kItems = kSmallMax / 1024;  // 15
-    __shared__ uint32_t s_w[16];
-    uint16_t *s_upos = reinterpret_cast<uint16_t *>(s_dyn);   // [n rounded up to 8]
-    uint16_t *s_seg = s_upos + ((n + 7) & ~7);                // [n+2]
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    // ---- pass A (coalesced, batches of kBatch positions per thread to stay light on registers: this
-    // body shares a kernel with the apply blocks and must not raise their register budget)
-    constexpr int kBatch = 5;
-    static_assert(kItems % kBatch == 0, "kItems must be a multiple of kBatch");
-    for (int k0 = 0; k0 < kItems; k0 += kBatch) {
-        uint32_t a[kBatch], b[kBatch];
+    int b, uint32_t *s_w) {
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    uint32_t *s_before = s_w, *s_heads = s_w + 16, *s_first = s_w + 32, *s_cand = s_w + 48;
+    const int p = b * 1024 + tid;
+    const int cp = min(p, n - 1);
+    // everything this thread needs from memory, requested together (branch-free)
+    const uint32_t k = sorted[cp];
+    const uint32_t kprev = sorted[max(cp - 1, 0)];
+    const int32_t pv = perm[cp];
+    const int q1 = p + 1024;  // first probe behind the chunk; positions >= n act as heads
+    const uint32_t k1 = sorted[min(q1, n - 1)];
+    const uint32_t k1prev = sorted[max(min(q1, n - 1) - 1, 0)];
+    uint32_t before = 0;
+    for (int c = 0; c < b; c += 4) {
+        uint32_t x[4], y[4];
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            const int p = threadIdx.x + (k0 + k) * 1024;
-            a[k] = sorted[min(p, n - 1)];              // branch-free loads
-            b[k] = sorted[max(min(p, n - 1) - 1, 0)];
+        for (int t = 0; t < 4; ++t) {
+            const int q = min(c + t, b - 1) * 1024 + tid;  // < n: chunks before b are complete
+            x[t] = sorted[q];
+            y[t] = sorted[max(q - 1, 0)];
         }
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            const int p = threadIdx.x + (k0 + k) * 1024;
-            if (p < n)
-                s_upos[p] = (p == 0 || a[k] != b[k]) ? 0x8000u : 0u;
-        }
-        if ((k0 + kBatch) * 1024 >= n)
-            break;
+        for (int t = 0; t < 4; ++t)
+            before += (c + t < b) && ((c + t) * 1024 + tid == 0 || x[t] != y[t]);
+    }
+    const bool valid = p < n;
+    const bool head = valid && (p == 0 || k != kprev);
+    const unsigned long long hm = __ballot(head);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        before += __shfl_xor(before, o, 64);
+    const unsigned long long m1 = __ballot(q1 >= n || k1 != k1prev);
+    if (lane == 0) {
+        s_before[w] = before;
+        s_heads[w] = __builtin_popcountll(hm);
+        s_first[w] = hm ? static_cast<uint32_t>(w * 64 + __builtin_ctzll(hm)) : 0xFFFFFFFFu;
+        s_cand[w] = m1 ? static_cast<uint32_t>(q1 + __builtin_ctzll(m1)) : 0xFFFFFFFFu;
     }
     __syncthreads();
-    // ---- pass B
-    const int p0 = threadIdx.x * kItems;
-    uint32_t c = 0;
-    uint32_t flags = 0;
+    uint32_t base = 0, woff = 0, total = 0, next_in_block = 0xFFFFFFFFu, next_after = 0xFFFFFFFFu;
+    {
+        const uint32_t vb = s_before[lane & 15], vh = s_heads[lane & 15];
+        const uint32_t vf = s_first[lane & 15], vc = s_cand[lane & 15];
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const int p = p0 + k;
-        const uint32_t hd = (p < n) ? (s_upos[p] >> 15) : 0u;
-        flags |= hd << k;
-        c += hd;
-    }
-    uint32_t x = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o, 64);
-        if (lane >= o)
-            x += y;
-    }
-    if (lane == 63)
-        s_w[w] = x;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
-    for (int k = 0; k < 16; ++k) {
-        if (k < w)
-            woff += s_w[k];
-        total += s_w[k];
-    }
-    uint32_t u = woff + x - c;
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const int p = p0 + k;
-        if (p < n) {
-            const uint32_t hd = (flags >> k) & 1u;
-            if (hd) {
-                s_seg[u] = static_cast<uint16_t>(p);
-                ++u;
-            }
-            s_upos[p] = static_cast<uint16_t>((u - 1) | (hd << 15));
+        for (int t = 0; t < 16; ++t) {
+            base += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(vb), t));
+            const uint32_t h = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(vh), t));
+            woff += (t < w) ? h : 0u;
+            total += h;
+            const uint32_t f = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(vf), t));
+            if (t > w && next_in_block == 0xFFFFFFFFu)
+                next_in_block = f;  // first head of a later wave of this chunk (chunk-relative)
+            next_after = min(next_after, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(vc), t)));
         }
     }
-    if (threadIdx.x == 0) {
-        hdr->n_unique = total;
-        s_seg[total] = static_cast<uint16_t>(n);
-    }
-    __syncthreads();
-    // ---- pass C
-    for (int k = threadIdx.x; k <= static_cast<int>(total); k += 1024) {
-        const int32_t a = s_seg[k];
-        seg[k] = a;
-        if (k < static_cast<int>(total))
-            counts[k] = static_cast<int32_t>(s_seg[k + 1]) - a;
-    }
-    for (int k0 = 0; k0 < kItems; k0 += kBatch) {
-        uint32_t a[kBatch];
-        int32_t pv[kBatch];
+    // the run that is open at the end of the chunk ends at the first head behind it
+    for (int c = b + 2; next_after == 0xFFFFFFFFu; ++c) {
+        const int q = c * 1024 + tid;
+        const int cq = min(q, n - 1);
+        const unsigned long long m = __ballot(q >= n || sorted[cq] != sorted[max(cq - 1, 0)]);
+        __syncthreads();
+        if (lane == 0)
+            s_cand[w] = m ? static_cast<uint32_t>(q + __builtin_ctzll(m)) : 0xFFFFFFFFu;
+        __syncthreads();
+        const uint32_t vc = s_cand[lane & 15];
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            const int p = threadIdx.x + (k0 + k) * 1024;
-            a[k] = sorted[min(p, n - 1)];
-            pv[k] = perm[min(p, n - 1)];
+        for (int t = 0; t < 16; ++t)
+            next_after = min(next_after, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(vc), t)));
+    }
+    if (valid) {
+        const unsigned long long upto = hm & ((2ull << lane) - 1ull);  // heads of this wave at lanes <= lane
+        const int32_t ui = static_cast<int32_t>(base + woff + __builtin_popcountll(upto)) - 1;
+        upos[p] = ui;
+        inverse[pv] = ui;
+        if (head) {
+            uniq[ui] = k;
+            seg[ui] = p;
+            const unsigned long long later = lane == 63 ? 0ull : (hm >> (lane + 1));
+            int32_t nxt;
+            if (later)
+                nxt = p + 1 + __builtin_ctzll(later);
+            else if (next_in_block != 0xFFFFFFFFu)
+                nxt = b * 1024 + static_cast<int32_t>(next_in_block);
+            else
+                nxt = static_cast<int32_t>(min(next_after, static_cast<uint32_t>(n)));
+            counts[ui] = nxt - p;
         }
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            const int p = threadIdx.x + (k0 + k) * 1024;
-            if (p < n) {
-                const uint32_t v = s_upos[p];
-                const int32_t ui = static_cast<int32_t>(v & 0x7FFFu);
-                upos[p] = ui;
-                inverse[pv[k]] = ui;
-                if (v >> 15)
-                    uniq[ui] = a[k];
-            }
-        }
-        if ((k0 + kBatch) * 1024 >= n)
-            break;
+    }
+    if (tid == 0 && (b + 1) * 1024 >= n) {  // the last chunk
+        const uint32_t U = base + total;
+        hdr->n_unique = U;
+        seg[U] = n;
     }
 }
 

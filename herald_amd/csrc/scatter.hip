@@ -30,30 +30,33 @@
 namespace ha {
 
 template <int MODE, int VEC>
-__global__ __launch_bounds__(1024) void apply_kernel(
+__global__ __launch_bounds__(1024, 8) void apply_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr) {
-    apply_body<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, blockIdx.x);
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
+    apply_body<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, blockIdx.x, s_apply);
 }
 
 // cache flavour: destination / source rows through index maps (see ApplyMaps)
 template <int VEC>
-__global__ __launch_bounds__(1024) void apply_mapped_kernel(
+__global__ __launch_bounds__(1024, 8) void apply_mapped_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ src,
     float lr, ApplyMaps maps) {
-    apply_body<kModeSgd, VEC>(dst, dst_rows, width, sorted, perm, upos, n, src, lr, blockIdx.x, nullptr, maps);
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
+    apply_body<kModeSgd, VEC>(dst, dst_rows, width, sorted, perm, upos, n, src, lr, blockIdx.x, s_apply, nullptr, maps);
 }
 
 // diagnostic twin of apply_kernel<kModeSgd,4>: same body plus per-wave time stamps
-__global__ __launch_bounds__(1024) void apply_timeline_kernel(
+__global__ __launch_bounds__(1024, 8) void apply_timeline_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     int n, const float *__restrict__ grads, float lr, unsigned long long *dbg) {
-    apply_body<kModeSgd, 4>(dst, dst_rows, width, sorted, perm, nullptr, n, grads, lr, blockIdx.x, dbg);
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
+    apply_body<kModeSgd, 4>(dst, dst_rows, width, sorted, perm, nullptr, n, grads, lr, blockIdx.x, s_apply, dbg);
 }
 
 }  // namespace ha
@@ -80,11 +83,11 @@ static int apply_launch(float *dst, int64_t dst_rows, int64_t width,
                         (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
                         (reinterpret_cast<uintptr_t>(grads) % 16 == 0);
     if (vec_ok) {
-        hipLaunchKernelGGL((apply_kernel<MODE, 4>), dim3(blocks), dim3(1024), 0,
+        hipLaunchKernelGGL((apply_kernel<MODE, 4>), dim3(blocks), dim3(1024), kApplyLdsBytes,
                            stream, dst, (uint64_t)dst_rows, (int)width,
                            v.sorted, v.perm, v.upos, (int)n, grads, lr);
     } else {
-        hipLaunchKernelGGL((apply_kernel<MODE, 1>), dim3(blocks), dim3(1024), 0,
+        hipLaunchKernelGGL((apply_kernel<MODE, 1>), dim3(blocks), dim3(1024), kApplyLdsBytes,
                            stream, dst, (uint64_t)dst_rows, (int)width,
                            v.sorted, v.perm, v.upos, (int)n, grads, lr);
     }
@@ -134,7 +137,7 @@ extern "C" int ha_debug_apply_timeline(float *table, int64_t rows, int64_t width
     if (ha_plan_view_of(const_cast<void *>(plan_ws), n, &v) != 0)
         return -1;
     const unsigned blocks = static_cast<unsigned>((n + ha::kPosPerBlock - 1) / ha::kPosPerBlock);
-    hipLaunchKernelGGL(ha::apply_timeline_kernel, dim3(blocks), dim3(1024), 0, ha::as_stream(stream),
+    hipLaunchKernelGGL(ha::apply_timeline_kernel, dim3(blocks), dim3(1024), ha::kApplyLdsBytes, ha::as_stream(stream),
                        table, (uint64_t)rows, (int)width, v.sorted, v.perm, (int)n, grads, lr, dbg);
     HA_LAUNCH_CHECK();
     return 0;
@@ -160,10 +163,10 @@ extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
                         (reinterpret_cast<uintptr_t>(src) % 16 == 0);
     const ha::ApplyMaps maps{rowmap, valmap, dst_init};
     if (vec_ok)
-        hipLaunchKernelGGL((ha::apply_mapped_kernel<4>), dim3(blocks), dim3(1024), 0, ha::as_stream(stream),
+        hipLaunchKernelGGL((ha::apply_mapped_kernel<4>), dim3(blocks), dim3(1024), ha::kApplyLdsBytes, ha::as_stream(stream),
                            dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos, (int)n, src, lr, maps);
     else
-        hipLaunchKernelGGL((ha::apply_mapped_kernel<1>), dim3(blocks), dim3(1024), 0, ha::as_stream(stream),
+        hipLaunchKernelGGL((ha::apply_mapped_kernel<1>), dim3(blocks), dim3(1024), ha::kApplyLdsBytes, ha::as_stream(stream),
                            dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos, (int)n, src, lr, maps);
     HA_LAUNCH_CHECK();
     return 0;

@@ -23,9 +23,9 @@ struct ApplyMaps {
 
 constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per 1024-thread workgroup
 constexpr int kLookBack = 16;      // positions a wave looks back to find its offset in its run
-constexpr int kLongRun = 48;       // runs at least this long are split over waves of different workgroups
+constexpr int kLongRun = 48;       // runs at least this long are handled by their full workgroups
 constexpr int kShortRun = 3;       // runs up to this long: one wave, whole row, 16-byte accesses
-constexpr int kHotDepth = 16;      // split mode: loads per chunk (a 64-block is 4 chunks)
+constexpr int kChunk = 16;         // occurrence rows requested per batch (one register each)
 
 template <int MODE>
 __device__ __forceinline__ float step(float acc, float g, float lr) {
@@ -124,123 +124,52 @@ __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
         short_block<MODE, VEC, 1>(dst_row, grads, width, c, pv, lane0, len, lr, init);
 }
 
-// ---- longer runs: column-split over the run's own waves ------------------------------------------
-// The wave at offset o of a run owns the 64-column slice(s) o, o+W, ... (W = min(run length, 16)
-// workers) and walks ALL occurrences of the run in order: one dword per lane = 256 contiguous bytes
-// per occurrence row.  One wave issues roughly one instruction every four cycles, so the loop is
-// written for the fewest instructions per occurrence (v_readlane of a byte offset computed 64
-// occurrences at a time, v_add, global_load_dword, v_mul, v_sub), with two register half-rings of
-// kHotDepth loads in flight.  The run's end is found on the fly: every block of 64 occurrence
-// indices is loaded together with the 64 sorted keys of those positions, one block ahead of the
-// row loads that must stay in flight (so the in-order vmcnt wait never drains the ring).
-template <int MODE, bool OFF32>
-__device__ __forceinline__ void split_slice(float *__restrict__ dst_row,
-                                            const float *__restrict__ grads,
-                                            const uint32_t *__restrict__ sorted,
-                                            const int32_t *__restrict__ perm,
-                                            int start, int n, uint32_t key,
-                                            int width, int col, float lr,
-                                            const int32_t *__restrict__ valmap,
-                                            bool init) {
-    const int lane = lane_id();
+// ---- medium runs (kShortRun < L < kLongRun): column-split over the run's own first waves --------
+// The wave at offset o of the run owns the 64-column slice(s) o, o+W, ... (W = min(L, 16) workers)
+// and applies ALL occurrences of the run to its slice in order: one dword per lane = 256 contiguous
+// bytes per occurrence row.  Every occurrence index of such a run is already in the wave's window of
+// sorted positions (p-16 .. p+47), so the row loads are issued straight away, up to 32 in flight.
+template <int MODE>
+__device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
+                                             const float *__restrict__ grads,
+                                             int width, int col, int pv, int lane_s,
+                                             int len, float lr, bool init) {
     const bool live = col < width;
     const int lcol = live ? col : 0;
     float acc = 0.f;
     if (MODE == kModeSgd && init)
         acc = dst_row[lcol];
-    const char *gbase = reinterpret_cast<const char *>(grads);
-    const uint32_t col4 = static_cast<uint32_t>(lcol) * 4u;
-    const uint32_t rowbytes = static_cast<uint32_t>(width) * 4u;
-
-    // block b = occurrences [64b, 64b+64) of the run = sorted positions start+64b+lane
-    auto load_block = [&](int b, uint32_t &pv, int &cnt) {
-        const int q = start + 64 * b + lane;
-        const int cq = min(q, n - 1);
-        const uint32_t ks = sorted[cq];
-        uint32_t idx = static_cast<uint32_t>(perm[cq]);
-        if (valmap)  // wave-uniform
-            idx = static_cast<uint32_t>(valmap[idx]);
-        pv = OFF32 ? idx * rowbytes : idx;
-        const unsigned long long m = __ballot(q < n && ks == key);
-        cnt = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
-    };
-    auto load_chunk = [&](float(&g)[kHotDepth], uint32_t pv, int lane0) {
+    auto load_chunk = [&](float(&g)[kChunk], int t0) {
 #pragma unroll
-        for (int t = 0; t < kHotDepth; ++t) {
-            const uint32_t s = static_cast<uint32_t>(
-                __builtin_amdgcn_readlane(static_cast<int>(pv), lane0 + t));
-            if (OFF32)
-                g[t] = *reinterpret_cast<const float *>(gbase + static_cast<size_t>(s + col4));
-            else
-                g[t] = *reinterpret_cast<const float *>(
-                    gbase + static_cast<size_t>(s) * rowbytes + col4);
+        for (int t = 0; t < kChunk; ++t) {
+            const int idx = __builtin_amdgcn_readlane(pv, lane_s + min(t0 + t, len - 1));
+            g[t] = (grads + static_cast<size_t>(idx) * width)[lcol];
         }
     };
-    auto consume = [&](const float(&g)[kHotDepth], int cnt) {  // cnt = valid entries (may be >= depth)
-        if (cnt >= kHotDepth) {
+    auto consume = [&](const float(&g)[kChunk], int cnt) {  // cnt = valid entries (may exceed kChunk)
+        if (cnt >= kChunk) {
 #pragma unroll
-            for (int t = 0; t < kHotDepth; ++t)
+            for (int t = 0; t < kChunk; ++t)
                 acc = step<MODE>(acc, g[t], lr);
         } else {
 #pragma unroll
-            for (int t = 0; t < kHotDepth; ++t) {
+            for (int t = 0; t < kChunk; ++t) {
                 const float nx = step<MODE>(acc, g[t], lr);
                 acc = (t < cnt) ? nx : acc;
             }
         }
     };
-
-    // three register chunks rotate: while chunk c is consumed, chunks c+1 and c+2 are in flight
-    // (up to 48 row loads per wave; vmcnt counts 63 at most)
-    float ga[kHotDepth], gb[kHotDepth], gc[kHotDepth];
-    uint32_t pv_cur, pv_nxt;
-    int cnt_cur, cnt_nxt;
-    load_block(0, pv_cur, cnt_cur);
-    load_chunk(ga, pv_cur, 0);
-    if (cnt_cur > 16)
-        load_chunk(gb, pv_cur, 16);
-    // invariant at loop top: chunks 0 (ga) and 1 (gb) of the current block are in flight
-    for (int b = 0;; b += 3) {
-        // ---- block b: ga=c0 gb=c1 ; stream c2->gc c3->ga ; next block c0->gb c1->gc
-        load_block(b + 1, pv_nxt, cnt_nxt);
-        if (cnt_cur < 64) cnt_nxt = 0;
-        if (cnt_cur > 32) load_chunk(gc, pv_cur, 32);
-        consume(ga, cnt_cur);
-        if (cnt_cur > 48) load_chunk(ga, pv_cur, 48);
-        if (cnt_cur > 16) consume(gb, cnt_cur - 16);
-        if (cnt_nxt > 0) load_chunk(gb, pv_nxt, 0);
-        if (cnt_cur > 32) consume(gc, cnt_cur - 32);
-        if (cnt_nxt > 16) load_chunk(gc, pv_nxt, 16);
-        if (cnt_cur > 48) consume(ga, cnt_cur - 48);
-        if (cnt_nxt == 0) break;
-        pv_cur = pv_nxt; cnt_cur = cnt_nxt;
-        // ---- block b+1: gb=c0 gc=c1 ; c2->ga c3->gb ; next block c0->gc c1->ga
-        load_block(b + 2, pv_nxt, cnt_nxt);
-        if (cnt_cur < 64) cnt_nxt = 0;
-        if (cnt_cur > 32) load_chunk(ga, pv_cur, 32);
-        consume(gb, cnt_cur);
-        if (cnt_cur > 48) load_chunk(gb, pv_cur, 48);
-        if (cnt_cur > 16) consume(gc, cnt_cur - 16);
-        if (cnt_nxt > 0) load_chunk(gc, pv_nxt, 0);
-        if (cnt_cur > 32) consume(ga, cnt_cur - 32);
-        if (cnt_nxt > 16) load_chunk(ga, pv_nxt, 16);
-        if (cnt_cur > 48) consume(gb, cnt_cur - 48);
-        if (cnt_nxt == 0) break;
-        pv_cur = pv_nxt; cnt_cur = cnt_nxt;
-        // ---- block b+2: gc=c0 ga=c1 ; c2->gb c3->gc ; next block c0->ga c1->gb
-        load_block(b + 3, pv_nxt, cnt_nxt);
-        if (cnt_cur < 64) cnt_nxt = 0;
-        if (cnt_cur > 32) load_chunk(gb, pv_cur, 32);
-        consume(gc, cnt_cur);
-        if (cnt_cur > 48) load_chunk(gc, pv_cur, 48);
-        if (cnt_cur > 16) consume(ga, cnt_cur - 16);
-        if (cnt_nxt > 0) load_chunk(ga, pv_nxt, 0);
-        if (cnt_cur > 32) consume(gb, cnt_cur - 32);
-        if (cnt_nxt > 16) load_chunk(gb, pv_nxt, 16);
-        if (cnt_cur > 48) consume(gc, cnt_cur - 48);
-        if (cnt_nxt == 0) break;
-        pv_cur = pv_nxt; cnt_cur = cnt_nxt;
-    }
+    float ga[kChunk], gb[kChunk];
+    load_chunk(ga, 0);
+    if (len > kChunk)
+        load_chunk(gb, kChunk);
+    consume(ga, len);
+    if (len > 2 * kChunk)
+        load_chunk(ga, 2 * kChunk);
+    if (len > kChunk)
+        consume(gb, len - kChunk);
+    if (len > 2 * kChunk)
+        consume(ga, len - 2 * kChunk);
     if (live) {
         if (MODE == kModePush)
             acc = __fadd_rn(dst_row[col], acc);
@@ -248,35 +177,207 @@ __device__ __forceinline__ void split_slice(float *__restrict__ dst_row,
     }
 }
 
-// One wave per sorted position p (wave-uniform p; no workgroup-level synchronisation).
+// ---- long runs (L >= kLongRun): the workgroups that lie wholly inside the run ---------------------
+// A compute unit pulls only ~25 GB/s from HBM and one wave keeps at most 63 loads in flight, so a run
+// of hundreds of occurrence rows is neither streamed by one wave nor by one compute unit.  The run
+// [s, e) is handled by its FULL workgroups (16 consecutive sorted positions, all of this key; a run
+// of >= 48 has at least two, and consecutive workgroups sit on different XCDs / compute units): the
+// first W = min(F, nslice) of its F full workgroups are workers, worker j owns the 64-column slices
+// j, j+W, ...  All 16 waves of a worker load occurrence rows of the owned slices (16 dwords per lane
+// in one batch), multiply by lr and park the products in LDS in occurrence order; one wave per slice
+// then runs the ordered chain `acc = acc - m[t]` out of LDS (one ds_read_b128 per four occurrences)
+// and writes the slice of the row.  Blocks of kCoopUnits (slice, occurrence) units repeat until the
+// run is exhausted.
+constexpr int kCoopUnits = 256;   // units of 64 floats per LDS block (64 KiB)
+constexpr int kCoopScan = 1024;   // sorted positions the 16 waves scan each way for the run's ends
+constexpr size_t kApplyLdsBytes = static_cast<size_t>(kCoopUnits) * kWave * 4 + 32 * 4;
+
+template <int MODE>
+__device__ __forceinline__ float chain_step(float acc, float m) {
+    return MODE == kModeSgd ? __fsub_rn(acc, m) : __fadd_rn(acc, m);
+}
+
+// Returns false when the run is shorter than kLongRun (the caller falls through to the per-wave
+// paths).  Called by all 16 waves of a full workgroup; wg0 = its first sorted position.
+template <int MODE>
+__device__ __forceinline__ bool coop_run(
+    float *__restrict__ dst, uint64_t dst_rows, int width,
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
+    float lr, int wg0, int w, uint32_t key, uint32_t bk, uint32_t fk,
+    ApplyMaps maps, uint32_t *lds) {
+    const int lane = lane_id();
+    float *s_m = reinterpret_cast<float *>(lds);
+    int *s_cnt = reinterpret_cast<int *>(lds + kCoopUnits * kWave);
+
+    // run start / end from the 2 x 1024 scanned positions (wave w looked at chunk w each way)
+    {
+        const int qb = wg0 - kWave * (w + 1) + lane;
+        const unsigned long long mb = __ballot(qb >= 0 && bk == key);
+        const int cb = (~mb == 0ull) ? kWave : __builtin_clzll(~mb);
+        const int qf = wg0 + kPosPerBlock + kWave * w + lane;
+        const unsigned long long mf = __ballot(qf < n && fk == key);
+        const int cf = (~mf == 0ull) ? kWave : __builtin_ctzll(~mf);
+        if (lane == 0) {
+            s_cnt[w] = cb;
+            s_cnt[16 + w] = cf;
+        }
+    }
+    __syncthreads();
+    auto combine = [&](int base) {  // contiguous matches over the 16 chunks, nearest chunk first
+        const int c = s_cnt[base + (lane & 15)];
+        const uint32_t fullm = static_cast<uint32_t>(__ballot(c == kWave)) & 0xFFFFu;
+        const int k = uniform(__builtin_ctz(~fullm));  // first chunk that is not all matches (16 = none)
+        return k >= 16 ? kCoopScan : kWave * k + __builtin_amdgcn_readlane(c, k);
+    };
+    const int back_total = uniform(combine(0));
+    int fwd_total = uniform(combine(16));
+    if (back_total >= kCoopScan)
+        return true;  // >= 64 full workgroups precede this one: never a worker
+    const int s = wg0 - back_total;
+    int e = wg0 + kPosPerBlock + fwd_total;
+    while (fwd_total >= kCoopScan) {  // giant run: keep scanning forward, 1024 positions at a time
+        const int qf = e + kWave * w + lane;
+        const uint32_t ks = sorted[min(qf, n - 1)];
+        const unsigned long long mf = __ballot(qf < n && ks == key);
+        const int cf = (~mf == 0ull) ? kWave : __builtin_ctzll(~mf);
+        __syncthreads();
+        if (lane == 0)
+            s_cnt[16 + w] = cf;
+        __syncthreads();
+        fwd_total = uniform(combine(16));
+        e += fwd_total;
+    }
+    const int len = e - s;
+    if (len < kLongRun)
+        return false;
+    const int a = (s + kPosPerBlock - 1) & ~(kPosPerBlock - 1);  // first full workgroup of the run
+    const int j = (wg0 - a) / kPosPerBlock;
+    const int nfull = (e - a) / kPosPerBlock;
+    const int nslice = (width + kWave - 1) / kWave;
+    const int workers = min(min(nfull, nslice), kCoopScan / kPosPerBlock);
+    if (j >= workers)
+        return true;
+
+    uint64_t row;
+    bool init = true;
+    if (maps.rowmap) {
+        const int r = maps.rowmap[upos[wg0]];
+        if (r < 0)
+            return true;
+        row = static_cast<uint64_t>(r);
+        if (maps.dst_init)
+            init = maps.dst_init[r] != 0;
+    } else if (MODE == kModeReduce) {
+        row = static_cast<uint64_t>(upos[wg0]);
+    } else {
+        row = key;
+    }
+    if (row >= dst_rows)
+        return true;
+    float *dst_row = dst + row * static_cast<uint64_t>(width);
+
+    const int my_slices = (nslice - j + workers - 1) / workers;  // slices j, j+workers, ...
+    for (int g0 = 0; g0 < my_slices; g0 += 8) {
+        const int sg = min(8, my_slices - g0);               // slices handled at once
+        const int tlen = ((kCoopUnits / sg) / kChunk) * kChunk;  // occurrences per LDS block
+        const int upc = tlen / kChunk;                       // 16-occurrence units per slice
+        const int cl = w / upc;                              // this wave loads for local slice cl ...
+        const int tc = w - cl * upc;                         // ... occurrences tc*16 .. tc*16+15 of the block
+        const bool loader = cl < sg;
+        const int lslice = j + (g0 + (loader ? cl : 0)) * workers;
+        const int lcol_raw = lslice * kWave + lane;
+        const int lcol = lcol_raw < width ? lcol_raw : 0;
+        // chain role: wave w < sg owns local slice w
+        const bool chain = w < sg;
+        const int ccol = (j + (g0 + (chain ? w : 0)) * workers) * kWave + lane;
+        const bool clive = chain && ccol < width;
+        float acc = 0.f;
+        if (MODE == kModeSgd && init && chain)
+            acc = dst_row[ccol < width ? ccol : 0];
+        float4v *s_wr = reinterpret_cast<float4v *>(s_m) +
+                        (static_cast<size_t>(cl * tlen + tc * kChunk) / 4) * kWave + lane;
+        const float4v *s_rd = reinterpret_cast<const float4v *>(s_m) +
+                              (static_cast<size_t>(w * tlen) / 4) * kWave + lane;
+        for (int base = 0; base < len; base += tlen) {
+            if (loader) {
+                const int t = base + tc * kChunk + (lane & 15);
+                int idx = perm[min(s + t, n - 1)];
+                if (maps.valmap)
+                    idx = maps.valmap[idx];
+                float g[kChunk];
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) {
+                    const int r = __builtin_amdgcn_readlane(idx, i);
+                    g[i] = (grads + static_cast<size_t>(r) * width)[lcol];
+                }
+#pragma unroll
+                for (int i = 0; i < kChunk; i += 4)
+                    s_wr[(i / 4) * kWave] = float4v{__fmul_rn(lr, g[i]), __fmul_rn(lr, g[i + 1]),
+                                                    __fmul_rn(lr, g[i + 2]), __fmul_rn(lr, g[i + 3])};
+            }
+            __syncthreads();
+            if (chain) {
+                const int cnt = min(tlen, len - base);
+                int k = 0;
+#pragma unroll 4
+                for (; k + 4 <= cnt; k += 4) {
+                    const float4v m = s_rd[(k / 4) * kWave];
+                    acc = chain_step<MODE>(acc, m[0]);
+                    acc = chain_step<MODE>(acc, m[1]);
+                    acc = chain_step<MODE>(acc, m[2]);
+                    acc = chain_step<MODE>(acc, m[3]);
+                }
+                if (k < cnt) {
+                    const float4v m = s_rd[(k / 4) * kWave];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float nx = chain_step<MODE>(acc, m[i]);
+                        acc = (k + i < cnt) ? nx : acc;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (clive) {
+            if (MODE == kModePush)
+                acc = __fadd_rn(dst_row[ccol], acc);
+            dst_row[ccol] = acc;
+        }
+    }
+    return true;
+}
+
+// One wave per sorted position p; `lds` = kApplyLdsBytes of workgroup memory (long runs only).
 template <int MODE, int VEC>
 __device__ __forceinline__ void apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int p, int *dbg_info, ApplyMaps maps);
+    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds);
 
-// One wave per sorted position p.  `dbg` (tools/timeline.py only) receives
-// {realtime start, realtime end, role/len, shader cycles} per position.
+// `dbg` (tools/timeline.py only) receives {realtime start, realtime end, role/len, shader cycles}
+// per position.  The early return below is taken by whole waves of the LAST workgroup only, which is
+// never a full one, so the barriers of coop_run see all 16 waves.
 template <int MODE, int VEC>
 __device__ __forceinline__ void apply_body(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int vblock, unsigned long long *dbg = nullptr,
+    float lr, int vblock, uint32_t *lds, unsigned long long *dbg = nullptr,
     ApplyMaps maps = ApplyMaps{nullptr, nullptr, nullptr}) {
     const int w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int p = vblock * kPosPerBlock + w;
     if (p >= n)
         return;
     if (dbg == nullptr) {
-        apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, nullptr, maps);
+        apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds);
         return;
     }
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     int info = 0;
-    apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, &info, maps);
+    apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds);
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -293,78 +394,44 @@ __device__ __forceinline__ void apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int p, int *dbg_info, ApplyMaps maps) {
+    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds) {
     const int lane = lane_id();
-    // window of sorted positions p-16 .. p+47 (branch-free loads)
+    const int wg0 = p - w;
+    // window of sorted positions p-16 .. p+47, plus -- speculatively, in the same round trip -- this
+    // wave's share of the 1024 positions before and after the workgroup (used by long runs only)
     const int q = p - kLookBack + lane;
     const int cq = max(0, min(q, n - 1));
     const uint32_t ks = sorted[cq];
     int pv = perm[cq];
+    const uint32_t bk = sorted[max(wg0 - kWave * (w + 1) + lane, 0)];
+    const uint32_t fk = sorted[min(wg0 + kPosPerBlock + kWave * w + lane, n - 1)];
     if (maps.valmap)  // wave-uniform
         pv = maps.valmap[pv];
     const uint32_t key = static_cast<uint32_t>(
         __builtin_amdgcn_readlane(static_cast<int>(ks), kLookBack));
+    // a FULL workgroup: its 16 positions hold one key (every wave of it reaches the same verdict)
+    const uint32_t key_first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ks), kLookBack - w));
+    const uint32_t key_last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ks), kLookBack - w + kPosPerBlock - 1));
+    if (wg0 + kPosPerBlock <= n && key_first == key_last) {
+        if (dbg_info)
+            *dbg_info = (w << 16) | 0x7FFF;
+        if (coop_run<MODE>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds))
+            return;
+    }
     const unsigned long long eq = __ballot(q >= 0 && q < n && ks == key);
     const uint32_t inv_lo = static_cast<uint32_t>(~eq) & 0xFFFFu;
-    const int back = inv_lo == 0 ? kLookBack : (__builtin_clz(inv_lo) - 16);
+    const int o = inv_lo == 0 ? kLookBack : (__builtin_clz(inv_lo) - 16);   // offset in the run, capped
     const unsigned long long inv_hi = (~eq) >> kLookBack;  // bit t <-> position p+t, 48 valid bits
     const int fwd = __builtin_ctzll(inv_hi | (1ull << 48));  // 1..48
-    // A compute unit pulls only ~25 GB/s from HBM (66 GB/s from L2), so a long run (hundreds of
-    // occurrence rows) must not be streamed by the waves of ONE workgroup.  Runs of >= kLongRun
-    // occurrences are therefore column-split over waves of DIFFERENT workgroups: the designated worker
-    // of slice group k is the wave at run offset 16*k (positions 16 apart sit in consecutive
-    // workgroups, which the dispatcher spreads over compute units and XCDs).
-    int o = back;
-    bool long_worker = false;   // designated worker of a long run
-    int long_workers = 0, long_k = 0;
-    const int nslice = (width + kWave - 1) / kWave;
-    if (back >= kLookBack) {
-        // deep inside a run: exact offset up to 16*nslice by an extended look-back
-        const int maxo = kLookBack * nslice;
-        int cnt = kLookBack;
-        for (int base = p - kLookBack; cnt < maxo; base -= kWave) {
-            const int qq = base - 1 - lane;                 // positions base-1, base-2, ...
-            const unsigned long long m = __ballot(qq >= 0 && sorted[max(qq, 0)] == key);
-            const int c = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
-            cnt += c;
-            if (c < 64)
-                break;
-        }
-        o = cnt;
-        if (o >= maxo || (o % kLookBack) != 0 || o + fwd < kLongRun)
-            return;  // not a designated offset, or the run is not a long one
-        long_worker = true;
-    } else if (o + fwd >= kLongRun) {
-        // a long run (every wave of the run reaches the same verdict: o + fwd is the exact length
-        // unless fwd == 48, and then it is >= 48 anyway): only offsets 0, 16, 32, ... work
-        if (o != 0)
-            return;
-        long_worker = true;
-    }
-    if (long_worker) {
-        // run length capped at 16*nslice decides how many designated workers exist
-        const int cap = kLookBack * nslice;
-        int lcap = o + fwd;
-        if (fwd >= 48) {
-            for (int base = p + 48; lcap < cap; base += kWave) {
-                const int qq = base + lane;
-                const unsigned long long m = __ballot(qq < n && sorted[min(qq, n - 1)] == key);
-                const int c = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
-                lcap += c;
-                if (c < 64)
-                    break;
-            }
-        }
-        lcap = min(lcap, cap);
-        long_workers = min(nslice, lcap / kLookBack);
-        long_k = o / kLookBack;
-        if (long_k >= long_workers)
-            return;
-    }
-    const bool exact = fwd < 48 && !long_worker;
-    const int len_known = o + fwd;  // exact run length when `exact`
+    // per-wave paths: runs shorter than kLongRun; their workers sit at offsets < 16, so both ends of
+    // the run are inside the window and the length is exact
+    if (o >= kLookBack || fwd >= 48)
+        return;
+    const int len = o + fwd;
+    if (len >= kLongRun)
+        return;
     if (dbg_info)
-        *dbg_info = (o << 16) | (len_known & 0x7FFF) | (exact ? 0 : 0x8000);
+        *dbg_info = (o << 16) | len;
 
     uint64_t row;
     bool init = true;
@@ -384,25 +451,14 @@ __device__ __forceinline__ void apply_body_impl(
         return;  // out-of-range id: ignored (undefined behaviour in the reference)
     float *dst_row = dst + row * static_cast<uint64_t>(width);
 
-    if (exact && len_known <= kShortRun) {
+    if (len <= kShortRun) {
         if (o == 0)
-            short_row<MODE, VEC>(dst_row, grads, width, pv, kLookBack, len_known, lr, init);
+            short_row<MODE, VEC>(dst_row, grads, width, pv, kLookBack, len, lr, init);
         return;
     }
-    // split mode.  Medium runs (4..47): the first min(L,16) waves of the run (same workgroup), worker o
-    // takes slices o, o+W, ...  Long runs: designated worker k of long_workers takes slices k, k+W, ...
-    const int workers = long_worker ? long_workers : min(len_known, kLookBack);
-    const int me = long_worker ? long_k : o;
-    if (me >= workers)
-        return;
-    const bool off32 = static_cast<uint64_t>(n) * static_cast<uint64_t>(width) * 4ull < (1ull << 32);
-    const int start = p - o;
-    for (int c0 = me * kWave; c0 < width; c0 += workers * kWave) {
-        if (off32)
-            split_slice<MODE, true>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr, maps.valmap, init);
-        else
-            split_slice<MODE, false>(dst_row, grads, sorted, perm, start, n, key, width, c0 + lane, lr, maps.valmap, init);
-    }
+    const int workers = min(len, kLookBack);
+    for (int c0 = o * kWave; c0 < width; c0 += workers * kWave)
+        medium_slice<MODE>(dst_row, grads, width, c0 + lane, pv, kLookBack - o, len, lr, init);
 }
 
 }  // namespace ha

@@ -45,6 +45,8 @@ for case in ("criteo", "distinct"):
         if m.any():
             print("   run len %4d-%-5d heads %4d: dur p50 %.2f max %.2f us, end max %.2f" %
                   (lo, hi, m.sum(), np.median(dur[m]), dur[m].max(), e[m].max()))
+    print("   start by position:", " ".join("%d:%.2f" % (q, s[q]) for q in range(0, n, 416)))
+    print("   end   by position:", " ".join("%d:%.2f" % (q, e[q]) for q in range(0, n, 416)))
     top = np.argsort(-e * live)[:6]
     for p in top:
         print("   late wave p=%d o=%d len=%d start %.2f end %.2f cycles %d" % (p, o[p], ln[p], s[p], e[p], d[p, 3]))
