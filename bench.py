@@ -54,6 +54,22 @@ def algorithmic_bytes(n, u, width):
     return fwd, bwd
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary (profiles/rNN/
+    pmc_traffic.json, produced by tools/profile_round.sh in separate --pmc passes), or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                ks = json.load(fh)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, v in ks.items():
+            if name.startswith(kernel_prefix):
+                return v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def init_table(rows, width, dev, seed=123):
     t = torch.empty((rows, width), dtype=torch.float32, device=dev)
     g = torch.Generator(device=dev)
@@ -243,9 +259,11 @@ def main():
         dom = "bwd_fused_kernel(sgd apply+finish)" if a_ms >= g_ms else "fwd_fused_kernel(gather+rank)"
         dom_bytes = bwd_b if a_ms >= g_ms else fwd_b
         dom_ms = max(a_ms, g_ms)
+        traffic, traffic_src = pmc_traffic("ha::bwd_fused_kernel" if a_ms >= g_ms else "ha::fwd_fused_kernel")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_launch_us": dom_ms * 1e3, "algorithmic_bytes_per_launch": dom_bytes}
 
     step_gbs = (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9
