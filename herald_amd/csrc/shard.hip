@@ -46,6 +46,33 @@ __global__ __launch_bounds__(256) void shard_bucket_kernel(
     }
 }
 
+// meta[0] = n_unique, meta[1+g] = number of unique keys owned by shard g (int64: the dtype the counts
+// all-to-all and the host read-back use)
+__global__ __launch_bounds__(64) void shard_meta_kernel(
+    const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq,
+    ShardStarts st, int nshard, int64_t *__restrict__ meta) {
+    const int U = static_cast<int>(hdr->n_unique);
+    const int g = threadIdx.x;
+    if (g == 0)
+        meta[0] = U;
+    if (g < nshard) {
+        int bound[2];
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t target = st.start[g + e];
+            int lo = 0, hi = U;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (uniq[mid] < target)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            bound[e] = (g + e == nshard) ? U : lo;
+        }
+        meta[1 + g] = bound[1] - bound[0];
+    }
+}
+
 }  // namespace ha
 
 using namespace ha;
@@ -72,4 +99,50 @@ extern "C" int ha_shard_bucket(const void *plan_ws, int64_t n,
                        p.hdr, p.uniq, st, nshard, offsets, local_keys);
     HA_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename IdT>
+static int shard_route(const IdT *ids, int64_t n, void *plan_ws, const int64_t *starts_host, int nshard,
+                       int64_t *meta, uint32_t *local_keys, ha_stream_t stream,
+                       int (*build)(const IdT *, int64_t, void *, ha_stream_t)) {
+    HA_REQUIRE(plan_ws && starts_host && meta && local_keys, "shard_route: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards, "shard_route: nshard must be in [1,%d]", kMaxShards);
+    HA_REQUIRE(n >= 0, "shard_route: bad n");
+    if (build(ids, n, plan_ws, stream))
+        return -1;
+    PlanPtrs p = plan_layout(plan_ws, n);
+    ShardStarts st;
+    for (int g = 0; g <= nshard; ++g) {
+        HA_REQUIRE(starts_host[g] >= 0 && starts_host[g] <= 0xFFFFFFFEll, "shard_route: start out of range");
+        st.start[g] = static_cast<uint32_t>(starts_host[g]);
+    }
+    if (n == 0) {
+        HA_CHECK_HIP(hipMemsetAsync(meta, 0, sizeof(int64_t) * (1 + nshard), as_stream(stream)));
+        return 0;
+    }
+    int blocks = static_cast<int>((n + 255) / 256);
+    if (blocks > 1024)
+        blocks = 1024;
+    // the per-shard offsets of ha_shard_bucket are not needed here; they land in the radix scratch
+    // of the plan (free after the build, >= 257 words)
+    hipLaunchKernelGGL(shard_bucket_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       p.hdr, p.uniq, st, nshard, reinterpret_cast<int32_t *>(p.hist), local_keys);
+    hipLaunchKernelGGL(shard_meta_kernel, dim3(1), dim3(64), 0, as_stream(stream),
+                       p.hdr, p.uniq, st, nshard, meta);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ha_shard_route_f32ids(const float *ids, int64_t n, void *plan_ws,
+                                     const int64_t *starts_host, int nshard, int64_t *meta,
+                                     uint32_t *local_keys, ha_stream_t stream) {
+    return shard_route<float>(ids, n, plan_ws, starts_host, nshard, meta, local_keys, stream,
+                              ha_plan_build_f32ids);
+}
+
+extern "C" int ha_shard_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws,
+                                     const int64_t *starts_host, int nshard, int64_t *meta,
+                                     uint32_t *local_keys, ha_stream_t stream) {
+    return shard_route<uint64_t>(ids, n, plan_ws, starts_host, nshard, meta, local_keys, stream,
+                                 ha_plan_build_u64ids);
 }

@@ -14,10 +14,15 @@ The reference keeps the embedding table on parameter servers and moves rows over
                  after the Python op multiplied the values by -lr
                  (python/hetu/gpu_ops/ParameterServerCommunicate.py:58-59).
 
-Here every rank owns one shard in its HBM and is a worker at the same time; the exchange is two
-all-to-alls per direction over RCCL (torch.distributed "nccl" backend == RCCL over xGMI):
-    pull:  counts  ->  shard-local keys  ->  [owner gathers]  ->  rows back
-    push:  counts  ->  keys + worker-reduced rows  ->  [owner applies, rank order]
+Here every rank owns one shard in its HBM and is a worker at the same time; the exchange is all-to-all
+over RCCL (torch.distributed "nccl" backend == RCCL over xGMI):
+    route: counts  ->  shard-local keys                          (once per batch, shared by pull and push)
+    pull : [owner gathers]  ->  rows back  ->  [expand to the positions]
+    push : [worker dedup-reduces]  ->  reduced rows  ->  [owner applies, rank order]
+The routing of a batch depends on its ids only, and the ids are known one step ahead (the reference
+prefetches them too: ParameterServerCommunicate.py:96-139), so `prefetch(ids)` builds it on a side stream
+and a second process group while the rows of the current batch are exchanged; the only host read-back
+of a step (n_unique and the 2W counts) is then long complete when the host needs it.
 The reference's servers apply concurrent pushes in arrival order (non-deterministic); here an owner
 applies the W incoming sorted lists in RANK order, `row = (row + r_0) + r_1 ...`, which is one of the
 orders the reference can produce and makes the result reproducible.
@@ -41,50 +46,112 @@ def partition(rows, nshard):
     return starts
 
 
+class _SideStream:
+    """`with` block that makes a side stream current (torch.cuda.set_stream both ways: the generic
+    torch.cuda.stream() context costs several microseconds per use on the step's host path)."""
+    __slots__ = ("side", "prev")
+
+    def __init__(self, side, after_current):
+        self.side = side
+        self.prev = torch.cuda.current_stream()
+        if after_current:
+            side.wait_stream(self.prev)
+
+    def __enter__(self):
+        torch.cuda.set_stream(self.side)
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False
+
+
 class HipEngine:
-    """Device compute of the sharded store through the C-ABI (herald_amd.ops)."""
+    """Device compute of the sharded store through the C-ABI (libherald_amd)."""
+
+    NSLOT = 3   # routing workspaces in rotation: current batch, prefetched batch, one spare
 
     def __init__(self, device):
         from . import _lib, ops
         self.ops = ops
         self.lib = _lib.load()
+        self.check = _lib.check
         self.device = torch.device(device)
-        self._plans = {}
+        self.side = torch.cuda.Stream(device=self.device)
+        self._slots = {}
+        self._owner_plan = None
 
-    def _plan(self, slot, n):
-        p = self._plans.get(slot)
-        if p is None or p.capacity < n:
-            p = self.ops.IndexPlan(max(n, 1), self.device)
-            self._plans[slot] = p
-        return p
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
 
-    def plan(self, ids, slot="batch"):
-        """Sorted-unique plan of a batch of ids (float32 or int64)."""
-        return self._plan(slot, ids.numel()).build(ids.reshape(-1))
-
-    def bucket(self, plan, starts):
-        """-> (offsets int32[W+1] device, local_keys int32[n] device); no host sync."""
+    # -- routing -------------------------------------------------------------------------------------
+    def route_issue(self, ids, starts, slot):
+        """Enqueue plan build + shard-local keys + meta for a batch of ids (float32 or int64) into the
+        routing workspace `slot`.  -> RouteBuffers: plan, local (int32[n] shard-local keys), meta
+        (int64[1+W] = n_unique, send counts), recv (int64[W]), host (pinned int64[1+2W]), keys_recv
+        (int32[W*n]: what this rank can be asked for at most), free (event of its last consumer)."""
+        n = ids.numel()
         w = len(starts) - 1
-        offsets = torch.empty(w + 1, dtype=torch.int32, device=self.device)
-        local = torch.empty(max(plan.n, 1), dtype=torch.int32, device=self.device)
-        st = (ctypes.c_int64 * (w + 1))(*starts)
-        from ._lib import check
-        check(self.lib.ha_shard_bucket(ctypes.c_void_p(plan.ws.data_ptr()), plan.n, st, w,
-                                       ctypes.c_void_p(offsets.data_ptr()), ctypes.c_void_p(local.data_ptr()),
-                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-              "ha_shard_bucket")
-        return offsets, local
+        st = self._slots.get(slot)
+        if st is None or st.plan.capacity < n or st.meta.numel() != 1 + w:
+            st = RouteBuffers()
+            st.plan = self.ops.IndexPlan(max(n, 1), self.device)
+            st.local = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+            st.meta_all = torch.empty(1 + 2 * w, dtype=torch.int64, device=self.device)
+            st.meta = st.meta_all[:1 + w]     # n_unique, send counts (written by ha_shard_route_*)
+            st.recv = st.meta_all[1 + w:]     # receive counts (written by the counts all-to-all)
+            st.host = torch.empty(1 + 2 * w, dtype=torch.int64, pin_memory=True)
+            st.ev_host, st.ev_ready, st.ev_free = (torch.cuda.Event() for _ in range(3))
+            st.keys_recv = torch.empty(max(w * n, 1), dtype=torch.int32, device=self.device)
+            st.starts = (ctypes.c_int64 * (w + 1))(*starts)
+            self._slots[slot] = st
+        self.wait_event(st.free)   # the previous batch routed through this workspace is fully consumed
+        st.free = None
+        plan = st.plan
+        if ids.dtype == torch.float32:
+            fn = self.lib.ha_shard_route_f32ids
+        elif ids.dtype in (torch.int64, torch.uint64):
+            fn = self.lib.ha_shard_route_u64ids
+        else:
+            raise TypeError("ids must be float32 or (u)int64")
+        self.check(fn(ids.data_ptr(), n, plan.ws.data_ptr(), st.starts, w, st.meta.data_ptr(),
+                      st.local.data_ptr(), self._stream()), "ha_shard_route")
+        plan.n = n
+        plan._view = None
+        return st
 
+    def on_side(self, after_current=True):
+        """Context: the side stream is current; with after_current it first waits for the work queued
+        on the main stream (inputs produced there)."""
+        return _SideStream(self.side, after_current)
+
+    def record(self, ev=None):
+        if ev is None:
+            ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def wait_event(self, ev):
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def to_host(self, b):
+        """Asynchronous device -> pinned host copy of a RouteBuffers' [n_unique | send | recv]; -> event."""
+        b.host.copy_(b.meta_all, non_blocking=True)
+        return self.record(b.ev_host)
+
+    def host_sync(self, ev):
+        if ev is not None:
+            ev.synchronize()
+
+    # -- rows ----------------------------------------------------------------------------------------
     def gather_keys(self, table, keys_i32):
         """rows[j,:] = table[keys[j],:] for shard-local uint32 keys held in an int32 tensor."""
-        from ._lib import check
         n = keys_i32.numel()
         out = torch.empty((n, table.shape[1]), dtype=torch.float32, device=self.device)
-        check(self.lib.ha_gather_u32keys(ctypes.c_void_p(table.data_ptr()), table.shape[0], table.shape[1],
-                                         ctypes.c_void_p(keys_i32.data_ptr()), n,
-                                         ctypes.c_void_p(out.data_ptr()),
-                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-              "ha_gather_u32keys")
+        self.check(self.lib.ha_gather_u32keys(table.data_ptr(), table.shape[0], table.shape[1],
+                                              keys_i32.data_ptr(), n, out.data_ptr(), self._stream()),
+                   "ha_gather_u32keys")
         return out
 
     def expand(self, rows, plan):
@@ -96,32 +163,43 @@ class HipEngine:
 
     def acc_apply(self, table, keys_i32, values):
         """table[key,:] = (table[key,:] + v_a) + v_b ... in the order the (key, value) pairs are listed."""
-        from ._lib import check
         n = keys_i32.numel()
         if n == 0:
             return
-        p = self._plan("owner", n)
-        check(self.lib.ha_plan_build_u32keys(ctypes.c_void_p(keys_i32.data_ptr()), n,
-                                             ctypes.c_void_p(p.ws.data_ptr()), 32,
-                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-              "ha_plan_build_u32keys")
+        p = self._owner_plan
+        if p is None or p.capacity < n:
+            p = self._owner_plan = self.ops.IndexPlan(max(n, 1), self.device)
+        self.check(self.lib.ha_plan_build_u32keys(keys_i32.data_ptr(), n, p.ws.data_ptr(), 32, self._stream()),
+                   "ha_plan_build_u32keys")
         p.n = n
         p._view = None
         self.ops.sgd_apply(table, p, values, -1.0)
 
-    def n_unique_and(self, plan, *tensors):
-        """One host sync: (n_unique, [tensor.tolist() ...])."""
-        packed = torch.cat([plan.n_unique_dev().to(torch.int64)] + [t.reshape(-1).to(torch.int64) for t in tensors])
-        host = packed.tolist()
-        out, k = [], 1
-        for t in tensors:
-            out.append(host[k:k + t.numel()])
-            k += t.numel()
-        return host[0], out
+
+class RouteBuffers:
+    """Persistent device / pinned-host buffers of one routing workspace (see HipEngine.route_issue)."""
+    __slots__ = ("plan", "local", "meta_all", "meta", "recv", "host", "keys_recv", "starts", "free",
+                 "ev_host", "ev_ready", "ev_free")
+
+    def __init__(self):
+        self.free = None
+        self.ev_host = self.ev_ready = self.ev_free = None
+
+
+class Route:
+    """Routing of one id batch: its plan, which owner gets which of its unique keys, and the keys this
+    rank will be asked for.  Shared by the pull and the push of the batch."""
+    __slots__ = ("buf", "plan", "pending", "u", "send_cnt", "recv_cnt", "keys_recv", "ready", "shape")
+
+    def __init__(self):
+        self.pending = None
+        self.ready = None
 
 
 class ShardedEmbedding:
-    """One row-range shard per rank + all-to-all pull/push.  `table` is this rank's shard."""
+    """One row-range shard per rank + all-to-all pull/push.  `table` is this rank's shard.
+    Construct it on every rank of `group` at the same point of the program (it creates a second
+    process group for the prefetched routing exchange)."""
 
     def __init__(self, rows, width, device, group=None, engine=None, table=None):
         self.group = group
@@ -137,41 +215,60 @@ class ShardedEmbedding:
         assert tuple(table.shape) == (self.local_rows, width)
         self.table = table
         self.stats = {"xgmi_bytes_out": 0, "xgmi_bytes_in": 0}
+        self._slot = 0
+        self.side_group = None
+        if self.world > 1:
+            ranks = None if group is None else dist.get_process_group_ranks(group)
+            self.side_group = dist.new_group(ranks=ranks)
 
     # -- exchange plumbing ---------------------------------------------------------------------------
-    def _a2a(self, out, inp, out_splits, in_splits):
+    def _a2a(self, out, inp, out_splits, in_splits, group=None):
         if self.world == 1:
             out.copy_(inp)
         else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=group if group is not None else self.group)
         return out
 
-    def _route(self, plan):
-        """Counts all-to-all.  -> (U, send_counts, recv_counts, local_keys) with host-side counts.
-        The routing of a plan is cached on the plan object: pull and push of the same batch (the
-        training step) pay for one counts exchange and one host synchronisation."""
-        cached = getattr(plan, "_route_cache", None)
-        if cached is not None and cached[0] is self:
-            return cached[1]
-        r = self._route_uncached(plan)
-        try:
-            plan._route_cache = (self, r)
-        except AttributeError:
-            pass
+    # -- routing: phase 1 (enqueue, no host wait) and phase 2 (host reads 1+2W counts, keys exchange) ----
+    def prefetch(self, ids, after_current=True):
+        """Start the routing of a batch of ids on the side stream: plan, shard-local keys, counts
+        all-to-all and the asynchronous read-back; no host wait.  Returns a Route for pull(route=) /
+        push(route=).  after_current=False when `ids` is not produced by work queued on the current
+        stream (ids resident since an earlier step): the routing then starts at once."""
+        eng = self.engine
+        r = Route()
+        r.shape = tuple(ids.shape)
+        slot = self._slot
+        self._slot = (self._slot + 1) % eng.NSLOT
+        with eng.on_side(after_current):
+            b = r.buf = eng.route_issue(ids.reshape(-1), self.starts, slot)
+            r.plan = b.plan
+            self._a2a(b.recv, b.meta[1:], None, None, group=self.side_group)
+            r.pending = eng.to_host(b)
         return r
 
-    def _route_uncached(self, plan):
+    def complete(self, r):
+        """Second phase of a route: the host reads n_unique and the 2W counts (waits for the read-back
+        of prefetch) and the shard-local keys are exchanged on the side stream.  pull / push call it
+        when needed; calling it at the end of the previous step keeps both off the critical path."""
+        if r.pending is False:
+            return r
         eng = self.engine
-        offsets, local = eng.bucket(plan, self.starts)
-        send_cnt_dev = (offsets[1:] - offsets[:-1]).to(torch.int64)
-        recv_cnt_dev = torch.empty_like(send_cnt_dev)
-        self._a2a(recv_cnt_dev, send_cnt_dev, None, None)
-        u, (send_cnt, recv_cnt) = eng.n_unique_and(plan, send_cnt_dev, recv_cnt_dev)
-        # the shard-local keys every owner will be asked for (pull) / handed rows for (push)
-        keys_send = local[:u].contiguous()
-        keys_recv = torch.empty(sum(recv_cnt), dtype=keys_send.dtype, device=self.device)
-        self._a2a(keys_recv, keys_send, recv_cnt, send_cnt)
-        return u, send_cnt, recv_cnt, keys_recv
+        b = r.buf
+        eng.host_sync(r.pending)
+        vals = b.host.tolist()
+        w = self.world
+        r.u, r.send_cnt, r.recv_cnt = vals[0], vals[1:1 + w], vals[1 + w:1 + 2 * w]
+        r.keys_recv = b.keys_recv[:sum(r.recv_cnt)]
+        with eng.on_side(False):
+            self._a2a(r.keys_recv, b.local[:r.u], r.recv_cnt, r.send_cnt, group=self.side_group)
+            r.ready = eng.record(b.ev_ready)
+        r.pending = False
+        return r
+
+    def _release(self, r):
+        """The last consumer of a route's buffers is queued on the current stream."""
+        r.buf.free = self.engine.record(r.buf.ev_free)
 
     def _account(self, send_cnt, recv_cnt, bytes_per_key_out, bytes_per_key_in):
         r = self.rank
@@ -181,36 +278,40 @@ class ShardedEmbedding:
         self.stats["xgmi_bytes_in"] += in_keys * bytes_per_key_out + out_keys * bytes_per_key_in
 
     # -- SparsePull -------------------------------------------------------------------------------------
-    def pull(self, ids, plan=None, return_plan=False):
-        """out[i,:] = table_global[ids[i],:] for this rank's batch of ids."""
+    def pull(self, ids=None, route=None, return_route=False):
+        """out[i,:] = table_global[ids[i],:] for this rank's batch of ids (or of a prefetched route)."""
         eng = self.engine
-        if plan is None:
-            plan = eng.plan(ids)
-        u, send_cnt, recv_cnt, keys_recv = self._route(plan)
-        rows_send = eng.gather_keys(self.table, keys_recv)
-        rows_recv = torch.empty((u, self.width), dtype=torch.float32, device=self.device)
-        self._a2a(rows_recv, rows_send, send_cnt, recv_cnt)
-        out = eng.expand(rows_recv, plan)
-        self._account(send_cnt, recv_cnt, 4, 4 * self.width)
-        out = out.reshape(tuple(ids.shape) + (self.width,))
-        return (out, plan) if return_plan else out
+        if route is None:
+            route = self.prefetch(ids)
+        r = self.complete(route)
+        eng.wait_event(r.ready)
+        rows_send = eng.gather_keys(self.table, r.keys_recv)
+        rows_recv = torch.empty((r.u, self.width), dtype=torch.float32, device=self.device)
+        self._a2a(rows_recv, rows_send, r.send_cnt, r.recv_cnt)
+        out = eng.expand(rows_recv, r.plan)
+        self._account(r.send_cnt, r.recv_cnt, 4, 4 * self.width)
+        out = out.reshape(r.shape + (self.width,))
+        self._release(r)
+        return (out, r) if return_route else out
 
     # -- SparsePush -------------------------------------------------------------------------------------
-    def push(self, ids, values, lr=None, plan=None):
+    def push(self, ids, values, lr=None, route=None):
         """table_global[id,:] += sum over this rank's positions of (-lr * values)  (scale 1 if lr is None),
-        pushes of different ranks applied in rank order."""
+        pushes of different ranks applied in rank order.  `route` = the Route of the same ids (from
+        prefetch / pull(return_route=True)) saves the routing exchange."""
         eng = self.engine
-        if plan is None:
-            plan = eng.plan(ids)
+        if route is None:
+            route = self.prefetch(ids)
+        r = self.complete(route)
         scale = 1.0 if lr is None else -float(lr)
-        reduced = eng.reduce_scaled(plan, values.reshape(-1, self.width), scale)
-        u, send_cnt, recv_cnt, keys_recv = self._route(plan)
-        nrecv = sum(recv_cnt)
-        rows_send = reduced[:u].contiguous()
-        rows_recv = torch.empty((nrecv, self.width), dtype=torch.float32, device=self.device)
-        self._a2a(rows_recv, rows_send, recv_cnt, send_cnt)
-        eng.acc_apply(self.table, keys_recv, rows_recv)
-        self._account(send_cnt, recv_cnt, 4 * self.width, 0)
+        eng.wait_event(r.ready)   # the plan and the keys were produced on the side stream
+        reduced = eng.reduce_scaled(r.plan, values.reshape(-1, self.width), scale)
+        rows_send = reduced[:r.u]
+        rows_recv = torch.empty((sum(r.recv_cnt), self.width), dtype=torch.float32, device=self.device)
+        self._a2a(rows_recv, rows_send, r.recv_cnt, r.send_cnt)
+        eng.acc_apply(self.table, r.keys_recv, rows_recv)
+        self._account(r.send_cnt, r.recv_cnt, 4 * self.width, 0)
+        self._release(r)
 
     # -- SSPushPull (push this batch, pull the next one): ParameterServerCommunicate.py:74-76 ------------
     def push_pull(self, push_ids, values, lr, pull_ids):

@@ -35,10 +35,18 @@ def run(args, rank, world, dev):
     grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(2)]
     lr = 1e-6
 
+    # The routing of batch k+1 (plan, counts and keys exchange, the one host read-back) is prefetched on
+    # the side stream while the rows of batch k are pulled and pushed: its ids are resident one step
+    # ahead (the reference's dataloader / PS prefetch does the same).
+    state = {"route": emb.prefetch(ids_dev[0], after_current=False)}
+
     def step(k):
-        ids = ids_dev[k % nb]
-        out, plan = emb.pull(ids, return_plan=True)      # forward lookup
-        emb.push(ids, grads[k % 2], lr, plan=plan)       # backward: -lr scale, dedup-reduce, exchange, apply
+        cur = state["route"]
+        nxt = emb.prefetch(ids_dev[(k + 1) % nb], after_current=False)
+        out = emb.pull(route=cur)                            # forward lookup
+        emb.push(None, grads[k % 2], lr, route=cur)          # backward: -lr scale, dedup-reduce, exchange, apply
+        emb.complete(nxt)                                    # host counts + keys exchange of the next batch
+        state["route"] = nxt
         return out
 
     for k in range(args.warmup):

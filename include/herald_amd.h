@@ -285,6 +285,16 @@ int ha_shard_bucket(const void *plan_ws, int64_t n, const int64_t *starts_host,
                     int nshard, int32_t *offsets, uint32_t *local_keys,
                     ha_stream_t stream);
 
+/* One call for the routing of a batch: ha_plan_build_* of the ids, then the shard-local keys as
+ * ha_shard_bucket writes them, and meta[0] = n_unique, meta[1+g] = number of unique keys owned by
+ * shard g (device int64[1+nshard]: the send counts of the counts all-to-all and of the host read-back). */
+int ha_shard_route_f32ids(const float *ids, int64_t n, void *plan_ws,
+                          const int64_t *starts_host, int nshard, int64_t *meta,
+                          uint32_t *local_keys, ha_stream_t stream);
+int ha_shard_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws,
+                          const int64_t *starts_host, int nshard, int64_t *meta,
+                          uint32_t *local_keys, ha_stream_t stream);
+
 /* ---- HET embedding cache (replaces the hetu_cache plugin, src/hetu_cache) ----
  * An opaque device-resident cache of `limit` lines in front of a store (the "server": a table shard
  * plus one int64 version per row, ps-lite/include/ps/server/param.h:119-138).  Semantics of

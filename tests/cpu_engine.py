@@ -1,6 +1,8 @@
 """Test double for herald_amd.sharded's engine: the same interface as HipEngine, computed by the CPU
 oracle on CPU tensors, so that the multi-rank exchange logic can run under gloo without a GPU.
 Lives in tests/ only -- the product has no CPU path."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -19,20 +21,46 @@ class _Plan:
 
 
 class CpuEngine:
+    NSLOT = 3
+
     def __init__(self):
         self.device = torch.device("cpu")
 
-    def plan(self, ids, slot="batch"):
-        return _Plan(ids)
-
-    def bucket(self, plan, starts):
+    # -- routing (same contract as HipEngine.route_issue; streams and events are no-ops on the CPU) --
+    def route_issue(self, ids, starts, slot):
+        plan = _Plan(ids)
         st = np.asarray(starts, dtype=np.uint64)
-        offsets = np.searchsorted(plan.uniq, st, side="left").astype(np.int32)
+        offsets = np.searchsorted(plan.uniq, st, side="left").astype(np.int64)
         offsets[-1] = plan.uniq.size
         owner = np.searchsorted(st, plan.uniq, side="right") - 1
         local = np.zeros(max(plan.n, 1), dtype=np.int32)
         local[:plan.uniq.size] = (plan.uniq - st[owner]).astype(np.int32)
-        return torch.from_numpy(offsets), torch.from_numpy(local)
+        w = len(starts) - 1
+        meta = np.concatenate([[plan.uniq.size], offsets[1:] - offsets[:-1]]).astype(np.int64)
+        from herald_amd.sharded import RouteBuffers
+        b = RouteBuffers()
+        b.plan, b.local, b.meta = plan, torch.from_numpy(local), torch.from_numpy(meta)
+        b.meta_all = torch.cat([b.meta, torch.zeros(w, dtype=torch.int64)])
+        b.meta, b.recv = b.meta_all[:1 + w], b.meta_all[1 + w:]
+        b.host = torch.empty(1 + 2 * w, dtype=torch.int64)
+        b.keys_recv = torch.empty(max(w * plan.n, 1), dtype=torch.int32)
+        return b
+
+    def on_side(self, after_current=True):
+        return contextlib.nullcontext()
+
+    def record(self, ev=None):
+        return None
+
+    def wait_event(self, ev):
+        pass
+
+    def to_host(self, b):
+        b.host.copy_(b.meta_all)
+        return None
+
+    def host_sync(self, ev):
+        pass
 
     def gather_keys(self, table, keys_i32):
         return torch.from_numpy(table.numpy()[keys_i32.numpy().astype(np.int64)])
@@ -52,6 +80,3 @@ class CpuEngine:
         v = values.numpy()
         for j, k in enumerate(keys_i32.numpy().astype(np.int64)):
             t[k] = t[k] + v[j]
-
-    def n_unique_and(self, plan, *tensors):
-        return int(plan.uniq.size), [t.reshape(-1).tolist() for t in tensors]

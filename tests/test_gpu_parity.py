@@ -262,9 +262,9 @@ def test_sharded_single_rank_hip_engine(dev):
     ids[:500] = ids[0]
     vals = rng.standard_normal((n, width), dtype=np.float32)
     emb = ShardedEmbedding(rows, width, dev, table=_dev(table, dev))
-    out, plan = emb.pull(_dev(ids, dev), return_plan=True)
+    out, route = emb.pull(_dev(ids, dev), return_route=True)
     np.testing.assert_array_equal(out.cpu().numpy(), cpu.sparse_pull(table, ids))
-    emb.push(_dev(ids, dev), _dev(vals, dev), 0.01, plan=plan)
+    emb.push(_dev(ids, dev), _dev(vals, dev), 0.01, route=route)
     want = cpu.sparse_push(table.copy(), ids, vals, 0.01)
     np.testing.assert_array_equal(emb.table.cpu().numpy(), want)
     # a second push without lr scaling (IndexedSlices add semantics)

@@ -60,6 +60,25 @@ def _worker(rank, world, port, rows, width, n, out_dir):
     out2 = emb.pull(ids)                                     # pull after push sees every rank's update
     np.testing.assert_array_equal(out2.numpy(), want[all_ids[rank].astype(np.int64)])
 
+    # software-pipelined schedule of bench.py's N>1 leg: the routing of batch k+1 is prefetched and
+    # completed while batch k is pulled and pushed; results equal the serial pull / push sequence
+    batches = [[rng.integers(0, rows, size=n).astype(np.float32) for _ in range(world)] for _ in range(4)]
+    bvals = [[rng.standard_normal((n, width), dtype=np.float32) for _ in range(world)] for _ in range(4)]
+    route = emb.prefetch(torch.from_numpy(batches[0][rank]), after_current=False)
+    for k in range(4):
+        cur = route
+        if k + 1 < 4:
+            route = emb.prefetch(torch.from_numpy(batches[k + 1][rank]), after_current=False)
+        got = emb.pull(route=cur)
+        np.testing.assert_array_equal(got.numpy(), want[batches[k][rank].astype(np.int64)])
+        emb.push(None, torch.from_numpy(bvals[k][rank]), lr, route=cur)
+        if k + 1 < 4:
+            emb.complete(route)
+        dist.barrier()
+        for r in range(world):
+            cpu.sparse_push(want, batches[k][r], bvals[k][r], lr)
+        np.testing.assert_array_equal(emb.table.numpy(), want[starts[rank]:starts[rank + 1]])
+
     # 2-D id batches and the checkpoint format round trip
     ids2 = ids[: (n // 4) * 4].reshape(-1, 4)
     assert tuple(emb.pull(ids2).shape) == (ids2.shape[0], 4, width)
