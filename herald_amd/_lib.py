@@ -151,6 +151,20 @@ def _declare(L):
     L.ha_laia_next.argtypes = [vp, i64, i64, vp, vp, i64, vp]
     L.ha_laia_snapshot_keys.restype = i64
     L.ha_laia_snapshot_keys.argtypes = [vp, i64, vp, i64]
+    L.ha_laia_next_topk.restype = c.c_int
+    L.ha_laia_next_topk.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp, i64, vp]
+    L.ha_laia_counters.restype = c.c_int
+    L.ha_laia_counters.argtypes = [vp, vp]
+    L.ha_shm_ring_open.restype = vp
+    L.ha_shm_ring_open.argtypes = [c.c_char_p, c.c_int, i64]
+    L.ha_shm_ring_close.restype = None
+    L.ha_shm_ring_close.argtypes = [vp]
+    L.ha_shm_ring_send.restype = c.c_int
+    L.ha_shm_ring_send.argtypes = [vp, vp, i64]
+    L.ha_shm_ring_recv.restype = i64
+    L.ha_shm_ring_recv.argtypes = [vp, vp, i64, vp]
+    L.ha_shm_ring_pending_words.restype = i64
+    L.ha_shm_ring_pending_words.argtypes = [vp]
     A, S = c.POINTER(DLArray), c.POINTER(DLStream)
     dl = {
         "DLGpuEmbeddingLookUp": [A, A, A, S],

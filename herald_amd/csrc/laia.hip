@@ -135,12 +135,13 @@ __global__ __launch_bounds__(256) void laia_score_kernel(
     }
 }
 
-// plan pairs: (w, row) for rows valid at w in samples not assigned to w; touched pairs: (owner, row)
+// plan pairs: (w, row) for rows valid at w in samples not assigned to w (LaiaScheduler), or -- own_plan,
+// TopkScheduler -- (owner, row) for rows valid at the sample's own worker; touched pairs: (owner, row)
 __global__ __launch_bounds__(256) void laia_pairs_kernel(
     const uint32_t *__restrict__ samples, long long S, int T, long long start, int B, int W,
     const unsigned long long *__restrict__ mask, const int32_t *__restrict__ owner, long long R,
     uint32_t *__restrict__ plan_pairs, unsigned long long *__restrict__ plan_count,
-    uint32_t *__restrict__ touch_pairs) {
+    uint32_t *__restrict__ touch_pairs, int own_plan) {
     const long long total = static_cast<long long>(B) * T;
     for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
         const long long i = e / T;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void laia_pairs_kernel(
         const uint32_t emb = samples[((start + i) % S) * T + j];
         const int ow = owner[i];
         touch_pairs[e] = static_cast<uint32_t>(ow * R + emb);
-        unsigned long long m = mask[e] & ~(1ull << ow);
+        unsigned long long m = own_plan ? (mask[e] & (1ull << ow)) : (mask[e] & ~(1ull << ow));
         while (m) {
             const int w = __builtin_ctzll(m);
             m &= m - 1;
@@ -156,6 +157,37 @@ __global__ __launch_bounds__(256) void laia_pairs_kernel(
             plan_pairs[pos] = static_cast<uint32_t>(w * R + emb);
         }
     }
+}
+
+// TopkScheduler scoring (topk_scheduler.cc:411-429): only the tables order[0..top_k) count, visited in
+// that order; cand[i] = the worker whose running score first reached the sample's final maximum
+// (worker 0 when no table hits).  One thread per sample.
+struct TableOrder {
+    int32_t t[64];
+};
+__global__ __launch_bounds__(256) void laia_topk_score_kernel(
+    const unsigned long long *__restrict__ mask, int B, int T, int W, TableOrder order, int top_k,
+    int32_t *__restrict__ scores, int32_t *__restrict__ cand) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B)
+        return;
+    int32_t *sc = scores + static_cast<long long>(i) * W;
+    for (int z = 0; z < W; ++z)
+        sc[z] = 0;
+    int top = 0, c = 0;
+    for (int k = 0; k < top_k; ++k) {
+        unsigned long long m = mask[static_cast<long long>(i) * T + order.t[k]];
+        while (m) {  // ascending worker index, like the z loop
+            const int z = __builtin_ctzll(m);
+            m &= m - 1;
+            const int v = ++sc[z];
+            if (v > top) {
+                top = v;
+                c = z;
+            }
+        }
+    }
+    cand[i] = c;
 }
 
 __global__ __launch_bounds__(256) void laia_delta_kernel(const uint32_t *__restrict__ dkeys,
@@ -176,7 +208,9 @@ struct Laia {
     uint32_t *d_samples = nullptr;
     uint8_t *d_valid = nullptr;
     unsigned long long *d_mask = nullptr, *d_count = nullptr;
-    int32_t *d_scores = nullptr, *d_owner = nullptr;
+    int32_t *d_scores = nullptr, *d_owner = nullptr, *d_cand = nullptr;
+    // TopkScheduler traffic counters per worker (topk_scheduler.cc:319-331)
+    std::vector<long long> miss_pull, miss_push, update_pull, update_push;
     uint32_t *d_plan_pairs = nullptr, *d_touch_pairs = nullptr, *d_dkeys = nullptr;
     uint8_t *d_dvals = nullptr;
     void *d_plan_ws = nullptr;
@@ -219,6 +253,10 @@ extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sam
     l.snaps.resize(l.W);
     for (auto &s : l.snaps)
         s.init(l.cache_size);
+    l.miss_pull.assign(l.W, 0);
+    l.miss_push.assign(l.W, 0);
+    l.update_pull.assign(l.W, 0);
+    l.update_push.assign(l.W, 0);
     const size_t BT = static_cast<size_t>(l.Bcap) * l.T;
     l.plan_cap = BT * (l.W > 1 ? l.W - 1 : 1);
     if (l.plan_cap < BT)
@@ -231,6 +269,7 @@ extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sam
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_count), 8) == 0;
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_scores), static_cast<size_t>(l.Bcap) * l.W * 4) == 0;
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_owner), static_cast<size_t>(l.Bcap) * 4) == 0;
+    ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_cand), static_cast<size_t>(l.Bcap) * 4) == 0;
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_plan_pairs), l.plan_cap * 4) == 0;
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_touch_pairs), BT * 4) == 0;
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_dkeys), l.delta_cap * 4) == 0;
@@ -292,8 +331,21 @@ static int sorted_unique_to_host(Laia &l, const uint32_t *d_keys, size_t n, std:
 //   dist_out   [W * mini_bs]   global sample indices per worker (laia_scheduler.cc:245)
 //   plan_out   concatenated sorted plans of workers 0..W-1, plan_off[W+1] their offsets;
 //              plan_cap_elems bounds plan_out.
-extern "C" int ha_laia_next(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out,
-                            uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off) {
+struct TopkParams {
+    const int32_t *order;  // table order, top_k entries used
+    int top_k, num_threads;
+};
+
+// thread slice of `total` items: thread 0 takes the remainder (topk_scheduler.cc:398-407)
+static void topk_slice(long long total, int nt, int t, long long *s0, long long *s1) {
+    const long long x = total / nt, y = total % nt;
+    *s0 = t == 0 ? 0 : y + t * x;
+    *s1 = t == 0 ? x + y : *s0 + x;
+}
+
+static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out,
+                          uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off,
+                          const TopkParams *topk) {
     HA_REQUIRE(h && dist_out && plan_out && plan_off && mini_bs > 0, "laia_next: bad arguments");
     Laia &l = h->l;
     const int W = l.W, T = l.T;
@@ -307,17 +359,73 @@ extern "C" int ha_laia_next(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     // ---- score
     hipLaunchKernelGGL(laia_probe_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T,
                        start, (int)B, W, l.d_valid, l.R, l.d_mask);
-    hipLaunchKernelGGL(laia_score_kernel, dim3((int)((B * W + 255) / 256)), dim3(256), 0, l.stream,
-                       l.d_mask, (int)B, T, W, l.d_scores);
+    std::vector<int32_t> cand;
+    if (topk) {
+        HA_REQUIRE(topk->top_k >= 1 && topk->top_k <= T && T <= 64 && topk->num_threads >= 1,
+                   "laia_next_topk: need 1 <= top_k <= num_table <= 64 and num_threads >= 1");
+        TableOrder order;
+        for (int k = 0; k < topk->top_k; ++k) {
+            HA_REQUIRE(topk->order[k] >= 0 && topk->order[k] < T, "laia_next_topk: table index out of range");
+            order.t[k] = topk->order[k];
+        }
+        hipLaunchKernelGGL(laia_topk_score_kernel, dim3((int)((B + 255) / 256)), dim3(256), 0, l.stream,
+                           l.d_mask, (int)B, T, W, order, topk->top_k, l.d_scores, l.d_cand);
+        cand.resize(static_cast<size_t>(B));
+    } else {
+        hipLaunchKernelGGL(laia_score_kernel, dim3((int)((B * W + 255) / 256)), dim3(256), 0, l.stream,
+                           l.d_mask, (int)B, T, W, l.d_scores);
+    }
     HA_LAUNCH_CHECK();
     std::vector<int32_t> scores(static_cast<size_t>(B) * W);
     HA_CHECK_HIP(hipMemcpyAsync(scores.data(), l.d_scores, scores.size() * 4, hipMemcpyDeviceToHost, l.stream));
+    if (topk)
+        HA_CHECK_HIP(hipMemcpyAsync(cand.data(), l.d_cand, cand.size() * 4, hipMemcpyDeviceToHost, l.stream));
     HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    std::vector<int32_t> owner(static_cast<size_t>(B));
+    if (topk) {
+        // ---- assign (topk_scheduler.cc:393-455): the batch and every worker's quota are cut into
+        // per-thread slices; each slice is assigned sequentially, offering a sample to the workers in the
+        // order (j + candidate) % W, strictly greater score wins, stop at the candidate itself
+        const int nt = topk->num_threads;
+        for (int t = 0; t < nt; ++t) {
+            long long s0, s1, q0, q1;
+            topk_slice(B, nt, t, &s0, &s1);
+            topk_slice(mini_bs, nt, t, &q0, &q1);
+            HA_REQUIRE(s1 - s0 <= W * (q1 - q0),
+                       "laia_next_topk: thread %d has %lld samples for %d workers x quota %lld (the reference "
+                       "writes dist[-1] here); pick num_threads dividing mini_batch_size", t, s1 - s0, W, q1 - q0);
+        }
+        for (long long k = 0; k < static_cast<long long>(W) * mini_bs; ++k)
+            dist_out[k] = 0;  // dist.reset(0), topk_scheduler.cc:382
+        std::vector<long long> wl(W);
+        for (int t = 0; t < nt; ++t) {
+            long long s0, s1, q0, q1;
+            topk_slice(B, nt, t, &s0, &s1);
+            topk_slice(mini_bs, nt, t, &q0, &q1);
+            std::fill(wl.begin(), wl.end(), 0);
+            for (long long i = s0; i < s1; ++i) {
+                const int c = cand[static_cast<size_t>(i)];
+                int best = -1, best_w = -1;
+                for (int j = 0; j < W; ++j) {
+                    const int w = (j + c) % W;
+                    const int sc = scores[static_cast<size_t>(i) * W + w];
+                    if (best < sc && wl[w] < q1 - q0) {
+                        best = sc;
+                        best_w = w;
+                        if (best_w == c)
+                            break;
+                    }
+                }
+                dist_out[static_cast<size_t>(best_w) * mini_bs + q0 + wl[best_w]] = (i + start) % l.S;
+                wl[best_w] += 1;
+                owner[static_cast<size_t>(i)] = best_w;
+            }
+        }
+    }
     // ---- assign (laia_scheduler.cc:226-249): sequential, capacity mini_bs per worker, workers visited
     // in the order (j + batch_id) % W, strictly greater score wins
-    std::vector<int32_t> owner(static_cast<size_t>(B));
     std::vector<long long> workload(W, 0);
-    for (long long i = 0; i < B; ++i) {
+    for (long long i = 0; !topk && i < B; ++i) {
         int max_score = -1, max_worker = -1;
         for (int j = 0; j < W; ++j) {
             const int w = static_cast<int>((j + batch_id) % W);
@@ -335,7 +443,8 @@ extern "C" int ha_laia_next(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     HA_CHECK_HIP(hipMemcpyAsync(l.d_owner, owner.data(), owner.size() * 4, hipMemcpyHostToDevice, l.stream));
     HA_CHECK_HIP(hipMemsetAsync(l.d_count, 0, 8, l.stream));
     hipLaunchKernelGGL(laia_pairs_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start,
-                       (int)B, W, l.d_mask, l.d_owner, l.R, l.d_plan_pairs, l.d_count, l.d_touch_pairs);
+                       (int)B, W, l.d_mask, l.d_owner, l.R, l.d_plan_pairs, l.d_count, l.d_touch_pairs,
+                       topk ? 1 : 0);
     HA_LAUNCH_CHECK();
     unsigned long long npairs = 0;
     HA_CHECK_HIP(hipMemcpyAsync(&npairs, l.d_count, 8, hipMemcpyDeviceToHost, l.stream));
@@ -368,10 +477,21 @@ extern "C" int ha_laia_next(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
         for (int w = 0; w < W; ++w) {
             delta.clear();
             const unsigned long long base = static_cast<unsigned long long>(w) * l.R;
+            const size_t pk_begin = pk;
             for (; pk < plan_keys.size() && plan_keys[pk] / l.R == static_cast<unsigned long long>(w); ++pk)
                 l.snaps[w].outdate(static_cast<int32_t>(plan_keys[pk] - base), delta);
-            for (; tk < touch_keys.size() && touch_keys[tk] / l.R == static_cast<unsigned long long>(w); ++tk)
-                l.snaps[w].get(static_cast<int32_t>(touch_keys[tk] - base), delta);
+            l.update_push[w] += static_cast<long long>(pk - pk_begin);
+            for (; tk < touch_keys.size() && touch_keys[tk] / l.R == static_cast<unsigned long long>(w); ++tk) {
+                const int res = l.snaps[w].get(static_cast<int32_t>(touch_keys[tk] - base), delta);
+                if (res < 0) {  // traffic counters, topk_scheduler.cc:319-331
+                    if (res == -2)
+                        l.update_pull[w] += 1;
+                } else {
+                    l.miss_pull[w] += 1;
+                    if (res > 0)
+                        l.miss_push[w] += 1;
+                }
+            }
             // keep the last value per row
             std::unordered_map<int32_t, uint8_t> last;
             last.reserve(delta.size() * 2);
@@ -395,6 +515,34 @@ extern "C" int ha_laia_next(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     return 0;
 }
 
+extern "C" int ha_laia_next(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out,
+                            uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off) {
+    return laia_next_impl(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off, nullptr);
+}
+
+extern "C" int ha_laia_next_topk(ha_laia *h, int64_t batch_id, int64_t mini_bs,
+                                 const int32_t *table_order, int64_t top_k, int64_t num_threads,
+                                 int64_t *dist_out, uint64_t *plan_out, int64_t plan_cap_elems,
+                                 int64_t *plan_off) {
+    HA_REQUIRE(table_order && top_k >= 1 && top_k <= 64 && num_threads >= 1 && num_threads <= (1 << 20),
+               "laia_next_topk: bad arguments");
+    const TopkParams tp{table_order, static_cast<int>(top_k), static_cast<int>(num_threads)};
+    return laia_next_impl(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off, &tp);
+}
+
+// out[4*W] = miss_pull[W], miss_push[W], update_pull[W], update_push[W] accumulated so far
+extern "C" int ha_laia_counters(ha_laia *h, int64_t *out) {
+    HA_REQUIRE(h && out, "laia_counters: bad arguments");
+    const Laia &l = h->l;
+    for (int w = 0; w < l.W; ++w) {
+        out[w] = l.miss_pull[w];
+        out[l.W + w] = l.miss_push[w];
+        out[2 * l.W + w] = l.update_pull[w];
+        out[3 * l.W + w] = l.update_push[w];
+    }
+    return 0;
+}
+
 // valid keys of worker w's snapshot, ascending (MiniLRUCache::get_keys); returns the count
 extern "C" int64_t ha_laia_snapshot_keys(ha_laia *h, int64_t w, int32_t *out, int64_t cap) {
     if (!h || w < 0 || w >= h->l.W)
@@ -408,4 +556,143 @@ extern "C" int64_t ha_laia_snapshot_keys(ha_laia *h, int64_t w, int32_t *out, in
     for (size_t i = 0; i < keys.size() && static_cast<int64_t>(i) < cap; ++i)
         out[i] = keys[i];
     return static_cast<int64_t>(keys.size());
+}
+
+// ---- local-shared plan distribution -----------------------------------------------------------------
+// The reference's TopkScheduler runs on local rank 0 only and hands every local worker its
+// [plan, dist] stream through a boost::interprocess shared-memory ring named "laia_cache_<i>"
+// (laia/include/share_mem.h:40-193, ring_buffer.h:13-125).  Same topology here (one process per GPU):
+// a single-producer / single-consumer ring of uint64 words in POSIX shared memory, one message =
+// [length, payload...]; send / recv never block (the callers poll, topk_scheduler.cc:204-247).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <string>
+
+struct ha_shm_ring {
+    struct Header {
+        std::atomic<uint64_t> head;  // words consumed
+        std::atomic<uint64_t> tail;  // words produced
+        uint64_t capacity;           // payload words (power of two)
+        uint64_t pad[5];
+    };
+    Header *hdr = nullptr;
+    uint64_t *data = nullptr;
+    size_t bytes = 0;
+    std::string name;
+    bool owner = false;
+};
+
+extern "C" ha_shm_ring *ha_shm_ring_open(const char *name, int create, int64_t capacity_words) {
+    if (!name || (create && capacity_words < 16)) {
+        ha::set_error("ha_shm_ring_open: bad arguments");
+        return nullptr;
+    }
+    std::string nm = name[0] == '/' ? std::string(name) : "/" + std::string(name);
+    uint64_t cap = 16;
+    if (create) {
+        while (cap < static_cast<uint64_t>(capacity_words))
+            cap <<= 1;
+        (void)shm_unlink(nm.c_str());
+    }
+    const int fd = shm_open(nm.c_str(), create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) {
+        ha::set_error("ha_shm_ring_open: shm_open(%s) failed", nm.c_str());
+        return nullptr;
+    }
+    size_t bytes = 0;
+    if (create) {
+        bytes = sizeof(ha_shm_ring::Header) + cap * 8;
+        if (ftruncate(fd, static_cast<off_t>(bytes)) != 0) {
+            close(fd);
+            (void)shm_unlink(nm.c_str());
+            ha::set_error("ha_shm_ring_open: ftruncate failed");
+            return nullptr;
+        }
+    } else {
+        struct stat st;
+        if (fstat(fd, &st) != 0 || static_cast<size_t>(st.st_size) < sizeof(ha_shm_ring::Header) + 16 * 8) {
+            close(fd);
+            ha::set_error("ha_shm_ring_open: %s is not an initialised ring", nm.c_str());
+            return nullptr;
+        }
+        bytes = static_cast<size_t>(st.st_size);
+    }
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        ha::set_error("ha_shm_ring_open: mmap failed");
+        return nullptr;
+    }
+    ha_shm_ring *r = new ha_shm_ring();
+    r->hdr = static_cast<ha_shm_ring::Header *>(p);
+    r->data = reinterpret_cast<uint64_t *>(r->hdr + 1);
+    r->bytes = bytes;
+    r->name = nm;
+    r->owner = create != 0;
+    if (create) {
+        r->hdr->head.store(0);
+        r->hdr->tail.store(0);
+        r->hdr->capacity = cap;
+    }
+    return r;
+}
+
+extern "C" void ha_shm_ring_close(ha_shm_ring *r) {
+    if (!r)
+        return;
+    munmap(r->hdr, r->bytes);
+    if (r->owner)
+        (void)shm_unlink(r->name.c_str());
+    delete r;
+}
+
+// 1 = sent, 0 = not enough room right now, -1 = message can never fit
+extern "C" int ha_shm_ring_send(ha_shm_ring *r, const uint64_t *words, int64_t n) {
+    if (!r || n < 0 || (n > 0 && !words))
+        return -1;
+    const uint64_t cap = r->hdr->capacity, need = static_cast<uint64_t>(n) + 1;
+    if (need > cap)
+        return -1;
+    const uint64_t tail = r->hdr->tail.load(std::memory_order_relaxed);
+    const uint64_t head = r->hdr->head.load(std::memory_order_acquire);
+    if (cap - (tail - head) < need)
+        return 0;
+    r->data[tail & (cap - 1)] = static_cast<uint64_t>(n);
+    for (int64_t i = 0; i < n; ++i)
+        r->data[(tail + 1 + static_cast<uint64_t>(i)) & (cap - 1)] = words[i];
+    r->hdr->tail.store(tail + need, std::memory_order_release);
+    return 1;
+}
+
+// >= 0: length of the received message (copied to out); -1: nothing to read; -2: out too small
+// (the message stays queued; *needed = its length)
+extern "C" int64_t ha_shm_ring_recv(ha_shm_ring *r, uint64_t *out, int64_t cap_words, int64_t *needed) {
+    if (!r)
+        return -1;
+    const uint64_t cap = r->hdr->capacity;
+    const uint64_t head = r->hdr->head.load(std::memory_order_relaxed);
+    const uint64_t tail = r->hdr->tail.load(std::memory_order_acquire);
+    if (tail == head)
+        return -1;
+    const uint64_t n = r->data[head & (cap - 1)];
+    if (needed)
+        *needed = static_cast<int64_t>(n);
+    if (static_cast<int64_t>(n) > cap_words)
+        return -2;
+    for (uint64_t i = 0; i < n; ++i)
+        out[i] = r->data[(head + 1 + i) & (cap - 1)];
+    r->hdr->head.store(head + 1 + n, std::memory_order_release);
+    return static_cast<int64_t>(n);
+}
+
+// number of queued messages is not tracked; queued words > 0 <=> something to read
+extern "C" int64_t ha_shm_ring_pending_words(ha_shm_ring *r) {
+    if (!r)
+        return 0;
+    return static_cast<int64_t>(r->hdr->tail.load(std::memory_order_acquire) -
+                                r->hdr->head.load(std::memory_order_acquire));
 }

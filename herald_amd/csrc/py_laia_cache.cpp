@@ -1,7 +1,8 @@
 // pybind11 module `laia_cache`: the plugin surface of the reference (laia/src/python_binding.cc:8-23)
 // on top of ha_laia_* (libherald_amd.so).  LaiaScheduler().start(...) spawns the background thread of
 // LaiaScheduler::launch (laia/src/laia_scheduler.cc:115-169); pop() blocks (GIL released); the stream
-// is [plan, dist] per global batch and ends with [0].
+// is [plan, dist] per global batch and ends with [0].  TopkScheduler adds the top-k-table scheduler
+// (laia/src/topk_scheduler.cc) and its local-shared distribution through ha_shm_ring_*.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -9,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <queue>
@@ -20,6 +22,20 @@
 
 namespace py = pybind11;
 
+static const std::vector<int32_t> &topk_table_order(const std::string &dataset) {
+    // pre-profiled orders, topk_scheduler.cc:151-165
+    static const std::vector<int32_t> criteo{9, 13, 22, 20, 12, 21, 17, 14, 24, 3, 5, 10, 16,
+                                             15, 19, 2, 4, 11, 7, 25, 23, 18, 8, 1, 0, 6};
+    static const std::vector<int32_t> avazu{1, 2, 4, 5, 15, 7, 6, 16, 12, 0, 17, 8, 14, 10, 9, 11, 13, 3};
+    static const std::vector<int32_t> movie{0, 1};
+    static const std::vector<int32_t> criteosearch{0, 11, 3, 4, 5, 14, 1, 6, 2, 13, 16, 9, 8, 10, 12, 7, 15};
+    if (dataset == "criteo") return criteo;
+    if (dataset == "avazu") return avazu;
+    if (dataset == "movie") return movie;
+    if (dataset == "criteosearch") return criteosearch;
+    throw std::runtime_error("dataset not supported");
+}
+
 class LaiaScheduler {
 public:
     LaiaScheduler() = default;
@@ -29,11 +45,44 @@ public:
             thread_.join();
         if (h_)
             ha_laia_destroy(h_);
+        if (my_ring_)
+            ha_shm_ring_close(my_ring_);
+        for (auto *r : rings_)
+            ha_shm_ring_close(r);
     }
     // argument order of the .cc (laia_scheduler.cc:31-33): num_sample, num_table
     void start(py::array_t<uint64_t, py::array::c_style | py::array::forcecast> samples, size_t num_sample,
                size_t num_table, size_t epoch_num, size_t mini_batch_size, size_t batch_num, size_t nrank,
                size_t rank, size_t cache_size, size_t num_threads, size_t top_k_table) {
+        (void)num_threads;
+        (void)top_k_table;
+        start_impl(samples, num_sample, num_table, epoch_num, mini_batch_size, batch_num, nrank, rank, cache_size);
+    }
+    std::vector<uint64_t> pop() {
+        py::gil_scoped_release release;
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty(); });
+        auto v = std::move(q_.front());
+        q_.pop();
+        if (!error_.empty() && v.size() == 1 && v[0] == 0 && q_.empty()) {
+            const std::string e = error_;
+            lk.unlock();
+            py::gil_scoped_acquire acq;
+            throw std::runtime_error(e);
+        }
+        return v;
+    }
+    size_t length() {
+        if (local_shared_)
+            return (size_t)ha_shm_ring_pending_words(my_ring_);
+        std::lock_guard<std::mutex> lk(mu_);
+        return q_.size();
+    }
+
+protected:
+    void start_impl(py::array_t<uint64_t, py::array::c_style | py::array::forcecast> samples, size_t num_sample,
+                    size_t num_table, size_t epoch_num, size_t mini_batch_size, size_t batch_num, size_t nrank,
+                    size_t rank, size_t cache_size) {
         if (samples.ndim() != 2)
             throw std::runtime_error("Input should be 2D numpy array");
         if ((size_t)samples.shape(0) != num_sample || (size_t)samples.shape(1) != num_table)
@@ -53,26 +102,6 @@ public:
         nrank_ = nrank; rank_ = rank; num_table_ = num_table;
         thread_ = std::thread([this] { launch(); });
     }
-    std::vector<uint64_t> pop() {
-        py::gil_scoped_release release;
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [this] { return !q_.empty(); });
-        auto v = std::move(q_.front());
-        q_.pop();
-        if (!error_.empty() && v.size() == 1 && v[0] == 0 && q_.empty()) {
-            const std::string e = error_;
-            lk.unlock();
-            py::gil_scoped_acquire acq;
-            throw std::runtime_error(e);
-        }
-        return v;
-    }
-    size_t length() {
-        std::lock_guard<std::mutex> lk(mu_);
-        return q_.size();
-    }
-
-private:
     void push(std::vector<uint64_t> v) {
         std::lock_guard<std::mutex> lk(mu_);
         q_.push(std::move(v));
@@ -91,21 +120,59 @@ private:
             if (epoch_id == epoch_num_)
                 batch_num += 1;  // one more allocation for the cache prefetch (laia_scheduler.cc:126-128)
             while (batch_id < batch_num && !close_) {
-                if (ha_laia_next(h_, (int64_t)batch_id, (int64_t)mini_bs_, dist.data(), plan.data(), (int64_t)cap,
-                                 off.data()) != 0) {
+                const int rc = topk_
+                    ? ha_laia_next_topk(h_, (int64_t)batch_id, (int64_t)mini_bs_, order_.data(),
+                                        (int64_t)order_.size(), (int64_t)num_threads_, dist.data(), plan.data(),
+                                        (int64_t)cap, off.data())
+                    : ha_laia_next(h_, (int64_t)batch_id, (int64_t)mini_bs_, dist.data(), plan.data(),
+                                   (int64_t)cap, off.data());
+                if (rc != 0) {
                     error_ = std::string("ha_laia_next: ") + ha_last_error();
-                    push({0});
+                    finish();
                     return;
                 }
-                push(std::vector<uint64_t>(plan.begin() + off[rank_], plan.begin() + off[rank_ + 1]));
-                std::vector<uint64_t> d(mini_bs_);
-                for (size_t i = 0; i < mini_bs_; ++i)
-                    d[i] = (uint64_t)dist[rank_ * mini_bs_ + i];
-                push(std::move(d));
+                // standalone: this rank's stream into the queue; local-shared: every local worker's
+                // stream into its ring (topk_scheduler.cc:304-318)
+                const size_t nout = local_shared_ ? local_size_ : 1;
+                for (size_t i = 0; i < nout; ++i) {
+                    const size_t w = rank_ + i;
+                    std::vector<uint64_t> p(plan.begin() + off[w], plan.begin() + off[w + 1]);
+                    std::vector<uint64_t> d(mini_bs_);
+                    for (size_t k = 0; k < mini_bs_; ++k)
+                        d[k] = (uint64_t)dist[w * mini_bs_ + k];
+                    if (local_shared_) {
+                        if (!ring_send(rings_[i], p) || !ring_send(rings_[i], d))
+                            return;
+                    } else {
+                        push(std::move(p));
+                        push(std::move(d));
+                    }
+                }
                 ++batch_id;
             }
         }
-        push({0});  // notify python to end (laia_scheduler.cc:168)
+        finish();
+    }
+    void finish() {  // notify python to end (laia_scheduler.cc:168, topk_scheduler.cc:347-354)
+        if (local_shared_) {
+            for (auto *r : rings_)
+                ring_send(r, {0});
+        } else {
+            push({0});
+        }
+    }
+    bool ring_send(ha_shm_ring *r, const std::vector<uint64_t> &v) {
+        while (!close_) {  // poll every 10 us like push_to_local_worker (topk_scheduler.cc:204-222)
+            const int rc = ha_shm_ring_send(r, v.data(), (int64_t)v.size());
+            if (rc == 1)
+                return true;
+            if (rc < 0) {
+                error_ = "message does not fit the shared-memory ring";
+                return false;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
+        }
+        return false;
     }
     ha_laia *h_ = nullptr;
     int dev_ = 0;
@@ -116,12 +183,63 @@ private:
     std::condition_variable cv_;
     std::queue<std::vector<uint64_t>> q_;
     std::string error_;
+    // TopkScheduler state
+    bool topk_ = false, local_shared_ = false;
+    std::vector<int32_t> order_;
+    size_t num_threads_ = 1, local_rank_ = 0, local_size_ = 1;
+    std::vector<ha_shm_ring *> rings_;
+    ha_shm_ring *my_ring_ = nullptr;
 };
 
-class TopkScheduler {
+class TopkScheduler : public LaiaScheduler {
 public:
-    void start(py::args, py::kwargs) {
-        throw std::runtime_error("TopkScheduler is not built yet (SURVEY.md 8f.1); use LaiaScheduler");
+    void start(py::array_t<uint64_t, py::array::c_style | py::array::forcecast> samples, size_t num_sample,
+               size_t num_table, size_t epoch_num, size_t mini_batch_size, size_t batch_num, size_t nrank,
+               size_t rank, size_t cache_size, size_t num_threads, const std::string &dataset,
+               size_t top_k_table, bool local_shared, size_t local_rank, size_t local_size) {
+        const auto &order = topk_table_order(dataset);
+        size_t k = top_k_table ? top_k_table : num_table;    // topk_scheduler.cc:131-133
+        k = std::min(k, order.size());                        // :167-168
+        order_.assign(order.begin(), order.begin() + k);
+        topk_ = true;
+        num_threads_ = num_threads;
+        local_shared_ = local_shared;
+        local_rank_ = local_rank;
+        local_size_ = local_size;
+        if (local_shared_) {
+            if (local_rank_ == 0) {  // rank 0 creates every local worker's ring (:68-84)
+                for (size_t i = 0; i < local_size_; ++i) {
+                    auto *r = ha_shm_ring_open(("laia_cache_" + std::to_string(i)).c_str(), 1, (int64_t)1 << 24);
+                    if (!r)
+                        throw std::runtime_error(std::string("ha_shm_ring_open: ") + ha_last_error());
+                    rings_.push_back(r);
+                }
+            }
+            my_ring_ = ha_shm_ring_open(("laia_cache_" + std::to_string(local_rank_)).c_str(), 0, 0);
+            if (!my_ring_)
+                throw std::runtime_error(std::string("ha_shm_ring_open: ") + ha_last_error());
+            if (local_rank_ != 0)
+                return;  // only local rank 0 schedules (:176-180)
+        }
+        start_impl(samples, num_sample, num_table, epoch_num, mini_batch_size, batch_num, nrank, rank, cache_size);
+    }
+    std::vector<uint64_t> pop_from_local_worker() {
+        if (!local_shared_)
+            throw std::runtime_error("pop_from_local_worker needs local_shared");
+        py::gil_scoped_release release;
+        std::vector<uint64_t> buf(1 << 16);
+        for (;;) {  // polls every 10 us (topk_scheduler.cc:236-260)
+            int64_t need = 0;
+            const int64_t n = ha_shm_ring_recv(my_ring_, buf.data(), (int64_t)buf.size(), &need);
+            if (n >= 0) {
+                buf.resize((size_t)n);
+                return buf;
+            }
+            if (n == -2)
+                buf.resize((size_t)need + 16);
+            else
+                std::this_thread::sleep_for(std::chrono::microseconds(10));
+        }
     }
 };
 
@@ -132,5 +250,10 @@ PYBIND11_MODULE(laia_cache, m) {
         .def("start", &LaiaScheduler::start)
         .def("pop", &LaiaScheduler::pop)
         .def("length", &LaiaScheduler::length);
-    py::class_<TopkScheduler>(m, "TopkScheduler").def(py::init<>()).def("start", &TopkScheduler::start);
+    py::class_<TopkScheduler>(m, "TopkScheduler")
+        .def(py::init<>())
+        .def("start", &TopkScheduler::start)
+        .def("pop", &TopkScheduler::pop)
+        .def("pop_from_local_worker", &TopkScheduler::pop_from_local_worker)
+        .def("length", &TopkScheduler::length);
 }

@@ -5,6 +5,12 @@ Reference surfaces mirrored (paths relative to /root/reference):
         batch_num, nrank, rank, cache_size, num_threads, top_k_table) / .pop() / .length()
         laia/src/python_binding.cc:8-23, laia/src/laia_scheduler.cc:31-113.  The stream protocol is the
         reference's: alternating [plan, dist] lists, terminated by [0]; pop() blocks.
+  laia_cache.TopkScheduler().start(samples, num_sample, num_table, epoch_num, mini_batch_size,
+        batch_num, nrank, rank, cache_size, num_threads, dataset, top_k_table, local_shared,
+        local_rank, local_size) / .pop() / .pop_from_local_worker() / .length()
+        laia/src/python_binding.cc:16-22, laia/src/topk_scheduler.cc:47-354.  With local_shared the
+        scheduler runs on local rank 0 only and every local worker i receives its stream through the
+        shared-memory ring "laia_cache_<i>" (laia/include/share_mem.h:40-193).
   LAIAScheduler(sparse_data, batch_size, ...)   python/hetu/laia/laia_dataloader.py:29-169
         (5-deep queue, the first plan is discarded so that dist(b) is paired with plan(b+1)).
 
@@ -15,6 +21,7 @@ reference, the scheduler runs ahead of training in a background thread.
 import ctypes
 import queue
 import threading
+import time
 
 import numpy as np
 
@@ -68,15 +75,24 @@ class LaiaScheduler:
                 if epoch_id == epoch_num:
                     batch_num += 1          # one more allocation for the cache prefetch (:126-128)
                 while batch_id < batch_num and not self._close:
-                    rc = self._L.ha_laia_next(self._h, batch_id, mini_bs, dist.ctypes.data, plan.ctypes.data, cap,
-                                              off.ctypes.data)
+                    rc = self._next(batch_id, mini_bs, dist, plan, cap, off)
                     if rc != 0:
                         raise _lib.HeraldAmdError("ha_laia_next failed: %s" % self._L.ha_last_error().decode())
-                    self._q.put([int(x) for x in plan[off[rank]:off[rank + 1]]])
-                    self._q.put([int(x) for x in dist[rank * mini_bs:(rank + 1) * mini_bs]])
+                    self._emit(plan, dist, off, mini_bs, rank)
                     batch_id += 1
         except Exception as e:   # surfaced by pop()
             self._error = e
+        self._finish()
+
+    def _next(self, batch_id, mini_bs, dist, plan, cap, off):
+        return self._L.ha_laia_next(self._h, batch_id, mini_bs, dist.ctypes.data, plan.ctypes.data, cap,
+                                    off.ctypes.data)
+
+    def _emit(self, plan, dist, off, mini_bs, rank):
+        self._q.put([int(x) for x in plan[off[rank]:off[rank + 1]]])
+        self._q.put([int(x) for x in dist[rank * mini_bs:(rank + 1) * mini_bs]])
+
+    def _finish(self):
         self._q.put([0])
 
     def pop(self):
@@ -109,6 +125,152 @@ class LaiaScheduler:
             pass
 
 
+# pre-profiled table orders (laia/src/topk_scheduler.cc:151-165) and how many of them count
+# (python/hetu/laia/laia_dataloader.py:19-24)
+TOPK_TABLE_ORDER = {
+    "criteo": [9, 13, 22, 20, 12, 21, 17, 14, 24, 3, 5, 10, 16, 15, 19, 2, 4, 11, 7, 25, 23, 18, 8, 1, 0, 6],
+    "avazu": [1, 2, 4, 5, 15, 7, 6, 16, 12, 0, 17, 8, 14, 10, 9, 11, 13, 3],
+    "movie": [0, 1],
+    "criteosearch": [0, 11, 3, 4, 5, 14, 1, 6, 2, 13, 16, 9, 8, 10, 12, 7, 15],
+}
+top_k_table = {"criteo": 20, "avazu": 17, "movie": 2, "criteosearch": 16}
+local_worker_num = 8
+_RING_WORDS = 1 << 24   # 128 MiB of uint64 words per local worker (the reference maps 1 GiB, :76)
+
+
+class _Ring:
+    """ha_shm_ring_* : message-framed single-producer / single-consumer ring in POSIX shared memory."""
+
+    def __init__(self, L, name, create):
+        self._L = L
+        self._h = L.ha_shm_ring_open(name.encode(), 1 if create else 0, _RING_WORDS if create else 0)
+        if not self._h:
+            raise _lib.HeraldAmdError("ha_shm_ring_open(%s): %s" % (name, L.ha_last_error().decode()))
+        self._buf = np.empty(1 << 16, dtype=np.uint64)
+
+    def send(self, words, closing=lambda: False):
+        """Blocks (polling every 10 us like push_to_local_worker, topk_scheduler.cc:204-222)."""
+        a = np.ascontiguousarray(np.asarray(words, dtype=np.uint64))
+        while not closing():
+            rc = self._L.ha_shm_ring_send(self._h, a.ctypes.data, a.size)
+            if rc == 1:
+                return True
+            if rc < 0:
+                raise _lib.HeraldAmdError("message of %d words does not fit the ring" % a.size)
+            time.sleep(10e-6)
+        return False
+
+    def recv(self):
+        """Blocks until a message is there (pop_from_local_worker, topk_scheduler.cc:236-260)."""
+        need = ctypes.c_int64(0)
+        while True:
+            n = self._L.ha_shm_ring_recv(self._h, self._buf.ctypes.data, self._buf.size, ctypes.byref(need))
+            if n >= 0:
+                return [int(x) for x in self._buf[:n]]
+            if n == -2:
+                self._buf = np.empty(int(need.value) + 16, dtype=np.uint64)
+                continue
+            time.sleep(10e-6)
+
+    def pending(self):
+        return int(self._L.ha_shm_ring_pending_words(self._h))
+
+    def close(self):
+        if self._h:
+            self._L.ha_shm_ring_close(self._h)
+            self._h = None
+
+
+class TopkScheduler(LaiaScheduler):
+    """laia_cache.TopkScheduler: LaiaScheduler restricted to the dataset's pre-profiled top-k tables,
+    with per-thread quotas and own-sample plans (ha_laia_next_topk), standalone or local-shared."""
+
+    def start(self, samples, num_sample, num_table, epoch_num, mini_batch_size, batch_num, nrank, rank,
+              cache_size, num_threads, dataset, top_k_table, local_shared=False, local_rank=0, local_size=1,
+              key_limit=None, device=None):
+        if dataset not in TOPK_TABLE_ORDER:
+            raise ValueError("dataset not supported")                           # :163-166
+        order = TOPK_TABLE_ORDER[dataset]
+        k = int(top_k_table) if top_k_table else int(num_table)                  # :131-133
+        k = min(k, len(order))                                                   # :167-168
+        self._order = np.ascontiguousarray(np.asarray(order[:k], dtype=np.int32))
+        self._nt = int(num_threads)
+        self._local_shared, self._local_rank, self._local_size = bool(local_shared), int(local_rank), int(local_size)
+        self._rings, self._my_ring = [], None
+        if self._local_shared:
+            if self._local_rank == 0:
+                # rank 0 creates every local worker's ring, then opens its own (:68-84)
+                self._rings = [_Ring(self._L, "laia_cache_%d" % i, True) for i in range(self._local_size)]
+            self._my_ring = _Ring(self._L, "laia_cache_%d" % self._local_rank, False)
+            if self._local_rank != 0:
+                return                                                           # only local rank 0 schedules (:176-180)
+        super().start(samples, num_sample, num_table, epoch_num, mini_batch_size, batch_num, nrank, rank,
+                      cache_size, num_threads, k, key_limit=key_limit, device=device)
+
+    def _next(self, batch_id, mini_bs, dist, plan, cap, off):
+        return self._L.ha_laia_next_topk(self._h, batch_id, mini_bs, self._order.ctypes.data, self._order.size,
+                                         self._nt, dist.ctypes.data, plan.ctypes.data, cap, off.ctypes.data)
+
+    def _emit(self, plan, dist, off, mini_bs, rank):
+        if not self._local_shared:
+            return super()._emit(plan, dist, off, mini_bs, rank)
+        for i in range(self._local_size):                                        # :308-318
+            w = rank + i
+            if not (self._rings[i].send(plan[off[w]:off[w + 1]], lambda: self._close) and
+                    self._rings[i].send(dist[w * mini_bs:(w + 1) * mini_bs], lambda: self._close)):
+                return
+
+    def _finish(self):
+        if not self._local_shared:
+            return super()._finish()
+        for r in self._rings:                                                    # :350-353
+            r.send([0], lambda: self._close)
+
+    def pop_from_local_worker(self):
+        assert self._local_shared
+        item = self._my_ring.recv()
+        if self._error is not None:
+            raise self._error
+        return item
+
+    def length(self):
+        if not self._local_shared:                                               # :187-193
+            return super().length()
+        return self._my_ring.pending()
+
+    def report_cache_perf(self):
+        """Average miss_pull / miss_push / update_pull / update_push per worker (:504-527)."""
+        if self._thread is not None:
+            self._thread.join()
+        W = self._cfg[3]
+        c = np.zeros(4 * W, dtype=np.int64)
+        _lib.check(self._L.ha_laia_counters(self._h, c.ctypes.data), "ha_laia_counters")
+        c = c.reshape(4, W)
+        return {"miss_pull": int(c[0].sum() // W), "miss_push": int(c[1].sum() // W),
+                "update_pull": int(c[2].sum() // W), "update_push": int(c[3].sum() // W),
+                "per_worker": {"miss_pull": c[0].tolist(), "miss_push": c[1].tolist(),
+                               "update_pull": c[2].tolist(), "update_push": c[3].tolist()}}
+
+    def close(self):
+        super().close()
+        if self._my_ring is not None:
+            self._my_ring.close()
+            self._my_ring = None
+        for r in self._rings:
+            r.close()
+        self._rings = []
+
+
+def topk_num_threads(mini_batch_size, wanted=80):
+    """The reference starts TopkScheduler with 80 pool threads (laia_dataloader.py:85); its per-thread
+    quotas only add up when the thread count divides the mini batch (otherwise it writes dist[-1]),
+    so the glue takes the largest divisor of mini_batch_size that is <= wanted."""
+    for nt in range(min(wanted, mini_batch_size), 0, -1):
+        if mini_batch_size % nt == 0:
+            return nt
+    return 1
+
+
 class LAIAScheduler:
     """python/hetu/laia/laia_dataloader.py:29-169 on top of the LaiaScheduler above."""
 
@@ -118,10 +280,10 @@ class LAIAScheduler:
         self.drop_last = drop_last
         self.init = False
         self.dataset = dataset
-        if local_shared:
-            raise NotImplementedError("TopkScheduler / local-shared distribution is not built yet (SURVEY 8f.1)")
+        self.local_shared = local_shared
 
-    def start(self, nrank, rank, cache_limit, dataset_num=3, epoch_num=-1, key_limit=None):
+    def start(self, nrank, rank, cache_limit, dataset_num=3, epoch_num=-1, key_limit=None, local_rank=0,
+              local_size=local_worker_num):
         assert not self.init, "LAIA scheduler can only be initialized once"
         self.samples_num = len(self.sparse_data) // nrank
         self.queue_size = 5
@@ -129,10 +291,20 @@ class LAIAScheduler:
         assert self.batch_size > 0, "Batch size %d invalid." % self.batch_size
         self.batch_num = (int(np.ceil(self.samples_num / self.batch_size)) if not self.drop_last
                           else self.samples_num // self.batch_size)
-        self.sched = LaiaScheduler()
-        self.sched.start(self.sparse_data, self.sparse_data.shape[0], self.sparse_data.shape[1], epoch_num,
-                         self.batch_size, self.batch_num, int(nrank), int(rank), int(cache_limit), 16, 24,
-                         key_limit=key_limit)
+        if not self.local_shared:
+            self.sched = LaiaScheduler()
+            self.sched.start(self.sparse_data, self.sparse_data.shape[0], self.sparse_data.shape[1], epoch_num,
+                             self.batch_size, self.batch_num, int(nrank), int(rank), int(cache_limit), 16, 24,
+                             key_limit=key_limit)
+        else:
+            # only local rank 0 schedules; the others open their ring (laia_dataloader.py:72-95)
+            self.sched = TopkScheduler()
+            if local_rank != 0:
+                time.sleep(3)      # "allow local major worker to start first"
+            self.sched.start(self.sparse_data, self.sparse_data.shape[0], self.sparse_data.shape[1], epoch_num,
+                             self.batch_size, self.batch_num, int(nrank), int(rank), int(cache_limit),
+                             topk_num_threads(self.batch_size), self.dataset, int(top_k_table[self.dataset]),
+                             True, int(local_rank), int(local_size), key_limit=key_limit)
         self.channel_close = False
         self.input_index, self.comm_plan, self.arr_map = [], [], {}
         for i in range(self.queue_size):
@@ -148,7 +320,7 @@ class LAIAScheduler:
     def _channel_get(self):
         if self.channel_close:
             raise RuntimeError("Channle have been closed, but still try to get value from it")
-        res = self.sched.pop()
+        res = self.sched.pop() if not self.local_shared else self.sched.pop_from_local_worker()
         assert isinstance(res, list)
         if len(res) == 1 and res[0] == 0:
             self.channel_close = True

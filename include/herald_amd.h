@@ -364,6 +364,33 @@ int ha_laia_next(ha_laia *sched, int64_t batch_id, int64_t mini_bs,
 int64_t ha_laia_snapshot_keys(ha_laia *sched, int64_t worker, int32_t *out,
                               int64_t cap);
 
+/* TopkScheduler::get_dist + the snapshot update of its launch() for one global batch
+ * (laia/src/topk_scheduler.cc:362-502, 319-345): only the tables table_order[0..top_k) are scored, the
+ * batch and every worker's quota are cut into num_threads slices assigned independently, a sample is
+ * offered to the workers starting at the one that first reached its top score, and plan[w] = keys of w's
+ * own samples that w's snapshot holds valid.  Outputs as ha_laia_next.  num_threads must divide the
+ * work so that no slice holds more samples than nrank x its quota (the reference writes out of bounds
+ * there). */
+int ha_laia_next_topk(ha_laia *sched, int64_t batch_id, int64_t mini_bs,
+                      const int32_t *table_order, int64_t top_k, int64_t num_threads,
+                      int64_t *dist_out, uint64_t *plan_out, int64_t plan_cap_elems,
+                      int64_t *plan_off);
+/* out[4*nrank] = miss_pull, miss_push, update_pull, update_push per worker, accumulated over the
+ * batches scheduled so far (TopkScheduler::report_cache_perf, topk_scheduler.cc:504-527). */
+int ha_laia_counters(ha_laia *sched, int64_t *out);
+
+/* Local-shared plan distribution (laia/include/share_mem.h:40-193, ring_buffer.h:13-125): a
+ * single-producer / single-consumer ring of uint64 words in POSIX shared memory, message-framed.
+ * The scheduler of local rank 0 creates "laia_cache_<i>" for every local worker i and sends it its
+ * [plan, dist] stream; worker i opens its ring and receives.  send: 1 sent / 0 no room yet / -1 never
+ * fits.  recv: message length / -1 empty / -2 `out` too small (*needed = length). */
+typedef struct ha_shm_ring ha_shm_ring;
+ha_shm_ring *ha_shm_ring_open(const char *name, int create, int64_t capacity_words);
+void ha_shm_ring_close(ha_shm_ring *ring);
+int ha_shm_ring_send(ha_shm_ring *ring, const uint64_t *words, int64_t n);
+int64_t ha_shm_ring_recv(ha_shm_ring *ring, uint64_t *out, int64_t cap_words, int64_t *needed);
+int64_t ha_shm_ring_pending_words(ha_shm_ring *ring);
+
 /* Development aid: ha_sgd_apply with per-wave time stamps, dbg[4*n] u64 =
  * {s_memrealtime start, end (10 ns ticks), role/len, shader cycles} per sorted position. */
 int ha_debug_apply_timeline(float *table, int64_t rows, int64_t width,

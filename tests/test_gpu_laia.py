@@ -61,3 +61,67 @@ def test_laia_python_glue_pairs_dist_with_next_plan(dev):
         assert sched.get_comm_plan(b) == model[2 * b + 2]
     sched.step_forward(0)
     sched.sched.close()
+
+
+# ---- TopkScheduler (laia/src/topk_scheduler.cc) -------------------------------------------------------
+def _drain(pop):
+    got = []
+    while True:
+        item = pop()
+        got.append(item)
+        if item == [0]:
+            return got
+
+
+@pytest.mark.parametrize("dataset,T,top_k,W,rank,mini_bs,nt", [
+    ("criteo", 26, 20, 4, 1, 32, 4), ("criteo", 26, 0, 8, 6, 16, 16), ("avazu", 18, 17, 2, 0, 30, 5),
+    ("movie", 2, 2, 3, 2, 12, 1), ("criteosearch", 17, 16, 4, 3, 24, 8)])
+def test_topk_stream_and_counters_match_model(dev, dataset, T, top_k, W, rank, mini_bs, nt):
+    samples, key_limit = _samples(1500, T, 9000, seed=W * 7 + T)
+    model = laia_model.TopkSchedulerModel(samples, 2, mini_bs, 5, W, rank, 300, nt, dataset, top_k)
+    want = model.emit()[rank]
+    s = hlaia.TopkScheduler()
+    s.start(samples, 1500, T, 2, mini_bs, 5, W, rank, 300, nt, dataset, top_k, key_limit=key_limit)
+    got = _drain(s.pop)
+    assert len(got) == len(want) == 2 * (5 * 2 + 1) + 1
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "stream element %d differs (%s)" % (k, "plan" if k % 2 == 0 else "dist")
+    perf = s.report_cache_perf()
+    s.close()
+    assert perf["per_worker"] == {"miss_pull": model.miss_pull, "miss_push": model.miss_push,
+                                  "update_pull": model.update_pull, "update_push": model.update_push}
+    # every sample of a batch is assigned exactly once
+    B = W * mini_bs
+    m2 = laia_model.TopkSchedulerModel(samples, 1, mini_bs, 1, W, rank, 300, nt, dataset, top_k)
+    _, dist = m2.get_dist(0)
+    assert sorted(p for d in dist for p in d) == list(range(B))
+
+
+def test_topk_rejects_quota_overflow(dev):
+    samples, key_limit = _samples(400, 2, 300, seed=3)
+    s = hlaia.TopkScheduler()
+    # 3 threads do not divide mini_bs 16: threads 1 and 2 get 21 samples for 4 x 5 slots
+    s.start(samples, 400, 2, 1, 16, 2, 4, 0, 50, 3, "movie", 2, key_limit=key_limit)
+    with pytest.raises(Exception, match="quota"):
+        _drain(s.pop)
+    s.close()
+    with pytest.raises(ValueError):
+        laia_model.TopkSchedulerModel(samples, 1, 16, 2, 4, 0, 50, 3, "movie", 2)
+
+
+def test_topk_local_shared_rings(dev):
+    """local rank 0 schedules for the node's workers and hands each its stream through its ring."""
+    T, W, mini_bs, nt = 18, 4, 20, 4
+    samples, key_limit = _samples(1000, T, 5000, seed=21)
+    model = laia_model.TopkSchedulerModel(samples, 1, mini_bs, 4, W, 2, 200, nt, "avazu", 17)
+    want = model.emit(ranks=[2, 3])         # node of two workers whose first global rank is 2
+    major = hlaia.TopkScheduler()
+    major.start(samples, 1000, T, 1, mini_bs, 4, W, 2, 200, nt, "avazu", 17, True, 0, 2, key_limit=key_limit)
+    minor = hlaia.TopkScheduler()
+    minor.start(samples, 1000, T, 1, mini_bs, 4, W, 2, 200, nt, "avazu", 17, True, 1, 2, key_limit=key_limit)
+    got1 = _drain(minor.pop_from_local_worker)
+    got0 = _drain(major.pop_from_local_worker)
+    minor.close()
+    major.close()
+    assert got0 == want[2]
+    assert got1 == want[3]

@@ -31,7 +31,8 @@ def test_plugin_surface_matches_reference():
     assert hasattr(hetu_cache, "Embedding") and hasattr(hetu_cache, "_waittype") and hasattr(hetu_cache, "debug")
     for name in ("start", "pop", "length"):
         assert hasattr(laia_cache.LaiaScheduler, name)
-    assert hasattr(laia_cache, "TopkScheduler")
+    for name in ("start", "pop", "pop_from_local_worker", "length"):
+        assert hasattr(laia_cache.TopkScheduler, name)
 
 
 @pytest.mark.gpu
@@ -97,5 +98,36 @@ def test_laia_cache_plugin_against_model(dev):
         if got[-1] == [0]:
             break
     assert got == want
-    with pytest.raises(RuntimeError):
-        laia_cache.TopkScheduler().start()
+
+
+@pytest.mark.gpu
+def test_laia_cache_plugin_topk_against_model(dev):
+    from oracle import laia_model
+    _, laia_cache = _import()
+    rng = np.random.default_rng(33)
+    S, T, W, mini_bs, batch_num, epochs, cache_size, nt = 1200, 26, 4, 16, 4, 1, 250, 8
+    samples = np.stack([j * 300 + np.minimum(rng.zipf(1.3, size=S) - 1, 299) for j in range(T)], axis=1).astype(np.uint64)
+    # standalone queue mode
+    want = laia_model.TopkSchedulerModel(samples, epochs, mini_bs, batch_num, W, 1, cache_size, nt, "criteo", 20).emit()[1]
+    s = laia_cache.TopkScheduler()
+    s.start(samples.astype(np.intc), S, T, epochs, mini_bs, batch_num, W, 1, cache_size, nt, "criteo", 20, False, 0, 1)
+    got = []
+    while True:
+        got.append(list(s.pop()))
+        if got[-1] == [0]:
+            break
+    assert got == want
+    # local-shared mode: local rank 0 (global rank 2) feeds the rings of the node's two workers
+    want = laia_model.TopkSchedulerModel(samples, epochs, mini_bs, batch_num, W, 2, cache_size, nt, "criteo", 20).emit(ranks=[2, 3])
+    major, minor = laia_cache.TopkScheduler(), laia_cache.TopkScheduler()
+    major.start(samples.astype(np.intc), S, T, epochs, mini_bs, batch_num, W, 2, cache_size, nt, "criteo", 20, True, 0, 2)
+    minor.start(samples.astype(np.intc), S, T, epochs, mini_bs, batch_num, W, 2, cache_size, nt, "criteo", 20, True, 1, 2)
+    for sched, rank in ((minor, 3), (major, 2)):
+        got = []
+        while True:
+            got.append(list(sched.pop_from_local_worker()))
+            if got[-1] == [0]:
+                break
+        assert got == want[rank]
+    with pytest.raises(RuntimeError, match="dataset not supported"):
+        laia_cache.TopkScheduler().start(samples.astype(np.intc), S, T, 1, mini_bs, 1, W, 0, 10, 1, "nope", 2, False, 0, 1)
