@@ -42,6 +42,8 @@ def parse_args():
     p.add_argument("--distinct-batches", type=int, default=1024)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true")
+    p.add_argument("--no-cache-tier", action="store_true",
+                   help="skip the secondary measurement of the LRU cache tier (limit 0.1 x rows)")
     p.add_argument("--graph-steps", type=int, default=32,
                    help="steps captured per hipGraph (1 = eager launches)")
     return p.parse_args()
@@ -126,6 +128,43 @@ def cpu_baseline(args, ids_host):
                   "sparse SGD (1 thread, as cpu_SGDOptimizerSparseUpdate mandates), %.1f ms/step"
                   % (steps, args.batch, args.width, rows_cpu, cpu.num_threads(), 1e3 * el / steps),
     }
+
+
+def cache_tier(args, table, ids_dev, out, grad, dev):
+    """Secondary line: the same batches through the HET cache tier of configs[1] (LRU, limit 0.1 x rows,
+    bound 100; cache.cc:60-257): one embedding_lookup + one embedding_update per batch, keys and
+    gradients resident in HBM.  Runs last (it takes the table over as its server store)."""
+    from herald_amd import cache as hcache
+    n = ids_dev.shape[1]
+    versions = torch.zeros(args.rows, dtype=torch.int64, device=dev)
+    hcache.register_table(0, table, versions)
+    limit = int(0.1 * args.rows)
+    c = hcache.CacheSparseTable(limit, args.rows, args.width, 0, "LRU", bound=100, max_batch=n, device=dev)
+    nb = min(ids_dev.shape[0], 512)
+
+    def step(k):
+        c.embedding_lookup(ids_dev[k % nb], out)
+        c.embedding_update(ids_dev[k % nb], grad)
+
+    for k in range(64):
+        step(k)
+    torch.cuda.synchronize()
+    steps = 256
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(64 + k)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    c.perf_enabled(True)       # the counters are read back per call: outside the timed loop
+    for k in range(32):
+        step(64 + steps + k)
+    torch.cuda.synchronize()
+    pulls = [r for r in c.perf() if r["type"] == "Pull"]
+    miss = float(np.mean([r["num_miss"] / max(r["num_unique"], 1) for r in pulls])) if pulls else None
+    return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps, "policy": "LRU",
+            "limit_rows": limit, "bound": 100, "steps": steps, "unique_miss_rate": miss,
+            "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
+                    "(~23 small launches, launch-latency bound); not part of `value`"}
 
 
 def main():
@@ -287,6 +326,8 @@ def main():
     }
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ids_host)
+    if not args.no_cache_tier:
+        result["cache_tier"] = cache_tier(args, table, ids_dev, out, grads[0], dev)
     print(json.dumps(result))
 
 
