@@ -88,6 +88,7 @@ class _CacheBase:
         self._pull_bound = self._push_bound = 5
         self.perf_enabled = False
         self._perf = []
+        self._last_lookup = None
         self._store = None
         self.stream = stream
         if self.node_id in _TABLES:
@@ -195,6 +196,8 @@ class _CacheBase:
             check(self._L.ha_cache_lookup(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
                                           ctypes.c_void_p(dest.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
                   "ha_cache_lookup")
+            # an update of the very same (unmodified) device key tensor can reuse this call's index plan
+            self._last_lookup = None if keep else (k.data_ptr(), k.numel(), k._version)
             if self.perf_enabled:
                 self._perf_record(0)
             w = Wait(s, keep + [k, dest])
@@ -219,15 +222,23 @@ class _CacheBase:
             k, kind = self._keys(keys, keep)
             g = self._grads(grads, keep)
             assert g.numel() == k.numel() * self._width
-            check(self._L.ha_cache_update(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
-                                          ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
-                  "ha_cache_update")
+            same = k.numel() > 0 and self._last_lookup == (k.data_ptr(), k.numel(), k._version)
+            self._last_lookup = None
+            if same:
+                check(self._L.ha_cache_update_same_keys(self._h, k.numel(), ctypes.c_void_p(g.data_ptr()),
+                                                        ctypes.c_void_p(s.cuda_stream)),
+                      "ha_cache_update_same_keys")
+            else:
+                check(self._L.ha_cache_update(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
+                                              ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
+                      "ha_cache_update")
             if self.perf_enabled:
                 self._perf_record(1)
             return Wait(s, keep + [k, g])
 
     def embedding_update_with_push_keys(self, keys, push_keys, grads):
         """As embedding_update, the push set being the lines listed in the (sorted) push keys (cache.cc:248-335)."""
+        self._last_lookup = None
         keep = []
         s = self._stream()
         with torch.cuda.stream(s):
@@ -244,6 +255,7 @@ class _CacheBase:
 
     def embedding_push_pull(self, pullkeys, dest, pushkeys, grads):
         """Push the gradients of pushkeys, then pull pullkeys into dest (cache.cc:356-422)."""
+        self._last_lookup = None
         keep = []
         s = self._stream()
         with torch.cuda.stream(s):

@@ -129,12 +129,14 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *s_w, u
 }
 
 // ---- probe: slot of every unique key --------------------------------------------------------------
-__global__ __launch_bounds__(256) void cache_probe_kernel(
+// (bodies take the calling thread's index and the number of threads that share the loop, so that the
+// same code runs as its own grid or as one phase of a single-workgroup bookkeeping kernel)
+__device__ __forceinline__ void cache_probe_body(
     CacheCtl *ctl, const PlanHeader *hdr, const uint32_t *uniq,
     const int32_t *slot_of, long long length, int bypass, int32_t *uslot,
-    uint32_t *flag) {
+    uint32_t *flag, int tid0, int nthr) {
     const int U = static_cast<int>(hdr->n_unique);
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
+    for (int u = tid0; u < U; u += nthr) {
         const uint32_t k = uniq[u];
         int s = -1;
         if (!bypass && k < static_cast<unsigned long long>(length))
@@ -142,12 +144,19 @@ __global__ __launch_bounds__(256) void cache_probe_kernel(
         uslot[u] = s;
         flag[u] = s < 0 ? 1u : 0u;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (tid0 == 0)
         ctl->U = U;
+}
+__global__ __launch_bounds__(256) void cache_probe_kernel(
+    CacheCtl *ctl, const PlanHeader *hdr, const uint32_t *uniq,
+    const int32_t *slot_of, long long length, int bypass, int32_t *uslot,
+    uint32_t *flag) {
+    cache_probe_body(ctl, hdr, uniq, slot_of, length, bypass, uslot, flag,
+                     blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // exclusive scan of flag[0..U) -> rank, total -> *total_out.  Single workgroup.
-__global__ __launch_bounds__(1024) void cache_scan_kernel(
+__device__ __forceinline__ void cache_scan_body(
     const PlanHeader *hdr, const uint32_t *flag, uint32_t *rank, long long *total_out,
     long long *nhit_out) {
     __shared__ uint32_t s_w[16];
@@ -168,14 +177,19 @@ __global__ __launch_bounds__(1024) void cache_scan_kernel(
             *nhit_out = U - static_cast<long long>(carry);
     }
 }
+__global__ __launch_bounds__(1024) void cache_scan_kernel(
+    const PlanHeader *hdr, const uint32_t *flag, uint32_t *rank, long long *total_out,
+    long long *nhit_out) {
+    cache_scan_body(hdr, flag, rank, total_out, nhit_out);
+}
 
 // hits: LRU touch (stamp + log append).  misses: take a slot from the free stack, new line.
-__global__ __launch_bounds__(256) void cache_assign_kernel(
-    const CacheCtl *ctl, CacheCtl *ctl_mut, Cache c, const uint32_t *uniq, const uint32_t *flag,
-    const uint32_t *rank, int miss_state) {
+__device__ __forceinline__ void cache_assign_body(
+    const CacheCtl *ctl, CacheCtl *ctl_mut, const Cache &c, const uint32_t *uniq, const uint32_t *flag,
+    const uint32_t *rank, int miss_state, int tid0, int nthr) {
     const int U = static_cast<int>(ctl->U);
     const long long clock = ctl->clock, tail = ctl->log_tail, ftop = ctl->free_top;
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
+    for (int u = tid0; u < U; u += nthr) {
         if (!flag[u]) {
             const int s = c.uslot[u];
             const unsigned long long st = static_cast<unsigned long long>(clock + u);
@@ -218,13 +232,22 @@ __global__ __launch_bounds__(256) void cache_assign_kernel(
         }
     }
 }
+__global__ __launch_bounds__(256) void cache_assign_kernel(
+    const CacheCtl *ctl, CacheCtl *ctl_mut, Cache c, const uint32_t *uniq, const uint32_t *flag,
+    const uint32_t *rank, int miss_state) {
+    cache_assign_body(ctl, ctl_mut, c, uniq, flag, rank, miss_state, blockIdx.x * 256 + threadIdx.x,
+                      gridDim.x * 256);
+}
 
 // Makes the touches of cache_assign_kernel permanent: the stamps clock .. clock+U-1 are used, the LRU
 // log grew by one entry per hit.
-__global__ void cache_commit_touch_kernel(CacheCtl *ctl, Cache c) {
+__device__ __forceinline__ void cache_commit_touch_body(CacheCtl *ctl, const Cache &c) {
     if (c.policy == kLRU)
         ctl->log_tail += ctl->nhit;
     ctl->clock += ctl->U;
+}
+__global__ void cache_commit_touch_kernel(CacheCtl *ctl, Cache c) {
+    cache_commit_touch_body(ctl, c);
 }
 // push_pull: the pull phase's new lines keep their stack entries out of reach of the push phase
 __global__ void cache_retire_kernel(CacheCtl *ctl, int retire) {
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(256) void cache_dest_kernel(Cache c, const int32_t 
 // this batch evicts the oldest line of the lowest non-empty bucket (lfu_cache.cc:31-42,
 // lfuopt_cache.cc:48-60): argmin (use, stamp) over the resident, non-stored lines.  Single workgroup;
 // exits immediately when the situation does not arise.
-__global__ __launch_bounds__(1024) void cache_scan_victim_kernel(CacheCtl *ctl, Cache c) {
+__device__ __forceinline__ void cache_scan_victim_body(CacheCtl *ctl, const Cache &c) {
     __shared__ unsigned long long s_best[16];
     __shared__ int s_slot[16];
     if (threadIdx.x == 0)
@@ -341,10 +364,13 @@ __global__ __launch_bounds__(1024) void cache_scan_victim_kernel(CacheCtl *ctl, 
         ctl->scan_victim = s_slot[0];
     }
 }
+__global__ __launch_bounds__(1024) void cache_scan_victim_kernel(CacheCtl *ctl, Cache c) {
+    cache_scan_victim_body(ctl, c);
+}
 
 // batchedInsert of the misses (sorted order) + LRU eviction + log compaction.  Single workgroup.
-__global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
-    CacheCtl *ctl, Cache c, const uint32_t *uniq, const uint32_t *flag,
+__device__ __forceinline__ void cache_insert_evict_body(
+    CacheCtl *ctl, const Cache &c, const uint32_t *uniq, const uint32_t *flag,
     const uint32_t *rank, int do_insert) {
     __shared__ uint32_t s_w[16];
     __shared__ long long s_head, s_need, s_clean, s_dirty;
@@ -544,9 +570,14 @@ __global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
         }
     }
 }
+__global__ __launch_bounds__(1024) void cache_insert_evict_kernel(
+    CacheCtl *ctl, Cache c, const uint32_t *uniq, const uint32_t *flag,
+    const uint32_t *rank, int do_insert) {
+    cache_insert_evict_body(ctl, c, uniq, flag, rank, do_insert);
+}
 
 // after a lookup: report (type 0)
-__global__ void cache_report_pull_kernel(CacheCtl *ctl, Cache c, long long n) {
+__device__ __forceinline__ void cache_report_pull_body(CacheCtl *ctl, const Cache &c, long long n) {
     ctl->perf[0] = 0;
     ctl->perf[1] = n;
     ctl->perf[2] = ctl->U;
@@ -556,15 +587,152 @@ __global__ void cache_report_pull_kernel(CacheCtl *ctl, Cache c, long long n) {
     ctl->perf[6] = ctl->size == c.limit;
     ctl->pulled = 0;
 }
+__global__ void cache_report_pull_kernel(CacheCtl *ctl, Cache c, long long n) {
+    cache_report_pull_body(ctl, c, n);
+}
+
+// ---- fused lookup: one bookkeeping workgroup + one row kernel ---------------------------------------
+// ha_cache_lookup = plan (2 launches) + cache_lookup_book_kernel + cache_lookup_rows_kernel.  The
+// bookkeeping phases (probe, miss scan, slot assignment / LRU touch, pull decision, victim scan,
+// insert + evict, report) touch a few KB per phase and depend on each other through grid-wide
+// results, so they run as phases of ONE 1024-thread workgroup separated by workgroup barriers
+// instead of as eight dependent launches.  The pull decision of syncEmbedding (cache.cc:84-93:
+// version -1 or lagging by more than pull_bound) is taken here, once per unique key, and parked in
+// data_row[u]; the row kernel only moves rows.
+__global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
+    Cache c, const PlanHeader *hdr, const uint32_t *uniq, long long n, int bypass) {
+    __shared__ uint32_t s_cnt[16];
+    CacheCtl *ctl = c.ctl;
+    const int tid = threadIdx.x;
+    cache_probe_body(ctl, hdr, uniq, c.slot_of, c.length, bypass, c.uslot, c.flag, tid, 1024);
+    __syncthreads();
+    cache_scan_body(hdr, c.flag, c.rank, &ctl->M, &ctl->nhit);
+    __syncthreads();
+    cache_assign_body(ctl, ctl, c, uniq, c.flag, c.rank, static_cast<int>(kPending), tid, 1024);
+    __syncthreads();
+    if (tid == 0)
+        cache_commit_touch_body(ctl, c);
+    // pull decision per unique key
+    const int U = static_cast<int>(hdr->n_unique);
+    uint32_t cnt = 0;
+    for (int u = tid; u < U; u += 1024) {
+        const int s = c.uslot[u];
+        const long long lk = static_cast<long long>(uniq[u]) - c.row_start;
+        int pull = 0;
+        if (lk >= 0 && lk < c.store_rows) {
+            const long long v = c.version[s];
+            pull = (v == -1 || c.srv_ver[lk] - v > c.pull_bound) ? 1 : 0;
+        }
+        c.data_row[u] = pull;
+        cnt += pull;
+    }
+    for (int o = 32; o >= 1; o >>= 1)
+        cnt += __shfl_xor(cnt, o, 64);
+    if (lane_id() == 0)
+        s_cnt[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < 16; ++k)
+            tot += s_cnt[k];
+        ctl->pulled = tot;
+    }
+    if (c.policy != kLRU) {
+        __syncthreads();
+        cache_scan_victim_body(ctl, c);
+    }
+    __syncthreads();
+    cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1);
+    __syncthreads();
+    if (tid == 0)
+        cache_report_pull_body(ctl, c, n);
+}
+
+// One wave per SORTED position p of the batch: dest[perm[p],:] = the row of its key.  Keys marked for
+// a pull read the store row (+ the line's pending gradient, Line::addup) and the wave of the key's
+// first position also refreshes the cache line and its version; the others copy the cached row.
+template <int VEC>
+__global__ __launch_bounds__(256) void cache_lookup_rows_kernel(
+    Cache c, const uint32_t *__restrict__ uniq, const int32_t *__restrict__ upos,
+    const int32_t *__restrict__ perm, long long n, float *__restrict__ dest) {
+    const int lane = lane_id();
+    const long long p = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (p >= n)
+        return;
+    const int u = upos[p];
+    const bool head = p == 0 || upos[p - 1] != u;
+    const int s = c.uslot[u];
+    const long long lk = static_cast<long long>(uniq[u]) - c.row_start;
+    const bool pull = c.data_row[u] != 0;
+    float *line = c.data + static_cast<long long>(s) * c.width;
+    float *out = dest + static_cast<long long>(perm[p]) * c.width;
+    if (!pull) {
+        if (VEC == 4) {
+            for (long long j = lane * 4; j < c.width; j += kWave * 4)
+                st4(out + j, ld4(line + j));
+        } else {
+            for (long long j = lane; j < c.width; j += kWave)
+                out[j] = line[j];
+        }
+        return;
+    }
+    const bool hg = c.hasgrad[s] != 0;
+    const float *src = c.table + lk * c.width;
+    const float *g = c.grad + static_cast<long long>(s) * c.width;
+    if (VEC == 4) {
+        for (long long j = lane * 4; j < c.width; j += kWave * 4) {
+            float4v x = ld4(src + j);
+            if (hg) {
+                const float4v gv = ld4(g + j);
+                x = float4v{__fadd_rn(x[0], gv[0]), __fadd_rn(x[1], gv[1]), __fadd_rn(x[2], gv[2]),
+                            __fadd_rn(x[3], gv[3])};
+            }
+            st4(out + j, x);
+            if (head)
+                st4(line + j, x);
+        }
+    } else {
+        for (long long j = lane; j < c.width; j += kWave) {
+            float x = src[j];
+            if (hg)
+                x = __fadd_rn(x, g[j]);  // Line::addup(): data += grad
+            out[j] = x;
+            if (head)
+                line[j] = x;
+        }
+    }
+    if (head && lane == 0)
+        c.version[s] = c.srv_ver[lk];
+}
 
 // ---- update ----------------------------------------------------------------------------------------
 // rows for the two accumulate passes: grad row = slot (every line), data row = slot for lines with data
-__global__ __launch_bounds__(256) void cache_update_rows_kernel(const CacheCtl *ctl, Cache c) {
+__device__ __forceinline__ void cache_update_rows_body(const CacheCtl *ctl, const Cache &c, int tid0, int nthr) {
     const int U = static_cast<int>(ctl->U);
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
+    for (int u = tid0; u < U; u += nthr) {
         const int s = c.uslot[u];
         c.data_row[u] = c.state[s] == kTransient ? -1 : s;
     }
+}
+__global__ __launch_bounds__(256) void cache_update_rows_kernel(const CacheCtl *ctl, Cache c) {
+    cache_update_rows_body(ctl, c, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+// fused update, phase 1: probe, miss scan, slot assignment (misses become transient lines without
+// data, cache.cc:146-150) / LRU touch, accumulate-row maps -- one workgroup, see cache_lookup_book_kernel
+__global__ __launch_bounds__(1024) void cache_update_book_kernel(
+    Cache c, const PlanHeader *hdr, const uint32_t *uniq, int bypass) {
+    CacheCtl *ctl = c.ctl;
+    const int tid = threadIdx.x;
+    cache_probe_body(ctl, hdr, uniq, c.slot_of, c.length, bypass, c.uslot, c.flag, tid, 1024);
+    __syncthreads();
+    cache_scan_body(hdr, c.flag, c.rank, &ctl->M, &ctl->nhit);
+    __syncthreads();
+    cache_assign_body(ctl, ctl, c, uniq, c.flag, c.rank, static_cast<int>(kTransient), tid, 1024);
+    __syncthreads();
+    if (tid == 0)
+        cache_commit_touch_body(ctl, c);
+    cache_update_rows_body(ctl, c, tid, 1024);
 }
 
 // bookkeeping after the accumulate: updates += count, push decision
@@ -621,6 +789,52 @@ __global__ __launch_bounds__(256) void cache_push_lines_kernel(const CacheCtl *c
     }
 }
 
+// fused update, phase 3: cache_update_flags_kernel + cache_push_lines_kernel, one wave per unique key
+// (the push decision of a line and the server side of its push need nothing from other lines)
+__global__ __launch_bounds__(256) void cache_update_flags_push_kernel(
+    const CacheCtl *ctl, Cache c, const uint32_t *uniq, const int32_t *counts,
+    const uint32_t *push_keys, long long n_push_keys, int with_push_keys) {
+    const int U = static_cast<int>(ctl->U);
+    const int lane = lane_id();
+    for (int u = blockIdx.x * 4 + (threadIdx.x >> 6); u < U; u += gridDim.x * 4) {
+        const int s = c.uslot[u];
+        const int upd = c.updates[s] + counts[u];
+        const bool has_data = c.state[s] != kTransient;
+        const uint32_t k = uniq[u];
+        bool push;
+        if (!with_push_keys) {
+            push = upd > c.push_bound || !has_data;  // cache.cc:159
+        } else {
+            long long lo = 0, hi = n_push_keys;      // cache.cc:295-299
+            while (lo < hi) {
+                const long long mid = (lo + hi) >> 1;
+                if (push_keys[mid] < k)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            push = has_data && lo < n_push_keys && push_keys[lo] == k;
+        }
+        if (lane == 0) {
+            c.hasgrad[s] = 1;
+            c.updates[s] = upd;
+            c.pushflag[u] = push ? 1 : 0;
+            c.flag[u] = push ? 1u : 0u;
+        }
+        if (!push)
+            continue;
+        const long long lk = static_cast<long long>(k) - c.row_start;
+        if (lk < 0 || lk >= c.store_rows)
+            continue;
+        float *row = c.table + lk * c.width;
+        const float *g = c.grad + static_cast<long long>(s) * c.width;
+        for (long long j = lane; j < c.width; j += kWave)
+            row[j] = __fadd_rn(row[j], g[j]);
+        if (lane == 0)
+            c.srv_ver[lk] += upd;
+    }
+}
+
 // pending evicted lines, pushed after the batch's lines (same-key order of the reference's merge:
 // the current line first, then the older evicted ones in eviction order).  Entry j is applied by the
 // wave of the FIRST entry with its key, which then walks the later duplicates in order.
@@ -658,11 +872,11 @@ __global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl 
 }
 
 // after the push: version bump, zeroGrad, transient lines dropped, evicted slots freed.
-__global__ __launch_bounds__(256) void cache_update_cleanup_kernel(const CacheCtl *ctl, Cache c,
-                                                                   int with_push_keys) {
+__device__ __forceinline__ void cache_update_cleanup_body(const CacheCtl *ctl, const Cache &c,
+                                                          int with_push_keys, int wave0, int nwaves) {
     const int U = static_cast<int>(ctl->U);
     const int lane = lane_id();
-    for (int u = blockIdx.x * 4 + (threadIdx.x >> 6); u < U; u += gridDim.x * 4) {
+    for (int u = wave0; u < U; u += nwaves) {
         const int s = c.uslot[u];
         const bool has_data = c.state[s] != kTransient;
         const bool pushed = c.pushflag[u] != 0;
@@ -687,9 +901,12 @@ __global__ __launch_bounds__(256) void cache_update_cleanup_kernel(const CacheCt
             c.state[s] = kFree;  // its stack entry was never retired (free_top unchanged)
     }
 }
+__global__ __launch_bounds__(256) void cache_update_cleanup_kernel(const CacheCtl *ctl, Cache c,
+                                                                   int with_push_keys) {
+    cache_update_cleanup_body(ctl, c, with_push_keys, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4);
+}
 
-__global__ __launch_bounds__(1024) void cache_update_commit_kernel(CacheCtl *ctl, Cache c,
-                                                                   long long n) {
+__device__ __forceinline__ void cache_update_commit_body(CacheCtl *ctl, const Cache &c, long long n) {
     __shared__ uint32_t s_w[16];
     const int U = static_cast<int>(ctl->U);
     const long long En = ctl->evict_n;
@@ -717,6 +934,20 @@ __global__ __launch_bounds__(1024) void cache_update_commit_kernel(CacheCtl *ctl
         ctl->free_top = ftop + En;
         ctl->evict_n = 0;
     }
+}
+__global__ __launch_bounds__(1024) void cache_update_commit_kernel(CacheCtl *ctl, Cache c,
+                                                                   long long n) {
+    cache_update_commit_body(ctl, c, n);
+}
+// fused update, last phase: block 0 = commit (evicted slots freed, report), the others = clean-up
+// (version bump, zeroGrad, transient lines dropped); the two touch disjoint state
+__global__ __launch_bounds__(1024) void cache_update_finish_kernel(CacheCtl *ctl, Cache c, long long n,
+                                                                   int with_push_keys) {
+    if (blockIdx.x == 0)
+        cache_update_commit_body(ctl, c, n);
+    else
+        cache_update_cleanup_body(ctl, c, with_push_keys,
+                                  (blockIdx.x - 1) * 16 + (threadIdx.x >> 6), (gridDim.x - 1) * 16);
 }
 
 __global__ __launch_bounds__(256) void cache_f32_to_u32_kernel(const float *in, long long n,
@@ -783,6 +1014,7 @@ using namespace ha;
 struct ha_cache {
     Cache c;
     std::vector<void *> allocs;
+    int64_t plan_n = -1;   // n of the lookup whose plan is still in plan_ws (ha_cache_update_same_keys)
 };
 
 extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
@@ -924,24 +1156,21 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     hipStream_t s = as_stream(stream);
     if (cache_plan(h, keys, key_kind, n, s))
         return -1;
+    h->plan_n = n;
     PlanPtrs p = plan_layout(c.plan_ws, n);
-    const dim3 g = CACHE_GRID(n), b(256);
-    hipLaunchKernelGGL(cache_probe_kernel, g, b, 0, s, c.ctl, p.hdr, p.uniq, c.slot_of,
-                       (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
-    hipLaunchKernelGGL(cache_scan_kernel, dim3(1), dim3(1024), 0, s, p.hdr, c.flag, c.rank,
-                       &c.ctl->M, &c.ctl->nhit);
-    hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c.ctl, c, p.uniq, c.flag, c.rank,
-                       static_cast<int>(kPending));
-    hipLaunchKernelGGL(cache_commit_touch_kernel, dim3(1), dim3(1), 0, s, c.ctl, c);
-    hipLaunchKernelGGL(cache_sync_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq);
-    if (n > 0)
-        hipLaunchKernelGGL(cache_dest_kernel, CACHE_GRID(n * c.width), b, 0, s, c, p.inverse,
-                           (long long)n, dest);
-    if (c.policy != kLRU)
-        hipLaunchKernelGGL(cache_scan_victim_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c);
-    hipLaunchKernelGGL(cache_insert_evict_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, p.uniq,
-                       c.flag, c.rank, c.bypass ? 0 : 1);
-    hipLaunchKernelGGL(cache_report_pull_kernel, dim3(1), dim3(1), 0, s, c.ctl, c, (long long)n);
+    hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
+                       (long long)n, c.bypass ? 1 : 0);
+    if (n > 0) {
+        const unsigned blocks = static_cast<unsigned>((n + 3) / 4);
+        const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0) &&
+                            (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
+        if (vec_ok)
+            hipLaunchKernelGGL(cache_lookup_rows_kernel<4>, dim3(blocks), dim3(256), 0, s, c, p.uniq, p.upos,
+                               p.perm, (long long)n, dest);
+        else
+            hipLaunchKernelGGL(cache_lookup_rows_kernel<1>, dim3(blocks), dim3(256), 0, s, c, p.uniq, p.upos,
+                               p.perm, (long long)n, dest);
+    }
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -953,12 +1182,18 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
                              int64_t n_push, int with_push_keys, hipStream_t s,
                              bool defer_cleanup = false) {
     HA_REQUIRE(h && h->c.table, "cache_update: no store bound");
-    HA_REQUIRE(n >= 0 && (n == 0 || (keys && grads)), "cache_update: bad arguments");
+    HA_REQUIRE(n >= 0 && (n == 0 || grads), "cache_update: bad arguments");
     Cache &c = h->c;
-    if (cache_plan(h, keys, key_kind, n, s))
-        return -1;
+    // keys == nullptr: the batch of the preceding ha_cache_lookup, whose plan is still in the workspace
+    if (keys != nullptr) {
+        if (cache_plan(h, keys, key_kind, n, s))
+            return -1;
+    } else {
+        HA_REQUIRE(h->plan_n == n && n > 0, "cache_update_same_keys: no lookup of %ld keys precedes this update", (long)n);
+    }
+    h->plan_n = -1;
     PlanPtrs p = plan_layout(c.plan_ws, n);
-    const dim3 g = CACHE_GRID(n), b(256);
+    const dim3 b(256);
     const uint32_t *pk = nullptr;
     if (with_push_keys) {
         HA_REQUIRE(n_push <= c.nmax, "cache_update: too many push keys");
@@ -972,14 +1207,8 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
         }
         pk = c.pushkeys_u32;
     }
-    hipLaunchKernelGGL(cache_probe_kernel, g, b, 0, s, c.ctl, p.hdr, p.uniq, c.slot_of,
-                       (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
-    hipLaunchKernelGGL(cache_scan_kernel, dim3(1), dim3(1024), 0, s, p.hdr, c.flag, c.rank,
-                       &c.ctl->M, &c.ctl->nhit);
-    hipLaunchKernelGGL(cache_assign_kernel, g, b, 0, s, c.ctl, c.ctl, c, p.uniq, c.flag, c.rank,
-                       static_cast<int>(kTransient));
-    hipLaunchKernelGGL(cache_commit_touch_kernel, dim3(1), dim3(1), 0, s, c.ctl, c);
-    hipLaunchKernelGGL(cache_update_rows_kernel, g, b, 0, s, c.ctl, c);
+    hipLaunchKernelGGL(cache_update_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
+                       c.bypass ? 1 : 0);
     HA_LAUNCH_CHECK();
     // Line::accumulate per occurrence, occurrence order: grad += g (every line), data += g (lines
     // with data).  lr = -1 turns the SGD chain `acc - lr*g` into `acc + g` bit for bit.
@@ -991,21 +1220,31 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
                             nullptr, s))
             return -1;
     }
-    hipLaunchKernelGGL(cache_update_flags_kernel, g, b, 0, s, c.ctl, c, p.uniq, p.counts, pk,
-                       (long long)n_push, with_push_keys);
-    hipLaunchKernelGGL(cache_push_lines_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq);
+    hipLaunchKernelGGL(cache_update_flags_push_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq, p.counts,
+                       pk, (long long)n_push, with_push_keys);
     hipLaunchKernelGGL(cache_push_evicted_kernel, CACHE_GRID(c.nmax * 64), b, 0, s, c.ctl, c);
     // the evicted lines that were pending before this call are pushed now: their slots are free again
-    hipLaunchKernelGGL(cache_update_commit_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, (long long)n);
-    if (!defer_cleanup)
-        hipLaunchKernelGGL(cache_update_cleanup_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, with_push_keys);
+    if (!defer_cleanup) {
+        const unsigned cblocks = 1u + static_cast<unsigned>((n + 15) / 16 > 1024 ? 1024 : (n + 15) / 16);
+        hipLaunchKernelGGL(cache_update_finish_kernel, dim3(cblocks), dim3(1024), 0, s, c.ctl, c, (long long)n,
+                           with_push_keys);
+    } else {
+        hipLaunchKernelGGL(cache_update_commit_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, (long long)n);
+    }
     HA_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int ha_cache_update(ha_cache *h, const void *keys, int key_kind, int64_t n,
                                const float *grads, ha_stream_t stream) {
+    HA_REQUIRE(n == 0 || keys, "cache_update: null keys");
     return cache_update_impl(h, keys, key_kind, n, grads, nullptr, 0, 0, 0, as_stream(stream));
+}
+
+extern "C" int ha_cache_update_same_keys(ha_cache *h, int64_t n, const float *grads,
+                                         ha_stream_t stream) {
+    HA_REQUIRE(h, "cache_update_same_keys: null handle");
+    return cache_update_impl(h, nullptr, 0, n, grads, nullptr, 0, 0, 0, as_stream(stream));
 }
 
 extern "C" int ha_cache_update_with_push_keys(ha_cache *h, const void *keys, int key_kind,

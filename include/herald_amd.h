@@ -318,6 +318,9 @@ int ha_cache_lookup(ha_cache *cache, const void *keys, int key_kind, int64_t n,
                     float *dest, ha_stream_t stream);
 int ha_cache_update(ha_cache *cache, const void *keys, int key_kind, int64_t n,
                     const float *grads, ha_stream_t stream);
+/* ha_cache_update for the key batch of the immediately preceding ha_cache_lookup on this cache (the
+ * training step's lookup / update pair): its index plan is still in the workspace and is reused. */
+int ha_cache_update_same_keys(ha_cache *cache, int64_t n, const float *grads, ha_stream_t stream);
 int ha_cache_update_with_push_keys(ha_cache *cache, const void *keys,
                                    int key_kind, int64_t n,
                                    const void *push_keys, int push_kind,

@@ -177,3 +177,44 @@ def test_push_pull_trace(dev, policy):
         np.testing.assert_array_equal(versions.cpu().numpy(), server.ver)
         np.testing.assert_array_equal(table.cpu().numpy(), server.table)
         _compare_state(gpu, model, k)
+
+
+def test_update_of_the_looked_up_key_tensor_reuses_the_plan(dev):
+    """embedding_update(keys) right after embedding_lookup(keys) on the same unmodified device tensor
+    goes through ha_cache_update_same_keys; the result equals the two-plan path and the oracle."""
+    rng = np.random.default_rng(77)
+    rows, width, n = 4000, 64, 900
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    results = []
+    for reuse in (True, False):
+        table = torch.from_numpy(table0.copy()).to(dev)
+        versions = torch.zeros(rows, dtype=torch.int64, device=dev)
+        hcache.register_table(31 + int(reuse), table, versions)
+        c = hcache.CacheSparseTable(300, rows, width, 31 + int(reuse), "LRU", bound=2, max_batch=n, device=dev)
+        for step in range(6):
+            ids = torch.from_numpy(((np.arange(n) * 7 + step * 13) % 500).astype(np.int64)).to(dev)
+            grads = torch.from_numpy(np.full((n, width), 0.25 * (step + 1), dtype=np.float32)).to(dev)
+            dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+            c.embedding_lookup(ids, dest, sync=True)
+            keys_for_update = ids if reuse else ids.clone()
+            assert (c.cache._last_lookup is not None)
+            c.embedding_update(keys_for_update, grads, sync=True)
+            assert c.cache._last_lookup is None
+        torch.cuda.synchronize()
+        results.append((table.cpu().numpy(), versions.cpu().numpy(), dest.cpu().numpy()))
+    for a, b in zip(results[0], results[1]):
+        np.testing.assert_array_equal(a, b)
+    # a modified key tensor must not reuse the stale plan
+    table = torch.from_numpy(table0.copy()).to(dev)
+    versions = torch.zeros(rows, dtype=torch.int64, device=dev)
+    hcache.register_table(40, table, versions)
+    c = hcache.CacheSparseTable(300, rows, width, 40, "LRU", bound=0, max_batch=n, device=dev)
+    ids = torch.arange(n, dtype=torch.int64, device=dev)
+    dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+    c.embedding_lookup(ids, dest, sync=True)
+    ids += 1000                                   # in-place change bumps the tensor version
+    c.embedding_update(ids, torch.ones((n, width), dtype=torch.float32, device=dev), sync=True)
+    torch.cuda.synchronize()
+    t = table.cpu().numpy()
+    np.testing.assert_array_equal(t[:1000], table0[:1000])                  # untouched rows
+    np.testing.assert_array_equal(t[1000:1000 + n], table0[1000:1000 + n] + 1.0)
