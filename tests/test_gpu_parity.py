@@ -293,3 +293,83 @@ def test_shard_bucket_matches_partitioner(dev, lib):
     owner = np.searchsorted(starts, uniq.astype(np.int64), side="right") - 1
     np.testing.assert_array_equal(local.cpu().numpy()[:uniq.size].astype(np.int64),
                                   uniq.astype(np.int64) - starts[owner])
+
+
+def _runs_batch(rng, run_lengths, n_singles, rows):
+    """ids whose sorted order contains one run of every requested length (at whatever alignment the
+    lengths before it produce) between single-occurrence keys, in shuffled position order."""
+    keys = rng.choice(rows, size=len(run_lengths) + n_singles, replace=False)
+    parts = [np.full(L, keys[i], dtype=np.int64) for i, L in enumerate(run_lengths)]
+    parts.append(keys[len(run_lengths):])
+    ids = np.concatenate(parts)
+    rng.shuffle(ids)
+    return ids.astype(np.float32)
+
+
+@pytest.mark.parametrize("width", [64, 200, 512, 1030, 2048])
+@pytest.mark.parametrize("mode", ["sgd", "push", "reduce"])
+def test_apply_every_run_length_class(dev, width, mode):
+    """Short (1-3), medium (4-47) and long (>= 48, full-workgroup cooperative) runs at many lengths and
+    alignments, ragged last slices (width 200 / 1030), more slices than full workgroups (width 2048)."""
+    rng = np.random.default_rng(width * 3 + len(mode))
+    rows = 60000
+    lengths = [2, 3, 4, 5, 15, 16, 17, 30, 31, 32, 33, 46, 47, 48, 49, 50, 62, 63, 64, 65, 79, 80, 81, 95, 96,
+               97, 127, 128, 129, 143, 144, 160, 200, 255, 256, 257, 300, 511, 512, 513, 1000]
+    ids = _runs_batch(rng, lengths, 3000, rows)
+    n = ids.size
+    assert n <= 15360
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    plan = ops.IndexPlan(n, dev).build(_dev(ids, dev))
+    if mode == "sgd":
+        t = _dev(table, dev)
+        ops.sgd_apply(t, plan, _dev(grads, dev), 0.37)
+        want = cpu.sgd_sparse_update(table.copy(), ids, grads, 0.37)
+        np.testing.assert_array_equal(t.cpu().numpy(), want)
+    elif mode == "push":
+        t = _dev(table, dev)
+        ops.push_apply(t, plan, _dev(grads, dev))
+        uniq, _, red = cpu.dedup_reduce(ids, grads)
+        np.testing.assert_array_equal(t.cpu().numpy(), cpu.push_apply(table.copy(), uniq, red))
+    else:
+        red = ops.dedup_reduce(plan, _dev(grads, dev))
+        uniq, _, want = cpu.dedup_reduce(ids, grads)
+        np.testing.assert_array_equal(red[:uniq.size].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("lengths", [[1023, 1024, 1025, 1040, 2047, 2500], [5000, 9000], [15360]])
+def test_apply_giant_runs(dev, lengths):
+    """Runs longer than the 1024 positions a workgroup scans each way, and a batch that is one run."""
+    rng = np.random.default_rng(sum(lengths))
+    rows, width = 5000, 128
+    ids = _runs_batch(rng, lengths, max(0, 15360 - sum(lengths)) // 3, rows)
+    n = ids.size
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    t = _dev(table, dev)
+    ops.sgd_sparse_update(t, _dev(ids, dev), _dev(grads, dev), 0.5)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t.cpu().numpy(), cpu.sgd_sparse_update(table.copy(), ids, grads, 0.5))
+
+
+def test_apply_config_c_batch(dev):
+    """BASELINE configs[2]: bs=4096 d=128 (n = 106,496 ids: radix sort path, runs of thousands)."""
+    rows, width = 2000000, 128
+    raw = synth.criteo_batch(4096, 1, rows=rows)
+    ids = np.minimum(synth.as_f32_ids(raw).reshape(-1), np.float32(rows - 1))
+    n = ids.size
+    assert n == 4096 * 26
+    rng = np.random.default_rng(5)
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    t = _dev(table, dev)
+    plan = ops.IndexPlan(n, dev)
+    out = ops.lookup_sort(t, _dev(ids, dev), plan)
+    np.testing.assert_array_equal(out.cpu().numpy(), cpu.embedding_lookup(table, ids))
+    ops.sgd_apply_finish(t, plan, _dev(grads, dev), 0.01)
+    torch.cuda.synchronize()
+    want = cpu.sgd_sparse_update(table, ids, grads, 0.01)       # in place: the table is 1 GB
+    np.testing.assert_array_equal(t.cpu().numpy(), want)
+    uniq, inv, cnt = cpu.unique(cpu.ids_to_keys(ids))
+    assert plan.n_unique() == uniq.size and int(cnt.max()) > 1000
+    np.testing.assert_array_equal(plan.counts(uniq.size).cpu().numpy().astype(np.int64), cnt)
