@@ -95,6 +95,12 @@ def test_lru_trace_criteo_width(dev):
                check_every=4)
 
 
+def test_lru_trace_long_runs_full_width(dev):
+    # one key repeats ~600 times per batch: the mapped accumulate takes the cooperative long-run path
+    # (8 slices of 64 columns) for both the gradient buffer and the data rows
+    _run_trace(dev, limit=500, rows=3000, width=512, n=2000, steps=4, pull_bound=1, push_bound=2, seed=9)
+
+
 def test_log_compaction_keeps_lru_order(dev):
     # a tiny cache driven for many steps forces the stamp log to wrap and compact
     gpu, _ = _run_trace(dev, limit=8, rows=64, width=4, n=16, steps=400, pull_bound=0, push_bound=0, seed=7,
