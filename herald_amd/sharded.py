@@ -21,7 +21,7 @@ over RCCL (torch.distributed "nccl" backend == RCCL over xGMI):
     push : [worker dedup-reduces]  ->  reduced rows  ->  [owner applies, rank order]
 The routing of a batch depends on its ids only, and the ids are known one step ahead (the reference
 prefetches them too: ParameterServerCommunicate.py:96-139), so `prefetch(ids)` builds it on a side stream
-and a second process group while the rows of the current batch are exchanged; the only host read-back
+while the rows of the current batch are exchanged; the only host read-back
 of a step (n_unique and the 2W counts) is then long complete when the host needs it.
 The reference's servers apply concurrent pushes in arrival order (non-deterministic); here an owner
 applies the W incoming sorted lists in RANK order, `row = (row + r_0) + r_1 ...`, which is one of the
@@ -198,10 +198,14 @@ class Route:
 
 class ShardedEmbedding:
     """One row-range shard per rank + all-to-all pull/push.  `table` is this rank's shard.
-    Construct it on every rank of `group` at the same point of the program (it creates a second
-    process group for the prefetched routing exchange)."""
 
-    def __init__(self, rows, width, device, group=None, engine=None, table=None):
+    All collectives of a store go through ONE communicator in program order (identical on every rank),
+    so the prefetched routing exchanges can never cross the row exchanges differently on two ranks.
+    side_group=True creates a second process group for the routing exchanges (they then overlap the
+    row exchanges instead of queueing between them); construct the store on every rank of `group` at
+    the same point of the program in that case."""
+
+    def __init__(self, rows, width, device, group=None, engine=None, table=None, side_group=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -217,7 +221,7 @@ class ShardedEmbedding:
         self.stats = {"xgmi_bytes_out": 0, "xgmi_bytes_in": 0}
         self._slot = 0
         self.side_group = None
-        if self.world > 1:
+        if self.world > 1 and side_group:
             ranks = None if group is None else dist.get_process_group_ranks(group)
             self.side_group = dist.new_group(ranks=ranks)
 

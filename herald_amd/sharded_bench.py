@@ -24,7 +24,8 @@ def run(args, rank, world, dev):
         np.minimum(f, np.float32(args.rows - 1), out=f)
         ids_host[b] = f
     ids_dev = torch.from_numpy(ids_host).to(dev)
-    emb = ShardedEmbedding(args.rows, args.width, dev)
+    import os
+    emb = ShardedEmbedding(args.rows, args.width, dev, side_group=os.environ.get("HA_SHARD_SIDE_GROUP") == "1")
     g = torch.Generator(device=dev)
     g.manual_seed(123 + rank)
     chunk = 1 << 20

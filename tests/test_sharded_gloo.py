@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, rows, width, n, out_dir):
+def _worker(rank, world, port, rows, width, n, out_dir, side_group=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -43,7 +43,8 @@ def _worker(rank, world, port, rows, width, n, out_dir):
     starts = partition(rows, world)
     assert starts == list(cpu.partition(rows, world))
     shard = torch.from_numpy(table_g[starts[rank]:starts[rank + 1]].copy())
-    emb = ShardedEmbedding(rows, width, "cpu", engine=CpuEngine(), table=shard)
+    emb = ShardedEmbedding(rows, width, "cpu", engine=CpuEngine(), table=shard, side_group=side_group)
+    assert (emb.side_group is not None) == (side_group and world > 1)
 
     ids = torch.from_numpy(all_ids[rank])
     out = emb.pull(ids)
@@ -92,9 +93,11 @@ def _worker(rank, world, port, rows, width, n, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rows,width,n", [(2, 1001, 8, 300), (3, 50, 4, 64)])
-def test_sharded_pull_push_gloo(tmp_path, world, rows, width, n):
-    mp.spawn(_worker, args=(world, _free_port(), rows, width, n, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,rows,width,n,side_group", [(2, 1001, 8, 300, False), (3, 50, 4, 64, False),
+                                                          (2, 400, 4, 120, True)])
+def test_sharded_pull_push_gloo(tmp_path, world, rows, width, n, side_group):
+    mp.spawn(_worker, args=(world, _free_port(), rows, width, n, str(tmp_path), side_group), nprocs=world,
+             join=True)
 
 
 def test_partition_is_average_partitioner():
