@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Wide & Deep on Criteo-shaped data with the embedding path on herald_amd (MI355X).
+
+The model is the reference's examples/ctr/models/wdl_criteo.py:8-46 (33,762,577 x d embedding table,
+26 sparse fields, 13 dense features, a 13-256-256-256 tower, one 256+26d -> 1 output layer, sigmoid +
+binary cross entropy, SGD on every parameter).  The dense tower runs on PyTorch-ROCm; everything that
+touches the embedding table goes through the operator mirrors of herald_amd.hetu_ops, i.e. through
+libherald_amd.so, in the three placements the reference's run_hetu.py offers:
+
+  --embedding hbm    table in this GPU's HBM: EmbeddingLookUp -> DLGpuEmbeddingLookUp,
+                     sparse SGD -> SGDOptimizerSparseUpdate           (comm_mode None)
+  --embedding ps     row-range sharded store (one shard per rank): SparsePull / SparsePush through
+                     ParameterServerCommunicateOp                     (comm_mode PS; torchrun for N > 1)
+  --embedding cache  HET cache (LRU / LFU / LFUOpt, bounded staleness) in front of the store
+                     (comm_mode Hybrid + --cache POLICY --bound B, run_hetu.py:178-190)
+
+Data is synthetic (herald_amd.synth: per-field zipf over the public Criteo cardinalities); labels come
+from a fixed random linear rule so that the loss has something to learn.
+
+    python examples/ctr/run_wdl.py --embedding hbm --rows 2000000 --width 128 --steps 200
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from herald_amd import hetu_ops, synth
+from herald_amd.sharded import ShardedEmbedding
+
+NFIELD, NDENSE = 26, 13
+
+
+class Tower(torch.nn.Module):
+    """The dense part of wdl_criteo (models/wdl_criteo.py:19-36); weights ~ N(0, 0.01) like init.random_normal."""
+
+    def __init__(self, width, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+
+        def w(*shape):
+            return torch.nn.Parameter(torch.randn(*shape, generator=g) * 0.01)
+        self.W1, self.W2, self.W3 = w(NDENSE, 256), w(256, 256), w(256, 256)
+        self.W4 = w(256 + NFIELD * width, 1)
+
+    def forward(self, dense, emb_flat):
+        y3 = torch.relu(torch.relu(dense @ self.W1) @ self.W2) @ self.W3
+        return torch.sigmoid(torch.cat([emb_flat, y3], dim=1) @ self.W4)
+
+
+def make_batches(nbatch, batch, rows, seed=0, rank=0, world=1):
+    """-> list of (ids float32 [batch, 26], dense float32 [batch, 13], label float32 [batch, 1])."""
+    rng = np.random.default_rng(seed + 1000 * rank)
+    wd = rng.standard_normal(NDENSE).astype(np.float32)
+    out = []
+    for b in range(nbatch):
+        raw = synth.criteo_batch(batch, step=b * world + rank, rows=rows)
+        ids = np.minimum(synth.as_f32_ids(raw), np.float32(rows - 1))
+        dense = rng.standard_normal((batch, NDENSE)).astype(np.float32)
+        score = dense @ wd + ((raw[:, :4].sum(axis=1) % 7) - 3).astype(np.float32)
+        out.append((ids, dense, (score > 0).astype(np.float32).reshape(-1, 1)))
+    return out
+
+
+def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, cache="LRU", bound=0,
+          cache_limit=None, seed=0, device="cuda:0", table_init=None, log_every=0):
+    """Runs `steps` training steps; returns (losses, embedding parameter, tower)."""
+    dev = torch.device(device)
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    tower = Tower(width, seed).to(dev)
+    opt = torch.optim.SGD(tower.parameters(), lr=lr)
+    batches = make_batches(min(steps + 1, 64), batch, rows, seed, rank, world)
+    dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in b) for b in batches]
+    state = {"k": 0}
+
+    def ids_of(k):
+        return dev_batches[k % len(dev_batches)][0]
+
+    if table_init is None:
+        g = torch.Generator(device=dev).manual_seed(seed + 1)
+        table_init = torch.randn((rows, width), generator=g, device=dev) * 0.01    # init.random_normal(stddev=0.01)
+    if embedding == "hbm":
+        param = hetu_ops.EmbeddingParameter(table=table_init.clone())
+        config = hetu_ops.Config(comm_mode=None)
+        comm = None
+    else:
+        store = ShardedEmbedding(rows, width, dev)
+        store.table.copy_(table_init[store.starts[store.rank]:store.starts[store.rank + 1]])
+        param = hetu_ops.EmbeddingParameter(store=store)
+        config = hetu_ops.Config(comm_mode="PS" if embedding == "ps" else "Hybrid", bsp=0, prefetch=True,
+                                 cstable_policy=cache if embedding == "cache" else None, cache_bound=bound,
+                                 cache_limit=cache_limit if cache_limit is not None else max(rows // 10, batch * NFIELD))
+        comm = hetu_ops.ParameterServerCommunicateOp(param, lr, next_ids=lambda: ids_of(state["k"] + 1))
+        barrier = dist.barrier if world > 1 else (lambda: None)
+        comm.forward_hook(config, first_ids=ids_of(0), barrier=barrier)
+    lookup = hetu_ops.EmbeddingLookUp(param)
+    lookup.forward_hook(config)
+    lookup_grad = hetu_ops.EmbeddingLookUp_Gradient(param.shape)
+
+    losses = []
+    t0 = time.perf_counter()
+    for k in range(steps):
+        state["k"] = k
+        ids, dense, label = dev_batches[k % len(dev_batches)]
+        emb = torch.empty((batch, NFIELD, width), dtype=torch.float32, device=dev)
+        lookup.compute(ids, emb)                                   # embedding_lookup_op
+        emb.requires_grad_(True)
+        pred = tower(dense, emb.reshape(batch, NFIELD * width))
+        loss = torch.nn.functional.binary_cross_entropy(pred, label)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        grad = lookup_grad.compute(emb.grad, ids)                  # IndexedSlices(indices, values)
+        if comm is None:
+            hetu_ops.sgd_update_sparse(param, grad, lr)            # OptimizerOp, sparse SGD branch
+        else:
+            comm.compute(grad)                                     # -lr scale, push, (barrier), pull of batch k+1
+        losses.append(float(loss.detach()))
+        if log_every and (k + 1) % log_every == 0 and rank == 0:
+            print("step %d loss %.5f (%.1f ms/step)" % (k + 1, np.mean(losses[-log_every:]),
+                                                        1e3 * (time.perf_counter() - t0) / (k + 1)))
+    torch.cuda.synchronize()
+    return losses, param, tower
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--embedding", choices=["hbm", "ps", "cache"], default="hbm")
+    ap.add_argument("--cache", choices=["LRU", "LFU", "LFUOpt"], default="LRU")
+    ap.add_argument("--bound", type=int, default=100)
+    ap.add_argument("--rows", type=int, default=33762577)
+    ap.add_argument("--width", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--lr", type=float, default=0.1)
+    args = ap.parse_args()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    losses, _, _ = train(args.embedding, args.rows, args.width, args.batch, args.steps, args.lr, args.cache,
+                         args.bound, device="cuda:%d" % local_rank, log_every=max(1, args.steps // 10))
+    if local_rank == 0:
+        print("first 10 steps: loss %.5f   last 10 steps: loss %.5f" % (np.mean(losses[:10]), np.mean(losses[-10:])))
+
+
+if __name__ == "__main__":
+    main()
