@@ -100,6 +100,7 @@ def _declare(L):
         "ha_plan_export_f32": [vp, i64, vp, vp, vp],
         "ha_dedup_reduce": [vp, i64, vp, i64, vp, vp],
         "ha_apply_mapped": [vp, i64, i64, vp, i64, vp, f32, vp, vp, vp, vp],
+        "ha_apply_mapped2": [vp, i64, vp, i64, vp, i64, vp, f32, vp, vp, vp, vp],
         "ha_shard_bucket": [vp, i64, vp, c.c_int, vp, vp, vp],
         "ha_shard_route_f32ids": [vp, i64, vp, vp, c.c_int, vp, vp, vp],
         "ha_shard_route_u64ids": [vp, i64, vp, vp, c.c_int, vp, vp, vp],

@@ -43,6 +43,10 @@ extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
                                float lr, const int32_t *rowmap,
                                const int32_t *valmap, const uint8_t *dst_init,
                                ha_stream_t stream);
+extern "C" int ha_apply_mapped2(float *dst, int64_t dst_rows, float *dst2, int64_t width,
+                                const void *plan_ws, int64_t n, const float *src, float lr,
+                                const int32_t *rowmap, const int32_t *rowmap2,
+                                const uint8_t *dst_init, ha_stream_t stream);
 
 namespace ha {
 
@@ -1213,11 +1217,8 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     // Line::accumulate per occurrence, occurrence order: grad += g (every line), data += g (lines
     // with data).  lr = -1 turns the SGD chain `acc - lr*g` into `acc + g` bit for bit.
     if (n > 0) {
-        if (ha_apply_mapped(c.grad, c.S, c.width, c.plan_ws, n, grads, -1.0f, c.uslot, nullptr,
-                            c.hasgrad, s))
-            return -1;
-        if (ha_apply_mapped(c.data, c.S, c.width, c.plan_ws, n, grads, -1.0f, c.data_row, nullptr,
-                            nullptr, s))
+        if (ha_apply_mapped2(c.grad, c.S, c.data, c.width, c.plan_ws, n, grads, -1.0f, c.uslot, c.data_row,
+                             c.hasgrad, s))
             return -1;
     }
     hipLaunchKernelGGL(cache_update_flags_push_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq, p.counts,

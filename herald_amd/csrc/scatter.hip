@@ -50,6 +50,18 @@ __global__ __launch_bounds__(1024, 8) void apply_mapped_kernel(
     apply_body<kModeSgd, VEC>(dst, dst_rows, width, sorted, perm, upos, n, src, lr, blockIdx.x, s_apply, nullptr, maps);
 }
 
+// two destinations, one pass (the cache's Line::accumulate: gradient buffer and data row)
+template <int VEC>
+__global__ __launch_bounds__(1024, 8) void apply_mapped2_kernel(
+    float *__restrict__ dst, uint64_t dst_rows, int width,
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ upos, int n, const float *__restrict__ src,
+    float lr, ApplyMaps maps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
+    apply_body<kModeSgd, VEC, true>(dst, dst_rows, width, sorted, perm, upos, n, src, lr, blockIdx.x, s_apply,
+                                    nullptr, maps);
+}
+
 // diagnostic twin of apply_kernel<kModeSgd,4>: same body plus per-wave time stamps
 __global__ __launch_bounds__(1024, 8) void apply_timeline_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
@@ -161,13 +173,45 @@ extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
     const unsigned blocks = static_cast<unsigned>((n + ha::kPosPerBlock - 1) / ha::kPosPerBlock);
     const bool vec_ok = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
                         (reinterpret_cast<uintptr_t>(src) % 16 == 0);
-    const ha::ApplyMaps maps{rowmap, valmap, dst_init};
+    const ha::ApplyMaps maps{rowmap, valmap, dst_init, nullptr, nullptr};
     if (vec_ok)
         hipLaunchKernelGGL((ha::apply_mapped_kernel<4>), dim3(blocks), dim3(1024), ha::kApplyLdsBytes, ha::as_stream(stream),
                            dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos, (int)n, src, lr, maps);
     else
         hipLaunchKernelGGL((ha::apply_mapped_kernel<1>), dim3(blocks), dim3(1024), ha::kApplyLdsBytes, ha::as_stream(stream),
                            dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos, (int)n, src, lr, maps);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ha_apply_mapped into TWO destinations with one pass over `src`: for every unique key u
+//   dst [rowmap[u],:]  = (dst_init[rowmap[u]] ? dst[rowmap[u],:] : 0) - lr*src[i0,:] - lr*src[i1,:] ...
+//   dst2[rowmap2[u],:] =  dst2[rowmap2[u],:]                          - lr*src[i0,:] - lr*src[i1,:] ...
+// (rowmap2[u] < 0: no second row for u).  Each result is bit-identical to its own ha_apply_mapped call.
+extern "C" int ha_apply_mapped2(float *dst, int64_t dst_rows, float *dst2, int64_t width,
+                                const void *plan_ws, int64_t n, const float *src, float lr,
+                                const int32_t *rowmap, const int32_t *rowmap2,
+                                const uint8_t *dst_init, ha_stream_t stream) {
+    HA_REQUIRE(n >= 0 && width >= 1 && width < (1 << 30), "apply_mapped2: bad sizes");
+    if (n == 0)
+        return 0;
+    HA_REQUIRE(dst && dst2 && plan_ws && src && rowmap && rowmap2, "apply_mapped2: null pointer");
+    ha_plan_view v;
+    if (ha_plan_view_of(const_cast<void *>(plan_ws), n, &v) != 0)
+        return -1;
+    const unsigned blocks = static_cast<unsigned>((n + ha::kPosPerBlock - 1) / ha::kPosPerBlock);
+    const bool vec_ok = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(dst2) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+    const ha::ApplyMaps maps{rowmap, nullptr, dst_init, dst2, rowmap2};
+    if (vec_ok)
+        hipLaunchKernelGGL((ha::apply_mapped2_kernel<4>), dim3(blocks), dim3(1024), ha::kApplyLdsBytes,
+                           ha::as_stream(stream), dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos,
+                           (int)n, src, lr, maps);
+    else
+        hipLaunchKernelGGL((ha::apply_mapped2_kernel<1>), dim3(blocks), dim3(1024), ha::kApplyLdsBytes,
+                           ha::as_stream(stream), dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos,
+                           (int)n, src, lr, maps);
     HA_LAUNCH_CHECK();
     return 0;
 }

@@ -19,6 +19,17 @@ struct ApplyMaps {
     const int32_t *rowmap;
     const int32_t *valmap;
     const uint8_t *dst_init;
+    // optional SECOND destination that receives the same ordered chain (DUAL kernels only): the cache
+    // accumulates a batch into a line's gradient buffer and into its data row in one pass
+    // (Line::accumulate, src/hetu_cache/include/embedding.h:78-91).  rowmap2[u] < 0 = no second row.
+    float *dst2;
+    const int32_t *rowmap2;
+};
+
+// second destination row of the current key (on == false: none)
+struct Second {
+    float *row;
+    bool on;
 };
 
 constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per 1024-thread workgroup
@@ -61,14 +72,14 @@ struct Vec<1> {
 // ---- short runs (1..kShortRun occurrences): one wave, whole row --------------------------------
 // Columns [cbase, cbase + VB*64*VEC); the table row and every occurrence row are requested in one
 // batch (branch-free, clamped), then applied in occurrence order.
-template <int MODE, int VEC, int VB>
+template <int MODE, int VEC, int VB, bool DUAL>
 __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                                             const float *__restrict__ grads,
                                             int width, int cbase, int pv,
                                             int lane0, int len, float lr,
-                                            bool init) {
+                                            bool init, Second d2) {
     const int lane = lane_id();
-    Vec<VEC> acc[VB], g[kShortRun][VB];
+    Vec<VEC> acc[VB], g[kShortRun][VB], acc2[DUAL ? VB : 1];
     int col[VB], lcol[VB];
 #pragma unroll
     for (int b = 0; b < VB; ++b) {
@@ -77,6 +88,8 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
         acc[b].zero();
         if (MODE == kModeSgd && init)  // wave-uniform
             acc[b].load(dst_row + lcol[b]);
+        if (DUAL && d2.on)
+            acc2[b].load(d2.row + lcol[b]);
     }
 #pragma unroll
     for (int t = 0; t < kShortRun; ++t) {
@@ -92,8 +105,11 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
 #pragma unroll
             for (int b = 0; b < VB; ++b)
 #pragma unroll
-                for (int k = 0; k < VEC; ++k)
+                for (int k = 0; k < VEC; ++k) {
                     acc[b].set(k, step<MODE>(acc[b].get(k), g[t][b].get(k), lr));
+                    if (DUAL && d2.on)
+                        acc2[b].set(k, step<MODE>(acc2[b].get(k), g[t][b].get(k), lr));
+                }
         }
     }
 #pragma unroll
@@ -107,21 +123,23 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                     acc[b].set(k, __fadd_rn(cur.get(k), acc[b].get(k)));
             }
             acc[b].store(dst_row + col[b]);
+            if (DUAL && d2.on)
+                acc2[b].store(d2.row + col[b]);
         }
     }
 }
 
-template <int MODE, int VEC>
+template <int MODE, int VEC, bool DUAL>
 __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
                                           const float *__restrict__ grads,
                                           int width, int pv, int lane0, int len,
-                                          float lr, bool init) {
+                                          float lr, bool init, Second d2) {
     constexpr int kCols1 = kWave * VEC;
     int c = 0;
     for (; width - c > kCols1; c += 2 * kCols1)
-        short_block<MODE, VEC, 2>(dst_row, grads, width, c, pv, lane0, len, lr, init);
+        short_block<MODE, VEC, 2, DUAL>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2);
     for (; c < width; c += kCols1)
-        short_block<MODE, VEC, 1>(dst_row, grads, width, c, pv, lane0, len, lr, init);
+        short_block<MODE, VEC, 1, DUAL>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2);
 }
 
 // ---- medium runs (kShortRun < L < kLongRun): column-split over the run's own first waves --------
@@ -129,16 +147,18 @@ __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
 // and applies ALL occurrences of the run to its slice in order: one dword per lane = 256 contiguous
 // bytes per occurrence row.  Every occurrence index of such a run is already in the wave's window of
 // sorted positions (p-16 .. p+47), so the row loads are issued straight away, up to 32 in flight.
-template <int MODE>
+template <int MODE, bool DUAL>
 __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
                                              const float *__restrict__ grads,
                                              int width, int col, int pv, int lane_s,
-                                             int len, float lr, bool init) {
+                                             int len, float lr, bool init, Second d2) {
     const bool live = col < width;
     const int lcol = live ? col : 0;
-    float acc = 0.f;
+    float acc = 0.f, acc2 = 0.f;
     if (MODE == kModeSgd && init)
         acc = dst_row[lcol];
+    if (DUAL && d2.on)
+        acc2 = d2.row[lcol];
     auto load_chunk = [&](float(&g)[kChunk], int t0) {
 #pragma unroll
         for (int t = 0; t < kChunk; ++t) {
@@ -149,13 +169,20 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
     auto consume = [&](const float(&g)[kChunk], int cnt) {  // cnt = valid entries (may exceed kChunk)
         if (cnt >= kChunk) {
 #pragma unroll
-            for (int t = 0; t < kChunk; ++t)
+            for (int t = 0; t < kChunk; ++t) {
                 acc = step<MODE>(acc, g[t], lr);
+                if (DUAL)
+                    acc2 = step<MODE>(acc2, g[t], lr);
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < kChunk; ++t) {
                 const float nx = step<MODE>(acc, g[t], lr);
                 acc = (t < cnt) ? nx : acc;
+                if (DUAL) {
+                    const float nx2 = step<MODE>(acc2, g[t], lr);
+                    acc2 = (t < cnt) ? nx2 : acc2;
+                }
             }
         }
     };
@@ -174,6 +201,8 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
         if (MODE == kModePush)
             acc = __fadd_rn(dst_row[col], acc);
         dst_row[col] = acc;
+        if (DUAL && d2.on)
+            d2.row[col] = acc2;
     }
 }
 
@@ -199,7 +228,7 @@ __device__ __forceinline__ float chain_step(float acc, float m) {
 
 // Returns false when the run is shorter than kLongRun (the caller falls through to the per-wave
 // paths).  Called by all 16 waves of a full workgroup; wg0 = its first sorted position.
-template <int MODE>
+template <int MODE, bool DUAL>
 __device__ __forceinline__ bool coop_run(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
@@ -276,6 +305,12 @@ __device__ __forceinline__ bool coop_run(
     if (row >= dst_rows)
         return true;
     float *dst_row = dst + row * static_cast<uint64_t>(width);
+    Second d2{nullptr, false};
+    if (DUAL && maps.rowmap2) {
+        const int r2 = maps.rowmap2[upos[wg0]];
+        d2.on = r2 >= 0;
+        d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
+    }
 
     const int my_slices = (nslice - j + workers - 1) / workers;  // slices j, j+workers, ...
     for (int g0 = 0; g0 < my_slices; g0 += 8) {
@@ -292,9 +327,11 @@ __device__ __forceinline__ bool coop_run(
         const bool chain = w < sg;
         const int ccol = (j + (g0 + (chain ? w : 0)) * workers) * kWave + lane;
         const bool clive = chain && ccol < width;
-        float acc = 0.f;
+        float acc = 0.f, acc2 = 0.f;
         if (MODE == kModeSgd && init && chain)
             acc = dst_row[ccol < width ? ccol : 0];
+        if (DUAL && d2.on && chain)
+            acc2 = d2.row[ccol < width ? ccol : 0];
         float4v *s_wr = reinterpret_cast<float4v *>(s_m) +
                         (static_cast<size_t>(cl * tlen + tc * kChunk) / 4) * kWave + lane;
         const float4v *s_rd = reinterpret_cast<const float4v *>(s_m) +
@@ -327,6 +364,12 @@ __device__ __forceinline__ bool coop_run(
                     acc = chain_step<MODE>(acc, m[1]);
                     acc = chain_step<MODE>(acc, m[2]);
                     acc = chain_step<MODE>(acc, m[3]);
+                    if (DUAL) {
+                        acc2 = chain_step<MODE>(acc2, m[0]);
+                        acc2 = chain_step<MODE>(acc2, m[1]);
+                        acc2 = chain_step<MODE>(acc2, m[2]);
+                        acc2 = chain_step<MODE>(acc2, m[3]);
+                    }
                 }
                 if (k < cnt) {
                     const float4v m = s_rd[(k / 4) * kWave];
@@ -334,6 +377,10 @@ __device__ __forceinline__ bool coop_run(
                     for (int i = 0; i < 3; ++i) {
                         const float nx = chain_step<MODE>(acc, m[i]);
                         acc = (k + i < cnt) ? nx : acc;
+                        if (DUAL) {
+                            const float nx2 = chain_step<MODE>(acc2, m[i]);
+                            acc2 = (k + i < cnt) ? nx2 : acc2;
+                        }
                     }
                 }
             }
@@ -343,13 +390,15 @@ __device__ __forceinline__ bool coop_run(
             if (MODE == kModePush)
                 acc = __fadd_rn(dst_row[ccol], acc);
             dst_row[ccol] = acc;
+            if (DUAL && d2.on)
+                d2.row[ccol] = acc2;
         }
     }
     return true;
 }
 
 // One wave per sorted position p; `lds` = kApplyLdsBytes of workgroup memory (long runs only).
-template <int MODE, int VEC>
+template <int MODE, int VEC, bool DUAL>
 __device__ __forceinline__ void apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
@@ -359,25 +408,25 @@ __device__ __forceinline__ void apply_body_impl(
 // `dbg` (tools/timeline.py only) receives {realtime start, realtime end, role/len, shader cycles}
 // per position.  The early return below is taken by whole waves of the LAST workgroup only, which is
 // never a full one, so the barriers of coop_run see all 16 waves.
-template <int MODE, int VEC>
+template <int MODE, int VEC, bool DUAL = false>
 __device__ __forceinline__ void apply_body(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr, int vblock, uint32_t *lds, unsigned long long *dbg = nullptr,
-    ApplyMaps maps = ApplyMaps{nullptr, nullptr, nullptr}) {
+    ApplyMaps maps = ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int p = vblock * kPosPerBlock + w;
     if (p >= n)
         return;
     if (dbg == nullptr) {
-        apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds);
+        apply_body_impl<MODE, VEC, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds);
         return;
     }
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     int info = 0;
-    apply_body_impl<MODE, VEC>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds);
+    apply_body_impl<MODE, VEC, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds);
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -389,7 +438,7 @@ __device__ __forceinline__ void apply_body(
     }
 }
 
-template <int MODE, int VEC>
+template <int MODE, int VEC, bool DUAL>
 __device__ __forceinline__ void apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
@@ -415,7 +464,7 @@ __device__ __forceinline__ void apply_body_impl(
     if (wg0 + kPosPerBlock <= n && key_first == key_last) {
         if (dbg_info)
             *dbg_info = (w << 16) | 0x7FFF;
-        if (coop_run<MODE>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds))
+        if (coop_run<MODE, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds))
             return;
     }
     const unsigned long long eq = __ballot(q >= 0 && q < n && ks == key);
@@ -450,15 +499,21 @@ __device__ __forceinline__ void apply_body_impl(
     if (row >= dst_rows)
         return;  // out-of-range id: ignored (undefined behaviour in the reference)
     float *dst_row = dst + row * static_cast<uint64_t>(width);
+    Second d2{nullptr, false};
+    if (DUAL && maps.rowmap2) {
+        const int r2 = maps.rowmap2[upos[p]];
+        d2.on = r2 >= 0;
+        d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
+    }
 
     if (len <= kShortRun) {
         if (o == 0)
-            short_row<MODE, VEC>(dst_row, grads, width, pv, kLookBack, len, lr, init);
+            short_row<MODE, VEC, DUAL>(dst_row, grads, width, pv, kLookBack, len, lr, init, d2);
         return;
     }
     const int workers = min(len, kLookBack);
     for (int c0 = o * kWave; c0 < width; c0 += workers * kWave)
-        medium_slice<MODE>(dst_row, grads, width, c0 + lane, pv, kLookBack - o, len, lr, init);
+        medium_slice<MODE, DUAL>(dst_row, grads, width, c0 + lane, pv, kLookBack - o, len, lr, init, d2);
 }
 
 }  // namespace ha

@@ -255,6 +255,14 @@ int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
                     const void *plan_ws, int64_t n, const float *src, float lr,
                     const int32_t *rowmap, const int32_t *valmap,
                     const uint8_t *dst_init, ha_stream_t stream);
+/* ha_apply_mapped into two destinations with one pass over src (the cache's Line::accumulate writes the
+ * same ordered sum into a line's gradient buffer and into its data row, embedding.h:78-91):
+ * dst as ha_apply_mapped with (rowmap, dst_init); dst2[rowmap2[u],:] always starts from its stored
+ * value; rowmap2[u] < 0 = no second row.  Each result equals its own ha_apply_mapped call bit for bit. */
+int ha_apply_mapped2(float *dst, int64_t dst_rows, float *dst2, int64_t width,
+                     const void *plan_ws, int64_t n, const float *src, float lr,
+                     const int32_t *rowmap, const int32_t *rowmap2,
+                     const uint8_t *dst_init, ha_stream_t stream);
 
 /* ---- fused launches (two per training step) --------------------------------
  * ha_lookup_sort_*    == ha_gather_* + ha_plan_sort_*   in ONE launch (forward: the lookup of a

@@ -373,3 +373,36 @@ def test_apply_config_c_batch(dev):
     uniq, inv, cnt = cpu.unique(cpu.ids_to_keys(ids))
     assert plan.n_unique() == uniq.size and int(cnt.max()) > 1000
     np.testing.assert_array_equal(plan.counts(uniq.size).cpu().numpy().astype(np.int64), cnt)
+
+
+def test_apply_mapped2_equals_two_mapped_passes(dev, lib):
+    """ha_apply_mapped2 (one pass, two destinations) == two ha_apply_mapped calls, bit for bit, over
+    short / medium / long runs, with un-initialised first-destination rows and skipped second rows."""
+    import ctypes
+    rng = np.random.default_rng(91)
+    width, slots = 192, 6000
+    ids = _runs_batch(rng, [2, 3, 4, 9, 17, 40, 47, 48, 49, 100, 300, 700], 1500, 50000)
+    n = ids.size
+    plan = ops.IndexPlan(n, dev).build(_dev(ids, dev))
+    u = plan.n_unique()
+    src = _dev(rng.standard_normal((n, width), dtype=np.float32), dev)
+    rowmap = rng.permutation(slots)[:u].astype(np.int32)
+    rowmap2 = rowmap.copy()
+    rowmap2[rng.random(u) < 0.3] = -1                       # lines without a data row
+    init = (rng.random(slots) < 0.5).astype(np.uint8)       # lines whose gradient buffer exists already
+    a0 = rng.standard_normal((slots, width), dtype=np.float32)
+    b0 = rng.standard_normal((slots, width), dtype=np.float32)
+    d_rowmap, d_rowmap2, d_init = _dev(rowmap, dev), _dev(rowmap2, dev), _dev(init, dev)
+    vp = ctypes.c_void_p
+    a1, b1 = _dev(a0, dev), _dev(b0, dev)
+    assert lib.ha_apply_mapped(vp(a1.data_ptr()), slots, width, vp(plan.ws.data_ptr()), n, vp(src.data_ptr()),
+                               ctypes.c_float(-1.0), vp(d_rowmap.data_ptr()), None, vp(d_init.data_ptr()), None) == 0
+    assert lib.ha_apply_mapped(vp(b1.data_ptr()), slots, width, vp(plan.ws.data_ptr()), n, vp(src.data_ptr()),
+                               ctypes.c_float(-1.0), vp(d_rowmap2.data_ptr()), None, None, None) == 0
+    a2, b2 = _dev(a0, dev), _dev(b0, dev)
+    assert lib.ha_apply_mapped2(vp(a2.data_ptr()), slots, vp(b2.data_ptr()), width, vp(plan.ws.data_ptr()), n,
+                                vp(src.data_ptr()), ctypes.c_float(-1.0), vp(d_rowmap.data_ptr()),
+                                vp(d_rowmap2.data_ptr()), vp(d_init.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    assert not torch.equal(a1, _dev(a0, dev))
