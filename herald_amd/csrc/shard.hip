@@ -146,3 +146,17 @@ extern "C" int ha_shard_route_u64ids(const uint64_t *ids, int64_t n, void *plan_
     return shard_route<uint64_t>(ids, n, plan_ws, starts_host, nshard, meta, local_keys, stream,
                                  ha_plan_build_u64ids);
 }
+
+// Owner side of a sparse push in one call: index plan of the received shard-local keys (the W sorted
+// lists concatenated in rank order) + `row = (row + v_a) + v_b ...` in list order -- the server `+=`
+// of PSHandler::serve(SparsePush), PSFHandle.h:130-164, made deterministic (rank order).
+extern "C" int ha_shard_serve_push(float *table, int64_t rows, int64_t width, const uint32_t *keys,
+                                   int64_t n, const float *values, void *plan_ws, ha_stream_t stream) {
+    HA_REQUIRE(n >= 0, "shard_serve_push: bad n");
+    if (n == 0)
+        return 0;
+    HA_REQUIRE(table && keys && values && plan_ws, "shard_serve_push: null pointer");
+    if (ha_plan_build_u32keys(keys, n, plan_ws, 32, stream))
+        return -1;
+    return ha_sgd_apply(table, rows, width, plan_ws, n, values, -1.0f, stream);
+}

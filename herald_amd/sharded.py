@@ -79,6 +79,15 @@ class HipEngine:
         self.side = torch.cuda.Stream(device=self.device)
         self._slots = {}
         self._owner_plan = None
+        self._bufs = {}
+
+    def _buf(self, name, rows, width):
+        """Grow-only scratch rows that never leave the store (exchange staging)."""
+        b = self._bufs.get(name)
+        if b is None or b.shape[0] < rows or b.shape[1] != width:
+            b = torch.empty((max(rows, 1) * 5 // 4 + 16, width), dtype=torch.float32, device=self.device)
+            self._bufs[name] = b
+        return b[:rows]
 
     @staticmethod
     def _stream():
@@ -145,10 +154,12 @@ class HipEngine:
             ev.synchronize()
 
     # -- rows ----------------------------------------------------------------------------------------
-    def gather_keys(self, table, keys_i32):
-        """rows[j,:] = table[keys[j],:] for shard-local uint32 keys held in an int32 tensor."""
+    def gather_keys(self, table, keys_i32, scratch=None):
+        """rows[j,:] = table[keys[j],:] for shard-local uint32 keys held in an int32 tensor; `scratch`
+        names a reusable staging buffer (the result is then only valid until its next use)."""
         n = keys_i32.numel()
-        out = torch.empty((n, table.shape[1]), dtype=torch.float32, device=self.device)
+        out = (self._buf(scratch, n, table.shape[1]) if scratch else
+               torch.empty((n, table.shape[1]), dtype=torch.float32, device=self.device))
         self.check(self.lib.ha_gather_u32keys(table.data_ptr(), table.shape[0], table.shape[1],
                                               keys_i32.data_ptr(), n, out.data_ptr(), self._stream()),
                    "ha_gather_u32keys")
@@ -158,8 +169,15 @@ class HipEngine:
         """out[i,:] = rows[inverse[i],:] -- every position receives its unique row (sparse.h:17-31)."""
         return self.gather_keys(rows, plan.inverse())
 
+    def rows_buffer(self, name, rows, width):
+        return self._buf(name, rows, width)
+
     def reduce_scaled(self, plan, values, scale):
-        return self.ops.dedup_reduce(plan, values, scale=scale)
+        out = self._buf("reduced", max(plan.n, 1), values.shape[1])
+        self.check(self.lib.ha_dedup_reduce_scaled(plan.ws.data_ptr(), plan.n, values.data_ptr(), values.shape[1],
+                                                   ctypes.c_float(scale), out.data_ptr(), self._stream()),
+                   "ha_dedup_reduce_scaled")
+        return out
 
     def acc_apply(self, table, keys_i32, values):
         """table[key,:] = (table[key,:] + v_a) + v_b ... in the order the (key, value) pairs are listed."""
@@ -168,12 +186,10 @@ class HipEngine:
             return
         p = self._owner_plan
         if p is None or p.capacity < n:
-            p = self._owner_plan = self.ops.IndexPlan(max(n, 1), self.device)
-        self.check(self.lib.ha_plan_build_u32keys(keys_i32.data_ptr(), n, p.ws.data_ptr(), 32, self._stream()),
-                   "ha_plan_build_u32keys")
-        p.n = n
-        p._view = None
-        self.ops.sgd_apply(table, p, values, -1.0)
+            p = self._owner_plan = self.ops.IndexPlan(max(n, 1) * 5 // 4 + 16, self.device)
+        self.check(self.lib.ha_shard_serve_push(table.data_ptr(), table.shape[0], table.shape[1],
+                                                keys_i32.data_ptr(), n, values.data_ptr(), p.ws.data_ptr(),
+                                                self._stream()), "ha_shard_serve_push")
 
 
 class RouteBuffers:
@@ -289,8 +305,8 @@ class ShardedEmbedding:
             route = self.prefetch(ids)
         r = self.complete(route)
         eng.wait_event(r.ready)
-        rows_send = eng.gather_keys(self.table, r.keys_recv)
-        rows_recv = torch.empty((r.u, self.width), dtype=torch.float32, device=self.device)
+        rows_send = eng.gather_keys(self.table, r.keys_recv, scratch="pull_send")
+        rows_recv = eng.rows_buffer("pull_recv", r.u, self.width)
         self._a2a(rows_recv, rows_send, r.send_cnt, r.recv_cnt)
         out = eng.expand(rows_recv, r.plan)
         self._account(r.send_cnt, r.recv_cnt, 4, 4 * self.width)
@@ -311,7 +327,7 @@ class ShardedEmbedding:
         eng.wait_event(r.ready)   # the plan and the keys were produced on the side stream
         reduced = eng.reduce_scaled(r.plan, values.reshape(-1, self.width), scale)
         rows_send = reduced[:r.u]
-        rows_recv = torch.empty((sum(r.recv_cnt), self.width), dtype=torch.float32, device=self.device)
+        rows_recv = eng.rows_buffer("push_recv", sum(r.recv_cnt), self.width)
         self._a2a(rows_recv, rows_send, r.recv_cnt, r.send_cnt)
         eng.acc_apply(self.table, r.keys_recv, rows_recv)
         self._account(r.send_cnt, r.recv_cnt, 4 * self.width, 0)

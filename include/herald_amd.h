@@ -303,6 +303,13 @@ int ha_shard_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws,
                           const int64_t *starts_host, int nshard, int64_t *meta,
                           uint32_t *local_keys, ha_stream_t stream);
 
+/* Owner side of a sparse push (PSHandler::serve(SparsePush), ps-lite/include/ps/server/PSFHandle.h:130-164):
+ * table[keys[j],:] = (table[keys[j],:] + values[a,:]) + values[b,:] ... over the positions a < b < ... that
+ * list the key, i.e. in list order (the W received sorted lists concatenated in rank order).
+ * plan_ws: ha_plan_bytes(n) of scratch. */
+int ha_shard_serve_push(float *table, int64_t rows, int64_t width, const uint32_t *keys,
+                        int64_t n, const float *values, void *plan_ws, ha_stream_t stream);
+
 /* ---- HET embedding cache (replaces the hetu_cache plugin, src/hetu_cache) ----
  * An opaque device-resident cache of `limit` lines in front of a store (the "server": a table shard
  * plus one int64 version per row, ps-lite/include/ps/server/param.h:119-138).  Semantics of

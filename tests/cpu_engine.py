@@ -62,8 +62,11 @@ class CpuEngine:
     def host_sync(self, ev):
         pass
 
-    def gather_keys(self, table, keys_i32):
+    def gather_keys(self, table, keys_i32, scratch=None):
         return torch.from_numpy(table.numpy()[keys_i32.numpy().astype(np.int64)])
+
+    def rows_buffer(self, name, rows, width):
+        return torch.empty((rows, width), dtype=torch.float32)
 
     def expand(self, rows, plan):
         return torch.from_numpy(rows.numpy()[plan.inv])
