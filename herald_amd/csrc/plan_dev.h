@@ -90,7 +90,7 @@ inline size_t rank_small_lds_bytes(int n) {
 constexpr int kRankTile = 32;
 
 template <typename IdT>
-__device__ __forceinline__ void rank_tile_body(
+__device__ __forceinline__ void rank_tile_body_int(
     const IdT *__restrict__ ids, int n, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ sorted, int32_t *__restrict__ perm, int tile,
     uint32_t *s_mem) {
@@ -167,6 +167,140 @@ __device__ __forceinline__ void rank_tile_body(
         perm[r] = i;
         keys[i] = ki;
     }
+}
+
+// float32 ids (the operator boundary, python/hetu/dataloader.py:14): same tiling, half the VALU work.
+// A key is the truncation of a float, i.e. itself a float, so the staged keys stay floats and
+//   [k_j <  k_i] = clamp(k_i - k_j)     (distinct integer-valued floats differ by >= 1, equal ones by 0)
+//   [k_j <= k_i] = 1 - clamp(k_j - k_i)
+// One v_pk_add_f32 with a negated operand and the clamp modifier evaluates the indicator for TWO keys
+// and a second packed add accumulates both: 1 VALU instruction per comparison where the integer form
+// (v_cmp + v_addc) needs 2.  Counts stay below 2^24, so the float accumulators are exact.  Pad keys
+// are +inf (clamp(k_i - inf) = 0).  Only the key pairs overlapping the tile need the index tie-break.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2v pk_sub_clamp01(float2v a, float2v b) {  // clamp(a - b, 0, 1) per half
+    float2v d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+__device__ __forceinline__ void rank_tile_body_f32(
+    const float *__restrict__ ids, int n, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ sorted, int32_t *__restrict__ perm, int tile,
+    uint32_t *s_mem) {
+    const int npad = (n + 127) & ~127;
+    float *s_keys = reinterpret_cast<float *>(s_mem);   // [npad] keys as floats
+    uint32_t *s_part = s_mem + npad;                    // [32 splits][32 elements]
+    for (int base = 0; base < npad; base += 8192) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = base + threadIdx.x + k * 1024;
+            const float kv = static_cast<float>(to_key<float>(ids[min(j, n - 1)]));  // exact: a truncated float
+            v[k] = j < n ? kv : __builtin_inff();
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = base + threadIdx.x + k * 1024;
+            if (j < npad)
+                s_keys[j] = v[k];
+        }
+    }
+    __syncthreads();
+
+    const int lane = lane_id();
+    const int il = lane & 31, h = lane >> 5;
+    const int w = uniform(static_cast<int>(threadIdx.x >> 6));
+    const int i0 = tile * kRankTile;
+    const int i = i0 + il;
+    const float ki = s_keys[min(i, npad - 1)];
+    const float2v ki2 = {ki, ki};
+
+    const int pairs = npad >> 3;
+    const int ppw = pairs >> 4;
+    const int pb = w * ppw, pe = pb + ppw;
+    const int tile_pb = i0 >> 3, tile_pe = (i0 + kRankTile) >> 3;
+
+    const float *kp = s_keys + 4 * h;
+    float2v gt = {0.f, 0.f};   // sum of [k_j > k_i] over the keys before the tile
+    float2v lt = {0.f, 0.f};   // sum of [k_j < k_i] over the keys behind the tile
+    const int pa = min(pe, tile_pb);
+    {   // four key quads per trip: the LDS reads of a trip are issued before its arithmetic
+        int p = pb;
+        for (; p + 4 <= pa; p += 4) {
+            float4v k[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                k[t] = *reinterpret_cast<const float4v *>(kp + 8 * (p + t));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                gt += pk_sub_clamp01(float2v{k[t][0], k[t][1]}, ki2);
+                gt += pk_sub_clamp01(float2v{k[t][2], k[t][3]}, ki2);
+            }
+        }
+        for (; p < pa; ++p) {
+            const float4v k = *reinterpret_cast<const float4v *>(kp + 8 * p);
+            gt += pk_sub_clamp01(float2v{k[0], k[1]}, ki2);
+            gt += pk_sub_clamp01(float2v{k[2], k[3]}, ki2);
+        }
+    }
+    uint32_t rank = pa > pb ? 4u * static_cast<uint32_t>(pa - pb) : 0u;   // "<=" = all minus ">"
+    for (int p = max(pb, tile_pb); p < min(pe, tile_pe); ++p) {
+        const float4v k = *reinterpret_cast<const float4v *>(kp + 8 * p);
+        const int j = 8 * p + 4 * h;
+        rank += (k[0] < ki) || (k[0] == ki && (j + 0) < i);
+        rank += (k[1] < ki) || (k[1] == ki && (j + 1) < i);
+        rank += (k[2] < ki) || (k[2] == ki && (j + 2) < i);
+        rank += (k[3] < ki) || (k[3] == ki && (j + 3) < i);
+    }
+    {
+        int p = max(pb, tile_pe);
+        for (; p + 4 <= pe; p += 4) {
+            float4v k[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                k[t] = *reinterpret_cast<const float4v *>(kp + 8 * (p + t));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                lt += pk_sub_clamp01(ki2, float2v{k[t][0], k[t][1]});
+                lt += pk_sub_clamp01(ki2, float2v{k[t][2], k[t][3]});
+            }
+        }
+        for (; p < pe; ++p) {
+            const float4v k = *reinterpret_cast<const float4v *>(kp + 8 * p);
+            lt += pk_sub_clamp01(ki2, float2v{k[0], k[1]});
+            lt += pk_sub_clamp01(ki2, float2v{k[2], k[3]});
+        }
+    }
+    rank += static_cast<uint32_t>(lt[0] + lt[1]) - static_cast<uint32_t>(gt[0] + gt[1]);
+    s_part[(w * 2 + h) * 32 + il] = rank;   // partial ranks may wrap below zero; their sum does not
+    __syncthreads();
+    if (threadIdx.x < 32 && i < n) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            r += s_part[k * 32 + il];
+        const uint32_t key = static_cast<uint32_t>(ki);
+        sorted[r] = key;
+        perm[r] = i;
+        keys[i] = key;
+    }
+}
+
+template <typename IdT>
+__device__ __forceinline__ void rank_tile_body(
+    const IdT *__restrict__ ids, int n, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ sorted, int32_t *__restrict__ perm, int tile,
+    uint32_t *s_mem) {
+    rank_tile_body_int<IdT>(ids, n, keys, sorted, perm, tile, s_mem);
+}
+template <>
+__device__ __forceinline__ void rank_tile_body<float>(
+    const float *__restrict__ ids, int n, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ sorted, int32_t *__restrict__ perm, int tile,
+    uint32_t *s_mem) {
+    rank_tile_body_f32(ids, n, keys, sorted, perm, tile, s_mem);
 }
 
 // Small-n finish (n <= kSmallMax): ceil(n/1024) independent workgroups, one sorted position per
