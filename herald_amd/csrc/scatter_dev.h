@@ -54,7 +54,9 @@ template <>
 struct Vec<4> {
     float4v v;
     __device__ __forceinline__ void load(const float *p) { v = ld4(p); }
-    __device__ __forceinline__ void store(float *p) const { st4(p, v); }
+    // updated rows are written around the L2 (non-temporal): nothing re-reads them inside the launch and
+    // dirty lines left in the L2 lengthen the boundary to the next kernel
+    __device__ __forceinline__ void store(float *p) const { st4_nt(p, v); }
     __device__ __forceinline__ void zero() { v = float4v{0.f, 0.f, 0.f, 0.f}; }
     __device__ __forceinline__ float get(int k) const { return v[k]; }
     __device__ __forceinline__ void set(int k, float x) { v[k] = x; }
@@ -63,7 +65,7 @@ template <>
 struct Vec<1> {
     float v;
     __device__ __forceinline__ void load(const float *p) { v = *p; }
-    __device__ __forceinline__ void store(float *p) const { *p = v; }
+    __device__ __forceinline__ void store(float *p) const { __builtin_nontemporal_store(v, p); }
     __device__ __forceinline__ void zero() { v = 0.f; }
     __device__ __forceinline__ float get(int) const { return v; }
     __device__ __forceinline__ void set(int, float x) { v = x; }
@@ -200,9 +202,9 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
     if (live) {
         if (MODE == kModePush)
             acc = __fadd_rn(dst_row[col], acc);
-        dst_row[col] = acc;
+        __builtin_nontemporal_store(acc, dst_row + col);
         if (DUAL && d2.on)
-            d2.row[col] = acc2;
+            __builtin_nontemporal_store(acc2, d2.row + col);
     }
 }
 
@@ -389,9 +391,9 @@ __device__ __forceinline__ bool coop_run(
         if (clive) {
             if (MODE == kModePush)
                 acc = __fadd_rn(dst_row[ccol], acc);
-            dst_row[ccol] = acc;
+            __builtin_nontemporal_store(acc, dst_row + ccol);
             if (DUAL && d2.on)
-                d2.row[ccol] = acc2;
+                __builtin_nontemporal_store(acc2, d2.row + ccol);
         }
     }
     return true;
