@@ -289,21 +289,31 @@ def main():
                                                      stream=main_s))
         a_ms = timed_graph(lambda i: ops.sgd_apply_finish(table, kplans[i], grads[i % ngrad], LR,
                                                           stream=main_s))
+        # Durations inside the timed sequence: the two launches alternate there and each boundary also
+        # pays for what the predecessor left behind (dirty lines, cold TLBs), so a launch lasts longer
+        # than in a graph of its own kind.  The step time measured over the timed region is split in the
+        # ratio of the isolated timings; rocprofv3's per-kernel averages of the same command
+        # (profiles/) agree with these in-sequence figures.
+        share = ms_per_step / (g_ms + a_ms)
+        g_seq, a_seq = g_ms * share, a_ms * share
         kernels = {
-            "fwd_fused_kernel(gather+rank)": {"avg_us": g_ms * 1e3, "algorithmic_bytes": fwd_b,
-                                              "GBps": fwd_b / (g_ms * 1e-3) / 1e9},
-            "bwd_fused_kernel(sgd apply+finish)": {"avg_us": a_ms * 1e3, "algorithmic_bytes": bwd_b,
-                                                   "GBps": bwd_b / (a_ms * 1e-3) / 1e9},
+            "fwd_fused_kernel(gather+rank)": {"avg_us": g_seq * 1e3, "isolated_us": g_ms * 1e3,
+                                              "algorithmic_bytes": fwd_b,
+                                              "GBps": fwd_b / (g_seq * 1e-3) / 1e9},
+            "bwd_fused_kernel(sgd apply+finish)": {"avg_us": a_seq * 1e3, "isolated_us": a_ms * 1e3,
+                                                   "algorithmic_bytes": bwd_b,
+                                                   "GBps": bwd_b / (a_seq * 1e-3) / 1e9},
         }
         dom = "bwd_fused_kernel(sgd apply+finish)" if a_ms >= g_ms else "fwd_fused_kernel(gather+rank)"
         dom_bytes = bwd_b if a_ms >= g_ms else fwd_b
-        dom_ms = max(a_ms, g_ms)
+        dom_ms = max(a_seq, g_seq)
         traffic, traffic_src = pmc_traffic("ha::bwd_fused_kernel" if a_ms >= g_ms else "ha::fwd_fused_kernel")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": traffic_src,
-                    "avg_launch_us": dom_ms * 1e3, "algorithmic_bytes_per_launch": dom_bytes}
+                    "avg_launch_us": dom_ms * 1e3, "isolated_launch_us": max(a_ms, g_ms) * 1e3,
+                    "algorithmic_bytes_per_launch": dom_bytes}
 
     step_gbs = (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9
     result = {
