@@ -203,10 +203,12 @@ def main():
     #   forward : gather(ids) + stable sort of ids            (ha_lookup_sort_f32ids)
     #   backward: fused SGD apply + plan finish (uniq/counts) (ha_sgd_apply_finish)
     # The table dependency gather(k) -> apply(k) -> gather(k+1) is the stream order.
+    # The backward launch is handed the ids of the NEXT batch (resident one step ahead, as the reference's
+    # prefetching data loader provides them): its idle waves touch the rows the next lookup will gather.
     def step(k):
         ids = ids_dev[k % nb]
         ops.lookup_sort(table, ids, plan, out=out, stream=main_s)
-        ops.sgd_apply_finish(table, plan, grads[k % ngrad], LR, stream=main_s)
+        ops.sgd_apply_finish(table, plan, grads[k % ngrad], LR, stream=main_s, next_ids=ids_dev[(k + 1) % nb])
 
     graphs = {}
 
@@ -287,8 +289,8 @@ def main():
 
         g_ms = timed_graph(lambda i: ops.lookup_sort(table, ids_dev[(wu + i) % nb], kplans[i], out=out,
                                                      stream=main_s))
-        a_ms = timed_graph(lambda i: ops.sgd_apply_finish(table, kplans[i], grads[i % ngrad], LR,
-                                                          stream=main_s))
+        a_ms = timed_graph(lambda i: ops.sgd_apply_finish(table, kplans[i], grads[i % ngrad], LR, stream=main_s,
+                                                          next_ids=ids_dev[(wu + i + 1) % nb]))
         # Durations inside the timed sequence: the two launches alternate there and each boundary also
         # pays for what the predecessor left behind (dirty lines, cold TLBs), so a launch lasts longer
         # than in a graph of its own kind.  The step time measured over the timed region is split in the

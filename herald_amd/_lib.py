@@ -114,6 +114,7 @@ def _declare(L):
         "ha_lookup_sort_u64ids": [vp, i64, i64, vp, i64, vp, vp, vp],
         "ha_sgd_apply_finish": [vp, i64, i64, vp, i64, vp, f32, vp],
         "ha_push_apply_finish": [vp, i64, i64, vp, i64, vp, vp],
+        "ha_sgd_apply_finish_prefetch_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

@@ -31,6 +31,10 @@ __global__ __launch_bounds__(1024) void fwd_fused_kernel(
                                                 out, b - n_rank_tiles);
 }
 
+// pf_ids != nullptr: a wave that left early or applied a short run (more than half of them) ends by
+// touching the table row the NEXT batch's position p will gather, so that the forward launch that
+// follows finds it in the memory-side cache instead of HBM (the ids of the next batch are known one
+// step ahead).  The row is loaded and dropped; waves with medium / long-run work skip this.
 template <int MODE, int VEC>
 __global__ __launch_bounds__(1024, 8) void bwd_fused_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
@@ -38,14 +42,29 @@ __global__ __launch_bounds__(1024, 8) void bwd_fused_kernel(
     int n, const float *__restrict__ grads, float lr,
     PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
-    int32_t *__restrict__ inverse, int32_t *__restrict__ upos, int n_finish_blocks) {
+    int32_t *__restrict__ inverse, int32_t *__restrict__ upos, int n_finish_blocks,
+    const float *__restrict__ pf_ids, int pf_n) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const int b = blockIdx.x;
-    if (b < n_finish_blocks)
+    if (b < n_finish_blocks) {
         finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, b, s_dyn);
-    else
-        apply_body<MODE, VEC>(dst, dst_rows, width, sorted, perm, nullptr, n,
-                              grads, lr, b - n_finish_blocks, s_dyn);
+        return;
+    }
+    const bool heavy = apply_body<MODE, VEC>(dst, dst_rows, width, sorted, perm, nullptr, n,
+                                             grads, lr, b - n_finish_blocks, s_dyn);
+    if (VEC == 4 && pf_ids != nullptr && !heavy) {
+        const int p = (b - n_finish_blocks) * kPosPerBlock + static_cast<int>(threadIdx.x >> 6);
+        if (p < pf_n) {
+            const uint32_t key = f32_to_key(pf_ids[p]);
+            if (key < dst_rows) {
+                const float *row = dst + static_cast<uint64_t>(key) * static_cast<uint64_t>(width);
+                float4v x = {0.f, 0.f, 0.f, 0.f};
+                for (int j = lane_id() * 4; j < width; j += kWave * 4)
+                    x += ld4(row + j);
+                asm volatile("" ::"v"(x));   // keep the loads
+            }
+        }
+    }
 }
 
 static int nv_shift_of(uint32_t nv) {
@@ -110,7 +129,7 @@ static bool fallback_u64(const float *table, int64_t rows, int64_t width,
 template <int MODE>
 static int apply_finish(float *dst, int64_t rows, int64_t width, void *plan_ws,
                         int64_t n, const float *grads, float lr,
-                        hipStream_t stream) {
+                        hipStream_t stream, const float *pf_ids = nullptr, int64_t pf_n = 0) {
     HA_REQUIRE(n >= 0 && width >= 1 && width < (1 << 30), "apply_finish: bad sizes");
     HA_REQUIRE(plan_ws != nullptr, "apply_finish: null plan workspace");
     if (n == 0 || n > kSmallMax) {
@@ -134,11 +153,13 @@ static int apply_finish(float *dst, int64_t rows, int64_t width, void *plan_ws,
     if (vec_ok)
         hipLaunchKernelGGL((bwd_fused_kernel<MODE, 4>), dim3(blocks), dim3(1024), lds,
                            stream, dst, (uint64_t)rows, (int)width, p.sorted, p.perm,
-                           ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, fblocks);
+                           ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, fblocks,
+                           pf_ids, (int)(pf_n < n ? pf_n : n));
     else
         hipLaunchKernelGGL((bwd_fused_kernel<MODE, 1>), dim3(blocks), dim3(1024), lds,
                            stream, dst, (uint64_t)rows, (int)width, p.sorted, p.perm,
-                           ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, fblocks);
+                           ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, fblocks,
+                           pf_ids, (int)(pf_n < n ? pf_n : n));
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -175,4 +196,13 @@ extern "C" int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
                                     ha_stream_t stream) {
     return apply_finish<kModePush>(table, rows, width, plan_ws, n, grads, 1.f,
                                    as_stream(stream));
+}
+
+extern "C" int ha_sgd_apply_finish_prefetch_f32ids(float *table, int64_t rows, int64_t width,
+                                                   void *plan_ws, int64_t n, const float *grads,
+                                                   float lr, const float *next_ids, int64_t next_n,
+                                                   ha_stream_t stream) {
+    HA_REQUIRE(next_n >= 0 && (next_n == 0 || next_ids), "apply_finish_prefetch: bad next batch");
+    return apply_finish<kModeSgd>(table, rows, width, plan_ws, n, grads, lr, as_stream(stream),
+                                  next_n > 0 ? next_ids : nullptr, next_n);
 }

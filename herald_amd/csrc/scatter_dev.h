@@ -401,7 +401,7 @@ __device__ __forceinline__ bool coop_run(
 
 // One wave per sorted position p; `lds` = kApplyLdsBytes of workgroup memory (long runs only).
 template <int MODE, int VEC, bool DUAL>
-__device__ __forceinline__ void apply_body_impl(
+__device__ __forceinline__ bool apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
@@ -410,8 +410,9 @@ __device__ __forceinline__ void apply_body_impl(
 // `dbg` (tools/timeline.py only) receives {realtime start, realtime end, role/len, shader cycles}
 // per position.  The early return below is taken by whole waves of the LAST workgroup only, which is
 // never a full one, so the barriers of coop_run see all 16 waves.
+// Returns true when the wave did medium / long-run work (false: it left early or applied a short run).
 template <int MODE, int VEC, bool DUAL = false>
-__device__ __forceinline__ void apply_body(
+__device__ __forceinline__ bool apply_body(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
@@ -420,15 +421,13 @@ __device__ __forceinline__ void apply_body(
     const int w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int p = vblock * kPosPerBlock + w;
     if (p >= n)
-        return;
-    if (dbg == nullptr) {
-        apply_body_impl<MODE, VEC, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds);
-        return;
-    }
+        return false;
+    if (dbg == nullptr)
+        return apply_body_impl<MODE, VEC, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     int info = 0;
-    apply_body_impl<MODE, VEC, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds);
+    const bool heavy = apply_body_impl<MODE, VEC, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds);
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -438,10 +437,11 @@ __device__ __forceinline__ void apply_body(
         dbg[p * 4 + 2] = static_cast<unsigned long long>(info);
         dbg[p * 4 + 3] = c1 - c0;
     }
+    return heavy;
 }
 
 template <int MODE, int VEC, bool DUAL>
-__device__ __forceinline__ void apply_body_impl(
+__device__ __forceinline__ bool apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
@@ -467,7 +467,7 @@ __device__ __forceinline__ void apply_body_impl(
         if (dbg_info)
             *dbg_info = (w << 16) | 0x7FFF;
         if (coop_run<MODE, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds))
-            return;
+            return true;
     }
     const unsigned long long eq = __ballot(q >= 0 && q < n && ks == key);
     const uint32_t inv_lo = static_cast<uint32_t>(~eq) & 0xFFFFu;
@@ -477,10 +477,10 @@ __device__ __forceinline__ void apply_body_impl(
     // per-wave paths: runs shorter than kLongRun; their workers sit at offsets < 16, so both ends of
     // the run are inside the window and the length is exact
     if (o >= kLookBack || fwd >= 48)
-        return;
+        return false;
     const int len = o + fwd;
     if (len >= kLongRun)
-        return;
+        return false;
     if (dbg_info)
         *dbg_info = (o << 16) | len;
 
@@ -489,7 +489,7 @@ __device__ __forceinline__ void apply_body_impl(
     if (maps.rowmap) {
         const int r = maps.rowmap[upos[p]];
         if (r < 0)
-            return;  // unique key without a destination
+            return false;  // unique key without a destination
         row = static_cast<uint64_t>(r);
         if (maps.dst_init)
             init = maps.dst_init[r] != 0;
@@ -499,7 +499,7 @@ __device__ __forceinline__ void apply_body_impl(
         row = key;
     }
     if (row >= dst_rows)
-        return;  // out-of-range id: ignored (undefined behaviour in the reference)
+        return false;  // out-of-range id: ignored (undefined behaviour in the reference)
     float *dst_row = dst + row * static_cast<uint64_t>(width);
     Second d2{nullptr, false};
     if (DUAL && maps.rowmap2) {
@@ -511,11 +511,12 @@ __device__ __forceinline__ void apply_body_impl(
     if (len <= kShortRun) {
         if (o == 0)
             short_row<MODE, VEC, DUAL>(dst_row, grads, width, pv, kLookBack, len, lr, init, d2);
-        return;
+        return false;
     }
     const int workers = min(len, kLookBack);
     for (int c0 = o * kWave; c0 < width; c0 += workers * kWave)
         medium_slice<MODE, DUAL>(dst_row, grads, width, c0 + lane, pv, kLookBack - o, len, lr, init, d2);
+    return o < workers;
 }
 
 }  // namespace ha

@@ -268,10 +268,18 @@ def lookup_sort(table, ids, plan, out=None, stream=None):
     return out
 
 
-def sgd_apply_finish(table, plan, grads, lr, stream=None):
-    """Backward of one batch in ONE launch: sgd_apply + plan.finish()."""
+def sgd_apply_finish(table, plan, grads, lr, stream=None, next_ids=None):
+    """Backward of one batch in ONE launch: sgd_apply + plan.finish().  next_ids (float32): the ids of
+    the batch whose lookup follows -- their rows are touched on the way out so that the lookup finds
+    them in the Infinity Cache (ha_sgd_apply_finish_prefetch_f32ids)."""
     _require(table, torch.float32, "table")
     _require(grads, torch.float32, "grads")
+    if next_ids is not None and next_ids.dtype == torch.float32:
+        _require(next_ids, torch.float32, "next_ids")
+        check(_lib.load().ha_sgd_apply_finish_prefetch_f32ids(
+            _ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws), plan.n, _ptr(grads), ctypes.c_float(lr),
+            _ptr(next_ids), next_ids.numel(), _stream_ptr(stream)), "ha_sgd_apply_finish_prefetch_f32ids")
+        return table
     check(_lib.load().ha_sgd_apply_finish(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws),
                                           plan.n, _ptr(grads), ctypes.c_float(lr), _stream_ptr(stream)),
           "ha_sgd_apply_finish")

@@ -283,6 +283,15 @@ int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
                          void *plan_ws, int64_t n, const float *grads,
                          ha_stream_t stream);
 
+/* ha_sgd_apply_finish that also warms the memory-side cache for the NEXT batch: waves that have no
+ * medium / long-run work (more than half of them) end by touching the table row that position p of
+ * next_ids will gather, so the ha_lookup_sort_* / ha_gather_* that follows reads it from the
+ * Infinity Cache instead of HBM.  The ids of the next batch are known one step ahead (the reference
+ * prefetches too: ParameterServerCommunicate.py:96-139).  Results are those of ha_sgd_apply_finish. */
+int ha_sgd_apply_finish_prefetch_f32ids(float *table, int64_t rows, int64_t width,
+                                        void *plan_ws, int64_t n, const float *grads, float lr,
+                                        const float *next_ids, int64_t next_n, ha_stream_t stream);
+
 /* ---- row-range sharding (in-node replacement of the PS/worker split) -------
  * For the plan's sorted unique keys: offsets[g] = index of the first unique key owned by shard g
  * (offsets[nshard] = n_unique) and local_keys[u] = uniq[u] - starts[owner(u)], where shard g owns

@@ -252,6 +252,28 @@ def test_fused_step_matches_oracle_and_unfused(dev, width, n):
     np.testing.assert_array_equal(t2.cpu().numpy(), cpu.push_apply(table.copy(), uniq, red))
 
 
+def test_backward_with_next_batch_prefetch_is_the_same_backward(dev):
+    """ha_sgd_apply_finish_prefetch_f32ids only touches rows of the next batch: table and plan equal the
+    plain backward bit for bit (ids of the next batch may exceed the table or the batch length)."""
+    rng = np.random.default_rng(17)
+    rows, width, n = 20000, 128, 6656
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = (synth.criteo_batch(256, 2).reshape(-1) % rows).astype(np.float32)
+    nxt = (synth.criteo_batch(300, 3).reshape(-1) % (rows + 500)).astype(np.float32)     # longer, partly out of range
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    res = []
+    for use_next in (False, True):
+        t = _dev(table, dev)
+        plan = ops.IndexPlan(n, dev)
+        ops.lookup_sort(t, _dev(ids, dev), plan)
+        ops.sgd_apply_finish(t, plan, _dev(grads, dev), 0.1, next_ids=_dev(nxt, dev) if use_next else None)
+        torch.cuda.synchronize()
+        res.append((t.cpu().numpy(), plan.inverse().cpu().numpy(), plan.counts().cpu().numpy()))
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[0][0], cpu.sgd_sparse_update(table.copy(), ids, grads, 0.1))
+
+
 def test_sharded_single_rank_hip_engine(dev):
     """herald_amd.sharded with the HIP engine at world_size 1: SparsePull / SparsePush semantics."""
     from herald_amd.sharded import ShardedEmbedding
