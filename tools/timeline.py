@@ -11,8 +11,10 @@ L = _lib.load()
 L.ha_debug_apply_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
                                       ctypes.c_void_p]
-rows, width, n = 2000000, 512, 6656
-table = torch.randn((rows, width), device=dev) * 0.01
+rows, width, n = int(os.environ.get("ROWS", "2000000")), 512, 6656
+table = torch.empty((rows, width), device=dev)
+for _s in range(0, rows, 1 << 20):
+    table[_s:_s + (1 << 20)].normal_(0, 0.01)
 grads = torch.randn((n, width), device=dev)
 for case in ("criteo", "distinct"):
     for rep in range(3):
