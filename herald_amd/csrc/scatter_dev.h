@@ -338,24 +338,40 @@ __device__ __forceinline__ bool coop_run(
                         (static_cast<size_t>(cl * tlen + tc * kChunk) / 4) * kWave + lane;
         const float4v *s_rd = reinterpret_cast<const float4v *>(s_m) +
                               (static_cast<size_t>(w * tlen) / 4) * kWave + lane;
+        // the rows of block b+1 are requested before the chain of block b runs (registers are free
+        // again once block b sits in LDS), so a giant run costs its ordered chain, not chain + loads
+        float g[kChunk];
+        auto load_idx = [&](int base) {   // occurrence index of this wave's 16 positions of a block
+            const int t = base + tc * kChunk + (lane & 15);
+            int idx = perm[min(s + t, n - 1)];
+            if (maps.valmap)
+                idx = maps.valmap[idx];
+            return idx;
+        };
+        auto request = [&](int idx) {
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                const int r = __builtin_amdgcn_readlane(idx, i);
+                g[i] = (grads + static_cast<size_t>(r) * width)[lcol];
+            }
+        };
+        int idx_next = 0;
+        if (loader) {
+            request(load_idx(0));
+            idx_next = load_idx(tlen);      // one block ahead of the rows, two ahead of the chain
+        }
         for (int base = 0; base < len; base += tlen) {
             if (loader) {
-                const int t = base + tc * kChunk + (lane & 15);
-                int idx = perm[min(s + t, n - 1)];
-                if (maps.valmap)
-                    idx = maps.valmap[idx];
-                float g[kChunk];
-#pragma unroll
-                for (int i = 0; i < kChunk; ++i) {
-                    const int r = __builtin_amdgcn_readlane(idx, i);
-                    g[i] = (grads + static_cast<size_t>(r) * width)[lcol];
-                }
 #pragma unroll
                 for (int i = 0; i < kChunk; i += 4)
                     s_wr[(i / 4) * kWave] = float4v{__fmul_rn(lr, g[i]), __fmul_rn(lr, g[i + 1]),
                                                     __fmul_rn(lr, g[i + 2]), __fmul_rn(lr, g[i + 3])};
             }
             __syncthreads();
+            if (loader && base + tlen < len) {
+                request(idx_next);
+                idx_next = load_idx(base + 2 * tlen);
+            }
             if (chain) {
                 const int cnt = min(tlen, len - base);
                 int k = 0;
