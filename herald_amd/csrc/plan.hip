@@ -272,6 +272,35 @@ __global__ __launch_bounds__(1024) void finish_small_kernel(
     finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, blockIdx.x, s_w);
 }
 
+// heads per 1024-position chunk (first launch of the two-launch finish of medium-sized batches)
+__global__ __launch_bounds__(1024) void finish_chunk_heads_kernel(
+    const uint32_t *__restrict__ sorted, int n, uint32_t *__restrict__ chunk_heads) {
+    __shared__ uint32_t s_w[16];
+    const int p = blockIdx.x * 1024 + threadIdx.x;
+    const int cp = min(p, n - 1);
+    const uint32_t k = sorted[cp], kprev = sorted[max(cp - 1, 0)];
+    const unsigned long long hm = __ballot(p < n && (p == 0 || k != kprev));
+    if (lane_id() == 0)
+        s_w[threadIdx.x >> 6] = __builtin_popcountll(hm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int i = 0; i < 16; ++i)
+            t += s_w[i];
+        chunk_heads[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void finish_chunked_kernel(
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    int n, PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
+    int32_t *__restrict__ seg, int32_t *__restrict__ counts,
+    int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
+    const uint32_t *__restrict__ chunk_heads) {
+    __shared__ uint32_t s_w[kFinishLdsWords];
+    finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, blockIdx.x, s_w, chunk_heads);
+}
+
 __global__ void plan_empty_kernel(PlanHeader *hdr, int32_t *seg) {
     hdr->n_unique = 0;
     seg[0] = 0;
@@ -363,6 +392,15 @@ static int plan_finish(void *ws, int64_t n, hipStream_t stream) {
         hipLaunchKernelGGL(finish_small_kernel, dim3(finish_blocks(ni)), dim3(1024), 0, stream,
                            p.sorted, p.perm, ni, p.hdr, p.uniq, p.seg,
                            p.counts, p.inverse, p.upos);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
+    if (n <= kFinishChunkedMax) {
+        // heads per chunk into the radix histogram scratch (free after the sort, >= n/16 words)
+        const int chunks = finish_blocks(ni);
+        hipLaunchKernelGGL(finish_chunk_heads_kernel, dim3(chunks), dim3(1024), 0, stream, p.sorted, ni, p.hist);
+        hipLaunchKernelGGL(finish_chunked_kernel, dim3(chunks), dim3(1024), 0, stream, p.sorted, p.perm, ni,
+                           p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, p.hist);
         HA_LAUNCH_CHECK();
         return 0;
     }

@@ -314,7 +314,9 @@ __device__ __forceinline__ void rank_tile_body<float>(
 //     outside it, and its end is found by probing the following chunks (the first probe is requested
 //     together with everything else, so the common case costs no extra round trip).
 // Registers: a handful per thread -- this body shares a kernel with the apply blocks and must not
-// raise their budget.  LDS: 64 words.
+// raise their budget.  LDS: 64 words.  For batches up to kFinishChunkedMax ids the same body runs
+// behind one counting launch (heads per chunk) instead of recounting: two launches in all.
+constexpr int kFinishChunkedMax = 1 << 20;
 constexpr int kFinishLdsWords = 64;
 inline int finish_blocks(int n) { return (n + 1023) / 1024; }
 
@@ -323,7 +325,7 @@ __device__ __forceinline__ void finish_block_body(
     int n, PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
-    int b, uint32_t *s_w) {
+    int b, uint32_t *s_w, const uint32_t *__restrict__ chunk_heads = nullptr) {
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t *s_before = s_w, *s_heads = s_w + 16, *s_first = s_w + 32, *s_cand = s_w + 48;
     const int p = b * 1024 + tid;
@@ -336,7 +338,10 @@ __device__ __forceinline__ void finish_block_body(
     const uint32_t k1 = sorted[min(q1, n - 1)];
     const uint32_t k1prev = sorted[max(min(q1, n - 1) - 1, 0)];
     uint32_t before = 0;
-    for (int c = 0; c < b; c += 4) {
+    // larger batches: the heads of every chunk were counted by a first launch (chunk_heads)
+    for (int c = tid; chunk_heads != nullptr && c < b; c += 1024)
+        before += chunk_heads[c];
+    for (int c = 0; chunk_heads == nullptr && c < b; c += 4) {
         uint32_t x[4], y[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {

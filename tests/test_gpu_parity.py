@@ -94,7 +94,7 @@ def test_plan_small_path(dev, n):
     _check_plan(ids, dev)
 
 
-@pytest.mark.parametrize("n", [15361, 26624, 106496, 300000])
+@pytest.mark.parametrize("n", [15361, 26624, 106496, 300000, 1048576, 1100000])
 def test_plan_radix_path(dev, n):
     rng = np.random.default_rng(n)
     ids = synth.as_f32_ids(rng.integers(0, synth.CRITEO_ROWS, size=n))
