@@ -360,6 +360,10 @@ __device__ __forceinline__ bool coop_run(
             request(load_idx(0));
             idx_next = load_idx(tlen);      // one block ahead of the rows, two ahead of the chain
         }
+        // the accumulators' initial loads are older than every row request: resolve them here, or the
+        // chain's first use makes the compiler drain the in-order load counter inside the loop and the
+        // rows requested for the next block are waited for before the chain instead of behind it
+        asm volatile("" ::"v"(acc), "v"(acc2));
         for (int base = 0; base < len; base += tlen) {
             if (loader) {
 #pragma unroll
@@ -472,6 +476,11 @@ __device__ __forceinline__ bool apply_body_impl(
     int pv = perm[cq];
     const uint32_t bk = sorted[max(wg0 - kWave * (w + 1) + lane, 0)];
     const uint32_t fk = sorted[min(wg0 + kPosPerBlock + kWave * w + lane, n - 1)];
+    // a full workgroup is a worker of its run only if the run starts less than nslice workgroups
+    // before it: one more (uniform) key decides that for workgroups deep inside a long run, which
+    // then leave without the scan exchange
+    const int deep = wg0 - kPosPerBlock * ((width + kWave - 1) / kWave) - kPosPerBlock;
+    const uint32_t dk = sorted[max(deep, 0)];
     if (maps.valmap)  // wave-uniform
         pv = maps.valmap[pv];
     const uint32_t key = static_cast<uint32_t>(
@@ -480,6 +489,8 @@ __device__ __forceinline__ bool apply_body_impl(
     const uint32_t key_first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ks), kLookBack - w));
     const uint32_t key_last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ks), kLookBack - w + kPosPerBlock - 1));
     if (wg0 + kPosPerBlock <= n && key_first == key_last) {
+        if (deep >= 0 && dk == key)
+            return false;   // >= nslice full workgroups of this run precede: not a worker
         if (dbg_info)
             *dbg_info = (w << 16) | 0x7FFF;
         if (coop_run<MODE, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds))

@@ -11,7 +11,8 @@ L = _lib.load()
 L.ha_debug_apply_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
                                       ctypes.c_void_p]
-rows, width, n = int(os.environ.get("ROWS", "2000000")), 512, 6656
+BATCH = int(os.environ.get("BATCH", "256"))
+rows, width, n = int(os.environ.get("ROWS", "2000000")), int(os.environ.get("WIDTH", "512")), BATCH * 26
 table = torch.empty((rows, width), device=dev)
 for _s in range(0, rows, 1 << 20):
     table[_s:_s + (1 << 20)].normal_(0, 0.01)
@@ -19,7 +20,7 @@ grads = torch.randn((n, width), device=dev)
 for case in ("criteo", "distinct"):
     for rep in range(3):
         if case == "criteo":
-            ids = np.minimum(synth.as_f32_ids(synth.criteo_batch(256, rep, rows=rows)).reshape(-1), rows - 1)
+            ids = np.minimum(synth.as_f32_ids(synth.criteo_batch(BATCH, rep, rows=rows)).reshape(-1), rows - 1)
         else:
             ids = np.random.default_rng(rep).choice(rows, size=n, replace=False).astype(np.float32)
         d_ids = torch.from_numpy(ids).to(dev)
@@ -47,8 +48,8 @@ for case in ("criteo", "distinct"):
         if m.any():
             print("   run len %4d-%-5d heads %4d: dur p50 %.2f max %.2f us, end max %.2f" %
                   (lo, hi, m.sum(), np.median(dur[m]), dur[m].max(), e[m].max()))
-    print("   start by position:", " ".join("%d:%.2f" % (q, s[q]) for q in range(0, n, 416)))
-    print("   end   by position:", " ".join("%d:%.2f" % (q, e[q]) for q in range(0, n, 416)))
+
+
     top = np.argsort(-e * live)[:6]
     for p in top:
         print("   late wave p=%d o=%d len=%d start %.2f end %.2f cycles %d" % (p, o[p], ln[p], s[p], e[p], d[p, 3]))
