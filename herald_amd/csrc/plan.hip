@@ -16,7 +16,8 @@
 //                    One launch, no inter-workgroup communication, O(n^2/64) VALU wave-instructions
 //                    spread over ceil(n/64) CUs: ~2 us for the 6,656-id wdl_criteo batch, where a
 //                    multi-pass radix sort would pay >= 12 dependent kernel boundaries.
-//   larger n       : LSD radix sort, 8-bit digits, wave-ballot multisplit ranking (stable).
+//   larger n       : LSD radix sort, 11-bit digits (3 passes for any 32-bit key), wave-ballot
+//                    multisplit ranking (stable); up to 64 tiles a pass is two launches.
 #include "plan_dev.h"
 
 namespace ha {
@@ -41,19 +42,22 @@ __global__ __launch_bounds__(256) void plan_convert_kernel(
         keys[i] = to_key<IdT>(ids[i]);
 }
 
-// per-block digit histogram; hist[d * nblk + blk]
+// per-block digit histogram; hist[d * nblk + blk] (digit-major: the flat exclusive scan of the large
+// path orders it) or hist[blk * kRadixBuckets + d] (tile-major: coalesced for the fused scatter)
 __global__ __launch_bounds__(256) void radix_hist_kernel(
     const uint32_t *__restrict__ keys, int n, int shift, int nblk,
-    uint32_t *__restrict__ hist) {
-    __shared__ uint32_t s_h[256];
-    s_h[threadIdx.x] = 0;
+    uint32_t *__restrict__ hist, int tile_major) {
+    __shared__ uint32_t s_h[kRadixBuckets];
+    for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
+        s_h[d] = 0;
     __syncthreads();
     const int base = blockIdx.x * kRadixTile;
     const int end = min(n, base + kRadixTile);
     for (int j = base + threadIdx.x; j < end; j += 256)
-        atomicAdd(&s_h[(keys[j] >> shift) & 255u], 1u);
+        atomicAdd(&s_h[(keys[j] >> shift) & (kRadixBuckets - 1u)], 1u);
     __syncthreads();
-    hist[threadIdx.x * nblk + blockIdx.x] = s_h[threadIdx.x];
+    for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
+        hist[tile_major ? blockIdx.x * kRadixBuckets + d : d * nblk + blockIdx.x] = s_h[d];
 }
 
 // exclusive scan of `m` uint32 values in place, single workgroup of 1024 threads
@@ -93,17 +97,25 @@ __global__ __launch_bounds__(1024) void scan_exclusive_kernel(
         *total_out = s_carry;
 }
 
-// stable scatter of one digit pass.  Each of the 4 waves owns a contiguous quarter of the tile
-// and walks it in rows of 64 keys; within a row, lanes with equal digits are ranked by a
-// ballot match (8 ballots), the per-wave running digit counters live in LDS.
+// stable scatter of one digit pass (kRadixBits = 11: three passes sort any 32-bit key, two sort 22
+// bits).  Each of the 4 waves owns a contiguous quarter of the tile and walks it in rows of 64 keys;
+// within a row, lanes with equal digits are ranked by a ballot match (11 ballots), the per-wave running
+// digit counters live in LDS (4 x 2048 words).  PRESCANNED = false (up to kRadixFusedBlocks tiles):
+// the block derives its own global digit bases from the raw per-block histograms -- every thread sums
+// eight digits over all tiles, one block scan orders the digits -- so a pass is two launches
+// (histogram, scatter) instead of three.  PRESCANNED = true: `hist` was scanned by scan_exclusive_kernel.
+template <bool PRESCANNED>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ perm_in,
     int n, int shift, int nblk, const uint32_t *__restrict__ hist,
     uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out) {
     constexpr int kRows = kRadixTile / 256;  // rows of 64 keys per wave
-    __shared__ uint32_t s_cnt[4][256];
+    constexpr int kPerThread = kRadixBuckets / 256;
+    __shared__ uint32_t s_cnt[4][kRadixBuckets];
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_tot[PRESCANNED ? 1 : kRadixBuckets], s_mine[PRESCANNED ? 1 : kRadixBuckets];
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    for (int k = threadIdx.x; k < 4 * 256; k += 256)
+    for (int k = threadIdx.x; k < 4 * kRadixBuckets; k += 256)
         (&s_cnt[0][0])[k] = 0;
     __syncthreads();
 
@@ -112,16 +124,21 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
     int32_t val[kRows];
     uint32_t lrank[kRows];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // all keys / values of the wave's rows first (branch-free, one batch of loads), then the ranking
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int j = min(wbase + r * 64 + lane, n - 1);
+        key[r] = keys_in[j];
+        val[r] = perm_in ? perm_in[j] : j;
+    }
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
         const int j = wbase + r * 64 + lane;
         const bool ok = j < n;
-        key[r] = ok ? keys_in[j] : 0u;
-        val[r] = ok ? (perm_in ? perm_in[j] : j) : 0;
-        const uint32_t d = (key[r] >> shift) & 255u;
+        const uint32_t d = (key[r] >> shift) & (kRadixBuckets - 1u);
         unsigned long long m = __ballot(ok);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < kRadixBits; ++b) {
             const unsigned long long bb = __ballot((d >> b) & 1u);
             m &= ((d >> b) & 1u) ? bb : ~bb;
         }
@@ -140,15 +157,84 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // digit d = threadIdx.x: exclusive prefix over the 4 waves + global base
+    // digits d = threadIdx.x * kPerThread ..: global base of the digit in this tile, then the exclusive
+    // prefix over the 4 waves
     {
-        const int d = threadIdx.x;
-        uint32_t run = hist[d * nblk + blockIdx.x];
+        uint32_t run[kPerThread];
+        const int d0 = threadIdx.x * kPerThread;
+        if (PRESCANNED) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t c = s_cnt[k][d];
-            s_cnt[k][d] = run;
-            run += c;
+            for (int q = 0; q < kPerThread; ++q)
+                run[q] = hist[(d0 + q) * nblk + blockIdx.x];
+        } else {
+            // coalesced pass over the tile-major histograms (thread t sums digits t, t+256, ...), then
+            // through LDS to the thread that owns eight consecutive digits
+            uint32_t tot[kPerThread], mine[kPerThread];
+#pragma unroll
+            for (int q = 0; q < kPerThread; ++q)
+                tot[q] = mine[q] = 0;
+            for (int k0 = 0; k0 < nblk; k0 += 4) {   // four tiles per trip: 32 independent loads in flight
+                uint32_t v[4][kPerThread];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const uint32_t *h = hist + static_cast<size_t>(min(k0 + kk, nblk - 1)) * kRadixBuckets + threadIdx.x;
+#pragma unroll
+                    for (int q = 0; q < kPerThread; ++q)
+                        v[kk][q] = h[q * 256];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = k0 + kk;
+#pragma unroll
+                    for (int q = 0; q < kPerThread; ++q) {
+                        mine[q] += k < static_cast<int>(blockIdx.x) ? v[kk][q] : 0u;   // k < blockIdx.x implies k < nblk
+                        tot[q] += k < nblk ? v[kk][q] : 0u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kPerThread; ++q) {
+                s_tot[q * 256 + threadIdx.x] = tot[q];
+                s_mine[q * 256 + threadIdx.x] = mine[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kPerThread; ++q) {
+                tot[q] = s_tot[d0 + q];
+                mine[q] = s_mine[d0 + q];
+            }
+            uint32_t local = 0;
+#pragma unroll
+            for (int q = 0; q < kPerThread; ++q)
+                local += tot[q];
+            uint32_t x = local;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(x, o, 64);
+                if (lane >= o)
+                    x += y;
+            }
+            if (lane == 63)
+                s_scan[w] = x;
+            __syncthreads();
+            uint32_t off = x - local;
+            for (int k = 0; k < w; ++k)
+                off += s_scan[k];
+#pragma unroll
+            for (int q = 0; q < kPerThread; ++q) {
+                run[q] = off + mine[q];
+                off += tot[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kPerThread; ++q) {
+            uint32_t r = run[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c = s_cnt[k][d0 + q];
+                s_cnt[k][d0 + q] = r;
+                r += c;
+            }
         }
     }
     __syncthreads();
@@ -156,7 +242,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
     for (int r = 0; r < kRows; ++r) {
         const int j = wbase + r * 64 + lane;
         if (j < n) {
-            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t d = (key[r] >> shift) & (kRadixBuckets - 1u);
             const uint32_t pos = s_cnt[w][d] + lrank[r];
             keys_out[pos] = key[r];
             perm_out[pos] = val[r];
@@ -344,11 +430,11 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
         HA_LAUNCH_CHECK();
     }
     const int nblk = (ni + kRadixTile - 1) / kRadixTile;
-    int passes = (key_bits + 7) / 8;
+    int passes = (key_bits + kRadixBits - 1) / kRadixBits;
     if (passes < 1)
         passes = 1;
-    if (passes > 4)
-        passes = 4;
+    if (passes > (32 + kRadixBits - 1) / kRadixBits)
+        passes = (32 + kRadixBits - 1) / kRadixBits;
     // Pass 0 reads `keys` (kept intact) with the identity permutation; pass k writes buffer
     // B = (sorted, perm) when (passes-1-k) is even and A = (keys_alt, perm_alt) otherwise, so the
     // last pass lands in B and consecutive passes never alias.
@@ -358,17 +444,20 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
         const bool toB = ((passes - 1 - pass) & 1) == 0;
         uint32_t *kout = toB ? p.sorted : p.keys_alt;
         int32_t *vout = toB ? p.perm : p.perm_alt;
-        const int shift = pass * 8;
+        const int shift = pass * kRadixBits;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, stream,
-                           kin, ni, shift, nblk, p.hist);
+                           kin, ni, shift, nblk, p.hist, nblk <= kRadixFusedBlocks ? 1 : 0);
         HA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0,
-                           stream, p.hist, 256 * nblk,
-                           static_cast<uint32_t *>(nullptr));
-        HA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0,
-                           stream, kin, vin, ni, shift, nblk, p.hist, kout,
-                           vout);
+        if (nblk <= kRadixFusedBlocks) {
+            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(256), 0,
+                               stream, kin, vin, ni, shift, nblk, p.hist, kout, vout);
+        } else {
+            hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream,
+                               p.hist, kRadixBuckets * nblk, static_cast<uint32_t *>(nullptr));
+            HA_LAUNCH_CHECK();
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblk), dim3(256), 0,
+                               stream, kin, vin, ni, shift, nblk, p.hist, kout, vout);
+        }
         HA_LAUNCH_CHECK();
         kin = kout;
         vin = vout;

@@ -27,6 +27,9 @@ struct PlanPtrs {
 };
 
 constexpr int kRadixTile = 4096;  // keys per workgroup per radix pass
+constexpr int kRadixBits = 11;    // digit width: ceil(32/11) = 3 passes sort any key, 2 passes 22 bits
+constexpr int kRadixBuckets = 1 << kRadixBits;
+constexpr int kRadixFusedBlocks = 64;  // up to this many tiles the scatter scans the histograms itself
 constexpr int kFinishTile = 8192; // sorted positions per workgroup in the finish pass
 
 static inline PlanPtrs plan_layout(void *ws, int64_t n) {
@@ -51,7 +54,7 @@ static inline PlanPtrs plan_layout(void *ws, int64_t n) {
     p.keys_alt = reinterpret_cast<uint32_t *>(take(n4));
     p.perm_alt = reinterpret_cast<int32_t *>(take(n4));
     const size_t nblk = (static_cast<size_t>(n) + kRadixTile - 1) / kRadixTile;
-    p.hist = reinterpret_cast<uint32_t *>(take((nblk * 256 + 1) * 4));
+    p.hist = reinterpret_cast<uint32_t *>(take((nblk * kRadixBuckets + 1) * 4));
     const size_t nfin = (static_cast<size_t>(n) + kFinishTile - 1) / kFinishTile;
     p.block_sums = reinterpret_cast<uint32_t *>(take((nfin + 1) * 4));
     p.bytes = off;
