@@ -15,6 +15,11 @@
 
 namespace ha {
 
+// scatter.hip
+template <int MODE>
+int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, int64_t n,
+                    const float *grads, float lr, hipStream_t stream);
+
 template <typename IdT, int NV_SHIFT>
 __global__ __launch_bounds__(1024) void fwd_fused_kernel(
     const float *__restrict__ table, uint64_t rows, uint32_t nv,
@@ -132,14 +137,13 @@ static int apply_finish(float *dst, int64_t rows, int64_t width, void *plan_ws,
                         hipStream_t stream, const float *pf_ids = nullptr, int64_t pf_n = 0) {
     HA_REQUIRE(n >= 0 && width >= 1 && width < (1 << 30), "apply_finish: bad sizes");
     HA_REQUIRE(plan_ws != nullptr, "apply_finish: null plan workspace");
-    if (n == 0 || n > kSmallMax) {
-        int rc = 0;
-        if (n > 0)
-            rc = MODE == kModeSgd ? ha_sgd_apply(dst, rows, width, plan_ws, n, grads, lr, stream)
-                                  : ha_push_apply(dst, rows, width, plan_ws, n, grads, stream);
-        if (rc)
-            return rc;
+    if (n == 0)
         return ha_plan_finish(plan_ws, n, stream);
+    if (n > kSmallMax) {
+        // larger batches: finish the plan first, then apply by unique key (scatter.hip)
+        if (ha_plan_finish(plan_ws, n, stream))
+            return -1;
+        return apply_by_unique<MODE>(dst, rows, width, plan_ws, n, grads, lr, stream);
     }
     HA_REQUIRE(dst && grads, "apply_finish: null pointer");
     PlanPtrs p = plan_layout(plan_ws, n);

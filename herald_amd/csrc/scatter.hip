@@ -26,6 +26,7 @@
 //     two-instruction chain per occurrence and column is the only ordered part;
 //   * every other wave of a run exits.
 #include "scatter_dev.h"
+#include "plan_dev.h"
 
 namespace ha {
 
@@ -60,6 +61,71 @@ __global__ __launch_bounds__(1024, 8) void apply_mapped2_kernel(
     extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
     apply_body<kModeSgd, VEC, true>(dst, dst_rows, width, sorted, perm, upos, n, src, lr, blockIdx.x, s_apply,
                                     nullptr, maps);
+}
+
+// ---- larger batches (n > kSmallMax) with a FINISHED plan: waves map to unique keys ------------------
+// One wave per sorted position costs ~5 ns of dispatch per workgroup and most positions of a large
+// batch sit inside long runs, so here a fixed grid of workgroups loops over the unique keys instead
+// (uniq / seg / counts of the plan): short and medium runs are applied by the wave that owns the key,
+// keys with >= kLongRun occurrences are collected in a list ...
+template <int MODE, int VEC>
+__global__ __launch_bounds__(1024, 8) void apply_unique_kernel(
+    float *__restrict__ dst, uint64_t dst_rows, int width, PlanHeader *__restrict__ hdr,
+    const uint32_t *__restrict__ uniq, const int32_t *__restrict__ seg,
+    const int32_t *__restrict__ counts, const int32_t *__restrict__ perm, int n,
+    const float *__restrict__ grads, float lr, uint32_t *__restrict__ long_list) {
+    const int U = static_cast<int>(hdr->n_unique);
+    const int lane = lane_id();
+    const int nwaves = gridDim.x * 16;
+    for (int u = blockIdx.x * 16 + static_cast<int>(threadIdx.x >> 6); u < U; u += nwaves) {
+        const int s = uniform(seg[u]), len = uniform(counts[u]);
+        const uint32_t key = uniform(uniq[u]);
+        if (len >= kLongRun) {
+            if (lane == 0) {
+                const unsigned long long i =
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->reserved[0]), 1ull);
+                long_list[i] = static_cast<uint32_t>(u);
+            }
+            continue;
+        }
+        if (key >= dst_rows)
+            continue;  // out-of-range id: ignored
+        float *dst_row = dst + static_cast<uint64_t>(key) * static_cast<uint64_t>(width);
+        const int pv = perm[min(s + lane, n - 1)];   // lanes 0 .. len-1: the run's occurrence indices
+        if (len <= kShortRun) {
+            short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, true, Second{nullptr, false});
+        } else {
+            for (int c0 = 0; c0 < width; c0 += kWave)
+                medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, true,
+                                          Second{nullptr, false});
+        }
+    }
+}
+
+// ... and served here: work item = (long key, 64-column slice); the 16 waves of a workgroup load the
+// occurrence rows of the slice block by block into LDS and one wave runs the ordered chain
+// (coop_slices, scatter_dev.h).
+template <int MODE>
+__global__ __launch_bounds__(1024, 8) void apply_long_kernel(
+    float *__restrict__ dst, uint64_t dst_rows, int width, const PlanHeader *__restrict__ hdr,
+    const uint32_t *__restrict__ uniq, const int32_t *__restrict__ seg,
+    const int32_t *__restrict__ counts, const int32_t *__restrict__ perm, int n,
+    const float *__restrict__ grads, float lr, const uint32_t *__restrict__ long_list) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
+    const int nslice = (width + kWave - 1) / kWave;
+    const long long items = hdr->reserved[0] * nslice;
+    const int w = static_cast<int>(threadIdx.x >> 6);
+    const ApplyMaps maps{nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int u = static_cast<int>(long_list[it / nslice]);
+        const int j = static_cast<int>(it % nslice);
+        const uint32_t key = uniq[u];
+        if (key < dst_rows)
+            coop_slices<MODE, false>(dst + static_cast<uint64_t>(key) * static_cast<uint64_t>(width), true,
+                                     Second{nullptr, false}, grads, perm, maps, n, lr, seg[u], counts[u], width,
+                                     j, nslice, w, reinterpret_cast<float *>(s_apply));
+        __syncthreads();
+    }
 }
 
 // diagnostic twin of apply_kernel<kModeSgd,4>: same body plus per-wave time stamps
@@ -107,6 +173,32 @@ static int apply_launch(float *dst, int64_t dst_rows, int64_t width,
     return 0;
 }
 
+}  // namespace ha
+
+// apply of a FINISHED plan by unique key (larger batches); plan scratch keys_alt holds the long list
+namespace ha {
+template <int MODE>
+int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, int64_t n,
+                    const float *grads, float lr, hipStream_t stream) {
+    HA_REQUIRE(dst && plan_ws && grads && n > 0 && width >= 1 && width < (1 << 30), "apply_by_unique: bad arguments");
+    PlanPtrs p = plan_layout(plan_ws, n);
+    HA_CHECK_HIP(hipMemsetAsync(&p.hdr->reserved[0], 0, sizeof(int64_t), stream));
+    const bool vec_ok = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(grads) % 16 == 0);
+    const dim3 grid(512), block(1024);   // two workgroups per compute unit, looping over the keys
+    if (vec_ok)
+        hipLaunchKernelGGL((apply_unique_kernel<MODE, 4>), grid, block, 0, stream, dst, (uint64_t)dst_rows,
+                           (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt);
+    else
+        hipLaunchKernelGGL((apply_unique_kernel<MODE, 1>), grid, block, 0, stream, dst, (uint64_t)dst_rows,
+                           (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt);
+    hipLaunchKernelGGL((apply_long_kernel<MODE>), grid, block, kApplyLdsBytes, stream, dst, (uint64_t)dst_rows,
+                       (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+template int apply_by_unique<kModeSgd>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t);
+template int apply_by_unique<kModePush>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t);
 }  // namespace ha
 
 extern "C" int ha_sgd_apply(float *table, int64_t rows, int64_t width,

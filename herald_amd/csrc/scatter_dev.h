@@ -228,92 +228,15 @@ __device__ __forceinline__ float chain_step(float acc, float m) {
     return MODE == kModeSgd ? __fsub_rn(acc, m) : __fadd_rn(acc, m);
 }
 
-// Returns false when the run is shorter than kLongRun (the caller falls through to the per-wave
-// paths).  Called by all 16 waves of a full workgroup; wg0 = its first sorted position.
+// The worker part of a long run [s, s+len): this workgroup owns the 64-column slices j, j+workers, ...
+// All 16 waves call it (workgroup barriers inside); s_m = kCoopUnits x 64 floats of LDS.
 template <int MODE, bool DUAL>
-__device__ __forceinline__ bool coop_run(
-    float *__restrict__ dst, uint64_t dst_rows, int width,
-    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
-    const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int wg0, int w, uint32_t key, uint32_t bk, uint32_t fk,
-    ApplyMaps maps, uint32_t *lds) {
+__device__ __forceinline__ void coop_slices(
+    float *__restrict__ dst_row, bool init, Second d2, const float *__restrict__ grads,
+    const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr, int s, int len,
+    int width, int j, int workers, int w, float *s_m) {
     const int lane = lane_id();
-    float *s_m = reinterpret_cast<float *>(lds);
-    int *s_cnt = reinterpret_cast<int *>(lds + kCoopUnits * kWave);
-
-    // run start / end from the 2 x 1024 scanned positions (wave w looked at chunk w each way)
-    {
-        const int qb = wg0 - kWave * (w + 1) + lane;
-        const unsigned long long mb = __ballot(qb >= 0 && bk == key);
-        const int cb = (~mb == 0ull) ? kWave : __builtin_clzll(~mb);
-        const int qf = wg0 + kPosPerBlock + kWave * w + lane;
-        const unsigned long long mf = __ballot(qf < n && fk == key);
-        const int cf = (~mf == 0ull) ? kWave : __builtin_ctzll(~mf);
-        if (lane == 0) {
-            s_cnt[w] = cb;
-            s_cnt[16 + w] = cf;
-        }
-    }
-    __syncthreads();
-    auto combine = [&](int base) {  // contiguous matches over the 16 chunks, nearest chunk first
-        const int c = s_cnt[base + (lane & 15)];
-        const uint32_t fullm = static_cast<uint32_t>(__ballot(c == kWave)) & 0xFFFFu;
-        const int k = uniform(__builtin_ctz(~fullm));  // first chunk that is not all matches (16 = none)
-        return k >= 16 ? kCoopScan : kWave * k + __builtin_amdgcn_readlane(c, k);
-    };
-    const int back_total = uniform(combine(0));
-    int fwd_total = uniform(combine(16));
-    if (back_total >= kCoopScan)
-        return true;  // >= 64 full workgroups precede this one: never a worker
-    const int s = wg0 - back_total;
-    int e = wg0 + kPosPerBlock + fwd_total;
-    while (fwd_total >= kCoopScan) {  // giant run: keep scanning forward, 1024 positions at a time
-        const int qf = e + kWave * w + lane;
-        const uint32_t ks = sorted[min(qf, n - 1)];
-        const unsigned long long mf = __ballot(qf < n && ks == key);
-        const int cf = (~mf == 0ull) ? kWave : __builtin_ctzll(~mf);
-        __syncthreads();
-        if (lane == 0)
-            s_cnt[16 + w] = cf;
-        __syncthreads();
-        fwd_total = uniform(combine(16));
-        e += fwd_total;
-    }
-    const int len = e - s;
-    if (len < kLongRun)
-        return false;
-    const int a = (s + kPosPerBlock - 1) & ~(kPosPerBlock - 1);  // first full workgroup of the run
-    const int j = (wg0 - a) / kPosPerBlock;
-    const int nfull = (e - a) / kPosPerBlock;
     const int nslice = (width + kWave - 1) / kWave;
-    const int workers = min(min(nfull, nslice), kCoopScan / kPosPerBlock);
-    if (j >= workers)
-        return true;
-
-    uint64_t row;
-    bool init = true;
-    if (maps.rowmap) {
-        const int r = maps.rowmap[upos[wg0]];
-        if (r < 0)
-            return true;
-        row = static_cast<uint64_t>(r);
-        if (maps.dst_init)
-            init = maps.dst_init[r] != 0;
-    } else if (MODE == kModeReduce) {
-        row = static_cast<uint64_t>(upos[wg0]);
-    } else {
-        row = key;
-    }
-    if (row >= dst_rows)
-        return true;
-    float *dst_row = dst + row * static_cast<uint64_t>(width);
-    Second d2{nullptr, false};
-    if (DUAL && maps.rowmap2) {
-        const int r2 = maps.rowmap2[upos[wg0]];
-        d2.on = r2 >= 0;
-        d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
-    }
-
     const int my_slices = (nslice - j + workers - 1) / workers;  // slices j, j+workers, ...
     for (int g0 = 0; g0 < my_slices; g0 += 8) {
         const int sg = min(8, my_slices - g0);               // slices handled at once
@@ -416,6 +339,95 @@ __device__ __forceinline__ bool coop_run(
                 __builtin_nontemporal_store(acc2, d2.row + ccol);
         }
     }
+}
+
+// Returns false when the run is shorter than kLongRun (the caller falls through to the per-wave
+// paths).  Called by all 16 waves of a full workgroup; wg0 = its first sorted position.
+template <int MODE, bool DUAL>
+__device__ __forceinline__ bool coop_run(
+    float *__restrict__ dst, uint64_t dst_rows, int width,
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
+    float lr, int wg0, int w, uint32_t key, uint32_t bk, uint32_t fk,
+    ApplyMaps maps, uint32_t *lds) {
+    const int lane = lane_id();
+    float *s_m = reinterpret_cast<float *>(lds);
+    int *s_cnt = reinterpret_cast<int *>(lds + kCoopUnits * kWave);
+
+    // run start / end from the 2 x 1024 scanned positions (wave w looked at chunk w each way)
+    {
+        const int qb = wg0 - kWave * (w + 1) + lane;
+        const unsigned long long mb = __ballot(qb >= 0 && bk == key);
+        const int cb = (~mb == 0ull) ? kWave : __builtin_clzll(~mb);
+        const int qf = wg0 + kPosPerBlock + kWave * w + lane;
+        const unsigned long long mf = __ballot(qf < n && fk == key);
+        const int cf = (~mf == 0ull) ? kWave : __builtin_ctzll(~mf);
+        if (lane == 0) {
+            s_cnt[w] = cb;
+            s_cnt[16 + w] = cf;
+        }
+    }
+    __syncthreads();
+    auto combine = [&](int base) {  // contiguous matches over the 16 chunks, nearest chunk first
+        const int c = s_cnt[base + (lane & 15)];
+        const uint32_t fullm = static_cast<uint32_t>(__ballot(c == kWave)) & 0xFFFFu;
+        const int k = uniform(__builtin_ctz(~fullm));  // first chunk that is not all matches (16 = none)
+        return k >= 16 ? kCoopScan : kWave * k + __builtin_amdgcn_readlane(c, k);
+    };
+    const int back_total = uniform(combine(0));
+    int fwd_total = uniform(combine(16));
+    if (back_total >= kCoopScan)
+        return true;  // >= 64 full workgroups precede this one: never a worker
+    const int s = wg0 - back_total;
+    int e = wg0 + kPosPerBlock + fwd_total;
+    while (fwd_total >= kCoopScan) {  // giant run: keep scanning forward, 1024 positions at a time
+        const int qf = e + kWave * w + lane;
+        const uint32_t ks = sorted[min(qf, n - 1)];
+        const unsigned long long mf = __ballot(qf < n && ks == key);
+        const int cf = (~mf == 0ull) ? kWave : __builtin_ctzll(~mf);
+        __syncthreads();
+        if (lane == 0)
+            s_cnt[16 + w] = cf;
+        __syncthreads();
+        fwd_total = uniform(combine(16));
+        e += fwd_total;
+    }
+    const int len = e - s;
+    if (len < kLongRun)
+        return false;
+    const int a = (s + kPosPerBlock - 1) & ~(kPosPerBlock - 1);  // first full workgroup of the run
+    const int j = (wg0 - a) / kPosPerBlock;
+    const int nfull = (e - a) / kPosPerBlock;
+    const int nslice = (width + kWave - 1) / kWave;
+    const int workers = min(min(nfull, nslice), kCoopScan / kPosPerBlock);
+    if (j >= workers)
+        return true;
+
+    uint64_t row;
+    bool init = true;
+    if (maps.rowmap) {
+        const int r = maps.rowmap[upos[wg0]];
+        if (r < 0)
+            return true;
+        row = static_cast<uint64_t>(r);
+        if (maps.dst_init)
+            init = maps.dst_init[r] != 0;
+    } else if (MODE == kModeReduce) {
+        row = static_cast<uint64_t>(upos[wg0]);
+    } else {
+        row = key;
+    }
+    if (row >= dst_rows)
+        return true;
+    float *dst_row = dst + row * static_cast<uint64_t>(width);
+    Second d2{nullptr, false};
+    if (DUAL && maps.rowmap2) {
+        const int r2 = maps.rowmap2[upos[wg0]];
+        d2.on = r2 >= 0;
+        d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
+    }
+
+    coop_slices<MODE, DUAL>(dst_row, init, d2, grads, perm, maps, n, lr, s, len, width, j, workers, w, s_m);
     return true;
 }
 
