@@ -26,6 +26,7 @@ for case in ("criteo", "distinct"):
         d_ids = torch.from_numpy(ids).to(dev)
         plan = ops.IndexPlan(n, dev).sort(d_ids)
         dbg = torch.zeros(n * 4, dtype=torch.int64, device=dev)
+        ops.embedding_lookup(table, d_ids)     # as in a training step: the lookup of the batch precedes its apply
         torch.cuda.synchronize()
         rc = L.ha_debug_apply_timeline(ctypes.c_void_p(table.data_ptr()), rows, width,
                                        ctypes.c_void_p(plan.ws.data_ptr()), n,
