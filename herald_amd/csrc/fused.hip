@@ -72,6 +72,22 @@ __global__ __launch_bounds__(1024, 8) void bwd_fused_kernel(
     }
 }
 
+// Forward of a larger batch (n > kSmallMax): the first launch of the radix sort (id -> key conversion
+// and the tile histograms of the first digit, 256-thread blocks) carries the gather blocks, so the
+// gather runs beside the latency-bound sort instead of in front of it.
+template <typename IdT, int NV_SHIFT>
+__global__ __launch_bounds__(256) void fwd_large_kernel(
+    const float *__restrict__ table, uint64_t rows, uint32_t nv,
+    const IdT *__restrict__ ids, int n, uint64_t total_vec, float *__restrict__ out,
+    uint32_t *__restrict__ keys, uint32_t *__restrict__ hist, int nblk, int tile_major) {
+    __shared__ uint32_t s_h[kRadixBuckets];
+    const int b = blockIdx.x;
+    if (b < nblk)
+        radix_first_tile_body<IdT>(ids, n, nblk, b, keys, hist, tile_major, s_h);
+    else
+        gather_vec4_body<IdT, 4, NV_SHIFT, 256>(table, rows, nv, ids, total_vec, out, b - nblk);
+}
+
 static int nv_shift_of(uint32_t nv) {
     for (int s = 2; s <= 8; ++s)
         if (nv == (1u << s))
@@ -91,6 +107,28 @@ static int lookup_sort(const float *table, int64_t rows, int64_t width,
                         (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
                         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     const int shift = vec_ok ? nv_shift_of(static_cast<uint32_t>(width / 4)) : -1;
+    if (n > kSmallMax && shift >= 0 && n < (1ll << 31)) {
+        HA_REQUIRE(table && ids && out, "lookup_sort: null pointer");
+        PlanPtrs p = plan_layout(plan_ws, n);
+        const int ni = static_cast<int>(n), nblk = radix_tiles(n);
+        const uint32_t nv = static_cast<uint32_t>(width / 4);
+        const uint64_t total_vec = static_cast<uint64_t>(n) * nv;
+        const unsigned gblocks = static_cast<unsigned>((total_vec + 1023) / 1024);
+#define HA_FWDL_CASE(S)                                                                          \
+    case S:                                                                                      \
+        hipLaunchKernelGGL((fwd_large_kernel<IdT, S>), dim3(nblk + gblocks), dim3(256), 0, stream, \
+                           table, (uint64_t)rows, nv, ids, ni, total_vec, out, p.keys, p.hist,   \
+                           nblk, radix_tile_major(n));                                           \
+        break;
+        switch (shift) {
+            HA_FWDL_CASE(2) HA_FWDL_CASE(3) HA_FWDL_CASE(4) HA_FWDL_CASE(5)
+            HA_FWDL_CASE(6) HA_FWDL_CASE(7) HA_FWDL_CASE(8)
+        default: break;
+        }
+#undef HA_FWDL_CASE
+        HA_LAUNCH_CHECK();
+        return plan_radix_sort(plan_ws, n, 32, true, stream);
+    }
     if (n == 0 || n > kSmallMax || shift < 0)
         return fallback(table, rows, width, ids, n, out, plan_ws, stream) ? 0 : -1;
     HA_REQUIRE(table && ids && out, "lookup_sort: null pointer");

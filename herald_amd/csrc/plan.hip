@@ -33,15 +33,6 @@ __global__ __launch_bounds__(1024) void plan_rank_small_kernel(
 // ===========================================================================
 // General path: LSD radix sort (8-bit digits), stable.
 // ===========================================================================
-template <typename IdT>
-__global__ __launch_bounds__(256) void plan_convert_kernel(
-    const IdT *__restrict__ ids, int n, uint32_t *__restrict__ keys) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    const int stride = gridDim.x * 256;
-    for (; i < n; i += stride)
-        keys[i] = to_key<IdT>(ids[i]);
-}
-
 // per-block digit histogram; hist[d * nblk + blk] (digit-major: the flat exclusive scan of the large
 // path orders it) or hist[blk * kRadixBuckets + d] (tile-major: coalesced for the fused scatter)
 __global__ __launch_bounds__(256) void radix_hist_kernel(
@@ -387,6 +378,14 @@ __global__ __launch_bounds__(1024) void finish_chunked_kernel(
     finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, blockIdx.x, s_w, chunk_heads);
 }
 
+template <typename IdT>
+__global__ __launch_bounds__(256) void radix_first_kernel(
+    const IdT *__restrict__ ids, int n, int nblk, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ hist, int tile_major) {
+    __shared__ uint32_t s_h[kRadixBuckets];
+    radix_first_tile_body<IdT>(ids, n, nblk, blockIdx.x, keys, hist, tile_major, s_h);
+}
+
 __global__ void plan_empty_kernel(PlanHeader *hdr, int32_t *seg) {
     hdr->n_unique = 0;
     seg[0] = 0;
@@ -420,16 +419,21 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
         }
         return 0;
     }
-    // ---- radix path
-    {
-        int blocks = (ni + 255) / 256;
-        if (blocks > 4096)
-            blocks = 4096;
-        hipLaunchKernelGGL(plan_convert_kernel<IdT>, dim3(blocks), dim3(256),
-                           0, stream, ids, ni, p.keys);
-        HA_LAUNCH_CHECK();
-    }
-    const int nblk = (ni + kRadixTile - 1) / kRadixTile;
+    // ---- radix path: conversion + first histogram in one launch, then the passes
+    hipLaunchKernelGGL(radix_first_kernel<IdT>, dim3(radix_tiles(n)), dim3(256), 0, stream, ids, ni,
+                       radix_tiles(n), p.keys, p.hist, radix_tile_major(n));
+    HA_LAUNCH_CHECK();
+    return plan_radix_sort(ws, n, key_bits, sort_only, stream);
+}
+
+}  // namespace ha
+
+// keys[] and the pass-0 histograms are in place (radix_first_tile_body); runs the scatter of pass 0, the
+// remaining passes and, unless sort_only, the finish
+int ha::plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipStream_t stream) {
+    PlanPtrs p = plan_layout(ws, n);
+    const int ni = static_cast<int>(n);
+    const int nblk = radix_tiles(n);
     int passes = (key_bits + kRadixBits - 1) / kRadixBits;
     if (passes < 1)
         passes = 1;
@@ -445,9 +449,11 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
         uint32_t *kout = toB ? p.sorted : p.keys_alt;
         int32_t *vout = toB ? p.perm : p.perm_alt;
         const int shift = pass * kRadixBits;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, stream,
-                           kin, ni, shift, nblk, p.hist, nblk <= kRadixFusedBlocks ? 1 : 0);
-        HA_LAUNCH_CHECK();
+        if (pass > 0) {
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, stream,
+                               kin, ni, shift, nblk, p.hist, nblk <= kRadixFusedBlocks ? 1 : 0);
+            HA_LAUNCH_CHECK();
+        }
         if (nblk <= kRadixFusedBlocks) {
             hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(256), 0,
                                stream, kin, vin, ni, shift, nblk, p.hist, kout, vout);
@@ -466,6 +472,8 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
         return 0;
     return plan_finish(ws, n, stream);
 }
+
+namespace ha {
 
 static int plan_finish(void *ws, int64_t n, hipStream_t stream) {
     HA_REQUIRE(ws != nullptr && n >= 0, "plan_finish: bad arguments");

@@ -82,6 +82,34 @@ inline size_t rank_small_lds_bytes(int n) {
     return (static_cast<size_t>(npad) + 32 * 32) * 4;
 }
 
+// First radix pass, one tile of kRadixTile ids by a 256-thread block: keys[j] = to_key(ids[j]) and the
+// tile's histogram of digit 0 (tile-major or digit-major, see radix_hist_kernel in plan.hip).  Shared by
+// plan.hip and by the forward launch of larger batches (fused.hip), where gather blocks ride along.
+template <typename IdT>
+__device__ __forceinline__ void radix_first_tile_body(const IdT *__restrict__ ids, int n, int nblk, int tile,
+                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ hist,
+                                                      int tile_major, uint32_t *s_h /* kRadixBuckets words */) {
+    for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
+        s_h[d] = 0;
+    __syncthreads();
+    const int base = tile * kRadixTile;
+    const int end = min(n, base + kRadixTile);
+    for (int j = base + threadIdx.x; j < end; j += 256) {
+        const uint32_t k = to_key<IdT>(ids[j]);
+        keys[j] = k;
+        atomicAdd(&s_h[k & (kRadixBuckets - 1u)], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
+        hist[tile_major ? tile * kRadixBuckets + d : d * nblk + tile] = s_h[d];
+}
+
+// plan.hip: the radix sort of n > kSmallMax keys; first_hist_done = keys and the pass-0 histograms were
+// produced by radix_first_tile_body already
+int plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipStream_t stream);
+inline int radix_tiles(int64_t n) { return static_cast<int>((n + kRadixTile - 1) / kRadixTile); }
+inline int radix_tile_major(int64_t n) { return radix_tiles(n) <= kRadixFusedBlocks ? 1 : 0; }
+
 // ===========================================================================
 // Small path: stable rank by counting.
 //
