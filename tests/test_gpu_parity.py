@@ -428,3 +428,51 @@ def test_apply_mapped2_equals_two_mapped_passes(dev, lib):
     torch.cuda.synchronize()
     assert torch.equal(a1, a2) and torch.equal(b1, b2)
     assert not torch.equal(a1, _dev(a0, dev))
+
+
+def test_random_shapes_sweep(dev):
+    """40 random (n, width, key range, skew) configurations: lookup + plan + SGD apply + push apply
+    through both the fused and the unfused entry points against the oracle."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n = int(rng.choice([1, 2, 15, 16, 17, 63, 100, 257, 1000, 3333, 6656, 9000, 15360, 15361, 17000]))
+        width = int(rng.choice([1, 2, 4, 5, 8, 20, 64, 68, 100, 128, 192, 256, 300]))
+        rows = int(rng.choice([3, 50, 1000, 40000]))
+        skew = float(rng.choice([0.0, 1.1, 2.0]))
+        if skew == 0.0:
+            ids = rng.integers(0, rows, size=n)
+        else:
+            ids = np.minimum(rng.zipf(skew, size=n) - 1, rows - 1)
+        ids = ids.astype(np.float32)
+        table = rng.standard_normal((rows, width), dtype=np.float32)
+        grads = rng.standard_normal((n, width), dtype=np.float32)
+        lr = float(rng.choice([1e-3, 0.5]))
+        msg = "case %d: n=%d width=%d rows=%d skew=%.1f" % (case, n, width, rows, skew)
+        want_out = cpu.embedding_lookup(table, ids)
+        want_t = cpu.sgd_sparse_update(table.copy(), ids, grads, lr)
+        uniq, inv, cnt = cpu.unique(cpu.ids_to_keys(ids))
+        _, _, red = cpu.dedup_reduce(ids, grads)
+        want_p = cpu.push_apply(table.copy(), uniq, red)
+        d_ids, d_g = _dev(ids, dev), _dev(grads, dev)
+        # fused
+        t = _dev(table, dev)
+        plan = ops.IndexPlan(n, dev)
+        out = ops.lookup_sort(t, d_ids, plan)
+        ops.sgd_apply_finish(t, plan, d_g, lr)
+        np.testing.assert_array_equal(out.cpu().numpy(), want_out, err_msg=msg)
+        np.testing.assert_array_equal(t.cpu().numpy(), want_t, err_msg=msg)
+        assert plan.n_unique() == uniq.size, msg
+        np.testing.assert_array_equal(plan.inverse().cpu().numpy().astype(np.int64), inv, err_msg=msg)
+        np.testing.assert_array_equal(plan.counts(uniq.size).cpu().numpy().astype(np.int64), cnt, err_msg=msg)
+        # unfused
+        t2 = _dev(table, dev)
+        plan2 = ops.IndexPlan(n, dev).build(d_ids)
+        ops.sgd_apply(t2, plan2, d_g, lr)
+        np.testing.assert_array_equal(t2.cpu().numpy(), want_t, err_msg=msg)
+        t3 = _dev(table, dev)
+        ops.push_apply(t3, plan2, d_g)
+        np.testing.assert_array_equal(t3.cpu().numpy(), want_p, err_msg=msg)
+        t4 = _dev(table, dev)
+        ops.lookup_sort(t4, d_ids, plan)
+        ops.push_apply_finish(t4, plan, d_g)
+        np.testing.assert_array_equal(t4.cpu().numpy(), want_p, err_msg=msg)
