@@ -37,6 +37,15 @@ bool g_err_is_empty();
 
 #define HA_LAUNCH_CHECK() HA_CHECK_HIP(hipGetLastError())
 
+// Dynamic LDS beyond 64 KiB (gfx950 offers 160 KiB per workgroup) has to be allowed per kernel.
+#define HA_ALLOW_LDS(kernel, bytes)                                                              \
+    do {                                                                                         \
+        if ((bytes) > 65536)                                                                     \
+            HA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                             static_cast<int>(bytes)));                          \
+    } while (0)
+
 static inline hipStream_t as_stream(ha_stream_t s) {
     return reinterpret_cast<hipStream_t>(s);
 }

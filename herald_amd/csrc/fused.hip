@@ -142,6 +142,7 @@ static int lookup_sort(const float *table, int64_t rows, int64_t width,
     const size_t lds = rank_small_lds_bytes(ni);
 #define HA_FWD_CASE(S)                                                          \
     case S:                                                                     \
+        HA_ALLOW_LDS((fwd_fused_kernel<IdT, S>), lds);                          \
         hipLaunchKernelGGL((fwd_fused_kernel<IdT, S>), grid, block, lds, stream, \
                            table, (uint64_t)rows, nv, ids, ni, total_vec, out,  \
                            p.keys, p.sorted, p.perm, tiles);                    \

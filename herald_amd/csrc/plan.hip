@@ -409,6 +409,7 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
     const int ni = static_cast<int>(n);
     if (n <= kSmallMax) {
         const size_t lds = rank_small_lds_bytes(ni);
+        HA_ALLOW_LDS(plan_rank_small_kernel<IdT>, lds);
         hipLaunchKernelGGL(plan_rank_small_kernel<IdT>,
                            dim3((ni + kRankTile - 1) / kRankTile), dim3(1024),
                            lds, stream, ids, ni, p.keys, p.sorted, p.perm);

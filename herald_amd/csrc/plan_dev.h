@@ -5,7 +5,7 @@
 
 namespace ha {
 
-constexpr int kSmallMax = 15360;     // rank-by-counting up to here (keys + partial ranks = 64 KiB LDS)
+constexpr int kSmallMax = 36864;     // rank-by-counting up to here (keys + partial ranks = 148 KiB of the 160 KiB LDS)
 constexpr uint32_t kPadKey = 0xFFFFFFFFu;
 
 struct PlanHeader {

@@ -33,7 +33,7 @@ def test_dlarray_struct_layout_matches_reference():
 
 
 def test_plan_workspace_size_is_monotone(lib):
-    sizes = [lib.ha_plan_bytes(n) for n in (0, 1, 64, 6656, 15360, 15361, 106496, 1 << 20)]
+    sizes = [lib.ha_plan_bytes(n) for n in (0, 1, 64, 6656, 15360, 15361, 36864, 36865, 106496, 1 << 20)]
     assert all(b > 0 for b in sizes)
     assert sizes == sorted(sizes)
 

@@ -87,14 +87,14 @@ def _check_plan(ids_f32, dev):
     return plan
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1000, 6656, 15360])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1000, 6656, 15360, 15361, 26624, 36864])
 def test_plan_small_path(dev, n):
     rng = np.random.default_rng(n)
     ids = rng.integers(0, max(2, n // 2 + 1), size=n).astype(np.float32)
     _check_plan(ids, dev)
 
 
-@pytest.mark.parametrize("n", [15361, 26624, 106496, 300000, 1048576, 1100000])
+@pytest.mark.parametrize("n", [36865, 50000, 106496, 300000, 1048576, 1100000])
 def test_plan_radix_path(dev, n):
     rng = np.random.default_rng(n)
     ids = synth.as_f32_ids(rng.integers(0, synth.CRITEO_ROWS, size=n))
@@ -219,7 +219,8 @@ def test_full_size_step_properties(dev):
     assert torch.equal(before, ops.embedding_lookup(t0, ids))
 
 
-@pytest.mark.parametrize("width,n", [(512, 6656), (128, 6656), (64, 100), (512, 15360), (200, 300), (512, 20000)])
+@pytest.mark.parametrize("width,n", [(512, 6656), (128, 6656), (64, 100), (512, 15360), (200, 300), (512, 20000),
+                                      (512, 26624), (128, 36864), (512, 40000)])
 def test_fused_step_matches_oracle_and_unfused(dev, width, n):
     """ha_lookup_sort_* + ha_sgd_apply_finish (two launches) == oracle == the unfused four calls."""
     rng = np.random.default_rng(width + n)
@@ -435,7 +436,7 @@ def test_random_shapes_sweep(dev):
     through both the fused and the unfused entry points against the oracle."""
     rng = np.random.default_rng(2024)
     for case in range(40):
-        n = int(rng.choice([1, 2, 15, 16, 17, 63, 100, 257, 1000, 3333, 6656, 9000, 15360, 15361, 17000]))
+        n = int(rng.choice([1, 2, 15, 16, 17, 63, 100, 257, 1000, 3333, 6656, 9000, 15360, 15361, 17000, 36864, 36865]))
         width = int(rng.choice([1, 2, 4, 5, 8, 20, 64, 68, 100, 128, 192, 256, 300]))
         rows = int(rng.choice([3, 50, 1000, 40000]))
         skew = float(rng.choice([0.0, 1.1, 2.0]))

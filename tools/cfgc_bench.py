@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from herald_amd import ops, synth
 dev = torch.device("cuda:0")
-rows, width, bs = 33762577, 128, 4096
+rows, width, bs = 33762577, int(os.environ.get("WIDTH", "128")), int(os.environ.get("BATCH", "4096"))
 n = bs * 26
 table = torch.empty((rows, width), device=dev)
 for s in range(0, rows, 1 << 21):
