@@ -125,6 +125,11 @@ class ParameterServerCommunicateOp:
         if self.use_cache_table:
             width = p.shape[1]
             store = p.store
+            if store.world > 1:
+                # the cache kernels pull / push against a store in the same HBM; rows owned by another
+                # rank would need the exchange of sharded.py underneath them
+                raise NotImplementedError("the HET cache over a store sharded across %d ranks is not built yet; "
+                                          "use comm_mode='PS' without cstable_policy" % store.world)
             hcache.register_table(p.id, store.table, row_start=store.starts[store.rank])
             self.cache = hcache.CacheSparseTable(config.cache_limit, p.shape[0], width, p.id, config.cstable_policy,
                                                  config.cache_bound, device=store.table.device)
