@@ -486,7 +486,7 @@ static int plan_finish(void *ws, int64_t n, hipStream_t stream) {
         return 0;
     }
     const int ni = static_cast<int>(n);
-    if (n <= 16384) {   // one launch: every chunk recounts the heads before it (<= 15 chunks)
+    if (n <= kSmallMax) {
         hipLaunchKernelGGL(finish_small_kernel, dim3(finish_blocks(ni)), dim3(1024), 0, stream,
                            p.sorted, p.perm, ni, p.hdr, p.uniq, p.seg,
                            p.counts, p.inverse, p.upos);
