@@ -1,0 +1,47 @@
+"""bench.py's JSON contract on a small table: the N=1 line (roofline + cpu_baseline + cache_tier) and the
+sharded N>1 leg forced at world size 1 through the nccl backend (HA_FORCE_SHARDED=1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *args):
+    env = dict(os.environ)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_n1_line_has_the_contract_fields(dev):
+    d = _run({}, "--rows", "1000000", "--steps", "256", "--warmup", "64", "--distinct-batches", "64")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 256 and d["unit"] == "rows/s" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["scaling"] == "weak" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["ids_per_step"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "rows/s"
+    assert d["value"] > 20 * cb["value"]
+    assert d["cache_tier"]["value"] > 0
+
+
+def test_bench_sharded_leg_runs_on_nccl_at_world_size_1(dev):
+    d = _run({"HA_FORCE_SHARDED": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29641", "RANK": "0",
+              "WORLD_SIZE": "1", "LOCAL_RANK": "0"},
+             "--rows", "1000000", "--steps", "64", "--warmup", "16")
+    assert d["n_gpus"] == 1 and d["steps"] == 64 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "sharded" in d["config"]["workload"] and "xgmi" in d
