@@ -143,7 +143,14 @@ class ParameterServerCommunicateOp:
                 self.compute = self._compute_no_prefetch
         else:
             self._push, self._pull, self._push_pull = self._push_sparse, self._pull_sparse, self._push_pull_sparse
-            self.compute = self._compute_bsp_prefetch if config.prefetch else self._compute_no_prefetch
+            # :235-242: bsp >= 0 -> ssp (push, ssp_sync(version), pull), else asp (push_pull) when prefetching
+            if config.prefetch and config.bsp >= 0:
+                self.compute = self._compute_ssp_prefetch
+                self.ssp_version = 0
+            elif config.prefetch:
+                self.compute = self._compute_asp_prefetch
+            else:
+                self.compute = self._compute_no_prefetch
         if config.prefetch:                                            # first prefetch (:168-176, 196-205)
             ids = first_ids if first_ids is not None else self.next_ids()
             self.sparse_pull_val = torch.empty(tuple(ids.shape) + (p.shape[1],), dtype=torch.float32,
@@ -157,6 +164,19 @@ class ParameterServerCommunicateOp:
     def _compute_asp_prefetch(self, grad):
         self._mult_lr(grad)
         self.config.ps_map[self.parameter] = (self._push_pull(grad), self.sparse_pull_val)
+
+    def _compute_ssp_prefetch(self, grad):
+        """:41-46.  ssp_sync(version) lets a worker run ahead of the slowest one by at most `bsp` versions
+        (ps-lite/include/ps/server/ssp_handler.h:41-67).  The sparse push / pull of a sharded store are
+        collectives over all ranks, so no rank can run ahead at all: every tolerance is served by the
+        lock step of the exchange itself, which satisfies the bound; only the version counter is kept."""
+        self._mult_lr(grad)
+        w = self._push(grad)
+        if w is not None:
+            w.wait()
+        self.barrier()
+        self.config.ps_map[self.parameter] = (self._pull(self.next_ids()), self.sparse_pull_val)
+        self.ssp_version += 1
 
     def _compute_bsp_prefetch(self, grad):
         self._mult_lr(grad)
