@@ -595,6 +595,17 @@ __global__ void cache_report_pull_kernel(CacheCtl *ctl, Cache c, long long n) {
     cache_report_pull_body(ctl, c, n);
 }
 
+// plan finish of the cache's batch with the probe (and the pull decision of a lookup) done by the thread
+// that writes each unique key (HeadProbe, plan_dev.h)
+__global__ __launch_bounds__(1024) void cache_finish_probe_kernel(
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm, int n,
+    PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq, int32_t *__restrict__ seg,
+    int32_t *__restrict__ counts, int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
+    HeadProbe hp) {
+    __shared__ uint32_t s_w[kFinishLdsWords];
+    finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, blockIdx.x, s_w, nullptr, &hp);
+}
+
 // ---- fused lookup: one bookkeeping workgroup + one row kernel ---------------------------------------
 // ha_cache_lookup = plan (2 launches) + cache_lookup_book_kernel + cache_lookup_rows_kernel.  The
 // bookkeeping phases (probe, miss scan, slot assignment / LRU touch, pull decision, victim scan,
@@ -604,11 +615,15 @@ __global__ void cache_report_pull_kernel(CacheCtl *ctl, Cache c, long long n) {
 // version -1 or lagging by more than pull_bound) is taken here, once per unique key, and parked in
 // data_row[u]; the row kernel only moves rows.
 __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
-    Cache c, const PlanHeader *hdr, const uint32_t *uniq, long long n, int bypass) {
+    Cache c, const PlanHeader *hdr, const uint32_t *uniq, long long n, int bypass, int probed) {
     __shared__ uint32_t s_cnt[16];
     CacheCtl *ctl = c.ctl;
     const int tid = threadIdx.x;
-    cache_probe_body(ctl, hdr, uniq, c.slot_of, c.length, bypass, c.uslot, c.flag, tid, 1024);
+    // probed: uslot / flag / the pull decisions (data_row) were written by cache_finish_probe_kernel
+    if (!probed)
+        cache_probe_body(ctl, hdr, uniq, c.slot_of, c.length, bypass, c.uslot, c.flag, tid, 1024);
+    else if (tid == 0)
+        ctl->U = hdr->n_unique;
     __syncthreads();
     cache_scan_body(hdr, c.flag, c.rank, &ctl->M, &ctl->nhit);
     __syncthreads();
@@ -620,14 +635,18 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
     const int U = static_cast<int>(hdr->n_unique);
     uint32_t cnt = 0;
     for (int u = tid; u < U; u += 1024) {
-        const int s = c.uslot[u];
-        const long long lk = static_cast<long long>(uniq[u]) - c.row_start;
         int pull = 0;
-        if (lk >= 0 && lk < c.store_rows) {
-            const long long v = c.version[s];
-            pull = (v == -1 || c.srv_ver[lk] - v > c.pull_bound) ? 1 : 0;
+        if (probed) {
+            pull = c.data_row[u];
+        } else {
+            const int s = c.uslot[u];
+            const long long lk = static_cast<long long>(uniq[u]) - c.row_start;
+            if (lk >= 0 && lk < c.store_rows) {
+                const long long v = c.version[s];
+                pull = (v == -1 || c.srv_ver[lk] - v > c.pull_bound) ? 1 : 0;
+            }
+            c.data_row[u] = pull;
         }
-        c.data_row[u] = pull;
         cnt += pull;
     }
     for (int o = 32; o >= 1; o >>= 1)
@@ -725,10 +744,13 @@ __global__ __launch_bounds__(256) void cache_update_rows_kernel(const CacheCtl *
 // fused update, phase 1: probe, miss scan, slot assignment (misses become transient lines without
 // data, cache.cc:146-150) / LRU touch, accumulate-row maps -- one workgroup, see cache_lookup_book_kernel
 __global__ __launch_bounds__(1024) void cache_update_book_kernel(
-    Cache c, const PlanHeader *hdr, const uint32_t *uniq, int bypass) {
+    Cache c, const PlanHeader *hdr, const uint32_t *uniq, int bypass, int probed) {
     CacheCtl *ctl = c.ctl;
     const int tid = threadIdx.x;
-    cache_probe_body(ctl, hdr, uniq, c.slot_of, c.length, bypass, c.uslot, c.flag, tid, 1024);
+    if (!probed)
+        cache_probe_body(ctl, hdr, uniq, c.slot_of, c.length, bypass, c.uslot, c.flag, tid, 1024);
+    else if (tid == 0)
+        ctl->U = hdr->n_unique;
     __syncthreads();
     cache_scan_body(hdr, c.flag, c.rank, &ctl->M, &ctl->nhit);
     __syncthreads();
@@ -1145,11 +1167,32 @@ extern "C" int ha_cache_bind_store(ha_cache *h, float *table, int64_t *versions,
 }
 
 // key_kind: 0 = float32 ids (the *_raw entry points, cache.cc:49-58), 1 = uint64 keys
-static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hipStream_t s) {
+// Index plan of the batch.  *probed = 1 when the finish also probed the cache for every unique key
+// (batches up to kSmallMax keys: sort, then cache_finish_probe_kernel); want_pull adds the pull decision.
+static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hipStream_t s,
+                      int want_pull = 0, int *probed = nullptr) {
     HA_REQUIRE(n <= h->c.nmax, "cache: batch of %ld keys exceeds max_batch %ld", (long)n, (long)h->c.nmax);
+    Cache &c = h->c;
+    if (probed)
+        *probed = 0;
+    if (probed && n > 0 && n <= kSmallMax) {
+        const int rc = key_kind == 0 ? ha_plan_sort_f32ids(static_cast<const float *>(keys), n, c.plan_ws, s)
+                                     : ha_plan_sort_u64ids(static_cast<const uint64_t *>(keys), n, c.plan_ws, s);
+        if (rc)
+            return rc;
+        PlanPtrs p = plan_layout(c.plan_ws, n);
+        const HeadProbe hp{c.slot_of, (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag,
+                           want_pull ? c.data_row : nullptr, c.version, c.srv_ver,
+                           (long long)c.row_start, (long long)c.store_rows, (long long)c.pull_bound};
+        hipLaunchKernelGGL(cache_finish_probe_kernel, dim3(finish_blocks((int)n)), dim3(1024), 0, s, p.sorted,
+                           p.perm, (int)n, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, hp);
+        HA_LAUNCH_CHECK();
+        *probed = 1;
+        return 0;
+    }
     if (key_kind == 0)
-        return ha_plan_build_f32ids(static_cast<const float *>(keys), n, h->c.plan_ws, s);
-    return ha_plan_build_u64ids(static_cast<const uint64_t *>(keys), n, h->c.plan_ws, s);
+        return ha_plan_build_f32ids(static_cast<const float *>(keys), n, c.plan_ws, s);
+    return ha_plan_build_u64ids(static_cast<const uint64_t *>(keys), n, c.plan_ws, s);
 }
 
 extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int64_t n,
@@ -1158,12 +1201,13 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     HA_REQUIRE(n >= 0 && (n == 0 || (keys && dest)), "cache_lookup: bad arguments");
     Cache &c = h->c;
     hipStream_t s = as_stream(stream);
-    if (cache_plan(h, keys, key_kind, n, s))
+    int probed = 0;
+    if (cache_plan(h, keys, key_kind, n, s, 1, &probed))
         return -1;
     h->plan_n = n;
     PlanPtrs p = plan_layout(c.plan_ws, n);
     hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
-                       (long long)n, c.bypass ? 1 : 0);
+                       (long long)n, c.bypass ? 1 : 0, probed);
     if (n > 0) {
         const unsigned blocks = static_cast<unsigned>((n + 3) / 4);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0) &&
@@ -1189,8 +1233,9 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     HA_REQUIRE(n >= 0 && (n == 0 || grads), "cache_update: bad arguments");
     Cache &c = h->c;
     // keys == nullptr: the batch of the preceding ha_cache_lookup, whose plan is still in the workspace
+    int probed = 0;
     if (keys != nullptr) {
-        if (cache_plan(h, keys, key_kind, n, s))
+        if (cache_plan(h, keys, key_kind, n, s, 0, &probed))
             return -1;
     } else {
         HA_REQUIRE(h->plan_n == n && n > 0, "cache_update_same_keys: no lookup of %ld keys precedes this update", (long)n);
@@ -1212,7 +1257,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
         pk = c.pushkeys_u32;
     }
     hipLaunchKernelGGL(cache_update_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
-                       c.bypass ? 1 : 0);
+                       c.bypass ? 1 : 0, probed);
     HA_LAUNCH_CHECK();
     // Line::accumulate per occurrence, occurrence order: grad += g (every line), data += g (lines
     // with data).  lr = -1 turns the SGD chain `acc - lr*g` into `acc + g` bit for bit.

@@ -348,6 +348,36 @@ __device__ __forceinline__ void rank_tile_body<float>(
 // raise their budget.  LDS: 64 words.  For batches up to kFinishChunkedMax ids the same body runs
 // behind one counting launch (heads per chunk) instead of recounting: two launches in all.
 constexpr int kFinishChunkedMax = 1 << 20;
+
+// Optional per-unique-key hook of the finish (the embedding cache): the thread that writes uniq[u] also
+// probes the cache's direct map and, for a lookup, takes syncEmbedding's pull decision -- random,
+// translation-bound accesses that spread over every finish workgroup here instead of running on the
+// single bookkeeping workgroup (cache.hip).
+struct HeadProbe {
+    const int32_t *slot_of;   // key -> slot (-1 absent)
+    long long length;
+    int bypass;
+    int32_t *uslot;           // [u] slot or -1
+    uint32_t *flag;           // [u] 1 = miss
+    int32_t *pull;            // [u] pull decision, or nullptr (update flow)
+    const long long *version; // [slot]
+    const long long *srv_ver; // [row - row_start]
+    long long row_start, store_rows, pull_bound;
+};
+__device__ __forceinline__ void head_probe(const HeadProbe &hp, int u, uint32_t k) {
+    const bool known = k < static_cast<unsigned long long>(hp.length);
+    const int sv = hp.slot_of[known ? k : 0];
+    const int s = (!hp.bypass && known) ? sv : -1;
+    hp.uslot[u] = s;
+    hp.flag[u] = s < 0 ? 1u : 0u;
+    if (hp.pull) {
+        const long long lk = static_cast<long long>(k) - hp.row_start;
+        const bool inr = lk >= 0 && lk < hp.store_rows;
+        const long long v = s >= 0 ? hp.version[s] : -1;
+        const long long srv = hp.srv_ver[inr ? lk : 0];
+        hp.pull[u] = (inr && (v == -1 || srv - v > hp.pull_bound)) ? 1 : 0;
+    }
+}
 constexpr int kFinishLdsWords = 64;
 inline int finish_blocks(int n) { return (n + 1023) / 1024; }
 
@@ -356,7 +386,8 @@ __device__ __forceinline__ void finish_block_body(
     int n, PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
-    int b, uint32_t *s_w, const uint32_t *__restrict__ chunk_heads = nullptr) {
+    int b, uint32_t *s_w, const uint32_t *__restrict__ chunk_heads = nullptr,
+    const HeadProbe *hp = nullptr) {
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t *s_before = s_w, *s_heads = s_w + 16, *s_first = s_w + 32, *s_cand = s_w + 48;
     const int p = b * 1024 + tid;
@@ -436,6 +467,8 @@ __device__ __forceinline__ void finish_block_body(
         if (head) {
             uniq[ui] = k;
             seg[ui] = p;
+            if (hp)
+                head_probe(*hp, ui, k);
             const unsigned long long later = lane == 63 ? 0ull : (hm >> (lane + 1));
             int32_t nxt;
             if (later)
