@@ -166,14 +166,37 @@ __device__ __forceinline__ void cache_scan_body(
     __shared__ uint32_t s_w[16];
     const int U = static_cast<int>(hdr->n_unique);
     uint32_t carry = 0;
-    for (int base = 0; base < U; base += 1024) {
-        const int u = base + threadIdx.x;
-        const uint32_t v = u < U ? flag[u] : 0u;
+    if (U <= 16 * 1024) {
+        // thread t owns the K = ceil(U/1024) consecutive flags t*K ..: one block scan of the per-thread
+        // sums instead of one per 1024 flags
+        const int K = (U + 1023) >> 10;
+        const int u0 = threadIdx.x * K;
+        uint32_t f[16];
+        uint32_t local = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            f[i] = (i < K && u0 + i < U) ? flag[u0 + i] : 0u;
+            local += f[i];
+        }
         uint32_t tot;
-        const uint32_t ex = block_scan_1024(v, s_w, &tot);
-        if (u < U)
-            rank[u] = carry + ex;
-        carry += tot;
+        uint32_t ex = block_scan_1024(local, s_w, &tot);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < K && u0 + i < U)
+                rank[u0 + i] = ex;
+            ex += f[i];
+        }
+        carry = tot;
+    } else {
+        for (int base = 0; base < U; base += 1024) {
+            const int u = base + threadIdx.x;
+            const uint32_t v = u < U ? flag[u] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_scan_1024(v, s_w, &tot);
+            if (u < U)
+                rank[u] = carry + ex;
+            carry += tot;
+        }
     }
     if (threadIdx.x == 0) {
         *total_out = carry;
