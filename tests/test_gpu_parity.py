@@ -477,3 +477,28 @@ def test_random_shapes_sweep(dev):
         ops.lookup_sort(t4, d_ids, plan)
         ops.push_apply_finish(t4, plan, d_g)
         np.testing.assert_array_equal(t4.cpu().numpy(), want_p, err_msg=msg)
+
+
+def test_many_criteo_batches_through_the_fused_step(dev):
+    """60 consecutive Criteo-shaped batches (bs=256, d=512) through the two fused launches, with the
+    next-batch prefetch on, against the oracle after every step (rare interleavings of the cooperative
+    long-run path would show up here)."""
+    rows, width = 300000, 512
+    rng = np.random.default_rng(99)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    want = table.copy()
+    t = _dev(table, dev)
+    plan = ops.IndexPlan(6656, dev)
+    batches = [np.minimum(synth.as_f32_ids(synth.criteo_batch(256, 1000 + k, rows=rows)).reshape(-1),
+                          np.float32(rows - 1)) for k in range(61)]
+    d_batches = [_dev(b, dev) for b in batches]
+    for k in range(60):
+        grads = rng.standard_normal((6656, width), dtype=np.float32)
+        out = ops.lookup_sort(t, d_batches[k], plan)
+        ops.sgd_apply_finish(t, plan, _dev(grads, dev), 0.05, next_ids=d_batches[k + 1])
+        np.testing.assert_array_equal(out.cpu().numpy(), cpu.embedding_lookup(want, batches[k]), err_msg="step %d" % k)
+        cpu.sgd_sparse_update(want, batches[k], grads, 0.05)
+        touched = np.unique(batches[k].astype(np.int64))
+        np.testing.assert_array_equal(t[torch.from_numpy(touched).to(dev)].cpu().numpy(), want[touched],
+                                      err_msg="step %d" % k)
+    np.testing.assert_array_equal(t.cpu().numpy(), want)
