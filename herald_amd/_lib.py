@@ -95,6 +95,7 @@ def _declare(L):
         "ha_plan_build_u64ids": [vp, i64, vp, vp],
         "ha_plan_build_u32keys": [vp, i64, vp, c.c_int, vp],
         "ha_plan_sort_f32ids": [vp, i64, vp, vp],
+        "ha_plan_sort_u32keys": [vp, i64, vp, c.c_int, vp],
         "ha_plan_sort_u64ids": [vp, i64, vp, vp],
         "ha_plan_finish": [vp, i64, vp],
         "ha_plan_export_f32": [vp, i64, vp, vp, vp],

@@ -580,6 +580,11 @@ extern "C" int ha_plan_build_u32keys(const uint32_t *keys, int64_t n, void *ws,
     return plan_build<uint32_t>(keys, n, ws, key_bits, false, as_stream(stream));
 }
 
+extern "C" int ha_plan_sort_u32keys(const uint32_t *keys, int64_t n, void *ws, int key_bits,
+                                    ha_stream_t stream) {
+    return plan_build<uint32_t>(keys, n, ws, key_bits, true, as_stream(stream));
+}
+
 extern "C" int ha_plan_sort_f32ids(const float *ids, int64_t n, void *ws,
                                    ha_stream_t stream) {
     return plan_build<float>(ids, n, ws, 32, true, as_stream(stream));

@@ -156,7 +156,8 @@ extern "C" int ha_shard_serve_push(float *table, int64_t rows, int64_t width, co
     if (n == 0)
         return 0;
     HA_REQUIRE(table && keys && values && plan_ws, "shard_serve_push: null pointer");
-    if (ha_plan_build_u32keys(keys, n, plan_ws, 32, stream))
+    // sort, then the fused apply + finish launch (lr = -1 turns `acc - lr*v` into `acc + v` bit for bit)
+    if (ha_plan_sort_u32keys(keys, n, plan_ws, 32, stream))
         return -1;
-    return ha_sgd_apply(table, rows, width, plan_ws, n, values, -1.0f, stream);
+    return ha_sgd_apply_finish(table, rows, width, plan_ws, n, values, -1.0f, stream);
 }

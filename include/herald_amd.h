@@ -201,6 +201,7 @@ int ha_plan_build_u64ids(const uint64_t *ids, int64_t n, void *ws,
 /* Two-phase form.  ha_plan_sort_* produces only `keys`, `sorted` and `perm` -- all that
  * ha_sgd_apply / ha_push_apply need; ha_plan_finish adds n_unique, uniq, counts, seg, inverse and
  * upos (needed by ha_dedup_reduce, ha_plan_export_f32 and the cache).  build == sort + finish. */
+int ha_plan_sort_u32keys(const uint32_t *keys, int64_t n, void *plan_ws, int key_bits, ha_stream_t stream);
 int ha_plan_sort_f32ids(const float *ids, int64_t n, void *ws,
                         ha_stream_t stream);
 int ha_plan_sort_u64ids(const uint64_t *ids, int64_t n, void *ws,
