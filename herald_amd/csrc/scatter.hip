@@ -88,9 +88,10 @@ __global__ __launch_bounds__(1024, 8) void apply_unique_kernel(
             }
             continue;
         }
-        if (key >= dst_rows)
+        const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(key);
+        if (row >= dst_rows)
             continue;  // out-of-range id: ignored
-        float *dst_row = dst + static_cast<uint64_t>(key) * static_cast<uint64_t>(width);
+        float *dst_row = dst + row * static_cast<uint64_t>(width);
         const int pv = perm[min(s + lane, n - 1)];   // lanes 0 .. len-1: the run's occurrence indices
         if (len <= kShortRun) {
             short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, true, Second{nullptr, false});
@@ -119,9 +120,9 @@ __global__ __launch_bounds__(1024, 8) void apply_long_kernel(
     for (long long it = blockIdx.x; it < items; it += gridDim.x) {
         const int u = static_cast<int>(long_list[it / nslice]);
         const int j = static_cast<int>(it % nslice);
-        const uint32_t key = uniq[u];
-        if (key < dst_rows)
-            coop_slices<MODE, false>(dst + static_cast<uint64_t>(key) * static_cast<uint64_t>(width), true,
+        const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
+        if (row < dst_rows)
+            coop_slices<MODE, false>(dst + row * static_cast<uint64_t>(width), true,
                                      Second{nullptr, false}, grads, perm, maps, n, lr, seg[u], counts[u], width,
                                      j, nslice, w, reinterpret_cast<float *>(s_apply));
         __syncthreads();
@@ -145,6 +146,10 @@ extern "C" int ha_plan_view_of(void *ws, int64_t n, ha_plan_view *view);
 namespace ha {
 
 template <int MODE>
+int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, int64_t n,
+                    const float *grads, float lr, hipStream_t stream);
+
+template <int MODE>
 static int apply_launch(float *dst, int64_t dst_rows, int64_t width,
                         const void *plan_ws, int64_t n, const float *grads,
                         float lr, hipStream_t stream) {
@@ -152,6 +157,8 @@ static int apply_launch(float *dst, int64_t dst_rows, int64_t width,
     if (n == 0)
         return 0;
     HA_REQUIRE(dst && plan_ws && grads, "apply: null pointer");
+    if (MODE == kModeReduce && n > kSmallMax)   // dedup-reduce reads a FINISHED plan: map waves to unique keys
+        return apply_by_unique<MODE>(dst, dst_rows, width, const_cast<void *>(plan_ws), n, grads, lr, stream);
     ha_plan_view v;
     if (ha_plan_view_of(const_cast<void *>(plan_ws), n, &v) != 0)
         return -1;
@@ -199,6 +206,7 @@ int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, 
 }
 template int apply_by_unique<kModeSgd>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t);
 template int apply_by_unique<kModePush>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t);
+template int apply_by_unique<kModeReduce>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t);
 }  // namespace ha
 
 extern "C" int ha_sgd_apply(float *table, int64_t rows, int64_t width,

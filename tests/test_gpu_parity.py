@@ -132,6 +132,21 @@ def test_sgd_apply_bit_exact(dev, width, n):
     np.testing.assert_array_equal(t.cpu().numpy(), want)
 
 
+def test_dedup_reduce_large_batch(dev):
+    """n > 36,864: the dedup-reduce maps waves to unique keys (runs of thousands included)."""
+    rng = np.random.default_rng(41)
+    n, width = 60000, 64
+    ids = _runs_batch(rng, [3000, 1500, 700, 100, 48, 47, 5], 20000, 500000)
+    ids = np.concatenate([ids, rng.integers(0, 500000, size=n - ids.size).astype(np.float32)])
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    plan = ops.IndexPlan(n, dev).build(_dev(ids, dev))
+    uniq, _, want = cpu.dedup_reduce(ids, grads)
+    red = ops.dedup_reduce(plan, _dev(grads, dev))
+    np.testing.assert_array_equal(red[:uniq.size].cpu().numpy(), want)
+    red2 = ops.dedup_reduce(plan, _dev(grads, dev), scale=0.5)       # scale_values multiplies by -lr
+    np.testing.assert_array_equal(red2[:uniq.size].cpu().numpy(), cpu.dedup_reduce(ids, cpu.scale_values(grads, -0.5))[2])
+
+
 @pytest.mark.parametrize("width", [4, 128, 512])
 def test_dedup_reduce_bit_exact(dev, width):
     rng = np.random.default_rng(width)
