@@ -6,13 +6,13 @@
  * HIP path against (and time beside it).  Each function cites the reference code it follows
  * (paths relative to /root/reference).
  *
- * Parity pin: the reference's own CPU ops need oneDNN's <dnnl.hpp> to compile
- * (src/dnnl_ops/EmbeddingLookup.cpp:11) which this image lacks, so they cannot be built here
- * without stand-in headers.  These restatements are pinned instead by
- *   - numpy identities the reference's own tests use as their oracle
- *     (tests/test_embedding_op.py, tests/test_optimizer.py:117-198; tests/golden/ fixtures), and
- *   - oracle/_ref/ref_unique (the reference's header-only hetu::Unique<T>, compiled from
- *     /root/reference where it lies) for the dedup order.
+ * Parity pin: PINNED to the reference compiled here.  oracle/build_ref.sh compiles the reference's own
+ * src/dnnl_ops/EmbeddingLookup.cpp and src/dnnl_ops/Optimizers.cpp unchanged (oneDNN's real
+ * <dnnl.hpp> ships with PyTorch: torch/include/dnnl.hpp) into oracle/_ref/libref_dnnl.so;
+ * tests/golden/make_golden.py runs cpu_EmbeddingLookup / cpu_SGDOptimizerSparseUpdate from it and
+ * commits tests/golden/dnnl_ops.json; tests/test_golden.py holds oracle_embedding_lookup and
+ * oracle_sgd_sparse_update to those vectors bit for bit (and live against the .so where it exists).
+ * The dedup order is pinned the same way by oracle/_ref's hetu::Unique<T> (tests/golden/unique.json).
  *
  * Build: gcc -O3 -fopenmp -ffp-contract=off -fPIC -shared oracle.c  (see herald_amd/_build.py).
  * The reference is built with "-O3 -Wall" for baseline x86-64 (CMakeLists.txt:15), i.e. without

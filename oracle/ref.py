@@ -103,3 +103,70 @@ class MiniLRU:
         buf = np.empty(1 << 16, dtype=np.int32)
         n = lib().ref_minilru_keys(self.h, buf.ctypes.data, buf.size)
         return [int(x) for x in buf[:n]]
+
+
+# ---- the reference's own CPU operators of the hot path (oracle/_ref/libref_dnnl.so) -------------
+# src/dnnl_ops/EmbeddingLookup.cpp:16-35 and src/dnnl_ops/Optimizers.cpp:51-74 compiled unchanged
+# (oracle/build_ref.sh), called through a ctypes mirror of DLArray (src/common/dlarray.h:40-55).
+_DNNL_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_dnnl.so")
+_D = None
+
+
+class _DLContext(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int), ("device_type", ctypes.c_int)]
+
+
+class _DLArray(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("ctx", _DLContext), ("ndim", ctypes.c_int),
+                ("shape", ctypes.POINTER(ctypes.c_int64)), ("stride", ctypes.POINTER(ctypes.c_int64))]
+
+
+def _dl(a):
+    """DLArray view of a C-contiguous float32 numpy array (device_type 1 = CPU)."""
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+    arr = _DLArray(a.ctypes.data, _DLContext(0, 1), a.ndim, shape, None)
+    arr._keep = (a, shape)
+    return arr
+
+
+def dnnl_available():
+    return os.path.exists(_DNNL_PATH)
+
+
+def _dnnl():
+    global _D
+    if _D is None:
+        L = ctypes.CDLL(_DNNL_PATH)
+        P = ctypes.POINTER(_DLArray)
+        L.cpu_EmbeddingLookup.argtypes = [P, P, P]
+        L.cpu_EmbeddingLookup.restype = ctypes.c_int
+        L.cpu_SGDOptimizerSparseUpdate.argtypes = [P, P, P, ctypes.c_float]
+        L.cpu_SGDOptimizerSparseUpdate.restype = ctypes.c_int
+        _D = L
+    return _D
+
+
+def dnnl_embedding_lookup(table, ids):
+    """The reference's cpu_EmbeddingLookup: out[..., :] = table[size_t(ids[...]), :]."""
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    ids = np.ascontiguousarray(ids, dtype=np.float32)
+    out = np.empty(ids.shape + (table.shape[1],), dtype=np.float32)
+    if ids.size == 0:
+        return out
+    t, i, o = _dl(table), _dl(ids), _dl(out)
+    rc = _dnnl().cpu_EmbeddingLookup(ctypes.byref(t), ctypes.byref(i), ctypes.byref(o))
+    assert rc == 0
+    return out
+
+
+def dnnl_sgd_sparse_update(table, ids, grads, lr):
+    """The reference's cpu_SGDOptimizerSparseUpdate, in place on `table` (float32, C-contiguous)."""
+    assert table.dtype == np.float32 and table.flags["C_CONTIGUOUS"]
+    ids = np.ascontiguousarray(ids, dtype=np.float32)
+    grads = np.ascontiguousarray(grads, dtype=np.float32)
+    t, i, g = _dl(table), _dl(ids), _dl(grads)
+    rc = _dnnl().cpu_SGDOptimizerSparseUpdate(ctypes.byref(t), ctypes.byref(i), ctypes.byref(g),
+                                              ctypes.c_float(lr))
+    assert rc == 0
+    return table

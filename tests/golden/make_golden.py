@@ -13,6 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
 from oracle import ref  # noqa: E402
 
 
@@ -61,8 +62,52 @@ def unique_vectors(seed):
     return out
 
 
+def dnnl_cases(seed):
+    """cpu_EmbeddingLookup / cpu_SGDOptimizerSparseUpdate of the REFERENCE (oracle/_ref/libref_dnnl.so =
+    src/dnnl_ops/EmbeddingLookup.cpp + Optimizers.cpp compiled unchanged) on closed-form tables
+    (formula.py): SURVEY 8(c)'s list -- d in {4, 64, 128, 512}, duplicates, a hot id, ids > 2^24,
+    empty and single-id batches, 2-D id arrays."""
+    import formula
+    rng = np.random.default_rng(seed)
+    specs = [
+        # name, rows, width, ids (float32 array, any rank), lr
+        ("d4_dups", 37, 4, rng.integers(0, 37, size=(6, 5)), 0.01),
+        ("d4_hot", 11, 4, np.concatenate([np.full(40, 7), rng.integers(0, 11, size=24)])[rng.permutation(64)], 0.5),
+        ("d64_dups", 101, 64, rng.integers(0, 101, size=(4, 8)), 0.01),
+        ("d64_hot", 9, 64, np.concatenate([np.full(50, 3), rng.integers(0, 9, size=14)])[rng.permutation(64)], 1e-3),
+        ("d128_dups", 53, 128, rng.integers(0, 53, size=24), 1e-6),
+        ("d512_dups", 29, 512, np.array([5, 28, 5, 0, 17, 5, 28, 11, 0, 5, 3, 28]), 1e-6),
+        ("empty", 5, 4, np.zeros((0,), dtype=np.int64), 0.01),
+        ("single", 5, 64, np.array([4]), 0.01),
+        # float32 ids above 2^24: only even numbers are representable; the reference truncates the float
+        ("big_ids_d4", 33762577, 4, np.array([16777216, 16777218, 33762576, 20000002, 16777218, 25000000,
+                                               33762576, 1, 0, 16777220], dtype=np.float32), 0.01),
+    ]
+    out = []
+    for name, rows, width, ids, lr in specs:
+        ids = np.asarray(ids).astype(np.float32)
+        tab = formula.table(rows, width)
+        n = ids.size
+        grads = rng.standard_normal((n, width)).astype(np.float32)
+        got = ref.dnnl_embedding_lookup(tab, ids)
+        assert got.shape == ids.shape + (width,)
+        upd = tab.copy()
+        if n:
+            ref.dnnl_sgd_sparse_update(upd, ids.reshape(-1), grads, lr)
+        keys = sorted(set(int(x) for x in ids.reshape(-1)))
+        changed = np.nonzero((upd != tab).any(axis=1))[0].tolist()
+        assert set(changed) <= set(keys)
+        out.append({"name": name, "rows": rows, "width": width, "ids_shape": list(ids.shape),
+                    "ids_bits": formula.bits(ids), "lr_bits": formula.bits(np.float32(lr))[0],
+                    "grads_bits": formula.bits(grads), "out_bits": formula.bits(got),
+                    "touched_rows": keys, "touched_bits": formula.bits(upd[keys]) if keys else []})
+    return out
+
+
 def main():
     assert ref.available(), "build oracle/_ref first (oracle/build_ref.sh)"
+    assert ref.dnnl_available(), "build oracle/_ref/libref_dnnl.so first (oracle/build_ref.sh)"
+    json.dump(dnnl_cases(7), open(os.path.join(HERE, "dnnl_ops.json"), "w"))
     for kind in ("lru", "lfu", "lfuopt"):
         traces = [policy_trace(kind, 8, 40, 400, 1), policy_trace(kind, 3, 12, 300, 2),
                   policy_trace(kind, 25, 30, 300, 3)]
