@@ -46,7 +46,30 @@ def parse_args():
                    help="skip the secondary measurement of the LRU cache tier (limit 0.1 x rows)")
     p.add_argument("--graph-steps", type=int, default=32,
                    help="steps captured per hipGraph (1 = eager launches)")
+    p.add_argument("--grad-buffers", type=int, default=24,
+                   help="distinct gradient / output buffers cycled through (24 x 13.6 MB = 327 MB > the "
+                        "256 MiB Infinity Cache, so gradient reads and output writes are HBM traffic)")
     return p.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes (one rank per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and wait for them.  This parent never touches the GPU
+    and never re-execs itself."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    return rc
 
 
 def algorithmic_bytes(n, u, width):
@@ -101,7 +124,14 @@ def make_batches(args, rank, world):
 def cpu_baseline(args, ids_host):
     """Reference CPU path restated (oracle/oracle.c), timed on this box's host cores on a bounded
     sample: a 1M-row slice of the table, ids folded into it, gather (OpenMP) + serial sparse SGD."""
-    from oracle import cpu
+    from oracle import cpu, ref
+    kind = "port"
+    lookup, update = cpu.embedding_lookup, cpu.sgd_sparse_update
+    if ref.dnnl_available():
+        # the reference's own cpu_EmbeddingLookup / cpu_SGDOptimizerSparseUpdate (oracle/_ref/libref_dnnl.so,
+        # src/dnnl_ops/*.cpp compiled unchanged by oracle/build_ref.sh; prebuilt, travels with the snapshot)
+        kind = "reference"
+        lookup, update = ref.dnnl_embedding_lookup, ref.dnnl_sgd_sparse_update
     rows_cpu = min(args.rows, 1_000_000)
     rng = np.random.default_rng(7)
     table = (rng.standard_normal((rows_cpu, args.width), dtype=np.float32) * np.float32(0.01))
@@ -111,22 +141,25 @@ def cpu_baseline(args, ids_host):
     t_budget = 12.0
     # warm-up
     idf = np.mod(ids_host[0], rows_cpu).astype(np.float32)
-    cpu.embedding_lookup(table, idf)
-    cpu.sgd_sparse_update(table, idf, grads, LR)
+    lookup(table, idf)
+    update(table, idf, grads, LR)
     t0 = time.perf_counter()
     while True:
         idf = np.mod(ids_host[steps % ids_host.shape[0]], rows_cpu).astype(np.float32)
-        cpu.embedding_lookup(table, idf)
-        cpu.sgd_sparse_update(table, idf, grads, LR)
+        lookup(table, idf)
+        update(table, idf, grads, LR)
         steps += 1
         el = time.perf_counter() - t0
         if el > t_budget or steps >= 400:
             break
     return {
-        "value": n * steps / el, "unit": "rows/s", "cores": cpu.num_threads(), "kind": "port",
-        "sample": "%d steps of bs=%d d=%d on a %d-row table slice: OpenMP gather (%d threads) + serial "
+        "value": n * steps / el, "unit": "rows/s", "cores": cpu.num_threads(), "kind": kind,
+        "sample": "%d steps of bs=%d d=%d on a %d-row table slice: %s OpenMP gather (%d threads) + serial "
                   "sparse SGD (1 thread, as cpu_SGDOptimizerSparseUpdate mandates), %.1f ms/step"
-                  % (steps, args.batch, args.width, rows_cpu, cpu.num_threads(), 1e3 * el / steps),
+                  % (steps, args.batch, args.width, rows_cpu,
+                     "the reference's compiled cpu_EmbeddingLookup / cpu_SGDOptimizerSparseUpdate:"
+                     if kind == "reference" else "oracle.c:",
+                     cpu.num_threads(), 1e3 * el / steps),
     }
 
 
@@ -164,11 +197,13 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
     return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps, "policy": "LRU",
             "limit_rows": limit, "bound": 100, "steps": steps, "unique_miss_rate": miss,
             "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
-                    "(~23 small launches, launch-latency bound); not part of `value`"}
+                    "(10 launches per pair, launch-latency bound); not part of `value`"}
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))          # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,19 +218,21 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         from herald_amd import sharded_bench
-        return sharded_bench.run(args, rank, world, dev)
+        return sharded_bench.run(args, rank, world, dev, cpu_baseline_fn=cpu_baseline)
 
     n = args.batch * args.fields
+    G = max(1, args.graph_steps)
+    if args.distinct_batches >= G:
+        args.distinct_batches -= args.distinct_batches % G     # graphs never straddle the wrap-around
     ids_host, uniq_counts = make_batches(args, rank, world)
     ids_dev = torch.from_numpy(ids_host).to(dev)
     table = init_table(args.rows, args.width, dev)
-    out = torch.empty((n, args.width), dtype=torch.float32, device=dev)
-    ngrad = 4
+    nbuf = max(1, args.grad_buffers)
     gen = torch.Generator(device=dev)
     gen.manual_seed(456)
-    grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(ngrad)]
+    grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(nbuf)]
+    outs = [torch.empty((n, args.width), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     nb = ids_dev.shape[0]
-    G = max(1, args.graph_steps)
     plan = ops.IndexPlan(n, dev)
     main_s = torch.cuda.Stream(device=dev)
 
@@ -205,55 +242,67 @@ def main():
     # The table dependency gather(k) -> apply(k) -> gather(k+1) is the stream order.
     # The backward launch is handed the ids of the NEXT batch (resident one step ahead, as the reference's
     # prefetching data loader provides them): its idle waves touch the rows the next lookup will gather.
+    # Batch b always uses gradient / output buffer b % nbuf, so a captured graph depends on b only.
     def step(k):
-        ids = ids_dev[k % nb]
-        ops.lookup_sort(table, ids, plan, out=out, stream=main_s)
-        ops.sgd_apply_finish(table, plan, grads[k % ngrad], LR, stream=main_s, next_ids=ids_dev[(k + 1) % nb])
-
-    graphs = {}
-
-    def capture(k0):
-        """Graph of G consecutive steps starting at batch k0 (k0 % G == 0)."""
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=main_s):
-            for k in range(k0, k0 + G):
-                step(k)
-        return g
+        b = k % nb
+        ops.lookup_sort(table, ids_dev[b], plan, out=outs[b % nbuf], stream=main_s)
+        ops.sgd_apply_finish(table, plan, grads[b % nbuf], LR, stream=main_s, next_ids=ids_dev[(b + 1) % nb])
 
     use_graph = G > 1
-    ngraphs = max(1, nb // G) if use_graph else 0
-    if use_graph:
-        torch.cuda.synchronize()
-        for gi in range(ngraphs):
-            graphs[gi] = capture(gi * G)
-        torch.cuda.synchronize()
+    graphs = {}
+
+    def chunks(k0, count):
+        """[k0, k0+count) cut at the multiples of G: (first step, length) pieces of at most G steps."""
+        k, end = k0, k0 + count
+        while k < end:
+            ln = min(end, (k // G + 1) * G) - k
+            yield k, ln
+            k += ln
+
+    def graph_for(k, ln):
+        key = (k % nb, ln)
+        if key not in graphs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=main_s):
+                for j in range(k, k + ln):
+                    step(j)
+            graphs[key] = g
+        return graphs[key]
 
     def run(k0, count):
-        """Exactly `count` steps starting at step index k0."""
-        k = k0
-        endk = k0 + count
+        """Exactly `count` steps starting at step index k0; returns the number of graph replays."""
+        replays = 0
         with torch.cuda.stream(main_s):
-            while k < endk:
-                if use_graph and k % G == 0 and k + G <= endk:
-                    graphs[(k // G) % ngraphs].replay()
-                    k += G
+            for k, ln in chunks(k0, count):
+                if use_graph:
+                    graph_for(k, ln).replay()
+                    replays += 1
                 else:
-                    step(k)
-                    k += 1
+                    for j in range(k, k + ln):
+                        step(j)
+        return replays
 
-    wu = ((args.warmup + G - 1) // G) * G if use_graph else args.warmup
+    wu = args.warmup
+    if use_graph:     # capture everything the warm-up and the timed region replay, before either runs
+        torch.cuda.synchronize()
+        for k, ln in list(chunks(0, wu)) + list(chunks(wu, args.steps)):
+            graph_for(k, ln)
+        torch.cuda.synchronize()
     run(0, wu)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(main_s)
-    run(wu, args.steps)
+    replays = run(wu, args.steps)
     e1.record(main_s)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
-    total_ms = max(dev_ms, wall * 1e3)      # host-bound launches count as well
+    # the K steps' time on the stream (HIP events); if the host needed longer than that to enqueue them,
+    # the run is host-bound and the host time counts
+    total_ms = max(dev_ms, t_enq * 1e3)
     ms_per_step = total_ms / args.steps
     rows_per_s = n * args.steps / (total_ms * 1e-3)
 
@@ -287,34 +336,34 @@ def main():
                 main_s.synchronize()
             return a.elapsed_time(bq) / (reps * KL)
 
-        g_ms = timed_graph(lambda i: ops.lookup_sort(table, ids_dev[(wu + i) % nb], kplans[i], out=out,
-                                                     stream=main_s))
-        a_ms = timed_graph(lambda i: ops.sgd_apply_finish(table, kplans[i], grads[i % ngrad], LR, stream=main_s,
+        g_ms = timed_graph(lambda i: ops.lookup_sort(table, ids_dev[(wu + i) % nb], kplans[i],
+                                                     out=outs[i % nbuf], stream=main_s))
+        a_ms = timed_graph(lambda i: ops.sgd_apply_finish(table, kplans[i], grads[i % nbuf], LR, stream=main_s,
                                                           next_ids=ids_dev[(wu + i + 1) % nb]))
-        # Durations inside the timed sequence: the two launches alternate there and each boundary also
-        # pays for what the predecessor left behind (dirty lines, cold TLBs), so a launch lasts longer
-        # than in a graph of its own kind.  The step time measured over the timed region is split in the
-        # ratio of the isolated timings; rocprofv3's per-kernel averages of the same command
-        # (profiles/) agree with these in-sequence figures.
+        # `measured_us`: HIP events around a graph of 64 back-to-back launches of this kernel over 64
+        # distinct batches (boundary to the next launch included).  `in_step_us` scales both so that
+        # they sum to the step time of the timed region (the two launches alternate there and every
+        # boundary also pays for what the predecessor left behind); it is derived, not measured.
         share = ms_per_step / (g_ms + a_ms)
-        g_seq, a_seq = g_ms * share, a_ms * share
         kernels = {
-            "fwd_fused_kernel(gather+rank)": {"avg_us": g_seq * 1e3, "isolated_us": g_ms * 1e3,
+            "fwd_fused_kernel(gather+rank)": {"measured_us": g_ms * 1e3, "in_step_us": g_ms * share * 1e3,
                                               "algorithmic_bytes": fwd_b,
-                                              "GBps": fwd_b / (g_seq * 1e-3) / 1e9},
-            "bwd_fused_kernel(sgd apply+finish)": {"avg_us": a_seq * 1e3, "isolated_us": a_ms * 1e3,
+                                              "GBps": fwd_b / (g_ms * 1e-3) / 1e9},
+            "bwd_fused_kernel(sgd apply+finish)": {"measured_us": a_ms * 1e3, "in_step_us": a_ms * share * 1e3,
                                                    "algorithmic_bytes": bwd_b,
-                                                   "GBps": bwd_b / (a_seq * 1e-3) / 1e9},
+                                                   "GBps": bwd_b / (a_ms * 1e-3) / 1e9},
         }
-        dom = "bwd_fused_kernel(sgd apply+finish)" if a_ms >= g_ms else "fwd_fused_kernel(gather+rank)"
-        dom_bytes = bwd_b if a_ms >= g_ms else fwd_b
-        dom_ms = max(a_seq, g_seq)
-        traffic, traffic_src = pmc_traffic("ha::bwd_fused_kernel" if a_ms >= g_ms else "ha::fwd_fused_kernel")
+        bwd_dom = a_ms >= g_ms
+        dom = "bwd_fused_kernel(sgd apply+finish)" if bwd_dom else "fwd_fused_kernel(gather+rank)"
+        dom_bytes = bwd_b if bwd_dom else fwd_b
+        dom_ms = max(a_ms, g_ms)
+        traffic, traffic_src = pmc_traffic("ha::bwd_fused_kernel" if bwd_dom else "ha::fwd_fused_kernel")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": traffic_src,
-                    "avg_launch_us": dom_ms * 1e3, "isolated_launch_us": max(a_ms, g_ms) * 1e3,
+                    "avg_launch_us": dom_ms * 1e3,
+                    "avg_launch_source": "HIP events around a hipGraph of 64 back-to-back launches, 5 replays",
                     "algorithmic_bytes_per_launch": dom_bytes}
 
     step_gbs = (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9
@@ -329,17 +378,20 @@ def main():
                                % (args.batch, args.width, args.fields, args.rows,
                                   args.rows * args.width * 4 / 1e9),
                    "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,
-                   "launch": ("hipGraph of %d steps" % G) if use_graph else "eager",
+                   "grad_and_out_buffers": nbuf,
+                   "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
+                             else "eager",
                    "parallelism": "1 GPU"},
         "step_algorithmic_bytes": fwd_b + bwd_b,
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,
-        "device_ms": dev_ms, "wall_ms": wall * 1e3,
+        "device_ms": dev_ms, "enqueue_ms": t_enq * 1e3, "wall_ms": wall * 1e3,
+        "host_bound": bool(t_enq * 1e3 > dev_ms),
         "roofline": roofline, "kernels": kernels,
     }
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ids_host)
     if not args.no_cache_tier:
-        result["cache_tier"] = cache_tier(args, table, ids_dev, out, grads[0], dev)
+        result["cache_tier"] = cache_tier(args, table, ids_dev, outs[0], grads[0], dev)
     print(json.dumps(result))
 
 

@@ -11,7 +11,7 @@ XGMI_LINK_GBS = 153.0   # per link, 7 links per GPU (MI355X_MICROARCH / task sta
 HBM_PEAK_GBS = 8000.0
 
 
-def run(args, rank, world, dev):
+def run(args, rank, world, dev, cpu_baseline_fn=None):
     from herald_amd import synth
     from herald_amd.sharded import ShardedEmbedding
 
@@ -66,8 +66,21 @@ def run(args, rank, world, dev):
     el = float(t.item())
     xg = torch.tensor([emb.stats["xgmi_bytes_out"], emb.stats["xgmi_bytes_in"]], dtype=torch.float64, device=dev)
     dist.all_reduce(xg, op=dist.ReduceOp.MAX)
+    # per-GPU unique counts of the batches this rank ran (for the local kernels' algorithmic bytes)
+    used = [(args.warmup + k) % nb for k in range(args.steps)]
+    u_mean = float(np.mean([np.unique(ids_host[b]).size for b in sorted(set(used))]))
+    ranks_seen = dist.get_world_size()
     if rank == 0:
         rows_per_s = world * n * args.steps / el
+        # HBM side of one rank's step: the rows it serves and the gradients it applies are, summed over
+        # the ranks, the same N*(8d+4) + N*(4d+4) + U*8d bytes as at N=1 (weak scaling: every rank brings
+        # its own batch); per GPU that is the N=1 figure, moved in `el / steps`.
+        d = args.width
+        step_bytes = n * (8 * d + 4) + n * (4 * d + 4) + u_mean * 8 * d
+        hbm_gbs = step_bytes / (el / args.steps) / 1e9
+        cpu_base = None
+        if cpu_baseline_fn is not None and not args.no_cpu_baseline:
+            cpu_base = cpu_baseline_fn(args, ids_host)
         xgmi_gbs = float(xg[0].item()) / el / 1e9
         links = min(world - 1, 7)
         print(json.dumps({
@@ -81,6 +94,13 @@ def run(args, rank, world, dev):
                        "ids_per_step_per_gpu": n, "parallelism": "row-sharded x%d" % world},
             "xgmi": {"egress_GBps_per_gpu_max": xgmi_gbs, "peak_GBps_per_gpu": links * XGMI_LINK_GBS,
                      "frac": xgmi_gbs / (max(links, 1) * XGMI_LINK_GBS)},
-            "roofline": None, "cpu_baseline": None,
+            "ranks_seen": ranks_seen,
+            "roofline": {"bound": "hbm", "kernel": "per-GPU local kernels of one sharded step (gather of served "
+                                                   "rows, dedup-reduce, apply of received gradients)",
+                         "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_step_per_gpu": step_bytes,
+                         "note": "whole-step time (exchanges and host work included), not a kernel duration"},
+            "cpu_baseline": cpu_base,
         }))
     dist.destroy_process_group()

@@ -34,9 +34,20 @@ def test_bench_n1_line_has_the_contract_fields(dev):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "rows/s"
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "rows/s"
     assert d["value"] > 20 * cb["value"]
     assert d["cache_tier"]["value"] > 0
+
+
+def test_bench_short_driver_run_replays_graphs(dev):
+    """The driver's `--steps 20 --warmup 5`: every timed step runs inside a hipGraph replay, the line
+    reports the warm-up it was asked for and the launch mode it really used."""
+    d = _run({}, "--rows", "1000000", "--steps", "20", "--warmup", "5", "--distinct-batches", "64",
+             "--no-cache-tier", "--no-cpu-baseline")
+    assert d["steps"] == 20 and d["warmup"] == 5
+    assert "hipGraph" in d["config"]["launch"] and d["config"]["launch"].startswith("1 ")
+    assert d["config"]["grad_and_out_buffers"] >= 24
+    assert abs(d["ms_per_step"] * 20 - max(d["device_ms"], d["enqueue_ms"])) < 1e-6
 
 
 def test_bench_sharded_leg_runs_on_nccl_at_world_size_1(dev):
@@ -45,3 +56,4 @@ def test_bench_sharded_leg_runs_on_nccl_at_world_size_1(dev):
              "--rows", "1000000", "--steps", "64", "--warmup", "16")
     assert d["n_gpus"] == 1 and d["steps"] == 64 and d["value"] > 0 and d["scaling"] == "weak"
     assert "sharded" in d["config"]["workload"] and "xgmi" in d
+    assert d["ranks_seen"] == 1 and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
