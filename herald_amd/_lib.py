@@ -85,6 +85,10 @@ def _declare(L):
     L.ha_plan_bytes.restype = sz
     L.ha_plan_bytes.argtypes = [i64]
     L.ha_plan_view_of.argtypes = [vp, i64, c.POINTER(PlanView)]
+    L.ha_pend_bytes.restype = sz
+    L.ha_pend_bytes.argtypes = []
+    L.ha_plan_handoff_timeout.restype = vp
+    L.ha_plan_handoff_timeout.argtypes = [vp]
     sigs = {
         "ha_gather_f32ids": [vp, i64, i64, vp, i64, vp, vp],
         "ha_gather_u64ids": [vp, i64, i64, vp, i64, vp, vp],
@@ -116,6 +120,11 @@ def _declare(L):
         "ha_sgd_apply_finish": [vp, i64, i64, vp, i64, vp, f32, vp],
         "ha_push_apply_finish": [vp, i64, i64, vp, i64, vp, vp],
         "ha_sgd_apply_finish_prefetch_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp],
+        "ha_pend_reset": [vp, vp],
+        "ha_lookup_sort_pend_f32ids": [vp, i64, i64, vp, i64, vp, vp, vp, vp],
+        "ha_lookup_sort_pend_u64ids": [vp, i64, i64, vp, i64, vp, vp, vp, vp],
+        "ha_sgd_push_pull_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, vp],
+        "ha_sgd_push_pull_u64ids": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

@@ -98,4 +98,31 @@ __device__ __forceinline__ void st4_nt(float *p, float4v v) {
     __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(p));
 }
 
+// Device-coherent (agent scope, `sc1`) accesses for data another workgroup of the SAME launch reads or
+// wrote: the store is written through the XCD's L2, the load bypasses the CU's L1
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").  The
+// compiler does not count inline-asm memory instructions in its vmcnt bookkeeping: a 16-byte load's
+// result may only be used behind wait_loads(), and stores are followed by an explicit s_waitcnt
+// (signal_done, scatter_dev.h) before anything that publishes them.
+__device__ __forceinline__ void st4_sc1(float *p, float4v v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st1_sc1(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4v ld4_sc1_async(const float *p) {
+    float4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void wait_loads(float4v &a, float4v &b, float4v &c, float4v &d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+// Pending table of a batch (step.hip): 2^kPendBits words indexed by a multiplicative hash of the key.
+constexpr int kPendBits = 16;
+__device__ __forceinline__ uint32_t pend_slot(uint32_t key) {
+    return (key * 0x9E3779B1u) >> (32 - kPendBits);
+}
+
 }  // namespace ha

@@ -207,6 +207,15 @@ static int apply_finish(float *dst, int64_t rows, int64_t width, void *plan_ws,
     return 0;
 }
 
+// step.hip: batches outside the single-launch regime
+template <int MODE>
+int apply_finish_entry(float *dst, int64_t rows, int64_t width, void *plan_ws, int64_t n,
+                       const float *grads, float lr, hipStream_t stream) {
+    return apply_finish<MODE>(dst, rows, width, plan_ws, n, grads, lr, stream);
+}
+template int apply_finish_entry<kModeSgd>(float *, int64_t, int64_t, void *, int64_t, const float *, float,
+                                          hipStream_t);
+
 }  // namespace ha
 
 using namespace ha;

@@ -38,6 +38,17 @@ constexpr int kLongRun = 48;       // runs at least this long are handled by the
 constexpr int kShortRun = 3;       // runs up to this long: one wave, whole row, 16-byte accesses
 constexpr int kChunk = 16;         // occurrence rows requested per batch (one register each)
 
+// ---- in-launch hand-off of updated rows (step.hip: apply(k) runs beside the lookup of batch k+1) ----
+// Every occurrence of a key registered `nslice` units (64-column slices of the row) in the pending table
+// of its batch; a wave that has written s slices of a row with L occurrences gives L*s units back, after
+// its device-coherent stores have been acknowledged.  A reader may load the row once the word is 0.
+__device__ __forceinline__ void signal_done(uint32_t *pend_word, int units) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane_id() == 0)
+        __hip_atomic_fetch_add(pend_word, static_cast<uint32_t>(-units), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int MODE>
 __device__ __forceinline__ float step(float acc, float g, float lr) {
     if (MODE == kModeSgd)
@@ -57,6 +68,8 @@ struct Vec<4> {
     // updated rows are written around the L2 (non-temporal): nothing re-reads them inside the launch and
     // dirty lines left in the L2 lengthen the boundary to the next kernel
     __device__ __forceinline__ void store(float *p) const { st4_nt(p, v); }
+    // device-coherent write-through store (a row another workgroup of the SAME launch reads, step.hip)
+    __device__ __forceinline__ void store_sc1(float *p) const { st4_sc1(p, v); }
     __device__ __forceinline__ void zero() { v = float4v{0.f, 0.f, 0.f, 0.f}; }
     __device__ __forceinline__ float get(int k) const { return v[k]; }
     __device__ __forceinline__ void set(int k, float x) { v[k] = x; }
@@ -66,6 +79,7 @@ struct Vec<1> {
     float v;
     __device__ __forceinline__ void load(const float *p) { v = *p; }
     __device__ __forceinline__ void store(float *p) const { __builtin_nontemporal_store(v, p); }
+    __device__ __forceinline__ void store_sc1(float *p) const { st1_sc1(p, v); }
     __device__ __forceinline__ void zero() { v = 0.f; }
     __device__ __forceinline__ float get(int) const { return v; }
     __device__ __forceinline__ void set(int, float x) { v = x; }
@@ -74,7 +88,7 @@ struct Vec<1> {
 // ---- short runs (1..kShortRun occurrences): one wave, whole row --------------------------------
 // Columns [cbase, cbase + VB*64*VEC); the table row and every occurrence row are requested in one
 // batch (branch-free, clamped), then applied in occurrence order.
-template <int MODE, int VEC, int VB, bool DUAL>
+template <int MODE, int VEC, int VB, bool DUAL, bool SIG = false>
 __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                                             const float *__restrict__ grads,
                                             int width, int cbase, int pv,
@@ -124,14 +138,17 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                 for (int k = 0; k < VEC; ++k)
                     acc[b].set(k, __fadd_rn(cur.get(k), acc[b].get(k)));
             }
-            acc[b].store(dst_row + col[b]);
+            if (SIG)
+                acc[b].store_sc1(dst_row + col[b]);
+            else
+                acc[b].store(dst_row + col[b]);
             if (DUAL && d2.on)
                 acc2[b].store(d2.row + col[b]);
         }
     }
 }
 
-template <int MODE, int VEC, bool DUAL>
+template <int MODE, int VEC, bool DUAL, bool SIG = false>
 __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
                                           const float *__restrict__ grads,
                                           int width, int pv, int lane0, int len,
@@ -139,9 +156,9 @@ __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
     constexpr int kCols1 = kWave * VEC;
     int c = 0;
     for (; width - c > kCols1; c += 2 * kCols1)
-        short_block<MODE, VEC, 2, DUAL>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2);
+        short_block<MODE, VEC, 2, DUAL, SIG>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2);
     for (; c < width; c += kCols1)
-        short_block<MODE, VEC, 1, DUAL>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2);
+        short_block<MODE, VEC, 1, DUAL, SIG>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2);
 }
 
 // ---- medium runs (kShortRun < L < kLongRun): column-split over the run's own first waves --------
@@ -149,7 +166,7 @@ __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
 // and applies ALL occurrences of the run to its slice in order: one dword per lane = 256 contiguous
 // bytes per occurrence row.  Every occurrence index of such a run is already in the wave's window of
 // sorted positions (p-16 .. p+47), so the row loads are issued straight away, up to 32 in flight.
-template <int MODE, bool DUAL>
+template <int MODE, bool DUAL, bool SIG = false>
 __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
                                              const float *__restrict__ grads,
                                              int width, int col, int pv, int lane_s,
@@ -202,7 +219,10 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
     if (live) {
         if (MODE == kModePush)
             acc = __fadd_rn(dst_row[col], acc);
-        __builtin_nontemporal_store(acc, dst_row + col);
+        if (SIG)
+            st1_sc1(dst_row + col, acc);
+        else
+            __builtin_nontemporal_store(acc, dst_row + col);
         if (DUAL && d2.on)
             __builtin_nontemporal_store(acc2, d2.row + col);
     }
@@ -230,11 +250,11 @@ __device__ __forceinline__ float chain_step(float acc, float m) {
 
 // The worker part of a long run [s, s+len): this workgroup owns the 64-column slices j, j+workers, ...
 // All 16 waves call it (workgroup barriers inside); s_m = kCoopUnits x 64 floats of LDS.
-template <int MODE, bool DUAL>
+template <int MODE, bool DUAL, bool SIG = false>
 __device__ __forceinline__ void coop_slices(
     float *__restrict__ dst_row, bool init, Second d2, const float *__restrict__ grads,
     const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr, int s, int len,
-    int width, int j, int workers, int w, float *s_m) {
+    int width, int j, int workers, int w, float *s_m, uint32_t *pend_word = nullptr) {
     const int lane = lane_id();
     const int nslice = (width + kWave - 1) / kWave;
     const int my_slices = (nslice - j + workers - 1) / workers;  // slices j, j+workers, ...
@@ -334,22 +354,28 @@ __device__ __forceinline__ void coop_slices(
         if (clive) {
             if (MODE == kModePush)
                 acc = __fadd_rn(dst_row[ccol], acc);
-            __builtin_nontemporal_store(acc, dst_row + ccol);
+            if (SIG)
+                st1_sc1(dst_row + ccol, acc);
+            else
+                __builtin_nontemporal_store(acc, dst_row + ccol);
             if (DUAL && d2.on)
                 __builtin_nontemporal_store(acc2, d2.row + ccol);
         }
+        // this wave's slice of the row is complete: `len` occurrences x 1 slice (see signal_done)
+        if (SIG && chain && (j + (g0 + w) * workers) * kWave < width)
+            signal_done(pend_word, len);
     }
 }
 
 // Returns false when the run is shorter than kLongRun (the caller falls through to the per-wave
 // paths).  Called by all 16 waves of a full workgroup; wg0 = its first sorted position.
-template <int MODE, bool DUAL>
+template <int MODE, bool DUAL, bool SIG = false>
 __device__ __forceinline__ bool coop_run(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr, int wg0, int w, uint32_t key, uint32_t bk, uint32_t fk,
-    ApplyMaps maps, uint32_t *lds) {
+    ApplyMaps maps, uint32_t *lds, uint32_t *pend = nullptr) {
     const int lane = lane_id();
     float *s_m = reinterpret_cast<float *>(lds);
     int *s_cnt = reinterpret_cast<int *>(lds + kCoopUnits * kWave);
@@ -427,39 +453,40 @@ __device__ __forceinline__ bool coop_run(
         d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
     }
 
-    coop_slices<MODE, DUAL>(dst_row, init, d2, grads, perm, maps, n, lr, s, len, width, j, workers, w, s_m);
+    coop_slices<MODE, DUAL, SIG>(dst_row, init, d2, grads, perm, maps, n, lr, s, len, width, j, workers, w, s_m,
+                                 SIG ? pend + pend_slot(key) : nullptr);
     return true;
 }
 
 // One wave per sorted position p; `lds` = kApplyLdsBytes of workgroup memory (long runs only).
-template <int MODE, int VEC, bool DUAL>
+template <int MODE, int VEC, bool DUAL, bool SIG = false>
 __device__ __forceinline__ bool apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds);
+    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds, uint32_t *pend = nullptr);
 
 // `dbg` (tools/timeline.py only) receives {realtime start, realtime end, role/len, shader cycles}
 // per position.  The early return below is taken by whole waves of the LAST workgroup only, which is
 // never a full one, so the barriers of coop_run see all 16 waves.
 // Returns true when the wave did medium / long-run work (false: it left early or applied a short run).
-template <int MODE, int VEC, bool DUAL = false>
+template <int MODE, int VEC, bool DUAL = false, bool SIG = false>
 __device__ __forceinline__ bool apply_body(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr, int vblock, uint32_t *lds, unsigned long long *dbg = nullptr,
-    ApplyMaps maps = ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+    ApplyMaps maps = ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr}, uint32_t *pend = nullptr) {
     const int w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int p = vblock * kPosPerBlock + w;
     if (p >= n)
         return false;
     if (dbg == nullptr)
-        return apply_body_impl<MODE, VEC, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds);
+        return apply_body_impl<MODE, VEC, DUAL, SIG>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds, pend);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     int info = 0;
-    const bool heavy = apply_body_impl<MODE, VEC, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds);
+    const bool heavy = apply_body_impl<MODE, VEC, DUAL, SIG>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds, pend);
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -472,12 +499,12 @@ __device__ __forceinline__ bool apply_body(
     return heavy;
 }
 
-template <int MODE, int VEC, bool DUAL>
+template <int MODE, int VEC, bool DUAL, bool SIG>
 __device__ __forceinline__ bool apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds) {
+    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds, uint32_t *pend) {
     const int lane = lane_id();
     const int wg0 = p - w;
     // window of sorted positions p-16 .. p+47, plus -- speculatively, in the same round trip -- this
@@ -505,7 +532,7 @@ __device__ __forceinline__ bool apply_body_impl(
             return false;   // >= nslice full workgroups of this run precede: not a worker
         if (dbg_info)
             *dbg_info = (w << 16) | 0x7FFF;
-        if (coop_run<MODE, DUAL>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds))
+        if (coop_run<MODE, DUAL, SIG>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds, pend))
             return true;
     }
     const unsigned long long eq = __ballot(q >= 0 && q < n && ks == key);
@@ -547,14 +574,23 @@ __device__ __forceinline__ bool apply_body_impl(
         d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
     }
 
+    const int nslice = (width + kWave - 1) / kWave;
     if (len <= kShortRun) {
-        if (o == 0)
-            short_row<MODE, VEC, DUAL>(dst_row, grads, width, pv, kLookBack, len, lr, init, d2);
+        if (o == 0) {
+            short_row<MODE, VEC, DUAL, SIG>(dst_row, grads, width, pv, kLookBack, len, lr, init, d2);
+            if (SIG)   // the whole row: len occurrences x every slice
+                signal_done(pend + pend_slot(key), len * nslice);
+        }
         return false;
     }
     const int workers = min(len, kLookBack);
-    for (int c0 = o * kWave; c0 < width; c0 += workers * kWave)
-        medium_slice<MODE, DUAL>(dst_row, grads, width, c0 + lane, pv, kLookBack - o, len, lr, init, d2);
+    int mine = 0;
+    for (int c0 = o * kWave; c0 < width; c0 += workers * kWave) {
+        medium_slice<MODE, DUAL, SIG>(dst_row, grads, width, c0 + lane, pv, kLookBack - o, len, lr, init, d2);
+        ++mine;
+    }
+    if (SIG && mine > 0)
+        signal_done(pend + pend_slot(key), len * mine);
     return o < workers;
 }
 

@@ -1,0 +1,299 @@
+// ONE launch per training step: the backward of batch k beside the forward of batch k+1.
+//
+//   ha_sgd_push_pull_*  ==  ha_sgd_apply_finish(plan k, grads k)  then  ha_lookup_sort_*(ids k+1)
+//
+// which is the reference's embedding_push_pull (src/hetu_cache/src/cache.cc:356-422: push the
+// gradients of one batch and pull the rows of the next in one request) applied to the HBM-resident
+// table: table rows are updated in occurrence order exactly as cpu_SGDOptimizerSparseUpdate does
+// (src/dnnl_ops/Optimizers.cpp:51-74) and the lookup of batch k+1 returns the rows AFTER that update
+// (src/dnnl_ops/EmbeddingLookup.cpp:16-35 run behind it).  Results are bit-identical to the two
+// separate launches; what changes is the schedule: the two row streams (gradient + table rows of batch
+// k, table + output rows of batch k+1) overlap inside one grid and one dependent kernel boundary
+// (1.7-1.9 us between streaming kernels on MI355X) disappears per step.
+//
+// Grid = four roles selected by blockIdx, 1024-thread workgroups, in this order:
+//   [finish(k)] [apply(k)] [rank(k+1)] [gather(k+1)]
+// Roughly two thirds of the positions of a Criteo batch name a row that the previous batch also
+// updates, so the gather cannot simply run beside the apply.  Hand-off, per row:
+//   * every batch owns a pending table (2^16 words, hashed by key).  When batch k is sorted (rank role
+//     of the launch before), each occurrence of a key adds `nslice` units to its word;
+//   * an apply wave that has written s of the row's 64-column slices for a key with L occurrences
+//     stores them device-coherently (`sc1`, written through the XCD's L2), waits for the stores
+//     (s_waitcnt vmcnt(0)) and gives L*s units back with an agent-scope atomic (signal_done,
+//     scatter_dev.h).  The table returns to all-zero by itself at the end of the launch;
+//   * a gather wave polls the words of its keys with relaxed agent-scope loads and reads the rows with
+//     `sc1` loads only once they are 0 (a hash collision only makes it wait longer).
+// Apply workgroups have lower block numbers than gather workgroups and never wait themselves, so
+// every wave a gather wave waits for is resident or ahead of it in the dispatch order.  A poll loop
+// that exceeds kSpinMax gives up and raises plan_next's header flag (reserved[0]) instead of hanging.
+#include "plan_dev.h"
+#include "gather_dev.h"
+#include "scatter_dev.h"
+
+namespace ha {
+
+// fused.hip
+template <int MODE>
+int apply_finish_entry(float *dst, int64_t rows, int64_t width, void *plan_ws, int64_t n,
+                       const float *grads, float lr, hipStream_t stream);
+
+constexpr int kSpinMax = 1 << 18;   // polls of ~0.3 us each before a gather wave gives up (~0.1 s)
+
+struct StepArgs {
+    // table
+    float *table;
+    uint64_t rows;
+    int width;
+    // batch k: apply + finish
+    const uint32_t *sorted;
+    const int32_t *perm;
+    int n_cur;
+    const float *grads;
+    float lr;
+    PlanHeader *hdr;
+    uint32_t *uniq;
+    int32_t *seg, *counts, *inverse, *upos;
+    uint32_t *pend_cur;     // words of batch k (nullptr: nothing to wait for)
+    int nfin, napply;
+    // batch k+1: rank + gather
+    const void *next_ids;
+    int n_next;
+    float *out;
+    uint32_t *nkeys, *nsorted;
+    int32_t *nperm;
+    PlanHeader *nhdr;
+    uint32_t *pend_next;    // words batch k+1 registers in
+    int nrank;
+    int nv, nv_shift, group;  // vectors per row, log2(nv) or -1, positions per gather wave
+};
+
+// One wave copies `group` consecutive positions (group * nv <= 256 sixteen-byte vectors: four loads
+// per lane in flight, the same depth as gather_vec4_body), after the rows it needs have been released.
+template <typename IdT>
+__device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_index) {
+    const int lane = lane_id();
+    const int p0 = wave_index * a.group;
+    if (p0 >= a.n_next)
+        return;
+    const int cnt = min(a.group, a.n_next - p0);
+    const IdT *ids = static_cast<const IdT *>(a.next_ids);
+    uint32_t key = 0;
+    bool ok = false;
+    if (lane < cnt) {
+        const uint64_t r = id_to_row<IdT>(ids[p0 + lane]);
+        ok = r < a.rows;
+        key = ok ? static_cast<uint32_t>(r) : 0u;
+    }
+    if (a.pend_cur != nullptr) {
+        const uint32_t *word = a.pend_cur + pend_slot(key);
+        for (int spins = 0;; ++spins) {
+            uint32_t c = 0;
+            if (ok)
+                c = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(c != 0) == 0ull)
+                break;
+            if (spins >= kSpinMax) {
+                if (lane == 0)
+                    a.nhdr->reserved[0] = 1;   // hand-off timed out: the rows below may be stale
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    const int total = cnt * a.nv;
+    float *dst = a.out + static_cast<uint64_t>(p0) * static_cast<uint64_t>(a.nv) * 4u;
+    for (int base = 0; base < total; base += 4 * kWave) {
+        float4v v[4];
+        int e[4];
+        bool live[4], okv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            e[u] = base + u * kWave + lane;
+            live[u] = e[u] < total;
+            const int ec = live[u] ? e[u] : total - 1;
+            const int pos = a.nv_shift >= 0 ? (ec >> a.nv_shift) : (ec / a.nv);
+            const int col = ec - pos * a.nv;
+            const uint32_t k = static_cast<uint32_t>(__shfl(static_cast<int>(key), pos, kWave));
+            okv[u] = __shfl(static_cast<int>(ok), pos, kWave) != 0;
+            v[u] = ld4_sc1_async(a.table + (static_cast<uint64_t>(k) * static_cast<uint64_t>(a.nv) +
+                                            static_cast<uint64_t>(col)) * 4u);
+        }
+        wait_loads(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (live[u])
+                st4_nt(dst + static_cast<uint64_t>(e[u]) * 4u, okv[u] ? v[u] : float4v{0.f, 0.f, 0.f, 0.f});
+    }
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(1024, 8) void step_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    int b = blockIdx.x;
+    if (b < a.nfin) {
+        finish_block_body(a.sorted, a.perm, a.n_cur, a.hdr, a.uniq, a.seg, a.counts, a.inverse, a.upos, b,
+                          s_dyn);
+        return;
+    }
+    b -= a.nfin;
+    if (b < a.napply) {
+        apply_body<kModeSgd, 4, false, true>(a.table, a.rows, a.width, a.sorted, a.perm, nullptr, a.n_cur,
+                                             a.grads, a.lr, b, s_dyn, nullptr,
+                                             ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr}, a.pend_cur);
+        return;
+    }
+    b -= a.napply;
+    if (b < a.nrank) {
+        const IdT *ids = static_cast<const IdT *>(a.next_ids);
+        rank_tile_body<IdT>(ids, a.n_next, a.nkeys, a.nsorted, a.nperm, b, s_dyn);
+        // register the batch: every occurrence adds one unit per 64-column slice of its row
+        const int i = b * kRankTile + static_cast<int>(threadIdx.x);
+        if (threadIdx.x < kRankTile && i < a.n_next) {
+            const uint64_t r = id_to_row<IdT>(ids[i]);
+            if (r < a.rows)
+                __hip_atomic_fetch_add(a.pend_next + pend_slot(static_cast<uint32_t>(r)),
+                                       static_cast<uint32_t>((a.width + kWave - 1) / kWave), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (b == 0 && threadIdx.x == 0)
+            a.nhdr->reserved[0] = 0;
+        return;
+    }
+    b -= a.nrank;
+    gather_wait_body<IdT>(a, b * kPosPerBlock + static_cast<int>(threadIdx.x >> 6));
+}
+
+static bool step_fast(int64_t n, int64_t width) {
+    return n > 0 && n <= kSmallMax && width % 4 == 0 && width < (1 << 30);
+}
+
+template <typename IdT>
+static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                     const float *grads, float lr, void *pend_cur, const IdT *next_ids, int64_t n_next,
+                     float *next_out, void *plan_next, void *pend_next, hipStream_t stream,
+                     int (*lookup_sort_plain)(const float *, int64_t, int64_t, const IdT *, int64_t, float *,
+                                              void *, ha_stream_t)) {
+    HA_REQUIRE(rows >= 0 && rows < (1ll << 32) && width >= 1 && n_cur >= 0 && n_next >= 0,
+               "push_pull: bad sizes");
+    HA_REQUIRE(n_cur == 0 || (plan_cur && grads && table), "push_pull: null pointer (current batch)");
+    HA_REQUIRE(n_next == 0 || (plan_next && next_ids && next_out && table), "push_pull: null pointer (next batch)");
+    const bool fast_cur = step_fast(n_cur, width), fast_next = step_fast(n_next, width);
+    HA_REQUIRE(!(fast_cur && !pend_cur) && !(fast_next && !pend_next), "push_pull: null pending table");
+    if (fast_cur || fast_next)
+        HA_REQUIRE(reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
+                       (!fast_cur || reinterpret_cast<uintptr_t>(grads) % 16 == 0) &&
+                       (!fast_next || reinterpret_cast<uintptr_t>(next_out) % 16 == 0),
+                   "push_pull: table, grads and out must be 16-byte aligned");
+    // batches outside the single-launch regime run as the separate launches (their plans were never
+    // registered in a pending table, so nothing waits for them)
+    if (n_cur > 0 && !fast_cur) {
+        if (apply_finish_entry<kModeSgd>(table, rows, width, plan_cur, n_cur, grads, lr, stream))
+            return -1;
+    } else if (n_cur == 0 && plan_cur) {
+        if (ha_plan_finish(plan_cur, 0, stream))
+            return -1;
+    }
+    if (fast_cur || fast_next) {
+        StepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.table = table;
+        a.rows = static_cast<uint64_t>(rows);
+        a.width = static_cast<int>(width);
+        size_t lds = kFinishLdsWords * 4;
+        if (fast_cur) {
+            PlanPtrs p = plan_layout(plan_cur, n_cur);
+            a.sorted = p.sorted;
+            a.perm = p.perm;
+            a.n_cur = static_cast<int>(n_cur);
+            a.grads = grads;
+            a.lr = lr;
+            a.hdr = p.hdr;
+            a.uniq = p.uniq;
+            a.seg = p.seg;
+            a.counts = p.counts;
+            a.inverse = p.inverse;
+            a.upos = p.upos;
+            a.pend_cur = static_cast<uint32_t *>(pend_cur);
+            a.nfin = finish_blocks(a.n_cur);
+            a.napply = (a.n_cur + kPosPerBlock - 1) / kPosPerBlock;
+            lds = kApplyLdsBytes;
+        }
+        unsigned ngather = 0;
+        if (fast_next) {
+            PlanPtrs q = plan_layout(plan_next, n_next);
+            a.next_ids = next_ids;
+            a.n_next = static_cast<int>(n_next);
+            a.out = next_out;
+            a.nkeys = q.keys;
+            a.nsorted = q.sorted;
+            a.nperm = q.perm;
+            a.nhdr = q.hdr;
+            a.pend_next = static_cast<uint32_t *>(pend_next);
+            a.nrank = (a.n_next + kRankTile - 1) / kRankTile;
+            a.nv = static_cast<int>(width / 4);
+            a.nv_shift = -1;
+            for (int s = 0; s < 30; ++s)
+                if (a.nv == (1 << s))
+                    a.nv_shift = s;
+            a.group = a.nv >= 256 ? 1 : (256 / a.nv > kWave ? kWave : 256 / a.nv);
+            const int waves = (a.n_next + a.group - 1) / a.group;
+            ngather = static_cast<unsigned>((waves + kPosPerBlock - 1) / kPosPerBlock);
+            lds = lds > rank_small_lds_bytes(a.n_next) ? lds : rank_small_lds_bytes(a.n_next);
+        }
+        const unsigned blocks = static_cast<unsigned>(a.nfin + a.napply + a.nrank) + ngather;
+        HA_ALLOW_LDS((step_kernel<IdT>), lds);
+        hipLaunchKernelGGL((step_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
+        HA_LAUNCH_CHECK();
+    }
+    if (n_next > 0 && !fast_next)
+        return lookup_sort_plain(table, rows, width, next_ids, n_next, next_out, plan_next, stream);
+    return 0;
+}
+
+}  // namespace ha
+
+using namespace ha;
+
+extern "C" size_t ha_pend_bytes(void) {
+    return sizeof(uint32_t) << kPendBits;
+}
+
+extern "C" int64_t *ha_plan_handoff_timeout(void *plan_ws) {
+    return plan_ws ? &static_cast<PlanHeader *>(plan_ws)->reserved[0] : nullptr;
+}
+
+extern "C" int ha_pend_reset(void *pend, ha_stream_t stream) {
+    HA_REQUIRE(pend != nullptr, "ha_pend_reset: null pointer");
+    HA_CHECK_HIP(hipMemsetAsync(pend, 0, ha_pend_bytes(), as_stream(stream)));
+    return 0;
+}
+
+extern "C" int ha_sgd_push_pull_f32ids(float *table, int64_t rows, int64_t width, void *plan_cur,
+                                       int64_t n_cur, const float *grads, float lr, void *pend_cur,
+                                       const float *next_ids, int64_t n_next, float *next_out,
+                                       void *plan_next, void *pend_next, ha_stream_t stream) {
+    return push_pull<float>(table, rows, width, plan_cur, n_cur, grads, lr, pend_cur, next_ids, n_next,
+                            next_out, plan_next, pend_next, as_stream(stream), ha_lookup_sort_f32ids);
+}
+
+extern "C" int ha_sgd_push_pull_u64ids(float *table, int64_t rows, int64_t width, void *plan_cur,
+                                       int64_t n_cur, const float *grads, float lr, void *pend_cur,
+                                       const uint64_t *next_ids, int64_t n_next, float *next_out,
+                                       void *plan_next, void *pend_next, ha_stream_t stream) {
+    return push_pull<uint64_t>(table, rows, width, plan_cur, n_cur, grads, lr, pend_cur, next_ids, n_next,
+                               next_out, plan_next, pend_next, as_stream(stream), ha_lookup_sort_u64ids);
+}
+
+extern "C" int ha_lookup_sort_pend_f32ids(const float *table, int64_t rows, int64_t width, const float *ids,
+                                          int64_t n, float *out, void *plan_ws, void *pend,
+                                          ha_stream_t stream) {
+    return push_pull<float>(const_cast<float *>(table), rows, width, nullptr, 0, nullptr, 0.f, nullptr, ids, n,
+                            out, plan_ws, pend, as_stream(stream), ha_lookup_sort_f32ids);
+}
+
+extern "C" int ha_lookup_sort_pend_u64ids(const float *table, int64_t rows, int64_t width,
+                                          const uint64_t *ids, int64_t n, float *out, void *plan_ws,
+                                          void *pend, ha_stream_t stream) {
+    return push_pull<uint64_t>(const_cast<float *>(table), rows, width, nullptr, 0, nullptr, 0.f, nullptr, ids,
+                               n, out, plan_ws, pend, as_stream(stream), ha_lookup_sort_u64ids);
+}

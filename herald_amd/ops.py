@@ -160,6 +160,11 @@ class IndexPlan:
         """Host int (synchronises the current stream)."""
         return int(self._slice(self.view().n_unique, 1, torch.int64).item())
 
+    def handoff_timed_out(self):
+        """True if a hand-off wait of the sgd_push_pull launch that sorted this plan gave up (host sync)."""
+        addr = _lib.load().ha_plan_handoff_timeout(_ptr(self.ws))
+        return bool(self._slice(addr, 1, torch.int64).item())
+
     def n_unique_dev(self):
         return self._slice(self.view().n_unique, 1, torch.int64)
 
@@ -284,6 +289,79 @@ def sgd_apply_finish(table, plan, grads, lr, stream=None, next_ids=None):
                                           plan.n, _ptr(grads), ctypes.c_float(lr), _stream_ptr(stream)),
           "ha_sgd_apply_finish")
     return table
+
+
+# ---- one launch per training step: backward of batch k beside the forward of batch k+1 ---------------
+class PendingTable:
+    """Per-batch hand-off table of ha_sgd_push_pull_* (include/herald_amd.h): all-zero when idle; the
+    launch that sorts a batch registers its keys here, the launch that applies the batch drains it."""
+
+    def __init__(self, device=None):
+        L = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda")
+        self.buf = torch.zeros(L.ha_pend_bytes(), dtype=torch.uint8, device=self.device)
+
+    def reset(self, stream=None):
+        check(_lib.load().ha_pend_reset(_ptr(self.buf), _stream_ptr(stream)), "ha_pend_reset")
+        return self
+
+    def is_idle(self):
+        """Host check (synchronises): every registered unit was given back."""
+        return not bool(self.buf.view(torch.int32).any().item())
+
+
+def _ids_kind(ids):
+    if ids.dtype == torch.float32:
+        return "f32ids"
+    if ids.dtype in (torch.int64, torch.uint64):
+        return "u64ids"
+    raise TypeError("ids must be float32 or (u)int64")
+
+
+def lookup_sort_pend(table, ids, plan, pend, out=None, stream=None):
+    """lookup_sort that also registers the batch in `pend` (first batch of a push_pull sequence)."""
+    L = _lib.load()
+    _require(table, torch.float32, "table")
+    n = ids.numel()
+    width = table.shape[1]
+    if n > plan.capacity:
+        raise ValueError("plan capacity %d < %d ids" % (plan.capacity, n))
+    if out is None:
+        out = torch.empty(tuple(ids.shape) + (width,), dtype=torch.float32, device=table.device)
+    fn = getattr(L, "ha_lookup_sort_pend_" + _ids_kind(ids))
+    check(fn(_ptr(table), table.shape[0], width, _ptr(ids), n, _ptr(out), _ptr(plan.ws), _ptr(pend.buf),
+             _stream_ptr(stream)), "ha_lookup_sort_pend")
+    plan.n = n
+    plan._view = None
+    return out
+
+
+def sgd_push_pull(table, plan_cur, grads, lr, pend_cur, next_ids=None, plan_next=None, pend_next=None,
+                  next_out=None, stream=None):
+    """ONE launch: sgd_apply_finish(plan_cur, grads) and, behind it in effect, lookup_sort(next_ids) ->
+    (next_out, plan_next).  plan_cur must have been sorted by lookup_sort_pend / sgd_push_pull with
+    pend_cur as its pending table.  next_ids=None: the last batch (apply only).  Returns next_out."""
+    L = _lib.load()
+    _require(table, torch.float32, "table")
+    _require(grads, torch.float32, "grads")
+    width = table.shape[1]
+    if next_ids is None:
+        check(L.ha_sgd_push_pull_f32ids(_ptr(table), table.shape[0], width, _ptr(plan_cur.ws), plan_cur.n,
+                                        _ptr(grads), ctypes.c_float(lr), _ptr(pend_cur.buf), None, 0, None,
+                                        None, None, _stream_ptr(stream)), "ha_sgd_push_pull")
+        return None
+    n = next_ids.numel()
+    if n > plan_next.capacity:
+        raise ValueError("plan capacity %d < %d ids" % (plan_next.capacity, n))
+    if next_out is None:
+        next_out = torch.empty(tuple(next_ids.shape) + (width,), dtype=torch.float32, device=table.device)
+    fn = getattr(L, "ha_sgd_push_pull_" + _ids_kind(next_ids))
+    check(fn(_ptr(table), table.shape[0], width, _ptr(plan_cur.ws), plan_cur.n, _ptr(grads),
+             ctypes.c_float(lr), _ptr(pend_cur.buf), _ptr(next_ids), n, _ptr(next_out), _ptr(plan_next.ws),
+             _ptr(pend_next.buf), _stream_ptr(stream)), "ha_sgd_push_pull")
+    plan_next.n = n
+    plan_next._view = None
+    return next_out
 
 
 def push_apply_finish(table, plan, grads, stream=None):

@@ -284,6 +284,50 @@ int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
                          void *plan_ws, int64_t n, const float *grads,
                          ha_stream_t stream);
 
+/* ---- ONE launch per training step: backward of batch k beside the forward of batch k+1 -------------
+ * ha_sgd_push_pull_* == ha_sgd_apply_finish(plan_cur, grads) followed by ha_lookup_sort_*(next_ids ->
+ * next_out, plan_next), as ONE launch.  This is the reference's embedding_push_pull
+ * (src/hetu_cache/src/cache.cc:356-422, python/hetu/cstable.py: push the gradients of one batch and
+ * pull the rows of the next in one request) on the HBM-resident table; the rows returned for batch k+1
+ * are the rows AFTER batch k's update, and every result is bit-identical to the two separate launches
+ * (cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:51-74, then cpu_EmbeddingLookup,
+ * src/dnnl_ops/EmbeddingLookup.cpp:16-35).  The ids of the next batch are known one step ahead (the
+ * reference prefetches too: ParameterServerCommunicate.py:96-139, dataloader.py:63-98).
+ *
+ * Rows that both batches touch are handed from the applying wave to the gathering wave inside the
+ * launch through a per-batch PENDING TABLE (ha_pend_bytes() bytes of device memory, all-zero when
+ * idle: ha_pend_reset).  The launch that SORTS a batch registers its keys in that batch's table
+ * (ha_lookup_sort_pend_* for the first batch, ha_sgd_push_pull_* for every later one: pend_next); the
+ * launch that APPLIES the batch drains it (pend_cur) and leaves it all-zero again.  So a plan sorted
+ * with pending table P must be applied by ha_sgd_push_pull_* with pend_cur = P (n_next = 0 for the
+ * last batch), and two tables alternate between consecutive batches.
+ *   n_cur == 0: only the lookup + sort of the next batch (== ha_lookup_sort_pend_*);
+ *   n_next == 0: only the apply + finish of the current batch.
+ * table / grads / next_out must be 16-byte aligned.  Batches above the single-launch sort limit
+ * (36,864 ids) or with width % 4 != 0 run as the separate launches (nothing is registered for them).
+ * Should a hand-off wait ever exceed its bound (~0.1 s; never observed), word reserved[0] of
+ * plan_next's header is set to 1 (ha_plan_handoff_timeout) instead of hanging the device. */
+size_t ha_pend_bytes(void);
+int ha_pend_reset(void *pend, ha_stream_t stream);
+int ha_lookup_sort_pend_f32ids(const float *table, int64_t rows, int64_t width,
+                               const float *ids, int64_t n, float *out,
+                               void *plan_ws, void *pend, ha_stream_t stream);
+int ha_lookup_sort_pend_u64ids(const float *table, int64_t rows, int64_t width,
+                               const uint64_t *ids, int64_t n, float *out,
+                               void *plan_ws, void *pend, ha_stream_t stream);
+int ha_sgd_push_pull_f32ids(float *table, int64_t rows, int64_t width,
+                            void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                            void *pend_cur, const float *next_ids, int64_t n_next,
+                            float *next_out, void *plan_next, void *pend_next,
+                            ha_stream_t stream);
+int ha_sgd_push_pull_u64ids(float *table, int64_t rows, int64_t width,
+                            void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                            void *pend_cur, const uint64_t *next_ids, int64_t n_next,
+                            float *next_out, void *plan_next, void *pend_next,
+                            ha_stream_t stream);
+/* device address of the hand-off time-out flag (int64, 0 = fine) of a plan workspace */
+int64_t *ha_plan_handoff_timeout(void *plan_ws);
+
 /* ha_sgd_apply_finish that also warms the memory-side cache for the NEXT batch: waves that have no
  * medium / long-run work (more than half of them) end by touching the table row that position p of
  * next_ids will gather, so the ha_lookup_sort_* / ha_gather_* that follows reads it from the

@@ -1,0 +1,177 @@
+"""Full-scale addressing parity (BASELINE configs[1] as written): the real 33,762,577 x 512 fp32 table
+(69.1 GB) in HBM, filled on the device by a closed form of (row, column); Criteo-shaped batches whose
+float32 ids reach beyond 2^24 and whose rows lie beyond the 4 GiB and 64 GiB byte offsets go through
+the fused forward / backward launches and through the HET cache at limit 0.1 x rows.  Only the touched
+rows come back to the host; the oracle runs on a compact table of exactly those rows."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from herald_amd import cache as hcache
+from herald_amd import ops, synth
+from oracle import cache_model, cpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLD)
+import formula  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+ROWS, WIDTH, FIELDS, BATCH = 33762577, 512, 26, 256
+
+
+def _need_big_gpu(dev):
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 100 * (1 << 30):
+        pytest.skip("needs ~90 GB of free HBM")
+
+
+@pytest.fixture(scope="module")
+def big_table(dev):
+    """formula.table(ROWS, WIDTH) computed on the device (no host copy): same integer arithmetic, then
+    int -> float32 (exact below 2^24), one float32 multiply and one float32 subtract as separate ops."""
+    _need_big_gpu(dev)
+    t = torch.empty((ROWS, WIDTH), dtype=torch.float32, device=dev)
+    c = torch.arange(WIDTH, dtype=torch.int64, device=dev)[None, :] * 40503
+    step = 1 << 18
+    for s in range(0, ROWS, step):
+        e = min(ROWS, s + step)
+        r = torch.arange(s, e, dtype=torch.int64, device=dev)[:, None] * 2654435761
+        v = ((r + c) % 2000003).to(torch.float32)
+        v = v * np.float32(1e-4)
+        t[s:e] = v - np.float32(100.0)
+    torch.cuda.synchronize()
+    # spot check of the fill against the host formula, including the last row (offset 69.1 GB)
+    probe = [0, 1, 2097153, 16777217, 33554433, ROWS - 1]
+    got = t[torch.tensor(probe, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(got, formula.rows_of(probe, WIDTH))
+    yield t
+    del t
+    torch.cuda.empty_cache()
+
+
+def _batches(count, first=0):
+    out = []
+    for b in range(count):
+        f = synth.as_f32_ids(synth.criteo_batch(BATCH, step=first + b, rows=ROWS, nfields=FIELDS)).reshape(-1)
+        np.minimum(f, np.float32(ROWS - 1), out=f)
+        out.append(f)
+    return out
+
+
+# odd rows above 2^24 are not representable as float32 ids: no batch can touch them
+SENTINELS = [2097153, 4194305, 16777217, 20000001, 33554433, 33600001, ROWS - 2]
+
+
+def test_fused_step_on_the_full_table(dev, big_table):
+    table = big_table
+    batches = _batches(8)
+    keys_all = np.unique(np.concatenate([cpu.ids_to_keys(f) for f in batches]))
+    assert keys_all.max() > (1 << 24) and keys_all.max() * WIDTH * 4 > (64 << 30)
+    assert (keys_all * WIDTH * 4 > (4 << 30)).sum() > 1000
+    compact = formula.rows_of(keys_all, WIDTH)                  # the touched rows, as the oracle's table
+    lr = 0.01
+    plan = ops.IndexPlan(BATCH * FIELDS, dev)
+    rng = np.random.default_rng(11)
+    d_ids = [torch.from_numpy(f).to(dev) for f in batches]
+    for b, f in enumerate(batches):
+        grads = rng.standard_normal((f.size, WIDTH), dtype=np.float32)
+        cid = np.searchsorted(keys_all, cpu.ids_to_keys(f)).astype(np.float32)   # < 2^24: exact
+        want_out = cpu.embedding_lookup(compact, cid)
+        cpu.sgd_sparse_update(compact, cid, grads, lr)
+        out = ops.lookup_sort(table, d_ids[b], plan)
+        nxt = d_ids[b + 1] if b + 1 < len(batches) else None
+        ops.sgd_apply_finish(table, plan, torch.from_numpy(grads).to(dev), lr, next_ids=nxt)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), want_out, err_msg="gather, batch %d" % b)
+        u, inv, cnt = cpu.unique(cpu.ids_to_keys(f))
+        assert plan.n_unique() == u.size
+        np.testing.assert_array_equal((plan.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF), u.astype(np.int64))
+        np.testing.assert_array_equal(plan.counts().cpu().numpy().astype(np.int64), cnt)
+    got = table[torch.from_numpy(keys_all.astype(np.int64)).to(dev)].cpu().numpy()
+    np.testing.assert_array_equal(got, compact, err_msg="updated rows")
+    assert not np.array_equal(compact, formula.rows_of(keys_all, WIDTH))      # the updates were visible
+    sent = table[torch.tensor(SENTINELS, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(sent, formula.rows_of(SENTINELS, WIDTH), err_msg="untouched sentinel rows")
+    # put the touched rows back so that the next test starts from the closed form again
+    table[torch.from_numpy(keys_all.astype(np.int64)).to(dev)] = torch.from_numpy(
+        formula.rows_of(keys_all, WIDTH)).to(dev)
+    torch.cuda.synchronize()
+
+
+class _LazyRows:
+    """Server table of the cache model holding only the rows that were written; the rest is the closed form."""
+
+    def __init__(self, width):
+        self.width, self.rows = width, {}
+
+    def __getitem__(self, k):
+        k = int(k)
+        r = self.rows.get(k)
+        return r if r is not None else formula.rows_of([k], self.width)[0]
+
+    def __setitem__(self, k, v):
+        self.rows[int(k)] = np.asarray(v, dtype=np.float32)
+
+
+class _LazyVer(dict):
+    def __missing__(self, k):
+        return 0
+
+
+class _LazyServer(cache_model.Server):
+    def __init__(self, width):
+        self.table = _LazyRows(width)
+        self.ver = _LazyVer()
+
+
+@pytest.mark.parametrize("pull_bound,push_bound", [(2, 2)])
+def test_lru_cache_at_limit_0_1_on_the_full_table(dev, big_table, pull_bound, push_bound):
+    """configs[1]'s cache tier as written: LRU, limit = 0.1 x rows = 3,376,257 lines, length 33,762,577,
+    6,656 keys per batch; rows, perf counters and server versions every step, resident lines at the end."""
+    table = big_table
+    limit = int(0.1 * ROWS)
+    n = BATCH * FIELDS
+    server = _LazyServer(WIDTH)
+    model = cache_model.CacheModel("lru", limit, WIDTH, server, pull_bound, push_bound)
+    versions = torch.zeros(ROWS, dtype=torch.int64, device=dev)
+    gpu = hcache.LRUCache(limit, ROWS, WIDTH, node_id=0, max_batch=n, device=dev)
+    gpu.bind_store(table, versions)
+    gpu.pull_bound, gpu.push_bound = pull_bound, push_bound
+    gpu.perf_enabled = True
+    rng = np.random.default_rng(21)
+    batches = _batches(10, first=100)
+    for step, f in enumerate(batches):
+        want = model.lookup(cpu.ids_to_keys(f))
+        dest = torch.empty((n, WIDTH), dtype=torch.float32, device=dev)
+        gpu.embedding_lookup(torch.from_numpy(f).to(dev), dest).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % step)
+        grads = (rng.standard_normal((n, WIDTH), dtype=np.float32) * np.float32(-0.01))
+        model.update(cpu.ids_to_keys(f), grads)
+        gpu.embedding_update(torch.from_numpy(f).to(dev), torch.from_numpy(grads).to(dev)).wait()
+        for got, exp in zip(gpu.perf[-2:], model.perf[-2:]):
+            for fld in ("type", "num_all", "num_unique", "num_miss", "num_transfered", "is_full"):
+                assert got[fld] == exp[fld], (step, fld, got, exp)
+    touched = sorted(server.ver.keys())
+    tv = versions[torch.tensor(touched, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(tv, np.array([server.ver[k] for k in touched], dtype=np.int64))
+    assert int(versions.sum().item()) == sum(server.ver.values())          # nothing else was versioned
+    written = sorted(server.table.rows.keys())
+    if written:
+        got = table[torch.tensor(written, device=dev)].cpu().numpy()
+        np.testing.assert_array_equal(got, np.stack([server.table.rows[k] for k in written]),
+                                      err_msg="server rows after pushes")
+    res, lines = model.resident(), gpu.lines()
+    assert sorted(lines.keys()) == sorted(res.keys())
+    for k, ln in res.items():
+        g = lines[k]
+        assert g.version == ln.version and g.updates == ln.updates, k
+        np.testing.assert_array_equal(g.data, ln.data, err_msg="data of key %d" % k)
+        if ln.grad is not None:
+            np.testing.assert_array_equal(g.grad, ln.grad, err_msg="grad of key %d" % k)
+    sent = table[torch.tensor(SENTINELS, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(sent, formula.rows_of(SENTINELS, WIDTH))
+    assert gpu.size() == model.policy.size()
