@@ -46,6 +46,9 @@ def parse_args():
                    help="skip the secondary measurement of the LRU cache tier (limit 0.1 x rows)")
     p.add_argument("--graph-steps", type=int, default=32,
                    help="steps captured per hipGraph (1 = eager launches)")
+    p.add_argument("--launches", type=int, default=1, choices=(1, 2),
+                   help="launches per step: 1 = ha_sgd_push_pull (apply(k) beside lookup(k+1), default), "
+                        "2 = ha_lookup_sort + ha_sgd_apply_finish")
     p.add_argument("--grad-buffers", type=int, default=24,
                    help="distinct gradient / output buffers cycled through (24 x 13.6 MB = 327 MB > the "
                         "256 MiB Infinity Cache, so gradient reads and output writes are HBM traffic)")
@@ -233,21 +236,40 @@ def main():
     grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(nbuf)]
     outs = [torch.empty((n, args.width), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     nb = ids_dev.shape[0]
-    plan = ops.IndexPlan(n, dev)
     main_s = torch.cuda.Stream(device=dev)
+    one = args.launches == 1
+    if one:
+        # One step = ONE launch (ha_sgd_push_pull_f32ids): the backward of batch k (fused SGD apply + plan
+        # finish) beside the forward of batch k+1 (gather + stable sort), rows both batches touch handed
+        # over inside the launch.  Every step applies one batch and looks one batch up, as before; the
+        # lookup of the very first batch is the prologue below (untimed, like the table fill).
+        plans = [ops.IndexPlan(n, dev), ops.IndexPlan(n, dev)]
+        pends = [ops.PendingTable(dev), ops.PendingTable(dev)]
+        with torch.cuda.stream(main_s):
+            ops.lookup_sort_pend(table, ids_dev[0], plans[0], pends[0], out=outs[0], stream=main_s)
 
-    # One step = two launches on one stream:
-    #   forward : gather(ids) + stable sort of ids            (ha_lookup_sort_f32ids)
-    #   backward: fused SGD apply + plan finish (uniq/counts) (ha_sgd_apply_finish)
-    # The table dependency gather(k) -> apply(k) -> gather(k+1) is the stream order.
-    # The backward launch is handed the ids of the NEXT batch (resident one step ahead, as the reference's
-    # prefetching data loader provides them): its idle waves touch the rows the next lookup will gather.
-    # Batch b always uses gradient / output buffer b % nbuf, so a captured graph depends on b only.
-    def step(k):
-        b = k % nb
-        ops.lookup_sort(table, ids_dev[b], plan, out=outs[b % nbuf], stream=main_s)
-        ops.sgd_apply_finish(table, plan, grads[b % nbuf], LR, stream=main_s, next_ids=ids_dev[(b + 1) % nb])
+        def step(k):
+            b = k % nb
+            bn = (b + 1) % nb
+            ops.sgd_push_pull(table, plans[k % 2], grads[b % nbuf], LR, pends[k % 2], ids_dev[bn],
+                              plans[(k + 1) % 2], pends[(k + 1) % 2], next_out=outs[bn % nbuf], stream=main_s)
+    else:
+        plan = ops.IndexPlan(n, dev)
 
+        # One step = two launches on one stream:
+        #   forward : gather(ids) + stable sort of ids            (ha_lookup_sort_f32ids)
+        #   backward: fused SGD apply + plan finish (uniq/counts) (ha_sgd_apply_finish)
+        # The table dependency gather(k) -> apply(k) -> gather(k+1) is the stream order.
+        # The backward launch is handed the ids of the NEXT batch (resident one step ahead, as the
+        # reference's prefetching data loader provides them): its idle waves touch the rows the next
+        # lookup will gather.
+        def step(k):
+            b = k % nb
+            ops.lookup_sort(table, ids_dev[b], plan, out=outs[b % nbuf], stream=main_s)
+            ops.sgd_apply_finish(table, plan, grads[b % nbuf], LR, stream=main_s, next_ids=ids_dev[(b + 1) % nb])
+
+    # Batch b always uses gradient / output buffer b % nbuf, so a captured graph depends on b only
+    # (nb is even, so the plan / pending-table parity of step k is that of batch k % nb as well).
     use_graph = G > 1
     graphs = {}
 
@@ -315,7 +337,20 @@ def main():
     # to the next launch included)
     kernels = {}
     roofline = None
-    if not args.no_kernel_pass:
+    if one:
+        # the step IS one launch of ha::step_kernel: its average duration is the HIP-event time of the
+        # timed region / K, measured on the launch stream
+        traffic, traffic_src = pmc_traffic("ha::step_kernel")
+        dom_bytes = fwd_b + bwd_b
+        ach = dom_bytes / (dev_ms / args.steps * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "ha::step_kernel (SGD apply + finish of batch k, gather + sort of batch k+1)",
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_us": dev_ms / args.steps * 1e3,
+                    "avg_launch_source": "HIP events around the timed region on the launch stream / steps "
+                                         "(one launch per step)",
+                    "algorithmic_bytes_per_launch": dom_bytes}
+    elif not args.no_kernel_pass:
         KL = 64
         kplans = [ops.IndexPlan(n, dev).sort(ids_dev[(wu + i) % nb], stream=main_s) for i in range(KL)]
         main_s.synchronize()
@@ -373,12 +408,14 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "wdl_criteo bs=%d d=%d, %d fields, full %d-row fp32 table in HBM (%.1f GB), "
-                               "gather + dedup plan + fused SGD scatter-apply per step; the LRU "
+                               "gather + dedup plan + fused SGD scatter-apply per step (%s); the LRU "
                                "cache-limit-0.1 tier is not part of this line"
                                % (args.batch, args.width, args.fields, args.rows,
-                                  args.rows * args.width * 4 / 1e9),
+                                  args.rows * args.width * 4 / 1e9,
+                                  "one launch: apply(k) beside lookup(k+1)" if one else "two launches"),
                    "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,
                    "grad_and_out_buffers": nbuf,
+                   "launches_per_step": args.launches,
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
                              else "eager",
                    "parallelism": "1 GPU"},
@@ -388,6 +425,9 @@ def main():
         "host_bound": bool(t_enq * 1e3 > dev_ms),
         "roofline": roofline, "kernels": kernels,
     }
+    if one:
+        torch.cuda.synchronize()
+        result["handoff_timeouts"] = int(plans[0].handoff_timed_out()) + int(plans[1].handoff_timed_out())
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ids_host)
     if not args.no_cache_tier:

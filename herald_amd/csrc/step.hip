@@ -155,8 +155,6 @@ __global__ __launch_bounds__(1024, 8) void step_kernel(const StepArgs a) {
                                        static_cast<uint32_t>((a.width + kWave - 1) / kWave), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (b == 0 && threadIdx.x == 0)
-            a.nhdr->reserved[0] = 0;
         return;
     }
     b -= a.nrank;
@@ -241,7 +239,11 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
             lds = lds > rank_small_lds_bytes(a.n_next) ? lds : rank_small_lds_bytes(a.n_next);
         }
         const unsigned blocks = static_cast<unsigned>(a.nfin + a.napply + a.nrank) + ngather;
-        HA_ALLOW_LDS((step_kernel<IdT>), lds);
+        static bool lds_allowed = false;   // once, and outside any stream capture (the first call is eager)
+        if (!lds_allowed) {
+            HA_ALLOW_LDS((step_kernel<IdT>), 160 * 1024);
+            lds_allowed = true;
+        }
         hipLaunchKernelGGL((step_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
         HA_LAUNCH_CHECK();
     }

@@ -108,6 +108,8 @@ class IndexPlan:
         self.device = torch.device(device if device is not None else "cuda")
         self.nbytes = L.ha_plan_bytes(self.capacity)
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.ws[:256].zero_()      # the header: n_unique and the (sticky) hand-off time-out flag
+        torch.cuda.current_stream(self.device).synchronize()   # users launch on streams of their own
         self.n = 0
         self._view = None
         self._route_cache = None
@@ -300,6 +302,9 @@ class PendingTable:
         L = _lib.load()
         self.device = torch.device(device if device is not None else "cuda")
         self.buf = torch.zeros(L.ha_pend_bytes(), dtype=torch.uint8, device=self.device)
+        # the zero fill ran on torch's current stream; launches that register keys here come on streams
+        # of the caller's choice, so it must have landed before the constructor returns
+        torch.cuda.current_stream(self.device).synchronize()
 
     def reset(self, stream=None):
         check(_lib.load().ha_pend_reset(_ptr(self.buf), _stream_ptr(stream)), "ha_pend_reset")
