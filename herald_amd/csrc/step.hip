@@ -63,14 +63,18 @@ struct StepArgs {
     int32_t *nperm;
     PlanHeader *nhdr;
     uint32_t *pend_next;    // words batch k+1 registers in
-    int nrank;
+    int nrank, ngather;
     int nv, nv_shift, group;  // vectors per row, log2(nv) or -1, positions per gather wave
+    unsigned long long *dbg;  // tools/step_timeline.py only: {start, after-wait, end, role | xcc << 8} per wave
 };
 
 // One wave copies `group` consecutive positions (group * nv <= 256 sixteen-byte vectors: four loads
 // per lane in flight, the same depth as gather_vec4_body), after the rows it needs have been released.
+// (Copying the released positions of a wave first and the others as they follow was measured: no gain,
+// the extra polls cost what the earlier copies save.)
 template <typename IdT>
-__device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_index) {
+__device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_index,
+                                                 unsigned long long *t_mid = nullptr) {
     const int lane = lane_id();
     const int p0 = wave_index * a.group;
     if (p0 >= a.n_next)
@@ -100,17 +104,17 @@ __device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_ind
             __builtin_amdgcn_s_sleep(4);
         }
     }
+    if (t_mid)
+        *t_mid = __builtin_amdgcn_s_memrealtime();
     const int total = cnt * a.nv;
     float *dst = a.out + static_cast<uint64_t>(p0) * static_cast<uint64_t>(a.nv) * 4u;
     for (int base = 0; base < total; base += 4 * kWave) {
         float4v v[4];
-        int e[4];
-        bool live[4], okv[4];
+        bool okv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            e[u] = base + u * kWave + lane;
-            live[u] = e[u] < total;
-            const int ec = live[u] ? e[u] : total - 1;
+            const int e = base + u * kWave + lane;
+            const int ec = e < total ? e : total - 1;
             const int pos = a.nv_shift >= 0 ? (ec >> a.nv_shift) : (ec / a.nv);
             const int col = ec - pos * a.nv;
             const uint32_t k = static_cast<uint32_t>(__shfl(static_cast<int>(key), pos, kWave));
@@ -120,27 +124,30 @@ __device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_ind
         }
         wait_loads(v[0], v[1], v[2], v[3]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (live[u])
-                st4_nt(dst + static_cast<uint64_t>(e[u]) * 4u, okv[u] ? v[u] : float4v{0.f, 0.f, 0.f, 0.f});
+        for (int u = 0; u < 4; ++u) {
+            const int e = base + u * kWave + lane;
+            if (e < total)
+                st4_nt(dst + static_cast<uint64_t>(e) * 4u, okv[u] ? v[u] : float4v{0.f, 0.f, 0.f, 0.f});
+        }
     }
 }
 
+// Block order: finish | apply | rank | gather.  Apply workgroups never wait and come before every gather
+// workgroup, so whatever a gather wave waits for is resident or ahead of it in the dispatch order.
+// (apply | gather | rank | finish and an alternating gather / rank order were measured: slower.)
 template <typename IdT>
-__global__ __launch_bounds__(1024, 8) void step_kernel(const StepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+__device__ __forceinline__ int step_roles(const StepArgs &a, uint32_t *s_dyn, unsigned long long *t_mid) {
     int b = blockIdx.x;
     if (b < a.nfin) {
-        finish_block_body(a.sorted, a.perm, a.n_cur, a.hdr, a.uniq, a.seg, a.counts, a.inverse, a.upos, b,
-                          s_dyn);
-        return;
+        finish_block_body(a.sorted, a.perm, a.n_cur, a.hdr, a.uniq, a.seg, a.counts, a.inverse, a.upos, b, s_dyn);
+        return 0;
     }
     b -= a.nfin;
     if (b < a.napply) {
         apply_body<kModeSgd, 4, false, true>(a.table, a.rows, a.width, a.sorted, a.perm, nullptr, a.n_cur,
                                              a.grads, a.lr, b, s_dyn, nullptr,
                                              ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr}, a.pend_cur);
-        return;
+        return 1;
     }
     b -= a.napply;
     if (b < a.nrank) {
@@ -155,14 +162,45 @@ __global__ __launch_bounds__(1024, 8) void step_kernel(const StepArgs a) {
                                        static_cast<uint32_t>((a.width + kWave - 1) / kWave), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         }
-        return;
+        return 2;
     }
     b -= a.nrank;
-    gather_wait_body<IdT>(a, b * kPosPerBlock + static_cast<int>(threadIdx.x >> 6));
+    gather_wait_body<IdT>(a, b * kPosPerBlock + static_cast<int>(threadIdx.x >> 6), t_mid);
+    return 3;
 }
 
-static bool step_fast(int64_t n, int64_t width) {
-    return n > 0 && n <= kSmallMax && width % 4 == 0 && width < (1 << 30);
+template <typename IdT>
+__global__ __launch_bounds__(1024, 8) void step_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    step_roles<IdT>(a, s_dyn, nullptr);
+}
+
+// the same grid with per-wave time stamps (development aid, tools/step_timeline.py)
+template <typename IdT>
+__global__ __launch_bounds__(1024, 8) void step_timeline_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tm = 0;
+    const int role = step_roles<IdT>(a, s_dyn, &tm);
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (lane_id() == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *d = a.dbg + (static_cast<size_t>(blockIdx.x) * 16 + (threadIdx.x >> 6)) * 4;
+        d[0] = t0;
+        d[1] = tm;
+        d[2] = t1;
+        d[3] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8);
+    }
+}
+
+// The in-launch hand-off needs every 128-byte line of the table to belong to ONE row (a line is written
+// whole by one store instruction and is never in a reader's L2 before its last write of the launch):
+// rows of a multiple of 32 floats in a 128-byte aligned table.  Everything else takes the separate launches.
+static bool step_fast(int64_t n, int64_t width, const void *table) {
+    return n > 0 && n <= kSmallMax && width % 32 == 0 && width < (1 << 30) &&
+           reinterpret_cast<uintptr_t>(table) % 128 == 0;
 }
 
 template <typename IdT>
@@ -170,18 +208,18 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
                      const float *grads, float lr, void *pend_cur, const IdT *next_ids, int64_t n_next,
                      float *next_out, void *plan_next, void *pend_next, hipStream_t stream,
                      int (*lookup_sort_plain)(const float *, int64_t, int64_t, const IdT *, int64_t, float *,
-                                              void *, ha_stream_t)) {
+                                              void *, ha_stream_t),
+                     unsigned long long *dbg = nullptr) {
     HA_REQUIRE(rows >= 0 && rows < (1ll << 32) && width >= 1 && n_cur >= 0 && n_next >= 0,
                "push_pull: bad sizes");
     HA_REQUIRE(n_cur == 0 || (plan_cur && grads && table), "push_pull: null pointer (current batch)");
     HA_REQUIRE(n_next == 0 || (plan_next && next_ids && next_out && table), "push_pull: null pointer (next batch)");
-    const bool fast_cur = step_fast(n_cur, width), fast_next = step_fast(n_next, width);
+    const bool fast_cur = step_fast(n_cur, width, table), fast_next = step_fast(n_next, width, table);
     HA_REQUIRE(!(fast_cur && !pend_cur) && !(fast_next && !pend_next), "push_pull: null pending table");
     if (fast_cur || fast_next)
-        HA_REQUIRE(reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
-                       (!fast_cur || reinterpret_cast<uintptr_t>(grads) % 16 == 0) &&
+        HA_REQUIRE((!fast_cur || reinterpret_cast<uintptr_t>(grads) % 16 == 0) &&
                        (!fast_next || reinterpret_cast<uintptr_t>(next_out) % 16 == 0),
-                   "push_pull: table, grads and out must be 16-byte aligned");
+                   "push_pull: grads and out must be 16-byte aligned");
     // batches outside the single-launch regime run as the separate launches (their plans were never
     // registered in a pending table, so nothing waits for them)
     if (n_cur > 0 && !fast_cur) {
@@ -216,7 +254,6 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
             a.napply = (a.n_cur + kPosPerBlock - 1) / kPosPerBlock;
             lds = kApplyLdsBytes;
         }
-        unsigned ngather = 0;
         if (fast_next) {
             PlanPtrs q = plan_layout(plan_next, n_next);
             a.next_ids = next_ids;
@@ -235,16 +272,22 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
                     a.nv_shift = s;
             a.group = a.nv >= 256 ? 1 : (256 / a.nv > kWave ? kWave : 256 / a.nv);
             const int waves = (a.n_next + a.group - 1) / a.group;
-            ngather = static_cast<unsigned>((waves + kPosPerBlock - 1) / kPosPerBlock);
+            a.ngather = (waves + kPosPerBlock - 1) / kPosPerBlock;
             lds = lds > rank_small_lds_bytes(a.n_next) ? lds : rank_small_lds_bytes(a.n_next);
         }
-        const unsigned blocks = static_cast<unsigned>(a.nfin + a.napply + a.nrank) + ngather;
+        const unsigned blocks = static_cast<unsigned>(a.nfin + a.napply + a.nrank + a.ngather);
         static bool lds_allowed = false;   // once, and outside any stream capture (the first call is eager)
         if (!lds_allowed) {
             HA_ALLOW_LDS((step_kernel<IdT>), 160 * 1024);
             lds_allowed = true;
         }
-        hipLaunchKernelGGL((step_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
+        if (dbg) {
+            a.dbg = dbg;
+            HA_ALLOW_LDS((step_timeline_kernel<IdT>), 160 * 1024);
+            hipLaunchKernelGGL((step_timeline_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
+        } else {
+            hipLaunchKernelGGL((step_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
+        }
         HA_LAUNCH_CHECK();
     }
     if (n_next > 0 && !fast_next)
@@ -276,6 +319,17 @@ extern "C" int ha_sgd_push_pull_f32ids(float *table, int64_t rows, int64_t width
                                        void *plan_next, void *pend_next, ha_stream_t stream) {
     return push_pull<float>(table, rows, width, plan_cur, n_cur, grads, lr, pend_cur, next_ids, n_next,
                             next_out, plan_next, pend_next, as_stream(stream), ha_lookup_sort_f32ids);
+}
+
+// development aid: ha_sgd_push_pull_f32ids with per-wave time stamps; dbg = uint64[blocks * 16 * 4]
+extern "C" int ha_debug_step_timeline(float *table, int64_t rows, int64_t width, void *plan_cur,
+                                      int64_t n_cur, const float *grads, float lr, void *pend_cur,
+                                      const float *next_ids, int64_t n_next, float *next_out,
+                                      void *plan_next, void *pend_next, unsigned long long *dbg,
+                                      ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "step timeline: null debug buffer");
+    return push_pull<float>(table, rows, width, plan_cur, n_cur, grads, lr, pend_cur, next_ids, n_next,
+                            next_out, plan_next, pend_next, as_stream(stream), ha_lookup_sort_f32ids, dbg);
 }
 
 extern "C" int ha_sgd_push_pull_u64ids(float *table, int64_t rows, int64_t width, void *plan_cur,

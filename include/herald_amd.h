@@ -303,8 +303,9 @@ int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
  * last batch), and two tables alternate between consecutive batches.
  *   n_cur == 0: only the lookup + sort of the next batch (== ha_lookup_sort_pend_*);
  *   n_next == 0: only the apply + finish of the current batch.
- * table / grads / next_out must be 16-byte aligned.  Batches above the single-launch sort limit
- * (36,864 ids) or with width % 4 != 0 run as the separate launches (nothing is registered for them).
+ * grads / next_out must be 16-byte aligned.  The single launch needs rows that own their 128-byte lines
+ * (width % 32 == 0, table 128-byte aligned) and batches up to the single-launch sort limit (36,864 ids);
+ * anything else runs as the separate launches with the same results (nothing is registered then).
  * Should a hand-off wait ever exceed its bound (~0.1 s; never observed), word reserved[0] of
  * plan_next's header is set to 1 (ha_plan_handoff_timeout) instead of hanging the device. */
 size_t ha_pend_bytes(void);
@@ -325,6 +326,13 @@ int ha_sgd_push_pull_u64ids(float *table, int64_t rows, int64_t width,
                             void *pend_cur, const uint64_t *next_ids, int64_t n_next,
                             float *next_out, void *plan_next, void *pend_next,
                             ha_stream_t stream);
+/* development aid (tools/step_timeline.py): ha_sgd_push_pull_f32ids with per-wave time stamps,
+ * dbg = device uint64[(number of workgroups) * 16 * 4] */
+int ha_debug_step_timeline(float *table, int64_t rows, int64_t width,
+                           void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                           void *pend_cur, const float *next_ids, int64_t n_next,
+                           float *next_out, void *plan_next, void *pend_next,
+                           unsigned long long *dbg, ha_stream_t stream);
 /* device address of the hand-off time-out flag (int64, 0 = fine) of a plan workspace */
 int64_t *ha_plan_handoff_timeout(void *plan_ws);
 

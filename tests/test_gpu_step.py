@@ -56,7 +56,7 @@ def _run_sequence(dev, table0, batches, grads, lr, ids_dtype=np.float32, check_p
     assert pends[0].is_idle() and pends[1].is_idle(), "pending tables must drain to zero"
 
 
-@pytest.mark.parametrize("width", [4, 16, 64, 128, 200, 512, 1024, 2048])
+@pytest.mark.parametrize("width", [4, 16, 32, 64, 96, 128, 200, 512, 1024, 2048])
 @pytest.mark.parametrize("rows,n", [(40, 700), (5000, 6656), (300, 63), (7, 1)])
 def test_push_pull_sequence_bit_exact(dev, width, rows, n):
     """Small tables: almost every row of batch k+1 is updated by batch k (every path of the hand-off:
@@ -68,6 +68,33 @@ def test_push_pull_sequence_bit_exact(dev, width, rows, n):
                for k in range(steps)]
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
     _run_sequence(dev, table0, batches, grads, 0.05)
+
+
+def test_push_pull_unaligned_table_takes_the_separate_launches(dev):
+    """A table that does not start on a 128-byte line cannot use the in-launch hand-off: same results."""
+    rng = np.random.default_rng(12)
+    rows, width, n = 500, 64, 2000
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    flat = torch.empty(rows * width + 4, dtype=torch.float32, device=dev)
+    table = flat[4:].view(rows, width)
+    assert table.data_ptr() % 128 != 0
+    table.copy_(torch.from_numpy(table0))
+    want = table0.copy()
+    ids = [rng.integers(0, rows, size=n).astype(np.float32) for _ in range(3)]
+    g = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(3)]
+    plans = [ops.IndexPlan(n, dev), ops.IndexPlan(n, dev)]
+    pends = [ops.PendingTable(dev), ops.PendingTable(dev)]
+    out = ops.lookup_sort_pend(table, _dev(ids[0], dev), plans[0], pends[0])
+    for k in range(3):
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), cpu.embedding_lookup(want, ids[k]))
+        cpu.sgd_sparse_update(want, ids[k], g[k], 0.1)
+        nxt = _dev(ids[k + 1], dev) if k < 2 else None
+        out = ops.sgd_push_pull(table, plans[k % 2], _dev(g[k], dev), 0.1, pends[k % 2], nxt,
+                                plans[(k + 1) % 2] if k < 2 else None, pends[(k + 1) % 2] if k < 2 else None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(table.cpu().numpy(), want)
+    assert pends[0].is_idle() and pends[1].is_idle()
 
 
 def test_push_pull_criteo_stream(dev):
