@@ -190,6 +190,11 @@ def _declare(L):
         "AdaGradOptimizerSparseUpdate": [A, A, A, A, f32, f32, S],
         "AdamOptimizerSparseUpdate": [A, A, A, A, A, f32, f32, f32, f32, f32, f32, S],
         "AdamWOptimizerSparseUpdate": [A, A, A, A, A, f32, f32, f32, f32, f32, f32, f32, S],
+        "AddL2RegularizationSparse": [A, A, A, f32, S],
+        "MomentumOptimizerSparseUpdate": [A, A, A, A, f32, f32, c.c_bool, S],
+        "LambOptimizerSparseUpdate": [A, A, A, A, A, f32, f32, f32, f32, f32, f32, f32, S],
+        "cpu_EmbeddingLookup": [A, A, A],
+        "cpu_SGDOptimizerSparseUpdate": [A, A, A, f32],
     }
     for name, args in dl.items():
         fn = getattr(L, name)

@@ -34,7 +34,7 @@ struct Scratch {
 static std::mutex g_scratch_mu;
 static std::unordered_map<uint64_t, Scratch> g_scratch;
 
-static int scratch_get(hipStream_t stream, size_t bytes, void **out) {
+int scratch_get(hipStream_t stream, size_t bytes, void **out) {
     int dev = 0;
     HA_CHECK_HIP(hipGetDevice(&dev));
     const uint64_t key = (static_cast<uint64_t>(dev) << 56) ^
@@ -238,6 +238,41 @@ extern "C" int SGDOptimizerSparseUpdate(DLArrayHandle param,
         static_cast<const float *>(grad_indices->data), n,
         static_cast<const float *>(grad_values->data), lr,
         dl_stream(stream_handle));
+}
+
+// ---- the reference's CPU operator names (src/common/c_runtime_api.h:811-818) -------------------------
+// python/hetu/_base.py:8-11,72 feature-probes these two symbols with hasattr and, when present, routes
+// EmbeddingLookUp.compute / SGDOptimizer.update of host-context nodes to them (EmbeddingLookUp.py:16-28,
+// optimizer.py:204-214).  This library is the GPU engine: arrays whose context is the GPU are served by
+// the HIP kernels (on the null stream, complete on return, as a host operator is); host arrays are
+// refused with an error -- there is no CPU fallback in the product (the reference's own dnnl_ops remain
+// the CPU implementation).
+static int same_device(const DLArray *a, const DLArray *b, const DLArray *c, const char *name) {
+    HA_REQUIRE(a && b && c && a->data && b->data && c->data, "%s: null array", name);
+    HA_REQUIRE(a->ctx.device_type == kGPU && b->ctx.device_type == kGPU && c->ctx.device_type == kGPU,
+               "%s: host arrays are not served by herald_amd (GPU engine, no CPU fallback); "
+               "device_type = %d/%d/%d", name, (int)a->ctx.device_type, (int)b->ctx.device_type,
+               (int)c->ctx.device_type);
+    return 0;
+}
+
+extern "C" int cpu_EmbeddingLookup(const DLArrayHandle in_mat, const DLArrayHandle ids, DLArrayHandle out_mat) {
+    if (same_device(in_mat, ids, out_mat, "cpu_EmbeddingLookup"))
+        return -1;
+    if (DLGpuEmbeddingLookUp(in_mat, ids, out_mat, nullptr))
+        return -1;
+    HA_CHECK_HIP(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+extern "C" int cpu_SGDOptimizerSparseUpdate(DLArrayHandle param, const DLArrayHandle grad_indices,
+                                            const DLArrayHandle grad_values, float lr) {
+    if (same_device(param, grad_indices, grad_values, "cpu_SGDOptimizerSparseUpdate"))
+        return -1;
+    if (SGDOptimizerSparseUpdate(param, grad_indices, grad_values, lr, nullptr))
+        return -1;
+    HA_CHECK_HIP(hipStreamSynchronize(nullptr));
+    return 0;
 }
 
 extern "C" int ha_sgd_sparse_update_f32ids(float *table, int64_t rows,

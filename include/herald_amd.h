@@ -131,6 +131,39 @@ int AdamWOptimizerSparseUpdate(DLArrayHandle param,
                                float beta1t, float beta2t, float eps,
                                float weight_decay,
                                DLStreamHandle stream_handle);
+/* src/common/c_runtime_api.h:639-643 / src/ops/OptimizersSparse.cu:3-51:
+ * grad_values[i,:] += l2reg * param[grad_indices[i],:]  (deduplicated slices, OptimizerLink.py:15-20) */
+int AddL2RegularizationSparse(const DLArrayHandle param,
+                              const DLArrayHandle grad_indices,
+                              DLArrayHandle grad_values, float l2reg,
+                              DLStreamHandle stream_handle);
+/* src/common/c_runtime_api.h:653-656 / src/ops/OptimizersSparse.cu:101-231: indices may repeat
+ * (OptimizerLink.py:37-49 does not deduplicate).  velocity[id,:] += -lr*g per occurrence (Nesterov: the
+ * parameter row too), in occurrence order instead of the reference's atomics; then the reference's DENSE
+ * second phase over the whole array: param += velocity, velocity *= momentum (Nesterov: velocity *=
+ * momentum first, then param += velocity). */
+int MomentumOptimizerSparseUpdate(DLArrayHandle param,
+                                  const DLArrayHandle grad_indices,
+                                  const DLArrayHandle grad_values,
+                                  DLArrayHandle velocity, float lr,
+                                  float momentum, bool nesterov,
+                                  DLStreamHandle stream_handle);
+/* src/common/c_runtime_api.h:693-699 / src/ops/OptimizersSparse.cu:524-722 (deduplicated slices) */
+int LambOptimizerSparseUpdate(DLArrayHandle param,
+                              const DLArrayHandle grad_indices,
+                              const DLArrayHandle grad_values,
+                              DLArrayHandle expavg, DLArrayHandle expavgsq,
+                              float lr, float beta1, float beta2, float beta1t,
+                              float beta2t, float eps, float weight_decay,
+                              DLStreamHandle stream_handle);
+/* src/common/c_runtime_api.h:811-818, the reference's CPU operator names that python/hetu/_base.py:8-11,72
+ * feature-probes.  Served by the HIP kernels for arrays whose DLContext is the GPU (null stream,
+ * complete on return); host arrays are refused (-1, ha_last_error) -- the product has no CPU path. */
+int cpu_EmbeddingLookup(const DLArrayHandle in_mat, const DLArrayHandle ids,
+                        DLArrayHandle out_mat);
+int cpu_SGDOptimizerSparseUpdate(DLArrayHandle param,
+                                 const DLArrayHandle grad_indices,
+                                 const DLArrayHandle grad_values, float lr);
 
 /* ========================================================================= *
  * (2) Plain-pointer engine entry points.  All pointers are DEVICE pointers

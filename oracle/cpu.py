@@ -180,3 +180,48 @@ def adam_sparse(param, m, v, ids, grads, lr, beta1, beta2, beta1t, beta2t, eps, 
     else:
         upd = (cm / (np.sqrt(cv, dtype=f) + f(eps))).astype(f)
         param[idx] = (param[idx] - f(lr) * (upd + f(weight_decay) * param[idx])).astype(f)
+
+
+def l2_sparse(param, ids, grads, l2reg):
+    """add_l2_regularization_sparse, OptimizersSparse.cu:3-18 (ids unique): grads += l2reg * param[ids]."""
+    f = np.float32
+    idx = np.asarray(ids).astype(np.int64)
+    return (np.asarray(grads, dtype=f) + f(l2reg) * param[idx]).astype(f)
+
+
+def momentum_sparse(param, veloc, ids, grads, lr, momentum, nesterov):
+    """MomentumOptimizerSparseUpdate, OptimizersSparse.cu:101-231: ids may repeat; first phase
+    velocity[id] += -lr*g per occurrence (Nesterov: param[id] too), here in occurrence order (the
+    reference's float atomics pick an arbitrary one); second phase DENSE over the whole arrays.  In place."""
+    f = np.float32
+    idx = np.asarray(ids).astype(np.int64).reshape(-1)
+    g = np.asarray(grads, dtype=f).reshape(idx.size, -1)
+    for i, r in enumerate(idx):
+        t = (-f(lr) * g[i]).astype(f)
+        veloc[r] = (veloc[r] + t).astype(f)
+        if nesterov:
+            param[r] = (param[r] + t).astype(f)
+    if nesterov:
+        veloc[...] = (f(momentum) * veloc).astype(f)
+        param[...] = (param + veloc).astype(f)
+    else:
+        param[...] = (param + veloc).astype(f)
+        veloc[...] = (f(momentum) * veloc).astype(f)
+
+
+def lamb_sparse(param, m, v, ids, grads, lr, beta1, beta2, beta1t, beta2t, eps, weight_decay):
+    """LambOptimizerSparseUpdate, OptimizersSparse.cu:524-722 (ids unique): norm2 of the indexed parameter
+    rows, Adam moments -> update direction, norm2 of the direction, scaled step.  In place."""
+    f = np.float32
+    idx = np.asarray(ids).astype(np.int64)
+    g = np.asarray(grads, dtype=f)
+    norm_p = f(np.sqrt(np.sum(param[idx].astype(np.float64) ** 2)))
+    cm = (f(beta1) * m[idx] + (f(1) - f(beta1)) * g).astype(f)
+    cv = (f(beta2) * v[idx] + (f(1) - f(beta2)) * g * g).astype(f)
+    m[idx] = cm
+    v[idx] = cv
+    cm = (cm / (f(1) - f(beta1t))).astype(f)
+    cv = (cv / (f(1) - f(beta2t))).astype(f)
+    upd = (cm / (np.sqrt(cv, dtype=f) + f(eps))).astype(f)
+    norm_u = f(np.sqrt(np.sum(upd.astype(np.float64) ** 2)))
+    param[idx] = (param[idx] - f(lr) * (norm_p / norm_u) * (upd + f(weight_decay) * param[idx])).astype(f)

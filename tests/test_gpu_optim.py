@@ -56,3 +56,99 @@ def test_adam_and_adamw_sparse(dev, wd):
     np.testing.assert_allclose(p.cpu().numpy(), param, **TOL)
     np.testing.assert_allclose(dm.cpu().numpy(), m, **TOL)
     np.testing.assert_allclose(dv.cpu().numpy(), v, **TOL)
+
+
+def _dedup_case(dev, seed, rows, width, n):
+    rng = np.random.default_rng(seed)
+    param = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = rng.integers(0, rows, size=n).astype(np.float32)
+    vals = rng.standard_normal((n, width), dtype=np.float32)
+    uniq, _, red = cpu.dedup_reduce(ids, vals)
+    return param, uniq.astype(np.float32), red
+
+
+@pytest.mark.parametrize("rows,width,n", [(500, 400, 100), (300, 7, 64), (2000, 512, 1500), (50, 1030, 20)])
+def test_sparse_optimizers_every_width_path(dev, rows, width, n):
+    """16-byte vector path (width % 4 == 0), scalar path (width 7), wide rows, more rows than one pass of
+    the grid: AdaGrad, Adam, AdamW and sparse L2 against the numpy oracle."""
+    param, uniq, red = _dedup_case(dev, rows + width, rows, width, n)
+    d_ids, d_red = torch.from_numpy(uniq).to(dev), torch.from_numpy(red).to(dev)
+    # sparse L2 (OptimizerLink.py:8-21): grads += l2reg * param[ids]
+    g2 = d_red.clone()
+    ops.dl_call("AddL2RegularizationSparse", [torch.from_numpy(param).to(dev), d_ids, g2],
+                scalars=[ctypes.c_float(0.3)])
+    np.testing.assert_allclose(g2.cpu().numpy(), cpu.l2_sparse(param, uniq, red, 0.3), rtol=1e-6, atol=1e-6)
+    # AdaGrad
+    p0, acc = param.copy(), np.abs(np.random.default_rng(5).standard_normal(param.shape, dtype=np.float32))
+    p, a = torch.from_numpy(p0.copy()).to(dev), torch.from_numpy(acc.copy()).to(dev)
+    ops.dl_call("AdaGradOptimizerSparseUpdate", [p, d_ids, d_red, a], scalars=[ctypes.c_float(0.1), ctypes.c_float(1e-7)])
+    cpu.adagrad_sparse(p0, acc, uniq, red, 0.1, 1e-7)
+    np.testing.assert_allclose(p.cpu().numpy(), p0, **TOL)
+    np.testing.assert_allclose(a.cpu().numpy(), acc, **TOL)
+    # AdamW
+    p1, m, v = param.copy(), np.zeros_like(param), np.zeros_like(param)
+    dp, dm, dv = [torch.from_numpy(x.copy()).to(dev) for x in (p1, m, v)]
+    sc = [ctypes.c_float(x) for x in (0.01, 0.9, 0.999, 0.9, 0.999, 1e-7, 0.01)]
+    ops.dl_call("AdamWOptimizerSparseUpdate", [dp, d_ids, d_red, dm, dv], scalars=sc)
+    cpu.adam_sparse(p1, m, v, uniq, red, 0.01, 0.9, 0.999, np.float32(0.9), np.float32(0.999), 1e-7, 0.01)
+    np.testing.assert_allclose(dp.cpu().numpy(), p1, **TOL)
+    np.testing.assert_allclose(dm.cpu().numpy(), m, **TOL)
+    np.testing.assert_allclose(dv.cpu().numpy(), v, **TOL)
+
+
+@pytest.mark.parametrize("nesterov", [False, True])
+@pytest.mark.parametrize("rows,width,n", [(500, 400, 100), (64, 128, 900), (40, 6, 50)])
+def test_momentum_sparse_with_repeated_ids(dev, nesterov, rows, width, n):
+    """MomentumOptimizerSparseUpdate is called WITHOUT deduplication (OptimizerLink.py:37-49): ids repeat.
+    Three steps, velocity carried over, dense second phase over the whole table."""
+    rng = np.random.default_rng(rows * 3 + width + int(nesterov))
+    param = rng.standard_normal((rows, width), dtype=np.float32)
+    veloc = np.zeros_like(param)
+    p, v = torch.from_numpy(param.copy()).to(dev), torch.from_numpy(veloc.copy()).to(dev)
+    for _ in range(3):
+        ids = np.minimum(rng.zipf(1.5, size=n) - 1, rows - 1).astype(np.float32)
+        g = rng.standard_normal((n, width), dtype=np.float32)
+        ops.dl_call("MomentumOptimizerSparseUpdate", [p, torch.from_numpy(ids).to(dev), torch.from_numpy(g).to(dev), v],
+                    scalars=[ctypes.c_float(0.01), ctypes.c_float(0.9), ctypes.c_bool(nesterov)])
+        cpu.momentum_sparse(param, veloc, ids, g, 0.01, 0.9, nesterov)
+    np.testing.assert_allclose(p.cpu().numpy(), param, **TOL)
+    np.testing.assert_allclose(v.cpu().numpy(), veloc, **TOL)
+
+
+@pytest.mark.parametrize("rows,width,n", [(500, 400, 100), (3000, 512, 2500), (60, 10, 30)])
+def test_lamb_sparse(dev, rows, width, n):
+    param, uniq, red = _dedup_case(dev, 77 + rows, rows, width, n)
+    m, v = np.zeros_like(param), np.zeros_like(param)
+    dp, dm, dv = [torch.from_numpy(x.copy()).to(dev) for x in (param, m, v)]
+    d_ids, d_red = torch.from_numpy(uniq).to(dev), torch.from_numpy(red).to(dev)
+    b1, b2 = 0.9, 0.999
+    for t in range(1, 4):
+        sc = [ctypes.c_float(x) for x in (0.01, b1, b2, b1 ** t, b2 ** t, 1e-7, 0.01)]
+        ops.dl_call("LambOptimizerSparseUpdate", [dp, d_ids, d_red, dm, dv], scalars=sc)
+        cpu.lamb_sparse(param, m, v, uniq, red, 0.01, b1, b2, np.float32(b1 ** t), np.float32(b2 ** t), 1e-7, 0.01)
+    np.testing.assert_allclose(dp.cpu().numpy(), param, **TOL)
+    np.testing.assert_allclose(dm.cpu().numpy(), m, **TOL)
+    np.testing.assert_allclose(dv.cpu().numpy(), v, **TOL)
+
+
+def test_cpu_named_symbols_serve_gpu_arrays_and_refuse_host_arrays(dev):
+    """cpu_EmbeddingLookup / cpu_SGDOptimizerSparseUpdate (c_runtime_api.h:811-818; hasattr-probed by
+    python/hetu/_base.py:8-11,72): GPU arrays run on the HIP kernels and are complete on return; host
+    arrays are an error -- never a CPU fallback."""
+    from herald_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(4)
+    table = rng.standard_normal((300, 64), dtype=np.float32)
+    ids = rng.integers(0, 300, size=(20, 5)).astype(np.float32)
+    g = rng.standard_normal((100, 64), dtype=np.float32)
+    t, i, gg = [torch.from_numpy(x).to(dev) for x in (table.copy(), ids, g)]
+    out = torch.empty((20, 5, 64), dtype=torch.float32, device=dev)
+    hs = [ops.DLHolder(x) for x in (t, i, out, gg)]
+    assert L.cpu_EmbeddingLookup(hs[0].handle, hs[1].handle, hs[2].handle) == 0
+    np.testing.assert_array_equal(out.cpu().numpy(), cpu.embedding_lookup(table, ids))   # no sync needed
+    flat = ops.DLHolder(i.reshape(-1))
+    assert L.cpu_SGDOptimizerSparseUpdate(hs[0].handle, flat.handle, hs[3].handle, ctypes.c_float(0.1)) == 0
+    np.testing.assert_array_equal(t.cpu().numpy(), cpu.sgd_sparse_update(table.copy(), ids.reshape(-1), g, 0.1))
+    host = [ops.DLHolder(torch.from_numpy(x)) for x in (table, ids, np.empty((20, 5, 64), np.float32))]
+    assert L.cpu_EmbeddingLookup(host[0].handle, host[1].handle, host[2].handle) == -1
+    assert b"no CPU fallback" in L.ha_last_error()
