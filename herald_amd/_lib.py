@@ -169,6 +169,8 @@ def _declare(L):
     L.ha_laia_next_topk.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp, i64, vp]
     L.ha_laia_counters.restype = c.c_int
     L.ha_laia_counters.argtypes = [vp, vp]
+    L.ha_laia_timing.restype = c.c_int
+    L.ha_laia_timing.argtypes = [vp, vp]
     L.ha_shm_ring_open.restype = vp
     L.ha_shm_ring_open.argtypes = [c.c_char_p, c.c_int, i64]
     L.ha_shm_ring_close.restype = None

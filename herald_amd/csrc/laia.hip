@@ -20,6 +20,7 @@
 #include "plan_dev.h"
 
 #include <algorithm>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -217,7 +218,15 @@ struct Laia {
     size_t plan_cap = 0, delta_cap = 0;
     int Bcap = 0;
     std::vector<void *> allocs;
+    // wall time per phase, summed over the calls (ha_laia_timing): the whole call, the host's greedy
+    // assignment, the host's snapshot (MiniLRU) bookkeeping; the rest is GPU work, transfers and waits
+    double t_total_us = 0, t_assign_us = 0, t_snap_us = 0;
+    long long t_calls = 0;
 };
+
+static inline double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 }  // namespace ha
 
@@ -351,6 +360,7 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
     const int W = l.W, T = l.T;
     const long long B = mini_bs * W;
     HA_REQUIRE(B <= l.Bcap, "laia_next: global batch %lld exceeds max_batch %d", B, l.Bcap);
+    const double t_begin = now_us();
     const long long start = (batch_id * B) % l.S;  // laia_scheduler.cc:182
     const long long BT = B * T;
     int blocks = static_cast<int>((BT + 255) / 256);
@@ -381,6 +391,7 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
     if (topk)
         HA_CHECK_HIP(hipMemcpyAsync(cand.data(), l.d_cand, cand.size() * 4, hipMemcpyDeviceToHost, l.stream));
     HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    const double t_assign0 = now_us();
     std::vector<int32_t> owner(static_cast<size_t>(B));
     if (topk) {
         // ---- assign (topk_scheduler.cc:393-455): the batch and every worker's quota are cut into
@@ -439,6 +450,7 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
         workload[max_worker] += 1;
         owner[static_cast<size_t>(i)] = max_worker;
     }
+    l.t_assign_us += now_us() - t_assign0;
     // ---- plan + touched rows
     HA_CHECK_HIP(hipMemcpyAsync(l.d_owner, owner.data(), owner.size() * 4, hipMemcpyHostToDevice, l.stream));
     HA_CHECK_HIP(hipMemsetAsync(l.d_count, 0, 8, l.stream));
@@ -471,6 +483,7 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
     // touched key in ascending order
     std::vector<uint32_t> dkeys;
     std::vector<uint8_t> dvals;
+    const double t_snap0 = now_us();
     {
         size_t pk = 0, tk = 0;
         std::vector<std::pair<int32_t, uint8_t>> delta;
@@ -503,6 +516,7 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
             }
         }
     }
+    l.t_snap_us += now_us() - t_snap0;
     if (!dkeys.empty()) {
         HA_REQUIRE(dkeys.size() <= l.delta_cap, "laia_next: delta buffer too small");
         HA_CHECK_HIP(hipMemcpyAsync(l.d_dkeys, dkeys.data(), dkeys.size() * 4, hipMemcpyHostToDevice, l.stream));
@@ -512,6 +526,18 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
         HA_LAUNCH_CHECK();
         HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     }
+    l.t_total_us += now_us() - t_begin;
+    l.t_calls += 1;
+    return 0;
+}
+
+// out[4] = {calls, total us, host assignment us, host snapshot us} summed since creation
+extern "C" int ha_laia_timing(ha_laia *h, double *out) {
+    HA_REQUIRE(h && out, "ha_laia_timing: null pointer");
+    out[0] = static_cast<double>(h->l.t_calls);
+    out[1] = h->l.t_total_us;
+    out[2] = h->l.t_assign_us;
+    out[3] = h->l.t_snap_us;
     return 0;
 }
 

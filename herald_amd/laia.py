@@ -109,6 +109,15 @@ class LaiaScheduler:
         n = self._L.ha_laia_snapshot_keys(self._h, int(worker), buf.ctypes.data, buf.size)
         return buf[:n].tolist()
 
+    def timing(self):
+        """Scheduler cost per global batch (us): whole ha_laia_next call, of which host greedy assignment and
+        host snapshot (MiniLRU) bookkeeping; the rest is GPU kernels + transfers + waits."""
+        t = np.zeros(4, dtype=np.float64)
+        _lib.check(self._L.ha_laia_timing(self._h, t.ctypes.data), "ha_laia_timing")
+        calls = max(t[0], 1.0)
+        return {"batches": int(t[0]), "us_per_batch": t[1] / calls, "host_assign_us": t[2] / calls,
+                "host_snapshot_us": t[3] / calls, "gpu_and_transfer_us": (t[1] - t[2] - t[3]) / calls}
+
     def close(self):
         self._close = True
         if self._thread is not None:
@@ -346,3 +355,70 @@ class LAIAScheduler:
             new_batch_id = (min_batch_id + self.queue_size) % self.batch_num
             self.arr_map[new_batch_id] = arr_index
             self.cur_min_step += 1
+
+
+class LAIADataloader:
+    """python/hetu/laia/laia_dataloader.py:152-230: the data loader of a laia-scheduled training set.  The
+    samples of a batch are the ones the scheduler assigned to this worker (`get_input_index`); a sparse
+    loader returns the TUPLE `(ids, comm_plan)` -- the plan is the one the scheduler paired with this
+    batch (LAIAScheduler.start discards the first plan, so dist(b) travels with plan(b+1)) and becomes
+    `IndexedSlices.push_indices` in EmbeddingLookUp_Gradient (EmbeddingLookUp.py:95-103), i.e. the push
+    keys of `embedding_update_with_push_keys`.  The constructor fields are those of the reference's
+    `Dataloader` base (python/hetu/dataloader.py:12-19).  Arrays are float32 like every reference
+    NDArray (ndarray.array default dtype); with `device` they are torch tensors resident on it (the
+    reference returns host NDArrays and lets the executor copy them), else numpy arrays."""
+
+    def __init__(self, sched, sched_id, is_sparse, raw_data, batch_size, name="default", func=None,
+                 drop_last=True, device=None):
+        self.func = func if func else lambda x: x
+        self.raw_data = np.array(self.func(raw_data), np.float32)
+        self.batch_size = batch_size
+        self.drop_last = drop_last
+        self.name = str(name)
+        assert drop_last, "drop_last must be True"
+        self.sched = sched
+        self.sched_id = sched_id
+        self.is_sparse = is_sparse
+        self.device = device
+        self._raw_dev = None
+
+    def init_states(self, rank=None, nrank=None):
+        if nrank is None:
+            nrank = 1
+        self.samples_num = self.sched.samples_num
+        self.batch_num = self.sched.batch_num
+        self.batch_size = self.sched.batch_size
+        self.batch_index = 0
+        self.rank = rank
+        if self.device is not None:
+            import torch
+            self._raw_dev = torch.from_numpy(self.raw_data).to(self.device)
+
+    def _rows(self, idx):
+        if self._raw_dev is None:
+            return self.raw_data[idx]
+        import torch
+        return self._raw_dev[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.device)]
+
+    def _get_arr(self, batchind):
+        idx = self.sched.get_input_index(self.batch_index)
+        if not self.is_sparse:
+            return self._rows(idx)
+        plan = np.asarray(self.sched.get_comm_plan(self.batch_index), dtype=np.float32)
+        if self._raw_dev is not None:
+            import torch
+            plan = torch.from_numpy(plan).to(self.device)
+        return (self._rows(idx), plan)
+
+    def get_arr(self):
+        """The current batch; steps the scheduler's queue forward (laia_dataloader.py:201-206)."""
+        res = self._get_arr(self.batch_index)
+        self.batch_index = (self.batch_index + 1) % self.batch_num
+        self.sched.step_forward(self.sched_id)
+        return res
+
+    def get_next_arr(self):
+        return self._get_arr(self.batch_index)
+
+    def get_cur_shape(self):
+        return tuple([len(self.sched.get_input_index(self.batch_index))] + list(self.raw_data.shape[1:]))

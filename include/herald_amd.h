@@ -491,6 +491,10 @@ int ha_laia_next_topk(ha_laia *sched, int64_t batch_id, int64_t mini_bs,
 /* out[4*nrank] = miss_pull, miss_push, update_pull, update_push per worker, accumulated over the
  * batches scheduled so far (TopkScheduler::report_cache_perf, topk_scheduler.cc:504-527). */
 int ha_laia_counters(ha_laia *sched, int64_t *out);
+/* Wall time of the scheduler per phase, summed since ha_laia_create (scheduler us per global
+ * batch): out[4] = {calls of ha_laia_next*, whole calls us, host greedy assignment us, host snapshot
+ * (MiniLRU) bookkeeping us}; the remainder of the total is GPU kernels, transfers and waits. */
+int ha_laia_timing(ha_laia *h, double *out);
 
 /* Local-shared plan distribution (laia/include/share_mem.h:40-193, ring_buffer.h:13-125): a
  * single-producer / single-consumer ring of uint64 words in POSIX shared memory, message-framed.
