@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -29,14 +30,19 @@ namespace ha {
 // ---- host-side snapshot: the semantics of MiniLRUCache (hash mode) ---------------------------------
 struct Snapshot {
     int cap = 0;
-    std::unordered_map<int32_t, int> node_of;
+    // key -> node: a direct map over the row range where that fits in memory (one load per probe, like the
+    // device-side validity bytes), a hash map for very large key spaces
+    bool direct = false;
+    std::vector<int32_t> dmap;
+    std::unordered_map<int32_t, int> hmap;
+    size_t live = 0;
     std::vector<int> prev, next;
     std::vector<int32_t> key;
     std::vector<uint8_t> valid;
     std::vector<int> free_nodes;
     int front = -1, back = -1;
 
-    void init(int capacity) {
+    void init(int capacity, long long key_range, bool use_direct) {
         cap = capacity;
         const int n = capacity + 2;
         prev.assign(n, -1);
@@ -46,9 +52,40 @@ struct Snapshot {
         free_nodes.clear();
         for (int i = n - 1; i >= 0; --i)
             free_nodes.push_back(i);
-        node_of.clear();
-        node_of.reserve(static_cast<size_t>(capacity) * 3);  // set_cap, mini_lru_cache.h:49-52
+        direct = use_direct;
+        hmap.clear();
+        dmap.clear();
+        if (direct)
+            dmap.assign(static_cast<size_t>(key_range), -1);
+        else
+            hmap.reserve(static_cast<size_t>(capacity) * 3);  // set_cap, mini_lru_cache.h:49-52
+        live = 0;
         front = back = -1;
+    }
+    int find(int32_t k) const {
+        if (direct)
+            return dmap[static_cast<size_t>(k)];
+        auto it = hmap.find(k);
+        return it == hmap.end() ? -1 : it->second;
+    }
+    void bind(int32_t k, int x) {
+        if (direct)
+            dmap[static_cast<size_t>(k)] = x;
+        else
+            hmap[k] = x;
+        ++live;
+    }
+    void unbind(int32_t k) {
+        if (direct)
+            dmap[static_cast<size_t>(k)] = -1;
+        else
+            hmap.erase(k);
+        --live;
+    }
+    // validity of key k as the device mirror must show it
+    uint8_t state(int32_t k) const {
+        const int x = find(k);
+        return x >= 0 && valid[x] ? 1 : 0;
     }
     void unlink(int x) {
         if (prev[x] >= 0) next[prev[x]] = next[x]; else front = next[x];
@@ -61,41 +98,41 @@ struct Snapshot {
         front = x;
         if (back < 0) back = x;
     }
-    // delta: (key, new validity byte) pairs to mirror on the device
-    void outdate(int32_t k, std::vector<std::pair<int32_t, uint8_t>> &delta) {
-        auto it = node_of.find(k);
-        if (it != node_of.end() && valid[it->second]) {
-            valid[it->second] = 0;
-            delta.emplace_back(k, 0);
+    // touched: keys whose validity byte may have changed (the caller mirrors state(k) on the device;
+    // a key listed twice is written twice with the same final value)
+    void outdate(int32_t k, std::vector<int32_t> &touched) {
+        const int x = find(k);
+        if (x >= 0 && valid[x]) {
+            valid[x] = 0;
+            touched.push_back(k);
         }
     }
-    int get(int32_t k, std::vector<std::pair<int32_t, uint8_t>> &delta) {
-        auto it = node_of.find(k);
-        if (it != node_of.end()) {
-            const int x = it->second;
+    int get(int32_t k, std::vector<int32_t> &touched) {
+        int x = find(k);
+        if (x >= 0) {
             const int res = valid[x] ? -1 : -2;
             unlink(x);
             push_front(x);
             if (!valid[x]) {
                 valid[x] = 1;
-                delta.emplace_back(k, 1);
+                touched.push_back(k);
             }
             return res;
         }
-        const int x = free_nodes.back();
+        x = free_nodes.back();
         free_nodes.pop_back();
         key[x] = k;
         valid[x] = 1;
         push_front(x);
-        node_of[k] = x;
-        delta.emplace_back(k, 1);
-        if (static_cast<int>(node_of.size()) > cap) {
+        bind(k, x);
+        touched.push_back(k);
+        if (static_cast<long long>(live) > cap) {
             const int e = back;
             const bool flag = valid[e] != 0;
             unlink(e);
-            node_of.erase(key[e]);
+            unbind(key[e]);
             if (flag)
-                delta.emplace_back(key[e], 0);
+                touched.push_back(key[e]);
             free_nodes.push_back(e);
             return flag ? 1 : 0;
         }
@@ -260,8 +297,11 @@ extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sam
     l.Bcap = static_cast<int>(max_batch);
     l.samples_host.assign(samples_host, samples_host + num_sample * num_table);
     l.snaps.resize(l.W);
+    // direct maps while all W of them stay below 2 GiB of host memory, hash maps beyond
+    const bool use_direct = static_cast<unsigned long long>(l.W) * static_cast<unsigned long long>(l.R) * 4ull <=
+                            (2ull << 30);
     for (auto &s : l.snaps)
-        s.init(l.cache_size);
+        s.init(l.cache_size, l.R, use_direct);
     l.miss_pull.assign(l.W, 0);
     l.miss_push.assign(l.W, 0);
     l.update_pull.assign(l.W, 0);
@@ -270,7 +310,7 @@ extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sam
     l.plan_cap = BT * (l.W > 1 ? l.W - 1 : 1);
     if (l.plan_cap < BT)
         l.plan_cap = BT;
-    l.delta_cap = BT * 2 + static_cast<size_t>(l.W) * 16;
+    l.delta_cap = l.plan_cap + BT * 2 + static_cast<size_t>(l.W) * 16;   // outdated plan keys + two per get()
     bool ok = hipStreamCreate(&l.stream) == hipSuccess;
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_samples), num_sample * num_table * 4) == 0;
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_valid), static_cast<size_t>(l.W) * l.R) == 0;
@@ -485,17 +525,32 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
     std::vector<uint8_t> dvals;
     const double t_snap0 = now_us();
     {
-        size_t pk = 0, tk = 0;
-        std::vector<std::pair<int32_t, uint8_t>> delta;
-        for (int w = 0; w < W; ++w) {
-            delta.clear();
+        // the W snapshots are independent (the reference keeps one per worker and walks them one after
+        // the other, laia_scheduler.cc:146-162): one host thread per worker
+        std::vector<size_t> pk0(W + 1), tk0(W + 1);
+        {
+            size_t pk = 0, tk = 0;
+            for (int w = 0; w < W; ++w) {
+                pk0[w] = pk;
+                tk0[w] = tk;
+                while (pk < plan_keys.size() && plan_keys[pk] / l.R == static_cast<unsigned long long>(w))
+                    ++pk;
+                while (tk < touch_keys.size() && touch_keys[tk] / l.R == static_cast<unsigned long long>(w))
+                    ++tk;
+            }
+            pk0[W] = pk;
+            tk0[W] = tk;
+        }
+        std::vector<std::vector<int32_t>> touched(W);
+        auto work = [&](int w) {
             const unsigned long long base = static_cast<unsigned long long>(w) * l.R;
-            const size_t pk_begin = pk;
-            for (; pk < plan_keys.size() && plan_keys[pk] / l.R == static_cast<unsigned long long>(w); ++pk)
-                l.snaps[w].outdate(static_cast<int32_t>(plan_keys[pk] - base), delta);
-            l.update_push[w] += static_cast<long long>(pk - pk_begin);
-            for (; tk < touch_keys.size() && touch_keys[tk] / l.R == static_cast<unsigned long long>(w); ++tk) {
-                const int res = l.snaps[w].get(static_cast<int32_t>(touch_keys[tk] - base), delta);
+            std::vector<int32_t> &td = touched[w];
+            td.reserve((pk0[w + 1] - pk0[w]) + 2 * (tk0[w + 1] - tk0[w]));
+            for (size_t pk = pk0[w]; pk < pk0[w + 1]; ++pk)
+                l.snaps[w].outdate(static_cast<int32_t>(plan_keys[pk] - base), td);
+            l.update_push[w] += static_cast<long long>(pk0[w + 1] - pk0[w]);
+            for (size_t tk = tk0[w]; tk < tk0[w + 1]; ++tk) {
+                const int res = l.snaps[w].get(static_cast<int32_t>(touch_keys[tk] - base), td);
                 if (res < 0) {  // traffic counters, topk_scheduler.cc:319-331
                     if (res == -2)
                         l.update_pull[w] += 1;
@@ -505,14 +560,23 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
                         l.miss_push[w] += 1;
                 }
             }
-            // keep the last value per row
-            std::unordered_map<int32_t, uint8_t> last;
-            last.reserve(delta.size() * 2);
-            for (auto &d : delta)
-                last[d.first] = d.second;
-            for (auto &kv : last) {
-                dkeys.push_back(static_cast<uint32_t>(base + static_cast<uint32_t>(kv.first)));
-                dvals.push_back(kv.second);
+        };
+        if (W > 1 && touch_keys.size() > 4096) {
+            std::vector<std::thread> pool;
+            for (int w = 1; w < W; ++w)
+                pool.emplace_back(work, w);
+            work(0);
+            for (auto &t : pool)
+                t.join();
+        } else {
+            for (int w = 0; w < W; ++w)
+                work(w);
+        }
+        for (int w = 0; w < W; ++w) {
+            const unsigned long long base = static_cast<unsigned long long>(w) * l.R;
+            for (int32_t k : touched[w]) {
+                dkeys.push_back(static_cast<uint32_t>(base + static_cast<uint32_t>(k)));
+                dvals.push_back(l.snaps[w].state(k));
             }
         }
     }
@@ -575,9 +639,9 @@ extern "C" int64_t ha_laia_snapshot_keys(ha_laia *h, int64_t w, int32_t *out, in
         return -1;
     Snapshot &s = h->l.snaps[static_cast<size_t>(w)];
     std::vector<int32_t> keys;
-    for (auto &kv : s.node_of)
-        if (s.valid[kv.second])
-            keys.push_back(kv.first);
+    for (int x = s.front; x >= 0; x = s.next[x])   // every resident node is on the list
+        if (s.valid[x])
+            keys.push_back(s.key[x]);
     std::sort(keys.begin(), keys.end());
     for (size_t i = 0; i < keys.size() && static_cast<int64_t>(i) < cap; ++i)
         out[i] = keys[i];
