@@ -205,11 +205,12 @@ class RouteBuffers:
 class Route:
     """Routing of one id batch: its plan, which owner gets which of its unique keys, and the keys this
     rank will be asked for.  Shared by the pull and the push of the batch."""
-    __slots__ = ("buf", "plan", "pending", "u", "send_cnt", "recv_cnt", "keys_recv", "ready", "shape")
+    __slots__ = ("buf", "plan", "pending", "u", "send_cnt", "recv_cnt", "keys_recv", "ready", "shape", "released")
 
     def __init__(self):
         self.pending = None
         self.ready = None
+        self.released = False
 
 
 class ShardedEmbedding:
@@ -221,8 +222,12 @@ class ShardedEmbedding:
     row exchanges instead of queueing between them); construct the store on every rank of `group` at
     the same point of the program in that case."""
 
-    def __init__(self, rows, width, device, group=None, engine=None, table=None, side_group=False):
+    def __init__(self, rows, width, device, group=None, engine=None, table=None, side_group=False, a2a=None):
+        """a2a: optional replacement of torch.distributed.all_to_all_single with the same arguments
+        (out, inp, out_splits, in_splits, group) -- e.g. a host-staged exchange where the process group's
+        backend cannot move device tensors (several ranks sharing one GPU under gloo in the tests)."""
         self.group = group
+        self._a2a_fn = a2a
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rows, self.width = int(rows), int(width)
@@ -236,6 +241,7 @@ class ShardedEmbedding:
         self.table = table
         self.stats = {"xgmi_bytes_out": 0, "xgmi_bytes_in": 0}
         self._slot = 0
+        self._live = {}
         self.side_group = None
         if self.world > 1 and side_group:
             ranks = None if group is None else dist.get_process_group_ranks(group)
@@ -245,6 +251,8 @@ class ShardedEmbedding:
     def _a2a(self, out, inp, out_splits, in_splits, group=None):
         if self.world == 1:
             out.copy_(inp)
+        elif self._a2a_fn is not None:
+            self._a2a_fn(out, inp, out_splits, in_splits, group if group is not None else self.group)
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=group if group is not None else self.group)
         return out
@@ -260,6 +268,11 @@ class ShardedEmbedding:
         r.shape = tuple(ids.shape)
         slot = self._slot
         self._slot = (self._slot + 1) % eng.NSLOT
+        old = self._live.get(slot)
+        if old is not None and not old.released:
+            raise RuntimeError("routing workspace %d is still in use by a batch that was prefetched but "
+                               "neither pulled nor pushed (at most %d batches in flight)" % (slot, eng.NSLOT))
+        self._live[slot] = r
         with eng.on_side(after_current):
             b = r.buf = eng.route_issue(ids.reshape(-1), self.starts, slot)
             r.plan = b.plan
@@ -279,7 +292,10 @@ class ShardedEmbedding:
         vals = b.host.tolist()
         w = self.world
         r.u, r.send_cnt, r.recv_cnt = vals[0], vals[1:1 + w], vals[1 + w:1 + 2 * w]
-        r.keys_recv = b.keys_recv[:sum(r.recv_cnt)]
+        need = sum(r.recv_cnt)
+        if b.keys_recv.numel() < need:     # a peer's batch is larger than this rank's (ragged last batch)
+            b.keys_recv = torch.empty(need * 5 // 4 + 16, dtype=torch.int32, device=b.keys_recv.device)
+        r.keys_recv = b.keys_recv[:need]
         with eng.on_side(False):
             self._a2a(r.keys_recv, b.local[:r.u], r.recv_cnt, r.send_cnt, group=self.side_group)
             r.ready = eng.record(b.ev_ready)
@@ -287,8 +303,13 @@ class ShardedEmbedding:
         return r
 
     def _release(self, r):
-        """The last consumer of a route's buffers is queued on the current stream."""
+        """A consumer of a route's buffers is queued on the current stream.  The workspace may be reused
+        once the LAST of them has run: pull and push of one batch both record here, the later record
+        overwrites the earlier one (same stream, program order), and route_issue waits for it.  A route
+        is live from prefetch() until its push (or, for pull-only use, its pull); with NSLOT = 3 workspaces
+        at most two newer batches may be prefetched meanwhile -- prefetch() asserts that."""
         r.buf.free = self.engine.record(r.buf.ev_free)
+        r.released = True
 
     def _account(self, send_cnt, recv_cnt, bytes_per_key_out, bytes_per_key_in):
         r = self.rank
@@ -339,11 +360,39 @@ class ShardedEmbedding:
         return self.pull(pull_ids)
 
     # -- checkpoint format of the reference: raw fp32 `<name>_<part>.dat` per shard ------------------------
+    CKPT_CHUNK_BYTES = 64 << 20
+
+    def _ckpt_chunk_rows(self):
+        return max(1, self.CKPT_CHUNK_BYTES // (4 * self.width))
+
     def save(self, path_prefix):
-        """PSAgent ParamSave (PSAgent.h:447-476, PSFHandle.h:401-439): raw little-endian fp32 rows."""
-        self.table.detach().cpu().numpy().tofile("%s_%d.dat" % (path_prefix, self.rank))
+        """PSAgent ParamSave (PSAgent.h:447-476, PSFHandle.h:401-439): raw little-endian fp32 rows in
+        `<prefix>_<rank>.dat`.  The shard is streamed through one 64 MiB staging buffer (pinned when the
+        shard lives on a GPU): no whole-shard host copy, a 35 GB shard needs 64 MiB of host memory."""
+        chunk = self._ckpt_chunk_rows()
+        pin = self.table.is_cuda
+        stage = torch.empty((min(chunk, max(self.local_rows, 1)), self.width), dtype=torch.float32, pin_memory=pin)
+        with open("%s_%d.dat" % (path_prefix, self.rank), "wb") as f:
+            for s in range(0, self.local_rows, chunk):
+                e = min(self.local_rows, s + chunk)
+                stage[:e - s].copy_(self.table[s:e])          # synchronous for pinned destinations
+                f.write(memoryview(stage[:e - s].numpy()).cast("B"))
 
     def load(self, path_prefix):
-        import numpy as np
-        a = np.fromfile("%s_%d.dat" % (path_prefix, self.rank), dtype=np.float32)
-        self.table.copy_(torch.from_numpy(a.reshape(self.local_rows, self.width)).to(self.device))
+        """Inverse of save; also reads tables written by the reference's servers (same raw layout)."""
+        import os
+        path = "%s_%d.dat" % (path_prefix, self.rank)
+        want = self.local_rows * self.width * 4
+        if os.path.getsize(path) != want:
+            raise ValueError("%s holds %d bytes, this shard needs %d" % (path, os.path.getsize(path), want))
+        chunk = self._ckpt_chunk_rows()
+        pin = self.table.is_cuda
+        stage = torch.empty((min(chunk, max(self.local_rows, 1)), self.width), dtype=torch.float32, pin_memory=pin)
+        with open(path, "rb") as f:
+            for s in range(0, self.local_rows, chunk):
+                e = min(self.local_rows, s + chunk)
+                got = f.readinto(memoryview(stage[:e - s].numpy()).cast("B"))
+                assert got == (e - s) * self.width * 4
+                self.table[s:e].copy_(stage[:e - s])
+                if pin:
+                    torch.cuda.current_stream().synchronize()   # the staging buffer is reused

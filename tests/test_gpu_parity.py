@@ -517,3 +517,28 @@ def test_many_criteo_batches_through_the_fused_step(dev):
         np.testing.assert_array_equal(t[torch.from_numpy(touched).to(dev)].cpu().numpy(), want[touched],
                                       err_msg="step %d" % k)
     np.testing.assert_array_equal(t.cpu().numpy(), want)
+
+
+def test_sharded_checkpoint_round_trip_chunked(dev, tmp_path):
+    """Embedding checkpoint `<name>_<part>.dat` (raw fp32 rows, PSFHandle.h:401-439) of a GPU shard larger
+    than the staging buffer: streamed in 64 MiB chunks both ways, byte-identical to the numpy layout the
+    reference's servers write, and loadable from a file written by numpy."""
+    from herald_amd.sharded import ShardedEmbedding
+    rows, width = 300_001, 128                          # 153.6 MB: three chunks, the last one ragged
+    emb = ShardedEmbedding(rows, width, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    emb.table.normal_(0, 1, generator=g)
+    ref = emb.table.cpu().numpy()
+    emb.save(str(tmp_path / "emb"))
+    path = str(tmp_path / "emb_0.dat")
+    np.testing.assert_array_equal(np.fromfile(path, dtype=np.float32).reshape(rows, width), ref)
+    emb.table.zero_()
+    emb.load(str(tmp_path / "emb"))
+    np.testing.assert_array_equal(emb.table.cpu().numpy(), ref)
+    (ref * np.float32(2)).tofile(str(tmp_path / "other_0.dat"))      # a table written elsewhere
+    emb.load(str(tmp_path / "other"))
+    np.testing.assert_array_equal(emb.table.cpu().numpy(), ref * np.float32(2))
+    open(str(tmp_path / "short_0.dat"), "wb").write(b"1234")
+    with pytest.raises(ValueError):
+        emb.load(str(tmp_path / "short"))

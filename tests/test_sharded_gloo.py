@@ -80,6 +80,19 @@ def _worker(rank, world, port, rows, width, n, out_dir, side_group=False):
             cpu.sparse_push(want, batches[k][r], bvals[k][r], lr)
         np.testing.assert_array_equal(emb.table.numpy(), want[starts[rank]:starts[rank + 1]])
 
+    # SSPushPull (ParameterServerCommunicate.py:74-76): push this batch, then pull the next one; the pushes
+    # are a collective, so every rank's update is in the rows any rank pulls
+    pp_ids = [rng.integers(0, rows, size=n).astype(np.float32) for _ in range(world)]
+    pp_next = [rng.integers(0, rows, size=n).astype(np.float32) for _ in range(world)]
+    pp_vals = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(world)]
+    got = emb.push_pull(torch.from_numpy(pp_ids[rank]), torch.from_numpy(pp_vals[rank]), lr,
+                        torch.from_numpy(pp_next[rank]))
+    for r in range(world):
+        cpu.sparse_push(want, pp_ids[r], pp_vals[r], lr)
+    np.testing.assert_array_equal(got.numpy(), want[pp_next[rank].astype(np.int64)])
+    dist.barrier()
+    np.testing.assert_array_equal(emb.table.numpy(), want[starts[rank]:starts[rank + 1]])
+
     # 2-D id batches and the checkpoint format round trip
     ids2 = ids[: (n // 4) * 4].reshape(-1, 4)
     assert tuple(emb.pull(ids2).shape) == (ids2.shape[0], 4, width)
