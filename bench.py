@@ -180,7 +180,7 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
 
     def step(k):
         c.embedding_lookup(ids_dev[k % nb], out)
-        c.embedding_update(ids_dev[k % nb], grad)
+        c.embedding_update(ids_dev[k % nb], grad, same_as_lookup=True)
 
     for k in range(64):
         step(k)

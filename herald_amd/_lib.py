@@ -32,6 +32,14 @@ class DLStream(ctypes.Structure):
     _fields_ = [("device_id", ctypes.c_int), ("handle", ctypes.c_void_p)]
 
 
+class CacheRemote(ctypes.Structure):
+    """ha_cache_remote (include/herald_amd.h): device addresses of a remote-mode cache's inbox / outbox."""
+    _fields_ = [("req_keys", ctypes.c_void_p), ("req_versions", ctypes.c_void_p), ("inbox_pull", ctypes.c_void_p),
+                ("inbox_idx", ctypes.c_void_p), ("inbox_versions", ctypes.c_void_p), ("inbox_rows", ctypes.c_void_p),
+                ("out_keys", ctypes.c_void_p), ("out_updates", ctypes.c_void_p), ("out_rows", ctypes.c_void_p),
+                ("out_capacity", ctypes.c_int64), ("max_batch", ctypes.c_int64)]
+
+
 class PlanView(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int64), ("n_unique", ctypes.c_void_p), ("keys", ctypes.c_void_p),
                 ("sorted", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("inverse", ctypes.c_void_p),
@@ -152,6 +160,15 @@ def _declare(L):
         "ha_cache_perf": [vp, vp, vp],
         "ha_cache_state": [vp, vp, vp],
         "ha_cache_snapshot": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
+        "ha_cache_set_remote": [vp],
+        "ha_cache_remote_buffers": [vp, vp],
+        "ha_cache_lookup_begin": [vp, vp, c.c_int, i64, vp, vp],
+        "ha_cache_lookup_finish": [vp, i64, vp, vp],
+        "ha_cache_outbox_count": [vp, vp, vp],
+        "ha_cache_push_pull_begin": [vp, vp, c.c_int, i64, vp, c.c_int, i64, vp, vp, vp],
+        "ha_cache_push_pull_finish": [vp, vp, vp],
+        "ha_store_serve_sync": [vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp],
+        "ha_store_add_versions": [vp, i64, vp, vp, i64, vp],
     }
     for name, args in cache_sigs.items():
         fn = getattr(L, name)

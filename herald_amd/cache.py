@@ -90,6 +90,7 @@ class _CacheBase:
         self._perf = []
         self._last_lookup = None
         self._store = None
+        self._remote = None
         self.stream = stream
         if self.node_id in _TABLES:
             self.bind_store(*_TABLES[self.node_id])
@@ -108,6 +109,109 @@ class _CacheBase:
         check(self._L.ha_cache_bind_store(self._h, ctypes.c_void_p(table.data_ptr()),
                                           ctypes.c_void_p(versions.data_ptr()), table.shape[0], int(row_start)),
               "ha_cache_bind_store")
+
+    # ---- remote store (rows owned by other ranks / kept in host memory) -----------------------------------
+    def bind_remote(self, store):
+        """Put the cache in front of a store it cannot address: `store` implements
+            sync(keys, versions, bound, pull, idx, ver_out, rows_out)   the owner's kSyncEmbedding
+            push(keys, updates, rows)                                     the owner's kPushEmbedding
+        on device tensors (herald_amd.remote_store: LocalStore, ShardedStore, HostStore).  The cache kernels
+        then fill a request / an outbox and read an inbox (include/herald_amd.h, ha_cache_remote)."""
+        check(self._L.ha_cache_set_remote(self._h), "ha_cache_set_remote")
+        r = _lib.CacheRemote()
+        check(self._L.ha_cache_remote_buffers(self._h, ctypes.byref(r)), "ha_cache_remote_buffers")
+        nb, w, cap = int(r.max_batch), self._width, int(r.out_capacity)
+        dv = self.device
+        self._rb = {
+            "req_keys": _dev_view(r.req_keys, (nb,), torch.int32, dv),
+            "req_ver": _dev_view(r.req_versions, (nb,), torch.int64, dv),
+            "pull": _dev_view(r.inbox_pull, (nb,), torch.int32, dv),
+            "idx": _dev_view(r.inbox_idx, (nb,), torch.int32, dv),
+            "ver": _dev_view(r.inbox_versions, (nb,), torch.int64, dv),
+            "rows": _dev_view(r.inbox_rows, (nb, w), torch.float32, dv),
+            "out_keys": _dev_view(r.out_keys, (cap,), torch.int32, dv),
+            "out_upd": _dev_view(r.out_updates, (cap,), torch.int32, dv),
+            "out_rows": _dev_view(r.out_rows, (cap, w), torch.float32, dv),
+        }
+        self._remote = store
+
+    def _sync_request(self, u):
+        b = self._rb
+        self._remote.sync(b["req_keys"][:u], b["req_ver"][:u], self._pull_bound, b["pull"][:u], b["idx"][:u],
+                          b["ver"][:u], b["rows"])
+
+    def _push_outbox(self, s):
+        cnt = ctypes.c_int64(0)
+        check(self._L.ha_cache_outbox_count(self._h, ctypes.byref(cnt), ctypes.c_void_p(s.cuda_stream)),
+              "ha_cache_outbox_count")
+        m = int(cnt.value)
+        b = self._rb
+        self._remote.push(b["out_keys"][:m], b["out_upd"][:m], b["out_rows"][:m])
+
+    def _lookup_remote(self, keys, dest):
+        keep = []
+        s = self._stream()
+        with torch.cuda.stream(s):
+            k, kind = self._keys(keys, keep)
+            host_dest = None
+            if isinstance(dest, np.ndarray):
+                host_dest = dest
+                dest = torch.empty((k.numel(), self._width), dtype=torch.float32, device=self.device)
+            assert dest.numel() == k.numel() * self._width and dest.dtype == torch.float32
+            u = ctypes.c_int64(0)
+            check(self._L.ha_cache_lookup_begin(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
+                                                ctypes.byref(u), ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup_begin")
+            self._sync_request(int(u.value))
+            check(self._L.ha_cache_lookup_finish(self._h, k.numel(), ctypes.c_void_p(dest.data_ptr()),
+                                                 ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup_finish")
+            self._last_lookup = None
+            if self.perf_enabled:
+                self._perf_record(0)
+            w = Wait(s, keep + [k, dest])
+            if host_dest is not None:
+                w._after = (lambda hd=host_dest, dd=dest: np.copyto(hd.reshape(dd.shape), dd.cpu().numpy()))
+        return w
+
+    def _update_remote(self, keys, grads, push_keys):
+        keep = []
+        s = self._stream()
+        with torch.cuda.stream(s):
+            k, kind = self._keys(keys, keep)
+            g = self._grads(grads, keep)
+            assert g.numel() == k.numel() * self._width
+            if push_keys is None:
+                check(self._L.ha_cache_update(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
+                                              ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
+                      "ha_cache_update")
+            else:
+                pk, pkind = self._keys(push_keys, keep)
+                check(self._L.ha_cache_update_with_push_keys(
+                    self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(), ctypes.c_void_p(pk.data_ptr()), pkind,
+                    pk.numel(), ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
+                    "ha_cache_update_with_push_keys")
+            self._push_outbox(s)
+            if self.perf_enabled:
+                self._perf_record(1)
+            return Wait(s, keep + [k, g])
+
+    def _push_pull_remote(self, pullkeys, dest, pushkeys, grads):
+        keep = []
+        s = self._stream()
+        with torch.cuda.stream(s):
+            pk, pkind = self._keys(pullkeys, keep)
+            sk, skind = self._keys(pushkeys, keep)
+            g = self._grads(grads, keep)
+            assert dest.is_cuda and dest.dtype == torch.float32 and dest.numel() == pk.numel() * self._width
+            u = ctypes.c_int64(0)
+            check(self._L.ha_cache_push_pull_begin(self._h, ctypes.c_void_p(pk.data_ptr()), pkind, pk.numel(),
+                                                   ctypes.c_void_p(sk.data_ptr()), skind, sk.numel(),
+                                                   ctypes.c_void_p(g.data_ptr()), ctypes.byref(u),
+                                                   ctypes.c_void_p(s.cuda_stream)), "ha_cache_push_pull_begin")
+            self._push_outbox(s)                 # the server pushes before it syncs
+            self._sync_request(int(u.value))
+            check(self._L.ha_cache_push_pull_finish(self._h, ctypes.c_void_p(dest.data_ptr()),
+                                                    ctypes.c_void_p(s.cuda_stream)), "ha_cache_push_pull_finish")
+            return Wait(s, keep + [pk, sk, g, dest])
 
     # ---- properties of the reference ----------------------------------------------------------------------
     @property
@@ -182,6 +286,8 @@ class _CacheBase:
     # ---- batch API ---------------------------------------------------------------------------------------------------
     def embedding_lookup(self, keys, dest):
         """dest[i,:] = line(keys[i]).data after the staleness-bounded pull (cache.cc:60-107)."""
+        if self._remote is not None:
+            return self._lookup_remote(keys, dest)
         keep = []
         s = self._stream()
         with torch.cuda.stream(s):
@@ -197,7 +303,7 @@ class _CacheBase:
                                           ctypes.c_void_p(dest.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
                   "ha_cache_lookup")
             # an update of the very same (unmodified) device key tensor can reuse this call's index plan
-            self._last_lookup = None if keep else (k.data_ptr(), k.numel(), k._version)
+            self._last_lookup = None if keep else (k.data_ptr(), k.numel())
             if self.perf_enabled:
                 self._perf_record(0)
             w = Wait(s, keep + [k, dest])
@@ -214,15 +320,23 @@ class _CacheBase:
         assert grads.dtype == torch.float32 and grads.is_contiguous()
         return grads
 
-    def embedding_update(self, keys, grads):
-        """Line::accumulate per occurrence + bounded push (cache.cc:132-197)."""
+    def embedding_update(self, keys, grads, same_as_lookup=False):
+        """Line::accumulate per occurrence + bounded push (cache.cc:132-197).  same_as_lookup=True: the
+        caller states that `keys` is the very batch of the embedding_lookup that precedes this call (same
+        tensor, contents unchanged); the update then reuses that call's index plan instead of sorting the
+        keys again.  It is explicit because a tensor's identity says nothing about its contents when
+        raw-pointer writers (HIP kernels, DLPack aliases) fill it."""
+        if self._remote is not None:
+            return self._update_remote(keys, grads, None)
         keep = []
         s = self._stream()
         with torch.cuda.stream(s):
             k, kind = self._keys(keys, keep)
             g = self._grads(grads, keep)
             assert g.numel() == k.numel() * self._width
-            same = k.numel() > 0 and self._last_lookup == (k.data_ptr(), k.numel(), k._version)
+            same = bool(same_as_lookup) and k.numel() > 0 and self._last_lookup == (k.data_ptr(), k.numel())
+            if same_as_lookup and not same:
+                raise ValueError("same_as_lookup=True, but no embedding_lookup of this key tensor precedes")
             self._last_lookup = None
             if same:
                 check(self._L.ha_cache_update_same_keys(self._h, k.numel(), ctypes.c_void_p(g.data_ptr()),
@@ -238,6 +352,8 @@ class _CacheBase:
 
     def embedding_update_with_push_keys(self, keys, push_keys, grads):
         """As embedding_update, the push set being the lines listed in the (sorted) push keys (cache.cc:248-335)."""
+        if self._remote is not None:
+            return self._update_remote(keys, grads, push_keys)
         self._last_lookup = None
         keep = []
         s = self._stream()
@@ -255,6 +371,8 @@ class _CacheBase:
 
     def embedding_push_pull(self, pullkeys, dest, pushkeys, grads):
         """Push the gradients of pushkeys, then pull pullkeys into dest (cache.cc:356-422)."""
+        if self._remote is not None:
+            return self._push_pull_remote(pullkeys, dest, pushkeys, grads)
         self._last_lookup = None
         keep = []
         s = self._stream()
@@ -353,6 +471,21 @@ class _CacheBase:
             self.size(), self._limit, self.node_id, self._width, self._pull_bound, self._push_bound)
 
 
+class _DevPtr:
+    """__cuda_array_interface__ holder: lets torch wrap a device buffer the library owns (no copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _dev_view(ptr, shape, dtype, device):
+    typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.float32: "<f4"}[dtype]
+    if 0 in shape:
+        return torch.empty(shape, dtype=dtype, device=device)
+    return torch.as_tensor(_DevPtr(ptr, shape, typestr), device=device)
+
+
 _HIP = None
 
 
@@ -390,6 +523,13 @@ class CacheSparseTable:
         self.cache.pull_bound = bound
         self.cache.push_bound = bound
 
+    @classmethod
+    def wrap(cls, cache):
+        """CacheSparseTable around an existing cache object (e.g. one bound to a remote store)."""
+        t = cls.__new__(cls)
+        t.cache = cache
+        return t
+
     def _finish(self, wait, sync):
         if sync:
             wait.wait()
@@ -400,8 +540,8 @@ class CacheSparseTable:
             keys = keys[0]
         return self._finish(self.cache.embedding_lookup(keys, dest), sync)
 
-    def embedding_update(self, keys, grads, sync=False):
-        return self._finish(self.cache.embedding_update(keys, grads), sync)
+    def embedding_update(self, keys, grads, sync=False, same_as_lookup=False):
+        return self._finish(self.cache.embedding_update(keys, grads, same_as_lookup=same_as_lookup), sync)
 
     def embedding_update_with_push_keys(self, keys, push_keys, grads, sync=False):
         return self._finish(self.cache.embedding_update_with_push_keys(keys, push_keys, grads), sync)

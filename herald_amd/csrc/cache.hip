@@ -69,6 +69,7 @@ struct CacheCtl {
     long long scan_victim; // slot of the lowest (use, stamp) line outside the lowest bucket, or -1
     // last op report: type(0 pull,1 push), num_all, num_unique, num_miss, num_transfered, num_evict, is_full
     long long perf[8];
+    long long out_n;       // remote mode: outbox entries of the last update (U + E), -1 on overflow
 };
 
 struct Cache {
@@ -104,7 +105,23 @@ struct Cache {
     float *table;
     long long *srv_ver;
     int64_t store_rows, row_start;
+    // REMOTE store (rows owned by other ranks, or kept in host memory): the cache never touches the store
+    // itself.  A lookup exports (key, cached version) of its unique keys, the store's owner takes
+    // syncEmbedding's decision and the answer arrives in the INBOX; an update leaves the lines to push
+    // (pushEmbedding) in the OUTBOX.  herald_amd/cache.py moves both (sharded.py exchange / host staging).
+    int remote;
+    uint32_t *req_keys;    // [nmax] unique keys of the batch
+    long long *req_ver;    // [nmax] cached version of each (-1: no data yet)
+    int32_t *inbox_pull;   // [nmax] the owner's decision (1 = row follows)
+    int32_t *inbox_idx;    // [nmax] its row in inbox_rows
+    long long *inbox_ver;  // [nmax] server version of the row
+    float *inbox_rows;     // [nmax, width]
+    int64_t out_cap;       // outbox entries: batch lines at [0, U), pending evicted lines at [U, U + E)
+    uint32_t *out_keys;    // kNoPush = entry not pushed
+    int32_t *out_upd;
+    float *out_rows;       // [out_cap, width]
 };
+constexpr uint32_t kNoPush = 0xFFFFFFFFu;
 
 #define CACHE_GRID(n) dim3(static_cast<unsigned>(((n) + 255) / 256 > 2048 ? 2048 : ((n) + 255) / 256 < 1 ? 1 : ((n) + 255) / 256))
 
@@ -312,14 +329,23 @@ __global__ __launch_bounds__(256) void cache_sync_kernel(CacheCtl *ctl, Cache c,
         const int s = c.uslot[u];
         const uint32_t k = uniq[u];
         const long long lk = static_cast<long long>(k) - c.row_start;
-        if (lk < 0 || lk >= c.store_rows)
-            continue;
-        const long long v = c.version[s];
-        const long long sv = c.srv_ver[lk];
-        if (!(v == -1 || sv - v > c.pull_bound))
-            continue;
+        long long sv;
+        const float *src;
+        if (c.remote) {   // the owner took the decision (ha_store_serve_sync); its answer is in the inbox
+            if (!c.inbox_pull[u])
+                continue;
+            sv = c.inbox_ver[u];
+            src = c.inbox_rows + static_cast<long long>(c.inbox_idx[u]) * c.width;
+        } else {
+            if (lk < 0 || lk >= c.store_rows)
+                continue;
+            const long long v = c.version[s];
+            sv = c.srv_ver[lk];
+            if (!(v == -1 || sv - v > c.pull_bound))
+                continue;
+            src = c.table + lk * c.width;
+        }
         const bool hg = c.hasgrad[s] != 0;
-        const float *src = c.table + lk * c.width;
         float *dst = c.data + static_cast<long long>(s) * c.width;
         const float *g = c.grad + static_cast<long long>(s) * c.width;
         for (long long j = lane; j < c.width; j += kWave) {
@@ -723,7 +749,8 @@ __global__ __launch_bounds__(256) void cache_lookup_rows_kernel(
         return;
     }
     const bool hg = c.hasgrad[s] != 0;
-    const float *src = c.table + lk * c.width;
+    const float *src = c.remote ? c.inbox_rows + static_cast<long long>(c.inbox_idx[u]) * c.width
+                                : c.table + lk * c.width;
     const float *g = c.grad + static_cast<long long>(s) * c.width;
     if (VEC == 4) {
         for (long long j = lane * 4; j < c.width; j += kWave * 4) {
@@ -748,7 +775,7 @@ __global__ __launch_bounds__(256) void cache_lookup_rows_kernel(
         }
     }
     if (head && lane == 0)
-        c.version[s] = c.srv_ver[lk];
+        c.version[s] = c.remote ? c.inbox_ver[u] : c.srv_ver[lk];
 }
 
 // ---- update ----------------------------------------------------------------------------------------
@@ -870,6 +897,19 @@ __global__ __launch_bounds__(256) void cache_update_flags_push_kernel(
             c.pushflag[u] = push ? 1 : 0;
             c.flag[u] = push ? 1u : 0u;
         }
+        if (c.remote) {   // outbox entry u: the line's gradient row and update count, or "not pushed"
+            if (lane == 0) {
+                c.out_keys[u] = push ? k : kNoPush;
+                c.out_upd[u] = upd;
+            }
+            if (push) {
+                const float *g = c.grad + static_cast<long long>(s) * c.width;
+                float *o = c.out_rows + static_cast<long long>(u) * c.width;
+                for (long long j = lane; j < c.width; j += kWave)
+                    o[j] = g[j];
+            }
+            continue;
+        }
         if (!push)
             continue;
         const long long lk = static_cast<long long>(k) - c.row_start;
@@ -890,9 +930,25 @@ __global__ __launch_bounds__(256) void cache_update_flags_push_kernel(
 __global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl *ctl, Cache c) {
     const int En = static_cast<int>(ctl->evict_n);
     const int lane = lane_id();
+    if (c.remote && blockIdx.x == 0 && threadIdx.x == 0)
+        c.ctl->out_n = ctl->U + En <= c.out_cap ? ctl->U + En : -1;
     for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < En; j += gridDim.x * 4) {
         const int s = c.evict_slots[j];
         const uint32_t k = c.key[s];
+        if (c.remote) {   // one outbox entry per evicted line, in eviction order behind the batch's lines
+            const long long e = ctl->U + j;
+            if (e < c.out_cap) {
+                if (lane == 0) {
+                    c.out_keys[e] = k;
+                    c.out_upd[e] = c.updates[s];
+                }
+                const float *g = c.grad + static_cast<long long>(s) * c.width;
+                float *o = c.out_rows + e * c.width;
+                for (long long q = lane; q < c.width; q += kWave)
+                    o[q] = g[q];
+            }
+            continue;
+        }
         bool earlier = false;
         for (int b = 0; b < j && !earlier; b += kWave) {
             const int t = b + lane;
@@ -1064,6 +1120,7 @@ struct ha_cache {
     Cache c;
     std::vector<void *> allocs;
     int64_t plan_n = -1;   // n of the lookup whose plan is still in plan_ws (ha_cache_update_same_keys)
+    int64_t pp_pull = -1, pp_push = 0;   // sizes of the push_pull between its begin and finish (remote store)
 };
 
 extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
@@ -1218,9 +1275,131 @@ static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hi
     return ha_plan_build_u64ids(static_cast<const uint64_t *>(keys), n, c.plan_ws, s);
 }
 
+// ---- remote store: inbox / outbox ------------------------------------------------------------------------
+// request of a lookup: (key, cached version) of every unique key -- what the reference's client hands to
+// syncEmbedding (hetu_client.cc:6-23: keys + the lines' versions)
+__global__ __launch_bounds__(256) void cache_export_req_kernel(Cache c, const PlanHeader *hdr,
+                                                               const uint32_t *uniq) {
+    const int U = static_cast<int>(hdr->n_unique);
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
+        const int s = c.uslot[u];
+        c.req_keys[u] = uniq[u];
+        c.req_ver[u] = s >= 0 ? c.version[s] : -1;
+    }
+}
+
+extern "C" int ha_cache_set_remote(ha_cache *h) {
+    HA_REQUIRE(h, "cache_set_remote: null handle");
+    Cache &c = h->c;
+    if (c.remote)
+        return 0;
+    c.out_cap = 5 * c.nmax;
+    bool ok = true;
+#define REMOTE_ALLOC(field, count)                                                  \
+    do {                                                                            \
+        if (ok && dmalloc(&c.field, static_cast<size_t>(count)) != 0)               \
+            ok = false;                                                             \
+        else if (ok)                                                                \
+            h->allocs.push_back(c.field);                                           \
+    } while (0)
+    REMOTE_ALLOC(req_keys, c.nmax);
+    REMOTE_ALLOC(req_ver, c.nmax);
+    REMOTE_ALLOC(inbox_pull, c.nmax);
+    REMOTE_ALLOC(inbox_idx, c.nmax);
+    REMOTE_ALLOC(inbox_ver, c.nmax);
+    REMOTE_ALLOC(inbox_rows, c.nmax * c.width);
+    REMOTE_ALLOC(out_keys, c.out_cap);
+    REMOTE_ALLOC(out_upd, c.out_cap);
+    REMOTE_ALLOC(out_rows, c.out_cap * c.width);
+#undef REMOTE_ALLOC
+    HA_REQUIRE(ok, "cache_set_remote: out of device memory");
+    c.remote = 1;
+    return 0;
+}
+
+extern "C" int ha_cache_remote_buffers(ha_cache *h, ha_cache_remote *out) {
+    HA_REQUIRE(h && out && h->c.remote, "cache_remote_buffers: the cache is not in remote-store mode");
+    const Cache &c = h->c;
+    out->req_keys = c.req_keys;
+    out->req_versions = reinterpret_cast<int64_t *>(c.req_ver);
+    out->inbox_pull = c.inbox_pull;
+    out->inbox_idx = c.inbox_idx;
+    out->inbox_versions = reinterpret_cast<int64_t *>(c.inbox_ver);
+    out->inbox_rows = c.inbox_rows;
+    out->out_keys = c.out_keys;
+    out->out_updates = c.out_upd;
+    out->out_rows = c.out_rows;
+    out->out_capacity = c.out_cap;
+    out->max_batch = c.nmax;
+    return 0;
+}
+
+// first half of a lookup against a remote store: plan, probe, request export.  *n_unique_host (optional)
+// receives the number of unique keys = request entries (synchronises the stream).
+extern "C" int ha_cache_lookup_begin(ha_cache *h, const void *keys, int key_kind, int64_t n,
+                                     int64_t *n_unique_host, ha_stream_t stream) {
+    HA_REQUIRE(h && h->c.remote, "cache_lookup_begin: the cache is not in remote-store mode");
+    HA_REQUIRE(n >= 0 && (n == 0 || keys), "cache_lookup_begin: bad arguments");
+    Cache &c = h->c;
+    hipStream_t s = as_stream(stream);
+    int probed = 0;
+    if (cache_plan(h, keys, key_kind, n, s, 0, &probed))
+        return -1;
+    h->plan_n = n;
+    PlanPtrs p = plan_layout(c.plan_ws, n);
+    if (!probed)   // larger batches: the plan was built unfused, probe separately
+        hipLaunchKernelGGL(cache_probe_kernel, CACHE_GRID(n), dim3(256), 0, s, c.ctl, p.hdr, p.uniq, c.slot_of,
+                           (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
+    hipLaunchKernelGGL(cache_export_req_kernel, CACHE_GRID(n), dim3(256), 0, s, c, p.hdr, p.uniq);
+    HA_LAUNCH_CHECK();
+    if (n_unique_host) {
+        HA_CHECK_HIP(hipMemcpyAsync(n_unique_host, &p.hdr->n_unique, 8, hipMemcpyDeviceToHost, s));
+        HA_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+// second half: the inbox holds the owner's answer for the request of ha_cache_lookup_begin
+extern "C" int ha_cache_lookup_finish(ha_cache *h, int64_t n, float *dest, ha_stream_t stream) {
+    HA_REQUIRE(h && h->c.remote, "cache_lookup_finish: the cache is not in remote-store mode");
+    HA_REQUIRE(h->plan_n == n && (n == 0 || dest), "cache_lookup_finish: no ha_cache_lookup_begin of %ld keys precedes",
+               (long)n);
+    Cache c = h->c;
+    c.data_row = c.inbox_pull;   // the decisions the bookkeeping and the row kernel read
+    hipStream_t s = as_stream(stream);
+    PlanPtrs p = plan_layout(c.plan_ws, n);
+    hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
+                       (long long)n, c.bypass ? 1 : 0, 1);
+    if (n > 0) {
+        const unsigned blocks = static_cast<unsigned>((n + 3) / 4);
+        const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0);
+        if (vec_ok)
+            hipLaunchKernelGGL(cache_lookup_rows_kernel<4>, dim3(blocks), dim3(256), 0, s, c, p.uniq, p.upos,
+                               p.perm, (long long)n, dest);
+        else
+            hipLaunchKernelGGL(cache_lookup_rows_kernel<1>, dim3(blocks), dim3(256), 0, s, c, p.uniq, p.upos,
+                               p.perm, (long long)n, dest);
+    }
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+// entries of the outbox the last ha_cache_update* left (synchronises the stream)
+extern "C" int ha_cache_outbox_count(ha_cache *h, int64_t *count_host, ha_stream_t stream) {
+    HA_REQUIRE(h && h->c.remote && count_host, "cache_outbox_count: the cache is not in remote-store mode");
+    long long v = 0;
+    HA_CHECK_HIP(hipMemcpyAsync(&v, &h->c.ctl->out_n, 8, hipMemcpyDeviceToHost, as_stream(stream)));
+    HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    HA_REQUIRE(v >= 0, "cache outbox overflow: more pending evicted lines than the outbox holds (%ld entries)",
+               (long)h->c.out_cap);
+    *count_host = v;
+    return 0;
+}
+
 extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int64_t n,
                                float *dest, ha_stream_t stream) {
-    HA_REQUIRE(h && h->c.table, "cache_lookup: no store bound");
+    HA_REQUIRE(h && h->c.table && !h->c.remote, "cache_lookup: no local store bound (remote stores use "
+               "ha_cache_lookup_begin / ha_cache_lookup_finish)");
     HA_REQUIRE(n >= 0 && (n == 0 || (keys && dest)), "cache_lookup: bad arguments");
     Cache &c = h->c;
     hipStream_t s = as_stream(stream);
@@ -1252,7 +1431,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
                              const float *grads, const void *push_keys, int push_kind,
                              int64_t n_push, int with_push_keys, hipStream_t s,
                              bool defer_cleanup = false) {
-    HA_REQUIRE(h && h->c.table, "cache_update: no store bound");
+    HA_REQUIRE(h && (h->c.table || h->c.remote), "cache_update: no store bound");
     HA_REQUIRE(n >= 0 && (n == 0 || grads), "cache_update: bad arguments");
     Cache &c = h->c;
     // keys == nullptr: the batch of the preceding ha_cache_lookup, whose plan is still in the workspace
@@ -1328,16 +1507,7 @@ extern "C" int ha_cache_update_with_push_keys(ha_cache *h, const void *keys, int
 // (touch, accumulate, push incl. pending evictions) on scratch set A, then -- as
 // PSHandler::serve(kPushSyncEmbedding) pushes before it syncs (PSFhandle_embedding.cc:66-79) -- the
 // staleness-bounded pull, the copy to dest and the insert of the pull misses.
-extern "C" int ha_cache_push_pull(ha_cache *h, const void *pull_keys, int pull_kind, int64_t n_pull,
-                                  float *dest, const void *push_keys, int push_kind, int64_t n_push,
-                                  const float *grads, ha_stream_t stream) {
-    HA_REQUIRE(h && h->c.table, "cache_push_pull: no store bound");
-    HA_REQUIRE(n_pull >= 0 && n_push >= 0 && n_pull <= h->c.nmax && n_push <= h->c.nmax,
-               "cache_push_pull: bad sizes");
-    HA_REQUIRE((n_pull == 0 || (pull_keys && dest)) && (n_push == 0 || (push_keys && grads)),
-               "cache_push_pull: null pointer");
-    Cache &c = h->c;
-    hipStream_t s = as_stream(stream);
+static Cache scratch_b_view(const Cache &c) {
     Cache cb = c;  // view with the B scratch set
     cb.plan_ws = c.plan_ws_b;
     cb.uslot = c.uslot_b;
@@ -1345,6 +1515,20 @@ extern "C" int ha_cache_push_pull(ha_cache *h, const void *pull_keys, int pull_k
     cb.flag = c.flag_b;
     cb.rank = c.rank_b;
     cb.pushflag = c.pushflag_b;
+    return cb;
+}
+
+// pull phase part 1 + the push phase.  Local store: the push lands in the table; remote: in the outbox,
+// and the request of the pull keys is exported.
+static int push_pull_begin(ha_cache *h, const void *pull_keys, int pull_kind, int64_t n_pull,
+                           const void *push_keys, int push_kind, int64_t n_push, const float *grads,
+                           hipStream_t s) {
+    HA_REQUIRE(n_pull >= 0 && n_push >= 0 && n_pull <= h->c.nmax && n_push <= h->c.nmax,
+               "cache_push_pull: bad sizes");
+    HA_REQUIRE((n_pull == 0 || pull_keys) && (n_push == 0 || (push_keys && grads)),
+               "cache_push_pull: null pointer");
+    Cache &c = h->c;
+    Cache cb = scratch_b_view(c);
     const dim3 b(256);
     // ---- pull phase, part 1
     if (pull_kind == 0 ? ha_plan_build_f32ids(static_cast<const float *>(pull_keys), n_pull, cb.plan_ws, s)
@@ -1366,10 +1550,21 @@ extern "C" int ha_cache_push_pull(ha_cache *h, const void *pull_keys, int pull_k
     // ---- push phase (a complete embedding_update on scratch set A)
     if (cache_update_impl(h, push_keys, push_kind, n_push, grads, nullptr, 0, 0, 0, s, true))
         return -1;
-    // ---- pull phase, part 2
+    // ---- pull phase, part 2 starts: restore the parked pull state
     hipLaunchKernelGGL(cache_park_kernel, dim3(1), dim3(1), 0, s, c.ctl, 2);  // park the push phase's U
     hipLaunchKernelGGL(cache_retire_kernel, dim3(1), dim3(1), 0, s, c.ctl, 0);
     hipLaunchKernelGGL(cache_park_kernel, dim3(1), dim3(1), 0, s, c.ctl, 1);
+    if (c.remote)   // the request: the pull keys and the versions their lines hold AFTER the push phase
+        hipLaunchKernelGGL(cache_export_req_kernel, CACHE_GRID(n_pull), b, 0, s, cb, pp.hdr, pp.uniq);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+static int push_pull_finish(ha_cache *h, int64_t n_pull, float *dest, int64_t n_push, hipStream_t s) {
+    Cache &c = h->c;
+    Cache cb = scratch_b_view(c);
+    const dim3 b(256);
+    PlanPtrs pp = plan_layout(cb.plan_ws, n_pull);
     hipLaunchKernelGGL(cache_sync_kernel, CACHE_GRID(n_pull * 64), b, 0, s, c.ctl, cb, pp.uniq);
     if (n_pull > 0)
         hipLaunchKernelGGL(cache_dest_kernel, CACHE_GRID(n_pull * c.width), b, 0, s, cb, pp.inverse,
@@ -1384,6 +1579,46 @@ extern "C" int ha_cache_push_pull(ha_cache *h, const void *pull_keys, int pull_k
     hipLaunchKernelGGL(cache_update_cleanup_kernel, CACHE_GRID(n_push * 64), b, 0, s, c.ctl, c, 0);
     HA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int ha_cache_push_pull(ha_cache *h, const void *pull_keys, int pull_kind, int64_t n_pull,
+                                  float *dest, const void *push_keys, int push_kind, int64_t n_push,
+                                  const float *grads, ha_stream_t stream) {
+    HA_REQUIRE(h && h->c.table && !h->c.remote, "cache_push_pull: needs a local store (over a remote store: "
+               "ha_cache_push_pull_begin, the exchange, ha_cache_push_pull_finish)");
+    HA_REQUIRE(n_pull == 0 || dest, "cache_push_pull: null dest");
+    hipStream_t s = as_stream(stream);
+    if (push_pull_begin(h, pull_keys, pull_kind, n_pull, push_keys, push_kind, n_push, grads, s))
+        return -1;
+    return push_pull_finish(h, n_pull, dest, n_push, s);
+}
+
+// embedding_push_pull over a remote store.  begin: pull phase part 1 + push phase; the OUTBOX holds the
+// lines to push (ha_cache_outbox_count), the REQUEST the pull keys.  The host pushes the outbox, then
+// syncs the request (the server pushes before it syncs, PSFhandle_embedding.cc:66-79), then calls finish.
+extern "C" int ha_cache_push_pull_begin(ha_cache *h, const void *pull_keys, int pull_kind, int64_t n_pull,
+                                        const void *push_keys, int push_kind, int64_t n_push,
+                                        const float *grads, int64_t *n_unique_pull_host, ha_stream_t stream) {
+    HA_REQUIRE(h && h->c.remote, "cache_push_pull_begin: the cache is not in remote-store mode");
+    hipStream_t s = as_stream(stream);
+    if (push_pull_begin(h, pull_keys, pull_kind, n_pull, push_keys, push_kind, n_push, grads, s))
+        return -1;
+    h->pp_pull = n_pull;
+    h->pp_push = n_push;
+    if (n_unique_pull_host) {
+        PlanPtrs pp = plan_layout(h->c.plan_ws_b, n_pull);
+        HA_CHECK_HIP(hipMemcpyAsync(n_unique_pull_host, &pp.hdr->n_unique, 8, hipMemcpyDeviceToHost, s));
+        HA_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+extern "C" int ha_cache_push_pull_finish(ha_cache *h, float *dest, ha_stream_t stream) {
+    HA_REQUIRE(h && h->c.remote && h->pp_pull >= 0, "cache_push_pull_finish: no ha_cache_push_pull_begin precedes");
+    HA_REQUIRE(h->pp_pull == 0 || dest, "cache_push_pull_finish: null dest");
+    const int64_t n_pull = h->pp_pull, n_push = h->pp_push;
+    h->pp_pull = -1;
+    return push_pull_finish(h, n_pull, dest, n_push, as_stream(stream));
 }
 
 // out[8]: last op report {type, num_all, num_unique, num_miss, num_transfered, num_evict, is_full, size}

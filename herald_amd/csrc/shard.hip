@@ -161,3 +161,141 @@ extern "C" int ha_shard_serve_push(float *table, int64_t rows, int64_t width, co
         return -1;
     return ha_sgd_apply_finish(table, rows, width, plan_ws, n, values, -1.0f, stream);
 }
+
+// ---- owner side of the cache protocol over a sharded / host-resident store --------------------------------
+// kSyncEmbedding (ps-lite/src/PSFhandle_embedding.cc:30-64): for every requested (key, client version) the
+// server answers "pull" when the client has no data (version -1) or lags by more than the bound, and then
+// returns its version and the row.  One workgroup takes the decisions and packs the answer positions in
+// request order (running prefix over chunks of 1024 requests); a second launch copies the pulled rows,
+// one wave per row.
+namespace ha {
+
+__global__ __launch_bounds__(1024) void store_sync_decide_kernel(
+    const long long *__restrict__ srv_ver, long long rows, const uint32_t *__restrict__ keys,
+    const long long *__restrict__ versions, long long m, long long bound, int32_t *__restrict__ pull,
+    int32_t *__restrict__ idx, long long *__restrict__ ver_out, long long *__restrict__ count) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    if (tid == 0)
+        s_base = 0;
+    __syncthreads();
+    for (long long c0 = 0; c0 < m; c0 += 1024) {
+        const long long j = c0 + tid;
+        int p = 0;
+        long long sv = 0;
+        if (j < m) {
+            const uint32_t k = keys[j];
+            if (k < static_cast<unsigned long long>(rows)) {
+                sv = srv_ver[k];
+                const long long v = versions[j];
+                p = (v == -1 || sv - v > bound) ? 1 : 0;
+            }
+        }
+        // exclusive scan of p over the chunk
+        uint32_t x = static_cast<uint32_t>(p);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o)
+                x += y;
+        }
+        if (lane == 63)
+            s_w[w] = x;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) {
+            if (k < w)
+                woff += s_w[k];
+            tot += s_w[k];
+        }
+        const uint32_t base = s_base;
+        if (j < m) {
+            pull[j] = p;
+            idx[j] = static_cast<int32_t>(base + woff + x - static_cast<uint32_t>(p));
+            ver_out[j] = sv;
+        }
+        __syncthreads();
+        if (tid == 0)
+            s_base = base + tot;
+        __syncthreads();
+    }
+    if (tid == 0)
+        *count = s_base;
+}
+
+__global__ __launch_bounds__(256) void store_sync_rows_kernel(
+    const float *__restrict__ table, int width, const uint32_t *__restrict__ keys,
+    const int32_t *__restrict__ pull, const int32_t *__restrict__ idx, long long m,
+    float *__restrict__ rows_out) {
+    const int lane = lane_id();
+    const long long nw = static_cast<long long>(gridDim.x) * 4;
+    for (long long j = blockIdx.x * 4ll + (threadIdx.x >> 6); j < m; j += nw) {
+        if (!pull[j])
+            continue;
+        const float *src = table + static_cast<uint64_t>(keys[j]) * static_cast<uint64_t>(width);
+        float *dst = rows_out + static_cast<uint64_t>(idx[j]) * static_cast<uint64_t>(width);
+        if ((width & 3) == 0 && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(rows_out)) & 15) == 0) {
+            for (int c = lane * 4; c < width; c += kWave * 4)
+                st4(dst + c, ld4(src + c));
+        } else {
+            for (int c = lane; c < width; c += kWave)
+                dst[c] = src[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void store_add_versions_kernel(long long *__restrict__ srv_ver, long long rows,
+                                                                 const uint32_t *__restrict__ keys,
+                                                                 const int32_t *__restrict__ updates, long long m) {
+    for (long long j = blockIdx.x * 256ll + threadIdx.x; j < m; j += gridDim.x * 256ll) {
+        const uint32_t k = keys[j];
+        if (k < static_cast<unsigned long long>(rows))   // integer adds: any order gives the same sum
+            atomicAdd(reinterpret_cast<unsigned long long *>(srv_ver + k),
+                      static_cast<unsigned long long>(static_cast<long long>(updates[j])));
+    }
+}
+
+}  // namespace ha
+
+extern "C" int ha_store_serve_sync(const float *table, const int64_t *server_versions, int64_t rows,
+                                   int64_t width, const uint32_t *keys, const int64_t *versions, int64_t m,
+                                   int64_t bound, int32_t *pull, int32_t *idx, int64_t *ver_out,
+                                   float *rows_out, int64_t *count_dev, void *scan_ws, ha_stream_t stream) {
+    (void)scan_ws;
+    HA_REQUIRE(m >= 0 && rows >= 0 && width >= 1 && width < (1ll << 30), "store_serve_sync: bad sizes");
+    HA_REQUIRE(count_dev, "store_serve_sync: null count");
+    if (m == 0) {
+        HA_CHECK_HIP(hipMemsetAsync(count_dev, 0, 8, as_stream(stream)));
+        return 0;
+    }
+    HA_REQUIRE(table && server_versions && keys && versions && pull && idx && ver_out && rows_out,
+               "store_serve_sync: null pointer");
+    hipLaunchKernelGGL(store_sync_decide_kernel, dim3(1), dim3(1024), 0, as_stream(stream),
+                       reinterpret_cast<const long long *>(server_versions), (long long)rows, keys,
+                       reinterpret_cast<const long long *>(versions), (long long)m, (long long)bound, pull, idx,
+                       reinterpret_cast<long long *>(ver_out), reinterpret_cast<long long *>(count_dev));
+    unsigned blocks = static_cast<unsigned>((m + 3) / 4);
+    if (blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(store_sync_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), table, (int)width,
+                       keys, pull, idx, (long long)m, rows_out);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ha_store_add_versions(int64_t *server_versions, int64_t rows, const uint32_t *keys,
+                                     const int32_t *updates, int64_t m, ha_stream_t stream) {
+    HA_REQUIRE(m >= 0 && rows >= 0, "store_add_versions: bad sizes");
+    if (m == 0)
+        return 0;
+    HA_REQUIRE(server_versions && keys && updates, "store_add_versions: null pointer");
+    unsigned blocks = static_cast<unsigned>((m + 255) / 256);
+    if (blocks > 4096)
+        blocks = 4096;
+    hipLaunchKernelGGL(store_add_versions_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<long long *>(server_versions), (long long)rows, keys, updates,
+                       (long long)m);
+    HA_LAUNCH_CHECK();
+    return 0;
+}

@@ -126,13 +126,26 @@ class ParameterServerCommunicateOp:
             width = p.shape[1]
             store = p.store
             if store.world > 1:
-                # the cache kernels pull / push against a store in the same HBM; rows owned by another
-                # rank would need the exchange of sharded.py underneath them
-                raise NotImplementedError("the HET cache over a store sharded across %d ranks is not built yet; "
-                                          "use comm_mode='PS' without cstable_policy" % store.world)
-            hcache.register_table(p.id, store.table, row_start=store.starts[store.rank])
-            self.cache = hcache.CacheSparseTable(config.cache_limit, p.shape[0], width, p.id, config.cstable_policy,
-                                                 config.cache_bound, device=store.table.device)
+                # the table is sharded over the ranks: the cache talks to the owners through the inbox /
+                # outbox exchange (remote_store.ShardedStore) -- only misses, stale lines and pushed lines
+                # cross the fabric (PSAgent.h:537-627 / PSFhandle_embedding.cc:5-79)
+                from . import remote_store
+                versions = torch.zeros(store.local_rows, dtype=torch.int64, device=store.table.device)
+                rstore = remote_store.ShardedStore(p.shape[0], width, store.table.device,
+                                                   remote_store.LocalStore(store.table, versions),
+                                                   group=store.group, a2a=store._a2a_fn)
+                cls = {"lru": hcache.LRUCache, "lfu": hcache.LFUCache, "lfuopt": hcache.LFUOptCache}[
+                    config.cstable_policy.lower()]
+                raw = cls(config.cache_limit, p.shape[0], width, node_id=-1 - p.id, device=store.table.device)
+                raw.pull_bound = raw.push_bound = config.cache_bound
+                raw.bind_remote(rstore)
+                self.cache = hcache.CacheSparseTable.wrap(raw)
+                self.remote_store = rstore
+            else:
+                hcache.register_table(p.id, store.table, row_start=store.starts[store.rank])
+                self.cache = hcache.CacheSparseTable(config.cache_limit, p.shape[0], width, p.id,
+                                                     config.cstable_policy, config.cache_bound,
+                                                     device=store.table.device)
             p.cache = self.cache
             self._push, self._pull, self._push_pull = self._push_cache, self._pull_cache, self._push_pull_cache
             if config.bsp == 0 and config.prefetch:

@@ -443,6 +443,62 @@ int ha_cache_push_pull(ha_cache *cache, const void *pull_keys, int pull_kind,
                        int64_t n_pull, float *dest, const void *push_keys,
                        int push_kind, int64_t n_push, const float *grads,
                        ha_stream_t stream);
+/* ---- the cache over a REMOTE store (rows owned by other ranks, or kept in host memory) ---------------
+ * The reference's cache never touches the table: it talks to the servers through syncEmbedding /
+ * pushEmbedding (src/hetu_cache/src/hetu_client.cc:6-39 -> ps-lite PSAgent.h:537-627 ->
+ * PSFhandle_embedding.cc:5-64).  In remote mode the cache kernels do the same through two device
+ * buffers the host side moves (herald_amd/cache.py: exchange of sharded.py, or staging from pinned
+ * host memory):
+ *   lookup  = ha_cache_lookup_begin   : plan + probe; REQUEST = (req_keys[u], req_versions[u]) for the
+ *                                       n_unique keys of the batch, ascending (version -1 = no data);
+ *             [the owner decides per key  pull = version == -1 || server_version - version > pull_bound
+ *              (kSyncEmbedding, PSFhandle_embedding.cc:30-64) and answers INBOX: inbox_pull[u], and for
+ *              pulled keys inbox_versions[u] and the row inbox_rows[inbox_idx[u], :]]
+ *             ha_cache_lookup_finish  : touch / insert / evict bookkeeping, rows to `dest`, lines refreshed.
+ *   update  = ha_cache_update* as before, except that the lines to push land in the OUTBOX instead of the
+ *             store: entries [0, U) = the batch's unique keys in ascending order (out_keys[u] = key, or
+ *             0xFFFFFFFF when that line is not pushed), entries [U, U+E) = pending evicted lines in eviction
+ *             order; out_updates = the line's update count, out_rows = its gradient row.  The owner applies
+ *             row += gradient, version += updates per entry, entries of one sender in list order
+ *             (kPushEmbedding, PSFhandle_embedding.cc:5-28).  ha_cache_outbox_count = U + E.
+ * embedding_push_pull over a remote store = update, exchange, lookup (the server pushes before it syncs,
+ * PSFhandle_embedding.cc:66-79). */
+typedef struct {
+    uint32_t *req_keys;
+    int64_t *req_versions;
+    int32_t *inbox_pull, *inbox_idx;
+    int64_t *inbox_versions;
+    float *inbox_rows;
+    uint32_t *out_keys;
+    int32_t *out_updates;
+    float *out_rows;
+    int64_t out_capacity, max_batch;
+} ha_cache_remote;
+int ha_cache_set_remote(ha_cache *cache);
+int ha_cache_remote_buffers(ha_cache *cache, ha_cache_remote *out);
+int ha_cache_lookup_begin(ha_cache *cache, const void *keys, int key_kind, int64_t n,
+                          int64_t *n_unique_host, ha_stream_t stream);
+int ha_cache_lookup_finish(ha_cache *cache, int64_t n, float *dest, ha_stream_t stream);
+int ha_cache_outbox_count(ha_cache *cache, int64_t *count_host, ha_stream_t stream);
+/* embedding_push_pull (cache.cc:356-422) over a remote store: begin = touch of the pull keys + the whole
+ * push phase (OUTBOX filled, REQUEST = the pull keys' versions after the push phase); the host pushes the
+ * outbox and then syncs the request; finish = pull, rows to dest, insert of the pull misses, the push
+ * phase's deferred version bump / zeroGrad. */
+int ha_cache_push_pull_begin(ha_cache *cache, const void *pull_keys, int pull_kind, int64_t n_pull,
+                             const void *push_keys, int push_kind, int64_t n_push,
+                             const float *grads, int64_t *n_unique_pull_host, ha_stream_t stream);
+int ha_cache_push_pull_finish(ha_cache *cache, float *dest, ha_stream_t stream);
+/* Owner side of a remote lookup (kSyncEmbedding, PSFhandle_embedding.cc:30-64) for m requested shard-local
+ * keys: pull[j] = versions[j] == -1 || server_versions[key] - versions[j] > bound; pulled rows are packed
+ * in request order into rows_out, idx[j] = its row there, ver_out[j] = the server version; *count_dev
+ * (device int64) = number of pulled rows.  scan_ws: reserved, may be NULL. */
+int ha_store_serve_sync(const float *table, const int64_t *server_versions, int64_t rows, int64_t width,
+                        const uint32_t *keys, const int64_t *versions, int64_t m, int64_t bound,
+                        int32_t *pull, int32_t *idx, int64_t *ver_out, float *rows_out,
+                        int64_t *count_dev, void *scan_ws, ha_stream_t stream);
+/* Owner side of the version half of a push: server_versions[keys[j]] += updates[j] (keys >= rows skipped). */
+int ha_store_add_versions(int64_t *server_versions, int64_t rows, const uint32_t *keys,
+                          const int32_t *updates, int64_t m, ha_stream_t stream);
 /* Synchronising inspectors.  perf out[8] = {type(0 pull / 1 push), num_all, num_unique, num_miss,
  * num_transfered, num_evict, is_full, size} of the last call (the perf dict of cache.cc:89-106).
  * state out[8] = {size, pending evictions, free slots, log head, log tail, clock, slots, log cap}. */

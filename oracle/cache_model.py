@@ -334,6 +334,12 @@ class CacheModel:
                           "num_transfered": len(should_push)})
 
     def push_pull(self, pull_keys, push_keys, grads):                          # _embeddingPushPull :356-422
+        self.push_pull_begin(pull_keys, push_keys, grads)
+        return self.push_pull_finish()
+
+    def push_pull_begin(self, pull_keys, push_keys, grads):
+        """Everything up to and including the server's push half of kPushSyncEmbedding.  (Split so that
+        the tests can interleave several workers: all pushes of a round reach the server before any sync.)"""
         pull_keys = np.asarray(pull_keys, dtype=np.uint64).reshape(-1)
         push_keys = np.asarray(push_keys, dtype=np.uint64).reshape(-1)
         grads = np.asarray(grads, dtype=np.float32).reshape(push_keys.size, self.width)
@@ -355,6 +361,11 @@ class CacheModel:
                 should_push.append(pembeds[i])
         should_push.extend(evict[it:])
         self.server.push_embedding(should_push)                                 # server: push, then sync
+        self._pp = (pull_keys, inv, embeds, should_insert, pkeys, pembeds)
+
+    def push_pull_finish(self):
+        pull_keys, inv, embeds, should_insert, pkeys, pembeds = self._pp
+        self._pp = None
         self.server.sync_embedding(embeds, self.pull_bound)                     # (PSFhandle_embedding.cc:66-79)
         dest = np.empty((pull_keys.size, self.width), dtype=np.float32)
         for j in range(pull_keys.size):

@@ -24,7 +24,9 @@ def _compare_state(gpu, model, step):
 
 
 def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_keys_mode=False, seed=0,
-               zipf=True, check_every=1, policy="lru"):
+               zipf=True, check_every=1, policy="lru", bind=None):
+    """bind(gpu_cache, table, versions): how the cache reaches its store (default: bind_store, the table in
+    the same HBM; test_gpu_cache_remote.py passes remote stores here)."""
     rng = np.random.default_rng(seed)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
     server = cache_model.Server(table0)
@@ -33,7 +35,10 @@ def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_k
     versions = torch.zeros(rows, dtype=torch.int64, device=dev)
     cls = {"lru": hcache.LRUCache, "lfu": hcache.LFUCache, "lfuopt": hcache.LFUOptCache}[policy]
     gpu = cls(limit, rows, width, node_id=0, max_batch=max(n, 64), device=dev)
-    gpu.bind_store(table, versions)
+    if bind is None:
+        gpu.bind_store(table, versions)
+    else:
+        bind(gpu, table, versions)
     gpu.pull_bound, gpu.push_bound = pull_bound, push_bound
     gpu.perf_enabled = True
     for step in range(steps):
@@ -158,6 +163,10 @@ def test_lfu_with_push_keys(dev, policy):
 @pytest.mark.parametrize("policy", ["lru", "lfu", "lfuopt"])
 def test_push_pull_trace(dev, policy):
     """embedding_push_pull (ASP prefetch): push batch k while pulling batch k+1, step by step."""
+    run_push_pull_trace(dev, policy)
+
+
+def run_push_pull_trace(dev, policy, bind=None):
     rng = np.random.default_rng(21)
     rows, width, n, limit = 300, 8, 48, 30
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
@@ -167,7 +176,10 @@ def test_push_pull_trace(dev, policy):
     versions = torch.zeros(rows, dtype=torch.int64, device=dev)
     cls = {"lru": hcache.LRUCache, "lfu": hcache.LFUCache, "lfuopt": hcache.LFUOptCache}[policy]
     gpu = cls(limit, rows, width, node_id=0, max_batch=64, device=dev)
-    gpu.bind_store(table, versions)
+    if bind is None:
+        gpu.bind_store(table, versions)
+    else:
+        bind(gpu, table, versions)
     gpu.pull_bound = gpu.push_bound = 2
     batches = [((np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1) * 31) % rows).astype(np.float32) for _ in range(40)]
     want = model.lookup(batches[0].astype(np.uint64))
@@ -186,8 +198,9 @@ def test_push_pull_trace(dev, policy):
 
 
 def test_update_of_the_looked_up_key_tensor_reuses_the_plan(dev):
-    """embedding_update(keys) right after embedding_lookup(keys) on the same unmodified device tensor
-    goes through ha_cache_update_same_keys; the result equals the two-plan path and the oracle."""
+    """embedding_update(keys, same_as_lookup=True) right after embedding_lookup(keys) on the same device
+    tensor goes through ha_cache_update_same_keys; the result equals the two-plan path.  The reuse is
+    explicit: without the flag the keys are always sorted again, whatever the tensor's identity says."""
     rng = np.random.default_rng(77)
     rows, width, n = 4000, 64, 900
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
@@ -202,15 +215,14 @@ def test_update_of_the_looked_up_key_tensor_reuses_the_plan(dev):
             grads = torch.from_numpy(np.full((n, width), 0.25 * (step + 1), dtype=np.float32)).to(dev)
             dest = torch.empty((n, width), dtype=torch.float32, device=dev)
             c.embedding_lookup(ids, dest, sync=True)
-            keys_for_update = ids if reuse else ids.clone()
             assert (c.cache._last_lookup is not None)
-            c.embedding_update(keys_for_update, grads, sync=True)
+            c.embedding_update(ids, grads, sync=True, same_as_lookup=reuse)
             assert c.cache._last_lookup is None
         torch.cuda.synchronize()
         results.append((table.cpu().numpy(), versions.cpu().numpy(), dest.cpu().numpy()))
     for a, b in zip(results[0], results[1]):
         np.testing.assert_array_equal(a, b)
-    # a modified key tensor must not reuse the stale plan
+    # without the flag a key tensor that was rewritten in place (no matter how) never meets a stale plan
     table = torch.from_numpy(table0.copy()).to(dev)
     versions = torch.zeros(rows, dtype=torch.int64, device=dev)
     hcache.register_table(40, table, versions)
@@ -218,8 +230,10 @@ def test_update_of_the_looked_up_key_tensor_reuses_the_plan(dev):
     ids = torch.arange(n, dtype=torch.int64, device=dev)
     dest = torch.empty((n, width), dtype=torch.float32, device=dev)
     c.embedding_lookup(ids, dest, sync=True)
-    ids += 1000                                   # in-place change bumps the tensor version
+    ids += 1000
     c.embedding_update(ids, torch.ones((n, width), dtype=torch.float32, device=dev), sync=True)
+    with pytest.raises(ValueError):               # the flag without a preceding lookup of that tensor
+        c.embedding_update(ids.clone(), torch.ones((n, width), dtype=torch.float32, device=dev), same_as_lookup=True)
     torch.cuda.synchronize()
     t = table.cpu().numpy()
     np.testing.assert_array_equal(t[:1000], table0[:1000])                  # untouched rows
