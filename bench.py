@@ -44,6 +44,10 @@ def parse_args():
     p.add_argument("--no-kernel-pass", action="store_true")
     p.add_argument("--no-cache-tier", action="store_true",
                    help="skip the secondary measurement of the LRU cache tier (limit 0.1 x rows)")
+    p.add_argument("--no-cold-tier", action="store_true",
+                   help="skip the secondary measurement of the host-DRAM cold tier (BASELINE configs[4] shape)")
+    p.add_argument("--cold-rows", type=int, default=33554432,
+                   help="rows of the pinned host table of the cold-tier line (x 64 floats = 8 GiB)")
     p.add_argument("--graph-steps", type=int, default=32,
                    help="steps captured per hipGraph (1 = eager launches)")
     p.add_argument("--launches", type=int, default=1, choices=(1, 2),
@@ -201,6 +205,51 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
             "limit_rows": limit, "bound": 100, "steps": steps, "unique_miss_rate": miss,
             "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
                     "(10 launches per pair, launch-latency bound); not part of `value`"}
+
+
+def cold_tier(args, dev):
+    """Secondary line, BASELINE configs[4] shape on one GPU: avazu-like power-law ids (22 fields, uint64),
+    d=64, the table in PINNED HOST DRAM (HostStore), an LRU hot tier of 0.1 x rows lines in HBM in front of
+    it (HET cache in remote-store mode): misses / stale lines are staged from the host over PCIe by the
+    owner-side kernels on a copy stream, pushed lines are written back the same way."""
+    from herald_amd import cache as hcache, remote_store, synth
+    rows, width, fields, bs = args.cold_rows, 64, 22, args.batch
+    n = bs * fields
+    store = remote_store.HostStore(rows, width, dev)
+    limit = int(0.1 * rows)
+    c = hcache.LRUCache(limit, rows, width, node_id=-7, max_batch=n, device=dev)
+    c.bind_remote(store)
+    c.pull_bound = c.push_bound = 100
+    nb = 256
+    ids = [torch.from_numpy(synth.criteo_batch(bs, 9000 + b, rows=rows, nfields=fields).reshape(-1)).to(dev)
+           for b in range(nb)]
+    out = torch.empty((n, width), dtype=torch.float32, device=dev)
+    grad = torch.randn((n, width), dtype=torch.float32, device=dev) * 1e-3
+
+    def step(k):
+        c.embedding_lookup(ids[k % nb], out)
+        c.embedding_update(ids[k % nb], grad)
+
+    for k in range(128):
+        step(k)
+    torch.cuda.synchronize()
+    store.traffic(reset=True)
+    steps = 256
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(128 + k)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tr = store.traffic()
+    return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps,
+            "workload": "power-law ids, %d fields, bs=%d, d=%d; %d-row fp32 table (%.1f GiB) in pinned host DRAM; "
+                        "LRU hot tier of %d lines in HBM (bound 100)" % (fields, bs, width, rows,
+                                                                        rows * width * 4 / 2 ** 30, limit),
+            "hot_tier_hit_rate": 1.0 - tr["rows_pulled"] / max(tr["keys_synced"], 1),
+            "rows_pulled_per_step": tr["rows_pulled"] / steps, "lines_pushed_per_step": tr["lines_pushed"] / steps,
+            "pcie_GBps": tr["pcie_bytes"] / el / 1e9, "steps": steps,
+            "note": "lookup + update per batch through the remote-store protocol (request / inbox / outbox, two "
+                    "host read-backs per call); not part of `value`"}
 
 
 def main():
@@ -432,6 +481,10 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, ids_host)
     if not args.no_cache_tier:
         result["cache_tier"] = cache_tier(args, table, ids_dev, outs[0], grads[0], dev)
+    if not args.no_cold_tier:
+        del table
+        torch.cuda.empty_cache()
+        result["cold_tier"] = cold_tier(args, dev)
     print(json.dumps(result))
 
 

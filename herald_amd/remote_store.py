@@ -88,13 +88,16 @@ class HostStore(LocalStore):
         versions = torch.zeros(rows, dtype=torch.int64, device=device)
         super().__init__(table, versions)
         self.copy_stream = stream if stream is not None else torch.cuda.Stream(device=device)
-        self.stats = {"pcie_bytes_in": 0, "pcie_bytes_out": 0, "rows_pulled": 0, "rows_pushed": 0}
+        # device-side traffic counters (no host sync on the path): keys synced, rows pulled, lines pushed
+        self._acc = torch.zeros(3, dtype=torch.int64, device=device)
 
     def sync(self, keys, versions, bound, pull, idx, ver_out, rows_out):
         cur = torch.cuda.current_stream()
         self.copy_stream.wait_stream(cur)
         with torch.cuda.stream(self.copy_stream):
             cnt = super().sync(keys, versions, bound, pull, idx, ver_out, rows_out)
+            self._acc[0] += keys.numel()
+            self._acc[1:2] += cnt
         cur.wait_stream(self.copy_stream)
         return cnt
 
@@ -103,7 +106,17 @@ class HostStore(LocalStore):
         self.copy_stream.wait_stream(cur)
         with torch.cuda.stream(self.copy_stream):
             super().push(keys, updates, rows)
+            self._acc[2] += ((keys.to(torch.int64) & 0xFFFFFFFF) < self.rows).sum()
         cur.wait_stream(self.copy_stream)
+
+    def traffic(self, reset=False):
+        """{'keys_synced', 'rows_pulled', 'lines_pushed', 'pcie_bytes'} since creation / the last reset
+        (host sync).  A pulled row crosses PCIe once, a pushed line is a read-modify-write of its row."""
+        a = self._acc.cpu().tolist()
+        if reset:
+            self._acc.zero_()
+        return {"keys_synced": a[0], "rows_pulled": a[1], "lines_pushed": a[2],
+                "pcie_bytes": 4 * self.width * (a[1] + 2 * a[2])}
 
 
 class ShardedStore:

@@ -175,3 +175,50 @@ def test_lru_cache_at_limit_0_1_on_the_full_table(dev, big_table, pull_bound, pu
     sent = table[torch.tensor(SENTINELS, device=dev)].cpu().numpy()
     np.testing.assert_array_equal(sent, formula.rows_of(SENTINELS, WIDTH))
     assert gpu.size() == model.policy.size()
+
+
+def test_cold_tier_on_an_8gib_pinned_host_table(dev):
+    """BASELINE configs[4]'s mechanism at a size beyond 8 GiB: a 33,554,432 x 64 fp32 table (8 GiB) in PINNED
+    HOST memory behind an LRU hot tier in HBM (HostStore + remote-store protocol).  The host table is a closed
+    form of (row, column); only the touched rows are compared, against oracle/cache_model.py."""
+    from herald_amd import remote_store
+    rows, width, n = 33554432, 64, 22 * 256
+    table = torch.empty((rows, width), dtype=torch.float32, pin_memory=True)
+    step = 1 << 20
+    for s in range(0, rows, step):
+        e = min(rows, s + step)
+        table[s:e] = torch.from_numpy(formula.rows_of(np.arange(s, e), width))
+    store = remote_store.HostStore(rows, width, dev, table=table)
+    limit = int(0.1 * rows)
+    server = _LazyServer(width)
+    model = cache_model.CacheModel("lru", limit, width, server, 2, 2)
+    gpu = hcache.LRUCache(limit, rows, width, node_id=0, max_batch=n, device=dev)
+    gpu.bind_remote(store)
+    gpu.pull_bound = gpu.push_bound = 2
+    gpu.perf_enabled = True
+    rng = np.random.default_rng(31)
+    for k in range(8):
+        ids = synth.criteo_batch(256, 700 + k, rows=rows, nfields=22).reshape(-1)      # int64 keys
+        want = model.lookup(ids.astype(np.uint64))
+        dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+        gpu.embedding_lookup(torch.from_numpy(ids).to(dev), dest).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % k)
+        g = rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01)
+        model.update(ids.astype(np.uint64), g)
+        gpu.embedding_update(torch.from_numpy(ids).to(dev), torch.from_numpy(g).to(dev)).wait()
+        for got, exp in zip(gpu.perf[-2:], model.perf[-2:]):
+            for fld in ("type", "num_all", "num_unique", "num_miss", "num_transfered"):
+                assert got[fld] == exp[fld], (k, fld, got, exp)
+    torch.cuda.synchronize()
+    written = sorted(server.table.rows.keys())
+    assert written and max(written) * width * 4 > (4 << 30)                     # rows beyond the 4 GiB offset
+    np.testing.assert_array_equal(table[torch.tensor(written)].numpy(), np.stack([server.table.rows[k] for k in written]),
+                                  err_msg="host rows after pushes")
+    touched = sorted(server.ver.keys())
+    np.testing.assert_array_equal(store.versions[torch.tensor(touched, device=dev)].cpu().numpy(),
+                                  np.array([server.ver[k] for k in touched], dtype=np.int64))
+    probe = [1, rows // 2 + 1, rows - 1]
+    probe = [p for p in probe if p not in set(written)]
+    np.testing.assert_array_equal(table[torch.tensor(probe)].numpy(), formula.rows_of(probe, width))
+    tr = store.traffic()
+    assert 0 < tr["rows_pulled"] <= tr["keys_synced"] and tr["lines_pushed"] > 0
