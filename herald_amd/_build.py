@@ -72,6 +72,19 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+PS_LIB = os.path.join(PKG, "libherald_ps.so")
+
+
+def build_ps_shim(force=False):
+    """libherald_ps.so: the libps.so names (include/herald_ps.h) over libherald_amd.so's ha_ps_* engine."""
+    src = os.path.join(CSRC, "libps_shim.cpp")
+    deps = [src, os.path.join(ROOT, "include", "herald_ps.h"), os.path.join(ROOT, "include", "herald_amd.h"), LIB]
+    if force or _newer(deps, PS_LIB):
+        _run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", src, "-o", PS_LIB, "-L", PKG, "-lherald_amd",
+              "-Wl,-rpath,$ORIGIN"])
+    return PS_LIB
+
+
 def build_plugins(force=False):
     """pybind11 modules `hetu_cache` and `laia_cache` (host C++ over the C-ABI) -> herald_amd/plugins/."""
     import sysconfig
@@ -124,6 +137,7 @@ def build_ref(force=False):
 
 def build_all(force=False, verbose=False):
     lib = build_lib(force=force, verbose=verbose)
+    build_ps_shim(force=force)
     build_plugins(force=force)
     build_oracle(force=force)
     build_ref(force=force)

@@ -47,12 +47,17 @@ class PlanView(ctypes.Structure):
                 ("upos", ctypes.c_void_p)]
 
 
-def declared_symbols():
-    """Names of every function include/herald_amd.h declares."""
-    text = open(HEADER_PATH).read()
+def declared_symbols(header=None):
+    """Names of every function a header of include/ declares (default: herald_amd.h)."""
+    text = open(header or HEADER_PATH).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"\(\s*\*\s*\w+\s*\)\s*\([^;{}]*\)\s*;", ";", text)   # function-pointer members of structs
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text)
-    return sorted(set(n for n in names if n not in ("defined",)))
+    return sorted(set(n for n in names if n not in ("defined", "int", "void", "float")))
+
+
+PS_LIB_PATH = os.path.join(_PKG, "libherald_ps.so")
+PS_HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "herald_ps.h")
 
 
 def load(build_if_missing=True):

@@ -578,6 +578,44 @@ int ha_sgd_sparse_update_f32ids(float *table, int64_t rows, int64_t width,
                                 const float *grads, float lr,
                                 ha_stream_t stream);
 
+/* ---- in-node parameter-server engine behind the libps names (include/herald_ps.h) --------------------
+ * ps-lite/src/python_binding.cc:6-151 -> Worker -> PSAgent (PSAgent.h:124-237) -> servers
+ * (PSFHandle.h:101-164, 401-439).  Every process owns the AveragePartitioner row range of its rank
+ * (partitioner.h:46-57) of every tensor, in its GPU's HBM.  Index / value DLArrays may be device or host
+ * arrays.  Calls are asynchronous on the tensor's stream; ha_ps_wait joins it.  With nrank > 1 the sparse
+ * exchange is provided by the host side as a backend (herald_amd/ps.py registers the RCCL all-to-all of
+ * herald_amd/sharded.py); without one everything is served locally. */
+typedef struct {
+    /* ids_dev: float32 ids (global row numbers); out_dev / vals_dev: [n, width]; stream: the tensor's */
+    int (*sparse_pull)(int node, const float *ids_dev, int64_t n, float *out_dev, void *stream);
+    int (*sparse_push)(int node, const float *ids_dev, int64_t n, const float *vals_dev, void *stream);
+    int (*barrier)(void);
+} ha_ps_backend;
+typedef struct {
+    float *table;          /* this rank's rows [row_start, row_start + rows_local) */
+    int64_t len, width, row_start, rows_local;
+    void *stream;
+} ha_ps_tensor_info;
+int ha_ps_configure(int rank, int nrank);
+int ha_ps_set_backend(const ha_ps_backend *backend);
+int ha_ps_rank(void);
+int ha_ps_nrank(void);
+/* init_type: 0 Constant(a), 1 Uniform(a, b), 2 Normal(mean a, stddev b), 3 TruncatedNormal (psf/misc.h:7-12);
+ * values are a function of (seed, element index) only: the same table whatever the number of ranks */
+int ha_ps_init_tensor(int node, int ptype, int64_t len, int64_t width, int init_type,
+                      double a, double b, uint64_t seed);
+/* serve an existing device shard (rows of this rank's range) instead of allocating one */
+int ha_ps_attach_tensor(int node, float *table_dev, int64_t len, int64_t width);
+int ha_ps_tensor(int node, ha_ps_tensor_info *out);
+int ha_ps_sparse_pull(int node, const DLArray *index, DLArray *value);
+int ha_ps_sparse_push(int node, const DLArray *index, const DLArray *value);
+int ha_ps_dense_pull(int node, DLArray *arr);
+int ha_ps_wait(int node);
+int ha_ps_barrier(void);
+int ha_ps_clear(int node);
+int ha_ps_save(int node, const char *address);   /* <address>/<node>_<rank>.dat, raw fp32 rows */
+int ha_ps_load(int node, const char *address);
+
 #ifdef __cplusplus
 }
 #endif
