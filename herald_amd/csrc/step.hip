@@ -37,6 +37,9 @@ template <int MODE>
 int apply_finish_entry(float *dst, int64_t rows, int64_t width, void *plan_ws, int64_t n,
                        const float *grads, float lr, hipStream_t stream);
 
+constexpr int kGatherLoads = 2;    // sixteen-byte loads a gather lane keeps in flight: one 2 KiB row per wave at
+                                   // d = 512 (measured: 8 -> 18.4 us per step, 4 -> 16.2, 2 -> 15.6: the finer the
+                                   // waves, the less a released row waits for its wave's other rows)
 constexpr int kSpinMax = 1 << 18;   // polls of ~0.3 us each before a gather wave gives up (~0.1 s)
 
 struct StepArgs {
@@ -68,8 +71,16 @@ struct StepArgs {
     unsigned long long *dbg;  // tools/step_timeline.py only: {start, after-wait, end, role | xcc << 8} per wave
 };
 
-// One wave copies `group` consecutive positions (group * nv <= 256 sixteen-byte vectors: four loads
-// per lane in flight, the same depth as gather_vec4_body), after the rows it needs have been released.
+// the results of the inline-asm loads may be used only behind this (common.h, ld4_sc1_async)
+__device__ __forceinline__ void wait_gather_loads(float4v (&v)[2]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+}
+__device__ __forceinline__ void wait_gather_loads(float4v (&v)[4]) {
+    wait_loads(v[0], v[1], v[2], v[3]);
+}
+
+// One wave copies `group` consecutive positions (group * nv <= kGatherLoads * 64 sixteen-byte vectors, all of
+// a lane's loads in flight together), after the rows it needs have been released.
 // (Copying the released positions of a wave first and the others as they follow was measured: no gain,
 // the extra polls cost what the earlier copies save.)
 template <typename IdT>
@@ -108,11 +119,11 @@ __device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_ind
         *t_mid = __builtin_amdgcn_s_memrealtime();
     const int total = cnt * a.nv;
     float *dst = a.out + static_cast<uint64_t>(p0) * static_cast<uint64_t>(a.nv) * 4u;
-    for (int base = 0; base < total; base += 4 * kWave) {
-        float4v v[4];
-        bool okv[4];
+    for (int base = 0; base < total; base += kGatherLoads * kWave) {
+        float4v v[kGatherLoads];
+        bool okv[kGatherLoads];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kGatherLoads; ++u) {
             const int e = base + u * kWave + lane;
             const int ec = e < total ? e : total - 1;
             const int pos = a.nv_shift >= 0 ? (ec >> a.nv_shift) : (ec / a.nv);
@@ -122,9 +133,9 @@ __device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_ind
             v[u] = ld4_sc1_async(a.table + (static_cast<uint64_t>(k) * static_cast<uint64_t>(a.nv) +
                                             static_cast<uint64_t>(col)) * 4u);
         }
-        wait_loads(v[0], v[1], v[2], v[3]);
+        wait_gather_loads(v);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kGatherLoads; ++u) {
             const int e = base + u * kWave + lane;
             if (e < total)
                 st4_nt(dst + static_cast<uint64_t>(e) * 4u, okv[u] ? v[u] : float4v{0.f, 0.f, 0.f, 0.f});
@@ -134,7 +145,11 @@ __device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_ind
 
 // Block order: finish | apply | rank | gather.  Apply workgroups never wait and come before every gather
 // workgroup, so whatever a gather wave waits for is resident or ahead of it in the dispatch order.
-// (apply | gather | rank | finish and an alternating gather / rank order were measured: slower.)
+// (Measured and rejected: apply | gather | rank | finish (the rank tiles then form a 4 us tail), gather and
+// rank alternating 1:1 or 2:1 (18 us), and a second design in which the launch that sorts a batch also
+// finishes its plan behind its rank tiles and the apply maps persistent waves to UNIQUE keys from lists of
+// short / medium / long runs (20-24 us: with a few hundred persistent waves each key pays three dependent
+// round trips one after the other; one wave per sorted position has every row's loads in flight at t = 0).)
 template <typename IdT>
 __device__ __forceinline__ int step_roles(const StepArgs &a, uint32_t *s_dyn, unsigned long long *t_mid) {
     int b = blockIdx.x;
@@ -270,7 +285,10 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
             for (int s = 0; s < 30; ++s)
                 if (a.nv == (1 << s))
                     a.nv_shift = s;
-            a.group = a.nv >= 256 ? 1 : (256 / a.nv > kWave ? kWave : 256 / a.nv);
+            {
+                const int vecs = kGatherLoads * kWave;   // vectors one wave copies per round trip
+                a.group = a.nv >= vecs ? 1 : (vecs / a.nv > kWave ? kWave : vecs / a.nv);
+            }
             const int waves = (a.n_next + a.group - 1) / a.group;
             a.ngather = (waves + kPosPerBlock - 1) / kPosPerBlock;
             lds = lds > rank_small_lds_bytes(a.n_next) ? lds : rank_small_lds_bytes(a.n_next);

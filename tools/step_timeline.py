@@ -23,7 +23,7 @@ grads = [torch.randn((n, width), device=dev) for _ in range(24)]
 outs = [torch.empty((n, width), device=dev) for _ in range(24)]
 plans = [ops.IndexPlan(n, dev), ops.IndexPlan(n, dev)]
 pends = [ops.PendingTable(dev), ops.PendingTable(dev)]
-NBLK = 7 + 416 + 208 + 208 + 8
+NBLK = 2400
 dbg = torch.zeros(NBLK * 16 * 4, dtype=torch.int64, device=dev)
 ops.lookup_sort_pend(table, ids[0], plans[0], pends[0], out=outs[0])
 P = lambda t: vp(t.data_ptr())
@@ -48,7 +48,7 @@ tm = np.where(d[:, 1] > 0, (d[:, 1] - base) * 0.01, np.nan)
 t1 = (d[:, 2] - base) * 0.01
 role = d[:, 3] & 0xFF
 print("span %.2f us, waves %d" % (t1[live].max(), live.sum()))
-for r, name in enumerate(("finish", "apply", "rank", "gather")):
+for r, name in enumerate(("finish", "apply/short", "rank", "gather", "long", "medium")):
     m = live & (role == r)
     if not m.any():
         continue
@@ -63,7 +63,7 @@ print("gather wait: p50 %.2f p90 %.2f max %.2f us; waves waiting > 0.5us: %d of 
 # occupancy over time: resident waves per role in 1 us bins
 for lo in np.arange(0, t1[live].max(), 1.0):
     row = []
-    for r in range(4):
+    for r in range(6):
         mm = live & (role == r) & (t0 < lo + 1.0) & (t1 > lo)
         row.append(int(mm.sum()))
-    print("t=%4.1f us resident waves finish/apply/rank/gather: %s" % (lo, row))
+    print("t=%4.1f us resident waves finish/short/rank/gather/long/medium: %s" % (lo, row))
