@@ -23,7 +23,8 @@ def _run(extra_env, *args):
 
 
 def test_bench_n1_line_has_the_contract_fields(dev):
-    d = _run({}, "--rows", "1000000", "--steps", "256", "--warmup", "64", "--distinct-batches", "64")
+    d = _run({}, "--rows", "1000000", "--steps", "256", "--warmup", "64", "--distinct-batches", "64",
+             "--cold-rows", "2000000")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -37,17 +38,31 @@ def test_bench_n1_line_has_the_contract_fields(dev):
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "rows/s"
     assert d["value"] > 20 * cb["value"]
     assert d["cache_tier"]["value"] > 0
+    ct = d["cold_tier"]
+    assert ct["value"] > 0 and 0 <= ct["hot_tier_hit_rate"] <= 1 and ct["pcie_GBps"] >= 0
+    assert d["config"]["launches_per_step"] == 1 and d["handoff_timeouts"] == 0
+    assert "step_kernel" in rf["kernel"]
+    assert abs(rf["avg_launch_us"] - d["device_ms"] / d["steps"] * 1e3) < 1e-6
 
 
 def test_bench_short_driver_run_replays_graphs(dev):
     """The driver's `--steps 20 --warmup 5`: every timed step runs inside a hipGraph replay, the line
     reports the warm-up it was asked for and the launch mode it really used."""
     d = _run({}, "--rows", "1000000", "--steps", "20", "--warmup", "5", "--distinct-batches", "64",
-             "--no-cache-tier", "--no-cpu-baseline")
+             "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier")
     assert d["steps"] == 20 and d["warmup"] == 5
     assert "hipGraph" in d["config"]["launch"] and d["config"]["launch"].startswith("1 ")
     assert d["config"]["grad_and_out_buffers"] >= 24
     assert abs(d["ms_per_step"] * 20 - max(d["device_ms"], d["enqueue_ms"])) < 1e-6
+
+
+def test_bench_two_launch_mode_still_reports_measured_kernel_times(dev):
+    d = _run({}, "--rows", "1000000", "--steps", "64", "--warmup", "32", "--distinct-batches", "64", "--launches", "2",
+             "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier")
+    assert d["config"]["launches_per_step"] == 2
+    k = d["kernels"]
+    assert all("measured_us" in v and v["measured_us"] > 0 for v in k.values()) and len(k) == 2
+    assert d["roofline"]["avg_launch_us"] == max(v["measured_us"] for v in k.values())
 
 
 def test_bench_sharded_leg_runs_on_nccl_at_world_size_1(dev):
