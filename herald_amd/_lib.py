@@ -115,6 +115,10 @@ def _declare(L):
         "ha_plan_sort_u32keys": [vp, i64, vp, c.c_int, vp],
         "ha_plan_sort_u64ids": [vp, i64, vp, vp],
         "ha_plan_finish": [vp, i64, vp],
+        "ha_plan_build_f32ids_lim": [vp, i64, vp, c.c_uint64, vp],
+        "ha_plan_sort_f32ids_lim": [vp, i64, vp, c.c_uint64, vp],
+        "ha_plan_build_u64ids_lim": [vp, i64, vp, c.c_uint64, vp],
+        "ha_plan_sort_u64ids_lim": [vp, i64, vp, c.c_uint64, vp],
         "ha_plan_export_f32": [vp, i64, vp, vp, vp],
         "ha_dedup_reduce": [vp, i64, vp, i64, vp, vp],
         "ha_apply_mapped": [vp, i64, i64, vp, i64, vp, f32, vp, vp, vp, vp],

@@ -1256,8 +1256,9 @@ static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hi
     if (probed)
         *probed = 0;
     if (probed && n > 0 && n <= kSmallMax) {
-        const int rc = key_kind == 0 ? ha_plan_sort_f32ids(static_cast<const float *>(keys), n, c.plan_ws, s)
-                                     : ha_plan_sort_u64ids(static_cast<const uint64_t *>(keys), n, c.plan_ws, s);
+        const uint64_t lim = static_cast<uint64_t>(c.length);
+        const int rc = key_kind == 0 ? ha_plan_sort_f32ids_lim(static_cast<const float *>(keys), n, c.plan_ws, lim, s)
+                                     : ha_plan_sort_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, lim, s);
         if (rc)
             return rc;
         PlanPtrs p = plan_layout(c.plan_ws, n);
@@ -1271,8 +1272,8 @@ static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hi
         return 0;
     }
     if (key_kind == 0)
-        return ha_plan_build_f32ids(static_cast<const float *>(keys), n, c.plan_ws, s);
-    return ha_plan_build_u64ids(static_cast<const uint64_t *>(keys), n, c.plan_ws, s);
+        return ha_plan_build_f32ids_lim(static_cast<const float *>(keys), n, c.plan_ws, static_cast<uint64_t>(c.length), s);
+    return ha_plan_build_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, static_cast<uint64_t>(c.length), s);
 }
 
 // ---- remote store: inbox / outbox ------------------------------------------------------------------------

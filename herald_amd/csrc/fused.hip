@@ -79,11 +79,11 @@ template <typename IdT, int NV_SHIFT>
 __global__ __launch_bounds__(256) void fwd_large_kernel(
     const float *__restrict__ table, uint64_t rows, uint32_t nv,
     const IdT *__restrict__ ids, int n, uint64_t total_vec, float *__restrict__ out,
-    uint32_t *__restrict__ keys, uint32_t *__restrict__ hist, int nblk, int tile_major) {
+    uint32_t *__restrict__ keys, uint32_t *__restrict__ hist, int nblk, int tile_major, int shift, int msd) {
     __shared__ uint32_t s_h[kRadixBuckets];
     const int b = blockIdx.x;
     if (b < nblk)
-        radix_first_tile_body<IdT>(ids, n, nblk, b, keys, hist, tile_major, s_h);
+        radix_first_tile_body<IdT>(ids, n, nblk, b, keys, hist, tile_major, s_h, shift, msd != 0);
     else
         gather_vec4_body<IdT, 4, NV_SHIFT, 256>(table, rows, nv, ids, total_vec, out, b - nblk);
 }
@@ -107,7 +107,11 @@ static int lookup_sort(const float *table, int64_t rows, int64_t width,
                         (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
                         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     const int shift = vec_ok ? nv_shift_of(static_cast<uint32_t>(width / 4)) : -1;
-    if (n > kSmallMax && shift >= 0 && n < (1ll << 31)) {
+    // batches above ~12 k ids with a known key range (the table's rows): bucket sort (plan.hip) -- its first
+    // launch carries the gather blocks, like the radix sort's
+    const bool bucket = bucket_sort_applies(n, static_cast<uint64_t>(rows));
+    const int msd_shift = bucket ? bucket_shift(static_cast<uint64_t>(rows)) : 0;
+    if ((n > kSmallMax || bucket) && shift >= 0 && n < (1ll << 31)) {
         HA_REQUIRE(table && ids && out, "lookup_sort: null pointer");
         PlanPtrs p = plan_layout(plan_ws, n);
         const int ni = static_cast<int>(n), nblk = radix_tiles(n);
@@ -118,7 +122,7 @@ static int lookup_sort(const float *table, int64_t rows, int64_t width,
     case S:                                                                                      \
         hipLaunchKernelGGL((fwd_large_kernel<IdT, S>), dim3(nblk + gblocks), dim3(256), 0, stream, \
                            table, (uint64_t)rows, nv, ids, ni, total_vec, out, p.keys, p.hist,   \
-                           nblk, radix_tile_major(n));                                           \
+                           nblk, bucket ? 1 : radix_tile_major(n), msd_shift, bucket ? 1 : 0);   \
         break;
         switch (shift) {
             HA_FWDL_CASE(2) HA_FWDL_CASE(3) HA_FWDL_CASE(4) HA_FWDL_CASE(5)
@@ -127,6 +131,8 @@ static int lookup_sort(const float *table, int64_t rows, int64_t width,
         }
 #undef HA_FWDL_CASE
         HA_LAUNCH_CHECK();
+        if (bucket)
+            return plan_bucket_sort(plan_ws, n, msd_shift, true, stream);
         return plan_radix_sort(plan_ws, n, 32, true, stream);
     }
     if (n == 0 || n > kSmallMax || shift < 0)

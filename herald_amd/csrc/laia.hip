@@ -550,6 +550,17 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
                 l.snaps[w].outdate(static_cast<int32_t>(plan_keys[pk] - base), td);
             l.update_push[w] += static_cast<long long>(pk0[w + 1] - pk0[w]);
             for (size_t tk = tk0[w]; tk < tk0[w + 1]; ++tk) {
+                // the direct map and the list nodes are random host-memory accesses: look a few keys ahead
+                if (l.snaps[w].direct && tk + 16 < tk0[w + 1])
+                    __builtin_prefetch(&l.snaps[w].dmap[touch_keys[tk + 16] - base]);
+                if (l.snaps[w].direct && tk + 4 < tk0[w + 1]) {
+                    const int x = l.snaps[w].dmap[touch_keys[tk + 4] - base];
+                    if (x >= 0) {
+                        __builtin_prefetch(&l.snaps[w].prev[x]);
+                        __builtin_prefetch(&l.snaps[w].next[x]);
+                        __builtin_prefetch(&l.snaps[w].valid[x]);
+                    }
+                }
                 const int res = l.snaps[w].get(static_cast<int32_t>(touch_keys[tk] - base), td);
                 if (res < 0) {  // traffic counters, topk_scheduler.cc:319-331
                     if (res == -2)

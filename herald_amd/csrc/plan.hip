@@ -95,11 +95,12 @@ __global__ __launch_bounds__(1024) void scan_exclusive_kernel(
 // the block derives its own global digit bases from the raw per-block histograms -- every thread sums
 // eight digits over all tiles, one block scan orders the digits -- so a pass is two launches
 // (histogram, scatter) instead of three.  PRESCANNED = true: `hist` was scanned by scan_exclusive_kernel.
-template <bool PRESCANNED>
+template <bool PRESCANNED, bool MSD = false>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ perm_in,
     int n, int shift, int nblk, const uint32_t *__restrict__ hist,
-    uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out) {
+    uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out,
+    uint32_t *__restrict__ bucket_start = nullptr) {
     constexpr int kRows = kRadixTile / 256;  // rows of 64 keys per wave
     constexpr int kPerThread = kRadixBuckets / 256;
     __shared__ uint32_t s_cnt[4][kRadixBuckets];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
     for (int r = 0; r < kRows; ++r) {
         const int j = wbase + r * 64 + lane;
         const bool ok = j < n;
-        const uint32_t d = (key[r] >> shift) & (kRadixBuckets - 1u);
+        const uint32_t d = radix_digit(key[r], shift, MSD);
         unsigned long long m = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < kRadixBits; ++b) {
@@ -213,9 +214,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
                 off += s_scan[k];
 #pragma unroll
             for (int q = 0; q < kPerThread; ++q) {
+                if (MSD && blockIdx.x == 0)       // first sorted position of every bucket (mine == 0 here)
+                    bucket_start[d0 + q] = off;
                 run[q] = off + mine[q];
                 off += tot[q];
             }
+            if (MSD && blockIdx.x == 0 && threadIdx.x == 255)
+                bucket_start[kRadixBuckets] = off;
         }
 #pragma unroll
         for (int q = 0; q < kPerThread; ++q) {
@@ -233,11 +238,83 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
     for (int r = 0; r < kRows; ++r) {
         const int j = wbase + r * 64 + lane;
         if (j < n) {
-            const uint32_t d = (key[r] >> shift) & (kRadixBuckets - 1u);
+            const uint32_t d = radix_digit(key[r], shift, MSD);
             const uint32_t pos = s_cnt[w][d] + lrank[r];
             keys_out[pos] = key[r];
             perm_out[pos] = val[r];
         }
+    }
+}
+
+// ===========================================================================
+// Bucket sort, last launch: stable rank by counting INSIDE the buckets.
+//
+// After one most-significant-digit scatter the keys are grouped into 2,048 ordered key ranges (stable inside
+// a range); the final position of a key is the start of its range plus its rank among the keys of that range.
+// A workgroup owns 32 consecutive grouped positions and counts against the union of the ranges its elements
+// lie in -- every key of a lower range is smaller, every key of a higher one larger, so the plain comparison
+// over the union gives the global rank minus the union's start.  The union streams through LDS in chunks of
+// 8,192 keys, so a range of any size works; the work is the sum of (range size)^2 / 64 instead of n^2 / 64:
+// for a Criteo batch of 26,624 (106,496) ids ~30x (~35x) less than ranking against all keys, and three
+// launches in all where the 11-bit LSD sort needs six.
+// ===========================================================================
+constexpr int kBucketChunk = 8192;
+
+__global__ __launch_bounds__(1024) void bucket_rank_kernel(
+    const uint32_t *__restrict__ keys_g, const int32_t *__restrict__ perm_g, int n, int shift,
+    const uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ sorted, int32_t *__restrict__ perm) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[kBucketChunk];
+    __shared__ uint32_t s_part[32 * 32];
+    const int lane = lane_id();
+    const int il = lane & 31, h = lane >> 5;
+    const int w = uniform(static_cast<int>(threadIdx.x >> 6));
+    const int i0 = blockIdx.x * kRankTile;
+    const int i = i0 + il;
+    const uint32_t ki = keys_g[min(i, n - 1)];
+    const uint32_t kfirst = keys_g[i0], klast = keys_g[min(i0 + kRankTile - 1, n - 1)];
+    const int lo = static_cast<int>(bucket_start[radix_digit(kfirst, shift, true)]);
+    const int hi = static_cast<int>(bucket_start[radix_digit(klast, shift, true) + 1]);
+    uint32_t rank = 0;
+    for (int c0 = lo; c0 < hi; c0 += kBucketChunk) {
+        const int cn = min(kBucketChunk, hi - c0);
+        const int npad = (cn + 127) & ~127;
+        {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = static_cast<int>(threadIdx.x) + k * 1024;
+                const uint32_t kv = keys_g[min(c0 + t, n - 1)];   // branch-free load
+                v[k] = t < cn ? kv : kPadKey;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = static_cast<int>(threadIdx.x) + k * 1024;
+                if (t < npad)
+                    s_keys[t] = v[k];
+            }
+        }
+        __syncthreads();
+        const int pairs = npad >> 3, ppw = pairs >> 4;   // npad % 128 == 0
+        const uint32_t *kp = s_keys + 4 * h;
+        for (int p = w * ppw; p < (w + 1) * ppw; ++p) {
+            const uint4 k = *reinterpret_cast<const uint4 *>(kp + 8 * p);
+            const int j = c0 + 8 * p + 4 * h;
+            rank += (k.x < ki) || (k.x == ki && (j + 0) < i);
+            rank += (k.y < ki) || (k.y == ki && (j + 1) < i);
+            rank += (k.z < ki) || (k.z == ki && (j + 2) < i);
+            rank += (k.w < ki) || (k.w == ki && (j + 3) < i);
+        }
+        __syncthreads();
+    }
+    s_part[(w * 2 + h) * 32 + il] = rank;
+    __syncthreads();
+    if (threadIdx.x < 32 && i < n) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            r += s_part[k * 32 + il];
+        sorted[lo + r] = ki;
+        perm[lo + r] = perm_g[i];
     }
 }
 
@@ -381,9 +458,9 @@ __global__ __launch_bounds__(1024) void finish_chunked_kernel(
 template <typename IdT>
 __global__ __launch_bounds__(256) void radix_first_kernel(
     const IdT *__restrict__ ids, int n, int nblk, uint32_t *__restrict__ keys,
-    uint32_t *__restrict__ hist, int tile_major) {
+    uint32_t *__restrict__ hist, int tile_major, int shift, int msd) {
     __shared__ uint32_t s_h[kRadixBuckets];
-    radix_first_tile_body<IdT>(ids, n, nblk, blockIdx.x, keys, hist, tile_major, s_h);
+    radix_first_tile_body<IdT>(ids, n, nblk, blockIdx.x, keys, hist, tile_major, s_h, shift, msd != 0);
 }
 
 __global__ void plan_empty_kernel(PlanHeader *hdr, int32_t *seg) {
@@ -395,7 +472,7 @@ static int plan_finish(void *ws, int64_t n, hipStream_t stream);
 
 template <typename IdT>
 static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
-                      bool sort_only, hipStream_t stream) {
+                      bool sort_only, hipStream_t stream, uint64_t key_limit = 0) {
     HA_REQUIRE(n >= 0 && n < (1ll << 31), "plan: bad n=%ld", (long)n);
     HA_REQUIRE(ws != nullptr, "plan: null workspace");
     PlanPtrs p = plan_layout(ws, n);
@@ -407,6 +484,15 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
     }
     HA_REQUIRE(ids != nullptr, "plan: null ids");
     const int ni = static_cast<int>(n);
+    if (key_limit == 0 && key_bits < 32)
+        key_limit = 1ull << key_bits;
+    if (bucket_sort_applies(n, key_limit)) {
+        const int shift = bucket_shift(key_limit);
+        hipLaunchKernelGGL(radix_first_kernel<IdT>, dim3(radix_tiles(n)), dim3(256), 0, stream, ids, ni,
+                           radix_tiles(n), p.keys, p.hist, 1, shift, 1);
+        HA_LAUNCH_CHECK();
+        return plan_bucket_sort(ws, n, shift, sort_only, stream);
+    }
     if (n <= kSmallMax) {
         const size_t lds = rank_small_lds_bytes(ni);
         HA_ALLOW_LDS(plan_rank_small_kernel<IdT>, lds);
@@ -422,7 +508,7 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
     }
     // ---- radix path: conversion + first histogram in one launch, then the passes
     hipLaunchKernelGGL(radix_first_kernel<IdT>, dim3(radix_tiles(n)), dim3(256), 0, stream, ids, ni,
-                       radix_tiles(n), p.keys, p.hist, radix_tile_major(n));
+                       radix_tiles(n), p.keys, p.hist, radix_tile_major(n), 0, 0);
     HA_LAUNCH_CHECK();
     return plan_radix_sort(ws, n, key_bits, sort_only, stream);
 }
@@ -472,6 +558,23 @@ int ha::plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipSt
     if (sort_only)
         return 0;
     return plan_finish(ws, n, stream);
+}
+
+// keys[] and the tile-major histograms of the most significant digit are in place: scatter, then rank inside
+// the buckets; unless sort_only, the finish
+int ha::plan_bucket_sort(void *ws, int64_t n, int shift, bool sort_only, hipStream_t stream) {
+    PlanPtrs p = plan_layout(ws, n);
+    const int ni = static_cast<int>(n);
+    const int nblk = radix_tiles(n);
+    hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(nblk), dim3(256), 0, stream, p.keys,
+                       static_cast<const int32_t *>(nullptr), ni, shift, nblk, p.hist, p.keys_alt, p.perm_alt,
+                       p.bucket_start);
+    hipLaunchKernelGGL(bucket_rank_kernel, dim3((ni + kRankTile - 1) / kRankTile), dim3(1024), 0, stream,
+                       p.keys_alt, p.perm_alt, ni, shift, p.bucket_start, p.sorted, p.perm);
+    HA_LAUNCH_CHECK();
+    if (sort_only)
+        return 0;
+    return ha_plan_finish(ws, n, stream);
 }
 
 namespace ha {
@@ -593,6 +696,23 @@ extern "C" int ha_plan_sort_f32ids(const float *ids, int64_t n, void *ws,
 extern "C" int ha_plan_sort_u64ids(const uint64_t *ids, int64_t n, void *ws,
                                    ha_stream_t stream) {
     return plan_build<uint64_t>(ids, n, ws, 32, true, as_stream(stream));
+}
+
+extern "C" int ha_plan_build_f32ids_lim(const float *ids, int64_t n, void *ws, uint64_t key_limit,
+                                        ha_stream_t stream) {
+    return plan_build<float>(ids, n, ws, 32, false, as_stream(stream), key_limit);
+}
+extern "C" int ha_plan_sort_f32ids_lim(const float *ids, int64_t n, void *ws, uint64_t key_limit,
+                                       ha_stream_t stream) {
+    return plan_build<float>(ids, n, ws, 32, true, as_stream(stream), key_limit);
+}
+extern "C" int ha_plan_build_u64ids_lim(const uint64_t *ids, int64_t n, void *ws, uint64_t key_limit,
+                                        ha_stream_t stream) {
+    return plan_build<uint64_t>(ids, n, ws, 32, false, as_stream(stream), key_limit);
+}
+extern "C" int ha_plan_sort_u64ids_lim(const uint64_t *ids, int64_t n, void *ws, uint64_t key_limit,
+                                       ha_stream_t stream) {
+    return plan_build<uint64_t>(ids, n, ws, 32, true, as_stream(stream), key_limit);
 }
 
 extern "C" int ha_plan_finish(void *ws, int64_t n, ha_stream_t stream) {

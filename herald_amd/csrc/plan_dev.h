@@ -22,6 +22,7 @@ struct PlanPtrs {
     uint32_t *keys_alt;
     int32_t *perm_alt;
     uint32_t *hist;        // [256 * nblocks]
+    uint32_t *bucket_start;  // [kRadixBuckets + 1] first sorted position of every most-significant-digit bucket
     uint32_t *block_sums;  // finish scan scratch
     size_t bytes;
 };
@@ -55,6 +56,7 @@ static inline PlanPtrs plan_layout(void *ws, int64_t n) {
     p.perm_alt = reinterpret_cast<int32_t *>(take(n4));
     const size_t nblk = (static_cast<size_t>(n) + kRadixTile - 1) / kRadixTile;
     p.hist = reinterpret_cast<uint32_t *>(take((nblk * kRadixBuckets + 1) * 4));
+    p.bucket_start = reinterpret_cast<uint32_t *>(take((kRadixBuckets + 2) * 4));
     const size_t nfin = (static_cast<size_t>(n) + kFinishTile - 1) / kFinishTile;
     p.block_sums = reinterpret_cast<uint32_t *>(take((nfin + 1) * 4));
     p.bytes = off;
@@ -85,10 +87,19 @@ inline size_t rank_small_lds_bytes(int n) {
 // First radix pass, one tile of kRadixTile ids by a 256-thread block: keys[j] = to_key(ids[j]) and the
 // tile's histogram of digit 0 (tile-major or digit-major, see radix_hist_kernel in plan.hip).  Shared by
 // plan.hip and by the forward launch of larger batches (fused.hip), where gather blocks ride along.
+// Digit of a key for one pass: `msd` = the bucket sort's single most-significant-digit pass
+// (plan.hip, bucket_rank_kernel): the top kRadixBits of the table's key range, everything beyond the range in
+// the last bucket -- buckets are ordered key ranges, keys keep their full value.
+__device__ __forceinline__ uint32_t radix_digit(uint32_t k, int shift, bool msd) {
+    const uint32_t d = k >> shift;
+    return msd ? (d < kRadixBuckets - 1u ? d : kRadixBuckets - 1u) : (d & (kRadixBuckets - 1u));
+}
+
 template <typename IdT>
 __device__ __forceinline__ void radix_first_tile_body(const IdT *__restrict__ ids, int n, int nblk, int tile,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ hist,
-                                                      int tile_major, uint32_t *s_h /* kRadixBuckets words */) {
+                                                      int tile_major, uint32_t *s_h /* kRadixBuckets words */,
+                                                      int shift = 0, bool msd = false) {
     for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
         s_h[d] = 0;
     __syncthreads();
@@ -97,7 +108,7 @@ __device__ __forceinline__ void radix_first_tile_body(const IdT *__restrict__ id
     for (int j = base + threadIdx.x; j < end; j += 256) {
         const uint32_t k = to_key<IdT>(ids[j]);
         keys[j] = k;
-        atomicAdd(&s_h[k & (kRadixBuckets - 1u)], 1u);
+        atomicAdd(&s_h[radix_digit(k, shift, msd)], 1u);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
@@ -107,6 +118,22 @@ __device__ __forceinline__ void radix_first_tile_body(const IdT *__restrict__ id
 // plan.hip: the radix sort of n > kSmallMax keys; first_hist_done = keys and the pass-0 histograms were
 // produced by radix_first_tile_body already
 int plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipStream_t stream);
+// plan.hip: bucket sort (one most-significant-digit scatter + rank-by-counting inside the buckets) for
+// kBucketMin < n <= kBucketMax (= kSmallMax) keys below a known limit; the first launch (radix_first_tile_body with the
+// shift of bucket_shift() and msd = true) has been made by the caller
+constexpr int kBucketMin = 12288;
+constexpr int kBucketMax = kSmallMax;   // beyond: several low-cardinality fields share a range and its equal keys make
+                                        // the in-range counting quadratic (measured at n = 106,496: 232 vs 129 us per step)
+inline bool bucket_sort_applies(int64_t n, uint64_t key_limit) {
+    return n > kBucketMin && n <= kBucketMax && key_limit > 0 && key_limit <= 0xFFFFFFFFull;
+}
+inline int bucket_shift(uint64_t key_limit) {
+    int bits = 0;
+    while (bits < 32 && (1ull << bits) < key_limit)
+        ++bits;
+    return bits > kRadixBits ? bits - kRadixBits : 0;
+}
+int plan_bucket_sort(void *ws, int64_t n, int shift, bool sort_only, hipStream_t stream);
 inline int radix_tiles(int64_t n) { return static_cast<int>((n + kRadixTile - 1) / kRadixTile); }
 inline int radix_tile_major(int64_t n) { return radix_tiles(n) <= kRadixFusedBlocks ? 1 : 0; }
 

@@ -104,11 +104,11 @@ extern "C" int ha_shard_bucket(const void *plan_ws, int64_t n,
 template <typename IdT>
 static int shard_route(const IdT *ids, int64_t n, void *plan_ws, const int64_t *starts_host, int nshard,
                        int64_t *meta, uint32_t *local_keys, ha_stream_t stream,
-                       int (*build)(const IdT *, int64_t, void *, ha_stream_t)) {
+                       int (*build)(const IdT *, int64_t, void *, uint64_t, ha_stream_t)) {
     HA_REQUIRE(plan_ws && starts_host && meta && local_keys, "shard_route: null pointer");
     HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards, "shard_route: nshard must be in [1,%d]", kMaxShards);
     HA_REQUIRE(n >= 0, "shard_route: bad n");
-    if (build(ids, n, plan_ws, stream))
+    if (build(ids, n, plan_ws, static_cast<uint64_t>(starts_host[nshard]), stream))   // keys < total rows
         return -1;
     PlanPtrs p = plan_layout(plan_ws, n);
     ShardStarts st;
@@ -137,14 +137,14 @@ extern "C" int ha_shard_route_f32ids(const float *ids, int64_t n, void *plan_ws,
                                      const int64_t *starts_host, int nshard, int64_t *meta,
                                      uint32_t *local_keys, ha_stream_t stream) {
     return shard_route<float>(ids, n, plan_ws, starts_host, nshard, meta, local_keys, stream,
-                              ha_plan_build_f32ids);
+                              ha_plan_build_f32ids_lim);
 }
 
 extern "C" int ha_shard_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws,
                                      const int64_t *starts_host, int nshard, int64_t *meta,
                                      uint32_t *local_keys, ha_stream_t stream) {
     return shard_route<uint64_t>(ids, n, plan_ws, starts_host, nshard, meta, local_keys, stream,
-                                 ha_plan_build_u64ids);
+                                 ha_plan_build_u64ids_lim);
 }
 
 // Owner side of a sparse push in one call: index plan of the received shard-local keys (the W sorted

@@ -25,7 +25,7 @@
 //     `sc1` loads only once they are 0 (a hash collision only makes it wait longer).
 // Apply workgroups have lower block numbers than gather workgroups and never wait themselves, so
 // every wave a gather wave waits for is resident or ahead of it in the dispatch order.  A poll loop
-// that exceeds kSpinMax gives up and raises plan_next's header flag (reserved[0]) instead of hanging.
+// that exceeds kSpinMax gives up and raises plan_next's header flag (header word 8) instead of hanging.
 #include "plan_dev.h"
 #include "gather_dev.h"
 #include "scatter_dev.h"
@@ -40,6 +40,7 @@ int apply_finish_entry(float *dst, int64_t rows, int64_t width, void *plan_ws, i
 constexpr int kGatherLoads = 2;    // sixteen-byte loads a gather lane keeps in flight: one 2 KiB row per wave at
                                    // d = 512 (measured: 8 -> 18.4 us per step, 4 -> 16.2, 2 -> 15.6: the finer the
                                    // waves, the less a released row waits for its wave's other rows)
+constexpr int kHandoffFlagWord = 8;   // plan header word of the sticky time-out flag (words 0..3 serve plan.hip / scatter.hip)
 constexpr int kSpinMax = 1 << 18;   // polls of ~0.3 us each before a gather wave gives up (~0.1 s)
 
 struct StepArgs {
@@ -109,7 +110,7 @@ __device__ __forceinline__ void gather_wait_body(const StepArgs &a, int wave_ind
                 break;
             if (spins >= kSpinMax) {
                 if (lane == 0)
-                    a.nhdr->reserved[0] = 1;   // hand-off timed out: the rows below may be stale
+                    a.nhdr->reserved[kHandoffFlagWord] = 1;   // hand-off timed out: the rows below may be stale
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
@@ -214,7 +215,9 @@ __global__ __launch_bounds__(1024, 8) void step_timeline_kernel(const StepArgs a
 // whole by one store instruction and is never in a reader's L2 before its last write of the launch):
 // rows of a multiple of 32 floats in a 128-byte aligned table.  Everything else takes the separate launches.
 static bool step_fast(int64_t n, int64_t width, const void *table) {
-    return n > 0 && n <= kSmallMax && width % 32 == 0 && width < (1 << 30) &&
+    // above kBucketMin ids the rank-by-counting tiles of the single launch (O(n^2)) lose against the bucket
+    // sort of the separate launches
+    return n > 0 && n <= kBucketMin && width % 32 == 0 && width < (1 << 30) &&
            reinterpret_cast<uintptr_t>(table) % 128 == 0;
 }
 
@@ -322,7 +325,7 @@ extern "C" size_t ha_pend_bytes(void) {
 }
 
 extern "C" int64_t *ha_plan_handoff_timeout(void *plan_ws) {
-    return plan_ws ? &static_cast<PlanHeader *>(plan_ws)->reserved[0] : nullptr;
+    return plan_ws ? &static_cast<PlanHeader *>(plan_ws)->reserved[kHandoffFlagWord] : nullptr;
 }
 
 extern "C" int ha_pend_reset(void *pend, ha_stream_t stream) {

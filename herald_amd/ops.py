@@ -114,16 +114,18 @@ class IndexPlan:
         self._view = None
         self._route_cache = None
 
-    def sort(self, ids, stream=None):
+    def sort(self, ids, stream=None, key_limit=None):
         """Stable sort only (keys / sorted / perm): all that sgd_apply and push_apply consume."""
-        return self.build(ids, stream, sort_only=True)
+        return self.build(ids, stream, sort_only=True, key_limit=key_limit)
 
     def finish(self, stream=None):
         """Second phase after sort(): n_unique, uniq, counts, seg, inverse, upos."""
         check(_lib.load().ha_plan_finish(_ptr(self.ws), self.n, _stream_ptr(stream)), "ha_plan_finish")
         return self
 
-    def build(self, ids, stream=None, sort_only=False):
+    def build(self, ids, stream=None, sort_only=False, key_limit=None):
+        """key_limit: a bound on the valid keys (the table's row count) -- lets batches of 12,289 .. 36,864 ids take
+        the bucket sort (ha_plan_*_lim); results are identical with and without it."""
         L = _lib.load()
         n = ids.numel()
         if n > self.capacity:
@@ -131,12 +133,16 @@ class IndexPlan:
         if not ids.is_cuda or not ids.is_contiguous():
             raise ValueError("ids must be a contiguous device tensor")
         # the workspace layout depends on n, so a view is per build
-        if ids.dtype == torch.float32:
-            fn = L.ha_plan_sort_f32ids if sort_only else L.ha_plan_build_f32ids
-            rc = fn(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
+        if ids.dtype not in (torch.float32, torch.int64, torch.uint64):
+            raise TypeError("ids must be float32 or (u)int64")
+        kind = "f32ids" if ids.dtype == torch.float32 else "u64ids"
+        name = "ha_plan_%s_%s" % ("sort" if sort_only else "build", kind)
+        if key_limit is not None:
+            rc = getattr(L, name + "_lim")(_ptr(ids), n, _ptr(self.ws), int(key_limit), _stream_ptr(stream))
+        elif ids.dtype == torch.float32:
+            rc = getattr(L, name)(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
         elif ids.dtype in (torch.int64, torch.uint64):
-            fn = L.ha_plan_sort_u64ids if sort_only else L.ha_plan_build_u64ids
-            rc = fn(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
+            rc = getattr(L, name)(_ptr(ids), n, _ptr(self.ws), _stream_ptr(stream))
         else:
             raise TypeError("ids must be float32 or (u)int64")
         check(rc, "ha_plan_build")

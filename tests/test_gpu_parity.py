@@ -542,3 +542,47 @@ def test_sharded_checkpoint_round_trip_chunked(dev, tmp_path):
     open(str(tmp_path / "short_0.dat"), "wb").write(b"1234")
     with pytest.raises(ValueError):
         emb.load(str(tmp_path / "short"))
+
+
+@pytest.mark.parametrize("n,limit,hi", [(12289, 33762577, 33762577), (20000, 1000, 1000), (26624, 33762577, 33762577),
+                                        (36864, 1 << 20, 1 << 20), (40000, 5000, 9000), (106496, 33762577, 33762577),
+                                        (262144, 1 << 31, 1 << 31), (262145, 33762577, 33762577), (30000, 7, 1)])
+def test_bucket_sort_path_with_key_limit(dev, n, limit, hi):
+    """ha_plan_*_lim: batches above ~12 k ids with a known key range take the bucket sort (one
+    most-significant-digit scatter + rank-by-counting inside the ranges).  Same plan as np.unique / a stable
+    argsort: tiny key ranges (every key its own bucket), keys at and beyond the limit (last bucket), all keys
+    equal (one bucket streamed through LDS in chunks), Criteo-like skew, and the sizes around both ends."""
+    rng = np.random.default_rng(n + limit)
+    if hi == 1:
+        keys = np.full(n, 5, dtype=np.int64)
+    elif limit == 33762577:
+        b = max(1, n // 26)
+        keys = synth.criteo_batch(b, 3).reshape(-1)[:n]
+        keys = np.concatenate([keys, rng.integers(0, hi, size=n - keys.size)])
+    else:
+        keys = rng.integers(0, hi, size=n)
+    d_ids = _dev(keys.astype(np.int64), dev)
+    plan = ops.IndexPlan(n, dev).build(d_ids, key_limit=limit)
+    torch.cuda.synchronize()
+    k64 = keys.astype(np.uint64)
+    uniq, inv, cnt = cpu.unique(k64)
+    assert plan.n_unique() == uniq.size
+    perm = plan.perm().cpu().numpy()
+    np.testing.assert_array_equal(perm, np.argsort(k64, kind="stable"))
+    np.testing.assert_array_equal(_u32(plan.sorted_keys()), k64[perm])
+    np.testing.assert_array_equal(_u32(plan.uniq()), uniq)
+    np.testing.assert_array_equal(plan.inverse().cpu().numpy().astype(np.int64), inv)
+    np.testing.assert_array_equal(plan.counts().cpu().numpy().astype(np.int64), cnt)
+    # float32 ids through the fused forward (gather blocks ride in the first launch) + the SGD apply
+    if limit == 33762577 and n <= 106496:
+        rows, width = 60000, 32
+        fid = (keys % rows).astype(np.float32)
+        table = rng.standard_normal((rows, width), dtype=np.float32)
+        g = rng.standard_normal((n, width), dtype=np.float32)
+        t = _dev(table, dev)
+        p2 = ops.IndexPlan(n, dev)
+        out = ops.lookup_sort(t, _dev(fid, dev), p2)
+        ops.sgd_apply_finish(t, p2, _dev(g, dev), 0.05)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), cpu.embedding_lookup(table, fid))
+        np.testing.assert_array_equal(t.cpu().numpy(), cpu.sgd_sparse_update(table.copy(), fid, g, 0.05))

@@ -39,3 +39,15 @@ def step():
     ops.sgd_apply_finish(table, plan, grads, 1e-6)
 t = timeit(step)
 print("step         %.1f us  -> %.1f M rows/s" % (t, n / t))
+plans = [ops.IndexPlan(n, dev), ops.IndexPlan(n, dev)]
+pends = [ops.PendingTable(dev), ops.PendingTable(dev)]
+ops.lookup_sort_pend(table, ids[0], plans[0], pends[0], out=out)
+kk = [0]
+def step1():
+    j = kk[0]
+    ops.sgd_push_pull(table, plans[j % 2], grads, 1e-6, pends[j % 2], ids[(j + 1) % NB], plans[(j + 1) % 2],
+                      pends[(j + 1) % 2], next_out=out)
+    kk[0] += 1
+t = timeit(step1, reps=50)
+print("one-launch step %.1f us  -> %.1f M rows/s   (time-outs: %s %s)" % (t, n / t, plans[0].handoff_timed_out(),
+                                                                         plans[1].handoff_timed_out()))
