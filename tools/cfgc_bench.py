@@ -30,6 +30,9 @@ def nxt():
 print("n=%d unique~%d" % (n, np.unique(ids[0].cpu().numpy()).size))
 print("gather       %.1f us" % timeit(lambda: ops.embedding_lookup(table, nxt(), out=out)))
 print("sort         %.1f us" % timeit(lambda: plan.sort(nxt())))
+print("sort (limit) %.1f us" % timeit(lambda: plan.sort(nxt(), key_limit=rows)))
+print("lookup_sort  %.1f us" % timeit(lambda: ops.lookup_sort(table, nxt(), plan, out=out)))
+print("apply_finish %.1f us" % timeit(lambda: ops.sgd_apply_finish(table, plan, grads, 1e-6)))
 plan.sort(ids[0])
 print("finish       %.1f us" % timeit(lambda: plan.finish()))
 print("apply        %.1f us" % timeit(lambda: ops.sgd_apply(table, plan, grads, 1e-6)))
