@@ -186,25 +186,44 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
         c.embedding_lookup(ids_dev[k % nb], out)
         c.embedding_update(ids_dev[k % nb], grad, same_as_lookup=True)
 
+    # the ten launches of a lookup + update pair are replayed from hipGraphs of 16 pairs (the calls enqueue
+    # kernels only, nothing is read back while the counters are off)
+    GS = 16
+    side = torch.cuda.Stream(device=dev)
+    c.cache.stream = side
     for k in range(64):
         step(k)
     torch.cuda.synchronize()
-    steps = 256
-    t0 = time.perf_counter()
-    for k in range(steps):
-        step(64 + k)
+    graphs = []
+    for g0 in range(0, nb, GS):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for k in range(g0, g0 + GS):
+                step(k)
+        graphs.append(g)
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    steps = 256
+    with torch.cuda.stream(side):
+        for i in range(4):
+            graphs[i % len(graphs)].replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps // GS):
+            graphs[(4 + i) % len(graphs)].replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
     c.perf_enabled(True)       # the counters are read back per call: outside the timed loop
-    for k in range(32):
-        step(64 + steps + k)
+    for k in range(32):        # batches the cache has not seen yet
+        b = (nb + k) % ids_dev.shape[0]
+        c.embedding_lookup(ids_dev[b], out)
+        c.embedding_update(ids_dev[b], grad, same_as_lookup=True)
     torch.cuda.synchronize()
     pulls = [r for r in c.perf() if r["type"] == "Pull"]
     miss = float(np.mean([r["num_miss"] / max(r["num_unique"], 1) for r in pulls])) if pulls else None
     return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps, "policy": "LRU",
             "limit_rows": limit, "bound": 100, "steps": steps, "unique_miss_rate": miss,
             "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
-                    "(10 launches per pair, launch-latency bound); not part of `value`"}
+                    "(10 launches per pair, replayed from hipGraphs of 16 pairs); not part of `value`"}
 
 
 def cold_tier(args, dev):

@@ -21,8 +21,8 @@ from ._lib import DLArray, DLContext, DLStream, PlanView, check
 
 
 def _stream_ptr(stream=None):
-    if stream is None:
-        stream = torch.cuda.current_stream()
+    if stream is None:      # raw handle of torch's current stream, without building a Stream object
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
     if isinstance(stream, int):
         return ctypes.c_void_p(stream)
     return ctypes.c_void_p(stream.cuda_stream)
