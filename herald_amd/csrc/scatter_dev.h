@@ -241,7 +241,8 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
 // run is exhausted.
 constexpr int kCoopUnits = 256;   // units of 64 floats per LDS block (64 KiB)
 constexpr int kCoopScan = 1024;   // sorted positions the 16 waves scan each way for the run's ends
-constexpr size_t kApplyLdsBytes = static_cast<size_t>(kCoopUnits) * kWave * 4 + 32 * 4;
+constexpr int kCoopPermSpan = 512;   // sorted positions each way whose occurrence indices a full workgroup keeps in LDS
+constexpr size_t kApplyLdsBytes = static_cast<size_t>(kCoopUnits) * kWave * 4 + 32 * 4 + 2 * kCoopPermSpan * 4;
 
 template <int MODE>
 __device__ __forceinline__ float chain_step(float acc, float m) {
@@ -254,7 +255,8 @@ template <int MODE, bool DUAL, bool SIG = false>
 __device__ __forceinline__ void coop_slices(
     float *__restrict__ dst_row, bool init, Second d2, const float *__restrict__ grads,
     const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr, int s, int len,
-    int width, int j, int workers, int w, float *s_m, uint32_t *pend_word = nullptr) {
+    int width, int j, int workers, int w, float *s_m, uint32_t *pend_word = nullptr,
+    const int32_t *s_perm = nullptr, int s_perm_first = 0) {
     const int lane = lane_id();
     const int nslice = (width + kWave - 1) / kWave;
     const int my_slices = (nslice - j + workers - 1) / workers;  // slices j, j+workers, ...
@@ -284,9 +286,18 @@ __device__ __forceinline__ void coop_slices(
         // the rows of block b+1 are requested before the chain of block b runs (registers are free
         // again once block b sits in LDS), so a giant run costs its ordered chain, not chain + loads
         float g[kChunk];
+        // s_perm (optional): occurrence indices of the sorted positions [s_perm_first, s_perm_first + 2 * span)
+        // fetched in the SAME round trip as the run boundaries, so a run that fits the span starts its row
+        // requests one dependent load earlier
         auto load_idx = [&](int base) {   // occurrence index of this wave's 16 positions of a block
             const int t = base + tc * kChunk + (lane & 15);
-            int idx = perm[min(s + t, n - 1)];
+            const int pos = min(s + t, n - 1);
+            const int rel = pos - s_perm_first;
+            int idx;
+            if (s_perm != nullptr && rel >= 0 && rel < 2 * kCoopPermSpan)
+                idx = s_perm[rel];
+            else
+                idx = perm[pos];
             if (maps.valmap)
                 idx = maps.valmap[idx];
             return idx;
@@ -375,10 +386,12 @@ __device__ __forceinline__ bool coop_run(
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr, int wg0, int w, uint32_t key, uint32_t bk, uint32_t fk,
-    ApplyMaps maps, uint32_t *lds, uint32_t *pend = nullptr) {
+    ApplyMaps maps, uint32_t *lds, uint32_t *pend = nullptr, int spv = 0) {
     const int lane = lane_id();
     float *s_m = reinterpret_cast<float *>(lds);
     int *s_cnt = reinterpret_cast<int *>(lds + kCoopUnits * kWave);
+    int32_t *s_perm = reinterpret_cast<int32_t *>(lds + kCoopUnits * kWave + 32);
+    s_perm[threadIdx.x] = spv;   // perm[wg0 - span + thread], read speculatively with the window (visible behind the barrier below)
 
     // run start / end from the 2 x 1024 scanned positions (wave w looked at chunk w each way)
     {
@@ -454,7 +467,7 @@ __device__ __forceinline__ bool coop_run(
     }
 
     coop_slices<MODE, DUAL, SIG>(dst_row, init, d2, grads, perm, maps, n, lr, s, len, width, j, workers, w, s_m,
-                                 SIG ? pend + pend_slot(key) : nullptr);
+                                 SIG ? pend + pend_slot(key) : nullptr, s_perm, wg0 - kCoopPermSpan);
     return true;
 }
 
@@ -520,6 +533,9 @@ __device__ __forceinline__ bool apply_body_impl(
     // then leave without the scan exchange
     const int deep = wg0 - kPosPerBlock * ((width + kWave - 1) / kWave) - kPosPerBlock;
     const uint32_t dk = sorted[max(deep, 0)];
+    // speculative, same round trip: this thread's share of the occurrence indices around the workgroup
+    // (used only if the workgroup turns out to be a worker of a long run)
+    const int spv = perm[max(0, min(wg0 - kCoopPermSpan + static_cast<int>(threadIdx.x), n - 1))];
     if (maps.valmap)  // wave-uniform
         pv = maps.valmap[pv];
     const uint32_t key = static_cast<uint32_t>(
@@ -532,7 +548,7 @@ __device__ __forceinline__ bool apply_body_impl(
             return false;   // >= nslice full workgroups of this run precede: not a worker
         if (dbg_info)
             *dbg_info = (w << 16) | 0x7FFF;
-        if (coop_run<MODE, DUAL, SIG>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds, pend))
+        if (coop_run<MODE, DUAL, SIG>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds, pend, spv))
             return true;
     }
     const unsigned long long eq = __ballot(q >= 0 && q < n && ks == key);
