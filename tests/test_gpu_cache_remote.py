@@ -115,7 +115,7 @@ def host_staged_a2a(out, inp, out_splits, in_splits, group):
     out.copy_(o)
 
 
-def _shard_worker(rank, world, port, rows, width, n, limit, steps, policy, mode):
+def _shard_worker(rank, world, port, rows, width, n, limit, steps, policy, mode, host_local=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -126,8 +126,12 @@ def _shard_worker(rank, world, port, rows, width, n, limit, steps, policy, mode)
     rng = np.random.default_rng(99)                       # identical on every rank
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
     starts = partition(rows, world)
-    shard = torch.from_numpy(table0[starts[rank]:starts[rank + 1]].copy()).to(dev)
-    local = remote_store.LocalStore(shard)
+    if host_local:      # BASELINE configs[4]'s composition: every rank's shard in pinned host DRAM
+        shard = torch.from_numpy(table0[starts[rank]:starts[rank + 1]].copy()).pin_memory()
+        local = remote_store.HostStore(shard.shape[0], width, dev, table=shard)
+    else:
+        shard = torch.from_numpy(table0[starts[rank]:starts[rank + 1]].copy()).to(dev)
+        local = remote_store.LocalStore(shard)
     store = remote_store.ShardedStore(rows, width, dev, local, a2a=host_staged_a2a)
     cls = {"lru": hcache.LRUCache, "lfu": hcache.LFUCache, "lfuopt": hcache.LFUOptCache}[policy]
     gpu = cls(limit, rows, width, node_id=0, max_batch=n, device=dev)
@@ -194,3 +198,76 @@ def _shard_worker(rank, world, port, rows, width, n, limit, steps, policy, mode)
                                                (4, "lfu", "lookup_update"), (2, "lru", "push_pull")])
 def test_caches_over_a_sharded_store(dev, world, policy, mode):
     mp.spawn(_shard_worker, args=(world, _free_port(), 6000, 32, 500, 400, 10, policy, mode), nprocs=world, join=True)
+
+
+def test_caches_over_a_sharded_host_dram_table(dev):
+    """configs[4] composed at small scale: the table row-range sharded over the ranks AND kept in pinned host
+    DRAM on each of them, an HBM hot tier per rank in front."""
+    mp.spawn(_shard_worker, args=(2, _free_port(), 6000, 64, 500, 400, 8, "lru", "lookup_update", True), nprocs=2,
+             join=True)
+
+
+# ---- BASELINE configs[3] composed: laia scheduler -> LAIADataloader -> cache over the sharded table ----------
+def _laia_worker(rank, world, port):
+    """Every rank runs its own laia scheduler over the same samples (as run_laia.py does), takes ITS share of
+    each global batch and ITS push plan from the LAIADataloader, looks the rows up through its cache over the
+    table sharded across the ranks, and pushes with embedding_update_with_push_keys.  Oracle: the laia model's
+    stream per rank, one cache model per rank, one server."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from herald_amd import hetu_ops, laia as hlaia, synth
+    from herald_amd.sharded import partition
+    from oracle import laia_model
+    rows, width, mini_bs, limit, T = 60000, 32, 64, 3000, 26
+    samples = np.concatenate([synth.criteo_batch(64, step=300 + s, rows=rows, nfields=T) for s in range(world * 8)], axis=0)
+    rng = np.random.default_rng(17)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    starts = partition(rows, world)
+    local = remote_store.LocalStore(torch.from_numpy(table0[starts[rank]:starts[rank + 1]].copy()).to(dev))
+    store = remote_store.ShardedStore(rows, width, dev, local, a2a=host_staged_a2a)
+    gpu = hcache.LRUCache(limit, rows, width, node_id=0, max_batch=mini_bs * T, device=dev)
+    gpu.bind_remote(store)
+    gpu.pull_bound = gpu.push_bound = 3
+    sched = hlaia.LAIAScheduler(samples.astype(np.float32), batch_size=mini_bs)
+    sched.start(nrank=world, rank=rank, cache_limit=limit, dataset_num=1, epoch_num=1, key_limit=rows)
+    dl = hlaia.LAIADataloader(sched, 0, True, samples.astype(np.float32), mini_bs, name="train", device=dev)
+    dl.init_states(rank, world)
+    grad_op = hetu_ops.EmbeddingLookUp_Gradient((rows, width), enable_push_index=True)
+    # oracle side: every rank's stream, cache model and the one server
+    server = cache_model.Server(table0)
+    models = [cache_model.CacheModel("lru", limit, width, server, 3, 3) for _ in range(world)]
+    streams = [laia_model.LaiaSchedulerModel(sched.sparse_data.astype(np.uint64), 1, sched.batch_size, sched.batch_num,
+                                             world, r, limit).emit() for r in range(world)]
+    for b in range(4):
+        ids, plan = dl.get_arr()
+        np.testing.assert_array_equal(ids.cpu().numpy(), samples[streams[rank][2 * b + 1]].astype(np.float32))
+        np.testing.assert_array_equal(plan.cpu().numpy(), np.asarray(streams[rank][2 * b + 2], dtype=np.float32))
+        keys = [samples[streams[r][2 * b + 1]].reshape(-1).astype(np.uint64) for r in range(world)]
+        wants = [models[r].lookup(keys[r]) for r in range(world)]
+        dest = torch.empty((mini_bs * T, width), dtype=torch.float32, device=dev)
+        gpu.embedding_lookup(ids.reshape(-1), dest).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), wants[rank], err_msg="lookup, batch %d rank %d" % (b, rank))
+        grads = [np.random.default_rng(900 + 10 * b + r).standard_normal((mini_bs * T, width), dtype=np.float32) *
+                 np.float32(-0.01) for r in range(world)]
+        slices = grad_op.compute(torch.from_numpy(grads[rank]).to(dev), (ids, plan))
+        gpu.embedding_update_with_push_keys(slices.indices.reshape(-1), slices.push_indices, slices.values).wait()
+        for r in range(world):                                                   # pushes land in rank order
+            models[r].update_with_push_keys(keys[r], np.asarray(streams[r][2 * b + 2], dtype=np.uint64), grads[r])
+        torch.cuda.synchronize()
+        dist.barrier()
+        np.testing.assert_array_equal(local.versions.cpu().numpy(), server.ver[starts[rank]:starts[rank + 1]],
+                                      err_msg="versions, batch %d rank %d" % (b, rank))
+        np.testing.assert_array_equal(local.table.cpu().numpy(), server.table[starts[rank]:starts[rank + 1]],
+                                      err_msg="shard, batch %d rank %d" % (b, rank))
+    sched.sched.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_laia_dataloader_cache_and_sharded_table_composed(dev, world):
+    mp.spawn(_laia_worker, args=(world, _free_port()), nprocs=world, join=True)
