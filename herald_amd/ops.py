@@ -32,6 +32,12 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _raw_stream(stream=None):
+    """Raw hipStream_t value of `stream` (None = torch's current stream)."""
+    p = _stream_ptr(stream).value
+    return p if p is not None else 0
+
+
 def _require(t, dtype, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError("%s must be a CUDA/HIP torch tensor" % name)
@@ -113,6 +119,16 @@ class IndexPlan:
         self.n = 0
         self._view = None
         self._route_cache = None
+        self._produced_on = None     # raw stream of the launch that last wrote the plan
+
+    def produced_on(self, stream=None):
+        """Record the stream of the launch that (re)wrote this plan; the host-side readers below wait for it."""
+        self._produced_on = _raw_stream(stream)
+
+    def _sync_producer(self):
+        if self._produced_on is not None:
+            torch.cuda.ExternalStream(self._produced_on, device=self.device).synchronize() \
+                if self._produced_on else torch.cuda.synchronize(self.device)
 
     def sort(self, ids, stream=None, key_limit=None):
         """Stable sort only (keys / sorted / perm): all that sgd_apply and push_apply consume."""
@@ -121,6 +137,7 @@ class IndexPlan:
     def finish(self, stream=None):
         """Second phase after sort(): n_unique, uniq, counts, seg, inverse, upos."""
         check(_lib.load().ha_plan_finish(_ptr(self.ws), self.n, _stream_ptr(stream)), "ha_plan_finish")
+        self.produced_on(stream)
         return self
 
     def build(self, ids, stream=None, sort_only=False, key_limit=None):
@@ -149,6 +166,7 @@ class IndexPlan:
         self.n = n
         self._view = None
         self._route_cache = None
+        self.produced_on(stream)
         return self
 
     # -- typed views into the workspace (no copies) --
@@ -165,12 +183,15 @@ class IndexPlan:
         return self.ws[off:off + count * itemsize].view(dtype)
 
     def n_unique(self):
-        """Host int (synchronises the current stream)."""
+        """Host int.  Waits for the stream of the launch that last wrote the plan (whichever stream the caller
+        passed to build / finish / lookup_sort / sgd_apply_finish / sgd_push_pull), then reads the count."""
+        self._sync_producer()
         return int(self._slice(self.view().n_unique, 1, torch.int64).item())
 
     def handoff_timed_out(self):
         """True if a hand-off wait of the sgd_push_pull launch that sorted this plan gave up (host sync)."""
         addr = _lib.load().ha_plan_handoff_timeout(_ptr(self.ws))
+        self._sync_producer()
         return bool(self._slice(addr, 1, torch.int64).item())
 
     def n_unique_dev(self):
@@ -278,6 +299,7 @@ def lookup_sort(table, ids, plan, out=None, stream=None):
              _stream_ptr(stream)), "ha_lookup_sort")
     plan.n = n
     plan._view = None
+    plan.produced_on(stream)
     return out
 
 
@@ -292,10 +314,12 @@ def sgd_apply_finish(table, plan, grads, lr, stream=None, next_ids=None):
         check(_lib.load().ha_sgd_apply_finish_prefetch_f32ids(
             _ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws), plan.n, _ptr(grads), ctypes.c_float(lr),
             _ptr(next_ids), next_ids.numel(), _stream_ptr(stream)), "ha_sgd_apply_finish_prefetch_f32ids")
+        plan.produced_on(stream)
         return table
     check(_lib.load().ha_sgd_apply_finish(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws),
                                           plan.n, _ptr(grads), ctypes.c_float(lr), _stream_ptr(stream)),
           "ha_sgd_apply_finish")
+    plan.produced_on(stream)
     return table
 
 
@@ -344,6 +368,7 @@ def lookup_sort_pend(table, ids, plan, pend, out=None, stream=None):
              _stream_ptr(stream)), "ha_lookup_sort_pend")
     plan.n = n
     plan._view = None
+    plan.produced_on(stream)
     return out
 
 
@@ -360,6 +385,7 @@ def sgd_push_pull(table, plan_cur, grads, lr, pend_cur, next_ids=None, plan_next
         check(L.ha_sgd_push_pull_f32ids(_ptr(table), table.shape[0], width, _ptr(plan_cur.ws), plan_cur.n,
                                         _ptr(grads), ctypes.c_float(lr), _ptr(pend_cur.buf), None, 0, None,
                                         None, None, _stream_ptr(stream)), "ha_sgd_push_pull")
+        plan_cur.produced_on(stream)
         return None
     n = next_ids.numel()
     if n > plan_next.capacity:
@@ -372,6 +398,8 @@ def sgd_push_pull(table, plan_cur, grads, lr, pend_cur, next_ids=None, plan_next
              _ptr(pend_next.buf), _stream_ptr(stream)), "ha_sgd_push_pull")
     plan_next.n = n
     plan_next._view = None
+    plan_cur.produced_on(stream)
+    plan_next.produced_on(stream)
     return next_out
 
 
@@ -381,6 +409,7 @@ def push_apply_finish(table, plan, grads, stream=None):
     check(_lib.load().ha_push_apply_finish(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws),
                                            plan.n, _ptr(grads), _stream_ptr(stream)),
           "ha_push_apply_finish")
+    plan.produced_on(stream)
     return table
 
 

@@ -129,6 +129,7 @@ class HipEngine:
                       st.local.data_ptr(), self._stream()), "ha_shard_route")
         plan.n = n
         plan._view = None
+        plan._produced_on = self._stream()
         return st
 
     def on_side(self, after_current=True):

@@ -586,3 +586,27 @@ def test_bucket_sort_path_with_key_limit(dev, n, limit, hi):
         torch.cuda.synchronize()
         np.testing.assert_array_equal(out.cpu().numpy(), cpu.embedding_lookup(table, fid))
         np.testing.assert_array_equal(t.cpu().numpy(), cpu.sgd_sparse_update(table.copy(), fid, g, 0.05))
+
+
+def test_plan_host_readers_wait_for_the_producing_stream(dev):
+    """n_unique() / export_f32() / deduplicate() of a plan built on an explicit side stream (behind a long
+    kernel on that stream) read the finished values, not stale ones, whatever torch's current stream is."""
+    rng = np.random.default_rng(3)
+    side = torch.cuda.Stream(device=dev)
+    big = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    plan = ops.IndexPlan(6656, dev)
+    plan.build(_dev(np.zeros(6656, dtype=np.float32), dev))          # a first content: one unique key
+    torch.cuda.synchronize()
+    ids = rng.integers(0, 100000, size=6656).astype(np.float32)
+    d_ids = _dev(ids, dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(8):
+            big.add_(1.0)                                             # keeps the side stream busy for milliseconds
+    plan.build(d_ids, stream=side)
+    assert plan.n_unique() == np.unique(ids).size                     # current stream is NOT `side`
+    uf, invf = plan.export_f32()
+    ru, rinv = np.unique(ids, return_inverse=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(uf.cpu().numpy(), ru)
+    np.testing.assert_array_equal(invf.cpu().numpy(), rinv.astype(np.float32))
