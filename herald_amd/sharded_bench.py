@@ -102,5 +102,6 @@ def run(args, rank, world, dev, cpu_baseline_fn=None):
                          "algorithmic_bytes_per_step_per_gpu": step_bytes,
                          "note": "whole-step time (exchanges and host work included), not a kernel duration"},
             "cpu_baseline": cpu_base,
-        }))
+        }), flush=True)
+    dist.barrier()          # rank 0 may still be timing the CPU baseline: tear the group down together
     dist.destroy_process_group()
