@@ -137,6 +137,7 @@ def _declare(L):
         "ha_sgd_apply_finish": [vp, i64, i64, vp, i64, vp, f32, vp],
         "ha_push_apply_finish": [vp, i64, i64, vp, i64, vp, vp],
         "ha_sgd_apply_finish_prefetch_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp],
+        "ha_sparse_opt_fused_f32ids": [c.c_int, vp, i64, i64, vp, i64, vp, vp, vp, vp, vp, vp],
         "ha_pend_reset": [vp, vp],
         "ha_lookup_sort_pend_f32ids": [vp, i64, i64, vp, i64, vp, vp, vp, vp],
         "ha_lookup_sort_pend_u64ids": [vp, i64, i64, vp, i64, vp, vp, vp, vp],

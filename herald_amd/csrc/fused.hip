@@ -18,7 +18,7 @@ namespace ha {
 // scatter.hip
 template <int MODE>
 int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, int64_t n,
-                    const float *grads, float lr, hipStream_t stream);
+                    const float *grads, float lr, hipStream_t stream, ApplyMaps maps = ApplyMaps{});
 
 template <typename IdT, int NV_SHIFT>
 __global__ __launch_bounds__(1024) void fwd_fused_kernel(

@@ -17,56 +17,12 @@
 // order).  Arithmetic keeps the reference's expression order (library built with -ffp-contract=off);
 // tolerance against the numpy oracle 1e-5 as in the reference's own tests
 // (tests/test_optimizer.py:117-300), Lamb's two norms are accumulated in double.
-#include "common.h"
-
-#include <math.h>
+#include "optim_dev.h"
 
 namespace ha {
 
 // capi.hip
 int scratch_get(hipStream_t stream, size_t bytes, void **out);
-
-enum OptKind { kAdaGrad = 0, kAdam = 1, kAdamW = 2, kL2 = 3, kLambUpdate = 4, kLambStep = 5 };
-
-struct OptArgs {
-    float lr, eps, beta1, beta2, beta1t, beta2t, weight_decay;
-    float *update;        // Lamb: [n, width] scratch holding the update direction
-    double *part_param;   // Lamb: per-row sums of param^2
-    double *part_update;  // Lamb: per-row sums of update^2
-    const double *norms;  // Lamb: {sum param^2, sum update^2}
-};
-
-// One element.  p = parameter, g = gradient (in/out for kL2), s1 / s2 = optimizer state.
-template <int KIND>
-__device__ __forceinline__ void opt_step(float &p, float &g, float &s1, float &s2, const OptArgs &a,
-                                         float &upd, double &sp, double &su, float ratio) {
-    if (KIND == kL2) {
-        g = g + a.weight_decay * p;                       // grad += l2reg * param  (:17)
-    } else if (KIND == kAdaGrad) {
-        const float acc = s1 + g * g;
-        s1 = acc;
-        p = p - a.lr * g / (sqrtf(acc) + a.eps);
-    } else if (KIND == kLambStep) {
-        p = p - a.lr * ratio * (upd + a.weight_decay * p);   // :577
-    } else {
-        float m = a.beta1 * s1 + (1.f - a.beta1) * g;
-        float v = a.beta2 * s2 + (1.f - a.beta2) * g * g;
-        s1 = m;
-        s2 = v;
-        m = m / (1.f - a.beta1t);
-        v = v / (1.f - a.beta2t);
-        if (KIND == kAdam) {
-            p = p - a.lr * m / (sqrtf(v) + a.eps);
-        } else if (KIND == kAdamW) {
-            const float update = m / (sqrtf(v) + a.eps);
-            p = p - a.lr * (update + a.weight_decay * p);
-        } else {  // kLambUpdate: the direction and the two squared norms (:539-561)
-            upd = m / (sqrtf(v) + a.eps);
-            sp += static_cast<double>(p) * static_cast<double>(p);
-            su += static_cast<double>(upd) * static_cast<double>(upd);
-        }
-    }
-}
 
 template <int KIND>
 struct Uses {

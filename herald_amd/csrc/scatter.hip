@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024, 8) void apply_unique_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width, PlanHeader *__restrict__ hdr,
     const uint32_t *__restrict__ uniq, const int32_t *__restrict__ seg,
     const int32_t *__restrict__ counts, const int32_t *__restrict__ perm, int n,
-    const float *__restrict__ grads, float lr, uint32_t *__restrict__ long_list) {
+    const float *__restrict__ grads, float lr, uint32_t *__restrict__ long_list, ApplyMaps maps) {
     const int U = static_cast<int>(hdr->n_unique);
     const int lane = lane_id();
     const int nwaves = gridDim.x * 16;
@@ -93,12 +93,14 @@ __global__ __launch_bounds__(1024, 8) void apply_unique_kernel(
             continue;  // out-of-range id: ignored
         float *dst_row = dst + row * static_cast<uint64_t>(width);
         const int pv = perm[min(s + lane, n - 1)];   // lanes 0 .. len-1: the run's occurrence indices
+        Second d2{nullptr, false};
+        if (MODE == kModeOpt)
+            opt_rows(d2, maps, row, width);
         if (len <= kShortRun) {
-            short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, true, Second{nullptr, false});
+            short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, true, d2);
         } else {
             for (int c0 = 0; c0 < width; c0 += kWave)
-                medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, true,
-                                          Second{nullptr, false});
+                medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, true, d2);
         }
     }
 }
@@ -111,20 +113,22 @@ __global__ __launch_bounds__(1024, 8) void apply_long_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width, const PlanHeader *__restrict__ hdr,
     const uint32_t *__restrict__ uniq, const int32_t *__restrict__ seg,
     const int32_t *__restrict__ counts, const int32_t *__restrict__ perm, int n,
-    const float *__restrict__ grads, float lr, const uint32_t *__restrict__ long_list) {
+    const float *__restrict__ grads, float lr, const uint32_t *__restrict__ long_list, ApplyMaps maps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
     const int nslice = (width + kWave - 1) / kWave;
     const long long items = hdr->reserved[0] * nslice;
     const int w = static_cast<int>(threadIdx.x >> 6);
-    const ApplyMaps maps{nullptr, nullptr, nullptr, nullptr, nullptr};
     for (long long it = blockIdx.x; it < items; it += gridDim.x) {
         const int u = static_cast<int>(long_list[it / nslice]);
         const int j = static_cast<int>(it % nslice);
         const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
-        if (row < dst_rows)
-            coop_slices<MODE, false>(dst + row * static_cast<uint64_t>(width), true,
-                                     Second{nullptr, false}, grads, perm, maps, n, lr, seg[u], counts[u], width,
-                                     j, nslice, w, reinterpret_cast<float *>(s_apply));
+        if (row < dst_rows) {
+            Second d2{nullptr, false};
+            if (MODE == kModeOpt)
+                opt_rows(d2, maps, row, width);
+            coop_slices<MODE, false>(dst + row * static_cast<uint64_t>(width), true, d2, grads, perm, maps, n, lr,
+                                     seg[u], counts[u], width, j, nslice, w, reinterpret_cast<float *>(s_apply));
+        }
         __syncthreads();
     }
 }
@@ -147,7 +151,7 @@ namespace ha {
 
 template <int MODE>
 int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, int64_t n,
-                    const float *grads, float lr, hipStream_t stream);
+                    const float *grads, float lr, hipStream_t stream, ApplyMaps maps = ApplyMaps{});
 
 template <int MODE>
 static int apply_launch(float *dst, int64_t dst_rows, int64_t width,
@@ -186,7 +190,7 @@ static int apply_launch(float *dst, int64_t dst_rows, int64_t width,
 namespace ha {
 template <int MODE>
 int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, int64_t n,
-                    const float *grads, float lr, hipStream_t stream) {
+                    const float *grads, float lr, hipStream_t stream, ApplyMaps maps) {
     HA_REQUIRE(dst && plan_ws && grads && n > 0 && width >= 1 && width < (1 << 30), "apply_by_unique: bad arguments");
     PlanPtrs p = plan_layout(plan_ws, n);
     HA_CHECK_HIP(hipMemsetAsync(&p.hdr->reserved[0], 0, sizeof(int64_t), stream));
@@ -195,19 +199,88 @@ int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, 
     const dim3 grid(512), block(1024);   // two workgroups per compute unit, looping over the keys
     if (vec_ok)
         hipLaunchKernelGGL((apply_unique_kernel<MODE, 4>), grid, block, 0, stream, dst, (uint64_t)dst_rows,
-                           (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt);
+                           (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt, maps);
     else
         hipLaunchKernelGGL((apply_unique_kernel<MODE, 1>), grid, block, 0, stream, dst, (uint64_t)dst_rows,
-                           (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt);
+                           (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt, maps);
     hipLaunchKernelGGL((apply_long_kernel<MODE>), grid, block, kApplyLdsBytes, stream, dst, (uint64_t)dst_rows,
-                       (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt);
+                       (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt, maps);
     HA_LAUNCH_CHECK();
     return 0;
 }
-template int apply_by_unique<kModeSgd>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t);
-template int apply_by_unique<kModePush>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t);
-template int apply_by_unique<kModeReduce>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t);
+template int apply_by_unique<kModeSgd>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t, ApplyMaps);
+template int apply_by_unique<kModePush>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t, ApplyMaps);
+template int apply_by_unique<kModeReduce>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t, ApplyMaps);
+template int apply_by_unique<kModeOpt>(float *, int64_t, int64_t, void *, int64_t, const float *, float, hipStream_t, ApplyMaps);
 }  // namespace ha
+
+// ---- fused deduplicate + optimizer step ---------------------------------------------------------------
+// The reference deduplicates the sparse gradient (host np.unique + DeduplicateIndexedSlices, python/hetu/
+// ndarray.py:532-554: the reduced rows are written to HBM) and then runs the optimizer kernel on the reduced
+// slices (python/hetu/gpu_links/OptimizerLink.py:52-100).  Here one launch does both: the apply's
+// occurrence-ordered sum of a key's gradient rows stays in registers and is consumed by the optimizer step of
+// that row (kModeOpt, scatter_dev.h) -- same sums, same expressions, so the result equals
+// ha_dedup_reduce + {AdaGrad,Adam,AdamW}OptimizerSparseUpdate bit for bit.
+namespace ha {
+template <int VEC>
+__global__ __launch_bounds__(1024, 4) void apply_opt_kernel(
+    float *__restrict__ dst, uint64_t dst_rows, int width, const uint32_t *__restrict__ sorted,
+    const int32_t *__restrict__ perm, int n, const float *__restrict__ grads, ApplyMaps maps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
+    apply_body<kModeOpt, VEC>(dst, dst_rows, width, sorted, perm, nullptr, n, grads, 1.f, blockIdx.x, s_apply,
+                              nullptr, maps);
+}
+}  // namespace ha
+
+extern "C" int ha_sparse_opt_fused_f32ids(int kind, float *param, int64_t rows, int64_t width, const float *ids,
+                                          int64_t n, const float *grads, float *state1, float *state2,
+                                          const float *hyper_host, void *plan_ws, ha_stream_t stream) {
+    using namespace ha;
+    HA_REQUIRE(kind == kAdaGrad || kind == kAdam || kind == kAdamW, "sparse_opt_fused: kind must be 0 (AdaGrad), "
+               "1 (Adam) or 2 (AdamW)");
+    HA_REQUIRE(n >= 0 && rows >= 0 && width >= 1 && width < (1 << 30), "sparse_opt_fused: bad sizes");
+    if (n == 0)
+        return 0;
+    HA_REQUIRE(param && ids && grads && state1 && (kind == kAdaGrad || state2) && hyper_host && plan_ws,
+               "sparse_opt_fused: null pointer");
+    hipStream_t s = as_stream(stream);
+    if (ha_plan_sort_f32ids_lim(ids, n, plan_ws, static_cast<uint64_t>(rows), stream))
+        return -1;
+    ApplyMaps maps{};
+    maps.opt_s1 = state1;
+    maps.opt_s2 = kind == kAdaGrad ? nullptr : state2;
+    maps.opt_kind = kind;
+    maps.oa = OptArgs{};
+    maps.oa.lr = hyper_host[0];
+    maps.oa.eps = hyper_host[1];
+    maps.oa.beta1 = hyper_host[2];
+    maps.oa.beta2 = hyper_host[3];
+    maps.oa.beta1t = hyper_host[4];
+    maps.oa.beta2t = hyper_host[5];
+    maps.oa.weight_decay = hyper_host[6];
+    if (n > kSmallMax) {
+        if (ha_plan_finish(plan_ws, n, stream))
+            return -1;
+        return apply_by_unique<kModeOpt>(param, rows, width, plan_ws, n, grads, 1.f, s, maps);
+    }
+    PlanPtrs p = plan_layout(plan_ws, n);
+    const unsigned blocks = static_cast<unsigned>((n + kPosPerBlock - 1) / kPosPerBlock);
+    const bool vec_ok = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(param) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(grads) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(state1) % 16 == 0) &&
+                        (state2 == nullptr || reinterpret_cast<uintptr_t>(state2) % 16 == 0);
+    if (vec_ok) {
+        HA_ALLOW_LDS((apply_opt_kernel<4>), kApplyLdsBytes);
+        hipLaunchKernelGGL((apply_opt_kernel<4>), dim3(blocks), dim3(1024), kApplyLdsBytes, s, param, (uint64_t)rows,
+                           (int)width, p.sorted, p.perm, (int)n, grads, maps);
+    } else {
+        HA_ALLOW_LDS((apply_opt_kernel<1>), kApplyLdsBytes);
+        hipLaunchKernelGGL((apply_opt_kernel<1>), dim3(blocks), dim3(1024), kApplyLdsBytes, s, param, (uint64_t)rows,
+                           (int)width, p.sorted, p.perm, (int)n, grads, maps);
+    }
+    HA_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ha_sgd_apply(float *table, int64_t rows, int64_t width,
                             const void *plan_ws, int64_t n, const float *grads,

@@ -2,6 +2,7 @@
 // (semantics and work mapping: scatter.hip).
 #pragma once
 #include "common.h"
+#include "optim_dev.h"
 
 namespace ha {
 
@@ -9,6 +10,8 @@ enum ApplyMode {
     kModeSgd = 0,     // row = row - lr*g  (two roundings per occurrence)
     kModePush = 1,    // row = row + (0 + g0 + g1 ...)   (reduce in order, then one add)
     kModeReduce = 2,  // out[u] = 0 + g0 + g1 ...
+    kModeOpt = 3,     // g = 0 + g0 + g1 ... (the dedup-reduce), then one AdaGrad / Adam / AdamW step of the row
+                      // with it: the reduced gradient never leaves the registers (fused deduplicate + optimizer)
 };
 
 // Optional indirections used by the embedding cache (cache.hip): the destination row of unique key u
@@ -24,13 +27,64 @@ struct ApplyMaps {
     // (Line::accumulate, src/hetu_cache/include/embedding.h:78-91).  rowmap2[u] < 0 = no second row.
     float *dst2;
     const int32_t *rowmap2;
+    // kModeOpt: optimizer state arrays (row-major like dst), kind and hyper-parameters
+    float *opt_s1, *opt_s2;
+    int opt_kind;
+    OptArgs oa;
 };
 
 // second destination row of the current key (on == false: none)
 struct Second {
     float *row;
     bool on;
+    // kModeOpt: the state rows of the current key
+    float *s1, *s2;
+    int opt_kind;
+    OptArgs oa;
 };
+
+// kModeOpt epilogue: p / s1 / s2 at `col` of the current key's rows take one optimizer step with gradient g
+template <int VEC>
+__device__ __forceinline__ void opt_epilogue(float *__restrict__ dst_row, const Second &d2, int col, const float *g) {
+    float p[VEC], x1[VEC], x2[VEC];
+    const bool two = d2.opt_kind != kAdaGrad;
+    if (VEC == 4) {
+        *reinterpret_cast<float4v *>(p) = ld4(dst_row + col);
+        *reinterpret_cast<float4v *>(x1) = ld4(d2.s1 + col);
+        if (two)
+            *reinterpret_cast<float4v *>(x2) = ld4(d2.s2 + col);
+    } else {
+        p[0] = dst_row[col];
+        x1[0] = d2.s1[col];
+        if (two)
+            x2[0] = d2.s2[col];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        if (!two)
+            x2[k] = 0.f;
+        opt_step_rt(d2.opt_kind, p[k], g[k], x1[k], x2[k], d2.oa);
+    }
+    if (VEC == 4) {
+        st4(dst_row + col, *reinterpret_cast<float4v *>(p));
+        st4(d2.s1 + col, *reinterpret_cast<float4v *>(x1));
+        if (two)
+            st4(d2.s2 + col, *reinterpret_cast<float4v *>(x2));
+    } else {
+        dst_row[col] = p[0];
+        d2.s1[col] = x1[0];
+        if (two)
+            d2.s2[col] = x2[0];
+    }
+}
+
+// kModeOpt: the state rows of destination row `row`
+__device__ __forceinline__ void opt_rows(Second &d2, const ApplyMaps &maps, uint64_t row, int width) {
+    d2.s1 = maps.opt_s1 + row * static_cast<uint64_t>(width);
+    d2.s2 = maps.opt_s2 ? maps.opt_s2 + row * static_cast<uint64_t>(width) : nullptr;
+    d2.opt_kind = maps.opt_kind;
+    d2.oa = maps.oa;
+}
 
 constexpr int kPosPerBlock = 16;   // sorted positions (= waves) per 1024-thread workgroup
 constexpr int kLookBack = 16;      // positions a wave looks back to find its offset in its run
@@ -138,7 +192,13 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                 for (int k = 0; k < VEC; ++k)
                     acc[b].set(k, __fadd_rn(cur.get(k), acc[b].get(k)));
             }
-            if (SIG)
+            if (MODE == kModeOpt) {
+                float gsum[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    gsum[k] = acc[b].get(k);
+                opt_epilogue<VEC>(dst_row, d2, col[b], gsum);
+            } else if (SIG)
                 acc[b].store_sc1(dst_row + col[b]);
             else
                 acc[b].store(dst_row + col[b]);
@@ -219,7 +279,9 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
     if (live) {
         if (MODE == kModePush)
             acc = __fadd_rn(dst_row[col], acc);
-        if (SIG)
+        if (MODE == kModeOpt)
+            opt_epilogue<1>(dst_row, d2, col, &acc);
+        else if (SIG)
             st1_sc1(dst_row + col, acc);
         else
             __builtin_nontemporal_store(acc, dst_row + col);
@@ -365,7 +427,9 @@ __device__ __forceinline__ void coop_slices(
         if (clive) {
             if (MODE == kModePush)
                 acc = __fadd_rn(dst_row[ccol], acc);
-            if (SIG)
+            if (MODE == kModeOpt)
+                opt_epilogue<1>(dst_row, d2, ccol, &acc);
+            else if (SIG)
                 st1_sc1(dst_row + ccol, acc);
             else
                 __builtin_nontemporal_store(acc, dst_row + ccol);
@@ -465,6 +529,8 @@ __device__ __forceinline__ bool coop_run(
         d2.on = r2 >= 0;
         d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
     }
+    if (MODE == kModeOpt)
+        opt_rows(d2, maps, row, width);
 
     coop_slices<MODE, DUAL, SIG>(dst_row, init, d2, grads, perm, maps, n, lr, s, len, width, j, workers, w, s_m,
                                  SIG ? pend + pend_slot(key) : nullptr, s_perm, wg0 - kCoopPermSpan);
@@ -589,6 +655,8 @@ __device__ __forceinline__ bool apply_body_impl(
         d2.on = r2 >= 0;
         d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
     }
+    if (MODE == kModeOpt)
+        opt_rows(d2, maps, row, width);
 
     const int nslice = (width + kWave - 1) / kWave;
     if (len <= kShortRun) {

@@ -323,6 +323,28 @@ def sgd_apply_finish(table, plan, grads, lr, stream=None, next_ids=None):
     return table
 
 
+# ---- fused deduplicate + optimizer step ------------------------------------------------------------------
+_OPT_KINDS = {"adagrad": 0, "adam": 1, "adamw": 2}
+
+
+def sparse_opt_fused(kind, param, ids, grads, state1, state2=None, lr=0.01, eps=1e-7, beta1=0.9, beta2=0.999,
+                     beta1t=0.9, beta2t=0.999, weight_decay=0.0, plan=None, stream=None):
+    """grad.deduplicate() + {AdaGrad,Adam,AdamW}OptimizerSparseUpdate (OptimizerLink.py:52-100) in one call on
+    the RAW (not deduplicated) float32 ids and their gradient rows; bit-identical to the two-step sequence."""
+    _require(param, torch.float32, "param")
+    _require(ids, torch.float32, "ids")
+    _require(grads, torch.float32, "grads")
+    n = ids.numel()
+    if plan is None:
+        plan = IndexPlan(max(n, 1), param.device)
+    hyper = (ctypes.c_float * 7)(lr, eps, beta1, beta2, beta1t, beta2t, weight_decay)
+    check(_lib.load().ha_sparse_opt_fused_f32ids(_OPT_KINDS[kind], _ptr(param), param.shape[0], param.shape[1],
+                                                 _ptr(ids), n, _ptr(grads), _ptr(state1),
+                                                 _ptr(state2) if state2 is not None else None, hyper, _ptr(plan.ws),
+                                                 _stream_ptr(stream)), "ha_sparse_opt_fused_f32ids")
+    return param
+
+
 # ---- one launch per training step: backward of batch k beside the forward of batch k+1 ---------------
 class PendingTable:
     """Per-batch hand-off table of ha_sgd_push_pull_* (include/herald_amd.h): all-zero when idle; the

@@ -307,6 +307,18 @@ int ha_apply_mapped2(float *dst, int64_t dst_rows, float *dst2, int64_t width,
                      const int32_t *rowmap, const int32_t *rowmap2,
                      const uint8_t *dst_init, ha_stream_t stream);
 
+/* ---- fused deduplicate + optimizer step -----------------------------------------------------------
+ * One call for what the reference does in two (python/hetu/gpu_links/OptimizerLink.py:52-100:
+ * grad.deduplicate(stream), then {AdaGrad,Adam,AdamW}OptimizerSparseUpdate on the reduced slices): index plan
+ * of the raw ids, then ONE launch in which every key's gradient rows are summed in occurrence order in
+ * registers and consumed by that row's optimizer step -- the reduced slices never travel through HBM.
+ * Bit-identical to ha_dedup_reduce + the optimizer symbol.  kind: 0 AdaGrad (state1 = accumulator, state2
+ * unused), 1 Adam, 2 AdamW (state1 = exp_avg, state2 = exp_avg_sq).  hyper_host: 7 host floats
+ * {lr, eps, beta1, beta2, beta1t, beta2t, weight_decay}.  plan_ws: ha_plan_bytes(n) of device scratch. */
+int ha_sparse_opt_fused_f32ids(int kind, float *param, int64_t rows, int64_t width, const float *ids,
+                               int64_t n, const float *grads, float *state1, float *state2,
+                               const float *hyper_host, void *plan_ws, ha_stream_t stream);
+
 /* ---- fused launches (two per training step) --------------------------------
  * ha_lookup_sort_*    == ha_gather_* + ha_plan_sort_*   in ONE launch (forward: the lookup of a
  *                        batch and the index plan its backward will need);

@@ -152,3 +152,50 @@ def test_cpu_named_symbols_serve_gpu_arrays_and_refuse_host_arrays(dev):
     host = [ops.DLHolder(torch.from_numpy(x)) for x in (table, ids, np.empty((20, 5, 64), np.float32))]
     assert L.cpu_EmbeddingLookup(host[0].handle, host[1].handle, host[2].handle) == -1
     assert b"no CPU fallback" in L.ha_last_error()
+
+
+@pytest.mark.parametrize("kind", ["adagrad", "adam", "adamw"])
+@pytest.mark.parametrize("rows,width,n", [(500, 400, 100), (3000, 512, 6656), (40, 64, 3000), (300, 7, 200),
+                                          (100000, 128, 40000)])
+def test_fused_dedup_plus_optimizer_equals_the_two_step_sequence(dev, kind, rows, width, n):
+    """ha_sparse_opt_fused_f32ids on the RAW ids (duplicates, hot keys: short, medium and long runs; the
+    by-unique path above 36,864 ids) == grad.deduplicate() + the optimizer symbol, bit for bit; and within the
+    reference tests' 1e-5 of the numpy oracle."""
+    rng = np.random.default_rng(rows + width + n)
+    param = rng.standard_normal((rows, width), dtype=np.float32)
+    hot = rng.integers(0, rows, size=6)
+    ids = np.where(rng.random(n) < 0.4, hot[rng.integers(0, 6, size=n)], rng.integers(0, rows, size=n)).astype(np.float32)
+    vals = rng.standard_normal((n, width), dtype=np.float32)
+    s1 = np.abs(rng.standard_normal((rows, width), dtype=np.float32)) if kind == "adagrad" else np.zeros_like(param)
+    s2 = np.zeros_like(param)
+    hyper = dict(lr=0.01, eps=1e-7, beta1=0.9, beta2=0.999, beta1t=0.9, beta2t=0.999, weight_decay=0.01)
+    # fused
+    fp, f1, f2 = [torch.from_numpy(x.copy()).to(dev) for x in (param, s1, s2)]
+    ops.sparse_opt_fused(kind, fp, torch.from_numpy(ids).to(dev), torch.from_numpy(vals).to(dev), f1,
+                         None if kind == "adagrad" else f2, **hyper)
+    # two steps through the reference-named symbols
+    tp, t1, t2 = [torch.from_numpy(x.copy()).to(dev) for x in (param, s1, s2)]
+    sl = ops.IndexedSlices(torch.from_numpy(ids).to(dev), torch.from_numpy(vals).to(dev), (rows, width)).deduplicate()
+    di, dv = sl.indices.contiguous(), sl.values.contiguous()
+    if kind == "adagrad":
+        ops.dl_call("AdaGradOptimizerSparseUpdate", [tp, di, dv, t1], scalars=[ctypes.c_float(0.01), ctypes.c_float(1e-7)])
+    else:
+        sc = [ctypes.c_float(x) for x in (0.01, 0.9, 0.999, 0.9, 0.999, 1e-7)]
+        if kind == "adam":
+            ops.dl_call("AdamOptimizerSparseUpdate", [tp, di, dv, t1, t2], scalars=sc)
+        else:
+            ops.dl_call("AdamWOptimizerSparseUpdate", [tp, di, dv, t1, t2], scalars=sc + [ctypes.c_float(0.01)])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(fp.cpu().numpy(), tp.cpu().numpy())
+    np.testing.assert_array_equal(f1.cpu().numpy(), t1.cpu().numpy())
+    if kind != "adagrad":
+        np.testing.assert_array_equal(f2.cpu().numpy(), t2.cpu().numpy())
+    # numpy oracle
+    uniq, _, red = cpu.dedup_reduce(ids, vals)
+    if kind == "adagrad":
+        cpu.adagrad_sparse(param, s1, uniq, red, 0.01, 1e-7)
+    else:
+        cpu.adam_sparse(param, s1, s2, uniq, red, 0.01, 0.9, 0.999, np.float32(0.9), np.float32(0.999), 1e-7,
+                        0.01 if kind == "adamw" else None)
+    np.testing.assert_allclose(fp.cpu().numpy(), param, **TOL)
+    np.testing.assert_allclose(f1.cpu().numpy(), s1, **TOL)
