@@ -9,6 +9,8 @@ libherald_amd.so, in the three placements the reference's run_hetu.py offers:
 
   --embedding hbm    table in this GPU's HBM: EmbeddingLookUp -> DLGpuEmbeddingLookUp,
                      sparse SGD -> SGDOptimizerSparseUpdate           (comm_mode None)
+  --embedding step   as hbm, but ONE launch per training step: ha_sgd_push_pull applies the sparse SGD of batch
+                     k and looks batch k+1 up (rows both batches touch handed over inside the launch)
   --embedding ps     row-range sharded store (one shard per rank): SparsePull / SparsePush through
                      ParameterServerCommunicateOp                     (comm_mode PS; torchrun for N > 1)
   --embedding cache  HET cache (LRU / LFU / LFUOpt, bounded staleness) in front of the store
@@ -87,7 +89,7 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
     if table_init is None:
         g = torch.Generator(device=dev).manual_seed(seed + 1)
         table_init = torch.randn((rows, width), generator=g, device=dev) * 0.01    # init.random_normal(stddev=0.01)
-    if embedding == "hbm":
+    if embedding in ("hbm", "step"):
         param = hetu_ops.EmbeddingParameter(table=table_init.clone())
         config = hetu_ops.Config(comm_mode=None)
         comm = None
@@ -105,13 +107,26 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
     lookup.forward_hook(config)
     lookup_grad = hetu_ops.EmbeddingLookUp_Gradient(param.shape)
 
+    fused = None
+    if embedding == "step":
+        from herald_amd import ops
+        n = batch * NFIELD
+        fused = {"plans": [ops.IndexPlan(n, dev), ops.IndexPlan(n, dev)],
+                 "pends": [ops.PendingTable(dev), ops.PendingTable(dev)],
+                 "outs": [torch.empty((batch, NFIELD, width), dtype=torch.float32, device=dev) for _ in range(2)]}
+        ops.lookup_sort_pend(param.table, ids_of(0).reshape(-1), fused["plans"][0], fused["pends"][0],
+                             out=fused["outs"][0])                  # the lookup of the first batch
+
     losses = []
     t0 = time.perf_counter()
     for k in range(steps):
         state["k"] = k
         ids, dense, label = dev_batches[k % len(dev_batches)]
-        emb = torch.empty((batch, NFIELD, width), dtype=torch.float32, device=dev)
-        lookup.compute(ids, emb)                                   # embedding_lookup_op
+        if fused is not None:
+            emb = fused["outs"][k % 2].detach().clone()            # looked up by the previous step's launch
+        else:
+            emb = torch.empty((batch, NFIELD, width), dtype=torch.float32, device=dev)
+            lookup.compute(ids, emb)                               # embedding_lookup_op
         emb.requires_grad_(True)
         pred = tower(dense, emb.reshape(batch, NFIELD * width))
         loss = torch.nn.functional.binary_cross_entropy(pred, label)
@@ -119,7 +134,12 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         loss.backward()
         opt.step()
         grad = lookup_grad.compute(emb.grad, ids)                  # IndexedSlices(indices, values)
-        if comm is None:
+        if fused is not None:
+            # sparse SGD of this batch + lookup of the next one, one launch (plans / pending tables alternate)
+            ops.sgd_push_pull(param.table, fused["plans"][k % 2], grad.values.reshape(-1, width).contiguous(), lr,
+                              fused["pends"][k % 2], ids_of(k + 1).reshape(-1), fused["plans"][(k + 1) % 2],
+                              fused["pends"][(k + 1) % 2], next_out=fused["outs"][(k + 1) % 2])
+        elif comm is None:
             hetu_ops.sgd_update_sparse(param, grad, lr)            # OptimizerOp, sparse SGD branch
         else:
             comm.compute(grad)                                     # -lr scale, push, (barrier), pull of batch k+1
@@ -133,7 +153,7 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--embedding", choices=["hbm", "ps", "cache"], default="hbm")
+    ap.add_argument("--embedding", choices=["hbm", "step", "ps", "cache"], default="hbm")
     ap.add_argument("--cache", choices=["LRU", "LFU", "LFUOpt"], default="LRU")
     ap.add_argument("--bound", type=int, default=100)
     ap.add_argument("--rows", type=int, default=33762577)
