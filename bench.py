@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -50,6 +51,10 @@ def parse_args():
                    help="rows of the pinned host table of the cold-tier line (x 64 floats = 8 GiB)")
     p.add_argument("--graph-steps", type=int, default=32,
                    help="steps captured per hipGraph (1 = eager launches)")
+    p.add_argument("--lookahead", type=int, default=1, choices=(1, 3),
+                   help="with --launches 1: 3 = ha_step_* (batch k+1 was sorted and finished by earlier launches: "
+                        "updated rows are forwarded from the applying waves, nothing waits inside the launch), "
+                        "1 = ha_sgd_push_pull_* (in-launch hand-off through pending tables; default: faster today)")
     p.add_argument("--launches", type=int, default=1, choices=(1, 2),
                    help="launches per step: 1 = ha_sgd_push_pull (apply(k) beside lookup(k+1), default), "
                         "2 = ha_lookup_sort + ha_sgd_apply_finish")
@@ -293,8 +298,15 @@ def main():
 
     n = args.batch * args.fields
     G = max(1, args.graph_steps)
-    if args.distinct_batches >= G:
-        args.distinct_batches -= args.distinct_batches % G     # graphs never straddle the wrap-around
+    one = args.launches == 1
+    ahead2 = one and args.lookahead == 3
+    # graphs never straddle the wrap-around of the batch list; ha_step_* rotates four plans and four key tables,
+    # so the list is also cut to a multiple of 4 (a graph then depends on k % nb only)
+    period = (G * 4 // math.gcd(G, 4)) if ahead2 else G
+    if args.distinct_batches >= period:
+        args.distinct_batches -= args.distinct_batches % period
+    elif ahead2:
+        raise SystemExit("--lookahead 3 needs --distinct-batches >= lcm(graph steps, 4) = %d" % period)
     ids_host, uniq_counts = make_batches(args, rank, world)
     ids_dev = torch.from_numpy(ids_host).to(dev)
     table = init_table(args.rows, args.width, dev)
@@ -305,8 +317,24 @@ def main():
     outs = [torch.empty((n, args.width), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     nb = ids_dev.shape[0]
     main_s = torch.cuda.Stream(device=dev)
-    one = args.launches == 1
-    if one:
+    if ahead2:
+        # One step = ONE launch (ha_step_f32ids): SGD apply of batch k, the rows of batch k+1 (forwarded from
+        # the applying waves where both batches name a row, copied from the table otherwise), plan finish of
+        # batch k+2, stable sort of batch k+3.  Every step applies one batch, looks one batch up, finishes one
+        # plan and sorts one batch, as before; sorting the first three batches and looking the first one up is
+        # the prologue (untimed).
+        pipe = ops.StepPipeline(table, n, LR)
+        plans = pipe.plans
+        with torch.cuda.stream(main_s):
+            pipe.reset(stream=main_s)
+            pipe.launch(-3, 0, None, 0, None, 0, ids_dev[0], stream=main_s)
+            pipe.launch(-2, 0, None, 0, None, n, ids_dev[1 % nb], stream=main_s)
+            pipe.launch(-1, 0, None, n, outs[0], n, ids_dev[2 % nb], stream=main_s)
+
+        def step(k):
+            b = k % nb
+            pipe.launch(k, n, grads[b % nbuf], n, outs[(b + 1) % nb % nbuf], n, ids_dev[(b + 3) % nb], stream=main_s)
+    elif one:
         # One step = ONE launch (ha_sgd_push_pull_f32ids): the backward of batch k (fused SGD apply + plan
         # finish) beside the forward of batch k+1 (gather + stable sort), rows both batches touch handed
         # over inside the launch.  Every step applies one batch and looks one batch up, as before; the
@@ -408,10 +436,13 @@ def main():
     if one:
         # the step IS one launch of ha::step_kernel: its average duration is the HIP-event time of the
         # timed region / K, measured on the launch stream
-        traffic, traffic_src = pmc_traffic("ha::step_kernel")
+        kname = "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
+        traffic, traffic_src = pmc_traffic(kname)
         dom_bytes = fwd_b + bwd_b
         ach = dom_bytes / (dev_ms / args.steps * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "ha::step_kernel (SGD apply + finish of batch k, gather + sort of batch k+1)",
+        roofline = {"bound": "hbm", "kernel": kname + (" (SGD apply of batch k, rows of batch k+1, plan finish of "
+                                                       "batch k+2, sort of batch k+3)" if ahead2 else
+                                                       " (SGD apply + finish of batch k, gather + sort of batch k+1)"),
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": dev_ms / args.steps * 1e3,
@@ -480,10 +511,11 @@ def main():
                                "cache-limit-0.1 tier is not part of this line"
                                % (args.batch, args.width, args.fields, args.rows,
                                   args.rows * args.width * 4 / 1e9,
+                                  "one launch: apply(k), rows of k+1 forwarded / copied, finish(k+2), sort(k+3)" if ahead2 else
                                   "one launch: apply(k) beside lookup(k+1)" if one else "two launches"),
                    "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,
                    "grad_and_out_buffers": nbuf,
-                   "launches_per_step": args.launches,
+                   "launches_per_step": args.launches, "lookahead_batches": (3 if ahead2 else 1),
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
                              else "eager",
                    "parallelism": "1 GPU"},
@@ -493,7 +525,7 @@ def main():
         "host_bound": bool(t_enq * 1e3 > dev_ms),
         "roofline": roofline, "kernels": kernels,
     }
-    if one:
+    if one and not ahead2:
         torch.cuda.synchronize()
         result["handoff_timeouts"] = int(plans[0].handoff_timed_out()) + int(plans[1].handoff_timed_out())
     if not args.no_cpu_baseline:

@@ -102,6 +102,10 @@ def _declare(L):
     L.ha_pend_bytes.argtypes = []
     L.ha_plan_handoff_timeout.restype = vp
     L.ha_plan_handoff_timeout.argtypes = [vp]
+    L.ha_step_tab_bytes.restype = sz
+    L.ha_step_tab_bytes.argtypes = []
+    L.ha_step_max_ids.restype = i64
+    L.ha_step_max_ids.argtypes = []
     sigs = {
         "ha_gather_f32ids": [vp, i64, i64, vp, i64, vp, vp],
         "ha_gather_u64ids": [vp, i64, i64, vp, i64, vp, vp],
@@ -143,6 +147,11 @@ def _declare(L):
         "ha_lookup_sort_pend_u64ids": [vp, i64, i64, vp, i64, vp, vp, vp, vp],
         "ha_sgd_push_pull_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, vp],
         "ha_sgd_push_pull_u64ids": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, vp],
+        "ha_step_tab_reset": [vp, vp],
+        "ha_step_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp],
+        "ha_step_u64ids": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp],
+        "ha_debug_step_fwd_timeline": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp,
+                                       vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

@@ -125,4 +125,15 @@ __device__ __forceinline__ uint32_t pend_slot(uint32_t key) {
     return (key * 0x9E3779B1u) >> (32 - kPendBits);
 }
 
+
+// Key table of a batch (step.hip, ha_step_*): open addressing, 2^kTabBits entries {key, first sorted
+// position, occurrences - 1, unused}, all-ones = empty; filled by the rank tiles of the launch that sorts
+// the batch (32-bit atomics: claim the key, min the position, add the count), read by later launches only.
+constexpr int kTabBits = 15;
+constexpr uint32_t kTabMask = (1u << kTabBits) - 1u;
+constexpr uint32_t kTabEmpty = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t tab_slot(uint32_t key) {
+    return (key * 0x9E3779B1u) >> (32 - kTabBits);
+}
+
 }  // namespace ha

@@ -151,7 +151,7 @@ template <typename IdT>
 __device__ __forceinline__ void rank_tile_body_int(
     const IdT *__restrict__ ids, int n, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ sorted, int32_t *__restrict__ perm, int tile,
-    uint32_t *s_mem) {
+    uint32_t *s_mem, uint32_t *r_out = nullptr, uint32_t *key_out = nullptr) {
     const int npad = (n + 127) & ~127;      // 32 j-splits x 4 keys
     uint32_t *s_keys = s_mem;               // [npad]
     uint32_t *s_part = s_mem + npad;        // [32 splits][32 elements]
@@ -224,6 +224,10 @@ __device__ __forceinline__ void rank_tile_body_int(
         sorted[r] = ki;
         perm[r] = i;
         keys[i] = ki;
+        if (r_out) {
+            *r_out = r;
+            *key_out = ki;
+        }
     }
 }
 
@@ -246,7 +250,7 @@ __device__ __forceinline__ float2v pk_sub_clamp01(float2v a, float2v b) {  // cl
 __device__ __forceinline__ void rank_tile_body_f32(
     const float *__restrict__ ids, int n, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ sorted, int32_t *__restrict__ perm, int tile,
-    uint32_t *s_mem) {
+    uint32_t *s_mem, uint32_t *r_out = nullptr, uint32_t *key_out = nullptr) {
     const int npad = (n + 127) & ~127;
     float *s_keys = reinterpret_cast<float *>(s_mem);   // [npad] keys as floats
     uint32_t *s_part = s_mem + npad;                    // [32 splits][32 elements]
@@ -343,6 +347,10 @@ __device__ __forceinline__ void rank_tile_body_f32(
         sorted[r] = key;
         perm[r] = i;
         keys[i] = key;
+        if (r_out) {
+            *r_out = r;
+            *key_out = key;
+        }
     }
 }
 
@@ -350,15 +358,15 @@ template <typename IdT>
 __device__ __forceinline__ void rank_tile_body(
     const IdT *__restrict__ ids, int n, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ sorted, int32_t *__restrict__ perm, int tile,
-    uint32_t *s_mem) {
-    rank_tile_body_int<IdT>(ids, n, keys, sorted, perm, tile, s_mem);
+    uint32_t *s_mem, uint32_t *r_out = nullptr, uint32_t *key_out = nullptr) {
+    rank_tile_body_int<IdT>(ids, n, keys, sorted, perm, tile, s_mem, r_out, key_out);
 }
 template <>
 __device__ __forceinline__ void rank_tile_body<float>(
     const float *__restrict__ ids, int n, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ sorted, int32_t *__restrict__ perm, int tile,
-    uint32_t *s_mem) {
-    rank_tile_body_f32(ids, n, keys, sorted, perm, tile, s_mem);
+    uint32_t *s_mem, uint32_t *r_out, uint32_t *key_out) {
+    rank_tile_body_f32(ids, n, keys, sorted, perm, tile, s_mem, r_out, key_out);
 }
 
 // Small-n finish (n <= kSmallMax): ceil(n/1024) independent workgroups, one sorted position per
@@ -414,7 +422,7 @@ __device__ __forceinline__ void finish_block_body(
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
     int b, uint32_t *s_w, const uint32_t *__restrict__ chunk_heads = nullptr,
-    const HeadProbe *hp = nullptr) {
+    const HeadProbe *hp = nullptr, uint32_t *key_tab = nullptr, uint64_t key_rows = 0) {
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t *s_before = s_w, *s_heads = s_w + 16, *s_first = s_w + 32, *s_cand = s_w + 48;
     const int p = b * 1024 + tid;
@@ -505,6 +513,20 @@ __device__ __forceinline__ void finish_block_body(
             else
                 nxt = static_cast<int32_t>(min(next_after, static_cast<uint32_t>(n)));
             counts[ui] = nxt - p;
+            // key table of the batch (step.hip, ha_step_*): one entry per unique key of the table's range --
+            // claim a slot (keys are unique here, so only different keys ever meet), then plain stores
+            if (key_tab != nullptr && k < key_rows) {
+                uint32_t sl = tab_slot(k);
+                for (;;) {
+                    uint32_t expect = kTabEmpty;
+                    if (__hip_atomic_compare_exchange_strong(key_tab + 4 * sl, &expect, k, __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        break;
+                    sl = (sl + 1) & kTabMask;
+                }
+                key_tab[4 * sl + 1] = static_cast<uint32_t>(p);
+                key_tab[4 * sl + 2] = static_cast<uint32_t>(nxt - p - 1);
+            }
         }
     }
     if (tid == 0 && (b + 1) * 1024 >= n) {  // the last chunk

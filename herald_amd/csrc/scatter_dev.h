@@ -103,6 +103,47 @@ __device__ __forceinline__ void signal_done(uint32_t *pend_word, int units) {
                                __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- forwarding of updated rows (step.hip, ha_step_*: two batches of lookahead) ------------------------
+// The next batch was sorted by an EARLIER launch, so its sorted keys, occurrence indices and key table
+// (common.h, StepTab) are complete when this launch starts: the wave that holds the final values of a row
+// (slice) in registers also writes them to every output row of the next batch that names the key -- the
+// lookup of that batch then only copies the rows this batch does not touch, nothing waits inside the
+// launch and the updated rows are not read back from HBM.
+enum Handoff { kHandNone = 0, kHandSignal = 1, kHandForward = 2 };
+struct Hand {
+    uint32_t *pend;            // kHandSignal: pending table of this batch
+    const uint4 *tab;          // kHandForward: key table of the NEXT batch (nullptr: no next batch)
+    const int32_t *nperm;      //   its occurrence indices in sorted order (= output rows)
+    int n_next;
+    float *out;                //   its output rows [n_next, width]
+};
+// destinations of the current key in the next batch (wave-uniform except dv)
+struct Fwd {
+    int start, m;   // sorted positions [start, start + m) of the next batch hold the key; m == 0: none
+    int dv;         // lane l: output row of position start + l (l < min(m, 64))
+};
+__device__ __forceinline__ uint4 fwd_probe(const Hand &hd, uint32_t key) {   // the first probe, issued early
+    return hd.tab[tab_slot(key)];
+}
+__device__ __forceinline__ Fwd fwd_resolve(const Hand &hd, uint32_t key, uint4 e) {
+    Fwd f{0, 0, 0};
+    uint32_t sl = tab_slot(key);
+    while (e.x != key) {          // wave-uniform
+        if (e.x == kTabEmpty)
+            return f;
+        sl = (sl + 1) & kTabMask;
+        e = hd.tab[sl];
+    }
+    f.start = static_cast<int>(e.y);
+    f.m = static_cast<int>(e.z + 1u);
+    f.dv = hd.nperm[min(f.start + lane_id(), hd.n_next - 1)];
+    return f;
+}
+// occurrence indices of destinations [j0, j0 + 64) of the key (the first 64 come with fwd_resolve)
+__device__ __forceinline__ int fwd_dests(const Hand &hd, const Fwd &f, int j0) {
+    return j0 == 0 ? f.dv : hd.nperm[min(f.start + j0 + lane_id(), hd.n_next - 1)];
+}
+
 template <int MODE>
 __device__ __forceinline__ float step(float acc, float g, float lr) {
     if (MODE == kModeSgd)
@@ -142,12 +183,14 @@ struct Vec<1> {
 // ---- short runs (1..kShortRun occurrences): one wave, whole row --------------------------------
 // Columns [cbase, cbase + VB*64*VEC); the table row and every occurrence row are requested in one
 // batch (branch-free, clamped), then applied in occurrence order.
-template <int MODE, int VEC, int VB, bool DUAL, bool SIG = false>
+template <int MODE, int VEC, int VB, bool DUAL, int HAND = kHandNone>
 __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                                             const float *__restrict__ grads,
                                             int width, int cbase, int pv,
                                             int lane0, int len, float lr,
-                                            bool init, Second d2) {
+                                            bool init, Second d2, const Hand &hd = Hand{},
+                                            uint32_t key = 0, uint4 pe = uint4{0, 0, 0, 0}, Fwd *fw = nullptr,
+                                            bool resolve = false) {
     const int lane = lane_id();
     Vec<VEC> acc[VB], g[kShortRun][VB], acc2[DUAL ? VB : 1];
     int col[VB], lcol[VB];
@@ -169,6 +212,9 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
         for (int b = 0; b < VB; ++b)
             g[t][b].load(src + lcol[b]);
     }
+    // the destinations in the next batch: probe issued before the row requests, resolved behind them
+    if (HAND == kHandForward && resolve)
+        *fw = fwd_resolve(hd, key, pe);
 #pragma unroll
     for (int t = 0; t < kShortRun; ++t) {
         if (t < len) {  // wave-uniform
@@ -198,7 +244,7 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                 for (int k = 0; k < VEC; ++k)
                     gsum[k] = acc[b].get(k);
                 opt_epilogue<VEC>(dst_row, d2, col[b], gsum);
-            } else if (SIG)
+            } else if (HAND == kHandSignal)
                 acc[b].store_sc1(dst_row + col[b]);
             else
                 acc[b].store(dst_row + col[b]);
@@ -206,19 +252,42 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                 acc2[b].store(d2.row + col[b]);
         }
     }
+    if (HAND == kHandForward) {
+        for (int j0 = 0; j0 < fw->m; j0 += kWave) {
+            const int dv = fwd_dests(hd, *fw, j0);
+            const int cnt = min(kWave, fw->m - j0);
+            for (int j = 0; j < cnt; ++j) {
+                float *o = hd.out + static_cast<size_t>(__builtin_amdgcn_readlane(dv, j)) * width;
+#pragma unroll
+                for (int b = 0; b < VB; ++b)
+                    if (col[b] < width)
+                        acc[b].store(o + col[b]);
+            }
+        }
+    }
 }
 
-template <int MODE, int VEC, bool DUAL, bool SIG = false>
+template <int MODE, int VEC, bool DUAL, int HAND = kHandNone>
 __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
                                           const float *__restrict__ grads,
                                           int width, int pv, int lane0, int len,
-                                          float lr, bool init, Second d2) {
+                                          float lr, bool init, Second d2, const Hand &hd = Hand{},
+                                          uint32_t key = 0) {
     constexpr int kCols1 = kWave * VEC;
+    Fwd fw{0, 0, 0};
+    uint4 pe{0, 0, 0, 0};
+    bool resolve = HAND == kHandForward && hd.tab != nullptr;
+    if (resolve)
+        pe = fwd_probe(hd, key);
     int c = 0;
-    for (; width - c > kCols1; c += 2 * kCols1)
-        short_block<MODE, VEC, 2, DUAL, SIG>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2);
-    for (; c < width; c += kCols1)
-        short_block<MODE, VEC, 1, DUAL, SIG>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2);
+    for (; width - c > kCols1; c += 2 * kCols1) {
+        short_block<MODE, VEC, 2, DUAL, HAND>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2, hd, key, pe, &fw, resolve);
+        resolve = false;
+    }
+    for (; c < width; c += kCols1) {
+        short_block<MODE, VEC, 1, DUAL, HAND>(dst_row, grads, width, c, pv, lane0, len, lr, init, d2, hd, key, pe, &fw, resolve);
+        resolve = false;
+    }
 }
 
 // ---- medium runs (kShortRun < L < kLongRun): column-split over the run's own first waves --------
@@ -226,11 +295,13 @@ __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
 // and applies ALL occurrences of the run to its slice in order: one dword per lane = 256 contiguous
 // bytes per occurrence row.  Every occurrence index of such a run is already in the wave's window of
 // sorted positions (p-16 .. p+47), so the row loads are issued straight away, up to 32 in flight.
-template <int MODE, bool DUAL, bool SIG = false>
+template <int MODE, bool DUAL, int HAND = kHandNone>
 __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
                                              const float *__restrict__ grads,
                                              int width, int col, int pv, int lane_s,
-                                             int len, float lr, bool init, Second d2) {
+                                             int len, float lr, bool init, Second d2,
+                                             const Hand &hd = Hand{}, uint32_t key = 0,
+                                             uint4 pe = uint4{0, 0, 0, 0}, Fwd *fw = nullptr, bool resolve = false) {
     const bool live = col < width;
     const int lcol = live ? col : 0;
     float acc = 0.f, acc2 = 0.f;
@@ -269,6 +340,8 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
     load_chunk(ga, 0);
     if (len > kChunk)
         load_chunk(gb, kChunk);
+    if (HAND == kHandForward && resolve)
+        *fw = fwd_resolve(hd, key, pe);
     consume(ga, len);
     if (len > 2 * kChunk)
         load_chunk(ga, 2 * kChunk);
@@ -281,12 +354,23 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
             acc = __fadd_rn(dst_row[col], acc);
         if (MODE == kModeOpt)
             opt_epilogue<1>(dst_row, d2, col, &acc);
-        else if (SIG)
+        else if (HAND == kHandSignal)
             st1_sc1(dst_row + col, acc);
         else
             __builtin_nontemporal_store(acc, dst_row + col);
         if (DUAL && d2.on)
             __builtin_nontemporal_store(acc2, d2.row + col);
+    }
+    if (HAND == kHandForward) {
+        for (int j0 = 0; j0 < fw->m; j0 += kWave) {
+            const int dv = fwd_dests(hd, *fw, j0);
+            const int cnt = min(kWave, fw->m - j0);
+            for (int j = 0; j < cnt; ++j) {
+                float *o = hd.out + static_cast<size_t>(__builtin_amdgcn_readlane(dv, j)) * width;
+                if (live)
+                    __builtin_nontemporal_store(acc, o + col);
+            }
+        }
     }
 }
 
@@ -313,15 +397,22 @@ __device__ __forceinline__ float chain_step(float acc, float m) {
 
 // The worker part of a long run [s, s+len): this workgroup owns the 64-column slices j, j+workers, ...
 // All 16 waves call it (workgroup barriers inside); s_m = kCoopUnits x 64 floats of LDS.
-template <int MODE, bool DUAL, bool SIG = false>
+template <int MODE, bool DUAL, int HAND = kHandNone>
 __device__ __forceinline__ void coop_slices(
     float *__restrict__ dst_row, bool init, Second d2, const float *__restrict__ grads,
     const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr, int s, int len,
     int width, int j, int workers, int w, float *s_m, uint32_t *pend_word = nullptr,
-    const int32_t *s_perm = nullptr, int s_perm_first = 0) {
+    const int32_t *s_perm = nullptr, int s_perm_first = 0, const Hand &hd = Hand{}, uint32_t key = 0) {
     const int lane = lane_id();
     const int nslice = (width + kWave - 1) / kWave;
     const int my_slices = (nslice - j + workers - 1) / workers;  // slices j, j+workers, ...
+    // destinations of the key in the next batch, wave w takes w, w + 16, ...: looked up before the chain (two
+    // dependent reads that would otherwise follow it)
+    Fwd fw{0, 0, 0};
+    if (HAND == kHandForward && hd.tab != nullptr) {
+        fw = fwd_resolve(hd, key, fwd_probe(hd, key));
+        fw.dv = hd.nperm[min(fw.start + w + kPosPerBlock * lane, hd.n_next - 1)];
+    }
     for (int g0 = 0; g0 < my_slices; g0 += 8) {
         const int sg = min(8, my_slices - g0);               // slices handled at once
         const int tlen = ((kCoopUnits / sg) / kChunk) * kChunk;  // occurrences per LDS block
@@ -429,7 +520,7 @@ __device__ __forceinline__ void coop_slices(
                 acc = __fadd_rn(dst_row[ccol], acc);
             if (MODE == kModeOpt)
                 opt_epilogue<1>(dst_row, d2, ccol, &acc);
-            else if (SIG)
+            else if (HAND == kHandSignal)
                 st1_sc1(dst_row + ccol, acc);
             else
                 __builtin_nontemporal_store(acc, dst_row + ccol);
@@ -437,20 +528,41 @@ __device__ __forceinline__ void coop_slices(
                 __builtin_nontemporal_store(acc2, d2.row + ccol);
         }
         // this wave's slice of the row is complete: `len` occurrences x 1 slice (see signal_done)
-        if (SIG && chain && (j + (g0 + w) * workers) * kWave < width)
+        if (HAND == kHandSignal && chain && (j + (g0 + w) * workers) * kWave < width)
             signal_done(pend_word, len);
+        if (HAND == kHandForward && hd.tab != nullptr) {
+            // a key of a long run is usually frequent in the next batch as well: the finished slices go through
+            // LDS and all 16 waves write them, wave w to destinations w, w + 16, ...
+            if (chain)
+                s_m[w * kWave + lane] = acc;
+            __syncthreads();
+            for (int j0 = 0; j0 < fw.m; j0 += kPosPerBlock * kWave) {
+                const int dv = j0 == 0 ? fw.dv
+                                       : hd.nperm[min(fw.start + j0 + w + kPosPerBlock * lane, hd.n_next - 1)];
+                const int cnt = (min(kPosPerBlock * kWave, fw.m - j0) - w + kPosPerBlock - 1) / kPosPerBlock;
+                for (int c = 0; c < sg; ++c) {
+                    const int col = (j + (g0 + c) * workers) * kWave + lane;
+                    const float v = s_m[c * kWave + lane];
+                    if (col < width)
+                        for (int t = 0; t < cnt; ++t)
+                            __builtin_nontemporal_store(
+                                v, hd.out + static_cast<size_t>(__builtin_amdgcn_readlane(dv, t)) * width + col);
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
 // Returns false when the run is shorter than kLongRun (the caller falls through to the per-wave
 // paths).  Called by all 16 waves of a full workgroup; wg0 = its first sorted position.
-template <int MODE, bool DUAL, bool SIG = false>
+template <int MODE, bool DUAL, int HAND = kHandNone>
 __device__ __forceinline__ bool coop_run(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr, int wg0, int w, uint32_t key, uint32_t bk, uint32_t fk,
-    ApplyMaps maps, uint32_t *lds, uint32_t *pend = nullptr, int spv = 0) {
+    ApplyMaps maps, uint32_t *lds, const Hand &hd = Hand{}, int spv = 0) {
     const int lane = lane_id();
     float *s_m = reinterpret_cast<float *>(lds);
     int *s_cnt = reinterpret_cast<int *>(lds + kCoopUnits * kWave);
@@ -532,40 +644,41 @@ __device__ __forceinline__ bool coop_run(
     if (MODE == kModeOpt)
         opt_rows(d2, maps, row, width);
 
-    coop_slices<MODE, DUAL, SIG>(dst_row, init, d2, grads, perm, maps, n, lr, s, len, width, j, workers, w, s_m,
-                                 SIG ? pend + pend_slot(key) : nullptr, s_perm, wg0 - kCoopPermSpan);
+    coop_slices<MODE, DUAL, HAND>(dst_row, init, d2, grads, perm, maps, n, lr, s, len, width, j, workers, w, s_m,
+                                 HAND == kHandSignal ? hd.pend + pend_slot(key) : nullptr, s_perm,
+                                 wg0 - kCoopPermSpan, hd, key);
     return true;
 }
 
 // One wave per sorted position p; `lds` = kApplyLdsBytes of workgroup memory (long runs only).
-template <int MODE, int VEC, bool DUAL, bool SIG = false>
+template <int MODE, int VEC, bool DUAL, int HAND = kHandNone>
 __device__ __forceinline__ bool apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds, uint32_t *pend = nullptr);
+    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds, const Hand &hd = Hand{});
 
 // `dbg` (tools/timeline.py only) receives {realtime start, realtime end, role/len, shader cycles}
 // per position.  The early return below is taken by whole waves of the LAST workgroup only, which is
 // never a full one, so the barriers of coop_run see all 16 waves.
 // Returns true when the wave did medium / long-run work (false: it left early or applied a short run).
-template <int MODE, int VEC, bool DUAL = false, bool SIG = false>
+template <int MODE, int VEC, bool DUAL = false, int HAND = kHandNone>
 __device__ __forceinline__ bool apply_body(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
     float lr, int vblock, uint32_t *lds, unsigned long long *dbg = nullptr,
-    ApplyMaps maps = ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr}, uint32_t *pend = nullptr) {
+    ApplyMaps maps = ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr}, const Hand &hd = Hand{}) {
     const int w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int p = vblock * kPosPerBlock + w;
     if (p >= n)
         return false;
     if (dbg == nullptr)
-        return apply_body_impl<MODE, VEC, DUAL, SIG>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds, pend);
+        return apply_body_impl<MODE, VEC, DUAL, HAND>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, nullptr, maps, lds, hd);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     int info = 0;
-    const bool heavy = apply_body_impl<MODE, VEC, DUAL, SIG>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds, pend);
+    const bool heavy = apply_body_impl<MODE, VEC, DUAL, HAND>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, p, w, &info, maps, lds, hd);
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -578,12 +691,12 @@ __device__ __forceinline__ bool apply_body(
     return heavy;
 }
 
-template <int MODE, int VEC, bool DUAL, bool SIG>
+template <int MODE, int VEC, bool DUAL, int HAND>
 __device__ __forceinline__ bool apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ upos, int n, const float *__restrict__ grads,
-    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds, uint32_t *pend) {
+    float lr, int p, int w, int *dbg_info, ApplyMaps maps, uint32_t *lds, const Hand &hd) {
     const int lane = lane_id();
     const int wg0 = p - w;
     // window of sorted positions p-16 .. p+47, plus -- speculatively, in the same round trip -- this
@@ -614,7 +727,7 @@ __device__ __forceinline__ bool apply_body_impl(
             return false;   // >= nslice full workgroups of this run precede: not a worker
         if (dbg_info)
             *dbg_info = (w << 16) | 0x7FFF;
-        if (coop_run<MODE, DUAL, SIG>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds, pend, spv))
+        if (coop_run<MODE, DUAL, HAND>(dst, dst_rows, width, sorted, perm, upos, n, grads, lr, wg0, w, key, bk, fk, maps, lds, hd, spv))
             return true;
     }
     const unsigned long long eq = __ballot(q >= 0 && q < n && ks == key);
@@ -661,20 +774,26 @@ __device__ __forceinline__ bool apply_body_impl(
     const int nslice = (width + kWave - 1) / kWave;
     if (len <= kShortRun) {
         if (o == 0) {
-            short_row<MODE, VEC, DUAL, SIG>(dst_row, grads, width, pv, kLookBack, len, lr, init, d2);
-            if (SIG)   // the whole row: len occurrences x every slice
-                signal_done(pend + pend_slot(key), len * nslice);
+            short_row<MODE, VEC, DUAL, HAND>(dst_row, grads, width, pv, kLookBack, len, lr, init, d2, hd, key);
+            if (HAND == kHandSignal)   // the whole row: len occurrences x every slice
+                signal_done(hd.pend + pend_slot(key), len * nslice);
         }
         return false;
     }
     const int workers = min(len, kLookBack);
     int mine = 0;
+    Fwd fw{0, 0, 0};
+    uint4 pe{0, 0, 0, 0};
+    bool resolve = HAND == kHandForward && hd.tab != nullptr && o * kWave < width;
+    if (resolve)
+        pe = fwd_probe(hd, key);
     for (int c0 = o * kWave; c0 < width; c0 += workers * kWave) {
-        medium_slice<MODE, DUAL, SIG>(dst_row, grads, width, c0 + lane, pv, kLookBack - o, len, lr, init, d2);
+        medium_slice<MODE, DUAL, HAND>(dst_row, grads, width, c0 + lane, pv, kLookBack - o, len, lr, init, d2, hd, key, pe, &fw, resolve);
+        resolve = false;
         ++mine;
     }
-    if (SIG && mine > 0)
-        signal_done(pend + pend_slot(key), len * mine);
+    if (HAND == kHandSignal && mine > 0)
+        signal_done(hd.pend + pend_slot(key), len * mine);
     return o < workers;
 }
 

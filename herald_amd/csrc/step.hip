@@ -160,9 +160,10 @@ __device__ __forceinline__ int step_roles(const StepArgs &a, uint32_t *s_dyn, un
     }
     b -= a.nfin;
     if (b < a.napply) {
-        apply_body<kModeSgd, 4, false, true>(a.table, a.rows, a.width, a.sorted, a.perm, nullptr, a.n_cur,
-                                             a.grads, a.lr, b, s_dyn, nullptr,
-                                             ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr}, a.pend_cur);
+        apply_body<kModeSgd, 4, false, kHandSignal>(a.table, a.rows, a.width, a.sorted, a.perm, nullptr, a.n_cur,
+                                                    a.grads, a.lr, b, s_dyn, nullptr,
+                                                    ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr},
+                                                    Hand{a.pend_cur, nullptr, nullptr, 0, nullptr});
         return 1;
     }
     b -= a.napply;
@@ -316,6 +317,290 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
     return 0;
 }
 
+
+// =====================================================================================================
+// ha_step_*: the same step with THREE batches of lookahead and no waiting inside the launch.
+//
+//   launch k:  [clear table k+3] [finish(k+2) + key table k+2] [apply(k) + forward to out(k+1)] [rank(k+3)]
+//              [gather(k+1) \ k]
+//
+// Batch k+1 was sorted by launch k-2 and its plan finished by launch k-1, which also entered its unique
+// keys in the batch's KEY TABLE (common.h: key -> first sorted position, occurrences).  So when launch k
+// starts, the wave that ends up with the final values of a row of batch k in its registers (scatter_dev.h,
+// kHandForward) finds the key's positions in batch k+1 with one probe and writes the row to every output
+// row of that batch that names it; the gather role copies only the rows of batch k+1 that batch k does
+// NOT touch (membership = the key table of batch k).  Compared with step_kernel above: no pending words,
+// no polling, no device-coherent stores, no atomics on shared words (a key table is filled by the finish
+// blocks: one claim per unique key), the two thirds of the positions both batches share are not read back
+// from HBM, and rows narrower than a 128-byte line need no special case (nothing written in the launch is
+// read in it).  Nothing in the launch needs the rank tiles' result; they share the chip with the apply
+// waves from the start (VALU work beside memory work) and the short gather waves fill in behind.
+// =====================================================================================================
+constexpr int kStepMax = kBucketMin;   // ids per batch (rank-by-counting tiles; key table at <= 37.5 % load)
+constexpr int kClearBlocks = 4;        // workgroups that clear one key table (512 KiB)
+
+struct FwdArgs {
+    float *table;
+    uint64_t rows;
+    int width;
+    // batch k: apply
+    const uint32_t *sorted;
+    const int32_t *perm;
+    int n_cur;
+    const float *grads;
+    float lr;
+    const uint4 *tab_cur;      // keys of batch k (nullptr: the gather copies every row)
+    int napply;
+    // batch k+1: forward + gather
+    const uint32_t *nkeys;
+    const int32_t *nperm;
+    int n_next;
+    float *out;
+    const uint4 *tab_next;
+    int ngather, nv, nv_shift, group;
+    // batch k+2: finish + key table
+    const uint32_t *fsorted;
+    const int32_t *fperm;
+    int n_fin;
+    PlanHeader *fhdr;
+    uint32_t *funiq;
+    int32_t *fseg, *fcounts, *finverse, *fupos;
+    uint32_t *tab_fin;
+    int nfin;
+    // batch k+3: rank
+    const void *ahead_ids;
+    int n_ahead;
+    uint32_t *akeys, *asorted;
+    int32_t *aperm;
+    int nrank;
+    // the table whose batch is done
+    uint4 *tab_clear;
+    int nclear;
+    unsigned long long *dbg;
+};
+
+// One wave copies `group` consecutive positions of batch k+1 -- those whose key batch k does not update.
+__device__ __forceinline__ void gather_rest_body(const FwdArgs &a, int wave_index, unsigned long long *t_mid) {
+    const int lane = lane_id();
+    const int p0 = wave_index * a.group;
+    if (p0 >= a.n_next)
+        return;
+    const int cnt = min(a.group, a.n_next - p0);
+    uint32_t key = 0;
+    bool ok = false, skip = true;
+    if (lane < cnt) {
+        key = a.nkeys[p0 + lane];
+        ok = key < a.rows;
+        skip = false;
+        if (ok && a.tab_cur != nullptr) {
+            uint32_t sl = tab_slot(key);
+            for (;;) {
+                const uint32_t k = a.tab_cur[sl].x;
+                if (k == key) {
+                    skip = true;   // forwarded by the wave that applies the key
+                    break;
+                }
+                if (k == kTabEmpty)
+                    break;
+                sl = (sl + 1) & kTabMask;
+            }
+        }
+    }
+    if (t_mid)
+        *t_mid = __builtin_amdgcn_s_memrealtime();
+    if (__ballot(!skip) == 0ull)
+        return;
+    const int total = cnt * a.nv;
+    float *dst = a.out + static_cast<uint64_t>(p0) * static_cast<uint64_t>(a.nv) * 4u;
+    for (int base = 0; base < total; base += kGatherLoads * kWave) {
+        float4v v[kGatherLoads];
+        bool okv[kGatherLoads], sk[kGatherLoads];
+#pragma unroll
+        for (int u = 0; u < kGatherLoads; ++u) {
+            const int e = base + u * kWave + lane;
+            const int ec = e < total ? e : total - 1;
+            const int pos = a.nv_shift >= 0 ? (ec >> a.nv_shift) : (ec / a.nv);
+            const int col = ec - pos * a.nv;
+            const uint32_t k = static_cast<uint32_t>(__shfl(static_cast<int>(key), pos, kWave));
+            okv[u] = __shfl(static_cast<int>(ok), pos, kWave) != 0;
+            sk[u] = __shfl(static_cast<int>(skip), pos, kWave) != 0;
+            v[u] = ld4(a.table + (static_cast<uint64_t>(okv[u] ? k : 0u) * static_cast<uint64_t>(a.nv) +
+                                  static_cast<uint64_t>(col)) * 4u);
+        }
+#pragma unroll
+        for (int u = 0; u < kGatherLoads; ++u) {
+            const int e = base + u * kWave + lane;
+            if (e < total && !sk[u])
+                st4_nt(dst + static_cast<uint64_t>(e) * 4u, okv[u] ? v[u] : float4v{0.f, 0.f, 0.f, 0.f});
+        }
+    }
+}
+
+template <typename IdT>
+__device__ __forceinline__ int fwd_roles(const FwdArgs &a, uint32_t *s_dyn, unsigned long long *t_mid) {
+    int b = blockIdx.x;
+    if (b < a.nclear) {
+        // all-ones = empty (common.h); 2^kTabBits entries of 16 bytes over nclear workgroups
+        const int per = (1 << kTabBits) / a.nclear;
+        for (int e = threadIdx.x; e < per; e += 1024)
+            a.tab_clear[b * per + e] = uint4{kTabEmpty, kTabEmpty, kTabEmpty, kTabEmpty};
+        return 4;
+    }
+    b -= a.nclear;
+    if (b < a.nfin) {
+        finish_block_body(a.fsorted, a.fperm, a.n_fin, a.fhdr, a.funiq, a.fseg, a.fcounts, a.finverse, a.fupos, b,
+                          s_dyn, nullptr, nullptr, a.tab_fin, a.rows);
+        return 0;
+    }
+    b -= a.nfin;
+    // Workgroup b of the rest: rank tile b of batch k+3, then sorted positions 16b .. 16b+15 of batch k, then
+    // output rows 16b*group .. of batch k+1 -- every role's workgroups are resident from the start (at most
+    // max(tiles, positions / 16) + a few workgroups: 427 of the chip's 512 slots at 6,656 ids).
+    if (b < a.nrank)
+        rank_tile_body<IdT>(static_cast<const IdT *>(a.ahead_ids), a.n_ahead, a.akeys, a.asorted, a.aperm, b, s_dyn);
+    if (b < a.napply)
+        apply_body<kModeSgd, 4, false, kHandForward>(a.table, a.rows, a.width, a.sorted, a.perm, nullptr, a.n_cur,
+                                                     a.grads, a.lr, b, s_dyn, nullptr,
+                                                     ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr},
+                                                     Hand{nullptr, a.tab_next, a.nperm, a.n_next, a.out});
+    if (t_mid)
+        *t_mid = __builtin_amdgcn_s_memrealtime();
+    if (b < a.ngather)
+        gather_rest_body(a, b * kPosPerBlock + static_cast<int>(threadIdx.x >> 6), nullptr);
+    return b < a.nrank ? 2 : 1;
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(1024, 8) void step_fwd_kernel(const FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    fwd_roles<IdT>(a, s_dyn, nullptr);
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(1024, 8) void step_fwd_timeline_kernel(const FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tm = 0;
+    const int role = fwd_roles<IdT>(a, s_dyn, &tm);
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (lane_id() == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *d = a.dbg + (static_cast<size_t>(blockIdx.x) * 16 + (threadIdx.x >> 6)) * 4;
+        d[0] = t0;
+        d[1] = tm;
+        d[2] = t1;
+        d[3] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8);
+    }
+}
+
+template <typename IdT>
+static int step_fwd(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                    float lr, const void *tab_cur, void *plan_next, int64_t n_next, float *next_out,
+                    const void *tab_next, void *plan_fin, int64_t n_fin, void *tab_fin, const IdT *ahead_ids,
+                    int64_t n_ahead, void *plan_ahead, void *tab_clear, hipStream_t stream,
+                    unsigned long long *dbg = nullptr) {
+    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
+                   width < (1 << 30) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
+               "ha_step: the table must be 16-byte aligned with rows of a multiple of 4 floats "
+               "(other tables: ha_sgd_push_pull_* or the separate launches)");
+    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && n_fin >= 0 && n_ahead >= 0 && n_cur <= kStepMax &&
+                   n_next <= kStepMax && n_fin <= kStepMax && n_ahead <= kStepMax,
+               "ha_step: at most %d ids per batch (larger batches: ha_lookup_sort_* + ha_sgd_apply_finish)", kStepMax);
+    HA_REQUIRE(n_cur == 0 || (plan_cur && grads && reinterpret_cast<uintptr_t>(grads) % 16 == 0),
+               "ha_step: current batch needs its plan and 16-byte aligned gradients");
+    HA_REQUIRE(n_next == 0 || (plan_next && next_out && reinterpret_cast<uintptr_t>(next_out) % 16 == 0),
+               "ha_step: next batch needs its plan and a 16-byte aligned output");
+    HA_REQUIRE(n_next == 0 || n_cur == 0 || (tab_cur && tab_next),
+               "ha_step: the key tables of the current and the next batch are needed to forward rows");
+    HA_REQUIRE(n_fin == 0 || (plan_fin && tab_fin), "ha_step: null pointer (batch to finish)");
+    HA_REQUIRE(n_ahead == 0 || (ahead_ids && plan_ahead), "ha_step: null pointer (batch ahead)");
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.table = table;
+    a.rows = static_cast<uint64_t>(rows);
+    a.width = static_cast<int>(width);
+    size_t lds = kFinishLdsWords * 4;
+    if (n_cur > 0) {
+        PlanPtrs p = plan_layout(plan_cur, n_cur);
+        a.sorted = p.sorted;
+        a.perm = p.perm;
+        a.n_cur = static_cast<int>(n_cur);
+        a.grads = grads;
+        a.lr = lr;
+        a.napply = (a.n_cur + kPosPerBlock - 1) / kPosPerBlock;
+        lds = kApplyLdsBytes;
+    }
+    if (n_next > 0) {
+        PlanPtrs q = plan_layout(plan_next, n_next);
+        a.nkeys = q.keys;
+        a.nperm = q.perm;
+        a.n_next = static_cast<int>(n_next);
+        a.out = next_out;
+        if (n_cur > 0) {
+            a.tab_cur = static_cast<const uint4 *>(tab_cur);
+            a.tab_next = static_cast<const uint4 *>(tab_next);
+        }
+        a.nv = static_cast<int>(width / 4);
+        a.nv_shift = -1;
+        for (int s = 0; s < 30; ++s)
+            if (a.nv == (1 << s))
+                a.nv_shift = s;
+        const int vecs = kGatherLoads * kWave;
+        a.group = a.nv >= vecs ? 1 : (vecs / a.nv > kWave ? kWave : vecs / a.nv);
+        const int waves = (a.n_next + a.group - 1) / a.group;
+        a.ngather = (waves + kPosPerBlock - 1) / kPosPerBlock;
+    }
+    if (n_fin > 0) {
+        PlanPtrs f = plan_layout(plan_fin, n_fin);
+        a.fsorted = f.sorted;
+        a.fperm = f.perm;
+        a.n_fin = static_cast<int>(n_fin);
+        a.fhdr = f.hdr;
+        a.funiq = f.uniq;
+        a.fseg = f.seg;
+        a.fcounts = f.counts;
+        a.finverse = f.inverse;
+        a.fupos = f.upos;
+        a.tab_fin = static_cast<uint32_t *>(tab_fin);
+        a.nfin = finish_blocks(a.n_fin);
+    }
+    if (n_ahead > 0) {
+        PlanPtrs r = plan_layout(plan_ahead, n_ahead);
+        a.ahead_ids = ahead_ids;
+        a.n_ahead = static_cast<int>(n_ahead);
+        a.akeys = r.keys;
+        a.asorted = r.sorted;
+        a.aperm = r.perm;
+        a.nrank = (a.n_ahead + kRankTile - 1) / kRankTile;
+        lds = lds > rank_small_lds_bytes(a.n_ahead) ? lds : rank_small_lds_bytes(a.n_ahead);
+    }
+    if (tab_clear) {
+        a.tab_clear = static_cast<uint4 *>(tab_clear);
+        a.nclear = kClearBlocks;
+    }
+    const int nwork = a.napply > a.ngather ? (a.napply > a.nrank ? a.napply : a.nrank)
+                                           : (a.ngather > a.nrank ? a.ngather : a.nrank);
+    const unsigned blocks = static_cast<unsigned>(a.nclear + a.nfin + nwork);
+    if (blocks == 0)
+        return 0;
+    static bool lds_allowed = false;   // once, and outside any stream capture (the first call is eager)
+    if (!lds_allowed) {
+        HA_ALLOW_LDS((step_fwd_kernel<IdT>), 160 * 1024);
+        lds_allowed = true;
+    }
+    if (dbg) {
+        a.dbg = dbg;
+        HA_ALLOW_LDS((step_fwd_timeline_kernel<IdT>), 160 * 1024);
+        hipLaunchKernelGGL((step_fwd_timeline_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((step_fwd_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
+    }
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace ha
 
 using namespace ha;
@@ -373,4 +658,52 @@ extern "C" int ha_lookup_sort_pend_u64ids(const float *table, int64_t rows, int6
                                           void *pend, ha_stream_t stream) {
     return push_pull<uint64_t>(const_cast<float *>(table), rows, width, nullptr, 0, nullptr, 0.f, nullptr, ids,
                                n, out, plan_ws, pend, as_stream(stream), ha_lookup_sort_u64ids);
+}
+
+// ---- two batches of lookahead (see step_fwd above) ----------------------------------------------------
+extern "C" size_t ha_step_tab_bytes(void) {
+    return sizeof(uint4) << kTabBits;
+}
+
+extern "C" int64_t ha_step_max_ids(void) {
+    return kStepMax;
+}
+
+extern "C" int ha_step_tab_reset(void *tab, ha_stream_t stream) {
+    HA_REQUIRE(tab != nullptr, "ha_step_tab_reset: null pointer");
+    HA_CHECK_HIP(hipMemsetAsync(tab, 0xFF, ha_step_tab_bytes(), as_stream(stream)));
+    return 0;
+}
+
+extern "C" int ha_step_f32ids(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                              const float *grads, float lr, const void *tab_cur, void *plan_next, int64_t n_next,
+                              float *next_out, const void *tab_next, void *plan_fin, int64_t n_fin, void *tab_fin,
+                              const float *ahead_ids, int64_t n_ahead, void *plan_ahead, void *tab_clear,
+                              ha_stream_t stream) {
+    return step_fwd<float>(table, rows, width, plan_cur, n_cur, grads, lr, tab_cur, plan_next, n_next, next_out,
+                           tab_next, plan_fin, n_fin, tab_fin, ahead_ids, n_ahead, plan_ahead, tab_clear,
+                           as_stream(stream));
+}
+
+extern "C" int ha_step_u64ids(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                              const float *grads, float lr, const void *tab_cur, void *plan_next, int64_t n_next,
+                              float *next_out, const void *tab_next, void *plan_fin, int64_t n_fin, void *tab_fin,
+                              const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead, void *tab_clear,
+                              ha_stream_t stream) {
+    return step_fwd<uint64_t>(table, rows, width, plan_cur, n_cur, grads, lr, tab_cur, plan_next, n_next, next_out,
+                              tab_next, plan_fin, n_fin, tab_fin, ahead_ids, n_ahead, plan_ahead, tab_clear,
+                              as_stream(stream));
+}
+
+// development aid: ha_step_f32ids with per-wave time stamps; dbg = uint64[blocks * 16 * 4]
+extern "C" int ha_debug_step_fwd_timeline(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                                          const float *grads, float lr, const void *tab_cur, void *plan_next,
+                                          int64_t n_next, float *next_out, const void *tab_next, void *plan_fin,
+                                          int64_t n_fin, void *tab_fin, const float *ahead_ids, int64_t n_ahead,
+                                          void *plan_ahead, void *tab_clear, unsigned long long *dbg,
+                                          ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "step timeline: null debug buffer");
+    return step_fwd<float>(table, rows, width, plan_cur, n_cur, grads, lr, tab_cur, plan_next, n_next, next_out,
+                           tab_next, plan_fin, n_fin, tab_fin, ahead_ids, n_ahead, plan_ahead, tab_clear,
+                           as_stream(stream), dbg);
 }

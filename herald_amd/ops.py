@@ -425,6 +425,123 @@ def sgd_push_pull(table, plan_cur, grads, lr, pend_cur, next_ids=None, plan_next
     return next_out
 
 
+# ---- the step with two batches of lookahead: nothing waits inside the launch --------------------------
+def step_max_ids():
+    return int(_lib.load().ha_step_max_ids())
+
+
+class StepPipeline:
+    """Drives ha_step_* (include/herald_amd.h) over a stream of id batches: one launch per training step that
+    applies the sparse SGD of batch k (cpu_SGDOptimizerSparseUpdate order), writes the rows of batch k+1 after
+    that update (forwarded from the applying waves' registers where both batches name a row), finishes the plan
+    of batch k+2 and sorts batch k+3.  Four plans and four key tables rotate.
+
+        pipe = StepPipeline(table, capacity, lr)
+        out0 = pipe.start(ids0, ids1, ids2)           # rows of batch 0 (three launches)
+        out1 = pipe.step(grads0, ids3)                # apply 0, rows of batch 1, sort 3   (one launch)
+        out2 = pipe.step(grads1, ids4) ...            # ahead_ids=None at the end of the stream
+    `pipe.plan_of(j)` is the plan of batch j (finished -- unique keys / inverse / counts -- once the call that
+    applies batch j-2 has been made)."""
+
+    NPLAN, NTAB = 4, 4
+
+    def __init__(self, table, capacity, lr, device=None):
+        L = _lib.load()
+        _require(table, torch.float32, "table")
+        self.table, self.lr = table, float(lr)
+        self.device = table.device if device is None else torch.device(device)
+        if capacity > step_max_ids():
+            raise ValueError("ha_step_* takes at most %d ids per batch (got capacity %d): use sgd_push_pull / "
+                             "lookup_sort + sgd_apply_finish" % (step_max_ids(), capacity))
+        self.capacity = capacity
+        self.plans = [IndexPlan(capacity, self.device) for _ in range(self.NPLAN)]
+        self.tab_bytes = int(L.ha_step_tab_bytes())
+        self.tabs = torch.empty(self.NTAB * self.tab_bytes, dtype=torch.uint8, device=self.device)
+        self.c = None            # index of the batch the next step() applies
+        self.n = {}              # batch index -> number of ids (batches in flight)
+        self.shape = {}
+        self.reset()
+
+    def _tab(self, c):
+        return self.tabs.data_ptr() + (c % self.NTAB) * self.tab_bytes
+
+    def plan_of(self, c):
+        return self.plans[c % self.NPLAN]
+
+    def reset(self, stream=None):
+        L = _lib.load()
+        for t in range(self.NTAB):
+            check(L.ha_step_tab_reset(self._tab(t), _stream_ptr(stream)), "ha_step_tab_reset")
+        if stream is None:
+            torch.cuda.current_stream(self.device).synchronize()
+        self.c, self.n, self.shape = None, {}, {}
+        return self
+
+    def launch(self, c, n_cur, grads, n_next, out, n_fin, ahead_ids, stream=None):
+        """Call c of the stream, stateless (for callers that replay captured launches and keep the batch sizes
+        themselves): batch c (n_cur ids) is applied, the rows of batch c+1 (n_next ids) go to `out`, the plan of
+        batch c+2 (n_fin ids) is finished and its key table filled, `ahead_ids` = batch c+3 is sorted."""
+        L = _lib.load()
+        t = self.table
+        width = t.shape[1]
+        n_ahead = 0 if ahead_ids is None else ahead_ids.numel()
+        if max(n_cur, n_next, n_fin, n_ahead) > self.capacity:
+            raise ValueError("plan capacity %d < %d ids" % (self.capacity, max(n_cur, n_next, n_fin, n_ahead)))
+        if n_cur:
+            _require(grads, torch.float32, "grads")
+            if grads.numel() != n_cur * width:
+                raise ValueError("grads must hold %d x %d values" % (n_cur, width))
+        if n_next:
+            _require(out, torch.float32, "out")
+            if out.numel() != n_next * width:
+                raise ValueError("out must hold %d x %d values" % (n_next, width))
+        kind = _ids_kind(ahead_ids) if n_ahead else "f32ids"
+        fn = getattr(L, "ha_step_" + kind)
+        check(fn(_ptr(t), t.shape[0], width,
+                 _ptr(self.plan_of(c).ws) if n_cur else None, n_cur, _ptr(grads) if n_cur else None,
+                 ctypes.c_float(self.lr), self._tab(c) if n_cur else None,
+                 _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
+                 self._tab(c + 1) if n_next else None,
+                 _ptr(self.plan_of(c + 2).ws) if n_fin else None, n_fin, self._tab(c + 2) if n_fin else None,
+                 _ptr(ahead_ids) if n_ahead else None, n_ahead,
+                 _ptr(self.plan_of(c + 3).ws) if n_ahead else None,
+                 self._tab(c + 3), _stream_ptr(stream)), "ha_step")
+        if n_fin:
+            self.plan_of(c + 2).produced_on(stream)
+        if n_ahead:
+            pl = self.plan_of(c + 3)
+            pl.n = n_ahead
+            pl._view = None
+            pl.produced_on(stream)
+
+    def _call(self, c, grads, ahead_ids, out, stream):
+        n_cur, n_next, n_fin = self.n.get(c, 0), self.n.get(c + 1, 0), self.n.get(c + 2, 0)
+        n_ahead = 0 if ahead_ids is None else ahead_ids.numel()
+        if n_next and out is None:
+            out = torch.empty(tuple(self.shape[c + 1]) + (self.table.shape[1],), dtype=torch.float32,
+                              device=self.table.device)
+        self.launch(c, n_cur, grads, n_next, out, n_fin, ahead_ids, stream)
+        if n_cur:
+            del self.n[c]
+        if n_ahead:
+            self.n[c + 3] = n_ahead
+            self.shape[c + 3] = tuple(ahead_ids.shape)
+        self.c = c + 1
+        return out if n_next else None
+
+    def start(self, ids0, ids1=None, ids2=None, out=None, stream=None):
+        """Sorts batches 0, 1 and 2 and returns the rows of batch 0."""
+        self._call(-3, None, ids0, None, stream)
+        self._call(-2, None, ids1, None, stream)
+        return self._call(-1, None, ids2, out, stream)
+
+    def step(self, grads, ahead_ids=None, out=None, stream=None):
+        """Applies `grads` of the current batch; returns the rows of the next batch (None at the end)."""
+        if self.c is None or self.c not in self.n:
+            raise RuntimeError("StepPipeline.step without a batch in flight (call start first)")
+        return self._call(self.c, grads, ahead_ids, out, stream)
+
+
 def push_apply_finish(table, plan, grads, stream=None):
     _require(table, torch.float32, "table")
     _require(grads, torch.float32, "grads")

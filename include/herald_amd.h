@@ -390,6 +390,51 @@ int ha_debug_step_timeline(float *table, int64_t rows, int64_t width,
 /* device address of the hand-off time-out flag (int64, 0 = fine) of a plan workspace */
 int64_t *ha_plan_handoff_timeout(void *plan_ws);
 
+/* The step with THREE batches of lookahead: ONE launch that
+ *   - applies the gradients of batch k (plan_cur)
+ *     == ha_sgd_apply(table, plan_cur, grads, lr)             [cpu_SGDOptimizerSparseUpdate, Optimizers.cpp:51-74]
+ *   - writes the rows of batch k+1 AFTER that update to next_out (plan_next)
+ *     == ha_gather_*(table, ids of batch k+1)                 [cpu_EmbeddingLookup, EmbeddingLookup.cpp:16-35]
+ *   - finishes the plan of batch k+2 (plan_fin: unique keys, inverse, counts)   == ha_plan_finish
+ *   - sorts batch k+3 (ahead_ids -> plan_ahead)               == ha_plan_sort_*(ahead_ids)
+ * with results bit-identical to those calls.  Nothing waits inside the launch: batch k+1 was sorted and
+ * finished by earlier calls, so the wave that holds the final values of a row of batch k writes them
+ * straight to every output row of batch k+1 that names the key, and only the rows batch k does not touch
+ * are copied from the table -- the rows both batches share (two thirds of the positions of consecutive
+ * Criteo batches) are not read back from HBM.  The ids are known three batches ahead (the reference's
+ * dataloader and laia scheduler run further ahead than that: dataloader.py:63-98, laia_scheduler.cc).
+ *
+ * Every batch owns a KEY TABLE (ha_step_tab_bytes() bytes of device memory, ha_step_tab_reset before first
+ * use): filled by the call that finishes the batch's plan (tab_fin), read by the two calls after it
+ * (tab_next, then tab_cur), and cleared by the call after those (tab_clear) -- four tables and four plans
+ * rotate.  A stream of batches 0..B-1 is driven as calls c = -3 .. B-1 with cur = c, next = c+1, fin = c+2,
+ * ahead = c+3 and n = 0 / null pointers for batches outside [0, B); call c uses tables T[c%4] (cur),
+ * T[(c+1)%4] (next), T[(c+2)%4] (fin) and clears T[(c+3)%4].  Limits: at most ha_step_max_ids() ids per
+ * batch, width % 4 == 0, table / grads / next_out 16-byte aligned; anything else is refused (-1): use
+ * ha_sgd_push_pull_* or the separate calls. */
+size_t ha_step_tab_bytes(void);
+int64_t ha_step_max_ids(void);
+int ha_step_tab_reset(void *tab, ha_stream_t stream);
+int ha_step_f32ids(float *table, int64_t rows, int64_t width,
+                   void *plan_cur, int64_t n_cur, const float *grads, float lr, const void *tab_cur,
+                   void *plan_next, int64_t n_next, float *next_out, const void *tab_next,
+                   void *plan_fin, int64_t n_fin, void *tab_fin,
+                   const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                   void *tab_clear, ha_stream_t stream);
+int ha_step_u64ids(float *table, int64_t rows, int64_t width,
+                   void *plan_cur, int64_t n_cur, const float *grads, float lr, const void *tab_cur,
+                   void *plan_next, int64_t n_next, float *next_out, const void *tab_next,
+                   void *plan_fin, int64_t n_fin, void *tab_fin,
+                   const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                   void *tab_clear, ha_stream_t stream);
+/* development aid (tools/step_fwd_timeline.py): ha_step_f32ids with per-wave time stamps */
+int ha_debug_step_fwd_timeline(float *table, int64_t rows, int64_t width,
+                               void *plan_cur, int64_t n_cur, const float *grads, float lr, const void *tab_cur,
+                               void *plan_next, int64_t n_next, float *next_out, const void *tab_next,
+                               void *plan_fin, int64_t n_fin, void *tab_fin,
+                               const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               void *tab_clear, unsigned long long *dbg, ha_stream_t stream);
+
 /* ha_sgd_apply_finish that also warms the memory-side cache for the NEXT batch: waves that have no
  * medium / long-run work (more than half of them) end by touching the table row that position p of
  * next_ids will gather, so the ha_lookup_sort_* / ha_gather_* that follows reads it from the
