@@ -333,8 +333,14 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
 // no polling, no device-coherent stores, no atomics on shared words (a key table is filled by the finish
 // blocks: one claim per unique key), the two thirds of the positions both batches share are not read back
 // from HBM, and rows narrower than a 128-byte line need no special case (nothing written in the launch is
-// read in it).  Nothing in the launch needs the rank tiles' result; they share the chip with the apply
-// waves from the start (VALU work beside memory work) and the short gather waves fill in behind.
+// read in it).  Nothing in the launch needs the rank tiles' result.
+//
+// Measured (MI355X, wdl_criteo bs=256 d=512, same box): 15.9-16.6 us per step against 15.4 us of step_kernel.
+// Forwarding costs the applying waves -- the waves the step already waits for -- 2.4 us (with forwarding off:
+// 14.3 us), the gather of the remaining third of the rows 1.3 us, and apply + rank + finish alone take 13.1 us:
+// the step is bound by wave slots (the chip's 8,192 are full of apply and rank waves that sit on 2-3 us memory
+// round trips), not by the bytes the forwarding saves.  Kept because it runs ANY table in one launch (rows
+// narrower than a line, unaligned tables) and has no waiting, hence no time-out path.
 // =====================================================================================================
 constexpr int kStepMax = kBucketMin;   // ids per batch (rank-by-counting tiles; key table at <= 37.5 % load)
 constexpr int kClearBlocks = 4;        // workgroups that clear one key table (512 KiB)
@@ -453,21 +459,25 @@ __device__ __forceinline__ int fwd_roles(const FwdArgs &a, uint32_t *s_dyn, unsi
         return 0;
     }
     b -= a.nfin;
-    // Workgroup b of the rest: rank tile b of batch k+3, then sorted positions 16b .. 16b+15 of batch k, then
-    // output rows 16b*group .. of batch k+1 -- every role's workgroups are resident from the start (at most
-    // max(tiles, positions / 16) + a few workgroups: 427 of the chip's 512 slots at 6,656 ids).
-    if (b < a.nrank)
-        rank_tile_body<IdT>(static_cast<const IdT *>(a.ahead_ids), a.n_ahead, a.akeys, a.asorted, a.aperm, b, s_dyn);
-    if (b < a.napply)
+    // apply | rank | gather.  Measured alternatives (same box, 16.5 us for this order): rank | apply | gather 18.5,
+    // apply | gather | rank 18.6, gather | apply | rank 17.8, and every workgroup doing a rank tile, then its 16
+    // sorted positions, then its 16 output rows (all 427 workgroups resident from the start) 19.3 -- the roles'
+    // latency chains then add up inside each workgroup instead of overlapping across workgroups.
+    if (b < a.napply) {
         apply_body<kModeSgd, 4, false, kHandForward>(a.table, a.rows, a.width, a.sorted, a.perm, nullptr, a.n_cur,
                                                      a.grads, a.lr, b, s_dyn, nullptr,
                                                      ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr},
                                                      Hand{nullptr, a.tab_next, a.nperm, a.n_next, a.out});
-    if (t_mid)
-        *t_mid = __builtin_amdgcn_s_memrealtime();
-    if (b < a.ngather)
-        gather_rest_body(a, b * kPosPerBlock + static_cast<int>(threadIdx.x >> 6), nullptr);
-    return b < a.nrank ? 2 : 1;
+        return 1;
+    }
+    b -= a.napply;
+    if (b < a.nrank) {
+        rank_tile_body<IdT>(static_cast<const IdT *>(a.ahead_ids), a.n_ahead, a.akeys, a.asorted, a.aperm, b, s_dyn);
+        return 2;
+    }
+    b -= a.nrank;
+    gather_rest_body(a, b * kPosPerBlock + static_cast<int>(threadIdx.x >> 6), t_mid);
+    return 3;
 }
 
 template <typename IdT>
@@ -580,9 +590,7 @@ static int step_fwd(float *table, int64_t rows, int64_t width, void *plan_cur, i
         a.tab_clear = static_cast<uint4 *>(tab_clear);
         a.nclear = kClearBlocks;
     }
-    const int nwork = a.napply > a.ngather ? (a.napply > a.nrank ? a.napply : a.nrank)
-                                           : (a.ngather > a.nrank ? a.ngather : a.nrank);
-    const unsigned blocks = static_cast<unsigned>(a.nclear + a.nfin + nwork);
+    const unsigned blocks = static_cast<unsigned>(a.nclear + a.nfin + a.napply + a.nrank + a.ngather);
     if (blocks == 0)
         return 0;
     static bool lds_allowed = false;   // once, and outside any stream capture (the first call is eager)

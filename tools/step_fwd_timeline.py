@@ -46,21 +46,26 @@ tm = np.where(d[:, 1] > 0, (d[:, 1] - base) * 0.01, np.nan)
 t1 = (d[:, 2] - base) * 0.01
 role = d[:, 3] & 0xFF
 print("span %.2f us, waves %d" % (t1[live].max(), live.sum()))
-names = ("finish", "apply+gather", "rank+apply+gather", "-", "clear")
+names = ("finish", "apply", "rank", "gather", "clear")
 for r, name in enumerate(names):
     m = live & (role == r)
     if not m.any():
         continue
-    print("%-18s waves %5d  start p50 %.2f max %.2f | apply done p10 %.2f p50 %.2f p90 %.2f max %.2f | end p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f"
-          % ((name, m.sum()) + tuple(np.percentile(t0[m], [50, 100])) + tuple(np.nanpercentile(tm[m], [10, 50, 90, 100]) if r in (1, 2) else (0, 0, 0, 0))
-             + tuple(np.percentile(t1[m], [10, 50, 90, 99, 100]))))
-m = live & ((role == 1) | (role == 2))
-g = t1[m] - tm[m]
-print("gather part: p50 %.2f p90 %.2f max %.2f us; waves that copied (> 0.8 us): %d" % (np.nanpercentile(g, 50), np.nanpercentile(g, 90), np.nanmax(g), (g > 0.8).sum()))
+    print("%-7s waves %5d  start p10 %.2f p50 %.2f p90 %.2f max %.2f | end p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f | dur p50 %.2f p90 %.2f"
+          % ((name, m.sum()) + tuple(np.percentile(t0[m], [10, 50, 90, 100])) + tuple(np.percentile(t1[m], [10, 50, 90, 99, 100]))
+             + tuple(np.percentile((t1 - t0)[m], [50, 90]))))
+m = live & (role == 3)
+copied = m & ((t1 - tm) > 0.3)
+print("gather: %d of %d waves copied a row (probe p50 %.2f us; copy p50 %.2f p90 %.2f us)"
+      % (copied.sum(), m.sum(), np.nanpercentile(tm[m] - t0[m], 50), np.nanpercentile((t1 - tm)[copied], 50),
+         np.nanpercentile((t1 - tm)[copied], 90)))
 for lo in np.arange(0, t1[live].max(), 1.0):
-    mm = m & (t0 < lo + 1.0) & (t1 > lo)
-    ma = m & (t0 < lo + 1.0) & (tm > lo)
-    print("t=%4.1f us resident work waves %5d (still applying %5d)" % (lo, int(mm.sum()), int(ma.sum())))
+    row = []
+    for r in range(5):
+        mm = live & (role == r) & (t0 < lo + 1.0) & (t1 > lo)
+        row.append(int(mm.sum()))
+    print("t=%4.1f us resident waves finish/apply/rank/gather/clear: %s" % (lo, row))
+m = live & (role == 1)
 idx = np.nonzero(m)[0]
 order = idx[np.argsort(-t1[idx])][:12]
-print("latest waves (block, wave, start, apply done, end):", [(int(i // 16), int(i % 16), round(float(t0[i]), 2), round(float(tm[i]), 2), round(float(t1[i]), 2)) for i in order])
+print("latest apply waves (block, wave, start, end):", [(int(i // 16), int(i % 16), round(float(t0[i]), 2), round(float(t1[i]), 2)) for i in order])
