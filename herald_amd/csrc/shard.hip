@@ -73,9 +73,129 @@ __global__ __launch_bounds__(64) void shard_meta_kernel(
     }
 }
 
+// Routing message of one batch, one launch: send[g] = [count_g, the shard-local keys owner g is asked for ...]
+// in a FIXED frame of 1 + cap words per owner, so that the keys travel in one equal-split all-to-all together
+// with their counts (no counts exchange, no host read-back before the keys can move); meta = n_unique and
+// the W counts for the one asynchronous read-back that sizes the row exchanges.
+__global__ __launch_bounds__(256) void shard_pack_kernel(
+    const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq, ShardStarts st, int nshard, int cap,
+    int64_t *__restrict__ meta, int32_t *__restrict__ send) {
+    __shared__ int s_off[kMaxShards + 1];
+    const int U = static_cast<int>(hdr->n_unique);
+    if (threadIdx.x <= static_cast<unsigned>(nshard)) {
+        const uint32_t target = st.start[threadIdx.x];
+        int lo = 0, hi = U;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (uniq[mid] < target)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        s_off[threadIdx.x] = static_cast<int>(threadIdx.x) == nshard ? U : lo;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0)
+            meta[0] = U;
+        if (threadIdx.x < static_cast<unsigned>(nshard)) {
+            const int c = s_off[threadIdx.x + 1] - s_off[threadIdx.x];
+            meta[1 + threadIdx.x] = c;
+            send[static_cast<size_t>(threadIdx.x) * (1 + cap)] = c;
+        }
+    }
+    const int stride = gridDim.x * 256;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += stride) {
+        const uint32_t k = uniq[u];
+        int g = 0;
+        while (g + 1 < nshard && u >= s_off[g + 1])
+            ++g;
+        send[static_cast<size_t>(g) * (1 + cap) + 1 + (u - s_off[g])] = static_cast<int32_t>(k - st.start[g]);
+    }
+}
+
+// Receiving side: recv[g] = [count_g, keys ...] from rank g -> the W key lists concatenated in rank order
+// (what the owner-side gather / serve_push take) and the W counts next to the sender's meta.
+__global__ __launch_bounds__(256) void shard_unpack_kernel(const int32_t *__restrict__ recv, int nshard, int cap,
+                                                           int64_t *__restrict__ recv_cnt,
+                                                           uint32_t *__restrict__ keys_out) {
+    __shared__ int s_pre[kMaxShards + 1];
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int g = 0; g < nshard; ++g) {
+            s_pre[g] = run;
+            int c = recv[static_cast<size_t>(g) * (1 + cap)];
+            c = c < 0 ? 0 : (c > cap ? cap : c);
+            run += c;
+        }
+        s_pre[nshard] = run;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < static_cast<unsigned>(nshard))
+        recv_cnt[threadIdx.x] = s_pre[threadIdx.x + 1] - s_pre[threadIdx.x];
+    const int total = s_pre[nshard];
+    const int stride = gridDim.x * 256;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < total; j += stride) {
+        int g = 0;
+        while (g + 1 < nshard && j >= s_pre[g + 1])
+            ++g;
+        keys_out[j] = static_cast<uint32_t>(recv[static_cast<size_t>(g) * (1 + cap) + 1 + (j - s_pre[g])]);
+    }
+}
+
 }  // namespace ha
 
 using namespace ha;
+
+template <typename IdT>
+static int shard_route_pack(const IdT *ids, int64_t n, void *plan_ws, const int64_t *starts_host, int nshard,
+                            int64_t cap, int64_t *meta, int32_t *send, ha_stream_t stream,
+                            int (*build)(const IdT *, int64_t, void *, uint64_t, ha_stream_t)) {
+    HA_REQUIRE(plan_ws && starts_host && meta && send, "shard_route_pack: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards, "shard_route_pack: nshard must be in [1,%d]", kMaxShards);
+    HA_REQUIRE(n >= 0 && cap >= n && cap < (1ll << 30), "shard_route_pack: the frame (%ld keys) must hold the batch (%ld ids)",
+               static_cast<long>(cap), static_cast<long>(n));
+    if (build(ids, n, plan_ws, static_cast<uint64_t>(starts_host[nshard]), stream))   // keys < total rows
+        return -1;
+    PlanPtrs p = plan_layout(plan_ws, n);
+    ShardStarts st;
+    for (int g = 0; g <= nshard; ++g) {
+        HA_REQUIRE(starts_host[g] >= 0 && starts_host[g] <= 0xFFFFFFFEll, "shard_route_pack: start out of range");
+        st.start[g] = static_cast<uint32_t>(starts_host[g]);
+    }
+    int blocks = static_cast<int>((n + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(shard_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p.hdr, p.uniq, st, nshard,
+                       static_cast<int>(cap), meta, send);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ha_shard_route_pack_f32ids(const float *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
+                                          int nshard, int64_t cap, int64_t *meta, int32_t *send,
+                                          ha_stream_t stream) {
+    return shard_route_pack<float>(ids, n, plan_ws, starts_host, nshard, cap, meta, send, stream,
+                                   ha_plan_build_f32ids_lim);
+}
+
+extern "C" int ha_shard_route_pack_u64ids(const uint64_t *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
+                                          int nshard, int64_t cap, int64_t *meta, int32_t *send,
+                                          ha_stream_t stream) {
+    return shard_route_pack<uint64_t>(ids, n, plan_ws, starts_host, nshard, cap, meta, send, stream,
+                                      ha_plan_build_u64ids_lim);
+}
+
+extern "C" int ha_shard_route_unpack(const int32_t *recv, int nshard, int64_t cap, int64_t *recv_cnt,
+                                     uint32_t *keys_out, ha_stream_t stream) {
+    HA_REQUIRE(recv && recv_cnt && keys_out, "shard_route_unpack: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && cap >= 0 && cap < (1ll << 30), "shard_route_unpack: bad sizes");
+    long long want = (static_cast<long long>(nshard) * cap + 255) / 256;
+    const int blocks = want < 1 ? 1 : (want > 256 ? 256 : static_cast<int>(want));
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), recv, nshard,
+                       static_cast<int>(cap), recv_cnt, keys_out);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ha_shard_bucket(const void *plan_ws, int64_t n,
                                const int64_t *starts_host, int nshard,

@@ -16,13 +16,13 @@ The reference keeps the embedding table on parameter servers and moves rows over
 
 Here every rank owns one shard in its HBM and is a worker at the same time; the exchange is all-to-all
 over RCCL (torch.distributed "nccl" backend == RCCL over xGMI):
-    route: counts  ->  shard-local keys                          (once per batch, shared by pull and push)
+    route: [count | shard-local keys] frames, ONE equal-split exchange   (once per batch, shared by pull and push)
     pull : [owner gathers]  ->  rows back  ->  [expand to the positions]
     push : [worker dedup-reduces]  ->  reduced rows  ->  [owner applies, rank order]
 The routing of a batch depends on its ids only, and the ids are known one step ahead (the reference
-prefetches them too: ParameterServerCommunicate.py:96-139), so `prefetch(ids)` builds it on a side stream
-while the rows of the current batch are exchanged; the only host read-back
-of a step (n_unique and the 2W counts) is then long complete when the host needs it.
+prefetches them too: ParameterServerCommunicate.py:96-139), so `prefetch(ids)` enqueues it ahead of the
+row exchanges of the current batch; the only host read-back of a step (n_unique and the 2W counts, which
+size the row exchanges) is then long complete when the host needs it.
 The reference's servers apply concurrent pushes in arrival order (non-deterministic); here an owner
 applies the W incoming sorted lists in RANK order, `row = (row + r_0) + r_1 ...`, which is one of the
 orders the reference can produce and makes the result reproducible.
@@ -96,41 +96,49 @@ class HipEngine:
         return torch._C._cuda_getCurrentRawStream(self._devidx)
 
     # -- routing -------------------------------------------------------------------------------------
-    def route_issue(self, ids, starts, slot):
-        """Enqueue plan build + shard-local keys + meta for a batch of ids (float32 or int64) into the
-        routing workspace `slot`.  -> RouteBuffers: plan, local (int32[n] shard-local keys), meta
-        (int64[1+W] = n_unique, send counts), recv (int64[W]), host (pinned int64[1+2W]), keys_recv
-        (int32[W*n]: what this rank can be asked for at most), free (event of its last consumer)."""
+    def route_issue(self, ids, starts, slot, cap):
+        """Enqueue plan build + routing frames for a batch of ids (float32 or int64) into the routing
+        workspace `slot`.  -> RouteBuffers: plan, send / recv (int32[W, 1+cap] frames: count, shard-local
+        keys), meta_all (int64[1+2W] = n_unique, send counts, receive counts), host (pinned copy of it),
+        keys_recv (int32[W*cap]: the received key lists in rank order), free (event of its last consumer)."""
         n = ids.numel()
         w = len(starts) - 1
         st = self._slots.get(slot)
-        if st is None or st.plan.capacity < n or st.meta.numel() != 1 + w:
+        if st is None or st.plan.capacity < n or st.meta.numel() != 1 + w or st.cap != cap:
             st = RouteBuffers()
-            st.plan = self.ops.IndexPlan(max(n, 1), self.device)
-            st.local = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+            st.cap = cap
+            st.plan = self.ops.IndexPlan(max(cap, 1), self.device)
+            st.send = torch.empty((w, 1 + cap), dtype=torch.int32, device=self.device)
+            st.recv = torch.empty((w, 1 + cap), dtype=torch.int32, device=self.device)
             st.meta_all = torch.empty(1 + 2 * w, dtype=torch.int64, device=self.device)
-            st.meta = st.meta_all[:1 + w]     # n_unique, send counts (written by ha_shard_route_*)
-            st.recv = st.meta_all[1 + w:]     # receive counts (written by the counts all-to-all)
+            st.meta = st.meta_all[:1 + w]       # n_unique, send counts (written by ha_shard_route_pack_*)
+            st.recv_cnt = st.meta_all[1 + w:]   # receive counts (written by ha_shard_route_unpack)
             st.host = torch.empty(1 + 2 * w, dtype=torch.int64, pin_memory=True)
             st.ev_host, st.ev_ready, st.ev_free = (torch.cuda.Event() for _ in range(3))
-            st.keys_recv = torch.empty(max(w * n, 1), dtype=torch.int32, device=self.device)
+            st.keys_recv = torch.empty(max(w * cap, 1), dtype=torch.int32, device=self.device)
             st.starts = (ctypes.c_int64 * (w + 1))(*starts)
             self._slots[slot] = st
         self.wait_event(st.free)   # the previous batch routed through this workspace is fully consumed
         st.free = None
         plan = st.plan
         if ids.dtype == torch.float32:
-            fn = self.lib.ha_shard_route_f32ids
+            fn = self.lib.ha_shard_route_pack_f32ids
         elif ids.dtype in (torch.int64, torch.uint64):
-            fn = self.lib.ha_shard_route_u64ids
+            fn = self.lib.ha_shard_route_pack_u64ids
         else:
             raise TypeError("ids must be float32 or (u)int64")
-        self.check(fn(ids.data_ptr(), n, plan.ws.data_ptr(), st.starts, w, st.meta.data_ptr(),
-                      st.local.data_ptr(), self._stream()), "ha_shard_route")
+        self.check(fn(ids.data_ptr(), n, plan.ws.data_ptr(), st.starts, w, cap, st.meta.data_ptr(),
+                      st.send.data_ptr(), self._stream()), "ha_shard_route_pack")
         plan.n = n
         plan._view = None
         plan._produced_on = self._stream()
         return st
+
+    def route_unpack(self, st):
+        """Received frames -> key lists in rank order + receive counts (device)."""
+        self.check(self.lib.ha_shard_route_unpack(st.recv.data_ptr(), st.recv.shape[0], st.cap,
+                                                  st.recv_cnt.data_ptr(), st.keys_recv.data_ptr(), self._stream()),
+                   "ha_shard_route_unpack")
 
     def on_side(self, after_current=True):
         """Context: the side stream is current; with after_current it first waits for the work queued
@@ -197,8 +205,8 @@ class HipEngine:
 
 class RouteBuffers:
     """Persistent device / pinned-host buffers of one routing workspace (see HipEngine.route_issue)."""
-    __slots__ = ("plan", "local", "meta_all", "meta", "recv", "host", "keys_recv", "starts", "free",
-                 "ev_host", "ev_ready", "ev_free")
+    __slots__ = ("plan", "cap", "send", "recv", "meta_all", "meta", "recv_cnt", "host", "keys_recv", "starts",
+                 "free", "ev_host", "ev_ready", "ev_free")
 
     def __init__(self):
         self.free = None
@@ -225,12 +233,22 @@ class ShardedEmbedding:
     row exchanges instead of queueing between them); construct the store on every rank of `group` at
     the same point of the program in that case."""
 
-    def __init__(self, rows, width, device, group=None, engine=None, table=None, side_group=False, a2a=None):
+    def __init__(self, rows, width, device, group=None, engine=None, table=None, side_group=False, a2a=None,
+                 max_ids=None, side_stream=None):
         """a2a: optional replacement of torch.distributed.all_to_all_single with the same arguments
         (out, inp, out_splits, in_splits, group) -- e.g. a host-staged exchange where the process group's
-        backend cannot move device tensors (several ranks sharing one GPU under gloo in the tests)."""
+        backend cannot move device tensors (several ranks sharing one GPU under gloo in the tests).
+        max_ids: the largest batch (ids per rank) any rank will route -- the size of the fixed routing frame,
+        which must be the same on every rank; None: agreed at the first routing call (max over the ranks of
+        their first batch; a later, larger batch is then an error).
+        side_stream: True runs the routing on the engine's side stream (it then overlaps the row exchanges on
+        the device), False on the caller's stream (fewer events and stream switches on the host: the step is
+        host-bound at small batches).  Default: False (HA_SHARD_SIDE_STREAM=1 turns it on)."""
+        import os
         self.group = group
         self._a2a_fn = a2a
+        self.max_ids = None if max_ids is None else int(max_ids)
+        self.side_stream = (os.environ.get("HA_SHARD_SIDE_STREAM") == "1") if side_stream is None else bool(side_stream)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rows, self.width = int(rows), int(width)
@@ -261,12 +279,33 @@ class ShardedEmbedding:
         return out
 
     # -- routing: phase 1 (enqueue, no host wait) and phase 2 (host reads 1+2W counts, keys exchange) ----
+    def _frame(self, n):
+        """Keys per owner in the routing frame: fixed for the life of the store, identical on all ranks."""
+        if self.max_ids is None:
+            cap = int(n)
+            if self.world > 1:
+                t = torch.tensor([cap], dtype=torch.int64, device=self.device)
+                if self._a2a_fn is not None and self.device.type == "cuda":
+                    t = t.cpu()      # the group's backend cannot move device tensors (see a2a)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                cap = int(t.item())
+            self.max_ids = max(cap, 1)
+        return self.max_ids
+
+    def _on_route_stream(self, after_current):
+        import contextlib
+        return self.engine.on_side(after_current) if self.side_stream else contextlib.nullcontext()
+
     def prefetch(self, ids, after_current=True):
-        """Start the routing of a batch of ids on the side stream: plan, shard-local keys, counts
-        all-to-all and the asynchronous read-back; no host wait.  Returns a Route for pull(route=) /
-        push(route=).  after_current=False when `ids` is not produced by work queued on the current
-        stream (ids resident since an earlier step): the routing then starts at once."""
+        """Start the routing of a batch of ids: plan, routing frames ([count | shard-local keys] per owner),
+        ONE equal-split all-to-all, received key lists, and the asynchronous read-back of the counts; no
+        host wait.  Returns a Route for pull(route=) / push(route=).  after_current=False (side-stream
+        routing only) when `ids` is not produced by work queued on the current stream."""
         eng = self.engine
+        cap = self._frame(ids.numel())
+        if ids.numel() > cap:
+            raise ValueError("a batch of %d ids does not fit the routing frame of %d keys agreed for this store "
+                             "(construct ShardedEmbedding with max_ids >= the largest batch)" % (ids.numel(), cap))
         r = Route()
         r.shape = tuple(ids.shape)
         slot = self._slot
@@ -276,32 +315,26 @@ class ShardedEmbedding:
             raise RuntimeError("routing workspace %d is still in use by a batch that was prefetched but "
                                "neither pulled nor pushed (at most %d batches in flight)" % (slot, eng.NSLOT))
         self._live[slot] = r
-        with eng.on_side(after_current):
-            b = r.buf = eng.route_issue(ids.reshape(-1), self.starts, slot)
+        with self._on_route_stream(after_current):
+            b = r.buf = eng.route_issue(ids.reshape(-1), self.starts, slot, cap)
             r.plan = b.plan
-            self._a2a(b.recv, b.meta[1:], None, None, group=self.side_group)
+            self._a2a(b.recv, b.send, None, None, group=self.side_group)
+            eng.route_unpack(b)
             r.pending = eng.to_host(b)
+            r.ready = eng.record(b.ev_ready) if self.side_stream else None
         return r
 
     def complete(self, r):
-        """Second phase of a route: the host reads n_unique and the 2W counts (waits for the read-back
-        of prefetch) and the shard-local keys are exchanged on the side stream.  pull / push call it
-        when needed; calling it at the end of the previous step keeps both off the critical path."""
+        """Second phase of a route: the host reads n_unique and the 2W counts (waits for the read-back of
+        prefetch); nothing is enqueued.  pull / push call it when needed."""
         if r.pending is False:
             return r
-        eng = self.engine
         b = r.buf
-        eng.host_sync(r.pending)
+        self.engine.host_sync(r.pending)
         vals = b.host.tolist()
         w = self.world
         r.u, r.send_cnt, r.recv_cnt = vals[0], vals[1:1 + w], vals[1 + w:1 + 2 * w]
-        need = sum(r.recv_cnt)
-        if b.keys_recv.numel() < need:     # a peer's batch is larger than this rank's (ragged last batch)
-            b.keys_recv = torch.empty(need * 5 // 4 + 16, dtype=torch.int32, device=b.keys_recv.device)
-        r.keys_recv = b.keys_recv[:need]
-        with eng.on_side(False):
-            self._a2a(r.keys_recv, b.local[:r.u], r.recv_cnt, r.send_cnt, group=self.side_group)
-            r.ready = eng.record(b.ev_ready)
+        r.keys_recv = b.keys_recv[:sum(r.recv_cnt)]
         r.pending = False
         return r
 
@@ -311,7 +344,8 @@ class ShardedEmbedding:
         overwrites the earlier one (same stream, program order), and route_issue waits for it.  A route
         is live from prefetch() until its push (or, for pull-only use, its pull); with NSLOT = 3 workspaces
         at most two newer batches may be prefetched meanwhile -- prefetch() asserts that."""
-        r.buf.free = self.engine.record(r.buf.ev_free)
+        if self.side_stream:       # on one stream the program order already protects the workspace
+            r.buf.free = self.engine.record(r.buf.ev_free)
         r.released = True
 
     def _account(self, send_cnt, recv_cnt, bytes_per_key_out, bytes_per_key_in):

@@ -464,6 +464,23 @@ int ha_shard_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws,
                           const int64_t *starts_host, int nshard, int64_t *meta,
                           uint32_t *local_keys, ha_stream_t stream);
 
+/* The routing of a batch as ONE message per owner: ha_plan_build_* of the ids, then
+ * send[g * (1 + cap) + 0] = number of this rank's unique keys that shard g owns, followed by those keys as
+ * shard-local offsets (PSAgent.h:537-560), in a fixed frame of 1 + cap int32 per owner (cap >= n), and
+ * meta[0] = n_unique, meta[1+g] = the same counts (device int64[1+nshard]) for the host read-back that sizes the
+ * row exchanges.  The frames of all ranks travel in one equal-split all-to-all -- the reference sends key
+ * lists and their lengths in one message too (PSAgent::vecPullSparse, PSAgent.h:185-237).
+ * ha_shard_route_unpack turns the received frames recv[g] into the W key lists concatenated in rank order
+ * (keys_out: what ha_gather_u32keys / ha_shard_serve_push take) and recv_cnt[g] (device int64[nshard]). */
+int ha_shard_route_pack_f32ids(const float *ids, int64_t n, void *plan_ws,
+                               const int64_t *starts_host, int nshard, int64_t cap,
+                               int64_t *meta, int32_t *send, ha_stream_t stream);
+int ha_shard_route_pack_u64ids(const uint64_t *ids, int64_t n, void *plan_ws,
+                               const int64_t *starts_host, int nshard, int64_t cap,
+                               int64_t *meta, int32_t *send, ha_stream_t stream);
+int ha_shard_route_unpack(const int32_t *recv, int nshard, int64_t cap, int64_t *recv_cnt,
+                          uint32_t *keys_out, ha_stream_t stream);
+
 /* Owner side of a sparse push (PSHandler::serve(SparsePush), ps-lite/include/ps/server/PSFHandle.h:130-164):
  * table[keys[j],:] = (table[keys[j],:] + values[a,:]) + values[b,:] ... over the positions a < b < ... that
  * list the key, i.e. in list order (the W received sorted lists concatenated in rank order).

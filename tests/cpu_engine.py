@@ -27,24 +27,40 @@ class CpuEngine:
         self.device = torch.device("cpu")
 
     # -- routing (same contract as HipEngine.route_issue; streams and events are no-ops on the CPU) --
-    def route_issue(self, ids, starts, slot):
+    def route_issue(self, ids, starts, slot, cap):
         plan = _Plan(ids)
+        assert plan.n <= cap
         st = np.asarray(starts, dtype=np.uint64)
         offsets = np.searchsorted(plan.uniq, st, side="left").astype(np.int64)
         offsets[-1] = plan.uniq.size
         owner = np.searchsorted(st, plan.uniq, side="right") - 1
-        local = np.zeros(max(plan.n, 1), dtype=np.int32)
-        local[:plan.uniq.size] = (plan.uniq - st[owner]).astype(np.int32)
+        local = (plan.uniq - st[owner]).astype(np.int32)
         w = len(starts) - 1
+        send = np.full((w, 1 + cap), -7, dtype=np.int32)        # padding is never read
+        for g in range(w):
+            c = int(offsets[g + 1] - offsets[g])
+            send[g, 0] = c
+            send[g, 1:1 + c] = local[offsets[g]:offsets[g + 1]]
         meta = np.concatenate([[plan.uniq.size], offsets[1:] - offsets[:-1]]).astype(np.int64)
         from herald_amd.sharded import RouteBuffers
         b = RouteBuffers()
-        b.plan, b.local, b.meta = plan, torch.from_numpy(local), torch.from_numpy(meta)
-        b.meta_all = torch.cat([b.meta, torch.zeros(w, dtype=torch.int64)])
-        b.meta, b.recv = b.meta_all[:1 + w], b.meta_all[1 + w:]
+        b.plan, b.cap = plan, cap
+        b.send = torch.from_numpy(send)
+        b.recv = torch.empty((w, 1 + cap), dtype=torch.int32)
+        b.meta_all = torch.cat([torch.from_numpy(meta), torch.zeros(w, dtype=torch.int64)])
+        b.meta, b.recv_cnt = b.meta_all[:1 + w], b.meta_all[1 + w:]
         b.host = torch.empty(1 + 2 * w, dtype=torch.int64)
-        b.keys_recv = torch.empty(max(w * plan.n, 1), dtype=torch.int32)
+        b.keys_recv = torch.empty(max(w * cap, 1), dtype=torch.int32)
         return b
+
+    def route_unpack(self, b):
+        r = b.recv.numpy()
+        at = 0
+        for g in range(r.shape[0]):
+            c = int(r[g, 0])
+            b.recv_cnt[g] = c
+            b.keys_recv[at:at + c] = torch.from_numpy(r[g, 1:1 + c].copy())
+            at += c
 
     def on_side(self, after_current=True):
         return contextlib.nullcontext()

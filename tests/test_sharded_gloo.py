@@ -93,6 +93,17 @@ def _worker(rank, world, port, rows, width, n, out_dir, side_group=False):
     dist.barrier()
     np.testing.assert_array_equal(emb.table.numpy(), want[starts[rank]:starts[rank + 1]])
 
+    # ragged batches: rank r brings n - 7r ids (the routing frame was agreed as the max over the ranks of the
+    # first batch = n), empty batches, and a batch larger than the frame is refused
+    rg = [rng.integers(0, rows, size=max(n - 7 * r, 0)).astype(np.float32) for r in range(world)]
+    rg[world - 1] = rg[world - 1][:0]                                  # the last rank brings nothing
+    got = emb.pull(torch.from_numpy(rg[rank]))
+    np.testing.assert_array_equal(got.numpy().reshape(-1, width), want[rg[rank].astype(np.int64)].reshape(-1, width))
+    assert emb.max_ids == n
+    with pytest.raises(ValueError, match="routing frame"):
+        emb.prefetch(torch.zeros(n + 1))
+    dist.barrier()
+
     # 2-D id batches and the checkpoint format round trip
     ids2 = ids[: (n // 4) * 4].reshape(-1, 4)
     assert tuple(emb.pull(ids2).shape) == (ids2.shape[0], 4, width)
