@@ -428,7 +428,7 @@ __global__ __launch_bounds__(1024) void finish_small_kernel(
 
 // heads per 1024-position chunk (first launch of the two-launch finish of medium-sized batches)
 __global__ __launch_bounds__(1024) void finish_chunk_heads_kernel(
-    const uint32_t *__restrict__ sorted, int n, uint32_t *__restrict__ chunk_heads) {
+    const uint32_t *__restrict__ sorted, int n, uint32_t *__restrict__ chunk_heads, PlanHeader *hdr) {
     __shared__ uint32_t s_w[16];
     const int p = blockIdx.x * 1024 + threadIdx.x;
     const int cp = min(p, n - 1);
@@ -442,6 +442,8 @@ __global__ __launch_bounds__(1024) void finish_chunk_heads_kernel(
         for (int i = 0; i < 16; ++i)
             t += s_w[i];
         chunk_heads[blockIdx.x] = t;
+        if (blockIdx.x == 0 && hdr != nullptr)
+            hdr->reserved[0] = 0;   // counter of the long-run list the second launch fills
     }
 }
 
@@ -450,9 +452,10 @@ __global__ __launch_bounds__(1024) void finish_chunked_kernel(
     int n, PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
-    const uint32_t *__restrict__ chunk_heads) {
+    const uint32_t *__restrict__ chunk_heads, uint32_t *__restrict__ long_list, int long_min) {
     __shared__ uint32_t s_w[kFinishLdsWords];
-    finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, blockIdx.x, s_w, chunk_heads);
+    finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, blockIdx.x, s_w, chunk_heads, nullptr,
+                      nullptr, 0, long_list, long_min);
 }
 
 template <typename IdT>
@@ -599,9 +602,11 @@ static int plan_finish(void *ws, int64_t n, hipStream_t stream) {
     if (n <= kFinishChunkedMax) {
         // heads per chunk into the radix histogram scratch (free after the sort, >= n/16 words)
         const int chunks = finish_blocks(ni);
-        hipLaunchKernelGGL(finish_chunk_heads_kernel, dim3(chunks), dim3(1024), 0, stream, p.sorted, ni, p.hist);
+        // the second launch also lists the keys with runs of kPlanLongRun or more occurrences (keys_alt, counter
+        // in header word 0): the apply of larger batches starts with them (scatter.hip)
+        hipLaunchKernelGGL(finish_chunk_heads_kernel, dim3(chunks), dim3(1024), 0, stream, p.sorted, ni, p.hist, p.hdr);
         hipLaunchKernelGGL(finish_chunked_kernel, dim3(chunks), dim3(1024), 0, stream, p.sorted, p.perm, ni,
-                           p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, p.hist);
+                           p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, p.hist, p.keys_alt, kPlanLongRun);
         HA_LAUNCH_CHECK();
         return 0;
     }

@@ -121,7 +121,8 @@ int plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipStream
 // plan.hip: bucket sort (one most-significant-digit scatter + rank-by-counting inside the buckets) for
 // kBucketMin < n <= kBucketMax (= kSmallMax) keys below a known limit; the first launch (radix_first_tile_body with the
 // shift of bucket_shift() and msd = true) has been made by the caller
-constexpr int kBucketMin = 12288;
+constexpr int kBucketMin = 18432;   // measured (d = 128, Criteo ids): rank-by-counting 25.8 / 36.0 / 46.6 us per step at
+                                    // 13,312 / 16,640 / 19,968 ids, bucket sort 38.4 / 42.0 / 45.9
 constexpr int kBucketMax = kSmallMax;   // beyond: several low-cardinality fields share a range and its equal keys make
                                         // the in-range counting quadratic (measured at n = 106,496: 232 vs 129 us per step)
 inline bool bucket_sort_applies(int64_t n, uint64_t key_limit) {
@@ -383,6 +384,7 @@ __device__ __forceinline__ void rank_tile_body<float>(
 // raise their budget.  LDS: 64 words.  For batches up to kFinishChunkedMax ids the same body runs
 // behind one counting launch (heads per chunk) instead of recounting: two launches in all.
 constexpr int kFinishChunkedMax = 1 << 20;
+constexpr int kPlanLongRun = 48;   // = kLongRun of scatter_dev.h: the chunked finish lists the keys with such runs
 
 // Optional per-unique-key hook of the finish (the embedding cache): the thread that writes uniq[u] also
 // probes the cache's direct map and, for a lookup, takes syncEmbedding's pull decision -- random,
@@ -422,7 +424,8 @@ __device__ __forceinline__ void finish_block_body(
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
     int b, uint32_t *s_w, const uint32_t *__restrict__ chunk_heads = nullptr,
-    const HeadProbe *hp = nullptr, uint32_t *key_tab = nullptr, uint64_t key_rows = 0) {
+    const HeadProbe *hp = nullptr, uint32_t *key_tab = nullptr, uint64_t key_rows = 0,
+    uint32_t *long_list = nullptr, int long_min = 0) {
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t *s_before = s_w, *s_heads = s_w + 16, *s_first = s_w + 32, *s_cand = s_w + 48;
     const int p = b * 1024 + tid;
@@ -513,6 +516,12 @@ __device__ __forceinline__ void finish_block_body(
             else
                 nxt = static_cast<int32_t>(min(next_after, static_cast<uint32_t>(n)));
             counts[ui] = nxt - p;
+            // list of the keys with long runs (scatter.hip, apply of larger batches): counter in header word 0
+            if (long_list != nullptr && nxt - p >= long_min) {
+                const unsigned long long at =
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->reserved[0]), 1ull);
+                long_list[at] = static_cast<uint32_t>(ui);
+            }
             // key table of the batch (step.hip, ha_step_*): one entry per unique key of the table's range --
             // claim a slot (keys are unique here, so only different keys ever meet), then plain stores
             if (key_tab != nullptr && k < key_rows) {

@@ -27,6 +27,7 @@
 //   * every other wave of a run exits.
 #include "scatter_dev.h"
 #include "plan_dev.h"
+static_assert(ha::kPlanLongRun == ha::kLongRun, "the finish lists exactly the runs the cooperative path takes");
 
 namespace ha {
 
@@ -133,6 +134,58 @@ __global__ __launch_bounds__(1024, 8) void apply_long_kernel(
     }
 }
 
+// Both in ONE launch when the finish has already listed the long keys (batches up to kFinishChunkedMax ids):
+// a workgroup first serves its share of the (long key, slice) items -- they are the launch's critical path, a
+// 2,000-occurrence run is an ordered chain of 2,000 steps whatever else happens -- and then joins the loop over
+// the unique keys.  One launch and one dependent boundary less, and the short keys no longer wait for the list.
+template <int MODE, int VEC>
+__global__ __launch_bounds__(1024, 8) void apply_listed_kernel(
+    float *__restrict__ dst, uint64_t dst_rows, int width, const PlanHeader *__restrict__ hdr,
+    const uint32_t *__restrict__ uniq, const int32_t *__restrict__ seg,
+    const int32_t *__restrict__ counts, const int32_t *__restrict__ perm, int n,
+    const float *__restrict__ grads, float lr, const uint32_t *__restrict__ long_list, ApplyMaps maps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
+    const int nslice = (width + kWave - 1) / kWave;
+    const long long items = hdr->reserved[0] * nslice;
+    const int w = static_cast<int>(threadIdx.x >> 6);
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int u = static_cast<int>(long_list[it / nslice]);
+        const int j = static_cast<int>(it % nslice);
+        const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
+        if (row < dst_rows) {
+            Second d2{nullptr, false};
+            if (MODE == kModeOpt)
+                opt_rows(d2, maps, row, width);
+            coop_slices<MODE, false>(dst + row * static_cast<uint64_t>(width), true, d2, grads, perm, maps, n, lr,
+                                     seg[u], counts[u], width, j, nslice, w, reinterpret_cast<float *>(s_apply));
+        }
+        __syncthreads();
+    }
+    const int U = static_cast<int>(hdr->n_unique);
+    const int lane = lane_id();
+    const int nwaves = gridDim.x * 16;
+    for (int u = blockIdx.x * 16 + w; u < U; u += nwaves) {
+        const int s = uniform(seg[u]), len = uniform(counts[u]);
+        if (len >= kLongRun)
+            continue;
+        const uint32_t key = uniform(uniq[u]);
+        const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(key);
+        if (row >= dst_rows)
+            continue;  // out-of-range id: ignored
+        float *dst_row = dst + row * static_cast<uint64_t>(width);
+        const int pv = perm[min(s + lane, n - 1)];   // lanes 0 .. len-1: the run's occurrence indices
+        Second d2{nullptr, false};
+        if (MODE == kModeOpt)
+            opt_rows(d2, maps, row, width);
+        if (len <= kShortRun) {
+            short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, true, d2);
+        } else {
+            for (int c0 = 0; c0 < width; c0 += kWave)
+                medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, true, d2);
+        }
+    }
+}
+
 // diagnostic twin of apply_kernel<kModeSgd,4>: same body plus per-wave time stamps
 __global__ __launch_bounds__(1024, 8) void apply_timeline_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width,
@@ -193,10 +246,25 @@ int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, 
                     const float *grads, float lr, hipStream_t stream, ApplyMaps maps) {
     HA_REQUIRE(dst && plan_ws && grads && n > 0 && width >= 1 && width < (1 << 30), "apply_by_unique: bad arguments");
     PlanPtrs p = plan_layout(plan_ws, n);
-    HA_CHECK_HIP(hipMemsetAsync(&p.hdr->reserved[0], 0, sizeof(int64_t), stream));
     const bool vec_ok = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
                         (reinterpret_cast<uintptr_t>(grads) % 16 == 0);
     const dim3 grid(512), block(1024);   // two workgroups per compute unit, looping over the keys
+    if (n > kSmallMax && n <= kFinishChunkedMax) {
+        // the chunked finish (plan.hip) left the list of long keys in keys_alt / header word 0
+        // (grids of 448 / 384 / 256 workgroups, to leave slots to a sort running beside it on another stream:
+        // 57.8 / 57.2 / 59.0 us alone against 52.5 us, and no faster together -- tools/cfgc_bench.py)
+        if (vec_ok)
+            hipLaunchKernelGGL((apply_listed_kernel<MODE, 4>), grid, block, kApplyLdsBytes, stream, dst,
+                               (uint64_t)dst_rows, (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads,
+                               lr, p.keys_alt, maps);
+        else
+            hipLaunchKernelGGL((apply_listed_kernel<MODE, 1>), grid, block, kApplyLdsBytes, stream, dst,
+                               (uint64_t)dst_rows, (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads,
+                               lr, p.keys_alt, maps);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
+    HA_CHECK_HIP(hipMemsetAsync(&p.hdr->reserved[0], 0, sizeof(int64_t), stream));
     if (vec_ok)
         hipLaunchKernelGGL((apply_unique_kernel<MODE, 4>), grid, block, 0, stream, dst, (uint64_t)dst_rows,
                            (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads, lr, p.keys_alt, maps);

@@ -342,7 +342,7 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
 // round trips), not by the bytes the forwarding saves.  Kept because it runs ANY table in one launch (rows
 // narrower than a line, unaligned tables) and has no waiting, hence no time-out path.
 // =====================================================================================================
-constexpr int kStepMax = kBucketMin;   // ids per batch (rank-by-counting tiles; key table at <= 37.5 % load)
+constexpr int kStepMax = 12288;        // ids per batch (key table at <= 37.5 % load)
 constexpr int kClearBlocks = 4;        // workgroups that clear one key table (512 KiB)
 
 struct FwdArgs {

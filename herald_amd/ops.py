@@ -141,7 +141,7 @@ class IndexPlan:
         return self
 
     def build(self, ids, stream=None, sort_only=False, key_limit=None):
-        """key_limit: a bound on the valid keys (the table's row count) -- lets batches of 12,289 .. 36,864 ids take
+        """key_limit: a bound on the valid keys (the table's row count) -- lets batches of 18,433 .. 36,864 ids take
         the bucket sort (ha_plan_*_lim); results are identical with and without it."""
         L = _lib.load()
         n = ids.numel()

@@ -240,7 +240,7 @@ int ha_plan_sort_f32ids(const float *ids, int64_t n, void *ws,
 int ha_plan_sort_u64ids(const uint64_t *ids, int64_t n, void *ws,
                         ha_stream_t stream);
 /* The same with a known key range (key_limit = number of table rows, or any bound on the valid keys):
- * batches of 12,289 .. 36,864 ids then take the bucket sort -- one most-significant-digit scatter into
+ * batches of 18,433 .. 36,864 ids then take the bucket sort -- one most-significant-digit scatter into
  * 2,048 ordered key ranges + stable rank-by-counting inside the ranges, three launches -- instead of the
  * O(n^2) single-launch sort or the three-pass LSD radix sort.  Keys at or above the limit are still sorted
  * correctly (they share the last range).  Identical results. */
@@ -358,7 +358,7 @@ int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
  *   n_cur == 0: only the lookup + sort of the next batch (== ha_lookup_sort_pend_*);
  *   n_next == 0: only the apply + finish of the current batch.
  * grads / next_out must be 16-byte aligned.  The single launch needs rows that own their 128-byte lines
- * (width % 32 == 0, table 128-byte aligned) and batches of at most 12,288 ids (above that the bucket sort of the separate launches wins);
+ * (width % 32 == 0, table 128-byte aligned) and batches of at most 18,432 ids (above that the bucket sort of the separate launches wins);
  * anything else runs as the separate launches with the same results (nothing is registered then).
  * Should a hand-off wait ever exceed its bound (~0.1 s; never observed), word 9 (int64) of
  * plan_next's 256-byte header is set to 1 (ha_plan_handoff_timeout) instead of hanging the device. */

@@ -544,7 +544,7 @@ def test_sharded_checkpoint_round_trip_chunked(dev, tmp_path):
         emb.load(str(tmp_path / "short"))
 
 
-@pytest.mark.parametrize("n,limit,hi", [(12289, 33762577, 33762577), (20000, 1000, 1000), (26624, 33762577, 33762577),
+@pytest.mark.parametrize("n,limit,hi", [(18433, 33762577, 33762577), (20000, 1000, 1000), (26624, 33762577, 33762577),
                                         (36864, 1 << 20, 1 << 20), (40000, 5000, 9000), (106496, 33762577, 33762577),
                                         (262144, 1 << 31, 1 << 31), (262145, 33762577, 33762577), (30000, 7, 1)])
 def test_bucket_sort_path_with_key_limit(dev, n, limit, hi):

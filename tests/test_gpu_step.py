@@ -70,6 +70,18 @@ def test_push_pull_sequence_bit_exact(dev, width, rows, n):
     _run_sequence(dev, table0, batches, grads, 0.05)
 
 
+def test_push_pull_largest_single_launch_batches(dev):
+    """16,640 and 18,432 ids per batch: the upper end of the single-launch regime (rank-by-counting tiles)."""
+    rng = np.random.default_rng(44)
+    rows, width = 90000, 64
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    for n in (16640, 18432):
+        batches = [rng.integers(0, rows, size=n) if k % 2 else np.minimum(rng.zipf(1.2, size=n) - 1, rows - 1)
+                   for k in range(4)]
+        grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(4)]
+        _run_sequence(dev, table0, batches, grads, 0.05)
+
+
 def test_push_pull_unaligned_table_takes_the_separate_launches(dev):
     """A table that does not start on a 128-byte line cannot use the in-launch hand-off: same results."""
     rng = np.random.default_rng(12)

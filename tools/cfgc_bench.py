@@ -54,3 +54,58 @@ def step1():
 t = timeit(step1, reps=50)
 print("one-launch step %.1f us  -> %.1f M rows/s   (time-outs: %s %s)" % (t, n / t, plans[0].handoff_timed_out(),
                                                                          plans[1].handoff_timed_out()))
+
+# ---- the sort of batch k+1 on a second stream beside gather(k) + apply(k): a graph of NB steps --------------
+main_s, side_s = torch.cuda.Stream(), torch.cuda.Stream()
+pl = [ops.IndexPlan(n, dev) for _ in range(2)]
+NG = 16
+def pipelined_graph():
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(main_s):
+        pl[0].sort(ids[0], key_limit=rows, stream=main_s)          # prologue (eager): plan of batch 0
+        main_s.synchronize()
+        with torch.cuda.graph(g, stream=main_s):
+            for k in range(NG):
+                # side stream: sort batch k+1 into the other plan (free since apply(k-1) finished on main)
+                side_s.wait_stream(main_s)
+                with torch.cuda.stream(side_s):
+                    pl[(k + 1) % 2].sort(ids[(k + 1) % NB], key_limit=rows, stream=side_s)
+                ops.embedding_lookup(table, ids[k % NB], out=out, stream=main_s)
+                ops.sgd_apply_finish(table, pl[k % 2], grads, 1e-6, stream=main_s)
+                main_s.wait_stream(side_s)
+    return g
+def time_graph(g, reps=10):
+    with torch.cuda.stream(main_s):
+        g.replay(); main_s.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(main_s)
+        for _ in range(reps):
+            g.replay()
+        b.record(main_s); main_s.synchronize()
+    return a.elapsed_time(b) * 1e3 / (reps * NG)
+try:
+    t = time_graph(pipelined_graph())
+    print("two streams (sort of batch k+1 beside gather + apply of batch k) %.1f us  -> %.1f M rows/s" % (t, n / t))
+except Exception as e:   # noqa
+    print("two-stream schedule failed:", e)
+
+# the same schedule launched eagerly (are the graph's parallel branches really concurrent?)
+def eager_two_streams(steps=200):
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    with torch.cuda.stream(main_s):
+        pl[0].sort(ids[0], key_limit=rows, stream=main_s)
+    main_s.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(main_s)
+    for k in range(steps):
+        side_s.wait_stream(main_s)
+        pl[(k + 1) % 2].sort(ids[(k + 1) % NB], key_limit=rows, stream=side_s)
+        ops.embedding_lookup(table, ids[k % NB], out=out, stream=main_s)
+        ops.sgd_apply_finish(table, pl[k % 2], grads, 1e-6, stream=main_s)
+        main_s.wait_stream(side_s)
+    b.record(main_s)
+    main_s.synchronize()
+    return a.elapsed_time(b) * 1e3 / steps
+eager_two_streams(20)
+t = eager_two_streams()
+print("two streams, eager launches %.1f us  -> %.1f M rows/s" % (t, n / t))
