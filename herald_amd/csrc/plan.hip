@@ -35,19 +35,19 @@ __global__ __launch_bounds__(1024) void plan_rank_small_kernel(
 // ===========================================================================
 // per-block digit histogram; hist[d * nblk + blk] (digit-major: the flat exclusive scan of the large
 // path orders it) or hist[blk * kRadixBuckets + d] (tile-major: coalesced for the fused scatter)
-__global__ __launch_bounds__(256) void radix_hist_kernel(
+__global__ __launch_bounds__(1024) void radix_hist_kernel(
     const uint32_t *__restrict__ keys, int n, int shift, int nblk,
     uint32_t *__restrict__ hist, int tile_major) {
     __shared__ uint32_t s_h[kRadixBuckets];
-    for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
+    for (int d = threadIdx.x; d < kRadixBuckets; d += 1024)
         s_h[d] = 0;
     __syncthreads();
     const int base = blockIdx.x * kRadixTile;
     const int end = min(n, base + kRadixTile);
-    for (int j = base + threadIdx.x; j < end; j += 256)
+    for (int j = base + threadIdx.x; j < end; j += 1024)
         atomicAdd(&s_h[(keys[j] >> shift) & (kRadixBuckets - 1u)], 1u);
     __syncthreads();
-    for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
+    for (int d = threadIdx.x; d < kRadixBuckets; d += 1024)
         hist[tile_major ? blockIdx.x * kRadixBuckets + d : d * nblk + blockIdx.x] = s_h[d];
 }
 
@@ -89,26 +89,37 @@ __global__ __launch_bounds__(1024) void scan_exclusive_kernel(
 }
 
 // stable scatter of one digit pass (kRadixBits = 11: three passes sort any 32-bit key, two sort 22
-// bits).  Each of the 4 waves owns a contiguous quarter of the tile and walks it in rows of 64 keys;
-// within a row, lanes with equal digits are ranked by a ballot match (11 ballots), the per-wave running
-// digit counters live in LDS (4 x 2048 words).  PRESCANNED = false (up to kRadixFusedBlocks tiles):
-// the block derives its own global digit bases from the raw per-block histograms -- every thread sums
-// eight digits over all tiles, one block scan orders the digits -- so a pass is two launches
-// (histogram, scatter) instead of three.  PRESCANNED = true: `hist` was scanned by scan_exclusive_kernel.
+// bits).  One 1024-thread workgroup per tile of 4,096 keys: each of the 16 waves owns a contiguous 256 keys
+// and walks them in four rows of 64; within a row, lanes with equal digits are ranked by a ballot match (11
+// ballots), the per-wave running digit counters live in LDS as 16-bit words (16 x 2048: a wave sees at most
+// 256 keys).  Position of a key = global base of its digit in this tile (s_base) + keys of the digit in the
+// tile's earlier waves (the counters after an exclusive prefix over the waves) + its rank inside the wave.
+// PRESCANNED = false (up to kRadixFusedBlocks tiles): the block derives its own global digit bases from the
+// raw per-block histograms -- every thread sums two digits over all tiles, one block scan orders the digits --
+// so a pass is two launches (histogram, scatter) instead of three.  PRESCANNED = true: `hist` was scanned by
+// scan_exclusive_kernel.  (256-thread blocks with sixteen rows per wave, the first version: 12.7 us per pass at
+// 106,496 keys -- 26 blocks of four waves are a latency chain, not a throughput problem.)
+constexpr int kScatterThreads = 1024;
+constexpr int kScatterWaves = kScatterThreads / kWave;
+constexpr size_t kScatterLdsBytes =
+    static_cast<size_t>(kScatterWaves) * kRadixBuckets * 2 + 3 * kRadixBuckets * 4 + kScatterWaves * 4;
+
 template <bool PRESCANNED, bool MSD = false>
-__global__ __launch_bounds__(256) void radix_scatter_kernel(
+__global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ perm_in,
     int n, int shift, int nblk, const uint32_t *__restrict__ hist,
     uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out,
     uint32_t *__restrict__ bucket_start = nullptr) {
-    constexpr int kRows = kRadixTile / 256;  // rows of 64 keys per wave
-    constexpr int kPerThread = kRadixBuckets / 256;
-    __shared__ uint32_t s_cnt[4][kRadixBuckets];
-    __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_tot[PRESCANNED ? 1 : kRadixBuckets], s_mine[PRESCANNED ? 1 : kRadixBuckets];
+    constexpr int kRows = kRadixTile / kScatterThreads;        // rows of 64 keys per wave
+    constexpr int kPerThread = kRadixBuckets / kScatterThreads;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    uint16_t *s_cnt = reinterpret_cast<uint16_t *>(s_dyn);                 // [waves][kRadixBuckets]
+    uint32_t *s_base = s_dyn + kScatterWaves * kRadixBuckets / 2;          // [kRadixBuckets]
+    uint32_t *s_tot = s_base + kRadixBuckets, *s_mine = s_tot + kRadixBuckets;
+    uint32_t *s_scan = s_mine + kRadixBuckets;                             // [waves]
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    for (int k = threadIdx.x; k < 4 * kRadixBuckets; k += 256)
-        (&s_cnt[0][0])[k] = 0;
+    for (int k = threadIdx.x; k < kScatterWaves * kRadixBuckets / 2; k += kScatterThreads)
+        s_dyn[k] = 0;
     __syncthreads();
 
     const int wbase = blockIdx.x * kRadixTile + w * (kRows * 64);
@@ -116,6 +127,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
     int32_t val[kRows];
     uint32_t lrank[kRows];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint16_t *my_cnt = s_cnt + w * kRadixBuckets;
     // all keys / values of the wave's rows first (branch-free, one batch of loads), then the ranking
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
@@ -138,19 +150,18 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
         const uint32_t before = __popcll(m & lt_mask);
         const uint32_t cnt = __popcll(m);
         uint32_t basec = 0;
-        if (ok) {
-            basec = s_cnt[w][d];
-        }
+        if (ok)
+            basec = my_cnt[d];
         lrank[r] = basec + before;
         // all lanes of the group have read basec before the leader bumps it
         __builtin_amdgcn_wave_barrier();
         if (ok && before == 0)
-            s_cnt[w][d] = basec + cnt;
+            my_cnt[d] = static_cast<uint16_t>(basec + cnt);
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // digits d = threadIdx.x * kPerThread ..: global base of the digit in this tile, then the exclusive
-    // prefix over the 4 waves
+    // prefix over the waves
     {
         uint32_t run[kPerThread];
         const int d0 = threadIdx.x * kPerThread;
@@ -159,23 +170,23 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
             for (int q = 0; q < kPerThread; ++q)
                 run[q] = hist[(d0 + q) * nblk + blockIdx.x];
         } else {
-            // coalesced pass over the tile-major histograms (thread t sums digits t, t+256, ...), then
-            // through LDS to the thread that owns eight consecutive digits
+            // coalesced pass over the tile-major histograms (thread t sums digits t, t+1024), then
+            // through LDS to the thread that owns consecutive digits
             uint32_t tot[kPerThread], mine[kPerThread];
 #pragma unroll
             for (int q = 0; q < kPerThread; ++q)
                 tot[q] = mine[q] = 0;
-            for (int k0 = 0; k0 < nblk; k0 += 4) {   // four tiles per trip: 32 independent loads in flight
-                uint32_t v[4][kPerThread];
+            for (int k0 = 0; k0 < nblk; k0 += 8) {   // eight tiles per trip: 16 independent loads in flight
+                uint32_t v[8][kPerThread];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int kk = 0; kk < 8; ++kk) {
                     const uint32_t *h = hist + static_cast<size_t>(min(k0 + kk, nblk - 1)) * kRadixBuckets + threadIdx.x;
 #pragma unroll
                     for (int q = 0; q < kPerThread; ++q)
-                        v[kk][q] = h[q * 256];
+                        v[kk][q] = h[q * kScatterThreads];
                 }
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int kk = 0; kk < 8; ++kk) {
                     const int k = k0 + kk;
 #pragma unroll
                     for (int q = 0; q < kPerThread; ++q) {
@@ -186,8 +197,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
             }
 #pragma unroll
             for (int q = 0; q < kPerThread; ++q) {
-                s_tot[q * 256 + threadIdx.x] = tot[q];
-                s_mine[q * 256 + threadIdx.x] = mine[q];
+                s_tot[q * kScatterThreads + threadIdx.x] = tot[q];
+                s_mine[q * kScatterThreads + threadIdx.x] = mine[q];
             }
             __syncthreads();
 #pragma unroll
@@ -219,17 +230,18 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
                 run[q] = off + mine[q];
                 off += tot[q];
             }
-            if (MSD && blockIdx.x == 0 && threadIdx.x == 255)
+            if (MSD && blockIdx.x == 0 && threadIdx.x == kScatterThreads - 1)
                 bucket_start[kRadixBuckets] = off;
         }
 #pragma unroll
         for (int q = 0; q < kPerThread; ++q) {
-            uint32_t r = run[q];
+            s_base[d0 + q] = run[q];
+            uint32_t acc = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t c = s_cnt[k][d0 + q];
-                s_cnt[k][d0 + q] = r;
-                r += c;
+            for (int k = 0; k < kScatterWaves; ++k) {
+                const uint32_t c = s_cnt[k * kRadixBuckets + d0 + q];
+                s_cnt[k * kRadixBuckets + d0 + q] = static_cast<uint16_t>(acc);
+                acc += c;
             }
         }
     }
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(
         const int j = wbase + r * 64 + lane;
         if (j < n) {
             const uint32_t d = radix_digit(key[r], shift, MSD);
-            const uint32_t pos = s_cnt[w][d] + lrank[r];
+            const uint32_t pos = s_base[d] + my_cnt[d] + lrank[r];
             keys_out[pos] = key[r];
             perm_out[pos] = val[r];
         }
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(1024) void finish_chunked_kernel(
 }
 
 template <typename IdT>
-__global__ __launch_bounds__(256) void radix_first_kernel(
+__global__ __launch_bounds__(1024) void radix_first_kernel(
     const IdT *__restrict__ ids, int n, int nblk, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ hist, int tile_major, int shift, int msd) {
     __shared__ uint32_t s_h[kRadixBuckets];
@@ -491,7 +503,7 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
         key_limit = 1ull << key_bits;
     if (bucket_sort_applies(n, key_limit)) {
         const int shift = bucket_shift(key_limit);
-        hipLaunchKernelGGL(radix_first_kernel<IdT>, dim3(radix_tiles(n)), dim3(256), 0, stream, ids, ni,
+        hipLaunchKernelGGL(radix_first_kernel<IdT>, dim3(radix_tiles(n)), dim3(1024), 0, stream, ids, ni,
                            radix_tiles(n), p.keys, p.hist, 1, shift, 1);
         HA_LAUNCH_CHECK();
         return plan_bucket_sort(ws, n, shift, sort_only, stream);
@@ -510,7 +522,7 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
         return 0;
     }
     // ---- radix path: conversion + first histogram in one launch, then the passes
-    hipLaunchKernelGGL(radix_first_kernel<IdT>, dim3(radix_tiles(n)), dim3(256), 0, stream, ids, ni,
+    hipLaunchKernelGGL(radix_first_kernel<IdT>, dim3(radix_tiles(n)), dim3(1024), 0, stream, ids, ni,
                        radix_tiles(n), p.keys, p.hist, radix_tile_major(n), 0, 0);
     HA_LAUNCH_CHECK();
     return plan_radix_sort(ws, n, key_bits, sort_only, stream);
@@ -520,7 +532,21 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
 
 // keys[] and the pass-0 histograms are in place (radix_first_tile_body); runs the scatter of pass 0, the
 // remaining passes and, unless sort_only, the finish
+static int scatter_allow_lds() {
+    using namespace ha;
+    static bool done = false;   // once, and outside any stream capture (the first call is eager)
+    if (!done) {
+        HA_ALLOW_LDS((radix_scatter_kernel<false, false>), kScatterLdsBytes);
+        HA_ALLOW_LDS((radix_scatter_kernel<true, false>), kScatterLdsBytes);
+        HA_ALLOW_LDS((radix_scatter_kernel<false, true>), kScatterLdsBytes);
+        done = true;
+    }
+    return 0;
+}
+
 int ha::plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipStream_t stream) {
+    if (scatter_allow_lds())
+        return -1;
     PlanPtrs p = plan_layout(ws, n);
     const int ni = static_cast<int>(n);
     const int nblk = radix_tiles(n);
@@ -540,18 +566,18 @@ int ha::plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipSt
         int32_t *vout = toB ? p.perm : p.perm_alt;
         const int shift = pass * kRadixBits;
         if (pass > 0) {
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, stream,
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(1024), 0, stream,
                                kin, ni, shift, nblk, p.hist, nblk <= kRadixFusedBlocks ? 1 : 0);
             HA_LAUNCH_CHECK();
         }
         if (nblk <= kRadixFusedBlocks) {
-            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(256), 0,
+            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(kScatterThreads), kScatterLdsBytes,
                                stream, kin, vin, ni, shift, nblk, p.hist, kout, vout);
         } else {
             hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream,
                                p.hist, kRadixBuckets * nblk, static_cast<uint32_t *>(nullptr));
             HA_LAUNCH_CHECK();
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblk), dim3(256), 0,
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblk), dim3(kScatterThreads), kScatterLdsBytes,
                                stream, kin, vin, ni, shift, nblk, p.hist, kout, vout);
         }
         HA_LAUNCH_CHECK();
@@ -566,10 +592,12 @@ int ha::plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipSt
 // keys[] and the tile-major histograms of the most significant digit are in place: scatter, then rank inside
 // the buckets; unless sort_only, the finish
 int ha::plan_bucket_sort(void *ws, int64_t n, int shift, bool sort_only, hipStream_t stream) {
+    if (scatter_allow_lds())
+        return -1;
     PlanPtrs p = plan_layout(ws, n);
     const int ni = static_cast<int>(n);
     const int nblk = radix_tiles(n);
-    hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(nblk), dim3(256), 0, stream, p.keys,
+    hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(nblk), dim3(kScatterThreads), kScatterLdsBytes, stream, p.keys,
                        static_cast<const int32_t *>(nullptr), ni, shift, nblk, p.hist, p.keys_alt, p.perm_alt,
                        p.bucket_start);
     hipLaunchKernelGGL(bucket_rank_kernel, dim3((ni + kRankTile - 1) / kRankTile), dim3(1024), 0, stream,

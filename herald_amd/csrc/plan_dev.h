@@ -100,18 +100,19 @@ __device__ __forceinline__ void radix_first_tile_body(const IdT *__restrict__ id
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ hist,
                                                       int tile_major, uint32_t *s_h /* kRadixBuckets words */,
                                                       int shift = 0, bool msd = false) {
-    for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
+    const int nt = blockDim.x;   // 256 beside gather blocks (fused.hip), 1024 alone
+    for (int d = threadIdx.x; d < kRadixBuckets; d += nt)
         s_h[d] = 0;
     __syncthreads();
     const int base = tile * kRadixTile;
     const int end = min(n, base + kRadixTile);
-    for (int j = base + threadIdx.x; j < end; j += 256) {
+    for (int j = base + threadIdx.x; j < end; j += nt) {
         const uint32_t k = to_key<IdT>(ids[j]);
         keys[j] = k;
         atomicAdd(&s_h[radix_digit(k, shift, msd)], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < kRadixBuckets; d += 256)
+    for (int d = threadIdx.x; d < kRadixBuckets; d += nt)
         hist[tile_major ? tile * kRadixBuckets + d : d * nblk + tile] = s_h[d];
 }
 
