@@ -45,6 +45,8 @@ def parse_args():
     p.add_argument("--no-kernel-pass", action="store_true")
     p.add_argument("--no-cache-tier", action="store_true",
                    help="skip the secondary measurement of the LRU cache tier (limit 0.1 x rows)")
+    p.add_argument("--no-laia", action="store_true",
+                   help="skip the secondary measurement of the laia scheduler (configs[3] shape)")
     p.add_argument("--no-cold-tier", action="store_true",
                    help="skip the secondary measurement of the host-DRAM cold tier (BASELINE configs[4] shape)")
     p.add_argument("--cold-rows", type=int, default=33554432,
@@ -229,6 +231,29 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
             "limit_rows": limit, "bound": 100, "steps": steps, "unique_miss_rate": miss,
             "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
                     "(10 launches per pair, replayed from hipGraphs of 16 pairs); not part of `value`"}
+
+
+def laia_scheduler(args):
+    """Secondary measurement (scheduler us per 4096-sample global batch, configs[3] shape): the laia
+    LaiaScheduler for 4 workers x mini batch 1024, 26 tables over the full key space, cache_size = 0.1 x rows;
+    GPU probing / plan extraction and the host's greedy assignment + MiniLRU snapshots reported separately."""
+    from herald_amd import laia as hlaia, synth
+    W, mini_bs, T, batch_num = 4, 1024, args.fields, 8
+    per = 256
+    need = W * mini_bs * batch_num + 1000
+    parts = [synth.criteo_batch(per, step=5000 + s, rows=args.rows, nfields=T) for s in range((need + per - 1) // per)]
+    samples = np.concatenate(parts, axis=0)[:need].astype(np.uint64)
+    s = hlaia.LaiaScheduler()
+    s.start(samples, samples.shape[0], T, 1, mini_bs, batch_num, W, 0, int(0.1 * args.rows), 16, 24, key_limit=args.rows)
+    while s.pop() != [0]:
+        pass
+    tm = s.timing()
+    s.close()
+    return {"us_per_global_batch": tm["us_per_batch"], "global_batch_samples": W * mini_bs, "workers": W,
+            "tables": T, "cache_size": int(0.1 * args.rows), "batches": tm["batches"],
+            "host_assign_us": tm["host_assign_us"], "host_snapshot_us": tm["host_snapshot_us"],
+            "gpu_and_transfer_us": tm["gpu_and_transfer_us"],
+            "note": "the scheduler runs ahead of training in its own thread; not part of `value`"}
 
 
 def cold_tier(args, dev):
@@ -532,6 +557,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, ids_host)
     if not args.no_cache_tier:
         result["cache_tier"] = cache_tier(args, table, ids_dev, outs[0], grads[0], dev)
+    if not args.no_laia:
+        result["laia_scheduler"] = laia_scheduler(args)
     if not args.no_cold_tier:
         del table
         torch.cuda.empty_cache()

@@ -19,8 +19,13 @@
 // The emitted (plan, dist) sequence is bit-identical to the reference's.
 #include "plan_dev.h"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -28,40 +33,92 @@
 namespace ha {
 
 // ---- host-side snapshot: the semantics of MiniLRUCache (hash mode) ---------------------------------
-struct Snapshot {
+// The reference keeps a linked list in use order (mini_lru_cache.h: splice to the front on every get, evict
+// from the back).  Every touch of a list costs four to five dependent random host-memory accesses (the
+// node, both neighbours, the head).  Here -- like the GPU cache's LRU (cache.hip) -- a touch stamps the node with a
+// monotone counter and appends (node, stamp) to a ring log; the list order IS the stamp order, an entry is
+// stale once its node was touched again or left the snapshot, and the eviction victim is the first live
+// entry from the log's head.  One random access per touch (the node) besides the key map, the log is
+// sequential; each entry is looked at once more when the head passes it.
+struct alignas(128) Snapshot {   // one worker thread per snapshot: keep their hot fields in different cache lines
+    struct Node {
+        uint32_t stamp;   // 0 = not resident
+        int32_t key;
+        uint8_t valid;
+    };
+    struct Entry {
+        int32_t node;
+        uint32_t stamp;
+    };
     int cap = 0;
     // key -> node: a direct map over the row range where that fits in memory (one load per probe, like the
     // device-side validity bytes), a hash map for very large key spaces
     bool direct = false;
-    std::vector<int32_t> dmap;
+    int32_t *dmap = nullptr;      // mmap'ed, transparent huge pages requested: 135 MB of random probes per worker
+    size_t dmap_len = 0;
     std::unordered_map<int32_t, int> hmap;
     size_t live = 0;
-    std::vector<int> prev, next;
-    std::vector<int32_t> key;
-    std::vector<uint8_t> valid;
+    std::vector<Node> node;
     std::vector<int> free_nodes;
-    int front = -1, back = -1;
+    std::vector<Entry> log;       // ring
+    size_t log_head = 0, log_size = 0;
+    uint32_t counter = 0;
 
     void init(int capacity, long long key_range, bool use_direct) {
         cap = capacity;
         const int n = capacity + 2;
-        prev.assign(n, -1);
-        next.assign(n, -1);
-        key.assign(n, 0);
-        valid.assign(n, 0);
+        node.assign(n, Node{0u, 0, 0});
         free_nodes.clear();
         for (int i = n - 1; i >= 0; --i)
             free_nodes.push_back(i);
+        size_t lg = 1;
+        while (lg < static_cast<size_t>(n) * 4)
+            lg <<= 1;
+        log.assign(lg, Entry{0, 0u});
+        log_head = log_size = 0;
+        counter = 0;
         direct = use_direct;
         hmap.clear();
-        dmap.clear();
-        if (direct)
-            dmap.assign(static_cast<size_t>(key_range), -1);
-        else
+        release();
+        if (direct) {
+            dmap_len = static_cast<size_t>(key_range);
+            const size_t bytes = (dmap_len * sizeof(int32_t) + (2u << 20) - 1) & ~((size_t(2) << 20) - 1);
+            void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m == MAP_FAILED) {
+                direct = false;     // fall back to the hash map
+                dmap_len = 0;
+            } else {
+                madvise(m, bytes, MADV_HUGEPAGE);
+                dmap = static_cast<int32_t *>(m);
+                memset(dmap, 0xFF, dmap_len * sizeof(int32_t));   // -1 = absent
+            }
+        }
+        if (!direct)
             hmap.reserve(static_cast<size_t>(capacity) * 3);  // set_cap, mini_lru_cache.h:49-52
         live = 0;
-        front = back = -1;
     }
+    void release() {
+        if (dmap != nullptr) {
+            munmap(dmap, (dmap_len * sizeof(int32_t) + (2u << 20) - 1) & ~((size_t(2) << 20) - 1));
+            dmap = nullptr;
+            dmap_len = 0;
+        }
+    }
+    Snapshot() = default;
+    Snapshot(const Snapshot &) = delete;
+    Snapshot &operator=(const Snapshot &) = delete;
+    Snapshot(Snapshot &&o) noexcept { *this = std::move(o); }
+    Snapshot &operator=(Snapshot &&o) noexcept {
+        if (this != &o) {
+            release();
+            cap = o.cap; direct = o.direct; dmap = o.dmap; dmap_len = o.dmap_len; hmap = std::move(o.hmap);
+            live = o.live; node = std::move(o.node); free_nodes = std::move(o.free_nodes); log = std::move(o.log);
+            log_head = o.log_head; log_size = o.log_size; counter = o.counter;
+            o.dmap = nullptr; o.dmap_len = 0;
+        }
+        return *this;
+    }
+    ~Snapshot() { release(); }
     int find(int32_t k) const {
         if (direct)
             return dmap[static_cast<size_t>(k)];
@@ -85,58 +142,94 @@ struct Snapshot {
     // validity of key k as the device mirror must show it
     uint8_t state(int32_t k) const {
         const int x = find(k);
-        return x >= 0 && valid[x] ? 1 : 0;
+        return x >= 0 && node[x].valid ? 1 : 0;
     }
-    void unlink(int x) {
-        if (prev[x] >= 0) next[prev[x]] = next[x]; else front = next[x];
-        if (next[x] >= 0) prev[next[x]] = prev[x]; else back = prev[x];
+    // drop the stale entries (in place, order kept) when the ring is full
+    void compact() {
+        const size_t mask = log.size() - 1;
+        size_t w = 0;
+        for (size_t i = 0; i < log_size; ++i) {
+            const Entry e = log[(log_head + i) & mask];
+            if (node[e.node].stamp == e.stamp) {
+                log[(log_head + w) & mask] = e;
+                ++w;
+            }
+        }
+        log_size = w;
     }
-    void push_front(int x) {
-        prev[x] = -1;
-        next[x] = front;
-        if (front >= 0) prev[front] = x;
-        front = x;
-        if (back < 0) back = x;
+    void renumber() {   // the 32-bit counter wrapped: restamp the live entries 1, 2, ... in order
+        compact();
+        const size_t mask = log.size() - 1;
+        for (size_t i = 0; i < log_size; ++i) {
+            Entry &e = log[(log_head + i) & mask];
+            e.stamp = static_cast<uint32_t>(i + 1);
+            node[e.node].stamp = e.stamp;
+        }
+        counter = static_cast<uint32_t>(log_size);
+    }
+    void touch(int x) {   // move to the front of the use order
+        if (counter == 0xFFFFFFFFu)
+            renumber();
+        if (log_size == log.size())
+            compact();      // live entries <= cap + 1 < log.size() / 4: always room afterwards
+        node[x].stamp = ++counter;
+        log[(log_head + log_size) & (log.size() - 1)] = Entry{x, counter};
+        ++log_size;
+    }
+    int pop_back() {      // the least recently used resident node
+        const size_t mask = log.size() - 1;
+        for (;;) {
+            const Entry e = log[log_head];
+            log_head = (log_head + 1) & mask;
+            --log_size;
+            if (node[e.node].stamp == e.stamp)
+                return e.node;
+        }
     }
     // touched: keys whose validity byte may have changed (the caller mirrors state(k) on the device;
     // a key listed twice is written twice with the same final value)
     void outdate(int32_t k, std::vector<int32_t> &touched) {
         const int x = find(k);
-        if (x >= 0 && valid[x]) {
-            valid[x] = 0;
+        if (x >= 0 && node[x].valid) {
+            node[x].valid = 0;
             touched.push_back(k);
         }
     }
     int get(int32_t k, std::vector<int32_t> &touched) {
         int x = find(k);
         if (x >= 0) {
-            const int res = valid[x] ? -1 : -2;
-            unlink(x);
-            push_front(x);
-            if (!valid[x]) {
-                valid[x] = 1;
+            const int res = node[x].valid ? -1 : -2;
+            touch(x);
+            if (!node[x].valid) {
+                node[x].valid = 1;
                 touched.push_back(k);
             }
             return res;
         }
         x = free_nodes.back();
         free_nodes.pop_back();
-        key[x] = k;
-        valid[x] = 1;
-        push_front(x);
+        node[x].key = k;
+        node[x].valid = 1;
+        touch(x);
         bind(k, x);
         touched.push_back(k);
         if (static_cast<long long>(live) > cap) {
-            const int e = back;
-            const bool flag = valid[e] != 0;
-            unlink(e);
-            unbind(key[e]);
+            const int e = pop_back();
+            const bool flag = node[e].valid != 0;
+            node[e].stamp = 0;
+            unbind(node[e].key);
             if (flag)
-                touched.push_back(key[e]);
+                touched.push_back(node[e].key);
             free_nodes.push_back(e);
             return flag ? 1 : 0;
         }
         return 0;
+    }
+    // valid resident keys (any order)
+    void valid_keys(std::vector<int32_t> &out) const {
+        for (const Node &nd : node)
+            if (nd.stamp != 0 && nd.valid)
+                out.push_back(nd.key);
     }
 };
 
@@ -237,7 +330,76 @@ __global__ __launch_bounds__(256) void laia_delta_kernel(const uint32_t *__restr
         valid[dkeys[e]] = dvals[e];
 }
 
+// A few persistent host threads for the per-worker snapshot updates (creating std::threads per batch costs
+// ~200 us, the update itself ~150 us per worker).  run(n, f): f(1) .. f(n-1) on the pool, f(0) on the caller.
+struct SnapshotPool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job;
+    unsigned long long gen = 0;
+    int njobs = 0, pending = 0;
+    bool stop = false;
+
+    void ensure(int n) {
+        while (static_cast<int>(threads.size()) < n) {
+            const int id = static_cast<int>(threads.size()) + 1;
+            threads.emplace_back([this, id] {
+                unsigned long long seen = 0;
+                for (;;) {
+                    std::function<void(int)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_go.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop)
+                            return;
+                        seen = gen;
+                        if (id >= njobs)
+                            continue;
+                        f = job;
+                    }
+                    f(id);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0)
+                            cv_done.notify_one();
+                    }
+                }
+            });
+        }
+    }
+    void run(int n, const std::function<void(int)> &f) {
+        if (n <= 1) {
+            if (n == 1)
+                f(0);
+            return;
+        }
+        ensure(n - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = f;
+            njobs = n;
+            pending = n - 1;
+            ++gen;
+        }
+        cv_go.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~SnapshotPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto &t : threads)
+            t.join();
+    }
+};
+
 struct Laia {
+    SnapshotPool pool;
     long long S = 0, R = 0;
     int T = 0, W = 0, cache_size = 0;
     std::vector<uint64_t> samples_host;
@@ -542,52 +704,59 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
             tk0[W] = tk;
         }
         std::vector<std::vector<int32_t>> touched(W);
+        std::vector<std::vector<uint8_t>> tstate(W);
         auto work = [&](int w) {
             const unsigned long long base = static_cast<unsigned long long>(w) * l.R;
-            std::vector<int32_t> &td = touched[w];
+            std::vector<int32_t> td;     // thread-local (the shared vectors' headers are neighbours in memory)
             td.reserve((pk0[w + 1] - pk0[w]) + 2 * (tk0[w + 1] - tk0[w]));
             for (size_t pk = pk0[w]; pk < pk0[w + 1]; ++pk)
                 l.snaps[w].outdate(static_cast<int32_t>(plan_keys[pk] - base), td);
+
             l.update_push[w] += static_cast<long long>(pk0[w + 1] - pk0[w]);
+            // per-thread counters, written back once: the workers' slots of the shared arrays sit in one cache
+            // line, and bumping them per key made the four threads fight over it (300+ ns per key)
+            long long c_update_pull = 0, c_miss_pull = 0, c_miss_push = 0;
             for (size_t tk = tk0[w]; tk < tk0[w + 1]; ++tk) {
                 // the direct map and the list nodes are random host-memory accesses: look a few keys ahead
                 if (l.snaps[w].direct && tk + 16 < tk0[w + 1])
                     __builtin_prefetch(&l.snaps[w].dmap[touch_keys[tk + 16] - base]);
                 if (l.snaps[w].direct && tk + 4 < tk0[w + 1]) {
                     const int x = l.snaps[w].dmap[touch_keys[tk + 4] - base];
-                    if (x >= 0) {
-                        __builtin_prefetch(&l.snaps[w].prev[x]);
-                        __builtin_prefetch(&l.snaps[w].next[x]);
-                        __builtin_prefetch(&l.snaps[w].valid[x]);
-                    }
+                    if (x >= 0)
+                        __builtin_prefetch(&l.snaps[w].node[x]);
                 }
                 const int res = l.snaps[w].get(static_cast<int32_t>(touch_keys[tk] - base), td);
                 if (res < 0) {  // traffic counters, topk_scheduler.cc:319-331
                     if (res == -2)
-                        l.update_pull[w] += 1;
+                        c_update_pull += 1;
                 } else {
-                    l.miss_pull[w] += 1;
+                    c_miss_pull += 1;
                     if (res > 0)
-                        l.miss_push[w] += 1;
+                        c_miss_push += 1;
                 }
             }
+            l.update_pull[w] += c_update_pull;
+            l.miss_pull[w] += c_miss_pull;
+            l.miss_push[w] += c_miss_push;
+            // the final validity of every key whose byte may have changed, looked up here (in the worker's own
+            // thread, while its nodes are warm) rather than by the merging thread
+            std::vector<uint8_t> ts(td.size());
+            for (size_t i = 0; i < td.size(); ++i)
+                ts[i] = l.snaps[w].state(td[i]);
+            touched[w] = std::move(td);
+            tstate[w] = std::move(ts);
         };
         if (W > 1 && touch_keys.size() > 4096) {
-            std::vector<std::thread> pool;
-            for (int w = 1; w < W; ++w)
-                pool.emplace_back(work, w);
-            work(0);
-            for (auto &t : pool)
-                t.join();
+            l.pool.run(W, work);
         } else {
             for (int w = 0; w < W; ++w)
                 work(w);
         }
         for (int w = 0; w < W; ++w) {
             const unsigned long long base = static_cast<unsigned long long>(w) * l.R;
-            for (int32_t k : touched[w]) {
-                dkeys.push_back(static_cast<uint32_t>(base + static_cast<uint32_t>(k)));
-                dvals.push_back(l.snaps[w].state(k));
+            for (size_t i = 0; i < touched[w].size(); ++i) {
+                dkeys.push_back(static_cast<uint32_t>(base + static_cast<uint32_t>(touched[w][i])));
+                dvals.push_back(tstate[w][i]);
             }
         }
     }
@@ -650,9 +819,7 @@ extern "C" int64_t ha_laia_snapshot_keys(ha_laia *h, int64_t w, int32_t *out, in
         return -1;
     Snapshot &s = h->l.snaps[static_cast<size_t>(w)];
     std::vector<int32_t> keys;
-    for (int x = s.front; x >= 0; x = s.next[x])   // every resident node is on the list
-        if (s.valid[x])
-            keys.push_back(s.key[x]);
+    s.valid_keys(keys);
     std::sort(keys.begin(), keys.end());
     for (size_t i = 0; i < keys.size() && static_cast<int64_t>(i) < cap; ++i)
         out[i] = keys[i];

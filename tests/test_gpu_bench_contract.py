@@ -49,7 +49,7 @@ def test_bench_short_driver_run_replays_graphs(dev):
     """The driver's `--steps 20 --warmup 5`: every timed step runs inside a hipGraph replay, the line
     reports the warm-up it was asked for and the launch mode it really used."""
     d = _run({}, "--rows", "1000000", "--steps", "20", "--warmup", "5", "--distinct-batches", "64",
-             "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier")
+             "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier", "--no-laia")
     assert d["steps"] == 20 and d["warmup"] == 5
     assert "hipGraph" in d["config"]["launch"] and d["config"]["launch"].startswith("1 ")
     assert d["config"]["grad_and_out_buffers"] >= 24
@@ -58,7 +58,7 @@ def test_bench_short_driver_run_replays_graphs(dev):
 
 def test_bench_two_launch_mode_still_reports_measured_kernel_times(dev):
     d = _run({}, "--rows", "1000000", "--steps", "64", "--warmup", "32", "--distinct-batches", "64", "--launches", "2",
-             "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier")
+             "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier", "--no-laia")
     assert d["config"]["launches_per_step"] == 2
     k = d["kernels"]
     assert all("measured_us" in v and v["measured_us"] > 0 for v in k.values()) and len(k) == 2
