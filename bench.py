@@ -269,7 +269,7 @@ def cold_tier(args, dev):
     c = hcache.LRUCache(limit, rows, width, node_id=-7, max_batch=n, device=dev)
     c.bind_remote(store)
     c.pull_bound = c.push_bound = 100
-    nb = 256
+    nb = 320     # 20 graphs of 16 batches: four replayed as warm-up, sixteen (not seen before) timed
     ids = [torch.from_numpy(synth.criteo_batch(bs, 9000 + b, rows=rows, nfields=fields).reshape(-1)).to(dev)
            for b in range(nb)]
     out = torch.empty((n, width), dtype=torch.float32, device=dev)
@@ -279,16 +279,33 @@ def cold_tier(args, dev):
         c.embedding_lookup(ids[k % nb], out)
         c.embedding_update(ids[k % nb], grad)
 
+    # Neither call reads anything back (the store is on this device: request and outbox are handed over padded),
+    # so the pairs are replayed from hipGraphs of 16 like the HBM cache tier's
+    GS = 16
+    side = torch.cuda.Stream(device=dev)
+    c.stream = side
     for k in range(128):
         step(k)
     torch.cuda.synchronize()
-    store.traffic(reset=True)
-    steps = 256
-    t0 = time.perf_counter()
-    for k in range(steps):
-        step(128 + k)
+    graphs = []
+    for g0 in range(0, nb, GS):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for k in range(g0, g0 + GS):
+                step(128 + k)
+        graphs.append(g)
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    steps = 256
+    with torch.cuda.stream(side):
+        for i in range(4):
+            graphs[i % len(graphs)].replay()
+        torch.cuda.synchronize()
+        store.traffic(reset=True)
+        t0 = time.perf_counter()
+        for i in range(steps // GS):
+            graphs[(4 + i) % len(graphs)].replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
     tr = store.traffic()
     return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps,
             "workload": "power-law ids, %d fields, bs=%d, d=%d; %d-row fp32 table (%.1f GiB) in pinned host DRAM; "
@@ -297,8 +314,8 @@ def cold_tier(args, dev):
             "hot_tier_hit_rate": 1.0 - tr["rows_pulled"] / max(tr["keys_synced"], 1),
             "rows_pulled_per_step": tr["rows_pulled"] / steps, "lines_pushed_per_step": tr["lines_pushed"] / steps,
             "pcie_GBps": tr["pcie_bytes"] / el / 1e9, "steps": steps,
-            "note": "lookup + update per batch through the remote-store protocol (request / inbox / outbox, two "
-                    "host read-backs per call); not part of `value`"}
+            "note": "lookup + update per batch through the remote-store protocol (request / inbox / outbox, handed "
+                    "over padded: no host read-back), replayed from hipGraphs of 16 pairs; not part of `value`"}
 
 
 def main():

@@ -187,6 +187,8 @@ def _declare(L):
         "ha_cache_lookup_begin": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_lookup_finish": [vp, i64, vp, vp],
         "ha_cache_outbox_count": [vp, vp, vp],
+        "ha_cache_outbox_pad": [vp, i64],
+        "ha_store_count_valid": [vp, i64, i64, vp, vp],
         "ha_cache_push_pull_begin": [vp, vp, c.c_int, i64, vp, c.c_int, i64, vp, vp, vp],
         "ha_cache_push_pull_finish": [vp, vp, vp],
         "ha_store_serve_sync": [vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp],

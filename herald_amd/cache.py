@@ -134,19 +134,33 @@ class _CacheBase:
             "out_rows": _dev_view(r.out_rows, (cap, w), torch.float32, dv),
         }
         self._remote = store
+        self._out_cap = cap
+        self._evict_bound = 0     # keys of the lookups since the last update: bounds their pending evictions
 
     def _sync_request(self, u):
         b = self._rb
         self._remote.sync(b["req_keys"][:u], b["req_ver"][:u], self._pull_bound, b["pull"][:u], b["idx"][:u],
                           b["ver"][:u], b["rows"])
 
-    def _push_outbox(self, s):
-        cnt = ctypes.c_int64(0)
-        check(self._L.ha_cache_outbox_count(self._h, ctypes.byref(cnt), ctypes.c_void_p(s.cuda_stream)),
-              "ha_cache_outbox_count")
-        m = int(cnt.value)
+    def _host_counts(self):
+        """Does the store size its work on the host (an exchange between ranks)?  Otherwise the request and the
+        outbox are handed over padded and no call of the step reads anything back (include/herald_amd.h)."""
+        return getattr(self._remote, "host_counts", True)
+
+    def _outbox_bound(self, n):
+        """Entries that bound U + E of an update of n keys: its own unique keys plus the evictions of every
+        lookup since the last update (each at most its number of keys); None: beyond the outbox, count on the host."""
+        m = n + self._evict_bound
+        return m if m <= self._out_cap else None
+
+    def _push_outbox(self, s, bound=None):
         b = self._rb
-        self._remote.push(b["out_keys"][:m], b["out_upd"][:m], b["out_rows"][:m])
+        if bound is None:
+            cnt = ctypes.c_int64(0)
+            check(self._L.ha_cache_outbox_count(self._h, ctypes.byref(cnt), ctypes.c_void_p(s.cuda_stream)),
+                  "ha_cache_outbox_count")
+            bound = int(cnt.value)
+        self._remote.push(b["out_keys"][:bound], b["out_upd"][:bound], b["out_rows"][:bound])
 
     def _lookup_remote(self, keys, dest):
         keep = []
@@ -158,10 +172,17 @@ class _CacheBase:
                 host_dest = dest
                 dest = torch.empty((k.numel(), self._width), dtype=torch.float32, device=self.device)
             assert dest.numel() == k.numel() * self._width and dest.dtype == torch.float32
-            u = ctypes.c_int64(0)
-            check(self._L.ha_cache_lookup_begin(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
-                                                ctypes.byref(u), ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup_begin")
-            self._sync_request(int(u.value))
+            if self._host_counts():
+                u = ctypes.c_int64(0)
+                check(self._L.ha_cache_lookup_begin(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
+                                                    ctypes.byref(u), ctypes.c_void_p(s.cuda_stream)),
+                      "ha_cache_lookup_begin")
+                self._sync_request(int(u.value))
+            else:       # the request is padded to the batch size: nothing to read back
+                check(self._L.ha_cache_lookup_begin(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(), None,
+                                                    ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup_begin")
+                self._sync_request(k.numel())
+            self._evict_bound += k.numel()
             check(self._L.ha_cache_lookup_finish(self._h, k.numel(), ctypes.c_void_p(dest.data_ptr()),
                                                  ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup_finish")
             self._last_lookup = None
@@ -179,6 +200,8 @@ class _CacheBase:
             k, kind = self._keys(keys, keep)
             g = self._grads(grads, keep)
             assert g.numel() == k.numel() * self._width
+            bound = None if self._host_counts() else self._outbox_bound(k.numel())
+            check(self._L.ha_cache_outbox_pad(self._h, bound or 0), "ha_cache_outbox_pad")
             if push_keys is None:
                 check(self._L.ha_cache_update(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
                                               ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
@@ -189,7 +212,8 @@ class _CacheBase:
                     self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(), ctypes.c_void_p(pk.data_ptr()), pkind,
                     pk.numel(), ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
                     "ha_cache_update_with_push_keys")
-            self._push_outbox(s)
+            self._push_outbox(s, bound)
+            self._evict_bound = 0
             if self.perf_enabled:
                 self._perf_record(1)
             return Wait(s, keep + [k, g])
@@ -202,13 +226,17 @@ class _CacheBase:
             sk, skind = self._keys(pushkeys, keep)
             g = self._grads(grads, keep)
             assert dest.is_cuda and dest.dtype == torch.float32 and dest.numel() == pk.numel() * self._width
+            hc = self._host_counts()
+            bound = None if hc else self._outbox_bound(sk.numel())
+            check(self._L.ha_cache_outbox_pad(self._h, bound or 0), "ha_cache_outbox_pad")
             u = ctypes.c_int64(0)
             check(self._L.ha_cache_push_pull_begin(self._h, ctypes.c_void_p(pk.data_ptr()), pkind, pk.numel(),
                                                    ctypes.c_void_p(sk.data_ptr()), skind, sk.numel(),
-                                                   ctypes.c_void_p(g.data_ptr()), ctypes.byref(u),
+                                                   ctypes.c_void_p(g.data_ptr()), ctypes.byref(u) if hc else None,
                                                    ctypes.c_void_p(s.cuda_stream)), "ha_cache_push_pull_begin")
-            self._push_outbox(s)                 # the server pushes before it syncs
-            self._sync_request(int(u.value))
+            self._push_outbox(s, bound)          # the server pushes before it syncs
+            self._sync_request(int(u.value) if hc else pk.numel())
+            self._evict_bound = pk.numel()       # the pull phase's evictions stay pending until the next update
             check(self._L.ha_cache_push_pull_finish(self._h, ctypes.c_void_p(dest.data_ptr()),
                                                     ctypes.c_void_p(s.cuda_stream)), "ha_cache_push_pull_finish")
             return Wait(s, keep + [pk, sk, g, dest])

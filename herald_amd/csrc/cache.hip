@@ -927,11 +927,20 @@ __global__ __launch_bounds__(256) void cache_update_flags_push_kernel(
 // pending evicted lines, pushed after the batch's lines (same-key order of the reference's merge:
 // the current line first, then the older evicted ones in eviction order).  Entry j is applied by the
 // wave of the FIRST entry with its key, which then walks the later duplicates in order.
-__global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl *ctl, Cache c) {
+__global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl *ctl, Cache c, long long pad_to) {
     const int En = static_cast<int>(ctl->evict_n);
     const int lane = lane_id();
     if (c.remote && blockIdx.x == 0 && threadIdx.x == 0)
         c.ctl->out_n = ctl->U + En <= c.out_cap ? ctl->U + En : -1;
+    // entries [U + E, pad_to) are marked "not pushed": an owner that takes the outbox without a host-side count
+    // (ha_cache_outbox_pad) serves pad_to entries
+    if (c.remote) {
+        const long long lim = pad_to < c.out_cap ? pad_to : c.out_cap;
+        for (long long e = ctl->U + En + blockIdx.x * 256ll + threadIdx.x; e < lim; e += gridDim.x * 256ll) {
+            c.out_keys[e] = kNoPush;
+            c.out_upd[e] = 0;
+        }
+    }
     for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < En; j += gridDim.x * 4) {
         const int s = c.evict_slots[j];
         const uint32_t k = c.key[s];
@@ -1121,6 +1130,7 @@ struct ha_cache {
     std::vector<void *> allocs;
     int64_t plan_n = -1;   // n of the lookup whose plan is still in plan_ws (ha_cache_update_same_keys)
     int64_t pp_pull = -1, pp_push = 0;   // sizes of the push_pull between its begin and finish (remote store)
+    int64_t out_pad = 0;   // remote store: the updates mark outbox entries [U + E, out_pad) as not pushed
 };
 
 extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
@@ -1279,13 +1289,20 @@ static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hi
 // ---- remote store: inbox / outbox ------------------------------------------------------------------------
 // request of a lookup: (key, cached version) of every unique key -- what the reference's client hands to
 // syncEmbedding (hetu_client.cc:6-23: keys + the lines' versions)
+// Entries [n_unique, n) are padded with a key no store owns (0xFFFFFFFF: never pulled), so that an owner that
+// needs no host-side count (a local or host-resident store) can serve all n entries without a read-back.
 __global__ __launch_bounds__(256) void cache_export_req_kernel(Cache c, const PlanHeader *hdr,
-                                                               const uint32_t *uniq) {
+                                                               const uint32_t *uniq, int n) {
     const int U = static_cast<int>(hdr->n_unique);
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
-        const int s = c.uslot[u];
-        c.req_keys[u] = uniq[u];
-        c.req_ver[u] = s >= 0 ? c.version[s] : -1;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+        if (u < U) {
+            const int s = c.uslot[u];
+            c.req_keys[u] = uniq[u];
+            c.req_ver[u] = s >= 0 ? c.version[s] : -1;
+        } else {
+            c.req_keys[u] = kNoPush;
+            c.req_ver[u] = 0;
+        }
     }
 }
 
@@ -1351,7 +1368,7 @@ extern "C" int ha_cache_lookup_begin(ha_cache *h, const void *keys, int key_kind
     if (!probed)   // larger batches: the plan was built unfused, probe separately
         hipLaunchKernelGGL(cache_probe_kernel, CACHE_GRID(n), dim3(256), 0, s, c.ctl, p.hdr, p.uniq, c.slot_of,
                            (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
-    hipLaunchKernelGGL(cache_export_req_kernel, CACHE_GRID(n), dim3(256), 0, s, c, p.hdr, p.uniq);
+    hipLaunchKernelGGL(cache_export_req_kernel, CACHE_GRID(n), dim3(256), 0, s, c, p.hdr, p.uniq, (int)n);
     HA_LAUNCH_CHECK();
     if (n_unique_host) {
         HA_CHECK_HIP(hipMemcpyAsync(n_unique_host, &p.hdr->n_unique, 8, hipMemcpyDeviceToHost, s));
@@ -1394,6 +1411,17 @@ extern "C" int ha_cache_outbox_count(ha_cache *h, int64_t *count_host, ha_stream
     HA_REQUIRE(v >= 0, "cache outbox overflow: more pending evicted lines than the outbox holds (%ld entries)",
                (long)h->c.out_cap);
     *count_host = v;
+    return 0;
+}
+
+// Remote store without host-side counts: the following updates pad the outbox to `entries` (<= its capacity), so
+// the owner can be handed outbox[0, entries) straight away.  The caller guarantees entries >= U + E: the batch
+// has at most n unique keys and every lookup since the last update evicted at most as many lines as it has keys.
+extern "C" int ha_cache_outbox_pad(ha_cache *h, int64_t entries) {
+    HA_REQUIRE(h && h->c.remote, "cache_outbox_pad: the cache is not in remote-store mode");
+    HA_REQUIRE(entries >= 0 && entries <= h->c.out_cap, "cache_outbox_pad: %ld entries exceed the outbox (%ld)",
+               (long)entries, (long)h->c.out_cap);
+    h->out_pad = entries;
     return 0;
 }
 
@@ -1471,7 +1499,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     }
     hipLaunchKernelGGL(cache_update_flags_push_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq, p.counts,
                        pk, (long long)n_push, with_push_keys);
-    hipLaunchKernelGGL(cache_push_evicted_kernel, CACHE_GRID(c.nmax * 64), b, 0, s, c.ctl, c);
+    hipLaunchKernelGGL(cache_push_evicted_kernel, CACHE_GRID(c.nmax * 64), b, 0, s, c.ctl, c, (long long)h->out_pad);
     // the evicted lines that were pending before this call are pushed now: their slots are free again
     if (!defer_cleanup) {
         const unsigned cblocks = 1u + static_cast<unsigned>((n + 15) / 16 > 1024 ? 1024 : (n + 15) / 16);
@@ -1556,7 +1584,7 @@ static int push_pull_begin(ha_cache *h, const void *pull_keys, int pull_kind, in
     hipLaunchKernelGGL(cache_retire_kernel, dim3(1), dim3(1), 0, s, c.ctl, 0);
     hipLaunchKernelGGL(cache_park_kernel, dim3(1), dim3(1), 0, s, c.ctl, 1);
     if (c.remote)   // the request: the pull keys and the versions their lines hold AFTER the push phase
-        hipLaunchKernelGGL(cache_export_req_kernel, CACHE_GRID(n_pull), b, 0, s, cb, pp.hdr, pp.uniq);
+        hipLaunchKernelGGL(cache_export_req_kernel, CACHE_GRID(n_pull), b, 0, s, cb, pp.hdr, pp.uniq, (int)n_pull);
     HA_LAUNCH_CHECK();
     return 0;
 }

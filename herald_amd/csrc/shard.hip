@@ -404,6 +404,36 @@ extern "C" int ha_store_serve_sync(const float *table, const int64_t *server_ver
     return 0;
 }
 
+namespace ha {
+__global__ __launch_bounds__(256) void store_count_valid_kernel(const uint32_t *__restrict__ keys, long long m,
+                                                                long long rows, long long *__restrict__ acc) {
+    long long c = 0;
+    for (long long j = blockIdx.x * 256ll + threadIdx.x; j < m; j += gridDim.x * 256ll)
+        c += keys[j] < static_cast<unsigned long long>(rows) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        c += __shfl_xor(c, o, 64);
+    if (lane_id() == 0 && c)
+        atomicAdd(reinterpret_cast<unsigned long long *>(acc), static_cast<unsigned long long>(c));
+}
+}  // namespace ha
+
+// *acc += number of keys below `rows` (entries a store applies; 0xFFFFFFFF marks "not pushed"): device-side
+// traffic accounting of the stores, no host synchronisation
+extern "C" int ha_store_count_valid(const uint32_t *keys, int64_t m, int64_t rows, int64_t *acc, ha_stream_t stream) {
+    HA_REQUIRE(m >= 0 && rows >= 0 && acc, "store_count_valid: bad arguments");
+    if (m == 0)
+        return 0;
+    HA_REQUIRE(keys, "store_count_valid: null keys");
+    unsigned blocks = static_cast<unsigned>((m + 255) / 256);
+    if (blocks > 256)
+        blocks = 256;
+    hipLaunchKernelGGL(store_count_valid_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), keys, (long long)m,
+                       (long long)rows, reinterpret_cast<long long *>(acc));
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ha_store_add_versions(int64_t *server_versions, int64_t rows, const uint32_t *keys,
                                      const int32_t *updates, int64_t m, ha_stream_t stream) {
     HA_REQUIRE(m >= 0 && rows >= 0, "store_add_versions: bad sizes");

@@ -41,6 +41,8 @@ def _s():
 class LocalStore:
     """A table shard (rows [0, R) in shard-local numbering) and its per-row versions on this device."""
 
+    host_counts = False   # served on this device: request / outbox are taken padded, no host read-back (cache.py)
+
     def __init__(self, table, versions=None):
         assert table.dtype == torch.float32 and table.is_contiguous() and table.dim() == 2
         self.table = table
@@ -96,7 +98,9 @@ class HostStore(LocalStore):
         self.copy_stream.wait_stream(cur)
         with torch.cuda.stream(self.copy_stream):
             cnt = super().sync(keys, versions, bound, pull, idx, ver_out, rows_out)
-            self._acc[0] += keys.numel()
+            # keys actually asked for (the request is padded with 0xFFFFFFFF) and rows pulled, on the device
+            check(self._L.ha_store_count_valid(_p(keys), keys.numel(), self.rows, _p(self._acc[0:1]), _s()),
+                  "ha_store_count_valid")
             self._acc[1:2] += cnt
         cur.wait_stream(self.copy_stream)
         return cnt
@@ -106,7 +110,8 @@ class HostStore(LocalStore):
         self.copy_stream.wait_stream(cur)
         with torch.cuda.stream(self.copy_stream):
             super().push(keys, updates, rows)
-            self._acc[2] += ((keys.to(torch.int64) & 0xFFFFFFFF) < self.rows).sum()
+            check(self._L.ha_store_count_valid(_p(keys), keys.numel(), self.rows, _p(self._acc[2:3]), _s()),
+                  "ha_store_count_valid")
         cur.wait_stream(self.copy_stream)
 
     def traffic(self, reset=False):
@@ -120,6 +125,8 @@ class HostStore(LocalStore):
 
 
 class ShardedStore:
+    host_counts = True    # the exchanges are sized on the host: the cache reads n_unique / the outbox count back
+
     """Row-range shards (AveragePartitioner ranges, ps-lite/include/ps/partitioner.h:46-57) over the ranks of a
     process group; every rank owns `local` (a LocalStore or HostStore of its range) and is a client of all.
     One sync = counts all-to-all (host read-back), keys + versions out, decisions + versions back, pulled-row

@@ -563,6 +563,12 @@ int ha_cache_lookup_begin(ha_cache *cache, const void *keys, int key_kind, int64
                           int64_t *n_unique_host, ha_stream_t stream);
 int ha_cache_lookup_finish(ha_cache *cache, int64_t n, float *dest, ha_stream_t stream);
 int ha_cache_outbox_count(ha_cache *cache, int64_t *count_host, ha_stream_t stream);
+/* Owners that need no host-side counts (a store on this device or in host memory: no exchange to size): the
+ * REQUEST is always padded to n entries with key 0xFFFFFFFF (never pulled) -- pass n_unique_host = NULL and serve
+ * n entries --, and after ha_cache_outbox_pad(entries) the updates mark OUTBOX entries [U + E, entries) as not
+ * pushed, so outbox[0, entries) can be handed over without ha_cache_outbox_count.  entries must bound U + E: the
+ * batch's n plus the n of every lookup since the last update (each evicts at most as many lines as it has keys). */
+int ha_cache_outbox_pad(ha_cache *cache, int64_t entries);
 /* embedding_push_pull (cache.cc:356-422) over a remote store: begin = touch of the pull keys + the whole
  * push phase (OUTBOX filled, REQUEST = the pull keys' versions after the push phase); the host pushes the
  * outbox and then syncs the request; finish = pull, rows to dest, insert of the pull misses, the push
@@ -582,6 +588,8 @@ int ha_store_serve_sync(const float *table, const int64_t *server_versions, int6
 /* Owner side of the version half of a push: server_versions[keys[j]] += updates[j] (keys >= rows skipped). */
 int ha_store_add_versions(int64_t *server_versions, int64_t rows, const uint32_t *keys,
                           const int32_t *updates, int64_t m, ha_stream_t stream);
+/* *acc += number of keys below `rows` (device-side traffic accounting of a store) */
+int ha_store_count_valid(const uint32_t *keys, int64_t m, int64_t rows, int64_t *acc, ha_stream_t stream);
 /* Synchronising inspectors.  perf out[8] = {type(0 pull / 1 push), num_all, num_unique, num_miss,
  * num_transfered, num_evict, is_full, size} of the last call (the perf dict of cache.cc:89-106).
  * state out[8] = {size, pending evictions, free slots, log head, log tail, clock, slots, log cap}. */
