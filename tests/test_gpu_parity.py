@@ -610,3 +610,31 @@ def test_plan_host_readers_wait_for_the_producing_stream(dev):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(uf.cpu().numpy(), ru)
     np.testing.assert_array_equal(invf.cpu().numpy(), rinv.astype(np.float32))
+
+
+@pytest.mark.parametrize("n,width", [(26624, 64), (50000, 32)])
+def test_sort_ahead_schedule_equals_the_single_stream_sequence(dev, n, width):
+    """ops.SortAhead: the sort of batch k+1 on a side stream beside lookup + apply of batch k -- same rows, same
+    table, same finished plans as the calls on one stream (also under a captured graph)."""
+    rng = np.random.default_rng(n)
+    rows = 300000
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    steps = 4
+    ids = [(synth.criteo_batch((n + 25) // 26, 40 + k).reshape(-1)[:n] % rows).astype(np.float32) for k in range(steps)]
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
+    want = table0.copy()
+    t = _dev(table0, dev)
+    sa = ops.SortAhead(t, n, 0.05)
+    d_ids = [_dev(i, dev) for i in ids]
+    sa.begin(d_ids[0])
+    for k in range(steps):
+        out = sa.lookup(d_ids[k], d_ids[k + 1] if k + 1 < steps else None)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), cpu.embedding_lookup(want, ids[k]))
+        cpu.sgd_sparse_update(want, ids[k], grads[k], 0.05)
+        plan = sa.apply(_dev(grads[k], dev))
+        torch.cuda.synchronize()
+        uniq, inv, cnt = cpu.unique(cpu.ids_to_keys(ids[k]))
+        assert plan.n_unique() == uniq.size
+        np.testing.assert_array_equal(plan.inverse().cpu().numpy().astype(np.int64), inv)
+    np.testing.assert_array_equal(t.cpu().numpy(), want)
