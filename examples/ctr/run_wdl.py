@@ -11,6 +11,8 @@ libherald_amd.so, in the three placements the reference's run_hetu.py offers:
                      sparse SGD -> SGDOptimizerSparseUpdate           (comm_mode None)
   --embedding step   as hbm, but ONE launch per training step: ha_sgd_push_pull applies the sparse SGD of batch
                      k and looks batch k+1 up (rows both batches touch handed over inside the launch)
+  --embedding step3  the same step through ops.StepPipeline (ha_step_*): ids three batches ahead, updated rows
+                     forwarded to the next batch's output by the applying waves, nothing waits inside the launch
   --embedding ps     row-range sharded store (one shard per rank): SparsePull / SparsePush through
                      ParameterServerCommunicateOp                     (comm_mode PS; torchrun for N > 1)
   --embedding cache  HET cache (LRU / LFU / LFUOpt, bounded staleness) in front of the store
@@ -89,7 +91,7 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
     if table_init is None:
         g = torch.Generator(device=dev).manual_seed(seed + 1)
         table_init = torch.randn((rows, width), generator=g, device=dev) * 0.01    # init.random_normal(stddev=0.01)
-    if embedding in ("hbm", "step"):
+    if embedding in ("hbm", "step", "step3"):
         param = hetu_ops.EmbeddingParameter(table=table_init.clone())
         config = hetu_ops.Config(comm_mode=None)
         comm = None
@@ -117,12 +119,20 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         ops.lookup_sort_pend(param.table, ids_of(0).reshape(-1), fused["plans"][0], fused["pends"][0],
                              out=fused["outs"][0])                  # the lookup of the first batch
 
+    pipe = None
+    if embedding == "step3":
+        from herald_amd import ops
+        pipe = ops.StepPipeline(param.table, batch * NFIELD, lr)
+        pipe_out = pipe.start(ids_of(0), ids_of(1), ids_of(2))     # rows of the first batch
+
     losses = []
     t0 = time.perf_counter()
     for k in range(steps):
         state["k"] = k
         ids, dense, label = dev_batches[k % len(dev_batches)]
-        if fused is not None:
+        if pipe is not None:
+            emb = pipe_out.detach().clone()                        # written by the previous step's launch
+        elif fused is not None:
             emb = fused["outs"][k % 2].detach().clone()            # looked up by the previous step's launch
         else:
             emb = torch.empty((batch, NFIELD, width), dtype=torch.float32, device=dev)
@@ -134,7 +144,10 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         loss.backward()
         opt.step()
         grad = lookup_grad.compute(emb.grad, ids)                  # IndexedSlices(indices, values)
-        if fused is not None:
+        if pipe is not None:
+            # sparse SGD of this batch, rows of the next one, plan finish of batch k+2, sort of batch k+3: one launch
+            pipe_out = pipe.step(grad.values.reshape(-1, width).contiguous(), ids_of(k + 3))
+        elif fused is not None:
             # sparse SGD of this batch + lookup of the next one, one launch (plans / pending tables alternate)
             ops.sgd_push_pull(param.table, fused["plans"][k % 2], grad.values.reshape(-1, width).contiguous(), lr,
                               fused["pends"][k % 2], ids_of(k + 1).reshape(-1), fused["plans"][(k + 1) % 2],
@@ -153,7 +166,7 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--embedding", choices=["hbm", "step", "ps", "cache"], default="hbm")
+    ap.add_argument("--embedding", choices=["hbm", "step", "step3", "ps", "cache"], default="hbm")
     ap.add_argument("--cache", choices=["LRU", "LFU", "LFUOpt"], default="LRU")
     ap.add_argument("--bound", type=int, default=100)
     ap.add_argument("--rows", type=int, default=33762577)

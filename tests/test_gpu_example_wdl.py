@@ -53,7 +53,7 @@ def _global_table(param):
     return param.table if param.table is not None else param.store.table
 
 
-@pytest.mark.parametrize("embedding,kw", [("hbm", {}), ("step", {}), ("ps", {}), ("cache", {"cache": "LRU", "bound": 0}),
+@pytest.mark.parametrize("embedding,kw", [("hbm", {}), ("step", {}), ("step3", {}), ("ps", {}), ("cache", {"cache": "LRU", "bound": 0}),
                                           ("cache", {"cache": "LFUOpt", "bound": 0, "cache_limit": 2000})])
 def test_wdl_training_matches_pytorch(dev, reference, embedding, kw):
     import run_wdl
@@ -84,8 +84,9 @@ def test_wdl_one_launch_step_equals_the_two_call_path_bit_for_bit(dev):
     g = torch.Generator(device=dev).manual_seed(3)
     table_init = torch.randn((20000, 32), generator=g, device=dev) * 0.01
     la, pa, ta = run_wdl.train("hbm", 20000, 32, 128, 10, 0.05, table_init=table_init, device=str(dev))
-    lb, pb, tb = run_wdl.train("step", 20000, 32, 128, 10, 0.05, table_init=table_init, device=str(dev))
-    assert la == lb
-    assert torch.equal(pa.table, pb.table)
-    for p, q in zip(ta.parameters(), tb.parameters()):
-        assert torch.equal(p, q)
+    for mode in ("step", "step3"):
+        lb, pb, tb = run_wdl.train(mode, 20000, 32, 128, 10, 0.05, table_init=table_init, device=str(dev))
+        assert la == lb, mode
+        assert torch.equal(pa.table, pb.table), mode
+        for p, q in zip(ta.parameters(), tb.parameters()):
+            assert torch.equal(p, q), mode
