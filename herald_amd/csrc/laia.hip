@@ -274,18 +274,40 @@ __global__ __launch_bounds__(256) void laia_pairs_kernel(
     uint32_t *__restrict__ plan_pairs, unsigned long long *__restrict__ plan_count,
     uint32_t *__restrict__ touch_pairs, int own_plan) {
     const long long total = static_cast<long long>(B) * T;
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
-        const long long i = e / T;
-        const int j = static_cast<int>(e - i * T);
-        const uint32_t emb = samples[((start + i) % S) * T + j];
-        const int ow = owner[i];
-        touch_pairs[e] = static_cast<uint32_t>(ow * R + emb);
-        unsigned long long m = own_plan ? (mask[e] & (1ull << ow)) : (mask[e] & ~(1ull << ow));
+    const int lane = threadIdx.x & 63;
+    // every wave makes the same number of trips (the ballots / shuffles below need all lanes)
+    const long long trips = (total + gridDim.x * 256ll - 1) / (gridDim.x * 256ll);
+    for (long long t = 0; t < trips; ++t) {
+        const long long e = t * gridDim.x * 256ll + blockIdx.x * 256ll + threadIdx.x;
+        unsigned long long m = 0;
+        uint32_t emb = 0;
+        if (e < total) {
+            const long long i = e / T;
+            const int j = static_cast<int>(e - i * T);
+            emb = samples[((start + i) % S) * T + j];
+            const int ow = owner[i];
+            touch_pairs[e] = static_cast<uint32_t>(ow * R + emb);
+            m = own_plan ? (mask[e] & (1ull << ow)) : (mask[e] & ~(1ull << ow));
+        }
+        // one counter bump per wave instead of one per pair (a quarter of a million on one address per batch)
+        const int cnt = __builtin_popcountll(m);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += y;
+        }
+        const int wave_total = __shfl(incl, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 63 && wave_total > 0)
+            base = atomicAdd(plan_count, static_cast<unsigned long long>(wave_total));
+        base = __shfl(base, 63, 64);
+        unsigned long long pos = base + static_cast<unsigned long long>(incl - cnt);
         while (m) {
             const int w = __builtin_ctzll(m);
             m &= m - 1;
-            const unsigned long long pos = atomicAdd(plan_count, 1ull);
-            plan_pairs[pos] = static_cast<uint32_t>(w * R + emb);
+            plan_pairs[pos++] = static_cast<uint32_t>(w * R + emb);
         }
     }
 }
@@ -413,7 +435,8 @@ struct Laia {
     std::vector<long long> miss_pull, miss_push, update_pull, update_push;
     uint32_t *d_plan_pairs = nullptr, *d_touch_pairs = nullptr, *d_dkeys = nullptr;
     uint8_t *d_dvals = nullptr;
-    void *d_plan_ws = nullptr;
+    void *d_plan_ws = nullptr, *d_plan_ws2 = nullptr;
+    uint32_t *h_touch = nullptr, *h_plan = nullptr;   // pinned: sorted-unique results (+ 2 words: their counts)
     size_t plan_cap = 0, delta_cap = 0;
     int Bcap = 0;
     std::vector<void *> allocs;
@@ -486,6 +509,9 @@ extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sam
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_dkeys), l.delta_cap * 4) == 0;
     ok = ok && laia_alloc(l, reinterpret_cast<void **>(&l.d_dvals), l.delta_cap) == 0;
     ok = ok && laia_alloc(l, &l.d_plan_ws, ha_plan_bytes(static_cast<int64_t>(l.plan_cap))) == 0;
+    ok = ok && laia_alloc(l, &l.d_plan_ws2, ha_plan_bytes(static_cast<int64_t>(BT))) == 0;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&l.h_touch), (BT + 4) * 4, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&l.h_plan), (l.plan_cap + 4) * 4, hipHostMallocDefault) == hipSuccess;
     if (ok) {
         std::vector<uint32_t> s32(l.samples_host.size());
         for (size_t i = 0; i < s32.size(); ++i)
@@ -498,6 +524,10 @@ extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sam
             set_error("ha_laia_create: device allocation failed");
         for (void *p : l.allocs)
             (void)hipFree(p);
+        if (l.h_touch)
+            (void)hipHostFree(l.h_touch);
+        if (l.h_plan)
+            (void)hipHostFree(l.h_plan);
         if (l.stream)
             (void)hipStreamDestroy(l.stream);
         delete h;
@@ -512,30 +542,12 @@ extern "C" void ha_laia_destroy(ha_laia *h) {
     (void)hipStreamSynchronize(h->l.stream);
     for (void *p : h->l.allocs)
         (void)hipFree(p);
+    if (h->l.h_touch)
+        (void)hipHostFree(h->l.h_touch);
+    if (h->l.h_plan)
+        (void)hipHostFree(h->l.h_plan);
     (void)hipStreamDestroy(h->l.stream);
     delete h;
-}
-
-// sorted-unique of n composite keys (device) -> host vector
-static int sorted_unique_to_host(Laia &l, const uint32_t *d_keys, size_t n, std::vector<uint32_t> &out) {
-    out.clear();
-    if (n == 0)
-        return 0;
-    int bits = 1;
-    while ((static_cast<unsigned long long>(l.W) * l.R) >> bits)
-        ++bits;
-    if (ha_plan_build_u32keys(d_keys, static_cast<int64_t>(n), l.d_plan_ws, bits, l.stream))
-        return -1;
-    PlanPtrs p = plan_layout(l.d_plan_ws, static_cast<int64_t>(n));
-    long long U = 0;
-    HA_CHECK_HIP(hipMemcpyAsync(&U, &p.hdr->n_unique, 8, hipMemcpyDeviceToHost, l.stream));
-    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
-    out.resize(static_cast<size_t>(U));
-    if (U > 0) {
-        HA_CHECK_HIP(hipMemcpyAsync(out.data(), p.uniq, static_cast<size_t>(U) * 4, hipMemcpyDeviceToHost, l.stream));
-        HA_CHECK_HIP(hipStreamSynchronize(l.stream));
-    }
-    return 0;
 }
 
 // One global batch: get_dist(batch_id) followed by the snapshot update of launch().
@@ -660,14 +672,34 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
                        (int)B, W, l.d_mask, l.d_owner, l.R, l.d_plan_pairs, l.d_count, l.d_touch_pairs,
                        topk ? 1 : 0);
     HA_LAUNCH_CHECK();
-    unsigned long long npairs = 0;
-    HA_CHECK_HIP(hipMemcpyAsync(&npairs, l.d_count, 8, hipMemcpyDeviceToHost, l.stream));
-    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    // Two synchronisations for the rest of the GPU part (five before): the sort of the touched pairs does not need
+    // the number of plan pairs, so it is enqueued first and its result -- count and all BT candidate entries --
+    // comes back together with that number; the plan pairs' sort follows and returns the same way.
     std::vector<uint32_t> plan_keys, touch_keys;
-    if (sorted_unique_to_host(l, l.d_plan_pairs, static_cast<size_t>(npairs), plan_keys))
+    int key_bits = 1;
+    while ((static_cast<unsigned long long>(l.W) * l.R) >> key_bits)
+        ++key_bits;
+    unsigned long long npairs = 0;
+    long long u_touch = 0, u_plan = 0;
+    if (ha_plan_build_u32keys(l.d_touch_pairs, static_cast<int64_t>(BT), l.d_plan_ws2, key_bits, l.stream))
         return -1;
-    if (sorted_unique_to_host(l, l.d_touch_pairs, static_cast<size_t>(BT), touch_keys))
-        return -1;
+    {
+        PlanPtrs pt = plan_layout(l.d_plan_ws2, static_cast<int64_t>(BT));
+        HA_CHECK_HIP(hipMemcpyAsync(&npairs, l.d_count, 8, hipMemcpyDeviceToHost, l.stream));
+        HA_CHECK_HIP(hipMemcpyAsync(&u_touch, &pt.hdr->n_unique, 8, hipMemcpyDeviceToHost, l.stream));
+        HA_CHECK_HIP(hipMemcpyAsync(l.h_touch, pt.uniq, static_cast<size_t>(BT) * 4, hipMemcpyDeviceToHost, l.stream));
+        HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+        touch_keys.assign(l.h_touch, l.h_touch + u_touch);
+    }
+    if (npairs > 0) {
+        if (ha_plan_build_u32keys(l.d_plan_pairs, static_cast<int64_t>(npairs), l.d_plan_ws, key_bits, l.stream))
+            return -1;
+        PlanPtrs pp = plan_layout(l.d_plan_ws, static_cast<int64_t>(npairs));
+        HA_CHECK_HIP(hipMemcpyAsync(&u_plan, &pp.hdr->n_unique, 8, hipMemcpyDeviceToHost, l.stream));
+        HA_CHECK_HIP(hipMemcpyAsync(l.h_plan, pp.uniq, static_cast<size_t>(npairs) * 4, hipMemcpyDeviceToHost, l.stream));
+        HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+        plan_keys.assign(l.h_plan, l.h_plan + u_plan);
+    }
     // ---- emit plans (composite keys are sorted by worker, then row)
     HA_REQUIRE(static_cast<long long>(plan_keys.size()) <= plan_cap_elems, "laia_next: plan buffer too small");
     {
