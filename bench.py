@@ -225,7 +225,7 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
         c.embedding_lookup(ids_dev[b], out)
         c.embedding_update(ids_dev[b], grad, same_as_lookup=True)
     torch.cuda.synchronize()
-    pulls = [r for r in c.perf() if r["type"] == "Pull"]
+    pulls = [r for r in c.perf if r["type"] == "Pull"]
     miss = float(np.mean([r["num_miss"] / max(r["num_unique"], 1) for r in pulls])) if pulls else None
     return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps, "policy": "LRU",
             "limit_rows": limit, "bound": 100, "steps": steps, "unique_miss_rate": miss,
@@ -419,8 +419,12 @@ def main():
             yield k, ln
             k += ln
 
+    # plans / pending tables (one-launch step) and plans / key tables (lookahead step) rotate with the STEP
+    # index, so a captured graph is only valid for steps with the same rotation phase
+    rot = 4 if ahead2 else (2 if one else 1)
+
     def graph_for(k, ln):
-        key = (k % nb, ln)
+        key = (k % nb, k % rot, ln)
         if key not in graphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=main_s):
@@ -570,16 +574,27 @@ def main():
     if one and not ahead2:
         torch.cuda.synchronize()
         result["handoff_timeouts"] = int(plans[0].handoff_timed_out()) + int(plans[1].handoff_timed_out())
+    def secondary(name, fn):
+        """Secondary lines must never cost the headline: a failure is recorded, not raised."""
+        try:
+            result[name] = fn()
+        except Exception as ex:      # noqa: BLE001 -- anything (allocation, capture, a stream error)
+            result[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            try:
+                torch.cuda.synchronize()
+            except Exception:        # noqa: BLE001
+                pass
+
     if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, ids_host)
+        secondary("cpu_baseline", lambda: cpu_baseline(args, ids_host))
     if not args.no_cache_tier:
-        result["cache_tier"] = cache_tier(args, table, ids_dev, outs[0], grads[0], dev)
+        secondary("cache_tier", lambda: cache_tier(args, table, ids_dev, outs[0], grads[0], dev))
     if not args.no_laia:
-        result["laia_scheduler"] = laia_scheduler(args)
+        secondary("laia_scheduler", lambda: laia_scheduler(args))
     if not args.no_cold_tier:
         del table
         torch.cuda.empty_cache()
-        result["cold_tier"] = cold_tier(args, dev)
+        secondary("cold_tier", lambda: cold_tier(args, dev))
     print(json.dumps(result))
 
 

@@ -156,11 +156,15 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
             hetu_ops.sgd_update_sparse(param, grad, lr)            # OptimizerOp, sparse SGD branch
         else:
             comm.compute(grad)                                     # -lr scale, push, (barrier), pull of batch k+1
-        losses.append(float(loss.detach()))
+        losses.append(float(loss.detach()))       # synchronises: a cheap place to poll the hand-off flag
+        if fused is not None and log_every and (k + 1) % log_every == 0:
+            ops.check_handoff(fused["plans"])
         if log_every and (k + 1) % log_every == 0 and rank == 0:
             print("step %d loss %.5f (%.1f ms/step)" % (k + 1, np.mean(losses[-log_every:]),
                                                         1e3 * (time.perf_counter() - t0) / (k + 1)))
     torch.cuda.synchronize()
+    if fused is not None:
+        ops.check_handoff(fused["plans"])
     return losses, param, tower
 
 

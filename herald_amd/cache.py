@@ -486,6 +486,26 @@ class _CacheBase:
         grad = self._rows("grad", [snap["slots"][i]])[0]
         return Embedding(k, snap["version"][i], data, grad, snap["updates"][i])
 
+    def insert(self, key, embedding=None):
+        """insert(EmbeddingPT) of the policies (lru_cache.cc:9-25, lfu_cache.cc:20-45, lfuopt_cache.cc:13-42): the line
+        enters the cache like a lookup miss would bring it in (same touch / evict bookkeeping, a dirty victim joins the
+        pending evictions), then takes the given version and data.  `insert(Embedding)` or `insert(key, row)`."""
+        if isinstance(key, Embedding):
+            e = key
+        else:
+            row = np.asarray(embedding, dtype=np.float32).reshape(-1)
+            e = Embedding(int(key), -1, row)
+        if e.data.size != self._width:
+            raise ValueError("embedding width %d, cache width %d" % (e.data.size, self._width))
+        dest = torch.empty((1, self._width), dtype=torch.float32, device=self.device)
+        k = torch.tensor([int(e.key)], dtype=torch.int64, device=self.device)
+        self.embedding_lookup(k, dest).wait()
+        row = torch.from_numpy(np.ascontiguousarray(e.data, dtype=np.float32)).to(self.device)
+        s = self._stream()
+        check(self._L.ha_cache_set_line(self._h, int(e.key), int(e.version), ctypes.c_void_p(row.data_ptr()),
+                                        ctypes.c_void_p(s.cuda_stream)), "ha_cache_set_line")
+        Wait(s, keep=(row,)).wait()
+
     def lines(self):
         """All resident lines as {key: Embedding} (test helper)."""
         snap = self._snapshot()
@@ -588,5 +608,79 @@ class CacheSparseTable:
     def perf_enabled(self, enable=True):
         self.cache.perf_enabled = enable
 
+    @property
     def perf(self):
+        """One dict per call while the counters are on: type ("Pull" / "Push"), is_full, num_all, num_unique,
+        num_miss, num_evict, num_transfered, time (cstable.py:160-168, filled by cache.cc:89-106,179-196)."""
         return self.cache.perf
+
+    # ---- the rest of the reference wrapper's surface (python/hetu/cstable.py:170-248) ----
+    def bypass(self):
+        """Every key misses from now on: lookups and updates go straight to the store (cache.h bypass_)."""
+        self.cache.bypass()
+
+    def undobypass(self):
+        self.cache.undo_bypass()
+
+    def __repr__(self):
+        return repr(self.cache)
+
+    # single-key debugging calls
+    def lookup(self, key):
+        """The resident line of `key` as an Embedding (key, version, data, grad), or None."""
+        return self.cache.lookup(key)
+
+    def count(self, key):
+        return self.cache.count(key)
+
+    def insert(self, key, embedding=None):
+        """Enter one line (the policies' insert(EmbeddingPT), lru_cache.cc:9-25): `insert(Embedding)` as the
+        plugin takes it, or `insert(key, row)`."""
+        return self.cache.insert(key, embedding)
+
+    def keys(self):
+        return self.cache.keys()
+
+    def get_perf(self):
+        return self.perf
+
+    def _perf_rows(self, include_cold_start):
+        return [r for r in self.perf if include_cold_start or r["is_full"]]
+
+    def overall_miss_rate(self, include_cold_start=False):
+        """Unique-key miss rate over the recorded lookups; -1 without records (cstable.py:202-212)."""
+        rows = self._perf_rows(include_cold_start)
+        if not rows:
+            return -1
+        pulls = [r for r in rows if r["type"] == "Pull"]
+        return float(np.sum([r["num_miss"] for r in pulls]) / np.sum([r["num_unique"] for r in pulls]))
+
+    def overall_data_rate(self, include_cold_start=False):
+        """Rows that crossed to / from the store per key handed in, lookups and updates alike: the traffic relative
+        to a cache-less sparse pull / push (cstable.py:214-224)."""
+        rows = self._perf_rows(include_cold_start)
+        if not rows:
+            return -1
+        return float(np.sum([r["num_transfered"] for r in rows]) / np.sum([r["num_all"] for r in rows]))
+
+    def debug_keys(self, comm=None):
+        """Overlap of the resident key sets between workers: rt[i][j] = |keys_i & keys_j| / |keys_i| on rank 0
+        (cstable.py:226-248 exchanges them through a file and BarrierWorker; here through `comm`, a
+        torch.distributed process group or the default one; single process: a 1 x 1 matrix)."""
+        mine = sorted(int(k) for k in self.keys())
+        import torch.distributed as dist
+        if comm is None and not (dist.is_available() and dist.is_initialized()):
+            sets, rank = [set(mine)], 0
+        else:
+            world = dist.get_world_size(group=comm)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine, group=comm)
+            sets, rank = [set(g) for g in gathered], dist.get_rank(group=comm)
+        if rank != 0:
+            return None
+        rt = np.zeros((len(sets), len(sets)))
+        for i, a in enumerate(sets):
+            for j, b in enumerate(sets):
+                if a:
+                    rt[i][j] = len(a & b) / len(a)
+        return rt

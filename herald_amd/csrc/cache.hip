@@ -1115,6 +1115,19 @@ __global__ __launch_bounds__(256) void cache_snapshot_kernel(Cache c, long long 
     }
 }
 
+__global__ __launch_bounds__(256) void cache_set_line_kernel(Cache c, long long key, long long version,
+                                                             const float *data) {
+    if (key < 0 || key >= c.length)
+        return;
+    const int s = c.slot_of[key];
+    if (s < 0 || (c.state[s] != kResident && c.state[s] != kStored))
+        return;
+    if (threadIdx.x == 0)
+        c.version[s] = version;
+    for (long long j = threadIdx.x; j < c.width; j += 256)
+        c.data[static_cast<long long>(s) * c.width + j] = data[j];
+}
+
 template <typename T>
 static int dmalloc(T **p, size_t count) {
     HA_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 256));
@@ -1689,6 +1702,15 @@ extern "C" int ha_cache_snapshot(ha_cache *h, int64_t cap, uint32_t *keys, int64
                        (long long)cap, keys, reinterpret_cast<long long *>(version), updates,
                        reinterpret_cast<unsigned long long *>(stamp), slots,
                        reinterpret_cast<unsigned long long *>(count_dev));
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ha_cache_set_line(ha_cache *h, int64_t key, int64_t version, const float *data_dev,
+                                 ha_stream_t stream) {
+    HA_REQUIRE(h && data_dev, "cache_set_line: null pointer");
+    hipLaunchKernelGGL(cache_set_line_kernel, dim3(1), dim3(256), 0, as_stream(stream), h->c,
+                       static_cast<long long>(key), static_cast<long long>(version), data_dev);
     HA_LAUNCH_CHECK();
     return 0;
 }

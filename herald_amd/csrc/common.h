@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 
 #include "../../include/herald_amd.h"
 
@@ -45,6 +46,19 @@ bool g_err_is_empty();
                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                              static_cast<int>(bytes)));                          \
     } while (0)
+
+// "Once per DEVICE" guard for per-device function attributes (hipFuncSetAttribute applies to the current device
+// only): true the first time it is called with the current device, from whichever thread.
+struct DeviceOnce {
+    std::atomic<unsigned long long> seen[4];   // 256 devices
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess)
+            return true;
+        const unsigned long long bit = 1ull << (d & 63);
+        return (seen[(d >> 6) & 3].fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+    }
+};
 
 static inline hipStream_t as_stream(ha_stream_t s) {
     return reinterpret_cast<hipStream_t>(s);

@@ -534,12 +534,11 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
 // remaining passes and, unless sort_only, the finish
 static int scatter_allow_lds() {
     using namespace ha;
-    static bool done = false;   // once, and outside any stream capture (the first call is eager)
-    if (!done) {
+    static DeviceOnce once;   // once per device, and outside any stream capture (the first call is eager)
+    if (once.first()) {
         HA_ALLOW_LDS((radix_scatter_kernel<false, false>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<true, false>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<false, true>), kScatterLdsBytes);
-        done = true;
     }
     return 0;
 }

@@ -243,8 +243,12 @@ extern "C" int ha_ps_sparse_pull(int node, const DLArray *index, DLArray *value)
             return -1;
         out = nd->st_val;
     }
+    // with several ranks this process holds ONE row range of the table: global ids can only be served by the
+    // registered exchange (herald_amd.ps.attach_sharded); the local kernels would address the shard with them
+    HA_REQUIRE(g_ps_nrank == 1 || g_ps_backend.sparse_pull,
+               "SparsePull: %d ranks configured but no sharded backend registered (ha_ps_set_backend)", g_ps_nrank);
     int rc;
-    if (g_ps_nrank > 1 && g_ps_backend.sparse_pull)
+    if (g_ps_nrank > 1)
         rc = g_ps_backend.sparse_pull(node, ids, n, out, nd->stream);
     else
         rc = ps_local_pull(*nd, ids, n, out);
@@ -266,7 +270,9 @@ extern "C" int ha_ps_sparse_push(int node, const DLArray *index, const DLArray *
     const float *ids = nullptr, *vals = nullptr;
     if (ps_in(*nd, index, true, &ids) || ps_in(*nd, value, false, &vals))
         return -1;
-    if (g_ps_nrank > 1 && g_ps_backend.sparse_push)
+    HA_REQUIRE(g_ps_nrank == 1 || g_ps_backend.sparse_push,
+               "SparsePush: %d ranks configured but no sharded backend registered (ha_ps_set_backend)", g_ps_nrank);
+    if (g_ps_nrank > 1)
         return g_ps_backend.sparse_push(node, ids, n, vals, nd->stream);
     return ps_local_push(*nd, ids, n, vals);
 }

@@ -255,9 +255,22 @@ public:
         }
         return py::none();
     }
-    void insert(py::object) {
-        throw std::runtime_error("insert(Embedding) is a debug hook of the reference; lines enter this cache "
-                                 "through embedding_lookup");
+    // insert(EmbeddingPT) of the policies (lru_cache.cc:9-25): the line enters the cache like a lookup miss would
+    // bring it in (same touch / evict bookkeeping), then takes the given version and data
+    void insert(std::shared_ptr<Embedding> e) {
+        if (!e || (size_t)e->data.size() != width_)
+            throw std::runtime_error("insert: the embedding must hold `width` floats");
+        uint64_t *k;
+        float *row;
+        hip_check(hipMalloc((void **)&k, 8), "hipMalloc");
+        hip_check(hipMalloc((void **)&row, width_ * 4), "hipMalloc");
+        hip_check(hipMemcpyAsync(k, &e->key, 8, hipMemcpyHostToDevice, stream_), "memcpy");
+        ha_check(ha_cache_lookup(h_, k, 1, 1, row, stream_), "ha_cache_lookup");
+        hip_check(hipMemcpyAsync(row, e->data.data(), width_ * 4, hipMemcpyHostToDevice, stream_), "memcpy");
+        ha_check(ha_cache_set_line(h_, (int64_t)e->key, e->version, row, stream_), "ha_cache_set_line");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        (void)hipFree(k);
+        (void)hipFree(row);
     }
     std::string repr() {
         std::stringstream ss;

@@ -298,11 +298,9 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
             lds = lds > rank_small_lds_bytes(a.n_next) ? lds : rank_small_lds_bytes(a.n_next);
         }
         const unsigned blocks = static_cast<unsigned>(a.nfin + a.napply + a.nrank + a.ngather);
-        static bool lds_allowed = false;   // once, and outside any stream capture (the first call is eager)
-        if (!lds_allowed) {
+        static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
+        if (lds_allowed.first())
             HA_ALLOW_LDS((step_kernel<IdT>), 160 * 1024);
-            lds_allowed = true;
-        }
         if (dbg) {
             a.dbg = dbg;
             HA_ALLOW_LDS((step_timeline_kernel<IdT>), 160 * 1024);
@@ -593,11 +591,9 @@ static int step_fwd(float *table, int64_t rows, int64_t width, void *plan_cur, i
     const unsigned blocks = static_cast<unsigned>(a.nclear + a.nfin + a.napply + a.nrank + a.ngather);
     if (blocks == 0)
         return 0;
-    static bool lds_allowed = false;   // once, and outside any stream capture (the first call is eager)
-    if (!lds_allowed) {
+    static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
+    if (lds_allowed.first())
         HA_ALLOW_LDS((step_fwd_kernel<IdT>), 160 * 1024);
-        lds_allowed = true;
-    }
     if (dbg) {
         a.dbg = dbg;
         HA_ALLOW_LDS((step_fwd_timeline_kernel<IdT>), 160 * 1024);

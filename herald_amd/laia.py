@@ -280,81 +280,114 @@ def topk_num_threads(mini_batch_size, wanted=80):
     return 1
 
 
+class _PlanDistStream:
+    """The scheduler's output as (dist, plan) pairs.  The native schedulers emit `plan(0), dist(0), plan(1), dist(1), ...`
+    and finally `[0]` (laia/src/laia_scheduler.cc:138-139, 166); the training loop wants dist(b) together with
+    plan(b+1) -- the rows this worker holds that somebody else touches next step -- so the very first plan is
+    dropped and every pair is (dist(b), plan(b+1)) (python/hetu/laia/laia_dataloader.py:108-114)."""
+
+    def __init__(self, pop, ready):
+        self._pop, self._ready = pop, ready
+        self.closed = False
+        self._take()                      # plan(0): nobody pushes before the first step
+
+    def _take(self):
+        if self.closed:
+            raise RuntimeError("the laia scheduler's stream has ended; nothing left to read")
+        msg = self._pop()
+        if not isinstance(msg, list):
+            raise TypeError("laia scheduler returned %r, expected a list" % type(msg))
+        if msg == [0]:                    # terminator
+            self.closed = True
+            return []
+        return msg
+
+    def pair(self):
+        dist = self._take()
+        plan = [] if self.closed else self._take()
+        return dist, plan
+
+    def pair_ready(self):
+        return self._ready() >= 2
+
+
 class LAIAScheduler:
-    """python/hetu/laia/laia_dataloader.py:29-169 on top of the LaiaScheduler above."""
+    """The host side of a laia-scheduled epoch: which samples this worker trains on in batch b and which cached rows
+    it pushes after it.  Public surface of python/hetu/laia/laia_dataloader.py:29-169 (`start`, `get_input_index`,
+    `get_comm_plan`, `step_forward`, `samples_num / batch_num / batch_size`), own body: a window of WINDOW
+    consecutive batches {batch id -> (dist, plan)} over the native scheduler's stream; a batch leaves the window once
+    EVERY data loader that shares the scheduler has stepped past it, and the window then takes the next pair --
+    without blocking the training loop while it still holds a batch the slowest loader has not consumed."""
+
+    WINDOW = 5
 
     def __init__(self, sparse_data, batch_size, drop_last=True, dataset="criteo", local_shared=False):
-        self.sparse_data = np.array(sparse_data, np.float32).astype(np.intc)
-        self.batch_size = batch_size
-        self.drop_last = drop_last
-        self.init = False
-        self.dataset = dataset
-        self.local_shared = local_shared
+        # the reference hands float32 ids over and the scheduler reads C ints (laia_dataloader.py:31)
+        self.sparse_data = np.asarray(sparse_data, dtype=np.float32).astype(np.intc)
+        self.batch_size, self.drop_last = batch_size, drop_last
+        self.dataset, self.local_shared = dataset, local_shared
+        self.sched = None
+
+    def _native(self, nrank, rank, cache_limit, epoch_num, key_limit, local_rank, local_size):
+        data = self.sparse_data
+        head = (data, data.shape[0], data.shape[1], epoch_num, self.batch_size, self.batch_num, int(nrank), int(rank),
+                int(cache_limit))
+        if not self.local_shared:
+            s = LaiaScheduler()
+            s.start(*head, 16, 24, key_limit=key_limit)
+            return s, s.pop
+        # one scheduler per node: local rank 0 computes and feeds the others' shared-memory rings, so it has to
+        # be up before they open theirs (laia_dataloader.py:72-95)
+        s = TopkScheduler()
+        if local_rank != 0:
+            time.sleep(3)
+        s.start(*head, topk_num_threads(self.batch_size), self.dataset, int(top_k_table[self.dataset]), True,
+                int(local_rank), int(local_size), key_limit=key_limit)
+        return s, s.pop_from_local_worker
 
     def start(self, nrank, rank, cache_limit, dataset_num=3, epoch_num=-1, key_limit=None, local_rank=0,
               local_size=local_worker_num):
-        assert not self.init, "LAIA scheduler can only be initialized once"
+        if self.sched is not None:
+            raise RuntimeError("LAIAScheduler.start may be called once")
         self.samples_num = len(self.sparse_data) // nrank
-        self.queue_size = 5
-        self.batch_size = min(int(self.batch_size), self.samples_num // self.queue_size)
-        assert self.batch_size > 0, "Batch size %d invalid." % self.batch_size
-        self.batch_num = (int(np.ceil(self.samples_num / self.batch_size)) if not self.drop_last
-                          else self.samples_num // self.batch_size)
-        if not self.local_shared:
-            self.sched = LaiaScheduler()
-            self.sched.start(self.sparse_data, self.sparse_data.shape[0], self.sparse_data.shape[1], epoch_num,
-                             self.batch_size, self.batch_num, int(nrank), int(rank), int(cache_limit), 16, 24,
-                             key_limit=key_limit)
-        else:
-            # only local rank 0 schedules; the others open their ring (laia_dataloader.py:72-95)
-            self.sched = TopkScheduler()
-            if local_rank != 0:
-                time.sleep(3)      # "allow local major worker to start first"
-            self.sched.start(self.sparse_data, self.sparse_data.shape[0], self.sparse_data.shape[1], epoch_num,
-                             self.batch_size, self.batch_num, int(nrank), int(rank), int(cache_limit),
-                             topk_num_threads(self.batch_size), self.dataset, int(top_k_table[self.dataset]),
-                             True, int(local_rank), int(local_size), key_limit=key_limit)
-        self.channel_close = False
-        self.input_index, self.comm_plan, self.arr_map = [], [], {}
-        for i in range(self.queue_size):
-            if i == 0:
-                self._channel_get()          # discard the first comm_plan
-            self.input_index.append(self._channel_get())
-            self.comm_plan.append(self._channel_get())
-            self.arr_map[i] = i
-        self.step = [0] * dataset_num
-        self.cur_min_step = 0
-        self.init = True
+        # the window must never hold the same batch id twice: at least WINDOW batches per epoch
+        self.batch_size = min(int(self.batch_size), self.samples_num // self.WINDOW)
+        if self.batch_size <= 0:
+            raise ValueError("batch size %d is not usable with %d samples per worker" % (self.batch_size, self.samples_num))
+        full, rest = divmod(self.samples_num, self.batch_size)
+        self.batch_num = full if (self.drop_last or rest == 0) else full + 1
+        self.sched, pop = self._native(nrank, rank, cache_limit, epoch_num, key_limit, local_rank, local_size)
+        self._stream = _PlanDistStream(pop, self.sched.length)
+        self._window = {b: self._stream.pair() for b in range(self.WINDOW)}
+        self._cursor = [0] * dataset_num      # batches each data loader has consumed
+        self._released = 0                    # batches that have left the window
 
-    def _channel_get(self):
-        if self.channel_close:
-            raise RuntimeError("Channle have been closed, but still try to get value from it")
-        res = self.sched.pop() if not self.local_shared else self.sched.pop_from_local_worker()
-        assert isinstance(res, list)
-        if len(res) == 1 and res[0] == 0:
-            self.channel_close = True
-            return []
-        return res
+    @property
+    def init(self):
+        return self.sched is not None
+
+    @property
+    def channel_close(self):
+        return self._stream.closed
 
     def get_input_index(self, batch_id):
-        return self.input_index[self.arr_map[batch_id]]
+        return self._window[batch_id][0]
 
     def get_comm_plan(self, batch_id):
-        return self.comm_plan[self.arr_map[batch_id]]
+        return self._window[batch_id][1]
 
     def step_forward(self, dataset_id):
-        self.step[dataset_id] += 1
-        new_min_step = min(self.step)
-        while self.cur_min_step < new_min_step:
-            if self.channel_close or (self.sched.length() < 2 and new_min_step - self.cur_min_step < self.queue_size):
-                break
-            min_batch_id = self.cur_min_step % self.batch_num
-            arr_index = self.arr_map.pop(min_batch_id)
-            self.input_index[arr_index] = self._channel_get()
-            self.comm_plan[arr_index] = self._channel_get()
-            new_batch_id = (min_batch_id + self.queue_size) % self.batch_num
-            self.arr_map[new_batch_id] = arr_index
-            self.cur_min_step += 1
+        self._cursor[dataset_id] += 1
+        done = min(self._cursor)
+        while self._released < done and not self._stream.closed:
+            backlog = done - self._released
+            if backlog < self.WINDOW and not self._stream.pair_ready():
+                break                          # the scheduler is still computing and nobody is starved yet
+            oldest = self._released % self.batch_num
+            nxt = self._stream.pair()          # may block (or raise) before anything is changed
+            del self._window[oldest]
+            self._window[(oldest + self.WINDOW) % self.batch_num] = nxt
+            self._released += 1
 
 
 class LAIADataloader:

@@ -186,7 +186,15 @@ class IndexPlan:
         """Host int.  Waits for the stream of the launch that last wrote the plan (whichever stream the caller
         passed to build / finish / lookup_sort / sgd_apply_finish / sgd_push_pull), then reads the count."""
         self._sync_producer()
+        self._raise_if_handoff_timed_out()
         return int(self._slice(self.view().n_unique, 1, torch.int64).item())
+
+    def _raise_if_handoff_timed_out(self):
+        addr = _lib.load().ha_plan_handoff_timeout(_ptr(self.ws))
+        if bool(self._slice(addr, 1, torch.int64).item()):
+            raise _lib.HeraldAmdError(
+                "a hand-off wait of the ha_sgd_push_pull launch that sorted this plan timed out: the rows that "
+                "lookup returned may predate the update of the previous batch (include/herald_amd.h)")
 
     def handoff_timed_out(self):
         """True if a hand-off wait of the sgd_push_pull launch that sorted this plan gave up (host sync)."""
@@ -423,6 +431,15 @@ def sgd_push_pull(table, plan_cur, grads, lr, pend_cur, next_ids=None, plan_next
     plan_cur.produced_on(stream)
     plan_next.produced_on(stream)
     return next_out
+
+
+def check_handoff(plans):
+    """Raises if any of `plans` carries the sticky hand-off time-out flag of ha_sgd_push_pull_* (a gather wave gave
+    up waiting for a row of the previous batch, so a lookup may have returned stale rows).  Synchronises with the
+    streams that produced the plans: call it where the training loop synchronises anyway (logging, evaluation)."""
+    for p in plans:
+        p._sync_producer()
+        p._raise_if_handoff_timed_out()
 
 
 class SortAhead:

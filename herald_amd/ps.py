@@ -117,9 +117,23 @@ def attach_sharded(node_id, emb, barrier=None):
     _ATTACHED[int(node_id)] = emb
     dev = emb.device
 
+    def served(node):
+        """The store behind `node`: attached explicitly, or -- a tensor InitTensor created on every rank with this
+        engine's partition (ha_ps_init_tensor allocates exactly the AveragePartitioner range) -- wrapped on first
+        use in a ShardedEmbedding with the exchange settings of the store this backend was registered with.  Every
+        rank reaches this at the same call (SparsePull / SparsePush are issued by all workers)."""
+        e = _ATTACHED.get(node)
+        if e is None:
+            from .sharded import ShardedEmbedding
+            shard, info = tensor(node, dev)
+            e = ShardedEmbedding(int(info.len), int(info.width), dev, group=emb.group, table=shard,
+                                 a2a=emb._a2a_fn, side_stream=emb.side_stream)
+            _ATTACHED[node] = e
+        return e
+
     def pull_cb(node, ids_ptr, n, out_ptr, stream):
         try:
-            e = _ATTACHED[node]
+            e = served(node)
             with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
                 ids = _dev_view(ids_ptr, (n,), torch.float32, dev)
                 out = _dev_view(out_ptr, (n, e.width), torch.float32, dev)
@@ -131,7 +145,7 @@ def attach_sharded(node_id, emb, barrier=None):
 
     def push_cb(node, ids_ptr, n, vals_ptr, stream):
         try:
-            e = _ATTACHED[node]
+            e = served(node)
             with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
                 ids = _dev_view(ids_ptr, (n,), torch.float32, dev)
                 vals = _dev_view(vals_ptr, (n, e.width), torch.float32, dev)

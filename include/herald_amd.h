@@ -361,7 +361,11 @@ int ha_push_apply_finish(float *table, int64_t rows, int64_t width,
  * (width % 32 == 0, table 128-byte aligned) and batches of at most 18,432 ids (above that the bucket sort of the separate launches wins);
  * anything else runs as the separate launches with the same results (nothing is registered then).
  * Should a hand-off wait ever exceed its bound (~0.1 s; never observed), word 9 (int64) of
- * plan_next's 256-byte header is set to 1 (ha_plan_handoff_timeout) instead of hanging the device. */
+ * plan_next's 256-byte header is set to 1 (ha_plan_handoff_timeout) instead of hanging the device: the rows of
+ * that lookup may then be stale, and the flag stays set.  The library never reads it back (that would put a
+ * host synchronisation into every step); a caller that trains on the rows MUST poll it at a point where it
+ * synchronises anyway (herald_amd.ops: IndexPlan.n_unique() raises, ops.check_handoff(plans) after a
+ * synchronisation; examples/ctr/run_wdl.py checks it at every logging interval). */
 size_t ha_pend_bytes(void);
 int ha_pend_reset(void *pend, ha_stream_t stream);
 int ha_lookup_sort_pend_f32ids(const float *table, int64_t rows, int64_t width,
@@ -600,6 +604,10 @@ int ha_cache_state(ha_cache *cache, int64_t *out_host, ha_stream_t stream);
 int ha_cache_snapshot(ha_cache *cache, int64_t cap, uint32_t *keys,
                       int64_t *version, int32_t *updates, uint64_t *stamp,
                       int32_t *slots, uint64_t *count_dev, ha_stream_t stream);
+/* Debug hook behind hetu_cache's insert(EmbeddingPT) (src/hetu_cache/src/python_api.cc:58, lru_cache.cc:9-25):
+ * the RESIDENT line of `key` takes `version` and the `width` floats at data_dev; a key that is not resident
+ * is left alone (the caller brings the line in with a one-key lookup first). */
+int ha_cache_set_line(ha_cache *cache, int64_t key, int64_t version, const float *data_dev, ha_stream_t stream);
 float *ha_cache_data(ha_cache *cache);
 float *ha_cache_grad(ha_cache *cache);
 int64_t ha_cache_limit(ha_cache *cache);

@@ -104,6 +104,89 @@ def dnnl_cases(seed):
     return out
 
 
+def _reference_cpu_deduplicate():
+    """IndexedSlices.cpu_deduplicate as the REFERENCE wrote it: the method's text is read from
+    /root/reference/python/hetu/ndarray.py at generation time (never copied into the repo) and executed on
+    a bare object.  The `hetu` package itself cannot be imported here (it dlopens libc_runtime_api.so), so the
+    three names the method takes from its module are bound to array CONTAINERS only -- `array(a, ctx)` wraps a
+    numpy array, `cpu(i)` is a tag, `is_gpu_ctx` says no; every arithmetic step (np.unique, the occurrence-order
+    `new_values[ind] += flatten[i]` loop in float32) is the reference's own statement."""
+    import ast
+    import textwrap
+    path = "/root/reference/python/hetu/ndarray.py"
+    src = open(path).read()
+    tree = ast.parse(src)
+    fn = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == "IndexedSlices":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == "cpu_deduplicate":
+                    fn = item
+    assert fn is not None, "IndexedSlices.cpu_deduplicate not found in %s" % path
+    text = textwrap.dedent("\n".join(src.splitlines()[fn.lineno - 1:fn.end_lineno]))
+
+    class Box:                      # the NDArray container: data + ctx, nothing else
+        def __init__(self, a, ctx=None):
+            self.a, self.ctx, self.shape = np.asarray(a), ctx, np.asarray(a).shape
+
+        def asnumpy(self):
+            return self.a
+
+    ns = {"np": np, "array": lambda a, ctx=None: Box(a, ctx), "cpu": lambda i: ("cpu", i),
+          "is_gpu_ctx": lambda ctx: False}
+    exec(compile(text, path, "exec"), ns)
+    method = ns["cpu_deduplicate"]
+
+    def run(ids, values, push=None):
+        class Slices:
+            pass
+        sl = Slices()
+        sl.indices, sl.values = Box(ids, ("cpu", 0)), Box(values, ("cpu", 0))
+        sl.push_indices = None if push is None else Box(push, ("cpu", 0))
+        method(sl)
+        return sl.indices.a, sl.values.a, (None if push is None else sl.push_indices.a)
+    return run
+
+
+def dedup_cases(seed):
+    """IndexedSlices.cpu_deduplicate (python/hetu/ndarray.py:556-576): float32 ids of any rank with duplicates,
+    a hot id, ids above 2^24, empty and single-id batches, push_indices; d in {4, 64, 512}."""
+    import formula
+    from oracle import cpu
+    run = _reference_cpu_deduplicate()
+    rng = np.random.default_rng(seed)
+    specs = [
+        ("d4_dups", rng.integers(0, 9, size=(5, 4)), 4, None),
+        ("d64_hot", np.concatenate([np.full(70, 3), rng.integers(0, 40, size=58)])[rng.permutation(128)], 64, None),
+        ("d512_dups", rng.integers(0, 12, size=20), 512, None),
+        ("d4_push", rng.integers(0, 30, size=40), 4, rng.integers(0, 30, size=17)),
+        ("empty", np.zeros((0,), dtype=np.int64), 4, None),
+        ("single", np.array([6]), 64, None),
+        ("big_ids", np.array([16777216, 16777218, 33762576, 20000002, 16777218, 33762576, 1, 0, 16777218],
+                             dtype=np.float32), 4, None),
+    ]
+    out = []
+    for name, ids, width, push in specs:
+        ids = np.asarray(ids).astype(np.float32)
+        vals = rng.standard_normal(ids.shape + (width,)).astype(np.float32)
+        pf = None if push is None else np.asarray(push).astype(np.float32)
+        # The reference pins numpy 1.20.3 (environment.yml:43), whose np.unique returns a FLAT inverse for ids of
+        # any rank; numpy >= 2.0 (this container: 2.2) returns it in the ids' shape, which would turn the method's
+        # `for i, ind in enumerate(inverse)` into a loop over rows.  Ids are therefore handed over flattened -- the
+        # method flattens the values itself (`reshape((-1, last_dim))`), so under numpy 1.20 the result is the same.
+        u, red, pu = run(ids.reshape(-1), vals, pf)
+        # the repo's restatement of the same loop (oracle/cpu.py) must agree before the vector is written
+        ru, rred = cpu.np_cpu_deduplicate(ids, vals)
+        assert np.array_equal(u, ru) and np.array_equal(red, rred), name
+        assert red.dtype == np.float32
+        out.append({"name": name, "width": width, "ids_shape": list(ids.shape), "ids_bits": formula.bits(ids),
+                    "values_bits": formula.bits(vals), "uniq_bits": formula.bits(np.asarray(u, dtype=np.float32)),
+                    "reduced_bits": formula.bits(red),
+                    "push_bits": None if pf is None else formula.bits(pf),
+                    "push_uniq_bits": None if pu is None else formula.bits(np.asarray(pu, dtype=np.float32))})
+    return out
+
+
 def main():
     assert ref.available(), "build oracle/_ref first (oracle/build_ref.sh)"
     assert ref.dnnl_available(), "build oracle/_ref/libref_dnnl.so first (oracle/build_ref.sh)"
@@ -115,6 +198,7 @@ def main():
     json.dump([minilru_trace(6, 30, 500, 4), minilru_trace(50, 60, 500, 5)],
               open(os.path.join(HERE, "minilru.json"), "w"))
     json.dump(unique_vectors(6), open(os.path.join(HERE, "unique.json"), "w"))
+    json.dump(dedup_cases(8), open(os.path.join(HERE, "dedup.json"), "w"))
     print("golden vectors written to", HERE)
 
 

@@ -75,3 +75,46 @@ def test_hip_matches_reference_dnnl_golden(dev, case, path):
     if probe:
         got = table[torch.tensor(probe, device=dev)].cpu().numpy()
         np.testing.assert_array_equal(got, formula.rows_of(probe, w))
+
+
+DEDUP = json.load(open(os.path.join(GOLD, "dedup.json")))
+
+
+@pytest.mark.parametrize("case", DEDUP, ids=lambda c: c["name"])
+@pytest.mark.parametrize("path", ["dedup_reduce", "indexed_slices", "dl_symbol"])
+def test_hip_dedup_matches_reference_cpu_deduplicate_golden(dev, case, path):
+    """HIP dedup-reduce against tests/golden/dedup.json = the reference's IndexedSlices.cpu_deduplicate
+    (python/hetu/ndarray.py:556-576) executed from its own text by make_golden.py: unique ids, reduced rows and
+    the deduplicated push indices, bit for bit, through ha_dedup_reduce, through ops.IndexedSlices.deduplicate
+    (the reference's GPU call sequence, ndarray.py:532-554) and through the DeduplicateIndexedSlices symbol."""
+    ids = formula.from_bits(case["ids_bits"], case["ids_shape"])
+    n, w = ids.size, case["width"]
+    vals = formula.from_bits(case["values_bits"], (n, w))
+    uniq = formula.from_bits(case["uniq_bits"], (len(case["uniq_bits"]),))
+    red = formula.from_bits(case["reduced_bits"], (uniq.size, w))
+    if n == 0:
+        pytest.skip("empty batch: nothing to launch (the reference returns empty arrays)")
+    d_ids = torch.from_numpy(ids).to(dev)
+    d_vals = torch.from_numpy(vals).to(dev)
+    if path == "dedup_reduce":
+        plan = ops.IndexPlan(n, dev).build(d_ids.reshape(-1))
+        got = ops.dedup_reduce(plan, d_vals)[:plan.n_unique()]
+        got_u, _ = plan.export_f32()
+    elif path == "indexed_slices":
+        push = None
+        if case["push_bits"] is not None:
+            push = torch.from_numpy(formula.from_bits(case["push_bits"], (len(case["push_bits"]),))).to(dev)
+        sl = ops.IndexedSlices(d_ids, d_vals.reshape(tuple(ids.shape) + (w,)), push_indices=push).deduplicate()
+        got, got_u = sl.values, sl.indices
+        if push is not None:
+            want_p = formula.from_bits(case["push_uniq_bits"], (len(case["push_uniq_bits"]),))
+            np.testing.assert_array_equal(sl.push_indices.cpu().numpy().view(np.uint32), want_p.view(np.uint32))
+    else:
+        ru, rinv = np.unique(ids.reshape(-1), return_inverse=True)      # the host step of ndarray.py:534
+        got = torch.zeros((ru.size, w), dtype=torch.float32, device=dev)
+        ops.dl_call("DeduplicateIndexedSlices",
+                    [d_vals, torch.from_numpy(rinv.reshape(-1).astype(np.float32)).to(dev), got])
+        got_u = torch.from_numpy(ru.astype(np.float32))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got_u.cpu().numpy().view(np.uint32), uniq.view(np.uint32))
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), red.view(np.uint32))

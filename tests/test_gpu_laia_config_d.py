@@ -90,7 +90,7 @@ def test_laia_dataloader_drives_update_with_push_keys(dev):
         assert slices.push_indices is plan
         cst.embedding_update_with_push_keys(slices.indices.reshape(-1), slices.push_indices, slices.values).wait()
         model.update_with_push_keys(keys, np.asarray(stream[2 * b + 2], dtype=np.uint64), g)
-        for got, exp in zip(cst.perf()[-2:], model.perf[-2:]):
+        for got, exp in zip(cst.perf[-2:], model.perf[-2:]):
             for f in ("type", "num_all", "num_unique", "num_miss", "num_transfered", "is_full"):
                 assert got[f] == exp[f], (b, f, got, exp)
     np.testing.assert_array_equal(versions.cpu().numpy(), server.ver)

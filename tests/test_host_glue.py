@@ -1,0 +1,147 @@
+"""Host-side glue that needs no GPU: LAIAScheduler's window over the native scheduler's stream
+(python/hetu/laia/laia_dataloader.py:29-169) and CacheSparseTable's helper surface (python/hetu/cstable.py:170-248),
+driven by in-process doubles of the native objects."""
+import numpy as np
+import pytest
+
+from herald_amd import cache as hcache
+from herald_amd import laia as hlaia
+
+
+class _FakeNative:
+    """Emits plan(0), dist(0), plan(1), dist(1), ... then [0] like LaiaScheduler::launch (laia_scheduler.cc:138-166);
+    `ready` bounds how many messages length() reports as computed."""
+
+    def __init__(self, batches):
+        self.msgs = []
+        for b in range(batches):
+            self.msgs.append([1000 + b])        # plan(b)
+            self.msgs.append([b, b + 100])      # dist(b)
+        self.msgs.append([0])
+        self.ready = len(self.msgs)
+        self.pops = 0
+
+    def pop(self):
+        assert self.ready > 0, "the glue blocked on a scheduler that has nothing ready"
+        self.ready -= 1
+        self.pops += 1
+        return self.msgs.pop(0)
+
+    def length(self):
+        return min(self.ready, len(self.msgs))
+
+
+def _scheduler(batches, dataset_num, monkeypatch, samples=60, batch=10):
+    s = hlaia.LAIAScheduler(np.zeros((samples, 3), dtype=np.float32), batch_size=batch)
+    fake = _FakeNative(batches)
+    monkeypatch.setattr(s, "_native", lambda *a: (fake, fake.pop))
+    s.start(nrank=1, rank=0, cache_limit=8, dataset_num=dataset_num)
+    return s, fake
+
+
+def test_laia_window_pairs_dist_with_the_next_plan(monkeypatch):
+    s, fake = _scheduler(batches=12, dataset_num=1, monkeypatch=monkeypatch)
+    assert (s.samples_num, s.batch_size, s.batch_num) == (60, 10, 6)
+    assert fake.pops == 1 + 2 * s.WINDOW                 # plan(0) dropped, five pairs prefetched
+    for b in range(11):
+        bid = b % s.batch_num
+        assert s.get_input_index(bid) == [b, b + 100]    # dist(b)
+        assert s.get_comm_plan(bid) == [1000 + b + 1]    # travels with plan(b+1)
+        s.step_forward(0)
+    # the stream ended: dist(11) is the last pair, its plan is the terminator -> empty
+    assert s.channel_close
+    assert s.get_input_index(11 % s.batch_num) == [11, 111] and s.get_comm_plan(11 % s.batch_num) == []
+
+
+def test_laia_window_waits_for_the_slowest_loader_and_never_blocks_early(monkeypatch):
+    s, fake = _scheduler(batches=40, dataset_num=3, monkeypatch=monkeypatch)
+    p0 = fake.pops
+    s.step_forward(0)
+    s.step_forward(1)
+    assert fake.pops == p0 and 0 in s._window            # loader 2 still needs batch 0
+    s.step_forward(2)
+    assert fake.pops == p0 + 2 and 0 not in s._window and 5 in s._window
+    # scheduler has nothing computed: the window keeps serving what it holds instead of blocking
+    fake.ready = 0
+    for _ in range(3):
+        for d in range(3):
+            s.step_forward(d)
+    assert fake.pops == p0 + 2 and sorted(s._window) == [1, 2, 3, 4, 5]
+    assert s.get_input_index(4) == [4, 104]
+    # ... until nothing usable is left: then it has to wait for the scheduler (here: the double asserts)
+    for d in range(3):
+        s.step_forward(d)
+    with pytest.raises(AssertionError):
+        for d in range(3):
+            s.step_forward(d)
+    fake.ready = 100
+    for d in range(3):
+        s.step_forward(d)
+    assert s._released >= 5
+
+
+def test_laia_start_only_once_and_batch_size_floor(monkeypatch):
+    s, _ = _scheduler(batches=12, dataset_num=1, monkeypatch=monkeypatch, samples=60, batch=50)
+    assert s.batch_size == 12 and s.batch_num == 5       # at least WINDOW batches per epoch
+    with pytest.raises(RuntimeError):
+        s.start(1, 0, 8)
+    with pytest.raises(ValueError):
+        hlaia.LAIAScheduler(np.zeros((3, 3), dtype=np.float32), batch_size=4).start(1, 0, 8)
+
+
+class _FakeCache:
+    limit, width = 7, 4
+
+    def __init__(self):
+        self.perf = [
+            {"type": "Pull", "is_full": False, "num_all": 10, "num_unique": 8, "num_miss": 8, "num_transfered": 8},
+            {"type": "Push", "is_full": False, "num_all": 10, "num_unique": 8, "num_miss": 0, "num_transfered": 2,
+             "num_evict": 0},
+            {"type": "Pull", "is_full": True, "num_all": 20, "num_unique": 10, "num_miss": 2, "num_transfered": 3},
+            {"type": "Push", "is_full": True, "num_all": 20, "num_unique": 10, "num_miss": 0, "num_transfered": 5,
+             "num_evict": 1},
+        ]
+        self.calls = []
+
+    def bypass(self):
+        self.calls.append("bypass")
+
+    def undo_bypass(self):
+        self.calls.append("undo_bypass")
+
+    def keys(self):
+        return np.array([3, 1, 2], dtype=np.uint64)
+
+    def count(self, k):
+        return int(k in (1, 2, 3))
+
+    def lookup(self, k):
+        return hcache.Embedding(k, 5, np.arange(4, dtype=np.float32)) if self.count(k) else None
+
+    def insert(self, key, embedding=None):
+        self.calls.append(("insert", key, embedding))
+
+    def __repr__(self):
+        return "<Cache : 3/7 , id:0 , width:4 , bound:5 5>"
+
+
+def test_cache_sparse_table_helper_surface():
+    t = hcache.CacheSparseTable.wrap(_FakeCache())
+    assert t.get_perf() is t.perf and len(t.perf) == 4
+    assert t.overall_miss_rate() == pytest.approx(2 / 10)                       # full-cache records only
+    assert t.overall_miss_rate(include_cold_start=True) == pytest.approx(10 / 18)
+    assert t.overall_data_rate() == pytest.approx(8 / 40)
+    assert t.overall_data_rate(include_cold_start=True) == pytest.approx(18 / 60)
+    t.bypass()
+    t.undobypass()
+    e = hcache.Embedding(9, 1, np.ones(4, dtype=np.float32))
+    t.insert(e)
+    assert t.cache.calls == ["bypass", "undo_bypass", ("insert", e, None)]
+    assert t.count(2) == 1 and t.count(9) == 0 and t.lookup(9) is None and t.lookup(1).version == 5
+    assert sorted(int(k) for k in t.keys()) == [1, 2, 3]
+    assert repr(t).startswith("<Cache : 3/7")
+    rt = t.debug_keys()
+    assert rt.shape == (1, 1) and rt[0, 0] == 1.0
+    empty = hcache.CacheSparseTable.wrap(_FakeCache())
+    empty.cache.perf = []
+    assert empty.overall_miss_rate() == -1 and empty.overall_data_rate() == -1

@@ -28,4 +28,4 @@ for k in range(K): step(64 + k)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print("cache tier: %.1f us/step, %.1f M rows/s" % (el / K * 1e6, n * K / el / 1e6))
-print(c.perf() if hasattr(c, "perf") else "")
+print(c.perf if hasattr(c, "perf") else "")
