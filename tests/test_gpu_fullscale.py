@@ -102,6 +102,94 @@ def test_fused_step_on_the_full_table(dev, big_table):
     torch.cuda.synchronize()
 
 
+def _restore(table, keys_all, dev):
+    table[torch.from_numpy(keys_all.astype(np.int64)).to(dev)] = torch.from_numpy(
+        formula.rows_of(keys_all, WIDTH)).to(dev)
+    torch.cuda.synchronize()
+
+
+def _stream_inputs(count, first, seed):
+    batches = _batches(count, first=first)
+    keys_all = np.unique(np.concatenate([cpu.ids_to_keys(f) for f in batches]))
+    assert keys_all.max() > (1 << 24) and keys_all.max() * WIDTH * 4 > (64 << 30)
+    assert (keys_all * WIDTH * 4 > (4 << 30)).sum() > 1000
+    rng = np.random.default_rng(seed)
+    grads = [rng.standard_normal((f.size, WIDTH), dtype=np.float32) for f in batches]
+    cids = [np.searchsorted(keys_all, cpu.ids_to_keys(f)).astype(np.float32) for f in batches]   # < 2^24: exact
+    return batches, keys_all, grads, cids
+
+
+def _check_table(table, keys_all, compact, dev):
+    got = table[torch.from_numpy(keys_all.astype(np.int64)).to(dev)].cpu().numpy()
+    np.testing.assert_array_equal(got, compact, err_msg="updated rows")
+    assert not np.array_equal(compact, formula.rows_of(keys_all, WIDTH))      # the updates were visible
+    sent = table[torch.tensor(SENTINELS, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(sent, formula.rows_of(SENTINELS, WIDTH), err_msg="untouched sentinel rows")
+
+
+def test_one_launch_push_pull_step_on_the_full_table(dev, big_table):
+    """The kernel bench.py times by default (ha_sgd_push_pull_f32ids = ha::step_kernel: in-launch hand-off through
+    the pending tables, its own row addressing and `sc1` loads) on the 69.1 GB table: an 8-batch Criteo stream,
+    every output row of every step, the touched rows, the sentinels, the pending tables drained and no hand-off
+    time-out -- rows beyond the 4 GiB / 64 GiB byte offsets, float32 ids above 2^24."""
+    table = big_table
+    batches, keys_all, grads, cids = _stream_inputs(8, first=300, seed=12)
+    compact = formula.rows_of(keys_all, WIDTH)
+    lr = 0.01
+    n = BATCH * FIELDS
+    plans = [ops.IndexPlan(n, dev), ops.IndexPlan(n, dev)]
+    pends = [ops.PendingTable(dev), ops.PendingTable(dev)]
+    d_ids = [torch.from_numpy(f).to(dev) for f in batches]
+    out = ops.lookup_sort_pend(table, d_ids[0], plans[0], pends[0])
+    for b in range(len(batches)):
+        torch.cuda.synchronize()
+        want_out = cpu.embedding_lookup(compact, cids[b])
+        np.testing.assert_array_equal(out.cpu().numpy(), want_out, err_msg="rows of batch %d" % b)
+        cpu.sgd_sparse_update(compact, cids[b], grads[b], lr)
+        last = b + 1 == len(batches)
+        out = ops.sgd_push_pull(table, plans[b % 2], torch.from_numpy(grads[b]).to(dev), lr, pends[b % 2],
+                                None if last else d_ids[b + 1], None if last else plans[(b + 1) % 2],
+                                None if last else pends[(b + 1) % 2])
+        torch.cuda.synchronize()
+        u, inv, cnt = cpu.unique(cpu.ids_to_keys(batches[b]))
+        pl = plans[b % 2]
+        assert pl.n_unique() == u.size
+        np.testing.assert_array_equal(pl.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, u.astype(np.int64))
+        np.testing.assert_array_equal(pl.counts().cpu().numpy().astype(np.int64), cnt)
+        np.testing.assert_array_equal(pl.inverse().cpu().numpy().astype(np.int64), inv)
+    assert not plans[0].handoff_timed_out() and not plans[1].handoff_timed_out()
+    assert pends[0].is_idle() and pends[1].is_idle()
+    _check_table(table, keys_all, compact, dev)
+    _restore(table, keys_all, dev)
+
+
+def test_lookahead_step_pipeline_on_the_full_table(dev, big_table):
+    """ha_step_* (ops.StepPipeline: ids three batches ahead, rows forwarded from the applying waves) on the 69.1 GB
+    table, same stream shape and checks as the push_pull step."""
+    table = big_table
+    batches, keys_all, grads, cids = _stream_inputs(9, first=400, seed=13)
+    compact = formula.rows_of(keys_all, WIDTH)
+    lr = 0.01
+    pipe = ops.StepPipeline(table, BATCH * FIELDS, lr)
+    d_ids = [torch.from_numpy(f).to(dev) for f in batches]
+    B = len(batches)
+    out = pipe.start(d_ids[0], d_ids[1], d_ids[2])
+    for b in range(B):
+        torch.cuda.synchronize()
+        want_out = cpu.embedding_lookup(compact, cids[b])
+        np.testing.assert_array_equal(out.cpu().numpy().reshape(-1, WIDTH), want_out, err_msg="rows of batch %d" % b)
+        cpu.sgd_sparse_update(compact, cids[b], grads[b], lr)
+        out = pipe.step(torch.from_numpy(grads[b]).to(dev), d_ids[b + 3] if b + 3 < B else None)
+        torch.cuda.synchronize()
+        u, inv, cnt = cpu.unique(cpu.ids_to_keys(batches[b]))
+        pl = pipe.plan_of(b)
+        assert pl.n_unique() == u.size
+        np.testing.assert_array_equal(pl.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, u.astype(np.int64))
+        np.testing.assert_array_equal(pl.counts().cpu().numpy().astype(np.int64), cnt)
+    _check_table(table, keys_all, compact, dev)
+    _restore(table, keys_all, dev)
+
+
 class _LazyRows:
     """Server table of the cache model holding only the rows that were written; the rest is the closed form."""
 
@@ -222,3 +310,147 @@ def test_cold_tier_on_an_8gib_pinned_host_table(dev):
     np.testing.assert_array_equal(table[torch.tensor(probe)].numpy(), formula.rows_of(probe, width))
     tr = store.traffic()
     assert 0 < tr["rows_pulled"] <= tr["keys_synced"] and tr["lines_pushed"] > 0
+
+
+
+def _host_budget_bytes():
+    """Bytes of host DRAM this test may pin: 40 % of MemAvailable, at most 272 GB."""
+    avail = 0
+    with open("/proc/meminfo") as fh:
+        for line in fh:
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    return min(int(avail * 0.4), 272 << 30)
+
+
+def _fill_host_table(table, dev):
+    """formula.rows_of for every row, computed on the GPU chunk by chunk and copied into the pinned table."""
+    rows, width = table.shape
+    c = torch.arange(width, dtype=torch.int64, device=dev)[None, :] * 40503
+    step = max(1, (1 << 26) // width)
+    for s in range(0, rows, step):
+        e = min(rows, s + step)
+        r = torch.arange(s, e, dtype=torch.int64, device=dev)[:, None] * 2654435761
+        v = ((r + c) % 2000003).to(torch.float32)
+        v = v * np.float32(1e-4)
+        table[s:e].copy_(v - np.float32(100.0), non_blocking=True)
+    torch.cuda.synchronize()
+
+
+class _Pinned:
+    """rows x width float32 in page-locked host memory taken straight from hipHostMalloc and given back with
+    hipHostFree: torch's pinned allocator rounds requests up to a power of two and keeps freed blocks, which at
+    these sizes would pin up to twice the budget."""
+
+    def __init__(self, rows, width):
+        import ctypes
+        self.hip = hcache._hip()
+        self.hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        self.hip.hipHostFree.argtypes = [ctypes.c_void_p]
+        self.ptr = ctypes.c_void_p()
+        nbytes = rows * width * 4
+        rc = self.hip.hipHostMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(nbytes), 0)
+        if rc != 0 or not self.ptr.value:
+            pytest.skip("hipHostMalloc of %d GB failed (%d)" % (nbytes >> 30, rc))
+        buf = (ctypes.c_float * (rows * width)).from_address(self.ptr.value)
+        self.tensor = torch.from_numpy(np.ctypeslib.as_array(buf).reshape(rows, width))
+
+    def free(self):
+        self.tensor = None
+        torch.cuda.synchronize()
+        if self.ptr.value:
+            self.hip.hipHostFree(self.ptr)
+            self.ptr.value = None
+
+
+def _cold_tier_run(dev, rows, width, steps, seed, first):
+    pin = _Pinned(rows, width)
+    try:
+        return _cold_tier_body(dev, pin.tensor, rows, width, steps, seed, first)
+    finally:
+        pin.free()
+
+
+def _cold_tier_body(dev, table, rows, width, steps, seed, first):
+    from herald_amd import remote_store
+    n = 22 * 256
+    assert table.is_pinned()
+    _fill_host_table(table, dev)
+    probe0 = [0, 1, rows // 3, rows - 1]
+    np.testing.assert_array_equal(table[torch.tensor(probe0)].numpy(), formula.rows_of(probe0, width))
+    store = remote_store.HostStore(rows, width, dev, table=table)
+    limit = int(0.1 * rows)
+    server = _LazyServer(width)
+    model = cache_model.CacheModel("lru", limit, width, server, 2, 2)
+    gpu = hcache.LRUCache(limit, rows, width, node_id=0, max_batch=n, device=dev)
+    gpu.bind_remote(store)
+    gpu.pull_bound = gpu.push_bound = 2
+    gpu.perf_enabled = True
+    rng = np.random.default_rng(seed)
+    top = 0
+    for k in range(steps):
+        ids = synth.criteo_batch(256, first + k, rows=rows, nfields=22).reshape(-1)      # int64 keys (u64 entry points)
+        top = max(top, int(ids.max()))
+        want = model.lookup(ids.astype(np.uint64))
+        dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+        gpu.embedding_lookup(torch.from_numpy(ids).to(dev), dest).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % k)
+        g = rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01)
+        model.update(ids.astype(np.uint64), g)
+        gpu.embedding_update(torch.from_numpy(ids).to(dev), torch.from_numpy(g).to(dev)).wait()
+        for got, exp in zip(gpu.perf[-2:], model.perf[-2:]):
+            for fld in ("type", "num_all", "num_unique", "num_miss", "num_transfered"):
+                assert got[fld] == exp[fld], (k, fld, got, exp)
+    torch.cuda.synchronize()
+    written = sorted(server.table.rows.keys())
+    assert written
+    np.testing.assert_array_equal(table[torch.tensor(written)].numpy(), np.stack([server.table.rows[k] for k in written]),
+                                  err_msg="host rows after pushes")
+    touched = sorted(server.ver.keys())
+    np.testing.assert_array_equal(store.versions[torch.tensor(touched, device=dev)].cpu().numpy(),
+                                  np.array([server.ver[k] for k in touched], dtype=np.int64))
+    assert int(store.versions.sum().item()) == sum(server.ver.values())
+    probe = [p for p in (1, rows // 2 + 1, rows - 2) if p not in set(written)]
+    np.testing.assert_array_equal(table[torch.tensor(probe)].numpy(), formula.rows_of(probe, width))
+    res = model.resident()
+    assert sorted(int(k) for k in gpu.keys()) == sorted(res.keys())
+    assert gpu.size() == model.policy.size()
+    del gpu, store
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return top, max(written)
+
+
+def test_cold_tier_at_one_billion_rows(dev):
+    """BASELINE configs[4] at its ROW COUNT: length = 1e9 (direct map 4 GB, versions 8 GB in HBM, LRU hot tier of
+    1e8 lines), uint64 ids over the whole key space, the table in pinned host DRAM at d = 64 (256 GB) when the box
+    can pin that much, else at the widest d in {32, 16, 8, 4} that fits 40 % of the free host memory (the index side
+    -- key space, direct map, versions, eviction -- is at full scale either way).  Closed-form table, touched rows,
+    versions and the resident set against oracle/cache_model.py; row offsets beyond 4 GiB (and 64 GiB where d >= 32)."""
+    rows = 1_000_000_000
+    free, _ = torch.cuda.mem_get_info(dev)
+    budget = _host_budget_bytes()
+    width = next((w for w in (64, 32, 16, 8, 4) if rows * w * 4 <= budget), None)
+    # HBM: direct map 4 B + versions 8 B per row, data + gradient lines of the hot tier
+    if width is None or free < rows * 12 + int(0.1 * rows) * width * 8 + (8 << 30):
+        pytest.skip("needs %d GB of pinnable host memory (have budget %d GB) and ~%d GB of HBM"
+                    % (rows * 4 * 4 >> 30, budget >> 30, (rows * 12 + int(0.1 * rows) * 4 * 8) >> 30))
+    top, far = _cold_tier_run(dev, rows, width, steps=6, seed=41, first=900)
+    assert top > 900_000_000                                   # keys from the far end of the key space
+    assert far * width * 4 > (4 << 30)
+    if width >= 32:
+        assert far * width * 4 > (64 << 30)
+    print("configs[4] at rows=1e9: width %d (%d GB pinned)" % (width, rows * width * 4 >> 30))
+
+
+def test_cold_tier_d64_at_the_largest_row_count_that_fits(dev):
+    """configs[4]'s row width (d = 64) at the largest power-of-two-free row count the box can pin (at most 1e9)."""
+    budget = _host_budget_bytes()
+    rows = min(1_000_000_000, budget // 256)
+    if rows == 1_000_000_000:
+        pytest.skip("d = 64 ran at 1e9 rows in test_cold_tier_at_one_billion_rows")
+    if rows < 40_000_000:
+        pytest.skip("needs more than 10 GB of pinnable host memory")
+    top, far = _cold_tier_run(dev, rows, 64, steps=6, seed=43, first=950)
+    assert far * 256 > (8 << 30)
+    print("configs[4] at d=64: rows %d (%d GB pinned)" % (rows, rows * 256 >> 30))
