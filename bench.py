@@ -57,6 +57,11 @@ def parse_args():
                    help="with --launches 1: 3 = ha_step_* (batch k+1 was sorted and finished by earlier launches: "
                         "updated rows are forwarded from the applying waves, nothing waits inside the launch), "
                         "1 = ha_sgd_push_pull_* (in-launch hand-off through pending tables; default: faster today)")
+    p.add_argument("--engine", default=None, choices=("handoff", "forward", "queue"),
+                   help="one-launch step kernel: handoff = ha_sgd_push_pull_* (--lookahead 1), forward = ha_step_* "
+                        "(--lookahead 3), queue = ha_qstep_* (ids three batches ahead; every launch is driven by a work "
+                        "queue the previous launch built, plans sorted + finished by one workgroup in LDS; keys with 16+ "
+                        "occurrences applied as row - tree_sum(lr*g), within BASELINE.json's 1e-5)")
     p.add_argument("--launches", type=int, default=1, choices=(1, 2),
                    help="launches per step: 1 = ha_sgd_push_pull (apply(k) beside lookup(k+1), default), "
                         "2 = ha_lookup_sort + ha_sgd_apply_finish")
@@ -341,7 +346,10 @@ def main():
     n = args.batch * args.fields
     G = max(1, args.graph_steps)
     one = args.launches == 1
-    ahead2 = one and args.lookahead == 3
+    if args.engine is None:
+        args.engine = "forward" if args.lookahead == 3 else "handoff"
+    queue = one and args.engine == "queue"
+    ahead2 = one and args.engine in ("forward", "queue")
     # graphs never straddle the wrap-around of the batch list; ha_step_* rotates four plans and four key tables,
     # so the list is also cut to a multiple of 4 (a graph then depends on k % nb only)
     period = (G * 4 // math.gcd(G, 4)) if ahead2 else G
@@ -365,7 +373,7 @@ def main():
         # batch k+2, stable sort of batch k+3.  Every step applies one batch, looks one batch up, finishes one
         # plan and sorts one batch, as before; sorting the first three batches and looking the first one up is
         # the prologue (untimed).
-        pipe = ops.StepPipeline(table, n, LR)
+        pipe = (ops.QueueStepPipeline if queue else ops.StepPipeline)(table, n, LR)
         plans = pipe.plans
         with torch.cuda.stream(main_s):
             pipe.reset(stream=main_s)
@@ -482,11 +490,13 @@ def main():
     if one:
         # the step IS one launch of ha::step_kernel: its average duration is the HIP-event time of the
         # timed region / K, measured on the launch stream
-        kname = "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
+        kname = "ha::qstep_kernel" if queue else "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
         traffic, traffic_src = pmc_traffic(kname)
         dom_bytes = fwd_b + bwd_b
         ach = dom_bytes / (dev_ms / args.steps * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": kname + (" (SGD apply of batch k, rows of batch k+1, plan finish of "
+        roofline = {"bound": "hbm", "kernel": kname + (" (SGD apply of batch k + rows of batch k+1 from the work queue, "
+                                                       "queue of step k+1, plan of batch k+3)" if queue else
+                                                       " (SGD apply of batch k, rows of batch k+1, plan finish of "
                                                        "batch k+2, sort of batch k+3)" if ahead2 else
                                                        " (SGD apply + finish of batch k, gather + sort of batch k+1)"),
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -557,11 +567,14 @@ def main():
                                "cache-limit-0.1 tier is not part of this line"
                                % (args.batch, args.width, args.fields, args.rows,
                                   args.rows * args.width * 4 / 1e9,
+                                  "one launch from a work queue: apply(k) + rows of k+1 per unique key, queue(k+1), "
+                                  "plan(k+3); keys with 16+ occurrences as row - tree_sum(lr*g)" if queue else
                                   "one launch: apply(k), rows of k+1 forwarded / copied, finish(k+2), sort(k+3)" if ahead2 else
                                   "one launch: apply(k) beside lookup(k+1)" if one else "two launches"),
                    "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,
                    "grad_and_out_buffers": nbuf,
                    "launches_per_step": args.launches, "lookahead_batches": (3 if ahead2 else 1),
+                   "engine": args.engine if one else "two launches",
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
                              else "eager",
                    "parallelism": "1 GPU"},

@@ -106,6 +106,12 @@ def _declare(L):
     L.ha_step_tab_bytes.argtypes = []
     L.ha_step_max_ids.restype = i64
     L.ha_step_max_ids.argtypes = []
+    L.ha_qstep_max_ids.restype = i64
+    L.ha_qstep_max_ids.argtypes = []
+    L.ha_qstep_queue_bytes.restype = sz
+    L.ha_qstep_queue_bytes.argtypes = [i64, i64]
+    L.ha_qstep_queue_header.restype = vp
+    L.ha_qstep_queue_header.argtypes = [vp]
     sigs = {
         "ha_gather_f32ids": [vp, i64, i64, vp, i64, vp, vp],
         "ha_gather_u64ids": [vp, i64, i64, vp, i64, vp, vp],
@@ -153,6 +159,10 @@ def _declare(L):
         "ha_step_tab_reset": [vp, vp],
         "ha_step_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp],
         "ha_step_u64ids": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp],
+        "ha_qstep_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp],
+        "ha_qstep_u64ids": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp],
+        "ha_debug_qstep_timeline": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp,
+                                    vp, vp],
         "ha_debug_step_fwd_timeline": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp,
                                        vp, vp, vp],
     }

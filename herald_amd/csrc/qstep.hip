@@ -1,0 +1,965 @@
+// ha_qstep_*: ONE launch per training step, driven by a WORK QUEUE that earlier launches prepared.
+//
+//   launch c:  [coop items of queue c] [A: plan of batch c+3] [B: queue c+1 from plans c+1, c+2] [wave items of queue c]
+//
+// Same contract as ha_step_* (step.hip): batch c is applied in the reference's occurrence order
+// (cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:51-74), the rows of batch c+1 are those AFTER that
+// update (cpu_EmbeddingLookup, src/dnnl_ops/EmbeddingLookup.cpp:16-35, run behind it), ids are known three batches
+// ahead (the prefetching data loader / the laia scheduler hand them over early, python/hetu/dataloader.py:63-98).
+// What is different is who does the bookkeeping and when:
+//
+//   A  one 1024-thread workgroup sorts a whole batch in LDS (stable LSD radix sort of 16-bit occurrence indices by
+//      9-bit digits of the keys, per-wave ballot multisplit) and finishes its plan in place (unique keys, segment
+//      starts, counts, inverse) -- 16 waves for a few microseconds instead of the 208 rank-by-counting workgroups
+//      + 7 finish workgroups of step.hip, i.e. ~3,300 wave slots less held through the step;
+//   B  one workgroup joins the unique keys of two consecutive batches (binary search in LDS), classifies every key
+//      of their union by its occurrences in the batch to apply (c) and in the batch to look up (m), and writes the
+//      QUEUE of the next launch: one 32-byte item per unit of work, heaviest classes first;
+//   workers  one wave per item, no searching, no probing, no waiting: the item names the key, the column slice,
+//      where the occurrence indices and the destinations are.  A wave applies its key's gradient rows to the table
+//      row it holds in registers, writes the row back and writes it to every output row of the next batch that
+//      names the key (so rows both batches touch are never re-read); keys only the next batch names are plain
+//      copies (c = 0).  ~2,700 + ~2,000 one-wave items per Criteo step instead of 6,656 + 6,656 + 3,328 waves.
+//
+// Item classes (c = occurrences to apply, m = destinations to write):
+//   S  c <= 3 and m <= 16      one wave, <= 512 columns of the row, 16-byte vectors, ordered chain       (bit-exact)
+//   M  c <= 15                 one wave per 128-column slice, 8-byte vectors, ordered chain               (bit-exact)
+//   L  16 <= c < 64            one wave per 32-column slice: lane = (occurrence group r of 8, column quad); every lane
+//                              sums lr*g over its occurrences r, r+8, ... in order, the eight partial sums are added as
+//                              a fixed tree, one subtract                                                  (tolerance)
+//   G  c >= 64                 one WORKGROUP per 64-column slice: wave w takes occurrences 16w..16w+15 of every block
+//                              of 256, partial sums meet in LDS, fixed tree over the waves, one subtract; all 16 waves
+//                              write the destinations                                                      (tolerance)
+//   Z  key beyond the table    zeros to its destinations (the library's definition of such ids)
+// "tolerance": the reference subtracts lr*g occurrence by occurrence (two roundings each); L and G subtract a
+// deterministic tree sum instead -- within the 1e-5 relative the north star allows for accumulated gradients
+// (tests/test_gpu_qstep.py holds both: bit-exact below 16 occurrences, 1e-5 above).  Callers that need the serial
+// chain for every run length use ha_step_* / ha_sgd_push_pull_*.
+#include "plan_dev.h"
+#include "gather_dev.h"
+
+namespace ha {
+
+constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers + counters = 75 KiB of LDS, two workgroups per CU
+constexpr int kQCoopSlots = 48;      // workgroups reserved for G items (they loop if there are more)
+constexpr int kQWorkerMax = 448;     // worker workgroups: with A, B and the coop slots the launch stays below the
+                                     // chip's 512 resident 1024-thread workgroups; the waves loop beyond that
+constexpr int kQDigit = 9, kQBins = 1 << kQDigit;
+constexpr int kQSmallC = 3, kQSmallM = 16, kQMediumC = 15, kQLongC = 64;
+enum QKind { kQS = 0, kQM = 1, kQL = 2, kQZ = 3, kQG = 4, kQNone = 15 };
+
+struct QHeader {
+    uint32_t n_wave, n_coop;
+    uint32_t n_long, n_medium, n_small, n_zero;   // wave items per class (diagnostics, tests)
+    uint32_t reserved[58];
+};
+static_assert(sizeof(QHeader) == 256, "queue header is one 256-byte line");
+struct QEntry {
+    uint32_t w[8];   // kind | col0/4 << 4, key, c | cols/4 << 16, first sorted position (apply batch), m,
+                     // first sorted position (lookup batch), occurrence indices 0..3 as 16-bit halves
+};
+static_assert(sizeof(QEntry) == 32, "queue items are 32 bytes");
+
+struct QLayout {
+    QHeader *hdr;
+    QEntry *coop, *wave;
+    uint32_t cap_coop, cap_wave;
+    size_t bytes;
+};
+static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
+// Bounds (every key owns at least as many positions of the two batches as it has items per 512 columns):
+// wave items <= ceil(width/512) * (n_a + n_g), coop items <= ceil(width/64) * n_a / 64.
+static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
+    QLayout q;
+    char *b = static_cast<char *>(ws);
+    q.cap_coop = static_cast<uint32_t>(ceil_div(width, 64) * (ceil_div(n_cap, kQLongC) + 1));
+    q.cap_wave = static_cast<uint32_t>(ceil_div(width, 512) * 2 * n_cap + 64);
+    q.hdr = reinterpret_cast<QHeader *>(b);
+    q.coop = reinterpret_cast<QEntry *>(b ? b + sizeof(QHeader) : nullptr);
+    q.wave = q.coop ? q.coop + q.cap_coop : nullptr;
+    q.bytes = sizeof(QHeader) + (static_cast<size_t>(q.cap_coop) + q.cap_wave) * sizeof(QEntry);
+    return q;
+}
+
+struct QPlan {   // what the roles read / write of a plan workspace
+    PlanHeader *hdr;
+    uint32_t *keys, *sorted, *uniq;
+    int32_t *perm, *inverse, *counts, *seg, *upos;
+    int n;
+};
+static inline QPlan qplan(void *ws, int64_t n) {
+    QPlan q;
+    memset(&q, 0, sizeof(q));
+    if (ws == nullptr || n <= 0)
+        return q;
+    PlanPtrs p = plan_layout(ws, n);
+    q.hdr = p.hdr; q.keys = p.keys; q.sorted = p.sorted; q.uniq = p.uniq;
+    q.perm = p.perm; q.inverse = p.inverse; q.counts = p.counts; q.seg = p.seg; q.upos = p.upos;
+    q.n = static_cast<int>(n);
+    return q;
+}
+
+struct QArgs {
+    float *table;
+    uint64_t rows;
+    int width;
+    // workers: queue of this launch, occurrence indices of the batch to apply, destinations of the batch to look up
+    const QHeader *qh;
+    const QEntry *qcoop, *qwave;
+    uint32_t cap_coop, cap_wave;
+    const int32_t *perm_a;
+    int n_a;
+    const float *grads;
+    float lr;
+    const int32_t *perm_g;
+    int n_g;
+    float *out;
+    int ncoop, nworker;
+    // A: the batch to sort + finish
+    const void *ahead_ids;
+    QPlan pa;
+    int has_a;
+    // B: the queue to build from (ba, bg)
+    QPlan ba, bg;
+    QHeader *bqh;
+    QEntry *bcoop, *bwave;
+    uint32_t bcap_coop, bcap_wave;
+    int has_b;
+    unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind} per wave
+};
+
+// ---- 1024-thread exclusive scan (two barriers); s_w = 16 words -------------------------------------------------
+__device__ __forceinline__ uint32_t qscan(uint32_t v, uint32_t *s_w, uint32_t *total) {
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o)
+            x += y;
+    }
+    __syncthreads();
+    if (lane == 63)
+        s_w[w] = x;
+    __syncthreads();
+    const uint32_t mine = s_w[lane & 15];
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t t = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine), k));
+        woff += k < w ? t : 0u;
+        tot += t;
+    }
+    *total = tot;
+    return woff + x - v;
+}
+
+// =====================================================================================================
+// Role A: stable sort + plan finish of one batch by ONE workgroup, everything in LDS.
+//   s_key[npad] u32 | s_idx[2][npad] u16 | s_cnt[16][512] u16 | s_dbase[512] u16 | s_w[32] u32
+// =====================================================================================================
+static inline size_t qsort_lds_bytes(int n) {
+    const size_t npad = (static_cast<size_t>(n) + 1023) & ~static_cast<size_t>(1023);
+    return npad * 4 + 2 * npad * 2 + 16 * kQBins * 2 + kQBins * 2 + 32 * 4;
+}
+
+template <typename IdT>
+__device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, const QPlan &p, uint32_t *lds) {
+    const int n = p.n;
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const int npad = (n + 1023) & ~1023;
+    uint32_t *s_key = lds;
+    uint16_t *s_idx = reinterpret_cast<uint16_t *>(lds + npad);
+    uint16_t *s_cnt = s_idx + 2 * npad;
+    uint16_t *s_dbase = s_cnt + 16 * kQBins;
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(s_dbase + kQBins);
+
+    // keys (pads = all ones: they sort behind every real key, see the pass count below) and the widest key
+    uint32_t kmax = 0;
+    for (int base = 0; base < npad; base += 8192) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = base + tid + k * 1024;
+            v[k] = to_key<IdT>(ids[min(j, n - 1)]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = base + tid + k * 1024;
+            if (j < npad) {
+                if (j < n)
+                    kmax = max(kmax, v[k]);
+                s_key[j] = j < n ? v[k] : kPadKey;
+                s_idx[j] = static_cast<uint16_t>(j);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        kmax = max(kmax, static_cast<uint32_t>(__shfl_xor(static_cast<int>(kmax), o, 64)));
+    if (lane == 0)
+        s_w[16 + w] = kmax;
+    __syncthreads();
+    {
+        const uint32_t mine = s_w[16 + (lane & 15)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            kmax = max(kmax, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine), k)));
+    }
+    // Only the digits that can differ between real keys are sorted.  A pad's truncated value is all ones, i.e. >= every
+    // real key's, and pads have the highest indices, so the stable sort leaves them at the end either way.
+    const int bits = 32 - __builtin_clz(kmax | 1u);
+    const int npass = uniform((bits + kQDigit - 1) / kQDigit);
+    const int C = npad >> 4;          // positions per wave, a multiple of 64
+    const int nrow = C >> 6;          // <= 8
+
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = pass * kQDigit;
+        uint16_t *cur = s_idx + (pass & 1) * npad, *nxt = s_idx + ((pass & 1) ^ 1) * npad;
+        for (int i = tid; i < 16 * kQBins / 2; i += 1024)
+            reinterpret_cast<uint32_t *>(s_cnt)[i] = 0;
+        __syncthreads();
+        uint32_t off[8], dig[8], idx[8];
+        uint16_t *my_cnt = s_cnt + w * kQBins;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < nrow) {   // wave-uniform
+                const uint32_t i = cur[w * C + r * 64 + lane];
+                const uint32_t d = (s_key[i] >> shift) & (kQBins - 1);
+                unsigned long long peers = ~0ull;
+#pragma unroll
+                for (int b = 0; b < kQDigit; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const unsigned long long bal = __ballot(bit);
+                    peers &= bit ? bal : ~bal;
+                }
+                const uint32_t below = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
+                const uint32_t old = my_cnt[d];
+                // LDS operations of one wave execute in order: the leader's update lands behind every peer's read
+                // and ahead of the next row's reads
+                if (below == 0)
+                    my_cnt[d] = static_cast<uint16_t>(old + __builtin_popcountll(peers));
+                off[r] = old + below;
+                dig[r] = d;
+                idx[r] = i;
+            }
+        }
+        __syncthreads();
+        // digit-major, wave-minor exclusive scan of the 512 x 16 counters
+        uint32_t total = 0;
+        if (tid < kQBins) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t v = s_cnt[k * kQBins + tid];
+                s_cnt[k * kQBins + tid] = static_cast<uint16_t>(total);
+                total += v;
+            }
+        }
+        uint32_t all;
+        const uint32_t dbase = qscan(total, s_w, &all);
+        if (tid < kQBins)
+            s_dbase[tid] = static_cast<uint16_t>(dbase);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < nrow)
+                nxt[static_cast<uint32_t>(s_dbase[dig[r]]) + my_cnt[dig[r]] + off[r]] = static_cast<uint16_t>(idx[r]);
+        __syncthreads();
+    }
+
+    // ---- finish: one thread per P consecutive sorted positions --------------------------------------------
+    const uint16_t *fin = s_idx + (npass & 1) * npad;
+    uint16_t *s_ui = s_idx + ((npass & 1) ^ 1) * npad;   // unique index of every sorted position
+    uint16_t *s_seg = s_cnt;                             // first position of every unique key, [U + 1]
+    const int P = npad >> 10;                            // <= 8
+    const int q0 = tid * P;
+    uint32_t kprev = q0 > 0 ? s_key[fin[q0 - 1]] : 0u;
+    uint32_t heads = 0, nh = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < P) {
+            const int q = q0 + j;
+            const uint32_t k = s_key[fin[q]];
+            const bool h = q < n && (q == 0 || k != kprev);
+            heads |= h ? (1u << j) : 0u;
+            nh += h;
+            kprev = k;
+        }
+    }
+    uint32_t U;
+    const uint32_t ubase = qscan(nh, s_w, &U);
+    {
+        uint32_t ui = ubase;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < P) {
+                const int q = q0 + j;
+                if (heads & (1u << j)) {
+                    s_seg[ui] = static_cast<uint16_t>(q);
+                    ++ui;
+                }
+                s_ui[q] = static_cast<uint16_t>(ui - 1);   // positions >= n: never read
+            }
+        }
+    }
+    if (tid == 0) {
+        s_seg[U] = static_cast<uint16_t>(n);
+        p.hdr->n_unique = U;
+        p.seg[U] = n;
+    }
+    __syncthreads();
+    for (int q = tid; q < n; q += 1024) {
+        const uint32_t i = fin[q];
+        const int32_t ui = s_ui[q];
+        p.sorted[q] = s_key[i];
+        p.perm[q] = static_cast<int32_t>(i);
+        p.upos[q] = ui;
+        p.inverse[i] = ui;
+        p.keys[q] = s_key[q];
+    }
+    for (uint32_t u = tid; u < U; u += 1024) {
+        const uint32_t q = s_seg[u];
+        p.uniq[u] = s_key[fin[q]];
+        p.seg[u] = static_cast<int32_t>(q);
+        p.counts[u] = static_cast<int32_t>(s_seg[u + 1]) - static_cast<int32_t>(q);
+    }
+}
+
+// =====================================================================================================
+// Role B: the queue of the NEXT launch from the finished plans of its two batches.
+//   s_ua[npad_a] u32 | s_ug[npad_g] u32 | s_w[16] u32
+// =====================================================================================================
+static inline size_t qjoin_lds_bytes(int n_a, int n_g) {
+    return (static_cast<size_t>(n_a) + n_g + 2) * 4 + 32 * 4 + 8 * 1024 * 2;
+}
+
+__device__ __forceinline__ int q_kind(uint32_t c, uint32_t m, bool in_table) {
+    if (!in_table)
+        return m > 0 ? kQZ : kQNone;
+    if (c >= static_cast<uint32_t>(kQLongC))
+        return kQG;
+    if (c > static_cast<uint32_t>(kQMediumC))
+        return kQL;
+    if (c > static_cast<uint32_t>(kQSmallC) || m > static_cast<uint32_t>(kQSmallM))
+        return kQM;
+    return kQS;
+}
+__device__ __forceinline__ int q_slice(int kind) {   // columns per item
+    return kind == kQL ? 32 : kind == kQG ? 64 : kind == kQM ? 128 : 512;
+}
+
+// lower bound of `key` in s[0, n): the index of the first element >= key
+__device__ __forceinline__ int q_lower_bound(const uint32_t *s, int n, uint32_t key) {
+    int pos = 0;
+#pragma unroll
+    for (int step = 8192; step >= 1; step >>= 1)
+        if (pos + step <= n && s[pos + step - 1] < key)
+            pos += step;
+    return pos;
+}
+
+__device__ __forceinline__ void q_emit(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
+                                       uint32_t fs, int width, const int32_t *perm_a, int n_a) {
+    const int slice = q_slice(kind);
+    if (kind == kQZ)
+        c = 0;    // ids beyond the table are never applied; their destinations get zeros
+    uint32_t o01 = 0, o23 = 0;
+    if (kind == kQS && c > 0) {
+        uint32_t o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            o[t] = static_cast<uint32_t>(perm_a[min(static_cast<int>(st) + t, n_a - 1)]);
+        o01 = o[0] | (o[1] << 16);
+        o23 = o[2] | (o[3] << 16);
+    }
+    int j = 0;
+    for (int col0 = 0; col0 < width; col0 += slice, ++j) {
+        const int cols = min(slice, width - col0);
+        uint4 lo, hi;
+        lo.x = static_cast<uint32_t>(kind) | (static_cast<uint32_t>(col0 / 4) << 4);
+        lo.y = key;
+        lo.z = c | (static_cast<uint32_t>(cols / 4) << 16);
+        lo.w = st;
+        hi.x = m;
+        hi.y = fs;
+        hi.z = o01;
+        hi.w = o23;
+        uint4 *d = reinterpret_cast<uint4 *>(dst + j);
+        d[0] = lo;
+        d[1] = hi;
+    }
+}
+
+struct QCount {   // items per class: coop (G), long, medium, small (S and Z)
+    uint32_t g, l, m, s;
+};
+// (selects on VALUES: an if / else chain over four variables is merged into `*select(&x..) += n`, which puts them --
+// and, through the by-reference captures of a lambda, the whole argument block -- into scratch memory)
+__device__ __forceinline__ QCount q_count(QCount t, int kind, uint32_t per512, uint32_t per128, uint32_t per32) {
+    t.g += kind == kQG ? (per32 + 1u) / 2u : 0u;   // 64-column slices: ceil(width / 64)
+    t.l += kind == kQL ? per32 : 0u;
+    t.m += kind == kQM ? per128 : 0u;
+    t.s += (kind == kQS || kind == kQZ) ? per512 : 0u;
+    return t;
+}
+
+__device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const uint64_t rows, const int width,
+                                           QHeader *bqh, QEntry *bcoop, QEntry *bwave, const uint32_t bcap_coop,
+                                           const uint32_t bcap_wave, uint32_t *lds) {
+    const int tid = threadIdx.x;
+    const int Ua = pa.n > 0 ? static_cast<int>(pa.hdr->n_unique) : 0;
+    const int Ug = pg.n > 0 ? static_cast<int>(pg.hdr->n_unique) : 0;
+    uint32_t *s_ua = lds, *s_ug = lds + Ua + 1, *s_w = lds + Ua + Ug + 2;
+    uint16_t *s_match = reinterpret_cast<uint16_t *>(s_w + 32) + tid;   // [round][thread]: thread-private words
+    for (int i = tid; i < Ua; i += 1024)
+        s_ua[i] = pa.uniq[i];
+    for (int i = tid; i < Ug; i += 1024)
+        s_ug[i] = pg.uniq[i];
+    __syncthreads();
+    const uint32_t per512 = (width + 511) / 512, per128 = (width + 127) / 128, per32 = (width + 31) / 32;
+    const int ra = (Ua + 1023) >> 10, rg = (Ug + 1023) >> 10;   // rounds, <= 8 (kQMax <= 8192)
+    // pass 1: what every key of the union costs.  Keys of the batch to apply first (matched against the batch to
+    // look up: the unique index in g or 0xFFFF goes to s_match), then the keys only the lookup names (bit r of
+    // `found` = the key of round r is also in a).
+    uint32_t found = 0;
+    QCount t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < ra) {
+            const int x = r * 1024 + tid;
+            if (x < Ua) {
+                const uint32_t key = s_ua[x];
+                const int y = q_lower_bound(s_ug, Ug, key);
+                const bool hit = y < Ug && s_ug[y] == key;
+                s_match[r * 1024] = static_cast<uint16_t>(hit ? y : 0xFFFF);
+                const uint32_t c = static_cast<uint32_t>(pa.counts[x]);
+                const uint32_t m = hit ? static_cast<uint32_t>(pg.counts[y]) : 0u;
+                t = q_count(t, q_kind(c, m, key < rows), per512, per128, per32);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < rg) {
+            const int y = r * 1024 + tid;
+            if (y < Ug) {
+                const uint32_t key = s_ug[y];
+                const int x = q_lower_bound(s_ua, Ua, key);
+                const bool hit = x < Ua && s_ua[x] == key;
+                found |= hit ? (1u << r) : 0u;
+                if (!hit)
+                    t = q_count(t, q_kind(0u, static_cast<uint32_t>(pg.counts[y]), key < rows), per512, per128, per32);
+            }
+        }
+    }
+    uint32_t nL, nM, nS, nG;
+    QCount b;
+    b.l = qscan(t.l, s_w, &nL);
+    b.m = qscan(t.m, s_w, &nM) + nL;            // queue order: long, medium, small
+    b.s = qscan(t.s, s_w, &nS) + nL + nM;
+    b.g = qscan(t.g, s_w, &nG);
+    if (tid == 0) {
+        bqh->n_wave = min(nL + nM + nS, bcap_wave);
+        bqh->n_coop = min(nG, bcap_coop);
+        bqh->n_long = nL;
+        bqh->n_medium = nM;
+        bqh->n_small = nS;
+        bqh->n_zero = 0;
+    }
+    // pass 2: the items, thread by thread in the order they were counted
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < ra) {
+            const int x = r * 1024 + tid;
+            if (x < Ua) {
+                const uint32_t key = s_ua[x];
+                const uint32_t ym = s_match[r * 1024];
+                const bool hit = ym != 0xFFFFu;
+                const uint32_t c = static_cast<uint32_t>(pa.counts[x]);
+                const uint32_t st = static_cast<uint32_t>(pa.seg[x]);
+                const uint32_t m = hit ? static_cast<uint32_t>(pg.counts[ym]) : 0u;
+                const uint32_t fs = hit ? static_cast<uint32_t>(pg.seg[ym]) : 0u;
+                const int kind = q_kind(c, m, key < rows);
+                if (kind != kQNone) {
+                    const uint32_t at = kind == kQG ? b.g : kind == kQL ? b.l : kind == kQM ? b.m : b.s;
+                    const QCount nb = q_count(b, kind, per512, per128, per32);
+                    const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
+                    b = nb;
+                    // the layout's bound makes the test always true; never write beyond the queue
+                    if (at + cnt <= (kind == kQG ? bcap_coop : bcap_wave))
+                        q_emit((kind == kQG ? bcoop : bwave) + at, kind, key, c, st, m, fs, width, pa.perm, pa.n);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < rg) {
+            const int y = r * 1024 + tid;
+            if (y < Ug && !(found & (1u << r))) {
+                const uint32_t key = s_ug[y];
+                const uint32_t m = static_cast<uint32_t>(pg.counts[y]);
+                const int kind = q_kind(0u, m, key < rows);
+                if (kind != kQNone) {
+                    const uint32_t at = kind == kQM ? b.m : b.s;     // c == 0: medium (many destinations), small or zero
+                    const QCount nb = q_count(b, kind, per512, per128, per32);
+                    const uint32_t cnt = (nb.m - b.m) + (nb.s - b.s);
+                    b = nb;
+                    if (at + cnt <= bcap_wave)
+                        q_emit(bwave + at, kind, key, 0u, 0u, m, static_cast<uint32_t>(pg.seg[y]), width, pa.perm, pa.n);
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// Workers
+// =====================================================================================================
+typedef float float2v_ __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float4v sgd4(float4v acc, float4v g, float lr) {
+    float4v r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __fsub_rn(acc[k], __fmul_rn(lr, g[k]));
+    return r;
+}
+__device__ __forceinline__ float4v acc4(float4v p, float4v g, float lr) {   // p + lr * g, two roundings
+    float4v r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __fadd_rn(p[k], __fmul_rn(lr, g[k]));
+    return r;
+}
+__device__ __forceinline__ float4v add4(float4v x, float4v y) {
+    float4v r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __fadd_rn(x[k], y[k]);
+    return r;
+}
+__device__ __forceinline__ float4v sub4(float4v x, float4v y) {
+    float4v r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __fsub_rn(x[k], y[k]);
+    return r;
+}
+__device__ __forceinline__ float4v shfl_xor4(float4v v, int mask) {
+    float4v r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __shfl_xor(v[k], mask, 64);
+    return r;
+}
+
+struct QItem {
+    int kind, col0, cols;
+    uint32_t key, c, st, m, fs, o01, o23;
+};
+__device__ __forceinline__ QItem q_load(const QEntry *e) {
+    // the address is wave-uniform: scalar loads
+    const uint4 lo = reinterpret_cast<const uint4 *>(e)[0], hi = reinterpret_cast<const uint4 *>(e)[1];
+    QItem it;
+    it.kind = static_cast<int>(uniform(lo.x & 15u));
+    it.col0 = static_cast<int>(uniform(lo.x >> 4)) * 4;
+    it.key = uniform(lo.y);
+    it.c = uniform(lo.z & 0xFFFFu);
+    it.cols = static_cast<int>(uniform(lo.z >> 16)) * 4;
+    it.st = uniform(lo.w);
+    it.m = uniform(hi.x);
+    it.fs = uniform(hi.y);
+    it.o01 = uniform(hi.z);
+    it.o23 = uniform(hi.w);
+    return it;
+}
+
+// S / Z: <= 512 columns by one wave, c <= 3 occurrences, two 16-byte vectors per lane
+__device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
+    const int lane = lane_id();
+    const int width = a.width;
+    const int ca = it.col0 + 4 * lane, cb = ca + 256;
+    const bool a0 = 4 * lane < it.cols, a1 = 256 + 4 * lane < it.cols;
+    const int la = a0 ? ca : it.col0, lb = a1 ? cb : it.col0;   // loads stay branch-free: clamped columns
+    float *row = a.table + static_cast<uint64_t>(it.kind == kQZ ? 0u : it.key) * static_cast<uint64_t>(width);
+    float4v r0{0.f, 0.f, 0.f, 0.f}, r1{0.f, 0.f, 0.f, 0.f};
+    if (it.kind != kQZ) {   // every branch on the item is wave-uniform
+        r0 = ld4(row + la);
+        r1 = ld4(row + lb);
+    }
+    int dv = 0;
+    if (it.m > 0)
+        dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
+    float4v g0[kQSmallC], g1[kQSmallC];
+#pragma unroll
+    for (int t = 0; t < kQSmallC; ++t) {
+        if (static_cast<uint32_t>(t) < it.c) {
+            const uint32_t o = t == 0 ? (it.o01 & 0xFFFFu) : t == 1 ? (it.o01 >> 16) : (it.o23 & 0xFFFFu);
+            const float *src = a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width);
+            g0[t] = ld4(src + la);
+            g1[t] = ld4(src + lb);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kQSmallC; ++t) {
+        if (static_cast<uint32_t>(t) < it.c) {
+            r0 = sgd4(r0, g0[t], a.lr);
+            r1 = sgd4(r1, g1[t], a.lr);
+        }
+    }
+    if (it.c > 0) {
+        if (a0)
+            st4_nt(row + ca, r0);
+        if (a1)
+            st4_nt(row + cb, r1);
+    }
+    for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
+        if (j0 > 0)
+            dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
+        const int cnt = static_cast<int>(min(64u, it.m - j0));
+        for (int j = 0; j < cnt; ++j) {
+            float *o = a.out + static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(dv, j))) *
+                                   static_cast<uint64_t>(width);
+            if (a0)
+                st4_nt(o + ca, r0);
+            if (a1)
+                st4_nt(o + cb, r1);
+        }
+    }
+}
+
+// M: one 128-column slice, c <= 15 occurrences, 8 bytes per lane, ordered chain
+__device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
+    const int lane = lane_id();
+    const int width = a.width;
+    const int col = it.col0 + 2 * lane;
+    const bool act = 2 * lane < it.cols;
+    const int lc = act ? col : it.col0;
+    float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
+    int pidx = 0, dv = 0;
+    if (it.c > 0)
+        pidx = a.perm_a[it.st + min(static_cast<uint32_t>(lane), it.c - 1u)];
+    if (it.m > 0)
+        dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
+    float2v_ r = *reinterpret_cast<const float2v_ *>(row + lc);
+    // branch-free: lanes >= c hold the index of the last occurrence, so the loads beyond c repeat a line the wave
+    // has just asked for and the chain skips them by select (uniform branches around 15 loads make the compiler
+    // spill; clamped loads are what scatter_dev.h does as well)
+    float2v_ g[kQMediumC];
+    const float *gbase = it.c > 0 ? a.grads : a.table;   // c == 0: a pure copy, nothing is applied
+#pragma unroll
+    for (int t = 0; t < kQMediumC; ++t) {
+        const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(pidx, t));
+        g[t] = *reinterpret_cast<const float2v_ *>(gbase + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + lc);
+    }
+#pragma unroll
+    for (int t = 0; t < kQMediumC; ++t) {
+        const float x0 = __fsub_rn(r[0], __fmul_rn(a.lr, g[t][0]));
+        const float x1 = __fsub_rn(r[1], __fmul_rn(a.lr, g[t][1]));
+        const bool on = static_cast<uint32_t>(t) < it.c;
+        r[0] = on ? x0 : r[0];
+        r[1] = on ? x1 : r[1];
+    }
+    if (it.c > 0 && act)
+        __builtin_nontemporal_store(r, reinterpret_cast<float2v_ *>(row + col));
+    for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
+        if (j0 > 0)
+            dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
+        const int cnt = static_cast<int>(min(64u, it.m - j0));
+        for (int j = 0; j < cnt; ++j) {
+            float *o = a.out + static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(dv, j))) *
+                                   static_cast<uint64_t>(width);
+            if (act)
+                __builtin_nontemporal_store(r, reinterpret_cast<float2v_ *>(o + col));
+        }
+    }
+}
+
+// L: one 32-column slice, 16 <= c < 64: lane = (occurrence group r of 8, column quad c4); fixed-order tree
+__device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
+    const int lane = lane_id();
+    const int width = a.width;
+    const int r = lane >> 3, c4 = lane & 7;
+    const bool act = 4 * c4 < it.cols;
+    const int col = it.col0 + (act ? 4 * c4 : 0);
+    float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
+    const int pidx = a.perm_a[it.st + min(static_cast<uint32_t>(lane), it.c - 1u)];
+    int dv = 0;
+    if (it.m > 0)
+        dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
+    const float4v cur = ld4(row + col);
+    float4v g[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const uint32_t occ = static_cast<uint32_t>(8 * t + r);
+        const uint32_t o = static_cast<uint32_t>(__shfl(pidx, static_cast<int>(min(occ, it.c - 1u)), 64));
+        g[t] = ld4(a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + col);   // branch-free (clamped)
+    }
+    float4v p{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float4v q = acc4(p, g[t], a.lr);
+        const bool valid = static_cast<uint32_t>(8 * t + r) < it.c;
+        p = valid ? q : p;
+    }
+    p = add4(p, shfl_xor4(p, 8));
+    p = add4(p, shfl_xor4(p, 16));
+    p = add4(p, shfl_xor4(p, 32));
+    const float4v nv = sub4(cur, p);
+    if (r == 0 && act)
+        st4_nt(row + col, nv);
+    for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
+        if (j0 > 0)
+            dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
+        const uint32_t cnt = min(64u, it.m - j0);
+        for (uint32_t j = 0; j < cnt; j += 8) {
+            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(min(j + r, cnt - 1u)), 64));
+            if (j + r < cnt && act)
+                st4_nt(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+        }
+    }
+}
+
+// G: one 64-column slice by a whole workgroup, c >= 64.  lane = (row r of 4, column quad c4 of 16); wave w takes
+// occurrences 16w .. 16w+15 of every block of 256 (four 16-byte loads per lane and block).  s_part = 16 x 64 floats.
+__device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s_part) {
+    const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
+    const int width = a.width;
+    const int r = lane >> 4, c4 = lane & 15;
+    const bool act = 4 * c4 < it.cols;
+    const int col = it.col0 + (act ? 4 * c4 : 0);
+    float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
+    const float4v cur = ld4(row + col);
+    // destinations of this wave: j = 64 * k + 4 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 2, l & 3):
+    // one register covers the first 16 rounds (1,024 destinations)
+    int dv = 0;
+    if (it.m > 0)
+        dv = a.perm_g[it.fs + min(static_cast<uint32_t>(64 * (lane >> 2) + 4 * w + (lane & 3)), it.m - 1u)];
+    float4v p{0.f, 0.f, 0.f, 0.f};
+    for (uint32_t base = 0; base < it.c; base += 256) {
+        const uint32_t mine = base + 16u * static_cast<uint32_t>(w);   // this wave's first occurrence of the block
+        if (mine >= it.c)
+            break;   // wave-uniform; no barrier inside the loop
+        const int pidx = a.perm_a[it.st + min(mine + static_cast<uint32_t>(lane & 15), it.c - 1u)];
+        float4v g[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t o = static_cast<uint32_t>(__shfl(pidx, 4 * t + r, 64));
+            g[t] = ld4(a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + col);   // branch-free (clamped)
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4v q = acc4(p, g[t], a.lr);
+            const bool valid = mine + static_cast<uint32_t>(4 * t + r) < it.c;
+            p = valid ? q : p;
+        }
+    }
+    p = add4(p, shfl_xor4(p, 16));
+    p = add4(p, shfl_xor4(p, 32));
+    if (lane < 16)
+        *reinterpret_cast<float4v *>(s_part + w * 64 + 4 * c4) = p;
+    __syncthreads();
+    // fixed tree over the 16 wave partials: lane group r adds the partials of waves 4r .. 4r+3 as (a + b) + (c + d),
+    // the four group sums meet by two butterfly steps -- ((q0 + q1) + (q2 + q3)) in every lane (IEEE addition
+    // commutes, so both partners of a step hold the same bits)
+    const float *sp = s_part + (4 * r) * 64 + 4 * c4;
+    float4v total = add4(add4(*reinterpret_cast<const float4v *>(sp), *reinterpret_cast<const float4v *>(sp + 64)),
+                         add4(*reinterpret_cast<const float4v *>(sp + 128), *reinterpret_cast<const float4v *>(sp + 192)));
+    total = add4(total, shfl_xor4(total, 16));
+    total = add4(total, shfl_xor4(total, 32));
+    const float4v nv = sub4(cur, total);
+    if (w == 0 && r == 0 && act)
+        st4_nt(row + col, nv);
+    for (uint32_t k0 = 0; k0 * 64u < it.m; k0 += 16) {
+        if (k0 > 0)
+            dv = a.perm_g[it.fs + min(64u * (k0 + static_cast<uint32_t>(lane >> 2)) + static_cast<uint32_t>(4 * w + (lane & 3)),
+                                      it.m - 1u)];
+        const uint32_t rounds = min(16u, (it.m - 64u * k0 + 63u) / 64u);
+        for (uint32_t k = 0; k < rounds; ++k) {
+            const uint32_t j = 64u * (k0 + k) + static_cast<uint32_t>(4 * w + r);
+            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(4 * k) + r, 64));
+            if (j < it.m && act)
+                st4_nt(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+        }
+    }
+    __syncthreads();   // s_part is reused by the next item of this workgroup
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    int role, kind = -1;
+    int b = blockIdx.x;
+    if (b < a.ncoop) {
+        role = 0;
+        const uint32_t n = a.qh->n_coop;
+        for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
+            const QItem it = q_load(a.qcoop + e);
+            q_coop(a, it, reinterpret_cast<float *>(s_dyn));
+            kind = it.kind;
+        }
+    } else if ((b -= a.ncoop) == 0 && a.has_a) {
+        role = 1;
+        qsort_finish_body<IdT>(static_cast<const IdT *>(a.ahead_ids), a.pa, s_dyn);
+    } else if ((b -= a.has_a) == 0 && a.has_b) {
+        role = 2;
+        qjoin_body(a.ba, a.bg, a.rows, a.width, a.bqh, a.bcoop, a.bwave, a.bcap_coop, a.bcap_wave, s_dyn);
+    } else {
+        b -= a.has_b;
+        role = 3;
+        const uint32_t n = a.qh ? a.qh->n_wave : 0u;
+        const uint32_t stride = static_cast<uint32_t>(a.nworker) * 16u;
+        const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
+        for (uint32_t e = static_cast<uint32_t>(b) * 16u + wv; e < n; e += stride) {
+            const QItem it = q_load(a.qwave + e);
+            kind = it.kind;
+            if (it.kind == kQL)
+                q_long(a, it);
+            else if (it.kind == kQM)
+                q_medium(a, it);
+            else
+                q_small(a, it);
+        }
+    }
+    if (a.dbg) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (lane_id() == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long *d = a.dbg + (static_cast<size_t>(blockIdx.x) * 16 + (threadIdx.x >> 6)) * 4;
+            d[0] = t0;
+            d[1] = t1;
+            d[2] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8);
+            d[3] = static_cast<unsigned long long>(static_cast<unsigned>(kind));
+        }
+    }
+}
+
+template <typename IdT>
+static int qstep(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                 float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, void *plan_b1,
+                 int64_t n_b1, void *queue_build, int64_t queue_n_cap, const IdT *ahead_ids, int64_t n_ahead,
+                 void *plan_ahead, hipStream_t stream, unsigned long long *dbg = nullptr) {
+    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
+                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
+               "ha_qstep: the table must be 16-byte aligned with rows of a multiple of 4 floats");
+    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && n_b1 >= 0 && n_ahead >= 0 && n_cur <= kQMax && n_next <= kQMax &&
+                   n_b1 <= kQMax && n_ahead <= kQMax && queue_n_cap >= 1 && queue_n_cap <= kQMax &&
+                   n_cur <= queue_n_cap && n_next <= queue_n_cap && n_b1 <= queue_n_cap,
+               "ha_qstep: at most %d ids per batch and no more than the queues were sized for "
+               "(larger batches: ha_step_* / ha_lookup_sort_* + ha_sgd_apply_finish)", kQMax);
+    HA_REQUIRE(n_cur == 0 || (plan_cur && grads && reinterpret_cast<uintptr_t>(grads) % 16 == 0),
+               "ha_qstep: current batch needs its plan and 16-byte aligned gradients");
+    HA_REQUIRE(n_next == 0 || (plan_next && next_out && reinterpret_cast<uintptr_t>(next_out) % 16 == 0),
+               "ha_qstep: next batch needs its plan and a 16-byte aligned output");
+    HA_REQUIRE((n_cur == 0 && n_next == 0) || queue_cur, "ha_qstep: the queue of this launch is missing");
+    HA_REQUIRE((n_next == 0 && n_b1 == 0) || queue_build, "ha_qstep: the queue to build is missing");
+    HA_REQUIRE(n_b1 == 0 || plan_b1, "ha_qstep: null pointer (batch after next)");
+    HA_REQUIRE(n_ahead == 0 || (ahead_ids && plan_ahead), "ha_qstep: null pointer (batch ahead)");
+    QArgs a;
+    memset(&a, 0, sizeof(a));
+    a.table = table;
+    a.rows = static_cast<uint64_t>(rows);
+    a.width = static_cast<int>(width);
+    a.lr = lr;
+    a.dbg = dbg;
+    size_t lds = 0;
+    if (n_cur > 0 || n_next > 0) {
+        const QLayout q = queue_layout(const_cast<void *>(queue_cur), queue_n_cap, width);
+        a.qh = q.hdr;
+        a.qcoop = q.coop;
+        a.qwave = q.wave;
+        a.cap_coop = q.cap_coop;
+        a.cap_wave = q.cap_wave;
+        a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
+        a.n_a = static_cast<int>(n_cur);
+        a.grads = grads;
+        a.perm_g = n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr;
+        a.n_g = static_cast<int>(n_next);
+        a.out = next_out;
+        a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
+        // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
+        const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
+        a.nworker = static_cast<int>(bound / 16 + 1 < kQWorkerMax ? bound / 16 + 1 : kQWorkerMax);
+        lds = 16 * 64 * 4;
+    }
+    if (n_ahead > 0) {
+        a.ahead_ids = ahead_ids;
+        a.pa = qplan(plan_ahead, n_ahead);
+        a.has_a = 1;
+        lds = lds > qsort_lds_bytes(a.pa.n) ? lds : qsort_lds_bytes(a.pa.n);
+    }
+    if (n_next > 0 || n_b1 > 0) {
+        a.ba = qplan(plan_next, n_next);
+        a.bg = qplan(plan_b1, n_b1);
+        const QLayout q = queue_layout(queue_build, queue_n_cap, width);
+        a.bqh = q.hdr;
+        a.bcoop = q.coop;
+        a.bwave = q.wave;
+        a.bcap_coop = q.cap_coop;
+        a.bcap_wave = q.cap_wave;
+        a.has_b = 1;
+        lds = lds > qjoin_lds_bytes(a.ba.n, a.bg.n) ? lds : qjoin_lds_bytes(a.ba.n, a.bg.n);
+    }
+    const unsigned blocks = static_cast<unsigned>(a.ncoop + a.has_a + a.has_b + a.nworker);
+    if (blocks == 0)
+        return 0;
+    static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
+    if (lds_allowed.first())
+        HA_ALLOW_LDS((qstep_kernel<IdT>), 160 * 1024);
+    hipLaunchKernelGGL((qstep_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ha
+
+using namespace ha;
+
+extern "C" int64_t ha_qstep_max_ids(void) { return kQMax; }
+
+extern "C" size_t ha_qstep_queue_bytes(int64_t n_cap, int64_t width) {
+    if (n_cap < 1 || width < 4)
+        return 0;
+    return queue_layout(nullptr, n_cap, width).bytes;
+}
+
+extern "C" int ha_qstep_f32ids(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                               const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out,
+                               const void *queue_cur, void *plan_b1, int64_t n_b1, void *queue_build,
+                               int64_t queue_n_cap, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               ha_stream_t stream) {
+    return qstep<float>(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur,
+                        plan_b1, n_b1, queue_build, queue_n_cap, ahead_ids, n_ahead, plan_ahead, as_stream(stream));
+}
+
+extern "C" int ha_qstep_u64ids(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                               const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out,
+                               const void *queue_cur, void *plan_b1, int64_t n_b1, void *queue_build,
+                               int64_t queue_n_cap, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               ha_stream_t stream) {
+    return qstep<uint64_t>(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur,
+                           plan_b1, n_b1, queue_build, queue_n_cap, ahead_ids, n_ahead, plan_ahead,
+                           as_stream(stream));
+}
+
+// development aid: ha_qstep_f32ids with per-wave time stamps; dbg = device uint64[blocks * 16 * 4] (zeroed)
+extern "C" int ha_debug_qstep_timeline(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                                       const float *grads, float lr, void *plan_next, int64_t n_next,
+                                       float *next_out, const void *queue_cur, void *plan_b1, int64_t n_b1,
+                                       void *queue_build, int64_t queue_n_cap, const float *ahead_ids,
+                                       int64_t n_ahead, void *plan_ahead, unsigned long long *dbg,
+                                       ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "qstep timeline: null debug buffer");
+    return qstep<float>(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur,
+                        plan_b1, n_b1, queue_build, queue_n_cap, ahead_ids, n_ahead, plan_ahead, as_stream(stream),
+                        dbg);
+}
+
+// queue header of a built queue: {n_wave, n_coop, n_long, n_medium, n_small} (tests / tools; device pointer)
+extern "C" const uint32_t *ha_qstep_queue_header(const void *queue) {
+    return reinterpret_cast<const uint32_t *>(queue);
+}

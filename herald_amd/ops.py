@@ -607,6 +607,102 @@ class StepPipeline:
         return self._call(self.c, grads, ahead_ids, out, stream)
 
 
+def qstep_max_ids():
+    return int(_lib.load().ha_qstep_max_ids())
+
+
+class QueueStepPipeline(StepPipeline):
+    """StepPipeline over ha_qstep_* (include/herald_amd.h, csrc/qstep.hip): the same stream protocol --
+
+        pipe = QueueStepPipeline(table, capacity, lr)
+        out0 = pipe.start(ids0, ids1, ids2)           # rows of batch 0 (three launches)
+        out1 = pipe.step(grads0, ids3)                # apply 0, rows of batch 1, plan of batch 3   (one launch)
+
+    -- but every launch is driven by a work queue the previous launch prepared (one wave per unique key / column
+    slice, no probing, no waiting), the plan of a batch is sorted and finished by one workgroup in LDS, and keys
+    with 16 or more occurrences in a batch are applied as `row - tree_sum(lr * g)` (deterministic, within the 1e-5
+    relative BASELINE.json allows for accumulated gradients) instead of the serial chain; below 16 occurrences the
+    result is the reference's bit for bit.  `plan_of(j)` is complete (unique keys / inverse / counts) as soon as the
+    call that sorts batch j has run, i.e. three calls before batch j is applied."""
+
+    NQUEUE = 2
+
+    def __init__(self, table, capacity, lr, device=None):
+        L = _lib.load()
+        _require(table, torch.float32, "table")
+        self.table, self.lr = table, float(lr)
+        self.device = table.device if device is None else torch.device(device)
+        if capacity > qstep_max_ids():
+            raise ValueError("ha_qstep_* takes at most %d ids per batch (got capacity %d): use StepPipeline / "
+                             "sgd_push_pull / lookup_sort + sgd_apply_finish" % (qstep_max_ids(), capacity))
+        if table.shape[1] % 4 != 0:
+            raise ValueError("ha_qstep_* needs rows of a multiple of 4 floats")
+        self.capacity = max(int(capacity), 1)
+        self.plans = [IndexPlan(self.capacity, self.device) for _ in range(self.NPLAN)]
+        self.queue_bytes = int(L.ha_qstep_queue_bytes(self.capacity, table.shape[1]))
+        self.queues = torch.empty(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
+        self.c, self.n, self.shape = None, {}, {}
+
+    def _queue(self, c):
+        return self.queues.data_ptr() + (c % self.NQUEUE) * self.queue_bytes
+
+    def reset(self, stream=None):
+        self.c, self.n, self.shape = None, {}, {}
+        return self
+
+    def step(self, grads, ahead_ids=None, out=None, stream=None):
+        """Applies `grads` of the current batch (None if that batch is empty); returns the rows of the next batch
+        (None at the end of the stream or if the next batch is empty)."""
+        if self.c is None:
+            raise RuntimeError("QueueStepPipeline.step before start")
+        return self._call(self.c, grads, ahead_ids, out, stream)
+
+    def queue_header(self, c):
+        """{wave items, workgroup items, long, medium, small} of the queue call c reads (host copy; synchronises)."""
+        off = (c % self.NQUEUE) * self.queue_bytes
+        torch.cuda.synchronize(self.device)
+        h = self.queues[off:off + 20].view(torch.int32).cpu().tolist()
+        return dict(zip(("wave_items", "workgroup_items", "long", "medium", "small"), h))
+
+    def launch(self, c, n_cur, grads, n_next, out, n_fin, ahead_ids, stream=None, dbg=None):
+        """Call c, stateless: batch c (n_cur ids) is applied from queue c, the rows of batch c+1 (n_next ids) go to
+        `out`, queue c+1 is built from the plans of batches c+1 and c+2 (n_fin ids), `ahead_ids` = batch c+3 is
+        sorted and finished."""
+        L = _lib.load()
+        t = self.table
+        width = t.shape[1]
+        n_ahead = 0 if ahead_ids is None else ahead_ids.numel()
+        if max(n_cur, n_next, n_fin, n_ahead) > self.capacity:
+            raise ValueError("plan capacity %d < %d ids" % (self.capacity, max(n_cur, n_next, n_fin, n_ahead)))
+        if n_cur:
+            _require(grads, torch.float32, "grads")
+            if grads.numel() != n_cur * width:
+                raise ValueError("grads must hold %d x %d values" % (n_cur, width))
+        if n_next:
+            _require(out, torch.float32, "out")
+            if out.numel() != n_next * width:
+                raise ValueError("out must hold %d x %d values" % (n_next, width))
+        kind = _ids_kind(ahead_ids) if n_ahead else "f32ids"
+        args = [_ptr(t), t.shape[0], width,
+                _ptr(self.plan_of(c).ws) if n_cur else None, n_cur, _ptr(grads) if n_cur else None,
+                ctypes.c_float(self.lr),
+                _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
+                self._queue(c) if (n_cur or n_next) else None,
+                _ptr(self.plan_of(c + 2).ws) if n_fin else None, n_fin,
+                self._queue(c + 1) if (n_next or n_fin) else None, self.capacity,
+                _ptr(ahead_ids) if n_ahead else None, n_ahead,
+                _ptr(self.plan_of(c + 3).ws) if n_ahead else None]
+        if dbg is None:
+            check(getattr(L, "ha_qstep_" + kind)(*args, _stream_ptr(stream)), "ha_qstep")
+        else:
+            check(L.ha_debug_qstep_timeline(*args, _ptr(dbg), _stream_ptr(stream)), "ha_debug_qstep_timeline")
+        if n_ahead:
+            pl = self.plan_of(c + 3)
+            pl.n = n_ahead
+            pl._view = None
+            pl.produced_on(stream)
+
+
 def push_apply_finish(table, plan, grads, stream=None):
     _require(table, torch.float32, "table")
     _require(grads, torch.float32, "grads")

@@ -439,6 +439,48 @@ int ha_debug_step_fwd_timeline(float *table, int64_t rows, int64_t width,
                                const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
                                void *tab_clear, unsigned long long *dbg, ha_stream_t stream);
 
+/* The same step driven by a WORK QUEUE that earlier launches prepared (csrc/qstep.hip): call c
+ *   - applies the gradients of batch c and writes the rows of batch c+1 after that update, item by item from
+ *     QUEUE c: one wave per (unique key, column slice) that applies the key's occurrences to the row it holds
+ *     in registers, writes the row back and writes it to every output row of batch c+1 naming the key; keys
+ *     only batch c+1 names are copies.  No probing, no waiting, no key tables;
+ *   - builds QUEUE c+1 from the finished plans of batches c+1 (plan_next) and c+2 (plan_b1) -- one workgroup;
+ *   - sorts AND finishes the plan of batch c+3 (ahead_ids -> plan_ahead: sorted keys, occurrence indices,
+ *     unique keys, counts, inverse == ha_plan_build_*) -- one workgroup, an LDS radix sort.
+ * Semantics and references as ha_step_* above (cpu_SGDOptimizerSparseUpdate, Optimizers.cpp:51-74;
+ * cpu_EmbeddingLookup, EmbeddingLookup.cpp:16-35), with ONE difference: keys with fewer than 16 occurrences in
+ * the batch take the reference's serial chain row = (row - lr*g0) - lr*g1 ... bit for bit; a key with 16 or more
+ * occurrences takes row - T, T = a fixed (deterministic) tree sum of the lr*g_i -- within the 1e-5 relative that
+ * BASELINE.json's north star allows for accumulated gradients, not bit-identical to the serial chain.  Integer
+ * results (plans) are exact.  Callers that need the serial chain for every run length use ha_step_*.
+ * A stream of batches 0..B-1 is driven as calls c = -3 .. B-1 (n = 0 / null for batches outside [0, B)); four
+ * plans rotate (c .. c+3) and two queues alternate: call c reads queue_cur = Q[c % 2], which call c-1 wrote as
+ * its queue_build, and writes Q[(c+1) % 2].  Each queue is ha_qstep_queue_bytes(n_cap, width) bytes (no
+ * initialisation needed); queue_n_cap = the n_cap both queues were sized with.  Limits: at most
+ * ha_qstep_max_ids() ids per batch, width % 4 == 0, table / grads / next_out 16-byte aligned. */
+int64_t ha_qstep_max_ids(void);
+size_t ha_qstep_queue_bytes(int64_t n_cap, int64_t width);
+int ha_qstep_f32ids(float *table, int64_t rows, int64_t width,
+                    void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                    void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                    void *plan_b1, int64_t n_b1, void *queue_build, int64_t queue_n_cap,
+                    const float *ahead_ids, int64_t n_ahead, void *plan_ahead, ha_stream_t stream);
+int ha_qstep_u64ids(float *table, int64_t rows, int64_t width,
+                    void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                    void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                    void *plan_b1, int64_t n_b1, void *queue_build, int64_t queue_n_cap,
+                    const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead, ha_stream_t stream);
+/* a built queue's first words (device memory): {wave items, workgroup items, long, medium, small items} */
+const uint32_t *ha_qstep_queue_header(const void *queue);
+/* development aid (tools/qstep_timeline.py): ha_qstep_f32ids with per-wave time stamps,
+ * dbg = device uint64[(number of workgroups) * 16 * 4], zeroed */
+int ha_debug_qstep_timeline(float *table, int64_t rows, int64_t width,
+                            void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                            void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                            void *plan_b1, int64_t n_b1, void *queue_build, int64_t queue_n_cap,
+                            const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                            unsigned long long *dbg, ha_stream_t stream);
+
 /* ha_sgd_apply_finish that also warms the memory-side cache for the NEXT batch: waves that have no
  * medium / long-run work (more than half of them) end by touching the table row that position p of
  * next_ids will gather, so the ha_lookup_sort_* / ha_gather_* that follows reads it from the

@@ -1,0 +1,95 @@
+"""TEST INFRASTRUCTURE ONLY (imported by tests/ and tools/, never by herald_amd/): numpy model of the
+floating-point order of ha_qstep_* (herald_amd/csrc/qstep.hip).
+
+The reference applies a sparse SGD step occurrence by occurrence, `row[j] -= lr * g[i][j]` in the order the ids
+appear (cpu_SGDOptimizerSparseUpdate, /root/reference/src/dnnl_ops/Optimizers.cpp:65-72).  ha_qstep_* keeps that
+serial chain for keys with fewer than 16 occurrences in a batch and subtracts a fixed TREE SUM of the lr * g_i for
+keys with more (BASELINE.json's north star allows 1e-5 relative on accumulated gradients).  This file restates the
+tree so that the tolerance mode can ALSO be held bit for bit -- it is deterministic --, next to the tolerance check
+against the serial chain (oracle/cpu.py).  Every operation is a separate float32 rounding, as in the kernel."""
+import numpy as np
+
+F = np.float32
+LONG_MIN, COOP_MIN = 16, 64      # kQMediumC + 1, kQLongC of qstep.hip
+
+
+def _acc(p, lr, g):
+    return (p + (F(lr) * g).astype(F)).astype(F)
+
+
+def tree_long(rows_g, lr):
+    """16 <= c < 64: lane group r sums occurrences r, r+8, ... in order; the eight sums meet as
+    ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7))."""
+    c, width = rows_g.shape
+    p = [np.zeros(width, F) for _ in range(8)]
+    for t in range(8):
+        for r in range(8):
+            occ = 8 * t + r
+            if occ < c:
+                p[r] = _acc(p[r], lr, rows_g[occ])
+    s1 = [(p[0] + p[1]).astype(F), (p[2] + p[3]).astype(F), (p[4] + p[5]).astype(F), (p[6] + p[7]).astype(F)]
+    s2 = [(s1[0] + s1[1]).astype(F), (s1[2] + s1[3]).astype(F)]
+    return (s2[0] + s2[1]).astype(F)
+
+
+def tree_coop(rows_g, lr):
+    """c >= 64: wave w (16) x lane group r (4): occurrences base + 16 w + 4 t + r over blocks of 256 in order; per wave
+    (p0+p1)+(p2+p3); waves 4q..4q+3 as (a+b)+(c+d); the four quads as (q0+q1)+(q2+q3)."""
+    c, width = rows_g.shape
+    part = []
+    for w in range(16):
+        p = [np.zeros(width, F) for _ in range(4)]
+        for base in range(0, c, 256):
+            mine = base + 16 * w
+            if mine >= c:
+                break
+            for t in range(4):
+                for r in range(4):
+                    occ = mine + 4 * t + r
+                    if occ < c:
+                        p[r] = _acc(p[r], lr, rows_g[occ])
+        part.append((((p[0] + p[1]).astype(F)) + ((p[2] + p[3]).astype(F))).astype(F))
+    quad = [(((part[4 * q] + part[4 * q + 1]).astype(F)) + ((part[4 * q + 2] + part[4 * q + 3]).astype(F))).astype(F)
+            for q in range(4)]
+    return (((quad[0] + quad[1]).astype(F)) + ((quad[2] + quad[3]).astype(F))).astype(F)
+
+
+def sgd_sparse_update(table, ids, grads, lr):
+    """In place: table after one ha_qstep apply of (ids, grads).  ids: integer array (keys beyond the table are
+    ignored, as by the library)."""
+    ids = np.asarray(ids).reshape(-1).astype(np.int64)
+    grads = np.asarray(grads, dtype=F).reshape(ids.size, -1)
+    order = np.argsort(ids, kind="stable")
+    sk = ids[order]
+    starts = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]]) if ids.size else np.zeros(0, np.int64)
+    ends = np.r_[starts[1:], ids.size]
+    for s, e in zip(starts, ends):
+        key = int(sk[s])
+        if key < 0 or key >= table.shape[0]:
+            continue
+        occ = order[s:e]                      # occurrence order (stable sort)
+        c = e - s
+        if c < LONG_MIN:
+            row = table[key].copy()
+            for i in occ:
+                row = (row - (F(lr) * grads[i]).astype(F)).astype(F)
+            table[key] = row
+        elif c < COOP_MIN:
+            table[key] = (table[key] - tree_long(grads[occ], lr)).astype(F)
+        else:
+            table[key] = (table[key] - tree_coop(grads[occ], lr)).astype(F)
+    return table
+
+
+def tolerance(ids, grads, lr, rows, rel=1e-5):
+    """Per-row absolute bound of the difference between the tree mode and the serial chain: `rel` x the accumulated
+    gradient magnitude lr * sum_i |g_i| of the row's key (zero for keys below LONG_MIN occurrences: exact)."""
+    ids = np.asarray(ids).reshape(-1).astype(np.int64)
+    g = np.abs(np.asarray(grads, dtype=F).reshape(ids.size, -1)).astype(np.float64)
+    ok = (ids >= 0) & (ids < rows)
+    tol = {}
+    for k in np.unique(ids[ok]):
+        sel = ids == k
+        cnt = int(sel.sum())
+        tol[int(k)] = (rel * lr * g[sel].sum(axis=0)) if cnt >= LONG_MIN else np.zeros(g.shape[1])
+    return tol

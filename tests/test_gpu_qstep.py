@@ -1,0 +1,275 @@
+"""ha_qstep_* (csrc/qstep.hip, ops.QueueStepPipeline): ONE launch per step driven by a work queue.
+
+Held to three references on the same seeded streams:
+  * integer results (sorted keys, occurrence indices, unique keys, counts, inverse of every batch's plan): exact
+    against np.unique / the oracle's Unique restatement;
+  * lookup rows and the table BIT FOR BIT against oracle/qstep_model.py, the numpy restatement of the kernel's
+    floating-point order (serial occurrence-order chain below 16 occurrences of a key -- the reference's
+    cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:65-72 -- and a fixed tree sum from 16 on);
+  * and against the reference's serial chain for EVERY key (oracle/cpu.py = the compiled-reference-pinned port):
+    bit-exact for keys below 16 occurrences, within 1e-5 x (lr x sum|g|) -- BASELINE.json's tolerance for
+    accumulated gradients -- for the others."""
+import numpy as np
+import pytest
+import torch
+
+from herald_amd import ops, synth
+from oracle import cpu, qstep_model
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5       # BASELINE.json north_star: accumulated fp32 gradients within 1e-5 relative
+
+
+def _dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _lookup(t, ids_int):
+    width = t.shape[1]
+    out = np.zeros((ids_int.size, width), np.float32)
+    ok = (ids_int >= 0) & (ids_int < t.shape[0])
+    if ok.any():
+        out[ok] = t[ids_int[ok]]
+    return out
+
+
+def _check_plan(pl, ids_int, what):
+    keys = np.minimum(ids_int.astype(np.uint64), 0xFFFFFFFE).astype(np.uint32)
+    u, inv, cnt = cpu.unique(keys)
+    order = np.argsort(keys, kind="stable")
+    assert pl.n_unique() == u.size, what
+    np.testing.assert_array_equal(pl.sorted_keys().cpu().numpy().astype(np.int64) & 0xFFFFFFFF,
+                                  keys[order].astype(np.int64), err_msg=what + ": sorted keys")
+    np.testing.assert_array_equal(pl.perm().cpu().numpy().astype(np.int64), order, err_msg=what + ": perm (stable)")
+    np.testing.assert_array_equal(pl.keys().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys.astype(np.int64),
+                                  err_msg=what + ": keys")
+    np.testing.assert_array_equal(pl.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, u.astype(np.int64),
+                                  err_msg=what + ": unique keys")
+    np.testing.assert_array_equal(pl.counts().cpu().numpy().astype(np.int64), cnt, err_msg=what + ": counts")
+    np.testing.assert_array_equal(pl.inverse().cpu().numpy().astype(np.int64), inv, err_msg=what + ": inverse")
+    seg = pl.seg().cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(seg, np.r_[0, np.cumsum(cnt)], err_msg=what + ": segment starts")
+
+
+def _within(got, exact, tol_rows, keys, what):
+    """got vs the serial chain: rows of `keys` may differ by tol_rows[key] (0 = bit-exact)."""
+    for j, k in enumerate(keys):
+        d = np.abs(got[j].astype(np.float64) - exact[j].astype(np.float64))
+        bound = tol_rows.get(int(k))
+        if bound is None or not bound.any():
+            assert np.array_equal(got[j], exact[j]), "%s: key %d must be bit-exact" % (what, k)
+        else:
+            assert (d <= bound + REL * np.abs(exact[j])).all(), "%s: key %d off by %g (bound %g)" % (
+                what, k, d.max(), bound.min())
+
+
+def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=None, check_plans=True):
+    """Drives the pipeline over the whole stream; every lookup and the final table against both oracles."""
+    width = table0.shape[1]
+    rows = table0.shape[0]
+    model_t = table0.copy()       # floating-point order of the kernel
+    exact_t = table0.copy()       # the reference's serial chain
+    drift = {}                    # key -> accumulated tolerance of its row (tree-mode updates so far)
+    if table is None:
+        table = _dev(table0, dev)
+    cap = max(max(b.size for b in batches), 1)
+    pipe = ops.QueueStepPipeline(table, cap, lr)
+    cast = (lambda b: _dev(b.astype(np.float32), dev)) if ids_dtype == np.float32 else \
+        (lambda b: _dev(b.astype(np.int64), dev))
+    d_ids = [cast(b) for b in batches]
+    B = len(batches)
+    out = pipe.start(d_ids[0], d_ids[1] if B > 1 else None, d_ids[2] if B > 2 else None)
+    for k in range(B):
+        torch.cuda.synchronize()
+        ids = batches[k].astype(np.int64)
+        if ids.size:
+            got = out.cpu().numpy().reshape(-1, width)
+            np.testing.assert_array_equal(got, _lookup(model_t, ids), err_msg="lookup rows of batch %d (kernel order)" % k)
+            ok = (ids >= 0) & (ids < rows)
+            _within(got[ok], exact_t[ids[ok]], drift, ids[ok], "lookup rows of batch %d" % k)
+            qstep_model.sgd_sparse_update(model_t, ids, grads[k], lr)
+            if ok.any():
+                cpu.sgd_sparse_update(exact_t, ids[ok].astype(np.float32), grads[k][ok], lr)
+            for key, b in qstep_model.tolerance(ids, grads[k], lr, rows, REL).items():
+                if b.any():
+                    drift[key] = drift.get(key, 0) + b
+        else:
+            assert out is None
+        out = pipe.step(_dev(grads[k], dev) if ids.size else None, d_ids[k + 3] if k + 3 < B else None)
+        torch.cuda.synchronize()
+        assert (out is None) == (k + 1 >= B or batches[k + 1].size == 0)
+        if check_plans and ids.size:
+            _check_plan(pipe.plan_of(k), ids, "plan of batch %d" % k)
+    got_t = table.cpu().numpy()
+    np.testing.assert_array_equal(got_t, model_t, err_msg="table after the stream (kernel order)")
+    touched = np.array(sorted(drift.keys()), dtype=np.int64)
+    same = np.ones(rows, bool)
+    same[touched] = False
+    np.testing.assert_array_equal(got_t[same], exact_t[same], err_msg="rows without a long run: the serial chain, bit for bit")
+    _within(got_t[touched], exact_t[touched], drift, touched, "table after the stream")
+    return pipe
+
+
+@pytest.mark.parametrize("width", [4, 32, 64, 96, 128, 200, 512, 1024])
+@pytest.mark.parametrize("rows,n", [(40, 700), (5000, 6656), (300, 63), (7, 1)])
+def test_qstep_stream_small_tables(dev, width, rows, n):
+    """Small tables: almost every row of batch k+1 is updated by batch k; every class of item (small, medium, long,
+    workgroup, pure copies, keys with more than 64 / 1024 destinations)."""
+    rng = np.random.default_rng(width * 131 + rows + n)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    steps = 6
+    batches = [np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1) if k % 2 else rng.integers(0, rows, size=n)
+               for k in range(steps)]
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
+    _run_stream(dev, table0, batches, grads, 0.05)
+
+
+def test_qstep_all_below_16_occurrences_is_the_reference_bit_for_bit(dev):
+    """No key reaches 16 occurrences (ten keys have exactly 15): the whole stream equals the reference's serial
+    chain bit for bit (_run_stream compares every row without a long run with assert_array_equal)."""
+    rng = np.random.default_rng(5)
+    rows, width, n = 4000, 128, 3000
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    batches = []
+    for k in range(6):
+        base = rng.integers(100, rows, size=n - 150)
+        hot = np.repeat(rng.choice(100, size=10, replace=False), 15)
+        b = rng.permutation(np.concatenate([base, hot]))
+        assert np.unique(b, return_counts=True)[1].max() == 15
+        batches.append(b)
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in batches]
+    _run_stream(dev, table0, batches, grads, 0.03)
+
+
+@pytest.mark.parametrize("kind", ["one_key", "two_keys", "giant_next", "copies_only"])
+def test_qstep_degenerate_batches(dev, kind):
+    """A whole batch of one key (one run of 2,000 occurrences, 2,000 destinations), two alternating keys, a key rare
+    in the batch to apply and everywhere in the next one, and batches that share no key (pure copies)."""
+    rng = np.random.default_rng(17)
+    rows, width, n = 600, 256, 2000
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    if kind == "one_key":
+        batches = [np.full(n, 5), np.full(n, 5), np.full(n, 7), np.full(n, 5)]
+    elif kind == "two_keys":
+        batches = [np.tile([3, 9], n // 2), np.tile([9, 3], n // 2), np.tile([3, 11], n // 2), np.tile([3, 9], n // 2)]
+    elif kind == "giant_next":
+        a = rng.integers(100, rows, size=n)
+        a[7] = 42
+        batches = [a, np.full(n, 42), a.copy(), np.full(n, 42)]
+    else:
+        batches = [rng.integers(0, 200, size=n), rng.integers(200, 400, size=n), rng.integers(400, 600, size=n),
+                   rng.integers(0, 200, size=n)]
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in batches]
+    _run_stream(dev, table0, batches, grads, 0.02)
+
+
+def test_qstep_ragged_empty_and_out_of_range(dev):
+    """Batches of different sizes, an EMPTY batch in the middle of the stream, ids beyond the table (zeros on lookup,
+    ignored by the apply) and uint64 ids beyond 2^32."""
+    rng = np.random.default_rng(23)
+    rows, width = 900, 64
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    sizes = [1200, 1, 0, 777, 64, 1025, 0, 300, 2]
+    batches = []
+    for k, n in enumerate(sizes):
+        b = rng.integers(0, rows + 60, size=n)            # ~6 % beyond the table
+        if n > 10:
+            b[3] = (1 << 33) + 5
+            b[4] = 0xFFFFFFFF
+        batches.append(b)
+    grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
+    _run_stream(dev, table0, batches, grads, 0.05, ids_dtype=np.int64)
+
+
+def test_qstep_float_ids_above_2_24_and_capacity_limit(dev):
+    """float32 ids as the operator boundary hands them over, rows above 2^24 (table slice addressed through a view
+    trick is not possible: a real 17.3 M x 4 table), and the documented size limit."""
+    rows, width = 17_300_000, 4
+    table = torch.zeros((rows, width), dtype=torch.float32, device=dev)
+    rng = np.random.default_rng(29)
+    hot = np.array([16777216, 16777218, 17299998, 3, 16777220], dtype=np.int64)
+    table0_rows = rng.standard_normal((hot.size, width), dtype=np.float32)
+    table[_dev(hot, dev)] = _dev(table0_rows, dev)
+    n = 512
+    batches = [hot[rng.integers(0, hot.size, size=n)] for _ in range(5)]
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in batches]
+    compact = table0_rows.copy()
+    pipe = ops.QueueStepPipeline(table, n, 0.01)
+    d = [_dev(b.astype(np.float32), dev) for b in batches]
+    out = pipe.start(d[0], d[1], d[2])
+    for k in range(5):
+        torch.cuda.synchronize()
+        cid = np.searchsorted(np.sort(hot), batches[k])
+        srt = np.argsort(hot)
+        want = compact[srt][cid]
+        np.testing.assert_array_equal(out.cpu().numpy().reshape(-1, width), want)
+        tmp = compact[srt].copy()
+        qstep_model.sgd_sparse_update(tmp, cid, grads[k], 0.01)
+        compact[srt] = tmp
+        out = pipe.step(_dev(grads[k], dev), d[k + 3] if k + 3 < 5 else None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(table[_dev(hot, dev)].cpu().numpy(), compact)
+    assert float(table.abs().sum().item()) == pytest.approx(float(np.abs(compact.astype(np.float64)).sum()), rel=1e-6)
+    with pytest.raises(ValueError):
+        ops.QueueStepPipeline(table, ops.qstep_max_ids() + 1, 0.01)
+
+
+def test_qstep_criteo_stream_and_queue_shape(dev):
+    """BASELINE configs[1]'s batch shape on a 400 k-row table slice: 12 Criteo batches (bs=256, 26 fields, d=512), the
+    queue's class counts against a host count of the same rule, and every row against both oracles."""
+    rows, width, bs = 400_000, 512, 256
+    rng = np.random.default_rng(31)
+    table0 = (rng.standard_normal((rows, width), dtype=np.float32) * np.float32(0.01))
+    batches = [synth.criteo_batch(bs, step=k, rows=rows).reshape(-1) for k in range(12)]
+    grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
+    pipe = _run_stream(dev, table0, batches, grads, 0.01)
+    # queue of the last apply-only call was built from (batch 11, nothing): counts by class
+    a = batches[-1]
+    u, c = np.unique(a, return_counts=True)
+    per512, per128, per32, per64 = 1, 4, 16, 8
+    want = {"workgroup_items": int((c >= 64).sum()) * per64, "long": int(((c >= 16) & (c < 64)).sum()) * per32,
+            "medium": int(((c > 3) & (c < 16)).sum()) * per128, "small": int((c <= 3).sum()) * per512}
+    hdr = pipe.queue_header(len(batches) - 1)
+    for k, v in want.items():
+        assert hdr[k] == v, (k, hdr, want)
+    assert hdr["wave_items"] == want["long"] + want["medium"] + want["small"]
+
+
+def test_qstep_graph_replay_is_deterministic(dev):
+    """The launches replayed from a hipGraph (as bench.py does) give the same bits as eager launches."""
+    rows, width, bs = 300_000, 128, 128
+    rng = np.random.default_rng(37)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    nb = 8
+    ids = [_dev(synth.criteo_batch(bs, step=k, rows=rows).reshape(-1).astype(np.float32), dev) for k in range(nb)]
+    n = ids[0].numel()
+    grads = [_dev(rng.standard_normal((n, width), dtype=np.float32), dev) for _ in range(nb)]
+    results = []
+    for mode in ("eager", "graph"):
+        table = _dev(table0, dev)
+        pipe = ops.QueueStepPipeline(table, n, 0.05)
+        outs = [torch.empty((n, width), dtype=torch.float32, device=dev) for _ in range(nb)]
+        s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s):
+            pipe.launch(-3, 0, None, 0, None, 0, ids[0], stream=s)
+            pipe.launch(-2, 0, None, 0, None, n, ids[1], stream=s)
+            pipe.launch(-1, 0, None, n, outs[0], n, ids[2], stream=s)
+
+            def step(k):
+                pipe.launch(k, n, grads[k % nb], n, outs[(k + 1) % nb], n, ids[(k + 3) % nb], stream=s)
+            if mode == "eager":
+                for k in range(16):
+                    step(k)
+            else:
+                s.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    for k in range(8):
+                        step(k)
+                g.replay()
+                g.replay()
+        torch.cuda.synchronize()
+        results.append((table.cpu().numpy(), [o.cpu().numpy() for o in outs]))
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    for a, b in zip(results[0][1], results[1][1]):
+        np.testing.assert_array_equal(a, b)
