@@ -125,8 +125,15 @@ struct QArgs {
     QEntry *bcoop, *bwave;
     uint32_t bcap_coop, bcap_wave;
     int has_b;
+    uint32_t lds_bytes;        // dynamic LDS of the launch (B keeps its inputs there when they fit)
     unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind} per wave
 };
+
+// development aid: phase time stamps of the single-workgroup roles (thread 0; ph = nullptr in production)
+__device__ __forceinline__ void q_phase(unsigned long long *ph, int k) {
+    if (ph != nullptr && threadIdx.x == 0)
+        ph[k] = __builtin_amdgcn_s_memrealtime();
+}
 
 // ---- 1024-thread exclusive scan (two barriers); s_w = 16 words -------------------------------------------------
 __device__ __forceinline__ uint32_t qscan(uint32_t v, uint32_t *s_w, uint32_t *total) {
@@ -163,8 +170,16 @@ static inline size_t qsort_lds_bytes(int n) {
     return npad * 4 + 2 * npad * 2 + 16 * kQBins * 2 + kQBins * 2 + 32 * 4;
 }
 
-template <typename IdT>
-__device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, const QPlan &p, uint32_t *lds) {
+// RANK_ATOMIC: the rank of a key among the equal digits of its wave comes back from ONE LDS atomic
+// (ds_add_rtn_u32 on the wave's counter: two 16-bit counters per word) instead of nine ballots + a 64-bit peer mask
+// per key (~110 VALU instructions per row of 64 keys, which made a pass VALU-bound: 6.5-8 us).  A stable sort needs
+// the lanes of one wave-instruction that hit the same counter to be served in ascending lane order.  gfx950 does
+// that (checked over 7e7 lane-operations, four collision patterns); because the ISA does not promise it, the host
+// side verifies it once per device before the first launch (lds_atomics_lane_ordered) and takes the ballot form
+// otherwise -- and every parity test compares the occurrence order with a stable argsort.
+template <typename IdT, bool RANK_ATOMIC>
+__device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, const QPlan &p, uint32_t *lds,
+                                                  unsigned long long *ph = nullptr) {
     const int n = p.n;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const int npad = (n + 1023) & ~1023;
@@ -174,6 +189,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
     uint16_t *s_dbase = s_cnt + 16 * kQBins;
     uint32_t *s_w = reinterpret_cast<uint32_t *>(s_dbase + kQBins);
 
+    q_phase(ph, 0);
     // keys (pads = all ones: they sort behind every real key, see the pass count below) and the widest key
     uint32_t kmax = 0;
     for (int base = 0; base < npad; base += 8192) {
@@ -213,7 +229,9 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
     const int C = npad >> 4;          // positions per wave, a multiple of 64
     const int nrow = C >> 6;          // <= 8
 
+    q_phase(ph, 1);
     for (int pass = 0; pass < npass; ++pass) {
+        q_phase(ph, 2 + pass);
         const int shift = pass * kQDigit;
         uint16_t *cur = s_idx + (pass & 1) * npad, *nxt = s_idx + ((pass & 1) ^ 1) * npad;
         for (int i = tid; i < 16 * kQBins / 2; i += 1024)
@@ -221,9 +239,29 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         __syncthreads();
         uint32_t off[8], dig[8], idx[8];
         uint16_t *my_cnt = s_cnt + w * kQBins;
+        if (RANK_ATOMIC) {
+            // all of a wave's index reads, then all key reads, then the atomics in row order (one wave's LDS
+            // operations execute in order, so row r+1 finds the counts of rows 0..r)
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                idx[r] = r < nrow ? cur[w * C + r * 64 + lane] : 0u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                dig[r] = (s_key[idx[r]] >> shift) & (kQBins - 1);
+            uint32_t *cnt32 = reinterpret_cast<uint32_t *>(my_cnt);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r < nrow) {   // wave-uniform
+                    const uint32_t sh = (dig[r] & 1u) * 16u;
+                    const uint32_t old = __hip_atomic_fetch_add(cnt32 + (dig[r] >> 1), 1u << sh, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                    off[r] = (old >> sh) & 0xFFFFu;
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            if (r < nrow) {   // wave-uniform
+            if (!RANK_ATOMIC && r < nrow) {   // wave-uniform
                 const uint32_t i = cur[w * C + r * 64 + lane];
                 const uint32_t d = (s_key[i] >> shift) & (kQBins - 1);
                 unsigned long long peers = ~0ull;
@@ -267,6 +305,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         __syncthreads();
     }
 
+    q_phase(ph, 6);
     // ---- finish: one thread per P consecutive sorted positions --------------------------------------------
     const uint16_t *fin = s_idx + (npass & 1) * npad;
     uint16_t *s_ui = s_idx + ((npass & 1) ^ 1) * npad;   // unique index of every sorted position
@@ -308,6 +347,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         p.seg[U] = n;
     }
     __syncthreads();
+    q_phase(ph, 7);
     for (int q = tid; q < n; q += 1024) {
         const uint32_t i = fin[q];
         const int32_t ui = s_ui[q];
@@ -323,15 +363,22 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         p.seg[u] = static_cast<int32_t>(q);
         p.counts[u] = static_cast<int32_t>(s_seg[u + 1]) - static_cast<int32_t>(q);
     }
+    q_phase(ph, 8);
 }
 
 // =====================================================================================================
 // Role B: the queue of the NEXT launch from the finished plans of its two batches.
 //   s_ua[npad_a] u32 | s_ug[npad_g] u32 | s_w[16] u32
 // =====================================================================================================
+// minimum (unique keys + scan words + per-thread match words) and the size at which B keeps ALL its inputs in LDS
+// (counts, segment starts, the matched batch's counts / starts, the occurrence indices: 16-bit each)
 static inline size_t qjoin_lds_bytes(int n_a, int n_g) {
     return (static_cast<size_t>(n_a) + n_g + 2) * 4 + 32 * 4 + 8 * 1024 * 2;
 }
+static inline size_t qjoin_lds_resident_bytes(int n_a, int n_g) {
+    return (static_cast<size_t>(n_a) + n_g + 2) * 4 + 32 * 4 + (static_cast<size_t>(n_a) * 5 + static_cast<size_t>(n_g) * 2 + 8) * 2;
+}
+constexpr size_t kQLdsBudget = 76800;   // 75 KiB: two workgroups per CU
 
 __device__ __forceinline__ int q_kind(uint32_t c, uint32_t m, bool in_table) {
     if (!in_table)
@@ -358,20 +405,11 @@ __device__ __forceinline__ int q_lower_bound(const uint32_t *s, int n, uint32_t 
     return pos;
 }
 
-__device__ __forceinline__ void q_emit(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
-                                       uint32_t fs, int width, const int32_t *perm_a, int n_a) {
+__device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
+                                             uint32_t fs, int width, uint32_t o01, uint32_t o23) {
     const int slice = q_slice(kind);
     if (kind == kQZ)
         c = 0;    // ids beyond the table are never applied; their destinations get zeros
-    uint32_t o01 = 0, o23 = 0;
-    if (kind == kQS && c > 0) {
-        uint32_t o[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            o[t] = static_cast<uint32_t>(perm_a[min(static_cast<int>(st) + t, n_a - 1)]);
-        o01 = o[0] | (o[1] << 16);
-        o23 = o[2] | (o[3] << 16);
-    }
     int j = 0;
     for (int col0 = 0; col0 < width; col0 += slice, ++j) {
         const int cols = min(slice, width - col0);
@@ -389,6 +427,20 @@ __device__ __forceinline__ void q_emit(QEntry *dst, int kind, uint32_t key, uint
         d[1] = hi;
     }
 }
+// the first occurrence indices of a small item from the plan in global memory
+__device__ __forceinline__ void q_emit(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
+                                       uint32_t fs, int width, const int32_t *perm_a, int n_a) {
+    uint32_t o01 = 0, o23 = 0;
+    if (kind == kQS && c > 0) {
+        uint32_t o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            o[t] = static_cast<uint32_t>(perm_a[min(static_cast<int>(st) + t, n_a - 1)]);
+        o01 = o[0] | (o[1] << 16);
+        o23 = o[2] | (o[3] << 16);
+    }
+    q_emit_words(dst, kind, key, c, st, m, fs, width, o01, o23);
+}
 
 struct QCount {   // items per class: coop (G), long, medium, small (S and Z)
     uint32_t g, l, m, s;
@@ -403,10 +455,11 @@ __device__ __forceinline__ QCount q_count(QCount t, int kind, uint32_t per512, u
     return t;
 }
 
-__device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const uint64_t rows, const int width,
-                                           QHeader *bqh, QEntry *bcoop, QEntry *bwave, const uint32_t bcap_coop,
-                                           const uint32_t bcap_wave, uint32_t *lds) {
+__device__ __forceinline__ void qjoin_body_global(const QPlan pa, const QPlan pg, const uint64_t rows, const int width,
+                                                  QHeader *bqh, QEntry *bcoop, QEntry *bwave, const uint32_t bcap_coop,
+                                                  const uint32_t bcap_wave, uint32_t *lds, unsigned long long *ph) {
     const int tid = threadIdx.x;
+    q_phase(ph, 0);
     const int Ua = pa.n > 0 ? static_cast<int>(pa.hdr->n_unique) : 0;
     const int Ug = pg.n > 0 ? static_cast<int>(pg.hdr->n_unique) : 0;
     uint32_t *s_ua = lds, *s_ug = lds + Ua + 1, *s_w = lds + Ua + Ug + 2;
@@ -416,6 +469,7 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     for (int i = tid; i < Ug; i += 1024)
         s_ug[i] = pg.uniq[i];
     __syncthreads();
+    q_phase(ph, 1);
     const uint32_t per512 = (width + 511) / 512, per128 = (width + 127) / 128, per32 = (width + 31) / 32;
     const int ra = (Ua + 1023) >> 10, rg = (Ug + 1023) >> 10;   // rounds, <= 8 (kQMax <= 8192)
     // pass 1: what every key of the union costs.  Keys of the batch to apply first (matched against the batch to
@@ -452,6 +506,7 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             }
         }
     }
+    q_phase(ph, 2);
     uint32_t nL, nM, nS, nG;
     QCount b;
     b.l = qscan(t.l, s_w, &nL);
@@ -466,6 +521,7 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
         bqh->n_small = nS;
         bqh->n_zero = 0;
     }
+    q_phase(ph, 3);
     // pass 2: the items, thread by thread in the order they were counted
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -511,6 +567,142 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             }
         }
     }
+    q_phase(ph, 4);
+}
+
+// The same join with EVERYTHING it reads staged in LDS by one batch of independent loads (unique keys, counts and
+// segment starts of both batches, the occurrence indices of the batch to apply): the version above pays a dependent
+// trip to memory per round and per field -- about ten of them at 2-3 us each while the workers' burst is in flight.
+//   s_ua[Ua+1] s_ug[Ug+1] u32 | s_w[32] | u16: ca sa ma fa [Ua], cg sg [Ug], perm [n_a]
+__device__ __forceinline__ void qjoin_body_resident(const QPlan pa, const QPlan pg, const int Ua, const int Ug,
+                                                    const uint64_t rows, const int width, QHeader *bqh, QEntry *bcoop,
+                                                    QEntry *bwave, const uint32_t bcap_coop, const uint32_t bcap_wave,
+                                                    uint32_t *lds, unsigned long long *ph) {
+    const int tid = threadIdx.x;
+    uint32_t *s_ua = lds, *s_ug = lds + Ua + 1, *s_w = lds + Ua + Ug + 2;
+    uint16_t *ca = reinterpret_cast<uint16_t *>(s_w + 32), *sa = ca + Ua, *ma = sa + Ua, *fa = ma + Ua;
+    uint16_t *cg = fa + Ua, *sg = cg + Ug, *pp = sg + Ug;
+    for (int i = tid; i < Ua; i += 1024) {
+        s_ua[i] = pa.uniq[i];
+        ca[i] = static_cast<uint16_t>(pa.counts[i]);
+        sa[i] = static_cast<uint16_t>(pa.seg[i]);
+    }
+    for (int i = tid; i < Ug; i += 1024) {
+        s_ug[i] = pg.uniq[i];
+        cg[i] = static_cast<uint16_t>(pg.counts[i]);
+        sg[i] = static_cast<uint16_t>(pg.seg[i]);
+    }
+    for (int i = tid; i < pa.n; i += 1024)
+        pp[i] = static_cast<uint16_t>(pa.perm[i]);
+    __syncthreads();
+    q_phase(ph, 1);
+    const uint32_t per512 = (width + 511) / 512, per128 = (width + 127) / 128, per32 = (width + 31) / 32;
+    const int ra = (Ua + 1023) >> 10, rg = (Ug + 1023) >> 10;
+    uint32_t found = 0;
+    QCount t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < ra) {
+            const int x = r * 1024 + tid;
+            if (x < Ua) {
+                const uint32_t key = s_ua[x];
+                const int y = q_lower_bound(s_ug, Ug, key);
+                const bool hit = y < Ug && s_ug[y] == key;
+                const uint32_t m = hit ? cg[y] : 0u;
+                ma[x] = static_cast<uint16_t>(m);
+                fa[x] = hit ? sg[y] : static_cast<uint16_t>(0);
+                t = q_count(t, q_kind(ca[x], m, key < rows), per512, per128, per32);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < rg) {
+            const int y = r * 1024 + tid;
+            if (y < Ug) {
+                const uint32_t key = s_ug[y];
+                const int x = q_lower_bound(s_ua, Ua, key);
+                const bool hit = x < Ua && s_ua[x] == key;
+                found |= hit ? (1u << r) : 0u;
+                if (!hit)
+                    t = q_count(t, q_kind(0u, cg[y], key < rows), per512, per128, per32);
+            }
+        }
+    }
+    q_phase(ph, 2);
+    uint32_t nL, nM, nS, nG;
+    QCount b;
+    b.l = qscan(t.l, s_w, &nL);
+    b.m = qscan(t.m, s_w, &nM) + nL;
+    b.s = qscan(t.s, s_w, &nS) + nL + nM;
+    b.g = qscan(t.g, s_w, &nG);
+    if (tid == 0) {
+        bqh->n_wave = min(nL + nM + nS, bcap_wave);
+        bqh->n_coop = min(nG, bcap_coop);
+        bqh->n_long = nL;
+        bqh->n_medium = nM;
+        bqh->n_small = nS;
+        bqh->n_zero = 0;
+    }
+    q_phase(ph, 3);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < ra) {
+            const int x = r * 1024 + tid;
+            if (x < Ua) {
+                const uint32_t key = s_ua[x], c = ca[x], st = sa[x], m = ma[x], fs = fa[x];
+                const int kind = q_kind(c, m, key < rows);
+                if (kind != kQNone) {
+                    const uint32_t at = kind == kQG ? b.g : kind == kQL ? b.l : kind == kQM ? b.m : b.s;
+                    const QCount nb = q_count(b, kind, per512, per128, per32);
+                    const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
+                    b = nb;
+                    uint32_t o01 = 0, o23 = 0;
+                    if (kind == kQS && c > 0) {
+                        const int last = pa.n - 1;
+                        o01 = static_cast<uint32_t>(pp[min(static_cast<int>(st), last)]) |
+                              (static_cast<uint32_t>(pp[min(static_cast<int>(st) + 1, last)]) << 16);
+                        o23 = static_cast<uint32_t>(pp[min(static_cast<int>(st) + 2, last)]);
+                    }
+                    if (at + cnt <= (kind == kQG ? bcap_coop : bcap_wave))
+                        q_emit_words((kind == kQG ? bcoop : bwave) + at, kind, key, c, st, m, fs, width, o01, o23);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < rg) {
+            const int y = r * 1024 + tid;
+            if (y < Ug && !(found & (1u << r))) {
+                const uint32_t key = s_ug[y], m = cg[y];
+                const int kind = q_kind(0u, m, key < rows);
+                if (kind != kQNone) {
+                    const uint32_t at = kind == kQM ? b.m : b.s;
+                    const QCount nb = q_count(b, kind, per512, per128, per32);
+                    const uint32_t cnt = (nb.m - b.m) + (nb.s - b.s);
+                    b = nb;
+                    if (at + cnt <= bcap_wave)
+                        q_emit_words(bwave + at, kind, key, 0u, 0u, m, sg[y], width, 0u, 0u);
+                }
+            }
+        }
+    }
+    q_phase(ph, 4);
+}
+
+__device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const uint64_t rows, const int width,
+                                           QHeader *bqh, QEntry *bcoop, QEntry *bwave, const uint32_t bcap_coop,
+                                           const uint32_t bcap_wave, uint32_t *lds, uint32_t lds_bytes,
+                                           unsigned long long *ph = nullptr) {
+    q_phase(ph, 0);
+    const int Ua = pa.n > 0 ? static_cast<int>(pa.hdr->n_unique) : 0;
+    const int Ug = pg.n > 0 ? static_cast<int>(pg.hdr->n_unique) : 0;
+    const uint32_t need = static_cast<uint32_t>((Ua + Ug + 2) * 4 + 32 * 4 + (4 * Ua + 2 * Ug + pa.n + 8) * 2);
+    if (need <= lds_bytes)    // workgroup-uniform
+        qjoin_body_resident(pa, pg, Ua, Ug, rows, width, bqh, bcoop, bwave, bcap_coop, bcap_wave, lds, ph);
+    else
+        qjoin_body_global(pa, pg, rows, width, bqh, bcoop, bwave, bcap_coop, bcap_wave, lds, ph);
 }
 
 // =====================================================================================================
@@ -786,13 +978,23 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
     __syncthreads();   // s_part is reused by the next item of this workgroup
 }
 
-template <typename IdT>
+// Block order: A, B, coop items, wave items.  The two single-workgroup roles are the longest-running ones and start
+// with a trip to memory: dispatched first, their loads are out before the workers' burst.
+template <typename IdT, bool RANK_ATOMIC>
 __global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
     int b = blockIdx.x;
-    if (b < a.ncoop) {
+    if (b == 0 && a.has_a) {
+        role = 1;
+        qsort_finish_body<IdT, RANK_ATOMIC>(static_cast<const IdT *>(a.ahead_ids), a.pa, s_dyn,
+                                            a.dbg ? a.dbg + static_cast<size_t>(gridDim.x) * 64 : nullptr);
+    } else if ((b -= a.has_a) == 0 && a.has_b) {
+        role = 2;
+        qjoin_body(a.ba, a.bg, a.rows, a.width, a.bqh, a.bcoop, a.bwave, a.bcap_coop, a.bcap_wave, s_dyn, a.lds_bytes,
+                   a.dbg ? a.dbg + static_cast<size_t>(gridDim.x) * 64 + 16 : nullptr);
+    } else if ((b -= a.has_b) < a.ncoop) {
         role = 0;
         const uint32_t n = a.qh->n_coop;
         for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
@@ -800,14 +1002,8 @@ __global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
             q_coop(a, it, reinterpret_cast<float *>(s_dyn));
             kind = it.kind;
         }
-    } else if ((b -= a.ncoop) == 0 && a.has_a) {
-        role = 1;
-        qsort_finish_body<IdT>(static_cast<const IdT *>(a.ahead_ids), a.pa, s_dyn);
-    } else if ((b -= a.has_a) == 0 && a.has_b) {
-        role = 2;
-        qjoin_body(a.ba, a.bg, a.rows, a.width, a.bqh, a.bcoop, a.bwave, a.bcap_coop, a.bcap_wave, s_dyn);
     } else {
-        b -= a.has_b;
+        b -= a.ncoop;
         role = 3;
         const uint32_t n = a.qh ? a.qh->n_wave : 0u;
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * 16u;
@@ -836,6 +1032,67 @@ __global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
             d[3] = static_cast<unsigned long long>(static_cast<unsigned>(kind));
         }
     }
+}
+
+// One wave-instruction's LDS atomics on one address: are the lanes served in ascending lane order?  Four collision
+// patterns (all lanes one counter; two; sixteen; 512 counters), seven rows, 16 waves.
+__global__ __launch_bounds__(1024) void q_lds_order_check_kernel(uint32_t *bad) {
+    __shared__ uint32_t cnt[16][kQBins / 2];
+    __shared__ uint32_t ref[16][kQBins];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    for (int i = threadIdx.x; i < 16 * kQBins / 2; i += 1024)
+        (&cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 16 * kQBins; i += 1024)
+        (&ref[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t s = 12345u + 977u * threadIdx.x, wrong = 0;
+    for (int r = 0; r < 7; ++r) {
+        s = s * 1664525u + 1013904223u;
+        const uint32_t x = s >> 16;
+        const int mode = w & 3;
+        const uint32_t d = mode == 0 ? 7u : mode == 1 ? (x & 1u) * 255u + 3u : mode == 2 ? (x & 15u) * 3u : (x & 511u);
+        const uint32_t sh = (d & 1u) * 16u;
+        const uint32_t old = (__hip_atomic_fetch_add(&cnt[w][d >> 1], 1u << sh, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP) >> sh) & 0xFFFFu;
+        // reference rank: lanes of this wave one after the other
+        uint32_t want = 0;
+        for (int l = 0; l < 64; ++l) {
+            if (lane == l) {
+                want = ref[w][d];
+                ref[w][d] = want + 1;
+            }
+        }
+        wrong += old != want;
+    }
+    if (wrong)
+        atomicAdd(bad, wrong);
+}
+
+// 1 = lane-ordered (use the atomic ranking), 0 = not / could not be checked (ballot ranking).  Checked once per device,
+// synchronously: the first ha_qstep_* call on a device must not be made inside a stream capture (as for the LDS
+// attribute).  HA_QSTEP_BALLOT=1 forces the ballot form.
+static int lds_atomics_lane_ordered() {
+    static std::atomic<int> state[256];   // 0 unknown, 1 yes, 2 no
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 256)
+        return 0;
+    int st = state[d].load(std::memory_order_acquire);
+    if (st == 0) {
+        st = 2;
+        const char *env = getenv("HA_QSTEP_BALLOT");
+        uint32_t *bad = nullptr, host = 1;
+        if (!(env && env[0] == '1') && hipMalloc(reinterpret_cast<void **>(&bad), 4) == hipSuccess) {
+            if (hipMemset(bad, 0, 4) == hipSuccess) {
+                hipLaunchKernelGGL(q_lds_order_check_kernel, dim3(8), dim3(1024), 0, nullptr, bad);
+                if (hipGetLastError() == hipSuccess &&
+                    hipMemcpy(&host, bad, 4, hipMemcpyDeviceToHost) == hipSuccess && host == 0)
+                    st = 1;
+            }
+            (void)hipFree(bad);
+        }
+        state[d].store(st, std::memory_order_release);
+    }
+    return st == 1;
 }
 
 template <typename IdT>
@@ -903,14 +1160,25 @@ static int qstep(float *table, int64_t rows, int64_t width, void *plan_cur, int6
         a.bcap_wave = q.cap_wave;
         a.has_b = 1;
         lds = lds > qjoin_lds_bytes(a.ba.n, a.bg.n) ? lds : qjoin_lds_bytes(a.ba.n, a.bg.n);
+        // room for B to keep its inputs in LDS where that fits beside a second workgroup on the CU (it decides on
+        // the device, from the number of unique keys)
+        const size_t res = qjoin_lds_resident_bytes(a.ba.n, a.bg.n);
+        const size_t want = res < kQLdsBudget ? res : kQLdsBudget;
+        lds = lds > want ? lds : want;
     }
     const unsigned blocks = static_cast<unsigned>(a.ncoop + a.has_a + a.has_b + a.nworker);
     if (blocks == 0)
         return 0;
+    a.lds_bytes = static_cast<uint32_t>(lds);
     static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
-    if (lds_allowed.first())
-        HA_ALLOW_LDS((qstep_kernel<IdT>), 160 * 1024);
-    hipLaunchKernelGGL((qstep_kernel<IdT>), dim3(blocks), dim3(1024), lds, stream, a);
+    if (lds_allowed.first()) {
+        HA_ALLOW_LDS((qstep_kernel<IdT, true>), 160 * 1024);
+        HA_ALLOW_LDS((qstep_kernel<IdT, false>), 160 * 1024);
+    }
+    if (lds_atomics_lane_ordered())
+        hipLaunchKernelGGL((qstep_kernel<IdT, true>), dim3(blocks), dim3(1024), lds, stream, a);
+    else
+        hipLaunchKernelGGL((qstep_kernel<IdT, false>), dim3(blocks), dim3(1024), lds, stream, a);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -946,7 +1214,8 @@ extern "C" int ha_qstep_u64ids(float *table, int64_t rows, int64_t width, void *
                            as_stream(stream));
 }
 
-// development aid: ha_qstep_f32ids with per-wave time stamps; dbg = device uint64[blocks * 16 * 4] (zeroed)
+// development aid: ha_qstep_f32ids with per-wave time stamps; dbg = device uint64[blocks * 16 * 4 + 32] (zeroed);
+// the last 32 words receive phase stamps of the plan (A) and queue (B) workgroups
 extern "C" int ha_debug_qstep_timeline(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
                                        const float *grads, float lr, void *plan_next, int64_t n_next,
                                        float *next_out, const void *queue_cur, void *plan_b1, int64_t n_b1,
