@@ -44,14 +44,14 @@ constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers 
 constexpr int kQCoopSlots = 48;      // workgroups reserved for G items (they loop if there are more)
 constexpr int kQWorkerMax = 448;     // worker workgroups: with A, B and the coop slots the launch stays below the
                                      // chip's 512 resident 1024-thread workgroups; the waves loop beyond that
-constexpr int kQDigit = 9, kQBins = 1 << kQDigit;
 constexpr int kQSmallC = 3, kQSmallM = 16, kQMediumC = 15, kQLongC = 64;
 enum QKind { kQS = 0, kQM = 1, kQL = 2, kQZ = 3, kQG = 4, kQNone = 15 };
 
 struct QHeader {
-    uint32_t n_wave, n_coop;
-    uint32_t n_long, n_medium, n_small, n_zero;   // wave items per class (diagnostics, tests)
-    uint32_t reserved[58];
+    uint32_t n_wave, n_coop;                       // items of the keys the batch to apply names (one workgroup writes them)
+    uint32_t n_long, n_medium, n_small;            //   per class (diagnostics, tests)
+    uint32_t n_copy, n_copy_medium, n_copy_small;  // items of the keys only the lookup names (another workgroup)
+    uint32_t reserved[56];
 };
 static_assert(sizeof(QHeader) == 256, "queue header is one 256-byte line");
 struct QEntry {
@@ -62,22 +62,24 @@ static_assert(sizeof(QEntry) == 32, "queue items are 32 bytes");
 
 struct QLayout {
     QHeader *hdr;
-    QEntry *coop, *wave;
-    uint32_t cap_coop, cap_wave;
+    QEntry *coop, *wave, *copy;
+    uint32_t cap_coop, cap_wave, cap_copy;
     size_t bytes;
 };
 static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 // Bounds (every key owns at least as many positions of the two batches as it has items per 512 columns):
-// wave items <= ceil(width/512) * (n_a + n_g), coop items <= ceil(width/64) * n_a / 64.
+// wave items <= ceil(width/512) * n_a, copy items <= ceil(width/512) * n_g, coop items <= ceil(width/64) * n_a / 64.
 static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
     QLayout q;
     char *b = static_cast<char *>(ws);
     q.cap_coop = static_cast<uint32_t>(ceil_div(width, 64) * (ceil_div(n_cap, kQLongC) + 1));
-    q.cap_wave = static_cast<uint32_t>(ceil_div(width, 512) * 2 * n_cap + 64);
+    q.cap_wave = static_cast<uint32_t>(ceil_div(width, 512) * n_cap + 64);
+    q.cap_copy = static_cast<uint32_t>(ceil_div(width, 512) * n_cap + 64);
     q.hdr = reinterpret_cast<QHeader *>(b);
     q.coop = reinterpret_cast<QEntry *>(b ? b + sizeof(QHeader) : nullptr);
     q.wave = q.coop ? q.coop + q.cap_coop : nullptr;
-    q.bytes = sizeof(QHeader) + (static_cast<size_t>(q.cap_coop) + q.cap_wave) * sizeof(QEntry);
+    q.copy = q.wave ? q.wave + q.cap_wave : nullptr;
+    q.bytes = sizeof(QHeader) + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * sizeof(QEntry);
     return q;
 }
 
@@ -85,6 +87,7 @@ struct QPlan {   // what the roles read / write of a plan workspace
     PlanHeader *hdr;
     uint32_t *keys, *sorted, *uniq;
     int32_t *perm, *inverse, *counts, *seg, *upos;
+    uint32_t *occ;     // [2 * n]: per group, the first three occurrence indices as 16-bit words (A writes, B reads)
     int n;
 };
 static inline QPlan qplan(void *ws, int64_t n) {
@@ -95,6 +98,7 @@ static inline QPlan qplan(void *ws, int64_t n) {
     PlanPtrs p = plan_layout(ws, n);
     q.hdr = p.hdr; q.keys = p.keys; q.sorted = p.sorted; q.uniq = p.uniq;
     q.perm = p.perm; q.inverse = p.inverse; q.counts = p.counts; q.seg = p.seg; q.upos = p.upos;
+    q.occ = p.keys_alt;     // keys_alt and perm_alt are adjacent scratch arrays of n words each
     q.n = static_cast<int>(n);
     return q;
 }
@@ -105,7 +109,7 @@ struct QArgs {
     int width;
     // workers: queue of this launch, occurrence indices of the batch to apply, destinations of the batch to look up
     const QHeader *qh;
-    const QEntry *qcoop, *qwave;
+    const QEntry *qcoop, *qwave, *qcopy;
     uint32_t cap_coop, cap_wave;
     const int32_t *perm_a;
     int n_a;
@@ -122,9 +126,9 @@ struct QArgs {
     // B: the queue to build from (ba, bg)
     QPlan ba, bg;
     QHeader *bqh;
-    QEntry *bcoop, *bwave;
-    uint32_t bcap_coop, bcap_wave;
-    int has_b;
+    QEntry *bcoop, *bwave, *bcopy;
+    uint32_t bcap_coop, bcap_wave, bcap_copy;
+    int has_b;                 // 0, or 2: one workgroup for the keys of the batch to apply, one for the copies
     uint32_t lds_bytes;        // dynamic LDS of the launch (B keeps its inputs there when they fit)
     unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind} per wave
 };
@@ -162,221 +166,280 @@ __device__ __forceinline__ uint32_t qscan(uint32_t v, uint32_t *s_w, uint32_t *t
 }
 
 // =====================================================================================================
-// Role A: stable sort + plan finish of one batch by ONE workgroup, everything in LDS.
-//   s_key[npad] u32 | s_idx[2][npad] u16 | s_cnt[16][512] u16 | s_dbase[512] u16 | s_w[32] u32
+// Role A: the plan of one batch by ONE workgroup, everything in LDS -- by HASHING, not by sorting.
+//
+// A stable LSD radix sort of 7,168 keys by one workgroup costs 20+ us (three passes of 4-8 us each: measured with
+// ballot ranking and with LDS-atomic ranking alike; the LDS unit of one CU is the bound), twice the time the workers
+// of a step need.  Nothing on this path needs KEY ORDER: the workers need, per unique key, its occurrences in
+// OCCURRENCE order (the reference's serial chain, Optimizers.cpp:65-72) and the join with the next batch.  So:
+//   1. every thread claims a slot of an open-addressing table (8,192 words) for each of its keys (ds_cmpst);
+//   2. occupied slots are numbered 0..U-1 by a scan: the GROUP of a key (groups are in slot order, not key order);
+//   3. ONE wave walks the positions in order, row by row, and takes rank = atomic_add(count[group], 1): the rank of a
+//      position among the occurrences of its key.  One wave's LDS operations execute in program order and the lanes of
+//      one atomic instruction that hit the same counter are served in ascending lane order (verified per device by
+//      lds_atomics_lane_ordered; otherwise the wave ranks each row with a leader loop), so ranks follow positions;
+//   4. counts -> segment starts by a scan; perm[seg[group] + rank] = position.
+// The workspace is laid out like an index plan (plan_dev.h) and holds the same relations -- uniq / counts / seg /
+// inverse / perm / upos / sorted, perm ascending inside every segment -- except that the unique keys are in slot order
+// (header word kGroupedFlagWord = 1).  ha_plan_build_* is the entry point for key-ordered plans.
+//   s_tab[8192] u32 | s_lab[npad] u16 | s_cnt[npad + 4] u16 | s_rank[npad] u16 | s_w[32] u32
 // =====================================================================================================
+constexpr int kQTabBits = 13, kQTabSize = 1 << kQTabBits;
+constexpr uint32_t kQTabEmpty = 0xFFFFFFFFu;      // keys are <= 0xFFFFFFFE (to_key)
+constexpr int kGroupedFlagWord = 12;             // plan header word: 1 = unique keys in slot order, not key order
+__device__ __forceinline__ uint32_t q_hash(uint32_t key) {
+    return (key * 0x9E3779B1u) >> (32 - kQTabBits);
+}
 static inline size_t qsort_lds_bytes(int n) {
     const size_t npad = (static_cast<size_t>(n) + 1023) & ~static_cast<size_t>(1023);
-    return npad * 4 + 2 * npad * 2 + 16 * kQBins * 2 + kQBins * 2 + 32 * 4;
+    return kQTabSize * 4 + 3 * npad * 2 + 8 + 32 * 4;
 }
 
-// RANK_ATOMIC: the rank of a key among the equal digits of its wave comes back from ONE LDS atomic
-// (ds_add_rtn_u32 on the wave's counter: two 16-bit counters per word) instead of nine ballots + a 64-bit peer mask
-// per key (~110 VALU instructions per row of 64 keys, which made a pass VALU-bound: 6.5-8 us).  A stable sort needs
-// the lanes of one wave-instruction that hit the same counter to be served in ascending lane order.  gfx950 does
-// that (checked over 7e7 lane-operations, four collision patterns); because the ISA does not promise it, the host
-// side verifies it once per device before the first launch (lds_atomics_lane_ordered) and takes the ballot form
-// otherwise -- and every parity test compares the occurrence order with a stable argsort.
 template <typename IdT, bool RANK_ATOMIC>
 __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, const QPlan &p, uint32_t *lds,
                                                   unsigned long long *ph = nullptr) {
     const int n = p.n;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const int npad = (n + 1023) & ~1023;
-    uint32_t *s_key = lds;
-    uint16_t *s_idx = reinterpret_cast<uint16_t *>(lds + npad);
-    uint16_t *s_cnt = s_idx + 2 * npad;
-    uint16_t *s_dbase = s_cnt + 16 * kQBins;
-    uint32_t *s_w = reinterpret_cast<uint32_t *>(s_dbase + kQBins);
-
+    const int P = npad >> 10;                     // positions per thread, <= 7
+    uint32_t *s_tab = lds;
+    uint16_t *s_lab = reinterpret_cast<uint16_t *>(lds + kQTabSize);
+    uint16_t *s_cnt = s_lab + npad;
+    uint16_t *s_rank = s_cnt + npad + 4;      // (a spare counter behind the groups' for positions beyond the batch)
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(s_rank + npad);
     q_phase(ph, 0);
-    // keys (pads = all ones: they sort behind every real key, see the pass count below) and the widest key
-    uint32_t kmax = 0;
-    for (int base = 0; base < npad; base += 8192) {
-        uint32_t v[8];
+    // keys of positions tid, tid + 1024, ... stay in registers; the table and the counters are cleared meanwhile
+    uint32_t key[7];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = base + tid + k * 1024;
-            v[k] = to_key<IdT>(ids[min(j, n - 1)]);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = base + tid + k * 1024;
-            if (j < npad) {
-                if (j < n)
-                    kmax = max(kmax, v[k]);
-                s_key[j] = j < n ? v[k] : kPadKey;
-                s_idx[j] = static_cast<uint16_t>(j);
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1)
-        kmax = max(kmax, static_cast<uint32_t>(__shfl_xor(static_cast<int>(kmax), o, 64)));
-    if (lane == 0)
-        s_w[16 + w] = kmax;
+    for (int k = 0; k < 7; ++k)
+        key[k] = to_key<IdT>(ids[min(tid + k * 1024, n - 1)]);
+    for (int i = tid; i < kQTabSize; i += 1024)
+        s_tab[i] = kQTabEmpty;
+    for (int i = tid; i < npad / 2 + 2; i += 1024)
+        reinterpret_cast<uint32_t *>(s_cnt)[i] = 0;
     __syncthreads();
-    {
-        const uint32_t mine = s_w[16 + (lane & 15)];
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            kmax = max(kmax, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine), k)));
-    }
-    // Only the digits that can differ between real keys are sorted.  A pad's truncated value is all ones, i.e. >= every
-    // real key's, and pads have the highest indices, so the stable sort leaves them at the end either way.
-    const int bits = 32 - __builtin_clz(kmax | 1u);
-    const int npass = uniform((bits + kQDigit - 1) / kQDigit);
-    const int C = npad >> 4;          // positions per wave, a multiple of 64
-    const int nrow = C >> 6;          // <= 8
-
     q_phase(ph, 1);
-    for (int pass = 0; pass < npass; ++pass) {
-        q_phase(ph, 2 + pass);
-        const int shift = pass * kQDigit;
-        uint16_t *cur = s_idx + (pass & 1) * npad, *nxt = s_idx + ((pass & 1) ^ 1) * npad;
-        for (int i = tid; i < 16 * kQBins / 2; i += 1024)
-            reinterpret_cast<uint32_t *>(s_cnt)[i] = 0;
-        __syncthreads();
-        uint32_t off[8], dig[8], idx[8];
-        uint16_t *my_cnt = s_cnt + w * kQBins;
-        if (RANK_ATOMIC) {
-            // all of a wave's index reads, then all key reads, then the atomics in row order (one wave's LDS
-            // operations execute in order, so row r+1 finds the counts of rows 0..r)
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                idx[r] = r < nrow ? cur[w * C + r * 64 + lane] : 0u;
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                dig[r] = (s_key[idx[r]] >> shift) & (kQBins - 1);
-            uint32_t *cnt32 = reinterpret_cast<uint32_t *>(my_cnt);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (r < nrow) {   // wave-uniform
-                    const uint32_t sh = (dig[r] & 1u) * 16u;
-                    const uint32_t old = __hip_atomic_fetch_add(cnt32 + (dig[r] >> 1), 1u << sh, __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-                    off[r] = (old >> sh) & 0xFFFFu;
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (!RANK_ATOMIC && r < nrow) {   // wave-uniform
-                const uint32_t i = cur[w * C + r * 64 + lane];
-                const uint32_t d = (s_key[i] >> shift) & (kQBins - 1);
-                unsigned long long peers = ~0ull;
-#pragma unroll
-                for (int b = 0; b < kQDigit; ++b) {
-                    const bool bit = (d >> b) & 1u;
-                    const unsigned long long bal = __ballot(bit);
-                    peers &= bit ? bal : ~bal;
-                }
-                const uint32_t below = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
-                const uint32_t old = my_cnt[d];
-                // LDS operations of one wave execute in order: the leader's update lands behind every peer's read
-                // and ahead of the next row's reads
-                if (below == 0)
-                    my_cnt[d] = static_cast<uint16_t>(old + __builtin_popcountll(peers));
-                off[r] = old + below;
-                dig[r] = d;
-                idx[r] = i;
-            }
-        }
-        __syncthreads();
-        // digit-major, wave-minor exclusive scan of the 512 x 16 counters
-        uint32_t total = 0;
-        if (tid < kQBins) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t v = s_cnt[k * kQBins + tid];
-                s_cnt[k * kQBins + tid] = static_cast<uint16_t>(total);
-                total += v;
-            }
-        }
-        uint32_t all;
-        const uint32_t dbase = qscan(total, s_w, &all);
-        if (tid < kQBins)
-            s_dbase[tid] = static_cast<uint16_t>(dbase);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (r < nrow)
-                nxt[static_cast<uint32_t>(s_dbase[dig[r]]) + my_cnt[dig[r]] + off[r]] = static_cast<uint16_t>(idx[r]);
-        __syncthreads();
-    }
-
-    q_phase(ph, 6);
-    // ---- finish: one thread per P consecutive sorted positions --------------------------------------------
-    const uint16_t *fin = s_idx + (npass & 1) * npad;
-    uint16_t *s_ui = s_idx + ((npass & 1) ^ 1) * npad;   // unique index of every sorted position
-    uint16_t *s_seg = s_cnt;                             // first position of every unique key, [U + 1]
-    const int P = npad >> 10;                            // <= 8
-    const int q0 = tid * P;
-    uint32_t kprev = q0 > 0 ? s_key[fin[q0 - 1]] : 0u;
-    uint32_t heads = 0, nh = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j < P) {
-            const int q = q0 + j;
-            const uint32_t k = s_key[fin[q]];
-            const bool h = q < n && (q == 0 || k != kprev);
-            heads |= h ? (1u << j) : 0u;
-            nh += h;
-            kprev = k;
-        }
-    }
-    uint32_t U;
-    const uint32_t ubase = qscan(nh, s_w, &U);
+    // 1. claim a slot per key: the first attempts of a thread's keys go out back to back, collisions are walked after
     {
-        uint32_t ui = ubase;
+        uint32_t h[7], seen[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            h[k] = q_hash(key[k]);
+            seen[k] = key[k];
+            if (k < P && tid + k * 1024 < n) {
+                seen[k] = kQTabEmpty;
+                if (__hip_atomic_compare_exchange_strong(s_tab + h[k], &seen[k], key[k], __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    seen[k] = key[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int i = tid + k * 1024;
+            if (k < P && i < n) {
+                while (seen[k] != key[k]) {       // somebody else's key sits here: next slot
+                    h[k] = (h[k] + 1) & (kQTabSize - 1);
+                    seen[k] = kQTabEmpty;
+                    if (__hip_atomic_compare_exchange_strong(s_tab + h[k], &seen[k], key[k], __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                        seen[k] = key[k];
+                }
+                s_lab[i] = static_cast<uint16_t>(h[k]);
+            }
+        }
+    }
+    __syncthreads();
+    q_phase(ph, 2);
+    // 2. number the occupied slots (thread t: slots 8t .. 8t+7); the table then maps slot -> group
+    uint32_t U;
+    {
+        uint32_t kk[8], occ = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (j < P) {
-                const int q = q0 + j;
-                if (heads & (1u << j)) {
-                    s_seg[ui] = static_cast<uint16_t>(q);
-                    ++ui;
+            kk[j] = s_tab[tid * 8 + j];
+            occ += kk[j] != kQTabEmpty;
+        }
+        uint32_t g = qscan(occ, s_w, &U);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (kk[j] != kQTabEmpty) {
+                p.uniq[g] = kk[j];
+                s_tab[tid * 8 + j] = g;
+                ++g;
+            }
+        }
+    }
+    __syncthreads();
+    q_phase(ph, 3);
+    uint32_t lab[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int i = tid + k * 1024;
+        lab[k] = 0;
+        if (k < P && i < n) {
+            lab[k] = s_tab[s_lab[i]];
+            s_lab[i] = static_cast<uint16_t>(lab[k]);
+        }
+    }
+    __syncthreads();
+    q_phase(ph, 4);
+    // 3. ranks in position order: wave 0, eight rows per trip -- all reads, then all atomics, then the extraction and
+    // the stores (branch-free: a position beyond the batch counts on a spare counter, so no wait sits between atomics)
+    if (w == 0) {
+        uint32_t *cnt32 = reinterpret_cast<uint32_t *>(s_cnt);
+        const uint32_t spare = static_cast<uint32_t>(npad);      // s_cnt has npad + 2 entries
+        uint32_t nx[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            nx[r] = s_lab[min(r * 64 + lane, npad - 1)];
+        for (int r0 = 0; r0 < npad; r0 += 8 * 64) {
+            uint32_t lb[8], rk[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = r0 + r * 64 + lane;
+                lb[r] = i < n ? nx[r] : spare;
+            }
+            // the labels of the next trip are on their way while this trip's atomics run
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                nx[r] = s_lab[min(r0 + 8 * 64 + r * 64 + lane, npad - 1)];
+            if (RANK_ATOMIC) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    rk[r] = __hip_atomic_fetch_add(cnt32 + (lb[r] >> 1), 1u << ((lb[r] & 1u) * 16u), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    rk[r] = (rk[r] >> ((lb[r] & 1u) * 16u)) & 0xFFFFu;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    // leader loop: the lanes of one group at a time, lowest lane first
+                    rk[r] = 0;
+                    unsigned long long todo = ~0ull;
+                    while (todo) {
+                        const int lead = __builtin_ctzll(todo);
+                        const uint32_t gl = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lb[r]), lead));
+                        const unsigned long long same = __ballot(lb[r] == gl);
+                        const uint32_t base = s_cnt[gl];
+                        if (lb[r] == gl)
+                            rk[r] = base + __builtin_popcountll(same & ((1ull << lane) - 1ull));
+                        if (lane == lead)
+                            s_cnt[gl] = static_cast<uint16_t>(base + __builtin_popcountll(same));
+                        todo &= ~same;
+                    }
                 }
-                s_ui[q] = static_cast<uint16_t>(ui - 1);   // positions >= n: never read
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = r0 + r * 64 + lane;
+                if (i < n)
+                    s_rank[i] = static_cast<uint16_t>(rk[r]);
+            }
+        }
+    } else {
+        // the other waves write what is known already
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int i = tid + k * 1024;
+            if (k < P && i < n) {
+                p.keys[i] = key[k];
+                p.inverse[i] = static_cast<int32_t>(lab[k]);
+            }
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int i = tid + k * 1024;
+            if (k < P && i < n) {
+                p.keys[i] = key[k];
+                p.inverse[i] = static_cast<int32_t>(lab[k]);
+            }
+        }
+    }
+    q_phase(ph, 5);
+    // 4. counts -> segment starts (thread t: groups G t .. G t + G - 1, G = npad / 1024); s_cnt then holds the starts
+    {
+        uint32_t c[7], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint32_t g = tid * P + j;
+            c[j] = (j < P && g < U) ? s_cnt[g] : 0u;
+            sum += c[j];
+        }
+        uint32_t all;
+        uint32_t at = qscan(sum, s_w, &all);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint32_t g = tid * P + j;
+            if (j < P && g < U) {
+                s_cnt[g] = static_cast<uint16_t>(at);
+                p.seg[g] = static_cast<int32_t>(at);
+                p.counts[g] = static_cast<int32_t>(c[j]);
+                at += c[j];
             }
         }
     }
     if (tid == 0) {
-        s_seg[U] = static_cast<uint16_t>(n);
         p.hdr->n_unique = U;
+        p.hdr->reserved[kGroupedFlagWord] = 1;
         p.seg[U] = n;
     }
     __syncthreads();
+    q_phase(ph, 6);
+    // Outputs.  Every array leaves through LDS so that the global stores are contiguous (scattered 4-byte stores of one
+    // CU -- perm, sorted keys, group of a position -- drained for 5-8 us behind the role): keys by position go to the
+    // table's space, perm and the group of every grouped position to the label / rank arrays.
+    {
+        uint32_t q[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int i = tid + k * 1024;
+            q[k] = (k < P && i < n) ? static_cast<uint32_t>(s_cnt[lab[k]]) + s_rank[i] : 0u;
+        }
+        __syncthreads();      // labels, ranks and the table have been read by everyone
+        uint16_t *s_perm = s_lab, *s_gq = s_rank;
+        uint32_t *s_key = s_tab;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int i = tid + k * 1024;
+            if (k < P && i < n) {
+                s_perm[q[k]] = static_cast<uint16_t>(i);
+                s_gq[q[k]] = static_cast<uint16_t>(lab[k]);
+                s_key[i] = key[k];
+            }
+        }
+        __syncthreads();
+        for (int qq = tid; qq < n; qq += 1024) {
+            const uint32_t i = s_perm[qq];
+            p.perm[qq] = static_cast<int32_t>(i);
+            p.sorted[qq] = s_key[i];
+            p.upos[qq] = static_cast<int32_t>(s_gq[qq]);
+        }
+        // the first three occurrences of every key also go to the group's own words (the queue builder embeds them in
+        // small items; entries beyond the group's count are never used)
+        for (uint32_t g = tid; g < U; g += 1024) {
+            const int st = s_cnt[g];
+            uint2 oc;
+            oc.x = static_cast<uint32_t>(s_perm[min(st, n - 1)]) | (static_cast<uint32_t>(s_perm[min(st + 1, n - 1)]) << 16);
+            oc.y = s_perm[min(st + 2, n - 1)];
+            reinterpret_cast<uint2 *>(p.occ)[g] = oc;
+        }
+    }
     q_phase(ph, 7);
-    for (int q = tid; q < n; q += 1024) {
-        const uint32_t i = fin[q];
-        const int32_t ui = s_ui[q];
-        p.sorted[q] = s_key[i];
-        p.perm[q] = static_cast<int32_t>(i);
-        p.upos[q] = ui;
-        p.inverse[i] = ui;
-        p.keys[q] = s_key[q];
-    }
-    for (uint32_t u = tid; u < U; u += 1024) {
-        const uint32_t q = s_seg[u];
-        p.uniq[u] = s_key[fin[q]];
-        p.seg[u] = static_cast<int32_t>(q);
-        p.counts[u] = static_cast<int32_t>(s_seg[u + 1]) - static_cast<int32_t>(q);
-    }
-    q_phase(ph, 8);
 }
 
 // =====================================================================================================
 // Role B: the queue of the NEXT launch from the finished plans of its two batches.
-//   s_ua[npad_a] u32 | s_ug[npad_g] u32 | s_w[16] u32
 // =====================================================================================================
-// minimum (unique keys + scan words + per-thread match words) and the size at which B keeps ALL its inputs in LDS
-// (counts, segment starts, the matched batch's counts / starts, the occurrence indices: 16-bit each)
+// the table + the keys in it (+, where it fits, the lookup groups' packed count / start)
 static inline size_t qjoin_lds_bytes(int n_a, int n_g) {
-    return (static_cast<size_t>(n_a) + n_g + 2) * 4 + 32 * 4 + 8 * 1024 * 2;
+    return kQTabSize * 4 + static_cast<size_t>(n_a > n_g ? n_a : n_g) * 4 + 32 * 4;
 }
-static inline size_t qjoin_lds_resident_bytes(int n_a, int n_g) {
-    return (static_cast<size_t>(n_a) + n_g + 2) * 4 + 32 * 4 + (static_cast<size_t>(n_a) * 5 + static_cast<size_t>(n_g) * 2 + 8) * 2;
+static inline size_t qjoin_lds_resident_bytes(int n_g) {
+    return kQTabSize * 4 + static_cast<size_t>(n_g) * 8 + 32 * 4;
 }
 constexpr size_t kQLdsBudget = 76800;   // 75 KiB: two workgroups per CU
 
@@ -393,16 +456,6 @@ __device__ __forceinline__ int q_kind(uint32_t c, uint32_t m, bool in_table) {
 }
 __device__ __forceinline__ int q_slice(int kind) {   // columns per item
     return kind == kQL ? 32 : kind == kQG ? 64 : kind == kQM ? 128 : 512;
-}
-
-// lower bound of `key` in s[0, n): the index of the first element >= key
-__device__ __forceinline__ int q_lower_bound(const uint32_t *s, int n, uint32_t key) {
-    int pos = 0;
-#pragma unroll
-    for (int step = 8192; step >= 1; step >>= 1)
-        if (pos + step <= n && s[pos + step - 1] < key)
-            pos += step;
-    return pos;
 }
 
 __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
@@ -427,21 +480,6 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
         d[1] = hi;
     }
 }
-// the first occurrence indices of a small item from the plan in global memory
-__device__ __forceinline__ void q_emit(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
-                                       uint32_t fs, int width, const int32_t *perm_a, int n_a) {
-    uint32_t o01 = 0, o23 = 0;
-    if (kind == kQS && c > 0) {
-        uint32_t o[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            o[t] = static_cast<uint32_t>(perm_a[min(static_cast<int>(st) + t, n_a - 1)]);
-        o01 = o[0] | (o[1] << 16);
-        o23 = o[2] | (o[3] << 16);
-    }
-    q_emit_words(dst, kind, key, c, st, m, fs, width, o01, o23);
-}
-
 struct QCount {   // items per class: coop (G), long, medium, small (S and Z)
     uint32_t g, l, m, s;
 };
@@ -455,254 +493,242 @@ __device__ __forceinline__ QCount q_count(QCount t, int kind, uint32_t per512, u
     return t;
 }
 
-__device__ __forceinline__ void qjoin_body_global(const QPlan pa, const QPlan pg, const uint64_t rows, const int width,
-                                                  QHeader *bqh, QEntry *bcoop, QEntry *bwave, const uint32_t bcap_coop,
-                                                  const uint32_t bcap_wave, uint32_t *lds, unsigned long long *ph) {
-    const int tid = threadIdx.x;
-    q_phase(ph, 0);
-    const int Ua = pa.n > 0 ? static_cast<int>(pa.hdr->n_unique) : 0;
-    const int Ug = pg.n > 0 ? static_cast<int>(pg.hdr->n_unique) : 0;
-    uint32_t *s_ua = lds, *s_ug = lds + Ua + 1, *s_w = lds + Ua + Ug + 2;
-    uint16_t *s_match = reinterpret_cast<uint16_t *>(s_w + 32) + tid;   // [round][thread]: thread-private words
-    for (int i = tid; i < Ua; i += 1024)
-        s_ua[i] = pa.uniq[i];
-    for (int i = tid; i < Ug; i += 1024)
-        s_ug[i] = pg.uniq[i];
-    __syncthreads();
-    q_phase(ph, 1);
-    const uint32_t per512 = (width + 511) / 512, per128 = (width + 127) / 128, per32 = (width + 31) / 32;
-    const int ra = (Ua + 1023) >> 10, rg = (Ug + 1023) >> 10;   // rounds, <= 8 (kQMax <= 8192)
-    // pass 1: what every key of the union costs.  Keys of the batch to apply first (matched against the batch to
-    // look up: the unique index in g or 0xFFFF goes to s_match), then the keys only the lookup names (bit r of
-    // `found` = the key of round r is also in a).
-    uint32_t found = 0;
-    QCount t{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < ra) {
-            const int x = r * 1024 + tid;
-            if (x < Ua) {
-                const uint32_t key = s_ua[x];
-                const int y = q_lower_bound(s_ug, Ug, key);
-                const bool hit = y < Ug && s_ug[y] == key;
-                s_match[r * 1024] = static_cast<uint16_t>(hit ? y : 0xFFFF);
-                const uint32_t c = static_cast<uint32_t>(pa.counts[x]);
-                const uint32_t m = hit ? static_cast<uint32_t>(pg.counts[y]) : 0u;
-                t = q_count(t, q_kind(c, m, key < rows), per512, per128, per32);
-            }
-        }
+// Hash join of the two batches' groups by TWO workgroups, everything after the first trips to memory in LDS:
+//   part 0  the groups of the batch to LOOK UP (g) enter an open-addressing table (slot -> group index; their keys and --
+//           where it fits -- their packed count | start << 16 sit beside it); every group of the batch to APPLY (a)
+//           probes it: a hit yields the destinations (m, fs).  Items of every key the batch to apply names.
+//   part 1  the keys of the batch to apply enter the table; every group of the lookup batch probes it: a MISS is a key
+//           only the lookup names -- a pure copy (or zeros, beyond the table).  Items of the copies, in their own
+//           region of the queue.
+// Each part: classes, scans, items (thread by thread in the order they were counted).  Two passes over the probing side,
+// each one batch of independent loads (branch-free: 32-bit unsigned clamped indices, scalar base + one offset register
+// per round -- signed or predicated indices cost a 64-bit address pair per load) and a probe per group: pass 1 counts
+// the items per class, pass 2 -- behind the scans -- reads the groups again with everything an item needs and probes
+// again.  Nothing but the running item numbers lives across the scans (holding five words per group and round did:
+// the role spilled at the kernel's 64 registers).
+struct QJoin {      // what every part of the join needs (passed by reference to inlined code only)
+    QPlan pa, pg;
+    uint64_t rows;
+    int width, Ua, Ug, Ub;      // Ub: keys in the table
+    bool cs_res;
+    uint32_t *s_tab, *s_bk, *s_cs, *s_w;
+    QHeader *bqh;
+    QEntry *bcoop, *bwave, *bcopy;
+    uint32_t bcap_coop, bcap_wave, bcap_copy, per512, per128, per32;
+};
+
+// group index of `key` in the table, or 0xFFFFFFFF
+__device__ __forceinline__ uint32_t qjoin_probe(const QJoin &j, uint32_t key) {
+    uint32_t h = q_hash(key);
+    for (;;) {
+        const uint32_t e = j.s_tab[h];
+        if (e == kQTabEmpty || j.s_bk[e] == key)
+            return e;
+        h = (h + 1) & (kQTabSize - 1);
     }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < rg) {
-            const int y = r * 1024 + tid;
-            if (y < Ug) {
-                const uint32_t key = s_ug[y];
-                const int x = q_lower_bound(s_ua, Ua, key);
-                const bool hit = x < Ua && s_ua[x] == key;
-                found |= hit ? (1u << r) : 0u;
-                if (!hit)
-                    t = q_count(t, q_kind(0u, static_cast<uint32_t>(pg.counts[y]), key < rows), per512, per128, per32);
-            }
-        }
-    }
-    q_phase(ph, 2);
-    uint32_t nL, nM, nS, nG;
-    QCount b;
-    b.l = qscan(t.l, s_w, &nL);
-    b.m = qscan(t.m, s_w, &nM) + nL;            // queue order: long, medium, small
-    b.s = qscan(t.s, s_w, &nS) + nL + nM;
-    b.g = qscan(t.g, s_w, &nG);
-    if (tid == 0) {
-        bqh->n_wave = min(nL + nM + nS, bcap_wave);
-        bqh->n_coop = min(nG, bcap_coop);
-        bqh->n_long = nL;
-        bqh->n_medium = nM;
-        bqh->n_small = nS;
-        bqh->n_zero = 0;
-    }
-    q_phase(ph, 3);
-    // pass 2: the items, thread by thread in the order they were counted
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < ra) {
-            const int x = r * 1024 + tid;
-            if (x < Ua) {
-                const uint32_t key = s_ua[x];
-                const uint32_t ym = s_match[r * 1024];
-                const bool hit = ym != 0xFFFFu;
-                const uint32_t c = static_cast<uint32_t>(pa.counts[x]);
-                const uint32_t st = static_cast<uint32_t>(pa.seg[x]);
-                const uint32_t m = hit ? static_cast<uint32_t>(pg.counts[ym]) : 0u;
-                const uint32_t fs = hit ? static_cast<uint32_t>(pg.seg[ym]) : 0u;
-                const int kind = q_kind(c, m, key < rows);
-                if (kind != kQNone) {
-                    const uint32_t at = kind == kQG ? b.g : kind == kQL ? b.l : kind == kQM ? b.m : b.s;
-                    const QCount nb = q_count(b, kind, per512, per128, per32);
-                    const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
-                    b = nb;
-                    // the layout's bound makes the test always true; never write beyond the queue
-                    if (at + cnt <= (kind == kQG ? bcap_coop : bcap_wave))
-                        q_emit((kind == kQG ? bcoop : bwave) + at, kind, key, c, st, m, fs, width, pa.perm, pa.n);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < rg) {
-            const int y = r * 1024 + tid;
-            if (y < Ug && !(found & (1u << r))) {
-                const uint32_t key = s_ug[y];
-                const uint32_t m = static_cast<uint32_t>(pg.counts[y]);
-                const int kind = q_kind(0u, m, key < rows);
-                if (kind != kQNone) {
-                    const uint32_t at = kind == kQM ? b.m : b.s;     // c == 0: medium (many destinations), small or zero
-                    const QCount nb = q_count(b, kind, per512, per128, per32);
-                    const uint32_t cnt = (nb.m - b.m) + (nb.s - b.s);
-                    b = nb;
-                    if (at + cnt <= bcap_wave)
-                        q_emit(bwave + at, kind, key, 0u, 0u, m, static_cast<uint32_t>(pg.seg[y]), width, pa.perm, pa.n);
-                }
-            }
-        }
-    }
-    q_phase(ph, 4);
+}
+__device__ __forceinline__ uint32_t qjoin_dest(const QJoin &j, uint32_t e) {   // m | fs << 16 of lookup group e
+    if (e == kQTabEmpty)
+        return 0u;
+    return j.cs_res ? j.s_cs[e] : (static_cast<uint32_t>(j.pg.counts[e]) | (static_cast<uint32_t>(j.pg.seg[e]) << 16));
+}
+__device__ __forceinline__ QCount qjoin_emit_one(const QJoin &j, QCount b, QEntry *wave, uint32_t cap_wave, uint32_t key,
+                                                 uint32_t c, uint32_t st, uint32_t m, uint32_t fs, uint32_t o01, uint32_t o2) {
+    const int kind = q_kind(c, m, key < j.rows);
+    if (kind == kQNone)
+        return b;
+    const uint32_t at = kind == kQG ? b.g : kind == kQL ? b.l : kind == kQM ? b.m : b.s;
+    const QCount nb = q_count(b, kind, j.per512, j.per128, j.per32);
+    const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
+    // the layout's bound makes the test always true; never write beyond the queue
+    if (at + cnt <= (kind == kQG ? j.bcap_coop : cap_wave))
+        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st, m, fs, j.width, o01, o2);
+    return nb;
 }
 
-// The same join with EVERYTHING it reads staged in LDS by one batch of independent loads (unique keys, counts and
-// segment starts of both batches, the occurrence indices of the batch to apply): the version above pays a dependent
-// trip to memory per round and per field -- about ten of them at 2-3 us each while the workers' burst is in flight.
-//   s_ua[Ua+1] s_ug[Ug+1] u32 | s_w[32] | u16: ca sa ma fa [Ua], cg sg [Ug], perm [n_a]
-__device__ __forceinline__ void qjoin_body_resident(const QPlan pa, const QPlan pg, const int Ua, const int Ug,
-                                                    const uint64_t rows, const int width, QHeader *bqh, QEntry *bcoop,
-                                                    QEntry *bwave, const uint32_t bcap_coop, const uint32_t bcap_wave,
-                                                    uint32_t *lds, unsigned long long *ph) {
-    const int tid = threadIdx.x;
-    uint32_t *s_ua = lds, *s_ug = lds + Ua + 1, *s_w = lds + Ua + Ug + 2;
-    uint16_t *ca = reinterpret_cast<uint16_t *>(s_w + 32), *sa = ca + Ua, *ma = sa + Ua, *fa = ma + Ua;
-    uint16_t *cg = fa + Ua, *sg = cg + Ug, *pp = sg + Ug;
-    for (int i = tid; i < Ua; i += 1024) {
-        s_ua[i] = pa.uniq[i];
-        ca[i] = static_cast<uint16_t>(pa.counts[i]);
-        sa[i] = static_cast<uint16_t>(pa.seg[i]);
-    }
-    for (int i = tid; i < Ug; i += 1024) {
-        s_ug[i] = pg.uniq[i];
-        cg[i] = static_cast<uint16_t>(pg.counts[i]);
-        sg[i] = static_cast<uint16_t>(pg.seg[i]);
-    }
-    for (int i = tid; i < pa.n; i += 1024)
-        pp[i] = static_cast<uint16_t>(pa.perm[i]);
-    __syncthreads();
-    q_phase(ph, 1);
-    const uint32_t per512 = (width + 511) / 512, per128 = (width + 127) / 128, per32 = (width + 31) / 32;
-    const int ra = (Ua + 1023) >> 10, rg = (Ug + 1023) >> 10;
-    uint32_t found = 0;
-    QCount t{0u, 0u, 0u, 0u};
+// ---- part 0: groups of the batch to apply, thread t: groups t, t + 1024, ... --------------------------------------
+template <int R0, int R1>
+__device__ __forceinline__ QCount qjoin_count_groups(const QJoin &j, QCount t) {
+    const uint32_t tid = threadIdx.x, last = static_cast<uint32_t>(max(j.Ua, 1) - 1);
+    uint32_t ka[R1 - R0], c[R1 - R0];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < ra) {
-            const int x = r * 1024 + tid;
-            if (x < Ua) {
-                const uint32_t key = s_ua[x];
-                const int y = q_lower_bound(s_ug, Ug, key);
-                const bool hit = y < Ug && s_ug[y] == key;
-                const uint32_t m = hit ? cg[y] : 0u;
-                ma[x] = static_cast<uint16_t>(m);
-                fa[x] = hit ? sg[y] : static_cast<uint16_t>(0);
-                t = q_count(t, q_kind(ca[x], m, key < rows), per512, per128, per32);
-            }
-        }
+    for (int r = R0; r < R1; ++r) {
+        const uint32_t x = min(static_cast<uint32_t>(r) * 1024u + tid, last);
+        ka[r - R0] = j.pa.uniq[x];
+        c[r - R0] = static_cast<uint32_t>(j.pa.counts[x]);
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < rg) {
-            const int y = r * 1024 + tid;
-            if (y < Ug) {
-                const uint32_t key = s_ug[y];
-                const int x = q_lower_bound(s_ua, Ua, key);
-                const bool hit = x < Ua && s_ua[x] == key;
-                found |= hit ? (1u << r) : 0u;
-                if (!hit)
-                    t = q_count(t, q_kind(0u, cg[y], key < rows), per512, per128, per32);
-            }
+    for (int r = R0; r < R1; ++r) {
+        if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ua) {
+            const uint32_t mf = qjoin_dest(j, qjoin_probe(j, ka[r - R0]));
+            t = q_count(t, q_kind(c[r - R0], mf & 0xFFFFu, ka[r - R0] < j.rows), j.per512, j.per128, j.per32);
         }
     }
-    q_phase(ph, 2);
-    uint32_t nL, nM, nS, nG;
-    QCount b;
-    b.l = qscan(t.l, s_w, &nL);
-    b.m = qscan(t.m, s_w, &nM) + nL;
-    b.s = qscan(t.s, s_w, &nS) + nL + nM;
-    b.g = qscan(t.g, s_w, &nG);
-    if (tid == 0) {
-        bqh->n_wave = min(nL + nM + nS, bcap_wave);
-        bqh->n_coop = min(nG, bcap_coop);
-        bqh->n_long = nL;
-        bqh->n_medium = nM;
-        bqh->n_small = nS;
-        bqh->n_zero = 0;
-    }
-    q_phase(ph, 3);
+    return t;
+}
+template <int R0, int R1>
+__device__ __forceinline__ QCount qjoin_emit_groups(const QJoin &j, QCount b) {
+    const uint32_t tid = threadIdx.x, last = static_cast<uint32_t>(max(j.Ua, 1) - 1);
+    uint32_t ka[R1 - R0], cst[R1 - R0], o01[R1 - R0], o2[R1 - R0];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < ra) {
-            const int x = r * 1024 + tid;
-            if (x < Ua) {
-                const uint32_t key = s_ua[x], c = ca[x], st = sa[x], m = ma[x], fs = fa[x];
-                const int kind = q_kind(c, m, key < rows);
-                if (kind != kQNone) {
-                    const uint32_t at = kind == kQG ? b.g : kind == kQL ? b.l : kind == kQM ? b.m : b.s;
-                    const QCount nb = q_count(b, kind, per512, per128, per32);
-                    const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
-                    b = nb;
-                    uint32_t o01 = 0, o23 = 0;
-                    if (kind == kQS && c > 0) {
-                        const int last = pa.n - 1;
-                        o01 = static_cast<uint32_t>(pp[min(static_cast<int>(st), last)]) |
-                              (static_cast<uint32_t>(pp[min(static_cast<int>(st) + 1, last)]) << 16);
-                        o23 = static_cast<uint32_t>(pp[min(static_cast<int>(st) + 2, last)]);
-                    }
-                    if (at + cnt <= (kind == kQG ? bcap_coop : bcap_wave))
-                        q_emit_words((kind == kQG ? bcoop : bwave) + at, kind, key, c, st, m, fs, width, o01, o23);
-                }
-            }
-        }
+    for (int r = R0; r < R1; ++r) {
+        const uint32_t x = min(static_cast<uint32_t>(r) * 1024u + tid, last);
+        const uint2 oc = reinterpret_cast<const uint2 *>(j.pa.occ)[x];
+        ka[r - R0] = j.pa.uniq[x];
+        cst[r - R0] = static_cast<uint32_t>(j.pa.counts[x]) | (static_cast<uint32_t>(j.pa.seg[x]) << 16);
+        o01[r - R0] = oc.x;
+        o2[r - R0] = oc.y & 0xFFFFu;
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < rg) {
-            const int y = r * 1024 + tid;
-            if (y < Ug && !(found & (1u << r))) {
-                const uint32_t key = s_ug[y], m = cg[y];
-                const int kind = q_kind(0u, m, key < rows);
-                if (kind != kQNone) {
-                    const uint32_t at = kind == kQM ? b.m : b.s;
-                    const QCount nb = q_count(b, kind, per512, per128, per32);
-                    const uint32_t cnt = (nb.m - b.m) + (nb.s - b.s);
-                    b = nb;
-                    if (at + cnt <= bcap_wave)
-                        q_emit_words(bwave + at, kind, key, 0u, 0u, m, sg[y], width, 0u, 0u);
-                }
-            }
+    for (int r = R0; r < R1; ++r) {
+        if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ua) {
+            const uint32_t mf = qjoin_dest(j, qjoin_probe(j, ka[r - R0]));
+            b = qjoin_emit_one(j, b, j.bwave, j.bcap_wave, ka[r - R0], cst[r - R0] & 0xFFFFu, cst[r - R0] >> 16,
+                               mf & 0xFFFFu, mf >> 16, o01[r - R0], o2[r - R0]);
         }
     }
-    q_phase(ph, 4);
+    return b;
+}
+
+// ---- part 1: groups of the lookup batch, the ones the table (keys of the batch to apply) does not hold ------------
+template <int R0, int R1>
+__device__ __forceinline__ QCount qjoin_count_copies(const QJoin &j, QCount t) {
+    const uint32_t tid = threadIdx.x, last = static_cast<uint32_t>(max(j.Ug, 1) - 1);
+    uint32_t kg[R1 - R0], m[R1 - R0];
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+        const uint32_t y = min(static_cast<uint32_t>(r) * 1024u + tid, last);
+        kg[r - R0] = j.pg.uniq[y];
+        m[r - R0] = static_cast<uint32_t>(j.pg.counts[y]);
+    }
+#pragma unroll
+    for (int r = R0; r < R1; ++r)
+        if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
+            t = q_count(t, q_kind(0u, m[r - R0], kg[r - R0] < j.rows), j.per512, j.per128, j.per32);
+    return t;
+}
+template <int R0, int R1>
+__device__ __forceinline__ QCount qjoin_emit_copies(const QJoin &j, QCount b) {
+    const uint32_t tid = threadIdx.x, last = static_cast<uint32_t>(max(j.Ug, 1) - 1);
+    uint32_t kg[R1 - R0], mfs[R1 - R0];
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+        const uint32_t y = min(static_cast<uint32_t>(r) * 1024u + tid, last);
+        kg[r - R0] = j.pg.uniq[y];
+        mfs[r - R0] = static_cast<uint32_t>(j.pg.counts[y]) | (static_cast<uint32_t>(j.pg.seg[y]) << 16);
+    }
+#pragma unroll
+    for (int r = R0; r < R1; ++r)
+        if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
+            b = qjoin_emit_one(j, b, j.bcopy, j.bcap_copy, kg[r - R0], 0u, 0u, mfs[r - R0] & 0xFFFFu, mfs[r - R0] >> 16,
+                               0u, 0u);
+    return b;
 }
 
 __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const uint64_t rows, const int width,
-                                           QHeader *bqh, QEntry *bcoop, QEntry *bwave, const uint32_t bcap_coop,
-                                           const uint32_t bcap_wave, uint32_t *lds, uint32_t lds_bytes,
+                                           QHeader *bqh, QEntry *bcoop, QEntry *bwave, QEntry *bcopy,
+                                           const uint32_t bcap_coop, const uint32_t bcap_wave, const uint32_t bcap_copy,
+                                           uint32_t *lds, uint32_t lds_bytes, const int part,
                                            unsigned long long *ph = nullptr) {
+    const int tid = threadIdx.x;
     q_phase(ph, 0);
-    const int Ua = pa.n > 0 ? static_cast<int>(pa.hdr->n_unique) : 0;
-    const int Ug = pg.n > 0 ? static_cast<int>(pg.hdr->n_unique) : 0;
-    const uint32_t need = static_cast<uint32_t>((Ua + Ug + 2) * 4 + 32 * 4 + (4 * Ua + 2 * Ug + pa.n + 8) * 2);
-    if (need <= lds_bytes)    // workgroup-uniform
-        qjoin_body_resident(pa, pg, Ua, Ug, rows, width, bqh, bcoop, bwave, bcap_coop, bcap_wave, lds, ph);
-    else
-        qjoin_body_global(pa, pg, rows, width, bqh, bcoop, bwave, bcap_coop, bcap_wave, lds, ph);
+    QJoin j;
+    j.pa = pa;
+    j.pg = pg;
+    j.rows = rows;
+    j.width = width;
+    // (wave-uniform values read through the vector memory path: back to scalar registers, or every pointer and
+    // bound derived from them lives in vector registers and every branch on them becomes a divergent one)
+    j.Ua = uniform(pa.n > 0 ? static_cast<int>(pa.hdr->n_unique) : 0);
+    j.Ug = uniform(pg.n > 0 ? static_cast<int>(pg.hdr->n_unique) : 0);
+    j.Ub = part == 0 ? j.Ug : j.Ua;
+    j.cs_res = part == 0 && static_cast<uint32_t>(kQTabSize * 4 + j.Ug * 8 + 32 * 4) <= lds_bytes;   // workgroup-uniform
+    j.s_tab = lds;
+    j.s_bk = lds + kQTabSize;
+    j.s_cs = j.s_bk + j.Ub;
+    j.s_w = j.s_bk + (j.cs_res ? 2 * j.Ub : j.Ub);
+    j.bqh = bqh;
+    j.bcoop = bcoop;
+    j.bwave = bwave;
+    j.bcopy = bcopy;
+    j.bcap_coop = bcap_coop;
+    j.bcap_wave = bcap_wave;
+    j.bcap_copy = bcap_copy;
+    j.per512 = (width + 511) / 512;
+    j.per128 = (width + 127) / 128;
+    j.per32 = (width + 31) / 32;
+    // the table: keys (+ packed count / start of a lookup group) to LDS, then every key claims a slot
+    const uint32_t *bkeys = part == 0 ? pg.uniq : pa.uniq;
+    for (int i = tid; i < kQTabSize; i += 1024)
+        j.s_tab[i] = kQTabEmpty;
+    for (int y = tid; y < j.Ub; y += 1024) {
+        j.s_bk[y] = bkeys[y];
+        if (j.cs_res)
+            j.s_cs[y] = static_cast<uint32_t>(pg.counts[y]) | (static_cast<uint32_t>(pg.seg[y]) << 16);
+    }
+    __syncthreads();
+    q_phase(ph, 1);
+    for (int y = tid; y < j.Ub; y += 1024) {
+        uint32_t h = q_hash(j.s_bk[y]);
+        for (;;) {
+            uint32_t seen = kQTabEmpty;
+            if (__hip_atomic_compare_exchange_strong(j.s_tab + h, &seen, static_cast<uint32_t>(y), __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                break;
+            h = (h + 1) & (kQTabSize - 1);
+        }
+    }
+    __syncthreads();      // the table is complete
+    q_phase(ph, 2);
+    QCount t{0u, 0u, 0u, 0u};
+    if (part == 0) {      // workgroup-uniform everywhere below (a batch that is absent has null plan pointers)
+        if (j.Ua > 0)
+            t = qjoin_count_groups<0, 4>(j, t);
+        if (j.Ua > 4096)
+            t = qjoin_count_groups<4, 7>(j, t);
+        q_phase(ph, 3);
+        uint32_t nL, nM, nS, nG;
+        QCount b;
+        b.l = qscan(t.l, j.s_w, &nL);
+        b.m = qscan(t.m, j.s_w, &nM) + nL;            // queue order: long, medium, small
+        b.s = qscan(t.s, j.s_w, &nS) + nL + nM;
+        b.g = qscan(t.g, j.s_w, &nG);
+        if (tid == 0) {
+            bqh->n_wave = min(nL + nM + nS, bcap_wave);
+            bqh->n_coop = min(nG, bcap_coop);
+            bqh->n_long = nL;
+            bqh->n_medium = nM;
+            bqh->n_small = nS;
+        }
+        q_phase(ph, 4);
+        if (j.Ua > 0)
+            b = qjoin_emit_groups<0, 3>(j, b);
+        if (j.Ua > 3072)
+            b = qjoin_emit_groups<3, 5>(j, b);
+        if (j.Ua > 5120)
+            b = qjoin_emit_groups<5, 7>(j, b);
+    } else {
+        if (j.Ug > 0)
+            t = qjoin_count_copies<0, 4>(j, t);
+        if (j.Ug > 4096)
+            t = qjoin_count_copies<4, 7>(j, t);
+        q_phase(ph, 3);
+        uint32_t nM, nS;
+        QCount b{0u, 0u, 0u, 0u};
+        b.m = qscan(t.m, j.s_w, &nM);                 // copies: medium (many destinations), then small / zero
+        b.s = qscan(t.s, j.s_w, &nS) + nM;
+        if (tid == 0) {
+            bqh->n_copy = min(nM + nS, bcap_copy);
+            bqh->n_copy_medium = nM;
+            bqh->n_copy_small = nS;
+        }
+        q_phase(ph, 4);
+        if (j.Ug > 0)
+            b = qjoin_emit_copies<0, 4>(j, b);
+        if (j.Ug > 4096)
+            b = qjoin_emit_copies<4, 7>(j, b);
+    }
+    q_phase(ph, 5);
 }
 
 // =====================================================================================================
@@ -986,14 +1012,16 @@ __global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
     int b = blockIdx.x;
+    if (b < a.has_a + a.has_b)
+        __builtin_amdgcn_s_setprio(3);   // the single-workgroup roles share their CU with a worker workgroup
     if (b == 0 && a.has_a) {
         role = 1;
         qsort_finish_body<IdT, RANK_ATOMIC>(static_cast<const IdT *>(a.ahead_ids), a.pa, s_dyn,
                                             a.dbg ? a.dbg + static_cast<size_t>(gridDim.x) * 64 : nullptr);
-    } else if ((b -= a.has_a) == 0 && a.has_b) {
+    } else if ((b -= a.has_a) >= 0 && b < a.has_b) {
         role = 2;
-        qjoin_body(a.ba, a.bg, a.rows, a.width, a.bqh, a.bcoop, a.bwave, a.bcap_coop, a.bcap_wave, s_dyn, a.lds_bytes,
-                   a.dbg ? a.dbg + static_cast<size_t>(gridDim.x) * 64 + 16 : nullptr);
+        qjoin_body(a.ba, a.bg, a.rows, a.width, a.bqh, a.bcoop, a.bwave, a.bcopy, a.bcap_coop, a.bcap_wave, a.bcap_copy,
+                   s_dyn, a.lds_bytes, b, a.dbg ? a.dbg + static_cast<size_t>(gridDim.x) * 64 + 16 + 8 * b : nullptr);
     } else if ((b -= a.has_b) < a.ncoop) {
         role = 0;
         const uint32_t n = a.qh->n_coop;
@@ -1005,11 +1033,11 @@ __global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
     } else {
         b -= a.ncoop;
         role = 3;
-        const uint32_t n = a.qh ? a.qh->n_wave : 0u;
+        const uint32_t n0 = a.qh ? a.qh->n_wave : 0u, n = n0 + (a.qh ? a.qh->n_copy : 0u);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * 16u;
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
         for (uint32_t e = static_cast<uint32_t>(b) * 16u + wv; e < n; e += stride) {
-            const QItem it = q_load(a.qwave + e);
+            const QItem it = q_load(e < n0 ? a.qwave + e : a.qcopy + (e - n0));
             kind = it.kind;
             if (it.kind == kQL)
                 q_long(a, it);
@@ -1037,12 +1065,12 @@ __global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
 // One wave-instruction's LDS atomics on one address: are the lanes served in ascending lane order?  Four collision
 // patterns (all lanes one counter; two; sixteen; 512 counters), seven rows, 16 waves.
 __global__ __launch_bounds__(1024) void q_lds_order_check_kernel(uint32_t *bad) {
-    __shared__ uint32_t cnt[16][kQBins / 2];
-    __shared__ uint32_t ref[16][kQBins];
+    __shared__ uint32_t cnt[16][256];
+    __shared__ uint32_t ref[16][512];
     const int w = threadIdx.x >> 6, lane = lane_id();
-    for (int i = threadIdx.x; i < 16 * kQBins / 2; i += 1024)
+    for (int i = threadIdx.x; i < 16 * 256; i += 1024)
         (&cnt[0][0])[i] = 0;
-    for (int i = threadIdx.x; i < 16 * kQBins; i += 1024)
+    for (int i = threadIdx.x; i < 16 * 512; i += 1024)
         (&ref[0][0])[i] = 0;
     __syncthreads();
     uint32_t s = 12345u + 977u * threadIdx.x, wrong = 0;
@@ -1129,6 +1157,7 @@ static int qstep(float *table, int64_t rows, int64_t width, void *plan_cur, int6
         a.qh = q.hdr;
         a.qcoop = q.coop;
         a.qwave = q.wave;
+        a.qcopy = q.copy;
         a.cap_coop = q.cap_coop;
         a.cap_wave = q.cap_wave;
         a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
@@ -1156,13 +1185,15 @@ static int qstep(float *table, int64_t rows, int64_t width, void *plan_cur, int6
         a.bqh = q.hdr;
         a.bcoop = q.coop;
         a.bwave = q.wave;
+        a.bcopy = q.copy;
         a.bcap_coop = q.cap_coop;
         a.bcap_wave = q.cap_wave;
-        a.has_b = 1;
+        a.bcap_copy = q.cap_copy;
+        a.has_b = 2;
         lds = lds > qjoin_lds_bytes(a.ba.n, a.bg.n) ? lds : qjoin_lds_bytes(a.ba.n, a.bg.n);
-        // room for B to keep its inputs in LDS where that fits beside a second workgroup on the CU (it decides on
-        // the device, from the number of unique keys)
-        const size_t res = qjoin_lds_resident_bytes(a.ba.n, a.bg.n);
+        // room for B to keep the lookup batch's counts / starts in LDS too where that fits beside a second workgroup
+        // on the CU (it decides on the device, from the number of unique keys)
+        const size_t res = qjoin_lds_resident_bytes(a.bg.n);
         const size_t want = res < kQLdsBudget ? res : kQLdsBudget;
         lds = lds > want ? lds : want;
     }

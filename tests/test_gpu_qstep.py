@@ -1,8 +1,8 @@
 """ha_qstep_* (csrc/qstep.hip, ops.QueueStepPipeline): ONE launch per step driven by a work queue.
 
 Held to three references on the same seeded streams:
-  * integer results (sorted keys, occurrence indices, unique keys, counts, inverse of every batch's plan): exact
-    against np.unique / the oracle's Unique restatement;
+  * integer results (unique keys, dedup counts, segment starts, inverse and the occurrence lists of every batch's
+    plan): exact against np.unique (the groups are in hash-slot order, so group by group);
   * lookup rows and the table BIT FOR BIT against oracle/qstep_model.py, the numpy restatement of the kernel's
     floating-point order (serial occurrence-order chain below 16 occurrences of a key -- the reference's
     cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:65-72 -- and a fixed tree sum from 16 on);
@@ -34,21 +34,31 @@ def _lookup(t, ids_int):
 
 
 def _check_plan(pl, ids_int, what):
-    keys = np.minimum(ids_int.astype(np.uint64), 0xFFFFFFFE).astype(np.uint32)
-    u, inv, cnt = cpu.unique(keys)
-    order = np.argsort(keys, kind="stable")
+    """The plan of a batch as ha_qstep_* leaves it: the relations of an index plan (unique keys, counts, segment
+    starts, inverse, occurrence lists in occurrence order) with the unique keys in the order of the hash table's
+    slots, not in key order (ha_plan_build_* gives key order): compared group by group with np.unique."""
+    keys = np.minimum(ids_int.astype(np.uint64), 0xFFFFFFFE).astype(np.int64)
+    u, inv, cnt = np.unique(keys, return_inverse=True, return_counts=True)
     assert pl.n_unique() == u.size, what
-    np.testing.assert_array_equal(pl.sorted_keys().cpu().numpy().astype(np.int64) & 0xFFFFFFFF,
-                                  keys[order].astype(np.int64), err_msg=what + ": sorted keys")
-    np.testing.assert_array_equal(pl.perm().cpu().numpy().astype(np.int64), order, err_msg=what + ": perm (stable)")
-    np.testing.assert_array_equal(pl.keys().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys.astype(np.int64),
-                                  err_msg=what + ": keys")
-    np.testing.assert_array_equal(pl.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, u.astype(np.int64),
-                                  err_msg=what + ": unique keys")
-    np.testing.assert_array_equal(pl.counts().cpu().numpy().astype(np.int64), cnt, err_msg=what + ": counts")
-    np.testing.assert_array_equal(pl.inverse().cpu().numpy().astype(np.int64), inv, err_msg=what + ": inverse")
+    U = u.size
+    got_u = pl.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    got_c = pl.counts().cpu().numpy().astype(np.int64)
     seg = pl.seg().cpu().numpy().astype(np.int64)
-    np.testing.assert_array_equal(seg, np.r_[0, np.cumsum(cnt)], err_msg=what + ": segment starts")
+    perm = pl.perm().cpu().numpy().astype(np.int64)
+    ginv = pl.inverse().cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(np.sort(got_u), u, err_msg=what + ": the set of unique keys")
+    order = np.argsort(got_u)                         # group index of every key in key order
+    np.testing.assert_array_equal(got_c[order], cnt, err_msg=what + ": dedup counts per key")
+    np.testing.assert_array_equal(seg, np.r_[0, np.cumsum(got_c)], err_msg=what + ": segment starts")
+    np.testing.assert_array_equal(pl.keys().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys, err_msg=what + ": keys")
+    np.testing.assert_array_equal(got_u[ginv], keys, err_msg=what + ": inverse")
+    np.testing.assert_array_equal(np.sort(perm), np.arange(keys.size), err_msg=what + ": perm is a permutation")
+    np.testing.assert_array_equal(keys[perm], np.repeat(got_u, got_c), err_msg=what + ": perm groups the occurrences")
+    inside = np.ones(keys.size, bool)
+    inside[seg[:U]] = False                           # first position of every segment
+    assert (np.diff(perm)[inside[1:]] > 0).all(), what + ": occurrences of a key in occurrence order"
+    np.testing.assert_array_equal(pl.sorted_keys().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys[perm],
+                                  err_msg=what + ": keys in grouped order")
 
 
 def _within(got, exact, tol_rows, keys, what):

@@ -32,13 +32,15 @@ for k in range(nb - 1):
         pipe.step(grads[k % 24], ids[k + 3], out=outs[(k + 1) % 24])
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy()
-nblk = 48 + 2 + min(448, (2 * n) // 16 + 1)
+nblk = 1 + 2 + 48 + min(448, (2 * n) // 16 + 1)
 ph = raw[nblk * 64:nblk * 64 + 32]
-for name, off, labels in (("plan A", 0, ["ids->LDS", "pass setup", "pass 0", "pass 1", "pass 2", "pass 3", "finish scan", "stores"]),
-                          ("queue B", 16, ["uniq->LDS", "count pass", "scans", "emit"])):
-    st = ph[off:off + 16]
+for name, off in (("plan A (0 ids 1 claim 2 number 3 label 4 rank 5 scan 6 out 7)", 0),
+                  ("queue B0 = keys of the batch to apply (0 load 1 table 2 count 3 scans 4 emit 5)", 16),
+                  ("queue B1 = copies", 24)):
+    st = ph[off:off + 8]
     pts = [(i, int(v)) for i, v in enumerate(st) if v > 0]
-    print(name, "phases (us):", ", ".join("%d:%.2f" % (i, (v - pts[0][1]) * 0.01) for i, v in pts))
+    if pts:
+        print(name, "phases (us):", ", ".join("%d:%.2f" % (i, (v - pts[0][1]) * 0.01) for i, v in pts))
 d = raw[:nblk * 64].reshape(-1, 4)
 live = d[:, 0] > 0
 base = d[live, 0].min()
