@@ -62,6 +62,11 @@ def parse_args():
                         "(--lookahead 3), queue = ha_qstep_* (ids three batches ahead; every launch is driven by a work "
                         "queue the previous launch built, plans sorted + finished by one workgroup in LDS; keys with 16+ "
                         "occurrences applied as row - tree_sum(lr*g), within BASELINE.json's 1e-5)")
+    p.add_argument("--queue-side-streams", type=int, default=2, choices=(2, 3, 4),
+                   help="--engine queue: side streams the preparation launches rotate over (= steps each has to finish)")
+    p.add_argument("--queue-serial", action="store_true",
+                   help="--engine queue with the preparation launch in front of every step on the timed stream instead of "
+                        "beside the steps on side streams")
     p.add_argument("--launches", type=int, default=1, choices=(1, 2),
                    help="launches per step: 1 = ha_sgd_push_pull (apply(k) beside lookup(k+1), default), "
                         "2 = ha_lookup_sort + ha_sgd_apply_finish")
@@ -352,11 +357,13 @@ def main():
     ahead2 = one and args.engine in ("forward", "queue")
     # graphs never straddle the wrap-around of the batch list; ha_step_* rotates four plans and four key tables,
     # so the list is also cut to a multiple of 4 (a graph then depends on k % nb only)
-    period = (G * 4 // math.gcd(G, 4)) if ahead2 else G
+    # buffers (and side streams) of step k and step k + rot_ring are the same
+    rot_ring = ({0: 8, 2: 8, 3: 12, 4: 12}[0 if args.queue_serial else args.queue_side_streams]) if queue else 4
+    period = (G * rot_ring // math.gcd(G, rot_ring)) if ahead2 else G
     if args.distinct_batches >= period:
         args.distinct_batches -= args.distinct_batches % period
     elif ahead2:
-        raise SystemExit("--lookahead 3 needs --distinct-batches >= lcm(graph steps, 4) = %d" % period)
+        raise SystemExit("this engine needs --distinct-batches >= lcm(graph steps, %d) = %d" % (rot_ring, period))
     ids_host, uniq_counts = make_batches(args, rank, world)
     ids_dev = torch.from_numpy(ids_host).to(dev)
     table = init_table(args.rows, args.width, dev)
@@ -373,17 +380,33 @@ def main():
         # batch k+2, stable sort of batch k+3.  Every step applies one batch, looks one batch up, finishes one
         # plan and sorts one batch, as before; sorting the first three batches and looking the first one up is
         # the prologue (untimed).
-        pipe = (ops.QueueStepPipeline if queue else ops.StepPipeline)(table, n, LR)
-        plans = pipe.plans
-        with torch.cuda.stream(main_s):
-            pipe.reset(stream=main_s)
-            pipe.launch(-3, 0, None, 0, None, 0, ids_dev[0], stream=main_s)
-            pipe.launch(-2, 0, None, 0, None, n, ids_dev[1 % nb], stream=main_s)
-            pipe.launch(-1, 0, None, n, outs[0], n, ids_dev[2 % nb], stream=main_s)
+        if queue:
+            # One step = ONE launch on the timed stream (ha_qapply: the items of step k -- SGD apply of batch k, rows of
+            # batch k+1 -- from the queue prepared for it) + one preparation launch (ha_qprep_*: plan of batch k+5, queue
+            # of step k+2; two workgroups + one) on one of two SIDE streams, captured into the same graphs (three
+            # branches).  --queue-serial: the preparation in front of the step on the timed stream (lookahead 3).
+            pipe = ops.QueueStepPipeline(table, n, LR, overlap=0 if args.queue_serial else args.queue_side_streams)
+            LA = pipe.LOOKAHEAD
+            n_of = lambda b: n if b >= 0 else 0
+            with torch.cuda.stream(main_s):
+                for c in range(-LA, 0):
+                    pipe.launch(c, n_of, None, outs[0], ids_dev[(c + LA) % nb], stream=main_s)
 
-        def step(k):
-            b = k % nb
-            pipe.launch(k, n, grads[b % nbuf], n, outs[(b + 1) % nb % nbuf], n, ids_dev[(b + 3) % nb], stream=main_s)
+            def step(k):
+                b = k % nb
+                pipe.launch(k, n_of, grads[b % nbuf], outs[(b + 1) % nb % nbuf], ids_dev[(b + LA) % nb], stream=main_s)
+        else:
+            pipe = ops.StepPipeline(table, n, LR)
+            with torch.cuda.stream(main_s):
+                pipe.reset(stream=main_s)
+                pipe.launch(-3, 0, None, 0, None, 0, ids_dev[0], stream=main_s)
+                pipe.launch(-2, 0, None, 0, None, n, ids_dev[1 % nb], stream=main_s)
+                pipe.launch(-1, 0, None, n, outs[0], n, ids_dev[2 % nb], stream=main_s)
+
+            def step(k):
+                b = k % nb
+                pipe.launch(k, n, grads[b % nbuf], n, outs[(b + 1) % nb % nbuf], n, ids_dev[(b + 3) % nb], stream=main_s)
+        plans = pipe.plans
     elif one:
         # One step = ONE launch (ha_sgd_push_pull_f32ids): the backward of batch k (fused SGD apply + plan
         # finish) beside the forward of batch k+1 (gather + stable sort), rows both batches touch handed
@@ -429,15 +452,19 @@ def main():
 
     # plans / pending tables (one-launch step) and plans / key tables (lookahead step) rotate with the STEP
     # index, so a captured graph is only valid for steps with the same rotation phase
-    rot = 4 if ahead2 else (2 if one else 1)
+    rot = rot_ring if ahead2 else (2 if one else 1)
 
     def graph_for(k, ln):
         key = (k % nb, k % rot, ln)
         if key not in graphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=main_s):
+                if queue:
+                    pipe.begin_capture()
                 for j in range(k, k + ln):
                     step(j)
+                if queue:
+                    pipe.end_capture(main_s)     # the side streams rejoin the captured stream
             graphs[key] = g
         return graphs[key]
 
@@ -494,8 +521,8 @@ def main():
         traffic, traffic_src = pmc_traffic(kname)
         dom_bytes = fwd_b + bwd_b
         ach = dom_bytes / (dev_ms / args.steps * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": kname + (" (SGD apply of batch k + rows of batch k+1 from the work queue, "
-                                                       "queue of step k+1, plan of batch k+3)" if queue else
+        roofline = {"bound": "hbm", "kernel": kname + (" (the items of a step: SGD apply of batch k + rows of batch k+1 "
+                                                       "from its work queue)" if queue else
                                                        " (SGD apply of batch k, rows of batch k+1, plan finish of "
                                                        "batch k+2, sort of batch k+3)" if ahead2 else
                                                        " (SGD apply + finish of batch k, gather + sort of batch k+1)"),
@@ -567,13 +594,18 @@ def main():
                                "cache-limit-0.1 tier is not part of this line"
                                % (args.batch, args.width, args.fields, args.rows,
                                   args.rows * args.width * 4 / 1e9,
-                                  "one launch from a work queue: apply(k) + rows of k+1 per unique key, queue(k+1), "
-                                  "plan(k+3); keys with 16+ occurrences as row - tree_sum(lr*g)" if queue else
+                                  "one launch per step from a work queue: apply(k) + rows of k+1 per unique key; the "
+                                  "queue of step k+2 and the plan of batch k+5 prepared by a second launch on a side "
+                                  "stream inside the same graphs; keys with 16+ occurrences as row - tree_sum(lr*g)"
+                                  if queue and not args.queue_serial else
+                                  "two launches per step: preparation (plan of batch k+3, queue of step k+1), then the "
+                                  "items of step k from its queue" if queue else
                                   "one launch: apply(k), rows of k+1 forwarded / copied, finish(k+2), sort(k+3)" if ahead2 else
                                   "one launch: apply(k) beside lookup(k+1)" if one else "two launches"),
                    "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,
                    "grad_and_out_buffers": nbuf,
-                   "launches_per_step": args.launches, "lookahead_batches": (3 if ahead2 else 1),
+                   "launches_per_step": args.launches,
+                   "lookahead_batches": (pipe.LOOKAHEAD if queue else 3 if ahead2 else 1),
                    "engine": args.engine if one else "two launches",
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
                              else "eager",

@@ -1123,14 +1123,80 @@ static int lds_atomics_lane_ordered() {
     return st == 1;
 }
 
+static void q_fill_apply(QArgs &a, size_t &lds, void *plan_cur, int64_t n_cur, const float *grads, void *plan_next,
+                         int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap, int64_t width) {
+    const QLayout q = queue_layout(const_cast<void *>(queue_cur), queue_n_cap, width);
+    a.qh = q.hdr;
+    a.qcoop = q.coop;
+    a.qwave = q.wave;
+    a.qcopy = q.copy;
+    a.cap_coop = q.cap_coop;
+    a.cap_wave = q.cap_wave;
+    a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
+    a.n_a = static_cast<int>(n_cur);
+    a.grads = grads;
+    a.perm_g = n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr;
+    a.n_g = static_cast<int>(n_next);
+    a.out = next_out;
+    a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
+    // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
+    const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
+    a.nworker = static_cast<int>(bound / 16 + 1 < kQWorkerMax ? bound / 16 + 1 : kQWorkerMax);
+    lds = lds > 16 * 64 * 4 ? lds : 16 * 64 * 4;
+}
+static void q_fill_join(QArgs &a, size_t &lds, void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build,
+                        int64_t queue_n_cap, int64_t width) {
+    a.ba = qplan(plan_a, n_a);
+    a.bg = qplan(plan_g, n_g);
+    const QLayout q = queue_layout(queue_build, queue_n_cap, width);
+    a.bqh = q.hdr;
+    a.bcoop = q.coop;
+    a.bwave = q.wave;
+    a.bcopy = q.copy;
+    a.bcap_coop = q.cap_coop;
+    a.bcap_wave = q.cap_wave;
+    a.bcap_copy = q.cap_copy;
+    a.has_b = 2;
+    lds = lds > qjoin_lds_bytes(a.ba.n, a.bg.n) ? lds : qjoin_lds_bytes(a.ba.n, a.bg.n);
+    // room for the join to keep the lookup batch's counts / starts in LDS too where that fits beside a second
+    // workgroup on the CU (it decides on the device, from the number of unique keys)
+    const size_t res = qjoin_lds_resident_bytes(a.bg.n);
+    const size_t want = res < kQLdsBudget ? res : kQLdsBudget;
+    lds = lds > want ? lds : want;
+}
+template <typename IdT>
+static int q_launch(QArgs &a, size_t lds, hipStream_t stream) {
+    const unsigned blocks = static_cast<unsigned>(a.ncoop + a.has_a + a.has_b + a.nworker);
+    if (blocks == 0)
+        return 0;
+    a.lds_bytes = static_cast<uint32_t>(lds);
+    static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
+    if (lds_allowed.first()) {
+        HA_ALLOW_LDS((qstep_kernel<IdT, true>), 160 * 1024);
+        HA_ALLOW_LDS((qstep_kernel<IdT, false>), 160 * 1024);
+    }
+    if (lds_atomics_lane_ordered())
+        hipLaunchKernelGGL((qstep_kernel<IdT, true>), dim3(blocks), dim3(1024), lds, stream, a);
+    else
+        hipLaunchKernelGGL((qstep_kernel<IdT, false>), dim3(blocks), dim3(1024), lds, stream, a);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+static int q_check_table(const float *table, int64_t rows, int64_t width) {
+    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
+                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
+               "ha_qstep: the table must be 16-byte aligned with rows of a multiple of 4 floats");
+    return 0;
+}
+
+// everything in ONE launch (see the head of the file)
 template <typename IdT>
 static int qstep(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
                  float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, void *plan_b1,
                  int64_t n_b1, void *queue_build, int64_t queue_n_cap, const IdT *ahead_ids, int64_t n_ahead,
                  void *plan_ahead, hipStream_t stream, unsigned long long *dbg = nullptr) {
-    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
-                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
-               "ha_qstep: the table must be 16-byte aligned with rows of a multiple of 4 floats");
+    if (q_check_table(table, rows, width))
+        return -1;
     HA_REQUIRE(n_cur >= 0 && n_next >= 0 && n_b1 >= 0 && n_ahead >= 0 && n_cur <= kQMax && n_next <= kQMax &&
                    n_b1 <= kQMax && n_ahead <= kQMax && queue_n_cap >= 1 && queue_n_cap <= kQMax &&
                    n_cur <= queue_n_cap && n_next <= queue_n_cap && n_b1 <= queue_n_cap,
@@ -1152,66 +1218,86 @@ static int qstep(float *table, int64_t rows, int64_t width, void *plan_cur, int6
     a.lr = lr;
     a.dbg = dbg;
     size_t lds = 0;
-    if (n_cur > 0 || n_next > 0) {
-        const QLayout q = queue_layout(const_cast<void *>(queue_cur), queue_n_cap, width);
-        a.qh = q.hdr;
-        a.qcoop = q.coop;
-        a.qwave = q.wave;
-        a.qcopy = q.copy;
-        a.cap_coop = q.cap_coop;
-        a.cap_wave = q.cap_wave;
-        a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
-        a.n_a = static_cast<int>(n_cur);
-        a.grads = grads;
-        a.perm_g = n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr;
-        a.n_g = static_cast<int>(n_next);
-        a.out = next_out;
-        a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
-        // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
-        const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
-        a.nworker = static_cast<int>(bound / 16 + 1 < kQWorkerMax ? bound / 16 + 1 : kQWorkerMax);
-        lds = 16 * 64 * 4;
-    }
+    if (n_cur > 0 || n_next > 0)
+        q_fill_apply(a, lds, plan_cur, n_cur, grads, plan_next, n_next, next_out, queue_cur, queue_n_cap, width);
     if (n_ahead > 0) {
         a.ahead_ids = ahead_ids;
         a.pa = qplan(plan_ahead, n_ahead);
         a.has_a = 1;
         lds = lds > qsort_lds_bytes(a.pa.n) ? lds : qsort_lds_bytes(a.pa.n);
     }
-    if (n_next > 0 || n_b1 > 0) {
-        a.ba = qplan(plan_next, n_next);
-        a.bg = qplan(plan_b1, n_b1);
-        const QLayout q = queue_layout(queue_build, queue_n_cap, width);
-        a.bqh = q.hdr;
-        a.bcoop = q.coop;
-        a.bwave = q.wave;
-        a.bcopy = q.copy;
-        a.bcap_coop = q.cap_coop;
-        a.bcap_wave = q.cap_wave;
-        a.bcap_copy = q.cap_copy;
-        a.has_b = 2;
-        lds = lds > qjoin_lds_bytes(a.ba.n, a.bg.n) ? lds : qjoin_lds_bytes(a.ba.n, a.bg.n);
-        // room for B to keep the lookup batch's counts / starts in LDS too where that fits beside a second workgroup
-        // on the CU (it decides on the device, from the number of unique keys)
-        const size_t res = qjoin_lds_resident_bytes(a.bg.n);
-        const size_t want = res < kQLdsBudget ? res : kQLdsBudget;
-        lds = lds > want ? lds : want;
+    if (n_next > 0 || n_b1 > 0)
+        q_fill_join(a, lds, plan_next, n_next, plan_b1, n_b1, queue_build, queue_n_cap, width);
+    return q_launch<IdT>(a, lds, stream);
+}
+
+// The two halves as launches of their own (the same kernel with part of its roles): ha_qprep_* = the plan of one batch
+// and / or the queue of one step, ha_qapply = the items of one step.  On one stream, ha_qprep_*(batch c+3; queue c+1
+// from plans c+1, c+2) followed by ha_qapply(step c) is ha_qstep_*; on streams of their own the preparation runs
+// BESIDE the steps -- one workgroup needs 15-20 us for a plan and as long for a queue, twice the time the items of a
+// step take, so inside the step's launch they are its tail (26 us per step), two steps ahead on a side stream they
+// cost the step nothing (herald_amd.ops.QueueStepPipeline(overlap=True)).
+template <typename IdT>
+static int qprep(int64_t rows, int64_t width, const IdT *ahead_ids, int64_t n_ahead, void *plan_ahead, void *plan_a,
+                 int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap, hipStream_t stream,
+                 unsigned long long *dbg = nullptr) {
+    HA_REQUIRE(rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 && width <= (1 << 20),
+               "ha_qprep: rows of a multiple of 4 floats");
+    HA_REQUIRE(n_a >= 0 && n_g >= 0 && n_ahead >= 0 && n_a <= kQMax && n_g <= kQMax && n_ahead <= kQMax,
+               "ha_qprep: at most %d ids per batch", kQMax);
+    HA_REQUIRE((n_a == 0 && n_g == 0) || (queue_build && queue_n_cap >= 1 && queue_n_cap <= kQMax && n_a <= queue_n_cap &&
+                                          n_g <= queue_n_cap),
+               "ha_qprep: the queue to build is missing or smaller than the batches");
+    HA_REQUIRE((n_a == 0 || plan_a) && (n_g == 0 || plan_g), "ha_qprep: null plan");
+    HA_REQUIRE(n_ahead == 0 || (ahead_ids && plan_ahead), "ha_qprep: null pointer (batch to plan)");
+    {   // development aid (timing only, results are then stale): HA_QPREP_SKIP_AFTER=N drops every call after the Nth
+        static const char *skip = getenv("HA_QPREP_SKIP_AFTER");
+        static std::atomic<long> calls{0};
+        if (skip != nullptr && calls.fetch_add(1) >= atol(skip))
+            return 0;
     }
-    const unsigned blocks = static_cast<unsigned>(a.ncoop + a.has_a + a.has_b + a.nworker);
-    if (blocks == 0)
+    QArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = static_cast<uint64_t>(rows);
+    a.width = static_cast<int>(width);
+    a.dbg = dbg;
+    size_t lds = 0;
+    if (n_ahead > 0) {
+        a.ahead_ids = ahead_ids;
+        a.pa = qplan(plan_ahead, n_ahead);
+        a.has_a = 1;
+        lds = qsort_lds_bytes(a.pa.n);
+    }
+    if (n_a > 0 || n_g > 0)
+        q_fill_join(a, lds, plan_a, n_a, plan_g, n_g, queue_build, queue_n_cap, width);
+    return q_launch<IdT>(a, lds, stream);
+}
+
+static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                  void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
+                  hipStream_t stream, unsigned long long *dbg = nullptr) {
+    if (q_check_table(table, rows, width))
+        return -1;
+    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && n_cur <= kQMax && n_next <= kQMax && queue_n_cap >= 1 &&
+                   queue_n_cap <= kQMax && n_cur <= queue_n_cap && n_next <= queue_n_cap,
+               "ha_qapply: at most %d ids per batch and no more than the queue was sized for", kQMax);
+    HA_REQUIRE(n_cur == 0 || (plan_cur && grads && reinterpret_cast<uintptr_t>(grads) % 16 == 0),
+               "ha_qapply: current batch needs its plan and 16-byte aligned gradients");
+    HA_REQUIRE(n_next == 0 || (plan_next && next_out && reinterpret_cast<uintptr_t>(next_out) % 16 == 0),
+               "ha_qapply: next batch needs its plan and a 16-byte aligned output");
+    if (n_cur == 0 && n_next == 0)
         return 0;
-    a.lds_bytes = static_cast<uint32_t>(lds);
-    static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
-    if (lds_allowed.first()) {
-        HA_ALLOW_LDS((qstep_kernel<IdT, true>), 160 * 1024);
-        HA_ALLOW_LDS((qstep_kernel<IdT, false>), 160 * 1024);
-    }
-    if (lds_atomics_lane_ordered())
-        hipLaunchKernelGGL((qstep_kernel<IdT, true>), dim3(blocks), dim3(1024), lds, stream, a);
-    else
-        hipLaunchKernelGGL((qstep_kernel<IdT, false>), dim3(blocks), dim3(1024), lds, stream, a);
-    HA_LAUNCH_CHECK();
-    return 0;
+    HA_REQUIRE(queue_cur != nullptr, "ha_qapply: the queue of this step is missing");
+    QArgs a;
+    memset(&a, 0, sizeof(a));
+    a.table = table;
+    a.rows = static_cast<uint64_t>(rows);
+    a.width = static_cast<int>(width);
+    a.lr = lr;
+    a.dbg = dbg;
+    size_t lds = 0;
+    q_fill_apply(a, lds, plan_cur, n_cur, grads, plan_next, n_next, next_out, queue_cur, queue_n_cap, width);
+    return q_launch<float>(a, lds, stream);
 }
 
 }  // namespace ha
@@ -1257,6 +1343,40 @@ extern "C" int ha_debug_qstep_timeline(float *table, int64_t rows, int64_t width
     return qstep<float>(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur,
                         plan_b1, n_b1, queue_build, queue_n_cap, ahead_ids, n_ahead, plan_ahead, as_stream(stream),
                         dbg);
+}
+
+extern "C" int ha_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build,
+                               int64_t queue_n_cap, ha_stream_t stream) {
+    return qprep<float>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_a, n_a, plan_g, n_g, queue_build, queue_n_cap,
+                        as_stream(stream));
+}
+extern "C" int ha_qprep_u64ids(int64_t rows, int64_t width, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build,
+                               int64_t queue_n_cap, ha_stream_t stream) {
+    return qprep<uint64_t>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_a, n_a, plan_g, n_g, queue_build,
+                           queue_n_cap, as_stream(stream));
+}
+extern "C" int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                         float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                         int64_t queue_n_cap, ha_stream_t stream) {
+    return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
+                  as_stream(stream));
+}
+// development aids: the two halves with time stamps (dbg as for ha_debug_qstep_timeline)
+extern "C" int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead,
+                                     void *plan_ahead, void *plan_a, int64_t n_a, void *plan_g, int64_t n_g,
+                                     void *queue_build, int64_t queue_n_cap, unsigned long long *dbg, ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "qprep timeline: null debug buffer");
+    return qprep<float>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_a, n_a, plan_g, n_g, queue_build, queue_n_cap,
+                        as_stream(stream), dbg);
+}
+extern "C" int ha_debug_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                               const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out,
+                               const void *queue_cur, int64_t queue_n_cap, unsigned long long *dbg, ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "qapply timeline: null debug buffer");
+    return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
+                  as_stream(stream), dbg);
 }
 
 // queue header of a built queue: {n_wave, n_coop, n_long, n_medium, n_small} (tests / tools; device pointer)

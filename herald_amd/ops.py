@@ -611,23 +611,29 @@ def qstep_max_ids():
     return int(_lib.load().ha_qstep_max_ids())
 
 
-class QueueStepPipeline(StepPipeline):
-    """StepPipeline over ha_qstep_* (include/herald_amd.h, csrc/qstep.hip): the same stream protocol --
+class QueueStepPipeline:
+    """Drives ha_qprep_* / ha_qapply (include/herald_amd.h, csrc/qstep.hip) over a stream of id batches: every training
+    step is ONE launch on the caller's stream that applies the sparse SGD of batch c (cpu_SGDOptimizerSparseUpdate order)
+    and writes the rows of batch c+1 after that update, item by item from a work queue (one wave per unique key / column
+    slice, no probing, no waiting); the queue and the per-batch plans behind it are prepared by single-workgroup launches
+    that run a few batches ahead --
+
+        overlap=True   on two side streams BESIDE the steps (a plan or a queue keeps one workgroup busy for 15-20 us,
+                       about twice the time the items of a step take); ids are needed LOOKAHEAD = 5 batches ahead;
+        overlap=False  on the caller's stream, in front of every step (LOOKAHEAD = 3, the call sequence of ha_qstep_*).
 
         pipe = QueueStepPipeline(table, capacity, lr)
-        out0 = pipe.start(ids0, ids1, ids2)           # rows of batch 0 (three launches)
-        out1 = pipe.step(grads0, ids3)                # apply 0, rows of batch 1, plan of batch 3   (one launch)
+        out0 = pipe.start(ids0, ..., ids4)            # the first LOOKAHEAD batches; returns the rows of batch 0
+        out1 = pipe.step(grads0, ids5)                # apply 0, rows of batch 1; batch 5 enters the pipeline
+        ...                                           # ahead_ids=None once the stream of batches ends
 
-    -- but every launch is driven by a work queue the previous launch prepared (one wave per unique key / column
-    slice, no probing, no waiting), the plan of a batch is sorted and finished by one workgroup in LDS, and keys
-    with 16 or more occurrences in a batch are applied as `row - tree_sum(lr * g)` (deterministic, within the 1e-5
-    relative BASELINE.json allows for accumulated gradients) instead of the serial chain; below 16 occurrences the
-    result is the reference's bit for bit.  `plan_of(j)` is complete (unique keys / inverse / counts) as soon as the
-    call that sorts batch j has run, i.e. three calls before batch j is applied."""
+    Keys with 16 or more occurrences in a batch are applied as `row - tree_sum(lr * g)` (deterministic, within the 1e-5
+    relative BASELINE.json allows for accumulated gradients); below 16 occurrences the result is the reference's serial
+    chain bit for bit.  `plan_of(j)` holds the unique keys / counts / inverse / occurrence lists of batch j with the
+    unique keys in hash-slot order (not np.unique's order), from the moment its preparation has run."""
 
-    NQUEUE = 2
 
-    def __init__(self, table, capacity, lr, device=None):
+    def __init__(self, table, capacity, lr, device=None, overlap=True):
         L = _lib.load()
         _require(table, torch.float32, "table")
         self.table, self.lr = table, float(lr)
@@ -638,42 +644,70 @@ class QueueStepPipeline(StepPipeline):
         if table.shape[1] % 4 != 0:
             raise ValueError("ha_qstep_* needs rows of a multiple of 4 floats")
         self.capacity = max(int(capacity), 1)
+        # overlap: False / 0 = the preparation on the caller's stream; True = two side streams; k >= 2 = k side streams
+        # (the preparation of call c then has k steps to finish)
+        self.nside = 2 if overlap is True else int(overlap or 0)
+        if self.nside not in (0, 2, 3, 4):
+            raise ValueError("overlap must be False, True or 2..4 side streams")
+        self.overlap = self.nside > 0
+        self.JOIN_AHEAD = self.nside if self.overlap else 1   # the preparation of call c builds the queue of step c + JOIN_AHEAD
+        self.LOOKAHEAD = self.JOIN_AHEAD + (3 if self.overlap else 2)
+        # ring sizes: plans >= LOOKAHEAD + 3, queues >= JOIN_AHEAD + 2; replayed captures must cover a multiple of
+        # ROTATION calls (plans, queues and side streams of call c and call c + ROTATION are the same)
+        self.NPLAN, self.NQUEUE, self.ROTATION = {0: (8, 4, 8), 2: (8, 4, 8), 3: (12, 6, 12), 4: (12, 6, 12)}[self.nside]
         self.plans = [IndexPlan(self.capacity, self.device) for _ in range(self.NPLAN)]
         self.queue_bytes = int(L.ha_qstep_queue_bytes(self.capacity, table.shape[1]))
         self.queues = torch.empty(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
+        self.side = [torch.cuda.Stream(device=self.device) for _ in range(self.nside)]
+        self.reset()
+
+    # ---- bookkeeping ------------------------------------------------------------------------------------------
+    def reset(self, stream=None):
         self.c, self.n, self.shape = None, {}, {}
+        self._ev_side = {}          # call index -> event behind its preparation
+        return self
+
+    def plan_of(self, b):
+        return self.plans[b % self.NPLAN]
 
     def _queue(self, c):
         return self.queues.data_ptr() + (c % self.NQUEUE) * self.queue_bytes
 
-    def reset(self, stream=None):
-        self.c, self.n, self.shape = None, {}, {}
-        return self
-
-    def step(self, grads, ahead_ids=None, out=None, stream=None):
-        """Applies `grads` of the current batch (None if that batch is empty); returns the rows of the next batch
-        (None at the end of the stream or if the next batch is empty)."""
-        if self.c is None:
-            raise RuntimeError("QueueStepPipeline.step before start")
-        return self._call(self.c, grads, ahead_ids, out, stream)
-
     def queue_header(self, c):
-        """{wave items, workgroup items, long, medium, small} of the queue call c reads (host copy; synchronises)."""
+        """{wave items, workgroup items, long, medium, small, copy items} of the queue step c reads (host copy;
+        synchronises)."""
         off = (c % self.NQUEUE) * self.queue_bytes
         torch.cuda.synchronize(self.device)
-        h = self.queues[off:off + 20].view(torch.int32).cpu().tolist()
-        return dict(zip(("wave_items", "workgroup_items", "long", "medium", "small"), h))
+        h = self.queues[off:off + 24].view(torch.int32).cpu().tolist()
+        return dict(zip(("wave_items", "workgroup_items", "long", "medium", "small", "copy_items"), h))
 
-    def launch(self, c, n_cur, grads, n_next, out, n_fin, ahead_ids, stream=None, dbg=None):
-        """Call c, stateless: batch c (n_cur ids) is applied from queue c, the rows of batch c+1 (n_next ids) go to
-        `out`, queue c+1 is built from the plans of batches c+1 and c+2 (n_fin ids), `ahead_ids` = batch c+3 is
-        sorted and finished."""
+    def begin_capture(self):
+        """Call at the start of a stream capture: launches captured from here on must not wait for events recorded
+        before the capture (whatever ran before it is ordered by the stream the graph is launched on)."""
+        self._ev_side = {}
+
+    def end_capture(self, stream=None):
+        """Call before a stream capture ends: the side streams rejoin `stream`."""
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        for ev in self._ev_side.values():
+            main.wait_event(ev)
+        self._ev_side = {}
+
+    # ---- one call -----------------------------------------------------------------------------------------------
+    def launch(self, c, n_of, grads, out, ahead_ids, stream=None, dbg_prep=None, dbg_apply=None):
+        """Call c, stateless about the batch sizes (`n_of(b)` = ids of batch b, 0 outside the stream): the preparation
+        -- plan of batch c + LOOKAHEAD (`ahead_ids`), queue of step c + JOIN_AHEAD -- and step c itself: batch c
+        applied with `grads`, the rows of batch c + 1 to `out`."""
         L = _lib.load()
         t = self.table
-        width = t.shape[1]
+        rows, width = t.shape
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        n_cur, n_next = n_of(c), n_of(c + 1)
+        jb = c + self.JOIN_AHEAD
+        n_a, n_g = n_of(jb), n_of(jb + 1)
         n_ahead = 0 if ahead_ids is None else ahead_ids.numel()
-        if max(n_cur, n_next, n_fin, n_ahead) > self.capacity:
-            raise ValueError("plan capacity %d < %d ids" % (self.capacity, max(n_cur, n_next, n_fin, n_ahead)))
+        if max(n_cur, n_next, n_a, n_g, n_ahead) > self.capacity:
+            raise ValueError("plan capacity %d < %d ids" % (self.capacity, max(n_cur, n_next, n_a, n_g, n_ahead)))
         if n_cur:
             _require(grads, torch.float32, "grads")
             if grads.numel() != n_cur * width:
@@ -682,25 +716,90 @@ class QueueStepPipeline(StepPipeline):
             _require(out, torch.float32, "out")
             if out.numel() != n_next * width:
                 raise ValueError("out must hold %d x %d values" % (n_next, width))
-        kind = _ids_kind(ahead_ids) if n_ahead else "f32ids"
-        args = [_ptr(t), t.shape[0], width,
-                _ptr(self.plan_of(c).ws) if n_cur else None, n_cur, _ptr(grads) if n_cur else None,
-                ctypes.c_float(self.lr),
-                _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
-                self._queue(c) if (n_cur or n_next) else None,
-                _ptr(self.plan_of(c + 2).ws) if n_fin else None, n_fin,
-                self._queue(c + 1) if (n_next or n_fin) else None, self.capacity,
-                _ptr(ahead_ids) if n_ahead else None, n_ahead,
-                _ptr(self.plan_of(c + 3).ws) if n_ahead else None]
-        if dbg is None:
-            check(getattr(L, "ha_qstep_" + kind)(*args, _stream_ptr(stream)), "ha_qstep")
-        else:
-            check(L.ha_debug_qstep_timeline(*args, _ptr(dbg), _stream_ptr(stream)), "ha_debug_qstep_timeline")
+        # -- the preparation
+        if n_ahead or n_a or n_g:
+            s = main
+            if self.overlap:
+                s = self.side[c % self.nside]
+                # One wait on the caller's stream as it stands now: the ids are there, the buffers about to be rewritten
+                # are free, and -- because step c-1 waited for the preparation of call c-3 before it was enqueued -- so
+                # are the plans this call's queue builds on (the other side stream's work).  (Waiting for that older
+                # event directly is legal, but hipStreamEndCapture crashes on a wait for an event that is not the last
+                # thing captured on its stream.)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                s.wait_event(ev)
+            kind = _ids_kind(ahead_ids) if n_ahead else "f32ids"
+            args = [rows, width, _ptr(ahead_ids) if n_ahead else None, n_ahead,
+                    _ptr(self.plan_of(c + self.LOOKAHEAD).ws) if n_ahead else None,
+                    _ptr(self.plan_of(jb).ws) if n_a else None, n_a,
+                    _ptr(self.plan_of(jb + 1).ws) if n_g else None, n_g,
+                    self._queue(jb) if (n_a or n_g) else None, self.capacity]
+            if dbg_prep is None:
+                check(getattr(L, "ha_qprep_" + kind)(*args, _stream_ptr(s)), "ha_qprep")
+            else:
+                check(L.ha_debug_qprep_f32ids(*args, _ptr(dbg_prep), _stream_ptr(s)), "ha_debug_qprep")
+            if n_ahead:
+                pl = self.plan_of(c + self.LOOKAHEAD)
+                pl.n = n_ahead
+                pl._view = None
+                pl.produced_on(s)
+            if self.overlap:
+                ev = torch.cuda.Event()
+                ev.record(s)
+                self._ev_side[c] = ev
+        # -- the step
+        if self.overlap:
+            ready = self._ev_side.get(c - self.JOIN_AHEAD)
+            if ready is not None:
+                main.wait_event(ready)
+            for old in [k for k in self._ev_side if k < c - self.nside - 2]:
+                del self._ev_side[old]
+        if n_cur or n_next:
+            args = [_ptr(t), rows, width, _ptr(self.plan_of(c).ws) if n_cur else None, n_cur,
+                    _ptr(grads) if n_cur else None, ctypes.c_float(self.lr),
+                    _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
+                    self._queue(c), self.capacity]
+            if dbg_apply is None:
+                check(L.ha_qapply(*args, _stream_ptr(main)), "ha_qapply")
+            else:
+                check(L.ha_debug_qapply(*args, _ptr(dbg_apply), _stream_ptr(main)), "ha_debug_qapply")
+
+    # ---- the stream protocol --------------------------------------------------------------------------------------
+    def _call(self, c, grads, ahead_ids, out, stream):
+        n_ahead = 0 if ahead_ids is None else ahead_ids.numel()
         if n_ahead:
-            pl = self.plan_of(c + 3)
-            pl.n = n_ahead
-            pl._view = None
-            pl.produced_on(stream)
+            self.n[c + self.LOOKAHEAD] = n_ahead
+            self.shape[c + self.LOOKAHEAD] = tuple(ahead_ids.shape)
+        n_of = lambda b: self.n.get(b, 0)
+        n_next = n_of(c + 1)
+        if n_next and out is None:
+            out = torch.empty(tuple(self.shape[c + 1]) + (self.table.shape[1],), dtype=torch.float32,
+                              device=self.table.device)
+        self.launch(c, n_of, grads, out, ahead_ids, stream)
+        self.n.pop(c, None)
+        self.c = c + 1
+        return out if n_next else None
+
+    def start(self, *ids, out=None, stream=None):
+        """Takes the first LOOKAHEAD batches (fewer, or None entries, if the stream is shorter) and returns the rows of
+        batch 0."""
+        if len(ids) > self.LOOKAHEAD:
+            raise ValueError("start takes the first %d batches" % self.LOOKAHEAD)
+        ids = list(ids) + [None] * (self.LOOKAHEAD - len(ids))
+        res = None
+        for k, b in enumerate(ids):
+            c = k - self.LOOKAHEAD
+            res = self._call(c, None, b, out if c == -1 else None, stream)
+        return res
+
+    def step(self, grads, ahead_ids=None, out=None, stream=None):
+        """Applies `grads` of the current batch (None if that batch is empty); `ahead_ids` = the batch LOOKAHEAD ahead of
+        it (None once the stream ends).  Returns the rows of the next batch (None at the end of the stream or if the
+        next batch is empty)."""
+        if self.c is None:
+            raise RuntimeError("QueueStepPipeline.step before start")
+        return self._call(self.c, grads, ahead_ids, out, stream)
 
 
 def push_apply_finish(table, plan, grads, stream=None):

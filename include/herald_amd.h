@@ -470,7 +470,34 @@ int ha_qstep_u64ids(float *table, int64_t rows, int64_t width,
                     void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
                     void *plan_b1, int64_t n_b1, void *queue_build, int64_t queue_n_cap,
                     const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead, ha_stream_t stream);
-/* a built queue's first words (device memory): {wave items, workgroup items, long, medium, small items} */
+/* The two halves of ha_qstep_* as launches of their own (the same kernel with part of its roles), for callers that
+ * run the preparation on a stream BESIDE the steps -- a plan or a queue keeps one workgroup busy for 15-20 us, about
+ * twice the time the items of a step take, so inside the step's launch they are its tail:
+ *   ha_qprep_*  sorts-by-hashing and finishes the plan of one batch (ahead_ids -> plan_ahead; n_ahead = 0: none) and /
+ *               or builds the queue of one step from the finished plans of the batch that step applies (plan_a) and of
+ *               the batch it looks up (plan_g) (n_a = n_g = 0: none);
+ *   ha_qapply   the items of one step: queue_cur was built by ha_qprep_* from (plan_cur, plan_next).
+ * ha_qprep_*(batch c+3; queue c+1 from plans c+1, c+2) followed by ha_qapply(step c) on one stream == ha_qstep_*(c).
+ * The plan ha_qprep_* / ha_qstep_* leave holds the relations of an index plan (unique keys, counts, segment starts,
+ * inverse, occurrence lists ascending inside every segment) with the unique keys in the order of its hash table's
+ * slots, NOT in key order (ha_plan_build_* gives np.unique's order). */
+int ha_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                    void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
+                    ha_stream_t stream);
+int ha_qprep_u64ids(int64_t rows, int64_t width, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                    void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
+                    ha_stream_t stream);
+int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
+              void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
+              ha_stream_t stream);
+/* development aids: the halves with time stamps (dbg as for ha_debug_qstep_timeline) */
+int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                          void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
+                          unsigned long long *dbg, ha_stream_t stream);
+int ha_debug_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                    float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                    int64_t queue_n_cap, unsigned long long *dbg, ha_stream_t stream);
+/* a built queue's first words (device memory): {wave items, workgroup items, long, medium, small, copy items} */
 const uint32_t *ha_qstep_queue_header(const void *queue);
 /* development aid (tools/qstep_timeline.py): ha_qstep_f32ids with per-wave time stamps,
  * dbg = device uint64[(number of workgroups) * 16 * 4], zeroed */

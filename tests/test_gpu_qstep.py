@@ -73,7 +73,7 @@ def _within(got, exact, tol_rows, keys, what):
                 what, k, d.max(), bound.min())
 
 
-def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=None, check_plans=True):
+def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=None, check_plans=True, overlap=True):
     """Drives the pipeline over the whole stream; every lookup and the final table against both oracles."""
     width = table0.shape[1]
     rows = table0.shape[0]
@@ -83,12 +83,13 @@ def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=Non
     if table is None:
         table = _dev(table0, dev)
     cap = max(max(b.size for b in batches), 1)
-    pipe = ops.QueueStepPipeline(table, cap, lr)
+    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=overlap)
+    L = pipe.LOOKAHEAD
     cast = (lambda b: _dev(b.astype(np.float32), dev)) if ids_dtype == np.float32 else \
         (lambda b: _dev(b.astype(np.int64), dev))
     d_ids = [cast(b) for b in batches]
     B = len(batches)
-    out = pipe.start(d_ids[0], d_ids[1] if B > 1 else None, d_ids[2] if B > 2 else None)
+    out = pipe.start(*[d_ids[i] if i < B else None for i in range(L)])
     for k in range(B):
         torch.cuda.synchronize()
         ids = batches[k].astype(np.int64)
@@ -105,7 +106,7 @@ def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=Non
                     drift[key] = drift.get(key, 0) + b
         else:
             assert out is None
-        out = pipe.step(_dev(grads[k], dev) if ids.size else None, d_ids[k + 3] if k + 3 < B else None)
+        out = pipe.step(_dev(grads[k], dev) if ids.size else None, d_ids[k + L] if k + L < B else None)
         torch.cuda.synchronize()
         assert (out is None) == (k + 1 >= B or batches[k + 1].size == 0)
         if check_plans and ids.size:
@@ -120,18 +121,19 @@ def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=Non
     return pipe
 
 
+@pytest.mark.parametrize("overlap", [True, False], ids=["side_streams", "one_stream"])
 @pytest.mark.parametrize("width", [4, 32, 64, 96, 128, 200, 512, 1024])
 @pytest.mark.parametrize("rows,n", [(40, 700), (5000, 6656), (300, 63), (7, 1)])
-def test_qstep_stream_small_tables(dev, width, rows, n):
+def test_qstep_stream_small_tables(dev, width, rows, n, overlap):
     """Small tables: almost every row of batch k+1 is updated by batch k; every class of item (small, medium, long,
     workgroup, pure copies, keys with more than 64 / 1024 destinations)."""
     rng = np.random.default_rng(width * 131 + rows + n)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
-    steps = 6
+    steps = 9
     batches = [np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1) if k % 2 else rng.integers(0, rows, size=n)
                for k in range(steps)]
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
-    _run_stream(dev, table0, batches, grads, 0.05)
+    _run_stream(dev, table0, batches, grads, 0.05, overlap=overlap)
 
 
 def test_qstep_all_below_16_occurrences_is_the_reference_bit_for_bit(dev):
@@ -173,7 +175,8 @@ def test_qstep_degenerate_batches(dev, kind):
     _run_stream(dev, table0, batches, grads, 0.02)
 
 
-def test_qstep_ragged_empty_and_out_of_range(dev):
+@pytest.mark.parametrize("overlap", [True, False], ids=["side_streams", "one_stream"])
+def test_qstep_ragged_empty_and_out_of_range(dev, overlap):
     """Batches of different sizes, an EMPTY batch in the middle of the stream, ids beyond the table (zeros on lookup,
     ignored by the apply) and uint64 ids beyond 2^32."""
     rng = np.random.default_rng(23)
@@ -188,7 +191,7 @@ def test_qstep_ragged_empty_and_out_of_range(dev):
             b[4] = 0xFFFFFFFF
         batches.append(b)
     grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
-    _run_stream(dev, table0, batches, grads, 0.05, ids_dtype=np.int64)
+    _run_stream(dev, table0, batches, grads, 0.05, ids_dtype=np.int64, overlap=overlap)
 
 
 def test_qstep_float_ids_above_2_24_and_capacity_limit(dev):
@@ -205,8 +208,9 @@ def test_qstep_float_ids_above_2_24_and_capacity_limit(dev):
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in batches]
     compact = table0_rows.copy()
     pipe = ops.QueueStepPipeline(table, n, 0.01)
+    L = pipe.LOOKAHEAD
     d = [_dev(b.astype(np.float32), dev) for b in batches]
-    out = pipe.start(d[0], d[1], d[2])
+    out = pipe.start(*d[:L])
     for k in range(5):
         torch.cuda.synchronize()
         cid = np.searchsorted(np.sort(hot), batches[k])
@@ -216,7 +220,7 @@ def test_qstep_float_ids_above_2_24_and_capacity_limit(dev):
         tmp = compact[srt].copy()
         qstep_model.sgd_sparse_update(tmp, cid, grads[k], 0.01)
         compact[srt] = tmp
-        out = pipe.step(_dev(grads[k], dev), d[k + 3] if k + 3 < 5 else None)
+        out = pipe.step(_dev(grads[k], dev), d[k + L] if k + L < 5 else None)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(table[_dev(hot, dev)].cpu().numpy(), compact)
     assert float(table.abs().sum().item()) == pytest.approx(float(np.abs(compact.astype(np.float64)).sum()), rel=1e-6)
@@ -245,8 +249,10 @@ def test_qstep_criteo_stream_and_queue_shape(dev):
     assert hdr["wave_items"] == want["long"] + want["medium"] + want["small"]
 
 
-def test_qstep_graph_replay_is_deterministic(dev):
-    """The launches replayed from a hipGraph (as bench.py does) give the same bits as eager launches."""
+@pytest.mark.parametrize("overlap", [True, False], ids=["side_streams", "one_stream"])
+def test_qstep_graph_replay_is_deterministic(dev, overlap):
+    """The launches replayed from a hipGraph (as bench.py does; with the preparation on side streams the graph has
+    three branches) give the same bits as eager launches."""
     rows, width, bs = 300_000, 128, 128
     rng = np.random.default_rng(37)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
@@ -257,25 +263,28 @@ def test_qstep_graph_replay_is_deterministic(dev):
     results = []
     for mode in ("eager", "graph"):
         table = _dev(table0, dev)
-        pipe = ops.QueueStepPipeline(table, n, 0.05)
+        pipe = ops.QueueStepPipeline(table, n, 0.05, overlap=overlap)
+        L = pipe.LOOKAHEAD
         outs = [torch.empty((n, width), dtype=torch.float32, device=dev) for _ in range(nb)]
         s = torch.cuda.Stream(device=dev)
+        n_of = lambda b: n if b >= 0 else 0
         with torch.cuda.stream(s):
-            pipe.launch(-3, 0, None, 0, None, 0, ids[0], stream=s)
-            pipe.launch(-2, 0, None, 0, None, n, ids[1], stream=s)
-            pipe.launch(-1, 0, None, n, outs[0], n, ids[2], stream=s)
+            for c in range(-L, 0):
+                pipe.launch(c, n_of, None, outs[0], ids[(c + L) % nb], stream=s)
 
             def step(k):
-                pipe.launch(k, n, grads[k % nb], n, outs[(k + 1) % nb], n, ids[(k + 3) % nb], stream=s)
+                pipe.launch(k, n_of, grads[k % nb], outs[(k + 1) % nb], ids[(k + L) % nb], stream=s)
             if mode == "eager":
                 for k in range(16):
                     step(k)
             else:
-                s.synchronize()
+                torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s):
+                    pipe.begin_capture()
                     for k in range(8):
                         step(k)
+                    pipe.end_capture(s)
                 g.replay()
                 g.replay()
         torch.cuda.synchronize()

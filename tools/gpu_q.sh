@@ -9,8 +9,10 @@ tail -2 $O/qstep_tests_ballot.log
 timeout 600 python tools/qstep_timeline.py > $O/qstep_timeline.txt 2>&1; echo "timeline rc=$?"
 head -14 $O/qstep_timeline.txt
 B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier"
-for e in queue handoff; do
-  timeout 600 python bench.py $B --engine $e > $O/bench_$e.json 2> $O/bench_$e.err; echo "bench $e rc=$?"
+SERIAL=1 timeout 600 python tools/qstep_timeline.py > $O/qstep_timeline_serial.txt 2>&1
+head -6 $O/qstep_timeline_serial.txt
+for e in queue "queue --queue-serial" handoff; do
+  timeout 600 python bench.py $B --engine $e > "$O/bench_$e.json" 2> "$O/bench_$e.err"; echo "bench $e rc=$?"
   python - <<PY
 import json
 try:

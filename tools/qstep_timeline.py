@@ -18,29 +18,36 @@ for b in range(nb + 3):
     ids.append(torch.from_numpy(f).to(dev))
 grads = [torch.randn((n, width), device=dev) for _ in range(24)]
 outs = [torch.empty((n, width), device=dev) for _ in range(24)]
-pipe = ops.QueueStepPipeline(table, n, 1e-6)
+OVERLAP = os.environ.get("SERIAL", "0") != "1"
+pipe = ops.QueueStepPipeline(table, n, 1e-6, overlap=OVERLAP)
+LA = pipe.LOOKAHEAD
 NBLK = 1024
 dbg = torch.zeros(NBLK * 16 * 4, dtype=torch.int64, device=dev)
-pipe.start(ids[0], ids[1], ids[2], out=outs[0])
-for k in range(nb - 1):
-    if k == nb - 2:
-        dbg.zero_()
+dbgp = torch.zeros(4 * 64 + 64, dtype=torch.int64, device=dev)
+n_of = lambda b: n if b >= 0 else 0
+for c in range(-LA, 0):
+    pipe.launch(c, n_of, None, outs[0], ids[c + LA])
+for k in range(nb - LA - 1):
+    if k == nb - LA - 2:
         torch.cuda.synchronize()
         print("queue of the stamped launch:", pipe.queue_header(k))
-        pipe.launch(k, n, grads[k % 24], n, outs[(k + 1) % 24], n, ids[k + 3], dbg=dbg)
+        pipe.launch(k, n_of, grads[k % 24], outs[(k + 1) % 24], ids[k + LA], dbg_prep=dbgp, dbg_apply=dbg)
     else:
-        pipe.step(grads[k % 24], ids[k + 3], out=outs[(k + 1) % 24])
+        pipe.launch(k, n_of, grads[k % 24], outs[(k + 1) % 24], ids[k + LA])
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy()
-nblk = 1 + 2 + 48 + min(448, (2 * n) // 16 + 1)
-ph = raw[nblk * 64:nblk * 64 + 32]
+rawp = dbgp.cpu().numpy()
+nblk = 48 + min(448, (2 * n) // 16 + 1)
+ph = rawp[3 * 64:3 * 64 + 32]
+t_apply0 = int(raw[raw > 0].min()) if (raw > 0).any() else 0
 for name, off in (("plan A (0 ids 1 claim 2 number 3 label 4 rank 5 scan 6 out 7)", 0),
                   ("queue B0 = keys of the batch to apply (0 load 1 table 2 count 3 scans 4 emit 5)", 16),
                   ("queue B1 = copies", 24)):
     st = ph[off:off + 8]
     pts = [(i, int(v)) for i, v in enumerate(st) if v > 0]
     if pts:
-        print(name, "phases (us):", ", ".join("%d:%.2f" % (i, (v - pts[0][1]) * 0.01) for i, v in pts))
+        print(name, "phases (us):", ", ".join("%d:%.2f" % (i, (v - pts[0][1]) * 0.01) for i, v in pts),
+              "| first stamp %.2f us after the step's first wave" % ((pts[0][1] - t_apply0) * 0.01))
 d = raw[:nblk * 64].reshape(-1, 4)
 live = d[:, 0] > 0
 base = d[live, 0].min()
