@@ -62,8 +62,9 @@ def parse_args():
                         "(--lookahead 3), queue = ha_qstep_* (ids three batches ahead; every launch is driven by a work "
                         "queue the previous launch built, plans sorted + finished by one workgroup in LDS; keys with 16+ "
                         "occurrences applied as row - tree_sum(lr*g), within BASELINE.json's 1e-5)")
-    p.add_argument("--queue-side-streams", type=int, default=2, choices=(2, 3, 4),
-                   help="--engine queue: side streams the preparation launches rotate over (= steps each has to finish)")
+    p.add_argument("--queue-block", type=int, default=8,
+                   help="--engine queue: steps per block (the plans / queues of a block are prepared by two launches on a "
+                        "side stream beside the steps of the block before; ids are needed 3 blocks ahead)")
     p.add_argument("--queue-serial", action="store_true",
                    help="--engine queue with the preparation launch in front of every step on the timed stream instead of "
                         "beside the steps on side streams")
@@ -358,7 +359,7 @@ def main():
     # graphs never straddle the wrap-around of the batch list; ha_step_* rotates four plans and four key tables,
     # so the list is also cut to a multiple of 4 (a graph then depends on k % nb only)
     # buffers (and side streams) of step k and step k + rot_ring are the same
-    rot_ring = ({0: 8, 2: 8, 3: 12, 4: 12}[0 if args.queue_serial else args.queue_side_streams]) if queue else 4
+    rot_ring = (4 * (1 if args.queue_serial else args.queue_block)) if queue else 4
     period = (G * rot_ring // math.gcd(G, rot_ring)) if ahead2 else G
     if args.distinct_batches >= period:
         args.distinct_batches -= args.distinct_batches % period
@@ -374,6 +375,7 @@ def main():
     outs = [torch.empty((n, args.width), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     nb = ids_dev.shape[0]
     main_s = torch.cuda.Stream(device=dev)
+    before_chunk = None
     if ahead2:
         # One step = ONE launch (ha_step_f32ids): SGD apply of batch k, the rows of batch k+1 (forwarded from
         # the applying waves where both batches name a row, copied from the table otherwise), plan finish of
@@ -382,19 +384,27 @@ def main():
         # the prologue (untimed).
         if queue:
             # One step = ONE launch on the timed stream (ha_qapply: the items of step k -- SGD apply of batch k, rows of
-            # batch k+1 -- from the queue prepared for it) + one preparation launch (ha_qprep_*: plan of batch k+5, queue
-            # of step k+2; two workgroups + one) on one of two SIDE streams, captured into the same graphs (three
-            # branches).  --queue-serial: the preparation in front of the step on the timed stream (lookahead 3).
-            pipe = ops.QueueStepPipeline(table, n, LR, overlap=0 if args.queue_serial else args.queue_side_streams)
-            LA = pipe.LOOKAHEAD
-            n_of = lambda b: n if b >= 0 else 0
+            # batch k+1 -- from the queue prepared for it).  The preparation runs a BLOCK of steps at a time on a side
+            # stream, beside the steps of the block before: at the start of block b, one launch plans the batches of
+            # block b+2 (one workgroup each) and one builds the queues of block b+1 (two workgroups each).  All of it
+            # happens inside the timed region, every block; --queue-serial: block = 1 on the timed stream.
+            pipe = ops.QueueStepPipeline(table, n, LR, block=args.queue_block, overlap=not args.queue_serial)
+            LA, Bk = pipe.LOOKAHEAD, pipe.block
+            G = Bk                       # graphs are cut at block starts (the side work is enqueued between them)
+            ids_of = lambda j: ids_dev[j % nb] if j >= 0 else None
             with torch.cuda.stream(main_s):
                 for c in range(-LA, 0):
-                    pipe.launch(c, n_of, None, outs[0], ids_dev[(c + LA) % nb], stream=main_s)
+                    if c % Bk == 0:
+                        pipe.prepare_block(c // Bk, ids_of, stream=main_s)
+                pipe.apply(-1, None, outs[0], stream=main_s, n_cur=0, n_next=n)
+
+            def before_chunk(k):
+                if k % Bk == 0:
+                    pipe.prepare_block(k // Bk, ids_of, stream=main_s)
 
             def step(k):
                 b = k % nb
-                pipe.launch(k, n_of, grads[b % nbuf], outs[(b + 1) % nb % nbuf], ids_dev[(b + LA) % nb], stream=main_s)
+                pipe.apply(k, grads[b % nbuf], outs[(b + 1) % nb % nbuf], stream=main_s, n_cur=n, n_next=n)
         else:
             pipe = ops.StepPipeline(table, n, LR)
             with torch.cuda.stream(main_s):
@@ -459,12 +469,8 @@ def main():
         if key not in graphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=main_s):
-                if queue:
-                    pipe.begin_capture()
                 for j in range(k, k + ln):
                     step(j)
-                if queue:
-                    pipe.end_capture(main_s)     # the side streams rejoin the captured stream
             graphs[key] = g
         return graphs[key]
 
@@ -473,6 +479,8 @@ def main():
         replays = 0
         with torch.cuda.stream(main_s):
             for k, ln in chunks(k0, count):
+                if before_chunk is not None:
+                    before_chunk(k)
                 if use_graph:
                     graph_for(k, ln).replay()
                     replays += 1
@@ -594,12 +602,12 @@ def main():
                                "cache-limit-0.1 tier is not part of this line"
                                % (args.batch, args.width, args.fields, args.rows,
                                   args.rows * args.width * 4 / 1e9,
-                                  "one launch per step from a work queue: apply(k) + rows of k+1 per unique key; the "
-                                  "queue of step k+2 and the plan of batch k+5 prepared by a second launch on a side "
-                                  "stream inside the same graphs; keys with 16+ occurrences as row - tree_sum(lr*g)"
-                                  if queue and not args.queue_serial else
-                                  "two launches per step: preparation (plan of batch k+3, queue of step k+1), then the "
-                                  "items of step k from its queue" if queue else
+                                  "one launch per step from a work queue: apply(k) + rows of k+1 per unique key; plans "
+                                  "and queues prepared a block of %d steps at a time by two launches on a side stream, "
+                                  "inside the timed region; keys with 16+ occurrences as row - tree_sum(lr*g)"
+                                  % args.queue_block if queue and not args.queue_serial else
+                                  "three launches per step: plan of batch k+2, queue of step k+1, then the items of step "
+                                  "k from its queue" if queue else
                                   "one launch: apply(k), rows of k+1 forwarded / copied, finish(k+2), sort(k+3)" if ahead2 else
                                   "one launch: apply(k) beside lookup(k+1)" if one else "two launches"),
                    "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,

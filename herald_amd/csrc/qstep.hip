@@ -1,20 +1,27 @@
-// ha_qstep_*: ONE launch per training step, driven by a WORK QUEUE that earlier launches prepared.
+// ha_qapply / ha_qplan_batch_* / ha_qqueue_batch: ONE launch per training step, driven by a WORK QUEUE that
+// preparation launches -- on a stream of their own, a block of steps at a time -- have built.
 //
-//   launch c:  [coop items of queue c] [A: plan of batch c+3] [B: queue c+1 from plans c+1, c+2] [wave items of queue c]
+//   step c (caller's stream):     ha_qapply        [coop items of queue c] [wave items of queue c]
+//   every B steps (side stream):  ha_qplan_batch   plans of the B batches two blocks ahead, one workgroup each
+//                                 ha_qqueue_batch  queues of the B steps of the next block, two workgroups each
 //
 // Same contract as ha_step_* (step.hip): batch c is applied in the reference's occurrence order
 // (cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:51-74), the rows of batch c+1 are those AFTER that
-// update (cpu_EmbeddingLookup, src/dnnl_ops/EmbeddingLookup.cpp:16-35, run behind it), ids are known three batches
-// ahead (the prefetching data loader / the laia scheduler hand them over early, python/hetu/dataloader.py:63-98).
-// What is different is who does the bookkeeping and when:
+// update (cpu_EmbeddingLookup, src/dnnl_ops/EmbeddingLookup.cpp:16-35, run behind it); the ids are known ahead (the
+// reference's data loader holds the epoch, its laia scheduler walks it in a thread of its own: dataloader.py:63-98,
+// laia/src/laia_scheduler.cc:115-169).  What is different is who does the bookkeeping and when:
 //
-//   A  one 1024-thread workgroup sorts a whole batch in LDS (stable LSD radix sort of 16-bit occurrence indices by
-//      9-bit digits of the keys, per-wave ballot multisplit) and finishes its plan in place (unique keys, segment
-//      starts, counts, inverse) -- 16 waves for a few microseconds instead of the 208 rank-by-counting workgroups
-//      + 7 finish workgroups of step.hip, i.e. ~3,300 wave slots less held through the step;
-//   B  one workgroup joins the unique keys of two consecutive batches (binary search in LDS), classifies every key
-//      of their union by its occurrences in the batch to apply (c) and in the batch to look up (m), and writes the
-//      QUEUE of the next launch: one 32-byte item per unit of work, heaviest classes first;
+//   plan   one 1024-thread workgroup groups a whole batch by key in LDS (hash table, ranks in occurrence order) and
+//          finishes its plan (unique keys, segment starts, counts, inverse, occurrence lists) -- instead of the 208
+//          rank-by-counting workgroups + 7 finish workgroups of step.hip inside every step's launch;
+//   queue  two workgroups join the unique keys of two consecutive batches (hash table in LDS), classify every key of
+//          their union by its occurrences in the batch to apply (c) and in the batch to look up (m), and write the
+//          QUEUE of a step: one 32-byte item per unit of work, heaviest classes first.
+//          A plan takes one workgroup ~15 us and a queue ~13-20 us whatever else runs -- longer than the items of a
+//          step (11 us) -- so they cannot ride in the step's launch (26 us per step, measured) nor follow the steps one
+//          by one on a side stream (a captured graph runs its branches level by level: 24 us).  They are BATCHED instead:
+//          the plans of a block of batches side by side in one launch, the queues of a block of steps in another,
+//          beside the steps of the block before (~2.6 us of side-stream time per step);
 //   workers  one wave per item, no searching, no probing, no waiting: the item names the key, the column slice,
 //      where the occurrence indices and the destinations are.  A wave applies its key's gradient rows to the table
 //      row it holds in registers, writes the row back and writes it to every output row of the next batch that
@@ -119,17 +126,6 @@ struct QArgs {
     int n_g;
     float *out;
     int ncoop, nworker;
-    // A: the batch to sort + finish
-    const void *ahead_ids;
-    QPlan pa;
-    int has_a;
-    // B: the queue to build from (ba, bg)
-    QPlan ba, bg;
-    QHeader *bqh;
-    QEntry *bcoop, *bwave, *bcopy;
-    uint32_t bcap_coop, bcap_wave, bcap_copy;
-    int has_b;                 // 0, or 2: one workgroup for the keys of the batch to apply, one for the copies
-    uint32_t lds_bytes;        // dynamic LDS of the launch (B keeps its inputs there when they fit)
     unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind} per wave
 };
 
@@ -441,7 +437,6 @@ static inline size_t qjoin_lds_bytes(int n_a, int n_g) {
 static inline size_t qjoin_lds_resident_bytes(int n_g) {
     return kQTabSize * 4 + static_cast<size_t>(n_g) * 8 + 32 * 4;
 }
-constexpr size_t kQLdsBudget = 76800;   // 75 KiB: two workgroups per CU
 
 __device__ __forceinline__ int q_kind(uint32_t c, uint32_t m, bool in_table) {
     if (!in_table)
@@ -1004,25 +999,14 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
     __syncthreads();   // s_part is reused by the next item of this workgroup
 }
 
-// Block order: A, B, coop items, wave items.  The two single-workgroup roles are the longest-running ones and start
-// with a trip to memory: dispatched first, their loads are out before the workers' burst.
-template <typename IdT, bool RANK_ATOMIC>
-__global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
+// ---- the three launches ----------------------------------------------------------------------------------------
+// The items of one step: workgroups [0, ncoop) take the G items, the others one wave item per wave.
+__global__ __launch_bounds__(1024, 8) void qapply_kernel(const QArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
     int b = blockIdx.x;
-    if (b < a.has_a + a.has_b)
-        __builtin_amdgcn_s_setprio(3);   // the single-workgroup roles share their CU with a worker workgroup
-    if (b == 0 && a.has_a) {
-        role = 1;
-        qsort_finish_body<IdT, RANK_ATOMIC>(static_cast<const IdT *>(a.ahead_ids), a.pa, s_dyn,
-                                            a.dbg ? a.dbg + static_cast<size_t>(gridDim.x) * 64 : nullptr);
-    } else if ((b -= a.has_a) >= 0 && b < a.has_b) {
-        role = 2;
-        qjoin_body(a.ba, a.bg, a.rows, a.width, a.bqh, a.bcoop, a.bwave, a.bcopy, a.bcap_coop, a.bcap_wave, a.bcap_copy,
-                   s_dyn, a.lds_bytes, b, a.dbg ? a.dbg + static_cast<size_t>(gridDim.x) * 64 + 16 + 8 * b : nullptr);
-    } else if ((b -= a.has_b) < a.ncoop) {
+    if (b < a.ncoop) {
         role = 0;
         const uint32_t n = a.qh->n_coop;
         for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
@@ -1033,7 +1017,7 @@ __global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
     } else {
         b -= a.ncoop;
         role = 3;
-        const uint32_t n0 = a.qh ? a.qh->n_wave : 0u, n = n0 + (a.qh ? a.qh->n_copy : 0u);
+        const uint32_t n0 = a.qh->n_wave, n = n0 + a.qh->n_copy;
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * 16u;
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
         for (uint32_t e = static_cast<uint32_t>(b) * 16u + wv; e < n; e += stride) {
@@ -1060,6 +1044,40 @@ __global__ __launch_bounds__(1024, 8) void qstep_kernel(const QArgs a) {
             d[3] = static_cast<unsigned long long>(static_cast<unsigned>(kind));
         }
     }
+}
+
+// The plans of up to kQBatch batches, one workgroup each (a plan keeps ONE workgroup busy for ~15 us whatever else
+// runs: batches of a block of steps are planned side by side in one launch instead of one after the other).
+constexpr int kQBatch = 16;
+struct QPlanBatch {
+    int count;
+    const void *ids[kQBatch];
+    QPlan plan[kQBatch];
+    unsigned long long *ph;     // development aid: phase stamps of workgroup 0
+};
+template <typename IdT, bool RANK_ATOMIC>
+__global__ __launch_bounds__(1024, 4) void qplan_kernel(const QPlanBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const int i = blockIdx.x;
+    qsort_finish_body<IdT, RANK_ATOMIC>(static_cast<const IdT *>(b.ids[i]), b.plan[i], s_dyn, i == 0 ? b.ph : nullptr);
+}
+
+// The queues of up to kQJoinBatch steps, two workgroups each.
+constexpr int kQJoinBatch = 8;
+struct QJoinBatch {
+    int count, width;
+    uint64_t rows;
+    uint32_t lds_bytes, cap_coop, cap_wave, cap_copy;
+    QPlan pa[kQJoinBatch], pg[kQJoinBatch];
+    QHeader *qh[kQJoinBatch];
+    QEntry *coop[kQJoinBatch], *wave[kQJoinBatch], *copy[kQJoinBatch];
+    unsigned long long *ph;     // development aid: phase stamps of workgroups 0 and 1
+};
+__global__ __launch_bounds__(1024, 4) void qqueue_kernel(const QJoinBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const int i = blockIdx.x >> 1, part = blockIdx.x & 1;
+    qjoin_body(b.pa[i], b.pg[i], b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave,
+               b.cap_copy, s_dyn, b.lds_bytes, part, (i == 0 && b.ph) ? b.ph + 8 * part : nullptr);
 }
 
 // One wave-instruction's LDS atomics on one address: are the lanes served in ascending lane order?  Four collision
@@ -1123,161 +1141,97 @@ static int lds_atomics_lane_ordered() {
     return st == 1;
 }
 
-static void q_fill_apply(QArgs &a, size_t &lds, void *plan_cur, int64_t n_cur, const float *grads, void *plan_next,
-                         int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap, int64_t width) {
-    const QLayout q = queue_layout(const_cast<void *>(queue_cur), queue_n_cap, width);
-    a.qh = q.hdr;
-    a.qcoop = q.coop;
-    a.qwave = q.wave;
-    a.qcopy = q.copy;
-    a.cap_coop = q.cap_coop;
-    a.cap_wave = q.cap_wave;
-    a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
-    a.n_a = static_cast<int>(n_cur);
-    a.grads = grads;
-    a.perm_g = n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr;
-    a.n_g = static_cast<int>(n_next);
-    a.out = next_out;
-    a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
-    // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
-    const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
-    a.nworker = static_cast<int>(bound / 16 + 1 < kQWorkerMax ? bound / 16 + 1 : kQWorkerMax);
-    lds = lds > 16 * 64 * 4 ? lds : 16 * 64 * 4;
-}
-static void q_fill_join(QArgs &a, size_t &lds, void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build,
-                        int64_t queue_n_cap, int64_t width) {
-    a.ba = qplan(plan_a, n_a);
-    a.bg = qplan(plan_g, n_g);
-    const QLayout q = queue_layout(queue_build, queue_n_cap, width);
-    a.bqh = q.hdr;
-    a.bcoop = q.coop;
-    a.bwave = q.wave;
-    a.bcopy = q.copy;
-    a.bcap_coop = q.cap_coop;
-    a.bcap_wave = q.cap_wave;
-    a.bcap_copy = q.cap_copy;
-    a.has_b = 2;
-    lds = lds > qjoin_lds_bytes(a.ba.n, a.bg.n) ? lds : qjoin_lds_bytes(a.ba.n, a.bg.n);
-    // room for the join to keep the lookup batch's counts / starts in LDS too where that fits beside a second
-    // workgroup on the CU (it decides on the device, from the number of unique keys)
-    const size_t res = qjoin_lds_resident_bytes(a.bg.n);
-    const size_t want = res < kQLdsBudget ? res : kQLdsBudget;
-    lds = lds > want ? lds : want;
-}
 template <typename IdT>
-static int q_launch(QArgs &a, size_t lds, hipStream_t stream) {
-    const unsigned blocks = static_cast<unsigned>(a.ncoop + a.has_a + a.has_b + a.nworker);
-    if (blocks == 0)
-        return 0;
-    a.lds_bytes = static_cast<uint32_t>(lds);
+static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *plans, int64_t count, hipStream_t stream,
+                       unsigned long long *ph = nullptr) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (ids && n && plans)), "ha_qplan_batch: null pointer");
     static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
     if (lds_allowed.first()) {
-        HA_ALLOW_LDS((qstep_kernel<IdT, true>), 160 * 1024);
-        HA_ALLOW_LDS((qstep_kernel<IdT, false>), 160 * 1024);
+        HA_ALLOW_LDS((qplan_kernel<IdT, true>), 160 * 1024);
+        HA_ALLOW_LDS((qplan_kernel<IdT, false>), 160 * 1024);
     }
-    if (lds_atomics_lane_ordered())
-        hipLaunchKernelGGL((qstep_kernel<IdT, true>), dim3(blocks), dim3(1024), lds, stream, a);
-    else
-        hipLaunchKernelGGL((qstep_kernel<IdT, false>), dim3(blocks), dim3(1024), lds, stream, a);
-    HA_LAUNCH_CHECK();
-    return 0;
-}
-static int q_check_table(const float *table, int64_t rows, int64_t width) {
-    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
-                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
-               "ha_qstep: the table must be 16-byte aligned with rows of a multiple of 4 floats");
+    const bool ordered = lds_atomics_lane_ordered() != 0;
+    for (int64_t k0 = 0; k0 < count; k0 += kQBatch) {
+        QPlanBatch b;
+        memset(&b, 0, sizeof(b));
+        b.ph = k0 == 0 ? ph : nullptr;
+        size_t lds = 0;
+        for (int64_t k = k0; k < count && b.count < kQBatch; ++k) {
+            HA_REQUIRE(n[k] >= 0 && n[k] <= kQMax, "ha_qplan_batch: at most %d ids per batch", kQMax);
+            if (n[k] == 0)
+                continue;      // an empty batch has no plan
+            HA_REQUIRE(ids[k] && plans[k], "ha_qplan_batch: null pointer (batch %lld)", (long long)k);
+            b.ids[b.count] = ids[k];
+            b.plan[b.count] = qplan(plans[k], n[k]);
+            lds = lds > qsort_lds_bytes(static_cast<int>(n[k])) ? lds : qsort_lds_bytes(static_cast<int>(n[k]));
+            ++b.count;
+        }
+        if (b.count == 0)
+            continue;
+        if (ordered)
+            hipLaunchKernelGGL((qplan_kernel<IdT, true>), dim3(b.count), dim3(1024), lds, stream, b);
+        else
+            hipLaunchKernelGGL((qplan_kernel<IdT, false>), dim3(b.count), dim3(1024), lds, stream, b);
+        HA_LAUNCH_CHECK();
+    }
     return 0;
 }
 
-// everything in ONE launch (see the head of the file)
-template <typename IdT>
-static int qstep(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
-                 float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, void *plan_b1,
-                 int64_t n_b1, void *queue_build, int64_t queue_n_cap, const IdT *ahead_ids, int64_t n_ahead,
-                 void *plan_ahead, hipStream_t stream, unsigned long long *dbg = nullptr) {
-    if (q_check_table(table, rows, width))
-        return -1;
-    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && n_b1 >= 0 && n_ahead >= 0 && n_cur <= kQMax && n_next <= kQMax &&
-                   n_b1 <= kQMax && n_ahead <= kQMax && queue_n_cap >= 1 && queue_n_cap <= kQMax &&
-                   n_cur <= queue_n_cap && n_next <= queue_n_cap && n_b1 <= queue_n_cap,
-               "ha_qstep: at most %d ids per batch and no more than the queues were sized for "
-               "(larger batches: ha_step_* / ha_lookup_sort_* + ha_sgd_apply_finish)", kQMax);
-    HA_REQUIRE(n_cur == 0 || (plan_cur && grads && reinterpret_cast<uintptr_t>(grads) % 16 == 0),
-               "ha_qstep: current batch needs its plan and 16-byte aligned gradients");
-    HA_REQUIRE(n_next == 0 || (plan_next && next_out && reinterpret_cast<uintptr_t>(next_out) % 16 == 0),
-               "ha_qstep: next batch needs its plan and a 16-byte aligned output");
-    HA_REQUIRE((n_cur == 0 && n_next == 0) || queue_cur, "ha_qstep: the queue of this launch is missing");
-    HA_REQUIRE((n_next == 0 && n_b1 == 0) || queue_build, "ha_qstep: the queue to build is missing");
-    HA_REQUIRE(n_b1 == 0 || plan_b1, "ha_qstep: null pointer (batch after next)");
-    HA_REQUIRE(n_ahead == 0 || (ahead_ids && plan_ahead), "ha_qstep: null pointer (batch ahead)");
-    QArgs a;
-    memset(&a, 0, sizeof(a));
-    a.table = table;
-    a.rows = static_cast<uint64_t>(rows);
-    a.width = static_cast<int>(width);
-    a.lr = lr;
-    a.dbg = dbg;
-    size_t lds = 0;
-    if (n_cur > 0 || n_next > 0)
-        q_fill_apply(a, lds, plan_cur, n_cur, grads, plan_next, n_next, next_out, queue_cur, queue_n_cap, width);
-    if (n_ahead > 0) {
-        a.ahead_ids = ahead_ids;
-        a.pa = qplan(plan_ahead, n_ahead);
-        a.has_a = 1;
-        lds = lds > qsort_lds_bytes(a.pa.n) ? lds : qsort_lds_bytes(a.pa.n);
-    }
-    if (n_next > 0 || n_b1 > 0)
-        q_fill_join(a, lds, plan_next, n_next, plan_b1, n_b1, queue_build, queue_n_cap, width);
-    return q_launch<IdT>(a, lds, stream);
-}
-
-// The two halves as launches of their own (the same kernel with part of its roles): ha_qprep_* = the plan of one batch
-// and / or the queue of one step, ha_qapply = the items of one step.  On one stream, ha_qprep_*(batch c+3; queue c+1
-// from plans c+1, c+2) followed by ha_qapply(step c) is ha_qstep_*; on streams of their own the preparation runs
-// BESIDE the steps -- one workgroup needs 15-20 us for a plan and as long for a queue, twice the time the items of a
-// step take, so inside the step's launch they are its tail (26 us per step), two steps ahead on a side stream they
-// cost the step nothing (herald_amd.ops.QueueStepPipeline(overlap=True)).
-template <typename IdT>
-static int qprep(int64_t rows, int64_t width, const IdT *ahead_ids, int64_t n_ahead, void *plan_ahead, void *plan_a,
-                 int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap, hipStream_t stream,
-                 unsigned long long *dbg = nullptr) {
+static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
+                        const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
+                        hipStream_t stream, unsigned long long *ph = nullptr) {
     HA_REQUIRE(rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 && width <= (1 << 20),
-               "ha_qprep: rows of a multiple of 4 floats");
-    HA_REQUIRE(n_a >= 0 && n_g >= 0 && n_ahead >= 0 && n_a <= kQMax && n_g <= kQMax && n_ahead <= kQMax,
-               "ha_qprep: at most %d ids per batch", kQMax);
-    HA_REQUIRE((n_a == 0 && n_g == 0) || (queue_build && queue_n_cap >= 1 && queue_n_cap <= kQMax && n_a <= queue_n_cap &&
-                                          n_g <= queue_n_cap),
-               "ha_qprep: the queue to build is missing or smaller than the batches");
-    HA_REQUIRE((n_a == 0 || plan_a) && (n_g == 0 || plan_g), "ha_qprep: null plan");
-    HA_REQUIRE(n_ahead == 0 || (ahead_ids && plan_ahead), "ha_qprep: null pointer (batch to plan)");
-    {   // development aid (timing only, results are then stale): HA_QPREP_SKIP_AFTER=N drops every call after the Nth
-        static const char *skip = getenv("HA_QPREP_SKIP_AFTER");
-        static std::atomic<long> calls{0};
-        if (skip != nullptr && calls.fetch_add(1) >= atol(skip))
-            return 0;
+               "ha_qqueue_batch: rows of a multiple of 4 floats");
+    HA_REQUIRE(count >= 0 && (count == 0 || (plans_a && n_a && plans_g && n_g && queues)), "ha_qqueue_batch: null pointer");
+    HA_REQUIRE(count == 0 || (queue_n_cap >= 1 && queue_n_cap <= kQMax), "ha_qqueue_batch: bad queue capacity");
+    static DeviceOnce lds_allowed;
+    if (lds_allowed.first())
+        HA_ALLOW_LDS(qqueue_kernel, 160 * 1024);
+    for (int64_t k0 = 0; k0 < count; k0 += kQJoinBatch) {
+        QJoinBatch b;
+        memset(&b, 0, sizeof(b));
+        b.rows = static_cast<uint64_t>(rows);
+        b.width = static_cast<int>(width);
+        b.ph = k0 == 0 ? ph : nullptr;
+        size_t lds = 0;
+        for (int64_t k = k0; k < count && b.count < kQJoinBatch; ++k) {
+            HA_REQUIRE(n_a[k] >= 0 && n_g[k] >= 0 && n_a[k] <= queue_n_cap && n_g[k] <= queue_n_cap,
+                       "ha_qqueue_batch: a batch is larger than the queues were sized for");
+            if (n_a[k] == 0 && n_g[k] == 0)
+                continue;      // nothing to apply, nothing to look up: no queue
+            HA_REQUIRE(queues[k] && (n_a[k] == 0 || plans_a[k]) && (n_g[k] == 0 || plans_g[k]),
+                       "ha_qqueue_batch: null pointer (step %lld)", (long long)k);
+            const int i = b.count++;
+            b.pa[i] = qplan(plans_a[k], n_a[k]);
+            b.pg[i] = qplan(plans_g[k], n_g[k]);
+            const QLayout q = queue_layout(queues[k], queue_n_cap, width);
+            b.qh[i] = q.hdr;
+            b.coop[i] = q.coop;
+            b.wave[i] = q.wave;
+            b.copy[i] = q.copy;
+            b.cap_coop = q.cap_coop;
+            b.cap_wave = q.cap_wave;
+            b.cap_copy = q.cap_copy;
+            const size_t need = qjoin_lds_bytes(b.pa[i].n, b.pg[i].n), res = qjoin_lds_resident_bytes(b.pg[i].n);
+            lds = lds > need ? lds : need;
+            lds = lds > res ? lds : res;      // the lookup batch's counts / starts in LDS too (a launch of its own: no
+                                              // second workgroup has to fit on the CU)
+        }
+        if (b.count == 0)
+            continue;
+        b.lds_bytes = static_cast<uint32_t>(lds);
+        hipLaunchKernelGGL(qqueue_kernel, dim3(2 * b.count), dim3(1024), lds, stream, b);
+        HA_LAUNCH_CHECK();
     }
-    QArgs a;
-    memset(&a, 0, sizeof(a));
-    a.rows = static_cast<uint64_t>(rows);
-    a.width = static_cast<int>(width);
-    a.dbg = dbg;
-    size_t lds = 0;
-    if (n_ahead > 0) {
-        a.ahead_ids = ahead_ids;
-        a.pa = qplan(plan_ahead, n_ahead);
-        a.has_a = 1;
-        lds = qsort_lds_bytes(a.pa.n);
-    }
-    if (n_a > 0 || n_g > 0)
-        q_fill_join(a, lds, plan_a, n_a, plan_g, n_g, queue_build, queue_n_cap, width);
-    return q_launch<IdT>(a, lds, stream);
+    return 0;
 }
 
 static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                   void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
                   hipStream_t stream, unsigned long long *dbg = nullptr) {
-    if (q_check_table(table, rows, width))
-        return -1;
+    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
+                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
+               "ha_qapply: the table must be 16-byte aligned with rows of a multiple of 4 floats");
     HA_REQUIRE(n_cur >= 0 && n_next >= 0 && n_cur <= kQMax && n_next <= kQMax && queue_n_cap >= 1 &&
                    queue_n_cap <= kQMax && n_cur <= queue_n_cap && n_next <= queue_n_cap,
                "ha_qapply: at most %d ids per batch and no more than the queue was sized for", kQMax);
@@ -1295,9 +1249,24 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
     a.width = static_cast<int>(width);
     a.lr = lr;
     a.dbg = dbg;
-    size_t lds = 0;
-    q_fill_apply(a, lds, plan_cur, n_cur, grads, plan_next, n_next, next_out, queue_cur, queue_n_cap, width);
-    return q_launch<float>(a, lds, stream);
+    const QLayout q = queue_layout(const_cast<void *>(queue_cur), queue_n_cap, width);
+    a.qh = q.hdr;
+    a.qcoop = q.coop;
+    a.qwave = q.wave;
+    a.qcopy = q.copy;
+    a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
+    a.n_a = static_cast<int>(n_cur);
+    a.grads = grads;
+    a.perm_g = n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr;
+    a.n_g = static_cast<int>(n_next);
+    a.out = next_out;
+    a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
+    // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
+    const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
+    a.nworker = static_cast<int>(bound / 16 + 1 < kQWorkerMax ? bound / 16 + 1 : kQWorkerMax);
+    hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(1024), 16 * 64 * 4, stream, a);
+    HA_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace ha
@@ -1312,50 +1281,18 @@ extern "C" size_t ha_qstep_queue_bytes(int64_t n_cap, int64_t width) {
     return queue_layout(nullptr, n_cap, width).bytes;
 }
 
-extern "C" int ha_qstep_f32ids(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
-                               const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out,
-                               const void *queue_cur, void *plan_b1, int64_t n_b1, void *queue_build,
-                               int64_t queue_n_cap, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
-                               ha_stream_t stream) {
-    return qstep<float>(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur,
-                        plan_b1, n_b1, queue_build, queue_n_cap, ahead_ids, n_ahead, plan_ahead, as_stream(stream));
+extern "C" int ha_qplan_batch_f32ids(const float *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                                     ha_stream_t stream) {
+    return qplan_batch<float>(ids, n, plans, count, as_stream(stream));
 }
-
-extern "C" int ha_qstep_u64ids(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
-                               const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out,
-                               const void *queue_cur, void *plan_b1, int64_t n_b1, void *queue_build,
-                               int64_t queue_n_cap, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
-                               ha_stream_t stream) {
-    return qstep<uint64_t>(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur,
-                           plan_b1, n_b1, queue_build, queue_n_cap, ahead_ids, n_ahead, plan_ahead,
-                           as_stream(stream));
+extern "C" int ha_qplan_batch_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                                     ha_stream_t stream) {
+    return qplan_batch<uint64_t>(ids, n, plans, count, as_stream(stream));
 }
-
-// development aid: ha_qstep_f32ids with per-wave time stamps; dbg = device uint64[blocks * 16 * 4 + 32] (zeroed);
-// the last 32 words receive phase stamps of the plan (A) and queue (B) workgroups
-extern "C" int ha_debug_qstep_timeline(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
-                                       const float *grads, float lr, void *plan_next, int64_t n_next,
-                                       float *next_out, const void *queue_cur, void *plan_b1, int64_t n_b1,
-                                       void *queue_build, int64_t queue_n_cap, const float *ahead_ids,
-                                       int64_t n_ahead, void *plan_ahead, unsigned long long *dbg,
-                                       ha_stream_t stream) {
-    HA_REQUIRE(dbg != nullptr, "qstep timeline: null debug buffer");
-    return qstep<float>(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur,
-                        plan_b1, n_b1, queue_build, queue_n_cap, ahead_ids, n_ahead, plan_ahead, as_stream(stream),
-                        dbg);
-}
-
-extern "C" int ha_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
-                               void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build,
-                               int64_t queue_n_cap, ha_stream_t stream) {
-    return qprep<float>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_a, n_a, plan_g, n_g, queue_build, queue_n_cap,
-                        as_stream(stream));
-}
-extern "C" int ha_qprep_u64ids(int64_t rows, int64_t width, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
-                               void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build,
-                               int64_t queue_n_cap, ha_stream_t stream) {
-    return qprep<uint64_t>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_a, n_a, plan_g, n_g, queue_build,
-                           queue_n_cap, as_stream(stream));
+extern "C" int ha_qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a,
+                               void *const *plans_g, const int64_t *n_g, void *const *queues, int64_t queue_n_cap,
+                               int64_t count, ha_stream_t stream) {
+    return qqueue_batch(rows, width, plans_a, n_a, plans_g, n_g, queues, queue_n_cap, count, as_stream(stream));
 }
 extern "C" int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
                          float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
@@ -1363,14 +1300,55 @@ extern "C" int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_c
     return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
                   as_stream(stream));
 }
-// development aids: the two halves with time stamps (dbg as for ha_debug_qstep_timeline)
-extern "C" int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead,
-                                     void *plan_ahead, void *plan_a, int64_t n_a, void *plan_g, int64_t n_g,
-                                     void *queue_build, int64_t queue_n_cap, unsigned long long *dbg, ha_stream_t stream) {
-    HA_REQUIRE(dbg != nullptr, "qprep timeline: null debug buffer");
-    return qprep<float>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_a, n_a, plan_g, n_g, queue_build, queue_n_cap,
-                        as_stream(stream), dbg);
+
+// ha_qprep_*: one plan and / or one queue; ha_qstep_*: that followed by the step -- the serial forms
+template <typename IdT>
+static int qprep_one(int64_t rows, int64_t width, const IdT *ahead_ids, int64_t n_ahead, void *plan_ahead, void *plan_a,
+                     int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap, hipStream_t s) {
+    if (n_ahead > 0 && qplan_batch<IdT>(&ahead_ids, &n_ahead, &plan_ahead, 1, s))
+        return -1;
+    if (n_a > 0 || n_g > 0)
+        return qqueue_batch(rows, width, &plan_a, &n_a, &plan_g, &n_g, &queue_build, queue_n_cap, 1, s);
+    return 0;
 }
+extern "C" int ha_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build,
+                               int64_t queue_n_cap, ha_stream_t stream) {
+    return qprep_one<float>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_a, n_a, plan_g, n_g, queue_build,
+                            queue_n_cap, as_stream(stream));
+}
+extern "C" int ha_qprep_u64ids(int64_t rows, int64_t width, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build,
+                               int64_t queue_n_cap, ha_stream_t stream) {
+    return qprep_one<uint64_t>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_a, n_a, plan_g, n_g, queue_build,
+                               queue_n_cap, as_stream(stream));
+}
+extern "C" int ha_qstep_f32ids(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                               const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out,
+                               const void *queue_cur, void *plan_b1, int64_t n_b1, void *queue_build,
+                               int64_t queue_n_cap, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               ha_stream_t stream) {
+    if (qprep_one<float>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_next, n_next, plan_b1, n_b1, queue_build,
+                         queue_n_cap, as_stream(stream)))
+        return -1;
+    return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
+                  as_stream(stream));
+}
+extern "C" int ha_qstep_u64ids(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
+                               const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out,
+                               const void *queue_cur, void *plan_b1, int64_t n_b1, void *queue_build,
+                               int64_t queue_n_cap, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                               ha_stream_t stream) {
+    if (qprep_one<uint64_t>(rows, width, ahead_ids, n_ahead, plan_ahead, plan_next, n_next, plan_b1, n_b1, queue_build,
+                            queue_n_cap, as_stream(stream)))
+        return -1;
+    return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
+                  as_stream(stream));
+}
+
+// development aids: the items of a step with per-wave time stamps (dbg = device uint64[(workgroups) * 16 * 4], zeroed);
+// one plan + one queue with the phase stamps of their workgroups (ph = device uint64[32], zeroed: plan at 0, the
+// queue's two workgroups at 16 and 24)
 extern "C" int ha_debug_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,
                                const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out,
                                const void *queue_cur, int64_t queue_n_cap, unsigned long long *dbg, ha_stream_t stream) {
@@ -1378,8 +1356,20 @@ extern "C" int ha_debug_qapply(float *table, int64_t rows, int64_t width, void *
     return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
                   as_stream(stream), dbg);
 }
+extern "C" int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead,
+                                     void *plan_ahead, void *plan_a, int64_t n_a, void *plan_g, int64_t n_g,
+                                     void *queue_build, int64_t queue_n_cap, unsigned long long *ph, ha_stream_t stream) {
+    HA_REQUIRE(ph != nullptr, "qprep phases: null debug buffer");
+    if (n_ahead > 0 && qplan_batch<float>(&ahead_ids, &n_ahead, &plan_ahead, 1, as_stream(stream), ph))
+        return -1;
+    if (n_a > 0 || n_g > 0)
+        return qqueue_batch(rows, width, &plan_a, &n_a, &plan_g, &n_g, &queue_build, queue_n_cap, 1, as_stream(stream),
+                            ph + 16);
+    return 0;
+}
 
-// queue header of a built queue: {n_wave, n_coop, n_long, n_medium, n_small} (tests / tools; device pointer)
+// queue header of a built queue: {wave items, workgroup items, long, medium, small, copy items} (tests / tools; device
+// pointer)
 extern "C" const uint32_t *ha_qstep_queue_header(const void *queue) {
     return reinterpret_cast<const uint32_t *>(queue);
 }

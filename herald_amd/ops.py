@@ -612,28 +612,27 @@ def qstep_max_ids():
 
 
 class QueueStepPipeline:
-    """Drives ha_qprep_* / ha_qapply (include/herald_amd.h, csrc/qstep.hip) over a stream of id batches: every training
-    step is ONE launch on the caller's stream that applies the sparse SGD of batch c (cpu_SGDOptimizerSparseUpdate order)
-    and writes the rows of batch c+1 after that update, item by item from a work queue (one wave per unique key / column
-    slice, no probing, no waiting); the queue and the per-batch plans behind it are prepared by single-workgroup launches
-    that run a few batches ahead --
+    """Drives ha_qapply / ha_qplan_batch_* / ha_qqueue_batch (include/herald_amd.h, csrc/qstep.hip) over a stream of id
+    batches.  Every training step is ONE launch on the caller's stream: it applies the sparse SGD of batch c
+    (cpu_SGDOptimizerSparseUpdate order) and writes the rows of batch c+1 after that update, item by item from a work
+    queue (one wave per unique key / column slice, no probing, no waiting).  The queues and the per-batch plans behind
+    them are prepared a BLOCK of `block` steps at a time: at the start of block b the plans of the batches of block b+2
+    (one workgroup each, one launch) and the queues of the steps of block b+1 (two workgroups each, one launch) go to a
+    side stream and run beside the steps of block b.  Ids are needed LOOKAHEAD = 3 * block batches ahead.
 
-        overlap=True   on two side streams BESIDE the steps (a plan or a queue keeps one workgroup busy for 15-20 us,
-                       about twice the time the items of a step take); ids are needed LOOKAHEAD = 5 batches ahead;
-        overlap=False  on the caller's stream, in front of every step (LOOKAHEAD = 3, the call sequence of ha_qstep_*).
+        overlap=False  block = 1 and everything on the caller's stream (three launches per step, LOOKAHEAD = 3).
 
-        pipe = QueueStepPipeline(table, capacity, lr)
-        out0 = pipe.start(ids0, ..., ids4)            # the first LOOKAHEAD batches; returns the rows of batch 0
-        out1 = pipe.step(grads0, ids5)                # apply 0, rows of batch 1; batch 5 enters the pipeline
+        pipe = QueueStepPipeline(table, capacity, lr, block=8)
+        out0 = pipe.start(ids[:pipe.LOOKAHEAD])       # the first LOOKAHEAD batches; returns the rows of batch 0
+        out1 = pipe.step(grads0, ids[LOOKAHEAD])      # apply 0, rows of batch 1; one more batch enters the pipeline
         ...                                           # ahead_ids=None once the stream of batches ends
 
     Keys with 16 or more occurrences in a batch are applied as `row - tree_sum(lr * g)` (deterministic, within the 1e-5
     relative BASELINE.json allows for accumulated gradients); below 16 occurrences the result is the reference's serial
     chain bit for bit.  `plan_of(j)` holds the unique keys / counts / inverse / occurrence lists of batch j with the
-    unique keys in hash-slot order (not np.unique's order), from the moment its preparation has run."""
+    unique keys in hash-slot order (not np.unique's order) once its block has been prepared."""
 
-
-    def __init__(self, table, capacity, lr, device=None, overlap=True):
+    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True):
         L = _lib.load()
         _require(table, torch.float32, "table")
         self.table, self.lr = table, float(lr)
@@ -644,27 +643,23 @@ class QueueStepPipeline:
         if table.shape[1] % 4 != 0:
             raise ValueError("ha_qstep_* needs rows of a multiple of 4 floats")
         self.capacity = max(int(capacity), 1)
-        # overlap: False / 0 = the preparation on the caller's stream; True = two side streams; k >= 2 = k side streams
-        # (the preparation of call c then has k steps to finish)
-        self.nside = 2 if overlap is True else int(overlap or 0)
-        if self.nside not in (0, 2, 3, 4):
-            raise ValueError("overlap must be False, True or 2..4 side streams")
-        self.overlap = self.nside > 0
-        self.JOIN_AHEAD = self.nside if self.overlap else 1   # the preparation of call c builds the queue of step c + JOIN_AHEAD
-        self.LOOKAHEAD = self.JOIN_AHEAD + (3 if self.overlap else 2)
-        # ring sizes: plans >= LOOKAHEAD + 3, queues >= JOIN_AHEAD + 2; replayed captures must cover a multiple of
-        # ROTATION calls (plans, queues and side streams of call c and call c + ROTATION are the same)
-        self.NPLAN, self.NQUEUE, self.ROTATION = {0: (8, 4, 8), 2: (8, 4, 8), 3: (12, 6, 12), 4: (12, 6, 12)}[self.nside]
+        self.overlap = bool(overlap)
+        self.block = int(block) if self.overlap else 1
+        if not 1 <= self.block <= 16:
+            raise ValueError("block must be 1..16")
+        self.LOOKAHEAD = 3 * self.block
+        self.NPLAN, self.NQUEUE = 4 * self.block, 2 * self.block
+        self.ROTATION = 4 * self.block     # plans and queues of call c and call c + ROTATION are the same
         self.plans = [IndexPlan(self.capacity, self.device) for _ in range(self.NPLAN)]
         self.queue_bytes = int(L.ha_qstep_queue_bytes(self.capacity, table.shape[1]))
         self.queues = torch.empty(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
-        self.side = [torch.cuda.Stream(device=self.device) for _ in range(self.nside)]
+        self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self.reset()
 
     # ---- bookkeeping ------------------------------------------------------------------------------------------
     def reset(self, stream=None):
-        self.c, self.n, self.shape = None, {}, {}
-        self._ev_side = {}          # call index -> event behind its preparation
+        self.c, self.n, self.shape, self.ids = None, {}, {}, {}
+        self._ev_side = {}          # block index -> event behind the side work launched at its start
         return self
 
     def plan_of(self, b):
@@ -681,33 +676,82 @@ class QueueStepPipeline:
         h = self.queues[off:off + 24].view(torch.int32).cpu().tolist()
         return dict(zip(("wave_items", "workgroup_items", "long", "medium", "small", "copy_items"), h))
 
-    def begin_capture(self):
-        """Call at the start of a stream capture: launches captured from here on must not wait for events recorded
-        before the capture (whatever ran before it is ordered by the stream the graph is launched on)."""
-        self._ev_side = {}
-
-    def end_capture(self, stream=None):
-        """Call before a stream capture ends: the side streams rejoin `stream`."""
+    # ---- the preparation of a block ------------------------------------------------------------------------------
+    def prepare_block(self, b, ids_of, stream=None, ph=None):
+        """Start of block b (call before the first step of the block, NOT inside a stream capture when overlap is on):
+        the plans of the batches of block b+2 and the queues of the steps of block b+1 are enqueued (side stream), and the
+        caller's stream is made to wait for the side work enqueued at the start of block b-1 -- the queues of block b.
+        `ids_of(j)` = device id tensor of batch j, or None outside the stream of batches."""
+        L = _lib.load()
+        rows, width = self.table.shape
         main = stream if stream is not None else torch.cuda.current_stream(self.device)
-        for ev in self._ev_side.values():
-            main.wait_event(ev)
-        self._ev_side = {}
+        B = self.block
+        s = self.side if self.overlap else main
+        if self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(main)                    # the buffers about to be rewritten are free, the ids are there
+            s.wait_event(ev)
+        # plans of block b+2
+        todo = [(j, ids_of(j)) for j in range((b + 2) * B, (b + 3) * B)]
+        todo = [(j, t) for j, t in todo if t is not None and t.numel() > 0]
+        for kind in ("f32ids", "u64ids"):
+            sel = [(j, t) for j, t in todo if _ids_kind(t) == kind]
+            if not sel:
+                continue
+            for j, t in sel:
+                if t.numel() > self.capacity:
+                    raise ValueError("plan capacity %d < %d ids" % (self.capacity, t.numel()))
+                if not t.is_cuda or not t.is_contiguous():
+                    raise ValueError("ids must be contiguous device tensors")
+            cnt = len(sel)
+            ids_arr = (ctypes.c_void_p * cnt)(*[t.data_ptr() for _, t in sel])
+            n_arr = (ctypes.c_int64 * cnt)(*[t.numel() for _, t in sel])
+            pl_arr = (ctypes.c_void_p * cnt)(*[self.plan_of(j).ws.data_ptr() for j, _ in sel])
+            if ph is not None and kind == "f32ids":
+                t0 = sel[0][1]
+                check(L.ha_debug_qprep_f32ids(rows, width, _ptr(t0), t0.numel(), _ptr(self.plan_of(sel[0][0]).ws), None, 0,
+                                              None, 0, None, self.capacity, _ptr(ph), _stream_ptr(s)), "ha_debug_qprep")
+            check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, _stream_ptr(s)), "ha_qplan_batch")
+            for j, t in sel:
+                pl = self.plan_of(j)
+                pl.n = t.numel()
+                pl._view = None
+                pl.produced_on(s)
+                if self.overlap:
+                    t.record_stream(s)     # the ids are read on the side stream: their memory must outlive that
+        for j, t in todo:
+            self.n[j] = t.numel()
+        # queues of the steps of block b+1 (step j: batch j applied, batch j+1 looked up)
+        steps = [j for j in range((b + 1) * B, (b + 2) * B) if self.n.get(j, 0) or self.n.get(j + 1, 0)]
+        if steps:
+            cnt = len(steps)
+            pa = (ctypes.c_void_p * cnt)(*[self.plan_of(j).ws.data_ptr() if self.n.get(j, 0) else None for j in steps])
+            na = (ctypes.c_int64 * cnt)(*[self.n.get(j, 0) for j in steps])
+            pg = (ctypes.c_void_p * cnt)(*[self.plan_of(j + 1).ws.data_ptr() if self.n.get(j + 1, 0) else None
+                                           for j in steps])
+            ng = (ctypes.c_int64 * cnt)(*[self.n.get(j + 1, 0) for j in steps])
+            qs = (ctypes.c_void_p * cnt)(*[self._queue(j) for j in steps])
+            if ph is not None:
+                check(L.ha_debug_qprep_f32ids(rows, width, None, 0, None, pa[0], na[0], pg[0], ng[0], qs[0], self.capacity,
+                                              _ptr(ph), _stream_ptr(s)), "ha_debug_qprep")
+            check(L.ha_qqueue_batch(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, _stream_ptr(s)), "ha_qqueue_batch")
+        if self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self._ev_side[b] = ev
+            ready = self._ev_side.pop(b - 1, None)
+            if ready is not None:
+                main.wait_event(ready)
 
-    # ---- one call -----------------------------------------------------------------------------------------------
-    def launch(self, c, n_of, grads, out, ahead_ids, stream=None, dbg_prep=None, dbg_apply=None):
-        """Call c, stateless about the batch sizes (`n_of(b)` = ids of batch b, 0 outside the stream): the preparation
-        -- plan of batch c + LOOKAHEAD (`ahead_ids`), queue of step c + JOIN_AHEAD -- and step c itself: batch c
-        applied with `grads`, the rows of batch c + 1 to `out`."""
+    # ---- one step ----------------------------------------------------------------------------------------------------
+    def apply(self, c, grads, out, stream=None, dbg=None, n_cur=None, n_next=None):
+        """Step c on `stream`: batch c applied with `grads`, the rows of batch c+1 to `out`.  n_cur / n_next: the ids of
+        the two batches (default: as recorded when their plans were prepared)."""
         L = _lib.load()
         t = self.table
         rows, width = t.shape
-        main = stream if stream is not None else torch.cuda.current_stream(self.device)
-        n_cur, n_next = n_of(c), n_of(c + 1)
-        jb = c + self.JOIN_AHEAD
-        n_a, n_g = n_of(jb), n_of(jb + 1)
-        n_ahead = 0 if ahead_ids is None else ahead_ids.numel()
-        if max(n_cur, n_next, n_a, n_g, n_ahead) > self.capacity:
-            raise ValueError("plan capacity %d < %d ids" % (self.capacity, max(n_cur, n_next, n_a, n_g, n_ahead)))
+        n_cur = self.n.get(c, 0) if n_cur is None else int(n_cur)
+        n_next = self.n.get(c + 1, 0) if n_next is None else int(n_next)
         if n_cur:
             _require(grads, torch.float32, "grads")
             if grads.numel() != n_cur * width:
@@ -716,77 +760,44 @@ class QueueStepPipeline:
             _require(out, torch.float32, "out")
             if out.numel() != n_next * width:
                 raise ValueError("out must hold %d x %d values" % (n_next, width))
-        # -- the preparation
-        if n_ahead or n_a or n_g:
-            s = main
-            if self.overlap:
-                s = self.side[c % self.nside]
-                # One wait on the caller's stream as it stands now: the ids are there, the buffers about to be rewritten
-                # are free, and -- because step c-1 waited for the preparation of call c-3 before it was enqueued -- so
-                # are the plans this call's queue builds on (the other side stream's work).  (Waiting for that older
-                # event directly is legal, but hipStreamEndCapture crashes on a wait for an event that is not the last
-                # thing captured on its stream.)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                s.wait_event(ev)
-            kind = _ids_kind(ahead_ids) if n_ahead else "f32ids"
-            args = [rows, width, _ptr(ahead_ids) if n_ahead else None, n_ahead,
-                    _ptr(self.plan_of(c + self.LOOKAHEAD).ws) if n_ahead else None,
-                    _ptr(self.plan_of(jb).ws) if n_a else None, n_a,
-                    _ptr(self.plan_of(jb + 1).ws) if n_g else None, n_g,
-                    self._queue(jb) if (n_a or n_g) else None, self.capacity]
-            if dbg_prep is None:
-                check(getattr(L, "ha_qprep_" + kind)(*args, _stream_ptr(s)), "ha_qprep")
-            else:
-                check(L.ha_debug_qprep_f32ids(*args, _ptr(dbg_prep), _stream_ptr(s)), "ha_debug_qprep")
-            if n_ahead:
-                pl = self.plan_of(c + self.LOOKAHEAD)
-                pl.n = n_ahead
-                pl._view = None
-                pl.produced_on(s)
-            if self.overlap:
-                ev = torch.cuda.Event()
-                ev.record(s)
-                self._ev_side[c] = ev
-        # -- the step
-        if self.overlap:
-            ready = self._ev_side.get(c - self.JOIN_AHEAD)
-            if ready is not None:
-                main.wait_event(ready)
-            for old in [k for k in self._ev_side if k < c - self.nside - 2]:
-                del self._ev_side[old]
-        if n_cur or n_next:
-            args = [_ptr(t), rows, width, _ptr(self.plan_of(c).ws) if n_cur else None, n_cur,
-                    _ptr(grads) if n_cur else None, ctypes.c_float(self.lr),
-                    _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
-                    self._queue(c), self.capacity]
-            if dbg_apply is None:
-                check(L.ha_qapply(*args, _stream_ptr(main)), "ha_qapply")
-            else:
-                check(L.ha_debug_qapply(*args, _ptr(dbg_apply), _stream_ptr(main)), "ha_debug_qapply")
+        if not (n_cur or n_next):
+            return
+        args = [_ptr(t), rows, width, _ptr(self.plan_of(c).ws) if n_cur else None, n_cur,
+                _ptr(grads) if n_cur else None, ctypes.c_float(self.lr),
+                _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
+                self._queue(c), self.capacity]
+        if dbg is None:
+            check(L.ha_qapply(*args, _stream_ptr(stream)), "ha_qapply")
+        else:
+            check(L.ha_debug_qapply(*args, _ptr(dbg), _stream_ptr(stream)), "ha_debug_qapply")
 
     # ---- the stream protocol --------------------------------------------------------------------------------------
     def _call(self, c, grads, ahead_ids, out, stream):
-        n_ahead = 0 if ahead_ids is None else ahead_ids.numel()
-        if n_ahead:
-            self.n[c + self.LOOKAHEAD] = n_ahead
+        if c % self.block == 0:
+            self.prepare_block(c // self.block, lambda j: self.ids.get(j), stream)
+            for j in [j for j in self.ids if j < c + 3 * self.block]:
+                del self.ids[j]            # planned (enqueued): the plan holds what the steps need
+        if ahead_ids is not None and ahead_ids.numel():
+            self.ids[c + self.LOOKAHEAD] = ahead_ids
             self.shape[c + self.LOOKAHEAD] = tuple(ahead_ids.shape)
-        n_of = lambda b: self.n.get(b, 0)
-        n_next = n_of(c + 1)
+        n_next = self.n.get(c + 1, 0)
         if n_next and out is None:
             out = torch.empty(tuple(self.shape[c + 1]) + (self.table.shape[1],), dtype=torch.float32,
                               device=self.table.device)
-        self.launch(c, n_of, grads, out, ahead_ids, stream)
-        self.n.pop(c, None)
+        self.apply(c, grads, out, stream)
+        for d in (self.n, self.shape):
+            d.pop(c - 1, None)
         self.c = c + 1
         return out if n_next else None
 
-    def start(self, *ids, out=None, stream=None):
-        """Takes the first LOOKAHEAD batches (fewer, or None entries, if the stream is shorter) and returns the rows of
-        batch 0."""
+    def start(self, ids, out=None, stream=None):
+        """`ids`: the first LOOKAHEAD batches of the stream (a shorter list if the stream is shorter; None / empty
+        entries are empty batches).  Returns the rows of batch 0."""
+        ids = list(ids)
         if len(ids) > self.LOOKAHEAD:
             raise ValueError("start takes the first %d batches" % self.LOOKAHEAD)
-        ids = list(ids) + [None] * (self.LOOKAHEAD - len(ids))
+        ids = ids + [None] * (self.LOOKAHEAD - len(ids))
+        self.reset()
         res = None
         for k, b in enumerate(ids):
             c = k - self.LOOKAHEAD

@@ -439,27 +439,52 @@ int ha_debug_step_fwd_timeline(float *table, int64_t rows, int64_t width,
                                const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
                                void *tab_clear, unsigned long long *dbg, ha_stream_t stream);
 
-/* The same step driven by a WORK QUEUE that earlier launches prepared (csrc/qstep.hip): call c
- *   - applies the gradients of batch c and writes the rows of batch c+1 after that update, item by item from
- *     QUEUE c: one wave per (unique key, column slice) that applies the key's occurrences to the row it holds
- *     in registers, writes the row back and writes it to every output row of batch c+1 naming the key; keys
- *     only batch c+1 names are copies.  No probing, no waiting, no key tables;
- *   - builds QUEUE c+1 from the finished plans of batches c+1 (plan_next) and c+2 (plan_b1) -- one workgroup;
- *   - sorts AND finishes the plan of batch c+3 (ahead_ids -> plan_ahead: sorted keys, occurrence indices,
- *     unique keys, counts, inverse == ha_plan_build_*) -- one workgroup, an LDS radix sort.
+/* The same step driven by a WORK QUEUE that preparation launches have built (csrc/qstep.hip).
+ *   ha_qapply        step c, ONE launch: applies the gradients of batch c and writes the rows of batch c+1 after that
+ *                    update, item by item from QUEUE c: one wave per (unique key, column slice) applies the key's
+ *                    occurrences to the row it holds in registers, writes the row back and writes it to every output
+ *                    row of batch c+1 naming the key; keys only batch c+1 names are copies.  No probing, no waiting.
+ *   ha_qplan_batch_* the plans of `count` batches, one workgroup each in one launch: unique keys, counts, segment
+ *                    starts, inverse and occurrence lists (ascending inside every segment) of an index plan -- with
+ *                    the unique keys in the order of a hash table's slots, NOT in key order (ha_plan_build_* gives
+ *                    np.unique's order).
+ *   ha_qqueue_batch  the queues of `count` steps, two workgroups each in one launch: queue k from the finished plans
+ *                    of the batch step k applies (plans_a[k], n_a[k] ids; 0 = none) and of the batch it looks up
+ *                    (plans_g[k]).
+ * A plan takes one workgroup ~15 us and a queue ~13-20 us, longer than the items of a step (~11 us): callers prepare a
+ * BLOCK of steps at a time on a stream of their own, beside the steps of the block before
+ * (herald_amd.ops.QueueStepPipeline); ha_qprep_* (one plan and / or one queue) and ha_qstep_* (that, then the step: three
+ * launches on one stream) are the serial forms.
  * Semantics and references as ha_step_* above (cpu_SGDOptimizerSparseUpdate, Optimizers.cpp:51-74;
- * cpu_EmbeddingLookup, EmbeddingLookup.cpp:16-35), with ONE difference: keys with fewer than 16 occurrences in
- * the batch take the reference's serial chain row = (row - lr*g0) - lr*g1 ... bit for bit; a key with 16 or more
- * occurrences takes row - T, T = a fixed (deterministic) tree sum of the lr*g_i -- within the 1e-5 relative that
- * BASELINE.json's north star allows for accumulated gradients, not bit-identical to the serial chain.  Integer
- * results (plans) are exact.  Callers that need the serial chain for every run length use ha_step_*.
- * A stream of batches 0..B-1 is driven as calls c = -3 .. B-1 (n = 0 / null for batches outside [0, B)); four
- * plans rotate (c .. c+3) and two queues alternate: call c reads queue_cur = Q[c % 2], which call c-1 wrote as
- * its queue_build, and writes Q[(c+1) % 2].  Each queue is ha_qstep_queue_bytes(n_cap, width) bytes (no
- * initialisation needed); queue_n_cap = the n_cap both queues were sized with.  Limits: at most
- * ha_qstep_max_ids() ids per batch, width % 4 == 0, table / grads / next_out 16-byte aligned. */
+ * cpu_EmbeddingLookup, EmbeddingLookup.cpp:16-35), with ONE difference: keys with fewer than 16 occurrences in a batch
+ * take the reference's serial chain row = (row - lr*g0) - lr*g1 ... bit for bit; a key with 16 or more occurrences takes
+ * row - T, T = a fixed (deterministic) tree sum of the lr*g_i -- within the 1e-5 relative that BASELINE.json's north star
+ * allows for accumulated gradients, not bit-identical to the serial chain.  Integer results are exact.  Callers that need
+ * the serial chain for every run length use ha_step_*.
+ * A queue is ha_qstep_queue_bytes(n_cap, width) bytes (no initialisation); queue_n_cap = the n_cap it was sized with.
+ * Limits: at most ha_qstep_max_ids() ids per batch, width % 4 == 0, table / grads / next_out 16-byte aligned.  ids / n /
+ * plans / queues arguments of the batch calls are HOST arrays of `count` entries (device pointers inside). */
 int64_t ha_qstep_max_ids(void);
 size_t ha_qstep_queue_bytes(int64_t n_cap, int64_t width);
+int ha_qplan_batch_f32ids(const float *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                          ha_stream_t stream);
+int ha_qplan_batch_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                          ha_stream_t stream);
+int ha_qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
+                    const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count, ha_stream_t stream);
+int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
+              void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
+              ha_stream_t stream);
+/* serial forms: ha_qprep_* = the plan of one batch (ahead_ids -> plan_ahead; n_ahead = 0: none) and / or the queue of one
+ * step from (plan_a, plan_g) (n_a = n_g = 0: none); ha_qstep_*(call c) = ha_qprep_*(batch c+3; queue c+1 from plans
+ * c+1 = plan_next, c+2 = plan_b1) followed by ha_qapply(step c).  A stream of batches 0..B-1 is driven as calls
+ * c = -3 .. B-1 (n = 0 / null for batches outside [0, B)); four plans rotate and two queues alternate. */
+int ha_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                    void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
+                    ha_stream_t stream);
+int ha_qprep_u64ids(int64_t rows, int64_t width, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                    void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
+                    ha_stream_t stream);
 int ha_qstep_f32ids(float *table, int64_t rows, int64_t width,
                     void *plan_cur, int64_t n_cur, const float *grads, float lr,
                     void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
@@ -470,43 +495,17 @@ int ha_qstep_u64ids(float *table, int64_t rows, int64_t width,
                     void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
                     void *plan_b1, int64_t n_b1, void *queue_build, int64_t queue_n_cap,
                     const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead, ha_stream_t stream);
-/* The two halves of ha_qstep_* as launches of their own (the same kernel with part of its roles), for callers that
- * run the preparation on a stream BESIDE the steps -- a plan or a queue keeps one workgroup busy for 15-20 us, about
- * twice the time the items of a step take, so inside the step's launch they are its tail:
- *   ha_qprep_*  sorts-by-hashing and finishes the plan of one batch (ahead_ids -> plan_ahead; n_ahead = 0: none) and /
- *               or builds the queue of one step from the finished plans of the batch that step applies (plan_a) and of
- *               the batch it looks up (plan_g) (n_a = n_g = 0: none);
- *   ha_qapply   the items of one step: queue_cur was built by ha_qprep_* from (plan_cur, plan_next).
- * ha_qprep_*(batch c+3; queue c+1 from plans c+1, c+2) followed by ha_qapply(step c) on one stream == ha_qstep_*(c).
- * The plan ha_qprep_* / ha_qstep_* leave holds the relations of an index plan (unique keys, counts, segment starts,
- * inverse, occurrence lists ascending inside every segment) with the unique keys in the order of its hash table's
- * slots, NOT in key order (ha_plan_build_* gives np.unique's order). */
-int ha_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
-                    void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
-                    ha_stream_t stream);
-int ha_qprep_u64ids(int64_t rows, int64_t width, const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead,
-                    void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
-                    ha_stream_t stream);
-int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
-              void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
-              ha_stream_t stream);
-/* development aids: the halves with time stamps (dbg as for ha_debug_qstep_timeline) */
-int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
-                          void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
-                          unsigned long long *dbg, ha_stream_t stream);
+/* a built queue's first words (device memory): {wave items, workgroup items, long, medium, small, copy items} */
+const uint32_t *ha_qstep_queue_header(const void *queue);
+/* development aids (tools/qstep_timeline.py): the items of a step with per-wave time stamps, dbg = device
+ * uint64[(workgroups) * 16 * 4], zeroed; one plan + one queue with the phase stamps of their workgroups, ph = device
+ * uint64[32], zeroed */
 int ha_debug_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
                     float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
                     int64_t queue_n_cap, unsigned long long *dbg, ha_stream_t stream);
-/* a built queue's first words (device memory): {wave items, workgroup items, long, medium, small, copy items} */
-const uint32_t *ha_qstep_queue_header(const void *queue);
-/* development aid (tools/qstep_timeline.py): ha_qstep_f32ids with per-wave time stamps,
- * dbg = device uint64[(number of workgroups) * 16 * 4], zeroed */
-int ha_debug_qstep_timeline(float *table, int64_t rows, int64_t width,
-                            void *plan_cur, int64_t n_cur, const float *grads, float lr,
-                            void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
-                            void *plan_b1, int64_t n_b1, void *queue_build, int64_t queue_n_cap,
-                            const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
-                            unsigned long long *dbg, ha_stream_t stream);
+int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, int64_t n_ahead, void *plan_ahead,
+                          void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
+                          unsigned long long *ph, ha_stream_t stream);
 
 /* ha_sgd_apply_finish that also warms the memory-side cache for the NEXT batch: waves that have no
  * medium / long-run work (more than half of them) end by touching the table row that position p of

@@ -73,7 +73,11 @@ def _within(got, exact, tol_rows, keys, what):
                 what, k, d.max(), bound.min())
 
 
-def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=None, check_plans=True, overlap=True):
+MODES = [(True, 8), (True, 2), (False, 1)]     # (preparation beside the steps, steps per block)
+MODE_IDS = ["side_stream_block8", "side_stream_block2", "one_stream"]
+
+
+def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=None, check_plans=True, mode=(True, 2)):
     """Drives the pipeline over the whole stream; every lookup and the final table against both oracles."""
     width = table0.shape[1]
     rows = table0.shape[0]
@@ -83,13 +87,13 @@ def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=Non
     if table is None:
         table = _dev(table0, dev)
     cap = max(max(b.size for b in batches), 1)
-    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=overlap)
+    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=mode[0], block=mode[1])
     L = pipe.LOOKAHEAD
     cast = (lambda b: _dev(b.astype(np.float32), dev)) if ids_dtype == np.float32 else \
         (lambda b: _dev(b.astype(np.int64), dev))
     d_ids = [cast(b) for b in batches]
     B = len(batches)
-    out = pipe.start(*[d_ids[i] if i < B else None for i in range(L)])
+    out = pipe.start(d_ids[:L])
     for k in range(B):
         torch.cuda.synchronize()
         ids = batches[k].astype(np.int64)
@@ -121,10 +125,10 @@ def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=Non
     return pipe
 
 
-@pytest.mark.parametrize("overlap", [True, False], ids=["side_streams", "one_stream"])
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
 @pytest.mark.parametrize("width", [4, 32, 64, 96, 128, 200, 512, 1024])
 @pytest.mark.parametrize("rows,n", [(40, 700), (5000, 6656), (300, 63), (7, 1)])
-def test_qstep_stream_small_tables(dev, width, rows, n, overlap):
+def test_qstep_stream_small_tables(dev, width, rows, n, mode):
     """Small tables: almost every row of batch k+1 is updated by batch k; every class of item (small, medium, long,
     workgroup, pure copies, keys with more than 64 / 1024 destinations)."""
     rng = np.random.default_rng(width * 131 + rows + n)
@@ -133,7 +137,7 @@ def test_qstep_stream_small_tables(dev, width, rows, n, overlap):
     batches = [np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1) if k % 2 else rng.integers(0, rows, size=n)
                for k in range(steps)]
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
-    _run_stream(dev, table0, batches, grads, 0.05, overlap=overlap)
+    _run_stream(dev, table0, batches, grads, 0.05, mode=mode)
 
 
 def test_qstep_all_below_16_occurrences_is_the_reference_bit_for_bit(dev):
@@ -175,8 +179,8 @@ def test_qstep_degenerate_batches(dev, kind):
     _run_stream(dev, table0, batches, grads, 0.02)
 
 
-@pytest.mark.parametrize("overlap", [True, False], ids=["side_streams", "one_stream"])
-def test_qstep_ragged_empty_and_out_of_range(dev, overlap):
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_qstep_ragged_empty_and_out_of_range(dev, mode):
     """Batches of different sizes, an EMPTY batch in the middle of the stream, ids beyond the table (zeros on lookup,
     ignored by the apply) and uint64 ids beyond 2^32."""
     rng = np.random.default_rng(23)
@@ -191,7 +195,7 @@ def test_qstep_ragged_empty_and_out_of_range(dev, overlap):
             b[4] = 0xFFFFFFFF
         batches.append(b)
     grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
-    _run_stream(dev, table0, batches, grads, 0.05, ids_dtype=np.int64, overlap=overlap)
+    _run_stream(dev, table0, batches, grads, 0.05, ids_dtype=np.int64, mode=mode)
 
 
 def test_qstep_float_ids_above_2_24_and_capacity_limit(dev):
@@ -210,7 +214,7 @@ def test_qstep_float_ids_above_2_24_and_capacity_limit(dev):
     pipe = ops.QueueStepPipeline(table, n, 0.01)
     L = pipe.LOOKAHEAD
     d = [_dev(b.astype(np.float32), dev) for b in batches]
-    out = pipe.start(*d[:L])
+    out = pipe.start(d[:L])
     for k in range(5):
         torch.cuda.synchronize()
         cid = np.searchsorted(np.sort(hot), batches[k])
@@ -249,44 +253,45 @@ def test_qstep_criteo_stream_and_queue_shape(dev):
     assert hdr["wave_items"] == want["long"] + want["medium"] + want["small"]
 
 
-@pytest.mark.parametrize("overlap", [True, False], ids=["side_streams", "one_stream"])
-def test_qstep_graph_replay_is_deterministic(dev, overlap):
-    """The launches replayed from a hipGraph (as bench.py does; with the preparation on side streams the graph has
-    three branches) give the same bits as eager launches."""
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_qstep_graph_replay_is_deterministic(dev, mode):
+    """The steps of a block replayed from a hipGraph (as bench.py does; the preparation of the blocks ahead is enqueued
+    between the replays) give the same bits as eager launches."""
     rows, width, bs = 300_000, 128, 128
     rng = np.random.default_rng(37)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
-    nb = 8
-    ids = [_dev(synth.criteo_batch(bs, step=k, rows=rows).reshape(-1).astype(np.float32), dev) for k in range(nb)]
-    n = ids[0].numel()
-    grads = [_dev(rng.standard_normal((n, width), dtype=np.float32), dev) for _ in range(nb)]
     results = []
-    for mode in ("eager", "graph"):
+    for how in ("eager", "graph"):
         table = _dev(table0, dev)
-        pipe = ops.QueueStepPipeline(table, n, 0.05, overlap=overlap)
-        L = pipe.LOOKAHEAD
+        pipe = ops.QueueStepPipeline(table, bs * 26, 0.05, overlap=mode[0], block=mode[1])
+        Bk, L, nb = pipe.block, pipe.LOOKAHEAD, pipe.ROTATION
+        ids = [_dev(synth.criteo_batch(bs, step=k, rows=rows).reshape(-1).astype(np.float32), dev) for k in range(nb)]
+        n = ids[0].numel()
+        g_rng = np.random.default_rng(41)
+        grads = [_dev(g_rng.standard_normal((n, width), dtype=np.float32), dev) for _ in range(nb)]
         outs = [torch.empty((n, width), dtype=torch.float32, device=dev) for _ in range(nb)]
         s = torch.cuda.Stream(device=dev)
-        n_of = lambda b: n if b >= 0 else 0
+        ids_of = lambda j: ids[j % nb] if j >= 0 else None
+        graphs = {}
         with torch.cuda.stream(s):
-            for c in range(-L, 0):
-                pipe.launch(c, n_of, None, outs[0], ids[(c + L) % nb], stream=s)
-
-            def step(k):
-                pipe.launch(k, n_of, grads[k % nb], outs[(k + 1) % nb], ids[(k + L) % nb], stream=s)
-            if mode == "eager":
-                for k in range(16):
-                    step(k)
-            else:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s):
-                    pipe.begin_capture()
-                    for k in range(8):
-                        step(k)
-                    pipe.end_capture(s)
-                g.replay()
-                g.replay()
+            for c in range(-L, 2 * nb):
+                if c % Bk == 0:
+                    pipe.prepare_block(c // Bk, ids_of, stream=s)
+                if c < -1:
+                    continue
+                if c == -1 or how == "eager":
+                    pipe.apply(c, grads[c % nb] if c >= 0 else None, outs[(c + 1) % nb], stream=s,
+                               n_cur=n if c >= 0 else 0, n_next=n)
+                elif c % Bk == 0:
+                    key = c % nb
+                    if key not in graphs:
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=s):
+                            for k in range(c, c + Bk):
+                                pipe.apply(k, grads[k % nb], outs[(k + 1) % nb], stream=s, n_cur=n, n_next=n)
+                        graphs[key] = g
+                    graphs[key].replay()
         torch.cuda.synchronize()
         results.append((table.cpu().numpy(), [o.cpu().numpy() for o in outs]))
     np.testing.assert_array_equal(results[0][0], results[1][0])

@@ -6,12 +6,8 @@ timeout 900 python -m pytest tests/test_gpu_qstep.py -q -x --timeout 300 > $O/qs
 tail -3 $O/qstep_tests.log
 HA_QSTEP_BALLOT=1 timeout 900 python -m pytest tests/test_gpu_qstep.py -q -x --timeout 300 -k "small_tables or ragged" > $O/qstep_tests_ballot.log 2>&1; echo "qstep tests (ballot form) rc=$?"
 tail -2 $O/qstep_tests_ballot.log
-timeout 600 python tools/qstep_timeline.py > $O/qstep_timeline.txt 2>&1; echo "timeline rc=$?"
-head -14 $O/qstep_timeline.txt
 B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier"
-SERIAL=1 timeout 600 python tools/qstep_timeline.py > $O/qstep_timeline_serial.txt 2>&1
-head -6 $O/qstep_timeline_serial.txt
-for e in queue "queue --queue-serial" handoff; do
+for e in queue "queue --queue-block 4" "queue --queue-block 16" handoff; do
   timeout 600 python bench.py $B --engine $e > "$O/bench_$e.json" 2> "$O/bench_$e.err"; echo "bench $e rc=$?"
   python - <<PY
 import json
