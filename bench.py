@@ -53,16 +53,21 @@ def parse_args():
                    help="rows of the pinned host table of the cold-tier line (x 64 floats = 8 GiB)")
     p.add_argument("--graph-steps", type=int, default=32,
                    help="steps captured per hipGraph (1 = eager launches)")
-    p.add_argument("--lookahead", type=int, default=1, choices=(1, 3),
-                   help="with --launches 1: 3 = ha_step_* (batch k+1 was sorted and finished by earlier launches: "
-                        "updated rows are forwarded from the applying waves, nothing waits inside the launch), "
-                        "1 = ha_sgd_push_pull_* (in-launch hand-off through pending tables; default: faster today)")
+    p.add_argument("--lookahead", type=int, default=None, choices=(1, 3),
+                   help="older spelling of --engine: 1 = handoff, 3 = forward")
+    p.add_argument("--pre-roll", type=int, default=2,
+                   help="how many of the W warm-up steps run right in front of the timed region (no synchronisation in "
+                        "between); 0 = all W before the synchronisation")
+    p.add_argument("--no-gate", action="store_true",
+                   help="do not hold the stream until the host has enqueued the timed region")
     p.add_argument("--engine", default=None, choices=("handoff", "forward", "queue"),
-                   help="one-launch step kernel: handoff = ha_sgd_push_pull_* (--lookahead 1), forward = ha_step_* "
-                        "(--lookahead 3), queue = ha_qstep_* (ids three batches ahead; every launch is driven by a work "
-                        "queue the previous launch built, plans sorted + finished by one workgroup in LDS; keys with 16+ "
-                        "occurrences applied as row - tree_sum(lr*g), within BASELINE.json's 1e-5)")
-    p.add_argument("--queue-block", type=int, default=8,
+                   help="the one-launch step: queue (default) = ha_qapply, every step driven by a work queue; plans and "
+                        "queues are prepared a block of steps at a time on a side stream inside the timed region; keys "
+                        "with 16+ occurrences in a batch applied as row - tree_sum(lr*g), within BASELINE.json's 1e-5 "
+                        "(everything else bit-exact).  handoff = ha_sgd_push_pull_* (ids one batch ahead, in-launch "
+                        "hand-off through pending tables, bit-exact throughout).  forward = ha_step_* (ids three batches "
+                        "ahead, rows forwarded from the applying waves, bit-exact throughout)")
+    p.add_argument("--queue-block", type=int, default=16,
                    help="--engine queue: steps per block (the plans / queues of a block are prepared by two launches on a "
                         "side stream beside the steps of the block before; ids are needed 3 blocks ahead)")
     p.add_argument("--queue-serial", action="store_true",
@@ -353,7 +358,7 @@ def main():
     G = max(1, args.graph_steps)
     one = args.launches == 1
     if args.engine is None:
-        args.engine = "forward" if args.lookahead == 3 else "handoff"
+        args.engine = {None: "queue", 1: "handoff", 3: "forward"}[args.lookahead]
     queue = one and args.engine == "queue"
     ahead2 = one and args.engine in ("forward", "queue")
     # graphs never straddle the wrap-around of the batch list; ha_step_* rotates four plans and four key tables,
@@ -449,7 +454,7 @@ def main():
 
     # Batch b always uses gradient / output buffer b % nbuf, so a captured graph depends on b only
     # (nb is even, so the plan / pending-table parity of step k is that of batch k % nb as well).
-    use_graph = G > 1
+    use_graph = G > 1 and args.graph_steps > 1      # --graph-steps 1: plain launches (the PMC passes)
     graphs = {}
 
     def chunks(k0, count):
@@ -489,21 +494,38 @@ def main():
                         step(j)
         return replays
 
+    # The W warm-up steps are split: W - P of them, a synchronisation, and the last P (`--pre-roll`, default 2) right in
+    # front of the timed region on the same stream.  The timed region is exactly K steps between two events, with a
+    # synchronisation before the sequence and after it.  What the split and the gate below remove is not work but idle
+    # time that a short run otherwise measures: (1) the first launch after an idle period takes 95-135 us and the second
+    # 19-31 us (profiles/r02/timelines/first_steps_after_idle.txt) -- they are now warm-up launches; (2) the device
+    # reaching the first event before the host has enqueued the K steps behind it -- the stream is held by a gate kernel
+    # (ha_stream_gate) that the host opens once pre-roll, events and timed steps are all queued.
     wu = args.warmup
+    pre = min(max(args.pre_roll, 0), wu)
     if use_graph:     # capture everything the warm-up and the timed region replay, before either runs
         torch.cuda.synchronize()
-        for k, ln in list(chunks(0, wu)) + list(chunks(wu, args.steps)):
+        for k, ln in list(chunks(0, wu - pre)) + list(chunks(wu - pre, pre)) + list(chunks(wu, args.steps)):
             graph_for(k, ln)
         torch.cuda.synchronize()
-    run(0, wu)
+    run(0, wu - pre)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
+    gate = None
+    if not args.no_gate:
+        from herald_amd import _lib as _hl
+        gate = torch.zeros(1, dtype=torch.int32).pin_memory()
+        with torch.cuda.stream(main_s):
+            _hl.check(_hl.load().ha_stream_gate(gate.data_ptr(), main_s.cuda_stream), "ha_stream_gate")
+    run(wu - pre, pre)
     t0 = time.perf_counter()
     e0.record(main_s)
     replays = run(wu, args.steps)
     e1.record(main_s)
     t_enq = time.perf_counter() - t0
+    if gate is not None:
+        gate[0] = 1             # everything is queued: open the gate
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
@@ -525,7 +547,7 @@ def main():
     if one:
         # the step IS one launch of ha::step_kernel: its average duration is the HIP-event time of the
         # timed region / K, measured on the launch stream
-        kname = "ha::qstep_kernel" if queue else "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
+        kname = "ha::qapply_kernel" if queue else "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
         traffic, traffic_src = pmc_traffic(kname)
         dom_bytes = fwd_b + bwd_b
         ach = dom_bytes / (dev_ms / args.steps * 1e-3) / 1e9
@@ -621,6 +643,9 @@ def main():
         "step_algorithmic_bytes": fwd_b + bwd_b,
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,
         "device_ms": dev_ms, "enqueue_ms": t_enq * 1e3, "wall_ms": wall * 1e3,
+        "timed_region": "exactly %d steps between two HIP events on the launch stream; %d of the %d warm-up steps run "
+                        "right in front of it%s" % (args.steps, pre, wu, ", behind a gate the host opens once everything "
+                                                    "is enqueued" if gate is not None else ""),
         "host_bound": bool(t_enq * 1e3 > dev_ms),
         "roofline": roofline, "kernels": kernels,
     }

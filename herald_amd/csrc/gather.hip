@@ -172,3 +172,25 @@ extern "C" int ha_gather_u32keys(const float *table, int64_t rows,
     return ha::gather_launch<uint32_t>(table, rows, width, keys, n, out,
                                        ha::as_stream(stream));
 }
+
+
+// A gate for a stream: the launch returns at once, the stream behind it does not move on until the HOST has written a
+// non-zero value to *flag (pinned, device-visible host memory) -- or ~2 s have passed.  Lets a caller enqueue a whole
+// sequence (events, graphs) behind the gate and release it when everything is queued, so that the device never sits
+// inside the sequence waiting for the host to enqueue its next piece (bench.py: the timed region of a short run).
+namespace ha {
+__global__ void stream_gate_kernel(const volatile uint32_t *flag) {
+    for (int i = 0; i < (1 << 21); ++i) {
+        if (__hip_atomic_load(const_cast<const uint32_t *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+            break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+}  // namespace ha
+
+extern "C" int ha_stream_gate(const uint32_t *flag, ha_stream_t stream) {
+    HA_REQUIRE(flag != nullptr, "ha_stream_gate: null flag");
+    hipLaunchKernelGGL(ha::stream_gate_kernel, dim3(1), dim3(1), 0, ha::as_stream(stream), flag);
+    HA_LAUNCH_CHECK();
+    return 0;
+}

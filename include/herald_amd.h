@@ -507,6 +507,12 @@ int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, i
                           void *plan_a, int64_t n_a, void *plan_g, int64_t n_g, void *queue_build, int64_t queue_n_cap,
                           unsigned long long *ph, ha_stream_t stream);
 
+/* A gate for a stream: the stream behind this call does not move on until the host has written a non-zero value to
+ * *flag (pinned, device-visible host memory), or about 2 s have passed.  For callers that enqueue a whole sequence
+ * behind the gate and release it once everything is queued (bench.py: the device must not wait for the host inside a
+ * short timed region). */
+int ha_stream_gate(const uint32_t *flag, ha_stream_t stream);
+
 /* ha_sgd_apply_finish that also warms the memory-side cache for the NEXT batch: waves that have no
  * medium / long-run work (more than half of them) end by touching the table row that position p of
  * next_ids will gather, so the ha_lookup_sort_* / ha_gather_* that follows reads it from the

@@ -40,9 +40,17 @@ def test_bench_n1_line_has_the_contract_fields(dev):
     assert d["cache_tier"]["value"] > 0
     ct = d["cold_tier"]
     assert ct["value"] > 0 and 0 <= ct["hot_tier_hit_rate"] <= 1 and ct["pcie_GBps"] >= 0
-    assert d["config"]["launches_per_step"] == 1 and d["handoff_timeouts"] == 0
-    assert "step_kernel" in rf["kernel"]
+    assert d["config"]["launches_per_step"] == 1 and d["config"]["engine"] == "queue"
+    assert "qapply_kernel" in rf["kernel"]
     assert abs(rf["avg_launch_us"] - d["device_ms"] / d["steps"] * 1e3) < 1e-6
+
+
+def test_bench_handoff_engine_line(dev):
+    """--engine handoff: the bit-exact one-launch step with the in-launch hand-off (round 2's default)."""
+    d = _run({}, "--rows", "1000000", "--steps", "128", "--warmup", "32", "--distinct-batches", "64", "--engine", "handoff",
+             "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier", "--no-laia")
+    assert d["config"]["engine"] == "handoff" and d["handoff_timeouts"] == 0
+    assert "step_kernel" in d["roofline"]["kernel"] and d["value"] > 0
 
 
 def test_bench_short_driver_run_replays_graphs(dev):
@@ -51,7 +59,7 @@ def test_bench_short_driver_run_replays_graphs(dev):
     d = _run({}, "--rows", "1000000", "--steps", "20", "--warmup", "5", "--distinct-batches", "64",
              "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier", "--no-laia")
     assert d["steps"] == 20 and d["warmup"] == 5
-    assert "hipGraph" in d["config"]["launch"] and d["config"]["launch"].startswith("1 ")
+    assert "hipGraph" in d["config"]["launch"]        # steps 5..24: the blocks [0, 16) and [16, 32) -> two replays
     assert d["config"]["grad_and_out_buffers"] >= 24
     assert abs(d["ms_per_step"] * 20 - max(d["device_ms"], d["enqueue_ms"])) < 1e-6
 

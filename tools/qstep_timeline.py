@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of ha_qstep_* (work-queue step; development aid): roles, item kinds, start / end."""
+"""Per-wave timeline of ha_qapply (the items of one work-queue step) and the phase stamps of a plan / a queue workgroup
+(development aid): roles, item kinds, start / end."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,43 +12,42 @@ rows, width, n = int(os.environ.get("ROWS", "33762577")), int(os.environ.get("WI
 table = torch.empty((rows, width), device=dev)
 for _s in range(0, rows, 1 << 20):
     table[_s:_s + (1 << 20)].normal_(0, 0.01)
-nb = 40
+BK = int(os.environ.get("BLOCK", "16"))
+pipe_probe_la = 3 * BK
+nsteps = 3 * BK + 2
 ids = []
-for b in range(nb + 3):
+for b in range(nsteps + pipe_probe_la + 2 * BK):
     f = np.minimum(synth.as_f32_ids(synth.criteo_batch(256, b, rows=rows)).reshape(-1), rows - 1)
     ids.append(torch.from_numpy(f).to(dev))
 grads = [torch.randn((n, width), device=dev) for _ in range(24)]
 outs = [torch.empty((n, width), device=dev) for _ in range(24)]
-OVERLAP = os.environ.get("SERIAL", "0") != "1"
-pipe = ops.QueueStepPipeline(table, n, 1e-6, overlap=OVERLAP)
+pipe = ops.QueueStepPipeline(table, n, 1e-6, block=BK)
 LA = pipe.LOOKAHEAD
 NBLK = 1024
 dbg = torch.zeros(NBLK * 16 * 4, dtype=torch.int64, device=dev)
-dbgp = torch.zeros(4 * 64 + 64, dtype=torch.int64, device=dev)
-n_of = lambda b: n if b >= 0 else 0
-for c in range(-LA, 0):
-    pipe.launch(c, n_of, None, outs[0], ids[c + LA])
-for k in range(nb - LA - 1):
-    if k == nb - LA - 2:
+dbgp = torch.zeros(64, dtype=torch.int64, device=dev)
+ids_of = lambda j: ids[j] if 0 <= j < len(ids) else None
+stamp = 2 * BK + BK // 2          # a step in the middle of a block (the side work of that block is long under way)
+for c in range(-LA, nsteps):
+    if c % BK == 0:
+        pipe.prepare_block(c // BK, ids_of, ph=dbgp if c == 2 * BK else None)
+    if c < -1:
+        continue
+    if c == stamp:
         torch.cuda.synchronize()
-        print("queue of the stamped launch:", pipe.queue_header(k))
-        pipe.launch(k, n_of, grads[k % 24], outs[(k + 1) % 24], ids[k + LA], dbg_prep=dbgp, dbg_apply=dbg)
-    else:
-        pipe.launch(k, n_of, grads[k % 24], outs[(k + 1) % 24], ids[k + LA])
+        print("queue of the stamped step:", pipe.queue_header(c))
+    pipe.apply(c, grads[c % 24] if c >= 0 else None, outs[(c + 1) % 24], dbg=dbg if c == stamp else None)
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy()
-rawp = dbgp.cpu().numpy()
-nblk = 48 + min(448, (2 * n) // 16 + 1)
-ph = rawp[3 * 64:3 * 64 + 32]
-t_apply0 = int(raw[raw > 0].min()) if (raw > 0).any() else 0
-for name, off in (("plan A (0 ids 1 claim 2 number 3 label 4 rank 5 scan 6 out 7)", 0),
-                  ("queue B0 = keys of the batch to apply (0 load 1 table 2 count 3 scans 4 emit 5)", 16),
-                  ("queue B1 = copies", 24)):
+ph = dbgp.cpu().numpy()
+nblk = 64 + min(448, (2 * n) // 16 + 1)
+for name, off in (("plan workgroup (0 ids 1 claim 2 number 3 label 4 rank 5 scan 6 out 7)", 0),
+                  ("queue workgroup 0 = keys of the batch to apply (0 load 1 table 2 count 3 scans 4 emit 5)", 16),
+                  ("queue workgroup 1 = copies", 24)):
     st = ph[off:off + 8]
     pts = [(i, int(v)) for i, v in enumerate(st) if v > 0]
     if pts:
-        print(name, "phases (us):", ", ".join("%d:%.2f" % (i, (v - pts[0][1]) * 0.01) for i, v in pts),
-              "| first stamp %.2f us after the step's first wave" % ((pts[0][1] - t_apply0) * 0.01))
+        print(name, "phases (us):", ", ".join("%d:%.2f" % (i, (v - pts[0][1]) * 0.01) for i, v in pts))
 d = raw[:nblk * 64].reshape(-1, 4)
 live = d[:, 0] > 0
 base = d[live, 0].min()
@@ -57,8 +57,8 @@ role = d[:, 2] & 0xFF
 kind = d[:, 3].astype(np.int64)
 kind = np.where(kind > 100, -1, kind)      # 0xFFFFFFFF = the wave had no item
 print("span %.2f us, stamped waves %d" % (t1[live].max(), live.sum()))
-groups = [("coop G", (role == 0) & (kind == 4)), ("coop idle", (role == 0) & (kind < 0)), ("plan A", role == 1),
-          ("queue B", role == 2), ("long L", (role == 3) & (kind == 2)), ("medium M", (role == 3) & (kind == 1)),
+groups = [("coop G", (role == 0) & (kind == 4)), ("coop idle", (role == 0) & (kind < 0)),
+          ("long L", (role == 3) & (kind == 2)), ("medium M", (role == 3) & (kind == 1)),
           ("small S", (role == 3) & (kind == 0)), ("zero Z", (role == 3) & (kind == 3)),
           ("worker idle", (role == 3) & (kind < 0))]
 for name, sel in groups:
