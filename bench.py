@@ -58,6 +58,8 @@ def parse_args():
     p.add_argument("--pre-roll", type=int, default=2,
                    help="how many of the W warm-up steps run right in front of the timed region (no synchronisation in "
                         "between); 0 = all W before the synchronisation")
+    p.add_argument("--clock-warm", type=int, default=2,
+                   help="untimed 512 MiB device copies enqueued right before the pre-roll (0 = none)")
     p.add_argument("--no-gate", action="store_true",
                    help="do not hold the stream until the host has enqueued the timed region")
     p.add_argument("--engine", default=None, choices=("handoff", "forward", "queue"),
@@ -512,12 +514,20 @@ def main():
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
+    warm = [torch.zeros(1 << 27, dtype=torch.float32, device=dev) for _ in range(2)] if args.clock_warm > 0 else None
+    torch.cuda.synchronize()
     gate = None
     if not args.no_gate:
         from herald_amd import _lib as _hl
         gate = torch.zeros(1, dtype=torch.int32).pin_memory()
         with torch.cuda.stream(main_s):
             _hl.check(_hl.load().ha_stream_gate(gate.data_ptr(), main_s.cuda_stream), "ha_stream_gate")
+    if args.clock_warm > 0:
+        # untimed, behind the gate: device-to-device copies that keep the memory system busy for ~170 us each, so that
+        # the pre-roll and the timed steps do not start on clocks that an idle device has dropped
+        with torch.cuda.stream(main_s):
+            for _ in range(args.clock_warm):
+                warm[0].copy_(warm[1])
     run(wu - pre, pre)
     t0 = time.perf_counter()
     e0.record(main_s)

@@ -767,6 +767,41 @@ __device__ __forceinline__ float4v shfl_xor4(float4v v, int mask) {
     return r;
 }
 
+// Cache policy of the three heavy streams (A/B knobs of tools/ab_variants.sh; the defaults are what measured best)
+#ifndef QV_ROW_NT
+#define QV_ROW_NT 1
+#endif
+#ifndef QV_OUT_NT
+#define QV_OUT_NT 1
+#endif
+#ifndef QV_GRAD_NT
+#define QV_GRAD_NT 0
+#endif
+template <typename V>
+__device__ __forceinline__ void q_st_row(float *p, V v) {
+#if QV_ROW_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+#else
+    *reinterpret_cast<V *>(p) = v;
+#endif
+}
+template <typename V>
+__device__ __forceinline__ void q_st_out(float *p, V v) {
+#if QV_OUT_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+#else
+    *reinterpret_cast<V *>(p) = v;
+#endif
+}
+template <typename V>
+__device__ __forceinline__ V q_ld_grad(const float *p) {
+#if QV_GRAD_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+#else
+    return *reinterpret_cast<const V *>(p);
+#endif
+}
+
 struct QItem {
     int kind, col0, cols;
     uint32_t key, c, st, m, fs, o01, o23;
@@ -810,8 +845,8 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
         if (static_cast<uint32_t>(t) < it.c) {
             const uint32_t o = t == 0 ? (it.o01 & 0xFFFFu) : t == 1 ? (it.o01 >> 16) : (it.o23 & 0xFFFFu);
             const float *src = a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width);
-            g0[t] = ld4(src + la);
-            g1[t] = ld4(src + lb);
+            g0[t] = q_ld_grad<float4v>(src + la);
+            g1[t] = q_ld_grad<float4v>(src + lb);
         }
     }
 #pragma unroll
@@ -823,9 +858,9 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
     }
     if (it.c > 0) {
         if (a0)
-            st4_nt(row + ca, r0);
+            q_st_row(row + ca, r0);
         if (a1)
-            st4_nt(row + cb, r1);
+            q_st_row(row + cb, r1);
     }
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
@@ -835,9 +870,9 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
             float *o = a.out + static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(dv, j))) *
                                    static_cast<uint64_t>(width);
             if (a0)
-                st4_nt(o + ca, r0);
+                q_st_out(o + ca, r0);
             if (a1)
-                st4_nt(o + cb, r1);
+                q_st_out(o + cb, r1);
         }
     }
 }
@@ -864,7 +899,7 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
 #pragma unroll
     for (int t = 0; t < kQMediumC; ++t) {
         const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(pidx, t));
-        g[t] = *reinterpret_cast<const float2v_ *>(gbase + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + lc);
+        g[t] = q_ld_grad<float2v_>(gbase + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + lc);
     }
 #pragma unroll
     for (int t = 0; t < kQMediumC; ++t) {
@@ -875,7 +910,7 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
         r[1] = on ? x1 : r[1];
     }
     if (it.c > 0 && act)
-        __builtin_nontemporal_store(r, reinterpret_cast<float2v_ *>(row + col));
+        q_st_row(row + col, r);
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
             dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
@@ -884,7 +919,7 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
             float *o = a.out + static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(dv, j))) *
                                    static_cast<uint64_t>(width);
             if (act)
-                __builtin_nontemporal_store(r, reinterpret_cast<float2v_ *>(o + col));
+                q_st_out(o + col, r);
         }
     }
 }
@@ -907,7 +942,7 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     for (int t = 0; t < 8; ++t) {
         const uint32_t occ = static_cast<uint32_t>(8 * t + r);
         const uint32_t o = static_cast<uint32_t>(__shfl(pidx, static_cast<int>(min(occ, it.c - 1u)), 64));
-        g[t] = ld4(a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + col);   // branch-free (clamped)
+        g[t] = q_ld_grad<float4v>(a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + col);   // branch-free (clamped)
     }
     float4v p{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -921,7 +956,7 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     p = add4(p, shfl_xor4(p, 32));
     const float4v nv = sub4(cur, p);
     if (r == 0 && act)
-        st4_nt(row + col, nv);
+        q_st_row(row + col, nv);
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
             dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
@@ -929,7 +964,7 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
         for (uint32_t j = 0; j < cnt; j += 8) {
             const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(min(j + r, cnt - 1u)), 64));
             if (j + r < cnt && act)
-                st4_nt(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
         }
     }
 }
@@ -959,7 +994,7 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const uint32_t o = static_cast<uint32_t>(__shfl(pidx, 4 * t + r, 64));
-            g[t] = ld4(a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + col);   // branch-free (clamped)
+            g[t] = q_ld_grad<float4v>(a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + col);   // branch-free (clamped)
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -983,7 +1018,7 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
     total = add4(total, shfl_xor4(total, 32));
     const float4v nv = sub4(cur, total);
     if (w == 0 && r == 0 && act)
-        st4_nt(row + col, nv);
+        q_st_row(row + col, nv);
     for (uint32_t k0 = 0; k0 * 64u < it.m; k0 += 16) {
         if (k0 > 0)
             dv = a.perm_g[it.fs + min(64u * (k0 + static_cast<uint32_t>(lane >> 2)) + static_cast<uint32_t>(4 * w + (lane & 3)),
@@ -993,7 +1028,7 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
             const uint32_t j = 64u * (k0 + k) + static_cast<uint32_t>(4 * w + r);
             const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(4 * k) + r, 64));
             if (j < it.m && act)
-                st4_nt(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
         }
     }
     __syncthreads();   // s_part is reused by the next item of this workgroup
