@@ -85,12 +85,17 @@ extern "C" int ha_device_count(void) {
     return n;
 }
 
+namespace ha {
+void host_map_release();
+}
+
 extern "C" int ha_scratch_release(void) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     for (auto &kv : g_scratch)
         if (kv.second.ptr)
             (void)hipFree(kv.second.ptr);
     g_scratch.clear();
+    host_map_release();
     return 0;
 }
 
@@ -243,23 +248,89 @@ extern "C" int SGDOptimizerSparseUpdate(DLArrayHandle param,
 // ---- the reference's CPU operator names (src/common/c_runtime_api.h:811-818) -------------------------
 // python/hetu/_base.py:8-11,72 feature-probes these two symbols with hasattr and, when present, routes
 // EmbeddingLookUp.compute / SGDOptimizer.update of host-context nodes to them (EmbeddingLookUp.py:16-28,
-// optimizer.py:204-214).  This library is the GPU engine: arrays whose context is the GPU are served by
-// the HIP kernels (on the null stream, complete on return, as a host operator is); host arrays are
-// refused with an error -- there is no CPU fallback in the product (the reference's own dnnl_ops remain
-// the CPU implementation).
-static int same_device(const DLArray *a, const DLArray *b, const DLArray *c, const char *name) {
-    HA_REQUIRE(a && b && c && a->data && b->data && c->data, "%s: null array", name);
-    HA_REQUIRE(a->ctx.device_type == kGPU && b->ctx.device_type == kGPU && c->ctx.device_type == kGPU,
-               "%s: host arrays are not served by herald_amd (GPU engine, no CPU fallback); "
-               "device_type = %d/%d/%d", name, (int)a->ctx.device_type, (int)b->ctx.device_type,
-               (int)c->ctx.device_type);
+// optimizer.py:204-214).  This library is the GPU engine and has no CPU arithmetic: arrays whose context is
+// the GPU are used where they lie; HOST arrays are made visible to the device for the call --
+//   * below 64 MiB (ids, gradients, looked-up rows): a device copy, H2D before the kernel, D2H behind it;
+//   * from 64 MiB (tables): the host range is page-locked and mapped (hipHostRegister, kept registered until
+//     ha_scratch_release: callers pass the same parameter array every step), and the kernels read / write only
+//     the rows the ids name across PCIe -- a 69 GB table is never copied;
+// the kernels are the ones the GPU-context call runs (null stream, complete on return, as a host operator is).
+namespace ha {
+
+constexpr size_t kHostMapFrom = size_t(64) << 20;
+static std::mutex g_hostmap_mu;
+static std::unordered_map<void *, size_t> g_hostmap;   // registered host ranges (base -> bytes)
+
+static int host_map(void *host, size_t bytes, void **dev) {
+    std::lock_guard<std::mutex> lk(g_hostmap_mu);
+    auto it = g_hostmap.find(host);
+    if (it != g_hostmap.end() && it->second < bytes) {   // the same base with a larger extent: register anew
+        HA_CHECK_HIP(hipHostUnregister(host));
+        g_hostmap.erase(it);
+        it = g_hostmap.end();
+    }
+    if (it == g_hostmap.end()) {
+        HA_CHECK_HIP(hipHostRegister(host, bytes, hipHostRegisterMapped));
+        g_hostmap[host] = bytes;
+    }
+    HA_CHECK_HIP(hipHostGetDevicePointer(dev, host, 0));
     return 0;
 }
 
+void host_map_release() {
+    std::lock_guard<std::mutex> lk(g_hostmap_mu);
+    for (auto &kv : g_hostmap)
+        (void)hipHostUnregister(kv.first);
+    g_hostmap.clear();
+}
+
+// One array of a cpu_* call as the device sees it.
+struct DeviceView {
+    DLArray arr;            // the caller's array with `data` replaced by a device-visible address, ctx = GPU
+    void *copy = nullptr;   // device copy (small host arrays)
+    void *host = nullptr;
+    size_t bytes = 0;
+    ~DeviceView() {
+        if (copy)
+            (void)hipFree(copy);
+    }
+    int open(const DLArray *a, bool read, const char *name) {
+        HA_REQUIRE(a && a->data, "%s: null array", name);
+        arr = *a;
+        if (a->ctx.device_type == kGPU)
+            return 0;
+        HA_REQUIRE(a->ctx.device_type == kCPU, "%s: unknown device_type %d", name, (int)a->ctx.device_type);
+        bytes = static_cast<size_t>(dl_numel(a)) * 4;
+        host = a->data;
+        int dev = 0;
+        HA_CHECK_HIP(hipGetDevice(&dev));
+        arr.ctx.device_type = kGPU;
+        arr.ctx.device_id = dev;
+        if (bytes >= kHostMapFrom)
+            return host_map(host, bytes, &arr.data);
+        HA_CHECK_HIP(hipMalloc(&copy, bytes ? bytes : 4));
+        arr.data = copy;
+        if (read && bytes)
+            HA_CHECK_HIP(hipMemcpyAsync(copy, host, bytes, hipMemcpyHostToDevice, nullptr));
+        return 0;
+    }
+    int close(bool written) {   // behind the kernel, on the null stream
+        if (copy && written && bytes)
+            HA_CHECK_HIP(hipMemcpyAsync(host, copy, bytes, hipMemcpyDeviceToHost, nullptr));
+        return 0;
+    }
+};
+
+}  // namespace ha
+
 extern "C" int cpu_EmbeddingLookup(const DLArrayHandle in_mat, const DLArrayHandle ids, DLArrayHandle out_mat) {
-    if (same_device(in_mat, ids, out_mat, "cpu_EmbeddingLookup"))
+    DeviceView t, i, o;
+    if (t.open(in_mat, true, "cpu_EmbeddingLookup(in_mat)") || i.open(ids, true, "cpu_EmbeddingLookup(ids)") ||
+        o.open(out_mat, false, "cpu_EmbeddingLookup(out_mat)"))
         return -1;
-    if (DLGpuEmbeddingLookUp(in_mat, ids, out_mat, nullptr))
+    if (DLGpuEmbeddingLookUp(&t.arr, &i.arr, &o.arr, nullptr))
+        return -1;
+    if (o.close(true))
         return -1;
     HA_CHECK_HIP(hipStreamSynchronize(nullptr));
     return 0;
@@ -267,9 +338,14 @@ extern "C" int cpu_EmbeddingLookup(const DLArrayHandle in_mat, const DLArrayHand
 
 extern "C" int cpu_SGDOptimizerSparseUpdate(DLArrayHandle param, const DLArrayHandle grad_indices,
                                             const DLArrayHandle grad_values, float lr) {
-    if (same_device(param, grad_indices, grad_values, "cpu_SGDOptimizerSparseUpdate"))
+    DeviceView p, i, g;
+    if (p.open(param, true, "cpu_SGDOptimizerSparseUpdate(param)") ||
+        i.open(grad_indices, true, "cpu_SGDOptimizerSparseUpdate(grad_indices)") ||
+        g.open(grad_values, true, "cpu_SGDOptimizerSparseUpdate(grad_values)"))
         return -1;
-    if (SGDOptimizerSparseUpdate(param, grad_indices, grad_values, lr, nullptr))
+    if (SGDOptimizerSparseUpdate(&p.arr, &i.arr, &g.arr, lr, nullptr))
+        return -1;
+    if (p.close(true))
         return -1;
     HA_CHECK_HIP(hipStreamSynchronize(nullptr));
     return 0;

@@ -267,6 +267,167 @@ extern "C" int ha_shard_route_u64ids(const uint64_t *ids, int64_t n, void *plan_
                                  ha_plan_build_u64ids_lim);
 }
 
+// ---- fixed-size frames: the sharded step without host-known counts (graph-replayable) ---------------------------
+// The sized exchanges above need the per-owner counts on the host before the rows can move.  Here every owner gets a
+// FIXED key frame [count, overflow flag, rcap shard-local keys padded with kNoKey] and a fixed row frame of rcap rows,
+// so pull and push are equal-split all-to-alls whose sizes the host knows without a read-back, and every kernel runs
+// over W * rcap slots (padding slots: key beyond any table -> zero row on the pull side, skipped on the push side).
+// A batch that names more than rcap unique keys of one owner sets the flag; every frame of the sender carries it, so
+// after the key exchange every rank knows whether ANY rank overflowed (herald_amd/sharded.py then takes the sized
+// exchange for that batch).  Routing semantics as above (PSAgent.h:185-237, partitioner.h:46-57).
+namespace ha {
+
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
+// send[g] = [count_g, flag, keys ...]; rowmap[u] = frame slot (g * rcap + j) of unique key u, -1 beyond rcap;
+// posmap[i] = frame slot of the unique key of position i (what the expand gathers from), the zero row W * rcap
+// beyond rcap
+__global__ __launch_bounds__(256) void shard_pack_frames_kernel(
+    const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq, const int32_t *__restrict__ inverse, int n,
+    ShardStarts st, int nshard, int rcap, int32_t *__restrict__ send, int32_t *__restrict__ rowmap,
+    int32_t *__restrict__ posmap) {
+    __shared__ int s_off[kMaxShards + 1];
+    __shared__ int s_flag;
+    const int U = n > 0 ? static_cast<int>(hdr->n_unique) : 0;
+    if (threadIdx.x <= static_cast<unsigned>(nshard)) {
+        const uint32_t target = st.start[threadIdx.x];
+        int lo = 0, hi = U;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (uniq[mid] < target)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        s_off[threadIdx.x] = static_cast<int>(threadIdx.x) == nshard ? U : lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int f = 0;
+        for (int g = 0; g < nshard; ++g)
+            f |= (s_off[g + 1] - s_off[g]) > rcap;
+        s_flag = f;
+    }
+    __syncthreads();
+    const size_t fw = 2 + static_cast<size_t>(rcap);
+    if (blockIdx.x == 0 && threadIdx.x < static_cast<unsigned>(nshard)) {
+        send[threadIdx.x * fw] = s_off[threadIdx.x + 1] - s_off[threadIdx.x];
+        send[threadIdx.x * fw + 1] = s_flag;
+    }
+    const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    const int slots = nshard * rcap;
+    for (int p = tid; p < slots; p += stride) {
+        const int g = p / rcap, j = p - g * rcap;
+        const bool live = j < s_off[g + 1] - s_off[g];
+        send[g * fw + 2 + j] = static_cast<int32_t>(live ? uniq[s_off[g] + j] - st.start[g] : kNoKey);
+    }
+    for (int u = tid; u < U; u += stride) {
+        int g = 0;
+        while (g + 1 < nshard && u >= s_off[g + 1])
+            ++g;
+        const int j = u - s_off[g];
+        rowmap[u] = j < rcap ? g * rcap + j : -1;
+    }
+    for (int i = tid; i < n; i += stride) {
+        const int u = inverse[i];
+        int g = 0;
+        while (g + 1 < nshard && u >= s_off[g + 1])
+            ++g;
+        const int j = u - s_off[g];
+        posmap[i] = j < rcap ? g * rcap + j : slots;
+    }
+}
+
+// recv[g] = [count_g, flag_g, keys ...] from rank g -> keys_fixed[g * rcap + j] (kNoKey beyond the count) and
+// state = {any rank overflowed, keys received}
+__global__ __launch_bounds__(256) void shard_unpack_frames_kernel(const int32_t *__restrict__ recv, int nshard, int rcap,
+                                                                  uint32_t *__restrict__ keys_fixed,
+                                                                  int32_t *__restrict__ state) {
+    const size_t fw = 2 + static_cast<size_t>(rcap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int f = 0, total = 0;
+        for (int g = 0; g < nshard; ++g) {
+            const int c = recv[g * fw];
+            f |= (recv[g * fw + 1] != 0) | (c > rcap) | (c < 0);
+            total += c < 0 ? 0 : (c > rcap ? rcap : c);
+        }
+        state[0] = f;
+        state[1] = total;
+    }
+    const int slots = nshard * rcap, stride = gridDim.x * 256;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < slots; p += stride) {
+        const int g = p / rcap, j = p - g * rcap;
+        const int c = recv[g * fw];
+        keys_fixed[p] = j < c ? static_cast<uint32_t>(recv[g * fw + 2 + j]) : kNoKey;
+    }
+}
+
+}  // namespace ha
+
+static int shard_starts_of(const int64_t *starts_host, int nshard, ShardStarts *st, const char *who) {
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards, "%s: nshard must be in [1,%d]", who, kMaxShards);
+    for (int g = 0; g <= nshard; ++g) {
+        HA_REQUIRE(starts_host[g] >= 0 && starts_host[g] <= 0xFFFFFFFEll, "%s: start out of range", who);
+        st->start[g] = static_cast<uint32_t>(starts_host[g]);
+    }
+    return 0;
+}
+
+extern "C" int ha_shard_frames_pack(const void *plan_ws, int64_t n, const int64_t *starts_host, int nshard, int64_t rcap,
+                                    int32_t *send, int32_t *rowmap, int32_t *posmap, ha_stream_t stream) {
+    HA_REQUIRE(plan_ws && starts_host && send && rowmap && posmap, "shard_frames_pack: null pointer");
+    HA_REQUIRE(n >= 0 && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30), "shard_frames_pack: bad sizes");
+    ShardStarts st;
+    if (shard_starts_of(starts_host, nshard, &st, "shard_frames_pack"))
+        return -1;
+    PlanPtrs p = plan_layout(const_cast<void *>(plan_ws), n > 0 ? n : 1);
+    const int64_t work = n > nshard * rcap ? n : nshard * rcap;
+    int blocks = static_cast<int>((work + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(shard_pack_frames_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p.hdr, p.uniq, p.inverse,
+                       static_cast<int>(n), st, nshard, static_cast<int>(rcap), send, rowmap, posmap);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename IdT>
+static int shard_frames_route(const IdT *ids, int64_t n, void *plan_ws, const int64_t *starts_host, int nshard,
+                              int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap, ha_stream_t stream,
+                              int (*build)(const IdT *, int64_t, void *, uint64_t, ha_stream_t)) {
+    HA_REQUIRE(plan_ws && starts_host, "shard_frames_route: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards, "shard_frames_route: nshard must be in [1,%d]", kMaxShards);
+    if (n > 0 && build(ids, n, plan_ws, static_cast<uint64_t>(starts_host[nshard]), stream))   // keys < total rows
+        return -1;
+    return ha_shard_frames_pack(plan_ws, n, starts_host, nshard, rcap, send, rowmap, posmap, stream);
+}
+
+extern "C" int ha_shard_frames_route_f32ids(const float *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
+                                            int nshard, int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap,
+                                            ha_stream_t stream) {
+    return shard_frames_route<float>(ids, n, plan_ws, starts_host, nshard, rcap, send, rowmap, posmap, stream,
+                                     ha_plan_build_f32ids_lim);
+}
+
+extern "C" int ha_shard_frames_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
+                                            int nshard, int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap,
+                                            ha_stream_t stream) {
+    return shard_frames_route<uint64_t>(ids, n, plan_ws, starts_host, nshard, rcap, send, rowmap, posmap, stream,
+                                        ha_plan_build_u64ids_lim);
+}
+
+extern "C" int ha_shard_frames_unpack(const int32_t *recv, int nshard, int64_t rcap, uint32_t *keys_fixed, int32_t *state,
+                                      ha_stream_t stream) {
+    HA_REQUIRE(recv && keys_fixed && state, "shard_frames_unpack: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30),
+               "shard_frames_unpack: bad sizes");
+    long long want = (static_cast<long long>(nshard) * rcap + 255) / 256;
+    const int blocks = want < 1 ? 1 : (want > 256 ? 256 : static_cast<int>(want));
+    hipLaunchKernelGGL(shard_unpack_frames_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), recv, nshard,
+                       static_cast<int>(rcap), keys_fixed, state);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
 // Owner side of a sparse push in one call: index plan of the received shard-local keys (the W sorted
 // lists concatenated in rank order) + `row = (row + v_a) + v_b ...` in list order -- the server `+=`
 // of PSHandler::serve(SparsePush), PSFHandle.h:130-164, made deterministic (rank order).

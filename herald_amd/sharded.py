@@ -203,6 +203,102 @@ class HipEngine:
                                                 self._stream()), "ha_shard_serve_push")
 
 
+    # -- fixed frames (FramedStep): no launch or exchange size depends on a device-side count ---------------------
+    def frames_buffers(self, w, rcap, n_cap, width):
+        """Persistent buffers of one routing slot of a FramedStep."""
+        fb = FrameBuffers()
+        fb.w, fb.rcap, fb.n_cap = w, rcap, n_cap
+        fb.plan = self.ops.IndexPlan(max(n_cap, 1), self.device)
+        fb.ksend = torch.empty((w, 2 + rcap), dtype=torch.int32, device=self.device)
+        fb.krecv = torch.empty((w, 2 + rcap), dtype=torch.int32, device=self.device)
+        fb.keys_fixed = torch.empty(w * rcap, dtype=torch.int32, device=self.device)
+        fb.rowmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
+        fb.posmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
+        fb.state = torch.zeros(2, dtype=torch.int32, device=self.device)
+        fb.state_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        fb.ids = {}           # dtype -> static copy of the batch's ids (the graphs read this address)
+        fb.n, fb.cur, fb.shape, fb.routed = 0, None, (0,), False
+        return fb
+
+    def frames_ids(self, fb, ids):
+        """Copy a batch's ids to the slot's static buffer (the captured routing reads it from there)."""
+        t = fb.ids.get(ids.dtype)
+        if t is None:
+            t = fb.ids[ids.dtype] = torch.zeros(max(fb.n_cap, 1), dtype=ids.dtype, device=self.device)
+        fb.n = ids.numel()
+        fb.cur = t[:fb.n]
+        fb.cur.copy_(ids.reshape(-1), non_blocking=True)
+        return fb.cur
+
+    def frames_route(self, fb, starts):
+        ids = fb.cur
+        fn = self.lib.ha_shard_frames_route_f32ids if ids.dtype == torch.float32 else self.lib.ha_shard_frames_route_u64ids
+        st = (ctypes.c_int64 * len(starts))(*starts)
+        self.check(fn(ids.data_ptr(), fb.n, fb.plan.ws.data_ptr(), st, fb.w, fb.rcap, fb.ksend.data_ptr(),
+                      fb.rowmap.data_ptr(), fb.posmap.data_ptr(), self._stream()), "ha_shard_frames_route")
+        fb.plan.n = fb.n
+        fb.plan._view = None
+
+    def frames_unpack(self, fb, krecv):
+        self.check(self.lib.ha_shard_frames_unpack(krecv.data_ptr(), fb.w, fb.rcap, fb.keys_fixed.data_ptr(),
+                                                   fb.state.data_ptr(), self._stream()), "ha_shard_frames_unpack")
+        fb.state_host.copy_(fb.state, non_blocking=True)
+
+    def frames_overflowed(self, fb):
+        return bool(fb.state_host[0].item())
+
+    def frames_serve_pull(self, table, fb, rows_send):
+        """rows_send[g * rcap + j, :] = table[key j of rank g] (zero rows in the unused slots)."""
+        m = fb.w * fb.rcap
+        self.check(self.lib.ha_gather_u32keys(table.data_ptr(), table.shape[0], table.shape[1], fb.keys_fixed.data_ptr(),
+                                              m, rows_send.data_ptr(), self._stream()), "ha_gather_u32keys")
+
+    def frames_expand(self, rows_recv, fb, out):
+        """out[i, :] = the pulled row of position i (a slot index beyond the frames reads as a zero row)."""
+        if fb.n:
+            self.check(self.lib.ha_gather_u32keys(rows_recv.data_ptr(), rows_recv.shape[0], rows_recv.shape[1],
+                                                  fb.posmap.data_ptr(), fb.n, out.data_ptr(), self._stream()),
+                       "ha_gather_u32keys")
+
+    def frames_reduce(self, fb, values, scale, rows_send, zero_flags):
+        """rows_send[slot of unique key u, :] = 0 + scale * v_a + scale * v_b ... over the positions of u in order
+        (PSAgent::vecPushSparse's worker-side reduce, PSAgent.h:124-183), straight into the push frames."""
+        if fb.n:
+            self.check(self.lib.ha_apply_mapped(rows_send.data_ptr(), fb.w * fb.rcap, rows_send.shape[1],
+                                                fb.plan.ws.data_ptr(), fb.n, values.data_ptr(), ctypes.c_float(-scale),
+                                                fb.rowmap.data_ptr(), None, zero_flags.data_ptr(), self._stream()),
+                       "ha_apply_mapped")
+
+    def frames_serve_push(self, table, fb, rows_recv):
+        """Owner side: the w received lists applied in rank order; unused slots carry a key beyond any table."""
+        m = fb.w * fb.rcap
+        p = self._owner_plan
+        if p is None or p.capacity < m:
+            p = self._owner_plan = self.ops.IndexPlan(m + 16, self.device)
+        self.check(self.lib.ha_shard_serve_push(table.data_ptr(), table.shape[0], table.shape[1],
+                                                fb.keys_fixed.data_ptr(), m, rows_recv.data_ptr(), p.ws.data_ptr(),
+                                                self._stream()), "ha_shard_serve_push")
+
+    def graph_capture(self, fn):
+        """Capture `fn()` (enqueues work on the current stream) into a hipGraph; -> object with .replay()."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):          # torch's capture stream becomes current: _stream() follows it
+            fn()
+        return g
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def empty_rows(self, rows, width):
+        return torch.empty((rows, width), dtype=torch.float32, device=self.device)
+
+
+class FrameBuffers:
+    """Persistent buffers of one routing slot of a FramedStep (see HipEngine.frames_buffers)."""
+    __slots__ = ("w", "rcap", "n_cap", "plan", "ksend", "krecv", "keys_fixed", "rowmap", "posmap", "state",
+                 "state_host", "ids", "cur", "n", "shape", "routed")
+
+
 class RouteBuffers:
     """Persistent device / pinned-host buffers of one routing workspace (see HipEngine.route_issue)."""
     __slots__ = ("plan", "cap", "send", "recv", "meta_all", "meta", "recv_cnt", "host", "keys_recv", "starts",
@@ -433,3 +529,191 @@ class ShardedEmbedding:
                 self.table[s:e].copy_(stage[:e - s])
                 if pin:
                     torch.cuda.current_stream().synchronize()   # the staging buffer is reused
+
+
+class FramedStep:
+    """The sharded step with FIXED frames: every launch and every exchange has a size the host knows without reading
+    anything back, so a step replays from hipGraphs (pull and push are one graph each; the routing of the batch two
+    steps ahead rides in the pull graph).  Same semantics as ShardedEmbedding.pull / push (PSAgent::vecPullSparse /
+    vecPushSparse, PSAgent.h:124-237; rank-ordered server `+=`, PSFHandle.h:130-164).
+
+        fs = FramedStep(emb, max_ids)                  # row_cap: rows per owner and exchange (default max_ids / W)
+        fs.start(ids0, ids1)                           # routes the first two batches
+        rows0 = fs.pull(ids2)                          # rows of batch 0; batch 2 is routed meanwhile
+        fs.push(grads0, lr)                            # batch 0 applied on its owners (rank order)
+        rows1 = fs.pull(ids3) ...                      # ahead ids = None once the stream of batches ends
+
+    Per owner g a batch may name at most row_cap unique keys.  A batch that names more on ANY rank is detected by the
+    routing itself (the flag travels in the key frames, so all ranks agree) two steps before it is pulled; that batch
+    alone takes ShardedEmbedding's sized exchange (one host read-back), the others keep replaying.  The host reads one
+    pinned word per step, written two steps earlier -- it never waits for the step in flight.
+
+    graphs=False enqueues the same kernels and exchanges eagerly (exchanges that cannot be captured: the host-staged
+    all-to-all of the one-GPU multi-rank tests, the CPU engine of the gloo tests)."""
+
+    NSLOT = 3
+
+    def __init__(self, emb, max_ids, row_cap=None, graphs=True):
+        self.emb, self.eng = emb, emb.engine
+        w = emb.world
+        self.max_ids = int(max_ids)
+        self.rcap = int(row_cap) if row_cap is not None else max(-(-self.max_ids // w), 1)
+        self.graphs = bool(graphs)
+        self.slots = [self.eng.frames_buffers(w, self.rcap, self.max_ids, emb.width) for _ in range(self.NSLOT)]
+        m = w * self.rcap
+        self.pull_send = self.eng.empty_rows(m, emb.width)
+        self.push_send = self.eng.empty_rows(m, emb.width)
+        self.pull_recv = self.eng.empty_rows(m, emb.width)
+        self.push_recv = self.eng.empty_rows(m, emb.width)
+        self.zero_flags = self.eng.zeros((m,), torch.uint8)
+        self._graphs = {}
+        self._ev = {}                # batch index -> event behind the enqueue of its routing
+        self.k = None
+        self.fallbacks = 0
+        emb._frame(self.max_ids)     # the sized path (overflowed batches) agrees on its frame now, on every rank
+
+    # -- plumbing ---------------------------------------------------------------------------------------------------
+    def _exchange(self, out, inp):
+        """Equal-split all-to-all of whole frames; at world size 1 the frames ARE the received frames."""
+        if self.emb.world == 1:
+            return inp
+        self.emb._a2a(out, inp, None, None)
+        return out
+
+    def _slot(self, j):
+        return self.slots[j % self.NSLOT]
+
+    def _route(self, j):
+        """Enqueue the routing of batch j (its ids are in the slot's static buffer)."""
+        fb = self._slot(j)
+        self.eng.frames_route(fb, self.emb.starts)
+        krecv = self._exchange(fb.krecv, fb.ksend)
+        self.eng.frames_unpack(fb, krecv)
+
+    def _pull(self, j, out):
+        fb = self._slot(j)
+        self.eng.frames_serve_pull(self.emb.table, fb, self.pull_send)
+        got = self._exchange(self.pull_recv, self.pull_send)
+        self.eng.frames_expand(got, fb, out)
+
+    def _push(self, j, values, scale):
+        fb = self._slot(j)
+        self.eng.frames_reduce(fb, values, scale, self.push_send, self.zero_flags)
+        got = self._exchange(self.push_recv, self.push_send)
+        self.eng.frames_serve_push(self.emb.table, fb, got)
+
+    def _run(self, key, fn):
+        """Enqueue `fn`: eagerly at the first use of `key` (lazy one-time initialisation -- kernel attributes, scratch
+        allocations -- must not fall into a capture), captured into a hipGraph at the second, replayed from then on."""
+        if not self.graphs:
+            fn()
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 256:
+                self._graphs.clear()
+            self._graphs[key] = False
+            fn()
+            return
+        if g is False:
+            try:
+                g = self._graphs[key] = self.eng.graph_capture(fn)
+            except Exception as e:          # an exchange that cannot be captured: stay eager from here on
+                import warnings
+                warnings.warn("FramedStep: hipGraph capture failed (%s); continuing without graphs" % (e,))
+                self.graphs = False
+                fn()
+                return
+        g.replay()
+
+    def _stage(self, j, ids):
+        """Batch j enters the pipeline: its ids go to the static buffer of its slot.  ids = None: the stream of batches
+        has ended (on every rank); an EMPTY tensor is a batch in which this rank names nothing -- it still takes part
+        in the exchanges."""
+        fb = self._slot(j)
+        if ids is None:
+            fb.n, fb.cur, fb.shape, fb.routed = 0, None, (0,), False
+            return False
+        if ids.numel() > self.max_ids:
+            raise ValueError("a batch of %d ids exceeds max_ids = %d of this FramedStep" % (ids.numel(), self.max_ids))
+        self.eng.frames_ids(fb, ids)
+        fb.shape = tuple(ids.shape)
+        fb.routed = True
+        return True
+
+    def _account(self):
+        emb = self.emb
+        w = emb.world
+        if w > 1:
+            per_peer = 4 * (2 + self.rcap) + 2 * 4 * self.rcap * emb.width     # key frame + pull rows + push rows
+            emb.stats["xgmi_bytes_out"] += (w - 1) * per_peer
+            emb.stats["xgmi_bytes_in"] += (w - 1) * per_peer
+
+    # -- the stream protocol ----------------------------------------------------------------------------------------
+    def start(self, ids0, ids1=None):
+        """Route the first two batches of the stream (ids1 = None: a stream of one batch)."""
+        self.k = 0
+        self._ev = {}
+        for j, ids in ((0, ids0), (1, ids1)):
+            if self._stage(j, ids):
+                fb = self._slot(j)
+                self._run(("route", j % self.NSLOT, fb.n, fb.cur.dtype), lambda j=j: self._route(j))
+            self._ev[j] = self.eng.record()
+        return self
+
+    def _overflowed(self, j):
+        """Host: did any rank overflow its frames for batch j?  Reads the pinned word its routing wrote (enqueued two
+        steps ago: the wait is for work that is long complete in steady state)."""
+        fb = self._slot(j)
+        if not fb.routed:
+            return False
+        self.eng.host_sync(self._ev.pop(j, None))
+        return self.eng.frames_overflowed(fb)
+
+    def pull(self, ahead_ids=None, out=None):
+        """Rows of the current batch k; `ahead_ids` = batch k+2 (routed in the same graph), None at the end."""
+        if self.k is None:
+            raise RuntimeError("FramedStep.pull before start")
+        k = self.k
+        fb = self._slot(k)
+        if not fb.routed:
+            raise RuntimeError("FramedStep.pull: the stream of batches has ended")
+        self._over = self._overflowed(k)
+        ahead = self._stage(k + 2, ahead_ids)
+        fa = self._slot(k + 2)
+        width = self.emb.width
+        if fb.n and out is None:
+            out = self.eng.empty_rows(fb.n, width)
+        if self._over:
+            # sized exchange for this batch only (collective: every rank saw the flag); the routing ahead still runs
+            self.fallbacks += 1
+            if ahead:
+                self._run(("route", (k + 2) % self.NSLOT, fa.n, fa.cur.dtype), lambda: self._route(k + 2))
+            self._sized = self.emb.prefetch(fb.cur)
+            rows = self.emb.pull(route=self._sized, return_route=False)
+            if fb.n:
+                out.copy_(rows.reshape(out.shape))
+        else:
+            def seg():
+                if ahead:
+                    self._route(k + 2)
+                self._pull(k, out)
+            self._run(("pull", k % self.NSLOT, fb.n, fa.n if ahead else -1, fa.cur.dtype if ahead else None,
+                       out.data_ptr() if fb.n else 0), seg)
+            self._account()
+        self._ev[k + 2] = self.eng.record()
+        return out.reshape(fb.shape + (width,)) if fb.n else None
+
+    def push(self, values, lr=None):
+        """Apply the gradients `values` of the current batch on its owners (scale -lr; 1 if lr is None)."""
+        k = self.k
+        fb = self._slot(k)
+        scale = 1.0 if lr is None else -float(lr)
+        if self._over:
+            self.emb.push(None, values, lr, route=self._sized)
+            self._sized = None
+        else:
+            v = values.reshape(-1, self.emb.width) if fb.n else None
+            self._run(("push", k % self.NSLOT, fb.n, v.data_ptr() if fb.n else 0, scale),
+                      lambda: self._push(k, v, scale))
+        self.k = k + 1

@@ -157,8 +157,12 @@ int LambOptimizerSparseUpdate(DLArrayHandle param,
                               float beta2t, float eps, float weight_decay,
                               DLStreamHandle stream_handle);
 /* src/common/c_runtime_api.h:811-818, the reference's CPU operator names that python/hetu/_base.py:8-11,72
- * feature-probes.  Served by the HIP kernels for arrays whose DLContext is the GPU (null stream,
- * complete on return); host arrays are refused (-1, ha_last_error) -- the product has no CPU path. */
+ * feature-probes.  Served by the HIP kernels (null stream, complete on return); there is no CPU arithmetic
+ * behind them.  Arrays whose DLContext is the GPU are used where they lie.  HOST arrays (what the reference's
+ * callers pass: EmbeddingLookUp.py:16-17, optimizer.py:203-207) are made visible to the device for the call:
+ * below 64 MiB copied (H2D, kernel, D2H for the written one), from 64 MiB page-locked and mapped with
+ * hipHostRegister -- the kernels then move only the rows the ids name across PCIe; the registration is kept
+ * until ha_scratch_release() (callers pass the same parameter array every step). */
 int cpu_EmbeddingLookup(const DLArrayHandle in_mat, const DLArrayHandle ids,
                         DLArrayHandle out_mat);
 int cpu_SGDOptimizerSparseUpdate(DLArrayHandle param,
@@ -558,6 +562,30 @@ int ha_shard_route_pack_u64ids(const uint64_t *ids, int64_t n, void *plan_ws,
                                int64_t *meta, int32_t *send, ha_stream_t stream);
 int ha_shard_route_unpack(const int32_t *recv, int nshard, int64_t cap, int64_t *recv_cnt,
                           uint32_t *keys_out, ha_stream_t stream);
+
+/* The same routing with FIXED frames, for a step whose launches and exchange sizes do not depend on device-side
+ * counts (it replays from a hipGraph; PSAgent::vecPullSparse / vecPushSparse, PSAgent.h:124-237, with the next
+ * batch routed ahead as ParameterServerCommunicate.py:147-185 prefetches it).  Per owner g:
+ *   send[g * (2 + rcap)] = { count_g, overflow, rcap shard-local keys, 0xFFFFFFFF beyond count_g }
+ * `overflow` = this batch names more than rcap unique keys of SOME owner (the same word in every frame of the sender:
+ * after the equal-split key exchange every rank knows whether any rank overflowed and takes the sized exchange above
+ * for that batch).  rowmap[u] = frame slot g * rcap + j of the plan's unique key u (-1 beyond rcap): the row map
+ * ha_apply_mapped takes to reduce the gradients of a batch straight into the push frames; posmap[i] = frame slot
+ * of position i (nshard * rcap, a zero row, beyond rcap): the key list ha_gather_u32keys takes to expand the
+ * pulled row frames to the positions.  ha_shard_frames_unpack: received key frames -> keys_fixed[nshard * rcap]
+ * (rank order, 0xFFFFFFFF in unused slots: a zero row for ha_gather_u32keys, skipped by ha_shard_serve_push) and
+ * state = { any rank overflowed, keys received } (device int32[2]).  ha_shard_frames_pack is the second half of
+ * ha_shard_frames_route_* for a plan that is already built. */
+int ha_shard_frames_route_f32ids(const float *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
+                                 int nshard, int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap,
+                                 ha_stream_t stream);
+int ha_shard_frames_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
+                                 int nshard, int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap,
+                                 ha_stream_t stream);
+int ha_shard_frames_pack(const void *plan_ws, int64_t n, const int64_t *starts_host, int nshard, int64_t rcap,
+                         int32_t *send, int32_t *rowmap, int32_t *posmap, ha_stream_t stream);
+int ha_shard_frames_unpack(const int32_t *recv, int nshard, int64_t rcap, uint32_t *keys_fixed, int32_t *state,
+                           ha_stream_t stream);
 
 /* Owner side of a sparse push (PSHandler::serve(SparsePush), ps-lite/include/ps/server/PSFHandle.h:130-164):
  * table[keys[j],:] = (table[keys[j],:] + values[a,:]) + values[b,:] ... over the positions a < b < ... that

@@ -99,3 +99,90 @@ class CpuEngine:
         v = values.numpy()
         for j, k in enumerate(keys_i32.numpy().astype(np.int64)):
             t[k] = t[k] + v[j]
+
+    # -- fixed frames (herald_amd.sharded.FramedStep; same contract as HipEngine.frames_*) ---------------------------
+    def frames_buffers(self, w, rcap, n_cap, width):
+        from herald_amd.sharded import FrameBuffers
+        fb = FrameBuffers()
+        fb.w, fb.rcap, fb.n_cap = w, rcap, n_cap
+        fb.ksend = torch.zeros((w, 2 + rcap), dtype=torch.int32)
+        fb.krecv = torch.zeros((w, 2 + rcap), dtype=torch.int32)
+        fb.keys_fixed = torch.zeros(w * rcap, dtype=torch.int32)
+        fb.state_host = torch.zeros(2, dtype=torch.int32)
+        fb.n, fb.cur, fb.shape, fb.routed = 0, None, (0,), False
+        return fb
+
+    def frames_ids(self, fb, ids):
+        fb.cur = ids.reshape(-1).clone()
+        fb.n = fb.cur.numel()
+        return fb.cur
+
+    def frames_route(self, fb, starts):
+        plan = fb.plan = _Plan(fb.cur)
+        st = np.asarray(starts, dtype=np.uint64)
+        off = np.searchsorted(plan.uniq, st, side="left").astype(np.int64)
+        off[-1] = plan.uniq.size
+        cnt = off[1:] - off[:-1]
+        send = np.full((fb.w, 2 + fb.rcap), -1, dtype=np.int32)
+        send[:, 0] = cnt
+        send[:, 1] = int((cnt > fb.rcap).any())
+        rowmap = np.full(plan.uniq.size, -1, dtype=np.int64)
+        for g in range(fb.w):
+            c = int(min(cnt[g], fb.rcap))
+            send[g, 2:2 + c] = (plan.uniq[off[g]:off[g] + c] - st[g]).astype(np.int32)
+            rowmap[off[g]:off[g] + c] = g * fb.rcap + np.arange(c)
+        fb.ksend.copy_(torch.from_numpy(send))
+        fb.rowmap = rowmap
+        fb.posmap = rowmap[plan.inv] if plan.n else np.zeros(0, np.int64)
+
+    def frames_unpack(self, fb, krecv):
+        r = krecv.numpy()
+        keys = np.full(fb.w * fb.rcap, -1, dtype=np.int32)
+        over = 0
+        for g in range(fb.w):
+            c = int(r[g, 0])
+            over |= int(r[g, 1] != 0 or c > fb.rcap)
+            c = min(c, fb.rcap)
+            keys[g * fb.rcap:g * fb.rcap + c] = r[g, 2:2 + c]
+        fb.keys_fixed.copy_(torch.from_numpy(keys))
+        fb.state_host[0] = over
+
+    def frames_overflowed(self, fb):
+        return bool(fb.state_host[0].item())
+
+    def frames_serve_pull(self, table, fb, rows_send):
+        t, k = table.numpy(), fb.keys_fixed.numpy()
+        out = rows_send.numpy()
+        out[:] = 0
+        live = k >= 0
+        out[live] = t[k[live].astype(np.int64)]
+
+    def frames_expand(self, rows_recv, fb, out):
+        if fb.n:
+            r = rows_recv.numpy()
+            o = out.numpy().reshape(fb.n, -1)
+            ok = fb.posmap >= 0
+            o[:] = 0
+            o[ok] = r[fb.posmap[ok]]
+
+    def frames_reduce(self, fb, values, scale, rows_send, zero_flags):
+        if not fb.n:
+            return
+        v = (values.numpy().reshape(fb.n, -1) * np.float32(scale)).astype(np.float32)
+        red = np.zeros((fb.plan.uniq.size, v.shape[1]), dtype=np.float32)
+        for i, u in enumerate(fb.plan.inv):
+            red[u] += v[i]
+        ok = fb.rowmap >= 0
+        rows_send.numpy()[fb.rowmap[ok]] = red[ok]
+
+    def frames_serve_push(self, table, fb, rows_recv):
+        t, v = table.numpy(), rows_recv.numpy()
+        for p, k in enumerate(fb.keys_fixed.numpy().astype(np.int64)):
+            if k >= 0:
+                t[k] = t[k] + v[p]
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype)
+
+    def empty_rows(self, rows, width):
+        return torch.full((rows, width), float("nan"), dtype=torch.float32)      # stale frame slots must never be used

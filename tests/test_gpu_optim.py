@@ -131,10 +131,9 @@ def test_lamb_sparse(dev, rows, width, n):
     np.testing.assert_allclose(dv.cpu().numpy(), v, **TOL)
 
 
-def test_cpu_named_symbols_serve_gpu_arrays_and_refuse_host_arrays(dev):
+def test_cpu_named_symbols_serve_gpu_arrays(dev):
     """cpu_EmbeddingLookup / cpu_SGDOptimizerSparseUpdate (c_runtime_api.h:811-818; hasattr-probed by
-    python/hetu/_base.py:8-11,72): GPU arrays run on the HIP kernels and are complete on return; host
-    arrays are an error -- never a CPU fallback."""
+    python/hetu/_base.py:8-11,72): GPU arrays run on the HIP kernels and are complete on return."""
     from herald_amd import _lib
     L = _lib.load()
     rng = np.random.default_rng(4)
@@ -149,9 +148,39 @@ def test_cpu_named_symbols_serve_gpu_arrays_and_refuse_host_arrays(dev):
     flat = ops.DLHolder(i.reshape(-1))
     assert L.cpu_SGDOptimizerSparseUpdate(hs[0].handle, flat.handle, hs[3].handle, ctypes.c_float(0.1)) == 0
     np.testing.assert_array_equal(t.cpu().numpy(), cpu.sgd_sparse_update(table.copy(), ids.reshape(-1), g, 0.1))
-    host = [ops.DLHolder(torch.from_numpy(x)) for x in (table, ids, np.empty((20, 5, 64), np.float32))]
-    assert L.cpu_EmbeddingLookup(host[0].handle, host[1].handle, host[2].handle) == -1
-    assert b"no CPU fallback" in L.ha_last_error()
+
+
+@pytest.mark.parametrize("rows,width", [(300, 64), (40000, 512)])
+def test_cpu_named_symbols_serve_host_arrays(dev, rows, width):
+    """The same two names on HOST arrays, what the reference's callers pass (EmbeddingLookUp.py:16-17,
+    optimizer.py:203-207): the HIP kernels still do the work -- small arrays are copied to the device and back, a
+    table of 64 MiB or more (the second case: 78 MiB) is page-locked and mapped, only the named rows cross PCIe.
+    Bit-exact against the oracle; a table on the GPU with ids on the host works as well."""
+    from herald_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(rows)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = rng.integers(0, rows, size=(20, 5)).astype(np.float32)
+    ids[3, :] = ids[0, 0]                      # a run of equal ids
+    g = rng.standard_normal((100, width), dtype=np.float32)
+    want_out = cpu.embedding_lookup(table, ids)
+    want_t = cpu.sgd_sparse_update(table.copy(), ids.reshape(-1), g, 0.1)
+    h_t, h_i, h_g = torch.from_numpy(table.copy()), torch.from_numpy(ids), torch.from_numpy(g)
+    h_o = torch.full((20, 5, width), -7.0)
+    hs = [ops.DLHolder(x) for x in (h_t, h_i, h_o, h_g)]
+    assert L.cpu_EmbeddingLookup(hs[0].handle, hs[1].handle, hs[2].handle) == 0, L.ha_last_error()
+    np.testing.assert_array_equal(h_o.numpy(), want_out)
+    flat = ops.DLHolder(h_i.reshape(-1))
+    for _ in range(2):                         # the second call finds the table still registered
+        h_t.copy_(torch.from_numpy(table))
+        assert L.cpu_SGDOptimizerSparseUpdate(hs[0].handle, flat.handle, hs[3].handle, ctypes.c_float(0.1)) == 0, \
+            L.ha_last_error()
+        np.testing.assert_array_equal(h_t.numpy(), want_t)
+    d_t = torch.from_numpy(table.copy()).to(dev)
+    mixed = ops.DLHolder(d_t)
+    assert L.cpu_SGDOptimizerSparseUpdate(mixed.handle, flat.handle, hs[3].handle, ctypes.c_float(0.1)) == 0
+    np.testing.assert_array_equal(d_t.cpu().numpy(), want_t)
+    assert L.ha_scratch_release() == 0         # unregisters the host ranges before the arrays are freed
 
 
 @pytest.mark.parametrize("kind", ["adagrad", "adam", "adamw"])

@@ -124,6 +124,75 @@ def test_sharded_pull_push_gloo(tmp_path, world, rows, width, n, side_group):
              join=True)
 
 
+def _framed_worker(rank, world, port, rows, width, n, row_cap, expect_fallback):
+    """FramedStep (fixed frames, no host-known counts) under gloo: a stream of batches with keys shared between the
+    ranks, runs inside a rank, an empty batch on the last rank and -- with a small row_cap -- batches that overflow
+    their frames on SOME rank and must take the sized exchange on ALL ranks."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_engine import CpuEngine
+    from herald_amd.sharded import FramedStep, ShardedEmbedding, partition
+    from oracle import cpu
+
+    rng = np.random.default_rng(99)
+    table_g = rng.standard_normal((rows, width), dtype=np.float32)
+    starts = partition(rows, world)
+    emb = ShardedEmbedding(rows, width, "cpu", engine=CpuEngine(),
+                           table=torch.from_numpy(table_g[starts[rank]:starts[rank + 1]].copy()))
+    nb = 6
+    batches, vals = [], []
+    for k in range(nb):
+        per = []
+        for r in range(world):
+            m = n if not (k == 2 and r == world - 1) else 0           # one empty batch on the last rank
+            ids = rng.integers(0, rows, size=m).astype(np.float32)
+            if m:
+                ids[: m // 4] = (np.arange(m // 4) * 3) % rows        # keys every rank names
+                ids[m // 4: m // 3] = ids[0]                          # a run
+            if k == 4 and m:                                          # everything from rank 0's range: many unique keys of ONE owner
+                ids = rng.permutation(starts[1])[:m].astype(np.float32) if starts[1] >= m else ids % starts[1]
+            per.append(ids)
+        batches.append(per)
+        vals.append([rng.standard_normal((b.size, width), dtype=np.float32) for b in per])
+    fs = FramedStep(emb, n, row_cap=row_cap, graphs=False)
+    tid = lambda k: torch.from_numpy(batches[k][rank]) if k < nb else None
+    fs.start(tid(0), tid(1))
+    want = table_g.copy()
+    lr = 0.05
+    for k in range(nb):
+        got = fs.pull(tid(k + 2))
+        ids = batches[k][rank]
+        if ids.size:
+            np.testing.assert_array_equal(got.numpy().reshape(-1, width), want[ids.astype(np.int64)],
+                                          err_msg="pull, step %d rank %d" % (k, rank))
+        else:
+            assert got is None
+        fs.push(torch.from_numpy(vals[k][rank]), lr)
+        dist.barrier()
+        for r in range(world):                                        # rank order
+            if batches[k][r].size:
+                cpu.sparse_push(want, batches[k][r], vals[k][r], lr)
+        np.testing.assert_array_equal(emb.table.numpy(), want[starts[rank]:starts[rank + 1]],
+                                      err_msg="shard after push, step %d rank %d" % (k, rank))
+    assert (fs.fallbacks > 0) == expect_fallback, fs.fallbacks
+    with pytest.raises(RuntimeError, match="ended"):
+        fs.pull(None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,rows,width,n,row_cap,expect_fallback",
+                         [(2, 1001, 8, 120, None, True),       # default row_cap = n / W: batch 4 overflows owner 0
+                          (2, 1001, 8, 120, 120, False),       # row_cap = n can never overflow
+                          (3, 700, 4, 90, 40, True)])
+def test_framed_step_gloo(world, rows, width, n, row_cap, expect_fallback):
+    mp.spawn(_framed_worker, args=(world, _free_port(), rows, width, n, row_cap, expect_fallback), nprocs=world,
+             join=True)
+
+
 def test_partition_is_average_partitioner():
     from herald_amd.sharded import partition
     s = partition(33762577, 8)
