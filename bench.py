@@ -47,6 +47,8 @@ def parse_args():
                    help="skip the secondary measurement of the LRU cache tier (limit 0.1 x rows)")
     p.add_argument("--no-laia", action="store_true",
                    help="skip the secondary measurement of the laia scheduler (configs[3] shape)")
+    p.add_argument("--no-config-c", action="store_true",
+                   help="N>1 (sharded) leg: skip the second measurement at BASELINE configs[2]'s shape (bs=4096 d=128)")
     p.add_argument("--no-cold-tier", action="store_true",
                    help="skip the secondary measurement of the host-DRAM cold tier (BASELINE configs[4] shape)")
     p.add_argument("--cold-rows", type=int, default=33554432,

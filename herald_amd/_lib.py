@@ -139,10 +139,16 @@ def _declare(L):
         "ha_shard_route_pack_f32ids": [vp, i64, vp, vp, c.c_int, i64, vp, vp, vp],
         "ha_shard_route_pack_u64ids": [vp, i64, vp, vp, c.c_int, i64, vp, vp, vp],
         "ha_shard_route_unpack": [vp, c.c_int, i64, vp, vp, vp],
-        "ha_shard_frames_route_f32ids": [vp, i64, vp, vp, c.c_int, i64, vp, vp, vp, vp],
-        "ha_shard_frames_route_u64ids": [vp, i64, vp, vp, c.c_int, i64, vp, vp, vp, vp],
-        "ha_shard_frames_pack": [vp, i64, vp, c.c_int, i64, vp, vp, vp, vp],
-        "ha_shard_frames_unpack": [vp, c.c_int, i64, vp, vp, vp],
+        "ha_shard_frames_route_f32ids": [vp, i64, vp, vp, c.c_int, i64, i64, vp, vp, vp, vp],
+        "ha_shard_frames_route_u64ids": [vp, i64, vp, vp, c.c_int, i64, i64, vp, vp, vp, vp],
+        "ha_shard_frames_pack": [vp, i64, vp, c.c_int, i64, i64, vp, vp, vp, vp],
+        "ha_shard_frames_unpack": [vp, c.c_int, i64, i64, vp, vp, vp],
+        "ha_shard_frames_serve_push": [vp, i64, i64, vp, c.c_int, i64, vp, vp, vp],
+        "ha_shard_frames_pack_batch": [vp, vp, c.c_int, vp, c.c_int, i64, i64, vp, vp, vp, vp],
+        "ha_shard_frames_unpack_batch": [vp, c.c_int, c.c_int, i64, i64, vp, vp, vp],
+        "ha_plan_build_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
+        "ha_plan_build_batch_u64ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
+        "ha_shard_frames_serve_pull": [vp, i64, i64, vp, c.c_int, i64, i64, vp, vp, vp, vp],
         "ha_shard_serve_push": [vp, i64, i64, vp, i64, vp, vp, vp],
         "ha_dedup_reduce_scaled": [vp, i64, vp, i64, f32, vp, vp],
         "ha_debug_apply_timeline": [vp, i64, i64, vp, i64, vp, f32, vp, vp],

@@ -730,6 +730,101 @@ extern "C" int ha_plan_sort_u64ids(const uint64_t *ids, int64_t n, void *ws,
     return plan_build<uint64_t>(ids, n, ws, 32, true, as_stream(stream));
 }
 
+// ---- several small plans in two launches -------------------------------------------------------------------------
+// The plans of up to kPlanBatchMax batches of at most kSmallMax ids each: blockIdx.y names the batch, blockIdx.x the
+// tile of plan_rank_small_kernel / the block of finish_small_kernel.  What a caller that knows its ids several
+// batches ahead uses (herald_amd/sharded.py routes a block of batches at a time beside the steps): two launches per
+// block instead of two per batch.
+namespace ha {
+
+constexpr int kPlanBatchMax = 16;
+struct PlanBatch {
+    const void *ids[kPlanBatchMax];
+    int n[kPlanBatchMax];
+    PlanHeader *hdr[kPlanBatchMax];
+    uint32_t *keys[kPlanBatchMax], *sorted[kPlanBatchMax], *uniq[kPlanBatchMax];
+    int32_t *perm[kPlanBatchMax], *inverse[kPlanBatchMax], *counts[kPlanBatchMax], *seg[kPlanBatchMax],
+        *upos[kPlanBatchMax];
+};
+
+template <typename IdT>
+__global__ __launch_bounds__(1024) void plan_rank_small_batch_kernel(const PlanBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    const int i = blockIdx.y, n = b.n[i];
+    if (static_cast<int>(blockIdx.x) * kRankTile >= n)
+        return;
+    rank_tile_body<IdT>(static_cast<const IdT *>(b.ids[i]), n, b.keys[i], b.sorted[i], b.perm[i], blockIdx.x, s_mem);
+}
+
+__global__ __launch_bounds__(1024) void finish_small_batch_kernel(const PlanBatch b) {
+    __shared__ uint32_t s_w[kFinishLdsWords];
+    const int i = blockIdx.y, n = b.n[i];
+    if (n == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            b.hdr[i]->n_unique = 0;
+            b.seg[i][0] = 0;
+        }
+        return;
+    }
+    if (static_cast<int>(blockIdx.x) >= (n + 1023) / 1024)   // finish_blocks(n)
+        return;
+    finish_block_body(b.sorted[i], b.perm[i], n, b.hdr[i], b.uniq[i], b.seg[i], b.counts[i], b.inverse[i], b.upos[i],
+                      blockIdx.x, s_w);
+}
+
+template <typename IdT>
+static int plan_build_batch(const IdT *const *ids, const int64_t *n, void *const *ws, int count, uint64_t key_limit,
+                            hipStream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (ids && n && ws)), "plan_build_batch: bad arguments");
+    bool small = true;
+    for (int i = 0; i < count; ++i) {
+        HA_REQUIRE(n[i] >= 0 && ws[i] != nullptr && (n[i] == 0 || ids[i] != nullptr), "plan_build_batch: bad batch %d", i);
+        small = small && n[i] <= kSmallMax && !bucket_sort_applies(n[i], key_limit);
+    }
+    if (!small) {   // some batch takes a multi-launch sort: one plan at a time
+        for (int i = 0; i < count; ++i)
+            if (plan_build<IdT>(ids[i], n[i], ws[i], 32, false, stream, key_limit))
+                return -1;
+        return 0;
+    }
+    for (int at = 0; at < count; at += kPlanBatchMax) {
+        const int m = count - at < kPlanBatchMax ? count - at : kPlanBatchMax;
+        PlanBatch b;
+        memset(&b, 0, sizeof(b));
+        int nmax = 0;
+        for (int i = 0; i < m; ++i) {
+            const int ni = static_cast<int>(n[at + i]);
+            PlanPtrs p = plan_layout(ws[at + i], ni);
+            b.ids[i] = ids[at + i];
+            b.n[i] = ni;
+            b.hdr[i] = p.hdr; b.keys[i] = p.keys; b.sorted[i] = p.sorted; b.uniq[i] = p.uniq; b.perm[i] = p.perm;
+            b.inverse[i] = p.inverse; b.counts[i] = p.counts; b.seg[i] = p.seg; b.upos[i] = p.upos;
+            nmax = ni > nmax ? ni : nmax;
+        }
+        if (nmax > 0) {
+            const size_t lds = rank_small_lds_bytes(nmax);
+            HA_ALLOW_LDS(plan_rank_small_batch_kernel<IdT>, lds);
+            hipLaunchKernelGGL(plan_rank_small_batch_kernel<IdT>, dim3((nmax + kRankTile - 1) / kRankTile, m), dim3(1024),
+                               lds, stream, b);
+        }
+        hipLaunchKernelGGL(finish_small_batch_kernel, dim3(nmax > 0 ? finish_blocks(nmax) : 1, m), dim3(1024), 0, stream,
+                           b);
+        HA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace ha
+
+extern "C" int ha_plan_build_batch_f32ids_lim(const float *const *ids, const int64_t *n, void *const *ws, int count,
+                                              uint64_t key_limit, ha_stream_t stream) {
+    return ha::plan_build_batch<float>(ids, n, ws, count, key_limit, ha::as_stream(stream));
+}
+extern "C" int ha_plan_build_batch_u64ids_lim(const uint64_t *const *ids, const int64_t *n, void *const *ws, int count,
+                                              uint64_t key_limit, ha_stream_t stream) {
+    return ha::plan_build_batch<uint64_t>(ids, n, ws, count, key_limit, ha::as_stream(stream));
+}
+
 extern "C" int ha_plan_build_f32ids_lim(const float *ids, int64_t n, void *ws, uint64_t key_limit,
                                         ha_stream_t stream) {
     return plan_build<float>(ids, n, ws, 32, false, as_stream(stream), key_limit);

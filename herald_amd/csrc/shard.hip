@@ -282,12 +282,11 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 // send[g] = [count_g, flag, keys ...]; rowmap[u] = frame slot (g * rcap + j) of unique key u, -1 beyond rcap;
 // posmap[i] = frame slot of the unique key of position i (what the expand gathers from), the zero row W * rcap
 // beyond rcap
-__global__ __launch_bounds__(256) void shard_pack_frames_kernel(
+__device__ __forceinline__ void shard_pack_frames_body(
     const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq, const int32_t *__restrict__ inverse, int n,
-    ShardStarts st, int nshard, int rcap, int32_t *__restrict__ send, int32_t *__restrict__ rowmap,
-    int32_t *__restrict__ posmap) {
-    __shared__ int s_off[kMaxShards + 1];
-    __shared__ int s_flag;
+    const ShardStarts &st, int nshard, int rcap, size_t fw, int32_t *__restrict__ send, int32_t *__restrict__ rowmap,
+    int32_t *__restrict__ posmap, int *s_off, int *s_flag_p) {
+    int &s_flag = *s_flag_p;
     const int U = n > 0 ? static_cast<int>(hdr->n_unique) : 0;
     if (threadIdx.x <= static_cast<unsigned>(nshard)) {
         const uint32_t target = st.start[threadIdx.x];
@@ -309,7 +308,6 @@ __global__ __launch_bounds__(256) void shard_pack_frames_kernel(
         s_flag = f;
     }
     __syncthreads();
-    const size_t fw = 2 + static_cast<size_t>(rcap);
     if (blockIdx.x == 0 && threadIdx.x < static_cast<unsigned>(nshard)) {
         send[threadIdx.x * fw] = s_off[threadIdx.x + 1] - s_off[threadIdx.x];
         send[threadIdx.x * fw + 1] = s_flag;
@@ -338,12 +336,39 @@ __global__ __launch_bounds__(256) void shard_pack_frames_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void shard_pack_frames_kernel(
+    const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq, const int32_t *__restrict__ inverse, int n,
+    ShardStarts st, int nshard, int rcap, size_t fw, int32_t *__restrict__ send, int32_t *__restrict__ rowmap,
+    int32_t *__restrict__ posmap) {
+    __shared__ int s_off[kMaxShards + 1];
+    __shared__ int s_flag;
+    shard_pack_frames_body(hdr, uniq, inverse, n, st, nshard, rcap, fw, send, rowmap, posmap, s_off, &s_flag);
+}
+
+// the same for up to kFrameBatchMax batches in one launch (blockIdx.y = batch; batch i's frames start i * (2 + rcap)
+// words into every owner's stride)
+constexpr int kFrameBatchMax = 16;
+struct FramePackBatch {
+    const PlanHeader *hdr[kFrameBatchMax];
+    const uint32_t *uniq[kFrameBatchMax];
+    const int32_t *inverse[kFrameBatchMax];
+    int n[kFrameBatchMax];
+    int32_t *rowmap[kFrameBatchMax], *posmap[kFrameBatchMax];
+};
+__global__ __launch_bounds__(256) void shard_pack_frames_batch_kernel(const FramePackBatch b, ShardStarts st, int nshard,
+                                                                      int rcap, size_t fw, int32_t *__restrict__ send) {
+    __shared__ int s_off[kMaxShards + 1];
+    __shared__ int s_flag;
+    const int i = blockIdx.y;
+    shard_pack_frames_body(b.hdr[i], b.uniq[i], b.inverse[i], b.n[i], st, nshard, rcap, fw,
+                           send + static_cast<size_t>(i) * (2 + static_cast<size_t>(rcap)), b.rowmap[i], b.posmap[i], s_off,
+                           &s_flag);
+}
+
 // recv[g] = [count_g, flag_g, keys ...] from rank g -> keys_fixed[g * rcap + j] (kNoKey beyond the count) and
 // state = {any rank overflowed, keys received}
-__global__ __launch_bounds__(256) void shard_unpack_frames_kernel(const int32_t *__restrict__ recv, int nshard, int rcap,
-                                                                  uint32_t *__restrict__ keys_fixed,
-                                                                  int32_t *__restrict__ state) {
-    const size_t fw = 2 + static_cast<size_t>(rcap);
+__device__ __forceinline__ void shard_unpack_frames_body(const int32_t *__restrict__ recv, int nshard, int rcap, size_t fw,
+                                                         uint32_t *__restrict__ keys_fixed, int32_t *__restrict__ state) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int f = 0, total = 0;
         for (int g = 0; g < nshard; ++g) {
@@ -362,6 +387,112 @@ __global__ __launch_bounds__(256) void shard_unpack_frames_kernel(const int32_t 
     }
 }
 
+__global__ __launch_bounds__(256) void shard_unpack_frames_kernel(const int32_t *__restrict__ recv, int nshard, int rcap,
+                                                                  size_t fw, uint32_t *__restrict__ keys_fixed,
+                                                                  int32_t *__restrict__ state) {
+    shard_unpack_frames_body(recv, nshard, rcap, fw, keys_fixed, state);
+}
+
+struct FrameUnpackBatch {
+    uint32_t *keys_fixed[kFrameBatchMax];
+    int32_t *state[kFrameBatchMax];
+};
+__global__ __launch_bounds__(256) void shard_unpack_frames_batch_kernel(const int32_t *__restrict__ recv, int nshard,
+                                                                        int rcap, size_t fw, const FrameUnpackBatch b) {
+    const int i = blockIdx.y;
+    shard_unpack_frames_body(recv + static_cast<size_t>(i) * (2 + static_cast<size_t>(rcap)), nshard, rcap, fw,
+                             b.keys_fixed[i], b.state[i]);
+}
+
+// Owner side of a framed pull, one launch: received key frames -> keys_fixed / state (what shard_unpack_frames_kernel
+// writes) AND the rows of the live slots into the row frames (PSHandler::serve(SparsePull), PSFHandle.h:101-128).
+// One wave per slot; unused slots are not written (the expand never reads them).
+template <int VEC>
+__global__ __launch_bounds__(256) void shard_serve_pull_frames_kernel(
+    const float *__restrict__ table, uint64_t rows, int width, const int32_t *__restrict__ recv, int nshard, int rcap,
+    size_t fw, float *__restrict__ rows_out, uint32_t *__restrict__ keys_fixed, int32_t *__restrict__ state) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int f = 0, total = 0;
+        for (int g = 0; g < nshard; ++g) {
+            const int c = recv[g * fw];
+            f |= (recv[g * fw + 1] != 0) | (c > rcap) | (c < 0);
+            total += c < 0 ? 0 : (c > rcap ? rcap : c);
+        }
+        state[0] = f;
+        state[1] = total;
+    }
+    const int lane = threadIdx.x & 63;
+    const int slots = nshard * rcap;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= slots)
+        return;
+    const int g = p / rcap, j = p - g * rcap;
+    const int c = recv[g * fw];
+    const uint32_t key = j < c ? static_cast<uint32_t>(recv[g * fw + 2 + j]) : kNoKey;
+    if (lane == 0)
+        keys_fixed[p] = key;
+    if (key == kNoKey)
+        return;
+    float *dst = rows_out + static_cast<uint64_t>(p) * static_cast<uint64_t>(width);
+    const bool ok = key < rows;     // a key beyond the shard reads as zeros (the library's definition)
+    const float *src = table + static_cast<uint64_t>(ok ? key : 0u) * static_cast<uint64_t>(width);
+    if (VEC == 4) {
+        for (int col = 4 * lane; col < width; col += 256) {
+            const float4v v = ok ? ld4(src + col) : float4v{0.f, 0.f, 0.f, 0.f};
+            st4_nt(dst + col, v);
+        }
+    } else {
+        for (int col = lane; col < width; col += 64)
+            dst[col] = ok ? src[col] : 0.f;
+    }
+}
+
+// Stable merge of the W received key lists of a framed push (each ascending, unique inside a list, kNoKey = the
+// largest key in the unused slots): slot p = (s, j) gets rank j + sum over s' < s of upper_bound(list s', key) + sum
+// over s' > s of lower_bound(list s', key) -- the position of (key, s) in the rank-ordered merge -- by binary searches
+// over the lists staged in LDS; sorted[rank] = key, perm[rank] = p: what the sort of an index plan produces, in one
+// short launch instead of a rank-by-counting of W * rcap keys against each other.
+__global__ __launch_bounds__(256) void shard_merge_rank_kernel(const uint32_t *__restrict__ keys, int nshard, int rcap,
+                                                               uint32_t *__restrict__ sorted, int32_t *__restrict__ perm) {
+    extern __shared__ uint32_t s_keys[];
+    const int slots = nshard * rcap;
+    for (int q = threadIdx.x; q < slots; q += 256)
+        s_keys[q] = keys[q];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= slots)
+        return;
+    const int s = p / rcap, j = p - s * rcap;
+    const uint32_t key = s_keys[p];
+    int rank = j;
+    for (int t = 0; t < nshard; ++t) {
+        if (t == s)
+            continue;
+        const uint32_t *list = s_keys + t * rcap;
+        int lo = 0, hi = rcap;
+        if (t < s) {            // upper bound: equal keys of earlier ranks come first
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (list[mid] <= key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+        } else {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (list[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+        }
+        rank += lo;
+    }
+    sorted[rank] = key;
+    perm[rank] = p;
+}
+
 }  // namespace ha
 
 static int shard_starts_of(const int64_t *starts_host, int nshard, ShardStarts *st, const char *who) {
@@ -374,9 +505,11 @@ static int shard_starts_of(const int64_t *starts_host, int nshard, ShardStarts *
 }
 
 extern "C" int ha_shard_frames_pack(const void *plan_ws, int64_t n, const int64_t *starts_host, int nshard, int64_t rcap,
-                                    int32_t *send, int32_t *rowmap, int32_t *posmap, ha_stream_t stream) {
+                                    int64_t frame_stride, int32_t *send, int32_t *rowmap, int32_t *posmap,
+                                    ha_stream_t stream) {
     HA_REQUIRE(plan_ws && starts_host && send && rowmap && posmap, "shard_frames_pack: null pointer");
-    HA_REQUIRE(n >= 0 && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30), "shard_frames_pack: bad sizes");
+    HA_REQUIRE(n >= 0 && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30) && frame_stride >= 2 + rcap,
+               "shard_frames_pack: bad sizes");
     ShardStarts st;
     if (shard_starts_of(starts_host, nshard, &st, "shard_frames_pack"))
         return -1;
@@ -385,45 +518,129 @@ extern "C" int ha_shard_frames_pack(const void *plan_ws, int64_t n, const int64_
     int blocks = static_cast<int>((work + 255) / 256);
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(shard_pack_frames_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p.hdr, p.uniq, p.inverse,
-                       static_cast<int>(n), st, nshard, static_cast<int>(rcap), send, rowmap, posmap);
+                       static_cast<int>(n), st, nshard, static_cast<int>(rcap), static_cast<size_t>(frame_stride), send,
+                       rowmap, posmap);
     HA_LAUNCH_CHECK();
     return 0;
 }
 
 template <typename IdT>
 static int shard_frames_route(const IdT *ids, int64_t n, void *plan_ws, const int64_t *starts_host, int nshard,
-                              int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap, ha_stream_t stream,
+                              int64_t rcap, int64_t frame_stride, int32_t *send, int32_t *rowmap, int32_t *posmap,
+                              ha_stream_t stream,
                               int (*build)(const IdT *, int64_t, void *, uint64_t, ha_stream_t)) {
     HA_REQUIRE(plan_ws && starts_host, "shard_frames_route: null pointer");
     HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards, "shard_frames_route: nshard must be in [1,%d]", kMaxShards);
     if (n > 0 && build(ids, n, plan_ws, static_cast<uint64_t>(starts_host[nshard]), stream))   // keys < total rows
         return -1;
-    return ha_shard_frames_pack(plan_ws, n, starts_host, nshard, rcap, send, rowmap, posmap, stream);
+    return ha_shard_frames_pack(plan_ws, n, starts_host, nshard, rcap, frame_stride, send, rowmap, posmap, stream);
 }
 
 extern "C" int ha_shard_frames_route_f32ids(const float *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
-                                            int nshard, int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap,
-                                            ha_stream_t stream) {
-    return shard_frames_route<float>(ids, n, plan_ws, starts_host, nshard, rcap, send, rowmap, posmap, stream,
+                                            int nshard, int64_t rcap, int64_t frame_stride, int32_t *send,
+                                            int32_t *rowmap, int32_t *posmap, ha_stream_t stream) {
+    return shard_frames_route<float>(ids, n, plan_ws, starts_host, nshard, rcap, frame_stride, send, rowmap, posmap, stream,
                                      ha_plan_build_f32ids_lim);
 }
 
 extern "C" int ha_shard_frames_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
-                                            int nshard, int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap,
-                                            ha_stream_t stream) {
-    return shard_frames_route<uint64_t>(ids, n, plan_ws, starts_host, nshard, rcap, send, rowmap, posmap, stream,
+                                            int nshard, int64_t rcap, int64_t frame_stride, int32_t *send,
+                                            int32_t *rowmap, int32_t *posmap, ha_stream_t stream) {
+    return shard_frames_route<uint64_t>(ids, n, plan_ws, starts_host, nshard, rcap, frame_stride, send, rowmap, posmap, stream,
                                         ha_plan_build_u64ids_lim);
 }
 
-extern "C" int ha_shard_frames_unpack(const int32_t *recv, int nshard, int64_t rcap, uint32_t *keys_fixed, int32_t *state,
-                                      ha_stream_t stream) {
+extern "C" int ha_shard_frames_pack_batch(const void *const *plan_ws, const int64_t *n, int count,
+                                          const int64_t *starts_host, int nshard, int64_t rcap, int64_t frame_stride,
+                                          int32_t *send, int32_t *const *rowmap, int32_t *const *posmap,
+                                          ha_stream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (plan_ws && n && send && rowmap && posmap)) && starts_host,
+               "shard_frames_pack_batch: null pointer");
+    HA_REQUIRE(rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30) && frame_stride >= count * (2 + rcap),
+               "shard_frames_pack_batch: the stride must hold the frames of all batches");
+    ShardStarts st;
+    if (shard_starts_of(starts_host, nshard, &st, "shard_frames_pack_batch"))
+        return -1;
+    for (int at = 0; at < count; at += kFrameBatchMax) {
+        const int m = count - at < kFrameBatchMax ? count - at : kFrameBatchMax;
+        FramePackBatch b;
+        memset(&b, 0, sizeof(b));
+        int64_t work = static_cast<int64_t>(nshard) * rcap;
+        for (int i = 0; i < m; ++i) {
+            HA_REQUIRE(plan_ws[at + i] && n[at + i] >= 0 && rowmap[at + i] && posmap[at + i],
+                       "shard_frames_pack_batch: bad batch %d", at + i);
+            PlanPtrs p = plan_layout(const_cast<void *>(plan_ws[at + i]), n[at + i] > 0 ? n[at + i] : 1);
+            b.hdr[i] = p.hdr; b.uniq[i] = p.uniq; b.inverse[i] = p.inverse;
+            b.n[i] = static_cast<int>(n[at + i]);
+            b.rowmap[i] = rowmap[at + i];
+            b.posmap[i] = posmap[at + i];
+            work = n[at + i] > work ? n[at + i] : work;
+        }
+        int blocks = static_cast<int>((work + 255) / 256);
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+        hipLaunchKernelGGL(shard_pack_frames_batch_kernel, dim3(blocks, m), dim3(256), 0, as_stream(stream), b, st, nshard,
+                           static_cast<int>(rcap), static_cast<size_t>(frame_stride),
+                           send + static_cast<size_t>(at) * (2 + static_cast<size_t>(rcap)));
+        HA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int ha_shard_frames_unpack_batch(const int32_t *recv, int count, int nshard, int64_t rcap, int64_t frame_stride,
+                                            uint32_t *const *keys_fixed, int32_t *const *state, ha_stream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (recv && keys_fixed && state)), "shard_frames_unpack_batch: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30) &&
+                   frame_stride >= count * (2 + rcap), "shard_frames_unpack_batch: bad sizes");
+    for (int at = 0; at < count; at += kFrameBatchMax) {
+        const int m = count - at < kFrameBatchMax ? count - at : kFrameBatchMax;
+        FrameUnpackBatch b;
+        memset(&b, 0, sizeof(b));
+        for (int i = 0; i < m; ++i) {
+            HA_REQUIRE(keys_fixed[at + i] && state[at + i], "shard_frames_unpack_batch: bad batch %d", at + i);
+            b.keys_fixed[i] = keys_fixed[at + i];
+            b.state[i] = state[at + i];
+        }
+        long long want = (static_cast<long long>(nshard) * rcap + 255) / 256;
+        const int blocks = want < 1 ? 1 : (want > 64 ? 64 : static_cast<int>(want));
+        hipLaunchKernelGGL(shard_unpack_frames_batch_kernel, dim3(blocks, m), dim3(256), 0, as_stream(stream),
+                           recv + static_cast<size_t>(at) * (2 + static_cast<size_t>(rcap)), nshard, static_cast<int>(rcap),
+                           static_cast<size_t>(frame_stride), b);
+        HA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int ha_shard_frames_serve_pull(const float *table, int64_t rows, int64_t width, const int32_t *recv, int nshard,
+                                          int64_t rcap, int64_t frame_stride, float *rows_out, uint32_t *keys_fixed,
+                                          int32_t *state, ha_stream_t stream) {
+    HA_REQUIRE(table && recv && rows_out && keys_fixed && state, "shard_frames_serve_pull: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30) &&
+                   rows >= 0 && width >= 1 && width < (1 << 30) && frame_stride >= 2 + rcap,
+               "shard_frames_serve_pull: bad sizes");
+    const unsigned blocks = static_cast<unsigned>((static_cast<int64_t>(nshard) * rcap + 3) / 4);
+    const bool vec = width % 4 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(rows_out) % 16 == 0;
+    if (vec)
+        hipLaunchKernelGGL(shard_serve_pull_frames_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), table,
+                           static_cast<uint64_t>(rows), static_cast<int>(width), recv, nshard, static_cast<int>(rcap),
+                           static_cast<size_t>(frame_stride), rows_out, keys_fixed, state);
+    else
+        hipLaunchKernelGGL(shard_serve_pull_frames_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), table,
+                           static_cast<uint64_t>(rows), static_cast<int>(width), recv, nshard, static_cast<int>(rcap),
+                           static_cast<size_t>(frame_stride), rows_out, keys_fixed, state);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ha_shard_frames_unpack(const int32_t *recv, int nshard, int64_t rcap, int64_t frame_stride,
+                                      uint32_t *keys_fixed, int32_t *state, ha_stream_t stream) {
     HA_REQUIRE(recv && keys_fixed && state, "shard_frames_unpack: null pointer");
-    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30),
-               "shard_frames_unpack: bad sizes");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30) &&
+                   frame_stride >= 2 + rcap, "shard_frames_unpack: bad sizes");
     long long want = (static_cast<long long>(nshard) * rcap + 255) / 256;
     const int blocks = want < 1 ? 1 : (want > 256 ? 256 : static_cast<int>(want));
     hipLaunchKernelGGL(shard_unpack_frames_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), recv, nshard,
-                       static_cast<int>(rcap), keys_fixed, state);
+                       static_cast<int>(rcap), static_cast<size_t>(frame_stride), keys_fixed, state);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -440,6 +657,25 @@ extern "C" int ha_shard_serve_push(float *table, int64_t rows, int64_t width, co
     // sort, then the fused apply + finish launch (lr = -1 turns `acc - lr*v` into `acc + v` bit for bit)
     if (ha_plan_sort_u32keys(keys, n, plan_ws, 32, stream))
         return -1;
+    return ha_sgd_apply_finish(table, rows, width, plan_ws, n, values, -1.0f, stream);
+}
+
+// Owner side of a FRAMED push: keys_fixed = nshard lists of rcap slots in rank order (ha_shard_frames_unpack), values
+// = the received row frames.  As ha_shard_serve_push, with the sort replaced by the merge of the sorted lists.
+extern "C" int ha_shard_frames_serve_push(float *table, int64_t rows, int64_t width, const uint32_t *keys_fixed, int nshard,
+                                          int64_t rcap, const float *values, void *plan_ws, ha_stream_t stream) {
+    HA_REQUIRE(table && keys_fixed && values && plan_ws, "shard_frames_serve_push: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30),
+               "shard_frames_serve_push: bad sizes");
+    const int64_t n = static_cast<int64_t>(nshard) * rcap;
+    const size_t lds = static_cast<size_t>(n) * 4;
+    if (lds > (size_t(64) << 10))     // lists that do not fit 64 KiB of LDS: the general sort
+        return ha_shard_serve_push(table, rows, width, keys_fixed, n, values, plan_ws, stream);
+    PlanPtrs p = plan_layout(plan_ws, n);
+    HA_ALLOW_LDS(shard_merge_rank_kernel, lds);
+    hipLaunchKernelGGL(shard_merge_rank_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), lds,
+                       as_stream(stream), keys_fixed, nshard, static_cast<int>(rcap), p.sorted, p.perm);
+    HA_LAUNCH_CHECK();
     return ha_sgd_apply_finish(table, rows, width, plan_ws, n, values, -1.0f, stream);
 }
 

@@ -204,54 +204,95 @@ class HipEngine:
 
 
     # -- fixed frames (FramedStep): no launch or exchange size depends on a device-side count ---------------------
-    def frames_buffers(self, w, rcap, n_cap, width):
-        """Persistent buffers of one routing slot of a FramedStep."""
-        fb = FrameBuffers()
-        fb.w, fb.rcap, fb.n_cap = w, rcap, n_cap
-        fb.plan = self.ops.IndexPlan(max(n_cap, 1), self.device)
-        fb.ksend = torch.empty((w, 2 + rcap), dtype=torch.int32, device=self.device)
-        fb.krecv = torch.empty((w, 2 + rcap), dtype=torch.int32, device=self.device)
-        fb.keys_fixed = torch.empty(w * rcap, dtype=torch.int32, device=self.device)
-        fb.rowmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
-        fb.posmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
-        fb.state = torch.zeros(2, dtype=torch.int32, device=self.device)
-        fb.state_host = torch.zeros(2, dtype=torch.int32).pin_memory()
-        fb.ids = {}           # dtype -> static copy of the batch's ids (the graphs read this address)
-        fb.n, fb.cur, fb.shape, fb.routed = 0, None, (0,), False
-        return fb
+    def frames_block(self, w, rcap, n_cap, block):
+        """Persistent buffers of one routing block of a FramedStep: the key frames of `block` batches, laid out
+        [owner][batch][2 + rcap] so that they travel in one equal-split all-to-all, and per batch the plan, the received
+        keys in rank order, the row / position maps and the pinned overflow word."""
+        blk = FrameBlock()
+        blk.ksend = torch.empty((w, block, 2 + rcap), dtype=torch.int32, device=self.device)
+        blk.krecv = torch.empty((w, block, 2 + rcap), dtype=torch.int32, device=self.device)
+        blk.kgot, blk.ev, blk.live = None, None, False
+        blk.slots = []
+        for i in range(block):
+            fb = FrameBuffers()
+            fb.i, fb.w, fb.rcap, fb.stride = i, w, rcap, block * (2 + rcap)
+            fb.plan = self.ops.IndexPlan(max(n_cap, 1), self.device)
+            fb.keys_fixed = torch.empty(w * rcap, dtype=torch.int32, device=self.device)
+            fb.rowmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
+            fb.posmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
+            fb.state_host = torch.zeros(2, dtype=torch.int32).pin_memory()    # written by the kernels directly
+            fb.n, fb.ids, fb.shape, fb.routed = 0, None, (0,), False
+            blk.slots.append(fb)
+        return blk
 
-    def frames_ids(self, fb, ids):
-        """Copy a batch's ids to the slot's static buffer (the captured routing reads it from there)."""
-        t = fb.ids.get(ids.dtype)
-        if t is None:
-            t = fb.ids[ids.dtype] = torch.zeros(max(fb.n_cap, 1), dtype=ids.dtype, device=self.device)
-        fb.n = ids.numel()
-        fb.cur = t[:fb.n]
-        fb.cur.copy_(ids.reshape(-1), non_blocking=True)
-        return fb.cur
+    def _frame_ptr(self, t, fb):
+        return t.data_ptr() + fb.i * (2 + fb.rcap) * 4
 
-    def frames_route(self, fb, starts):
-        ids = fb.cur
-        fn = self.lib.ha_shard_frames_route_f32ids if ids.dtype == torch.float32 else self.lib.ha_shard_frames_route_u64ids
-        st = (ctypes.c_int64 * len(starts))(*starts)
-        self.check(fn(ids.data_ptr(), fb.n, fb.plan.ws.data_ptr(), st, fb.w, fb.rcap, fb.ksend.data_ptr(),
-                      fb.rowmap.data_ptr(), fb.posmap.data_ptr(), self._stream()), "ha_shard_frames_route")
+    def frames_plan(self, fb, starts):
+        """First half of the routing of a batch: the index plan of its ids (keys < total rows)."""
+        ids = fb.ids
+        if fb.n:
+            fn = self.lib.ha_plan_build_f32ids_lim if ids.dtype == torch.float32 else self.lib.ha_plan_build_u64ids_lim
+            self.check(fn(ids.data_ptr(), fb.n, fb.plan.ws.data_ptr(), starts[-1], self._stream()), "ha_plan_build")
         fb.plan.n = fb.n
         fb.plan._view = None
 
-    def frames_unpack(self, fb, krecv):
-        self.check(self.lib.ha_shard_frames_unpack(krecv.data_ptr(), fb.w, fb.rcap, fb.keys_fixed.data_ptr(),
-                                                   fb.state.data_ptr(), self._stream()), "ha_shard_frames_unpack")
-        fb.state_host.copy_(fb.state, non_blocking=True)
+    def frames_pack(self, blk, fb, starts):
+        """Second half: key frames, row map (reduce) and position map (expand)."""
+        st = (ctypes.c_int64 * len(starts))(*starts)
+        self.check(self.lib.ha_shard_frames_pack(fb.plan.ws.data_ptr(), fb.n, st, fb.w, fb.rcap, fb.stride,
+                                                 self._frame_ptr(blk.ksend, fb), fb.rowmap.data_ptr(),
+                                                 fb.posmap.data_ptr(), self._stream()), "ha_shard_frames_pack")
+
+    def frames_unpack(self, blk, fb):
+        """Received key frames -> keys_fixed and the overflow word, written straight to pinned host memory (no copy
+        in the stream: the host reads it a block later)."""
+        self.check(self.lib.ha_shard_frames_unpack(self._frame_ptr(blk.kgot, fb), fb.w, fb.rcap, fb.stride,
+                                                   fb.keys_fixed.data_ptr(), fb.state_host.data_ptr(), self._stream()),
+                   "ha_shard_frames_unpack")
+
+    def frames_route_block(self, blk, starts, exchange):
+        """The routing of a block of batches in four launches and one key exchange: plans (two launches for all batches
+        of one id dtype), key frames + maps (one), `exchange(krecv, ksend)` -> the received frames, received keys and
+        overflow words (one).  Slots without a batch send empty frames."""
+        vp = ctypes.c_void_p
+        slots = blk.slots
+        for kind, fn in ((torch.float32, self.lib.ha_plan_build_batch_f32ids_lim),
+                         (None, self.lib.ha_plan_build_batch_u64ids_lim)):
+            sel = [fb for fb in slots if fb.n and (fb.ids.dtype == torch.float32) == (kind is not None)]
+            if sel:
+                cnt = len(sel)
+                self.check(fn((vp * cnt)(*[fb.ids.data_ptr() for fb in sel]), (ctypes.c_int64 * cnt)(*[fb.n for fb in sel]),
+                              (vp * cnt)(*[fb.plan.ws.data_ptr() for fb in sel]), cnt, starts[-1], self._stream()),
+                           "ha_plan_build_batch")
+        for fb in slots:
+            fb.plan.n = fb.n
+            fb.plan._view = None
+        cnt = len(slots)
+        fb0 = slots[0]
+        st = (ctypes.c_int64 * len(starts))(*starts)
+        self.check(self.lib.ha_shard_frames_pack_batch((vp * cnt)(*[fb.plan.ws.data_ptr() for fb in slots]),
+                                                       (ctypes.c_int64 * cnt)(*[fb.n for fb in slots]), cnt, st, fb0.w,
+                                                       fb0.rcap, fb0.stride, blk.ksend.data_ptr(),
+                                                       (vp * cnt)(*[fb.rowmap.data_ptr() for fb in slots]),
+                                                       (vp * cnt)(*[fb.posmap.data_ptr() for fb in slots]), self._stream()),
+                   "ha_shard_frames_pack_batch")
+        blk.kgot = exchange(blk.krecv, blk.ksend)
+        self.check(self.lib.ha_shard_frames_unpack_batch(blk.kgot.data_ptr(), cnt, fb0.w, fb0.rcap, fb0.stride,
+                                                         (vp * cnt)(*[fb.keys_fixed.data_ptr() for fb in slots]),
+                                                         (vp * cnt)(*[fb.state_host.data_ptr() for fb in slots]),
+                                                         self._stream()), "ha_shard_frames_unpack_batch")
 
     def frames_overflowed(self, fb):
         return bool(fb.state_host[0].item())
 
-    def frames_serve_pull(self, table, fb, rows_send):
-        """rows_send[g * rcap + j, :] = table[key j of rank g] (zero rows in the unused slots)."""
-        m = fb.w * fb.rcap
-        self.check(self.lib.ha_gather_u32keys(table.data_ptr(), table.shape[0], table.shape[1], fb.keys_fixed.data_ptr(),
-                                              m, rows_send.data_ptr(), self._stream()), "ha_gather_u32keys")
+    def frames_serve_pull(self, table, blk, fb, rows_send):
+        """rows_send[g * rcap + j, :] = table[key j of rank g] for the live slots of the received key frames."""
+        self.check(self.lib.ha_shard_frames_serve_pull(table.data_ptr(), table.shape[0], table.shape[1],
+                                                       self._frame_ptr(blk.kgot, fb), fb.w, fb.rcap, fb.stride,
+                                                       rows_send.data_ptr(), fb.keys_fixed.data_ptr(),
+                                                       fb.state_host.data_ptr(), self._stream()),
+                   "ha_shard_frames_serve_pull")
 
     def frames_expand(self, rows_recv, fb, out):
         """out[i, :] = the pulled row of position i (a slot index beyond the frames reads as a zero row)."""
@@ -275,9 +316,13 @@ class HipEngine:
         p = self._owner_plan
         if p is None or p.capacity < m:
             p = self._owner_plan = self.ops.IndexPlan(m + 16, self.device)
-        self.check(self.lib.ha_shard_serve_push(table.data_ptr(), table.shape[0], table.shape[1],
-                                                fb.keys_fixed.data_ptr(), m, rows_recv.data_ptr(), p.ws.data_ptr(),
-                                                self._stream()), "ha_shard_serve_push")
+        self.check(self.lib.ha_shard_frames_serve_push(table.data_ptr(), table.shape[0], table.shape[1],
+                                                       fb.keys_fixed.data_ptr(), fb.w, fb.rcap, rows_recv.data_ptr(),
+                                                       p.ws.data_ptr(), self._stream()), "ha_shard_frames_serve_push")
+
+    def hold_for_side(self, t):
+        if t is not None and t.is_cuda:
+            t.record_stream(self.side)
 
     def graph_capture(self, fn):
         """Capture `fn()` (enqueues work on the current stream) into a hipGraph; -> object with .replay()."""
@@ -293,10 +338,15 @@ class HipEngine:
         return torch.empty((rows, width), dtype=torch.float32, device=self.device)
 
 
+class FrameBlock:
+    """Key frames of one routing block of a FramedStep (see HipEngine.frames_block)."""
+    __slots__ = ("ksend", "krecv", "kgot", "ev", "live", "slots")
+
+
 class FrameBuffers:
-    """Persistent buffers of one routing slot of a FramedStep (see HipEngine.frames_buffers)."""
-    __slots__ = ("w", "rcap", "n_cap", "plan", "ksend", "krecv", "keys_fixed", "rowmap", "posmap", "state",
-                 "state_host", "ids", "cur", "n", "shape", "routed")
+    """Per-batch buffers inside a FrameBlock."""
+    __slots__ = ("i", "w", "rcap", "stride", "plan", "keys_fixed", "rowmap", "posmap", "state_host", "ids", "n",
+                 "shape", "routed")
 
 
 class RouteBuffers:
@@ -533,71 +583,124 @@ class ShardedEmbedding:
 
 class FramedStep:
     """The sharded step with FIXED frames: every launch and every exchange has a size the host knows without reading
-    anything back, so a step replays from hipGraphs (pull and push are one graph each; the routing of the batch two
-    steps ahead rides in the pull graph).  Same semantics as ShardedEmbedding.pull / push (PSAgent::vecPullSparse /
+    anything back, so the pull and the push of a step replay from one hipGraph each (three launches and one
+    equal-split all-to-all per graph).  Same semantics as ShardedEmbedding.pull / push (PSAgent::vecPullSparse /
     vecPushSparse, PSAgent.h:124-237; rank-ordered server `+=`, PSFHandle.h:130-164).
 
-        fs = FramedStep(emb, max_ids)                  # row_cap: rows per owner and exchange (default max_ids / W)
-        fs.start(ids0, ids1)                           # routes the first two batches
-        rows0 = fs.pull(ids2)                          # rows of batch 0; batch 2 is routed meanwhile
-        fs.push(grads0, lr)                            # batch 0 applied on its owners (rank order)
-        rows1 = fs.pull(ids3) ...                      # ahead ids = None once the stream of batches ends
+    The ROUTING of the batches -- index plan, key frames, key exchange -- depends on their ids only, and the reference
+    prefetches ids too (ParameterServerCommunicate.py:147-185).  It runs a BLOCK of `block` batches at a time, one
+    block ahead of the steps that use it, on the engine's side stream beside them: per block one launch chain per
+    batch and ONE key exchange for all of them (frames laid out [owner][batch][...]), instead of one exchange per step.
+    Ids are needed LOOKAHEAD = 2 * block batches ahead.
 
-    Per owner g a batch may name at most row_cap unique keys.  A batch that names more on ANY rank is detected by the
-    routing itself (the flag travels in the key frames, so all ranks agree) two steps before it is pulled; that batch
-    alone takes ShardedEmbedding's sized exchange (one host read-back), the others keep replaying.  The host reads one
-    pinned word per step, written two steps earlier -- it never waits for the step in flight.
+        fs = FramedStep(emb, max_ids, block=8)
+        fs.start(ids[:fs.LOOKAHEAD])                   # the first LOOKAHEAD batches (fewer if the stream is shorter)
+        rows0 = fs.pull(ids[LOOKAHEAD])                # rows of batch 0; one more batch enters the pipeline
+        fs.push(grads0, lr)                            # batch 0 applied on its owners (rank order)
+        rows1 = fs.pull(ids[LOOKAHEAD + 1]) ...        # ahead ids = None once the stream of batches has ended
+
+    Per owner a batch may name at most row_cap unique keys (default max_ids / W).  A batch that names more on ANY rank
+    is detected by the routing itself (the flag travels in the key frames, so all ranks agree) a block before it is
+    pulled; that batch alone takes ShardedEmbedding's sized exchange (one host read-back), the others keep replaying.
 
     graphs=False enqueues the same kernels and exchanges eagerly (exchanges that cannot be captured: the host-staged
-    all-to-all of the one-GPU multi-rank tests, the CPU engine of the gloo tests)."""
+    all-to-all of the one-GPU multi-rank tests, the CPU engine of the gloo tests).  At world size > 1 the routing runs
+    beside the steps only if the store has a second communicator (side_group=True); otherwise at the block start on
+    the caller's stream."""
 
-    NSLOT = 3
-
-    def __init__(self, emb, max_ids, row_cap=None, graphs=True):
+    def __init__(self, emb, max_ids, row_cap=None, block=8, graphs=True):
         self.emb, self.eng = emb, emb.engine
         w = emb.world
         self.max_ids = int(max_ids)
         self.rcap = int(row_cap) if row_cap is not None else max(-(-self.max_ids // w), 1)
+        self.block = int(block)
+        if self.block < 1:
+            raise ValueError("block must be >= 1")
+        self.LOOKAHEAD = 2 * self.block
         self.graphs = bool(graphs)
-        self.slots = [self.eng.frames_buffers(w, self.rcap, self.max_ids, emb.width) for _ in range(self.NSLOT)]
+        self.blocks = [self.eng.frames_block(w, self.rcap, self.max_ids, self.block) for _ in range(3)]
         m = w * self.rcap
         self.pull_send = self.eng.empty_rows(m, emb.width)
         self.push_send = self.eng.empty_rows(m, emb.width)
         self.pull_recv = self.eng.empty_rows(m, emb.width)
         self.push_recv = self.eng.empty_rows(m, emb.width)
         self.zero_flags = self.eng.zeros((m,), torch.uint8)
+        self.side = w == 1 or emb.side_group is not None
         self._graphs = {}
-        self._ev = {}                # batch index -> event behind the enqueue of its routing
         self.k = None
         self.fallbacks = 0
         emb._frame(self.max_ids)     # the sized path (overflowed batches) agrees on its frame now, on every rank
 
     # -- plumbing ---------------------------------------------------------------------------------------------------
-    def _exchange(self, out, inp):
+    def _exchange(self, out, inp, group=None):
         """Equal-split all-to-all of whole frames; at world size 1 the frames ARE the received frames."""
         if self.emb.world == 1:
             return inp
-        self.emb._a2a(out, inp, None, None)
+        self.emb._a2a(out, inp, None, None, group=group)
         return out
 
-    def _slot(self, j):
-        return self.slots[j % self.NSLOT]
+    def _fb(self, j):
+        blk = self.blocks[(j // self.block) % 3]
+        return blk, blk.slots[j % self.block]
 
-    def _route(self, j):
-        """Enqueue the routing of batch j (its ids are in the slot's static buffer)."""
-        fb = self._slot(j)
-        self.eng.frames_route(fb, self.emb.starts)
-        krecv = self._exchange(fb.krecv, fb.ksend)
-        self.eng.frames_unpack(fb, krecv)
+    def _stage(self, j, ids):
+        """Batch j enters the pipeline.  ids = None: the stream of batches has ended (on every rank); an EMPTY tensor is
+        a batch in which this rank names nothing -- it still takes part in the exchanges."""
+        _, fb = self._fb(j)
+        if ids is None:
+            fb.n, fb.ids, fb.shape, fb.routed = 0, None, (0,), False
+            return
+        if ids.numel() > self.max_ids:
+            raise ValueError("a batch of %d ids exceeds max_ids = %d of this FramedStep" % (ids.numel(), self.max_ids))
+        if ids.dtype not in (torch.float32, torch.int64, torch.uint64):
+            raise TypeError("ids must be float32 or (u)int64")
+        fb.ids, fb.n, fb.shape, fb.routed = ids.reshape(-1), ids.numel(), tuple(ids.shape), True
+
+    def _route_block(self, b):
+        """Enqueue the routing of block b: plans and key frames of its batches, one key exchange, received keys."""
+        import contextlib
+        blk = self.blocks[b % 3]
+        blk.live = any(fb.routed for fb in blk.slots)
+        if not blk.live:
+            blk.ev = None
+            return
+        eng, starts = self.eng, self.emb.starts
+        ctx = eng.on_side(after_current=True) if self.side else contextlib.nullcontext()
+        with ctx:
+            if self.side and hasattr(eng, "hold_for_side"):
+                for fb in blk.slots:
+                    eng.hold_for_side(fb.ids)
+            exchange = lambda out, inp: self._exchange(out, inp, group=self.emb.side_group if self.side else None)
+            if hasattr(eng, "frames_route_block"):
+                eng.frames_route_block(blk, starts, exchange)
+            else:
+                for fb in blk.slots:       # a slot without a batch (the stream ended inside the block): an empty frame
+                    eng.frames_plan(fb, starts)
+                    eng.frames_pack(blk, fb, starts)
+                blk.kgot = exchange(blk.krecv, blk.ksend)
+                for fb in blk.slots:
+                    if fb.routed:
+                        eng.frames_unpack(blk, fb)
+            blk.ev = eng.record()
+        if self.emb.world > 1:
+            per_peer = 4 * self.block * (2 + self.rcap)
+            self.emb.stats["xgmi_bytes_out"] += (self.emb.world - 1) * per_peer
+            self.emb.stats["xgmi_bytes_in"] += (self.emb.world - 1) * per_peer
+
+    def _block_start(self, b):
+        """First step of block b: its routing (enqueued a block ago) must be complete before its first pull; the routing
+        of block b+1 starts beside the steps of block b."""
+        self.eng.wait_event(self.blocks[b % 3].ev)
+        self._route_block(b + 1)
 
     def _pull(self, j, out):
-        fb = self._slot(j)
-        self.eng.frames_serve_pull(self.emb.table, fb, self.pull_send)
+        blk, fb = self._fb(j)
+        self.eng.frames_serve_pull(self.emb.table, blk, fb, self.pull_send)
         got = self._exchange(self.pull_recv, self.pull_send)
         self.eng.frames_expand(got, fb, out)
 
     def _push(self, j, values, scale):
-        fb = self._slot(j)
+        _, fb = self._fb(j)
         self.eng.frames_reduce(fb, values, scale, self.push_send, self.zero_flags)
         got = self._exchange(self.push_recv, self.push_send)
         self.eng.frames_serve_push(self.emb.table, fb, got)
@@ -610,7 +713,7 @@ class FramedStep:
             return
         g = self._graphs.get(key)
         if g is None:
-            if len(self._graphs) >= 256:
+            if len(self._graphs) >= 512:
                 self._graphs.clear()
             self._graphs[key] = False
             fn()
@@ -626,94 +729,108 @@ class FramedStep:
                 return
         g.replay()
 
-    def _stage(self, j, ids):
-        """Batch j enters the pipeline: its ids go to the static buffer of its slot.  ids = None: the stream of batches
-        has ended (on every rank); an EMPTY tensor is a batch in which this rank names nothing -- it still takes part
-        in the exchanges."""
-        fb = self._slot(j)
-        if ids is None:
-            fb.n, fb.cur, fb.shape, fb.routed = 0, None, (0,), False
-            return False
-        if ids.numel() > self.max_ids:
-            raise ValueError("a batch of %d ids exceeds max_ids = %d of this FramedStep" % (ids.numel(), self.max_ids))
-        self.eng.frames_ids(fb, ids)
-        fb.shape = tuple(ids.shape)
-        fb.routed = True
-        return True
-
     def _account(self):
         emb = self.emb
         w = emb.world
         if w > 1:
-            per_peer = 4 * (2 + self.rcap) + 2 * 4 * self.rcap * emb.width     # key frame + pull rows + push rows
+            per_peer = 2 * 4 * self.rcap * emb.width     # pull rows + push rows
             emb.stats["xgmi_bytes_out"] += (w - 1) * per_peer
             emb.stats["xgmi_bytes_in"] += (w - 1) * per_peer
 
     # -- the stream protocol ----------------------------------------------------------------------------------------
-    def start(self, ids0, ids1=None):
-        """Route the first two batches of the stream (ids1 = None: a stream of one batch)."""
+    def start(self, ids_list):
+        """`ids_list`: the first LOOKAHEAD batches of the stream (fewer if the stream is shorter)."""
+        ids_list = list(ids_list)
+        if len(ids_list) > self.LOOKAHEAD:
+            raise ValueError("start takes the first %d batches" % self.LOOKAHEAD)
+        for j in range(3 * self.block):
+            self._stage(j, ids_list[j] if j < len(ids_list) else None)
         self.k = 0
-        self._ev = {}
-        for j, ids in ((0, ids0), (1, ids1)):
-            if self._stage(j, ids):
-                fb = self._slot(j)
-                self._run(("route", j % self.NSLOT, fb.n, fb.cur.dtype), lambda j=j: self._route(j))
-            self._ev[j] = self.eng.record()
+        self._pending = False
+        self._route_block(0)
         return self
 
     def _overflowed(self, j):
-        """Host: did any rank overflow its frames for batch j?  Reads the pinned word its routing wrote (enqueued two
-        steps ago: the wait is for work that is long complete in steady state)."""
-        fb = self._slot(j)
-        if not fb.routed:
-            return False
-        self.eng.host_sync(self._ev.pop(j, None))
+        """Host: did any rank overflow its frames for batch j?  Reads the pinned word its routing wrote (enqueued a
+        block ago: the wait is for work that is long complete in steady state)."""
+        blk, fb = self._fb(j)
+        self.eng.host_sync(blk.ev)
         return self.eng.frames_overflowed(fb)
 
     def pull(self, ahead_ids=None, out=None):
-        """Rows of the current batch k; `ahead_ids` = batch k+2 (routed in the same graph), None at the end."""
+        """Rows of the current batch k; `ahead_ids` = batch k + LOOKAHEAD (None once the stream has ended)."""
         if self.k is None:
             raise RuntimeError("FramedStep.pull before start")
+        if self._pending:
+            raise RuntimeError("FramedStep: pull and push alternate (push the current batch first)")
         k = self.k
-        fb = self._slot(k)
+        blk, fb = self._fb(k)
         if not fb.routed:
             raise RuntimeError("FramedStep.pull: the stream of batches has ended")
+        if k % self.block == 0:
+            self._block_start(k // self.block)
+        self._stage(k + self.LOOKAHEAD, ahead_ids)
         self._over = self._overflowed(k)
-        ahead = self._stage(k + 2, ahead_ids)
-        fa = self._slot(k + 2)
         width = self.emb.width
         if fb.n and out is None:
             out = self.eng.empty_rows(fb.n, width)
         if self._over:
-            # sized exchange for this batch only (collective: every rank saw the flag); the routing ahead still runs
+            # sized exchange for this batch only (a collective: every rank saw the flag)
             self.fallbacks += 1
-            if ahead:
-                self._run(("route", (k + 2) % self.NSLOT, fa.n, fa.cur.dtype), lambda: self._route(k + 2))
-            self._sized = self.emb.prefetch(fb.cur)
+            self._sized = self.emb.prefetch(fb.ids)
             rows = self.emb.pull(route=self._sized, return_route=False)
             if fb.n:
                 out.copy_(rows.reshape(out.shape))
         else:
-            def seg():
-                if ahead:
-                    self._route(k + 2)
-                self._pull(k, out)
-            self._run(("pull", k % self.NSLOT, fb.n, fa.n if ahead else -1, fa.cur.dtype if ahead else None,
-                       out.data_ptr() if fb.n else 0), seg)
+            self._run(("pull", k % (3 * self.block), fb.n, out.data_ptr() if fb.n else 0), lambda: self._pull(k, out))
             self._account()
-        self._ev[k + 2] = self.eng.record()
+        self._pending = True
         return out.reshape(fb.shape + (width,)) if fb.n else None
 
     def push(self, values, lr=None):
         """Apply the gradients `values` of the current batch on its owners (scale -lr; 1 if lr is None)."""
+        if not self._pending:
+            raise RuntimeError("FramedStep: pull and push alternate (pull the current batch first)")
         k = self.k
-        fb = self._slot(k)
+        _, fb = self._fb(k)
         scale = 1.0 if lr is None else -float(lr)
         if self._over:
             self.emb.push(None, values, lr, route=self._sized)
             self._sized = None
         else:
             v = values.reshape(-1, self.emb.width) if fb.n else None
-            self._run(("push", k % self.NSLOT, fb.n, v.data_ptr() if fb.n else 0, scale),
+            self._run(("push", k % (3 * self.block), fb.n, v.data_ptr() if fb.n else 0, scale),
                       lambda: self._push(k, v, scale))
+        self._pending = False
         self.k = k + 1
+
+    # -- measurement aid (bench.py's N>1 leg): the five launches of a step one by one -----------------------------------
+    def kernel_times(self, values, lr, reps=30):
+        """Average duration (us, HIP events on the current stream, `reps` back-to-back launches) of each launch of the
+        CURRENT batch's pull and push, without the exchanges.  Call between a pull and its push; the push launches do
+        apply `values` to the table `reps` times (synthetic benchmarks only)."""
+        if not self._pending:
+            raise RuntimeError("kernel_times: call after pull, before push")
+        k = self.k
+        blk, fb = self._fb(k)
+        eng, emb = self.eng, self.emb
+        out = eng.empty_rows(max(fb.n, 1), emb.width)
+        v = values.reshape(-1, emb.width)
+        scale = 1.0 if lr is None else -float(lr)
+        rows_in = self.pull_send if emb.world == 1 else self.pull_recv
+        grads_in = self.push_send if emb.world == 1 else self.push_recv
+        calls = (("serve_pull (owner gather into row frames)", lambda: eng.frames_serve_pull(emb.table, blk, fb, self.pull_send)),
+                 ("expand (row frames -> positions)", lambda: eng.frames_expand(rows_in, fb, out)),
+                 ("reduce (gradients -> push frames)", lambda: eng.frames_reduce(fb, v, scale, self.push_send, self.zero_flags)),
+                 ("serve_push (sort received keys + rank-ordered apply)", lambda: eng.frames_serve_push(emb.table, fb, grads_in)))
+        res = {}
+        for name, fn in calls:
+            fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            b.synchronize()
+            res[name] = a.elapsed_time(b) * 1e3 / reps
+        return res

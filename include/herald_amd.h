@@ -248,6 +248,12 @@ int ha_plan_sort_u64ids(const uint64_t *ids, int64_t n, void *ws,
  * 2,048 ordered key ranges + stable rank-by-counting inside the ranges, three launches -- instead of the
  * O(n^2) single-launch sort or the three-pass LSD radix sort.  Keys at or above the limit are still sorted
  * correctly (they share the last range).  Identical results. */
+/* The plans of `count` batches (ids[i], n[i] -> ws[i]; host arrays of device pointers): two launches for all of them
+ * when every batch takes the rank-by-counting path (n <= 36,864 and no bucket sort), else one build per batch. */
+int ha_plan_build_batch_f32ids_lim(const float *const *ids, const int64_t *n, void *const *ws, int count,
+                                   uint64_t key_limit, ha_stream_t stream);
+int ha_plan_build_batch_u64ids_lim(const uint64_t *const *ids, const int64_t *n, void *const *ws, int count,
+                                   uint64_t key_limit, ha_stream_t stream);
 int ha_plan_build_f32ids_lim(const float *ids, int64_t n, void *ws, uint64_t key_limit, ha_stream_t stream);
 int ha_plan_sort_f32ids_lim(const float *ids, int64_t n, void *ws, uint64_t key_limit, ha_stream_t stream);
 int ha_plan_build_u64ids_lim(const uint64_t *ids, int64_t n, void *ws, uint64_t key_limit, ha_stream_t stream);
@@ -577,15 +583,35 @@ int ha_shard_route_unpack(const int32_t *recv, int nshard, int64_t cap, int64_t 
  * state = { any rank overflowed, keys received } (device int32[2]).  ha_shard_frames_pack is the second half of
  * ha_shard_frames_route_* for a plan that is already built. */
 int ha_shard_frames_route_f32ids(const float *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
-                                 int nshard, int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap,
-                                 ha_stream_t stream);
+                                 int nshard, int64_t rcap, int64_t frame_stride, int32_t *send, int32_t *rowmap,
+                                 int32_t *posmap, ha_stream_t stream);
 int ha_shard_frames_route_u64ids(const uint64_t *ids, int64_t n, void *plan_ws, const int64_t *starts_host,
-                                 int nshard, int64_t rcap, int32_t *send, int32_t *rowmap, int32_t *posmap,
-                                 ha_stream_t stream);
+                                 int nshard, int64_t rcap, int64_t frame_stride, int32_t *send, int32_t *rowmap,
+                                 int32_t *posmap, ha_stream_t stream);
 int ha_shard_frames_pack(const void *plan_ws, int64_t n, const int64_t *starts_host, int nshard, int64_t rcap,
-                         int32_t *send, int32_t *rowmap, int32_t *posmap, ha_stream_t stream);
-int ha_shard_frames_unpack(const int32_t *recv, int nshard, int64_t rcap, uint32_t *keys_fixed, int32_t *state,
-                           ha_stream_t stream);
+                         int64_t frame_stride, int32_t *send, int32_t *rowmap, int32_t *posmap, ha_stream_t stream);
+int ha_shard_frames_unpack(const int32_t *recv, int nshard, int64_t rcap, int64_t frame_stride, uint32_t *keys_fixed,
+                           int32_t *state, ha_stream_t stream);
+/* A block of batches in one launch each (the plans by ha_plan_build_batch_*): batch i's frames start
+ * i * (2 + rcap) words into every owner's stride, rowmap / posmap / keys_fixed / state are per-batch arrays of `count`
+ * device pointers given on the host. */
+int ha_shard_frames_pack_batch(const void *const *plan_ws, const int64_t *n, int count, const int64_t *starts_host,
+                               int nshard, int64_t rcap, int64_t frame_stride, int32_t *send, int32_t *const *rowmap,
+                               int32_t *const *posmap, ha_stream_t stream);
+int ha_shard_frames_unpack_batch(const int32_t *recv, int count, int nshard, int64_t rcap, int64_t frame_stride,
+                                 uint32_t *const *keys_fixed, int32_t *const *state, ha_stream_t stream);
+/* frame_stride: int32 words between the frames of consecutive owners, >= 2 + rcap.  With 2 + rcap the frames of one
+ * batch are contiguous; a larger stride interleaves the frames of SEVERAL batches per owner, [owner][batch][2 + rcap],
+ * so that the key frames of a block of batches travel in one equal-split all-to-all (herald_amd/sharded.py routes a
+ * block of batches at a time, ahead of the steps that use them).
+ * ha_shard_frames_serve_pull: ha_shard_frames_unpack and the owner-side gather of a pull in ONE launch
+ * (PSHandler::serve(SparsePull), ps-lite/include/ps/server/PSFHandle.h:101-128): rows_out[g * rcap + j, :] =
+ * table[key j of rank g, :] for the live slots (unused slots are not written), keys_fixed and state as
+ * ha_shard_frames_unpack.  `state` may be pinned host memory: the host then reads the overflow word without a copy
+ * in the stream. */
+int ha_shard_frames_serve_pull(const float *table, int64_t rows, int64_t width, const int32_t *recv, int nshard,
+                               int64_t rcap, int64_t frame_stride, float *rows_out, uint32_t *keys_fixed,
+                               int32_t *state, ha_stream_t stream);
 
 /* Owner side of a sparse push (PSHandler::serve(SparsePush), ps-lite/include/ps/server/PSFHandle.h:130-164):
  * table[keys[j],:] = (table[keys[j],:] + values[a,:]) + values[b,:] ... over the positions a < b < ... that
@@ -593,6 +619,13 @@ int ha_shard_frames_unpack(const int32_t *recv, int nshard, int64_t rcap, uint32
  * plan_ws: ha_plan_bytes(n) of scratch. */
 int ha_shard_serve_push(float *table, int64_t rows, int64_t width, const uint32_t *keys,
                         int64_t n, const float *values, void *plan_ws, ha_stream_t stream);
+
+/* ha_shard_serve_push for the received frames of a framed push: keys_fixed = nshard lists of rcap slots in rank order,
+ * each ascending with 0xFFFFFFFF in the unused slots (ha_shard_frames_unpack), values[nshard * rcap, width] the row
+ * frames.  The lists are merged (stable: equal keys in rank order) instead of sorted; plan_ws: ha_plan_bytes(nshard *
+ * rcap). */
+int ha_shard_frames_serve_push(float *table, int64_t rows, int64_t width, const uint32_t *keys_fixed, int nshard,
+                               int64_t rcap, const float *values, void *plan_ws, ha_stream_t stream);
 
 /* ---- HET embedding cache (replaces the hetu_cache plugin, src/hetu_cache) ----
  * An opaque device-resident cache of `limit` lines in front of a store (the "server": a table shard

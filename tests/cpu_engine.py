@@ -101,24 +101,26 @@ class CpuEngine:
             t[k] = t[k] + v[j]
 
     # -- fixed frames (herald_amd.sharded.FramedStep; same contract as HipEngine.frames_*) ---------------------------
-    def frames_buffers(self, w, rcap, n_cap, width):
-        from herald_amd.sharded import FrameBuffers
-        fb = FrameBuffers()
-        fb.w, fb.rcap, fb.n_cap = w, rcap, n_cap
-        fb.ksend = torch.zeros((w, 2 + rcap), dtype=torch.int32)
-        fb.krecv = torch.zeros((w, 2 + rcap), dtype=torch.int32)
-        fb.keys_fixed = torch.zeros(w * rcap, dtype=torch.int32)
-        fb.state_host = torch.zeros(2, dtype=torch.int32)
-        fb.n, fb.cur, fb.shape, fb.routed = 0, None, (0,), False
-        return fb
+    def frames_block(self, w, rcap, n_cap, block):
+        from herald_amd.sharded import FrameBlock, FrameBuffers
+        blk = FrameBlock()
+        blk.ksend = torch.full((w, block, 2 + rcap), -99, dtype=torch.int32)
+        blk.krecv = torch.full((w, block, 2 + rcap), -99, dtype=torch.int32)
+        blk.kgot, blk.ev, blk.live, blk.slots = None, None, False, []
+        for i in range(block):
+            fb = FrameBuffers()
+            fb.i, fb.w, fb.rcap = i, w, rcap
+            fb.keys_fixed = torch.zeros(w * rcap, dtype=torch.int32)
+            fb.state_host = torch.zeros(2, dtype=torch.int32)
+            fb.n, fb.ids, fb.shape, fb.routed = 0, None, (0,), False
+            blk.slots.append(fb)
+        return blk
 
-    def frames_ids(self, fb, ids):
-        fb.cur = ids.reshape(-1).clone()
-        fb.n = fb.cur.numel()
-        return fb.cur
+    def frames_plan(self, fb, starts):
+        fb.plan = _Plan(fb.ids if fb.n else torch.zeros(0))
 
-    def frames_route(self, fb, starts):
-        plan = fb.plan = _Plan(fb.cur)
+    def frames_pack(self, blk, fb, starts):
+        plan = fb.plan
         st = np.asarray(starts, dtype=np.uint64)
         off = np.searchsorted(plan.uniq, st, side="left").astype(np.int64)
         off[-1] = plan.uniq.size
@@ -131,12 +133,12 @@ class CpuEngine:
             c = int(min(cnt[g], fb.rcap))
             send[g, 2:2 + c] = (plan.uniq[off[g]:off[g] + c] - st[g]).astype(np.int32)
             rowmap[off[g]:off[g] + c] = g * fb.rcap + np.arange(c)
-        fb.ksend.copy_(torch.from_numpy(send))
+        blk.ksend[:, fb.i, :] = torch.from_numpy(send)
         fb.rowmap = rowmap
         fb.posmap = rowmap[plan.inv] if plan.n else np.zeros(0, np.int64)
 
-    def frames_unpack(self, fb, krecv):
-        r = krecv.numpy()
+    def frames_unpack(self, blk, fb):
+        r = blk.kgot[:, fb.i, :].numpy()
         keys = np.full(fb.w * fb.rcap, -1, dtype=np.int32)
         over = 0
         for g in range(fb.w):
@@ -150,12 +152,11 @@ class CpuEngine:
     def frames_overflowed(self, fb):
         return bool(fb.state_host[0].item())
 
-    def frames_serve_pull(self, table, fb, rows_send):
+    def frames_serve_pull(self, table, blk, fb, rows_send):
+        self.frames_unpack(blk, fb)            # the HIP kernel rewrites keys_fixed / state as well
         t, k = table.numpy(), fb.keys_fixed.numpy()
-        out = rows_send.numpy()
-        out[:] = 0
         live = k >= 0
-        out[live] = t[k[live].astype(np.int64)]
+        rows_send.numpy()[live] = t[k[live].astype(np.int64)]      # unused slots are not written
 
     def frames_expand(self, rows_recv, fb, out):
         if fb.n:

@@ -32,27 +32,29 @@ def _stream(rows, n, nb, kind, seed=0):
     return out
 
 
-@pytest.mark.parametrize("rows,width,n,kind,graphs", [(50000, 128, 6656, "criteo", True), (50000, 128, 6656, "criteo", False),
-                                                      (3000, 64, 900, "mixed", True), (200, 32, 40, "mixed", True)])
-def test_framed_step_world1_replays_from_graphs(dev, rows, width, n, kind, graphs):
+@pytest.mark.parametrize("rows,width,n,kind,graphs,block", [(50000, 128, 6656, "criteo", True, 4), (50000, 128, 6656, "criteo", False, 4),
+                                                            (3000, 64, 900, "mixed", True, 2), (200, 32, 40, "mixed", True, 1),
+                                                            (3000, 64, 900, "mixed", True, 16)])
+def test_framed_step_world1_replays_from_graphs(dev, rows, width, n, kind, graphs, block):
     """World size 1: pull and push of every step replay from hipGraphs (three routing slots -> three graphs of each
     kind for a fixed set of buffers); every pulled row and the table after every push equal the oracle's."""
     from herald_amd.sharded import FramedStep, ShardedEmbedding
-    nb = 12
+    nb = 9 * block + 3 if block < 16 else 20
     ids = _stream(rows, n, nb, kind)
     n = ids[0].size
     rng = np.random.default_rng(5)
     table = rng.standard_normal((rows, width), dtype=np.float32)
     emb = ShardedEmbedding(rows, width, dev, table=torch.from_numpy(table.copy()).to(dev))
-    fs = FramedStep(emb, n, graphs=graphs)
+    fs = FramedStep(emb, n, graphs=graphs, block=block)
+    LA = fs.LOOKAHEAD
     d_ids = [torch.from_numpy(x).to(dev) for x in ids]
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(3)]
     d_grads = [torch.from_numpy(g).to(dev) for g in grads]
     outs = [torch.empty((n, width), device=dev) for _ in range(3)]
     want = table.copy()
-    fs.start(d_ids[0], d_ids[1])
+    fs.start(d_ids[:LA])
     for k in range(nb):
-        got = fs.pull(d_ids[k + 2] if k + 2 < nb else None, out=outs[k % 3])
+        got = fs.pull(d_ids[k + LA] if k + LA < nb else None, out=outs[k % 3])
         torch.cuda.synchronize()
         np.testing.assert_array_equal(got.cpu().numpy().reshape(n, width), want[ids[k].astype(np.int64)],
                                       err_msg="pull of step %d" % k)
@@ -61,7 +63,7 @@ def test_framed_step_world1_replays_from_graphs(dev, rows, width, n, kind, graph
         torch.cuda.synchronize()
         np.testing.assert_array_equal(emb.table.cpu().numpy(), want, err_msg="table after step %d" % k)
     assert fs.fallbacks == 0
-    if graphs:
+    if graphs and block < 16:
         assert fs.graphs and sum(1 for g in fs._graphs.values() if g) >= 6, fs._graphs
 
 
@@ -75,15 +77,16 @@ def test_framed_step_overflow_takes_the_sized_exchange(dev):
     rng = np.random.default_rng(6)
     table = rng.standard_normal((rows, width), dtype=np.float32)
     emb = ShardedEmbedding(rows, width, dev, table=torch.from_numpy(table.copy()).to(dev))
-    fs = FramedStep(emb, n, row_cap=64)
+    fs = FramedStep(emb, n, row_cap=64, block=2)
+    LA = fs.LOOKAHEAD
     d_ids = [torch.from_numpy(x).to(dev) for x in ids]
     want = table.copy()
     for_u64 = torch.from_numpy(ids[4].astype(np.int64)).to(dev)     # a uint64-keyed batch in the same stream
     d_ids[4] = for_u64
-    fs.start(d_ids[0], d_ids[1])
+    fs.start(d_ids[:LA])
     for k in range(nb):
         g = rng.standard_normal((n, width), dtype=np.float32)
-        got = fs.pull(d_ids[k + 2] if k + 2 < nb else None)
+        got = fs.pull(d_ids[k + LA] if k + LA < nb else None)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(got.cpu().numpy().reshape(n, width), want[ids[k].astype(np.int64)])
         fs.push(torch.from_numpy(g).to(dev), 0.1)
@@ -127,14 +130,15 @@ def _worker(rank, world, port, rows, width, n, kind, row_cap, expect_fallback):
     nn = streams[0][0].size
     if world > 2:
         streams[world - 1][2] = streams[world - 1][2][:0]             # an empty batch on the last rank
-    fs = FramedStep(emb, nn, row_cap=row_cap, graphs=False)          # the host-staged exchange cannot be captured
+    fs = FramedStep(emb, nn, row_cap=row_cap, block=2, graphs=False)  # the host-staged exchange cannot be captured
     tid = lambda k: torch.from_numpy(streams[rank][k]).to(dev) if k < nb else None
-    fs.start(tid(0), tid(1))
+    LA = fs.LOOKAHEAD
+    fs.start([tid(k) for k in range(LA)])
     want = table_g.copy()
     for k in range(nb):
         vals = [np.random.default_rng(500 + k * world + r).standard_normal((streams[r][k].size, width), dtype=np.float32)
                 for r in range(world)]
-        got = fs.pull(tid(k + 2))
+        got = fs.pull(tid(k + LA))
         torch.cuda.synchronize()
         mine = streams[rank][k]
         if mine.size:

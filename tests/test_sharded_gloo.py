@@ -124,7 +124,7 @@ def test_sharded_pull_push_gloo(tmp_path, world, rows, width, n, side_group):
              join=True)
 
 
-def _framed_worker(rank, world, port, rows, width, n, row_cap, expect_fallback):
+def _framed_worker(rank, world, port, rows, width, n, row_cap, block, expect_fallback):
     """FramedStep (fixed frames, no host-known counts) under gloo: a stream of batches with keys shared between the
     ranks, runs inside a rank, an empty batch on the last rank and -- with a small row_cap -- batches that overflow
     their frames on SOME rank and must take the sized exchange on ALL ranks."""
@@ -157,13 +157,14 @@ def _framed_worker(rank, world, port, rows, width, n, row_cap, expect_fallback):
             per.append(ids)
         batches.append(per)
         vals.append([rng.standard_normal((b.size, width), dtype=np.float32) for b in per])
-    fs = FramedStep(emb, n, row_cap=row_cap, graphs=False)
+    fs = FramedStep(emb, n, row_cap=row_cap, block=block, graphs=False)
     tid = lambda k: torch.from_numpy(batches[k][rank]) if k < nb else None
-    fs.start(tid(0), tid(1))
+    LA = fs.LOOKAHEAD
+    fs.start([tid(k) for k in range(min(LA, nb))])
     want = table_g.copy()
     lr = 0.05
     for k in range(nb):
-        got = fs.pull(tid(k + 2))
+        got = fs.pull(tid(k + LA))
         ids = batches[k][rank]
         if ids.size:
             np.testing.assert_array_equal(got.numpy().reshape(-1, width), want[ids.astype(np.int64)],
@@ -184,12 +185,13 @@ def _framed_worker(rank, world, port, rows, width, n, row_cap, expect_fallback):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rows,width,n,row_cap,expect_fallback",
-                         [(2, 1001, 8, 120, None, True),       # default row_cap = n / W: batch 4 overflows owner 0
-                          (2, 1001, 8, 120, 120, False),       # row_cap = n can never overflow
-                          (3, 700, 4, 90, 40, True)])
-def test_framed_step_gloo(world, rows, width, n, row_cap, expect_fallback):
-    mp.spawn(_framed_worker, args=(world, _free_port(), rows, width, n, row_cap, expect_fallback), nprocs=world,
+@pytest.mark.parametrize("world,rows,width,n,row_cap,block,expect_fallback",
+                         [(2, 1001, 8, 120, None, 2, True),    # default row_cap = n / W: batch 4 overflows owner 0
+                          (2, 1001, 8, 120, 120, 1, False),    # row_cap = n can never overflow; blocks of one batch
+                          (3, 700, 4, 90, 40, 4, True),        # the stream ends inside a block
+                          (2, 1001, 8, 120, 120, 8, False)])   # the whole stream is shorter than the lookahead
+def test_framed_step_gloo(world, rows, width, n, row_cap, block, expect_fallback):
+    mp.spawn(_framed_worker, args=(world, _free_port(), rows, width, n, row_cap, block, expect_fallback), nprocs=world,
              join=True)
 
 

@@ -38,7 +38,7 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
                 s = k.setdefault(counter, [0.0, 0])
                 s[0] += float(r["Counter_Value"])
                 s[1] += 1
-out = {"note": "rocprofv3 --pmc passes (separate runs) of `bench.py --steps 64 --warmup 32 --graph-steps 1`; "
+out = {"note": "rocprofv3 --pmc passes (separate runs) of the bench command of the calling script (tools/profile_round.sh, tools/profile_sharded.sh); "
                "FETCH_SIZE / WRITE_SIZE are per-dispatch means in KB as reported; hbm_bytes_per_launch applies "
                "the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced "
                "read): 2*FETCH + WRITE",
