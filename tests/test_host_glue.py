@@ -1,6 +1,8 @@
 """Host-side glue that needs no GPU: LAIAScheduler's window over the native scheduler's stream
 (python/hetu/laia/laia_dataloader.py:29-169) and CacheSparseTable's helper surface (python/hetu/cstable.py:170-248),
 driven by in-process doubles of the native objects."""
+import os
+
 import numpy as np
 import pytest
 
@@ -145,3 +147,46 @@ def test_cache_sparse_table_helper_surface():
     empty = hcache.CacheSparseTable.wrap(_FakeCache())
     empty.cache.perf = []
     assert empty.overall_miss_rate() == -1 and empty.overall_data_rate() == -1
+
+
+def test_bench_gpus_2_starts_two_children_and_the_parent_never_touches_the_gpu(monkeypatch):
+    """`python bench.py --gpus 2` without a launcher: the parent starts one fresh child per rank (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous, the same command line) and waits for them; it makes no GPU call
+    itself (every torch.cuda entry point is booby-trapped here) and does not re-exec."""
+    import importlib
+    import subprocess
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    started = []
+
+    class Child:
+        def __init__(self, cmd, env=None, **kw):
+            started.append((cmd, env))
+
+        def wait(self):
+            return 0
+
+    def trap(*a, **k):
+        raise AssertionError("the parent touched the GPU")
+
+    monkeypatch.setattr(subprocess, "Popen", Child)
+    for name in ("set_device", "is_available", "current_stream", "synchronize", "init", "Stream", "Event"):
+        monkeypatch.setattr(torch.cuda, name, trap)
+    monkeypatch.setattr(os, "execv", trap)
+    monkeypatch.setattr(os, "execve", trap)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "7", "--warmup", "3"])
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(v, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    assert len(started) == 2
+    ports = set()
+    for r, (cmd, env) in enumerate(started):
+        assert cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "2", "--steps", "7", "--warmup", "3"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"]) == (str(r), str(r), "2")
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        ports.add(env["MASTER_PORT"])
+    assert len(ports) == 1
