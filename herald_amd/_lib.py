@@ -143,6 +143,8 @@ def _declare(L):
         "ha_shard_frames_route_u64ids": [vp, i64, vp, vp, c.c_int, i64, i64, vp, vp, vp, vp],
         "ha_shard_frames_pack": [vp, i64, vp, c.c_int, i64, i64, vp, vp, vp, vp],
         "ha_shard_frames_unpack": [vp, c.c_int, i64, i64, vp, vp, vp],
+        "ha_set_tolerance_mode": [c.c_int],
+        "ha_get_tolerance_mode": [],
         "ha_shard_frames_serve_push": [vp, i64, i64, vp, c.c_int, i64, vp, vp, vp],
         "ha_shard_frames_pack_batch": [vp, vp, c.c_int, vp, c.c_int, i64, i64, vp, vp, vp, vp],
         "ha_shard_frames_unpack_batch": [vp, c.c_int, c.c_int, i64, i64, vp, vp, vp],

@@ -48,15 +48,17 @@ __global__ __launch_bounds__(1024, 8) void bwd_fused_kernel(
     PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq,
     int32_t *__restrict__ seg, int32_t *__restrict__ counts,
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos, int n_finish_blocks,
-    const float *__restrict__ pf_ids, int pf_n) {
+    const float *__restrict__ pf_ids, int pf_n, int tree_from) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const int b = blockIdx.x;
     if (b < n_finish_blocks) {
         finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, b, s_dyn);
         return;
     }
+    ApplyMaps maps{};
+    maps.tree_from = tree_from;
     const bool heavy = apply_body<MODE, VEC>(dst, dst_rows, width, sorted, perm, nullptr, n,
-                                             grads, lr, b - n_finish_blocks, s_dyn);
+                                             grads, lr, b - n_finish_blocks, s_dyn, nullptr, maps);
     if (VEC == 4 && pf_ids != nullptr && !heavy) {
         const int p = (b - n_finish_blocks) * kPosPerBlock + static_cast<int>(threadIdx.x >> 6);
         if (p < pf_n) {
@@ -203,12 +205,12 @@ static int apply_finish(float *dst, int64_t rows, int64_t width, void *plan_ws,
         hipLaunchKernelGGL((bwd_fused_kernel<MODE, 4>), dim3(blocks), dim3(1024), lds,
                            stream, dst, (uint64_t)rows, (int)width, p.sorted, p.perm,
                            ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, fblocks,
-                           pf_ids, (int)(pf_n < n ? pf_n : n));
+                           pf_ids, (int)(pf_n < n ? pf_n : n), tolerance_tree_from());
     else
         hipLaunchKernelGGL((bwd_fused_kernel<MODE, 1>), dim3(blocks), dim3(1024), lds,
                            stream, dst, (uint64_t)rows, (int)width, p.sorted, p.perm,
                            ni, grads, lr, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, fblocks,
-                           pf_ids, (int)(pf_n < n ? pf_n : n));
+                           pf_ids, (int)(pf_n < n ? pf_n : n), tolerance_tree_from());
     HA_LAUNCH_CHECK();
     return 0;
 }

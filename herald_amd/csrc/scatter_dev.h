@@ -31,7 +31,14 @@ struct ApplyMaps {
     float *opt_s1, *opt_s2;
     int opt_kind;
     OptArgs oa;
+    // tolerance mode (ha_set_tolerance_mode): runs of at least this many occurrences (0 = never) are applied as
+    // `row - tree_sum(lr * g)` in a fixed order instead of the serial chain (coop_slice_tree below)
+    int tree_from;
 };
+
+// host: the run length from which the tolerance mode applies (0 = exact everywhere; scatter.hip,
+// ha_set_tolerance_mode)
+int tolerance_tree_from();
 
 // second destination row of the current key (on == false: none)
 struct Second {
@@ -395,6 +402,74 @@ __device__ __forceinline__ float chain_step(float acc, float m) {
     return MODE == kModeSgd ? __fsub_rn(acc, m) : __fadd_rn(acc, m);
 }
 
+// Tolerance mode of a long run (BASELINE.json's north star allows 1e-5 relative on accumulated gradients and names
+// wavefront segmented reduce for gradient coalescing): ONE 64-column slice by a whole workgroup, no ordered chain.
+// lane = (row r of 4, column quad c4 of 16); wave w takes occurrences 16w .. 16w+15 of every block of 256 (four
+// 16-byte loads per lane and block) and sums lr * g over them in order; the four lane groups meet as (p0 + p1) +
+// (p2 + p3), the 16 wave partials through LDS as quads (a + b) + (c + d) and (q0 + q1) + (q2 + q3); one subtract /
+// add per element.  The same order as q_coop of qstep.hip -- oracle/qstep_model.py tree_coop restates it bit for bit.
+// s_part = 16 x 64 floats.  Called by all 16 waves; needs width % 4 == 0 and 16-byte aligned rows.
+template <int MODE>
+__device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, bool init, const float *__restrict__ grads,
+                                                const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr,
+                                                int s, int len, int width, int slice, int w, float *s_part) {
+    const int lane = lane_id();
+    const int r = lane >> 4, c4 = lane & 15;
+    const int col0 = slice * kWave;
+    const bool act = col0 + 4 * c4 < width;
+    const int col = act ? col0 + 4 * c4 : col0;
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (MODE != kModeReduce && init)
+        cur = *reinterpret_cast<const float4v *>(dst_row + col);
+    float4v p{0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < len; base += 256) {
+        const int mine = base + 16 * w;   // this wave's first occurrence of the block
+        if (mine >= len)
+            break;   // wave-uniform; no barrier inside the loop
+        int pidx = perm[min(s + min(mine + (lane & 15), len - 1), n - 1)];
+        if (maps.valmap)
+            pidx = maps.valmap[pidx];
+        float4v g[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int o = __shfl(pidx, 4 * t + r, 64);
+            g[t] = *reinterpret_cast<const float4v *>(grads + static_cast<size_t>(o) * width + col);   // clamped: branch-free
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool valid = mine + 4 * t + r < len;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float q = __fadd_rn(p[k], __fmul_rn(lr, g[t][k]));
+                p[k] = valid ? q : p[k];
+            }
+        }
+    }
+    auto add4 = [](float4v x, float4v y) {
+        return float4v{__fadd_rn(x[0], y[0]), __fadd_rn(x[1], y[1]), __fadd_rn(x[2], y[2]), __fadd_rn(x[3], y[3])};
+    };
+    auto xor4 = [](float4v v, int m) {
+        return float4v{__shfl_xor(v[0], m, 64), __shfl_xor(v[1], m, 64), __shfl_xor(v[2], m, 64), __shfl_xor(v[3], m, 64)};
+    };
+    p = add4(p, xor4(p, 16));
+    p = add4(p, xor4(p, 32));
+    if (lane < 16)
+        *reinterpret_cast<float4v *>(s_part + w * 64 + 4 * c4) = p;
+    __syncthreads();
+    const float *sp = s_part + (4 * r) * 64 + 4 * c4;
+    float4v total = add4(add4(*reinterpret_cast<const float4v *>(sp), *reinterpret_cast<const float4v *>(sp + 64)),
+                         add4(*reinterpret_cast<const float4v *>(sp + 128), *reinterpret_cast<const float4v *>(sp + 192)));
+    total = add4(total, xor4(total, 16));
+    total = add4(total, xor4(total, 32));
+    float4v nv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        nv[k] = MODE == kModeSgd ? __fsub_rn(cur[k], total[k]) : __fadd_rn(cur[k], total[k]);
+    if (w == 0 && r == 0 && act)
+        __builtin_nontemporal_store(nv, reinterpret_cast<float4v *>(dst_row + col));
+    __syncthreads();   // s_part is reused by the next slice of this workgroup
+}
+
 // The worker part of a long run [s, s+len): this workgroup owns the 64-column slices j, j+workers, ...
 // All 16 waves call it (workgroup barriers inside); s_m = kCoopUnits x 64 floats of LDS.
 template <int MODE, bool DUAL, int HAND = kHandNone>
@@ -406,6 +481,12 @@ __device__ __forceinline__ void coop_slices(
     const int lane = lane_id();
     const int nslice = (width + kWave - 1) / kWave;
     const int my_slices = (nslice - j + workers - 1) / workers;  // slices j, j+workers, ...
+    if (!DUAL && HAND == kHandNone && MODE != kModeOpt && maps.tree_from > 0 && len >= maps.tree_from &&
+        (width & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst_row) | reinterpret_cast<uintptr_t>(grads)) & 15) == 0) {
+        for (int g0 = 0; g0 < my_slices; ++g0)   // every condition above is uniform over the workgroup
+            coop_slice_tree<MODE>(dst_row, init, grads, perm, maps, n, lr, s, len, width, j + g0 * workers, w, s_m);
+        return;
+    }
     // destinations of the key in the next batch, wave w takes w, w + 16, ...: looked up before the chain (two
     // dependent reads that would otherwise follow it)
     Fwd fw{0, 0, 0};

@@ -78,6 +78,17 @@ class DLStreamHolder:
         return ctypes.byref(self.s)
 
 
+# ---- tolerance mode --------------------------------------------------------------------------------------
+def set_tolerance_mode(on):
+    """Process-wide (include/herald_amd.h, ha_set_tolerance_mode): runs of 64 or more occurrences of a key are applied
+    as `row - tree_sum(lr * g)` in a fixed order (within BASELINE.json's 1e-5 on accumulated gradients) instead of the
+    reference's serial chain; shorter runs stay bit-exact.  Default off.  Returns the previous setting."""
+    L = _lib.load()
+    prev = bool(L.ha_get_tolerance_mode())
+    check(L.ha_set_tolerance_mode(1 if on else 0), "ha_set_tolerance_mode")
+    return prev
+
+
 # ---- forward gather ----------------------------------------------------------------------------------
 def embedding_lookup(table, ids, out=None, stream=None):
     """out[..., :] = table[(size_t)ids[...], :]; ids float32 (operator boundary) or int64/uint64 keys."""

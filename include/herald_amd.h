@@ -174,6 +174,16 @@ int cpu_SGDOptimizerSparseUpdate(DLArrayHandle param,
  *     unless a parameter name ends in _host.
  * ========================================================================= */
 
+/* Tolerance mode (process-wide, default off).  Off: every sparse update is the reference's serial chain, occurrence by
+ * occurrence (cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:65-72), bit for bit.  On: runs of 64 or more
+ * occurrences of one key in a batch are applied as `row - tree_sum(lr * g)` in a fixed, deterministic order -- within
+ * the 1e-5 relative BASELINE.json's north star allows for accumulated fp32 gradients; shorter runs stay bit-exact.
+ * Read at launch time by ha_sgd_apply*, ha_push_apply*, ha_dedup_reduce*, ha_apply_mapped, ha_shard_serve_push and the
+ * entry points built on them (not by ha_sgd_push_pull_* / ha_step_*, which are bit-exact throughout, nor by
+ * ha_qstep_* / ha_qapply, which have their own documented tolerance classes). */
+int ha_set_tolerance_mode(int on);
+int ha_get_tolerance_mode(void);
+
 /* ---- forward gather (replaces cpu_EmbeddingLookup / embedding_lookup_kernel) */
 /* out[i,:] = table[(size_t)ids[i],:], ids float32.  width % 4 == 0 takes the
  * 16-byte vector path; any width >= 1 is supported.                          */

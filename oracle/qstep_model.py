@@ -54,36 +54,52 @@ def tree_coop(rows_g, lr):
     return (((quad[0] + quad[1]).astype(F)) + ((quad[2] + quad[3]).astype(F))).astype(F)
 
 
-def sgd_sparse_update(table, ids, grads, lr):
+def sgd_sparse_update(table, ids, grads, lr, long_min=LONG_MIN, coop_min=COOP_MIN, mode="sgd"):
     """In place: table after one ha_qstep apply of (ids, grads).  ids: integer array (keys beyond the table are
-    ignored, as by the library)."""
+    ignored, as by the library).
+
+    long_min=None, coop_min=64 restates the library's TOLERANCE MODE (ha_set_tolerance_mode, csrc/scatter_dev.h
+    coop_slice_tree: the same tree as ha_qstep's workgroup items, from 64 occurrences; everything shorter is the
+    serial chain).  mode: "sgd" row - sum(lr*g) / chain row -= lr*g;  "push" row + sum(g) (lr is ignored: the
+    library reduces from 0 in order, then adds once -- ha_push_apply);  the reduced rows of ha_dedup_reduce_scaled
+    are mode="push" on a zero table with grads pre-scaled."""
     ids = np.asarray(ids).reshape(-1).astype(np.int64)
     grads = np.asarray(grads, dtype=F).reshape(ids.size, -1)
     order = np.argsort(ids, kind="stable")
     sk = ids[order]
     starts = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]]) if ids.size else np.zeros(0, np.int64)
     ends = np.r_[starts[1:], ids.size]
+    one = F(1.0) if mode == "push" else F(lr)
     for s, e in zip(starts, ends):
         key = int(sk[s])
         if key < 0 or key >= table.shape[0]:
             continue
         occ = order[s:e]                      # occurrence order (stable sort)
         c = e - s
-        if c < LONG_MIN:
+        if c >= coop_min:
+            t = tree_coop(grads[occ], one)
+        elif long_min is not None and c >= long_min:
+            t = tree_long(grads[occ], one)
+        else:
+            t = None
+        if t is not None:
+            table[key] = (table[key] - t).astype(F) if mode == "sgd" else (table[key] + t).astype(F)
+        elif mode == "sgd":
             row = table[key].copy()
             for i in occ:
                 row = (row - (F(lr) * grads[i]).astype(F)).astype(F)
             table[key] = row
-        elif c < COOP_MIN:
-            table[key] = (table[key] - tree_long(grads[occ], lr)).astype(F)
         else:
-            table[key] = (table[key] - tree_coop(grads[occ], lr)).astype(F)
+            acc = np.zeros(table.shape[1], F)
+            for i in occ:
+                acc = (acc + grads[i]).astype(F)
+            table[key] = (table[key] + acc).astype(F)
     return table
 
 
-def tolerance(ids, grads, lr, rows, rel=1e-5):
+def tolerance(ids, grads, lr, rows, rel=1e-5, tree_min=LONG_MIN):
     """Per-row absolute bound of the difference between the tree mode and the serial chain: `rel` x the accumulated
-    gradient magnitude lr * sum_i |g_i| of the row's key (zero for keys below LONG_MIN occurrences: exact)."""
+    gradient magnitude lr * sum_i |g_i| of the row's key (zero for keys below `tree_min` occurrences: exact)."""
     ids = np.asarray(ids).reshape(-1).astype(np.int64)
     g = np.abs(np.asarray(grads, dtype=F).reshape(ids.size, -1)).astype(np.float64)
     ok = (ids >= 0) & (ids < rows)
@@ -91,5 +107,5 @@ def tolerance(ids, grads, lr, rows, rel=1e-5):
     for k in np.unique(ids[ok]):
         sel = ids == k
         cnt = int(sel.sum())
-        tol[int(k)] = (rel * lr * g[sel].sum(axis=0)) if cnt >= LONG_MIN else np.zeros(g.shape[1])
+        tol[int(k)] = (rel * lr * g[sel].sum(axis=0)) if cnt >= tree_min else np.zeros(g.shape[1])
     return tol

@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from herald_amd import ops, synth
 dev = torch.device("cuda:0")
+if os.environ.get("TOL") == "1":
+    ops.set_tolerance_mode(True)       # runs of 64+ occurrences as a fixed-order tree sum (BASELINE.json's 1e-5)
+print("tolerance mode:", bool(__import__("herald_amd._lib", fromlist=["x"]).load().ha_get_tolerance_mode()))
 rows, width, bs = 33762577, int(os.environ.get("WIDTH", "128")), int(os.environ.get("BATCH", "4096"))
 n = bs * 26
 table = torch.empty((rows, width), device=dev)
