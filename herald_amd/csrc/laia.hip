@@ -352,6 +352,618 @@ __global__ __launch_bounds__(256) void laia_delta_kernel(const uint32_t *__restr
         valid[dkeys[e]] = dvals[e];
 }
 
+// =====================================================================================================
+// Device-resident scheduler state (round 3): the MiniLRU snapshots, the greedy assignment and the sorted-unique
+// key lists on the GPU -- per global batch the host only launches kernels and receives `dist` and the plans.
+// Semantics: LaiaScheduler::get_dist + the snapshot update of launch() (laia/src/laia_scheduler.cc:146-271),
+// MiniLRUCache get / insert / outdate (laia/include/mini_lru_cache.h:54-128).
+//
+//  * assignment (laia_scheduler.cc:226-249: samples in order, strictly greater score wins among the workers that
+//    still have quota, visited in the order (j + batch_id) % W): until a worker's quota fills every sample's choice
+//    is independent of the others, so ONE workgroup runs rounds of { argmax over the available workers, prefix
+//    counts per worker, first sample at which a quota fills }: at most W + 1 rounds instead of B dependent steps.
+//  * sorted-unique (worker, row) lists without a sort: laia_bits_kernel sets one bit per touched / plan pair in two
+//    bitmaps over W x Rpad rows (and one bit per non-empty 64-bit word in a summary), and an ordered compaction of
+//    the summary (count, scan, emit -- which also clears what it read) yields the rows ascending per worker.
+//  * MiniLRU per worker as a stamp log (as the host Snapshot above and cache.hip): stamp[w][row] (0 = absent), a
+//    ring log of (row, stamp), valid bytes = the device mirror the probe reads.  A batch's get()s come in ascending
+//    row order and the rows are distinct, so row i of n ends with stamp counter + i + 1 whatever happens; what has
+//    to be worked out is the eviction victims.  With live0 lines resident, A rows of the batch absent at its start
+//    and capacity cap (>= n, checked at creation): exactly N = max(0, live0 + A - cap) lines that are NOT in the
+//    batch are evicted -- the first N such live log entries from the head -- independent of the order of events.
+//    A line that IS in the batch can be evicted before its turn and re-inserted (one more miss, one more eviction);
+//    going through the batch lines among the first entries in log order: line j at batch position p is evicted
+//    early iff  live0 + A(p-1) + EB(p-1) - cap >= 1 + (non-batch lines before j) + (early-evicted lines before j),
+//    EB(i) = early-evicted lines found so far with position <= i.  /tmp prototype and tests/test_gpu_laia.py hold
+//    this against the sequential MiniLRU model.
+constexpr int kLaiaAssignPer = 16;                 // samples per thread of the assignment workgroup: B <= 16,384
+constexpr int kLaiaBitsChunk = 4096;               // rows per summary bit-word (64 data words)
+
+struct LruState {   // per worker, device memory
+    unsigned long long log_head, log_size;
+    unsigned long long miss_pull, miss_push, update_pull, update_push;
+    uint32_t counter;
+    int32_t live;
+    int32_t err;      // sticky: 1 = log window ran out (never expected), 2 = candidate list overflow
+    int32_t pad;
+};
+
+// ---- assignment ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long laia_block_scan_u64(unsigned long long v, unsigned long long *s_w,
+                                                                  unsigned long long *total) {
+    // exclusive scan over the 1024 threads of a workgroup; every 16-bit field of v stays below 2^16 in total
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(incl, o, 64);
+        if (lane >= o)
+            incl += y;
+    }
+    if (lane == 63)
+        s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+        const unsigned long long x = s_w[k];
+        if (k < wv)
+            base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__restrict__ scores, int B, int W, int mini_bs,
+                                                           long long batch_id, long long start, long long S,
+                                                           int32_t *__restrict__ owner, long long *__restrict__ dist) {
+    __shared__ unsigned long long s_w[16];
+    __shared__ int s_base[64], s_add[64];
+    __shared__ int s_istar;
+    __shared__ signed char s_pref[1024 * kLaiaAssignPer];   // choice of sample i this round, -1 = already final
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int i0 = t * per, i1 = min(B, i0 + per);
+    const int rot = static_cast<int>(batch_id % W);
+    if (t < 64) {
+        s_base[t] = 0;
+        s_add[t] = 0;
+    }
+    unsigned long long avail = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+    int i_start = 0;
+    __syncthreads();
+    while (i_start < B) {
+        // choice of every open sample among the workers that still have quota (a thread reads only its own entries)
+        for (int i = i0; i < i1; ++i) {
+            int bw = -1;
+            if (i >= i_start) {
+                int best = -1;
+                for (int j = 0; j < W; ++j) {
+                    int w = j + rot;
+                    w = w >= W ? w - W : w;
+                    if (!((avail >> w) & 1ull))
+                        continue;
+                    const int sc = scores[static_cast<long long>(i) * W + w];
+                    if (best < sc) {
+                        best = sc;
+                        bw = w;
+                    }
+                }
+            }
+            s_pref[i] = static_cast<signed char>(bw);
+        }
+        if (t == 0)
+            s_istar = B;      // = nobody fills: the rest of the batch is final
+        __syncthreads();
+        // groups of four workers: 16-bit packed counts, one scan per group; find the first sample that fills a quota
+        for (int g = 0; g * 4 < W; ++g) {
+            unsigned long long mine = 0;
+            for (int i = i0; i < i1; ++i) {
+                const int pf = s_pref[i];
+                if (pf >= 0 && (pf >> 2) == g)
+                    mine += 1ull << (16 * (pf & 3));
+            }
+            unsigned long long tot;
+            const unsigned long long ex = laia_block_scan_u64(mine, s_w, &tot);
+            for (int f = 0; f < 4 && 4 * g + f < W; ++f) {
+                const int w = 4 * g + f;
+                const int need = mini_bs - s_base[w];            // occurrences until w is full (>= 1 while available)
+                const int before = static_cast<int>((ex >> (16 * f)) & 0xFFFFull);
+                const int local = static_cast<int>((mine >> (16 * f)) & 0xFFFFull);
+                if (((avail >> w) & 1ull) && before < need && need <= before + local) {
+                    int seen = before;
+                    for (int i = i0; i < i1; ++i)
+                        if (s_pref[i] == w && ++seen == need)
+                            atomicMin(&s_istar, i);
+                }
+            }
+        }
+        __syncthreads();
+        const int istar = s_istar;      // last sample of this round (B: all remaining)
+        // finalise [i_start, istar]: slots in sample order
+        for (int g = 0; g * 4 < W; ++g) {
+            unsigned long long mine = 0;
+            for (int i = i0; i < i1 && i <= istar; ++i) {
+                const int pf = s_pref[i];
+                if (pf >= 0 && (pf >> 2) == g)
+                    mine += 1ull << (16 * (pf & 3));
+            }
+            unsigned long long tot;
+            unsigned long long ex = laia_block_scan_u64(mine, s_w, &tot);
+            for (int i = i0; i < i1 && i <= istar; ++i) {
+                const int pf = s_pref[i];
+                if (pf >= 0 && (pf >> 2) == g) {
+                    const int f = pf & 3;
+                    const int slot = s_base[pf] + static_cast<int>((ex >> (16 * f)) & 0xFFFFull);
+                    ex += 1ull << (16 * f);
+                    owner[i] = pf;
+                    dist[static_cast<long long>(pf) * mini_bs + slot] = (i + start) % S;
+                }
+            }
+            if (t == 0)
+                for (int f = 0; f < 4 && 4 * g + f < W; ++f)
+                    s_add[4 * g + f] = static_cast<int>((tot >> (16 * f)) & 0xFFFFull);
+        }
+        __syncthreads();
+        if (t < W) {
+            s_base[t] += s_add[t];
+            s_add[t] = 0;
+        }
+        __syncthreads();
+        for (int w = 0; w < W; ++w)
+            if (s_base[w] >= mini_bs)
+                avail &= ~(1ull << w);
+        i_start = istar + 1;
+        __syncthreads();
+    }
+}
+
+// ---- (worker, row) bitmaps ----------------------------------------------------------------------------------
+// touch: (owner of the sample, row); plan: (w, row) for the rows valid at w in samples not assigned to w.
+// Thread e takes (table j, sample i) = (e / B, e % B): the lanes of a wave hold consecutive samples of ONE table, so a hot
+// row -- named by thousands of samples of a batch -- shows up many times per wave.  Every distinct bit of a wave is set
+// by one lane (leader loop over the distinct values), and only if a look at the word says it is not set yet: a few
+// atomics per hot row and batch instead of thousands on one address.
+__device__ __forceinline__ void laia_set_bits(unsigned long long *__restrict__ bits, unsigned long long *__restrict__ sum,
+                                              unsigned long long b, bool on) {
+    // leader = the lowest lane of every distinct value (register-only loop), then all leaders go to memory at once
+    unsigned long long todo = __ballot(on);
+    bool leader = false;
+    while (todo) {
+        const int first = __builtin_ctzll(todo);
+        const unsigned long long v = __shfl(b, first, 64);
+        const unsigned long long same = __ballot(on && b == v);
+        todo &= ~same;
+        leader = leader || static_cast<int>(threadIdx.x & 63) == first;
+    }
+    if (leader && !((__atomic_load_n(&bits[b >> 6], __ATOMIC_RELAXED) >> (b & 63)) & 1ull)) {
+        const unsigned long long old = atomicOr(&bits[b >> 6], 1ull << (b & 63));
+        if (old == 0)
+            atomicOr(&sum[b >> 12], 1ull << ((b >> 6) & 63));
+    }
+}
+
+__global__ __launch_bounds__(256) void laia_bits_kernel(const uint32_t *__restrict__ samples, long long S, int T,
+                                                        long long start, int B, int W,
+                                                        const unsigned long long *__restrict__ mask,
+                                                        const int32_t *__restrict__ owner, long long R, long long Rpad,
+                                                        unsigned long long *__restrict__ tbits,
+                                                        unsigned long long *__restrict__ tsum,
+                                                        unsigned long long *__restrict__ pbits,
+                                                        unsigned long long *__restrict__ psum) {
+    const long long total = static_cast<long long>(B) * T;
+    const long long trips = (total + gridDim.x * 256ll - 1) / (gridDim.x * 256ll);     // whole waves make every trip
+    for (long long tr = 0; tr < trips; ++tr) {
+        const long long e = tr * gridDim.x * 256ll + blockIdx.x * 256ll + threadIdx.x;
+        uint32_t emb = 0;
+        int ow = 0;
+        unsigned long long m = 0;
+        bool live = false;
+        if (e < total) {
+            const int j = static_cast<int>(e / B);
+            const long long i = e - static_cast<long long>(j) * B;
+            emb = samples[((start + i) % S) * T + j];
+            live = emb < R;
+            ow = owner[i];
+            m = live ? (mask[i * T + j] & ~(1ull << ow)) : 0ull;
+        }
+        laia_set_bits(tbits, tsum, static_cast<unsigned long long>(ow) * Rpad + emb, live);
+        for (int w = 0; w < W; ++w)
+            if (__ballot((m >> w) & 1ull))       // wave-uniform: some lane names worker w
+                laia_set_bits(pbits, psum, static_cast<unsigned long long>(w) * Rpad + emb, ((m >> w) & 1ull) != 0);
+    }
+}
+
+struct LaiaBits {
+    unsigned long long *bits[2], *sum[2];   // 0 = touch, 1 = plan
+    uint32_t *rows[2];                      // output: rows ascending per worker
+    int32_t *off[2];                        // [W + 1]
+    uint32_t *cnt[2];                       // per-thread counts, then exclusive offsets  [nsum]
+    uint32_t *blk[2];                       // per-block totals, then exclusive offsets   [nblk + 1]
+};
+
+__device__ __forceinline__ uint32_t laia_block_scan_u32(uint32_t v, uint32_t *s_w, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o, 64);
+        if (lane >= o)
+            incl += y;
+    }
+    if (lane == 63)
+        s_w[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int k = 0; k < nw; ++k) {
+        const uint32_t x = s_w[k];
+        if (k < wv)
+            base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// one WAVE per summary word (4,096 rows, lane k = its data word k): number of set bits below it
+__global__ __launch_bounds__(1024) void laia_bits_count_kernel(LaiaBits a, long long nsum) {
+    __shared__ uint32_t s_c[16];
+    const int which = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long x = blockIdx.x * 16ll + wv;
+    uint32_t c = 0;
+    if (x < nsum) {
+        const unsigned long long sw = a.sum[which][x];      // wave-uniform
+        if (sw != 0 && ((sw >> lane) & 1ull))
+            c = __builtin_popcountll(a.bits[which][x * 64 + lane]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            c += __shfl_xor(c, o, 64);
+    }
+    if (lane == 0)
+        s_c[wv] = c;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        uint32_t ex = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) {
+            if (k < static_cast<int>(threadIdx.x))
+                ex += s_c[k];
+            tot += s_c[k];
+        }
+        const long long y = blockIdx.x * 16ll + threadIdx.x;
+        if (y < nsum)
+            a.cnt[which][y] = ex;
+        if (threadIdx.x == 0)
+            a.blk[which][blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(1024) void laia_bits_scan_kernel(LaiaBits a, int nblk) {
+    __shared__ uint32_t s_w[16];
+    const int which = blockIdx.x;
+    uint32_t run = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const uint32_t v = b < nblk ? a.blk[which][b] : 0u;
+        uint32_t tot;
+        const uint32_t ex = laia_block_scan_u32(v, s_w, &tot);
+        if (b < nblk)
+            a.blk[which][b] = run + ex;
+        run += tot;
+    }
+    if (threadIdx.x == 0)
+        a.blk[which][nblk] = run;
+}
+
+// emits the rows in order (one wave per summary word, lane k its data word k), writes the per-worker offsets and
+// clears the words it read
+__global__ __launch_bounds__(1024) void laia_bits_emit_kernel(LaiaBits a, long long nsum, long long sum_per_worker, int W,
+                                                              long long Rpad) {
+    const int which = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long x = blockIdx.x * 16ll + wv;
+    if (x >= nsum)
+        return;
+    const uint32_t at0 = a.blk[which][blockIdx.x] + a.cnt[which][x];
+    if (lane == 0) {
+        if (x % sum_per_worker == 0)
+            a.off[which][x / sum_per_worker] = static_cast<int32_t>(at0);
+        if (x == nsum - 1)
+            a.off[which][W] = static_cast<int32_t>(a.blk[which][gridDim.x]);
+    }
+    const unsigned long long sw = a.sum[which][x];      // wave-uniform
+    if (sw == 0)
+        return;
+    unsigned long long dw = 0;
+    if ((sw >> lane) & 1ull) {
+        dw = a.bits[which][x * 64 + lane];
+        a.bits[which][x * 64 + lane] = 0;
+    }
+    if (lane == 0)
+        a.sum[which][x] = 0;
+    const uint32_t c = __builtin_popcountll(dw);
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o, 64);
+        if (lane >= o)
+            incl += y;
+    }
+    uint32_t at = at0 + incl - c;
+    const long long w = x / sum_per_worker;
+    const unsigned long long base = static_cast<unsigned long long>(x * 64 + lane) * 64ull - static_cast<unsigned long long>(w) * Rpad;
+    while (dw) {
+        const int b = __builtin_ctzll(dw);
+        dw &= dw - 1;
+        a.rows[which][at++] = static_cast<uint32_t>(base + b);
+    }
+}
+
+// ---- the MiniLRU update of one worker, one workgroup ---------------------------------------------------------
+struct LaiaLru {
+    uint32_t *stamp;        // [W * R]
+    uint8_t *valid;         // [W * R]
+    uint32_t *log_key, *log_stamp;   // [W * L]
+    LruState *state;        // [W]
+    const uint32_t *touch_rows, *plan_rows;
+    const int32_t *tw_off, *pl_off;
+    uint32_t *flag;         // [W * BT]  bit 0 resident at batch start, bit 1 valid (after the outdates), bit 2 evicted early
+    uint32_t *newcnt;       // [W * (BT + 1)]  A(i): rows of the batch absent at its start among the first i
+    uint32_t *cand;         // [W * 3 * cand_cap]  (position, non-batch lines before, A(position - 1))
+    long long R, L;
+    int BT, cap, cand_cap;
+};
+
+__device__ __forceinline__ int laia_find(const uint32_t *__restrict__ a, int n, uint32_t key) {   // index or -1
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return (lo < n && a[lo] == key) ? lo : -1;
+}
+
+// drop the stale entries of the ring in place (order kept); renumber: restamp the live entries 1, 2, ...
+__device__ void laia_log_compact(const LaiaLru &a, int w, bool renumber, uint32_t *s_w, unsigned long long *s_u64) {
+    LruState &st = a.state[w];
+    uint32_t *lk = a.log_key + static_cast<long long>(w) * a.L;
+    uint32_t *ls = a.log_stamp + static_cast<long long>(w) * a.L;
+    uint32_t *stamp = a.stamp + static_cast<long long>(w) * a.R;
+    const unsigned long long mask = static_cast<unsigned long long>(a.L) - 1ull;
+    const unsigned long long head = st.log_head, size = st.log_size;
+    unsigned long long wr = 0;
+    for (unsigned long long r0 = 0; r0 < size; r0 += 1024) {
+        const unsigned long long r = r0 + threadIdx.x;
+        uint32_t key = 0, sp = 0;
+        bool live = false;
+        if (r < size) {
+            key = lk[(head + r) & mask];
+            sp = ls[(head + r) & mask];
+            live = stamp[key] == sp && sp != 0;
+        }
+        uint32_t tot;
+        const uint32_t ex = laia_block_scan_u32(live ? 1u : 0u, s_w, &tot);   // barriers: reads before writes
+        if (live) {
+            const unsigned long long d = wr + ex;
+            const uint32_t ns = renumber ? static_cast<uint32_t>(d + 1) : sp;
+            lk[(head + d) & mask] = key;
+            ls[(head + d) & mask] = ns;
+            if (renumber)
+                stamp[key] = ns;
+        }
+        wr += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st.log_size = wr;
+        if (renumber)
+            st.counter = static_cast<uint32_t>(wr);
+    }
+    __syncthreads();
+    (void)s_u64;
+}
+
+__global__ __launch_bounds__(1024) void laia_lru_kernel(const LaiaLru a, uint32_t debug_wrap_at) {
+    __shared__ uint32_t s_w[16];
+    __shared__ unsigned long long s_u64[4];
+    __shared__ uint32_t s_eb[1024];       // positions of the early-evicted lines (more: sticky error)
+    __shared__ uint32_t s_misc[8];
+    const int w = blockIdx.x, t = threadIdx.x;
+    LruState &st = a.state[w];
+    uint32_t *stamp = a.stamp + static_cast<long long>(w) * a.R;
+    uint8_t *valid = a.valid + static_cast<long long>(w) * a.R;
+    uint32_t *lk = a.log_key + static_cast<long long>(w) * a.L;
+    uint32_t *ls = a.log_stamp + static_cast<long long>(w) * a.L;
+    const uint32_t *T = a.touch_rows + a.tw_off[w];
+    const uint32_t *P = a.plan_rows + a.pl_off[w];
+    const int n = a.tw_off[w + 1] - a.tw_off[w], m = a.pl_off[w + 1] - a.pl_off[w];
+    uint32_t *flag = a.flag + static_cast<long long>(w) * a.BT;
+    uint32_t *newcnt = a.newcnt + static_cast<long long>(w) * (a.BT + 1);
+    uint32_t *cand = a.cand + static_cast<long long>(w) * 3 * a.cand_cap;
+    const unsigned long long mask = static_cast<unsigned long long>(a.L) - 1ull;
+    if (t < 8)
+        s_misc[t] = 0;
+    __syncthreads();
+
+    // room in the log for n appends, and the 32-bit stamp counter
+    const bool wrap = static_cast<unsigned long long>(st.counter) + static_cast<unsigned long long>(n) >=
+                      static_cast<unsigned long long>(debug_wrap_at);
+    if (wrap || st.log_size + static_cast<unsigned long long>(n) > static_cast<unsigned long long>(a.L))
+        laia_log_compact(a, w, wrap, s_w, s_u64);
+
+    // 1. outdate the plan keys (mini_lru_cache.h:120-128)
+    for (int i = t; i < m; i += 1024) {
+        const uint32_t r = P[i];
+        if (stamp[r] != 0 && valid[r])
+            valid[r] = 0;
+    }
+    __syncthreads();
+    // 2. the rows of the batch: resident? valid?  A(i) = absent rows among the first i
+    const int per = (n + 1023) / 1024;
+    uint32_t mine = 0;
+    for (int q = 0; q < per; ++q) {
+        const int i = t * per + q;
+        if (i < n) {
+            const uint32_t r = T[i];
+            const bool old = stamp[r] != 0;
+            flag[i] = (old ? 1u : 0u) | (valid[r] ? 2u : 0u);
+            mine += old ? 0u : 1u;
+        }
+    }
+    uint32_t new_total;
+    uint32_t run = laia_block_scan_u32(mine, s_w, &new_total);
+    for (int q = 0; q < per; ++q) {
+        const int i = t * per + q;
+        if (i < n) {
+            newcnt[i] = run;                      // A(i): before row i (0-based) = among the first i rows
+            run += (flag[i] & 1u) ? 0u : 1u;
+        }
+    }
+    if (t == 0)
+        newcnt[n] = new_total;
+    const int live0 = st.live;
+    const long long Nll = static_cast<long long>(live0) + new_total - a.cap;
+    const uint32_t N = Nll > 0 ? static_cast<uint32_t>(Nll) : 0u;
+    __syncthreads();
+    // 3. the first N live log entries that are not rows of the batch are the victims; batch rows met on the way are
+    //    candidates for an early eviction
+    unsigned long long consumed = 0;      // log entries passed (up to and including the N-th victim)
+    uint32_t nb_base = 0, ncand = 0, push_valid = 0;
+    const unsigned long long head = st.log_head, size = st.log_size;
+    while (nb_base < N && consumed < size) {
+        const unsigned long long r = consumed + t;
+        uint32_t key = 0;
+        int pos = -1;
+        bool live = false;
+        if (r < size) {
+            key = lk[(head + r) & mask];
+            live = stamp[key] == ls[(head + r) & mask];
+            if (live)
+                pos = laia_find(T, n, key);
+        }
+        const bool nonbatch = live && pos < 0;
+        uint32_t tot_nb, tot_c;
+        const uint32_t ex_nb = laia_block_scan_u32(nonbatch ? 1u : 0u, s_w, &tot_nb);
+        const bool victim = nonbatch && nb_base + ex_nb < N;
+        const bool is_cand = live && pos >= 0 && nb_base + ex_nb < N;     // before the last victim
+        const uint32_t ex_c = laia_block_scan_u32(is_cand ? 1u : 0u, s_w, &tot_c);
+        if (victim) {
+            if (valid[key])
+                atomicAdd(&s_misc[0], 1u);
+            valid[key] = 0;
+            stamp[key] = 0;
+        }
+        if (is_cand) {
+            const uint32_t c = ncand + ex_c;
+            if (c < static_cast<uint32_t>(a.cand_cap)) {
+                cand[3 * c + 0] = static_cast<uint32_t>(pos);            // 0-based position
+                cand[3 * c + 1] = nb_base + ex_nb;                         // non-batch lines before it
+                cand[3 * c + 2] = newcnt[pos];                             // A(position - 1) for the 1-based position
+            }
+        }
+        // the N-th victim ends the window: entries behind it stay in the log
+        uint32_t last = 0xFFFFFFFFu;
+        if (victim && nb_base + ex_nb + 1 == N)
+            last = t;
+        // (at most one thread has it)
+        if (last != 0xFFFFFFFFu)
+            s_misc[1] = last + 1;
+        __syncthreads();
+        if (nb_base + tot_nb >= N) {
+            consumed += s_misc[1];
+        } else {
+            consumed += (size - consumed < 1024ull) ? (size - consumed) : 1024ull;
+        }
+        nb_base += tot_nb;
+        ncand += tot_c;
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (nb_base < N)
+            st.err = 1;
+        if (ncand > static_cast<uint32_t>(a.cand_cap))
+            st.err = 2;
+    }
+    if (ncand > static_cast<uint32_t>(a.cand_cap))
+        ncand = static_cast<uint32_t>(a.cand_cap);
+    push_valid = 0;
+    __syncthreads();
+    // 4. early evictions, in log order (one thread; the candidates are few: lines near the LRU end that this very
+    //    batch names)
+    if (t == 0) {
+        uint32_t eb = 0;
+        for (uint32_t c = 0; c < ncand; ++c) {
+            const uint32_t pos = cand[3 * c], nbb = cand[3 * c + 1], A = cand[3 * c + 2];
+            uint32_t ebc = 0;
+            for (uint32_t k = 0; k < eb && k < 1024u; ++k)
+                ebc += s_eb[k] < pos ? 1u : 0u;          // early-evicted lines with a (0-based) position < pos
+            const long long lhs = static_cast<long long>(live0) + A + ebc - a.cap;
+            if (lhs >= static_cast<long long>(1u + nbb + eb)) {
+                if (eb < 1024u)
+                    s_eb[eb] = pos;
+                else
+                    st.err = 2;
+                eb += 1;
+                if (flag[pos] & 2u)
+                    push_valid += 1;
+                flag[pos] |= 4u;
+            }
+        }
+        s_misc[2] = eb;
+        s_misc[3] = push_valid;
+    }
+    __syncthreads();
+    const uint32_t eb_total = s_misc[2];
+    // 5. every row of the batch ends resident, valid, stamped in batch order; log appends
+    const uint32_t counter0 = st.counter;
+    const unsigned long long tail = head + size;
+    uint32_t upd = 0;
+    for (int i = t; i < n; i += 1024) {
+        const uint32_t r = T[i];
+        const uint32_t f = flag[i];
+        if ((f & 1u) && !(f & 2u) && !(f & 4u))
+            upd += 1;                                  // get() of a resident, outdated line: -2
+        stamp[r] = counter0 + static_cast<uint32_t>(i) + 1u;
+        valid[r] = 1;
+        lk[(tail + i) & mask] = r;
+        ls[(tail + i) & mask] = counter0 + static_cast<uint32_t>(i) + 1u;
+    }
+    uint32_t upd_total;
+    (void)laia_block_scan_u32(upd, s_w, &upd_total);
+    if (t == 0) {
+        st.counter = counter0 + static_cast<uint32_t>(n);
+        st.live = live0 + static_cast<int>(new_total) - static_cast<int>(nb_base < N ? nb_base : N);
+        st.log_head = (head + consumed) & mask;
+        st.log_size = size - consumed + static_cast<unsigned long long>(n);
+        st.miss_pull += new_total + eb_total;
+        st.miss_push += s_misc[0] + s_misc[3];
+        st.update_pull += upd_total;
+        st.update_push += static_cast<unsigned long long>(m);
+    }
+}
+
+
+// ---- host side of the device-resident mode ------------------------------------------------------------------------
+struct LaiaDev {
+    bool on = false;
+    long long Rpad = 0, L = 0, nsum = 0, sum_per_worker = 0;
+    int nblk = 0, cand_cap = 0;
+    uint32_t debug_wrap_at = 0xFFFFFF00u;
+    LaiaBits bits{};
+    LaiaLru lru{};
+    long long *d_dist = nullptr;
+    // pinned: dist [W * Bcap], offsets [2 * (W + 1)], plan rows [plan_cap], states [W]
+    long long *h_dist = nullptr;
+    int32_t *h_off = nullptr;
+    uint32_t *h_plan_rows = nullptr;
+    LruState *h_state = nullptr;
+};
+
 // A few persistent host threads for the per-worker snapshot updates (creating std::threads per batch costs
 // ~200 us, the update itself ~150 us per worker).  run(n, f): f(1) .. f(n-1) on the pool, f(0) on the caller.
 struct SnapshotPool {
@@ -444,6 +1056,9 @@ struct Laia {
     // assignment, the host's snapshot (MiniLRU) bookkeeping; the rest is GPU work, transfers and waits
     double t_total_us = 0, t_assign_us = 0, t_snap_us = 0;
     long long t_calls = 0;
+    LaiaDev dev;              // device-resident mode (LaiaScheduler with cache_size >= max_batch * tables)
+    bool host_ready = false;  // the host snapshots are initialised at the first call that needs them
+    bool decided = false;     // device or host mode: fixed by the first ha_laia_next* call
 };
 
 static inline double now_us() {
@@ -481,12 +1096,7 @@ extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sam
     l.cache_size = static_cast<int>(cache_size);
     l.Bcap = static_cast<int>(max_batch);
     l.samples_host.assign(samples_host, samples_host + num_sample * num_table);
-    l.snaps.resize(l.W);
-    // direct maps while all W of them stay below 2 GiB of host memory, hash maps beyond
-    const bool use_direct = static_cast<unsigned long long>(l.W) * static_cast<unsigned long long>(l.R) * 4ull <=
-                            (2ull << 30);
-    for (auto &s : l.snaps)
-        s.init(l.cache_size, l.R, use_direct);
+    l.snaps.resize(l.W);      // initialised by laia_host_snaps() when the host mode is first used
     l.miss_pull.assign(l.W, 0);
     l.miss_push.assign(l.W, 0);
     l.update_pull.assign(l.W, 0);
@@ -546,6 +1156,10 @@ extern "C" void ha_laia_destroy(ha_laia *h) {
         (void)hipHostFree(h->l.h_touch);
     if (h->l.h_plan)
         (void)hipHostFree(h->l.h_plan);
+    for (void *p : {static_cast<void *>(h->l.dev.h_dist), static_cast<void *>(h->l.dev.h_off),
+                    static_cast<void *>(h->l.dev.h_plan_rows), static_cast<void *>(h->l.dev.h_state)})
+        if (p)
+            (void)hipHostFree(p);
     (void)hipStreamDestroy(h->l.stream);
     delete h;
 }
@@ -566,11 +1180,175 @@ static void topk_slice(long long total, int nt, int t, long long *s0, long long 
     *s1 = t == 0 ? x + y : *s0 + x;
 }
 
+static void laia_host_snaps(Laia &l) {
+    if (l.host_ready)
+        return;
+    // direct maps while all W of them stay below 2 GiB of host memory, hash maps beyond
+    const bool use_direct = static_cast<unsigned long long>(l.W) * static_cast<unsigned long long>(l.R) * 4ull <=
+                            (2ull << 30);
+    for (auto &s : l.snaps)
+        s.init(l.cache_size, l.R, use_direct);
+    l.host_ready = true;
+}
+
+// Device-resident mode is possible when a batch can never evict its own rows (cache_size >= max_batch * tables) and the
+// batch fits the assignment workgroup; HA_LAIA_HOST=1 keeps the host snapshots.
+static bool laia_dev_eligible(const Laia &l) {
+    const char *e = getenv("HA_LAIA_HOST");
+    if (e && e[0] == '1')
+        return false;
+    return static_cast<long long>(l.cache_size) >= static_cast<long long>(l.Bcap) * l.T && l.Bcap <= 1024 * kLaiaAssignPer;
+}
+
+static int laia_dev_init(Laia &l) {
+    LaiaDev &d = l.dev;
+    const long long W = l.W, R = l.R;
+    const size_t BT = static_cast<size_t>(l.Bcap) * l.T;
+    d.Rpad = (R + kLaiaBitsChunk - 1) / kLaiaBitsChunk * kLaiaBitsChunk;
+    d.sum_per_worker = d.Rpad / kLaiaBitsChunk;
+    d.nsum = W * d.sum_per_worker;
+    d.nblk = static_cast<int>((d.nsum + 15) / 16);
+    long long L = 1024;
+    while (L < 4ll * (static_cast<long long>(l.cache_size) + static_cast<long long>(BT) + 2))
+        L <<= 1;
+    if (const char *e = getenv("HA_LAIA_DEBUG_LOG")) {      // tests: a short log forces compactions
+        long long v = atoll(e);
+        L = 1024;
+        while (L < v)
+            L <<= 1;
+    }
+    if (const char *e = getenv("HA_LAIA_DEBUG_WRAP"))       // tests: renumber the stamps early
+        d.debug_wrap_at = static_cast<uint32_t>(strtoul(e, nullptr, 10));
+    HA_REQUIRE(L >= static_cast<long long>(l.cache_size) + 2 * static_cast<long long>(BT) + 2,
+               "laia: the log must hold the resident lines and two batches");
+    d.L = L;
+    d.cand_cap = static_cast<int>(BT < 65536 ? BT : 65536);
+    const size_t nwords = static_cast<size_t>(W) * d.Rpad / 64;
+    bool ok = true;
+    auto alloc = [&](void **p, size_t bytes, bool zero) {
+        ok = ok && laia_alloc(l, p, bytes) == 0;
+        if (ok && zero)
+            ok = hipMemsetAsync(*p, 0, bytes, l.stream) == hipSuccess;
+    };
+    alloc(reinterpret_cast<void **>(&d.lru.stamp), static_cast<size_t>(W) * R * 4, true);
+    alloc(reinterpret_cast<void **>(&d.lru.log_key), static_cast<size_t>(W) * L * 4, false);
+    alloc(reinterpret_cast<void **>(&d.lru.log_stamp), static_cast<size_t>(W) * L * 4, false);
+    alloc(reinterpret_cast<void **>(&d.lru.state), static_cast<size_t>(W) * sizeof(LruState), true);
+    alloc(reinterpret_cast<void **>(&d.lru.flag), static_cast<size_t>(W) * BT * 4, false);
+    alloc(reinterpret_cast<void **>(&d.lru.newcnt), static_cast<size_t>(W) * (BT + 1) * 4, false);
+    alloc(reinterpret_cast<void **>(&d.lru.cand), static_cast<size_t>(W) * 3 * d.cand_cap * 4, false);
+    for (int k = 0; k < 2; ++k) {
+        alloc(reinterpret_cast<void **>(&d.bits.bits[k]), nwords * 8, true);
+        alloc(reinterpret_cast<void **>(&d.bits.sum[k]), static_cast<size_t>(d.nsum) * 8, true);
+        alloc(reinterpret_cast<void **>(&d.bits.rows[k]), (k == 0 ? BT : l.plan_cap) * 4, false);
+        alloc(reinterpret_cast<void **>(&d.bits.off[k]), static_cast<size_t>(W + 1) * 4, true);
+        alloc(reinterpret_cast<void **>(&d.bits.cnt[k]), static_cast<size_t>(d.nsum) * 4, false);
+        alloc(reinterpret_cast<void **>(&d.bits.blk[k]), static_cast<size_t>(d.nblk + 1) * 4, false);
+    }
+    alloc(reinterpret_cast<void **>(&d.d_dist), static_cast<size_t>(W) * l.Bcap * 8, false);
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_dist), static_cast<size_t>(W) * l.Bcap * 8, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_off), static_cast<size_t>(2 * (W + 1)) * 4, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_plan_rows), (l.plan_cap + 4) * 4, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_state), static_cast<size_t>(W) * sizeof(LruState), hipHostMallocDefault) == hipSuccess;
+    HA_REQUIRE(ok, "laia: device allocation of the resident scheduler state failed");
+    d.lru.valid = l.d_valid;
+    d.lru.touch_rows = d.bits.rows[0];
+    d.lru.plan_rows = d.bits.rows[1];
+    d.lru.tw_off = d.bits.off[0];
+    d.lru.pl_off = d.bits.off[1];
+    d.lru.R = R;
+    d.lru.L = L;
+    d.lru.BT = static_cast<int>(BT);
+    d.lru.cap = l.cache_size;
+    d.lru.cand_cap = d.cand_cap;
+    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    d.on = true;
+    return 0;
+}
+
+static int laia_dev_states(Laia &l) {   // -> l.dev.h_state (synchronises the scheduler's stream)
+    HA_CHECK_HIP(hipMemcpyAsync(l.dev.h_state, l.dev.lru.state, static_cast<size_t>(l.W) * sizeof(LruState),
+                                hipMemcpyDeviceToHost, l.stream));
+    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    return 0;
+}
+
+// One global batch with the scheduler state on the device: eight launches, `dist` + offsets + states back in one copy
+// phase, the plan rows in a second (their number is only known then).
+static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out, uint64_t *plan_out,
+                            int64_t plan_cap_elems, int64_t *plan_off) {
+    Laia &l = h->l;
+    LaiaDev &d = l.dev;
+    const int W = l.W, T = l.T;
+    const long long B = mini_bs * W;
+    HA_REQUIRE(B <= l.Bcap, "laia_next: global batch %lld exceeds max_batch %d", B, l.Bcap);
+    const double t_begin = now_us();
+    const long long start = (batch_id * B) % l.S;  // laia_scheduler.cc:182
+    const long long BT = B * T;
+    int blocks = static_cast<int>((BT + 255) / 256);
+    if (blocks > 4096)
+        blocks = 4096;
+    hipLaunchKernelGGL(laia_probe_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
+                       l.d_valid, l.R, l.d_mask);
+    hipLaunchKernelGGL(laia_score_kernel, dim3((int)((B * W + 255) / 256)), dim3(256), 0, l.stream, l.d_mask, (int)B, T,
+                       W, l.d_scores);
+    hipLaunchKernelGGL(laia_assign_kernel, dim3(1), dim3(1024), 0, l.stream, l.d_scores, (int)B, W, (int)mini_bs,
+                       (long long)batch_id, start, l.S, l.d_owner, d.d_dist);
+    hipLaunchKernelGGL(laia_bits_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
+                       l.d_mask, l.d_owner, l.R, d.Rpad, d.bits.bits[0], d.bits.sum[0], d.bits.bits[1], d.bits.sum[1]);
+    hipLaunchKernelGGL(laia_bits_count_kernel, dim3(d.nblk, 2), dim3(1024), 0, l.stream, d.bits, d.nsum);
+    hipLaunchKernelGGL(laia_bits_scan_kernel, dim3(2), dim3(1024), 0, l.stream, d.bits, d.nblk);
+    hipLaunchKernelGGL(laia_bits_emit_kernel, dim3(d.nblk, 2), dim3(1024), 0, l.stream, d.bits, d.nsum, d.sum_per_worker, W,
+                       d.Rpad);
+    hipLaunchKernelGGL(laia_lru_kernel, dim3(W), dim3(1024), 0, l.stream, d.lru, d.debug_wrap_at);
+    HA_LAUNCH_CHECK();
+    HA_CHECK_HIP(hipMemcpyAsync(d.h_dist, d.d_dist, static_cast<size_t>(B) * 8, hipMemcpyDeviceToHost, l.stream));
+    HA_CHECK_HIP(hipMemcpyAsync(d.h_off, d.bits.off[0], static_cast<size_t>(W + 1) * 4, hipMemcpyDeviceToHost, l.stream));
+    HA_CHECK_HIP(hipMemcpyAsync(d.h_off + (W + 1), d.bits.off[1], static_cast<size_t>(W + 1) * 4, hipMemcpyDeviceToHost,
+                                l.stream));
+    HA_CHECK_HIP(hipMemcpyAsync(d.h_state, d.lru.state, static_cast<size_t>(W) * sizeof(LruState), hipMemcpyDeviceToHost,
+                                l.stream));
+    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    for (int w = 0; w < W; ++w)
+        HA_REQUIRE(d.h_state[w].err == 0, "laia: the device snapshot of worker %d is inconsistent (code %d)", w,
+                   d.h_state[w].err);
+    const int32_t *pl_off = d.h_off + (W + 1);
+    const long long nplan = pl_off[W];
+    HA_REQUIRE(nplan <= plan_cap_elems && nplan <= static_cast<long long>(l.plan_cap), "laia_next: plan buffer too small");
+    if (nplan > 0) {
+        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows, d.bits.rows[1], static_cast<size_t>(nplan) * 4, hipMemcpyDeviceToHost,
+                                    l.stream));
+        HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+    }
+    for (long long k = 0; k < B; ++k)
+        dist_out[k] = d.h_dist[k];
+    for (int w = 0; w <= W; ++w)
+        plan_off[w] = pl_off[w];
+    for (long long k = 0; k < nplan; ++k)
+        plan_out[k] = d.h_plan_rows[k];
+    l.t_total_us += now_us() - t_begin;
+    l.t_calls += 1;
+    return 0;
+}
+
 static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out,
                           uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off,
                           const TopkParams *topk) {
     HA_REQUIRE(h && dist_out && plan_out && plan_off && mini_bs > 0, "laia_next: bad arguments");
     Laia &l = h->l;
+    if (!l.decided) {      // LaiaScheduler with a large cache keeps its snapshots on the device; everything else on the host
+        l.decided = true;
+        if (topk == nullptr && laia_dev_eligible(l)) {
+            if (laia_dev_init(l))
+                return -1;
+        }
+    }
+    if (l.dev.on) {
+        HA_REQUIRE(topk == nullptr, "laia_next_topk: this scheduler keeps its snapshots on the device (it was first "
+                                    "used as a LaiaScheduler); create a separate one for the top-k schedule");
+        return laia_next_device(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off);
+    }
+    laia_host_snaps(l);
     const int W = l.W, T = l.T;
     const long long B = mini_bs * W;
     HA_REQUIRE(B <= l.Bcap, "laia_next: global batch %lld exceeds max_batch %d", B, l.Bcap);
@@ -835,7 +1613,18 @@ extern "C" int ha_laia_next_topk(ha_laia *h, int64_t batch_id, int64_t mini_bs,
 // out[4*W] = miss_pull[W], miss_push[W], update_pull[W], update_push[W] accumulated so far
 extern "C" int ha_laia_counters(ha_laia *h, int64_t *out) {
     HA_REQUIRE(h && out, "laia_counters: bad arguments");
-    const Laia &l = h->l;
+    Laia &l = h->l;
+    if (l.dev.on) {
+        if (laia_dev_states(l))
+            return -1;
+        for (int w = 0; w < l.W; ++w) {
+            out[w] = static_cast<int64_t>(l.dev.h_state[w].miss_pull);
+            out[l.W + w] = static_cast<int64_t>(l.dev.h_state[w].miss_push);
+            out[2 * l.W + w] = static_cast<int64_t>(l.dev.h_state[w].update_pull);
+            out[3 * l.W + w] = static_cast<int64_t>(l.dev.h_state[w].update_push);
+        }
+        return 0;
+    }
     for (int w = 0; w < l.W; ++w) {
         out[w] = l.miss_pull[w];
         out[l.W + w] = l.miss_push[w];
@@ -849,6 +1638,23 @@ extern "C" int ha_laia_counters(ha_laia *h, int64_t *out) {
 extern "C" int64_t ha_laia_snapshot_keys(ha_laia *h, int64_t w, int32_t *out, int64_t cap) {
     if (!h || w < 0 || w >= h->l.W)
         return -1;
+    if (h->l.dev.on) {     // the valid bytes of worker w ARE its valid resident keys
+        Laia &l = h->l;
+        std::vector<uint8_t> v(static_cast<size_t>(l.R));
+        if (hipStreamSynchronize(l.stream) != hipSuccess ||
+            hipMemcpy(v.data(), l.d_valid + static_cast<size_t>(w) * l.R, v.size(), hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        int64_t cnt = 0;
+        for (size_t k = 0; k < v.size(); ++k)
+            if (v[k]) {
+                if (cnt < cap)
+                    out[cnt] = static_cast<int32_t>(k);
+                ++cnt;
+            }
+        return cnt;
+    }
+    if (!h->l.host_ready)
+        return 0;
     Snapshot &s = h->l.snaps[static_cast<size_t>(w)];
     std::vector<int32_t> keys;
     s.valid_keys(keys);

@@ -125,3 +125,58 @@ def test_topk_local_shared_rings(dev):
     major.close()
     assert got0 == want[2]
     assert got1 == want[3]
+
+
+# ---- device-resident scheduler state (cache_size >= global batch x tables) ----------------------------------------
+def _run_device(monkeypatch, W, rank, T, mini_bs, batch_num, epochs, cache_size, nkeys, S, seed, env=None, host=False):
+    """LaiaScheduler whose MiniLRU snapshots, greedy assignment and sorted-unique key lists live on the GPU
+    (csrc/laia.hip, laia_next_device): stream, final snapshots and traffic counters against the sequential model."""
+    import numpy as _np
+    from herald_amd import _lib
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    if host:
+        monkeypatch.setenv("HA_LAIA_HOST", "1")
+    assert host or cache_size >= W * mini_bs * T
+    samples, key_limit = _samples(S, T, nkeys, seed)
+    model = laia_model.LaiaSchedulerModel(samples, epochs, mini_bs, batch_num, W, rank, cache_size)
+    want = model.emit()
+    s = hlaia.LaiaScheduler()
+    s.start(samples, S, T, epochs, mini_bs, batch_num, W, rank, cache_size, 16, 24, key_limit=key_limit)
+    got = []
+    while True:
+        item = s.pop()
+        got.append(item)
+        if item == [0]:
+            break
+    assert len(got) == len(want)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "stream element %d differs (%s)" % (k, "plan" if k % 2 == 0 else "dist")
+    for w in range(W):
+        assert s.snapshot_keys(w) == model.snaps[w].keys(), "valid resident keys of worker %d" % w
+    cnt = _np.zeros(4 * W, dtype=_np.int64)
+    _lib.check(s._L.ha_laia_counters(s._h, cnt.ctypes.data), "ha_laia_counters")
+    s.close()
+    return got, cnt.reshape(4, W)
+
+
+@pytest.mark.parametrize("W,rank,T,mini_bs,cache_size,nkeys", [(4, 1, 6, 16, 400, 3000), (1, 0, 5, 32, 200, 900),
+                                                               (8, 6, 4, 8, 300, 2500), (3, 2, 7, 20, 500, 1200),
+                                                               (2, 0, 26, 64, 3400, 30000)])
+def test_laia_device_resident_state_matches_model(dev, monkeypatch, W, rank, T, mini_bs, cache_size, nkeys):
+    """Caches a few batches large: every batch evicts, lines near the LRU end are named again (evicted early and
+    re-inserted), workers fill their quota at different samples; the counters equal the host mode's."""
+    args = dict(W=W, rank=rank, T=T, mini_bs=mini_bs, batch_num=25, epochs=2, cache_size=cache_size, nkeys=nkeys, S=4000,
+                seed=100 + W)
+    _, cnt_dev = _run_device(monkeypatch, **args)
+    _, cnt_host = _run_device(monkeypatch, host=True, **args)
+    np.testing.assert_array_equal(cnt_dev, cnt_host)
+    assert cnt_dev[0].sum() > 0 and (W == 1 or cnt_dev[3].sum() > 0)
+
+
+def test_laia_device_log_compaction_and_stamp_renumbering(dev, monkeypatch):
+    """A short log (compacted every few batches) and an early wrap of the 32-bit stamp counter (live entries restamped
+    1, 2, ...): the stream does not change."""
+    args = dict(W=4, rank=3, T=6, mini_bs=16, batch_num=40, epochs=2, cache_size=400, nkeys=3000, S=5000, seed=5)
+    _run_device(monkeypatch, env={"HA_LAIA_DEBUG_LOG": "2048"}, **args)
+    _run_device(monkeypatch, env={"HA_LAIA_DEBUG_LOG": "2048", "HA_LAIA_DEBUG_WRAP": "3000"}, **args)
