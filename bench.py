@@ -255,10 +255,12 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
 
 def laia_scheduler(args):
     """Secondary measurement (scheduler us per 4096-sample global batch, configs[3] shape): the laia
-    LaiaScheduler for 4 workers x mini batch 1024, 26 tables over the full key space, cache_size = 0.1 x rows;
-    GPU probing / plan extraction and the host's greedy assignment + MiniLRU snapshots reported separately."""
+    LaiaScheduler for 4 workers x mini batch 1024, 26 tables over the full key space, cache_size = 0.1 x rows.  With a
+    cache of at least one global batch of rows the scheduler state lives on the GPU (MiniLRU snapshots, assignment,
+    sorted-unique key lists: csrc/laia.hip, laia_next_device) and the host parts are zero; HA_LAIA_HOST=1 measures the
+    host-snapshot mode."""
     from herald_amd import laia as hlaia, synth
-    W, mini_bs, T, batch_num = 4, 1024, args.fields, 8
+    W, mini_bs, T, batch_num = 4, 1024, args.fields, 48
     per = 256
     need = W * mini_bs * batch_num + 1000
     parts = [synth.criteo_batch(per, step=5000 + s, rows=args.rows, nfields=T) for s in range((need + per - 1) // per)]
@@ -273,6 +275,7 @@ def laia_scheduler(args):
             "tables": T, "cache_size": int(0.1 * args.rows), "batches": tm["batches"],
             "host_assign_us": tm["host_assign_us"], "host_snapshot_us": tm["host_snapshot_us"],
             "gpu_and_transfer_us": tm["gpu_and_transfer_us"],
+            "mode": "host snapshots" if os.environ.get("HA_LAIA_HOST") == "1" else "device-resident state",
             "note": "the scheduler runs ahead of training in its own thread; not part of `value`"}
 
 

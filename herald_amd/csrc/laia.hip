@@ -385,7 +385,8 @@ struct LruState {   // per worker, device memory
     uint32_t counter;
     int32_t live;
     int32_t err;      // sticky: 1 = log window ran out (never expected), 2 = candidate list overflow
-    int32_t pad;
+    uint32_t apply_counter0;           // for laia_lru_apply_kernel: stamp of the batch's first row - 1 ...
+    unsigned long long apply_tail;     // ... and the log position of its entry
 };
 
 // ---- assignment ------------------------------------------------------------------------------------------
@@ -456,7 +457,9 @@ __global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__rest
         if (t == 0)
             s_istar = B;      // = nobody fills: the rest of the batch is final
         __syncthreads();
-        // groups of four workers: 16-bit packed counts, one scan per group; find the first sample that fills a quota
+        // groups of four workers: 16-bit packed counts, ONE scan per group and round -- the number of earlier open
+        // samples with the same choice gives both the sample that fills a quota and every sample's slot
+        unsigned long long exs[16];       // W <= 64: up to 16 groups
         for (int g = 0; g * 4 < W; ++g) {
             unsigned long long mine = 0;
             for (int i = i0; i < i1; ++i) {
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__rest
             }
             unsigned long long tot;
             const unsigned long long ex = laia_block_scan_u64(mine, s_w, &tot);
+            exs[g] = ex;
             for (int f = 0; f < 4 && 4 * g + f < W; ++f) {
                 const int w = 4 * g + f;
                 const int need = mini_bs - s_base[w];            // occurrences until w is full (>= 1 while available)
@@ -482,28 +486,16 @@ __global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__rest
         __syncthreads();
         const int istar = s_istar;      // last sample of this round (B: all remaining)
         // finalise [i_start, istar]: slots in sample order
-        for (int g = 0; g * 4 < W; ++g) {
-            unsigned long long mine = 0;
-            for (int i = i0; i < i1 && i <= istar; ++i) {
-                const int pf = s_pref[i];
-                if (pf >= 0 && (pf >> 2) == g)
-                    mine += 1ull << (16 * (pf & 3));
+        for (int i = i0; i < i1 && i <= istar; ++i) {
+            const int pf = s_pref[i];
+            if (pf >= 0) {
+                const int g = pf >> 2, f = pf & 3;
+                const int slot = s_base[pf] + static_cast<int>((exs[g] >> (16 * f)) & 0xFFFFull);
+                exs[g] += 1ull << (16 * f);
+                owner[i] = pf;
+                dist[static_cast<long long>(pf) * mini_bs + slot] = (i + start) % S;
+                atomicAdd(&s_add[pf], 1);
             }
-            unsigned long long tot;
-            unsigned long long ex = laia_block_scan_u64(mine, s_w, &tot);
-            for (int i = i0; i < i1 && i <= istar; ++i) {
-                const int pf = s_pref[i];
-                if (pf >= 0 && (pf >> 2) == g) {
-                    const int f = pf & 3;
-                    const int slot = s_base[pf] + static_cast<int>((ex >> (16 * f)) & 0xFFFFull);
-                    ex += 1ull << (16 * f);
-                    owner[i] = pf;
-                    dist[static_cast<long long>(pf) * mini_bs + slot] = (i + start) % S;
-                }
-            }
-            if (t == 0)
-                for (int f = 0; f < 4 && 4 * g + f < W; ++f)
-                    s_add[4 * g + f] = static_cast<int>((tot >> (16 * f)) & 0xFFFFull);
         }
         __syncthreads();
         if (t < W) {
@@ -702,6 +694,8 @@ __global__ __launch_bounds__(1024) void laia_bits_emit_kernel(LaiaBits a, long l
 }
 
 // ---- the MiniLRU update of one worker, one workgroup ---------------------------------------------------------
+constexpr int kLaiaLruBlocks = 32;   // workgroups per worker in the parallel phases of the MiniLRU update
+
 struct LaiaLru {
     uint32_t *stamp;        // [W * R]
     uint8_t *valid;         // [W * R]
@@ -710,7 +704,8 @@ struct LaiaLru {
     const uint32_t *touch_rows, *plan_rows;
     const int32_t *tw_off, *pl_off;
     uint32_t *flag;         // [W * BT]  bit 0 resident at batch start, bit 1 valid (after the outdates), bit 2 evicted early
-    uint32_t *newcnt;       // [W * (BT + 1)]  A(i): rows of the batch absent at its start among the first i
+    uint32_t *newcnt;       // [W * (BT + 1)]  rows of the batch absent at its start before row i, within its block's chunk
+    uint32_t *blocktot;     // [W * kLaiaLruBlocks]  such rows per chunk
     uint32_t *cand;         // [W * 3 * cand_cap]  (position, non-batch lines before, A(position - 1))
     long long R, L;
     int BT, cap, cand_cap;
@@ -768,11 +763,61 @@ __device__ void laia_log_compact(const LaiaLru &a, int w, bool renumber, uint32_
     (void)s_u64;
 }
 
-__global__ __launch_bounds__(1024) void laia_lru_kernel(const LaiaLru a, uint32_t debug_wrap_at) {
+__device__ __forceinline__ int laia_chunk(int n) {   // batch rows per workgroup of the parallel phases
+    return (n + kLaiaLruBlocks - 1) / kLaiaLruBlocks;
+}
+
+// Phase 1 (W x kLaiaLruBlocks workgroups): outdate the plan keys (mini_lru_cache.h:120-128); per row of the batch:
+// resident? valid after the outdates? and the number of absent rows before it inside its chunk.
+__global__ __launch_bounds__(256) void laia_lru_classify_kernel(const LaiaLru a) {
+    __shared__ uint32_t s_w[4];
+    const int w = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+    uint32_t *stamp = a.stamp + static_cast<long long>(w) * a.R;
+    uint8_t *valid = a.valid + static_cast<long long>(w) * a.R;
+    const uint32_t *T = a.touch_rows + a.tw_off[w];
+    const uint32_t *P = a.plan_rows + a.pl_off[w];
+    const int n = a.tw_off[w + 1] - a.tw_off[w], m = a.pl_off[w + 1] - a.pl_off[w];
+    uint32_t *flag = a.flag + static_cast<long long>(w) * a.BT;
+    uint32_t *newcnt = a.newcnt + static_cast<long long>(w) * (a.BT + 1);
+    for (int i = g * 256 + t; i < m; i += kLaiaLruBlocks * 256) {
+        const uint32_t r = P[i];
+        if (stamp[r] != 0 && valid[r])
+            valid[r] = 0;
+    }
+    const int chunk = laia_chunk(n), c0 = g * chunk, c1 = min(n, c0 + chunk);
+    const int per = (chunk + 255) / 256;
+    uint32_t mine = 0;
+    for (int q = 0; q < per; ++q) {
+        const int i = c0 + t * per + q;
+        if (i < c1) {
+            const uint32_t r = T[i];
+            const bool old = stamp[r] != 0;
+            // a row that is also a plan key is outdated by another thread of this launch: decide that from the list
+            const bool val = valid[r] && laia_find(P, m, r) < 0;
+            flag[i] = (old ? 1u : 0u) | (val ? 2u : 0u);
+            mine += old ? 0u : 1u;
+        }
+    }
+    uint32_t tot;
+    uint32_t run = laia_block_scan_u32(mine, s_w, &tot);
+    for (int q = 0; q < per; ++q) {
+        const int i = c0 + t * per + q;
+        if (i < c1) {
+            newcnt[i] = run;
+            run += (flag[i] & 1u) ? 0u : 1u;
+        }
+    }
+    if (t == 0)
+        a.blocktot[w * kLaiaLruBlocks + g] = tot;
+}
+
+// Phase 2 (one workgroup per worker): the victims and the early evictions
+__global__ __launch_bounds__(1024) void laia_lru_window_kernel(const LaiaLru a, uint32_t debug_wrap_at) {
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_u64[4];
     __shared__ uint32_t s_eb[1024];       // positions of the early-evicted lines (more: sticky error)
     __shared__ uint32_t s_misc[8];
+    __shared__ uint32_t s_boff[kLaiaLruBlocks + 1];
     const int w = blockIdx.x, t = threadIdx.x;
     LruState &st = a.state[w];
     uint32_t *stamp = a.stamp + static_cast<long long>(w) * a.R;
@@ -780,15 +825,24 @@ __global__ __launch_bounds__(1024) void laia_lru_kernel(const LaiaLru a, uint32_
     uint32_t *lk = a.log_key + static_cast<long long>(w) * a.L;
     uint32_t *ls = a.log_stamp + static_cast<long long>(w) * a.L;
     const uint32_t *T = a.touch_rows + a.tw_off[w];
-    const uint32_t *P = a.plan_rows + a.pl_off[w];
     const int n = a.tw_off[w + 1] - a.tw_off[w], m = a.pl_off[w + 1] - a.pl_off[w];
     uint32_t *flag = a.flag + static_cast<long long>(w) * a.BT;
-    uint32_t *newcnt = a.newcnt + static_cast<long long>(w) * (a.BT + 1);
+    const uint32_t *newcnt = a.newcnt + static_cast<long long>(w) * (a.BT + 1);
     uint32_t *cand = a.cand + static_cast<long long>(w) * 3 * a.cand_cap;
     const unsigned long long mask = static_cast<unsigned long long>(a.L) - 1ull;
     if (t < 8)
         s_misc[t] = 0;
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int g = 0; g < kLaiaLruBlocks; ++g) {
+            s_boff[g] = run;
+            run += a.blocktot[w * kLaiaLruBlocks + g];
+        }
+        s_boff[kLaiaLruBlocks] = run;
+    }
     __syncthreads();
+    const uint32_t new_total = s_boff[kLaiaLruBlocks];
+    const int chunk = laia_chunk(n);
 
     // room in the log for n appends, and the 32-bit stamp counter
     const bool wrap = static_cast<unsigned long long>(st.counter) + static_cast<unsigned long long>(n) >=
@@ -796,44 +850,13 @@ __global__ __launch_bounds__(1024) void laia_lru_kernel(const LaiaLru a, uint32_
     if (wrap || st.log_size + static_cast<unsigned long long>(n) > static_cast<unsigned long long>(a.L))
         laia_log_compact(a, w, wrap, s_w, s_u64);
 
-    // 1. outdate the plan keys (mini_lru_cache.h:120-128)
-    for (int i = t; i < m; i += 1024) {
-        const uint32_t r = P[i];
-        if (stamp[r] != 0 && valid[r])
-            valid[r] = 0;
-    }
-    __syncthreads();
-    // 2. the rows of the batch: resident? valid?  A(i) = absent rows among the first i
-    const int per = (n + 1023) / 1024;
-    uint32_t mine = 0;
-    for (int q = 0; q < per; ++q) {
-        const int i = t * per + q;
-        if (i < n) {
-            const uint32_t r = T[i];
-            const bool old = stamp[r] != 0;
-            flag[i] = (old ? 1u : 0u) | (valid[r] ? 2u : 0u);
-            mine += old ? 0u : 1u;
-        }
-    }
-    uint32_t new_total;
-    uint32_t run = laia_block_scan_u32(mine, s_w, &new_total);
-    for (int q = 0; q < per; ++q) {
-        const int i = t * per + q;
-        if (i < n) {
-            newcnt[i] = run;                      // A(i): before row i (0-based) = among the first i rows
-            run += (flag[i] & 1u) ? 0u : 1u;
-        }
-    }
-    if (t == 0)
-        newcnt[n] = new_total;
     const int live0 = st.live;
     const long long Nll = static_cast<long long>(live0) + new_total - a.cap;
     const uint32_t N = Nll > 0 ? static_cast<uint32_t>(Nll) : 0u;
-    __syncthreads();
-    // 3. the first N live log entries that are not rows of the batch are the victims; batch rows met on the way are
-    //    candidates for an early eviction
+    // the first N live log entries that are not rows of the batch are the victims; batch rows met on the way are
+    // candidates for an early eviction
     unsigned long long consumed = 0;      // log entries passed (up to and including the N-th victim)
-    uint32_t nb_base = 0, ncand = 0, push_valid = 0;
+    uint32_t nb_base = 0, ncand = 0;
     const unsigned long long head = st.log_head, size = st.log_size;
     while (nb_base < N && consumed < size) {
         const unsigned long long r = consumed + t;
@@ -863,22 +886,16 @@ __global__ __launch_bounds__(1024) void laia_lru_kernel(const LaiaLru a, uint32_
             if (c < static_cast<uint32_t>(a.cand_cap)) {
                 cand[3 * c + 0] = static_cast<uint32_t>(pos);            // 0-based position
                 cand[3 * c + 1] = nb_base + ex_nb;                         // non-batch lines before it
-                cand[3 * c + 2] = newcnt[pos];                             // A(position - 1) for the 1-based position
+                cand[3 * c + 2] = s_boff[pos / chunk] + newcnt[pos];       // A(position - 1) for the 1-based position
             }
         }
-        // the N-th victim ends the window: entries behind it stay in the log
-        uint32_t last = 0xFFFFFFFFu;
         if (victim && nb_base + ex_nb + 1 == N)
-            last = t;
-        // (at most one thread has it)
-        if (last != 0xFFFFFFFFu)
-            s_misc[1] = last + 1;
+            s_misc[1] = t + 1;         // the N-th victim ends the window: entries behind it stay in the log
         __syncthreads();
-        if (nb_base + tot_nb >= N) {
+        if (nb_base + tot_nb >= N)
             consumed += s_misc[1];
-        } else {
+        else
             consumed += (size - consumed < 1024ull) ? (size - consumed) : 1024ull;
-        }
         nb_base += tot_nb;
         ncand += tot_c;
         __syncthreads();
@@ -891,12 +908,10 @@ __global__ __launch_bounds__(1024) void laia_lru_kernel(const LaiaLru a, uint32_
     }
     if (ncand > static_cast<uint32_t>(a.cand_cap))
         ncand = static_cast<uint32_t>(a.cand_cap);
-    push_valid = 0;
     __syncthreads();
-    // 4. early evictions, in log order (one thread; the candidates are few: lines near the LRU end that this very
-    //    batch names)
+    // early evictions, in log order (one thread; the candidates are few: lines near the LRU end that this very batch names)
     if (t == 0) {
-        uint32_t eb = 0;
+        uint32_t eb = 0, push_valid = 0;
         for (uint32_t c = 0; c < ncand; ++c) {
             const uint32_t pos = cand[3 * c], nbb = cand[3 * c + 1], A = cand[3 * c + 2];
             uint32_t ebc = 0;
@@ -914,16 +929,35 @@ __global__ __launch_bounds__(1024) void laia_lru_kernel(const LaiaLru a, uint32_
                 flag[pos] |= 4u;
             }
         }
-        s_misc[2] = eb;
-        s_misc[3] = push_valid;
+        st.apply_counter0 = st.counter;
+        st.apply_tail = head + size;
+        st.counter = st.counter + static_cast<uint32_t>(n);
+        st.live = live0 + static_cast<int>(new_total) - static_cast<int>(nb_base < N ? nb_base : N);
+        st.log_head = (head + consumed) & mask;
+        st.log_size = size - consumed + static_cast<unsigned long long>(n);
+        st.miss_pull += new_total + eb;
+        st.miss_push += s_misc[0] + push_valid;
+        st.update_push += static_cast<unsigned long long>(m);
     }
-    __syncthreads();
-    const uint32_t eb_total = s_misc[2];
-    // 5. every row of the batch ends resident, valid, stamped in batch order; log appends
-    const uint32_t counter0 = st.counter;
-    const unsigned long long tail = head + size;
+}
+
+// Phase 3 (W x kLaiaLruBlocks workgroups): every row of the batch ends resident, valid, stamped in batch order; log appends
+__global__ __launch_bounds__(256) void laia_lru_apply_kernel(const LaiaLru a) {
+    __shared__ uint32_t s_w[4];
+    const int w = blockIdx.y, t = threadIdx.x;
+    LruState &st = a.state[w];
+    uint32_t *stamp = a.stamp + static_cast<long long>(w) * a.R;
+    uint8_t *valid = a.valid + static_cast<long long>(w) * a.R;
+    uint32_t *lk = a.log_key + static_cast<long long>(w) * a.L;
+    uint32_t *ls = a.log_stamp + static_cast<long long>(w) * a.L;
+    const uint32_t *T = a.touch_rows + a.tw_off[w];
+    const int n = a.tw_off[w + 1] - a.tw_off[w];
+    const uint32_t *flag = a.flag + static_cast<long long>(w) * a.BT;
+    const unsigned long long mask = static_cast<unsigned long long>(a.L) - 1ull;
+    const uint32_t counter0 = st.apply_counter0;
+    const unsigned long long tail = st.apply_tail;
     uint32_t upd = 0;
-    for (int i = t; i < n; i += 1024) {
+    for (int i = blockIdx.x * 256 + t; i < n; i += kLaiaLruBlocks * 256) {
         const uint32_t r = T[i];
         const uint32_t f = flag[i];
         if ((f & 1u) && !(f & 2u) && !(f & 4u))
@@ -933,20 +967,11 @@ __global__ __launch_bounds__(1024) void laia_lru_kernel(const LaiaLru a, uint32_
         lk[(tail + i) & mask] = r;
         ls[(tail + i) & mask] = counter0 + static_cast<uint32_t>(i) + 1u;
     }
-    uint32_t upd_total;
-    (void)laia_block_scan_u32(upd, s_w, &upd_total);
-    if (t == 0) {
-        st.counter = counter0 + static_cast<uint32_t>(n);
-        st.live = live0 + static_cast<int>(new_total) - static_cast<int>(nb_base < N ? nb_base : N);
-        st.log_head = (head + consumed) & mask;
-        st.log_size = size - consumed + static_cast<unsigned long long>(n);
-        st.miss_pull += new_total + eb_total;
-        st.miss_push += s_misc[0] + s_misc[3];
-        st.update_pull += upd_total;
-        st.update_push += static_cast<unsigned long long>(m);
-    }
+    uint32_t tot;
+    (void)laia_block_scan_u32(upd, s_w, &tot);
+    if (t == 0 && tot)
+        atomicAdd(&st.update_pull, static_cast<unsigned long long>(tot));
 }
-
 
 // ---- host side of the device-resident mode ------------------------------------------------------------------------
 struct LaiaDev {
@@ -957,7 +982,11 @@ struct LaiaDev {
     LaiaBits bits{};
     LaiaLru lru{};
     long long *d_dist = nullptr;
-    // pinned: dist [W * Bcap], offsets [2 * (W + 1)], plan rows [plan_cap], states [W]
+    // what the host reads per batch sits in ONE device block -- dist [W * Bcap], offsets [2 * (W + 1)], states [W] --
+    // mirrored in pinned memory by a single copy; the plan rows follow in a second one (their number is only known then)
+    char *d_out = nullptr, *h_out = nullptr;
+    size_t out_bytes = 0, off_at = 0, state_at = 0;
+    long long plan_guess = 0;      // plan rows copied along with the block (the last batch's count and a margin)
     long long *h_dist = nullptr;
     int32_t *h_off = nullptr;
     uint32_t *h_plan_rows = nullptr;
@@ -1156,8 +1185,7 @@ extern "C" void ha_laia_destroy(ha_laia *h) {
         (void)hipHostFree(h->l.h_touch);
     if (h->l.h_plan)
         (void)hipHostFree(h->l.h_plan);
-    for (void *p : {static_cast<void *>(h->l.dev.h_dist), static_cast<void *>(h->l.dev.h_off),
-                    static_cast<void *>(h->l.dev.h_plan_rows), static_cast<void *>(h->l.dev.h_state)})
+    for (void *p : {static_cast<void *>(h->l.dev.h_out), static_cast<void *>(h->l.dev.h_plan_rows)})
         if (p)
             (void)hipHostFree(p);
     (void)hipStreamDestroy(h->l.stream);
@@ -1233,23 +1261,32 @@ static int laia_dev_init(Laia &l) {
     alloc(reinterpret_cast<void **>(&d.lru.stamp), static_cast<size_t>(W) * R * 4, true);
     alloc(reinterpret_cast<void **>(&d.lru.log_key), static_cast<size_t>(W) * L * 4, false);
     alloc(reinterpret_cast<void **>(&d.lru.log_stamp), static_cast<size_t>(W) * L * 4, false);
-    alloc(reinterpret_cast<void **>(&d.lru.state), static_cast<size_t>(W) * sizeof(LruState), true);
     alloc(reinterpret_cast<void **>(&d.lru.flag), static_cast<size_t>(W) * BT * 4, false);
     alloc(reinterpret_cast<void **>(&d.lru.newcnt), static_cast<size_t>(W) * (BT + 1) * 4, false);
     alloc(reinterpret_cast<void **>(&d.lru.cand), static_cast<size_t>(W) * 3 * d.cand_cap * 4, false);
+    alloc(reinterpret_cast<void **>(&d.lru.blocktot), static_cast<size_t>(W) * kLaiaLruBlocks * 4, true);
     for (int k = 0; k < 2; ++k) {
         alloc(reinterpret_cast<void **>(&d.bits.bits[k]), nwords * 8, true);
         alloc(reinterpret_cast<void **>(&d.bits.sum[k]), static_cast<size_t>(d.nsum) * 8, true);
         alloc(reinterpret_cast<void **>(&d.bits.rows[k]), (k == 0 ? BT : l.plan_cap) * 4, false);
-        alloc(reinterpret_cast<void **>(&d.bits.off[k]), static_cast<size_t>(W + 1) * 4, true);
         alloc(reinterpret_cast<void **>(&d.bits.cnt[k]), static_cast<size_t>(d.nsum) * 4, false);
         alloc(reinterpret_cast<void **>(&d.bits.blk[k]), static_cast<size_t>(d.nblk + 1) * 4, false);
     }
-    alloc(reinterpret_cast<void **>(&d.d_dist), static_cast<size_t>(W) * l.Bcap * 8, false);
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_dist), static_cast<size_t>(W) * l.Bcap * 8, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_off), static_cast<size_t>(2 * (W + 1)) * 4, hipHostMallocDefault) == hipSuccess;
+    d.off_at = static_cast<size_t>(l.Bcap) * 8;                                   // dist holds one entry per sample
+    d.state_at = (d.off_at + static_cast<size_t>(2 * (W + 1)) * 4 + 15) / 16 * 16;
+    d.out_bytes = d.state_at + static_cast<size_t>(W) * sizeof(LruState);
+    alloc(reinterpret_cast<void **>(&d.d_out), d.out_bytes, true);
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_out), d.out_bytes, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_plan_rows), (l.plan_cap + 4) * 4, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_state), static_cast<size_t>(W) * sizeof(LruState), hipHostMallocDefault) == hipSuccess;
+    if (ok) {
+        d.d_dist = reinterpret_cast<long long *>(d.d_out);
+        d.bits.off[0] = reinterpret_cast<int32_t *>(d.d_out + d.off_at);
+        d.bits.off[1] = d.bits.off[0] + (W + 1);
+        d.lru.state = reinterpret_cast<LruState *>(d.d_out + d.state_at);
+        d.h_dist = reinterpret_cast<long long *>(d.h_out);
+        d.h_off = reinterpret_cast<int32_t *>(d.h_out + d.off_at);
+        d.h_state = reinterpret_cast<LruState *>(d.h_out + d.state_at);
+    }
     HA_REQUIRE(ok, "laia: device allocation of the resident scheduler state failed");
     d.lru.valid = l.d_valid;
     d.lru.touch_rows = d.bits.rows[0];
@@ -1267,8 +1304,7 @@ static int laia_dev_init(Laia &l) {
 }
 
 static int laia_dev_states(Laia &l) {   // -> l.dev.h_state (synchronises the scheduler's stream)
-    HA_CHECK_HIP(hipMemcpyAsync(l.dev.h_state, l.dev.lru.state, static_cast<size_t>(l.W) * sizeof(LruState),
-                                hipMemcpyDeviceToHost, l.stream));
+    HA_CHECK_HIP(hipMemcpyAsync(l.dev.h_out, l.dev.d_out, l.dev.out_bytes, hipMemcpyDeviceToHost, l.stream));
     HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     return 0;
 }
@@ -1300,14 +1336,15 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     hipLaunchKernelGGL(laia_bits_scan_kernel, dim3(2), dim3(1024), 0, l.stream, d.bits, d.nblk);
     hipLaunchKernelGGL(laia_bits_emit_kernel, dim3(d.nblk, 2), dim3(1024), 0, l.stream, d.bits, d.nsum, d.sum_per_worker, W,
                        d.Rpad);
-    hipLaunchKernelGGL(laia_lru_kernel, dim3(W), dim3(1024), 0, l.stream, d.lru, d.debug_wrap_at);
+    hipLaunchKernelGGL(laia_lru_classify_kernel, dim3(kLaiaLruBlocks, W), dim3(256), 0, l.stream, d.lru);
+    hipLaunchKernelGGL(laia_lru_window_kernel, dim3(W), dim3(1024), 0, l.stream, d.lru, d.debug_wrap_at);
+    hipLaunchKernelGGL(laia_lru_apply_kernel, dim3(kLaiaLruBlocks, W), dim3(256), 0, l.stream, d.lru);
     HA_LAUNCH_CHECK();
-    HA_CHECK_HIP(hipMemcpyAsync(d.h_dist, d.d_dist, static_cast<size_t>(B) * 8, hipMemcpyDeviceToHost, l.stream));
-    HA_CHECK_HIP(hipMemcpyAsync(d.h_off, d.bits.off[0], static_cast<size_t>(W + 1) * 4, hipMemcpyDeviceToHost, l.stream));
-    HA_CHECK_HIP(hipMemcpyAsync(d.h_off + (W + 1), d.bits.off[1], static_cast<size_t>(W + 1) * 4, hipMemcpyDeviceToHost,
-                                l.stream));
-    HA_CHECK_HIP(hipMemcpyAsync(d.h_state, d.lru.state, static_cast<size_t>(W) * sizeof(LruState), hipMemcpyDeviceToHost,
-                                l.stream));
+    HA_CHECK_HIP(hipMemcpyAsync(d.h_out, d.d_out, d.out_bytes, hipMemcpyDeviceToHost, l.stream));
+    long long guess = d.plan_guess < static_cast<long long>(l.plan_cap) ? d.plan_guess : static_cast<long long>(l.plan_cap);
+    if (guess > 0)
+        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows, d.bits.rows[1], static_cast<size_t>(guess) * 4, hipMemcpyDeviceToHost,
+                                    l.stream));
     HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     for (int w = 0; w < W; ++w)
         HA_REQUIRE(d.h_state[w].err == 0, "laia: the device snapshot of worker %d is inconsistent (code %d)", w,
@@ -1315,11 +1352,12 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     const int32_t *pl_off = d.h_off + (W + 1);
     const long long nplan = pl_off[W];
     HA_REQUIRE(nplan <= plan_cap_elems && nplan <= static_cast<long long>(l.plan_cap), "laia_next: plan buffer too small");
-    if (nplan > 0) {
-        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows, d.bits.rows[1], static_cast<size_t>(nplan) * 4, hipMemcpyDeviceToHost,
-                                    l.stream));
+    if (nplan > guess) {      // more plan rows than guessed: fetch the rest
+        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows + guess, d.bits.rows[1] + guess, static_cast<size_t>(nplan - guess) * 4,
+                                    hipMemcpyDeviceToHost, l.stream));
         HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     }
+    d.plan_guess = nplan + nplan / 4 + 4096;
     for (long long k = 0; k < B; ++k)
         dist_out[k] = d.h_dist[k];
     for (int w = 0; w <= W; ++w)
