@@ -518,7 +518,7 @@ __global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__rest
 // by one lane (leader loop over the distinct values), and only if a look at the word says it is not set yet: a few
 // atomics per hot row and batch instead of thousands on one address.
 __device__ __forceinline__ void laia_set_bits(unsigned long long *__restrict__ bits, unsigned long long *__restrict__ sum,
-                                              unsigned long long b, bool on) {
+                                              uint32_t *__restrict__ nset, unsigned long long b, bool on) {
     // leader = the lowest lane of every distinct value (register-only loop), then all leaders go to memory at once
     unsigned long long todo = __ballot(on);
     bool leader = false;
@@ -533,6 +533,8 @@ __device__ __forceinline__ void laia_set_bits(unsigned long long *__restrict__ b
         const unsigned long long old = atomicOr(&bits[b >> 6], 1ull << (b & 63));
         if (old == 0)
             atomicOr(&sum[b >> 12], 1ull << ((b >> 6) & 63));
+        if (!((old >> (b & 63)) & 1ull))
+            atomicAdd(&nset[b >> 12], 1u);      // bits set below this summary word: what the compaction scans
     }
 }
 
@@ -543,7 +545,8 @@ __global__ __launch_bounds__(256) void laia_bits_kernel(const uint32_t *__restri
                                                         unsigned long long *__restrict__ tbits,
                                                         unsigned long long *__restrict__ tsum,
                                                         unsigned long long *__restrict__ pbits,
-                                                        unsigned long long *__restrict__ psum) {
+                                                        unsigned long long *__restrict__ psum,
+                                                        uint32_t *__restrict__ tnset, uint32_t *__restrict__ pnset) {
     const long long total = static_cast<long long>(B) * T;
     const long long trips = (total + gridDim.x * 256ll - 1) / (gridDim.x * 256ll);     // whole waves make every trip
     for (long long tr = 0; tr < trips; ++tr) {
@@ -560,10 +563,10 @@ __global__ __launch_bounds__(256) void laia_bits_kernel(const uint32_t *__restri
             ow = owner[i];
             m = live ? (mask[i * T + j] & ~(1ull << ow)) : 0ull;
         }
-        laia_set_bits(tbits, tsum, static_cast<unsigned long long>(ow) * Rpad + emb, live);
+        laia_set_bits(tbits, tsum, tnset, static_cast<unsigned long long>(ow) * Rpad + emb, live);
         for (int w = 0; w < W; ++w)
             if (__ballot((m >> w) & 1ull))       // wave-uniform: some lane names worker w
-                laia_set_bits(pbits, psum, static_cast<unsigned long long>(w) * Rpad + emb, ((m >> w) & 1ull) != 0);
+                laia_set_bits(pbits, psum, pnset, static_cast<unsigned long long>(w) * Rpad + emb, ((m >> w) & 1ull) != 0);
     }
 }
 
@@ -571,7 +574,8 @@ struct LaiaBits {
     unsigned long long *bits[2], *sum[2];   // 0 = touch, 1 = plan
     uint32_t *rows[2];                      // output: rows ascending per worker
     int32_t *off[2];                        // [W + 1]
-    uint32_t *cnt[2];                       // per-thread counts, then exclusive offsets  [nsum]
+    uint32_t *nset[2];                      // bits set below every summary word (counted by laia_bits_kernel)  [nsum]
+    uint32_t *cnt[2];                       // exclusive offsets inside a block  [nsum]
     uint32_t *blk[2];                       // per-block totals, then exclusive offsets   [nblk + 1]
 };
 
@@ -599,36 +603,25 @@ __device__ __forceinline__ uint32_t laia_block_scan_u32(uint32_t v, uint32_t *s_
     return base + incl - v;
 }
 
-// one WAVE per summary word (4,096 rows, lane k = its data word k): number of set bits below it
+// exclusive offsets of the summary words inside blocks of 16 (the counts come from laia_bits_kernel), block totals
 __global__ __launch_bounds__(1024) void laia_bits_count_kernel(LaiaBits a, long long nsum) {
-    __shared__ uint32_t s_c[16];
     const int which = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long x = blockIdx.x * 16ll + wv;
-    uint32_t c = 0;
-    if (x < nsum) {
-        const unsigned long long sw = a.sum[which][x];      // wave-uniform
-        if (sw != 0 && ((sw >> lane) & 1ull))
-            c = __builtin_popcountll(a.bits[which][x * 64 + lane]);
+    const long long y = blockIdx.x * 1024ll + threadIdx.x;     // summary word; 16 consecutive ones form an emit block
+    const int lane = threadIdx.x & 63;
+    uint32_t c = y < nsum ? a.nset[which][y] : 0u;
+    if (y < nsum && c)
+        a.nset[which][y] = 0;
+    uint32_t incl = c;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            c += __shfl_xor(c, o, 64);
+    for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if ((lane & 15) >= o)
+            incl += v;
     }
-    if (lane == 0)
-        s_c[wv] = c;
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        uint32_t ex = 0, tot = 0;
-        for (int k = 0; k < 16; ++k) {
-            if (k < static_cast<int>(threadIdx.x))
-                ex += s_c[k];
-            tot += s_c[k];
-        }
-        const long long y = blockIdx.x * 16ll + threadIdx.x;
-        if (y < nsum)
-            a.cnt[which][y] = ex;
-        if (threadIdx.x == 0)
-            a.blk[which][blockIdx.x] = tot;
+    if (y < nsum) {
+        a.cnt[which][y] = incl - c;
+        if ((lane & 15) == 15 || y == nsum - 1)
+            a.blk[which][y >> 4] = incl;
     }
 }
 
@@ -1270,6 +1263,7 @@ static int laia_dev_init(Laia &l) {
         alloc(reinterpret_cast<void **>(&d.bits.sum[k]), static_cast<size_t>(d.nsum) * 8, true);
         alloc(reinterpret_cast<void **>(&d.bits.rows[k]), (k == 0 ? BT : l.plan_cap) * 4, false);
         alloc(reinterpret_cast<void **>(&d.bits.cnt[k]), static_cast<size_t>(d.nsum) * 4, false);
+        alloc(reinterpret_cast<void **>(&d.bits.nset[k]), static_cast<size_t>(d.nsum) * 4, true);
         alloc(reinterpret_cast<void **>(&d.bits.blk[k]), static_cast<size_t>(d.nblk + 1) * 4, false);
     }
     d.off_at = static_cast<size_t>(l.Bcap) * 8;                                   // dist holds one entry per sample
@@ -1331,8 +1325,10 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     hipLaunchKernelGGL(laia_assign_kernel, dim3(1), dim3(1024), 0, l.stream, l.d_scores, (int)B, W, (int)mini_bs,
                        (long long)batch_id, start, l.S, l.d_owner, d.d_dist);
     hipLaunchKernelGGL(laia_bits_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
-                       l.d_mask, l.d_owner, l.R, d.Rpad, d.bits.bits[0], d.bits.sum[0], d.bits.bits[1], d.bits.sum[1]);
-    hipLaunchKernelGGL(laia_bits_count_kernel, dim3(d.nblk, 2), dim3(1024), 0, l.stream, d.bits, d.nsum);
+                       l.d_mask, l.d_owner, l.R, d.Rpad, d.bits.bits[0], d.bits.sum[0], d.bits.bits[1], d.bits.sum[1],
+                       d.bits.nset[0], d.bits.nset[1]);
+    hipLaunchKernelGGL(laia_bits_count_kernel, dim3(static_cast<unsigned>((d.nsum + 1023) / 1024), 2), dim3(1024), 0, l.stream,
+                       d.bits, d.nsum);
     hipLaunchKernelGGL(laia_bits_scan_kernel, dim3(2), dim3(1024), 0, l.stream, d.bits, d.nblk);
     hipLaunchKernelGGL(laia_bits_emit_kernel, dim3(d.nblk, 2), dim3(1024), 0, l.stream, d.bits, d.nsum, d.sum_per_worker, W,
                        d.Rpad);
@@ -1358,12 +1354,14 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
         HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     }
     d.plan_guess = nplan + nplan / 4 + 4096;
+    const double t_out0 = now_us();
     for (long long k = 0; k < B; ++k)
         dist_out[k] = d.h_dist[k];
     for (int w = 0; w <= W; ++w)
         plan_off[w] = pl_off[w];
     for (long long k = 0; k < nplan; ++k)
         plan_out[k] = d.h_plan_rows[k];
+    l.t_assign_us += now_us() - t_out0;      // device mode: the host's share is copying dist and the plans out
     l.t_total_us += now_us() - t_begin;
     l.t_calls += 1;
     return 0;

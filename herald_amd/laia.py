@@ -89,8 +89,8 @@ class LaiaScheduler:
                                     off.ctypes.data)
 
     def _emit(self, plan, dist, off, mini_bs, rank):
-        self._q.put([int(x) for x in plan[off[rank]:off[rank + 1]]])
-        self._q.put([int(x) for x in dist[rank * mini_bs:(rank + 1) * mini_bs]])
+        self._q.put(plan[off[rank]:off[rank + 1]].tolist())        # Python ints, as the reference's pybind lists
+        self._q.put(dist[rank * mini_bs:(rank + 1) * mini_bs].tolist())
 
     def _finish(self):
         self._q.put([0])
@@ -175,7 +175,7 @@ class _Ring:
         while True:
             n = self._L.ha_shm_ring_recv(self._h, self._buf.ctypes.data, self._buf.size, ctypes.byref(need))
             if n >= 0:
-                return [int(x) for x in self._buf[:n]]
+                return self._buf[:n].tolist()
             if n == -2:
                 self._buf = np.empty(int(need.value) + 16, dtype=np.uint64)
                 continue
