@@ -53,8 +53,10 @@ def parse_args():
                    help="skip the secondary measurement of the host-DRAM cold tier (BASELINE configs[4] shape)")
     p.add_argument("--cold-rows", type=int, default=33554432,
                    help="rows of the pinned host table of the cold-tier line (x 64 floats = 8 GiB)")
-    p.add_argument("--graph-steps", type=int, default=32,
-                   help="steps captured per hipGraph (1 = eager launches)")
+    p.add_argument("--graph-steps", type=int, default=None,
+                   help="steps captured per hipGraph (1 = plain launches).  Default: plain launches for the queue engine "
+                        "(one ~14 us launch per step: the host enqueues them in ~9 us each and a launch-to-launch boundary "
+                        "on a stream is shorter than one inside a hipGraph: 13.6 vs 14.0 us per step), 32 otherwise")
     p.add_argument("--lookahead", type=int, default=None, choices=(1, 3),
                    help="older spelling of --engine: 1 = handoff, 3 = forward")
     p.add_argument("--pre-roll", type=int, default=2,
@@ -362,11 +364,13 @@ def main():
         return sharded_bench.run(args, rank, world, dev, cpu_baseline_fn=cpu_baseline)
 
     n = args.batch * args.fields
-    G = max(1, args.graph_steps)
     one = args.launches == 1
     if args.engine is None:
         args.engine = {None: "queue", 1: "handoff", 3: "forward"}[args.lookahead]
     queue = one and args.engine == "queue"
+    if args.graph_steps is None:
+        args.graph_steps = 1 if queue else 32
+    G = max(1, args.graph_steps)
     ahead2 = one and args.engine in ("forward", "queue")
     # graphs never straddle the wrap-around of the batch list; ha_step_* rotates four plans and four key tables,
     # so the list is also cut to a multiple of 4 (a graph then depends on k % nb only)
@@ -414,9 +418,15 @@ def main():
                 if k % Bk == 0:
                     pipe.prepare_block(k // Bk, ids_of, stream=main_s)
 
+            calls = {}
+
             def step(k):
                 b = k % nb
-                pipe.apply(k, grads[b % nbuf], outs[(b + 1) % nb % nbuf], stream=main_s, n_cur=n, n_next=n)
+                key = (k % rot_ring, b % nbuf, (b + 1) % nb % nbuf)
+                fn = calls.get(key)
+                if fn is None:      # arguments converted once per (rotation phase, buffers)
+                    fn = calls[key] = pipe.apply_call(k, grads[b % nbuf], outs[(b + 1) % nb % nbuf], main_s, n, n)
+                fn()
         else:
             pipe = ops.StepPipeline(table, n, LR)
             with torch.cuda.stream(main_s):
@@ -522,7 +532,9 @@ def main():
     warm = [torch.zeros(1 << 27, dtype=torch.float32, device=dev) for _ in range(2)] if args.clock_warm > 0 else None
     torch.cuda.synchronize()
     gate = None
-    if not args.no_gate:
+    # the gate holds the stream until everything behind it is enqueued: with plain launches that is one queue packet per
+    # step, so only short runs are gated (a full hardware queue behind a closed gate would never drain)
+    if not args.no_gate and (use_graph or args.steps + pre <= 512):
         from herald_amd import _lib as _hl
         gate = torch.zeros(1, dtype=torch.int32).pin_memory()
         with torch.cuda.stream(main_s):
@@ -653,7 +665,7 @@ def main():
                    "lookahead_batches": (pipe.LOOKAHEAD if queue else 3 if ahead2 else 1),
                    "engine": args.engine if one else "two launches",
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
-                             else "eager",
+                             else "plain launches, one per step, enqueued ahead of the device",
                    "parallelism": "1 GPU"},
         "step_algorithmic_bytes": fwd_b + bwd_b,
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,

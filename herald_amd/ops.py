@@ -782,6 +782,26 @@ class QueueStepPipeline:
         else:
             check(L.ha_debug_qapply(*args, _ptr(dbg), _stream_ptr(stream)), "ha_debug_qapply")
 
+    def apply_call(self, c, grads, out, stream, n_cur, n_next):
+        """-> zero-argument callable that enqueues step c's launch with the arguments converted once (the steps of a
+        long run repeat every ROTATION steps with a fixed set of buffers; the per-call ctypes conversion of apply() costs
+        more host time than the launch itself)."""
+        L = _lib.load()
+        t = self.table
+        rows, width = t.shape
+        args = (ctypes.c_void_p(t.data_ptr()), ctypes.c_int64(rows), ctypes.c_int64(width),
+                ctypes.c_void_p(self.plan_of(c).ws.data_ptr() if n_cur else None), ctypes.c_int64(n_cur),
+                ctypes.c_void_p(grads.data_ptr() if n_cur else None), ctypes.c_float(self.lr),
+                ctypes.c_void_p(self.plan_of(c + 1).ws.data_ptr() if n_next else None), ctypes.c_int64(n_next),
+                ctypes.c_void_p(out.data_ptr() if n_next else None), ctypes.c_void_p(self._queue(c)),
+                ctypes.c_int64(self.capacity), _stream_ptr(stream))
+        fn = L.ha_qapply
+
+        def call():
+            if fn(*args) != 0:
+                check(-1, "ha_qapply")
+        return call
+
     # ---- the stream protocol --------------------------------------------------------------------------------------
     def _call(self, c, grads, ahead_ids, out, stream):
         if c % self.block == 0:

@@ -53,15 +53,18 @@ def test_bench_handoff_engine_line(dev):
     assert "step_kernel" in d["roofline"]["kernel"] and d["value"] > 0
 
 
-def test_bench_short_driver_run_replays_graphs(dev):
-    """The driver's `--steps 20 --warmup 5`: every timed step runs inside a hipGraph replay, the line
-    reports the warm-up it was asked for and the launch mode it really used."""
-    d = _run({}, "--rows", "1000000", "--steps", "20", "--warmup", "5", "--distinct-batches", "64",
-             "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier", "--no-laia")
+def test_bench_short_driver_run(dev):
+    """The driver's `--steps 20 --warmup 5`: the line reports the warm-up it was asked for and the launch mode it really
+    used -- plain launches for the queue engine by default, hipGraph replays on request."""
+    common = ("--rows", "1000000", "--steps", "20", "--warmup", "5", "--distinct-batches", "64",
+              "--no-cache-tier", "--no-cpu-baseline", "--no-cold-tier", "--no-laia")
+    d = _run({}, *common)
     assert d["steps"] == 20 and d["warmup"] == 5
-    assert "hipGraph" in d["config"]["launch"]        # steps 5..24: the blocks [0, 16) and [16, 32) -> two replays
+    assert "plain launches" in d["config"]["launch"] and "gate" in d["timed_region"]
     assert d["config"]["grad_and_out_buffers"] >= 24
     assert abs(d["ms_per_step"] * 20 - max(d["device_ms"], d["enqueue_ms"])) < 1e-6
+    g = _run({}, *common, "--graph-steps", "16")
+    assert "hipGraph" in g["config"]["launch"]        # steps 5..24: the blocks [0, 16) and [16, 32) -> two replays
 
 
 def test_bench_two_launch_mode_still_reports_measured_kernel_times(dev):
