@@ -55,8 +55,9 @@ def parse_args():
                    help="rows of the pinned host table of the cold-tier line (x 64 floats = 8 GiB)")
     p.add_argument("--graph-steps", type=int, default=None,
                    help="steps captured per hipGraph (1 = plain launches).  Default: plain launches for the queue engine "
-                        "(one ~14 us launch per step: the host enqueues them in ~9 us each and a launch-to-launch boundary "
-                        "on a stream is shorter than one inside a hipGraph: 13.6 vs 14.0 us per step), 32 otherwise")
+                        "(one ~14 us launch per step: the host enqueues a block of them by one library call, ~9 us each, and "
+                        "a launch-to-launch boundary on a stream is shorter than one inside a hipGraph: 13.5 vs 14.0 us per "
+                        "step), 32 otherwise")
     p.add_argument("--lookahead", type=int, default=None, choices=(1, 3),
                    help="older spelling of --engine: 1 = handoff, 3 = forward")
     p.add_argument("--pre-roll", type=int, default=2,
@@ -407,7 +408,8 @@ def main():
             pipe = ops.QueueStepPipeline(table, n, LR, block=args.queue_block, overlap=not args.queue_serial)
             LA, Bk = pipe.LOOKAHEAD, pipe.block
             G = Bk                       # graphs are cut at block starts (the side work is enqueued between them)
-            ids_of = lambda j: ids_dev[j % nb] if j >= 0 else None
+            ids_rows = [ids_dev[i] for i in range(nb)]        # the batches as tensors of their own, sliced once
+            ids_of = lambda j: ids_rows[j % nb] if j >= 0 else None
             with torch.cuda.stream(main_s):
                 for c in range(-LA, 0):
                     if c % Bk == 0:
@@ -425,8 +427,9 @@ def main():
                 key = (k % rot_ring, b % nbuf, (b + 1) % nb % nbuf)
                 fn = calls.get(key)
                 if fn is None:      # arguments converted once per (rotation phase, buffers)
-                    fn = calls[key] = pipe.apply_call(k, grads[b % nbuf], outs[(b + 1) % nb % nbuf], main_s, n, n)
-                fn()
+                    fn = calls[key] = pipe.apply_call(k, grads[b % nbuf], outs[(b + 1) % nb % nbuf], main_s, n, n,
+                                                     sized=args.graph_steps <= 1)
+                fn(k)
         else:
             pipe = ops.StepPipeline(table, n, LR)
             with torch.cuda.stream(main_s):
@@ -473,6 +476,19 @@ def main():
     # (nb is even, so the plan / pending-table parity of step k is that of batch k % nb as well).
     use_graph = G > 1 and args.graph_steps > 1      # --graph-steps 1: plain launches (the PMC passes)
     graphs = {}
+    step_chunk = None
+    if queue and not use_graph:
+        packs = {}
+
+        def step_chunk(k, ln):
+            b = k % nb
+            key = (k % rot_ring, b, ln)
+            fn = packs.get(key)
+            if fn is None:      # arguments converted once per (rotation phase, first batch, length)
+                bs = [(k + i) % nb for i in range(ln)]
+                fn = packs[key] = pipe.apply_steps_call(k, [grads[x % nbuf] for x in bs],
+                                                        [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
+            fn(k)
 
     def chunks(k0, count):
         """[k0, k0+count) cut at the multiples of G: (first step, length) pieces of at most G steps."""
@@ -501,11 +517,19 @@ def main():
         replays = 0
         with torch.cuda.stream(main_s):
             for k, ln in chunks(k0, count):
+                _t = time.perf_counter()
                 if before_chunk is not None:
                     before_chunk(k)
+                if os.environ.get("HA_BENCH_TRACE"):
+                    sys.stderr.write("before_chunk(%d) %.1f us\n" % (k, (time.perf_counter() - _t) * 1e6))
+                    _t = time.perf_counter()
                 if use_graph:
                     graph_for(k, ln).replay()
                     replays += 1
+                elif step_chunk is not None:
+                    step_chunk(k, ln)          # the steps of a chunk enqueued by one library call
+                    if os.environ.get("HA_BENCH_TRACE"):
+                        sys.stderr.write("step_chunk(%d, %d) %.1f us\n" % (k, ln, (time.perf_counter() - _t) * 1e6))
                 else:
                     for j in range(k, k + ln):
                         step(j)
@@ -520,6 +544,13 @@ def main():
     # (ha_stream_gate) that the host opens once pre-roll, events and timed steps are all queued.
     wu = args.warmup
     pre = min(max(args.pre_roll, 0), wu)
+    if step_chunk is not None:      # convert the arguments of everything the warm-up and the timed region enqueue
+        for k, ln in list(chunks(0, wu - pre)) + list(chunks(wu - pre, pre)) + list(chunks(wu, args.steps)):
+            b = k % nb
+            if (k % rot_ring, b, ln) not in packs:
+                bs = [(k + i) % nb for i in range(ln)]
+                packs[(k % rot_ring, b, ln)] = pipe.apply_steps_call(k, [grads[x % nbuf] for x in bs],
+                                                                     [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
     if use_graph:     # capture everything the warm-up and the timed region replay, before either runs
         torch.cuda.synchronize()
         for k, ln in list(chunks(0, wu - pre)) + list(chunks(wu - pre, pre)) + list(chunks(wu, args.steps)):
@@ -527,6 +558,12 @@ def main():
         torch.cuda.synchronize()
     run(0, wu - pre)
     torch.cuda.synchronize()
+    # plain launches allocate a few Python objects per step; a generation-2 pass of the cyclic garbage collector over
+    # everything torch has imported takes 35-65 ms -- two thousand steps -- and would land in the timed region of every
+    # other short run: collect now, keep the collector off until the steps are enqueued
+    import gc
+    gc.collect()
+    gc.disable()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     warm = [torch.zeros(1 << 27, dtype=torch.float32, device=dev) for _ in range(2)] if args.clock_warm > 0 else None
@@ -555,6 +592,7 @@ def main():
         gate[0] = 1             # everything is queued: open the gate
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    gc.enable()
     dev_ms = e0.elapsed_time(e1)
     # the K steps' time on the stream (HIP events); if the host needed longer than that to enqueue them,
     # the run is host-bound and the host time counts

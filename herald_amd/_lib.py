@@ -180,6 +180,9 @@ def _declare(L):
         "ha_qqueue_batch": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp],
         "ha_stream_gate": [vp, vp],
         "ha_qapply": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, vp],
+        "ha_qapply_sized": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, vp],
+        "ha_qapply_steps": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "ha_qqueue_batch_counts": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp, vp],
         "ha_debug_qprep_f32ids": [i64, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp],
         "ha_debug_qapply": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, vp, vp],
         "ha_debug_step_fwd_timeline": [vp, i64, i64, vp, i64, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp,

@@ -624,7 +624,7 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
                                            QHeader *bqh, QEntry *bcoop, QEntry *bwave, QEntry *bcopy,
                                            const uint32_t bcap_coop, const uint32_t bcap_wave, const uint32_t bcap_copy,
                                            uint32_t *lds, uint32_t lds_bytes, const int part,
-                                           unsigned long long *ph = nullptr) {
+                                           unsigned long long *ph = nullptr, uint32_t *mirror = nullptr) {
     const int tid = threadIdx.x;
     q_phase(ph, 0);
     QJoin j;
@@ -694,6 +694,10 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             bqh->n_long = nL;
             bqh->n_medium = nM;
             bqh->n_small = nS;
+            if (mirror) {       // pinned host words: the host sizes the step's launch by them
+                mirror[0] = min(nL + nM + nS, bcap_wave) + 1u;      // + 1: 0 = not written yet
+                mirror[1] = min(nG, bcap_coop) + 1u;
+            }
         }
         q_phase(ph, 4);
         if (j.Ua > 0)
@@ -716,6 +720,8 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             bqh->n_copy = min(nM + nS, bcap_copy);
             bqh->n_copy_medium = nM;
             bqh->n_copy_small = nS;
+            if (mirror)
+                mirror[2] = min(nM + nS, bcap_copy) + 1u;
         }
         q_phase(ph, 4);
         if (j.Ug > 0)
@@ -1106,13 +1112,14 @@ struct QJoinBatch {
     QPlan pa[kQJoinBatch], pg[kQJoinBatch];
     QHeader *qh[kQJoinBatch];
     QEntry *coop[kQJoinBatch], *wave[kQJoinBatch], *copy[kQJoinBatch];
+    uint32_t *mirror[kQJoinBatch];   // optional pinned host words per step: {wave items, workgroup items, copy items} + 1
     unsigned long long *ph;     // development aid: phase stamps of workgroups 0 and 1
 };
 __global__ __launch_bounds__(1024, 4) void qqueue_kernel(const QJoinBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const int i = blockIdx.x >> 1, part = blockIdx.x & 1;
     qjoin_body(b.pa[i], b.pg[i], b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave,
-               b.cap_copy, s_dyn, b.lds_bytes, part, (i == 0 && b.ph) ? b.ph + 8 * part : nullptr);
+               b.cap_copy, s_dyn, b.lds_bytes, part, (i == 0 && b.ph) ? b.ph + 8 * part : nullptr, b.mirror[i]);
 }
 
 // One wave-instruction's LDS atomics on one address: are the lanes served in ascending lane order?  Four collision
@@ -1214,7 +1221,7 @@ static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *pla
 
 static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
                         const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
-                        hipStream_t stream, unsigned long long *ph = nullptr) {
+                        hipStream_t stream, unsigned long long *ph = nullptr, uint32_t *const *counts_host = nullptr) {
     HA_REQUIRE(rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 && width <= (1 << 20),
                "ha_qqueue_batch: rows of a multiple of 4 floats");
     HA_REQUIRE(count >= 0 && (count == 0 || (plans_a && n_a && plans_g && n_g && queues)), "ha_qqueue_batch: null pointer");
@@ -1241,6 +1248,7 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
             b.pg[i] = qplan(plans_g[k], n_g[k]);
             const QLayout q = queue_layout(queues[k], queue_n_cap, width);
             b.qh[i] = q.hdr;
+            b.mirror[i] = counts_host ? counts_host[k] : nullptr;
             b.coop[i] = q.coop;
             b.wave[i] = q.wave;
             b.copy[i] = q.copy;
@@ -1263,7 +1271,7 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
 
 static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                   void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
-                  hipStream_t stream, unsigned long long *dbg = nullptr) {
+                  hipStream_t stream, unsigned long long *dbg = nullptr, int64_t wave_items = -1) {
     HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
                    width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
                "ha_qapply: the table must be 16-byte aligned with rows of a multiple of 4 floats");
@@ -1299,6 +1307,10 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
     // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
     const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
     a.nworker = static_cast<int>(bound / 16 + 1 < kQWorkerMax ? bound / 16 + 1 : kQWorkerMax);
+    // the caller knows how many wave items the queue holds (ha_qstep_queue_mirror): no workgroups that find nothing --
+    // a shorter launch ramp, and free slots for the preparation launches that run beside the steps
+    if (wave_items >= 0 && wave_items / 16 + 1 < a.nworker)
+        a.nworker = static_cast<int>(wave_items / 16 + 1);
     hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(1024), 16 * 64 * 4, stream, a);
     HA_LAUNCH_CHECK();
     return 0;
@@ -1334,6 +1346,37 @@ extern "C" int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_c
                          int64_t queue_n_cap, ha_stream_t stream) {
     return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
                   as_stream(stream));
+}
+extern "C" int ha_qapply_sized(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                               float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                               int64_t queue_n_cap, int64_t wave_items, ha_stream_t stream) {
+    return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
+                  as_stream(stream), nullptr, wave_items);
+}
+// `count` consecutive steps enqueued by one call (the host side of a launch through ctypes costs more than the launch):
+// per-step arrays of what ha_qapply_sized takes.
+extern "C" int ha_qapply_steps(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                               void *const *plan_cur, const int64_t *n_cur, const float *const *grads,
+                               void *const *plan_next, const int64_t *n_next, float *const *next_out,
+                               const void *const *queue_cur, const int64_t *wave_items, ha_stream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (plan_cur && n_cur && grads && plan_next && n_next && next_out && queue_cur)),
+               "ha_qapply_steps: null pointer");
+    for (int64_t k = 0; k < count; ++k)
+        if (qapply(table, rows, width, plan_cur[k], n_cur[k], grads[k], lr, plan_next[k], n_next[k], next_out[k],
+                   queue_cur[k], queue_n_cap, as_stream(stream), nullptr, wave_items ? wave_items[k] : -1))
+            return -1;
+    return 0;
+}
+
+// ha_qqueue_batch that also writes {wave items + 1, workgroup items + 1, copy items + 1} of step k's queue to the three
+// pinned host words counts_host[k] (device-visible; NULL entries: none).  The caller zeroes the words before the call and
+// reads them whenever it likes: 0 = not built yet.  ha_qapply_sized takes the sum as a hint only -- a stale or missing
+// value costs time, never correctness (the waves of the apply loop over the items).
+extern "C" int ha_qqueue_batch_counts(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a,
+                                      void *const *plans_g, const int64_t *n_g, void *const *queues, int64_t queue_n_cap,
+                                      int64_t count, uint32_t *const *counts_host, ha_stream_t stream) {
+    return qqueue_batch(rows, width, plans_a, n_a, plans_g, n_g, queues, queue_n_cap, count, as_stream(stream), nullptr,
+                        counts_host);
 }
 
 // ha_qprep_*: one plan and / or one queue; ha_qstep_*: that followed by the step -- the serial forms

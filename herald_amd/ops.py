@@ -13,6 +13,7 @@ torch is plumbing only: it owns the device allocations and the stream; every com
 call into libherald_amd.so.  There is no fallback: a missing library raises HeraldAmdError.
 """
 import ctypes
+import os
 
 import torch
 
@@ -663,14 +664,28 @@ class QueueStepPipeline:
         self.ROTATION = 4 * self.block     # plans and queues of call c and call c + ROTATION are the same
         self.plans = [IndexPlan(self.capacity, self.device) for _ in range(self.NPLAN)]
         self.queue_bytes = int(L.ha_qstep_queue_bytes(self.capacity, table.shape[1]))
-        self.queues = torch.empty(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
+        self.queues = torch.zeros(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
+        # {wave items, workgroup items, copy items} (+ 1; 0 = not built yet) of the queue of step c, written to pinned host
+        # memory by the launch that builds it, in a ring long enough that a build still in flight cannot write into the
+        # slot of a later step: queues are built a block ahead, so the host usually knows the numbers when it enqueues
+        # the step and sizes the launch by them (a hint: a missing or stale one costs time, never correctness)
+        self.COUNTS = 8192
+        self.counts = torch.zeros((self.COUNTS, 4), dtype=torch.int32).pin_memory()
+        self._counts_np = self.counts.numpy()
+        self._counts_c = (ctypes.c_int32 * (self.COUNTS * 4)).from_address(self.counts.data_ptr())   # cheap scalar reads
+        self._counts_base = self.counts.data_ptr()
+        self._L = L
+        self._plan_ptr = [p.ws.data_ptr() for p in self.plans]
+        self._queue_ptr = [self.queues.data_ptr() + q * self.queue_bytes for q in range(self.NQUEUE)]
+        self._ev_pool = []
         self.reset()
 
     # ---- bookkeeping ------------------------------------------------------------------------------------------
     def reset(self, stream=None):
         self.c, self.n, self.shape, self.ids = None, {}, {}, {}
         self._ev_side = {}          # block index -> event behind the side work launched at its start
+        self._held = {}             # block index -> id tensors its plan launch reads (kept alive, not record_stream'ed)
         return self
 
     def plan_of(self, b):
@@ -692,67 +707,96 @@ class QueueStepPipeline:
         """Start of block b (call before the first step of the block, NOT inside a stream capture when overlap is on):
         the plans of the batches of block b+2 and the queues of the steps of block b+1 are enqueued (side stream), and the
         caller's stream is made to wait for the side work enqueued at the start of block b-1 -- the queues of block b.
-        `ids_of(j)` = device id tensor of batch j, or None outside the stream of batches."""
-        L = _lib.load()
+        `ids_of(j)` = device id tensor of batch j, or None outside the stream of batches.  (Host cost matters here: the
+        call sits between two steps of the caller's stream -- ~60 us for a block of 16.)"""
+        L = self._L
         rows, width = self.table.shape
         main = stream if stream is not None else torch.cuda.current_stream(self.device)
         B = self.block
         s = self.side if self.overlap else main
+        sp = _stream_ptr(s)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
         if self.overlap:
-            ev = torch.cuda.Event()
+            ev = self._event()
             ev.record(main)                    # the buffers about to be rewritten are free, the ids are there
             s.wait_event(ev)
         # plans of block b+2
-        todo = [(j, ids_of(j)) for j in range((b + 2) * B, (b + 3) * B)]
-        todo = [(j, t) for j, t in todo if t is not None and t.numel() > 0]
-        for kind in ("f32ids", "u64ids"):
-            sel = [(j, t) for j, t in todo if _ids_kind(t) == kind]
-            if not sel:
+        sel = {"f32ids": [], "u64ids": []}
+        held = []
+        for j in range((b + 2) * B, (b + 3) * B):
+            t = ids_of(j)
+            if t is None:
                 continue
-            for j, t in sel:
-                if t.numel() > self.capacity:
-                    raise ValueError("plan capacity %d < %d ids" % (self.capacity, t.numel()))
-                if not t.is_cuda or not t.is_contiguous():
-                    raise ValueError("ids must be contiguous device tensors")
-            cnt = len(sel)
-            ids_arr = (ctypes.c_void_p * cnt)(*[t.data_ptr() for _, t in sel])
-            n_arr = (ctypes.c_int64 * cnt)(*[t.numel() for _, t in sel])
-            pl_arr = (ctypes.c_void_p * cnt)(*[self.plan_of(j).ws.data_ptr() for j, _ in sel])
+            m = t.numel()
+            if m == 0:
+                continue
+            if m > self.capacity:
+                raise ValueError("plan capacity %d < %d ids" % (self.capacity, m))
+            if not t.is_cuda or not t.is_contiguous():
+                raise ValueError("ids must be contiguous device tensors")
+            sel[_ids_kind(t)].append((j, t, m))
+            held.append(t)
+            self.n[j] = m
+        for kind, lst in sel.items():
+            if not lst:
+                continue
+            cnt = len(lst)
+            ids_arr = (vp * cnt)(*[t.data_ptr() for _, t, _ in lst])
+            n_arr = (i64 * cnt)(*[m for _, _, m in lst])
+            pl_arr = (vp * cnt)(*[self._plan_ptr[j % self.NPLAN] for j, _, _ in lst])
             if ph is not None and kind == "f32ids":
-                t0 = sel[0][1]
-                check(L.ha_debug_qprep_f32ids(rows, width, _ptr(t0), t0.numel(), _ptr(self.plan_of(sel[0][0]).ws), None, 0,
-                                              None, 0, None, self.capacity, _ptr(ph), _stream_ptr(s)), "ha_debug_qprep")
-            check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, _stream_ptr(s)), "ha_qplan_batch")
-            for j, t in sel:
-                pl = self.plan_of(j)
-                pl.n = t.numel()
+                j0, t0, m0 = lst[0]
+                check(L.ha_debug_qprep_f32ids(rows, width, _ptr(t0), m0, _ptr(self.plan_of(j0).ws), None, 0,
+                                              None, 0, None, self.capacity, _ptr(ph), sp), "ha_debug_qprep")
+            check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
+            for j, _, m in lst:
+                pl = self.plans[j % self.NPLAN]
+                pl.n = m
                 pl._view = None
-                pl.produced_on(s)
-                if self.overlap:
-                    t.record_stream(s)     # the ids are read on the side stream: their memory must outlive that
-        for j, t in todo:
-            self.n[j] = t.numel()
+                pl._produced_on = sp.value if sp.value is not None else 0
+        # the ids are read on the side stream: keep them alive until the plans of the block after next are enqueued
+        self._held[b] = held
+        self._held.pop(b - 2, None)
         # queues of the steps of block b+1 (step j: batch j applied, batch j+1 looked up)
-        steps = [j for j in range((b + 1) * B, (b + 2) * B) if self.n.get(j, 0) or self.n.get(j + 1, 0)]
+        nget = self.n.get
+        steps = [j for j in range((b + 1) * B, (b + 2) * B) if nget(j, 0) or nget(j + 1, 0)]
         if steps:
             cnt = len(steps)
-            pa = (ctypes.c_void_p * cnt)(*[self.plan_of(j).ws.data_ptr() if self.n.get(j, 0) else None for j in steps])
-            na = (ctypes.c_int64 * cnt)(*[self.n.get(j, 0) for j in steps])
-            pg = (ctypes.c_void_p * cnt)(*[self.plan_of(j + 1).ws.data_ptr() if self.n.get(j + 1, 0) else None
-                                           for j in steps])
-            ng = (ctypes.c_int64 * cnt)(*[self.n.get(j + 1, 0) for j in steps])
-            qs = (ctypes.c_void_p * cnt)(*[self._queue(j) for j in steps])
+            pp, NP, NQ = self._plan_ptr, self.NPLAN, self.NQUEUE
+            pa = (vp * cnt)(*[pp[j % NP] if nget(j, 0) else None for j in steps])
+            na = (i64 * cnt)(*[nget(j, 0) for j in steps])
+            pg = (vp * cnt)(*[pp[(j + 1) % NP] if nget(j + 1, 0) else None for j in steps])
+            ng = (i64 * cnt)(*[nget(j + 1, 0) for j in steps])
+            qs = (vp * cnt)(*[self._queue_ptr[j % NQ] for j in steps])
             if ph is not None:
                 check(L.ha_debug_qprep_f32ids(rows, width, None, 0, None, pa[0], na[0], pg[0], ng[0], qs[0], self.capacity,
-                                              _ptr(ph), _stream_ptr(s)), "ha_debug_qprep")
-            check(L.ha_qqueue_batch(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, _stream_ptr(s)), "ha_qqueue_batch")
+                                              _ptr(ph), sp), "ha_debug_qprep")
+            base, ring, cc = self._counts_base, self.COUNTS, self._counts_c
+            for j in steps:
+                at = 4 * (j % ring)
+                cc[at] = 0
+                cc[at + 2] = 0
+            cs = (vp * cnt)(*[base + 16 * (j % ring) for j in steps])
+            check(L.ha_qqueue_batch_counts(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, sp), "ha_qqueue_batch")
         if self.overlap:
-            ev = torch.cuda.Event()
+            ev = self._event()
             ev.record(s)
             self._ev_side[b] = ev
             ready = self._ev_side.pop(b - 1, None)
             if ready is not None:
                 main.wait_event(ready)
+                self._ev_pool.append(ready)
+
+    def _event(self):
+        return self._ev_pool.pop() if self._ev_pool else torch.cuda.Event()
+
+    def wave_items(self, c):
+        """Wave + copy items of the queue of step c if its numbers have landed in pinned memory, else -1."""
+        if os.environ.get("HA_QHINT") == "0":
+            return -1
+        at = 4 * (c % self.COUNTS)
+        w, cp = self._counts_c[at], self._counts_c[at + 2]
+        return w + cp - 2 if w > 0 and cp > 0 else -1
 
     # ---- one step ----------------------------------------------------------------------------------------------------
     def apply(self, c, grads, out, stream=None, dbg=None, n_cur=None, n_next=None):
@@ -778,28 +822,61 @@ class QueueStepPipeline:
                 _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
                 self._queue(c), self.capacity]
         if dbg is None:
-            check(L.ha_qapply(*args, _stream_ptr(stream)), "ha_qapply")
+            check(L.ha_qapply_sized(*args, self.wave_items(c), _stream_ptr(stream)), "ha_qapply")
         else:
             check(L.ha_debug_qapply(*args, _ptr(dbg), _stream_ptr(stream)), "ha_debug_qapply")
 
-    def apply_call(self, c, grads, out, stream, n_cur, n_next):
-        """-> zero-argument callable that enqueues step c's launch with the arguments converted once (the steps of a
-        long run repeat every ROTATION steps with a fixed set of buffers; the per-call ctypes conversion of apply() costs
-        more host time than the launch itself)."""
+    def apply_call(self, c, grads, out, stream, n_cur, n_next, sized=True):
+        """-> callable(step index) that enqueues the launch of the steps c, c + ROTATION, ... with the arguments converted
+        once (the steps of a long run repeat every ROTATION steps with a fixed set of buffers; the per-call ctypes
+        conversion of apply() costs more host time than the launch itself)."""
         L = _lib.load()
         t = self.table
         rows, width = t.shape
+        hint = ctypes.c_int64(-1)
         args = (ctypes.c_void_p(t.data_ptr()), ctypes.c_int64(rows), ctypes.c_int64(width),
                 ctypes.c_void_p(self.plan_of(c).ws.data_ptr() if n_cur else None), ctypes.c_int64(n_cur),
                 ctypes.c_void_p(grads.data_ptr() if n_cur else None), ctypes.c_float(self.lr),
                 ctypes.c_void_p(self.plan_of(c + 1).ws.data_ptr() if n_next else None), ctypes.c_int64(n_next),
                 ctypes.c_void_p(out.data_ptr() if n_next else None), ctypes.c_void_p(self._queue(c)),
-                ctypes.c_int64(self.capacity), _stream_ptr(stream))
-        fn = L.ha_qapply
+                ctypes.c_int64(self.capacity), hint, _stream_ptr(stream))
+        fn = L.ha_qapply_sized
 
-        def call():
+        def call(k):
+            if sized:       # not inside a graph capture: a captured launch keeps the grid it was captured with
+                hint.value = self.wave_items(k)
             if fn(*args) != 0:
                 check(-1, "ha_qapply")
+        return call
+
+    def apply_steps_call(self, c0, grads_list, out_list, stream, n, sized=True):
+        """-> callable(first step index) that enqueues len(grads_list) consecutive steps c0, c0 + 1, ... (and the same
+        phases ROTATION steps later) by ONE library call, arguments converted once; every batch has n ids."""
+        L = _lib.load()
+        t = self.table
+        rows, width = t.shape
+        cnt = len(grads_list)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        pc = (vp * cnt)(*[self.plan_of(c0 + i).ws.data_ptr() for i in range(cnt)])
+        pn = (vp * cnt)(*[self.plan_of(c0 + i + 1).ws.data_ptr() for i in range(cnt)])
+        ns = (i64 * cnt)(*[n] * cnt)
+        gs = (vp * cnt)(*[g.data_ptr() for g in grads_list])
+        os_ = (vp * cnt)(*[o.data_ptr() for o in out_list])
+        qs = (vp * cnt)(*[self._queue(c0 + i) for i in range(cnt)])
+        hints = (i64 * cnt)(*[-1] * cnt)
+        head = (vp(t.data_ptr()), i64(rows), i64(width), ctypes.c_float(self.lr), i64(self.capacity), i64(cnt))
+        sp = _stream_ptr(stream)
+        fn = L.ha_qapply_steps
+        counts, ring = self._counts_c, self.COUNTS
+
+        def call(k0):
+            if sized:
+                for i in range(cnt):
+                    at = 4 * ((k0 + i) % ring)
+                    w, cp = counts[at], counts[at + 2]
+                    hints[i] = w + cp - 2 if w > 0 and cp > 0 else -1
+            if fn(*head, pc, ns, gs, pn, ns, os_, qs, hints, sp) != 0:
+                check(-1, "ha_qapply_steps")
         return call
 
     # ---- the stream protocol --------------------------------------------------------------------------------------

@@ -495,6 +495,22 @@ int ha_qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int
 int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
               void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
               ha_stream_t stream);
+/* ha_qapply with the number of wave items of the queue (wave + copy items; -1 = unknown) when the caller knows it: the launch
+ * then has no workgroups that find nothing.  A hint only: too small a number costs time (the waves loop over the items), never
+ * correctness.  ha_qqueue_batch_counts = ha_qqueue_batch that also writes {wave items + 1, workgroup items + 1, copy items + 1}
+ * of step k's queue to three pinned host words counts_host[k] (0 = not built yet; the caller zeroes them before the call):
+ * queues are built a block of steps ahead, so the host usually has the numbers when it enqueues the step. */
+int ha_qapply_sized(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                    float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                    int64_t queue_n_cap, int64_t wave_items, ha_stream_t stream);
+/* `count` consecutive steps enqueued by one call: per-step arrays of ha_qapply_sized's arguments (wave_items may be NULL). */
+int ha_qapply_steps(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                    void *const *plan_cur, const int64_t *n_cur, const float *const *grads, void *const *plan_next,
+                    const int64_t *n_next, float *const *next_out, const void *const *queue_cur,
+                    const int64_t *wave_items, ha_stream_t stream);
+int ha_qqueue_batch_counts(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
+                           const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
+                           uint32_t *const *counts_host, ha_stream_t stream);
 /* serial forms: ha_qprep_* = the plan of one batch (ahead_ids -> plan_ahead; n_ahead = 0: none) and / or the queue of one
  * step from (plan_a, plan_g) (n_a = n_g = 0: none); ha_qstep_*(call c) = ha_qprep_*(batch c+3; queue c+1 from plans
  * c+1 = plan_next, c+2 = plan_b1) followed by ha_qapply(step c).  A stream of batches 0..B-1 is driven as calls
