@@ -447,6 +447,15 @@ __global__ __launch_bounds__(256) void shard_serve_pull_frames_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void shard_identity_rank_kernel(const uint32_t *__restrict__ keys, int n,
+                                                                 uint32_t *__restrict__ sorted, int32_t *__restrict__ perm) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n) {
+        sorted[p] = keys[p];
+        perm[p] = p;
+    }
+}
+
 // Stable merge of the W received key lists of a framed push (each ascending, unique inside a list, kNoKey = the
 // largest key in the unused slots): slot p = (s, j) gets rank j + sum over s' < s of upper_bound(list s', key) + sum
 // over s' > s of lower_bound(list s', key) -- the position of (key, s) in the rank-ordered merge -- by binary searches
@@ -669,9 +678,15 @@ extern "C" int ha_shard_frames_serve_push(float *table, int64_t rows, int64_t wi
                "shard_frames_serve_push: bad sizes");
     const int64_t n = static_cast<int64_t>(nshard) * rcap;
     const size_t lds = static_cast<size_t>(n) * 4;
+    PlanPtrs p = plan_layout(plan_ws, n);
+    if (nshard == 1) {     // one list: it IS the merged order
+        hipLaunchKernelGGL(shard_identity_rank_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                           as_stream(stream), keys_fixed, static_cast<int>(n), p.sorted, p.perm);
+        HA_LAUNCH_CHECK();
+        return ha_sgd_apply_finish(table, rows, width, plan_ws, n, values, -1.0f, stream);
+    }
     if (lds > (size_t(64) << 10))     // lists that do not fit 64 KiB of LDS: the general sort
         return ha_shard_serve_push(table, rows, width, keys_fixed, n, values, plan_ws, stream);
-    PlanPtrs p = plan_layout(plan_ws, n);
     HA_ALLOW_LDS(shard_merge_rank_kernel, lds);
     hipLaunchKernelGGL(shard_merge_rank_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), lds,
                        as_stream(stream), keys_fixed, nshard, static_cast<int>(rcap), p.sorted, p.perm);
