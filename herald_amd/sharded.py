@@ -211,7 +211,7 @@ class HipEngine:
         blk = FrameBlock()
         blk.ksend = torch.empty((w, block, 2 + rcap), dtype=torch.int32, device=self.device)
         blk.krecv = torch.empty((w, block, 2 + rcap), dtype=torch.int32, device=self.device)
-        blk.kgot, blk.ev, blk.live = None, None, False
+        blk.kgot, blk.ev, blk.live, blk.synced = None, None, False, False
         blk.slots = []
         for i in range(block):
             fb = FrameBuffers()
@@ -221,6 +221,7 @@ class HipEngine:
             fb.rowmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
             fb.posmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
             fb.state_host = torch.zeros(2, dtype=torch.int32).pin_memory()    # written by the kernels directly
+            fb.state_c = (ctypes.c_int32 * 2).from_address(fb.state_host.data_ptr())
             fb.n, fb.ids, fb.shape, fb.routed = 0, None, (0,), False
             blk.slots.append(fb)
         return blk
@@ -284,7 +285,7 @@ class HipEngine:
                                                          self._stream()), "ha_shard_frames_unpack_batch")
 
     def frames_overflowed(self, fb):
-        return bool(fb.state_host[0].item())
+        return fb.state_c[0] != 0
 
     def frames_serve_pull(self, table, blk, fb, rows_send):
         """rows_send[g * rcap + j, :] = table[key j of rank g] for the live slots of the received key frames."""
@@ -320,6 +321,46 @@ class HipEngine:
                                                        fb.keys_fixed.data_ptr(), fb.w, fb.rcap, rows_recv.data_ptr(),
                                                        p.ws.data_ptr(), self._stream()), "ha_shard_frames_serve_push")
 
+    # the same launches as callables with their arguments converted once (a step is five launches of 4-9 us: converting
+    # the arguments through ctypes on every call costs more host time than the kernels take)
+    def _call(self, fn, what, *args):
+        check = self.check
+
+        def call():
+            if fn(*args) != 0:
+                check(-1, what)
+        return call
+
+    def frames_serve_pull_call(self, table, blk, fb, rows_send):
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        return self._call(self.lib.ha_shard_frames_serve_pull, "ha_shard_frames_serve_pull", vp(table.data_ptr()),
+                          i64(table.shape[0]), i64(table.shape[1]), vp(self._frame_ptr(blk.kgot, fb)), ctypes.c_int(fb.w),
+                          i64(fb.rcap), i64(fb.stride), vp(rows_send.data_ptr()), vp(fb.keys_fixed.data_ptr()),
+                          vp(fb.state_host.data_ptr()), vp(self._stream()))
+
+    def frames_expand_call(self, rows_recv, fb, out):
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        return self._call(self.lib.ha_gather_u32keys, "ha_gather_u32keys", vp(rows_recv.data_ptr()), i64(rows_recv.shape[0]),
+                          i64(rows_recv.shape[1]), vp(fb.posmap.data_ptr()), i64(fb.n), vp(out.data_ptr()),
+                          vp(self._stream()))
+
+    def frames_reduce_call(self, fb, values, scale, rows_send, zero_flags):
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        return self._call(self.lib.ha_apply_mapped, "ha_apply_mapped", vp(rows_send.data_ptr()), i64(fb.w * fb.rcap),
+                          i64(rows_send.shape[1]), vp(fb.plan.ws.data_ptr()), i64(fb.n), vp(values.data_ptr()),
+                          ctypes.c_float(-scale), vp(fb.rowmap.data_ptr()), vp(None), vp(zero_flags.data_ptr()),
+                          vp(self._stream()))
+
+    def frames_serve_push_call(self, table, fb, rows_recv):
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        m = fb.w * fb.rcap
+        p = self._owner_plan
+        if p is None or p.capacity < m:
+            p = self._owner_plan = self.ops.IndexPlan(m + 16, self.device)
+        return self._call(self.lib.ha_shard_frames_serve_push, "ha_shard_frames_serve_push", vp(table.data_ptr()),
+                          i64(table.shape[0]), i64(table.shape[1]), vp(fb.keys_fixed.data_ptr()), ctypes.c_int(fb.w),
+                          i64(fb.rcap), vp(rows_recv.data_ptr()), vp(p.ws.data_ptr()), vp(self._stream()))
+
     def hold_for_side(self, t):
         if t is not None and t.is_cuda:
             t.record_stream(self.side)
@@ -340,12 +381,12 @@ class HipEngine:
 
 class FrameBlock:
     """Key frames of one routing block of a FramedStep (see HipEngine.frames_block)."""
-    __slots__ = ("ksend", "krecv", "kgot", "ev", "live", "slots")
+    __slots__ = ("ksend", "krecv", "kgot", "ev", "live", "slots", "synced")
 
 
 class FrameBuffers:
     """Per-batch buffers inside a FrameBlock."""
-    __slots__ = ("i", "w", "rcap", "stride", "plan", "keys_fixed", "rowmap", "posmap", "state_host", "ids", "n",
+    __slots__ = ("i", "w", "rcap", "stride", "plan", "keys_fixed", "rowmap", "posmap", "state_host", "state_c", "ids", "n",
                  "shape", "routed")
 
 
@@ -627,6 +668,8 @@ class FramedStep:
         self.zero_flags = self.eng.zeros((m,), torch.uint8)
         self.side = w == 1 or emb.side_group is not None
         self._graphs = {}
+        self._calls = {}
+        self._fast_ok = hasattr(self.eng, "frames_serve_pull_call")
         self.k = None
         self.fallbacks = 0
         emb._frame(self.max_ids)     # the sized path (overflowed batches) agrees on its frame now, on every rank
@@ -661,6 +704,7 @@ class FramedStep:
         import contextlib
         blk = self.blocks[b % 3]
         blk.live = any(fb.routed for fb in blk.slots)
+        blk.synced = False
         if not blk.live:
             blk.ev = None
             return
@@ -704,6 +748,39 @@ class FramedStep:
         self.eng.frames_reduce(fb, values, scale, self.push_send, self.zero_flags)
         got = self._exchange(self.push_recv, self.push_send)
         self.eng.frames_serve_push(self.emb.table, fb, got)
+
+    def _fast(self, key, build):
+        """Plain launches with arguments converted once per key (engines that offer it; not with graphs)."""
+        c = self._calls.get(key)
+        if c is None:
+            if len(self._calls) >= 4096:
+                self._calls.clear()
+            c = self._calls[key] = build()
+        return c
+
+    def _pull_fast(self, j, out, stream_key):
+        blk, fb = self._fb(j)
+        eng, emb = self.eng, self.emb
+        rows_in = self.pull_send if emb.world == 1 else self.pull_recv
+        a, b = self._fast(("pull", j % (3 * self.block), fb.n, out.data_ptr() if fb.n else 0, blk.kgot.data_ptr(), stream_key),
+                          lambda: (eng.frames_serve_pull_call(emb.table, blk, fb, self.pull_send),
+                                   eng.frames_expand_call(rows_in, fb, out) if fb.n else None))
+        a()
+        self._exchange(self.pull_recv, self.pull_send)
+        if b is not None:
+            b()
+
+    def _push_fast(self, j, values, scale, stream_key):
+        _, fb = self._fb(j)
+        eng, emb = self.eng, self.emb
+        rows_in = self.push_send if emb.world == 1 else self.push_recv
+        a, b = self._fast(("push", j % (3 * self.block), fb.n, values.data_ptr() if fb.n else 0, scale, stream_key),
+                          lambda: (eng.frames_reduce_call(fb, values, scale, self.push_send, self.zero_flags) if fb.n else None,
+                                   eng.frames_serve_push_call(emb.table, fb, rows_in)))
+        if a is not None:
+            a()
+        self._exchange(self.push_recv, self.push_send)
+        b()
 
     def _run(self, key, fn):
         """Enqueue `fn`: eagerly at the first use of `key` (lazy one-time initialisation -- kernel attributes, scratch
@@ -754,7 +831,9 @@ class FramedStep:
         """Host: did any rank overflow its frames for batch j?  Reads the pinned word its routing wrote (enqueued a
         block ago: the wait is for work that is long complete in steady state)."""
         blk, fb = self._fb(j)
-        self.eng.host_sync(blk.ev)
+        if not blk.synced:
+            self.eng.host_sync(blk.ev)
+            blk.synced = True
         return self.eng.frames_overflowed(fb)
 
     def pull(self, ahead_ids=None, out=None):
@@ -782,7 +861,10 @@ class FramedStep:
             if fb.n:
                 out.copy_(rows.reshape(out.shape))
         else:
-            self._run(("pull", k % (3 * self.block), fb.n, out.data_ptr() if fb.n else 0), lambda: self._pull(k, out))
+            if self._fast_ok and not self.graphs:
+                self._pull_fast(k, out, self.eng._stream())
+            else:
+                self._run(("pull", k % (3 * self.block), fb.n, out.data_ptr() if fb.n else 0), lambda: self._pull(k, out))
             self._account()
         self._pending = True
         return out.reshape(fb.shape + (width,)) if fb.n else None
@@ -799,8 +881,11 @@ class FramedStep:
             self._sized = None
         else:
             v = values.reshape(-1, self.emb.width) if fb.n else None
-            self._run(("push", k % (3 * self.block), fb.n, v.data_ptr() if fb.n else 0, scale),
-                      lambda: self._push(k, v, scale))
+            if self._fast_ok and not self.graphs:
+                self._push_fast(k, v, scale, self.eng._stream())
+            else:
+                self._run(("push", k % (3 * self.block), fb.n, v.data_ptr() if fb.n else 0, scale),
+                          lambda: self._push(k, v, scale))
         self._pending = False
         self.k = k + 1
 

@@ -23,7 +23,9 @@ for k in range(6 * fs.block + 12): step(k)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for k in range(6 * fs.block + 12, 6 * fs.block + 12 + steps): step(k)
+t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
+print("host enqueue us/step %.2f" % (t_host / steps * 1e6))
 print("us/step %.2f  (graphs %s, %d captured, fallbacks %d, row_cap %d)" % ((time.perf_counter() - t0) / steps * 1e6, fs.graphs, sum(1 for x in fs._graphs.values() if x), fs.fallbacks, fs.rcap))
 if os.environ.get("HOSTPROF") == "1":
     pr = cProfile.Profile(); pr.enable()
