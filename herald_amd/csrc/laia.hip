@@ -266,6 +266,34 @@ __global__ __launch_bounds__(256) void laia_score_kernel(
     }
 }
 
+// probe + score in one launch: a wave takes floor(64 / T) whole samples, lane = (sample, table); mask as laia_probe_kernel,
+// scores[i][w] = number of tables of sample i valid at w by ballots over the sample's lanes (T <= 64)
+__global__ __launch_bounds__(256) void laia_probe_score_kernel(
+    const uint32_t *__restrict__ samples, long long S, int T, long long start, int B, int W,
+    const uint8_t *__restrict__ valid, long long R, unsigned long long *__restrict__ mask, int32_t *__restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const int spw = 64 / T;                                     // samples per wave
+    const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const int sl = lane / T, j = lane - sl * T;                 // sample slot of the lane, table
+    const long long i = wave * spw + sl;
+    const bool on = sl < spw && i < B;
+    unsigned long long m = 0;
+    if (on) {
+        const uint32_t emb = samples[((start + i) % S) * T + j];
+        if (emb < R)
+            for (int w = 0; w < W; ++w)
+                if (valid[static_cast<long long>(w) * R + emb])
+                    m |= 1ull << w;
+        mask[i * T + j] = m;
+    }
+    const unsigned long long seg = (T >= 64 ? ~0ull : ((1ull << T) - 1ull)) << (sl * T);   // the lanes of this lane's sample
+    for (int w = 0; w < W; ++w) {
+        const unsigned long long b = __ballot(on && ((m >> w) & 1ull));
+        if (on && j == 0)
+            scores[i * W + w] = __builtin_popcountll(b & seg);
+    }
+}
+
 // plan pairs: (w, row) for rows valid at w in samples not assigned to w (LaiaScheduler), or -- own_plan,
 // TopkScheduler -- (owner, row) for rows valid at the sample's own worker; touched pairs: (owner, row)
 __global__ __launch_bounds__(256) void laia_pairs_kernel(
@@ -418,11 +446,13 @@ __device__ __forceinline__ unsigned long long laia_block_scan_u64(unsigned long 
 
 __global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__restrict__ scores, int B, int W, int mini_bs,
                                                            long long batch_id, long long start, long long S,
-                                                           int32_t *__restrict__ owner, long long *__restrict__ dist) {
+                                                           int32_t *__restrict__ owner, long long *__restrict__ dist,
+                                                           int lds_scores) {
     __shared__ unsigned long long s_w[16];
     __shared__ int s_base[64], s_add[64];
     __shared__ int s_istar;
     __shared__ signed char s_pref[1024 * kLaiaAssignPer];   // choice of sample i this round, -1 = already final
+    extern __shared__ unsigned char s_sc[];                 // the scores as bytes (<= tables <= 255), when B * W fits
     const int t = threadIdx.x;
     const int per = (B + 1023) / 1024;
     const int i0 = t * per, i1 = min(B, i0 + per);
@@ -433,6 +463,9 @@ __global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__rest
     }
     unsigned long long avail = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
     int i_start = 0;
+    if (lds_scores)
+        for (int e = t; e < B * W; e += 1024)
+            s_sc[e] = static_cast<unsigned char>(scores[e]);
     __syncthreads();
     while (i_start < B) {
         // choice of every open sample among the workers that still have quota (a thread reads only its own entries)
@@ -445,7 +478,7 @@ __global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__rest
                     w = w >= W ? w - W : w;
                     if (!((avail >> w) & 1ull))
                         continue;
-                    const int sc = scores[static_cast<long long>(i) * W + w];
+                    const int sc = lds_scores ? static_cast<int>(s_sc[i * W + w]) : scores[static_cast<long long>(i) * W + w];
                     if (best < sc) {
                         best = sc;
                         bw = w;
@@ -1318,12 +1351,20 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     int blocks = static_cast<int>((BT + 255) / 256);
     if (blocks > 4096)
         blocks = 4096;
-    hipLaunchKernelGGL(laia_probe_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
-                       l.d_valid, l.R, l.d_mask);
-    hipLaunchKernelGGL(laia_score_kernel, dim3((int)((B * W + 255) / 256)), dim3(256), 0, l.stream, l.d_mask, (int)B, T,
-                       W, l.d_scores);
-    hipLaunchKernelGGL(laia_assign_kernel, dim3(1), dim3(1024), 0, l.stream, l.d_scores, (int)B, W, (int)mini_bs,
-                       (long long)batch_id, start, l.S, l.d_owner, d.d_dist);
+    if (T <= 64) {
+        const long long waves = (B + (64 / T) - 1) / (64 / T);
+        hipLaunchKernelGGL(laia_probe_score_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, l.stream,
+                           l.d_samples, l.S, T, start, (int)B, W, l.d_valid, l.R, l.d_mask, l.d_scores);
+    } else {
+        hipLaunchKernelGGL(laia_probe_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
+                           l.d_valid, l.R, l.d_mask);
+        hipLaunchKernelGGL(laia_score_kernel, dim3((int)((B * W + 255) / 256)), dim3(256), 0, l.stream, l.d_mask, (int)B, T,
+                           W, l.d_scores);
+    }
+    const size_t sc_bytes = static_cast<size_t>(B) * W;
+    const int lds_scores = sc_bytes <= (size_t(32) << 10) && T <= 255 ? 1 : 0;
+    hipLaunchKernelGGL(laia_assign_kernel, dim3(1), dim3(1024), lds_scores ? sc_bytes : 0, l.stream, l.d_scores, (int)B, W,
+                       (int)mini_bs, (long long)batch_id, start, l.S, l.d_owner, d.d_dist, lds_scores);
     hipLaunchKernelGGL(laia_bits_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
                        l.d_mask, l.d_owner, l.R, d.Rpad, d.bits.bits[0], d.bits.sum[0], d.bits.bits[1], d.bits.sum[1],
                        d.bits.nset[0], d.bits.nset[1]);
