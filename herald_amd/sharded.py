@@ -640,7 +640,7 @@ class FramedStep:
         fs.push(grads0, lr)                            # batch 0 applied on its owners (rank order)
         rows1 = fs.pull(ids[LOOKAHEAD + 1]) ...        # ahead ids = None once the stream of batches has ended
 
-    Per owner a batch may name at most row_cap unique keys (default max_ids / W).  A batch that names more on ANY rank
+    Per owner a batch may name at most row_cap unique keys (default 1.5 x max_ids / W, at most max_ids).  A batch that names more on ANY rank
     is detected by the routing itself (the flag travels in the key frames, so all ranks agree) a block before it is
     pulled; that batch alone takes ShardedEmbedding's sized exchange (one host read-back), the others keep replaying.
 
@@ -653,7 +653,10 @@ class FramedStep:
         self.emb, self.eng = emb, emb.engine
         w = emb.world
         self.max_ids = int(max_ids)
-        self.rcap = int(row_cap) if row_cap is not None else max(-(-self.max_ids // w), 1)
+        # default: 1.5 x the even share -- row-range shards are not evenly loaded (at W = 8 the owner of the small Criteo
+        # tables is named 944 unique keys by a 6,656-id batch whose even share is 832), and a batch beyond the cap costs a
+        # sized exchange on every rank
+        self.rcap = int(row_cap) if row_cap is not None else min(self.max_ids, max(-(-3 * self.max_ids // (2 * w)), 1))
         self.block = int(block)
         if self.block < 1:
             raise ValueError("block must be >= 1")

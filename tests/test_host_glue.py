@@ -190,3 +190,24 @@ def test_bench_gpus_2_starts_two_children_and_the_parent_never_touches_the_gpu(m
         assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
         ports.add(env["MASTER_PORT"])
     assert len(ports) == 1
+
+
+def test_framed_step_default_row_cap_holds_the_criteo_batches():
+    """The default row_cap of sharded.FramedStep (1.5 x the even share) against the per-owner unique counts of the
+    synthetic Criteo batches bench.py routes over the full key space at W = 2, 4, 8: a batch beyond the cap would send every
+    rank through the sized exchange."""
+    from herald_amd import synth
+    from herald_amd.sharded import partition
+    rows = 33762577
+    for bs in (256, 4096):
+        n = bs * 26
+        for W in (2, 4, 8):
+            cap = min(n, -(-3 * n // (2 * W)))
+            st = np.array(partition(rows, W))
+            worst = 0
+            for b in range(4):
+                for r in range(W):
+                    ids = np.minimum(synth.criteo_batch(bs, step=b * W + r, rows=rows).reshape(-1), rows - 1)
+                    cnt = np.bincount(np.searchsorted(st[1:], np.unique(ids), side="right"), minlength=W)
+                    worst = max(worst, int(cnt.max()))
+            assert worst <= cap, (bs, W, worst, cap)
