@@ -237,6 +237,8 @@ def _declare(L):
     L.ha_laia_destroy.argtypes = [vp]
     L.ha_laia_next.restype = c.c_int
     L.ha_laia_next.argtypes = [vp, i64, i64, vp, vp, i64, vp]
+    L.ha_laia_next_for_rank.restype = c.c_int
+    L.ha_laia_next_for_rank.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp]
     L.ha_laia_snapshot_keys.restype = i64
     L.ha_laia_snapshot_keys.argtypes = [vp, i64, vp, i64]
     L.ha_laia_next_topk.restype = c.c_int

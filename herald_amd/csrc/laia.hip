@@ -1013,6 +1013,7 @@ struct LaiaDev {
     char *d_out = nullptr, *h_out = nullptr;
     size_t out_bytes = 0, off_at = 0, state_at = 0;
     long long plan_guess = 0;      // plan rows copied along with the block (the last batch's count and a margin)
+    long long rank_lo = 0, rank_hi = 0;   // ... or one worker's range of them (ha_laia_next_for_rank)
     long long *h_dist = nullptr;
     int32_t *h_off = nullptr;
     uint32_t *h_plan_rows = nullptr;
@@ -1339,7 +1340,7 @@ static int laia_dev_states(Laia &l) {   // -> l.dev.h_state (synchronises the sc
 // One global batch with the scheduler state on the device: eight launches, `dist` + offsets + states back in one copy
 // phase, the plan rows in a second (their number is only known then).
 static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out, uint64_t *plan_out,
-                            int64_t plan_cap_elems, int64_t *plan_off) {
+                            int64_t plan_cap_elems, int64_t *plan_off, int only_rank) {
     Laia &l = h->l;
     LaiaDev &d = l.dev;
     const int W = l.W, T = l.T;
@@ -1378,30 +1379,49 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     hipLaunchKernelGGL(laia_lru_apply_kernel, dim3(kLaiaLruBlocks, W), dim3(256), 0, l.stream, d.lru);
     HA_LAUNCH_CHECK();
     HA_CHECK_HIP(hipMemcpyAsync(d.h_out, d.d_out, d.out_bytes, hipMemcpyDeviceToHost, l.stream));
-    long long guess = d.plan_guess < static_cast<long long>(l.plan_cap) ? d.plan_guess : static_cast<long long>(l.plan_cap);
-    if (guess > 0)
-        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows, d.bits.rows[1], static_cast<size_t>(guess) * 4, hipMemcpyDeviceToHost,
-                                    l.stream));
+    // the plan rows are copied along speculatively: all of them up to the last batch's count + 25 %, or -- only_rank --
+    // the last batch's range of that worker, widened; what the guess misses is fetched in a second copy
+    long long g0 = 0, g1 = d.plan_guess;
+    if (only_rank >= 0) {
+        g0 = d.rank_lo;
+        g1 = d.rank_hi;
+    }
+    g1 = g1 < static_cast<long long>(l.plan_cap) ? g1 : static_cast<long long>(l.plan_cap);
+    g0 = g0 < g1 ? g0 : g1;
+    if (g1 > g0)
+        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows + g0, d.bits.rows[1] + g0, static_cast<size_t>(g1 - g0) * 4,
+                                    hipMemcpyDeviceToHost, l.stream));
     HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     for (int w = 0; w < W; ++w)
         HA_REQUIRE(d.h_state[w].err == 0, "laia: the device snapshot of worker %d is inconsistent (code %d)", w,
                    d.h_state[w].err);
     const int32_t *pl_off = d.h_off + (W + 1);
     const long long nplan = pl_off[W];
-    HA_REQUIRE(nplan <= plan_cap_elems && nplan <= static_cast<long long>(l.plan_cap), "laia_next: plan buffer too small");
-    if (nplan > guess) {      // more plan rows than guessed: fetch the rest
-        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows + guess, d.bits.rows[1] + guess, static_cast<size_t>(nplan - guess) * 4,
+    const long long a0 = only_rank >= 0 ? pl_off[only_rank] : 0, a1 = only_rank >= 0 ? pl_off[only_rank + 1] : nplan;
+    HA_REQUIRE(a1 - a0 <= plan_cap_elems && nplan <= static_cast<long long>(l.plan_cap), "laia_next: plan buffer too small");
+    if (a1 > a0 && (a0 < g0 || a1 > g1)) {      // not (all) inside what was guessed: fetch the range itself
+        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows + a0, d.bits.rows[1] + a0, static_cast<size_t>(a1 - a0) * 4,
                                     hipMemcpyDeviceToHost, l.stream));
         HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     }
     d.plan_guess = nplan + nplan / 4 + 4096;
+    if (only_rank >= 0) {
+        const long long margin = (a1 - a0) / 4 + 2048;
+        d.rank_lo = a0 > margin ? a0 - margin : 0;
+        d.rank_hi = a1 + margin;
+    }
     const double t_out0 = now_us();
     for (long long k = 0; k < B; ++k)
         dist_out[k] = d.h_dist[k];
-    for (int w = 0; w <= W; ++w)
-        plan_off[w] = pl_off[w];
-    for (long long k = 0; k < nplan; ++k)
-        plan_out[k] = d.h_plan_rows[k];
+    if (only_rank >= 0) {       // only that worker's plan, at the front: offsets 0 .. count around it
+        for (int w = 0; w <= W; ++w)
+            plan_off[w] = w <= only_rank ? 0 : a1 - a0;
+    } else {
+        for (int w = 0; w <= W; ++w)
+            plan_off[w] = pl_off[w];
+    }
+    for (long long k = a0; k < a1; ++k)
+        plan_out[k - a0] = d.h_plan_rows[k];
     l.t_assign_us += now_us() - t_out0;      // device mode: the host's share is copying dist and the plans out
     l.t_total_us += now_us() - t_begin;
     l.t_calls += 1;
@@ -1410,7 +1430,7 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
 
 static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out,
                           uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off,
-                          const TopkParams *topk) {
+                          const TopkParams *topk, int only_rank = -1) {
     HA_REQUIRE(h && dist_out && plan_out && plan_off && mini_bs > 0, "laia_next: bad arguments");
     Laia &l = h->l;
     if (!l.decided) {      // LaiaScheduler with a large cache keeps its snapshots on the device; everything else on the host
@@ -1423,7 +1443,7 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
     if (l.dev.on) {
         HA_REQUIRE(topk == nullptr, "laia_next_topk: this scheduler keeps its snapshots on the device (it was first "
                                     "used as a LaiaScheduler); create a separate one for the top-k schedule");
-        return laia_next_device(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off);
+        return laia_next_device(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off, only_rank);
     }
     laia_host_snaps(l);
     const int W = l.W, T = l.T;
@@ -1675,6 +1695,26 @@ extern "C" int ha_laia_timing(ha_laia *h, double *out) {
 extern "C" int ha_laia_next(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out,
                             uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off) {
     return laia_next_impl(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off, nullptr);
+}
+
+// ha_laia_next when the caller wants the plan of ONE worker only (what LaiaScheduler::launch queues for its rank,
+// laia_scheduler.cc:140-168): plan_out = that worker's plan, plan_off[w] = 0 up to `rank` and its length behind it; dist_out
+// as ha_laia_next.  With the scheduler state on the device only that worker's plan rows cross PCIe.
+extern "C" int ha_laia_next_for_rank(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t rank, int64_t *dist_out,
+                                     uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off) {
+    HA_REQUIRE(h && rank >= 0 && rank < h->l.W, "laia_next_for_rank: bad rank");
+    const int W = h->l.W;
+    const bool dev_before = h->l.dev.on || (!h->l.decided && laia_dev_eligible(h->l));
+    if (laia_next_impl(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off, nullptr, static_cast<int>(rank)))
+        return -1;
+    if (!dev_before) {      // host mode returned all plans: keep the rank's
+        const int64_t a0 = plan_off[rank], a1 = plan_off[rank + 1];
+        for (int64_t k = a0; k < a1; ++k)
+            plan_out[k - a0] = plan_out[k];
+        for (int w = 0; w <= W; ++w)
+            plan_off[w] = w <= rank ? 0 : a1 - a0;
+    }
+    return 0;
 }
 
 extern "C" int ha_laia_next_topk(ha_laia *h, int64_t batch_id, int64_t mini_bs,

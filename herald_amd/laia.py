@@ -85,8 +85,9 @@ class LaiaScheduler:
         self._finish()
 
     def _next(self, batch_id, mini_bs, dist, plan, cap, off):
-        return self._L.ha_laia_next(self._h, batch_id, mini_bs, dist.ctypes.data, plan.ctypes.data, cap,
-                                    off.ctypes.data)
+        # only this rank's plan is queued (laia_scheduler.cc:140-168): with the state on the device only its rows come back
+        return self._L.ha_laia_next_for_rank(self._h, batch_id, mini_bs, self._cfg[4], dist.ctypes.data, plan.ctypes.data,
+                                             cap, off.ctypes.data)
 
     def _emit(self, plan, dist, off, mini_bs, rank):
         self._q.put(plan[off[rank]:off[rank + 1]].tolist())        # Python ints, as the reference's pybind lists

@@ -790,6 +790,11 @@ void ha_laia_destroy(ha_laia *sched);
 int ha_laia_next(ha_laia *sched, int64_t batch_id, int64_t mini_bs,
                  int64_t *dist_out, uint64_t *plan_out, int64_t plan_cap_elems,
                  int64_t *plan_off);
+/* ha_laia_next for a caller that wants ONE worker's plan (what LaiaScheduler::launch queues for its own rank,
+ * laia/src/laia_scheduler.cc:140-168): plan_out holds that plan, plan_off[w] = 0 for w <= rank and its length behind;
+ * dist_out as ha_laia_next.  With the scheduler state on the device only that worker's plan rows cross PCIe. */
+int ha_laia_next_for_rank(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t rank, int64_t *dist_out,
+                          uint64_t *plan_out, int64_t plan_cap_elems, int64_t *plan_off);
 int64_t ha_laia_snapshot_keys(ha_laia *sched, int64_t worker, int32_t *out,
                               int64_t cap);
 
