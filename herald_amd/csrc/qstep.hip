@@ -1050,7 +1050,8 @@ __global__ __launch_bounds__(1024, 8) void qapply_kernel(const QArgs a) {
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
     int b = blockIdx.x;
-    if (b < a.ncoop) {
+    const bool coop = b < a.ncoop;
+    if (coop) {
         role = 0;
         const uint32_t n = a.qh->n_coop;
         for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
