@@ -63,7 +63,7 @@ def parse_args():
     p.add_argument("--pre-roll", type=int, default=2,
                    help="how many of the W warm-up steps run right in front of the timed region (no synchronisation in "
                         "between); 0 = all W before the synchronisation")
-    p.add_argument("--clock-warm", type=int, default=2,
+    p.add_argument("--clock-warm", type=int, default=8,
                    help="untimed 512 MiB device copies enqueued right before the pre-roll (0 = none)")
     p.add_argument("--no-gate", action="store_true",
                    help="do not hold the stream until the host has enqueued the timed region")
