@@ -11,6 +11,8 @@ libherald_amd.so, in the three placements the reference's run_hetu.py offers:
                      sparse SGD -> SGDOptimizerSparseUpdate           (comm_mode None)
   --embedding step   as hbm, but ONE launch per training step: ha_sgd_push_pull applies the sparse SGD of batch
                      k and looks batch k+1 up (rows both batches touch handed over inside the launch)
+  --embedding queue  the work-queue step (ops.QueueStepPipeline / ha_qapply, what bench.py times): plans and queues a block
+                     of steps ahead beside the model, long runs as fixed-order tree sums (1e-5 tolerance)
   --embedding step3  the same step through ops.StepPipeline (ha_step_*): ids three batches ahead, updated rows
                      forwarded to the next batch's output by the applying waves, nothing waits inside the launch
   --embedding ps     row-range sharded store (one shard per rank): SparsePull / SparsePush through
@@ -91,7 +93,7 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
     if table_init is None:
         g = torch.Generator(device=dev).manual_seed(seed + 1)
         table_init = torch.randn((rows, width), generator=g, device=dev) * 0.01    # init.random_normal(stddev=0.01)
-    if embedding in ("hbm", "step", "step3"):
+    if embedding in ("hbm", "step", "step3", "queue"):
         param = hetu_ops.EmbeddingParameter(table=table_init.clone())
         config = hetu_ops.Config(comm_mode=None)
         comm = None
@@ -124,6 +126,13 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         from herald_amd import ops
         pipe = ops.StepPipeline(param.table, batch * NFIELD, lr)
         pipe_out = pipe.start(ids_of(0), ids_of(1), ids_of(2))     # rows of the first batch
+    qpipe = None
+    if embedding == "queue":
+        # the work-queue step (ha_qapply; what bench.py times): plans and queues a block of steps ahead on a side stream,
+        # one launch per step between the model's backward and the next forward
+        from herald_amd import ops
+        qpipe = pipe = ops.QueueStepPipeline(param.table, batch * NFIELD, lr, block=4)
+        pipe_out = pipe.start([ids_of(j) for j in range(pipe.LOOKAHEAD)])
 
     losses = []
     t0 = time.perf_counter()
@@ -146,7 +155,8 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         grad = lookup_grad.compute(emb.grad, ids)                  # IndexedSlices(indices, values)
         if pipe is not None:
             # sparse SGD of this batch, rows of the next one, plan finish of batch k+2, sort of batch k+3: one launch
-            pipe_out = pipe.step(grad.values.reshape(-1, width).contiguous(), ids_of(k + 3))
+            pipe_out = pipe.step(grad.values.reshape(-1, width).contiguous(),
+                                 ids_of(k + (qpipe.LOOKAHEAD if qpipe is not None else 3)))
         elif fused is not None:
             # sparse SGD of this batch + lookup of the next one, one launch (plans / pending tables alternate)
             ops.sgd_push_pull(param.table, fused["plans"][k % 2], grad.values.reshape(-1, width).contiguous(), lr,
@@ -170,7 +180,7 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--embedding", choices=["hbm", "step", "step3", "ps", "cache"], default="hbm")
+    ap.add_argument("--embedding", choices=["hbm", "step", "step3", "queue", "ps", "cache"], default="hbm")
     ap.add_argument("--cache", choices=["LRU", "LFU", "LFUOpt"], default="LRU")
     ap.add_argument("--bound", type=int, default=100)
     ap.add_argument("--rows", type=int, default=33762577)

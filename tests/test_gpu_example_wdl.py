@@ -53,7 +53,7 @@ def _global_table(param):
     return param.table if param.table is not None else param.store.table
 
 
-@pytest.mark.parametrize("embedding,kw", [("hbm", {}), ("step", {}), ("step3", {}), ("ps", {}), ("cache", {"cache": "LRU", "bound": 0}),
+@pytest.mark.parametrize("embedding,kw", [("hbm", {}), ("step", {}), ("step3", {}), ("queue", {}), ("ps", {}), ("cache", {"cache": "LRU", "bound": 0}),
                                           ("cache", {"cache": "LFUOpt", "bound": 0, "cache_limit": 2000})])
 def test_wdl_training_matches_pytorch(dev, reference, embedding, kw):
     import run_wdl
