@@ -677,45 +677,49 @@ __global__ __launch_bounds__(1024) void laia_bits_scan_kernel(LaiaBits a, int nb
 
 // emits the rows in order (one wave per summary word, lane k its data word k), writes the per-worker offsets and
 // clears the words it read
-__global__ __launch_bounds__(1024) void laia_bits_emit_kernel(LaiaBits a, long long nsum, long long sum_per_worker, int W,
-                                                              long long Rpad) {
+__global__ __launch_bounds__(256) void laia_bits_emit_kernel(LaiaBits a, long long nsum, long long sum_per_worker, int W,
+                                                             long long Rpad) {
+    // a block = the 16 summary words of one offset group, four per wave (most are empty: fewer, longer-lived waves)
     const int which = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long x = blockIdx.x * 16ll + wv;
-    if (x >= nsum)
-        return;
-    const uint32_t at0 = a.blk[which][blockIdx.x] + a.cnt[which][x];
-    if (lane == 0) {
-        if (x % sum_per_worker == 0)
-            a.off[which][x / sum_per_worker] = static_cast<int32_t>(at0);
-        if (x == nsum - 1)
-            a.off[which][W] = static_cast<int32_t>(a.blk[which][gridDim.x]);
-    }
-    const unsigned long long sw = a.sum[which][x];      // wave-uniform
-    if (sw == 0)
-        return;
-    unsigned long long dw = 0;
-    if ((sw >> lane) & 1ull) {
-        dw = a.bits[which][x * 64 + lane];
-        a.bits[which][x * 64 + lane] = 0;
-    }
-    if (lane == 0)
-        a.sum[which][x] = 0;
-    const uint32_t c = __builtin_popcountll(dw);
-    uint32_t incl = c;
+    const uint32_t blk0 = a.blk[which][blockIdx.x];
+    for (int i = 0; i < 4; ++i) {
+        const long long x = blockIdx.x * 16ll + wv * 4 + i;
+        if (x >= nsum)
+            return;
+        const uint32_t at0 = blk0 + a.cnt[which][x];
+        if (lane == 0) {
+            if (x % sum_per_worker == 0)
+                a.off[which][x / sum_per_worker] = static_cast<int32_t>(at0);
+            if (x == nsum - 1)
+                a.off[which][W] = static_cast<int32_t>(a.blk[which][gridDim.x]);
+        }
+        const unsigned long long sw = a.sum[which][x];      // wave-uniform
+        if (sw == 0)
+            continue;
+        unsigned long long dw = 0;
+        if ((sw >> lane) & 1ull) {
+            dw = a.bits[which][x * 64 + lane];
+            a.bits[which][x * 64 + lane] = 0;
+        }
+        if (lane == 0)
+            a.sum[which][x] = 0;
+        const uint32_t c = __builtin_popcountll(dw);
+        uint32_t incl = c;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(incl, o, 64);
-        if (lane >= o)
-            incl += y;
-    }
-    uint32_t at = at0 + incl - c;
-    const long long w = x / sum_per_worker;
-    const unsigned long long base = static_cast<unsigned long long>(x * 64 + lane) * 64ull - static_cast<unsigned long long>(w) * Rpad;
-    while (dw) {
-        const int b = __builtin_ctzll(dw);
-        dw &= dw - 1;
-        a.rows[which][at++] = static_cast<uint32_t>(base + b);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += y;
+        }
+        uint32_t at = at0 + incl - c;
+        const long long w = x / sum_per_worker;
+        const unsigned long long base = static_cast<unsigned long long>(x * 64 + lane) * 64ull - static_cast<unsigned long long>(w) * Rpad;
+        while (dw) {
+            const int b = __builtin_ctzll(dw);
+            dw &= dw - 1;
+            a.rows[which][at++] = static_cast<uint32_t>(base + b);
+        }
     }
 }
 
@@ -1372,7 +1376,7 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     hipLaunchKernelGGL(laia_bits_count_kernel, dim3(static_cast<unsigned>((d.nsum + 1023) / 1024), 2), dim3(1024), 0, l.stream,
                        d.bits, d.nsum);
     hipLaunchKernelGGL(laia_bits_scan_kernel, dim3(2), dim3(1024), 0, l.stream, d.bits, d.nblk);
-    hipLaunchKernelGGL(laia_bits_emit_kernel, dim3(d.nblk, 2), dim3(1024), 0, l.stream, d.bits, d.nsum, d.sum_per_worker, W,
+    hipLaunchKernelGGL(laia_bits_emit_kernel, dim3(d.nblk, 2), dim3(256), 0, l.stream, d.bits, d.nsum, d.sum_per_worker, W,
                        d.Rpad);
     hipLaunchKernelGGL(laia_lru_classify_kernel, dim3(kLaiaLruBlocks, W), dim3(256), 0, l.stream, d.lru);
     hipLaunchKernelGGL(laia_lru_window_kernel, dim3(W), dim3(1024), 0, l.stream, d.lru, d.debug_wrap_at);
