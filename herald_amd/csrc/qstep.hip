@@ -48,7 +48,10 @@
 namespace ha {
 
 constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers + counters = 75 KiB of LDS, two workgroups per CU
-constexpr int kQCoopSlots = 64;      // workgroups reserved for G items (they loop if there are more)
+#ifndef QV_COOPSLOTS
+#define QV_COOPSLOTS 64
+#endif
+constexpr int kQCoopSlots = QV_COOPSLOTS;      // workgroups reserved for G items (they loop if there are more)
 constexpr int kQWorkerMax = 448;     // worker workgroups: with A, B and the coop slots the launch stays below the
                                      // chip's 512 resident 1024-thread workgroups; the waves loop beyond that
 constexpr int kQSmallC = 3, kQSmallM = 16, kQMediumC = 15, kQLongC = 64;
