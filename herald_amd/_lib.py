@@ -199,7 +199,7 @@ def _declare(L):
     for name in ("ha_cache_data", "ha_cache_grad"):
         getattr(L, name).restype = vp
         getattr(L, name).argtypes = [vp]
-    for name in ("ha_cache_limit", "ha_cache_width"):
+    for name in ("ha_cache_limit", "ha_cache_width", "ha_cache_fused_updates"):
         getattr(L, name).restype = i64
         getattr(L, name).argtypes = [vp]
     cache_sigs = {

@@ -68,8 +68,9 @@ struct CacheCtl {
     long long parked[4];   // push_pull: U, M, nhit of the parked pull phase; U of the push phase
     long long scan_victim; // slot of the lowest (use, stamp) line outside the lowest bucket, or -1
     // last op report: type(0 pull,1 push), num_all, num_unique, num_miss, num_transfered, num_evict, is_full
-    long long perf[8];
+    long long perf[8];     // [7]: pushed lines of a cache_update_same_post_kernel update, to be added to [4]
     long long out_n;       // remote mode: outbox entries of the last update (U + E), -1 on overflow
+    long long snap[4];     // {clock, log_tail, free_top, evict_n} as the last lookup left them (cache_update_same_post_kernel)
 };
 
 struct Cache {
@@ -233,46 +234,70 @@ __device__ __forceinline__ void cache_assign_body(
     const uint32_t *rank, int miss_state, int tid0, int nthr) {
     const int U = static_cast<int>(ctl->U);
     const long long clock = ctl->clock, tail = ctl->log_tail, ftop = ctl->free_top;
-    for (int u = tid0; u < U; u += nthr) {
-        if (!flag[u]) {
-            const int s = c.uslot[u];
-            const unsigned long long st = static_cast<unsigned long long>(clock + u);
-            if (c.policy == kLRU) {
-                // lru_cache.cc:27-39: move to the list front
-                c.stamp[s] = st;
-                const long long pos = (tail + (u - static_cast<long long>(rank[u]))) % c.Lcap;
-                c.log_slot[pos] = static_cast<uint32_t>(s);
-                c.log_stamp[pos] = st;
-            } else if (c.policy == kLFU) {
-                // lfu_cache.cc:22-29,51-68: use+1, front of the next bucket
-                const int f = c.freq[s];
-                if (f == 1)
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_base), ~0ull);
-                c.freq[s] = f + 1;
-                c.stamp[s] = st;
-            } else if (c.state[s] == kResident) {
-                // lfuopt_cache.cc:26-41: use+1 or promotion to the never-evicted store
-                const int f = c.freq[s];
-                if (f == 0)
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_base), ~0ull);
-                if (f + 1 < kUseCntMax) {
-                    c.freq[s] = f + 1;
-                    c.stamp[s] = st;
-                } else {
-                    c.state[s] = kStored;
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_hash), ~0ull);
-                }
-            }
-        } else {
-            const long long idx = ftop - 1 - static_cast<long long>(rank[u]);
+    // eight keys per thread and round: their flags / slots / ranks / keys in ONE batch of loads, the free slots of the
+    // misses in a second one, then the stores -- a key-by-key loop is two dependent trips to memory per key (seven keys
+    // per thread at the criteo batch: the single-workgroup bookkeeping kernels spent most of their time there)
+    constexpr int R = 8;
+    for (int base = tid0; base < U; base += nthr * R) {
+        uint32_t f[R], rk[R], kk[R];
+        int us[R], fs[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int u = min(base + i * nthr, U - 1);
+            f[i] = flag[u];
+            us[i] = c.uslot[u];
+            rk[i] = rank[u];
+            kk[i] = uniq[u];
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const long long idx = ftop - 1 - static_cast<long long>(rk[i]);
             // running out of slots is a sizing error reported by the host wrapper (nmax)
-            const int s = idx >= 0 ? c.free_list[idx] : 0;
-            c.uslot[u] = s;
-            c.key[s] = uniq[u];
-            c.version[s] = -1;
-            c.updates[s] = 0;
-            c.hasgrad[s] = 0;
-            c.state[s] = static_cast<uint8_t>(miss_state);
+            fs[i] = (f[i] && idx >= 0 && base + i * nthr < U) ? c.free_list[idx] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int u = base + i * nthr;
+            if (u >= U)
+                break;
+            if (!f[i]) {
+                const int s = us[i];
+                const unsigned long long st = static_cast<unsigned long long>(clock + u);
+                if (c.policy == kLRU) {
+                    // lru_cache.cc:27-39: move to the list front
+                    c.stamp[s] = st;
+                    const long long pos = (tail + (u - static_cast<long long>(rk[i]))) % c.Lcap;
+                    c.log_slot[pos] = static_cast<uint32_t>(s);
+                    c.log_stamp[pos] = st;
+                } else if (c.policy == kLFU) {
+                    // lfu_cache.cc:22-29,51-68: use+1, front of the next bucket
+                    const int fq = c.freq[s];
+                    if (fq == 1)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_base), ~0ull);
+                    c.freq[s] = fq + 1;
+                    c.stamp[s] = st;
+                } else if (c.state[s] == kResident) {
+                    // lfuopt_cache.cc:26-41: use+1 or promotion to the never-evicted store
+                    const int fq = c.freq[s];
+                    if (fq == 0)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_base), ~0ull);
+                    if (fq + 1 < kUseCntMax) {
+                        c.freq[s] = fq + 1;
+                        c.stamp[s] = st;
+                    } else {
+                        c.state[s] = kStored;
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_hash), ~0ull);
+                    }
+                }
+            } else {
+                const int s = fs[i];
+                c.uslot[u] = s;
+                c.key[s] = kk[i];
+                c.version[s] = -1;
+                c.updates[s] = 0;
+                c.hasgrad[s] = 0;
+                c.state[s] = static_cast<uint8_t>(miss_state);
+            }
         }
     }
 }
@@ -460,10 +485,24 @@ __device__ __forceinline__ void cache_insert_evict_body(
     }
     const int base_use = c.policy == kLFU ? 1 : 0;
     if (do_insert) {
-        for (int u = threadIdx.x; u < U; u += 1024) {
-            if (flag[u]) {
-                const int s = c.uslot[u];
-                const long long q = rank[u];
+        constexpr int R = 8;       // batched loads, see cache_assign_body
+        for (int base = threadIdx.x; base < U; base += 1024 * R) {
+            uint32_t f[R], rk[R], kk[R];
+            int us[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int u = min(base + i * 1024, U - 1);
+                f[i] = flag[u];
+                us[i] = c.uslot[u];
+                rk[i] = rank[u];
+                kk[i] = uniq[u];
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if (base + i * 1024 >= U || !f[i])
+                    continue;
+                const int s = us[i];
+                const long long q = rk[i];
                 if (q < v_new) {
                     // inserted and evicted again inside this batch (or dropped): never becomes resident;
                     // a fresh line has updates == 0, so it does not enter evict_
@@ -471,7 +510,7 @@ __device__ __forceinline__ void cache_insert_evict_body(
                     continue;
                 }
                 const unsigned long long st = static_cast<unsigned long long>(clock + q);
-                c.slot_of[uniq[u]] = s;
+                c.slot_of[kk[i]] = s;
                 c.stamp[s] = st;
                 c.freq[s] = base_use;
                 c.state[s] = kResident;
@@ -638,7 +677,12 @@ __device__ __forceinline__ void cache_report_pull_body(CacheCtl *ctl, const Cach
     ctl->perf[4] = ctl->pulled;
     ctl->perf[5] = 0;
     ctl->perf[6] = ctl->size == c.limit;
+    ctl->perf[7] = 0;
     ctl->pulled = 0;
+    ctl->snap[0] = ctl->clock;
+    ctl->snap[1] = ctl->log_tail;
+    ctl->snap[2] = ctl->free_top;
+    ctl->snap[3] = ctl->evict_n;
 }
 __global__ void cache_report_pull_kernel(CacheCtl *ctl, Cache c, long long n) {
     cache_report_pull_body(ctl, c, n);
@@ -663,8 +707,10 @@ __global__ __launch_bounds__(1024) void cache_finish_probe_kernel(
 // instead of as eight dependent launches.  The pull decision of syncEmbedding (cache.cc:84-93:
 // version -1 or lagging by more than pull_bound) is taken here, once per unique key, and parked in
 // data_row[u]; the row kernel only moves rows.
+// defer_evict: the kernel ends with the pull decisions; victim scan, insert + evict and the report run as workgroup 0
+// of cache_lookup_rows_kernel, beside the row copies (which need slots and pull decisions only).
 __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
-    Cache c, const PlanHeader *hdr, const uint32_t *uniq, long long n, int bypass, int probed) {
+    Cache c, const PlanHeader *hdr, const uint32_t *uniq, long long n, int bypass, int probed, int defer_evict) {
     __shared__ uint32_t s_cnt[16];
     CacheCtl *ctl = c.ctl;
     const int tid = threadIdx.x;
@@ -683,11 +729,20 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
     // pull decision per unique key
     const int U = static_cast<int>(hdr->n_unique);
     uint32_t cnt = 0;
-    for (int u = tid; u < U; u += 1024) {
+    if (probed) {   // the decisions are there: count them, eight independent loads per thread and round
+        for (int base = tid; base < U; base += 8 * 1024) {
+            int pl[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                pl[i] = c.data_row[min(base + i * 1024, U - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                cnt += base + i * 1024 < U ? static_cast<uint32_t>(pl[i]) : 0u;
+        }
+    }
+    for (int u = tid; u < U && !probed; u += 1024) {
         int pull = 0;
-        if (probed) {
-            pull = c.data_row[u];
-        } else {
+        {
             const int s = c.uslot[u];
             const long long lk = static_cast<long long>(uniq[u]) - c.row_start;
             if (lk >= 0 && lk < c.store_rows) {
@@ -709,6 +764,8 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
             tot += s_cnt[k];
         ctl->pulled = tot;
     }
+    if (defer_evict)
+        return;
     if (c.policy != kLRU) {
         __syncthreads();
         cache_scan_victim_body(ctl, c);
@@ -723,12 +780,28 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
 // One wave per SORTED position p of the batch: dest[perm[p],:] = the row of its key.  Keys marked for
 // a pull read the store row (+ the line's pending gradient, Line::addup) and the wave of the key's
 // first position also refreshes the cache line and its version; the others copy the cached row.
+// evict_block: workgroup 0 is the rest of the bookkeeping instead (victim scan, insert of the misses + eviction, report --
+// see cache_lookup_book_kernel).  It touches slot_of / stamp / state / log / free stack / evict list / control block,
+// the row waves read uslot / data_row / hasgrad and write rows and versions: disjoint, in the reference's order as well
+// (cache.cc:95-104: the rows are copied before the policy inserts and evicts).
 template <int VEC>
-__global__ __launch_bounds__(256) void cache_lookup_rows_kernel(
+__global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
     Cache c, const uint32_t *__restrict__ uniq, const int32_t *__restrict__ upos,
-    const int32_t *__restrict__ perm, long long n, float *__restrict__ dest) {
+    const int32_t *__restrict__ perm, long long n, float *__restrict__ dest, int evict_block, int bypass) {
+    if (evict_block && blockIdx.x == 0) {
+        CacheCtl *ctl = c.ctl;
+        if (c.policy != kLRU) {
+            cache_scan_victim_body(ctl, c);
+            __syncthreads();
+        }
+        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            cache_report_pull_body(ctl, c, n);
+        return;
+    }
     const int lane = lane_id();
-    const long long p = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const long long p = (static_cast<long long>(blockIdx.x) - evict_block) * 16ll + (threadIdx.x >> 6);
     if (p >= n)
         return;
     const int u = upos[p];
@@ -985,6 +1058,137 @@ __global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl 
     }
 }
 
+// ---- update of the keys of the preceding lookup, LRU, local store (ha_cache_update_same_keys' usual case) ----------
+// After a lookup whose evict list was empty before it, with limit >= max_batch: every key of the batch is resident
+// with data (the batch's lines are the newest of the cache and at most `limit` lines survive an eviction), its slot
+// is still in uslot[], and the pending evicted lines are the victims of that one lookup -- distinct keys, none of them
+// in the batch.  Nothing of the update then depends on another line: no probe, no miss scan, no slot assignment.  The
+// accumulate (ha_apply_mapped2 with uslot as both row maps) is followed by THIS launch, one wave per unique key:
+//   touch (stamp clock + u, log entry tail + u: cache_assign_body's hit branch with rank 0), updates += count, the
+//   bounded push (cache.cc:159: updates > push_bound) with its server side (ver += updates, row += grad) and its
+//   clean-up (version += updates, zeroGrad),
+// further waves: one per pending evicted line (server side of its push, slot back on the free stack), and workgroup 0
+// commits what cache_commit_touch_body / cache_update_commit_body commit.  Two launches instead of five; results
+// identical to the general path (tests/test_gpu_cache.py: LRU traces with same_as_lookup against the model).
+// row[0..width) += g[0..width) (and g = 0 when `zero`), by one wave: all loads of a pass issued before its first store
+template <int VEC>
+__device__ __forceinline__ void cache_row_add(float *__restrict__ row, float *__restrict__ g, long long width, int lane,
+                                              bool zero) {
+    if (VEC == 4) {
+        for (long long j0 = 0; j0 < width; j0 += kWave * 8) {
+            const long long j = j0 + lane * 4, j2 = j + kWave * 4;
+            const bool a = j < width, b = j2 < width;
+            float4v r0{0.f, 0.f, 0.f, 0.f}, r1 = r0, g0 = r0, g1 = r0;
+            if (a) {
+                r0 = ld4(row + j);
+                g0 = ld4(g + j);
+            }
+            if (b) {
+                r1 = ld4(row + j2);
+                g1 = ld4(g + j2);
+            }
+            const float4v z{0.f, 0.f, 0.f, 0.f};
+            if (a) {
+                st4(row + j, float4v{__fadd_rn(r0[0], g0[0]), __fadd_rn(r0[1], g0[1]), __fadd_rn(r0[2], g0[2]),
+                                     __fadd_rn(r0[3], g0[3])});
+                if (zero)
+                    st4(g + j, z);
+            }
+            if (b) {
+                st4(row + j2, float4v{__fadd_rn(r1[0], g1[0]), __fadd_rn(r1[1], g1[1]), __fadd_rn(r1[2], g1[2]),
+                                      __fadd_rn(r1[3], g1[3])});
+                if (zero)
+                    st4(g + j2, z);
+            }
+        }
+    } else {
+        for (long long j = lane; j < width; j += kWave) {
+            row[j] = __fadd_rn(row[j], g[j]);
+            if (zero)
+                g[j] = 0.f;
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
+    Cache c, const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq,
+    const int32_t *__restrict__ counts, long long n) {
+    CacheCtl *ctl = c.ctl;
+    const int lane = lane_id();
+    const int U = static_cast<int>(hdr->n_unique);
+    // the control block as the lookup left it (cache_report_pull_body's copy): every wave reads the COPY, workgroup 0
+    // commits to the block itself -- no wave waits for another, no grid-wide counter (one same-address atomic per
+    // workgroup to elect the last one cost 14.5 us for 520 workgroups: device-scope atomics on one address serialise
+    // at ~30 ns each; with a __threadfence before it, 47 us)
+    const long long clock = ctl->snap[0], tail = ctl->snap[1], ftop = ctl->snap[2];
+    const int En = static_cast<int>(ctl->snap[3]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->perf[0] = 1;
+        ctl->perf[1] = n;
+        ctl->perf[2] = U;
+        ctl->perf[3] = 0;            // lines not in the cache
+        ctl->perf[4] = En;           // + perf[7], the batch's pushed lines (counted by their waves; ha_cache_perf adds)
+        ctl->perf[5] = En;
+        ctl->perf[6] = ctl->size == c.limit;
+        ctl->U = U;
+        ctl->M = 0;
+        ctl->nhit = U;
+        ctl->clock = clock + U;
+        ctl->log_tail = tail + U;
+        ctl->free_top = ftop + En;
+        ctl->evict_n = 0;
+    }
+    for (int item = blockIdx.x * 16 + static_cast<int>(threadIdx.x >> 6); item < U + En; item += gridDim.x * 16) {
+        if (item < U) {
+            const int u = item;
+            const int s = uniform(c.uslot[u]);
+            const uint32_t k = uniform(uniq[u]);
+            const int upd = uniform(c.updates[s] + counts[u]);
+            const bool push = upd > c.push_bound;
+            if (lane == 0) {
+                const unsigned long long st = static_cast<unsigned long long>(clock + u);
+                const long long pos = (tail + u) % c.Lcap;
+                c.stamp[s] = st;
+                c.log_slot[pos] = static_cast<uint32_t>(s);
+                c.log_stamp[pos] = st;
+                c.hasgrad[s] = 1;
+                c.updates[s] = push ? 0 : upd;
+                if (push) {
+                    c.version[s] += upd;
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->perf[7]), 1ull);
+                }
+            }
+            if (!push)
+                continue;
+            float *g = c.grad + static_cast<long long>(s) * c.width;
+            const long long lk = static_cast<long long>(k) - c.row_start;
+            if (lk >= 0 && lk < c.store_rows) {
+                cache_row_add<VEC>(c.table + lk * c.width, g, c.width, lane, true);
+                if (lane == 0)
+                    c.srv_ver[lk] += upd;
+            } else {
+                for (long long j = lane; j < c.width; j += kWave)
+                    g[j] = 0.f;
+            }
+        } else {
+            const int j = item - U;
+            const int s = uniform(c.evict_slots[j]);
+            const long long lk = static_cast<long long>(uniform(c.key[s])) - c.row_start;
+            if (lk >= 0 && lk < c.store_rows) {
+                cache_row_add<VEC>(c.table + lk * c.width, c.grad + static_cast<long long>(s) * c.width, c.width, lane,
+                                   false);
+                if (lane == 0)
+                    c.srv_ver[lk] += c.updates[s];
+            }
+            if (lane == 0) {
+                c.state[s] = kFree;
+                c.free_list[ftop + j] = s;
+            }
+        }
+    }
+}
+
 // after the push: version bump, zeroGrad, transient lines dropped, evicted slots freed.
 __device__ __forceinline__ void cache_update_cleanup_body(const CacheCtl *ctl, const Cache &c,
                                                           int with_push_keys, int wave0, int nwaves) {
@@ -1045,6 +1249,7 @@ __device__ __forceinline__ void cache_update_commit_body(CacheCtl *ctl, const Ca
         ctl->perf[4] = tot + En;     // num_transfered
         ctl->perf[5] = En;           // num_evict
         ctl->perf[6] = ctl->size == c.limit;
+        ctl->perf[7] = 0;
         ctl->free_top = ftop + En;
         ctl->evict_n = 0;
     }
@@ -1144,6 +1349,12 @@ struct ha_cache {
     int64_t plan_n = -1;   // n of the lookup whose plan is still in plan_ws (ha_cache_update_same_keys)
     int64_t pp_pull = -1, pp_push = 0;   // sizes of the push_pull between its begin and finish (remote store)
     int64_t out_pad = 0;   // remote store: the updates mark outbox entries [U + E, out_pad) as not pushed
+    // cache_update_same_post_kernel's preconditions, tracked on the host (no read-back): evict_empty = the last call
+    // was an update (it pushes every pending evicted line); same_fast = the plan in plan_ws belongs to a lookup that
+    // started from an empty evict list on an LRU cache with limit >= max_batch and a local store
+    bool evict_empty = true, same_fast = false;
+    int fused_update = 3;  // HA_CACHE_FUSED: bit 0 = the two-launch update, bit 1 = eviction beside the lookup's row copies
+    int64_t fused_count = 0;
 };
 
 extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
@@ -1157,6 +1368,8 @@ extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
         return nullptr;
     }
     ha_cache *h = new ha_cache();
+    if (const char *e = getenv("HA_CACHE_FUSED"))
+        h->fused_update = atoi(e);
     Cache &c = h->c;
     memset(&c, 0, sizeof(c));
     c.policy = policy;
@@ -1377,6 +1590,8 @@ extern "C" int ha_cache_lookup_begin(ha_cache *h, const void *keys, int key_kind
     if (cache_plan(h, keys, key_kind, n, s, 0, &probed))
         return -1;
     h->plan_n = n;
+    h->same_fast = false;
+    h->evict_empty = false;
     PlanPtrs p = plan_layout(c.plan_ws, n);
     if (!probed)   // larger batches: the plan was built unfused, probe separately
         hipLaunchKernelGGL(cache_probe_kernel, CACHE_GRID(n), dim3(256), 0, s, c.ctl, p.hdr, p.uniq, c.slot_of,
@@ -1399,17 +1614,18 @@ extern "C" int ha_cache_lookup_finish(ha_cache *h, int64_t n, float *dest, ha_st
     c.data_row = c.inbox_pull;   // the decisions the bookkeeping and the row kernel read
     hipStream_t s = as_stream(stream);
     PlanPtrs p = plan_layout(c.plan_ws, n);
+    const int evb = (h->fused_update & 2) && n > 0 ? 1 : 0;
     hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
-                       (long long)n, c.bypass ? 1 : 0, 1);
+                       (long long)n, c.bypass ? 1 : 0, 1, evb);
     if (n > 0) {
-        const unsigned blocks = static_cast<unsigned>((n + 3) / 4);
+        const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + evb;
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0);
         if (vec_ok)
-            hipLaunchKernelGGL(cache_lookup_rows_kernel<4>, dim3(blocks), dim3(256), 0, s, c, p.uniq, p.upos,
-                               p.perm, (long long)n, dest);
+            hipLaunchKernelGGL(cache_lookup_rows_kernel<4>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos,
+                               p.perm, (long long)n, dest, evb, c.bypass ? 1 : 0);
         else
-            hipLaunchKernelGGL(cache_lookup_rows_kernel<1>, dim3(blocks), dim3(256), 0, s, c, p.uniq, p.upos,
-                               p.perm, (long long)n, dest);
+            hipLaunchKernelGGL(cache_lookup_rows_kernel<1>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos,
+                               p.perm, (long long)n, dest, evb, c.bypass ? 1 : 0);
     }
     HA_LAUNCH_CHECK();
     return 0;
@@ -1449,19 +1665,22 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     if (cache_plan(h, keys, key_kind, n, s, 1, &probed))
         return -1;
     h->plan_n = n;
+    h->same_fast = (h->fused_update & 1) && h->evict_empty && c.policy == kLRU && !c.bypass && c.limit >= n && n > 0;
+    h->evict_empty = false;
     PlanPtrs p = plan_layout(c.plan_ws, n);
+    const int evb = (h->fused_update & 2) && n > 0 ? 1 : 0;
     hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
-                       (long long)n, c.bypass ? 1 : 0, probed);
+                       (long long)n, c.bypass ? 1 : 0, probed, evb);
     if (n > 0) {
-        const unsigned blocks = static_cast<unsigned>((n + 3) / 4);
+        const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + evb;
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0) &&
                             (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
         if (vec_ok)
-            hipLaunchKernelGGL(cache_lookup_rows_kernel<4>, dim3(blocks), dim3(256), 0, s, c, p.uniq, p.upos,
-                               p.perm, (long long)n, dest);
+            hipLaunchKernelGGL(cache_lookup_rows_kernel<4>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos,
+                               p.perm, (long long)n, dest, evb, c.bypass ? 1 : 0);
         else
-            hipLaunchKernelGGL(cache_lookup_rows_kernel<1>, dim3(blocks), dim3(256), 0, s, c, p.uniq, p.upos,
-                               p.perm, (long long)n, dest);
+            hipLaunchKernelGGL(cache_lookup_rows_kernel<1>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos,
+                               p.perm, (long long)n, dest, evb, c.bypass ? 1 : 0);
     }
     HA_LAUNCH_CHECK();
     return 0;
@@ -1487,6 +1706,25 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     h->plan_n = -1;
     PlanPtrs p = plan_layout(c.plan_ws, n);
     const dim3 b(256);
+    const bool fast = keys == nullptr && h->same_fast && !with_push_keys && !defer_cleanup && !c.bypass && !c.remote;
+    h->same_fast = false;
+    h->evict_empty = true;     // every path below pushes the pending evicted lines
+    if (fast) {
+        ++h->fused_count;
+        // every key is resident with data in uslot[]: accumulate, then touch / flags / push / commit in one launch
+        if (ha_apply_mapped2(c.grad, c.S, c.data, c.width, c.plan_ws, n, grads, -1.0f, c.uslot, c.uslot, c.hasgrad, s))
+            return -1;
+        const unsigned pblocks = static_cast<unsigned>((2 * n + 15) / 16 > 1024 ? 1024 : (2 * n + 15) / 16);
+        const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
+        if (vec_ok)
+            hipLaunchKernelGGL(cache_update_same_post_kernel<4>, dim3(pblocks), dim3(1024), 0, s, c, p.hdr, p.uniq,
+                               p.counts, (long long)n);
+        else
+            hipLaunchKernelGGL(cache_update_same_post_kernel<1>, dim3(pblocks), dim3(1024), 0, s, c, p.hdr, p.uniq,
+                               p.counts, (long long)n);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
     const uint32_t *pk = nullptr;
     if (with_push_keys) {
         HA_REQUIRE(n_push <= c.nmax, "cache_update: too many push keys");
@@ -1592,6 +1830,7 @@ static int push_pull_begin(ha_cache *h, const void *pull_keys, int pull_kind, in
     // ---- push phase (a complete embedding_update on scratch set A)
     if (cache_update_impl(h, push_keys, push_kind, n_push, grads, nullptr, 0, 0, 0, s, true))
         return -1;
+    h->evict_empty = false;    // the pull phase's insert evicts after this push
     // ---- pull phase, part 2 starts: restore the parked pull state
     hipLaunchKernelGGL(cache_park_kernel, dim3(1), dim3(1), 0, s, c.ctl, 2);  // park the push phase's U
     hipLaunchKernelGGL(cache_retire_kernel, dim3(1), dim3(1), 0, s, c.ctl, 0);
@@ -1671,6 +1910,7 @@ extern "C" int ha_cache_perf(ha_cache *h, int64_t *out_host, ha_stream_t stream)
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
     for (int i = 0; i < 7; ++i)
         out_host[i] = ctl.perf[i];
+    out_host[4] += ctl.perf[7];
     out_host[7] = ctl.size;
     return 0;
 }
@@ -1719,3 +1959,4 @@ extern "C" float *ha_cache_data(ha_cache *h) { return h ? h->c.data : nullptr; }
 extern "C" float *ha_cache_grad(ha_cache *h) { return h ? h->c.grad : nullptr; }
 extern "C" int64_t ha_cache_limit(ha_cache *h) { return h ? h->c.limit : -1; }
 extern "C" int64_t ha_cache_width(ha_cache *h) { return h ? h->c.width : -1; }
+extern "C" int64_t ha_cache_fused_updates(ha_cache *h) { return h ? h->fused_count : -1; }

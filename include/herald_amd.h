@@ -773,6 +773,10 @@ float *ha_cache_data(ha_cache *cache);
 float *ha_cache_grad(ha_cache *cache);
 int64_t ha_cache_limit(ha_cache *cache);
 int64_t ha_cache_width(ha_cache *cache);
+/* Updates that took the two-launch path of ha_cache_update_same_keys (LRU, local store, the keys of the preceding
+ * lookup, limit >= batch: accumulate + one launch for touch / push / commit) since the cache was created.
+ * HA_CACHE_FUSED=0 in the environment keeps every update on the general path. */
+int64_t ha_cache_fused_updates(ha_cache *cache);
 
 /* ---- laia embedding scheduler (replaces the laia_cache plugin, laia/) --------
  * LaiaScheduler::get_dist + the snapshot update of launch() (laia/src/laia_scheduler.cc:115-271) for

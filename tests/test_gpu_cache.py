@@ -24,9 +24,11 @@ def _compare_state(gpu, model, step):
 
 
 def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_keys_mode=False, seed=0,
-               zipf=True, check_every=1, policy="lru", bind=None):
+               zipf=True, check_every=1, policy="lru", bind=None, same=False, extra_lookup_every=0):
     """bind(gpu_cache, table, versions): how the cache reaches its store (default: bind_store, the table in
-    the same HBM; test_gpu_cache_remote.py passes remote stores here)."""
+    the same HBM; test_gpu_cache_remote.py passes remote stores here).  same: the update names the lookup's key
+    tensor (same_as_lookup=True -> ha_cache_update_same_keys); extra_lookup_every=k: every k-th step looks another
+    batch up first, so that the evict list is not empty when the step's own lookup starts."""
     rng = np.random.default_rng(seed)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
     server = cache_model.Server(table0)
@@ -48,9 +50,15 @@ def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_k
         else:
             keys = rng.integers(0, rows, size=n)
         fk = keys.astype(np.float32)                      # the *_raw entry points take float32 ids
-        want = model.lookup(fk.astype(np.uint64))
         dest = torch.empty((n, width), dtype=torch.float32, device=dev)
-        gpu.embedding_lookup(torch.from_numpy(fk).to(dev), dest).wait()
+        if extra_lookup_every and step % extra_lookup_every == extra_lookup_every - 1:
+            xk = rng.integers(0, rows, size=n).astype(np.float32)
+            want = model.lookup(xk.astype(np.uint64))
+            gpu.embedding_lookup(torch.from_numpy(xk).to(dev), dest).wait()
+            np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="extra lookup rows at step %d" % step)
+        want = model.lookup(fk.astype(np.uint64))
+        kt = torch.from_numpy(fk).to(dev)
+        gpu.embedding_lookup(kt, dest).wait()
         np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % step)
         grads = (rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01))
         if push_keys_mode:
@@ -61,7 +69,10 @@ def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_k
                                                 torch.from_numpy(grads).to(dev)).wait()
         else:
             model.update(fk.astype(np.uint64), grads)
-            gpu.embedding_update(torch.from_numpy(fk).to(dev), torch.from_numpy(grads).to(dev)).wait()
+            if same:
+                gpu.embedding_update(kt, torch.from_numpy(grads).to(dev), same_as_lookup=True).wait()
+            else:
+                gpu.embedding_update(torch.from_numpy(fk).to(dev), torch.from_numpy(grads).to(dev)).wait()
         # perf dicts (cache.cc:89-106,179-196)
         for got, exp in zip(gpu.perf[-2:], model.perf[-2:]):
             for f in ("type", "num_all", "num_unique", "num_miss", "num_transfered", "is_full"):
@@ -104,6 +115,48 @@ def test_lru_trace_long_runs_full_width(dev):
     # one key repeats ~600 times per batch: the mapped accumulate takes the cooperative long-run path
     # (8 slices of 64 columns) for both the gradient buffer and the data rows
     _run_trace(dev, limit=500, rows=3000, width=512, n=2000, steps=4, pull_bound=1, push_bound=2, seed=9)
+
+
+def _fused(gpu):
+    return int(gpu._L.ha_cache_fused_updates(gpu._h))
+
+
+@pytest.mark.parametrize("pull_bound,push_bound", [(0, 0), (3, 3), (100, 100)])
+@pytest.mark.parametrize("zipf", [True, False])
+def test_lru_trace_update_of_the_looked_up_keys(dev, pull_bound, push_bound, zipf):
+    """limit >= batch and the update names the lookup's key tensor: accumulate + ONE launch for touch / bounded push /
+    evicted lines / commit (cache_update_same_post_kernel) -- the same trace, state and reports as the model."""
+    gpu, _ = _run_trace(dev, limit=100, rows=1500, width=8, n=64, steps=80, pull_bound=pull_bound,
+                        push_bound=push_bound, zipf=zipf, seed=11, same=True)
+    assert _fused(gpu) == 80
+
+
+def test_lru_trace_update_of_the_looked_up_keys_with_lookups_between(dev):
+    # every third step looks two batches up before its update: its evict list holds the victims of both lookups
+    # (a key among them may be back in the batch), so that update takes the general path
+    gpu, _ = _run_trace(dev, limit=80, rows=300, width=8, n=64, steps=60, pull_bound=1, push_bound=2, zipf=False,
+                        seed=12, same=True, extra_lookup_every=3)
+    assert _fused(gpu) == 40
+
+
+def test_lru_trace_update_of_the_looked_up_keys_long_runs_full_width(dev):
+    gpu, _ = _run_trace(dev, limit=2500, rows=6000, width=512, n=2000, steps=5, pull_bound=1, push_bound=2, seed=13,
+                        same=True)
+    assert _fused(gpu) == 5
+
+
+def test_lru_trace_update_of_the_looked_up_keys_log_compaction(dev):
+    gpu, _ = _run_trace(dev, limit=24, rows=96, width=4, n=16, steps=500, pull_bound=0, push_bound=1, seed=14,
+                        check_every=50, same=True)
+    assert _fused(gpu) == 500
+    st = gpu.state()
+    assert st["log_tail"] - st["log_head"] <= st["log_cap"]
+
+
+def test_lru_limit_smaller_than_batch_never_takes_the_fused_update(dev):
+    gpu, _ = _run_trace(dev, limit=5, rows=200, width=4, n=40, steps=10, pull_bound=1, push_bound=1, zipf=False,
+                        seed=15, same=True)
+    assert _fused(gpu) == 0
 
 
 def test_log_compaction_keeps_lru_order(dev):
