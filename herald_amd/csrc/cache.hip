@@ -554,20 +554,27 @@ __device__ __forceinline__ void cache_insert_evict_body(
         const long long pos = head + threadIdx.x;
         int s = -1;
         bool valid = false;
+        int upd_s = 0;
+        uint32_t key_s = 0;
         if (pos < tail) {
             s = static_cast<int>(c.log_slot[pos % c.Lcap]);
-            valid = c.state[s] == kResident && c.stamp[s] == c.log_stamp[pos % c.Lcap] &&
+            // everything a victim needs in the same trip as the validity test (one trip per chunk less, twice)
+            const uint8_t st8 = c.state[s];
+            const unsigned long long stp = c.stamp[s];
+            upd_s = c.updates[s];
+            key_s = c.key[s];
+            valid = st8 == kResident && stp == c.log_stamp[pos % c.Lcap] &&
                     (c.policy == kLRU || c.freq[s] == base_use);
         }
         uint32_t tot;
         const uint32_t r = block_scan_1024(valid ? 1u : 0u, s_w, &tot);
         const bool take = valid && static_cast<long long>(r) < left;
-        const bool dirty = take && c.updates[s] != 0;
+        const bool dirty = take && upd_s != 0;
         uint32_t tot_d, tot_c;
         const uint32_t rd = block_scan_1024(dirty ? 1u : 0u, s_w, &tot_d);
         const uint32_t rc = block_scan_1024((take && !dirty) ? 1u : 0u, s_w, &tot_c);
         if (take) {
-            c.slot_of[c.key[s]] = -1;
+            c.slot_of[key_s] = -1;
             if (dirty) {
                 c.state[s] = kEvictedDirty;
                 c.evict_slots[ctl->evict_n + s_dirty + rd] = s;
@@ -777,6 +784,11 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
         cache_report_pull_body(ctl, c, n);
 }
 
+// (Tried: finish + probe + pull decisions + slot assignment of a lookup of <= 8192 keys as ONE workgroup whose threads keep
+// their keys in registers from the sorted list to the stores -- 38 us instead of 6.8 + 8.6: the ~5,000 probes of slot_of /
+// version / srv_ver are random accesses into 135 / 27 / 270 MB and one compute unit's address translation serves them one
+// after the other.  Random accesses belong on many compute units -- the finish's probe hook, the row kernel --, the single
+// bookkeeping workgroup keeps to scans and sequential lists.)
 // One wave per SORTED position p of the batch: dest[perm[p],:] = the row of its key.  Keys marked for
 // a pull read the store row (+ the line's pending gradient, Line::addup) and the wave of the key's
 // first position also refreshes the cache line and its version; the others copy the cached row.
@@ -1135,8 +1147,7 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
         ctl->M = 0;
         ctl->nhit = U;
         ctl->clock = clock + U;
-        ctl->log_tail = tail + U;
-        ctl->free_top = ftop + En;
+        ctl->free_top = ftop + En;       // log_tail stays: the touches replace the lookup's entries
         ctl->evict_n = 0;
     }
     for (int item = blockIdx.x * 16 + static_cast<int>(threadIdx.x >> 6); item < U + En; item += gridDim.x * 16) {
@@ -1148,7 +1159,11 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
             const bool push = upd > c.push_bound;
             if (lane == 0) {
                 const unsigned long long st = static_cast<unsigned long long>(clock + u);
-                const long long pos = (tail + u) % c.Lcap;
+                // The log's last U entries are the lookup's touches and inserts of exactly these lines: all stale the
+                // moment this update touches them.  The new entries REPLACE them (same positions, stamps still ascending)
+                // instead of following them: the log does not collect U dead entries per step for the eviction to wade
+                // through (the general path appends; the order of the valid entries -- all eviction sees -- is the same).
+                const long long pos = (tail - U + u) % c.Lcap;
                 c.stamp[s] = st;
                 c.log_slot[pos] = static_cast<uint32_t>(s);
                 c.log_stamp[pos] = st;
@@ -1662,13 +1677,13 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     Cache &c = h->c;
     hipStream_t s = as_stream(stream);
     int probed = 0;
+    const int evb = (h->fused_update & 2) && n > 0 ? 1 : 0;
+    PlanPtrs p = plan_layout(c.plan_ws, n);
     if (cache_plan(h, keys, key_kind, n, s, 1, &probed))
         return -1;
     h->plan_n = n;
     h->same_fast = (h->fused_update & 1) && h->evict_empty && c.policy == kLRU && !c.bypass && c.limit >= n && n > 0;
     h->evict_empty = false;
-    PlanPtrs p = plan_layout(c.plan_ws, n);
-    const int evb = (h->fused_update & 2) && n > 0 ? 1 : 0;
     hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
                        (long long)n, c.bypass ? 1 : 0, probed, evb);
     if (n > 0) {
