@@ -213,6 +213,7 @@ def _declare(L):
         "ha_cache_push_pull": [vp, vp, c.c_int, i64, vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_perf": [vp, vp, vp],
         "ha_cache_state": [vp, vp, vp],
+        "ha_cache_phase_times": [vp, vp, vp],
         "ha_cache_snapshot": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
         "ha_cache_set_line": [vp, i64, i64, vp, vp],
         "ha_cache_set_remote": [vp],

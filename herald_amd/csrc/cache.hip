@@ -70,8 +70,23 @@ struct CacheCtl {
     // last op report: type(0 pull,1 push), num_all, num_unique, num_miss, num_transfered, num_evict, is_full
     long long perf[8];     // [7]: pushed lines of a cache_update_same_post_kernel update, to be added to [4]
     long long out_n;       // remote mode: outbox entries of the last update (U + E), -1 on overflow
+    unsigned long long ph[16];   // ha_cache_phase_times: 100 MHz clock at the phase boundaries of the last lookup's bookkeeping
     long long snap[4];     // {clock, log_tail, free_top, evict_n} as the last lookup left them (cache_update_same_post_kernel)
 };
+
+// Per-line bookkeeping as ONE 32-byte record: the bookkeeping kernels reach lines at random slots from a single
+// workgroup, where every separate array costs its own address translation per line (the eviction walk read stamp,
+// state, updates and key of ~1,000 victims from four arrays: 10 us of one compute unit's time at the criteo batch).
+struct alignas(32) LineMeta {
+    unsigned long long stamp;
+    long long version;
+    uint32_t key;
+    int32_t updates;
+    int32_t freq;
+    uint8_t state;
+    uint8_t pad[3];
+};
+static_assert(sizeof(LineMeta) == 32, "one line record = 32 bytes");
 
 struct Cache {
     int policy;
@@ -80,12 +95,8 @@ struct Cache {
     bool bypass;
     CacheCtl *ctl;
     int32_t *slot_of;
-    uint32_t *key;
-    long long *version;
-    int32_t *updates;
-    int32_t *freq;
-    uint8_t *hasgrad, *state;
-    unsigned long long *stamp;
+    LineMeta *line;        // [S] key / version / updates / freq / state / stamp of the line in slot s
+    uint8_t *hasgrad;      // [S] dense: the accumulate kernels read it through their own row map (ApplyMaps::dst_init)
     float *data, *grad;
     int32_t *free_list;
     uint32_t *log_slot;
@@ -123,7 +134,16 @@ struct Cache {
     float *out_rows;       // [out_cap, width]
 };
 constexpr uint32_t kNoPush = 0xFFFFFFFFu;
+// phase boundary i of a single-workgroup bookkeeping body (ha_cache_phase_times); `ctl` in scope
+#define CACHE_PH(i)                                                  \
+    do {                                                             \
+        if (threadIdx.x == 0)                                        \
+            ctl->ph[i] = __builtin_amdgcn_s_memrealtime();           \
+    } while (0)
 
+#ifndef HA_CACHE_BOOK_FUSED
+#define HA_CACHE_BOOK_FUSED 1
+#endif
 #define CACHE_GRID(n) dim3(static_cast<unsigned>(((n) + 255) / 256 > 2048 ? 2048 : ((n) + 255) / 256 < 1 ? 1 : ((n) + 255) / 256))
 
 // ---- block-wide exclusive scan helper (1024 threads) ----------------------------------------------
@@ -140,13 +160,49 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *s_w, u
     if (lane == 63)
         s_w[w] = x;
     __syncthreads();
-    uint32_t woff = 0, tot = 0;
-    for (int k = 0; k < 16; ++k) {
-        if (k < w)
-            woff += s_w[k];
-        tot += s_w[k];
+    uint32_t t = s_w[lane & 15];      // the sixteen wave totals: one read per lane, four scan steps over lanes 0..15
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t y = __shfl_up(t, o, 64);
+        if ((lane & 15) >= o)
+            t += y;
     }
-    *total = tot;
+    *total = __shfl(t, 15, 64);
+    const uint32_t woff = w > 0 ? __shfl(t, w - 1, 64) : 0u;
+    return woff + x - v;
+}
+
+// ring position base + off for base < cap, 0 <= off < cap: one 64-bit division per caller (for the base) instead of one
+// per entry
+__device__ __forceinline__ long long ring_at(long long base_mod, long long off, long long cap) {
+    const long long q = base_mod + off;
+    return q >= cap ? q - cap : q;
+}
+
+// block-wide exclusive scan of four 16-bit counters packed into 64 bits (every total < 65536)
+__device__ __forceinline__ unsigned long long block_scan_1024_x4(unsigned long long v, unsigned long long *s_w64,
+                                                                 unsigned long long *total) {
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    unsigned long long x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(x, o, 64);
+        if (lane >= o)
+            x += y;
+    }
+    __syncthreads();
+    if (lane == 63)
+        s_w64[w] = x;
+    __syncthreads();
+    unsigned long long t = s_w64[lane & 15];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const unsigned long long y = __shfl_up(t, o, 64);
+        if ((lane & 15) >= o)
+            t += y;
+    }
+    *total = __shfl(t, 15, 64);
+    const unsigned long long woff = w > 0 ? __shfl(t, w - 1, 64) : 0ull;
     return woff + x - v;
 }
 
@@ -234,6 +290,7 @@ __device__ __forceinline__ void cache_assign_body(
     const uint32_t *rank, int miss_state, int tid0, int nthr) {
     const int U = static_cast<int>(ctl->U);
     const long long clock = ctl->clock, tail = ctl->log_tail, ftop = ctl->free_top;
+    const long long tail_mod = tail % c.Lcap;       // the batch (<= nmax keys) is shorter than the ring
     // eight keys per thread and round: their flags / slots / ranks / keys in ONE batch of loads, the free slots of the
     // misses in a second one, then the stores -- a key-by-key loop is two dependent trips to memory per key (seven keys
     // per thread at the criteo batch: the single-workgroup bookkeeping kernels spent most of their time there)
@@ -265,38 +322,38 @@ __device__ __forceinline__ void cache_assign_body(
                 const unsigned long long st = static_cast<unsigned long long>(clock + u);
                 if (c.policy == kLRU) {
                     // lru_cache.cc:27-39: move to the list front
-                    c.stamp[s] = st;
-                    const long long pos = (tail + (u - static_cast<long long>(rk[i]))) % c.Lcap;
+                    c.line[s].stamp = st;
+                    const long long pos = ring_at(tail_mod, u - static_cast<long long>(rk[i]), c.Lcap);
                     c.log_slot[pos] = static_cast<uint32_t>(s);
                     c.log_stamp[pos] = st;
                 } else if (c.policy == kLFU) {
                     // lfu_cache.cc:22-29,51-68: use+1, front of the next bucket
-                    const int fq = c.freq[s];
+                    const int fq = c.line[s].freq;
                     if (fq == 1)
                         atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_base), ~0ull);
-                    c.freq[s] = fq + 1;
-                    c.stamp[s] = st;
-                } else if (c.state[s] == kResident) {
+                    c.line[s].freq = fq + 1;
+                    c.line[s].stamp = st;
+                } else if (c.line[s].state == kResident) {
                     // lfuopt_cache.cc:26-41: use+1 or promotion to the never-evicted store
-                    const int fq = c.freq[s];
+                    const int fq = c.line[s].freq;
                     if (fq == 0)
                         atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_base), ~0ull);
                     if (fq + 1 < kUseCntMax) {
-                        c.freq[s] = fq + 1;
-                        c.stamp[s] = st;
+                        c.line[s].freq = fq + 1;
+                        c.line[s].stamp = st;
                     } else {
-                        c.state[s] = kStored;
+                        c.line[s].state = kStored;
                         atomicAdd(reinterpret_cast<unsigned long long *>(&ctl_mut->n_hash), ~0ull);
                     }
                 }
             } else {
                 const int s = fs[i];
                 c.uslot[u] = s;
-                c.key[s] = kk[i];
-                c.version[s] = -1;
-                c.updates[s] = 0;
+                c.line[s].key = kk[i];
+                c.line[s].version = -1;
+                c.line[s].updates = 0;
                 c.hasgrad[s] = 0;
-                c.state[s] = static_cast<uint8_t>(miss_state);
+                c.line[s].state = static_cast<uint8_t>(miss_state);
             }
         }
     }
@@ -364,7 +421,7 @@ __global__ __launch_bounds__(256) void cache_sync_kernel(CacheCtl *ctl, Cache c,
         } else {
             if (lk < 0 || lk >= c.store_rows)
                 continue;
-            const long long v = c.version[s];
+            const long long v = c.line[s].version;
             sv = c.srv_ver[lk];
             if (!(v == -1 || sv - v > c.pull_bound))
                 continue;
@@ -380,7 +437,7 @@ __global__ __launch_bounds__(256) void cache_sync_kernel(CacheCtl *ctl, Cache c,
             dst[j] = x;
         }
         if (lane == 0) {
-            c.version[s] = sv;
+            c.line[s].version = sv;
             atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->pulled), 1ull);
         }
     }
@@ -411,10 +468,10 @@ __device__ __forceinline__ void cache_scan_victim_body(CacheCtl *ctl, const Cach
     unsigned long long best = ~0ull;
     int slot = -1;
     for (long long s = threadIdx.x; s < c.S; s += 1024) {
-        if (c.state[s] != kResident)
+        if (c.line[s].state != kResident)
             continue;
         // stamps stay far below 2^48
-        const unsigned long long k = (static_cast<unsigned long long>(c.freq[s]) << 48) | c.stamp[s];
+        const unsigned long long k = (static_cast<unsigned long long>(c.line[s].freq) << 48) | c.line[s].stamp;
         if (k < best) {
             best = k;
             slot = static_cast<int>(s);
@@ -458,6 +515,8 @@ __device__ __forceinline__ void cache_insert_evict_body(
     // cache_commit_touch_kernel: misses are stamped clock + rank and logged from the current tail
     const long long clock = ctl->clock, tail0 = ctl->log_tail;
     const long long size0 = ctl->size;
+    const long long evict_n0 = ctl->evict_n, free_top0 = ctl->free_top;   // (read once: not a trip per round)
+    const long long log_head0 = ctl->log_head;
     // Number of evictions and how many of the batch's own first inserts they consume (v_new), see the
     // file header: LRU evicts after an insert while size > limit, LFU/LFUOpt before it while
     // size == limit, and prefer old lines of the lowest bucket, then their own new lines.
@@ -484,6 +543,7 @@ __device__ __forceinline__ void cache_insert_evict_body(
         need = ev;
     }
     const int base_use = c.policy == kLFU ? 1 : 0;
+    const long long tail0_mod = tail0 % c.Lcap;
     if (do_insert) {
         constexpr int R = 8;       // batched loads, see cache_assign_body
         for (int base = threadIdx.x; base < U; base += 1024 * R) {
@@ -506,39 +566,40 @@ __device__ __forceinline__ void cache_insert_evict_body(
                 if (q < v_new) {
                     // inserted and evicted again inside this batch (or dropped): never becomes resident;
                     // a fresh line has updates == 0, so it does not enter evict_
-                    c.state[s] = kFree;
+                    c.line[s].state = kFree;
                     continue;
                 }
                 const unsigned long long st = static_cast<unsigned long long>(clock + q);
                 c.slot_of[kk[i]] = s;
-                c.stamp[s] = st;
-                c.freq[s] = base_use;
-                c.state[s] = kResident;
-                const long long pos = (tail0 + (q - v_new)) % c.Lcap;
+                c.line[s].stamp = st;
+                c.line[s].freq = base_use;
+                c.line[s].state = kResident;
+                const long long pos = ring_at(tail0_mod, q - v_new, c.Lcap);
                 c.log_slot[pos] = static_cast<uint32_t>(s);
                 c.log_stamp[pos] = st;
             }
         }
     }
     __syncthreads();
+    CACHE_PH(9);
     const long long inserted = M - v_new;
     const long long tail = tail0 + inserted;
     long long size = size0 + inserted;
     if (threadIdx.x == 0) {
-        s_head = ctl->log_head;
+        s_head = log_head0;
         s_need = need;
         s_clean = 0;
         s_dirty = 0;
         if (scan_take) {
             // the one victim outside the lowest bucket
             const int vs = static_cast<int>(ctl->scan_victim);
-            c.slot_of[c.key[vs]] = -1;
-            if (c.updates[vs] != 0) {
-                c.state[vs] = kEvictedDirty;
+            c.slot_of[c.line[vs].key] = -1;
+            if (c.line[vs].updates != 0) {
+                c.line[vs].state = kEvictedDirty;
                 c.evict_slots[ctl->evict_n] = vs;
                 s_dirty = 1;
             } else {
-                c.state[vs] = kFree;
+                c.line[vs].state = kFree;
                 c.free_list[ctl->free_top - M] = vs;
                 s_clean = 1;
             }
@@ -547,10 +608,17 @@ __device__ __forceinline__ void cache_insert_evict_body(
     __syncthreads();
     const long long E = need + scan_take;
     // ---- evict the `need` oldest valid log entries
+    if (threadIdx.x == 0) {
+        ctl->ph[13] = 0;                                            // rounds
+        ctl->ph[14] = static_cast<unsigned long long>(need);        // lines to evict
+        ctl->ph[15] = static_cast<unsigned long long>(s_head);      // log head before the walk
+    }
     while (true) {
         const long long head = s_head, left = s_need;
         if (left <= 0 || head >= tail)
             break;
+        if (threadIdx.x == 0)
+            ctl->ph[13] += 1;
         const long long pos = head + threadIdx.x;
         int s = -1;
         bool valid = false;
@@ -559,12 +627,12 @@ __device__ __forceinline__ void cache_insert_evict_body(
         if (pos < tail) {
             s = static_cast<int>(c.log_slot[pos % c.Lcap]);
             // everything a victim needs in the same trip as the validity test (one trip per chunk less, twice)
-            const uint8_t st8 = c.state[s];
-            const unsigned long long stp = c.stamp[s];
-            upd_s = c.updates[s];
-            key_s = c.key[s];
+            const uint8_t st8 = c.line[s].state;
+            const unsigned long long stp = c.line[s].stamp;
+            upd_s = c.line[s].updates;
+            key_s = c.line[s].key;
             valid = st8 == kResident && stp == c.log_stamp[pos % c.Lcap] &&
-                    (c.policy == kLRU || c.freq[s] == base_use);
+                    (c.policy == kLRU || c.line[s].freq == base_use);
         }
         uint32_t tot;
         const uint32_t r = block_scan_1024(valid ? 1u : 0u, s_w, &tot);
@@ -576,12 +644,12 @@ __device__ __forceinline__ void cache_insert_evict_body(
         if (take) {
             c.slot_of[key_s] = -1;
             if (dirty) {
-                c.state[s] = kEvictedDirty;
-                c.evict_slots[ctl->evict_n + s_dirty + rd] = s;
+                c.line[s].state = kEvictedDirty;
+                c.evict_slots[evict_n0 + s_dirty + rd] = s;
             } else {
-                c.state[s] = kFree;
+                c.line[s].state = kFree;
                 // freed slots go on top of the stack AFTER this call's allocations are retired
-                c.free_list[ctl->free_top - M + s_clean + rc] = s;
+                c.free_list[free_top0 - M + s_clean + rc] = s;
             }
         }
         __syncthreads();
@@ -601,7 +669,9 @@ __device__ __forceinline__ void cache_insert_evict_body(
             if (threadIdx.x == 0)
                 s_last = head;
             __syncthreads();
-            if (take)
+            // one LDS atomic per wave (its last victim), not one per victim on the same word
+            const unsigned long long tm = __ballot(take);
+            if (tm != 0ull && lane_id() == 63 - __builtin_clzll(tm))
                 atomicMax(reinterpret_cast<unsigned long long *>(&s_last),
                           static_cast<unsigned long long>(pos + 1));
             __syncthreads();
@@ -611,7 +681,10 @@ __device__ __forceinline__ void cache_insert_evict_body(
         }
     }
     __syncthreads();
+    CACHE_PH(10);
     long long head = s_head;
+    if (threadIdx.x == 0)
+        ctl->ph[15] = static_cast<unsigned long long>(head) - ctl->ph[15];       // entries the walk consumed
     long long new_tail = tail;
     // ---- compact the log in place when it is nearly full (valid entries keep their order)
     if (tail - head > c.Lcap - 4 * c.nmax - 2048) {
@@ -627,8 +700,8 @@ __device__ __forceinline__ void cache_insert_evict_body(
             if (pos < tail) {
                 s = static_cast<int>(c.log_slot[pos % c.Lcap]);
                 st = c.log_stamp[pos % c.Lcap];
-                valid = c.state[s] == kResident && c.stamp[s] == st &&
-                        (c.policy == kLRU || c.freq[s] == base_use);
+                valid = c.line[s].state == kResident && c.line[s].stamp == st &&
+                        (c.policy == kLRU || c.line[s].freq == base_use);
             }
             uint32_t tot;
             const uint32_t r = block_scan_1024(valid ? 1u : 0u, s_w, &tot);
@@ -721,20 +794,113 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
     __shared__ uint32_t s_cnt[16];
     CacheCtl *ctl = c.ctl;
     const int tid = threadIdx.x;
+    CACHE_PH(0);
     // probed: uslot / flag / the pull decisions (data_row) were written by cache_finish_probe_kernel
     if (!probed)
         cache_probe_body(ctl, hdr, uniq, c.slot_of, c.length, bypass, c.uslot, c.flag, tid, 1024);
     else if (tid == 0)
         ctl->U = hdr->n_unique;
     __syncthreads();
+    CACHE_PH(1);
+    const int U = static_cast<int>(hdr->n_unique);
+    if (probed && c.policy == kLRU && U <= 8 * 1024 && (HA_CACHE_BOOK_FUSED)) {
+        // Up to 8192 unique keys, flags and pull decisions in place, LRU: thread t owns the keys t, t + 1024, ... from
+        // the loads to the stores -- flags / slots / keys / decisions in ONE batch, the miss ranks from one packed scan
+        // (per 1024-key slice a 16-bit counter), the free slots of the misses in a second batch; nothing passes through
+        // memory between what used to be three phases with a trip each at their start.
+        const long long clock = ctl->clock, tail = ctl->log_tail, ftop = ctl->free_top;
+        const long long tail_mod = tail % c.Lcap;
+        uint32_t f[8], kk[8];
+        int us[8], fs[8];
+        uint32_t pc = 0;
+        unsigned long long v_lo = 0, v_hi = 0;      // misses of slices 0..3 / 4..7, 16 bits each
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int u = min(tid + i * 1024, max(U - 1, 0));
+            const bool on = tid + i * 1024 < U;
+            f[i] = c.flag[u];
+            us[i] = c.uslot[u];
+            kk[i] = uniq[u];
+            const int pl = c.data_row[u];
+            f[i] = on ? f[i] : 0u;
+            pc += on ? static_cast<uint32_t>(pl) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v_lo |= static_cast<unsigned long long>(f[i]) << (16 * i);
+            v_hi |= static_cast<unsigned long long>(f[i + 4]) << (16 * i);
+        }
+        __shared__ unsigned long long s_w64[16];
+        unsigned long long t_lo, t_hi;
+        const unsigned long long e_lo = block_scan_1024_x4(v_lo, s_w64, &t_lo);
+        const unsigned long long e_hi = block_scan_1024_x4(v_hi, s_w64, &t_hi);
+        uint32_t ptot;
+        block_scan_1024(pc, s_cnt, &ptot);
+        uint32_t rk[8];
+        uint32_t before = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned long long e = i < 4 ? e_lo : e_hi, t = i < 4 ? t_lo : t_hi;
+            rk[i] = before + static_cast<uint32_t>((e >> (16 * (i & 3))) & 0xFFFFull);
+            before += static_cast<uint32_t>((t >> (16 * (i & 3))) & 0xFFFFull);
+        }
+        const uint32_t M = before;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long idx = ftop - 1 - static_cast<long long>(rk[i]);
+            // running out of slots is a sizing error reported by the host wrapper (nmax)
+            fs[i] = (f[i] && idx >= 0) ? c.free_list[idx] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int u = tid + i * 1024;
+            if (u >= U)
+                break;
+            c.rank[u] = rk[i];
+            if (!f[i]) {                            // the LRU hit branch of cache_assign_body
+                const int sl = us[i];
+                const unsigned long long st = static_cast<unsigned long long>(clock + u);
+                const long long pos = ring_at(tail_mod, u - static_cast<long long>(rk[i]), c.Lcap);
+                c.line[sl].stamp = st;
+                c.log_slot[pos] = static_cast<uint32_t>(sl);
+                c.log_stamp[pos] = st;
+            } else {
+                const int sl = fs[i];
+                c.uslot[u] = sl;
+                c.line[sl].key = kk[i];
+                c.line[sl].version = -1;
+                c.line[sl].updates = 0;
+                c.hasgrad[sl] = 0;
+                c.line[sl].state = static_cast<uint8_t>(kPending);
+            }
+        }
+        __syncthreads();        // every thread has read the control block
+        if (tid == 0) {         // cache_scan_body's totals, cache_commit_touch_body, the pull count
+            ctl->M = M;
+            ctl->nhit = static_cast<long long>(U) - M;
+            ctl->log_tail = tail + (static_cast<long long>(U) - M);
+            ctl->clock = clock + U;
+            ctl->pulled = ptot;
+        }
+        CACHE_PH(4);
+        if (defer_evict)
+            return;
+        __syncthreads();
+        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1);
+        __syncthreads();
+        if (tid == 0)
+            cache_report_pull_body(ctl, c, n);
+        return;
+    }
     cache_scan_body(hdr, c.flag, c.rank, &ctl->M, &ctl->nhit);
     __syncthreads();
+    CACHE_PH(2);
     cache_assign_body(ctl, ctl, c, uniq, c.flag, c.rank, static_cast<int>(kPending), tid, 1024);
     __syncthreads();
+    CACHE_PH(3);
     if (tid == 0)
         cache_commit_touch_body(ctl, c);
     // pull decision per unique key
-    const int U = static_cast<int>(hdr->n_unique);
     uint32_t cnt = 0;
     if (probed) {   // the decisions are there: count them, eight independent loads per thread and round
         for (int base = tid; base < U; base += 8 * 1024) {
@@ -753,7 +919,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
             const int s = c.uslot[u];
             const long long lk = static_cast<long long>(uniq[u]) - c.row_start;
             if (lk >= 0 && lk < c.store_rows) {
-                const long long v = c.version[s];
+                const long long v = c.line[s].version;
                 pull = (v == -1 || c.srv_ver[lk] - v > c.pull_bound) ? 1 : 0;
             }
             c.data_row[u] = pull;
@@ -771,6 +937,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
             tot += s_cnt[k];
         ctl->pulled = tot;
     }
+    CACHE_PH(4);
     if (defer_evict)
         return;
     if (c.policy != kLRU) {
@@ -802,6 +969,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
     const int32_t *__restrict__ perm, long long n, float *__restrict__ dest, int evict_block, int bypass) {
     if (evict_block && blockIdx.x == 0) {
         CacheCtl *ctl = c.ctl;
+        CACHE_PH(8);
         if (c.policy != kLRU) {
             cache_scan_victim_body(ctl, c);
             __syncthreads();
@@ -810,6 +978,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
         __syncthreads();
         if (threadIdx.x == 0)
             cache_report_pull_body(ctl, c, n);
+        CACHE_PH(12);
         return;
     }
     const int lane = lane_id();
@@ -860,7 +1029,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
         }
     }
     if (head && lane == 0)
-        c.version[s] = c.remote ? c.inbox_ver[u] : c.srv_ver[lk];
+        c.line[s].version = c.remote ? c.inbox_ver[u] : c.srv_ver[lk];
 }
 
 // ---- update ----------------------------------------------------------------------------------------
@@ -869,7 +1038,7 @@ __device__ __forceinline__ void cache_update_rows_body(const CacheCtl *ctl, cons
     const int U = static_cast<int>(ctl->U);
     for (int u = tid0; u < U; u += nthr) {
         const int s = c.uslot[u];
-        c.data_row[u] = c.state[s] == kTransient ? -1 : s;
+        c.data_row[u] = c.line[s].state == kTransient ? -1 : s;
     }
 }
 __global__ __launch_bounds__(256) void cache_update_rows_kernel(const CacheCtl *ctl, Cache c) {
@@ -904,9 +1073,9 @@ __global__ __launch_bounds__(256) void cache_update_flags_kernel(
     for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
         const int s = c.uslot[u];
         c.hasgrad[s] = 1;
-        const int upd = c.updates[s] + counts[u];
-        c.updates[s] = upd;
-        const bool has_data = c.state[s] != kTransient;
+        const int upd = c.line[s].updates + counts[u];
+        c.line[s].updates = upd;
+        const bool has_data = c.line[s].state != kTransient;
         bool push;
         if (!with_push_keys) {
             push = upd > c.push_bound || !has_data;  // cache.cc:159
@@ -946,7 +1115,7 @@ __global__ __launch_bounds__(256) void cache_push_lines_kernel(const CacheCtl *c
         for (long long j = lane; j < c.width; j += kWave)
             row[j] = __fadd_rn(row[j], g[j]);
         if (lane == 0)
-            c.srv_ver[lk] += c.updates[s];
+            c.srv_ver[lk] += c.line[s].updates;
     }
 }
 
@@ -959,8 +1128,8 @@ __global__ __launch_bounds__(256) void cache_update_flags_push_kernel(
     const int lane = lane_id();
     for (int u = blockIdx.x * 4 + (threadIdx.x >> 6); u < U; u += gridDim.x * 4) {
         const int s = c.uslot[u];
-        const int upd = c.updates[s] + counts[u];
-        const bool has_data = c.state[s] != kTransient;
+        const int upd = c.line[s].updates + counts[u];
+        const bool has_data = c.line[s].state != kTransient;
         const uint32_t k = uniq[u];
         bool push;
         if (!with_push_keys) {
@@ -978,7 +1147,7 @@ __global__ __launch_bounds__(256) void cache_update_flags_push_kernel(
         }
         if (lane == 0) {
             c.hasgrad[s] = 1;
-            c.updates[s] = upd;
+            c.line[s].updates = upd;
             c.pushflag[u] = push ? 1 : 0;
             c.flag[u] = push ? 1u : 0u;
         }
@@ -1028,13 +1197,13 @@ __global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl 
     }
     for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < En; j += gridDim.x * 4) {
         const int s = c.evict_slots[j];
-        const uint32_t k = c.key[s];
+        const uint32_t k = c.line[s].key;
         if (c.remote) {   // one outbox entry per evicted line, in eviction order behind the batch's lines
             const long long e = ctl->U + j;
             if (e < c.out_cap) {
                 if (lane == 0) {
                     c.out_keys[e] = k;
-                    c.out_upd[e] = c.updates[s];
+                    c.out_upd[e] = c.line[s].updates;
                 }
                 const float *g = c.grad + static_cast<long long>(s) * c.width;
                 float *o = c.out_rows + e * c.width;
@@ -1046,7 +1215,7 @@ __global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl 
         bool earlier = false;
         for (int b = 0; b < j && !earlier; b += kWave) {
             const int t = b + lane;
-            const bool m = t < j && c.key[c.evict_slots[t]] == k;
+            const bool m = t < j && c.line[c.evict_slots[t]].key == k;
             earlier = __ballot(m) != 0ull;
         }
         if (earlier)
@@ -1058,12 +1227,12 @@ __global__ __launch_bounds__(256) void cache_push_evicted_kernel(const CacheCtl 
         long long vadd = 0;
         for (int t = j; t < En; ++t) {
             const int st = c.evict_slots[t];
-            if (c.key[st] != k)
+            if (c.line[st].key != k)
                 continue;
             const float *g = c.grad + static_cast<long long>(st) * c.width;
             for (long long q = lane; q < c.width; q += kWave)
                 row[q] = __fadd_rn(row[q], g[q]);
-            vadd += c.updates[st];
+            vadd += c.line[st].updates;
         }
         if (lane == 0)
             c.srv_ver[lk] += vadd;
@@ -1135,6 +1304,7 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
     // at ~30 ns each; with a __threadfence before it, 47 us)
     const long long clock = ctl->snap[0], tail = ctl->snap[1], ftop = ctl->snap[2];
     const int En = static_cast<int>(ctl->snap[3]);
+    const long long tailU_mod = (tail - U) % c.Lcap;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl->perf[0] = 1;
         ctl->perf[1] = n;
@@ -1155,7 +1325,7 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
             const int u = item;
             const int s = uniform(c.uslot[u]);
             const uint32_t k = uniform(uniq[u]);
-            const int upd = uniform(c.updates[s] + counts[u]);
+            const int upd = uniform(c.line[s].updates + counts[u]);
             const bool push = upd > c.push_bound;
             if (lane == 0) {
                 const unsigned long long st = static_cast<unsigned long long>(clock + u);
@@ -1163,14 +1333,14 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
                 // moment this update touches them.  The new entries REPLACE them (same positions, stamps still ascending)
                 // instead of following them: the log does not collect U dead entries per step for the eviction to wade
                 // through (the general path appends; the order of the valid entries -- all eviction sees -- is the same).
-                const long long pos = (tail - U + u) % c.Lcap;
-                c.stamp[s] = st;
+                const long long pos = ring_at(tailU_mod, u, c.Lcap);
+                c.line[s].stamp = st;
                 c.log_slot[pos] = static_cast<uint32_t>(s);
                 c.log_stamp[pos] = st;
                 c.hasgrad[s] = 1;
-                c.updates[s] = push ? 0 : upd;
+                c.line[s].updates = push ? 0 : upd;
                 if (push) {
-                    c.version[s] += upd;
+                    c.line[s].version += upd;
                     atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->perf[7]), 1ull);
                 }
             }
@@ -1189,15 +1359,15 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
         } else {
             const int j = item - U;
             const int s = uniform(c.evict_slots[j]);
-            const long long lk = static_cast<long long>(uniform(c.key[s])) - c.row_start;
+            const long long lk = static_cast<long long>(uniform(c.line[s].key)) - c.row_start;
             if (lk >= 0 && lk < c.store_rows) {
                 cache_row_add<VEC>(c.table + lk * c.width, c.grad + static_cast<long long>(s) * c.width, c.width, lane,
                                    false);
                 if (lane == 0)
-                    c.srv_ver[lk] += c.updates[s];
+                    c.srv_ver[lk] += c.line[s].updates;
             }
             if (lane == 0) {
-                c.state[s] = kFree;
+                c.line[s].state = kFree;
                 c.free_list[ftop + j] = s;
             }
         }
@@ -1211,16 +1381,16 @@ __device__ __forceinline__ void cache_update_cleanup_body(const CacheCtl *ctl, c
     const int lane = lane_id();
     for (int u = wave0; u < U; u += nwaves) {
         const int s = c.uslot[u];
-        const bool has_data = c.state[s] != kTransient;
+        const bool has_data = c.line[s].state != kTransient;
         const bool pushed = c.pushflag[u] != 0;
         bool zero;
         if (!with_push_keys) {
             zero = pushed && has_data;                    // cache.cc:171-177
             if (zero && lane == 0)
-                c.version[s] += c.updates[s];
+                c.line[s].version += c.line[s].updates;
         } else {
             if (lane == 0)
-                c.version[s] += c.updates[s];             // every touched line (cache.cc:308-310)
+                c.line[s].version += c.line[s].updates;             // every touched line (cache.cc:308-310)
             zero = pushed;
         }
         if (zero) {
@@ -1228,10 +1398,10 @@ __device__ __forceinline__ void cache_update_cleanup_body(const CacheCtl *ctl, c
             for (long long j = lane; j < c.width; j += kWave)
                 g[j] = 0.f;
             if (lane == 0)
-                c.updates[s] = 0;
+                c.line[s].updates = 0;
         }
         if (!has_data && lane == 0)
-            c.state[s] = kFree;  // its stack entry was never retired (free_top unchanged)
+            c.line[s].state = kFree;  // its stack entry was never retired (free_top unchanged)
     }
 }
 __global__ __launch_bounds__(256) void cache_update_cleanup_kernel(const CacheCtl *ctl, Cache c,
@@ -1246,7 +1416,7 @@ __device__ __forceinline__ void cache_update_commit_body(CacheCtl *ctl, const Ca
     const long long ftop = ctl->free_top;
     for (long long j = threadIdx.x; j < En; j += 1024) {
         const int s = c.evict_slots[j];
-        c.state[s] = kFree;
+        c.line[s].state = kFree;
         c.free_list[ftop + j] = s;
     }
     // number of pushed lines of the batch
@@ -1301,12 +1471,12 @@ __global__ __launch_bounds__(256) void cache_init_kernel(Cache c) {
         c.slot_of[i] = -1;
     for (long long i = tid; i < c.S; i += stride) {
         c.free_list[i] = static_cast<int32_t>(c.S - 1 - i);  // slot 0 is handed out first
-        c.state[i] = kFree;
-        c.updates[i] = 0;
-        c.freq[i] = 0;
+        c.line[i].state = kFree;
+        c.line[i].updates = 0;
+        c.line[i].freq = 0;
         c.hasgrad[i] = 0;
-        c.version[i] = -1;
-        c.stamp[i] = 0;
+        c.line[i].version = -1;
+        c.line[i].stamp = 0;
     }
     if (tid == 0) {
         memset(c.ctl, 0, sizeof(CacheCtl));
@@ -1322,14 +1492,14 @@ __global__ __launch_bounds__(256) void cache_snapshot_kernel(Cache c, long long 
                                                              int32_t *slots,
                                                              unsigned long long *count) {
     for (long long s = blockIdx.x * 256ll + threadIdx.x; s < c.S; s += gridDim.x * 256ll) {
-        if (c.state[s] != kResident && c.state[s] != kStored)
+        if (c.line[s].state != kResident && c.line[s].state != kStored)
             continue;
         const unsigned long long i = atomicAdd(count, 1ull);
         if (static_cast<long long>(i) < cap) {
-            keys[i] = c.key[s];
-            version[i] = c.version[s];
-            updates[i] = c.updates[s];
-            stamp[i] = c.stamp[s];
+            keys[i] = c.line[s].key;
+            version[i] = c.line[s].version;
+            updates[i] = c.line[s].updates;
+            stamp[i] = c.line[s].stamp;
             slots[i] = static_cast<int32_t>(s);
         }
     }
@@ -1340,10 +1510,10 @@ __global__ __launch_bounds__(256) void cache_set_line_kernel(Cache c, long long 
     if (key < 0 || key >= c.length)
         return;
     const int s = c.slot_of[key];
-    if (s < 0 || (c.state[s] != kResident && c.state[s] != kStored))
+    if (s < 0 || (c.line[s].state != kResident && c.line[s].state != kStored))
         return;
     if (threadIdx.x == 0)
-        c.version[s] = version;
+        c.line[s].version = version;
     for (long long j = threadIdx.x; j < c.width; j += 256)
         c.data[static_cast<long long>(s) * c.width + j] = data[j];
 }
@@ -1407,13 +1577,8 @@ extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
     } while (0)
     CACHE_ALLOC(ctl, 1);
     CACHE_ALLOC(slot_of, length);
-    CACHE_ALLOC(key, c.S);
-    CACHE_ALLOC(version, c.S);
-    CACHE_ALLOC(updates, c.S);
-    CACHE_ALLOC(freq, c.S);
+    CACHE_ALLOC(line, c.S);
     CACHE_ALLOC(hasgrad, c.S);
-    CACHE_ALLOC(state, c.S);
-    CACHE_ALLOC(stamp, c.S);
     CACHE_ALLOC(data, c.S * width);
     CACHE_ALLOC(grad, c.S * width);
     CACHE_ALLOC(free_list, c.S);
@@ -1514,7 +1679,8 @@ static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hi
             return rc;
         PlanPtrs p = plan_layout(c.plan_ws, n);
         const HeadProbe hp{c.slot_of, (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag,
-                           want_pull ? c.data_row : nullptr, c.version, c.srv_ver,
+                           want_pull ? c.data_row : nullptr, &c.line[0].version,
+                           static_cast<int>(sizeof(LineMeta) / sizeof(long long)), c.srv_ver,
                            (long long)c.row_start, (long long)c.store_rows, (long long)c.pull_bound};
         hipLaunchKernelGGL(cache_finish_probe_kernel, dim3(finish_blocks((int)n)), dim3(1024), 0, s, p.sorted,
                            p.perm, (int)n, p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, hp);
@@ -1539,7 +1705,7 @@ __global__ __launch_bounds__(256) void cache_export_req_kernel(Cache c, const Pl
         if (u < U) {
             const int s = c.uslot[u];
             c.req_keys[u] = uniq[u];
-            c.req_ver[u] = s >= 0 ? c.version[s] : -1;
+            c.req_ver[u] = s >= 0 ? c.line[s].version : -1;
         } else {
             c.req_keys[u] = kNoPush;
             c.req_ver[u] = 0;
@@ -1931,6 +2097,20 @@ extern "C" int ha_cache_perf(ha_cache *h, int64_t *out_host, ha_stream_t stream)
 }
 
 // out[8]: {size, evict_n, free_top, log_head, log_tail, clock, S, Lcap}
+// out[16]: the 100 MHz clock at the phase boundaries of the last lookup's bookkeeping (tools/cache_phases.py):
+// [0..4] cache_lookup_book_kernel: start, probe / U, miss scan, slot assignment + touch, commit + pull count;
+// [8..12] workgroup 0 of cache_lookup_rows_kernel: start, insert of the misses, eviction, -, report;
+// [13..15] the eviction walk: rounds, lines to evict, log entries consumed
+extern "C" int ha_cache_phase_times(ha_cache *h, uint64_t *out_host, ha_stream_t stream) {
+    HA_REQUIRE(h && out_host, "cache_phase_times: bad arguments");
+    CacheCtl ctl;
+    HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
+    HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    for (int i = 0; i < 16; ++i)
+        out_host[i] = ctl.ph[i];
+    return 0;
+}
+
 extern "C" int ha_cache_state(ha_cache *h, int64_t *out_host, ha_stream_t stream) {
     HA_REQUIRE(h && out_host, "cache_state: bad arguments");
     CacheCtl ctl;

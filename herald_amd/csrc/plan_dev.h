@@ -398,7 +398,8 @@ struct HeadProbe {
     int32_t *uslot;           // [u] slot or -1
     uint32_t *flag;           // [u] 1 = miss
     int32_t *pull;            // [u] pull decision, or nullptr (update flow)
-    const long long *version; // [slot]
+    const long long *version; // version of slot s at version[s * version_stride] (the cache keeps it inside a line record)
+    int version_stride;
     const long long *srv_ver; // [row - row_start]
     long long row_start, store_rows, pull_bound;
 };
@@ -411,7 +412,7 @@ __device__ __forceinline__ void head_probe(const HeadProbe &hp, int u, uint32_t 
     if (hp.pull) {
         const long long lk = static_cast<long long>(k) - hp.row_start;
         const bool inr = lk >= 0 && lk < hp.store_rows;
-        const long long v = s >= 0 ? hp.version[s] : -1;
+        const long long v = s >= 0 ? hp.version[static_cast<long long>(s) * hp.version_stride] : -1;
         const long long srv = hp.srv_ver[inr ? lk : 0];
         hp.pull[u] = (inr && (v == -1 || srv - v > hp.pull_bound)) ? 1 : 0;
     }

@@ -760,6 +760,9 @@ int ha_store_count_valid(const uint32_t *keys, int64_t m, int64_t rows, int64_t 
  * state out[8] = {size, pending evictions, free slots, log head, log tail, clock, slots, log cap}. */
 int ha_cache_perf(ha_cache *cache, int64_t *out_host, ha_stream_t stream);
 int ha_cache_state(ha_cache *cache, int64_t *out_host, ha_stream_t stream);
+/* Diagnostics: out_host[16] = the GPU's 100 MHz clock at the phase boundaries of the last lookup's bookkeeping
+ * ([0..4] the bookkeeping workgroup, [8..12] the insert / eviction workgroup beside the row copies). */
+int ha_cache_phase_times(ha_cache *cache, uint64_t *out_host, ha_stream_t stream);
 /* Resident lines, unordered, into device arrays of capacity cap; *count_dev (zeroed by the
  * caller) receives the number of resident lines; slots[] index the rows of ha_cache_data/grad. */
 int ha_cache_snapshot(ha_cache *cache, int64_t cap, uint32_t *keys,
