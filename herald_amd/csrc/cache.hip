@@ -504,9 +504,11 @@ __global__ __launch_bounds__(1024) void cache_scan_victim_kernel(CacheCtl *ctl, 
 }
 
 // batchedInsert of the misses (sorted order) + LRU eviction + log compaction.  Single workgroup.
+// lines_done: the bookkeeping kernel already wrote the new lines' records and slot_of (cache_lookup_book_kernel with
+// defer_evict == 2); only their log entries are left.
 __device__ __forceinline__ void cache_insert_evict_body(
     CacheCtl *ctl, const Cache &c, const uint32_t *uniq, const uint32_t *flag,
-    const uint32_t *rank, int do_insert) {
+    const uint32_t *rank, int do_insert, bool lines_done = false) {
     __shared__ uint32_t s_w[16];
     __shared__ long long s_head, s_need, s_clean, s_dirty;
     const int U = static_cast<int>(ctl->U);
@@ -570,10 +572,12 @@ __device__ __forceinline__ void cache_insert_evict_body(
                     continue;
                 }
                 const unsigned long long st = static_cast<unsigned long long>(clock + q);
-                c.slot_of[kk[i]] = s;
-                c.line[s].stamp = st;
-                c.line[s].freq = base_use;
-                c.line[s].state = kResident;
+                if (!lines_done) {
+                    c.slot_of[kk[i]] = s;
+                    c.line[s].stamp = st;
+                    c.line[s].freq = base_use;
+                    c.line[s].state = kResident;
+                }
                 const long long pos = ring_at(tail0_mod, q - v_new, c.Lcap);
                 c.log_slot[pos] = static_cast<uint32_t>(s);
                 c.log_stamp[pos] = st;
@@ -871,7 +875,17 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
                 c.line[sl].version = -1;
                 c.line[sl].updates = 0;
                 c.hasgrad[sl] = 0;
-                c.line[sl].state = static_cast<uint8_t>(kPending);
+                if (defer_evict == 2) {
+                    // the new line's side of batchedInsert as well (the same record; cache_insert_evict_body then only
+                    // appends the log entries): LRU with limit >= batch inserts every miss, stamp = clock after the
+                    // touches + its rank
+                    c.line[sl].stamp = static_cast<unsigned long long>(clock + U + rk[i]);
+                    c.line[sl].freq = 0;
+                    c.line[sl].state = kResident;
+                    c.slot_of[kk[i]] = sl;
+                } else {
+                    c.line[sl].state = static_cast<uint8_t>(kPending);
+                }
             }
         }
         __syncthreads();        // every thread has read the control block
@@ -886,7 +900,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
         if (defer_evict)
             return;
         __syncthreads();
-        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1);
+        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1, false);
         __syncthreads();
         if (tid == 0)
             cache_report_pull_body(ctl, c, n);
@@ -974,7 +988,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
             cache_scan_victim_body(ctl, c);
             __syncthreads();
         }
-        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1);
+        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1, evict_block == 2);
         __syncthreads();
         if (threadIdx.x == 0)
             cache_report_pull_body(ctl, c, n);
@@ -982,7 +996,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
         return;
     }
     const int lane = lane_id();
-    const long long p = (static_cast<long long>(blockIdx.x) - evict_block) * 16ll + (threadIdx.x >> 6);
+    const long long p = (static_cast<long long>(blockIdx.x) - (evict_block ? 1 : 0)) * 16ll + (threadIdx.x >> 6);
     if (p >= n)
         return;
     const int u = upos[p];
@@ -1693,6 +1707,19 @@ static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hi
     return ha_plan_build_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, static_cast<uint64_t>(c.length), s);
 }
 
+// How a lookup's victim scan / insert / eviction / report run: 0 = at the end of cache_lookup_book_kernel, 1 = as workgroup 0
+// of cache_lookup_rows_kernel, beside the row copies, 2 = the same with the new lines' records and slot_of entries already
+// written by the bookkeeping kernel (its register-resident path: probed plan of <= 8192 keys, LRU; every miss is inserted
+// when limit >= batch and the cache is not bypassed).
+static int cache_evict_mode(const ha_cache *h, int64_t n, int probed) {
+    const Cache &c = h->c;
+    if (!(h->fused_update & 2) || n <= 0)
+        return 0;
+    if (HA_CACHE_BOOK_FUSED && probed && c.policy == kLRU && !c.bypass && c.limit >= n && n <= 8 * 1024)
+        return 2;
+    return 1;
+}
+
 // ---- remote store: inbox / outbox ------------------------------------------------------------------------
 // request of a lookup: (key, cached version) of every unique key -- what the reference's client hands to
 // syncEmbedding (hetu_client.cc:6-23: keys + the lines' versions)
@@ -1795,11 +1822,11 @@ extern "C" int ha_cache_lookup_finish(ha_cache *h, int64_t n, float *dest, ha_st
     c.data_row = c.inbox_pull;   // the decisions the bookkeeping and the row kernel read
     hipStream_t s = as_stream(stream);
     PlanPtrs p = plan_layout(c.plan_ws, n);
-    const int evb = (h->fused_update & 2) && n > 0 ? 1 : 0;
+    const int evb = cache_evict_mode(h, n, 1);
     hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
                        (long long)n, c.bypass ? 1 : 0, 1, evb);
     if (n > 0) {
-        const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + evb;
+        const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + (evb ? 1 : 0);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0);
         if (vec_ok)
             hipLaunchKernelGGL(cache_lookup_rows_kernel<4>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos,
@@ -1843,17 +1870,17 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     Cache &c = h->c;
     hipStream_t s = as_stream(stream);
     int probed = 0;
-    const int evb = (h->fused_update & 2) && n > 0 ? 1 : 0;
     PlanPtrs p = plan_layout(c.plan_ws, n);
     if (cache_plan(h, keys, key_kind, n, s, 1, &probed))
         return -1;
+    const int evb = cache_evict_mode(h, n, probed);
     h->plan_n = n;
     h->same_fast = (h->fused_update & 1) && h->evict_empty && c.policy == kLRU && !c.bypass && c.limit >= n && n > 0;
     h->evict_empty = false;
     hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
                        (long long)n, c.bypass ? 1 : 0, probed, evb);
     if (n > 0) {
-        const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + evb;
+        const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + (evb ? 1 : 0);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0) &&
                             (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
         if (vec_ok)

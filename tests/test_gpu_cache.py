@@ -291,3 +291,14 @@ def test_update_of_the_looked_up_key_tensor_reuses_the_plan(dev):
     t = table.cpu().numpy()
     np.testing.assert_array_equal(t[:1000], table0[:1000])                  # untouched rows
     np.testing.assert_array_equal(t[1000:1000 + n], table0[1000:1000 + n] + 1.0)
+
+
+def test_phase_clock_of_the_last_lookup(dev):
+    """ha_cache_phase_times: the bookkeeping workgroup's stamps ascend, and the insert / eviction workgroup (beside the row
+    copies) starts after it."""
+    import ctypes
+    gpu, _ = _run_trace(dev, limit=100, rows=1500, width=8, n=64, steps=6, pull_bound=1, push_bound=1, seed=21, same=True)
+    ph = (ctypes.c_uint64 * 16)()
+    hcache.check(gpu._L.ha_cache_phase_times(gpu._h, ph, ctypes.c_void_p(gpu._stream().cuda_stream)), "phase_times")
+    assert 0 < ph[0] <= ph[1] <= ph[4] <= ph[8] <= ph[9] <= ph[10] <= ph[12]
+    assert ph[14] >= 0 and ph[13] <= 64
