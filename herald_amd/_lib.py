@@ -98,6 +98,7 @@ def _declare(L):
     L.ha_plan_bytes.restype = sz
     L.ha_plan_bytes.argtypes = [i64]
     L.ha_plan_view_of.argtypes = [vp, i64, c.POINTER(PlanView)]
+    L.ha_plan_radix_stamps.argtypes = [vp, i64, vp, vp]
     L.ha_pend_bytes.restype = sz
     L.ha_pend_bytes.argtypes = []
     L.ha_plan_handoff_timeout.restype = vp

@@ -104,12 +104,19 @@ constexpr int kScatterWaves = kScatterThreads / kWave;
 constexpr size_t kScatterLdsBytes =
     static_cast<size_t>(kScatterWaves) * kRadixBuckets * 2 + 3 * kRadixBuckets * 4 + kScatterWaves * 4;
 
-template <bool PRESCANNED, bool MSD = false>
+// FUSED (passes after the first, up to kRadixFusedBlocks tiles -- all of them resident at once): the pass is ONE launch.
+// The ranking leaves the tile's own digit histogram in LDS; the workgroup publishes it (device-coherent stores, then
+// its flag = `flag_value`), waits until every tile of the pass has done so, and sums the others' histograms with
+// device-coherent loads -- a barrier across the 26 workgroups of a 106,496-key pass in the middle of the launch instead
+// of a kernel boundary and a second read of the keys.  The flags are zeroed by the first pass's scatter (`flags_reset`),
+// pass k waits for the value k: no epoch survives a call, so the launches replay from a hipGraph unchanged.
+template <bool PRESCANNED, bool MSD = false, bool FUSED = false>
 __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ perm_in,
-    int n, int shift, int nblk, const uint32_t *__restrict__ hist,
+    int n, int shift, int nblk, const uint32_t *hist,
     uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out,
-    uint32_t *__restrict__ bucket_start = nullptr) {
+    uint32_t *__restrict__ bucket_start = nullptr, uint32_t *flags = nullptr, uint32_t flag_value = 0,
+    uint32_t *flags_reset = nullptr) {
     constexpr int kRows = kRadixTile / kScatterThreads;        // rows of 64 keys per wave
     constexpr int kPerThread = kRadixBuckets / kScatterThreads;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -118,8 +125,20 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
     uint32_t *s_tot = s_base + kRadixBuckets, *s_mine = s_tot + kRadixBuckets;
     uint32_t *s_scan = s_mine + kRadixBuckets;                             // [waves]
     const int lane = lane_id(), w = threadIdx.x >> 6;
+    // HA_RADIX_STAMPS=1 (tools/radix_phases.py): the last workgroup's clock at its phase boundaries, in the bucket-start
+    // scratch of the (unused here) bucket sort; slot 8 * pass + phase
+    unsigned long long *stamps = (!MSD && bucket_start != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+                                     ? reinterpret_cast<unsigned long long *>(bucket_start) + 8 * flag_value : nullptr;
+#define RADIX_STAMP(i)                                                  \
+    do {                                                                \
+        if (stamps)                                                     \
+            stamps[i] = __builtin_amdgcn_s_memrealtime();               \
+    } while (0)
+    RADIX_STAMP(0);
     for (int k = threadIdx.x; k < kScatterWaves * kRadixBuckets / 2; k += kScatterThreads)
         s_dyn[k] = 0;
+    if (flags_reset != nullptr && blockIdx.x == 0 && threadIdx.x < kRadixFusedBlocks)
+        flags_reset[threadIdx.x] = 0;      // the fused passes behind this launch count from here
     __syncthreads();
 
     const int wbase = blockIdx.x * kRadixTile + w * (kRows * 64);
@@ -135,6 +154,7 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
         key[r] = keys_in[j];
         val[r] = perm_in ? perm_in[j] : j;
     }
+    RADIX_STAMP(1);
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
         const int j = wbase + r * 64 + lane;
@@ -160,6 +180,34 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    RADIX_STAMP(2);
+    if (FUSED) {
+        // this tile's histogram, then the flag.  A count is at most kRadixTile = 4096: two digits per word (thread t the
+        // digits 2t, 2t + 1 -- the ones it owns below), half the bytes every workgroup pulls through its one compute
+        // unit when it sums the tiles (26 x 8 KB as 32-bit counts: 3.6 us of an 11.9 us pass)
+        static_assert(kPerThread == 2 && kRadixTile <= 0xFFFF, "two 16-bit counts per thread and word");
+        uint32_t *mine_h = const_cast<uint32_t *>(hist) + static_cast<size_t>(blockIdx.x) * kRadixBuckets;
+        {
+            uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+            for (int k = 0; k < kScatterWaves; ++k) {
+                const uint32_t pair = *reinterpret_cast<const uint32_t *>(s_cnt + k * kRadixBuckets + 2 * threadIdx.x);
+                c0 += pair & 0xFFFFu;
+                c1 += pair >> 16;
+            }
+            __hip_atomic_store(mine_h + threadIdx.x, c0 | (c1 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0);      // the stores have left for memory before the flag follows them
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(flags + blockIdx.x, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (static_cast<int>(threadIdx.x) < nblk) {
+            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flag_value)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    }
+    RADIX_STAMP(3);
     // digits d = threadIdx.x * kPerThread ..: global base of the digit in this tile, then the exclusive
     // prefix over the waves
     {
@@ -176,17 +224,41 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
 #pragma unroll
             for (int q = 0; q < kPerThread; ++q)
                 tot[q] = mine[q] = 0;
-            for (int k0 = 0; k0 < nblk; k0 += 8) {   // eight tiles per trip: 16 independent loads in flight
-                uint32_t v[8][kPerThread];
+            if (FUSED) {
+                // packed counts, already with the thread that owns the two digits: one batch of device-coherent loads
+                constexpr int kPk = 32;
+                for (int k0 = 0; k0 < nblk; k0 += kPk) {
+                    uint32_t v[kPk];
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
+                    for (int kk = 0; kk < kPk; ++kk)
+                        v[kk] = __hip_atomic_load(hist + static_cast<size_t>(min(k0 + kk, nblk - 1)) * kRadixBuckets + threadIdx.x,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int kk = 0; kk < kPk; ++kk) {
+                        const int k = k0 + kk;
+                        const uint32_t lo = k < nblk ? v[kk] & 0xFFFFu : 0u, hi = k < nblk ? v[kk] >> 16 : 0u;
+                        tot[0] += lo;
+                        tot[1] += hi;
+                        mine[0] += k < static_cast<int>(blockIdx.x) ? lo : 0u;
+                        mine[1] += k < static_cast<int>(blockIdx.x) ? hi : 0u;
+                    }
+                }
+            }
+            constexpr int kTrip = FUSED ? 1 : 8;               // tiles per trip: 2 x kTrip independent loads in flight (the fused
+                                                     // pass reads past the L2: fewer, longer trips)
+            for (int k0 = 0; !FUSED && k0 < nblk; k0 += kTrip) {
+                uint32_t v[kTrip][kPerThread];
+#pragma unroll
+                for (int kk = 0; kk < kTrip; ++kk) {
                     const uint32_t *h = hist + static_cast<size_t>(min(k0 + kk, nblk - 1)) * kRadixBuckets + threadIdx.x;
 #pragma unroll
                     for (int q = 0; q < kPerThread; ++q)
-                        v[kk][q] = h[q * kScatterThreads];
+                        v[kk][q] = FUSED ? __hip_atomic_load(h + q * kScatterThreads, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)
+                                         : h[q * kScatterThreads];
                 }
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
+                for (int kk = 0; kk < kTrip; ++kk) {
                     const int k = k0 + kk;
 #pragma unroll
                     for (int q = 0; q < kPerThread; ++q) {
@@ -195,16 +267,21 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
                     }
                 }
             }
+            if (!FUSED) {
 #pragma unroll
-            for (int q = 0; q < kPerThread; ++q) {
-                s_tot[q * kScatterThreads + threadIdx.x] = tot[q];
-                s_mine[q * kScatterThreads + threadIdx.x] = mine[q];
+                for (int q = 0; q < kPerThread; ++q) {
+                    s_tot[q * kScatterThreads + threadIdx.x] = tot[q];
+                    s_mine[q * kScatterThreads + threadIdx.x] = mine[q];
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            RADIX_STAMP(4);
+            if (!FUSED) {
 #pragma unroll
-            for (int q = 0; q < kPerThread; ++q) {
-                tot[q] = s_tot[d0 + q];
-                mine[q] = s_mine[d0 + q];
+                for (int q = 0; q < kPerThread; ++q) {
+                    tot[q] = s_tot[d0 + q];
+                    mine[q] = s_mine[d0 + q];
+                }
             }
             uint32_t local = 0;
 #pragma unroll
@@ -246,6 +323,7 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
         }
     }
     __syncthreads();
+    RADIX_STAMP(5);
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
         const int j = wbase + r * 64 + lane;
@@ -256,6 +334,11 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
             perm_out[pos] = val[r];
         }
     }
+    if (stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        stamps[6] = __builtin_amdgcn_s_memrealtime();
+    }
+#undef RADIX_STAMP
 }
 
 // ===========================================================================
@@ -539,8 +622,30 @@ static int scatter_allow_lds() {
         HA_ALLOW_LDS((radix_scatter_kernel<false, false>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<true, false>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<false, true>), kScatterLdsBytes);
+        HA_ALLOW_LDS((radix_scatter_kernel<false, false, true>), kScatterLdsBytes);
     }
     return 0;
+}
+
+// Diagnostics (HA_RADIX_STAMPS=1 in the environment): out_host[24] = the 100 MHz clock at the phase boundaries of the last
+// radix sort's scatter launches, eight slots per pass: start, keys loaded, ranked, histograms exchanged (fused passes),
+// sums read, digit bases ready, scattered.
+extern "C" int ha_plan_radix_stamps(void *ws, int64_t n, uint64_t *out_host, ha_stream_t stream) {
+    HA_REQUIRE(ws && out_host && n > 0, "plan_radix_stamps: bad arguments");
+    ha::PlanPtrs p = ha::plan_layout(ws, n);
+    HA_CHECK_HIP(hipMemcpyAsync(out_host, p.bucket_start, 24 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                ha::as_stream(stream)));
+    HA_CHECK_HIP(hipStreamSynchronize(ha::as_stream(stream)));
+    return 0;
+}
+
+// HA_RADIX_FUSED=0: every pass after the first as two launches (histogram, scatter) again
+static bool radix_pass_fused() {
+    static const bool on = [] {
+        const char *e = getenv("HA_RADIX_FUSED");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
 }
 
 int ha::plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipStream_t stream) {
@@ -564,14 +669,23 @@ int ha::plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipSt
         uint32_t *kout = toB ? p.sorted : p.keys_alt;
         int32_t *vout = toB ? p.perm : p.perm_alt;
         const int shift = pass * kRadixBits;
-        if (pass > 0) {
+        const bool one_launch = radix_pass_fused() && nblk <= kRadixFusedBlocks;
+        static const bool stamp_on = getenv("HA_RADIX_STAMPS") && atoi(getenv("HA_RADIX_STAMPS")) != 0;
+        uint32_t *dbg = stamp_on ? p.bucket_start : nullptr;
+        if (pass > 0 && !one_launch) {
             hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(1024), 0, stream,
                                kin, ni, shift, nblk, p.hist, nblk <= kRadixFusedBlocks ? 1 : 0);
             HA_LAUNCH_CHECK();
         }
-        if (nblk <= kRadixFusedBlocks) {
+        if (pass > 0 && one_launch) {
+            hipLaunchKernelGGL((radix_scatter_kernel<false, false, true>), dim3(nblk), dim3(kScatterThreads),
+                               kScatterLdsBytes, stream, kin, vin, ni, shift, nblk, p.hist, kout, vout,
+                               dbg, p.pass_flags, static_cast<uint32_t>(pass), static_cast<uint32_t *>(nullptr));
+        } else if (nblk <= kRadixFusedBlocks) {
             hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(kScatterThreads), kScatterLdsBytes,
-                               stream, kin, vin, ni, shift, nblk, p.hist, kout, vout);
+                               stream, kin, vin, ni, shift, nblk, p.hist, kout, vout,
+                               dbg, static_cast<uint32_t *>(nullptr), 0u,
+                               one_launch ? p.pass_flags : static_cast<uint32_t *>(nullptr));
         } else {
             hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream,
                                p.hist, kRadixBuckets * nblk, static_cast<uint32_t *>(nullptr));

@@ -240,6 +240,9 @@ size_t ha_plan_bytes(int64_t n);
 /* Fill `view` with the addresses of the sub-arrays of workspace `ws` (host-side
  * pointer arithmetic only; no device access). */
 int ha_plan_view_of(void *ws, int64_t n, ha_plan_view *view);
+/* Diagnostics: with HA_RADIX_STAMPS=1 in the environment the scatter launches of the radix sort (n > 36,864) stamp the GPU's
+ * 100 MHz clock at their phase boundaries; out_host[24], eight slots per pass (tools/radix_phases.py). */
+int ha_plan_radix_stamps(void *ws, int64_t n, uint64_t *out_host, ha_stream_t stream);
 /* Build the plan from float32 ids / uint64 keys. */
 int ha_plan_build_f32ids(const float *ids, int64_t n, void *ws,
                          ha_stream_t stream);
