@@ -102,6 +102,42 @@ def test_plan_radix_path(dev, n):
     _check_plan(ids, dev)
 
 
+def test_plan_radix_path_replays_from_a_graph(dev):
+    """The one-launch radix passes exchange their histograms behind flags that the first pass's scatter zeroes: nothing
+    of a call survives it, so a captured build replays on new ids (and on the same ones) with the right result."""
+    from herald_amd import ops
+    n = 106496
+    rng = np.random.default_rng(5)
+    buf = torch.zeros(n, dtype=torch.float32, device=dev)
+    plan = ops.IndexPlan(n, dev)
+    side = torch.cuda.Stream(device=dev)
+    first = synth.as_f32_ids(rng.integers(0, synth.CRITEO_ROWS, size=n))
+    buf.copy_(torch.from_numpy(first).to(dev))
+    with torch.cuda.stream(side):
+        plan.build(buf, stream=side, key_limit=synth.CRITEO_ROWS)       # first use: eager
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        plan.build(buf, stream=side, key_limit=synth.CRITEO_ROWS)
+    for rep in range(4):
+        ids = synth.as_f32_ids(rng.integers(0, 1000 if rep == 2 else synth.CRITEO_ROWS, size=n))
+        if rep == 3:
+            ids = first
+        buf.copy_(torch.from_numpy(ids).to(dev))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        keys = cpu.ids_to_keys(ids)
+        uniq, inv, cnt = cpu.unique(keys)
+        plan._view = None
+        u = plan.n_unique()
+        assert u == uniq.size
+        np.testing.assert_array_equal(_u32(plan.uniq(u)), uniq)
+        np.testing.assert_array_equal(plan.inverse().cpu().numpy().astype(np.int64), inv)
+        np.testing.assert_array_equal(plan.counts(u).cpu().numpy().astype(np.int64), cnt)
+        np.testing.assert_array_equal(plan.perm().cpu().numpy(), np.argsort(keys, kind="stable"))
+
+
 def test_plan_all_equal_and_all_distinct(dev):
     _check_plan(np.full(6656, 12345.0, dtype=np.float32), dev)
     _check_plan(np.arange(6656, dtype=np.float32)[::-1].copy(), dev)
