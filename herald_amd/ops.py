@@ -623,6 +623,82 @@ def qstep_max_ids():
     return int(_lib.load().ha_qstep_max_ids())
 
 
+class SortAheadPipeline:
+    """Training steps on batches too large for the work-queue step (more than ha_qstep_max_ids ids: BASELINE configs[2] /
+    [3] hand a GPU 106,496 / 26,624 ids per step): per step one gather launch and one apply + finish launch on the
+    caller's stream, with the index plans SORTED a block of batches ahead on a side stream.  The sort depends on the ids
+    only (the data loader has them a block ahead, as for QueueStepPipeline), so the two streams meet once per BLOCK -- one
+    event each way -- instead of twice per step: a cross-stream dependency costs 10-20 us on this part, as much as the
+    sort of a 26,624-id batch it is meant to hide.
+
+        pipe = SortAheadPipeline(table, max_ids, lr, block=8)
+        pipe.prepare_block(ids_of_steps_0_to_7)              # side stream
+        for k in range(8):                                   # caller's stream
+            if k == 0: pipe.prepare_block(ids_of_steps_8_to_15)
+            out = pipe.lookup(k, ids[k]);  ...;  pipe.apply(k, grads)
+
+    Results are those of embedding_lookup + sgd_apply_finish step by step (bit-exact; tolerance mode as set)."""
+
+    NBLOCKS = 3          # blocks of plans in flight: being applied, sorted and waiting, being sorted
+
+    def __init__(self, table, max_ids, lr, block=8, key_limit=None, device=None):
+        _require(table, torch.float32, "table")
+        self.table, self.lr, self.block = table, float(lr), int(block)
+        self.device = table.device if device is None else torch.device(device)
+        self.key_limit = int(table.shape[0]) if key_limit is None else int(key_limit)
+        self.plans = [[IndexPlan(max_ids, self.device) for _ in range(self.block)] for _ in range(self.NBLOCKS)]
+        self.side = torch.cuda.Stream(device=self.device)      # (a high-priority side stream: no difference, 47.4 / 47.2 us)
+        self._sorted = [torch.cuda.Event() for _ in range(self.NBLOCKS)]      # side -> main: the block's plans are sorted
+        self._freed = [None] * self.NBLOCKS                                   # main -> side: the block's plans were applied
+        self._first = [0] * self.NBLOCKS       # number of the first step of the block each slot holds
+        self._count = [0] * self.NBLOCKS
+        self._next_block = 0
+        self._waited = -1
+
+    def prepare_block(self, ids_list):
+        """Sort the plans of the next `len(ids_list)` (<= block) steps on the side stream."""
+        if not 0 < len(ids_list) <= self.block:
+            raise ValueError("a block holds 1..%d batches" % self.block)
+        b = self._next_block
+        slot = b % self.NBLOCKS
+        # the side stream follows the caller's stream up to here (one event per block; also what makes the pair of streams
+        # capturable into one hipGraph): the sorts run beside the steps enqueued after this call
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            if self._freed[slot] is not None:
+                self.side.wait_event(self._freed[slot])      # its plans' previous users have finished
+            for i, ids in enumerate(ids_list):
+                self.plans[slot][i].sort(ids, stream=self.side, key_limit=self.key_limit)
+            self._sorted[slot].record(self.side)
+        self._first[slot] = (self._first[(b - 1) % self.NBLOCKS] + self._count[(b - 1) % self.NBLOCKS]) if b else 0
+        self._count[slot] = len(ids_list)
+        self._next_block = b + 1
+        return b
+
+    def _plan(self, k, stream):
+        for b in range(max(self._next_block - self.NBLOCKS, 0), self._next_block):
+            slot = b % self.NBLOCKS
+            if self._first[slot] <= k < self._first[slot] + self._count[slot]:
+                if b > self._waited:           # once per block
+                    (stream or torch.cuda.current_stream(self.device)).wait_event(self._sorted[slot])
+                    self._waited = b
+                return slot, k - self._first[slot]
+        raise ValueError("step %d is not in a prepared block" % k)
+
+    def lookup(self, k, ids, out=None, stream=None):
+        self._plan(k, stream)                  # the block's sorts are ordered before anything of the step
+        return embedding_lookup(self.table, ids, out=out, stream=stream)
+
+    def apply(self, k, grads, stream=None):
+        slot, i = self._plan(k, stream)
+        sgd_apply_finish(self.table, self.plans[slot][i], grads, self.lr, stream=stream)
+        if i == self._count[slot] - 1:         # last step of the block: its plans may be overwritten
+            ev = torch.cuda.Event()
+            ev.record(stream or torch.cuda.current_stream(self.device))
+            self._freed[slot] = ev
+        return self.plans[slot][i]
+
+
 class QueueStepPipeline:
     """Drives ha_qapply / ha_qplan_batch_* / ha_qqueue_batch (include/herald_amd.h, csrc/qstep.hip) over a stream of id
     batches.  Every training step is ONE launch on the caller's stream: it applies the sparse SGD of batch c

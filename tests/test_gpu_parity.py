@@ -138,6 +138,38 @@ def test_plan_radix_path_replays_from_a_graph(dev):
         np.testing.assert_array_equal(plan.perm().cpu().numpy(), np.argsort(keys, kind="stable"))
 
 
+@pytest.mark.parametrize("n,block", [(40000, 3), (9000, 2)])
+def test_sort_ahead_pipeline_equals_the_step_by_step_calls(dev, n, block):
+    """ops.SortAheadPipeline (batches beyond the work-queue step's 7,168 ids): plans sorted a block ahead on a side stream,
+    gather + apply-and-finish per step -- every output row and the table after every step as the CPU sequence has them."""
+    rng = np.random.default_rng(n)
+    rows, width, steps = 50000, 16, 7
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    ids = [synth.as_f32_ids(rng.integers(0, rows if k % 2 else 300, size=n)) for k in range(steps)]
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
+    t = _dev(table0, dev)
+    pipe = ops.SortAheadPipeline(t, n, 0.25, block=block)
+    d_ids = [_dev(x, dev) for x in ids]
+    d_grads = [_dev(g, dev) for g in grads]
+    want = table0.copy()
+    starts = list(range(0, steps, block))
+    pipe.prepare_block(d_ids[0:block])
+    for k in range(steps):
+        if k % block == 0 and k + block < steps:
+            pipe.prepare_block(d_ids[k + block:k + 2 * block])          # the next block, beside this one's steps
+        out = pipe.lookup(k, d_ids[k])
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), want[ids[k].astype(np.int64)], err_msg="lookup of step %d" % k)
+        plan = pipe.apply(k, d_grads[k])
+        want = cpu.sgd_sparse_update(want, ids[k], grads[k], 0.25)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(t.cpu().numpy(), want, err_msg="table after step %d" % k)
+        assert plan.n_unique() == np.unique(ids[k]).size
+    assert starts[-1] < steps
+    with pytest.raises(ValueError):
+        pipe.lookup(steps + 5, d_ids[0])
+
+
 def test_plan_all_equal_and_all_distinct(dev):
     _check_plan(np.full(6656, 12345.0, dtype=np.float32), dev)
     _check_plan(np.arange(6656, dtype=np.float32)[::-1].copy(), dev)

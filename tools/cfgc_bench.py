@@ -92,6 +92,53 @@ try:
 except Exception as e:   # noqa
     print("two-stream schedule failed:", e)
 
+# ---- the product schedule for these shapes: ops.SortAheadPipeline (plans sorted a BLOCK ahead on the side stream, the
+# streams meet once per block) ----------------------------------------------------------------------------------------
+def sort_ahead(block, graph):
+    """48 steps = 48 / block blocks (a multiple of the pipeline's three plan slots and of the period of the 16 id buffers, so
+    that the captured sequence ends in the state it starts from and replays are exact)."""
+    pipe = ops.SortAheadPipeline(table, n, 1e-6, block=block, key_limit=rows)
+    nblk = 48 // block
+    blocks = [[ids[(b * block + i) % NB] for i in range(block)] for b in range(nblk + 1)]
+    def body():
+        k = 0
+        for b in range(nblk):
+            pipe.prepare_block(blocks[b + 1])
+            for i in range(block):
+                pipe.lookup(b * block + i + body.base, blocks[b][i], out=out, stream=main_s)
+                pipe.apply(b * block + i + body.base, grads, stream=main_s)
+        main_s.wait_stream(pipe.side)
+        body.base += nblk * block
+    body.base = 0
+    a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(main_s):
+        pipe.prepare_block(blocks[0])
+        pipe._plan(0, main_s)          # the wait for the prologue's block: outside the capture
+        main_s.wait_stream(pipe.side)
+        if graph:
+            main_s.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=main_s):
+                body()
+            run = g.replay
+        else:
+            run = body
+        run(); main_s.synchronize()
+        a.record(main_s)
+        for _ in range(4):
+            run()
+        b_.record(main_s)
+        main_s.synchronize()
+    return a.elapsed_time(b_) * 1e3 / (4 * nblk * block)
+for blk in (4, 8, 16):
+    for graph in (True, False):
+        try:
+            t = sort_ahead(blk, graph)
+            print("SortAheadPipeline, blocks of %2d, %s %.1f us  -> %.1f M rows/s" % (
+                blk, "one hipGraph of 48 steps" if graph else "eager launches        ", t, n / t))
+        except Exception as e:   # noqa
+            print("SortAheadPipeline (block %d, graph %s) failed: %s" % (blk, graph, e))
+
 # the same schedule launched eagerly (are the graph's parallel branches really concurrent?)
 def eager_two_streams(steps=200):
     evs = [torch.cuda.Event(), torch.cuda.Event()]
