@@ -272,7 +272,7 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
             "evicted_lines_per_step": evict, "cache_full": bool(pulls and pulls[-1]["is_full"]),
             "prefilled_keys": prefilled,
             "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
-                    "(6 launches per pair, replayed from hipGraphs of 16 pairs), cache filled to its limit before "
+                    "(5 launches per pair, replayed from hipGraphs of 16 pairs), cache filled to its limit before "
                     "the timed pairs; not part of `value`"}
 
 

@@ -71,6 +71,7 @@ struct CacheCtl {
     long long perf[8];     // [7]: pushed lines of a cache_update_same_post_kernel update, to be added to [4]
     long long out_n;       // remote mode: outbox entries of the last update (U + E), -1 on overflow
     unsigned long long ph[16];   // ha_cache_phase_times: 100 MHz clock at the phase boundaries of the last lookup's bookkeeping
+    unsigned long long fb_xw[64];     // cache_finish_book_kernel, per finish chunk: valid << 63 | heads << 32 | pulls << 16 | misses
     long long snap[4];     // {clock, log_tail, free_top, evict_n} as the last lookup left them (cache_update_same_post_kernel)
 };
 
@@ -763,6 +764,8 @@ __device__ __forceinline__ void cache_report_pull_body(CacheCtl *ctl, const Cach
     ctl->perf[6] = ctl->size == c.limit;
     ctl->perf[7] = 0;
     ctl->pulled = 0;
+    for (int i = 0; i < 64; ++i)          // cache_finish_book_kernel's exchange words: every lookup starts from zero
+        ctl->fb_xw[i] = 0;
     ctl->snap[0] = ctl->clock;
     ctl->snap[1] = ctl->log_tail;
     ctl->snap[2] = ctl->free_top;
@@ -781,6 +784,130 @@ __global__ __launch_bounds__(1024) void cache_finish_probe_kernel(
     HeadProbe hp) {
     __shared__ uint32_t s_w[kFinishLdsWords];
     finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, blockIdx.x, s_w, nullptr, &hp);
+}
+
+// ---- LRU lookup, local store, not bypassed: the finish of the index plan IS the bookkeeping ------------------------------
+// cache_finish_probe_kernel + cache_lookup_book_kernel in one launch.  The finish's workgroups (one per 1024 sorted
+// positions, at most 36: all resident) hold, per run head, the unique index and the key; they probe the direct map and take
+// the pull decision as before, count their misses and pulls, and EXCHANGE the counts: every workgroup publishes one word
+// (valid | heads | pulls | misses, a device-coherent store) and waits for the words of all the others -- the same
+// barrier-inside-a-launch the one-launch radix passes use (plan.hip).  With the misses of the earlier chunks known, the
+// rank of every miss is known, and each workgroup does the slot assignment / LRU touch / new-line records of its OWN keys
+// (cache_assign_body's work, spread over the finish's compute units instead of one); the last chunk's workgroup knows the
+// totals and commits the control block.  What is left of the bookkeeping kernel -- nothing: victim scan, insert, eviction
+// and report already run beside the row copies.  The report at the end of every lookup zeroes the exchange words, so the
+// words of one lookup never satisfy the next (and a captured lookup replays).
+__global__ __launch_bounds__(1024) void cache_finish_book_kernel(
+    const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm, int n,
+    PlanHeader *__restrict__ hdr, uint32_t *__restrict__ uniq, int32_t *__restrict__ seg,
+    int32_t *__restrict__ counts, int32_t *__restrict__ inverse, int32_t *__restrict__ upos, Cache c, int pre_insert) {
+    __shared__ uint32_t s_w[kFinishLdsWords];
+    __shared__ uint32_t s_sc[16];
+    __shared__ uint32_t s_tot[4];       // misses / pulls of the chunks before this one, of all chunks; heads of all chunks
+    CacheCtl *ctl = c.ctl;
+    const int b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
+    // the control block as the previous call left it (committed below, behind the exchange: by then every workgroup has read it)
+    const long long clock = ctl->clock, tail = ctl->log_tail, ftop = ctl->free_top;
+    if (b == nb - 1)
+        CACHE_PH(0);
+    HeadOut ho{false, 0, 0u};
+    finish_block_body(sorted, perm, n, hdr, uniq, seg, counts, inverse, upos, b, s_w, nullptr, nullptr, nullptr, 0, nullptr, 0, &ho);
+    // probe + syncEmbedding's pull decision (head_probe, plan_dev.h), branch-free
+    const uint32_t k = ho.key;
+    const bool known = ho.head && k < static_cast<unsigned long long>(c.length);
+    const int sv = c.slot_of[known ? k : 0u];
+    const int s = known ? sv : -1;
+    const long long lk = static_cast<long long>(k) - c.row_start;
+    const bool inr = ho.head && lk >= 0 && lk < c.store_rows;
+    const long long ver = c.line[s >= 0 ? s : 0].version;
+    const long long srv = c.srv_ver[inr ? lk : 0];
+    const bool miss = ho.head && s < 0;
+    const bool pull = inr && (s < 0 || ver == -1 || srv - ver > c.pull_bound);
+    unsigned long long tot4;
+    __shared__ unsigned long long s_w64[16];
+    const unsigned long long ex4 = block_scan_1024_x4((miss ? 1ull : 0ull) | (pull ? 1ull << 16 : 0ull) | (ho.head ? 1ull << 32 : 0ull),
+                                                      s_w64, &tot4);
+    // the exchange word: valid | heads | pulls | misses of this chunk (the report at the end of every lookup zeroes the words)
+    if (tid == 0)
+        __hip_atomic_store(&ctl->fb_xw[b], (1ull << 63) | tot4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        uint32_t mb = 0, ma = 0, pa = 0, ha = 0;
+        for (int c0 = 0; c0 < nb; c0 += 64) {
+            const int cb = c0 + tid;
+            unsigned long long w = 0;
+            if (cb < nb) {
+                do {
+                    w = __hip_atomic_load(&ctl->fb_xw[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while (!(w >> 63));
+            }
+            const uint32_t m = static_cast<uint32_t>(w & 0xFFFFull);
+            mb += cb < b ? m : 0u;
+            ma += m;
+            pa += static_cast<uint32_t>((w >> 16) & 0xFFFFull);
+            ha += static_cast<uint32_t>((w >> 32) & 0xFFFFull);
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            mb += __shfl_xor(mb, o, 64);
+            ma += __shfl_xor(ma, o, 64);
+            pa += __shfl_xor(pa, o, 64);
+            ha += __shfl_xor(ha, o, 64);
+        }
+        if (tid == 0) {
+            s_tot[0] = mb;
+            s_tot[1] = ma;
+            s_tot[2] = pa;
+            s_tot[3] = ha;
+        }
+    }
+    __syncthreads();
+    if (b == nb - 1)
+        CACHE_PH(1);
+    const uint32_t rank = s_tot[0] + static_cast<uint32_t>(ex4 & 0xFFFFull);
+    const long long U = s_tot[3], M = s_tot[1];
+    const long long fidx = ftop - 1 - static_cast<long long>(rank);
+    // running out of slots is a sizing error reported by the host wrapper (nmax)
+    const int fs = (miss && fidx >= 0) ? c.free_list[fidx] : 0;
+    if (ho.head) {
+        const int u = ho.ui;
+        c.flag[u] = miss ? 1u : 0u;
+        c.rank[u] = rank;
+        c.data_row[u] = pull ? 1 : 0;
+        if (!miss) {                    // lru_cache.cc:27-39: move to the list front
+            const unsigned long long st = static_cast<unsigned long long>(clock + u);
+            const long long pos = ring_at(tail % c.Lcap, u - static_cast<long long>(rank), c.Lcap);
+            c.uslot[u] = s;
+            c.line[s].stamp = st;
+            c.log_slot[pos] = static_cast<uint32_t>(s);
+            c.log_stamp[pos] = st;
+        } else {
+            c.uslot[u] = fs;
+            c.line[fs].key = k;
+            c.line[fs].version = -1;
+            c.line[fs].updates = 0;
+            c.hasgrad[fs] = 0;
+            if (pre_insert) {
+                // the new line's side of batchedInsert as well (cache_insert_evict_body then only appends the log
+                // entries): LRU with limit >= batch inserts every miss, stamp = clock after the touches + its rank
+                c.line[fs].stamp = static_cast<unsigned long long>(clock + U + rank);
+                c.line[fs].freq = 0;
+                c.line[fs].state = kResident;
+                c.slot_of[k] = fs;
+            } else {
+                c.line[fs].state = static_cast<uint8_t>(kPending);
+            }
+        }
+    }
+    if (b == nb - 1) {      // commit: cache_scan_body's totals, cache_commit_touch_body, the pull count
+        if (tid == 0) {
+            ctl->U = U;
+            ctl->M = M;
+            ctl->nhit = U - M;
+            ctl->log_tail = tail + (U - M);
+            ctl->clock = clock + U;
+            ctl->pulled = s_tot[2];
+        }
+        CACHE_PH(4);
+    }
 }
 
 // ---- fused lookup: one bookkeeping workgroup + one row kernel ---------------------------------------
@@ -1552,7 +1679,8 @@ struct ha_cache {
     // was an update (it pushes every pending evicted line); same_fast = the plan in plan_ws belongs to a lookup that
     // started from an empty evict list on an LRU cache with limit >= max_batch and a local store
     bool evict_empty = true, same_fast = false;
-    int fused_update = 3;  // HA_CACHE_FUSED: bit 0 = the two-launch update, bit 1 = eviction beside the lookup's row copies
+    int fused_update = 7;  // HA_CACHE_FUSED: bit 0 = the two-launch update, bit 1 = eviction beside the lookup's row copies,
+                           // bit 2 = the plan's finish does the lookup's bookkeeping (cache_finish_book_kernel)
     int64_t fused_count = 0;
 };
 
@@ -1871,14 +1999,28 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     hipStream_t s = as_stream(stream);
     int probed = 0;
     PlanPtrs p = plan_layout(c.plan_ws, n);
-    if (cache_plan(h, keys, key_kind, n, s, 1, &probed))
+    // LRU, not bypassed, a batch the counting sort takes: sort, then the finish that is the bookkeeping as well
+    const bool finish_book = (h->fused_update & 4) && (h->fused_update & 2) && c.policy == kLRU && !c.bypass && n > 0 &&
+                             n <= kSmallMax && finish_blocks((int)n) <= 64;
+    if (finish_book) {
+        HA_REQUIRE(n <= c.nmax, "cache: batch of %ld keys exceeds max_batch %ld", (long)n, (long)c.nmax);
+        const uint64_t lim = static_cast<uint64_t>(c.length);
+        if (key_kind == 0 ? ha_plan_sort_f32ids_lim(static_cast<const float *>(keys), n, c.plan_ws, lim, s)
+                          : ha_plan_sort_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, lim, s))
+            return -1;
+        hipLaunchKernelGGL(cache_finish_book_kernel, dim3(finish_blocks((int)n)), dim3(1024), 0, s, p.sorted, p.perm, (int)n,
+                           p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, c, c.limit >= n ? 1 : 0);
+        probed = 1;
+    } else if (cache_plan(h, keys, key_kind, n, s, 1, &probed)) {
         return -1;
-    const int evb = cache_evict_mode(h, n, probed);
+    }
+    const int evb = finish_book ? (c.limit >= n ? 2 : 1) : cache_evict_mode(h, n, probed);
     h->plan_n = n;
     h->same_fast = (h->fused_update & 1) && h->evict_empty && c.policy == kLRU && !c.bypass && c.limit >= n && n > 0;
     h->evict_empty = false;
-    hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
-                       (long long)n, c.bypass ? 1 : 0, probed, evb);
+    if (!finish_book)
+        hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
+                           (long long)n, c.bypass ? 1 : 0, probed, evb);
     if (n > 0) {
         const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + (evb ? 1 : 0);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0) &&

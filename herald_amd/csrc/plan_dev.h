@@ -419,6 +419,13 @@ __device__ __forceinline__ void head_probe(const HeadProbe &hp, int u, uint32_t 
         hp.pull[u] = (inr && (v == -1 || srv - v > hp.pull_bound)) ? 1 : 0;
     }
 }
+// What the finish leaves with the thread of a sorted position for code that continues in the same launch (cache.hip,
+// cache_finish_book_kernel): whether the position starts a run, the run's unique index and key.
+struct HeadOut {
+    bool head;
+    int32_t ui;
+    uint32_t key;
+};
 constexpr int kFinishLdsWords = 64;
 inline int finish_blocks(int n) { return (n + 1023) / 1024; }
 
@@ -429,7 +436,7 @@ __device__ __forceinline__ void finish_block_body(
     int32_t *__restrict__ inverse, int32_t *__restrict__ upos,
     int b, uint32_t *s_w, const uint32_t *__restrict__ chunk_heads = nullptr,
     const HeadProbe *hp = nullptr, uint32_t *key_tab = nullptr, uint64_t key_rows = 0,
-    uint32_t *long_list = nullptr, int long_min = 0) {
+    uint32_t *long_list = nullptr, int long_min = 0, HeadOut *ho = nullptr) {
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t *s_before = s_w, *s_heads = s_w + 16, *s_first = s_w + 32, *s_cand = s_w + 48;
     const int p = b * 1024 + tid;
@@ -509,6 +516,11 @@ __device__ __forceinline__ void finish_block_body(
         if (head) {
             uniq[ui] = k;
             seg[ui] = p;
+            if (ho) {
+                ho->head = true;
+                ho->ui = ui;
+                ho->key = k;
+            }
             if (hp)
                 head_probe(*hp, ui, k);
             const unsigned long long later = lane == 63 ? 0ull : (hm >> (lane + 1));
