@@ -38,13 +38,13 @@ for step in range(64):
 raw = np.array(acc, dtype=np.float64)
 a = raw / 100.0      # us
 names = {1: "probe / U", 2: "miss scan", 3: "assign + touch", 4: "commit + pull count"}
-print("bookkeeping workgroup (us, mean over %d lookups):" % len(acc))
+print("bookkeeping (us, mean over %d lookups):" % len(acc))
 if (a[:, 3] >= a[:, 1]).all() and (a[:, 3] <= a[:, 4]).all():      # the phase-by-phase path (> 8192 unique keys)
     for i in range(1, 5):
         print("  %-22s %6.2f" % (names[i], (a[:, i] - a[:, i - 1]).mean()))
-else:
-    print("  %-22s %6.2f" % (names[1], (a[:, 1] - a[:, 0]).mean()))
-    print("  %-22s %6.2f" % ("scan + assign + count", (a[:, 4] - a[:, 1]).mean()))
+else:           # cache_finish_book_kernel (the last chunk's workgroup) or the register-resident book
+    print("  %-34s %6.2f" % ("finish + probe + count exchange", (a[:, 1] - a[:, 0]).mean()))
+    print("  %-34s %6.2f" % ("assignment / touch / commit", (a[:, 4] - a[:, 1]).mean()))
 print("  total                  %6.2f" % (a[:, 4] - a[:, 0]).mean())
 print("insert / eviction workgroup:")
 print("  header + insert        %6.2f" % (a[:, 9] - a[:, 8]).mean())
