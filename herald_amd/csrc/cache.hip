@@ -505,11 +505,11 @@ __global__ __launch_bounds__(1024) void cache_scan_victim_kernel(CacheCtl *ctl, 
 }
 
 // batchedInsert of the misses (sorted order) + LRU eviction + log compaction.  Single workgroup.
-// lines_done: the bookkeeping kernel already wrote the new lines' records and slot_of (cache_lookup_book_kernel with
-// defer_evict == 2); only their log entries are left.
+// lines_done = 1: the bookkeeping kernel already wrote the new lines' records and slot_of (cache_lookup_book_kernel with
+// defer_evict == 2), only their log entries are left; 2: those as well (cache_finish_book_kernel) -- nothing to insert.
 __device__ __forceinline__ void cache_insert_evict_body(
     CacheCtl *ctl, const Cache &c, const uint32_t *uniq, const uint32_t *flag,
-    const uint32_t *rank, int do_insert, bool lines_done = false) {
+    const uint32_t *rank, int do_insert, int lines_done = 0) {
     __shared__ uint32_t s_w[16];
     __shared__ long long s_head, s_need, s_clean, s_dirty;
     const int U = static_cast<int>(ctl->U);
@@ -547,7 +547,7 @@ __device__ __forceinline__ void cache_insert_evict_body(
     }
     const int base_use = c.policy == kLFU ? 1 : 0;
     const long long tail0_mod = tail0 % c.Lcap;
-    if (do_insert) {
+    if (do_insert && lines_done < 2) {
         constexpr int R = 8;       // batched loads, see cache_assign_body
         for (int base = threadIdx.x; base < U; base += 1024 * R) {
             uint32_t f[R], rk[R], kk[R];
@@ -888,10 +888,15 @@ __global__ __launch_bounds__(1024) void cache_finish_book_kernel(
             if (pre_insert) {
                 // the new line's side of batchedInsert as well (cache_insert_evict_body then only appends the log
                 // entries): LRU with limit >= batch inserts every miss, stamp = clock after the touches + its rank
-                c.line[fs].stamp = static_cast<unsigned long long>(clock + U + rank);
+                const unsigned long long st = static_cast<unsigned long long>(clock + U + rank);
+                c.line[fs].stamp = st;
                 c.line[fs].freq = 0;
                 c.line[fs].state = kResident;
                 c.slot_of[k] = fs;
+                // ... and its log entry, behind the U - M touches of this lookup (cache_insert_evict_body's tail0 + rank)
+                const long long pos = ring_at((tail + (U - M)) % c.Lcap, rank, c.Lcap);
+                c.log_slot[pos] = static_cast<uint32_t>(fs);
+                c.log_stamp[pos] = st;
             } else {
                 c.line[fs].state = static_cast<uint8_t>(kPending);
             }
@@ -1027,7 +1032,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
         if (defer_evict)
             return;
         __syncthreads();
-        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1, false);
+        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1, 0);
         __syncthreads();
         if (tid == 0)
             cache_report_pull_body(ctl, c, n);
@@ -1115,7 +1120,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
             cache_scan_victim_body(ctl, c);
             __syncthreads();
         }
-        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1, evict_block == 2);
+        cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1, evict_block - 1);
         __syncthreads();
         if (threadIdx.x == 0)
             cache_report_pull_body(ctl, c, n);
@@ -2014,7 +2019,7 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     } else if (cache_plan(h, keys, key_kind, n, s, 1, &probed)) {
         return -1;
     }
-    const int evb = finish_book ? (c.limit >= n ? 2 : 1) : cache_evict_mode(h, n, probed);
+    const int evb = finish_book ? (c.limit >= n ? 3 : 1) : cache_evict_mode(h, n, probed);
     h->plan_n = n;
     h->same_fast = (h->fused_update & 1) && h->evict_empty && c.policy == kLRU && !c.bypass && c.limit >= n && n > 0;
     h->evict_empty = false;
