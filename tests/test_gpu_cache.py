@@ -153,6 +153,16 @@ def test_lru_trace_update_of_the_looked_up_keys_log_compaction(dev):
     assert st["log_tail"] - st["log_head"] <= st["log_cap"]
 
 
+@pytest.mark.parametrize("limit", [30000, 9000])
+def test_lru_trace_many_finish_chunks(dev, limit):
+    """20,000 keys per batch: the plan's finish is 20 workgroups that exchange their miss / pull / head counts inside the
+    launch (cache_finish_book_kernel); limit >= batch also inserts there, limit < batch leaves the insert to the eviction
+    workgroup."""
+    gpu, _ = _run_trace(dev, limit=limit, rows=120000, width=4, n=20000, steps=4, pull_bound=1, push_bound=2, zipf=False,
+                        seed=31, same=True, check_every=2)
+    assert _fused(gpu) == (4 if limit >= 20000 else 0)
+
+
 def test_lru_limit_smaller_than_batch_never_takes_the_fused_update(dev):
     gpu, _ = _run_trace(dev, limit=5, rows=200, width=4, n=40, steps=10, pull_bound=1, push_bound=1, zipf=False,
                         seed=15, same=True)
