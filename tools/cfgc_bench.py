@@ -124,11 +124,14 @@ def sort_ahead(block, graph):
         else:
             run = body
         run(); main_s.synchronize()
+        import gc
+        gc.collect(); gc.disable()          # a collection inside the eager loop is 5-60 ms of host time (bench.py does the same)
         a.record(main_s)
         for _ in range(4):
             run()
         b_.record(main_s)
         main_s.synchronize()
+        gc.enable()
     return a.elapsed_time(b_) * 1e3 / (4 * nblk * block)
 for blk in (4, 8, 16):
     for graph in (True, False):
