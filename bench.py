@@ -323,7 +323,7 @@ def cold_tier(args, dev):
 
     def step(k):
         c.embedding_lookup(ids[k % nb], out)
-        c.embedding_update(ids[k % nb], grad)
+        c.embedding_update(ids[k % nb], grad, same_as_lookup=True)
 
     # Neither call reads anything back (the store is on this device: request and outbox are handed over padded),
     # so the pairs are replayed from hipGraphs of 16 like the HBM cache tier's

@@ -185,7 +185,8 @@ class _CacheBase:
             self._evict_bound += k.numel()
             check(self._L.ha_cache_lookup_finish(self._h, k.numel(), ctypes.c_void_p(dest.data_ptr()),
                                                  ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup_finish")
-            self._last_lookup = None
+            # the plan of ha_cache_lookup_begin stays in the workspace: an update of the same key tensor can reuse it
+            self._last_lookup = None if keep else (k.data_ptr(), k.numel())
             if self.perf_enabled:
                 self._perf_record(0)
             w = Wait(s, keep + [k, dest])
@@ -193,16 +194,23 @@ class _CacheBase:
                 w._after = (lambda hd=host_dest, dd=dest: np.copyto(hd.reshape(dd.shape), dd.cpu().numpy()))
         return w
 
-    def _update_remote(self, keys, grads, push_keys):
+    def _update_remote(self, keys, grads, push_keys, same_as_lookup=False):
         keep = []
         s = self._stream()
         with torch.cuda.stream(s):
             k, kind = self._keys(keys, keep)
             g = self._grads(grads, keep)
             assert g.numel() == k.numel() * self._width
+            same = bool(same_as_lookup) and k.numel() > 0 and self._last_lookup == (k.data_ptr(), k.numel())
+            if same_as_lookup and not same:
+                raise ValueError("same_as_lookup=True, but no embedding_lookup of this key tensor precedes")
+            self._last_lookup = None
             bound = None if self._host_counts() else self._outbox_bound(k.numel())
             check(self._L.ha_cache_outbox_pad(self._h, bound or 0), "ha_cache_outbox_pad")
-            if push_keys is None:
+            if push_keys is None and same:       # the lookup's index plan is still in the workspace
+                check(self._L.ha_cache_update_same_keys(self._h, k.numel(), ctypes.c_void_p(g.data_ptr()),
+                                                        ctypes.c_void_p(s.cuda_stream)), "ha_cache_update_same_keys")
+            elif push_keys is None:
                 check(self._L.ha_cache_update(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
                                               ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
                       "ha_cache_update")
@@ -220,6 +228,7 @@ class _CacheBase:
 
     def _push_pull_remote(self, pullkeys, dest, pushkeys, grads):
         keep = []
+        self._last_lookup = None
         s = self._stream()
         with torch.cuda.stream(s):
             pk, pkind = self._keys(pullkeys, keep)
@@ -355,7 +364,7 @@ class _CacheBase:
         keys again.  It is explicit because a tensor's identity says nothing about its contents when
         raw-pointer writers (HIP kernels, DLPack aliases) fill it."""
         if self._remote is not None:
-            return self._update_remote(keys, grads, None)
+            return self._update_remote(keys, grads, None, same_as_lookup)
         keep = []
         s = self._stream()
         with torch.cuda.stream(s):

@@ -38,6 +38,16 @@ def test_remote_protocol_traces(dev, policy, pull_bound, push_bound):
                policy=policy, seed=11, bind=_bind_local)
 
 
+@pytest.mark.parametrize("policy", ["lru", "lfu"])
+def test_remote_update_of_the_looked_up_keys_reuses_the_plan(dev, policy):
+    """same_as_lookup=True through a remote store: the update reuses the index plan ha_cache_lookup_begin left in the
+    workspace (ha_cache_update_same_keys, general path: the outbox carries the pushes)."""
+    _run_trace(dev, limit=100, rows=1500, width=8, n=64, steps=50, pull_bound=2, push_bound=2, policy=policy, seed=17,
+               bind=_bind_local, same=True)
+    _run_trace(dev, limit=16, rows=300, width=4, n=48, steps=30, pull_bound=1, push_bound=1, zipf=False, policy=policy,
+               seed=18, bind=_bind_local, same=True, extra_lookup_every=4)
+
+
 def test_remote_heavy_eviction_and_limit_below_batch(dev):
     _run_trace(dev, limit=16, rows=1000, width=4, n=48, steps=40, pull_bound=2, push_bound=2, zipf=False, seed=3,
                bind=_bind_local)
@@ -89,11 +99,15 @@ def test_cold_tier_host_store(dev):
         keys = ((np.minimum(rng.zipf(1.2, size=n) - 1, rows - 1) * 7919) % rows).astype(np.float32)
         want = model.lookup(keys.astype(np.uint64))
         dest = torch.empty((n, width), dtype=torch.float32, device=dev)
-        gpu.embedding_lookup(torch.from_numpy(keys).to(dev), dest).wait()
+        kt = torch.from_numpy(keys).to(dev)
+        gpu.embedding_lookup(kt, dest).wait()
         np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup, step %d" % step)
         g = rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01)
         model.update(keys.astype(np.uint64), g)
-        gpu.embedding_update(torch.from_numpy(keys).to(dev), torch.from_numpy(g).to(dev)).wait()
+        if step % 2:            # every other step: the update names the lookup's key tensor (plan reuse)
+            gpu.embedding_update(kt, torch.from_numpy(g).to(dev), same_as_lookup=True).wait()
+        else:
+            gpu.embedding_update(torch.from_numpy(keys).to(dev), torch.from_numpy(g).to(dev)).wait()
         torch.cuda.synchronize()
         np.testing.assert_array_equal(st.versions.cpu().numpy(), server.ver, err_msg="versions, step %d" % step)
         np.testing.assert_array_equal(st.table.numpy(), server.table, err_msg="host table, step %d" % step)
