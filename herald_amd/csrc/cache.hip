@@ -1440,7 +1440,7 @@ __device__ __forceinline__ void cache_row_add(float *__restrict__ row, float *__
 template <int VEC>
 __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
     Cache c, const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq,
-    const int32_t *__restrict__ counts, long long n) {
+    const int32_t *__restrict__ counts, long long n, long long pad_to) {
     CacheCtl *ctl = c.ctl;
     const int lane = lane_id();
     const int U = static_cast<int>(hdr->n_unique);
@@ -1465,6 +1465,18 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
         ctl->clock = clock + U;
         ctl->free_top = ftop + En;       // log_tail stays: the touches replace the lookup's entries
         ctl->evict_n = 0;
+        if (c.remote)
+            ctl->out_n = U + En <= c.out_cap ? U + En : -1;
+    }
+    // REMOTE store: nothing here touches the store; the pushes go to the OUTBOX as cache_update_flags_push_kernel /
+    // cache_push_evicted_kernel leave them -- entry u = batch line u (kNoPush when it is not pushed), entry U + j = pending
+    // evicted line j, entries up to pad_to marked not pushed (an owner that takes the outbox without a host-side count)
+    if (c.remote && blockIdx.x == 0) {
+        const long long lim = pad_to < c.out_cap ? pad_to : c.out_cap;
+        for (long long e = static_cast<long long>(U) + En + threadIdx.x; e < lim; e += 1024) {
+            c.out_keys[e] = kNoPush;
+            c.out_upd[e] = 0;
+        }
     }
     for (int item = blockIdx.x * 16 + static_cast<int>(threadIdx.x >> 6); item < U + En; item += gridDim.x * 16) {
         if (item < U) {
@@ -1490,9 +1502,21 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
                     atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->perf[7]), 1ull);
                 }
             }
+            if (c.remote && lane == 0) {
+                c.out_keys[u] = push ? k : kNoPush;
+                c.out_upd[u] = upd;
+            }
             if (!push)
                 continue;
             float *g = c.grad + static_cast<long long>(s) * c.width;
+            if (c.remote) {         // the gradient row travels, the line's buffer starts from zero again
+                float *o = c.out_rows + static_cast<long long>(u) * c.width;
+                for (long long j = lane; j < c.width; j += kWave) {
+                    o[j] = g[j];
+                    g[j] = 0.f;
+                }
+                continue;
+            }
             const long long lk = static_cast<long long>(k) - c.row_start;
             if (lk >= 0 && lk < c.store_rows) {
                 cache_row_add<VEC>(c.table + lk * c.width, g, c.width, lane, true);
@@ -1505,6 +1529,24 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
         } else {
             const int j = item - U;
             const int s = uniform(c.evict_slots[j]);
+            if (c.remote) {
+                const long long e = static_cast<long long>(U) + j;
+                if (e < c.out_cap) {
+                    if (lane == 0) {
+                        c.out_keys[e] = c.line[s].key;
+                        c.out_upd[e] = c.line[s].updates;
+                    }
+                    const float *g = c.grad + static_cast<long long>(s) * c.width;
+                    float *o = c.out_rows + e * c.width;
+                    for (long long q = lane; q < c.width; q += kWave)
+                        o[q] = g[q];
+                }
+                if (lane == 0) {
+                    c.line[s].state = kFree;
+                    c.free_list[ftop + j] = s;
+                }
+                continue;
+            }
             const long long lk = static_cast<long long>(uniform(c.line[s].key)) - c.row_start;
             if (lk >= 0 && lk < c.store_rows) {
                 cache_row_add<VEC>(c.table + lk * c.width, c.grad + static_cast<long long>(s) * c.width, c.width, lane,
@@ -1931,7 +1973,8 @@ extern "C" int ha_cache_lookup_begin(ha_cache *h, const void *keys, int key_kind
     if (cache_plan(h, keys, key_kind, n, s, 0, &probed))
         return -1;
     h->plan_n = n;
-    h->same_fast = false;
+    // (remote store: the update of these keys can take the two-launch path as well -- its pushes go to the outbox)
+    h->same_fast = (h->fused_update & 1) && h->evict_empty && c.policy == kLRU && !c.bypass && c.limit >= n && n > 0;
     h->evict_empty = false;
     PlanPtrs p = plan_layout(c.plan_ws, n);
     if (!probed)   // larger batches: the plan was built unfused, probe separately
@@ -2061,7 +2104,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     h->plan_n = -1;
     PlanPtrs p = plan_layout(c.plan_ws, n);
     const dim3 b(256);
-    const bool fast = keys == nullptr && h->same_fast && !with_push_keys && !defer_cleanup && !c.bypass && !c.remote;
+    const bool fast = keys == nullptr && h->same_fast && !with_push_keys && !defer_cleanup && !c.bypass;
     h->same_fast = false;
     h->evict_empty = true;     // every path below pushes the pending evicted lines
     if (fast) {
@@ -2070,13 +2113,13 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
         if (ha_apply_mapped2(c.grad, c.S, c.data, c.width, c.plan_ws, n, grads, -1.0f, c.uslot, c.uslot, c.hasgrad, s))
             return -1;
         const unsigned pblocks = static_cast<unsigned>((2 * n + 15) / 16 > 1024 ? 1024 : (2 * n + 15) / 16);
-        const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
+        const bool vec_ok = !c.remote && (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
         if (vec_ok)
             hipLaunchKernelGGL(cache_update_same_post_kernel<4>, dim3(pblocks), dim3(1024), 0, s, c, p.hdr, p.uniq,
-                               p.counts, (long long)n);
+                               p.counts, (long long)n, (long long)h->out_pad);
         else
             hipLaunchKernelGGL(cache_update_same_post_kernel<1>, dim3(pblocks), dim3(1024), 0, s, c, p.hdr, p.uniq,
-                               p.counts, (long long)n);
+                               p.counts, (long long)n, (long long)h->out_pad);
         HA_LAUNCH_CHECK();
         return 0;
     }

@@ -42,10 +42,19 @@ def test_remote_protocol_traces(dev, policy, pull_bound, push_bound):
 def test_remote_update_of_the_looked_up_keys_reuses_the_plan(dev, policy):
     """same_as_lookup=True through a remote store: the update reuses the index plan ha_cache_lookup_begin left in the
     workspace (ha_cache_update_same_keys, general path: the outbox carries the pushes)."""
-    _run_trace(dev, limit=100, rows=1500, width=8, n=64, steps=50, pull_bound=2, push_bound=2, policy=policy, seed=17,
-               bind=_bind_local, same=True)
-    _run_trace(dev, limit=16, rows=300, width=4, n=48, steps=30, pull_bound=1, push_bound=1, zipf=False, policy=policy,
-               seed=18, bind=_bind_local, same=True, extra_lookup_every=4)
+    gpu, _ = _run_trace(dev, limit=100, rows=1500, width=8, n=64, steps=50, pull_bound=2, push_bound=2, policy=policy,
+                        seed=17, bind=_bind_local, same=True)
+    # LRU, limit >= batch: the two-launch update, its pushes and evicted lines in the outbox (cache_update_same_post_kernel)
+    assert int(gpu._L.ha_cache_fused_updates(gpu._h)) == (50 if policy == "lru" else 0)
+    gpu, _ = _run_trace(dev, limit=16, rows=300, width=4, n=48, steps=30, pull_bound=1, push_bound=1, zipf=False,
+                        policy=policy, seed=18, bind=_bind_local, same=True, extra_lookup_every=4)
+    assert int(gpu._L.ha_cache_fused_updates(gpu._h)) == 0
+
+
+def test_remote_update_of_the_looked_up_keys_with_evictions_and_wide_rows(dev):
+    gpu, _ = _run_trace(dev, limit=600, rows=5000, width=128, n=416, steps=14, pull_bound=2, push_bound=1, seed=19,
+                        check_every=4, bind=_bind_local, same=True, zipf=False)
+    assert int(gpu._L.ha_cache_fused_updates(gpu._h)) == 14
 
 
 def test_remote_heavy_eviction_and_limit_below_batch(dev):
