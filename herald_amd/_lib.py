@@ -228,6 +228,7 @@ def _declare(L):
         "ha_cache_push_pull_finish": [vp, vp, vp],
         "ha_store_serve_sync": [vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp],
         "ha_store_add_versions": [vp, i64, vp, vp, i64, vp],
+        "ha_store_push_distinct": [vp, vp, i64, i64, vp, vp, vp, i64, vp],
     }
     for name, args in cache_sigs.items():
         fn = getattr(L, name)

@@ -153,14 +153,17 @@ class _CacheBase:
         m = n + self._evict_bound
         return m if m <= self._out_cap else None
 
-    def _push_outbox(self, s, bound=None):
+    def _push_outbox(self, s, bound=None, distinct=False):
         b = self._rb
         if bound is None:
             cnt = ctypes.c_int64(0)
             check(self._L.ha_cache_outbox_count(self._h, ctypes.byref(cnt), ctypes.c_void_p(s.cuda_stream)),
                   "ha_cache_outbox_count")
             bound = int(cnt.value)
-        self._remote.push(b["out_keys"][:bound], b["out_upd"][:bound], b["out_rows"][:bound])
+        if distinct:
+            self._remote.push(b["out_keys"][:bound], b["out_upd"][:bound], b["out_rows"][:bound], distinct=True)
+        else:
+            self._remote.push(b["out_keys"][:bound], b["out_upd"][:bound], b["out_rows"][:bound])
 
     def _lookup_remote(self, keys, dest):
         keep = []
@@ -207,6 +210,7 @@ class _CacheBase:
             self._last_lookup = None
             bound = None if self._host_counts() else self._outbox_bound(k.numel())
             check(self._L.ha_cache_outbox_pad(self._h, bound or 0), "ha_cache_outbox_pad")
+            fused0 = int(self._L.ha_cache_fused_updates(self._h))
             if push_keys is None and same:       # the lookup's index plan is still in the workspace
                 check(self._L.ha_cache_update_same_keys(self._h, k.numel(), ctypes.c_void_p(g.data_ptr()),
                                                         ctypes.c_void_p(s.cuda_stream)), "ha_cache_update_same_keys")
@@ -220,7 +224,9 @@ class _CacheBase:
                     self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(), ctypes.c_void_p(pk.data_ptr()), pkind,
                     pk.numel(), ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
                     "ha_cache_update_with_push_keys")
-            self._push_outbox(s, bound)
+            # an update that took the two-launch path leaves pairwise distinct keys in the outbox (the batch's unique keys
+            # and the victims of one lookup): the store applies them without sorting
+            self._push_outbox(s, bound, distinct=int(self._L.ha_cache_fused_updates(self._h)) > fused0)
             self._evict_bound = 0
             if self.perf_enabled:
                 self._perf_record(1)

@@ -788,7 +788,45 @@ __global__ __launch_bounds__(256) void store_add_versions_kernel(long long *__re
     }
 }
 
+// pushEmbedding's server side (PSFhandle_embedding.cc:23-27) for a list whose live keys are pairwise DISTINCT: one wave per
+// entry, row += gradient row, version += update count; no sort, no dedup, no order to keep.
+__global__ __launch_bounds__(256) void store_push_distinct_kernel(float *__restrict__ table, long long *__restrict__ srv_ver,
+                                                                  long long rows, int width,
+                                                                  const uint32_t *__restrict__ keys,
+                                                                  const int32_t *__restrict__ updates,
+                                                                  const float *__restrict__ grad_rows, long long m) {
+    const int lane = threadIdx.x & 63;
+    for (long long j = blockIdx.x * 4ll + (threadIdx.x >> 6); j < m; j += gridDim.x * 4ll) {
+        const uint32_t k = keys[j];
+        if (k >= static_cast<unsigned long long>(rows))       // 0xFFFFFFFF = not pushed
+            continue;
+        float *row = table + static_cast<long long>(k) * width;
+        const float *g = grad_rows + j * width;
+        for (int c = lane; c < width; c += 64)
+            row[c] = __fadd_rn(row[c], g[c]);
+        if (lane == 0)
+            srv_ver[k] += updates[j];
+    }
+}
+
 }  // namespace ha
+
+extern "C" int ha_store_push_distinct(float *table, int64_t *server_versions, int64_t rows, int64_t width,
+                                      const uint32_t *keys, const int32_t *updates, const float *grad_rows, int64_t m,
+                                      ha_stream_t stream) {
+    HA_REQUIRE(m >= 0 && rows >= 0 && width >= 1 && width < (1ll << 30), "store_push_distinct: bad sizes");
+    if (m == 0)
+        return 0;
+    HA_REQUIRE(table && server_versions && keys && updates && grad_rows, "store_push_distinct: null pointer");
+    unsigned blocks = static_cast<unsigned>((m + 3) / 4);
+    if (blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(ha::store_push_distinct_kernel, dim3(blocks), dim3(256), 0, ha::as_stream(stream), table,
+                       reinterpret_cast<long long *>(server_versions), (long long)rows, (int)width, keys, updates,
+                       grad_rows, (long long)m);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ha_store_serve_sync(const float *table, const int64_t *server_versions, int64_t rows,
                                    int64_t width, const uint32_t *keys, const int64_t *versions, int64_t m,

@@ -64,9 +64,15 @@ class LocalStore:
                                           _p(self._count), None, _s()), "ha_store_serve_sync")
         return self._count          # device int64[1]: number of rows written to rows_out
 
-    def push(self, keys, updates, rows):
+    def push(self, keys, updates, rows, distinct=False):
+        """distinct=True: the caller vouches that the live keys of the list are pairwise distinct (the outbox of a
+        two-launch cache update): one launch, no sort."""
         m = keys.numel()
         if m == 0:
+            return
+        if distinct:
+            check(self._L.ha_store_push_distinct(_p(self.table), _p(self.versions), self.rows, self.width, _p(keys),
+                                                 _p(updates), _p(rows), m, _s()), "ha_store_push_distinct")
             return
         if self._plan_cap < m:
             self._plan_cap = m * 5 // 4 + 64
@@ -105,11 +111,11 @@ class HostStore(LocalStore):
         cur.wait_stream(self.copy_stream)
         return cnt
 
-    def push(self, keys, updates, rows):
+    def push(self, keys, updates, rows, distinct=False):
         cur = torch.cuda.current_stream()
         self.copy_stream.wait_stream(cur)
         with torch.cuda.stream(self.copy_stream):
-            super().push(keys, updates, rows)
+            super().push(keys, updates, rows, distinct)
             check(self._L.ha_store_count_valid(_p(keys), keys.numel(), self.rows, _p(self._acc[2:3]), _s()),
                   "ha_store_count_valid")
         cur.wait_stream(self.copy_stream)
@@ -213,7 +219,8 @@ class ShardedStore:
         self.stats["xgmi_bytes_in"] += out_keys * 12 + in_rows * 4 * self.width
 
     # -- kPushEmbedding -----------------------------------------------------------------------------------------
-    def push(self, keys, updates, rows):
+    def push(self, keys, updates, rows, distinct=False):
+        # (distinct is a single-store shortcut; the W lists an owner receives may repeat a key across senders)
         m, w, dev = keys.numel(), self.world, self.device
         # stable sort by key: groups by owner, keeps the list order of equal keys (the batch's line before
         # the older evicted ones), moves the not-pushed entries (0xFFFFFFFF) behind every owner's range

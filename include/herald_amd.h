@@ -756,6 +756,12 @@ int ha_store_serve_sync(const float *table, const int64_t *server_versions, int6
 /* Owner side of the version half of a push: server_versions[keys[j]] += updates[j] (keys >= rows skipped). */
 int ha_store_add_versions(int64_t *server_versions, int64_t rows, const uint32_t *keys,
                           const int32_t *updates, int64_t m, ha_stream_t stream);
+/* The same server side for a push list whose live keys (< rows; 0xFFFFFFFF = not pushed) are pairwise DISTINCT -- what
+ * ha_cache_update_same_keys' two-launch path leaves in the outbox (the batch's unique keys and the victims of one lookup):
+ * one launch, table[key,:] += grad_rows[j,:] and server_versions[key] += updates[j], no sort.  The caller vouches for the
+ * distinctness (herald_amd.cache asks ha_cache_fused_updates); lists with repeated keys need ha_shard_serve_push's order. */
+int ha_store_push_distinct(float *table, int64_t *server_versions, int64_t rows, int64_t width, const uint32_t *keys,
+                           const int32_t *updates, const float *grad_rows, int64_t m, ha_stream_t stream);
 /* *acc += number of keys below `rows` (device-side traffic accounting of a store) */
 int ha_store_count_valid(const uint32_t *keys, int64_t m, int64_t rows, int64_t *acc, ha_stream_t stream);
 /* Synchronising inspectors.  perf out[8] = {type(0 pull / 1 push), num_all, num_unique, num_miss,
