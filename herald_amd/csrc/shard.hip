@@ -709,6 +709,62 @@ __global__ __launch_bounds__(1024) void store_sync_decide_kernel(
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    if (m <= 8 * 1024) {
+        // up to 8192 entries: thread t owns the consecutive entries Kt .. Kt+K-1 -- keys and cached versions in one batch
+        // of loads, the server versions in a second, ONE block scan of the per-thread pull counts (a chunk of 1024 entries at
+        // a time it was two dependent trips and a scan per chunk: 11 us for the 5,720-entry request of the cold-tier batch)
+        const int K = static_cast<int>((m + 1023) >> 10);
+        const long long j0 = static_cast<long long>(tid) * K;
+        uint32_t kk[8];
+        long long vv[8], sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long j = min(j0 + i, m - 1);
+            kk[i] = keys[j];
+            vv[i] = versions[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            sv[i] = srv_ver[kk[i] < static_cast<unsigned long long>(rows) ? kk[i] : 0];
+        uint32_t local = 0, pm = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool on = i < K && j0 + i < m && kk[i] < static_cast<unsigned long long>(rows);
+            const bool p = on && (vv[i] == -1 || sv[i] - vv[i] > bound);
+            pm |= p ? (1u << i) : 0u;
+            local += p ? 1u : 0u;
+        }
+        uint32_t x = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o)
+                x += y;
+        }
+        if (lane == 63)
+            s_w[w] = x;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) {
+            if (k < w)
+                woff += s_w[k];
+            tot += s_w[k];
+        }
+        uint32_t at = woff + x - local;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < K && j0 + i < m) {
+                const bool on = kk[i] < static_cast<unsigned long long>(rows);
+                pull[j0 + i] = (pm >> i) & 1u;
+                idx[j0 + i] = static_cast<int32_t>(at);
+                ver_out[j0 + i] = on ? sv[i] : 0;
+                at += (pm >> i) & 1u;
+            }
+        }
+        if (tid == 0)
+            *count = tot;
+        return;
+    }
     if (tid == 0)
         s_base = 0;
     __syncthreads();

@@ -86,8 +86,8 @@ class LocalStore:
 
 class HostStore(LocalStore):
     """Cold tier: the table in pinned (device-visible) host memory, the versions in HBM.  The owner-side
-    kernels read / update the rows over PCIe; `stream` (default: a store-owned copy stream) carries them so
-    that staging overlaps whatever runs on the caller's stream until the cache needs the inbox."""
+    kernels read / update the rows over PCIe; `stream` (default: the caller's stream) carries them -- pass a copy
+    stream when the caller has work of its own to overlap the staging with."""
 
     def __init__(self, rows, width, device, table=None, stream=None):
         if table is None:
@@ -95,30 +95,41 @@ class HostStore(LocalStore):
         assert table.is_pinned() and tuple(table.shape) == (rows, width)
         versions = torch.zeros(rows, dtype=torch.int64, device=device)
         super().__init__(table, versions)
-        self.copy_stream = stream if stream is not None else torch.cuda.Stream(device=device)
+        # stream=None: the owner-side kernels run on the caller's stream.  (A store-owned copy stream only pays when the
+        # caller has other work to overlap: the cache needs the inbox at once, and the two cross-stream dependencies per
+        # call cost more than the kernels between them.)
+        self.copy_stream = stream
         # device-side traffic counters (no host sync on the path): keys synced, rows pulled, lines pushed
         self._acc = torch.zeros(3, dtype=torch.int64, device=device)
 
-    def sync(self, keys, versions, bound, pull, idx, ver_out, rows_out):
+    def _on_store_stream(self):
+        import contextlib
+        if self.copy_stream is None:
+            return contextlib.nullcontext(), None
         cur = torch.cuda.current_stream()
         self.copy_stream.wait_stream(cur)
-        with torch.cuda.stream(self.copy_stream):
+        return torch.cuda.stream(self.copy_stream), cur
+
+    def sync(self, keys, versions, bound, pull, idx, ver_out, rows_out):
+        ctx, cur = self._on_store_stream()
+        with ctx:
             cnt = super().sync(keys, versions, bound, pull, idx, ver_out, rows_out)
             # keys actually asked for (the request is padded with 0xFFFFFFFF) and rows pulled, on the device
             check(self._L.ha_store_count_valid(_p(keys), keys.numel(), self.rows, _p(self._acc[0:1]), _s()),
                   "ha_store_count_valid")
             self._acc[1:2] += cnt
-        cur.wait_stream(self.copy_stream)
+        if cur is not None:
+            cur.wait_stream(self.copy_stream)
         return cnt
 
     def push(self, keys, updates, rows, distinct=False):
-        cur = torch.cuda.current_stream()
-        self.copy_stream.wait_stream(cur)
-        with torch.cuda.stream(self.copy_stream):
+        ctx, cur = self._on_store_stream()
+        with ctx:
             super().push(keys, updates, rows, distinct)
             check(self._L.ha_store_count_valid(_p(keys), keys.numel(), self.rows, _p(self._acc[2:3]), _s()),
                   "ha_store_count_valid")
-        cur.wait_stream(self.copy_stream)
+        if cur is not None:
+            cur.wait_stream(self.copy_stream)
 
     def traffic(self, reset=False):
         """{'keys_synced', 'rows_pulled', 'lines_pushed', 'pcie_bytes'} since creation / the last reset

@@ -82,16 +82,18 @@ def test_remote_push_pull_trace(dev, policy):
     run_push_pull_trace(dev, policy, bind=_bind_local)
 
 
-def test_cold_tier_host_store(dev):
-    """The table in pinned host memory (HostStore): rows are staged over PCIe by the owner-side kernels on the
-    store's copy stream, versions stay in HBM.  Same trace, same oracle; the host table ends up equal to the
-    model's server table."""
+@pytest.mark.parametrize("own_stream", [False, True])
+def test_cold_tier_host_store(dev, own_stream):
+    """The table in pinned host memory (HostStore): rows are staged over PCIe by the owner-side kernels (on the caller's
+    stream, or on a copy stream handed to the store), versions stay in HBM.  Same trace, same oracle; the host table ends
+    up equal to the model's server table."""
     host = {}
 
     def bind(gpu, table, versions):
         t = torch.empty(tuple(table.shape), dtype=torch.float32, pin_memory=True)
         t.copy_(table)
-        st = remote_store.HostStore(table.shape[0], table.shape[1], dev, table=t)
+        st = remote_store.HostStore(table.shape[0], table.shape[1], dev, table=t,
+                                    stream=torch.cuda.Stream(device=dev) if own_stream else None)
         host["store"], host["dev_table"], host["dev_versions"] = st, table, versions
         gpu.bind_remote(st)
 
