@@ -606,6 +606,13 @@ class CacheSparseTable:
     def embedding_update(self, keys, grads, sync=False, same_as_lookup=False):
         return self._finish(self.cache.embedding_update(keys, grads, same_as_lookup=same_as_lookup), sync)
 
+    def looked_up_last(self, keys):
+        """True when `keys` is the device tensor the cache's last operation, an embedding_lookup, was given (same storage,
+        same length).  A caller that also knows the CONTENTS are unchanged since -- an executor between the lookup of a
+        batch and the push of its gradients -- may then say embedding_update(..., same_as_lookup=True)."""
+        return (torch.is_tensor(keys) and keys.is_cuda and keys.numel() > 0 and
+                self.cache._last_lookup == (keys.data_ptr(), keys.numel()))
+
     def embedding_update_with_push_keys(self, keys, push_keys, grads, sync=False):
         return self._finish(self.cache.embedding_update_with_push_keys(keys, push_keys, grads), sync)
 

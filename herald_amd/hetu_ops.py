@@ -209,7 +209,11 @@ class ParameterServerCommunicateOp:
     def _push_cache(self, grad):
         vals = grad.values.reshape(-1, self.parameter.shape[1])
         if grad.push_indices is None:
-            return self.cache.embedding_update(grad.indices.reshape(-1), vals)
+            # The executor pushes the gradients of the batch it looked up last (bsp / ssp: push(k) follows pull(k) as the
+            # cache's next operation, ParameterServerCommunicate.py:41-56) and does not write the ids in between: when the
+            # indices ARE that lookup's tensor the update reuses its index plan (and takes the two-launch path).
+            idx = grad.indices.reshape(-1)
+            return self.cache.embedding_update(idx, vals, same_as_lookup=self.cache.looked_up_last(idx))
         return self.cache.embedding_update_with_push_keys(grad.indices.reshape(-1), grad.push_indices.reshape(-1), vals)
 
     def _pull_cache(self, ids):
