@@ -456,6 +456,69 @@ __global__ __launch_bounds__(256) void shard_identity_rank_kernel(const uint32_t
     }
 }
 
+// Owner side of a framed push, the apply: the merged list holds every key at most once per sender (W <= kMaxShards
+// entries per run, in rank order), so a wave per run HEAD adds the run's value rows to the table row in that order --
+// table[key,:] = ((table[key,:] + v_0) + v_1) ... : bit for bit what ha_sgd_apply_finish computes with lr = -1
+// (acc - (-1 * v)), without the finish of an index plan nobody reads and without its treatment of the padding (the
+// unused slots of the frames carry one key beyond any table: a "run" of tens of thousands of positions to the
+// generic apply).  perm == nullptr: the list is one sender's frame as it arrived.
+template <int VEC>
+__global__ __launch_bounds__(256) void shard_frames_apply_kernel(float *__restrict__ table, unsigned long long rows, int width,
+                                                                 const uint32_t *__restrict__ sorted,
+                                                                 const int32_t *__restrict__ perm, int n,
+                                                                 const float *__restrict__ values) {
+    const int lane = threadIdx.x & 63;
+    for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += gridDim.x * 4) {
+        const uint32_t key = sorted[p];
+        if (key >= rows || (p > 0 && sorted[p - 1] == key))
+            continue;           // padding / beyond the table / not the head of its run
+        int len = 1;
+        while (p + len < n && sorted[p + len] == key)
+            ++len;
+        float *row = table + static_cast<unsigned long long>(key) * width;
+        if (VEC == 4) {
+            for (int c = lane * 4; c < width; c += 256) {
+                float4v acc = ld4(row + c);
+                for (int t = 0; t < len; ++t) {
+                    const long long src = perm ? perm[p + t] : p + t;
+                    const float4v v = ld4(values + src * width + c);
+                    acc = float4v{__fadd_rn(acc[0], v[0]), __fadd_rn(acc[1], v[1]), __fadd_rn(acc[2], v[2]),
+                                  __fadd_rn(acc[3], v[3])};
+                }
+                st4(row + c, acc);
+            }
+        } else {
+            for (int c = lane; c < width; c += 64) {
+                float acc = row[c];
+                for (int t = 0; t < len; ++t) {
+                    const long long src = perm ? perm[p + t] : p + t;
+                    acc = __fadd_rn(acc, values[src * width + c]);
+                }
+                row[c] = acc;
+            }
+        }
+    }
+}
+
+static int shard_frames_apply(float *table, int64_t rows, int64_t width, const uint32_t *sorted, const int32_t *perm,
+                              int64_t n, const float *values, hipStream_t s) {
+    unsigned blocks = static_cast<unsigned>((n + 3) / 4);
+    if (blocks > 16384)
+        blocks = 16384;
+    const bool vec_ok = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(values) % 16 == 0);
+    if (vec_ok)
+        hipLaunchKernelGGL(shard_frames_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, table,
+                           static_cast<unsigned long long>(rows), static_cast<int>(width), sorted, perm,
+                           static_cast<int>(n), values);
+    else
+        hipLaunchKernelGGL(shard_frames_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, table,
+                           static_cast<unsigned long long>(rows), static_cast<int>(width), sorted, perm,
+                           static_cast<int>(n), values);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
 // Stable merge of the W received key lists of a framed push (each ascending, unique inside a list, kNoKey = the
 // largest key in the unused slots): slot p = (s, j) gets rank j + sum over s' < s of upper_bound(list s', key) + sum
 // over s' > s of lower_bound(list s', key) -- the position of (key, s) in the rank-ordered merge -- by binary searches
@@ -679,19 +742,15 @@ extern "C" int ha_shard_frames_serve_push(float *table, int64_t rows, int64_t wi
     const int64_t n = static_cast<int64_t>(nshard) * rcap;
     const size_t lds = static_cast<size_t>(n) * 4;
     PlanPtrs p = plan_layout(plan_ws, n);
-    if (nshard == 1) {     // one list: it IS the merged order
-        hipLaunchKernelGGL(shard_identity_rank_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
-                           as_stream(stream), keys_fixed, static_cast<int>(n), p.sorted, p.perm);
-        HA_LAUNCH_CHECK();
-        return ha_sgd_apply_finish(table, rows, width, plan_ws, n, values, -1.0f, stream);
-    }
+    if (nshard == 1)       // one list: it IS the merged order, its keys are distinct
+        return shard_frames_apply(table, rows, width, keys_fixed, nullptr, n, values, as_stream(stream));
     if (lds > (size_t(64) << 10))     // lists that do not fit 64 KiB of LDS: the general sort
         return ha_shard_serve_push(table, rows, width, keys_fixed, n, values, plan_ws, stream);
     HA_ALLOW_LDS(shard_merge_rank_kernel, lds);
     hipLaunchKernelGGL(shard_merge_rank_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), lds,
                        as_stream(stream), keys_fixed, nshard, static_cast<int>(rcap), p.sorted, p.perm);
     HA_LAUNCH_CHECK();
-    return ha_sgd_apply_finish(table, rows, width, plan_ws, n, values, -1.0f, stream);
+    return shard_frames_apply(table, rows, width, p.sorted, p.perm, n, values, as_stream(stream));
 }
 
 // ---- owner side of the cache protocol over a sharded / host-resident store --------------------------------
