@@ -447,15 +447,6 @@ __global__ __launch_bounds__(256) void shard_serve_pull_frames_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void shard_identity_rank_kernel(const uint32_t *__restrict__ keys, int n,
-                                                                 uint32_t *__restrict__ sorted, int32_t *__restrict__ perm) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p < n) {
-        sorted[p] = keys[p];
-        perm[p] = p;
-    }
-}
-
 // Owner side of a framed push, the apply: the merged list holds every key at most once per sender (W <= kMaxShards
 // entries per run, in rank order), so a wave per run HEAD adds the run's value rows to the table row in that order --
 // table[key,:] = ((table[key,:] + v_0) + v_1) ... : bit for bit what ha_sgd_apply_finish computes with lr = -1
