@@ -72,6 +72,7 @@ struct CacheCtl {
     long long out_n;       // remote mode: outbox entries of the last update (U + E), -1 on overflow
     unsigned long long ph[16];   // ha_cache_phase_times: 100 MHz clock at the phase boundaries of the last lookup's bookkeeping
     unsigned long long fb_xw[64];     // cache_finish_book_kernel, per finish chunk: valid << 63 | heads << 32 | pulls << 16 | misses
+    long long fb_timeout;             // sticky: a workgroup of cache_finish_book_kernel gave up waiting for another one's word
     long long snap[4];     // {clock, log_tail, free_top, evict_n} as the last lookup left them (cache_update_same_post_kernel)
 };
 
@@ -836,8 +837,16 @@ __global__ __launch_bounds__(1024) void cache_finish_book_kernel(
             const int cb = c0 + tid;
             unsigned long long w = 0;
             if (cb < nb) {
+                // every finish workgroup is resident (at most 36), so every word arrives; the programming model does not
+                // promise that: after about a second of polling the sticky flag is set (ha_cache_perf / ha_cache_state
+                // then fail) and the launch goes on instead of hanging the device
+                unsigned spins = 0;
                 do {
                     w = __hip_atomic_load(&ctl->fb_xw[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1u << 20)) {
+                        ctl->fb_timeout = 1;
+                        break;
+                    }
                 } while (!(w >> 63));
             }
             const uint32_t m = static_cast<uint32_t>(w & 0xFFFFull);
@@ -2306,6 +2315,8 @@ extern "C" int ha_cache_perf(ha_cache *h, int64_t *out_host, ha_stream_t stream)
     CacheCtl ctl;
     HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a wait inside cache_finish_book_kernel timed out (the cache's state is not to be "
+               "trusted; HA_CACHE_FUSED=3 keeps the bookkeeping in a launch of its own)");
     for (int i = 0; i < 7; ++i)
         out_host[i] = ctl.perf[i];
     out_host[4] += ctl.perf[7];
@@ -2333,6 +2344,8 @@ extern "C" int ha_cache_state(ha_cache *h, int64_t *out_host, ha_stream_t stream
     CacheCtl ctl;
     HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a wait inside cache_finish_book_kernel timed out (the cache's state is not to be "
+               "trusted; HA_CACHE_FUSED=3 keeps the bookkeeping in a launch of its own)");
     out_host[0] = ctl.size;
     out_host[1] = ctl.evict_n;
     out_host[2] = ctl.free_top;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
     int n, int shift, int nblk, const uint32_t *hist,
     uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out,
     uint32_t *__restrict__ bucket_start = nullptr, uint32_t *flags = nullptr, uint32_t flag_value = 0,
-    uint32_t *flags_reset = nullptr) {
+    uint32_t *flags_reset = nullptr, long long *timeout_word = nullptr) {
     constexpr int kRows = kRadixTile / kScatterThreads;        // rows of 64 keys per wave
     constexpr int kPerThread = kRadixBuckets / kScatterThreads;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -202,8 +202,19 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
         if (threadIdx.x == 0)
             __hip_atomic_store(flags + blockIdx.x, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (static_cast<int>(threadIdx.x) < nblk) {
-            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flag_value)
+            // All tiles of a pass are resident at once (at most kRadixFusedBlocks workgroups), so every flag arrives; the
+            // programming model does not promise that, hence the bound: about a second of polling, then the sticky word
+            // of the plan header is set (ha_plan_handoff_timeout; IndexPlan.n_unique() raises) and the pass goes on with
+            // whatever the histograms hold instead of hanging the device.
+            unsigned spins = 0;
+            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flag_value) {
                 __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 20)) {
+                    if (timeout_word)
+                        *timeout_word = 1;
+                    break;
+                }
+            }
         }
         __syncthreads();
     }
@@ -680,7 +691,8 @@ int ha::plan_radix_sort(void *ws, int64_t n, int key_bits, bool sort_only, hipSt
         if (pass > 0 && one_launch) {
             hipLaunchKernelGGL((radix_scatter_kernel<false, false, true>), dim3(nblk), dim3(kScatterThreads),
                                kScatterLdsBytes, stream, kin, vin, ni, shift, nblk, p.hist, kout, vout,
-                               dbg, p.pass_flags, static_cast<uint32_t>(pass), static_cast<uint32_t *>(nullptr));
+                               dbg, p.pass_flags, static_cast<uint32_t>(pass), static_cast<uint32_t *>(nullptr),
+                               reinterpret_cast<long long *>(&p.hdr->reserved[kHandoffFlagWord]));
         } else if (nblk <= kRadixFusedBlocks) {
             hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(kScatterThreads), kScatterLdsBytes,
                                stream, kin, vin, ni, shift, nblk, p.hist, kout, vout,

@@ -13,6 +13,10 @@ struct PlanHeader {
     int64_t reserved[31];
 };
 static_assert(sizeof(PlanHeader) == 256, "plan header is one 256-byte line");
+// plan header word of the sticky time-out flag (words 0..3 serve plan.hip / scatter.hip): set by a launch whose wait for other
+// workgroups of the SAME launch gave up -- the hand-off of ha_sgd_push_pull (step.hip), the histogram exchange of the
+// one-launch radix passes (plan.hip); read through ha_plan_handoff_timeout
+constexpr int kHandoffFlagWord = 8;
 
 struct PlanPtrs {
     PlanHeader *hdr;

@@ -40,7 +40,6 @@ int apply_finish_entry(float *dst, int64_t rows, int64_t width, void *plan_ws, i
 constexpr int kGatherLoads = 2;    // sixteen-byte loads a gather lane keeps in flight: one 2 KiB row per wave at
                                    // d = 512 (measured: 8 -> 18.4 us per step, 4 -> 16.2, 2 -> 15.6: the finer the
                                    // waves, the less a released row waits for its wave's other rows)
-constexpr int kHandoffFlagWord = 8;   // plan header word of the sticky time-out flag (words 0..3 serve plan.hip / scatter.hip)
 constexpr int kSpinMax = 1 << 18;   // polls of ~0.3 us each before a gather wave gives up (~0.1 s)
 
 struct StepArgs {

@@ -205,8 +205,9 @@ class IndexPlan:
         addr = _lib.load().ha_plan_handoff_timeout(_ptr(self.ws))
         if bool(self._slice(addr, 1, torch.int64).item()):
             raise _lib.HeraldAmdError(
-                "a hand-off wait of the ha_sgd_push_pull launch that sorted this plan timed out: the rows that "
-                "lookup returned may predate the update of the previous batch (include/herald_amd.h)")
+                "a wait inside a launch that wrote this plan timed out -- the hand-off of ha_sgd_push_pull (the rows that "
+                "lookup returned may predate the update of the previous batch) or the histogram exchange of a radix pass "
+                "(the order of the plan is not to be trusted): include/herald_amd.h, ha_plan_handoff_timeout")
 
     def handoff_timed_out(self):
         """True if a hand-off wait of the sgd_push_pull launch that sorted this plan gave up (host sync)."""

@@ -414,7 +414,10 @@ int ha_debug_step_timeline(float *table, int64_t rows, int64_t width,
                            void *pend_cur, const float *next_ids, int64_t n_next,
                            float *next_out, void *plan_next, void *pend_next,
                            unsigned long long *dbg, ha_stream_t stream);
-/* device address of the hand-off time-out flag (int64, 0 = fine) of a plan workspace */
+/* device address of the sticky time-out flag (int64, 0 = fine) of a plan workspace: set by a launch whose wait for other
+ * workgroups of the same launch exceeded its bound -- the hand-off above, or the histogram exchange of the one-launch radix
+ * passes that sort more than 36,864 ids (all tiles of a pass are resident at once, so the wait is microseconds; the bound
+ * keeps a scheduling surprise from hanging the device) */
 int64_t *ha_plan_handoff_timeout(void *plan_ws);
 
 /* The step with THREE batches of lookahead: ONE launch that
