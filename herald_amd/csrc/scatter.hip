@@ -153,12 +153,19 @@ __global__ __launch_bounds__(1024, 8) void apply_listed_kernel(
     for (long long it = blockIdx.x; it < items; it += gridDim.x) {
         const int u = static_cast<int>(long_list[it / nslice]);
         const int j = static_cast<int>(it % nslice);
-        const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
+        uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
+        bool init = true;
+        if (maps.rowmap) {      // destination rows through an index map (ha_apply_mapped): -1 = no destination
+            const int r = maps.rowmap[u];
+            row = r < 0 ? ~0ull : static_cast<uint64_t>(r);
+            if (r >= 0 && maps.dst_init)
+                init = maps.dst_init[r] != 0;
+        }
         if (row < dst_rows) {
             Second d2{nullptr, false};
             if (MODE == kModeOpt)
                 opt_rows(d2, maps, row, width);
-            coop_slices<MODE, false>(dst + row * static_cast<uint64_t>(width), true, d2, grads, perm, maps, n, lr,
+            coop_slices<MODE, false>(dst + row * static_cast<uint64_t>(width), init, d2, grads, perm, maps, n, lr,
                                      seg[u], counts[u], width, j, nslice, w, reinterpret_cast<float *>(s_apply));
         }
         __syncthreads();
@@ -171,19 +178,26 @@ __global__ __launch_bounds__(1024, 8) void apply_listed_kernel(
         if (len >= kLongRun)
             continue;
         const uint32_t key = uniform(uniq[u]);
-        const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(key);
+        uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(key);
+        bool init = true;
+        if (maps.rowmap) {
+            const int r = uniform(maps.rowmap[u]);
+            row = r < 0 ? ~0ull : static_cast<uint64_t>(r);
+            if (r >= 0 && maps.dst_init)
+                init = maps.dst_init[r] != 0;
+        }
         if (row >= dst_rows)
-            continue;  // out-of-range id: ignored
+            continue;  // out-of-range id / no destination: ignored
         float *dst_row = dst + row * static_cast<uint64_t>(width);
         const int pv = perm[min(s + lane, n - 1)];   // lanes 0 .. len-1: the run's occurrence indices
         Second d2{nullptr, false};
         if (MODE == kModeOpt)
             opt_rows(d2, maps, row, width);
         if (len <= kShortRun) {
-            short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, true, d2);
+            short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, init, d2);
         } else {
             for (int c0 = 0; c0 < width; c0 += kWave)
-                medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, true, d2);
+                medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, init, d2);
         }
     }
 }
@@ -423,6 +437,16 @@ extern "C" int ha_debug_apply_timeline(float *table, int64_t rows, int64_t width
 // dst[rowmap[u],:] = (init ? dst[rowmap[u],:] : 0) - lr*src[valmap[i0],:] - lr*src[valmap[i1],:] ...
 // over the occurrences i0 < i1 < ... of unique key u of a FINISHED plan.  rowmap / valmap / dst_init
 // may each be NULL (identity / identity / always init).  Used by the embedding cache.
+namespace ha {
+static bool mapped_by_unique() {      // HA_MAPPED_BY_UNIQUE=0: ha_apply_mapped always one wave per sorted position
+    static const bool on = [] {
+        const char *e = getenv("HA_MAPPED_BY_UNIQUE");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+}  // namespace ha
+
 extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
                                const void *plan_ws, int64_t n, const float *src,
                                float lr, const int32_t *rowmap,
@@ -440,6 +464,12 @@ extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
                         (reinterpret_cast<uintptr_t>(src) % 16 == 0);
     ha::ApplyMaps maps{rowmap, valmap, dst_init, nullptr, nullptr};
     maps.tree_from = ha::tolerance_tree_from();
+    // Larger batches whose chunked finish listed the long keys: waves map to UNIQUE keys (a wave per sorted position
+    // spends most of a 106,496-id batch of 128-wide rows on positions that own no row: the framed push's reduce 45.7 us)
+    if (valmap == nullptr && rowmap != nullptr && n > ha::kSmallMax && n <= ha::kFinishChunkedMax &&
+        ha::mapped_by_unique())
+        return ha::apply_by_unique<ha::kModeSgd>(dst, dst_rows, width, const_cast<void *>(plan_ws), n, src, lr,
+                                                 ha::as_stream(stream), maps);
     if (vec_ok)
         hipLaunchKernelGGL((ha::apply_mapped_kernel<4>), dim3(blocks), dim3(1024), ha::kApplyLdsBytes, ha::as_stream(stream),
                            dst, (uint64_t)dst_rows, (int)width, v.sorted, v.perm, v.upos, (int)n, src, lr, maps);

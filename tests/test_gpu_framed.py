@@ -34,12 +34,16 @@ def _stream(rows, n, nb, kind, seed=0):
 
 @pytest.mark.parametrize("rows,width,n,kind,graphs,block", [(50000, 128, 6656, "criteo", True, 4), (50000, 128, 6656, "criteo", False, 4),
                                                             (3000, 64, 900, "mixed", True, 2), (200, 32, 40, "mixed", True, 1),
-                                                            (3000, 64, 900, "mixed", True, 16)])
+                                                            (3000, 64, 900, "mixed", True, 16),
+                                                            # beyond 36,864 ids: radix-sorted plans, the push's reduce by unique
+                                                            # key (a 4,000-occurrence run in the "mixed" batches)
+                                                            (200000, 128, 40014, "criteo", False, 1),
+                                                            (60000, 32, 50000, "mixed", False, 1)])
 def test_framed_step_world1_replays_from_graphs(dev, rows, width, n, kind, graphs, block):
     """World size 1: pull and push of every step replay from hipGraphs (three routing slots -> three graphs of each
     kind for a fixed set of buffers); every pulled row and the table after every push equal the oracle's."""
     from herald_amd.sharded import FramedStep, ShardedEmbedding
-    nb = 9 * block + 3 if block < 16 else 20
+    nb = (9 * block + 3 if block < 16 else 20) if n < 30000 else 5
     ids = _stream(rows, n, nb, kind)
     n = ids[0].size
     rng = np.random.default_rng(5)
