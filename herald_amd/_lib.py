@@ -156,6 +156,7 @@ def _declare(L):
         "ha_dedup_reduce_scaled": [vp, i64, vp, i64, f32, vp, vp],
         "ha_debug_apply_timeline": [vp, i64, i64, vp, i64, vp, f32, vp, vp],
         "ha_sgd_apply": [vp, i64, i64, vp, i64, vp, f32, vp],
+        "ha_sgd_apply_finished": [vp, i64, i64, vp, i64, vp, f32, vp],
         "ha_push_apply": [vp, i64, i64, vp, i64, vp, vp],
         "ha_sgd_sparse_update_f32ids": [vp, i64, i64, vp, i64, vp, f32, vp],
         "ha_lookup_sort_f32ids": [vp, i64, i64, vp, i64, vp, vp, vp],

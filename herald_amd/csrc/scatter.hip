@@ -395,6 +395,18 @@ extern "C" int ha_sgd_apply(float *table, int64_t rows, int64_t width,
                                           lr, ha::as_stream(stream));
 }
 
+// ha_sgd_apply for a FINISHED plan (ha_plan_build_*, or ha_plan_sort_* + ha_plan_finish): batches of more than 36,864 ids
+// map their waves to unique keys (the finish listed the long keys), smaller ones run as ha_sgd_apply.  Same results.
+extern "C" int ha_sgd_apply_finished(float *table, int64_t rows, int64_t width, void *plan_ws, int64_t n,
+                                     const float *grads, float lr, ha_stream_t stream) {
+    if (n > ha::kSmallMax && n <= ha::kFinishChunkedMax) {
+        HA_REQUIRE(table && plan_ws && grads && width >= 1 && width < (1 << 30), "sgd_apply_finished: bad arguments");
+        return ha::apply_by_unique<ha::kModeSgd>(table, rows, width, plan_ws, n, grads, lr, ha::as_stream(stream),
+                                                 ha::ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr});
+    }
+    return ha::apply_launch<ha::kModeSgd>(table, rows, width, plan_ws, n, grads, lr, ha::as_stream(stream));
+}
+
 extern "C" int ha_push_apply(float *table, int64_t rows, int64_t width,
                              const void *plan_ws, int64_t n, const float *grads,
                              ha_stream_t stream) {

@@ -270,12 +270,15 @@ def dedup_reduce(plan, grads, out=None, stream=None, scale=None):
     return out
 
 
-def sgd_apply(table, plan, grads, lr, stream=None):
-    """table[key,:] -= lr*grads[i,:] per occurrence, occurrence order (bit-exact cpu_SGDOptimizerSparseUpdate)."""
+def sgd_apply(table, plan, grads, lr, stream=None, finished=False):
+    """table[key,:] -= lr*grads[i,:] per occurrence, occurrence order (bit-exact cpu_SGDOptimizerSparseUpdate).
+    finished=True: the plan went through build() / finish() -- batches of more than 36,864 ids then map waves to unique
+    keys (ha_sgd_apply_finished); same results."""
     _require(table, torch.float32, "table")
     _require(grads, torch.float32, "grads")
-    check(_lib.load().ha_sgd_apply(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws), plan.n,
-                                   _ptr(grads), ctypes.c_float(lr), _stream_ptr(stream)), "ha_sgd_apply")
+    fn = _lib.load().ha_sgd_apply_finished if finished else _lib.load().ha_sgd_apply
+    check(fn(_ptr(table), table.shape[0], table.shape[1], _ptr(plan.ws), plan.n,
+             _ptr(grads), ctypes.c_float(lr), _stream_ptr(stream)), "ha_sgd_apply")
     return table
 
 
@@ -642,11 +645,16 @@ class SortAheadPipeline:
 
     NBLOCKS = 3          # blocks of plans in flight: being applied, sorted and waiting, being sorted
 
-    def __init__(self, table, max_ids, lr, block=8, key_limit=None, device=None):
+    def __init__(self, table, max_ids, lr, block=8, key_limit=None, device=None, finish_ahead=None):
         _require(table, torch.float32, "table")
         self.table, self.lr, self.block = table, float(lr), int(block)
         self.device = table.device if device is None else torch.device(device)
         self.key_limit = int(table.shape[0]) if key_limit is None else int(key_limit)
+        # finish_ahead=True: sort AND finish on the side stream, the apply maps its waves to unique keys
+        # (ha_sgd_apply_finished).  Alone that apply is a third faster than the apply-and-finish launch at 106,496 ids;
+        # beside the sorts it is not -- its 512 resident workgroups leave the sort's launches no room, 70 against 60 us per
+        # step (tools/cfgc_bench.py) -- so it is off unless asked for.
+        self.finish_ahead = bool(finish_ahead)
         self.plans = [[IndexPlan(max_ids, self.device) for _ in range(self.block)] for _ in range(self.NBLOCKS)]
         self.side = torch.cuda.Stream(device=self.device)      # (a high-priority side stream: no difference, 47.4 / 47.2 us)
         self._sorted = [torch.cuda.Event() for _ in range(self.NBLOCKS)]      # side -> main: the block's plans are sorted
@@ -669,7 +677,10 @@ class SortAheadPipeline:
             if self._freed[slot] is not None:
                 self.side.wait_event(self._freed[slot])      # its plans' previous users have finished
             for i, ids in enumerate(ids_list):
-                self.plans[slot][i].sort(ids, stream=self.side, key_limit=self.key_limit)
+                if self.finish_ahead:       # sort AND finish beside the steps: the apply then goes by unique key
+                    self.plans[slot][i].build(ids, stream=self.side, key_limit=self.key_limit)
+                else:
+                    self.plans[slot][i].sort(ids, stream=self.side, key_limit=self.key_limit)
             self._sorted[slot].record(self.side)
         self._first[slot] = (self._first[(b - 1) % self.NBLOCKS] + self._count[(b - 1) % self.NBLOCKS]) if b else 0
         self._count[slot] = len(ids_list)
@@ -692,7 +703,11 @@ class SortAheadPipeline:
 
     def apply(self, k, grads, stream=None):
         slot, i = self._plan(k, stream)
-        sgd_apply_finish(self.table, self.plans[slot][i], grads, self.lr, stream=stream)
+        if self.finish_ahead:
+            sgd_apply(self.table, self.plans[slot][i], grads, self.lr, stream=stream, finished=True)
+            self.plans[slot][i].produced_on(self.side)
+        else:
+            sgd_apply_finish(self.table, self.plans[slot][i], grads, self.lr, stream=stream)
         if i == self._count[slot] - 1:         # last step of the block: its plans may be overwritten
             ev = torch.cuda.Event()
             ev.record(stream or torch.cuda.current_stream(self.device))

@@ -305,6 +305,11 @@ int ha_dedup_reduce_scaled(const void *plan_ws, int64_t n, const float *grads,
 int ha_sgd_apply(float *table, int64_t rows, int64_t width,
                  const void *plan_ws, int64_t n, const float *grads, float lr,
                  ha_stream_t stream);
+/* The same for a plan that is already FINISHED (ha_plan_build_*, or ha_plan_sort_* followed by ha_plan_finish): batches of
+ * more than 36,864 ids map their waves to the unique keys the finish listed instead of to sorted positions (about a third
+ * less time for 106,496 ids of 128-wide rows); smaller batches run as ha_sgd_apply.  Bit-identical results. */
+int ha_sgd_apply_finished(float *table, int64_t rows, int64_t width, void *plan_ws, int64_t n, const float *grads,
+                          float lr, ha_stream_t stream);
 
 /* table[key,:] += scale * reduced_in_occurrence_order (PS push semantics:
  * worker pre-multiplies by -lr, server does +=;

@@ -138,8 +138,8 @@ def test_plan_radix_path_replays_from_a_graph(dev):
         np.testing.assert_array_equal(plan.perm().cpu().numpy(), np.argsort(keys, kind="stable"))
 
 
-@pytest.mark.parametrize("n,block", [(40000, 3), (9000, 2)])
-def test_sort_ahead_pipeline_equals_the_step_by_step_calls(dev, n, block):
+@pytest.mark.parametrize("n,block,finish_ahead", [(40000, 3, False), (40000, 2, True), (9000, 2, False)])
+def test_sort_ahead_pipeline_equals_the_step_by_step_calls(dev, n, block, finish_ahead):
     """ops.SortAheadPipeline (batches beyond the work-queue step's 7,168 ids): plans sorted a block ahead on a side stream,
     gather + apply-and-finish per step -- every output row and the table after every step as the CPU sequence has them."""
     rng = np.random.default_rng(n)
@@ -148,7 +148,7 @@ def test_sort_ahead_pipeline_equals_the_step_by_step_calls(dev, n, block):
     ids = [synth.as_f32_ids(rng.integers(0, rows if k % 2 else 300, size=n)) for k in range(steps)]
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
     t = _dev(table0, dev)
-    pipe = ops.SortAheadPipeline(t, n, 0.25, block=block)
+    pipe = ops.SortAheadPipeline(t, n, 0.25, block=block, finish_ahead=finish_ahead)
     d_ids = [_dev(x, dev) for x in ids]
     d_grads = [_dev(g, dev) for g in grads]
     want = table0.copy()
@@ -168,6 +168,35 @@ def test_sort_ahead_pipeline_equals_the_step_by_step_calls(dev, n, block):
     assert starts[-1] < steps
     with pytest.raises(ValueError):
         pipe.lookup(steps + 5, d_ids[0])
+
+
+@pytest.mark.parametrize("n,width", [(40000, 128), (106496, 64)])
+def test_sgd_apply_on_a_finished_plan_maps_waves_to_unique_keys(dev, n, width):
+    """ha_sgd_apply_finished above 36,864 ids: bit-equal to the CPU chain, and -- with the tolerance mode on -- bit-equal
+    to ha_sgd_apply's fixed-order trees (one tree shape, whichever way the waves are mapped)."""
+    rng = np.random.default_rng(n + width)
+    rows = 300000
+    ids = synth.as_f32_ids(rng.integers(0, rows, size=n))
+    ids[100:100 + 3000] = 77.0                  # a 3,000-occurrence run
+    ids[5000:5050] = 99.0                       # runs around the long-run threshold
+    ids[6000:6063] = 1234.0
+    ids[7000:7064] = 4321.0
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    plan = ops.IndexPlan(n, dev).build(_dev(ids, dev))
+    t = _dev(table, dev)
+    ops.sgd_apply(t, plan, _dev(grads, dev), 0.3, finished=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t.cpu().numpy(), cpu.sgd_sparse_update(table.copy(), ids, grads, 0.3))
+    ops.set_tolerance_mode(True)
+    try:
+        a, b = _dev(table, dev), _dev(table, dev)
+        ops.sgd_apply(a, plan, _dev(grads, dev), 0.3, finished=True)
+        ops.sgd_apply(b, plan, _dev(grads, dev), 0.3)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    finally:
+        ops.set_tolerance_mode(False)
 
 
 def test_plan_all_equal_and_all_distinct(dev):
