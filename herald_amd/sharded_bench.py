@@ -149,7 +149,7 @@ def _pmc_traffic():
     except Exception:
         return {}
     names = {"serve_pull": "ha::shard_serve_pull_frames_kernel", "expand": "ha::gather_vec4_kernel",
-             "reduce": "ha::apply_mapped_kernel", "serve_push": "ha::bwd_fused_kernel"}
+             "reduce": "ha::apply_mapped_kernel", "serve_push": "ha::shard_frames_apply_kernel"}
     out = {}
     for short, kn in names.items():
         hit = [v for name, v in k.items() if name.startswith(kn)]
