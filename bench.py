@@ -397,6 +397,11 @@ def main():
     # so the list is also cut to a multiple of 4 (a graph then depends on k % nb only)
     # buffers (and side streams) of step k and step k + rot_ring are the same
     rot_ring = (4 * (1 if args.queue_serial else args.queue_block)) if queue else 4
+    # Step numbers start at K0, chosen so that step K0 + 16 starts a block whatever the block size: a window of
+    # `--steps 20 --warmup 5` then holds exactly one block boundary (one preparation of a block on the side stream, one
+    # wait of the timed stream for it), as it did when blocks were 16 steps -- a short run times its share of the pipeline's
+    # preparation work, not a stretch between two boundaries.
+    K0 = (args.queue_block - 16) if (queue and not args.queue_serial and args.queue_block > 16) else 0
     period = (G * rot_ring // math.gcd(G, rot_ring)) if ahead2 else G
     if args.distinct_batches >= period:
         args.distinct_batches -= args.distinct_batches % period
@@ -429,12 +434,12 @@ def main():
             LA, Bk = pipe.LOOKAHEAD, pipe.block
             G = Bk                       # graphs are cut at block starts (the side work is enqueued between them)
             ids_rows = [ids_dev[i] for i in range(nb)]        # the batches as tensors of their own, sliced once
-            ids_of = lambda j: ids_rows[j % nb] if j >= 0 else None
+            ids_of = lambda j: ids_rows[j % nb] if j >= K0 else None          # the stream of batches starts at step K0
             with torch.cuda.stream(main_s):
-                for c in range(-LA, 0):
+                for c in range(K0 - LA, K0):
                     if c % Bk == 0:
                         pipe.prepare_block(c // Bk, ids_of, stream=main_s)
-                pipe.apply(-1, None, outs[0], stream=main_s, n_cur=0, n_next=n)
+                pipe.apply(K0 - 1, None, outs[0], stream=main_s, n_cur=0, n_next=n)
 
             def before_chunk(k):
                 if k % Bk == 0:
@@ -565,7 +570,7 @@ def main():
     wu = args.warmup
     pre = min(max(args.pre_roll, 0), wu)
     if step_chunk is not None:      # convert the arguments of everything the warm-up and the timed region enqueue
-        for k, ln in list(chunks(0, wu - pre)) + list(chunks(wu - pre, pre)) + list(chunks(wu, args.steps)):
+        for k, ln in list(chunks(K0, wu - pre)) + list(chunks(K0 + wu - pre, pre)) + list(chunks(K0 + wu, args.steps)):
             b = k % nb
             if (k % rot_ring, b, ln) not in packs:
                 bs = [(k + i) % nb for i in range(ln)]
@@ -573,10 +578,10 @@ def main():
                                                                      [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
     if use_graph:     # capture everything the warm-up and the timed region replay, before either runs
         torch.cuda.synchronize()
-        for k, ln in list(chunks(0, wu - pre)) + list(chunks(wu - pre, pre)) + list(chunks(wu, args.steps)):
+        for k, ln in list(chunks(K0, wu - pre)) + list(chunks(K0 + wu - pre, pre)) + list(chunks(K0 + wu, args.steps)):
             graph_for(k, ln)
         torch.cuda.synchronize()
-    run(0, wu - pre)
+    run(K0, wu - pre)
     torch.cuda.synchronize()
     # plain launches allocate a few Python objects per step; a generation-2 pass of the cyclic garbage collector over
     # everything torch has imported takes 35-65 ms -- two thousand steps -- and would land in the timed region of every
@@ -602,10 +607,10 @@ def main():
         with torch.cuda.stream(main_s):
             for _ in range(args.clock_warm):
                 warm[0].copy_(warm[1])
-    run(wu - pre, pre)
+    run(K0 + wu - pre, pre)
     t0 = time.perf_counter()
     e0.record(main_s)
-    replays = run(wu, args.steps)
+    replays = run(K0 + wu, args.steps)
     e1.record(main_s)
     t_enq = time.perf_counter() - t0
     if gate is not None:
@@ -620,7 +625,7 @@ def main():
     ms_per_step = total_ms / args.steps
     rows_per_s = n * args.steps / (total_ms * 1e-3)
 
-    used = [(wu + k) % nb for k in range(args.steps)]
+    used = [(K0 + wu + k) % nb for k in range(args.steps)]
     u_mean = float(np.mean(uniq_counts[used]))
     fwd_b, bwd_b = algorithmic_bytes(n, u_mean, args.width)
 
@@ -732,6 +737,8 @@ def main():
                         "right in front of it%s" % (args.steps, pre, wu, ", behind a gate the host opens once everything "
                                                     "is enqueued" if gate is not None else ""),
         "host_bound": bool(t_enq * 1e3 > dev_ms),
+        "block_boundaries_in_timed_region": (len([k for k in range(K0 + wu, K0 + wu + args.steps) if k % args.queue_block == 0])
+                                             if queue and not args.queue_serial else None),
         "roofline": roofline, "kernels": kernels,
     }
     if one and not ahead2:

@@ -749,8 +749,8 @@ class QueueStepPipeline:
         self.capacity = max(int(capacity), 1)
         self.overlap = bool(overlap)
         self.block = int(block) if self.overlap else 1
-        if not 1 <= self.block <= 16:
-            raise ValueError("block must be 1..16")
+        if not 1 <= self.block <= 64:
+            raise ValueError("block must be 1..64")
         self.LOOKAHEAD = 3 * self.block
         self.NPLAN, self.NQUEUE = 4 * self.block, 2 * self.block
         self.ROTATION = 4 * self.block     # plans and queues of call c and call c + ROTATION are the same
