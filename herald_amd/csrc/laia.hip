@@ -683,25 +683,38 @@ __global__ __launch_bounds__(256) void laia_bits_emit_kernel(LaiaBits a, long lo
     const int which = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t blk0 = a.blk[which][blockIdx.x];
+    // the wave's four summary words, their offsets and then their data words: each a batch of loads (word by word it was
+    // three dependent trips to memory per summary word, four words per wave)
+    const long long x0 = blockIdx.x * 16ll + wv * 4;
+    uint32_t cn[4];
+    unsigned long long sw4[4], dw4[4];
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long long x = blockIdx.x * 16ll + wv * 4 + i;
+        const long long x = x0 + i < nsum ? x0 + i : nsum - 1;
+        cn[i] = a.cnt[which][x];
+        sw4[i] = x0 + i < nsum ? a.sum[which][x] : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        dw4[i] = ((sw4[i] >> lane) & 1ull) ? a.bits[which][(x0 + i) * 64 + lane] : 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long x = x0 + i;
         if (x >= nsum)
             return;
-        const uint32_t at0 = blk0 + a.cnt[which][x];
+        const uint32_t at0 = blk0 + cn[i];
         if (lane == 0) {
             if (x % sum_per_worker == 0)
                 a.off[which][x / sum_per_worker] = static_cast<int32_t>(at0);
             if (x == nsum - 1)
                 a.off[which][W] = static_cast<int32_t>(a.blk[which][gridDim.x]);
         }
-        const unsigned long long sw = a.sum[which][x];      // wave-uniform
+        const unsigned long long sw = sw4[i];      // wave-uniform
         if (sw == 0)
             continue;
-        unsigned long long dw = 0;
-        if ((sw >> lane) & 1ull) {
-            dw = a.bits[which][x * 64 + lane];
+        unsigned long long dw = dw4[i];
+        if ((sw >> lane) & 1ull)
             a.bits[which][x * 64 + lane] = 0;
-        }
         if (lane == 0)
             a.sum[which][x] = 0;
         const uint32_t c = __builtin_popcountll(dw);
