@@ -109,6 +109,8 @@ def _declare(L):
     L.ha_step_max_ids.argtypes = []
     L.ha_qstep_max_ids.restype = i64
     L.ha_qstep_max_ids.argtypes = []
+    L.ha_qstep_init.restype = c.c_int
+    L.ha_qstep_init.argtypes = []
     L.ha_qstep_queue_bytes.restype = sz
     L.ha_qstep_queue_bytes.argtypes = [i64, i64]
     L.ha_qstep_queue_header.restype = vp

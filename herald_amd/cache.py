@@ -36,6 +36,24 @@ def register_table(node_id, table, versions=None, row_start=0):
     return versions
 
 
+
+class _LookupMark:
+    """What embedding_lookup remembers of its key tensor so that an update can prove it was handed the same one:
+    a STRONG reference (the caching allocator cannot hand the block to another tensor meanwhile), the address /
+    length, and the autograd version counter (views share it: an in-place write through torch bumps it).  Raw-pointer
+    writers are invisible to it -- which is why same_as_lookup stays an explicit statement of the caller."""
+    __slots__ = ("tensor", "ptr", "numel", "version")
+
+    def __init__(self, k):
+        self.tensor, self.ptr, self.numel, self.version = k, k.data_ptr(), k.numel(), k._version
+
+
+def _is_marked(mark, k):
+    return (mark is not None and torch.is_tensor(k) and mark.ptr == k.data_ptr() and mark.numel == k.numel() and
+            mark.tensor.dtype == k.dtype and mark.tensor.untyped_storage().data_ptr() == k.untyped_storage().data_ptr()
+            and mark.version == k._version and mark.tensor._version == mark.version)
+
+
 class Wait:
     """The `_waittype` of the reference (a shared_future): wait() blocks until the call is done."""
 
@@ -189,7 +207,7 @@ class _CacheBase:
             check(self._L.ha_cache_lookup_finish(self._h, k.numel(), ctypes.c_void_p(dest.data_ptr()),
                                                  ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup_finish")
             # the plan of ha_cache_lookup_begin stays in the workspace: an update of the same key tensor can reuse it
-            self._last_lookup = None if keep else (k.data_ptr(), k.numel())
+            self._last_lookup = None if keep else _LookupMark(k)
             if self.perf_enabled:
                 self._perf_record(0)
             w = Wait(s, keep + [k, dest])
@@ -204,7 +222,7 @@ class _CacheBase:
             k, kind = self._keys(keys, keep)
             g = self._grads(grads, keep)
             assert g.numel() == k.numel() * self._width
-            same = bool(same_as_lookup) and k.numel() > 0 and self._last_lookup == (k.data_ptr(), k.numel())
+            same = bool(same_as_lookup) and k.numel() > 0 and _is_marked(self._last_lookup, k)
             if same_as_lookup and not same:
                 raise ValueError("same_as_lookup=True, but no embedding_lookup of this key tensor precedes")
             self._last_lookup = None
@@ -346,7 +364,7 @@ class _CacheBase:
                                           ctypes.c_void_p(dest.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
                   "ha_cache_lookup")
             # an update of the very same (unmodified) device key tensor can reuse this call's index plan
-            self._last_lookup = None if keep else (k.data_ptr(), k.numel())
+            self._last_lookup = None if keep else _LookupMark(k)
             if self.perf_enabled:
                 self._perf_record(0)
             w = Wait(s, keep + [k, dest])
@@ -377,7 +395,7 @@ class _CacheBase:
             k, kind = self._keys(keys, keep)
             g = self._grads(grads, keep)
             assert g.numel() == k.numel() * self._width
-            same = bool(same_as_lookup) and k.numel() > 0 and self._last_lookup == (k.data_ptr(), k.numel())
+            same = bool(same_as_lookup) and k.numel() > 0 and _is_marked(self._last_lookup, k)
             if same_as_lookup and not same:
                 raise ValueError("same_as_lookup=True, but no embedding_lookup of this key tensor precedes")
             self._last_lookup = None
@@ -611,7 +629,7 @@ class CacheSparseTable:
         same length).  A caller that also knows the CONTENTS are unchanged since -- an executor between the lookup of a
         batch and the push of its gradients -- may then say embedding_update(..., same_as_lookup=True)."""
         return (torch.is_tensor(keys) and keys.is_cuda and keys.numel() > 0 and
-                self.cache._last_lookup == (keys.data_ptr(), keys.numel()))
+                _is_marked(self.cache._last_lookup, keys))
 
     def embedding_update_with_push_keys(self, keys, push_keys, grads, sync=False):
         return self._finish(self.cache.embedding_update_with_push_keys(keys, push_keys, grads), sync)

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <atomic>
+#include <mutex>
 
 #include "../../include/herald_amd.h"
 
@@ -48,15 +49,28 @@ bool g_err_is_empty();
     } while (0)
 
 // "Once per DEVICE" guard for per-device function attributes (hipFuncSetAttribute applies to the current device
-// only): true the first time it is called with the current device, from whichever thread.
+// only).  run(f): f() is executed once per device (f returns 0 on success); a thread that arrives while another is
+// still inside f WAITS for it -- it must not launch a kernel whose LDS attribute is not set yet --, and a failed
+// run is retried by the next caller.
 struct DeviceOnce {
-    std::atomic<unsigned long long> seen[4];   // 256 devices
-    bool first() {
+    std::atomic<unsigned long long> done[4];   // 256 devices
+    std::mutex mu;
+    template <typename F>
+    int run(F f) {
         int d = 0;
         if (hipGetDevice(&d) != hipSuccess)
-            return true;
+            d = 0;
         const unsigned long long bit = 1ull << (d & 63);
-        return (seen[(d >> 6) & 3].fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+        std::atomic<unsigned long long> &word = done[(d >> 6) & 3];
+        if (word.load(std::memory_order_acquire) & bit)
+            return 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (word.load(std::memory_order_acquire) & bit)
+            return 0;
+        const int rc = f();
+        if (rc == 0)
+            word.fetch_or(bit, std::memory_order_release);
+        return rc;
     }
 };
 

@@ -629,13 +629,13 @@ static int plan_build(const IdT *ids, int64_t n, void *ws, int key_bits,
 static int scatter_allow_lds() {
     using namespace ha;
     static DeviceOnce once;   // once per device, and outside any stream capture (the first call is eager)
-    if (once.first()) {
+    return once.run([]() -> int {
         HA_ALLOW_LDS((radix_scatter_kernel<false, false>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<true, false>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<false, true>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<false, false, true>), kScatterLdsBytes);
-    }
-    return 0;
+        return 0;
+    });
 }
 
 // Diagnostics (HA_RADIX_STAMPS=1 in the environment): out_host[24] = the 100 MHz clock at the phase boundaries of the last

@@ -63,7 +63,9 @@ struct QHeader {
     uint32_t n_wave, n_coop;                       // items of the keys the batch to apply names (one workgroup writes them)
     uint32_t n_long, n_medium, n_small;            //   per class (diagnostics, tests)
     uint32_t n_copy, n_copy_medium, n_copy_small;  // items of the keys only the lookup names (another workgroup)
-    uint32_t reserved[56];
+    uint32_t overflow_wave, overflow_copy;         // 1 = the builder counted more items than the queue holds (never, by the
+                                                   // layout's bounds; checked by the host so that it could only fail loudly)
+    uint32_t reserved[54];
 };
 static_assert(sizeof(QHeader) == 256, "queue header is one 256-byte line");
 struct QEntry {
@@ -79,13 +81,15 @@ struct QLayout {
     size_t bytes;
 };
 static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
-// Bounds (every key owns at least as many positions of the two batches as it has items per 512 columns):
-// wave items <= ceil(width/512) * n_a, copy items <= ceil(width/512) * n_g, coop items <= ceil(width/64) * n_a / 64.
+// Bounds.  A key with c occurrences in the batch to apply and m in the batch to look up has per512 items (S), per128 <=
+// 4 per512 (M: c >= 4 or m >= 17) or per32 <= 16 per512 (L: c >= 16): never more than per512 * (c + m) -- but NOT
+// per512 * c (a key with c = 1, m = 17 is an M item: 4 items for one position of the batch to apply).  Hence
+// wave items <= ceil(width/512) * (n_a + n_g), copy items <= ceil(width/512) * n_g, coop items <= ceil(width/64) * n_a / 64.
 static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
     QLayout q;
     char *b = static_cast<char *>(ws);
     q.cap_coop = static_cast<uint32_t>(ceil_div(width, 64) * (ceil_div(n_cap, kQLongC) + 1));
-    q.cap_wave = static_cast<uint32_t>(ceil_div(width, 512) * n_cap + 64);
+    q.cap_wave = static_cast<uint32_t>(ceil_div(width, 512) * 2 * n_cap + 64);
     q.cap_copy = static_cast<uint32_t>(ceil_div(width, 512) * n_cap + 64);
     q.hdr = reinterpret_cast<QHeader *>(b);
     q.coop = reinterpret_cast<QEntry *>(b ? b + sizeof(QHeader) : nullptr);
@@ -188,6 +192,9 @@ __device__ __forceinline__ uint32_t qscan(uint32_t v, uint32_t *s_w, uint32_t *t
 constexpr int kQTabBits = 13, kQTabSize = 1 << kQTabBits;
 constexpr uint32_t kQTabEmpty = 0xFFFFFFFFu;      // keys are <= 0xFFFFFFFE (to_key)
 constexpr int kGroupedFlagWord = 12;             // plan header word: 1 = unique keys in slot order, not key order
+constexpr int kOrderFlagWord = 13;               // plan header word: 1 = an occurrence list is NOT in position order (the plan
+                                                 // workgroup checks every list it writes; the queue builder hands the word on
+                                                 // to the host: the serial chain's order is what bit-exactness rests on)
 __device__ __forceinline__ uint32_t q_hash(uint32_t key) {
     return (key * 0x9E3779B1u) >> (32 - kQTabBits);
 }
@@ -386,6 +393,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
     if (tid == 0) {
         p.hdr->n_unique = U;
         p.hdr->reserved[kGroupedFlagWord] = 1;
+        p.hdr->reserved[kOrderFlagWord] = 0;
         p.seg[U] = n;
     }
     __syncthreads();
@@ -413,12 +421,19 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
             }
         }
         __syncthreads();
+        bool disorder = false;
         for (int qq = tid; qq < n; qq += 1024) {
             const uint32_t i = s_perm[qq];
             p.perm[qq] = static_cast<int32_t>(i);
             p.sorted[qq] = s_key[i];
             p.upos[qq] = static_cast<int32_t>(s_gq[qq]);
+            // the ranking rests on one wave-instruction's same-address LDS atomics being served in lane order (probed per
+            // device, lds_atomics_lane_ordered); every list is checked as it leaves, so a pattern the probe did not
+            // sample cannot silently reorder a chain
+            disorder |= qq > 0 && s_gq[qq] == s_gq[qq - 1] && i <= s_perm[qq - 1];
         }
+        if (disorder)
+            p.hdr->reserved[kOrderFlagWord] = 1;
         // the first three occurrences of every key also go to the group's own words (the queue builder embeds them in
         // small items; entries beyond the group's count are never used)
         for (uint32_t g = tid; g < U; g += 1024) {
@@ -699,9 +714,15 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             bqh->n_long = nL;
             bqh->n_medium = nM;
             bqh->n_small = nS;
+            uint32_t over = (nL + nM + nS > bcap_wave || nG > bcap_coop) ? 1u : 0u;
+            if ((pa.n > 0 && pa.hdr->reserved[kOrderFlagWord] != 0) || (pg.n > 0 && pg.hdr->reserved[kOrderFlagWord] != 0))
+                over |= 2u;
+            bqh->overflow_wave = over;
             if (mirror) {       // pinned host words: the host sizes the step's launch by them
                 mirror[0] = min(nL + nM + nS, bcap_wave) + 1u;      // + 1: 0 = not written yet
                 mirror[1] = min(nG, bcap_coop) + 1u;
+                if (over)
+                    mirror[3] = over;    // sticky: the host never clears it (1 = queue overflow, 2 = occurrence order)
             }
         }
         q_phase(ph, 4);
@@ -725,8 +746,12 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             bqh->n_copy = min(nM + nS, bcap_copy);
             bqh->n_copy_medium = nM;
             bqh->n_copy_small = nS;
-            if (mirror)
+            bqh->overflow_copy = nM + nS > bcap_copy ? 1u : 0u;
+            if (mirror) {
                 mirror[2] = min(nM + nS, bcap_copy) + 1u;
+                if (nM + nS > bcap_copy)
+                    mirror[3] = 1u;
+            }
         }
         q_phase(ph, 4);
         if (j.Ug > 0)
@@ -1212,10 +1237,12 @@ static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *pla
                        unsigned long long *ph = nullptr) {
     HA_REQUIRE(count >= 0 && (count == 0 || (ids && n && plans)), "ha_qplan_batch: null pointer");
     static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
-    if (lds_allowed.first()) {
-        HA_ALLOW_LDS((qplan_kernel<IdT, true>), 160 * 1024);
-        HA_ALLOW_LDS((qplan_kernel<IdT, false>), 160 * 1024);
-    }
+    if (lds_allowed.run([]() -> int {
+            HA_ALLOW_LDS((qplan_kernel<IdT, true>), 160 * 1024);
+            HA_ALLOW_LDS((qplan_kernel<IdT, false>), 160 * 1024);
+            return 0;
+        }))
+        return -1;
     const bool ordered = lds_atomics_lane_ordered() != 0;
     for (int64_t k0 = 0; k0 < count; k0 += kQBatch) {
         QPlanBatch b;
@@ -1251,8 +1278,11 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
     HA_REQUIRE(count >= 0 && (count == 0 || (plans_a && n_a && plans_g && n_g && queues)), "ha_qqueue_batch: null pointer");
     HA_REQUIRE(count == 0 || (queue_n_cap >= 1 && queue_n_cap <= kQMax), "ha_qqueue_batch: bad queue capacity");
     static DeviceOnce lds_allowed;
-    if (lds_allowed.first())
-        HA_ALLOW_LDS(qqueue_kernel, 160 * 1024);
+    if (lds_allowed.run([]() -> int {
+            HA_ALLOW_LDS(qqueue_kernel, 160 * 1024);
+            return 0;
+        }))
+        return -1;
     for (int64_t k0 = 0; k0 < count; k0 += kQJoinBatch) {
         QJoinBatch b;
         memset(&b, 0, sizeof(b));
@@ -1345,6 +1375,19 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
 using namespace ha;
 
 extern "C" int64_t ha_qstep_max_ids(void) { return kQMax; }
+
+// Per-device set-up of the ha_q* entry points, to be called once OUTSIDE any stream capture (ops.QueueStepPipeline does):
+// the LDS attributes of the plan / queue kernels and the lane-order probe of the LDS atomics (a small synchronous launch
+// on the null stream).  The entry points still do the same lazily on their first call.  Returns 1 if the atomic ranking
+// is used, 0 for the ballot ranking, -1 on error.
+extern "C" int ha_qstep_init(void) {
+    const float *ids = nullptr;
+    const uint64_t *ids64 = nullptr;
+    if (qplan_batch<float>(&ids, nullptr, nullptr, 0, nullptr) || qplan_batch<uint64_t>(&ids64, nullptr, nullptr, 0, nullptr) ||
+        qqueue_batch(0, 4, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, nullptr))
+        return -1;
+    return lds_atomics_lane_ordered();
+}
 
 extern "C" size_t ha_qstep_queue_bytes(int64_t n_cap, int64_t width) {
     if (n_cap < 1 || width < 4)

@@ -298,8 +298,11 @@ static int push_pull(float *table, int64_t rows, int64_t width, void *plan_cur, 
         }
         const unsigned blocks = static_cast<unsigned>(a.nfin + a.napply + a.nrank + a.ngather);
         static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
-        if (lds_allowed.first())
-            HA_ALLOW_LDS((step_kernel<IdT>), 160 * 1024);
+        if (lds_allowed.run([]() -> int {
+                HA_ALLOW_LDS((step_kernel<IdT>), 160 * 1024);
+                return 0;
+            }))
+            return -1;
         if (dbg) {
             a.dbg = dbg;
             HA_ALLOW_LDS((step_timeline_kernel<IdT>), 160 * 1024);
@@ -591,8 +594,11 @@ static int step_fwd(float *table, int64_t rows, int64_t width, void *plan_cur, i
     if (blocks == 0)
         return 0;
     static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
-    if (lds_allowed.first())
-        HA_ALLOW_LDS((step_fwd_kernel<IdT>), 160 * 1024);
+    if (lds_allowed.run([]() -> int {
+            HA_ALLOW_LDS((step_fwd_kernel<IdT>), 160 * 1024);
+            return 0;
+        }))
+        return -1;
     if (dbg) {
         a.dbg = dbg;
         HA_ALLOW_LDS((step_fwd_timeline_kernel<IdT>), 160 * 1024);

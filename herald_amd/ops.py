@@ -746,6 +746,9 @@ class QueueStepPipeline:
                              "sgd_push_pull / lookup_sort + sgd_apply_finish" % (qstep_max_ids(), capacity))
         if table.shape[1] % 4 != 0:
             raise ValueError("ha_qstep_* needs rows of a multiple of 4 floats")
+        with torch.cuda.device(self.device):
+            if L.ha_qstep_init() < 0:      # LDS attributes + the lane-order probe, outside any stream capture
+                check(-1, "ha_qstep_init")
         self.capacity = max(int(capacity), 1)
         self.overlap = bool(overlap)
         self.block = int(block) if self.overlap else 1
@@ -792,8 +795,15 @@ class QueueStepPipeline:
         synchronises)."""
         off = (c % self.NQUEUE) * self.queue_bytes
         torch.cuda.synchronize(self.device)
-        h = self.queues[off:off + 24].view(torch.int32).cpu().tolist()
-        return dict(zip(("wave_items", "workgroup_items", "long", "medium", "small", "copy_items"), h))
+        h = self.queues[off:off + 40].view(torch.int32).cpu().tolist()
+        d = dict(zip(("wave_items", "workgroup_items", "long", "medium", "small", "copy_items"), h))
+        d["overflow"] = int(h[8] != 0 or h[9] != 0)
+        return d
+
+    def overflowed(self):
+        """True if any queue built so far counted more items than it holds (the layout's bounds exclude it; the builder
+        raises a sticky word in pinned memory instead of dropping items silently)."""
+        return bool(self._counts_np[:, 3].any())
 
     # ---- the preparation of a block ------------------------------------------------------------------------------
     def prepare_block(self, b, ids_of, stream=None, ph=None):
@@ -885,9 +895,12 @@ class QueueStepPipeline:
 
     def wave_items(self, c):
         """Wave + copy items of the queue of step c if its numbers have landed in pinned memory, else -1."""
+        at = 4 * (c % self.COUNTS)
+        if self._counts_c[at + 3]:
+            raise RuntimeError("ha_qqueue_batch: the work queue of step %d is unusable (flags %d: 1 = overflow, 2 = an "
+                               "occurrence list out of position order)" % (c, self._counts_c[at + 3]))
         if os.environ.get("HA_QHINT") == "0":
             return -1
-        at = 4 * (c % self.COUNTS)
         w, cp = self._counts_c[at], self._counts_c[at + 2]
         return w + cp - 2 if w > 0 and cp > 0 else -1
 
@@ -967,6 +980,9 @@ class QueueStepPipeline:
                 for i in range(cnt):
                     at = 4 * ((k0 + i) % ring)
                     w, cp = counts[at], counts[at + 2]
+                    if counts[at + 3]:
+                        raise RuntimeError("ha_qqueue_batch: the work queue of step %d is unusable (flags %d: 1 = overflow, "
+                                           "2 = an occurrence list out of position order)" % (k0 + i, counts[at + 3]))
                     if w > 0 and cp > 0:
                         self._last_items = w + cp - 2
                     # the queue of this step may not be built yet when the host is far ahead of the device: item counts

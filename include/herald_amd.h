@@ -494,7 +494,18 @@ int ha_debug_step_fwd_timeline(float *table, int64_t rows, int64_t width,
  * the serial chain for every run length use ha_step_*.
  * A queue is ha_qstep_queue_bytes(n_cap, width) bytes (no initialisation); queue_n_cap = the n_cap it was sized with.
  * Limits: at most ha_qstep_max_ids() ids per batch, width % 4 == 0, table / grads / next_out 16-byte aligned.  ids / n /
- * plans / queues arguments of the batch calls are HOST arrays of `count` entries (device pointers inside). */
+ * plans / queues arguments of the batch calls are HOST arrays of `count` entries (device pointers inside).
+ * CALLER REQUIREMENT (lookahead): step c reads queue c, which is built from the plans of batches c and c+1 -- the ids of
+ * batch c+1 must be on the device before queue c is built, and the queue must be complete before ha_qapply(c) starts.
+ * The serial forms need the ids 3 batches ahead; the block-pipelined schedule of ops.QueueStepPipeline (plans of block
+ * b+2 and queues of block b+1 beside the steps of block b) needs them 3 * block batches ahead (48 at bench.py's block of
+ * 16).  The reference's dataloader contract is one batch ahead in a 3-deep ring (python/hetu/dataloader.py:63-98) and
+ * laia's queue is 5 deep: a caller that cannot name its ids that far ahead uses ha_step_* (3 batches) or
+ * ha_sgd_push_pull_* (1 batch).
+ * ha_qstep_init: per-device set-up (LDS attributes of the plan / queue kernels, the lane-order probe of the LDS atomics:
+ * one small synchronous launch on the null stream), to be called once per device OUTSIDE any stream capture; the entry
+ * points do the same lazily on their first call.  Returns 1 (atomic ranking), 0 (ballot ranking; HA_QSTEP_BALLOT=1) or -1. */
+int ha_qstep_init(void);
 int64_t ha_qstep_max_ids(void);
 size_t ha_qstep_queue_bytes(int64_t n_cap, int64_t width);
 int ha_qplan_batch_f32ids(const float *const *ids, const int64_t *n, void *const *plans, int64_t count,
@@ -509,8 +520,12 @@ int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t
 /* ha_qapply with the number of wave items of the queue (wave + copy items; -1 = unknown) when the caller knows it: the launch
  * then has no workgroups that find nothing.  A hint only: too small a number costs time (the waves loop over the items), never
  * correctness.  ha_qqueue_batch_counts = ha_qqueue_batch that also writes {wave items + 1, workgroup items + 1, copy items + 1}
- * of step k's queue to three pinned host words counts_host[k] (0 = not built yet; the caller zeroes them before the call):
- * queues are built a block of steps ahead, so the host usually has the numbers when it enqueues the step. */
+ * of step k's queue to the first three of FOUR pinned host words counts_host[k] (0 = not built yet; the caller zeroes
+ * them before the call): queues are built a block of steps ahead, so the host usually has the numbers when it enqueues
+ * the step.  The fourth word is only ever written non-zero: bit 0 = the builder counted more items than the queue
+ * holds (excluded by the layout's bounds), bit 1 = a plan's occurrence list was not in position order (the serial
+ * chain's order; excluded on hardware whose LDS atomics the probe of ha_qstep_init accepted).  Either is a bug: the
+ * caller must fail loudly (ops.QueueStepPipeline raises). */
 int ha_qapply_sized(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
                     float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
                     int64_t queue_n_cap, int64_t wave_items, ha_stream_t stream);
@@ -542,7 +557,8 @@ int ha_qstep_u64ids(float *table, int64_t rows, int64_t width,
                     void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
                     void *plan_b1, int64_t n_b1, void *queue_build, int64_t queue_n_cap,
                     const uint64_t *ahead_ids, int64_t n_ahead, void *plan_ahead, ha_stream_t stream);
-/* a built queue's first words (device memory): {wave items, workgroup items, long, medium, small, copy items} */
+/* a built queue's first words (device memory): {wave items, workgroup items, long, medium, small, copy items, copy
+ * medium, copy small, overflow / order word of the apply part, overflow word of the copy part} */
 const uint32_t *ha_qstep_queue_header(const void *queue);
 /* development aids (tools/qstep_timeline.py): the items of a step with per-wave time stamps, dbg = device
  * uint64[(workgroups) * 16 * 4], zeroed; one plan + one queue with the phase stamps of their workgroups, ph = device

@@ -12,7 +12,7 @@ import torch
 
 from herald_amd import cache as hcache
 from herald_amd import ops, synth
-from oracle import cache_model, cpu
+from oracle import cache_model, cpu, qstep_model
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 sys.path.insert(0, GOLD)
@@ -128,8 +128,8 @@ def _check_table(table, keys_all, compact, dev):
 
 
 def test_one_launch_push_pull_step_on_the_full_table(dev, big_table):
-    """The kernel bench.py times by default (ha_sgd_push_pull_f32ids = ha::step_kernel: in-launch hand-off through
-    the pending tables, its own row addressing and `sc1` loads) on the 69.1 GB table: an 8-batch Criteo stream,
+    """ha_sgd_push_pull_f32ids = ha::step_kernel (bench.py --engine handoff; round 2's default: in-launch hand-off
+    through the pending tables, its own row addressing and `sc1` loads) on the 69.1 GB table: an 8-batch Criteo stream,
     every output row of every step, the touched rows, the sentinels, the pending tables drained and no hand-off
     time-out -- rows beyond the 4 GiB / 64 GiB byte offsets, float32 ids above 2^24."""
     table = big_table
@@ -187,6 +187,90 @@ def test_lookahead_step_pipeline_on_the_full_table(dev, big_table):
         np.testing.assert_array_equal(pl.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, u.astype(np.int64))
         np.testing.assert_array_equal(pl.counts().cpu().numpy().astype(np.int64), cnt)
     _check_table(table, keys_all, compact, dev)
+    _restore(table, keys_all, dev)
+
+
+@pytest.mark.parametrize("overlap,block,count", [(True, 16, 20), (False, 1, 9)], ids=["side_stream_block16", "one_stream"])
+def test_queue_step_on_the_full_table(dev, big_table, overlap, block, count):
+    """THE KERNEL bench.py TIMES BY DEFAULT -- ha::qapply_kernel behind ops.QueueStepPipeline (csrc/qstep.hip) -- on the
+    table bench.py uses: 33,762,577 x 512 fp32 (69.1 GB), Criteo batches of 6,656 float32 ids reaching beyond 2^24, rows
+    beyond the 4 GiB and 64 GiB byte offsets.  As bench.py drives it (blocks of 16 prepared on a side stream; the stream
+    of 20 batches crosses a block boundary) and in the serial form.  Every lookup row of every step
+      * bit for bit against oracle/qstep_model.py (the kernel's floating-point order), and
+      * against the reference's serial chain (oracle/cpu.py, pinned to the compiled cpu_SGDOptimizerSparseUpdate,
+        /root/reference/src/dnnl_ops/Optimizers.cpp:51-74; lookups: EmbeddingLookup.cpp:16-35): bit-exact for every key
+        that never had 16 or more occurrences in a batch, within 1e-5 x lr x sum|g| (BASELINE.json) for the others;
+    the plans group by group against np.unique, the touched rows and the sentinels at the end.  Prints the observed
+    maximum of |tree - chain| / (lr x sum|g|) over the tolerance-class rows."""
+    table = big_table
+    REL = 1e-5
+    batches, keys_all, grads, cids = _stream_inputs(count, first=500 if overlap else 600, seed=14 + block)
+    n = BATCH * FIELDS
+    model_t = formula.rows_of(keys_all, WIDTH)        # kernel order, on the compact table of the touched rows
+    exact_t = model_t.copy()                          # the reference's chain
+    lr = 0.01
+    drift = {}                                        # compact row -> accumulated tolerance (float64 per column)
+    worst = worst_g = 0.0
+    pipe = ops.QueueStepPipeline(table, n, lr, block=block, overlap=overlap)
+    L = pipe.LOOKAHEAD
+    d_ids = [torch.from_numpy(f).to(dev) for f in batches]
+    out = pipe.start(d_ids[:L])
+    for b in range(count):
+        torch.cuda.synchronize()
+        ci = cids[b].astype(np.int64)
+        got = out.cpu().numpy().reshape(-1, WIDTH)
+        np.testing.assert_array_equal(got, model_t[ci], err_msg="rows of batch %d (kernel order)" % b)
+        want = exact_t[ci]
+        loose = np.array([int(c) in drift for c in ci])
+        np.testing.assert_array_equal(got[~loose], want[~loose], err_msg="rows of batch %d without a long run: bit-exact" % b)
+        for j in np.flatnonzero(loose):
+            d = np.abs(got[j].astype(np.float64) - want[j].astype(np.float64))
+            assert (d <= drift[int(ci[j])] + REL * np.abs(want[j])).all(), "batch %d position %d off by %g" % (b, j, d.max())
+        qstep_model.sgd_sparse_update(model_t, ci, grads[b], lr)
+        cpu.sgd_sparse_update(exact_t, cids[b], grads[b], lr)
+        for key, bound in qstep_model.tolerance(ci, grads[b], lr, keys_all.size, REL).items():
+            if bound.any():
+                drift[key] = drift.get(key, 0) + bound
+        out = pipe.step(torch.from_numpy(grads[b]).to(dev), d_ids[b + L] if b + L < count else None)
+        torch.cuda.synchronize()
+        # the plan of batch b: np.unique's relations with the groups in hash-slot order
+        pl = pipe.plan_of(b)
+        keys = cpu.ids_to_keys(batches[b]).astype(np.int64)
+        u, cnt = np.unique(keys, return_counts=True)
+        assert pl.n_unique() == u.size
+        got_u = pl.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        order = np.argsort(got_u)
+        np.testing.assert_array_equal(got_u[order], u, err_msg="unique keys of batch %d" % b)
+        np.testing.assert_array_equal(pl.counts().cpu().numpy().astype(np.int64)[order], cnt, err_msg="dedup counts of batch %d" % b)
+        np.testing.assert_array_equal(got_u[pl.inverse().cpu().numpy().astype(np.int64)], keys, err_msg="inverse of batch %d" % b)
+        perm = pl.perm().cpu().numpy().astype(np.int64)
+        seg = pl.seg().cpu().numpy().astype(np.int64)
+        np.testing.assert_array_equal(keys[perm], np.repeat(got_u, pl.counts().cpu().numpy()), err_msg="occurrence lists of batch %d" % b)
+        inside = np.ones(keys.size, bool)
+        inside[seg[:u.size]] = False
+        assert (np.diff(perm)[inside[1:]] > 0).all(), "occurrence order of batch %d" % b
+    assert out is None and not pipe.overflowed()
+    got_t = table[torch.from_numpy(keys_all.astype(np.int64)).to(dev)].cpu().numpy()
+    np.testing.assert_array_equal(got_t, model_t, err_msg="touched rows (kernel order)")
+    loose = np.zeros(keys_all.size, bool)
+    loose[list(drift.keys())] = True
+    assert loose.any() and not loose.all()
+    np.testing.assert_array_equal(got_t[~loose], exact_t[~loose], err_msg="touched rows without a long run: the serial chain")
+    for j in np.flatnonzero(loose):
+        d = np.abs(got_t[j].astype(np.float64) - exact_t[j].astype(np.float64))
+        assert (d <= drift[j] + REL * np.abs(exact_t[j])).all(), "row %d off by %g" % (keys_all[j], d.max())
+        worst = max(worst, float((d / (drift[j] / REL + np.abs(exact_t[j]))).max()))
+        worst_g = max(worst_g, float((d / np.maximum(drift[j] / REL, 1e-30)).max()))
+    # (the rows of this table are ~1e2 and lr x sum|g| ~1e-1: one ulp of a row is already 6e-5 of the accumulated
+    # gradient, so the figure relative to the gradient alone is dominated by the final subtraction's rounding)
+    print("queue step on the full table (%s): %d tolerance-class rows, max |tree - chain| / (lr * sum|g| + |row|) = %.3g "
+          "(bound %.0e); relative to lr * sum|g| alone: %.3g" % ("block %d" % block if overlap else "serial",
+                                                                 int(loose.sum()), worst, REL, worst_g))
+    assert worst <= REL
+    assert not np.array_equal(model_t, formula.rows_of(keys_all, WIDTH))
+    sent = table[torch.tensor(SENTINELS, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(sent, formula.rows_of(SENTINELS, WIDTH), err_msg="untouched sentinel rows")
+    del pipe
     _restore(table, keys_all, dev)
 
 
