@@ -151,6 +151,12 @@ def _declare(L):
         "ha_shard_frames_serve_push": [vp, i64, i64, vp, c.c_int, i64, vp, vp, vp],
         "ha_shard_frames_pack_batch": [vp, vp, c.c_int, vp, c.c_int, i64, i64, vp, vp, vp, vp],
         "ha_shard_frames_unpack_batch": [vp, c.c_int, c.c_int, i64, i64, vp, vp, vp],
+        "ha_shard_frames_pack_batch_sized": [vp, vp, c.c_int, vp, c.c_int, c.c_int, i64, i64, vp, vp, vp, vp, vp, vp],
+        "ha_shard_frames_unpack_batch_sized": [vp, c.c_int, c.c_int, i64, i64, vp, vp, vp, vp],
+        "ha_shard_sized_serve_pull": [vp, i64, i64, vp, c.c_int, c.c_int, i64, vp, vp, vp],
+        "ha_gather2_u32map": [vp, i64, vp, i64, i64, vp, i64, vp, vp],
+        "ha_shard_sized_serve_push": [vp, i64, i64, vp, c.c_int, c.c_int, i64, vp, i64, vp, vp, vp],
+        "ha_push_apply_scaled_finished": [vp, i64, i64, vp, i64, vp, f32, vp],
         "ha_plan_build_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_plan_build_batch_u64ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_shard_frames_serve_pull": [vp, i64, i64, vp, c.c_int, i64, i64, vp, vp, vp, vp],

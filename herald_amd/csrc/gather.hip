@@ -166,6 +166,94 @@ extern "C" int ha_gather_u64ids(const float *table, int64_t rows, int64_t width,
                                        ha::as_stream(stream));
 }
 
+// out[i,:] = (map[i] & 0x80000000) ? table[map[i] & 0x7FFFFFFF,:] : recv[map[i],:]; an index beyond its array reads as
+// a zero row.  The expand of a sized pull (shard.hip): positions whose key THIS rank owns read the table itself, the
+// others the rows received from their owners -- PSAgent::vecPullSparse's scatter of the returned rows to all positions
+// (ps-lite/include/ps/psf/sparse.h:17-31).  Same lane mapping as the forward gather (flat 16-byte vectors).
+namespace ha {
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gather2_vec4_kernel(const float *__restrict__ table, uint64_t rows,
+                                                           const float *__restrict__ recv, uint64_t recv_rows, uint32_t nv,
+                                                           const uint32_t *__restrict__ map, uint64_t total_vec,
+                                                           float *__restrict__ out) {
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * (256 * UNROLL) + threadIdx.x;
+    const uint64_t last = total_vec - 1;
+    float4v v[UNROLL];
+    bool ok[UNROLL];
+    uint32_t m[UNROLL];
+    uint64_t col[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        uint64_t e = base + static_cast<uint64_t>(u) * 256;
+        e = e < last ? e : last;
+        const uint64_t i = e / nv;
+        col[u] = e - i * nv;
+        m[u] = map[i];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const bool local = (m[u] & 0x80000000u) != 0;
+        const uint64_t r = m[u] & 0x7FFFFFFFu;
+        ok[u] = r < (local ? rows : recv_rows);
+        const float *src = local ? table : recv;
+        v[u] = ld4(src + ((ok[u] ? r : 0) * nv + col[u]) * 4u);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint64_t e = base + static_cast<uint64_t>(u) * 256;
+        if (e < total_vec)
+            st4_nt(out + e * 4u, ok[u] ? v[u] : float4v{0.f, 0.f, 0.f, 0.f});
+    }
+}
+__global__ __launch_bounds__(256) void gather2_scalar_kernel(const float *__restrict__ table, uint64_t rows,
+                                                             const float *__restrict__ recv, uint64_t recv_rows, uint32_t width,
+                                                             const uint32_t *__restrict__ map, uint64_t total,
+                                                             float *__restrict__ out) {
+    uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
+    for (; e < total; e += stride) {
+        const uint64_t i = e / width, c = e - i * width;
+        const uint32_t m = map[i];
+        const bool local = (m & 0x80000000u) != 0;
+        const uint64_t r = m & 0x7FFFFFFFu;
+        out[e] = r < (local ? rows : recv_rows) ? (local ? table : recv)[r * width + c] : 0.f;
+    }
+}
+}  // namespace ha
+
+extern "C" int ha_gather2_u32map(const float *table, int64_t rows, const float *recv, int64_t recv_rows, int64_t width,
+                                 const uint32_t *map, int64_t n, float *out, ha_stream_t stream) {
+    HA_REQUIRE(rows >= 0 && recv_rows >= 0 && width >= 1 && n >= 0, "gather2: bad sizes");
+    if (n == 0)
+        return 0;
+    HA_REQUIRE(map && out && (table || rows == 0) && (recv || recv_rows == 0), "gather2: null pointer");
+    // a side that has no rows is never dereferenced beyond its clamped row 0: give it a valid address
+    if (!table) table = recv;
+    if (!recv) recv = table;
+    HA_REQUIRE(table != nullptr, "gather2: no source at all");
+    const bool vec_ok = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(recv) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    if (!vec_ok) {
+        const uint64_t total = static_cast<uint64_t>(n) * width;
+        uint64_t blocks = (total + 255) / 256;
+        if (blocks > 16384)
+            blocks = 16384;
+        hipLaunchKernelGGL(ha::gather2_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, ha::as_stream(stream), table,
+                           (uint64_t)rows, recv, (uint64_t)recv_rows, (uint32_t)width, map, total, out);
+        HA_LAUNCH_CHECK();
+        return 0;
+    }
+    const uint32_t nv = static_cast<uint32_t>(width / 4);
+    const uint64_t total_vec = static_cast<uint64_t>(n) * nv;
+    constexpr int UNROLL = 4;
+    const uint64_t blocks64 = (total_vec + 256 * UNROLL - 1) / (256 * UNROLL);
+    HA_REQUIRE(blocks64 < (1ull << 31), "gather2: batch too large");
+    hipLaunchKernelGGL((ha::gather2_vec4_kernel<UNROLL>), dim3(static_cast<unsigned>(blocks64)), dim3(256), 0,
+                       ha::as_stream(stream), table, (uint64_t)rows, recv, (uint64_t)recv_rows, nv, map, total_vec, out);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ha_gather_u32keys(const float *table, int64_t rows,
                                  int64_t width, const uint32_t *keys, int64_t n,
                                  float *out, ha_stream_t stream) {

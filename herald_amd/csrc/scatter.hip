@@ -414,6 +414,21 @@ extern "C" int ha_push_apply(float *table, int64_t rows, int64_t width,
                                            grads, 1.f, ha::as_stream(stream));
 }
 
+// ha_push_apply with every value multiplied by `scale` before it is summed, for a FINISHED plan: table[key,:] +=
+// (0 + scale*g_i0) + scale*g_i1 ... -- worker-side `values *= -lr` + occurrence-ordered reduce + server `+=` of a PS sparse
+// push in ONE launch, bit-identical to ha_dedup_reduce_scaled followed by the server add (ParameterServerCommunicate.py:58-59,
+// PSAgent.h:146-160, PSFHandle.h:130-164).  What a rank does for the keys of a batch that it owns itself when nobody else
+// pushes (herald_amd/sharded.py at world size 1).  Batches beyond 36,864 ids map their waves to unique keys.
+extern "C" int ha_push_apply_scaled_finished(float *table, int64_t rows, int64_t width, void *plan_ws, int64_t n,
+                                             const float *grads, float scale, ha_stream_t stream) {
+    if (n > ha::kSmallMax && n <= ha::kFinishChunkedMax) {
+        HA_REQUIRE(table && plan_ws && grads && width >= 1 && width < (1 << 30), "push_apply_scaled_finished: bad arguments");
+        return ha::apply_by_unique<ha::kModePush>(table, rows, width, plan_ws, n, grads, scale, ha::as_stream(stream),
+                                                  ha::ApplyMaps{nullptr, nullptr, nullptr, nullptr, nullptr});
+    }
+    return ha::apply_launch<ha::kModePush>(table, rows, width, plan_ws, n, grads, scale, ha::as_stream(stream));
+}
+
 extern "C" int ha_dedup_reduce(const void *plan_ws, int64_t n,
                                const float *grads, int64_t width,
                                float *reduced, ha_stream_t stream) {

@@ -744,6 +744,344 @@ extern "C" int ha_shard_frames_serve_push(float *table, int64_t rows, int64_t wi
     return shard_frames_apply(table, rows, width, p.sorted, p.perm, n, values, as_stream(stream));
 }
 
+// ---- sized frames: the same routing, the rows travel in exchanges sized by the REAL counts -----------------------------
+// The key frames above are routed a block of batches ahead of the steps that use them, so the per-owner counts of a
+// batch -- how many unique keys this rank names of every owner (send counts) and how many every peer names of this
+// rank's range (receive counts) -- are on the device a block early; the unpack launch copies them to pinned host
+// memory, and the host sizes the two row exchanges of the step by them without a stall (the reference's messages
+// carry exactly U_s keys and U_s x d floats per server: PSAgent::vecPullSparse / vecPushSparse, ps-lite/include/ps/
+// worker/PSAgent.h:167-172,217-226; ps/psf/sparse.h:9-32).  Rows are laid out COMPACTLY in rank order, and the keys
+// a rank owns itself never enter a row exchange:
+//   meta (int32[2 + 2W], one copy on the device, one in pinned host memory):
+//       [0] any rank overflowed its key frames  [1] keys received  [2 + g] send count g  [2 + W + g] receive count g
+//   pull  owner: rows_out[roff(g) + j] = table[key j of peer g], g != self, roff = running sum of the receive counts of
+//         the peers before g (self excluded)  ->  all-to-all with the real splits  ->  expand by posmap:
+//         posmap[i] = 0x80000000 | shard-local key   (position i names a key of THIS rank: read from the table itself)
+//                   = compact index of its unique key among the unique keys of the other owners, in key order
+//                   = 0xFFFFFFFF (a zero row) beyond the frames
+//   push  reduce by rowmap into ONE buffer of (2W + 1) * rcap rows:  A = [0, W rcap) rows for the other owners, compact
+//         in key order;  S = [W rcap, (W + 1) rcap) this rank's own keys;  B = [(W + 1) rcap, ...) the rows received
+//         (compact, rank order);  all-to-all A -> B with the real splits; owner: merge of the W key lists in rank
+//         order, values of list g at B + roff(g) + j, of this rank's own list at S + j.
+namespace ha {
+
+__device__ __forceinline__ void shard_pack_sized_maps(
+    const PlanHeader *__restrict__ hdr, const uint32_t *__restrict__ uniq, const int32_t *__restrict__ inverse, int n,
+    const ShardStarts &st, int nshard, int self, int rcap, int32_t *__restrict__ rowmap, int32_t *__restrict__ posmap,
+    int32_t *__restrict__ meta_dev, int32_t *__restrict__ meta_host, const int *s_off, int s_flag) {
+    const int U = n > 0 ? static_cast<int>(hdr->n_unique) : 0;
+    if (blockIdx.x == 0 && threadIdx.x < static_cast<unsigned>(nshard)) {
+        const int c = s_off[threadIdx.x + 1] - s_off[threadIdx.x];
+        meta_dev[2 + threadIdx.x] = c;
+        meta_host[2 + threadIdx.x] = c;
+    }
+    const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    const int own0 = s_off[self], own1 = s_off[self + 1];
+    for (int u = tid; u < U; u += stride) {
+        int r = -1;
+        if (!s_flag)
+            r = u < own0 ? u : u < own1 ? nshard * rcap + (u - own0) : u - (own1 - own0);
+        rowmap[u] = r;
+    }
+    for (int i = tid; i < n; i += stride) {
+        const int u = inverse[i];
+        uint32_t e = 0xFFFFFFFFu;
+        if (!s_flag) {
+            const uint32_t local = uniq[u] - st.start[self];       // (the last owner also gets the keys beyond the table)
+            e = u < own0 ? static_cast<uint32_t>(u)
+                         : u < own1 ? (local < 0x7FFFFFFFu ? (0x80000000u | local) : 0xFFFFFFFFu)
+                                    : static_cast<uint32_t>(u - (own1 - own0));
+        }
+        posmap[i] = static_cast<int32_t>(e);
+    }
+}
+
+struct FrameSizedBatch {
+    int32_t *meta_dev[kFrameBatchMax], *meta_host[kFrameBatchMax];
+};
+__global__ __launch_bounds__(256) void shard_pack_sized_batch_kernel(const FramePackBatch b, const FrameSizedBatch m,
+                                                                     ShardStarts st, int nshard, int self, int rcap,
+                                                                     size_t fw, int32_t *__restrict__ send) {
+    __shared__ int s_off[kMaxShards + 1];
+    __shared__ int s_flag;
+    const int i = blockIdx.y;
+    const int n = b.n[i];
+    const int U = n > 0 ? static_cast<int>(b.hdr[i]->n_unique) : 0;
+    if (threadIdx.x <= static_cast<unsigned>(nshard)) {
+        const uint32_t target = st.start[threadIdx.x];
+        int lo = 0, hi = U;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (b.uniq[i][mid] < target)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        s_off[threadIdx.x] = static_cast<int>(threadIdx.x) == nshard ? U : lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int f = 0;
+        for (int g = 0; g < nshard; ++g)
+            f |= (s_off[g + 1] - s_off[g]) > rcap;
+        s_flag = f;
+    }
+    __syncthreads();
+    int32_t *snd = send + static_cast<size_t>(i) * (2 + static_cast<size_t>(rcap));
+    if (blockIdx.x == 0 && threadIdx.x < static_cast<unsigned>(nshard)) {
+        snd[threadIdx.x * fw] = s_off[threadIdx.x + 1] - s_off[threadIdx.x];
+        snd[threadIdx.x * fw + 1] = s_flag;
+    }
+    const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    const int slots = nshard * rcap;
+    for (int p = tid; p < slots; p += stride) {
+        const int g = p / rcap, j = p - g * rcap;
+        const bool live = j < s_off[g + 1] - s_off[g];
+        snd[g * fw + 2 + j] = static_cast<int32_t>(live ? b.uniq[i][s_off[g] + j] - st.start[g] : kNoKey);
+    }
+    shard_pack_sized_maps(b.hdr[i], b.uniq[i], b.inverse[i], n, st, nshard, self, rcap, b.rowmap[i], b.posmap[i],
+                          m.meta_dev[i], m.meta_host[i], s_off, s_flag);
+}
+
+__global__ __launch_bounds__(256) void shard_unpack_sized_batch_kernel(const int32_t *__restrict__ recv, int nshard,
+                                                                       int rcap, size_t fw, const FrameUnpackBatch b,
+                                                                       const FrameSizedBatch m) {
+    const int i = blockIdx.y;
+    const int32_t *rcv = recv + static_cast<size_t>(i) * (2 + static_cast<size_t>(rcap));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int f = 0, total = 0;
+        for (int g = 0; g < nshard; ++g) {
+            const int c = rcv[g * fw];
+            f |= (rcv[g * fw + 1] != 0) | (c > rcap) | (c < 0);
+            const int cc = c < 0 ? 0 : (c > rcap ? rcap : c);
+            total += cc;
+            m.meta_dev[i][2 + nshard + g] = cc;
+            m.meta_host[i][2 + nshard + g] = cc;
+        }
+        m.meta_dev[i][0] = f;
+        m.meta_dev[i][1] = total;
+        m.meta_host[i][1] = total;
+        __threadfence_system();
+        m.meta_host[i][0] = f;          // the word the host polls last
+    }
+    const int slots = nshard * rcap, stride = gridDim.x * 256;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < slots; p += stride) {
+        const int g = p / rcap, j = p - g * rcap;
+        const int c = rcv[g * fw];
+        b.keys_fixed[i][p] = j < c ? static_cast<uint32_t>(rcv[g * fw + 2 + j]) : kNoKey;
+    }
+}
+
+// running sum of the receive counts of the peers before g, this rank's own list excluded (wave-uniform loop, W <= 64)
+__device__ __forceinline__ int shard_roff(const int32_t *__restrict__ meta, int nshard, int self, int g) {
+    int off = 0;
+    for (int t = 0; t < g; ++t)
+        off += t == self ? 0 : meta[2 + nshard + t];
+    return off;
+}
+
+// Owner side of a sized pull: one wave per live slot of the OTHER ranks' key lists (PSHandler::serve(SparsePull),
+// PSFHandle.h:101-128); this rank's own keys are read by the expand straight from the table.
+template <int VEC>
+__global__ __launch_bounds__(256) void shard_serve_pull_sized_kernel(
+    const float *__restrict__ table, uint64_t rows, int width, const uint32_t *__restrict__ keys_fixed, int nshard, int self,
+    int rcap, const int32_t *__restrict__ meta, float *__restrict__ rows_out) {
+    const int lane = threadIdx.x & 63;
+    const int slots = nshard * rcap;
+    const int p = uniform(static_cast<int>(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (p >= slots)
+        return;
+    const int g = p / rcap, j = p - g * rcap;
+    if (g == self || j >= meta[2 + nshard + g])
+        return;
+    const uint32_t key = keys_fixed[p];
+    float *dst = rows_out + static_cast<uint64_t>(shard_roff(meta, nshard, self, g) + j) * static_cast<uint64_t>(width);
+    const bool ok = key < rows;
+    const float *src = table + static_cast<uint64_t>(ok ? key : 0u) * static_cast<uint64_t>(width);
+    if (VEC == 4) {
+        for (int col = 4 * lane; col < width; col += 256) {
+            const float4v v = ok ? ld4(src + col) : float4v{0.f, 0.f, 0.f, 0.f};
+            st4_nt(dst + col, v);
+        }
+    } else {
+        for (int col = lane; col < width; col += 64)
+            dst[col] = ok ? src[col] : 0.f;
+    }
+}
+
+// Merge of the W received key lists (each ascending over its first count_g slots) in rank order, as
+// shard_merge_rank_kernel, over the LIVE slots only and with the value row of every entry: sorted[rank] = key,
+// perm[rank] = row of the push buffer that holds the entry's values.  The lists sit in LDS where they fit (lds != 0).
+__global__ __launch_bounds__(256) void shard_merge_rank_sized_kernel(const uint32_t *__restrict__ keys, int nshard, int self,
+                                                                     int rcap, const int32_t *__restrict__ meta, int lds,
+                                                                     uint32_t *__restrict__ sorted, int32_t *__restrict__ perm) {
+    extern __shared__ uint32_t s_keys[];
+    const int slots = nshard * rcap;
+    if (lds) {
+        for (int q = threadIdx.x; q < slots; q += 256)
+            s_keys[q] = keys[q];
+        __syncthreads();
+    }
+    const uint32_t *kk = lds ? s_keys : keys;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= slots)
+        return;
+    const int s = p / rcap, j = p - s * rcap;
+    if (j >= meta[2 + nshard + s])
+        return;
+    const uint32_t key = kk[p];
+    int rank = j;
+    for (int t = 0; t < nshard; ++t) {
+        if (t == s)
+            continue;
+        const uint32_t *list = kk + t * rcap;
+        int lo = 0, hi = meta[2 + nshard + t];
+        if (t < s) {            // upper bound: equal keys of earlier ranks come first
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (list[mid] <= key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+        } else {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (list[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+        }
+        rank += lo;
+    }
+    sorted[rank] = key;
+    perm[rank] = s == self ? nshard * rcap + j : (nshard + 1) * rcap + shard_roff(meta, nshard, self, s) + j;
+}
+
+}  // namespace ha
+
+extern "C" int ha_shard_frames_pack_batch_sized(const void *const *plan_ws, const int64_t *n, int count,
+                                                const int64_t *starts_host, int nshard, int self, int64_t rcap,
+                                                int64_t frame_stride, int32_t *send, int32_t *const *rowmap,
+                                                int32_t *const *posmap, int32_t *const *meta_dev,
+                                                int32_t *const *meta_host, ha_stream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (plan_ws && n && send && rowmap && posmap && meta_dev && meta_host)) &&
+                   starts_host, "shard_frames_pack_batch_sized: null pointer");
+    HA_REQUIRE(rcap >= 1 && static_cast<int64_t>(2 * nshard + 1) * rcap < (1ll << 30) && frame_stride >= count * (2 + rcap) &&
+                   self >= 0 && self < nshard, "shard_frames_pack_batch_sized: bad sizes");
+    ShardStarts st;
+    if (shard_starts_of(starts_host, nshard, &st, "shard_frames_pack_batch_sized"))
+        return -1;
+    HA_REQUIRE(starts_host[self + 1] - starts_host[self] < (1ll << 31), "shard_frames_pack_batch_sized: a shard holds at most 2^31 rows");
+    for (int at = 0; at < count; at += kFrameBatchMax) {
+        const int m = count - at < kFrameBatchMax ? count - at : kFrameBatchMax;
+        FramePackBatch b;
+        FrameSizedBatch ms;
+        memset(&b, 0, sizeof(b));
+        memset(&ms, 0, sizeof(ms));
+        int64_t work = static_cast<int64_t>(nshard) * rcap;
+        for (int i = 0; i < m; ++i) {
+            HA_REQUIRE(plan_ws[at + i] && n[at + i] >= 0 && rowmap[at + i] && posmap[at + i] && meta_dev[at + i] &&
+                           meta_host[at + i], "shard_frames_pack_batch_sized: bad batch %d", at + i);
+            PlanPtrs p = plan_layout(const_cast<void *>(plan_ws[at + i]), n[at + i] > 0 ? n[at + i] : 1);
+            b.hdr[i] = p.hdr; b.uniq[i] = p.uniq; b.inverse[i] = p.inverse;
+            b.n[i] = static_cast<int>(n[at + i]);
+            b.rowmap[i] = rowmap[at + i];
+            b.posmap[i] = posmap[at + i];
+            ms.meta_dev[i] = meta_dev[at + i];
+            ms.meta_host[i] = meta_host[at + i];
+            work = n[at + i] > work ? n[at + i] : work;
+        }
+        int blocks = static_cast<int>((work + 255) / 256);
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+        hipLaunchKernelGGL(shard_pack_sized_batch_kernel, dim3(blocks, m), dim3(256), 0, as_stream(stream), b, ms, st, nshard,
+                           self, static_cast<int>(rcap), static_cast<size_t>(frame_stride),
+                           send + static_cast<size_t>(at) * (2 + static_cast<size_t>(rcap)));
+        HA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int ha_shard_frames_unpack_batch_sized(const int32_t *recv, int count, int nshard, int64_t rcap,
+                                                  int64_t frame_stride, uint32_t *const *keys_fixed,
+                                                  int32_t *const *meta_dev, int32_t *const *meta_host,
+                                                  ha_stream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (recv && keys_fixed && meta_dev && meta_host)),
+               "shard_frames_unpack_batch_sized: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && rcap >= 1 && static_cast<int64_t>(nshard) * rcap < (1ll << 30) &&
+                   frame_stride >= count * (2 + rcap), "shard_frames_unpack_batch_sized: bad sizes");
+    for (int at = 0; at < count; at += kFrameBatchMax) {
+        const int m = count - at < kFrameBatchMax ? count - at : kFrameBatchMax;
+        FrameUnpackBatch b;
+        FrameSizedBatch ms;
+        memset(&b, 0, sizeof(b));
+        memset(&ms, 0, sizeof(ms));
+        for (int i = 0; i < m; ++i) {
+            HA_REQUIRE(keys_fixed[at + i] && meta_dev[at + i] && meta_host[at + i], "shard_frames_unpack_batch_sized: bad batch %d",
+                       at + i);
+            b.keys_fixed[i] = keys_fixed[at + i];
+            ms.meta_dev[i] = meta_dev[at + i];
+            ms.meta_host[i] = meta_host[at + i];
+        }
+        long long want = (static_cast<long long>(nshard) * rcap + 255) / 256;
+        const int blocks = want < 1 ? 1 : (want > 64 ? 64 : static_cast<int>(want));
+        hipLaunchKernelGGL(shard_unpack_sized_batch_kernel, dim3(blocks, m), dim3(256), 0, as_stream(stream),
+                           recv + static_cast<size_t>(at) * (2 + static_cast<size_t>(rcap)), nshard, static_cast<int>(rcap),
+                           static_cast<size_t>(frame_stride), b, ms);
+        HA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int ha_shard_sized_serve_pull(const float *table, int64_t rows, int64_t width, const uint32_t *keys_fixed,
+                                         int nshard, int self, int64_t rcap, const int32_t *meta_dev, float *rows_out,
+                                         ha_stream_t stream) {
+    HA_REQUIRE(table && keys_fixed && meta_dev && rows_out, "shard_sized_serve_pull: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && self >= 0 && self < nshard && rcap >= 1 &&
+                   static_cast<int64_t>(nshard) * rcap < (1ll << 30) && rows >= 0 && width >= 1 && width < (1 << 30),
+               "shard_sized_serve_pull: bad sizes");
+    if (nshard == 1)
+        return 0;      // nobody else to serve
+    const unsigned blocks = static_cast<unsigned>((static_cast<int64_t>(nshard) * rcap + 3) / 4);
+    const bool vec = width % 4 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(rows_out) % 16 == 0;
+    if (vec)
+        hipLaunchKernelGGL(shard_serve_pull_sized_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), table,
+                           static_cast<uint64_t>(rows), static_cast<int>(width), keys_fixed, nshard, self,
+                           static_cast<int>(rcap), meta_dev, rows_out);
+    else
+        hipLaunchKernelGGL(shard_serve_pull_sized_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), table,
+                           static_cast<uint64_t>(rows), static_cast<int>(width), keys_fixed, nshard, self,
+                           static_cast<int>(rcap), meta_dev, rows_out);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Owner side of a sized push: `total` = the keys received (host-known: the sum of the receive counts), push_buf = the
+// (2W + 1) * rcap-row buffer described above, plan_ws: ha_plan_bytes(nshard * rcap) of scratch.
+extern "C" int ha_shard_sized_serve_push(float *table, int64_t rows, int64_t width, const uint32_t *keys_fixed, int nshard,
+                                         int self, int64_t rcap, const int32_t *meta_dev, int64_t total,
+                                         const float *push_buf, void *plan_ws, ha_stream_t stream) {
+    HA_REQUIRE(table && keys_fixed && meta_dev && push_buf && plan_ws, "shard_sized_serve_push: null pointer");
+    HA_REQUIRE(nshard >= 1 && nshard <= kMaxShards && self >= 0 && self < nshard && rcap >= 1 &&
+                   static_cast<int64_t>(2 * nshard + 1) * rcap < (1ll << 30) && total >= 0 &&
+                   total <= static_cast<int64_t>(nshard) * rcap, "shard_sized_serve_push: bad sizes");
+    if (total == 0)
+        return 0;
+    const int64_t slots = static_cast<int64_t>(nshard) * rcap;
+    if (nshard == 1)       // this rank's own list IS the merged order: distinct keys, values in region S
+        return shard_frames_apply(table, rows, width, keys_fixed, nullptr, total,
+                                  push_buf + static_cast<size_t>(rcap) * static_cast<size_t>(width), as_stream(stream));
+    PlanPtrs p = plan_layout(plan_ws, slots);
+    const size_t lds = static_cast<size_t>(slots) * 4 <= (size_t(64) << 10) ? static_cast<size_t>(slots) * 4 : 0;
+    hipLaunchKernelGGL(shard_merge_rank_sized_kernel, dim3(static_cast<unsigned>((slots + 255) / 256)), dim3(256), lds,
+                       as_stream(stream), keys_fixed, nshard, self, static_cast<int>(rcap), meta_dev, lds ? 1 : 0, p.sorted,
+                       p.perm);
+    HA_LAUNCH_CHECK();
+    return shard_frames_apply(table, rows, width, p.sorted, p.perm, total, push_buf, as_stream(stream));
+}
+
 // ---- owner side of the cache protocol over a sharded / host-resident store --------------------------------
 // kSyncEmbedding (ps-lite/src/PSFhandle_embedding.cc:30-64): for every requested (key, client version) the
 // server answers "pull" when the client has no data (version -1) or lags by more than the bound, and then

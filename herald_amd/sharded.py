@@ -220,8 +220,11 @@ class HipEngine:
             fb.keys_fixed = torch.empty(w * rcap, dtype=torch.int32, device=self.device)
             fb.rowmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
             fb.posmap = torch.empty(max(n_cap, 1), dtype=torch.int32, device=self.device)
-            fb.state_host = torch.zeros(2, dtype=torch.int32).pin_memory()    # written by the kernels directly
-            fb.state_c = (ctypes.c_int32 * 2).from_address(fb.state_host.data_ptr())
+            # {overflow, keys received, send counts[w], receive counts[w]}: written by the routing kernels straight to
+            # pinned host memory (sized frames read all of it, fixed frames the first two words), and its device copy
+            fb.state_host = torch.zeros(2 + 2 * w, dtype=torch.int32).pin_memory()
+            fb.state_c = (ctypes.c_int32 * (2 + 2 * w)).from_address(fb.state_host.data_ptr())
+            fb.meta_dev = torch.zeros(2 + 2 * w, dtype=torch.int32, device=self.device)
             fb.n, fb.ids, fb.shape, fb.routed = 0, None, (0,), False
             blk.slots.append(fb)
         return blk
@@ -252,10 +255,11 @@ class HipEngine:
                                                    fb.keys_fixed.data_ptr(), fb.state_host.data_ptr(), self._stream()),
                    "ha_shard_frames_unpack")
 
-    def frames_route_block(self, blk, starts, exchange):
+    def frames_route_block(self, blk, starts, exchange, sized_rank=None):
         """The routing of a block of batches in four launches and one key exchange: plans (two launches for all batches
         of one id dtype), key frames + maps (one), `exchange(krecv, ksend)` -> the received frames, received keys and
-        overflow words (one).  Slots without a batch send empty frames."""
+        overflow words (one).  Slots without a batch send empty frames.  sized_rank = this rank: the SIZED maps and the
+        per-owner counts (device + pinned host) instead of the fixed-frame maps."""
         vp = ctypes.c_void_p
         slots = blk.slots
         for kind, fn in ((torch.float32, self.lib.ha_plan_build_batch_f32ids_lim),
@@ -272,17 +276,28 @@ class HipEngine:
         cnt = len(slots)
         fb0 = slots[0]
         st = (ctypes.c_int64 * len(starts))(*starts)
-        self.check(self.lib.ha_shard_frames_pack_batch((vp * cnt)(*[fb.plan.ws.data_ptr() for fb in slots]),
-                                                       (ctypes.c_int64 * cnt)(*[fb.n for fb in slots]), cnt, st, fb0.w,
-                                                       fb0.rcap, fb0.stride, blk.ksend.data_ptr(),
-                                                       (vp * cnt)(*[fb.rowmap.data_ptr() for fb in slots]),
-                                                       (vp * cnt)(*[fb.posmap.data_ptr() for fb in slots]), self._stream()),
-                   "ha_shard_frames_pack_batch")
+        plans = (vp * cnt)(*[fb.plan.ws.data_ptr() for fb in slots])
+        ns = (ctypes.c_int64 * cnt)(*[fb.n for fb in slots])
+        rowmaps = (vp * cnt)(*[fb.rowmap.data_ptr() for fb in slots])
+        posmaps = (vp * cnt)(*[fb.posmap.data_ptr() for fb in slots])
+        keysf = (vp * cnt)(*[fb.keys_fixed.data_ptr() for fb in slots])
+        hosts = (vp * cnt)(*[fb.state_host.data_ptr() for fb in slots])
+        if sized_rank is None:
+            self.check(self.lib.ha_shard_frames_pack_batch(plans, ns, cnt, st, fb0.w, fb0.rcap, fb0.stride,
+                                                           blk.ksend.data_ptr(), rowmaps, posmaps, self._stream()),
+                       "ha_shard_frames_pack_batch")
+            blk.kgot = exchange(blk.krecv, blk.ksend)
+            self.check(self.lib.ha_shard_frames_unpack_batch(blk.kgot.data_ptr(), cnt, fb0.w, fb0.rcap, fb0.stride, keysf,
+                                                             hosts, self._stream()), "ha_shard_frames_unpack_batch")
+            return
+        metas = (vp * cnt)(*[fb.meta_dev.data_ptr() for fb in slots])
+        self.check(self.lib.ha_shard_frames_pack_batch_sized(plans, ns, cnt, st, fb0.w, int(sized_rank), fb0.rcap, fb0.stride,
+                                                             blk.ksend.data_ptr(), rowmaps, posmaps, metas, hosts,
+                                                             self._stream()), "ha_shard_frames_pack_batch_sized")
         blk.kgot = exchange(blk.krecv, blk.ksend)
-        self.check(self.lib.ha_shard_frames_unpack_batch(blk.kgot.data_ptr(), cnt, fb0.w, fb0.rcap, fb0.stride,
-                                                         (vp * cnt)(*[fb.keys_fixed.data_ptr() for fb in slots]),
-                                                         (vp * cnt)(*[fb.state_host.data_ptr() for fb in slots]),
-                                                         self._stream()), "ha_shard_frames_unpack_batch")
+        self.check(self.lib.ha_shard_frames_unpack_batch_sized(blk.kgot.data_ptr(), cnt, fb0.w, fb0.rcap, fb0.stride, keysf,
+                                                               metas, hosts, self._stream()),
+                   "ha_shard_frames_unpack_batch_sized")
 
     def frames_overflowed(self, fb):
         return fb.state_c[0] != 0
@@ -320,6 +335,72 @@ class HipEngine:
         self.check(self.lib.ha_shard_frames_serve_push(table.data_ptr(), table.shape[0], table.shape[1],
                                                        fb.keys_fixed.data_ptr(), fb.w, fb.rcap, rows_recv.data_ptr(),
                                                        p.ws.data_ptr(), self._stream()), "ha_shard_frames_serve_push")
+
+    # -- sized frames: rows in compact rank-ordered lists, exchanges sized by the real counts, own keys served locally ----
+    def frames_counts(self, fb):
+        """(send counts, receive counts) of a routed batch from the pinned words its routing wrote (host; call behind
+        the block's event)."""
+        w, c = fb.w, fb.state_c
+        return [c[2 + g] for g in range(w)], [c[2 + w + g] for g in range(w)]
+
+    def sized_serve_pull_call(self, table, fb, rank, rows_send):
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        return self._call(self.lib.ha_shard_sized_serve_pull, "ha_shard_sized_serve_pull", vp(table.data_ptr()),
+                          i64(table.shape[0]), i64(table.shape[1]), vp(fb.keys_fixed.data_ptr()), ctypes.c_int(fb.w),
+                          ctypes.c_int(rank), i64(fb.rcap), vp(fb.meta_dev.data_ptr()), vp(rows_send.data_ptr()),
+                          vp(self._stream()))
+
+    def sized_expand_call(self, table, rows_recv, fb, out):
+        """out[i, :] = the row of position i: from this rank's own shard, or from the rows the owners sent."""
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        return self._call(self.lib.ha_gather2_u32map, "ha_gather2_u32map", vp(table.data_ptr()), i64(table.shape[0]),
+                          vp(rows_recv.data_ptr()), i64(rows_recv.shape[0]), i64(table.shape[1]), vp(fb.posmap.data_ptr()),
+                          i64(fb.n), vp(out.data_ptr()), vp(self._stream()))
+
+    def sized_reduce_call(self, fb, values, scale, push_buf, zero_flags):
+        """Occurrence-ordered reduce of scale * values by unique key straight into the push buffer (region A: keys of
+        the other owners, compact; region S: this rank's own keys)."""
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        return self._call(self.lib.ha_apply_mapped, "ha_apply_mapped", vp(push_buf.data_ptr()), i64(push_buf.shape[0]),
+                          i64(push_buf.shape[1]), vp(fb.plan.ws.data_ptr()), i64(fb.n), vp(values.data_ptr()),
+                          ctypes.c_float(-scale), vp(fb.rowmap.data_ptr()), vp(None), vp(zero_flags.data_ptr()),
+                          vp(self._stream()))
+
+    def sized_serve_push_call(self, table, fb, rank, total, push_buf):
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        m = fb.w * fb.rcap
+        p = self._owner_plan
+        if p is None or p.capacity < m:
+            p = self._owner_plan = self.ops.IndexPlan(m + 16, self.device)
+        return self._call(self.lib.ha_shard_sized_serve_push, "ha_shard_sized_serve_push", vp(table.data_ptr()),
+                          i64(table.shape[0]), i64(table.shape[1]), vp(fb.keys_fixed.data_ptr()), ctypes.c_int(fb.w),
+                          ctypes.c_int(rank), i64(fb.rcap), vp(fb.meta_dev.data_ptr()), i64(total), vp(push_buf.data_ptr()),
+                          vp(p.ws.data_ptr()), vp(self._stream()))
+
+    def sized_push_alone_call(self, table, fb, values, scale):
+        """World size 1: reduce + server add of the batch in one launch (every key is this rank's own)."""
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        return self._call(self.lib.ha_push_apply_scaled_finished, "ha_push_apply_scaled_finished", vp(table.data_ptr()),
+                          i64(table.shape[0]), i64(table.shape[1]), vp(fb.plan.ws.data_ptr()), i64(fb.n),
+                          vp(values.data_ptr()), ctypes.c_float(scale), vp(self._stream()))
+
+    def sized_serve_pull(self, table, fb, rank, rows_send):
+        self.sized_serve_pull_call(table, fb, rank, rows_send)()
+
+    def sized_expand(self, table, rows_recv, fb, out):
+        if fb.n:
+            self.sized_expand_call(table, rows_recv, fb, out)()
+
+    def sized_reduce(self, fb, values, scale, push_buf, zero_flags):
+        if fb.n:
+            self.sized_reduce_call(fb, values, scale, push_buf, zero_flags)()
+
+    def sized_serve_push(self, table, fb, rank, total, push_buf):
+        self.sized_serve_push_call(table, fb, rank, total, push_buf)()
+
+    def sized_push_alone(self, table, fb, values, scale):
+        if fb.n:
+            self.sized_push_alone_call(table, fb, values, scale)()
 
     # the same launches as callables with their arguments converted once (a step is five launches of 4-9 us: converting
     # the arguments through ctypes on every call costs more host time than the kernels take)
@@ -386,8 +467,8 @@ class FrameBlock:
 
 class FrameBuffers:
     """Per-batch buffers inside a FrameBlock."""
-    __slots__ = ("i", "w", "rcap", "stride", "plan", "keys_fixed", "rowmap", "posmap", "state_host", "state_c", "ids", "n",
-                 "shape", "routed")
+    __slots__ = ("i", "w", "rcap", "stride", "plan", "keys_fixed", "rowmap", "posmap", "state_host", "state_c", "meta_dev",
+                 "ids", "n", "shape", "routed", "send_cnt", "recv_cnt", "pos_local")
 
 
 class RouteBuffers:
@@ -649,7 +730,13 @@ class FramedStep:
     beside the steps only if the store has a second communicator (side_group=True); otherwise at the block start on
     the caller's stream."""
 
-    def __init__(self, emb, max_ids, row_cap=None, block=8, graphs=True):
+    def __init__(self, emb, max_ids, row_cap=None, block=8, graphs=True, sized=None):
+        """sized (default: on unless graphs): the row exchanges carry exactly the rows the batch names -- the per-owner
+        counts of a batch reach pinned host memory with its routing, a block before the step that needs them, so sizing
+        the all-to-alls by them stalls nothing -- in compact rank-ordered lists, and the keys a rank owns itself are
+        served from / applied to its shard without entering a frame.  sized=False keeps the FIXED row frames of
+        row_cap rows per peer (equal-split exchanges whose sizes never depend on a count: the form that replays from
+        hipGraphs)."""
         self.emb, self.eng = emb, emb.engine
         w = emb.world
         self.max_ids = int(max_ids)
@@ -662,13 +749,21 @@ class FramedStep:
             raise ValueError("block must be >= 1")
         self.LOOKAHEAD = 2 * self.block
         self.graphs = bool(graphs)
+        self.sized = (not self.graphs) if sized is None else bool(sized)
+        if self.sized and self.graphs:
+            raise ValueError("FramedStep: sized exchanges are enqueued per step (graphs=True needs sized=False)")
         self.blocks = [self.eng.frames_block(w, self.rcap, self.max_ids, self.block) for _ in range(3)]
         m = w * self.rcap
         self.pull_send = self.eng.empty_rows(m, emb.width)
-        self.push_send = self.eng.empty_rows(m, emb.width)
         self.pull_recv = self.eng.empty_rows(m, emb.width)
-        self.push_recv = self.eng.empty_rows(m, emb.width)
-        self.zero_flags = self.eng.zeros((m,), torch.uint8)
+        if self.sized:
+            # regions A (rows for the other owners) | S (own keys) | B (rows received): see csrc/shard.hip
+            self.push_buf = self.eng.empty_rows((2 * w + 1) * self.rcap, emb.width)
+            self.zero_flags = self.eng.zeros(((2 * w + 1) * self.rcap,), torch.uint8)
+        else:
+            self.push_send = self.eng.empty_rows(m, emb.width)
+            self.push_recv = self.eng.empty_rows(m, emb.width)
+            self.zero_flags = self.eng.zeros((m,), torch.uint8)
         self.side = w == 1 or emb.side_group is not None
         self._graphs = {}
         self._calls = {}
@@ -718,21 +813,25 @@ class FramedStep:
                 for fb in blk.slots:
                     eng.hold_for_side(fb.ids)
             exchange = lambda out, inp: self._exchange(out, inp, group=self.emb.side_group if self.side else None)
+            sized_rank = self.emb.rank if self.sized else None
             if hasattr(eng, "frames_route_block"):
-                eng.frames_route_block(blk, starts, exchange)
+                eng.frames_route_block(blk, starts, exchange, sized_rank)
             else:
                 for fb in blk.slots:       # a slot without a batch (the stream ended inside the block): an empty frame
                     eng.frames_plan(fb, starts)
-                    eng.frames_pack(blk, fb, starts)
+                    eng.frames_pack(blk, fb, starts, sized_rank)
                 blk.kgot = exchange(blk.krecv, blk.ksend)
                 for fb in blk.slots:
                     if fb.routed:
                         eng.frames_unpack(blk, fb)
             blk.ev = eng.record()
+        for fb in blk.slots:
+            fb.send_cnt = fb.recv_cnt = None
         if self.emb.world > 1:
             per_peer = 4 * self.block * (2 + self.rcap)
             self.emb.stats["xgmi_bytes_out"] += (self.emb.world - 1) * per_peer
             self.emb.stats["xgmi_bytes_in"] += (self.emb.world - 1) * per_peer
+            self.emb.stats["xgmi_key_frame_bytes"] = self.emb.stats.get("xgmi_key_frame_bytes", 0) + (self.emb.world - 1) * per_peer
 
     def _block_start(self, b):
         """First step of block b: its routing (enqueued a block ago) must be complete before its first pull; the routing
@@ -751,6 +850,77 @@ class FramedStep:
         self.eng.frames_reduce(fb, values, scale, self.push_send, self.zero_flags)
         got = self._exchange(self.push_recv, self.push_send)
         self.eng.frames_serve_push(self.emb.table, fb, got)
+
+    # -- sized exchanges -----------------------------------------------------------------------------------------------
+    def _counts(self, fb):
+        if fb.send_cnt is None:
+            fb.send_cnt, fb.recv_cnt = self.eng.frames_counts(fb)
+        return fb.send_cnt, fb.recv_cnt
+
+    def _pull_sized(self, j, out, stream_key):
+        blk, fb = self._fb(j)
+        eng, emb = self.eng, self.emb
+        w, r = emb.world, emb.rank
+        send_cnt, recv_cnt = self._counts(fb)
+        if w > 1:
+            ins = [c if g != r else 0 for g, c in enumerate(recv_cnt)]     # rows this rank serves to peer g
+            outs = [c if g != r else 0 for g, c in enumerate(send_cnt)]    # rows owner g sends back
+            if self._fast_ok:
+                self._fast(("spull", j % (3 * self.block), stream_key),
+                           lambda: eng.sized_serve_pull_call(emb.table, fb, r, self.pull_send))()
+            else:
+                eng.sized_serve_pull(emb.table, fb, r, self.pull_send)
+            emb._a2a(self.pull_recv[:sum(outs)], self.pull_send[:sum(ins)], outs, ins)
+            self._account_sized(ins, outs, send_cnt, recv_cnt)
+        if fb.n:
+            if self._fast_ok:
+                self._fast(("sexp", j % (3 * self.block), fb.n, out.data_ptr(), stream_key),
+                           lambda: eng.sized_expand_call(emb.table, self.pull_recv, fb, out))()
+            else:
+                eng.sized_expand(emb.table, self.pull_recv, fb, out)
+
+    def _push_sized(self, j, values, scale, stream_key):
+        _, fb = self._fb(j)
+        eng, emb = self.eng, self.emb
+        w, r = emb.world, emb.rank
+        send_cnt, recv_cnt = self._counts(fb)
+        if w == 1:          # nobody else pushes: reduce + server add of the own keys in one launch
+            if fb.n:
+                if self._fast_ok:
+                    self._fast(("salone", j % (3 * self.block), fb.n, values.data_ptr(), scale, stream_key),
+                               lambda: eng.sized_push_alone_call(emb.table, fb, values, scale))()
+                else:
+                    eng.sized_push_alone(emb.table, fb, values, scale)
+            return
+        if fb.n:
+            if self._fast_ok:
+                self._fast(("sred", j % (3 * self.block), fb.n, values.data_ptr(), scale, stream_key),
+                           lambda: eng.sized_reduce_call(fb, values, scale, self.push_buf, self.zero_flags))()
+            else:
+                eng.sized_reduce(fb, values, scale, self.push_buf, self.zero_flags)
+        ins = [c if g != r else 0 for g, c in enumerate(send_cnt)]          # reduced rows for owner g
+        outs = [c if g != r else 0 for g, c in enumerate(recv_cnt)]         # rows peer g pushes to this rank
+        b0 = (w + 1) * self.rcap
+        emb._a2a(self.push_buf[b0:b0 + sum(outs)], self.push_buf[:sum(ins)], outs, ins)
+        self._account_sized(ins, outs, send_cnt, recv_cnt, pull=False)
+        eng.sized_serve_push(emb.table, fb, r, sum(recv_cnt), self.push_buf)
+
+    def _account_sized(self, ins, outs, send_cnt, recv_cnt, pull=True):
+        """Bytes that crossed the fabric in one sized row exchange: every one of them a row some batch names."""
+        st = self.emb.stats
+        bo, bi = 4 * self.emb.width * sum(ins), 4 * self.emb.width * sum(outs)
+        st["xgmi_bytes_out"] += bo
+        st["xgmi_bytes_in"] += bi
+        st["xgmi_row_bytes"] = st.get("xgmi_row_bytes", 0) + bo + bi
+        st["xgmi_row_bytes_out"] = st.get("xgmi_row_bytes_out", 0) + bo
+        # useful egress: every row carried is one a batch names; of the key frames, the words in use (count, flag, keys)
+        st["xgmi_useful_bytes_out"] = st.get("xgmi_useful_bytes_out", 0) + bo + \
+            (4 * (2 * (self.emb.world - 1) + sum(outs)) if pull else 0)
+        if pull:        # how unevenly the owners are named (row-range shards of a skewed key space)
+            named = sum(recv_cnt)
+            st["owner_rows_sum"] = st.get("owner_rows_sum", 0) + named
+            st["owner_rows_max"] = max(st.get("owner_rows_max", 0), named)
+            st["owner_steps"] = st.get("owner_steps", 0) + 1
 
     def _fast(self, key, build):
         """Plain launches with arguments converted once per key (engines that offer it; not with graphs)."""
@@ -813,9 +983,10 @@ class FramedStep:
         emb = self.emb
         w = emb.world
         if w > 1:
-            per_peer = 2 * 4 * self.rcap * emb.width     # pull rows + push rows
+            per_peer = 2 * 4 * self.rcap * emb.width     # pull rows + push rows: whole frames travel, padding included
             emb.stats["xgmi_bytes_out"] += (w - 1) * per_peer
             emb.stats["xgmi_bytes_in"] += (w - 1) * per_peer
+            emb.stats["xgmi_frame_padded_bytes"] = emb.stats.get("xgmi_frame_padded_bytes", 0) + 2 * (w - 1) * per_peer
 
     # -- the stream protocol ----------------------------------------------------------------------------------------
     def start(self, ids_list):
@@ -863,6 +1034,8 @@ class FramedStep:
             rows = self.emb.pull(route=self._sized, return_route=False)
             if fb.n:
                 out.copy_(rows.reshape(out.shape))
+        elif self.sized:
+            self._pull_sized(k, out, self.eng._stream() if self._fast_ok else 0)
         else:
             if self._fast_ok and not self.graphs:
                 self._pull_fast(k, out, self.eng._stream())
@@ -882,6 +1055,9 @@ class FramedStep:
         if self._over:
             self.emb.push(None, values, lr, route=self._sized)
             self._sized = None
+        elif self.sized:
+            self._push_sized(k, values.reshape(-1, self.emb.width) if fb.n else None, scale,
+                             self.eng._stream() if self._fast_ok else 0)
         else:
             v = values.reshape(-1, self.emb.width) if fb.n else None
             if self._fast_ok and not self.graphs:
@@ -905,12 +1081,33 @@ class FramedStep:
         out = eng.empty_rows(max(fb.n, 1), emb.width)
         v = values.reshape(-1, emb.width)
         scale = 1.0 if lr is None else -float(lr)
+        if self.sized:
+            r, total = emb.rank, sum(self._counts(fb)[1])
+            calls = []
+            if emb.world > 1:
+                calls.append(("serve_pull (owner gather of the other ranks' keys, compact)",
+                              lambda: eng.sized_serve_pull(emb.table, fb, r, self.pull_send)))
+            calls.append(("expand (own keys from the shard, the others from the received rows -> positions)",
+                          lambda: eng.sized_expand(emb.table, self.pull_recv, fb, out)))
+            if emb.world > 1:
+                calls.append(("reduce (gradients -> push buffer, own keys apart)",
+                              lambda: eng.sized_reduce(fb, v, scale, self.push_buf, self.zero_flags)))
+                calls.append(("serve_push (merge of the received lists + rank-ordered apply)",
+                              lambda: eng.sized_serve_push(emb.table, fb, r, total, self.push_buf)))
+            else:
+                calls.append(("push_alone (reduce + server add of the own keys, one launch)",
+                              lambda: eng.sized_push_alone(emb.table, fb, v, scale)))
+            return self._time_calls(calls, reps)
         rows_in = self.pull_send if emb.world == 1 else self.pull_recv
         grads_in = self.push_send if emb.world == 1 else self.push_recv
         calls = (("serve_pull (owner gather into row frames)", lambda: eng.frames_serve_pull(emb.table, blk, fb, self.pull_send)),
                  ("expand (row frames -> positions)", lambda: eng.frames_expand(rows_in, fb, out)),
                  ("reduce (gradients -> push frames)", lambda: eng.frames_reduce(fb, v, scale, self.push_send, self.zero_flags)),
                  ("serve_push (sort received keys + rank-ordered apply)", lambda: eng.frames_serve_push(emb.table, fb, grads_in)))
+        return self._time_calls(calls, reps)
+
+    @staticmethod
+    def _time_calls(calls, reps):
         res = {}
         for name, fn in calls:
             fn()

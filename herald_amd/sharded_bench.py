@@ -11,6 +11,34 @@ XGMI_LINK_GBS = 153.0   # per link, 7 links per GPU (MI355X_MICROARCH / task sta
 HBM_PEAK_GBS = 8000.0
 
 
+def _world1_same_path(args, rank, dev, emb, ids_dev, grads, n, lr, steps=300, warmup=40):
+    """The SAME engine (FramedStep, sized exchanges) at world size 1 on this rank's own shard: what a step of the N>1
+    path costs before a byte crosses a link -- the N=1 line of bench.py comes from another engine (the work-queue
+    step), so the step from N=1 to N=2 in a scaling curve is this number + communication, not communication alone.
+    Every rank runs it (a GPU each: they stay in lockstep); ids are folded into the shard's row range."""
+    from herald_amd.sharded import FramedStep, ShardedEmbedding
+    solo = None
+    for r in range(dist.get_world_size()):          # new_group is a collective: every rank creates every group
+        g = dist.new_group(ranks=[r])
+        if r == rank:
+            solo = g
+    one = ShardedEmbedding(emb.local_rows, emb.width, dev, group=solo, table=emb.table)
+    assert one.world == 1
+    local = [torch.remainder(t, float(emb.local_rows)) for t in ids_dev[:64]]
+    fs = FramedStep(one, n, block=int(__import__("os").environ.get("HA_SHARD_BLOCK", "8")), graphs=False)
+    nb, LA = len(local), fs.LOOKAHEAD
+    outs = [torch.empty((n, emb.width), dtype=torch.float32, device=dev) for _ in range(2)]
+    fs.start([local[j % nb] for j in range(LA)])
+    for k in range(warmup + steps):
+        if k == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        fs.pull(local[(k + LA) % nb], out=outs[k % 2])
+        fs.push(grads[k % 2], lr)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
 def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
     """One sharded workload: `steps` timed steps of bs=`batch`, d=`width` per GPU -> dict of what rank 0 reports."""
     import os
@@ -40,16 +68,23 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
     gen.manual_seed(456 + rank)
     grads = [torch.randn((n, width), dtype=torch.float32, device=dev, generator=gen) for _ in range(2)]
     lr = 1e-6
-    framed = os.environ.get("HA_SHARD_SIZED") != "1"
+    framed = os.environ.get("HA_SHARD_READBACK", os.environ.get("HA_SHARD_SIZED")) != "1"
     fs = None
+    same_path = None
+    if framed and world > 1 and per_kernel and os.environ.get("HA_SHARD_NO_WORLD1") != "1":
+        same_path = _world1_same_path(args, rank, dev, emb, ids_dev, grads, n, lr)
     if framed:
-        # Fixed frames (herald_amd.sharded.FramedStep): no launch or exchange size depends on a device-side count, so
-        # a step needs no host read-back (and can replay from hipGraphs: HA_SHARD_GRAPHS=1 -- measured slower than
-        # plain launches for graphs of three kernels, so it is not the default); the routing runs a block of batches at
-        # a time, one block ahead, beside the steps (four launches and one key exchange per block).  A batch that
-        # overflows its frames on any rank takes the sized exchange (counted below).
+        # herald_amd.sharded.FramedStep: the routing (plans, key frames, ONE key exchange) runs a block of batches at a
+        # time, one block ahead, beside the steps; it leaves the per-owner counts of every batch in pinned host memory, so
+        # the two row exchanges of a step are SIZED by the real counts without a read-back in the step -- exactly the rows
+        # the batch names cross the fabric, and the keys a rank owns itself are read from / applied to its shard
+        # directly.  HA_SHARD_FIXED=1 (or HA_SHARD_GRAPHS=1: hipGraph replay, measured slower than plain launches for
+        # graphs of three kernels): the fixed row frames of round 3, equal-split exchanges that carry their padding.  A
+        # batch that overflows its KEY frames on any rank takes the exchange with a read-back (counted below).
+        graphs = os.environ.get("HA_SHARD_GRAPHS") == "1"
         fs = FramedStep(emb, n, row_cap=int(os.environ["HA_SHARD_ROW_CAP"]) if "HA_SHARD_ROW_CAP" in os.environ else None,
-                        block=int(os.environ.get("HA_SHARD_BLOCK", "8")), graphs=os.environ.get("HA_SHARD_GRAPHS") == "1")
+                        block=int(os.environ.get("HA_SHARD_BLOCK", "8")), graphs=graphs,
+                        sized=not (graphs or os.environ.get("HA_SHARD_FIXED") == "1"))
         outs = [torch.empty((n, width), dtype=torch.float32, device=dev) for _ in range(2)]
         LA = fs.LOOKAHEAD
         fs.start([ids_dev[j % nb] for j in range(LA)])
@@ -78,6 +113,7 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
     torch.cuda.synchronize()
     dist.barrier()
     emb.stats = {"xgmi_bytes_out": 0, "xgmi_bytes_in": 0}
+    fb0 = fs.fallbacks if fs is not None else 0
     t0 = time.perf_counter()
     for k in range(steps):
         step(warmup + k)
@@ -87,8 +123,12 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
     t = torch.tensor([el], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
-    xg = torch.tensor([emb.stats["xgmi_bytes_out"], emb.stats["xgmi_bytes_in"]], dtype=torch.float64, device=dev)
+    st = emb.stats
+    xg = torch.tensor([st["xgmi_bytes_out"], st["xgmi_bytes_in"], st.get("xgmi_row_bytes_out", -1.0),
+                       st.get("xgmi_useful_bytes_out", -1.0), st.get("owner_rows_max", 0)], dtype=torch.float64, device=dev)
     dist.all_reduce(xg, op=dist.ReduceOp.MAX)
+    named = torch.tensor([st.get("owner_rows_sum", 0), st.get("owner_steps", 0)], dtype=torch.float64, device=dev)
+    dist.all_reduce(named, op=dist.ReduceOp.SUM)
     used = [(warmup + k) % nb for k in range(steps)]
     u_mean = float(np.mean([np.unique(ids_host[b]).size for b in sorted(set(used))]))
     d = width
@@ -103,8 +143,13 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
         fs.push(grads[0], lr)
         torch.cuda.synchronize()
         alg = {"serve_pull": u_mean * (8 * d + 4), "expand": n * (4 * d + 4) + u_mean * 4 * d,
-               "reduce": n * (4 * d + 4) + u_mean * 4 * d, "serve_push": u_mean * (12 * d + 4)}
-        traffic = _pmc_traffic()
+               "reduce": n * (4 * d + 4) + u_mean * 4 * d, "serve_push": u_mean * (12 * d + 4),
+               # sized frames at world size 1: the lookup itself (id map, row read, row write per position) and the
+               # reduce + server add in one launch (gradient row per position, one read-modify-write per unique row)
+               "push_alone": n * (4 * d + 4) + u_mean * 8 * d}
+        if fs.sized:
+            alg["expand"] = n * (8 * d + 4)
+        traffic = _pmc_traffic(batch, width)
         kernels = {}
         for name, us in times.items():
             short = name.split(" ")[0]
@@ -120,11 +165,27 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
                     "(AveragePartitioner), sparse pull/push by RCCL all-to-all" % (batch, width, args.fields, args.rows, world),
         "sparse_update": "runs >= 64 occurrences: fixed-order tree sum (1e-5 tolerance); shorter: the reference's serial chain"
                          if tolerance else "the reference's serial chain, bit-exact",
-        "exchange": ("fixed frames of %d rows per owner, routing in blocks of %d batches, %s; %d of %d steps took the "
-                     "sized exchange" % (fs.rcap, fs.block, "hipGraph replay" if fs.graphs else "plain launches, no host "
-                                         "read-back", fs.fallbacks, steps + warmup)) if framed else "sized (host read-back)",
+        "exchange": (("row exchanges sized by the real per-owner counts (known a routing block ahead, no read-back in the "
+                      "step), own keys served from the shard; key frames of %d keys per owner, routing in blocks of %d "
+                      "batches; %d of %d timed steps overflowed their key frames and took the exchange with a read-back"
+                      % (fs.rcap, fs.block, fs.fallbacks - fb0, steps)) if fs.sized else
+                     ("fixed frames of %d rows per owner (padding travels), routing in blocks of %d batches, %s; %d of %d "
+                      "timed steps took the sized exchange" % (fs.rcap, fs.block, "hipGraph replay" if fs.graphs else
+                                                               "plain launches, no host read-back", fs.fallbacks - fb0, steps)))
+                    if framed else "sized per step (host read-back of the counts)",
+        # egress of the busiest GPU.  bytes_carried: everything handed to the all-to-alls (rows + key frames);
+        # bytes_useful: the rows some batch names + the key words in use -- with sized exchanges every row carried is one
+        # (fixed frames: null, the frames do not say how full they are).  frac is priced on what was CARRIED.
         "xgmi": {"egress_GBps_per_gpu_max": xgmi_gbs, "peak_GBps_per_gpu": links * XGMI_LINK_GBS,
-                 "frac": xgmi_gbs / (max(links, 1) * XGMI_LINK_GBS)},
+                 "frac": xgmi_gbs / (max(links, 1) * XGMI_LINK_GBS),
+                 "bytes_carried_per_step": float(xg[0].item()) / steps,
+                 "row_bytes_carried_per_step": float(xg[2].item()) / steps if xg[2].item() >= 0 else None,
+                 "bytes_useful_per_step": float(xg[3].item()) / steps if xg[3].item() >= 0 else None,
+                 # unique rows an owner is named per step by all ranks together: row-range shards of the Criteo key space
+                 # are unevenly loaded (the small tables sit in one range) -- inherent to the partitioning north_star names
+                 "owner_rows_mean": float(named[0].item() / named[1].item()) if named[1].item() > 0 else None,
+                 "owner_rows_max": float(xg[4].item()) if named[1].item() > 0 else None},
+        "same_path_world1_ms_per_step": same_path,
         "roofline": {"bound": "hbm", "kernel": "per-GPU local kernels of one sharded step (gather of served rows, "
                                                "dedup-reduce, apply of received gradients)",
                      "achieved": step_bytes / (el / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -135,21 +196,23 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
     }
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the sharded step's kernels from the newest profiles/r*/pmc_traffic_sharded.json
-    (rocprofv3 --pmc passes of the world-size-1 run, tools/profile_sharded.sh); {} if there is none."""
+def _pmc_traffic(batch, width):
+    """HBM bytes per launch of the sharded step's kernels AT THIS SHAPE from the newest
+    profiles/r*/pmc_traffic_sharded_bs<batch>_d<width>.json (rocprofv3 --pmc passes of the world-size-1 run at that
+    shape, tools/profile_sharded.sh); {} -- every `traffic` null -- if no file was made for the shape."""
     import glob
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "pmc_traffic_sharded.json")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "pmc_traffic_sharded_bs%d_d%d.json" % (batch, width))))
     if not files:
         return {}
     try:
         k = json.load(open(files[-1]))["kernels"]
     except Exception:
         return {}
-    names = {"serve_pull": "ha::shard_serve_pull_frames_kernel", "expand": "ha::gather_vec4_kernel",
-             "reduce": "ha::apply_mapped_kernel", "serve_push": "ha::shard_frames_apply_kernel"}
+    names = {"serve_pull": "ha::shard_serve_pull", "expand": "ha::gather",
+             "reduce": "ha::apply_mapped_kernel", "serve_push": "ha::shard_frames_apply_kernel",
+             "push_alone": "ha::apply_"}
     out = {}
     for short, kn in names.items():
         hit = [v for name, v in k.items() if name.startswith(kn)]
@@ -181,6 +244,9 @@ def run(args, rank, world, dev, cpu_baseline_fn=None):
                        "parallelism": "row-sharded x%d" % world, "exchange": main["exchange"],
                        "sparse_update": main["sparse_update"]},
             "xgmi": main["xgmi"], "ranks_seen": dist.get_world_size(), "roofline": main["roofline"],
+            # the N>1 engine at world size 1 on one shard (ms per step; null at N = 1, where this line IS that number):
+            # bench.py's N=1 line runs the work-queue engine instead, so N=1 -> N=2 = an engine change + communication
+            "same_path_world1_ms_per_step": main["same_path_world1_ms_per_step"],
             "cpu_baseline": cpu_base,
         }
         if second is not None:
@@ -192,6 +258,7 @@ def run(args, rank, world, dev, cpu_baseline_fn=None):
                                     "config": {"workload": second["workload"], "ids_per_step_per_gpu": second["n"],
                                                "exchange": second["exchange"], "sparse_update": second["sparse_update"]},
                                     "xgmi": second["xgmi"], "roofline": second["roofline"],
+                                    "same_path_world1_ms_per_step": second["same_path_world1_ms_per_step"],
                                     "note": "BASELINE configs[2]'s per-GPU shape; not part of `value`"}
         print(json.dumps(line), flush=True)
     dist.barrier()          # rank 0 may still be timing the CPU baseline: tear the group down together

@@ -666,6 +666,47 @@ int ha_shard_frames_serve_pull(const float *table, int64_t rows, int64_t width, 
                                int64_t rcap, int64_t frame_stride, float *rows_out, uint32_t *keys_fixed,
                                int32_t *state, ha_stream_t stream);
 
+/* SIZED frames: the same key frames, routed a block of batches ahead, also leave the per-owner counts of every batch on
+ * the device and in pinned host memory, so that the two row exchanges of a step carry exactly the rows the batch names
+ * (the reference's messages hold U_s keys and U_s x d floats per server: PSAgent::vecPullSparse / vecPushSparse,
+ * ps-lite/include/ps/worker/PSAgent.h:167-172,217-226; ps/psf/sparse.h:9-32) without a host read-back in the step, and
+ * the keys a rank owns itself never enter an exchange.
+ *   meta (int32[2 + 2 nshard]; meta_dev on the device, meta_host in pinned host memory, same contents):
+ *     [0] some rank overflowed its key frames (the batch then takes the sized exchange with a read-back, as above)
+ *     [1] keys received   [2 + g] unique keys this rank names of owner g   [2 + nshard + g] keys rank g names of this rank
+ *   ha_shard_frames_pack_batch_sized   = ha_shard_frames_pack_batch + the send counts and the SIZED maps (self = this rank):
+ *     posmap[i] = 0x80000000 | shard-local key  if position i names a key of this rank (the expand reads the table itself)
+ *               = index of its unique key among the unique keys of the OTHER owners in key order (= the row of the
+ *                 received rows: the all-to-all concatenates the owners' answers in rank order)
+ *               = 0xFFFFFFFF (a zero row) for a batch that overflowed
+ *     rowmap[u] = the same compact index for a key of another owner (region A of the push buffer), nshard * rcap + j for
+ *                 the j-th key of this rank's own range (region S); -1 for a batch that overflowed
+ *   ha_shard_frames_unpack_batch_sized = ha_shard_frames_unpack_batch + the receive counts; meta_host[0] is written last
+ *   ha_shard_sized_serve_pull  rows_out[roff(g) + j,:] = table[key j of rank g,:] for the other ranks' requests, roff(g) =
+ *     sum of the receive counts of the ranks before g without this rank (PSHandler::serve(SparsePull), PSFHandle.h:101-128)
+ *   ha_gather2_u32map          the expand: out[i,:] = table[map & 0x7FFFFFFF,:] if map[i] has bit 31, else recv[map[i],:]
+ *   ha_shard_sized_serve_push  push_buf = (2 nshard + 1) * rcap rows: A = rows for the other owners [0, nshard rcap), S =
+ *     this rank's own keys [nshard rcap, +rcap), B = the rows received, compact in rank order [(nshard + 1) rcap, ...);
+ *     the nshard key lists are merged in rank order and table[key,:] = ((table[key,:] + v_0) + v_1) ... (PSFHandle.h:130-164);
+ *     total = keys received (host-known); plan_ws: ha_plan_bytes(nshard * rcap) of scratch
+ *   ha_push_apply_scaled_finished  a rank alone (nshard = 1): reduce and server add of its own keys in ONE launch. */
+int ha_shard_frames_pack_batch_sized(const void *const *plan_ws, const int64_t *n, int count, const int64_t *starts_host,
+                                     int nshard, int self, int64_t rcap, int64_t frame_stride, int32_t *send,
+                                     int32_t *const *rowmap, int32_t *const *posmap, int32_t *const *meta_dev,
+                                     int32_t *const *meta_host, ha_stream_t stream);
+int ha_shard_frames_unpack_batch_sized(const int32_t *recv, int count, int nshard, int64_t rcap, int64_t frame_stride,
+                                       uint32_t *const *keys_fixed, int32_t *const *meta_dev, int32_t *const *meta_host,
+                                       ha_stream_t stream);
+int ha_shard_sized_serve_pull(const float *table, int64_t rows, int64_t width, const uint32_t *keys_fixed, int nshard,
+                              int self, int64_t rcap, const int32_t *meta_dev, float *rows_out, ha_stream_t stream);
+int ha_gather2_u32map(const float *table, int64_t rows, const float *recv, int64_t recv_rows, int64_t width,
+                      const uint32_t *map, int64_t n, float *out, ha_stream_t stream);
+int ha_shard_sized_serve_push(float *table, int64_t rows, int64_t width, const uint32_t *keys_fixed, int nshard, int self,
+                              int64_t rcap, const int32_t *meta_dev, int64_t total, const float *push_buf, void *plan_ws,
+                              ha_stream_t stream);
+int ha_push_apply_scaled_finished(float *table, int64_t rows, int64_t width, void *plan_ws, int64_t n, const float *grads,
+                                  float scale, ha_stream_t stream);
+
 /* Owner side of a sparse push (PSHandler::serve(SparsePush), ps-lite/include/ps/server/PSFHandle.h:130-164):
  * table[keys[j],:] = (table[keys[j],:] + values[a,:]) + values[b,:] ... over the positions a < b < ... that
  * list the key, i.e. in list order (the W received sorted lists concatenated in rank order).

@@ -111,7 +111,8 @@ class CpuEngine:
             fb = FrameBuffers()
             fb.i, fb.w, fb.rcap = i, w, rcap
             fb.keys_fixed = torch.zeros(w * rcap, dtype=torch.int32)
-            fb.state_host = torch.zeros(2, dtype=torch.int32)
+            fb.state_host = torch.zeros(2 + 2 * w, dtype=torch.int32)
+            fb.send_cnt = fb.recv_cnt = None
             fb.n, fb.ids, fb.shape, fb.routed = 0, None, (0,), False
             blk.slots.append(fb)
         return blk
@@ -119,7 +120,7 @@ class CpuEngine:
     def frames_plan(self, fb, starts):
         fb.plan = _Plan(fb.ids if fb.n else torch.zeros(0))
 
-    def frames_pack(self, blk, fb, starts):
+    def frames_pack(self, blk, fb, starts, sized_rank=None):
         plan = fb.plan
         st = np.asarray(starts, dtype=np.uint64)
         off = np.searchsorted(plan.uniq, st, side="left").astype(np.int64)
@@ -136,6 +137,20 @@ class CpuEngine:
         blk.ksend[:, fb.i, :] = torch.from_numpy(send)
         fb.rowmap = rowmap
         fb.posmap = rowmap[plan.inv] if plan.n else np.zeros(0, np.int64)
+        if sized_rank is not None:
+            # sized frames (csrc/shard.hip): compact rank-ordered lists, own keys in a region of their own / read locally
+            r, U = int(sized_rank), plan.uniq.size
+            own0, own1 = int(off[r]), int(off[r + 1])
+            u = np.arange(U)
+            over = bool((cnt > fb.rcap).any())
+            rm = np.where(u < own0, u, np.where(u < own1, fb.w * fb.rcap + (u - own0), u - (own1 - own0)))
+            fb.rowmap = np.full(U, -1, np.int64) if over else rm
+            local = (u >= own0) & (u < own1)
+            fb.pos_local = (local[plan.inv] if plan.n else np.zeros(0, bool))
+            key_local = (plan.uniq.astype(np.int64) - int(st[r]))
+            idx = np.where(local, key_local, np.where(u < own0, u, u - (own1 - own0)))
+            fb.posmap = np.full(plan.n, -1, np.int64) if over else (idx[plan.inv] if plan.n else np.zeros(0, np.int64))
+            fb.state_host[2:2 + fb.w] = torch.from_numpy(cnt.astype(np.int32))
 
     def frames_unpack(self, blk, fb):
         r = blk.kgot[:, fb.i, :].numpy()
@@ -148,6 +163,9 @@ class CpuEngine:
             keys[g * fb.rcap:g * fb.rcap + c] = r[g, 2:2 + c]
         fb.keys_fixed.copy_(torch.from_numpy(keys))
         fb.state_host[0] = over
+        got = np.minimum(np.maximum(r[:, 0], 0), fb.rcap).astype(np.int32)
+        fb.state_host[1] = int(got.sum())
+        fb.state_host[2 + fb.w:2 + 2 * fb.w] = torch.from_numpy(got)
 
     def frames_overflowed(self, fb):
         return bool(fb.state_host[0].item())
@@ -181,6 +199,65 @@ class CpuEngine:
         for p, k in enumerate(fb.keys_fixed.numpy().astype(np.int64)):
             if k >= 0:
                 t[k] = t[k] + v[p]
+
+    # -- sized frames (same contract as HipEngine.sized_*) ---------------------------------------------------------------
+    def frames_counts(self, fb):
+        s = fb.state_host.tolist()
+        return s[2:2 + fb.w], s[2 + fb.w:2 + 2 * fb.w]
+
+    @staticmethod
+    def _roff(recv_cnt, rank, g):
+        return sum(c for t, c in enumerate(recv_cnt[:g]) if t != rank)
+
+    def sized_serve_pull(self, table, fb, rank, rows_send):
+        _, recv_cnt = self.frames_counts(fb)
+        t, k, o = table.numpy(), fb.keys_fixed.numpy().astype(np.int64), rows_send.numpy()
+        for g in range(fb.w):
+            if g == rank:
+                continue
+            at = self._roff(recv_cnt, rank, g)
+            for j in range(recv_cnt[g]):
+                o[at + j] = t[k[g * fb.rcap + j]]
+
+    def sized_expand(self, table, rows_recv, fb, out):
+        if fb.n:
+            o = out.numpy().reshape(fb.n, -1)
+            t, r = table.numpy(), rows_recv.numpy()
+            for i in range(fb.n):
+                m = int(fb.posmap[i])
+                o[i] = 0 if m < 0 else (t[m] if fb.pos_local[i] else r[m])
+
+    def sized_reduce(self, fb, values, scale, push_buf, zero_flags):
+        if not fb.n:
+            return
+        v = (values.numpy().reshape(fb.n, -1) * np.float32(scale)).astype(np.float32)
+        red = np.zeros((fb.plan.uniq.size, v.shape[1]), dtype=np.float32)
+        for i, u in enumerate(fb.plan.inv):
+            red[u] += v[i]
+        ok = fb.rowmap >= 0
+        push_buf.numpy()[fb.rowmap[ok]] = red[ok]
+
+    def sized_serve_push(self, table, fb, rank, total, push_buf):
+        _, recv_cnt = self.frames_counts(fb)
+        assert total == sum(recv_cnt)
+        t, v, k = table.numpy(), push_buf.numpy(), fb.keys_fixed.numpy().astype(np.int64)
+        s0, b0 = fb.w * fb.rcap, (fb.w + 1) * fb.rcap
+        for g in range(fb.w):                                     # rank order
+            at = s0 if g == rank else b0 + self._roff(recv_cnt, rank, g)
+            for j in range(recv_cnt[g]):
+                key = k[g * fb.rcap + j]
+                t[key] = t[key] + v[at + j]
+
+    def sized_push_alone(self, table, fb, values, scale):
+        if not fb.n:
+            return
+        v = (values.numpy().reshape(fb.n, -1) * np.float32(scale)).astype(np.float32)
+        red = np.zeros((fb.plan.uniq.size, v.shape[1]), dtype=np.float32)
+        for i, u in enumerate(fb.plan.inv):
+            red[u] += v[i]
+        t = table.numpy()
+        for u, key in enumerate(fb.plan.uniq.astype(np.int64)):
+            t[key] = t[key] + red[u]
 
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype)

@@ -50,6 +50,7 @@ def test_framed_step_world1_replays_from_graphs(dev, rows, width, n, kind, graph
     table = rng.standard_normal((rows, width), dtype=np.float32)
     emb = ShardedEmbedding(rows, width, dev, table=torch.from_numpy(table.copy()).to(dev))
     fs = FramedStep(emb, n, graphs=graphs, block=block)
+    assert fs.sized == (not graphs)         # eager launches: sized exchanges, own keys served from the shard directly
     LA = fs.LOOKAHEAD
     d_ids = [torch.from_numpy(x).to(dev) for x in ids]
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(3)]
@@ -116,7 +117,7 @@ def _staged(out, inp, out_splits, in_splits, group):
     out.copy_(o)
 
 
-def _worker(rank, world, port, rows, width, n, kind, row_cap, expect_fallback):
+def _worker(rank, world, port, rows, width, n, kind, row_cap, expect_fallback, sized=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -134,7 +135,8 @@ def _worker(rank, world, port, rows, width, n, kind, row_cap, expect_fallback):
     nn = streams[0][0].size
     if world > 2:
         streams[world - 1][2] = streams[world - 1][2][:0]             # an empty batch on the last rank
-    fs = FramedStep(emb, nn, row_cap=row_cap, block=2, graphs=False)  # the host-staged exchange cannot be captured
+    fs = FramedStep(emb, nn, row_cap=row_cap, block=2, graphs=False, sized=sized)  # (a host-staged exchange cannot be captured)
+    assert fs.sized == sized
     tid = lambda k: torch.from_numpy(streams[rank][k]).to(dev) if k < nb else None
     LA = fs.LOOKAHEAD
     fs.start([tid(k) for k in range(LA)])
@@ -157,12 +159,31 @@ def _worker(rank, world, port, rows, width, n, kind, row_cap, expect_fallback):
         np.testing.assert_array_equal(emb.table.cpu().numpy(), want[starts[rank]:starts[rank + 1]],
                                       err_msg="shard after push, step %d rank %d" % (k, rank))
     assert (fs.fallbacks > 0) == expect_fallback, fs.fallbacks
+    if sized and not expect_fallback:
+        # the row exchanges carried exactly the rows the batches name (the reference's messages hold U_s x d floats per
+        # server: PSAgent.h:167-172,217-226) -- no frame padding crosses the fabric
+        st = np.asarray(starts)
+        real = 0
+        for k in range(nb):
+            u = [np.unique(cpu.ids_to_keys(streams[r][k])).astype(np.int64) for r in range(world)]
+            mine = u[rank]
+            real += int(((mine < st[rank]) | (mine >= st[rank + 1])).sum())
+            real += sum(int(((u[r] >= st[rank]) & (u[r] < st[rank + 1])).sum()) for r in range(world) if r != rank)
+        carried = emb.stats["xgmi_row_bytes"]
+        assert carried == 2 * 4 * width * real, (carried, 2 * 4 * width * real)
+        assert carried <= 1.15 * 2 * 4 * width * real
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rows,width,n,kind,row_cap,expect_fallback",
-                         [(2, 5000, 64, 1300, "mixed", 300, True), (2, 5000, 64, 1300, "mixed", None, False),
-                          (4, 200000, 128, 6656, "criteo", None, False), (8, 33762, 32, 2600, "mixed", 700, False), (8, 33762, 32, 2600, "mixed", 400, True)])
-def test_framed_step_at_world_size_gt_1_on_one_gpu(dev, world, rows, width, n, kind, row_cap, expect_fallback):
-    mp.spawn(_worker, args=(world, _free_port(), rows, width, n, kind, row_cap, expect_fallback), nprocs=world, join=True)
+@pytest.mark.parametrize("world,rows,width,n,kind,row_cap,expect_fallback,sized",
+                         [(2, 5000, 64, 1300, "mixed", 300, True, True), (2, 5000, 64, 1300, "mixed", None, False, True),
+                          (4, 200000, 128, 6656, "criteo", None, False, True), (8, 33762, 32, 2600, "mixed", 700, False, True),
+                          (8, 33762, 32, 2600, "mixed", 400, True, True),
+                          # BASELINE configs[1] / configs[2] streams at W = 8 (bs 256 and bs 4096 per rank, 26 fields)
+                          (8, 337625, 32, 6656, "criteo", None, False, True), (8, 337625, 16, 106496, "criteo", None, False, True),
+                          # fixed row frames (the form that replays from hipGraphs)
+                          (2, 5000, 64, 1300, "mixed", None, False, False), (8, 33762, 32, 2600, "mixed", 400, True, False)])
+def test_framed_step_at_world_size_gt_1_on_one_gpu(dev, world, rows, width, n, kind, row_cap, expect_fallback, sized):
+    mp.spawn(_worker, args=(world, _free_port(), rows, width, n, kind, row_cap, expect_fallback, sized), nprocs=world,
+             join=True)

@@ -124,10 +124,11 @@ def test_sharded_pull_push_gloo(tmp_path, world, rows, width, n, side_group):
              join=True)
 
 
-def _framed_worker(rank, world, port, rows, width, n, row_cap, block, expect_fallback):
-    """FramedStep (fixed frames, no host-known counts) under gloo: a stream of batches with keys shared between the
-    ranks, runs inside a rank, an empty batch on the last rank and -- with a small row_cap -- batches that overflow
-    their frames on SOME rank and must take the sized exchange on ALL ranks."""
+def _framed_worker(rank, world, port, rows, width, n, row_cap, block, expect_fallback, sized=True):
+    """FramedStep under gloo, with SIZED row exchanges (the default: exactly the rows the batches name travel, own keys
+    stay local) and with fixed row frames: a stream of batches with keys shared between the ranks, runs inside a rank,
+    an empty batch on the last rank and -- with a small row_cap -- batches that overflow their key frames on SOME rank
+    and must take the exchange with a read-back on ALL ranks."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -157,7 +158,8 @@ def _framed_worker(rank, world, port, rows, width, n, row_cap, block, expect_fal
             per.append(ids)
         batches.append(per)
         vals.append([rng.standard_normal((b.size, width), dtype=np.float32) for b in per])
-    fs = FramedStep(emb, n, row_cap=row_cap, block=block, graphs=False)
+    fs = FramedStep(emb, n, row_cap=row_cap, block=block, graphs=False, sized=sized)
+    assert fs.sized == sized
     tid = lambda k: torch.from_numpy(batches[k][rank]) if k < nb else None
     LA = fs.LOOKAHEAD
     fs.start([tid(k) for k in range(min(LA, nb))])
@@ -179,20 +181,37 @@ def _framed_worker(rank, world, port, rows, width, n, row_cap, block, expect_fal
         np.testing.assert_array_equal(emb.table.numpy(), want[starts[rank]:starts[rank + 1]],
                                       err_msg="shard after push, step %d rank %d" % (k, rank))
     assert (fs.fallbacks > 0) == expect_fallback, fs.fallbacks
+    if sized and not expect_fallback:
+        # what crossed the "fabric" in the row exchanges is exactly the rows the batches name (PSAgent.h:167-172,217-226):
+        # per step and direction, the unique keys this rank names of the other owners + the ones the others name of its range
+        st = np.asarray(starts)
+        real = 0
+        for k in range(nb):
+            u = [np.unique(cpu.ids_to_keys(b)).astype(np.int64) for b in batches[k]]
+            mine = u[rank]
+            real += int(((mine < st[rank]) | (mine >= st[rank + 1])).sum())
+            real += sum(int(((u[r] >= st[rank]) & (u[r] < st[rank + 1])).sum()) for r in range(world) if r != rank)
+        carried = emb.stats["xgmi_row_bytes"]
+        assert carried == 2 * 4 * width * real, (carried, 2 * 4 * width * real)       # pull and push
+        assert carried <= 1.15 * 2 * 4 * width * real
+        assert emb.stats["owner_steps"] == nb and emb.stats["owner_rows_max"] * nb >= emb.stats["owner_rows_sum"] > 0
     with pytest.raises(RuntimeError, match="ended"):
         fs.pull(None)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rows,width,n,row_cap,block,expect_fallback",
-                         [(2, 1001, 8, 120, None, 2, True),    # default row_cap = n / W: batch 4 overflows owner 0
-                          (2, 1001, 8, 120, 120, 1, False),    # row_cap = n can never overflow; blocks of one batch
-                          (3, 700, 4, 90, 40, 4, True),        # the stream ends inside a block
-                          (2, 1001, 8, 120, 120, 8, False)])   # the whole stream is shorter than the lookahead
-def test_framed_step_gloo(world, rows, width, n, row_cap, block, expect_fallback):
-    mp.spawn(_framed_worker, args=(world, _free_port(), rows, width, n, row_cap, block, expect_fallback), nprocs=world,
-             join=True)
+@pytest.mark.parametrize("world,rows,width,n,row_cap,block,expect_fallback,sized",
+                         [(2, 1001, 8, 120, None, 2, True, True),    # default row_cap = n / W: batch 4 overflows owner 0
+                          (2, 1001, 8, 120, 120, 1, False, True),    # row_cap = n can never overflow; blocks of one batch
+                          (3, 700, 4, 90, 40, 4, True, True),        # the stream ends inside a block
+                          (3, 700, 4, 90, 90, 4, False, True),       # three ranks, no overflow: the bytes carried are the rows named
+                          (2, 1001, 8, 120, 120, 8, False, True),    # the whole stream is shorter than the lookahead
+                          (2, 1001, 8, 120, None, 2, True, False),   # fixed row frames (the graph-replay form)
+                          (3, 700, 4, 90, 90, 4, False, False)])
+def test_framed_step_gloo(world, rows, width, n, row_cap, block, expect_fallback, sized):
+    mp.spawn(_framed_worker, args=(world, _free_port(), rows, width, n, row_cap, block, expect_fallback, sized),
+             nprocs=world, join=True)
 
 
 def test_partition_is_average_partitioner():
