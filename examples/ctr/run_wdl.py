@@ -20,10 +20,22 @@ libherald_amd.so, in the three placements the reference's run_hetu.py offers:
   --embedding cache  HET cache (LRU / LFU / LFUOpt, bounded staleness) in front of the store
                      (comm_mode Hybrid + --cache POLICY --bound B, run_hetu.py:178-190)
 
+  --laia             the reference's run_laia.py loop (examples/ctr/run_laia.py:214-236): every rank runs the laia
+                     scheduler over the whole sample set (herald_amd.laia.LAIAScheduler: LaiaScheduler, or with
+                     --local-shared the TopkScheduler whose local rank 0 feeds the others through shared-memory rings),
+                     three LAIADataloaders (sparse ids, labels, dense features) hand it ITS share of each global batch,
+                     the sparse one as the tuple (ids, push plan); the rows come through the HET cache over the table
+                     row-sharded across the ranks, EmbeddingLookUp_Gradient(enable_push_index=True) turns the plan into
+                     IndexedSlices.push_indices and the communicate op pushes with embedding_update_with_push_keys;
+                     the dense tower's gradients are all-reduced (Hybrid).  torchrun for N > 1.
+  --model dcn        Deep & Cross (examples/ctr/models/dcn_criteo.py:8-74; the reference hard-codes d = 128 there, the
+                     embedding width is a parameter here) instead of Wide & Deep.
+
 Data is synthetic (herald_amd.synth: per-field zipf over the public Criteo cardinalities); labels come
 from a fixed random linear rule so that the loss has something to learn.
 
     python examples/ctr/run_wdl.py --embedding hbm --rows 2000000 --width 128 --steps 200
+    torchrun --nproc-per-node 4 --master-addr 127.0.0.1 examples/ctr/run_wdl.py --laia --model dcn --width 128
 """
 import argparse
 import os
@@ -60,6 +72,126 @@ class Tower(torch.nn.Module):
         return torch.sigmoid(torch.cat([emb_flat, y3], dim=1) @ self.W4)
 
 
+class CrossTower(torch.nn.Module):
+    """The dense part of dcn_criteo (models/dcn_criteo.py:8-74): x0 = [embeddings | dense features], three cross
+    layers x_{l+1} = x0 * (x_l w_l) + x_l + b_l, a 3-layer DNN on x0, one output layer over [cross | dnn]; every
+    weight ~ N(0, 0.01)."""
+
+    def __init__(self, width, seed=0, layers=3):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+
+        def w(*shape):
+            return torch.nn.Parameter(torch.randn(*shape, generator=g) * 0.01)
+        n = NFIELD * width + NDENSE
+        self.cw = torch.nn.ParameterList([w(n, 1) for _ in range(layers)])
+        self.cb = torch.nn.ParameterList([w(n) for _ in range(layers)])
+        self.W1, self.W2, self.W3 = w(n, 256), w(256, 256), w(256, 256)
+        self.W4 = w(256 + n, 1)
+
+    def forward(self, dense, emb_flat):
+        x0 = torch.cat([emb_flat, dense], dim=1)
+        x1 = x0
+        for cw, cb in zip(self.cw, self.cb):
+            x1 = x0 * (x1 @ cw) + x1 + cb
+        y3 = torch.relu(torch.relu(x0 @ self.W1) @ self.W2) @ self.W3
+        return torch.sigmoid(torch.cat([x1, y3], dim=1) @ self.W4)
+
+
+def make_tower(model, width, seed=0):
+    return {"wdl": Tower, "dcn": CrossTower}[model](width, seed)
+
+
+def make_samples(nsamples, rows, seed=0):
+    """One sample set for every rank (the laia scheduler distributes it): ids float32 [S, 26], dense [S, 13],
+    labels [S, 1]."""
+    rng = np.random.default_rng(seed + 77)
+    wd = rng.standard_normal(NDENSE).astype(np.float32)
+    chunk = 256
+    raw = np.concatenate([synth.criteo_batch(chunk, step=5000 + seed * 131 + c, rows=rows)
+                          for c in range(-(-nsamples // chunk))], axis=0)[:nsamples]
+    ids = np.minimum(synth.as_f32_ids(raw), np.float32(rows - 1))
+    dense = rng.standard_normal((nsamples, NDENSE)).astype(np.float32)
+    score = dense @ wd + ((raw[:, :4].sum(axis=1) % 7) - 3).astype(np.float32)
+    return ids, dense, (score > 0).astype(np.float32).reshape(-1, 1)
+
+
+def train_laia(model="wdl", rows=200000, width=32, batch=64, steps=20, lr=0.01, cache="LRU", bound=0, cache_limit=None,
+               seed=0, device="cuda:0", table_init=None, a2a=None, allreduce=None, local_shared=False, nsamples=None,
+               perf=False, log_every=0):
+    """The laia-driven loop (run_laia.py:214-236).  `batch` = samples per worker and step; a2a / allreduce: optional
+    replacements of the collectives (several ranks on one GPU under gloo in the tests).  Returns (losses, embedding
+    parameter, tower, communicate op)."""
+    import torch.distributed as dist
+    from herald_amd import laia as hlaia
+    dev = torch.device(device)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if nsamples is None:
+        nsamples = world * batch * max(steps + 2, hlaia.LAIAScheduler.WINDOW + 1)
+    ids_all, dense_all, label_all = make_samples(nsamples, rows, seed)
+    limit = cache_limit if cache_limit is not None else max(rows // 10, batch * NFIELD)
+    # the scheduler walks the whole sample set (every rank the same: laia_dataloader.py:29-95) ...
+    sched = hlaia.LAIAScheduler(ids_all, batch, dataset="criteo", local_shared=local_shared)
+    epochs = -(-steps * batch * world // nsamples) + 1
+    sched.start(nrank=world, rank=rank, cache_limit=limit, dataset_num=3, epoch_num=epochs, key_limit=rows,
+                local_rank=rank, local_size=world)
+    # ... and three loaders hand this worker its share of every global batch (run_laia.py:188-199)
+    sparse_dl = hlaia.LAIADataloader(sched, 0, True, ids_all, batch, name="train", device=dev)
+    label_dl = hlaia.LAIADataloader(sched, 1, False, label_all, batch, name="train", device=dev)
+    dense_dl = hlaia.LAIADataloader(sched, 2, False, dense_all, batch, name="train", device=dev)
+    for dl in (sparse_dl, label_dl, dense_dl):
+        dl.init_states(rank, world)
+    batch = sched.batch_size
+    tower = make_tower(model, width, seed).to(dev)
+    opt = torch.optim.SGD(tower.parameters(), lr=lr)
+    if table_init is None:
+        g = torch.Generator(device=dev).manual_seed(seed + 1)
+        table_init = torch.randn((rows, width), generator=g, device=dev) * 0.01
+    store = ShardedEmbedding(rows, width, dev, a2a=a2a)
+    store.table.copy_(table_init[store.starts[store.rank]:store.starts[store.rank + 1]])
+    param = hetu_ops.EmbeddingParameter(store=store)
+    config = hetu_ops.Config(comm_mode="Hybrid", bsp=0, prefetch=True, cstable_policy=cache, cache_bound=bound,
+                             cache_limit=limit, cache_perf_enable=perf)
+    comm = hetu_ops.ParameterServerCommunicateOp(param, lr, next_ids=sparse_dl.get_next_arr)
+    barrier = dist.barrier if world > 1 else (lambda: None)
+    comm.forward_hook(config, first_ids=sparse_dl.get_next_arr(), barrier=barrier)
+    lookup = hetu_ops.EmbeddingLookUp(param, enable_push_index=True)
+    lookup.forward_hook(config)
+    lookup_grad = hetu_ops.EmbeddingLookUp_Gradient(param.shape, enable_push_index=True)
+    if allreduce is None:
+        def allreduce(t):
+            dist.all_reduce(t)
+
+    losses = []
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ids_plan = sparse_dl.get_arr()                             # (ids [batch, 26], push plan): this worker's samples
+        label = label_dl.get_arr()
+        dense = dense_dl.get_arr()
+        emb = torch.empty((batch, NFIELD, width), dtype=torch.float32, device=dev)
+        lookup.compute(ids_plan, emb)                              # the rows the communicate op pulled for this batch
+        emb.requires_grad_(True)
+        pred = tower(dense, emb.reshape(batch, NFIELD * width))
+        loss = torch.nn.functional.binary_cross_entropy(pred, label)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if world > 1:                                              # Hybrid: dense parameters by all-reduce, averaged
+            for p_ in tower.parameters():
+                allreduce(p_.grad)
+                p_.grad.div_(world)
+        opt.step()
+        grad = lookup_grad.compute(emb.grad, ids_plan)             # IndexedSlices(indices, values, push_indices = plan)
+        comm.compute(grad)              # -lr scale, embedding_update_with_push_keys, barrier, lookup of the next batch
+        losses.append(float(loss.detach()))
+        if log_every and (k + 1) % log_every == 0 and rank == 0:
+            print("step %d loss %.5f (%.1f ms/step)" % (k + 1, np.mean(losses[-log_every:]),
+                                                        1e3 * (time.perf_counter() - t0) / (k + 1)))
+    torch.cuda.synchronize()
+    sched.sched.close()
+    return losses, param, tower, comm
+
+
 def make_batches(nbatch, batch, rows, seed=0, rank=0, world=1):
     """-> list of (ids float32 [batch, 26], dense float32 [batch, 13], label float32 [batch, 1])."""
     rng = np.random.default_rng(seed + 1000 * rank)
@@ -75,13 +207,17 @@ def make_batches(nbatch, batch, rows, seed=0, rank=0, world=1):
 
 
 def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, cache="LRU", bound=0,
-          cache_limit=None, seed=0, device="cuda:0", table_init=None, log_every=0):
-    """Runs `steps` training steps; returns (losses, embedding parameter, tower)."""
+          cache_limit=None, seed=0, device="cuda:0", table_init=None, log_every=0, model="wdl", a2a=None, allreduce=None):
+    """Runs `steps` training steps; returns (losses, embedding parameter, tower).  a2a / allreduce: optional
+    replacements of the collectives at world size > 1 (several ranks on one GPU under gloo in the tests)."""
     dev = torch.device(device)
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    tower = Tower(width, seed).to(dev)
+    tower = make_tower(model, width, seed).to(dev)
+    if allreduce is None:
+        def allreduce(t):
+            dist.all_reduce(t)
     opt = torch.optim.SGD(tower.parameters(), lr=lr)
     batches = make_batches(min(steps + 1, 64), batch, rows, seed, rank, world)
     dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in b) for b in batches]
@@ -98,7 +234,7 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         config = hetu_ops.Config(comm_mode=None)
         comm = None
     else:
-        store = ShardedEmbedding(rows, width, dev)
+        store = ShardedEmbedding(rows, width, dev, a2a=a2a)
         store.table.copy_(table_init[store.starts[store.rank]:store.starts[store.rank + 1]])
         param = hetu_ops.EmbeddingParameter(store=store)
         config = hetu_ops.Config(comm_mode="PS" if embedding == "ps" else "Hybrid", bsp=0, prefetch=True,
@@ -151,6 +287,10 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         loss = torch.nn.functional.binary_cross_entropy(pred, label)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if world > 1:                                              # data parallel: dense parameters by all-reduce, averaged
+            for p_ in tower.parameters():
+                allreduce(p_.grad)
+                p_.grad.div_(world)
         opt.step()
         grad = lookup_grad.compute(emb.grad, ids)                  # IndexedSlices(indices, values)
         if pipe is not None:
@@ -188,14 +328,22 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--lr", type=float, default=0.1)
+    ap.add_argument("--model", choices=["wdl", "dcn"], default="wdl")
+    ap.add_argument("--laia", action="store_true", help="the laia-scheduled loop of run_laia.py (cache over the sharded table)")
+    ap.add_argument("--local-shared", action="store_true", help="--laia with the TopkScheduler + shared-memory rings")
     args = ap.parse_args()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    losses, _, _ = train(args.embedding, args.rows, args.width, args.batch, args.steps, args.lr, args.cache,
-                         args.bound, device="cuda:%d" % local_rank, log_every=max(1, args.steps // 10))
+    if args.laia:
+        losses = train_laia(args.model, args.rows, args.width, args.batch, args.steps, args.lr, args.cache, args.bound,
+                            device="cuda:%d" % local_rank, local_shared=args.local_shared,
+                            log_every=max(1, args.steps // 10))[0]
+    else:
+        losses = train(args.embedding, args.rows, args.width, args.batch, args.steps, args.lr, args.cache,
+                       args.bound, device="cuda:%d" % local_rank, log_every=max(1, args.steps // 10), model=args.model)[0]
     if local_rank == 0:
         print("first 10 steps: loss %.5f   last 10 steps: loss %.5f" % (np.mean(losses[:10]), np.mean(losses[-10:])))
 

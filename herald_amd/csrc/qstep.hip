@@ -36,9 +36,13 @@
 //   L  16 <= c < 64            one wave per 32-column slice: lane = (occurrence group r of 8, column quad); every lane
 //                              sums lr*g over its occurrences r, r+8, ... in order, the eight partial sums are added as
 //                              a fixed tree, one subtract                                                  (tolerance)
-//   G  c >= 64                 one WORKGROUP per 64-column slice: wave w takes occurrences 16w..16w+15 of every block
-//                              of 256, partial sums meet in LDS, fixed tree over the waves, one subtract; all 16 waves
-//                              write the destinations                                                      (tolerance)
+//   G  c >= 64                 one WORKGROUP (four waves) per 32-column slice: wave w takes occurrences 64w..64w+63 of
+//                              every block of 256 the way an L item takes its run, the four partial sums meet in LDS as
+//                              (w0 + w1) + (w2 + w3), one subtract; all four waves write the destinations    (tolerance)
+// Workgroups are 256 threads -- four items each: the ~6,000 items of a Criteo step spread over the 256 compute units
+// in units of 4 waves (20 or 24 per CU) instead of 16 (16 or 32 per CU: the CUs that got two workgroups were the
+// launch's tail -- a kernel of the step's traffic shape without any bookkeeping takes 12.0 us per launch in 1024-thread
+// workgroups and 10.6 us in 256-thread ones, tools/floor_bench.hip).
 //   Z  key beyond the table    zeros to its destinations (the library's definition of such ids)
 // "tolerance": the reference subtracts lr*g occurrence by occurrence (two roundings each); L and G subtract a
 // deterministic tree sum instead -- within the 1e-5 relative the north star allows for accumulated gradients
@@ -51,11 +55,16 @@ namespace ha {
 
 constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers + counters = 75 KiB of LDS, two workgroups per CU
 #ifndef QV_COOPSLOTS
-#define QV_COOPSLOTS 64
+#define QV_COOPSLOTS 256
 #endif
+#ifndef QV_WG
+#define QV_WG 256
+#endif
+constexpr int kQWg = QV_WG;                    // threads per workgroup of the apply launch
+constexpr int kQWpw = kQWg / 64;               // waves (= wave items) per workgroup
 constexpr int kQCoopSlots = QV_COOPSLOTS;      // workgroups reserved for G items (they loop if there are more)
-constexpr int kQWorkerMax = 448;     // worker workgroups: with A, B and the coop slots the launch stays below the
-                                     // chip's 512 resident 1024-thread workgroups; the waves loop beyond that
+constexpr int kQWorkerMax = 448 * 16 / kQWpw;  // worker workgroups: with the coop slots the launch stays below the
+                                               // chip's 8,192 resident waves; the waves loop beyond that
 constexpr int kQSmallC = 3, kQSmallM = 16, kQMediumC = 15, kQLongC = 64;
 enum QKind { kQS = 0, kQM = 1, kQL = 2, kQZ = 3, kQG = 4, kQNone = 15 };
 
@@ -84,11 +93,11 @@ static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + 
 // Bounds.  A key with c occurrences in the batch to apply and m in the batch to look up has per512 items (S), per128 <=
 // 4 per512 (M: c >= 4 or m >= 17) or per32 <= 16 per512 (L: c >= 16): never more than per512 * (c + m) -- but NOT
 // per512 * c (a key with c = 1, m = 17 is an M item: 4 items for one position of the batch to apply).  Hence
-// wave items <= ceil(width/512) * (n_a + n_g), copy items <= ceil(width/512) * n_g, coop items <= ceil(width/64) * n_a / 64.
+// wave items <= ceil(width/512) * (n_a + n_g), copy items <= ceil(width/512) * n_g, coop items <= ceil(width/32) * n_a / 64.
 static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
     QLayout q;
     char *b = static_cast<char *>(ws);
-    q.cap_coop = static_cast<uint32_t>(ceil_div(width, 64) * (ceil_div(n_cap, kQLongC) + 1));
+    q.cap_coop = static_cast<uint32_t>(ceil_div(width, 32) * (ceil_div(n_cap, kQLongC) + 1));
     q.cap_wave = static_cast<uint32_t>(ceil_div(width, 512) * 2 * n_cap + 64);
     q.cap_copy = static_cast<uint32_t>(ceil_div(width, 512) * n_cap + 64);
     q.hdr = reinterpret_cast<QHeader *>(b);
@@ -470,7 +479,7 @@ __device__ __forceinline__ int q_kind(uint32_t c, uint32_t m, bool in_table) {
     return kQS;
 }
 __device__ __forceinline__ int q_slice(int kind) {   // columns per item
-    return kind == kQL ? 32 : kind == kQG ? 64 : kind == kQM ? 128 : 512;
+    return (kind == kQL || kind == kQG) ? 32 : kind == kQM ? 128 : 512;
 }
 
 __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
@@ -501,7 +510,7 @@ struct QCount {   // items per class: coop (G), long, medium, small (S and Z)
 // (selects on VALUES: an if / else chain over four variables is merged into `*select(&x..) += n`, which puts them --
 // and, through the by-reference captures of a lambda, the whole argument block -- into scratch memory)
 __device__ __forceinline__ QCount q_count(QCount t, int kind, uint32_t per512, uint32_t per128, uint32_t per32) {
-    t.g += kind == kQG ? (per32 + 1u) / 2u : 0u;   // 64-column slices: ceil(width / 64)
+    t.g += kind == kQG ? per32 : 0u;
     t.l += kind == kQL ? per32 : 0u;
     t.m += kind == kQM ? per128 : 0u;
     t.s += (kind == kQS || kind == kQZ) ? per512 : 0u;
@@ -816,6 +825,17 @@ __device__ __forceinline__ float4v shfl_xor4(float4v v, int mask) {
 #ifndef QV_INTERLEAVE
 #define QV_INTERLEAVE 1
 #endif
+#ifndef QV_ROWLD_NT
+#define QV_ROWLD_NT 0
+#endif
+template <typename V>
+__device__ __forceinline__ V q_ld_row(const float *p) {     // the table row an item updates / copies: read once per launch
+#if QV_ROWLD_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+#else
+    return *reinterpret_cast<const V *>(p);
+#endif
+}
 template <typename V>
 __device__ __forceinline__ void q_st_row(float *p, V v) {
 #if QV_ROW_NT
@@ -872,8 +892,8 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
     float *row = a.table + static_cast<uint64_t>(it.kind == kQZ ? 0u : it.key) * static_cast<uint64_t>(width);
     float4v r0{0.f, 0.f, 0.f, 0.f}, r1{0.f, 0.f, 0.f, 0.f};
     if (it.kind != kQZ) {   // every branch on the item is wave-uniform
-        r0 = ld4(row + la);
-        r1 = ld4(row + lb);
+        r0 = q_ld_row<float4v>(row + la);
+        r1 = q_ld_row<float4v>(row + lb);
     }
     int dv = 0;
     if (it.m > 0)
@@ -929,7 +949,7 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
         pidx = a.perm_a[it.st + min(static_cast<uint32_t>(lane), it.c - 1u)];
     if (it.m > 0)
         dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
-    float2v_ r = *reinterpret_cast<const float2v_ *>(row + lc);
+    float2v_ r = q_ld_row<float2v_>(row + lc);
     // branch-free: lanes >= c hold the index of the last occurrence, so the loads beyond c repeat a line the wave
     // has just asked for and the chain skips them by select (uniform branches around 15 loads make the compiler
     // spill; clamped loads are what scatter_dev.h does as well)
@@ -975,7 +995,7 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     int dv = 0;
     if (it.m > 0)
         dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
-    const float4v cur = ld4(row + col);
+    const float4v cur = q_ld_row<float4v>(row + col);
     float4v g[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -1008,64 +1028,62 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     }
 }
 
-// G: one 64-column slice by a whole workgroup, c >= 64.  lane = (row r of 4, column quad c4 of 16); wave w takes
-// occurrences 16w .. 16w+15 of every block of 256 (four 16-byte loads per lane and block).  s_part = 16 x 64 floats.
+// G: one 32-column slice by a whole workgroup of FOUR waves, c >= 64.  Every wave works like an L item on its share of
+// the run -- lane = (occurrence group r of 8, column quad c4 of 8), wave w takes occurrences 64w .. 64w+63 of every
+// block of 256 (eight 16-byte loads per lane and block) --, the four wave sums meet in LDS as (w0 + w1) + (w2 + w3).
+// s_part = 4 x 32 floats.
 __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s_part) {
     const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int width = a.width;
-    const int r = lane >> 4, c4 = lane & 15;
+    const int r = lane >> 3, c4 = lane & 7;
     const bool act = 4 * c4 < it.cols;
     const int col = it.col0 + (act ? 4 * c4 : 0);
     float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
-    const float4v cur = ld4(row + col);
-    // destinations of this wave: j = 64 * k + 4 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 2, l & 3):
-    // one register covers the first 16 rounds (1,024 destinations)
+    const float4v cur = q_ld_row<float4v>(row + col);
+    // destinations of this wave: j = 32 * k + 8 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 3, l & 7):
+    // one register covers eight rounds (256 destinations)
     int dv = 0;
     if (it.m > 0)
-        dv = a.perm_g[it.fs + min(static_cast<uint32_t>(64 * (lane >> 2) + 4 * w + (lane & 3)), it.m - 1u)];
+        dv = a.perm_g[it.fs + min(static_cast<uint32_t>(32 * (lane >> 3) + 8 * w + (lane & 7)), it.m - 1u)];
     float4v p{0.f, 0.f, 0.f, 0.f};
     for (uint32_t base = 0; base < it.c; base += 256) {
-        const uint32_t mine = base + 16u * static_cast<uint32_t>(w);   // this wave's first occurrence of the block
+        const uint32_t mine = base + 64u * static_cast<uint32_t>(w);   // this wave's first occurrence of the block
         if (mine >= it.c)
             break;   // wave-uniform; no barrier inside the loop
-        const int pidx = a.perm_a[it.st + min(mine + static_cast<uint32_t>(lane & 15), it.c - 1u)];
-        float4v g[4];
+        const int pidx = a.perm_a[it.st + min(mine + static_cast<uint32_t>(lane), it.c - 1u)];
+        float4v g[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t o = static_cast<uint32_t>(__shfl(pidx, 4 * t + r, 64));
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t o = static_cast<uint32_t>(__shfl(pidx, 8 * t + r, 64));
             g[t] = q_ld_grad<float4v>(a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + col);   // branch-free (clamped)
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 8; ++t) {
             const float4v q = acc4(p, g[t], a.lr);
-            const bool valid = mine + static_cast<uint32_t>(4 * t + r) < it.c;
+            const bool valid = mine + static_cast<uint32_t>(8 * t + r) < it.c;
             p = valid ? q : p;
         }
     }
+    p = add4(p, shfl_xor4(p, 8));
     p = add4(p, shfl_xor4(p, 16));
     p = add4(p, shfl_xor4(p, 32));
-    if (lane < 16)
-        *reinterpret_cast<float4v *>(s_part + w * 64 + 4 * c4) = p;
+    if (lane < 8)
+        *reinterpret_cast<float4v *>(s_part + w * 32 + 4 * c4) = p;
     __syncthreads();
-    // fixed tree over the 16 wave partials: lane group r adds the partials of waves 4r .. 4r+3 as (a + b) + (c + d),
-    // the four group sums meet by two butterfly steps -- ((q0 + q1) + (q2 + q3)) in every lane (IEEE addition
-    // commutes, so both partners of a step hold the same bits)
-    const float *sp = s_part + (4 * r) * 64 + 4 * c4;
-    float4v total = add4(add4(*reinterpret_cast<const float4v *>(sp), *reinterpret_cast<const float4v *>(sp + 64)),
-                         add4(*reinterpret_cast<const float4v *>(sp + 128), *reinterpret_cast<const float4v *>(sp + 192)));
-    total = add4(total, shfl_xor4(total, 16));
-    total = add4(total, shfl_xor4(total, 32));
+    const float *sp = s_part + 4 * c4;
+    const float4v total = add4(add4(*reinterpret_cast<const float4v *>(sp), *reinterpret_cast<const float4v *>(sp + 32)),
+                               add4(*reinterpret_cast<const float4v *>(sp + 64), *reinterpret_cast<const float4v *>(sp + 96)));
     const float4v nv = sub4(cur, total);
     if (w == 0 && r == 0 && act)
         q_st_row(row + col, nv);
-    for (uint32_t k0 = 0; k0 * 64u < it.m; k0 += 16) {
+    for (uint32_t k0 = 0; k0 * 32u < it.m; k0 += 8) {
         if (k0 > 0)
-            dv = a.perm_g[it.fs + min(64u * (k0 + static_cast<uint32_t>(lane >> 2)) + static_cast<uint32_t>(4 * w + (lane & 3)),
+            dv = a.perm_g[it.fs + min(32u * (k0 + static_cast<uint32_t>(lane >> 3)) + static_cast<uint32_t>(8 * w + (lane & 7)),
                                       it.m - 1u)];
-        const uint32_t rounds = min(16u, (it.m - 64u * k0 + 63u) / 64u);
+        const uint32_t rounds = min(8u, (it.m - 32u * k0 + 31u) / 32u);
         for (uint32_t k = 0; k < rounds; ++k) {
-            const uint32_t j = 64u * (k0 + k) + static_cast<uint32_t>(4 * w + r);
-            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(4 * k) + r, 64));
+            const uint32_t j = 32u * (k0 + k) + static_cast<uint32_t>(8 * w + r);
+            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(8 * k) + r, 64));
             if (j < it.m && act)
                 q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
         }
@@ -1075,7 +1093,8 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
 
 // ---- the three launches ----------------------------------------------------------------------------------------
 // The items of one step: workgroups [0, ncoop) take the G items, the others one wave item per wave.
-__global__ __launch_bounds__(1024, 8) void qapply_kernel(const QArgs a) {
+static_assert(kQWg == 256, "q_coop shares a slice among exactly four waves");
+__global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
@@ -1093,9 +1112,9 @@ __global__ __launch_bounds__(1024, 8) void qapply_kernel(const QArgs a) {
         b -= a.ncoop;
         role = 3;
         const uint32_t n0 = a.qh->n_wave, n = n0 + a.qh->n_copy;
-        const uint32_t stride = static_cast<uint32_t>(a.nworker) * 16u;
+        const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
-        for (uint32_t e = static_cast<uint32_t>(b) * 16u + wv; e < n; e += stride) {
+        for (uint32_t e = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv; e < n; e += stride) {
 #if QV_INTERLEAVE
             // Wave items and copy items ALTERNATE over the launch while both last (then the rest of the longer list):
             // a copy writes m rows for one it reads, an apply item reads more than it writes, and a compute unit that
@@ -1127,7 +1146,7 @@ __global__ __launch_bounds__(1024, 8) void qapply_kernel(const QArgs a) {
         if (lane_id() == 0) {
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long *d = a.dbg + (static_cast<size_t>(blockIdx.x) * 16 + (threadIdx.x >> 6)) * 4;
+            unsigned long long *d = a.dbg + (static_cast<size_t>(blockIdx.x) * kQWpw + (threadIdx.x >> 6)) * 4;
             d[0] = t0;
             d[1] = t1;
             d[2] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8);
@@ -1360,12 +1379,12 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
     a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
     // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
     const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
-    a.nworker = static_cast<int>(bound / 16 + 1 < kQWorkerMax ? bound / 16 + 1 : kQWorkerMax);
+    a.nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
     // the caller knows how many wave items the queue holds (ha_qstep_queue_mirror): no workgroups that find nothing --
     // a shorter launch ramp, and free slots for the preparation launches that run beside the steps
-    if (wave_items >= 0 && wave_items / 16 + 1 < a.nworker)
-        a.nworker = static_cast<int>(wave_items / 16 + 1);
-    hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(1024), 16 * 64 * 4, stream, a);
+    if (wave_items >= 0 && wave_items / kQWpw + 1 < a.nworker)
+        a.nworker = static_cast<int>(wave_items / kQWpw + 1);
+    hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 32 * 4, stream, a);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -1491,7 +1510,7 @@ extern "C" int ha_qstep_u64ids(float *table, int64_t rows, int64_t width, void *
                   as_stream(stream));
 }
 
-// development aids: the items of a step with per-wave time stamps (dbg = device uint64[(workgroups) * 16 * 4], zeroed);
+// development aids: the items of a step with per-wave time stamps (dbg = device uint64[(workgroups) * 4 * 4], zeroed);
 // one plan + one queue with the phase stamps of their workgroups (ph = device uint64[32], zeroed: plan at 0, the
 // queue's two workgroups at 16 and 24)
 extern "C" int ha_debug_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur,

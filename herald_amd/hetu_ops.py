@@ -23,10 +23,11 @@ from .sharded import ShardedEmbedding
 
 class Config:
     def __init__(self, comm_mode=None, bsp=0, prefetch=True, cstable_policy=None, cache_bound=100, cache_limit=0,
-                 use_sparse_pull=True):
+                 use_sparse_pull=True, cache_perf_enable=False):
         self.comm_mode, self.bsp, self.prefetch = comm_mode, bsp, prefetch
         self.cstable_policy, self.cache_bound, self.cache_limit = cstable_policy, cache_bound, cache_limit
         self.use_sparse_pull = use_sparse_pull
+        self.cache_perf_enable = cache_perf_enable        # executor.py: cache_perf_enable (run_hetu.py:508-515 dumps the dicts)
         self.ps_map = {}
 
 
@@ -147,6 +148,8 @@ class ParameterServerCommunicateOp:
                                                      config.cstable_policy, config.cache_bound,
                                                      device=store.table.device)
             p.cache = self.cache
+            if getattr(config, "cache_perf_enable", False):
+                self.cache.perf_enabled(True)
             self._push, self._pull, self._push_pull = self._push_cache, self._pull_cache, self._push_pull_cache
             if config.bsp == 0 and config.prefetch:
                 self.compute = self._compute_bsp_prefetch
@@ -166,6 +169,8 @@ class ParameterServerCommunicateOp:
                 self.compute = self._compute_no_prefetch
         if config.prefetch:                                            # first prefetch (:168-176, 196-205)
             ids = first_ids if first_ids is not None else self.next_ids()
+            if isinstance(ids, tuple):          # a laia data loader hands over (ids, push plan): cstable.py:49
+                ids = ids[0]
             self.sparse_pull_val = torch.empty(tuple(ids.shape) + (p.shape[1],), dtype=torch.float32,
                                                device=ids.device)
             config.ps_map[p] = (self._pull(ids), self.sparse_pull_val)
@@ -217,10 +222,13 @@ class ParameterServerCommunicateOp:
         return self.cache.embedding_update_with_push_keys(grad.indices.reshape(-1), grad.push_indices.reshape(-1), vals)
 
     def _pull_cache(self, ids):
+        if isinstance(ids, tuple):              # (ids, push plan) of a laia-scheduled batch (cstable.py:49)
+            ids = ids[0]
         return self.cache.embedding_lookup(ids.reshape(-1), self.sparse_pull_val.reshape(-1, self.parameter.shape[1]))
 
     def _push_pull_cache(self, grad):
-        return self.cache.embedding_push_pull(self.next_ids().reshape(-1),
+        nxt = self.next_ids()
+        return self.cache.embedding_push_pull((nxt[0] if isinstance(nxt, tuple) else nxt).reshape(-1),
                                               self.sparse_pull_val.reshape(-1, self.parameter.shape[1]),
                                               grad.indices.reshape(-1),
                                               grad.values.reshape(-1, self.parameter.shape[1]))
@@ -231,6 +239,8 @@ class ParameterServerCommunicateOp:
         return None
 
     def _pull_sparse(self, ids):
+        if isinstance(ids, tuple):
+            ids = ids[0]
         self.sparse_pull_val.copy_(self.parameter.store.pull(ids))
         return None
 

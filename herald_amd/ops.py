@@ -819,7 +819,10 @@ class QueueStepPipeline:
         s = self.side if self.overlap else main
         sp = _stream_ptr(s)
         vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        if self.overlap:
+        # HA_QNOSYNC=1 (MEASUREMENT ONLY, unsafe): no events between the two streams -- what the two packets on the
+        # caller's stream cost at a block boundary
+        nosync = os.environ.get("HA_QNOSYNC") == "1"
+        if self.overlap and not nosync:
             ev = self._event()
             ev.record(main)                    # the buffers about to be rewritten are free, the ids are there
             s.wait_event(ev)
@@ -881,7 +884,7 @@ class QueueStepPipeline:
                 cc[at + 2] = 0
             cs = (vp * cnt)(*[base + 16 * (j % ring) for j in steps])
             check(L.ha_qqueue_batch_counts(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, sp), "ha_qqueue_batch")
-        if self.overlap:
+        if self.overlap and not nosync:
             ev = self._event()
             ev.record(s)
             self._ev_side[b] = ev

@@ -561,7 +561,7 @@ int ha_qstep_u64ids(float *table, int64_t rows, int64_t width,
  * medium, copy small, overflow / order word of the apply part, overflow word of the copy part} */
 const uint32_t *ha_qstep_queue_header(const void *queue);
 /* development aids (tools/qstep_timeline.py): the items of a step with per-wave time stamps, dbg = device
- * uint64[(workgroups) * 16 * 4], zeroed; one plan + one queue with the phase stamps of their workgroups, ph = device
+ * uint64[(workgroups) * 4 * 4], zeroed; one plan + one queue with the phase stamps of their workgroups, ph = device
  * uint64[32], zeroed */
 int ha_debug_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
                     float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,

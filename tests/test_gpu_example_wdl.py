@@ -90,3 +90,150 @@ def test_wdl_one_launch_step_equals_the_two_call_path_bit_for_bit(dev):
         assert torch.equal(pa.table, pb.table), mode
         for p, q in zip(ta.parameters(), tb.parameters()):
             assert torch.equal(p, q), mode
+
+
+# ---- Deep & Cross (examples/ctr/models/dcn_criteo.py) through the same embedding placements -----------------------
+def test_dcn_training_matches_pytorch(dev):
+    """--model dcn: the cross network + DNN tower over [embeddings | dense features] with the table in HBM, against the
+    same loop in plain PyTorch ops."""
+    import run_wdl
+    g = torch.Generator(device=dev).manual_seed(5)
+    table_init = torch.randn((ROWS, WIDTH), generator=g, device=dev) * 0.01
+    tower = run_wdl.make_tower("dcn", WIDTH, 0).to(dev)
+    table = table_init.clone()
+    opt = torch.optim.SGD(tower.parameters(), lr=LR)
+    batches = run_wdl.make_batches(min(STEPS + 1, 64), BATCH, ROWS, 0)
+    ref = []
+    for k in range(STEPS):
+        ids, dense, label = (torch.from_numpy(a).to(dev) for a in batches[k % len(batches)])
+        idx = ids.long()
+        emb = table[idx].clone().requires_grad_(True)
+        loss = torch.nn.functional.binary_cross_entropy(tower(dense, emb.reshape(BATCH, run_wdl.NFIELD * WIDTH)), label)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        table.index_add_(0, idx.reshape(-1), emb.grad.reshape(-1, WIDTH), alpha=-LR)
+        ref.append(float(loss.detach()))
+    for mode in ("hbm", "queue"):
+        losses, param, tw = run_wdl.train(mode, ROWS, WIDTH, BATCH, STEPS, LR, table_init=table_init, device=str(dev),
+                                          model="dcn")
+        np.testing.assert_allclose(losses, ref, rtol=1e-4)
+        torch.testing.assert_close(param.table, table, rtol=RTOL, atol=ATOL)
+        for p, q in zip(tw.parameters(), tower.parameters()):
+            torch.testing.assert_close(p, q, rtol=1e-4, atol=1e-7)
+
+
+# ---- the laia-driven loop at world size 2 (run_laia.py:214-236) ---------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _laia_example_worker(rank, world, port, model, local_shared):
+    """One rank of `run_wdl.py --laia` on a GPU shared by all ranks (collectives staged through the host under gloo):
+    LAIAScheduler -> LAIADataloader tuples (ids, plan) -> HET cache over the row-sharded table ->
+    embedding_update_with_push_keys, dense tower all-reduced.  Held to
+      * a single-process PyTorch run of the same global step (every rank's samples as the laia MODEL's stream assigns
+        them, dense gradients averaged, embedding gradients applied to one table): this rank's losses at rtol 1e-4;
+      * oracle/cache_model.py fed with the same key / plan streams (one model per rank, one server): the perf
+        counters of this rank's cache, every lookup and every update."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "examples", "ctr"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    import run_wdl
+    from herald_amd import laia as hlaia
+    from oracle import cache_model, laia_model
+    rows, width, mini_bs, steps, lr, limit = 40000, 16, 32, 8, 0.05, 3000
+
+    def staged_a2a(out, inp, out_splits, in_splits, group):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu().contiguous(), out_splits, in_splits, group=group)
+        out.copy_(o)
+
+    def staged_allreduce(t):
+        c = t.detach().cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+
+    g = torch.Generator(device=dev).manual_seed(9)
+    table_init = torch.randn((rows, width), generator=g, device=dev) * 0.01
+    losses, param, tower, comm = run_wdl.train_laia(model, rows, width, mini_bs, steps, lr, cache="LRU", bound=0,
+                                                    cache_limit=limit, device=str(dev), table_init=table_init,
+                                                    a2a=staged_a2a, allreduce=staged_allreduce,
+                                                    local_shared=local_shared, perf=True)
+    # ---- the same global steps in one process, plain PyTorch --------------------------------------------------------
+    nsamples = world * mini_bs * max(steps + 2, hlaia.LAIAScheduler.WINDOW + 1)
+    ids_all, dense_all, label_all = run_wdl.make_samples(nsamples, rows, 0)
+    sparse = ids_all.astype(np.intc)
+    batch_num = (nsamples // world) // mini_bs
+    epochs = -(-steps * mini_bs * world // nsamples) + 1
+    if local_shared:
+        streams = [laia_model.TopkSchedulerModel(sparse.astype(np.uint64), epochs, mini_bs, batch_num, world, r, limit,
+                                                 hlaia.topk_num_threads(mini_bs), "criteo", hlaia.top_k_table["criteo"]).emit()
+                   for r in range(world)]
+    else:
+        streams = [laia_model.LaiaSchedulerModel(sparse.astype(np.uint64), epochs, mini_bs, batch_num, world, r, limit).emit()
+                   for r in range(world)]
+    ref_tower = run_wdl.make_tower(model, width, 0).to(dev)
+    opt = torch.optim.SGD(ref_tower.parameters(), lr=lr)
+    table = table_init.clone()
+    ref_losses = []
+    for k in range(steps):
+        per_rank, pgrads = [], None
+        for r in range(world):
+            sel = np.asarray(streams[r][2 * k + 1], dtype=np.int64)
+            idx = torch.from_numpy(ids_all[sel]).to(dev).long()
+            dense = torch.from_numpy(dense_all[sel]).to(dev)
+            label = torch.from_numpy(label_all[sel]).to(dev)
+            emb = table[idx].clone().requires_grad_(True)
+            loss = torch.nn.functional.binary_cross_entropy(ref_tower(dense, emb.reshape(mini_bs, run_wdl.NFIELD * width)), label)
+            ref_tower.zero_grad(set_to_none=True)
+            loss.backward()
+            gs = [p.grad.clone() for p in ref_tower.parameters()]
+            pgrads = gs if pgrads is None else [a + b for a, b in zip(pgrads, gs)]
+            per_rank.append((idx, emb.grad.clone(), float(loss.detach())))
+        for p, gsum in zip(ref_tower.parameters(), pgrads):
+            p.grad = gsum / world
+        opt.step()
+        for idx, eg, _ in per_rank:                               # rank order
+            table.index_add_(0, idx.reshape(-1), eg.reshape(-1, width), alpha=-lr)
+        ref_losses.append(per_rank[rank][2])
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-4, err_msg="losses of rank %d" % rank)
+    for p, q in zip(tower.parameters(), ref_tower.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-3, atol=1e-6)
+    # ---- the cache's counters against the cache model, all ranks in lock step ---------------------------------------------
+    server = cache_model.Server(table_init.cpu().numpy().copy())
+    models = [cache_model.CacheModel("lru", limit, width, server, 0, 0) for _ in range(world)]
+    keys = lambda r, k: ids_all[np.asarray(streams[r][2 * k + 1], dtype=np.int64)].reshape(-1).astype(np.uint64)
+    zero = np.zeros((mini_bs * run_wdl.NFIELD, width), np.float32)
+    for r in range(world):
+        models[r].lookup(keys(r, 0))
+    for k in range(steps):
+        for r in range(world):
+            models[r].update_with_push_keys(keys(r, k), np.asarray(streams[r][2 * k + 2], dtype=np.uint64), zero)
+        for r in range(world):
+            models[r].lookup(keys(r, k + 1))
+    got, want = comm.cache.perf, models[rank].perf
+    assert len(got) == len(want) == 2 * steps + 1
+    for i, (a, b) in enumerate(zip(got, want)):
+        for fld in ("type", "num_all", "num_unique", "num_miss", "num_transfered"):
+            assert a[fld] == b[fld], (rank, i, fld, a, b)
+    assert sum(p["num_transfered"] for p in got if p["type"] == "Push") > 0        # plans and evictions did push lines
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,local_shared", [("wdl", False), ("dcn", False), ("dcn", True)])
+def test_laia_example_world2_on_one_gpu(dev, model, local_shared):
+    import torch.multiprocessing as mp
+    mp.spawn(_laia_example_worker, args=(2, _free_port(), model, local_shared), nprocs=2, join=True)

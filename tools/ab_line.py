@@ -1,6 +1,10 @@
+"""stdin: bench.py's output; prints `<name> <kind> us/step X frac Y` from the last JSON line (A/B helper)."""
 import json, sys
-d = json.loads(sys.stdin.read())
-k = d["kernels"]
-print(" bench us/step %.2f | isolated fwd %.2f bwd %.2f" % (
-    d["ms_per_step"] * 1e3, k["fwd_fused_kernel(gather+rank)"]["isolated_us"],
-    k["bwd_fused_kernel(sgd apply+finish)"]["isolated_us"]))
+name, kind = (sys.argv + ["", ""])[1:3]
+lines = [l for l in sys.stdin.read().splitlines() if l.startswith("{")]
+if not lines:
+    print("%-24s %-6s no result" % (name, kind))
+else:
+    d = json.loads(lines[-1])
+    r = d.get("roofline") or {}
+    print("%-24s %-6s us/step %.2f  frac %.3f" % (name, kind, d["ms_per_step"] * 1e3, r.get("frac") or 0.0))

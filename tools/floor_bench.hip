@@ -25,24 +25,30 @@ struct RowArgs {
 };
 __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
-template <int IPW, int C, int M>
+template <int IPW, int C, int M, int FLAGS = 0>
 __global__ __launch_bounds__(1024, 8 / IPW) void rows_kernel(const RowArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     f4 r0[IPW], r1[IPW], g0[IPW][C], g1[IPW][C];
-    float *row[IPW];
+    float *row[IPW], *wrow[IPW];
     int item[IPW];
 #pragma unroll
     for (int k = 0; k < IPW; ++k) {
         item[k] = __builtin_amdgcn_readfirstlane(wave * IPW + k);
         const uint64_t r = (uint64_t)mix(item[k] * 2654435761u + a.seed) % a.rows;
         row[k] = a.table + r * 512;
+        wrow[k] = (FLAGS & 1) ? a.table + ((uint64_t)mix(item[k] * 40503u + a.seed + 17u) % a.rows) * 512 : row[k];
     }
 #pragma unroll
     for (int k = 0; k < IPW; ++k) {
         if (item[k] < a.items) {
-            r0[k] = *(const f4 *)(row[k] + 4 * lane);
-            r1[k] = *(const f4 *)(row[k] + 256 + 4 * lane);
+            if (FLAGS & 4) {
+                r0[k] = __builtin_nontemporal_load((const f4 *)(row[k] + 4 * lane));
+                r1[k] = __builtin_nontemporal_load((const f4 *)(row[k] + 256 + 4 * lane));
+            } else {
+                r0[k] = *(const f4 *)(row[k] + 4 * lane);
+                r1[k] = *(const f4 *)(row[k] + 256 + 4 * lane);
+            }
 #pragma unroll
             for (int t = 0; t < C; ++t) {
                 const float *g = a.grads + ((uint64_t)item[k] * C + t) * 512;
@@ -56,13 +62,23 @@ __global__ __launch_bounds__(1024, 8 / IPW) void rows_kernel(const RowArgs a) {
         if (item[k] < a.items) {
 #pragma unroll
             for (int t = 0; t < C; ++t) { r0[k] -= 0.001f * g0[k][t]; r1[k] -= 0.001f * g1[k][t]; }
-            __builtin_nontemporal_store(r0[k], (f4 *)(row[k] + 4 * lane));
-            __builtin_nontemporal_store(r1[k], (f4 *)(row[k] + 256 + 4 * lane));
+            if (FLAGS & 2) {
+                *(f4 *)(wrow[k] + 4 * lane) = r0[k];
+                *(f4 *)(wrow[k] + 256 + 4 * lane) = r1[k];
+            } else {
+                __builtin_nontemporal_store(r0[k], (f4 *)(wrow[k] + 4 * lane));
+                __builtin_nontemporal_store(r1[k], (f4 *)(wrow[k] + 256 + 4 * lane));
+            }
 #pragma unroll
             for (int t = 0; t < M; ++t) {
                 float *o = a.out + ((uint64_t)item[k] * M + t) * 512;
-                __builtin_nontemporal_store(r0[k], (f4 *)(o + 4 * lane));
-                __builtin_nontemporal_store(r1[k], (f4 *)(o + 256 + 4 * lane));
+                if (FLAGS & 8) {
+                    *(f4 *)(o + 4 * lane) = r0[k];
+                    *(f4 *)(o + 256 + 4 * lane) = r1[k];
+                } else {
+                    __builtin_nontemporal_store(r0[k], (f4 *)(o + 4 * lane));
+                    __builtin_nontemporal_store(r1[k], (f4 *)(o + 256 + 4 * lane));
+                }
             }
         }
     }
@@ -128,5 +144,34 @@ int main(int argc, char **argv) {
         run("copy only (C=0,M=1)", 6940, 1, 0, 1, wg);
         run("apply only (C=1,M=0)", 6940, 1, 1, 0, wg);
     }
+    printf("# variants of the step-like / apply-only kernels (256-thread workgroups unless said otherwise)\n");
+    auto runf = [&](const char *name, int items, int c, int m, int wg, int flags) {
+        RowArgs a{table, rows, nullptr, nullptr, items, c, m, 0};
+        const int wpw = wg / 64, grid = (items + wpw - 1) / wpw;
+        const float us = time_launches(s, 1000, [&](int i) {
+            RowArgs b = a; b.grads = grads[i % NB]; b.out = outs[i % NB]; b.seed = i * 7919u;
+#define LF(C_, M_, F) hipLaunchKernelGGL((rows_kernel<1, C_, M_, F>), dim3(grid), dim3(wg), 0, s, b)
+            if (c == 1 && m == 1) { switch (flags) { case 0: LF(1, 1, 0); break; case 1: LF(1, 1, 1); break; case 2: LF(1, 1, 2); break;
+                                                     case 4: LF(1, 1, 4); break; case 6: LF(1, 1, 6); break; case 8: LF(1, 1, 8); break; } }
+            else if (c == 1 && m == 0) { switch (flags) { case 0: LF(1, 0, 0); break; case 1: LF(1, 0, 1); break; case 2: LF(1, 0, 2); break;
+                                                          case 4: LF(1, 0, 4); break; case 6: LF(1, 0, 6); break; } }
+#undef LF
+        });
+        const double bytes = (double)items * 2048.0 * (2 + c + m);
+        printf("%-44s items %5d C %d M %d wg %4d flags %d: %6.2f us/launch  %.2f MB  %.2f TB/s\n", name, items, c, m, wg, flags, us,
+               bytes / 1e6, bytes / us / 1e6);
+    };
+    for (int wg : {64, 128, 256, 512, 1024})
+        runf("step-like by workgroup size", 5200, 1, 1, wg, 0);
+    runf("step-like, row written to ANOTHER row", 5200, 1, 1, 256, 1);
+    runf("step-like, plain row stores", 5200, 1, 1, 256, 2);
+    runf("step-like, nt row loads", 5200, 1, 1, 256, 4);
+    runf("step-like, nt row loads + plain row stores", 5200, 1, 1, 256, 6);
+    runf("step-like, plain out stores", 5200, 1, 1, 256, 8);
+    runf("apply-only", 6940, 1, 0, 256, 0);
+    runf("apply-only, row written to ANOTHER row", 6940, 1, 0, 256, 1);
+    runf("apply-only, plain row stores", 6940, 1, 0, 256, 2);
+    runf("apply-only, nt row loads", 6940, 1, 0, 256, 4);
+    runf("apply-only, nt row loads + plain row stores", 6940, 1, 0, 256, 6);
     return 0;
 }

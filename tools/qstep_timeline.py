@@ -23,8 +23,9 @@ grads = [torch.randn((n, width), device=dev) for _ in range(24)]
 outs = [torch.empty((n, width), device=dev) for _ in range(24)]
 pipe = ops.QueueStepPipeline(table, n, 1e-6, block=BK)
 LA = pipe.LOOKAHEAD
-NBLK = 1024
-dbg = torch.zeros(NBLK * 16 * 4, dtype=torch.int64, device=dev)
+NBLK = 2304
+WPW = 4      # waves per workgroup of the apply launch
+dbg = torch.zeros(NBLK * WPW * 4, dtype=torch.int64, device=dev)
 dbgp = torch.zeros(64, dtype=torch.int64, device=dev)
 ids_of = lambda j: ids[j] if 0 <= j < len(ids) else None
 stamp = 2 * BK + BK // 2          # a step in the middle of a block (the side work of that block is long under way)
@@ -40,7 +41,7 @@ for c in range(-LA, nsteps):
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy()
 ph = dbgp.cpu().numpy()
-nblk = 64 + min(448, (2 * n) // 16 + 1)
+nblk = 256 + min(1792, (2 * n) // WPW + 1)
 for name, off in (("plan workgroup (0 ids 1 claim 2 number 3 label 4 rank 5 scan 6 out 7)", 0),
                   ("queue workgroup 0 = keys of the batch to apply (0 load 1 table 2 count 3 scans 4 emit 5)", 16),
                   ("queue workgroup 1 = copies", 24)):
@@ -48,7 +49,7 @@ for name, off in (("plan workgroup (0 ids 1 claim 2 number 3 label 4 rank 5 scan
     pts = [(i, int(v)) for i, v in enumerate(st) if v > 0]
     if pts:
         print(name, "phases (us):", ", ".join("%d:%.2f" % (i, (v - pts[0][1]) * 0.01) for i, v in pts))
-d = raw[:nblk * 64].reshape(-1, 4)
+d = raw[:nblk * WPW * 4].reshape(-1, 4)
 live = d[:, 0] > 0
 base = d[live, 0].min()
 t0 = (d[:, 0] - base) * 0.01
@@ -77,4 +78,4 @@ for lo in np.arange(0, t1[live].max(), 1.0):
 idx = np.nonzero(live)[0]
 order = idx[np.argsort(-t1[idx])][:12]
 print("latest waves (block, wave, role, kind, start, end):",
-      [(int(i // 16), int(i % 16), int(role[i]), int(kind[i]), round(float(t0[i]), 2), round(float(t1[i]), 2)) for i in order])
+      [(int(i // WPW), int(i % WPW), int(role[i]), int(kind[i]), round(float(t0[i]), 2), round(float(t1[i]), 2)) for i in order])
