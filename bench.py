@@ -430,7 +430,11 @@ def main():
             # stream, beside the steps of the block before: at the start of block b, one launch plans the batches of
             # block b+2 (one workgroup each) and one builds the queues of block b+1 (two workgroups each).  All of it
             # happens inside the timed region, every block; --queue-serial: block = 1 on the timed stream.
-            pipe = ops.QueueStepPipeline(table, n, LR, block=args.queue_block, overlap=not args.queue_serial)
+            # sync="flags": nothing but apply launches on the timed stream -- every queue carries the epoch of its step (the
+            # apply checks it before its first item) and the last launch of a block completes the event the side stream waits
+            # for (no event record / wait between two steps); hipGraph replays (--graph-steps > 1) keep the event pair
+            qsync = "events" if (args.graph_steps > 1 or os.environ.get("HA_QSYNC") == "events") else "flags"
+            pipe = ops.QueueStepPipeline(table, n, LR, block=args.queue_block, overlap=not args.queue_serial, sync=qsync)
             LA, Bk = pipe.LOOKAHEAD, pipe.block
             G = Bk                       # graphs are cut at block starts (the side work is enqueued between them)
             ids_rows = [ids_dev[i] for i in range(nb)]        # the batches as tensors of their own, sliced once
@@ -727,6 +731,11 @@ def main():
                    "launches_per_step": args.launches,
                    "lookahead_batches": (pipe.LOOKAHEAD if queue else 3 if ahead2 else 1),
                    "engine": args.engine if one else "two launches",
+                   # keys with 16+ occurrences in a batch: row - tree_sum(lr*g) in a fixed order (within BASELINE.json's 1e-5
+                   # on accumulated gradients; everything else the reference's serial chain bit for bit).  The other engines
+                   # (--engine handoff / forward) are the serial chain throughout: numbers are like for like only per engine.
+                   "numerics": "tolerance>=16" if queue else "bit-exact",
+                   "stream_sync": (pipe.sync if queue and not args.queue_serial else None),
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
                              else "plain launches, one per step, enqueued ahead of the device",
                    "parallelism": "1 GPU"},
@@ -744,6 +753,10 @@ def main():
     if one and not ahead2:
         torch.cuda.synchronize()
         result["handoff_timeouts"] = int(plans[0].handoff_timed_out()) + int(plans[1].handoff_timed_out())
+    if queue:
+        torch.cuda.synchronize()
+        if pipe.overflowed():        # a queue overflowed / was read before it was complete: the number means nothing
+            raise SystemExit("bench.py: the work-queue engine raised its sticky error word")
     def secondary(name, fn):
         """Secondary lines must never cost the headline: a failure is recorded, not raised."""
         try:

@@ -111,6 +111,14 @@ def _declare(L):
     L.ha_qstep_max_ids.argtypes = []
     L.ha_qstep_init.restype = c.c_int
     L.ha_qstep_init.argtypes = []
+    L.ha_event_create.restype = vp
+    L.ha_event_create.argtypes = []
+    L.ha_qbig_max_ids.restype = i64
+    L.ha_qbig_max_ids.argtypes = []
+    L.ha_qbig_plan_bytes.restype = sz
+    L.ha_qbig_plan_bytes.argtypes = [i64]
+    L.ha_qbig_buckets.restype = c.c_int
+    L.ha_qbig_buckets.argtypes = [i64]
     L.ha_qstep_queue_bytes.restype = sz
     L.ha_qstep_queue_bytes.argtypes = [i64, i64]
     L.ha_qstep_queue_header.restype = vp
@@ -157,6 +165,17 @@ def _declare(L):
         "ha_gather2_u32map": [vp, i64, vp, i64, i64, vp, i64, vp, vp],
         "ha_shard_sized_serve_push": [vp, i64, i64, vp, c.c_int, c.c_int, i64, vp, i64, vp, vp, vp],
         "ha_push_apply_scaled_finished": [vp, i64, i64, vp, i64, vp, f32, vp],
+        "ha_qbig_plan_batch_f32ids": [vp, vp, vp, i64, i64, vp],
+        "ha_qbig_plan_batch_u64ids": [vp, vp, vp, i64, i64, vp],
+        "ha_qbig_queue_batch": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
+        "ha_qbig_apply": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, c.c_uint32, vp, vp, vp],
+        "ha_event_destroy": [vp],
+        "ha_event_record": [vp, vp],
+        "ha_stream_wait_event": [vp, vp],
+        "ha_qqueue_batch_epochs": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
+        "ha_qapply_steps_sync": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "ha_qapply_sync": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, c.c_uint32, vp, vp, vp],
+        "ha_qbig_plan_view": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
         "ha_plan_build_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_plan_build_batch_u64ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_shard_frames_serve_pull": [vp, i64, i64, vp, c.c_int, i64, i64, vp, vp, vp, vp],

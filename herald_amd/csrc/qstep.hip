@@ -48,6 +48,8 @@
 // deterministic tree sum instead -- within the 1e-5 relative the north star allows for accumulated gradients
 // (tests/test_gpu_qstep.py holds both: bit-exact below 16 occurrences, 1e-5 above).  Callers that need the serial
 // chain for every run length use ha_step_* / ha_sgd_push_pull_*.
+#include <hip/hip_ext.h>
+
 #include "plan_dev.h"
 #include "gather_dev.h"
 
@@ -74,13 +76,26 @@ struct QHeader {
     uint32_t n_copy, n_copy_medium, n_copy_small;  // items of the keys only the lookup names (another workgroup)
     uint32_t overflow_wave, overflow_copy;         // 1 = the builder counted more items than the queue holds (never, by the
                                                    // layout's bounds; checked by the host so that it could only fail loudly)
-    uint32_t reserved[54];
+    // "this queue is complete": the step's EPOCH (a non-zero tag of the step it was built for), written by the builder's
+    // two parts behind a device-scope release once their items are in place.  An apply launch that is given the epoch
+    // of its step checks both words before it reads an item (ha_qapply_steps_sync): callers that order the two streams
+    // without a wait on the apply's stream rest on it.  `done`: wide path, bucket workgroups that have finished.
+    uint32_t epoch_wave, epoch_copy, done;
+    uint32_t reserved[51];
 };
 static_assert(sizeof(QHeader) == 256, "queue header is one 256-byte line");
 struct QEntry {
-    uint32_t w[8];   // kind | col0/4 << 4, key, c | cols/4 << 16, first sorted position (apply batch), m,
-                     // first sorted position (lookup batch), occurrence indices 0..3 as 16-bit halves
+    uint32_t w[8];   // kind | col0/4 << 4, key, c, first position of the key's occurrence list (apply batch), m, first
+                     // position of its destination list (lookup batch), the first three occurrence indices as 21-bit
+                     // fields of the last two words (batches of up to 2^21 ids; the slice's width follows from kind / col0)
 };
+constexpr uint32_t kQOccMask = 0x1FFFFFu;
+__host__ __device__ __forceinline__ uint2 q_occ_pack(uint32_t o0, uint32_t o1, uint32_t o2) {
+    const unsigned long long v = static_cast<unsigned long long>(o0 & kQOccMask) |
+                                 (static_cast<unsigned long long>(o1 & kQOccMask) << 21) |
+                                 (static_cast<unsigned long long>(o2 & kQOccMask) << 42);
+    return uint2{static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32)};
+}
 static_assert(sizeof(QEntry) == 32, "queue items are 32 bytes");
 
 struct QLayout {
@@ -112,7 +127,7 @@ struct QPlan {   // what the roles read / write of a plan workspace
     PlanHeader *hdr;
     uint32_t *keys, *sorted, *uniq;
     int32_t *perm, *inverse, *counts, *seg, *upos;
-    uint32_t *occ;     // [2 * n]: per group, the first three occurrence indices as 16-bit words (A writes, B reads)
+    uint32_t *occ;     // [2 * n]: per group, the first three occurrence indices packed by q_occ_pack (A writes, B reads)
     int n;
 };
 static inline QPlan qplan(void *ws, int64_t n) {
@@ -135,7 +150,7 @@ struct QArgs {
     // workers: queue of this launch, occurrence indices of the batch to apply, destinations of the batch to look up
     const QHeader *qh;
     const QEntry *qcoop, *qwave, *qcopy;
-    uint32_t cap_coop, cap_wave;
+    uint32_t cap_coop, cap_wave, cap_copy;
     const int32_t *perm_a;
     int n_a;
     const float *grads;
@@ -144,6 +159,8 @@ struct QArgs {
     int n_g;
     float *out;
     int ncoop, nworker;
+    uint32_t epoch;            // 0: no check; else the tag queue `qh` must carry before an item is read
+    uint32_t *err;             // pinned host word raised (8) when the queue never became ready (may be NULL)
     unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind} per wave
 };
 
@@ -212,9 +229,14 @@ static inline size_t qsort_lds_bytes(int n) {
     return kQTabSize * 4 + 3 * npad * 2 + 8 + 32 * 4;
 }
 
-template <typename IdT, bool RANK_ATOMIC>
+// BUCKET: the batch is one hash bucket of a larger batch (the wide path below): `ids` are its keys in position order,
+// pos_map[i] the position of its i-th id in the whole batch -- occurrence lists and the groups' first occurrences leave
+// as positions of the whole batch, and only what the queue builder and the apply read is written (unique keys, counts,
+// segment starts, occurrence lists, first occurrences).
+template <typename IdT, bool RANK_ATOMIC, bool BUCKET = false>
 __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, const QPlan &p, uint32_t *lds,
-                                                  unsigned long long *ph = nullptr) {
+                                                  unsigned long long *ph = nullptr,
+                                                  const uint32_t *__restrict__ pos_map = nullptr) {
     const int n = p.n;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const int npad = (n + 1023) & ~1023;
@@ -354,7 +376,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
                     s_rank[i] = static_cast<uint16_t>(rk[r]);
             }
         }
-    } else {
+    } else if (!BUCKET) {
         // the other waves write what is known already
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -366,7 +388,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         }
     }
     __syncthreads();
-    if (w == 0) {
+    if (w == 0 && !BUCKET) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int i = tid + k * 1024;
@@ -433,9 +455,13 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         bool disorder = false;
         for (int qq = tid; qq < n; qq += 1024) {
             const uint32_t i = s_perm[qq];
-            p.perm[qq] = static_cast<int32_t>(i);
-            p.sorted[qq] = s_key[i];
-            p.upos[qq] = static_cast<int32_t>(s_gq[qq]);
+            if (BUCKET) {
+                p.perm[qq] = static_cast<int32_t>(pos_map[i]);
+            } else {
+                p.perm[qq] = static_cast<int32_t>(i);
+                p.sorted[qq] = s_key[i];
+                p.upos[qq] = static_cast<int32_t>(s_gq[qq]);
+            }
             // the ranking rests on one wave-instruction's same-address LDS atomics being served in lane order (probed per
             // device, lds_atomics_lane_ordered); every list is checked as it leaves, so a pattern the probe did not
             // sample cannot silently reorder a chain
@@ -447,10 +473,13 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         // small items; entries beyond the group's count are never used)
         for (uint32_t g = tid; g < U; g += 1024) {
             const int st = s_cnt[g];
-            uint2 oc;
-            oc.x = static_cast<uint32_t>(s_perm[min(st, n - 1)]) | (static_cast<uint32_t>(s_perm[min(st + 1, n - 1)]) << 16);
-            oc.y = s_perm[min(st + 2, n - 1)];
-            reinterpret_cast<uint2 *>(p.occ)[g] = oc;
+            uint32_t o0 = s_perm[min(st, n - 1)], o1 = s_perm[min(st + 1, n - 1)], o2 = s_perm[min(st + 2, n - 1)];
+            if (BUCKET) {
+                o0 = pos_map[o0];
+                o1 = pos_map[o1];
+                o2 = pos_map[o2];
+            }
+            reinterpret_cast<uint2 *>(p.occ)[g] = q_occ_pack(o0, o1, o2);
         }
     }
     q_phase(ph, 7);
@@ -493,7 +522,8 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
         uint4 lo, hi;
         lo.x = static_cast<uint32_t>(kind) | (static_cast<uint32_t>(col0 / 4) << 4);
         lo.y = key;
-        lo.z = c | (static_cast<uint32_t>(cols / 4) << 16);
+        lo.z = c;
+        (void)cols;
         lo.w = st;
         hi.x = m;
         hi.y = fs;
@@ -539,6 +569,7 @@ struct QJoin {      // what every part of the join needs (passed by reference to
     QHeader *bqh;
     QEntry *bcoop, *bwave, *bcopy;
     uint32_t bcap_coop, bcap_wave, bcap_copy, per512, per128, per32;
+    uint32_t st_base, fs_base;      // wide path: where this bucket's occurrence / destination lists start in the batch's
 };
 
 // group index of `key` in the table, or 0xFFFFFFFF
@@ -566,7 +597,7 @@ __device__ __forceinline__ QCount qjoin_emit_one(const QJoin &j, QCount b, QEntr
     const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
     // the layout's bound makes the test always true; never write beyond the queue
     if (at + cnt <= (kind == kQG ? j.bcap_coop : cap_wave))
-        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st, m, fs, j.width, o01, o2);
+        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st + j.st_base, m, fs + j.fs_base, j.width, o01, o2);
     return nb;
 }
 
@@ -601,7 +632,7 @@ __device__ __forceinline__ QCount qjoin_emit_groups(const QJoin &j, QCount b) {
         ka[r - R0] = j.pa.uniq[x];
         cst[r - R0] = static_cast<uint32_t>(j.pa.counts[x]) | (static_cast<uint32_t>(j.pa.seg[x]) << 16);
         o01[r - R0] = oc.x;
-        o2[r - R0] = oc.y & 0xFFFFu;
+        o2[r - R0] = oc.y;
     }
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
@@ -649,16 +680,24 @@ __device__ __forceinline__ QCount qjoin_emit_copies(const QJoin &j, QCount b) {
     return b;
 }
 
+// WIDE: pa / pg are ONE hash bucket of two larger batches (the wide path below); the workgroup appends its items to the
+// step's queue behind those of the other buckets (one atomic add per region on the header's counters, zeroed before
+// the launch), st_base / fs_base = where the bucket's occurrence / destination lists start in the batches' lists.
+template <bool WIDE = false>
 __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const uint64_t rows, const int width,
                                            QHeader *bqh, QEntry *bcoop, QEntry *bwave, QEntry *bcopy,
                                            const uint32_t bcap_coop, const uint32_t bcap_wave, const uint32_t bcap_copy,
                                            uint32_t *lds, uint32_t lds_bytes, const int part,
-                                           unsigned long long *ph = nullptr, uint32_t *mirror = nullptr) {
+                                           unsigned long long *ph = nullptr, uint32_t *mirror = nullptr,
+                                           const uint32_t st_base = 0, const uint32_t fs_base = 0,
+                                           const uint32_t epoch = 0, const uint32_t wide_parts = 0) {
     const int tid = threadIdx.x;
     q_phase(ph, 0);
     QJoin j;
     j.pa = pa;
     j.pg = pg;
+    j.st_base = st_base;
+    j.fs_base = fs_base;
     j.rows = rows;
     j.width = width;
     // (wave-uniform values read through the vector memory path: back to scalar registers, or every pointer and
@@ -717,7 +756,34 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
         b.m = qscan(t.m, j.s_w, &nM) + nL;            // queue order: long, medium, small
         b.s = qscan(t.s, j.s_w, &nS) + nL + nM;
         b.g = qscan(t.g, j.s_w, &nG);
-        if (tid == 0) {
+        if (WIDE) {
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t tot = nL + nM + nS;
+                const uint32_t bw = tot ? atomicAdd(&bqh->n_wave, tot) : 0u;
+                const uint32_t bc = nG ? atomicAdd(&bqh->n_coop, nG) : 0u;
+                if (nL) atomicAdd(&bqh->n_long, nL);
+                if (nM) atomicAdd(&bqh->n_medium, nM);
+                if (nS) atomicAdd(&bqh->n_small, nS);
+                uint32_t over = (bw + tot > bcap_wave || bc + nG > bcap_coop) ? 1u : 0u;
+                if ((pa.n > 0 && pa.hdr->reserved[kOrderFlagWord] != 0) || (pg.n > 0 && pg.hdr->reserved[kOrderFlagWord] != 0))
+                    over |= 2u;
+                if (over) {
+                    atomicOr(&bqh->overflow_wave, over);
+                    if (mirror)
+                        mirror[3] = over;
+                }
+                j.s_w[20] = bw;
+                j.s_w[21] = bc;
+            }
+            __syncthreads();
+            const uint32_t bw = j.s_w[20], bc = j.s_w[21];
+            b.l += bw;
+            b.m += bw;
+            b.s += bw;
+            b.g += bc;
+        }
+        if (!WIDE && tid == 0) {
             bqh->n_wave = min(nL + nM + nS, bcap_wave);
             bqh->n_coop = min(nG, bcap_coop);
             bqh->n_long = nL;
@@ -751,7 +817,26 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
         QCount b{0u, 0u, 0u, 0u};
         b.m = qscan(t.m, j.s_w, &nM);                 // copies: medium (many destinations), then small / zero
         b.s = qscan(t.s, j.s_w, &nS) + nM;
-        if (tid == 0) {
+        if (WIDE) {
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t tot = nM + nS;
+                const uint32_t bw = tot ? atomicAdd(&bqh->n_copy, tot) : 0u;
+                if (nM) atomicAdd(&bqh->n_copy_medium, nM);
+                if (nS) atomicAdd(&bqh->n_copy_small, nS);
+                if (bw + tot > bcap_copy) {
+                    atomicOr(&bqh->overflow_copy, 1u);
+                    if (mirror)
+                        mirror[3] = 1u;
+                }
+                j.s_w[20] = bw;
+            }
+            __syncthreads();
+            const uint32_t bw = j.s_w[20];
+            b.m += bw;
+            b.s += bw;
+        }
+        if (!WIDE && tid == 0) {
             bqh->n_copy = min(nM + nS, bcap_copy);
             bqh->n_copy_medium = nM;
             bqh->n_copy_small = nS;
@@ -769,6 +854,19 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             b = qjoin_emit_copies<4, 7>(j, b);
     }
     q_phase(ph, 5);
+    // the queue is complete once every builder workgroup has passed this point: items visible device-wide (release), then
+    // the epoch words -- by this part for its own region (narrow path: two workgroups per step), or by whichever of the
+    // step's `wide_parts` bucket workgroups finishes last
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (!WIDE) {
+            __hip_atomic_store(part == 0 ? &bqh->epoch_wave : &bqh->epoch_copy, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (atomicAdd(&bqh->done, 1u) + 1u == wide_parts) {
+            __hip_atomic_store(&bqh->epoch_wave, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&bqh->epoch_copy, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // =====================================================================================================
@@ -865,15 +963,15 @@ struct QItem {
     int kind, col0, cols;
     uint32_t key, c, st, m, fs, o01, o23;
 };
-__device__ __forceinline__ QItem q_load(const QEntry *e) {
+__device__ __forceinline__ QItem q_load(const QEntry *e, int width) {
     // the address is wave-uniform: scalar loads
     const uint4 lo = reinterpret_cast<const uint4 *>(e)[0], hi = reinterpret_cast<const uint4 *>(e)[1];
     QItem it;
     it.kind = static_cast<int>(uniform(lo.x & 15u));
     it.col0 = static_cast<int>(uniform(lo.x >> 4)) * 4;
     it.key = uniform(lo.y);
-    it.c = uniform(lo.z & 0xFFFFu);
-    it.cols = static_cast<int>(uniform(lo.z >> 16)) * 4;
+    it.c = uniform(lo.z);
+    it.cols = min(q_slice(it.kind), width - it.col0);
     it.st = uniform(lo.w);
     it.m = uniform(hi.x);
     it.fs = uniform(hi.y);
@@ -902,7 +1000,8 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
 #pragma unroll
     for (int t = 0; t < kQSmallC; ++t) {
         if (static_cast<uint32_t>(t) < it.c) {
-            const uint32_t o = t == 0 ? (it.o01 & 0xFFFFu) : t == 1 ? (it.o01 >> 16) : (it.o23 & 0xFFFFu);
+            const uint32_t o = t == 0 ? (it.o01 & kQOccMask)
+                                      : t == 1 ? (((it.o01 >> 21) | (it.o23 << 11)) & kQOccMask) : ((it.o23 >> 10) & kQOccMask);
             const float *src = a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width);
             g0[t] = q_ld_grad<float4v>(src + la);
             g1[t] = q_ld_grad<float4v>(src + lb);
@@ -1040,13 +1139,14 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
     const int col = it.col0 + (act ? 4 * c4 : 0);
     float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
     const float4v cur = q_ld_row<float4v>(row + col);
-    // destinations of this wave: j = 32 * k + 8 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 3, l & 7):
-    // one register covers eight rounds (256 destinations)
+    // destinations of this wave: j = 8 W * k + 8 * w + r in round k (W waves).  Lane l fetches the one of (k, r) =
+    // (l >> 3, l & 7): one register covers eight rounds
+    constexpr uint32_t kDW = 8u * kQWpw, kBlk = 64u * kQWpw;
     int dv = 0;
     if (it.m > 0)
-        dv = a.perm_g[it.fs + min(static_cast<uint32_t>(32 * (lane >> 3) + 8 * w + (lane & 7)), it.m - 1u)];
+        dv = a.perm_g[it.fs + min(kDW * static_cast<uint32_t>(lane >> 3) + static_cast<uint32_t>(8 * w + (lane & 7)), it.m - 1u)];
     float4v p{0.f, 0.f, 0.f, 0.f};
-    for (uint32_t base = 0; base < it.c; base += 256) {
+    for (uint32_t base = 0; base < it.c; base += kBlk) {
         const uint32_t mine = base + 64u * static_cast<uint32_t>(w);   // this wave's first occurrence of the block
         if (mine >= it.c)
             break;   // wave-uniform; no barrier inside the loop
@@ -1071,18 +1171,22 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
         *reinterpret_cast<float4v *>(s_part + w * 32 + 4 * c4) = p;
     __syncthreads();
     const float *sp = s_part + 4 * c4;
-    const float4v total = add4(add4(*reinterpret_cast<const float4v *>(sp), *reinterpret_cast<const float4v *>(sp + 32)),
-                               add4(*reinterpret_cast<const float4v *>(sp + 64), *reinterpret_cast<const float4v *>(sp + 96)));
+    float4v total = add4(add4(*reinterpret_cast<const float4v *>(sp), *reinterpret_cast<const float4v *>(sp + 32)),
+                         add4(*reinterpret_cast<const float4v *>(sp + 64), *reinterpret_cast<const float4v *>(sp + 96)));
+#pragma unroll
+    for (int q = 1; q < kQWpw / 4; ++q)        // (timing variants with larger workgroups; the product has four waves)
+        total = add4(total, add4(add4(*reinterpret_cast<const float4v *>(sp + 128 * q), *reinterpret_cast<const float4v *>(sp + 128 * q + 32)),
+                                 add4(*reinterpret_cast<const float4v *>(sp + 128 * q + 64), *reinterpret_cast<const float4v *>(sp + 128 * q + 96))));
     const float4v nv = sub4(cur, total);
     if (w == 0 && r == 0 && act)
         q_st_row(row + col, nv);
-    for (uint32_t k0 = 0; k0 * 32u < it.m; k0 += 8) {
+    for (uint32_t k0 = 0; k0 * kDW < it.m; k0 += 8) {
         if (k0 > 0)
-            dv = a.perm_g[it.fs + min(32u * (k0 + static_cast<uint32_t>(lane >> 3)) + static_cast<uint32_t>(8 * w + (lane & 7)),
+            dv = a.perm_g[it.fs + min(kDW * (k0 + static_cast<uint32_t>(lane >> 3)) + static_cast<uint32_t>(8 * w + (lane & 7)),
                                       it.m - 1u)];
-        const uint32_t rounds = min(8u, (it.m - 32u * k0 + 31u) / 32u);
+        const uint32_t rounds = min(8u, (it.m - kDW * k0 + kDW - 1u) / kDW);
         for (uint32_t k = 0; k < rounds; ++k) {
-            const uint32_t j = 32u * (k0 + k) + static_cast<uint32_t>(8 * w + r);
+            const uint32_t j = kDW * (k0 + k) + static_cast<uint32_t>(8 * w + r);
             const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(8 * k) + r, 64));
             if (j < it.m && act)
                 q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
@@ -1093,25 +1197,44 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
 
 // ---- the three launches ----------------------------------------------------------------------------------------
 // The items of one step: workgroups [0, ncoop) take the G items, the others one wave item per wave.
-static_assert(kQWg == 256, "q_coop shares a slice among exactly four waves");
+static_assert(kQWg == 256 || kQWg == 512 || kQWg == 1024, "workgroups of 4, 8 or 16 waves (the product and its model: 4)");
 __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
     int b = blockIdx.x;
+    if (a.epoch != 0u) {
+        // The caller orders this launch behind the queue's builder without a wait on this stream (the builder ran a block of
+        // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
+        // ~1 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
+        bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;     // (read with the header's counts)
+        for (int spin = 0; !ready && spin < (1 << 20); ++spin) {
+            const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
+            if (ready)
+                break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        if (!ready) {
+            if (a.err != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+                __hip_atomic_store(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
     const bool coop = b < a.ncoop;
     if (coop) {
         role = 0;
-        const uint32_t n = a.qh->n_coop;
+        const uint32_t n = min(a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
         for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
-            const QItem it = q_load(a.qcoop + e);
+            const QItem it = q_load(a.qcoop + e, a.width);
             q_coop(a, it, reinterpret_cast<float *>(s_dyn));
             kind = it.kind;
         }
     } else {
         b -= a.ncoop;
         role = 3;
-        const uint32_t n0 = a.qh->n_wave, n = n0 + a.qh->n_copy;
+        const uint32_t n0 = min(a.qh->n_wave, a.cap_wave), n = n0 + min(a.qh->n_copy, a.cap_copy);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
         for (uint32_t e = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv; e < n; e += stride) {
@@ -1127,9 +1250,9 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
                 src = (e & 1u) ? a.qcopy + (e >> 1) : a.qwave + (e >> 1);
             else
                 src = n0 > n1 ? a.qwave + (e - n1) : a.qcopy + (e - n0);
-            const QItem it = q_load(src);
+            const QItem it = q_load(src, a.width);
 #else
-            const QItem it = q_load(e < n0 ? a.qwave + e : a.qcopy + (e - n0));
+            const QItem it = q_load(e < n0 ? a.qwave + e : a.qcopy + (e - n0), a.width);
 #endif
             kind = it.kind;
             if (it.kind == kQL)
@@ -1181,13 +1304,15 @@ struct QJoinBatch {
     QHeader *qh[kQJoinBatch];
     QEntry *coop[kQJoinBatch], *wave[kQJoinBatch], *copy[kQJoinBatch];
     uint32_t *mirror[kQJoinBatch];   // optional pinned host words per step: {wave items, workgroup items, copy items} + 1
+    uint32_t epoch[kQJoinBatch];     // the tag the finished queue carries (0: none asked for)
     unsigned long long *ph;     // development aid: phase stamps of workgroups 0 and 1
 };
 __global__ __launch_bounds__(1024, 4) void qqueue_kernel(const QJoinBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const int i = blockIdx.x >> 1, part = blockIdx.x & 1;
     qjoin_body(b.pa[i], b.pg[i], b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave,
-               b.cap_copy, s_dyn, b.lds_bytes, part, (i == 0 && b.ph) ? b.ph + 8 * part : nullptr, b.mirror[i]);
+               b.cap_copy, s_dyn, b.lds_bytes, part, (i == 0 && b.ph) ? b.ph + 8 * part : nullptr, b.mirror[i], 0u, 0u,
+               b.epoch[i]);
 }
 
 // One wave-instruction's LDS atomics on one address: are the lanes served in ascending lane order?  Four collision
@@ -1291,7 +1416,8 @@ static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *pla
 
 static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
                         const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
-                        hipStream_t stream, unsigned long long *ph = nullptr, uint32_t *const *counts_host = nullptr) {
+                        hipStream_t stream, unsigned long long *ph = nullptr, uint32_t *const *counts_host = nullptr,
+                        const uint32_t *epochs = nullptr) {
     HA_REQUIRE(rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 && width <= (1 << 20),
                "ha_qqueue_batch: rows of a multiple of 4 floats");
     HA_REQUIRE(count >= 0 && (count == 0 || (plans_a && n_a && plans_g && n_g && queues)), "ha_qqueue_batch: null pointer");
@@ -1322,6 +1448,7 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
             const QLayout q = queue_layout(queues[k], queue_n_cap, width);
             b.qh[i] = q.hdr;
             b.mirror[i] = counts_host ? counts_host[k] : nullptr;
+            b.epoch[i] = epochs ? epochs[k] : 0u;
             b.coop[i] = q.coop;
             b.wave[i] = q.wave;
             b.copy[i] = q.copy;
@@ -1342,24 +1469,48 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
     return 0;
 }
 
+static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t *perm_cur, int64_t n_cur, const float *grads,
+                        float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
+                        int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg = nullptr,
+                        int64_t wave_items = -1, uint32_t epoch = 0, uint32_t *err = nullptr, hipEvent_t done = nullptr);
+
 static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                   void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
-                  hipStream_t stream, unsigned long long *dbg = nullptr, int64_t wave_items = -1) {
+                  hipStream_t stream, unsigned long long *dbg = nullptr, int64_t wave_items = -1, uint32_t epoch = 0,
+                  uint32_t *err = nullptr, hipEvent_t done = nullptr) {
+    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && (n_cur == 0 || plan_cur) && (n_next == 0 || plan_next),
+               "ha_qapply: a batch needs its plan");
+    return qapply_lists(table, rows, width, n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr, n_cur, grads, lr,
+                        n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr, n_next, next_out, queue_cur, queue_n_cap,
+                        kQMax, stream, dbg, wave_items, epoch, err, done);
+}
+
+// perm_cur / perm_next: the occurrence lists of the batch to apply / the destination lists of the batch to look up (what
+// the items' `st` / `fs` index); n_max: the largest batch of the path that built the queue
+static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t *perm_cur, int64_t n_cur, const float *grads,
+                        float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
+                        int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg,
+                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done) {
     HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
                    width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
                "ha_qapply: the table must be 16-byte aligned with rows of a multiple of 4 floats");
-    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && n_cur <= kQMax && n_next <= kQMax && queue_n_cap >= 1 &&
-                   queue_n_cap <= kQMax && n_cur <= queue_n_cap && n_next <= queue_n_cap,
-               "ha_qapply: at most %d ids per batch and no more than the queue was sized for", kQMax);
-    HA_REQUIRE(n_cur == 0 || (plan_cur && grads && reinterpret_cast<uintptr_t>(grads) % 16 == 0),
+    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && n_cur <= n_max && n_next <= n_max && queue_n_cap >= 1 &&
+                   queue_n_cap <= n_max && n_cur <= queue_n_cap && n_next <= queue_n_cap,
+               "ha_qapply: at most %lld ids per batch and no more than the queue was sized for", (long long)n_max);
+    HA_REQUIRE(n_cur == 0 || (perm_cur && grads && reinterpret_cast<uintptr_t>(grads) % 16 == 0),
                "ha_qapply: current batch needs its plan and 16-byte aligned gradients");
-    HA_REQUIRE(n_next == 0 || (plan_next && next_out && reinterpret_cast<uintptr_t>(next_out) % 16 == 0),
+    HA_REQUIRE(n_next == 0 || (perm_next && next_out && reinterpret_cast<uintptr_t>(next_out) % 16 == 0),
                "ha_qapply: next batch needs its plan and a 16-byte aligned output");
-    if (n_cur == 0 && n_next == 0)
+    if (n_cur == 0 && n_next == 0) {
+        if (done != nullptr)        // nothing to launch: the event still has to mark this point of the stream
+            HA_CHECK_HIP(hipEventRecord(done, stream));
         return 0;
+    }
     HA_REQUIRE(queue_cur != nullptr, "ha_qapply: the queue of this step is missing");
     QArgs a;
     memset(&a, 0, sizeof(a));
+    a.epoch = epoch;
+    a.err = err;
     a.table = table;
     a.rows = static_cast<uint64_t>(rows);
     a.width = static_cast<int>(width);
@@ -1370,10 +1521,13 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
     a.qcoop = q.coop;
     a.qwave = q.wave;
     a.qcopy = q.copy;
-    a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
+    a.cap_coop = q.cap_coop;
+    a.cap_wave = q.cap_wave;
+    a.cap_copy = q.cap_copy;
+    a.perm_a = perm_cur;
     a.n_a = static_cast<int>(n_cur);
     a.grads = grads;
-    a.perm_g = n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr;
+    a.perm_g = perm_next;
     a.n_g = static_cast<int>(n_next);
     a.out = next_out;
     a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
@@ -1384,8 +1538,397 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
     // a shorter launch ramp, and free slots for the preparation launches that run beside the steps
     if (wave_items >= 0 && wave_items / kQWpw + 1 < a.nworker)
         a.nworker = static_cast<int>(wave_items / kQWpw + 1);
-    hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 32 * 4, stream, a);
+    if (done != nullptr)
+        // the event completes with THIS launch (the dispatch packet's own completion signal): no packet of its own on the
+        // stream -- an event record between two launches of a stream costs what a short kernel costs
+        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 32 * 4, stream,
+                              nullptr, done, 0, a);
+    else
+        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 32 * 4, stream, a);
     HA_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// =====================================================================================================
+// The WIDE path: batches of more than kQMax ids (BASELINE configs[2] / configs[3] on one GPU: 106,496 and 26,624 ids).
+//
+// A plan workgroup groups at most kQMax ids (its keys sit in registers, its hash table in LDS).  A larger batch is cut
+// into P hash BUCKETS first -- bucket = top bits of key * 0x85EBCA6B, a multiplier of its own so that the table hash
+// inside a bucket stays uniform -- by ONE stable multisplit of (key, position): tile histograms, then a scatter that
+// ranks its tile with wave ballots (the order of the positions inside a bucket is the order of the batch, which is what
+// keeps the occurrence lists in the reference's order).  Every bucket is then a small batch of its own:
+//   plans   one workgroup per (batch, bucket), the SAME grouping body (qsort_finish_body<.., BUCKET>); unique keys,
+//           counts, segment starts and first occurrences go to the bucket's slice of per-batch arrays, the occurrence
+//           lists -- as positions of the whole batch -- to its slice of ONE list per batch (`gperm`);
+//   queues  equal keys of two batches fall into equal buckets, so bucket p of the batch to apply joins bucket p of the
+//           batch to look up and nothing else: two workgroups per (step, bucket), the SAME join body (qjoin_body<WIDE>),
+//           appending to the step's queue with one atomic add per region;
+//   apply   the same launch as the narrow path (qapply_kernel), items numbered across the buckets.
+// No sort anywhere: the 43 us radix sort of a 106,496-id batch (four launches of 26 workgroups) becomes two partition
+// launches and P-fold parallel plan / queue workgroups of ~2,000 ids each.  Limits: at most kQBigMax ids per batch
+// (positions are 21-bit fields of an item); a BUCKET holds at most kQMax ids -- with P = n / 2048 rounded up to a power
+// of two that leaves room for a key with ~5,000 occurrences (a key names a sample of a field once: c <= the batch
+// size, 4,096 at configs[2]); a bucket beyond that raises the sticky overflow word instead of dropping ids.
+// =====================================================================================================
+constexpr int kQBigTile = 4096;
+constexpr int kQBigBucketsMax = 64;
+constexpr int64_t kQBigMax = 1 << 17;
+constexpr int kQBigTilesMax = static_cast<int>(kQBigMax / kQBigTile);      // 32
+
+static inline int qbig_buckets(int64_t n_cap) {
+    int p = 2;
+    while (p < kQBigBucketsMax && static_cast<int64_t>(p) * 2048 < n_cap)
+        p *= 2;
+    return p;
+}
+__device__ __forceinline__ uint32_t qbig_bucket(uint32_t key, int logp) {
+    return (key * 0x85EBCA6Bu) >> (32 - logp);
+}
+
+struct QBigRef {        // one batch's wide-plan workspace (device pointers)
+    const void *ids;
+    int n;
+    uint32_t *meta;     // [0]: a bucket holds more than kQMax ids (sticky until the next partition)
+    uint32_t *boff;     // [P + 1] first position of every bucket in the bucket-ordered arrays
+    uint32_t *thist;    // [tiles * P] ids per (tile, bucket)
+    uint32_t *bkeys, *bpos;         // [n] keys / positions in bucket order (position order inside a bucket)
+    int32_t *gperm;     // [n] occurrence lists of all buckets' groups, as positions of the batch
+    uint32_t *uniq;     // [n] unique keys, bucket p's groups from boff[p]
+    int32_t *counts;    // [n]
+    int32_t *seg;       // [n + P + 1] bucket p's segment starts (local to the bucket) from boff[p] + p
+    uint32_t *occ;      // [2 n] first occurrences per group (q_occ_pack)
+    PlanHeader *bhdr;   // [P]
+};
+static inline size_t qbig_layout(void *ws, int64_t n_cap, QBigRef *r) {
+    char *b = static_cast<char *>(ws);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *q = b ? b + off : nullptr;
+        off += align_up(bytes, 256);
+        return q;
+    };
+    const int P = qbig_buckets(n_cap);
+    const size_t n4 = static_cast<size_t>(n_cap) * 4;
+    QBigRef t;
+    memset(&t, 0, sizeof(t));
+    t.meta = reinterpret_cast<uint32_t *>(take(256));
+    t.boff = reinterpret_cast<uint32_t *>(take((P + 1) * 4));
+    t.thist = reinterpret_cast<uint32_t *>(take(static_cast<size_t>(kQBigTilesMax) * P * 4));
+    t.bkeys = reinterpret_cast<uint32_t *>(take(n4));
+    t.bpos = reinterpret_cast<uint32_t *>(take(n4));
+    t.gperm = reinterpret_cast<int32_t *>(take(n4));
+    t.uniq = reinterpret_cast<uint32_t *>(take(n4));
+    t.counts = reinterpret_cast<int32_t *>(take(n4));
+    t.seg = reinterpret_cast<int32_t *>(take(n4 + (P + 1) * 4));
+    t.occ = reinterpret_cast<uint32_t *>(take(2 * n4));
+    t.bhdr = reinterpret_cast<PlanHeader *>(take(static_cast<size_t>(P) * sizeof(PlanHeader)));
+    if (r)
+        *r = t;
+    return off;
+}
+
+struct QBigBatch {
+    int count, P, logp;
+    QBigRef r[kQBatch];
+};
+
+template <typename IdT>
+__global__ __launch_bounds__(1024) void qbpart_hist_kernel(const QBigBatch b) {
+    __shared__ uint32_t s_h[kQBigBucketsMax];
+    const QBigRef &r = b.r[blockIdx.y];
+    const int n = r.n, base = static_cast<int>(blockIdx.x) * kQBigTile;
+    if (base >= n)
+        return;
+    if (threadIdx.x < kQBigBucketsMax)
+        s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const IdT *ids = static_cast<const IdT *>(r.ids);
+#pragma unroll
+    for (int k = 0; k < kQBigTile / 1024; ++k) {
+        const int i = base + k * 1024 + static_cast<int>(threadIdx.x);
+        if (i < n)
+            atomicAdd(&s_h[qbig_bucket(to_key<IdT>(ids[i]), b.logp)], 1u);
+    }
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < b.P)
+        r.thist[blockIdx.x * b.P + threadIdx.x] = s_h[threadIdx.x];
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(1024) void qbpart_scatter_kernel(const QBigBatch b) {
+    __shared__ uint32_t s_base[kQBigBucketsMax], s_tot[kQBigBucketsMax];
+    __shared__ uint32_t s_cnt[(kQBigTile / 64) * kQBigBucketsMax];      // [wave-row][bucket]
+    const QBigRef &r = b.r[blockIdx.y];
+    const int n = r.n, P = b.P, t = static_cast<int>(blockIdx.x), tid = static_cast<int>(threadIdx.x);
+    const int T = (n + kQBigTile - 1) / kQBigTile;
+    if (n == 0) {
+        if (t == 0 && tid <= P) {
+            r.boff[tid] = 0;
+            if (tid == 0)
+                r.meta[0] = 0;
+        }
+        return;
+    }
+    if (t >= T)
+        return;
+    uint32_t before = 0;
+    if (tid < P) {
+        uint32_t tot = 0;
+        for (int q = 0; q < T; ++q) {
+            const uint32_t v = r.thist[q * P + tid];
+            tot += v;
+            before += q < t ? v : 0u;
+        }
+        s_tot[tid] = tot;
+    }
+    for (int q = tid; q < (kQBigTile / 64) * kQBigBucketsMax; q += 1024)
+        s_cnt[q] = 0;
+    __syncthreads();
+    if (tid < P) {
+        uint32_t off = 0;
+        for (int q = 0; q < tid; ++q)
+            off += s_tot[q];
+        s_base[tid] = off + before;
+        if (t == 0) {
+            r.boff[tid] = off;
+            if (tid == P - 1)
+                r.boff[P] = static_cast<uint32_t>(n);
+        }
+    }
+    if (t == 0 && tid == 0) {
+        uint32_t over = 0;
+        for (int q = 0; q < P; ++q)
+            over |= s_tot[q] > static_cast<uint32_t>(kQMax) ? 1u : 0u;
+        r.meta[0] = over;
+    }
+    const IdT *ids = static_cast<const IdT *>(r.ids);
+    const int base = t * kQBigTile, lane = lane_id(), w = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t key[kQBigTile / 1024], dig[kQBigTile / 1024], rank[kQBigTile / 1024];
+#pragma unroll
+    for (int k = 0; k < kQBigTile / 1024; ++k) {
+        const int i = base + k * 1024 + tid;
+        const bool valid = i < n;
+        key[k] = to_key<IdT>(ids[min(i, n - 1)]);
+        dig[k] = qbig_bucket(key[k], b.logp);
+        unsigned long long m = __ballot(valid);
+        for (int bit = 0; bit < b.logp; ++bit) {
+            const bool on = (dig[k] >> bit) & 1u;
+            const unsigned long long bb = __ballot(on);
+            m &= on ? bb : ~bb;
+        }
+        rank[k] = static_cast<uint32_t>(__builtin_popcountll(m & below));
+        if (valid && rank[k] == 0)
+            s_cnt[(k * 16 + w) * kQBigBucketsMax + dig[k]] = static_cast<uint32_t>(__builtin_popcountll(m));
+    }
+    __syncthreads();
+    if (tid < P) {       // exclusive prefix over the tile's 64 wave-rows, bucket by bucket
+        uint32_t run = 0;
+        for (int q = 0; q < kQBigTile / 64; ++q) {
+            const uint32_t c = s_cnt[q * kQBigBucketsMax + tid];
+            s_cnt[q * kQBigBucketsMax + tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kQBigTile / 1024; ++k) {
+        const int i = base + k * 1024 + tid;
+        if (i < n) {
+            const uint32_t pos = s_base[dig[k]] + s_cnt[(k * 16 + w) * kQBigBucketsMax + dig[k]] + rank[k];
+            r.bkeys[pos] = key[k];
+            r.bpos[pos] = static_cast<uint32_t>(i);
+        }
+    }
+}
+
+__device__ __forceinline__ QPlan qbig_slice(const QBigRef &r, int p) {
+    QPlan q;
+    const uint32_t off = uniform(r.boff[p]), nb = uniform(r.boff[p + 1]) - off;
+    q.hdr = r.bhdr + p;
+    q.keys = r.bkeys + off;
+    q.sorted = nullptr;
+    q.uniq = r.uniq + off;
+    q.perm = r.gperm + off;
+    q.inverse = nullptr;
+    q.counts = r.counts + off;
+    q.seg = r.seg + off + p;
+    q.upos = nullptr;
+    q.occ = r.occ + 2 * static_cast<size_t>(off);
+    q.n = static_cast<int>(nb);
+    return q;
+}
+
+template <bool RANK_ATOMIC>
+__global__ __launch_bounds__(1024, 4) void qbplan_kernel(const QBigBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const QBigRef &r = b.r[blockIdx.y];
+    const int p = static_cast<int>(blockIdx.x);
+    const QPlan q = qbig_slice(r, p);
+    if (q.n == 0 || q.n > kQMax) {      // (an oversized bucket: the partition raised meta[0]; the queue builder hands it on)
+        if (threadIdx.x == 0) {
+            q.hdr->n_unique = 0;
+            q.hdr->reserved[kGroupedFlagWord] = 1;
+            q.hdr->reserved[kOrderFlagWord] = 0;
+            q.seg[0] = 0;
+        }
+        return;
+    }
+    qsort_finish_body<uint32_t, RANK_ATOMIC, true>(q.keys, q, s_dyn, nullptr, r.bpos + (q.keys - r.bkeys));
+}
+
+struct QBigZero {
+    int count;
+    QHeader *qh[kQBatch];
+};
+__global__ __launch_bounds__(64) void qbzero_kernel(const QBigZero z) {
+    reinterpret_cast<uint32_t *>(z.qh[blockIdx.x])[threadIdx.x] = 0;       // the 64 words of a queue header
+}
+
+struct QBigJoinBatch {
+    int count, width, P;
+    uint64_t rows;
+    uint32_t lds_bytes, cap_coop, cap_wave, cap_copy;
+    QBigRef a[kQJoinBatch], g[kQJoinBatch];
+    QHeader *qh[kQJoinBatch];
+    QEntry *coop[kQJoinBatch], *wave[kQJoinBatch], *copy[kQJoinBatch];
+    uint32_t *mirror[kQJoinBatch];
+    uint32_t epoch[kQJoinBatch];
+};
+__global__ __launch_bounds__(1024, 4) void qbqueue_kernel(const QBigJoinBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const int i = static_cast<int>(blockIdx.y), p = static_cast<int>(blockIdx.x >> 1), part = static_cast<int>(blockIdx.x & 1);
+    QPlan pa, pg;
+    memset(&pa, 0, sizeof(pa));
+    memset(&pg, 0, sizeof(pg));
+    uint32_t st_base = 0, fs_base = 0, bad = 0;
+    if (b.a[i].n > 0) {
+        pa = qbig_slice(b.a[i], p);
+        st_base = uniform(b.a[i].boff[p]);
+        bad |= b.a[i].meta[0];
+    }
+    if (b.g[i].n > 0) {
+        pg = qbig_slice(b.g[i], p);
+        fs_base = uniform(b.g[i].boff[p]);
+        bad |= b.g[i].meta[0];
+    }
+    if (bad && p == 0 && part == 0 && threadIdx.x == 0) {       // a bucket beyond kQMax ids: its keys are in no queue
+        atomicOr(&b.qh[i]->overflow_wave, 4u);
+        if (b.mirror[i])
+            b.mirror[i][3] = 4u;
+    }
+    qjoin_body<true>(pa, pg, b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave, b.cap_copy,
+                     s_dyn, b.lds_bytes, part, nullptr, b.mirror[i], st_base, fs_base, b.epoch[i], 2u * static_cast<uint32_t>(b.P));
+}
+
+template <typename IdT>
+static int qbig_plan_batch(const IdT *const *ids, const int64_t *n, void *const *ws, int64_t n_cap, int64_t count,
+                           hipStream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (ids && n && ws)), "ha_qbig_plan_batch: null pointer");
+    HA_REQUIRE(n_cap >= 1 && n_cap <= kQBigMax, "ha_qbig_plan_batch: at most %lld ids per batch", (long long)kQBigMax);
+    static DeviceOnce lds_allowed;
+    if (lds_allowed.run([]() -> int {
+            HA_ALLOW_LDS((qbplan_kernel<true>), 160 * 1024);
+            HA_ALLOW_LDS((qbplan_kernel<false>), 160 * 1024);
+            return 0;
+        }))
+        return -1;
+    const bool ordered = lds_atomics_lane_ordered() != 0;
+    const int P = qbig_buckets(n_cap);
+    int logp = 0;
+    while ((1 << logp) < P)
+        ++logp;
+    for (int64_t k0 = 0; k0 < count; k0 += kQBatch) {
+        QBigBatch b;
+        memset(&b, 0, sizeof(b));
+        b.P = P;
+        b.logp = logp;
+        int64_t nmax = 0;
+        for (int64_t k = k0; k < count && b.count < kQBatch; ++k) {
+            HA_REQUIRE(n[k] >= 0 && n[k] <= n_cap, "ha_qbig_plan_batch: a batch is larger than its workspace was sized for");
+            HA_REQUIRE(ws[k] && (n[k] == 0 || ids[k]), "ha_qbig_plan_batch: null pointer (batch %lld)", (long long)k);
+            QBigRef &r = b.r[b.count++];
+            qbig_layout(ws[k], n_cap, &r);
+            r.ids = ids[k];
+            r.n = static_cast<int>(n[k]);
+            nmax = nmax > n[k] ? nmax : n[k];
+        }
+        if (b.count == 0)
+            continue;
+        const unsigned tiles = static_cast<unsigned>(nmax > 0 ? (nmax + kQBigTile - 1) / kQBigTile : 1);
+        hipLaunchKernelGGL((qbpart_hist_kernel<IdT>), dim3(tiles, b.count), dim3(1024), 0, stream, b);
+        HA_LAUNCH_CHECK();
+        hipLaunchKernelGGL((qbpart_scatter_kernel<IdT>), dim3(tiles, b.count), dim3(1024), 0, stream, b);
+        HA_LAUNCH_CHECK();
+        const size_t lds = qsort_lds_bytes(kQMax);
+        if (ordered)
+            hipLaunchKernelGGL((qbplan_kernel<true>), dim3(P, b.count), dim3(1024), lds, stream, b);
+        else
+            hipLaunchKernelGGL((qbplan_kernel<false>), dim3(P, b.count), dim3(1024), lds, stream, b);
+        HA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+static int qbig_queue_batch(int64_t rows, int64_t width, void *const *ws_a, const int64_t *n_a, void *const *ws_g,
+                            const int64_t *n_g, void *const *queues, int64_t n_cap, int64_t count,
+                            uint32_t *const *counts_host, const uint32_t *epochs, hipStream_t stream) {
+    HA_REQUIRE(rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 && width <= (1 << 20),
+               "ha_qbig_queue_batch: rows of a multiple of 4 floats");
+    HA_REQUIRE(count >= 0 && (count == 0 || (ws_a && n_a && ws_g && n_g && queues)), "ha_qbig_queue_batch: null pointer");
+    HA_REQUIRE(n_cap >= 1 && n_cap <= kQBigMax, "ha_qbig_queue_batch: bad capacity");
+    static DeviceOnce lds_allowed;
+    if (lds_allowed.run([]() -> int {
+            HA_ALLOW_LDS(qbqueue_kernel, 160 * 1024);
+            return 0;
+        }))
+        return -1;
+    const int P = qbig_buckets(n_cap);
+    for (int64_t k0 = 0; k0 < count; k0 += kQJoinBatch) {
+        QBigJoinBatch b;
+        QBigZero z;
+        memset(&b, 0, sizeof(b));
+        memset(&z, 0, sizeof(z));
+        b.rows = static_cast<uint64_t>(rows);
+        b.width = static_cast<int>(width);
+        b.P = P;
+        for (int64_t k = k0; k < count && b.count < kQJoinBatch; ++k) {
+            HA_REQUIRE(n_a[k] >= 0 && n_g[k] >= 0 && n_a[k] <= n_cap && n_g[k] <= n_cap,
+                       "ha_qbig_queue_batch: a batch is larger than the queues were sized for");
+            if (n_a[k] == 0 && n_g[k] == 0)
+                continue;
+            HA_REQUIRE(queues[k] && (n_a[k] == 0 || ws_a[k]) && (n_g[k] == 0 || ws_g[k]),
+                       "ha_qbig_queue_batch: null pointer (step %lld)", (long long)k);
+            const int i = b.count++;
+            if (n_a[k] > 0)
+                qbig_layout(ws_a[k], n_cap, &b.a[i]);
+            if (n_g[k] > 0)
+                qbig_layout(ws_g[k], n_cap, &b.g[i]);
+            b.a[i].n = static_cast<int>(n_a[k]);
+            b.g[i].n = static_cast<int>(n_g[k]);
+            const QLayout q = queue_layout(queues[k], n_cap, width);
+            b.qh[i] = q.hdr;
+            z.qh[z.count++] = q.hdr;
+            b.mirror[i] = counts_host ? counts_host[k] : nullptr;
+            b.epoch[i] = epochs ? epochs[k] : 0u;
+            b.coop[i] = q.coop;
+            b.wave[i] = q.wave;
+            b.copy[i] = q.copy;
+            b.cap_coop = q.cap_coop;
+            b.cap_wave = q.cap_wave;
+            b.cap_copy = q.cap_copy;
+        }
+        if (b.count == 0)
+            continue;
+        const size_t need = qjoin_lds_bytes(kQMax, kQMax), res = qjoin_lds_resident_bytes(kQMax);
+        const size_t lds = need > res ? need : res;
+        b.lds_bytes = static_cast<uint32_t>(lds);
+        hipLaunchKernelGGL(qbzero_kernel, dim3(z.count), dim3(64), 0, stream, z);
+        HA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(qbqueue_kernel, dim3(2 * P, b.count), dim3(1024), lds, stream, b);
+        HA_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1454,6 +1997,70 @@ extern "C" int ha_qapply_steps(float *table, int64_t rows, int64_t width, float 
     return 0;
 }
 
+// ---- ordering the two streams without a packet on the apply's stream --------------------------------------------------
+// A caller that prepares queues on a side stream has two orders to keep.  (1) The apply of step c must not read queue c
+// before it is built: ha_qqueue_batch_epochs tags every finished queue with the caller's epoch of its step, and an apply
+// launch that is given the same epoch (ha_qapply_steps_sync / ha_qapply_sync) checks the tag before its first item
+// instead of the stream waiting on an event.  (2) The side stream must not rewrite plans / queues that steps still read:
+// the LAST launch of a block of steps completes an event of the library's own (ha_event_create) -- the event rides on
+// that launch's dispatch packet (hipExtLaunchKernelGGL), nothing is recorded between launches --, and the side stream
+// waits for it (ha_stream_wait_event).  The apply's stream then holds apply launches and nothing else: an event record
+// + an event wait at every block boundary cost ~1 us per step at blocks of 16 (profiles/r04).
+extern "C" void *ha_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+    return e;
+}
+extern "C" int ha_event_destroy(void *event) {
+    if (event)
+        HA_CHECK_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return 0;
+}
+extern "C" int ha_event_record(void *event, ha_stream_t stream) {
+    HA_REQUIRE(event != nullptr, "ha_event_record: null event");
+    HA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(event), as_stream(stream)));
+    return 0;
+}
+extern "C" int ha_stream_wait_event(ha_stream_t stream, void *event) {
+    HA_REQUIRE(event != nullptr, "ha_stream_wait_event: null event");
+    HA_CHECK_HIP(hipStreamWaitEvent(as_stream(stream), static_cast<hipEvent_t>(event), 0));
+    return 0;
+}
+extern "C" int ha_qqueue_batch_epochs(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a,
+                                      void *const *plans_g, const int64_t *n_g, void *const *queues, int64_t queue_n_cap,
+                                      int64_t count, uint32_t *const *counts_host, const uint32_t *epochs,
+                                      ha_stream_t stream) {
+    return qqueue_batch(rows, width, plans_a, n_a, plans_g, n_g, queues, queue_n_cap, count, as_stream(stream), nullptr,
+                        counts_host, epochs);
+}
+// ha_qapply_steps with, per step, the epoch its queue must carry (epochs may be NULL / an entry 0: no check), `err` = a
+// pinned host word raised to 8 if a queue never became ready, and `done_event` (ha_event_create; NULL: none) completed by
+// the last launch of the call.
+extern "C" int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                                    void *const *plan_cur, const int64_t *n_cur, const float *const *grads,
+                                    void *const *plan_next, const int64_t *n_next, float *const *next_out,
+                                    const void *const *queue_cur, const int64_t *wave_items, const uint32_t *epochs,
+                                    uint32_t *err, void *done_event, ha_stream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (plan_cur && n_cur && grads && plan_next && n_next && next_out && queue_cur)),
+               "ha_qapply_steps_sync: null pointer");
+    for (int64_t k = 0; k < count; ++k)
+        if (qapply(table, rows, width, plan_cur[k], n_cur[k], grads[k], lr, plan_next[k], n_next[k], next_out[k],
+                   queue_cur[k], queue_n_cap, as_stream(stream), nullptr, wave_items ? wave_items[k] : -1,
+                   epochs ? epochs[k] : 0u, err, k + 1 == count ? static_cast<hipEvent_t>(done_event) : nullptr))
+            return -1;
+    if (count == 0 && done_event)
+        HA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(done_event), as_stream(stream)));
+    return 0;
+}
+extern "C" int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                              float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                              int64_t queue_n_cap, int64_t wave_items, uint32_t epoch, uint32_t *err, void *done_event,
+                              ha_stream_t stream) {
+    return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
+                  as_stream(stream), nullptr, wave_items, epoch, err, static_cast<hipEvent_t>(done_event));
+}
+
 // ha_qqueue_batch that also writes {wave items + 1, workgroup items + 1, copy items + 1} of step k's queue to the three
 // pinned host words counts_host[k] (device-visible; NULL entries: none).  The caller zeroes the words before the call and
 // reads them whenever it likes: 0 = not built yet.  ha_qapply_sized takes the sum as a hint only -- a stale or missing
@@ -1508,6 +2115,57 @@ extern "C" int ha_qstep_u64ids(float *table, int64_t rows, int64_t width, void *
         return -1;
     return qapply(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_n_cap,
                   as_stream(stream));
+}
+
+// ---- the wide path (batches of up to ha_qbig_max_ids() ids): see the comment above qbig_buckets -------------------------
+extern "C" int64_t ha_qbig_max_ids(void) { return kQBigMax; }
+extern "C" size_t ha_qbig_plan_bytes(int64_t n_cap) {
+    if (n_cap < 1 || n_cap > kQBigMax)
+        return 0;
+    return qbig_layout(nullptr, n_cap, nullptr);
+}
+extern "C" int ha_qbig_buckets(int64_t n_cap) { return n_cap >= 1 && n_cap <= kQBigMax ? qbig_buckets(n_cap) : 0; }
+extern "C" int ha_qbig_plan_batch_f32ids(const float *const *ids, const int64_t *n, void *const *ws, int64_t n_cap,
+                                         int64_t count, ha_stream_t stream) {
+    return qbig_plan_batch<float>(ids, n, ws, n_cap, count, as_stream(stream));
+}
+extern "C" int ha_qbig_plan_batch_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *ws, int64_t n_cap,
+                                         int64_t count, ha_stream_t stream) {
+    return qbig_plan_batch<uint64_t>(ids, n, ws, n_cap, count, as_stream(stream));
+}
+extern "C" int ha_qbig_queue_batch(int64_t rows, int64_t width, void *const *ws_a, const int64_t *n_a, void *const *ws_g,
+                                   const int64_t *n_g, void *const *queues, int64_t n_cap, int64_t count,
+                                   uint32_t *const *counts_host, const uint32_t *epochs, ha_stream_t stream) {
+    return qbig_queue_batch(rows, width, ws_a, n_a, ws_g, n_g, queues, n_cap, count, counts_host, epochs, as_stream(stream));
+}
+extern "C" int ha_qbig_apply(float *table, int64_t rows, int64_t width, void *ws_cur, int64_t n_cur, const float *grads,
+                             float lr, void *ws_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t n_cap,
+                             uint32_t epoch, uint32_t *err, void *done_event, ha_stream_t stream) {
+    HA_REQUIRE(n_cap >= 1 && n_cap <= kQBigMax && (n_cur == 0 || ws_cur) && (n_next == 0 || ws_next), "ha_qbig_apply: bad arguments");
+    QBigRef a, g;
+    memset(&a, 0, sizeof(a));
+    memset(&g, 0, sizeof(g));
+    if (n_cur > 0)
+        qbig_layout(ws_cur, n_cap, &a);
+    if (n_next > 0)
+        qbig_layout(ws_next, n_cap, &g);
+    return qapply_lists(table, rows, width, a.gperm, n_cur, grads, lr, g.gperm, n_next, next_out, queue_cur, n_cap, kQBigMax,
+                        as_stream(stream), nullptr, -1, epoch, err, static_cast<hipEvent_t>(done_event));
+}
+// a wide plan's per-bucket results for tests: bucket offsets [P + 1], then per bucket its number of unique keys
+extern "C" int ha_qbig_plan_view(void *ws, int64_t n_cap, void **boff, void **bhdr, void **uniq, void **counts, void **seg,
+                                 void **gperm, void **meta) {
+    HA_REQUIRE(ws && n_cap >= 1 && n_cap <= kQBigMax, "ha_qbig_plan_view: bad arguments");
+    QBigRef r;
+    qbig_layout(ws, n_cap, &r);
+    if (boff) *boff = r.boff;
+    if (bhdr) *bhdr = r.bhdr;
+    if (uniq) *uniq = r.uniq;
+    if (counts) *counts = r.counts;
+    if (seg) *seg = r.seg;
+    if (gperm) *gperm = r.gperm;
+    if (meta) *meta = r.meta;
+    return 0;
 }
 
 // development aids: the items of a step with per-wave time stamps (dbg = device uint64[(workgroups) * 4 * 4], zeroed);

@@ -15,6 +15,8 @@ call into libherald_amd.so.  There is no fallback: a missing library raises Hera
 import ctypes
 import os
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -623,6 +625,54 @@ class StepPipeline:
         return self._call(self.c, grads, ahead_ids, out, stream)
 
 
+def qbig_max_ids():
+    """Largest batch of the work-queue step's wide path (hash buckets of at most qstep_max_ids() ids each)."""
+    return int(_lib.load().ha_qbig_max_ids())
+
+
+class WidePlan:
+    """The plan of a batch of more than qstep_max_ids() ids as ha_qbig_plan_batch_* leaves it: the batch cut into hash
+    buckets, per bucket the relations of an index plan (unique keys in hash-slot order, counts, segment starts local to
+    the bucket) and ONE list of occurrence lists for the whole batch (positions of the batch, ascending inside every
+    key's list)."""
+
+    def __init__(self, capacity, device):
+        L = _lib.load()
+        self.capacity, self.device = int(capacity), device
+        self.ws = torch.zeros(int(L.ha_qbig_plan_bytes(self.capacity)), dtype=torch.uint8, device=device)
+        self.buckets = int(L.ha_qbig_buckets(self.capacity))
+        self.n = 0
+        self._produced_on, self._view = 0, None
+
+    def groups(self):
+        """(unique keys, counts, occurrence lists) of the whole batch, bucket after bucket (host copies; synchronises)."""
+        L = _lib.load()
+        ptr = [ctypes.c_void_p() for _ in range(7)]
+        check(L.ha_qbig_plan_view(_ptr(self.ws), self.capacity, *[ctypes.byref(p) for p in ptr]), "ha_qbig_plan_view")
+        torch.cuda.synchronize(self.device)
+        base = self.ws.data_ptr()
+
+        def arr(p, count, dtype):
+            off = p.value - base
+            return self.ws[off:off + count * dtype.itemsize].view(dtype).cpu().numpy()
+        P, n = self.buckets, self.n
+        boff = arr(ptr[0], P + 1, torch.int32).astype(np.int64)
+        hdr = arr(ptr[1], P * 32, torch.int64).reshape(P, 32)
+        uniq = arr(ptr[2], max(n, 1), torch.int32).astype(np.int64) & 0xFFFFFFFF
+        counts = arr(ptr[3], max(n, 1), torch.int32).astype(np.int64)
+        gperm = arr(ptr[5], max(n, 1), torch.int32).astype(np.int64)
+        meta = arr(ptr[6], 1, torch.int32)
+        keys, cnts, lists = [], [], []
+        for p in range(P):
+            U = int(hdr[p, 0])
+            o = int(boff[p])
+            keys.append(uniq[o:o + U])
+            cnts.append(counts[o:o + U])
+            lists.append(gperm[o:int(boff[p + 1])])
+        return {"overflow": int(meta[0]), "bucket_sizes": np.diff(boff), "uniq": np.concatenate(keys) if keys else uniq[:0],
+                "counts": np.concatenate(cnts) if cnts else counts[:0], "perm": np.concatenate(lists) if lists else gperm[:0]}
+
+
 def qstep_max_ids():
     return int(_lib.load().ha_qstep_max_ids())
 
@@ -736,14 +786,25 @@ class QueueStepPipeline:
     chain bit for bit.  `plan_of(j)` holds the unique keys / counts / inverse / occurrence lists of batch j with the
     unique keys in hash-slot order (not np.unique's order) once its block has been prepared."""
 
-    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True):
+    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True, sync="events"):
+        """sync: how the preparation stream and the caller's stream are ordered when overlap is on.
+        "events" (default): an event record and an event wait on the caller's stream at every block start -- safe for any
+        caller (ids produced by work queued on the caller's stream, steps captured into hipGraphs).
+        "flags": NOTHING but apply launches on the caller's stream -- every queue carries the epoch of its step and the
+        apply checks it before its first item, the last launch of a block completes an event of its own that the
+        preparation stream waits for (ha_qapply_steps_sync, include/herald_amd.h): ~1 us per step less at blocks of 16.
+        Requirements: the ids handed to prepare_block / step are COMPLETE on the device when they are handed over (nothing
+        orders them behind work on the caller's stream), and the steps are enqueued eagerly (not captured)."""
         L = _lib.load()
         _require(table, torch.float32, "table")
         self.table, self.lr = table, float(lr)
         self.device = table.device if device is None else torch.device(device)
-        if capacity > qstep_max_ids():
-            raise ValueError("ha_qstep_* takes at most %d ids per batch (got capacity %d): use StepPipeline / "
-                             "sgd_push_pull / lookup_sort + sgd_apply_finish" % (qstep_max_ids(), capacity))
+        # batches beyond one plan workgroup's reach take the WIDE path: hash buckets of the batch planned and joined side
+        # by side (ha_qbig_*, csrc/qstep.hip), the same apply launch
+        self.wide = capacity > qstep_max_ids()
+        if capacity > qbig_max_ids():
+            raise ValueError("ha_qstep_* takes at most %d ids per batch (got capacity %d): use SortAheadPipeline / "
+                             "lookup_sort + sgd_apply_finish" % (qbig_max_ids(), capacity))
         if table.shape[1] % 4 != 0:
             raise ValueError("ha_qstep_* needs rows of a multiple of 4 floats")
         with torch.cuda.device(self.device):
@@ -751,13 +812,17 @@ class QueueStepPipeline:
                 check(-1, "ha_qstep_init")
         self.capacity = max(int(capacity), 1)
         self.overlap = bool(overlap)
+        if sync not in ("events", "flags"):
+            raise ValueError("sync must be 'events' or 'flags'")
+        self.sync = sync if self.overlap else "events"
+        self._done_ev, self._cev_pool = {}, []       # flags: block -> library event completed by its last apply launch
         self.block = int(block) if self.overlap else 1
         if not 1 <= self.block <= 64:
             raise ValueError("block must be 1..64")
         self.LOOKAHEAD = 3 * self.block
         self.NPLAN, self.NQUEUE = 4 * self.block, 2 * self.block
         self.ROTATION = 4 * self.block     # plans and queues of call c and call c + ROTATION are the same
-        self.plans = [IndexPlan(self.capacity, self.device) for _ in range(self.NPLAN)]
+        self.plans = [(WidePlan if self.wide else IndexPlan)(self.capacity, self.device) for _ in range(self.NPLAN)]
         self.queue_bytes = int(L.ha_qstep_queue_bytes(self.capacity, table.shape[1]))
         self.queues = torch.zeros(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
@@ -779,6 +844,8 @@ class QueueStepPipeline:
 
     # ---- bookkeeping ------------------------------------------------------------------------------------------
     def reset(self, stream=None):
+        self._cev_pool.extend(self._done_ev.values())
+        self._done_ev = {}
         self.c, self.n, self.shape, self.ids = None, {}, {}, {}
         self._ev_side = {}          # block index -> event behind the side work launched at its start
         self._held = {}             # block index -> id tensors its plan launch reads (kept alive, not record_stream'ed)
@@ -822,7 +889,15 @@ class QueueStepPipeline:
         # HA_QNOSYNC=1 (MEASUREMENT ONLY, unsafe): no events between the two streams -- what the two packets on the
         # caller's stream cost at a block boundary
         nosync = os.environ.get("HA_QNOSYNC") == "1"
-        if self.overlap and not nosync:
+        flags = self.sync == "flags"
+        if self.overlap and flags and not nosync:
+            # the steps of block b-1 are complete (their last launch carries the event): the plans / queues about to be
+            # rewritten are free.  Nothing is enqueued on the caller's stream.
+            cev = self._done_ev.pop(b - 1, None)
+            if cev is not None:
+                check(L.ha_stream_wait_event(sp, cev), "ha_stream_wait_event")
+                self._cev_pool.append(cev)
+        elif self.overlap and not nosync:
             ev = self._event()
             ev.record(main)                    # the buffers about to be rewritten are free, the ids are there
             s.wait_event(ev)
@@ -854,7 +929,11 @@ class QueueStepPipeline:
                 j0, t0, m0 = lst[0]
                 check(L.ha_debug_qprep_f32ids(rows, width, _ptr(t0), m0, _ptr(self.plan_of(j0).ws), None, 0,
                                               None, 0, None, self.capacity, _ptr(ph), sp), "ha_debug_qprep")
-            check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
+            if self.wide:
+                check(getattr(L, "ha_qbig_plan_batch_" + kind)(ids_arr, n_arr, pl_arr, self.capacity, cnt, sp),
+                      "ha_qbig_plan_batch")
+            else:
+                check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
             for j, _, m in lst:
                 pl = self.plans[j % self.NPLAN]
                 pl.n = m
@@ -883,8 +962,14 @@ class QueueStepPipeline:
                 cc[at] = 0
                 cc[at + 2] = 0
             cs = (vp * cnt)(*[base + 16 * (j % ring) for j in steps])
-            check(L.ha_qqueue_batch_counts(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, sp), "ha_qqueue_batch")
-        if self.overlap and not nosync:
+            eps = (ctypes.c_uint32 * cnt)(*[self._epoch(j) for j in steps])
+            if self.wide:
+                check(L.ha_qbig_queue_batch(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
+                      "ha_qbig_queue_batch")
+            else:
+                check(L.ha_qqueue_batch_epochs(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
+                      "ha_qqueue_batch")
+        if self.overlap and not nosync and not flags:
             ev = self._event()
             ev.record(s)
             self._ev_side[b] = ev
@@ -896,12 +981,34 @@ class QueueStepPipeline:
     def _event(self):
         return self._ev_pool.pop() if self._ev_pool else torch.cuda.Event()
 
+    @staticmethod
+    def _epoch(j):
+        """The tag of step j's queue (non-zero, distinct for the steps that share a queue slot)."""
+        return (j + (1 << 24)) & 0xFFFFFFFF
+
+    def _block_done_event(self, c):
+        """flags: the library event the launch of step c has to complete if c is the last step of its block, else None."""
+        if self.sync != "flags" or (c + 1) % self.block != 0:
+            return None
+        ev = self._cev_pool.pop() if self._cev_pool else ctypes.c_void_p(self._L.ha_event_create())
+        if not ev:
+            raise RuntimeError("ha_event_create failed")
+        old = self._done_ev.pop(c // self.block, None)
+        if old is not None:
+            self._cev_pool.append(old)
+        self._done_ev[c // self.block] = ev
+        return ev
+
+    def _err_ptr(self, c):
+        return ctypes.c_void_p(self._counts_base + 16 * (c % self.COUNTS) + 12)
+
     def wave_items(self, c):
         """Wave + copy items of the queue of step c if its numbers have landed in pinned memory, else -1."""
         at = 4 * (c % self.COUNTS)
         if self._counts_c[at + 3]:
             raise RuntimeError("ha_qqueue_batch: the work queue of step %d is unusable (flags %d: 1 = overflow, 2 = an "
-                               "occurrence list out of position order)" % (c, self._counts_c[at + 3]))
+                               "occurrence list out of position order, 4 = a hash bucket of a wide batch holds more than "
+                               "%d ids)" % (c, self._counts_c[at + 3], qstep_max_ids()))
         if os.environ.get("HA_QHINT") == "0":
             return -1
         w, cp = self._counts_c[at], self._counts_c[at + 2]
@@ -924,13 +1031,27 @@ class QueueStepPipeline:
             _require(out, torch.float32, "out")
             if out.numel() != n_next * width:
                 raise ValueError("out must hold %d x %d values" % (n_next, width))
+        flags = self.sync == "flags" and dbg is None
+        capturing = flags and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            raise RuntimeError("QueueStepPipeline(sync='flags'): steps cannot be captured into a hipGraph (use sync='events')")
+        done = self._block_done_event(c) if flags else None
         if not (n_cur or n_next):
+            if done is not None:         # the block's last step launches nothing: mark the point on the stream instead
+                check(L.ha_event_record(done, _stream_ptr(stream)), "ha_event_record")
             return
         args = [_ptr(t), rows, width, _ptr(self.plan_of(c).ws) if n_cur else None, n_cur,
                 _ptr(grads) if n_cur else None, ctypes.c_float(self.lr),
                 _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
                 self._queue(c), self.capacity]
-        if dbg is None:
+        if self.wide:
+            self.wave_items(c)           # (raises if the builder flagged this step's queue)
+            check(L.ha_qbig_apply(*args, self._epoch(c) if flags else 0, self._err_ptr(c) if flags else None, done,
+                                  _stream_ptr(stream)), "ha_qbig_apply")
+        elif flags:
+            check(L.ha_qapply_sync(*args, self.wave_items(c), self._epoch(c), self._err_ptr(c), done, _stream_ptr(stream)),
+                  "ha_qapply_sync")
+        elif dbg is None:
             check(L.ha_qapply_sized(*args, self.wave_items(c), _stream_ptr(stream)), "ha_qapply")
         else:
             check(L.ha_debug_qapply(*args, _ptr(dbg), _stream_ptr(stream)), "ha_debug_qapply")
@@ -939,6 +1060,8 @@ class QueueStepPipeline:
         """-> callable(step index) that enqueues the launch of the steps c, c + ROTATION, ... with the arguments converted
         once (the steps of a long run repeat every ROTATION steps with a fixed set of buffers; the per-call ctypes
         conversion of apply() costs more host time than the launch itself)."""
+        if self.sync == "flags":
+            raise RuntimeError("apply_call: use apply / apply_steps_call with sync='flags'")
         L = _lib.load()
         t = self.table
         rows, width = t.shape
@@ -977,6 +1100,9 @@ class QueueStepPipeline:
         sp = _stream_ptr(stream)
         fn = L.ha_qapply_steps
         counts, ring = self._counts_c, self.COUNTS
+        flags = self.sync == "flags"
+        eps = (ctypes.c_uint32 * cnt)()
+        fn_sync, epoch, last_err = L.ha_qapply_steps_sync, self._epoch, self._err_ptr
 
         def call(k0):
             if sized:
@@ -991,7 +1117,13 @@ class QueueStepPipeline:
                     # the queue of this step may not be built yet when the host is far ahead of the device: item counts
                     # vary by a few per cent from batch to batch, so the last known count (+ 6 %) sizes the launch then
                     hints[i] = w + cp - 2 if w > 0 and cp > 0 else (self._last_items * 17) // 16 if self._last_items > 0 else -1
-            if fn(*head, pc, ns, gs, pn, ns, os_, qs, hints, sp) != 0:
+            if flags:
+                for i in range(cnt):
+                    eps[i] = epoch(k0 + i)
+                done = self._block_done_event(k0 + cnt - 1)
+                if fn_sync(*head, pc, ns, gs, pn, ns, os_, qs, hints, eps, last_err(k0 + cnt - 1), done, sp) != 0:
+                    check(-1, "ha_qapply_steps_sync")
+            elif fn(*head, pc, ns, gs, pn, ns, os_, qs, hints, sp) != 0:
                 check(-1, "ha_qapply_steps")
         return call
 

@@ -770,6 +770,8 @@ class FramedStep:
         self._fast_ok = hasattr(self.eng, "frames_serve_pull_call")
         self.k = None
         self.fallbacks = 0
+        self._slot_of = [(self.blocks[(j // self.block) % 3], self.blocks[(j // self.block) % 3].slots[j % self.block])
+                         for j in range(3 * self.block)]
         emb._frame(self.max_ids)     # the sized path (overflowed batches) agrees on its frame now, on every rank
 
     # -- plumbing ---------------------------------------------------------------------------------------------------
@@ -781,8 +783,8 @@ class FramedStep:
         return out
 
     def _fb(self, j):
-        blk = self.blocks[(j // self.block) % 3]
-        return blk, blk.slots[j % self.block]
+        s = self._slot_of[j % (3 * self.block)]
+        return s
 
     def _stage(self, j, ids):
         """Batch j enters the pipeline.  ids = None: the stream of batches has ended (on every rank); an EMPTY tensor is
@@ -795,7 +797,7 @@ class FramedStep:
             raise ValueError("a batch of %d ids exceeds max_ids = %d of this FramedStep" % (ids.numel(), self.max_ids))
         if ids.dtype not in (torch.float32, torch.int64, torch.uint64):
             raise TypeError("ids must be float32 or (u)int64")
-        fb.ids, fb.n, fb.shape, fb.routed = ids.reshape(-1), ids.numel(), tuple(ids.shape), True
+        fb.ids, fb.n, fb.shape, fb.routed = (ids if ids.dim() == 1 else ids.reshape(-1)), ids.numel(), tuple(ids.shape), True
 
     def _route_block(self, b):
         """Enqueue the routing of block b: plans and key frames of its batches, one key exchange, received keys."""
@@ -861,8 +863,8 @@ class FramedStep:
         blk, fb = self._fb(j)
         eng, emb = self.eng, self.emb
         w, r = emb.world, emb.rank
-        send_cnt, recv_cnt = self._counts(fb)
         if w > 1:
+            send_cnt, recv_cnt = self._counts(fb)
             ins = [c if g != r else 0 for g, c in enumerate(recv_cnt)]     # rows this rank serves to peer g
             outs = [c if g != r else 0 for g, c in enumerate(send_cnt)]    # rows owner g sends back
             if self._fast_ok:
@@ -883,7 +885,8 @@ class FramedStep:
         _, fb = self._fb(j)
         eng, emb = self.eng, self.emb
         w, r = emb.world, emb.rank
-        send_cnt, recv_cnt = self._counts(fb)
+        if w > 1:
+            send_cnt, recv_cnt = self._counts(fb)
         if w == 1:          # nobody else pushes: reduce + server add of the own keys in one launch
             if fb.n:
                 if self._fast_ok:
@@ -1043,7 +1046,9 @@ class FramedStep:
                 self._run(("pull", k % (3 * self.block), fb.n, out.data_ptr() if fb.n else 0), lambda: self._pull(k, out))
             self._account()
         self._pending = True
-        return out.reshape(fb.shape + (width,)) if fb.n else None
+        if not fb.n:
+            return None
+        return out if out.dim() == len(fb.shape) + 1 and tuple(out.shape[:-1]) == fb.shape else out.reshape(fb.shape + (width,))
 
     def push(self, values, lr=None):
         """Apply the gradients `values` of the current batch on its owners (scale -lr; 1 if lr is None)."""

@@ -537,6 +537,63 @@ int ha_qapply_steps(float *table, int64_t rows, int64_t width, float lr, int64_t
 int ha_qqueue_batch_counts(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
                            const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
                            uint32_t *const *counts_host, ha_stream_t stream);
+/* Ordering the preparation stream and the apply's stream WITHOUT a packet on the apply's stream (an event record + an event
+ * wait at every block boundary cost ~1 us per step at blocks of 16):
+ *   (1) queue c must be complete before the apply of step c reads it: ha_qqueue_batch_epochs (= ha_qqueue_batch_counts +
+ *       `epochs`, one non-zero tag per step) makes the builder finish every queue with a device-scope release and the tag;
+ *       an apply launch that is handed the same tag (ha_qapply_steps_sync / ha_qapply_sync; epoch 0 = no check) looks at it
+ *       before its first item -- it is there on the first look when the preparation runs a block ahead; otherwise the
+ *       launch polls (~1 s at most), then raises *err = 8 (pinned host word) and does nothing.  The builder never waits
+ *       for an apply launch.
+ *   (2) the preparation must not rewrite plans / queues that steps still read: the last launch of a call completes
+ *       `done_event` (an event of ha_event_create; it rides on that launch's own dispatch packet -- hipExtLaunchKernelGGL
+ *       --, nothing is recorded between launches; with nothing to launch it is recorded on the stream), and the caller
+ *       makes the preparation stream wait for it (ha_stream_wait_event).
+ * The ids of the batches to plan must be complete on the device when the preparation is enqueued (nothing orders them
+ * behind work of the apply's stream any more). */
+void *ha_event_create(void);
+int ha_event_destroy(void *event);
+int ha_event_record(void *event, ha_stream_t stream);
+int ha_stream_wait_event(ha_stream_t stream, void *event);
+int ha_qqueue_batch_epochs(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
+                           const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
+                           uint32_t *const *counts_host, const uint32_t *epochs, ha_stream_t stream);
+int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                         void *const *plan_cur, const int64_t *n_cur, const float *const *grads, void *const *plan_next,
+                         const int64_t *n_next, float *const *next_out, const void *const *queue_cur,
+                         const int64_t *wave_items, const uint32_t *epochs, uint32_t *err, void *done_event,
+                         ha_stream_t stream);
+int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                   void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
+                   int64_t wave_items, uint32_t epoch, uint32_t *err, void *done_event, ha_stream_t stream);
+
+/* The WIDE path: batches of more than ha_qstep_max_ids() (7,168) and at most ha_qbig_max_ids() (131,072) ids -- BASELINE
+ * configs[2] / configs[3]'s per-GPU shapes, 106,496 and 26,624 ids per step.  The batch is cut into hash buckets by one
+ * stable multisplit (ha_qbig_buckets(n_cap) buckets; a bucket may hold at most ha_qstep_max_ids() ids: a key with more
+ * than ~5,000 occurrences in a batch overflows it -- the builder raises the queue's overflow word / counts_host[k][3] = 4
+ * instead of dropping ids); every bucket is planned and joined like a narrow batch, side by side (no sort anywhere), and
+ * the apply is the narrow path's launch over all buckets' items.  ws: ha_qbig_plan_bytes(n_cap) bytes per batch (no
+ * initialisation); queues: ha_qstep_queue_bytes(n_cap, width).  Semantics, tolerance classes and references as above
+ * (Unique<T>'s contract -- every key once, occurrences in order -- unqiue_tools.h:27-48; cpu_deduplicate, ndarray.py:556-576).
+ * ha_qbig_plan_batch_* = partition (two launches) + the bucket plans (one launch) of `count` batches; ha_qbig_queue_batch
+ * = the queues of `count` steps (two launches); ha_qbig_apply = step c (one launch; epoch / err / done_event as
+ * ha_qapply_sync, 0 / NULL / NULL for none).  ha_qbig_plan_view: device pointers into a plan workspace for tests. */
+int64_t ha_qbig_max_ids(void);
+size_t ha_qbig_plan_bytes(int64_t n_cap);
+int ha_qbig_buckets(int64_t n_cap);
+int ha_qbig_plan_batch_f32ids(const float *const *ids, const int64_t *n, void *const *ws, int64_t n_cap, int64_t count,
+                              ha_stream_t stream);
+int ha_qbig_plan_batch_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *ws, int64_t n_cap, int64_t count,
+                              ha_stream_t stream);
+int ha_qbig_queue_batch(int64_t rows, int64_t width, void *const *ws_a, const int64_t *n_a, void *const *ws_g,
+                        const int64_t *n_g, void *const *queues, int64_t n_cap, int64_t count, uint32_t *const *counts_host,
+                        const uint32_t *epochs, ha_stream_t stream);
+int ha_qbig_apply(float *table, int64_t rows, int64_t width, void *ws_cur, int64_t n_cur, const float *grads, float lr,
+                  void *ws_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t n_cap, uint32_t epoch,
+                  uint32_t *err, void *done_event, ha_stream_t stream);
+int ha_qbig_plan_view(void *ws, int64_t n_cap, void **boff, void **bhdr, void **uniq, void **counts, void **seg, void **gperm,
+                      void **meta);
+
 /* serial forms: ha_qprep_* = the plan of one batch (ahead_ids -> plan_ahead; n_ahead = 0: none) and / or the queue of one
  * step from (plan_a, plan_g) (n_a = n_g = 0: none); ha_qstep_*(call c) = ha_qprep_*(batch c+3; queue c+1 from plans
  * c+1 = plan_next, c+2 = plan_b1) followed by ha_qapply(step c).  A stream of batches 0..B-1 is driven as calls

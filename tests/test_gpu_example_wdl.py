@@ -179,7 +179,7 @@ def _laia_example_worker(rank, world, port, model, local_shared):
     epochs = -(-steps * mini_bs * world // nsamples) + 1
     if local_shared:
         streams = [laia_model.TopkSchedulerModel(sparse.astype(np.uint64), epochs, mini_bs, batch_num, world, r, limit,
-                                                 hlaia.topk_num_threads(mini_bs), "criteo", hlaia.top_k_table["criteo"]).emit()
+                                                 hlaia.topk_num_threads(mini_bs), "criteo", hlaia.top_k_table["criteo"]).emit()[r]
                    for r in range(world)]
     else:
         streams = [laia_model.LaiaSchedulerModel(sparse.astype(np.uint64), epochs, mini_bs, batch_num, world, r, limit).emit()

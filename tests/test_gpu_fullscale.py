@@ -190,12 +190,14 @@ def test_lookahead_step_pipeline_on_the_full_table(dev, big_table):
     _restore(table, keys_all, dev)
 
 
-@pytest.mark.parametrize("overlap,block,count", [(True, 16, 20), (False, 1, 9)], ids=["side_stream_block16", "one_stream"])
-def test_queue_step_on_the_full_table(dev, big_table, overlap, block, count):
+@pytest.mark.parametrize("overlap,block,count,sync", [(True, 16, 20, "flags"), (True, 16, 20, "events"), (False, 1, 9, "events")],
+                         ids=["as_bench_flags_block16", "events_block16", "one_stream"])
+def test_queue_step_on_the_full_table(dev, big_table, overlap, block, count, sync):
     """THE KERNEL bench.py TIMES BY DEFAULT -- ha::qapply_kernel behind ops.QueueStepPipeline (csrc/qstep.hip) -- on the
     table bench.py uses: 33,762,577 x 512 fp32 (69.1 GB), Criteo batches of 6,656 float32 ids reaching beyond 2^24, rows
-    beyond the 4 GiB and 64 GiB byte offsets.  As bench.py drives it (blocks of 16 prepared on a side stream; the stream
-    of 20 batches crosses a block boundary) and in the serial form.  Every lookup row of every step
+    beyond the 4 GiB and 64 GiB byte offsets.  As bench.py drives it (blocks of 16 prepared on a side stream, the two
+    streams ordered by epoch tags in the queues and launch-borne events -- sync="flags"; the stream of 20 batches crosses
+    a block boundary), with the event pair on the caller's stream instead, and in the serial form.  Every lookup row of every step
       * bit for bit against oracle/qstep_model.py (the kernel's floating-point order), and
       * against the reference's serial chain (oracle/cpu.py, pinned to the compiled cpu_SGDOptimizerSparseUpdate,
         /root/reference/src/dnnl_ops/Optimizers.cpp:51-74; lookups: EmbeddingLookup.cpp:16-35): bit-exact for every key
@@ -204,14 +206,15 @@ def test_queue_step_on_the_full_table(dev, big_table, overlap, block, count):
     maximum of |tree - chain| / (lr x sum|g|) over the tolerance-class rows."""
     table = big_table
     REL = 1e-5
-    batches, keys_all, grads, cids = _stream_inputs(count, first=500 if overlap else 600, seed=14 + block)
+    batches, keys_all, grads, cids = _stream_inputs(count, first=(500 if overlap else 600) + (40 if sync == "flags" else 0),
+                                                    seed=14 + block)
     n = BATCH * FIELDS
     model_t = formula.rows_of(keys_all, WIDTH)        # kernel order, on the compact table of the touched rows
     exact_t = model_t.copy()                          # the reference's chain
     lr = 0.01
     drift = {}                                        # compact row -> accumulated tolerance (float64 per column)
     worst = worst_g = 0.0
-    pipe = ops.QueueStepPipeline(table, n, lr, block=block, overlap=overlap)
+    pipe = ops.QueueStepPipeline(table, n, lr, block=block, overlap=overlap, sync=sync)
     L = pipe.LOOKAHEAD
     d_ids = [torch.from_numpy(f).to(dev) for f in batches]
     out = pipe.start(d_ids[:L])

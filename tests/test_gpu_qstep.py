@@ -77,8 +77,10 @@ def _within(got, exact, tol_rows, keys, what):
             OBSERVED["ratio"] = max(OBSERVED["ratio"], float((d / (bound / REL + np.abs(exact[j]) + 1e-30)).max()))
 
 
-MODES = [(True, 8), (True, 2), (False, 1)]     # (preparation beside the steps, steps per block)
-MODE_IDS = ["side_stream_block8", "side_stream_block2", "one_stream"]
+# (preparation beside the steps, steps per block[, how the two streams are ordered: "events" (default) or "flags" = epoch
+# tags in the queues + an event riding on the block's last launch: nothing but apply launches on the caller's stream])
+MODES = [(True, 8), (True, 2), (False, 1), (True, 4, "flags")]
+MODE_IDS = ["side_stream_block8", "side_stream_block2", "one_stream", "flags_block4"]
 
 
 def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=None, check_plans=True, mode=(True, 2)):
@@ -91,7 +93,7 @@ def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=Non
     if table is None:
         table = _dev(table0, dev)
     cap = max(max(b.size for b in batches), 1)
-    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=mode[0], block=mode[1])
+    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=mode[0], block=mode[1], sync=mode[2] if len(mode) > 2 else "events")
     L = pipe.LOOKAHEAD
     cast = (lambda b: _dev(b.astype(np.float32), dev)) if ids_dtype == np.float32 else \
         (lambda b: _dev(b.astype(np.int64), dev))
@@ -233,7 +235,7 @@ def test_qstep_float_ids_above_2_24_and_capacity_limit(dev):
     np.testing.assert_array_equal(table[_dev(hot, dev)].cpu().numpy(), compact)
     assert float(table.abs().sum().item()) == pytest.approx(float(np.abs(compact.astype(np.float64)).sum()), rel=1e-6)
     with pytest.raises(ValueError):
-        ops.QueueStepPipeline(table, ops.qstep_max_ids() + 1, 0.01)
+        ops.QueueStepPipeline(table, ops.qbig_max_ids() + 1, 0.01)
 
 
 def test_qstep_criteo_stream_and_queue_shape(dev):
@@ -289,7 +291,102 @@ def test_qstep_many_medium_items_from_destinations_alone(dev, width):
         assert hdr["wave_items"] > per512 * n + 64          # beyond the old capacity: nothing was dropped
 
 
-@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def _check_wide_plan(pl, ids_int, what):
+    """A batch beyond one plan workgroup's reach (ops.WidePlan): hash buckets of at most qstep_max_ids() ids, per bucket
+    the groups of an index plan; the union over the buckets against np.unique, the occurrence lists in occurrence order."""
+    keys = np.minimum(ids_int.astype(np.uint64), 0xFFFFFFFE).astype(np.int64)
+    u, cnt = np.unique(keys, return_counts=True)
+    g = pl.groups()
+    assert g["overflow"] == 0 and g["bucket_sizes"].max() <= ops.qstep_max_ids() and g["bucket_sizes"].sum() == keys.size, what
+    assert g["uniq"].size == u.size, what + ": number of unique keys"
+    order = np.argsort(g["uniq"], kind="stable")
+    np.testing.assert_array_equal(g["uniq"][order], u, err_msg=what + ": the set of unique keys (every key in ONE bucket)")
+    np.testing.assert_array_equal(g["counts"][order], cnt, err_msg=what + ": dedup counts per key")
+    perm = g["perm"]
+    np.testing.assert_array_equal(np.sort(perm), np.arange(keys.size), err_msg=what + ": the lists are a permutation")
+    np.testing.assert_array_equal(keys[perm], np.repeat(g["uniq"], g["counts"]), err_msg=what + ": lists group the occurrences")
+    starts = np.r_[0, np.cumsum(g["counts"])][:-1]
+    inside = np.ones(keys.size, bool)
+    inside[starts] = False
+    assert (np.diff(perm)[inside[1:]] > 0).all(), what + ": occurrences of a key in occurrence order"
+
+
+@pytest.mark.parametrize("mode", [(True, 4), (False, 1), (True, 2, "flags")], ids=["side_stream_block4", "one_stream", "flags_block2"])
+@pytest.mark.parametrize("bs,width,rows", [(1024, 64, 150_000), (4096, 32, 200_000), (300, 128, 50_000)],
+                         ids=["configs3_26624ids", "configs2_106496ids", "7800ids"])
+def test_qstep_wide_batches(dev, bs, width, rows, mode):
+    """Batches beyond 7,168 ids -- BASELINE configs[3] / configs[2]'s per-GPU shapes, 26,624 and 106,496 ids per step, and
+    one just above the narrow path's limit -- through the WIDE path of the work-queue step (hash buckets planned and
+    joined side by side, no sort; csrc/qstep.hip): Criteo streams (runs of thousands of occurrences: the 3-category
+    field names one key ~2,000 times at bs = 4,096), every lookup and the table after the stream
+      * bit for bit against oracle/qstep_model.py (the kernel's floating-point order), and
+      * against the reference's serial chain (oracle/cpu.py; cpu_SGDOptimizerSparseUpdate, Optimizers.cpp:51-74): rows
+        whose keys never had 16+ occurrences in a batch bit-exact, the others within 1e-5 x lr x sum|g| (+ 1e-5 |row|);
+    the plans bucket by bucket against np.unique."""
+    rng = np.random.default_rng(bs + width)
+    table0 = (rng.standard_normal((rows, width), dtype=np.float32) * np.float32(0.5))
+    steps = 5
+    batches = [synth.criteo_batch(bs, step=40 + k, rows=rows).reshape(-1) for k in range(steps)]
+    n = batches[0].size
+    assert n > ops.qstep_max_ids()
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
+    lr = 0.05
+    table = _dev(table0, dev)
+    pipe = ops.QueueStepPipeline(table, n, lr, overlap=mode[0], block=mode[1], sync=mode[2] if len(mode) > 2 else "events")
+    assert pipe.wide
+    L = pipe.LOOKAHEAD
+    d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
+    model_t, exact_t = table0.copy(), table0.copy()
+    drift = np.zeros((rows, width), np.float64)
+    out = pipe.start(d_ids[:L])
+    for k in range(steps):
+        torch.cuda.synchronize()
+        ids = batches[k].astype(np.int64)
+        got = out.cpu().numpy().reshape(-1, width)
+        np.testing.assert_array_equal(got, model_t[ids], err_msg="lookup rows of batch %d (kernel order)" % k)
+        d = np.abs(got.astype(np.float64) - exact_t[ids].astype(np.float64))
+        assert (d <= drift[ids] + REL * np.abs(exact_t[ids])).all(), "lookup rows of batch %d vs the serial chain" % k
+        loose = drift[ids].any(axis=1)
+        np.testing.assert_array_equal(got[~loose], exact_t[ids][~loose], err_msg="rows without a long run: bit-exact")
+        qstep_model.sgd_sparse_update(model_t, ids, grads[k], lr)
+        cpu.sgd_sparse_update(exact_t, ids.astype(np.float32), grads[k], lr)
+        cnt = np.bincount(ids, minlength=rows)
+        sumabs = np.zeros((rows, width), np.float64)
+        np.add.at(sumabs, ids, np.abs(grads[k]).astype(np.float64))
+        drift += np.where((cnt >= qstep_model.LONG_MIN)[:, None], REL * lr * sumabs, 0.0)
+        out = pipe.step(_dev(grads[k], dev), d_ids[k + L] if k + L < steps else None)
+        torch.cuda.synchronize()
+        assert not pipe.overflowed()
+        _check_wide_plan(pipe.plan_of(k), ids, "plan of batch %d" % k)
+    assert out is None
+    got_t = table.cpu().numpy()
+    np.testing.assert_array_equal(got_t, model_t, err_msg="table after the stream (kernel order)")
+    loose = drift.any(axis=1)
+    assert loose.any() and not loose.all()
+    np.testing.assert_array_equal(got_t[~loose], exact_t[~loose], err_msg="rows without a long run: the serial chain")
+    d = np.abs(got_t.astype(np.float64) - exact_t.astype(np.float64))
+    assert (d <= drift + REL * np.abs(exact_t)).all()
+    if bs == 4096:
+        assert np.bincount(batches[0]).max() > 1500          # the long runs the wide path exists for
+
+
+def test_qstep_wide_bucket_overflow_fails_loudly(dev):
+    """A hash bucket holds at most qstep_max_ids() ids: a batch of 20,000 copies of ONE key cannot be planned by the wide
+    path -- the builder raises its sticky word and the pipeline raises instead of dropping the ids."""
+    rows, width, n = 1000, 32, 20000
+    table = torch.zeros((rows, width), device=dev)
+    pipe = ops.QueueStepPipeline(table, n, 0.1, overlap=False)
+    ids = [torch.full((n,), 7.0, device=dev) for _ in range(4)]
+    with pytest.raises(RuntimeError, match="bucket"):
+        out = pipe.start(ids[:pipe.LOOKAHEAD])
+        for k in range(3):
+            torch.cuda.synchronize()
+            out = pipe.step(torch.ones((n, width), device=dev), None)
+        torch.cuda.synchronize()
+        pipe.wave_items(0)
+
+
+@pytest.mark.parametrize("mode", MODES[:3], ids=MODE_IDS[:3])
 def test_qstep_graph_replay_is_deterministic(dev, mode):
     """The steps of a block replayed from a hipGraph (as bench.py does; the preparation of the blocks ahead is enqueued
     between the replays) give the same bits as eager launches."""
