@@ -243,6 +243,8 @@ def _declare(L):
         "ha_cache_perf": [vp, vp, vp],
         "ha_cache_state": [vp, vp, vp],
         "ha_cache_phase_times": [vp, vp, vp],
+        "ha_cache_set_timing": [vp, c.c_int],
+        "ha_cache_stage_times": [vp, vp],
         "ha_cache_snapshot": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
         "ha_cache_set_line": [vp, i64, i64, vp, vp],
         "ha_cache_set_remote": [vp],

@@ -104,7 +104,8 @@ class _CacheBase:
         if not self._h:
             raise _lib.HeraldAmdError("ha_cache_create failed: %s" % self._L.ha_last_error().decode())
         self._pull_bound = self._push_bound = 5
-        self.perf_enabled = False
+        self._perf_enabled = False
+        self.perf_times = False
         self._perf = []
         self._last_lookup = None
         self._store = None
@@ -335,6 +336,17 @@ class _CacheBase:
             raise RuntimeError("keys are not contiguous")
         return keys, kind
 
+    @property
+    def perf_enabled(self):
+        return self._perf_enabled
+
+    @perf_enabled.setter
+    def perf_enabled(self, on):
+        """The reference's perf_enabled_: one dict per call in `perf` (counts + stage times)."""
+        self._perf_enabled = bool(on)
+        self.perf_times = bool(on)
+        check(self._L.ha_cache_set_timing(self._h, 1 if on else 0), "ha_cache_set_timing")
+
     def _perf_record(self, kind):
         out = (ctypes.c_int64 * 8)()
         check(self._L.ha_cache_perf(self._h, out, ctypes.c_void_p(self._stream().cuda_stream)), "ha_cache_perf")
@@ -342,6 +354,19 @@ class _CacheBase:
              "num_miss": out[3], "num_transfered": out[4], "is_full": bool(out[6])}
         if out[0] == 1:
             d["num_evict"] = out[5]
+        if self.perf_times:
+            # the reference's stage times (milliseconds; cache.cc:99-105 Pull, 189-194 Push), from HIP events between the
+            # call's launches: what its CPU stages are here -- sort = the index plan; lookup (+ prepare) = probe, miss scan
+            # and slot assignment; copy = rows to dest with the pulls, the insert and the eviction in the same launch
+            # (Push: the accumulate); transfer = the exchange with a remote store (Push: the push launches)
+            ms = (ctypes.c_double * 6)()
+            check(self._L.ha_cache_stage_times(self._h, ms), "ha_cache_stage_times")
+            t = [max(v, 0.0) for v in ms]
+            d.update({"time": t[0], "sort_time": t[1], "lookup_time": t[2], "copy_time": t[3], "transfer_time": t[4]})
+            if out[0] == 0:
+                d.update({"prepare_time": 0.0, "copy_time": t[3] + t[5], "insert_time": 0.0})
+            else:
+                d["cleanup_time"] = t[5]
         self._perf.append(d)
 
     # ---- batch API ---------------------------------------------------------------------------------------------------

@@ -1738,7 +1738,21 @@ struct ha_cache {
     int fused_update = 7;  // HA_CACHE_FUSED: bit 0 = the two-launch update, bit 1 = eviction beside the lookup's row copies,
                            // bit 2 = the plan's finish does the lookup's bookkeeping (cache_finish_book_kernel)
     int64_t fused_count = 0;
+    // stage times of the last call (ha_cache_set_timing): HIP events between the launches of a call -- the GPU analogue of
+    // the reference's std::chrono stamps between the stages of _embeddingLookup / _embeddingUpdate (cache.cc:61-106,133-196)
+    bool timing = false;
+    hipEvent_t tev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned tmask = 0;
 };
+enum { kTStart = 0, kTSort = 1, kTLookup = 2, kTCopy = 3, kTTransfer = 4, kTEnd = 5 };
+static inline void cache_mark(ha_cache *h, int slot, hipStream_t s, bool first = false) {
+    if (!h->timing)
+        return;
+    if (first)
+        h->tmask = 0;
+    if (hipEventRecord(h->tev[slot], s) == hipSuccess)
+        h->tmask |= 1u << slot;
+}
 
 extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
                                      int64_t width, int64_t max_batch) {
@@ -1979,8 +1993,10 @@ extern "C" int ha_cache_lookup_begin(ha_cache *h, const void *keys, int key_kind
     Cache &c = h->c;
     hipStream_t s = as_stream(stream);
     int probed = 0;
+    cache_mark(h, kTStart, s, true);
     if (cache_plan(h, keys, key_kind, n, s, 0, &probed))
         return -1;
+    cache_mark(h, kTSort, s);
     h->plan_n = n;
     // (remote store: the update of these keys can take the two-launch path as well -- its pushes go to the outbox)
     h->same_fast = (h->fused_update & 1) && h->evict_empty && c.policy == kLRU && !c.bypass && c.limit >= n && n > 0;
@@ -1990,6 +2006,7 @@ extern "C" int ha_cache_lookup_begin(ha_cache *h, const void *keys, int key_kind
         hipLaunchKernelGGL(cache_probe_kernel, CACHE_GRID(n), dim3(256), 0, s, c.ctl, p.hdr, p.uniq, c.slot_of,
                            (long long)c.length, c.bypass ? 1 : 0, c.uslot, c.flag);
     hipLaunchKernelGGL(cache_export_req_kernel, CACHE_GRID(n), dim3(256), 0, s, c, p.hdr, p.uniq, (int)n);
+    cache_mark(h, kTLookup, s);
     HA_LAUNCH_CHECK();
     if (n_unique_host) {
         HA_CHECK_HIP(hipMemcpyAsync(n_unique_host, &p.hdr->n_unique, 8, hipMemcpyDeviceToHost, s));
@@ -2008,6 +2025,7 @@ extern "C" int ha_cache_lookup_finish(ha_cache *h, int64_t n, float *dest, ha_st
     hipStream_t s = as_stream(stream);
     PlanPtrs p = plan_layout(c.plan_ws, n);
     const int evb = cache_evict_mode(h, n, 1);
+    cache_mark(h, kTTransfer, s);        // between ha_cache_lookup_begin's last launch and here: the exchange with the owners
     hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
                        (long long)n, c.bypass ? 1 : 0, 1, evb);
     if (n > 0) {
@@ -2020,6 +2038,7 @@ extern "C" int ha_cache_lookup_finish(ha_cache *h, int64_t n, float *dest, ha_st
             hipLaunchKernelGGL(cache_lookup_rows_kernel<1>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos,
                                p.perm, (long long)n, dest, evb, c.bypass ? 1 : 0);
     }
+    cache_mark(h, kTEnd, s);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -2056,6 +2075,7 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     hipStream_t s = as_stream(stream);
     int probed = 0;
     PlanPtrs p = plan_layout(c.plan_ws, n);
+    cache_mark(h, kTStart, s, true);
     // LRU, not bypassed, a batch the counting sort takes: sort, then the finish that is the bookkeeping as well
     const bool finish_book = (h->fused_update & 4) && (h->fused_update & 2) && c.policy == kLRU && !c.bypass && n > 0 &&
                              n <= kSmallMax && finish_blocks((int)n) <= 64;
@@ -2065,11 +2085,14 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
         if (key_kind == 0 ? ha_plan_sort_f32ids_lim(static_cast<const float *>(keys), n, c.plan_ws, lim, s)
                           : ha_plan_sort_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, lim, s))
             return -1;
+        cache_mark(h, kTSort, s);
         hipLaunchKernelGGL(cache_finish_book_kernel, dim3(finish_blocks((int)n)), dim3(1024), 0, s, p.sorted, p.perm, (int)n,
                            p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, c, c.limit >= n ? 1 : 0);
         probed = 1;
     } else if (cache_plan(h, keys, key_kind, n, s, 1, &probed)) {
         return -1;
+    } else {
+        cache_mark(h, kTSort, s);
     }
     const int evb = finish_book ? (c.limit >= n ? 3 : 1) : cache_evict_mode(h, n, probed);
     h->plan_n = n;
@@ -2078,6 +2101,7 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     if (!finish_book)
         hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
                            (long long)n, c.bypass ? 1 : 0, probed, evb);
+    cache_mark(h, kTLookup, s);
     if (n > 0) {
         const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + (evb ? 1 : 0);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0) &&
@@ -2089,6 +2113,7 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
             hipLaunchKernelGGL(cache_lookup_rows_kernel<1>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos,
                                p.perm, (long long)n, dest, evb, c.bypass ? 1 : 0);
     }
+    cache_mark(h, kTEnd, s);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -2104,9 +2129,11 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     Cache &c = h->c;
     // keys == nullptr: the batch of the preceding ha_cache_lookup, whose plan is still in the workspace
     int probed = 0;
+    cache_mark(h, kTStart, s, true);
     if (keys != nullptr) {
         if (cache_plan(h, keys, key_kind, n, s, 0, &probed))
             return -1;
+        cache_mark(h, kTSort, s);
     } else {
         HA_REQUIRE(h->plan_n == n && n > 0, "cache_update_same_keys: no lookup of %ld keys precedes this update", (long)n);
     }
@@ -2121,6 +2148,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
         // every key is resident with data in uslot[]: accumulate, then touch / flags / push / commit in one launch
         if (ha_apply_mapped2(c.grad, c.S, c.data, c.width, c.plan_ws, n, grads, -1.0f, c.uslot, c.uslot, c.hasgrad, s))
             return -1;
+        cache_mark(h, kTCopy, s);
         const unsigned pblocks = static_cast<unsigned>((2 * n + 15) / 16 > 1024 ? 1024 : (2 * n + 15) / 16);
         const bool vec_ok = !c.remote && (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
         if (vec_ok)
@@ -2129,6 +2157,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
         else
             hipLaunchKernelGGL(cache_update_same_post_kernel<1>, dim3(pblocks), dim3(1024), 0, s, c, p.hdr, p.uniq,
                                p.counts, (long long)n, (long long)h->out_pad);
+        cache_mark(h, kTEnd, s);
         HA_LAUNCH_CHECK();
         return 0;
     }
@@ -2147,6 +2176,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     }
     hipLaunchKernelGGL(cache_update_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
                        c.bypass ? 1 : 0, probed);
+    cache_mark(h, kTLookup, s);
     HA_LAUNCH_CHECK();
     // Line::accumulate per occurrence, occurrence order: grad += g (every line), data += g (lines
     // with data).  lr = -1 turns the SGD chain `acc - lr*g` into `acc + g` bit for bit.
@@ -2155,9 +2185,11 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
                              c.hasgrad, s))
             return -1;
     }
+    cache_mark(h, kTCopy, s);
     hipLaunchKernelGGL(cache_update_flags_push_kernel, CACHE_GRID(n * 64), b, 0, s, c.ctl, c, p.uniq, p.counts,
                        pk, (long long)n_push, with_push_keys);
     hipLaunchKernelGGL(cache_push_evicted_kernel, CACHE_GRID(c.nmax * 64), b, 0, s, c.ctl, c, (long long)h->out_pad);
+    cache_mark(h, kTTransfer, s);
     // the evicted lines that were pending before this call are pushed now: their slots are free again
     if (!defer_cleanup) {
         const unsigned cblocks = 1u + static_cast<unsigned>((n + 15) / 16 > 1024 ? 1024 : (n + 15) / 16);
@@ -2166,6 +2198,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     } else {
         hipLaunchKernelGGL(cache_update_commit_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, (long long)n);
     }
+    cache_mark(h, kTEnd, s);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -2321,6 +2354,48 @@ extern "C" int ha_cache_perf(ha_cache *h, int64_t *out_host, ha_stream_t stream)
         out_host[i] = ctl.perf[i];
     out_host[4] += ctl.perf[7];
     out_host[7] = ctl.size;
+    return 0;
+}
+
+// Stage times of the last lookup / update (milliseconds, as the reference's perf dict reports them: cache.cc:99-105,
+// 189-194), measured with HIP events between the call's launches on the caller's stream.  Off by default (an event record
+// between two launches costs about what a short launch costs).  out_ms[6]: for every stage boundary that the call passed,
+// the time since the boundary before it -- [1] sort (index plan), [2] lookup (probe, miss scan, slot assignment: the
+// reference's lookup + prepare), [3] copy (rows to dest + insert + eviction / the accumulate of an update), [4] transfer
+// (remote stores: the exchange with the owners; updates: the push launches), [5] the rest of the call (an update's
+// clean-up; a lookup's row launch); [0] = the whole call; -1 = boundary not passed.
+extern "C" int ha_cache_set_timing(ha_cache *h, int on) {
+    HA_REQUIRE(h, "cache_set_timing: null handle");
+    if (on && h->tev[0] == nullptr)
+        for (int i = 0; i < 6; ++i)
+            HA_CHECK_HIP(hipEventCreate(&h->tev[i]));
+    h->timing = on != 0;
+    h->tmask = 0;
+    return 0;
+}
+extern "C" int ha_cache_stage_times(ha_cache *h, double *out_ms) {
+    HA_REQUIRE(h && out_ms, "cache_stage_times: bad arguments");
+    for (int i = 0; i < 6; ++i)
+        out_ms[i] = -1.0;
+    if (!h->timing || !(h->tmask & 1u))
+        return 0;
+    int last = 0;
+    for (int i = 1; i < 6; ++i)
+        if (h->tmask & (1u << i))
+            last = i;
+    HA_CHECK_HIP(hipEventSynchronize(h->tev[last]));
+    int prev = 0;
+    for (int i = 1; i < 6; ++i) {
+        if (!(h->tmask & (1u << i)))
+            continue;
+        float ms = 0.f;
+        HA_CHECK_HIP(hipEventElapsedTime(&ms, h->tev[prev], h->tev[i]));
+        out_ms[i] = ms;
+        prev = i;
+    }
+    float all = 0.f;
+    HA_CHECK_HIP(hipEventElapsedTime(&all, h->tev[0], h->tev[last]));
+    out_ms[0] = all;
     return 0;
 }
 

@@ -139,7 +139,10 @@ public:
     void set_pull_bound(int64_t b) { pull_ = b; ha_check(ha_cache_set_bounds(h_, pull_, push_), "set_bounds"); }
     void set_push_bound(int64_t b) { push_ = b; ha_check(ha_cache_set_bounds(h_, pull_, push_), "set_bounds"); }
     bool perf_enabled() const { return perf_enabled_; }
-    void set_perf_enabled(bool v) { perf_enabled_ = v; }
+    void set_perf_enabled(bool v) {
+        perf_enabled_ = v;
+        ha_check(ha_cache_set_timing(h_, v ? 1 : 0), "set_timing");      // the perf dict's stage times (cache.cc:99-105)
+    }
     py::list perf() const { return perf_; }
     void bypass() { ha_check(ha_cache_set_bypass(h_, 1), "bypass"); }
     void undo_bypass() { ha_check(ha_cache_set_bypass(h_, 0), "undo_bypass"); }
@@ -320,6 +323,21 @@ private:
             d["num_transfered"] = out[4];
             if (out[0] == 1)
                 d["num_evict"] = out[5];
+            double ms[6];
+            ha_check(ha_cache_stage_times(h_, ms), "ha_cache_stage_times");
+            auto t = [&](int i) { return ms[i] > 0.0 ? ms[i] : 0.0; };
+            d["time"] = t(0);
+            d["sort_time"] = t(1);
+            d["lookup_time"] = t(2);
+            d["transfer_time"] = t(4);
+            if (out[0] == 0) {
+                d["prepare_time"] = 0.0;
+                d["copy_time"] = t(3) + t(5);
+                d["insert_time"] = 0.0;
+            } else {
+                d["copy_time"] = t(3);
+                d["cleanup_time"] = t(5);
+            }
             perf_.append(d);
         }
     }

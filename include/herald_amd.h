@@ -894,6 +894,13 @@ int ha_cache_state(ha_cache *cache, int64_t *out_host, ha_stream_t stream);
 /* Diagnostics: out_host[16] = the GPU's 100 MHz clock at the phase boundaries of the last lookup's bookkeeping
  * ([0..4] the bookkeeping workgroup, [8..12] the insert / eviction workgroup beside the row copies). */
 int ha_cache_phase_times(ha_cache *cache, uint64_t *out_host, ha_stream_t stream);
+/* Stage times of the last lookup / update in milliseconds, the fields of the reference's perf dict (`time, sort_time,
+ * lookup_time, prepare_time, transfer_time, copy_time, insert_time / cleanup_time`, src/hetu_cache/src/cache.cc:99-105,
+ * 189-194; dumped by examples/ctr/run_hetu.py:508-515), measured with HIP events between the call's launches once
+ * ha_cache_set_timing(cache, 1) was called (off by default).  out_ms[6] = {whole call, sort, lookup (+ prepare), copy (+
+ * insert), transfer, the rest}; -1 = a stage the call did not pass. */
+int ha_cache_set_timing(ha_cache *cache, int on);
+int ha_cache_stage_times(ha_cache *cache, double *out_ms);
 /* Resident lines, unordered, into device arrays of capacity cap; *count_dev (zeroed by the
  * caller) receives the number of resident lines; slots[] index the rows of ha_cache_data/grad. */
 int ha_cache_snapshot(ha_cache *cache, int64_t cap, uint32_t *keys,
