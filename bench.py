@@ -52,6 +52,9 @@ def parse_args():
                    help="skip the secondary measurement of the laia scheduler (configs[3] shape)")
     p.add_argument("--no-config-c", action="store_true",
                    help="N>1 (sharded) leg: skip the second measurement at BASELINE configs[2]'s shape (bs=4096 d=128)")
+    p.add_argument("--no-wide", action="store_true",
+                   help="skip the secondary measurements of the work-queue step at BASELINE configs[2] / configs[3]'s per-GPU "
+                        "shapes (bs=4096 d=128 and bs=1024 d=512 on one GPU: the wide path, batches beyond 7,168 ids)")
     p.add_argument("--no-cold-tier", action="store_true",
                    help="skip the secondary measurement of the host-DRAM cold tier (BASELINE configs[4] shape)")
     p.add_argument("--cold-rows", type=int, default=33554432,
@@ -774,6 +777,19 @@ def main():
         secondary("cache_tier", lambda: cache_tier(args, table, ids_dev, outs[0], grads[0], dev))
     if not args.no_laia:
         secondary("laia_scheduler", lambda: laia_scheduler(args))
+    if not args.no_wide and queue and args.width == 512 and args.rows >= (1 << 20):
+        from herald_amd import wide_bench
+        # configs[3]'s per-GPU shape on the headline's own table (bs=1024 d=512), configs[2]'s on a d=128 table of the same rows
+        secondary("wide_bs1024_d512", lambda: wide_bench.measure(table, args.rows, 1024, args.width, fields=args.fields))
+
+        def _wide_c():
+            t128 = init_table(args.rows, 128, dev)
+            try:
+                return wide_bench.measure(t128, args.rows, 4096, 128, fields=args.fields)
+            finally:
+                del t128
+                torch.cuda.empty_cache()
+        secondary("wide_bs4096_d128", _wide_c)
     if not args.no_cold_tier:
         del table
         torch.cuda.empty_cache()

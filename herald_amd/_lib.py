@@ -168,7 +168,7 @@ def _declare(L):
         "ha_qbig_plan_batch_f32ids": [vp, vp, vp, i64, i64, vp],
         "ha_qbig_plan_batch_u64ids": [vp, vp, vp, i64, i64, vp],
         "ha_qbig_queue_batch": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
-        "ha_qbig_apply": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, c.c_uint32, vp, vp, vp],
+        "ha_qbig_apply": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, c.c_uint32, vp, vp, vp],
         "ha_event_destroy": [vp],
         "ha_event_record": [vp, vp],
         "ha_stream_wait_event": [vp, vp],

@@ -59,6 +59,9 @@ constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers 
 #ifndef QV_COOPSLOTS
 #define QV_COOPSLOTS 256
 #endif
+#ifndef QV_GOLD
+#define QV_GOLD 0       // 1 (with -DQV_WG=1024 -DQV_COOPSLOTS=64): round 3's launch geometry, for same-box timing comparisons
+#endif
 #ifndef QV_WG
 #define QV_WG 256
 #endif
@@ -112,7 +115,7 @@ static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + 
 static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
     QLayout q;
     char *b = static_cast<char *>(ws);
-    q.cap_coop = static_cast<uint32_t>(ceil_div(width, 32) * (ceil_div(n_cap, kQLongC) + 1));
+    q.cap_coop = static_cast<uint32_t>(ceil_div(width, 32) * (ceil_div(n_cap, kQLongC) + 1));     // (QV_GOLD needs half)
     q.cap_wave = static_cast<uint32_t>(ceil_div(width, 512) * 2 * n_cap + 64);
     q.cap_copy = static_cast<uint32_t>(ceil_div(width, 512) * n_cap + 64);
     q.hdr = reinterpret_cast<QHeader *>(b);
@@ -508,7 +511,7 @@ __device__ __forceinline__ int q_kind(uint32_t c, uint32_t m, bool in_table) {
     return kQS;
 }
 __device__ __forceinline__ int q_slice(int kind) {   // columns per item
-    return (kind == kQL || kind == kQG) ? 32 : kind == kQM ? 128 : 512;
+    return kind == kQL ? 32 : kind == kQG ? (QV_GOLD ? 64 : 32) : kind == kQM ? 128 : 512;
 }
 
 __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
@@ -540,7 +543,7 @@ struct QCount {   // items per class: coop (G), long, medium, small (S and Z)
 // (selects on VALUES: an if / else chain over four variables is merged into `*select(&x..) += n`, which puts them --
 // and, through the by-reference captures of a lambda, the whole argument block -- into scratch memory)
 __device__ __forceinline__ QCount q_count(QCount t, int kind, uint32_t per512, uint32_t per128, uint32_t per32) {
-    t.g += kind == kQG ? per32 : 0u;
+    t.g += kind == kQG ? (QV_GOLD ? (per32 + 1u) / 2u : per32) : 0u;
     t.l += kind == kQL ? per32 : 0u;
     t.m += kind == kQM ? per128 : 0u;
     t.s += (kind == kQS || kind == kQZ) ? per512 : 0u;
@@ -865,6 +868,15 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
         } else if (atomicAdd(&bqh->done, 1u) + 1u == wide_parts) {
             __hip_atomic_store(&bqh->epoch_wave, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&bqh->epoch_copy, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (mirror) {       // every bucket has added its items: the counts are final (+ 1: 0 = not built yet)
+                const uint32_t nw = __hip_atomic_load(&bqh->n_wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t nc = __hip_atomic_load(&bqh->n_coop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t np = __hip_atomic_load(&bqh->n_copy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mirror[1] = min(nc, bcap_coop) + 1u;
+                mirror[2] = min(np, bcap_copy) + 1u;
+                __threadfence_system();
+                mirror[0] = min(nw, bcap_wave) + 1u;     // the word the host waits for, last
+            }
         }
     }
 }
@@ -1127,6 +1139,74 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     }
 }
 
+#if QV_GOLD   // timing variant: round 3's geometry (1024-thread workgroups, G items = sixteen waves per 64-column slice)
+// G: one 64-column slice by a whole workgroup, c >= 64.  lane = (row r of 4, column quad c4 of 16); wave w takes
+// occurrences 16w .. 16w+15 of every block of 256 (four 16-byte loads per lane and block).  s_part = 16 x 64 floats.
+__device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float *s_part) {
+    const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
+    const int width = a.width;
+    const int r = lane >> 4, c4 = lane & 15;
+    const bool act = 4 * c4 < it.cols;
+    const int col = it.col0 + (act ? 4 * c4 : 0);
+    float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
+    const float4v cur = q_ld_row<float4v>(row + col);
+    // destinations of this wave: j = 64 * k + 4 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 2, l & 3):
+    // one register covers the first 16 rounds (1,024 destinations)
+    int dv = 0;
+    if (it.m > 0)
+        dv = a.perm_g[it.fs + min(static_cast<uint32_t>(64 * (lane >> 2) + 4 * w + (lane & 3)), it.m - 1u)];
+    float4v p{0.f, 0.f, 0.f, 0.f};
+    for (uint32_t base = 0; base < it.c; base += 256) {
+        const uint32_t mine = base + 16u * static_cast<uint32_t>(w);   // this wave's first occurrence of the block
+        if (mine >= it.c)
+            break;   // wave-uniform; no barrier inside the loop
+        const int pidx = a.perm_a[it.st + min(mine + static_cast<uint32_t>(lane & 15), it.c - 1u)];
+        float4v g[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t o = static_cast<uint32_t>(__shfl(pidx, 4 * t + r, 64));
+            g[t] = q_ld_grad<float4v>(a.grads + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + col);   // branch-free (clamped)
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4v q = acc4(p, g[t], a.lr);
+            const bool valid = mine + static_cast<uint32_t>(4 * t + r) < it.c;
+            p = valid ? q : p;
+        }
+    }
+    p = add4(p, shfl_xor4(p, 16));
+    p = add4(p, shfl_xor4(p, 32));
+    if (lane < 16)
+        *reinterpret_cast<float4v *>(s_part + w * 64 + 4 * c4) = p;
+    __syncthreads();
+    // fixed tree over the 16 wave partials: lane group r adds the partials of waves 4r .. 4r+3 as (a + b) + (c + d),
+    // the four group sums meet by two butterfly steps -- ((q0 + q1) + (q2 + q3)) in every lane (IEEE addition
+    // commutes, so both partners of a step hold the same bits)
+    const float *sp = s_part + (4 * r) * 64 + 4 * c4;
+    float4v total = add4(add4(*reinterpret_cast<const float4v *>(sp), *reinterpret_cast<const float4v *>(sp + 64)),
+                         add4(*reinterpret_cast<const float4v *>(sp + 128), *reinterpret_cast<const float4v *>(sp + 192)));
+    total = add4(total, shfl_xor4(total, 16));
+    total = add4(total, shfl_xor4(total, 32));
+    const float4v nv = sub4(cur, total);
+    if (w == 0 && r == 0 && act)
+        q_st_row(row + col, nv);
+    for (uint32_t k0 = 0; k0 * 64u < it.m; k0 += 16) {
+        if (k0 > 0)
+            dv = a.perm_g[it.fs + min(64u * (k0 + static_cast<uint32_t>(lane >> 2)) + static_cast<uint32_t>(4 * w + (lane & 3)),
+                                      it.m - 1u)];
+        const uint32_t rounds = min(16u, (it.m - 64u * k0 + 63u) / 64u);
+        for (uint32_t k = 0; k < rounds; ++k) {
+            const uint32_t j = 64u * (k0 + k) + static_cast<uint32_t>(4 * w + r);
+            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(4 * k) + r, 64));
+            if (j < it.m && act)
+                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+        }
+    }
+    __syncthreads();   // s_part is reused by the next item of this workgroup
+}
+
+#endif
+
 // G: one 32-column slice by a whole workgroup of FOUR waves, c >= 64.  Every wave works like an L item on its share of
 // the run -- lane = (occurrence group r of 8, column quad c4 of 8), wave w takes occurrences 64w .. 64w+63 of every
 // block of 256 (eight 16-byte loads per lane and block) --, the four wave sums meet in LDS as (w0 + w1) + (w2 + w3).
@@ -1228,7 +1308,11 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
         const uint32_t n = min(a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
         for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
             const QItem it = q_load(a.qcoop + e, a.width);
+#if QV_GOLD
+            q_coop_r3(a, it, reinterpret_cast<float *>(s_dyn));
+#else
             q_coop(a, it, reinterpret_cast<float *>(s_dyn));
+#endif
             kind = it.kind;
         }
     } else {
@@ -1472,7 +1556,8 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
 static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t *perm_cur, int64_t n_cur, const float *grads,
                         float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
                         int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg = nullptr,
-                        int64_t wave_items = -1, uint32_t epoch = 0, uint32_t *err = nullptr, hipEvent_t done = nullptr);
+                        int64_t wave_items = -1, uint32_t epoch = 0, uint32_t *err = nullptr, hipEvent_t done = nullptr,
+                        int64_t coop_items = -1);
 
 static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                   void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
@@ -1490,7 +1575,7 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
 static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t *perm_cur, int64_t n_cur, const float *grads,
                         float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
                         int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg,
-                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done) {
+                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done, int64_t coop_items) {
     HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
                    width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
                "ha_qapply: the table must be 16-byte aligned with rows of a multiple of 4 floats");
@@ -1531,6 +1616,8 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     a.n_g = static_cast<int>(n_next);
     a.out = next_out;
     a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
+    if (coop_items >= 0)        // the caller knows the number of workgroup items (wide batches have thousands): one each, <= 2048
+        a.ncoop = static_cast<int>(coop_items < 2048 ? coop_items : 2048);
     // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
     const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
     a.nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
@@ -1541,10 +1628,10 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     if (done != nullptr)
         // the event completes with THIS launch (the dispatch packet's own completion signal): no packet of its own on the
         // stream -- an event record between two launches of a stream costs what a short kernel costs
-        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 32 * 4, stream,
+        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4, stream,
                               nullptr, done, 0, a);
     else
-        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 32 * 4, stream, a);
+        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4, stream, a);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -1566,19 +1653,22 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
 //           appending to the step's queue with one atomic add per region;
 //   apply   the same launch as the narrow path (qapply_kernel), items numbered across the buckets.
 // No sort anywhere: the 43 us radix sort of a 106,496-id batch (four launches of 26 workgroups) becomes two partition
-// launches and P-fold parallel plan / queue workgroups of ~2,000 ids each.  Limits: at most kQBigMax ids per batch
-// (positions are 21-bit fields of an item); a BUCKET holds at most kQMax ids -- with P = n / 2048 rounded up to a power
-// of two that leaves room for a key with ~5,000 occurrences (a key names a sample of a field once: c <= the batch
-// size, 4,096 at configs[2]); a bucket beyond that raises the sticky overflow word instead of dropping ids.
+// launches and P-fold parallel plan / queue workgroups of ~1,000 ids each.  Limits: at most kQBigMax ids per batch
+// (positions are 21-bit fields of an item); a BUCKET holds at most kQMax ids -- with P = n / 1024 rounded up to a power
+// of two that leaves room for ~6,000 occurrences of hot keys per bucket (a key names a sample of a field once: c <= the
+// batch size, 4,096 at configs[2]; two such keys in one bucket do not fit).  A batch with a bucket beyond that is NOT
+// planned here: its queues carry flag 4 (header word and the pinned mirror, written with the counts by the bucket
+// workgroup that finishes last), and the caller takes another path for the steps that touch it
+// (ops.QueueStepPipeline: the sorted plan + ha_sgd_apply / ha_gather_* for that step -- rare, and correct).
 // =====================================================================================================
 constexpr int kQBigTile = 4096;
-constexpr int kQBigBucketsMax = 64;
+constexpr int kQBigBucketsMax = 128;
 constexpr int64_t kQBigMax = 1 << 17;
 constexpr int kQBigTilesMax = static_cast<int>(kQBigMax / kQBigTile);      // 32
 
-static inline int qbig_buckets(int64_t n_cap) {
+static inline int qbig_buckets(int64_t n_cap) {     // ~1,024 ids per bucket on average: room for ~6,000 occurrences of hot keys
     int p = 2;
-    while (p < kQBigBucketsMax && static_cast<int64_t>(p) * 2048 < n_cap)
+    while (p < kQBigBucketsMax && static_cast<int64_t>(p) * 1024 < n_cap)
         p *= 2;
     return p;
 }
@@ -2140,7 +2230,7 @@ extern "C" int ha_qbig_queue_batch(int64_t rows, int64_t width, void *const *ws_
 }
 extern "C" int ha_qbig_apply(float *table, int64_t rows, int64_t width, void *ws_cur, int64_t n_cur, const float *grads,
                              float lr, void *ws_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t n_cap,
-                             uint32_t epoch, uint32_t *err, void *done_event, ha_stream_t stream) {
+                             int64_t coop_items, uint32_t epoch, uint32_t *err, void *done_event, ha_stream_t stream) {
     HA_REQUIRE(n_cap >= 1 && n_cap <= kQBigMax && (n_cur == 0 || ws_cur) && (n_next == 0 || ws_next), "ha_qbig_apply: bad arguments");
     QBigRef a, g;
     memset(&a, 0, sizeof(a));
@@ -2150,7 +2240,7 @@ extern "C" int ha_qbig_apply(float *table, int64_t rows, int64_t width, void *ws
     if (n_next > 0)
         qbig_layout(ws_next, n_cap, &g);
     return qapply_lists(table, rows, width, a.gperm, n_cur, grads, lr, g.gperm, n_next, next_out, queue_cur, n_cap, kQBigMax,
-                        as_stream(stream), nullptr, -1, epoch, err, static_cast<hipEvent_t>(done_event));
+                        as_stream(stream), nullptr, -1, epoch, err, static_cast<hipEvent_t>(done_event), coop_items);
 }
 // a wide plan's per-bucket results for tests: bucket offsets [P + 1], then per bucket its number of unique keys
 extern "C" int ha_qbig_plan_view(void *ws, int64_t n_cap, void **boff, void **bhdr, void **uniq, void **counts, void **seg,

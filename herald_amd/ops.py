@@ -840,6 +840,7 @@ class QueueStepPipeline:
         self._queue_ptr = [self.queues.data_ptr() + q * self.queue_bytes for q in range(self.NQUEUE)]
         self._ev_pool = []
         self._last_items = 0
+        self.fallbacks, self._fb_plan, self._wide_ids = 0, None, {}
         self.reset()
 
     # ---- bookkeeping ------------------------------------------------------------------------------------------
@@ -918,6 +919,9 @@ class QueueStepPipeline:
             sel[_ids_kind(t)].append((j, t, m))
             held.append(t)
             self.n[j] = m
+            if self.wide:            # (a step whose batch cannot be bucketed falls back to a sorted plan of the ids)
+                self._wide_ids[j] = t
+                self._wide_ids.pop(j - 5 * B, None)
         for kind, lst in sel.items():
             if not lst:
                 continue
@@ -1045,8 +1049,16 @@ class QueueStepPipeline:
                 _ptr(self.plan_of(c + 1).ws) if n_next else None, n_next, _ptr(out) if n_next else None,
                 self._queue(c), self.capacity]
         if self.wide:
-            self.wave_items(c)           # (raises if the builder flagged this step's queue)
-            check(L.ha_qbig_apply(*args, self._epoch(c) if flags else 0, self._err_ptr(c) if flags else None, done,
+            # The host waits until queue c is complete (the builder runs a block ahead; its last bucket workgroup writes the
+            # counts to pinned memory): only then is it known whether the batches of this step could be planned at all -- a
+            # hash bucket that holds more than qstep_max_ids() ids cannot (flag 4), and such a step takes the sorted plan.
+            flag, coop = self._wide_built(c)
+            if flag & 4:
+                self._wide_fallback(c, grads, out, stream, n_cur, n_next, done)
+                return
+            if flag:
+                self.wave_items(c)       # raises
+            check(L.ha_qbig_apply(*args, coop, self._epoch(c) if flags else 0, self._err_ptr(c) if flags else None, done,
                                   _stream_ptr(stream)), "ha_qbig_apply")
         elif flags:
             check(L.ha_qapply_sync(*args, self.wave_items(c), self._epoch(c), self._err_ptr(c), done, _stream_ptr(stream)),
@@ -1055,6 +1067,34 @@ class QueueStepPipeline:
             check(L.ha_qapply_sized(*args, self.wave_items(c), _stream_ptr(stream)), "ha_qapply")
         else:
             check(L.ha_debug_qapply(*args, _ptr(dbg), _stream_ptr(stream)), "ha_debug_qapply")
+
+    def _wide_built(self, c, timeout=20.0):
+        """Wide path: wait (host) for the pinned counts of queue c; -> (flags, workgroup items)."""
+        import time
+        at = 4 * (c % self.COUNTS)
+        cc = self._counts_c
+        if cc[at] == 0:
+            t0 = time.perf_counter()
+            while cc[at] == 0:
+                if time.perf_counter() - t0 > timeout:
+                    raise RuntimeError("QueueStepPipeline: the queue of step %d was not built within %.0f s (was its block "
+                                       "prepared?)" % (c, timeout))
+        return cc[at + 3], max(cc[at + 1] - 1, 0)
+
+    def _wide_fallback(self, c, grads, out, stream, n_cur, n_next, done):
+        """Step c without its queue: a batch it touches has a hash bucket beyond one plan workgroup's reach.  Batch c is
+        applied through a SORTED plan (the reference's serial chain for every key: stricter than the queue's tolerance
+        classes), then the rows of batch c+1 are gathered -- two launches + a sort instead of one launch, for this step only."""
+        self.fallbacks += 1
+        if n_cur:
+            if self._fb_plan is None:
+                self._fb_plan = IndexPlan(self.capacity, self.device)
+            self._fb_plan.build(self._wide_ids[c], stream=stream)
+            sgd_apply(self.table, self._fb_plan, grads.reshape(n_cur, -1), self.lr, stream=stream, finished=True)
+        if n_next:
+            embedding_lookup(self.table, self._wide_ids[c + 1].reshape(-1), out=out.reshape(n_next, -1), stream=stream)
+        if done is not None:
+            check(self._L.ha_event_record(done, _stream_ptr(stream)), "ha_event_record")
 
     def apply_call(self, c, grads, out, stream, n_cur, n_next, sized=True):
         """-> callable(step index) that enqueues the launch of the steps c, c + ROTATION, ... with the arguments converted

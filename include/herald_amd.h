@@ -569,15 +569,19 @@ int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, in
 
 /* The WIDE path: batches of more than ha_qstep_max_ids() (7,168) and at most ha_qbig_max_ids() (131,072) ids -- BASELINE
  * configs[2] / configs[3]'s per-GPU shapes, 106,496 and 26,624 ids per step.  The batch is cut into hash buckets by one
- * stable multisplit (ha_qbig_buckets(n_cap) buckets; a bucket may hold at most ha_qstep_max_ids() ids: a key with more
- * than ~5,000 occurrences in a batch overflows it -- the builder raises the queue's overflow word / counts_host[k][3] = 4
- * instead of dropping ids); every bucket is planned and joined like a narrow batch, side by side (no sort anywhere), and
+ * stable multisplit (ha_qbig_buckets(n_cap) buckets of ~1,024 ids; a bucket may hold at most ha_qstep_max_ids() ids: hot
+ * keys with more than ~6,000 occurrences together in one bucket overflow it -- the queues of the steps that touch such a
+ * batch carry flag 4, header word and counts_host[k][3], and the caller runs those steps another way: ops.QueueStepPipeline
+ * waits for counts_host[k][0] (written last, non-zero once queue k is complete) before it enqueues step k and falls back
+ * to the sorted plan + ha_sgd_apply / ha_gather_*); every bucket is planned and joined like a narrow batch, side by side
+ * (no sort anywhere), and
  * the apply is the narrow path's launch over all buckets' items.  ws: ha_qbig_plan_bytes(n_cap) bytes per batch (no
  * initialisation); queues: ha_qstep_queue_bytes(n_cap, width).  Semantics, tolerance classes and references as above
  * (Unique<T>'s contract -- every key once, occurrences in order -- unqiue_tools.h:27-48; cpu_deduplicate, ndarray.py:556-576).
  * ha_qbig_plan_batch_* = partition (two launches) + the bucket plans (one launch) of `count` batches; ha_qbig_queue_batch
- * = the queues of `count` steps (two launches); ha_qbig_apply = step c (one launch; epoch / err / done_event as
- * ha_qapply_sync, 0 / NULL / NULL for none).  ha_qbig_plan_view: device pointers into a plan workspace for tests. */
+ * = the queues of `count` steps (two launches); ha_qbig_apply = step c (one launch; coop_items = the queue's number of
+ * workgroup items if known, counts_host[k][1] - 1, else -1; epoch / err / done_event as ha_qapply_sync, 0 / NULL / NULL
+ * for none).  ha_qbig_plan_view: device pointers into a plan workspace for tests. */
 int64_t ha_qbig_max_ids(void);
 size_t ha_qbig_plan_bytes(int64_t n_cap);
 int ha_qbig_buckets(int64_t n_cap);
@@ -589,8 +593,8 @@ int ha_qbig_queue_batch(int64_t rows, int64_t width, void *const *ws_a, const in
                         const int64_t *n_g, void *const *queues, int64_t n_cap, int64_t count, uint32_t *const *counts_host,
                         const uint32_t *epochs, ha_stream_t stream);
 int ha_qbig_apply(float *table, int64_t rows, int64_t width, void *ws_cur, int64_t n_cur, const float *grads, float lr,
-                  void *ws_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t n_cap, uint32_t epoch,
-                  uint32_t *err, void *done_event, ha_stream_t stream);
+                  void *ws_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t n_cap, int64_t coop_items,
+                  uint32_t epoch, uint32_t *err, void *done_event, ha_stream_t stream);
 int ha_qbig_plan_view(void *ws, int64_t n_cap, void **boff, void **bhdr, void **uniq, void **counts, void **seg, void **gperm,
                       void **meta);
 

@@ -83,10 +83,12 @@ def test_bench_sharded_leg_runs_on_nccl_at_world_size_1(dev):
     assert d["n_gpus"] == 1 and d["steps"] == 64 and d["value"] > 0 and d["scaling"] == "weak"
     assert "sharded" in d["config"]["workload"] and "xgmi" in d
     assert d["ranks_seen"] == 1 and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
-    # the framed step (no host read-back), per-launch roofline, and BASELINE configs[2]'s shape in the same line
-    assert "fixed frames" in d["config"]["exchange"] and "0 of 80 steps took the sized exchange" in d["config"]["exchange"]
+    # the framed step with sized exchanges (no host read-back in the step), per-launch roofline, and BASELINE configs[2]'s
+    # shape in the same line; at world size 1 a step is the lookup + ONE reduce-and-add launch
+    assert "sized by the real per-owner counts" in d["config"]["exchange"] and "0 of 64 timed steps overflowed" in d["config"]["exchange"]
     ks = d["roofline"]["kernels"]
-    assert len(ks) == 4 and all(v["us"] > 0 and 0 < v["frac_of_hbm_peak"] < 1 for v in ks.values())
+    assert len(ks) == 2 and all(v["us"] > 0 and 0 < v["frac_of_hbm_peak"] < 1.3 for v in ks.values())
+    assert d["same_path_world1_ms_per_step"] is None and d["xgmi"]["bytes_carried_per_step"] == 0
     c = d["config_c"]
     assert "error" not in c, c
     assert "bs=4096 d=128" in c["config"]["workload"] and c["value"] > 0 and c["config"]["ids_per_step_per_gpu"] == 106496

@@ -312,7 +312,7 @@ def _check_wide_plan(pl, ids_int, what):
 
 
 @pytest.mark.parametrize("mode", [(True, 4), (False, 1), (True, 2, "flags")], ids=["side_stream_block4", "one_stream", "flags_block2"])
-@pytest.mark.parametrize("bs,width,rows", [(1024, 64, 150_000), (4096, 32, 200_000), (300, 128, 50_000)],
+@pytest.mark.parametrize("bs,width,rows", [(1024, 64, 400_000), (4096, 32, 1_000_000), (300, 128, 50_000)],
                          ids=["configs3_26624ids", "configs2_106496ids", "7800ids"])
 def test_qstep_wide_batches(dev, bs, width, rows, mode):
     """Batches beyond 7,168 ids -- BASELINE configs[3] / configs[2]'s per-GPU shapes, 26,624 and 106,496 ids per step, and
@@ -358,7 +358,7 @@ def test_qstep_wide_batches(dev, bs, width, rows, mode):
         torch.cuda.synchronize()
         assert not pipe.overflowed()
         _check_wide_plan(pipe.plan_of(k), ids, "plan of batch %d" % k)
-    assert out is None
+    assert out is None and pipe.fallbacks == 0
     got_t = table.cpu().numpy()
     np.testing.assert_array_equal(got_t, model_t, err_msg="table after the stream (kernel order)")
     loose = drift.any(axis=1)
@@ -370,20 +370,60 @@ def test_qstep_wide_batches(dev, bs, width, rows, mode):
         assert np.bincount(batches[0]).max() > 1500          # the long runs the wide path exists for
 
 
-def test_qstep_wide_bucket_overflow_fails_loudly(dev):
-    """A hash bucket holds at most qstep_max_ids() ids: a batch of 20,000 copies of ONE key cannot be planned by the wide
-    path -- the builder raises its sticky word and the pipeline raises instead of dropping the ids."""
-    rows, width, n = 1000, 32, 20000
-    table = torch.zeros((rows, width), device=dev)
-    pipe = ops.QueueStepPipeline(table, n, 0.1, overlap=False)
-    ids = [torch.full((n,), 7.0, device=dev) for _ in range(4)]
-    with pytest.raises(RuntimeError, match="bucket"):
-        out = pipe.start(ids[:pipe.LOOKAHEAD])
-        for k in range(3):
-            torch.cuda.synchronize()
-            out = pipe.step(torch.ones((n, width), device=dev), None)
+def test_qstep_wide_bucket_overflow_takes_the_sorted_plan(dev):
+    """A hash bucket holds at most qstep_max_ids() ids.  Two keys with 5,000 occurrences each that fall into ONE bucket
+    cannot be planned by the wide path: the queues of the steps that touch such a batch carry flag 4, and the pipeline
+    runs exactly those steps through the sorted plan (the serial chain for every key) -- nothing is dropped, the other
+    steps keep their queues.  Every lookup and the table against the reference's chain (bit-exact where no key ever had a
+    long run in a queue-driven step, within 1e-5 x lr x sum|g| otherwise)."""
+    rows, width, n, steps = 60_000, 32, 20_000, 6
+    rng = np.random.default_rng(77)
+    P = 32                                                     # ha_qbig_buckets(20,000)
+    bucket = lambda k: ((int(k) * 0x85EBCA6B) & 0xFFFFFFFF) >> 27
+    hot = [k for k in range(100, 4000) if bucket(k) == bucket(100)][:2]
+    assert len(hot) == 2
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    batches = []
+    for k in range(steps):
+        b = rng.integers(0, rows, size=n)
+        if k in (2, 3):                                        # steps 1, 2, 3 touch an unplannable batch
+            b[:5000] = hot[0]
+            b[5000:10000] = hot[1]
+            b = rng.permutation(b)
+        else:
+            b[:300] = rng.integers(0, 40, size=300)            # some medium / long runs in the queue-driven steps
+        batches.append(b)
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
+    lr = 0.02
+    table = _dev(table0, dev)
+    pipe = ops.QueueStepPipeline(table, n, lr, overlap=True, block=2, sync="flags")
+    assert pipe.wide and pipe.plans[0].buckets == P
+    L = pipe.LOOKAHEAD
+    d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
+    exact_t = table0.copy()
+    drift = np.zeros((rows, width), np.float64)
+    out = pipe.start(d_ids[:L])
+    for k in range(steps):
         torch.cuda.synchronize()
-        pipe.wave_items(0)
+        ids = batches[k].astype(np.int64)
+        got = out.cpu().numpy().reshape(-1, width)
+        d = np.abs(got.astype(np.float64) - exact_t[ids].astype(np.float64))
+        assert (d <= drift[ids] + REL * np.abs(exact_t[ids])).all(), "lookup rows of batch %d" % k
+        loose = drift[ids].any(axis=1)
+        np.testing.assert_array_equal(got[~loose], exact_t[ids][~loose], err_msg="rows without a long run, batch %d" % k)
+        cpu.sgd_sparse_update(exact_t, ids.astype(np.float32), grads[k], lr)
+        cnt = np.bincount(ids, minlength=rows)
+        sumabs = np.zeros((rows, width), np.float64)
+        np.add.at(sumabs, ids, np.abs(grads[k]).astype(np.float64))
+        drift += np.where((cnt >= qstep_model.LONG_MIN)[:, None], REL * lr * sumabs, 0.0)
+        out = pipe.step(_dev(grads[k], dev), d_ids[k + L] if k + L < steps else None)
+    torch.cuda.synchronize()
+    assert pipe.fallbacks == 3, pipe.fallbacks                # steps 1 (looks batch 2 up), 2 and 3 (apply batches 2 / 3)
+    got_t = table.cpu().numpy()
+    d = np.abs(got_t.astype(np.float64) - exact_t.astype(np.float64))
+    assert (d <= drift + REL * np.abs(exact_t)).all()
+    loose = drift.any(axis=1)
+    np.testing.assert_array_equal(got_t[~loose], exact_t[~loose])
 
 
 @pytest.mark.parametrize("mode", MODES[:3], ids=MODE_IDS[:3])

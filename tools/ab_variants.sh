@@ -2,7 +2,7 @@
 # A/B of compile-time variants of csrc/qstep.hip on ONE box (box-to-box differences are larger than the effects looked
 # for): usage  ab_variants.sh "<name>:<-D flags>" ...   (run through gpurun; the library of the box copy is relinked)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier"
+B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier --no-wide"
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc -I include"
 OBJS=$(ls herald_amd/_build/*.o | grep -v qstep.o)
 REPS=${REPS:-2}

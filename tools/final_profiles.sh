@@ -11,7 +11,7 @@ cd $R
 python3 bench.py > $O/bench_n1_default.json 2> $O/bench_n1_default.err
 python3 bench.py --steps 20 --warmup 5 > $O/bench_n1_steps20_warmup5.json 2> /dev/null
 grep '^{' gpurun_out/prof_$TAG/stats.log | tail -1 > $O/bench_under_rocprof.json
-python3 bench.py --lookahead 3 --no-cpu-baseline --no-cache-tier --no-cold-tier --no-laia > $O/bench_n1_lookahead3.json 2> /dev/null
+python3 bench.py --lookahead 3 --no-cpu-baseline --no-cache-tier --no-cold-tier --no-laia --no-wide > $O/bench_n1_lookahead3.json 2> /dev/null
 # shapes
 for bs in 512 1024 4096; do w=128; [ $bs = 1024 ] && w=512
   BATCH=$bs WIDTH=$w python3 tools/cfgc_bench.py 2>&1 | grep -v amdgpu.ids | tail -13 > $O/shape_bs${bs}_d${w}.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier"
+B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier --no-wide"
 show() { python -c "
 import json,sys
 try:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the work-queue step with plain launches and with hipGraph replays, long run and the 20-step run (same box)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier"
+B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier --no-wide"
 show() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1: us/step %.2f  dev_ms %.3f enq_ms %.3f host_bound %s' % (d['ms_per_step']*1e3, d['device_ms'], d['enqueue_ms'], d['host_bound']))"; }

@@ -5,7 +5,7 @@ O=gpurun_out/r4c; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_qstep.py tests/test_gpu_tolerance.py -x -q -m gpu > $O/t_qstep.log 2>&1; echo "qstep rc $?" >> $O/rc.txt
 timeout 1500 python -m pytest tests/test_gpu_fullscale.py -x -q -m gpu -k "queue_step" -s > $O/t_full.log 2>&1; echo "fullscale rc $?" >> $O/rc.txt
 timeout 1500 python -m pytest tests/test_gpu_example_wdl.py -x -q -m gpu > $O/t_example.log 2>&1; echo "example rc $?" >> $O/rc.txt
-B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier"
+B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier --no-wide"
 for i in 1 2; do
 timeout 400 python bench.py $B 2>/dev/null | python tools/ab_line.py base long >> $O/ab.txt
 timeout 400 python bench.py $B --steps 20 --warmup 5 2>/dev/null | python tools/ab_line.py base short >> $O/ab.txt

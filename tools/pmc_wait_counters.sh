@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcw_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
-ARGS="--steps 64 --warmup 32 --no-cpu-baseline --no-kernel-pass --no-cache-tier --no-cold-tier --no-laia"
+ARGS="--steps 64 --warmup 32 --no-cpu-baseline --no-kernel-pass --no-cache-tier --no-cold-tier --no-laia --no-wide"
 i=0
 while read -r group; do
   [ -z "$group" ] && continue
