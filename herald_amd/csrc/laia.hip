@@ -544,6 +544,41 @@ __global__ __launch_bounds__(1024) void laia_assign_kernel(const int32_t *__rest
     }
 }
 
+// TopkScheduler's assignment (topk_scheduler.cc:393-455): the batch and every worker's quota are cut into `nt` thread
+// slices (thread 0 takes the remainders, :398-407); a slice is assigned sequentially -- a sample is offered to the
+// workers in the order (j + candidate) % W, strictly greater score wins among the workers whose SLICE quota is not
+// used up, the walk stops at the candidate itself --, slices are independent of each other: one lane per slice.
+__global__ __launch_bounds__(128) void laia_topk_assign_kernel(const int32_t *__restrict__ scores, const int32_t *__restrict__ cand,
+                                                               int B, int W, int mini_bs, int nt, long long start, long long S,
+                                                               int32_t *__restrict__ owner, long long *__restrict__ dist) {
+    const int t = blockIdx.x * 128 + threadIdx.x;
+    if (t >= nt)
+        return;
+    const long long sx = B / nt, sy = B % nt, qx = mini_bs / nt, qy = mini_bs % nt;
+    const long long s0 = t == 0 ? 0 : sy + t * sx, s1 = t == 0 ? sx + sy : s0 + sx;
+    const long long q0 = t == 0 ? 0 : qy + t * qx, q1 = t == 0 ? qx + qy : q0 + qx;
+    int wl[64];
+    for (int w = 0; w < W; ++w)
+        wl[w] = 0;
+    for (long long i = s0; i < s1; ++i) {
+        const int c = cand[i];
+        int best = -1, best_w = -1;
+        for (int j = 0; j < W; ++j) {
+            const int w = (j + c) % W;
+            const int sc = scores[i * W + w];
+            if (best < sc && wl[w] < q1 - q0) {
+                best = sc;
+                best_w = w;
+                if (best_w == c)
+                    break;
+            }
+        }
+        dist[static_cast<long long>(best_w) * mini_bs + q0 + wl[best_w]] = (i + start) % S;
+        wl[best_w] += 1;
+        owner[i] = best_w;
+    }
+}
+
 // ---- (worker, row) bitmaps ----------------------------------------------------------------------------------
 // touch: (owner of the sample, row); plan: (w, row) for the rows valid at w in samples not assigned to w.
 // Thread e takes (table j, sample i) = (e / B, e % B): the lanes of a wave hold consecutive samples of ONE table, so a hot
@@ -579,7 +614,8 @@ __global__ __launch_bounds__(256) void laia_bits_kernel(const uint32_t *__restri
                                                         unsigned long long *__restrict__ tsum,
                                                         unsigned long long *__restrict__ pbits,
                                                         unsigned long long *__restrict__ psum,
-                                                        uint32_t *__restrict__ tnset, uint32_t *__restrict__ pnset) {
+                                                        uint32_t *__restrict__ tnset, uint32_t *__restrict__ pnset,
+                                                        int own_plan) {
     const long long total = static_cast<long long>(B) * T;
     const long long trips = (total + gridDim.x * 256ll - 1) / (gridDim.x * 256ll);     // whole waves make every trip
     for (long long tr = 0; tr < trips; ++tr) {
@@ -594,7 +630,9 @@ __global__ __launch_bounds__(256) void laia_bits_kernel(const uint32_t *__restri
             emb = samples[((start + i) % S) * T + j];
             live = emb < R;
             ow = owner[i];
-            m = live ? (mask[i * T + j] & ~(1ull << ow)) : 0ull;
+            // LaiaScheduler: rows valid at w in samples NOT assigned to w (laia_scheduler.cc:252-270); TopkScheduler: rows of
+            // w's OWN samples that w holds valid (topk_scheduler.cc:468-500)
+            m = live ? (own_plan ? (mask[i * T + j] & (1ull << ow)) : (mask[i * T + j] & ~(1ull << ow))) : 0ull;
         }
         laia_set_bits(tbits, tsum, tnset, static_cast<unsigned long long>(ow) * Rpad + emb, live);
         for (int w = 0; w < W; ++w)
@@ -1357,7 +1395,7 @@ static int laia_dev_states(Laia &l) {   // -> l.dev.h_state (synchronises the sc
 // One global batch with the scheduler state on the device: eight launches, `dist` + offsets + states back in one copy
 // phase, the plan rows in a second (their number is only known then).
 static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out, uint64_t *plan_out,
-                            int64_t plan_cap_elems, int64_t *plan_off, int only_rank) {
+                            int64_t plan_cap_elems, int64_t *plan_off, int only_rank, const TopkParams *topk = nullptr) {
     Laia &l = h->l;
     LaiaDev &d = l.dev;
     const int W = l.W, T = l.T;
@@ -1369,7 +1407,31 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     int blocks = static_cast<int>((BT + 255) / 256);
     if (blocks > 4096)
         blocks = 4096;
-    if (T <= 64) {
+    if (topk) {
+        HA_REQUIRE(topk->top_k >= 1 && topk->top_k <= T && T <= 64 && topk->num_threads >= 1 && W <= 64,
+                   "laia_next_topk: need 1 <= top_k <= num_table <= 64, num_threads >= 1 and at most 64 workers");
+        const int nt = topk->num_threads;
+        for (int t = 0; t < nt; ++t) {
+            long long s0, s1, q0, q1;
+            topk_slice(B, nt, t, &s0, &s1);
+            topk_slice(mini_bs, nt, t, &q0, &q1);
+            HA_REQUIRE(s1 - s0 <= W * (q1 - q0),
+                       "laia_next_topk: thread %d has %lld samples for %d workers x quota %lld (the reference "
+                       "writes dist[-1] here); pick num_threads dividing mini_batch_size", t, s1 - s0, W, q1 - q0);
+        }
+        TableOrder order;
+        for (int k = 0; k < topk->top_k; ++k) {
+            HA_REQUIRE(topk->order[k] >= 0 && topk->order[k] < T, "laia_next_topk: table index out of range");
+            order.t[k] = topk->order[k];
+        }
+        hipLaunchKernelGGL(laia_probe_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
+                           l.d_valid, l.R, l.d_mask);
+        hipLaunchKernelGGL(laia_topk_score_kernel, dim3((int)((B + 255) / 256)), dim3(256), 0, l.stream, l.d_mask, (int)B, T, W,
+                           order, topk->top_k, l.d_scores, l.d_cand);
+        HA_CHECK_HIP(hipMemsetAsync(d.d_dist, 0, static_cast<size_t>(W) * mini_bs * sizeof(long long), l.stream));   // dist.reset(0), :382
+        hipLaunchKernelGGL(laia_topk_assign_kernel, dim3((nt + 127) / 128), dim3(128), 0, l.stream, l.d_scores, l.d_cand, (int)B,
+                           W, (int)mini_bs, nt, start, l.S, l.d_owner, d.d_dist);
+    } else if (T <= 64) {
         const long long waves = (B + (64 / T) - 1) / (64 / T);
         hipLaunchKernelGGL(laia_probe_score_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, l.stream,
                            l.d_samples, l.S, T, start, (int)B, W, l.d_valid, l.R, l.d_mask, l.d_scores);
@@ -1381,11 +1443,12 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     }
     const size_t sc_bytes = static_cast<size_t>(B) * W;
     const int lds_scores = sc_bytes <= (size_t(32) << 10) && T <= 255 ? 1 : 0;
-    hipLaunchKernelGGL(laia_assign_kernel, dim3(1), dim3(1024), lds_scores ? sc_bytes : 0, l.stream, l.d_scores, (int)B, W,
-                       (int)mini_bs, (long long)batch_id, start, l.S, l.d_owner, d.d_dist, lds_scores);
+    if (!topk)
+        hipLaunchKernelGGL(laia_assign_kernel, dim3(1), dim3(1024), lds_scores ? sc_bytes : 0, l.stream, l.d_scores, (int)B, W,
+                           (int)mini_bs, (long long)batch_id, start, l.S, l.d_owner, d.d_dist, lds_scores);
     hipLaunchKernelGGL(laia_bits_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
                        l.d_mask, l.d_owner, l.R, d.Rpad, d.bits.bits[0], d.bits.sum[0], d.bits.bits[1], d.bits.sum[1],
-                       d.bits.nset[0], d.bits.nset[1]);
+                       d.bits.nset[0], d.bits.nset[1], topk ? 1 : 0);
     hipLaunchKernelGGL(laia_bits_count_kernel, dim3(static_cast<unsigned>((d.nsum + 1023) / 1024), 2), dim3(1024), 0, l.stream,
                        d.bits, d.nsum);
     hipLaunchKernelGGL(laia_bits_scan_kernel, dim3(2), dim3(1024), 0, l.stream, d.bits, d.nblk);
@@ -1450,18 +1513,15 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
                           const TopkParams *topk, int only_rank = -1) {
     HA_REQUIRE(h && dist_out && plan_out && plan_off && mini_bs > 0, "laia_next: bad arguments");
     Laia &l = h->l;
-    if (!l.decided) {      // LaiaScheduler with a large cache keeps its snapshots on the device; everything else on the host
-        l.decided = true;
-        if (topk == nullptr && laia_dev_eligible(l)) {
+    if (!l.decided) {      // a cache that holds at least one global batch of rows: the snapshots live on the device (both
+        l.decided = true;  // schedulers); smaller caches and HA_LAIA_HOST=1 keep them on the host
+        if (laia_dev_eligible(l)) {
             if (laia_dev_init(l))
                 return -1;
         }
     }
-    if (l.dev.on) {
-        HA_REQUIRE(topk == nullptr, "laia_next_topk: this scheduler keeps its snapshots on the device (it was first "
-                                    "used as a LaiaScheduler); create a separate one for the top-k schedule");
-        return laia_next_device(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off, only_rank);
-    }
+    if (l.dev.on)
+        return laia_next_device(h, batch_id, mini_bs, dist_out, plan_out, plan_cap_elems, plan_off, only_rank, topk);
     laia_host_snaps(l);
     const int W = l.W, T = l.T;
     const long long B = mini_bs * W;
@@ -1697,6 +1757,14 @@ static int laia_next_impl(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t
     l.t_total_us += now_us() - t_begin;
     l.t_calls += 1;
     return 0;
+}
+
+// 1 = the scheduler keeps its MiniLRU snapshots, assignment and key lists on the device (decided at its first batch: a
+// cache that holds at least one global batch of rows, both schedulers), 0 = host snapshots, -1 = not decided yet
+extern "C" int ha_laia_on_device(ha_laia *h) {
+    if (!h)
+        return -1;
+    return h->l.decided ? (h->l.dev.on ? 1 : 0) : -1;
 }
 
 // out[4] = {calls, total us, host assignment us, host snapshot us} summed since creation

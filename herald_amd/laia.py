@@ -259,7 +259,8 @@ class TopkScheduler(LaiaScheduler):
         return {"miss_pull": int(c[0].sum() // W), "miss_push": int(c[1].sum() // W),
                 "update_pull": int(c[2].sum() // W), "update_push": int(c[3].sum() // W),
                 "per_worker": {"miss_pull": c[0].tolist(), "miss_push": c[1].tolist(),
-                               "update_pull": c[2].tolist(), "update_push": c[3].tolist()}}
+                               "update_pull": c[2].tolist(), "update_push": c[3].tolist()},
+                "on_device": int(self._L.ha_laia_on_device(self._h))}
 
     def close(self):
         super().close()

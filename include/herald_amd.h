@@ -965,6 +965,10 @@ int ha_laia_counters(ha_laia *sched, int64_t *out);
  * batch): out[4] = {calls of ha_laia_next*, whole calls us, host greedy assignment us, host snapshot
  * (MiniLRU) bookkeeping us}; the remainder of the total is GPU kernels, transfers and waits. */
 int ha_laia_timing(ha_laia *h, double *out);
+/* 1 = the scheduler state (MiniLRU snapshots as stamp logs, assignment, sorted-unique plan / touched rows) lives on the
+ * device -- LaiaScheduler and TopkScheduler alike, whenever cache_size >= global batch x tables (decided at the first
+ * batch; HA_LAIA_HOST=1 keeps it on the host) --, 0 = host snapshots, -1 = no batch scheduled yet. */
+int ha_laia_on_device(ha_laia *h);
 
 /* Local-shared plan distribution (laia/include/share_mem.h:40-193, ring_buffer.h:13-125): a
  * single-producer / single-consumer ring of uint64 words in POSIX shared memory, message-framed.

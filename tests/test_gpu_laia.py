@@ -73,21 +73,26 @@ def _drain(pop):
             return got
 
 
-@pytest.mark.parametrize("dataset,T,top_k,W,rank,mini_bs,nt", [
-    ("criteo", 26, 20, 4, 1, 32, 4), ("criteo", 26, 0, 8, 6, 16, 16), ("avazu", 18, 17, 2, 0, 30, 5),
-    ("movie", 2, 2, 3, 2, 12, 1), ("criteosearch", 17, 16, 4, 3, 24, 8)])
-def test_topk_stream_and_counters_match_model(dev, dataset, T, top_k, W, rank, mini_bs, nt):
+@pytest.mark.parametrize("dataset,T,top_k,W,rank,mini_bs,nt,cache", [
+    ("criteo", 26, 20, 4, 1, 32, 4, 300), ("criteo", 26, 0, 8, 6, 16, 16, 300), ("avazu", 18, 17, 2, 0, 30, 5, 300),
+    ("movie", 2, 2, 3, 2, 12, 1, 300), ("criteosearch", 17, 16, 4, 3, 24, 8, 300),
+    # caches that hold a global batch of rows: the scheduler state lives on the DEVICE (stamp-log snapshots, one lane per
+    # thread slice assigns, own-sample plans by bitmap compaction)
+    ("criteo", 26, 20, 4, 1, 32, 4, 3400), ("criteo", 26, 0, 8, 6, 16, 16, 3500), ("avazu", 18, 17, 2, 0, 30, 5, 1100),
+    ("criteosearch", 17, 16, 4, 3, 24, 8, 1700)])
+def test_topk_stream_and_counters_match_model(dev, dataset, T, top_k, W, rank, mini_bs, nt, cache):
     samples, key_limit = _samples(1500, T, 9000, seed=W * 7 + T)
-    model = laia_model.TopkSchedulerModel(samples, 2, mini_bs, 5, W, rank, 300, nt, dataset, top_k)
+    model = laia_model.TopkSchedulerModel(samples, 2, mini_bs, 5, W, rank, cache, nt, dataset, top_k)
     want = model.emit()[rank]
     s = hlaia.TopkScheduler()
-    s.start(samples, 1500, T, 2, mini_bs, 5, W, rank, 300, nt, dataset, top_k, key_limit=key_limit)
+    s.start(samples, 1500, T, 2, mini_bs, 5, W, rank, cache, nt, dataset, top_k, key_limit=key_limit)
     got = _drain(s.pop)
     assert len(got) == len(want) == 2 * (5 * 2 + 1) + 1
     for k, (g, w) in enumerate(zip(got, want)):
         assert g == w, "stream element %d differs (%s)" % (k, "plan" if k % 2 == 0 else "dist")
     perf = s.report_cache_perf()
     s.close()
+    assert perf["on_device"] == (1 if cache >= W * mini_bs * T else 0)
     assert perf["per_worker"] == {"miss_pull": model.miss_pull, "miss_push": model.miss_push,
                                   "update_pull": model.update_pull, "update_push": model.update_push}
     # every sample of a batch is assigned exactly once
