@@ -36,13 +36,11 @@
 //   L  16 <= c < 64            one wave per 32-column slice: lane = (occurrence group r of 8, column quad); every lane
 //                              sums lr*g over its occurrences r, r+8, ... in order, the eight partial sums are added as
 //                              a fixed tree, one subtract                                                  (tolerance)
-//   G  c >= 64                 one WORKGROUP (four waves) per 32-column slice: wave w takes occurrences 64w..64w+63 of
-//                              every block of 256 the way an L item takes its run, the four partial sums meet in LDS as
-//                              (w0 + w1) + (w2 + w3), one subtract; all four waves write the destinations    (tolerance)
-// Workgroups are 256 threads -- four items each: the ~6,000 items of a Criteo step spread over the 256 compute units
-// in units of 4 waves (20 or 24 per CU) instead of 16 (16 or 32 per CU: the CUs that got two workgroups were the
-// launch's tail -- a kernel of the step's traffic shape without any bookkeeping takes 12.0 us per launch in 1024-thread
-// workgroups and 10.6 us in 256-thread ones, tools/floor_bench.hip).
+//   G  c >= 64                 one WORKGROUP per 64-column slice: wave w takes occurrences 16w..16w+15 of every block
+//                              of 256, partial sums meet in LDS, fixed tree over the waves, one subtract; all 16 waves
+//                              write the destinations                                                      (tolerance)
+//                              (QV_GOLD = 0, smaller workgroups: the workgroup's waves on a 32-column slice, each an L item
+//                              on its share of every block of occurrences)
 //   Z  key beyond the table    zeros to its destinations (the library's definition of such ids)
 // "tolerance": the reference subtracts lr*g occurrence by occurrence (two roundings each); L and G subtract a
 // deterministic tree sum instead -- within the 1e-5 relative the north star allows for accumulated gradients
@@ -56,14 +54,20 @@
 namespace ha {
 
 constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers + counters = 75 KiB of LDS, two workgroups per CU
-#ifndef QV_COOPSLOTS
-#define QV_COOPSLOTS 256
-#endif
+// Launch geometry.  QV_GOLD = 1 (the product): 1024-thread workgroups, sixteen wave items each; a G item is one WORKGROUP per
+// 64-column slice (sixteen waves x four lane groups).  QV_GOLD = 0 (-DQV_WG=256|512): smaller workgroups, a G item = the
+// workgroup's 4 / 8 waves on a 32-column slice -- a kernel of the step's traffic WITHOUT bookkeeping prefers those (10.6 vs
+// 12.0 us per launch, tools/floor_bench.hip: the items spread evenly over the compute units), the real launch does not: its
+// 2,000 small workgroups take 1.3 us to start instead of 0.6, and same-box A/B has 12.5 us per step for 1024 threads against
+// 12.75 for 512 and 12.9 for 256 (profiles/r04/ab_workgroup_size.txt).
 #ifndef QV_GOLD
-#define QV_GOLD 0       // 1 (with -DQV_WG=1024 -DQV_COOPSLOTS=64): round 3's launch geometry, for same-box timing comparisons
+#define QV_GOLD 1
 #endif
 #ifndef QV_WG
-#define QV_WG 256
+#define QV_WG (QV_GOLD ? 1024 : 256)
+#endif
+#ifndef QV_COOPSLOTS
+#define QV_COOPSLOTS (QV_GOLD ? 64 : 256)
 #endif
 constexpr int kQWg = QV_WG;                    // threads per workgroup of the apply launch
 constexpr int kQWpw = kQWg / 64;               // waves (= wave items) per workgroup
@@ -1047,6 +1051,52 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
     }
 }
 
+// Two S items by ONE wave, rows of at most 128 columns: lanes 0-31 take item A, lanes 32-63 item B (a 512-byte row is
+// 32 lanes of 16 bytes: a wave per item leaves half its lanes idle, and a batch of 106,496 ids of 128-wide rows is ~60,000
+// such items against 8,192 resident waves).  Everything is per lane: the item's words are read through the vector path
+// (one address per half-wave), loads are branch-free (clamped occurrences), stores are predicated.  Same arithmetic as
+// q_small: the serial chain of at most three occurrences.
+__device__ __forceinline__ void q_small_pair(const QArgs &a, const QEntry *ea, const QEntry *eb) {
+    const int lane = lane_id(), hl = lane & 31;
+    const int width = a.width;
+    const QEntry *e = lane < 32 ? ea : eb;
+    const uint4 lo = reinterpret_cast<const uint4 *>(e)[0], hi = reinterpret_cast<const uint4 *>(e)[1];
+    const bool zero = false;       // (S items only)
+    const uint32_t key = lo.y, c = lo.z, m = hi.x, fs = hi.y;
+    const int col = 4 * hl;
+    const bool act = col < width;
+    const int lc = act ? col : 0;
+    float *row = a.table + static_cast<uint64_t>(zero ? 0u : key) * static_cast<uint64_t>(width);
+    float4v r = q_ld_row<float4v>(row + lc);
+    if (zero)
+        r = float4v{0.f, 0.f, 0.f, 0.f};
+    int dv = 0;
+    if (m > 0)
+        dv = a.perm_g[fs + min(static_cast<uint32_t>(hl), m - 1u)];
+    const uint32_t o0 = hi.z & kQOccMask, o1 = ((hi.z >> 21) | (hi.w << 11)) & kQOccMask, o2 = (hi.w >> 10) & kQOccMask;
+    // c == 0 (a copy): nothing is applied; the three loads then re-read the row itself instead of a gradient row
+    const float *gb = c > 0 ? a.grads : a.table;
+    const uint64_t w64 = static_cast<uint64_t>(width);
+    const uint64_t i0 = c > 0 ? o0 : (zero ? 0u : key), i1 = c > 1 ? o1 : i0, i2 = c > 2 ? o2 : i0;
+    const float4v g0 = q_ld_grad<float4v>(gb + i0 * w64 + lc);
+    const float4v g1 = q_ld_grad<float4v>(gb + i1 * w64 + lc);
+    const float4v g2 = q_ld_grad<float4v>(gb + i2 * w64 + lc);
+    const float4v x0 = sgd4(r, g0, a.lr);
+    r = c > 0 ? x0 : r;
+    const float4v x1 = sgd4(r, g1, a.lr);
+    r = c > 1 ? x1 : r;
+    const float4v x2 = sgd4(r, g2, a.lr);
+    r = c > 2 ? x2 : r;
+    if (c > 0 && act)
+        q_st_row(row + col, r);
+#pragma unroll 4
+    for (int j = 0; j < kQSmallM; ++j) {
+        const uint32_t d = static_cast<uint32_t>(__shfl(dv, (lane & 32) + j, 64));
+        if (static_cast<uint32_t>(j) < m && act)
+            q_st_out(a.out + static_cast<uint64_t>(d) * w64 + col, r);
+    }
+}
+
 // M: one 128-column slice, c <= 15 occurrences, 8 bytes per lane, ordered chain
 __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
     const int lane = lane_id();
@@ -1139,7 +1189,7 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     }
 }
 
-#if QV_GOLD   // timing variant: round 3's geometry (1024-thread workgroups, G items = sixteen waves per 64-column slice)
+#if QV_GOLD   // the product's G item: sixteen waves per 64-column slice
 // G: one 64-column slice by a whole workgroup, c >= 64.  lane = (row r of 4, column quad c4 of 16); wave w takes
 // occurrences 16w .. 16w+15 of every block of 256 (four 16-byte loads per lane and block).  s_part = 16 x 64 floats.
 __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float *s_part) {
@@ -1277,7 +1327,8 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
 
 // ---- the three launches ----------------------------------------------------------------------------------------
 // The items of one step: workgroups [0, ncoop) take the G items, the others one wave item per wave.
-static_assert(kQWg == 256 || kQWg == 512 || kQWg == 1024, "workgroups of 4, 8 or 16 waves (the product and its model: 4)");
+static_assert(kQWg == 256 || kQWg == 512 || kQWg == 1024, "workgroups of 4, 8 or 16 waves");
+static_assert(!QV_GOLD || kQWg == 1024, "the sixteen-wave G item needs 1024-thread workgroups");
 __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1321,6 +1372,42 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
         const uint32_t n0 = min(a.qh->n_wave, a.cap_wave), n = n0 + min(a.qh->n_copy, a.cap_copy);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
+        if (a.width <= 128) {
+            // narrow rows: every wave takes a PAIR of consecutive items; two S / Z items share the wave (q_small_pair),
+            // anything else is done one after the other
+            const uint32_t n1 = n - n0, both = 2u * (n0 < n1 ? n0 : n1), npair = (n + 1u) / 2u;
+            for (uint32_t pe = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv; pe < npair; pe += stride) {
+                const QEntry *src[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t e = 2u * pe + static_cast<uint32_t>(h);
+                    src[h] = e >= n ? nullptr
+                                    : e < both ? ((e & 1u) ? a.qcopy + (e >> 1) : a.qwave + (e >> 1))
+                                               : (n0 > n1 ? a.qwave + (e - n1) : a.qcopy + (e - n0));
+                }
+                const uint32_t ka = uniform(src[0]->w[0] & 15u), kb = src[1] ? uniform(src[1]->w[0] & 15u) : 15u;
+                // (Z items -- ids beyond the table -- may have any number of destinations: they keep a wave of their own)
+                const bool sa = ka == static_cast<uint32_t>(kQS), sb = kb == static_cast<uint32_t>(kQS);
+                if (sa && sb) {
+                    q_small_pair(a, src[0], src[1]);
+                    kind = kQS;
+                    continue;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (src[h] == nullptr)
+                        continue;
+                    const QItem it = q_load(src[h], a.width);
+                    kind = it.kind;
+                    if (it.kind == kQL)
+                        q_long(a, it);
+                    else if (it.kind == kQM)
+                        q_medium(a, it);
+                    else
+                        q_small(a, it);
+                }
+            }
+        } else
         for (uint32_t e = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv; e < n; e += stride) {
 #if QV_INTERLEAVE
             // Wave items and copy items ALTERNATE over the launch while both last (then the rest of the longer list):
@@ -1616,8 +1703,10 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     a.n_g = static_cast<int>(n_next);
     a.out = next_out;
     a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
-    if (coop_items >= 0)        // the caller knows the number of workgroup items (wide batches have thousands): one each, <= 2048
-        a.ncoop = static_cast<int>(coop_items < 2048 ? coop_items : 2048);
+    if (coop_items >= 0) {      // the caller knows the number of workgroup items (wide batches have thousands): one workgroup
+        const int64_t most = 4096 / kQWpw;      // each, up to half of the chip's resident waves
+        a.ncoop = static_cast<int>(coop_items < most ? coop_items : most);
+    }
     // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
     const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
     a.nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);

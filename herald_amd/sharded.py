@@ -69,6 +69,7 @@ class HipEngine:
     """Device compute of the sharded store through the C-ABI (libherald_amd)."""
 
     NSLOT = 3   # routing workspaces in rotation: current batch, prefetched batch, one spare
+    RADIX_FROM = 36864   # ids per batch above which the index plan is a radix sort (csrc/plan_dev.h kSmallMax)
 
     def __init__(self, device):
         from . import _lib, ops
@@ -81,6 +82,7 @@ class HipEngine:
         self._slots = {}
         self._owner_plan = None
         self._bufs = {}
+        self._sort_streams = []
 
     def _buf(self, name, rows, width):
         """Grow-only scratch rows that never leave the store (exchange staging)."""
@@ -262,9 +264,28 @@ class HipEngine:
         per-owner counts (device + pinned host) instead of the fixed-frame maps."""
         vp = ctypes.c_void_p
         slots = blk.slots
+        big = [fb for fb in slots if fb.n > self.RADIX_FROM]
+        if len(big) > 1:
+            # Batches beyond the counting sort's reach are radix-sorted: four launches of ~26 workgroups each per batch
+            # -- a latency chain that leaves nine tenths of the chip idle (43 us at 106,496 ids).  The batches of a block
+            # are independent: their sorts go to a few streams side by side and meet again before the key frames are packed.
+            cur = torch.cuda.current_stream(self.device)
+            if not self._sort_streams:
+                self._sort_streams = [torch.cuda.Stream(device=self.device) for _ in range(4)]
+            used = self._sort_streams[:min(4, len(big))]
+            for st_ in used:
+                st_.wait_stream(cur)
+            for i, fb in enumerate(big):
+                fn1 = self.lib.ha_plan_build_f32ids_lim if fb.ids.dtype == torch.float32 else self.lib.ha_plan_build_u64ids_lim
+                st_ = used[i % len(used)]
+                self.check(fn1(fb.ids.data_ptr(), fb.n, fb.plan.ws.data_ptr(), starts[-1], st_.cuda_stream), "ha_plan_build")
+                fb.ids.record_stream(st_)
+            for st_ in used:
+                cur.wait_stream(st_)
+        done = set(id(fb) for fb in big) if len(big) > 1 else set()
         for kind, fn in ((torch.float32, self.lib.ha_plan_build_batch_f32ids_lim),
                          (None, self.lib.ha_plan_build_batch_u64ids_lim)):
-            sel = [fb for fb in slots if fb.n and (fb.ids.dtype == torch.float32) == (kind is not None)]
+            sel = [fb for fb in slots if fb.n and id(fb) not in done and (fb.ids.dtype == torch.float32) == (kind is not None)]
             if sel:
                 cnt = len(sel)
                 self.check(fn((vp * cnt)(*[fb.ids.data_ptr() for fb in sel]), (ctypes.c_int64 * cnt)(*[fb.n for fb in sel]),

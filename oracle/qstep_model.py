@@ -33,7 +33,8 @@ def tree_long(rows_g, lr):
 
 
 def tree_coop4(rows_g, lr):
-    """ha_qstep's workgroup items (c >= 64; csrc/qstep.hip q_coop): FOUR waves x lane group r (8): wave w sums the
+    """The workgroup items of the 256-thread launch geometry (csrc/qstep.hip built with -DQV_GOLD=0 -DQV_WG=256: a timing
+    variant, not the product -- the product's workgroup items are tree_coop below): FOUR waves x lane group r (8): wave w sums the
     occurrences base + 64 w + 8 t + r, t = 0..7, over the blocks of 256 in order; per wave the eight sums meet as
     ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) (an L item's tree); the four waves as (w0+w1) + (w2+w3)."""
     c, width = rows_g.shape
@@ -55,7 +56,8 @@ def tree_coop4(rows_g, lr):
 
 
 def tree_coop(rows_g, lr):
-    """The tolerance mode of the plan-driven applies (csrc/scatter_dev.h coop_slice_tree, c >= 64): wave w (16) x lane
+    """ha_qstep's workgroup items (c >= 64; csrc/qstep.hip q_coop_r3) and the tolerance mode of the plan-driven applies
+    (csrc/scatter_dev.h coop_slice_tree), the same tree: wave w (16) x lane
     group r (4): occurrences base + 16 w + 4 t + r over blocks of 256 in order; per wave
     (p0+p1)+(p2+p3); waves 4q..4q+3 as (a+b)+(c+d); the four quads as (q0+q1)+(q2+q3)."""
     c, width = rows_g.shape
@@ -82,8 +84,8 @@ def sgd_sparse_update(table, ids, grads, lr, long_min=LONG_MIN, coop_min=COOP_MI
     ignored, as by the library).
 
     long_min=None, coop_min=64 restates the library's TOLERANCE MODE (ha_set_tolerance_mode, csrc/scatter_dev.h
-    coop_slice_tree: a sixteen-wave tree of its own from 64 occurrences -- tree_coop; everything shorter is the serial
-    chain); with long_min set the workgroup items are ha_qstep's four-wave tree, tree_coop4.  mode: "sgd" row - sum(lr*g) / chain row -= lr*g;  "push" row + sum(g) (lr is ignored: the
+    coop_slice_tree: the same sixteen-wave tree as ha_qstep's workgroup items, from 64 occurrences; everything shorter is
+    the serial chain).  mode: "sgd" row - sum(lr*g) / chain row -= lr*g;  "push" row + sum(g) (lr is ignored: the
     library reduces from 0 in order, then adds once -- ha_push_apply);  the reduced rows of ha_dedup_reduce_scaled
     are mode="push" on a zero table with grads pre-scaled."""
     ids = np.asarray(ids).reshape(-1).astype(np.int64)
@@ -100,7 +102,7 @@ def sgd_sparse_update(table, ids, grads, lr, long_min=LONG_MIN, coop_min=COOP_MI
         occ = order[s:e]                      # occurrence order (stable sort)
         c = e - s
         if c >= coop_min:
-            t = tree_coop(grads[occ], one) if long_min is None else tree_coop4(grads[occ], one)
+            t = tree_coop(grads[occ], one)
         elif long_min is not None and c >= long_min:
             t = tree_long(grads[occ], one)
         else:

@@ -250,8 +250,8 @@ def test_qstep_criteo_stream_and_queue_shape(dev):
     # queue of the last apply-only call was built from (batch 11, nothing): counts by class
     a = batches[-1]
     u, c = np.unique(a, return_counts=True)
-    per512, per128, per32 = 1, 4, 16
-    want = {"workgroup_items": int((c >= 64).sum()) * per32, "long": int(((c >= 16) & (c < 64)).sum()) * per32,
+    per512, per128, per32, per64 = 1, 4, 16, 8
+    want = {"workgroup_items": int((c >= 64).sum()) * per64, "long": int(((c >= 16) & (c < 64)).sum()) * per32,
             "medium": int(((c > 3) & (c < 16)).sum()) * per128, "small": int((c <= 3).sum()) * per512}
     hdr = pipe.queue_header(len(batches) - 1)
     for k, v in want.items():

@@ -24,7 +24,7 @@ outs = [torch.empty((n, width), device=dev) for _ in range(24)]
 pipe = ops.QueueStepPipeline(table, n, 1e-6, block=BK)
 LA = pipe.LOOKAHEAD
 NBLK = 2304
-WPW = 4      # waves per workgroup of the apply launch
+WPW = int(os.environ.get("WPW", "16"))      # waves per workgroup of the apply launch (16 = the product's geometry)
 dbg = torch.zeros(NBLK * WPW * 4, dtype=torch.int64, device=dev)
 dbgp = torch.zeros(64, dtype=torch.int64, device=dev)
 ids_of = lambda j: ids[j] if 0 <= j < len(ids) else None
@@ -41,7 +41,7 @@ for c in range(-LA, nsteps):
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy()
 ph = dbgp.cpu().numpy()
-nblk = 256 + min(1792, (2 * n) // WPW + 1)
+nblk = (64 if WPW == 16 else 256) + min(448 * 16 // WPW, (2 * n) // WPW + 1)
 for name, off in (("plan workgroup (0 ids 1 claim 2 number 3 label 4 rank 5 scan 6 out 7)", 0),
                   ("queue workgroup 0 = keys of the batch to apply (0 load 1 table 2 count 3 scans 4 emit 5)", 16),
                   ("queue workgroup 1 = copies", 24)):
