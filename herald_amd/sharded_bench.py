@@ -17,13 +17,15 @@ def _world1_same_path(args, rank, dev, emb, ids_dev, grads, n, lr, steps=300, wa
     step), so the step from N=1 to N=2 in a scaling curve is this number + communication, not communication alone.
     Every rank runs it (a GPU each: they stay in lockstep); ids are folded into the shard's row range."""
     from herald_amd.sharded import FramedStep, ShardedEmbedding
-    solo = None
-    for r in range(dist.get_world_size()):          # new_group is a collective: every rank creates every group
-        g = dist.new_group(ranks=[r])
-        if r == rank:
-            solo = g
-    one = ShardedEmbedding(emb.local_rows, emb.width, dev, group=solo, table=emb.table)
-    assert one.world == 1
+    # a store that sees itself alone: no process group is involved (ShardedEmbedding reads world / rank from one)
+    one = ShardedEmbedding.__new__(ShardedEmbedding)
+    one.group, one._a2a_fn, one.max_ids, one.side_stream = None, None, None, False
+    one.world, one.rank = 1, 0
+    one.rows, one.width, one.device = emb.local_rows, emb.width, emb.device
+    one.starts = [0, emb.local_rows]
+    one.local_rows, one.engine, one.table = emb.local_rows, emb.engine, emb.table
+    one.stats = {"xgmi_bytes_out": 0, "xgmi_bytes_in": 0}
+    one._slot, one._live, one.side_group = 0, {}, None
     local = [torch.remainder(t, float(emb.local_rows)) for t in ids_dev[:64]]
     fs = FramedStep(one, n, block=int(__import__("os").environ.get("HA_SHARD_BLOCK", "8")), graphs=False)
     nb, LA = len(local), fs.LOOKAHEAD
@@ -72,7 +74,14 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
     fs = None
     same_path = None
     if framed and world > 1 and per_kernel and os.environ.get("HA_SHARD_NO_WORLD1") != "1":
-        same_path = _world1_same_path(args, rank, dev, emb, ids_dev, grads, n, lr)
+        try:        # a diagnostic: it must never cost the line (every rank takes the same branch: no collective inside)
+            same_path = _world1_same_path(args, rank, dev, emb, ids_dev, grads, n, lr)
+        except Exception as e:      # noqa: BLE001
+            same_path = None
+            if rank == 0:
+                import sys
+                sys.stderr.write("same-path world-1 measurement failed: %s: %s\n" % (type(e).__name__, e))
+        torch.cuda.synchronize()
     if framed:
         # herald_amd.sharded.FramedStep: the routing (plans, key frames, ONE key exchange) runs a block of batches at a
         # time, one block ahead, beside the steps; it leaves the per-owner counts of every batch in pinned host memory, so

@@ -92,3 +92,23 @@ def test_bench_sharded_leg_runs_on_nccl_at_world_size_1(dev):
     c = d["config_c"]
     assert "error" not in c, c
     assert "bs=4096 d=128" in c["config"]["workload"] and c["value"] > 0 and c["config"]["ids_per_step_per_gpu"] == 106496
+
+
+def test_same_path_world1_measurement_runs_on_a_shard(dev):
+    """The diagnostic of bench.py's N>1 line (`same_path_world1_ms_per_step`: the N>1 engine at world size 1 on the rank's
+    own shard) needs no process group: run it on a store of its own here."""
+    import numpy as np
+    import torch
+    from herald_amd import sharded_bench, synth
+    from herald_amd.sharded import ShardedEmbedding
+    rows, width, bs = 300_000, 64, 64
+    emb = ShardedEmbedding(rows, width, dev)
+    emb.table.normal_(0, 0.01)
+    n = bs * 26
+    ids = torch.from_numpy(np.stack([synth.as_f32_ids(synth.criteo_batch(bs, b, rows=4 * rows)).reshape(-1)
+                                     for b in range(64)])).to(dev)          # ids beyond the shard: folded into it
+    grads = [torch.randn((n, width), device=dev) for _ in range(2)]
+    before = emb.table.clone()
+    ms = sharded_bench._world1_same_path(None, 0, dev, emb, ids, grads, n, 1e-3, steps=40, warmup=20)
+    assert 0 < ms < 5.0
+    assert not torch.equal(before, emb.table)           # the steps did push into the shard
