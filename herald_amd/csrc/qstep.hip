@@ -108,9 +108,15 @@ static_assert(sizeof(QEntry) == 32, "queue items are 32 bytes");
 struct QLayout {
     QHeader *hdr;
     QEntry *coop, *wave, *copy;
+    float *part;           // [cap_coop * 64] partial sums of chunked workgroup items (one 64-column slice each)
+    uint32_t *pcnt;        // [cap_coop] chunks of a (key, slice) that have delivered theirs (at the index of its chunk 0)
     uint32_t cap_coop, cap_wave, cap_copy;
     size_t bytes;
 };
+constexpr uint32_t kQChunk = 256;      // occurrences per workgroup item: a key with more is cut into CHUNKS (QV_GOLD)
+__host__ __device__ __forceinline__ uint32_t q_nchunk(uint32_t c) {
+    return (QV_GOLD && c > kQChunk) ? (c + kQChunk - 1u) / kQChunk : 1u;
+}
 static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 // Bounds.  A key with c occurrences in the batch to apply and m in the batch to look up has per512 items (S), per128 <=
 // 4 per512 (M: c >= 4 or m >= 17) or per32 <= 16 per512 (L: c >= 16): never more than per512 * (c + m) -- but NOT
@@ -126,7 +132,10 @@ static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
     q.coop = reinterpret_cast<QEntry *>(b ? b + sizeof(QHeader) : nullptr);
     q.wave = q.coop ? q.coop + q.cap_coop : nullptr;
     q.copy = q.wave ? q.wave + q.cap_wave : nullptr;
-    q.bytes = sizeof(QHeader) + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * sizeof(QEntry);
+    const size_t items = sizeof(QHeader) + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * sizeof(QEntry);
+    q.part = reinterpret_cast<float *>(b ? b + items : nullptr);
+    q.pcnt = reinterpret_cast<uint32_t *>(b ? b + items + static_cast<size_t>(q.cap_coop) * 256 : nullptr);
+    q.bytes = items + static_cast<size_t>(q.cap_coop) * (256 + 4);
     return q;
 }
 
@@ -157,6 +166,8 @@ struct QArgs {
     // workers: queue of this launch, occurrence indices of the batch to apply, destinations of the batch to look up
     const QHeader *qh;
     const QEntry *qcoop, *qwave, *qcopy;
+    float *qpart;              // partial sums of chunked workgroup items (queue_layout)
+    uint32_t *qpcnt;
     uint32_t cap_coop, cap_wave, cap_copy;
     const int32_t *perm_a;
     int n_a;
@@ -519,11 +530,36 @@ __device__ __forceinline__ int q_slice(int kind) {   // columns per item
 }
 
 __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
-                                             uint32_t fs, int width, uint32_t o01, uint32_t o23) {
+                                             uint32_t fs, int width, uint32_t o01, uint32_t o23, uint32_t *pcnt = nullptr) {
     const int slice = q_slice(kind);
     if (kind == kQZ)
         c = 0;    // ids beyond the table are never applied; their destinations get zeros
     int j = 0;
+    const uint32_t nch = kind == kQG ? q_nchunk(c) : 1u;
+    if (nch > 1u) {
+        // a key with more than kQChunk occurrences: per slice `nch` consecutive items, chunk ch = occurrences [256 ch, ..);
+        // whichever of them finishes last adds the partial sums up (in chunk order) and writes the row and the destinations
+        for (int col0 = 0; col0 < width; col0 += slice) {
+            pcnt[j] = 0;
+            for (uint32_t ch = 0; ch < nch; ++ch, ++j) {
+                uint4 lo, hi;
+                lo.x = static_cast<uint32_t>(kind) | (static_cast<uint32_t>(col0 / 4) << 4);
+                lo.y = key;
+                lo.z = c;
+                lo.w = st;
+                hi.x = m;
+                hi.y = fs;
+                hi.z = ch | (nch << 16);
+                hi.w = 0;
+                uint4 *d = reinterpret_cast<uint4 *>(dst + j);
+                d[0] = lo;
+                d[1] = hi;
+            }
+        }
+        return;
+    }
+    if (kind == kQG)
+        o01 = 0;     // (one chunk)
     for (int col0 = 0; col0 < width; col0 += slice, ++j) {
         const int cols = min(slice, width - col0);
         uint4 lo, hi;
@@ -546,8 +582,8 @@ struct QCount {   // items per class: coop (G), long, medium, small (S and Z)
 };
 // (selects on VALUES: an if / else chain over four variables is merged into `*select(&x..) += n`, which puts them --
 // and, through the by-reference captures of a lambda, the whole argument block -- into scratch memory)
-__device__ __forceinline__ QCount q_count(QCount t, int kind, uint32_t per512, uint32_t per128, uint32_t per32) {
-    t.g += kind == kQG ? (QV_GOLD ? (per32 + 1u) / 2u : per32) : 0u;
+__device__ __forceinline__ QCount q_count(QCount t, int kind, uint32_t per512, uint32_t per128, uint32_t per32, uint32_t c) {
+    t.g += kind == kQG ? (QV_GOLD ? (per32 + 1u) / 2u : per32) * q_nchunk(c) : 0u;
     t.l += kind == kQL ? per32 : 0u;
     t.m += kind == kQM ? per128 : 0u;
     t.s += (kind == kQS || kind == kQZ) ? per512 : 0u;
@@ -575,6 +611,7 @@ struct QJoin {      // what every part of the join needs (passed by reference to
     uint32_t *s_tab, *s_bk, *s_cs, *s_w;
     QHeader *bqh;
     QEntry *bcoop, *bwave, *bcopy;
+    uint32_t *bpcnt;                // the queue's chunk counters (they follow the item regions: queue_layout)
     uint32_t bcap_coop, bcap_wave, bcap_copy, per512, per128, per32;
     uint32_t st_base, fs_base;      // wide path: where this bucket's occurrence / destination lists start in the batch's
 };
@@ -600,11 +637,12 @@ __device__ __forceinline__ QCount qjoin_emit_one(const QJoin &j, QCount b, QEntr
     if (kind == kQNone)
         return b;
     const uint32_t at = kind == kQG ? b.g : kind == kQL ? b.l : kind == kQM ? b.m : b.s;
-    const QCount nb = q_count(b, kind, j.per512, j.per128, j.per32);
+    const QCount nb = q_count(b, kind, j.per512, j.per128, j.per32, c);
     const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
     // the layout's bound makes the test always true; never write beyond the queue
     if (at + cnt <= (kind == kQG ? j.bcap_coop : cap_wave))
-        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st + j.st_base, m, fs + j.fs_base, j.width, o01, o2);
+        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st + j.st_base, m, fs + j.fs_base, j.width, o01, o2,
+                     kind == kQG ? j.bpcnt + at : nullptr);
     return nb;
 }
 
@@ -623,7 +661,7 @@ __device__ __forceinline__ QCount qjoin_count_groups(const QJoin &j, QCount t) {
     for (int r = R0; r < R1; ++r) {
         if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ua) {
             const uint32_t mf = qjoin_dest(j, qjoin_probe(j, ka[r - R0]));
-            t = q_count(t, q_kind(c[r - R0], mf & 0xFFFFu, ka[r - R0] < j.rows), j.per512, j.per128, j.per32);
+            t = q_count(t, q_kind(c[r - R0], mf & 0xFFFFu, ka[r - R0] < j.rows), j.per512, j.per128, j.per32, c[r - R0]);
         }
     }
     return t;
@@ -666,7 +704,7 @@ __device__ __forceinline__ QCount qjoin_count_copies(const QJoin &j, QCount t) {
 #pragma unroll
     for (int r = R0; r < R1; ++r)
         if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
-            t = q_count(t, q_kind(0u, m[r - R0], kg[r - R0] < j.rows), j.per512, j.per128, j.per32);
+            t = q_count(t, q_kind(0u, m[r - R0], kg[r - R0] < j.rows), j.per512, j.per128, j.per32, 0u);
     return t;
 }
 template <int R0, int R1>
@@ -722,6 +760,9 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     j.bwave = bwave;
     j.bcopy = bcopy;
     j.bcap_coop = bcap_coop;
+    // (the regions are contiguous: coop | wave | copy | partial sums | chunk counters)
+    j.bpcnt = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(bcoop + (static_cast<size_t>(bcap_coop) + bcap_wave + bcap_copy)) +
+                                           static_cast<size_t>(bcap_coop) * 256);
     j.bcap_wave = bcap_wave;
     j.bcap_copy = bcap_copy;
     j.per512 = (width + 511) / 512;
@@ -1192,25 +1233,28 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
 #if QV_GOLD   // the product's G item: sixteen waves per 64-column slice
 // G: one 64-column slice by a whole workgroup, c >= 64.  lane = (row r of 4, column quad c4 of 16); wave w takes
 // occurrences 16w .. 16w+15 of every block of 256 (four 16-byte loads per lane and block).  s_part = 16 x 64 floats.
-__device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float *s_part) {
+__device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float *s_part, uint32_t e) {
     const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int width = a.width;
     const int r = lane >> 4, c4 = lane & 15;
     const bool act = 4 * c4 < it.cols;
     const int col = it.col0 + (act ? 4 * c4 : 0);
     float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
-    const float4v cur = q_ld_row<float4v>(row + col);
+    // a key with more than kQChunk occurrences arrives as `nch` items per slice: this one sums chunk `ch`
+    const uint32_t ch = it.o01 & 0xFFFFu, nch = it.o01 >> 16;
+    const uint32_t c_lo = kQChunk * ch, c_hi = nch > 1u ? min(it.c, c_lo + kQChunk) : it.c;
+    float4v cur = q_ld_row<float4v>(row + col);
     // destinations of this wave: j = 64 * k + 4 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 2, l & 3):
     // one register covers the first 16 rounds (1,024 destinations)
     int dv = 0;
     if (it.m > 0)
         dv = a.perm_g[it.fs + min(static_cast<uint32_t>(64 * (lane >> 2) + 4 * w + (lane & 3)), it.m - 1u)];
     float4v p{0.f, 0.f, 0.f, 0.f};
-    for (uint32_t base = 0; base < it.c; base += 256) {
+    for (uint32_t base = c_lo; base < c_hi; base += 256) {
         const uint32_t mine = base + 16u * static_cast<uint32_t>(w);   // this wave's first occurrence of the block
-        if (mine >= it.c)
+        if (mine >= c_hi)
             break;   // wave-uniform; no barrier inside the loop
-        const int pidx = a.perm_a[it.st + min(mine + static_cast<uint32_t>(lane & 15), it.c - 1u)];
+        const int pidx = a.perm_a[it.st + min(mine + static_cast<uint32_t>(lane & 15), c_hi - 1u)];
         float4v g[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1220,7 +1264,7 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float4v q = acc4(p, g[t], a.lr);
-            const bool valid = mine + static_cast<uint32_t>(4 * t + r) < it.c;
+            const bool valid = mine + static_cast<uint32_t>(4 * t + r) < c_hi;
             p = valid ? q : p;
         }
     }
@@ -1237,6 +1281,31 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
                          add4(*reinterpret_cast<const float4v *>(sp + 128), *reinterpret_cast<const float4v *>(sp + 192)));
     total = add4(total, shfl_xor4(total, 16));
     total = add4(total, shfl_xor4(total, 32));
+    if (nch > 1u) {
+        // deliver this chunk's sum (device-coherent stores, drained, then the counter of the slice -- the hand-off rules of
+        // step.hip); whoever delivers last adds all of them up in chunk order.  Nobody waits for anybody.
+        const uint32_t first = e - ch;
+        if (w == 0 && r == 0)
+            st4_sc1(a.qpart + static_cast<size_t>(e) * 64 + 4 * c4, total);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_part);     // (the partial sums in LDS have been consumed)
+        if (threadIdx.x == 0)
+            *s_flag = __hip_atomic_fetch_add(a.qpcnt + first, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const bool last = *s_flag + 1u == nch;
+        __syncthreads();
+        if (!last)
+            return;
+        float4v tot = ld4_sc1_async(a.qpart + static_cast<size_t>(first) * 64 + 4 * c4), nx = tot, d0 = tot, d1 = tot;
+        wait_loads(tot, nx, d0, d1);
+        for (uint32_t jc = 1; jc < nch; ++jc) {
+            nx = ld4_sc1_async(a.qpart + static_cast<size_t>(first + jc) * 64 + 4 * c4);
+            wait_loads(nx, tot, d0, d1);
+            tot = add4(tot, nx);
+        }
+        total = tot;
+    }
     const float4v nv = sub4(cur, total);
     if (w == 0 && r == 0 && act)
         q_st_row(row + col, nv);
@@ -1360,7 +1429,7 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
         for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
             const QItem it = q_load(a.qcoop + e, a.width);
 #if QV_GOLD
-            q_coop_r3(a, it, reinterpret_cast<float *>(s_dyn));
+            q_coop_r3(a, it, reinterpret_cast<float *>(s_dyn), e);
 #else
             q_coop(a, it, reinterpret_cast<float *>(s_dyn));
 #endif
@@ -1693,6 +1762,8 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     a.qcoop = q.coop;
     a.qwave = q.wave;
     a.qcopy = q.copy;
+    a.qpart = q.part;
+    a.qpcnt = q.pcnt;
     a.cap_coop = q.cap_coop;
     a.cap_wave = q.cap_wave;
     a.cap_copy = q.cap_copy;

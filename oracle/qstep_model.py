@@ -79,13 +79,30 @@ def tree_coop(rows_g, lr):
     return (((quad[0] + quad[1]).astype(F)) + ((quad[2] + quad[3]).astype(F))).astype(F)
 
 
+CHUNK = 256      # kQChunk of qstep.hip
+
+
+def tree_coop_chunked(rows_g, lr):
+    """ha_qstep's workgroup items: a key with more than 256 occurrences is cut into chunks of 256 (csrc/qstep.hip q_emit_words /
+    q_coop_r3); every chunk is summed by a workgroup of its own with the tree above, and the chunk sums are added up in chunk
+    order by whichever workgroup finishes last: ((p0 + p1) + p2) + ..."""
+    c = rows_g.shape[0]
+    if c <= CHUNK:
+        return tree_coop(rows_g, lr)
+    tot = None
+    for lo in range(0, c, CHUNK):
+        p = tree_coop(rows_g[lo:lo + CHUNK], lr)
+        tot = p if tot is None else (tot + p).astype(F)
+    return tot
+
+
 def sgd_sparse_update(table, ids, grads, lr, long_min=LONG_MIN, coop_min=COOP_MIN, mode="sgd"):
     """In place: table after one ha_qstep apply of (ids, grads).  ids: integer array (keys beyond the table are
     ignored, as by the library).
 
     long_min=None, coop_min=64 restates the library's TOLERANCE MODE (ha_set_tolerance_mode, csrc/scatter_dev.h
-    coop_slice_tree: the same sixteen-wave tree as ha_qstep's workgroup items, from 64 occurrences; everything shorter is
-    the serial chain).  mode: "sgd" row - sum(lr*g) / chain row -= lr*g;  "push" row + sum(g) (lr is ignored: the
+    coop_slice_tree: the same sixteen-wave tree as ha_qstep's workgroup items, from 64 occurrences -- over the WHOLE run,
+    where ha_qstep cuts runs beyond 256 occurrences into chunks --; everything shorter is the serial chain).  mode: "sgd" row - sum(lr*g) / chain row -= lr*g;  "push" row + sum(g) (lr is ignored: the
     library reduces from 0 in order, then adds once -- ha_push_apply);  the reduced rows of ha_dedup_reduce_scaled
     are mode="push" on a zero table with grads pre-scaled."""
     ids = np.asarray(ids).reshape(-1).astype(np.int64)
@@ -102,7 +119,8 @@ def sgd_sparse_update(table, ids, grads, lr, long_min=LONG_MIN, coop_min=COOP_MI
         occ = order[s:e]                      # occurrence order (stable sort)
         c = e - s
         if c >= coop_min:
-            t = tree_coop(grads[occ], one)
+            # (the tolerance mode of the plan-driven applies -- long_min None -- keeps one tree for the whole run)
+            t = tree_coop(grads[occ], one) if long_min is None else tree_coop_chunked(grads[occ], one)
         elif long_min is not None and c >= long_min:
             t = tree_long(grads[occ], one)
         else:
