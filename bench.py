@@ -419,7 +419,13 @@ def main():
     grads = [torch.randn((n, args.width), dtype=torch.float32, device=dev, generator=gen) for _ in range(nbuf)]
     outs = [torch.empty((n, args.width), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     nb = ids_dev.shape[0]
-    main_s = torch.cuda.Stream(device=dev)
+    main_prio = 0
+    if os.environ.get("HA_BENCH_MAIN_PRIO") == "high":
+        try:
+            main_prio = min(torch.cuda.Stream.priority_range())
+        except Exception:      # noqa: BLE001
+            main_prio = 0
+    main_s = torch.cuda.Stream(device=dev, priority=main_prio)
     before_chunk = None
     if ahead2:
         # One step = ONE launch (ha_step_f32ids): SGD apply of batch k, the rows of batch k+1 (forwarded from

@@ -529,6 +529,13 @@ __device__ __forceinline__ int q_slice(int kind) {   // columns per item
     return kind == kQL ? 32 : kind == kQG ? (QV_GOLD ? 64 : 32) : kind == kQM ? 128 : 512;
 }
 
+__device__ __forceinline__ void q_st_item(QEntry *dst, uint4 lo, uint4 hi) {
+    float4v a, b;
+    __builtin_memcpy(&a, &lo, 16);
+    __builtin_memcpy(&b, &hi, 16);
+    st4_sc1(reinterpret_cast<float *>(dst), a);
+    st4_sc1(reinterpret_cast<float *>(dst) + 4, b);
+}
 __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key, uint32_t c, uint32_t st, uint32_t m,
                                              uint32_t fs, int width, uint32_t o01, uint32_t o23, uint32_t *pcnt = nullptr) {
     const int slice = q_slice(kind);
@@ -540,7 +547,7 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
         // a key with more than kQChunk occurrences: per slice `nch` consecutive items, chunk ch = occurrences [256 ch, ..);
         // whichever of them finishes last adds the partial sums up (in chunk order) and writes the row and the destinations
         for (int col0 = 0; col0 < width; col0 += slice) {
-            pcnt[j] = 0;
+            __hip_atomic_store(pcnt + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (uint32_t ch = 0; ch < nch; ++ch, ++j) {
                 uint4 lo, hi;
                 lo.x = static_cast<uint32_t>(kind) | (static_cast<uint32_t>(col0 / 4) << 4);
@@ -551,9 +558,7 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
                 hi.y = fs;
                 hi.z = ch | (nch << 16);
                 hi.w = 0;
-                uint4 *d = reinterpret_cast<uint4 *>(dst + j);
-                d[0] = lo;
-                d[1] = hi;
+                q_st_item(dst + j, lo, hi);
             }
         }
         return;
@@ -577,6 +582,10 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
         d[1] = hi;
     }
 }
+// (helper below) an item's two 16-byte halves, written THROUGH the L2 (`sc1`): once the writing thread's `s_waitcnt
+// vmcnt(0)` has passed they are in memory, so the builder can publish "this queue is complete" with a relaxed device-scope
+// atomic instead of a release fence -- an agent-scope release writes back all the dirty lines of the XCD's L2, per
+// workgroup, and the wide path has 2 x 128 builder workgroups per step
 struct QCount {   // items per class: coop (G), long, medium, small (S and Z)
     uint32_t g, l, m, s;
 };
@@ -905,14 +914,22 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     // the queue is complete once every builder workgroup has passed this point: items visible device-wide (release), then
     // the epoch words -- by this part for its own region (narrow path: two workgroups per step), or by whichever of the
     // step's `wide_parts` bucket workgroups finishes last
+    __builtin_amdgcn_s_waitcnt(0);      // this thread's items (write-through stores) are in memory
     __syncthreads();
     if (tid == 0) {
-        __threadfence();
         if (!WIDE) {
-            __hip_atomic_store(part == 0 ? &bqh->epoch_wave : &bqh->epoch_copy, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (atomicAdd(&bqh->done, 1u) + 1u == wide_parts) {
-            __hip_atomic_store(&bqh->epoch_wave, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&bqh->epoch_copy, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // the counts this part wrote above, through the L2 as well (device-scope atomic stores), then the tag
+            if (part == 0) {
+                __hip_atomic_store(&bqh->n_wave, bqh->n_wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&bqh->n_coop, bqh->n_coop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(&bqh->n_copy, bqh->n_copy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_store(part == 0 ? &bqh->epoch_wave : &bqh->epoch_copy, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (__hip_atomic_fetch_add(&bqh->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == wide_parts) {
+            __hip_atomic_store(&bqh->epoch_wave, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&bqh->epoch_copy, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mirror) {       // every bucket has added its items: the counts are final (+ 1: 0 = not built yet)
                 const uint32_t nw = __hip_atomic_load(&bqh->n_wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t nc = __hip_atomic_load(&bqh->n_coop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1290,19 +1307,26 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_part);     // (the partial sums in LDS have been consumed)
-        if (threadIdx.x == 0)
-            *s_flag = __hip_atomic_fetch_add(a.qpcnt + first, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0)      // (relaxed: the sum went through the L2 and was drained; a release would write the whole L2 back)
+            *s_flag = __hip_atomic_fetch_add(a.qpcnt + first, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const bool last = *s_flag + 1u == nch;
         __syncthreads();
         if (!last)
             return;
-        float4v tot = ld4_sc1_async(a.qpart + static_cast<size_t>(first) * 64 + 4 * c4), nx = tot, d0 = tot, d1 = tot;
-        wait_loads(tot, nx, d0, d1);
-        for (uint32_t jc = 1; jc < nch; ++jc) {
-            nx = ld4_sc1_async(a.qpart + static_cast<size_t>(first + jc) * 64 + 4 * c4);
-            wait_loads(nx, tot, d0, d1);
-            tot = add4(tot, nx);
+        // the chunk sums, four loads in flight at a time, added in chunk order
+        const float *pp = a.qpart + static_cast<size_t>(first) * 64 + 4 * c4;
+        float4v tot{0.f, 0.f, 0.f, 0.f};
+        for (uint32_t j0 = 0; j0 < nch; j0 += 4) {
+            float4v q0 = ld4_sc1_async(pp + static_cast<size_t>(min(j0, nch - 1u)) * 64);
+            float4v q1 = ld4_sc1_async(pp + static_cast<size_t>(min(j0 + 1u, nch - 1u)) * 64);
+            float4v q2 = ld4_sc1_async(pp + static_cast<size_t>(min(j0 + 2u, nch - 1u)) * 64);
+            float4v q3 = ld4_sc1_async(pp + static_cast<size_t>(min(j0 + 3u, nch - 1u)) * 64);
+            wait_loads(q0, q1, q2, q3);
+            tot = j0 == 0 ? q0 : add4(tot, q0);
+            if (j0 + 1u < nch) tot = add4(tot, q1);
+            if (j0 + 2u < nch) tot = add4(tot, q2);
+            if (j0 + 3u < nch) tot = add4(tot, q3);
         }
         total = tot;
     }

@@ -825,7 +825,15 @@ class QueueStepPipeline:
         self.plans = [(WidePlan if self.wide else IndexPlan)(self.capacity, self.device) for _ in range(self.NPLAN)]
         self.queue_bytes = int(L.ha_qstep_queue_bytes(self.capacity, table.shape[1]))
         self.queues = torch.zeros(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
-        self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
+        # the preparation runs beside the steps: its stream may be given the LOWEST priority (HA_QSIDE_PRIO=low), so that the
+        # apply launches win the dispatcher whenever both have workgroups to place
+        side_prio = 0
+        if os.environ.get("HA_QSIDE_PRIO") == "low":
+            try:
+                side_prio = max(torch.cuda.Stream.priority_range())
+            except Exception:      # noqa: BLE001
+                side_prio = 0
+        self.side = torch.cuda.Stream(device=self.device, priority=side_prio) if self.overlap else None
         # {wave items, workgroup items, copy items} (+ 1; 0 = not built yet) of the queue of step c, written to pinned host
         # memory by the launch that builds it, in a ring long enough that a build still in flight cannot write into the
         # slot of a later step: queues are built a block ahead, so the host usually knows the numbers when it enqueues
