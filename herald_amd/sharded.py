@@ -213,7 +213,7 @@ class HipEngine:
         blk = FrameBlock()
         blk.ksend = torch.empty((w, block, 2 + rcap), dtype=torch.int32, device=self.device)
         blk.krecv = torch.empty((w, block, 2 + rcap), dtype=torch.int32, device=self.device)
-        blk.kgot, blk.ev, blk.live, blk.synced = None, None, False, False
+        blk.kgot, blk.ev, blk.live, blk.synced, blk.carrays = None, None, False, False, None
         blk.slots = []
         for i in range(block):
             fb = FrameBuffers()
@@ -296,13 +296,19 @@ class HipEngine:
             fb.plan._view = None
         cnt = len(slots)
         fb0 = slots[0]
-        st = (ctypes.c_int64 * len(starts))(*starts)
-        plans = (vp * cnt)(*[fb.plan.ws.data_ptr() for fb in slots])
-        ns = (ctypes.c_int64 * cnt)(*[fb.n for fb in slots])
-        rowmaps = (vp * cnt)(*[fb.rowmap.data_ptr() for fb in slots])
-        posmaps = (vp * cnt)(*[fb.posmap.data_ptr() for fb in slots])
-        keysf = (vp * cnt)(*[fb.keys_fixed.data_ptr() for fb in slots])
-        hosts = (vp * cnt)(*[fb.state_host.data_ptr() for fb in slots])
+        c = blk.carrays            # the addresses of a block's buffers never change: converted once
+        if c is None or c[0] != tuple(starts):
+            c = blk.carrays = (tuple(starts), (ctypes.c_int64 * len(starts))(*starts),
+                               (vp * cnt)(*[fb.plan.ws.data_ptr() for fb in slots]),
+                               (vp * cnt)(*[fb.rowmap.data_ptr() for fb in slots]),
+                               (vp * cnt)(*[fb.posmap.data_ptr() for fb in slots]),
+                               (vp * cnt)(*[fb.keys_fixed.data_ptr() for fb in slots]),
+                               (vp * cnt)(*[fb.state_host.data_ptr() for fb in slots]),
+                               (vp * cnt)(*[fb.meta_dev.data_ptr() for fb in slots]),
+                               (ctypes.c_int64 * cnt)())
+        _, st, plans, rowmaps, posmaps, keysf, hosts, metas, ns = c
+        for i, fb in enumerate(slots):
+            ns[i] = fb.n
         if sized_rank is None:
             self.check(self.lib.ha_shard_frames_pack_batch(plans, ns, cnt, st, fb0.w, fb0.rcap, fb0.stride,
                                                            blk.ksend.data_ptr(), rowmaps, posmaps, self._stream()),
@@ -311,7 +317,6 @@ class HipEngine:
             self.check(self.lib.ha_shard_frames_unpack_batch(blk.kgot.data_ptr(), cnt, fb0.w, fb0.rcap, fb0.stride, keysf,
                                                              hosts, self._stream()), "ha_shard_frames_unpack_batch")
             return
-        metas = (vp * cnt)(*[fb.meta_dev.data_ptr() for fb in slots])
         self.check(self.lib.ha_shard_frames_pack_batch_sized(plans, ns, cnt, st, fb0.w, int(sized_rank), fb0.rcap, fb0.stride,
                                                              blk.ksend.data_ptr(), rowmaps, posmaps, metas, hosts,
                                                              self._stream()), "ha_shard_frames_pack_batch_sized")
@@ -483,12 +488,12 @@ class HipEngine:
 
 class FrameBlock:
     """Key frames of one routing block of a FramedStep (see HipEngine.frames_block)."""
-    __slots__ = ("ksend", "krecv", "kgot", "ev", "live", "slots", "synced")
+    __slots__ = ("ksend", "krecv", "kgot", "ev", "live", "slots", "synced", "carrays")
 
 
 class FrameBuffers:
     """Per-batch buffers inside a FrameBlock."""
-    __slots__ = ("i", "w", "rcap", "stride", "plan", "keys_fixed", "rowmap", "posmap", "state_host", "state_c", "meta_dev",
+    __slots__ = ("i", "w", "rcap", "stride", "plan", "keys_fixed", "rowmap", "posmap", "state_host", "state_c", "meta_dev", "out_shape",
                  "ids", "n", "shape", "routed", "send_cnt", "recv_cnt", "pos_local")
 
 
@@ -791,6 +796,7 @@ class FramedStep:
         self._fast_ok = hasattr(self.eng, "frames_serve_pull_call")
         self.k = None
         self.fallbacks = 0
+        self._ring = 3 * self.block
         self._slot_of = [(self.blocks[(j // self.block) % 3], self.blocks[(j // self.block) % 3].slots[j % self.block])
                          for j in range(3 * self.block)]
         emb._frame(self.max_ids)     # the sized path (overflowed batches) agrees on its frame now, on every rank
@@ -804,21 +810,24 @@ class FramedStep:
         return out
 
     def _fb(self, j):
-        s = self._slot_of[j % (3 * self.block)]
-        return s
+        return self._slot_of[j % self._ring]
 
     def _stage(self, j, ids):
         """Batch j enters the pipeline.  ids = None: the stream of batches has ended (on every rank); an EMPTY tensor is
         a batch in which this rank names nothing -- it still takes part in the exchanges."""
         _, fb = self._fb(j)
         if ids is None:
-            fb.n, fb.ids, fb.shape, fb.routed = 0, None, (0,), False
+            fb.n, fb.ids, fb.shape, fb.routed, fb.out_shape = 0, None, (0,), False, (0, self.emb.width)
             return
-        if ids.numel() > self.max_ids:
-            raise ValueError("a batch of %d ids exceeds max_ids = %d of this FramedStep" % (ids.numel(), self.max_ids))
-        if ids.dtype not in (torch.float32, torch.int64, torch.uint64):
+        n = ids.numel()
+        if n > self.max_ids:
+            raise ValueError("a batch of %d ids exceeds max_ids = %d of this FramedStep" % (n, self.max_ids))
+        dt = ids.dtype
+        if dt is not torch.float32 and dt is not torch.int64 and dt is not torch.uint64:
             raise TypeError("ids must be float32 or (u)int64")
-        fb.ids, fb.n, fb.shape, fb.routed = (ids if ids.dim() == 1 else ids.reshape(-1)), ids.numel(), tuple(ids.shape), True
+        shape = tuple(ids.shape)
+        fb.ids, fb.n, fb.shape, fb.routed = (ids if len(shape) == 1 else ids.reshape(-1)), n, shape, True
+        fb.out_shape = shape + (self.emb.width,)
 
     def _route_block(self, b):
         """Enqueue the routing of block b: plans and key frames of its batches, one key exchange, received keys."""
@@ -881,15 +890,23 @@ class FramedStep:
         return fb.send_cnt, fb.recv_cnt
 
     def _pull_sized(self, j, out, stream_key):
-        blk, fb = self._fb(j)
+        blk, fb = self._slot_of[j % self._ring]
         eng, emb = self.eng, self.emb
         w, r = emb.world, emb.rank
+        if w == 1 and self._fast_ok:       # the whole pull is one launch; its arguments are converted once per buffer set
+            if fb.n:
+                key = ("sexp", j % self._ring, fb.n, out.data_ptr(), stream_key)
+                c = self._calls.get(key)
+                if c is None:
+                    c = self._fast(key, lambda: eng.sized_expand_call(emb.table, self.pull_recv, fb, out))
+                c()
+            return
         if w > 1:
             send_cnt, recv_cnt = self._counts(fb)
             ins = [c if g != r else 0 for g, c in enumerate(recv_cnt)]     # rows this rank serves to peer g
             outs = [c if g != r else 0 for g, c in enumerate(send_cnt)]    # rows owner g sends back
             if self._fast_ok:
-                self._fast(("spull", j % (3 * self.block), stream_key),
+                self._fast(("spull", j % self._ring, stream_key),
                            lambda: eng.sized_serve_pull_call(emb.table, fb, r, self.pull_send))()
             else:
                 eng.sized_serve_pull(emb.table, fb, r, self.pull_send)
@@ -897,28 +914,30 @@ class FramedStep:
             self._account_sized(ins, outs, send_cnt, recv_cnt)
         if fb.n:
             if self._fast_ok:
-                self._fast(("sexp", j % (3 * self.block), fb.n, out.data_ptr(), stream_key),
+                self._fast(("sexp", j % self._ring, fb.n, out.data_ptr(), stream_key),
                            lambda: eng.sized_expand_call(emb.table, self.pull_recv, fb, out))()
             else:
                 eng.sized_expand(emb.table, self.pull_recv, fb, out)
 
     def _push_sized(self, j, values, scale, stream_key):
-        _, fb = self._fb(j)
+        _, fb = self._slot_of[j % self._ring]
         eng, emb = self.eng, self.emb
         w, r = emb.world, emb.rank
-        if w > 1:
-            send_cnt, recv_cnt = self._counts(fb)
         if w == 1:          # nobody else pushes: reduce + server add of the own keys in one launch
             if fb.n:
                 if self._fast_ok:
-                    self._fast(("salone", j % (3 * self.block), fb.n, values.data_ptr(), scale, stream_key),
-                               lambda: eng.sized_push_alone_call(emb.table, fb, values, scale))()
+                    key = ("salone", j % self._ring, fb.n, values.data_ptr(), scale, stream_key)
+                    c = self._calls.get(key)
+                    if c is None:
+                        c = self._fast(key, lambda: eng.sized_push_alone_call(emb.table, fb, values, scale))
+                    c()
                 else:
                     eng.sized_push_alone(emb.table, fb, values, scale)
             return
+        send_cnt, recv_cnt = self._counts(fb)
         if fb.n:
             if self._fast_ok:
-                self._fast(("sred", j % (3 * self.block), fb.n, values.data_ptr(), scale, stream_key),
+                self._fast(("sred", j % self._ring, fb.n, values.data_ptr(), scale, stream_key),
                            lambda: eng.sized_reduce_call(fb, values, scale, self.push_buf, self.zero_flags))()
             else:
                 eng.sized_reduce(fb, values, scale, self.push_buf, self.zero_flags)
@@ -959,7 +978,7 @@ class FramedStep:
         blk, fb = self._fb(j)
         eng, emb = self.eng, self.emb
         rows_in = self.pull_send if emb.world == 1 else self.pull_recv
-        a, b = self._fast(("pull", j % (3 * self.block), fb.n, out.data_ptr() if fb.n else 0, blk.kgot.data_ptr(), stream_key),
+        a, b = self._fast(("pull", j % self._ring, fb.n, out.data_ptr() if fb.n else 0, blk.kgot.data_ptr(), stream_key),
                           lambda: (eng.frames_serve_pull_call(emb.table, blk, fb, self.pull_send),
                                    eng.frames_expand_call(rows_in, fb, out) if fb.n else None))
         a()
@@ -971,7 +990,7 @@ class FramedStep:
         _, fb = self._fb(j)
         eng, emb = self.eng, self.emb
         rows_in = self.push_send if emb.world == 1 else self.push_recv
-        a, b = self._fast(("push", j % (3 * self.block), fb.n, values.data_ptr() if fb.n else 0, scale, stream_key),
+        a, b = self._fast(("push", j % self._ring, fb.n, values.data_ptr() if fb.n else 0, scale, stream_key),
                           lambda: (eng.frames_reduce_call(fb, values, scale, self.push_send, self.zero_flags) if fb.n else None,
                                    eng.frames_serve_push_call(emb.table, fb, rows_in)))
         if a is not None:
@@ -1041,17 +1060,20 @@ class FramedStep:
         if self._pending:
             raise RuntimeError("FramedStep: pull and push alternate (push the current batch first)")
         k = self.k
-        blk, fb = self._fb(k)
+        blk, fb = self._slot_of[k % self._ring]
         if not fb.routed:
             raise RuntimeError("FramedStep.pull: the stream of batches has ended")
         if k % self.block == 0:
             self._block_start(k // self.block)
         self._stage(k + self.LOOKAHEAD, ahead_ids)
-        self._over = self._overflowed(k)
+        if not blk.synced:          # the pinned words of the block's routing (enqueued a block ago)
+            self.eng.host_sync(blk.ev)
+            blk.synced = True
+        self._over = over = self.eng.frames_overflowed(fb)
         width = self.emb.width
         if fb.n and out is None:
             out = self.eng.empty_rows(fb.n, width)
-        if self._over:
+        if over:
             # sized exchange for this batch only (a collective: every rank saw the flag)
             self.fallbacks += 1
             self._sized = self.emb.prefetch(fb.ids)
@@ -1064,32 +1086,33 @@ class FramedStep:
             if self._fast_ok and not self.graphs:
                 self._pull_fast(k, out, self.eng._stream())
             else:
-                self._run(("pull", k % (3 * self.block), fb.n, out.data_ptr() if fb.n else 0), lambda: self._pull(k, out))
+                self._run(("pull", k % self._ring, fb.n, out.data_ptr() if fb.n else 0), lambda: self._pull(k, out))
             self._account()
         self._pending = True
         if not fb.n:
             return None
-        return out if out.dim() == len(fb.shape) + 1 and tuple(out.shape[:-1]) == fb.shape else out.reshape(fb.shape + (width,))
+        return out if out.shape == fb.out_shape else out.reshape(fb.out_shape)
 
     def push(self, values, lr=None):
         """Apply the gradients `values` of the current batch on its owners (scale -lr; 1 if lr is None)."""
         if not self._pending:
             raise RuntimeError("FramedStep: pull and push alternate (pull the current batch first)")
         k = self.k
-        _, fb = self._fb(k)
+        _, fb = self._slot_of[k % self._ring]
         scale = 1.0 if lr is None else -float(lr)
         if self._over:
             self.emb.push(None, values, lr, route=self._sized)
             self._sized = None
-        elif self.sized:
-            self._push_sized(k, values.reshape(-1, self.emb.width) if fb.n else None, scale,
-                             self.eng._stream() if self._fast_ok else 0)
         else:
-            v = values.reshape(-1, self.emb.width) if fb.n else None
-            if self._fast_ok and not self.graphs:
+            v = None
+            if fb.n:        # the launches read `values` as [n, width] rows
+                v = values if values.dim() == 2 and values.is_contiguous() else values.reshape(-1, self.emb.width).contiguous()
+            if self.sized:
+                self._push_sized(k, v, scale, self.eng._stream() if self._fast_ok else 0)
+            elif self._fast_ok and not self.graphs:
                 self._push_fast(k, v, scale, self.eng._stream())
             else:
-                self._run(("push", k % (3 * self.block), fb.n, v.data_ptr() if fb.n else 0, scale),
+                self._run(("push", k % self._ring, fb.n, v.data_ptr() if fb.n else 0, scale),
                           lambda: self._push(k, v, scale))
         self._pending = False
         self.k = k + 1
