@@ -825,12 +825,13 @@ class QueueStepPipeline:
         self.plans = [(WidePlan if self.wide else IndexPlan)(self.capacity, self.device) for _ in range(self.NPLAN)]
         self.queue_bytes = int(L.ha_qstep_queue_bytes(self.capacity, table.shape[1]))
         self.queues = torch.zeros(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
-        # the preparation runs beside the steps: its stream may be given the LOWEST priority (HA_QSIDE_PRIO=low), so that the
+        # the preparation runs beside the steps: its stream may be given the LOWEST priority (HA_QSIDE_PRIO=low; =high: the highest -- A/B knobs), so that the
         # apply launches win the dispatcher whenever both have workgroups to place
         side_prio = 0
-        if os.environ.get("HA_QSIDE_PRIO") == "low":
+        if os.environ.get("HA_QSIDE_PRIO") in ("low", "high"):
             try:
-                side_prio = max(torch.cuda.Stream.priority_range())
+                lo_hi = torch.cuda.Stream.priority_range()
+                side_prio = max(lo_hi) if os.environ["HA_QSIDE_PRIO"] == "low" else min(lo_hi)
             except Exception:      # noqa: BLE001
                 side_prio = 0
         self.side = torch.cuda.Stream(device=self.device, priority=side_prio) if self.overlap else None
