@@ -230,8 +230,10 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
             prefilled += n
         torch.cuda.synchronize()
 
-    def step(k):
+    def step(k, ahead=True):
         c.embedding_lookup(ids_dev[k % nb], out)
+        if ahead:       # the loader has the next batch's ids: their sort runs beside this batch's update
+            c.prefetch_keys(ids_dev[(k + 1) % nb])
         c.embedding_update(ids_dev[k % nb], grad, same_as_lookup=True)
 
     # the ten launches of a lookup + update pair are replayed from hipGraphs of 16 pairs (the calls enqueue
@@ -247,7 +249,7 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
             for k in range(g0, g0 + GS):
-                step(k)
+                step(k, ahead=k + 1 < g0 + GS)      # (a fork must join inside its graph)
         graphs.append(g)
     torch.cuda.synchronize()
     steps = 256
@@ -275,7 +277,7 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
             "evicted_lines_per_step": evict, "cache_full": bool(pulls and pulls[-1]["is_full"]),
             "prefilled_keys": prefilled,
             "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
-                    "(5 launches per pair, replayed from hipGraphs of 16 pairs), cache filled to its limit before "
+                    "(5 launches per pair, the next batch's sort forked beside the update, replayed from hipGraphs of 16 pairs), cache filled to its limit before "
                     "the timed pairs; not part of `value`"}
 
 

@@ -236,6 +236,8 @@ def _declare(L):
         "ha_cache_set_bypass": [vp, c.c_int],
         "ha_cache_bind_store": [vp, vp, vp, i64, i64],
         "ha_cache_lookup": [vp, vp, c.c_int, i64, vp, vp],
+        "ha_cache_sort_ahead": [vp, vp, c.c_int, i64, vp],
+        "ha_cache_lookup_presorted": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_update": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_update_same_keys": [vp, i64, vp, vp],
         "ha_cache_update_with_push_keys": [vp, vp, c.c_int, i64, vp, c.c_int, i64, vp, vp],

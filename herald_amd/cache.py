@@ -108,6 +108,7 @@ class _CacheBase:
         self.perf_times = False
         self._perf = []
         self._last_lookup = None
+        self._ahead = None
         self._store = None
         self._remote = None
         self.stream = stream
@@ -370,6 +371,21 @@ class _CacheBase:
         self._perf.append(d)
 
     # ---- batch API ---------------------------------------------------------------------------------------------------
+    def prefetch_keys(self, keys):
+        """State that `keys` (a device tensor) is the batch of the NEXT embedding_lookup: its sort runs now, on a stream of
+        the cache's own, beside the calls of the current batch (the data loader has the ids a batch early,
+        dataloader.py:63-98).  The tensor must not be written to until that lookup -- torch-visible writes are detected and
+        the lookup then sorts by itself; raw-pointer writers are the caller's responsibility, as with same_as_lookup.
+        Local stores only (a remote store's lookup is split around an exchange and sorts at its start)."""
+        self._ahead = None
+        if self._remote is not None or not torch.is_tensor(keys) or keys.numel() == 0:
+            return
+        s = self._stream()
+        k, kind = self._keys(keys, [])
+        check(self._L.ha_cache_sort_ahead(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
+                                          ctypes.c_void_p(s.cuda_stream)), "ha_cache_sort_ahead")
+        self._ahead = _LookupMark(k)
+
     def embedding_lookup(self, keys, dest):
         """dest[i,:] = line(keys[i]).data after the staleness-bounded pull (cache.cc:60-107)."""
         if self._remote is not None:
@@ -378,6 +394,9 @@ class _CacheBase:
         s = self._stream()
         with torch.cuda.stream(s):
             k, kind = self._keys(keys, keep)
+            lookup = self._L.ha_cache_lookup
+            if self._ahead is not None and _is_marked(self._ahead, k):
+                lookup, self._ahead = self._L.ha_cache_lookup_presorted, None
             host_dest = None
             if isinstance(dest, np.ndarray):
                 if not dest.flags.c_contiguous:
@@ -385,9 +404,8 @@ class _CacheBase:
                 host_dest = dest
                 dest = torch.empty((k.numel(), self._width), dtype=torch.float32, device=self.device)
             assert dest.numel() == k.numel() * self._width and dest.dtype == torch.float32
-            check(self._L.ha_cache_lookup(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
-                                          ctypes.c_void_p(dest.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
-                  "ha_cache_lookup")
+            check(lookup(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
+                         ctypes.c_void_p(dest.data_ptr()), ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup")
             # an update of the very same (unmodified) device key tensor can reuse this call's index plan
             self._last_lookup = None if keep else _LookupMark(k)
             if self.perf_enabled:
@@ -645,6 +663,10 @@ class CacheSparseTable:
         if isinstance(keys, tuple):
             keys = keys[0]
         return self._finish(self.cache.embedding_lookup(keys, dest), sync)
+
+    def prefetch_keys(self, keys):
+        """The next embedding_lookup's key batch, handed over a batch early (its sort overlaps the current batch)."""
+        self.cache.prefetch_keys(keys)
 
     def embedding_update(self, keys, grads, sync=False, same_as_lookup=False):
         return self._finish(self.cache.embedding_update(keys, grads, same_as_lookup=same_as_lookup), sync)

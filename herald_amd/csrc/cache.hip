@@ -36,6 +36,7 @@
 // accumulation and the ordered server `+=` reuse the apply kernels (scatter_dev.h, ha_apply_mapped).
 #include "plan_dev.h"
 
+#include <utility>
 #include <vector>
 
 extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
@@ -1743,6 +1744,15 @@ struct ha_cache {
     bool timing = false;
     hipEvent_t tev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned tmask = 0;
+    // ha_cache_sort_ahead: the stable sort of the NEXT lookup's keys runs on a stream of the cache's own, into a second plan
+    // workspace, beside the calls of the current batch (the sort reads the keys only -- the reference's data loader hands the
+    // ids over a batch early as well, dataloader.py:63-98)
+    void *plan_ws_alt = nullptr;
+    hipStream_t ahead_stream = nullptr;
+    hipEvent_t ahead_fork = nullptr, ahead_join = nullptr;
+    const void *ahead_keys = nullptr;
+    int64_t ahead_n = -1;
+    int ahead_kind = -1;
 };
 enum { kTStart = 0, kTSort = 1, kTLookup = 2, kTCopy = 3, kTTransfer = 4, kTEnd = 5 };
 static inline void cache_mark(ha_cache *h, int slot, hipStream_t s, bool first = false) {
@@ -1823,6 +1833,14 @@ extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
         } else {
             ok = false;
         }
+        char *p3 = nullptr;
+        if (ok && dmalloc(&p3, plan_bytes) == 0) {
+            h->plan_ws_alt = p3;
+            h->allocs.push_back(p3);
+            (void)hipMemset(p3, 0, 256);      // the plan header (sticky flags)
+        } else {
+            ok = false;
+        }
     }
 #undef CACHE_ALLOC
     if (!ok) {
@@ -1846,6 +1864,12 @@ extern "C" void ha_cache_destroy(ha_cache *h) {
     if (!h)
         return;
     (void)hipDeviceSynchronize();
+    if (h->ahead_stream)
+        (void)hipStreamDestroy(h->ahead_stream);
+    if (h->ahead_fork)
+        (void)hipEventDestroy(h->ahead_fork);
+    if (h->ahead_join)
+        (void)hipEventDestroy(h->ahead_join);
     for (void *p : h->allocs)
         (void)hipFree(p);
     delete h;
@@ -1878,15 +1902,16 @@ extern "C" int ha_cache_bind_store(ha_cache *h, float *table, int64_t *versions,
 // Index plan of the batch.  *probed = 1 when the finish also probed the cache for every unique key
 // (batches up to kSmallMax keys: sort, then cache_finish_probe_kernel); want_pull adds the pull decision.
 static int cache_plan(ha_cache *h, const void *keys, int key_kind, int64_t n, hipStream_t s,
-                      int want_pull = 0, int *probed = nullptr) {
+                      int want_pull = 0, int *probed = nullptr, bool presorted = false) {
     HA_REQUIRE(n <= h->c.nmax, "cache: batch of %ld keys exceeds max_batch %ld", (long)n, (long)h->c.nmax);
     Cache &c = h->c;
     if (probed)
         *probed = 0;
     if (probed && n > 0 && n <= kSmallMax) {
         const uint64_t lim = static_cast<uint64_t>(c.length);
-        const int rc = key_kind == 0 ? ha_plan_sort_f32ids_lim(static_cast<const float *>(keys), n, c.plan_ws, lim, s)
-                                     : ha_plan_sort_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, lim, s);
+        const int rc = presorted ? 0
+                       : key_kind == 0 ? ha_plan_sort_f32ids_lim(static_cast<const float *>(keys), n, c.plan_ws, lim, s)
+                                       : ha_plan_sort_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, lim, s);
         if (rc)
             return rc;
         PlanPtrs p = plan_layout(c.plan_ws, n);
@@ -2066,13 +2091,68 @@ extern "C" int ha_cache_outbox_pad(ha_cache *h, int64_t entries) {
     return 0;
 }
 
+// The sort of a lookup's keys, one batch early.  The caller's stream forks into the cache's own stream here (everything
+// enqueued on `stream` so far -- the calls that last used the second workspace among it -- precedes the sort) and joins it
+// again in the ha_cache_lookup_presorted of the same keys; both are event edges, so the pair can be captured into a hipGraph
+// as long as the join is captured too.  Batches the counting sort does not take (n > 36,864) are accepted and ignored: their
+// lookup sorts by itself.  The keys must not change between this call and their lookup.
+extern "C" int ha_cache_sort_ahead(ha_cache *h, const void *keys, int key_kind, int64_t n, ha_stream_t stream) {
+    HA_REQUIRE(h && (key_kind == 0 || key_kind == 1) && n >= 0 && (n == 0 || keys), "cache_sort_ahead: bad arguments");
+    HA_REQUIRE(n <= h->c.nmax, "cache: batch of %ld keys exceeds max_batch %ld", (long)n, (long)h->c.nmax);
+    hipStream_t s = as_stream(stream);
+    if (!h->ahead_stream) {
+        HA_REQUIRE(hipStreamCreateWithFlags(&h->ahead_stream, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&h->ahead_fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&h->ahead_join, hipEventDisableTiming) == hipSuccess,
+                   "cache_sort_ahead: cannot create the stream / events");
+    }
+    if (h->ahead_n >= 0)      // a sort nobody consumed: the caller's stream joins it before the workspace is reused
+        HA_REQUIRE(hipStreamWaitEvent(s, h->ahead_join, 0) == hipSuccess, "cache_sort_ahead: join failed");
+    h->ahead_n = -1;
+    if (n == 0 || n > kSmallMax)
+        return 0;
+    HA_REQUIRE(hipEventRecord(h->ahead_fork, s) == hipSuccess &&
+               hipStreamWaitEvent(h->ahead_stream, h->ahead_fork, 0) == hipSuccess, "cache_sort_ahead: fork failed");
+    const uint64_t lim = static_cast<uint64_t>(h->c.length);
+    if (key_kind == 0 ? ha_plan_sort_f32ids_lim(static_cast<const float *>(keys), n, h->plan_ws_alt, lim, h->ahead_stream)
+                      : ha_plan_sort_u64ids_lim(static_cast<const uint64_t *>(keys), n, h->plan_ws_alt, lim, h->ahead_stream))
+        return -1;
+    HA_REQUIRE(hipEventRecord(h->ahead_join, h->ahead_stream) == hipSuccess, "cache_sort_ahead: join record failed");
+    h->ahead_keys = keys;
+    h->ahead_n = n;
+    h->ahead_kind = key_kind;
+    return 0;
+}
+
+static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_t n, float *dest, hipStream_t s, bool presorted);
+
 extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int64_t n,
                                float *dest, ha_stream_t stream) {
+    return cache_lookup_impl(h, keys, key_kind, n, dest, as_stream(stream), false);
+}
+
+// The lookup of the keys ha_cache_sort_ahead was last given (same pointer, kind and count -- anything else is an error).
+extern "C" int ha_cache_lookup_presorted(ha_cache *h, const void *keys, int key_kind, int64_t n,
+                                         float *dest, ha_stream_t stream) {
+    HA_REQUIRE(h, "cache_lookup_presorted: null handle");
+    if (n == 0 || n > kSmallMax)      // sort_ahead ignored this batch
+        return cache_lookup_impl(h, keys, key_kind, n, dest, as_stream(stream), false);
+    HA_REQUIRE(h->ahead_n == n && h->ahead_keys == keys && h->ahead_kind == key_kind,
+               "cache_lookup_presorted: no ha_cache_sort_ahead of these %ld keys precedes", (long)n);
+    return cache_lookup_impl(h, keys, key_kind, n, dest, as_stream(stream), true);
+}
+
+static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_t n, float *dest, hipStream_t s,
+                             bool presorted) {
     HA_REQUIRE(h && h->c.table && !h->c.remote, "cache_lookup: no local store bound (remote stores use "
                "ha_cache_lookup_begin / ha_cache_lookup_finish)");
     HA_REQUIRE(n >= 0 && (n == 0 || (keys && dest)), "cache_lookup: bad arguments");
     Cache &c = h->c;
-    hipStream_t s = as_stream(stream);
+    if (presorted) {          // the sorted keys are in the second workspace: it becomes the plan of this batch
+        HA_REQUIRE(hipStreamWaitEvent(s, h->ahead_join, 0) == hipSuccess, "cache_lookup_presorted: join failed");
+        std::swap(c.plan_ws, h->plan_ws_alt);
+        h->ahead_n = -1;
+    }
     int probed = 0;
     PlanPtrs p = plan_layout(c.plan_ws, n);
     cache_mark(h, kTStart, s, true);
@@ -2082,14 +2162,14 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
     if (finish_book) {
         HA_REQUIRE(n <= c.nmax, "cache: batch of %ld keys exceeds max_batch %ld", (long)n, (long)c.nmax);
         const uint64_t lim = static_cast<uint64_t>(c.length);
-        if (key_kind == 0 ? ha_plan_sort_f32ids_lim(static_cast<const float *>(keys), n, c.plan_ws, lim, s)
-                          : ha_plan_sort_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, lim, s))
+        if (!presorted && (key_kind == 0 ? ha_plan_sort_f32ids_lim(static_cast<const float *>(keys), n, c.plan_ws, lim, s)
+                                         : ha_plan_sort_u64ids_lim(static_cast<const uint64_t *>(keys), n, c.plan_ws, lim, s)))
             return -1;
         cache_mark(h, kTSort, s);
         hipLaunchKernelGGL(cache_finish_book_kernel, dim3(finish_blocks((int)n)), dim3(1024), 0, s, p.sorted, p.perm, (int)n,
                            p.hdr, p.uniq, p.seg, p.counts, p.inverse, p.upos, c, c.limit >= n ? 1 : 0);
         probed = 1;
-    } else if (cache_plan(h, keys, key_kind, n, s, 1, &probed)) {
+    } else if (cache_plan(h, keys, key_kind, n, s, 1, &probed, presorted)) {
         return -1;
     } else {
         cache_mark(h, kTSort, s);

@@ -803,6 +803,14 @@ int ha_cache_bind_store(ha_cache *cache, float *table, int64_t *versions,
                         int64_t store_rows, int64_t row_start);
 int ha_cache_lookup(ha_cache *cache, const void *keys, int key_kind, int64_t n,
                     float *dest, ha_stream_t stream);
+/* The stable sort of a lookup's keys ONE BATCH EARLY, beside the calls of the current batch (the reference's loader hands
+ * the ids over a batch ahead: python/hetu/dataloader.py:63-98).  `stream` forks into a stream of the cache's own here and
+ * joins it in ha_cache_lookup_presorted(same keys, kind, n) -- anything else there is an error; the keys must not change in
+ * between.  Batches beyond 36,864 keys are accepted and ignored (their lookup sorts by itself).  Results are those of
+ * ha_cache_lookup, bit for bit (cache.cc:60-107). */
+int ha_cache_sort_ahead(ha_cache *cache, const void *keys, int key_kind, int64_t n, ha_stream_t stream);
+int ha_cache_lookup_presorted(ha_cache *cache, const void *keys, int key_kind, int64_t n,
+                              float *dest, ha_stream_t stream);
 int ha_cache_update(ha_cache *cache, const void *keys, int key_kind, int64_t n,
                     const float *grads, ha_stream_t stream);
 /* ha_cache_update for the key batch of the immediately preceding ha_cache_lookup on this cache (the

@@ -24,11 +24,13 @@ def _compare_state(gpu, model, step):
 
 
 def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_keys_mode=False, seed=0,
-               zipf=True, check_every=1, policy="lru", bind=None, same=False, extra_lookup_every=0):
+               zipf=True, check_every=1, policy="lru", bind=None, same=False, extra_lookup_every=0, ahead=False):
     """bind(gpu_cache, table, versions): how the cache reaches its store (default: bind_store, the table in
     the same HBM; test_gpu_cache_remote.py passes remote stores here).  same: the update names the lookup's key
     tensor (same_as_lookup=True -> ha_cache_update_same_keys); extra_lookup_every=k: every k-th step looks another
-    batch up first, so that the evict list is not empty when the step's own lookup starts."""
+    batch up first, so that the evict list is not empty when the step's own lookup starts.  ahead: every step hands the
+    NEXT step's key tensor to prefetch_keys between its lookup and its update (ha_cache_sort_ahead -> the next lookup is
+    ha_cache_lookup_presorted)."""
     rng = np.random.default_rng(seed)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
     server = cache_model.Server(table0)
@@ -43,12 +45,17 @@ def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_k
         bind(gpu, table, versions)
     gpu.pull_bound, gpu.push_bound = pull_bound, push_bound
     gpu.perf_enabled = True
-    for step in range(steps):
+    def draw(r):
         if zipf:
-            keys = np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1).astype(np.int64)
-            keys = (keys * 7919) % rows
-        else:
-            keys = rng.integers(0, rows, size=n)
+            return (np.minimum(r.zipf(1.3, size=n) - 1, rows - 1).astype(np.int64) * 7919) % rows
+        return r.integers(0, rows, size=n)
+
+    if ahead:       # the key batches exist before their steps, as a data loader's do
+        rk = np.random.default_rng(seed + 1000)
+        keys_all = [draw(rk) for _ in range(steps)]
+        kts = [torch.from_numpy(k.astype(np.float32)).to(dev) for k in keys_all]
+    for step in range(steps):
+        keys = keys_all[step] if ahead else draw(rng)
         fk = keys.astype(np.float32)                      # the *_raw entry points take float32 ids
         dest = torch.empty((n, width), dtype=torch.float32, device=dev)
         if extra_lookup_every and step % extra_lookup_every == extra_lookup_every - 1:
@@ -57,9 +64,11 @@ def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_k
             gpu.embedding_lookup(torch.from_numpy(xk).to(dev), dest).wait()
             np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="extra lookup rows at step %d" % step)
         want = model.lookup(fk.astype(np.uint64))
-        kt = torch.from_numpy(fk).to(dev)
+        kt = kts[step] if ahead else torch.from_numpy(fk).to(dev)
         gpu.embedding_lookup(kt, dest).wait()
         np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % step)
+        if ahead and step + 1 < steps:
+            gpu.prefetch_keys(kts[step + 1])
         grads = (rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01))
         if push_keys_mode:
             pk = np.unique(rng.choice(keys, size=max(1, n // 3)))
@@ -125,6 +134,48 @@ def test_lru_trace_long_runs_full_width(dev):
 
 def _fused(gpu):
     return int(gpu._L.ha_cache_fused_updates(gpu._h))
+
+
+@pytest.mark.parametrize("same,extra", [(True, 0), (False, 0), (True, 3)])
+def test_lru_trace_with_the_next_batch_sorted_ahead(dev, same, extra):
+    """prefetch_keys: the sort of the next lookup's keys runs on the cache's own stream beside the current update, into the
+    second plan workspace -- the same trace, state and reports as the model (and as without it); with `extra`, another
+    batch is looked up between a prefetch and its lookup."""
+    gpu, _ = _run_trace(dev, limit=100, rows=1500, width=8, n=64, steps=60, pull_bound=2, push_bound=2, seed=21,
+                        same=same, extra_lookup_every=extra, ahead=True)
+    if same and not extra:
+        assert _fused(gpu) == 60
+
+
+def test_lfu_trace_with_the_next_batch_sorted_ahead_criteo_width(dev):
+    _run_trace(dev, limit=300, rows=5000, width=128, n=416, steps=10, pull_bound=2, push_bound=2, seed=22, policy="lfu",
+               check_every=3, ahead=True)
+
+
+def test_prefetched_keys_that_change_before_their_lookup_are_sorted_again(dev):
+    """A torch-visible write to a prefetched key tensor voids the prefetch: the lookup sorts by itself."""
+    rows, width, n = 500, 8, 96
+    rng = np.random.default_rng(5)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    table = torch.from_numpy(table0.copy()).to(dev)
+    gpu = hcache.LRUCache(200, rows, width, node_id=0, max_batch=n, device=dev)
+    gpu.bind_store(table, torch.zeros(rows, dtype=torch.int64, device=dev))
+    k = torch.from_numpy(rng.integers(0, rows, size=n).astype(np.float32)).to(dev)
+    gpu.prefetch_keys(k)
+    k.copy_(torch.from_numpy(rng.integers(0, rows, size=n).astype(np.float32)))
+    dest = torch.empty((n, width), device=dev)
+    gpu.embedding_lookup(k, dest).wait()
+    np.testing.assert_array_equal(dest.cpu().numpy(), table0[k.cpu().numpy().astype(np.int64)])
+    # ... and the unchanged tensor takes the presorted path, through the C entry point that insists on the match
+    k2 = torch.from_numpy(rng.integers(0, rows, size=n).astype(np.float32)).to(dev)
+    gpu.prefetch_keys(k2)
+    gpu.embedding_lookup(k2, dest).wait()
+    np.testing.assert_array_equal(dest.cpu().numpy(), table0[k2.cpu().numpy().astype(np.int64)])
+    with pytest.raises(Exception):
+        from herald_amd import _lib
+        import ctypes
+        _lib.check(gpu._L.ha_cache_lookup_presorted(gpu._h, ctypes.c_void_p(k2.data_ptr()), 0, n,
+                                                    ctypes.c_void_p(dest.data_ptr()), None), "ha_cache_lookup_presorted")
 
 
 @pytest.mark.parametrize("pull_bound,push_bound", [(0, 0), (3, 3), (100, 100)])
