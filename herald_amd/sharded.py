@@ -213,7 +213,7 @@ class HipEngine:
         blk = FrameBlock()
         blk.ksend = torch.empty((w, block, 2 + rcap), dtype=torch.int32, device=self.device)
         blk.krecv = torch.empty((w, block, 2 + rcap), dtype=torch.int32, device=self.device)
-        blk.kgot, blk.ev, blk.live, blk.synced, blk.carrays = None, None, False, False, None
+        blk.kgot, blk.ev, blk.ev_obj, blk.live, blk.synced, blk.carrays = None, None, None, False, False, None
         blk.slots = []
         for i in range(block):
             fb = FrameBuffers()
@@ -282,10 +282,12 @@ class HipEngine:
                 fb.ids.record_stream(st_)
             for st_ in used:
                 cur.wait_stream(st_)
-        done = set(id(fb) for fb in big) if len(big) > 1 else set()
-        for kind, fn in ((torch.float32, self.lib.ha_plan_build_batch_f32ids_lim),
-                         (None, self.lib.ha_plan_build_batch_u64ids_lim)):
-            sel = [fb for fb in slots if fb.n and id(fb) not in done and (fb.ids.dtype == torch.float32) == (kind is not None)]
+        f32, u64 = [], []
+        many_big = len(big) > 1
+        for fb in slots:
+            if fb.n and not (many_big and fb.n > self.RADIX_FROM):
+                (f32 if fb.ids.dtype is torch.float32 else u64).append(fb)
+        for sel, fn in ((f32, self.lib.ha_plan_build_batch_f32ids_lim), (u64, self.lib.ha_plan_build_batch_u64ids_lim)):
             if sel:
                 cnt = len(sel)
                 self.check(fn((vp * cnt)(*[fb.ids.data_ptr() for fb in sel]), (ctypes.c_int64 * cnt)(*[fb.n for fb in sel]),
@@ -488,7 +490,7 @@ class HipEngine:
 
 class FrameBlock:
     """Key frames of one routing block of a FramedStep (see HipEngine.frames_block)."""
-    __slots__ = ("ksend", "krecv", "kgot", "ev", "live", "slots", "synced", "carrays")
+    __slots__ = ("ksend", "krecv", "kgot", "ev", "ev_obj", "live", "slots", "synced", "carrays")
 
 
 class FrameBuffers:
@@ -841,9 +843,8 @@ class FramedStep:
         eng, starts = self.eng, self.emb.starts
         ctx = eng.on_side(after_current=True) if self.side else contextlib.nullcontext()
         with ctx:
-            if self.side and hasattr(eng, "hold_for_side"):
-                for fb in blk.slots:
-                    eng.hold_for_side(fb.ids)
+            # (the id tensors of the block stay referenced by their slots until they are restaged three blocks later, long
+            # after this routing has completed: the allocator cannot hand their memory out under the side stream)
             exchange = lambda out, inp: self._exchange(out, inp, group=self.emb.side_group if self.side else None)
             sized_rank = self.emb.rank if self.sized else None
             if hasattr(eng, "frames_route_block"):
@@ -856,7 +857,7 @@ class FramedStep:
                 for fb in blk.slots:
                     if fb.routed:
                         eng.frames_unpack(blk, fb)
-            blk.ev = eng.record()
+            blk.ev = blk.ev_obj = eng.record(blk.ev_obj)      # (one event object per block, re-recorded)
         for fb in blk.slots:
             fb.send_cnt = fb.recv_cnt = None
         if self.emb.world > 1:

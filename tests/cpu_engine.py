@@ -106,7 +106,7 @@ class CpuEngine:
         blk = FrameBlock()
         blk.ksend = torch.full((w, block, 2 + rcap), -99, dtype=torch.int32)
         blk.krecv = torch.full((w, block, 2 + rcap), -99, dtype=torch.int32)
-        blk.kgot, blk.ev, blk.live, blk.slots, blk.synced = None, None, False, [], False
+        blk.kgot, blk.ev, blk.ev_obj, blk.live, blk.slots, blk.synced = None, None, None, False, [], False
         for i in range(block):
             fb = FrameBuffers()
             fb.i, fb.w, fb.rcap = i, w, rcap
