@@ -230,9 +230,11 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
             prefilled += n
         torch.cuda.synchronize()
 
+    use_ahead = os.environ.get("HA_CACHE_BENCH_AHEAD", "0") == "1"
+
     def step(k, ahead=True):
         c.embedding_lookup(ids_dev[k % nb], out)
-        if ahead:       # the loader has the next batch's ids: their sort runs beside this batch's update
+        if ahead and use_ahead:       # the loader has the next batch's ids: their sort runs beside this batch's update
             c.prefetch_keys(ids_dev[(k + 1) % nb])
         c.embedding_update(ids_dev[k % nb], grad, same_as_lookup=True)
 
