@@ -835,12 +835,6 @@ class QueueStepPipeline:
             except Exception:      # noqa: BLE001
                 side_prio = 0
         self.side = torch.cuda.Stream(device=self.device, priority=side_prio) if self.overlap else None
-        # wide batches: plans and queues of a block are ~100 us of launches each -- in a row they are as long as the four
-        # steps beside them and the steps end up waiting for their queues.  The queues get a stream of their own: all but
-        # the block's last step join plans of EARLIER calls only (HA_QWIDE_ONE_STREAM=1: the single stream, for A/B).
-        self.side2 = torch.cuda.Stream(device=self.device, priority=side_prio) \
-            if self.overlap and self.wide and os.environ.get("HA_QWIDE_ONE_STREAM") != "1" else None
-        self._ev_plans = {}
         # {wave items, workgroup items, copy items} (+ 1; 0 = not built yet) of the queue of step c, written to pinned host
         # memory by the launch that builds it, in a ring long enough that a build still in flight cannot write into the
         # slot of a later step: queues are built a block ahead, so the host usually knows the numbers when it enqueues
@@ -864,7 +858,6 @@ class QueueStepPipeline:
         self._done_ev = {}
         self.c, self.n, self.shape, self.ids = None, {}, {}, {}
         self._ev_side = {}          # block index -> event behind the side work launched at its start
-        self._ev_plans = {}         # wide, two preparation streams: block index -> event behind the plans of that call
         self._held = {}             # block index -> id tensors its plan launch reads (kept alive, not record_stream'ed)
         return self
 
@@ -907,29 +900,17 @@ class QueueStepPipeline:
         # caller's stream cost at a block boundary
         nosync = os.environ.get("HA_QNOSYNC") == "1"
         flags = self.sync == "flags"
-        two = self.side2 is not None
-        s2 = self.side2 if two else s
-        sp2 = _stream_ptr(s2)
         if self.overlap and flags and not nosync:
             # the steps of block b-1 are complete (their last launch carries the event): the plans / queues about to be
             # rewritten are free.  Nothing is enqueued on the caller's stream.
             cev = self._done_ev.pop(b - 1, None)
             if cev is not None:
                 check(L.ha_stream_wait_event(sp, cev), "ha_stream_wait_event")
-                if two:
-                    check(L.ha_stream_wait_event(sp2, cev), "ha_stream_wait_event")
                 self._cev_pool.append(cev)
         elif self.overlap and not nosync:
             ev = self._event()
             ev.record(main)                    # the buffers about to be rewritten are free, the ids are there
             s.wait_event(ev)
-            if two:
-                s2.wait_event(ev)
-        if two:         # the queues of this call join the plans of the calls before it (and one plan of this call: below)
-            pe = self._ev_plans.pop(b - 1, None)
-            if pe is not None:
-                s2.wait_event(pe)
-                self._ev_pool.append(pe)
         # plans of block b+2
         sel = {"f32ids": [], "u64ids": []}
         held = []
@@ -950,83 +931,60 @@ class QueueStepPipeline:
             if self.wide:            # (a step whose batch cannot be bucketed falls back to a sorted plan of the ids)
                 self._wide_ids[j] = t
                 self._wide_ids.pop(j - 5 * B, None)
-        first_ev = None
         for kind, lst in sel.items():
             if not lst:
                 continue
-            # (two streams: the block's FIRST batch is planned by a launch chain of its own -- the queue of the last step of
-            # the block before joins it, and must not wait for the other plans)
-            j_first = (b + 2) * B
-            parts = [lst[:1], lst[1:]] if two and lst[0][0] == j_first and len(lst) > 1 else [lst]
-            for part in parts:
-                cnt = len(part)
-                ids_arr = (vp * cnt)(*[t.data_ptr() for _, t, _ in part])
-                n_arr = (i64 * cnt)(*[m for _, _, m in part])
-                pl_arr = (vp * cnt)(*[self._plan_ptr[j % self.NPLAN] for j, _, _ in part])
-                if ph is not None and kind == "f32ids" and part is parts[0]:
-                    j0, t0, m0 = part[0]
-                    check(L.ha_debug_qprep_f32ids(rows, width, _ptr(t0), m0, _ptr(self.plan_of(j0).ws), None, 0,
-                                                  None, 0, None, self.capacity, _ptr(ph), sp), "ha_debug_qprep")
-                if self.wide:
-                    check(getattr(L, "ha_qbig_plan_batch_" + kind)(ids_arr, n_arr, pl_arr, self.capacity, cnt, sp),
-                          "ha_qbig_plan_batch")
-                else:
-                    check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
-                if two and part[0][0] == j_first:
-                    first_ev = self._event()
-                    first_ev.record(s)
+            cnt = len(lst)
+            ids_arr = (vp * cnt)(*[t.data_ptr() for _, t, _ in lst])
+            n_arr = (i64 * cnt)(*[m for _, _, m in lst])
+            pl_arr = (vp * cnt)(*[self._plan_ptr[j % self.NPLAN] for j, _, _ in lst])
+            if ph is not None and kind == "f32ids":
+                j0, t0, m0 = lst[0]
+                check(L.ha_debug_qprep_f32ids(rows, width, _ptr(t0), m0, _ptr(self.plan_of(j0).ws), None, 0,
+                                              None, 0, None, self.capacity, _ptr(ph), sp), "ha_debug_qprep")
+            if self.wide:
+                check(getattr(L, "ha_qbig_plan_batch_" + kind)(ids_arr, n_arr, pl_arr, self.capacity, cnt, sp),
+                      "ha_qbig_plan_batch")
+            else:
+                check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
             for j, _, m in lst:
                 pl = self.plans[j % self.NPLAN]
                 pl.n = m
                 pl._view = None
                 pl._produced_on = sp.value if sp.value is not None else 0
-        if two:
-            pe = self._event()
-            pe.record(s)
-            self._ev_plans[b] = pe
         # the ids are read on the side stream: keep them alive until the plans of the block after next are enqueued
         self._held[b] = held
         self._held.pop(b - 2, None)
         # queues of the steps of block b+1 (step j: batch j applied, batch j+1 looked up)
         nget = self.n.get
         steps = [j for j in range((b + 1) * B, (b + 2) * B) if nget(j, 0) or nget(j + 1, 0)]
-        last = (b + 2) * B - 1        # the one step whose lookup batch is planned by THIS call
-        groups = [steps]
-        if two and steps and steps[-1] == last and nget(last + 1, 0):
-            groups = [steps[:-1], steps[-1:]]
-        for gi, grp in enumerate(groups):
-            if not grp:
-                continue
-            if gi == 1 and first_ev is not None:
-                s2.wait_event(first_ev)
-            cnt = len(grp)
+        if steps:
+            cnt = len(steps)
             pp, NP, NQ = self._plan_ptr, self.NPLAN, self.NQUEUE
-            pa = (vp * cnt)(*[pp[j % NP] if nget(j, 0) else None for j in grp])
-            na = (i64 * cnt)(*[nget(j, 0) for j in grp])
-            pg = (vp * cnt)(*[pp[(j + 1) % NP] if nget(j + 1, 0) else None for j in grp])
-            ng = (i64 * cnt)(*[nget(j + 1, 0) for j in grp])
-            qs = (vp * cnt)(*[self._queue_ptr[j % NQ] for j in grp])
-            if ph is not None and gi == 0:
+            pa = (vp * cnt)(*[pp[j % NP] if nget(j, 0) else None for j in steps])
+            na = (i64 * cnt)(*[nget(j, 0) for j in steps])
+            pg = (vp * cnt)(*[pp[(j + 1) % NP] if nget(j + 1, 0) else None for j in steps])
+            ng = (i64 * cnt)(*[nget(j + 1, 0) for j in steps])
+            qs = (vp * cnt)(*[self._queue_ptr[j % NQ] for j in steps])
+            if ph is not None:
                 check(L.ha_debug_qprep_f32ids(rows, width, None, 0, None, pa[0], na[0], pg[0], ng[0], qs[0], self.capacity,
-                                              _ptr(ph), sp2), "ha_debug_qprep")
+                                              _ptr(ph), sp), "ha_debug_qprep")
             base, ring, cc = self._counts_base, self.COUNTS, self._counts_c
-            for j in grp:
+            for j in steps:
                 at = 4 * (j % ring)
                 cc[at] = 0
                 cc[at + 2] = 0
-            cs = (vp * cnt)(*[base + 16 * (j % ring) for j in grp])
-            eps = (ctypes.c_uint32 * cnt)(*[self._epoch(j) for j in grp])
+            cs = (vp * cnt)(*[base + 16 * (j % ring) for j in steps])
+            eps = (ctypes.c_uint32 * cnt)(*[self._epoch(j) for j in steps])
             if self.wide:
-                check(L.ha_qbig_queue_batch(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp2),
+                check(L.ha_qbig_queue_batch(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
                       "ha_qbig_queue_batch")
             else:
-                check(L.ha_qqueue_batch_epochs(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp2),
+                check(L.ha_qqueue_batch_epochs(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
                       "ha_qqueue_batch")
-        if first_ev is not None:
-            self._ev_pool.append(first_ev)
         if self.overlap and not nosync and not flags:
             ev = self._event()
-            ev.record(s2)       # (two streams: the queues' stream has waited for the plans it joins)
+            ev.record(s)
             self._ev_side[b] = ev
             ready = self._ev_side.pop(b - 1, None)
             if ready is not None:
