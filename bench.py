@@ -71,6 +71,10 @@ def parse_args():
                         "between); 0 = all W before the synchronisation")
     p.add_argument("--clock-warm", type=int, default=8,
                    help="untimed 512 MiB device copies enqueued right before the pre-roll (0 = none)")
+    p.add_argument("--cache-warm", type=int, default=96,
+                   help="untimed read-only lookups of the batches that PRECEDE the timed region in the stream of batches, "
+                        "enqueued after the clock-warm copies: a long run reaches the timed steps with the rows of its recent "
+                        "batches in the last-level cache; a 20-step run behind 1 GiB copies does not (0 = none)")
     p.add_argument("--no-gate", action="store_true",
                    help="do not hold the stream until the host has enqueued the timed region")
     p.add_argument("--engine", default=None, choices=("handoff", "forward", "queue"),
@@ -613,7 +617,7 @@ def main():
     gate = None
     # the gate holds the stream until everything behind it is enqueued: with plain launches that is one queue packet per
     # step, so only short runs are gated (a full hardware queue behind a closed gate would never drain)
-    if not args.no_gate and (use_graph or args.steps + pre <= 512):
+    if not args.no_gate and (use_graph or args.steps + pre + args.cache_warm <= 512):
         from herald_amd import _lib as _hl
         gate = torch.zeros(1, dtype=torch.int32).pin_memory()
         with torch.cuda.stream(main_s):
@@ -624,6 +628,16 @@ def main():
         with torch.cuda.stream(main_s):
             for _ in range(args.clock_warm):
                 warm[0].copy_(warm[1])
+    if args.cache_warm > 0:
+        # untimed, behind the gate, read-only: the rows of the `cache_warm` batches that precede the first pre-roll step in
+        # the stream of batches are looked up into a scratch buffer (not the batches of the timed steps: what a long run
+        # would have touched on its way here).  The table is not modified; these are not steps.
+        scratch = (warm[0] if warm is not None else torch.empty(1 << 27, dtype=torch.float32, device=dev))[:n * args.width] \
+            .view(n, args.width)
+        first = K0 + wu - pre
+        with torch.cuda.stream(main_s):
+            for k in range(first - args.cache_warm, first):
+                ops.embedding_lookup(table, ids_dev[k % nb], out=scratch, stream=main_s)
     run(K0 + wu - pre, pre)
     t0 = time.perf_counter()
     e0.record(main_s)
@@ -756,8 +770,12 @@ def main():
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,
         "device_ms": dev_ms, "enqueue_ms": t_enq * 1e3, "wall_ms": wall * 1e3,
         "timed_region": "exactly %d steps between two HIP events on the launch stream; %d of the %d warm-up steps run "
-                        "right in front of it%s" % (args.steps, pre, wu, ", behind a gate the host opens once everything "
-                                                    "is enqueued" if gate is not None else ""),
+                        "right in front of it%s%s" % (args.steps, pre, wu, ", behind a gate the host opens once everything "
+                                                      "is enqueued" if gate is not None else "",
+                                                      "; untimed prologue in front of those: %d device copies of 512 MiB (clocks) and "
+                                                      "%d read-only lookups of the batches that precede them in the stream (the "
+                                                      "last-level cache as a long run leaves it); the table is not modified by either"
+                                                      % (args.clock_warm, args.cache_warm)),
         "host_bound": bool(t_enq * 1e3 > dev_ms),
         "block_boundaries_in_timed_region": (len([k for k in range(K0 + wu, K0 + wu + args.steps) if k % args.queue_block == 0])
                                              if queue and not args.queue_serial else None),
