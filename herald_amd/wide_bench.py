@@ -8,7 +8,7 @@ import torch
 HBM_PEAK_GBS = 8000.0
 
 
-def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags", distinct=32, lr=1e-6):
+def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags", distinct=32, lr=1e-6, alone=False):
     from . import ops, synth
     dev = table.device
     n = batch * fields
@@ -44,6 +44,20 @@ def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags
     if pipe.overflowed():
         raise RuntimeError("the wide path raised its sticky error word")
     us = e0.elapsed_time(e1) * 1e3 / steps
+    alone_us = None
+    if alone:
+        # development aid: the apply launch of ONE step again and again with nothing beside it (its queue stays built;
+        # the table takes the same gradient positions repeatedly -- a timing, not a training step)
+        c = warm + steps - 2 if (warm + steps - 1) % block == block - 1 else warm + steps - 1
+        reps = 40
+        with torch.cuda.stream(s):
+            for i in range(reps + 4):
+                if i == 4:
+                    e0.record(s)
+                pipe.apply(c, grads[i % nbuf], outs[(i + 1) % nbuf], stream=s, n_cur=n, n_next=n)
+            e1.record(s)
+        torch.cuda.synchronize()
+        alone_us = e0.elapsed_time(e1) * 1e3 / reps
     alg = n * (12 * width + 8) + u_mean * 8 * width
     hdr = pipe.queue_header(warm + steps - 1)
     return {"workload": "wdl_criteo bs=%d d=%d on ONE GPU, %d ids per step, full %d-row table; work-queue step, wide path "
@@ -54,4 +68,4 @@ def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags
             "roofline": {"bound": "hbm", "kernel": "ha::qapply_kernel (launch-to-launch period, preparation beside it)",
                          "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / us / 1e3 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg},
-            "queue_items": hdr}
+            "queue_items": hdr, "apply_alone_us": alone_us}

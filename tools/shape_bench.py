@@ -11,7 +11,9 @@ table = torch.empty((rows, width), device=dev)
 for s in range(0, rows, 1 << 21):
     table[s:s + (1 << 21)].normal_(0, 0.01)
 r = wide_bench.measure(table, rows, bs, width, block=int(os.environ.get("BLOCK", "4")), steps=int(os.environ.get("STEPS", "96")),
-                       sync=os.environ.get("SYNC", "flags"))
+                       sync=os.environ.get("SYNC", "flags"), alone=os.environ.get("ALONE") == "1")
 print("bs=%d d=%d: %.2f us/step  %.1f M rows/s  frac %.3f of 8 TB/s  (%s)" % (bs, width, r["us_per_step"], r["rows_per_s"] / 1e6,
                                                                           r["roofline"]["frac"], r["stream_sync"]))
 print(json.dumps(r))
+if r.get("apply_alone_us"):
+    print("apply launch alone (no preparation beside it): %.2f us" % r["apply_alone_us"])
