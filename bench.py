@@ -71,7 +71,7 @@ def parse_args():
                         "between); 0 = all W before the synchronisation")
     p.add_argument("--clock-warm", type=int, default=8,
                    help="untimed 512 MiB device copies enqueued right before the pre-roll (0 = none)")
-    p.add_argument("--cache-warm", type=int, default=96,
+    p.add_argument("--cache-warm", type=int, default=256,
                    help="untimed read-only lookups of the batches that PRECEDE the timed region in the stream of batches, "
                         "enqueued after the clock-warm copies: a long run reaches the timed steps with the rows of its recent "
                         "batches in the last-level cache; a 20-step run behind 1 GiB copies does not (0 = none)")
