@@ -188,9 +188,12 @@ __device__ __forceinline__ void q_phase(unsigned long long *ph, int k) {
         ph[k] = __builtin_amdgcn_s_memrealtime();
 }
 
-// ---- 1024-thread exclusive scan (two barriers); s_w = 16 words -------------------------------------------------
-__device__ __forceinline__ uint32_t qscan(uint32_t v, uint32_t *s_w, uint32_t *total) {
-    const int lane = lane_id(), w = threadIdx.x >> 6;
+// ---- exclusive scan over the NW waves of a group of threads (two workgroup barriers); s_w = NW words of the group, w = the
+// calling wave's index inside it.  A 1024-thread workgroup is one group of 16 waves, or -- the wide path's small buckets --
+// four groups of 4 waves that walk the same phases side by side (every group calls with its own s_w).
+template <int NW>
+__device__ __forceinline__ uint32_t qscan_n(uint32_t v, uint32_t *s_w, uint32_t *total, int w) {
+    const int lane = lane_id();
     uint32_t x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -202,10 +205,10 @@ __device__ __forceinline__ uint32_t qscan(uint32_t v, uint32_t *s_w, uint32_t *t
     if (lane == 63)
         s_w[w] = x;
     __syncthreads();
-    const uint32_t mine = s_w[lane & 15];
+    const uint32_t mine = s_w[lane & (NW - 1)];
     uint32_t woff = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < NW; ++k) {
         const uint32_t t = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine), k));
         woff += k < w ? t : 0u;
         tot += t;
@@ -239,40 +242,48 @@ constexpr int kGroupedFlagWord = 12;             // plan header word: 1 = unique
 constexpr int kOrderFlagWord = 13;               // plan header word: 1 = an occurrence list is NOT in position order (the plan
                                                  // workgroup checks every list it writes; the queue builder hands the word on
                                                  // to the host: the serial chain's order is what bit-exactness rests on)
-__device__ __forceinline__ uint32_t q_hash(uint32_t key) {
-    return (key * 0x9E3779B1u) >> (32 - kQTabBits);
+__device__ __forceinline__ uint32_t q_hash(uint32_t key, int bits = kQTabBits) {
+    return (key * 0x9E3779B1u) >> (32 - bits);
 }
 static inline size_t qsort_lds_bytes(int n) {
     const size_t npad = (static_cast<size_t>(n) + 1023) & ~static_cast<size_t>(1023);
     return kQTabSize * 4 + 3 * npad * 2 + 8 + 32 * 4;
 }
+// the wide path's small buckets: four of them side by side in one workgroup, 256 threads and a 4,096-slot table each
+constexpr int kQSubThreads = 256, kQSubTabBits = 12, kQSubMax = 7 * kQSubThreads;      // ids per small bucket
+constexpr size_t kQSubPlanLds = (size_t(1) << kQSubTabBits) * 4 + 3 * size_t(kQSubMax) * 2 + 8 + 32 * 4 + 120;   // 27,392
+static_assert(kQSubPlanLds % 128 == 0, "the groups' LDS regions stay aligned");
 
 // BUCKET: the batch is one hash bucket of a larger batch (the wide path below): `ids` are its keys in position order,
 // pos_map[i] the position of its i-th id in the whole batch -- occurrence lists and the groups' first occurrences leave
 // as positions of the whole batch, and only what the queue builder and the apply read is written (unique keys, counts,
 // segment starts, occurrence lists, first occurrences).
-template <typename IdT, bool RANK_ATOMIC, bool BUCKET = false>
+// NT / TBITS: the threads that work on the batch and the bits of its table -- the whole workgroup and 8,192 slots, or (wide path,
+// buckets of at most 7 * 256 ids) a QUARTER of it and 4,096 slots: four buckets are then grouped side by side by one
+// workgroup, every barrier being one all four pass (`lds` = the group's own region, kQSubPlanLds apart).
+template <typename IdT, bool RANK_ATOMIC, bool BUCKET = false, int NT = 1024, int TBITS = kQTabBits>
 __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, const QPlan &p, uint32_t *lds,
                                                   unsigned long long *ph = nullptr,
                                                   const uint32_t *__restrict__ pos_map = nullptr) {
+    constexpr int TS = 1 << TBITS, SPT = TS / NT;     // table slots, slots numbered per thread
     const int n = p.n;
-    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const int npad = (n + 1023) & ~1023;
-    const int P = npad >> 10;                     // positions per thread, <= 7
+    const int tid = static_cast<int>(threadIdx.x) & (NT - 1), lane = lane_id(), w = tid >> 6;
+    const int npad = (n + NT - 1) & ~(NT - 1);
+    const int P = npad / NT;                      // positions per thread, <= 7
     uint32_t *s_tab = lds;
-    uint16_t *s_lab = reinterpret_cast<uint16_t *>(lds + kQTabSize);
+    uint16_t *s_lab = reinterpret_cast<uint16_t *>(lds + TS);
     uint16_t *s_cnt = s_lab + npad;
     uint16_t *s_rank = s_cnt + npad + 4;      // (a spare counter behind the groups' for positions beyond the batch)
     uint32_t *s_w = reinterpret_cast<uint32_t *>(s_rank + npad);
     q_phase(ph, 0);
-    // keys of positions tid, tid + 1024, ... stay in registers; the table and the counters are cleared meanwhile
+    // keys of positions tid, tid + NT, ... stay in registers; the table and the counters are cleared meanwhile
     uint32_t key[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k)
-        key[k] = to_key<IdT>(ids[min(tid + k * 1024, n - 1)]);
-    for (int i = tid; i < kQTabSize; i += 1024)
+        key[k] = to_key<IdT>(ids[max(min(tid + k * NT, n - 1), 0)]);
+    for (int i = tid; i < TS; i += NT)
         s_tab[i] = kQTabEmpty;
-    for (int i = tid; i < npad / 2 + 2; i += 1024)
+    for (int i = tid; i < npad / 2 + 2; i += NT)
         reinterpret_cast<uint32_t *>(s_cnt)[i] = 0;
     __syncthreads();
     q_phase(ph, 1);
@@ -281,9 +292,9 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         uint32_t h[7], seen[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            h[k] = q_hash(key[k]);
+            h[k] = q_hash(key[k], TBITS);
             seen[k] = key[k];
-            if (k < P && tid + k * 1024 < n) {
+            if (k < P && tid + k * NT < n) {
                 seen[k] = kQTabEmpty;
                 if (__hip_atomic_compare_exchange_strong(s_tab + h[k], &seen[k], key[k], __ATOMIC_RELAXED,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
@@ -292,10 +303,10 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         }
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            const int i = tid + k * 1024;
+            const int i = tid + k * NT;
             if (k < P && i < n) {
                 while (seen[k] != key[k]) {       // somebody else's key sits here: next slot
-                    h[k] = (h[k] + 1) & (kQTabSize - 1);
+                    h[k] = (h[k] + 1) & (TS - 1);
                     seen[k] = kQTabEmpty;
                     if (__hip_atomic_compare_exchange_strong(s_tab + h[k], &seen[k], key[k], __ATOMIC_RELAXED,
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
@@ -307,21 +318,21 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
     }
     __syncthreads();
     q_phase(ph, 2);
-    // 2. number the occupied slots (thread t: slots 8t .. 8t+7); the table then maps slot -> group
+    // 2. number the occupied slots (thread t: slots SPT t .. SPT t + SPT - 1); the table then maps slot -> group
     uint32_t U;
     {
-        uint32_t kk[8], occ = 0;
+        uint32_t kk[SPT], occ = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            kk[j] = s_tab[tid * 8 + j];
+        for (int j = 0; j < SPT; ++j) {
+            kk[j] = s_tab[tid * SPT + j];
             occ += kk[j] != kQTabEmpty;
         }
-        uint32_t g = qscan(occ, s_w, &U);
+        uint32_t g = qscan_n<NT / 64>(occ, s_w, &U, w);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < SPT; ++j) {
             if (kk[j] != kQTabEmpty) {
                 p.uniq[g] = kk[j];
-                s_tab[tid * 8 + j] = g;
+                s_tab[tid * SPT + j] = g;
                 ++g;
             }
         }
@@ -331,7 +342,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
     uint32_t lab[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-        const int i = tid + k * 1024;
+        const int i = tid + k * NT;
         lab[k] = 0;
         if (k < P && i < n) {
             lab[k] = s_tab[s_lab[i]];
@@ -398,7 +409,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         // the other waves write what is known already
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            const int i = tid + k * 1024;
+            const int i = tid + k * NT;
             if (k < P && i < n) {
                 p.keys[i] = key[k];
                 p.inverse[i] = static_cast<int32_t>(lab[k]);
@@ -409,7 +420,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
     if (w == 0 && !BUCKET) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            const int i = tid + k * 1024;
+            const int i = tid + k * NT;
             if (k < P && i < n) {
                 p.keys[i] = key[k];
                 p.inverse[i] = static_cast<int32_t>(lab[k]);
@@ -417,7 +428,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         }
     }
     q_phase(ph, 5);
-    // 4. counts -> segment starts (thread t: groups G t .. G t + G - 1, G = npad / 1024); s_cnt then holds the starts
+    // 4. counts -> segment starts (thread t: groups G t .. G t + G - 1, G = npad / NT); s_cnt then holds the starts
     {
         uint32_t c[7], sum = 0;
 #pragma unroll
@@ -427,7 +438,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
             sum += c[j];
         }
         uint32_t all;
-        uint32_t at = qscan(sum, s_w, &all);
+        uint32_t at = qscan_n<NT / 64>(sum, s_w, &all, w);
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const uint32_t g = tid * P + j;
@@ -454,7 +465,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         uint32_t q[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            const int i = tid + k * 1024;
+            const int i = tid + k * NT;
             q[k] = (k < P && i < n) ? static_cast<uint32_t>(s_cnt[lab[k]]) + s_rank[i] : 0u;
         }
         __syncthreads();      // labels, ranks and the table have been read by everyone
@@ -462,7 +473,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         uint32_t *s_key = s_tab;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            const int i = tid + k * 1024;
+            const int i = tid + k * NT;
             if (k < P && i < n) {
                 s_perm[q[k]] = static_cast<uint16_t>(i);
                 s_gq[q[k]] = static_cast<uint16_t>(lab[k]);
@@ -471,7 +482,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         }
         __syncthreads();
         bool disorder = false;
-        for (int qq = tid; qq < n; qq += 1024) {
+        for (int qq = tid; qq < n; qq += NT) {
             const uint32_t i = s_perm[qq];
             if (BUCKET) {
                 p.perm[qq] = static_cast<int32_t>(pos_map[i]);
@@ -489,7 +500,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
             p.hdr->reserved[kOrderFlagWord] = 1;
         // the first three occurrences of every key also go to the group's own words (the queue builder embeds them in
         // small items; entries beyond the group's count are never used)
-        for (uint32_t g = tid; g < U; g += 1024) {
+        for (uint32_t g = tid; g < U; g += NT) {
             const int st = s_cnt[g];
             uint32_t o0 = s_perm[min(st, n - 1)], o1 = s_perm[min(st + 1, n - 1)], o2 = s_perm[min(st + 2, n - 1)];
             if (BUCKET) {
@@ -623,16 +634,19 @@ struct QJoin {      // what every part of the join needs (passed by reference to
     uint32_t *bpcnt;                // the queue's chunk counters (they follow the item regions: queue_layout)
     uint32_t bcap_coop, bcap_wave, bcap_copy, per512, per128, per32;
     uint32_t st_base, fs_base;      // wide path: where this bucket's occurrence / destination lists start in the batch's
+    uint32_t tid, nt;               // the thread's index in its group of nt threads (the workgroup, or a quarter of it)
+    int tbits;                      // the table has 1 << tbits slots
 };
 
 // group index of `key` in the table, or 0xFFFFFFFF
 __device__ __forceinline__ uint32_t qjoin_probe(const QJoin &j, uint32_t key) {
-    uint32_t h = q_hash(key);
+    uint32_t h = q_hash(key, j.tbits);
+    const uint32_t mask = (1u << j.tbits) - 1u;
     for (;;) {
         const uint32_t e = j.s_tab[h];
         if (e == kQTabEmpty || j.s_bk[e] == key)
             return e;
-        h = (h + 1) & (kQTabSize - 1);
+        h = (h + 1) & mask;
     }
 }
 __device__ __forceinline__ uint32_t qjoin_dest(const QJoin &j, uint32_t e) {   // m | fs << 16 of lookup group e
@@ -655,20 +669,20 @@ __device__ __forceinline__ QCount qjoin_emit_one(const QJoin &j, QCount b, QEntr
     return nb;
 }
 
-// ---- part 0: groups of the batch to apply, thread t: groups t, t + 1024, ... --------------------------------------
+// ---- part 0: groups of the batch to apply, thread t of the group: groups t, t + nt, ... --------------------------------------
 template <int R0, int R1>
 __device__ __forceinline__ QCount qjoin_count_groups(const QJoin &j, QCount t) {
-    const uint32_t tid = threadIdx.x, last = static_cast<uint32_t>(max(j.Ua, 1) - 1);
+    const uint32_t tid = j.tid, last = static_cast<uint32_t>(max(j.Ua, 1) - 1);
     uint32_t ka[R1 - R0], c[R1 - R0];
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
-        const uint32_t x = min(static_cast<uint32_t>(r) * 1024u + tid, last);
+        const uint32_t x = min(static_cast<uint32_t>(r) * j.nt + tid, last);
         ka[r - R0] = j.pa.uniq[x];
         c[r - R0] = static_cast<uint32_t>(j.pa.counts[x]);
     }
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
-        if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ua) {
+        if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ua) {
             const uint32_t mf = qjoin_dest(j, qjoin_probe(j, ka[r - R0]));
             t = q_count(t, q_kind(c[r - R0], mf & 0xFFFFu, ka[r - R0] < j.rows), j.per512, j.per128, j.per32, c[r - R0]);
         }
@@ -677,11 +691,11 @@ __device__ __forceinline__ QCount qjoin_count_groups(const QJoin &j, QCount t) {
 }
 template <int R0, int R1>
 __device__ __forceinline__ QCount qjoin_emit_groups(const QJoin &j, QCount b) {
-    const uint32_t tid = threadIdx.x, last = static_cast<uint32_t>(max(j.Ua, 1) - 1);
+    const uint32_t tid = j.tid, last = static_cast<uint32_t>(max(j.Ua, 1) - 1);
     uint32_t ka[R1 - R0], cst[R1 - R0], o01[R1 - R0], o2[R1 - R0];
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
-        const uint32_t x = min(static_cast<uint32_t>(r) * 1024u + tid, last);
+        const uint32_t x = min(static_cast<uint32_t>(r) * j.nt + tid, last);
         const uint2 oc = reinterpret_cast<const uint2 *>(j.pa.occ)[x];
         ka[r - R0] = j.pa.uniq[x];
         cst[r - R0] = static_cast<uint32_t>(j.pa.counts[x]) | (static_cast<uint32_t>(j.pa.seg[x]) << 16);
@@ -690,7 +704,7 @@ __device__ __forceinline__ QCount qjoin_emit_groups(const QJoin &j, QCount b) {
     }
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
-        if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ua) {
+        if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ua) {
             const uint32_t mf = qjoin_dest(j, qjoin_probe(j, ka[r - R0]));
             b = qjoin_emit_one(j, b, j.bwave, j.bcap_wave, ka[r - R0], cst[r - R0] & 0xFFFFu, cst[r - R0] >> 16,
                                mf & 0xFFFFu, mf >> 16, o01[r - R0], o2[r - R0]);
@@ -702,33 +716,33 @@ __device__ __forceinline__ QCount qjoin_emit_groups(const QJoin &j, QCount b) {
 // ---- part 1: groups of the lookup batch, the ones the table (keys of the batch to apply) does not hold ------------
 template <int R0, int R1>
 __device__ __forceinline__ QCount qjoin_count_copies(const QJoin &j, QCount t) {
-    const uint32_t tid = threadIdx.x, last = static_cast<uint32_t>(max(j.Ug, 1) - 1);
+    const uint32_t tid = j.tid, last = static_cast<uint32_t>(max(j.Ug, 1) - 1);
     uint32_t kg[R1 - R0], m[R1 - R0];
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
-        const uint32_t y = min(static_cast<uint32_t>(r) * 1024u + tid, last);
+        const uint32_t y = min(static_cast<uint32_t>(r) * j.nt + tid, last);
         kg[r - R0] = j.pg.uniq[y];
         m[r - R0] = static_cast<uint32_t>(j.pg.counts[y]);
     }
 #pragma unroll
     for (int r = R0; r < R1; ++r)
-        if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
+        if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
             t = q_count(t, q_kind(0u, m[r - R0], kg[r - R0] < j.rows), j.per512, j.per128, j.per32, 0u);
     return t;
 }
 template <int R0, int R1>
 __device__ __forceinline__ QCount qjoin_emit_copies(const QJoin &j, QCount b) {
-    const uint32_t tid = threadIdx.x, last = static_cast<uint32_t>(max(j.Ug, 1) - 1);
+    const uint32_t tid = j.tid, last = static_cast<uint32_t>(max(j.Ug, 1) - 1);
     uint32_t kg[R1 - R0], mfs[R1 - R0];
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
-        const uint32_t y = min(static_cast<uint32_t>(r) * 1024u + tid, last);
+        const uint32_t y = min(static_cast<uint32_t>(r) * j.nt + tid, last);
         kg[r - R0] = j.pg.uniq[y];
         mfs[r - R0] = static_cast<uint32_t>(j.pg.counts[y]) | (static_cast<uint32_t>(j.pg.seg[y]) << 16);
     }
 #pragma unroll
     for (int r = R0; r < R1; ++r)
-        if (static_cast<int>(static_cast<uint32_t>(r) * 1024u + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
+        if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
             b = qjoin_emit_one(j, b, j.bcopy, j.bcap_copy, kg[r - R0], 0u, 0u, mfs[r - R0] & 0xFFFFu, mfs[r - R0] >> 16,
                                0u, 0u);
     return b;
@@ -737,17 +751,24 @@ __device__ __forceinline__ QCount qjoin_emit_copies(const QJoin &j, QCount b) {
 // WIDE: pa / pg are ONE hash bucket of two larger batches (the wide path below); the workgroup appends its items to the
 // step's queue behind those of the other buckets (one atomic add per region on the header's counters, zeroed before
 // the launch), st_base / fs_base = where the bucket's occurrence / destination lists start in the batches' lists.
-template <bool WIDE = false>
+// NT / TBITS as in qsort_finish_body: the whole workgroup joins one pair of plans, or (WIDE, buckets of at most 2,048 unique
+// keys each side) every quarter of it joins a pair of its own, side by side through the same barriers.  signal: this pair
+// counts towards the step's `wide_parts` (false: a quarter without a bucket).
+template <bool WIDE = false, int NT = 1024, int TBITS = kQTabBits>
 __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const uint64_t rows, const int width,
                                            QHeader *bqh, QEntry *bcoop, QEntry *bwave, QEntry *bcopy,
                                            const uint32_t bcap_coop, const uint32_t bcap_wave, const uint32_t bcap_copy,
                                            uint32_t *lds, uint32_t lds_bytes, const int part,
                                            unsigned long long *ph = nullptr, uint32_t *mirror = nullptr,
                                            const uint32_t st_base = 0, const uint32_t fs_base = 0,
-                                           const uint32_t epoch = 0, const uint32_t wide_parts = 0) {
-    const int tid = threadIdx.x;
+                                           const uint32_t epoch = 0, const uint32_t wide_parts = 0, const bool signal = true) {
+    constexpr int TS = 1 << TBITS;
+    const int tid = static_cast<int>(threadIdx.x) & (NT - 1), w = tid >> 6;
     q_phase(ph, 0);
     QJoin j;
+    j.tid = static_cast<uint32_t>(tid);
+    j.nt = NT;
+    j.tbits = TBITS;
     j.pa = pa;
     j.pg = pg;
     j.st_base = st_base;
@@ -759,9 +780,9 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     j.Ua = uniform(pa.n > 0 ? static_cast<int>(pa.hdr->n_unique) : 0);
     j.Ug = uniform(pg.n > 0 ? static_cast<int>(pg.hdr->n_unique) : 0);
     j.Ub = part == 0 ? j.Ug : j.Ua;
-    j.cs_res = part == 0 && static_cast<uint32_t>(kQTabSize * 4 + j.Ug * 8 + 32 * 4) <= lds_bytes;   // workgroup-uniform
+    j.cs_res = part == 0 && static_cast<uint32_t>(TS * 4 + j.Ug * 8 + 32 * 4) <= lds_bytes;   // uniform over the group
     j.s_tab = lds;
-    j.s_bk = lds + kQTabSize;
+    j.s_bk = lds + TS;
     j.s_cs = j.s_bk + j.Ub;
     j.s_w = j.s_bk + (j.cs_res ? 2 * j.Ub : j.Ub);
     j.bqh = bqh;
@@ -779,23 +800,23 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     j.per32 = (width + 31) / 32;
     // the table: keys (+ packed count / start of a lookup group) to LDS, then every key claims a slot
     const uint32_t *bkeys = part == 0 ? pg.uniq : pa.uniq;
-    for (int i = tid; i < kQTabSize; i += 1024)
+    for (int i = tid; i < TS; i += NT)
         j.s_tab[i] = kQTabEmpty;
-    for (int y = tid; y < j.Ub; y += 1024) {
+    for (int y = tid; y < j.Ub; y += NT) {
         j.s_bk[y] = bkeys[y];
         if (j.cs_res)
             j.s_cs[y] = static_cast<uint32_t>(pg.counts[y]) | (static_cast<uint32_t>(pg.seg[y]) << 16);
     }
     __syncthreads();
     q_phase(ph, 1);
-    for (int y = tid; y < j.Ub; y += 1024) {
-        uint32_t h = q_hash(j.s_bk[y]);
+    for (int y = tid; y < j.Ub; y += NT) {
+        uint32_t h = q_hash(j.s_bk[y], TBITS);
         for (;;) {
             uint32_t seen = kQTabEmpty;
             if (__hip_atomic_compare_exchange_strong(j.s_tab + h, &seen, static_cast<uint32_t>(y), __ATOMIC_RELAXED,
                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
                 break;
-            h = (h + 1) & (kQTabSize - 1);
+            h = (h + 1) & (TS - 1);
         }
     }
     __syncthreads();      // the table is complete
@@ -804,15 +825,15 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     if (part == 0) {      // workgroup-uniform everywhere below (a batch that is absent has null plan pointers)
         if (j.Ua > 0)
             t = qjoin_count_groups<0, 4>(j, t);
-        if (j.Ua > 4096)
-            t = qjoin_count_groups<4, 7>(j, t);
+        if (j.Ua > 4 * NT)
+            t = qjoin_count_groups<4, 8>(j, t);
         q_phase(ph, 3);
         uint32_t nL, nM, nS, nG;
         QCount b;
-        b.l = qscan(t.l, j.s_w, &nL);
-        b.m = qscan(t.m, j.s_w, &nM) + nL;            // queue order: long, medium, small
-        b.s = qscan(t.s, j.s_w, &nS) + nL + nM;
-        b.g = qscan(t.g, j.s_w, &nG);
+        b.l = qscan_n<NT / 64>(t.l, j.s_w, &nL, w);
+        b.m = qscan_n<NT / 64>(t.m, j.s_w, &nM, w) + nL;            // queue order: long, medium, small
+        b.s = qscan_n<NT / 64>(t.s, j.s_w, &nS, w) + nL + nM;
+        b.g = qscan_n<NT / 64>(t.g, j.s_w, &nG, w);
         if (WIDE) {
             __syncthreads();
             if (tid == 0) {
@@ -860,20 +881,20 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
         q_phase(ph, 4);
         if (j.Ua > 0)
             b = qjoin_emit_groups<0, 3>(j, b);
-        if (j.Ua > 3072)
+        if (j.Ua > 3 * NT)
             b = qjoin_emit_groups<3, 5>(j, b);
-        if (j.Ua > 5120)
-            b = qjoin_emit_groups<5, 7>(j, b);
+        if (j.Ua > 5 * NT)
+            b = qjoin_emit_groups<5, 8>(j, b);
     } else {
         if (j.Ug > 0)
             t = qjoin_count_copies<0, 4>(j, t);
-        if (j.Ug > 4096)
-            t = qjoin_count_copies<4, 7>(j, t);
+        if (j.Ug > 4 * NT)
+            t = qjoin_count_copies<4, 8>(j, t);
         q_phase(ph, 3);
         uint32_t nM, nS;
         QCount b{0u, 0u, 0u, 0u};
-        b.m = qscan(t.m, j.s_w, &nM);                 // copies: medium (many destinations), then small / zero
-        b.s = qscan(t.s, j.s_w, &nS) + nM;
+        b.m = qscan_n<NT / 64>(t.m, j.s_w, &nM, w);                 // copies: medium (many destinations), then small / zero
+        b.s = qscan_n<NT / 64>(t.s, j.s_w, &nS, w) + nM;
         if (WIDE) {
             __syncthreads();
             if (tid == 0) {
@@ -907,8 +928,8 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
         q_phase(ph, 4);
         if (j.Ug > 0)
             b = qjoin_emit_copies<0, 4>(j, b);
-        if (j.Ug > 4096)
-            b = qjoin_emit_copies<4, 7>(j, b);
+        if (j.Ug > 4 * NT)
+            b = qjoin_emit_copies<4, 8>(j, b);
     }
     q_phase(ph, 5);
     // the queue is complete once every builder workgroup has passed this point: items visible device-wide (release), then
@@ -927,7 +948,8 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             }
             __builtin_amdgcn_s_waitcnt(0);
             __hip_atomic_store(part == 0 ? &bqh->epoch_wave : &bqh->epoch_copy, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (__hip_atomic_fetch_add(&bqh->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == wide_parts) {
+        } else if (signal &&
+                   __hip_atomic_fetch_add(&bqh->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == wide_parts) {
             __hip_atomic_store(&bqh->epoch_wave, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&bqh->epoch_copy, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mirror) {       // every bucket has added its items: the counts are final (+ 1: 0 = not built yet)
@@ -1851,7 +1873,7 @@ constexpr int64_t kQBigMax = 1 << 17;
 constexpr int kQBigTilesMax = static_cast<int>(kQBigMax / kQBigTile);      // 32
 
 static inline int qbig_buckets(int64_t n_cap) {     // ~1,024 ids per bucket on average: room for ~6,000 occurrences of hot keys
-    int p = 2;
+    int p = 4;      // (a multiple of four: a workgroup takes four buckets)
     while (p < kQBigBucketsMax && static_cast<int64_t>(p) * 1024 < n_cap)
         p *= 2;
     return p;
@@ -2034,22 +2056,44 @@ __device__ __forceinline__ QPlan qbig_slice(const QBigRef &r, int p) {
     return q;
 }
 
-template <bool RANK_ATOMIC>
-__global__ __launch_bounds__(1024, 4) void qbplan_kernel(const QBigBatch b) {
+// One workgroup per FOUR buckets of a batch.  Buckets of at most kQSubMax ids (all but those of hot keys: ~830 ids on average)
+// are grouped side by side, a quarter of the workgroup each -- a bucket's ~800 ids keep 256 threads busy, not 1024, and a
+// 1024-thread workgroup per bucket would hold a quarter of the chip's wave slots for the steps beside it; if one of the four
+// is larger, the workgroup takes them one after the other with all its threads.
+// (Two instantiations, launched one after the other over the same grid: QUARTERS takes the workgroups whose four buckets are
+// small, the other one the rest -- one kernel with both bodies needs more registers than leave room for the steps' waves.)
+template <bool RANK_ATOMIC, bool QUARTERS>
+__global__ __launch_bounds__(1024, 8) void qbplan_kernel(const QBigBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const QBigRef &r = b.r[blockIdx.y];
-    const int p = static_cast<int>(blockIdx.x);
-    const QPlan q = qbig_slice(r, p);
-    if (q.n == 0 || q.n > kQMax) {      // (an oversized bucket: the partition raised meta[0]; the queue builder hands it on)
-        if (threadIdx.x == 0) {
-            q.hdr->n_unique = 0;
-            q.hdr->reserved[kGroupedFlagWord] = 1;
-            q.hdr->reserved[kOrderFlagWord] = 0;
-            q.seg[0] = 0;
-        }
+    const int p0 = static_cast<int>(blockIdx.x) * 4;
+    uint32_t largest = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        largest = max(largest, uniform(r.boff[p0 + s + 1]) - uniform(r.boff[p0 + s]));
+    if ((largest <= static_cast<uint32_t>(kQSubMax)) != QUARTERS)
+        return;
+    if (QUARTERS) {
+        const int sub = static_cast<int>(threadIdx.x) / kQSubThreads;
+        const QPlan q = qbig_slice(r, p0 + sub);
+        qsort_finish_body<uint32_t, RANK_ATOMIC, true, kQSubThreads, kQSubTabBits>(
+            q.keys, q, s_dyn + sub * (kQSubPlanLds / 4), nullptr, r.bpos + (q.keys - r.bkeys));
         return;
     }
-    qsort_finish_body<uint32_t, RANK_ATOMIC, true>(q.keys, q, s_dyn, nullptr, r.bpos + (q.keys - r.bkeys));
+    for (int s = 0; s < 4; ++s) {
+        const QPlan q = qbig_slice(r, p0 + s);
+        if (q.n == 0 || q.n > kQMax) {      // (an oversized bucket: the partition raised meta[0]; the queue builder hands it on)
+            if (threadIdx.x == 0) {
+                q.hdr->n_unique = 0;
+                q.hdr->reserved[kGroupedFlagWord] = 1;
+                q.hdr->reserved[kOrderFlagWord] = 0;
+                q.seg[0] = 0;
+            }
+            continue;
+        }
+        __syncthreads();      // the LDS of the bucket before
+        qsort_finish_body<uint32_t, RANK_ATOMIC, true>(q.keys, q, s_dyn, nullptr, r.bpos + (q.keys - r.bkeys));
+    }
 }
 
 struct QBigZero {
@@ -2070,30 +2114,63 @@ struct QBigJoinBatch {
     uint32_t *mirror[kQJoinBatch];
     uint32_t epoch[kQJoinBatch];
 };
-__global__ __launch_bounds__(1024, 4) void qbqueue_kernel(const QBigJoinBatch b) {
+constexpr int kQSubJoinKeys = 8 * kQSubThreads;        // unique keys per side a quarter-workgroup joins (2,048)
+constexpr size_t kQSubJoinLds = (size_t(1) << kQSubTabBits) * 4 + size_t(kQSubJoinKeys) * 8 + 32 * 4;      // 32,896
+static_assert(kQSubJoinLds % 128 == 0, "the groups' LDS regions stay aligned");
+// One workgroup per (step, part, FOUR buckets): quarters side by side where every bucket of the four has at most
+// kQSubJoinKeys unique keys on either side, else one after the other (see qbplan_kernel).
+template <bool QUARTERS>
+__global__ __launch_bounds__(1024, 8) void qbqueue_kernel(const QBigJoinBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    const int i = static_cast<int>(blockIdx.y), p = static_cast<int>(blockIdx.x >> 1), part = static_cast<int>(blockIdx.x & 1);
-    QPlan pa, pg;
-    memset(&pa, 0, sizeof(pa));
-    memset(&pg, 0, sizeof(pg));
-    uint32_t st_base = 0, fs_base = 0, bad = 0;
+    const int i = static_cast<int>(blockIdx.y), p0 = static_cast<int>(blockIdx.x >> 1) * 4, part = static_cast<int>(blockIdx.x & 1);
+    uint32_t bad = 0, most = 0;
     if (b.a[i].n > 0) {
-        pa = qbig_slice(b.a[i], p);
-        st_base = uniform(b.a[i].boff[p]);
         bad |= b.a[i].meta[0];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            most = max(most, uniform(static_cast<uint32_t>(b.a[i].bhdr[p0 + s].n_unique)));
     }
     if (b.g[i].n > 0) {
-        pg = qbig_slice(b.g[i], p);
-        fs_base = uniform(b.g[i].boff[p]);
         bad |= b.g[i].meta[0];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            most = max(most, uniform(static_cast<uint32_t>(b.g[i].bhdr[p0 + s].n_unique)));
     }
-    if (bad && p == 0 && part == 0 && threadIdx.x == 0) {       // a bucket beyond kQMax ids: its keys are in no queue
+    if (bad && p0 == 0 && part == 0 && threadIdx.x == 0) {       // a bucket beyond kQMax ids: its keys are in no queue
         atomicOr(&b.qh[i]->overflow_wave, 4u);
         if (b.mirror[i])
             b.mirror[i][3] = 4u;
     }
-    qjoin_body<true>(pa, pg, b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave, b.cap_copy,
-                     s_dyn, b.lds_bytes, part, nullptr, b.mirror[i], st_base, fs_base, b.epoch[i], 2u * static_cast<uint32_t>(b.P));
+    constexpr bool quarters = QUARTERS;
+    if ((most <= static_cast<uint32_t>(kQSubJoinKeys)) != QUARTERS)
+        return;
+    const int sub = quarters ? static_cast<int>(threadIdx.x) / kQSubThreads : 0;
+    for (int s = 0; s < (quarters ? 1 : 4); ++s) {
+        const int p = p0 + (quarters ? sub : s);
+        QPlan pa, pg;
+        memset(&pa, 0, sizeof(pa));
+        memset(&pg, 0, sizeof(pg));
+        uint32_t st_base = 0, fs_base = 0;
+        if (b.a[i].n > 0) {
+            pa = qbig_slice(b.a[i], p);
+            st_base = uniform(b.a[i].boff[p]);
+        }
+        if (b.g[i].n > 0) {
+            pg = qbig_slice(b.g[i], p);
+            fs_base = uniform(b.g[i].boff[p]);
+        }
+        if (quarters) {
+            qjoin_body<true, kQSubThreads, kQSubTabBits>(pa, pg, b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i],
+                                                         b.cap_coop, b.cap_wave, b.cap_copy, s_dyn + sub * (kQSubJoinLds / 4),
+                                                         static_cast<uint32_t>(kQSubJoinLds), part, nullptr, b.mirror[i], st_base,
+                                                         fs_base, b.epoch[i], 2u * static_cast<uint32_t>(b.P));
+        } else {
+            __syncthreads();      // the LDS of the bucket before
+            qjoin_body<true>(pa, pg, b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave,
+                             b.cap_copy, s_dyn, b.lds_bytes, part, nullptr, b.mirror[i], st_base, fs_base, b.epoch[i],
+                             2u * static_cast<uint32_t>(b.P));
+        }
+    }
 }
 
 template <typename IdT>
@@ -2103,8 +2180,10 @@ static int qbig_plan_batch(const IdT *const *ids, const int64_t *n, void *const 
     HA_REQUIRE(n_cap >= 1 && n_cap <= kQBigMax, "ha_qbig_plan_batch: at most %lld ids per batch", (long long)kQBigMax);
     static DeviceOnce lds_allowed;
     if (lds_allowed.run([]() -> int {
-            HA_ALLOW_LDS((qbplan_kernel<true>), 160 * 1024);
-            HA_ALLOW_LDS((qbplan_kernel<false>), 160 * 1024);
+            HA_ALLOW_LDS((qbplan_kernel<true, true>), 160 * 1024);
+            HA_ALLOW_LDS((qbplan_kernel<false, true>), 160 * 1024);
+            HA_ALLOW_LDS((qbplan_kernel<true, false>), 160 * 1024);
+            HA_ALLOW_LDS((qbplan_kernel<false, false>), 160 * 1024);
             return 0;
         }))
         return -1;
@@ -2135,11 +2214,13 @@ static int qbig_plan_batch(const IdT *const *ids, const int64_t *n, void *const 
         HA_LAUNCH_CHECK();
         hipLaunchKernelGGL((qbpart_scatter_kernel<IdT>), dim3(tiles, b.count), dim3(1024), 0, stream, b);
         HA_LAUNCH_CHECK();
-        const size_t lds = qsort_lds_bytes(kQMax);
-        if (ordered)
-            hipLaunchKernelGGL((qbplan_kernel<true>), dim3(P, b.count), dim3(1024), lds, stream, b);
-        else
-            hipLaunchKernelGGL((qbplan_kernel<false>), dim3(P, b.count), dim3(1024), lds, stream, b);
+        if (ordered) {
+            hipLaunchKernelGGL((qbplan_kernel<true, true>), dim3(P / 4, b.count), dim3(1024), 4 * kQSubPlanLds, stream, b);
+            hipLaunchKernelGGL((qbplan_kernel<true, false>), dim3(P / 4, b.count), dim3(1024), qsort_lds_bytes(kQMax), stream, b);
+        } else {
+            hipLaunchKernelGGL((qbplan_kernel<false, true>), dim3(P / 4, b.count), dim3(1024), 4 * kQSubPlanLds, stream, b);
+            hipLaunchKernelGGL((qbplan_kernel<false, false>), dim3(P / 4, b.count), dim3(1024), qsort_lds_bytes(kQMax), stream, b);
+        }
         HA_LAUNCH_CHECK();
     }
     return 0;
@@ -2154,7 +2235,8 @@ static int qbig_queue_batch(int64_t rows, int64_t width, void *const *ws_a, cons
     HA_REQUIRE(n_cap >= 1 && n_cap <= kQBigMax, "ha_qbig_queue_batch: bad capacity");
     static DeviceOnce lds_allowed;
     if (lds_allowed.run([]() -> int {
-            HA_ALLOW_LDS(qbqueue_kernel, 160 * 1024);
+            HA_ALLOW_LDS(qbqueue_kernel<true>, 160 * 1024);
+            HA_ALLOW_LDS(qbqueue_kernel<false>, 160 * 1024);
             return 0;
         }))
         return -1;
@@ -2196,11 +2278,12 @@ static int qbig_queue_batch(int64_t rows, int64_t width, void *const *ws_a, cons
         if (b.count == 0)
             continue;
         const size_t need = qjoin_lds_bytes(kQMax, kQMax), res = qjoin_lds_resident_bytes(kQMax);
-        const size_t lds = need > res ? need : res;
-        b.lds_bytes = static_cast<uint32_t>(lds);
+        const size_t lds1 = need > res ? need : res;
+        b.lds_bytes = static_cast<uint32_t>(lds1);      // (what a whole-workgroup join has; the launch also fits four quarters)
         hipLaunchKernelGGL(qbzero_kernel, dim3(z.count), dim3(64), 0, stream, z);
         HA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(qbqueue_kernel, dim3(2 * P, b.count), dim3(1024), lds, stream, b);
+        hipLaunchKernelGGL(qbqueue_kernel<true>, dim3(2 * (P / 4), b.count), dim3(1024), 4 * kQSubJoinLds, stream, b);
+        hipLaunchKernelGGL(qbqueue_kernel<false>, dim3(2 * (P / 4), b.count), dim3(1024), lds1, stream, b);
         HA_LAUNCH_CHECK();
     }
     return 0;
