@@ -295,6 +295,10 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
             h[k] = q_hash(key[k], TBITS);
             seen[k] = key[k];
             if (k < P && tid + k * NT < n) {
+                // (a bucket of the wide path may hold one key thousands of times: same-address atomics are served one
+                // lane at a time, a plain read of a slot that already holds the key is not)
+                if (BUCKET && k > 0 && s_tab[h[k]] == key[k])
+                    continue;
                 seen[k] = kQTabEmpty;
                 if (__hip_atomic_compare_exchange_strong(s_tab + h[k], &seen[k], key[k], __ATOMIC_RELAXED,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
@@ -1895,6 +1899,7 @@ struct QBigRef {        // one batch's wide-plan workspace (device pointers)
     int32_t *seg;       // [n + P + 1] bucket p's segment starts (local to the bucket) from boff[p] + p
     uint32_t *occ;      // [2 n] first occurrences per group (q_occ_pack)
     PlanHeader *bhdr;   // [P]
+    PlanHeader *dummy;  // a header + a few words nobody reads (a quarter-workgroup without a bucket of its own writes here)
 };
 static inline size_t qbig_layout(void *ws, int64_t n_cap, QBigRef *r) {
     char *b = static_cast<char *>(ws);
@@ -1919,6 +1924,7 @@ static inline size_t qbig_layout(void *ws, int64_t n_cap, QBigRef *r) {
     t.seg = reinterpret_cast<int32_t *>(take(n4 + (P + 1) * 4));
     t.occ = reinterpret_cast<uint32_t *>(take(2 * n4));
     t.bhdr = reinterpret_cast<PlanHeader *>(take(static_cast<size_t>(P) * sizeof(PlanHeader)));
+    t.dummy = reinterpret_cast<PlanHeader *>(take(2 * sizeof(PlanHeader)));
     if (r)
         *r = t;
     return off;
@@ -2056,44 +2062,41 @@ __device__ __forceinline__ QPlan qbig_slice(const QBigRef &r, int p) {
     return q;
 }
 
-// One workgroup per FOUR buckets of a batch.  Buckets of at most kQSubMax ids (all but those of hot keys: ~830 ids on average)
-// are grouped side by side, a quarter of the workgroup each -- a bucket's ~800 ids keep 256 threads busy, not 1024, and a
-// 1024-thread workgroup per bucket would hold a quarter of the chip's wave slots for the steps beside it; if one of the four
-// is larger, the workgroup takes them one after the other with all its threads.
+// Buckets of at most kQSubMax ids (all but those of hot keys: ~830 ids on average) are grouped FOUR to a workgroup, side by
+// side, a quarter of its threads each -- a bucket's ~800 ids keep 256 threads busy, not 1024, and the preparation runs beside
+// the steps.  The larger ones (a key with thousands of occurrences) get a workgroup each from a second launch.
 // (Two instantiations, launched one after the other over the same grid: QUARTERS takes the workgroups whose four buckets are
 // small, the other one the rest -- one kernel with both bodies needs more registers than leave room for the steps' waves.)
 template <bool RANK_ATOMIC, bool QUARTERS>
 __global__ __launch_bounds__(1024, 8) void qbplan_kernel(const QBigBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const QBigRef &r = b.r[blockIdx.y];
-    const int p0 = static_cast<int>(blockIdx.x) * 4;
-    uint32_t largest = 0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        largest = max(largest, uniform(r.boff[p0 + s + 1]) - uniform(r.boff[p0 + s]));
-    if ((largest <= static_cast<uint32_t>(kQSubMax)) != QUARTERS)
-        return;
-    if (QUARTERS) {
+    if (QUARTERS) {     // grid: P / 4 workgroups per batch; a quarter whose bucket is a large one plans an empty batch instead
         const int sub = static_cast<int>(threadIdx.x) / kQSubThreads;
-        const QPlan q = qbig_slice(r, p0 + sub);
+        QPlan q = qbig_slice(r, static_cast<int>(blockIdx.x) * 4 + sub);
+        if (q.n > kQSubMax) {
+            q.n = 0;
+            q.hdr = r.dummy;
+            q.seg = reinterpret_cast<int32_t *>(r.dummy + 1);
+        }
         qsort_finish_body<uint32_t, RANK_ATOMIC, true, kQSubThreads, kQSubTabBits>(
             q.keys, q, s_dyn + sub * (kQSubPlanLds / 4), nullptr, r.bpos + (q.keys - r.bkeys));
         return;
     }
-    for (int s = 0; s < 4; ++s) {
-        const QPlan q = qbig_slice(r, p0 + s);
-        if (q.n == 0 || q.n > kQMax) {      // (an oversized bucket: the partition raised meta[0]; the queue builder hands it on)
-            if (threadIdx.x == 0) {
-                q.hdr->n_unique = 0;
-                q.hdr->reserved[kGroupedFlagWord] = 1;
-                q.hdr->reserved[kOrderFlagWord] = 0;
-                q.seg[0] = 0;
-            }
-            continue;
+    // grid: P workgroups per batch, the ones with a small bucket leave at once
+    const QPlan q = qbig_slice(r, static_cast<int>(blockIdx.x));
+    if (q.n <= kQSubMax)
+        return;
+    if (q.n > kQMax) {      // (an oversized bucket: the partition raised meta[0]; the queue builder hands it on)
+        if (threadIdx.x == 0) {
+            q.hdr->n_unique = 0;
+            q.hdr->reserved[kGroupedFlagWord] = 1;
+            q.hdr->reserved[kOrderFlagWord] = 0;
+            q.seg[0] = 0;
         }
-        __syncthreads();      // the LDS of the bucket before
-        qsort_finish_body<uint32_t, RANK_ATOMIC, true>(q.keys, q, s_dyn, nullptr, r.bpos + (q.keys - r.bkeys));
+        return;
     }
+    qsort_finish_body<uint32_t, RANK_ATOMIC, true>(q.keys, q, s_dyn, nullptr, r.bpos + (q.keys - r.bkeys));
 }
 
 struct QBigZero {
@@ -2216,10 +2219,10 @@ static int qbig_plan_batch(const IdT *const *ids, const int64_t *n, void *const 
         HA_LAUNCH_CHECK();
         if (ordered) {
             hipLaunchKernelGGL((qbplan_kernel<true, true>), dim3(P / 4, b.count), dim3(1024), 4 * kQSubPlanLds, stream, b);
-            hipLaunchKernelGGL((qbplan_kernel<true, false>), dim3(P / 4, b.count), dim3(1024), qsort_lds_bytes(kQMax), stream, b);
+            hipLaunchKernelGGL((qbplan_kernel<true, false>), dim3(P, b.count), dim3(1024), qsort_lds_bytes(kQMax), stream, b);
         } else {
             hipLaunchKernelGGL((qbplan_kernel<false, true>), dim3(P / 4, b.count), dim3(1024), 4 * kQSubPlanLds, stream, b);
-            hipLaunchKernelGGL((qbplan_kernel<false, false>), dim3(P / 4, b.count), dim3(1024), qsort_lds_bytes(kQMax), stream, b);
+            hipLaunchKernelGGL((qbplan_kernel<false, false>), dim3(P, b.count), dim3(1024), qsort_lds_bytes(kQMax), stream, b);
         }
         HA_LAUNCH_CHECK();
     }
