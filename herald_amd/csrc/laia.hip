@@ -585,8 +585,9 @@ __global__ __launch_bounds__(128) void laia_topk_assign_kernel(const int32_t *__
 // row -- named by thousands of samples of a batch -- shows up many times per wave.  Every distinct bit of a wave is set
 // by one lane (leader loop over the distinct values), and only if a look at the word says it is not set yet: a few
 // atomics per hot row and batch instead of thousands on one address.
-__device__ __forceinline__ bool laia_bit_leader(unsigned long long b, bool on) {
-    // leader = the lowest lane of every distinct value (register-only loop)
+__device__ __forceinline__ void laia_set_bits(unsigned long long *__restrict__ bits, unsigned long long *__restrict__ sum,
+                                              uint32_t *__restrict__ nset, unsigned long long b, bool on) {
+    // leader = the lowest lane of every distinct value (register-only loop), then all leaders go to memory at once
     unsigned long long todo = __ballot(on);
     bool leader = false;
     while (todo) {
@@ -596,21 +597,15 @@ __device__ __forceinline__ bool laia_bit_leader(unsigned long long b, bool on) {
         todo &= ~same;
         leader = leader || static_cast<int>(threadIdx.x & 63) == first;
     }
-    return leader;
-}
-// the bookkeeping behind a bit this lane set (old = the word before): nobody waits for these two
-__device__ __forceinline__ void laia_bit_was_set(unsigned long long *__restrict__ sum, uint32_t *__restrict__ nset,
-                                                 unsigned long long b, unsigned long long old) {
-    if (old == 0)
-        atomicOr(&sum[b >> 12], 1ull << ((b >> 6) & 63));
-    if (!((old >> (b & 63)) & 1ull))
-        atomicAdd(&nset[b >> 12], 1u);      // bits set below this summary word: what the compaction scans
+    if (leader && !((__atomic_load_n(&bits[b >> 6], __ATOMIC_RELAXED) >> (b & 63)) & 1ull)) {
+        const unsigned long long old = atomicOr(&bits[b >> 6], 1ull << (b & 63));
+        if (old == 0)
+            atomicOr(&sum[b >> 12], 1ull << ((b >> 6) & 63));
+        if (!((old >> (b & 63)) & 1ull))
+            atomicAdd(&nset[b >> 12], 1u);      // bits set below this summary word: what the compaction scans
+    }
 }
 
-// The touch bit and the plan bits of up to four workers go to memory TOGETHER: all looks at the words first, then all the
-// atomics of the bits not set yet, then the (unawaited) bookkeeping -- two memory round trips per group of five sets instead
-// of two per set (the kernel is a chain of round trips: 35 us -> see profiles/r04).
-constexpr int kLaiaBitGroup = 4;
 __global__ __launch_bounds__(256) void laia_bits_kernel(const uint32_t *__restrict__ samples, long long S, int T,
                                                         long long start, int B, int W,
                                                         const unsigned long long *__restrict__ mask,
@@ -639,35 +634,10 @@ __global__ __launch_bounds__(256) void laia_bits_kernel(const uint32_t *__restri
             // w's OWN samples that w holds valid (topk_scheduler.cc:468-500)
             m = live ? (own_plan ? (mask[i * T + j] & (1ull << ow)) : (mask[i * T + j] & ~(1ull << ow))) : 0ull;
         }
-        for (int w0 = 0; w0 < W || w0 == 0; w0 += kLaiaBitGroup) {
-            // set 0 of the first group: the touch bit (owner of the sample, row); sets 1..4: the plan bits of workers w0..w0+3
-            unsigned long long b[kLaiaBitGroup + 1], word[kLaiaBitGroup + 1];
-            bool lead[kLaiaBitGroup + 1];
-            b[0] = static_cast<unsigned long long>(ow) * Rpad + emb;
-            lead[0] = w0 == 0 && laia_bit_leader(b[0], live);
-#pragma unroll
-            for (int k = 0; k < kLaiaBitGroup; ++k) {
-                const int w = w0 + k;
-                const bool on = w < W && ((m >> w) & 1ull) != 0;
-                b[k + 1] = static_cast<unsigned long long>(w < W ? w : 0) * Rpad + emb;
-                lead[k + 1] = __ballot(on) != 0 && laia_bit_leader(b[k + 1], on);      // (wave-uniform test first)
-            }
-#pragma unroll
-            for (int k = 0; k <= kLaiaBitGroup; ++k) {
-                const unsigned long long *src = k == 0 ? tbits : pbits;
-                word[k] = lead[k] ? __atomic_load_n(&src[b[k] >> 6], __ATOMIC_RELAXED) : ~0ull;
-            }
-#pragma unroll
-            for (int k = 0; k <= kLaiaBitGroup; ++k) {
-                lead[k] = lead[k] && !((word[k] >> (b[k] & 63)) & 1ull);
-                if (lead[k])
-                    word[k] = atomicOr(&(k == 0 ? tbits : pbits)[b[k] >> 6], 1ull << (b[k] & 63));
-            }
-#pragma unroll
-            for (int k = 0; k <= kLaiaBitGroup; ++k)
-                if (lead[k])
-                    laia_bit_was_set(k == 0 ? tsum : psum, k == 0 ? tnset : pnset, b[k], word[k]);
-        }
+        laia_set_bits(tbits, tsum, tnset, static_cast<unsigned long long>(ow) * Rpad + emb, live);
+        for (int w = 0; w < W; ++w)
+            if (__ballot((m >> w) & 1ull))       // wave-uniform: some lane names worker w
+                laia_set_bits(pbits, psum, pnset, static_cast<unsigned long long>(w) * Rpad + emb, ((m >> w) & 1ull) != 0);
     }
 }
 
