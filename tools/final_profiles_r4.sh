@@ -29,8 +29,13 @@ python3 bench.py --engine handoff --no-cpu-baseline $B 2>/dev/null | grep '^{' >
 python3 tools/qstep_timeline.py 2>&1 | grep -v amdgpu > $O/summary/timeline_qapply.txt
 tools/_bin/floor_bench 16 > $O/summary/floor_bench.txt 2>&1
 for sh in "4096 128" "1024 512"; do set -- $sh
-  BATCH=$1 WIDTH=$2 python3 tools/shape_bench.py 2>/dev/null > $O/summary/shape_bs$1_d$2.txt
+  ALONE=1 BATCH=$1 WIDTH=$2 python3 tools/shape_bench.py 2>/dev/null > $O/summary/shape_bs$1_d$2.txt
 done
+# ---- the laia scheduler's global batch by kernel ----
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/laia_stats -o laia -- python3 $R/tools/laia_profile.py > $O/laia_stats.log 2>&1
+f=$(find $O/laia_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/summary/laia_kernel_stats.csv
+cd $R
 # ---- the sharded step at world size 1 (the N>1 code path on one GPU), per-shape PMC ----
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29633 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 HA_FORCE_SHARDED=1
 cd /tmp
