@@ -146,21 +146,6 @@ def test_qstep_stream_small_tables(dev, width, rows, n, mode):
     _run_stream(dev, table0, batches, grads, 0.05, mode=mode)
 
 
-def test_qstep_with_the_preparation_confined_to_a_share_of_the_compute_units(dev, monkeypatch):
-    """HA_QSIDE_CUS: the preparation stream is one created with a compute-unit mask (ha_stream_create_cu_share) -- the same
-    stream of results, narrow and wide batches."""
-    monkeypatch.setenv("HA_QSIDE_CUS", "4")
-    rng = np.random.default_rng(77)
-    for rows, n, width in ((5000, 6656, 64), (300_000, 20_000, 32)):
-        table0 = rng.standard_normal((rows, width), dtype=np.float32)
-        steps = 7
-        batches = [np.minimum(rng.zipf(1.2, size=n) - 1, rows - 1) if k % 2 else rng.integers(0, rows, size=n)
-                   for k in range(steps)]
-        grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
-        pipe = _run_stream(dev, table0, batches, grads, 0.05, mode=(True, 2, "flags"), check_plans=n <= 7168)
-        assert pipe._side_raw is not None
-
-
 def test_qstep_all_below_16_occurrences_is_the_reference_bit_for_bit(dev):
     """No key reaches 16 occurrences (ten keys have exactly 15): the whole stream equals the reference's serial
     chain bit for bit (_run_stream compares every row without a long run with assert_array_equal)."""
