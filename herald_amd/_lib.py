@@ -113,10 +113,6 @@ def _declare(L):
     L.ha_qstep_init.argtypes = []
     L.ha_event_create.restype = vp
     L.ha_event_create.argtypes = []
-    L.ha_stream_create_cu_share.restype = vp
-    L.ha_stream_create_cu_share.argtypes = [c.c_int]
-    L.ha_stream_destroy.restype = c.c_int
-    L.ha_stream_destroy.argtypes = [vp]
     L.ha_qbig_max_ids.restype = i64
     L.ha_qbig_max_ids.argtypes = []
     L.ha_qbig_plan_bytes.restype = sz

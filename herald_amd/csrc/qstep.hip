@@ -2372,32 +2372,6 @@ extern "C" void *ha_event_create(void) {
         return nullptr;
     return e;
 }
-// A stream whose work is placed on a subset of the compute units: of every `one_in` consecutive groups of eight units, the
-// first (whatever the numbering of units over the XCDs is -- contiguous per XCD or interleaved --, every XCD contributes the
-// same share).  For work that runs BESIDE a bandwidth-bound stream and should crowd a part of the chip, not all of it
-// (ops.QueueStepPipeline's preparation stream, HA_QSIDE_CUS).  Returns NULL on failure.
-extern "C" void *ha_stream_create_cu_share(int one_in) {
-    if (one_in < 1 || one_in > 16)
-        return nullptr;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus <= 0 || cus > 1024)
-        return nullptr;
-    uint32_t mask[32];
-    memset(mask, 0, sizeof(mask));
-    for (int i = 0; i < cus; ++i)
-        if ((i / 8) % one_in == 0)
-            mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t st = nullptr;
-    if (hipExtStreamCreateWithCUMask(&st, static_cast<uint32_t>((cus + 31) / 32), mask) != hipSuccess)
-        return nullptr;
-    return st;
-}
-extern "C" int ha_stream_destroy(void *stream) {
-    if (stream)
-        HA_CHECK_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
-    return 0;
-}
 extern "C" int ha_event_destroy(void *event) {
     if (event)
         HA_CHECK_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));

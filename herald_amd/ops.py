@@ -835,17 +835,6 @@ class QueueStepPipeline:
             except Exception:      # noqa: BLE001
                 side_prio = 0
         self.side = torch.cuda.Stream(device=self.device, priority=side_prio) if self.overlap else None
-        # HA_QSIDE_CUS=k: the preparation is confined to one in k of the compute units of every XCD (A/B knob: its
-        # workgroups then crowd a part of the chip instead of all of it)
-        self._side_raw = None
-        share = int(os.environ.get("HA_QSIDE_CUS", "0") or 0)
-        if self.overlap and share > 1:
-            with torch.cuda.device(self.device):
-                raw = L.ha_stream_create_cu_share(share)
-            if not raw:
-                raise RuntimeError("ha_stream_create_cu_share(%d) failed" % share)
-            self._side_raw = raw
-            self.side = torch.cuda.ExternalStream(raw, device=self.device)
         # {wave items, workgroup items, copy items} (+ 1; 0 = not built yet) of the queue of step c, written to pinned host
         # memory by the launch that builds it, in a ring long enough that a build still in flight cannot write into the
         # slot of a later step: queues are built a block ahead, so the host usually knows the numbers when it enqueues

@@ -553,10 +553,6 @@ int ha_qqueue_batch_counts(int64_t rows, int64_t width, void *const *plans_a, co
  * behind work of the apply's stream any more). */
 void *ha_event_create(void);
 int ha_event_destroy(void *event);
-/* A stream confined to one in `one_in` of the compute units of every XCD (hipExtStreamCreateWithCUMask): for the preparation
- * beside a bandwidth-bound stream of steps.  NULL on failure; ha_stream_destroy frees it. */
-void *ha_stream_create_cu_share(int one_in);
-int ha_stream_destroy(void *stream);
 int ha_event_record(void *event, ha_stream_t stream);
 int ha_stream_wait_event(ha_stream_t stream, void *event);
 int ha_qqueue_batch_epochs(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
