@@ -178,11 +178,6 @@ struct QArgs {
     float *out;
     int ncoop, nworker;
     uint32_t epoch;            // 0: no check; else the tag queue `qh` must carry before an item is read
-    // the NEXT launch's queue (may be NULL): the table rows its copy items will read are fetched by this launch's waves once
-    // their own item is done -- they are the rows no earlier launch touched (HA_QPREFETCH=1; an experiment)
-    const QHeader *pf_qh;
-    const QEntry *pf_copy;
-    uint32_t pf_epoch, pf_cap;
     uint32_t *err;             // pinned host word raised (8) when the queue never became ready (may be NULL)
     unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind} per wave
 };
@@ -1557,20 +1552,6 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
             else
                 q_small(a, it);
         }
-        if (a.pf_qh != nullptr && a.pf_qh->epoch_copy == a.pf_epoch) {
-            const uint32_t np = min(a.pf_qh->n_copy, a.pf_cap);
-            const uint32_t e = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv;
-            if (e < np) {
-                const uint32_t key = uniform(a.pf_copy[e].w[1]);
-                if (key < a.rows) {
-                    const float *row = a.table + static_cast<uint64_t>(key) * static_cast<uint64_t>(a.width);
-                    for (int col = lane_id() * 4; col < a.width; col += 256) {
-                        const float4v v = *reinterpret_cast<const float4v *>(row + col);
-                        asm volatile("" ::"v"(v));
-                    }
-                }
-            }
-        }
     }
     if (a.dbg) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -1782,18 +1763,17 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
                         float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
                         int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg = nullptr,
                         int64_t wave_items = -1, uint32_t epoch = 0, uint32_t *err = nullptr, hipEvent_t done = nullptr,
-                        int64_t coop_items = -1, const void *queue_next = nullptr, uint32_t epoch_next = 0);
+                        int64_t coop_items = -1);
 
 static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                   void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
                   hipStream_t stream, unsigned long long *dbg = nullptr, int64_t wave_items = -1, uint32_t epoch = 0,
-                  uint32_t *err = nullptr, hipEvent_t done = nullptr, const void *queue_next = nullptr,
-                  uint32_t epoch_next = 0) {
+                  uint32_t *err = nullptr, hipEvent_t done = nullptr) {
     HA_REQUIRE(n_cur >= 0 && n_next >= 0 && (n_cur == 0 || plan_cur) && (n_next == 0 || plan_next),
                "ha_qapply: a batch needs its plan");
     return qapply_lists(table, rows, width, n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr, n_cur, grads, lr,
                         n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr, n_next, next_out, queue_cur, queue_n_cap,
-                        kQMax, stream, dbg, wave_items, epoch, err, done, -1, queue_next, epoch_next);
+                        kQMax, stream, dbg, wave_items, epoch, err, done);
 }
 
 // perm_cur / perm_next: the occurrence lists of the batch to apply / the destination lists of the batch to look up (what
@@ -1801,8 +1781,7 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
 static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t *perm_cur, int64_t n_cur, const float *grads,
                         float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
                         int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg,
-                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done, int64_t coop_items,
-                        const void *queue_next, uint32_t epoch_next) {
+                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done, int64_t coop_items) {
     HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
                    width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
                "ha_qapply: the table must be 16-byte aligned with rows of a multiple of 4 floats");
@@ -1838,14 +1817,6 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     a.cap_coop = q.cap_coop;
     a.cap_wave = q.cap_wave;
     a.cap_copy = q.cap_copy;
-    static const bool prefetch = getenv("HA_QPREFETCH") != nullptr && getenv("HA_QPREFETCH")[0] == '1';
-    if (prefetch && queue_next != nullptr && epoch_next != 0u) {
-        const QLayout qn = queue_layout(const_cast<void *>(queue_next), queue_n_cap, width);
-        a.pf_qh = qn.hdr;
-        a.pf_copy = qn.copy;
-        a.pf_cap = qn.cap_copy;
-        a.pf_epoch = epoch_next;
-    }
     a.perm_a = perm_cur;
     a.n_a = static_cast<int>(n_cur);
     a.grads = grads;
@@ -2436,8 +2407,7 @@ extern "C" int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, f
     for (int64_t k = 0; k < count; ++k)
         if (qapply(table, rows, width, plan_cur[k], n_cur[k], grads[k], lr, plan_next[k], n_next[k], next_out[k],
                    queue_cur[k], queue_n_cap, as_stream(stream), nullptr, wave_items ? wave_items[k] : -1,
-                   epochs ? epochs[k] : 0u, err, k + 1 == count ? static_cast<hipEvent_t>(done_event) : nullptr,
-                   k + 1 < count ? queue_cur[k + 1] : nullptr, epochs && k + 1 < count ? epochs[k + 1] : 0u))
+                   epochs ? epochs[k] : 0u, err, k + 1 == count ? static_cast<hipEvent_t>(done_event) : nullptr))
             return -1;
     if (count == 0 && done_event)
         HA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(done_event), as_stream(stream)));
