@@ -1020,12 +1020,6 @@ __device__ __forceinline__ float4v shfl_xor4(float4v v, int mask) {
 #ifndef QV_GRAD_NT
 #define QV_GRAD_NT 0
 #endif
-#ifndef QV_HDR_BATCH
-#define QV_HDR_BATCH 1     // the queue header's epoch words and counts in one batch of loads
-#endif
-#ifndef QV_SPEC_ITEM
-#define QV_SPEC_ITEM QV_HDR_BATCH     // the wave's first item is loaded beside the queue header, not behind it
-#endif
 #ifndef QV_INTERLEAVE
 #define QV_INTERLEAVE 1
 #endif
@@ -1065,28 +1059,13 @@ __device__ __forceinline__ V q_ld_grad(const float *p) {
 #endif
 }
 
-// loads that stay in the order they are written (the compiler does not reorder volatile asm statements; it does not count
-// them in its vmcnt bookkeeping either: the results are valid behind q_wait3)
-typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4v q_ld16_ordered(const void *p) {
-    u32x4v v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void q_wait3(u32x4v &a, u32x4v &b, u32x4v &c) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
-}
-
 struct QItem {
     int kind, col0, cols;
     uint32_t key, c, st, m, fs, o01, o23;
 };
-__device__ __forceinline__ QItem q_decode(const uint4 lo, const uint4 hi, int width);
 __device__ __forceinline__ QItem q_load(const QEntry *e, int width) {
     // the address is wave-uniform: scalar loads
-    return q_decode(reinterpret_cast<const uint4 *>(e)[0], reinterpret_cast<const uint4 *>(e)[1], width);
-}
-__device__ __forceinline__ QItem q_decode(const uint4 lo, const uint4 hi, int width) {
+    const uint4 lo = reinterpret_cast<const uint4 *>(e)[0], hi = reinterpret_cast<const uint4 *>(e)[1];
     QItem it;
     it.kind = static_cast<int>(uniform(lo.x & 15u));
     it.col0 = static_cast<int>(uniform(lo.x >> 4)) * 4;
@@ -1474,62 +1453,11 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
     int b = blockIdx.x;
-#if QV_SPEC_ITEM
-    // The item this wave takes if both lists reach beyond it is asked for BEFORE the header's counts and the epoch are in:
-    // header -> item -> rows were three trips to the L2 at the start of every wave, now two.  (Reading a slot the builder
-    // did not fill is harmless: the item is used only once the counts say it exists.)
-    const uint32_t e_spec = static_cast<uint32_t>(b - a.ncoop) * static_cast<uint32_t>(kQWpw) +
-                            uniform(static_cast<uint32_t>(threadIdx.x >> 6));
-    uint4 spec_lo{0u, 0u, 0u, 0u}, spec_hi{0u, 0u, 0u, 0u};
-    bool spec_ok = b >= a.ncoop && a.width > 128;
-    if (spec_ok) {
-        const QEntry *sp = (e_spec & 1u) ? a.qcopy + min(e_spec >> 1, a.cap_copy - 1u) : a.qwave + min(e_spec >> 1, a.cap_wave - 1u);
-        spec_lo = reinterpret_cast<const uint4 *>(sp)[0];
-        spec_hi = reinterpret_cast<const uint4 *>(sp)[1];
-    }
-#endif
-#if QV_HDR_BATCH
-    // The header in ONE batch of loads, the epoch words first (the three vectors share a cache line: they are served in issue
-    // order, so counts read behind a current epoch are the ones the builder wrote before it): the epoch check, then the counts,
-    // then the item were four trips to the L2 one after the other at the start of every wave.
-    const uint4 *hq = reinterpret_cast<const uint4 *>(a.qh);
-    // {overflow, overflow, epoch_wave, epoch_copy}, {n_wave, n_coop, ..}, {.., n_copy, ..}: volatile asm keeps the issue order
-    u32x4v h2 = q_ld16_ordered(hq + 2), h0 = q_ld16_ordered(hq), h1 = q_ld16_ordered(hq + 1);
-    q_wait3(h2, h0, h1);
-    static_assert(offsetof(QHeader, epoch_wave) == 40 && offsetof(QHeader, epoch_copy) == 44 && offsetof(QHeader, n_copy) == 20 &&
-                      offsetof(QHeader, n_coop) == 4 && offsetof(QHeader, n_wave) == 0, "the header words the apply reads");
     if (a.epoch != 0u) {
         // The caller orders this launch behind the queue's builder without a wait on this stream (the builder ran a block of
         // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
         // ~1 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
-        bool ready = uniform(static_cast<uint32_t>(h2.z == a.epoch && h2.w == a.epoch)) != 0u;
-        if (!ready) {
-            for (int spin = 0; !ready && spin < (1 << 20); ++spin) {
-                const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
-                if (ready)
-                    break;
-                __builtin_amdgcn_s_sleep(64);
-            }
-            if (!ready) {
-                if (a.err != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
-                    __hip_atomic_store(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                return;
-            }
-            h0 = q_ld16_ordered(hq);       // (behind the acquire: the counts of the finished queue; the early item is not used)
-            h1 = q_ld16_ordered(hq + 1);
-            q_wait3(h2, h0, h1);
-#if QV_SPEC_ITEM
-            spec_ok = false;
-#endif
-        }
-    }
-    const uint32_t hdr_n_wave = uniform(h0.x), hdr_n_coop = uniform(h0.y), hdr_n_copy = uniform(h1.y);
-#else
-    if (a.epoch != 0u) {
-        // (QV_HDR_BATCH=0: round 3's prologue, kept for the A/B -- epoch words, counts and the item one trip after the other)
-        bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;
+        bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;     // (read with the header's counts)
         for (int spin = 0; !ready && spin < (1 << 20); ++spin) {
             const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1544,12 +1472,10 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
             return;
         }
     }
-    const uint32_t hdr_n_wave = a.qh->n_wave, hdr_n_coop = a.qh->n_coop, hdr_n_copy = a.qh->n_copy;
-#endif
     const bool coop = b < a.ncoop;
     if (coop) {
         role = 0;
-        const uint32_t n = min(hdr_n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
+        const uint32_t n = min(a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
         for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
             const QItem it = q_load(a.qcoop + e, a.width);
 #if QV_GOLD
@@ -1562,7 +1488,7 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
     } else {
         b -= a.ncoop;
         role = 3;
-        const uint32_t n0 = min(hdr_n_wave, a.cap_wave), n = n0 + min(hdr_n_copy, a.cap_copy);
+        const uint32_t n0 = min(a.qh->n_wave, a.cap_wave), n = n0 + min(a.qh->n_copy, a.cap_copy);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
         if (a.width <= 128) {
@@ -1614,11 +1540,7 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
                 src = (e & 1u) ? a.qcopy + (e >> 1) : a.qwave + (e >> 1);
             else
                 src = n0 > n1 ? a.qwave + (e - n1) : a.qcopy + (e - n0);
-#if QV_SPEC_ITEM
-            const QItem it = (spec_ok && e == e_spec && e < both) ? q_decode(spec_lo, spec_hi, a.width) : q_load(src, a.width);
-#else
             const QItem it = q_load(src, a.width);
-#endif
 #else
             const QItem it = q_load(e < n0 ? a.qwave + e : a.qcopy + (e - n0), a.width);
 #endif
