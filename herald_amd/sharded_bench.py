@@ -96,10 +96,11 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
                         sized=not (graphs or os.environ.get("HA_SHARD_FIXED") == "1"))
         outs = [torch.empty((n, width), dtype=torch.float32, device=dev) for _ in range(2)]
         LA = fs.LOOKAHEAD
-        fs.start([ids_dev[j % nb] for j in range(LA)])
+        ids_rows = [ids_dev[i] for i in range(nb)]          # the batches as tensors of their own, sliced once
+        fs.start([ids_rows[j % nb] for j in range(LA)])
 
         def step(k):
-            out = fs.pull(ids_dev[(k + LA) % nb], out=outs[k % 2])    # forward lookup; batch k + LA enters the routing
+            out = fs.pull(ids_rows[(k + LA) % nb], out=outs[k % 2])    # forward lookup; batch k + LA enters the routing
             fs.push(grads[k % 2], lr)                                 # backward: reduce, exchange, rank-ordered apply
             return out
     else:
