@@ -27,7 +27,7 @@ def _world1_same_path(args, rank, dev, emb, ids_dev, grads, n, lr, steps=300, wa
     one.stats = {"xgmi_bytes_out": 0, "xgmi_bytes_in": 0}
     one._slot, one._live, one.side_group = 0, {}, None
     local = [torch.remainder(t, float(emb.local_rows)) for t in ids_dev[:64]]
-    fs = FramedStep(one, n, block=int(__import__("os").environ.get("HA_SHARD_BLOCK", "8")), graphs=False)
+    fs = FramedStep(one, n, block=int(__import__("os").environ.get("HA_SHARD_BLOCK", "16")), graphs=False)
     nb, LA = len(local), fs.LOOKAHEAD
     outs = [torch.empty((n, emb.width), dtype=torch.float32, device=dev) for _ in range(2)]
     fs.start([local[j % nb] for j in range(LA)])
@@ -92,7 +92,7 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
         # batch that overflows its KEY frames on any rank takes the exchange with a read-back (counted below).
         graphs = os.environ.get("HA_SHARD_GRAPHS") == "1"
         fs = FramedStep(emb, n, row_cap=int(os.environ["HA_SHARD_ROW_CAP"]) if "HA_SHARD_ROW_CAP" in os.environ else None,
-                        block=int(os.environ.get("HA_SHARD_BLOCK", "8")), graphs=graphs,
+                        block=int(os.environ.get("HA_SHARD_BLOCK", "16")), graphs=graphs,
                         sized=not (graphs or os.environ.get("HA_SHARD_FIXED") == "1"))
         outs = [torch.empty((n, width), dtype=torch.float32, device=dev) for _ in range(2)]
         LA = fs.LOOKAHEAD

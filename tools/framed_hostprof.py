@@ -12,7 +12,7 @@ emb = ShardedEmbedding(rows, width, dev)
 ids = [torch.from_numpy(np.minimum(synth.as_f32_ids(synth.criteo_batch(bs, b, rows=rows)).reshape(-1), rows - 1)).to(dev) for b in range(64)]
 g = [torch.randn((n, width), device=dev) for _ in range(2)]
 outs = [torch.empty((n, width), device=dev) for _ in range(2)]
-fs = FramedStep(emb, n, block=int(os.environ.get("HA_SHARD_BLOCK", "8")), graphs=False)
+fs = FramedStep(emb, n, block=int(os.environ.get("HA_SHARD_BLOCK", "16")), graphs=False)
 LA = fs.LOOKAHEAD
 fs.start([ids[j % 64] for j in range(LA)])
 def step(k):
