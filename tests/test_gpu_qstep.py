@@ -426,6 +426,40 @@ def test_qstep_wide_bucket_overflow_takes_the_sorted_plan(dev):
     np.testing.assert_array_equal(got_t[~loose], exact_t[~loose])
 
 
+@pytest.mark.parametrize("crowd", [1792, 1793, 2048, 2049, 3000, 6500], ids=lambda c: "bucket_of_%d_keys" % c)
+def test_qstep_wide_buckets_at_the_quarter_workgroup_limits(dev, crowd):
+    """A preparation workgroup of the wide path takes four buckets, a quarter of its threads each, as long as a bucket holds
+    at most 1,792 ids (plans) / 2,048 unique keys per side (queues); larger ones are left to the launches that give a bucket
+    the whole workgroup (csrc/qstep.hip qbplan_kernel / qbqueue_kernel).  One bucket is filled with `crowd` DISTINCT keys --
+    at, just beyond and far beyond both limits -- in the batch to apply AND the batch to look up (partly the same keys:
+    updated rows forwarded, partly others: copies); every lookup and the table against both oracles, the plans against
+    np.unique."""
+    rows, width, n, steps = 3_000_000, 16, 20_000, 5
+    rng = np.random.default_rng(crowd)
+    P, shift = 32, 27                                          # ha_qbig_buckets(20,000) = 32 buckets
+    allk = np.arange(rows, dtype=np.uint64)
+    inb = allk[((allk * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)) >> np.uint64(shift) == np.uint64(7)]
+    assert inb.size >= 2 * crowd
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    batches = []
+    for k in range(steps):
+        b = rng.integers(0, rows, size=n)
+        if k % 2 == 0:
+            pick = inb[:crowd]                                 # the same crowd in batches 0, 2, 4 ...
+        else:
+            pick = inb[crowd // 2: crowd // 2 + crowd]         # ... half of it and as many other keys of the bucket in 1, 3
+        b[:crowd] = pick.astype(np.int64)
+        b[crowd:crowd + 40] = pick[0]                          # (one of them 41 times: a long item inside the crowd)
+        batches.append(rng.permutation(b))
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
+    pipe = _run_stream(dev, table0, batches, grads, 0.05, mode=(True, 2, "flags"), check_plans=False)
+    assert pipe.wide and pipe.plans[0].buckets == P and pipe.fallbacks == 0
+    for k in range(steps - 2, steps):                          # (the plans of the last batches are still in their workspaces)
+        _check_wide_plan(pipe.plan_of(k), batches[k].astype(np.int64), "plan of batch %d" % k)
+        sizes = pipe.plan_of(k).groups()["bucket_sizes"]
+        assert sizes[7] >= crowd and np.delete(sizes, 7).max() < 1792
+
+
 @pytest.mark.parametrize("mode", MODES[:3], ids=MODE_IDS[:3])
 def test_qstep_graph_replay_is_deterministic(dev, mode):
     """The steps of a block replayed from a hipGraph (as bench.py does; the preparation of the blocks ahead is enqueued
