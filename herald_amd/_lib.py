@@ -113,6 +113,8 @@ def _declare(L):
     L.ha_qstep_init.argtypes = []
     L.ha_event_create.restype = vp
     L.ha_event_create.argtypes = []
+    L.ha_host_unmap.restype = c.c_int
+    L.ha_host_unmap.argtypes = [vp]
     L.ha_qbig_max_ids.restype = i64
     L.ha_qbig_max_ids.argtypes = []
     L.ha_qbig_plan_bytes.restype = sz

@@ -277,6 +277,20 @@ static int host_map(void *host, size_t bytes, void **dev) {
     return 0;
 }
 
+// Drops the registration of a host array (cpu_* entry points register arrays of >= 64 MiB instead of copying them, and keep
+// the registration for the next call).  Call it BEFORE freeing such an array: a later allocation at the same address would
+// otherwise be seen through the old mapping.  Unknown pointers are ignored.
+extern "C" int ha_host_unmap(void *host) {
+    std::lock_guard<std::mutex> lk(g_hostmap_mu);
+    auto it = g_hostmap.find(host);
+    if (it == g_hostmap.end())
+        return 0;
+    HA_CHECK_HIP(hipDeviceSynchronize());
+    HA_CHECK_HIP(hipHostUnregister(host));
+    g_hostmap.erase(it);
+    return 0;
+}
+
 void host_map_release() {
     std::lock_guard<std::mutex> lk(g_hostmap_mu);
     for (auto &kv : g_hostmap)

@@ -162,7 +162,10 @@ int LambOptimizerSparseUpdate(DLArrayHandle param,
  * callers pass: EmbeddingLookUp.py:16-17, optimizer.py:203-207) are made visible to the device for the call:
  * below 64 MiB copied (H2D, kernel, D2H for the written one), from 64 MiB page-locked and mapped with
  * hipHostRegister -- the kernels then move only the rows the ids name across PCIe; the registration is kept
- * until ha_scratch_release() (callers pass the same parameter array every step). */
+ * until ha_host_unmap(array) / ha_scratch_release() (callers pass the same parameter array every step).  An array
+ * of that size must be unmapped BEFORE it is freed: an allocation that lands on the same address later would be
+ * seen through the old mapping. */
+int ha_host_unmap(void *host_array);
 int cpu_EmbeddingLookup(const DLArrayHandle in_mat, const DLArrayHandle ids,
                         DLArrayHandle out_mat);
 int cpu_SGDOptimizerSparseUpdate(DLArrayHandle param,

@@ -180,7 +180,13 @@ def test_cpu_named_symbols_serve_host_arrays(dev, rows, width):
     mixed = ops.DLHolder(d_t)
     assert L.cpu_SGDOptimizerSparseUpdate(mixed.handle, flat.handle, hs[3].handle, ctypes.c_float(0.1)) == 0
     np.testing.assert_array_equal(d_t.cpu().numpy(), want_t)
-    assert L.ha_scratch_release() == 0         # unregisters the host ranges before the arrays are freed
+    # a registered host array is unmapped before it is freed (ha_host_unmap; unknown pointers are ignored) ...
+    assert L.ha_host_unmap(ctypes.c_void_p(h_t.data_ptr())) == 0 and L.ha_host_unmap(ctypes.c_void_p(h_t.data_ptr())) == 0
+    # ... after which the same array is simply registered again by the next call
+    h_t.copy_(torch.from_numpy(table))
+    assert L.cpu_SGDOptimizerSparseUpdate(hs[0].handle, flat.handle, hs[3].handle, ctypes.c_float(0.1)) == 0, L.ha_last_error()
+    np.testing.assert_array_equal(h_t.numpy(), want_t)
+    assert L.ha_scratch_release() == 0         # unregisters whatever is left before the arrays are freed
 
 
 @pytest.mark.parametrize("kind", ["adagrad", "adam", "adamw"])
