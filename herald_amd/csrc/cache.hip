@@ -620,52 +620,83 @@ __device__ __forceinline__ void cache_insert_evict_body(
         ctl->ph[14] = static_cast<unsigned long long>(need);        // lines to evict
         ctl->ph[15] = static_cast<unsigned long long>(s_head);      // log head before the walk
     }
+    // Two log entries per thread and round (2,048 entries: a Criteo batch's ~1,000 victims in ONE round instead of 1.3), and
+    // ONE packed scan per round -- valid entries in the low half, valid-and-dirty ones in the high half: every valid entry in
+    // front of a victim is a victim too, so a victim's rank among the dirty (clean) victims is its rank among the valid-dirty
+    // (valid-clean) entries.
+    __shared__ uint32_t s_cut_dirty;
     while (true) {
         const long long head = s_head, left = s_need;
         if (left <= 0 || head >= tail)
             break;
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             ctl->ph[13] += 1;
-        const long long pos = head + threadIdx.x;
-        int s = -1;
-        bool valid = false;
-        int upd_s = 0;
-        uint32_t key_s = 0;
-        if (pos < tail) {
-            s = static_cast<int>(c.log_slot[pos % c.Lcap]);
-            // everything a victim needs in the same trip as the validity test (one trip per chunk less, twice)
-            const uint8_t st8 = c.line[s].state;
-            const unsigned long long stp = c.line[s].stamp;
-            upd_s = c.line[s].updates;
-            key_s = c.line[s].key;
-            valid = st8 == kResident && stp == c.log_stamp[pos % c.Lcap] &&
-                    (c.policy == kLRU || c.line[s].freq == base_use);
+            s_cut_dirty = 0xFFFFFFFFu;
         }
+        const long long pos0 = head + 2ll * threadIdx.x;
+        int sl[2] = {-1, -1};
+        bool valid[2] = {false, false};
+        int upd_s[2] = {0, 0};
+        uint32_t key_s[2] = {0, 0};
+        {
+            // everything a victim needs in the same trip as the validity test, both entries' loads in one batch
+            uint8_t st8[2] = {0, 0};
+            unsigned long long stp[2] = {0, 0}, lst[2] = {0, 0};
+            uint32_t fq[2] = {0, 0};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (pos0 + i < tail) {
+                    sl[i] = static_cast<int>(c.log_slot[(pos0 + i) % c.Lcap]);
+                    lst[i] = c.log_stamp[(pos0 + i) % c.Lcap];
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (sl[i] >= 0) {
+                    st8[i] = c.line[sl[i]].state;
+                    stp[i] = c.line[sl[i]].stamp;
+                    upd_s[i] = c.line[sl[i]].updates;
+                    key_s[i] = c.line[sl[i]].key;
+                    fq[i] = static_cast<uint32_t>(c.line[sl[i]].freq);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                valid[i] = sl[i] >= 0 && st8[i] == kResident && stp[i] == lst[i] &&
+                           (c.policy == kLRU || fq[i] == static_cast<uint32_t>(base_use));
+        }
+        const uint32_t vd0 = valid[0] && upd_s[0] != 0 ? 1u : 0u, vd1 = valid[1] && upd_s[1] != 0 ? 1u : 0u;
+        const uint32_t v0 = valid[0] ? 1u : 0u, v1 = valid[1] ? 1u : 0u;
         uint32_t tot;
-        const uint32_t r = block_scan_1024(valid ? 1u : 0u, s_w, &tot);
-        const bool take = valid && static_cast<long long>(r) < left;
-        const bool dirty = take && upd_s != 0;
-        uint32_t tot_d, tot_c;
-        const uint32_t rd = block_scan_1024(dirty ? 1u : 0u, s_w, &tot_d);
-        const uint32_t rc = block_scan_1024((take && !dirty) ? 1u : 0u, s_w, &tot_c);
-        if (take) {
-            c.slot_of[key_s] = -1;
-            if (dirty) {
-                c.line[s].state = kEvictedDirty;
-                c.evict_slots[evict_n0 + s_dirty + rd] = s;
-            } else {
-                c.line[s].state = kFree;
-                // freed slots go on top of the stack AFTER this call's allocations are retired
-                c.free_list[free_top0 - M + s_clean + rc] = s;
+        const uint32_t ex = block_scan_1024((v0 + v1) | ((vd0 + vd1) << 16), s_w, &tot);
+        const uint32_t tot_valid = tot & 0xFFFFu, tot_vd = tot >> 16;
+        const uint32_t r[2] = {ex & 0xFFFFu, (ex & 0xFFFFu) + v0}, rd[2] = {ex >> 16, (ex >> 16) + vd0};
+        bool take[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            take[i] = valid[i] && static_cast<long long>(r[i]) < left;
+            const bool dirty = (i == 0 ? vd0 : vd1) != 0u;
+            if (take[i]) {
+                c.slot_of[key_s[i]] = -1;
+                if (dirty) {
+                    c.line[sl[i]].state = kEvictedDirty;
+                    c.evict_slots[evict_n0 + s_dirty + rd[i]] = sl[i];
+                } else {
+                    c.line[sl[i]].state = kFree;
+                    // freed slots go on top of the stack AFTER this call's allocations are retired
+                    c.free_list[free_top0 - M + s_clean + (r[i] - rd[i])] = sl[i];
+                }
+                if (static_cast<long long>(r[i]) == left - 1)       // the last victim of the walk: the dirty ones up to it
+                    s_cut_dirty = rd[i] + (dirty ? 1u : 0u);
             }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const long long taken = static_cast<long long>(tot) < left ? tot : left;
+            const long long taken = static_cast<long long>(tot_valid) < left ? tot_valid : left;
+            const uint32_t taken_dirty = static_cast<long long>(tot_valid) <= left && s_cut_dirty == 0xFFFFFFFFu ? tot_vd
+                                         : (s_cut_dirty != 0xFFFFFFFFu ? s_cut_dirty : tot_vd);
             s_need = left - taken;
-            s_clean += tot_c;
-            s_dirty += tot_d;
-            s_head = head + 1024 < tail ? head + 1024 : tail;
+            s_dirty += taken_dirty;
+            s_clean += static_cast<uint32_t>(taken) - taken_dirty;
+            s_head = head + 2048 < tail ? head + 2048 : tail;
         }
         __syncthreads();
         // entries past the last victim of a chunk that satisfied `need` are skipped too; they are
@@ -677,10 +708,10 @@ __device__ __forceinline__ void cache_insert_evict_body(
                 s_last = head;
             __syncthreads();
             // one LDS atomic per wave (its last victim), not one per victim on the same word
-            const unsigned long long tm = __ballot(take);
+            const long long mine = take[1] ? pos0 + 2 : (take[0] ? pos0 + 1 : 0);
+            const unsigned long long tm = __ballot(mine != 0);
             if (tm != 0ull && lane_id() == 63 - __builtin_clzll(tm))
-                atomicMax(reinterpret_cast<unsigned long long *>(&s_last),
-                          static_cast<unsigned long long>(pos + 1));
+                atomicMax(reinterpret_cast<unsigned long long *>(&s_last), static_cast<unsigned long long>(mine));
             __syncthreads();
             if (threadIdx.x == 0)
                 s_head = s_last;
