@@ -300,12 +300,18 @@ def laia_scheduler(args):
     parts = [synth.criteo_batch(per, step=5000 + s, rows=args.rows, nfields=T) for s in range((need + per - 1) // per)]
     samples = np.concatenate(parts, axis=0)[:need].astype(np.uint64)
     s = hlaia.LaiaScheduler()
-    s.start(samples, samples.shape[0], T, 1, mini_bs, batch_num, W, 0, int(0.1 * args.rows), 16, 24, key_limit=args.rows)
+    ahead = os.environ.get("HA_LAIA_AHEAD", "1") == "1"
+    s.start(samples, samples.shape[0], T, 1, mini_bs, batch_num, W, 0, int(0.1 * args.rows), 16, 24, key_limit=args.rows,
+            ahead=ahead)
     while s.pop() != [0]:
         pass
     tm = s.timing()
     s.close()
     return {"us_per_global_batch": tm["us_per_batch"], "global_batch_samples": W * mini_bs, "workers": W,
+            # the scheduler thread's whole loop per batch: the library call + queueing plan and dist as Python lists (the
+            # reference's launch(), laia_scheduler.cc:115-169) -- with `one_batch_ahead` the device works on batch k+1 during
+            # the latter, and `us_per_global_batch` (time inside the library call) is what is left to wait for
+            "thread_wall_us_per_global_batch": tm["thread_wall_us_per_batch"], "one_batch_ahead": ahead,
             "tables": T, "cache_size": int(0.1 * args.rows), "batches": tm["batches"],
             "host_assign_us": tm["host_assign_us"], "host_snapshot_us": tm["host_snapshot_us"],
             "gpu_and_transfer_us": tm["gpu_and_transfer_us"],

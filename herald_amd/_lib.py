@@ -274,6 +274,8 @@ def _declare(L):
     L.ha_laia_destroy.argtypes = [vp]
     L.ha_laia_next.restype = c.c_int
     L.ha_laia_next.argtypes = [vp, i64, i64, vp, vp, i64, vp]
+    L.ha_laia_hint_next.restype = c.c_int
+    L.ha_laia_hint_next.argtypes = [vp, i64]
     L.ha_laia_next_for_rank.restype = c.c_int
     L.ha_laia_next_for_rank.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp]
     L.ha_laia_snapshot_keys.restype = i64

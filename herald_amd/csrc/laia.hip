@@ -1073,7 +1073,28 @@ struct LaiaDev {
     int32_t *h_off = nullptr;
     uint32_t *h_plan_rows = nullptr;
     LruState *h_state = nullptr;
+    // One batch AHEAD (ha_laia_hint_next): the caller names the batch of its next call, and the call that returns batch k
+    // enqueues the launches and copies of that batch before it hands k's results over -- the device works on k+1 while the
+    // host (the reference's launch() loop, laia_scheduler.cc:115-169: queueing the plan and the dist) deals with k.  The
+    // pinned mirrors exist twice for it; the device buffers do not (k's copies are complete before k+1 is enqueued).
+    char *h_out_base = nullptr;
+    uint32_t *h_plan_base = nullptr;
+    size_t plan_words = 0;          // words per pinned plan mirror
+    int set = 0;                    // the mirror the pointers above are set to
+    long long next_hint = -1;       // batch the caller announced for its next call (-1: none)
+    long long inflight = -1;        // batch whose launches and copies are enqueued already (-1: none)
+    int inflight_set = 0, inflight_rank = -1, inflight_topk = 0;
+    long long inflight_mini_bs = 0;
+    long long issued_g0[2] = {0, 0}, issued_g1[2] = {0, 0};      // plan rows copied along, per mirror
 };
+static inline void laia_host_set(LaiaDev &d, int set) {
+    d.set = set;
+    d.h_out = d.h_out_base + static_cast<size_t>(set) * ((d.out_bytes + 255) / 256 * 256);
+    d.h_plan_rows = d.h_plan_base + static_cast<size_t>(set) * d.plan_words;
+    d.h_dist = reinterpret_cast<long long *>(d.h_out);
+    d.h_off = reinterpret_cast<int32_t *>(d.h_out + d.off_at);
+    d.h_state = reinterpret_cast<LruState *>(d.h_out + d.state_at);
+}
 
 // A few persistent host threads for the per-worker snapshot updates (creating std::threads per batch costs
 // ~200 us, the update itself ~150 us per worker).  run(n, f): f(1) .. f(n-1) on the pool, f(0) on the caller.
@@ -1267,7 +1288,7 @@ extern "C" void ha_laia_destroy(ha_laia *h) {
         (void)hipHostFree(h->l.h_touch);
     if (h->l.h_plan)
         (void)hipHostFree(h->l.h_plan);
-    for (void *p : {static_cast<void *>(h->l.dev.h_out), static_cast<void *>(h->l.dev.h_plan_rows)})
+    for (void *p : {static_cast<void *>(h->l.dev.h_out_base), static_cast<void *>(h->l.dev.h_plan_base)})
         if (p)
             (void)hipHostFree(p);
     (void)hipStreamDestroy(h->l.stream);
@@ -1359,16 +1380,16 @@ static int laia_dev_init(Laia &l) {
     d.state_at = (d.off_at + static_cast<size_t>(2 * (W + 1)) * 4 + 15) / 16 * 16;
     d.out_bytes = d.state_at + static_cast<size_t>(W) * sizeof(LruState);
     alloc(reinterpret_cast<void **>(&d.d_out), d.out_bytes, true);
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_out), d.out_bytes, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_plan_rows), (l.plan_cap + 4) * 4, hipHostMallocDefault) == hipSuccess;
+    d.plan_words = (static_cast<size_t>(l.plan_cap) + 4 + 63) / 64 * 64;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_out_base), 2 * ((d.out_bytes + 255) / 256 * 256),
+                             hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_plan_base), 2 * d.plan_words * 4, hipHostMallocDefault) == hipSuccess;
     if (ok) {
         d.d_dist = reinterpret_cast<long long *>(d.d_out);
         d.bits.off[0] = reinterpret_cast<int32_t *>(d.d_out + d.off_at);
         d.bits.off[1] = d.bits.off[0] + (W + 1);
         d.lru.state = reinterpret_cast<LruState *>(d.d_out + d.state_at);
-        d.h_dist = reinterpret_cast<long long *>(d.h_out);
-        d.h_off = reinterpret_cast<int32_t *>(d.h_out + d.off_at);
-        d.h_state = reinterpret_cast<LruState *>(d.h_out + d.state_at);
+        laia_host_set(d, 0);
     }
     HA_REQUIRE(ok, "laia: device allocation of the resident scheduler state failed");
     d.lru.valid = l.d_valid;
@@ -1392,16 +1413,17 @@ static int laia_dev_states(Laia &l) {   // -> l.dev.h_state (synchronises the sc
     return 0;
 }
 
-// One global batch with the scheduler state on the device: eight launches, `dist` + offsets + states back in one copy
-// phase, the plan rows in a second (their number is only known then).
-static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out, uint64_t *plan_out,
-                            int64_t plan_cap_elems, int64_t *plan_off, int only_rank, const TopkParams *topk = nullptr) {
+// One global batch with the scheduler state on the device, in two halves.  ISSUE: nine launches, then `dist` + offsets +
+// states to the pinned mirror `set` in one copy and -- speculatively -- the plan rows in a second (their number is only known
+// afterwards).  COLLECT (laia_next_device): wait, fetch what the speculation missed, hand the results over.  A call issues its
+// own batch unless the call before it did (ha_laia_hint_next).
+static int laia_dev_issue(ha_laia *h, int64_t batch_id, int64_t mini_bs, int only_rank, const TopkParams *topk, int set) {
     Laia &l = h->l;
     LaiaDev &d = l.dev;
     const int W = l.W, T = l.T;
     const long long B = mini_bs * W;
     HA_REQUIRE(B <= l.Bcap, "laia_next: global batch %lld exceeds max_batch %d", B, l.Bcap);
-    const double t_begin = now_us();
+    laia_host_set(d, set);
     const long long start = (batch_id * B) % l.S;  // laia_scheduler.cc:182
     const long long BT = B * T;
     int blocks = static_cast<int>((BT + 255) / 256);
@@ -1471,6 +1493,32 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     if (g1 > g0)
         HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows + g0, d.bits.rows[1] + g0, static_cast<size_t>(g1 - g0) * 4,
                                     hipMemcpyDeviceToHost, l.stream));
+    d.issued_g0[set] = g0;
+    d.issued_g1[set] = g1;
+    return 0;
+}
+
+static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64_t *dist_out, uint64_t *plan_out,
+                            int64_t plan_cap_elems, int64_t *plan_off, int only_rank, const TopkParams *topk = nullptr) {
+    Laia &l = h->l;
+    LaiaDev &d = l.dev;
+    const int W = l.W;
+    const long long B = mini_bs * W;
+    const double t_begin = now_us();
+    int set = d.set ^ 1;
+    if (d.inflight >= 0) {
+        // the call before this one enqueued a batch on the caller's word: it has to be this one (the device state is past it)
+        HA_REQUIRE(d.inflight == batch_id && d.inflight_mini_bs == mini_bs && d.inflight_rank == only_rank &&
+                       d.inflight_topk == (topk ? 1 : 0),
+                   "laia_next: batch %lld was announced (ha_laia_hint_next) and is enqueued; this call asks for batch %lld",
+                   d.inflight, (long long)batch_id);
+        set = d.inflight_set;
+        d.inflight = -1;
+    } else if (laia_dev_issue(h, batch_id, mini_bs, only_rank, topk, set)) {
+        return -1;
+    }
+    laia_host_set(d, set);
+    const long long g0 = d.issued_g0[set], g1 = d.issued_g1[set];
     HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     for (int w = 0; w < W; ++w)
         HA_REQUIRE(d.h_state[w].err == 0, "laia: the device snapshot of worker %d is inconsistent (code %d)", w,
@@ -1489,6 +1537,18 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
         const long long margin = (a1 - a0) / 4 + 2048;
         d.rank_lo = a0 > margin ? a0 - margin : 0;
         d.rank_hi = a1 + margin;
+    }
+    if (d.next_hint >= 0) {     // the caller's next batch: its launches and copies go out before this one's results are unpacked
+        const long long nb = d.next_hint;
+        d.next_hint = -1;
+        if (laia_dev_issue(h, nb, mini_bs, only_rank, topk, set ^ 1))
+            return -1;
+        d.inflight = nb;
+        d.inflight_set = set ^ 1;
+        d.inflight_mini_bs = mini_bs;
+        d.inflight_rank = only_rank;
+        d.inflight_topk = topk ? 1 : 0;
+        laia_host_set(d, set);
     }
     const double t_out0 = now_us();
     for (long long k = 0; k < B; ++k)
@@ -1774,6 +1834,18 @@ extern "C" int ha_laia_timing(ha_laia *h, double *out) {
     out[1] = h->l.t_total_us;
     out[2] = h->l.t_assign_us;
     out[3] = h->l.t_snap_us;
+    return 0;
+}
+
+// The caller's word that its NEXT ha_laia_next* call will ask for batch `next_batch_id` with the arguments of the call that
+// follows this hint (the reference's launch() walks the batches in order, laia_scheduler.cc:115-169): that call then enqueues
+// the announced batch's launches and copies before it returns its own results, and the device works on it while the host
+// queues plan and dist.  The scheduler's state on the device is one batch ahead from then on -- the announced call MUST
+// follow (anything else is an error), and counters / snapshots read in between include the announced batch.  Ignored while the
+// snapshots live on the host (small caches, HA_LAIA_HOST=1).  next_batch_id < 0 withdraws a hint that was not used yet.
+extern "C" int ha_laia_hint_next(ha_laia *h, int64_t next_batch_id) {
+    HA_REQUIRE(h, "laia_hint_next: null handle");
+    h->l.dev.next_hint = next_batch_id >= 0 ? next_batch_id : -1;
     return 0;
 }
 

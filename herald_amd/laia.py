@@ -38,13 +38,18 @@ class LaiaScheduler:
         self._error = None
 
     def start(self, samples, num_sample, num_table, epoch_num, mini_batch_size, batch_num, nrank, rank,
-              cache_size, num_threads=16, top_k_table=24, key_limit=None, device=None):
+              cache_size, num_threads=16, top_k_table=24, key_limit=None, device=None, ahead=None):
+        """ahead (default: the environment's HA_LAIA_AHEAD == "1"): the scheduler thread announces every next batch to the
+        library (ha_laia_hint_next), which then works on batch k+1 while this thread queues plan and dist of batch k."""
         samples = np.ascontiguousarray(np.asarray(samples).astype(np.uint64))   # pybind force-cast
         if samples.ndim != 2:
             raise RuntimeError("Input should be 2D numpy array")
         assert samples.shape == (num_sample, num_table)
         if key_limit is None:
             key_limit = int(samples.max()) + 1
+        import os
+        self._ahead = (os.environ.get("HA_LAIA_AHEAD") == "1") if ahead is None else bool(ahead)
+        self._wall = (0.0, 0)
         import torch
         if device is not None:
             torch.cuda.set_device(device)
@@ -68,6 +73,8 @@ class LaiaScheduler:
         plan = np.empty(cap, dtype=np.uint64)
         off = np.empty(W + 1, dtype=np.int64)
         epoch_id = 0
+        import time
+        t0, done = time.perf_counter(), 0
         try:
             while epoch_id < epoch_num and not self._close:
                 batch_id = 0
@@ -75,13 +82,19 @@ class LaiaScheduler:
                 if epoch_id == epoch_num:
                     batch_num += 1          # one more allocation for the cache prefetch (:126-128)
                 while batch_id < batch_num and not self._close:
+                    if getattr(self, "_ahead", False):
+                        # the batch of the NEXT call: the following one of this epoch, the first of the next epoch, or none
+                        nxt = batch_id + 1 if batch_id + 1 < batch_num else (0 if epoch_id < epoch_num else -1)
+                        self._L.ha_laia_hint_next(self._h, nxt)
                     rc = self._next(batch_id, mini_bs, dist, plan, cap, off)
                     if rc != 0:
                         raise _lib.HeraldAmdError("ha_laia_next failed: %s" % self._L.ha_last_error().decode())
                     self._emit(plan, dist, off, mini_bs, rank)
                     batch_id += 1
+                    done += 1
         except Exception as e:   # surfaced by pop()
             self._error = e
+        self._wall = (time.perf_counter() - t0, done)
         self._finish()
 
     def _next(self, batch_id, mini_bs, dist, plan, cap, off):
@@ -116,8 +129,11 @@ class LaiaScheduler:
         t = np.zeros(4, dtype=np.float64)
         _lib.check(self._L.ha_laia_timing(self._h, t.ctypes.data), "ha_laia_timing")
         calls = max(t[0], 1.0)
+        wall, done = getattr(self, "_wall", (0.0, 0))
         return {"batches": int(t[0]), "us_per_batch": t[1] / calls, "host_assign_us": t[2] / calls,
-                "host_snapshot_us": t[3] / calls, "gpu_and_transfer_us": (t[1] - t[2] - t[3]) / calls}
+                "host_snapshot_us": t[3] / calls, "gpu_and_transfer_us": (t[1] - t[2] - t[3]) / calls,
+                # the scheduler thread's loop as a whole (library calls + queueing plan and dist as Python lists)
+                "thread_wall_us_per_batch": 1e6 * wall / done if done else None}
 
     def close(self):
         self._close = True
@@ -197,7 +213,7 @@ class TopkScheduler(LaiaScheduler):
 
     def start(self, samples, num_sample, num_table, epoch_num, mini_batch_size, batch_num, nrank, rank,
               cache_size, num_threads, dataset, top_k_table, local_shared=False, local_rank=0, local_size=1,
-              key_limit=None, device=None):
+              key_limit=None, device=None, ahead=None):
         if dataset not in TOPK_TABLE_ORDER:
             raise ValueError("dataset not supported")                           # :163-166
         order = TOPK_TABLE_ORDER[dataset]
@@ -215,7 +231,7 @@ class TopkScheduler(LaiaScheduler):
             if self._local_rank != 0:
                 return                                                           # only local rank 0 schedules (:176-180)
         super().start(samples, num_sample, num_table, epoch_num, mini_batch_size, batch_num, nrank, rank,
-                      cache_size, num_threads, k, key_limit=key_limit, device=device)
+                      cache_size, num_threads, k, key_limit=key_limit, device=device, ahead=ahead)
 
     def _next(self, batch_id, mini_bs, dist, plan, cap, off):
         return self._L.ha_laia_next_topk(self._h, batch_id, mini_bs, self._order.ctypes.data, self._order.size,

@@ -950,6 +950,11 @@ void ha_laia_destroy(ha_laia *sched);
 int ha_laia_next(ha_laia *sched, int64_t batch_id, int64_t mini_bs,
                  int64_t *dist_out, uint64_t *plan_out, int64_t plan_cap_elems,
                  int64_t *plan_off);
+/* One batch ahead: the caller announces the batch of its NEXT ha_laia_next* call (the reference's launch() walks them in
+ * order, laia/src/laia_scheduler.cc:115-169); the call that follows the hint enqueues the announced batch before it returns
+ * its own results.  The announced call must follow; scheduler state read in between is one batch ahead.  Device-resident
+ * state only (ignored otherwise); next_batch_id < 0 withdraws an unused hint. */
+int ha_laia_hint_next(ha_laia *laia, int64_t next_batch_id);
 /* ha_laia_next for a caller that wants ONE worker's plan (what LaiaScheduler::launch queues for its own rank,
  * laia/src/laia_scheduler.cc:140-168): plan_out holds that plan, plan_off[w] = 0 for w <= rank and its length behind;
  * dist_out as ha_laia_next.  With the scheduler state on the device only that worker's plan rows cross PCIe. */

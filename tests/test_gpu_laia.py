@@ -179,6 +179,35 @@ def test_laia_device_resident_state_matches_model(dev, monkeypatch, W, rank, T, 
     assert cnt_dev[0].sum() > 0 and (W == 1 or cnt_dev[3].sum() > 0)
 
 
+@pytest.mark.parametrize("W,rank,T,mini_bs,cache_size,nkeys", [(4, 1, 6, 16, 400, 3000), (2, 0, 26, 64, 3400, 30000)])
+def test_laia_one_batch_ahead_is_the_same_stream(dev, monkeypatch, W, rank, T, mini_bs, cache_size, nkeys):
+    """HA_LAIA_AHEAD=1: the scheduler thread announces every next batch (ha_laia_hint_next) and the library enqueues it
+    before it hands the current batch over -- across the epoch boundary too (the batch after an epoch's last is batch 0) and
+    not beyond the stream's end: stream, final snapshots and counters are those of the plain run and of the model."""
+    args = dict(W=W, rank=rank, T=T, mini_bs=mini_bs, batch_num=25, epochs=2, cache_size=cache_size, nkeys=nkeys, S=4000,
+                seed=100 + W)
+    got_a, cnt_a = _run_device(monkeypatch, env={"HA_LAIA_AHEAD": "1"}, **args)
+    monkeypatch.delenv("HA_LAIA_AHEAD")
+    got_p, cnt_p = _run_device(monkeypatch, **args)
+    assert got_a == got_p
+    np.testing.assert_array_equal(cnt_a, cnt_p)
+
+
+def test_laia_an_announced_batch_must_follow(dev):
+    """A hint moves the device state one batch ahead: a call for another batch than the announced one is an error."""
+    from herald_amd import _lib
+    samples, key_limit = _samples(2000, 6, 3000, 3)
+    L = _lib.load()
+    h = L.ha_laia_create(samples.ctypes.data, 2000, 6, 2, 400, key_limit, 32)
+    assert h
+    dist, plan, off = np.empty(32, np.int64), np.empty(32 * 6 * 2 + 16, np.uint64), np.empty(3, np.int64)
+    call = lambda b: L.ha_laia_next(h, b, 16, dist.ctypes.data, plan.ctypes.data, plan.size, off.ctypes.data)
+    assert L.ha_laia_hint_next(h, 1) == 0 and call(0) == 0       # batch 0 returned, batch 1 enqueued
+    assert call(2) != 0 and b"announced" in L.ha_last_error()
+    assert call(1) == 0 and call(2) == 0                          # the announced one, then on without hints
+    L.ha_laia_destroy(h)
+
+
 def test_laia_device_log_compaction_and_stamp_renumbering(dev, monkeypatch):
     """A short log (compacted every few batches) and an early wrap of the 32-bit stamp counter (live entries restamped
     1, 2, ...): the stream does not change."""
