@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <queue>
 #include <stdexcept>
@@ -114,12 +115,17 @@ protected:
         const size_t cap = W * mini_bs_ * num_table_ * (W > 1 ? W - 1 : 1) + 16;
         std::vector<uint64_t> plan(cap);
         size_t epoch_id = 0, batch_num = batch_num_;
+        const char *ah = getenv("HA_LAIA_AHEAD");       // one batch ahead (ha_laia_hint_next), as herald_amd.laia's loop
+        const bool ahead_ = ah != nullptr && ah[0] == '1';
         while (epoch_id < epoch_num_ && !close_) {
             size_t batch_id = 0;
             ++epoch_id;
             if (epoch_id == epoch_num_)
                 batch_num += 1;  // one more allocation for the cache prefetch (laia_scheduler.cc:126-128)
             while (batch_id < batch_num && !close_) {
+                if (ahead_)     // the batch of the NEXT call: the following one, the first of the next epoch, or none
+                    (void)ha_laia_hint_next(h_, batch_id + 1 < batch_num ? (int64_t)(batch_id + 1)
+                                                                       : (epoch_id < epoch_num_ ? 0 : -1));
                 const int rc = topk_
                     ? ha_laia_next_topk(h_, (int64_t)batch_id, (int64_t)mini_bs_, order_.data(),
                                         (int64_t)order_.size(), (int64_t)num_threads_, dist.data(), plan.data(),
