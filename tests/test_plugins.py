@@ -101,6 +101,28 @@ def test_laia_cache_plugin_against_model(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ahead", ["0", "1"])
+def test_laia_cache_plugin_device_state_one_batch_ahead(dev, monkeypatch, ahead):
+    """A cache that holds a global batch of rows (the scheduler state lives on the device), with and without the launch
+    loop announcing its next batch (HA_LAIA_AHEAD, ha_laia_hint_next): the model's stream either way."""
+    from oracle import laia_model
+    _, laia_cache = _import()
+    monkeypatch.setenv("HA_LAIA_AHEAD", ahead)
+    rng = np.random.default_rng(34)
+    S, T, W, rank, mini_bs, batch_num, epochs, cache_size = 1500, 12, 4, 2, 24, 7, 2, 1400
+    samples = np.stack([j * 500 + np.minimum(rng.zipf(1.3, size=S) - 1, 499) for j in range(T)], axis=1).astype(np.uint64)
+    want = laia_model.LaiaSchedulerModel(samples, epochs, mini_bs, batch_num, W, rank, cache_size).emit()
+    s = laia_cache.LaiaScheduler()
+    s.start(samples.astype(np.intc), S, T, epochs, mini_bs, batch_num, W, rank, cache_size, 16, 24)
+    got = []
+    while True:
+        got.append(list(s.pop()))
+        if got[-1] == [0]:
+            break
+    assert got == want
+
+
+@pytest.mark.gpu
 def test_laia_cache_plugin_topk_against_model(dev):
     from oracle import laia_model
     _, laia_cache = _import()
