@@ -9,6 +9,9 @@ import torch.distributed as dist
 
 XGMI_LINK_GBS = 153.0   # per link, 7 links per GPU (MI355X_MICROARCH / task statement)
 HBM_PEAK_GBS = 8000.0
+# tests: a replacement of all_to_all_single for process groups whose backend cannot move device tensors (several ranks on
+# ONE GPU under gloo: tests/test_gpu_bench_contract.py); None = the group's own collective (RCCL)
+A2A_HOOK = None
 
 
 def _world1_same_path(args, rank, dev, emb, ids_dev, grads, n, lr, steps=300, warmup=40):
@@ -60,7 +63,7 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
         np.minimum(f, np.float32(args.rows - 1), out=f)
         ids_host[b] = f
     ids_dev = torch.from_numpy(ids_host).to(dev)
-    emb = ShardedEmbedding(args.rows, width, dev, side_group=os.environ.get("HA_SHARD_SIDE_GROUP") == "1")
+    emb = ShardedEmbedding(args.rows, width, dev, side_group=os.environ.get("HA_SHARD_SIDE_GROUP") == "1", a2a=A2A_HOOK)
     g = torch.Generator(device=dev)
     g.manual_seed(123 + rank)
     chunk = 1 << 20

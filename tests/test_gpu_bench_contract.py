@@ -116,3 +116,60 @@ def test_same_path_world1_measurement_runs_on_a_shard(dev):
     ms = sharded_bench._world1_same_path(None, 0, dev, emb, ids, grads, n, 1e-3, steps=40, warmup=20)
     assert 0 < ms < 5.0
     assert not torch.equal(before, emb.table)           # the steps did push into the shard
+
+
+def _n_gt_1_worker(rank, world, port, out_path):
+    """One rank of bench.py's N>1 leg (herald_amd.sharded_bench.run) with `world` processes on ONE GPU: a gloo group, the
+    row / key exchanges staged through the host (RCCL refuses two ranks on one device)."""
+    import argparse
+    import contextlib
+    import io
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from herald_amd import sharded_bench
+
+    def staged(out, inp, out_splits, in_splits, group):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+
+    sharded_bench.A2A_HOOK = staged
+    args = argparse.Namespace(rows=400_000, width=64, batch=64, fields=26, steps=24, warmup=6, distinct_batches=32,
+                              no_cpu_baseline=True, no_config_c=False)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sharded_bench.run(args, rank, world, torch.device("cuda:0"))
+    if rank == 0:
+        with open(out_path, "w") as f:
+            f.write(buf.getvalue())
+
+
+def test_bench_n_gt_1_leg_end_to_end_with_two_ranks_on_one_gpu(dev, tmp_path):
+    """Everything bench.py --gpus N runs on a rank -- the sized FramedStep over a real (gloo) group, the same-path world-1
+    diagnostic, the reductions of the xGMI statistics, configs[2]'s shape as the second measurement -- at world size 2, and
+    the line rank 0 prints: whole-job rows/s, bytes carried = bytes useful for the rows, owner skew, both shapes."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "line.json")
+    mp.spawn(_n_gt_1_worker, args=(2, port, out), nprocs=2, join=True)
+    lines = [l for l in open(out).read().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["steps"] == 24 and d["value"] > 0
+    assert abs(d["value"] - 2 * 64 * 26 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6       # whole-job rows/s
+    x = d["xgmi"]
+    assert x["bytes_carried_per_step"] > 0 and x["owner_rows_max"] >= x["owner_rows_mean"] > 0
+    assert d["same_path_world1_ms_per_step"] is not None and d["same_path_world1_ms_per_step"] > 0
+    assert "sized" in d["config"]["exchange"]
+    c = d["config_c"]
+    assert "error" not in c and c["value"] > 0 and c["config"]["ids_per_step_per_gpu"] == 4096 * 26
+    assert c["xgmi"]["bytes_carried_per_step"] > 0
