@@ -1179,25 +1179,10 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
     const bool pull = c.data_row[u] != 0;
     float *line = c.data + static_cast<long long>(s) * c.width;
     float *out = dest + static_cast<long long>(perm[p]) * c.width;
-    // (VEC == 4: up to four 16-byte vectors per lane are LOADED before the first is stored -- `out` and `line` may alias as far
-    // as the compiler knows, and a load behind a store is a second trip to memory; the output rows are written once and
-    // read by somebody else: non-temporal stores)
     if (!pull) {
         if (VEC == 4) {
-            for (long long j0 = lane * 4; j0 < c.width; j0 += 4ll * kWave * 4) {
-                float4v v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const long long j = j0 + static_cast<long long>(k) * kWave * 4;
-                    v[k] = ld4(line + (j < c.width ? j : j0));
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const long long j = j0 + static_cast<long long>(k) * kWave * 4;
-                    if (j < c.width)
-                        st4_nt(out + j, v[k]);
-                }
-            }
+            for (long long j = lane * 4; j < c.width; j += kWave * 4)
+                st4(out + j, ld4(line + j));
         } else {
             for (long long j = lane; j < c.width; j += kWave)
                 out[j] = line[j];
@@ -1209,27 +1194,16 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
                                 : c.table + lk * c.width;
     const float *g = c.grad + static_cast<long long>(s) * c.width;
     if (VEC == 4) {
-        for (long long j0 = lane * 4; j0 < c.width; j0 += 4ll * kWave * 4) {
-            float4v x[4], gv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const long long j = j0 + static_cast<long long>(k) * kWave * 4;
-                const long long jc = j < c.width ? j : j0;
-                x[k] = ld4(src + jc);
-                gv[k] = hg ? ld4(g + jc) : float4v{0.f, 0.f, 0.f, 0.f};
+        for (long long j = lane * 4; j < c.width; j += kWave * 4) {
+            float4v x = ld4(src + j);
+            if (hg) {
+                const float4v gv = ld4(g + j);
+                x = float4v{__fadd_rn(x[0], gv[0]), __fadd_rn(x[1], gv[1]), __fadd_rn(x[2], gv[2]),
+                            __fadd_rn(x[3], gv[3])};
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const long long j = j0 + static_cast<long long>(k) * kWave * 4;
-                if (j >= c.width)
-                    continue;
-                if (hg)
-                    x[k] = float4v{__fadd_rn(x[k][0], gv[k][0]), __fadd_rn(x[k][1], gv[k][1]), __fadd_rn(x[k][2], gv[k][2]),
-                                   __fadd_rn(x[k][3], gv[k][3])};
-                st4_nt(out + j, x[k]);
-                if (head)
-                    st4(line + j, x[k]);
-            }
+            st4(out + j, x);
+            if (head)
+                st4(line + j, x);
         }
     } else {
         for (long long j = lane; j < c.width; j += kWave) {
