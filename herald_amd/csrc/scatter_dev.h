@@ -422,23 +422,13 @@ __device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, boo
     if (MODE != kModeReduce && init)
         cur = *reinterpret_cast<const float4v *>(dst_row + col);
     float4v p{0.f, 0.f, 0.f, 0.f};
-    // the occurrence indices of block b+1 are requested BEFORE the rows of block b: a run of thousands of occurrences is a
-    // chain of blocks, and index -> rows were two trips to memory per block (a key named 4,096 times at bs 4096: 16 blocks).
-    // (The rows of block b+1 as well would need 16 more registers than the kernels around this have.)  The order of the
-    // additions is unchanged.
-    auto index_of = [&](int base) {
+    for (int base = 0; base < len; base += 256) {
         const int mine = base + 16 * w;   // this wave's first occurrence of the block
+        if (mine >= len)
+            break;   // wave-uniform; no barrier inside the loop
         int pidx = perm[min(s + min(mine + (lane & 15), len - 1), n - 1)];
         if (maps.valmap)
             pidx = maps.valmap[pidx];
-        return pidx;
-    };
-    int pidx = 16 * w < len ? index_of(0) : 0;
-    for (int base = 0; base < len; base += 256) {
-        const int mine = base + 16 * w;
-        if (mine >= len)
-            break;   // wave-uniform; no barrier inside the loop
-        const int pnext = mine + 256 < len ? index_of(base + 256) : 0;
         float4v g[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -454,7 +444,6 @@ __device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, boo
                 p[k] = valid ? q : p[k];
             }
         }
-        pidx = pnext;
     }
     auto add4 = [](float4v x, float4v y) {
         return float4v{__fadd_rn(x[0], y[0]), __fadd_rn(x[1], y[1]), __fadd_rn(x[2], y[2]), __fadd_rn(x[3], y[3])};
