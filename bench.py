@@ -87,6 +87,10 @@ def parse_args():
     p.add_argument("--queue-block", type=int, default=16,
                    help="--engine queue: steps per block (the plans / queues of a block are prepared by two launches on a "
                         "side stream beside the steps of the block before; ids are needed 3 blocks ahead)")
+    p.add_argument("--span", type=int, default=None,
+                   help="--engine queue: steps ONE launch spans (ha_qapply_span: the items of consecutive steps wait for each "
+                        "other row by row instead of a launch boundary per step; the same results bit for bit).  Default: the "
+                        "block (--queue-block); 0 / 1 = one launch per step.  Plain launches only (not with --graph-steps > 1)")
     p.add_argument("--queue-serial", action="store_true",
                    help="--engine queue with the preparation launch in front of every step on the timed stream instead of "
                         "beside the steps on side streams")
@@ -529,18 +533,30 @@ def main():
     use_graph = G > 1 and args.graph_steps > 1      # --graph-steps 1: plain launches (the PMC passes)
     graphs = {}
     step_chunk = None
+    span = 0
     if queue and not use_graph:
         packs = {}
+        span = min(pipe.SPAN_MAX, args.queue_block if args.span is None else args.span)
+        span = span if span >= 2 else 0
+
+        def make_pack(k, ln):
+            bs = [(k + i) % nb for i in range(ln)]
+            mk = pipe.apply_span_call if span else pipe.apply_steps_call
+            return mk(k, [grads[x % nbuf] for x in bs], [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
+
+        def pieces(k, ln):
+            """a chunk (inside one block) as launches of at most `span` steps"""
+            if not span:
+                return [(k, ln)]
+            return [(j, min(span, k + ln - j)) for j in range(k, k + ln, span)]
 
         def step_chunk(k, ln):
-            b = k % nb
-            key = (k % rot_ring, b, ln)
-            fn = packs.get(key)
-            if fn is None:      # arguments converted once per (rotation phase, first batch, length)
-                bs = [(k + i) % nb for i in range(ln)]
-                fn = packs[key] = pipe.apply_steps_call(k, [grads[x % nbuf] for x in bs],
-                                                        [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
-            fn(k)
+            for j, m in pieces(k, ln):
+                key = (j % rot_ring, j % nb, m)
+                fn = packs.get(key)
+                if fn is None:      # arguments converted once per (rotation phase, first batch, length)
+                    fn = packs[key] = make_pack(j, m)
+                fn(j)
 
     def chunks(k0, count):
         """[k0, k0+count) cut at the multiples of G: (first step, length) pieces of at most G steps."""
@@ -598,11 +614,9 @@ def main():
     pre = min(max(args.pre_roll, 0), wu)
     if step_chunk is not None:      # convert the arguments of everything the warm-up and the timed region enqueue
         for k, ln in list(chunks(K0, wu - pre)) + list(chunks(K0 + wu - pre, pre)) + list(chunks(K0 + wu, args.steps)):
-            b = k % nb
-            if (k % rot_ring, b, ln) not in packs:
-                bs = [(k + i) % nb for i in range(ln)]
-                packs[(k % rot_ring, b, ln)] = pipe.apply_steps_call(k, [grads[x % nbuf] for x in bs],
-                                                                     [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
+            for j, m in pieces(k, ln):
+                if (j % rot_ring, j % nb, m) not in packs:
+                    packs[(j % rot_ring, j % nb, m)] = make_pack(j, m)
     if use_graph:     # capture everything the warm-up and the timed region replay, before either runs
         torch.cuda.synchronize()
         for k, ln in list(chunks(K0, wu - pre)) + list(chunks(K0 + wu - pre, pre)) + list(chunks(K0 + wu, args.steps)):
@@ -677,20 +691,29 @@ def main():
     if one:
         # the step IS one launch of ha::step_kernel: its average duration is the HIP-event time of the
         # timed region / K, measured on the launch stream
-        kname = "ha::qapply_kernel" if queue else "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
+        kname = ("ha::qapply_span_kernel" if span else "ha::qapply_kernel") if queue else \
+            "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
         traffic, traffic_src = pmc_traffic(kname)
-        dom_bytes = fwd_b + bwd_b
-        ach = dom_bytes / (dev_ms / args.steps * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": kname + (" (the items of a step: SGD apply of batch k + rows of batch k+1 "
+        # launches of the timed region (a spanning launch covers several steps: bytes and duration are per LAUNCH, the
+        # PMC traffic per launch is that of its steps)
+        n_launch = sum(len(pieces(k, ln)) for k, ln in chunks(K0 + wu, args.steps)) if span else args.steps
+        per_launch = args.steps / n_launch
+        dom_bytes = (fwd_b + bwd_b) * per_launch
+        ach = dom_bytes / (dev_ms / n_launch * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": kname + ((" (the items of %.1f consecutive steps per launch, ordered row by row "
+                                                        "inside the launch: SGD apply of batch k + rows of batch k+1 from the "
+                                                        "work queue of every step)" % per_launch) if span else
+                                                       " (the items of a step: SGD apply of batch k + rows of batch k+1 "
                                                        "from its work queue)" if queue else
                                                        " (SGD apply of batch k, rows of batch k+1, plan finish of "
                                                        "batch k+2, sort of batch k+3)" if ahead2 else
                                                        " (SGD apply + finish of batch k, gather + sort of batch k+1)"),
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_launch_us": dev_ms / args.steps * 1e3,
-                    "avg_launch_source": "HIP events around the timed region on the launch stream / steps "
-                                         "(one launch per step)",
+                    "avg_launch_us": dev_ms / n_launch * 1e3,
+                    "avg_launch_source": "HIP events around the timed region on the launch stream / its %d launches "
+                                         "(%.2f steps per launch)" % (n_launch, per_launch),
+                    "steps_per_launch": per_launch,
                     "algorithmic_bytes_per_launch": dom_bytes}
     elif not args.no_kernel_pass:
         KL = 64
@@ -754,10 +777,11 @@ def main():
                                "cache-limit-0.1 tier is not part of this line"
                                % (args.batch, args.width, args.fields, args.rows,
                                   args.rows * args.width * 4 / 1e9,
-                                  "one launch per step from a work queue: apply(k) + rows of k+1 per unique key; plans "
-                                  "and queues prepared a block of %d steps at a time by two launches on a side stream, "
-                                  "inside the timed region; keys with 16+ occurrences as row - tree_sum(lr*g)"
-                                  % args.queue_block if queue and not args.queue_serial else
+                                  ("one launch per %s from the steps' work queues: apply(k) + rows of k+1 per unique key; plans "
+                                   "and queues prepared a block of %d steps at a time by two launches on a side stream, "
+                                   "inside the timed region; keys with 16+ occurrences as row - tree_sum(lr*g)"
+                                   % ("up to %d steps (their items ordered row by row inside the launch)" % span if span
+                                      else "step", args.queue_block)) if queue and not args.queue_serial else
                                   "three launches per step: plan of batch k+2, queue of step k+1, then the items of step "
                                   "k from its queue" if queue else
                                   "one launch: apply(k), rows of k+1 forwarded / copied, finish(k+2), sort(k+3)" if ahead2 else
@@ -773,7 +797,9 @@ def main():
                    "numerics": "tolerance>=16" if queue else "bit-exact",
                    "stream_sync": (pipe.sync if queue and not args.queue_serial else None),
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
+                             else ("plain launches, one per span of up to %d steps, enqueued ahead of the device" % span) if span
                              else "plain launches, one per step, enqueued ahead of the device",
+                   "span_steps": span,
                    "parallelism": "1 GPU"},
         "step_algorithmic_bytes": fwd_b + bwd_b,
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,

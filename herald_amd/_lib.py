@@ -117,6 +117,8 @@ def _declare(L):
     L.ha_host_unmap.argtypes = [vp]
     L.ha_qbig_max_ids.restype = i64
     L.ha_qbig_max_ids.argtypes = []
+    L.ha_qapply_span_max.restype = i64
+    L.ha_qapply_span_max.argtypes = []
     L.ha_qbig_plan_bytes.restype = sz
     L.ha_qbig_plan_bytes.argtypes = [i64]
     L.ha_qbig_buckets.restype = c.c_int
@@ -177,6 +179,9 @@ def _declare(L):
         "ha_qqueue_batch_epochs": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
         "ha_qapply_steps_sync": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qapply_sync": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, c.c_uint32, vp, vp, vp],
+        "ha_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "ha_debug_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp],
+        "ha_qqueue_batch_span": [i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
         "ha_qbig_plan_view": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
         "ha_plan_build_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_plan_build_batch_u64ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],

@@ -29,6 +29,8 @@ struct PlanPtrs {
     uint32_t *bucket_start;  // [kRadixBuckets + 1] first sorted position of every most-significant-digit bucket
     uint32_t *pass_flags;    // [kRadixFusedBlocks] one-launch radix passes: tile t has published its histogram of pass k
     uint32_t *block_sums;  // finish scan scratch
+    uint32_t *dep;         // [2 n] work-queue step spanning several batches (qstep.hip): per group, at its segment start,
+                           // {units of the row READY for this batch's apply, units APPLIED by it}
     size_t bytes;
 };
 
@@ -65,6 +67,7 @@ static inline PlanPtrs plan_layout(void *ws, int64_t n) {
     p.pass_flags = reinterpret_cast<uint32_t *>(take(kRadixFusedBlocks * 4));
     const size_t nfin = (static_cast<size_t>(n) + kFinishTile - 1) / kFinishTile;
     p.block_sums = reinterpret_cast<uint32_t *>(take((nfin + 1) * 4));
+    p.dep = reinterpret_cast<uint32_t *>(take(2 * n4));
     p.bytes = off;
     return p;
 }

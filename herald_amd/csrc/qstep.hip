@@ -88,7 +88,14 @@ struct QHeader {
     // of its step checks both words before it reads an item (ha_qapply_steps_sync): callers that order the two streams
     // without a wait on the apply's stream rest on it.  `done`: wide path, bucket workgroups that have finished.
     uint32_t epoch_wave, epoch_copy, done;
-    uint32_t reserved[51];
+    // a launch that SPANS several steps (qapply_span_kernel): workgroups of this step that have finished all their items (a
+    // copy item of step s + 2 reads a row whose last writer may be any earlier step: it waits for this count of step s), and
+    // "somebody gave up waiting" (in the header of the span's first step: every wait of the launch looks at it).  Zeroed
+    // by the queue's builder.
+    uint32_t wg_done, abort;
+    uint32_t all_done;         // 1: this step AND every earlier step of its launch have finished (set by the workgroup of the
+                               // step that finishes last, once the step before carries the word)
+    uint32_t reserved[48];
 };
 static_assert(sizeof(QHeader) == 256, "queue header is one 256-byte line");
 struct QEntry {
@@ -144,6 +151,7 @@ struct QPlan {   // what the roles read / write of a plan workspace
     uint32_t *keys, *sorted, *uniq;
     int32_t *perm, *inverse, *counts, *seg, *upos;
     uint32_t *occ;     // [2 * n]: per group, the first three occurrence indices packed by q_occ_pack (A writes, B reads)
+    uint32_t *dep;     // [2 * n]: {ready, applied} counters of the group whose occurrence list starts at position i, at 2 i
     int n;
 };
 static inline QPlan qplan(void *ws, int64_t n) {
@@ -155,6 +163,7 @@ static inline QPlan qplan(void *ws, int64_t n) {
     q.hdr = p.hdr; q.keys = p.keys; q.sorted = p.sorted; q.uniq = p.uniq;
     q.perm = p.perm; q.inverse = p.inverse; q.counts = p.counts; q.seg = p.seg; q.upos = p.upos;
     q.occ = p.keys_alt;     // keys_alt and perm_alt are adjacent scratch arrays of n words each
+    q.dep = p.dep;
     q.n = static_cast<int>(n);
     return q;
 }
@@ -179,7 +188,8 @@ struct QArgs {
     int ncoop, nworker;
     uint32_t epoch;            // 0: no check; else the tag queue `qh` must carry before an item is read
     uint32_t *err;             // pinned host word raised (8) when the queue never became ready (may be NULL)
-    unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind} per wave
+    unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind | step << 8} per wave
+    uint32_t step;             // index of the step in its launch (time stamps)
 };
 
 // development aid: phase time stamps of the single-workgroup roles (thread 0; ph = nullptr in production)
@@ -460,6 +470,9 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         p.hdr->reserved[kOrderFlagWord] = 0;
         p.seg[U] = n;
     }
+    if (!BUCKET && p.dep != nullptr)      // the dependency counters of a launch that spans several steps start at zero
+        for (int i = tid; i < 2 * n; i += NT)
+            p.dep[i] = 0u;
     __syncthreads();
     q_phase(ph, 6);
     // Outputs.  Every array leaves through LDS so that the global stores are contiguous (scattered 4-byte stores of one
@@ -640,6 +653,12 @@ struct QJoin {      // what every part of the join needs (passed by reference to
     uint32_t st_base, fs_base;      // wide path: where this bucket's occurrence / destination lists start in the batch's
     uint32_t tid, nt;               // the thread's index in its group of nt threads (the workgroup, or a quarter of it)
     int tbits;                      // the table has 1 << tbits slots
+    // part 1 only: the batch BEFORE the batch to apply (b).  A key only the lookup names is a plain copy of its row -- whose
+    // last writer is step s - 1 when b names it: the copy item then carries where b's group of the key starts (+ 1), and a
+    // launch that spans both steps makes the copy wait for that group's "applied" counter (qapply_span_kernel).
+    QPlan pb;
+    int Ubb;
+    uint32_t *s_tab2, *s_bk2;
 };
 
 // group index of `key` in the table, or 0xFFFFFFFF
@@ -649,6 +668,16 @@ __device__ __forceinline__ uint32_t qjoin_probe(const QJoin &j, uint32_t key) {
     for (;;) {
         const uint32_t e = j.s_tab[h];
         if (e == kQTabEmpty || j.s_bk[e] == key)
+            return e;
+        h = (h + 1) & mask;
+    }
+}
+__device__ __forceinline__ uint32_t qjoin_probe2(const QJoin &j, uint32_t key) {   // the same in the table of batch b's keys
+    uint32_t h = q_hash(key, j.tbits);
+    const uint32_t mask = (1u << j.tbits) - 1u;
+    for (;;) {
+        const uint32_t e = j.s_tab2[h];
+        if (e == kQTabEmpty || j.s_bk2[e] == key)
             return e;
         h = (h + 1) & mask;
     }
@@ -746,9 +775,16 @@ __device__ __forceinline__ QCount qjoin_emit_copies(const QJoin &j, QCount b) {
     }
 #pragma unroll
     for (int r = R0; r < R1; ++r)
-        if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
+        if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty) {
+            uint32_t dep = 0u;      // where the key's group starts in batch b's occurrence lists, + 1 (0: b does not name it)
+            if (j.Ubb > 0) {
+                const uint32_t e2 = qjoin_probe2(j, kg[r - R0]);
+                if (e2 != kQTabEmpty)
+                    dep = static_cast<uint32_t>(j.pb.seg[e2]) + 1u;
+            }
             b = qjoin_emit_one(j, b, j.bcopy, j.bcap_copy, kg[r - R0], 0u, 0u, mfs[r - R0] & 0xFFFFu, mfs[r - R0] >> 16,
-                               0u, 0u);
+                               dep, 0u);
+        }
     return b;
 }
 
@@ -765,7 +801,8 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
                                            uint32_t *lds, uint32_t lds_bytes, const int part,
                                            unsigned long long *ph = nullptr, uint32_t *mirror = nullptr,
                                            const uint32_t st_base = 0, const uint32_t fs_base = 0,
-                                           const uint32_t epoch = 0, const uint32_t wide_parts = 0, const bool signal = true) {
+                                           const uint32_t epoch = 0, const uint32_t wide_parts = 0, const bool signal = true,
+                                           const QPlan *pb = nullptr) {
     constexpr int TS = 1 << TBITS;
     const int tid = static_cast<int>(threadIdx.x) & (NT - 1), w = tid >> 6;
     q_phase(ph, 0);
@@ -789,6 +826,14 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     j.s_bk = lds + TS;
     j.s_cs = j.s_bk + j.Ub;
     j.s_w = j.s_bk + (j.cs_res ? 2 * j.Ub : j.Ub);
+    j.Ubb = 0;
+    j.s_tab2 = j.s_bk2 = nullptr;
+    if (!WIDE && part == 1 && pb != nullptr && pb->n > 0) {      // (the launch's LDS holds the second table: qqueue_batch)
+        j.pb = *pb;
+        j.Ubb = uniform(static_cast<int>(pb->hdr->n_unique));
+        j.s_tab2 = j.s_w + 32;
+        j.s_bk2 = j.s_tab2 + TS;
+    }
     j.bqh = bqh;
     j.bcoop = bcoop;
     j.bwave = bwave;
@@ -811,8 +856,24 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
         if (j.cs_res)
             j.s_cs[y] = static_cast<uint32_t>(pg.counts[y]) | (static_cast<uint32_t>(pg.seg[y]) << 16);
     }
+    if (j.Ubb > 0) {
+        for (int i = tid; i < TS; i += NT)
+            j.s_tab2[i] = kQTabEmpty;
+        for (int y = tid; y < j.Ubb; y += NT)
+            j.s_bk2[y] = j.pb.uniq[y];
+    }
     __syncthreads();
     q_phase(ph, 1);
+    for (int y = tid; y < j.Ubb; y += NT) {
+        uint32_t h = q_hash(j.s_bk2[y], TBITS);
+        for (;;) {
+            uint32_t seen = kQTabEmpty;
+            if (__hip_atomic_compare_exchange_strong(j.s_tab2 + h, &seen, static_cast<uint32_t>(y), __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                break;
+            h = (h + 1) & (TS - 1);
+        }
+    }
     for (int y = tid; y < j.Ub; y += NT) {
         uint32_t h = q_hash(j.s_bk[y], TBITS);
         for (;;) {
@@ -866,6 +927,9 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             b.g += bc;
         }
         if (!WIDE && tid == 0) {
+            __hip_atomic_store(&bqh->wg_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&bqh->abort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&bqh->all_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bqh->n_wave = min(nL + nM + nS, bcap_wave);
             bqh->n_coop = min(nG, bcap_coop);
             bqh->n_long = nL;
@@ -1059,6 +1123,105 @@ __device__ __forceinline__ V q_ld_grad(const float *p) {
 #endif
 }
 
+// ---- a launch that SPANS several steps (qapply_span_kernel) ---------------------------------------------------------------
+// Consecutive steps touch the same rows: step s applies batch s and writes the rows of batch s + 1, so EVERY key step s + 1
+// applies was read or written by an item of step s, and a key only batch s + 2 names may have been written by any step
+// before.  One launch per step orders them by the launch boundary -- a ramp, a tail that runs at a third of the chip's
+// waves, and the boundary itself, every 12 us.  A launch that spans a block of steps orders them item by item instead:
+//   ready[g]    (plan of batch s, at the start of group g's occurrence list)  units of 32 columns of g's row that step
+//               s - 1 has read / written for the last time (its apply item of the key, or its copy item): the apply
+//               item of g in step s waits for all of them, then loads the row;
+//   applied[g]  units of g's row that step s has written: a copy item of step s + 1 whose key batch s names (found by the
+//               queue builder's second table) waits for all of them;
+//   all_done    (queue header of step s) step s and every earlier step of the launch have finished -- the workgroup whose
+//               add to the header's `wg_done` completes the step's count waits for the word of the step before and sets it:
+//               copy items of step s + 2 wait for it (a row's last writer may be ANY earlier step; two steps back
+//               everything has long finished).
+// Waits never cross the launch's first step (what is before it is ordered by the stream).  Rows are handed over the way
+// step.hip does it: the writer stores them THROUGH the L2 (`sc1`), drains (`s_waitcnt vmcnt(0)`) and adds to the counter
+// with a relaxed device-scope atomic; the reader polls with relaxed device-scope loads and then loads the row with `sc1`
+// loads -- EVERY row load and store of a spanning launch is `sc1` (a row may have been rewritten by another XCD since
+// this one last saw it).  Gradient rows and the next batch's output rows are never handed over inside a launch.
+// Progress: workgroups are dispatched in grid order and every wait is for an item of an EARLIER step, i.e. of a workgroup
+// with a smaller index; waits are bounded (~2 s) and raise the launch's abort word + the caller's pinned error word.
+struct QDep {
+    uint32_t *dep_a;             // {ready, applied} pairs of the batch to apply (null: nothing is applied)
+    uint32_t *dep_g;             // ... of the batch to look up
+    const uint32_t *dep_b;       // ... of the batch before the batch to apply (null: this is the span's first step)
+    const uint32_t *done_pp;     // all_done of the step two back (null: none inside this launch)
+    const uint32_t *done_p;      // all_done of the step before (null: this is the span's first step)
+    uint32_t done_target;        // workgroups of THIS step
+    uint32_t full;               // units of a whole row
+    uint32_t wait_a;             // 0: the span's first step (no apply item waits)
+    uint32_t *abort_w, *err;
+    uint32_t *wacc;              // time stamps only: LDS words, per wave the 10 ns ticks it spent waiting (else null)
+};
+__device__ __forceinline__ void q_raise(const QDep &d) {
+    if (lane_id() == 0) {
+        if (d.err != nullptr)
+            __hip_atomic_store(d.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(d.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// wave-uniform p: true once *p >= target; false if the launch was aborted or the wait gave up (it then raises)
+__device__ __forceinline__ bool q_wait_ge(const uint32_t *p, uint32_t target, const QDep &d) {
+    uint32_t v = uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= target)
+        return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t spin = 1;; ++spin) {
+        __builtin_amdgcn_s_sleep(4);
+        v = uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= target) {
+            if (d.wacc != nullptr && lane_id() == 0)
+                d.wacc[threadIdx.x >> 6] += static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime() - t0);
+            return true;
+        }
+        if ((spin & 31u) == 0u) {
+            if (uniform(__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+                return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {      // 2 s of the 100 MHz counter
+                q_raise(d);
+                return false;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void q_signal(uint32_t *p, uint32_t units) {      // (behind the caller's s_waitcnt vmcnt(0))
+    if (lane_id() == 0)
+        __hip_atomic_fetch_add(p, units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void q_drain() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void wait_loads2(float4v &a, float4v &b) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+}
+__device__ __forceinline__ void wait_loads1(float4v &a) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a)::"memory");
+}
+__device__ __forceinline__ void st2_sc1(float *p, float2v_ v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// what an item of a spanning launch waits for before it touches its row (wave-uniform; false: give up, touch nothing)
+__device__ __forceinline__ bool q_dep_wait(const QDep &d, uint32_t c, uint32_t st, uint32_t dep1) {
+    if (c > 0u)
+        return d.wait_a == 0u || q_wait_ge(d.dep_a + 2u * st, d.full, d);
+    if (d.done_pp != nullptr && !q_wait_ge(d.done_pp, 1u, d))
+        return false;
+    if (d.dep_b != nullptr && dep1 != 0u)
+        return q_wait_ge(d.dep_b + 2u * (dep1 - 1u) + 1u, d.full, d);
+    return true;
+}
+// ... and what it adds once its row is in memory and its last read of the row is done (units of 32 columns)
+__device__ __forceinline__ void q_dep_signal(const QDep &d, uint32_t c, uint32_t st, uint32_t m, uint32_t fs, int cols) {
+    const uint32_t units = static_cast<uint32_t>(cols + 31) / 32u;
+    if (m > 0u)
+        q_signal(d.dep_g + 2u * fs, units);
+    if (c > 0u)
+        q_signal(d.dep_a + 2u * st + 1u, units);
+}
+
 struct QItem {
     int kind, col0, cols;
     uint32_t key, c, st, m, fs, o01, o23;
@@ -1081,7 +1244,10 @@ __device__ __forceinline__ QItem q_load(const QEntry *e, int width) {
 }
 
 // S / Z: <= 512 columns by one wave, c <= 3 occurrences, two 16-byte vectors per lane
-__device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
+// (SPAN: an item of a launch that spans several steps -- the row is loaded behind the item's wait, through the L2 both ways,
+// and the item's counters are raised at the end; false = the launch was aborted, nothing was touched)
+template <bool SPAN>
+__device__ __forceinline__ bool q_small(const QArgs &a, const QItem &it, const QDep &d) {
     const int lane = lane_id();
     const int width = a.width;
     const int ca = it.col0 + 4 * lane, cb = ca + 256;
@@ -1089,7 +1255,7 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
     const int la = a0 ? ca : it.col0, lb = a1 ? cb : it.col0;   // loads stay branch-free: clamped columns
     float *row = a.table + static_cast<uint64_t>(it.kind == kQZ ? 0u : it.key) * static_cast<uint64_t>(width);
     float4v r0{0.f, 0.f, 0.f, 0.f}, r1{0.f, 0.f, 0.f, 0.f};
-    if (it.kind != kQZ) {   // every branch on the item is wave-uniform
+    if (!SPAN && it.kind != kQZ) {   // every branch on the item is wave-uniform
         r0 = q_ld_row<float4v>(row + la);
         r1 = q_ld_row<float4v>(row + lb);
     }
@@ -1107,6 +1273,14 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
             g1[t] = q_ld_grad<float4v>(src + lb);
         }
     }
+    if (SPAN && it.kind != kQZ) {
+        // the gradient rows are on their way; the row itself only once whoever touched it in the step before is done
+        if (!q_dep_wait(d, it.c, it.st, it.o01))
+            return false;
+        r0 = ld4_sc1_async(row + la);
+        r1 = ld4_sc1_async(row + lb);
+        wait_loads2(r0, r1);
+    }
 #pragma unroll
     for (int t = 0; t < kQSmallC; ++t) {
         if (static_cast<uint32_t>(t) < it.c) {
@@ -1115,10 +1289,17 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
         }
     }
     if (it.c > 0) {
-        if (a0)
-            q_st_row(row + ca, r0);
-        if (a1)
-            q_st_row(row + cb, r1);
+        if (SPAN) {
+            if (a0)
+                st4_sc1(row + ca, r0);
+            if (a1)
+                st4_sc1(row + cb, r1);
+        } else {
+            if (a0)
+                q_st_row(row + ca, r0);
+            if (a1)
+                q_st_row(row + cb, r1);
+        }
     }
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
@@ -1133,6 +1314,11 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
                 q_st_out(o + cb, r1);
         }
     }
+    if (SPAN && it.kind != kQZ) {
+        q_drain();
+        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+    }
+    return true;
 }
 
 // Two S items by ONE wave, rows of at most 128 columns: lanes 0-31 take item A, lanes 32-63 item B (a 512-byte row is
@@ -1182,7 +1368,8 @@ __device__ __forceinline__ void q_small_pair(const QArgs &a, const QEntry *ea, c
 }
 
 // M: one 128-column slice, c <= 15 occurrences, 8 bytes per lane, ordered chain
-__device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
+template <bool SPAN>
+__device__ __forceinline__ bool q_medium(const QArgs &a, const QItem &it, const QDep &d) {
     const int lane = lane_id();
     const int width = a.width;
     const int col = it.col0 + 2 * lane;
@@ -1194,7 +1381,9 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
         pidx = a.perm_a[it.st + min(static_cast<uint32_t>(lane), it.c - 1u)];
     if (it.m > 0)
         dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
-    float2v_ r = q_ld_row<float2v_>(row + lc);
+    float2v_ r{0.f, 0.f};
+    if (!SPAN)
+        r = q_ld_row<float2v_>(row + lc);
     // branch-free: lanes >= c hold the index of the last occurrence, so the loads beyond c repeat a line the wave
     // has just asked for and the chain skips them by select (uniform branches around 15 loads make the compiler
     // spill; clamped loads are what scatter_dev.h does as well)
@@ -1205,6 +1394,13 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
         const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(pidx, t));
         g[t] = q_ld_grad<float2v_>(gbase + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + lc);
     }
+    if (SPAN) {
+        // (c == 0: the "gradient" loads above re-read the row itself, plainly -- their values are never used)
+        if (!q_dep_wait(d, it.c, it.st, it.o01))
+            return false;
+        r[0] = __hip_atomic_load(row + lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r[1] = __hip_atomic_load(row + lc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int t = 0; t < kQMediumC; ++t) {
         const float x0 = __fsub_rn(r[0], __fmul_rn(a.lr, g[t][0]));
@@ -1213,8 +1409,12 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
         r[0] = on ? x0 : r[0];
         r[1] = on ? x1 : r[1];
     }
-    if (it.c > 0 && act)
-        q_st_row(row + col, r);
+    if (it.c > 0 && act) {
+        if (SPAN)
+            st2_sc1(row + col, r);
+        else
+            q_st_row(row + col, r);
+    }
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
             dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
@@ -1226,10 +1426,16 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
                 q_st_out(o + col, r);
         }
     }
+    if (SPAN) {
+        q_drain();
+        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+    }
+    return true;
 }
 
 // L: one 32-column slice, 16 <= c < 64: lane = (occurrence group r of 8, column quad c4); fixed-order tree
-__device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
+template <bool SPAN>
+__device__ __forceinline__ bool q_long(const QArgs &a, const QItem &it, const QDep &d) {
     const int lane = lane_id();
     const int width = a.width;
     const int r = lane >> 3, c4 = lane & 7;
@@ -1240,7 +1446,9 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     int dv = 0;
     if (it.m > 0)
         dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
-    const float4v cur = q_ld_row<float4v>(row + col);
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (!SPAN)
+        cur = q_ld_row<float4v>(row + col);
     float4v g[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -1258,25 +1466,45 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     p = add4(p, shfl_xor4(p, 8));
     p = add4(p, shfl_xor4(p, 16));
     p = add4(p, shfl_xor4(p, 32));
+    if (SPAN) {      // the row is needed for the last subtraction only
+        if (!q_dep_wait(d, it.c, it.st, 0u))
+            return false;
+        cur = ld4_sc1_async(row + col);
+        wait_loads1(cur);
+    }
     const float4v nv = sub4(cur, p);
-    if (r == 0 && act)
-        q_st_row(row + col, nv);
+    if (r == 0 && act) {
+        if (SPAN)
+            st4_sc1(row + col, nv);
+        else
+            q_st_row(row + col, nv);
+    }
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
             dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
         const uint32_t cnt = min(64u, it.m - j0);
         for (uint32_t j = 0; j < cnt; j += 8) {
-            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(min(j + r, cnt - 1u)), 64));
+            const uint32_t dd = static_cast<uint32_t>(__shfl(dv, static_cast<int>(min(j + r, cnt - 1u)), 64));
             if (j + r < cnt && act)
-                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+                q_st_out(a.out + static_cast<uint64_t>(dd) * static_cast<uint64_t>(width) + col, nv);
         }
     }
+    if (SPAN) {
+        q_drain();
+        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+    }
+    return true;
 }
 
 #if QV_GOLD   // the product's G item: sixteen waves per 64-column slice
 // G: one 64-column slice by a whole workgroup, c >= 64.  lane = (row r of 4, column quad c4 of 16); wave w takes
 // occurrences 16w .. 16w+15 of every block of 256 (four 16-byte loads per lane and block).  s_part = 16 x 64 floats.
-__device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float *s_part, uint32_t e) {
+// SPAN: s_part[16 * 64] is followed by the workgroup's control words; [1] = "the wait of wave 0 succeeded".  The row is
+// loaded by all waves behind wave 0's wait and a barrier (only the workgroup that writes it needs it: a chunk that is not
+// the last one to deliver leaves before); wave 0 raises the counters behind the item's last barrier -- every wave has
+// used its copy of the row by then.
+template <bool SPAN>
+__device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float *s_part, uint32_t e, const QDep &d) {
     const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int width = a.width;
     const int r = lane >> 4, c4 = lane & 15;
@@ -1286,7 +1514,9 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
     // a key with more than kQChunk occurrences arrives as `nch` items per slice: this one sums chunk `ch`
     const uint32_t ch = it.o01 & 0xFFFFu, nch = it.o01 >> 16;
     const uint32_t c_lo = kQChunk * ch, c_hi = nch > 1u ? min(it.c, c_lo + kQChunk) : it.c;
-    float4v cur = q_ld_row<float4v>(row + col);
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (!SPAN)
+        cur = q_ld_row<float4v>(row + col);
     // destinations of this wave: j = 64 * k + 4 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 2, l & 3):
     // one register covers the first 16 rounds (1,024 destinations)
     int dv = 0;
@@ -1339,7 +1569,7 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
         const bool last = *s_flag + 1u == nch;
         __syncthreads();
         if (!last)
-            return;
+            return true;
         // the chunk sums, four loads in flight at a time, added in chunk order
         const float *pp = a.qpart + static_cast<size_t>(first) * 64 + 4 * c4;
         float4v tot{0.f, 0.f, 0.f, 0.f};
@@ -1356,9 +1586,28 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
         }
         total = tot;
     }
+    if (SPAN) {
+        uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_part) + kQWpw * 64;
+        if (w == 0) {
+            const bool ok = q_dep_wait(d, it.c, it.st, 0u);
+            if (lane == 0)
+                s_ctl[1] = ok ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool ok = uniform(s_ctl[1]) != 0u;
+        if (!ok)
+            return false;
+        cur = ld4_sc1_async(row + col);
+        wait_loads1(cur);
+        __syncthreads();     // every wave holds the OLD row before wave 0 stores the new one
+    }
     const float4v nv = sub4(cur, total);
-    if (w == 0 && r == 0 && act)
-        q_st_row(row + col, nv);
+    if (w == 0 && r == 0 && act) {
+        if (SPAN)
+            st4_sc1(row + col, nv);
+        else
+            q_st_row(row + col, nv);
+    }
     for (uint32_t k0 = 0; k0 * 64u < it.m; k0 += 16) {
         if (k0 > 0)
             dv = a.perm_g[it.fs + min(64u * (k0 + static_cast<uint32_t>(lane >> 2)) + static_cast<uint32_t>(4 * w + (lane & 3)),
@@ -1366,12 +1615,17 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
         const uint32_t rounds = min(16u, (it.m - 64u * k0 + 63u) / 64u);
         for (uint32_t k = 0; k < rounds; ++k) {
             const uint32_t j = 64u * (k0 + k) + static_cast<uint32_t>(4 * w + r);
-            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(4 * k) + r, 64));
+            const uint32_t dd = static_cast<uint32_t>(__shfl(dv, static_cast<int>(4 * k) + r, 64));
             if (j < it.m && act)
-                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+                q_st_out(a.out + static_cast<uint64_t>(dd) * static_cast<uint64_t>(width) + col, nv);
         }
     }
     __syncthreads();   // s_part is reused by the next item of this workgroup
+    if (SPAN && w == 0) {
+        q_drain();
+        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+    }
+    return true;
 }
 
 #endif
@@ -1380,14 +1634,17 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
 // the run -- lane = (occurrence group r of 8, column quad c4 of 8), wave w takes occurrences 64w .. 64w+63 of every
 // block of 256 (eight 16-byte loads per lane and block) --, the four wave sums meet in LDS as (w0 + w1) + (w2 + w3).
 // s_part = 4 x 32 floats.
-__device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s_part) {
+template <bool SPAN>
+__device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s_part, const QDep &d) {
     const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int width = a.width;
     const int r = lane >> 3, c4 = lane & 7;
     const bool act = 4 * c4 < it.cols;
     const int col = it.col0 + (act ? 4 * c4 : 0);
     float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
-    const float4v cur = q_ld_row<float4v>(row + col);
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (!SPAN)
+        cur = q_ld_row<float4v>(row + col);
     // destinations of this wave: j = 8 W * k + 8 * w + r in round k (W waves).  Lane l fetches the one of (k, r) =
     // (l >> 3, l & 7): one register covers eight rounds
     constexpr uint32_t kDW = 8u * kQWpw, kBlk = 64u * kQWpw;
@@ -1426,9 +1683,28 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
     for (int q = 1; q < kQWpw / 4; ++q)        // (timing variants with larger workgroups; the product has four waves)
         total = add4(total, add4(add4(*reinterpret_cast<const float4v *>(sp + 128 * q), *reinterpret_cast<const float4v *>(sp + 128 * q + 32)),
                                  add4(*reinterpret_cast<const float4v *>(sp + 128 * q + 64), *reinterpret_cast<const float4v *>(sp + 128 * q + 96))));
+    if (SPAN) {      // (as q_coop_r3)
+        uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_part) + kQWpw * 64;
+        if (w == 0) {
+            const bool ok = q_dep_wait(d, it.c, it.st, 0u);
+            if (lane == 0)
+                s_ctl[1] = ok ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool ok = uniform(s_ctl[1]) != 0u;
+        if (!ok)
+            return false;
+        cur = ld4_sc1_async(row + col);
+        wait_loads1(cur);
+        __syncthreads();
+    }
     const float4v nv = sub4(cur, total);
-    if (w == 0 && r == 0 && act)
-        q_st_row(row + col, nv);
+    if (w == 0 && r == 0 && act) {
+        if (SPAN)
+            st4_sc1(row + col, nv);
+        else
+            q_st_row(row + col, nv);
+    }
     for (uint32_t k0 = 0; k0 * kDW < it.m; k0 += 8) {
         if (k0 > 0)
             dv = a.perm_g[it.fs + min(kDW * (k0 + static_cast<uint32_t>(lane >> 3)) + static_cast<uint32_t>(8 * w + (lane & 7)),
@@ -1436,23 +1712,37 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
         const uint32_t rounds = min(8u, (it.m - kDW * k0 + kDW - 1u) / kDW);
         for (uint32_t k = 0; k < rounds; ++k) {
             const uint32_t j = kDW * (k0 + k) + static_cast<uint32_t>(8 * w + r);
-            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(8 * k) + r, 64));
+            const uint32_t dd = static_cast<uint32_t>(__shfl(dv, static_cast<int>(8 * k) + r, 64));
             if (j < it.m && act)
-                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+                q_st_out(a.out + static_cast<uint64_t>(dd) * static_cast<uint64_t>(width) + col, nv);
         }
     }
     __syncthreads();   // s_part is reused by the next item of this workgroup
+    if (SPAN && w == 0) {
+        q_drain();
+        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+    }
+    return true;
 }
 
 // ---- the three launches ----------------------------------------------------------------------------------------
 // The items of one step: workgroups [0, ncoop) take the G items, the others one wave item per wave.
 static_assert(kQWg == 256 || kQWg == 512 || kQWg == 1024, "workgroups of 4, 8 or 16 waves");
 static_assert(!QV_GOLD || kQWg == 1024, "the sixteen-wave G item needs 1024-thread workgroups");
-__global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+// The items of ONE step by the workgroup `b` of its step's grid: workgroups [0, ncoop) take the G items, the others one wave
+// item per wave.  SPAN: the step is one of several of a launch (qapply_span_kernel): `d` says what its items wait for and
+// raise, `gb` = the workgroup's index in the launch (time stamps).
+template <bool SPAN>
+__device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b, uint32_t *s_dyn, const unsigned gb) {
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
-    int b = blockIdx.x;
+    bool alive = true;
+    uint32_t *s_ctl = s_dyn + kQWpw * 64;     // SPAN: [0] waves of this workgroup that have finished, [1] q_coop_r3's
+    if (SPAN) {
+        if (threadIdx.x < 32)
+            s_ctl[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     if (a.epoch != 0u) {
         // The caller orders this launch behind the queue's builder without a wait on this stream (the builder ran a block of
         // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
@@ -1464,11 +1754,17 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
             ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
             if (ready)
                 break;
+            if (SPAN && (spin & 63) == 63 &&
+                uniform(__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+                break;
             __builtin_amdgcn_s_sleep(64);
         }
         if (!ready) {
-            if (a.err != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+            if (SPAN) {
+                q_raise(d);      // every wait of the launch sees the abort word: nothing else is applied
+            } else if (a.err != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
                 __hip_atomic_store(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return;
         }
     }
@@ -1476,12 +1772,12 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
     if (coop) {
         role = 0;
         const uint32_t n = min(a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
-        for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
+        for (uint32_t e = static_cast<uint32_t>(b); e < n && alive; e += static_cast<uint32_t>(a.ncoop)) {
             const QItem it = q_load(a.qcoop + e, a.width);
 #if QV_GOLD
-            q_coop_r3(a, it, reinterpret_cast<float *>(s_dyn), e);
+            alive = q_coop_r3<SPAN>(a, it, reinterpret_cast<float *>(s_dyn), e, d);
 #else
-            q_coop(a, it, reinterpret_cast<float *>(s_dyn));
+            alive = q_coop<SPAN>(a, it, reinterpret_cast<float *>(s_dyn), d);
 #endif
             kind = it.kind;
         }
@@ -1491,7 +1787,7 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
         const uint32_t n0 = min(a.qh->n_wave, a.cap_wave), n = n0 + min(a.qh->n_copy, a.cap_copy);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
-        if (a.width <= 128) {
+        if (!SPAN && a.width <= 128) {
             // narrow rows: every wave takes a PAIR of consecutive items; two S / Z items share the wave (q_small_pair),
             // anything else is done one after the other
             const uint32_t n1 = n - n0, both = 2u * (n0 < n1 ? n0 : n1), npair = (n + 1u) / 2u;
@@ -1519,15 +1815,15 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
                     const QItem it = q_load(src[h], a.width);
                     kind = it.kind;
                     if (it.kind == kQL)
-                        q_long(a, it);
+                        q_long<false>(a, it, d);
                     else if (it.kind == kQM)
-                        q_medium(a, it);
+                        q_medium<false>(a, it, d);
                     else
-                        q_small(a, it);
+                        q_small<false>(a, it, d);
                 }
             }
         } else
-        for (uint32_t e = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv; e < n; e += stride) {
+        for (uint32_t e = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv; e < n && alive; e += stride) {
 #if QV_INTERLEAVE
             // Wave items and copy items ALTERNATE over the launch while both last (then the rest of the longer list):
             // a copy writes m rows for one it reads, an apply item reads more than it writes, and a compute unit that
@@ -1546,11 +1842,47 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
 #endif
             kind = it.kind;
             if (it.kind == kQL)
-                q_long(a, it);
+                alive = q_long<SPAN>(a, it, d);
             else if (it.kind == kQM)
-                q_medium(a, it);
+                alive = q_medium<SPAN>(a, it, d);
             else
-                q_small(a, it);
+                alive = q_small<SPAN>(a, it, d);
+        }
+    }
+    if (SPAN && alive) {
+        // this workgroup's share of "step s has finished" (qh->wg_done): the wave that finishes last adds it -- every
+        // wave's stores have been drained behind its last item
+        bool last;
+        if (coop) {
+            last = threadIdx.x == 0;       // (behind the G item's closing barrier)
+        } else {
+            uint32_t old = 0;
+            if (lane_id() == 0)
+                old = __hip_atomic_fetch_add(s_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            last = lane_id() == 0 && old + 1u == static_cast<uint32_t>(kQWpw);
+        }
+        if (last) {
+            QHeader *h = const_cast<QHeader *>(a.qh);
+            const uint32_t before = __hip_atomic_fetch_add(&h->wg_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1u == d.done_target) {
+                // the step's last workgroup: once the step before is marked, this one is
+                bool ok = true;
+                if (d.done_p != nullptr) {
+                    uint32_t v = __hip_atomic_load(d.done_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long tw = __builtin_amdgcn_s_memrealtime();
+                    while (v == 0u) {
+                        __builtin_amdgcn_s_sleep(4);
+                        v = __hip_atomic_load(d.done_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v == 0u && (__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                        __builtin_amdgcn_s_memrealtime() - tw > 200000000ull)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                }
+                if (ok)
+                    __hip_atomic_store(&h->all_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (a.dbg) {
@@ -1559,13 +1891,102 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
         if (lane_id() == 0) {
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long *d = a.dbg + (static_cast<size_t>(blockIdx.x) * kQWpw + (threadIdx.x >> 6)) * 4;
-            d[0] = t0;
-            d[1] = t1;
-            d[2] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8);
-            d[3] = static_cast<unsigned long long>(static_cast<unsigned>(kind));
+            unsigned long long *dd = a.dbg + (static_cast<size_t>(gb) * kQWpw + (threadIdx.x >> 6)) * 4;
+            dd[0] = t0;
+            dd[1] = t1;
+            dd[2] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8) |
+                    (SPAN ? static_cast<unsigned long long>(s_ctl[8 + (threadIdx.x >> 6)]) << 16 : 0ull);
+            dd[3] = static_cast<unsigned long long>(static_cast<unsigned>(kind) & 0xFFu) |
+                    (static_cast<unsigned long long>(a.step) << 8);
         }
     }
+}
+
+__global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    QDep d;
+    __builtin_memset(&d, 0, sizeof(d));
+    qapply_body<false>(a, d, static_cast<int>(blockIdx.x), s_dyn, blockIdx.x);
+}
+
+// ---- ONE launch for a block of consecutive steps ---------------------------------------------------------------------------
+// The grid is the steps' grids one after the other ([coop workgroups | worker workgroups] of step 0, of step 1, ...): the
+// dispatcher hands out workgroups in that order, so the items of step s + 1 start as the waves of step s drain -- no
+// launch boundary, no ramp, no tail at a third of the chip -- and wait, item by item, for exactly the item of the step before
+// that touched their row (QDep above).  Step i applies batch i (plan i) and writes the rows of batch i + 1 (plan i + 1):
+// entry i carries what belongs to batch i; entry `nsteps` only the lists of the batch the last step looks up.
+constexpr int kQSpanMax = 32;
+struct QSpanStep {
+    const QHeader *qh;         // queue of step i
+    const int32_t *perm;       // occurrence lists of batch i (= the destination lists of step i - 1)
+    uint32_t *dep;             // {ready, applied} counters of batch i
+    const float *grads;        // gradient rows of batch i
+    float *out;                // rows of batch i + 1
+    int32_t n;                 // ids of batch i
+    uint32_t epoch;            // tag queue i must carry (0: no check)
+    uint32_t wg_end;           // workgroups of steps 0 .. i
+    uint16_t ncoop, nworker;
+};
+static_assert(sizeof(QSpanStep) == 56, "a step of a spanning launch: 56 bytes of kernel arguments");
+struct QSpanArgs {
+    float *table;
+    uint64_t rows;
+    int width, nsteps;
+    float lr;
+    uint32_t cap_coop, cap_wave, cap_copy;
+    uint32_t *err;
+    unsigned long long *dbg;
+    QSpanStep step[kQSpanMax + 1];
+};
+static_assert(sizeof(QSpanArgs) <= 4096, "kernel arguments");
+__global__ __launch_bounds__(kQWg, 8) void qapply_span_kernel(const QSpanArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const uint32_t gb = blockIdx.x;
+    int s = 0;
+    for (int k = 0; k + 1 < sa.nsteps; ++k)
+        s += gb >= sa.step[k].wg_end ? 1 : 0;
+    const QSpanStep &cur = sa.step[s], &nxt = sa.step[s + 1];
+    const uint32_t base = s > 0 ? sa.step[s - 1].wg_end : 0u;
+    QArgs a;
+    a.table = sa.table;
+    a.rows = sa.rows;
+    a.width = sa.width;
+    a.lr = sa.lr;
+    a.qh = cur.qh;
+    const QEntry *items = reinterpret_cast<const QEntry *>(cur.qh + 1);
+    a.qcoop = items;
+    a.qwave = items + sa.cap_coop;
+    a.qcopy = a.qwave + sa.cap_wave;
+    a.qpart = reinterpret_cast<float *>(const_cast<QEntry *>(a.qcopy + sa.cap_copy));
+    a.qpcnt = reinterpret_cast<uint32_t *>(a.qpart + static_cast<size_t>(sa.cap_coop) * 64);
+    a.cap_coop = sa.cap_coop;
+    a.cap_wave = sa.cap_wave;
+    a.cap_copy = sa.cap_copy;
+    a.perm_a = cur.perm;
+    a.n_a = cur.n;
+    a.grads = cur.grads;
+    a.perm_g = nxt.perm;
+    a.n_g = nxt.n;
+    a.out = cur.out;
+    a.ncoop = cur.ncoop;
+    a.nworker = cur.nworker;
+    a.epoch = cur.epoch;
+    a.err = sa.err;
+    a.dbg = sa.dbg;
+    QDep d;
+    d.dep_a = cur.dep;
+    d.dep_g = nxt.dep;
+    d.dep_b = s > 0 ? sa.step[s - 1].dep : nullptr;
+    d.done_pp = s > 1 ? &sa.step[s - 2].qh->all_done : nullptr;
+    d.done_p = s > 0 ? &sa.step[s - 1].qh->all_done : nullptr;
+    d.done_target = cur.wg_end - base;
+    a.step = static_cast<uint32_t>(s);
+    d.full = static_cast<uint32_t>(sa.width + 31) / 32u;
+    d.wait_a = s > 0 ? 1u : 0u;
+    d.abort_w = const_cast<uint32_t *>(&sa.step[0].qh->abort);
+    d.err = sa.err;
+    d.wacc = sa.dbg ? s_dyn + kQWpw * 64 + 8 : nullptr;
+    qapply_body<true>(a, d, static_cast<int>(gb - base), s_dyn, gb);
 }
 
 // The plans of up to kQBatch batches, one workgroup each (a plan keeps ONE workgroup busy for ~15 us whatever else
@@ -1591,6 +2012,7 @@ struct QJoinBatch {
     uint64_t rows;
     uint32_t lds_bytes, cap_coop, cap_wave, cap_copy;
     QPlan pa[kQJoinBatch], pg[kQJoinBatch];
+    QPlan pb[kQJoinBatch];           // the batch before `pa` (n = 0: none / not wanted): dependencies of the copy items
     QHeader *qh[kQJoinBatch];
     QEntry *coop[kQJoinBatch], *wave[kQJoinBatch], *copy[kQJoinBatch];
     uint32_t *mirror[kQJoinBatch];   // optional pinned host words per step: {wave items, workgroup items, copy items} + 1
@@ -1602,7 +2024,7 @@ __global__ __launch_bounds__(1024, 4) void qqueue_kernel(const QJoinBatch b) {
     const int i = blockIdx.x >> 1, part = blockIdx.x & 1;
     qjoin_body(b.pa[i], b.pg[i], b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave,
                b.cap_copy, s_dyn, b.lds_bytes, part, (i == 0 && b.ph) ? b.ph + 8 * part : nullptr, b.mirror[i], 0u, 0u,
-               b.epoch[i]);
+               b.epoch[i], 0u, true, &b.pb[i]);
 }
 
 // One wave-instruction's LDS atomics on one address: are the lanes served in ascending lane order?  Four collision
@@ -1707,7 +2129,7 @@ static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *pla
 static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
                         const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
                         hipStream_t stream, unsigned long long *ph = nullptr, uint32_t *const *counts_host = nullptr,
-                        const uint32_t *epochs = nullptr) {
+                        const uint32_t *epochs = nullptr, void *const *plans_b = nullptr, const int64_t *n_b = nullptr) {
     HA_REQUIRE(rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 && width <= (1 << 20),
                "ha_qqueue_batch: rows of a multiple of 4 floats");
     HA_REQUIRE(count >= 0 && (count == 0 || (plans_a && n_a && plans_g && n_g && queues)), "ha_qqueue_batch: null pointer");
@@ -1735,6 +2157,7 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
             const int i = b.count++;
             b.pa[i] = qplan(plans_a[k], n_a[k]);
             b.pg[i] = qplan(plans_g[k], n_g[k]);
+            b.pb[i] = qplan((plans_b && n_b && n_g[k] > 0) ? plans_b[k] : nullptr, (plans_b && n_b && n_g[k] > 0) ? n_b[k] : 0);
             const QLayout q = queue_layout(queues[k], queue_n_cap, width);
             b.qh[i] = q.hdr;
             b.mirror[i] = counts_host ? counts_host[k] : nullptr;
@@ -1749,6 +2172,10 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
             lds = lds > need ? lds : need;
             lds = lds > res ? lds : res;      // the lookup batch's counts / starts in LDS too (a launch of its own: no
                                               // second workgroup has to fit on the CU)
+            if (b.pb[i].n > 0) {              // part 1 holds the keys of the batch before as well
+                const size_t two = need + kQTabSize * 4 + static_cast<size_t>(b.pb[i].n) * 4;
+                lds = lds > two ? lds : two;
+            }
         }
         if (b.count == 0)
             continue;
@@ -1838,10 +2265,86 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     if (done != nullptr)
         // the event completes with THIS launch (the dispatch packet's own completion signal): no packet of its own on the
         // stream -- an event record between two launches of a stream costs what a short kernel costs
-        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4, stream,
+        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 128, stream,
                               nullptr, done, 0, a);
     else
-        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4, stream, a);
+        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 128, stream, a);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+// `count` consecutive steps by ONE launch (qapply_span_kernel): step k applies the batch of plans[k] with grads[k] and writes
+// the rows of the batch of plans[k + 1] to next_out[k] from queues[k]; plans / n have count + 1 entries.  The queues must
+// have been built with the batch before (ha_qqueue_batch_span: the copy items' dependencies) and the plans by
+// ha_qplan_batch_* (their counters start at zero); every batch's gradient rows are resident when the launch starts.
+static int qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                       void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
+                       const void *const *queues, const int64_t *wave_items, const uint32_t *epochs, uint32_t *err,
+                       hipEvent_t done, hipStream_t stream, unsigned long long *dbg = nullptr) {
+    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
+                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
+               "ha_qapply_span: the table must be 16-byte aligned with rows of a multiple of 4 floats");
+    HA_REQUIRE(count >= 1 && count <= kQSpanMax, "ha_qapply_span: 1..%d steps per launch", kQSpanMax);
+    HA_REQUIRE(plans && n && grads && next_out && queues, "ha_qapply_span: null pointer");
+    HA_REQUIRE(queue_n_cap >= 1 && queue_n_cap <= kQMax, "ha_qapply_span: bad queue capacity");
+    QSpanArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.table = table;
+    sa.rows = static_cast<uint64_t>(rows);
+    sa.width = static_cast<int>(width);
+    sa.nsteps = static_cast<int>(count);
+    sa.lr = lr;
+    sa.err = err;
+    sa.dbg = dbg;
+    const QLayout q0 = queue_layout(nullptr, queue_n_cap, width);
+    sa.cap_coop = q0.cap_coop;
+    sa.cap_wave = q0.cap_wave;
+    sa.cap_copy = q0.cap_copy;
+    uint32_t total = 0;
+    for (int64_t k = 0; k <= count; ++k) {
+        QSpanStep &st = sa.step[k];
+        HA_REQUIRE(n[k] >= 0 && n[k] <= queue_n_cap && (n[k] == 0 || plans[k]), "ha_qapply_span: batch %lld needs its plan",
+                   (long long)k);
+        st.n = static_cast<int32_t>(n[k]);
+        if (n[k] > 0) {
+            const PlanPtrs p = plan_layout(plans[k], n[k]);
+            st.perm = p.perm;
+            st.dep = p.dep;
+        }
+        if (k == count)
+            break;
+        const int64_t n_cur = n[k], n_next = n[k + 1];
+        HA_REQUIRE(n_cur == 0 || (grads[k] && reinterpret_cast<uintptr_t>(grads[k]) % 16 == 0),
+                   "ha_qapply_span: batch %lld needs 16-byte aligned gradients", (long long)k);
+        HA_REQUIRE(n_next == 0 || (next_out[k] && reinterpret_cast<uintptr_t>(next_out[k]) % 16 == 0),
+                   "ha_qapply_span: step %lld needs a 16-byte aligned output", (long long)k);
+        st.grads = grads[k];
+        st.out = next_out[k];
+        st.epoch = epochs ? epochs[k] : 0u;
+        int ncoop = 0, nworker = 0;
+        if (n_cur > 0 || n_next > 0) {
+            HA_REQUIRE(queues[k] != nullptr, "ha_qapply_span: the queue of step %lld is missing", (long long)k);
+            st.qh = static_cast<const QHeader *>(queues[k]);
+            ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
+            const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
+            nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
+            const int64_t wi = wave_items ? wave_items[k] : -1;
+            if (wi >= 0 && wi / kQWpw + 1 < nworker)
+                nworker = static_cast<int>(wi / kQWpw + 1);
+        }
+        st.ncoop = static_cast<uint16_t>(ncoop);
+        st.nworker = static_cast<uint16_t>(nworker);
+        total += static_cast<uint32_t>(ncoop + nworker);
+        st.wg_end = total;
+    }
+    // (every step's queue header carries the words later steps wait for, the first one the launch's abort word: a span
+    // holds no step without ids at both ends -- the caller cuts it there)
+    for (int64_t k = 0; k < count; ++k)
+        HA_REQUIRE(sa.step[k].qh != nullptr, "ha_qapply_span: step %lld of the span is empty (cut the span there)", (long long)k);
+    if (done != nullptr)
+        hipExtLaunchKernelGGL(qapply_span_kernel, dim3(total), dim3(kQWg), kQWpw * 64 * 4 + 128, stream, nullptr, done, 0, sa);
+    else
+        hipLaunchKernelGGL(qapply_span_kernel, dim3(total), dim3(kQWg), kQWpw * 64 * 4 + 128, stream, sa);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -2058,6 +2561,7 @@ __device__ __forceinline__ QPlan qbig_slice(const QBigRef &r, int p) {
     q.seg = r.seg + off + p;
     q.upos = nullptr;
     q.occ = r.occ + 2 * static_cast<size_t>(off);
+    q.dep = nullptr;
     q.n = static_cast<int>(nb);
     return q;
 }
@@ -2412,6 +2916,37 @@ extern "C" int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, f
     if (count == 0 && done_event)
         HA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(done_event), as_stream(stream)));
     return 0;
+}
+// `count` (<= ha_qapply_span_max()) consecutive steps by ONE launch whose items wait for each other row by row instead of a
+// launch boundary per step (qapply_span_kernel above).  plans / n: count + 1 entries (the batch of step k, ..., and the batch
+// the last step looks up); the other arrays per step as for ha_qapply_steps_sync.  Requirements beyond ha_qapply_steps_sync's:
+// the queues were built by ha_qqueue_batch_span (with the plan of the batch BEFORE each step's batch), the plans by
+// ha_qplan_batch_* and used by no other apply since (their dependency counters start at zero and count up once), every
+// batch's gradient rows are resident when the launch starts, and the span's first step has a queue (is not empty).
+extern "C" int64_t ha_qapply_span_max(void) { return kQSpanMax; }
+extern "C" int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                              void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
+                              const void *const *queues, const int64_t *wave_items, const uint32_t *epochs, uint32_t *err,
+                              void *done_event, ha_stream_t stream) {
+    return qapply_span(table, rows, width, lr, queue_n_cap, count, plans, n, grads, next_out, queues, wave_items, epochs, err,
+                       static_cast<hipEvent_t>(done_event), as_stream(stream));
+}
+extern "C" int ha_debug_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                                    void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
+                                    const void *const *queues, const int64_t *wave_items, unsigned long long *dbg,
+                                    ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "qapply span timeline: null debug buffer");
+    return qapply_span(table, rows, width, lr, queue_n_cap, count, plans, n, grads, next_out, queues, wave_items, nullptr,
+                       nullptr, nullptr, as_stream(stream), dbg);
+}
+// ha_qqueue_batch_epochs with, per step, the plan of the batch BEFORE the batch it applies (plans_b / n_b; NULL or n_b[k] = 0:
+// none): copy items then carry their dependency on that batch's apply (what ha_qapply_span waits for).
+extern "C" int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, const int64_t *n_b, void *const *plans_a,
+                                    const int64_t *n_a, void *const *plans_g, const int64_t *n_g, void *const *queues,
+                                    int64_t queue_n_cap, int64_t count, uint32_t *const *counts_host, const uint32_t *epochs,
+                                    ha_stream_t stream) {
+    return qqueue_batch(rows, width, plans_a, n_a, plans_g, n_g, queues, queue_n_cap, count, as_stream(stream), nullptr,
+                        counts_host, epochs, plans_b, n_b);
 }
 extern "C" int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
                               float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,

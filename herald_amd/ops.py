@@ -850,13 +850,30 @@ class QueueStepPipeline:
         self._ev_pool = []
         self._last_items = 0
         self.fallbacks, self._fb_plan, self._wide_ids = 0, None, {}
+        # steps one launch may SPAN (ha_qapply_span: the items of consecutive steps wait for each other row by row instead of
+        # a launch boundary per step): inside one block, narrow path only
+        self.SPAN_MAX = min(int(L.ha_qapply_span_max()), self.block) if (self.overlap and not self.wide) else 0
+        self._enq_last = None        # the last step handed to the device (ordering fallback of the flags mode)
         self.reset()
+
+    def close(self):
+        """Releases the library events of the flags mode (ha_event_create)."""
+        for ev in list(self._done_ev.values()) + self._cev_pool:
+            self._L.ha_event_destroy(ev)
+        self._done_ev, self._cev_pool = {}, []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass
 
     # ---- bookkeeping ------------------------------------------------------------------------------------------
     def reset(self, stream=None):
         self._cev_pool.extend(self._done_ev.values())
         self._done_ev = {}
         self.c, self.n, self.shape, self.ids = None, {}, {}, {}
+        self._enq_last, self._covered = None, -(1 << 60)
         self._ev_side = {}          # block index -> event behind the side work launched at its start
         self._held = {}             # block index -> id tensors its plan launch reads (kept alive, not record_stream'ed)
         return self
@@ -880,7 +897,19 @@ class QueueStepPipeline:
     def overflowed(self):
         """True if any queue built so far counted more items than it holds (the layout's bounds exclude it; the builder
         raises a sticky word in pinned memory instead of dropping items silently)."""
-        return bool(self._counts_np[:, 3].any())
+        return bool((self._counts_np[:, 3] & ~4).any())      # (4 = "this step takes the sorted plan": handled, not an error)
+
+    def _raise_if_failed(self, steps):
+        """The pinned error words of `steps`: 8 = an apply launch gave up waiting (for its queue's epoch tag, or -- a launch
+        that spans several steps -- for an item of the step before): the table is only partly updated from there on."""
+        cc, ring = self._counts_c, self.COUNTS
+        for j in steps:
+            f = cc[4 * (j % ring) + 3]
+            if f & ~4:
+                raise RuntimeError("QueueStepPipeline: step %d failed on the device (flags %d: 1 = queue overflow, 2 = an "
+                                   "occurrence list out of position order, 8 = an apply launch gave up waiting -- its queue was "
+                                   "never completed, or an item it depends on never finished; the table is partly updated)"
+                                   % (j, f))
 
     # ---- the preparation of a block ------------------------------------------------------------------------------
     def prepare_block(self, b, ids_of, stream=None, ph=None):
@@ -896,18 +925,27 @@ class QueueStepPipeline:
         s = self.side if self.overlap else main
         sp = _stream_ptr(s)
         vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        # HA_QNOSYNC=1 (MEASUREMENT ONLY, unsafe): no events between the two streams -- what the two packets on the
-        # caller's stream cost at a block boundary
-        nosync = os.environ.get("HA_QNOSYNC") == "1"
         flags = self.sync == "flags"
-        if self.overlap and flags and not nosync:
+        # a launch of the block before last that gave up (flags: a queue that never became ready; a spanning launch: an item
+        # that never finished) has left its word in pinned memory by now: stop here rather than train on a partly updated table
+        self._raise_if_failed(range(max((b - 2) * B, 0), max((b - 1) * B, 0)))
+        if self.overlap and flags:
             # the steps of block b-1 are complete (their last launch carries the event): the plans / queues about to be
             # rewritten are free.  Nothing is enqueued on the caller's stream.
             cev = self._done_ev.pop(b - 1, None)
             if cev is not None:
                 check(L.ha_stream_wait_event(sp, cev), "ha_stream_wait_event")
                 self._cev_pool.append(cev)
-        elif self.overlap and not nosync:
+                self._covered = b * B - 1
+            elif self._enq_last is not None and self._enq_last > self._covered:
+                # steps that may still read what is about to be rewritten were enqueued without an event of their own (a
+                # debug launch, a chunk that did not end with its block): order the side stream behind the caller's stream
+                ev = self._event()
+                ev.record(main)
+                s.wait_event(ev)
+                self._ev_pool.append(ev)
+                self._covered = self._enq_last
+        elif self.overlap:
             ev = self._event()
             ev.record(main)                    # the buffers about to be rewritten are free, the ids are there
             s.wait_event(ev)
@@ -974,15 +1012,19 @@ class QueueStepPipeline:
                 at = 4 * (j % ring)
                 cc[at] = 0
                 cc[at + 2] = 0
+                cc[at + 3] &= ~4         # "takes the sorted plan" belongs to the step that had the slot before
             cs = (vp * cnt)(*[base + 16 * (j % ring) for j in steps])
             eps = (ctypes.c_uint32 * cnt)(*[self._epoch(j) for j in steps])
             if self.wide:
                 check(L.ha_qbig_queue_batch(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
                       "ha_qbig_queue_batch")
             else:
-                check(L.ha_qqueue_batch_epochs(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
+                # (with the plan of the batch BEFORE the one a step applies: its copy items' dependencies, ha_qapply_span)
+                pb = (vp * cnt)(*[pp[(j - 1) % NP] if nget(j - 1, 0) else None for j in steps])
+                nb_ = (i64 * cnt)(*[nget(j - 1, 0) for j in steps])
+                check(L.ha_qqueue_batch_span(rows, width, pb, nb_, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
                       "ha_qqueue_batch")
-        if self.overlap and not nosync and not flags:
+        if self.overlap and not flags:
             ev = self._event()
             ev.record(s)
             self._ev_side[b] = ev
@@ -1049,6 +1091,7 @@ class QueueStepPipeline:
         if capturing:
             raise RuntimeError("QueueStepPipeline(sync='flags'): steps cannot be captured into a hipGraph (use sync='events')")
         done = self._block_done_event(c) if flags else None
+        self._enq_last = c if self._enq_last is None else max(self._enq_last, c)
         if not (n_cur or n_next):
             if done is not None:         # the block's last step launches nothing: mark the point on the stream instead
                 check(L.ha_event_record(done, _stream_ptr(stream)), "ha_event_record")
@@ -1124,6 +1167,7 @@ class QueueStepPipeline:
         fn = L.ha_qapply_sized
 
         def call(k):
+            self._enq_last = k if self._enq_last is None else max(self._enq_last, k)
             if sized:       # not inside a graph capture: a captured launch keeps the grid it was captured with
                 hint.value = self.wave_items(k)
             if fn(*args) != 0:
@@ -1152,8 +1196,15 @@ class QueueStepPipeline:
         flags = self.sync == "flags"
         eps = (ctypes.c_uint32 * cnt)()
         fn_sync, epoch, last_err = L.ha_qapply_steps_sync, self._epoch, self._err_ptr
+        B = self.block
 
         def call(k0):
+            if flags and k0 // B != (k0 + cnt - 1) // B:
+                # the block's done-event rides on the LAST launch of a call: a call that runs over a block boundary would
+                # leave the block before without one (and the side stream would rewrite queues that steps still read)
+                raise RuntimeError("apply_steps_call(sync='flags'): steps %d..%d cross a block boundary (block = %d)"
+                                   % (k0, k0 + cnt - 1, B))
+            self._enq_last = k0 + cnt - 1 if self._enq_last is None else max(self._enq_last, k0 + cnt - 1)
             if sized:
                 for i in range(cnt):
                     at = 4 * ((k0 + i) % ring)
@@ -1175,6 +1226,162 @@ class QueueStepPipeline:
             elif fn(*head, pc, ns, gs, pn, ns, os_, qs, hints, sp) != 0:
                 check(-1, "ha_qapply_steps")
         return call
+
+    # ---- several steps by ONE launch -----------------------------------------------------------------------------------
+    def _span_ok(self, c0, cnt):
+        if self.SPAN_MAX < 2:
+            raise RuntimeError("QueueStepPipeline: spanning launches need overlap=True, block >= 2 and batches of at most %d ids"
+                               % qstep_max_ids())
+        if not 1 <= cnt <= self.SPAN_MAX:
+            raise ValueError("a launch spans 1..%d steps (got %d)" % (self.SPAN_MAX, cnt))
+        if c0 // self.block != (c0 + cnt - 1) // self.block:
+            raise ValueError("steps %d..%d cross a block boundary (block = %d): a spanning launch stays inside one block -- the "
+                             "queues of the next block may still be under construction" % (c0, c0 + cnt - 1, self.block))
+
+    def apply_span(self, c0, grads_list, out_list, stream=None, dbg=None):
+        """Steps c0 .. c0 + len(grads_list) - 1 by ONE launch (ha_qapply_span, csrc/qstep.hip): step c0 + i applies batch
+        c0 + i with grads_list[i] and writes the rows of batch c0 + i + 1 to out_list[i].  The items of consecutive steps wait
+        for each other row by row (counters in the plans) instead of a launch boundary per step; the results are those of
+        `apply` step by step, bit for bit.  EVERY batch's gradients must be resident when the call is made -- a caller whose
+        gradients of step k + 1 depend on the rows of step k (a model between lookup and update, no staleness) cannot span."""
+        L = self._L
+        t = self.table
+        rows, width = t.shape
+        cnt = len(grads_list)
+        self._span_ok(c0, cnt)
+        if len(out_list) != cnt:
+            raise ValueError("one output per step")
+        ns = [self.n.get(c0 + i, 0) for i in range(cnt + 1)]
+        flags = self.sync == "flags" and dbg is None
+        if flags and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("QueueStepPipeline(sync='flags'): steps cannot be captured into a hipGraph (use sync='events')")
+        last = c0 + cnt - 1
+        done = self._block_done_event(last) if flags else None
+        self._enq_last = last if self._enq_last is None else max(self._enq_last, last)
+        sp = _stream_ptr(stream)
+        # a step without ids at both ends has no queue and launches nothing: the span is cut into the runs between such steps
+        # (what is on either side of one is ordered by the stream)
+        work = [bool(ns[i] or ns[i + 1]) for i in range(cnt)]
+        if not all(work):
+            runs, i = [], 0
+            while i < cnt:
+                if not work[i]:
+                    i += 1
+                    continue
+                j = i
+                while j < cnt and work[j]:
+                    j += 1
+                runs.append((i, j))
+                i = j
+            if done is not None:
+                self._done_ev.pop(last // self.block, None)       # (re-registered by the launch that carries it, or recorded)
+                self._cev_pool.append(done)
+            for r, (i, j) in enumerate(runs):
+                self.apply_span(c0 + i, grads_list[i:j], out_list[i:j], stream, dbg)
+            if flags and (not runs or runs[-1][1] != cnt):
+                ev = self._block_done_event(last)
+                if ev is not None:
+                    check(L.ha_event_record(ev, sp), "ha_event_record")
+            return
+        lead, c1, m = 0, c0, cnt
+        for i in range(m):
+            if ns[i]:
+                _require(grads_list[lead + i], torch.float32, "grads")
+                if grads_list[lead + i].numel() != ns[i] * width:
+                    raise ValueError("grads of step %d must hold %d x %d values" % (c1 + i, ns[i], width))
+            if ns[i + 1]:
+                _require(out_list[lead + i], torch.float32, "out")
+                if out_list[lead + i].numel() != ns[i + 1] * width:
+                    raise ValueError("out of step %d must hold %d x %d values" % (c1 + i, ns[i + 1], width))
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        pl = (vp * (m + 1))(*[self._plan_ptr[(c1 + i) % self.NPLAN] if ns[i] else None for i in range(m + 1)])
+        na = (i64 * (m + 1))(*ns)
+        gs = (vp * m)(*[grads_list[lead + i].data_ptr() if ns[i] else None for i in range(m)])
+        os_ = (vp * m)(*[out_list[lead + i].data_ptr() if ns[i + 1] else None for i in range(m)])
+        qs = (vp * m)(*[self._queue(c1 + i) for i in range(m)])
+        hints = (i64 * m)(*[self.wave_items(c1 + i) for i in range(m)])
+        head = (_ptr(t), rows, width, ctypes.c_float(self.lr), self.capacity, m)
+        if dbg is not None:
+            check(L.ha_debug_qapply_span(*head, pl, na, gs, os_, qs, hints, _ptr(dbg), sp), "ha_debug_qapply_span")
+            return
+        eps = (ctypes.c_uint32 * m)(*[self._epoch(c1 + i) if flags else 0 for i in range(m)])
+        check(L.ha_qapply_span(*head, pl, na, gs, os_, qs, hints, eps, self._err_ptr(last) if flags else None, done, sp),
+              "ha_qapply_span")
+
+    def apply_span_call(self, c0, grads_list, out_list, stream, n):
+        """-> callable(first step index): apply_span for the steps c0 .. (and the same phases ROTATION steps later) with the
+        arguments converted once; every batch has n ids (what bench.py enqueues)."""
+        L = self._L
+        t = self.table
+        rows, width = t.shape
+        cnt = len(grads_list)
+        self._span_ok(c0, cnt)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        pl = (vp * (cnt + 1))(*[self._plan_ptr[(c0 + i) % self.NPLAN] for i in range(cnt + 1)])
+        na = (i64 * (cnt + 1))(*[n] * (cnt + 1))
+        gs = (vp * cnt)(*[g.data_ptr() for g in grads_list])
+        os_ = (vp * cnt)(*[o.data_ptr() for o in out_list])
+        qs = (vp * cnt)(*[self._queue(c0 + i) for i in range(cnt)])
+        hints = (i64 * cnt)(*[-1] * cnt)
+        eps = (ctypes.c_uint32 * cnt)()
+        head = (vp(t.data_ptr()), i64(rows), i64(width), ctypes.c_float(self.lr), i64(self.capacity), i64(cnt))
+        sp = _stream_ptr(stream)
+        fn, epoch, last_err = L.ha_qapply_span, self._epoch, self._err_ptr
+        counts, ring = self._counts_c, self.COUNTS
+        flags = self.sync == "flags"
+        B = self.block
+
+        def call(k0):
+            if k0 // B != (k0 + cnt - 1) // B:
+                raise RuntimeError("apply_span_call: steps %d..%d cross a block boundary (block = %d)" % (k0, k0 + cnt - 1, B))
+            self._enq_last = k0 + cnt - 1 if self._enq_last is None else max(self._enq_last, k0 + cnt - 1)
+            for i in range(cnt):
+                at = 4 * ((k0 + i) % ring)
+                w, cp = counts[at], counts[at + 2]
+                if counts[at + 3]:
+                    self._raise_if_failed([k0 + i])
+                if w > 0 and cp > 0:
+                    self._last_items = w + cp - 2
+                hints[i] = w + cp - 2 if w > 0 and cp > 0 else (self._last_items * 17) // 16 if self._last_items > 0 else -1
+                eps[i] = epoch(k0 + i) if flags else 0
+            done = self._block_done_event(k0 + cnt - 1) if flags else None
+            if fn(*head, pl, na, gs, os_, qs, hints, eps, last_err(k0 + cnt - 1) if flags else None, done, sp) != 0:
+                check(-1, "ha_qapply_span")
+        return call
+
+    def step_span(self, grads_list, ahead_ids_list=None, outs=None, stream=None):
+        """The stream protocol of `step`, several steps at a time by one spanning launch: grads_list[i] = the gradients of
+        the i-th of the next len(grads_list) batches (None for an empty batch), ahead_ids_list[i] = the batch LOOKAHEAD ahead
+        of it (None once the stream ends).  Returns the list of the rows of the batches that follow them (None entries at the
+        end of the stream / for empty batches).  The steps must not cross a block boundary (see apply_span)."""
+        if self.c is None:
+            raise RuntimeError("QueueStepPipeline.step_span before start")
+        cnt = len(grads_list)
+        c0 = self.c
+        self._span_ok(c0, cnt)
+        ahead_ids_list = list(ahead_ids_list) if ahead_ids_list is not None else [None] * cnt
+        if c0 % self.block == 0:
+            self.prepare_block(c0 // self.block, lambda j: self.ids.get(j), stream)
+            for j in [j for j in self.ids if j < c0 + 3 * self.block]:
+                del self.ids[j]
+        for i, a in enumerate(ahead_ids_list):
+            if a is not None and a.numel():
+                self.ids[c0 + i + self.LOOKAHEAD] = a
+                self.shape[c0 + i + self.LOOKAHEAD] = tuple(a.shape)
+        res = []
+        for i in range(cnt):
+            n_next = self.n.get(c0 + i + 1, 0)
+            o = outs[i] if outs is not None else None
+            if n_next and o is None:
+                o = torch.empty(tuple(self.shape[c0 + i + 1]) + (self.table.shape[1],), dtype=torch.float32,
+                                device=self.table.device)
+            res.append(o if n_next else None)
+        self.apply_span(c0, grads_list, res, stream)
+        for c in range(c0, c0 + cnt):
+            for d in (self.n, self.shape):
+                d.pop(c - 1, None)
+        self.c = c0 + cnt
+        return res
 
     # ---- the stream protocol --------------------------------------------------------------------------------------
     def _call(self, c, grads, ahead_ids, out, stream):

@@ -570,6 +570,43 @@ int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, in
                    void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
                    int64_t wave_items, uint32_t epoch, uint32_t *err, void *done_event, ha_stream_t stream);
 
+/* ONE launch for up to ha_qapply_span_max() (32) consecutive steps.  A launch per step pays a launch boundary, a ramp and a
+ * tail at a third of the chip's waves every ~12 us; consecutive steps touch the same rows (step s applies batch s --
+ * cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:51-74 -- and writes the rows of batch s + 1 --
+ * cpu_EmbeddingLookup, src/dnnl_ops/EmbeddingLookup.cpp:16-35 --, so every key step s + 1 applies was read or written by
+ * step s), so the steps of a spanning launch are ordered ITEM BY ITEM: per unique key of a batch a "ready" counter (the
+ * step before has read / written the row for the last time) and an "applied" counter (this batch's update of the row is in
+ * memory) in the batch's plan, one "workgroups finished" count per step in its queue header; an apply item waits for its
+ * key's ready counter, a copy item (a key only the next batch names) for the applied counter of the batch before if that
+ * batch names the key -- found by the queue builder, which is handed that batch's plan as well (ha_qqueue_batch_span) --
+ * and for the step two back to have finished altogether.  Rows cross between steps THROUGH the L2 (sc1 stores, drained;
+ * relaxed device-scope counter adds; sc1 loads behind a relaxed poll); gradient rows and output rows are never handed over
+ * inside a launch.  Results: exactly those of `count` ha_qapply launches, bit for bit (the same items in the same
+ * per-key order).
+ *   plans / n: count + 1 entries -- the batch step k applies, ..., and the batch the last step looks up; grads / next_out
+ *   / queues / wave_items / epochs: per step as for ha_qapply_steps_sync; err / done_event: as there (err = 8 also when an
+ *   item gave up waiting for the item it depends on: ~2 s; every other wait of the launch then stops at once).
+ * Requirements beyond ha_qapply_steps_sync's: queues built by ha_qqueue_batch_span; plans built by ha_qplan_batch_* and
+ * applied by no other launch since (the counters start at zero and count up once); EVERY batch's gradient rows resident
+ * when the launch starts (a caller whose gradients of step k + 1 depend on the rows step k returns cannot span them); the
+ * first step of a span has a queue (is not empty at both ends); batches of at most ha_qstep_max_ids() ids. */
+int64_t ha_qapply_span_max(void);
+int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                   void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
+                   const void *const *queues, const int64_t *wave_items, const uint32_t *epochs, uint32_t *err,
+                   void *done_event, ha_stream_t stream);
+/* ha_qqueue_batch_epochs with, per step, the plan of the batch BEFORE the batch the step applies (plans_b / n_b; NULL, or
+ * n_b[k] = 0: none). */
+int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, const int64_t *n_b, void *const *plans_a,
+                         const int64_t *n_a, void *const *plans_g, const int64_t *n_g, void *const *queues,
+                         int64_t queue_n_cap, int64_t count, uint32_t *const *counts_host, const uint32_t *epochs,
+                         ha_stream_t stream);
+/* development aid: the spanning launch with per-wave time stamps (dbg as for ha_debug_qapply, indexed by the workgroup's
+ * index in the whole launch) */
+int ha_debug_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                         void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
+                         const void *const *queues, const int64_t *wave_items, unsigned long long *dbg, ha_stream_t stream);
+
 /* The WIDE path: batches of more than ha_qstep_max_ids() (7,168) and at most ha_qbig_max_ids() (131,072) ids -- BASELINE
  * configs[2] / configs[3]'s per-GPU shapes, 106,496 and 26,624 ids per step.  The batch is cut into hash buckets by one
  * stable multisplit (ha_qbig_buckets(n_cap) buckets of ~1,024 ids; a bucket may hold at most ha_qstep_max_ids() ids: hot

@@ -55,7 +55,7 @@ base = d[live, 0].min()
 t0 = (d[:, 0] - base) * 0.01
 t1 = (d[:, 1] - base) * 0.01
 role = d[:, 2] & 0xFF
-kind = d[:, 3].astype(np.int64)
+kind = (d[:, 3] & 0xFF).astype(np.int64)
 kind = np.where(kind > 100, -1, kind)      # 0xFFFFFFFF = the wave had no item
 print("span %.2f us, stamped waves %d" % (t1[live].max(), live.sum()))
 groups = [("coop G", (role == 0) & (kind == 4)), ("coop idle", (role == 0) & (kind < 0)),
