@@ -179,7 +179,7 @@ def _declare(L):
         "ha_qqueue_batch_epochs": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
         "ha_qapply_steps_sync": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qapply_sync": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, c.c_uint32, vp, vp, vp],
-        "ha_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "ha_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_debug_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qqueue_batch_span": [i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
         "ha_qbig_plan_view": [vp, i64, vp, vp, vp, vp, vp, vp, vp],

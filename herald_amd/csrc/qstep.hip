@@ -117,8 +117,10 @@ struct QLayout {
     QEntry *coop, *wave, *copy;
     float *part;           // [cap_coop * 64] partial sums of chunked workgroup items (one 64-column slice each)
     uint32_t *pcnt;        // [cap_coop] chunks of a (key, slice) that have delivered theirs (at the index of its chunk 0)
+    uint32_t *aflag;       // [cap_coop + cap_wave] spanning launches: "ready" units of a key, at its first apply item
+    uint32_t *cflag;       // [cap_copy] ... "applied" units of a key the step before names, at its first copy item
     uint32_t cap_coop, cap_wave, cap_copy;
-    size_t bytes;
+    size_t bytes, flag_off;
 };
 constexpr uint32_t kQChunk = 256;      // occurrences per workgroup item: a key with more is cut into CHUNKS (QV_GOLD)
 __host__ __device__ __forceinline__ uint32_t q_nchunk(uint32_t c) {
@@ -142,7 +144,10 @@ static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
     const size_t items = sizeof(QHeader) + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * sizeof(QEntry);
     q.part = reinterpret_cast<float *>(b ? b + items : nullptr);
     q.pcnt = reinterpret_cast<uint32_t *>(b ? b + items + static_cast<size_t>(q.cap_coop) * 256 : nullptr);
-    q.bytes = items + static_cast<size_t>(q.cap_coop) * (256 + 4);
+    q.flag_off = items + static_cast<size_t>(q.cap_coop) * (256 + 4);
+    q.aflag = reinterpret_cast<uint32_t *>(b ? b + q.flag_off : nullptr);
+    q.cflag = q.aflag ? q.aflag + q.cap_coop + q.cap_wave : nullptr;
+    q.bytes = q.flag_off + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * 4;
     return q;
 }
 
@@ -190,6 +195,12 @@ struct QArgs {
     uint32_t *err;             // pinned host word raised (8) when the queue never became ready (may be NULL)
     unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind | step << 8} per wave
     uint32_t step;             // index of the step in its launch (time stamps)
+    // a spanning launch: the queue's item counts + 1 where the caller knows them (0: read the header -- one more trip in
+    // front of the item), and the NEXT step's queue, whose tag is checked as well (this step's items read where that queue's
+    // builder put their keys' items)
+    uint32_t k_wave, k_coop, k_copy;
+    const QHeader *qh_next;
+    uint32_t epoch_next;
 };
 
 // development aid: phase time stamps of the single-workgroup roles (thread 0; ph = nullptr in production)
@@ -605,9 +616,7 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
         hi.y = fs;
         hi.z = o01;
         hi.w = o23;
-        uint4 *d = reinterpret_cast<uint4 *>(dst + j);
-        d[0] = lo;
-        d[1] = hi;
+        q_st_item(dst + j, lo, hi);      // (through the L2, like everything an apply launch may read before this one ends)
     }
 }
 // (helper below) an item's two 16-byte halves, written THROUGH the L2 (`sc1`): once the writing thread's `s_waitcnt
@@ -649,6 +658,7 @@ struct QJoin {      // what every part of the join needs (passed by reference to
     QHeader *bqh;
     QEntry *bcoop, *bwave, *bcopy;
     uint32_t *bpcnt;                // the queue's chunk counters (they follow the item regions: queue_layout)
+    uint32_t *baflag, *bcflag;      // ... and its flag words (behind the chunk counters)
     uint32_t bcap_coop, bcap_wave, bcap_copy, per512, per128, per32;
     uint32_t st_base, fs_base;      // wide path: where this bucket's occurrence / destination lists start in the batch's
     uint32_t tid, nt;               // the thread's index in its group of nt threads (the workgroup, or a quarter of it)
@@ -687,8 +697,13 @@ __device__ __forceinline__ uint32_t qjoin_dest(const QJoin &j, uint32_t e) {   /
         return 0u;
     return j.cs_res ? j.s_cs[e] : (static_cast<uint32_t>(j.pg.counts[e]) | (static_cast<uint32_t>(j.pg.seg[e]) << 16));
 }
+// COPY: an item of the copy region (a key only the lookup names); dep_b = where the key's group starts in the batch BEFORE
+// the batch to apply, + 1 (0: that batch does not name it).  Narrow path (the plans carry `dep` words): the item's flag word
+// starts at zero and the plan of its key's batch learns where it is (see QDep).
+template <bool COPY>
 __device__ __forceinline__ QCount qjoin_emit_one(const QJoin &j, QCount b, QEntry *wave, uint32_t cap_wave, uint32_t key,
-                                                 uint32_t c, uint32_t st, uint32_t m, uint32_t fs, uint32_t o01, uint32_t o2) {
+                                                 uint32_t c, uint32_t st, uint32_t m, uint32_t fs, uint32_t o01, uint32_t o2,
+                                                 uint32_t dep_b = 0u) {
     const int kind = q_kind(c, m, key < j.rows);
     if (kind == kQNone)
         return b;
@@ -696,9 +711,21 @@ __device__ __forceinline__ QCount qjoin_emit_one(const QJoin &j, QCount b, QEntr
     const QCount nb = q_count(b, kind, j.per512, j.per128, j.per32, c);
     const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
     // the layout's bound makes the test always true; never write beyond the queue
-    if (at + cnt <= (kind == kQG ? j.bcap_coop : cap_wave))
-        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st + j.st_base, m, fs + j.fs_base, j.width, o01, o2,
-                     kind == kQG ? j.bpcnt + at : nullptr);
+    if (at + cnt <= (kind == kQG ? j.bcap_coop : cap_wave)) {
+        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st + j.st_base, m, fs + j.fs_base, j.width,
+                     COPY ? dep_b : o01, o2, kind == kQG ? j.bpcnt + at : nullptr);
+        if (kind != kQZ && (COPY ? j.pg.dep : j.pa.dep) != nullptr) {
+            if (COPY) {
+                __hip_atomic_store(j.bcflag + at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dep_b != 0u)
+                    __hip_atomic_store(j.pb.dep + 2u * (dep_b - 1u) + 1u, at + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const uint32_t fidx = kind == kQG ? at : j.bcap_coop + at;
+                __hip_atomic_store(j.baflag + fidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(j.pa.dep + 2u * st, fidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     return nb;
 }
 
@@ -739,8 +766,8 @@ __device__ __forceinline__ QCount qjoin_emit_groups(const QJoin &j, QCount b) {
     for (int r = R0; r < R1; ++r) {
         if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ua) {
             const uint32_t mf = qjoin_dest(j, qjoin_probe(j, ka[r - R0]));
-            b = qjoin_emit_one(j, b, j.bwave, j.bcap_wave, ka[r - R0], cst[r - R0] & 0xFFFFu, cst[r - R0] >> 16,
-                               mf & 0xFFFFu, mf >> 16, o01[r - R0], o2[r - R0]);
+            b = qjoin_emit_one<false>(j, b, j.bwave, j.bcap_wave, ka[r - R0], cst[r - R0] & 0xFFFFu, cst[r - R0] >> 16,
+                                      mf & 0xFFFFu, mf >> 16, o01[r - R0], o2[r - R0]);
         }
     }
     return b;
@@ -782,8 +809,8 @@ __device__ __forceinline__ QCount qjoin_emit_copies(const QJoin &j, QCount b) {
                 if (e2 != kQTabEmpty)
                     dep = static_cast<uint32_t>(j.pb.seg[e2]) + 1u;
             }
-            b = qjoin_emit_one(j, b, j.bcopy, j.bcap_copy, kg[r - R0], 0u, 0u, mfs[r - R0] & 0xFFFFu, mfs[r - R0] >> 16,
-                               dep, 0u);
+            b = qjoin_emit_one<true>(j, b, j.bcopy, j.bcap_copy, kg[r - R0], 0u, 0u, mfs[r - R0] & 0xFFFFu, mfs[r - R0] >> 16,
+                                     0u, 0u, dep);
         }
     return b;
 }
@@ -844,6 +871,8 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
                                            static_cast<size_t>(bcap_coop) * 256);
     j.bcap_wave = bcap_wave;
     j.bcap_copy = bcap_copy;
+    j.baflag = j.bpcnt + bcap_coop;
+    j.bcflag = j.baflag + bcap_coop + bcap_wave;
     j.per512 = (width + 511) / 512;
     j.per128 = (width + 127) / 128;
     j.per32 = (width + 31) / 32;
@@ -1127,34 +1156,68 @@ __device__ __forceinline__ V q_ld_grad(const float *p) {
 // Consecutive steps touch the same rows: step s applies batch s and writes the rows of batch s + 1, so EVERY key step s + 1
 // applies was read or written by an item of step s, and a key only batch s + 2 names may have been written by any step
 // before.  One launch per step orders them by the launch boundary -- a ramp, a tail that runs at a third of the chip's
-// waves, and the boundary itself, every 12 us.  A launch that spans a block of steps orders them item by item instead:
-//   ready[g]    (plan of batch s, at the start of group g's occurrence list)  units of 32 columns of g's row that step
-//               s - 1 has read / written for the last time (its apply item of the key, or its copy item): the apply
-//               item of g in step s waits for all of them, then loads the row;
-//   applied[g]  units of g's row that step s has written: a copy item of step s + 1 whose key batch s names (found by the
-//               queue builder's second table) waits for all of them;
+// waves, and the boundary itself, every 12 us.  A launch that spans a block of steps orders them item by item instead.
+// The flags live in the CONSUMER's queue, one word per item, so that a wave fetches its flag BESIDE its item (one trip):
+//   aflag[i]    (queue of step s; i = the first item of a key of batch s: coop items, then wave items)  units of 32
+//               columns of the key's row that step s - 1 has read / written for the last time -- its apply item of the key,
+//               or its copy item, adds them once its row is in memory / once it has read the row: the apply items of the
+//               key in step s wait for all of them, then load the row;
+//   cflag[i]    (queue of step s; i = the first copy item of a key only batch s + 1 names)  units of the row that step
+//               s - 1 has APPLIED: a copy item whose key batch s - 1 names (the builder's second table says so) waits for
+//               all of them;
 //   all_done    (queue header of step s) step s and every earlier step of the launch have finished -- the workgroup whose
 //               add to the header's `wg_done` completes the step's count waits for the word of the step before and sets it:
 //               copy items of step s + 2 wait for it (a row's last writer may be ANY earlier step; two steps back
-//               everything has long finished).
-// Waits never cross the launch's first step (what is before it is ordered by the stream).  Rows are handed over the way
-// step.hip does it: the writer stores them THROUGH the L2 (`sc1`), drains (`s_waitcnt vmcnt(0)`) and adds to the counter
-// with a relaxed device-scope atomic; the reader polls with relaxed device-scope loads and then loads the row with `sc1`
-// loads -- EVERY row load and store of a spanning launch is `sc1` (a row may have been rewritten by another XCD since
-// this one last saw it).  Gradient rows and the next batch's output rows are never handed over inside a launch.
+//               everything has long finished; the word is fetched beside the item as well).
+// How a producer finds the word: the builder of queue s + 1 writes, into the PLAN of the batch (at the start of the key's
+// occurrence list; ha_qplan_batch_* zeroes both), the index of the key's apply item's word (plan of batch s + 1: dep[2 i])
+// and the index + 1 of its copy item's word (plan of batch s: dep[2 i + 1]); an item of step s reads them beside its
+// gradient rows.  Waits never cross the launch's first step (what is before it is ordered by the stream), signals never
+// its last.  Rows are handed over the way step.hip does it: the writer stores them THROUGH the L2 (`sc1`), drains
+// (`s_waitcnt vmcnt(0)`) and adds to the word with a relaxed device-scope atomic; the reader polls with relaxed
+// device-scope loads and then loads the row with `sc1` loads -- EVERY row load and store of a spanning launch is `sc1` (a
+// row may have been rewritten by another XCD since this one last saw it).  A copy item only READS its row: it signals as
+// soon as the row has arrived.  Gradient rows and the next batch's output rows are never handed over inside a launch.
 // Progress: workgroups are dispatched in grid order and every wait is for an item of an EARLIER step, i.e. of a workgroup
 // with a smaller index; waits are bounded (~2 s) and raise the launch's abort word + the caller's pinned error word.
 struct QDep {
-    uint32_t *dep_a;             // {ready, applied} pairs of the batch to apply (null: nothing is applied)
-    uint32_t *dep_g;             // ... of the batch to look up
-    const uint32_t *dep_b;       // ... of the batch before the batch to apply (null: this is the span's first step)
-    const uint32_t *done_pp;     // all_done of the step two back (null: none inside this launch)
-    const uint32_t *done_p;      // all_done of the step before (null: this is the span's first step)
-    uint32_t done_target;        // workgroups of THIS step
-    uint32_t full;               // units of a whole row
-    uint32_t wait_a;             // 0: the span's first step (no apply item waits)
+    const uint32_t *aflag, *cflag;   // this step's queue
+    uint32_t *aflag_n, *cflag_n;     // the next step's queue (null: this is the span's last step -- nothing is signalled)
+    const uint32_t *dep_a, *dep_g;   // plan words of the batch to apply / to look up (see above; null: no such batch)
+    const uint32_t *done_pp;         // all_done of the step two back (null: none inside this launch)
+    const uint32_t *done_p;          // all_done of the step before (null: this is the span's first step)
+    uint32_t done_target;            // workgroups of THIS step
+    uint32_t full;                   // units of a whole row
+    uint32_t wait_a;                 // 0: the span's first step (nothing waits for a flag)
+    uint32_t cap_coop;               // aflag index of wave item e: cap_coop + e
     uint32_t *abort_w, *err;
-    uint32_t *wacc;              // time stamps only: LDS words, per wave the 10 ns ticks it spent waiting (else null)
+    uint32_t *wacc;                  // time stamps only: LDS words, per wave the 10 ns ticks it spent waiting (else null)
+};
+// MEASUREMENT-ONLY build knobs of the spanning launch (tools/ab_span_variants.sh; every non-default value gives WRONG
+// results -- they exist to price the parts of an item): QV_SPAN_DRAIN = 0 no wait for the row's stores, QV_SPAN_ROWST = 1
+// non-temporal / 2 plain row stores, QV_SPAN_ROWLD = 1 plain row loads, QV_SPAN_NOWAIT = 1 nothing waits, nothing signals.
+#ifndef QV_SPAN_DRAIN
+#define QV_SPAN_DRAIN 1
+#endif
+#ifndef QV_SPAN_ROWST
+#define QV_SPAN_ROWST 0
+#endif
+#ifndef QV_SPAN_ROWLD
+#define QV_SPAN_ROWLD 0
+#endif
+#ifndef QV_SPAN_NOWAIT
+#define QV_SPAN_NOWAIT 0
+#endif
+#ifndef QV_SPAN_NODONE      // 1: copy items do not wait for "the step two back has finished"
+#define QV_SPAN_NODONE 0
+#endif
+#ifndef QV_SPAN_NOSIGLOAD   // 1 (with NOWAIT): the signals' index loads are skipped as well
+#define QV_SPAN_NOSIGLOAD 0
+#endif
+struct QSpec {       // what a wave fetched beside its item, in the same trip (wave-uniform)
+    uint32_t fidx;   // the flag word it guessed (aflag: cap_coop + e; cflag: e) ...
+    uint32_t fval;   // ... and its value
+    uint32_t done;   // all_done of the step two back (1: nothing to wait for)
 };
 __device__ __forceinline__ void q_raise(const QDep &d) {
     if (lane_id() == 0) {
@@ -1187,39 +1250,101 @@ __device__ __forceinline__ bool q_wait_ge(const uint32_t *p, uint32_t target, co
         }
     }
 }
-__device__ __forceinline__ void q_signal(uint32_t *p, uint32_t units) {      // (behind the caller's s_waitcnt vmcnt(0))
+__device__ __forceinline__ void q_signal(uint32_t *p, uint32_t units) {
     if (lane_id() == 0)
         __hip_atomic_fetch_add(p, units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void q_drain() {
+#if QV_SPAN_DRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
-__device__ __forceinline__ void wait_loads2(float4v &a, float4v &b) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+// time stamps only: mark k (1..7) of this wave = now, in LDS (the words behind the waves' wait accumulators)
+__device__ __forceinline__ void q_mark(const QDep &d, int k) {
+    if (d.wacc != nullptr && lane_id() == 0)
+        d.wacc[16 + (threadIdx.x >> 6) * 8 + k] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
 }
-__device__ __forceinline__ void wait_loads1(float4v &a) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a)::"memory");
+// `sc1` row accesses the compiler schedules and counts itself: buffer instructions on a descriptor of the row (base = the
+// row's first column of the item, offsets in bytes)
+typedef unsigned int uint4v_ __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2v_ __attribute__((ext_vector_type(2)));
+constexpr int kAuxSc1 = 16;      // cache-policy bits of the gfx940 family: sc0 = 1, nt = 2, sc1 = 16
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t q_row_rsrc(float *row) {
+    return __builtin_amdgcn_make_buffer_rsrc(row, 0, 0x7FFFFFFF, 0x00020000);
 }
-__device__ __forceinline__ void st2_sc1(float *p, float2v_ v) {
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ float4v q_ld4_sc1(__amdgpu_buffer_rsrc_t r, int col) {
+    const uint4v_ v = __builtin_amdgcn_raw_buffer_load_b128(r, col * 4, 0, QV_SPAN_ROWLD ? 0 : kAuxSc1);
+    float4v f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
 }
-// what an item of a spanning launch waits for before it touches its row (wave-uniform; false: give up, touch nothing)
-__device__ __forceinline__ bool q_dep_wait(const QDep &d, uint32_t c, uint32_t st, uint32_t dep1) {
+__device__ __forceinline__ void q_st4_sc1(__amdgpu_buffer_rsrc_t r, int col, float4v f) {
+    uint4v_ v;
+    __builtin_memcpy(&v, &f, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, col * 4, 0, QV_SPAN_ROWST == 1 ? 2 : QV_SPAN_ROWST == 2 ? 0 : kAuxSc1);
+}
+__device__ __forceinline__ float q_ld1_sc1(__amdgpu_buffer_rsrc_t r, int col) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, col * 4, 0, kAuxSc1));
+}
+__device__ __forceinline__ void q_st2_sc1(__amdgpu_buffer_rsrc_t r, int col, float2v_ f) {
+    uint2v_ v;
+    __builtin_memcpy(&v, &f, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, col * 4, 0, kAuxSc1);
+}
+// What an item waits for before it touches its row.  c > 0: an apply item whose key's flag word is aflag[fi]; c == 0: a copy
+// item, flag word cflag[fi], dep1 != 0 if the step before applies its key.
+//   q_dep_ask    the flag word's value, ASKED FOR as early as possible (the one fetched beside the item if that is the
+//                word, else a load whose result stays in a vector register: no wait here);
+//   q_dep_ready  looks at it (the first use of the value: behind whatever was issued in between);
+//   q_dep_wait   polls (false: give up, touch nothing).
+__device__ __forceinline__ uint32_t q_dep_ask(const QDep &d, const QSpec &sp, uint32_t c, uint32_t fi, uint32_t dep1) {
+    if (d.wait_a == 0u || (c == 0u && dep1 == 0u))
+        return d.full;
+    if (fi == sp.fidx)
+        return sp.fval;
+    return __hip_atomic_load((c > 0u ? d.aflag : d.cflag) + fi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool q_dep_ready(const QDep &d, const QSpec &sp, uint32_t c, uint32_t asked) {
+#if QV_SPAN_NOWAIT
+    return true;
+#endif
+    return (c > 0u || sp.done != 0u) && uniform(asked) >= d.full;
+}
+__device__ __forceinline__ bool q_dep_wait(const QDep &d, uint32_t c, uint32_t fi, uint32_t dep1) {
+    if (d.wait_a == 0u || QV_SPAN_NOWAIT)
+        return true;
     if (c > 0u)
-        return d.wait_a == 0u || q_wait_ge(d.dep_a + 2u * st, d.full, d);
+        return q_wait_ge(d.aflag + fi, d.full, d);
     if (d.done_pp != nullptr && !q_wait_ge(d.done_pp, 1u, d))
         return false;
-    if (d.dep_b != nullptr && dep1 != 0u)
-        return q_wait_ge(d.dep_b + 2u * (dep1 - 1u) + 1u, d.full, d);
-    return true;
+    return dep1 == 0u || q_wait_ge(d.cflag + fi, d.full, d);
 }
-// ... and what it adds once its row is in memory and its last read of the row is done (units of 32 columns)
-__device__ __forceinline__ void q_dep_signal(const QDep &d, uint32_t c, uint32_t st, uint32_t m, uint32_t fs, int cols) {
+// Where an item's signals go: ia = the word of the key's apply item in the next step's queue (m > 0), ic = 1 + the word
+// of its copy item there (c > 0; 0: the next step has none) -- read from the plans beside the gradient rows
+struct QSig {
+    uint32_t ia, ic;
+};
+__device__ __forceinline__ QSig q_sig_load(const QDep &d, uint32_t c, uint32_t st, uint32_t m, uint32_t fs) {
+    QSig g{0u, 0u};
+    if (d.aflag_n != nullptr && !QV_SPAN_NOSIGLOAD) {
+        // (device-coherent loads: the words were written by the builder of the next step's queue, possibly while this
+        // launch was already running -- behind its epoch tag, which this workgroup has checked)
+        if (m > 0u)
+            g.ia = __hip_atomic_load(d.dep_g + 2u * fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c > 0u)
+            g.ic = __hip_atomic_load(d.dep_a + 2u * st + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return g;
+}
+// (apply items: behind the caller's drain -- their row is in memory; copy items: once the row has arrived)
+__device__ __forceinline__ void q_dep_signal(const QDep &d, const QSig &g, uint32_t c, uint32_t m, int cols) {
+    if (d.aflag_n == nullptr || QV_SPAN_NOWAIT)
+        return;
     const uint32_t units = static_cast<uint32_t>(cols + 31) / 32u;
     if (m > 0u)
-        q_signal(d.dep_g + 2u * fs, units);
-    if (c > 0u)
-        q_signal(d.dep_a + 2u * st + 1u, units);
+        q_signal(d.aflag_n + uniform(g.ia), units);
+    if (c > 0u && uniform(g.ic) != 0u)
+        q_signal(d.cflag_n + (uniform(g.ic) - 1u), units);
 }
 
 struct QItem {
@@ -1246,8 +1371,9 @@ __device__ __forceinline__ QItem q_load(const QEntry *e, int width) {
 // S / Z: <= 512 columns by one wave, c <= 3 occurrences, two 16-byte vectors per lane
 // (SPAN: an item of a launch that spans several steps -- the row is loaded behind the item's wait, through the L2 both ways,
 // and the item's counters are raised at the end; false = the launch was aborted, nothing was touched)
+// SPAN arguments: e = the item's index in its region (wave items or copy items), sp = what was fetched beside it.
 template <bool SPAN>
-__device__ __forceinline__ bool q_small(const QArgs &a, const QItem &it, const QDep &d) {
+__device__ __forceinline__ bool q_small(const QArgs &a, const QItem &it, const QDep &d, uint32_t e, const QSpec &sp) {
     const int lane = lane_id();
     const int width = a.width;
     const int ca = it.col0 + 4 * lane, cb = ca + 256;
@@ -1273,13 +1399,31 @@ __device__ __forceinline__ bool q_small(const QArgs &a, const QItem &it, const Q
             g1[t] = q_ld_grad<float4v>(src + lb);
         }
     }
+    QSig sig{0u, 0u};
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
+    if (SPAN)
+        q_mark(d, 1);      // the item has arrived
     if (SPAN && it.kind != kQZ) {
-        // the gradient rows are on their way; the row itself only once whoever touched it in the step before is done
-        if (!q_dep_wait(d, it.c, it.st, it.o01))
+        // the flag word of the key's first slice (its own, fetched beside the item, for rows of at most 512 columns) says
+        // whether the row may be touched: if so its loads join the gradient rows' in ONE trip; else the gradient rows are on
+        // their way while the wave polls
+        const uint32_t fi = (it.c > 0u ? d.cap_coop : 0u) + e - static_cast<uint32_t>(it.col0 / 512);
+        const uint32_t asked = q_dep_ask(d, sp, it.c, fi, it.o01);
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+        if (!q_dep_ready(d, sp, it.c, asked) && !q_dep_wait(d, it.c, fi, it.o01))
             return false;
-        r0 = ld4_sc1_async(row + la);
-        r1 = ld4_sc1_async(row + lb);
-        wait_loads2(r0, r1);
+        q_mark(d, 2);      // the row may be touched
+        r0 = q_ld4_sc1(rr, la - it.col0);
+        r1 = q_ld4_sc1(rr, lb - it.col0);
+        if (d.wacc != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
+            q_mark(d, 3);  // row and gradient rows are here
+        }
+        if (it.c == 0u) {
+            // a copy only READS its row: whoever applies the key in the next step may go ahead once it has arrived
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
+            q_dep_signal(d, sig, 0u, it.m, it.cols);
+        }
     }
 #pragma unroll
     for (int t = 0; t < kQSmallC; ++t) {
@@ -1291,9 +1435,9 @@ __device__ __forceinline__ bool q_small(const QArgs &a, const QItem &it, const Q
     if (it.c > 0) {
         if (SPAN) {
             if (a0)
-                st4_sc1(row + ca, r0);
+                q_st4_sc1(rr, ca - it.col0, r0);
             if (a1)
-                st4_sc1(row + cb, r1);
+                q_st4_sc1(rr, cb - it.col0, r1);
         } else {
             if (a0)
                 q_st_row(row + ca, r0);
@@ -1314,9 +1458,12 @@ __device__ __forceinline__ bool q_small(const QArgs &a, const QItem &it, const Q
                 q_st_out(o + cb, r1);
         }
     }
-    if (SPAN && it.kind != kQZ) {
-        q_drain();
-        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+    if (SPAN)
+        q_mark(d, 4);          // stores issued
+    if (SPAN && it.c > 0u) {     // (kind S: the row this item wrote is in memory before anybody is told, and before the
+        q_drain();              // workgroup counts as finished)
+        q_mark(d, 5);
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
     }
     return true;
 }
@@ -1369,7 +1516,7 @@ __device__ __forceinline__ void q_small_pair(const QArgs &a, const QEntry *ea, c
 
 // M: one 128-column slice, c <= 15 occurrences, 8 bytes per lane, ordered chain
 template <bool SPAN>
-__device__ __forceinline__ bool q_medium(const QArgs &a, const QItem &it, const QDep &d) {
+__device__ __forceinline__ bool q_medium(const QArgs &a, const QItem &it, const QDep &d, uint32_t e, const QSpec &sp) {
     const int lane = lane_id();
     const int width = a.width;
     const int col = it.col0 + 2 * lane;
@@ -1384,6 +1531,13 @@ __device__ __forceinline__ bool q_medium(const QArgs &a, const QItem &it, const 
     float2v_ r{0.f, 0.f};
     if (!SPAN)
         r = q_ld_row<float2v_>(row + lc);
+    QSig sig{0u, 0u};
+    uint32_t fi = 0, asked = 0;
+    if (SPAN) {      // the flag word and the signals' indices are asked for beside the occurrence indices
+        fi = (it.c > 0u ? d.cap_coop : 0u) + e - static_cast<uint32_t>(it.col0 / 128);
+        asked = q_dep_ask(d, sp, it.c, fi, it.o01);
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+    }
     // branch-free: lanes >= c hold the index of the last occurrence, so the loads beyond c repeat a line the wave
     // has just asked for and the chain skips them by select (uniform branches around 15 loads make the compiler
     // spill; clamped loads are what scatter_dev.h does as well)
@@ -1394,12 +1548,17 @@ __device__ __forceinline__ bool q_medium(const QArgs &a, const QItem &it, const 
         const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(pidx, t));
         g[t] = q_ld_grad<float2v_>(gbase + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + lc);
     }
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
     if (SPAN) {
         // (c == 0: the "gradient" loads above re-read the row itself, plainly -- their values are never used)
-        if (!q_dep_wait(d, it.c, it.st, it.o01))
+        if (!q_dep_ready(d, sp, it.c, asked) && !q_dep_wait(d, it.c, fi, it.o01))
             return false;
-        r[0] = __hip_atomic_load(row + lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r[1] = __hip_atomic_load(row + lc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r[0] = q_ld1_sc1(rr, lc - it.col0);
+        r[1] = q_ld1_sc1(rr, lc - it.col0 + 1);
+        if (it.c == 0u) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory");
+            q_dep_signal(d, sig, 0u, it.m, it.cols);
+        }
     }
 #pragma unroll
     for (int t = 0; t < kQMediumC; ++t) {
@@ -1411,7 +1570,7 @@ __device__ __forceinline__ bool q_medium(const QArgs &a, const QItem &it, const 
     }
     if (it.c > 0 && act) {
         if (SPAN)
-            st2_sc1(row + col, r);
+            q_st2_sc1(rr, col - it.col0, r);
         else
             q_st_row(row + col, r);
     }
@@ -1426,16 +1585,16 @@ __device__ __forceinline__ bool q_medium(const QArgs &a, const QItem &it, const 
                 q_st_out(o + col, r);
         }
     }
-    if (SPAN) {
+    if (SPAN && it.c > 0u) {
         q_drain();
-        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
     }
     return true;
 }
 
 // L: one 32-column slice, 16 <= c < 64: lane = (occurrence group r of 8, column quad c4); fixed-order tree
 template <bool SPAN>
-__device__ __forceinline__ bool q_long(const QArgs &a, const QItem &it, const QDep &d) {
+__device__ __forceinline__ bool q_long(const QArgs &a, const QItem &it, const QDep &d, uint32_t e, const QSpec &sp) {
     const int lane = lane_id();
     const int width = a.width;
     const int r = lane >> 3, c4 = lane & 7;
@@ -1449,6 +1608,13 @@ __device__ __forceinline__ bool q_long(const QArgs &a, const QItem &it, const QD
     float4v cur{0.f, 0.f, 0.f, 0.f};
     if (!SPAN)
         cur = q_ld_row<float4v>(row + col);
+    QSig sig{0u, 0u};
+    uint32_t fi = 0, asked = 0;
+    if (SPAN) {      // the key's flag word is asked for beside the occurrence indices; it is needed at the very end
+        fi = d.cap_coop + e - static_cast<uint32_t>(it.col0 / 32);
+        asked = q_dep_ask(d, sp, it.c, fi, 0u);
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+    }
     float4v g[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -1466,16 +1632,16 @@ __device__ __forceinline__ bool q_long(const QArgs &a, const QItem &it, const QD
     p = add4(p, shfl_xor4(p, 8));
     p = add4(p, shfl_xor4(p, 16));
     p = add4(p, shfl_xor4(p, 32));
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
     if (SPAN) {      // the row is needed for the last subtraction only
-        if (!q_dep_wait(d, it.c, it.st, 0u))
+        if (!q_dep_ready(d, sp, it.c, asked) && !q_dep_wait(d, it.c, fi, 0u))
             return false;
-        cur = ld4_sc1_async(row + col);
-        wait_loads1(cur);
+        cur = q_ld4_sc1(rr, col - it.col0);
     }
     const float4v nv = sub4(cur, p);
     if (r == 0 && act) {
         if (SPAN)
-            st4_sc1(row + col, nv);
+            q_st4_sc1(rr, col - it.col0, nv);
         else
             q_st_row(row + col, nv);
     }
@@ -1491,7 +1657,7 @@ __device__ __forceinline__ bool q_long(const QArgs &a, const QItem &it, const QD
     }
     if (SPAN) {
         q_drain();
-        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
     }
     return true;
 }
@@ -1517,6 +1683,13 @@ __device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float
     float4v cur{0.f, 0.f, 0.f, 0.f};
     if (!SPAN)
         cur = q_ld_row<float4v>(row + col);
+    QSig sig{0u, 0u};
+    uint32_t fi = 0, fnow = 0;
+    if (SPAN && w == 0) {      // (wave 0 waits and signals for the workgroup)
+        fi = e - (static_cast<uint32_t>(it.col0 / 64) * (nch > 1u ? nch : 1u) + (nch > 1u ? ch : 0u));
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+        fnow = d.wait_a ? __hip_atomic_load(d.aflag + fi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d.full;
+    }
     // destinations of this wave: j = 64 * k + 4 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 2, l & 3):
     // one register covers the first 16 rounds (1,024 destinations)
     int dv = 0;
@@ -1586,10 +1759,11 @@ __device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float
         }
         total = tot;
     }
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
     if (SPAN) {
         uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_part) + kQWpw * 64;
         if (w == 0) {
-            const bool ok = q_dep_wait(d, it.c, it.st, 0u);
+            const bool ok = uniform(fnow) >= d.full || q_dep_wait(d, it.c, fi, 0u);
             if (lane == 0)
                 s_ctl[1] = ok ? 1u : 0u;
         }
@@ -1597,14 +1771,14 @@ __device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float
         const bool ok = uniform(s_ctl[1]) != 0u;
         if (!ok)
             return false;
-        cur = ld4_sc1_async(row + col);
-        wait_loads1(cur);
+        cur = q_ld4_sc1(rr, col - it.col0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur)::"memory");
         __syncthreads();     // every wave holds the OLD row before wave 0 stores the new one
     }
     const float4v nv = sub4(cur, total);
     if (w == 0 && r == 0 && act) {
         if (SPAN)
-            st4_sc1(row + col, nv);
+            q_st4_sc1(rr, col - it.col0, nv);
         else
             q_st_row(row + col, nv);
     }
@@ -1623,7 +1797,7 @@ __device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float
     __syncthreads();   // s_part is reused by the next item of this workgroup
     if (SPAN && w == 0) {
         q_drain();
-        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
     }
     return true;
 }
@@ -1635,7 +1809,7 @@ __device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float
 // block of 256 (eight 16-byte loads per lane and block) --, the four wave sums meet in LDS as (w0 + w1) + (w2 + w3).
 // s_part = 4 x 32 floats.
 template <bool SPAN>
-__device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s_part, const QDep &d) {
+__device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s_part, uint32_t e, const QDep &d) {
     const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int width = a.width;
     const int r = lane >> 3, c4 = lane & 7;
@@ -1645,6 +1819,13 @@ __device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s
     float4v cur{0.f, 0.f, 0.f, 0.f};
     if (!SPAN)
         cur = q_ld_row<float4v>(row + col);
+    QSig sig{0u, 0u};
+    uint32_t fi = 0, fnow = 0;
+    if (SPAN && w == 0) {
+        fi = e - static_cast<uint32_t>(it.col0 / 32);
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+        fnow = d.wait_a ? __hip_atomic_load(d.aflag + fi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d.full;
+    }
     // destinations of this wave: j = 8 W * k + 8 * w + r in round k (W waves).  Lane l fetches the one of (k, r) =
     // (l >> 3, l & 7): one register covers eight rounds
     constexpr uint32_t kDW = 8u * kQWpw, kBlk = 64u * kQWpw;
@@ -1683,10 +1864,11 @@ __device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s
     for (int q = 1; q < kQWpw / 4; ++q)        // (timing variants with larger workgroups; the product has four waves)
         total = add4(total, add4(add4(*reinterpret_cast<const float4v *>(sp + 128 * q), *reinterpret_cast<const float4v *>(sp + 128 * q + 32)),
                                  add4(*reinterpret_cast<const float4v *>(sp + 128 * q + 64), *reinterpret_cast<const float4v *>(sp + 128 * q + 96))));
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
     if (SPAN) {      // (as q_coop_r3)
         uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_part) + kQWpw * 64;
         if (w == 0) {
-            const bool ok = q_dep_wait(d, it.c, it.st, 0u);
+            const bool ok = uniform(fnow) >= d.full || q_dep_wait(d, it.c, fi, 0u);
             if (lane == 0)
                 s_ctl[1] = ok ? 1u : 0u;
         }
@@ -1694,14 +1876,14 @@ __device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s
         const bool ok = uniform(s_ctl[1]) != 0u;
         if (!ok)
             return false;
-        cur = ld4_sc1_async(row + col);
-        wait_loads1(cur);
+        cur = q_ld4_sc1(rr, col - it.col0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur)::"memory");
         __syncthreads();
     }
     const float4v nv = sub4(cur, total);
     if (w == 0 && r == 0 && act) {
         if (SPAN)
-            st4_sc1(row + col, nv);
+            q_st4_sc1(rr, col - it.col0, nv);
         else
             q_st_row(row + col, nv);
     }
@@ -1720,7 +1902,7 @@ __device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s
     __syncthreads();   // s_part is reused by the next item of this workgroup
     if (SPAN && w == 0) {
         q_drain();
-        q_dep_signal(d, it.c, it.st, it.m, it.fs, it.cols);
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
     }
     return true;
 }
@@ -1729,6 +1911,42 @@ __device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s
 // The items of one step: workgroups [0, ncoop) take the G items, the others one wave item per wave.
 static_assert(kQWg == 256 || kQWg == 512 || kQWg == 1024, "workgroups of 4, 8 or 16 waves");
 static_assert(!QV_GOLD || kQWg == 1024, "the sixteen-wave G item needs 1024-thread workgroups");
+// "The queue (and, in a spanning launch, the next step's queue) carries the tag of its step": peek = plain loads that travel
+// with the wave's first item, poll = the bounded wait of a launch that overtook the builder (device-coherent loads).
+struct QEp {
+    uint32_t w, c, nw, nc;
+};
+__device__ __forceinline__ QEp q_epoch_peek(const QArgs &a) {
+    QEp e;
+    e.w = a.qh->epoch_wave;
+    e.c = a.qh->epoch_copy;
+    e.nw = a.qh_next ? a.qh_next->epoch_wave : 0u;
+    e.nc = a.qh_next ? a.qh_next->epoch_copy : 0u;
+    return e;
+}
+__device__ __forceinline__ bool q_epoch_match(const QArgs &a, const QEp &e) {
+    return uniform(static_cast<uint32_t>(e.w == a.epoch && e.c == a.epoch &&
+                                         (a.qh_next == nullptr || (e.nw == a.epoch_next && e.nc == a.epoch_next)))) != 0u;
+}
+__device__ __forceinline__ bool q_epoch_poll(const QArgs &a, const QDep &d) {
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+        QEp e;
+        e.w = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        e.c = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        e.nw = e.nc = 0u;
+        if (a.qh_next != nullptr) {
+            e.nw = __hip_atomic_load(&a.qh_next->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            e.nc = __hip_atomic_load(&a.qh_next->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (q_epoch_match(a, e))
+            return true;
+        if ((spin & 63) == 63 && uniform(__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+            return false;
+        __builtin_amdgcn_s_sleep(64);
+    }
+    return false;
+}
+
 // The items of ONE step by the workgroup `b` of its step's grid: workgroups [0, ncoop) take the G items, the others one wave
 // item per wave.  SPAN: the step is one of several of a launch (qapply_span_kernel): `d` says what its items wait for and
 // raise, `gb` = the workgroup's index in the launch (time stamps).
@@ -1736,28 +1954,34 @@ template <bool SPAN>
 __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b, uint32_t *s_dyn, const unsigned gb) {
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
+    unsigned was_copy = 0;
     bool alive = true;
     uint32_t *s_ctl = s_dyn + kQWpw * 64;     // SPAN: [0] waves of this workgroup that have finished, [1] q_coop_r3's
     if (SPAN) {
-        if (threadIdx.x < 32)
-            s_ctl[threadIdx.x] = 0u;
+        for (int i = threadIdx.x; i < 8 + 16 + kQWpw * 8; i += kQWg)
+            s_ctl[i] = 0u;
         __syncthreads();
     }
-    if (a.epoch != 0u) {
-        // The caller orders this launch behind the queue's builder without a wait on this stream (the builder ran a block of
-        // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
-        // ~1 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
+    // The caller may order this launch behind the queue's builder without a wait on this stream (the builder ran a block of
+    // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
+    // ~1 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
+    // A spanning launch that knows the queue's item counts looks at the words BESIDE its first item (one trip) instead.
+    bool checked = a.epoch == 0u;
+    const bool coop = b < a.ncoop;
+    const bool counts_known = SPAN && (coop ? a.k_coop != 0u : (a.k_wave != 0u && a.k_copy != 0u));
+    if (!checked && !counts_known) {
         bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;     // (read with the header's counts)
-        for (int spin = 0; !ready && spin < (1 << 20); ++spin) {
-            const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
-            if (ready)
-                break;
-            if (SPAN && (spin & 63) == 63 &&
-                uniform(__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
-                break;
-            __builtin_amdgcn_s_sleep(64);
+        if (SPAN) {
+            ready = q_epoch_match(a, q_epoch_peek(a)) || q_epoch_poll(a, d);
+        } else {
+            for (int spin = 0; !ready && spin < (1 << 20); ++spin) {
+                const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
+                if (ready)
+                    break;
+                __builtin_amdgcn_s_sleep(64);
+            }
         }
         if (!ready) {
             if (SPAN) {
@@ -1767,24 +1991,40 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
             }
             return;
         }
+        checked = true;
     }
-    const bool coop = b < a.ncoop;
     if (coop) {
         role = 0;
-        const uint32_t n = min(a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
+        const uint32_t n = min((SPAN && a.k_coop) ? a.k_coop - 1u : a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
         for (uint32_t e = static_cast<uint32_t>(b); e < n && alive; e += static_cast<uint32_t>(a.ncoop)) {
-            const QItem it = q_load(a.qcoop + e, a.width);
+            QEp ep{0u, 0u, 0u, 0u};
+            if (SPAN && !checked)
+                ep = q_epoch_peek(a);
+            QItem it = q_load(a.qcoop + e, a.width);
+            if (SPAN && !checked) {
+                if (!q_epoch_match(a, ep)) {
+                    if (!q_epoch_poll(a, d)) {
+                        q_raise(d);
+                        alive = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_dcache_inv();      // (the item just read may be what the builder had not written yet)
+                    it = q_load(a.qcoop + e, a.width);
+                }
+                checked = true;
+            }
 #if QV_GOLD
             alive = q_coop_r3<SPAN>(a, it, reinterpret_cast<float *>(s_dyn), e, d);
 #else
-            alive = q_coop<SPAN>(a, it, reinterpret_cast<float *>(s_dyn), d);
+            alive = q_coop<SPAN>(a, it, reinterpret_cast<float *>(s_dyn), e, d);
 #endif
             kind = it.kind;
         }
     } else {
         b -= a.ncoop;
         role = 3;
-        const uint32_t n0 = min(a.qh->n_wave, a.cap_wave), n = n0 + min(a.qh->n_copy, a.cap_copy);
+        const uint32_t n0 = min((SPAN && a.k_wave) ? a.k_wave - 1u : a.qh->n_wave, a.cap_wave),
+                       n = n0 + min((SPAN && a.k_copy) ? a.k_copy - 1u : a.qh->n_copy, a.cap_copy);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
         if (!SPAN && a.width <= 128) {
@@ -1814,12 +2054,13 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
                         continue;
                     const QItem it = q_load(src[h], a.width);
                     kind = it.kind;
+                    const QSpec none{0u, 0u, 1u};
                     if (it.kind == kQL)
-                        q_long<false>(a, it, d);
+                        q_long<false>(a, it, d, 0u, none);
                     else if (it.kind == kQM)
-                        q_medium<false>(a, it, d);
+                        q_medium<false>(a, it, d, 0u, none);
                     else
-                        q_small<false>(a, it, d);
+                        q_small<false>(a, it, d, 0u, none);
                 }
             }
         } else
@@ -1832,21 +2073,60 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
             // item 13.2, copies spread evenly over all wave items 13.2, small wave items first 13.1-13.2).
             const uint32_t n1 = n - n0, both = 2u * (n0 < n1 ? n0 : n1);
             const QEntry *src;
-            if (e < both)
-                src = (e & 1u) ? a.qcopy + (e >> 1) : a.qwave + (e >> 1);
-            else
-                src = n0 > n1 ? a.qwave + (e - n1) : a.qcopy + (e - n0);
-            const QItem it = q_load(src, a.width);
+            bool cp;            // the item is a copy item (its index in its own region: er)
+            uint32_t er;
+            if (e < both) {
+                cp = (e & 1u) != 0u;
+                er = e >> 1;
+            } else {
+                cp = n0 <= n1;
+                er = n0 > n1 ? e - n1 : e - n0;
+            }
+            src = cp ? a.qcopy + er : a.qwave + er;
 #else
-            const QItem it = q_load(e < n0 ? a.qwave + e : a.qcopy + (e - n0), a.width);
+            const bool cp = e >= n0;
+            const uint32_t er = cp ? e - n0 : e;
+            const QEntry *src = cp ? a.qcopy + er : a.qwave + er;
 #endif
+            QEp ep{0u, 0u, 0u, 0u};
+            if (SPAN && !checked)
+                ep = q_epoch_peek(a);
+            QSpec sp{0u, 0u, 1u};
+            if (SPAN && d.wait_a) {
+                // beside the item, in the same trip: the flag word of this item (what it waits for if it is its key's first
+                // slice: always, for rows of at most 512 columns) and, for a copy, "the step two back has finished"
+                sp.fidx = cp ? er : d.cap_coop + er;
+                sp.fval = __hip_atomic_load((cp ? d.cflag : d.aflag) + sp.fidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cp && d.done_pp != nullptr)
+                    sp.done = __hip_atomic_load(d.done_pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            QItem it = q_load(src, a.width);
+            if (SPAN && !checked) {
+                if (!q_epoch_match(a, ep)) {
+                    if (!q_epoch_poll(a, d)) {
+                        q_raise(d);
+                        alive = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_dcache_inv();      // (the item just read may be what the builder had not written yet)
+                    it = q_load(src, a.width);
+                    if (d.wait_a)
+                        sp.fval = __hip_atomic_load((cp ? d.cflag : d.aflag) + sp.fidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                checked = true;
+            }
+            if (SPAN) {
+                sp.fval = uniform(sp.fval);
+                sp.done = uniform(sp.done);
+            }
             kind = it.kind;
+            was_copy = cp ? 1u : 0u;
             if (it.kind == kQL)
-                alive = q_long<SPAN>(a, it, d);
+                alive = q_long<SPAN>(a, it, d, er, sp);
             else if (it.kind == kQM)
-                alive = q_medium<SPAN>(a, it, d);
+                alive = q_medium<SPAN>(a, it, d, er, sp);
             else
-                alive = q_small<SPAN>(a, it, d);
+                alive = q_small<SPAN>(a, it, d, er, sp);
         }
     }
     if (SPAN && alive) {
@@ -1891,13 +2171,27 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
         if (lane_id() == 0) {
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long *dd = a.dbg + (static_cast<size_t>(gb) * kQWpw + (threadIdx.x >> 6)) * 4;
+            unsigned long long *dd = a.dbg + (static_cast<size_t>(gb) * kQWpw + (threadIdx.x >> 6)) * (SPAN ? 8 : 4);
+            if (SPAN) {
+                const uint32_t *mk = s_ctl + 8 + 16 + (threadIdx.x >> 6) * 8;
+                const uint32_t lo = static_cast<uint32_t>(t0);
+#pragma unroll
+                for (int k = 1; k <= 4; ++k)      // marks 1..5 as ticks since the wave's start, 16 bits each (0: not reached)
+                    dd[4] = 0;
+                unsigned long long pk = 0;
+#pragma unroll
+                for (int k = 1; k <= 4; ++k)
+                    pk |= static_cast<unsigned long long>(mk[k] ? ((mk[k] - lo) & 0xFFFFu) : 0u) << (16 * (k - 1));
+                dd[4] = pk;
+                dd[5] = mk[5] ? ((mk[5] - lo) & 0xFFFFu) : 0u;
+                dd[6] = dd[7] = 0;
+            }
             dd[0] = t0;
             dd[1] = t1;
             dd[2] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8) |
                     (SPAN ? static_cast<unsigned long long>(s_ctl[8 + (threadIdx.x >> 6)]) << 16 : 0ull);
             dd[3] = static_cast<unsigned long long>(static_cast<unsigned>(kind) & 0xFFu) |
-                    (static_cast<unsigned long long>(a.step) << 8);
+                    (static_cast<unsigned long long>(a.step) << 8) | (static_cast<unsigned long long>(was_copy) << 24);
         }
     }
 }
@@ -1926,14 +2220,17 @@ struct QSpanStep {
     uint32_t epoch;            // tag queue i must carry (0: no check)
     uint32_t wg_end;           // workgroups of steps 0 .. i
     uint16_t ncoop, nworker;
+    uint32_t k_wave, k_coop, k_copy;      // queue i's item counts + 1 where the caller knows them (0: in the header)
+    uint32_t pad;
 };
-static_assert(sizeof(QSpanStep) == 56, "a step of a spanning launch: 56 bytes of kernel arguments");
+static_assert(sizeof(QSpanStep) == 72, "a step of a spanning launch: 72 bytes of kernel arguments");
 struct QSpanArgs {
     float *table;
     uint64_t rows;
     int width, nsteps;
     float lr;
     uint32_t cap_coop, cap_wave, cap_copy;
+    uint32_t flag_off;         // bytes from a queue's header to its flag words
     uint32_t *err;
     unsigned long long *dbg;
     QSpanStep step[kQSpanMax + 1];
@@ -1941,12 +2238,14 @@ struct QSpanArgs {
 static_assert(sizeof(QSpanArgs) <= 4096, "kernel arguments");
 __global__ __launch_bounds__(kQWg, 8) void qapply_span_kernel(const QSpanArgs sa) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    const uint32_t gb = blockIdx.x;
-    int s = 0;
-    for (int k = 0; k + 1 < sa.nsteps; ++k)
-        s += gb >= sa.step[k].wg_end ? 1 : 0;
+    // grid: x = the workgroup's index in its step's grid (up to the largest step's; the others leave at once), y = the step --
+    // workgroups are handed out x first, so step by step, and a workgroup knows its step without a trip to the arguments
+    const int s = static_cast<int>(blockIdx.y);
     const QSpanStep &cur = sa.step[s], &nxt = sa.step[s + 1];
-    const uint32_t base = s > 0 ? sa.step[s - 1].wg_end : 0u;
+    if (blockIdx.x >= static_cast<uint32_t>(cur.ncoop) + cur.nworker)
+        return;
+    const uint32_t gb = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t base = gb - blockIdx.x;
     QArgs a;
     a.table = sa.table;
     a.rows = sa.rows;
@@ -1974,18 +2273,40 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_span_kernel(const QSpanArgs sa
     a.err = sa.err;
     a.dbg = sa.dbg;
     QDep d;
+    const bool has_next = s + 1 < sa.nsteps;
+    uint32_t *flags = a.qpcnt + sa.cap_coop;          // the queue's flag words follow its chunk counters (queue_layout)
+    d.aflag = flags;
+    d.cflag = flags + sa.cap_coop + sa.cap_wave;
+    d.aflag_n = d.cflag_n = nullptr;
+    a.qh_next = nullptr;
+    a.epoch_next = 0u;
+    if (has_next) {
+        uint32_t *fn = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(const_cast<QHeader *>(nxt.qh)) + sa.flag_off);
+        d.aflag_n = fn;
+        d.cflag_n = fn + sa.cap_coop + sa.cap_wave;
+        a.qh_next = nxt.qh;
+        a.epoch_next = nxt.epoch;
+    }
+    a.k_wave = cur.k_wave;
+    a.k_coop = cur.k_coop;
+    a.k_copy = cur.k_copy;
+    d.cap_coop = sa.cap_coop;
     d.dep_a = cur.dep;
     d.dep_g = nxt.dep;
-    d.dep_b = s > 0 ? sa.step[s - 1].dep : nullptr;
-    d.done_pp = s > 1 ? &sa.step[s - 2].qh->all_done : nullptr;
+    d.done_pp = (s > 1 && !QV_SPAN_NODONE) ? &sa.step[s - 2].qh->all_done : nullptr;
     d.done_p = s > 0 ? &sa.step[s - 1].qh->all_done : nullptr;
-    d.done_target = cur.wg_end - base;
+    d.done_target = static_cast<uint32_t>(cur.ncoop) + cur.nworker;
     a.step = static_cast<uint32_t>(s);
     d.full = static_cast<uint32_t>(sa.width + 31) / 32u;
     d.wait_a = s > 0 ? 1u : 0u;
     d.abort_w = const_cast<uint32_t *>(&sa.step[0].qh->abort);
     d.err = sa.err;
     d.wacc = sa.dbg ? s_dyn + kQWpw * 64 + 8 : nullptr;
+    // every argument of the step in scalar registers NOW (one batch of loads): fetched where it is first used, each costs
+    // the wave a trip to the argument buffer in the middle of its item
+    asm volatile("" ::"s"(a.grads), "s"(a.out), "s"(a.perm_a), "s"(a.perm_g), "s"(d.dep_a), "s"(d.dep_g), "s"(d.aflag_n),
+                 "s"(d.done_pp), "s"(d.done_p), "s"(a.qh_next), "s"(a.epoch), "s"(a.epoch_next), "s"(a.k_wave), "s"(a.k_copy),
+                 "s"(a.k_coop));
     qapply_body<true>(a, d, static_cast<int>(gb - base), s_dyn, gb);
 }
 
@@ -2265,10 +2586,10 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     if (done != nullptr)
         // the event completes with THIS launch (the dispatch packet's own completion signal): no packet of its own on the
         // stream -- an event record between two launches of a stream costs what a short kernel costs
-        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 128, stream,
+        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 1024, stream,
                               nullptr, done, 0, a);
     else
-        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 128, stream, a);
+        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, a);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -2280,7 +2601,8 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
 static int qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                        void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
                        const void *const *queues, const int64_t *wave_items, const uint32_t *epochs, uint32_t *err,
-                       hipEvent_t done, hipStream_t stream, unsigned long long *dbg = nullptr) {
+                       hipEvent_t done, hipStream_t stream, unsigned long long *dbg = nullptr,
+                       const uint32_t *const *counts_host = nullptr) {
     HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
                    width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
                "ha_qapply_span: the table must be 16-byte aligned with rows of a multiple of 4 floats");
@@ -2300,7 +2622,9 @@ static int qapply_span(float *table, int64_t rows, int64_t width, float lr, int6
     sa.cap_coop = q0.cap_coop;
     sa.cap_wave = q0.cap_wave;
     sa.cap_copy = q0.cap_copy;
+    sa.flag_off = static_cast<uint32_t>(q0.flag_off);
     uint32_t total = 0;
+    unsigned most = 1;
     for (int64_t k = 0; k <= count; ++k) {
         QSpanStep &st = sa.step[k];
         HA_REQUIRE(n[k] >= 0 && n[k] <= queue_n_cap && (n[k] == 0 || plans[k]), "ha_qapply_span: batch %lld needs its plan",
@@ -2328,23 +2652,39 @@ static int qapply_span(float *table, int64_t rows, int64_t width, float lr, int6
             ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
             const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
             nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
-            const int64_t wi = wave_items ? wave_items[k] : -1;
+            int64_t wi = wave_items ? wave_items[k] : -1;
+            // the counts the queue's builder left in pinned host memory ({wave, workgroup, copy items} + 1; 0 = not there
+            // yet): the waves then find their items without reading the queue's header first
+            const uint32_t *cn = counts_host ? counts_host[k] : nullptr;
+            if (cn != nullptr) {
+                const uint32_t w1 = cn[0], g1 = cn[1], c1 = cn[2];
+                if (w1 != 0u && g1 != 0u && c1 != 0u) {
+                    st.k_wave = w1;
+                    st.k_coop = g1;
+                    st.k_copy = c1;
+                    wi = static_cast<int64_t>(w1 - 1u) + static_cast<int64_t>(c1 - 1u);
+                    if (static_cast<int>(g1 - 1u) < ncoop)
+                        ncoop = static_cast<int>(g1 - 1u);
+                }
+            }
             if (wi >= 0 && wi / kQWpw + 1 < nworker)
                 nworker = static_cast<int>(wi / kQWpw + 1);
         }
         st.ncoop = static_cast<uint16_t>(ncoop);
         st.nworker = static_cast<uint16_t>(nworker);
         total += static_cast<uint32_t>(ncoop + nworker);
+        most = most > static_cast<unsigned>(ncoop + nworker) ? most : static_cast<unsigned>(ncoop + nworker);
         st.wg_end = total;
     }
     // (every step's queue header carries the words later steps wait for, the first one the launch's abort word: a span
     // holds no step without ids at both ends -- the caller cuts it there)
     for (int64_t k = 0; k < count; ++k)
         HA_REQUIRE(sa.step[k].qh != nullptr, "ha_qapply_span: step %lld of the span is empty (cut the span there)", (long long)k);
+    const dim3 grid(most, static_cast<unsigned>(count));
     if (done != nullptr)
-        hipExtLaunchKernelGGL(qapply_span_kernel, dim3(total), dim3(kQWg), kQWpw * 64 * 4 + 128, stream, nullptr, done, 0, sa);
+        hipExtLaunchKernelGGL(qapply_span_kernel, grid, dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, nullptr, done, 0, sa);
     else
-        hipLaunchKernelGGL(qapply_span_kernel, dim3(total), dim3(kQWg), kQWpw * 64 * 4 + 128, stream, sa);
+        hipLaunchKernelGGL(qapply_span_kernel, grid, dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, sa);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -2926,10 +3266,10 @@ extern "C" int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, f
 extern "C" int64_t ha_qapply_span_max(void) { return kQSpanMax; }
 extern "C" int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                               void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
-                              const void *const *queues, const int64_t *wave_items, const uint32_t *epochs, uint32_t *err,
-                              void *done_event, ha_stream_t stream) {
+                              const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host,
+                              const uint32_t *epochs, uint32_t *err, void *done_event, ha_stream_t stream) {
     return qapply_span(table, rows, width, lr, queue_n_cap, count, plans, n, grads, next_out, queues, wave_items, epochs, err,
-                       static_cast<hipEvent_t>(done_event), as_stream(stream));
+                       static_cast<hipEvent_t>(done_event), as_stream(stream), nullptr, counts_host);
 }
 extern "C" int ha_debug_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                                     void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,

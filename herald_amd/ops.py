@@ -1305,7 +1305,8 @@ class QueueStepPipeline:
             check(L.ha_debug_qapply_span(*head, pl, na, gs, os_, qs, hints, _ptr(dbg), sp), "ha_debug_qapply_span")
             return
         eps = (ctypes.c_uint32 * m)(*[self._epoch(c1 + i) if flags else 0 for i in range(m)])
-        check(L.ha_qapply_span(*head, pl, na, gs, os_, qs, hints, eps, self._err_ptr(last) if flags else None, done, sp),
+        cs = (vp * m)(*[self._counts_base + 16 * ((c1 + i) % self.COUNTS) for i in range(m)])
+        check(L.ha_qapply_span(*head, pl, na, gs, os_, qs, hints, cs, eps, self._err_ptr(last) if flags else None, done, sp),
               "ha_qapply_span")
 
     def apply_span_call(self, c0, grads_list, out_list, stream, n):
@@ -1324,6 +1325,8 @@ class QueueStepPipeline:
         qs = (vp * cnt)(*[self._queue(c0 + i) for i in range(cnt)])
         hints = (i64 * cnt)(*[-1] * cnt)
         eps = (ctypes.c_uint32 * cnt)()
+        cs = (vp * cnt)()
+        base = self._counts_base
         head = (vp(t.data_ptr()), i64(rows), i64(width), ctypes.c_float(self.lr), i64(self.capacity), i64(cnt))
         sp = _stream_ptr(stream)
         fn, epoch, last_err = L.ha_qapply_span, self._epoch, self._err_ptr
@@ -1331,10 +1334,23 @@ class QueueStepPipeline:
         flags = self.sync == "flags"
         B = self.block
 
+        import time
+        wait_counts = os.environ.get("HA_QSPAN_WAIT_COUNTS", "1") != "0"
+
         def call(k0):
             if k0 // B != (k0 + cnt - 1) // B:
                 raise RuntimeError("apply_span_call: steps %d..%d cross a block boundary (block = %d)" % (k0, k0 + cnt - 1, B))
             self._enq_last = k0 + cnt - 1 if self._enq_last is None else max(self._enq_last, k0 + cnt - 1)
+            if wait_counts:
+                # A launch that knows its queues' item counts finds every wave's item in one trip and is sized exactly; the
+                # builder leaves them in pinned memory a block ahead of the steps.  A host that runs further ahead than that
+                # waits here (the device still has the block before in front of it), at most 20 ms -- then the launch reads
+                # the counts from the queue headers instead.
+                at = 4 * ((k0 + cnt - 1) % ring)
+                if counts[at] == 0 or counts[at + 2] == 0:
+                    t_end = time.perf_counter() + 0.02
+                    while (counts[at] == 0 or counts[at + 2] == 0) and time.perf_counter() < t_end:
+                        pass
             for i in range(cnt):
                 at = 4 * ((k0 + i) % ring)
                 w, cp = counts[at], counts[at + 2]
@@ -1344,8 +1360,9 @@ class QueueStepPipeline:
                     self._last_items = w + cp - 2
                 hints[i] = w + cp - 2 if w > 0 and cp > 0 else (self._last_items * 17) // 16 if self._last_items > 0 else -1
                 eps[i] = epoch(k0 + i) if flags else 0
+                cs[i] = base + 4 * at
             done = self._block_done_event(k0 + cnt - 1) if flags else None
-            if fn(*head, pl, na, gs, os_, qs, hints, eps, last_err(k0 + cnt - 1) if flags else None, done, sp) != 0:
+            if fn(*head, pl, na, gs, os_, qs, hints, cs, eps, last_err(k0 + cnt - 1) if flags else None, done, sp) != 0:
                 check(-1, "ha_qapply_span")
         return call
 

@@ -593,8 +593,8 @@ int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, in
 int64_t ha_qapply_span_max(void);
 int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                    void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
-                   const void *const *queues, const int64_t *wave_items, const uint32_t *epochs, uint32_t *err,
-                   void *done_event, ha_stream_t stream);
+                   const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host,
+                   const uint32_t *epochs, uint32_t *err, void *done_event, ha_stream_t stream);
 /* ha_qqueue_batch_epochs with, per step, the plan of the batch BEFORE the batch the step applies (plans_b / n_b; NULL, or
  * n_b[k] = 0: none). */
 int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, const int64_t *n_b, void *const *plans_a,

@@ -25,8 +25,8 @@ outs = [torch.empty((n, width), device=dev) for _ in range(24)]
 pipe = ops.QueueStepPipeline(table, n, 1e-6, block=BK)
 LA = pipe.LOOKAHEAD
 WPW = int(os.environ.get("WPW", "16"))
-NBLK = 600 * SPAN * (16 // WPW)
-dbg = torch.zeros(NBLK * WPW * 4, dtype=torch.int64, device=dev)
+NBLK = 520 * (16 // WPW) * SPAN
+dbg = torch.zeros(NBLK * WPW * 8, dtype=torch.int64, device=dev)
 ids_of = lambda j: ids[j] if 0 <= j < len(ids) else None
 stamp = 2 * BK               # the third block's launch is the stamped one
 for c in range(-LA, 0):
@@ -45,7 +45,7 @@ while c < nsteps:
     c += m
 torch.cuda.synchronize()
 assert not pipe.overflowed()
-d = dbg.cpu().numpy().reshape(-1, 4)
+d = dbg.cpu().numpy().reshape(-1, 8)
 live = d[:, 0] > 0
 base = d[live, 0].min()
 t0 = (d[:, 0] - base) * 0.01
@@ -54,7 +54,9 @@ role = d[:, 2] & 0xFF
 wait = ((d[:, 2] >> 16) & 0xFFFFFFFF) * 0.01
 kind = (d[:, 3] & 0xFF).astype(np.int64)
 kind = np.where(kind > 100, -1, kind)
-step = (d[:, 3] >> 8).astype(np.int64)
+step = ((d[:, 3] >> 8) & 0xFFFF).astype(np.int64)
+iscopy = ((d[:, 3] >> 24) & 1).astype(bool)
+marks = np.stack([((d[:, 4] >> (16 * k)) & 0xFFFF) * 0.01 for k in range(4)] + [(d[:, 5] & 0xFFFF) * 0.01], axis=1)
 nst = int(step[live].max()) + 1
 print("launch of %d steps: span %.2f us = %.2f us per step, stamped waves %d" % (nst, t1[live].max(), t1[live].max() / nst, live.sum()))
 names = {4: "G", 2: "L", 1: "M", 0: "S", 3: "Z", -1: "idle"}
@@ -79,3 +81,17 @@ for lo in np.arange(0, T, max(1.0, round(T / 60))):
     act = mm & (kind >= 0)
     sts = np.unique(step[act]) if act.any() else []
     print("t=%5.1f us resident waves %5d (with an item %5d) of steps %s" % (lo, mm.sum(), act.sum(), list(map(int, sts))))
+
+print("phases of S items (us since the wave started; marks: 1 item arrived, 2 row may be touched, 3 row + gradient rows here, "
+      "4 stores issued, 5 row's stores in memory; then the wave's end):")
+for nm, sel in (("S apply, step 0", live & (kind == 0) & ~iscopy & (step == 0)), ("S copy,  step 0", live & (kind == 0) & iscopy & (step == 0)),
+                ("S apply, steps >= 2", live & (kind == 0) & ~iscopy & (step >= 2)), ("S copy,  steps >= 2", live & (kind == 0) & iscopy & (step >= 2))):
+    if not sel.any():
+        continue
+    mk = marks[sel]
+    end = (t1 - t0)[sel]
+    row = []
+    for k in range(5):
+        v = mk[:, k][mk[:, k] > 0]
+        row.append("m%d p50 %.2f p90 %.2f" % (k + 1, np.percentile(v, 50), np.percentile(v, 90)) if v.size else "m%d -" % (k + 1))
+    print("  %-20s n %6d | %s | end p50 %.2f p90 %.2f" % (nm, sel.sum(), " | ".join(row), np.percentile(end, 50), np.percentile(end, 90)))
