@@ -89,8 +89,12 @@ def parse_args():
                         "side stream beside the steps of the block before; ids are needed 3 blocks ahead)")
     p.add_argument("--span", type=int, default=None,
                    help="--engine queue: steps ONE launch spans (ha_qapply_span: the items of consecutive steps wait for each "
-                        "other row by row instead of a launch boundary per step; the same results bit for bit).  Default: the "
-                        "block (--queue-block); 0 / 1 = one launch per step.  Plain launches only (not with --graph-steps > 1)")
+                        "other row by row instead of a launch boundary per step; the same results bit for bit).  Default: 0 = one "
+                        "launch per step (the spanning launch measured slower: docs/EXPERIMENTS.md).  Plain launches only")
+    p.add_argument("--gated", action="store_true",
+                   help="--engine queue: one launch per step on TWO streams alternately, every item of a step waiting -- behind "
+                        "its gradient rows, before it touches a table row -- for one word the step before sets when it has "
+                        "finished (ha_qapply_gated_steps): the tail of a launch, the boundary and the next launch's ramp overlap")
     p.add_argument("--queue-serial", action="store_true",
                    help="--engine queue with the preparation launch in front of every step on the timed stream instead of "
                         "beside the steps on side streams")
@@ -536,12 +540,13 @@ def main():
     span = 0
     if queue and not use_graph:
         packs = {}
-        span = min(pipe.SPAN_MAX, args.queue_block if args.span is None else args.span)
+        span = min(pipe.SPAN_MAX, 0 if args.span is None else args.span)
         span = span if span >= 2 else 0
+        gated = args.gated and not span
 
         def make_pack(k, ln):
             bs = [(k + i) % nb for i in range(ln)]
-            mk = pipe.apply_span_call if span else pipe.apply_steps_call
+            mk = pipe.apply_span_call if span else pipe.apply_gated_call if gated else pipe.apply_steps_call
             return mk(k, [grads[x % nbuf] for x in bs], [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
 
         def pieces(k, ln):
@@ -660,8 +665,12 @@ def main():
                 ops.embedding_lookup(table, ids_dev[k % nb], out=scratch, stream=main_s)
     run(K0 + wu - pre, pre)
     t0 = time.perf_counter()
+    if queue:
+        pipe.join(main_s)      # (gated launches: the second stream's steps so far are in front of the start event)
     e0.record(main_s)
     replays = run(K0 + wu, args.steps)
+    if queue:
+        pipe.join(main_s)
     e1.record(main_s)
     t_enq = time.perf_counter() - t0
     if gate is not None:
@@ -691,7 +700,8 @@ def main():
     if one:
         # the step IS one launch of ha::step_kernel: its average duration is the HIP-event time of the
         # timed region / K, measured on the launch stream
-        kname = ("ha::qapply_span_kernel" if span else "ha::qapply_kernel") if queue else \
+        kname = ("ha::qapply_span_kernel" if span else "ha::qapply_gated_kernel" if (args.gated and not use_graph) else
+                 "ha::qapply_kernel") if queue else \
             "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
         traffic, traffic_src = pmc_traffic(kname)
         # launches of the timed region (a spanning launch covers several steps: bytes and duration are per LAUNCH, the
@@ -799,7 +809,7 @@ def main():
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
                              else ("plain launches, one per span of up to %d steps, enqueued ahead of the device" % span) if span
                              else "plain launches, one per step, enqueued ahead of the device",
-                   "span_steps": span,
+                   "span_steps": span, "gated_two_streams": bool(queue and not use_graph and args.gated and not span),
                    "parallelism": "1 GPU"},
         "step_algorithmic_bytes": fwd_b + bwd_b,
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,

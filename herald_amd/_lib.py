@@ -178,10 +178,13 @@ def _declare(L):
         "ha_stream_wait_event": [vp, vp],
         "ha_qqueue_batch_epochs": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
         "ha_qapply_steps_sync": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "ha_qapply_steps_counts": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qapply_sync": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, c.c_uint32, vp, vp, vp],
         "ha_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-        "ha_debug_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp],
+        "ha_debug_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qqueue_batch_span": [i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
+        "ha_qapply_gated_steps": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64],
+        "ha_debug_qapply_gated": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp, i64, vp, vp, vp],
         "ha_qbig_plan_view": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
         "ha_plan_build_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_plan_build_batch_u64ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],

@@ -119,9 +119,11 @@ struct QLayout {
     uint32_t *pcnt;        // [cap_coop] chunks of a (key, slice) that have delivered theirs (at the index of its chunk 0)
     uint32_t *aflag;       // [cap_coop + cap_wave] spanning launches: "ready" units of a key, at its first apply item
     uint32_t *cflag;       // [cap_copy] ... "applied" units of a key the step before names, at its first copy item
+    uint32_t *gate;        // [kQGates * 32] gated launches: "this step has finished", one copy per 128-byte line
     uint32_t cap_coop, cap_wave, cap_copy;
-    size_t bytes, flag_off;
+    size_t bytes, flag_off, gate_off;
 };
+constexpr int kQGates = 64;            // copies of a step's "finished" word (the waves of the next launch poll one each)
 constexpr uint32_t kQChunk = 256;      // occurrences per workgroup item: a key with more is cut into CHUNKS (QV_GOLD)
 __host__ __device__ __forceinline__ uint32_t q_nchunk(uint32_t c) {
     return (QV_GOLD && c > kQChunk) ? (c + kQChunk - 1u) / kQChunk : 1u;
@@ -147,7 +149,9 @@ static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
     q.flag_off = items + static_cast<size_t>(q.cap_coop) * (256 + 4);
     q.aflag = reinterpret_cast<uint32_t *>(b ? b + q.flag_off : nullptr);
     q.cflag = q.aflag ? q.aflag + q.cap_coop + q.cap_wave : nullptr;
-    q.bytes = q.flag_off + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * 4;
+    q.gate_off = align_up(q.flag_off + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * 4, 128);
+    q.gate = reinterpret_cast<uint32_t *>(b ? b + q.gate_off : nullptr);
+    q.bytes = q.gate_off + static_cast<size_t>(kQGates) * 128;
     return q;
 }
 
@@ -959,6 +963,16 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             __hip_atomic_store(&bqh->wg_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&bqh->abort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&bqh->all_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!WIDE && tid < kQGates) {      // (the gate words follow the flag words: queue_layout)
+            uint32_t *gate = reinterpret_cast<uint32_t *>(
+                reinterpret_cast<char *>(bqh) +
+                ((sizeof(QHeader) + (static_cast<size_t>(bcap_coop) + bcap_wave + bcap_copy) * sizeof(QEntry) +
+                  static_cast<size_t>(bcap_coop) * (256 + 4) + (static_cast<size_t>(bcap_coop) + bcap_wave + bcap_copy) * 4 +
+                  127) & ~static_cast<size_t>(127)));
+            __hip_atomic_store(gate + 32 * tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!WIDE && tid == 0) {
             bqh->n_wave = min(nL + nM + nS, bcap_wave);
             bqh->n_coop = min(nG, bcap_coop);
             bqh->n_long = nL;
@@ -1032,7 +1046,9 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     // the queue is complete once every builder workgroup has passed this point: items visible device-wide (release), then
     // the epoch words -- by this part for its own region (narrow path: two workgroups per step), or by whichever of the
     // step's `wide_parts` bucket workgroups finishes last
-    __builtin_amdgcn_s_waitcnt(0);      // this thread's items (write-through stores) are in memory
+    // (inline asm: the item stores are asm too, invisible to the compiler's scoreboard -- it deletes a builtin wait it
+    // believes has nothing to wait for, and the tag then overtakes the items)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this thread's items (write-through stores) are in memory
     __syncthreads();
     if (tid == 0) {
         if (!WIDE) {
@@ -1043,7 +1059,7 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             } else {
                 __hip_atomic_store(&bqh->n_copy, bqh->n_copy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __builtin_amdgcn_s_waitcnt(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __hip_atomic_store(part == 0 ? &bqh->epoch_wave : &bqh->epoch_copy, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (signal &&
                    __hip_atomic_fetch_add(&bqh->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == wide_parts) {
@@ -1192,6 +1208,12 @@ struct QDep {
     uint32_t cap_coop;               // aflag index of wave item e: cap_coop + e
     uint32_t *abort_w, *err;
     uint32_t *wacc;                  // time stamps only: LDS words, per wave the 10 ns ticks it spent waiting (else null)
+    // GATED launches (qapply_gated_kernel): ONE condition for every item -- "the step before has finished" -- instead of the
+    // per-key words: gate = this workgroup's copy of that step's word (null: nothing to wait for); gate_out = this step's
+    // own copies, set by the workgroup that finishes last
+    const uint32_t *gate;
+    uint32_t *gate_out;
+    uint32_t *gate_lds;              // two LDS words of the workgroup: [0] a wave polls the gate, [1] 1 = open, 2 = given up
 };
 // MEASUREMENT-ONLY build knobs of the spanning launch (tools/ab_span_variants.sh; every non-default value gives WRONG
 // results -- they exist to price the parts of an item): QV_SPAN_DRAIN = 0 no wait for the row's stores, QV_SPAN_ROWST = 1
@@ -1223,7 +1245,8 @@ __device__ __forceinline__ void q_raise(const QDep &d) {
     if (lane_id() == 0) {
         if (d.err != nullptr)
             __hip_atomic_store(d.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(d.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d.abort_w != nullptr)
+            __hip_atomic_store(d.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // wave-uniform p: true once *p >= target; false if the launch was aborted or the wait gave up (it then raises)
@@ -1233,7 +1256,10 @@ __device__ __forceinline__ bool q_wait_ge(const uint32_t *p, uint32_t target, co
         return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (uint32_t spin = 1;; ++spin) {
-        __builtin_amdgcn_s_sleep(4);
+        if (d.gate != nullptr)
+            __builtin_amdgcn_s_sleep(16);     // (one poller per workgroup, every wave of the launch behind it: ~0.5 us)
+        else
+            __builtin_amdgcn_s_sleep(4);
         v = uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (v >= target) {
             if (d.wacc != nullptr && lane_id() == 0)
@@ -1298,6 +1324,8 @@ __device__ __forceinline__ void q_st2_sc1(__amdgpu_buffer_rsrc_t r, int col, flo
 //   q_dep_ready  looks at it (the first use of the value: behind whatever was issued in between);
 //   q_dep_wait   polls (false: give up, touch nothing).
 __device__ __forceinline__ uint32_t q_dep_ask(const QDep &d, const QSpec &sp, uint32_t c, uint32_t fi, uint32_t dep1) {
+    if (d.gate != nullptr)      // (gated launch: the word says 1 once the step before has finished; `full` stands for that)
+        return __hip_atomic_load(d.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? d.full : 0u;
     if (d.wait_a == 0u || (c == 0u && dep1 == 0u))
         return d.full;
     if (fi == sp.fidx)
@@ -1310,7 +1338,37 @@ __device__ __forceinline__ bool q_dep_ready(const QDep &d, const QSpec &sp, uint
 #endif
     return (c > 0u || sp.done != 0u) && uniform(asked) >= d.full;
 }
+// The gate of a gated launch: EVERY wave of the launch waits for the same event, so one wave per workgroup polls the word
+// in memory (the first to get here) and the others watch an LDS word -- thousands of waves polling memory every few hundred
+// nanoseconds are hundreds of GB/s of requests to a handful of lines, beside the step that is still running.
+__device__ __forceinline__ bool q_gate_wait(const QDep &d) {
+    uint32_t *g = d.gate_lds;
+    uint32_t st = uniform(__hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (st != 0u)
+        return st == 1u;
+    uint32_t first = 0;
+    if (lane_id() == 0)
+        first = __hip_atomic_exchange(g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (uniform(first) == 0u) {
+        const bool ok = q_wait_ge(d.gate, 1u, d);
+        if (lane_id() == 0)
+            __hip_atomic_store(g + 1, ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return ok;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(8);
+        st = uniform(__hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (st != 0u) {
+            if (d.wacc != nullptr && lane_id() == 0)
+                d.wacc[threadIdx.x >> 6] += static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime() - t0);
+            return st == 1u;
+        }
+    }
+}
 __device__ __forceinline__ bool q_dep_wait(const QDep &d, uint32_t c, uint32_t fi, uint32_t dep1) {
+    if (d.gate != nullptr)
+        return q_gate_wait(d);
     if (d.wait_a == 0u || QV_SPAN_NOWAIT)
         return true;
     if (c > 0u)
@@ -1688,7 +1746,7 @@ __device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float
     if (SPAN && w == 0) {      // (wave 0 waits and signals for the workgroup)
         fi = e - (static_cast<uint32_t>(it.col0 / 64) * (nch > 1u ? nch : 1u) + (nch > 1u ? ch : 0u));
         sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
-        fnow = d.wait_a ? __hip_atomic_load(d.aflag + fi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d.full;
+        fnow = q_dep_ask(d, QSpec{0xFFFFFFFFu, 0u, 1u}, it.c, fi, 0u);
     }
     // destinations of this wave: j = 64 * k + 4 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 2, l & 3):
     // one register covers the first 16 rounds (1,024 destinations)
@@ -1733,7 +1791,7 @@ __device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float
         const uint32_t first = e - ch;
         if (w == 0 && r == 0)
             st4_sc1(a.qpart + static_cast<size_t>(e) * 64 + 4 * c4, total);
-        __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (asm: see qjoin_body)
         __syncthreads();
         uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_part);     // (the partial sums in LDS have been consumed)
         if (threadIdx.x == 0)      // (relaxed: the sum went through the L2 and was drained; a release would write the whole L2 back)
@@ -1824,7 +1882,7 @@ __device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s
     if (SPAN && w == 0) {
         fi = e - static_cast<uint32_t>(it.col0 / 32);
         sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
-        fnow = d.wait_a ? __hip_atomic_load(d.aflag + fi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d.full;
+        fnow = q_dep_ask(d, QSpec{0xFFFFFFFFu, 0u, 1u}, it.c, fi, 0u);
     }
     // destinations of this wave: j = 8 W * k + 8 * w + r in round k (W waves).  Lane l fetches the one of (k, r) =
     // (l >> 3, l & 7): one register covers eight rounds
@@ -1940,7 +1998,8 @@ __device__ __forceinline__ bool q_epoch_poll(const QArgs &a, const QDep &d) {
         }
         if (q_epoch_match(a, e))
             return true;
-        if ((spin & 63) == 63 && uniform(__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+        if ((spin & 63) == 63 && d.abort_w != nullptr &&
+            uniform(__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
             return false;
         __builtin_amdgcn_s_sleep(64);
     }
@@ -1968,7 +2027,7 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
     // A spanning launch that knows the queue's item counts looks at the words BESIDE its first item (one trip) instead.
     bool checked = a.epoch == 0u;
     const bool coop = b < a.ncoop;
-    const bool counts_known = SPAN && (coop ? a.k_coop != 0u : (a.k_wave != 0u && a.k_copy != 0u));
+    const bool counts_known = (a.width > 128 || SPAN) && (coop ? a.k_coop != 0u : (a.k_wave != 0u && a.k_copy != 0u));
     if (!checked && !counts_known) {
         bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;     // (read with the header's counts)
         if (SPAN) {
@@ -1995,13 +2054,13 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
     }
     if (coop) {
         role = 0;
-        const uint32_t n = min((SPAN && a.k_coop) ? a.k_coop - 1u : a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
+        const uint32_t n = min(a.k_coop ? a.k_coop - 1u : a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
         for (uint32_t e = static_cast<uint32_t>(b); e < n && alive; e += static_cast<uint32_t>(a.ncoop)) {
             QEp ep{0u, 0u, 0u, 0u};
-            if (SPAN && !checked)
+            if (!checked)
                 ep = q_epoch_peek(a);
             QItem it = q_load(a.qcoop + e, a.width);
-            if (SPAN && !checked) {
+            if (!checked) {
                 if (!q_epoch_match(a, ep)) {
                     if (!q_epoch_poll(a, d)) {
                         q_raise(d);
@@ -2023,8 +2082,8 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
     } else {
         b -= a.ncoop;
         role = 3;
-        const uint32_t n0 = min((SPAN && a.k_wave) ? a.k_wave - 1u : a.qh->n_wave, a.cap_wave),
-                       n = n0 + min((SPAN && a.k_copy) ? a.k_copy - 1u : a.qh->n_copy, a.cap_copy);
+        const uint32_t n0 = min(a.k_wave ? a.k_wave - 1u : a.qh->n_wave, a.cap_wave),
+                       n = n0 + min(a.k_copy ? a.k_copy - 1u : a.qh->n_copy, a.cap_copy);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
         if (!SPAN && a.width <= 128) {
@@ -2089,7 +2148,7 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
             const QEntry *src = cp ? a.qcopy + er : a.qwave + er;
 #endif
             QEp ep{0u, 0u, 0u, 0u};
-            if (SPAN && !checked)
+            if (!checked)
                 ep = q_epoch_peek(a);
             QSpec sp{0u, 0u, 1u};
             if (SPAN && d.wait_a) {
@@ -2101,7 +2160,7 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
                     sp.done = __hip_atomic_load(d.done_pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             QItem it = q_load(src, a.width);
-            if (SPAN && !checked) {
+            if (!checked) {
                 if (!q_epoch_match(a, ep)) {
                     if (!q_epoch_poll(a, d)) {
                         q_raise(d);
@@ -2144,7 +2203,12 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
         if (last) {
             QHeader *h = const_cast<QHeader *>(a.qh);
             const uint32_t before = __hip_atomic_fetch_add(&h->wg_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (before + 1u == d.done_target) {
+            if (d.gate_out != nullptr) {
+                // gated launch: the workgroup that finishes last opens the next launch's gate (every copy of the word)
+                if (before + 1u == d.done_target)
+                    for (int g = 0; g < kQGates; ++g)
+                        __hip_atomic_store(d.gate_out + 32 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (before + 1u == d.done_target) {
                 // the step's last workgroup: once the step before is marked, this one is
                 bool ok = true;
                 if (d.done_p != nullptr) {
@@ -2200,7 +2264,41 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     QDep d;
     __builtin_memset(&d, 0, sizeof(d));
+    d.err = a.err;
     qapply_body<false>(a, d, static_cast<int>(blockIdx.x), s_dyn, blockIdx.x);
+}
+
+// ---- one launch per step, GATED: consecutive launches on TWO streams overlap -----------------------------------------------
+// A launch per step on one stream pays, every step, the tail of its predecessor (the last 40 % of a launch run at a third of
+// the chip's waves), the boundary and its own ramp and prologue (arguments, item, gradient rows).  Here step s + 1 is launched
+// on the OTHER stream of a pair: its workgroups take the slots the waves of step s leave, read their items and gradient rows
+// -- the largest stream of the step, and one no step before can change -- and then wait at ONE word, "step s has finished",
+// before they touch a table row; step s sets it when its last workgroup has drained its row stores (every workgroup counts
+// itself on wg_done of the step's queue header; the last one writes the kQGates copies of the word behind the queue).  No
+// per-key bookkeeping: the order between the steps is the launch boundary's, only the machine is not drained for it.  Rows
+// cross between the launches through the L2 (`sc1` both ways, drained) as in the spanning launch.  Step s + 2 follows step s
+// on its stream, so at most two launches are in flight; step s is completely resident before step s + 1 gets a slot (step
+// s + 1 starts when step s - 1 -- which waited for step s - 2 -- has ended, and step s has been taking every slot that came
+// free since step s - 2 ended), and a launch is at most kQWorkerMax + kQCoopSlots workgroups: nothing a gated wave waits
+// for can be kept out of the machine by gated waves.  Waits are bounded (~2 s) and raise the pinned error word.
+struct QGate {
+    const uint32_t *gate_in;     // the copies of "the step before has finished" (null: nothing to wait for)
+    uint32_t *gate_out;          // this step's copies
+};
+__global__ __launch_bounds__(kQWg, 8) void qapply_gated_kernel(const QArgs a, const QGate g) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    QDep d;
+    __builtin_memset(&d, 0, sizeof(d));
+    d.gate = g.gate_in ? g.gate_in + 32 * (blockIdx.x % kQGates) : nullptr;
+    d.gate_out = g.gate_out;
+    d.gate_lds = s_dyn + kQWpw * 64 + 2;
+    d.done_target = gridDim.x;
+    d.full = static_cast<uint32_t>(a.width + 31) / 32u;
+    d.cap_coop = a.cap_coop;
+    d.abort_w = const_cast<uint32_t *>(&a.qh->abort);
+    d.err = a.err;
+    d.wacc = a.dbg ? s_dyn + kQWpw * 64 + 8 : nullptr;
+    qapply_body<true>(a, d, static_cast<int>(blockIdx.x), s_dyn, blockIdx.x);
 }
 
 // ---- ONE launch for a block of consecutive steps ---------------------------------------------------------------------------
@@ -2273,6 +2371,7 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_span_kernel(const QSpanArgs sa
     a.err = sa.err;
     a.dbg = sa.dbg;
     QDep d;
+    __builtin_memset(&d, 0, sizeof(d));
     const bool has_next = s + 1 < sa.nsteps;
     uint32_t *flags = a.qpcnt + sa.cap_coop;          // the queue's flag words follow its chunk counters (queue_layout)
     d.aflag = flags;
@@ -2511,17 +2610,17 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
                         float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
                         int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg = nullptr,
                         int64_t wave_items = -1, uint32_t epoch = 0, uint32_t *err = nullptr, hipEvent_t done = nullptr,
-                        int64_t coop_items = -1);
+                        int64_t coop_items = -1, const uint32_t *counts = nullptr);
 
 static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                   void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
                   hipStream_t stream, unsigned long long *dbg = nullptr, int64_t wave_items = -1, uint32_t epoch = 0,
-                  uint32_t *err = nullptr, hipEvent_t done = nullptr) {
+                  uint32_t *err = nullptr, hipEvent_t done = nullptr, const uint32_t *counts = nullptr) {
     HA_REQUIRE(n_cur >= 0 && n_next >= 0 && (n_cur == 0 || plan_cur) && (n_next == 0 || plan_next),
                "ha_qapply: a batch needs its plan");
     return qapply_lists(table, rows, width, n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr, n_cur, grads, lr,
                         n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr, n_next, next_out, queue_cur, queue_n_cap,
-                        kQMax, stream, dbg, wave_items, epoch, err, done);
+                        kQMax, stream, dbg, wave_items, epoch, err, done, -1, counts);
 }
 
 // perm_cur / perm_next: the occurrence lists of the batch to apply / the destination lists of the batch to look up (what
@@ -2529,7 +2628,8 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
 static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t *perm_cur, int64_t n_cur, const float *grads,
                         float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
                         int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg,
-                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done, int64_t coop_items) {
+                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done, int64_t coop_items,
+                        const uint32_t *counts) {
     HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
                    width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
                "ha_qapply: the table must be 16-byte aligned with rows of a multiple of 4 floats");
@@ -2579,6 +2679,16 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
     const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
     a.nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
+    // the queue's {wave, workgroup, copy items} + 1 as its builder left them in pinned host memory: the waves then find their
+    // items without reading the header's counts first (one trip less in front of every item), the launch is sized exactly
+    if (counts != nullptr && counts[0] != 0u && counts[1] != 0u && counts[2] != 0u && coop_items < 0) {
+        a.k_wave = counts[0];
+        a.k_coop = counts[1];
+        a.k_copy = counts[2];
+        wave_items = static_cast<int64_t>(counts[0] - 1u) + static_cast<int64_t>(counts[2] - 1u);
+        if (static_cast<int>(counts[1] - 1u) < a.ncoop)
+            a.ncoop = static_cast<int>(counts[1] - 1u);
+    }
     // the caller knows how many wave items the queue holds (ha_qstep_queue_mirror): no workgroups that find nothing --
     // a shorter launch ramp, and free slots for the preparation launches that run beside the steps
     if (wave_items >= 0 && wave_items / kQWpw + 1 < a.nworker)
@@ -2590,6 +2700,81 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
                               nullptr, done, 0, a);
     else
         hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, a);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Step c as a GATED launch (qapply_gated_kernel): as qapply_lists (narrow batches), and the launch waits -- item by item,
+// before an item touches a table row -- for the launch of the step before to have finished (queue_prev: that step's queue,
+// which must have been applied by a gated launch; null: nothing to wait for) and tells the next one.  counts: the queue's
+// {wave, workgroup, copy items} + 1 in pinned host memory (null / zeros: unknown).
+static int qapply_gated(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                        void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, const void *queue_prev,
+                        int64_t queue_n_cap, const uint32_t *counts, int64_t wave_items, uint32_t epoch, uint32_t *err,
+                        hipEvent_t done, hipStream_t stream, unsigned long long *dbg = nullptr) {
+    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
+                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
+               "ha_qapply_gated: the table must be 16-byte aligned with rows of a multiple of 4 floats");
+    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && queue_n_cap >= 1 && queue_n_cap <= kQMax && n_cur <= queue_n_cap &&
+                   n_next <= queue_n_cap && (n_cur > 0 || n_next > 0) && queue_cur != nullptr,
+               "ha_qapply_gated: a step with ids at one end at least, and its queue");
+    HA_REQUIRE((n_cur == 0 || (plan_cur && grads && reinterpret_cast<uintptr_t>(grads) % 16 == 0)) &&
+                   (n_next == 0 || (plan_next && next_out && reinterpret_cast<uintptr_t>(next_out) % 16 == 0)),
+               "ha_qapply_gated: plans, 16-byte aligned gradients and output");
+    QArgs a;
+    memset(&a, 0, sizeof(a));
+    a.epoch = epoch;
+    a.err = err;
+    a.table = table;
+    a.rows = static_cast<uint64_t>(rows);
+    a.width = static_cast<int>(width);
+    a.lr = lr;
+    a.dbg = dbg;
+    const QLayout q = queue_layout(const_cast<void *>(queue_cur), queue_n_cap, width);
+    a.qh = q.hdr;
+    a.qcoop = q.coop;
+    a.qwave = q.wave;
+    a.qcopy = q.copy;
+    a.qpart = q.part;
+    a.qpcnt = q.pcnt;
+    a.cap_coop = q.cap_coop;
+    a.cap_wave = q.cap_wave;
+    a.cap_copy = q.cap_copy;
+    a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
+    a.n_a = static_cast<int>(n_cur);
+    a.grads = grads;
+    a.perm_g = n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr;
+    a.n_g = static_cast<int>(n_next);
+    a.out = next_out;
+    a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
+    const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
+    a.nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
+    if (counts != nullptr && counts[0] != 0u && counts[1] != 0u && counts[2] != 0u) {
+        a.k_wave = counts[0];
+        a.k_coop = counts[1];
+        a.k_copy = counts[2];
+        wave_items = static_cast<int64_t>(counts[0] - 1u) + static_cast<int64_t>(counts[2] - 1u);
+        if (static_cast<int>(counts[1] - 1u) < a.ncoop)
+            a.ncoop = static_cast<int>(counts[1] - 1u);
+    }
+    if (wave_items >= 0 && wave_items / kQWpw + 1 < a.nworker)
+        a.nworker = static_cast<int>(wave_items / kQWpw + 1);
+    {   // (A/B knob: at most this many workgroups per gated launch -- two launches then fit the chip side by side)
+        static const int maxwg = getenv("HA_QGATED_MAXWG") ? atoi(getenv("HA_QGATED_MAXWG")) : 0;
+        if (maxwg > 0 && a.ncoop + a.nworker > maxwg) {
+            if (a.ncoop > maxwg / 4)
+                a.ncoop = maxwg / 4;
+            a.nworker = maxwg - a.ncoop;
+        }
+    }
+    QGate g;
+    g.gate_in = queue_prev ? queue_layout(const_cast<void *>(queue_prev), queue_n_cap, width).gate : nullptr;
+    g.gate_out = q.gate;
+    const dim3 grid(static_cast<unsigned>(a.ncoop + a.nworker));
+    if (done != nullptr)
+        hipExtLaunchKernelGGL(qapply_gated_kernel, grid, dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, nullptr, done, 0, a, g);
+    else
+        hipLaunchKernelGGL(qapply_gated_kernel, grid, dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, a, g);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -2966,8 +3151,10 @@ constexpr size_t kQSubJoinLds = (size_t(1) << kQSubTabBits) * 4 + size_t(kQSubJo
 static_assert(kQSubJoinLds % 128 == 0, "the groups' LDS regions stay aligned");
 // One workgroup per (step, part, FOUR buckets): quarters side by side where every bucket of the four has at most
 // kQSubJoinKeys unique keys on either side, else one after the other (see qbplan_kernel).
+// (The whole-workgroup form -- buckets of more than kQSubJoinKeys unique keys: rare -- gets 128 vector registers: at 64 it
+// spills to scratch memory.)
 template <bool QUARTERS>
-__global__ __launch_bounds__(1024, 8) void qbqueue_kernel(const QBigJoinBatch b) {
+__global__ __launch_bounds__(1024, QUARTERS ? 8 : 4) void qbqueue_kernel(const QBigJoinBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const int i = static_cast<int>(blockIdx.y), p0 = static_cast<int>(blockIdx.x >> 1) * 4, part = static_cast<int>(blockIdx.x & 1);
     uint32_t bad = 0, most = 0;
@@ -3263,6 +3450,40 @@ extern "C" int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, f
 // the queues were built by ha_qqueue_batch_span (with the plan of the batch BEFORE each step's batch), the plans by
 // ha_qplan_batch_* and used by no other apply since (their dependency counters start at zero and count up once), every
 // batch's gradient rows are resident when the launch starts, and the span's first step has a queue (is not empty).
+// `count` consecutive steps as GATED launches (see qapply_gated_kernel), step k on streams[k & 1 ^ first_on] -- the caller
+// hands over two streams; per-step arrays as for ha_qapply_steps_sync.  queue_prev: the queue of the step before the first
+// one if that step was a gated launch too (the chain continues), else NULL (the first launch waits for nothing: the caller
+// has ordered it behind the table's last writer).  counts_host: per step the three pinned words the queue's builder writes
+// (may be NULL).  done_event rides on the last launch.
+extern "C" int ha_qapply_gated_steps(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                                     void *const *plan_cur, const int64_t *n_cur, const float *const *grads,
+                                     void *const *plan_next, const int64_t *n_next, float *const *next_out,
+                                     const void *const *queue_cur, const void *queue_prev, const int64_t *wave_items,
+                                     const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err,
+                                     void *done_event, ha_stream_t stream_even, ha_stream_t stream_odd, int64_t first_index) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (plan_cur && n_cur && grads && plan_next && n_next && next_out && queue_cur)),
+               "ha_qapply_gated_steps: null pointer");
+    const void *prev = queue_prev;
+    for (int64_t k = 0; k < count; ++k) {
+        HA_REQUIRE(n_cur[k] > 0 || n_next[k] > 0, "ha_qapply_gated_steps: step %lld is empty (leave it out)", (long long)k);
+        const ha_stream_t st = ((first_index + k) & 1) ? stream_odd : stream_even;
+        if (qapply_gated(table, rows, width, plan_cur[k], n_cur[k], grads[k], lr, plan_next[k], n_next[k], next_out[k],
+                         queue_cur[k], prev, queue_n_cap, counts_host ? counts_host[k] : nullptr,
+                         wave_items ? wave_items[k] : -1, epochs ? epochs[k] : 0u, err,
+                         k + 1 == count ? static_cast<hipEvent_t>(done_event) : nullptr, as_stream(st)))
+            return -1;
+        prev = queue_cur[k];
+    }
+    return 0;
+}
+extern "C" int ha_debug_qapply_gated(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                                     float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                                     const void *queue_prev, int64_t queue_n_cap, const uint32_t *counts,
+                                     unsigned long long *dbg, ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "qapply gated timeline: null debug buffer");
+    return qapply_gated(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_prev,
+                        queue_n_cap, counts, -1, 0u, nullptr, nullptr, as_stream(stream), dbg);
+}
 extern "C" int64_t ha_qapply_span_max(void) { return kQSpanMax; }
 extern "C" int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                               void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
@@ -3273,11 +3494,11 @@ extern "C" int ha_qapply_span(float *table, int64_t rows, int64_t width, float l
 }
 extern "C" int ha_debug_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                                     void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
-                                    const void *const *queues, const int64_t *wave_items, unsigned long long *dbg,
-                                    ha_stream_t stream) {
+                                    const void *const *queues, const int64_t *wave_items,
+                                    const uint32_t *const *counts_host, unsigned long long *dbg, ha_stream_t stream) {
     HA_REQUIRE(dbg != nullptr, "qapply span timeline: null debug buffer");
     return qapply_span(table, rows, width, lr, queue_n_cap, count, plans, n, grads, next_out, queues, wave_items, nullptr,
-                       nullptr, nullptr, as_stream(stream), dbg);
+                       nullptr, nullptr, as_stream(stream), dbg, counts_host);
 }
 // ha_qqueue_batch_epochs with, per step, the plan of the batch BEFORE the batch it applies (plans_b / n_b; NULL or n_b[k] = 0:
 // none): copy items then carry their dependency on that batch's apply (what ha_qapply_span waits for).
@@ -3287,6 +3508,24 @@ extern "C" int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *pl
                                     ha_stream_t stream) {
     return qqueue_batch(rows, width, plans_a, n_a, plans_g, n_g, queues, queue_n_cap, count, as_stream(stream), nullptr,
                         counts_host, epochs, plans_b, n_b);
+}
+extern "C" int ha_qapply_steps_counts(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                                      void *const *plan_cur, const int64_t *n_cur, const float *const *grads,
+                                      void *const *plan_next, const int64_t *n_next, float *const *next_out,
+                                      const void *const *queue_cur, const int64_t *wave_items,
+                                      const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err,
+                                      void *done_event, ha_stream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (plan_cur && n_cur && grads && plan_next && n_next && next_out && queue_cur)),
+               "ha_qapply_steps_counts: null pointer");
+    for (int64_t k = 0; k < count; ++k)
+        if (qapply(table, rows, width, plan_cur[k], n_cur[k], grads[k], lr, plan_next[k], n_next[k], next_out[k],
+                   queue_cur[k], queue_n_cap, as_stream(stream), nullptr, wave_items ? wave_items[k] : -1,
+                   epochs ? epochs[k] : 0u, err, k + 1 == count ? static_cast<hipEvent_t>(done_event) : nullptr,
+                   counts_host ? counts_host[k] : nullptr))
+            return -1;
+    if (count == 0 && done_event)
+        HA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(done_event), as_stream(stream)));
+    return 0;
 }
 extern "C" int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
                               float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,

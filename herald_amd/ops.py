@@ -874,6 +874,7 @@ class QueueStepPipeline:
         self._done_ev = {}
         self.c, self.n, self.shape, self.ids = None, {}, {}, {}
         self._enq_last, self._covered = None, -(1 << 60)
+        self._gate_prev = None
         self._ev_side = {}          # block index -> event behind the side work launched at its start
         self._held = {}             # block index -> id tensors its plan launch reads (kept alive, not record_stream'ed)
         return self
@@ -935,6 +936,10 @@ class QueueStepPipeline:
             cev = self._done_ev.pop(b - 1, None)
             if cev is not None:
                 check(L.ha_stream_wait_event(sp, cev), "ha_stream_wait_event")
+                if getattr(self, "aux", None) is not None:
+                    # gated launches: the gate words of block b-1's last step are about to be rebuilt with its queue slot --
+                    # the first step of block b (on the second stream) is ordered behind that launch by its event instead
+                    check(L.ha_stream_wait_event(_stream_ptr(self.aux), cev), "ha_stream_wait_event")
                 self._cev_pool.append(cev)
                 self._covered = b * B - 1
             elif self._enq_last is not None and self._enq_last > self._covered:
@@ -1195,8 +1200,11 @@ class QueueStepPipeline:
         counts, ring = self._counts_c, self.COUNTS
         flags = self.sync == "flags"
         eps = (ctypes.c_uint32 * cnt)()
-        fn_sync, epoch, last_err = L.ha_qapply_steps_sync, self._epoch, self._err_ptr
+        fn_sync, epoch, last_err = L.ha_qapply_steps_counts, self._epoch, self._err_ptr
         B = self.block
+        cs = (vp * cnt)()
+        base = self._counts_base
+        use_counts = os.environ.get("HA_QCOUNTS", "0") != "0"      # (same-box A/B: no gain for one launch per step)
 
         def call(k0):
             if flags and k0 // B != (k0 + cnt - 1) // B:
@@ -1217,12 +1225,14 @@ class QueueStepPipeline:
                     # the queue of this step may not be built yet when the host is far ahead of the device: item counts
                     # vary by a few per cent from batch to batch, so the last known count (+ 6 %) sizes the launch then
                     hints[i] = w + cp - 2 if w > 0 and cp > 0 else (self._last_items * 17) // 16 if self._last_items > 0 else -1
+                    cs[i] = base + 4 * at if use_counts else None
             if flags:
                 for i in range(cnt):
                     eps[i] = epoch(k0 + i)
                 done = self._block_done_event(k0 + cnt - 1)
-                if fn_sync(*head, pc, ns, gs, pn, ns, os_, qs, hints, eps, last_err(k0 + cnt - 1), done, sp) != 0:
-                    check(-1, "ha_qapply_steps_sync")
+                if fn_sync(*head, pc, ns, gs, pn, ns, os_, qs, hints, cs if sized else None, eps, last_err(k0 + cnt - 1), done,
+                           sp) != 0:
+                    check(-1, "ha_qapply_steps_counts")
             elif fn(*head, pc, ns, gs, pn, ns, os_, qs, hints, sp) != 0:
                 check(-1, "ha_qapply_steps")
         return call
@@ -1301,11 +1311,11 @@ class QueueStepPipeline:
         qs = (vp * m)(*[self._queue(c1 + i) for i in range(m)])
         hints = (i64 * m)(*[self.wave_items(c1 + i) for i in range(m)])
         head = (_ptr(t), rows, width, ctypes.c_float(self.lr), self.capacity, m)
+        cs = (vp * m)(*[self._counts_base + 16 * ((c1 + i) % self.COUNTS) for i in range(m)])
         if dbg is not None:
-            check(L.ha_debug_qapply_span(*head, pl, na, gs, os_, qs, hints, _ptr(dbg), sp), "ha_debug_qapply_span")
+            check(L.ha_debug_qapply_span(*head, pl, na, gs, os_, qs, hints, cs, _ptr(dbg), sp), "ha_debug_qapply_span")
             return
         eps = (ctypes.c_uint32 * m)(*[self._epoch(c1 + i) if flags else 0 for i in range(m)])
-        cs = (vp * m)(*[self._counts_base + 16 * ((c1 + i) % self.COUNTS) for i in range(m)])
         check(L.ha_qapply_span(*head, pl, na, gs, os_, qs, hints, cs, eps, self._err_ptr(last) if flags else None, done, sp),
               "ha_qapply_span")
 
@@ -1365,6 +1375,187 @@ class QueueStepPipeline:
             if fn(*head, pl, na, gs, os_, qs, hints, cs, eps, last_err(k0 + cnt - 1) if flags else None, done, sp) != 0:
                 check(-1, "ha_qapply_span")
         return call
+
+    # ---- one launch per step, GATED: two streams, consecutive launches overlap ---------------------------------------------
+    def _gated_ok(self, c0, cnt):
+        if not self.overlap or self.wide:
+            raise RuntimeError("QueueStepPipeline: gated launches need overlap=True and batches of at most %d ids"
+                               % qstep_max_ids())
+        if cnt < 1:
+            raise ValueError("at least one step")
+        if self.sync == "flags" and c0 // self.block != (c0 + cnt - 1) // self.block:
+            raise ValueError("steps %d..%d cross a block boundary (block = %d): the block's done-event rides on the LAST "
+                             "launch of a call" % (c0, c0 + cnt - 1, self.block))
+
+    def _aux(self):
+        if getattr(self, "aux", None) is None:
+            self.aux = torch.cuda.Stream(device=self.device)
+            self._gate_prev = None          # (step, queue) of the last gated launch: the chain the next one waits on
+        return self.aux
+
+    def join(self, stream=None):
+        """Makes `stream` wait for the gated launches enqueued on the pipeline's second stream so far."""
+        if getattr(self, "aux", None) is None:
+            return
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        ev = self._event()
+        ev.record(self.aux)
+        main.wait_event(ev)
+        self._ev_pool.append(ev)
+
+    def apply_gated(self, c0, grads_list, out_list, stream=None):
+        """Steps c0 .. as GATED launches (ha_qapply_gated_steps, csrc/qstep.hip): one launch per step, odd steps on `stream`,
+        even steps on a second stream of the pipeline's own; every item of a step waits -- behind its gradient rows, before
+        it touches a table row -- for one word the step before sets when its last workgroup has finished.  Same results as
+        `apply` step by step; every step's gradients must be resident when the call is made (as for apply_span).  The
+        second stream is ordered behind `stream` at the start of the call and `stream` behind it at the end."""
+        L = self._L
+        t = self.table
+        rows, width = t.shape
+        cnt = len(grads_list)
+        self._gated_ok(c0, cnt)
+        if len(out_list) != cnt:
+            raise ValueError("one output per step")
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        aux = self._aux()
+        flags = self.sync == "flags"
+        if flags and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("QueueStepPipeline(sync='flags'): steps cannot be captured into a hipGraph (use sync='events')")
+        ns = [self.n.get(c0 + i, 0) for i in range(cnt + 1)]
+        last = c0 + cnt - 1
+        done = self._block_done_event(last) if flags else None
+        self._enq_last = last if self._enq_last is None else max(self._enq_last, last)
+        ev = self._event()
+        ev.record(main)
+        aux.wait_event(ev)
+        self._ev_pool.append(ev)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        work = [i for i in range(cnt) if ns[i] or ns[i + 1]]
+        for i in work:
+            if ns[i]:
+                _require(grads_list[i], torch.float32, "grads")
+                if grads_list[i].numel() != ns[i] * width:
+                    raise ValueError("grads of step %d must hold %d x %d values" % (c0 + i, ns[i], width))
+            if ns[i + 1]:
+                _require(out_list[i], torch.float32, "out")
+                if out_list[i].numel() != ns[i + 1] * width:
+                    raise ValueError("out of step %d must hold %d x %d values" % (c0 + i, ns[i + 1], width))
+        carried = False
+        for j, i in enumerate(work):
+            c = c0 + i
+            self._raise_if_failed([c])
+            prev = self._gate_prev[1] if (self._gate_prev is not None and self._gate_prev[0] < c and
+                                          self._gate_prev[0] // self.block == c // self.block) else None
+            is_last = j + 1 == len(work)
+            dn = done if (is_last and i == cnt - 1) else None
+            carried = carried or dn is not None
+            check(L.ha_qapply_gated_steps(
+                _ptr(t), rows, width, ctypes.c_float(self.lr), self.capacity, 1,
+                (vp * 1)(self._plan_ptr[c % self.NPLAN] if ns[i] else None), (i64 * 1)(ns[i]),
+                (vp * 1)(grads_list[i].data_ptr() if ns[i] else None),
+                (vp * 1)(self._plan_ptr[(c + 1) % self.NPLAN] if ns[i + 1] else None), (i64 * 1)(ns[i + 1]),
+                (vp * 1)(out_list[i].data_ptr() if ns[i + 1] else None), (vp * 1)(self._queue(c)), prev,
+                (i64 * 1)(self.wave_items(c)), (vp * 1)(self._counts_base + 16 * (c % self.COUNTS)),
+                (ctypes.c_uint32 * 1)(self._epoch(c) if flags else 0), self._err_ptr(c) if flags else None, dn,
+                _stream_ptr(aux), _stream_ptr(main), c), "ha_qapply_gated_steps")
+            self._gate_prev = (c, self._queue(c))
+        self.join(main)
+        if done is not None and not carried:      # the block's last step launched nothing: mark the point on the stream
+            check(L.ha_event_record(done, _stream_ptr(main)), "ha_event_record")
+
+    def apply_gated_call(self, c0, grads_list, out_list, stream, n):
+        """-> callable(first step index): the steps c0 .. (and the same phases ROTATION steps later) as gated launches with the
+        arguments converted once; every batch has n ids (what bench.py enqueues).  NO stream joins: the two streams are
+        ordered by the gates alone -- the caller joins (`join`) where it needs the results on `stream`."""
+        L = self._L
+        t = self.table
+        rows, width = t.shape
+        cnt = len(grads_list)
+        self._gated_ok(c0, cnt)
+        if self.sync != "flags":
+            raise RuntimeError("apply_gated_call needs sync='flags' (the block's done-event orders the second stream; use "
+                               "apply_gated with sync='events')")
+        aux = self._aux()
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        pc = (vp * cnt)(*[self._plan_ptr[(c0 + i) % self.NPLAN] for i in range(cnt)])
+        pn = (vp * cnt)(*[self._plan_ptr[(c0 + i + 1) % self.NPLAN] for i in range(cnt)])
+        ns = (i64 * cnt)(*[n] * cnt)
+        gs = (vp * cnt)(*[g.data_ptr() for g in grads_list])
+        os_ = (vp * cnt)(*[o.data_ptr() for o in out_list])
+        qs = (vp * cnt)(*[self._queue(c0 + i) for i in range(cnt)])
+        hints = (i64 * cnt)(*[-1] * cnt)
+        eps = (ctypes.c_uint32 * cnt)()
+        cs = (vp * cnt)()
+        base = self._counts_base
+        head = (vp(t.data_ptr()), i64(rows), i64(width), ctypes.c_float(self.lr), i64(self.capacity), i64(cnt))
+        sm, sa = _stream_ptr(stream), _stream_ptr(aux)
+        fn, epoch, last_err = L.ha_qapply_gated_steps, self._epoch, self._err_ptr
+        counts, ring = self._counts_c, self.COUNTS
+        flags = self.sync == "flags"
+        B = self.block
+        import time
+        wait_counts = os.environ.get("HA_QSPAN_WAIT_COUNTS", "1") != "0"
+
+        def call(k0):
+            if flags and k0 // B != (k0 + cnt - 1) // B:
+                raise RuntimeError("apply_gated_call: steps %d..%d cross a block boundary (block = %d)" % (k0, k0 + cnt - 1, B))
+            self._enq_last = k0 + cnt - 1 if self._enq_last is None else max(self._enq_last, k0 + cnt - 1)
+            if wait_counts:      # (see apply_span_call)
+                at = 4 * ((k0 + cnt - 1) % ring)
+                if counts[at] == 0 or counts[at + 2] == 0:
+                    t_end = time.perf_counter() + 0.02
+                    while (counts[at] == 0 or counts[at + 2] == 0) and time.perf_counter() < t_end:
+                        pass
+            for i in range(cnt):
+                at = 4 * ((k0 + i) % ring)
+                w, cp = counts[at], counts[at + 2]
+                if counts[at + 3]:
+                    self._raise_if_failed([k0 + i])
+                if w > 0 and cp > 0:
+                    self._last_items = w + cp - 2
+                hints[i] = w + cp - 2 if w > 0 and cp > 0 else (self._last_items * 17) // 16 if self._last_items > 0 else -1
+                eps[i] = epoch(k0 + i) if flags else 0
+                cs[i] = base + 4 * at
+            prev = self._gate_prev[1] if (self._gate_prev is not None and self._gate_prev[0] == k0 - 1 and
+                                          k0 % B != 0) else None        # (a block's first step: ordered by the event, see prepare_block)
+            done = self._block_done_event(k0 + cnt - 1) if flags else None
+            if fn(*head, pc, ns, gs, pn, ns, os_, qs, prev, hints, cs, eps, last_err(k0 + cnt - 1) if flags else None, done,
+                  sa, sm, i64(k0)) != 0:
+                check(-1, "ha_qapply_gated_steps")
+            self._gate_prev = (k0 + cnt - 1, qs[cnt - 1])
+        return call
+
+    def step_gated(self, grads_list, ahead_ids_list=None, outs=None, stream=None):
+        """The stream protocol of `step`, several steps at a time as gated launches (see apply_gated; arguments and result as
+        step_span)."""
+        if self.c is None:
+            raise RuntimeError("QueueStepPipeline.step_gated before start")
+        cnt = len(grads_list)
+        c0 = self.c
+        self._gated_ok(c0, cnt)
+        ahead_ids_list = list(ahead_ids_list) if ahead_ids_list is not None else [None] * cnt
+        if c0 % self.block == 0:
+            self.prepare_block(c0 // self.block, lambda j: self.ids.get(j), stream)
+            for j in [j for j in self.ids if j < c0 + 3 * self.block]:
+                del self.ids[j]
+        for i, a in enumerate(ahead_ids_list):
+            if a is not None and a.numel():
+                self.ids[c0 + i + self.LOOKAHEAD] = a
+                self.shape[c0 + i + self.LOOKAHEAD] = tuple(a.shape)
+        res = []
+        for i in range(cnt):
+            n_next = self.n.get(c0 + i + 1, 0)
+            o = outs[i] if outs is not None else None
+            if n_next and o is None:
+                o = torch.empty(tuple(self.shape[c0 + i + 1]) + (self.table.shape[1],), dtype=torch.float32,
+                                device=self.table.device)
+            res.append(o if n_next else None)
+        self.apply_gated(c0, grads_list, res, stream)
+        for c in range(c0, c0 + cnt):
+            for d in (self.n, self.shape):
+                d.pop(c - 1, None)
+        self.c = c0 + cnt
+        return res
 
     def step_span(self, grads_list, ahead_ids_list=None, outs=None, stream=None):
         """The stream protocol of `step`, several steps at a time by one spanning launch: grads_list[i] = the gradients of

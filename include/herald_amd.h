@@ -569,6 +569,14 @@ int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, float lr, in
 int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                    void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
                    int64_t wave_items, uint32_t epoch, uint32_t *err, void *done_event, ha_stream_t stream);
+/* ha_qapply_steps_sync with, per step, the three pinned words the queue's builder wrote (ha_qqueue_batch_counts; NULL / zeros:
+ * unknown): a launch that knows its queue's item counts is sized exactly, and its waves ask for their items without reading
+ * the counts from the queue's header first (the epoch tag is then looked at beside the item). */
+int ha_qapply_steps_counts(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                           void *const *plan_cur, const int64_t *n_cur, const float *const *grads, void *const *plan_next,
+                           const int64_t *n_next, float *const *next_out, const void *const *queue_cur,
+                           const int64_t *wave_items, const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err,
+                           void *done_event, ha_stream_t stream);
 
 /* ONE launch for up to ha_qapply_span_max() (32) consecutive steps.  A launch per step pays a launch boundary, a ramp and a
  * tail at a third of the chip's waves every ~12 us; consecutive steps touch the same rows (step s applies batch s --
@@ -595,6 +603,27 @@ int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t 
                    void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
                    const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host,
                    const uint32_t *epochs, uint32_t *err, void *done_event, ha_stream_t stream);
+/* One launch per step, GATED: consecutive steps go to TWO streams alternately (step k to stream_odd if first_index + k is odd,
+ * else stream_even), and instead of the stream ordering them, every item of step k + 1 waits -- after it has read its queue
+ * item and its gradient rows, before it touches a table row -- for ONE word that step k sets when its last workgroup has
+ * drained its row stores.  The waves of step k + 1 take the slots step k's waves leave: the tail of a launch, the boundary
+ * and the next launch's ramp overlap, and the gradient rows (the largest stream) are on their way early; the order between
+ * the steps is still the launch boundary's (cpu_SGDOptimizerSparseUpdate of batch k, then cpu_EmbeddingLookup of batch k + 1,
+ * src/dnnl_ops/Optimizers.cpp:51-74, EmbeddingLookup.cpp:16-35), results bit for bit those of ha_qapply_steps_sync.
+ * Per-step arrays as there; queue_prev = the queue of the step before the first one if THAT step was a gated launch too
+ * (else NULL: the caller orders the first launch behind the table's last writer); counts_host = per step the three pinned
+ * words of ha_qqueue_batch_counts (or NULL).  Requirements: no step is empty at both ends; batches of at most
+ * ha_qstep_max_ids() ids; EVERY step's gradient rows resident when it is enqueued (as for ha_qapply_span); at most two
+ * launches of a chain in flight (what two streams give); the queues built by ha_qqueue_batch_* of this library version
+ * (the gate words live behind the queue and start at zero). */
+int ha_qapply_gated_steps(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                          void *const *plan_cur, const int64_t *n_cur, const float *const *grads, void *const *plan_next,
+                          const int64_t *n_next, float *const *next_out, const void *const *queue_cur, const void *queue_prev,
+                          const int64_t *wave_items, const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err,
+                          void *done_event, ha_stream_t stream_even, ha_stream_t stream_odd, int64_t first_index);
+int ha_debug_qapply_gated(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                          void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, const void *queue_prev,
+                          int64_t queue_n_cap, const uint32_t *counts, unsigned long long *dbg, ha_stream_t stream);
 /* ha_qqueue_batch_epochs with, per step, the plan of the batch BEFORE the batch the step applies (plans_b / n_b; NULL, or
  * n_b[k] = 0: none). */
 int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, const int64_t *n_b, void *const *plans_a,
@@ -605,7 +634,8 @@ int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, cons
  * index in the whole launch) */
 int ha_debug_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                          void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
-                         const void *const *queues, const int64_t *wave_items, unsigned long long *dbg, ha_stream_t stream);
+                         const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host,
+                         unsigned long long *dbg, ha_stream_t stream);
 
 /* The WIDE path: batches of more than ha_qstep_max_ids() (7,168) and at most ha_qbig_max_ids() (131,072) ids -- BASELINE
  * configs[2] / configs[3]'s per-GPU shapes, 106,496 and 26,624 ids per step.  The batch is cut into hash buckets by one

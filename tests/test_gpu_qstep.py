@@ -512,7 +512,9 @@ def test_qstep_graph_replay_is_deterministic(dev, mode):
 # those of one launch per step, bit for bit: every lookup and the table against the kernel-order model AND the reference's
 # serial chain, exactly as for the per-step launches above.
 # =====================================================================================================================
-def _run_stream_span(dev, table0, batches, grads, lr, block, span, sync="events", ids_dtype=np.float32):
+def _run_stream_span(dev, table0, batches, grads, lr, block, span, sync="events", ids_dtype=np.float32, how="span"):
+    """how = "span": `span` steps per spanning launch (step_span); "gated": `span` steps per call as gated launches on two
+    streams (step_gated)."""
     width = table0.shape[1]
     rows = table0.shape[0]
     model_t = table0.copy()
@@ -522,6 +524,7 @@ def _run_stream_span(dev, table0, batches, grads, lr, block, span, sync="events"
     cap = max(max(b.size for b in batches), 1)
     pipe = ops.QueueStepPipeline(table, cap, lr, overlap=True, block=block, sync=sync)
     assert pipe.SPAN_MAX >= 2
+    step_many = pipe.step_span if how == "span" else pipe.step_gated
     L = pipe.LOOKAHEAD
     cast = (lambda b: _dev(b.astype(np.float32), dev)) if ids_dtype == np.float32 else \
         (lambda b: _dev(b.astype(np.int64), dev))
@@ -558,8 +561,8 @@ def _run_stream_span(dev, table0, batches, grads, lr, block, span, sync="events"
     launches = 0
     while k < B:
         cnt = min(span, B - k, block - k % block)                  # a span stays inside its block
-        outs = pipe.step_span([d_grads[k + i] for i in range(cnt)],
-                              [d_ids[k + i + L] if k + i + L < B else None for i in range(cnt)])
+        outs = step_many([d_grads[k + i] for i in range(cnt)],
+                         [d_ids[k + i + L] if k + i + L < B else None for i in range(cnt)])
         launches += 1
         torch.cuda.synchronize()
         assert not pipe.overflowed()
@@ -584,10 +587,14 @@ SPANS = [(8, 8, "events"), (8, 8, "flags"), (4, 3, "flags"), (16, 16, "flags"), 
 SPAN_IDS = ["block8_span8", "block8_span8_flags", "block4_span3_flags", "block16_span16_flags", "block2_span2"]
 
 
+HOWS = ["span", "gated"]
+
+
+@pytest.mark.parametrize("how", HOWS)
 @pytest.mark.parametrize("block,span,sync", SPANS, ids=SPAN_IDS)
 @pytest.mark.parametrize("width", [4, 32, 96, 128, 200, 512, 1024])
 @pytest.mark.parametrize("rows,n", [(40, 700), (5000, 6656), (300, 63), (7, 1)])
-def test_qspan_stream_small_tables(dev, width, rows, n, block, span, sync):
+def test_qspan_stream_small_tables(dev, width, rows, n, block, span, sync, how):
     """Small tables, 19 steps: nearly every row a step applies was written by the step before (the whole chain of waits), keys
     that skip a batch or two (copy items that depend on the step before / two before), every class of item."""
     rng = np.random.default_rng(width * 131 + rows + n)
@@ -596,12 +603,13 @@ def test_qspan_stream_small_tables(dev, width, rows, n, block, span, sync):
     batches = [np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1) if k % 2 else rng.integers(0, rows, size=n)
                for k in range(steps)]
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
-    _run_stream_span(dev, table0, batches, grads, 0.05, block, span, sync)
+    _run_stream_span(dev, table0, batches, grads, 0.05, block, span, sync, how=how)
 
 
+@pytest.mark.parametrize("how", HOWS)
 @pytest.mark.parametrize("block,span,sync", SPANS[:3], ids=SPAN_IDS[:3])
 @pytest.mark.parametrize("kind", ["one_key", "two_keys", "giant_next", "copies_only", "skip_one", "skip_two"])
-def test_qspan_degenerate_batches(dev, kind, block, span, sync):
+def test_qspan_degenerate_batches(dev, kind, block, span, sync, how):
     """One key per batch (a chain of workgroup items through every step), alternating keys, a key rare in one batch and
     everywhere in the next, batches that share no key, and keys that come back after ONE / TWO batches without them (a copy
     item whose row was last written by the step before / two steps before)."""
@@ -625,11 +633,12 @@ def test_qspan_degenerate_batches(dev, kind, block, span, sync):
         batches = [rng.integers(200 * (k % 3), 200 * (k % 3) + 200, size=n) if k % 4 else rng.integers(0, rows, size=n)
                    for k in range(steps)]
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in batches]
-    _run_stream_span(dev, table0, batches, grads, 0.02, block, span, sync)
+    _run_stream_span(dev, table0, batches, grads, 0.02, block, span, sync, how=how)
 
 
+@pytest.mark.parametrize("how", HOWS)
 @pytest.mark.parametrize("block,span,sync", SPANS[:3], ids=SPAN_IDS[:3])
-def test_qspan_ragged_empty_and_out_of_range(dev, block, span, sync):
+def test_qspan_ragged_empty_and_out_of_range(dev, block, span, sync, how):
     """Batches of different sizes, EMPTY batches (also at the start of a span and two in a row), ids beyond the table and
     uint64 ids beyond 2^32, through spanning launches."""
     rng = np.random.default_rng(23)
@@ -644,11 +653,12 @@ def test_qspan_ragged_empty_and_out_of_range(dev, block, span, sync):
             b[4] = 0xFFFFFFFF
         batches.append(b)
     grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
-    _run_stream_span(dev, table0, batches, grads, 0.05, block, span, sync, ids_dtype=np.int64)
+    _run_stream_span(dev, table0, batches, grads, 0.05, block, span, sync, ids_dtype=np.int64, how=how)
 
 
+@pytest.mark.parametrize("how", HOWS)
 @pytest.mark.parametrize("block,span,sync", [(16, 16, "flags"), (8, 8, "events")], ids=["block16_flags", "block8_events"])
-def test_qspan_criteo_stream(dev, block, span, sync):
+def test_qspan_criteo_stream(dev, block, span, sync, how):
     """BASELINE configs[1]'s batch shape (bs=256, 26 fields, d=512) on a 400 k-row table slice, 40 steps by spanning launches:
     every lookup and the table against both oracles; fewer launches than steps."""
     rows, width, bs = 400_000, 512, 256
@@ -657,7 +667,7 @@ def test_qspan_criteo_stream(dev, block, span, sync):
     steps = 40
     batches = [synth.criteo_batch(bs, step=k, rows=rows).reshape(-1) for k in range(steps)]
     grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
-    pipe, launches = _run_stream_span(dev, table0, batches, grads, 0.01, block, span, sync)
+    pipe, launches = _run_stream_span(dev, table0, batches, grads, 0.01, block, span, sync, how=how)
     assert launches == -(-steps // span)
 
 
