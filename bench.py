@@ -43,6 +43,9 @@ def parse_args():
     p.add_argument("--distinct-batches", type=int, default=1024)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true")
+    p.add_argument("--no-cpu-full-table", action="store_true",
+                   help="cpu_baseline: skip the second figure on a host copy of the whole table (needs rows x width x 4 bytes "
+                        "of host DRAM and ~30 s)")
     p.add_argument("--no-cache-prefill", action="store_true",
                    help="cache_tier: time the pairs on the cache as 64 warm-up batches leave it (far from full: no "
                         "evictions) instead of filling it to its limit first")
@@ -207,8 +210,37 @@ def cpu_baseline(args, ids_host):
         el = time.perf_counter() - t0
         if el > t_budget or steps >= 400:
             break
+    # The same on the table the GPU line uses (all `--rows` rows, host DRAM): a 1M-row slice (2 GB) sits partly in the host's
+    # last-level caches and flatters the CPU.  Only where the host has the memory; ids as they are (no folding).
+    full = None
+    try:
+        import psutil
+        need = args.rows * args.width * 4
+        if rows_cpu < args.rows and psutil.virtual_memory().available > need + (32 << 30) and not args.no_cpu_full_table:
+            del table
+            big = np.empty((args.rows, args.width), dtype=np.float32)
+            for s0 in range(0, args.rows, 1 << 20):      # (touch every page once: the timed steps must not fault them in)
+                big[s0:s0 + (1 << 20)] = np.float32(0.01)
+            idf = ids_host[0].astype(np.float32)
+            lookup(big, idf)
+            update(big, idf, grads, LR)
+            fs, t1 = 0, time.perf_counter()
+            while True:
+                idf = ids_host[fs % ids_host.shape[0]].astype(np.float32)
+                lookup(big, idf)
+                update(big, idf, grads, LR)
+                fs += 1
+                fel = time.perf_counter() - t1
+                if fel > 6.0 or fs >= 200:
+                    break
+            full = {"value": n * fs / fel, "unit": "rows/s", "rows": args.rows, "steps": fs, "ms_per_step": 1e3 * fel / fs,
+                    "table_GB": need / 1e9}
+            del big
+    except Exception as ex:      # noqa: BLE001 -- the slice figure stands
+        full = {"error": "%s: %s" % (type(ex).__name__, ex)}
     return {
         "value": n * steps / el, "unit": "rows/s", "cores": cpu.num_threads(), "kind": kind,
+        "full_table": full,
         "sample": "%d steps of bs=%d d=%d on a %d-row table slice: %s OpenMP gather (%d threads) + serial "
                   "sparse SGD (1 thread, as cpu_SGDOptimizerSparseUpdate mandates), %.1f ms/step"
                   % (steps, args.batch, args.width, rows_cpu,
@@ -311,15 +343,19 @@ def laia_scheduler(args):
     ahead = os.environ.get("HA_LAIA_AHEAD", "1") == "1"
     s.start(samples, samples.shape[0], T, 1, mini_bs, batch_num, W, 0, int(0.1 * args.rows), 16, 24, key_limit=args.rows,
             ahead=ahead)
-    while s.pop() != [0]:
-        pass
+    while True:
+        item = s.pop_arrays()
+        if len(item) == 1 and int(item[0]) == 0:
+            break
     tm = s.timing()
     s.close()
-    return {"us_per_global_batch": tm["us_per_batch"], "global_batch_samples": W * mini_bs, "workers": W,
-            # the scheduler thread's whole loop per batch: the library call + queueing plan and dist as Python lists (the
-            # reference's launch(), laia_scheduler.cc:115-169) -- with `one_batch_ahead` the device works on batch k+1 during
-            # the latter, and `us_per_global_batch` (time inside the library call) is what is left to wait for
+    # THE figure: the scheduler thread's period -- one (plan, dist) pair per this many microseconds, the reference's launch()
+    # loop as a whole (laia_scheduler.cc:115-169: the library call + handing the pair to the queue).  `in_call_us` is the part
+    # spent inside the library call (with `one_batch_ahead` the device works on batch k+1 behind it).
+    return {"us_per_global_batch": tm["thread_wall_us_per_batch"], "in_call_us_per_global_batch": tm["us_per_batch"],
+            "global_batch_samples": W * mini_bs, "workers": W,
             "thread_wall_us_per_global_batch": tm["thread_wall_us_per_batch"], "one_batch_ahead": ahead,
+            "hand_off": "arrays (pop_arrays); pop() converts to the reference's Python lists in the caller's thread",
             "tables": T, "cache_size": int(0.1 * args.rows), "batches": tm["batches"],
             "host_assign_us": tm["host_assign_us"], "host_snapshot_us": tm["host_snapshot_us"],
             "gpu_and_transfer_us": tm["gpu_and_transfer_us"],

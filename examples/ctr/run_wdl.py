@@ -207,7 +207,8 @@ def make_batches(nbatch, batch, rows, seed=0, rank=0, world=1):
 
 
 def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, cache="LRU", bound=0,
-          cache_limit=None, seed=0, device="cuda:0", table_init=None, log_every=0, model="wdl", a2a=None, allreduce=None):
+          cache_limit=None, seed=0, device="cuda:0", table_init=None, log_every=0, model="wdl", a2a=None, allreduce=None,
+          bsp=0, cache_perf=False, perf_csv_dir=None):
     """Runs `steps` training steps; returns (losses, embedding parameter, tower).  a2a / allreduce: optional
     replacements of the collectives at world size > 1 (several ranks on one GPU under gloo in the tests)."""
     dev = torch.device(device)
@@ -237,9 +238,10 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         store = ShardedEmbedding(rows, width, dev, a2a=a2a)
         store.table.copy_(table_init[store.starts[store.rank]:store.starts[store.rank + 1]])
         param = hetu_ops.EmbeddingParameter(store=store)
-        config = hetu_ops.Config(comm_mode="PS" if embedding == "ps" else "Hybrid", bsp=0, prefetch=True,
+        config = hetu_ops.Config(comm_mode="PS" if embedding == "ps" else "Hybrid", bsp=bsp, prefetch=True,
                                  cstable_policy=cache if embedding == "cache" else None, cache_bound=bound,
-                                 cache_limit=cache_limit if cache_limit is not None else max(rows // 10, batch * NFIELD))
+                                 cache_limit=cache_limit if cache_limit is not None else max(rows // 10, batch * NFIELD),
+                                 cache_perf_enable=cache_perf)
         comm = hetu_ops.ParameterServerCommunicateOp(param, lr, next_ids=lambda: ids_of(state["k"] + 1))
         barrier = dist.barrier if world > 1 else (lambda: None)
         comm.forward_hook(config, first_ids=ids_of(0), barrier=barrier)
@@ -315,23 +317,79 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
     torch.cuda.synchronize()
     if fused is not None:
         ops.check_handoff(fused["plans"])
+    if cache_perf and comm is not None and getattr(comm, "cache", None) is not None:
+        dump_cache_perf([comm.cache], rank, perf_csv_dir)
     return losses, param, tower
 
 
+def dump_cache_perf(caches, rank, csv_dir=None):
+    """What /root/reference/examples/ctr/run_hetu.py:508-515 does after training with --cache-perf: one CSV per cache
+    table, `csv/hetu_cache<idx>_<rank>.csv` beside the script, one row per cache call (the perf dicts: counts -- num_all,
+    num_unique, num_miss, num_evict, num_transfered, ... -- and stage times)."""
+    import csv
+    csv_dir = csv_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csv")
+    os.makedirs(csv_dir, exist_ok=True)
+    paths = []
+    for idx, c in enumerate(caches):
+        if c is None:
+            print("Cache perf is None")
+            continue
+        rows = list(c.get_perf())
+        path = os.path.join(csv_dir, "hetu_cache%d_%d.csv" % (idx, rank))
+        cols = sorted({k for r in rows for k in r})
+        with open(path, "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow([""] + cols)                      # pandas' to_csv layout: an index column first
+            for i, r in enumerate(rows):
+                w.writerow([i] + [r.get(k, "") for k in cols])
+        paths.append(path)
+    return paths
+
+
 def main():
+    # The reference's launch lines work as they are (/root/reference/examples/ctr/run_hetu.py:546-586, run_laia.py):
+    #   python run_wdl.py --model wdl_criteo --comm Hybrid --cache lru --bound 3 --bsp 0 -b 256 -e 512 -r 0.1 --cache-perf
+    # --comm / --cache choose the embedding engine unless --embedding names one (this build's own engines: the HBM-resident
+    # table with one launch per step, "queue" = the work-queue step with lookahead, ...).
     ap = argparse.ArgumentParser()
-    ap.add_argument("--embedding", choices=["hbm", "step", "step3", "queue", "ps", "cache"], default="hbm")
-    ap.add_argument("--cache", choices=["LRU", "LFU", "LFUOpt"], default="LRU")
-    ap.add_argument("--bound", type=int, default=100)
+    ap.add_argument("--model", default="wdl", help="wdl_criteo | dcn_criteo (the reference's names) or wdl | dcn")
+    ap.add_argument("-b", "--batch-size", "--batch", dest="batch", type=int, default=256)
+    ap.add_argument("-e", "--embedding-size", "--width", dest="width", type=int, default=128)
+    ap.add_argument("-r", "--cache-limit-ratio", type=float, default=0.1,
+                    help="ratio of cache limit to total embedding sizes")
+    ap.add_argument("--cache-perf", action="store_true",
+                    help="record the cache's per-call counters and stage times; csv/hetu_cache<idx>_<rank>.csv after training")
+    ap.add_argument("--val", action="store_true", help="accepted for the reference's launch lines (the data is synthetic)")
+    ap.add_argument("--all", action="store_true", help="accepted for the reference's launch lines (the data is synthetic)")
+    ap.add_argument("--comm", default=None, help="None, PS or Hybrid (sparse pull / push over the row-range sharded table)")
+    ap.add_argument("--bsp", type=int, default=-1, help="bsp 0, asp -1, ssp > 0")
+    ap.add_argument("--cache", default=None, help="cache policy: lru | lfu | lfuopt (with --comm PS / Hybrid)")
+    ap.add_argument("--bound", type=int, default=100, help="cache bound")
+    ap.add_argument("--nepoch", type=int, default=-1, help="epochs of `--steps` steps each (default: one)")
+    ap.add_argument("--embedding", choices=["hbm", "step", "step3", "queue", "ps", "cache"], default=None,
+                    help="this build's engine names; default: from --comm / --cache")
     ap.add_argument("--rows", type=int, default=33762577)
-    ap.add_argument("--width", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--lr", type=float, default=0.1)
-    ap.add_argument("--model", choices=["wdl", "dcn"], default="wdl")
     ap.add_argument("--laia", action="store_true", help="the laia-scheduled loop of run_laia.py (cache over the sharded table)")
     ap.add_argument("--local-shared", action="store_true", help="--laia with the TopkScheduler + shared-memory rings")
     args = ap.parse_args()
+    model = args.model.split("_")[0]
+    if model not in ("wdl", "dcn"):
+        ap.error("--model must be wdl_criteo, dcn_criteo, wdl or dcn")
+    args.model = model
+    comm = None if args.comm in (None, "None") else args.comm
+    if comm not in (None, "PS", "Hybrid"):
+        ap.error("--comm must be None, PS or Hybrid (dense AllReduce-only runs have no sparse path to replace)")
+    policy = {"lru": "LRU", "lfu": "LFU", "lfuopt": "LFUOpt"}.get((args.cache or "lru").lower())
+    if policy is None:
+        ap.error("--cache must be lru, lfu or lfuopt")
+    if args.embedding is None:
+        args.embedding = "hbm" if comm is None else ("cache" if args.cache else "ps")
+    args.cache = policy
+    if args.nepoch > 0:
+        args.steps *= args.nepoch
+    cache_limit = max(int(args.cache_limit_ratio * args.rows), args.batch * NFIELD)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -343,7 +401,9 @@ def main():
                             log_every=max(1, args.steps // 10))[0]
     else:
         losses = train(args.embedding, args.rows, args.width, args.batch, args.steps, args.lr, args.cache,
-                       args.bound, device="cuda:%d" % local_rank, log_every=max(1, args.steps // 10), model=args.model)[0]
+                       args.bound, cache_limit=cache_limit, device="cuda:%d" % local_rank,
+                       log_every=max(1, args.steps // 10), model=args.model, bsp=args.bsp if comm is not None else 0,
+                       cache_perf=args.cache_perf)[0]
     if local_rank == 0:
         print("first 10 steps: loss %.5f   last 10 steps: loss %.5f" % (np.mean(losses[:10]), np.mean(losses[-10:])))
 

@@ -103,17 +103,24 @@ class LaiaScheduler:
                                              cap, off.ctypes.data)
 
     def _emit(self, plan, dist, off, mini_bs, rank):
-        self._q.put(plan[off[rank]:off[rank + 1]].tolist())        # Python ints, as the reference's pybind lists
-        self._q.put(dist[rank * mini_bs:(rank + 1) * mini_bs].tolist())
+        # (arrays, copied out of the buffers the next call overwrites: turning ~20,000 keys into Python ints took the
+        # scheduler thread as long as computing them -- `pop` does it for callers that want the reference's lists)
+        self._q.put(plan[off[rank]:off[rank + 1]].copy())
+        self._q.put(dist[rank * mini_bs:(rank + 1) * mini_bs].copy())
 
     def _finish(self):
-        self._q.put([0])
+        self._q.put(np.zeros(1, dtype=np.int64))
 
-    def pop(self):
+    def pop_arrays(self):
+        """`pop` without the conversion: the plan as a uint64 array, the dist as an int64 array, the terminator as [0]."""
         item = self._q.get()
         if self._error is not None:
             raise self._error
         return item
+
+    def pop(self):
+        """Blocking; a list of Python ints, as the reference's pybind binding returns (laia/src/python_binding.cc:8-23)."""
+        return self.pop_arrays().tolist()
 
     def length(self):
         return self._q.qsize()
@@ -188,11 +195,14 @@ class _Ring:
 
     def recv(self):
         """Blocks until a message is there (pop_from_local_worker, topk_scheduler.cc:236-260)."""
+        return self.recv_array().tolist()
+
+    def recv_array(self):
         need = ctypes.c_int64(0)
         while True:
             n = self._L.ha_shm_ring_recv(self._h, self._buf.ctypes.data, self._buf.size, ctypes.byref(need))
             if n >= 0:
-                return self._buf[:n].tolist()
+                return self._buf[:n].copy()
             if n == -2:
                 self._buf = np.empty(int(need.value) + 16, dtype=np.uint64)
                 continue
@@ -252,12 +262,15 @@ class TopkScheduler(LaiaScheduler):
         for r in self._rings:                                                    # :350-353
             r.send([0], lambda: self._close)
 
-    def pop_from_local_worker(self):
+    def pop_from_local_worker_arrays(self):
         assert self._local_shared
-        item = self._my_ring.recv()
+        item = self._my_ring.recv_array()
         if self._error is not None:
             raise self._error
         return item
+
+    def pop_from_local_worker(self):
+        return self.pop_from_local_worker_arrays().tolist()
 
     def length(self):
         if not self._local_shared:                                               # :187-193
@@ -313,16 +326,16 @@ class _PlanDistStream:
         if self.closed:
             raise RuntimeError("the laia scheduler's stream has ended; nothing left to read")
         msg = self._pop()
-        if not isinstance(msg, list):
-            raise TypeError("laia scheduler returned %r, expected a list" % type(msg))
-        if msg == [0]:                    # terminator
+        if not isinstance(msg, (list, np.ndarray)):
+            raise TypeError("laia scheduler returned %r, expected a list or an array" % type(msg))
+        if len(msg) == 1 and int(msg[0]) == 0:     # terminator
             self.closed = True
-            return []
+            return msg[:0]
         return msg
 
     def pair(self):
         dist = self._take()
-        plan = [] if self.closed else self._take()
+        plan = dist[:0] if self.closed else self._take()
         return dist, plan
 
     def pair_ready(self):
@@ -353,7 +366,7 @@ class LAIAScheduler:
         if not self.local_shared:
             s = LaiaScheduler()
             s.start(*head, 16, 24, key_limit=key_limit)
-            return s, s.pop
+            return s, s.pop_arrays
         # one scheduler per node: local rank 0 computes and feeds the others' shared-memory rings, so it has to
         # be up before they open theirs (laia_dataloader.py:72-95)
         s = TopkScheduler()
@@ -361,7 +374,7 @@ class LAIAScheduler:
             time.sleep(3)
         s.start(*head, topk_num_threads(self.batch_size), self.dataset, int(top_k_table[self.dataset]), True,
                 int(local_rank), int(local_size), key_limit=key_limit)
-        return s, s.pop_from_local_worker
+        return s, s.pop_from_local_worker_arrays
 
     def start(self, nrank, rank, cache_limit, dataset_num=3, epoch_num=-1, key_limit=None, local_rank=0,
               local_size=local_worker_num):
@@ -389,10 +402,20 @@ class LAIAScheduler:
         return self._stream.closed
 
     def get_input_index(self, batch_id):
-        return self._window[batch_id][0]
+        """The samples of this worker in batch `batch_id`: a list, as the reference's (laia_dataloader.py:116-121)."""
+        d = self._window[batch_id][0]
+        return d.tolist() if isinstance(d, np.ndarray) else d
 
     def get_comm_plan(self, batch_id):
-        return self._window[batch_id][1]
+        p = self._window[batch_id][1]
+        return p.tolist() if isinstance(p, np.ndarray) else p
+
+    def get_input_index_array(self, batch_id):
+        """... as an integer array (what LAIADataloader indexes with: no Python ints in between)."""
+        return np.asarray(self._window[batch_id][0])
+
+    def get_comm_plan_array(self, batch_id):
+        return np.asarray(self._window[batch_id][1])
 
     def step_forward(self, dataset_id):
         self._cursor[dataset_id] += 1
@@ -452,10 +475,10 @@ class LAIADataloader:
         return self._raw_dev[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.device)]
 
     def _get_arr(self, batchind):
-        idx = self.sched.get_input_index(self.batch_index)
+        idx = self.sched.get_input_index_array(self.batch_index)
         if not self.is_sparse:
             return self._rows(idx)
-        plan = np.asarray(self.sched.get_comm_plan(self.batch_index), dtype=np.float32)
+        plan = self.sched.get_comm_plan_array(self.batch_index).astype(np.float32)
         if self._raw_dev is not None:
             import torch
             plan = torch.from_numpy(plan).to(self.device)
@@ -472,4 +495,4 @@ class LAIADataloader:
         return self._get_arr(self.batch_index)
 
     def get_cur_shape(self):
-        return tuple([len(self.sched.get_input_index(self.batch_index))] + list(self.raw_data.shape[1:]))
+        return tuple([len(self.sched.get_input_index_array(self.batch_index))] + list(self.raw_data.shape[1:]))

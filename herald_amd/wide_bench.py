@@ -8,6 +8,26 @@ import torch
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(batch, width):
+    """HBM bytes per ha::qapply_kernel launch at this shape from the newest committed PMC summary (profiles/rNN/
+    pmc_traffic_wide_bs<batch>_d<width>.json: separate rocprofv3 --pmc passes over tools/shape_bench.py), or None."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*", "pmc_traffic_wide_bs%d_d%d.json" % (batch, width))),
+                    reverse=True):
+        try:
+            with open(f) as fh:
+                ks = json.load(fh)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, v in ks.items():
+            if name.startswith("ha::qapply_kernel"):
+                return v["hbm_bytes_per_launch"], os.path.relpath(f, root)
+    return None, None
+
+
 def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags", distinct=32, lr=1e-6, alone=False):
     from . import ops, synth
     dev = table.device
@@ -60,6 +80,7 @@ def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags
         alone_us = e0.elapsed_time(e1) * 1e3 / reps
     alg = n * (12 * width + 8) + u_mean * 8 * width
     hdr = pipe.queue_header(warm + steps - 1)
+    traffic, traffic_src = pmc_traffic(batch, width)
     return {"workload": "wdl_criteo bs=%d d=%d on ONE GPU, %d ids per step, full %d-row table; work-queue step, wide path "
                         "(%d hash buckets per batch, no sort), blocks of %d steps prepared on a side stream inside the timed "
                         "region" % (batch, width, n, rows, pipe.plans[0].buckets if pipe.wide else 1, block),
@@ -67,5 +88,8 @@ def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags
             "numerics": "tolerance>=16", "stream_sync": pipe.sync,
             "roofline": {"bound": "hbm", "kernel": "ha::qapply_kernel (launch-to-launch period, preparation beside it)",
                          "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / us / 1e3 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg},
+                         "frac": alg / us / 1e3 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # the same period priced on the bytes the counters saw (2 x FETCH_SIZE + WRITE_SIZE per launch)
+                         "frac_by_traffic": (traffic / us / 1e3 / HBM_PEAK_GBS) if traffic else None,
+                         "algorithmic_bytes_per_launch": alg},
             "queue_items": hdr, "apply_alone_us": alone_us}

@@ -237,3 +237,27 @@ def _laia_example_worker(rank, world, port, model, local_shared):
 def test_laia_example_world2_on_one_gpu(dev, model, local_shared):
     import torch.multiprocessing as mp
     mp.spawn(_laia_example_worker, args=(2, _free_port(), model, local_shared), nprocs=2, join=True)
+
+
+def test_reference_launch_line_and_cache_perf_csv(dev, tmp_path):
+    """The reference's own launch vocabulary (/root/reference/examples/ctr/run_hetu.py:546-586: --model wdl_criteo --comm Hybrid
+    --cache lru --bound --bsp -b -e -r --cache-perf --val --all) drives run_wdl.py as it is, and --cache-perf leaves the CSV
+    run_hetu.py:508-515 writes: csv/hetu_cache<idx>_<rank>.csv, one row per cache call with the perf dict's columns."""
+    import csv
+    import subprocess
+    script = os.path.join(ROOT, "examples", "ctr", "run_wdl.py")
+    out = os.path.join(ROOT, "examples", "ctr", "csv", "hetu_cache0_0.csv")
+    if os.path.exists(out):
+        os.remove(out)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, script, "--model", "wdl_criteo", "--comm", "Hybrid", "--cache", "lru", "--bound", "3",
+                        "--bsp", "0", "-b", "64", "-e", "32", "-r", "0.1", "--cache-perf", "--val", "--all",
+                        "--rows", "100000", "--steps", "12"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "last 10 steps: loss" in r.stdout
+    with open(out) as fh:
+        rows = list(csv.DictReader(fh))
+    assert len(rows) >= 12
+    for col in ("num_all", "num_unique", "num_miss", "num_evict", "num_transfered", "type"):
+        assert col in rows[0], (col, list(rows[0]))
+    os.remove(out)

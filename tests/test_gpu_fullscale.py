@@ -277,6 +277,109 @@ def test_queue_step_on_the_full_table(dev, big_table, overlap, block, count, syn
     _restore(table, keys_all, dev)
 
 
+def _fill_formula(t, width, dev):
+    """formula.table(rows, width) on the device, as the big_table fixture does it."""
+    rows = t.shape[0]
+    c = torch.arange(width, dtype=torch.int64, device=dev)[None, :] * 40503
+    step = 1 << 20
+    for s in range(0, rows, step):
+        e = min(rows, s + step)
+        r = torch.arange(s, e, dtype=torch.int64, device=dev)[:, None] * 2654435761
+        v = ((r + c) % 2000003).to(torch.float32)
+        v = v * np.float32(1e-4)
+        t[s:e] = v - np.float32(100.0)
+
+
+@pytest.mark.parametrize("bs,width", [(1024, 512), (4096, 128)], ids=["configs3_26624ids_d512", "configs2_106496ids_d128"])
+def test_wide_queue_step_at_the_bench_shapes(dev, big_table, bs, width):
+    """THE WIDE PATH AT THE SHAPES bench.py TIMES IT AT (`wide_bs1024_d512`, `wide_bs4096_d128`): batches of 26,624 ids on the
+    33,762,577 x 512 table and of 106,496 ids on a 33,762,577 x 128 table (17.3 GB) -- chunked workgroup items x multi-slice rows
+    (a key with thousands of occurrences, every 64-column slice of its row), row offsets beyond 4 GiB and 64 GiB, float32 ids
+    beyond 2^24 --, six Criteo batches in blocks of four (the stream crosses a block boundary), the two streams ordered by
+    epoch tags (sync="flags", as the bench drives it).  The touched rows start from N(0, 0.01) values (the reference's
+    init.random_normal(stddev=0.01), wdl_criteo.py:13), so the tolerance classes are held against 1e-5 x lr x sum|g| WITHOUT
+    a |row| ~ 100 term beside it.  Every lookup row of every step and the touched rows at the end
+      * bit for bit against oracle/qstep_model.py (the kernel's floating-point order, chunk sums included), and
+      * against the reference's serial chain (oracle/cpu.py = the compiled cpu_SGDOptimizerSparseUpdate,
+        /root/reference/src/dnnl_ops/Optimizers.cpp:51-74; lookups /root/reference/src/dnnl_ops/EmbeddingLookup.cpp:16-35): rows
+        whose key never had 16+ occurrences in a batch bit-exact, the others within 1e-5 x (lr x sum|g| + |row|);
+    the plans bucket by bucket against np.unique (cpu_deduplicate's contract, /root/reference/python/hetu/ndarray.py:556-576)."""
+    from test_gpu_qstep import _check_wide_plan
+    REL = 1e-5
+    steps, block, lr = 6, 4, 0.01
+    if width == WIDTH:
+        table = big_table
+    else:
+        table = torch.empty((ROWS, width), dtype=torch.float32, device=dev)
+        _fill_formula(table, width, dev)
+    batches = []
+    for b in range(steps):
+        f = synth.as_f32_ids(synth.criteo_batch(bs, step=700 + b, rows=ROWS, nfields=FIELDS)).reshape(-1)
+        np.minimum(f, np.float32(ROWS - 1), out=f)
+        batches.append(f)
+    n = batches[0].size
+    assert n == bs * FIELDS and n > ops.qstep_max_ids()
+    keys = [cpu.ids_to_keys(f).astype(np.int64) for f in batches]
+    keys_all = np.unique(np.concatenate(keys))
+    assert keys_all.max() > (1 << 24) and keys_all.max() * width * 4 > ((64 << 30) if width == 512 else (16 << 30))
+    assert (keys_all * width * 4 > (4 << 30)).sum() > 1000
+    rng = np.random.default_rng(bs + width)
+    start_rows = (rng.standard_normal((keys_all.size, width), dtype=np.float32) * np.float32(0.01))
+    d_keys = torch.from_numpy(keys_all).to(dev)
+    table[d_keys] = torch.from_numpy(start_rows).to(dev)
+    model_t, exact_t = start_rows.copy(), start_rows.copy()
+    cids = [np.searchsorted(keys_all, k) for k in keys]
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
+    drift = np.zeros((keys_all.size, width), np.float64)
+    pipe = ops.QueueStepPipeline(table, n, lr, overlap=True, block=block, sync="flags")
+    assert pipe.wide
+    d_ids = [torch.from_numpy(f).to(dev) for f in batches]
+    out = pipe.start(d_ids[:pipe.LOOKAHEAD])
+    chunked = 0
+    for b in range(steps):
+        torch.cuda.synchronize()
+        ci = cids[b]
+        got = out.cpu().numpy().reshape(-1, width)
+        np.testing.assert_array_equal(got, model_t[ci], err_msg="rows of batch %d (kernel order)" % b)
+        d = np.abs(got.astype(np.float64) - exact_t[ci].astype(np.float64))
+        assert (d <= drift[ci] + REL * np.abs(exact_t[ci])).all(), "rows of batch %d vs the serial chain" % b
+        loose = drift[ci].any(axis=1)
+        np.testing.assert_array_equal(got[~loose], exact_t[ci][~loose], err_msg="rows of batch %d without a long run: bit-exact" % b)
+        qstep_model.sgd_sparse_update(model_t, ci, grads[b], lr)
+        cpu.sgd_sparse_update(exact_t, ci.astype(np.float32), grads[b], lr)
+        cnt = np.bincount(ci, minlength=keys_all.size)
+        chunked += int((cnt > qstep_model.CHUNK).sum())
+        sumabs = np.zeros((keys_all.size, width), np.float64)
+        np.add.at(sumabs, ci, np.abs(grads[b]).astype(np.float64))
+        drift += np.where((cnt >= qstep_model.LONG_MIN)[:, None], REL * lr * sumabs, 0.0)
+        out = pipe.step(torch.from_numpy(grads[b]).to(dev), None)
+        torch.cuda.synchronize()
+        assert not pipe.overflowed() and pipe.fallbacks == 0
+        _check_wide_plan(pipe.plan_of(b), keys[b], "plan of batch %d" % b)
+    assert out is None
+    if bs == 4096:
+        assert chunked > 0          # keys with more than 256 occurrences: chunk sums x every slice of a 128-column row
+    got_t = table[d_keys].cpu().numpy()
+    np.testing.assert_array_equal(got_t, model_t, err_msg="touched rows (kernel order)")
+    loose = drift.any(axis=1)
+    assert loose.any() and not loose.all()
+    np.testing.assert_array_equal(got_t[~loose], exact_t[~loose], err_msg="touched rows without a long run: the serial chain")
+    d = np.abs(got_t.astype(np.float64) - exact_t.astype(np.float64))
+    assert (d <= drift + REL * np.abs(exact_t)).all()
+    worst = float((d[loose] / (drift[loose] / REL + np.abs(exact_t[loose]))).max())
+    print("wide queue step, bs %d d %d: %d tolerance-class rows, max |tree - chain| / (lr * sum|g| + |row|) = %.3g (bound %.0e; "
+          "rows ~1e-2, so the |row| term is negligible)" % (bs, width, int(loose.sum()), worst, REL))
+    sents = [k for k in SENTINELS if k not in set(keys_all.tolist())]
+    sent = table[torch.tensor(sents, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(sent, formula.rows_of(sents, width), err_msg="untouched sentinel rows")
+    del pipe
+    if width == WIDTH:
+        _restore(table, keys_all, dev)
+    else:
+        del table
+        torch.cuda.empty_cache()
+
+
 class _LazyRows:
     """Server table of the cache model holding only the rows that were written; the rest is the closed form."""
 
