@@ -339,10 +339,17 @@ def laia_scheduler(args):
     need = W * mini_bs * batch_num + 1000
     parts = [synth.criteo_batch(per, step=5000 + s, rows=args.rows, nfields=T) for s in range((need + per - 1) // per)]
     samples = np.concatenate(parts, axis=0)[:need].astype(np.uint64)
-    s = hlaia.LaiaScheduler()
     ahead = os.environ.get("HA_LAIA_AHEAD", "1") == "1"
-    s.start(samples, samples.shape[0], T, 1, mini_bs, batch_num, W, 0, int(0.1 * args.rows), 16, 24, key_limit=args.rows,
-            ahead=ahead)
+    plug = hlaia.native_plugin() if os.environ.get("HA_LAIA_PYTHON_THREAD") != "1" else None
+    if plug is not None:
+        # the reference's surface: the pybind11 module `laia_cache`, its scheduler loop in a C++ thread (launch(),
+        # laia_scheduler.cc:115-169)
+        s = plug.LaiaScheduler()
+        s.start(samples, samples.shape[0], T, 1, mini_bs, batch_num, W, 0, int(0.1 * args.rows), 16, 24)
+    else:
+        s = hlaia.LaiaScheduler()
+        s.start(samples, samples.shape[0], T, 1, mini_bs, batch_num, W, 0, int(0.1 * args.rows), 16, 24, key_limit=args.rows,
+                ahead=ahead)
     while True:
         item = s.pop_arrays()
         if len(item) == 1 and int(item[0]) == 0:
@@ -356,6 +363,7 @@ def laia_scheduler(args):
             "global_batch_samples": W * mini_bs, "workers": W,
             "thread_wall_us_per_global_batch": tm["thread_wall_us_per_batch"], "one_batch_ahead": ahead,
             "hand_off": "arrays (pop_arrays); pop() converts to the reference's Python lists in the caller's thread",
+            "scheduler_thread": "C++ thread of the laia_cache plugin" if plug is not None else "Python thread (herald_amd.laia)",
             "tables": T, "cache_size": int(0.1 * args.rows), "batches": tm["batches"],
             "host_assign_us": tm["host_assign_us"], "host_snapshot_us": tm["host_snapshot_us"],
             "gpu_and_transfer_us": tm["gpu_and_transfer_us"],

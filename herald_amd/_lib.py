@@ -119,6 +119,8 @@ def _declare(L):
     L.ha_qbig_max_ids.argtypes = []
     L.ha_qapply_span_max.restype = i64
     L.ha_qapply_span_max.argtypes = []
+    L.ha_xchg_create.restype = vp
+    L.ha_xchg_create.argtypes = [vp, c.c_int, c.c_int]
     L.ha_qbig_plan_bytes.restype = sz
     L.ha_qbig_plan_bytes.argtypes = [i64]
     L.ha_qbig_buckets.restype = c.c_int
@@ -183,6 +185,11 @@ def _declare(L):
         "ha_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_debug_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qqueue_batch_span": [i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
+        "ha_xchg_available": [],
+        "ha_xchg_unique_id": [vp],
+        "ha_xchg_destroy": [vp],
+        "ha_xchg_bytes": [vp, vp, vp, vp, vp, vp],
+        "ha_xchg_rows": [vp, vp, vp, vp, vp, i64, vp],
         "ha_qapply_gated_steps": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64],
         "ha_debug_qapply_gated": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp, i64, vp, vp, vp],
         "ha_qbig_plan_view": [vp, i64, vp, vp, vp, vp, vp, vp, vp],

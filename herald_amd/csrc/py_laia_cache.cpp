@@ -14,6 +14,8 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
+#include <cstring>
+#include <chrono>
 #include <queue>
 #include <stdexcept>
 #include <thread>
@@ -73,6 +75,38 @@ public:
         }
         return v;
     }
+    // pop() without the per-element conversion: the message as a uint64 array (the plan's keys / the dist's sample indices;
+    // the terminator is [0]).  What herald_amd.laia's data loader glue reads.
+    py::array_t<uint64_t> pop_arrays() {
+        std::vector<uint64_t> v = pop();
+        py::array_t<uint64_t> a(static_cast<py::ssize_t>(v.size()));
+        if (!v.empty())
+            std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(uint64_t));
+        return a;
+    }
+    // {"batches", "us_per_batch" (inside the library call), "thread_wall_us_per_batch" (the scheduler thread's whole loop)}
+    py::dict timing() {
+        double t[4] = {0, 0, 0, 0};
+        if (h_)
+            (void)ha_laia_timing(h_, t);
+        const double calls = t[0] > 0 ? t[0] : 1.0;
+        py::dict d;
+        d["batches"] = static_cast<long long>(t[0]);
+        d["us_per_batch"] = t[1] / calls;
+        d["host_assign_us"] = t[2] / calls;
+        d["host_snapshot_us"] = t[3] / calls;
+        d["gpu_and_transfer_us"] = (t[1] - t[2] - t[3]) / calls;
+        const long long done = done_.load();
+        d["thread_wall_us_per_batch"] = done > 0 ? wall_us_.load() / static_cast<double>(done) : 0.0;
+        return d;
+    }
+    // stops the scheduler thread (the destructor does the same)
+    void close() {
+        close_ = true;
+        py::gil_scoped_release release;
+        if (thread_.joinable())
+            thread_.join();
+    }
     size_t length() {
         if (local_shared_)
             return (size_t)ha_shm_ring_pending_words(my_ring_);
@@ -115,8 +149,9 @@ protected:
         const size_t cap = W * mini_bs_ * num_table_ * (W > 1 ? W - 1 : 1) + 16;
         std::vector<uint64_t> plan(cap);
         size_t epoch_id = 0, batch_num = batch_num_;
-        const char *ah = getenv("HA_LAIA_AHEAD");       // one batch ahead (ha_laia_hint_next), as herald_amd.laia's loop
-        const bool ahead_ = ah != nullptr && ah[0] == '1';
+        const char *ah = getenv("HA_LAIA_AHEAD");       // one batch ahead (ha_laia_hint_next) unless HA_LAIA_AHEAD=0
+        const bool ahead_ = !(ah != nullptr && ah[0] == '0');
+        const auto t_start = std::chrono::steady_clock::now();
         while (epoch_id < epoch_num_ && !close_) {
             size_t batch_id = 0;
             ++epoch_id;
@@ -126,12 +161,14 @@ protected:
                 if (ahead_)     // the batch of the NEXT call: the following one, the first of the next epoch, or none
                     (void)ha_laia_hint_next(h_, batch_id + 1 < batch_num ? (int64_t)(batch_id + 1)
                                                                        : (epoch_id < epoch_num_ ? 0 : -1));
+                // (standalone LaiaScheduler: only this rank's plan is queued, laia_scheduler.cc:140-168 -- with the state on the
+                // device only its rows come back)
                 const int rc = topk_
                     ? ha_laia_next_topk(h_, (int64_t)batch_id, (int64_t)mini_bs_, order_.data(),
                                         (int64_t)order_.size(), (int64_t)num_threads_, dist.data(), plan.data(),
                                         (int64_t)cap, off.data())
-                    : ha_laia_next(h_, (int64_t)batch_id, (int64_t)mini_bs_, dist.data(), plan.data(),
-                                   (int64_t)cap, off.data());
+                    : ha_laia_next_for_rank(h_, (int64_t)batch_id, (int64_t)mini_bs_, (int64_t)rank_, dist.data(), plan.data(),
+                                            (int64_t)cap, off.data());
                 if (rc != 0) {
                     error_ = std::string("ha_laia_next: ") + ha_last_error();
                     finish();
@@ -155,6 +192,8 @@ protected:
                     }
                 }
                 ++batch_id;
+                done_.fetch_add(1);
+                wall_us_.store(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count());
             }
         }
         finish();
@@ -185,6 +224,8 @@ protected:
     size_t epoch_num_ = 0, mini_bs_ = 0, batch_num_ = 0, nrank_ = 0, rank_ = 0, num_table_ = 0;
     std::thread thread_;
     std::atomic<bool> close_{false};
+    std::atomic<long long> done_{0};
+    std::atomic<double> wall_us_{0.0};
     std::mutex mu_;
     std::condition_variable cv_;
     std::queue<std::vector<uint64_t>> q_;
@@ -255,11 +296,24 @@ PYBIND11_MODULE(laia_cache, m) {
         .def(py::init<>())
         .def("start", &LaiaScheduler::start)
         .def("pop", &LaiaScheduler::pop)
+        .def("pop_arrays", &LaiaScheduler::pop_arrays)
+        .def("timing", &LaiaScheduler::timing)
+        .def("close", &LaiaScheduler::close)
         .def("length", &LaiaScheduler::length);
     py::class_<TopkScheduler>(m, "TopkScheduler")
         .def(py::init<>())
         .def("start", &TopkScheduler::start)
         .def("pop", &TopkScheduler::pop)
+        .def("pop_arrays", &TopkScheduler::pop_arrays)
+        .def("timing", &TopkScheduler::timing)
+        .def("close", &TopkScheduler::close)
         .def("pop_from_local_worker", &TopkScheduler::pop_from_local_worker)
+        .def("pop_from_local_worker_arrays", [](TopkScheduler &s) {
+            std::vector<uint64_t> v = s.pop_from_local_worker();
+            py::array_t<uint64_t> a(static_cast<py::ssize_t>(v.size()));
+            if (!v.empty())
+                std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(uint64_t));
+            return a;
+        })
         .def("length", &TopkScheduler::length);
 }

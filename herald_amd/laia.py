@@ -19,6 +19,7 @@ the GPU, assignment and snapshot bookkeeping on the scheduler's own host thread 
 reference, the scheduler runs ahead of training in a background thread.
 """
 import ctypes
+import os
 import queue
 import threading
 import time
@@ -301,6 +302,23 @@ class TopkScheduler(LaiaScheduler):
         self._rings = []
 
 
+def native_plugin():
+    """The pybind11 module `laia_cache` (csrc/py_laia_cache.cpp: the reference's plugin surface, laia/src/python_binding.cc:8-23,
+    with the scheduler loop in a C++ thread of its own, as the reference's launch()) if it has been built, else None --
+    the classes above run the same loop in a Python thread."""
+    import importlib
+    import os
+    import sys
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plugins")
+    try:
+        import torch  # noqa: F401  (one HIP runtime for torch and the plugin)
+        if d not in sys.path:
+            sys.path.insert(0, d)
+        return importlib.import_module("laia_cache")
+    except Exception:      # noqa: BLE001 -- not built / not loadable: the Python classes serve
+        return None
+
+
 def topk_num_threads(mini_batch_size, wanted=80):
     """The reference starts TopkScheduler with 80 pool threads (laia_dataloader.py:85); its per-thread
     quotas only add up when the thread count divides the mini batch (otherwise it writes dist[-1]),
@@ -363,7 +381,13 @@ class LAIAScheduler:
         data = self.sparse_data
         head = (data, data.shape[0], data.shape[1], epoch_num, self.batch_size, self.batch_num, int(nrank), int(rank),
                 int(cache_limit))
+        plug = native_plugin() if os.environ.get("HA_LAIA_PYTHON_THREAD") != "1" else None
         if not self.local_shared:
+            if plug is not None and key_limit is None:
+                # the scheduler loop in the plugin's C++ thread: no interpreter between two global batches
+                s = plug.LaiaScheduler()
+                s.start(np.ascontiguousarray(data, dtype=np.uint64), *head[1:], 16, 24)
+                return s, s.pop_arrays
             s = LaiaScheduler()
             s.start(*head, 16, 24, key_limit=key_limit)
             return s, s.pop_arrays

@@ -520,6 +520,95 @@ class Route:
         self.released = False
 
 
+class NativeExchange:
+    """The all-to-all of a store's keys and rows as RCCL point-to-point calls made by the LIBRARY on the caller's stream
+    (ha_xchg_*, csrc/xchg.hip): what torch.distributed.all_to_all_single does -- a group of ncclSend / ncclRecv, one pair
+    per peer with a non-zero count -- without the Python call, the split-size lists and c10d's own stream with its event
+    hop there and back.  The communicator is the library's own: rank 0 of `group` makes the unique id, torch.distributed
+    carries it over.  `create` returns None where no RCCL can be resolved, the group's backend is not nccl, or the new
+    exchange does not reproduce torch's result on a first pattern (checked on every rank, agreed by an all-reduce)."""
+
+    @classmethod
+    def create(cls, group, device):
+        import os
+        if os.environ.get("HA_NATIVE_XCHG") == "0" or not dist.is_initialized():
+            return None
+        try:
+            if dist.get_backend(group) != "nccl":
+                return None
+            from . import _lib
+            L = _lib.load()
+            if not L.ha_xchg_available():
+                return None
+            x = cls(L, group, device)
+        except Exception:      # noqa: BLE001 -- anything at all: torch's exchange serves
+            return None
+        ok = torch.tensor([1 if x._self_check() else 0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            x.close()
+            return None
+        return x
+
+    def __init__(self, L, group, device):
+        self.L, self.group, self.device = L, group, torch.device(device)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            if L.ha_xchg_unique_id(ctypes.c_void_p(uid.data_ptr())) != 0:
+                raise RuntimeError(L.ha_last_error().decode())
+        uid = uid.to(self.device)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(uid, src=src, group=group)
+        uid = uid.cpu()
+        with torch.cuda.device(self.device):
+            self.h = L.ha_xchg_create(ctypes.c_void_p(uid.data_ptr()), self.world, self.rank)
+        if not self.h:
+            raise RuntimeError(L.ha_last_error().decode())
+        self._i64 = ctypes.c_int64 * self.world
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ha_xchg_destroy(ctypes.c_void_p(self.h))
+            self.h = None
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        """torch.distributed.all_to_all_single(out, inp, out_splits, in_splits) on the current stream: splits in rows of
+        dim 0 (None: equal parts)."""
+        w = self.world
+        row_in = inp.element_size() * (inp.numel() // inp.shape[0] if inp.shape[0] else 0)
+        row_out = out.element_size() * (out.numel() // out.shape[0] if out.shape[0] else 0)
+        if in_splits is None:
+            in_splits = [inp.shape[0] // w] * w
+        if out_splits is None:
+            out_splits = [out.shape[0] // w] * w
+        sb = self._i64(*[int(c) * row_in for c in in_splits])
+        rb = self._i64(*[int(c) * row_out for c in out_splits])
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if self.L.ha_xchg_bytes(ctypes.c_void_p(self.h), ctypes.c_void_p(inp.data_ptr()), sb, ctypes.c_void_p(out.data_ptr()),
+                                rb, ctypes.c_void_p(s)) != 0:
+            raise RuntimeError("ha_xchg_bytes: " + self.L.ha_last_error().decode())
+        return out
+
+    def _self_check(self):
+        """A small exchange with a different row count for every (sender, receiver) pair, through this object and through
+        torch.distributed: equal on this rank?"""
+        try:
+            w, r, width = self.world, self.rank, 8
+            ins = [0 if g == r else 1 + (r + 2 * g) % 3 for g in range(w)]
+            outs = [0 if g == r else 1 + (g + 2 * r) % 3 for g in range(w)]
+            inp = torch.cat([torch.full((c, width), float(100 * r + g), device=self.device) for g, c in enumerate(ins)] +
+                            [torch.zeros((0, width), device=self.device)])
+            want = torch.empty((sum(outs), width), device=self.device)
+            got = torch.full((sum(outs), width), -1.0, device=self.device)
+            dist.all_to_all_single(want, inp, outs, ins, group=self.group)
+            self.all_to_all(got, inp, outs, ins)
+            torch.cuda.synchronize(self.device)
+            return bool(torch.equal(got, want))
+        except Exception:      # noqa: BLE001
+            return False
+
+
 class ShardedEmbedding:
     """One row-range shard per rank + all-to-all pull/push.  `table` is this rank's shard.
 
@@ -563,6 +652,13 @@ class ShardedEmbedding:
         if self.world > 1 and side_group:
             ranks = None if group is None else dist.get_process_group_ranks(group)
             self.side_group = dist.new_group(ranks=ranks)
+        # the exchanges as RCCL calls made by the library (csrc/xchg.hip) where that is possible and reproduces torch's
+        # exchange; one communicator per process group in use (the routing's exchanges run on another stream)
+        self.native = self.native_side = None
+        if self.world > 1 and a2a is None:
+            self.native = NativeExchange.create(group, self.device)
+            if self.native is not None and self.side_group is not None:
+                self.native_side = NativeExchange.create(self.side_group, self.device)
 
     # -- exchange plumbing ---------------------------------------------------------------------------
     def _a2a(self, out, inp, out_splits, in_splits, group=None):
@@ -570,6 +666,10 @@ class ShardedEmbedding:
             out.copy_(inp)
         elif self._a2a_fn is not None:
             self._a2a_fn(out, inp, out_splits, in_splits, group if group is not None else self.group)
+        elif self.native is not None and (group is None or group is self.group):
+            self.native.all_to_all(out, inp, out_splits, in_splits)
+        elif self.native_side is not None and group is self.side_group:
+            self.native_side.all_to_all(out, inp, out_splits, in_splits)
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=group if group is not None else self.group)
         return out

@@ -186,6 +186,9 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
                       "timed steps took the sized exchange" % (fs.rcap, fs.block, "hipGraph replay" if fs.graphs else
                                                                "plain launches, no host read-back", fs.fallbacks - fb0, steps)))
                     if framed else "sized per step (host read-back of the counts)",
+        "collectives": ("RCCL send / recv groups issued by the library on the step's stream (ha_xchg_*, checked against "
+                        "torch.distributed's all-to-all at start-up)" if getattr(emb, "native", None) is not None else
+                        "torch.distributed.all_to_all_single" if dist.get_world_size() > 1 else "none (world size 1)"),
         # egress of the busiest GPU.  bytes_carried: everything handed to the all-to-alls (rows + key frames);
         # bytes_useful: the rows some batch names + the key words in use -- with sized exchanges every row carried is one
         # (fixed frames: null, the frames do not say how full they are).  frac is priced on what was CARRIED.
@@ -255,6 +258,7 @@ def run(args, rank, world, dev, cpu_baseline_fn=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": main["workload"], "ids_per_step_per_gpu": main["n"],
                        "parallelism": "row-sharded x%d" % world, "exchange": main["exchange"],
+                       "collectives": main["collectives"],
                        "sparse_update": main["sparse_update"]},
             "xgmi": main["xgmi"], "ranks_seen": dist.get_world_size(), "roofline": main["roofline"],
             # the N>1 engine at world size 1 on one shard (ms per step; null at N = 1, where this line IS that number):

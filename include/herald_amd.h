@@ -624,6 +624,23 @@ int ha_qapply_gated_steps(float *table, int64_t rows, int64_t width, float lr, i
 int ha_debug_qapply_gated(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                           void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, const void *queue_prev,
                           int64_t queue_n_cap, const uint32_t *counts, unsigned long long *dbg, ha_stream_t stream);
+/* The row / key exchange of the sharded sparse pull and push as RCCL point-to-point calls made by the LIBRARY on the caller's
+ * stream (the reference's worker sends and receives inside C++ too: PSAgent::vecPullSparse / vecPushSparse,
+ * ps-lite/include/ps/worker/PSAgent.h:124-237 -- U_s keys and U_s x d floats per server, ps/psf/sparse.h:9-32): one
+ * ncclGroupStart / ncclSend + ncclRecv per peer with a non-zero count / ncclGroupEnd -- no Python in the step, no second
+ * stream, capturable with the launches around it.  RCCL is resolved at run time (the copy the process has loaded, else
+ * /opt/rocm's): ha_xchg_available() = 0 where there is none.  ha_xchg_unique_id: rank 0 makes the 128-byte id, the caller
+ * carries it to the other ranks; ha_xchg_create: collective, one communicator per object, on the current device.  Counts are
+ * per peer, buffers hold the peers' parts back to back in rank order; this rank's own counts are normally 0. */
+int ha_xchg_available(void);
+int ha_xchg_unique_id(void *id128);
+void *ha_xchg_create(const void *id128, int world, int rank);
+int ha_xchg_destroy(void *xchg);
+int ha_xchg_bytes(void *xchg, const void *send, const int64_t *send_bytes, void *recv, const int64_t *recv_bytes,
+                  ha_stream_t stream);
+int ha_xchg_rows(void *xchg, const float *send, const int64_t *send_rows, float *recv, const int64_t *recv_rows, int64_t width,
+                 ha_stream_t stream);
+
 /* ha_qqueue_batch_epochs with, per step, the plan of the batch BEFORE the batch the step applies (plans_b / n_b; NULL, or
  * n_b[k] = 0: none). */
 int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, const int64_t *n_b, void *const *plans_a,
