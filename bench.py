@@ -858,6 +858,10 @@ def main():
         "step_algorithmic_bytes": fwd_b + bwd_b,
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,
         "device_ms": dev_ms, "enqueue_ms": t_enq * 1e3, "wall_ms": wall * 1e3,
+        # method_version 3 (rounds 4-5): behind the gate `ms_per_step` is the device's time over the region (HIP events);
+        # versions 1-2 (rounds 1-3) reported the larger of device and enqueue time.  That figure is kept beside it:
+        "method_version": 3,
+        "ms_per_step_incl_enqueue": max(dev_ms, t_enq * 1e3) / max(args.steps, 1),
         "timed_region": "exactly %d steps between two HIP events on the launch stream; %d of the %d warm-up steps run "
                         "right in front of it%s%s" % (args.steps, pre, wu, ", behind a gate the host opens once everything "
                                                       "is enqueued (the enqueue time of the steps, `enqueue_ms`, is therefore "

@@ -2045,7 +2045,9 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
         if (!ready) {
             if (SPAN) {
                 q_raise(d);      // every wait of the launch sees the abort word: nothing else is applied
-            } else if (a.err != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+            } else if (a.err != nullptr && threadIdx.x == 0) {
+                // ANY workgroup that gives up says so (another may have seen the tag just in time and applied its items:
+                // the step is then partially applied, and the host must hear of it -- QueueStepPipeline raises)
                 __hip_atomic_store(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
