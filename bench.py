@@ -275,6 +275,9 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
         torch.cuda.synchronize()
 
     use_ahead = os.environ.get("HA_CACHE_BENCH_AHEAD", "0") == "1"
+    # the ids of a block of 16 batches are known at its start (the lookahead the headline's work-queue step requires as
+    # well): their sorts are ONE launch at the head of the block (HA_CACHE_BENCH_BLOCK=0: every lookup sorts its own batch)
+    use_block = os.environ.get("HA_CACHE_BENCH_BLOCK", "1") == "1" and not use_ahead
 
     def step(k, ahead=True):
         c.embedding_lookup(ids_dev[k % nb], out)
@@ -288,12 +291,16 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
     side = torch.cuda.Stream(device=dev)
     c.cache.stream = side
     for k in range(64):
+        if use_block and k % GS == 0:
+            c.prefetch_keys_batch([ids_dev[j % nb] for j in range(k, k + GS)])
         step(k)
     torch.cuda.synchronize()
     graphs = []
     for g0 in range(0, nb, GS):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
+            if use_block:
+                c.prefetch_keys_batch([ids_dev[j % nb] for j in range(g0, g0 + GS)])
             for k in range(g0, g0 + GS):
                 step(k, ahead=k + 1 < g0 + GS)      # (a fork must join inside its graph)
         graphs.append(g)
@@ -323,8 +330,12 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
             "evicted_lines_per_step": evict, "cache_full": bool(pulls and pulls[-1]["is_full"]),
             "prefilled_keys": prefilled,
             "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
-                    "(5 launches per pair, the next batch's sort forked beside the update, replayed from hipGraphs of 16 pairs), cache filled to its limit before "
-                    "the timed pairs; not part of `value`"}
+                    "(%s, replayed from hipGraphs of 16 pairs), cache filled to its limit before "
+                    "the timed pairs; not part of `value`"
+                    % ("4 launches per pair + one launch per block of 16 batches that sorts their keys (the ids are known a "
+                       "block early, as for the headline's work-queue step)" if use_block else
+                       "5 launches per pair" + (", the next batch's sort forked beside the update" if use_ahead else "")),
+            "keys_sorted": "per block of 16 batches" if use_block else "per lookup"}
 
 
 def laia_scheduler(args):

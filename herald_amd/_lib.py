@@ -194,6 +194,8 @@ def _declare(L):
         "ha_debug_qapply_gated": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp, i64, vp, vp, vp],
         "ha_qbig_plan_view": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
         "ha_plan_build_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
+        "ha_plan_sort_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
+        "ha_plan_sort_batch_u64ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_plan_build_batch_u64ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_shard_frames_serve_pull": [vp, i64, i64, vp, c.c_int, i64, i64, vp, vp, vp, vp],
         "ha_shard_serve_push": [vp, i64, i64, vp, i64, vp, vp, vp],
@@ -255,6 +257,7 @@ def _declare(L):
         "ha_cache_lookup": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_sort_ahead": [vp, vp, c.c_int, i64, vp],
         "ha_cache_lookup_presorted": [vp, vp, c.c_int, i64, vp, vp],
+        "ha_cache_sort_ahead_batch": [vp, vp, c.c_int, vp, c.c_int, vp],
         "ha_cache_update": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_update_same_keys": [vp, i64, vp, vp],
         "ha_cache_update_with_push_keys": [vp, vp, c.c_int, i64, vp, c.c_int, i64, vp, vp],

@@ -109,6 +109,7 @@ class _CacheBase:
         self._perf = []
         self._last_lookup = None
         self._ahead = None
+        self._ahead_ring = []
         self._store = None
         self._remote = None
         self.stream = stream
@@ -378,6 +379,7 @@ class _CacheBase:
         the lookup then sorts by itself; raw-pointer writers are the caller's responsibility, as with same_as_lookup.
         Local stores only (a remote store's lookup is split around an exchange and sorts at its start)."""
         self._ahead = None
+        self._drop_ahead_ring()
         if self._remote is not None or not torch.is_tensor(keys) or keys.numel() == 0:
             return
         s = self._stream()
@@ -385,6 +387,32 @@ class _CacheBase:
         check(self._L.ha_cache_sort_ahead(self._h, ctypes.c_void_p(k.data_ptr()), kind, k.numel(),
                                           ctypes.c_void_p(s.cuda_stream)), "ha_cache_sort_ahead")
         self._ahead = _LookupMark(k)
+
+    def prefetch_keys_batch(self, keys_list):
+        """State that the device tensors of `keys_list` (at most 16, one dtype, 1 .. 36,864 keys each) are the batches of the
+        NEXT embedding_lookup calls, in this order: their sorts run now, in ONE launch on the cache's stream (a caller that has
+        its ids a block of batches early; no second stream, so the calls capture into a hipGraph without a fork).  Same
+        conditions on the tensors as prefetch_keys; a lookup of anything else drops what is left of the block."""
+        self._ahead = None
+        self._ahead_ring = []
+        if self._remote is not None or not keys_list:
+            return
+        s = self._stream()
+        ks = [self._keys(k, []) for k in keys_list]
+        kinds = {kind for _, kind in ks}
+        if len(kinds) != 1 or len(ks) > 16 or any(k.numel() == 0 for k, _ in ks):
+            raise ValueError("prefetch_keys_batch: 1-16 non-empty key tensors of one dtype")
+        ptrs = (ctypes.c_void_p * len(ks))(*[k.data_ptr() for k, _ in ks])
+        ns = (ctypes.c_int64 * len(ks))(*[k.numel() for k, _ in ks])
+        check(self._L.ha_cache_sort_ahead_batch(self._h, ptrs, kinds.pop(), ns, len(ks), ctypes.c_void_p(s.cuda_stream)),
+              "ha_cache_sort_ahead_batch")
+        self._ahead_ring = [_LookupMark(k) for k, _ in ks]
+
+    def _drop_ahead_ring(self):
+        if self._ahead_ring:
+            self._ahead_ring = []
+            check(self._L.ha_cache_sort_ahead_batch(self._h, None, 0, None, 0, ctypes.c_void_p(self._stream().cuda_stream)),
+                  "ha_cache_sort_ahead_batch")
 
     def embedding_lookup(self, keys, dest):
         """dest[i,:] = line(keys[i]).data after the staleness-bounded pull (cache.cc:60-107)."""
@@ -395,7 +423,13 @@ class _CacheBase:
         with torch.cuda.stream(s):
             k, kind = self._keys(keys, keep)
             lookup = self._L.ha_cache_lookup
-            if self._ahead is not None and _is_marked(self._ahead, k):
+            if self._ahead_ring:
+                if _is_marked(self._ahead_ring[0], k):
+                    lookup = self._L.ha_cache_lookup_presorted
+                    self._ahead_ring.pop(0)
+                else:           # not the batch that was announced: the rest of the block sorts by itself
+                    self._drop_ahead_ring()
+            elif self._ahead is not None and _is_marked(self._ahead, k):
                 lookup, self._ahead = self._L.ha_cache_lookup_presorted, None
             host_dest = None
             if isinstance(dest, np.ndarray):
@@ -667,6 +701,10 @@ class CacheSparseTable:
     def prefetch_keys(self, keys):
         """The next embedding_lookup's key batch, handed over a batch early (its sort overlaps the current batch)."""
         self.cache.prefetch_keys(keys)
+
+    def prefetch_keys_batch(self, keys_list):
+        """The key batches of the next (up to 16) embedding_lookup calls, in order: sorted in one launch now."""
+        self.cache.prefetch_keys_batch(keys_list)
 
     def embedding_update(self, keys, grads, sync=False, same_as_lookup=False):
         return self._finish(self.cache.embedding_update(keys, grads, same_as_lookup=same_as_lookup), sync)

@@ -1784,6 +1784,14 @@ struct ha_cache {
     const void *ahead_keys = nullptr;
     int64_t ahead_n = -1;
     int ahead_kind = -1;
+    // ha_cache_sort_ahead_batch: the sorts of the next kAheadRing lookups in ONE launch on the caller's stream, into a ring
+    // of plan workspaces the lookups take in order
+    static constexpr int kAheadRing = 16;
+    size_t plan_bytes = 0;
+    void *ring_ws[kAheadRing] = {};
+    const void *ring_keys[kAheadRing] = {};
+    int64_t ring_n[kAheadRing] = {};
+    int ring_kind = -1, ring_head = 0, ring_count = 0;
 };
 enum { kTStart = 0, kTSort = 1, kTLookup = 2, kTCopy = 3, kTTransfer = 4, kTEnd = 5 };
 static inline void cache_mark(ha_cache *h, int slot, hipStream_t s, bool first = false) {
@@ -1820,6 +1828,7 @@ extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
     c.pull_bound = 5;   // include/cache.h:27-28
     c.push_bound = 5;
     const size_t plan_bytes = ha_plan_bytes(max_batch);
+    h->plan_bytes = plan_bytes;
     bool ok = true;
 #define CACHE_ALLOC(field, count)                                                   \
     do {                                                                            \
@@ -2155,6 +2164,46 @@ extern "C" int ha_cache_sort_ahead(ha_cache *h, const void *keys, int key_kind, 
     return 0;
 }
 
+// The sorts of the next `count` (<= 16) lookups at once: ONE launch on the caller's stream (no second stream, no event edge --
+// inside a hipGraph of whole steps an edge costs more than the sort it hides), into a ring of plan workspaces.  The
+// ha_cache_lookup_presorted calls that follow must name these key buffers IN THIS ORDER (anything else there is an error);
+// plain ha_cache_lookup calls in between leave the ring alone.  A caller that has its ids a block of batches early -- the
+// work-queue step's requirement, INTEGRATION.md -- uses this; the reference's loader has them one batch early
+// (dataloader.py:63-98: ha_cache_sort_ahead).  The keys must not change until their lookups.  A call while sorted batches are
+// still unconsumed drops those.
+extern "C" int ha_cache_sort_ahead_batch(ha_cache *h, const void *const *keys, int key_kind, const int64_t *n, int count,
+                                         ha_stream_t stream) {
+    HA_REQUIRE(h && (key_kind == 0 || key_kind == 1) && count >= 0 && count <= ha_cache::kAheadRing &&
+               (count == 0 || (keys && n)), "cache_sort_ahead_batch: bad arguments (at most %d batches)", ha_cache::kAheadRing);
+    h->ring_count = 0;
+    h->ring_head = 0;
+    if (count == 0)
+        return 0;
+    for (int i = 0; i < count; ++i) {
+        HA_REQUIRE(n[i] > 0 && n[i] <= kSmallMax && n[i] <= h->c.nmax && keys[i] != nullptr,
+                   "cache_sort_ahead_batch: batch %d of %ld keys (1 .. min(max_batch, %d) per batch)", i, (long)n[i], kSmallMax);
+        if (h->ring_ws[i] == nullptr) {
+            char *p = nullptr;
+            HA_REQUIRE(dmalloc(&p, h->plan_bytes) == 0, "cache_sort_ahead_batch: out of device memory");
+            (void)hipMemset(p, 0, 256);      // the plan header (sticky flags)
+            h->ring_ws[i] = p;
+            h->allocs.push_back(p);
+        }
+    }
+    const uint64_t lim = static_cast<uint64_t>(h->c.length);
+    if (key_kind == 0 ? ha_plan_sort_batch_f32ids_lim(reinterpret_cast<const float *const *>(keys), n, h->ring_ws, count, lim, stream)
+                      : ha_plan_sort_batch_u64ids_lim(reinterpret_cast<const uint64_t *const *>(keys), n, h->ring_ws, count, lim,
+                                                      stream))
+        return -1;
+    for (int i = 0; i < count; ++i) {
+        h->ring_keys[i] = keys[i];
+        h->ring_n[i] = n[i];
+    }
+    h->ring_kind = key_kind;
+    h->ring_count = count;
+    return 0;
+}
+
 static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_t n, float *dest, hipStream_t s, bool presorted);
 
 extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int64_t n,
@@ -2166,6 +2215,18 @@ extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int6
 extern "C" int ha_cache_lookup_presorted(ha_cache *h, const void *keys, int key_kind, int64_t n,
                                          float *dest, ha_stream_t stream) {
     HA_REQUIRE(h, "cache_lookup_presorted: null handle");
+    if (h->ring_head < h->ring_count) {      // the next batch of ha_cache_sort_ahead_batch's ring
+        const int i = h->ring_head;
+        HA_REQUIRE(h->ring_keys[i] == keys && h->ring_n[i] == n && h->ring_kind == key_kind,
+                   "cache_lookup_presorted: batch %d of the last ha_cache_sort_ahead_batch is another one (%ld keys)", i,
+                   (long)h->ring_n[i]);
+        HA_REQUIRE(h->c.table && !h->c.remote, "cache_lookup: no local store bound");
+        void *ws = h->ring_ws[i];
+        h->ring_ws[i] = h->c.plan_ws;        // (all workspaces are of one size: the ring keeps the lookup's old one)
+        h->c.plan_ws = ws;
+        ++h->ring_head;
+        return cache_lookup_impl(h, keys, key_kind, n, dest, as_stream(stream), true);
+    }
     if (n == 0 || n > kSmallMax)      // sort_ahead ignored this batch
         return cache_lookup_impl(h, keys, key_kind, n, dest, as_stream(stream), false);
     HA_REQUIRE(h->ahead_n == n && h->ahead_keys == keys && h->ahead_kind == key_kind,
@@ -2179,7 +2240,7 @@ static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_
                "ha_cache_lookup_begin / ha_cache_lookup_finish)");
     HA_REQUIRE(n >= 0 && (n == 0 || (keys && dest)), "cache_lookup: bad arguments");
     Cache &c = h->c;
-    if (presorted) {          // the sorted keys are in the second workspace: it becomes the plan of this batch
+    if (presorted && h->ahead_n >= 0) {          // the sorted keys are in the second workspace: it becomes the plan of this batch
         HA_REQUIRE(hipStreamWaitEvent(s, h->ahead_join, 0) == hipSuccess, "cache_lookup_presorted: join failed");
         std::swap(c.plan_ws, h->plan_ws_alt);
         h->ahead_n = -1;

@@ -900,7 +900,7 @@ __global__ __launch_bounds__(1024) void finish_small_batch_kernel(const PlanBatc
 
 template <typename IdT>
 static int plan_build_batch(const IdT *const *ids, const int64_t *n, void *const *ws, int count, uint64_t key_limit,
-                            hipStream_t stream) {
+                            hipStream_t stream, bool sort_only = false) {
     HA_REQUIRE(count >= 0 && (count == 0 || (ids && n && ws)), "plan_build_batch: bad arguments");
     bool small = true;
     for (int i = 0; i < count; ++i) {
@@ -909,7 +909,7 @@ static int plan_build_batch(const IdT *const *ids, const int64_t *n, void *const
     }
     if (!small) {   // some batch takes a multi-launch sort: one plan at a time
         for (int i = 0; i < count; ++i)
-            if (plan_build<IdT>(ids[i], n[i], ws[i], 32, false, stream, key_limit))
+            if (plan_build<IdT>(ids[i], n[i], ws[i], 32, sort_only, stream, key_limit))
                 return -1;
         return 0;
     }
@@ -933,8 +933,9 @@ static int plan_build_batch(const IdT *const *ids, const int64_t *n, void *const
             hipLaunchKernelGGL(plan_rank_small_batch_kernel<IdT>, dim3((nmax + kRankTile - 1) / kRankTile, m), dim3(1024),
                                lds, stream, b);
         }
-        hipLaunchKernelGGL(finish_small_batch_kernel, dim3(nmax > 0 ? finish_blocks(nmax) : 1, m), dim3(1024), 0, stream,
-                           b);
+        if (!sort_only)
+            hipLaunchKernelGGL(finish_small_batch_kernel, dim3(nmax > 0 ? finish_blocks(nmax) : 1, m), dim3(1024), 0,
+                               stream, b);
         HA_LAUNCH_CHECK();
     }
     return 0;
@@ -949,6 +950,17 @@ extern "C" int ha_plan_build_batch_f32ids_lim(const float *const *ids, const int
 extern "C" int ha_plan_build_batch_u64ids_lim(const uint64_t *const *ids, const int64_t *n, void *const *ws, int count,
                                               uint64_t key_limit, ha_stream_t stream) {
     return ha::plan_build_batch<uint64_t>(ids, n, ws, count, key_limit, ha::as_stream(stream));
+}
+
+// the stable sorts alone (keys / sorted / perm of every workspace; what ha_plan_sort_*_lim leaves), ONE launch for up to
+// 16 batches of at most 36,864 ids
+extern "C" int ha_plan_sort_batch_f32ids_lim(const float *const *ids, const int64_t *n, void *const *ws, int count,
+                                             uint64_t key_limit, ha_stream_t stream) {
+    return ha::plan_build_batch<float>(ids, n, ws, count, key_limit, ha::as_stream(stream), true);
+}
+extern "C" int ha_plan_sort_batch_u64ids_lim(const uint64_t *const *ids, const int64_t *n, void *const *ws, int count,
+                                             uint64_t key_limit, ha_stream_t stream) {
+    return ha::plan_build_batch<uint64_t>(ids, n, ws, count, key_limit, ha::as_stream(stream), true);
 }
 
 extern "C" int ha_plan_build_f32ids_lim(const float *ids, int64_t n, void *ws, uint64_t key_limit,

@@ -270,6 +270,11 @@ int ha_plan_build_batch_f32ids_lim(const float *const *ids, const int64_t *n, vo
                                    uint64_t key_limit, ha_stream_t stream);
 int ha_plan_build_batch_u64ids_lim(const uint64_t *const *ids, const int64_t *n, void *const *ws, int count,
                                    uint64_t key_limit, ha_stream_t stream);
+/* the stable sorts alone of up to 16 small batches per launch (what ha_plan_sort_*_lim leaves in each workspace) */
+int ha_plan_sort_batch_f32ids_lim(const float *const *ids, const int64_t *n, void *const *ws, int count,
+                                  uint64_t key_limit, ha_stream_t stream);
+int ha_plan_sort_batch_u64ids_lim(const uint64_t *const *ids, const int64_t *n, void *const *ws, int count,
+                                  uint64_t key_limit, ha_stream_t stream);
 int ha_plan_build_f32ids_lim(const float *ids, int64_t n, void *ws, uint64_t key_limit, ha_stream_t stream);
 int ha_plan_sort_f32ids_lim(const float *ids, int64_t n, void *ws, uint64_t key_limit, ha_stream_t stream);
 int ha_plan_build_u64ids_lim(const uint64_t *ids, int64_t n, void *ws, uint64_t key_limit, ha_stream_t stream);
@@ -898,6 +903,12 @@ int ha_cache_lookup(ha_cache *cache, const void *keys, int key_kind, int64_t n,
 int ha_cache_sort_ahead(ha_cache *cache, const void *keys, int key_kind, int64_t n, ha_stream_t stream);
 int ha_cache_lookup_presorted(ha_cache *cache, const void *keys, int key_kind, int64_t n,
                               float *dest, ha_stream_t stream);
+/* The sorts of the next `count` (<= 16) lookups in ONE launch on `stream` -- no second stream, no event edge --, into a ring of
+ * plan workspaces: for a caller that has its ids a block of batches early (the work-queue step's lookahead).  The
+ * ha_cache_lookup_presorted calls that follow must name these key buffers in this order; 1 .. min(max_batch, 36,864) keys per
+ * batch; the first call allocates the ring (not inside a stream capture).  Results: those of ha_cache_lookup. */
+int ha_cache_sort_ahead_batch(ha_cache *cache, const void *const *keys, int key_kind, const int64_t *n, int count,
+                              ha_stream_t stream);
 int ha_cache_update(ha_cache *cache, const void *keys, int key_kind, int64_t n,
                     const float *grads, ha_stream_t stream);
 /* ha_cache_update for the key batch of the immediately preceding ha_cache_lookup on this cache (the

@@ -30,7 +30,8 @@ def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_k
     tensor (same_as_lookup=True -> ha_cache_update_same_keys); extra_lookup_every=k: every k-th step looks another
     batch up first, so that the evict list is not empty when the step's own lookup starts.  ahead: every step hands the
     NEXT step's key tensor to prefetch_keys between its lookup and its update (ha_cache_sort_ahead -> the next lookup is
-    ha_cache_lookup_presorted)."""
+    ha_cache_lookup_presorted); ahead=k (an int): every k-th step hands the key tensors of the next k steps to
+    prefetch_keys_batch (ha_cache_sort_ahead_batch: one launch sorts them all, the lookups take them in order)."""
     rng = np.random.default_rng(seed)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
     server = cache_model.Server(table0)
@@ -63,11 +64,13 @@ def _run_trace(dev, limit, rows, width, n, steps, pull_bound, push_bound, push_k
             want = model.lookup(xk.astype(np.uint64))
             gpu.embedding_lookup(torch.from_numpy(xk).to(dev), dest).wait()
             np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="extra lookup rows at step %d" % step)
+        if isinstance(ahead, int) and not isinstance(ahead, bool) and step % ahead == 0:
+            gpu.prefetch_keys_batch(kts[step:step + ahead])      # the batches of a block of steps, sorted in one launch
         want = model.lookup(fk.astype(np.uint64))
         kt = kts[step] if ahead else torch.from_numpy(fk).to(dev)
         gpu.embedding_lookup(kt, dest).wait()
         np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % step)
-        if ahead and step + 1 < steps:
+        if ahead is True and step + 1 < steps:
             gpu.prefetch_keys(kts[step + 1])
         grads = (rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01))
         if push_keys_mode:
@@ -145,6 +148,46 @@ def test_lru_trace_with_the_next_batch_sorted_ahead(dev, same, extra):
                         same=same, extra_lookup_every=extra, ahead=True)
     if same and not extra:
         assert _fused(gpu) == 60
+
+
+@pytest.mark.parametrize("same,extra,blk", [(True, 0, 16), (False, 0, 5), (True, 3, 7), (True, 0, 1)])
+def test_lru_trace_with_a_block_of_batches_sorted_ahead(dev, same, extra, blk):
+    """prefetch_keys_batch: the sorts of the next `blk` lookups in ONE launch, into a ring of plan workspaces -- the same
+    trace, state and reports as the model; with `extra`, a lookup that was not announced drops the rest of a block (those
+    lookups sort by themselves)."""
+    gpu, _ = _run_trace(dev, limit=100, rows=1500, width=8, n=64, steps=60, pull_bound=2, push_bound=2, seed=23,
+                        same=same, extra_lookup_every=extra, ahead=blk)
+    if same and not extra:
+        assert _fused(gpu) == 60
+
+
+def test_lru_trace_with_a_block_sorted_ahead_criteo_width_and_long_runs(dev):
+    _run_trace(dev, limit=300, rows=5000, width=128, n=416, steps=12, pull_bound=2, push_bound=2, seed=24,
+               check_every=4, ahead=4, same=True)
+    _run_trace(dev, limit=2500, rows=6000, width=512, n=2000, steps=5, pull_bound=1, push_bound=2, seed=25, ahead=16,
+               same=True)
+
+
+def test_block_sort_ahead_insists_on_the_announced_order(dev):
+    rows, width, n = 500, 8, 96
+    rng = np.random.default_rng(6)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    gpu = hcache.LRUCache(200, rows, width, node_id=0, max_batch=n, device=dev)
+    gpu.bind_store(torch.from_numpy(table0.copy()).to(dev), torch.zeros(rows, dtype=torch.int64, device=dev))
+    ks = [torch.from_numpy(rng.integers(0, rows, size=n).astype(np.float32)).to(dev) for _ in range(3)]
+    dest = torch.empty((n, width), device=dev)
+    gpu.prefetch_keys_batch(ks)
+    from herald_amd import _lib
+    import ctypes
+    with pytest.raises(Exception):      # the C entry point: batch 1 where batch 0 was announced
+        _lib.check(gpu._L.ha_cache_lookup_presorted(gpu._h, ctypes.c_void_p(ks[1].data_ptr()), 0, n,
+                                                    ctypes.c_void_p(dest.data_ptr()), None), "ha_cache_lookup_presorted")
+    # the Python class: a lookup of another batch drops the block, everything still answers right
+    for k in (ks[1], ks[0], ks[2]):
+        gpu.embedding_lookup(k, dest).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), table0[k.cpu().numpy().astype(np.int64)])
+    with pytest.raises(ValueError):
+        gpu.prefetch_keys_batch(ks * 6)      # more than 16 batches
 
 
 def test_lfu_trace_with_the_next_batch_sorted_ahead_criteo_width(dev):
