@@ -304,6 +304,8 @@ def _declare(L):
     L.ha_laia_counters.argtypes = [vp, vp]
     L.ha_laia_timing.restype = c.c_int
     L.ha_laia_timing.argtypes = [vp, vp]
+    L.ha_laia_timing_device.restype = c.c_int
+    L.ha_laia_timing_device.argtypes = [vp, vp]
     L.ha_laia_on_device.restype = c.c_int
     L.ha_laia_on_device.argtypes = [vp]
     L.ha_shm_ring_open.restype = vp

@@ -1067,8 +1067,6 @@ struct LaiaDev {
     // mirrored in pinned memory by a single copy; the plan rows follow in a second one (their number is only known then)
     char *d_out = nullptr, *h_out = nullptr;
     size_t out_bytes = 0, off_at = 0, state_at = 0;
-    long long plan_guess = 0;      // plan rows copied along with the block (the last batch's count and a margin)
-    long long rank_lo = 0, rank_hi = 0;   // ... or one worker's range of them (ha_laia_next_for_rank)
     long long *h_dist = nullptr;
     int32_t *h_off = nullptr;
     uint32_t *h_plan_rows = nullptr;
@@ -1076,7 +1074,14 @@ struct LaiaDev {
     // One batch AHEAD (ha_laia_hint_next): the caller names the batch of its next call, and the call that returns batch k
     // enqueues the launches and copies of that batch before it hands k's results over -- the device works on k+1 while the
     // host (the reference's launch() loop, laia_scheduler.cc:115-169: queueing the plan and the dist) deals with k.  The
-    // pinned mirrors exist twice for it; the device buffers do not (k's copies are complete before k+1 is enqueued).
+    // pinned mirrors exist twice for it.  Round 5: (1) batch k+1 is enqueued BEFORE the host waits for batch k; (2) the results
+    // reach the host WITHOUT copy commands: the batch's last kernel (laia_export_kernel) writes the block and exactly the plan
+    // rows the caller wants into the pinned mirror and then a sequence word the host polls.  (Two hipMemcpyAsync per batch on
+    // the scheduler's stream cost ~38 us of idle stream around them -- 13 us in front of and behind each copy -- where the
+    // kernels of a batch take 115; profiles/r05/laia_gaps_*.txt.)
+    unsigned *d_export_ctr = nullptr;            // blocks of the export kernel that have finished
+    unsigned long long *h_seq = nullptr;         // pinned: [2] the sequence number of the batch last exported into a mirror
+    unsigned long long seq_issued[2] = {0, 0}, seq_next = 0;
     char *h_out_base = nullptr;
     uint32_t *h_plan_base = nullptr;
     size_t plan_words = 0;          // words per pinned plan mirror
@@ -1085,7 +1090,6 @@ struct LaiaDev {
     long long inflight = -1;        // batch whose launches and copies are enqueued already (-1: none)
     int inflight_set = 0, inflight_rank = -1, inflight_topk = 0;
     long long inflight_mini_bs = 0;
-    long long issued_g0[2] = {0, 0}, issued_g1[2] = {0, 0};      // plan rows copied along, per mirror
 };
 static inline void laia_host_set(LaiaDev &d, int set) {
     d.set = set;
@@ -1187,6 +1191,9 @@ struct Laia {
     // wall time per phase, summed over the calls (ha_laia_timing): the whole call, the host's greedy
     // assignment, the host's snapshot (MiniLRU) bookkeeping; the rest is GPU work, transfers and waits
     double t_total_us = 0, t_assign_us = 0, t_snap_us = 0;
+    // device-resident mode, the same calls by what the host does in them (ha_laia_timing_device): enqueueing a batch's launches,
+    // waiting for the batch's sequence word, copying dist and plan out of the pinned mirror
+    double t_issue_us = 0, t_wait_us = 0, t_unpack_us = 0;
     long long t_calls = 0;
     LaiaDev dev;              // device-resident mode (LaiaScheduler with cache_size >= max_batch * tables)
     bool host_ready = false;  // the host snapshots are initialised at the first call that needs them
@@ -1291,6 +1298,8 @@ extern "C" void ha_laia_destroy(ha_laia *h) {
     for (void *p : {static_cast<void *>(h->l.dev.h_out_base), static_cast<void *>(h->l.dev.h_plan_base)})
         if (p)
             (void)hipHostFree(p);
+    if (h->l.dev.h_seq)
+        (void)hipHostFree(h->l.dev.h_seq);
     (void)hipStreamDestroy(h->l.stream);
     delete h;
 }
@@ -1380,6 +1389,10 @@ static int laia_dev_init(Laia &l) {
     d.state_at = (d.off_at + static_cast<size_t>(2 * (W + 1)) * 4 + 15) / 16 * 16;
     d.out_bytes = d.state_at + static_cast<size_t>(W) * sizeof(LruState);
     alloc(reinterpret_cast<void **>(&d.d_out), d.out_bytes, true);
+    alloc(reinterpret_cast<void **>(&d.d_export_ctr), 256, true);
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_seq), 256, hipHostMallocDefault) == hipSuccess;
+    if (ok)
+        d.h_seq[0] = d.h_seq[1] = 0;
     d.plan_words = (static_cast<size_t>(l.plan_cap) + 4 + 63) / 64 * 64;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&d.h_out_base), 2 * ((d.out_bytes + 255) / 256 * 256),
                              hipHostMallocDefault) == hipSuccess;
@@ -1405,6 +1418,35 @@ static int laia_dev_init(Laia &l) {
     HA_CHECK_HIP(hipStreamSynchronize(l.stream));
     d.on = true;
     return 0;
+}
+
+// The last kernel of a batch: the block the host reads (dist, offsets, states: `out_words` words at d_out) and the plan rows
+// of the worker the caller asked for (only_rank >= 0) or of all workers go straight into the pinned mirror -- plain stores to
+// host memory, drained by every wave --, and the block that finishes last publishes the batch's sequence number behind a
+// system-scope fence.  The host polls that word: no copy command, no event, nothing between this kernel and the next batch's
+// first one on the stream.
+__global__ __launch_bounds__(256) void laia_export_kernel(const uint32_t *__restrict__ d_out, long long out_words,
+                                                          const uint32_t *__restrict__ rows, const int32_t *__restrict__ off,
+                                                          int W, int only_rank, long long cap, uint32_t *__restrict__ h_out,
+                                                          uint32_t *__restrict__ h_plan, unsigned *__restrict__ ctr,
+                                                          unsigned long long *__restrict__ h_seq, unsigned long long seq) {
+    const long long stride = static_cast<long long>(gridDim.x) * 256, t0 = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    for (long long i = t0; i < out_words; i += stride)
+        h_out[i] = d_out[i];
+    long long a0 = only_rank >= 0 ? off[only_rank] : 0, a1 = only_rank >= 0 ? off[only_rank + 1] : off[W];
+    a1 = a1 < cap ? a1 : cap;
+    for (long long i = a0 + t0; i < a1; i += stride)
+        h_plan[i] = rows[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 static int laia_dev_states(Laia &l) {   // -> l.dev.h_state (synchronises the scheduler's stream)
@@ -1479,22 +1521,12 @@ static int laia_dev_issue(ha_laia *h, int64_t batch_id, int64_t mini_bs, int onl
     hipLaunchKernelGGL(laia_lru_classify_kernel, dim3(kLaiaLruBlocks, W), dim3(256), 0, l.stream, d.lru);
     hipLaunchKernelGGL(laia_lru_window_kernel, dim3(W), dim3(1024), 0, l.stream, d.lru, d.debug_wrap_at);
     hipLaunchKernelGGL(laia_lru_apply_kernel, dim3(kLaiaLruBlocks, W), dim3(256), 0, l.stream, d.lru);
+    d.seq_issued[set] = ++d.seq_next;
+    hipLaunchKernelGGL(laia_export_kernel, dim3(32), dim3(256), 0, l.stream, reinterpret_cast<const uint32_t *>(d.d_out),
+                       static_cast<long long>(d.out_bytes / 4), d.bits.rows[1], d.bits.off[1], W, only_rank,
+                       static_cast<long long>(l.plan_cap), reinterpret_cast<uint32_t *>(d.h_out), d.h_plan_rows, d.d_export_ctr,
+                       d.h_seq + set, d.seq_issued[set]);
     HA_LAUNCH_CHECK();
-    HA_CHECK_HIP(hipMemcpyAsync(d.h_out, d.d_out, d.out_bytes, hipMemcpyDeviceToHost, l.stream));
-    // the plan rows are copied along speculatively: all of them up to the last batch's count + 25 %, or -- only_rank --
-    // the last batch's range of that worker, widened; what the guess misses is fetched in a second copy
-    long long g0 = 0, g1 = d.plan_guess;
-    if (only_rank >= 0) {
-        g0 = d.rank_lo;
-        g1 = d.rank_hi;
-    }
-    g1 = g1 < static_cast<long long>(l.plan_cap) ? g1 : static_cast<long long>(l.plan_cap);
-    g0 = g0 < g1 ? g0 : g1;
-    if (g1 > g0)
-        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows + g0, d.bits.rows[1] + g0, static_cast<size_t>(g1 - g0) * 4,
-                                    hipMemcpyDeviceToHost, l.stream));
-    d.issued_g0[set] = g0;
-    d.issued_g1[set] = g1;
     return 0;
 }
 
@@ -1517,28 +1549,8 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     } else if (laia_dev_issue(h, batch_id, mini_bs, only_rank, topk, set)) {
         return -1;
     }
-    laia_host_set(d, set);
-    const long long g0 = d.issued_g0[set], g1 = d.issued_g1[set];
-    HA_CHECK_HIP(hipStreamSynchronize(l.stream));
-    for (int w = 0; w < W; ++w)
-        HA_REQUIRE(d.h_state[w].err == 0, "laia: the device snapshot of worker %d is inconsistent (code %d)", w,
-                   d.h_state[w].err);
-    const int32_t *pl_off = d.h_off + (W + 1);
-    const long long nplan = pl_off[W];
-    const long long a0 = only_rank >= 0 ? pl_off[only_rank] : 0, a1 = only_rank >= 0 ? pl_off[only_rank + 1] : nplan;
-    HA_REQUIRE(a1 - a0 <= plan_cap_elems && nplan <= static_cast<long long>(l.plan_cap), "laia_next: plan buffer too small");
-    if (a1 > a0 && (a0 < g0 || a1 > g1)) {      // not (all) inside what was guessed: fetch the range itself
-        HA_CHECK_HIP(hipMemcpyAsync(d.h_plan_rows + a0, d.bits.rows[1] + a0, static_cast<size_t>(a1 - a0) * 4,
-                                    hipMemcpyDeviceToHost, l.stream));
-        HA_CHECK_HIP(hipStreamSynchronize(l.stream));
-    }
-    d.plan_guess = nplan + nplan / 4 + 4096;
-    if (only_rank >= 0) {
-        const long long margin = (a1 - a0) / 4 + 2048;
-        d.rank_lo = a0 > margin ? a0 - margin : 0;
-        d.rank_hi = a1 + margin;
-    }
-    if (d.next_hint >= 0) {     // the caller's next batch: its launches and copies go out before this one's results are unpacked
+    const double t_issue0 = now_us();
+    if (d.next_hint >= 0) {     // the caller's next batch: its launches and copies go out BEFORE this one is waited for
         const long long nb = d.next_hint;
         d.next_hint = -1;
         if (laia_dev_issue(h, nb, mini_bs, only_rank, topk, set ^ 1))
@@ -1548,8 +1560,33 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
         d.inflight_mini_bs = mini_bs;
         d.inflight_rank = only_rank;
         d.inflight_topk = topk ? 1 : 0;
-        laia_host_set(d, set);
     }
+    laia_host_set(d, set);
+    const double t_wait_begin = now_us();
+    l.t_issue_us += t_wait_begin - t_issue0;
+    {   // the batch's sequence word (written by its export kernel); a stream that died shows up in the synchronise
+        const unsigned long long want = d.seq_issued[set];
+        volatile unsigned long long *word = d.h_seq + set;
+        const double t_wait0 = now_us();
+        unsigned spins = 0;
+        while (__atomic_load_n(const_cast<unsigned long long *>(word), __ATOMIC_ACQUIRE) != want) {
+            if ((++spins & 1023u) == 0 && now_us() - t_wait0 > 5e6) {
+                HA_CHECK_HIP(hipStreamSynchronize(l.stream));
+                HA_REQUIRE(__atomic_load_n(const_cast<unsigned long long *>(word), __ATOMIC_ACQUIRE) == want,
+                           "laia: the device never published batch %lld", (long long)batch_id);
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+    }
+    l.t_wait_us += now_us() - t_wait_begin;
+    for (int w = 0; w < W; ++w)
+        HA_REQUIRE(d.h_state[w].err == 0, "laia: the device snapshot of worker %d is inconsistent (code %d)", w,
+                   d.h_state[w].err);
+    const int32_t *pl_off = d.h_off + (W + 1);
+    const long long nplan = pl_off[W];
+    const long long a0 = only_rank >= 0 ? pl_off[only_rank] : 0, a1 = only_rank >= 0 ? pl_off[only_rank + 1] : nplan;
+    HA_REQUIRE(a1 - a0 <= plan_cap_elems && nplan <= static_cast<long long>(l.plan_cap), "laia_next: plan buffer too small");
     const double t_out0 = now_us();
     for (long long k = 0; k < B; ++k)
         dist_out[k] = d.h_dist[k];
@@ -1563,6 +1600,7 @@ static int laia_next_device(ha_laia *h, int64_t batch_id, int64_t mini_bs, int64
     for (long long k = a0; k < a1; ++k)
         plan_out[k - a0] = d.h_plan_rows[k];
     l.t_assign_us += now_us() - t_out0;      // device mode: the host's share is copying dist and the plans out
+    l.t_unpack_us += now_us() - t_out0;
     l.t_total_us += now_us() - t_begin;
     l.t_calls += 1;
     return 0;
@@ -1834,6 +1872,17 @@ extern "C" int ha_laia_timing(ha_laia *h, double *out) {
     out[1] = h->l.t_total_us;
     out[2] = h->l.t_assign_us;
     out[3] = h->l.t_snap_us;
+    return 0;
+}
+
+// device-resident mode: out[4] = {calls, us enqueueing the next batch's launches, us waiting for the batch's results, us copying
+// dist and plan out of the pinned mirror}, summed since creation (zeros while the snapshots live on the host)
+extern "C" int ha_laia_timing_device(ha_laia *h, double *out) {
+    HA_REQUIRE(h && out, "ha_laia_timing_device: null pointer");
+    out[0] = static_cast<double>(h->l.t_calls);
+    out[1] = h->l.t_issue_us;
+    out[2] = h->l.t_wait_us;
+    out[3] = h->l.t_unpack_us;
     return 0;
 }
 

@@ -96,8 +96,24 @@ public:
         d["host_assign_us"] = t[2] / calls;
         d["host_snapshot_us"] = t[3] / calls;
         d["gpu_and_transfer_us"] = (t[1] - t[2] - t[3]) / calls;
+        double td[4] = {0, 0, 0, 0};
+        if (h_)
+            (void)ha_laia_timing_device(h_, td);
+        d["issue_us"] = td[1] / calls;       // device-resident mode: enqueueing the next batch / waiting / copying out
+        d["wait_us"] = td[2] / calls;
+        d["unpack_us"] = td[3] / calls;
         const long long done = done_.load();
         d["thread_wall_us_per_batch"] = done > 0 ? wall_us_.load() / static_cast<double>(done) : 0.0;
+        // the same per batch WITHOUT the first kWarmBatches (the first call allocates and clears the scheduler's device state)
+        if (warm_set_.load() && done > kWarmBatches && t[0] > warm_t_[0]) {
+            const double n = static_cast<double>(done - kWarmBatches), nc = t[0] - warm_t_[0];
+            d["steady_from_batch"] = static_cast<long long>(kWarmBatches);
+            d["steady_thread_wall_us_per_batch"] = (wall_us_.load() - warm_wall_us_) / n;
+            d["steady_us_per_batch"] = (t[1] - warm_t_[1]) / nc;
+            d["steady_issue_us"] = (td[1] - warm_td_[1]) / nc;
+            d["steady_wait_us"] = (td[2] - warm_td_[2]) / nc;
+            d["steady_unpack_us"] = (td[3] - warm_td_[3]) / nc;
+        }
         return d;
     }
     // stops the scheduler thread (the destructor does the same)
@@ -192,8 +208,14 @@ protected:
                     }
                 }
                 ++batch_id;
-                done_.fetch_add(1);
+                const long long done_now = done_.fetch_add(1) + 1;
                 wall_us_.store(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count());
+                if (done_now == kWarmBatches) {     // what the first batches cost (the device state is allocated in the first call)
+                    warm_wall_us_ = wall_us_.load();
+                    (void)ha_laia_timing(h_, warm_t_);
+                    (void)ha_laia_timing_device(h_, warm_td_);
+                    warm_set_ = true;
+                }
             }
         }
         finish();
@@ -226,6 +248,9 @@ protected:
     std::atomic<bool> close_{false};
     std::atomic<long long> done_{0};
     std::atomic<double> wall_us_{0.0};
+    static constexpr long long kWarmBatches = 8;
+    std::atomic<bool> warm_set_{false};
+    double warm_wall_us_ = 0.0, warm_t_[4] = {0, 0, 0, 0}, warm_td_[4] = {0, 0, 0, 0};
     std::mutex mu_;
     std::condition_variable cv_;
     std::queue<std::vector<uint64_t>> q_;

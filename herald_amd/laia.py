@@ -138,7 +138,10 @@ class LaiaScheduler:
         _lib.check(self._L.ha_laia_timing(self._h, t.ctypes.data), "ha_laia_timing")
         calls = max(t[0], 1.0)
         wall, done = getattr(self, "_wall", (0.0, 0))
-        return {"batches": int(t[0]), "us_per_batch": t[1] / calls, "host_assign_us": t[2] / calls,
+        td = np.zeros(4, dtype=np.float64)
+        _lib.check(self._L.ha_laia_timing_device(self._h, td.ctypes.data), "ha_laia_timing_device")
+        return {"issue_us": td[1] / calls, "wait_us": td[2] / calls, "unpack_us": td[3] / calls,
+                "batches": int(t[0]), "us_per_batch": t[1] / calls, "host_assign_us": t[2] / calls,
                 "host_snapshot_us": t[3] / calls, "gpu_and_transfer_us": (t[1] - t[2] - t[3]) / calls,
                 # the scheduler thread's loop as a whole (library calls + queueing plan and dist as Python lists)
                 "thread_wall_us_per_batch": 1e6 * wall / done if done else None}

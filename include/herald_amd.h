@@ -1076,6 +1076,9 @@ int ha_laia_counters(ha_laia *sched, int64_t *out);
  * batch): out[4] = {calls of ha_laia_next*, whole calls us, host greedy assignment us, host snapshot
  * (MiniLRU) bookkeeping us}; the remainder of the total is GPU kernels, transfers and waits. */
 int ha_laia_timing(ha_laia *h, double *out);
+/* device-resident mode: out[4] = {calls, us enqueueing the next batch's launches, us waiting for a batch's results, us copying
+ * dist and plan out of the pinned mirror}, summed since creation */
+int ha_laia_timing_device(ha_laia *h, double *out);
 /* 1 = the scheduler state (MiniLRU snapshots as stamp logs, assignment, sorted-unique plan / touched rows) lives on the
  * device -- LaiaScheduler and TopkScheduler alike, whenever cache_size >= global batch x tables (decided at the first
  * batch; HA_LAIA_HOST=1 keeps it on the host) --, 0 = host snapshots, -1 = no batch scheduled yet. */
