@@ -140,19 +140,124 @@ __global__ __launch_bounds__(1024, 8) void apply_long_kernel(
 // a workgroup first serves its share of the (long key, slice) items -- they are the launch's critical path, a
 // 2,000-occurrence run is an ordered chain of 2,000 steps whatever else happens -- and then joins the loop over
 // the unique keys.  One launch and one dependent boundary less, and the short keys no longer wait for the list.
+//
+// TOLERANCE MODE, runs beyond 256 occurrences (BASELINE configs[2]'s per-GPU batch has a key with 4,096): one workgroup per
+// (key, slice) walks such a run block by block -- 16 dependent rounds of index load + row loads, ~39 us for a launch whose
+// bytes take 10.  A one-workgroup launch in front (apply_chunk_plan_kernel) cuts every such run into chunks of 256: the
+// item list becomes (key, chunk, slice), every workgroup reads the chunk offsets of the long keys into LDS and finds its
+// items there, chunk sums meet as described at coop_chunk_tree.  OPT-IN (ha_set_tolerance_mode(2)): measured at that shape,
+// ha_push_apply_scaled_finished takes 35.8 us with the chunks and 34.5 without (tools/push_chunk_ab.py) -- the long run is not
+// what the launch waits for; the chunks stay for batches where it is.  Conditions (all functions of the batch alone, so that the
+// oracle can restate them: oracle/qstep_model.py `chunked=`): tolerance mode on, at most kChunkKeysMax listed keys, width <= 256
+// (the chunk sums live in the 2 n words of the plan's `dep` array), no index maps / second destination.
+constexpr int kChunkKeysMax = 2040;
+constexpr size_t kListedLdsBytes = kApplyLdsBytes + (kChunkKeysMax + 8) * 4;
+struct ChunkPlan {
+    uint32_t *meta;     // [0] total chunks (0: unchunked), [1] listed keys; [8 ..] exclusive chunk offsets of the listed keys, [L] = total
+    uint32_t *ctr;      // [L * nslice] arrivals per (key, slice)
+    float *part;        // [total * nslice * 64] chunk sums
+};
+__global__ __launch_bounds__(1024) void apply_chunk_plan_kernel(const PlanHeader *__restrict__ hdr,
+                                                                const uint32_t *__restrict__ long_list,
+                                                                const int32_t *__restrict__ counts, int nslice, int tree_from,
+                                                                long long part_cap_floats, ChunkPlan cp) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const long long L = hdr->reserved[0];
+    if (tree_from <= 0 || L <= 0 || L > kChunkKeysMax) {
+        if (threadIdx.x == 0)
+            cp.meta[0] = 0u;
+        return;
+    }
+    if (threadIdx.x == 0)
+        s_carry = 0u;
+    __syncthreads();
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (int base = 0; base < L; base += 1024) {
+        const int i = base + threadIdx.x;
+        uint32_t nc = 0;
+        if (i < L) {
+            const int len = counts[long_list[i]];
+            nc = len >= tree_from && len > kTreeChunk ? static_cast<uint32_t>((len + kTreeChunk - 1) / kTreeChunk) : 1u;
+        }
+        uint32_t incl = nc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += y;
+        }
+        if (lane == 63)
+            s_w[w] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int k = 0; k < w; ++k)
+            before += s_w[k];
+        if (i < L)
+            cp.meta[8 + i] = before + incl - nc;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            s_carry = before + incl;
+        __syncthreads();
+    }
+    const uint32_t total = s_carry;
+    for (long long k = threadIdx.x; k < L * nslice; k += 1024)
+        cp.ctr[k] = 0u;
+    if (threadIdx.x == 0) {
+        cp.meta[8 + L] = total;
+        cp.meta[1] = static_cast<uint32_t>(L);
+        // (nothing to chunk, or the chunk sums would not fit: the launch runs unchunked)
+        cp.meta[0] = total > L && static_cast<long long>(total) * nslice * 64 <= part_cap_floats ? total : 0u;
+    }
+}
+
 template <int MODE, int VEC>
 __global__ __launch_bounds__(1024, 8) void apply_listed_kernel(
     float *__restrict__ dst, uint64_t dst_rows, int width, const PlanHeader *__restrict__ hdr,
     const uint32_t *__restrict__ uniq, const int32_t *__restrict__ seg,
     const int32_t *__restrict__ counts, const int32_t *__restrict__ perm, int n,
-    const float *__restrict__ grads, float lr, const uint32_t *__restrict__ long_list, ApplyMaps maps) {
+    const float *__restrict__ grads, float lr, const uint32_t *__restrict__ long_list, ApplyMaps maps, ChunkPlan cp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
     const int nslice = (width + kWave - 1) / kWave;
-    const long long items = hdr->reserved[0] * nslice;
     const int w = static_cast<int>(threadIdx.x >> 6);
+    const long long L = hdr->reserved[0];
+    const uint32_t total = cp.meta != nullptr ? uniform(cp.meta[0]) : 0u;      // chunks over all listed keys (0: unchunked)
+    uint32_t *s_off = s_apply + kApplyLdsBytes / 4;
+    if (total != 0u) {
+        for (int i = threadIdx.x; i <= L; i += 1024)
+            s_off[i] = cp.meta[8 + i];
+        __syncthreads();
+    }
+    const long long items = (total != 0u ? static_cast<long long>(total) : L) * nslice;
     for (long long it = blockIdx.x; it < items; it += gridDim.x) {
-        const int u = static_cast<int>(long_list[it / nslice]);
         const int j = static_cast<int>(it % nslice);
+        int li = static_cast<int>(it / nslice), ch = 0, nch = 1;
+        uint32_t q = 0;
+        if (total != 0u) {       // the listed key whose chunk range holds chunk q (offsets ascending, s_off[L] = total)
+            q = static_cast<uint32_t>(it / nslice);
+            int lo = 0, hi = static_cast<int>(L);
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_off[mid] <= q)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            li = lo;
+            ch = static_cast<int>(q - s_off[lo]);
+            nch = static_cast<int>(s_off[lo + 1] - s_off[lo]);
+        }
+        const int u = static_cast<int>(long_list[li]);
+        if (nch > 1) {           // (never with index maps or a second destination: the host leaves cp.meta null then)
+            const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
+            if (row < dst_rows)
+                coop_chunk_tree<MODE>(dst + row * static_cast<uint64_t>(width), true, grads, perm, maps, n, lr, seg[u], counts[u],
+                                      width, j, w, reinterpret_cast<float *>(s_apply),
+                                      cp.part + (static_cast<size_t>(s_off[li]) * nslice + static_cast<size_t>(j) * nch) * 64,
+                                      cp.ctr + static_cast<size_t>(li) * nslice + j, ch, nch);
+            __syncthreads();
+            continue;
+        }
         uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
         bool init = true;
         if (maps.rowmap) {      // destination rows through an index map (ha_apply_mapped): -1 = no destination
@@ -222,15 +327,18 @@ __global__ __launch_bounds__(1024, 8) void apply_timeline_kernel(
 // ha_sgd_apply*, ha_push_apply*, ha_dedup_reduce*, ha_apply_mapped, ha_shard_serve_push and what builds on them.
 namespace ha {
 static int g_tree_from = 0;
+static int g_tree_chunks = 0;      // mode 2: the applies of a finished plan cut runs beyond 256 occurrences into chunks
 int tolerance_tree_from() { return g_tree_from; }
 }  // namespace ha
 
 extern "C" int ha_set_tolerance_mode(int on) {
+    HA_REQUIRE(on >= 0 && on <= 2, "ha_set_tolerance_mode: 0 (off), 1 (trees) or 2 (trees, long runs in chunks)");
     ha::g_tree_from = on ? 64 : 0;
+    ha::g_tree_chunks = on == 2 ? 1 : 0;
     return 0;
 }
 extern "C" int ha_get_tolerance_mode(void) {
-    return ha::g_tree_from != 0;
+    return ha::g_tree_from == 0 ? 0 : 1 + ha::g_tree_chunks;
 }
 
 // defined in plan.hip
@@ -288,17 +396,35 @@ int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, 
                         (reinterpret_cast<uintptr_t>(grads) % 16 == 0);
     const dim3 grid(512), block(1024);   // two workgroups per compute unit, looping over the keys
     if (n > kSmallMax && n <= kFinishChunkedMax) {
+        // tolerance mode: runs beyond 256 occurrences in chunks (see apply_listed_kernel); scratch = radix scratch of the plan
+        // (perm_alt: offsets and counters) and its `dep` words (chunk sums)
+        ChunkPlan cp{nullptr, nullptr, nullptr};
+        const int nslice = static_cast<int>((width + kWave - 1) / kWave);
+        const bool plain = !maps.rowmap && !maps.valmap && !maps.dst_init && MODE != kModeOpt;
+        if (g_tree_chunks && maps.tree_from > 0 && plain && vec_ok && nslice <= 4) {
+            static DeviceOnce lds_allowed;
+            if (lds_allowed.run([]() -> int {
+                    HA_ALLOW_LDS((apply_listed_kernel<MODE, 4>), kListedLdsBytes);
+                    return 0;
+                }))
+                return -1;
+            cp.meta = reinterpret_cast<uint32_t *>(p.perm_alt);
+            cp.ctr = cp.meta + kChunkKeysMax + 16;
+            cp.part = reinterpret_cast<float *>(p.dep);
+            hipLaunchKernelGGL(apply_chunk_plan_kernel, dim3(1), dim3(1024), 0, stream, p.hdr, p.keys_alt, p.counts, nslice,
+                               maps.tree_from, static_cast<long long>(2 * n), cp);
+        }
         // the chunked finish (plan.hip) left the list of long keys in keys_alt / header word 0
         // (grids of 448 / 384 / 256 workgroups, to leave slots to a sort running beside it on another stream:
         // 57.8 / 57.2 / 59.0 us alone against 52.5 us, and no faster together -- tools/cfgc_bench.py)
         if (vec_ok)
-            hipLaunchKernelGGL((apply_listed_kernel<MODE, 4>), grid, block, kApplyLdsBytes, stream, dst,
-                               (uint64_t)dst_rows, (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads,
-                               lr, p.keys_alt, maps);
+            hipLaunchKernelGGL((apply_listed_kernel<MODE, 4>), grid, block, cp.meta ? kListedLdsBytes : kApplyLdsBytes, stream,
+                               dst, (uint64_t)dst_rows, (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads,
+                               lr, p.keys_alt, maps, cp);
         else
             hipLaunchKernelGGL((apply_listed_kernel<MODE, 1>), grid, block, kApplyLdsBytes, stream, dst,
                                (uint64_t)dst_rows, (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads,
-                               lr, p.keys_alt, maps);
+                               lr, p.keys_alt, maps, cp);
         HA_LAUNCH_CHECK();
         return 0;
     }

@@ -409,24 +409,19 @@ __device__ __forceinline__ float chain_step(float acc, float m) {
 // (p2 + p3), the 16 wave partials through LDS as quads (a + b) + (c + d) and (q0 + q1) + (q2 + q3); one subtract /
 // add per element.  The same order as q_coop of qstep.hip -- oracle/qstep_model.py tree_coop restates it bit for bit.
 // s_part = 16 x 64 floats.  Called by all 16 waves; needs width % 4 == 0 and 16-byte aligned rows.
-template <int MODE>
-__device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, bool init, const float *__restrict__ grads,
-                                                const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr,
-                                                int s, int len, int width, int slice, int w, float *s_part) {
+// the tree's sum over the occurrences [lo, hi) of the run at s: lr * g summed as described above, complete in every lane
+// (for its column quad).  Ends with the workgroup's partials consumed (a barrier precedes any reuse of s_part by the caller).
+__device__ __forceinline__ float4v coop_tree_sum(const float *__restrict__ grads, const int32_t *__restrict__ perm,
+                                                 const ApplyMaps &maps, int n, float lr, int s, int lo, int hi, int width,
+                                                 int col, int w, float *s_part) {
     const int lane = lane_id();
     const int r = lane >> 4, c4 = lane & 15;
-    const int col0 = slice * kWave;
-    const bool act = col0 + 4 * c4 < width;
-    const int col = act ? col0 + 4 * c4 : col0;
-    float4v cur{0.f, 0.f, 0.f, 0.f};
-    if (MODE != kModeReduce && init)
-        cur = *reinterpret_cast<const float4v *>(dst_row + col);
     float4v p{0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < len; base += 256) {
+    for (int base = lo; base < hi; base += 256) {
         const int mine = base + 16 * w;   // this wave's first occurrence of the block
-        if (mine >= len)
+        if (mine >= hi)
             break;   // wave-uniform; no barrier inside the loop
-        int pidx = perm[min(s + min(mine + (lane & 15), len - 1), n - 1)];
+        int pidx = perm[min(s + min(mine + (lane & 15), hi - 1), n - 1)];
         if (maps.valmap)
             pidx = maps.valmap[pidx];
         float4v g[4];
@@ -437,7 +432,7 @@ __device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, boo
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bool valid = mine + 4 * t + r < len;
+            const bool valid = mine + 4 * t + r < hi;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float q = __fadd_rn(p[k], __fmul_rn(lr, g[t][k]));
@@ -461,6 +456,22 @@ __device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, boo
                          add4(*reinterpret_cast<const float4v *>(sp + 128), *reinterpret_cast<const float4v *>(sp + 192)));
     total = add4(total, xor4(total, 16));
     total = add4(total, xor4(total, 32));
+    return total;
+}
+
+template <int MODE>
+__device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, bool init, const float *__restrict__ grads,
+                                                const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr,
+                                                int s, int len, int width, int slice, int w, float *s_part) {
+    const int lane = lane_id();
+    const int r = lane >> 4, c4 = lane & 15;
+    const int col0 = slice * kWave;
+    const bool act = col0 + 4 * c4 < width;
+    const int col = act ? col0 + 4 * c4 : col0;
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (MODE != kModeReduce && init)
+        cur = *reinterpret_cast<const float4v *>(dst_row + col);
+    const float4v total = coop_tree_sum(grads, perm, maps, n, lr, s, 0, len, width, col, w, s_part);
     float4v nv;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -468,6 +479,66 @@ __device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, boo
     if (w == 0 && r == 0 && act)
         __builtin_nontemporal_store(nv, reinterpret_cast<float4v *>(dst_row + col));
     __syncthreads();   // s_part is reused by the next slice of this workgroup
+}
+
+// The same for ONE CHUNK of 256 occurrences of a run that several workgroups share (apply_listed_kernel, runs beyond
+// kTreeChunk occurrences in tolerance mode): chunk `ch` of `nch` sums its occurrences with the tree, hands the sum over
+// through the L2 (`sc1` store, drained; a relaxed device-scope counter per (key, slice)), and whichever workgroup arrives last
+// adds the chunk sums in chunk order -- ((t0 + t1) + t2) + ... -- and applies them: the order of ha_qstep's chunked workgroup
+// items (csrc/qstep.hip q_coop_r3), oracle/qstep_model.py tree_coop_chunked.  part = nch x 64 floats of this (key, slice),
+// ctr = its counter (zero at the start of the launch).  Nobody waits for anybody.
+constexpr int kTreeChunk = 256;
+template <int MODE>
+__device__ __forceinline__ void coop_chunk_tree(float *__restrict__ dst_row, bool init, const float *__restrict__ grads,
+                                                const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr,
+                                                int s, int len, int width, int slice, int w, float *s_part,
+                                                float *__restrict__ part, uint32_t *__restrict__ ctr, int ch, int nch) {
+    const int lane = lane_id();
+    const int r = lane >> 4, c4 = lane & 15;
+    const int col0 = slice * kWave;
+    const bool act = col0 + 4 * c4 < width;
+    const int col = act ? col0 + 4 * c4 : col0;
+    const int lo = ch * kTreeChunk, hi = min(len, lo + kTreeChunk);
+    float4v total = coop_tree_sum(grads, perm, maps, n, lr, s, lo, hi, width, col, w, s_part);
+    if (w == 0 && r == 0)
+        st4_sc1(part + static_cast<size_t>(ch) * 64 + 4 * c4, total);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();      // (the partials in s_part have been read by every wave)
+    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_part);
+    if (threadIdx.x == 0)      // (relaxed: the sum went through the L2 and was drained)
+        *s_flag = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = *s_flag + 1u == static_cast<uint32_t>(nch);
+    __syncthreads();
+    if (!last)
+        return;
+    auto add4 = [](float4v x, float4v y) {
+        return float4v{__fadd_rn(x[0], y[0]), __fadd_rn(x[1], y[1]), __fadd_rn(x[2], y[2]), __fadd_rn(x[3], y[3])};
+    };
+    if (w != 0)
+        return;       // (one wave adds the chunk sums up; no barrier follows inside this call)
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (MODE != kModeReduce && init)
+        cur = *reinterpret_cast<const float4v *>(dst_row + col);
+    const float *pp = part + 4 * c4;
+    float4v tot{0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < nch; j0 += 4) {
+        float4v q0 = ld4_sc1_async(pp + static_cast<size_t>(min(j0, nch - 1)) * 64);
+        float4v q1 = ld4_sc1_async(pp + static_cast<size_t>(min(j0 + 1, nch - 1)) * 64);
+        float4v q2 = ld4_sc1_async(pp + static_cast<size_t>(min(j0 + 2, nch - 1)) * 64);
+        float4v q3 = ld4_sc1_async(pp + static_cast<size_t>(min(j0 + 3, nch - 1)) * 64);
+        wait_loads(q0, q1, q2, q3);
+        tot = j0 == 0 ? q0 : add4(tot, q0);
+        if (j0 + 1 < nch) tot = add4(tot, q1);
+        if (j0 + 2 < nch) tot = add4(tot, q2);
+        if (j0 + 3 < nch) tot = add4(tot, q3);
+    }
+    float4v nv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        nv[k] = MODE == kModeSgd ? __fsub_rn(cur[k], tot[k]) : __fadd_rn(cur[k], tot[k]);
+    if (r == 0 && act)
+        __builtin_nontemporal_store(nv, reinterpret_cast<float4v *>(dst_row + col));
 }
 
 // The worker part of a long run [s, s+len): this workgroup owns the 64-column slices j, j+workers, ...

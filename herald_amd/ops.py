@@ -85,11 +85,13 @@ class DLStreamHolder:
 def set_tolerance_mode(on):
     """Process-wide (include/herald_amd.h, ha_set_tolerance_mode): runs of 64 or more occurrences of a key are applied
     as `row - tree_sum(lr * g)` in a fixed order (within BASELINE.json's 1e-5 on accumulated gradients) instead of the
-    reference's serial chain; shorter runs stay bit-exact.  Default off.  Returns the previous setting."""
+    reference's serial chain; shorter runs stay bit-exact.  Default off.  on = 2 (or "chunked"): also cut runs beyond 256
+    occurrences into chunks in the applies of a finished plan (header).  Returns the previous setting (False / True / 2)."""
     L = _lib.load()
-    prev = bool(L.ha_get_tolerance_mode())
-    check(L.ha_set_tolerance_mode(1 if on else 0), "ha_set_tolerance_mode")
-    return prev
+    prev = int(L.ha_get_tolerance_mode())
+    mode = 2 if on in (2, "chunked") and on is not True else (1 if on else 0)
+    check(L.ha_set_tolerance_mode(mode), "ha_set_tolerance_mode")
+    return 2 if prev == 2 else bool(prev)
 
 
 # ---- forward gather ----------------------------------------------------------------------------------

@@ -181,6 +181,11 @@ int cpu_SGDOptimizerSparseUpdate(DLArrayHandle param,
  * occurrence (cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:65-72), bit for bit.  On: runs of 64 or more
  * occurrences of one key in a batch are applied as `row - tree_sum(lr * g)` in a fixed, deterministic order -- within
  * the 1e-5 relative BASELINE.json's north star allows for accumulated fp32 gradients; shorter runs stay bit-exact.
+ * on = 1: one sixteen-wave tree over the whole run (oracle/qstep_model.py tree_coop).  on = 2: as 1, and the applies of a
+ * FINISHED plan of 36,865 .. 2^20 ids on rows of up to 256 floats cut a run beyond 256 occurrences into chunks of 256 that
+ * workgroups of their own sum, the chunk sums added in chunk order (tree_coop_chunked; the rule: listed_chunking) -- for
+ * batches in which one key's run is the launch's critical path; at BASELINE configs[2]'s shape it is not (34.5 us without,
+ * 35.8 with), so 1 is what bench.py's N>1 leg uses.  ha_get_tolerance_mode returns 0 / 1 / 2.
  * Read at launch time by ha_sgd_apply*, ha_push_apply*, ha_dedup_reduce*, ha_apply_mapped, ha_shard_serve_push and the
  * entry points built on them (not by ha_sgd_push_pull_* / ha_step_*, which are bit-exact throughout, nor by
  * ha_qstep_* / ha_qapply, which have their own documented tolerance classes). */

@@ -96,13 +96,32 @@ def tree_coop_chunked(rows_g, lr):
     return tot
 
 
-def sgd_sparse_update(table, ids, grads, lr, long_min=LONG_MIN, coop_min=COOP_MIN, mode="sgd"):
+def listed_chunking(ids, width):
+    """Whether the plan-driven applies of a FINISHED plan cut runs beyond 256 occurrences into chunks in tolerance mode 2
+    (ha_set_tolerance_mode(2); csrc/scatter.hip apply_listed_kernel / apply_chunk_plan_kernel; the conditions are functions of the batch alone): a batch of
+    36,865 .. 2^20 ids, rows of at most 256 floats (a multiple of 4), at most 2,040 keys with 48+ occurrences, at least one run
+    beyond 256, and the chunk sums fit the plan's 2 n scratch words."""
+    ids = np.asarray(ids).reshape(-1)
+    n = ids.size
+    if not (36864 < n <= (1 << 20)) or width % 4 or width > 256:
+        return False
+    _, cnt = np.unique(ids, return_counts=True)
+    listed = cnt[cnt >= 48]
+    if listed.size == 0 or listed.size > 2040:
+        return False
+    total = int(np.where((listed >= 64) & (listed > CHUNK), (listed + CHUNK - 1) // CHUNK, 1).sum())
+    nslice = (width + 63) // 64
+    return total > listed.size and total * nslice * 64 <= 2 * n
+
+
+def sgd_sparse_update(table, ids, grads, lr, long_min=LONG_MIN, coop_min=COOP_MIN, mode="sgd", chunked=False):
     """In place: table after one ha_qstep apply of (ids, grads).  ids: integer array (keys beyond the table are
     ignored, as by the library).
 
     long_min=None, coop_min=64 restates the library's TOLERANCE MODE (ha_set_tolerance_mode, csrc/scatter_dev.h
     coop_slice_tree: the same sixteen-wave tree as ha_qstep's workgroup items, from 64 occurrences -- over the WHOLE run,
-    where ha_qstep cuts runs beyond 256 occurrences into chunks --; everything shorter is the serial chain).  mode: "sgd" row - sum(lr*g) / chain row -= lr*g;  "push" row + sum(g) (lr is ignored: the
+    where ha_qstep cuts runs beyond 256 occurrences into chunks; chunked=True: so do the applies of a finished plan when
+    listed_chunking(ids, width) holds --; everything shorter is the serial chain).  mode: "sgd" row - sum(lr*g) / chain row -= lr*g;  "push" row + sum(g) (lr is ignored: the
     library reduces from 0 in order, then adds once -- ha_push_apply);  the reduced rows of ha_dedup_reduce_scaled
     are mode="push" on a zero table with grads pre-scaled."""
     ids = np.asarray(ids).reshape(-1).astype(np.int64)
@@ -120,7 +139,7 @@ def sgd_sparse_update(table, ids, grads, lr, long_min=LONG_MIN, coop_min=COOP_MI
         c = e - s
         if c >= coop_min:
             # (the tolerance mode of the plan-driven applies -- long_min None -- keeps one tree for the whole run)
-            t = tree_coop(grads[occ], one) if long_min is None else tree_coop_chunked(grads[occ], one)
+            t = tree_coop(grads[occ], one) if long_min is None and not chunked else tree_coop_chunked(grads[occ], one)
         elif long_min is not None and c >= long_min:
             t = tree_long(grads[occ], one)
         else:

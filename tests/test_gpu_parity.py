@@ -173,7 +173,8 @@ def test_sort_ahead_pipeline_equals_the_step_by_step_calls(dev, n, block, finish
 @pytest.mark.parametrize("n,width", [(40000, 128), (106496, 64)])
 def test_sgd_apply_on_a_finished_plan_maps_waves_to_unique_keys(dev, n, width):
     """ha_sgd_apply_finished above 36,864 ids: bit-equal to the CPU chain, and -- with the tolerance mode on -- bit-equal
-    to ha_sgd_apply's fixed-order trees (one tree shape, whichever way the waves are mapped)."""
+    to ha_sgd_apply's fixed-order trees (one tree shape, whichever way the waves are mapped); tolerance mode 2: the finished
+    plan's apply sums runs beyond 256 occurrences in chunks of 256 (oracle/qstep_model.py listed_chunking)."""
     rng = np.random.default_rng(n + width)
     rows = 300000
     ids = synth.as_f32_ids(rng.integers(0, rows, size=n))
@@ -195,6 +196,16 @@ def test_sgd_apply_on_a_finished_plan_maps_waves_to_unique_keys(dev, n, width):
         ops.sgd_apply(b, plan, _dev(grads, dev), 0.3)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+        ops.set_tolerance_mode(2)
+        from oracle import qstep_model
+        assert qstep_model.listed_chunking(ids, width)
+        a, b = _dev(table, dev), _dev(table, dev)
+        ops.sgd_apply(a, plan, _dev(grads, dev), 0.3, finished=True)
+        ops.sgd_apply(b, plan, _dev(grads, dev), 0.3)
+        torch.cuda.synchronize()
+        for got, chunked in ((a, True), (b, False)):
+            want = qstep_model.sgd_sparse_update(table.copy(), ids, grads, 0.3, long_min=None, coop_min=64, chunked=chunked)
+            np.testing.assert_array_equal(got.cpu().numpy(), want)
     finally:
         ops.set_tolerance_mode(False)
 

@@ -32,8 +32,8 @@ def _batch(rows, n, runs, seed):
     return ids
 
 
-def _check(table0, got, ids, grads, lr, mode="sgd"):
-    model = qstep_model.sgd_sparse_update(table0.copy(), ids, grads, lr, long_min=None, coop_min=64, mode=mode)
+def _check(table0, got, ids, grads, lr, mode="sgd", chunked=False):
+    model = qstep_model.sgd_sparse_update(table0.copy(), ids, grads, lr, long_min=None, coop_min=64, mode=mode, chunked=chunked)
     np.testing.assert_array_equal(got, model)                                   # the tree, bit for bit
     exact = qstep_model.sgd_sparse_update(table0.copy(), ids, grads, lr, long_min=None, coop_min=1 << 30, mode=mode)
     tol = qstep_model.tolerance(ids, grads, lr if mode == "sgd" else 1.0, table0.shape[0], tree_min=64)
@@ -68,10 +68,16 @@ def test_small_batches_tree_from_64(dev, tolerance, rows, width, n, runs, entry)
     assert _check(table, t.cpu().numpy(), ids, grads, LR) >= 1       # the tree really ran: some row differs from the chain
 
 
+@pytest.fixture()
+def tolerance_chunked():
+    prev = ops.set_tolerance_mode(2)
+    yield
+    ops.set_tolerance_mode(prev)
+
+
 @pytest.mark.parametrize("width", [128, 64])
-def test_large_batch_by_unique_key(dev, tolerance, width):
-    """BASELINE configs[2]'s per-GPU shape (106,496 ids, 2,250-occurrence runs of the 3-category field): the by-unique
-    apply of a finished plan."""
+def test_large_batch_by_unique_key_one_tree_per_run(dev, tolerance, width):
+    """Mode 1 at BASELINE configs[2]'s per-GPU shape: one tree over every long run."""
     rows = 200000
     ids = (synth.criteo_batch(4096, 5).reshape(-1) % rows).astype(np.float32)
     n = ids.size
@@ -83,6 +89,50 @@ def test_large_batch_by_unique_key(dev, tolerance, width):
     ops.sgd_apply_finish(t, plan, torch.from_numpy(grads).to(dev), LR)
     torch.cuda.synchronize()
     assert _check(table, t.cpu().numpy(), ids, grads, LR) >= 1
+
+
+@pytest.mark.parametrize("width", [128, 64, 256, 512])
+def test_large_batch_by_unique_key(dev, tolerance_chunked, width):
+    """Mode 2 at BASELINE configs[2]'s per-GPU shape (106,496 ids, 2,250-occurrence runs of the 3-category field, one key 4,096
+    times): the by-unique apply of a finished plan.  Rows of up to 256 floats: runs beyond 256 occurrences are cut into chunks of 256 that
+    workgroups of their own sum (oracle: tree_coop_chunked); 512: one tree over the whole run, as before."""
+    rows = 200000
+    ids = (synth.criteo_batch(4096, 5).reshape(-1) % rows).astype(np.float32)
+    n = ids.size
+    rng = np.random.default_rng(2)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    t = torch.from_numpy(table.copy()).to(dev)
+    plan = ops.IndexPlan(n, dev).sort(torch.from_numpy(ids).to(dev))
+    ops.sgd_apply_finish(t, plan, torch.from_numpy(grads).to(dev), LR)
+    torch.cuda.synchronize()
+    chunked = qstep_model.listed_chunking(ids, width)
+    assert chunked == (width <= 256)
+    assert _check(table, t.cpu().numpy(), ids, grads, LR, chunked=chunked) >= 1
+    # the same plan applied again (the chunk counters start from zero in every launch), and the push / reduce forms
+    t2 = torch.from_numpy(table.copy()).to(dev)
+    ops.sgd_apply(t2, plan, torch.from_numpy(grads).to(dev), LR, finished=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t2.cpu().numpy(), t.cpu().numpy())
+
+
+@pytest.mark.parametrize("n,width,runs", [(40000, 128, (257, 256, 513, 3000, 64, 48, 47)), (50000, 32, (9000, 300)),
+                                          (37000, 256, (1024, 1025)), (60000, 128, ())])
+def test_chunked_runs_of_a_finished_plan(dev, tolerance_chunked, n, width, runs):
+    """The chunking rule at its edges (256 / 257 occurrences, a partial last chunk, no long run at all), sgd and push."""
+    rows = 90000
+    ids = _batch(rows, n, runs, seed=n)
+    rng = np.random.default_rng(4)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    grads = rng.standard_normal((n, width), dtype=np.float32)
+    d_ids, d_g = torch.from_numpy(ids).to(dev), torch.from_numpy(grads).to(dev)
+    chunked = qstep_model.listed_chunking(ids, width)
+    assert chunked == any(r > 256 for r in runs)
+    plan = ops.IndexPlan(n, dev).build(d_ids)
+    t = torch.from_numpy(table.copy()).to(dev)
+    ops.sgd_apply(t, plan, d_g, LR, finished=True)
+    torch.cuda.synchronize()
+    _check(table, t.cpu().numpy(), ids, grads, LR, chunked=chunked)
 
 
 def test_push_and_reduce_modes(dev, tolerance):
