@@ -253,13 +253,26 @@ def cpu_baseline(args, ids_host):
 def cache_tier(args, table, ids_dev, out, grad, dev):
     """Secondary line: the same batches through the HET cache tier of configs[1] (LRU, limit 0.1 x rows,
     bound 100; cache.cc:60-257): one embedding_lookup + one embedding_update per batch, keys and
-    gradients resident in HBM.  Runs last (it takes the table over as its server store)."""
+    gradients resident in HBM.  Runs last (it takes the table over as its server store).  The other two policies of the
+    reference (lfu_cache.cc, lfuopt_cache.cc) are timed the same way beside it (`lfu`, `lfuopt`)."""
+    res = _cache_tier_policy(args, table, ids_dev, out, grad, dev, "LRU")
+    if not args.no_cache_prefill and os.environ.get("HA_CACHE_BENCH_OTHER_POLICIES", "1") == "1":
+        for pol in ("LFU", "LFUOpt"):
+            try:
+                r = _cache_tier_policy(args, table, ids_dev, out, grad, dev, pol)
+                res[pol.lower()] = {k: r[k] for k in ("us_per_step", "value", "unique_miss_rate", "evicted_lines_per_step", "cache_full")}
+            except Exception as e:      # a secondary figure never takes the line down
+                res[pol.lower()] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
+def _cache_tier_policy(args, table, ids_dev, out, grad, dev, policy):
     from herald_amd import cache as hcache
     n = ids_dev.shape[1]
     versions = torch.zeros(args.rows, dtype=torch.int64, device=dev)
     hcache.register_table(0, table, versions)
     limit = int(0.1 * args.rows)
-    c = hcache.CacheSparseTable(limit, args.rows, args.width, 0, "LRU", bound=100, max_batch=n, device=dev)
+    c = hcache.CacheSparseTable(limit, args.rows, args.width, 0, policy, bound=100, max_batch=n, device=dev)
     nb = min(ids_dev.shape[0], 512)
     prefilled = 0
     if not args.no_cache_prefill:
@@ -325,7 +338,7 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
     pushes = [r for r in c.perf if r["type"] == "Push"]
     miss = float(np.mean([r["num_miss"] / max(r["num_unique"], 1) for r in pulls])) if pulls else None
     evict = float(np.mean([r["num_evict"] for r in pushes])) if pushes else None
-    return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps, "policy": "LRU",
+    return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps, "policy": policy,
             "limit_rows": limit, "bound": 100, "steps": steps, "unique_miss_rate": miss,
             "evicted_lines_per_step": evict, "cache_full": bool(pulls and pulls[-1]["is_full"]),
             "prefilled_keys": prefilled,

@@ -116,6 +116,10 @@ struct Cache {
     int32_t *uslot_b, *data_row_b;
     uint32_t *flag_b, *rank_b;
     uint8_t *pushflag_b;
+    // LFU / LFUOpt on a large cache: the argmin over the resident lines by kScanParts workgroups (cache_scan_victim_part_kernel),
+    // a partial result each; the single-workgroup bookkeeping then reduces these instead of walking every line
+    unsigned long long *scan_key;
+    int32_t *scan_slot;
     // store (the "server"): rows [row_start, row_start + store_rows) of the global table
     float *table;
     long long *srv_ver;
@@ -460,24 +464,41 @@ __global__ __launch_bounds__(256) void cache_dest_kernel(Cache c, const int32_t 
 // this batch evicts the oldest line of the lowest non-empty bucket (lfu_cache.cc:31-42,
 // lfuopt_cache.cc:48-60): argmin (use, stamp) over the resident, non-stored lines.  Single workgroup;
 // exits immediately when the situation does not arise.
-__device__ __forceinline__ void cache_scan_victim_body(CacheCtl *ctl, const Cache &c) {
+constexpr int kScanParts = 512;            // workgroups of the partial scan
+constexpr long long kScanWideFrom = 1 << 16;   // caches of at least this many slots use it
+__device__ __forceinline__ bool cache_scan_needed(const CacheCtl *ctl, const Cache &c) {
+    return c.policy != kLRU && ctl->M > 0 && ctl->n_base == 0 && ctl->size >= c.limit;
+}
+// `parts`: the partial results of cache_scan_victim_part_kernel, launched between the bookkeeping of this call and the
+// kernel this runs in (same condition, same lines -- nothing touches freq / stamp / state in between)
+__device__ __forceinline__ void cache_scan_victim_body(CacheCtl *ctl, const Cache &c, bool parts = false) {
     __shared__ unsigned long long s_best[16];
     __shared__ int s_slot[16];
     if (threadIdx.x == 0)
         ctl->scan_victim = -1;
-    const bool needed = c.policy != kLRU && ctl->M > 0 && ctl->n_base == 0 && ctl->size >= c.limit;
+    const bool needed = cache_scan_needed(ctl, c);
     if (!needed)
         return;
     unsigned long long best = ~0ull;
     int slot = -1;
-    for (long long s = threadIdx.x; s < c.S; s += 1024) {
-        if (c.line[s].state != kResident)
-            continue;
-        // stamps stay far below 2^48
-        const unsigned long long k = (static_cast<unsigned long long>(c.line[s].freq) << 48) | c.line[s].stamp;
-        if (k < best) {
-            best = k;
-            slot = static_cast<int>(s);
+    if (parts) {
+        for (int b = threadIdx.x; b < kScanParts; b += 1024) {
+            const unsigned long long k = c.scan_key[b];
+            if (k < best) {      // (ties cannot happen: stamps are unique)
+                best = k;
+                slot = c.scan_slot[b];
+            }
+        }
+    } else {
+        for (long long s = threadIdx.x; s < c.S; s += 1024) {
+            if (c.line[s].state != kResident)
+                continue;
+            // stamps stay far below 2^48
+            const unsigned long long k = (static_cast<unsigned long long>(c.line[s].freq) << 48) | c.line[s].stamp;
+            if (k < best) {
+                best = k;
+                slot = static_cast<int>(s);
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -502,8 +523,49 @@ __device__ __forceinline__ void cache_scan_victim_body(CacheCtl *ctl, const Cach
         ctl->scan_victim = s_slot[0];
     }
 }
-__global__ __launch_bounds__(1024) void cache_scan_victim_kernel(CacheCtl *ctl, Cache c) {
-    cache_scan_victim_body(ctl, c);
+__global__ __launch_bounds__(1024) void cache_scan_victim_kernel(CacheCtl *ctl, Cache c, int parts) {
+    cache_scan_victim_body(ctl, c, parts != 0);
+}
+// the same argmin, every workgroup over its stripe of the lines: scan_key / scan_slot [kScanParts]
+__global__ __launch_bounds__(1024) void cache_scan_victim_part_kernel(const CacheCtl *ctl, Cache c) {
+    __shared__ unsigned long long s_best[16];
+    __shared__ int s_slot[16];
+    if (!cache_scan_needed(ctl, c))
+        return;
+    unsigned long long best = ~0ull;
+    int slot = -1;
+    for (long long s = static_cast<long long>(blockIdx.x) * 1024 + threadIdx.x; s < c.S; s += static_cast<long long>(gridDim.x) * 1024) {
+        const LineMeta m = c.line[s];
+        if (m.state != kResident)
+            continue;
+        const unsigned long long k = (static_cast<unsigned long long>(m.freq) << 48) | m.stamp;
+        if (k < best) {
+            best = k;
+            slot = static_cast<int>(s);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_down(best, o, 64);
+        const int os = __shfl_down(slot, o, 64);
+        if (ob < best) {
+            best = ob;
+            slot = os;
+        }
+    }
+    if (lane_id() == 0) {
+        s_best[threadIdx.x >> 6] = best;
+        s_slot[threadIdx.x >> 6] = slot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k)
+            if (s_best[k] < s_best[0]) {
+                s_best[0] = s_best[k];
+                s_slot[0] = s_slot[k];
+            }
+        c.scan_key[blockIdx.x] = s_best[0];
+        c.scan_slot[blockIdx.x] = s_slot[0];
+    }
 }
 
 // batchedInsert of the misses (sorted order) + LRU eviction + log compaction.  Single workgroup.
@@ -1158,7 +1220,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_rows_kernel(
         CacheCtl *ctl = c.ctl;
         CACHE_PH(8);
         if (c.policy != kLRU) {
-            cache_scan_victim_body(ctl, c);
+            cache_scan_victim_body(ctl, c, c.S >= kScanWideFrom);      // (the partial scan ran in front of this launch)
             __syncthreads();
         }
         cache_insert_evict_body(ctl, c, uniq, c.flag, c.rank, bypass ? 0 : 1, evict_block - 1);
@@ -1858,6 +1920,8 @@ extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
     CACHE_ALLOC(flag_b, max_batch);
     CACHE_ALLOC(rank_b, max_batch);
     CACHE_ALLOC(pushflag_b, max_batch);
+    CACHE_ALLOC(scan_key, kScanParts);
+    CACHE_ALLOC(scan_slot, kScanParts);
     if (ok) {
         char *p = nullptr;
         if (dmalloc(&p, plan_bytes) == 0) {
@@ -2093,6 +2157,8 @@ extern "C" int ha_cache_lookup_finish(ha_cache *h, int64_t n, float *dest, ha_st
     cache_mark(h, kTTransfer, s);        // between ha_cache_lookup_begin's last launch and here: the exchange with the owners
     hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
                        (long long)n, c.bypass ? 1 : 0, 1, evb);
+    if (n > 0 && evb && c.policy != kLRU && c.S >= kScanWideFrom)      // LFU / LFUOpt: the victim scan of a large cache, in parallel
+        hipLaunchKernelGGL(cache_scan_victim_part_kernel, dim3(kScanParts), dim3(1024), 0, s, c.ctl, c);
     if (n > 0) {
         const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + (evb ? 1 : 0);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0);
@@ -2274,6 +2340,8 @@ static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_
         hipLaunchKernelGGL(cache_lookup_book_kernel, dim3(1), dim3(1024), 0, s, c, p.hdr, p.uniq,
                            (long long)n, c.bypass ? 1 : 0, probed, evb);
     cache_mark(h, kTLookup, s);
+    if (n > 0 && evb && c.policy != kLRU && c.S >= kScanWideFrom)      // LFU / LFUOpt: the victim scan of a large cache, in parallel
+        hipLaunchKernelGGL(cache_scan_victim_part_kernel, dim3(kScanParts), dim3(1024), 0, s, c.ctl, c);
     if (n > 0) {
         const unsigned blocks = static_cast<unsigned>((n + 15) / 16) + (evb ? 1 : 0);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0) &&
@@ -2462,8 +2530,12 @@ static int push_pull_finish(ha_cache *h, int64_t n_pull, float *dest, int64_t n_
     if (n_pull > 0)
         hipLaunchKernelGGL(cache_dest_kernel, CACHE_GRID(n_pull * c.width), b, 0, s, cb, pp.inverse,
                            (long long)n_pull, dest);
-    if (c.policy != kLRU)
-        hipLaunchKernelGGL(cache_scan_victim_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c);
+    if (c.policy != kLRU) {
+        const int parts = c.S >= kScanWideFrom ? 1 : 0;
+        if (parts)
+            hipLaunchKernelGGL(cache_scan_victim_part_kernel, dim3(kScanParts), dim3(1024), 0, s, c.ctl, c);
+        hipLaunchKernelGGL(cache_scan_victim_kernel, dim3(1), dim3(1024), 0, s, c.ctl, c, parts);
+    }
     hipLaunchKernelGGL(cache_insert_evict_kernel, dim3(1), dim3(1024), 0, s, c.ctl, cb, pp.uniq, cb.flag,
                        cb.rank, c.bypass ? 0 : 1);
     hipLaunchKernelGGL(cache_report_pull_kernel, dim3(1), dim3(1), 0, s, c.ctl, c, (long long)n_pull);

@@ -190,6 +190,15 @@ def test_block_sort_ahead_insists_on_the_announced_order(dev):
         gpu.prefetch_keys_batch(ks * 6)      # more than 16 batches
 
 
+@pytest.mark.parametrize("policy", ["lfu", "lfuopt"])
+def test_lfu_large_cache_parallel_victim_scan(dev, policy):
+    """A cache of 65,536+ slots, full, its lowest use bucket empty at the start of a lookup: the oldest line of the lowest
+    non-empty bucket (lfu_cache.cc:31-42, lfuopt_cache.cc:48-60) is found by 512 workgroups in a launch of their own
+    (cache_scan_victim_part_kernel) instead of one workgroup walking every line -- same trace as the model."""
+    _run_trace(dev, limit=66000, rows=400000, width=4, n=1024, steps=110, pull_bound=2, push_bound=2, zipf=False, seed=31,
+               policy=policy, check_every=55, same=False)
+
+
 def test_lfu_trace_with_the_next_batch_sorted_ahead_criteo_width(dev):
     _run_trace(dev, limit=300, rows=5000, width=128, n=416, steps=10, pull_bound=2, push_bound=2, seed=22, policy="lfu",
                check_every=3, ahead=True)
