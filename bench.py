@@ -169,7 +169,10 @@ def make_batches(args, rank, world):
     ids = np.empty((nb, args.batch * args.fields), dtype=np.float32)
     uniq = np.empty(nb, dtype=np.int64)
     for b in range(nb):
-        raw = synth.criteo_batch(args.batch, step=b * world + rank, rows=args.rows, nfields=args.fields)
+        # (HA_BENCH_SAME_BATCH=1, tools/l2_affinity_bound.sh only: every step names batch 0 -- an experiment, not the workload;
+        # the line says so in config.same_batch)
+        same = os.environ.get("HA_BENCH_SAME_BATCH") == "1"
+        raw = synth.criteo_batch(args.batch, step=0 if same else b * world + rank, rows=args.rows, nfields=args.fields)
         f = synth.as_f32_ids(raw).reshape(-1)
         # float32 rounding above 2^24 can land on `rows` itself; the reference would read out of
         # bounds there, the synthetic stream keeps ids inside the table
@@ -878,6 +881,7 @@ def main():
                                   "one launch: apply(k), rows of k+1 forwarded / copied, finish(k+2), sort(k+3)" if ahead2 else
                                   "one launch: apply(k) beside lookup(k+1)" if one else "two launches"),
                    "ids_per_step": n, "unique_per_step": u_mean, "distinct_batches": nb,
+                   "same_batch": os.environ.get("HA_BENCH_SAME_BATCH") == "1",
                    "grad_and_out_buffers": nbuf,
                    "launches_per_step": args.launches,
                    "lookahead_batches": (pipe.LOOKAHEAD if queue else 3 if ahead2 else 1),
