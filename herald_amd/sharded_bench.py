@@ -161,14 +161,17 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
                # reduce + server add in one launch (gradient row per position, one read-modify-write per unique row)
                "push_alone": n * (4 * d + 4) + u_mean * 8 * d}
         if fs.sized:
-            alg["expand"] = n * (8 * d + 4)
+            # (the lookup reads a table row per UNIQUE key from HBM -- the other occurrences hit a cache -- and writes one per
+            # position; the per-occurrence count n * 8d overstated it: 1.3 "of peak" at d = 128 in round 4's line)
+            alg["expand"] = n * (4 * d + 4) + u_mean * 4 * d
         traffic = _pmc_traffic(batch, width)
         kernels = {}
         for name, us in times.items():
             short = name.split(" ")[0]
+            tr = traffic.get(short)
             kernels[name] = {"us": us, "algorithmic_bytes": alg[short], "GBps": alg[short] / us / 1e3,
                              "frac_of_hbm_peak": alg[short] / us / 1e3 / HBM_PEAK_GBS,
-                             "traffic": traffic.get(short)}
+                             "traffic": tr, "frac_by_traffic": (tr / us / 1e3 / HBM_PEAK_GBS) if tr else None}
     links = min(world - 1, 7)
     xgmi_gbs = float(xg[0].item()) / el / 1e9
     return {
