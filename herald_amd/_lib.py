@@ -227,6 +227,7 @@ def _declare(L):
         "ha_qplan_batch_u64ids": [vp, vp, vp, i64, vp],
         "ha_qqueue_batch": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp],
         "ha_stream_gate": [vp, vp],
+        "ha_debug_occupy": [i64, i64, i64, i64, vp],
         "ha_qapply": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, vp],
         "ha_qapply_sized": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, vp],
         "ha_qapply_steps": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -276,6 +276,29 @@ __global__ void stream_gate_kernel(const volatile uint32_t *flag) {
 }
 }  // namespace ha
 
+// Measurement aid (tools/occupy_ab.py): `wgs` workgroups of `threads` threads and `lds_bytes` of LDS each that do nothing
+// but hold their wave slots for `ticks` ticks of the 100 MHz clock -- what a latency-bound preparation kernel takes from a
+// launch running beside it, without its memory traffic.
+namespace ha {
+__global__ void occupy_kernel(unsigned long long ticks) {
+    extern __shared__ uint32_t s_occ[];
+    if (threadIdx.x == 0)
+        s_occ[0] = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(16);
+}
+}  // namespace ha
+extern "C" int ha_debug_occupy(int64_t wgs, int64_t threads, int64_t lds_bytes, int64_t ticks, ha_stream_t stream) {
+    HA_REQUIRE(wgs >= 1 && threads >= 64 && threads <= 1024 && lds_bytes >= 4 && lds_bytes <= 160 * 1024 && ticks >= 0,
+               "ha_debug_occupy: bad arguments");
+    HA_ALLOW_LDS(ha::occupy_kernel, static_cast<size_t>(lds_bytes));
+    hipLaunchKernelGGL(ha::occupy_kernel, dim3(static_cast<unsigned>(wgs)), dim3(static_cast<unsigned>(threads)),
+                       static_cast<size_t>(lds_bytes), ha::as_stream(stream), static_cast<unsigned long long>(ticks));
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ha_stream_gate(const uint32_t *flag, ha_stream_t stream) {
     HA_REQUIRE(flag != nullptr, "ha_stream_gate: null flag");
     hipLaunchKernelGGL(ha::stream_gate_kernel, dim3(1), dim3(1), 0, ha::as_stream(stream), flag);

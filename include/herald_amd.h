@@ -733,6 +733,9 @@ int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *ahead_ids, i
  * behind the gate and release it once everything is queued (bench.py: the device must not wait for the host inside a
  * short timed region). */
 int ha_stream_gate(const uint32_t *flag, ha_stream_t stream);
+/* measurement aid (tools/occupy_ab.py): `wgs` workgroups of `threads` threads with `lds_bytes` of LDS that hold their wave
+ * slots for `ticks` x 10 ns and touch no memory */
+int ha_debug_occupy(int64_t wgs, int64_t threads, int64_t lds_bytes, int64_t ticks, ha_stream_t stream);
 
 /* ha_sgd_apply_finish that also warms the memory-side cache for the NEXT batch: waves that have no
  * medium / long-run work (more than half of them) end by touching the table row that position p of
