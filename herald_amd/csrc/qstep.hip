@@ -60,6 +60,9 @@ constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers 
 // 12.0 us per launch, tools/floor_bench.hip: the items spread evenly over the compute units), the real launch does not: its
 // 2,000 small workgroups take 1.3 us to start instead of 0.6, and same-box A/B has 12.5 us per step for 1024 threads against
 // 12.75 for 512 and 12.9 for 256 (profiles/r04/ab_workgroup_size.txt).
+#ifndef QV_ITEM_PLAIN
+#define QV_ITEM_PLAIN 0
+#endif
 #ifndef QV_GOLD
 #define QV_GOLD 1
 #endif
@@ -620,7 +623,13 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
         hi.y = fs;
         hi.z = o01;
         hi.w = o23;
+#if QV_ITEM_PLAIN      // A/B only (tools/ab_trees.sh): plain stores, as round 4 had them -- the epoch tag may then overtake the items
+        uint4 *dd = reinterpret_cast<uint4 *>(dst + j);
+        dd[0] = lo;
+        dd[1] = hi;
+#else
         q_st_item(dst + j, lo, hi);      // (through the L2, like everything an apply launch may read before this one ends)
+#endif
     }
 }
 // (helper below) an item's two 16-byte halves, written THROUGH the L2 (`sc1`): once the writing thread's `s_waitcnt
@@ -2027,7 +2036,9 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
     // A spanning launch that knows the queue's item counts looks at the words BESIDE its first item (one trip) instead.
     bool checked = a.epoch == 0u;
     const bool coop = b < a.ncoop;
-    const bool counts_known = (a.width > 128 || SPAN) && (coop ? a.k_coop != 0u : (a.k_wave != 0u && a.k_copy != 0u));
+    // (compile-time for one launch per step: with the peek / poll code in its item loops the kernel spills 52 scalar registers
+    // instead of 12 and a step takes 0.4 us longer -- and known counts bought it nothing)
+    const bool counts_known = SPAN && (coop ? a.k_coop != 0u : (a.k_wave != 0u && a.k_copy != 0u));
     if (!checked && !counts_known) {
         bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;     // (read with the header's counts)
         if (SPAN) {
@@ -2056,13 +2067,13 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
     }
     if (coop) {
         role = 0;
-        const uint32_t n = min(a.k_coop ? a.k_coop - 1u : a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
+        const uint32_t n = min((SPAN && a.k_coop) ? a.k_coop - 1u : a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
         for (uint32_t e = static_cast<uint32_t>(b); e < n && alive; e += static_cast<uint32_t>(a.ncoop)) {
             QEp ep{0u, 0u, 0u, 0u};
-            if (!checked)
+            if (SPAN && !checked)
                 ep = q_epoch_peek(a);
             QItem it = q_load(a.qcoop + e, a.width);
-            if (!checked) {
+            if (SPAN && !checked) {
                 if (!q_epoch_match(a, ep)) {
                     if (!q_epoch_poll(a, d)) {
                         q_raise(d);
@@ -2084,8 +2095,8 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
     } else {
         b -= a.ncoop;
         role = 3;
-        const uint32_t n0 = min(a.k_wave ? a.k_wave - 1u : a.qh->n_wave, a.cap_wave),
-                       n = n0 + min(a.k_copy ? a.k_copy - 1u : a.qh->n_copy, a.cap_copy);
+        const uint32_t n0 = min((SPAN && a.k_wave) ? a.k_wave - 1u : a.qh->n_wave, a.cap_wave),
+                       n = n0 + min((SPAN && a.k_copy) ? a.k_copy - 1u : a.qh->n_copy, a.cap_copy);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
         if (!SPAN && a.width <= 128) {
@@ -2150,7 +2161,7 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
             const QEntry *src = cp ? a.qcopy + er : a.qwave + er;
 #endif
             QEp ep{0u, 0u, 0u, 0u};
-            if (!checked)
+            if (SPAN && !checked)
                 ep = q_epoch_peek(a);
             QSpec sp{0u, 0u, 1u};
             if (SPAN && d.wait_a) {
@@ -2162,7 +2173,7 @@ __device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b
                     sp.done = __hip_atomic_load(d.done_pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             QItem it = q_load(src, a.width);
-            if (!checked) {
+            if (SPAN && !checked) {
                 if (!q_epoch_match(a, ep)) {
                     if (!q_epoch_poll(a, d)) {
                         q_raise(d);

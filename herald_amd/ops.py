@@ -788,7 +788,7 @@ class QueueStepPipeline:
     chain bit for bit.  `plan_of(j)` holds the unique keys / counts / inverse / occurrence lists of batch j with the
     unique keys in hash-slot order (not np.unique's order) once its block has been prepared."""
 
-    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True, sync="events"):
+    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True, sync="events", span=False):
         """sync: how the preparation stream and the caller's stream are ordered when overlap is on.
         "events" (default): an event record and an event wait on the caller's stream at every block start -- safe for any
         caller (ids produced by work queued on the caller's stream, steps captured into hipGraphs).
@@ -814,6 +814,10 @@ class QueueStepPipeline:
                 check(-1, "ha_qstep_init")
         self.capacity = max(int(capacity), 1)
         self.overlap = bool(overlap)
+        # span=True: the queues also carry what a launch that SPANS several steps waits for (ha_qapply_span: per-key flag
+        # words; their builder joins three batches instead of two -- 42 against 29 us per launch beside the steps, which costs
+        # the default one-launch-per-step form 0.5 us per step: off unless asked for)
+        self.span_queues = bool(span) or os.environ.get("HA_QSPAN_QUEUES") == "1"
         if sync not in ("events", "flags"):
             raise ValueError("sync must be 'events' or 'flags'")
         self.sync = sync if self.overlap else "events"
@@ -1027,8 +1031,11 @@ class QueueStepPipeline:
                       "ha_qbig_queue_batch")
             else:
                 # (with the plan of the batch BEFORE the one a step applies: its copy items' dependencies, ha_qapply_span)
-                pb = (vp * cnt)(*[pp[(j - 1) % NP] if nget(j - 1, 0) else None for j in steps])
-                nb_ = (i64 * cnt)(*[nget(j - 1, 0) for j in steps])
+                if self.span_queues:
+                    pb = (vp * cnt)(*[pp[(j - 1) % NP] if nget(j - 1, 0) else None for j in steps])
+                    nb_ = (i64 * cnt)(*[nget(j - 1, 0) for j in steps])
+                else:
+                    pb = nb_ = None
                 check(L.ha_qqueue_batch_span(rows, width, pb, nb_, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
                       "ha_qqueue_batch")
         if self.overlap and not flags:
@@ -1241,6 +1248,8 @@ class QueueStepPipeline:
 
     # ---- several steps by ONE launch -----------------------------------------------------------------------------------
     def _span_ok(self, c0, cnt):
+        if not self.span_queues:
+            raise RuntimeError("QueueStepPipeline: spanning launches need the queues built for them (span=True)")
         if self.SPAN_MAX < 2:
             raise RuntimeError("QueueStepPipeline: spanning launches need overlap=True, block >= 2 and batches of at most %d ids"
                                % qstep_max_ids())

@@ -522,7 +522,7 @@ def _run_stream_span(dev, table0, batches, grads, lr, block, span, sync="events"
     drift = {}
     table = _dev(table0, dev)
     cap = max(max(b.size for b in batches), 1)
-    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=True, block=block, sync=sync)
+    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=True, block=block, sync=sync, span=(how == "span"))
     assert pipe.SPAN_MAX >= 2
     step_many = pipe.step_span if how == "span" else pipe.step_gated
     L = pipe.LOOKAHEAD
@@ -683,7 +683,7 @@ def test_qspan_equals_step_by_step_bits_and_rejects_misuse(dev):
     res = []
     for span in (0, 8):
         table = _dev(table0, dev)
-        pipe = ops.QueueStepPipeline(table, batches[0].size, 0.05, overlap=True, block=8, sync="flags")
+        pipe = ops.QueueStepPipeline(table, batches[0].size, 0.05, overlap=True, block=8, sync="flags", span=bool(span))
         L = pipe.LOOKAHEAD
         d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
         d_g = [_dev(g, dev) for g in grads]
@@ -704,10 +704,15 @@ def test_qspan_equals_step_by_step_bits_and_rejects_misuse(dev):
     assert len(res[0][1]) == len(res[1][1]) == steps
     for a, b in zip(res[0][1], res[1][1]):
         np.testing.assert_array_equal(a, b)
-    pipe = ops.QueueStepPipeline(_dev(table0, dev), batches[0].size, 0.05, overlap=True, block=4)
+    plain = ops.QueueStepPipeline(_dev(table0, dev), batches[0].size, 0.05, overlap=True, block=4)
     d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
-    pipe.start(d_ids[:pipe.LOOKAHEAD])
+    plain.start(d_ids[:plain.LOOKAHEAD])
     g = [_dev(grads[i], dev) for i in range(6)]
+    with pytest.raises(RuntimeError):
+        plain.step_span(g[:2])                     # queues without the spanning launch's flag words (span=False)
+    plain.close()
+    pipe = ops.QueueStepPipeline(_dev(table0, dev), batches[0].size, 0.05, overlap=True, block=4, span=True)
+    pipe.start(d_ids[:pipe.LOOKAHEAD])
     with pytest.raises(ValueError):
         pipe.step_span(g[:5])                      # longer than the block
     pipe.step(g[0], None)

@@ -49,6 +49,7 @@ done
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/laia_stats -o laia -- python3 $R/tools/laia_profile.py > $O/laia_stats.log 2>&1
 f=$(find $O/laia_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/summary/laia_kernel_stats.csv
+python3 $R/tools/laia_gaps.py $O/laia_stats > $O/summary/laia_gaps_final.txt 2>/dev/null
 cd $R
 # ---- the sharded step at world size 1 (the N>1 code path on one GPU) ----
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29633 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 HA_FORCE_SHARDED=1

@@ -22,7 +22,7 @@ for b in range(nsteps + 4 * BK):
     ids.append(torch.from_numpy(f).to(dev))
 grads = [torch.randn((n, width), device=dev) for _ in range(24)]
 outs = [torch.empty((n, width), device=dev) for _ in range(24)]
-pipe = ops.QueueStepPipeline(table, n, 1e-6, block=BK)
+pipe = ops.QueueStepPipeline(table, n, 1e-6, block=BK, span=True)
 LA = pipe.LOOKAHEAD
 WPW = int(os.environ.get("WPW", "16"))
 NBLK = 520 * (16 // WPW) * SPAN

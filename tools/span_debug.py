@@ -22,7 +22,7 @@ d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 for rep in range(reps):
     table = d(table0)
     model_t = table0.copy()
-    pipe = ops.QueueStepPipeline(table, batches[0].size, 0.01, overlap=True, block=block, sync=sync)
+    pipe = ops.QueueStepPipeline(table, batches[0].size, 0.01, overlap=True, block=block, sync=sync, span=True)
     L = pipe.LOOKAHEAD
     d_ids = [d(b.astype(np.float32)) for b in batches]
     d_g = [d(g) for g in grads]
