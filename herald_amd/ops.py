@@ -1038,13 +1038,19 @@ class QueueStepPipeline:
                     pb = nb_ = None
                 check(L.ha_qqueue_batch_span(rows, width, pb, nb_, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
                       "ha_qqueue_batch")
-        if self.overlap and not flags:
+        gated = getattr(self, "aux", None) is not None
+        if self.overlap and (not flags or gated):
+            # (gated launches under sync="flags" as well: two launches of polling workgroups fill every wave slot of the chip, and
+            # a queue builder that has not started yet then finds no compute unit to start on -- the steps of a block are
+            # enqueued behind the event of their queues' builder, on both streams)
             ev = self._event()
             ev.record(s)
             self._ev_side[b] = ev
             ready = self._ev_side.pop(b - 1, None)
             if ready is not None:
                 main.wait_event(ready)
+                if gated:
+                    self.aux.wait_event(ready)
                 self._ev_pool.append(ready)
 
     def _event(self):
@@ -1398,10 +1404,15 @@ class QueueStepPipeline:
             raise ValueError("steps %d..%d cross a block boundary (block = %d): the block's done-event rides on the LAST "
                              "launch of a call" % (c0, c0 + cnt - 1, self.block))
 
-    def _aux(self):
+    def _aux(self, main=None):
         if getattr(self, "aux", None) is None:
             self.aux = torch.cuda.Stream(device=self.device)
             self._gate_prev = None          # (step, queue) of the last gated launch: the chain the next one waits on
+            if self.overlap:
+                # the queues enqueued for building so far (no event was kept for them under sync="flags"): both streams behind them
+                main = main if main is not None else torch.cuda.current_stream(self.device)
+                self.aux.wait_stream(self.side)
+                main.wait_stream(self.side)
         return self.aux
 
     def join(self, stream=None):
@@ -1428,7 +1439,7 @@ class QueueStepPipeline:
         if len(out_list) != cnt:
             raise ValueError("one output per step")
         main = stream if stream is not None else torch.cuda.current_stream(self.device)
-        aux = self._aux()
+        aux = self._aux(main)
         flags = self.sync == "flags"
         if flags and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("QueueStepPipeline(sync='flags'): steps cannot be captured into a hipGraph (use sync='events')")
@@ -1486,7 +1497,7 @@ class QueueStepPipeline:
         if self.sync != "flags":
             raise RuntimeError("apply_gated_call needs sync='flags' (the block's done-event orders the second stream; use "
                                "apply_gated with sync='events')")
-        aux = self._aux()
+        aux = self._aux(stream)
         vp, i64 = ctypes.c_void_p, ctypes.c_int64
         pc = (vp * cnt)(*[self._plan_ptr[(c0 + i) % self.NPLAN] for i in range(cnt)])
         pn = (vp * cnt)(*[self._plan_ptr[(c0 + i + 1) % self.NPLAN] for i in range(cnt)])
