@@ -550,7 +550,7 @@ def main():
             # for (no event record / wait between two steps); hipGraph replays (--graph-steps > 1) keep the event pair
             qsync = "events" if (args.graph_steps > 1 or os.environ.get("HA_QSYNC") == "events") else "flags"
             pipe = ops.QueueStepPipeline(table, n, LR, block=args.queue_block, overlap=not args.queue_serial, sync=qsync,
-                                         span=bool(args.span))
+                                         span=bool(args.span or args.gated))
             LA, Bk = pipe.LOOKAHEAD, pipe.block
             G = Bk                       # graphs are cut at block starts (the side work is enqueued between them)
             ids_rows = [ids_dev[i] for i in range(nb)]        # the batches as tensors of their own, sliced once

@@ -225,6 +225,8 @@ def _declare(L):
         "ha_qprep_u64ids": [i64, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp],
         "ha_qplan_batch_f32ids": [vp, vp, vp, i64, vp],
         "ha_qplan_batch_u64ids": [vp, vp, vp, i64, vp],
+        "ha_qplan_batch_span_f32ids": [vp, vp, vp, i64, vp],
+        "ha_qplan_batch_span_u64ids": [vp, vp, vp, i64, vp],
         "ha_qqueue_batch": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp],
         "ha_stream_gate": [vp, vp],
         "ha_debug_occupy": [i64, i64, i64, i64, vp],

@@ -60,6 +60,15 @@ constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers 
 // 12.0 us per launch, tools/floor_bench.hip: the items spread evenly over the compute units), the real launch does not: its
 // 2,000 small workgroups take 1.3 us to start instead of 0.6, and same-box A/B has 12.5 us per step for 1024 threads against
 // 12.75 for 512 and 12.9 for 256 (profiles/r04/ab_workgroup_size.txt).
+#ifndef QV_AB_LDS_EXTRA
+#define QV_AB_LDS_EXTRA 1024      // A/B: LDS bytes of qapply_kernel behind its 4 KB of partial sums (it uses none of them)
+#endif
+#ifndef QV_AB_NODEPZERO
+#define QV_AB_NODEPZERO 0         // A/B: the plan kernel leaves the 2 n dependency words of its plan alone
+#endif
+#ifndef QV_AB_BUILDER_R4
+#define QV_AB_BUILDER_R4 0        // A/B (UNSAFE): the queue builder as round 4 had it -- plain item stores, no gate / done words
+#endif
 #ifndef QV_ITEM_PLAIN
 #define QV_ITEM_PLAIN 0
 #endif
@@ -488,7 +497,7 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         p.hdr->reserved[kOrderFlagWord] = 0;
         p.seg[U] = n;
     }
-    if (!BUCKET && p.dep != nullptr)      // the dependency counters of a launch that spans several steps start at zero
+    if (!QV_AB_NODEPZERO && !BUCKET && p.dep != nullptr)      // the dependency counters of a launch that spans several steps start at zero
         for (int i = tid; i < 2 * n; i += NT)
             p.dep[i] = 0u;
     __syncthreads();
@@ -623,7 +632,7 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
         hi.y = fs;
         hi.z = o01;
         hi.w = o23;
-#if QV_ITEM_PLAIN      // A/B only (tools/ab_trees.sh): plain stores, as round 4 had them -- the epoch tag may then overtake the items
+#if QV_ITEM_PLAIN || QV_AB_BUILDER_R4      // A/B only (tools/ab_trees.sh): plain stores, as round 4 had them -- the epoch tag may then overtake the items
         uint4 *dd = reinterpret_cast<uint4 *>(dst + j);
         dd[0] = lo;
         dd[1] = hi;
@@ -842,7 +851,7 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
                                            unsigned long long *ph = nullptr, uint32_t *mirror = nullptr,
                                            const uint32_t st_base = 0, const uint32_t fs_base = 0,
                                            const uint32_t epoch = 0, const uint32_t wide_parts = 0, const bool signal = true,
-                                           const QPlan *pb = nullptr) {
+                                           const QPlan *pb = nullptr, const bool extras = true) {
     constexpr int TS = 1 << TBITS;
     const int tid = static_cast<int>(threadIdx.x) & (NT - 1), w = tid >> 6;
     q_phase(ph, 0);
@@ -968,12 +977,13 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             b.s += bw;
             b.g += bc;
         }
-        if (!WIDE && tid == 0) {
+        // (extras: what spanning and gated launches keep in the queue -- their "finished" counters and the gate words)
+        if (!QV_AB_BUILDER_R4 && extras && !WIDE && tid == 0) {
             __hip_atomic_store(&bqh->wg_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&bqh->abort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&bqh->all_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!WIDE && tid < kQGates) {      // (the gate words follow the flag words: queue_layout)
+        if (!QV_AB_BUILDER_R4 && extras && !WIDE && tid < kQGates) {      // (the gate words follow the flag words: queue_layout)
             uint32_t *gate = reinterpret_cast<uint32_t *>(
                 reinterpret_cast<char *>(bqh) +
                 ((sizeof(QHeader) + (static_cast<size_t>(bcap_coop) + bcap_wave + bcap_copy) * sizeof(QEntry) +
@@ -2451,13 +2461,14 @@ struct QJoinBatch {
     uint32_t *mirror[kQJoinBatch];   // optional pinned host words per step: {wave items, workgroup items, copy items} + 1
     uint32_t epoch[kQJoinBatch];     // the tag the finished queue carries (0: none asked for)
     unsigned long long *ph;     // development aid: phase stamps of workgroups 0 and 1
+    int extras;                 // 1: the queues are for spanning / gated launches (flag, gate and "finished" words)
 };
 __global__ __launch_bounds__(1024, 4) void qqueue_kernel(const QJoinBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const int i = blockIdx.x >> 1, part = blockIdx.x & 1;
     qjoin_body(b.pa[i], b.pg[i], b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave,
                b.cap_copy, s_dyn, b.lds_bytes, part, (i == 0 && b.ph) ? b.ph + 8 * part : nullptr, b.mirror[i], 0u, 0u,
-               b.epoch[i], 0u, true, &b.pb[i]);
+               b.epoch[i], 0u, true, &b.pb[i], b.extras != 0);
 }
 
 // One wave-instruction's LDS atomics on one address: are the lanes served in ascending lane order?  Four collision
@@ -2523,7 +2534,7 @@ static int lds_atomics_lane_ordered() {
 
 template <typename IdT>
 static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *plans, int64_t count, hipStream_t stream,
-                       unsigned long long *ph = nullptr) {
+                       unsigned long long *ph = nullptr, bool span = false) {
     HA_REQUIRE(count >= 0 && (count == 0 || (ids && n && plans)), "ha_qplan_batch: null pointer");
     static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
     if (lds_allowed.run([]() -> int {
@@ -2545,6 +2556,8 @@ static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *pla
             HA_REQUIRE(ids[k] && plans[k], "ha_qplan_batch: null pointer (batch %lld)", (long long)k);
             b.ids[b.count] = ids[k];
             b.plan[b.count] = qplan(plans[k], n[k]);
+            if (!span)      // (the 2 n dependency words of a plan are a spanning launch's: not cleared -- 0.1 us per step -- otherwise)
+                b.plan[b.count].dep = nullptr;
             lds = lds > qsort_lds_bytes(static_cast<int>(n[k])) ? lds : qsort_lds_bytes(static_cast<int>(n[k]));
             ++b.count;
         }
@@ -2562,7 +2575,8 @@ static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *pla
 static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
                         const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
                         hipStream_t stream, unsigned long long *ph = nullptr, uint32_t *const *counts_host = nullptr,
-                        const uint32_t *epochs = nullptr, void *const *plans_b = nullptr, const int64_t *n_b = nullptr) {
+                        const uint32_t *epochs = nullptr, void *const *plans_b = nullptr, const int64_t *n_b = nullptr,
+                        bool extras = false) {
     HA_REQUIRE(rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 && width <= (1 << 20),
                "ha_qqueue_batch: rows of a multiple of 4 floats");
     HA_REQUIRE(count >= 0 && (count == 0 || (plans_a && n_a && plans_g && n_g && queues)), "ha_qqueue_batch: null pointer");
@@ -2579,6 +2593,7 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
         b.rows = static_cast<uint64_t>(rows);
         b.width = static_cast<int>(width);
         b.ph = k0 == 0 ? ph : nullptr;
+        b.extras = extras ? 1 : 0;
         size_t lds = 0;
         for (int64_t k = k0; k < count && b.count < kQJoinBatch; ++k) {
             HA_REQUIRE(n_a[k] >= 0 && n_g[k] >= 0 && n_a[k] <= queue_n_cap && n_g[k] <= queue_n_cap,
@@ -2591,10 +2606,9 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
             b.pa[i] = qplan(plans_a[k], n_a[k]);
             b.pg[i] = qplan(plans_g[k], n_g[k]);
             b.pb[i] = qplan((plans_b && n_b && n_g[k] > 0) ? plans_b[k] : nullptr, (plans_b && n_b && n_g[k] > 0) ? n_b[k] : 0);
-            if (plans_b == nullptr) {
-                // not for a spanning launch (ha_qqueue_batch_span passes the array, even if all of its entries are null): no flag
-                // words in the queue, no dependency words in the plans -- two scattered stores per key that made the builder
-                // a third slower beside the steps (43 against 31 us per launch)
+            if (!extras) {
+                // not for a spanning / gated launch (ha_qqueue_batch_span): no flag words in the queue, no dependency words in
+                // the plans -- two scattered stores per key that made the builder a third slower beside the steps
                 b.pa[i].dep = nullptr;
                 b.pg[i].dep = nullptr;
             }
@@ -2716,10 +2730,10 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     if (done != nullptr)
         // the event completes with THIS launch (the dispatch packet's own completion signal): no packet of its own on the
         // stream -- an event record between two launches of a stream costs what a short kernel costs
-        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 1024, stream,
+        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + QV_AB_LDS_EXTRA, stream,
                               nullptr, done, 0, a);
     else
-        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, a);
+        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + QV_AB_LDS_EXTRA, stream, a);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -3376,6 +3390,15 @@ extern "C" int ha_qplan_batch_u64ids(const uint64_t *const *ids, const int64_t *
                                      ha_stream_t stream) {
     return qplan_batch<uint64_t>(ids, n, plans, count, as_stream(stream));
 }
+// the plans of batches whose queues ha_qqueue_batch_span builds (a spanning launch's dependency words are cleared)
+extern "C" int ha_qplan_batch_span_f32ids(const float *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                                          ha_stream_t stream) {
+    return qplan_batch<float>(ids, n, plans, count, as_stream(stream), nullptr, true);
+}
+extern "C" int ha_qplan_batch_span_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                                          ha_stream_t stream) {
+    return qplan_batch<uint64_t>(ids, n, plans, count, as_stream(stream), nullptr, true);
+}
 extern "C" int ha_qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a,
                                void *const *plans_g, const int64_t *n_g, void *const *queues, int64_t queue_n_cap,
                                int64_t count, ha_stream_t stream) {
@@ -3527,7 +3550,7 @@ extern "C" int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *pl
                                     int64_t queue_n_cap, int64_t count, uint32_t *const *counts_host, const uint32_t *epochs,
                                     ha_stream_t stream) {
     return qqueue_batch(rows, width, plans_a, n_a, plans_g, n_g, queues, queue_n_cap, count, as_stream(stream), nullptr,
-                        counts_host, epochs, plans_b, n_b);
+                        counts_host, epochs, plans_b, n_b, true);
 }
 extern "C" int ha_qapply_steps_counts(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                                       void *const *plan_cur, const int64_t *n_cur, const float *const *grads,

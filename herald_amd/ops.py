@@ -814,9 +814,9 @@ class QueueStepPipeline:
                 check(-1, "ha_qstep_init")
         self.capacity = max(int(capacity), 1)
         self.overlap = bool(overlap)
-        # span=True: the queues also carry what a launch that SPANS several steps waits for (ha_qapply_span: per-key flag
-        # words; their builder joins three batches instead of two -- 42 against 29 us per launch beside the steps, which costs
-        # the default one-launch-per-step form 0.5 us per step: off unless asked for)
+        # span=True: plans and queues also carry what spanning and gated launches need (ha_qapply_span, ha_qapply_gated_steps:
+        # per-key flag and dependency words, gate words, "finished" counters; the builder then joins three batches instead of
+        # two) -- together 0.2-0.3 us per step for the default one-launch-per-step form: off unless asked for
         self.span_queues = bool(span) or os.environ.get("HA_QSPAN_QUEUES") == "1"
         if sync not in ("events", "flags"):
             raise ValueError("sync must be 'events' or 'flags'")
@@ -995,7 +995,8 @@ class QueueStepPipeline:
                 check(getattr(L, "ha_qbig_plan_batch_" + kind)(ids_arr, n_arr, pl_arr, self.capacity, cnt, sp),
                       "ha_qbig_plan_batch")
             else:
-                check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
+                check(getattr(L, ("ha_qplan_batch_span_" if self.span_queues else "ha_qplan_batch_") + kind)(
+                    ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
             for j, _, m in lst:
                 pl = self.plans[j % self.NPLAN]
                 pl.n = m
@@ -1034,10 +1035,11 @@ class QueueStepPipeline:
                 if self.span_queues:
                     pb = (vp * cnt)(*[pp[(j - 1) % NP] if nget(j - 1, 0) else None for j in steps])
                     nb_ = (i64 * cnt)(*[nget(j - 1, 0) for j in steps])
+                    check(L.ha_qqueue_batch_span(rows, width, pb, nb_, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
+                          "ha_qqueue_batch")
                 else:
-                    pb = nb_ = None
-                check(L.ha_qqueue_batch_span(rows, width, pb, nb_, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
-                      "ha_qqueue_batch")
+                    check(L.ha_qqueue_batch_epochs(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
+                          "ha_qqueue_batch")
         gated = getattr(self, "aux", None) is not None
         if self.overlap and (not flags or gated):
             # (gated launches under sync="flags" as well: two launches of polling workgroups fill every wave slot of the chip, and
@@ -1395,6 +1397,8 @@ class QueueStepPipeline:
 
     # ---- one launch per step, GATED: two streams, consecutive launches overlap ---------------------------------------------
     def _gated_ok(self, c0, cnt):
+        if not self.span_queues:
+            raise RuntimeError("QueueStepPipeline: gated launches need the queues built for them (span=True)")
         if not self.overlap or self.wide:
             raise RuntimeError("QueueStepPipeline: gated launches need overlap=True and batches of at most %d ids"
                                % qstep_max_ids())

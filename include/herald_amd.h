@@ -525,6 +525,11 @@ int ha_qplan_batch_f32ids(const float *const *ids, const int64_t *n, void *const
                           ha_stream_t stream);
 int ha_qplan_batch_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count,
                           ha_stream_t stream);
+/* the same for batches whose queues ha_qqueue_batch_span builds (spanning / gated launches): the 2 n dependency words of
+ * every plan are cleared as well */
+int ha_qplan_batch_span_f32ids(const float *const *ids, const int64_t *n, void *const *plans, int64_t count, ha_stream_t stream);
+int ha_qplan_batch_span_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                               ha_stream_t stream);
 int ha_qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
                     const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count, ha_stream_t stream);
 int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,

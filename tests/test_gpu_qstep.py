@@ -522,7 +522,7 @@ def _run_stream_span(dev, table0, batches, grads, lr, block, span, sync="events"
     drift = {}
     table = _dev(table0, dev)
     cap = max(max(b.size for b in batches), 1)
-    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=True, block=block, sync=sync, span=(how == "span"))
+    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=True, block=block, sync=sync, span=True)
     assert pipe.SPAN_MAX >= 2
     step_many = pipe.step_span if how == "span" else pipe.step_gated
     L = pipe.LOOKAHEAD
