@@ -79,8 +79,38 @@ def load(build_if_missing=True):
     except OSError as e:
         raise HeraldAmdError("cannot load %s: %s" % (LIB_PATH, e))
     _declare(L)
+    # the engine of the launches that overlap consecutive steps (csrc/qspan.hip) exports its copies of the work-queue entry
+    # points under the prefix spn_: same prototypes
+    for name, fn in list(vars(L).items()):
+        if name.startswith(("ha_q", "ha_debug_q")):
+            try:
+                twin = getattr(L, "spn_" + name)
+            except AttributeError:
+                continue
+            twin.restype = fn.restype
+            twin.argtypes = fn.argtypes
     _lib = L
     return L
+
+
+class SpanView:
+    """The library as a pipeline built for spanning / gated launches sees it (QueueStepPipeline(span=True)): every work-queue
+    entry point resolves to the copy in csrc/qspan.hip (spn_ha_q*), everything else to the library itself."""
+
+    def __init__(self, L):
+        self.__dict__["_L"] = L
+
+    def __getattr__(self, name):
+        L = self.__dict__["_L"]
+        if name.startswith(("ha_q", "ha_debug_q")):
+            try:
+                fn = getattr(L, "spn_" + name)
+            except AttributeError:
+                fn = getattr(L, name)
+        else:
+            fn = getattr(L, name)
+        self.__dict__[name] = fn
+        return fn
 
 
 def check(rc, what=""):

@@ -46,16 +46,61 @@
 // deterministic tree sum instead -- within the 1e-5 relative the north star allows for accumulated gradients
 // (tests/test_gpu_qstep.py holds both: bit-exact below 16 occurrences, 1e-5 above).  Callers that need the serial
 // chain for every run length use ha_step_* / ha_sgd_push_pull_*.
-// NOTE (round 5): this file is the one-launch-per-step engine and the wide path as round 4 left them, plus the fixes of round 5
-// that concern them (items leave through the L2 in front of the epoch tag; waits the compiler cannot delete; 128 registers for
-// the whole-workgroup wide join; any workgroup that times out raises the error word).  The launches that OVERLAP consecutive
-// steps (ha_qapply_span, ha_qapply_gated_steps) and the plans / queues built for them live in csrc/qspan.hip, a copy of this
-// engine with their machinery in it: carrying that machinery here cost the default path 0.3-0.6 us per step
-// (docs/EXPERIMENTS.md, round 5 section 10).
 #include <hip/hip_ext.h>
 
 #include "plan_dev.h"
 #include "gather_dev.h"
+
+// ---- csrc/qspan.hip: the work-queue engine WITH the machinery of the launches that overlap consecutive steps (spanning
+// launch, gated launches: DESIGN.md 3g).  A copy of the engine in a namespace of its own: its kernels and its C entry
+// points carry the prefix spn_ (herald_amd.ops.QueueStepPipeline(span=True) binds them), the public names of the overlap
+// modes are re-exported at the end of the file.  csrc/qstep.hip is the default engine (one launch per step, wide path).
+namespace ha_orig = ha;
+#define ha ha_spn
+namespace ha_spn {
+using namespace ha_orig;
+}
+#define ha_debug_qapply spn_ha_debug_qapply
+#define ha_debug_qapply_gated spn_ha_debug_qapply_gated
+#define ha_debug_qapply_span spn_ha_debug_qapply_span
+#define ha_debug_qprep_f32ids spn_ha_debug_qprep_f32ids
+#define ha_event_create spn_ha_event_create
+#define ha_event_destroy spn_ha_event_destroy
+#define ha_event_record spn_ha_event_record
+#define ha_qapply spn_ha_qapply
+#define ha_qapply_gated_steps spn_ha_qapply_gated_steps
+#define ha_qapply_sized spn_ha_qapply_sized
+#define ha_qapply_span spn_ha_qapply_span
+#define ha_qapply_span_max spn_ha_qapply_span_max
+#define ha_qapply_steps spn_ha_qapply_steps
+#define ha_qapply_steps_counts spn_ha_qapply_steps_counts
+#define ha_qapply_steps_sync spn_ha_qapply_steps_sync
+#define ha_qapply_sync spn_ha_qapply_sync
+#define ha_qbig_apply spn_ha_qbig_apply
+#define ha_qbig_buckets spn_ha_qbig_buckets
+#define ha_qbig_max_ids spn_ha_qbig_max_ids
+#define ha_qbig_plan_batch_f32ids spn_ha_qbig_plan_batch_f32ids
+#define ha_qbig_plan_batch_u64ids spn_ha_qbig_plan_batch_u64ids
+#define ha_qbig_plan_bytes spn_ha_qbig_plan_bytes
+#define ha_qbig_plan_view spn_ha_qbig_plan_view
+#define ha_qbig_queue_batch spn_ha_qbig_queue_batch
+#define ha_qplan_batch_f32ids spn_ha_qplan_batch_f32ids
+#define ha_qplan_batch_span_f32ids spn_ha_qplan_batch_span_f32ids
+#define ha_qplan_batch_span_u64ids spn_ha_qplan_batch_span_u64ids
+#define ha_qplan_batch_u64ids spn_ha_qplan_batch_u64ids
+#define ha_qprep_f32ids spn_ha_qprep_f32ids
+#define ha_qprep_u64ids spn_ha_qprep_u64ids
+#define ha_qqueue_batch spn_ha_qqueue_batch
+#define ha_qqueue_batch_counts spn_ha_qqueue_batch_counts
+#define ha_qqueue_batch_epochs spn_ha_qqueue_batch_epochs
+#define ha_qqueue_batch_span spn_ha_qqueue_batch_span
+#define ha_qstep_f32ids spn_ha_qstep_f32ids
+#define ha_qstep_init spn_ha_qstep_init
+#define ha_qstep_max_ids spn_ha_qstep_max_ids
+#define ha_qstep_queue_bytes spn_ha_qstep_queue_bytes
+#define ha_qstep_queue_header spn_ha_qstep_queue_header
+#define ha_qstep_u64ids spn_ha_qstep_u64ids
+#define ha_stream_wait_event spn_ha_stream_wait_event
 
 namespace ha {
 
@@ -66,6 +111,21 @@ constexpr int kQMax = 7168;          // ids per batch: keys + two index buffers 
 // 12.0 us per launch, tools/floor_bench.hip: the items spread evenly over the compute units), the real launch does not: its
 // 2,000 small workgroups take 1.3 us to start instead of 0.6, and same-box A/B has 12.5 us per step for 1024 threads against
 // 12.75 for 512 and 12.9 for 256 (profiles/r04/ab_workgroup_size.txt).
+#ifndef QV_AB_LDS_EXTRA
+#define QV_AB_LDS_EXTRA 1024      // A/B: LDS bytes of qapply_kernel behind its 4 KB of partial sums (it uses none of them)
+#endif
+#ifndef QV_AB_NODEPZERO
+#define QV_AB_NODEPZERO 0         // A/B: the plan kernel leaves the 2 n dependency words of its plan alone
+#endif
+#ifndef QV_AB_BUILDER_WB
+#define QV_AB_BUILDER_WB 0        // A/B: narrow builder -- plain item stores, ONE agent-scope release (L2 write-back) per workgroup
+#endif                            // in front of the epoch tag instead of write-through stores that every thread drains
+#ifndef QV_AB_BUILDER_R4
+#define QV_AB_BUILDER_R4 0        // A/B (UNSAFE): the queue builder as round 4 had it -- plain item stores, no gate / done words
+#endif
+#ifndef QV_ITEM_PLAIN
+#define QV_ITEM_PLAIN 0
+#endif
 #ifndef QV_GOLD
 #define QV_GOLD 1
 #endif
@@ -94,7 +154,14 @@ struct QHeader {
     // of its step checks both words before it reads an item (ha_qapply_steps_sync): callers that order the two streams
     // without a wait on the apply's stream rest on it.  `done`: wide path, bucket workgroups that have finished.
     uint32_t epoch_wave, epoch_copy, done;
-    uint32_t reserved[51];
+    // a launch that SPANS several steps (qapply_span_kernel): workgroups of this step that have finished all their items (a
+    // copy item of step s + 2 reads a row whose last writer may be any earlier step: it waits for this count of step s), and
+    // "somebody gave up waiting" (in the header of the span's first step: every wait of the launch looks at it).  Zeroed
+    // by the queue's builder.
+    uint32_t wg_done, abort;
+    uint32_t all_done;         // 1: this step AND every earlier step of its launch have finished (set by the workgroup of the
+                               // step that finishes last, once the step before carries the word)
+    uint32_t reserved[48];
 };
 static_assert(sizeof(QHeader) == 256, "queue header is one 256-byte line");
 struct QEntry {
@@ -116,9 +183,13 @@ struct QLayout {
     QEntry *coop, *wave, *copy;
     float *part;           // [cap_coop * 64] partial sums of chunked workgroup items (one 64-column slice each)
     uint32_t *pcnt;        // [cap_coop] chunks of a (key, slice) that have delivered theirs (at the index of its chunk 0)
+    uint32_t *aflag;       // [cap_coop + cap_wave] spanning launches: "ready" units of a key, at its first apply item
+    uint32_t *cflag;       // [cap_copy] ... "applied" units of a key the step before names, at its first copy item
+    uint32_t *gate;        // [kQGates * 32] gated launches: "this step has finished", one copy per 128-byte line
     uint32_t cap_coop, cap_wave, cap_copy;
-    size_t bytes;
+    size_t bytes, flag_off, gate_off;
 };
+constexpr int kQGates = 64;            // copies of a step's "finished" word (the waves of the next launch poll one each)
 constexpr uint32_t kQChunk = 256;      // occurrences per workgroup item: a key with more is cut into CHUNKS (QV_GOLD)
 __host__ __device__ __forceinline__ uint32_t q_nchunk(uint32_t c) {
     return (QV_GOLD && c > kQChunk) ? (c + kQChunk - 1u) / kQChunk : 1u;
@@ -141,7 +212,15 @@ static inline QLayout queue_layout(void *ws, int64_t n_cap, int64_t width) {
     const size_t items = sizeof(QHeader) + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * sizeof(QEntry);
     q.part = reinterpret_cast<float *>(b ? b + items : nullptr);
     q.pcnt = reinterpret_cast<uint32_t *>(b ? b + items + static_cast<size_t>(q.cap_coop) * 256 : nullptr);
-    q.bytes = items + static_cast<size_t>(q.cap_coop) * (256 + 4);
+    q.flag_off = items + static_cast<size_t>(q.cap_coop) * (256 + 4);
+    q.aflag = reinterpret_cast<uint32_t *>(b ? b + q.flag_off : nullptr);
+    q.cflag = q.aflag ? q.aflag + q.cap_coop + q.cap_wave : nullptr;
+    q.gate_off = align_up(q.flag_off + (static_cast<size_t>(q.cap_coop) + q.cap_wave + q.cap_copy) * 4, 128);
+    q.gate = reinterpret_cast<uint32_t *>(b ? b + q.gate_off : nullptr);
+    q.bytes = q.gate_off + static_cast<size_t>(kQGates) * 128;
+#ifdef QV_AB_LAYOUT_R4      // A/B only: the queue as long as round 4 had it (no flag / gate words: one launch per step alone)
+    q.bytes = q.flag_off;
+#endif
     return q;
 }
 
@@ -150,6 +229,7 @@ struct QPlan {   // what the roles read / write of a plan workspace
     uint32_t *keys, *sorted, *uniq;
     int32_t *perm, *inverse, *counts, *seg, *upos;
     uint32_t *occ;     // [2 * n]: per group, the first three occurrence indices packed by q_occ_pack (A writes, B reads)
+    uint32_t *dep;     // [2 * n]: {ready, applied} counters of the group whose occurrence list starts at position i, at 2 i
     int n;
 };
 static inline QPlan qplan(void *ws, int64_t n) {
@@ -161,6 +241,7 @@ static inline QPlan qplan(void *ws, int64_t n) {
     q.hdr = p.hdr; q.keys = p.keys; q.sorted = p.sorted; q.uniq = p.uniq;
     q.perm = p.perm; q.inverse = p.inverse; q.counts = p.counts; q.seg = p.seg; q.upos = p.upos;
     q.occ = p.keys_alt;     // keys_alt and perm_alt are adjacent scratch arrays of n words each
+    q.dep = p.dep;
     q.n = static_cast<int>(n);
     return q;
 }
@@ -185,7 +266,14 @@ struct QArgs {
     int ncoop, nworker;
     uint32_t epoch;            // 0: no check; else the tag queue `qh` must carry before an item is read
     uint32_t *err;             // pinned host word raised (8) when the queue never became ready (may be NULL)
-    unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind} per wave
+    unsigned long long *dbg;   // tools/qstep_timeline.py: {start, end, role | xcc << 8, item kind | step << 8} per wave
+    uint32_t step;             // index of the step in its launch (time stamps)
+    // a spanning launch: the queue's item counts + 1 where the caller knows them (0: read the header -- one more trip in
+    // front of the item), and the NEXT step's queue, whose tag is checked as well (this step's items read where that queue's
+    // builder put their keys' items)
+    uint32_t k_wave, k_coop, k_copy;
+    const QHeader *qh_next;
+    uint32_t epoch_next;
 };
 
 // development aid: phase time stamps of the single-workgroup roles (thread 0; ph = nullptr in production)
@@ -466,6 +554,9 @@ __device__ __forceinline__ void qsort_finish_body(const IdT *__restrict__ ids, c
         p.hdr->reserved[kOrderFlagWord] = 0;
         p.seg[U] = n;
     }
+    if (!QV_AB_NODEPZERO && !BUCKET && p.dep != nullptr)      // the dependency counters of a launch that spans several steps start at zero
+        for (int i = tid; i < 2 * n; i += NT)
+            p.dep[i] = 0u;
     __syncthreads();
     q_phase(ph, 6);
     // Outputs.  Every array leaves through LDS so that the global stores are contiguous (scattered 4-byte stores of one
@@ -598,7 +689,13 @@ __device__ __forceinline__ void q_emit_words(QEntry *dst, int kind, uint32_t key
         hi.y = fs;
         hi.z = o01;
         hi.w = o23;
+#if QV_ITEM_PLAIN || QV_AB_BUILDER_R4 || QV_AB_BUILDER_WB      // A/B only (tools/ab_trees.sh): plain stores, as round 4 had them -- the epoch tag may then overtake the items
+        uint4 *dd = reinterpret_cast<uint4 *>(dst + j);
+        dd[0] = lo;
+        dd[1] = hi;
+#else
         q_st_item(dst + j, lo, hi);      // (through the L2, like everything an apply launch may read before this one ends)
+#endif
     }
 }
 // (helper below) an item's two 16-byte halves, written THROUGH the L2 (`sc1`): once the writing thread's `s_waitcnt
@@ -640,10 +737,17 @@ struct QJoin {      // what every part of the join needs (passed by reference to
     QHeader *bqh;
     QEntry *bcoop, *bwave, *bcopy;
     uint32_t *bpcnt;                // the queue's chunk counters (they follow the item regions: queue_layout)
+    uint32_t *baflag, *bcflag;      // ... and its flag words (behind the chunk counters)
     uint32_t bcap_coop, bcap_wave, bcap_copy, per512, per128, per32;
     uint32_t st_base, fs_base;      // wide path: where this bucket's occurrence / destination lists start in the batch's
     uint32_t tid, nt;               // the thread's index in its group of nt threads (the workgroup, or a quarter of it)
     int tbits;                      // the table has 1 << tbits slots
+    // part 1 only: the batch BEFORE the batch to apply (b).  A key only the lookup names is a plain copy of its row -- whose
+    // last writer is step s - 1 when b names it: the copy item then carries where b's group of the key starts (+ 1), and a
+    // launch that spans both steps makes the copy wait for that group's "applied" counter (qapply_span_kernel).
+    QPlan pb;
+    int Ubb;
+    uint32_t *s_tab2, *s_bk2;
 };
 
 // group index of `key` in the table, or 0xFFFFFFFF
@@ -657,13 +761,28 @@ __device__ __forceinline__ uint32_t qjoin_probe(const QJoin &j, uint32_t key) {
         h = (h + 1) & mask;
     }
 }
+__device__ __forceinline__ uint32_t qjoin_probe2(const QJoin &j, uint32_t key) {   // the same in the table of batch b's keys
+    uint32_t h = q_hash(key, j.tbits);
+    const uint32_t mask = (1u << j.tbits) - 1u;
+    for (;;) {
+        const uint32_t e = j.s_tab2[h];
+        if (e == kQTabEmpty || j.s_bk2[e] == key)
+            return e;
+        h = (h + 1) & mask;
+    }
+}
 __device__ __forceinline__ uint32_t qjoin_dest(const QJoin &j, uint32_t e) {   // m | fs << 16 of lookup group e
     if (e == kQTabEmpty)
         return 0u;
     return j.cs_res ? j.s_cs[e] : (static_cast<uint32_t>(j.pg.counts[e]) | (static_cast<uint32_t>(j.pg.seg[e]) << 16));
 }
+// COPY: an item of the copy region (a key only the lookup names); dep_b = where the key's group starts in the batch BEFORE
+// the batch to apply, + 1 (0: that batch does not name it).  Narrow path (the plans carry `dep` words): the item's flag word
+// starts at zero and the plan of its key's batch learns where it is (see QDep).
+template <bool COPY>
 __device__ __forceinline__ QCount qjoin_emit_one(const QJoin &j, QCount b, QEntry *wave, uint32_t cap_wave, uint32_t key,
-                                                 uint32_t c, uint32_t st, uint32_t m, uint32_t fs, uint32_t o01, uint32_t o2) {
+                                                 uint32_t c, uint32_t st, uint32_t m, uint32_t fs, uint32_t o01, uint32_t o2,
+                                                 uint32_t dep_b = 0u) {
     const int kind = q_kind(c, m, key < j.rows);
     if (kind == kQNone)
         return b;
@@ -671,9 +790,21 @@ __device__ __forceinline__ QCount qjoin_emit_one(const QJoin &j, QCount b, QEntr
     const QCount nb = q_count(b, kind, j.per512, j.per128, j.per32, c);
     const uint32_t cnt = (nb.g - b.g) + (nb.l - b.l) + (nb.m - b.m) + (nb.s - b.s);
     // the layout's bound makes the test always true; never write beyond the queue
-    if (at + cnt <= (kind == kQG ? j.bcap_coop : cap_wave))
-        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st + j.st_base, m, fs + j.fs_base, j.width, o01, o2,
-                     kind == kQG ? j.bpcnt + at : nullptr);
+    if (at + cnt <= (kind == kQG ? j.bcap_coop : cap_wave)) {
+        q_emit_words((kind == kQG ? j.bcoop : wave) + at, kind, key, c, st + j.st_base, m, fs + j.fs_base, j.width,
+                     COPY ? dep_b : o01, o2, kind == kQG ? j.bpcnt + at : nullptr);
+        if (kind != kQZ && (COPY ? j.pg.dep : j.pa.dep) != nullptr) {
+            if (COPY) {
+                __hip_atomic_store(j.bcflag + at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dep_b != 0u)
+                    __hip_atomic_store(j.pb.dep + 2u * (dep_b - 1u) + 1u, at + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const uint32_t fidx = kind == kQG ? at : j.bcap_coop + at;
+                __hip_atomic_store(j.baflag + fidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(j.pa.dep + 2u * st, fidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     return nb;
 }
 
@@ -714,8 +845,8 @@ __device__ __forceinline__ QCount qjoin_emit_groups(const QJoin &j, QCount b) {
     for (int r = R0; r < R1; ++r) {
         if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ua) {
             const uint32_t mf = qjoin_dest(j, qjoin_probe(j, ka[r - R0]));
-            b = qjoin_emit_one(j, b, j.bwave, j.bcap_wave, ka[r - R0], cst[r - R0] & 0xFFFFu, cst[r - R0] >> 16,
-                               mf & 0xFFFFu, mf >> 16, o01[r - R0], o2[r - R0]);
+            b = qjoin_emit_one<false>(j, b, j.bwave, j.bcap_wave, ka[r - R0], cst[r - R0] & 0xFFFFu, cst[r - R0] >> 16,
+                                      mf & 0xFFFFu, mf >> 16, o01[r - R0], o2[r - R0]);
         }
     }
     return b;
@@ -750,9 +881,16 @@ __device__ __forceinline__ QCount qjoin_emit_copies(const QJoin &j, QCount b) {
     }
 #pragma unroll
     for (int r = R0; r < R1; ++r)
-        if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty)
-            b = qjoin_emit_one(j, b, j.bcopy, j.bcap_copy, kg[r - R0], 0u, 0u, mfs[r - R0] & 0xFFFFu, mfs[r - R0] >> 16,
-                               0u, 0u);
+        if (static_cast<int>(static_cast<uint32_t>(r) * j.nt + tid) < j.Ug && qjoin_probe(j, kg[r - R0]) == kQTabEmpty) {
+            uint32_t dep = 0u;      // where the key's group starts in batch b's occurrence lists, + 1 (0: b does not name it)
+            if (j.Ubb > 0) {
+                const uint32_t e2 = qjoin_probe2(j, kg[r - R0]);
+                if (e2 != kQTabEmpty)
+                    dep = static_cast<uint32_t>(j.pb.seg[e2]) + 1u;
+            }
+            b = qjoin_emit_one<true>(j, b, j.bcopy, j.bcap_copy, kg[r - R0], 0u, 0u, mfs[r - R0] & 0xFFFFu, mfs[r - R0] >> 16,
+                                     0u, 0u, dep);
+        }
     return b;
 }
 
@@ -769,7 +907,8 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
                                            uint32_t *lds, uint32_t lds_bytes, const int part,
                                            unsigned long long *ph = nullptr, uint32_t *mirror = nullptr,
                                            const uint32_t st_base = 0, const uint32_t fs_base = 0,
-                                           const uint32_t epoch = 0, const uint32_t wide_parts = 0, const bool signal = true) {
+                                           const uint32_t epoch = 0, const uint32_t wide_parts = 0, const bool signal = true,
+                                           const QPlan *pb = nullptr, const bool extras = true) {
     constexpr int TS = 1 << TBITS;
     const int tid = static_cast<int>(threadIdx.x) & (NT - 1), w = tid >> 6;
     q_phase(ph, 0);
@@ -793,6 +932,14 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
     j.s_bk = lds + TS;
     j.s_cs = j.s_bk + j.Ub;
     j.s_w = j.s_bk + (j.cs_res ? 2 * j.Ub : j.Ub);
+    j.Ubb = 0;
+    j.s_tab2 = j.s_bk2 = nullptr;
+    if (!WIDE && part == 1 && pb != nullptr && pb->n > 0) {      // (the launch's LDS holds the second table: qqueue_batch)
+        j.pb = *pb;
+        j.Ubb = uniform(static_cast<int>(pb->hdr->n_unique));
+        j.s_tab2 = j.s_w + 32;
+        j.s_bk2 = j.s_tab2 + TS;
+    }
     j.bqh = bqh;
     j.bcoop = bcoop;
     j.bwave = bwave;
@@ -803,6 +950,8 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
                                            static_cast<size_t>(bcap_coop) * 256);
     j.bcap_wave = bcap_wave;
     j.bcap_copy = bcap_copy;
+    j.baflag = j.bpcnt + bcap_coop;
+    j.bcflag = j.baflag + bcap_coop + bcap_wave;
     j.per512 = (width + 511) / 512;
     j.per128 = (width + 127) / 128;
     j.per32 = (width + 31) / 32;
@@ -815,8 +964,24 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
         if (j.cs_res)
             j.s_cs[y] = static_cast<uint32_t>(pg.counts[y]) | (static_cast<uint32_t>(pg.seg[y]) << 16);
     }
+    if (j.Ubb > 0) {
+        for (int i = tid; i < TS; i += NT)
+            j.s_tab2[i] = kQTabEmpty;
+        for (int y = tid; y < j.Ubb; y += NT)
+            j.s_bk2[y] = j.pb.uniq[y];
+    }
     __syncthreads();
     q_phase(ph, 1);
+    for (int y = tid; y < j.Ubb; y += NT) {
+        uint32_t h = q_hash(j.s_bk2[y], TBITS);
+        for (;;) {
+            uint32_t seen = kQTabEmpty;
+            if (__hip_atomic_compare_exchange_strong(j.s_tab2 + h, &seen, static_cast<uint32_t>(y), __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                break;
+            h = (h + 1) & (TS - 1);
+        }
+    }
     for (int y = tid; y < j.Ub; y += NT) {
         uint32_t h = q_hash(j.s_bk[y], TBITS);
         for (;;) {
@@ -868,6 +1033,20 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
             b.m += bw;
             b.s += bw;
             b.g += bc;
+        }
+        // (extras: what spanning and gated launches keep in the queue -- their "finished" counters and the gate words)
+        if (!QV_AB_BUILDER_R4 && extras && !WIDE && tid == 0) {
+            __hip_atomic_store(&bqh->wg_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&bqh->abort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&bqh->all_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!QV_AB_BUILDER_R4 && extras && !WIDE && tid < kQGates) {      // (the gate words follow the flag words: queue_layout)
+            uint32_t *gate = reinterpret_cast<uint32_t *>(
+                reinterpret_cast<char *>(bqh) +
+                ((sizeof(QHeader) + (static_cast<size_t>(bcap_coop) + bcap_wave + bcap_copy) * sizeof(QEntry) +
+                  static_cast<size_t>(bcap_coop) * (256 + 4) + (static_cast<size_t>(bcap_coop) + bcap_wave + bcap_copy) * 4 +
+                  127) & ~static_cast<size_t>(127)));
+            __hip_atomic_store(gate + 32 * tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!WIDE && tid == 0) {
             bqh->n_wave = min(nL + nM + nS, bcap_wave);
@@ -957,6 +1136,9 @@ __device__ __forceinline__ void qjoin_body(const QPlan pa, const QPlan pg, const
                 __hip_atomic_store(&bqh->n_copy, bqh->n_copy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if QV_AB_BUILDER_WB
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // every thread's items are in this XCD's L2 (barrier above): write it back
+#endif
             __hip_atomic_store(part == 0 ? &bqh->epoch_wave : &bqh->epoch_copy, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (signal &&
                    __hip_atomic_fetch_add(&bqh->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == wide_parts) {
@@ -1065,6 +1247,243 @@ __device__ __forceinline__ V q_ld_grad(const float *p) {
 #endif
 }
 
+// ---- a launch that SPANS several steps (qapply_span_kernel) ---------------------------------------------------------------
+// Consecutive steps touch the same rows: step s applies batch s and writes the rows of batch s + 1, so EVERY key step s + 1
+// applies was read or written by an item of step s, and a key only batch s + 2 names may have been written by any step
+// before.  One launch per step orders them by the launch boundary -- a ramp, a tail that runs at a third of the chip's
+// waves, and the boundary itself, every 12 us.  A launch that spans a block of steps orders them item by item instead.
+// The flags live in the CONSUMER's queue, one word per item, so that a wave fetches its flag BESIDE its item (one trip):
+//   aflag[i]    (queue of step s; i = the first item of a key of batch s: coop items, then wave items)  units of 32
+//               columns of the key's row that step s - 1 has read / written for the last time -- its apply item of the key,
+//               or its copy item, adds them once its row is in memory / once it has read the row: the apply items of the
+//               key in step s wait for all of them, then load the row;
+//   cflag[i]    (queue of step s; i = the first copy item of a key only batch s + 1 names)  units of the row that step
+//               s - 1 has APPLIED: a copy item whose key batch s - 1 names (the builder's second table says so) waits for
+//               all of them;
+//   all_done    (queue header of step s) step s and every earlier step of the launch have finished -- the workgroup whose
+//               add to the header's `wg_done` completes the step's count waits for the word of the step before and sets it:
+//               copy items of step s + 2 wait for it (a row's last writer may be ANY earlier step; two steps back
+//               everything has long finished; the word is fetched beside the item as well).
+// How a producer finds the word: the builder of queue s + 1 writes, into the PLAN of the batch (at the start of the key's
+// occurrence list; ha_qplan_batch_* zeroes both), the index of the key's apply item's word (plan of batch s + 1: dep[2 i])
+// and the index + 1 of its copy item's word (plan of batch s: dep[2 i + 1]); an item of step s reads them beside its
+// gradient rows.  Waits never cross the launch's first step (what is before it is ordered by the stream), signals never
+// its last.  Rows are handed over the way step.hip does it: the writer stores them THROUGH the L2 (`sc1`), drains
+// (`s_waitcnt vmcnt(0)`) and adds to the word with a relaxed device-scope atomic; the reader polls with relaxed
+// device-scope loads and then loads the row with `sc1` loads -- EVERY row load and store of a spanning launch is `sc1` (a
+// row may have been rewritten by another XCD since this one last saw it).  A copy item only READS its row: it signals as
+// soon as the row has arrived.  Gradient rows and the next batch's output rows are never handed over inside a launch.
+// Progress: workgroups are dispatched in grid order and every wait is for an item of an EARLIER step, i.e. of a workgroup
+// with a smaller index; waits are bounded (~2 s) and raise the launch's abort word + the caller's pinned error word.
+struct QDep {
+    const uint32_t *aflag, *cflag;   // this step's queue
+    uint32_t *aflag_n, *cflag_n;     // the next step's queue (null: this is the span's last step -- nothing is signalled)
+    const uint32_t *dep_a, *dep_g;   // plan words of the batch to apply / to look up (see above; null: no such batch)
+    const uint32_t *done_pp;         // all_done of the step two back (null: none inside this launch)
+    const uint32_t *done_p;          // all_done of the step before (null: this is the span's first step)
+    uint32_t done_target;            // workgroups of THIS step
+    uint32_t full;                   // units of a whole row
+    uint32_t wait_a;                 // 0: the span's first step (nothing waits for a flag)
+    uint32_t cap_coop;               // aflag index of wave item e: cap_coop + e
+    uint32_t *abort_w, *err;
+    uint32_t *wacc;                  // time stamps only: LDS words, per wave the 10 ns ticks it spent waiting (else null)
+    // GATED launches (qapply_gated_kernel): ONE condition for every item -- "the step before has finished" -- instead of the
+    // per-key words: gate = this workgroup's copy of that step's word (null: nothing to wait for); gate_out = this step's
+    // own copies, set by the workgroup that finishes last
+    const uint32_t *gate;
+    uint32_t *gate_out;
+    uint32_t *gate_lds;              // two LDS words of the workgroup: [0] a wave polls the gate, [1] 1 = open, 2 = given up
+};
+// MEASUREMENT-ONLY build knobs of the spanning launch (tools/ab_span_variants.sh; every non-default value gives WRONG
+// results -- they exist to price the parts of an item): QV_SPAN_DRAIN = 0 no wait for the row's stores, QV_SPAN_ROWST = 1
+// non-temporal / 2 plain row stores, QV_SPAN_ROWLD = 1 plain row loads, QV_SPAN_NOWAIT = 1 nothing waits, nothing signals.
+#ifndef QV_SPAN_DRAIN
+#define QV_SPAN_DRAIN 1
+#endif
+#ifndef QV_SPAN_ROWST
+#define QV_SPAN_ROWST 0
+#endif
+#ifndef QV_SPAN_ROWLD
+#define QV_SPAN_ROWLD 0
+#endif
+#ifndef QV_SPAN_NOWAIT
+#define QV_SPAN_NOWAIT 0
+#endif
+#ifndef QV_SPAN_NODONE      // 1: copy items do not wait for "the step two back has finished"
+#define QV_SPAN_NODONE 0
+#endif
+#ifndef QV_SPAN_NOSIGLOAD   // 1 (with NOWAIT): the signals' index loads are skipped as well
+#define QV_SPAN_NOSIGLOAD 0
+#endif
+struct QSpec {       // what a wave fetched beside its item, in the same trip (wave-uniform)
+    uint32_t fidx;   // the flag word it guessed (aflag: cap_coop + e; cflag: e) ...
+    uint32_t fval;   // ... and its value
+    uint32_t done;   // all_done of the step two back (1: nothing to wait for)
+};
+__device__ __forceinline__ void q_raise(const QDep &d) {
+    if (lane_id() == 0) {
+        if (d.err != nullptr)
+            __hip_atomic_store(d.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (d.abort_w != nullptr)
+            __hip_atomic_store(d.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// wave-uniform p: true once *p >= target; false if the launch was aborted or the wait gave up (it then raises)
+__device__ __forceinline__ bool q_wait_ge(const uint32_t *p, uint32_t target, const QDep &d) {
+    uint32_t v = uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= target)
+        return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t spin = 1;; ++spin) {
+        if (d.gate != nullptr)
+            __builtin_amdgcn_s_sleep(16);     // (one poller per workgroup, every wave of the launch behind it: ~0.5 us)
+        else
+            __builtin_amdgcn_s_sleep(4);
+        v = uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= target) {
+            if (d.wacc != nullptr && lane_id() == 0)
+                d.wacc[threadIdx.x >> 6] += static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime() - t0);
+            return true;
+        }
+        if ((spin & 31u) == 0u) {
+            if (uniform(__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+                return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {      // 2 s of the 100 MHz counter
+                q_raise(d);
+                return false;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void q_signal(uint32_t *p, uint32_t units) {
+    if (lane_id() == 0)
+        __hip_atomic_fetch_add(p, units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void q_drain() {
+#if QV_SPAN_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// time stamps only: mark k (1..7) of this wave = now, in LDS (the words behind the waves' wait accumulators)
+__device__ __forceinline__ void q_mark(const QDep &d, int k) {
+    if (d.wacc != nullptr && lane_id() == 0)
+        d.wacc[16 + (threadIdx.x >> 6) * 8 + k] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+}
+// `sc1` row accesses the compiler schedules and counts itself: buffer instructions on a descriptor of the row (base = the
+// row's first column of the item, offsets in bytes)
+typedef unsigned int uint4v_ __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2v_ __attribute__((ext_vector_type(2)));
+constexpr int kAuxSc1 = 16;      // cache-policy bits of the gfx940 family: sc0 = 1, nt = 2, sc1 = 16
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t q_row_rsrc(float *row) {
+    return __builtin_amdgcn_make_buffer_rsrc(row, 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float4v q_ld4_sc1(__amdgpu_buffer_rsrc_t r, int col) {
+    const uint4v_ v = __builtin_amdgcn_raw_buffer_load_b128(r, col * 4, 0, QV_SPAN_ROWLD ? 0 : kAuxSc1);
+    float4v f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+__device__ __forceinline__ void q_st4_sc1(__amdgpu_buffer_rsrc_t r, int col, float4v f) {
+    uint4v_ v;
+    __builtin_memcpy(&v, &f, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, col * 4, 0, QV_SPAN_ROWST == 1 ? 2 : QV_SPAN_ROWST == 2 ? 0 : kAuxSc1);
+}
+__device__ __forceinline__ float q_ld1_sc1(__amdgpu_buffer_rsrc_t r, int col) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, col * 4, 0, kAuxSc1));
+}
+__device__ __forceinline__ void q_st2_sc1(__amdgpu_buffer_rsrc_t r, int col, float2v_ f) {
+    uint2v_ v;
+    __builtin_memcpy(&v, &f, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, col * 4, 0, kAuxSc1);
+}
+// What an item waits for before it touches its row.  c > 0: an apply item whose key's flag word is aflag[fi]; c == 0: a copy
+// item, flag word cflag[fi], dep1 != 0 if the step before applies its key.
+//   q_dep_ask    the flag word's value, ASKED FOR as early as possible (the one fetched beside the item if that is the
+//                word, else a load whose result stays in a vector register: no wait here);
+//   q_dep_ready  looks at it (the first use of the value: behind whatever was issued in between);
+//   q_dep_wait   polls (false: give up, touch nothing).
+__device__ __forceinline__ uint32_t q_dep_ask(const QDep &d, const QSpec &sp, uint32_t c, uint32_t fi, uint32_t dep1) {
+    if (d.gate != nullptr)      // (gated launch: the word says 1 once the step before has finished; `full` stands for that)
+        return __hip_atomic_load(d.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? d.full : 0u;
+    if (d.wait_a == 0u || (c == 0u && dep1 == 0u))
+        return d.full;
+    if (fi == sp.fidx)
+        return sp.fval;
+    return __hip_atomic_load((c > 0u ? d.aflag : d.cflag) + fi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool q_dep_ready(const QDep &d, const QSpec &sp, uint32_t c, uint32_t asked) {
+#if QV_SPAN_NOWAIT
+    return true;
+#endif
+    return (c > 0u || sp.done != 0u) && uniform(asked) >= d.full;
+}
+// The gate of a gated launch: EVERY wave of the launch waits for the same event, so one wave per workgroup polls the word
+// in memory (the first to get here) and the others watch an LDS word -- thousands of waves polling memory every few hundred
+// nanoseconds are hundreds of GB/s of requests to a handful of lines, beside the step that is still running.
+__device__ __forceinline__ bool q_gate_wait(const QDep &d) {
+    uint32_t *g = d.gate_lds;
+    uint32_t st = uniform(__hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (st != 0u)
+        return st == 1u;
+    uint32_t first = 0;
+    if (lane_id() == 0)
+        first = __hip_atomic_exchange(g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (uniform(first) == 0u) {
+        const bool ok = q_wait_ge(d.gate, 1u, d);
+        if (lane_id() == 0)
+            __hip_atomic_store(g + 1, ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return ok;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(8);
+        st = uniform(__hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (st != 0u) {
+            if (d.wacc != nullptr && lane_id() == 0)
+                d.wacc[threadIdx.x >> 6] += static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime() - t0);
+            return st == 1u;
+        }
+    }
+}
+__device__ __forceinline__ bool q_dep_wait(const QDep &d, uint32_t c, uint32_t fi, uint32_t dep1) {
+    if (d.gate != nullptr)
+        return q_gate_wait(d);
+    if (d.wait_a == 0u || QV_SPAN_NOWAIT)
+        return true;
+    if (c > 0u)
+        return q_wait_ge(d.aflag + fi, d.full, d);
+    if (d.done_pp != nullptr && !q_wait_ge(d.done_pp, 1u, d))
+        return false;
+    return dep1 == 0u || q_wait_ge(d.cflag + fi, d.full, d);
+}
+// Where an item's signals go: ia = the word of the key's apply item in the next step's queue (m > 0), ic = 1 + the word
+// of its copy item there (c > 0; 0: the next step has none) -- read from the plans beside the gradient rows
+struct QSig {
+    uint32_t ia, ic;
+};
+__device__ __forceinline__ QSig q_sig_load(const QDep &d, uint32_t c, uint32_t st, uint32_t m, uint32_t fs) {
+    QSig g{0u, 0u};
+    if (d.aflag_n != nullptr && !QV_SPAN_NOSIGLOAD) {
+        // (device-coherent loads: the words were written by the builder of the next step's queue, possibly while this
+        // launch was already running -- behind its epoch tag, which this workgroup has checked)
+        if (m > 0u)
+            g.ia = __hip_atomic_load(d.dep_g + 2u * fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c > 0u)
+            g.ic = __hip_atomic_load(d.dep_a + 2u * st + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return g;
+}
+// (apply items: behind the caller's drain -- their row is in memory; copy items: once the row has arrived)
+__device__ __forceinline__ void q_dep_signal(const QDep &d, const QSig &g, uint32_t c, uint32_t m, int cols) {
+    if (d.aflag_n == nullptr || QV_SPAN_NOWAIT)
+        return;
+    const uint32_t units = static_cast<uint32_t>(cols + 31) / 32u;
+    if (m > 0u)
+        q_signal(d.aflag_n + uniform(g.ia), units);
+    if (c > 0u && uniform(g.ic) != 0u)
+        q_signal(d.cflag_n + (uniform(g.ic) - 1u), units);
+}
+
 struct QItem {
     int kind, col0, cols;
     uint32_t key, c, st, m, fs, o01, o23;
@@ -1087,7 +1506,11 @@ __device__ __forceinline__ QItem q_load(const QEntry *e, int width) {
 }
 
 // S / Z: <= 512 columns by one wave, c <= 3 occurrences, two 16-byte vectors per lane
-__device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
+// (SPAN: an item of a launch that spans several steps -- the row is loaded behind the item's wait, through the L2 both ways,
+// and the item's counters are raised at the end; false = the launch was aborted, nothing was touched)
+// SPAN arguments: e = the item's index in its region (wave items or copy items), sp = what was fetched beside it.
+template <bool SPAN>
+__device__ __forceinline__ bool q_small(const QArgs &a, const QItem &it, const QDep &d, uint32_t e, const QSpec &sp) {
     const int lane = lane_id();
     const int width = a.width;
     const int ca = it.col0 + 4 * lane, cb = ca + 256;
@@ -1095,7 +1518,7 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
     const int la = a0 ? ca : it.col0, lb = a1 ? cb : it.col0;   // loads stay branch-free: clamped columns
     float *row = a.table + static_cast<uint64_t>(it.kind == kQZ ? 0u : it.key) * static_cast<uint64_t>(width);
     float4v r0{0.f, 0.f, 0.f, 0.f}, r1{0.f, 0.f, 0.f, 0.f};
-    if (it.kind != kQZ) {   // every branch on the item is wave-uniform
+    if (!SPAN && it.kind != kQZ) {   // every branch on the item is wave-uniform
         r0 = q_ld_row<float4v>(row + la);
         r1 = q_ld_row<float4v>(row + lb);
     }
@@ -1113,6 +1536,32 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
             g1[t] = q_ld_grad<float4v>(src + lb);
         }
     }
+    QSig sig{0u, 0u};
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
+    if (SPAN)
+        q_mark(d, 1);      // the item has arrived
+    if (SPAN && it.kind != kQZ) {
+        // the flag word of the key's first slice (its own, fetched beside the item, for rows of at most 512 columns) says
+        // whether the row may be touched: if so its loads join the gradient rows' in ONE trip; else the gradient rows are on
+        // their way while the wave polls
+        const uint32_t fi = (it.c > 0u ? d.cap_coop : 0u) + e - static_cast<uint32_t>(it.col0 / 512);
+        const uint32_t asked = q_dep_ask(d, sp, it.c, fi, it.o01);
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+        if (!q_dep_ready(d, sp, it.c, asked) && !q_dep_wait(d, it.c, fi, it.o01))
+            return false;
+        q_mark(d, 2);      // the row may be touched
+        r0 = q_ld4_sc1(rr, la - it.col0);
+        r1 = q_ld4_sc1(rr, lb - it.col0);
+        if (d.wacc != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
+            q_mark(d, 3);  // row and gradient rows are here
+        }
+        if (it.c == 0u) {
+            // a copy only READS its row: whoever applies the key in the next step may go ahead once it has arrived
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
+            q_dep_signal(d, sig, 0u, it.m, it.cols);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < kQSmallC; ++t) {
         if (static_cast<uint32_t>(t) < it.c) {
@@ -1121,10 +1570,17 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
         }
     }
     if (it.c > 0) {
-        if (a0)
-            q_st_row(row + ca, r0);
-        if (a1)
-            q_st_row(row + cb, r1);
+        if (SPAN) {
+            if (a0)
+                q_st4_sc1(rr, ca - it.col0, r0);
+            if (a1)
+                q_st4_sc1(rr, cb - it.col0, r1);
+        } else {
+            if (a0)
+                q_st_row(row + ca, r0);
+            if (a1)
+                q_st_row(row + cb, r1);
+        }
     }
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
@@ -1139,6 +1595,14 @@ __device__ __forceinline__ void q_small(const QArgs &a, const QItem &it) {
                 q_st_out(o + cb, r1);
         }
     }
+    if (SPAN)
+        q_mark(d, 4);          // stores issued
+    if (SPAN && it.c > 0u) {     // (kind S: the row this item wrote is in memory before anybody is told, and before the
+        q_drain();              // workgroup counts as finished)
+        q_mark(d, 5);
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
+    }
+    return true;
 }
 
 // Two S items by ONE wave, rows of at most 128 columns: lanes 0-31 take item A, lanes 32-63 item B (a 512-byte row is
@@ -1188,7 +1652,8 @@ __device__ __forceinline__ void q_small_pair(const QArgs &a, const QEntry *ea, c
 }
 
 // M: one 128-column slice, c <= 15 occurrences, 8 bytes per lane, ordered chain
-__device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
+template <bool SPAN>
+__device__ __forceinline__ bool q_medium(const QArgs &a, const QItem &it, const QDep &d, uint32_t e, const QSpec &sp) {
     const int lane = lane_id();
     const int width = a.width;
     const int col = it.col0 + 2 * lane;
@@ -1200,7 +1665,16 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
         pidx = a.perm_a[it.st + min(static_cast<uint32_t>(lane), it.c - 1u)];
     if (it.m > 0)
         dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
-    float2v_ r = q_ld_row<float2v_>(row + lc);
+    float2v_ r{0.f, 0.f};
+    if (!SPAN)
+        r = q_ld_row<float2v_>(row + lc);
+    QSig sig{0u, 0u};
+    uint32_t fi = 0, asked = 0;
+    if (SPAN) {      // the flag word and the signals' indices are asked for beside the occurrence indices
+        fi = (it.c > 0u ? d.cap_coop : 0u) + e - static_cast<uint32_t>(it.col0 / 128);
+        asked = q_dep_ask(d, sp, it.c, fi, it.o01);
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+    }
     // branch-free: lanes >= c hold the index of the last occurrence, so the loads beyond c repeat a line the wave
     // has just asked for and the chain skips them by select (uniform branches around 15 loads make the compiler
     // spill; clamped loads are what scatter_dev.h does as well)
@@ -1211,6 +1685,18 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
         const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(pidx, t));
         g[t] = q_ld_grad<float2v_>(gbase + static_cast<uint64_t>(o) * static_cast<uint64_t>(width) + lc);
     }
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
+    if (SPAN) {
+        // (c == 0: the "gradient" loads above re-read the row itself, plainly -- their values are never used)
+        if (!q_dep_ready(d, sp, it.c, asked) && !q_dep_wait(d, it.c, fi, it.o01))
+            return false;
+        r[0] = q_ld1_sc1(rr, lc - it.col0);
+        r[1] = q_ld1_sc1(rr, lc - it.col0 + 1);
+        if (it.c == 0u) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory");
+            q_dep_signal(d, sig, 0u, it.m, it.cols);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < kQMediumC; ++t) {
         const float x0 = __fsub_rn(r[0], __fmul_rn(a.lr, g[t][0]));
@@ -1219,8 +1705,12 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
         r[0] = on ? x0 : r[0];
         r[1] = on ? x1 : r[1];
     }
-    if (it.c > 0 && act)
-        q_st_row(row + col, r);
+    if (it.c > 0 && act) {
+        if (SPAN)
+            q_st2_sc1(rr, col - it.col0, r);
+        else
+            q_st_row(row + col, r);
+    }
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
             dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
@@ -1232,10 +1722,16 @@ __device__ __forceinline__ void q_medium(const QArgs &a, const QItem &it) {
                 q_st_out(o + col, r);
         }
     }
+    if (SPAN && it.c > 0u) {
+        q_drain();
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
+    }
+    return true;
 }
 
 // L: one 32-column slice, 16 <= c < 64: lane = (occurrence group r of 8, column quad c4); fixed-order tree
-__device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
+template <bool SPAN>
+__device__ __forceinline__ bool q_long(const QArgs &a, const QItem &it, const QDep &d, uint32_t e, const QSpec &sp) {
     const int lane = lane_id();
     const int width = a.width;
     const int r = lane >> 3, c4 = lane & 7;
@@ -1246,7 +1742,16 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     int dv = 0;
     if (it.m > 0)
         dv = a.perm_g[it.fs + min(static_cast<uint32_t>(lane), it.m - 1u)];
-    const float4v cur = q_ld_row<float4v>(row + col);
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (!SPAN)
+        cur = q_ld_row<float4v>(row + col);
+    QSig sig{0u, 0u};
+    uint32_t fi = 0, asked = 0;
+    if (SPAN) {      // the key's flag word is asked for beside the occurrence indices; it is needed at the very end
+        fi = d.cap_coop + e - static_cast<uint32_t>(it.col0 / 32);
+        asked = q_dep_ask(d, sp, it.c, fi, 0u);
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+    }
     float4v g[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -1264,25 +1769,45 @@ __device__ __forceinline__ void q_long(const QArgs &a, const QItem &it) {
     p = add4(p, shfl_xor4(p, 8));
     p = add4(p, shfl_xor4(p, 16));
     p = add4(p, shfl_xor4(p, 32));
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
+    if (SPAN) {      // the row is needed for the last subtraction only
+        if (!q_dep_ready(d, sp, it.c, asked) && !q_dep_wait(d, it.c, fi, 0u))
+            return false;
+        cur = q_ld4_sc1(rr, col - it.col0);
+    }
     const float4v nv = sub4(cur, p);
-    if (r == 0 && act)
-        q_st_row(row + col, nv);
+    if (r == 0 && act) {
+        if (SPAN)
+            q_st4_sc1(rr, col - it.col0, nv);
+        else
+            q_st_row(row + col, nv);
+    }
     for (uint32_t j0 = 0; j0 < it.m; j0 += 64) {
         if (j0 > 0)
             dv = a.perm_g[it.fs + min(j0 + static_cast<uint32_t>(lane), it.m - 1u)];
         const uint32_t cnt = min(64u, it.m - j0);
         for (uint32_t j = 0; j < cnt; j += 8) {
-            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(min(j + r, cnt - 1u)), 64));
+            const uint32_t dd = static_cast<uint32_t>(__shfl(dv, static_cast<int>(min(j + r, cnt - 1u)), 64));
             if (j + r < cnt && act)
-                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+                q_st_out(a.out + static_cast<uint64_t>(dd) * static_cast<uint64_t>(width) + col, nv);
         }
     }
+    if (SPAN) {
+        q_drain();
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
+    }
+    return true;
 }
 
 #if QV_GOLD   // the product's G item: sixteen waves per 64-column slice
 // G: one 64-column slice by a whole workgroup, c >= 64.  lane = (row r of 4, column quad c4 of 16); wave w takes
 // occurrences 16w .. 16w+15 of every block of 256 (four 16-byte loads per lane and block).  s_part = 16 x 64 floats.
-__device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float *s_part, uint32_t e) {
+// SPAN: s_part[16 * 64] is followed by the workgroup's control words; [1] = "the wait of wave 0 succeeded".  The row is
+// loaded by all waves behind wave 0's wait and a barrier (only the workgroup that writes it needs it: a chunk that is not
+// the last one to deliver leaves before); wave 0 raises the counters behind the item's last barrier -- every wave has
+// used its copy of the row by then.
+template <bool SPAN>
+__device__ __forceinline__ bool q_coop_r3(const QArgs &a, const QItem &it, float *s_part, uint32_t e, const QDep &d) {
     const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int width = a.width;
     const int r = lane >> 4, c4 = lane & 15;
@@ -1292,7 +1817,16 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
     // a key with more than kQChunk occurrences arrives as `nch` items per slice: this one sums chunk `ch`
     const uint32_t ch = it.o01 & 0xFFFFu, nch = it.o01 >> 16;
     const uint32_t c_lo = kQChunk * ch, c_hi = nch > 1u ? min(it.c, c_lo + kQChunk) : it.c;
-    float4v cur = q_ld_row<float4v>(row + col);
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (!SPAN)
+        cur = q_ld_row<float4v>(row + col);
+    QSig sig{0u, 0u};
+    uint32_t fi = 0, fnow = 0;
+    if (SPAN && w == 0) {      // (wave 0 waits and signals for the workgroup)
+        fi = e - (static_cast<uint32_t>(it.col0 / 64) * (nch > 1u ? nch : 1u) + (nch > 1u ? ch : 0u));
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+        fnow = q_dep_ask(d, QSpec{0xFFFFFFFFu, 0u, 1u}, it.c, fi, 0u);
+    }
     // destinations of this wave: j = 64 * k + 4 * w + r in round k.  Lane l fetches the one of (k, r) = (l >> 2, l & 3):
     // one register covers the first 16 rounds (1,024 destinations)
     int dv = 0;
@@ -1345,7 +1879,7 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
         const bool last = *s_flag + 1u == nch;
         __syncthreads();
         if (!last)
-            return;
+            return true;
         // the chunk sums, four loads in flight at a time, added in chunk order
         const float *pp = a.qpart + static_cast<size_t>(first) * 64 + 4 * c4;
         float4v tot{0.f, 0.f, 0.f, 0.f};
@@ -1362,9 +1896,29 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
         }
         total = tot;
     }
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
+    if (SPAN) {
+        uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_part) + kQWpw * 64;
+        if (w == 0) {
+            const bool ok = uniform(fnow) >= d.full || q_dep_wait(d, it.c, fi, 0u);
+            if (lane == 0)
+                s_ctl[1] = ok ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool ok = uniform(s_ctl[1]) != 0u;
+        if (!ok)
+            return false;
+        cur = q_ld4_sc1(rr, col - it.col0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur)::"memory");
+        __syncthreads();     // every wave holds the OLD row before wave 0 stores the new one
+    }
     const float4v nv = sub4(cur, total);
-    if (w == 0 && r == 0 && act)
-        q_st_row(row + col, nv);
+    if (w == 0 && r == 0 && act) {
+        if (SPAN)
+            q_st4_sc1(rr, col - it.col0, nv);
+        else
+            q_st_row(row + col, nv);
+    }
     for (uint32_t k0 = 0; k0 * 64u < it.m; k0 += 16) {
         if (k0 > 0)
             dv = a.perm_g[it.fs + min(64u * (k0 + static_cast<uint32_t>(lane >> 2)) + static_cast<uint32_t>(4 * w + (lane & 3)),
@@ -1372,12 +1926,17 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
         const uint32_t rounds = min(16u, (it.m - 64u * k0 + 63u) / 64u);
         for (uint32_t k = 0; k < rounds; ++k) {
             const uint32_t j = 64u * (k0 + k) + static_cast<uint32_t>(4 * w + r);
-            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(4 * k) + r, 64));
+            const uint32_t dd = static_cast<uint32_t>(__shfl(dv, static_cast<int>(4 * k) + r, 64));
             if (j < it.m && act)
-                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+                q_st_out(a.out + static_cast<uint64_t>(dd) * static_cast<uint64_t>(width) + col, nv);
         }
     }
     __syncthreads();   // s_part is reused by the next item of this workgroup
+    if (SPAN && w == 0) {
+        q_drain();
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
+    }
+    return true;
 }
 
 #endif
@@ -1386,14 +1945,24 @@ __device__ __forceinline__ void q_coop_r3(const QArgs &a, const QItem &it, float
 // the run -- lane = (occurrence group r of 8, column quad c4 of 8), wave w takes occurrences 64w .. 64w+63 of every
 // block of 256 (eight 16-byte loads per lane and block) --, the four wave sums meet in LDS as (w0 + w1) + (w2 + w3).
 // s_part = 4 x 32 floats.
-__device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s_part) {
+template <bool SPAN>
+__device__ __forceinline__ bool q_coop(const QArgs &a, const QItem &it, float *s_part, uint32_t e, const QDep &d) {
     const int lane = lane_id(), w = uniform(static_cast<int>(threadIdx.x >> 6));
     const int width = a.width;
     const int r = lane >> 3, c4 = lane & 7;
     const bool act = 4 * c4 < it.cols;
     const int col = it.col0 + (act ? 4 * c4 : 0);
     float *row = a.table + static_cast<uint64_t>(it.key) * static_cast<uint64_t>(width);
-    const float4v cur = q_ld_row<float4v>(row + col);
+    float4v cur{0.f, 0.f, 0.f, 0.f};
+    if (!SPAN)
+        cur = q_ld_row<float4v>(row + col);
+    QSig sig{0u, 0u};
+    uint32_t fi = 0, fnow = 0;
+    if (SPAN && w == 0) {
+        fi = e - static_cast<uint32_t>(it.col0 / 32);
+        sig = q_sig_load(d, it.c, it.st, it.m, it.fs);
+        fnow = q_dep_ask(d, QSpec{0xFFFFFFFFu, 0u, 1u}, it.c, fi, 0u);
+    }
     // destinations of this wave: j = 8 W * k + 8 * w + r in round k (W waves).  Lane l fetches the one of (k, r) =
     // (l >> 3, l & 7): one register covers eight rounds
     constexpr uint32_t kDW = 8u * kQWpw, kBlk = 64u * kQWpw;
@@ -1432,9 +2001,29 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
     for (int q = 1; q < kQWpw / 4; ++q)        // (timing variants with larger workgroups; the product has four waves)
         total = add4(total, add4(add4(*reinterpret_cast<const float4v *>(sp + 128 * q), *reinterpret_cast<const float4v *>(sp + 128 * q + 32)),
                                  add4(*reinterpret_cast<const float4v *>(sp + 128 * q + 64), *reinterpret_cast<const float4v *>(sp + 128 * q + 96))));
+    __amdgpu_buffer_rsrc_t rr = q_row_rsrc(row + it.col0);
+    if (SPAN) {      // (as q_coop_r3)
+        uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_part) + kQWpw * 64;
+        if (w == 0) {
+            const bool ok = uniform(fnow) >= d.full || q_dep_wait(d, it.c, fi, 0u);
+            if (lane == 0)
+                s_ctl[1] = ok ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool ok = uniform(s_ctl[1]) != 0u;
+        if (!ok)
+            return false;
+        cur = q_ld4_sc1(rr, col - it.col0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur)::"memory");
+        __syncthreads();
+    }
     const float4v nv = sub4(cur, total);
-    if (w == 0 && r == 0 && act)
-        q_st_row(row + col, nv);
+    if (w == 0 && r == 0 && act) {
+        if (SPAN)
+            q_st4_sc1(rr, col - it.col0, nv);
+        else
+            q_st_row(row + col, nv);
+    }
     for (uint32_t k0 = 0; k0 * kDW < it.m; k0 += 8) {
         if (k0 > 0)
             dv = a.perm_g[it.fs + min(kDW * (k0 + static_cast<uint32_t>(lane >> 3)) + static_cast<uint32_t>(8 * w + (lane & 7)),
@@ -1442,64 +2031,145 @@ __device__ __forceinline__ void q_coop(const QArgs &a, const QItem &it, float *s
         const uint32_t rounds = min(8u, (it.m - kDW * k0 + kDW - 1u) / kDW);
         for (uint32_t k = 0; k < rounds; ++k) {
             const uint32_t j = kDW * (k0 + k) + static_cast<uint32_t>(8 * w + r);
-            const uint32_t d = static_cast<uint32_t>(__shfl(dv, static_cast<int>(8 * k) + r, 64));
+            const uint32_t dd = static_cast<uint32_t>(__shfl(dv, static_cast<int>(8 * k) + r, 64));
             if (j < it.m && act)
-                q_st_out(a.out + static_cast<uint64_t>(d) * static_cast<uint64_t>(width) + col, nv);
+                q_st_out(a.out + static_cast<uint64_t>(dd) * static_cast<uint64_t>(width) + col, nv);
         }
     }
     __syncthreads();   // s_part is reused by the next item of this workgroup
+    if (SPAN && w == 0) {
+        q_drain();
+        q_dep_signal(d, sig, it.c, it.m, it.cols);
+    }
+    return true;
 }
 
 // ---- the three launches ----------------------------------------------------------------------------------------
 // The items of one step: workgroups [0, ncoop) take the G items, the others one wave item per wave.
 static_assert(kQWg == 256 || kQWg == 512 || kQWg == 1024, "workgroups of 4, 8 or 16 waves");
 static_assert(!QV_GOLD || kQWg == 1024, "the sixteen-wave G item needs 1024-thread workgroups");
-__global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+// "The queue (and, in a spanning launch, the next step's queue) carries the tag of its step": peek = plain loads that travel
+// with the wave's first item, poll = the bounded wait of a launch that overtook the builder (device-coherent loads).
+struct QEp {
+    uint32_t w, c, nw, nc;
+};
+__device__ __forceinline__ QEp q_epoch_peek(const QArgs &a) {
+    QEp e;
+    e.w = a.qh->epoch_wave;
+    e.c = a.qh->epoch_copy;
+    e.nw = a.qh_next ? a.qh_next->epoch_wave : 0u;
+    e.nc = a.qh_next ? a.qh_next->epoch_copy : 0u;
+    return e;
+}
+__device__ __forceinline__ bool q_epoch_match(const QArgs &a, const QEp &e) {
+    return uniform(static_cast<uint32_t>(e.w == a.epoch && e.c == a.epoch &&
+                                         (a.qh_next == nullptr || (e.nw == a.epoch_next && e.nc == a.epoch_next)))) != 0u;
+}
+__device__ __forceinline__ bool q_epoch_poll(const QArgs &a, const QDep &d) {
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+        QEp e;
+        e.w = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        e.c = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        e.nw = e.nc = 0u;
+        if (a.qh_next != nullptr) {
+            e.nw = __hip_atomic_load(&a.qh_next->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            e.nc = __hip_atomic_load(&a.qh_next->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (q_epoch_match(a, e))
+            return true;
+        if ((spin & 63) == 63 && d.abort_w != nullptr &&
+            uniform(__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+            return false;
+        __builtin_amdgcn_s_sleep(64);
+    }
+    return false;
+}
+
+// The items of ONE step by the workgroup `b` of its step's grid: workgroups [0, ncoop) take the G items, the others one wave
+// item per wave.  SPAN: the step is one of several of a launch (qapply_span_kernel): `d` says what its items wait for and
+// raise, `gb` = the workgroup's index in the launch (time stamps).
+template <bool SPAN>
+__device__ __forceinline__ void qapply_body(const QArgs &a, const QDep &d, int b, uint32_t *s_dyn, const unsigned gb) {
     const unsigned long long t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int role, kind = -1;
-    int b = blockIdx.x;
-    if (a.epoch != 0u) {
-        // The caller orders this launch behind the queue's builder without a wait on this stream (the builder ran a block of
-        // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
-        // ~1 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
+    unsigned was_copy = 0;
+    bool alive = true;
+    uint32_t *s_ctl = s_dyn + kQWpw * 64;     // SPAN: [0] waves of this workgroup that have finished, [1] q_coop_r3's
+    if (SPAN) {
+        for (int i = threadIdx.x; i < 8 + 16 + kQWpw * 8; i += kQWg)
+            s_ctl[i] = 0u;
+        __syncthreads();
+    }
+    // The caller may order this launch behind the queue's builder without a wait on this stream (the builder ran a block of
+    // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
+    // ~1 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
+    // A spanning launch that knows the queue's item counts looks at the words BESIDE its first item (one trip) instead.
+    bool checked = a.epoch == 0u;
+    const bool coop = b < a.ncoop;
+    // (compile-time for one launch per step: with the peek / poll code in its item loops the kernel spills 52 scalar registers
+    // instead of 12 and a step takes 0.4 us longer -- and known counts bought it nothing)
+    const bool counts_known = SPAN && (coop ? a.k_coop != 0u : (a.k_wave != 0u && a.k_copy != 0u));
+    if (!checked && !counts_known) {
         bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;     // (read with the header's counts)
-        for (int spin = 0; !ready && spin < (1 << 20); ++spin) {
-            const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
-            if (ready)
-                break;
-            __builtin_amdgcn_s_sleep(64);
+        if (SPAN) {
+            ready = q_epoch_match(a, q_epoch_peek(a)) || q_epoch_poll(a, d);
+        } else {
+            for (int spin = 0; !ready && spin < (1 << 20); ++spin) {
+                const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
+                if (ready)
+                    break;
+                __builtin_amdgcn_s_sleep(64);
+            }
         }
         if (!ready) {
-            // ANY workgroup that gives up says so (another may have seen the tag just in time and applied its items: the step is
-            // then partially applied, and the host must hear of it -- QueueStepPipeline raises)
-            if (a.err != nullptr && threadIdx.x == 0)
+            if (SPAN) {
+                q_raise(d);      // every wait of the launch sees the abort word: nothing else is applied
+            } else if (a.err != nullptr && threadIdx.x == 0) {
+                // ANY workgroup that gives up says so (another may have seen the tag just in time and applied its items:
+                // the step is then partially applied, and the host must hear of it -- QueueStepPipeline raises)
                 __hip_atomic_store(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return;
         }
+        checked = true;
     }
-    const bool coop = b < a.ncoop;
     if (coop) {
         role = 0;
-        const uint32_t n = min(a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
-        for (uint32_t e = static_cast<uint32_t>(b); e < n; e += static_cast<uint32_t>(a.ncoop)) {
-            const QItem it = q_load(a.qcoop + e, a.width);
+        const uint32_t n = min((SPAN && a.k_coop) ? a.k_coop - 1u : a.qh->n_coop, a.cap_coop);     // (a count beyond its region: the builder raised its overflow word)
+        for (uint32_t e = static_cast<uint32_t>(b); e < n && alive; e += static_cast<uint32_t>(a.ncoop)) {
+            QEp ep{0u, 0u, 0u, 0u};
+            if (SPAN && !checked)
+                ep = q_epoch_peek(a);
+            QItem it = q_load(a.qcoop + e, a.width);
+            if (SPAN && !checked) {
+                if (!q_epoch_match(a, ep)) {
+                    if (!q_epoch_poll(a, d)) {
+                        q_raise(d);
+                        alive = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_dcache_inv();      // (the item just read may be what the builder had not written yet)
+                    it = q_load(a.qcoop + e, a.width);
+                }
+                checked = true;
+            }
 #if QV_GOLD
-            q_coop_r3(a, it, reinterpret_cast<float *>(s_dyn), e);
+            alive = q_coop_r3<SPAN>(a, it, reinterpret_cast<float *>(s_dyn), e, d);
 #else
-            q_coop(a, it, reinterpret_cast<float *>(s_dyn));
+            alive = q_coop<SPAN>(a, it, reinterpret_cast<float *>(s_dyn), e, d);
 #endif
             kind = it.kind;
         }
     } else {
         b -= a.ncoop;
         role = 3;
-        const uint32_t n0 = min(a.qh->n_wave, a.cap_wave), n = n0 + min(a.qh->n_copy, a.cap_copy);
+        const uint32_t n0 = min((SPAN && a.k_wave) ? a.k_wave - 1u : a.qh->n_wave, a.cap_wave),
+                       n = n0 + min((SPAN && a.k_copy) ? a.k_copy - 1u : a.qh->n_copy, a.cap_copy);
         const uint32_t stride = static_cast<uint32_t>(a.nworker) * static_cast<uint32_t>(kQWpw);
         const uint32_t wv = uniform(static_cast<uint32_t>(threadIdx.x >> 6));
-        if (a.width <= 128) {
+        if (!SPAN && a.width <= 128) {
             // narrow rows: every wave takes a PAIR of consecutive items; two S / Z items share the wave (q_small_pair),
             // anything else is done one after the other
             const uint32_t n1 = n - n0, both = 2u * (n0 < n1 ? n0 : n1), npair = (n + 1u) / 2u;
@@ -1526,16 +2196,17 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
                         continue;
                     const QItem it = q_load(src[h], a.width);
                     kind = it.kind;
+                    const QSpec none{0u, 0u, 1u};
                     if (it.kind == kQL)
-                        q_long(a, it);
+                        q_long<false>(a, it, d, 0u, none);
                     else if (it.kind == kQM)
-                        q_medium(a, it);
+                        q_medium<false>(a, it, d, 0u, none);
                     else
-                        q_small(a, it);
+                        q_small<false>(a, it, d, 0u, none);
                 }
             }
         } else
-        for (uint32_t e = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv; e < n; e += stride) {
+        for (uint32_t e = static_cast<uint32_t>(b) * static_cast<uint32_t>(kQWpw) + wv; e < n && alive; e += stride) {
 #if QV_INTERLEAVE
             // Wave items and copy items ALTERNATE over the launch while both last (then the rest of the longer list):
             // a copy writes m rows for one it reads, an apply item reads more than it writes, and a compute unit that
@@ -1544,21 +2215,101 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
             // item 13.2, copies spread evenly over all wave items 13.2, small wave items first 13.1-13.2).
             const uint32_t n1 = n - n0, both = 2u * (n0 < n1 ? n0 : n1);
             const QEntry *src;
-            if (e < both)
-                src = (e & 1u) ? a.qcopy + (e >> 1) : a.qwave + (e >> 1);
-            else
-                src = n0 > n1 ? a.qwave + (e - n1) : a.qcopy + (e - n0);
-            const QItem it = q_load(src, a.width);
+            bool cp;            // the item is a copy item (its index in its own region: er)
+            uint32_t er;
+            if (e < both) {
+                cp = (e & 1u) != 0u;
+                er = e >> 1;
+            } else {
+                cp = n0 <= n1;
+                er = n0 > n1 ? e - n1 : e - n0;
+            }
+            src = cp ? a.qcopy + er : a.qwave + er;
 #else
-            const QItem it = q_load(e < n0 ? a.qwave + e : a.qcopy + (e - n0), a.width);
+            const bool cp = e >= n0;
+            const uint32_t er = cp ? e - n0 : e;
+            const QEntry *src = cp ? a.qcopy + er : a.qwave + er;
 #endif
+            QEp ep{0u, 0u, 0u, 0u};
+            if (SPAN && !checked)
+                ep = q_epoch_peek(a);
+            QSpec sp{0u, 0u, 1u};
+            if (SPAN && d.wait_a) {
+                // beside the item, in the same trip: the flag word of this item (what it waits for if it is its key's first
+                // slice: always, for rows of at most 512 columns) and, for a copy, "the step two back has finished"
+                sp.fidx = cp ? er : d.cap_coop + er;
+                sp.fval = __hip_atomic_load((cp ? d.cflag : d.aflag) + sp.fidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cp && d.done_pp != nullptr)
+                    sp.done = __hip_atomic_load(d.done_pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            QItem it = q_load(src, a.width);
+            if (SPAN && !checked) {
+                if (!q_epoch_match(a, ep)) {
+                    if (!q_epoch_poll(a, d)) {
+                        q_raise(d);
+                        alive = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_dcache_inv();      // (the item just read may be what the builder had not written yet)
+                    it = q_load(src, a.width);
+                    if (d.wait_a)
+                        sp.fval = __hip_atomic_load((cp ? d.cflag : d.aflag) + sp.fidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                checked = true;
+            }
+            if (SPAN) {
+                sp.fval = uniform(sp.fval);
+                sp.done = uniform(sp.done);
+            }
             kind = it.kind;
+            was_copy = cp ? 1u : 0u;
             if (it.kind == kQL)
-                q_long(a, it);
+                alive = q_long<SPAN>(a, it, d, er, sp);
             else if (it.kind == kQM)
-                q_medium(a, it);
+                alive = q_medium<SPAN>(a, it, d, er, sp);
             else
-                q_small(a, it);
+                alive = q_small<SPAN>(a, it, d, er, sp);
+        }
+    }
+    if (SPAN && alive) {
+        // this workgroup's share of "step s has finished" (qh->wg_done): the wave that finishes last adds it -- every
+        // wave's stores have been drained behind its last item
+        bool last;
+        if (coop) {
+            last = threadIdx.x == 0;       // (behind the G item's closing barrier)
+        } else {
+            uint32_t old = 0;
+            if (lane_id() == 0)
+                old = __hip_atomic_fetch_add(s_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            last = lane_id() == 0 && old + 1u == static_cast<uint32_t>(kQWpw);
+        }
+        if (last) {
+            QHeader *h = const_cast<QHeader *>(a.qh);
+            const uint32_t before = __hip_atomic_fetch_add(&h->wg_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d.gate_out != nullptr) {
+                // gated launch: the workgroup that finishes last opens the next launch's gate (every copy of the word)
+                if (before + 1u == d.done_target)
+                    for (int g = 0; g < kQGates; ++g)
+                        __hip_atomic_store(d.gate_out + 32 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (before + 1u == d.done_target) {
+                // the step's last workgroup: once the step before is marked, this one is
+                bool ok = true;
+                if (d.done_p != nullptr) {
+                    uint32_t v = __hip_atomic_load(d.done_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long tw = __builtin_amdgcn_s_memrealtime();
+                    while (v == 0u) {
+                        __builtin_amdgcn_s_sleep(4);
+                        v = __hip_atomic_load(d.done_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v == 0u && (__hip_atomic_load(d.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                        __builtin_amdgcn_s_memrealtime() - tw > 200000000ull)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                }
+                if (ok)
+                    __hip_atomic_store(&h->all_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (a.dbg) {
@@ -1567,13 +2318,178 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
         if (lane_id() == 0) {
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long *d = a.dbg + (static_cast<size_t>(blockIdx.x) * kQWpw + (threadIdx.x >> 6)) * 4;
-            d[0] = t0;
-            d[1] = t1;
-            d[2] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8);
-            d[3] = static_cast<unsigned long long>(static_cast<unsigned>(kind));
+            unsigned long long *dd = a.dbg + (static_cast<size_t>(gb) * kQWpw + (threadIdx.x >> 6)) * (SPAN ? 8 : 4);
+            if (SPAN) {
+                const uint32_t *mk = s_ctl + 8 + 16 + (threadIdx.x >> 6) * 8;
+                const uint32_t lo = static_cast<uint32_t>(t0);
+#pragma unroll
+                for (int k = 1; k <= 4; ++k)      // marks 1..5 as ticks since the wave's start, 16 bits each (0: not reached)
+                    dd[4] = 0;
+                unsigned long long pk = 0;
+#pragma unroll
+                for (int k = 1; k <= 4; ++k)
+                    pk |= static_cast<unsigned long long>(mk[k] ? ((mk[k] - lo) & 0xFFFFu) : 0u) << (16 * (k - 1));
+                dd[4] = pk;
+                dd[5] = mk[5] ? ((mk[5] - lo) & 0xFFFFu) : 0u;
+                dd[6] = dd[7] = 0;
+            }
+            dd[0] = t0;
+            dd[1] = t1;
+            dd[2] = static_cast<unsigned long long>(role) | (static_cast<unsigned long long>(xcc & 0xF) << 8) |
+                    (SPAN ? static_cast<unsigned long long>(s_ctl[8 + (threadIdx.x >> 6)]) << 16 : 0ull);
+            dd[3] = static_cast<unsigned long long>(static_cast<unsigned>(kind) & 0xFFu) |
+                    (static_cast<unsigned long long>(a.step) << 8) | (static_cast<unsigned long long>(was_copy) << 24);
         }
     }
+}
+
+__global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    QDep d;
+    __builtin_memset(&d, 0, sizeof(d));
+    d.err = a.err;
+    qapply_body<false>(a, d, static_cast<int>(blockIdx.x), s_dyn, blockIdx.x);
+}
+
+// ---- one launch per step, GATED: consecutive launches on TWO streams overlap -----------------------------------------------
+// A launch per step on one stream pays, every step, the tail of its predecessor (the last 40 % of a launch run at a third of
+// the chip's waves), the boundary and its own ramp and prologue (arguments, item, gradient rows).  Here step s + 1 is launched
+// on the OTHER stream of a pair: its workgroups take the slots the waves of step s leave, read their items and gradient rows
+// -- the largest stream of the step, and one no step before can change -- and then wait at ONE word, "step s has finished",
+// before they touch a table row; step s sets it when its last workgroup has drained its row stores (every workgroup counts
+// itself on wg_done of the step's queue header; the last one writes the kQGates copies of the word behind the queue).  No
+// per-key bookkeeping: the order between the steps is the launch boundary's, only the machine is not drained for it.  Rows
+// cross between the launches through the L2 (`sc1` both ways, drained) as in the spanning launch.  Step s + 2 follows step s
+// on its stream, so at most two launches are in flight; step s is completely resident before step s + 1 gets a slot (step
+// s + 1 starts when step s - 1 -- which waited for step s - 2 -- has ended, and step s has been taking every slot that came
+// free since step s - 2 ended), and a launch is at most kQWorkerMax + kQCoopSlots workgroups: nothing a gated wave waits
+// for can be kept out of the machine by gated waves.  Waits are bounded (~2 s) and raise the pinned error word.
+struct QGate {
+    const uint32_t *gate_in;     // the copies of "the step before has finished" (null: nothing to wait for)
+    uint32_t *gate_out;          // this step's copies
+};
+__global__ __launch_bounds__(kQWg, 8) void qapply_gated_kernel(const QArgs a, const QGate g) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    QDep d;
+    __builtin_memset(&d, 0, sizeof(d));
+    d.gate = g.gate_in ? g.gate_in + 32 * (blockIdx.x % kQGates) : nullptr;
+    d.gate_out = g.gate_out;
+    d.gate_lds = s_dyn + kQWpw * 64 + 2;
+    d.done_target = gridDim.x;
+    d.full = static_cast<uint32_t>(a.width + 31) / 32u;
+    d.cap_coop = a.cap_coop;
+    d.abort_w = const_cast<uint32_t *>(&a.qh->abort);
+    d.err = a.err;
+    d.wacc = a.dbg ? s_dyn + kQWpw * 64 + 8 : nullptr;
+    qapply_body<true>(a, d, static_cast<int>(blockIdx.x), s_dyn, blockIdx.x);
+}
+
+// ---- ONE launch for a block of consecutive steps ---------------------------------------------------------------------------
+// The grid is the steps' grids one after the other ([coop workgroups | worker workgroups] of step 0, of step 1, ...): the
+// dispatcher hands out workgroups in that order, so the items of step s + 1 start as the waves of step s drain -- no
+// launch boundary, no ramp, no tail at a third of the chip -- and wait, item by item, for exactly the item of the step before
+// that touched their row (QDep above).  Step i applies batch i (plan i) and writes the rows of batch i + 1 (plan i + 1):
+// entry i carries what belongs to batch i; entry `nsteps` only the lists of the batch the last step looks up.
+constexpr int kQSpanMax = 32;
+struct QSpanStep {
+    const QHeader *qh;         // queue of step i
+    const int32_t *perm;       // occurrence lists of batch i (= the destination lists of step i - 1)
+    uint32_t *dep;             // {ready, applied} counters of batch i
+    const float *grads;        // gradient rows of batch i
+    float *out;                // rows of batch i + 1
+    int32_t n;                 // ids of batch i
+    uint32_t epoch;            // tag queue i must carry (0: no check)
+    uint32_t wg_end;           // workgroups of steps 0 .. i
+    uint16_t ncoop, nworker;
+    uint32_t k_wave, k_coop, k_copy;      // queue i's item counts + 1 where the caller knows them (0: in the header)
+    uint32_t pad;
+};
+static_assert(sizeof(QSpanStep) == 72, "a step of a spanning launch: 72 bytes of kernel arguments");
+struct QSpanArgs {
+    float *table;
+    uint64_t rows;
+    int width, nsteps;
+    float lr;
+    uint32_t cap_coop, cap_wave, cap_copy;
+    uint32_t flag_off;         // bytes from a queue's header to its flag words
+    uint32_t *err;
+    unsigned long long *dbg;
+    QSpanStep step[kQSpanMax + 1];
+};
+static_assert(sizeof(QSpanArgs) <= 4096, "kernel arguments");
+__global__ __launch_bounds__(kQWg, 8) void qapply_span_kernel(const QSpanArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    // grid: x = the workgroup's index in its step's grid (up to the largest step's; the others leave at once), y = the step --
+    // workgroups are handed out x first, so step by step, and a workgroup knows its step without a trip to the arguments
+    const int s = static_cast<int>(blockIdx.y);
+    const QSpanStep &cur = sa.step[s], &nxt = sa.step[s + 1];
+    if (blockIdx.x >= static_cast<uint32_t>(cur.ncoop) + cur.nworker)
+        return;
+    const uint32_t gb = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t base = gb - blockIdx.x;
+    QArgs a;
+    a.table = sa.table;
+    a.rows = sa.rows;
+    a.width = sa.width;
+    a.lr = sa.lr;
+    a.qh = cur.qh;
+    const QEntry *items = reinterpret_cast<const QEntry *>(cur.qh + 1);
+    a.qcoop = items;
+    a.qwave = items + sa.cap_coop;
+    a.qcopy = a.qwave + sa.cap_wave;
+    a.qpart = reinterpret_cast<float *>(const_cast<QEntry *>(a.qcopy + sa.cap_copy));
+    a.qpcnt = reinterpret_cast<uint32_t *>(a.qpart + static_cast<size_t>(sa.cap_coop) * 64);
+    a.cap_coop = sa.cap_coop;
+    a.cap_wave = sa.cap_wave;
+    a.cap_copy = sa.cap_copy;
+    a.perm_a = cur.perm;
+    a.n_a = cur.n;
+    a.grads = cur.grads;
+    a.perm_g = nxt.perm;
+    a.n_g = nxt.n;
+    a.out = cur.out;
+    a.ncoop = cur.ncoop;
+    a.nworker = cur.nworker;
+    a.epoch = cur.epoch;
+    a.err = sa.err;
+    a.dbg = sa.dbg;
+    QDep d;
+    __builtin_memset(&d, 0, sizeof(d));
+    const bool has_next = s + 1 < sa.nsteps;
+    uint32_t *flags = a.qpcnt + sa.cap_coop;          // the queue's flag words follow its chunk counters (queue_layout)
+    d.aflag = flags;
+    d.cflag = flags + sa.cap_coop + sa.cap_wave;
+    d.aflag_n = d.cflag_n = nullptr;
+    a.qh_next = nullptr;
+    a.epoch_next = 0u;
+    if (has_next) {
+        uint32_t *fn = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(const_cast<QHeader *>(nxt.qh)) + sa.flag_off);
+        d.aflag_n = fn;
+        d.cflag_n = fn + sa.cap_coop + sa.cap_wave;
+        a.qh_next = nxt.qh;
+        a.epoch_next = nxt.epoch;
+    }
+    a.k_wave = cur.k_wave;
+    a.k_coop = cur.k_coop;
+    a.k_copy = cur.k_copy;
+    d.cap_coop = sa.cap_coop;
+    d.dep_a = cur.dep;
+    d.dep_g = nxt.dep;
+    d.done_pp = (s > 1 && !QV_SPAN_NODONE) ? &sa.step[s - 2].qh->all_done : nullptr;
+    d.done_p = s > 0 ? &sa.step[s - 1].qh->all_done : nullptr;
+    d.done_target = static_cast<uint32_t>(cur.ncoop) + cur.nworker;
+    a.step = static_cast<uint32_t>(s);
+    d.full = static_cast<uint32_t>(sa.width + 31) / 32u;
+    d.wait_a = s > 0 ? 1u : 0u;
+    d.abort_w = const_cast<uint32_t *>(&sa.step[0].qh->abort);
+    d.err = sa.err;
+    d.wacc = sa.dbg ? s_dyn + kQWpw * 64 + 8 : nullptr;
+    // every argument of the step in scalar registers NOW (one batch of loads): fetched where it is first used, each costs
+    // the wave a trip to the argument buffer in the middle of its item
+    asm volatile("" ::"s"(a.grads), "s"(a.out), "s"(a.perm_a), "s"(a.perm_g), "s"(d.dep_a), "s"(d.dep_g), "s"(d.aflag_n),
+                 "s"(d.done_pp), "s"(d.done_p), "s"(a.qh_next), "s"(a.epoch), "s"(a.epoch_next), "s"(a.k_wave), "s"(a.k_copy),
+                 "s"(a.k_coop));
+    qapply_body<true>(a, d, static_cast<int>(gb - base), s_dyn, gb);
 }
 
 // The plans of up to kQBatch batches, one workgroup each (a plan keeps ONE workgroup busy for ~15 us whatever else
@@ -1599,18 +2515,20 @@ struct QJoinBatch {
     uint64_t rows;
     uint32_t lds_bytes, cap_coop, cap_wave, cap_copy;
     QPlan pa[kQJoinBatch], pg[kQJoinBatch];
+    QPlan pb[kQJoinBatch];           // the batch before `pa` (n = 0: none / not wanted): dependencies of the copy items
     QHeader *qh[kQJoinBatch];
     QEntry *coop[kQJoinBatch], *wave[kQJoinBatch], *copy[kQJoinBatch];
     uint32_t *mirror[kQJoinBatch];   // optional pinned host words per step: {wave items, workgroup items, copy items} + 1
     uint32_t epoch[kQJoinBatch];     // the tag the finished queue carries (0: none asked for)
     unsigned long long *ph;     // development aid: phase stamps of workgroups 0 and 1
+    int extras;                 // 1: the queues are for spanning / gated launches (flag, gate and "finished" words)
 };
 __global__ __launch_bounds__(1024, 4) void qqueue_kernel(const QJoinBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const int i = blockIdx.x >> 1, part = blockIdx.x & 1;
     qjoin_body(b.pa[i], b.pg[i], b.rows, b.width, b.qh[i], b.coop[i], b.wave[i], b.copy[i], b.cap_coop, b.cap_wave,
                b.cap_copy, s_dyn, b.lds_bytes, part, (i == 0 && b.ph) ? b.ph + 8 * part : nullptr, b.mirror[i], 0u, 0u,
-               b.epoch[i]);
+               b.epoch[i], 0u, true, &b.pb[i], b.extras != 0);
 }
 
 // One wave-instruction's LDS atomics on one address: are the lanes served in ascending lane order?  Four collision
@@ -1676,7 +2594,7 @@ static int lds_atomics_lane_ordered() {
 
 template <typename IdT>
 static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *plans, int64_t count, hipStream_t stream,
-                       unsigned long long *ph = nullptr) {
+                       unsigned long long *ph = nullptr, bool span = false) {
     HA_REQUIRE(count >= 0 && (count == 0 || (ids && n && plans)), "ha_qplan_batch: null pointer");
     static DeviceOnce lds_allowed;   // once per device, and outside any stream capture (the first call is eager)
     if (lds_allowed.run([]() -> int {
@@ -1698,6 +2616,8 @@ static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *pla
             HA_REQUIRE(ids[k] && plans[k], "ha_qplan_batch: null pointer (batch %lld)", (long long)k);
             b.ids[b.count] = ids[k];
             b.plan[b.count] = qplan(plans[k], n[k]);
+            if (!span)      // (the 2 n dependency words of a plan are a spanning launch's: not cleared -- 0.1 us per step -- otherwise)
+                b.plan[b.count].dep = nullptr;
             lds = lds > qsort_lds_bytes(static_cast<int>(n[k])) ? lds : qsort_lds_bytes(static_cast<int>(n[k]));
             ++b.count;
         }
@@ -1715,7 +2635,8 @@ static int qplan_batch(const IdT *const *ids, const int64_t *n, void *const *pla
 static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
                         const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count,
                         hipStream_t stream, unsigned long long *ph = nullptr, uint32_t *const *counts_host = nullptr,
-                        const uint32_t *epochs = nullptr) {
+                        const uint32_t *epochs = nullptr, void *const *plans_b = nullptr, const int64_t *n_b = nullptr,
+                        bool extras = false) {
     HA_REQUIRE(rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 && width <= (1 << 20),
                "ha_qqueue_batch: rows of a multiple of 4 floats");
     HA_REQUIRE(count >= 0 && (count == 0 || (plans_a && n_a && plans_g && n_g && queues)), "ha_qqueue_batch: null pointer");
@@ -1732,6 +2653,7 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
         b.rows = static_cast<uint64_t>(rows);
         b.width = static_cast<int>(width);
         b.ph = k0 == 0 ? ph : nullptr;
+        b.extras = extras ? 1 : 0;
         size_t lds = 0;
         for (int64_t k = k0; k < count && b.count < kQJoinBatch; ++k) {
             HA_REQUIRE(n_a[k] >= 0 && n_g[k] >= 0 && n_a[k] <= queue_n_cap && n_g[k] <= queue_n_cap,
@@ -1743,6 +2665,13 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
             const int i = b.count++;
             b.pa[i] = qplan(plans_a[k], n_a[k]);
             b.pg[i] = qplan(plans_g[k], n_g[k]);
+            b.pb[i] = qplan((plans_b && n_b && n_g[k] > 0) ? plans_b[k] : nullptr, (plans_b && n_b && n_g[k] > 0) ? n_b[k] : 0);
+            if (!extras) {
+                // not for a spanning / gated launch (ha_qqueue_batch_span): no flag words in the queue, no dependency words in
+                // the plans -- two scattered stores per key that made the builder a third slower beside the steps
+                b.pa[i].dep = nullptr;
+                b.pg[i].dep = nullptr;
+            }
             const QLayout q = queue_layout(queues[k], queue_n_cap, width);
             b.qh[i] = q.hdr;
             b.mirror[i] = counts_host ? counts_host[k] : nullptr;
@@ -1757,6 +2686,10 @@ static int qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const
             lds = lds > need ? lds : need;
             lds = lds > res ? lds : res;      // the lookup batch's counts / starts in LDS too (a launch of its own: no
                                               // second workgroup has to fit on the CU)
+            if (b.pb[i].n > 0) {              // part 1 holds the keys of the batch before as well
+                const size_t two = need + kQTabSize * 4 + static_cast<size_t>(b.pb[i].n) * 4;
+                lds = lds > two ? lds : two;
+            }
         }
         if (b.count == 0)
             continue;
@@ -1771,17 +2704,17 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
                         float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
                         int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg = nullptr,
                         int64_t wave_items = -1, uint32_t epoch = 0, uint32_t *err = nullptr, hipEvent_t done = nullptr,
-                        int64_t coop_items = -1);
+                        int64_t coop_items = -1, const uint32_t *counts = nullptr);
 
 static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
                   void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, int64_t queue_n_cap,
                   hipStream_t stream, unsigned long long *dbg = nullptr, int64_t wave_items = -1, uint32_t epoch = 0,
-                  uint32_t *err = nullptr, hipEvent_t done = nullptr) {
+                  uint32_t *err = nullptr, hipEvent_t done = nullptr, const uint32_t *counts = nullptr) {
     HA_REQUIRE(n_cur >= 0 && n_next >= 0 && (n_cur == 0 || plan_cur) && (n_next == 0 || plan_next),
                "ha_qapply: a batch needs its plan");
     return qapply_lists(table, rows, width, n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr, n_cur, grads, lr,
                         n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr, n_next, next_out, queue_cur, queue_n_cap,
-                        kQMax, stream, dbg, wave_items, epoch, err, done);
+                        kQMax, stream, dbg, wave_items, epoch, err, done, -1, counts);
 }
 
 // perm_cur / perm_next: the occurrence lists of the batch to apply / the destination lists of the batch to look up (what
@@ -1789,7 +2722,8 @@ static int qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int
 static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t *perm_cur, int64_t n_cur, const float *grads,
                         float lr, const int32_t *perm_next, int64_t n_next, float *next_out, const void *queue_cur,
                         int64_t queue_n_cap, int64_t n_max, hipStream_t stream, unsigned long long *dbg,
-                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done, int64_t coop_items) {
+                        int64_t wave_items, uint32_t epoch, uint32_t *err, hipEvent_t done, int64_t coop_items,
+                        const uint32_t *counts) {
     HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
                    width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
                "ha_qapply: the table must be 16-byte aligned with rows of a multiple of 4 floats");
@@ -1839,6 +2773,16 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     // wave items <= ceil(width/512) * (n_cur + n_next); beyond kQWorkerMax workgroups the waves loop
     const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
     a.nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
+    // the queue's {wave, workgroup, copy items} + 1 as its builder left them in pinned host memory: the waves then find their
+    // items without reading the header's counts first (one trip less in front of every item), the launch is sized exactly
+    if (counts != nullptr && counts[0] != 0u && counts[1] != 0u && counts[2] != 0u && coop_items < 0) {
+        a.k_wave = counts[0];
+        a.k_coop = counts[1];
+        a.k_copy = counts[2];
+        wave_items = static_cast<int64_t>(counts[0] - 1u) + static_cast<int64_t>(counts[2] - 1u);
+        if (static_cast<int>(counts[1] - 1u) < a.ncoop)
+            a.ncoop = static_cast<int>(counts[1] - 1u);
+    }
     // the caller knows how many wave items the queue holds (ha_qstep_queue_mirror): no workgroups that find nothing --
     // a shorter launch ramp, and free slots for the preparation launches that run beside the steps
     if (wave_items >= 0 && wave_items / kQWpw + 1 < a.nworker)
@@ -1846,10 +2790,180 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     if (done != nullptr)
         // the event completes with THIS launch (the dispatch packet's own completion signal): no packet of its own on the
         // stream -- an event record between two launches of a stream costs what a short kernel costs
-        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4, stream,
+        hipExtLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + QV_AB_LDS_EXTRA, stream,
                               nullptr, done, 0, a);
     else
-        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4, stream, a);
+        hipLaunchKernelGGL(qapply_kernel, dim3(static_cast<unsigned>(a.ncoop + a.nworker)), dim3(kQWg), kQWpw * 64 * 4 + QV_AB_LDS_EXTRA, stream, a);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Step c as a GATED launch (qapply_gated_kernel): as qapply_lists (narrow batches), and the launch waits -- item by item,
+// before an item touches a table row -- for the launch of the step before to have finished (queue_prev: that step's queue,
+// which must have been applied by a gated launch; null: nothing to wait for) and tells the next one.  counts: the queue's
+// {wave, workgroup, copy items} + 1 in pinned host memory (null / zeros: unknown).
+static int qapply_gated(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
+                        void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, const void *queue_prev,
+                        int64_t queue_n_cap, const uint32_t *counts, int64_t wave_items, uint32_t epoch, uint32_t *err,
+                        hipEvent_t done, hipStream_t stream, unsigned long long *dbg = nullptr) {
+    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
+                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
+               "ha_qapply_gated: the table must be 16-byte aligned with rows of a multiple of 4 floats");
+    HA_REQUIRE(n_cur >= 0 && n_next >= 0 && queue_n_cap >= 1 && queue_n_cap <= kQMax && n_cur <= queue_n_cap &&
+                   n_next <= queue_n_cap && (n_cur > 0 || n_next > 0) && queue_cur != nullptr,
+               "ha_qapply_gated: a step with ids at one end at least, and its queue");
+    HA_REQUIRE((n_cur == 0 || (plan_cur && grads && reinterpret_cast<uintptr_t>(grads) % 16 == 0)) &&
+                   (n_next == 0 || (plan_next && next_out && reinterpret_cast<uintptr_t>(next_out) % 16 == 0)),
+               "ha_qapply_gated: plans, 16-byte aligned gradients and output");
+    QArgs a;
+    memset(&a, 0, sizeof(a));
+    a.epoch = epoch;
+    a.err = err;
+    a.table = table;
+    a.rows = static_cast<uint64_t>(rows);
+    a.width = static_cast<int>(width);
+    a.lr = lr;
+    a.dbg = dbg;
+    const QLayout q = queue_layout(const_cast<void *>(queue_cur), queue_n_cap, width);
+    a.qh = q.hdr;
+    a.qcoop = q.coop;
+    a.qwave = q.wave;
+    a.qcopy = q.copy;
+    a.qpart = q.part;
+    a.qpcnt = q.pcnt;
+    a.cap_coop = q.cap_coop;
+    a.cap_wave = q.cap_wave;
+    a.cap_copy = q.cap_copy;
+    a.perm_a = n_cur > 0 ? plan_layout(plan_cur, n_cur).perm : nullptr;
+    a.n_a = static_cast<int>(n_cur);
+    a.grads = grads;
+    a.perm_g = n_next > 0 ? plan_layout(plan_next, n_next).perm : nullptr;
+    a.n_g = static_cast<int>(n_next);
+    a.out = next_out;
+    a.ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
+    const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
+    a.nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
+    if (counts != nullptr && counts[0] != 0u && counts[1] != 0u && counts[2] != 0u) {
+        a.k_wave = counts[0];
+        a.k_coop = counts[1];
+        a.k_copy = counts[2];
+        wave_items = static_cast<int64_t>(counts[0] - 1u) + static_cast<int64_t>(counts[2] - 1u);
+        if (static_cast<int>(counts[1] - 1u) < a.ncoop)
+            a.ncoop = static_cast<int>(counts[1] - 1u);
+    }
+    if (wave_items >= 0 && wave_items / kQWpw + 1 < a.nworker)
+        a.nworker = static_cast<int>(wave_items / kQWpw + 1);
+    {   // (A/B knob: at most this many workgroups per gated launch -- two launches then fit the chip side by side)
+        static const int maxwg = getenv("HA_QGATED_MAXWG") ? atoi(getenv("HA_QGATED_MAXWG")) : 0;
+        if (maxwg > 0 && a.ncoop + a.nworker > maxwg) {
+            if (a.ncoop > maxwg / 4)
+                a.ncoop = maxwg / 4;
+            a.nworker = maxwg - a.ncoop;
+        }
+    }
+    QGate g;
+    g.gate_in = queue_prev ? queue_layout(const_cast<void *>(queue_prev), queue_n_cap, width).gate : nullptr;
+    g.gate_out = q.gate;
+    const dim3 grid(static_cast<unsigned>(a.ncoop + a.nworker));
+    if (done != nullptr)
+        hipExtLaunchKernelGGL(qapply_gated_kernel, grid, dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, nullptr, done, 0, a, g);
+    else
+        hipLaunchKernelGGL(qapply_gated_kernel, grid, dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, a, g);
+    HA_LAUNCH_CHECK();
+    return 0;
+}
+
+// `count` consecutive steps by ONE launch (qapply_span_kernel): step k applies the batch of plans[k] with grads[k] and writes
+// the rows of the batch of plans[k + 1] to next_out[k] from queues[k]; plans / n have count + 1 entries.  The queues must
+// have been built with the batch before (ha_qqueue_batch_span: the copy items' dependencies) and the plans by
+// ha_qplan_batch_* (their counters start at zero); every batch's gradient rows are resident when the launch starts.
+static int qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                       void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
+                       const void *const *queues, const int64_t *wave_items, const uint32_t *epochs, uint32_t *err,
+                       hipEvent_t done, hipStream_t stream, unsigned long long *dbg = nullptr,
+                       const uint32_t *const *counts_host = nullptr) {
+    HA_REQUIRE(table != nullptr && rows >= 0 && rows <= 0xFFFFFFFEll && width >= 4 && width % 4 == 0 &&
+                   width <= (1 << 20) && reinterpret_cast<uintptr_t>(table) % 16 == 0,
+               "ha_qapply_span: the table must be 16-byte aligned with rows of a multiple of 4 floats");
+    HA_REQUIRE(count >= 1 && count <= kQSpanMax, "ha_qapply_span: 1..%d steps per launch", kQSpanMax);
+    HA_REQUIRE(plans && n && grads && next_out && queues, "ha_qapply_span: null pointer");
+    HA_REQUIRE(queue_n_cap >= 1 && queue_n_cap <= kQMax, "ha_qapply_span: bad queue capacity");
+    QSpanArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.table = table;
+    sa.rows = static_cast<uint64_t>(rows);
+    sa.width = static_cast<int>(width);
+    sa.nsteps = static_cast<int>(count);
+    sa.lr = lr;
+    sa.err = err;
+    sa.dbg = dbg;
+    const QLayout q0 = queue_layout(nullptr, queue_n_cap, width);
+    sa.cap_coop = q0.cap_coop;
+    sa.cap_wave = q0.cap_wave;
+    sa.cap_copy = q0.cap_copy;
+    sa.flag_off = static_cast<uint32_t>(q0.flag_off);
+    uint32_t total = 0;
+    unsigned most = 1;
+    for (int64_t k = 0; k <= count; ++k) {
+        QSpanStep &st = sa.step[k];
+        HA_REQUIRE(n[k] >= 0 && n[k] <= queue_n_cap && (n[k] == 0 || plans[k]), "ha_qapply_span: batch %lld needs its plan",
+                   (long long)k);
+        st.n = static_cast<int32_t>(n[k]);
+        if (n[k] > 0) {
+            const PlanPtrs p = plan_layout(plans[k], n[k]);
+            st.perm = p.perm;
+            st.dep = p.dep;
+        }
+        if (k == count)
+            break;
+        const int64_t n_cur = n[k], n_next = n[k + 1];
+        HA_REQUIRE(n_cur == 0 || (grads[k] && reinterpret_cast<uintptr_t>(grads[k]) % 16 == 0),
+                   "ha_qapply_span: batch %lld needs 16-byte aligned gradients", (long long)k);
+        HA_REQUIRE(n_next == 0 || (next_out[k] && reinterpret_cast<uintptr_t>(next_out[k]) % 16 == 0),
+                   "ha_qapply_span: step %lld needs a 16-byte aligned output", (long long)k);
+        st.grads = grads[k];
+        st.out = next_out[k];
+        st.epoch = epochs ? epochs[k] : 0u;
+        int ncoop = 0, nworker = 0;
+        if (n_cur > 0 || n_next > 0) {
+            HA_REQUIRE(queues[k] != nullptr, "ha_qapply_span: the queue of step %lld is missing", (long long)k);
+            st.qh = static_cast<const QHeader *>(queues[k]);
+            ncoop = n_cur >= kQLongC ? kQCoopSlots : 0;
+            const int64_t bound = static_cast<int64_t>(ceil_div(width, 512)) * (n_cur + n_next);
+            nworker = static_cast<int>(bound / kQWpw + 1 < kQWorkerMax ? bound / kQWpw + 1 : kQWorkerMax);
+            int64_t wi = wave_items ? wave_items[k] : -1;
+            // the counts the queue's builder left in pinned host memory ({wave, workgroup, copy items} + 1; 0 = not there
+            // yet): the waves then find their items without reading the queue's header first
+            const uint32_t *cn = counts_host ? counts_host[k] : nullptr;
+            if (cn != nullptr) {
+                const uint32_t w1 = cn[0], g1 = cn[1], c1 = cn[2];
+                if (w1 != 0u && g1 != 0u && c1 != 0u) {
+                    st.k_wave = w1;
+                    st.k_coop = g1;
+                    st.k_copy = c1;
+                    wi = static_cast<int64_t>(w1 - 1u) + static_cast<int64_t>(c1 - 1u);
+                    if (static_cast<int>(g1 - 1u) < ncoop)
+                        ncoop = static_cast<int>(g1 - 1u);
+                }
+            }
+            if (wi >= 0 && wi / kQWpw + 1 < nworker)
+                nworker = static_cast<int>(wi / kQWpw + 1);
+        }
+        st.ncoop = static_cast<uint16_t>(ncoop);
+        st.nworker = static_cast<uint16_t>(nworker);
+        total += static_cast<uint32_t>(ncoop + nworker);
+        most = most > static_cast<unsigned>(ncoop + nworker) ? most : static_cast<unsigned>(ncoop + nworker);
+        st.wg_end = total;
+    }
+    // (every step's queue header carries the words later steps wait for, the first one the launch's abort word: a span
+    // holds no step without ids at both ends -- the caller cuts it there)
+    for (int64_t k = 0; k < count; ++k)
+        HA_REQUIRE(sa.step[k].qh != nullptr, "ha_qapply_span: step %lld of the span is empty (cut the span there)", (long long)k);
+    const dim3 grid(most, static_cast<unsigned>(count));
+    if (done != nullptr)
+        hipExtLaunchKernelGGL(qapply_span_kernel, grid, dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, nullptr, done, 0, sa);
+    else
+        hipLaunchKernelGGL(qapply_span_kernel, grid, dim3(kQWg), kQWpw * 64 * 4 + 1024, stream, sa);
     HA_LAUNCH_CHECK();
     return 0;
 }
@@ -2066,6 +3180,7 @@ __device__ __forceinline__ QPlan qbig_slice(const QBigRef &r, int p) {
     q.seg = r.seg + off + p;
     q.upos = nullptr;
     q.occ = r.occ + 2 * static_cast<size_t>(off);
+    q.dep = nullptr;
     q.n = static_cast<int>(nb);
     return q;
 }
@@ -2130,6 +3245,8 @@ constexpr size_t kQSubJoinLds = (size_t(1) << kQSubTabBits) * 4 + size_t(kQSubJo
 static_assert(kQSubJoinLds % 128 == 0, "the groups' LDS regions stay aligned");
 // One workgroup per (step, part, FOUR buckets): quarters side by side where every bucket of the four has at most
 // kQSubJoinKeys unique keys on either side, else one after the other (see qbplan_kernel).
+// (The whole-workgroup form -- buckets of more than kQSubJoinKeys unique keys: rare -- gets 128 vector registers: at 64 it
+// spills to scratch memory.)
 template <bool QUARTERS>
 __global__ __launch_bounds__(1024, QUARTERS ? 8 : 4) void qbqueue_kernel(const QBigJoinBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -2333,6 +3450,15 @@ extern "C" int ha_qplan_batch_u64ids(const uint64_t *const *ids, const int64_t *
                                      ha_stream_t stream) {
     return qplan_batch<uint64_t>(ids, n, plans, count, as_stream(stream));
 }
+// the plans of batches whose queues ha_qqueue_batch_span builds (a spanning launch's dependency words are cleared)
+extern "C" int ha_qplan_batch_span_f32ids(const float *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                                          ha_stream_t stream) {
+    return qplan_batch<float>(ids, n, plans, count, as_stream(stream), nullptr, true);
+}
+extern "C" int ha_qplan_batch_span_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count,
+                                          ha_stream_t stream) {
+    return qplan_batch<uint64_t>(ids, n, plans, count, as_stream(stream), nullptr, true);
+}
 extern "C" int ha_qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a,
                                void *const *plans_g, const int64_t *n_g, void *const *queues, int64_t queue_n_cap,
                                int64_t count, ha_stream_t stream) {
@@ -2421,17 +3547,88 @@ extern "C" int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, f
         HA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(done_event), as_stream(stream)));
     return 0;
 }
-// ha_qapply_steps_sync with the pinned count words of every step's queue beside the hints (one launch per step sizes its grid
-// by `wave_items`; the counts are what the spanning launch of csrc/qspan.hip takes)
+// `count` (<= ha_qapply_span_max()) consecutive steps by ONE launch whose items wait for each other row by row instead of a
+// launch boundary per step (qapply_span_kernel above).  plans / n: count + 1 entries (the batch of step k, ..., and the batch
+// the last step looks up); the other arrays per step as for ha_qapply_steps_sync.  Requirements beyond ha_qapply_steps_sync's:
+// the queues were built by ha_qqueue_batch_span (with the plan of the batch BEFORE each step's batch), the plans by
+// ha_qplan_batch_* and used by no other apply since (their dependency counters start at zero and count up once), every
+// batch's gradient rows are resident when the launch starts, and the span's first step has a queue (is not empty).
+// `count` consecutive steps as GATED launches (see qapply_gated_kernel), step k on streams[k & 1 ^ first_on] -- the caller
+// hands over two streams; per-step arrays as for ha_qapply_steps_sync.  queue_prev: the queue of the step before the first
+// one if that step was a gated launch too (the chain continues), else NULL (the first launch waits for nothing: the caller
+// has ordered it behind the table's last writer).  counts_host: per step the three pinned words the queue's builder writes
+// (may be NULL).  done_event rides on the last launch.
+extern "C" int ha_qapply_gated_steps(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                                     void *const *plan_cur, const int64_t *n_cur, const float *const *grads,
+                                     void *const *plan_next, const int64_t *n_next, float *const *next_out,
+                                     const void *const *queue_cur, const void *queue_prev, const int64_t *wave_items,
+                                     const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err,
+                                     void *done_event, ha_stream_t stream_even, ha_stream_t stream_odd, int64_t first_index) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (plan_cur && n_cur && grads && plan_next && n_next && next_out && queue_cur)),
+               "ha_qapply_gated_steps: null pointer");
+    const void *prev = queue_prev;
+    for (int64_t k = 0; k < count; ++k) {
+        HA_REQUIRE(n_cur[k] > 0 || n_next[k] > 0, "ha_qapply_gated_steps: step %lld is empty (leave it out)", (long long)k);
+        const ha_stream_t st = ((first_index + k) & 1) ? stream_odd : stream_even;
+        if (qapply_gated(table, rows, width, plan_cur[k], n_cur[k], grads[k], lr, plan_next[k], n_next[k], next_out[k],
+                         queue_cur[k], prev, queue_n_cap, counts_host ? counts_host[k] : nullptr,
+                         wave_items ? wave_items[k] : -1, epochs ? epochs[k] : 0u, err,
+                         k + 1 == count ? static_cast<hipEvent_t>(done_event) : nullptr, as_stream(st)))
+            return -1;
+        prev = queue_cur[k];
+    }
+    return 0;
+}
+extern "C" int ha_debug_qapply_gated(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
+                                     float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
+                                     const void *queue_prev, int64_t queue_n_cap, const uint32_t *counts,
+                                     unsigned long long *dbg, ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "qapply gated timeline: null debug buffer");
+    return qapply_gated(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_prev,
+                        queue_n_cap, counts, -1, 0u, nullptr, nullptr, as_stream(stream), dbg);
+}
+extern "C" int64_t ha_qapply_span_max(void) { return kQSpanMax; }
+extern "C" int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                              void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
+                              const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host,
+                              const uint32_t *epochs, uint32_t *err, void *done_event, ha_stream_t stream) {
+    return qapply_span(table, rows, width, lr, queue_n_cap, count, plans, n, grads, next_out, queues, wave_items, epochs, err,
+                       static_cast<hipEvent_t>(done_event), as_stream(stream), nullptr, counts_host);
+}
+extern "C" int ha_debug_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
+                                    void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
+                                    const void *const *queues, const int64_t *wave_items,
+                                    const uint32_t *const *counts_host, unsigned long long *dbg, ha_stream_t stream) {
+    HA_REQUIRE(dbg != nullptr, "qapply span timeline: null debug buffer");
+    return qapply_span(table, rows, width, lr, queue_n_cap, count, plans, n, grads, next_out, queues, wave_items, nullptr,
+                       nullptr, nullptr, as_stream(stream), dbg, counts_host);
+}
+// ha_qqueue_batch_epochs with, per step, the plan of the batch BEFORE the batch it applies (plans_b / n_b; NULL or n_b[k] = 0:
+// none): copy items then carry their dependency on that batch's apply (what ha_qapply_span waits for).
+extern "C" int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, const int64_t *n_b, void *const *plans_a,
+                                    const int64_t *n_a, void *const *plans_g, const int64_t *n_g, void *const *queues,
+                                    int64_t queue_n_cap, int64_t count, uint32_t *const *counts_host, const uint32_t *epochs,
+                                    ha_stream_t stream) {
+    return qqueue_batch(rows, width, plans_a, n_a, plans_g, n_g, queues, queue_n_cap, count, as_stream(stream), nullptr,
+                        counts_host, epochs, plans_b, n_b, true);
+}
 extern "C" int ha_qapply_steps_counts(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                                       void *const *plan_cur, const int64_t *n_cur, const float *const *grads,
                                       void *const *plan_next, const int64_t *n_next, float *const *next_out,
                                       const void *const *queue_cur, const int64_t *wave_items,
                                       const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err,
                                       void *done_event, ha_stream_t stream) {
-    (void)counts_host;
-    return ha_qapply_steps_sync(table, rows, width, lr, queue_n_cap, count, plan_cur, n_cur, grads, plan_next, n_next, next_out,
-                                queue_cur, wave_items, epochs, err, done_event, stream);
+    HA_REQUIRE(count >= 0 && (count == 0 || (plan_cur && n_cur && grads && plan_next && n_next && next_out && queue_cur)),
+               "ha_qapply_steps_counts: null pointer");
+    for (int64_t k = 0; k < count; ++k)
+        if (qapply(table, rows, width, plan_cur[k], n_cur[k], grads[k], lr, plan_next[k], n_next[k], next_out[k],
+                   queue_cur[k], queue_n_cap, as_stream(stream), nullptr, wave_items ? wave_items[k] : -1,
+                   epochs ? epochs[k] : 0u, err, k + 1 == count ? static_cast<hipEvent_t>(done_event) : nullptr,
+                   counts_host ? counts_host[k] : nullptr))
+            return -1;
+    if (count == 0 && done_event)
+        HA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(done_event), as_stream(stream)));
+    return 0;
 }
 extern "C" int ha_qapply_sync(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads,
                               float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur,
@@ -2574,4 +3771,39 @@ extern "C" int ha_debug_qprep_f32ids(int64_t rows, int64_t width, const float *a
 // pointer)
 extern "C" const uint32_t *ha_qstep_queue_header(const void *queue) {
     return reinterpret_cast<const uint32_t *>(queue);
+}
+
+
+// ---- the overlap modes under their public names (include/herald_amd.h)
+#undef ha_qapply_span_max
+extern "C" int64_t ha_qapply_span_max(void) {
+    return spn_ha_qapply_span_max();
+}
+#undef ha_qapply_span
+extern "C" int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count, void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out, const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err, void *done_event, ha_stream_t stream) {
+    return spn_ha_qapply_span(table, rows, width, lr, queue_n_cap, count, plans, n, grads, next_out, queues, wave_items, counts_host, epochs, err, done_event, stream);
+}
+#undef ha_debug_qapply_span
+extern "C" int ha_debug_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count, void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out, const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host, unsigned long long *dbg, ha_stream_t stream) {
+    return spn_ha_debug_qapply_span(table, rows, width, lr, queue_n_cap, count, plans, n, grads, next_out, queues, wave_items, counts_host, dbg, stream);
+}
+#undef ha_qqueue_batch_span
+extern "C" int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, const int64_t *n_b, void *const *plans_a, const int64_t *n_a, void *const *plans_g, const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count, uint32_t *const *counts_host, const uint32_t *epochs, ha_stream_t stream) {
+    return spn_ha_qqueue_batch_span(rows, width, plans_b, n_b, plans_a, n_a, plans_g, n_g, queues, queue_n_cap, count, counts_host, epochs, stream);
+}
+#undef ha_qplan_batch_span_f32ids
+extern "C" int ha_qplan_batch_span_f32ids(const float *const *ids, const int64_t *n, void *const *plans, int64_t count, ha_stream_t stream) {
+    return spn_ha_qplan_batch_span_f32ids(ids, n, plans, count, stream);
+}
+#undef ha_qplan_batch_span_u64ids
+extern "C" int ha_qplan_batch_span_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count, ha_stream_t stream) {
+    return spn_ha_qplan_batch_span_u64ids(ids, n, plans, count, stream);
+}
+#undef ha_qapply_gated_steps
+extern "C" int ha_qapply_gated_steps(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count, void *const *plan_cur, const int64_t *n_cur, const float *const *grads, void *const *plan_next, const int64_t *n_next, float *const *next_out, const void *const *queue_cur, const void *queue_prev, const int64_t *wave_items, const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err, void *done_event, ha_stream_t stream_even, ha_stream_t stream_odd, int64_t first_index) {
+    return spn_ha_qapply_gated_steps(table, rows, width, lr, queue_n_cap, count, plan_cur, n_cur, grads, plan_next, n_next, next_out, queue_cur, queue_prev, wave_items, counts_host, epochs, err, done_event, stream_even, stream_odd, first_index);
+}
+#undef ha_debug_qapply_gated
+extern "C" int ha_debug_qapply_gated(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr, void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, const void *queue_prev, int64_t queue_n_cap, const uint32_t *counts, unsigned long long *dbg, ha_stream_t stream) {
+    return spn_ha_debug_qapply_gated(table, rows, width, plan_cur, n_cur, grads, lr, plan_next, n_next, next_out, queue_cur, queue_prev, queue_n_cap, counts, dbg, stream);
 }

@@ -797,7 +797,12 @@ class QueueStepPipeline:
         preparation stream waits for (ha_qapply_steps_sync, include/herald_amd.h): ~1 us per step less at blocks of 16.
         Requirements: the ids handed to prepare_block / step are COMPLETE on the device when they are handed over (nothing
         orders them behind work on the caller's stream), and the steps are enqueued eagerly (not captured)."""
-        L = _lib.load()
+        # span=True: plans and queues also carry what spanning and gated launches need (ha_qapply_span, ha_qapply_gated_steps:
+        # per-key flag and dependency words, gate words, "finished" counters; the builder joins three batches instead of two).
+        # That engine is a translation unit of its own (csrc/qspan.hip, entry points spn_ha_q*): carrying its machinery in the
+        # default engine cost one launch per step 0.3-0.6 us per step (docs/EXPERIMENTS.md round 5 section 10).
+        self.span_queues = bool(span) or os.environ.get("HA_QSPAN_QUEUES") == "1"
+        L = _lib.SpanView(_lib.load()) if self.span_queues else _lib.load()
         _require(table, torch.float32, "table")
         self.table, self.lr = table, float(lr)
         self.device = table.device if device is None else torch.device(device)
@@ -814,10 +819,6 @@ class QueueStepPipeline:
                 check(-1, "ha_qstep_init")
         self.capacity = max(int(capacity), 1)
         self.overlap = bool(overlap)
-        # span=True: plans and queues also carry what spanning and gated launches need (ha_qapply_span, ha_qapply_gated_steps:
-        # per-key flag and dependency words, gate words, "finished" counters; the builder then joins three batches instead of
-        # two) -- together 0.2-0.3 us per step for the default one-launch-per-step form: off unless asked for
-        self.span_queues = bool(span) or os.environ.get("HA_QSPAN_QUEUES") == "1"
         if sync not in ("events", "flags"):
             raise ValueError("sync must be 'events' or 'flags'")
         self.sync = sync if self.overlap else "events"
@@ -1095,7 +1096,7 @@ class QueueStepPipeline:
     def apply(self, c, grads, out, stream=None, dbg=None, n_cur=None, n_next=None):
         """Step c on `stream`: batch c applied with `grads`, the rows of batch c+1 to `out`.  n_cur / n_next: the ids of
         the two batches (default: as recorded when their plans were prepared)."""
-        L = _lib.load()
+        L = self._L
         t = self.table
         rows, width = t.shape
         n_cur = self.n.get(c, 0) if n_cur is None else int(n_cur)
@@ -1176,7 +1177,7 @@ class QueueStepPipeline:
         conversion of apply() costs more host time than the launch itself)."""
         if self.sync == "flags":
             raise RuntimeError("apply_call: use apply / apply_steps_call with sync='flags'")
-        L = _lib.load()
+        L = self._L
         t = self.table
         rows, width = t.shape
         hint = ctypes.c_int64(-1)
@@ -1199,7 +1200,7 @@ class QueueStepPipeline:
     def apply_steps_call(self, c0, grads_list, out_list, stream, n, sized=True):
         """-> callable(first step index) that enqueues len(grads_list) consecutive steps c0, c0 + 1, ... (and the same
         phases ROTATION steps later) by ONE library call, arguments converted once; every batch has n ids."""
-        L = _lib.load()
+        L = self._L
         t = self.table
         rows, width = t.shape
         cnt = len(grads_list)
