@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 B="--no-cpu-baseline --no-cache-tier --no-laia --no-cold-tier --no-wide"
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc -I include"
-OBJS=$(ls herald_amd/_build/*.o | grep -v qstep.o)
+OBJS=$(ls herald_amd/_build/*.o | grep -v "/qstep.o")
 REPS=${REPS:-2}
 line() { python -c "
 import json,sys
