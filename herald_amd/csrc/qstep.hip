@@ -1462,13 +1462,15 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
     if (a.epoch != 0u) {
         // The caller orders this launch behind the queue's builder without a wait on this stream (the builder ran a block of
         // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
-        // ~1 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
+        // 2 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
         bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;     // (read with the header's counts)
-        for (int spin = 0; !ready && spin < (1 << 20); ++spin) {
+        // (bounded by the 100 MHz clock: 2 s.  A count of spins alone -- 2^20, round 4 -- came to ~40 s on a loaded chip)
+        const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();
+        for (int spin = 0; !ready && spin < (1 << 22); ++spin) {
             const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
-            if (ready)
+            if (ready || __builtin_amdgcn_s_memrealtime() - t_poll > 200000000ull)
                 break;
             __builtin_amdgcn_s_sleep(64);
         }

@@ -722,3 +722,31 @@ def test_qspan_equals_step_by_step_bits_and_rejects_misuse(dev):
     serial.start(d_ids[:serial.LOOKAHEAD])
     with pytest.raises(RuntimeError):
         serial.step_span(g[:2])
+
+
+def test_a_step_whose_queue_was_never_built_raises_and_applies_nothing(dev):
+    """sync="flags": nothing orders an apply launch behind its queue's builder but the epoch tag in the queue.  A step whose
+    queue is never built (here: its block is never prepared) polls for ~2 s, touches no row, and raises the pinned error
+    word of its step -- the pipeline then refuses to go on (a timed-out step must not pass silently)."""
+    rows, width, bs = 50_000, 64, 32
+    rng = np.random.default_rng(7)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    table = _dev(table0, dev)
+    batches = [synth.criteo_batch(bs, step=k, rows=rows).reshape(-1) for k in range(64)]
+    n = batches[0].size
+    pipe = ops.QueueStepPipeline(table, n, 0.05, overlap=True, block=2, sync="flags")
+    d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
+    pipe.start(d_ids[:pipe.LOOKAHEAD])
+    torch.cuda.synchronize()
+    before = table.cpu().numpy()
+    c = 40                                   # far beyond anything that was prepared: its queue slot holds another step's tag
+    pipe.n[c] = pipe.n[c + 1] = n            # (as if its plans existed: the launch is made)
+    g = _dev(rng.standard_normal((n, width), dtype=np.float32), dev)
+    out = torch.zeros((n, width), device=dev)
+    pipe.apply(c, g, out)
+    torch.cuda.synchronize()                 # ~2 s: every workgroup gives up
+    np.testing.assert_array_equal(table.cpu().numpy(), before)
+    assert not out.any()
+    with pytest.raises(RuntimeError, match="failed on the device"):
+        pipe._raise_if_failed([c])
+    assert pipe.overflowed()
