@@ -958,7 +958,12 @@ def main():
         del table
         torch.cuda.empty_cache()
         secondary("cold_tier", lambda: cold_tier(args, dev))
-    print(json.dumps(result))
+    try:        # (anything a native library left in C stdio's buffer goes out in front of the line, not behind it)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

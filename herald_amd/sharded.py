@@ -530,42 +530,64 @@ class NativeExchange:
 
     @classmethod
     def create(cls, group, device):
+        """Every rank of `group` calls this at the same point of the program.  The ranks AGREE (all-reduce) before every step
+        that is collective in RCCL or torch.distributed -- whether an RCCL library can be resolved at all, whether rank 0 got a
+        unique id, whether every communicator came up, whether the first exchange reproduced torch's -- so that a rank that
+        fails locally never leaves the others waiting inside a collective."""
         import os
         if os.environ.get("HA_NATIVE_XCHG") == "0" or not dist.is_initialized():
             return None
         try:
             if dist.get_backend(group) != "nccl":
                 return None
+        except Exception:      # noqa: BLE001
+            return None
+
+        def agree(flag):
+            t = torch.tensor([1 if flag else 0], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return int(t.item()) == 1
+
+        L = None
+        try:
             from . import _lib
             L = _lib.load()
-            if not L.ha_xchg_available():
-                return None
-            x = cls(L, group, device)
-        except Exception:      # noqa: BLE001 -- anything at all: torch's exchange serves
+            have = bool(L.ha_xchg_available())
+        except Exception:      # noqa: BLE001
+            have = False
+        if not agree(have):
             return None
-        ok = torch.tensor([1 if x._self_check() else 0], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) != 1:
-            x.close()
-            return None
-        return x
-
-    def __init__(self, L, group, device):
-        self.L, self.group, self.device = L, group, torch.device(device)
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
-            if L.ha_xchg_unique_id(ctypes.c_void_p(uid.data_ptr())) != 0:
-                raise RuntimeError(L.ha_last_error().decode())
-        uid = uid.to(self.device)
+        x = cls.__new__(cls)
+        x.L, x.group, x.device = L, group, torch.device(device)
+        x.world, x.rank = dist.get_world_size(group), dist.get_rank(group)
+        x.h = None
+        x._i64 = ctypes.c_int64 * x.world
+        # rank 0's unique id (all zeros + a flag byte if it could not be made), carried over by torch.distributed
+        uid = torch.zeros(129, dtype=torch.uint8)
+        if x.rank == 0:
+            try:
+                if L.ha_xchg_unique_id(ctypes.c_void_p(uid.data_ptr())) == 0:
+                    uid[128] = 1
+            except Exception:      # noqa: BLE001
+                pass
+        uid = uid.to(x.device)
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast(uid, src=src, group=group)
         uid = uid.cpu()
-        with torch.cuda.device(self.device):
-            self.h = L.ha_xchg_create(ctypes.c_void_p(uid.data_ptr()), self.world, self.rank)
-        if not self.h:
-            raise RuntimeError(L.ha_last_error().decode())
-        self._i64 = ctypes.c_int64 * self.world
+        if int(uid[128]) != 1:      # (the same word on every rank)
+            return None
+        try:
+            with torch.cuda.device(x.device):
+                x.h = L.ha_xchg_create(ctypes.c_void_p(uid.data_ptr()), x.world, x.rank)
+        except Exception:      # noqa: BLE001
+            x.h = None
+        if not agree(bool(x.h)):
+            x.close()
+            return None
+        if not agree(x._self_check()):
+            x.close()
+            return None
+        return x
 
     def close(self):
         if getattr(self, "h", None):

@@ -280,6 +280,13 @@ def run(args, rank, world, dev, cpu_baseline_fn=None):
                                     "xgmi": second["xgmi"], "roofline": second["roofline"],
                                     "same_path_world1_ms_per_step": second["same_path_world1_ms_per_step"],
                                     "note": "BASELINE configs[2]'s per-GPU shape; not part of `value`"}
+        # (RCCL writes its version banner to C stdout when NCCL_DEBUG=VERSION -- the GPU boxes set it -- and C stdio holds it back
+        # until the process exits: flushed HERE, so that the JSON line is the last line of the output, not the first of six)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:      # noqa: BLE001
+            pass
         print(json.dumps(line), flush=True)
     dist.barrier()          # rank 0 may still be timing the CPU baseline: tear the group down together
     dist.destroy_process_group()
