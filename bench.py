@@ -90,14 +90,6 @@ def parse_args():
     p.add_argument("--queue-block", type=int, default=16,
                    help="--engine queue: steps per block (the plans / queues of a block are prepared by two launches on a "
                         "side stream beside the steps of the block before; ids are needed 3 blocks ahead)")
-    p.add_argument("--span", type=int, default=None,
-                   help="--engine queue: steps ONE launch spans (ha_qapply_span: the items of consecutive steps wait for each "
-                        "other row by row instead of a launch boundary per step; the same results bit for bit).  Default: 0 = one "
-                        "launch per step (the spanning launch measured slower: docs/EXPERIMENTS.md).  Plain launches only")
-    p.add_argument("--gated", action="store_true",
-                   help="--engine queue: one launch per step on TWO streams alternately, every item of a step waiting -- behind "
-                        "its gradient rows, before it touches a table row -- for one word the step before sets when it has "
-                        "finished (ha_qapply_gated_steps): the tail of a launch, the boundary and the next launch's ramp overlap")
     p.add_argument("--queue-serial", action="store_true",
                    help="--engine queue with the preparation launch in front of every step on the timed stream instead of "
                         "beside the steps on side streams")
@@ -549,8 +541,7 @@ def main():
             # apply checks it before its first item) and the last launch of a block completes the event the side stream waits
             # for (no event record / wait between two steps); hipGraph replays (--graph-steps > 1) keep the event pair
             qsync = "events" if (args.graph_steps > 1 or os.environ.get("HA_QSYNC") == "events") else "flags"
-            pipe = ops.QueueStepPipeline(table, n, LR, block=args.queue_block, overlap=not args.queue_serial, sync=qsync,
-                                         span=bool(args.span or args.gated))
+            pipe = ops.QueueStepPipeline(table, n, LR, block=args.queue_block, overlap=not args.queue_serial, sync=qsync)
             LA, Bk = pipe.LOOKAHEAD, pipe.block
             G = Bk                       # graphs are cut at block starts (the side work is enqueued between them)
             ids_rows = [ids_dev[i] for i in range(nb)]        # the batches as tensors of their own, sliced once
@@ -622,31 +613,19 @@ def main():
     use_graph = G > 1 and args.graph_steps > 1      # --graph-steps 1: plain launches (the PMC passes)
     graphs = {}
     step_chunk = None
-    span = 0
     if queue and not use_graph:
         packs = {}
-        span = min(pipe.SPAN_MAX, 0 if args.span is None else args.span)
-        span = span if span >= 2 else 0
-        gated = args.gated and not span
 
         def make_pack(k, ln):
             bs = [(k + i) % nb for i in range(ln)]
-            mk = pipe.apply_span_call if span else pipe.apply_gated_call if gated else pipe.apply_steps_call
-            return mk(k, [grads[x % nbuf] for x in bs], [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
-
-        def pieces(k, ln):
-            """a chunk (inside one block) as launches of at most `span` steps"""
-            if not span:
-                return [(k, ln)]
-            return [(j, min(span, k + ln - j)) for j in range(k, k + ln, span)]
+            return pipe.apply_steps_call(k, [grads[x % nbuf] for x in bs], [outs[(x + 1) % nb % nbuf] for x in bs], main_s, n)
 
         def step_chunk(k, ln):
-            for j, m in pieces(k, ln):
-                key = (j % rot_ring, j % nb, m)
-                fn = packs.get(key)
-                if fn is None:      # arguments converted once per (rotation phase, first batch, length)
-                    fn = packs[key] = make_pack(j, m)
-                fn(j)
+            key = (k % rot_ring, k % nb, ln)
+            fn = packs.get(key)
+            if fn is None:      # arguments converted once per (rotation phase, first batch, length)
+                fn = packs[key] = make_pack(k, ln)
+            fn(k)
 
     def chunks(k0, count):
         """[k0, k0+count) cut at the multiples of G: (first step, length) pieces of at most G steps."""
@@ -704,9 +683,8 @@ def main():
     pre = min(max(args.pre_roll, 0), wu)
     if step_chunk is not None:      # convert the arguments of everything the warm-up and the timed region enqueue
         for k, ln in list(chunks(K0, wu - pre)) + list(chunks(K0 + wu - pre, pre)) + list(chunks(K0 + wu, args.steps)):
-            for j, m in pieces(k, ln):
-                if (j % rot_ring, j % nb, m) not in packs:
-                    packs[(j % rot_ring, j % nb, m)] = make_pack(j, m)
+            if (k % rot_ring, k % nb, ln) not in packs:
+                packs[(k % rot_ring, k % nb, ln)] = make_pack(k, ln)
     if use_graph:     # capture everything the warm-up and the timed region replay, before either runs
         torch.cuda.synchronize()
         for k, ln in list(chunks(K0, wu - pre)) + list(chunks(K0 + wu - pre, pre)) + list(chunks(K0 + wu, args.steps)):
@@ -750,12 +728,8 @@ def main():
                 ops.embedding_lookup(table, ids_dev[k % nb], out=scratch, stream=main_s)
     run(K0 + wu - pre, pre)
     t0 = time.perf_counter()
-    if queue:
-        pipe.join(main_s)      # (gated launches: the second stream's steps so far are in front of the start event)
     e0.record(main_s)
     replays = run(K0 + wu, args.steps)
-    if queue:
-        pipe.join(main_s)
     e1.record(main_s)
     t_enq = time.perf_counter() - t0
     if gate is not None:
@@ -785,20 +759,13 @@ def main():
     if one:
         # the step IS one launch of ha::step_kernel: its average duration is the HIP-event time of the
         # timed region / K, measured on the launch stream
-        kname = ("ha::qapply_span_kernel" if span else "ha::qapply_gated_kernel" if (args.gated and not use_graph) else
-                 "ha::qapply_kernel") if queue else \
-            "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
+        kname = "ha::qapply_kernel" if queue else "ha::step_fwd_kernel" if ahead2 else "ha::step_kernel"
         traffic, traffic_src = pmc_traffic(kname)
-        # launches of the timed region (a spanning launch covers several steps: bytes and duration are per LAUNCH, the
-        # PMC traffic per launch is that of its steps)
-        n_launch = sum(len(pieces(k, ln)) for k, ln in chunks(K0 + wu, args.steps)) if span else args.steps
-        per_launch = args.steps / n_launch
-        dom_bytes = (fwd_b + bwd_b) * per_launch
+        n_launch = args.steps           # one launch = one step
+        per_launch = 1.0
+        dom_bytes = fwd_b + bwd_b
         ach = dom_bytes / (dev_ms / n_launch * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": kname + ((" (the items of %.1f consecutive steps per launch, ordered row by row "
-                                                        "inside the launch: SGD apply of batch k + rows of batch k+1 from the "
-                                                        "work queue of every step)" % per_launch) if span else
-                                                       " (the items of a step: SGD apply of batch k + rows of batch k+1 "
+        roofline = {"bound": "hbm", "kernel": kname + (" (the items of a step: SGD apply of batch k + rows of batch k+1 "
                                                        "from its work queue)" if queue else
                                                        " (SGD apply of batch k, rows of batch k+1, plan finish of "
                                                        "batch k+2, sort of batch k+3)" if ahead2 else
@@ -875,8 +842,7 @@ def main():
                                   ("one launch per %s from the steps' work queues: apply(k) + rows of k+1 per unique key; plans "
                                    "and queues prepared a block of %d steps at a time by two launches on a side stream, "
                                    "inside the timed region; keys with 16+ occurrences as row - tree_sum(lr*g)"
-                                   % ("up to %d steps (their items ordered row by row inside the launch)" % span if span
-                                      else "step", args.queue_block)) if queue and not args.queue_serial else
+                                   % ("step", args.queue_block)) if queue and not args.queue_serial else
                                   "three launches per step: plan of batch k+2, queue of step k+1, then the items of step "
                                   "k from its queue" if queue else
                                   "one launch: apply(k), rows of k+1 forwarded / copied, finish(k+2), sort(k+3)" if ahead2 else
@@ -893,9 +859,7 @@ def main():
                    "numerics": "tolerance>=16" if queue else "bit-exact",
                    "stream_sync": (pipe.sync if queue and not args.queue_serial else None),
                    "launch": ("%d hipGraph replays of at most %d steps each" % (replays, G)) if use_graph
-                             else ("plain launches, one per span of up to %d steps, enqueued ahead of the device" % span) if span
                              else "plain launches, one per step, enqueued ahead of the device",
-                   "span_steps": span, "gated_two_streams": bool(queue and not use_graph and args.gated and not span),
                    "parallelism": "1 GPU"},
         "step_algorithmic_bytes": fwd_b + bwd_b,
         "step_hbm_GBps": step_gbs, "step_hbm_frac_of_peak": step_gbs / HBM_PEAK_GBS,

@@ -79,38 +79,8 @@ def load(build_if_missing=True):
     except OSError as e:
         raise HeraldAmdError("cannot load %s: %s" % (LIB_PATH, e))
     _declare(L)
-    # the engine of the launches that overlap consecutive steps (csrc/qspan.hip) exports its copies of the work-queue entry
-    # points under the prefix spn_: same prototypes
-    for name, fn in list(vars(L).items()):
-        if name.startswith(("ha_q", "ha_debug_q")):
-            try:
-                twin = getattr(L, "spn_" + name)
-            except AttributeError:
-                continue
-            twin.restype = fn.restype
-            twin.argtypes = fn.argtypes
     _lib = L
     return L
-
-
-class SpanView:
-    """The library as a pipeline built for spanning / gated launches sees it (QueueStepPipeline(span=True)): every work-queue
-    entry point resolves to the copy in csrc/qspan.hip (spn_ha_q*), everything else to the library itself."""
-
-    def __init__(self, L):
-        self.__dict__["_L"] = L
-
-    def __getattr__(self, name):
-        L = self.__dict__["_L"]
-        if name.startswith(("ha_q", "ha_debug_q")):
-            try:
-                fn = getattr(L, "spn_" + name)
-            except AttributeError:
-                fn = getattr(L, name)
-        else:
-            fn = getattr(L, name)
-        self.__dict__[name] = fn
-        return fn
 
 
 def check(rc, what=""):
@@ -147,8 +117,6 @@ def _declare(L):
     L.ha_host_unmap.argtypes = [vp]
     L.ha_qbig_max_ids.restype = i64
     L.ha_qbig_max_ids.argtypes = []
-    L.ha_qapply_span_max.restype = i64
-    L.ha_qapply_span_max.argtypes = []
     L.ha_xchg_create.restype = vp
     L.ha_xchg_create.argtypes = [vp, c.c_int, c.c_int]
     L.ha_qbig_plan_bytes.restype = sz
@@ -212,16 +180,11 @@ def _declare(L):
         "ha_qapply_steps_sync": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qapply_steps_counts": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qapply_sync": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, c.c_uint32, vp, vp, vp],
-        "ha_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-        "ha_debug_qapply_span": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-        "ha_qqueue_batch_span": [i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
         "ha_xchg_available": [],
         "ha_xchg_unique_id": [vp],
         "ha_xchg_destroy": [vp],
         "ha_xchg_bytes": [vp, vp, vp, vp, vp, vp],
         "ha_xchg_rows": [vp, vp, vp, vp, vp, i64, vp],
-        "ha_qapply_gated_steps": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64],
-        "ha_debug_qapply_gated": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp, i64, vp, vp, vp],
         "ha_qbig_plan_view": [vp, i64, vp, vp, vp, vp, vp, vp, vp],
         "ha_plan_build_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
         "ha_plan_sort_batch_f32ids_lim": [vp, vp, vp, c.c_int, c.c_uint64, vp],
@@ -255,8 +218,6 @@ def _declare(L):
         "ha_qprep_u64ids": [i64, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp],
         "ha_qplan_batch_f32ids": [vp, vp, vp, i64, vp],
         "ha_qplan_batch_u64ids": [vp, vp, vp, i64, vp],
-        "ha_qplan_batch_span_f32ids": [vp, vp, vp, i64, vp],
-        "ha_qplan_batch_span_u64ids": [vp, vp, vp, i64, vp],
         "ha_qqueue_batch": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp],
         "ha_stream_gate": [vp, vp],
         "ha_debug_occupy": [i64, i64, i64, i64, vp],

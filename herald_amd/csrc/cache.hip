@@ -2270,7 +2270,8 @@ extern "C" int ha_cache_sort_ahead_batch(ha_cache *h, const void *const *keys, i
     return 0;
 }
 
-static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_t n, float *dest, hipStream_t s, bool presorted);
+static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_t n, float *dest, hipStream_t s, bool presorted,
+                             bool from_ring = false);
 
 extern "C" int ha_cache_lookup(ha_cache *h, const void *keys, int key_kind, int64_t n,
                                float *dest, ha_stream_t stream) {
@@ -2291,7 +2292,7 @@ extern "C" int ha_cache_lookup_presorted(ha_cache *h, const void *keys, int key_
         h->ring_ws[i] = h->c.plan_ws;        // (all workspaces are of one size: the ring keeps the lookup's old one)
         h->c.plan_ws = ws;
         ++h->ring_head;
-        return cache_lookup_impl(h, keys, key_kind, n, dest, as_stream(stream), true);
+        return cache_lookup_impl(h, keys, key_kind, n, dest, as_stream(stream), true, true);
     }
     if (n == 0 || n > kSmallMax)      // sort_ahead ignored this batch
         return cache_lookup_impl(h, keys, key_kind, n, dest, as_stream(stream), false);
@@ -2301,12 +2302,14 @@ extern "C" int ha_cache_lookup_presorted(ha_cache *h, const void *keys, int key_
 }
 
 static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_t n, float *dest, hipStream_t s,
-                             bool presorted) {
+                             bool presorted, bool from_ring) {
     HA_REQUIRE(h && h->c.table && !h->c.remote, "cache_lookup: no local store bound (remote stores use "
                "ha_cache_lookup_begin / ha_cache_lookup_finish)");
     HA_REQUIRE(n >= 0 && (n == 0 || (keys && dest)), "cache_lookup: bad arguments");
     Cache &c = h->c;
-    if (presorted && h->ahead_n >= 0) {          // the sorted keys are in the second workspace: it becomes the plan of this batch
+    // (a batch from the ring of ha_cache_sort_ahead_batch has its sorted keys in c.plan_ws already: a pending sort of
+    // ha_cache_sort_ahead -- another batch's -- stays where it is)
+    if (presorted && !from_ring && h->ahead_n >= 0) {   // the sorted keys are in the second workspace: it becomes the plan of this batch
         HA_REQUIRE(hipStreamWaitEvent(s, h->ahead_join, 0) == hipSuccess, "cache_lookup_presorted: join failed");
         std::swap(c.plan_ws, h->plan_ws_alt);
         h->ahead_n = -1;

@@ -29,8 +29,7 @@ struct PlanPtrs {
     uint32_t *bucket_start;  // [kRadixBuckets + 1] first sorted position of every most-significant-digit bucket
     uint32_t *pass_flags;    // [kRadixFusedBlocks] one-launch radix passes: tile t has published its histogram of pass k
     uint32_t *block_sums;  // finish scan scratch
-    uint32_t *dep;         // [2 n] work-queue step spanning several batches (qstep.hip): per group, at its segment start,
-                           // {units of the row READY for this batch's apply, units APPLIED by it}
+    uint32_t *dep;         // [2 n] scratch words of a finished plan's consumers (scatter.hip: the chunk sums of tolerance mode 2)
     size_t bytes;
 };
 

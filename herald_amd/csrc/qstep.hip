@@ -46,12 +46,8 @@
 // deterministic tree sum instead -- within the 1e-5 relative the north star allows for accumulated gradients
 // (tests/test_gpu_qstep.py holds both: bit-exact below 16 occurrences, 1e-5 above).  Callers that need the serial
 // chain for every run length use ha_step_* / ha_sgd_push_pull_*.
-// NOTE (round 5): this file is the one-launch-per-step engine and the wide path as round 4 left them, plus the fixes of round 5
-// that concern them (items leave through the L2 in front of the epoch tag; waits the compiler cannot delete; 128 registers for
-// the whole-workgroup wide join; any workgroup that times out raises the error word).  The launches that OVERLAP consecutive
-// steps (ha_qapply_span, ha_qapply_gated_steps) and the plans / queues built for them live in csrc/qspan.hip, a copy of this
-// engine with their machinery in it: carrying that machinery here cost the default path 0.3-0.6 us per step
-// (docs/EXPERIMENTS.md, round 5 section 10).
+// NOTE (round 6): the launches that overlapped consecutive steps (round 5: a spanning launch, a gated two-stream form, a
+// persistent form -- all slower than one launch per step) are gone from the tree; docs/EXPERIMENTS.md round 5 keeps the write-up.
 #include <hip/hip_ext.h>
 
 #include "plan_dev.h"
@@ -2424,7 +2420,7 @@ extern "C" int ha_qapply_steps_sync(float *table, int64_t rows, int64_t width, f
     return 0;
 }
 // ha_qapply_steps_sync with the pinned count words of every step's queue beside the hints (one launch per step sizes its grid
-// by `wave_items`; the counts are what the spanning launch of csrc/qspan.hip takes)
+// by `wave_items`)
 extern "C" int ha_qapply_steps_counts(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
                                       void *const *plan_cur, const int64_t *n_cur, const float *const *grads,
                                       void *const *plan_next, const int64_t *n_next, float *const *next_out,

@@ -142,29 +142,40 @@ extern "C" int ha_xchg_bytes(void *h, const void *send, const int64_t *send_byte
     char *rp = static_cast<char *>(recv);
     int64_t so = 0, ro = 0;
     bool any = false;
+    // every argument is checked BEFORE the group is opened, and an error inside it closes the group first: a thread left
+    // inside an open RCCL group queues every later collective of the process (c10d's too) without ever launching it
     for (int g = 0; g < x->world; ++g) {
         HA_REQUIRE(send_bytes[g] >= 0 && recv_bytes[g] >= 0, "ha_xchg_bytes: negative count");
         any = any || (g != x->rank && (send_bytes[g] > 0 || recv_bytes[g] > 0));
     }
-    if (any)
-        HA_CHECK_NCCL(api().GroupStart());
-    for (int g = 0; g < x->world; ++g) {
-        if (g == x->rank) {
-            if (send_bytes[g] > 0) {
-                HA_REQUIRE(send_bytes[g] == recv_bytes[g], "ha_xchg_bytes: this rank's own counts differ");
-                HA_CHECK_HIP(hipMemcpyAsync(rp + ro, sp + so, static_cast<size_t>(send_bytes[g]), hipMemcpyDeviceToDevice, s));
-            }
-        } else {
+    HA_REQUIRE(send_bytes[x->rank] == 0 || send_bytes[x->rank] == recv_bytes[x->rank],
+               "ha_xchg_bytes: this rank's own counts differ");
+    HA_REQUIRE(!any || (send != nullptr && recv != nullptr), "ha_xchg_bytes: null buffers");
+    if (send_bytes[x->rank] > 0) {
+        int64_t so0 = 0, ro0 = 0;
+        for (int g = 0; g < x->rank; ++g) {
+            so0 += send_bytes[g];
+            ro0 += recv_bytes[g];
+        }
+        HA_CHECK_HIP(hipMemcpyAsync(rp + ro0, sp + so0, static_cast<size_t>(send_bytes[x->rank]), hipMemcpyDeviceToDevice, s));
+    }
+    if (!any)
+        return 0;
+    HA_CHECK_NCCL(api().GroupStart());
+    int bad = 0;
+    for (int g = 0; g < x->world && !bad; ++g) {
+        if (g != x->rank) {
             if (send_bytes[g] > 0)
-                HA_CHECK_NCCL(api().Send(sp + so, static_cast<size_t>(send_bytes[g]), kUint8, g, x->comm, s));
-            if (recv_bytes[g] > 0)
-                HA_CHECK_NCCL(api().Recv(rp + ro, static_cast<size_t>(recv_bytes[g]), kUint8, g, x->comm, s));
+                bad = api().Send(sp + so, static_cast<size_t>(send_bytes[g]), kUint8, g, x->comm, s);
+            if (!bad && recv_bytes[g] > 0)
+                bad = api().Recv(rp + ro, static_cast<size_t>(recv_bytes[g]), kUint8, g, x->comm, s);
         }
         so += send_bytes[g];
         ro += recv_bytes[g];
     }
-    if (any)
-        HA_CHECK_NCCL(api().GroupEnd());
+    const int end = api().GroupEnd();
+    HA_REQUIRE(bad == 0, "ha_xchg_bytes: ncclSend / ncclRecv failed (%d); the group was closed", bad);
+    HA_CHECK_NCCL(end);
     return 0;
 }
 

@@ -788,7 +788,7 @@ class QueueStepPipeline:
     chain bit for bit.  `plan_of(j)` holds the unique keys / counts / inverse / occurrence lists of batch j with the
     unique keys in hash-slot order (not np.unique's order) once its block has been prepared."""
 
-    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True, sync="events", span=False):
+    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True, sync="events"):
         """sync: how the preparation stream and the caller's stream are ordered when overlap is on.
         "events" (default): an event record and an event wait on the caller's stream at every block start -- safe for any
         caller (ids produced by work queued on the caller's stream, steps captured into hipGraphs).
@@ -797,12 +797,7 @@ class QueueStepPipeline:
         preparation stream waits for (ha_qapply_steps_sync, include/herald_amd.h): ~1 us per step less at blocks of 16.
         Requirements: the ids handed to prepare_block / step are COMPLETE on the device when they are handed over (nothing
         orders them behind work on the caller's stream), and the steps are enqueued eagerly (not captured)."""
-        # span=True: plans and queues also carry what spanning and gated launches need (ha_qapply_span, ha_qapply_gated_steps:
-        # per-key flag and dependency words, gate words, "finished" counters; the builder joins three batches instead of two).
-        # That engine is a translation unit of its own (csrc/qspan.hip, entry points spn_ha_q*): carrying its machinery in the
-        # default engine cost one launch per step 0.3-0.6 us per step (docs/EXPERIMENTS.md round 5 section 10).
-        self.span_queues = bool(span) or os.environ.get("HA_QSPAN_QUEUES") == "1"
-        L = _lib.SpanView(_lib.load()) if self.span_queues else _lib.load()
+        L = _lib.load()
         _require(table, torch.float32, "table")
         self.table, self.lr = table, float(lr)
         self.device = table.device if device is None else torch.device(device)
@@ -857,9 +852,6 @@ class QueueStepPipeline:
         self._ev_pool = []
         self._last_items = 0
         self.fallbacks, self._fb_plan, self._wide_ids = 0, None, {}
-        # steps one launch may SPAN (ha_qapply_span: the items of consecutive steps wait for each other row by row instead of
-        # a launch boundary per step): inside one block, narrow path only
-        self.SPAN_MAX = min(int(L.ha_qapply_span_max()), self.block) if (self.overlap and not self.wide) else 0
         self._enq_last = None        # the last step handed to the device (ordering fallback of the flags mode)
         self.reset()
 
@@ -881,7 +873,6 @@ class QueueStepPipeline:
         self._done_ev = {}
         self.c, self.n, self.shape, self.ids = None, {}, {}, {}
         self._enq_last, self._covered = None, -(1 << 60)
-        self._gate_prev = None
         self._ev_side = {}          # block index -> event behind the side work launched at its start
         self._held = {}             # block index -> id tensors its plan launch reads (kept alive, not record_stream'ed)
         return self
@@ -908,8 +899,7 @@ class QueueStepPipeline:
         return bool((self._counts_np[:, 3] & ~4).any())      # (4 = "this step takes the sorted plan": handled, not an error)
 
     def _raise_if_failed(self, steps):
-        """The pinned error words of `steps`: 8 = an apply launch gave up waiting (for its queue's epoch tag, or -- a launch
-        that spans several steps -- for an item of the step before): the table is only partly updated from there on."""
+        """The pinned error words of `steps`: 8 = an apply launch gave up waiting for its queue's epoch tag."""
         cc, ring = self._counts_c, self.COUNTS
         for j in steps:
             f = cc[4 * (j % ring) + 3]
@@ -934,8 +924,8 @@ class QueueStepPipeline:
         sp = _stream_ptr(s)
         vp, i64 = ctypes.c_void_p, ctypes.c_int64
         flags = self.sync == "flags"
-        # a launch of the block before last that gave up (flags: a queue that never became ready; a spanning launch: an item
-        # that never finished) has left its word in pinned memory by now: stop here rather than train on a partly updated table
+        # a launch of the block before last that gave up (flags: a queue that never became ready) has left its word in pinned
+        # memory by now: stop here
         self._raise_if_failed(range(max((b - 2) * B, 0), max((b - 1) * B, 0)))
         if self.overlap and flags:
             # the steps of block b-1 are complete (their last launch carries the event): the plans / queues about to be
@@ -943,10 +933,6 @@ class QueueStepPipeline:
             cev = self._done_ev.pop(b - 1, None)
             if cev is not None:
                 check(L.ha_stream_wait_event(sp, cev), "ha_stream_wait_event")
-                if getattr(self, "aux", None) is not None:
-                    # gated launches: the gate words of block b-1's last step are about to be rebuilt with its queue slot --
-                    # the first step of block b (on the second stream) is ordered behind that launch by its event instead
-                    check(L.ha_stream_wait_event(_stream_ptr(self.aux), cev), "ha_stream_wait_event")
                 self._cev_pool.append(cev)
                 self._covered = b * B - 1
             elif self._enq_last is not None and self._enq_last > self._covered:
@@ -996,8 +982,7 @@ class QueueStepPipeline:
                 check(getattr(L, "ha_qbig_plan_batch_" + kind)(ids_arr, n_arr, pl_arr, self.capacity, cnt, sp),
                       "ha_qbig_plan_batch")
             else:
-                check(getattr(L, ("ha_qplan_batch_span_" if self.span_queues else "ha_qplan_batch_") + kind)(
-                    ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
+                check(getattr(L, "ha_qplan_batch_" + kind)(ids_arr, n_arr, pl_arr, cnt, sp), "ha_qplan_batch")
             for j, _, m in lst:
                 pl = self.plans[j % self.NPLAN]
                 pl.n = m
@@ -1032,28 +1017,15 @@ class QueueStepPipeline:
                 check(L.ha_qbig_queue_batch(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
                       "ha_qbig_queue_batch")
             else:
-                # (with the plan of the batch BEFORE the one a step applies: its copy items' dependencies, ha_qapply_span)
-                if self.span_queues:
-                    pb = (vp * cnt)(*[pp[(j - 1) % NP] if nget(j - 1, 0) else None for j in steps])
-                    nb_ = (i64 * cnt)(*[nget(j - 1, 0) for j in steps])
-                    check(L.ha_qqueue_batch_span(rows, width, pb, nb_, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
-                          "ha_qqueue_batch")
-                else:
-                    check(L.ha_qqueue_batch_epochs(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
-                          "ha_qqueue_batch")
-        gated = getattr(self, "aux", None) is not None
-        if self.overlap and (not flags or gated):
-            # (gated launches under sync="flags" as well: two launches of polling workgroups fill every wave slot of the chip, and
-            # a queue builder that has not started yet then finds no compute unit to start on -- the steps of a block are
-            # enqueued behind the event of their queues' builder, on both streams)
+                check(L.ha_qqueue_batch_epochs(rows, width, pa, na, pg, ng, qs, self.capacity, cnt, cs, eps, sp),
+                      "ha_qqueue_batch")
+        if self.overlap and not flags:
             ev = self._event()
             ev.record(s)
             self._ev_side[b] = ev
             ready = self._ev_side.pop(b - 1, None)
             if ready is not None:
                 main.wait_event(ready)
-                if gated:
-                    self.aux.wait_event(ready)
                 self._ev_pool.append(ready)
 
     def _event(self):
@@ -1254,369 +1226,6 @@ class QueueStepPipeline:
             elif fn(*head, pc, ns, gs, pn, ns, os_, qs, hints, sp) != 0:
                 check(-1, "ha_qapply_steps")
         return call
-
-    # ---- several steps by ONE launch -----------------------------------------------------------------------------------
-    def _span_ok(self, c0, cnt):
-        if not self.span_queues:
-            raise RuntimeError("QueueStepPipeline: spanning launches need the queues built for them (span=True)")
-        if self.SPAN_MAX < 2:
-            raise RuntimeError("QueueStepPipeline: spanning launches need overlap=True, block >= 2 and batches of at most %d ids"
-                               % qstep_max_ids())
-        if not 1 <= cnt <= self.SPAN_MAX:
-            raise ValueError("a launch spans 1..%d steps (got %d)" % (self.SPAN_MAX, cnt))
-        if c0 // self.block != (c0 + cnt - 1) // self.block:
-            raise ValueError("steps %d..%d cross a block boundary (block = %d): a spanning launch stays inside one block -- the "
-                             "queues of the next block may still be under construction" % (c0, c0 + cnt - 1, self.block))
-
-    def apply_span(self, c0, grads_list, out_list, stream=None, dbg=None):
-        """Steps c0 .. c0 + len(grads_list) - 1 by ONE launch (ha_qapply_span, csrc/qstep.hip): step c0 + i applies batch
-        c0 + i with grads_list[i] and writes the rows of batch c0 + i + 1 to out_list[i].  The items of consecutive steps wait
-        for each other row by row (counters in the plans) instead of a launch boundary per step; the results are those of
-        `apply` step by step, bit for bit.  EVERY batch's gradients must be resident when the call is made -- a caller whose
-        gradients of step k + 1 depend on the rows of step k (a model between lookup and update, no staleness) cannot span."""
-        L = self._L
-        t = self.table
-        rows, width = t.shape
-        cnt = len(grads_list)
-        self._span_ok(c0, cnt)
-        if len(out_list) != cnt:
-            raise ValueError("one output per step")
-        ns = [self.n.get(c0 + i, 0) for i in range(cnt + 1)]
-        flags = self.sync == "flags" and dbg is None
-        if flags and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("QueueStepPipeline(sync='flags'): steps cannot be captured into a hipGraph (use sync='events')")
-        last = c0 + cnt - 1
-        done = self._block_done_event(last) if flags else None
-        self._enq_last = last if self._enq_last is None else max(self._enq_last, last)
-        sp = _stream_ptr(stream)
-        # a step without ids at both ends has no queue and launches nothing: the span is cut into the runs between such steps
-        # (what is on either side of one is ordered by the stream)
-        work = [bool(ns[i] or ns[i + 1]) for i in range(cnt)]
-        if not all(work):
-            runs, i = [], 0
-            while i < cnt:
-                if not work[i]:
-                    i += 1
-                    continue
-                j = i
-                while j < cnt and work[j]:
-                    j += 1
-                runs.append((i, j))
-                i = j
-            if done is not None:
-                self._done_ev.pop(last // self.block, None)       # (re-registered by the launch that carries it, or recorded)
-                self._cev_pool.append(done)
-            for r, (i, j) in enumerate(runs):
-                self.apply_span(c0 + i, grads_list[i:j], out_list[i:j], stream, dbg)
-            if flags and (not runs or runs[-1][1] != cnt):
-                ev = self._block_done_event(last)
-                if ev is not None:
-                    check(L.ha_event_record(ev, sp), "ha_event_record")
-            return
-        lead, c1, m = 0, c0, cnt
-        for i in range(m):
-            if ns[i]:
-                _require(grads_list[lead + i], torch.float32, "grads")
-                if grads_list[lead + i].numel() != ns[i] * width:
-                    raise ValueError("grads of step %d must hold %d x %d values" % (c1 + i, ns[i], width))
-            if ns[i + 1]:
-                _require(out_list[lead + i], torch.float32, "out")
-                if out_list[lead + i].numel() != ns[i + 1] * width:
-                    raise ValueError("out of step %d must hold %d x %d values" % (c1 + i, ns[i + 1], width))
-        vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        pl = (vp * (m + 1))(*[self._plan_ptr[(c1 + i) % self.NPLAN] if ns[i] else None for i in range(m + 1)])
-        na = (i64 * (m + 1))(*ns)
-        gs = (vp * m)(*[grads_list[lead + i].data_ptr() if ns[i] else None for i in range(m)])
-        os_ = (vp * m)(*[out_list[lead + i].data_ptr() if ns[i + 1] else None for i in range(m)])
-        qs = (vp * m)(*[self._queue(c1 + i) for i in range(m)])
-        hints = (i64 * m)(*[self.wave_items(c1 + i) for i in range(m)])
-        head = (_ptr(t), rows, width, ctypes.c_float(self.lr), self.capacity, m)
-        cs = (vp * m)(*[self._counts_base + 16 * ((c1 + i) % self.COUNTS) for i in range(m)])
-        if dbg is not None:
-            check(L.ha_debug_qapply_span(*head, pl, na, gs, os_, qs, hints, cs, _ptr(dbg), sp), "ha_debug_qapply_span")
-            return
-        eps = (ctypes.c_uint32 * m)(*[self._epoch(c1 + i) if flags else 0 for i in range(m)])
-        check(L.ha_qapply_span(*head, pl, na, gs, os_, qs, hints, cs, eps, self._err_ptr(last) if flags else None, done, sp),
-              "ha_qapply_span")
-
-    def apply_span_call(self, c0, grads_list, out_list, stream, n):
-        """-> callable(first step index): apply_span for the steps c0 .. (and the same phases ROTATION steps later) with the
-        arguments converted once; every batch has n ids (what bench.py enqueues)."""
-        L = self._L
-        t = self.table
-        rows, width = t.shape
-        cnt = len(grads_list)
-        self._span_ok(c0, cnt)
-        vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        pl = (vp * (cnt + 1))(*[self._plan_ptr[(c0 + i) % self.NPLAN] for i in range(cnt + 1)])
-        na = (i64 * (cnt + 1))(*[n] * (cnt + 1))
-        gs = (vp * cnt)(*[g.data_ptr() for g in grads_list])
-        os_ = (vp * cnt)(*[o.data_ptr() for o in out_list])
-        qs = (vp * cnt)(*[self._queue(c0 + i) for i in range(cnt)])
-        hints = (i64 * cnt)(*[-1] * cnt)
-        eps = (ctypes.c_uint32 * cnt)()
-        cs = (vp * cnt)()
-        base = self._counts_base
-        head = (vp(t.data_ptr()), i64(rows), i64(width), ctypes.c_float(self.lr), i64(self.capacity), i64(cnt))
-        sp = _stream_ptr(stream)
-        fn, epoch, last_err = L.ha_qapply_span, self._epoch, self._err_ptr
-        counts, ring = self._counts_c, self.COUNTS
-        flags = self.sync == "flags"
-        B = self.block
-
-        import time
-        wait_counts = os.environ.get("HA_QSPAN_WAIT_COUNTS", "1") != "0"
-
-        def call(k0):
-            if k0 // B != (k0 + cnt - 1) // B:
-                raise RuntimeError("apply_span_call: steps %d..%d cross a block boundary (block = %d)" % (k0, k0 + cnt - 1, B))
-            self._enq_last = k0 + cnt - 1 if self._enq_last is None else max(self._enq_last, k0 + cnt - 1)
-            if wait_counts:
-                # A launch that knows its queues' item counts finds every wave's item in one trip and is sized exactly; the
-                # builder leaves them in pinned memory a block ahead of the steps.  A host that runs further ahead than that
-                # waits here (the device still has the block before in front of it), at most 20 ms -- then the launch reads
-                # the counts from the queue headers instead.
-                at = 4 * ((k0 + cnt - 1) % ring)
-                if counts[at] == 0 or counts[at + 2] == 0:
-                    t_end = time.perf_counter() + 0.02
-                    while (counts[at] == 0 or counts[at + 2] == 0) and time.perf_counter() < t_end:
-                        pass
-            for i in range(cnt):
-                at = 4 * ((k0 + i) % ring)
-                w, cp = counts[at], counts[at + 2]
-                if counts[at + 3]:
-                    self._raise_if_failed([k0 + i])
-                if w > 0 and cp > 0:
-                    self._last_items = w + cp - 2
-                hints[i] = w + cp - 2 if w > 0 and cp > 0 else (self._last_items * 17) // 16 if self._last_items > 0 else -1
-                eps[i] = epoch(k0 + i) if flags else 0
-                cs[i] = base + 4 * at
-            done = self._block_done_event(k0 + cnt - 1) if flags else None
-            if fn(*head, pl, na, gs, os_, qs, hints, cs, eps, last_err(k0 + cnt - 1) if flags else None, done, sp) != 0:
-                check(-1, "ha_qapply_span")
-        return call
-
-    # ---- one launch per step, GATED: two streams, consecutive launches overlap ---------------------------------------------
-    def _gated_ok(self, c0, cnt):
-        if not self.span_queues:
-            raise RuntimeError("QueueStepPipeline: gated launches need the queues built for them (span=True)")
-        if not self.overlap or self.wide:
-            raise RuntimeError("QueueStepPipeline: gated launches need overlap=True and batches of at most %d ids"
-                               % qstep_max_ids())
-        if cnt < 1:
-            raise ValueError("at least one step")
-        if self.sync == "flags" and c0 // self.block != (c0 + cnt - 1) // self.block:
-            raise ValueError("steps %d..%d cross a block boundary (block = %d): the block's done-event rides on the LAST "
-                             "launch of a call" % (c0, c0 + cnt - 1, self.block))
-
-    def _aux(self, main=None):
-        if getattr(self, "aux", None) is None:
-            self.aux = torch.cuda.Stream(device=self.device)
-            self._gate_prev = None          # (step, queue) of the last gated launch: the chain the next one waits on
-            if self.overlap:
-                # the queues enqueued for building so far (no event was kept for them under sync="flags"): both streams behind them
-                main = main if main is not None else torch.cuda.current_stream(self.device)
-                self.aux.wait_stream(self.side)
-                main.wait_stream(self.side)
-        return self.aux
-
-    def join(self, stream=None):
-        """Makes `stream` wait for the gated launches enqueued on the pipeline's second stream so far."""
-        if getattr(self, "aux", None) is None:
-            return
-        main = stream if stream is not None else torch.cuda.current_stream(self.device)
-        ev = self._event()
-        ev.record(self.aux)
-        main.wait_event(ev)
-        self._ev_pool.append(ev)
-
-    def apply_gated(self, c0, grads_list, out_list, stream=None):
-        """Steps c0 .. as GATED launches (ha_qapply_gated_steps, csrc/qstep.hip): one launch per step, odd steps on `stream`,
-        even steps on a second stream of the pipeline's own; every item of a step waits -- behind its gradient rows, before
-        it touches a table row -- for one word the step before sets when its last workgroup has finished.  Same results as
-        `apply` step by step; every step's gradients must be resident when the call is made (as for apply_span).  The
-        second stream is ordered behind `stream` at the start of the call and `stream` behind it at the end."""
-        L = self._L
-        t = self.table
-        rows, width = t.shape
-        cnt = len(grads_list)
-        self._gated_ok(c0, cnt)
-        if len(out_list) != cnt:
-            raise ValueError("one output per step")
-        main = stream if stream is not None else torch.cuda.current_stream(self.device)
-        aux = self._aux(main)
-        flags = self.sync == "flags"
-        if flags and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("QueueStepPipeline(sync='flags'): steps cannot be captured into a hipGraph (use sync='events')")
-        ns = [self.n.get(c0 + i, 0) for i in range(cnt + 1)]
-        last = c0 + cnt - 1
-        done = self._block_done_event(last) if flags else None
-        self._enq_last = last if self._enq_last is None else max(self._enq_last, last)
-        ev = self._event()
-        ev.record(main)
-        aux.wait_event(ev)
-        self._ev_pool.append(ev)
-        vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        work = [i for i in range(cnt) if ns[i] or ns[i + 1]]
-        for i in work:
-            if ns[i]:
-                _require(grads_list[i], torch.float32, "grads")
-                if grads_list[i].numel() != ns[i] * width:
-                    raise ValueError("grads of step %d must hold %d x %d values" % (c0 + i, ns[i], width))
-            if ns[i + 1]:
-                _require(out_list[i], torch.float32, "out")
-                if out_list[i].numel() != ns[i + 1] * width:
-                    raise ValueError("out of step %d must hold %d x %d values" % (c0 + i, ns[i + 1], width))
-        carried = False
-        for j, i in enumerate(work):
-            c = c0 + i
-            self._raise_if_failed([c])
-            prev = self._gate_prev[1] if (self._gate_prev is not None and self._gate_prev[0] < c and
-                                          self._gate_prev[0] // self.block == c // self.block) else None
-            is_last = j + 1 == len(work)
-            dn = done if (is_last and i == cnt - 1) else None
-            carried = carried or dn is not None
-            check(L.ha_qapply_gated_steps(
-                _ptr(t), rows, width, ctypes.c_float(self.lr), self.capacity, 1,
-                (vp * 1)(self._plan_ptr[c % self.NPLAN] if ns[i] else None), (i64 * 1)(ns[i]),
-                (vp * 1)(grads_list[i].data_ptr() if ns[i] else None),
-                (vp * 1)(self._plan_ptr[(c + 1) % self.NPLAN] if ns[i + 1] else None), (i64 * 1)(ns[i + 1]),
-                (vp * 1)(out_list[i].data_ptr() if ns[i + 1] else None), (vp * 1)(self._queue(c)), prev,
-                (i64 * 1)(self.wave_items(c)), (vp * 1)(self._counts_base + 16 * (c % self.COUNTS)),
-                (ctypes.c_uint32 * 1)(self._epoch(c) if flags else 0), self._err_ptr(c) if flags else None, dn,
-                _stream_ptr(aux), _stream_ptr(main), c), "ha_qapply_gated_steps")
-            self._gate_prev = (c, self._queue(c))
-        self.join(main)
-        if done is not None and not carried:      # the block's last step launched nothing: mark the point on the stream
-            check(L.ha_event_record(done, _stream_ptr(main)), "ha_event_record")
-
-    def apply_gated_call(self, c0, grads_list, out_list, stream, n):
-        """-> callable(first step index): the steps c0 .. (and the same phases ROTATION steps later) as gated launches with the
-        arguments converted once; every batch has n ids (what bench.py enqueues).  NO stream joins: the two streams are
-        ordered by the gates alone -- the caller joins (`join`) where it needs the results on `stream`."""
-        L = self._L
-        t = self.table
-        rows, width = t.shape
-        cnt = len(grads_list)
-        self._gated_ok(c0, cnt)
-        if self.sync != "flags":
-            raise RuntimeError("apply_gated_call needs sync='flags' (the block's done-event orders the second stream; use "
-                               "apply_gated with sync='events')")
-        aux = self._aux(stream)
-        vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        pc = (vp * cnt)(*[self._plan_ptr[(c0 + i) % self.NPLAN] for i in range(cnt)])
-        pn = (vp * cnt)(*[self._plan_ptr[(c0 + i + 1) % self.NPLAN] for i in range(cnt)])
-        ns = (i64 * cnt)(*[n] * cnt)
-        gs = (vp * cnt)(*[g.data_ptr() for g in grads_list])
-        os_ = (vp * cnt)(*[o.data_ptr() for o in out_list])
-        qs = (vp * cnt)(*[self._queue(c0 + i) for i in range(cnt)])
-        hints = (i64 * cnt)(*[-1] * cnt)
-        eps = (ctypes.c_uint32 * cnt)()
-        cs = (vp * cnt)()
-        base = self._counts_base
-        head = (vp(t.data_ptr()), i64(rows), i64(width), ctypes.c_float(self.lr), i64(self.capacity), i64(cnt))
-        sm, sa = _stream_ptr(stream), _stream_ptr(aux)
-        fn, epoch, last_err = L.ha_qapply_gated_steps, self._epoch, self._err_ptr
-        counts, ring = self._counts_c, self.COUNTS
-        flags = self.sync == "flags"
-        B = self.block
-        import time
-        wait_counts = os.environ.get("HA_QSPAN_WAIT_COUNTS", "1") != "0"
-
-        def call(k0):
-            if flags and k0 // B != (k0 + cnt - 1) // B:
-                raise RuntimeError("apply_gated_call: steps %d..%d cross a block boundary (block = %d)" % (k0, k0 + cnt - 1, B))
-            self._enq_last = k0 + cnt - 1 if self._enq_last is None else max(self._enq_last, k0 + cnt - 1)
-            if wait_counts:      # (see apply_span_call)
-                at = 4 * ((k0 + cnt - 1) % ring)
-                if counts[at] == 0 or counts[at + 2] == 0:
-                    t_end = time.perf_counter() + 0.02
-                    while (counts[at] == 0 or counts[at + 2] == 0) and time.perf_counter() < t_end:
-                        pass
-            for i in range(cnt):
-                at = 4 * ((k0 + i) % ring)
-                w, cp = counts[at], counts[at + 2]
-                if counts[at + 3]:
-                    self._raise_if_failed([k0 + i])
-                if w > 0 and cp > 0:
-                    self._last_items = w + cp - 2
-                hints[i] = w + cp - 2 if w > 0 and cp > 0 else (self._last_items * 17) // 16 if self._last_items > 0 else -1
-                eps[i] = epoch(k0 + i) if flags else 0
-                cs[i] = base + 4 * at
-            prev = self._gate_prev[1] if (self._gate_prev is not None and self._gate_prev[0] == k0 - 1 and
-                                          k0 % B != 0) else None        # (a block's first step: ordered by the event, see prepare_block)
-            done = self._block_done_event(k0 + cnt - 1) if flags else None
-            if fn(*head, pc, ns, gs, pn, ns, os_, qs, prev, hints, cs, eps, last_err(k0 + cnt - 1) if flags else None, done,
-                  sa, sm, i64(k0)) != 0:
-                check(-1, "ha_qapply_gated_steps")
-            self._gate_prev = (k0 + cnt - 1, qs[cnt - 1])
-        return call
-
-    def step_gated(self, grads_list, ahead_ids_list=None, outs=None, stream=None):
-        """The stream protocol of `step`, several steps at a time as gated launches (see apply_gated; arguments and result as
-        step_span)."""
-        if self.c is None:
-            raise RuntimeError("QueueStepPipeline.step_gated before start")
-        cnt = len(grads_list)
-        c0 = self.c
-        self._gated_ok(c0, cnt)
-        ahead_ids_list = list(ahead_ids_list) if ahead_ids_list is not None else [None] * cnt
-        if c0 % self.block == 0:
-            self.prepare_block(c0 // self.block, lambda j: self.ids.get(j), stream)
-            for j in [j for j in self.ids if j < c0 + 3 * self.block]:
-                del self.ids[j]
-        for i, a in enumerate(ahead_ids_list):
-            if a is not None and a.numel():
-                self.ids[c0 + i + self.LOOKAHEAD] = a
-                self.shape[c0 + i + self.LOOKAHEAD] = tuple(a.shape)
-        res = []
-        for i in range(cnt):
-            n_next = self.n.get(c0 + i + 1, 0)
-            o = outs[i] if outs is not None else None
-            if n_next and o is None:
-                o = torch.empty(tuple(self.shape[c0 + i + 1]) + (self.table.shape[1],), dtype=torch.float32,
-                                device=self.table.device)
-            res.append(o if n_next else None)
-        self.apply_gated(c0, grads_list, res, stream)
-        for c in range(c0, c0 + cnt):
-            for d in (self.n, self.shape):
-                d.pop(c - 1, None)
-        self.c = c0 + cnt
-        return res
-
-    def step_span(self, grads_list, ahead_ids_list=None, outs=None, stream=None):
-        """The stream protocol of `step`, several steps at a time by one spanning launch: grads_list[i] = the gradients of
-        the i-th of the next len(grads_list) batches (None for an empty batch), ahead_ids_list[i] = the batch LOOKAHEAD ahead
-        of it (None once the stream ends).  Returns the list of the rows of the batches that follow them (None entries at the
-        end of the stream / for empty batches).  The steps must not cross a block boundary (see apply_span)."""
-        if self.c is None:
-            raise RuntimeError("QueueStepPipeline.step_span before start")
-        cnt = len(grads_list)
-        c0 = self.c
-        self._span_ok(c0, cnt)
-        ahead_ids_list = list(ahead_ids_list) if ahead_ids_list is not None else [None] * cnt
-        if c0 % self.block == 0:
-            self.prepare_block(c0 // self.block, lambda j: self.ids.get(j), stream)
-            for j in [j for j in self.ids if j < c0 + 3 * self.block]:
-                del self.ids[j]
-        for i, a in enumerate(ahead_ids_list):
-            if a is not None and a.numel():
-                self.ids[c0 + i + self.LOOKAHEAD] = a
-                self.shape[c0 + i + self.LOOKAHEAD] = tuple(a.shape)
-        res = []
-        for i in range(cnt):
-            n_next = self.n.get(c0 + i + 1, 0)
-            o = outs[i] if outs is not None else None
-            if n_next and o is None:
-                o = torch.empty(tuple(self.shape[c0 + i + 1]) + (self.table.shape[1],), dtype=torch.float32,
-                                device=self.table.device)
-            res.append(o if n_next else None)
-        self.apply_span(c0, grads_list, res, stream)
-        for c in range(c0, c0 + cnt):
-            for d in (self.n, self.shape):
-                d.pop(c - 1, None)
-        self.c = c0 + cnt
-        return res
 
     # ---- the stream protocol --------------------------------------------------------------------------------------
     def _call(self, c, grads, ahead_ids, out, stream):

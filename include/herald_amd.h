@@ -525,11 +525,6 @@ int ha_qplan_batch_f32ids(const float *const *ids, const int64_t *n, void *const
                           ha_stream_t stream);
 int ha_qplan_batch_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count,
                           ha_stream_t stream);
-/* the same for batches whose queues ha_qqueue_batch_span builds (spanning / gated launches): the 2 n dependency words of
- * every plan are cleared as well */
-int ha_qplan_batch_span_f32ids(const float *const *ids, const int64_t *n, void *const *plans, int64_t count, ha_stream_t stream);
-int ha_qplan_batch_span_u64ids(const uint64_t *const *ids, const int64_t *n, void *const *plans, int64_t count,
-                               ha_stream_t stream);
 int ha_qqueue_batch(int64_t rows, int64_t width, void *const *plans_a, const int64_t *n_a, void *const *plans_g,
                     const int64_t *n_g, void *const *queues, int64_t queue_n_cap, int64_t count, ha_stream_t stream);
 int ha_qapply(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
@@ -593,52 +588,6 @@ int ha_qapply_steps_counts(float *table, int64_t rows, int64_t width, float lr, 
                            const int64_t *wave_items, const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err,
                            void *done_event, ha_stream_t stream);
 
-/* ONE launch for up to ha_qapply_span_max() (32) consecutive steps.  A launch per step pays a launch boundary, a ramp and a
- * tail at a third of the chip's waves every ~12 us; consecutive steps touch the same rows (step s applies batch s --
- * cpu_SGDOptimizerSparseUpdate, src/dnnl_ops/Optimizers.cpp:51-74 -- and writes the rows of batch s + 1 --
- * cpu_EmbeddingLookup, src/dnnl_ops/EmbeddingLookup.cpp:16-35 --, so every key step s + 1 applies was read or written by
- * step s), so the steps of a spanning launch are ordered ITEM BY ITEM: per unique key of a batch a "ready" counter (the
- * step before has read / written the row for the last time) and an "applied" counter (this batch's update of the row is in
- * memory) in the batch's plan, one "workgroups finished" count per step in its queue header; an apply item waits for its
- * key's ready counter, a copy item (a key only the next batch names) for the applied counter of the batch before if that
- * batch names the key -- found by the queue builder, which is handed that batch's plan as well (ha_qqueue_batch_span) --
- * and for the step two back to have finished altogether.  Rows cross between steps THROUGH the L2 (sc1 stores, drained;
- * relaxed device-scope counter adds; sc1 loads behind a relaxed poll); gradient rows and output rows are never handed over
- * inside a launch.  Results: exactly those of `count` ha_qapply launches, bit for bit (the same items in the same
- * per-key order).
- *   plans / n: count + 1 entries -- the batch step k applies, ..., and the batch the last step looks up; grads / next_out
- *   / queues / wave_items / epochs: per step as for ha_qapply_steps_sync; err / done_event: as there (err = 8 also when an
- *   item gave up waiting for the item it depends on: ~2 s; every other wait of the launch then stops at once).
- * Requirements beyond ha_qapply_steps_sync's: queues built by ha_qqueue_batch_span; plans built by ha_qplan_batch_* and
- * applied by no other launch since (the counters start at zero and count up once); EVERY batch's gradient rows resident
- * when the launch starts (a caller whose gradients of step k + 1 depend on the rows step k returns cannot span them); the
- * first step of a span has a queue (is not empty at both ends); batches of at most ha_qstep_max_ids() ids. */
-int64_t ha_qapply_span_max(void);
-int ha_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
-                   void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
-                   const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host,
-                   const uint32_t *epochs, uint32_t *err, void *done_event, ha_stream_t stream);
-/* One launch per step, GATED: consecutive steps go to TWO streams alternately (step k to stream_odd if first_index + k is odd,
- * else stream_even), and instead of the stream ordering them, every item of step k + 1 waits -- after it has read its queue
- * item and its gradient rows, before it touches a table row -- for ONE word that step k sets when its last workgroup has
- * drained its row stores.  The waves of step k + 1 take the slots step k's waves leave: the tail of a launch, the boundary
- * and the next launch's ramp overlap, and the gradient rows (the largest stream) are on their way early; the order between
- * the steps is still the launch boundary's (cpu_SGDOptimizerSparseUpdate of batch k, then cpu_EmbeddingLookup of batch k + 1,
- * src/dnnl_ops/Optimizers.cpp:51-74, EmbeddingLookup.cpp:16-35), results bit for bit those of ha_qapply_steps_sync.
- * Per-step arrays as there; queue_prev = the queue of the step before the first one if THAT step was a gated launch too
- * (else NULL: the caller orders the first launch behind the table's last writer); counts_host = per step the three pinned
- * words of ha_qqueue_batch_counts (or NULL).  Requirements: no step is empty at both ends; batches of at most
- * ha_qstep_max_ids() ids; EVERY step's gradient rows resident when it is enqueued (as for ha_qapply_span); at most two
- * launches of a chain in flight (what two streams give); the queues built by ha_qqueue_batch_* of this library version
- * (the gate words live behind the queue and start at zero). */
-int ha_qapply_gated_steps(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
-                          void *const *plan_cur, const int64_t *n_cur, const float *const *grads, void *const *plan_next,
-                          const int64_t *n_next, float *const *next_out, const void *const *queue_cur, const void *queue_prev,
-                          const int64_t *wave_items, const uint32_t *const *counts_host, const uint32_t *epochs, uint32_t *err,
-                          void *done_event, ha_stream_t stream_even, ha_stream_t stream_odd, int64_t first_index);
-int ha_debug_qapply_gated(float *table, int64_t rows, int64_t width, void *plan_cur, int64_t n_cur, const float *grads, float lr,
-                          void *plan_next, int64_t n_next, float *next_out, const void *queue_cur, const void *queue_prev,
-                          int64_t queue_n_cap, const uint32_t *counts, unsigned long long *dbg, ha_stream_t stream);
 /* The row / key exchange of the sharded sparse pull and push as RCCL point-to-point calls made by the LIBRARY on the caller's
  * stream (the reference's worker sends and receives inside C++ too: PSAgent::vecPullSparse / vecPushSparse,
  * ps-lite/include/ps/worker/PSAgent.h:124-237 -- U_s keys and U_s x d floats per server, ps/psf/sparse.h:9-32): one
@@ -655,19 +604,6 @@ int ha_xchg_bytes(void *xchg, const void *send, const int64_t *send_bytes, void 
                   ha_stream_t stream);
 int ha_xchg_rows(void *xchg, const float *send, const int64_t *send_rows, float *recv, const int64_t *recv_rows, int64_t width,
                  ha_stream_t stream);
-
-/* ha_qqueue_batch_epochs with, per step, the plan of the batch BEFORE the batch the step applies (plans_b / n_b; NULL, or
- * n_b[k] = 0: none). */
-int ha_qqueue_batch_span(int64_t rows, int64_t width, void *const *plans_b, const int64_t *n_b, void *const *plans_a,
-                         const int64_t *n_a, void *const *plans_g, const int64_t *n_g, void *const *queues,
-                         int64_t queue_n_cap, int64_t count, uint32_t *const *counts_host, const uint32_t *epochs,
-                         ha_stream_t stream);
-/* development aid: the spanning launch with per-wave time stamps (dbg as for ha_debug_qapply, indexed by the workgroup's
- * index in the whole launch) */
-int ha_debug_qapply_span(float *table, int64_t rows, int64_t width, float lr, int64_t queue_n_cap, int64_t count,
-                         void *const *plans, const int64_t *n, const float *const *grads, float *const *next_out,
-                         const void *const *queues, const int64_t *wave_items, const uint32_t *const *counts_host,
-                         unsigned long long *dbg, ha_stream_t stream);
 
 /* The WIDE path: batches of more than ha_qstep_max_ids() (7,168) and at most ha_qbig_max_ids() (131,072) ids -- BASELINE
  * configs[2] / configs[3]'s per-GPU shapes, 106,496 and 26,624 ids per step.  The batch is cut into hash buckets by one

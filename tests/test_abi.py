@@ -68,17 +68,3 @@ def test_no_oracle_reference_in_product_code():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "liboracle" not in text or f == "_build.py", f
-
-
-def test_the_overlap_engine_is_a_library_of_its_own(lib):
-    """csrc/qspan.hip exports its copies of the work-queue entry points under the prefix spn_; a pipeline built with span=True
-    sees them through _lib.SpanView, everything else resolves to the library itself.  (Host-side functions only: no GPU.)"""
-    view = _lib.SpanView(lib)
-    assert view.ha_qstep_queue_bytes is lib.spn_ha_qstep_queue_bytes
-    assert view.ha_qapply_steps_sync is lib.spn_ha_qapply_steps_sync
-    assert view.ha_plan_bytes is lib.ha_plan_bytes and view.ha_event_create is lib.ha_event_create
-    # the overlap engine's queues also hold the flag and gate words of the spanning / gated launches
-    assert lib.spn_ha_qstep_queue_bytes(6656, 512) > lib.ha_qstep_queue_bytes(6656, 512)
-    assert lib.spn_ha_qstep_max_ids() == lib.ha_qstep_max_ids()
-    for name in ("ha_qapply_span", "ha_qapply_gated_steps", "ha_qqueue_batch_span", "ha_qplan_batch_span_f32ids"):
-        assert getattr(lib, name) is not None and getattr(lib, "spn_" + name) is not None

@@ -506,224 +506,6 @@ def test_qstep_graph_replay_is_deterministic(dev, mode):
         np.testing.assert_array_equal(a, b)
 
 
-# =====================================================================================================================
-# ONE launch for several steps (ha_qapply_span; ops.QueueStepPipeline.step_span): the items of consecutive steps wait for
-# each other row by row -- per-key counters in the plans -- instead of a launch boundary per step.  The results must be
-# those of one launch per step, bit for bit: every lookup and the table against the kernel-order model AND the reference's
-# serial chain, exactly as for the per-step launches above.
-# =====================================================================================================================
-def _run_stream_span(dev, table0, batches, grads, lr, block, span, sync="events", ids_dtype=np.float32, how="span"):
-    """how = "span": `span` steps per spanning launch (step_span); "gated": `span` steps per call as gated launches on two
-    streams (step_gated)."""
-    width = table0.shape[1]
-    rows = table0.shape[0]
-    model_t = table0.copy()
-    exact_t = table0.copy()
-    drift = {}
-    table = _dev(table0, dev)
-    cap = max(max(b.size for b in batches), 1)
-    pipe = ops.QueueStepPipeline(table, cap, lr, overlap=True, block=block, sync=sync, span=True)
-    assert pipe.SPAN_MAX >= 2
-    step_many = pipe.step_span if how == "span" else pipe.step_gated
-    L = pipe.LOOKAHEAD
-    cast = (lambda b: _dev(b.astype(np.float32), dev)) if ids_dtype == np.float32 else \
-        (lambda b: _dev(b.astype(np.int64), dev))
-    d_ids = [cast(b) for b in batches]
-    d_grads = [_dev(g, dev) if g.size else None for g in grads]     # every batch's gradients resident before its span starts
-    B = len(batches)
-    out = pipe.start(d_ids[:L])
-    torch.cuda.synchronize()
-
-    def check_lookup(k, out):
-        ids = batches[k].astype(np.int64)
-        if not ids.size:
-            assert out is None
-            return
-        got = out.cpu().numpy().reshape(-1, width)
-        np.testing.assert_array_equal(got, _lookup(model_t, ids), err_msg="lookup rows of batch %d (kernel order)" % k)
-        ok = (ids >= 0) & (ids < rows)
-        _within(got[ok], exact_t[ids[ok]], drift, ids[ok], "lookup rows of batch %d" % k)
-
-    def advance(k):
-        ids = batches[k].astype(np.int64)
-        if not ids.size:
-            return
-        ok = (ids >= 0) & (ids < rows)
-        qstep_model.sgd_sparse_update(model_t, ids, grads[k], lr)
-        if ok.any():
-            cpu.sgd_sparse_update(exact_t, ids[ok].astype(np.float32), grads[k][ok], lr)
-        for key, b in qstep_model.tolerance(ids, grads[k], lr, rows, REL).items():
-            if b.any():
-                drift[key] = drift.get(key, 0) + b
-
-    check_lookup(0, out)
-    k = 0
-    launches = 0
-    while k < B:
-        cnt = min(span, B - k, block - k % block)                  # a span stays inside its block
-        outs = step_many([d_grads[k + i] for i in range(cnt)],
-                         [d_ids[k + i + L] if k + i + L < B else None for i in range(cnt)])
-        launches += 1
-        torch.cuda.synchronize()
-        assert not pipe.overflowed()
-        for i in range(cnt):
-            advance(k + i)
-            if k + i + 1 < B:
-                check_lookup(k + i + 1, outs[i])
-            else:
-                assert outs[i] is None
-        k += cnt
-    got_t = table.cpu().numpy()
-    np.testing.assert_array_equal(got_t, model_t, err_msg="table after the stream (kernel order)")
-    touched = np.array(sorted(drift.keys()), dtype=np.int64)
-    same = np.ones(rows, bool)
-    same[touched] = False
-    np.testing.assert_array_equal(got_t[same], exact_t[same], err_msg="rows without a long run: the serial chain, bit for bit")
-    _within(got_t[touched], exact_t[touched], drift, touched, "table after the stream")
-    return pipe, launches
-
-
-SPANS = [(8, 8, "events"), (8, 8, "flags"), (4, 3, "flags"), (16, 16, "flags"), (2, 2, "events")]
-SPAN_IDS = ["block8_span8", "block8_span8_flags", "block4_span3_flags", "block16_span16_flags", "block2_span2"]
-
-
-HOWS = ["span", "gated"]
-
-
-@pytest.mark.parametrize("how", HOWS)
-@pytest.mark.parametrize("block,span,sync", SPANS, ids=SPAN_IDS)
-@pytest.mark.parametrize("width", [4, 32, 96, 128, 200, 512, 1024])
-@pytest.mark.parametrize("rows,n", [(40, 700), (5000, 6656), (300, 63), (7, 1)])
-def test_qspan_stream_small_tables(dev, width, rows, n, block, span, sync, how):
-    """Small tables, 19 steps: nearly every row a step applies was written by the step before (the whole chain of waits), keys
-    that skip a batch or two (copy items that depend on the step before / two before), every class of item."""
-    rng = np.random.default_rng(width * 131 + rows + n)
-    table0 = rng.standard_normal((rows, width), dtype=np.float32)
-    steps = 19
-    batches = [np.minimum(rng.zipf(1.3, size=n) - 1, rows - 1) if k % 2 else rng.integers(0, rows, size=n)
-               for k in range(steps)]
-    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
-    _run_stream_span(dev, table0, batches, grads, 0.05, block, span, sync, how=how)
-
-
-@pytest.mark.parametrize("how", HOWS)
-@pytest.mark.parametrize("block,span,sync", SPANS[:3], ids=SPAN_IDS[:3])
-@pytest.mark.parametrize("kind", ["one_key", "two_keys", "giant_next", "copies_only", "skip_one", "skip_two"])
-def test_qspan_degenerate_batches(dev, kind, block, span, sync, how):
-    """One key per batch (a chain of workgroup items through every step), alternating keys, a key rare in one batch and
-    everywhere in the next, batches that share no key, and keys that come back after ONE / TWO batches without them (a copy
-    item whose row was last written by the step before / two steps before)."""
-    rng = np.random.default_rng(17)
-    rows, width, n = 600, 256, 2000
-    table0 = rng.standard_normal((rows, width), dtype=np.float32)
-    steps = 17
-    if kind == "one_key":
-        batches = [np.full(n, 5 if k % 3 else 7) for k in range(steps)]
-    elif kind == "two_keys":
-        batches = [np.tile([3, 9] if k % 2 else [9, 11], n // 2) for k in range(steps)]
-    elif kind == "giant_next":
-        a = rng.integers(100, rows, size=n)
-        a[7] = 42
-        batches = [a.copy() if k % 2 == 0 else np.full(n, 42) for k in range(steps)]
-    elif kind == "copies_only":
-        batches = [rng.integers(200 * (k % 3), 200 * (k % 3) + 200, size=n) for k in range(steps)]
-    elif kind == "skip_one":        # batches k and k + 2 share their keys, k + 1 has others
-        batches = [rng.integers(300 * (k % 2), 300 * (k % 2) + 300, size=n) for k in range(steps)]
-    else:                           # ... k and k + 3
-        batches = [rng.integers(200 * (k % 3), 200 * (k % 3) + 200, size=n) if k % 4 else rng.integers(0, rows, size=n)
-                   for k in range(steps)]
-    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in batches]
-    _run_stream_span(dev, table0, batches, grads, 0.02, block, span, sync, how=how)
-
-
-@pytest.mark.parametrize("how", HOWS)
-@pytest.mark.parametrize("block,span,sync", SPANS[:3], ids=SPAN_IDS[:3])
-def test_qspan_ragged_empty_and_out_of_range(dev, block, span, sync, how):
-    """Batches of different sizes, EMPTY batches (also at the start of a span and two in a row), ids beyond the table and
-    uint64 ids beyond 2^32, through spanning launches."""
-    rng = np.random.default_rng(23)
-    rows, width = 900, 64
-    table0 = rng.standard_normal((rows, width), dtype=np.float32)
-    sizes = [1200, 1, 0, 777, 64, 1025, 0, 0, 300, 2, 5, 0, 900, 31, 0, 0, 0, 640, 3]
-    batches = []
-    for k, n in enumerate(sizes):
-        b = rng.integers(0, rows + 60, size=n)            # ~6 % beyond the table
-        if n > 10:
-            b[3] = (1 << 33) + 5
-            b[4] = 0xFFFFFFFF
-        batches.append(b)
-    grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
-    _run_stream_span(dev, table0, batches, grads, 0.05, block, span, sync, ids_dtype=np.int64, how=how)
-
-
-@pytest.mark.parametrize("how", HOWS)
-@pytest.mark.parametrize("block,span,sync", [(16, 16, "flags"), (8, 8, "events")], ids=["block16_flags", "block8_events"])
-def test_qspan_criteo_stream(dev, block, span, sync, how):
-    """BASELINE configs[1]'s batch shape (bs=256, 26 fields, d=512) on a 400 k-row table slice, 40 steps by spanning launches:
-    every lookup and the table against both oracles; fewer launches than steps."""
-    rows, width, bs = 400_000, 512, 256
-    rng = np.random.default_rng(31)
-    table0 = (rng.standard_normal((rows, width), dtype=np.float32) * np.float32(0.01))
-    steps = 40
-    batches = [synth.criteo_batch(bs, step=k, rows=rows).reshape(-1) for k in range(steps)]
-    grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
-    pipe, launches = _run_stream_span(dev, table0, batches, grads, 0.01, block, span, sync, how=how)
-    assert launches == -(-steps // span)
-
-
-def test_qspan_equals_step_by_step_bits_and_rejects_misuse(dev):
-    """The same stream through per-step launches and through spanning launches: identical tables and lookups, bit for bit;
-    a span across a block boundary, a span on a pipeline without a side stream and an over-long span are refused."""
-    rows, width, bs = 200_000, 128, 64
-    rng = np.random.default_rng(3)
-    table0 = rng.standard_normal((rows, width), dtype=np.float32)
-    steps = 24
-    batches = [synth.criteo_batch(bs, step=k, rows=rows).reshape(-1) for k in range(steps)]
-    grads = [rng.standard_normal((b.size, width), dtype=np.float32) for b in batches]
-    res = []
-    for span in (0, 8):
-        table = _dev(table0, dev)
-        pipe = ops.QueueStepPipeline(table, batches[0].size, 0.05, overlap=True, block=8, sync="flags", span=bool(span))
-        L = pipe.LOOKAHEAD
-        d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
-        d_g = [_dev(g, dev) for g in grads]
-        outs = [pipe.start(d_ids[:L])]
-        k = 0
-        while k < steps:
-            if span:
-                o = pipe.step_span(d_g[k:k + span], [d_ids[k + i + L] if k + i + L < steps else None for i in range(span)])
-                outs += o
-                k += span
-            else:
-                outs.append(pipe.step(d_g[k], d_ids[k + L] if k + L < steps else None))
-                k += 1
-        torch.cuda.synchronize()
-        assert not pipe.overflowed()
-        res.append((table.cpu().numpy(), [o.cpu().numpy() for o in outs if o is not None]))
-    np.testing.assert_array_equal(res[0][0], res[1][0])
-    assert len(res[0][1]) == len(res[1][1]) == steps
-    for a, b in zip(res[0][1], res[1][1]):
-        np.testing.assert_array_equal(a, b)
-    plain = ops.QueueStepPipeline(_dev(table0, dev), batches[0].size, 0.05, overlap=True, block=4)
-    d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
-    plain.start(d_ids[:plain.LOOKAHEAD])
-    g = [_dev(grads[i], dev) for i in range(6)]
-    with pytest.raises(RuntimeError):
-        plain.step_span(g[:2])                     # queues without the spanning launch's flag words (span=False)
-    plain.close()
-    pipe = ops.QueueStepPipeline(_dev(table0, dev), batches[0].size, 0.05, overlap=True, block=4, span=True)
-    pipe.start(d_ids[:pipe.LOOKAHEAD])
-    with pytest.raises(ValueError):
-        pipe.step_span(g[:5])                      # longer than the block
-    pipe.step(g[0], None)
-    with pytest.raises(ValueError):
-        pipe.step_span(g[1:5])                     # steps 1..4 of blocks of 4: crosses the boundary
-    serial = ops.QueueStepPipeline(_dev(table0, dev), batches[0].size, 0.05, overlap=False)
-    serial.start(d_ids[:serial.LOOKAHEAD])
-    with pytest.raises(RuntimeError):
-        serial.step_span(g[:2])
-
-
 def test_a_step_whose_queue_was_never_built_raises_and_applies_nothing(dev):
     """sync="flags": nothing orders an apply launch behind its queue's builder but the epoch tag in the queue.  A step whose
     queue is never built (here: its block is never prepared) polls for ~2 s, touches no row, and raises the pinned error
