@@ -252,6 +252,10 @@ def _declare(L):
         "ha_cache_sort_ahead": [vp, vp, c.c_int, i64, vp],
         "ha_cache_lookup_presorted": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_sort_ahead_batch": [vp, vp, c.c_int, vp, c.c_int, vp],
+        "ha_cache_plan_block": [vp, vp, c.c_int, vp, c.c_int, vp, vp],
+        "ha_cache_lookup_planned": [vp, i64, vp, vp],
+        "ha_cache_update_planned": [vp, i64, vp, vp],
+        "ha_cache_plan_pending": [vp],
         "ha_cache_update": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_update_same_keys": [vp, i64, vp, vp],
         "ha_cache_update_with_push_keys": [vp, vp, c.c_int, i64, vp, c.c_int, i64, vp, vp],

@@ -414,6 +414,72 @@ class _CacheBase:
             check(self._L.ha_cache_sort_ahead_batch(self._h, None, 0, None, 0, ctypes.c_void_p(self._stream().cuda_stream)),
                   "ha_cache_sort_ahead_batch")
 
+    # ---- the planned flow: the bookkeeping of a block of batches ahead, ONE launch per lookup / update ----------------------
+    def plan_block(self, keys_list, side=None):
+        """State that the device tensors of `keys_list` (1..16, one dtype, at most min(max_batch, 36,864) keys each) are the
+        batches of the NEXT embedding_lookup_planned / embedding_update_planned pairs, in this order (ha_cache_plan_block,
+        csrc/cache_block.hip: LRU over a local store, limit >= max_batch).  Their index plans and the bookkeeping of the whole
+        block -- hits, misses, slots, evictions, update counters, the bounded push: all of it follows from the ids -- run NOW on
+        `side` (default: a stream of the cache's own), beside whatever rows the cache's stream is still moving; every lookup and
+        every update of these batches is then ONE launch.  Plan block b + 1 when block b starts (two blocks may be outstanding).
+        Until the planned pairs are consumed the call-by-call methods raise; lines() / keys() / size() show the bookkeeping of
+        every planned batch (meaningful at the end of a block)."""
+        if self._remote is not None or not keys_list:
+            raise ValueError("plan_block: a non-empty list of key tensors, local store")
+        s = self._stream()
+        if side is None:
+            if getattr(self, "_plan_side", None) is None:
+                self._plan_side = torch.cuda.Stream(device=self.device)
+            side = self._plan_side
+        ks = [self._keys(k, []) for k in keys_list]
+        kinds = {kind for _, kind in ks}
+        if len(kinds) != 1 or len(ks) > 16:
+            raise ValueError("plan_block: 1-16 key tensors of one dtype")
+        ptrs = (ctypes.c_void_p * len(ks))(*[k.data_ptr() if k.numel() else None for k, _ in ks])
+        ns = (ctypes.c_int64 * len(ks))(*[k.numel() for k, _ in ks])
+        self._ahead = None
+        self._drop_ahead_ring()
+        self._last_lookup = None
+        check(self._L.ha_cache_plan_block(self._h, ptrs, kinds.pop(), ns, len(ks), ctypes.c_void_p(side.cuda_stream),
+                                          ctypes.c_void_p(s.cuda_stream)), "ha_cache_plan_block")
+        if not hasattr(self, "_planned"):
+            self._planned = []
+        self._planned.extend([k, False] for k, _ in ks)      # [key tensor (kept alive), its lookup done?]
+
+    def plan_pending(self):
+        """Planned calls (lookups + updates) still to be made."""
+        return int(self._L.ha_cache_plan_pending(self._h))
+
+    def embedding_lookup_planned(self, dest):
+        """The lookup of the next planned batch (cache.cc:60-107), ONE launch; dest: float32 device tensor [n, width]."""
+        if not getattr(self, "_planned", None) or self._planned[0][1]:
+            raise ValueError("embedding_lookup_planned: no planned batch is due for its lookup")
+        k = self._planned[0][0]
+        s = self._stream()
+        assert dest.is_cuda and dest.dtype == torch.float32 and dest.numel() == k.numel() * self._width
+        check(self._L.ha_cache_lookup_planned(self._h, k.numel(), ctypes.c_void_p(dest.data_ptr() if k.numel() else None),
+                                              ctypes.c_void_p(s.cuda_stream)), "ha_cache_lookup_planned")
+        self._planned[0][1] = True
+        if self.perf_enabled:
+            self._perf_record(0)
+        return Wait(s, [k, dest]) if self._planned_waits else None
+
+    def embedding_update_planned(self, grads):
+        """The update of the planned batch whose lookup was the last planned call (cache.cc:132-197), ONE launch."""
+        if not getattr(self, "_planned", None) or not self._planned[0][1]:
+            raise ValueError("embedding_update_planned: the lookup of the planned batch comes first")
+        k = self._planned[0][0]
+        s = self._stream()
+        assert grads.is_cuda and grads.dtype == torch.float32 and grads.is_contiguous() and grads.numel() == k.numel() * self._width
+        check(self._L.ha_cache_update_planned(self._h, k.numel(), ctypes.c_void_p(grads.data_ptr() if k.numel() else None),
+                                              ctypes.c_void_p(s.cuda_stream)), "ha_cache_update_planned")
+        self._planned.pop(0)
+        if self.perf_enabled:
+            self._perf_record(1)
+        return Wait(s, [k, grads]) if self._planned_waits else None
+
+    _planned_waits = True      # False: the planned calls return None instead of a wait handle (no event per call: bench loops)
+
     def embedding_lookup(self, keys, dest):
         """dest[i,:] = line(keys[i]).data after the staleness-bounded pull (cache.cc:60-107)."""
         if self._remote is not None:
@@ -708,6 +774,19 @@ class CacheSparseTable:
 
     def embedding_update(self, keys, grads, sync=False, same_as_lookup=False):
         return self._finish(self.cache.embedding_update(keys, grads, same_as_lookup=same_as_lookup), sync)
+
+    # the planned flow (csrc/cache_block.hip): the ids of a block of batches a block early -- bookkeeping ahead on a side stream,
+    # ONE launch per lookup and per update
+    def plan_block(self, keys_list, side=None):
+        self.cache.plan_block([k[0] if isinstance(k, tuple) else k for k in keys_list], side)
+
+    def embedding_lookup_planned(self, dest, sync=False):
+        w = self.cache.embedding_lookup_planned(dest)
+        return self._finish(w, sync) if w is not None else None
+
+    def embedding_update_planned(self, grads, sync=False):
+        w = self.cache.embedding_update_planned(grads)
+        return self._finish(w, sync) if w is not None else None
 
     def looked_up_last(self, keys):
         """True when `keys` is the device tensor the cache's last operation, an embedding_lookup, was given (same storage,

@@ -34,10 +34,7 @@
 // line was promoted or evicted) and the rare higher-bucket victim is found by one scan over the slots.
 // The batch index plan (plan.hip) supplies sorted unique keys / inverse / counts; occurrence-order
 // accumulation and the ordered server `+=` reuse the apply kernels (scatter_dev.h, ha_apply_mapped).
-#include "plan_dev.h"
-
-#include <utility>
-#include <vector>
+#include "cache_dev.h"
 
 extern "C" int ha_apply_mapped(float *dst, int64_t dst_rows, int64_t width,
                                const void *plan_ws, int64_t n, const float *src,
@@ -51,96 +48,6 @@ extern "C" int ha_apply_mapped2(float *dst, int64_t dst_rows, float *dst2, int64
 
 namespace ha {
 
-enum LineState : uint8_t { kFree = 0, kResident = 1, kEvictedDirty = 2, kTransient = 3, kPending = 4,
-                           kStored = 5 /* LFUOpt permanent store */ };
-enum Policy { kLRU = 0, kLFU = 1, kLFUOpt = 2 };
-constexpr int kUseCntMax = 10;  // lfuopt_cache.h:26
-
-struct CacheCtl {
-    long long size;       // resident lines
-    long long free_top;   // entries in free_list
-    long long log_head, log_tail;
-    long long evict_n;    // lines waiting in the evict list
-    long long clock;      // next stamp
-    // per-call scratch
-    long long U, M, nhit, E, pulled, C, dropped;
-    long long n_base;      // LFU/LFUOpt: resident lines in the lowest use bucket
-    long long n_hash;      // LFUOpt: resident lines outside the permanent store
-    long long parked[4];   // push_pull: U, M, nhit of the parked pull phase; U of the push phase
-    long long scan_victim; // slot of the lowest (use, stamp) line outside the lowest bucket, or -1
-    // last op report: type(0 pull,1 push), num_all, num_unique, num_miss, num_transfered, num_evict, is_full
-    long long perf[8];     // [7]: pushed lines of a cache_update_same_post_kernel update, to be added to [4]
-    long long out_n;       // remote mode: outbox entries of the last update (U + E), -1 on overflow
-    unsigned long long ph[16];   // ha_cache_phase_times: 100 MHz clock at the phase boundaries of the last lookup's bookkeeping
-    unsigned long long fb_xw[64];     // cache_finish_book_kernel, per finish chunk: valid << 63 | heads << 32 | pulls << 16 | misses
-    long long fb_timeout;             // sticky: a workgroup of cache_finish_book_kernel gave up waiting for another one's word
-    long long snap[4];     // {clock, log_tail, free_top, evict_n} as the last lookup left them (cache_update_same_post_kernel)
-};
-
-// Per-line bookkeeping as ONE 32-byte record: the bookkeeping kernels reach lines at random slots from a single
-// workgroup, where every separate array costs its own address translation per line (the eviction walk read stamp,
-// state, updates and key of ~1,000 victims from four arrays: 10 us of one compute unit's time at the criteo batch).
-struct alignas(32) LineMeta {
-    unsigned long long stamp;
-    long long version;
-    uint32_t key;
-    int32_t updates;
-    int32_t freq;
-    uint8_t state;
-    uint8_t pad[3];
-};
-static_assert(sizeof(LineMeta) == 32, "one line record = 32 bytes");
-
-struct Cache {
-    int policy;
-    int64_t limit, length, width, nmax, S, Lcap;
-    int64_t pull_bound, push_bound;
-    bool bypass;
-    CacheCtl *ctl;
-    int32_t *slot_of;
-    LineMeta *line;        // [S] key / version / updates / freq / state / stamp of the line in slot s
-    uint8_t *hasgrad;      // [S] dense: the accumulate kernels read it through their own row map (ApplyMaps::dst_init)
-    float *data, *grad;
-    int32_t *free_list;
-    uint32_t *log_slot;
-    unsigned long long *log_stamp;
-    int32_t *evict_slots;
-    // per-call scratch, sized nmax
-    void *plan_ws, *plan2_ws;
-    int32_t *uslot, *data_row;
-    uint32_t *flag, *rank;
-    uint8_t *pushflag;
-    uint32_t *pushkeys_u32;
-    // second scratch set (the pull phase of push_pull)
-    void *plan_ws_b;
-    int32_t *uslot_b, *data_row_b;
-    uint32_t *flag_b, *rank_b;
-    uint8_t *pushflag_b;
-    // LFU / LFUOpt on a large cache: the argmin over the resident lines by kScanParts workgroups (cache_scan_victim_part_kernel),
-    // a partial result each; the single-workgroup bookkeeping then reduces these instead of walking every line
-    unsigned long long *scan_key;
-    int32_t *scan_slot;
-    // store (the "server"): rows [row_start, row_start + store_rows) of the global table
-    float *table;
-    long long *srv_ver;
-    int64_t store_rows, row_start;
-    // REMOTE store (rows owned by other ranks, or kept in host memory): the cache never touches the store
-    // itself.  A lookup exports (key, cached version) of its unique keys, the store's owner takes
-    // syncEmbedding's decision and the answer arrives in the INBOX; an update leaves the lines to push
-    // (pushEmbedding) in the OUTBOX.  herald_amd/cache.py moves both (sharded.py exchange / host staging).
-    int remote;
-    uint32_t *req_keys;    // [nmax] unique keys of the batch
-    long long *req_ver;    // [nmax] cached version of each (-1: no data yet)
-    int32_t *inbox_pull;   // [nmax] the owner's decision (1 = row follows)
-    int32_t *inbox_idx;    // [nmax] its row in inbox_rows
-    long long *inbox_ver;  // [nmax] server version of the row
-    float *inbox_rows;     // [nmax, width]
-    int64_t out_cap;       // outbox entries: batch lines at [0, U), pending evicted lines at [U, U + E)
-    uint32_t *out_keys;    // kNoPush = entry not pushed
-    int32_t *out_upd;
-    float *out_rows;       // [out_cap, width]
-};
-constexpr uint32_t kNoPush = 0xFFFFFFFFu;
 // phase boundary i of a single-workgroup bookkeeping body (ha_cache_phase_times); `ctl` in scope
 #define CACHE_PH(i)                                                  \
     do {                                                             \
@@ -1809,61 +1716,9 @@ __global__ __launch_bounds__(256) void cache_set_line_kernel(Cache c, long long 
         c.data[static_cast<long long>(s) * c.width + j] = data[j];
 }
 
-template <typename T>
-static int dmalloc(T **p, size_t count) {
-    HA_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 256));
-    return 0;
-}
-
 }  // namespace ha
 
 using namespace ha;
-
-struct ha_cache {
-    Cache c;
-    std::vector<void *> allocs;
-    int64_t plan_n = -1;   // n of the lookup whose plan is still in plan_ws (ha_cache_update_same_keys)
-    int64_t pp_pull = -1, pp_push = 0;   // sizes of the push_pull between its begin and finish (remote store)
-    int64_t out_pad = 0;   // remote store: the updates mark outbox entries [U + E, out_pad) as not pushed
-    // cache_update_same_post_kernel's preconditions, tracked on the host (no read-back): evict_empty = the last call
-    // was an update (it pushes every pending evicted line); same_fast = the plan in plan_ws belongs to a lookup that
-    // started from an empty evict list on an LRU cache with limit >= max_batch and a local store
-    bool evict_empty = true, same_fast = false;
-    int fused_update = 7;  // HA_CACHE_FUSED: bit 0 = the two-launch update, bit 1 = eviction beside the lookup's row copies,
-                           // bit 2 = the plan's finish does the lookup's bookkeeping (cache_finish_book_kernel)
-    int64_t fused_count = 0;
-    // stage times of the last call (ha_cache_set_timing): HIP events between the launches of a call -- the GPU analogue of
-    // the reference's std::chrono stamps between the stages of _embeddingLookup / _embeddingUpdate (cache.cc:61-106,133-196)
-    bool timing = false;
-    hipEvent_t tev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    unsigned tmask = 0;
-    // ha_cache_sort_ahead: the stable sort of the NEXT lookup's keys runs on a stream of the cache's own, into a second plan
-    // workspace, beside the calls of the current batch (the sort reads the keys only -- the reference's data loader hands the
-    // ids over a batch early as well, dataloader.py:63-98)
-    void *plan_ws_alt = nullptr;
-    hipStream_t ahead_stream = nullptr;
-    hipEvent_t ahead_fork = nullptr, ahead_join = nullptr;
-    const void *ahead_keys = nullptr;
-    int64_t ahead_n = -1;
-    int ahead_kind = -1;
-    // ha_cache_sort_ahead_batch: the sorts of the next kAheadRing lookups in ONE launch on the caller's stream, into a ring
-    // of plan workspaces the lookups take in order
-    static constexpr int kAheadRing = 16;
-    size_t plan_bytes = 0;
-    void *ring_ws[kAheadRing] = {};
-    const void *ring_keys[kAheadRing] = {};
-    int64_t ring_n[kAheadRing] = {};
-    int ring_kind = -1, ring_head = 0, ring_count = 0;
-};
-enum { kTStart = 0, kTSort = 1, kTLookup = 2, kTCopy = 3, kTTransfer = 4, kTEnd = 5 };
-static inline void cache_mark(ha_cache *h, int slot, hipStream_t s, bool first = false) {
-    if (!h->timing)
-        return;
-    if (first)
-        h->tmask = 0;
-    if (hipEventRecord(h->tev[slot], s) == hipSuccess)
-        h->tmask |= 1u << slot;
-}
 
 extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
                                      int64_t width, int64_t max_batch) {
@@ -1974,6 +1829,11 @@ extern "C" void ha_cache_destroy(ha_cache *h) {
         (void)hipEventDestroy(h->ahead_fork);
     if (h->ahead_join)
         (void)hipEventDestroy(h->ahead_join);
+    if (h->plan_fork)
+        (void)hipEventDestroy(h->plan_fork);
+    for (PlanSlot &sl : h->plan)
+        if (sl.booked)
+            (void)hipEventDestroy(sl.booked);
     for (void *p : h->allocs)
         (void)hipFree(p);
     delete h;
@@ -1981,6 +1841,7 @@ extern "C" void ha_cache_destroy(ha_cache *h) {
 
 extern "C" int ha_cache_set_bounds(ha_cache *h, int64_t pull_bound, int64_t push_bound) {
     HA_REQUIRE(h, "cache: null handle");
+    HA_REQUIRE(ha_cache_plan_pending(h) == 0, "cache_set_bounds: planned batches are outstanding (their bookkeeping used the bounds)");
     h->c.pull_bound = pull_bound;
     h->c.push_bound = push_bound;
     return 0;
@@ -1988,6 +1849,7 @@ extern "C" int ha_cache_set_bounds(ha_cache *h, int64_t pull_bound, int64_t push
 
 extern "C" int ha_cache_set_bypass(ha_cache *h, int bypass) {
     HA_REQUIRE(h, "cache: null handle");
+    HA_REQUIRE(ha_cache_plan_pending(h) == 0, "cache_set_bypass: planned batches are outstanding");
     h->c.bypass = bypass != 0;
     return 0;
 }
@@ -2306,6 +2168,9 @@ static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_
     HA_REQUIRE(h && h->c.table && !h->c.remote, "cache_lookup: no local store bound (remote stores use "
                "ha_cache_lookup_begin / ha_cache_lookup_finish)");
     HA_REQUIRE(n >= 0 && (n == 0 || (keys && dest)), "cache_lookup: bad arguments");
+    HA_REQUIRE(ha_cache_plan_pending(h) == 0, "cache: %d planned calls are outstanding (ha_cache_plan_block): ha_cache_lookup_planned / "
+               "ha_cache_update_planned come first", ha_cache_plan_pending(h));
+    h->last_planned_type = -1;
     Cache &c = h->c;
     // (a batch from the ring of ha_cache_sort_ahead_batch has its sorted keys in c.plan_ws already: a pending sort of
     // ha_cache_sort_ahead -- another batch's -- stays where it is)
@@ -2369,6 +2234,9 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
                              bool defer_cleanup = false) {
     HA_REQUIRE(h && (h->c.table || h->c.remote), "cache_update: no store bound");
     HA_REQUIRE(n >= 0 && (n == 0 || grads), "cache_update: bad arguments");
+    HA_REQUIRE(ha_cache_plan_pending(h) == 0, "cache: %d planned calls are outstanding (ha_cache_plan_block): ha_cache_lookup_planned / "
+               "ha_cache_update_planned come first", ha_cache_plan_pending(h));
+    h->last_planned_type = -1;
     Cache &c = h->c;
     // keys == nullptr: the batch of the preceding ha_cache_lookup, whose plan is still in the workspace
     int probed = 0;
@@ -2490,6 +2358,9 @@ static int push_pull_begin(ha_cache *h, const void *pull_keys, int pull_kind, in
                "cache_push_pull: bad sizes");
     HA_REQUIRE((n_pull == 0 || pull_keys) && (n_push == 0 || (push_keys && grads)),
                "cache_push_pull: null pointer");
+    HA_REQUIRE(ha_cache_plan_pending(h) == 0, "cache: %d planned calls are outstanding (ha_cache_plan_block): ha_cache_lookup_planned / "
+               "ha_cache_update_planned come first", ha_cache_plan_pending(h));
+    h->last_planned_type = -1;
     Cache &c = h->c;
     Cache cb = scratch_b_view(c);
     const dim3 b(256);
@@ -2592,6 +2463,8 @@ extern "C" int ha_cache_push_pull_finish(ha_cache *h, float *dest, ha_stream_t s
 // out[8]: last op report {type, num_all, num_unique, num_miss, num_transfered, num_evict, is_full, size}
 extern "C" int ha_cache_perf(ha_cache *h, int64_t *out_host, ha_stream_t stream) {
     HA_REQUIRE(h && out_host, "cache_perf: bad arguments");
+    if (h->last_planned_type >= 0 && h->last_planned != nullptr)      // the last call was a planned lookup / update
+        return cache_perf_planned(h, out_host, as_stream(stream));
     CacheCtl ctl;
     HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
@@ -2663,6 +2536,9 @@ extern "C" int ha_cache_phase_times(ha_cache *h, uint64_t *out_host, ha_stream_t
 
 extern "C" int ha_cache_state(ha_cache *h, int64_t *out_host, ha_stream_t stream) {
     HA_REQUIRE(h && out_host, "cache_state: bad arguments");
+    for (PlanSlot &sl : h->plan)       // (a bookkeeping launch of the planned flow owns the control block while it runs)
+        if (sl.booked && sl.count > 0)
+            HA_CHECK_HIP(hipEventSynchronize(sl.booked));
     CacheCtl ctl;
     HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
@@ -2685,6 +2561,9 @@ extern "C" int ha_cache_snapshot(ha_cache *h, int64_t cap, uint32_t *keys, int64
                                  int32_t *updates, uint64_t *stamp, int32_t *slots,
                                  uint64_t *count_dev, ha_stream_t stream) {
     HA_REQUIRE(h && keys && version && updates && stamp && slots && count_dev, "cache_snapshot: null pointer");
+    for (PlanSlot &sl : h->plan)
+        if (sl.booked && sl.count > 0)
+            HA_CHECK_HIP(hipStreamWaitEvent(as_stream(stream), sl.booked, 0));
     hipLaunchKernelGGL(cache_snapshot_kernel, dim3(1024), dim3(256), 0, as_stream(stream), h->c,
                        (long long)cap, keys, reinterpret_cast<long long *>(version), updates,
                        reinterpret_cast<unsigned long long *>(stamp), slots,

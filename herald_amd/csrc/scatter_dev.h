@@ -34,6 +34,12 @@ struct ApplyMaps {
     // tolerance mode (ha_set_tolerance_mode): runs of at least this many occurrences (0 = never) are applied as
     // `row - tree_sum(lr * g)` in a fixed order instead of the serial chain (coop_slice_tree below)
     int tree_from;
+    // DUAL == 2 kernels, the cache's planned update (cache_block.hip): unique key u with push_row[u] >= 0 is PUSHED in the same
+    // pass -- push_tab[push_row[u],:] += the first destination's new value (the line's gradient after the batch,
+    // PSFhandle_embedding.cc:23-27), and the first destination is stored as zeros (Line::zeroGrad, embedding.h:112-118)
+    float *push_tab;
+    const long long *push_row;
+    const uint8_t *init_u;     // DUAL == 2: the first destination of unique key u starts from its stored value iff init_u[u] != 0
 };
 
 // host: the run length from which the tolerance mode applies (0 = exact everywhere; scatter.hip,
@@ -48,7 +54,9 @@ struct Second {
     float *s1, *s2;
     int opt_kind;
     OptArgs oa;
+    float *push;    // DUAL: the store row that takes the first destination's new value (nullptr: none), see ApplyMaps::push_tab
 };
+
 
 // kModeOpt epilogue: p / s1 / s2 at `col` of the current key's rows take one optimizer step with gradient g
 template <int VEC>
@@ -187,10 +195,21 @@ struct Vec<1> {
     __device__ __forceinline__ void set(int, float x) { v = x; }
 };
 
+template <int VEC>
+__device__ __forceinline__ void push_epilogue(float *__restrict__ push_row, int col, Vec<VEC> &acc) {
+    Vec<VEC> cur;
+    cur.load(push_row + col);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        cur.set(k, __fadd_rn(cur.get(k), acc.get(k)));
+    cur.store(push_row + col);
+    acc.zero();
+}
+
 // ---- short runs (1..kShortRun occurrences): one wave, whole row --------------------------------
 // Columns [cbase, cbase + VB*64*VEC); the table row and every occurrence row are requested in one
 // batch (branch-free, clamped), then applied in occurrence order.
-template <int MODE, int VEC, int VB, bool DUAL, int HAND = kHandNone>
+template <int MODE, int VEC, int VB, int DUAL, int HAND = kHandNone>
 __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                                             const float *__restrict__ grads,
                                             int width, int cbase, int pv,
@@ -245,6 +264,8 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                 for (int k = 0; k < VEC; ++k)
                     acc[b].set(k, __fadd_rn(cur.get(k), acc[b].get(k)));
             }
+            if (DUAL == 2 && d2.push)
+                push_epilogue<VEC>(d2.push, col[b], acc[b]);
             if (MODE == kModeOpt) {
                 float gsum[VEC];
 #pragma unroll
@@ -274,7 +295,7 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
     }
 }
 
-template <int MODE, int VEC, bool DUAL, int HAND = kHandNone>
+template <int MODE, int VEC, int DUAL, int HAND = kHandNone>
 __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
                                           const float *__restrict__ grads,
                                           int width, int pv, int lane0, int len,
@@ -302,7 +323,7 @@ __device__ __forceinline__ void short_row(float *__restrict__ dst_row,
 // and applies ALL occurrences of the run to its slice in order: one dword per lane = 256 contiguous
 // bytes per occurrence row.  Every occurrence index of such a run is already in the wave's window of
 // sorted positions (p-16 .. p+47), so the row loads are issued straight away, up to 32 in flight.
-template <int MODE, bool DUAL, int HAND = kHandNone>
+template <int MODE, int DUAL, int HAND = kHandNone>
 __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
                                              const float *__restrict__ grads,
                                              int width, int col, int pv, int lane_s,
@@ -359,6 +380,10 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
     if (live) {
         if (MODE == kModePush)
             acc = __fadd_rn(dst_row[col], acc);
+        if (DUAL == 2 && d2.push) {
+            d2.push[col] = __fadd_rn(d2.push[col], acc);
+            acc = 0.f;
+        }
         if (MODE == kModeOpt)
             opt_epilogue<1>(dst_row, d2, col, &acc);
         else if (HAND == kHandSignal)
@@ -543,7 +568,7 @@ __device__ __forceinline__ void coop_chunk_tree(float *__restrict__ dst_row, boo
 
 // The worker part of a long run [s, s+len): this workgroup owns the 64-column slices j, j+workers, ...
 // All 16 waves call it (workgroup barriers inside); s_m = kCoopUnits x 64 floats of LDS.
-template <int MODE, bool DUAL, int HAND = kHandNone>
+template <int MODE, int DUAL, int HAND = kHandNone>
 __device__ __forceinline__ void coop_slices(
     float *__restrict__ dst_row, bool init, Second d2, const float *__restrict__ grads,
     const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr, int s, int len,
@@ -670,6 +695,10 @@ __device__ __forceinline__ void coop_slices(
         if (clive) {
             if (MODE == kModePush)
                 acc = __fadd_rn(dst_row[ccol], acc);
+            if (DUAL == 2 && d2.push) {
+                d2.push[ccol] = __fadd_rn(d2.push[ccol], acc);
+                acc = 0.f;
+            }
             if (MODE == kModeOpt)
                 opt_epilogue<1>(dst_row, d2, ccol, &acc);
             else if (HAND == kHandSignal)
@@ -708,7 +737,7 @@ __device__ __forceinline__ void coop_slices(
 
 // Returns false when the run is shorter than kLongRun (the caller falls through to the per-wave
 // paths).  Called by all 16 waves of a full workgroup; wg0 = its first sorted position.
-template <int MODE, bool DUAL, int HAND = kHandNone>
+template <int MODE, int DUAL, int HAND = kHandNone>
 __device__ __forceinline__ bool coop_run(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
@@ -779,6 +808,8 @@ __device__ __forceinline__ bool coop_run(
         row = static_cast<uint64_t>(r);
         if (maps.dst_init)
             init = maps.dst_init[r] != 0;
+        if (DUAL == 2 && maps.init_u)
+            init = maps.init_u[upos[wg0]] != 0;
     } else if (MODE == kModeReduce) {
         row = static_cast<uint64_t>(upos[wg0]);
     } else {
@@ -793,6 +824,10 @@ __device__ __forceinline__ bool coop_run(
         d2.on = r2 >= 0;
         d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
     }
+    if (DUAL == 2 && maps.push_row) {
+        const long long pr = maps.push_row[upos[wg0]];
+        d2.push = pr >= 0 ? maps.push_tab + static_cast<uint64_t>(pr) * static_cast<uint64_t>(width) : nullptr;
+    }
     if (MODE == kModeOpt)
         opt_rows(d2, maps, row, width);
 
@@ -803,7 +838,7 @@ __device__ __forceinline__ bool coop_run(
 }
 
 // One wave per sorted position p; `lds` = kApplyLdsBytes of workgroup memory (long runs only).
-template <int MODE, int VEC, bool DUAL, int HAND = kHandNone>
+template <int MODE, int VEC, int DUAL, int HAND = kHandNone>
 __device__ __forceinline__ bool apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
@@ -814,7 +849,7 @@ __device__ __forceinline__ bool apply_body_impl(
 // per position.  The early return below is taken by whole waves of the LAST workgroup only, which is
 // never a full one, so the barriers of coop_run see all 16 waves.
 // Returns true when the wave did medium / long-run work (false: it left early or applied a short run).
-template <int MODE, int VEC, bool DUAL = false, int HAND = kHandNone>
+template <int MODE, int VEC, int DUAL = false, int HAND = kHandNone>
 __device__ __forceinline__ bool apply_body(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
@@ -843,7 +878,7 @@ __device__ __forceinline__ bool apply_body(
     return heavy;
 }
 
-template <int MODE, int VEC, bool DUAL, int HAND>
+template <int MODE, int VEC, int DUAL, int HAND>
 __device__ __forceinline__ bool apply_body_impl(
     float *__restrict__ dst, uint64_t dst_rows, int width,
     const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm,
@@ -906,6 +941,8 @@ __device__ __forceinline__ bool apply_body_impl(
         row = static_cast<uint64_t>(r);
         if (maps.dst_init)
             init = maps.dst_init[r] != 0;
+        if (DUAL == 2 && maps.init_u)
+            init = maps.init_u[upos[p]] != 0;
     } else if (MODE == kModeReduce) {
         row = static_cast<uint64_t>(upos[p]);
     } else {
@@ -919,6 +956,10 @@ __device__ __forceinline__ bool apply_body_impl(
         const int r2 = maps.rowmap2[upos[p]];
         d2.on = r2 >= 0;
         d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
+    }
+    if (DUAL == 2 && maps.push_row) {
+        const long long pr = maps.push_row[upos[p]];
+        d2.push = pr >= 0 ? maps.push_tab + static_cast<uint64_t>(pr) * static_cast<uint64_t>(width) : nullptr;
     }
     if (MODE == kModeOpt)
         opt_rows(d2, maps, row, width);

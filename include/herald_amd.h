@@ -858,6 +858,25 @@ int ha_cache_lookup_presorted(ha_cache *cache, const void *keys, int key_kind, i
  * batch; the first call allocates the ring (not inside a stream capture).  Results: those of ha_cache_lookup. */
 int ha_cache_sort_ahead_batch(ha_cache *cache, const void *const *keys, int key_kind, const int64_t *n, int count,
                               ha_stream_t stream);
+/* The PLANNED flow (csrc/cache_block.hip; LRU, local store, limit >= max_batch): CacheBase::_embeddingLookup and
+ * _embeddingUpdate of the same keys, batch after batch (src/hetu_cache/src/cache.cc:60-107, 132-197; the training loop of
+ * python/hetu/cstable.py:38-56), with the BOOKKEEPING of a block of up to 16 batches done ahead: which lines a batch hits and
+ * misses, the slots of the misses, the lines LRUCache::insert evicts for them (lru_cache.cc:9-25), update counters and the
+ * bounded push (cache.cc:159) follow from the ids alone.  ha_cache_plan_block enqueues, on `side`, the index plans of the
+ * block's batches and ONE bookkeeping launch that leaves per batch the items of its two row launches; `main` = the stream of
+ * those row launches (what is enqueued on it so far is ordered in front of the bookkeeping).  Then, per batch and in order,
+ * ha_cache_lookup_planned (ONE launch: the staleness-bounded pull decided as the rows are read, rows to dest) and
+ * ha_cache_update_planned (ONE launch: ordered accumulate, the pushed lines' store rows in the same pass, evicted dirty lines,
+ * versions).  Results: those of ha_cache_lookup + ha_cache_update_same_keys call by call.  At most two blocks are outstanding
+ * (plan block b + 1 when block b starts: its bookkeeping then runs beside block b's rows); the key buffers stay unchanged
+ * until the bookkeeping has run; the call-by-call entry points (and ha_cache_set_bounds / _bypass) are refused while planned
+ * calls are outstanding (ha_cache_plan_pending); ha_cache_perf after a planned call reports that call; ha_cache_state /
+ * ha_cache_snapshot see the bookkeeping of every planned batch, i.e. are meaningful at the end of a block. */
+int ha_cache_plan_block(ha_cache *cache, const void *const *keys, int key_kind, const int64_t *n, int count,
+                        ha_stream_t side, ha_stream_t main);
+int ha_cache_lookup_planned(ha_cache *cache, int64_t n, float *dest, ha_stream_t stream);
+int ha_cache_update_planned(ha_cache *cache, int64_t n, const float *grads, ha_stream_t stream);
+int ha_cache_plan_pending(ha_cache *cache);
 int ha_cache_update(ha_cache *cache, const void *keys, int key_kind, int64_t n,
                     const float *grads, ha_stream_t stream);
 /* ha_cache_update for the key batch of the immediately preceding ha_cache_lookup on this cache (the

@@ -1,0 +1,237 @@
+"""The PLANNED flow of the HET cache (csrc/cache_block.hip: ha_cache_plan_block / _lookup_planned / _update_planned) against
+oracle/cache_model.py -- the same model, the same comparisons as tests/test_gpu_cache.py holds the call-by-call flow to:
+lookup rows bit for bit and the perf dict's counts EVERY step, server table and versions every step, resident set / versions /
+update counters / data and gradient rows of every line whenever no bookkeeping has run ahead of the rows (the end of a block
+that was planned alone; the end of the stream otherwise).
+
+Reference: CacheBase::_embeddingLookup / _embeddingUpdate (src/hetu_cache/src/cache.cc:60-107, 132-197), LRUCache
+(src/hetu_cache/src/lru_cache.cc:5-39), Line (include/embedding.h:18-149), the server (ps-lite/src/PSFhandle_embedding.cc:5-64)."""
+import numpy as np
+import pytest
+import torch
+
+from herald_amd import cache as hcache
+from oracle import cache_model
+from test_gpu_cache import _compare_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(r, n, rows, zipf):
+    if zipf:
+        return (np.minimum(r.zipf(1.3, size=n) - 1, rows - 1).astype(np.int64) * 7919) % rows
+    return r.integers(0, rows, size=n)
+
+
+def _setup(dev, limit, rows, width, n, pull_bound, push_bound, seed):
+    rng = np.random.default_rng(seed)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    server = cache_model.Server(table0)
+    model = cache_model.CacheModel("lru", limit, width, server, pull_bound, push_bound)
+    table = torch.from_numpy(table0.copy()).to(dev)
+    versions = torch.zeros(rows, dtype=torch.int64, device=dev)
+    gpu = hcache.LRUCache(limit, rows, width, node_id=0, max_batch=max(n, 64), device=dev)
+    gpu.bind_store(table, versions)
+    gpu.pull_bound, gpu.push_bound = pull_bound, push_bound
+    gpu.perf_enabled = True
+    return rng, server, model, table, versions, gpu
+
+
+def _check_perf(gpu, model, step):
+    for got, exp in zip(gpu.perf[-2:], model.perf[-2:]):
+        for f in ("type", "num_all", "num_unique", "num_miss", "num_transfered", "is_full"):
+            assert got[f] == exp[f], (step, f, got, exp)
+        if exp["type"] == "Push":
+            assert got["num_evict"] == exp["num_evict"], (step, got, exp)
+
+
+def _planned_step(dev, gpu, model, keys, grads, width, step, versions, server):
+    want = model.lookup(keys.astype(np.uint64))
+    dest = torch.empty((keys.size, width), dtype=torch.float32, device=dev)
+    gpu.embedding_lookup_planned(dest).wait()
+    np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % step)
+    model.update(keys.astype(np.uint64), grads)
+    gpu.embedding_update_planned(torch.from_numpy(grads).to(dev)).wait()
+    _check_perf(gpu, model, step)
+    np.testing.assert_array_equal(versions.cpu().numpy(), server.ver, err_msg="server versions step %d" % step)
+
+
+def _run_planned(dev, limit, rows, width, n, steps, pull_bound, push_bound, block, seed=0, zipf=True, ahead=True,
+                 dtype=np.float32, sizes=None):
+    """ahead=True: block j + 1 is planned when block j starts (two blocks outstanding: its bookkeeping runs beside block j's
+    rows); False: a block is planned when the one before is consumed, and the whole state is compared at every block end."""
+    rng, server, model, table, versions, gpu = _setup(dev, limit, rows, width, n, pull_bound, push_bound, seed)
+    sizes = sizes or [n] * steps
+    keys_all = [_draw(rng, m, rows, zipf) for m in sizes]
+    kts = [torch.from_numpy(k.astype(dtype)).to(dev) for k in keys_all]
+    blocks = [list(range(b0, min(b0 + block, steps))) for b0 in range(0, steps, block)]
+    if ahead:
+        gpu.plan_block([kts[s] for s in blocks[0]])
+    for j, blk in enumerate(blocks):
+        if ahead and j + 1 < len(blocks):
+            gpu.plan_block([kts[s] for s in blocks[j + 1]])
+        elif not ahead:
+            gpu.plan_block([kts[s] for s in blk])
+        for step in blk:
+            grads = rng.standard_normal((sizes[step], width), dtype=np.float32) * np.float32(-0.01)
+            _planned_step(dev, gpu, model, keys_all[step], grads, width, step, versions, server)
+            np.testing.assert_array_equal(table.cpu().numpy(), server.table, err_msg="server table step %d" % step)
+        if not ahead or j + 1 == len(blocks):
+            assert gpu.plan_pending() == 0
+            _compare_state(gpu, model, blk[-1])
+    assert gpu.size() == model.policy.size()
+    np.testing.assert_array_equal(gpu.keys(), np.array(model.policy.keys(), dtype=np.uint64))
+    return gpu, model
+
+
+@pytest.mark.parametrize("pull_bound,push_bound", [(0, 0), (3, 3), (100, 100)])
+@pytest.mark.parametrize("block,ahead", [(1, False), (4, False), (16, True), (5, True)])
+def test_planned_lru_trace_small(dev, pull_bound, push_bound, block, ahead):
+    _run_planned(dev, limit=100, rows=1500, width=8, n=64, steps=64, pull_bound=pull_bound, push_bound=push_bound, block=block,
+                 seed=11, ahead=ahead)
+
+
+@pytest.mark.parametrize("ahead", [False, True])
+def test_planned_lru_uniform_heavy_eviction_at_limit_equal_batch(dev, ahead):
+    # limit == max_batch: every lookup evicts almost as many lines as it brings in
+    _run_planned(dev, limit=64, rows=1000, width=4, n=64, steps=48, pull_bound=2, push_bound=2, block=8, seed=3, zipf=False,
+                 ahead=ahead)
+
+
+def test_planned_lru_criteo_width_and_long_runs(dev):
+    # width 128 with medium runs; width 512 with one key ~600 times per batch: the cooperative long-run path of the accumulate
+    # takes the push epilogue (store row += gradient, gradient = 0) for both destinations' slices
+    _run_planned(dev, limit=500, rows=5000, width=128, n=416, steps=12, pull_bound=2, push_bound=2, block=4, seed=24)
+    _run_planned(dev, limit=2500, rows=6000, width=512, n=2000, steps=6, pull_bound=1, push_bound=2, block=3, seed=25)
+
+
+def test_planned_lru_odd_width_takes_the_scalar_kernels(dev):
+    _run_planned(dev, limit=120, rows=900, width=10, n=96, steps=20, pull_bound=1, push_bound=1, block=5, seed=8)
+
+
+def test_planned_lru_many_keys_per_workgroup_slice(dev):
+    """20,000 keys per batch: every bookkeeping workgroup owns several keys per thread, the eviction walk takes several
+    rounds of 8,192 log entries."""
+    _run_planned(dev, limit=30000, rows=120000, width=4, n=20000, steps=6, pull_bound=1, push_bound=2, block=3, seed=31,
+                 zipf=False, ahead=True)
+
+
+def test_planned_lru_large_cache_log_without_compaction(dev):
+    """A cache large enough that the stamp log is NOT compacted in front of every batch (small caches are: their log is
+    shorter than the walk's stride), full and evicting ~1,000 lines per lookup."""
+    gpu, _ = _run_planned(dev, limit=40000, rows=400000, width=4, n=1024, steps=70, pull_bound=2, push_bound=2, block=16,
+                          seed=33, zipf=False, ahead=True)
+    st = gpu.state()
+    assert st["size"] == 40000 and st["log_tail"] - st["log_head"] <= st["log_cap"]
+
+
+def test_planned_lru_ragged_empty_batches_and_uint64_keys(dev):
+    sizes = [64, 1, 0, 33, 64, 0, 0, 17, 64, 2]
+    _run_planned(dev, limit=100, rows=700, width=8, n=64, steps=len(sizes), pull_bound=1, push_bound=1, block=4, seed=9,
+                 dtype=np.int64, sizes=sizes)
+
+
+def test_planned_and_call_by_call_flows_alternate(dev):
+    """Call-by-call steps, a planned block, call-by-call steps, two planned blocks: one trace, the model's state throughout."""
+    limit, rows, width, n = 100, 1500, 8, 64
+    rng, server, model, table, versions, gpu = _setup(dev, limit, rows, width, n, 2, 2, seed=41)
+    step = 0
+
+    def classic(count):
+        nonlocal step
+        for _ in range(count):
+            keys = _draw(rng, n, rows, True)
+            fk = torch.from_numpy(keys.astype(np.float32)).to(dev)
+            dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+            want = model.lookup(keys.astype(np.uint64))
+            gpu.embedding_lookup(fk, dest).wait()
+            np.testing.assert_array_equal(dest.cpu().numpy(), want)
+            grads = rng.standard_normal((n, width), dtype=np.float32) * np.float32(0.01)
+            model.update(keys.astype(np.uint64), grads)
+            gpu.embedding_update(fk, torch.from_numpy(grads).to(dev), same_as_lookup=bool(step % 2)).wait()
+            _compare_state(gpu, model, step)
+            step += 1
+
+    def planned(count, blocks):
+        nonlocal step
+        ks = [[_draw(rng, n, rows, True) for _ in range(count)] for _ in range(blocks)]
+        kt = [[torch.from_numpy(k.astype(np.float32)).to(dev) for k in blk] for blk in ks]
+        gpu.plan_block(kt[0])
+        for b in range(blocks):
+            if b + 1 < blocks:
+                gpu.plan_block(kt[b + 1])
+            for k in ks[b]:
+                grads = rng.standard_normal((n, width), dtype=np.float32) * np.float32(0.01)
+                _planned_step(dev, gpu, model, k, grads, width, step, versions, server)
+                step += 1
+        _compare_state(gpu, model, step)
+
+    classic(7)
+    planned(5, 1)
+    classic(6)
+    planned(4, 2)
+    classic(3)
+    np.testing.assert_array_equal(table.cpu().numpy(), server.table)
+
+
+def test_planned_pull_decision_sees_what_another_worker_pushed_after_the_plan(dev):
+    """The bookkeeping of a block runs before its rows; the staleness-bounded pull (cache.cc:84-93) must still be decided from
+    the store's versions AS THE ROWS ARE READ: between two steps of a planned block another worker pushes to rows the cache
+    holds (server versions + rows change) -- the next lookups pull exactly the lines the model pulls."""
+    limit, rows, width, n = 200, 600, 8, 96
+    rng, server, model, table, versions, gpu = _setup(dev, limit, rows, width, n, 2, 100, seed=51)
+    keys_all = [_draw(rng, n, rows, True) for _ in range(8)]
+    kts = [torch.from_numpy(k.astype(np.float32)).to(dev) for k in keys_all]
+    gpu.plan_block(kts)
+    torch.cuda.synchronize()            # the whole block is booked before a single row moves
+    for step in range(8):
+        if step in (2, 5):               # another worker's push: +4 updates on the rows the next batch names
+            hot = np.unique(keys_all[step])[::2]
+            delta = rng.standard_normal((hot.size, width), dtype=np.float32)
+            server.ver[hot] += 4
+            server.table[hot] = (server.table[hot] + delta).astype(np.float32)
+            versions[torch.from_numpy(hot).to(dev)] += 4
+            table[torch.from_numpy(hot).to(dev)] += torch.from_numpy(delta).to(dev)
+        grads = rng.standard_normal((n, width), dtype=np.float32) * np.float32(0.01)
+        _planned_step(dev, gpu, model, keys_all[step], grads, width, step, versions, server)
+    assert sum(r["num_transfered"] for r in gpu.perf if r["type"] == "Pull") > sum(r["num_miss"] for r in gpu.perf if r["type"] == "Pull")
+    _compare_state(gpu, model, 8)
+    np.testing.assert_array_equal(table.cpu().numpy(), server.table)
+
+
+def test_planned_flow_refuses_misuse(dev):
+    rows, width, n = 500, 8, 64
+    rng = np.random.default_rng(6)
+    table = torch.from_numpy(rng.standard_normal((rows, width), dtype=np.float32)).to(dev)
+    ks = [torch.from_numpy(rng.integers(0, rows, size=n).astype(np.float32)).to(dev) for _ in range(3)]
+    dest = torch.empty((n, width), device=dev)
+    g = torch.zeros((n, width), device=dev)
+    small = hcache.LRUCache(32, rows, width, node_id=0, max_batch=n, device=dev)       # limit < max_batch
+    small.bind_store(table, torch.zeros(rows, dtype=torch.int64, device=dev))
+    with pytest.raises(Exception, match="limit"):
+        small.plan_block(ks[:1])
+    lfu = hcache.LFUCache(200, rows, width, node_id=0, max_batch=n, device=dev)
+    lfu.bind_store(table, torch.zeros(rows, dtype=torch.int64, device=dev))
+    with pytest.raises(Exception, match="LRU"):
+        lfu.plan_block(ks[:1])
+    gpu = hcache.LRUCache(200, rows, width, node_id=0, max_batch=n, device=dev)
+    gpu.bind_store(table, torch.zeros(rows, dtype=torch.int64, device=dev))
+    with pytest.raises(ValueError):
+        gpu.embedding_lookup_planned(dest)                 # nothing planned
+    gpu.plan_block(ks[:2])
+    with pytest.raises(ValueError):
+        gpu.embedding_update_planned(g)                    # the lookup comes first
+    with pytest.raises(Exception, match="planned"):
+        gpu.embedding_lookup(ks[0], dest)                  # call-by-call while planned calls are outstanding
+    with pytest.raises(Exception, match="planned"):
+        gpu.pull_bound = 7
+    gpu.plan_block(ks[2:])
+    with pytest.raises(Exception, match="outstanding"):
+        gpu.plan_block(ks[:1])                             # a third block
+    for _ in range(3):
+        gpu.embedding_lookup_planned(dest)
+        gpu.embedding_update_planned(g)
+    assert gpu.plan_pending() == 0
+    gpu.embedding_lookup(ks[0], dest).wait()               # and the call-by-call flow is back
+    with pytest.raises(ValueError):
+        gpu.plan_block(ks * 6)                             # more than 16 batches
