@@ -323,6 +323,41 @@ def _cache_tier_policy(args, table, ids_dev, out, grad, dev, policy):
             graphs[(4 + i) % len(graphs)].replay()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+    # THE figure for LRU: the planned flow (csrc/cache_block.hip).  The ids of a block of 16 batches are known at its start (as
+    # for the headline's work-queue step): the bookkeeping of block b + 1 -- hits, misses, slots, evictions, update counters, the
+    # bounded push -- runs on a side stream beside the rows of block b; every lookup and every update is ONE launch.  Plain
+    # launches, a block's 16 pairs enqueued by one library call; same cache, same steady state, continuing where the
+    # call-by-call measurement above stopped.
+    planned = None
+    if policy == "LRU" and os.environ.get("HA_CACHE_BENCH_PLANNED", "1") == "1":
+        blocks = [[ids_dev[j % nb] for j in range(g0, g0 + GS)] for g0 in range(0, nb, GS)]
+        outs16, grads16 = [out] * GS, [grad] * GS
+        import gc
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side):
+            c.plan_block(blocks[0])
+            nwarm, ntimed = 4, steps // GS
+            gc.collect()
+            gc.disable()        # (a collector pass in the middle of 6 ms of enqueueing is a host stall the device then waits out)
+            t0 = None
+            for b in range(nwarm + ntimed):
+                if b == nwarm:
+                    e0.record(side)
+                    t0 = time.perf_counter()
+                if b + 1 < nwarm + ntimed:
+                    c.plan_block(blocks[(b + 1) % len(blocks)])
+                c.run_planned_pairs(outs16, grads16)
+            e1.record(side)
+            t_enq = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            gc.enable()
+            pel = e0.elapsed_time(e1) * 1e-3
+        planned = {"us_per_step": 1e6 * pel / (ntimed * GS), "value": n * ntimed * GS / pel, "steps": ntimed * GS,
+                   "launches_per_pair": 2, "enqueue_us_per_step": 1e6 * t_enq / (ntimed * GS),
+                   "timed": "HIP events on the row stream around %d blocks of 16 pairs (plain launches, the host enqueues ahead "
+                            "of the device; each block's bookkeeping -- 4 launches -- on a side stream beside the rows of the "
+                            "block before, inside the timed region)" % ntimed,
+                   "bookkeeping": "a block of 16 batches ahead, on a side stream (4 launches per block)"}
     c.perf_enabled(True)       # the counters are read back per call: outside the timed loop
     for k in range(32):        # batches the cache has not seen yet
         b = (nb + k) % ids_dev.shape[0]
@@ -333,13 +368,19 @@ def _cache_tier_policy(args, table, ids_dev, out, grad, dev, policy):
     pushes = [r for r in c.perf if r["type"] == "Push"]
     miss = float(np.mean([r["num_miss"] / max(r["num_unique"], 1) for r in pulls])) if pulls else None
     evict = float(np.mean([r["num_evict"] for r in pushes])) if pushes else None
-    return {"value": n * steps / el, "unit": "rows/s", "us_per_step": 1e6 * el / steps, "policy": policy,
+    head = {"value": n * steps / el, "us_per_step": 1e6 * el / steps}
+    if planned is not None:
+        head = {"value": planned["value"], "us_per_step": planned["us_per_step"]}
+    return {"value": head["value"], "unit": "rows/s", "us_per_step": head["us_per_step"], "policy": policy,
+            "flow": "planned (ha_cache_plan_block: bookkeeping a block ahead, one launch per lookup / update)" if planned is not None
+                    else "call by call",
+            "planned": planned,
+            "call_by_call": {"us_per_step": 1e6 * el / steps, "value": n * steps / el, "steps": steps},
             "limit_rows": limit, "bound": 100, "steps": steps, "unique_miss_rate": miss,
             "evicted_lines_per_step": evict, "cache_full": bool(pulls and pulls[-1]["is_full"]),
             "prefilled_keys": prefilled,
-            "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch "
-                    "(%s, replayed from hipGraphs of 16 pairs), cache filled to its limit before "
-                    "the timed pairs; not part of `value`"
+            "note": "HET cache tier in front of the same HBM-resident table: lookup + update per batch; cache filled to its limit "
+                    "before the timed pairs; `call_by_call`: %s, replayed from hipGraphs of 16 pairs; not part of `value`"
                     % ("4 launches per pair + one launch per block of 16 batches that sorts their keys (the ids are known a "
                        "block early, as for the headline's work-queue step)" if use_block else
                        "5 launches per pair" + (", the next batch's sort forked beside the update" if use_ahead else "")),

@@ -256,6 +256,7 @@ def _declare(L):
         "ha_cache_lookup_planned": [vp, i64, vp, vp],
         "ha_cache_update_planned": [vp, i64, vp, vp],
         "ha_cache_plan_pending": [vp],
+        "ha_cache_run_planned_pairs": [vp, c.c_int, vp, vp, vp, vp],
         "ha_cache_update": [vp, vp, c.c_int, i64, vp, vp],
         "ha_cache_update_same_keys": [vp, i64, vp, vp],
         "ha_cache_update_with_push_keys": [vp, vp, c.c_int, i64, vp, c.c_int, i64, vp, vp],

@@ -429,7 +429,20 @@ class _CacheBase:
         s = self._stream()
         if side is None:
             if getattr(self, "_plan_side", None) is None:
-                self._plan_side = torch.cuda.Stream(device=self.device)
+                # A stream of another PRIORITY than the row stream: HIP multiplexes the streams of one priority onto a few
+                # hardware queues, and two streams that share a queue run in submission order -- the bookkeeping of block b + 1
+                # then sits between the rows of block b - 1 and block b instead of beside them (measured: 183 us of idle row
+                # stream per block in bench.py, where a dozen streams exist; none in a process with two).  HA_CACHE_PLAN_PRIO:
+                # high (default) / low / normal.
+                import os
+                prio = 0
+                want = os.environ.get("HA_CACHE_PLAN_PRIO", "high")
+                try:
+                    lo_hi = torch.cuda.Stream.priority_range()
+                    prio = min(lo_hi) if want == "high" else max(lo_hi) if want == "low" else 0
+                except Exception:      # noqa: BLE001
+                    prio = 0
+                self._plan_side = torch.cuda.Stream(device=self.device, priority=prio)
             side = self._plan_side
         ks = [self._keys(k, []) for k in keys_list]
         kinds = {kind for _, kind in ks}
@@ -477,6 +490,21 @@ class _CacheBase:
         if self.perf_enabled:
             self._perf_record(1)
         return Wait(s, [k, grads]) if self._planned_waits else None
+
+    def run_planned_pairs(self, dests, grads):
+        """The next len(dests) planned pairs by ONE library call (ha_cache_run_planned_pairs): lookup into dests[k], update with
+        grads[k].  For callers that have the pairs' gradient buffers at hand (a benchmark loop); no perf records."""
+        cnt = len(dests)
+        pl = getattr(self, "_planned", None) or []
+        if cnt > len(pl) or len(grads) != cnt or (pl and pl[0][1]):
+            raise ValueError("run_planned_pairs: %d pairs, %d planned" % (cnt, len(pl)))
+        s = self._stream()
+        ns = (ctypes.c_int64 * cnt)(*[pl[k][0].numel() for k in range(cnt)])
+        dp = (ctypes.c_void_p * cnt)(*[d.data_ptr() for d in dests])
+        gp = (ctypes.c_void_p * cnt)(*[g.data_ptr() for g in grads])
+        check(self._L.ha_cache_run_planned_pairs(self._h, cnt, ns, dp, gp, ctypes.c_void_p(s.cuda_stream)),
+              "ha_cache_run_planned_pairs")
+        del pl[:cnt]
 
     _planned_waits = True      # False: the planned calls return None instead of a wait handle (no event per call: bench loops)
 
@@ -787,6 +815,9 @@ class CacheSparseTable:
     def embedding_update_planned(self, grads, sync=False):
         w = self.cache.embedding_update_planned(grads)
         return self._finish(w, sync) if w is not None else None
+
+    def run_planned_pairs(self, dests, grads):
+        self.cache.run_planned_pairs(dests, grads)
 
     def looked_up_last(self, keys):
         """True when `keys` is the device tensor the cache's last operation, an embedding_lookup, was given (same storage,

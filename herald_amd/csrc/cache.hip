@@ -267,6 +267,7 @@ __device__ __forceinline__ void cache_assign_body(
                 c.line[s].version = -1;
                 c.line[s].updates = 0;
                 c.hasgrad[s] = 0;
+                c.line[s].hg = 0;
                 c.line[s].state = static_cast<uint8_t>(miss_state);
             }
         }
@@ -895,6 +896,7 @@ __global__ __launch_bounds__(1024) void cache_finish_book_kernel(
             c.line[fs].version = -1;
             c.line[fs].updates = 0;
             c.hasgrad[fs] = 0;
+            c.line[fs].hg = 0;
             if (pre_insert) {
                 // the new line's side of batchedInsert as well (cache_insert_evict_body then only appends the log
                 // entries): LRU with limit >= batch inserts every miss, stamp = clock after the touches + its rank
@@ -1017,6 +1019,7 @@ __global__ __launch_bounds__(1024) void cache_lookup_book_kernel(
                 c.line[sl].version = -1;
                 c.line[sl].updates = 0;
                 c.hasgrad[sl] = 0;
+                c.line[sl].hg = 0;
                 if (defer_evict == 2) {
                     // the new line's side of batchedInsert as well (the same record; cache_insert_evict_body then only
                     // appends the log entries): LRU with limit >= batch inserts every miss, stamp = clock after the
@@ -1229,6 +1232,7 @@ __global__ __launch_bounds__(256) void cache_update_flags_kernel(
     for (int u = blockIdx.x * 256 + threadIdx.x; u < U; u += gridDim.x * 256) {
         const int s = c.uslot[u];
         c.hasgrad[s] = 1;
+        c.line[s].hg = 1;
         const int upd = c.line[s].updates + counts[u];
         c.line[s].updates = upd;
         const bool has_data = c.line[s].state != kTransient;
@@ -1303,6 +1307,7 @@ __global__ __launch_bounds__(256) void cache_update_flags_push_kernel(
         }
         if (lane == 0) {
             c.hasgrad[s] = 1;
+            c.line[s].hg = 1;
             c.line[s].updates = upd;
             c.pushflag[u] = push ? 1 : 0;
             c.flag[u] = push ? 1u : 0u;
@@ -1506,6 +1511,7 @@ __global__ __launch_bounds__(1024) void cache_update_same_post_kernel(
                 c.log_slot[pos] = static_cast<uint32_t>(s);
                 c.log_stamp[pos] = st;
                 c.hasgrad[s] = 1;
+                c.line[s].hg = 1;
                 c.line[s].updates = push ? 0 : upd;
                 if (push) {
                     c.line[s].version += upd;
@@ -1673,6 +1679,7 @@ __global__ __launch_bounds__(256) void cache_init_kernel(Cache c) {
         c.line[i].updates = 0;
         c.line[i].freq = 0;
         c.hasgrad[i] = 0;
+        c.line[i].hg = 0;
         c.line[i].version = -1;
         c.line[i].stamp = 0;
     }

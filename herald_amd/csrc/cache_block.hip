@@ -71,9 +71,8 @@ struct BookArgs {
     const uint32_t *uniq[kPlanBlockMax];
     const int32_t *counts[kPlanBlockMax];
     int32_t *it_slot;        // [count][nmax] slot of unique key u (-1: a key beyond the cache's key range)
-    uint8_t *it_flag;        // [count][nmax] kItMiss | kItPush
+    uint8_t *it_flag;        // [count][nmax] kPosMiss | kPosInit (the line has a gradient buffer) | kPosPush
     int32_t *it_upd;         // [count][nmax] update counter of the line after this batch (what a push carries)
-    long long *it_push;      // [count][nmax] store row the line is pushed to, or -1
     int32_t *ev_slot;        // [count][nmax] evicted dirty lines of the batch's lookup, pushed by its update
     uint32_t *ev_key;
     int32_t *ev_upd;
@@ -81,7 +80,10 @@ struct BookArgs {
     unsigned long long *xw;  // [4][kBookWg] exchange words
     long long nmax;
 };
-enum : uint8_t { kItMiss = 1, kItPush = 4 };
+// a line record's word 3 = freq | state << 32 | hg << 40
+__device__ __forceinline__ unsigned long long line_w3(uint8_t state, bool hg) {
+    return (static_cast<unsigned long long>(state) << 32) | (hg ? 1ull << 40 : 0ull);
+}
 
 // One exchange between the workgroups of the bookkeeping launch: every workgroup publishes (a, b) -- both < 2^20 -- and
 // learns everybody's.  Word = seq << 40 | b << 20 | a; four word arrays in turn (a workgroup is at most one exchange ahead
@@ -227,7 +229,6 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
                 a.it_slot[at + u] = -1;
                 a.it_flag[at + u] = 0;
                 a.it_upd[at + u] = 0;
-                a.it_push[at + u] = -1;
             }
         }
 #pragma unroll
@@ -236,6 +237,8 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
             if (u < u1 && sl[j] >= 0) {
                 const int s = sl[j];
                 const unsigned long long w2 = ldc(line_word(c.line, s, 2));
+                const unsigned long long w3 = ldc(line_word(c.line, s, 3));
+                const bool hg = ((w3 >> 40) & 1ull) != 0ull;
                 const int upd = static_cast<int>(w2 >> 32) + counts[u];
                 const bool push = upd > c.push_bound;
                 const unsigned long long st = static_cast<unsigned long long>(clock + u);
@@ -245,10 +248,11 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
                 const long long pos = (tail + u) % c.Lcap;
                 stc(c.log_slot + pos, static_cast<uint32_t>(s));
                 stc(c.log_stamp + pos, st);
+                if (!hg)           // the batch's update gives the line its gradient buffer (Line::_maybeInitGrad)
+                    stc(line_word(c.line, s, 3), line_w3(kResident, true));
                 a.it_slot[at + u] = s;
-                a.it_flag[at + u] = push ? kItPush : 0;
+                a.it_flag[at + u] = static_cast<uint8_t>((hg ? kPosInit : 0) | (push ? kPosPush : 0));
                 a.it_upd[at + u] = upd;
-                a.it_push[at + u] = push ? static_cast<long long>(kk[j]) : -1;
             }
             uint32_t tot;
             rk[j] = wg_miss + book_rank(miss[j], s_w4, &tot);
@@ -274,15 +278,14 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
                 stc(line_word(c.line, s, 0), st);
                 stc(line_word(c.line, s, 2), static_cast<unsigned long long>(kk[j]) |
                                                  (static_cast<unsigned long long>(static_cast<uint32_t>(push ? 0 : upd)) << 32));
-                stc(line_word(c.line, s, 3), static_cast<unsigned long long>(kResident) << 32);
+                stc(line_word(c.line, s, 3), line_w3(kResident, true));
                 stc(c.slot_of + kk[j], s);
                 const long long pos = (tail + u) % c.Lcap;
                 stc(c.log_slot + pos, static_cast<uint32_t>(s));
                 stc(c.log_stamp + pos, st);
                 a.it_slot[at + u] = s;
-                a.it_flag[at + u] = static_cast<uint8_t>(kItMiss | (push ? kItPush : 0));
+                a.it_flag[at + u] = static_cast<uint8_t>(kPosMiss | (push ? kPosPush : 0));
                 a.it_upd[at + u] = upd;
-                a.it_push[at + u] = push ? static_cast<long long>(kk[j]) : -1;
             }
         }
         // ---- phase 3: LRUCache::insert's evictions --------------------------------------------------------------------------
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
             if (take) {
                 const uint32_t key = static_cast<uint32_t>(w2);
                 stc(c.slot_of + key, -1);
-                stc(line_word(c.line, ls, 3), static_cast<unsigned long long>(kFree) << 32);
+                stc(line_word(c.line, ls, 3), line_w3(kFree, false));
                 stc(c.free_list + (ftop - M + taken_before + vb + rv), ls);
                 if (dirty) {      // every valid entry in front of a victim is a victim: its rank among the dirty victims
                     const long long at_e = at + dirty_before + db + rd;
@@ -405,39 +408,57 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
     }
 }
 
+// ---- the items per sorted position (side stream, behind the bookkeeping launch) --------------------------------------------
+// pos_item[p] = {slot, key, kPos* flags (| kPosHead at the first position of a key), occurrence index perm[p]}: what a row
+// wave of position p needs, in ONE 16-byte record instead of three dependent lookups (upos[p] -> item of the key -> rows).
+struct PlanExpandPtrs {
+    const int32_t *upos[kPlanBlockMax];
+    const int32_t *perm[kPlanBlockMax];
+};
+__global__ __launch_bounds__(256) void cache_plan_expand_kernel(BookArgs a, PlanExpandPtrs e, int4 *pos_item, int32_t *it_upd_pos) {
+    const int i = blockIdx.y;
+    const int n = a.n[i];
+    const long long at = static_cast<long long>(i) * a.nmax;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        const int u = e.upos[i][p];
+        const bool head = p == 0 || e.upos[i][p - 1] != u;
+        pos_item[at + p] = int4{a.it_slot[at + u], static_cast<int>(a.uniq[i][u]),
+                                static_cast<int>(a.it_flag[at + u]) | (head ? kPosHead : 0), e.perm[i][p]};
+        it_upd_pos[at + p] = a.it_upd[at + u];
+    }
+}
+
 // ---- the lookup of a planned batch: ONE launch, a wave per sorted position -------------------------------------------------
 // dest[perm[p],:] = the line of the position's key after syncEmbedding (cache.cc:84-97).  The pull decision is taken by every
 // wave of a key from words nothing in this launch writes (the line's version, the store's version); the wave of the key's
-// first position refreshes the line and STAGES its new version (pver[u]; the update's launch commits it -- a store into the
-// record here would race with the other waves' reads).
+// first position refreshes the line and STAGES its new version (pver[p]; the update's launch commits it -- a store into the
+// record here would race with the other waves' reads).  Two round trips: the position's record; then versions and row together.
+// (Measured, docs/EXPERIMENTS.md round 6: the forward gather's shape -- the output as flat 16-byte vectors, four vectors of
+// different rows per lane, 256-thread workgroups -- 11.3 us against 9.1 for a wave per position; without the two version reads
+// 9.07 against 9.29 us; without the row stores 7.65: the launch is the part's "copy of 6,656 random 2 KB rows" (DESIGN.md
+// section 6, yardstick: 8.0 us), the staleness check is almost free beside it.)
 template <int VEC>
 __global__ __launch_bounds__(1024) void cache_lookup_planned_kernel(
-    Cache c, const uint32_t *__restrict__ uniq, const int32_t *__restrict__ upos, const int32_t *__restrict__ perm,
-    long long n, float *__restrict__ dest, const int32_t *__restrict__ it_slot, const uint8_t *__restrict__ it_flag,
-    long long *__restrict__ pver, uint8_t *__restrict__ phg) {
+    Cache c, const int4 *__restrict__ pos_item, long long n, float *__restrict__ dest, long long *__restrict__ pver) {
     const int lane = lane_id();
-    const long long p = static_cast<long long>(blockIdx.x) * 16ll + (threadIdx.x >> 6);
+    const long long p = static_cast<long long>(blockIdx.x) * 16ll + uniform(static_cast<int>(threadIdx.x >> 6));
     if (p >= n)
         return;
-    const int u = uniform(upos[p]);
-    const int up = uniform(upos[p > 0 ? p - 1 : 0]);
-    const bool head = p == 0 || up != u;
-    const int s = uniform(it_slot[u]);
-    const uint32_t fl = uniform(static_cast<uint32_t>(it_flag[u]));
-    const long long lk = static_cast<long long>(uniform(uniq[u]));
-    float *out = dest + static_cast<long long>(perm[p]) * c.width;
+    const int4 it = pos_item[p];
+    const int s = uniform(it.x);
+    const long long lk = static_cast<long long>(uniform(static_cast<uint32_t>(it.y)));
+    const int fl = uniform(it.z);
+    const bool head = (fl & kPosHead) != 0;
+    float *out = dest + static_cast<long long>(uniform(it.w)) * c.width;
     if (s < 0) {
         for (long long j = lane; j < c.width; j += kWave)
             out[j] = 0.f;
         return;
     }
     float *line = c.data + static_cast<long long>(s) * c.width;
-    const bool is_miss = (fl & kItMiss) != 0;
+    const bool is_miss = (fl & kPosMiss) != 0;
     const long long sv = c.srv_ver[lk];
     const long long v = is_miss ? -1 : c.line[s].version;
-    // does the line have a gradient buffer (Line::_maybeInitGrad)?  Staged for the update's accumulate, whose launch also SETS
-    // hasgrad -- it cannot read the flag it writes
-    const bool hg = !is_miss && c.hasgrad[s] != 0;
     // the cached row, requested beside the two versions (a hit that is not stale -- the usual case -- has it on the way)
     float4v x0{0.f, 0.f, 0.f, 0.f}, x1 = x0;
     const long long j0 = lane * 4, j1 = j0 + kWave * 4;
@@ -460,12 +481,11 @@ __global__ __launch_bounds__(1024) void cache_lookup_planned_kernel(
             for (long long j = lane; j < c.width; j += kWave)
                 out[j] = line[j];
         }
-        if (head && lane == 0) {
-            pver[u] = kVerKeep;
-            phg[u] = hg ? 1 : 0;
-        }
+        if (head && lane == 0)
+            pver[p] = kVerKeep;
         return;
     }
+    const bool hg = (fl & kPosInit) != 0;      // the line has a gradient buffer: Line::addup() re-adds it to the pulled row
     const float *src = c.table + lk * c.width;
     const float *gr = c.grad + static_cast<long long>(s) * c.width;
     if (VEC == 4) {
@@ -489,39 +509,37 @@ __global__ __launch_bounds__(1024) void cache_lookup_planned_kernel(
                 line[j] = x;
         }
     }
-    if (head && lane == 0) {
-        pver[u] = sv;
-        phg[u] = hg ? 1 : 0;       // (a new line has no gradient buffer yet)
-    }
+    if (head && lane == 0)
+        pver[p] = sv;
 }
 
 // ---- the update of a planned batch: ONE launch -----------------------------------------------------------------------------
-// workgroups [0, apply_blocks): the ordered accumulate (apply_body, DUAL: gradient buffer and data row; pushed lines take
-//     the push epilogue -- store row += the line's new gradient, gradient buffer = 0);
+// the first kPlanMetaBlocks workgroups: a thread per sorted position, the heads work: the line's version (staged by the
+//     lookup, + updates for a pushed line: cache.cc:171-177), the store's version of a pushed line, hasgrad;
 // the next kPlanEvictBlocks workgroups: a wave per evicted dirty line: store row += its gradient, store version += its updates
 //     (PSFhandle_embedding.cc:23-27); the slot is free already (the bookkeeping freed it, nothing reuses it before the next
 //     batch's lookup);
-// the last kPlanMetaBlocks workgroups: a thread per unique key: the line's version (staged by the lookup, + updates for a
-//     pushed line: cache.cc:171-177), the store's version of a pushed line, hasgrad.
+// the rest: the ordered accumulate (apply_body, DUAL == 2: gradient buffer and data row; pushed lines take the push epilogue --
+//     store row += the line's new gradient, gradient buffer = 0).
+// (The independent short roles come first in the grid: they start with the launch, not behind 400 accumulate workgroups.)
 constexpr int kPlanEvictBlocks = 64, kPlanMetaBlocks = 8;
 template <int VEC>
 __global__ __launch_bounds__(1024, 8) void cache_update_planned_kernel(
-    Cache c, const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm, const int32_t *__restrict__ upos,
-    const uint32_t *__restrict__ uniq, int n, const float *__restrict__ grads, ApplyMaps maps, int apply_blocks,
-    const uint8_t *__restrict__ it_flag, const int32_t *__restrict__ it_upd, const long long *__restrict__ pver,
+    Cache c, const uint32_t *__restrict__ sorted, const int32_t *__restrict__ perm, int n, const float *__restrict__ grads,
+    ApplyMaps maps, const int32_t *__restrict__ it_upd_pos, const long long *__restrict__ pver,
     const int32_t *__restrict__ ev_slot, const uint32_t *__restrict__ ev_key, const int32_t *__restrict__ ev_upd,
     const PlanRec *__restrict__ rec) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_apply[];
     const int b = blockIdx.x;
-    if (b < apply_blocks) {
-        apply_body<kModeSgd, VEC, 2>(c.grad, static_cast<uint64_t>(c.S), static_cast<int>(c.width), sorted, perm, upos, n,
-                                        grads, -1.0f, b, s_apply, nullptr, maps);
+    if (b >= kPlanMetaBlocks + kPlanEvictBlocks) {
+        apply_body<kModeSgd, VEC, 2>(c.grad, static_cast<uint64_t>(c.S), static_cast<int>(c.width), sorted, perm, nullptr, n,
+                                     grads, -1.0f, b - kPlanMetaBlocks - kPlanEvictBlocks, s_apply, nullptr, maps);
         return;
     }
     const int lane = lane_id();
-    if (b < apply_blocks + kPlanEvictBlocks) {
+    if (b >= kPlanMetaBlocks) {
         const int E = static_cast<int>(rec->E);
-        for (int j = (b - apply_blocks) * 16 + static_cast<int>(threadIdx.x >> 6); j < E; j += kPlanEvictBlocks * 16) {
+        for (int j = (b - kPlanMetaBlocks) * 16 + static_cast<int>(threadIdx.x >> 6); j < E; j += kPlanEvictBlocks * 16) {
             const int s = uniform(ev_slot[j]);
             const long long lk = static_cast<long long>(uniform(ev_key[j]));
             float *row = c.table + lk * c.width;
@@ -555,17 +573,17 @@ __global__ __launch_bounds__(1024, 8) void cache_update_planned_kernel(
         }
         return;
     }
-    const int U = static_cast<int>(rec->U);
-    for (int u = (b - apply_blocks - kPlanEvictBlocks) * 1024 + static_cast<int>(threadIdx.x); u < U; u += kPlanMetaBlocks * 1024) {
-        const int s = maps.rowmap[u];
-        if (s < 0)
+    for (int p = b * 1024 + static_cast<int>(threadIdx.x); p < n; p += kPlanMetaBlocks * 1024) {
+        const int4 it = maps.pos_item[p];
+        if (it.x < 0 || !(it.z & kPosHead))
             continue;
-        const bool push = (it_flag[u] & kItPush) != 0;
-        const long long pv = pver[u];
+        const int s = it.x;
+        const long long pv = pver[p];
         long long v = pv != kVerKeep ? pv : c.line[s].version;
-        if (push) {
-            v += it_upd[u];
-            c.srv_ver[uniq[u]] += it_upd[u];
+        if (it.z & kPosPush) {
+            const int upd = it_upd_pos[p];
+            v += upd;
+            c.srv_ver[static_cast<uint32_t>(it.y)] += upd;
         }
         c.line[s].version = v;
         c.hasgrad[s] = 1;
@@ -573,16 +591,16 @@ __global__ __launch_bounds__(1024, 8) void cache_update_planned_kernel(
 }
 
 // the perf dict's data-dependent counts of a planned batch, on demand: lines the lookup pulled, lines the update pushed
-__global__ __launch_bounds__(1024) void cache_plan_count_kernel(PlanRec *rec, const long long *pver, const uint8_t *it_flag,
-                                                                const int32_t *it_slot) {
+__global__ __launch_bounds__(1024) void cache_plan_count_kernel(PlanRec *rec, const long long *pver, const int4 *pos_item) {
     __shared__ unsigned long long s_p[16], s_q[16];
-    const int U = static_cast<int>(rec->U);
+    const int n = static_cast<int>(rec->n);
     unsigned long long pulled = 0, pushed = 0;
-    for (int u = threadIdx.x; u < U; u += 1024) {
-        if (it_slot[u] < 0)
+    for (int p = threadIdx.x; p < n; p += 1024) {
+        const int4 it = pos_item[p];
+        if (it.x < 0 || !(it.z & kPosHead))
             continue;
-        pulled += pver[u] != kVerKeep ? 1 : 0;
-        pushed += (it_flag[u] & kItPush) ? 1 : 0;
+        pulled += pver[p] != kVerKeep ? 1 : 0;
+        pushed += (it.z & kPosPush) ? 1 : 0;
     }
     for (int o = 32; o >= 1; o >>= 1) {
         pulled += __shfl_xor(pulled, o, 64);
@@ -624,9 +642,9 @@ static int plan_slot_alloc(ha_cache *h, PlanSlot &sl) {
     PLAN_ALLOC(it_slot, all);
     PLAN_ALLOC(it_flag, all);
     PLAN_ALLOC(it_upd, all);
-    PLAN_ALLOC(it_push, all);
+    PLAN_ALLOC(pos_item, all);
+    PLAN_ALLOC(it_upd_pos, all);
     PLAN_ALLOC(pver, all);
-    PLAN_ALLOC(phg, all);
     PLAN_ALLOC(ev_slot, all);
     PLAN_ALLOC(ev_key, all);
     PLAN_ALLOC(ev_upd, all);
@@ -711,12 +729,24 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
         a.counts[i] = p.counts;
         sl.n[i] = n[i];
     }
-    a.it_slot = sl.it_slot; a.it_flag = sl.it_flag; a.it_upd = sl.it_upd; a.it_push = sl.it_push;
+    a.it_slot = sl.it_slot; a.it_flag = sl.it_flag; a.it_upd = sl.it_upd;
     a.ev_slot = sl.ev_slot; a.ev_key = sl.ev_key; a.ev_upd = sl.ev_upd;
     a.rec = sl.rec;
     a.xw = h->plan_xw;
     a.nmax = c.nmax;
     hipLaunchKernelGGL(cache_book_block_kernel, dim3(kBookWg), dim3(kBookThreads), 0, ss, c, a);
+    {   // the items per sorted position
+        PlanExpandPtrs ep;
+        int nmx = 1;
+        for (int i = 0; i < count; ++i) {
+            PlanPtrs p = plan_layout(sl.ws[i], n[i]);
+            ep.upos[i] = p.upos;
+            ep.perm[i] = p.perm;
+            nmx = n[i] > nmx ? static_cast<int>(n[i]) : nmx;
+        }
+        hipLaunchKernelGGL(cache_plan_expand_kernel, dim3((nmx + 255) / 256, count), dim3(256), 0, ss, a, ep, sl.pos_item,
+                           sl.it_upd_pos);
+    }
     HA_LAUNCH_CHECK();
     HA_CHECK_HIP(hipEventRecord(sl.booked, ss));
     sl.booked_on = ss;
@@ -766,11 +796,11 @@ extern "C" int ha_cache_lookup_planned(ha_cache *h, int64_t n, float *dest, ha_s
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(dest) % 16 == 0) &&
                             (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
         if (vec_ok)
-            hipLaunchKernelGGL(cache_lookup_planned_kernel<4>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos, p.perm,
-                               (long long)n, dest, sl->it_slot + at, sl->it_flag + at, sl->pver + at, sl->phg + at);
+            hipLaunchKernelGGL(cache_lookup_planned_kernel<4>, dim3(blocks), dim3(1024), 0, s, c, sl->pos_item + at, (long long)n,
+                               dest, sl->pver + at);
         else
-            hipLaunchKernelGGL(cache_lookup_planned_kernel<1>, dim3(blocks), dim3(1024), 0, s, c, p.uniq, p.upos, p.perm,
-                               (long long)n, dest, sl->it_slot + at, sl->it_flag + at, sl->pver + at, sl->phg + at);
+            hipLaunchKernelGGL(cache_lookup_planned_kernel<1>, dim3(blocks), dim3(1024), 0, s, c, sl->pos_item + at, (long long)n,
+                               dest, sl->pver + at);
         HA_LAUNCH_CHECK();
     }
     cache_mark(h, kTEnd, s);
@@ -796,23 +826,20 @@ extern "C" int ha_cache_update_planned(ha_cache *h, int64_t n, const float *grad
         const long long at = static_cast<long long>(i) * c.nmax;
         const int apply_blocks = static_cast<int>((n + kPosPerBlock - 1) / kPosPerBlock);
         ApplyMaps maps{};
-        maps.rowmap = sl->it_slot + at;
-        maps.init_u = sl->phg + at;
         maps.dst2 = c.data;
-        maps.rowmap2 = sl->it_slot + at;
         maps.push_tab = c.table;
-        maps.push_row = sl->it_push + at;
+        maps.pos_item = sl->pos_item + at;
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(grads) % 16 == 0) &&
                             (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
         const dim3 grid(static_cast<unsigned>(apply_blocks + kPlanEvictBlocks + kPlanMetaBlocks));
         if (vec_ok)
-            hipLaunchKernelGGL(cache_update_planned_kernel<4>, grid, dim3(1024), kApplyLdsBytes, s, c, p.sorted, p.perm, p.upos,
-                               p.uniq, (int)n, grads, maps, apply_blocks, sl->it_flag + at, sl->it_upd + at, sl->pver + at,
-                               sl->ev_slot + at, sl->ev_key + at, sl->ev_upd + at, sl->rec + i);
+            hipLaunchKernelGGL(cache_update_planned_kernel<4>, grid, dim3(1024), kApplyLdsBytes, s, c, p.sorted, p.perm, (int)n,
+                               grads, maps, sl->it_upd_pos + at, sl->pver + at, sl->ev_slot + at, sl->ev_key + at, sl->ev_upd + at,
+                               sl->rec + i);
         else
-            hipLaunchKernelGGL(cache_update_planned_kernel<1>, grid, dim3(1024), kApplyLdsBytes, s, c, p.sorted, p.perm, p.upos,
-                               p.uniq, (int)n, grads, maps, apply_blocks, sl->it_flag + at, sl->it_upd + at, sl->pver + at,
-                               sl->ev_slot + at, sl->ev_key + at, sl->ev_upd + at, sl->rec + i);
+            hipLaunchKernelGGL(cache_update_planned_kernel<1>, grid, dim3(1024), kApplyLdsBytes, s, c, p.sorted, p.perm, (int)n,
+                               grads, maps, sl->it_upd_pos + at, sl->pver + at, sl->ev_slot + at, sl->ev_key + at, sl->ev_upd + at,
+                               sl->rec + i);
         HA_LAUNCH_CHECK();
     }
     cache_mark(h, kTEnd, s);
@@ -824,13 +851,26 @@ extern "C" int ha_cache_update_planned(ha_cache *h, int64_t n, const float *grad
     return 0;
 }
 
+// `count` planned pairs by ONE call: lookup of the next planned batch into dests[k], its update with grads[k], ... (a caller
+// that has the gradient buffers of the pairs at hand: a benchmark loop, a pipeline whose model runs elsewhere)
+extern "C" int ha_cache_run_planned_pairs(ha_cache *h, int count, const int64_t *n, float *const *dests,
+                                          const float *const *grads, ha_stream_t stream) {
+    HA_REQUIRE(h && count >= 0 && (count == 0 || (n && dests && grads)), "cache_run_planned_pairs: bad arguments");
+    for (int k = 0; k < count; ++k) {
+        if (ha_cache_lookup_planned(h, n[k], dests[k], stream))
+            return -1;
+        if (ha_cache_update_planned(h, n[k], grads[k], stream))
+            return -1;
+    }
+    return 0;
+}
+
 // out[8]: the report of the last planned call, as ha_cache_perf's (synchronises the stream)
 int ha::cache_perf_planned(ha_cache *h, int64_t *out_host, hipStream_t s) {
     PlanSlot *sl = h->last_planned;
     const int i = h->last_planned_idx;
     const long long at = static_cast<long long>(i) * h->c.nmax;
-    hipLaunchKernelGGL(cache_plan_count_kernel, dim3(1), dim3(1024), 0, s, sl->rec + i, sl->pver + at, sl->it_flag + at,
-                       sl->it_slot + at);
+    hipLaunchKernelGGL(cache_plan_count_kernel, dim3(1), dim3(1024), 0, s, sl->rec + i, sl->pver + at, sl->pos_item + at);
     PlanRec r;
     HA_CHECK_HIP(hipMemcpyAsync(&r, sl->rec + i, sizeof(r), hipMemcpyDeviceToHost, s));
     HA_CHECK_HIP(hipStreamSynchronize(s));

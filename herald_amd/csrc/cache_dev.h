@@ -46,7 +46,8 @@ struct alignas(32) LineMeta {
     int32_t updates;
     int32_t freq;
     uint8_t state;
-    uint8_t pad[3];
+    uint8_t hg;        // the bookkeeping's copy of hasgrad[slot]: the planned flow (cache_block.hip) decides from it a block ahead of the rows
+    uint8_t pad[2];
 };
 static_assert(sizeof(LineMeta) == 32, "one line record = 32 bytes");
 
@@ -118,9 +119,9 @@ struct PlanSlot {
     int32_t *it_slot = nullptr;         // [kPlanBlockMax][nmax] items per unique key, see BookArgs (cache_block.hip)
     uint8_t *it_flag = nullptr;
     int32_t *it_upd = nullptr;
-    long long *it_push = nullptr;
+    int32_t *it_upd_pos = nullptr;      // [kPlanBlockMax][nmax] it_upd per sorted position
+    int4 *pos_item = nullptr;           // [kPlanBlockMax][nmax] the same per SORTED POSITION: {slot, key, kPos* flags, occurrence index}
     long long *pver = nullptr;          // [kPlanBlockMax][nmax] line versions staged by the lookup for the update
-    uint8_t *phg = nullptr;             // [kPlanBlockMax][nmax] "the line has a gradient buffer", staged the same way
     int32_t *ev_slot = nullptr;         // [kPlanBlockMax][nmax] evicted dirty lines per batch
     uint32_t *ev_key = nullptr;
     int32_t *ev_upd = nullptr;

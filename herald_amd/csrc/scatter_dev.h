@@ -34,13 +34,15 @@ struct ApplyMaps {
     // tolerance mode (ha_set_tolerance_mode): runs of at least this many occurrences (0 = never) are applied as
     // `row - tree_sum(lr * g)` in a fixed order instead of the serial chain (coop_slice_tree below)
     int tree_from;
-    // DUAL == 2 kernels, the cache's planned update (cache_block.hip): unique key u with push_row[u] >= 0 is PUSHED in the same
-    // pass -- push_tab[push_row[u],:] += the first destination's new value (the line's gradient after the batch,
+    // DUAL == 2 kernels, the cache's planned update (cache_block.hip): a key whose record carries kPosPush is PUSHED in the
+    // same pass -- push_tab[key,:] += the first destination's new value (the line's gradient after the batch,
     // PSFhandle_embedding.cc:23-27), and the first destination is stored as zeros (Line::zeroGrad, embedding.h:112-118)
     float *push_tab;
-    const long long *push_row;
-    const uint8_t *init_u;     // DUAL == 2: the first destination of unique key u starts from its stored value iff init_u[u] != 0
+    // DUAL == 2: one record per SORTED POSITION {destination row (both destinations; -1 = skip), key, kPos* flags, occurrence
+    // index}: what the rowmap / init / push lookups through upos[p] give, in the round trip that fetches the window itself
+    const int4 *pos_item;
 };
+enum : int { kPosMiss = 1, kPosInit = 2, kPosPush = 4, kPosHead = 8 };
 
 // host: the run length from which the tolerance mode applies (0 = exact everywhere; scatter.hip,
 // ha_set_tolerance_mode)
@@ -801,15 +803,20 @@ __device__ __forceinline__ bool coop_run(
 
     uint64_t row;
     bool init = true;
-    if (maps.rowmap) {
+    int4 pit{0, 0, 0, 0};
+    if (DUAL == 2) {
+        pit = maps.pos_item[wg0];
+        if (pit.x < 0)
+            return true;
+        row = static_cast<uint64_t>(pit.x);
+        init = (pit.z & kPosInit) != 0;
+    } else if (maps.rowmap) {
         const int r = maps.rowmap[upos[wg0]];
         if (r < 0)
             return true;
         row = static_cast<uint64_t>(r);
         if (maps.dst_init)
             init = maps.dst_init[r] != 0;
-        if (DUAL == 2 && maps.init_u)
-            init = maps.init_u[upos[wg0]] != 0;
     } else if (MODE == kModeReduce) {
         row = static_cast<uint64_t>(upos[wg0]);
     } else {
@@ -819,14 +826,15 @@ __device__ __forceinline__ bool coop_run(
         return true;
     float *dst_row = dst + row * static_cast<uint64_t>(width);
     Second d2{nullptr, false};
-    if (DUAL && maps.rowmap2) {
+    if (DUAL == 2) {
+        d2.on = true;
+        d2.row = maps.dst2 + row * static_cast<uint64_t>(width);
+        d2.push = (pit.z & kPosPush) ? maps.push_tab + static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) * static_cast<uint64_t>(width)
+                                     : nullptr;
+    } else if (DUAL && maps.rowmap2) {
         const int r2 = maps.rowmap2[upos[wg0]];
         d2.on = r2 >= 0;
         d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
-    }
-    if (DUAL == 2 && maps.push_row) {
-        const long long pr = maps.push_row[upos[wg0]];
-        d2.push = pr >= 0 ? maps.push_tab + static_cast<uint64_t>(pr) * static_cast<uint64_t>(width) : nullptr;
     }
     if (MODE == kModeOpt)
         opt_rows(d2, maps, row, width);
@@ -902,6 +910,9 @@ __device__ __forceinline__ bool apply_body_impl(
     // speculative, same round trip: this thread's share of the occurrence indices around the workgroup
     // (used only if the workgroup turns out to be a worker of a long run)
     const int spv = perm[max(0, min(wg0 - kCoopPermSpan + static_cast<int>(threadIdx.x), n - 1))];
+    int4 pit{0, 0, 0, 0};      // DUAL == 2: this position's record, in the same round trip
+    if (DUAL == 2)
+        pit = maps.pos_item[p];
     if (maps.valmap)  // wave-uniform
         pv = maps.valmap[pv];
     const uint32_t key = static_cast<uint32_t>(
@@ -934,15 +945,18 @@ __device__ __forceinline__ bool apply_body_impl(
 
     uint64_t row;
     bool init = true;
-    if (maps.rowmap) {
+    if (DUAL == 2) {
+        if (pit.x < 0)
+            return false;
+        row = static_cast<uint64_t>(pit.x);
+        init = (pit.z & kPosInit) != 0;
+    } else if (maps.rowmap) {
         const int r = maps.rowmap[upos[p]];
         if (r < 0)
             return false;  // unique key without a destination
         row = static_cast<uint64_t>(r);
         if (maps.dst_init)
             init = maps.dst_init[r] != 0;
-        if (DUAL == 2 && maps.init_u)
-            init = maps.init_u[upos[p]] != 0;
     } else if (MODE == kModeReduce) {
         row = static_cast<uint64_t>(upos[p]);
     } else {
@@ -952,14 +966,15 @@ __device__ __forceinline__ bool apply_body_impl(
         return false;  // out-of-range id: ignored (undefined behaviour in the reference)
     float *dst_row = dst + row * static_cast<uint64_t>(width);
     Second d2{nullptr, false};
-    if (DUAL && maps.rowmap2) {
+    if (DUAL == 2) {
+        d2.on = true;
+        d2.row = maps.dst2 + row * static_cast<uint64_t>(width);
+        d2.push = (pit.z & kPosPush) ? maps.push_tab + static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) * static_cast<uint64_t>(width)
+                                     : nullptr;
+    } else if (DUAL && maps.rowmap2) {
         const int r2 = maps.rowmap2[upos[p]];
         d2.on = r2 >= 0;
         d2.row = maps.dst2 + static_cast<uint64_t>(d2.on ? r2 : 0) * static_cast<uint64_t>(width);
-    }
-    if (DUAL == 2 && maps.push_row) {
-        const long long pr = maps.push_row[upos[p]];
-        d2.push = pr >= 0 ? maps.push_tab + static_cast<uint64_t>(pr) * static_cast<uint64_t>(width) : nullptr;
     }
     if (MODE == kModeOpt)
         opt_rows(d2, maps, row, width);

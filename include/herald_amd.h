@@ -877,6 +877,9 @@ int ha_cache_plan_block(ha_cache *cache, const void *const *keys, int key_kind, 
 int ha_cache_lookup_planned(ha_cache *cache, int64_t n, float *dest, ha_stream_t stream);
 int ha_cache_update_planned(ha_cache *cache, int64_t n, const float *grads, ha_stream_t stream);
 int ha_cache_plan_pending(ha_cache *cache);
+/* `count` planned pairs by one call: ha_cache_lookup_planned(n[k], dests[k]) then ha_cache_update_planned(n[k], grads[k]) */
+int ha_cache_run_planned_pairs(ha_cache *cache, int count, const int64_t *n, float *const *dests, const float *const *grads,
+                               ha_stream_t stream);
 int ha_cache_update(ha_cache *cache, const void *keys, int key_kind, int64_t n,
                     const float *grads, ha_stream_t stream);
 /* ha_cache_update for the key batch of the immediately preceding ha_cache_lookup on this cache (the

@@ -458,6 +458,64 @@ def test_lru_cache_at_limit_0_1_on_the_full_table(dev, big_table, pull_bound, pu
     np.testing.assert_array_equal(sent, formula.rows_of(SENTINELS, WIDTH))
     assert gpu.size() == model.policy.size()
     assert int(gpu._L.ha_cache_fused_updates(gpu._h)) == len(batches) // 2
+    if written:        # the pushed rows back to the closed form: the next test starts from it
+        _restore(table, np.array(written, dtype=np.int64), dev)
+
+
+def test_lru_cache_planned_flow_at_limit_0_1_on_the_full_table(dev, big_table):
+    """The same tier through the PLANNED flow (csrc/cache_block.hip; what bench.py's cache_tier line times): blocks of 4
+    batches, the next block's bookkeeping planned while this block's rows move; rows, perf counters and server versions every
+    step, resident lines at the end."""
+    table = big_table
+    limit = int(0.1 * ROWS)
+    n = BATCH * FIELDS
+    server = _LazyServer(WIDTH)
+    model = cache_model.CacheModel("lru", limit, WIDTH, server, 2, 2)
+    versions = torch.zeros(ROWS, dtype=torch.int64, device=dev)
+    gpu = hcache.LRUCache(limit, ROWS, WIDTH, node_id=0, max_batch=n, device=dev)
+    gpu.bind_store(table, versions)
+    gpu.pull_bound, gpu.push_bound = 2, 2
+    gpu.perf_enabled = True
+    rng = np.random.default_rng(22)
+    batches = _batches(10, first=300)
+    kts = [torch.from_numpy(f).to(dev) for f in batches]
+    blocks = [list(range(b0, min(b0 + 4, len(batches)))) for b0 in range(0, len(batches), 4)]
+    gpu.plan_block([kts[i] for i in blocks[0]])
+    for j, blk in enumerate(blocks):
+        if j + 1 < len(blocks):
+            gpu.plan_block([kts[i] for i in blocks[j + 1]])
+        for step in blk:
+            f = batches[step]
+            want = model.lookup(cpu.ids_to_keys(f))
+            dest = torch.empty((n, WIDTH), dtype=torch.float32, device=dev)
+            gpu.embedding_lookup_planned(dest).wait()
+            np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="lookup rows at step %d" % step)
+            grads = (rng.standard_normal((n, WIDTH), dtype=np.float32) * np.float32(-0.01))
+            model.update(cpu.ids_to_keys(f), grads)
+            gpu.embedding_update_planned(torch.from_numpy(grads).to(dev)).wait()
+            for got, exp in zip(gpu.perf[-2:], model.perf[-2:]):
+                for fld in ("type", "num_all", "num_unique", "num_miss", "num_transfered", "is_full"):
+                    assert got[fld] == exp[fld], (step, fld, got, exp)
+    assert gpu.plan_pending() == 0
+    touched = sorted(server.ver.keys())
+    tv = versions[torch.tensor(touched, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(tv, np.array([server.ver[k] for k in touched], dtype=np.int64))
+    assert int(versions.sum().item()) == sum(server.ver.values())
+    written = sorted(server.table.rows.keys())
+    if written:
+        got = table[torch.tensor(written, device=dev)].cpu().numpy()
+        np.testing.assert_array_equal(got, np.stack([server.table.rows[k] for k in written]), err_msg="server rows after pushes")
+    res, lines = model.resident(), gpu.lines()
+    assert sorted(lines.keys()) == sorted(res.keys())
+    for k, ln in res.items():
+        g = lines[k]
+        assert g.version == ln.version and g.updates == ln.updates, k
+        np.testing.assert_array_equal(g.data, ln.data, err_msg="data of key %d" % k)
+        if ln.grad is not None:
+            np.testing.assert_array_equal(g.grad, ln.grad, err_msg="grad of key %d" % k)
+    assert gpu.size() == model.policy.size()
+    if written:
+        _restore(table, np.array(written, dtype=np.int64), dev)
 
 
 def test_cold_tier_on_an_8gib_pinned_host_table(dev):
