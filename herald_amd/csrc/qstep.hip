@@ -90,7 +90,12 @@ struct QHeader {
     // of its step checks both words before it reads an item (ha_qapply_steps_sync): callers that order the two streams
     // without a wait on the apply's stream rest on it.  `done`: wide path, bucket workgroups that have finished.
     uint32_t epoch_wave, epoch_copy, done;
-    uint32_t reserved[51];
+    // the apply launch's ONE decision about this queue (sync = "flags"): workgroup 0 resolves the epoch words -- there at the
+    // first look, or polled for up to 2 s -- and publishes the step's epoch (go) or its complement (the launch gave up:
+    // NOTHING of the step is applied); a workgroup that does not find the tag at its first look follows this word, never
+    // the tag itself (ADVICE round 4 / verdict round 5: a timed-out step must not be partly applied)
+    uint32_t verdict;
+    uint32_t reserved[50];
 };
 static_assert(sizeof(QHeader) == 256, "queue header is one 256-byte line");
 struct QEntry {
@@ -1459,24 +1464,43 @@ __global__ __launch_bounds__(kQWg, 8) void qapply_kernel(const QArgs a) {
         // The caller orders this launch behind the queue's builder without a wait on this stream (the builder ran a block of
         // steps ago): the epoch words say so.  They are there on the first look; if not, poll (device-coherent loads, bounded:
         // 2 s) -- the builder never waits for this launch -- and give up loudly rather than read a half-built queue.
-        bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch;     // (read with the header's counts)
-        // (bounded by the 100 MHz clock: 2 s.  A count of spins alone -- 2^20, round 4 -- came to ~40 s on a loaded chip)
-        const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();
-        for (int spin = 0; !ready && spin < (1 << 22); ++spin) {
-            const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
-            if (ready || __builtin_amdgcn_s_memrealtime() - t_poll > 200000000ull)
-                break;
-            __builtin_amdgcn_s_sleep(64);
-        }
-        if (!ready) {
-            // ANY workgroup that gives up says so (another may have seen the tag just in time and applied its items: the step is
-            // then partially applied, and the host must hear of it -- QueueStepPipeline raises)
-            if (a.err != nullptr && threadIdx.x == 0)
+        // One decision per launch: see QHeader::verdict.
+        const uint32_t fail = ~a.epoch;
+        bool ready = a.qh->epoch_wave == a.epoch && a.qh->epoch_copy == a.epoch &&      // (read with the header's counts)
+                     a.qh->verdict != fail;
+        if (blockIdx.x == 0) {
+            // (bounded by the 100 MHz clock: 2 s.  A count of spins alone -- 2^20, round 4 -- came to ~40 s on a loaded chip)
+            const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();
+            for (int spin = 0; !ready && spin < (1 << 22); ++spin) {
+                const uint32_t e0 = __hip_atomic_load(&a.qh->epoch_wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t e1 = __hip_atomic_load(&a.qh->epoch_copy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                ready = uniform(static_cast<uint32_t>(e0 == a.epoch && e1 == a.epoch)) != 0u;
+                if (ready || __builtin_amdgcn_s_memrealtime() - t_poll > 200000000ull)
+                    break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(const_cast<uint32_t *>(&a.qh->verdict), ready ? a.epoch : fail, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);      // (the one word an apply launch writes into its queue)
+                if (!ready && a.err != nullptr)
+                    __hip_atomic_store(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else if (!ready) {
+            // not there at the first look: workgroup 0 decides (a little beyond its 2 s: it may have started later)
+            const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();
+            uint32_t vd = 0u;
+            for (int spin = 0; spin < (1 << 23); ++spin) {
+                vd = uniform(__hip_atomic_load(&a.qh->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+                if (vd == a.epoch || vd == fail || __builtin_amdgcn_s_memrealtime() - t_poll > 400000000ull)
+                    break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            ready = vd == a.epoch;
+            if (!ready && vd != fail && a.err != nullptr && threadIdx.x == 0)      // (workgroup 0 never spoke: say so as well)
                 __hip_atomic_store(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
         }
+        if (!ready)
+            return;
     }
     const bool coop = b < a.ncoop;
     if (coop) {
@@ -1841,6 +1865,14 @@ static int qapply_lists(float *table, int64_t rows, int64_t width, const int32_t
     // a shorter launch ramp, and free slots for the preparation launches that run beside the steps
     if (wave_items >= 0 && wave_items / kQWpw + 1 < a.nworker)
         a.nworker = static_cast<int>(wave_items / kQWpw + 1);
+    // (sync = "flags": a launch whose queue is still being built POLLS -- workgroup 0 the epoch words, the others its verdict --
+    // and while it does, no compute unit is EMPTY; the builder's workgroups fit only an empty one: 106 scalar registers a wave,
+    // beside a workgroup of this kernel a SIMD's scalar file is short.  A builder that has not started by then starts when the
+    // poll gives up, after 2 s, and the step fails (cleanly: nothing applied).  Measured: sporadic time-outs at blocks of 2 steps,
+    // where the builder is only a block's worth of time ahead; none from blocks of 8.  Holding the builder kernels to 80 scalar
+    // registers lets them in -- and costs the steps 12 % (headline 13.7 us against 12.2, wide shapes 52 / 56 against 36 / 47):
+    // the preparation waiting for empty compute units is what keeps it out of the steps' way.  QueueStepPipeline therefore
+    // orders blocks of fewer than 8 steps by events; docs/EXPERIMENTS.md round 6.)
     if (done != nullptr)
         // the event completes with THIS launch (the dispatch packet's own completion signal): no packet of its own on the
         // stream -- an event record between two launches of a stream costs what a short kernel costs

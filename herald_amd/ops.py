@@ -788,7 +788,7 @@ class QueueStepPipeline:
     chain bit for bit.  `plan_of(j)` holds the unique keys / counts / inverse / occurrence lists of batch j with the
     unique keys in hash-slot order (not np.unique's order) once its block has been prepared."""
 
-    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True, sync="events"):
+    def __init__(self, table, capacity, lr, device=None, block=8, overlap=True, sync="events", min_flags_block=8):
         """sync: how the preparation stream and the caller's stream are ordered when overlap is on.
         "events" (default): an event record and an event wait on the caller's stream at every block start -- safe for any
         caller (ids produced by work queued on the caller's stream, steps captured into hipGraphs).
@@ -817,7 +817,20 @@ class QueueStepPipeline:
         if sync not in ("events", "flags"):
             raise ValueError("sync must be 'events' or 'flags'")
         self.sync = sync if self.overlap else "events"
+        # "flags" needs the queues' builder a comfortable block ahead of the steps: an apply launch that has to WAIT for its queue
+        # polls with every compute unit taken, and the builder's workgroups start only on an empty one (csrc/qstep.hip,
+        # qapply_lists) -- sporadic 2 s time-outs at blocks of 2 steps, 43 us per step at blocks of 4 (14 by events).  Blocks of
+        # fewer than 8 steps are ordered by events whatever was asked for.
+        # (min_flags_block: tests of the mechanism itself lower it)
+        if self.sync == "flags" and int(block) < int(min_flags_block):
+            self.sync = "events"
         self._done_ev, self._cev_pool = {}, []       # flags: block -> library event completed by its last apply launch
+        # done-events the preparation stream has been told to wait for, with a marker recorded on that stream behind the wait:
+        # an event is handed to a later launch only once its marker has completed (the wait has certainly been consumed -- the
+        # host runs many blocks ahead of the device, and a wait that is resolved against an event RE-BOUND to a later launch
+        # waits for a step whose queue this very stream has yet to build: a deadlock that ends in the apply's 2 s time-out;
+        # seen at blocks of 2 steps)
+        self._cev_busy = []
         self.block = int(block) if self.overlap else 1
         if not 1 <= self.block <= 64:
             raise ValueError("block must be 1..64")
@@ -857,9 +870,9 @@ class QueueStepPipeline:
 
     def close(self):
         """Releases the library events of the flags mode (ha_event_create)."""
-        for ev in list(self._done_ev.values()) + self._cev_pool:
+        for ev in list(self._done_ev.values()) + self._cev_pool + [e for e, _ in self._cev_busy]:
             self._L.ha_event_destroy(ev)
-        self._done_ev, self._cev_pool = {}, []
+        self._done_ev, self._cev_pool, self._cev_busy = {}, [], []
 
     def __del__(self):
         try:
@@ -869,7 +882,13 @@ class QueueStepPipeline:
 
     # ---- bookkeeping ------------------------------------------------------------------------------------------
     def reset(self, stream=None):
-        self._cev_pool.extend(self._done_ev.values())
+        if self._done_ev:
+            if self.side is not None:       # (nothing may be waiting for them, but an event in flight is not handed out either)
+                marker = self._event() if hasattr(self, "_ev_pool") else torch.cuda.Event()
+                marker.record(self.side)
+                self._cev_busy.extend((e, marker) for e in self._done_ev.values())
+            else:
+                self._cev_pool.extend(self._done_ev.values())
         self._done_ev = {}
         self.c, self.n, self.shape, self.ids = None, {}, {}, {}
         self._enq_last, self._covered = None, -(1 << 60)
@@ -933,7 +952,9 @@ class QueueStepPipeline:
             cev = self._done_ev.pop(b - 1, None)
             if cev is not None:
                 check(L.ha_stream_wait_event(sp, cev), "ha_stream_wait_event")
-                self._cev_pool.append(cev)
+                marker = self._event()
+                marker.record(s)
+                self._cev_busy.append((cev, marker))
                 self._covered = b * B - 1
             elif self._enq_last is not None and self._enq_last > self._covered:
                 # steps that may still read what is about to be rewritten were enqueued without an event of their own (a
@@ -1040,6 +1061,10 @@ class QueueStepPipeline:
         """flags: the library event the launch of step c has to complete if c is the last step of its block, else None."""
         if self.sync != "flags" or (c + 1) % self.block != 0:
             return None
+        if not self._cev_pool and self._cev_busy and self._cev_busy[0][1].query():
+            old_ev, marker = self._cev_busy.pop(0)      # the preparation stream is past its wait for this one
+            self._ev_pool.append(marker)
+            self._cev_pool.append(old_ev)
         ev = self._cev_pool.pop() if self._cev_pool else ctypes.c_void_p(self._L.ha_event_create())
         if not ev:
             raise RuntimeError("ha_event_create failed")

@@ -79,8 +79,8 @@ def _within(got, exact, tol_rows, keys, what):
 
 # (preparation beside the steps, steps per block[, how the two streams are ordered: "events" (default) or "flags" = epoch
 # tags in the queues + an event riding on the block's last launch: nothing but apply launches on the caller's stream])
-MODES = [(True, 8), (True, 2), (False, 1), (True, 4, "flags")]
-MODE_IDS = ["side_stream_block8", "side_stream_block2", "one_stream", "flags_block4"]
+MODES = [(True, 8), (True, 2), (False, 1), (True, 8, "flags")]
+MODE_IDS = ["side_stream_block8", "side_stream_block2", "one_stream", "flags_block8"]
 
 
 def _run_stream(dev, table0, batches, grads, lr, ids_dtype=np.float32, table=None, check_plans=True, mode=(True, 2)):
@@ -311,7 +311,7 @@ def _check_wide_plan(pl, ids_int, what):
     assert (np.diff(perm)[inside[1:]] > 0).all(), what + ": occurrences of a key in occurrence order"
 
 
-@pytest.mark.parametrize("mode", [(True, 4), (False, 1), (True, 2, "flags")], ids=["side_stream_block4", "one_stream", "flags_block2"])
+@pytest.mark.parametrize("mode", [(True, 4), (False, 1), (True, 8, "flags")], ids=["side_stream_block4", "one_stream", "flags_block8"])
 @pytest.mark.parametrize("bs,width,rows", [(1024, 64, 400_000), (4096, 32, 1_000_000), (300, 128, 50_000)],
                          ids=["configs3_26624ids", "configs2_106496ids", "7800ids"])
 def test_qstep_wide_batches(dev, bs, width, rows, mode):
@@ -396,7 +396,7 @@ def test_qstep_wide_bucket_overflow_takes_the_sorted_plan(dev):
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
     lr = 0.02
     table = _dev(table0, dev)
-    pipe = ops.QueueStepPipeline(table, n, lr, overlap=True, block=2, sync="flags")
+    pipe = ops.QueueStepPipeline(table, n, lr, overlap=True, block=2, sync="flags", min_flags_block=1)
     assert pipe.wide and pipe.plans[0].buckets == P
     L = pipe.LOOKAHEAD
     d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
@@ -452,7 +452,7 @@ def test_qstep_wide_buckets_at_the_quarter_workgroup_limits(dev, crowd):
         b[crowd:crowd + 40] = pick[0]                          # (one of them 41 times: a long item inside the crowd)
         batches.append(rng.permutation(b))
     grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(steps)]
-    pipe = _run_stream(dev, table0, batches, grads, 0.05, mode=(True, 2, "flags"), check_plans=False)
+    pipe = _run_stream(dev, table0, batches, grads, 0.05, mode=(True, 8, "flags"), check_plans=False)
     assert pipe.wide and pipe.plans[0].buckets == P and pipe.fallbacks == 0
     for k in range(steps - 2, steps):                          # (the plans of the last batches are still in their workspaces)
         _check_wide_plan(pipe.plan_of(k), batches[k].astype(np.int64), "plan of batch %d" % k)
@@ -516,7 +516,7 @@ def test_a_step_whose_queue_was_never_built_raises_and_applies_nothing(dev):
     table = _dev(table0, dev)
     batches = [synth.criteo_batch(bs, step=k, rows=rows).reshape(-1) for k in range(64)]
     n = batches[0].size
-    pipe = ops.QueueStepPipeline(table, n, 0.05, overlap=True, block=2, sync="flags")
+    pipe = ops.QueueStepPipeline(table, n, 0.05, overlap=True, block=2, sync="flags", min_flags_block=1)
     d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
     pipe.start(d_ids[:pipe.LOOKAHEAD])
     torch.cuda.synchronize()
@@ -532,3 +532,59 @@ def test_a_step_whose_queue_was_never_built_raises_and_applies_nothing(dev):
     with pytest.raises(RuntimeError, match="failed on the device"):
         pipe._raise_if_failed([c])
     assert pipe.overflowed()
+
+
+def test_a_step_whose_builder_is_late_applies_nothing_and_raises(dev):
+    """sync="flags", the builder DELAYED past the apply's bound (a 3.5 s occupant kernel in front of it on the preparation
+    stream): workgroup 0 of the apply polls for 2 s, publishes "gave up" in the queue, every other workgroup follows that word
+    -- the table and the output are exactly what they were, the error word is raised, and the builder completing afterwards
+    does not revive the step (one decision per launch: QHeader::verdict, csrc/qstep.hip)."""
+    import ctypes
+    from herald_amd import _lib
+    rows, width, bs = 50_000, 64, 32
+    rng = np.random.default_rng(9)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    table = _dev(table0, dev)
+    batches = [synth.criteo_batch(bs, step=k, rows=rows).reshape(-1) for k in range(32)]
+    n = batches[0].size
+    pipe = ops.QueueStepPipeline(table, n, 0.05, overlap=True, block=2, sync="flags", min_flags_block=1)
+    d_ids = [_dev(b.astype(np.float32), dev) for b in batches]
+    L = pipe.LOOKAHEAD
+    pipe.start(d_ids[:L])
+    grads = [_dev(rng.standard_normal((n, width), dtype=np.float32), dev) for _ in range(4)]
+    pipe.step(grads[0], d_ids[L])                 # step 0
+    pipe.step(grads[1], d_ids[L + 1])             # step 1: block 0 done
+    torch.cuda.synchronize()
+    # the preparation of block 1's start builds the queues of block 2 (steps 4, 5): hold it back
+    _lib.check(_lib.load().ha_debug_occupy(1, 64, 4, 350_000_000, ctypes.c_void_p(pipe.side.cuda_stream)), "occupy")
+    pipe.step(grads[2], d_ids[L + 2])             # step 2 (its queue was built a block ago): fine
+    pipe.step(grads[3], d_ids[L + 3])             # step 3
+    torch.cuda.synchronize()                      # (waits for the occupant and the late builder too)
+    before = table.cpu().numpy()
+    # queues of steps 4 and 5 exist NOW; rebuild the situation for step 6 instead: hold the builder of block 3's queues back
+    _lib.check(_lib.load().ha_debug_occupy(1, 64, 4, 350_000_000, ctypes.c_void_p(pipe.side.cuda_stream)), "occupy")
+    g = _dev(rng.standard_normal((n, width), dtype=np.float32), dev)
+    out4 = pipe.step(g, d_ids[L + 4])             # step 4: prepares block 2 -> the queues of steps 6, 7 sit behind the occupant
+    out5 = pipe.step(g, d_ids[L + 5])
+    main = torch.cuda.current_stream(dev)
+    main.synchronize()
+    after5 = table.cpu().numpy()
+    assert not np.array_equal(after5, before)     # steps 4 and 5 applied
+    out6 = torch.full((n, width), 7.0, device=dev)
+    pipe.n[6], pipe.n[7] = n, n
+    pipe.apply(6, g, out6)                        # its queue is not built yet: 2 s of polling, then "gave up"
+    main.synchronize()
+    np.testing.assert_array_equal(table.cpu().numpy(), after5)      # nothing of step 6 was applied
+    assert bool((out6 == 7.0).all())
+    torch.cuda.synchronize()                      # the occupant ends, the builder completes the queue of step 6
+    with pytest.raises(RuntimeError, match="failed on the device"):
+        pipe._raise_if_failed([6])
+    with pytest.raises(RuntimeError, match="unusable"):
+        pipe.apply(6, g, out6)                    # the pipeline does not launch the step again
+    # ... and a launch made past the host's check finds the queue's verdict: still nothing
+    import ctypes as ct
+    pipe._counts_c[4 * (6 % pipe.COUNTS) + 3] = 0
+    pipe.apply(6, g, out6)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(table.cpu().numpy(), after5)
+    assert bool((out6 == 7.0).all())
