@@ -144,6 +144,35 @@ int main(int argc, char **argv) {
         run("copy only (C=0,M=1)", 6940, 1, 0, 1, wg);
         run("apply only (C=1,M=0)", 6940, 1, 1, 0, wg);
     }
+    // ---- P independent chains: the step's items cut into P key classes, class p's launches back to back on stream p (a key's
+    // items of consecutive steps fall into the same class, so the chains never wait for each other): us per STEP = all P launches
+    printf("# P independent chains of step-like launches (5200 / P items each, 1024-thread workgroups): us per step\n");
+    for (int P : {1, 2, 3, 4}) {
+        std::vector<hipStream_t> ss(P);
+        for (int p = 0; p < P; ++p) CK(hipStreamCreateWithFlags(&ss[p], hipStreamNonBlocking));
+        const int items = 5200 / P, grid = (items + 15) / 16, reps = 1000;
+        auto launch_all = [&](int i) {
+            for (int p = 0; p < P; ++p) {
+                RowArgs b{table, rows, grads[i % NB] + (size_t)p * items * 512, outs[i % NB] + (size_t)p * items * 512, items, 1, 1,
+                          (uint32_t)(i * 7919u + p * 104729u)};
+                hipLaunchKernelGGL((rows_kernel<1, 1, 1>), dim3(grid), dim3(1024), 0, ss[p], b);
+            }
+        };
+        for (int i = 0; i < 20; ++i) launch_all(i);
+        for (int p = 0; p < P; ++p) CK(hipStreamSynchronize(ss[p]));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        std::vector<hipEvent_t> ej(P);
+        for (int p = 0; p < P; ++p) CK(hipEventCreateWithFlags(&ej[p], hipEventDisableTiming));
+        CK(hipEventRecord(e0, ss[0]));
+        for (int p = 1; p < P; ++p) CK(hipStreamWaitEvent(ss[p], e0, 0));
+        for (int i = 0; i < reps; ++i) launch_all(i);
+        for (int p = 1; p < P; ++p) { CK(hipEventRecord(ej[p], ss[p])); CK(hipStreamWaitEvent(ss[0], ej[p], 0)); }
+        CK(hipEventRecord(e1, ss[0]));
+        CK(hipStreamSynchronize(ss[0]));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("chains %d: %6.2f us per step (%d items per launch)  %.2f TB/s\n", P, ms * 1000.f / reps, items,
+               (double)items * P * 2048.0 * 4 / (ms * 1000.0 / reps) / 1e6);
+    }
     printf("# variants of the step-like / apply-only kernels (256-thread workgroups unless said otherwise)\n");
     auto runf = [&](const char *name, int items, int c, int m, int wg, int flags) {
         RowArgs a{table, rows, nullptr, nullptr, items, c, m, 0};

@@ -75,6 +75,38 @@ for lo in np.arange(0, t1[live].max(), 1.0):
         mm = live & sel & (t0 < lo + 1.0) & (t1 > lo)
         row.append(int(mm.sum()))
     print("t=%4.1f us resident waves %s: %s" % (lo, "/".join(g[0].split()[-1] for g in groups), row))
+# ---- tail census: what the waves that are still alive late in the launch are (item class, occurrences c, destinations m)
+cc = ((d[:, 3] >> 8) & 0xFFFFF).astype(np.int64)
+mm_ = ((d[:, 3] >> 28) & 0xFFFFF).astype(np.int64)
+col0 = ((d[:, 3] >> 48) & 0xFFFF).astype(np.int64) * 4
+names = {0: "S", 1: "M", 2: "L", 3: "Z", 4: "G", -1: "-"}
+span = t1[live].max()
+for cut in (float(os.environ.get("CUT", "7.0")), 8.0, 9.0):
+    late = live & (t1 > cut)
+    print("== waves alive after %.1f us: %d of %d (span %.2f)" % (cut, late.sum(), live.sum(), span))
+    for k in (0, 1, 2, 4):
+        sel = late & (kind == k)
+        allk = live & (kind == k)
+        if not allk.any():
+            continue
+        is_copy = sel & (cc == 0)
+        print("   %s: %5d late of %5d | apply c p50 %s max %s, m p50 %s max %s | copies (c = 0) %d, their m p50 %s max %s | start p50 %.2f dur p50 %.2f"
+              % (names[k], sel.sum(), allk.sum(),
+                 (int(np.median(cc[sel & (cc > 0)])) if (sel & (cc > 0)).any() else "-"), (int(cc[sel].max()) if sel.any() else "-"),
+                 (int(np.median(mm_[sel & (cc > 0)])) if (sel & (cc > 0)).any() else "-"),
+                 (int(mm_[sel & (cc > 0)].max()) if (sel & (cc > 0)).any() else "-"),
+                 is_copy.sum(), (int(np.median(mm_[is_copy])) if is_copy.any() else "-"), (int(mm_[is_copy].max()) if is_copy.any() else "-"),
+                 float(np.median(t0[sel])) if sel.any() else 0.0, float(np.median((t1 - t0)[sel])) if sel.any() else 0.0))
+# duration by (class, c) and by m, all waves
+for k in (0, 1, 2):
+    sel = live & (kind == k)
+    if not sel.any():
+        continue
+    rows_ = []
+    for cv in sorted(set(cc[sel].tolist()))[:20]:
+        s2 = sel & (cc == cv)
+        rows_.append("c=%d:%d waves dur %.2f end %.2f" % (cv, s2.sum(), np.median((t1 - t0)[s2]), np.median(t1[s2])))
+    print("   %s by c: %s" % (names[k], "; ".join(rows_)))
 idx = np.nonzero(live)[0]
 order = idx[np.argsort(-t1[idx])][:12]
 print("latest waves (block, wave, role, kind, start, end):",
