@@ -83,6 +83,14 @@ def load(build_if_missing=True):
     return L
 
 
+class ShardSlot(ctypes.Structure):
+    """ha_shard_slot (include/herald_amd.h): one routed batch of the sharded step."""
+    _fields_ = [("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("rcap", ctypes.c_int64), ("n", ctypes.c_int64),
+                ("plan_ws", ctypes.c_void_p), ("keys_fixed", ctypes.c_void_p), ("meta_dev", ctypes.c_void_p),
+                ("posmap", ctypes.c_void_p), ("rowmap", ctypes.c_void_p), ("counts_host", ctypes.c_void_p),
+                ("owner_plan_ws", ctypes.c_void_p)]
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = load().ha_last_error().decode("utf-8", "replace")
@@ -177,6 +185,10 @@ def _declare(L):
         "ha_event_record": [vp, vp],
         "ha_stream_wait_event": [vp, vp],
         "ha_qqueue_batch_epochs": [i64, i64, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp],
+        "ha_shard_step_pull": [vp, i64, i64, vp, vp, vp, vp, i64, vp, vp],
+        "ha_shard_step_push": [vp, i64, i64, vp, vp, vp, i64, vp, vp, f32, vp],
+        "ha_shard_step": [vp, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, vp],
+        "ha_shard_steps": [vp, i64, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, vp],
         "ha_qapply_steps_sync": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qapply_steps_counts": [vp, i64, i64, f32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "ha_qapply_sync": [vp, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, i64, i64, c.c_uint32, vp, vp, vp],

@@ -882,6 +882,125 @@ __global__ __launch_bounds__(1024) void plan_rank_small_batch_kernel(const PlanB
     rank_tile_body<IdT>(static_cast<const IdT *>(b.ids[i]), n, b.keys[i], b.sorted[i], b.perm[i], blockIdx.x, s_mem);
 }
 
+// The stable sort of a batch of at most kWgSortMax ids by ONE workgroup, everything in LDS: an LSD radix sort whose digit
+// width follows the batch's largest key (26-bit Criteo keys: three passes of 9 bits).  plan_rank_small_batch_kernel ranks by
+// counting -- n^2 / 2 comparisons spread over n / 32 workgroups with 148 KB of LDS each: 42 us of the WHOLE chip for a block of
+// sixteen 6,656-id batches.  That is the right trade on the critical path of one batch (8 us) and the wrong one for plans
+// that are built a block AHEAD on a side stream beside row launches that want every compute unit (the sharded step's routing,
+// the cache's planned flow): sixteen workgroups for ~25 us leave the other 240 compute units alone.  Same output (keys,
+// sorted keys, perm: positions ascending inside equal keys).
+//   per pass: wave w counts the digits of ITS contiguous chunk (LDS atomics), one scan over (digit, wave) gives every
+//   (wave, digit) its first output position, wave w walks its chunk again 64 elements at a time -- a lane's rank among the
+//   lanes of its group with the same digit from dbits ballots -- and scatters.
+constexpr int kWgSortMax = 8192;
+constexpr int kWgSortDigitBits = 9;
+constexpr size_t kWgSortLds = static_cast<size_t>(kWgSortMax) * (4 + 4 + 2 + 2) + 16 * (1 << kWgSortDigitBits) * 4;
+template <typename IdT>
+__global__ __launch_bounds__(1024) void plan_sort_wg_batch_kernel(const PlanBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    __shared__ uint32_t s_x[16];
+    const int i = blockIdx.x, n = b.n[i];
+    if (n == 0)
+        return;
+    uint32_t *kA = s_mem, *kB = kA + kWgSortMax;
+    uint16_t *iA = reinterpret_cast<uint16_t *>(kB + kWgSortMax), *iB = iA + kWgSortMax;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(iB + kWgSortMax);      // [16 waves][D digits]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const IdT *ids = static_cast<const IdT *>(b.ids[i]);
+    uint32_t mx = 0;
+    for (int j = tid; j < n; j += 1024) {
+        const uint32_t k = to_key<IdT>(ids[j]);
+        b.keys[i][j] = k;
+        kA[j] = k;
+        iA[j] = static_cast<uint16_t>(j);
+        mx = max(mx, k);
+    }
+    for (int o = 32; o >= 1; o >>= 1)
+        mx = max(mx, static_cast<uint32_t>(__shfl_xor(static_cast<int>(mx), o, 64)));
+    if (lane == 0)
+        s_x[w] = mx;
+    __syncthreads();
+    mx = 0;
+    for (int k = 0; k < 16; ++k)
+        mx = max(mx, s_x[k]);
+    const int bits = 32 - __builtin_clz(mx | 1u);
+    const int passes = (bits + kWgSortDigitBits - 1) / kWgSortDigitBits;
+    const int dbits = max((bits + passes - 1) / passes, 6), D = 1 << dbits;      // (>= 64 digits: the scan below gives every thread a share)
+    const int chunk = (((n + 15) / 16) + 63) & ~63;                       // elements per wave, whole groups of 64
+    const int c0 = min(w * chunk, n), c1 = min(c0 + chunk, n);
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * dbits;
+        for (int c = tid; c < 16 * D; c += 1024)
+            cnt[c] = 0;
+        __syncthreads();
+        for (int j = c0 + lane; j < c1; j += 64)
+            atomicAdd(&cnt[w * D + ((kA[j] >> shift) & (D - 1))], 1u);
+        __syncthreads();
+        // exclusive scan in (digit, wave) order: element e = d * 16 + wave; thread t owns e = t * E .. t * E + E - 1
+        const int E = 16 * D / 1024;       // 1, 2, 4 or 8 counters per thread
+        uint32_t v[8], sum = 0;
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid * E + q;
+            v[q] = (q < E) ? cnt[(e & 15) * D + (e >> 4)] : 0u;
+            sum += v[q];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += y;
+        }
+        if (lane == 63)
+            s_x[w] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int k = 0; k < w; ++k)
+            base += s_x[k];
+        uint32_t run = base + incl - sum;
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid * E + q;
+            if (q < E)
+                cnt[(e & 15) * D + (e >> 4)] = run;
+            run += v[q];
+        }
+        __syncthreads();
+        // stable scatter: the wave walks its chunk in order
+        for (int j0 = c0; j0 < c1; j0 += 64) {
+            const int j = j0 + lane;
+            const bool valid = j < c1;
+            const uint32_t k = valid ? kA[j] : 0u;
+            const uint32_t idx = valid ? iA[j] : 0u;
+            const uint32_t d = (k >> shift) & (D - 1);
+            unsigned long long mask = __ballot(valid);
+            for (int bit = 0; bit < dbits; ++bit) {
+                const unsigned long long m = __ballot(valid && ((d >> bit) & 1u));
+                mask &= ((d >> bit) & 1u) ? m : ~m;
+            }
+            const uint32_t rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            const uint32_t group = __builtin_popcountll(mask);
+            if (valid) {
+                const uint32_t at = cnt[w * D + d];
+                kB[at + rank] = k;
+                iB[at + rank] = static_cast<uint16_t>(idx);
+                if (rank + 1u == group)
+                    cnt[w * D + d] = at + group;
+            }
+        }
+        __syncthreads();
+        uint32_t *tk = kA;
+        kA = kB;
+        kB = tk;
+        uint16_t *ti = iA;
+        iA = iB;
+        iB = ti;
+    }
+    for (int j = tid; j < n; j += 1024) {
+        b.sorted[i][j] = kA[j];
+        b.perm[i][j] = static_cast<int32_t>(iA[j]);
+    }
+}
+
 __global__ __launch_bounds__(1024) void finish_small_batch_kernel(const PlanBatch b) {
     __shared__ uint32_t s_w[kFinishLdsWords];
     const int i = blockIdx.y, n = b.n[i];
@@ -927,7 +1046,11 @@ static int plan_build_batch(const IdT *const *ids, const int64_t *n, void *const
             b.inverse[i] = p.inverse; b.counts[i] = p.counts; b.seg[i] = p.seg; b.upos[i] = p.upos;
             nmax = ni > nmax ? ni : nmax;
         }
-        if (nmax > 0) {
+        static const bool wg_sort = !(getenv("HA_PLAN_WG_SORT") && atoi(getenv("HA_PLAN_WG_SORT")) == 0);
+        if (nmax > 0 && nmax <= kWgSortMax && wg_sort) {      // plans built ahead, beside other launches: a workgroup per batch
+            HA_ALLOW_LDS(plan_sort_wg_batch_kernel<IdT>, kWgSortLds);
+            hipLaunchKernelGGL(plan_sort_wg_batch_kernel<IdT>, dim3(m), dim3(1024), kWgSortLds, stream, b);
+        } else if (nmax > 0) {
             const size_t lds = rank_small_lds_bytes(nmax);
             HA_ALLOW_LDS(plan_rank_small_batch_kernel<IdT>, lds);
             hipLaunchKernelGGL(plan_rank_small_batch_kernel<IdT>, dim3((nmax + kRankTile - 1) / kRankTile, m), dim3(1024),

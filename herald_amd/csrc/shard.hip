@@ -1343,3 +1343,93 @@ extern "C" int ha_store_add_versions(int64_t *server_versions, int64_t rows, con
     HA_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- the sharded step as ONE native call ------------------------------------------------------------------------------------
+// What PSAgent::vecPullSparse / vecPushSparse do inside one C++ call each (ps-lite/include/ps/worker/PSAgent.h:124-237: dedup,
+// route, send, wait, scatter): the step's launches and its two row exchanges enqueued on the caller's stream by the library,
+// from the per-owner counts the routing left in pinned host memory a block ago -- no Python between them.
+//   pull half  owner gather of the rows the other ranks name (ha_shard_sized_serve_pull) -> rows exchange (ha_xchg_rows) ->
+//              positions from the own shard / the received rows (ha_gather2_u32map);
+//   push half  occurrence-ordered reduce of scale * values by unique key into the push buffer (ha_apply_mapped) -> rows
+//              exchange -> merge of the W lists in rank order + apply (ha_shard_sized_serve_push);
+//   world 1    the lookup + ONE reduce-and-add launch (ha_push_apply_scaled_finished); xchg may be NULL.
+// ha_shard_step = both halves for a caller that holds the batch's gradients when it asks for its rows (a benchmark loop, a
+// pipeline with staleness); ha_shard_steps = `count` such steps by one call.  slot->counts_host: the pinned words of the
+// batch's routing ([2 + g] = unique keys this rank names at owner g, [2 + world + g] = unique keys rank g names here; the
+// routing block's event must have completed: the caller waited for it when it checked the overflow word [0]).
+extern "C" int ha_shard_step_pull(const float *table, int64_t rows, int64_t width, const ha_shard_slot *slot, void *xchg,
+                                  float *pull_send, float *pull_recv, int64_t pull_rows, float *out, ha_stream_t stream) {
+    HA_REQUIRE(table && slot && slot->world >= 1 && slot->world <= 1024 && slot->rank >= 0 && slot->rank < slot->world,
+               "ha_shard_step_pull: bad arguments");
+    const int w = slot->world, r = slot->rank;
+    if (w > 1) {
+        HA_REQUIRE(xchg && slot->counts_host && pull_send && pull_recv, "ha_shard_step_pull: world > 1 needs the exchange, the "
+                   "counts and the row buffers");
+        int64_t ins[1024], outs[1024];
+        for (int g = 0; g < w; ++g) {
+            ins[g] = g == r ? 0 : slot->counts_host[2 + w + g];       // rows this rank serves to peer g
+            outs[g] = g == r ? 0 : slot->counts_host[2 + g];          // rows owner g sends back
+        }
+        if (ha_shard_sized_serve_pull(table, rows, width, slot->keys_fixed, w, r, slot->rcap, slot->meta_dev, pull_send, stream))
+            return -1;
+        if (ha_xchg_rows(xchg, pull_send, ins, pull_recv, outs, width, stream))
+            return -1;
+    }
+    if (slot->n > 0) {
+        HA_REQUIRE(out && slot->posmap, "ha_shard_step_pull: null output");
+        if (ha_gather2_u32map(table, rows, pull_recv, pull_rows, width, slot->posmap, slot->n, out, stream))
+            return -1;
+    }
+    return 0;
+}
+
+extern "C" int ha_shard_step_push(float *table, int64_t rows, int64_t width, const ha_shard_slot *slot, void *xchg,
+                                  float *push_buf, int64_t push_rows, const uint8_t *zero_flags, const float *values,
+                                  float scale, ha_stream_t stream) {
+    HA_REQUIRE(table && slot && slot->world >= 1 && slot->world <= 1024 && slot->rank >= 0 && slot->rank < slot->world,
+               "ha_shard_step_push: bad arguments");
+    const int w = slot->world, r = slot->rank;
+    if (w == 1) {      // nobody else pushes: reduce + server add of the own keys in one launch
+        if (slot->n > 0)
+            return ha_push_apply_scaled_finished(table, rows, width, slot->plan_ws, slot->n, values, scale, stream);
+        return 0;
+    }
+    HA_REQUIRE(xchg && slot->counts_host && push_buf && zero_flags && slot->owner_plan_ws,
+               "ha_shard_step_push: world > 1 needs the exchange, the counts, the push buffer and the owner's plan workspace");
+    int64_t ins[1024], outs[1024], total = 0, n_in = 0;
+    for (int g = 0; g < w; ++g) {
+        ins[g] = g == r ? 0 : slot->counts_host[2 + g];               // reduced rows for owner g
+        outs[g] = g == r ? 0 : slot->counts_host[2 + w + g];          // rows peer g pushes to this rank
+        total += slot->counts_host[2 + w + g];
+        n_in += ins[g];
+    }
+    (void)n_in;
+    if (slot->n > 0 &&
+        ha_apply_mapped(push_buf, push_rows, width, slot->plan_ws, slot->n, values, -scale, slot->rowmap, nullptr, zero_flags, stream))
+        return -1;
+    float *recv = push_buf + static_cast<int64_t>(w + 1) * slot->rcap * width;      // region B: rows received
+    if (ha_xchg_rows(xchg, push_buf, ins, recv, outs, width, stream))
+        return -1;
+    return ha_shard_sized_serve_push(table, rows, width, slot->keys_fixed, w, r, slot->rcap, slot->meta_dev, total, push_buf,
+                                     slot->owner_plan_ws, stream);
+}
+
+extern "C" int ha_shard_step(float *table, int64_t rows, int64_t width, const ha_shard_slot *slot, void *xchg, float *pull_send,
+                             float *pull_recv, int64_t pull_rows, float *push_buf, int64_t push_rows, const uint8_t *zero_flags,
+                             float *out, const float *values, float scale, ha_stream_t stream) {
+    if (ha_shard_step_pull(table, rows, width, slot, xchg, pull_send, pull_recv, pull_rows, out, stream))
+        return -1;
+    return ha_shard_step_push(table, rows, width, slot, xchg, push_buf, push_rows, zero_flags, values, scale, stream);
+}
+
+extern "C" int ha_shard_steps(float *table, int64_t rows, int64_t width, int64_t count, const ha_shard_slot *const *slots,
+                              void *xchg, float *pull_send, float *pull_recv, int64_t pull_rows, float *push_buf,
+                              int64_t push_rows, const uint8_t *zero_flags, float *const *outs, const float *const *values,
+                              float scale, ha_stream_t stream) {
+    HA_REQUIRE(count >= 0 && (count == 0 || (slots && outs && values)), "ha_shard_steps: null pointer");
+    for (int64_t k = 0; k < count; ++k)
+        if (ha_shard_step(table, rows, width, slots[k], xchg, pull_send, pull_recv, pull_rows, push_buf, push_rows, zero_flags,
+                          outs[k], values[k], scale, stream))
+            return -1;
+    return 0;
+}

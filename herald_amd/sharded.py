@@ -79,10 +79,32 @@ class HipEngine:
         self.device = torch.device(device)
         self._devidx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.side = torch.cuda.Stream(device=self.device)
+        self._side_normal, self._side_high = self.side, None
         self._slots = {}
         self._owner_plan = None
         self._bufs = {}
         self._sort_streams = []
+
+    def use_side_priority(self, high):
+        """The routing stream at ANOTHER priority than the step's stream (high=True), or at the same.  HIP multiplexes the
+        streams of one priority onto a few hardware queues, and two streams that share a queue run in submission order: the
+        routing of block b + 1 then sits BETWEEN the steps of two blocks instead of beside them (kernel trace of bench.py's
+        sharded leg at world size 1: every launch on one queue; docs/EXPERIMENTS.md round 6).  Worth it where the routing is
+        LIGHT -- batches of at most 8,192 ids, whose plans are a workgroup each (csrc/plan.hip plan_sort_wg_batch_kernel):
+        20.3 -> 18.5 us per step at configs[1]'s shape.  Chip-wide routing launches (the radix sorts and the pack / unpack of
+        106,496-id batches) at the higher priority push the steps aside: 74 -> 102 us at configs[2]'s shape."""
+        import os
+        if os.environ.get("HA_SHARD_SIDE_PRIO") in ("high", "normal"):
+            high = os.environ["HA_SHARD_SIDE_PRIO"] == "high"
+        if high and self._side_high is None:
+            try:
+                self._side_high = torch.cuda.Stream(device=self.device, priority=min(torch.cuda.Stream.priority_range()))
+            except Exception:      # noqa: BLE001
+                self._side_high = self._side_normal
+        new = self._side_high if high else self._side_normal
+        if new is not self.side:
+            new.wait_stream(self.side)        # whatever the other one still holds comes first
+            self.side = new
 
     def _buf(self, name, rows, width):
         """Grow-only scratch rows that never leave the store (exchange staging)."""
@@ -915,6 +937,8 @@ class FramedStep:
             self.push_recv = self.eng.empty_rows(m, emb.width)
             self.zero_flags = self.eng.zeros((m,), torch.uint8)
         self.side = w == 1 or emb.side_group is not None
+        if hasattr(self.eng, "use_side_priority"):
+            self.eng.use_side_priority(self.max_ids <= 8192)
         self._graphs = {}
         self._calls = {}
         self._fast_ok = hasattr(self.eng, "frames_serve_pull_call")
@@ -1176,7 +1200,7 @@ class FramedStep:
             blk.synced = True
         return self.eng.frames_overflowed(fb)
 
-    def pull(self, ahead_ids=None, out=None):
+    def pull(self, ahead_ids=None, out=None, _block_started=False):
         """Rows of the current batch k; `ahead_ids` = batch k + LOOKAHEAD (None once the stream has ended)."""
         if self.k is None:
             raise RuntimeError("FramedStep.pull before start")
@@ -1186,7 +1210,7 @@ class FramedStep:
         blk, fb = self._slot_of[k % self._ring]
         if not fb.routed:
             raise RuntimeError("FramedStep.pull: the stream of batches has ended")
-        if k % self.block == 0:
+        if k % self.block == 0 and not _block_started:
             self._block_start(k // self.block)
         self._stage(k + self.LOOKAHEAD, ahead_ids)
         if not blk.synced:          # the pinned words of the block's routing (enqueued a block ago)
@@ -1239,6 +1263,111 @@ class FramedStep:
                           lambda: self._push(k, v, scale))
         self._pending = False
         self.k = k + 1
+
+    # -- the step as ONE native call (ha_shard_step / ha_shard_steps, csrc/shard.hip) ---------------------------------------
+    def native_ok(self):
+        """Can a step be handed to the library as one call?  Sized exchanges, the HIP engine, and either nobody to exchange
+        with (world size 1) or the library's own RCCL exchange (sharded.NativeExchange)."""
+        return bool(self.sized and self._fast_ok and not self.graphs and hasattr(self.eng.lib, "ha_shard_steps") and
+                    (self.emb.world == 1 or getattr(self.emb, "native", None) is not None))
+
+    def _slot_desc(self, j):
+        """ha_shard_slot of ring slot j % ring (its buffers never move; n follows the batch that sits in it)."""
+        from . import _lib
+        i = j % self._ring
+        blk, fb = self._slot_of[i]
+        if not hasattr(self, "_descs"):
+            self._descs = {}
+        d = self._descs.get(i)
+        if d is None:
+            emb = self.emb
+            d = _lib.ShardSlot()
+            d.world, d.rank, d.rcap = emb.world, emb.rank, self.rcap
+            d.plan_ws = fb.plan.ws.data_ptr()
+            d.keys_fixed, d.meta_dev = fb.keys_fixed.data_ptr(), fb.meta_dev.data_ptr()
+            d.posmap, d.rowmap = fb.posmap.data_ptr(), fb.rowmap.data_ptr()
+            d.counts_host = fb.state_host.data_ptr()
+            if emb.world > 1:
+                p = self.eng._owner_plan
+                m = emb.world * self.rcap
+                if p is None or p.capacity < m:
+                    p = self.eng._owner_plan = self.eng.ops.IndexPlan(m + 16, self.eng.device)
+                d.owner_plan_ws = p.ws.data_ptr()
+            self._descs[i] = d
+        d.n = fb.n
+        return d
+
+    def steps(self, ahead_ids_list, values_list, lr=None, outs=None):
+        """len(values_list) consecutive steps -- pull of the current batch, push of its gradients values_list[i] -- by ONE
+        library call (ha_shard_steps): the reference's worker does a pull or a push inside one C++ call
+        (PSAgent::vecPullSparse / vecPushSparse, PSAgent.h:124-237); here the launches and the row exchanges of a whole run
+        of steps are enqueued without Python in between.  For callers that hold the gradients of a batch when they ask for its
+        rows (a benchmark loop, a pipeline with staleness); the steps must lie in ONE routing block.  ahead_ids_list[i] = batch
+        k + i + LOOKAHEAD (None entries once the stream has ended).  Falls back to pull / push step by step where the native
+        step is not available or a batch of the run overflowed its key frames.  Returns the rows of the batches."""
+        import ctypes
+        if self.k is None:
+            raise RuntimeError("FramedStep.steps before start")
+        if self._pending:
+            raise RuntimeError("FramedStep: push the current batch first")
+        cnt, k0 = len(values_list), self.k
+        ahead_ids_list = list(ahead_ids_list) if ahead_ids_list is not None else [None] * cnt
+        if cnt == 0:
+            return []
+        if k0 // self.block != (k0 + cnt - 1) // self.block:
+            raise ValueError("steps %d..%d cross a routing block boundary (block = %d)" % (k0, k0 + cnt - 1, self.block))
+        eng, emb, width = self.eng, self.emb, self.emb.width
+        fbs = [self._slot_of[(k0 + i) % self._ring][1] for i in range(cnt)]
+        if outs is None:
+            outs = [eng.empty_rows(fb.n, width) if fb.n else None for fb in fbs]
+        native = native_tried = self.native_ok() and all(fb.routed for fb in fbs)
+        if native:
+            if k0 % self.block == 0:
+                self._block_start(k0 // self.block)
+            blk = self._slot_of[k0 % self._ring][0]
+            if not blk.synced:
+                eng.host_sync(blk.ev)
+                blk.synced = True
+            native = not any(eng.frames_overflowed(fb) for fb in fbs)
+        started = native_tried and k0 % self.block == 0       # (the fallback below must not start the block again)
+        if not native:
+            res = []
+            for i in range(cnt):
+                res.append(self.pull(ahead_ids_list[i], out=outs[i], _block_started=started and i == 0))
+                self.push(values_list[i], lr)
+            return res
+        for i in range(cnt):
+            self._stage(k0 + i + self.LOOKAHEAD, ahead_ids_list[i])
+        scale = 1.0 if lr is None else -float(lr)
+        vp = ctypes.c_void_p
+        descs = [self._slot_desc(k0 + i) for i in range(cnt)]
+        vals = []
+        for i, fb in enumerate(fbs):
+            v = values_list[i]
+            if fb.n:
+                v = v if v.dim() == 2 and v.is_contiguous() else v.reshape(-1, width).contiguous()
+            vals.append(v)
+        sl = (ctypes.POINTER(type(descs[0])) * cnt)(*[ctypes.pointer(d) for d in descs])
+        op = (vp * cnt)(*[o.data_ptr() if (o is not None and fb.n) else None for o, fb in zip(outs, fbs)])
+        gp = (vp * cnt)(*[v.data_ptr() if fb.n else None for v, fb in zip(vals, fbs)])
+        xh = vp(emb.native.h) if emb.world > 1 else None
+        rc = eng.lib.ha_shard_steps(vp(emb.table.data_ptr()), emb.table.shape[0], width, cnt, sl, xh,
+                                    vp(self.pull_send.data_ptr()), vp(self.pull_recv.data_ptr()), self.pull_recv.shape[0],
+                                    vp(self.push_buf.data_ptr()), self.push_buf.shape[0], vp(self.zero_flags.data_ptr()), op, gp,
+                                    ctypes.c_float(scale), vp(eng._stream()))
+        if rc != 0:
+            eng.check(-1, "ha_shard_steps")
+        if emb.world > 1:
+            r = emb.rank
+            for fb in fbs:
+                send_cnt, recv_cnt = self._counts(fb)
+                self._account_sized([c if g != r else 0 for g, c in enumerate(recv_cnt)],
+                                    [c if g != r else 0 for g, c in enumerate(send_cnt)], send_cnt, recv_cnt)
+                self._account_sized([c if g != r else 0 for g, c in enumerate(send_cnt)],
+                                    [c if g != r else 0 for g, c in enumerate(recv_cnt)], send_cnt, recv_cnt, pull=False)
+        self.k = k0 + cnt
+        self._keep = (vals, outs)        # (the launches read them: alive until the next call)
+        return [None if not fb.n else (o if o.shape == fb.out_shape else o.reshape(fb.out_shape)) for o, fb in zip(outs, fbs)]
 
     # -- measurement aid (bench.py's N>1 leg): the five launches of a step one by one -----------------------------------
     def kernel_times(self, values, lr, reps=30):

@@ -34,12 +34,23 @@ def _world1_same_path(args, rank, dev, emb, ids_dev, grads, n, lr, steps=300, wa
     nb, LA = len(local), fs.LOOKAHEAD
     outs = [torch.empty((n, emb.width), dtype=torch.float32, device=dev) for _ in range(2)]
     fs.start([local[j % nb] for j in range(LA)])
-    for k in range(warmup + steps):
+    native = fs.native_ok() and __import__("os").environ.get("HA_SHARD_NATIVE", "1") != "0"
+    B = fs.block
+    warmup -= warmup % B
+    k = 0
+    while k < warmup + steps:
         if k == warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        fs.pull(local[(k + LA) % nb], out=outs[k % 2])
-        fs.push(grads[k % 2], lr)
+        if native:          # a routing block's steps by one library call (ha_shard_steps)
+            cnt = min(B - k % B, warmup + steps - k, (warmup - k) if k < warmup else 1 << 30)
+            fs.steps([local[(k + i + LA) % nb] for i in range(cnt)], [grads[(k + i) % 2] for i in range(cnt)], lr,
+                     outs=[outs[(k + i) % 2] for i in range(cnt)])
+            k += cnt
+        else:
+            fs.pull(local[(k + LA) % nb], out=outs[k % 2])
+            fs.push(grads[k % 2], lr)
+            k += 1
     torch.cuda.synchronize()
     return 1e3 * (time.perf_counter() - t0) / steps
 
@@ -106,6 +117,23 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
             out = fs.pull(ids_rows[(k + LA) % nb], out=outs[k % 2])    # forward lookup; batch k + LA enters the routing
             fs.push(grads[k % 2], lr)                                 # backward: reduce, exchange, rank-ordered apply
             return out
+
+        # ONE native call per run of steps inside a routing block (ha_shard_steps, csrc/shard.hip: the launches and the two row
+        # exchanges of every step enqueued by the library from the pinned counts -- no Python between them; PSAgent.h:124-237
+        # does a pull / a push inside one C++ call as well).  Needs the library's own exchange at world > 1.
+        native_steps = fs.native_ok() and os.environ.get("HA_SHARD_NATIVE", "1") != "0"
+
+        def run_steps(k0, count):
+            k, end = k0, k0 + count
+            while k < end:
+                if native_steps:
+                    cnt = min(fs.block - k % fs.block, end - k)
+                    fs.steps([ids_rows[(k + i + LA) % nb] for i in range(cnt)], [grads[(k + i) % 2] for i in range(cnt)], lr,
+                             outs=[outs[(k + i) % 2] for i in range(cnt)])
+                    k += cnt
+                else:
+                    step(k)
+                    k += 1
     else:
         # Sized exchanges: the routing of batch k+1 (plan, counts and keys exchange, the one host read-back) is
         # prefetched while the rows of batch k are pulled and pushed: its ids are resident one step ahead (the
@@ -121,15 +149,19 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
             state["route"] = nxt
             return out
 
-    for k in range(warmup):
-        step(k)
+        native_steps = False
+
+        def run_steps(k0, count):
+            for k in range(k0, k0 + count):
+                step(k)
+
+    run_steps(0, warmup)
     torch.cuda.synchronize()
     dist.barrier()
     emb.stats = {"xgmi_bytes_out": 0, "xgmi_bytes_in": 0}
     fb0 = fs.fallbacks if fs is not None else 0
     t0 = time.perf_counter()
-    for k in range(steps):
-        step(warmup + k)
+    run_steps(warmup, steps)
     torch.cuda.synchronize()
     dist.barrier()
     el = time.perf_counter() - t0
@@ -189,6 +221,8 @@ def _measure(args, rank, world, dev, batch, width, steps, warmup, per_kernel):
                       "timed steps took the sized exchange" % (fs.rcap, fs.block, "hipGraph replay" if fs.graphs else
                                                                "plain launches, no host read-back", fs.fallbacks - fb0, steps)))
                     if framed else "sized per step (host read-back of the counts)",
+        "step_calls": ("one library call per run of steps inside a routing block (ha_shard_steps)" if native_steps else
+                       "two Python calls per step (pull, push)"),
         "collectives": ("RCCL send / recv groups issued by the library on the step's stream (ha_xchg_*, checked against "
                         "torch.distributed's all-to-all at start-up)" if getattr(emb, "native", None) is not None else
                         "torch.distributed.all_to_all_single" if dist.get_world_size() > 1 else "none (world size 1)"),
@@ -261,7 +295,7 @@ def run(args, rank, world, dev, cpu_baseline_fn=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": main["workload"], "ids_per_step_per_gpu": main["n"],
                        "parallelism": "row-sharded x%d" % world, "exchange": main["exchange"],
-                       "collectives": main["collectives"],
+                       "collectives": main["collectives"], "step_calls": main["step_calls"],
                        "sparse_update": main["sparse_update"]},
             "xgmi": main["xgmi"], "ranks_seen": dist.get_world_size(), "roofline": main["roofline"],
             # the N>1 engine at world size 1 on one shard (ms per step; null at N = 1, where this line IS that number):

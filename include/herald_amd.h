@@ -809,6 +809,41 @@ int ha_shard_sized_serve_push(float *table, int64_t rows, int64_t width, const u
 int ha_push_apply_scaled_finished(float *table, int64_t rows, int64_t width, void *plan_ws, int64_t n, const float *grads,
                                   float scale, ha_stream_t stream);
 
+/* The sharded step as ONE native call: what PSAgent::vecPullSparse / vecPushSparse do inside one C++ call each
+ * (ps-lite/include/ps/worker/PSAgent.h:124-237) -- the step's launches and its two row exchanges enqueued on the caller's
+ * stream by the library, sized from the per-owner counts the routing left in pinned host memory a block ago.
+ * ha_shard_slot describes one routed batch (herald_amd/sharded.py fills it once per routing slot):
+ *   counts_host[2 + g] = unique keys this rank names at owner g, [2 + world + g] = unique keys rank g names here (pinned; the
+ *   routing block's event has completed -- the caller looked at the overflow word [0] behind it);
+ *   keys_fixed / meta_dev / posmap / rowmap: as ha_shard_frames_*_sized left them; plan_ws: the batch's index plan;
+ *   owner_plan_ws: ha_plan_bytes(world * rcap + 16) of scratch for the owner-side merge (world > 1).
+ * _pull: owner gather -> rows exchange (ha_xchg_rows on `xchg`) -> positions from the own shard / the received rows into out;
+ * _push: reduce of scale * values by unique key -> rows exchange -> rank-ordered merge + apply; world 1: the lookup and one
+ * reduce-and-add launch, xchg may be NULL.  ha_shard_step = both; ha_shard_steps = `count` steps (slots / outs / values per
+ * step).  pull_send / pull_recv: [pull_rows = world * rcap, width]; push_buf: [push_rows = (2 world + 1) rcap, width] (rows
+ * for the other owners | own keys | rows received); zero_flags: push_rows zero bytes. */
+typedef struct ha_shard_slot {
+    int32_t world, rank;
+    int64_t rcap, n;
+    void *plan_ws;
+    const uint32_t *keys_fixed;
+    const int32_t *meta_dev;
+    const uint32_t *posmap;
+    const int32_t *rowmap;
+    const int32_t *counts_host;
+    void *owner_plan_ws;
+} ha_shard_slot;
+int ha_shard_step_pull(const float *table, int64_t rows, int64_t width, const ha_shard_slot *slot, void *xchg, float *pull_send,
+                       float *pull_recv, int64_t pull_rows, float *out, ha_stream_t stream);
+int ha_shard_step_push(float *table, int64_t rows, int64_t width, const ha_shard_slot *slot, void *xchg, float *push_buf,
+                       int64_t push_rows, const uint8_t *zero_flags, const float *values, float scale, ha_stream_t stream);
+int ha_shard_step(float *table, int64_t rows, int64_t width, const ha_shard_slot *slot, void *xchg, float *pull_send,
+                  float *pull_recv, int64_t pull_rows, float *push_buf, int64_t push_rows, const uint8_t *zero_flags, float *out,
+                  const float *values, float scale, ha_stream_t stream);
+int ha_shard_steps(float *table, int64_t rows, int64_t width, int64_t count, const ha_shard_slot *const *slots, void *xchg,
+                   float *pull_send, float *pull_recv, int64_t pull_rows, float *push_buf, int64_t push_rows,
+                   const uint8_t *zero_flags, float *const *outs, const float *const *values, float scale, ha_stream_t stream);
+
 /* Owner side of a sparse push (PSHandler::serve(SparsePush), ps-lite/include/ps/server/PSFHandle.h:130-164):
  * table[keys[j],:] = (table[keys[j],:] + values[a,:]) + values[b,:] ... over the positions a < b < ... that
  * list the key, i.e. in list order (the W received sorted lists concatenated in rank order).

@@ -187,3 +187,54 @@ def _worker(rank, world, port, rows, width, n, kind, row_cap, expect_fallback, s
 def test_framed_step_at_world_size_gt_1_on_one_gpu(dev, world, rows, width, n, kind, row_cap, expect_fallback, sized):
     mp.spawn(_worker, args=(world, _free_port(), rows, width, n, kind, row_cap, expect_fallback, sized), nprocs=world,
              join=True)
+
+
+@pytest.mark.parametrize("rows,width,n,kind,block,run", [(50000, 128, 6656, "criteo", 4, 4), (3000, 64, 900, "mixed", 8, 3),
+                                                         (200, 32, 40, "mixed", 2, 2)])
+def test_framed_step_runs_of_steps_by_one_native_call(dev, rows, width, n, kind, block, run):
+    """FramedStep.steps: a run of steps (pull of a batch + push of its gradients) enqueued by ONE library call
+    (ha_shard_steps, csrc/shard.hip) -- every pulled row and the table equal the oracle's serial PS semantics
+    (oracle/cpu.py sparse_pull / sparse_push: PSAgent.h:124-237, PSFHandle.h:101-164), as for pull / push step by step; the
+    runs end where the stream does, and the last steps go step by step again."""
+    from herald_amd.sharded import FramedStep, ShardedEmbedding
+    nb = 6 * block + 3
+    ids = _stream(rows, n, nb, kind, seed=3)
+    n = ids[0].size
+    rng = np.random.default_rng(15)
+    table = rng.standard_normal((rows, width), dtype=np.float32)
+    emb = ShardedEmbedding(rows, width, dev, table=torch.from_numpy(table.copy()).to(dev))
+    fs = FramedStep(emb, n, graphs=False, block=block)
+    assert fs.sized and fs.native_ok()
+    LA = fs.LOOKAHEAD
+    d_ids = [torch.from_numpy(x).to(dev) for x in ids]
+    grads = [rng.standard_normal((n, width), dtype=np.float32) for _ in range(nb)]
+    d_grads = [torch.from_numpy(g).to(dev) for g in grads]
+    want = table.copy()
+    fs.start(d_ids[:LA])
+    k = 0
+    lr = 0.05
+    while k < nb:
+        cnt = min(run, nb - k, block - k % block)
+        if k >= nb - 3:              # the tail of the stream: step by step
+            out = fs.pull(d_ids[k + LA] if k + LA < nb else None)
+            got = [out]
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(got[0].cpu().numpy().reshape(-1, width), want[ids[k].astype(np.int64)])
+            fs.push(d_grads[k], lr)
+            cpu.sparse_push(want, ids[k], grads[k], lr)
+            k += 1
+            continue
+        outs = [torch.empty((n, width), device=dev) for _ in range(cnt)]
+        got = fs.steps([d_ids[k + i + LA] if k + i + LA < nb else None for i in range(cnt)], d_grads[k:k + cnt], lr, outs=outs)
+        torch.cuda.synchronize()
+        for i in range(cnt):
+            np.testing.assert_array_equal(got[i].cpu().numpy().reshape(-1, width), want[ids[k + i].astype(np.int64)],
+                                          err_msg="rows of batch %d" % (k + i))
+            cpu.sparse_push(want, ids[k + i], grads[k + i], lr)
+        k += cnt
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(emb.table.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        fs2 = FramedStep(emb, n, graphs=False, block=2)
+        fs2.start(d_ids[:fs2.LOOKAHEAD])
+        fs2.steps([None] * 3, d_grads[:3], lr)       # three steps from step 0 cross the boundary of blocks of 2

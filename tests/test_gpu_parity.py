@@ -746,3 +746,50 @@ def test_sort_ahead_schedule_equals_the_single_stream_sequence(dev, n, width):
         assert plan.n_unique() == uniq.size
         np.testing.assert_array_equal(plan.inverse().cpu().numpy().astype(np.int64), inv)
     np.testing.assert_array_equal(t.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("kind", ["f32", "u64"])
+def test_batched_plans_by_the_one_workgroup_radix_sort(dev, kind):
+    """ha_plan_build_batch_*_lim for batches of at most 8,192 ids: every batch is sorted by ONE workgroup (an LSD radix sort in
+    LDS, csrc/plan.hip plan_sort_wg_batch_kernel) -- sorted keys, perm (positions ascending inside equal keys: np.argsort
+    stable), unique keys, counts and inverse equal numpy's, for sizes around the group / chunk edges, key ranges from 5 bits to
+    the pad value, and heavy duplication."""
+    import ctypes
+    from herald_amd import _lib, ops
+    L = _lib.load()
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 63, 64, 65, 1023, 1024, 1025, 4097, 6656, 8191, 8192]
+    cases = []
+    for n in sizes:
+        for hi in (17, 300, 33_762_577, (1 << 32) - 3):
+            k = rng.integers(0, hi, size=n, dtype=np.uint64)
+            if n > 8:
+                k[: n // 4] = k[0]                      # a long run
+                k[n // 3] = min(hi - 1, 0xFFFFFFFE)
+            cases.append(k)
+    for c0 in range(0, len(cases), 16):
+        grp = cases[c0:c0 + 16]
+        if kind == "f32":
+            grp = [np.minimum(k, (1 << 24) - 1) for k in grp]          # float32 ids are exact below 2^24
+            tens = [torch.from_numpy(k.astype(np.float32)).to(dev) for k in grp]
+            fn = L.ha_plan_build_batch_f32ids_lim
+        else:
+            tens = [torch.from_numpy(k.astype(np.int64)).to(dev) for k in grp]
+            fn = L.ha_plan_build_batch_u64ids_lim
+        plans = [ops.IndexPlan(max(k.size, 1), dev) for k in grp]
+        cnt = len(grp)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        _lib.check(fn((vp * cnt)(*[t.data_ptr() for t in tens]), (i64 * cnt)(*[k.size for k in grp]),
+                      (vp * cnt)(*[p.ws.data_ptr() for p in plans]), cnt, ctypes.c_uint64(33_762_577), None), "plan_build_batch")
+        torch.cuda.synchronize()
+        for k, p in zip(grp, plans):
+            p.n, p._view = k.size, None
+            keys = np.minimum(k, 0xFFFFFFFE).astype(np.int64)
+            order = np.argsort(keys, kind="stable")
+            np.testing.assert_array_equal(p.perm().cpu().numpy().astype(np.int64), order)
+            np.testing.assert_array_equal(p.sorted_keys().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys[order])
+            u, inv, cn = np.unique(keys, return_inverse=True, return_counts=True)
+            assert p.n_unique() == u.size
+            np.testing.assert_array_equal(p.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, u)
+            np.testing.assert_array_equal(p.counts().cpu().numpy().astype(np.int64)[:u.size], cn)
+            np.testing.assert_array_equal(p.inverse().cpu().numpy().astype(np.int64), inv)
