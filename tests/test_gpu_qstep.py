@@ -534,13 +534,16 @@ def test_a_step_whose_queue_was_never_built_raises_and_applies_nothing(dev):
     assert pipe.overflowed()
 
 
-def test_a_step_whose_builder_is_late_applies_nothing_and_raises(dev):
+def test_a_step_whose_builder_is_late_applies_nothing_and_raises(dev, monkeypatch):
     """sync="flags", the builder DELAYED past the apply's bound (a 3.5 s occupant kernel in front of it on the preparation
     stream): workgroup 0 of the apply polls for 2 s, publishes "gave up" in the queue, every other workgroup follows that word
     -- the table and the output are exactly what they were, the error word is raised, and the builder completing afterwards
     does not revive the step (one decision per launch: QHeader::verdict, csrc/qstep.hip)."""
     import ctypes
     from herald_amd import _lib
+    # (the preparation stream at another priority than the step's: in a process that has created many streams two streams of one
+    # priority may share a hardware queue, and the apply would then simply run BEHIND the occupant and the builder)
+    monkeypatch.setenv("HA_QSIDE_PRIO", "high")
     rows, width, bs = 50_000, 64, 32
     rng = np.random.default_rng(9)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
