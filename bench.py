@@ -255,13 +255,20 @@ def cache_tier(args, table, ids_dev, out, grad, dev):
     reference (lfu_cache.cc, lfuopt_cache.cc) are timed the same way beside it (`lfu`, `lfuopt`)."""
     res = _cache_tier_policy(args, table, ids_dev, out, grad, dev, "LRU")
     if not args.no_cache_prefill and os.environ.get("HA_CACHE_BENCH_OTHER_POLICIES", "1") == "1":
-        for pol in ("LFU", "LFUOpt"):
+        for pol in os.environ.get("HA_CACHE_BENCH_POLICIES", "LFU,LFUOpt").split(","):
             try:
                 r = _cache_tier_policy(args, table, ids_dev, out, grad, dev, pol)
-                res[pol.lower()] = {k: r[k] for k in ("us_per_step", "value", "unique_miss_rate", "evicted_lines_per_step", "cache_full")}
+                res[pol.lower()] = {k: r[k] for k in ("us_per_step", "value", "flow", "unique_miss_rate", "evicted_lines_per_step",
+                                                      "cache_full")}
+                res[pol.lower()]["call_by_call_us_per_step"] = r["call_by_call"]["us_per_step"]
+                if r.get("planned"):
+                    res[pol.lower()]["enqueue_us_per_step"] = r["planned"]["enqueue_us_per_step"]
             except Exception as e:      # a secondary figure never takes the line down
                 res[pol.lower()] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
+
+
+_CACHE_ROW_STREAM = None
 
 
 def _cache_tier_policy(args, table, ids_dev, out, grad, dev, policy):
@@ -299,7 +306,12 @@ def _cache_tier_policy(args, table, ids_dev, out, grad, dev, policy):
     # the ten launches of a lookup + update pair are replayed from hipGraphs of 16 pairs (the calls enqueue
     # kernels only, nothing is read back while the counters are off)
     GS = 16
-    side = torch.cuda.Stream(device=dev)
+    # (ONE row stream for the three policies' measurements: a stream created later may share a hardware queue with other
+    # streams of the process -- the third policy's row launches then took 3x as long, profiles/r06/cache_tier_third_instance.txt)
+    global _CACHE_ROW_STREAM
+    if _CACHE_ROW_STREAM is None:
+        _CACHE_ROW_STREAM = torch.cuda.Stream(device=dev)
+    side = _CACHE_ROW_STREAM
     c.cache.stream = side
     for k in range(64):
         if use_block and k % GS == 0:
@@ -326,13 +338,13 @@ def _cache_tier_policy(args, table, ids_dev, out, grad, dev, policy):
             graphs[(4 + i) % len(graphs)].replay()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-    # THE figure for LRU: the planned flow (csrc/cache_block.hip).  The ids of a block of 16 batches are known at its start (as
+    # THE figure (all three policies): the planned flow (csrc/cache_block.hip).  The ids of a block of 16 batches are known at its start (as
     # for the headline's work-queue step): the bookkeeping of block b + 1 -- hits, misses, slots, evictions, update counters, the
     # bounded push -- runs on a side stream beside the rows of block b; every lookup and every update is ONE launch.  Plain
     # launches, a block's 16 pairs enqueued by one library call; same cache, same steady state, continuing where the
     # call-by-call measurement above stopped.
     planned = None
-    if policy == "LRU" and os.environ.get("HA_CACHE_BENCH_PLANNED", "1") == "1":
+    if os.environ.get("HA_CACHE_BENCH_PLANNED", "1") == "1":
         blocks = [[ids_dev[j % nb] for j in range(g0, g0 + GS)] for g0 in range(0, nb, GS)]
         outs16, grads16 = [out] * GS, [grad] * GS
         import gc

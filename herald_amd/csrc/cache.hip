@@ -2178,6 +2178,7 @@ static int cache_lookup_impl(ha_cache *h, const void *keys, int key_kind, int64_
     HA_REQUIRE(ha_cache_plan_pending(h) == 0, "cache: %d planned calls are outstanding (ha_cache_plan_block): ha_cache_lookup_planned / "
                "ha_cache_update_planned come first", ha_cache_plan_pending(h));
     h->last_planned_type = -1;
+    h->lfu_tree_ok = false;
     Cache &c = h->c;
     // (a batch from the ring of ha_cache_sort_ahead_batch has its sorted keys in c.plan_ws already: a pending sort of
     // ha_cache_sort_ahead -- another batch's -- stays where it is)
@@ -2244,6 +2245,7 @@ static int cache_update_impl(ha_cache *h, const void *keys, int key_kind, int64_
     HA_REQUIRE(ha_cache_plan_pending(h) == 0, "cache: %d planned calls are outstanding (ha_cache_plan_block): ha_cache_lookup_planned / "
                "ha_cache_update_planned come first", ha_cache_plan_pending(h));
     h->last_planned_type = -1;
+    h->lfu_tree_ok = false;
     Cache &c = h->c;
     // keys == nullptr: the batch of the preceding ha_cache_lookup, whose plan is still in the workspace
     int probed = 0;
@@ -2368,6 +2370,7 @@ static int push_pull_begin(ha_cache *h, const void *pull_keys, int pull_kind, in
     HA_REQUIRE(ha_cache_plan_pending(h) == 0, "cache: %d planned calls are outstanding (ha_cache_plan_block): ha_cache_lookup_planned / "
                "ha_cache_update_planned come first", ha_cache_plan_pending(h));
     h->last_planned_type = -1;
+    h->lfu_tree_ok = false;
     Cache &c = h->c;
     Cache cb = scratch_b_view(c);
     const dim3 b(256);
@@ -2475,8 +2478,9 @@ extern "C" int ha_cache_perf(ha_cache *h, int64_t *out_host, ha_stream_t stream)
     CacheCtl ctl;
     HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
-    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a wait inside cache_finish_book_kernel timed out (the cache's state is not to be "
-               "trusted; HA_CACHE_FUSED=3 keeps the bookkeeping in a launch of its own)");
+    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a wait between the workgroups of a bookkeeping launch timed out (code %ld; the cache's "
+               "state is not to be trusted; HA_CACHE_FUSED=3 keeps the call-by-call bookkeeping in a launch of its own)",
+               (long)ctl.fb_timeout);
     for (int i = 0; i < 7; ++i)
         out_host[i] = ctl.perf[i];
     out_host[4] += ctl.perf[7];
@@ -2549,8 +2553,9 @@ extern "C" int ha_cache_state(ha_cache *h, int64_t *out_host, ha_stream_t stream
     CacheCtl ctl;
     HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
-    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a wait inside cache_finish_book_kernel timed out (the cache's state is not to be "
-               "trusted; HA_CACHE_FUSED=3 keeps the bookkeeping in a launch of its own)");
+    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a wait between the workgroups of a bookkeeping launch timed out (code %ld; the cache's "
+               "state is not to be trusted; HA_CACHE_FUSED=3 keeps the call-by-call bookkeeping in a launch of its own)",
+               (long)ctl.fb_timeout);
     out_host[0] = ctl.size;
     out_host[1] = ctl.evict_n;
     out_host[2] = ctl.free_top;

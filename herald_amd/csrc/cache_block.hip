@@ -1,8 +1,9 @@
-// The PLANNED flow of the HET embedding cache: LRU, local store, the ids of a block of batches known a block early.
+// The PLANNED flow of the HET embedding cache: LRU / LFU / LFUOpt, local store, the ids of a block of batches known a block early.
 //
 // Reference flows (src/hetu_cache/src/cache.cc): _embeddingLookup :60-107 and _embeddingUpdate :132-197 of the SAME keys,
 // batch after batch -- what a training loop does (python/hetu/cstable.py:38-56: embedding_lookup, the model, embedding_update).
-// Policy: LRUCache (src/hetu_cache/src/lru_cache.cc:5-39).  Line::accumulate (include/embedding.h:78-91), Line::addup (:92-96),
+// Policies: LRUCache (src/hetu_cache/src/lru_cache.cc:5-39), LFUCache (src/lfu_cache.cc:9-70), LFUOptCache
+// (src/lfuopt_cache.cc:9-71; their bookkeeping: cache_book_lfu_kernel below).  Line::accumulate (include/embedding.h:78-91), Line::addup (:92-96),
 // the server's handlers (ps-lite/src/PSFhandle_embedding.cc:5-64).  Results: those of ha_cache_lookup + ha_cache_update_same_keys
 // call by call (rows, versions, update counters, resident set, server table and versions; tests/test_gpu_cache_planned.py holds
 // both to oracle/cache_model.py).
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
                 PlanRec r{};
                 r.size = size;
                 r.full = size == c.limit;
+                r.vh_slot = -1;
                 a.rec[i] = r;
             }
             continue;
@@ -389,6 +391,8 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
             r.size = size;
             r.full = size == c.limit;
             r.npush = -1;         // (counted when the perf dict asks: ha_cache_perf)
+            r.erep = dirty_before;
+            r.vh_slot = -1;
             a.rec[i] = r;
         }
         // the next batch probes what this one inserted and evicted
@@ -401,6 +405,455 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_block_kernel(Cache c,
         ctl->log_head = head;
         ctl->free_top = ftop;
         ctl->size = size;
+        ctl->evict_n = 0;
+        ctl->book_seq = static_cast<long long>(seq);
+        ctl->U = 0;
+        ctl->M = 0;
+    }
+}
+
+
+// ---- LFU / LFUOpt: the bookkeeping of a block of batches ---------------------------------------------------------------------
+// What the two policies do to a lookup + update pair of the SAME keys (lfu_cache.cc / lfuopt_cache.cc; every line found is
+// touched twice, by the lookup and by the update: use + 2, or -- LFUOpt -- into the never-evicted store once use reaches 10),
+// given that the lowest use bucket is EMPTY when the batch starts (it is after every pair: the update's touch lifts every line
+// the lookup inserted; ha_cache_plan_block checks it when the planned flow takes over from call-by-call calls):
+//   cache not full (free0 = limit - size > 0): the first free0 misses are inserted; every further insert evicts the back of
+//       the lowest bucket = the batch's own oldest insert (lfu_cache.cc:31-42): of M misses the first M - free0 never stay;
+//   cache full: the FIRST insert evicts the line with the least (use, arrival) of all lines outside LFUOpt's store -- lines
+//       of this batch included, as the lookup's touch left them -- and every further insert evicts the insert before it: one
+//       old line leaves, the batch's LAST miss stays (LFUOpt with nothing outside the store: every insert is dropped,
+//       lfuopt_cache.cc:18-24);
+//   the update does not find the keys whose inserts did not stay (nor the evicted line's, when the batch holds it): their
+//       gradients go to a line without data that is pushed at once (cache.cc:147-152,159).
+// "The least (use, arrival) of all lines" is the one global question; the call-by-call flow answers it by a scan over every
+// line (cache_scan_victim_*), 3.4 M records per batch at configs[1]'s cache.  Here a two-level minimum is kept instead: lkey[s]
+// = use << 48 | stamp of the line in slot s (all ones: none / stored), bmin[b] = the minimum of a block of 32 slots.  A batch's
+// touches rewrite their lines' keys and re-reduce those blocks; the question is one pass over bmin (106 K words at that cache).
+constexpr int kLfuBlk = 32;
+constexpr unsigned long long kKeyNone = ~0ull;
+struct LfuTree {
+    unsigned long long *lkey;    // [nblk * kLfuBlk]
+    unsigned long long *bmin;    // [nblk]
+    long long nblk;
+    unsigned long long *xk;      // [kBookWg] a query's candidate per workgroup: key, block
+    long long *xb;
+};
+__device__ __forceinline__ unsigned long long lfu_key(uint32_t use, unsigned long long stamp) {
+    // (a use count beyond 65,535 orders by arrival alone among its like: never the minimum in practice)
+    return (static_cast<unsigned long long>(use < 0xFFFFu ? use : 0xFFFFu) << 48) | (stamp & 0xFFFFFFFFFFFFull);
+}
+__global__ __launch_bounds__(256) void cache_lfu_keys_kernel(Cache c, LfuTree t) {
+    const long long s = blockIdx.x * 256ll + threadIdx.x;
+    if (s >= t.nblk * kLfuBlk)
+        return;
+    unsigned long long k = kKeyNone;
+    if (s < c.S) {
+        const LineMeta m = c.line[s];
+        if (m.state == kResident)
+            k = lfu_key(static_cast<uint32_t>(m.freq), m.stamp);
+    }
+    t.lkey[s] = k;
+}
+__global__ __launch_bounds__(256) void cache_lfu_mins_kernel(LfuTree t) {
+    const long long b = blockIdx.x * 256ll + threadIdx.x;
+    if (b >= t.nblk)
+        return;
+    unsigned long long m = kKeyNone;
+    for (int k = 0; k < kLfuBlk; ++k) {
+        const unsigned long long v = t.lkey[b * kLfuBlk + k];
+        m = v < m ? v : m;
+    }
+    t.bmin[b] = m;
+}
+
+// book_exchange with a 40-bit payload per workgroup
+__device__ __forceinline__ bool book_exchange_p(CacheCtl *ctl, unsigned long long *xw, unsigned long long seq,
+                                                unsigned long long payload, unsigned long long *s_p, int *s_abort) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned long long *words = xw + (seq & 3ull) * kBookWg;
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        stc(words + blockIdx.x, ((seq & 0xFFFFFFull) << 40) | (payload & 0xFFFFFFFFFFull));
+    if (tid < kBookWg) {
+        unsigned long long w = ldc(words + tid);
+        if ((w >> 40) != (seq & 0xFFFFFFull)) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                w = ldc(words + tid);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+                    *s_abort = 1;
+                    ctl->fb_timeout = 1;
+                    break;
+                }
+            } while ((w >> 40) != (seq & 0xFFFFFFull));
+        }
+        s_p[tid] = w & 0xFFFFFFFFFFull;
+    }
+    __syncthreads();
+    return *s_abort == 0;
+}
+// the block minimum of slot s's block from its 32 keys (an exchange separates this from the keys' stores)
+__device__ __forceinline__ void lfu_block_refresh(const LfuTree &t, long long s) {
+    const long long b = s / kLfuBlk;
+    const unsigned long long *p = t.lkey + b * kLfuBlk;
+    unsigned long long v[kLfuBlk];
+#pragma unroll
+    for (int k = 0; k < kLfuBlk; ++k)
+        v[k] = ldc(p + k);
+    unsigned long long m = kKeyNone;
+#pragma unroll
+    for (int k = 0; k < kLfuBlk; ++k)
+        m = v[k] < m ? v[k] : m;
+    stc(t.bmin + b, m);
+}
+// the slot with the least key of all (-1: there is none) and that key; one exchange.  Every workgroup settles the SLOT of
+// its candidate before the exchange (nobody rewrites keys between the exchange in front of a query and the query's own);
+// behind it the first workgroups through are already rewriting lines -- the answer must not be looked up again there.
+__device__ __forceinline__ bool lfu_query(CacheCtl *ctl, unsigned long long *xw, unsigned long long seq, const LfuTree &t,
+                                          unsigned long long *s_p, unsigned long long *s_k, long long *s_i, int *s_abort,
+                                          long long *slot_out, unsigned long long *key_out) {
+    const int tid = threadIdx.x, g = blockIdx.x, lane = lane_id(), w = tid >> 6;
+    unsigned long long best = kKeyNone;
+    long long bi = -1;
+    for (long long b = g * kBookThreads + tid; b < t.nblk; b += static_cast<long long>(kBookWg) * kBookThreads) {
+        const unsigned long long v = ldc(t.bmin + b);
+        if (v < best) {
+            best = v;
+            bi = b;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_xor(best, o, 64);
+        const long long oi = __shfl_xor(bi, o, 64);
+        if (ob < best) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        s_k[w] = best;
+        s_i[w] = bi;
+    }
+    __syncthreads();
+    if (w == 0) {
+        best = s_k[0];
+        bi = s_i[0];
+        for (int k = 1; k < kBookThreads / 64; ++k)
+            if (s_k[k] < best) {
+                best = s_k[k];
+                bi = s_i[k];
+            }
+        // (keys are unique: a stamp is given once) the slot of the block that carries the key
+        long long slot = -1;
+        if (best != kKeyNone) {
+            const unsigned long long v = lane < kLfuBlk ? ldc(t.lkey + bi * kLfuBlk + lane) : kKeyNone;
+            const unsigned long long m = __ballot(v == best);
+            slot = m ? bi * kLfuBlk + __builtin_ctzll(m) : -1;
+        }
+        if (lane == 0) {
+            stc(t.xk + g, slot >= 0 ? best : kKeyNone);
+            stc(t.xb + g, slot);
+        }
+    }
+    if (!book_exchange_p(ctl, xw, seq, 0ull, s_p, s_abort))
+        return false;
+    if (w == 0) {
+        best = lane < kBookWg ? ldc(t.xk + lane) : kKeyNone;
+        bi = lane < kBookWg ? ldc(t.xb + lane) : -1;
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ob = __shfl_xor(best, o, 64);
+            const long long oi = __shfl_xor(bi, o, 64);
+            if (ob < best) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_i[0] = best != kKeyNone ? bi : -1;
+            s_k[0] = best;
+        }
+    }
+    __syncthreads();
+    *slot_out = s_i[0];
+    *key_out = s_k[0];
+    __syncthreads();
+    return true;
+}
+// is `key` one of the batch's sorted unique keys?  (every thread of the workgroup asks; two probes)
+__device__ __forceinline__ bool lfu_in_batch(const uint32_t *uniq, int U, uint32_t key) {
+    const int tid = threadIdx.x;
+    const int stride = (U + kBookThreads - 1) / kBookThreads;
+    const int i0 = tid * stride;
+    const int cnt = __syncthreads_count(i0 < U && uniq[i0] <= key);
+    const int seg0 = (cnt > 0 ? cnt - 1 : 0) * stride;
+    return __syncthreads_or(cnt > 0 && tid < stride && seg0 + tid < U && uniq[seg0 + tid] == key) != 0;
+}
+
+__global__ __launch_bounds__(kBookThreads) void cache_book_lfu_kernel(Cache c, BookArgs a, LfuTree t) {
+    __shared__ unsigned long long s_p[kBookWg], s_k[kBookThreads / 64];
+    __shared__ long long s_i[kBookThreads / 64];
+    __shared__ uint32_t s_w4[kBookThreads / 64];
+    __shared__ int s_abort;
+    CacheCtl *ctl = c.ctl;
+    const int tid = threadIdx.x, g = blockIdx.x;
+    if (tid == 0)
+        s_abort = 0;
+    long long clock = ctl->clock, ftop = ctl->free_top, size = ctl->size, n_hash = ctl->n_hash;
+    unsigned long long seq = static_cast<unsigned long long>(ctl->book_seq);
+    const bool opt = c.policy == kLFUOpt;
+    const uint32_t new_use = opt ? 1u : 2u;       // a line the lookup inserted, after the update's touch
+    __syncthreads();
+    for (int i = 0; i < a.count; ++i) {
+        const int n = a.n[i];
+        const long long at = static_cast<long long>(i) * a.nmax;
+        if (n == 0) {
+            if (g == 0 && tid == 0) {
+                PlanRec r{};
+                r.size = size;
+                r.full = size == c.limit;
+                r.vh_slot = -1;
+                a.rec[i] = r;
+            }
+            continue;
+        }
+        const int U = static_cast<int>(a.hdr[i]->n_unique);
+        const uint32_t *uniq = a.uniq[i];
+        const int32_t *counts = a.counts[i];
+        const int per = (U + kBookWg - 1) / kBookWg;
+        const int u0 = min(g * per, U), u1 = min(u0 + per, U);
+        // ---- phase 1: probe; what the two touches will make of every line found ---------------------------------------------
+        int sl[kBookKeysPerThread];
+        uint32_t kk[kBookKeysPerThread], rk[kBookKeysPerThread];
+        unsigned long long w2[kBookKeysPerThread], w3[kBookKeysPerThread];
+        bool miss[kBookKeysPerThread];
+        uint32_t wg_miss = 0, wg_st1 = 0, wg_st2 = 0;
+#pragma unroll
+        for (int j = 0; j < kBookKeysPerThread; ++j) {
+            const int u = u0 + j * kBookThreads + tid;
+            const bool on = u < u1;
+            kk[j] = on ? uniq[u] : 0u;
+            const bool known = on && kk[j] < static_cast<unsigned long long>(c.length);
+            sl[j] = known ? ldc(c.slot_of + kk[j]) : -1;
+            miss[j] = known && sl[j] < 0;
+            if (on && !known) {
+                a.it_slot[at + u] = -1;
+                a.it_flag[at + u] = 0;
+                a.it_upd[at + u] = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kBookKeysPerThread; ++j) {
+            bool st1 = false, st2 = false;
+            w2[j] = w3[j] = 0ull;
+            if (sl[j] >= 0) {
+                w2[j] = ldc(line_word(c.line, sl[j], 2));
+                w3[j] = ldc(line_word(c.line, sl[j], 3));
+                const uint32_t f = static_cast<uint32_t>(w3[j]);
+                const bool res = static_cast<uint8_t>(w3[j] >> 32) == kResident;
+                st1 = opt && res && f + 1 >= static_cast<uint32_t>(kUseCntMax);     // lfuopt_cache.cc:33-39, by the lookup's touch
+                st2 = opt && res && !st1 && f + 2 >= static_cast<uint32_t>(kUseCntMax);   // by the update's
+            }
+            uint32_t tot;
+            rk[j] = wg_miss + book_rank(miss[j], s_w4, &tot);
+            wg_miss += tot;
+            wg_st1 += static_cast<uint32_t>(__syncthreads_count(st1));
+            wg_st2 += static_cast<uint32_t>(__syncthreads_count(st2));
+        }
+        if (!book_exchange_p(ctl, a.xw, ++seq, static_cast<unsigned long long>(wg_miss) | (static_cast<unsigned long long>(wg_st1) << 13) |
+                                                 (static_cast<unsigned long long>(wg_st2) << 26), s_p, &s_abort))
+            return;
+        long long mb = 0, M = 0, ST1 = 0, ST2 = 0;
+        for (int k = 0; k < kBookWg; ++k) {
+            const long long m_k = static_cast<long long>(s_p[k] & 0x1FFFull);
+            mb += k < g ? m_k : 0;
+            M += m_k;
+            ST1 += static_cast<long long>((s_p[k] >> 13) & 0x1FFFull);
+            ST2 += static_cast<long long>((s_p[k] >> 26) & 0x1FFFull);
+        }
+        const long long free0 = c.limit > size ? c.limit - size : 0;
+        const long long ev = M > free0 ? M - free0 : 0;
+        const bool drop_all = opt && ev > 0 && free0 == 0 && n_hash - ST1 == 0;
+        const bool scan = ev > 0 && free0 == 0 && !drop_all;
+        const long long v_new = drop_all ? M : (scan ? ev - 1 : ev);     // the batch's first v_new inserts do not stay
+        // ---- the line that leaves for the batch's first insert ----------------------------------------------------------------
+        long long vslot = -1;
+        unsigned long long vw2 = 0, vkey_lfu = kKeyNone;
+        bool vin = false;
+        if (scan) {
+            // as the tree stands (the lines as the batch found them): the lookup's touch only raises keys, so a minimum that
+            // is NOT a line of this batch is the minimum after the touch as well
+            // (of the line's record only the word {key, updates} is read: nobody writes it before the batch is booked; its
+            // state word is the first thing the fastest workgroup rewrites)
+            if (!lfu_query(ctl, a.xw, ++seq, t, s_p, s_k, s_i, &s_abort, &vslot, &vkey_lfu))
+                return;
+            if (vslot >= 0) {
+                vw2 = ldc(line_word(c.line, vslot, 2));
+                vin = lfu_in_batch(uniq, U, static_cast<uint32_t>(vw2));
+            }
+            if (vin) {
+                // it is one of the batch's lines: the keys of the batch's lines as the lookup's touch leaves them (use + 1,
+                // arrival in key order; LFUOpt: a line that reaches the store drops out), then the question again
+#pragma unroll
+                for (int j = 0; j < kBookKeysPerThread; ++j) {
+                    const int u = u0 + j * kBookThreads + tid;
+                    if (sl[j] >= 0 && static_cast<uint8_t>(w3[j] >> 32) == kResident) {
+                        const uint32_t f = static_cast<uint32_t>(w3[j]);
+                        const bool st1 = opt && f + 1 >= static_cast<uint32_t>(kUseCntMax);
+                        stc(t.lkey + sl[j], st1 ? kKeyNone : lfu_key(f + 1, static_cast<unsigned long long>(clock + u)));
+                    }
+                }
+                if (!book_exchange_p(ctl, a.xw, ++seq, 0ull, s_p, &s_abort))
+                    return;
+#pragma unroll
+                for (int j = 0; j < kBookKeysPerThread; ++j)
+                    if (sl[j] >= 0 && static_cast<uint8_t>(w3[j] >> 32) == kResident)
+                        lfu_block_refresh(t, sl[j]);
+                if (!book_exchange_p(ctl, a.xw, ++seq, 0ull, s_p, &s_abort))
+                    return;
+                if (!lfu_query(ctl, a.xw, ++seq, t, s_p, s_k, s_i, &s_abort, &vslot, &vkey_lfu))
+                    return;
+                if (vslot >= 0) {
+                    vw2 = ldc(line_word(c.line, vslot, 2));
+                    vin = lfu_in_batch(uniq, U, static_cast<uint32_t>(vw2));
+                }
+            }
+            if (vslot < 0) {       // (the counters say a line exists: the tree does not hold what they count)
+                if (tid == 0)
+                    ctl->fb_timeout = 2;
+                return;
+            }
+        }
+        const uint32_t vkey = static_cast<uint32_t>(vw2);
+        const int vupd = static_cast<int>(vw2 >> 32);
+        const bool vdirty = scan && vupd != 0;
+        // ---- phase 2: the state after the pair; the items --------------------------------------------------------------------
+        const long long clock2 = clock + U;
+        long long rf[kBookKeysPerThread];          // slots whose block minimum this thread re-reduces
+#pragma unroll
+        for (int j = 0; j < kBookKeysPerThread; ++j) {
+            const int u = u0 + j * kBookThreads + tid;
+            rf[j] = -1;
+            if (u >= u1)
+                continue;
+            if (sl[j] >= 0) {
+                const int s = sl[j];
+                const uint32_t f = static_cast<uint32_t>(w3[j]);
+                const uint8_t state = static_cast<uint8_t>(w3[j] >> 32);
+                const bool hg = ((w3[j] >> 40) & 1ull) != 0ull;
+                if (scan && s == vslot) {
+                    // this line is the one the batch's first insert evicts: the lookup still reads it (slot vh_slot of the
+                    // record), the update does not find it -- a line without data in a spare slot, pushed at once
+                    a.it_slot[at + u] = ldc(c.free_list + (ftop - M - 1));
+                    a.it_flag[at + u] = static_cast<uint8_t>(kPosTemp | kPosPush | kPosVictim | (hg ? kPosVictimHg : 0) |
+                                                             (vdirty ? kPosVictimPush : 0));
+                    a.it_upd[at + u] = counts[u];
+                    continue;
+                }
+                const int upd = static_cast<int>(w2[j] >> 32) + counts[u];
+                const bool push = upd > c.push_bound;
+                uint8_t ns = state;
+                uint32_t f2 = f;
+                if (state == kResident) {
+                    if (opt && f + 2 >= static_cast<uint32_t>(kUseCntMax))
+                        ns = kStored;
+                    else
+                        f2 = f + 2;
+                }
+                const unsigned long long st = static_cast<unsigned long long>(clock2 + u);
+                stc(line_word(c.line, s, 0), st);
+                stc(line_word(c.line, s, 2), static_cast<unsigned long long>(kk[j]) |
+                                                 (static_cast<unsigned long long>(static_cast<uint32_t>(push ? 0 : upd)) << 32));
+                stc(line_word(c.line, s, 3), static_cast<unsigned long long>(f2) | line_w3(ns, true));
+                if (state == kResident) {
+                    stc(t.lkey + s, ns == kStored ? kKeyNone : lfu_key(f2, st));
+                    rf[j] = s;
+                }
+                a.it_slot[at + u] = s;
+                a.it_flag[at + u] = static_cast<uint8_t>((hg ? kPosInit : 0) | (push ? kPosPush : 0));
+                a.it_upd[at + u] = upd;
+            } else if (miss[j]) {
+                // the batch's misses take the top M stack entries in rank order from below: the ones that stay are on top
+                const long long q = mb + rk[j];
+                const int s = ldc(c.free_list + (ftop - M + q));
+                const int upd = counts[u];
+                if (q < v_new) {          // inserted and evicted again by a later insert (or dropped): see the header
+                    a.it_slot[at + u] = s;
+                    a.it_flag[at + u] = static_cast<uint8_t>(kPosMiss | kPosTemp | kPosPush);
+                    a.it_upd[at + u] = upd;
+                    continue;
+                }
+                const bool push = upd > c.push_bound;
+                const unsigned long long st = static_cast<unsigned long long>(clock2 + u);
+                stc(line_word(c.line, s, 0), st);
+                stc(line_word(c.line, s, 2), static_cast<unsigned long long>(kk[j]) |
+                                                 (static_cast<unsigned long long>(static_cast<uint32_t>(push ? 0 : upd)) << 32));
+                stc(line_word(c.line, s, 3), static_cast<unsigned long long>(new_use) | line_w3(kResident, true));
+                stc(c.slot_of + kk[j], s);
+                stc(t.lkey + s, lfu_key(new_use, st));
+                rf[j] = s;
+                a.it_slot[at + u] = s;
+                a.it_flag[at + u] = static_cast<uint8_t>(kPosMiss | (push ? kPosPush : 0));
+                a.it_upd[at + u] = upd;
+            }
+        }
+        const long long stay = M - v_new;
+        // (the evicted line of the batch itself was counted among the lines the update's touch stores when its use was 8: the
+        // key it left with is use + 1)
+        const bool v_st2 = scan && vin && opt && static_cast<uint32_t>(vkey_lfu >> 48) + 1 >= static_cast<uint32_t>(kUseCntMax);
+        if (g == 0 && tid == 0) {
+            long long E = 0;
+            if (scan) {
+                stc(c.slot_of + vkey, -1);
+                stc(line_word(c.line, vslot, 3), line_w3(kFree, false));
+                stc(t.lkey + vslot, kKeyNone);
+                if (vdirty && !vin) {
+                    a.ev_slot[at] = static_cast<int32_t>(vslot);
+                    a.ev_key[at] = vkey;
+                    a.ev_upd[at] = vupd;
+                    E = 1;
+                }
+            }
+            PlanRec r{};
+            r.n = n;
+            r.U = U;
+            r.M = M;
+            r.E = E;
+            r.evicted = scan ? 1 : 0;
+            r.size = size + stay - (scan ? 1 : 0);
+            r.full = r.size == c.limit;
+            r.npush = -1;
+            r.erep = vdirty ? 1 : 0;
+            r.umiss = v_new + (scan && vin ? 1 : 0);
+            r.vh_slot = scan && vin ? vslot : -1;
+            r.vh_upd = scan && vin ? vupd : 0;
+            a.rec[i] = r;
+        }
+        // ---- the batch is booked: the next one probes what this one left; the blocks of the rewritten keys ---------------------
+        if (!book_exchange_p(ctl, a.xw, ++seq, 0ull, s_p, &s_abort))
+            return;
+#pragma unroll
+        for (int j = 0; j < kBookKeysPerThread; ++j)
+            if (rf[j] >= 0)
+                lfu_block_refresh(t, rf[j]);
+        if (scan && g == 0 && tid == 0) {
+            lfu_block_refresh(t, vslot);
+            stc(c.free_list + (ftop - stay), static_cast<int32_t>(vslot));    // (everybody has read the stack's old top)
+        }
+        ftop = ftop - stay + (scan ? 1 : 0);
+        size = size + stay - (scan ? 1 : 0);
+        n_hash = n_hash - ST1 - ST2 + (v_st2 ? 1 : 0) + stay - (scan ? 1 : 0);
+        clock += 2ll * U;
+    }
+    if (g == 0 && tid == 0) {
+        ctl->clock = clock;
+        ctl->free_top = ftop;
+        ctl->size = size;
+        ctl->n_hash = n_hash;
+        ctl->n_base = 0;
         ctl->evict_n = 0;
         ctl->book_seq = static_cast<long long>(seq);
         ctl->U = 0;
@@ -439,15 +892,20 @@ __global__ __launch_bounds__(256) void cache_plan_expand_kernel(BookArgs a, Plan
 // section 6, yardstick: 8.0 us), the staleness check is almost free beside it.)
 template <int VEC>
 __global__ __launch_bounds__(1024) void cache_lookup_planned_kernel(
-    Cache c, const int4 *__restrict__ pos_item, long long n, float *__restrict__ dest, long long *__restrict__ pver) {
+    Cache c, const int4 *__restrict__ pos_item, long long n, float *__restrict__ dest, long long *__restrict__ pver,
+    const PlanRec *__restrict__ rec) {
     const int lane = lane_id();
     const long long p = static_cast<long long>(blockIdx.x) * 16ll + uniform(static_cast<int>(threadIdx.x >> 6));
     if (p >= n)
         return;
     const int4 it = pos_item[p];
-    const int s = uniform(it.x);
+    int s = uniform(it.x);
     const long long lk = static_cast<long long>(uniform(static_cast<uint32_t>(it.y)));
-    const int fl = uniform(it.z);
+    int fl = uniform(it.z);
+    if (fl & kPosVictim) {      // (LFU policies) the line this batch's own lookup evicts: still in its old slot when the rows are read
+        s = uniform(static_cast<int>(rec->vh_slot));
+        fl = (fl & ~kPosInit) | ((fl & kPosVictimHg) ? kPosInit : 0);
+    }
     const bool head = (fl & kPosHead) != 0;
     float *out = dest + static_cast<long long>(uniform(it.w)) * c.width;
     if (s < 0) {
@@ -577,6 +1035,10 @@ __global__ __launch_bounds__(1024, 8) void cache_update_planned_kernel(
         const int4 it = maps.pos_item[p];
         if (it.x < 0 || !(it.z & kPosHead))
             continue;
+        if (it.z & kPosTemp) {     // (LFU policies) a line that is not in the cache: pushed, nothing of it stays
+            c.srv_ver[static_cast<uint32_t>(it.y)] += it_upd_pos[p] + ((it.z & kPosVictimPush) ? static_cast<int>(rec->vh_upd) : 0);
+            continue;
+        }
         const int s = it.x;
         const long long pv = pver[p];
         long long v = pv != kVerKeep ? pv : c.line[s].version;
@@ -685,10 +1147,11 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
     HA_REQUIRE(h && keys && n && (key_kind == 0 || key_kind == 1) && count >= 1 && count <= kPlanBlockMax,
                "cache_plan_block: bad arguments (1..%d batches)", kPlanBlockMax);
     Cache &c = h->c;
-    HA_REQUIRE(c.policy == kLRU && c.table && !c.remote && !c.bypass, "cache_plan_block: an LRU cache over a local store, not bypassed");
+    HA_REQUIRE(c.table && !c.remote && !c.bypass, "cache_plan_block: a cache over a local store, not bypassed");
     HA_REQUIRE(c.row_start == 0 && c.store_rows >= c.length, "cache_plan_block: the store must hold every key of the cache's range");
-    HA_REQUIRE(c.limit >= c.nmax, "cache_plan_block: limit (%ld) must be at least max_batch (%ld): the lines of a batch are never "
-               "evicted by its own lookup", (long)c.limit, (long)c.nmax);
+    HA_REQUIRE(c.policy != kLRU || c.limit >= c.nmax, "cache_plan_block: limit (%ld) must be at least max_batch (%ld): the lines of "
+               "a batch are never evicted by its own lookup", (long)c.limit, (long)c.nmax);
+    HA_REQUIRE(c.limit >= 1, "cache_plan_block: an empty cache");
     HA_REQUIRE(h->evict_empty || ha_cache_plan_pending(h) > 0, "cache_plan_block: evicted lines are pending (an update must follow "
                "the last lookup first)");
     HA_REQUIRE(h->ahead_n < 0, "cache_plan_block: a ha_cache_sort_ahead is pending");
@@ -706,6 +1169,31 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
         HA_CHECK_HIP(hipEventCreateWithFlags(&h->plan_fork, hipEventDisableTiming));
     }
     hipStream_t ss = as_stream(side), ms = as_stream(main);
+    LfuTree tree{};
+    if (c.policy != kLRU) {
+        if (!h->lfu_lkey) {
+            h->lfu_nblk = (c.S + kLfuBlk - 1) / kLfuBlk;
+            HA_REQUIRE(dmalloc(&h->lfu_lkey, static_cast<size_t>(h->lfu_nblk * kLfuBlk)) == 0 &&
+                       dmalloc(&h->lfu_bmin, static_cast<size_t>(h->lfu_nblk)) == 0 &&
+                       dmalloc(&h->lfu_xk, static_cast<size_t>(kBookWg)) == 0 && dmalloc(&h->lfu_xb, static_cast<size_t>(kBookWg)) == 0,
+                       "cache_plan_block: out of device memory");
+            h->allocs.push_back(h->lfu_lkey);
+            h->allocs.push_back(h->lfu_bmin);
+            h->allocs.push_back(h->lfu_xk);
+            h->allocs.push_back(h->lfu_xb);
+        }
+        tree = LfuTree{h->lfu_lkey, h->lfu_bmin, h->lfu_nblk, h->lfu_xk, h->lfu_xb};
+        if (!h->lfu_tree_ok) {
+            // the planned flow takes over from call-by-call calls (or starts): the lowest use bucket must be empty -- it is
+            // after every lookup + update pair, not after a lookup without its update (see cache_book_lfu_kernel)
+            HA_CHECK_HIP(hipStreamSynchronize(ms));
+            CacheCtl ctl_h;
+            HA_CHECK_HIP(hipMemcpy(&ctl_h, c.ctl, sizeof(ctl_h), hipMemcpyDeviceToHost));
+            HA_REQUIRE(ctl_h.n_base == 0, "cache_plan_block: %ld lines are in the lowest use bucket (a lookup without its update "
+                       "put them there): the planned flow of the LFU policies starts from a cache whose lines were all updated",
+                       (long)ctl_h.n_base);
+        }
+    }
     if (ss != ms) {
         HA_CHECK_HIP(hipEventRecord(h->plan_fork, ms));
         HA_CHECK_HIP(hipStreamWaitEvent(ss, h->plan_fork, 0));
@@ -734,7 +1222,17 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
     a.rec = sl.rec;
     a.xw = h->plan_xw;
     a.nmax = c.nmax;
-    hipLaunchKernelGGL(cache_book_block_kernel, dim3(kBookWg), dim3(kBookThreads), 0, ss, c, a);
+    if (c.policy == kLRU) {
+        hipLaunchKernelGGL(cache_book_block_kernel, dim3(kBookWg), dim3(kBookThreads), 0, ss, c, a);
+    } else {
+        if (!h->lfu_tree_ok) {
+            hipLaunchKernelGGL(cache_lfu_keys_kernel, dim3(static_cast<unsigned>((tree.nblk * kLfuBlk + 255) / 256)), dim3(256), 0, ss,
+                               c, tree);
+            hipLaunchKernelGGL(cache_lfu_mins_kernel, dim3(static_cast<unsigned>((tree.nblk + 255) / 256)), dim3(256), 0, ss, tree);
+            h->lfu_tree_ok = true;
+        }
+        hipLaunchKernelGGL(cache_book_lfu_kernel, dim3(kBookWg), dim3(kBookThreads), 0, ss, c, a, tree);
+    }
     {   // the items per sorted position
         PlanExpandPtrs ep;
         int nmx = 1;
@@ -797,10 +1295,10 @@ extern "C" int ha_cache_lookup_planned(ha_cache *h, int64_t n, float *dest, ha_s
                             (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
         if (vec_ok)
             hipLaunchKernelGGL(cache_lookup_planned_kernel<4>, dim3(blocks), dim3(1024), 0, s, c, sl->pos_item + at, (long long)n,
-                               dest, sl->pver + at);
+                               dest, sl->pver + at, sl->rec + i);
         else
             hipLaunchKernelGGL(cache_lookup_planned_kernel<1>, dim3(blocks), dim3(1024), 0, s, c, sl->pos_item + at, (long long)n,
-                               dest, sl->pver + at);
+                               dest, sl->pver + at, sl->rec + i);
         HA_LAUNCH_CHECK();
     }
     cache_mark(h, kTEnd, s);
@@ -829,6 +1327,7 @@ extern "C" int ha_cache_update_planned(ha_cache *h, int64_t n, const float *grad
         maps.dst2 = c.data;
         maps.push_tab = c.table;
         maps.pos_item = sl->pos_item + at;
+        maps.victim_row = reinterpret_cast<const int *>(&(sl->rec + i)->vh_slot);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(grads) % 16 == 0) &&
                             (reinterpret_cast<uintptr_t>(c.table) % 16 == 0);
         const dim3 grid(static_cast<unsigned>(apply_blocks + kPlanEvictBlocks + kPlanMetaBlocks));
@@ -872,15 +1371,19 @@ int ha::cache_perf_planned(ha_cache *h, int64_t *out_host, hipStream_t s) {
     const long long at = static_cast<long long>(i) * h->c.nmax;
     hipLaunchKernelGGL(cache_plan_count_kernel, dim3(1), dim3(1024), 0, s, sl->rec + i, sl->pver + at, sl->pos_item + at);
     PlanRec r;
+    long long sticky = 0;
     HA_CHECK_HIP(hipMemcpyAsync(&r, sl->rec + i, sizeof(r), hipMemcpyDeviceToHost, s));
+    HA_CHECK_HIP(hipMemcpyAsync(&sticky, &h->c.ctl->fb_timeout, sizeof(sticky), hipMemcpyDeviceToHost, s));
     HA_CHECK_HIP(hipStreamSynchronize(s));
+    HA_REQUIRE(sticky == 0, "cache: a wait between the workgroups of a bookkeeping launch timed out (code %ld; the cache's state is "
+               "not to be trusted)", (long)sticky);
     const int type = h->last_planned_type;
     out_host[0] = type;
     out_host[1] = r.n;
     out_host[2] = r.U;
-    out_host[3] = type == 0 ? r.M : 0;
-    out_host[4] = type == 0 ? r.pulled : r.npush + r.E;
-    out_host[5] = type == 0 ? 0 : r.E;
+    out_host[3] = type == 0 ? r.M : r.umiss;
+    out_host[4] = type == 0 ? r.pulled : r.npush + r.erep;
+    out_host[5] = type == 0 ? 0 : r.erep;
     out_host[6] = r.full;
     out_host[7] = r.size;
     return 0;

@@ -112,6 +112,11 @@ constexpr int kPlanBlockMax = 16;     // batches per planned block
 // what the bookkeeping launch leaves per planned batch (the perf dict's counts; pulled / npush are counted on demand)
 struct PlanRec {
     long long n, U, M, E, evicted, size, full, npush, pulled;
+    // the LFU policies (LRU: erep = E, umiss = 0, vh_slot = -1): erep = dirty lines the lookup evicted (the perf dict's
+    // num_evict; E counts those of them the update pushes by a wave of their own), umiss = keys the update does not find in
+    // the cache (num_miss of the Push record), vh_* = the evicted line when it is a line of the batch itself (slot, update
+    // counter; its key's record carries kPosVictim)
+    long long erep, umiss, vh_slot, vh_upd;
 };
 // the buffers of one planned block (two exist: the block being consumed and the next)
 struct PlanSlot {
@@ -180,6 +185,12 @@ struct ha_cache {
     int plan_next = 0;                  // blocks planned so far (slot = plan_next & 1)
     unsigned long long *plan_xw = nullptr;   // exchange words of the bookkeeping launch
     hipEvent_t plan_fork = nullptr;
+    // LFU / LFUOpt planned: the victim tree (cache_block.hip) -- the (use, stamp) key of every slot and the minimum of every
+    // block of 32 slots -- valid while only planned calls touch the cache (any call-by-call entry point clears lfu_tree_ok)
+    unsigned long long *lfu_lkey = nullptr, *lfu_bmin = nullptr, *lfu_xk = nullptr;
+    long long *lfu_xb = nullptr;
+    long long lfu_nblk = 0;
+    bool lfu_tree_ok = false;
     ha::PlanSlot *last_planned = nullptr;    // the last planned call: slot, batch, type (0 lookup / 1 update), for ha_cache_perf
     int last_planned_idx = 0, last_planned_type = -1;
 };

@@ -41,8 +41,15 @@ struct ApplyMaps {
     // DUAL == 2: one record per SORTED POSITION {destination row (both destinations; -1 = skip), key, kPos* flags, occurrence
     // index}: what the rowmap / init / push lookups through upos[p] give, in the round trip that fetches the window itself
     const int4 *pos_item;
+    // DUAL == 2, the LFU policies' planned update: a record with kPosTemp has NO second destination (a line that is not in the
+    // cache when the update runs: CacheBase::_embeddingUpdate's `new Line` without data, cache.cc:147-152); a record with
+    // kPosVictimPush is the key of the line the batch's own lookup evicted with updates pending (at most one per batch): its
+    // push adds that line's old gradient row -- dst row *victim_row -- BEHIND its own (the evicted line follows the batch's
+    // line of the same key in should_push, cache.cc:160-170).  kPosVictim / kPosVictimHg: for the lookup (cache_block.hip).
+    const int *victim_row;
 };
-enum : int { kPosMiss = 1, kPosInit = 2, kPosPush = 4, kPosHead = 8 };
+enum : int { kPosMiss = 1, kPosInit = 2, kPosPush = 4, kPosHead = 8, kPosTemp = 16, kPosVictim = 32, kPosVictimHg = 64,
+             kPosVictimPush = 128 };
 
 // host: the run length from which the tolerance mode applies (0 = exact everywhere; scatter.hip,
 // ha_set_tolerance_mode)
@@ -57,6 +64,7 @@ struct Second {
     int opt_kind;
     OptArgs oa;
     float *push;    // DUAL: the store row that takes the first destination's new value (nullptr: none), see ApplyMaps::push_tab
+    const float *push2;   // DUAL == 2: a second row added to the store row behind it (nullptr: none), see ApplyMaps::victim_row
 };
 
 
@@ -198,12 +206,19 @@ struct Vec<1> {
 };
 
 template <int VEC>
-__device__ __forceinline__ void push_epilogue(float *__restrict__ push_row, int col, Vec<VEC> &acc) {
+__device__ __forceinline__ void push_epilogue(float *__restrict__ push_row, int col, Vec<VEC> &acc, const float *push2 = nullptr) {
     Vec<VEC> cur;
     cur.load(push_row + col);
 #pragma unroll
     for (int k = 0; k < VEC; ++k)
         cur.set(k, __fadd_rn(cur.get(k), acc.get(k)));
+    if (push2) {         // (wave-uniform, rare)
+        Vec<VEC> old;
+        old.load(push2 + col);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            cur.set(k, __fadd_rn(cur.get(k), old.get(k)));
+    }
     cur.store(push_row + col);
     acc.zero();
 }
@@ -267,7 +282,7 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                     acc[b].set(k, __fadd_rn(cur.get(k), acc[b].get(k)));
             }
             if (DUAL == 2 && d2.push)
-                push_epilogue<VEC>(d2.push, col[b], acc[b]);
+                push_epilogue<VEC>(d2.push, col[b], acc[b], d2.push2);
             if (MODE == kModeOpt) {
                 float gsum[VEC];
 #pragma unroll
@@ -383,7 +398,10 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
         if (MODE == kModePush)
             acc = __fadd_rn(dst_row[col], acc);
         if (DUAL == 2 && d2.push) {
-            d2.push[col] = __fadd_rn(d2.push[col], acc);
+            float pr = __fadd_rn(d2.push[col], acc);
+            if (d2.push2)
+                pr = __fadd_rn(pr, d2.push2[col]);
+            d2.push[col] = pr;
             acc = 0.f;
         }
         if (MODE == kModeOpt)
@@ -698,7 +716,10 @@ __device__ __forceinline__ void coop_slices(
             if (MODE == kModePush)
                 acc = __fadd_rn(dst_row[ccol], acc);
             if (DUAL == 2 && d2.push) {
-                d2.push[ccol] = __fadd_rn(d2.push[ccol], acc);
+                float pr = __fadd_rn(d2.push[ccol], acc);
+                if (d2.push2)
+                    pr = __fadd_rn(pr, d2.push2[ccol]);
+                d2.push[ccol] = pr;
                 acc = 0.f;
             }
             if (MODE == kModeOpt)
@@ -827,10 +848,11 @@ __device__ __forceinline__ bool coop_run(
     float *dst_row = dst + row * static_cast<uint64_t>(width);
     Second d2{nullptr, false};
     if (DUAL == 2) {
-        d2.on = true;
+        d2.on = (pit.z & kPosTemp) == 0;
         d2.row = maps.dst2 + row * static_cast<uint64_t>(width);
         d2.push = (pit.z & kPosPush) ? maps.push_tab + static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) * static_cast<uint64_t>(width)
                                      : nullptr;
+        d2.push2 = (pit.z & kPosVictimPush) ? dst + static_cast<uint64_t>(*maps.victim_row) * static_cast<uint64_t>(width) : nullptr;
     } else if (DUAL && maps.rowmap2) {
         const int r2 = maps.rowmap2[upos[wg0]];
         d2.on = r2 >= 0;
@@ -967,10 +989,11 @@ __device__ __forceinline__ bool apply_body_impl(
     float *dst_row = dst + row * static_cast<uint64_t>(width);
     Second d2{nullptr, false};
     if (DUAL == 2) {
-        d2.on = true;
+        d2.on = (pit.z & kPosTemp) == 0;
         d2.row = maps.dst2 + row * static_cast<uint64_t>(width);
         d2.push = (pit.z & kPosPush) ? maps.push_tab + static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) * static_cast<uint64_t>(width)
                                      : nullptr;
+        d2.push2 = (pit.z & kPosVictimPush) ? dst + static_cast<uint64_t>(*maps.victim_row) * static_cast<uint64_t>(width) : nullptr;
     } else if (DUAL && maps.rowmap2) {
         const int r2 = maps.rowmap2[upos[p]];
         d2.on = r2 >= 0;

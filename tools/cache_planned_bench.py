@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The HET cache tier of BASELINE configs[1] through the PLANNED flow (csrc/cache_block.hip), development aid: LRU,
 limit = 0.1 x rows, bound 100, wdl_criteo bs=256 d=512 batches; cache filled to its limit first (planned pairs as well), then
-timed blocks of 16 pairs.  ROWS / BLOCKS / CLASSIC=1 (the call-by-call flow beside it) / KTRACE=<dir of a rocprofv3
+timed blocks of 16 pairs.  POLICY (LRU / LFU / LFUOpt) / ROWS / BLOCKS / CLASSIC=1 (the call-by-call flow beside it) / KTRACE=<dir of a rocprofv3
 --kernel-trace --output-format csv run>: per-kernel averages and the row stream's idle time from the trace."""
 import os
 import sys
@@ -25,7 +25,9 @@ def main():
     versions = torch.zeros(rows, dtype=torch.int64, device=dev)
     hcache.register_table(0, table, versions)
     limit = int(0.1 * rows)
-    c = hcache.CacheSparseTable(limit, rows, width, 0, "LRU", bound=100, max_batch=n, device=dev)
+    dummies = [hcache.CacheSparseTable(limit, rows, width, 0, "LRU", bound=100, max_batch=n, device=dev)
+               for _ in range(int(os.environ.get("DUMMIES", "0")))]       # (earlier instances that stay allocated, as in bench.py)
+    c = hcache.CacheSparseTable(limit, rows, width, 0, os.environ.get("POLICY", "LRU"), bound=100, max_batch=n, device=dev)
     NB = 512
     ids = [torch.from_numpy(np.minimum(synth.as_f32_ids(synth.criteo_batch(bs, b, rows=rows)).reshape(-1), rows - 1)).to(dev)
            for b in range(NB)]
@@ -40,12 +42,20 @@ def main():
     fill = [((base + lo) % rows).to(torch.float32) for lo in range(0, limit + n, n)]
     t0 = time.perf_counter()
     with torch.cuda.stream(main_s):
-        blocks = [fill[i:i + GS] for i in range(0, len(fill), GS)]
-        c.plan_block(blocks[0])
-        for b, blk in enumerate(blocks):
-            if b + 1 < len(blocks):
-                c.plan_block(blocks[b + 1])
-            c.run_planned_pairs(outs[:len(blk)], grads[:len(blk)])
+        if os.environ.get("FILL") == "classic":      # as bench.py: call-by-call pairs, then real batches call by call
+            for kk in fill:
+                c.embedding_lookup(kk, out)
+                c.embedding_update(kk, grad, same_as_lookup=True)
+            for k in range(int(os.environ.get("CLASSIC_PAIRS", "448"))):
+                c.embedding_lookup(ids[k % NB], out)
+                c.embedding_update(ids[k % NB], grad, same_as_lookup=True)
+        else:
+            blocks = [fill[i:i + GS] for i in range(0, len(fill), GS)]
+            c.plan_block(blocks[0])
+            for b, blk in enumerate(blocks):
+                if b + 1 < len(blocks):
+                    c.plan_block(blocks[b + 1])
+                c.run_planned_pairs(outs[:len(blk)], grads[:len(blk)])
     torch.cuda.synchronize()
     print("fill: %d pairs in %.2f s, size %d / %d" % (len(fill), time.perf_counter() - t0, c.cache.size(), limit))
     blocks = [[ids[j % NB] for j in range(g0, g0 + GS)] for g0 in range(0, NB, GS)]
