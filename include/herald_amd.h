@@ -896,8 +896,10 @@ int ha_cache_sort_ahead_batch(ha_cache *cache, const void *const *keys, int key_
 /* The PLANNED flow (csrc/cache_block.hip; LRU, local store, limit >= max_batch): CacheBase::_embeddingLookup and
  * _embeddingUpdate of the same keys, batch after batch (src/hetu_cache/src/cache.cc:60-107, 132-197; the training loop of
  * python/hetu/cstable.py:38-56), with the BOOKKEEPING of a block of up to 16 batches done ahead: which lines a batch hits and
- * misses, the slots of the misses, the lines LRUCache::insert evicts for them (lru_cache.cc:9-25), update counters and the
- * bounded push (cache.cc:159) follow from the ids alone.  ha_cache_plan_block enqueues, on `side`, the index plans of the
+ * misses, the slots of the misses, the lines the policy evicts for them (LRUCache::insert lru_cache.cc:9-25; LFUCache
+ * lfu_cache.cc:9-42 and LFUOptCache lfuopt_cache.cc:9-60: the least (use, arrival) of all lines, kept as a two-level minimum
+ * by the bookkeeping; they require that every resident line was updated since its lookup when the planned flow takes over --
+ * true after any lookup + update pair), update counters and the bounded push (cache.cc:159) follow from the ids alone.  ha_cache_plan_block enqueues, on `side`, the index plans of the
  * block's batches and ONE bookkeeping launch that leaves per batch the items of its two row launches; `main` = the stream of
  * those row launches (what is enqueued on it so far is ordered in front of the bookkeeping).  Then, per batch and in order,
  * ha_cache_lookup_planned (ONE launch: the staleness-bounded pull decided as the rows are read, rows to dest) and

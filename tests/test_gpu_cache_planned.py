@@ -263,7 +263,7 @@ def test_planned_flow_refuses_misuse(dev):
 # ---- LFU / LFUOpt (cache_book_lfu_kernel): the same comparisons -----------------------------------------------------------------
 @pytest.mark.parametrize("policy", ["lfu", "lfuopt"])
 @pytest.mark.parametrize("pull_bound,push_bound", [(0, 0), (3, 3), (100, 100)])
-@pytest.mark.parametrize("block,ahead", [(1, False), (4, False), (16, True), (5, True)])
+@pytest.mark.parametrize("block,ahead", [(1, False), (16, True), (5, True)])
 def test_planned_lfu_trace_small(dev, policy, pull_bound, push_bound, block, ahead):
     _run_planned(dev, limit=100, rows=1500, width=8, n=64, steps=64, pull_bound=pull_bound, push_bound=push_bound, block=block,
                  seed=12, ahead=ahead, policy=policy)
