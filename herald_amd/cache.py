@@ -35,6 +35,7 @@ def register_table(node_id, table, versions=None, row_start=0):
     _TABLES[int(node_id)] = (table, versions, int(row_start))
     return versions
 
+_PLAN_STREAMS = {}      # (device index, priority) -> the planning stream the caches of this process share
 
 
 class _LookupMark:
@@ -443,7 +444,18 @@ class _CacheBase:
                     prio = min(lo_hi) if want == "high" else max(lo_hi) if want == "low" else 0
                 except Exception:      # noqa: BLE001
                     prio = 0
-                self._plan_side = torch.cuda.Stream(device=self.device, priority=prio)
+                # ONE planning stream per device for all caches of the process (HA_CACHE_PLAN_SHARED=0: one per cache): which
+                # hardware queue a newly created stream lands on depends on what the process created before, and an unlucky
+                # pairing with the row stream's queue stretched the ROW launches threefold (bench.py's second / third cache:
+                # profiles/r06/cache_tier_third_instance.txt) -- the pair that the first cache got is kept.
+                shared = os.environ.get("HA_CACHE_PLAN_SHARED", "1") == "1"
+                key = (torch.device(self.device).index, prio)
+                if shared and key in _PLAN_STREAMS:
+                    self._plan_side = _PLAN_STREAMS[key]
+                else:
+                    self._plan_side = torch.cuda.Stream(device=self.device, priority=prio)
+                    if shared:
+                        _PLAN_STREAMS[key] = self._plan_side
             side = self._plan_side
         ks = [self._keys(k, []) for k in keys_list]
         kinds = {kind for _, kind in ks}
