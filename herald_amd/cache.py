@@ -124,7 +124,10 @@ class _CacheBase:
 
     # ---- store ---------------------------------------------------------------------------------------
     def bind_store(self, table, versions, row_start=0):
-        assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
+        """The store ("server") the cache fronts: rows [row_start, row_start + table.shape[0]) of the global table and their
+        versions (device int64).  `table`: device memory, or PINNED host memory (device-visible: the cache's kernels then reach
+        the store's rows over PCIe -- the cold tier of BASELINE configs[4] with the store addressed directly)."""
+        assert (table.is_cuda or table.is_pinned()) and table.dtype == torch.float32 and table.is_contiguous()
         assert versions.is_cuda and versions.dtype == torch.int64 and versions.numel() == table.shape[0]
         assert table.shape[1] == self._width
         self._store = (table, versions)

@@ -367,3 +367,34 @@ def test_planned_lfu_and_call_by_call_flows_alternate(dev, policy):
     planned(4, 2)
     classic(3)
     np.testing.assert_array_equal(table.cpu().numpy(), server.table)
+
+
+@pytest.mark.parametrize("policy", ["lru", "lfu"])
+def test_planned_flow_over_a_store_in_pinned_host_memory(dev, policy):
+    """The cold tier addressed directly: the store's rows in PINNED HOST memory (device-visible), its versions in HBM; the
+    planned lookups pull over PCIe, the updates push (read-modify-write) over PCIe -- the model's rows, counters, versions."""
+    limit, rows, width, n = 400, 20000, 64, 352
+    rng = np.random.default_rng(61)
+    table0 = rng.standard_normal((rows, width), dtype=np.float32)
+    server = cache_model.Server(table0)
+    model = cache_model.CacheModel(policy, limit, width, server, 2, 2)
+    table = torch.from_numpy(table0.copy()).pin_memory()
+    versions = torch.zeros(rows, dtype=torch.int64, device=dev)
+    cls = {"lru": hcache.LRUCache, "lfu": hcache.LFUCache}[policy]
+    gpu = cls(limit, rows, width, node_id=0, max_batch=n, device=dev)
+    gpu.bind_store(table, versions)
+    gpu.pull_bound, gpu.push_bound = 2, 2
+    gpu.perf_enabled = True
+    keys_all = [_draw(rng, n, rows, True) for _ in range(24)]
+    kts = [torch.from_numpy(k.astype(np.float32)).to(dev) for k in keys_all]
+    blocks = [list(range(b0, b0 + 8)) for b0 in range(0, 24, 8)]
+    gpu.plan_block([kts[s] for s in blocks[0]])
+    for j, blk in enumerate(blocks):
+        if j + 1 < len(blocks):
+            gpu.plan_block([kts[s] for s in blocks[j + 1]])
+        for step in blk:
+            grads = rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01)
+            _planned_step(dev, gpu, model, keys_all[step], grads, width, step, versions, server)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(table.numpy(), server.table, err_msg="the host table after the pushes")
+    _compare_state(gpu, model, 24)

@@ -563,6 +563,37 @@ def test_cold_tier_on_an_8gib_pinned_host_table(dev):
     np.testing.assert_array_equal(table[torch.tensor(probe)].numpy(), formula.rows_of(probe, width))
     tr = store.traffic()
     assert 0 < tr["rows_pulled"] <= tr["keys_synced"] and tr["lines_pushed"] > 0
+    # ---- the same store addressed DIRECTLY (what bench.py's cold_tier.planned times): a second cache bound to the pinned
+    # table and the HBM versions, six more batches through the planned flow -- pulls and pushes cross PCIe inside the lookup's /
+    # the update's one launch; the server model carries on from the state the first cache's pushes left
+    model2 = cache_model.CacheModel("lru", limit, width, server, 2, 2)
+    gpu2 = hcache.LRUCache(limit, rows, width, node_id=0, max_batch=n, device=dev)
+    gpu2.bind_store(table, store.versions)
+    gpu2.pull_bound = gpu2.push_bound = 2
+    gpu2.perf_enabled = True
+    idl = [synth.criteo_batch(256, 720 + k, rows=rows, nfields=22).reshape(-1) for k in range(6)]
+    idl[3] = idl[0].copy()                      # a batch again: hits, lines pushed by their update counters
+    kts = [torch.from_numpy(i).to(dev) for i in idl]
+    gpu2.plan_block(kts[:3])
+    gpu2.plan_block(kts[3:])
+    for k in range(6):
+        want = model2.lookup(idl[k].astype(np.uint64))
+        dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+        gpu2.embedding_lookup_planned(dest).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="planned lookup rows at step %d" % k)
+        g = rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01)
+        model2.update(idl[k].astype(np.uint64), g)
+        gpu2.embedding_update_planned(torch.from_numpy(g).to(dev)).wait()
+        for got, exp in zip(gpu2.perf[-2:], model2.perf[-2:]):
+            for fld in ("type", "num_all", "num_unique", "num_miss", "num_transfered"):
+                assert got[fld] == exp[fld], (k, fld, got, exp)
+    torch.cuda.synchronize()
+    written = sorted(server.table.rows.keys())
+    np.testing.assert_array_equal(table[torch.tensor(written)].numpy(), np.stack([server.table.rows[k] for k in written]),
+                                  err_msg="host rows after the planned pushes")
+    touched = sorted(server.ver.keys())
+    np.testing.assert_array_equal(store.versions[torch.tensor(touched, device=dev)].cpu().numpy(),
+                                  np.array([server.ver[k] for k in touched], dtype=np.int64))
 
 
 
