@@ -699,7 +699,36 @@ def _cold_tier_body(dev, table, rows, width, steps, seed, first):
     res = model.resident()
     assert sorted(int(k) for k in gpu.keys()) == sorted(res.keys())
     assert gpu.size() == model.policy.size()
+    versions = store.versions
     del gpu, store
+    torch.cuda.synchronize()
+    # ---- the same store addressed directly, through the planned flow (bench.py's cold_tier.planned): three more batches
+    model2 = cache_model.CacheModel("lru", limit, width, server, 2, 2)
+    gpu2 = hcache.LRUCache(limit, rows, width, node_id=0, max_batch=n, device=dev)
+    gpu2.bind_store(table, versions)
+    gpu2.pull_bound = gpu2.push_bound = 2
+    gpu2.perf_enabled = True
+    idl = [synth.criteo_batch(256, first + steps + k, rows=rows, nfields=22).reshape(-1) for k in range(2)]
+    idl.append(idl[0].copy())
+    gpu2.plan_block([torch.from_numpy(i).to(dev) for i in idl])
+    for k in range(3):
+        want = model2.lookup(idl[k].astype(np.uint64))
+        dest = torch.empty((n, width), dtype=torch.float32, device=dev)
+        gpu2.embedding_lookup_planned(dest).wait()
+        np.testing.assert_array_equal(dest.cpu().numpy(), want, err_msg="planned lookup rows at step %d" % k)
+        g = rng.standard_normal((n, width), dtype=np.float32) * np.float32(-0.01)
+        model2.update(idl[k].astype(np.uint64), g)
+        gpu2.embedding_update_planned(torch.from_numpy(g).to(dev)).wait()
+        for got, exp in zip(gpu2.perf[-2:], model2.perf[-2:]):
+            for fld in ("type", "num_all", "num_unique", "num_miss", "num_transfered"):
+                assert got[fld] == exp[fld], (k, fld, got, exp)
+    torch.cuda.synchronize()
+    written2 = sorted(server.table.rows.keys())
+    np.testing.assert_array_equal(table[torch.tensor(written2)].numpy(), np.stack([server.table.rows[k] for k in written2]),
+                                  err_msg="host rows after the planned pushes")
+    assert int(versions.sum().item()) == sum(server.ver.values())
+    assert sorted(int(k) for k in gpu2.keys()) == sorted(model2.resident().keys())
+    del gpu2, versions
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     return top, max(written)
