@@ -208,8 +208,10 @@ def make_batches(nbatch, batch, rows, seed=0, rank=0, world=1):
 
 def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, cache="LRU", bound=0,
           cache_limit=None, seed=0, device="cuda:0", table_init=None, log_every=0, model="wdl", a2a=None, allreduce=None,
-          bsp=0, cache_perf=False, perf_csv_dir=None):
-    """Runs `steps` training steps; returns (losses, embedding parameter, tower).  a2a / allreduce: optional
+          bsp=0, cache_perf=False, perf_csv_dir=None, cache_planned=False):
+    """Runs `steps` training steps; returns (losses, embedding parameter, tower).  cache_planned (--cache-planned, with
+    --embedding cache at bsp 0 on one rank): the cache's planned flow -- the loader's ring hands the communicate op the ids one
+    batch further ahead (`peek_ids`), the bookkeeping of batch k + 1 runs beside the step on batch k.  a2a / allreduce: optional
     replacements of the collectives at world size > 1 (several ranks on one GPU under gloo in the tests)."""
     dev = torch.device(device)
     import torch.distributed as dist
@@ -241,8 +243,9 @@ def train(embedding="hbm", rows=200000, width=32, batch=256, steps=50, lr=0.01, 
         config = hetu_ops.Config(comm_mode="PS" if embedding == "ps" else "Hybrid", bsp=bsp, prefetch=True,
                                  cstable_policy=cache if embedding == "cache" else None, cache_bound=bound,
                                  cache_limit=cache_limit if cache_limit is not None else max(rows // 10, batch * NFIELD),
-                                 cache_perf_enable=cache_perf)
-        comm = hetu_ops.ParameterServerCommunicateOp(param, lr, next_ids=lambda: ids_of(state["k"] + 1))
+                                 cache_perf_enable=cache_perf, cache_plan_ahead=cache_planned)
+        comm = hetu_ops.ParameterServerCommunicateOp(param, lr, next_ids=lambda: ids_of(state["k"] + 1),
+                                                     peek_ids=lambda j: ids_of(state["k"] + 1 + j))
         barrier = dist.barrier if world > 1 else (lambda: None)
         comm.forward_hook(config, first_ids=ids_of(0), barrier=barrier)
     lookup = hetu_ops.EmbeddingLookUp(param)
@@ -365,6 +368,8 @@ def main():
     ap.add_argument("--bsp", type=int, default=-1, help="bsp 0, asp -1, ssp > 0")
     ap.add_argument("--cache", default=None, help="cache policy: lru | lfu | lfuopt (with --comm PS / Hybrid)")
     ap.add_argument("--bound", type=int, default=100, help="cache bound")
+    ap.add_argument("--cache-planned", action="store_true",
+                    help="--embedding cache at --bsp 0: the cache's planned flow (bookkeeping of the next batch beside this step)")
     ap.add_argument("--nepoch", type=int, default=-1, help="epochs of `--steps` steps each (default: one)")
     ap.add_argument("--embedding", choices=["hbm", "step", "step3", "queue", "ps", "cache"], default=None,
                     help="this build's engine names; default: from --comm / --cache")
@@ -403,7 +408,7 @@ def main():
         losses = train(args.embedding, args.rows, args.width, args.batch, args.steps, args.lr, args.cache,
                        args.bound, cache_limit=cache_limit, device="cuda:%d" % local_rank,
                        log_every=max(1, args.steps // 10), model=args.model, bsp=args.bsp if comm is not None else 0,
-                       cache_perf=args.cache_perf)[0]
+                       cache_perf=args.cache_perf, cache_planned=args.cache_planned)[0]
     if local_rank == 0:
         print("first 10 steps: loss %.5f   last 10 steps: loss %.5f" % (np.mean(losses[:10]), np.mean(losses[-10:])))
 

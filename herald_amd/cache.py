@@ -422,7 +422,7 @@ class _CacheBase:
     def plan_block(self, keys_list, side=None):
         """State that the device tensors of `keys_list` (1..16, one dtype, at most min(max_batch, 36,864) keys each) are the
         batches of the NEXT embedding_lookup_planned / embedding_update_planned pairs, in this order (ha_cache_plan_block,
-        csrc/cache_block.hip: a local store; LRU: limit >= max_batch; LFU / LFUOpt: every resident line updated since its lookup, as
+        csrc/cache_block.hip: a local store; LRU: limit >= the batch; LFU / LFUOpt: every resident line updated since its lookup, as
         after any lookup + update pair).  Their index plans and the bookkeeping of the whole
         block -- hits, misses, slots, evictions, update counters, the bounded push: all of it follows from the ids -- run NOW on
         `side` (default: a stream of the cache's own), beside whatever rows the cache's stream is still moving; every lookup and

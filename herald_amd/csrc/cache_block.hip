@@ -1149,15 +1149,17 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
     Cache &c = h->c;
     HA_REQUIRE(c.table && !c.remote && !c.bypass, "cache_plan_block: a cache over a local store, not bypassed");
     HA_REQUIRE(c.row_start == 0 && c.store_rows >= c.length, "cache_plan_block: the store must hold every key of the cache's range");
-    HA_REQUIRE(c.policy != kLRU || c.limit >= c.nmax, "cache_plan_block: limit (%ld) must be at least max_batch (%ld): the lines of "
-               "a batch are never evicted by its own lookup", (long)c.limit, (long)c.nmax);
+
     HA_REQUIRE(c.limit >= 1, "cache_plan_block: an empty cache");
     HA_REQUIRE(h->evict_empty || ha_cache_plan_pending(h) > 0, "cache_plan_block: evicted lines are pending (an update must follow "
                "the last lookup first)");
     HA_REQUIRE(h->ahead_n < 0, "cache_plan_block: a ha_cache_sort_ahead is pending");
-    for (int i = 0; i < count; ++i)
+    for (int i = 0; i < count; ++i) {
         HA_REQUIRE(n[i] >= 0 && n[i] <= c.nmax && n[i] <= kSmallMax && (n[i] == 0 || keys[i]),
                    "cache_plan_block: batch %d of %ld keys (at most min(max_batch, %d))", i, (long)n[i], kSmallMax);
+        HA_REQUIRE(c.policy != kLRU || n[i] <= c.limit, "cache_plan_block: limit (%ld) must be at least the batch (%ld keys): the "
+                   "lines of an LRU batch are never evicted by its own lookup", (long)c.limit, (long)n[i]);
+    }
     PlanSlot &sl = h->plan[h->plan_next & 1];
     HA_REQUIRE(sl.count == 0 || sl.next_call >= 2 * sl.count, "cache_plan_block: two planned blocks are outstanding already");
     if (plan_slot_alloc(h, sl))

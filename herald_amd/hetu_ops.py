@@ -23,8 +23,13 @@ from .sharded import ShardedEmbedding
 
 class Config:
     def __init__(self, comm_mode=None, bsp=0, prefetch=True, cstable_policy=None, cache_bound=100, cache_limit=0,
-                 use_sparse_pull=True, cache_perf_enable=False):
+                 use_sparse_pull=True, cache_perf_enable=False, cache_plan_ahead=False):
         self.comm_mode, self.bsp, self.prefetch = comm_mode, bsp, prefetch
+        # not a HetuConfig field: the cache's PLANNED flow (csrc/cache_block.hip) for the bsp-prefetch schedule -- the bookkeeping
+        # of batch k + 1 runs on a side stream beside the model's step on batch k.  Needs ids one batch further ahead than
+        # get_next_arr gives them: ParameterServerCommunicateOp(..., peek_ids=...); the reference's loader ring is three batches
+        # deep (python/hetu/dataloader.py:63-98), so it has them.
+        self.cache_plan_ahead = cache_plan_ahead
         self.cstable_policy, self.cache_bound, self.cache_limit = cstable_policy, cache_bound, cache_limit
         self.use_sparse_pull = use_sparse_pull
         self.cache_perf_enable = cache_perf_enable        # executor.py: cache_perf_enable (run_hetu.py:508-515 dumps the dicts)
@@ -43,6 +48,10 @@ class EmbeddingParameter:
         self.is_embed = True
         self.cache = None
         self.shape = tuple(table.shape) if table is not None else (store.rows, store.width)
+
+
+def _same_tensor(a, b):
+    return a is not None and a.data_ptr() == b.data_ptr() and a.numel() == b.numel() and a.dtype == b.dtype
 
 
 def scale_(values, factor, stream=None):
@@ -114,10 +123,14 @@ def sgd_update_sparse(param, grad, lr, stream=None):
 
 
 class ParameterServerCommunicateOp:
-    def __init__(self, parameter, learning_rate, next_ids):
+    def __init__(self, parameter, learning_rate, next_ids, peek_ids=None):
+        """peek_ids(j) (optional, Config.cache_plan_ahead): the ids of the batch j batches after the one next_ids() returns,
+        without advancing the loader; None when there is none."""
         self.parameter = parameter
         self.learning_rate = -learning_rate                           # :24
         self.next_ids = next_ids
+        self.peek_ids = peek_ids
+        self._planned = None          # the planned flow: ids tensors of the planned batches, oldest first
 
     def forward_hook(self, config, first_ids=None, barrier=lambda: None):   # :130-242
         self.config, self.barrier = config, barrier
@@ -153,6 +166,8 @@ class ParameterServerCommunicateOp:
             self._push, self._pull, self._push_pull = self._push_cache, self._pull_cache, self._push_pull_cache
             if config.bsp == 0 and config.prefetch:
                 self.compute = self._compute_bsp_prefetch
+                if getattr(config, "cache_plan_ahead", False) and store.world == 1 and self.peek_ids is not None:
+                    self._planned = []        # pull(k + 1) follows push(k) of the same ids batch after batch: the planned pairs
             elif config.prefetch:
                 self.compute = self._compute_asp_prefetch
             else:
@@ -213,6 +228,13 @@ class ParameterServerCommunicateOp:
     # -- cache flavour (:68-72, 88-92, 104-105)
     def _push_cache(self, grad):
         vals = grad.values.reshape(-1, self.parameter.shape[1])
+        if self._planned is not None:
+            idx = grad.indices.reshape(-1)
+            if grad.push_indices is not None or not self._planned or not _same_tensor(self._planned[0], idx):
+                raise RuntimeError("ParameterServerCommunicateOp (cache_plan_ahead): the gradients pushed are not those of the "
+                                   "batch pulled last")
+            self._planned.pop(0)
+            return self.cache.embedding_update_planned(vals)
         if grad.push_indices is None:
             # The executor pushes the gradients of the batch it looked up last (bsp / ssp: push(k) follows pull(k) as the
             # cache's next operation, ParameterServerCommunicate.py:41-56) and does not write the ids in between: when the
@@ -224,7 +246,22 @@ class ParameterServerCommunicateOp:
     def _pull_cache(self, ids):
         if isinstance(ids, tuple):              # (ids, push plan) of a laia-scheduled batch (cstable.py:49)
             ids = ids[0]
-        return self.cache.embedding_lookup(ids.reshape(-1), self.sparse_pull_val.reshape(-1, self.parameter.shape[1]))
+        dest = self.sparse_pull_val.reshape(-1, self.parameter.shape[1])
+        if self._planned is not None:
+            flat = ids.reshape(-1)
+            if not self._planned:                                  # the first pull: nothing planned yet
+                self.cache.plan_block([flat])
+                self._planned.append(flat)
+            if len(self._planned) != 1 or not _same_tensor(self._planned[0], flat):
+                raise RuntimeError("ParameterServerCommunicateOp (cache_plan_ahead): pulls and pushes must alternate, batch "
+                                   "after batch, on the tensors the loader handed out")
+            nxt = self.peek_ids(1)                                 # the batch after this one: its bookkeeping runs from now on,
+            if nxt is not None:                                    # beside this batch's rows and the model's step
+                nxt = (nxt[0] if isinstance(nxt, tuple) else nxt).reshape(-1)
+                self.cache.plan_block([nxt])
+                self._planned.append(nxt)
+            return self.cache.embedding_lookup_planned(dest)      # (no next batch: the next pull plans for itself)
+        return self.cache.embedding_lookup(ids.reshape(-1), dest)
 
     def _push_pull_cache(self, grad):
         nxt = self.next_ids()

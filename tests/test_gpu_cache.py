@@ -196,8 +196,8 @@ def test_lfu_large_cache_parallel_victim_scan(dev, policy):
     """A cache of 65,536+ slots, full, its lowest use bucket empty at the start of a lookup: the oldest line of the lowest
     non-empty bucket (lfu_cache.cc:31-42, lfuopt_cache.cc:48-60) is found by 512 workgroups in a launch of their own
     (cache_scan_victim_part_kernel) instead of one workgroup walking every line -- same trace as the model."""
-    _run_trace(dev, limit=66000, rows=400000, width=4, n=1024, steps=110, pull_bound=2, push_bound=2, zipf=False, seed=31,
-               policy=policy, check_every=55, same=False)
+    _run_trace(dev, limit=62000, rows=400000, width=4, n=1024, steps=84, pull_bound=2, push_bound=2, zipf=False, seed=31,
+               policy=policy, check_every=42, same=False)
 
 
 def test_lfu_trace_with_the_next_batch_sorted_ahead_criteo_width(dev):

@@ -37,10 +37,17 @@ def test_gpu_table_sgd_step_sequence(dev):
         np.testing.assert_array_equal(emb.table.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("mode", ["bsp_prefetch", "asp_prefetch", "no_prefetch"])
+@pytest.mark.parametrize("mode", ["bsp_prefetch", "asp_prefetch", "no_prefetch", "bsp_prefetch_planned", "bsp_prefetch_planned_lfu"])
 def test_hybrid_cache_step_sequence(dev, mode):
-    """comm Hybrid + cache: ParameterServerCommunicateOp in its three schedules (cache.cc flows underneath)."""
+    """comm Hybrid + cache: ParameterServerCommunicateOp in its three schedules (cache.cc flows underneath); *_planned: the
+    bsp-prefetch schedule through the cache's planned flow (Config.cache_plan_ahead + peek_ids: batch k + 1's bookkeeping runs
+    beside batch k's step) -- the same rows, the same server table."""
     rows, width, bs, lr, limit, bound = 3000, 16, 8, 0.1, 200, 1
+    planned = mode.startswith("bsp_prefetch_planned")
+    policy = "lfu" if mode.endswith("_lfu") else "lru"
+    if planned:
+        limit = 300                     # (LRU planned: limit >= the batch)
+        mode = "bsp_prefetch"
     rng = np.random.default_rng(2)
     table0 = rng.standard_normal((rows, width), dtype=np.float32)
     store = ShardedEmbedding(rows, width, dev, table=torch.from_numpy(table0.copy()).to(dev))
@@ -48,25 +55,33 @@ def test_hybrid_cache_step_sequence(dev, mode):
     batches = _batches(8, bs, rows, 9)
     state = {"k": 0}
 
+    ring = [torch.from_numpy(b).to(dev) for b in batches]      # the loader's device buffers: one tensor per batch
+
     def next_ids():
-        return torch.from_numpy(batches[(state["k"] + 1) % len(batches)]).to(dev)
+        return ring[(state["k"] + 1) % len(batches)]
+
+    def peek_ids(j):
+        i = state["k"] + 1 + j
+        return ring[i] if i < len(batches) else None
 
     prefetch = mode != "no_prefetch"
     cfg = hetu_ops.Config(comm_mode="Hybrid", bsp=0 if mode != "asp_prefetch" else -1, prefetch=prefetch,
-                          cstable_policy="LRU", cache_bound=bound, cache_limit=limit)
-    comm = hetu_ops.ParameterServerCommunicateOp(emb, lr, next_ids)
-    comm.forward_hook(cfg, first_ids=torch.from_numpy(batches[0]).to(dev))
+                          cstable_policy=policy.upper(), cache_bound=bound, cache_limit=limit, cache_plan_ahead=planned)
+    comm = hetu_ops.ParameterServerCommunicateOp(emb, lr, next_ids, peek_ids=peek_ids if planned else None)
+    state["k"] = -1
+    comm.forward_hook(cfg, first_ids=ring[0])
+    assert (comm._planned is not None) == planned
     look = hetu_ops.EmbeddingLookUp(emb)
     look.forward_hook(cfg)
     gradop = hetu_ops.EmbeddingLookUp_Gradient(emb.shape)
 
     server = cache_model.Server(table0)
-    model = cache_model.CacheModel("lru", limit, width, server, bound, bound)
+    model = cache_model.CacheModel(policy, limit, width, server, bound, bound)
     pending = model.lookup(batches[0].reshape(-1).astype(np.uint64)) if prefetch else None
     for k in range(len(batches) - 1):
         state["k"] = k
         ids = batches[k]
-        d_ids = torch.from_numpy(ids).to(dev)
+        d_ids = ring[k]
         out = torch.empty((bs, 26, width), dtype=torch.float32, device=dev)
         look.compute(d_ids, out)
         want = pending if prefetch else model.lookup(ids.reshape(-1).astype(np.uint64))

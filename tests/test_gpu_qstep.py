@@ -535,7 +535,7 @@ def test_a_step_whose_queue_was_never_built_raises_and_applies_nothing(dev):
 
 
 def test_a_step_whose_builder_is_late_applies_nothing_and_raises(dev, monkeypatch):
-    """sync="flags", the builder DELAYED past the apply's bound (a 3.5 s occupant kernel in front of it on the preparation
+    """sync="flags", the builder DELAYED past the apply's bound (a 2.9 s occupant kernel in front of it on the preparation
     stream): workgroup 0 of the apply polls for 2 s, publishes "gave up" in the queue, every other workgroup follows that word
     -- the table and the output are exactly what they were, the error word is raised, and the builder completing afterwards
     does not revive the step (one decision per launch: QHeader::verdict, csrc/qstep.hip)."""
@@ -559,13 +559,13 @@ def test_a_step_whose_builder_is_late_applies_nothing_and_raises(dev, monkeypatc
     pipe.step(grads[1], d_ids[L + 1])             # step 1: block 0 done
     torch.cuda.synchronize()
     # the preparation of block 1's start builds the queues of block 2 (steps 4, 5): hold it back
-    _lib.check(_lib.load().ha_debug_occupy(1, 64, 4, 350_000_000, ctypes.c_void_p(pipe.side.cuda_stream)), "occupy")
+    _lib.check(_lib.load().ha_debug_occupy(1, 64, 4, 30_000_000, ctypes.c_void_p(pipe.side.cuda_stream)), "occupy")   # 0.3 s
     pipe.step(grads[2], d_ids[L + 2])             # step 2 (its queue was built a block ago): fine
     pipe.step(grads[3], d_ids[L + 3])             # step 3
     torch.cuda.synchronize()                      # (waits for the occupant and the late builder too)
     before = table.cpu().numpy()
     # queues of steps 4 and 5 exist NOW; rebuild the situation for step 6 instead: hold the builder of block 3's queues back
-    _lib.check(_lib.load().ha_debug_occupy(1, 64, 4, 350_000_000, ctypes.c_void_p(pipe.side.cuda_stream)), "occupy")
+    _lib.check(_lib.load().ha_debug_occupy(1, 64, 4, 290_000_000, ctypes.c_void_p(pipe.side.cuda_stream)), "occupy")   # 2.9 s
     g = _dev(rng.standard_normal((n, width), dtype=np.float32), dev)
     out4 = pipe.step(g, d_ids[L + 4])             # step 4: prepares block 2 -> the queues of steps 6, 7 sit behind the occupant
     out5 = pipe.step(g, d_ids[L + 5])

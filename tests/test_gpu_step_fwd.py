@@ -155,8 +155,8 @@ def test_step_single_batch_and_two_batches(dev):
 
 
 def test_step_criteo_stream(dev):
-    """40 consecutive Criteo-shaped batches (bs=256, d=512) on a 1M-row table, every output row checked."""
-    rows, width, steps = 1_000_000, 512, 40
+    """24 consecutive Criteo-shaped batches (bs=256, d=512) on a 1M-row table, every output row checked."""
+    rows, width, steps = 1_000_000, 512, 24
     rng = np.random.default_rng(77)
     table0 = (rng.standard_normal((rows, width), dtype=np.float32) * np.float32(0.01))
     batches = [synth.criteo_batch(256, step=s).reshape(-1) % rows for s in range(steps)]
