@@ -124,12 +124,13 @@ def sgd_update_sparse(param, grad, lr, stream=None):
 
 class ParameterServerCommunicateOp:
     def __init__(self, parameter, learning_rate, next_ids, peek_ids=None):
-        """peek_ids(j) (optional, Config.cache_plan_ahead): the ids of the batch j batches after the one next_ids() returns,
-        without advancing the loader; None when there is none."""
+        """peek_ids(j) (optional, Config.cache_plan_ahead): the ids of the batch j batches after the one next_ids() returns
+        (peek_ids(0) = that batch itself), without advancing the loader; None when there is none."""
         self.parameter = parameter
         self.learning_rate = -learning_rate                           # :24
         self.next_ids = next_ids
         self.peek_ids = peek_ids
+        self._peek_offset = 1
         self._planned = None          # the planned flow: ids tensors of the planned batches, oldest first
 
     def forward_hook(self, config, first_ids=None, barrier=lambda: None):   # :130-242
@@ -188,7 +189,10 @@ class ParameterServerCommunicateOp:
                 ids = ids[0]
             self.sparse_pull_val = torch.empty(tuple(ids.shape) + (p.shape[1],), dtype=torch.float32,
                                                device=ids.device)
+            # (peek_ids counts from the batch next_ids() returns: an explicit first batch is the one before it)
+            self._peek_offset = 0 if first_ids is not None else 1
             config.ps_map[p] = (self._pull(ids), self.sparse_pull_val)
+            self._peek_offset = 1
 
     # -- compute variants (:37-56)
     def _mult_lr(self, grad):
@@ -255,7 +259,7 @@ class ParameterServerCommunicateOp:
             if len(self._planned) != 1 or not _same_tensor(self._planned[0], flat):
                 raise RuntimeError("ParameterServerCommunicateOp (cache_plan_ahead): pulls and pushes must alternate, batch "
                                    "after batch, on the tensors the loader handed out")
-            nxt = self.peek_ids(1)                                 # the batch after this one: its bookkeeping runs from now on,
+            nxt = self.peek_ids(self._peek_offset)                 # the batch after this one: its bookkeeping runs from now on,
             if nxt is not None:                                    # beside this batch's rows and the model's step
                 nxt = (nxt[0] if isinstance(nxt, tuple) else nxt).reshape(-1)
                 self.cache.plan_block([nxt])

@@ -68,7 +68,6 @@ def test_hybrid_cache_step_sequence(dev, mode):
     cfg = hetu_ops.Config(comm_mode="Hybrid", bsp=0 if mode != "asp_prefetch" else -1, prefetch=prefetch,
                           cstable_policy=policy.upper(), cache_bound=bound, cache_limit=limit, cache_plan_ahead=planned)
     comm = hetu_ops.ParameterServerCommunicateOp(emb, lr, next_ids, peek_ids=peek_ids if planned else None)
-    state["k"] = -1
     comm.forward_hook(cfg, first_ids=ring[0])
     assert (comm._planned is not None) == planned
     look = hetu_ops.EmbeddingLookUp(emb)
