@@ -28,7 +28,9 @@ def pmc_traffic(batch, width):
     return None, None
 
 
-def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags", distinct=32, lr=1e-6, alone=False):
+def measure(table, rows, batch, width, fields=26, block=16, steps=96, sync="flags", distinct=32, lr=1e-6, alone=False):
+    """block: steps per preparation block (16 as the headline: 47.4–47.5 / 35.3–36.0 µs per step at the two shapes against
+    49.1 / 36.6 with blocks of 4, docs/EXPERIMENTS.md round 6 §9)."""
     from . import ops, synth
     dev = table.device
     n = batch * fields
@@ -46,7 +48,7 @@ def measure(table, rows, batch, width, fields=26, block=4, steps=96, sync="flags
     LA = pipe.LOOKAHEAD
     s = torch.cuda.Stream(device=dev)
     ids_of = lambda j: ids[j % distinct] if j >= 0 else None
-    warm = 6 * block
+    warm = max(24, 3 * block)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     with torch.cuda.stream(s):

@@ -10,7 +10,7 @@ rows, width, bs = 33762577, int(os.environ.get("WIDTH", "128")), int(os.environ.
 table = torch.empty((rows, width), device=dev)
 for s in range(0, rows, 1 << 21):
     table[s:s + (1 << 21)].normal_(0, 0.01)
-r = wide_bench.measure(table, rows, bs, width, block=int(os.environ.get("BLOCK", "4")), steps=int(os.environ.get("STEPS", "96")),
+r = wide_bench.measure(table, rows, bs, width, block=int(os.environ.get("BLOCK", "16")), steps=int(os.environ.get("STEPS", "96")),
                        sync=os.environ.get("SYNC", "flags"), alone=os.environ.get("ALONE") == "1")
 print("bs=%d d=%d: %.2f us/step  %.1f M rows/s  frac %.3f of 8 TB/s  (%s)" % (bs, width, r["us_per_step"], r["rows_per_s"] / 1e6,
                                                                           r["roofline"]["frac"], r["stream_sync"]))
