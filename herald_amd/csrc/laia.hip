@@ -390,9 +390,10 @@ __global__ __launch_bounds__(256) void laia_delta_kernel(const uint32_t *__restr
 //    still have quota, visited in the order (j + batch_id) % W): until a worker's quota fills every sample's choice
 //    is independent of the others, so ONE workgroup runs rounds of { argmax over the available workers, prefix
 //    counts per worker, first sample at which a quota fills }: at most W + 1 rounds instead of B dependent steps.
-//  * sorted-unique (worker, row) lists without a sort: laia_bits_kernel sets one bit per touched / plan pair in two
-//    bitmaps over W x Rpad rows (and one bit per non-empty 64-bit word in a summary), and an ordered compaction of
-//    the summary (count, scan, emit -- which also clears what it read) yields the rows ascending per worker.
+//  * sorted-unique (worker, row) lists without a sort: laia_bits_kernel sets one flag byte per touched / plan pair (and per
+//    group of 64 rows, per chunk of 4,096) with plain stores, laia_bits_pack_kernel turns the flags of the chunks that have
+//    any into bit words (one per 64 rows) + a summary word per chunk and counts them, and an ordered compaction (scan, emit
+//    -- which also clears what it read) yields the rows ascending per worker.
 //  * MiniLRU per worker as a stamp log (as the host Snapshot above and cache.hip): stamp[w][row] (0 = absent), a
 //    ring log of (row, stamp), valid bytes = the device mirror the probe reads.  A batch's get()s come in ascending
 //    row order and the rows are distinct, so row i of n ends with stamp counter + i + 1 whatever happens; what has
@@ -585,59 +586,43 @@ __global__ __launch_bounds__(128) void laia_topk_assign_kernel(const int32_t *__
 // row -- named by thousands of samples of a batch -- shows up many times per wave.  Every distinct bit of a wave is set
 // by one lane (leader loop over the distinct values), and only if a look at the word says it is not set yet: a few
 // atomics per hot row and batch instead of thousands on one address.
-__device__ __forceinline__ void laia_set_bits(unsigned long long *__restrict__ bits, unsigned long long *__restrict__ sum,
-                                              uint32_t *__restrict__ nset, unsigned long long b, bool on) {
-    // leader = the lowest lane of every distinct value (register-only loop), then all leaders go to memory at once
-    unsigned long long todo = __ballot(on);
-    bool leader = false;
-    while (todo) {
-        const int first = __builtin_ctzll(todo);
-        const unsigned long long v = __shfl(b, first, 64);
-        const unsigned long long same = __ballot(on && b == v);
-        todo &= ~same;
-        leader = leader || static_cast<int>(threadIdx.x & 63) == first;
-    }
-    if (leader && !((__atomic_load_n(&bits[b >> 6], __ATOMIC_RELAXED) >> (b & 63)) & 1ull)) {
-        const unsigned long long old = atomicOr(&bits[b >> 6], 1ull << (b & 63));
-        if (old == 0)
-            atomicOr(&sum[b >> 12], 1ull << ((b >> 6) & 63));
-        if (!((old >> (b & 63)) & 1ull))
-            atomicAdd(&nset[b >> 12], 1u);      // bits set below this summary word: what the compaction scans
-    }
-}
-
+// One flag BYTE per (worker, row) pair named and one per group of 64 rows -- plain stores, no
+// atomics, no look, no duplicate elimination (a flag is set to 1 by whoever names it).  Until round 6 this launch set BITS
+// with atomicOr (and counted the new ones per chunk with atomicAdd): 36-46 us of a 120 us global batch, all of it the ~130 k
+// scattered device-scope atomics of a batch -- they execute at the memory side, one 64-byte request each, and a batch's rows
+// share no lines (stage exits: loads 4.7 us, + duplicate elimination 7.3, + looks 7.7, + atomics 45.8; one atomic per wave and
+// address instead of one per lane: 43 -- docs/EXPERIMENTS.md round 6 section 10).  laia_bits_pack_kernel turns the flags of the
+// chunks that have any into the bit words the compaction reads.
+struct LaiaFlags {
+    uint8_t *row[2];        // [W * Rpad]        0 = touch, 1 = plan
+    uint8_t *g64[2];        // [W * Rpad / 64]   (a chunk of 4,096 rows = 64 of these = one 64-byte line)
+};
 __global__ __launch_bounds__(256) void laia_bits_kernel(const uint32_t *__restrict__ samples, long long S, int T,
                                                         long long start, int B, int W,
                                                         const unsigned long long *__restrict__ mask,
                                                         const int32_t *__restrict__ owner, long long R, long long Rpad,
-                                                        unsigned long long *__restrict__ tbits,
-                                                        unsigned long long *__restrict__ tsum,
-                                                        unsigned long long *__restrict__ pbits,
-                                                        unsigned long long *__restrict__ psum,
-                                                        uint32_t *__restrict__ tnset, uint32_t *__restrict__ pnset,
-                                                        int own_plan) {
+                                                        LaiaFlags f, int own_plan) {
     const long long total = static_cast<long long>(B) * T;
-    const long long trips = (total + gridDim.x * 256ll - 1) / (gridDim.x * 256ll);     // whole waves make every trip
-    for (long long tr = 0; tr < trips; ++tr) {
-        const long long e = tr * gridDim.x * 256ll + blockIdx.x * 256ll + threadIdx.x;
-        uint32_t emb = 0;
-        int ow = 0;
-        unsigned long long m = 0;
-        bool live = false;
-        if (e < total) {
-            const int j = static_cast<int>(e / B);
-            const long long i = e - static_cast<long long>(j) * B;
-            emb = samples[((start + i) % S) * T + j];
-            live = emb < R;
-            ow = owner[i];
-            // LaiaScheduler: rows valid at w in samples NOT assigned to w (laia_scheduler.cc:252-270); TopkScheduler: rows of
-            // w's OWN samples that w holds valid (topk_scheduler.cc:468-500)
-            m = live ? (own_plan ? (mask[i * T + j] & (1ull << ow)) : (mask[i * T + j] & ~(1ull << ow))) : 0ull;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        const int j = static_cast<int>(e / B);
+        const long long i = e - static_cast<long long>(j) * B;
+        const uint32_t emb = samples[((start + i) % S) * T + j];
+        if (emb >= R)
+            continue;
+        const int ow = owner[i];
+        // LaiaScheduler: rows valid at w in samples NOT assigned to w (laia_scheduler.cc:252-270); TopkScheduler: rows of
+        // w's OWN samples that w holds valid (topk_scheduler.cc:468-500)
+        unsigned long long m = own_plan ? (mask[i * T + j] & (1ull << ow)) : (mask[i * T + j] & ~(1ull << ow));
+        const unsigned long long b = static_cast<unsigned long long>(ow) * Rpad + emb;
+        f.row[0][b] = 1;
+        f.g64[0][b >> 6] = 1;
+        while (m) {
+            const int w = __builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned long long p = static_cast<unsigned long long>(w) * Rpad + emb;
+            f.row[1][p] = 1;
+            f.g64[1][p >> 6] = 1;
         }
-        laia_set_bits(tbits, tsum, tnset, static_cast<unsigned long long>(ow) * Rpad + emb, live);
-        for (int w = 0; w < W; ++w)
-            if (__ballot((m >> w) & 1ull))       // wave-uniform: some lane names worker w
-                laia_set_bits(pbits, psum, pnset, static_cast<unsigned long long>(w) * Rpad + emb, ((m >> w) & 1ull) != 0);
     }
 }
 
@@ -645,7 +630,6 @@ struct LaiaBits {
     unsigned long long *bits[2], *sum[2];   // 0 = touch, 1 = plan
     uint32_t *rows[2];                      // output: rows ascending per worker
     int32_t *off[2];                        // [W + 1]
-    uint32_t *nset[2];                      // bits set below every summary word (counted by laia_bits_kernel)  [nsum]
     uint32_t *cnt[2];                       // exclusive offsets inside a block  [nsum]
     uint32_t *blk[2];                       // per-block totals, then exclusive offsets   [nblk + 1]
 };
@@ -674,25 +658,79 @@ __device__ __forceinline__ uint32_t laia_block_scan_u32(uint32_t v, uint32_t *s_
     return base + incl - v;
 }
 
-// exclusive offsets of the summary words inside blocks of 16 (the counts come from laia_bits_kernel), block totals
-__global__ __launch_bounds__(1024) void laia_bits_count_kernel(LaiaBits a, long long nsum) {
+// The flags of a chunk (4,096 rows = one summary word) as the compaction wants them: the summary word (bit k = group k of 64
+// rows holds a flag), per group its 64-bit data word, the number of rows -- and the flags cleared.  A workgroup = the 16
+// chunks of one offset group, four per wave (most chunks are empty: fewer, longer-lived waves); it also leaves the exclusive
+// offsets of its chunks inside the group and the group's total (what the scan and the emit go by).
+__global__ __launch_bounds__(256) void laia_bits_pack_kernel(LaiaBits a, LaiaFlags f, long long nsum) {
+    __shared__ uint32_t s_c[16];
     const int which = blockIdx.y;
-    const long long y = blockIdx.x * 1024ll + threadIdx.x;     // summary word; 16 consecutive ones form an emit block
-    const int lane = threadIdx.x & 63;
-    uint32_t c = y < nsum ? a.nset[which][y] : 0u;
-    if (y < nsum && c)
-        a.nset[which][y] = 0;
-    uint32_t incl = c;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long x0 = blockIdx.x * 16ll + wv * 4;
+    uint8_t gf[4];
+    unsigned long long sw[4];
+    // (the group flags of a chunk are one 64-byte line: read for every chunk, 2 x 2 MB per batch at configs[3]'s size -- a
+    // flag per chunk in front of them was one more dependent trip for every wave)
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o, 64);
-        if ((lane & 15) >= o)
-            incl += v;
+    for (int i = 0; i < 4; ++i)
+        gf[i] = x0 + i < nsum ? f.g64[which][(x0 + i) * 64 + lane] : 0;
+    uint4 rb[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sw[i] = __ballot(gf[i] != 0);
+        const uint4 *p = reinterpret_cast<const uint4 *>(f.row[which] + ((x0 + i) * 64 + lane) * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            rb[i][q] = gf[i] ? p[q] : uint4{0u, 0u, 0u, 0u};
     }
-    if (y < nsum) {
-        a.cnt[which][y] = incl - c;
-        if ((lane & 15) == 15 || y == nsum - 1)
-            a.blk[which][y >> 4] = incl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long x = x0 + i;
+        uint32_t c = 0;
+        if (sw[i]) {                                                        // (wave-uniform)
+            unsigned long long dw = 0;
+            if (gf[i]) {
+                // 64 flag bytes (0 / 1) -> 64 bits: four bytes of a word to a nibble by one multiply
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t v[4] = {rb[i][q].x, rb[i][q].y, rb[i][q].z, rb[i][q].w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        dw |= static_cast<unsigned long long>((v[d] * 0x01020408u) >> 24 & 0xFu) << (16 * q + 4 * d);
+                }
+                uint4 *p = reinterpret_cast<uint4 *>(f.row[which] + (x * 64 + lane) * 64);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    p[q] = uint4{0u, 0u, 0u, 0u};
+                f.g64[which][x * 64 + lane] = 0;
+                a.bits[which][x * 64 + lane] = dw;
+            }
+            c = static_cast<uint32_t>(__builtin_popcountll(dw));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                c += __shfl_xor(c, o, 64);
+            if (lane == 0)
+                a.sum[which][x] = sw[i];
+        }
+        if (lane == 0)
+            s_c[wv * 4 + i] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const uint32_t c = s_c[threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (static_cast<int>(threadIdx.x) >= o)
+                incl += v;
+        }
+        const long long y = blockIdx.x * 16ll + threadIdx.x;
+        if (y < nsum) {
+            a.cnt[which][y] = incl - c;
+            if (threadIdx.x == 15 || y == nsum - 1)
+                a.blk[which][blockIdx.x] = incl;
+        }
     }
 }
 
@@ -1061,6 +1099,7 @@ struct LaiaDev {
     int nblk = 0, cand_cap = 0;
     uint32_t debug_wrap_at = 0xFFFFFF00u;
     LaiaBits bits{};
+    LaiaFlags flags{};
     LaiaLru lru{};
     long long *d_dist = nullptr;
     // what the host reads per batch sits in ONE device block -- dist [W * Bcap], offsets [2 * (W + 1)], states [W] --
@@ -1382,7 +1421,8 @@ static int laia_dev_init(Laia &l) {
         alloc(reinterpret_cast<void **>(&d.bits.sum[k]), static_cast<size_t>(d.nsum) * 8, true);
         alloc(reinterpret_cast<void **>(&d.bits.rows[k]), (k == 0 ? BT : l.plan_cap) * 4, false);
         alloc(reinterpret_cast<void **>(&d.bits.cnt[k]), static_cast<size_t>(d.nsum) * 4, false);
-        alloc(reinterpret_cast<void **>(&d.bits.nset[k]), static_cast<size_t>(d.nsum) * 4, true);
+        alloc(reinterpret_cast<void **>(&d.flags.row[k]), static_cast<size_t>(W) * d.Rpad, true);
+        alloc(reinterpret_cast<void **>(&d.flags.g64[k]), nwords, true);
         alloc(reinterpret_cast<void **>(&d.bits.blk[k]), static_cast<size_t>(d.nblk + 1) * 4, false);
     }
     d.off_at = static_cast<size_t>(l.Bcap) * 8;                                   // dist holds one entry per sample
@@ -1511,10 +1551,8 @@ static int laia_dev_issue(ha_laia *h, int64_t batch_id, int64_t mini_bs, int onl
         hipLaunchKernelGGL(laia_assign_kernel, dim3(1), dim3(1024), lds_scores ? sc_bytes : 0, l.stream, l.d_scores, (int)B, W,
                            (int)mini_bs, (long long)batch_id, start, l.S, l.d_owner, d.d_dist, lds_scores);
     hipLaunchKernelGGL(laia_bits_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
-                       l.d_mask, l.d_owner, l.R, d.Rpad, d.bits.bits[0], d.bits.sum[0], d.bits.bits[1], d.bits.sum[1],
-                       d.bits.nset[0], d.bits.nset[1], topk ? 1 : 0);
-    hipLaunchKernelGGL(laia_bits_count_kernel, dim3(static_cast<unsigned>((d.nsum + 1023) / 1024), 2), dim3(1024), 0, l.stream,
-                       d.bits, d.nsum);
+                       l.d_mask, l.d_owner, l.R, d.Rpad, d.flags, topk ? 1 : 0);
+    hipLaunchKernelGGL(laia_bits_pack_kernel, dim3(d.nblk, 2), dim3(256), 0, l.stream, d.bits, d.flags, d.nsum);
     hipLaunchKernelGGL(laia_bits_scan_kernel, dim3(2), dim3(1024), 0, l.stream, d.bits, d.nblk);
     hipLaunchKernelGGL(laia_bits_emit_kernel, dim3(d.nblk, 2), dim3(256), 0, l.stream, d.bits, d.nsum, d.sum_per_worker, W,
                        d.Rpad);
