@@ -659,78 +659,91 @@ __device__ __forceinline__ uint32_t laia_block_scan_u32(uint32_t v, uint32_t *s_
 }
 
 // The flags of a chunk (4,096 rows = one summary word) as the compaction wants them: the summary word (bit k = group k of 64
-// rows holds a flag), per group its 64-bit data word, the number of rows -- and the flags cleared.  A workgroup = the 16
-// chunks of one offset group, four per wave (most chunks are empty: fewer, longer-lived waves); it also leaves the exclusive
-// offsets of its chunks inside the group and the group's total (what the scan and the emit go by).
-__global__ __launch_bounds__(256) void laia_bits_pack_kernel(LaiaBits a, LaiaFlags f, long long nsum) {
-    __shared__ uint32_t s_c[16];
+// rows holds a flag), per group its 64-bit data word, the number of rows -- and the flags cleared.  ONE WAVE = the 16 chunks of
+// one offset group, in TWO trips to memory whatever the chunks hold: the sixteen lines of group flags at once, then the flagged
+// groups -- a handful per wave for the sparse tables -- dealt out one per LANE (64 per round), whichever chunk they belong to.
+// (A lane per group of its own chunk, four chunks a wave: 16.5 k waves, 27 us; the same with sixteen chunks a wave in four
+// dependent rounds: 30 us -- stage exits: the flag lines 6 us, + the row flags 21.)  It also leaves the exclusive offsets of its
+// chunks inside the group and the group's total (what the scan and the emit go by).
+__global__ __launch_bounds__(64) void laia_bits_pack_kernel(LaiaBits a, LaiaFlags f, long long nsum) {
+    __shared__ unsigned long long s_sw[16];
+    __shared__ uint32_t s_cnt[16], s_base[17];
     const int which = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long x0 = blockIdx.x * 16ll + wv * 4;
-    uint8_t gf[4];
-    unsigned long long sw[4];
-    // (the group flags of a chunk are one 64-byte line: read for every chunk, 2 x 2 MB per batch at configs[3]'s size -- a
-    // flag per chunk in front of them was one more dependent trip for every wave)
+    const int lane = threadIdx.x & 63;
+    const long long x0 = blockIdx.x * 16ll;
+    uint8_t gf[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        gf[i] = x0 + i < nsum ? f.g64[which][(x0 + i) * 64 + lane] : 0;
-    uint4 rb[4][4];
+    for (int c = 0; c < 16; ++c)
+        gf[c] = x0 + c < nsum ? f.g64[which][(x0 + c) * 64 + lane] : 0;
+    uint32_t total = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sw[i] = __ballot(gf[i] != 0);
-        const uint4 *p = reinterpret_cast<const uint4 *>(f.row[which] + ((x0 + i) * 64 + lane) * 64);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            rb[i][q] = gf[i] ? p[q] : uint4{0u, 0u, 0u, 0u};
+    for (int c = 0; c < 16; ++c) {
+        const unsigned long long sw = __ballot(gf[c] != 0);
+        if (lane == 0) {
+            s_sw[c] = sw;
+            s_base[c] = total;
+            s_cnt[c] = 0;
+            if (sw)
+                a.sum[which][x0 + c] = sw;
+        }
+        total += static_cast<uint32_t>(__builtin_popcountll(sw));      // (wave-uniform)
     }
+    if (lane == 0)
+        s_base[16] = total;
+    __builtin_amdgcn_s_barrier();          // (one wave: orders the LDS words)
+    // flagged group t of the wave (chunks in order, groups in order) -> lane t % 64, round t / 64
+    for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        int c = -1, k = 0;
+        if (t < total) {
+            c = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long long x = x0 + i;
-        uint32_t c = 0;
-        if (sw[i]) {                                                        // (wave-uniform)
-            unsigned long long dw = 0;
-            if (gf[i]) {
-                // 64 flag bytes (0 / 1) -> 64 bits: four bytes of a word to a nibble by one multiply
+            for (int q = 1; q < 16; ++q)
+                c += t >= s_base[q] ? 1 : 0;
+            // the (t - base)-th set bit of the chunk's summary word
+            unsigned long long w = s_sw[c];
+            for (uint32_t r = t - s_base[c]; r > 0; --r)
+                w &= w - 1;
+            k = __builtin_ctzll(w);
+        }
+        unsigned long long dw = 0;
+        if (c >= 0) {
+            const long long grp = (x0 + c) * 64 + k;
+            uint4 *p = reinterpret_cast<uint4 *>(f.row[which] + grp * 64);
+            uint4 rb[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t v[4] = {rb[i][q].x, rb[i][q].y, rb[i][q].z, rb[i][q].w};
+            for (int q = 0; q < 4; ++q)
+                rb[q] = p[q];
+            // 64 flag bytes (0 / 1) -> 64 bits: four bytes of a word to a nibble by one multiply
 #pragma unroll
-                    for (int d = 0; d < 4; ++d)
-                        dw |= static_cast<unsigned long long>((v[d] * 0x01020408u) >> 24 & 0xFu) << (16 * q + 4 * d);
-                }
-                uint4 *p = reinterpret_cast<uint4 *>(f.row[which] + (x * 64 + lane) * 64);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t v[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    p[q] = uint4{0u, 0u, 0u, 0u};
-                f.g64[which][x * 64 + lane] = 0;
-                a.bits[which][x * 64 + lane] = dw;
+                for (int d = 0; d < 4; ++d)
+                    dw |= static_cast<unsigned long long>((v[d] * 0x01020408u) >> 24 & 0xFu) << (16 * q + 4 * d);
             }
-            c = static_cast<uint32_t>(__builtin_popcountll(dw));
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-                c += __shfl_xor(c, o, 64);
-            if (lane == 0)
-                a.sum[which][x] = sw[i];
+            for (int q = 0; q < 4; ++q)
+                p[q] = uint4{0u, 0u, 0u, 0u};
+            f.g64[which][grp] = 0;
+            a.bits[which][grp] = dw;
+            atomicAdd(&s_cnt[c], static_cast<uint32_t>(__builtin_popcountll(dw)));
         }
-        if (lane == 0)
-            s_c[wv * 4 + i] = c;
     }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        const uint32_t c = s_c[threadIdx.x];
-        uint32_t incl = c;
+    __builtin_amdgcn_s_barrier();
+    const uint32_t myc = lane < 16 ? s_cnt[lane] : 0u;
+    uint32_t incl = myc;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o, 64);
-            if (static_cast<int>(threadIdx.x) >= o)
-                incl += v;
-        }
-        const long long y = blockIdx.x * 16ll + threadIdx.x;
-        if (y < nsum) {
-            a.cnt[which][y] = incl - c;
-            if (threadIdx.x == 15 || y == nsum - 1)
-                a.blk[which][blockIdx.x] = incl;
-        }
+    for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if (lane >= o)
+            incl += v;
+    }
+    const long long y = x0 + lane;
+    if (lane < 16 && y < nsum) {
+        a.cnt[which][y] = incl - myc;
+        if (lane == 15 || y == nsum - 1)
+            a.blk[which][blockIdx.x] = incl;
     }
 }
 
@@ -1552,7 +1565,7 @@ static int laia_dev_issue(ha_laia *h, int64_t batch_id, int64_t mini_bs, int onl
                            (int)mini_bs, (long long)batch_id, start, l.S, l.d_owner, d.d_dist, lds_scores);
     hipLaunchKernelGGL(laia_bits_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
                        l.d_mask, l.d_owner, l.R, d.Rpad, d.flags, topk ? 1 : 0);
-    hipLaunchKernelGGL(laia_bits_pack_kernel, dim3(d.nblk, 2), dim3(256), 0, l.stream, d.bits, d.flags, d.nsum);
+    hipLaunchKernelGGL(laia_bits_pack_kernel, dim3(d.nblk, 2), dim3(64), 0, l.stream, d.bits, d.flags, d.nsum);
     hipLaunchKernelGGL(laia_bits_scan_kernel, dim3(2), dim3(1024), 0, l.stream, d.bits, d.nblk);
     hipLaunchKernelGGL(laia_bits_emit_kernel, dim3(d.nblk, 2), dim3(256), 0, l.stream, d.bits, d.nsum, d.sum_per_worker, W,
                        d.Rpad);
