@@ -111,12 +111,13 @@ constexpr size_t kScatterLdsBytes =
 // of a kernel boundary and a second read of the keys.  The flags are zeroed by the first pass's scatter (`flags_reset`),
 // pass k waits for the value k: no epoch survives a call, so the launches replay from a hipGraph unchanged.
 template <bool PRESCANNED, bool MSD = false, bool FUSED = false>
-__global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
+__device__ __forceinline__ void radix_scatter_body(
+    const int bx,      // the tile (bx of a launch over ONE sort; of the batched launch: within the sort blockIdx.y names)
     const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ perm_in,
     int n, int shift, int nblk, const uint32_t *hist,
     uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out,
-    uint32_t *__restrict__ bucket_start = nullptr, uint32_t *flags = nullptr, uint32_t flag_value = 0,
-    uint32_t *flags_reset = nullptr, long long *timeout_word = nullptr) {
+    uint32_t *__restrict__ bucket_start, uint32_t *flags, uint32_t flag_value,
+    uint32_t *flags_reset, long long *timeout_word) {
     constexpr int kRows = kRadixTile / kScatterThreads;        // rows of 64 keys per wave
     constexpr int kPerThread = kRadixBuckets / kScatterThreads;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
     const int lane = lane_id(), w = threadIdx.x >> 6;
     // HA_RADIX_STAMPS=1 (tools/radix_phases.py): the last workgroup's clock at its phase boundaries, in the bucket-start
     // scratch of the (unused here) bucket sort; slot 8 * pass + phase
-    unsigned long long *stamps = (!MSD && bucket_start != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    unsigned long long *stamps = (!MSD && bucket_start != nullptr && bx == nblk - 1 && threadIdx.x == 0)
                                      ? reinterpret_cast<unsigned long long *>(bucket_start) + 8 * flag_value : nullptr;
 #define RADIX_STAMP(i)                                                  \
     do {                                                                \
@@ -137,11 +138,11 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
     RADIX_STAMP(0);
     for (int k = threadIdx.x; k < kScatterWaves * kRadixBuckets / 2; k += kScatterThreads)
         s_dyn[k] = 0;
-    if (flags_reset != nullptr && blockIdx.x == 0 && threadIdx.x < kRadixFusedBlocks)
+    if (flags_reset != nullptr && bx == 0 && threadIdx.x < kRadixFusedBlocks)
         flags_reset[threadIdx.x] = 0;      // the fused passes behind this launch count from here
     __syncthreads();
 
-    const int wbase = blockIdx.x * kRadixTile + w * (kRows * 64);
+    const int wbase = bx * kRadixTile + w * (kRows * 64);
     uint32_t key[kRows];
     int32_t val[kRows];
     uint32_t lrank[kRows];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
         // digits 2t, 2t + 1 -- the ones it owns below), half the bytes every workgroup pulls through its one compute
         // unit when it sums the tiles (26 x 8 KB as 32-bit counts: 3.6 us of an 11.9 us pass)
         static_assert(kPerThread == 2 && kRadixTile <= 0xFFFF, "two 16-bit counts per thread and word");
-        uint32_t *mine_h = const_cast<uint32_t *>(hist) + static_cast<size_t>(blockIdx.x) * kRadixBuckets;
+        uint32_t *mine_h = const_cast<uint32_t *>(hist) + static_cast<size_t>(bx) * kRadixBuckets;
         {
             uint32_t c0 = 0, c1 = 0;
 #pragma unroll
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
         __builtin_amdgcn_s_waitcnt(0);      // the stores have left for memory before the flag follows them
         __syncthreads();
         if (threadIdx.x == 0)
-            __hip_atomic_store(flags + blockIdx.x, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + bx, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (static_cast<int>(threadIdx.x) < nblk) {
             // All tiles of a pass are resident at once (at most kRadixFusedBlocks workgroups), so every flag arrives; the
             // programming model does not promise that, hence the bound: about a second of polling, then the sticky word
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
         if (PRESCANNED) {
 #pragma unroll
             for (int q = 0; q < kPerThread; ++q)
-                run[q] = hist[(d0 + q) * nblk + blockIdx.x];
+                run[q] = hist[(d0 + q) * nblk + bx];
         } else {
             // coalesced pass over the tile-major histograms (thread t sums digits t, t+1024), then
             // through LDS to the thread that owns consecutive digits
@@ -250,8 +251,8 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
                         const uint32_t lo = k < nblk ? v[kk] & 0xFFFFu : 0u, hi = k < nblk ? v[kk] >> 16 : 0u;
                         tot[0] += lo;
                         tot[1] += hi;
-                        mine[0] += k < static_cast<int>(blockIdx.x) ? lo : 0u;
-                        mine[1] += k < static_cast<int>(blockIdx.x) ? hi : 0u;
+                        mine[0] += k < static_cast<int>(bx) ? lo : 0u;
+                        mine[1] += k < static_cast<int>(bx) ? hi : 0u;
                     }
                 }
             }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
                     const int k = k0 + kk;
 #pragma unroll
                     for (int q = 0; q < kPerThread; ++q) {
-                        mine[q] += k < static_cast<int>(blockIdx.x) ? v[kk][q] : 0u;   // k < blockIdx.x implies k < nblk
+                        mine[q] += k < static_cast<int>(bx) ? v[kk][q] : 0u;   // k < bx implies k < nblk
                         tot[q] += k < nblk ? v[kk][q] : 0u;
                     }
                 }
@@ -313,12 +314,12 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
                 off += s_scan[k];
 #pragma unroll
             for (int q = 0; q < kPerThread; ++q) {
-                if (MSD && blockIdx.x == 0)       // first sorted position of every bucket (mine == 0 here)
+                if (MSD && bx == 0)       // first sorted position of every bucket (mine == 0 here)
                     bucket_start[d0 + q] = off;
                 run[q] = off + mine[q];
                 off += tot[q];
             }
-            if (MSD && blockIdx.x == 0 && threadIdx.x == kScatterThreads - 1)
+            if (MSD && bx == 0 && threadIdx.x == kScatterThreads - 1)
                 bucket_start[kRadixBuckets] = off;
         }
 #pragma unroll
@@ -350,6 +351,40 @@ __global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
         stamps[6] = __builtin_amdgcn_s_memrealtime();
     }
 #undef RADIX_STAMP
+}
+
+template <bool PRESCANNED, bool MSD = false, bool FUSED = false>
+__global__ __launch_bounds__(kScatterThreads) void radix_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ perm_in,
+    int n, int shift, int nblk, const uint32_t *hist,
+    uint32_t *__restrict__ keys_out, int32_t *__restrict__ perm_out,
+    uint32_t *__restrict__ bucket_start = nullptr, uint32_t *flags = nullptr, uint32_t flag_value = 0,
+    uint32_t *flags_reset = nullptr, long long *timeout_word = nullptr) {
+    radix_scatter_body<PRESCANNED, MSD, FUSED>(static_cast<int>(blockIdx.x), keys_in, perm_in, n, shift, nblk, hist, keys_out,
+                                               perm_out, bucket_start, flags, flag_value, flags_reset, timeout_word);
+}
+
+// The same pass for up to kRadixBatchMax sorts in ONE launch (blockIdx.y = the sort; plan_build_batch: the plans of a block of
+// batches built ahead -- 16 sorts of 106,496 keys as 16 x 6 launches of 26 workgroups each were 53 us apiece, a chain of launch
+// latencies; as 6 launches of 416 workgroups they are a throughput problem).  A sort's tiles wait for each other only (FUSED),
+// and they are consecutive in dispatch order.
+constexpr int kRadixBatchMax = 16;
+struct RadixBatch {
+    int n[kRadixBatchMax], nblk[kRadixBatchMax];
+    const uint32_t *kin[kRadixBatchMax];
+    const int32_t *vin[kRadixBatchMax];
+    uint32_t *hist[kRadixBatchMax], *kout[kRadixBatchMax], *flags[kRadixBatchMax];
+    int32_t *vout[kRadixBatchMax];
+    long long *timeout_word[kRadixBatchMax];
+};
+template <bool FUSED>
+__global__ __launch_bounds__(kScatterThreads) void radix_scatter_batch_kernel(const RadixBatch b, int shift, uint32_t flag_value) {
+    const int i = blockIdx.y;
+    if (static_cast<int>(blockIdx.x) >= b.nblk[i])
+        return;
+    radix_scatter_body<false, false, FUSED>(static_cast<int>(blockIdx.x), b.kin[i], b.vin[i], b.n[i], shift, b.nblk[i], b.hist[i],
+                                            b.kout[i], b.vout[i], nullptr, FUSED ? b.flags[i] : nullptr, flag_value,
+                                            FUSED ? nullptr : b.flags[i], b.timeout_word[i]);
 }
 
 // ===========================================================================
@@ -533,9 +568,8 @@ __global__ __launch_bounds__(1024) void finish_small_kernel(
 }
 
 // heads per 1024-position chunk (first launch of the two-launch finish of medium-sized batches)
-__global__ __launch_bounds__(1024) void finish_chunk_heads_kernel(
-    const uint32_t *__restrict__ sorted, int n, uint32_t *__restrict__ chunk_heads, PlanHeader *hdr) {
-    __shared__ uint32_t s_w[16];
+__device__ __forceinline__ void finish_chunk_heads_body(const uint32_t *__restrict__ sorted, int n,
+                                                        uint32_t *__restrict__ chunk_heads, PlanHeader *hdr, uint32_t *s_w) {
     const int p = blockIdx.x * 1024 + threadIdx.x;
     const int cp = min(p, n - 1);
     const uint32_t k = sorted[cp], kprev = sorted[max(cp - 1, 0)];
@@ -551,6 +585,11 @@ __global__ __launch_bounds__(1024) void finish_chunk_heads_kernel(
         if (blockIdx.x == 0 && hdr != nullptr)
             hdr->reserved[0] = 0;   // counter of the long-run list the second launch fills
     }
+}
+__global__ __launch_bounds__(1024) void finish_chunk_heads_kernel(
+    const uint32_t *__restrict__ sorted, int n, uint32_t *__restrict__ chunk_heads, PlanHeader *hdr) {
+    __shared__ uint32_t s_w[16];
+    finish_chunk_heads_body(sorted, n, chunk_heads, hdr, s_w);
 }
 
 __global__ __launch_bounds__(1024) void finish_chunked_kernel(
@@ -634,6 +673,8 @@ static int scatter_allow_lds() {
         HA_ALLOW_LDS((radix_scatter_kernel<true, false>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<false, true>), kScatterLdsBytes);
         HA_ALLOW_LDS((radix_scatter_kernel<false, false, true>), kScatterLdsBytes);
+        HA_ALLOW_LDS((radix_scatter_batch_kernel<false>), kScatterLdsBytes);
+        HA_ALLOW_LDS((radix_scatter_batch_kernel<true>), kScatterLdsBytes);
         return 0;
     });
 }
@@ -1017,6 +1058,101 @@ __global__ __launch_bounds__(1024) void finish_small_batch_kernel(const PlanBatc
                       blockIdx.x, s_w);
 }
 
+// ---- plans of kSmallMax < n <= kFinishChunkedMax ids (radix sort in one-launch passes + the two-launch finish), up to
+// kRadixBatchMax of them per launch: see radix_scatter_batch_kernel
+struct RadixFirstBatch {
+    const void *ids[kRadixBatchMax];
+    int n[kRadixBatchMax], nblk[kRadixBatchMax];
+    uint32_t *keys[kRadixBatchMax], *hist[kRadixBatchMax];
+};
+template <typename IdT>
+__global__ __launch_bounds__(1024) void radix_first_batch_kernel(const RadixFirstBatch b) {
+    __shared__ uint32_t s_h[kRadixBuckets];
+    const int i = blockIdx.y;
+    if (static_cast<int>(blockIdx.x) >= b.nblk[i])
+        return;
+    radix_first_tile_body<IdT>(static_cast<const IdT *>(b.ids[i]), b.n[i], b.nblk[i], blockIdx.x, b.keys[i], b.hist[i], 1, s_h, 0,
+                               false);
+}
+struct FinishChunkedBatch {
+    int n[kRadixBatchMax];
+    PlanHeader *hdr[kRadixBatchMax];
+    uint32_t *sorted[kRadixBatchMax], *uniq[kRadixBatchMax], *chunk_heads[kRadixBatchMax], *long_list[kRadixBatchMax];
+    int32_t *perm[kRadixBatchMax], *seg[kRadixBatchMax], *counts[kRadixBatchMax], *inverse[kRadixBatchMax], *upos[kRadixBatchMax];
+};
+__global__ __launch_bounds__(1024) void finish_chunk_heads_batch_kernel(const FinishChunkedBatch b) {
+    __shared__ uint32_t s_w[16];
+    const int i = blockIdx.y;
+    if (static_cast<int>(blockIdx.x) * 1024 >= b.n[i])
+        return;
+    finish_chunk_heads_body(b.sorted[i], b.n[i], b.chunk_heads[i], b.hdr[i], s_w);
+}
+__global__ __launch_bounds__(1024) void finish_chunked_batch_kernel(const FinishChunkedBatch b, int long_min) {
+    __shared__ uint32_t s_w[kFinishLdsWords];
+    const int i = blockIdx.y;
+    if (static_cast<int>(blockIdx.x) * 1024 >= b.n[i])
+        return;
+    finish_block_body(b.sorted[i], b.perm[i], b.n[i], b.hdr[i], b.uniq[i], b.seg[i], b.counts[i], b.inverse[i], b.upos[i], blockIdx.x,
+                      s_w, b.chunk_heads[i], nullptr, nullptr, 0, b.long_list[i], long_min);
+}
+
+template <typename IdT>
+static int plan_build_batch_radix(const IdT *const *ids, const int64_t *n, void *const *ws, int count, bool sort_only,
+                                  hipStream_t stream) {
+    if (scatter_allow_lds())
+        return -1;
+    constexpr int passes = (32 + kRadixBits - 1) / kRadixBits;
+    for (int at = 0; at < count; at += kRadixBatchMax) {
+        const int m = count - at < kRadixBatchMax ? count - at : kRadixBatchMax;
+        RadixFirstBatch fb;
+        RadixBatch rb[passes];
+        FinishChunkedBatch cb;
+        memset(&fb, 0, sizeof(fb));
+        memset(rb, 0, sizeof(rb));
+        memset(&cb, 0, sizeof(cb));
+        int tiles_max = 0, chunks_max = 0;
+        for (int i = 0; i < m; ++i) {
+            const int ni = static_cast<int>(n[at + i]);
+            PlanPtrs p = plan_layout(ws[at + i], ni);
+            const int nblk = radix_tiles(ni);
+            fb.ids[i] = ids[at + i]; fb.n[i] = ni; fb.nblk[i] = nblk; fb.keys[i] = p.keys; fb.hist[i] = p.hist;
+            // (as plan_radix_sort: pass 0 reads `keys` with the identity permutation; pass k writes B = (sorted, perm) when
+            // (passes - 1 - k) is even and A = (keys_alt, perm_alt) otherwise)
+            const uint32_t *kin = p.keys;
+            const int32_t *vin = nullptr;
+            for (int pass = 0; pass < passes; ++pass) {
+                const bool toB = ((passes - 1 - pass) & 1) == 0;
+                RadixBatch &r = rb[pass];
+                r.n[i] = ni; r.nblk[i] = nblk; r.kin[i] = kin; r.vin[i] = vin; r.hist[i] = p.hist;
+                r.kout[i] = toB ? p.sorted : p.keys_alt;
+                r.vout[i] = toB ? p.perm : p.perm_alt;
+                r.flags[i] = p.pass_flags;
+                r.timeout_word[i] = reinterpret_cast<long long *>(&p.hdr->reserved[kHandoffFlagWord]);
+                kin = r.kout[i];
+                vin = r.vout[i];
+            }
+            cb.n[i] = ni; cb.hdr[i] = p.hdr; cb.sorted[i] = p.sorted; cb.uniq[i] = p.uniq; cb.chunk_heads[i] = p.hist;
+            cb.long_list[i] = p.keys_alt; cb.perm[i] = p.perm; cb.seg[i] = p.seg; cb.counts[i] = p.counts;
+            cb.inverse[i] = p.inverse; cb.upos[i] = p.upos;
+            tiles_max = nblk > tiles_max ? nblk : tiles_max;
+            const int ch = finish_blocks(ni);
+            chunks_max = ch > chunks_max ? ch : chunks_max;
+        }
+        hipLaunchKernelGGL(radix_first_batch_kernel<IdT>, dim3(tiles_max, m), dim3(1024), 0, stream, fb);
+        hipLaunchKernelGGL(radix_scatter_batch_kernel<false>, dim3(tiles_max, m), dim3(kScatterThreads), kScatterLdsBytes, stream,
+                           rb[0], 0, 0u);
+        for (int pass = 1; pass < passes; ++pass)
+            hipLaunchKernelGGL(radix_scatter_batch_kernel<true>, dim3(tiles_max, m), dim3(kScatterThreads), kScatterLdsBytes, stream,
+                               rb[pass], pass * kRadixBits, static_cast<uint32_t>(pass));
+        if (!sort_only) {
+            hipLaunchKernelGGL(finish_chunk_heads_batch_kernel, dim3(chunks_max, m), dim3(1024), 0, stream, cb);
+            hipLaunchKernelGGL(finish_chunked_batch_kernel, dim3(chunks_max, m), dim3(1024), 0, stream, cb, kPlanLongRun);
+        }
+        HA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 template <typename IdT>
 static int plan_build_batch(const IdT *const *ids, const int64_t *n, void *const *ws, int count, uint64_t key_limit,
                             hipStream_t stream, bool sort_only = false) {
@@ -1026,6 +1162,13 @@ static int plan_build_batch(const IdT *const *ids, const int64_t *n, void *const
         HA_REQUIRE(n[i] >= 0 && ws[i] != nullptr && (n[i] == 0 || ids[i] != nullptr), "plan_build_batch: bad batch %d", i);
         small = small && n[i] <= kSmallMax && !bucket_sort_applies(n[i], key_limit);
     }
+    bool medium = count > 1;
+    for (int i = 0; i < count; ++i)
+        medium = medium && n[i] > kSmallMax && n[i] <= kFinishChunkedMax && radix_tiles(n[i]) <= kRadixFusedBlocks &&
+                 !bucket_sort_applies(n[i], key_limit);
+    static const bool batch_radix = !(getenv("HA_PLAN_BATCH_RADIX") && atoi(getenv("HA_PLAN_BATCH_RADIX")) == 0);
+    if (medium && batch_radix)      // every batch takes the radix sort in one-launch passes: the passes of all of them per launch
+        return plan_build_batch_radix<IdT>(ids, n, ws, count, sort_only, stream);
     if (!small) {   // some batch takes a multi-launch sort: one plan at a time
         for (int i = 0; i < count; ++i)
             if (plan_build<IdT>(ids[i], n[i], ws[i], 32, sort_only, stream, key_limit))

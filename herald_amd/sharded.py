@@ -32,6 +32,7 @@ test double injected by the CPU/gloo tests.  There is no CPU fallback in this mo
 engine argument the HIP engine is used and fails loudly when the library or a GPU is missing.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -89,10 +90,10 @@ class HipEngine:
         """The routing stream at ANOTHER priority than the step's stream (high=True), or at the same.  HIP multiplexes the
         streams of one priority onto a few hardware queues, and two streams that share a queue run in submission order: the
         routing of block b + 1 then sits BETWEEN the steps of two blocks instead of beside them (kernel trace of bench.py's
-        sharded leg at world size 1: every launch on one queue; docs/EXPERIMENTS.md round 6).  Worth it where the routing is
-        LIGHT -- batches of at most 8,192 ids, whose plans are a workgroup each (csrc/plan.hip plan_sort_wg_batch_kernel):
-        20.3 -> 18.5 us per step at configs[1]'s shape.  Chip-wide routing launches (the radix sorts and the pack / unpack of
-        106,496-id batches) at the higher priority push the steps aside: 74 -> 102 us at configs[2]'s shape."""
+        sharded leg at world size 1: every launch on one queue; docs/EXPERIMENTS.md round 6): 20.3 -> 18.5 us per step at
+        configs[1]'s shape.  (While the plans of 106,496-id batches were sorted one batch at a time -- 16 x 6 chip-wide launches
+        per block -- the higher priority pushed the steps aside, 74 -> 102 us at configs[2]'s shape; with the radix passes of a
+        block's batches in six launches, plan_build_batch_radix, it is 57.6 against 58.4 at the steps' own priority.)"""
         import os
         if os.environ.get("HA_SHARD_SIDE_PRIO") in ("high", "normal"):
             high = os.environ["HA_SHARD_SIDE_PRIO"] == "high"
@@ -287,6 +288,11 @@ class HipEngine:
         vp = ctypes.c_void_p
         slots = blk.slots
         big = [fb for fb in slots if fb.n > self.RADIX_FROM]
+        # (round 6: ha_plan_build_batch_* runs the radix passes of ALL the block's batches per launch -- csrc/plan.hip
+        # plan_build_batch_radix: six launches of 16 x 26 workgroups instead of 16 x 6 of 26; the four side streams below are what
+        # the engine did before, HA_SHARD_BIG_STREAMS=1)
+        if os.environ.get("HA_SHARD_BIG_STREAMS") != "1":
+            big = []
         if len(big) > 1:
             # Batches beyond the counting sort's reach are radix-sorted: four launches of ~26 workgroups each per batch
             # -- a latency chain that leaves nine tenths of the chip idle (43 us at 106,496 ids).  The batches of a block
@@ -938,7 +944,7 @@ class FramedStep:
             self.zero_flags = self.eng.zeros((m,), torch.uint8)
         self.side = w == 1 or emb.side_group is not None
         if hasattr(self.eng, "use_side_priority"):
-            self.eng.use_side_priority(self.max_ids <= 8192)
+            self.eng.use_side_priority(True)
         self._graphs = {}
         self._calls = {}
         self._fast_ok = hasattr(self.eng, "frames_serve_pull_call")

@@ -793,3 +793,57 @@ def test_batched_plans_by_the_one_workgroup_radix_sort(dev, kind):
             np.testing.assert_array_equal(p.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, u)
             np.testing.assert_array_equal(p.counts().cpu().numpy().astype(np.int64)[:u.size], cn)
             np.testing.assert_array_equal(p.inverse().cpu().numpy().astype(np.int64), inv)
+
+
+@pytest.mark.parametrize("kind", ["f32", "u64"])
+def test_batched_plans_of_medium_batches_by_batched_radix_passes(dev, kind):
+    """ha_plan_build_batch_*_lim for batches of 36,865 .. 262,144 ids: the radix passes and the two finish launches of ALL the
+    batches of a call per launch (csrc/plan.hip plan_build_batch_radix: blockIdx.y names the sort) -- sorted keys, perm (stable),
+    unique keys, counts, inverse and the list of long runs equal numpy's / the one-plan-at-a-time build's, for ragged sizes
+    around the tile edges, Criteo-shaped keys with runs of thousands, and full 32-bit keys."""
+    import ctypes
+    from herald_amd import _lib, ops, synth
+    L = _lib.load()
+    rng = np.random.default_rng(78)
+    rows = 33_762_577
+    sizes = [36865, 40960, 40961, 106496, 65536, 106496, 100001, 262144, 53248]
+    cases = []
+    for j, n in enumerate(sizes):
+        if j % 3 == 0:
+            k = synth.criteo_batch((n + 25) // 26, 40 + j, rows=rows).reshape(-1)[:n].astype(np.uint64)
+        elif j % 3 == 1:
+            k = rng.integers(0, rows, size=n, dtype=np.uint64)
+            k[: n // 5] = k[0]                         # a run of thousands
+        else:
+            k = rng.integers(0, (1 << 32) - 3 if kind == "u64" else (1 << 24) - 1, size=n, dtype=np.uint64)
+        cases.append(k)
+    if kind == "f32":
+        cases = [np.minimum(k, (1 << 24) - 1) for k in cases]
+        tens = [torch.from_numpy(k.astype(np.float32)).to(dev) for k in cases]
+        fn = L.ha_plan_build_batch_f32ids_lim
+    else:
+        tens = [torch.from_numpy(k.astype(np.int64)).to(dev) for k in cases]
+        fn = L.ha_plan_build_batch_u64ids_lim
+    plans = [ops.IndexPlan(k.size, dev) for k in cases]
+    cnt = len(cases)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    _lib.check(fn((vp * cnt)(*[t.data_ptr() for t in tens]), (i64 * cnt)(*[k.size for k in cases]),
+                  (vp * cnt)(*[p.ws.data_ptr() for p in plans]), cnt, ctypes.c_uint64(rows), None), "plan_build_batch")
+    torch.cuda.synchronize()
+    for k, t, p in zip(cases, tens, plans):
+        p.n, p._view = k.size, None
+        keys = np.minimum(k, 0xFFFFFFFE).astype(np.int64)
+        order = np.argsort(keys, kind="stable")
+        np.testing.assert_array_equal(p.perm().cpu().numpy().astype(np.int64), order)
+        np.testing.assert_array_equal(p.sorted_keys().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys[order])
+        u, inv, cn = np.unique(keys, return_inverse=True, return_counts=True)
+        assert p.n_unique() == u.size
+        np.testing.assert_array_equal(p.uniq().cpu().numpy().astype(np.int64) & 0xFFFFFFFF, u)
+        np.testing.assert_array_equal(p.counts().cpu().numpy().astype(np.int64)[:u.size], cn)
+        np.testing.assert_array_equal(p.inverse().cpu().numpy().astype(np.int64), inv)
+        # the same plan built alone: every array of the workspace's result equal
+        q = ops.IndexPlan(k.size, dev)
+        q.build(t, key_limit=rows)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(q.perm().cpu().numpy(), p.perm().cpu().numpy())
+        np.testing.assert_array_equal(q.counts().cpu().numpy()[:u.size], p.counts().cpu().numpy()[:u.size])
