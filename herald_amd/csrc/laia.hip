@@ -392,8 +392,8 @@ __global__ __launch_bounds__(256) void laia_delta_kernel(const uint32_t *__restr
 //    counts per worker, first sample at which a quota fills }: at most W + 1 rounds instead of B dependent steps.
 //  * sorted-unique (worker, row) lists without a sort: laia_bits_kernel sets one flag byte per touched / plan pair (and per
 //    group of 64 rows, per chunk of 4,096) with plain stores, laia_bits_pack_kernel turns the flags of the chunks that have
-//    any into bit words (one per 64 rows) + a summary word per chunk and counts them, and an ordered compaction (scan, emit
-//    -- which also clears what it read) yields the rows ascending per worker.
+//    any into bit words (one per 64 rows) + a summary word per chunk and counts them, and an ordered compaction (emit --
+//    which also clears what it read) yields the rows ascending per worker.
 //  * MiniLRU per worker as a stamp log (as the host Snapshot above and cache.hip): stamp[w][row] (0 = absent), a
 //    ring log of (row, stamp), valid bytes = the device mirror the probe reads.  A batch's get()s come in ascending
 //    row order and the rows are distinct, so row i of n ends with stamp counter + i + 1 whatever happens; what has
@@ -747,31 +747,26 @@ __global__ __launch_bounds__(64) void laia_bits_pack_kernel(LaiaBits a, LaiaFlag
     }
 }
 
-__global__ __launch_bounds__(1024) void laia_bits_scan_kernel(LaiaBits a, int nblk) {
-    __shared__ uint32_t s_w[16];
-    const int which = blockIdx.x;
-    uint32_t run = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 1024) {
-        const int b = b0 + threadIdx.x;
-        const uint32_t v = b < nblk ? a.blk[which][b] : 0u;
-        uint32_t tot;
-        const uint32_t ex = laia_block_scan_u32(v, s_w, &tot);
-        if (b < nblk)
-            a.blk[which][b] = run + ex;
-        run += tot;
-    }
-    if (threadIdx.x == 0)
-        a.blk[which][nblk] = run;
-}
-
 // emits the rows in order (one wave per summary word, lane k its data word k), writes the per-worker offsets and
 // clears the words it read
 __global__ __launch_bounds__(256) void laia_bits_emit_kernel(LaiaBits a, long long nsum, long long sum_per_worker, int W,
                                                              long long Rpad) {
     // a block = the 16 summary words of one offset group, four per wave (most are empty: fewer, longer-lived waves)
+    __shared__ uint32_t s_red[4];
     const int which = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t blk0 = a.blk[which][blockIdx.x];
+    // the rows in front of this offset group = the totals of the groups before it, summed here (a scan launch of two
+    // workgroups in between was 5 us of a 105 us global batch for 2 x 2,060 words)
+    uint32_t part = 0;
+    for (int b = threadIdx.x; b < static_cast<int>(blockIdx.x); b += 256)
+        part += a.blk[which][b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        part += __shfl_xor(part, o, 64);
+    if (lane == 0)
+        s_red[wv] = part;
+    __syncthreads();
+    const uint32_t blk0 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     // the wave's four summary words, their offsets and then their data words: each a batch of loads (word by word it was
     // three dependent trips to memory per summary word, four words per wave)
     const long long x0 = blockIdx.x * 16ll + wv * 4;
@@ -796,7 +791,7 @@ __global__ __launch_bounds__(256) void laia_bits_emit_kernel(LaiaBits a, long lo
             if (x % sum_per_worker == 0)
                 a.off[which][x / sum_per_worker] = static_cast<int32_t>(at0);
             if (x == nsum - 1)
-                a.off[which][W] = static_cast<int32_t>(a.blk[which][gridDim.x]);
+                a.off[which][W] = static_cast<int32_t>(blk0 + a.blk[which][blockIdx.x]);      // (the last group: everything)
         }
         const unsigned long long sw = sw4[i];      // wave-uniform
         if (sw == 0)
@@ -1566,7 +1561,6 @@ static int laia_dev_issue(ha_laia *h, int64_t batch_id, int64_t mini_bs, int onl
     hipLaunchKernelGGL(laia_bits_kernel, dim3(blocks), dim3(256), 0, l.stream, l.d_samples, l.S, T, start, (int)B, W,
                        l.d_mask, l.d_owner, l.R, d.Rpad, d.flags, topk ? 1 : 0);
     hipLaunchKernelGGL(laia_bits_pack_kernel, dim3(d.nblk, 2), dim3(64), 0, l.stream, d.bits, d.flags, d.nsum);
-    hipLaunchKernelGGL(laia_bits_scan_kernel, dim3(2), dim3(1024), 0, l.stream, d.bits, d.nblk);
     hipLaunchKernelGGL(laia_bits_emit_kernel, dim3(d.nblk, 2), dim3(256), 0, l.stream, d.bits, d.nsum, d.sum_per_worker, W,
                        d.Rpad);
     hipLaunchKernelGGL(laia_lru_classify_kernel, dim3(kLaiaLruBlocks, W), dim3(256), 0, l.stream, d.lru);
