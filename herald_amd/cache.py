@@ -35,7 +35,7 @@ def register_table(node_id, table, versions=None, row_start=0):
     _TABLES[int(node_id)] = (table, versions, int(row_start))
     return versions
 
-_PLAN_STREAMS = {}      # (device index, priority) -> the planning stream the caches of this process share
+_PLAN_STREAMS = {}      # (device index, priority, row stream) -> the planning stream the caches of this process share
 
 
 class _LookupMark:
@@ -452,11 +452,14 @@ class _CacheBase:
                 # pairing with the row stream's queue stretched the ROW launches threefold (bench.py's second / third cache:
                 # profiles/r06/cache_tier_third_instance.txt) -- the pair that the first cache got is kept.
                 shared = os.environ.get("HA_CACHE_PLAN_SHARED", "1") == "1"
-                key = (torch.device(self.device).index, prio)
+                key = (torch.device(self.device).index, prio, s.cuda_stream)
                 if shared and key in _PLAN_STREAMS:
                     self._plan_side = _PLAN_STREAMS[key]
                 else:
-                    self._plan_side = torch.cuda.Stream(device=self.device, priority=prio)
+                    # (and not an unlucky partner of the row stream: streams.pick_side_stream measures a few candidates once)
+                    from . import streams
+                    self._plan_side = streams.pick_side_stream(s, prio) if shared else \
+                        torch.cuda.Stream(device=self.device, priority=prio)
                     if shared:
                         _PLAN_STREAMS[key] = self._plan_side
             side = self._plan_side

@@ -1838,9 +1838,12 @@ extern "C" void ha_cache_destroy(ha_cache *h) {
         (void)hipEventDestroy(h->ahead_join);
     if (h->plan_fork)
         (void)hipEventDestroy(h->plan_fork);
-    for (PlanSlot &sl : h->plan)
+    for (PlanSlot &sl : h->plan) {
         if (sl.booked)
             (void)hipEventDestroy(sl.booked);
+        if (sl.rows_done)
+            (void)hipEventDestroy(sl.rows_done);
+    }
     for (void *p : h->allocs)
         (void)hipFree(p);
     delete h;

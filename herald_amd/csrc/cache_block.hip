@@ -1124,6 +1124,7 @@ static int plan_slot_alloc(ha_cache *h, PlanSlot &sl) {
     }
     HA_REQUIRE(ok, "cache_plan_block: out of device memory");
     HA_CHECK_HIP(hipEventCreateWithFlags(&sl.booked, hipEventDisableTiming));
+    HA_CHECK_HIP(hipEventCreateWithFlags(&sl.rows_done, hipEventDisableTiming));
     return 0;
 }
 
@@ -1160,8 +1161,12 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
         HA_REQUIRE(c.policy != kLRU || n[i] <= c.limit, "cache_plan_block: limit (%ld) must be at least the batch (%ld keys): the "
                    "lines of an LRU batch are never evicted by its own lookup", (long)c.limit, (long)n[i]);
     }
-    PlanSlot &sl = h->plan[h->plan_next & 1];
-    HA_REQUIRE(sl.count == 0 || sl.next_call >= 2 * sl.count, "cache_plan_block: two planned blocks are outstanding already");
+    PlanSlot &sl = h->plan[h->plan_next % ha_cache::kPlanSlots];
+    int blocks_out = 0;
+    for (const PlanSlot &q : h->plan)
+        blocks_out += q.count > 0 && q.next_call < 2 * q.count ? 1 : 0;
+    HA_REQUIRE(blocks_out < 2 && (sl.count == 0 || sl.next_call >= 2 * sl.count),
+               "cache_plan_block: two planned blocks are outstanding already");
     if (plan_slot_alloc(h, sl))
         return -1;
     if (!h->plan_xw) {
@@ -1197,11 +1202,19 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
         }
     }
     if (ss != ms) {
-        HA_CHECK_HIP(hipEventRecord(h->plan_fork, ms));
-        HA_CHECK_HIP(hipStreamWaitEvent(ss, h->plan_fork, 0));
+        if (sl.rows_recorded && h->last_planned_type >= 0) {
+            // the planned flow goes on: this slot's buffers were last read by the rows of the block two before the one being
+            // consumed -- nothing else of the row stream concerns the bookkeeping (it owns the control fields, the rows the
+            // data fields), and this event is long complete: no barrier parked on the planning stream's queue
+            HA_CHECK_HIP(hipStreamWaitEvent(ss, sl.rows_done, 0));
+        } else {
+            // the first blocks, or call-by-call entry points ran in between: everything enqueued on `main` so far comes first
+            HA_CHECK_HIP(hipEventRecord(h->plan_fork, ms));
+            HA_CHECK_HIP(hipStreamWaitEvent(ss, h->plan_fork, 0));
+        }
     }
-    // the block before this one (other slot) was booked on whatever side stream its call named: order behind it
-    PlanSlot &other = h->plan[(h->plan_next + 1) & 1];
+    // the block before this one was booked on whatever side stream its call named: order behind it
+    PlanSlot &other = h->plan[(h->plan_next + ha_cache::kPlanSlots - 1) % ha_cache::kPlanSlots];
     if (other.count > 0 && other.booked_on != ss)
         HA_CHECK_HIP(hipStreamWaitEvent(ss, other.booked, 0));
     const uint64_t lim = static_cast<uint64_t>(c.length);
@@ -1262,8 +1275,8 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
 
 // the slot and batch index of the next planned call of `type` (0 lookup, 1 update)
 static PlanSlot *plan_current(ha_cache *h, int type, int *idx) {
-    for (int k = 0; k < 2; ++k) {         // the older block first
-        PlanSlot &sl = h->plan[(h->plan_next + k) & 1];
+    for (int k = 0; k < ha_cache::kPlanSlots; ++k) {         // the older block first
+        PlanSlot &sl = h->plan[(h->plan_next + k) % ha_cache::kPlanSlots];
         if (sl.count > 0 && sl.next_call < 2 * sl.count) {
             if ((sl.next_call & 1) != type)
                 return nullptr;
@@ -1345,6 +1358,10 @@ extern "C" int ha_cache_update_planned(ha_cache *h, int64_t n, const float *grad
     }
     cache_mark(h, kTEnd, s);
     sl->next_call += 1;
+    if (sl->next_call == 2 * sl->count) {       // the block's last row launch is enqueued
+        HA_CHECK_HIP(hipEventRecord(sl->rows_done, s));
+        sl->rows_recorded = true;
+    }
     h->last_planned = sl;
     h->last_planned_idx = i;
     h->last_planned_type = 1;

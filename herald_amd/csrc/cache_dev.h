@@ -137,6 +137,8 @@ struct PlanSlot {
     bool waited = false;                // the row stream already waits for `booked`
     hipEvent_t booked = nullptr;        // behind the bookkeeping launch
     hipStream_t booked_on = nullptr;
+    hipEvent_t rows_done = nullptr;     // behind the block's last row launch (recorded by its last ha_cache_update_planned)
+    bool rows_recorded = false;
 };
 }  // namespace ha
 
@@ -181,8 +183,15 @@ struct ha_cache {
     int64_t ring_n[kAheadRing] = {};
     int ring_kind = -1, ring_head = 0, ring_count = 0;
     // the planned flow (cache_block.hip)
-    ha::PlanSlot plan[2];
-    int plan_next = 0;                  // blocks planned so far (slot = plan_next & 1)
+    // THREE slots for at most two outstanding blocks: the bookkeeping of block b + 1 reuses the buffers of block b - 2, whose
+    // rows are long done -- its wait for them (an event) passes at once.  With two slots it waited for the rows of block b - 1,
+    // i.e. for most of a block's duration, as a barrier parked at the head of the (high-priority) planning stream's hardware
+    // queue -- and such a barrier makes the row stream's launches take two to three times as long when the two streams'
+    // hardware queues are an unlucky pair (which they are for one in four orders of stream creation: profiles/r06/
+    // cache_tier_third_instance.txt, docs/EXPERIMENTS.md round 6 section 12).
+    static constexpr int kPlanSlots = 3;
+    ha::PlanSlot plan[kPlanSlots];
+    int plan_next = 0;                  // blocks planned so far (slot = plan_next % kPlanSlots)
     unsigned long long *plan_xw = nullptr;   // exchange words of the bookkeeping launch
     hipEvent_t plan_fork = nullptr;
     // LFU / LFUOpt planned: the victim tree (cache_block.hip) -- the (use, stamp) key of every slot and the minimum of every

@@ -33,7 +33,13 @@ def main():
            for b in range(NB)]
     out = torch.empty((n, width), device=dev)
     grad = torch.randn((n, width), device=dev) * 1e-3
-    main_s = torch.cuda.Stream(device=dev)
+    _skip = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("SKIP_STREAMS", "0")))]     # (shifts the pool)
+    _skip_hi = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(int(os.environ.get("SKIP_STREAMS_HI", "0")))]
+    for st in _skip + _skip_hi:                 # (a stream gets its hardware queue when it is first used)
+        with torch.cuda.stream(st):
+            torch.zeros(8, device=dev).add_(1)
+    torch.cuda.synchronize()
+    main_s = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("ROW_PRIO") == "high" else 0)
     c.cache.stream = main_s
     GS = 16
     outs, grads = [out] * GS, [grad] * GS
