@@ -398,3 +398,20 @@ def test_planned_flow_over_a_store_in_pinned_host_memory(dev, policy):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(table.numpy(), server.table, err_msg="the host table after the pushes")
     _compare_state(gpu, model, 24)
+
+
+def test_pick_side_stream_returns_a_cached_stream_of_the_priority(dev):
+    """herald_amd.streams.pick_side_stream: a stream of the asked priority beside the given main stream, the same object on the
+    next call (the measurement runs once per (device, main stream, priority)); HA_STREAM_CALIBRATE=0 skips the measurement."""
+    from herald_amd import streams
+    main = torch.cuda.Stream(device=dev)
+    a = streams.pick_side_stream(main, priority=-1)
+    assert isinstance(a, torch.cuda.Stream) and a.priority == -1 and a.cuda_stream != main.cuda_stream
+    assert streams.pick_side_stream(main, priority=-1) is a
+    b = streams.pick_side_stream(main, priority=0)
+    assert b is not a and b.priority == 0
+    x = torch.zeros(1024, device=dev)
+    with torch.cuda.stream(a):
+        x.add_(1)
+    a.synchronize()
+    assert float(x.sum()) == 1024.0
