@@ -983,8 +983,10 @@ class FramedStep:
         fb.ids, fb.n, fb.shape, fb.routed = (ids if len(shape) == 1 else ids.reshape(-1)), n, shape, True
         fb.out_shape = shape + (self.emb.width,)
 
-    def _route_block(self, b):
-        """Enqueue the routing of block b: plans and key frames of its batches, one key exchange, received keys."""
+    def _route_block(self, b, after=None):
+        """Enqueue the routing of block b: plans and key frames of its batches, one key exchange, received keys.  after: an
+        event of the step stream the routing stream waits for INSTEAD of everything queued on the step stream so far (steps():
+        the block's steps are enqueued first, its successor's routing follows them onto the device without waiting for them)."""
         import contextlib
         blk = self.blocks[b % 3]
         blk.live = any(fb.routed for fb in blk.slots)
@@ -993,7 +995,9 @@ class FramedStep:
             blk.ev = None
             return
         eng, starts = self.eng, self.emb.starts
-        ctx = eng.on_side(after_current=True) if self.side else contextlib.nullcontext()
+        if after is not None and self.side:
+            eng.side.wait_event(after)
+        ctx = eng.on_side(after_current=after is None) if self.side else contextlib.nullcontext()
         with ctx:
             # (the id tensors of the block stay referenced by their slots until they are restaged three blocks later, long
             # after this routing has completed: the allocator cannot hand their memory out under the side stream)
@@ -1327,15 +1331,30 @@ class FramedStep:
         if outs is None:
             outs = [eng.empty_rows(fb.n, width) if fb.n else None for fb in fbs]
         native = native_tried = self.native_ok() and all(fb.routed for fb in fbs)
+        # The host's work at a block boundary used to sit between two blocks' steps with the device idle: the routing of block
+        # b + 1 was enqueued (and, the device having nothing else, executed) BEFORE the steps of block b -- 95 us of a 290 us block
+        # at configs[1]'s shape (kernel trace, docs/EXPERIMENTS.md round 6 section 13).  Now the block's steps go first; the
+        # routing follows them onto the device and waits only for what it needs of the step stream: the previous block's end
+        # (the ids it reads were staged by then).
+        route_after = None
         if native:
             if k0 % self.block == 0:
-                self._block_start(k0 // self.block)
+                self.eng.wait_event(self.blocks[(k0 // self.block) % 3].ev)
+                route_after = getattr(self, "_ev_block_end", None)
+                if route_after is None or not self.side:
+                    self._route_block(k0 // self.block + 1)          # (the first block, or no side stream: as before)
+                    route_after = None
+                else:
+                    route_after = (k0 // self.block + 1, route_after)
             blk = self._slot_of[k0 % self._ring][0]
             if not blk.synced:
                 eng.host_sync(blk.ev)
                 blk.synced = True
             native = not any(eng.frames_overflowed(fb) for fb in fbs)
         started = native_tried and k0 % self.block == 0       # (the fallback below must not start the block again)
+        if not native and route_after is not None:
+            self._route_block(route_after[0])        # (the fallback pulls and pushes step by step: the routing in its old place)
+            route_after = None
         if not native:
             res = []
             for i in range(cnt):
@@ -1363,6 +1382,11 @@ class FramedStep:
                                     ctypes.c_float(scale), vp(eng._stream()))
         if rc != 0:
             eng.check(-1, "ha_shard_steps")
+        if route_after is not None:
+            self._route_block(route_after[0], after=route_after[1])
+        if (k0 + cnt) % self.block == 0:           # the block's last step is enqueued: what its successor's successor's routing waits for
+            self._ev_block_end = eng.record(getattr(self, "_ev_block_end_obj", None))
+            self._ev_block_end_obj = self._ev_block_end
         if emb.world > 1:
             r = emb.rank
             for fb in fbs:
