@@ -99,7 +99,10 @@ class HipEngine:
             high = os.environ["HA_SHARD_SIDE_PRIO"] == "high"
         if high and self._side_high is None:
             try:
-                self._side_high = torch.cuda.Stream(device=self.device, priority=min(torch.cuda.Stream.priority_range()))
+                # (not an unlucky partner of the step stream: herald_amd/streams.py measures a few candidates once)
+                from . import streams
+                self._side_high = streams.pick_side_stream(torch.cuda.current_stream(self.device),
+                                                           priority=min(torch.cuda.Stream.priority_range()))
             except Exception:      # noqa: BLE001
                 self._side_high = self._side_normal
         new = self._side_high if high else self._side_normal
