@@ -285,6 +285,8 @@ def _planned_timed(c, blocks, outs16, grads16, side, nwarm, ntimed, first_block,
     cands = [None, -1, 0, -1]
     at = first_block
     for prio in cands:
+        if os.environ.get("HA_BENCH_TRACE") == "1":
+            print("[bench]   planned try prio=%s at=%d" % (prio, at), file=sys.stderr, flush=True)
         plan_side = None if prio is None else torch.cuda.Stream(device=side.device, priority=prio)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(side):
@@ -304,6 +306,12 @@ def _planned_timed(c, blocks, outs16, grads16, side, nwarm, ntimed, first_block,
             torch.cuda.synchronize()
             gc.enable()
         at += nwarm + ntimed
+        if os.environ.get("HA_BENCH_TRACE") == "1":
+            try:
+                st = (c.cache if hasattr(c, "cache") else c).state()
+                print("[bench]   state after the try: size %d free %d" % (st["size"], st["free_slots"]), file=sys.stderr, flush=True)
+            except Exception as ex:      # noqa: BLE001
+                print("[bench]   state after the try RAISED: %s" % ex, file=sys.stderr, flush=True)
         us = 1e3 * e0.elapsed_time(e1) / (ntimed * GS)
         tries.append(round(us, 2))
         if best is None or us < best[0]:
@@ -315,6 +323,8 @@ def _planned_timed(c, blocks, outs16, grads16, side, nwarm, ntimed, first_block,
 
 def _cache_tier_policy(args, table, ids_dev, out, grad, dev, policy):
     from herald_amd import cache as hcache
+    if os.environ.get("HA_BENCH_TRACE") == "1":
+        print("[bench]  cache tier policy %s" % policy, file=sys.stderr, flush=True)
     n = ids_dev.shape[1]
     versions = torch.zeros(args.rows, dtype=torch.int64, device=dev)
     hcache.register_table(0, table, versions)
@@ -1117,6 +1127,8 @@ def main():
             raise SystemExit("bench.py: the work-queue engine raised its sticky error word")
     def secondary(name, fn):
         """Secondary lines must never cost the headline: a failure is recorded, not raised."""
+        if os.environ.get("HA_BENCH_TRACE") == "1":
+            print("[bench] leg %s" % name, file=sys.stderr, flush=True)
         try:
             result[name] = fn()
         except Exception as ex:      # noqa: BLE001 -- anything (allocation, capture, a stream error)

@@ -32,6 +32,8 @@ def register_table(node_id, table, versions=None, row_start=0):
     associates a device table shard (and its row versions) with a node id."""
     if versions is None:
         versions = torch.zeros(table.shape[0], dtype=torch.int64, device=table.device)
+        if versions.is_cuda:
+            torch.cuda.current_stream(versions.device).synchronize()   # (the cache's calls come on streams of the caller's choice)
     _TABLES[int(node_id)] = (table, versions, int(row_start))
     return versions
 

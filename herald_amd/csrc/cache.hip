@@ -1803,7 +1803,7 @@ extern "C" ha_cache *ha_cache_create(int policy, int64_t limit, int64_t length,
         if (ok && dmalloc(&p3, plan_bytes) == 0) {
             h->plan_ws_alt = p3;
             h->allocs.push_back(p3);
-            (void)hipMemset(p3, 0, 256);      // the plan header (sticky flags)
+            ok = dzero(p3, 256) == 0;      // the plan header (sticky flags)
         } else {
             ok = false;
         }
@@ -2123,7 +2123,7 @@ extern "C" int ha_cache_sort_ahead_batch(ha_cache *h, const void *const *keys, i
         if (h->ring_ws[i] == nullptr) {
             char *p = nullptr;
             HA_REQUIRE(dmalloc(&p, h->plan_bytes) == 0, "cache_sort_ahead_batch: out of device memory");
-            (void)hipMemset(p, 0, 256);      // the plan header (sticky flags)
+            HA_REQUIRE(dzero(p, 256) == 0, "cache_sort_ahead_batch: device memset failed");      // the plan header (sticky flags)
             h->ring_ws[i] = p;
             h->allocs.push_back(p);
         }
@@ -2481,9 +2481,10 @@ extern "C" int ha_cache_perf(ha_cache *h, int64_t *out_host, ha_stream_t stream)
     CacheCtl ctl;
     HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
-    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a wait between the workgroups of a bookkeeping launch timed out (code %ld; the cache's "
-               "state is not to be trusted; HA_CACHE_FUSED=3 keeps the call-by-call bookkeeping in a launch of its own)",
-               (long)ctl.fb_timeout);
+    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a bookkeeping launch gave up (code %ld: 1 = a wait between its workgroups timed out, 2 = the "
+               "LFU victim search found no line, 3 = a planned row launch met an item out of range; words %llu %llu %llu %llx %llx %llx "
+               "%llu %llu); the cache's state is not to be trusted; HA_CACHE_FUSED=3 keeps the call-by-call bookkeeping in a launch "
+               "of its own", (long)ctl.fb_timeout, ctl.ph[8], ctl.ph[9], ctl.ph[10], ctl.ph[11], ctl.ph[12], ctl.ph[13], ctl.ph[14], ctl.ph[15]);
     for (int i = 0; i < 7; ++i)
         out_host[i] = ctl.perf[i];
     out_host[4] += ctl.perf[7];
@@ -2556,9 +2557,10 @@ extern "C" int ha_cache_state(ha_cache *h, int64_t *out_host, ha_stream_t stream
     CacheCtl ctl;
     HA_CHECK_HIP(hipMemcpyAsync(&ctl, h->c.ctl, sizeof(ctl), hipMemcpyDeviceToHost, as_stream(stream)));
     HA_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
-    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a wait between the workgroups of a bookkeeping launch timed out (code %ld; the cache's "
-               "state is not to be trusted; HA_CACHE_FUSED=3 keeps the call-by-call bookkeeping in a launch of its own)",
-               (long)ctl.fb_timeout);
+    HA_REQUIRE(ctl.fb_timeout == 0, "cache: a bookkeeping launch gave up (code %ld: 1 = a wait between its workgroups timed out, 2 = the "
+               "LFU victim search found no line, 3 = a planned row launch met an item out of range; words %llu %llu %llu %llx %llx %llx "
+               "%llu %llu); the cache's state is not to be trusted; HA_CACHE_FUSED=3 keeps the call-by-call bookkeeping in a launch "
+               "of its own", (long)ctl.fb_timeout, ctl.ph[8], ctl.ph[9], ctl.ph[10], ctl.ph[11], ctl.ph[12], ctl.ph[13], ctl.ph[14], ctl.ph[15]);
     out_host[0] = ctl.size;
     out_host[1] = ctl.evict_n;
     out_host[2] = ctl.free_top;

@@ -722,8 +722,14 @@ __global__ __launch_bounds__(kBookThreads) void cache_book_lfu_kernel(Cache c, B
                 }
             }
             if (vslot < 0) {       // (the counters say a line exists: the tree does not hold what they count)
-                if (tid == 0)
+                if (tid == 0) {
                     ctl->fb_timeout = 2;
+                    ctl->ph[8] = static_cast<unsigned long long>(i);
+                    ctl->ph[9] = static_cast<unsigned long long>(size);
+                    ctl->ph[10] = static_cast<unsigned long long>(M);
+                    ctl->ph[11] = vkey_lfu;
+                    ctl->ph[12] = static_cast<unsigned long long>(n_hash);
+                }
                 return;
             }
         }
@@ -908,6 +914,22 @@ __global__ __launch_bounds__(1024) void cache_lookup_planned_kernel(
     }
     const bool head = (fl & kPosHead) != 0;
     float *out = dest + static_cast<long long>(uniform(it.w)) * c.width;
+    if (s >= c.S || lk >= c.store_rows || it.w < 0 || it.w >= n) {
+        // an item no bookkeeping launch wrote (it gave up, or the row launch ran in front of it): nothing is touched, the sticky
+        // word says so (ha_cache_state / ha_cache_perf raise)
+        if (lane == 0 && c.ctl->fb_timeout == 0) {
+            c.ctl->fb_timeout = 3;
+            c.ctl->ph[8] = static_cast<unsigned long long>(static_cast<uint32_t>(it.x));
+            c.ctl->ph[9] = static_cast<unsigned long long>(static_cast<uint32_t>(it.y));
+            c.ctl->ph[10] = static_cast<unsigned long long>(static_cast<uint32_t>(it.z));
+            c.ctl->ph[11] = static_cast<unsigned long long>(static_cast<uint32_t>(it.w));
+            c.ctl->ph[12] = static_cast<unsigned long long>(p) | (static_cast<unsigned long long>(rec->M) << 32);
+            c.ctl->ph[13] = static_cast<unsigned long long>(rec->n) | (static_cast<unsigned long long>(rec->U) << 32);
+            c.ctl->ph[14] = static_cast<unsigned long long>(rec->size);
+            c.ctl->ph[15] = static_cast<unsigned long long>(n);
+        }
+        return;
+    }
     if (s < 0) {
         for (long long j = lane; j < c.width; j += kWave)
             out[j] = 0.f;
@@ -996,10 +1018,12 @@ __global__ __launch_bounds__(1024, 8) void cache_update_planned_kernel(
     }
     const int lane = lane_id();
     if (b >= kPlanMetaBlocks) {
-        const int E = static_cast<int>(rec->E);
+        const int E = static_cast<int>(min(rec->E, static_cast<long long>(n)));
         for (int j = (b - kPlanMetaBlocks) * 16 + static_cast<int>(threadIdx.x >> 6); j < E; j += kPlanEvictBlocks * 16) {
             const int s = uniform(ev_slot[j]);
             const long long lk = static_cast<long long>(uniform(ev_key[j]));
+            if (s < 0 || s >= c.S || lk >= c.store_rows)
+                continue;
             float *row = c.table + lk * c.width;
             const float *g = c.grad + static_cast<long long>(s) * c.width;
             if (VEC == 4) {
@@ -1033,7 +1057,7 @@ __global__ __launch_bounds__(1024, 8) void cache_update_planned_kernel(
     }
     for (int p = b * 1024 + static_cast<int>(threadIdx.x); p < n; p += kPlanMetaBlocks * 1024) {
         const int4 it = maps.pos_item[p];
-        if (it.x < 0 || !(it.z & kPosHead))
+        if (it.x < 0 || !(it.z & kPosHead) || it.x >= c.S || static_cast<long long>(static_cast<uint32_t>(it.y)) >= c.store_rows)
             continue;
         if (it.z & kPosTemp) {     // (LFU policies) a line that is not in the cache: pushed, nothing of it stays
             c.srv_ver[static_cast<uint32_t>(it.y)] += it_upd_pos[p] + ((it.z & kPosVictimPush) ? static_cast<int>(rec->vh_upd) : 0);
@@ -1118,7 +1142,7 @@ static int plan_slot_alloc(ha_cache *h, PlanSlot &sl) {
             ok = false;
             break;
         }
-        (void)hipMemset(p, 0, 256);      // the plan header (sticky flags)
+        ok = dzero(p, 256) == 0;      // the plan header (sticky flags)
         sl.ws[i] = p;
         h->allocs.push_back(p);
     }
@@ -1172,7 +1196,8 @@ extern "C" int ha_cache_plan_block(ha_cache *h, const void *const *keys, int key
     if (!h->plan_xw) {
         HA_REQUIRE(dmalloc(&h->plan_xw, static_cast<size_t>(4 * kBookWg)) == 0, "cache_plan_block: out of device memory");
         h->allocs.push_back(h->plan_xw);
-        HA_CHECK_HIP(hipMemset(h->plan_xw, 0, 4 * kBookWg * 8));
+        if (dzero(h->plan_xw, 4 * kBookWg * 8))
+            return -1;
         HA_CHECK_HIP(hipEventCreateWithFlags(&h->plan_fork, hipEventDisableTiming));
     }
     hipStream_t ss = as_stream(side), ms = as_stream(main);
@@ -1341,6 +1366,7 @@ extern "C" int ha_cache_update_planned(ha_cache *h, int64_t n, const float *grad
         ApplyMaps maps{};
         maps.dst2 = c.data;
         maps.push_tab = c.table;
+        maps.push_rows = static_cast<uint64_t>(c.store_rows);
         maps.pos_item = sl->pos_item + at;
         maps.victim_row = reinterpret_cast<const int *>(&(sl->rec + i)->vh_slot);
         const bool vec_ok = (c.width % 4 == 0) && (reinterpret_cast<uintptr_t>(grads) % 16 == 0) &&
@@ -1394,8 +1420,8 @@ int ha::cache_perf_planned(ha_cache *h, int64_t *out_host, hipStream_t s) {
     HA_CHECK_HIP(hipMemcpyAsync(&r, sl->rec + i, sizeof(r), hipMemcpyDeviceToHost, s));
     HA_CHECK_HIP(hipMemcpyAsync(&sticky, &h->c.ctl->fb_timeout, sizeof(sticky), hipMemcpyDeviceToHost, s));
     HA_CHECK_HIP(hipStreamSynchronize(s));
-    HA_REQUIRE(sticky == 0, "cache: a wait between the workgroups of a bookkeeping launch timed out (code %ld; the cache's state is "
-               "not to be trusted)", (long)sticky);
+    HA_REQUIRE(sticky == 0, "cache: a bookkeeping launch gave up (code %ld, see ha_cache_state; the cache's state is not to be "
+               "trusted)", (long)sticky);
     const int type = h->last_planned_type;
     out_host[0] = type;
     out_host[1] = r.n;

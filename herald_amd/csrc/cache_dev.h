@@ -106,6 +106,15 @@ static int dmalloc(T **p, size_t count) {
     HA_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 256));
     return 0;
 }
+// Zeroes of a fresh allocation, COMPLETE when the call returns.  hipMemset on device memory is a launch on the null stream
+// that the host does not wait for, and the streams this library runs on are non-blocking ones (no implicit order with the null
+// stream): without the wait the zeroes can land after the first kernel that writes the buffer (a plan header's n_unique
+// went back to 0 that way, one new cache in eight).
+static int dzero(void *p, size_t bytes) {
+    HA_CHECK_HIP(hipMemsetAsync(p, 0, bytes, nullptr));
+    HA_CHECK_HIP(hipStreamSynchronize(nullptr));
+    return 0;
+}
 
 // ---- the planned flow (cache_block.hip) ----
 constexpr int kPlanBlockMax = 16;     // batches per planned block

@@ -1313,7 +1313,9 @@ extern "C" ha_laia *ha_laia_create(const uint64_t *samples_host, int64_t num_sam
         for (size_t i = 0; i < s32.size(); ++i)
             s32[i] = l.samples_host[i] > 0xFFFFFFFEull ? 0xFFFFFFFEu : static_cast<uint32_t>(l.samples_host[i]);
         ok = hipMemcpy(l.d_samples, s32.data(), s32.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && hipMemset(l.d_valid, 0, static_cast<size_t>(l.W) * l.R) == hipSuccess;
+        // (a launch on the null stream the host does not wait for; the scheduler's stream is a non-blocking one)
+        ok = ok && hipMemsetAsync(l.d_valid, 0, static_cast<size_t>(l.W) * l.R, nullptr) == hipSuccess &&
+             hipStreamSynchronize(nullptr) == hipSuccess;
     }
     if (!ok) {
         if (g_err_is_empty())

@@ -38,6 +38,7 @@ struct ApplyMaps {
     // same pass -- push_tab[key,:] += the first destination's new value (the line's gradient after the batch,
     // PSFhandle_embedding.cc:23-27), and the first destination is stored as zeros (Line::zeroGrad, embedding.h:112-118)
     float *push_tab;
+    uint64_t push_rows;      // rows of push_tab (a record whose key lies beyond is not pushed: defensive, see cache_block.hip)
     // DUAL == 2: one record per SORTED POSITION {destination row (both destinations; -1 = skip), key, kPos* flags, occurrence
     // index}: what the rowmap / init / push lookups through upos[p] give, in the round trip that fetches the window itself
     const int4 *pos_item;
@@ -850,8 +851,9 @@ __device__ __forceinline__ bool coop_run(
     if (DUAL == 2) {
         d2.on = (pit.z & kPosTemp) == 0;
         d2.row = maps.dst2 + row * static_cast<uint64_t>(width);
-        d2.push = (pit.z & kPosPush) ? maps.push_tab + static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) * static_cast<uint64_t>(width)
-                                     : nullptr;
+        d2.push = ((pit.z & kPosPush) && static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) < maps.push_rows)
+                      ? maps.push_tab + static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) * static_cast<uint64_t>(width)
+                      : nullptr;
         d2.push2 = (pit.z & kPosVictimPush) ? dst + static_cast<uint64_t>(*maps.victim_row) * static_cast<uint64_t>(width) : nullptr;
     } else if (DUAL && maps.rowmap2) {
         const int r2 = maps.rowmap2[upos[wg0]];
@@ -991,8 +993,9 @@ __device__ __forceinline__ bool apply_body_impl(
     if (DUAL == 2) {
         d2.on = (pit.z & kPosTemp) == 0;
         d2.row = maps.dst2 + row * static_cast<uint64_t>(width);
-        d2.push = (pit.z & kPosPush) ? maps.push_tab + static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) * static_cast<uint64_t>(width)
-                                     : nullptr;
+        d2.push = ((pit.z & kPosPush) && static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) < maps.push_rows)
+                      ? maps.push_tab + static_cast<uint64_t>(static_cast<uint32_t>(pit.y)) * static_cast<uint64_t>(width)
+                      : nullptr;
         d2.push2 = (pit.z & kPosVictimPush) ? dst + static_cast<uint64_t>(*maps.victim_row) * static_cast<uint64_t>(width) : nullptr;
     } else if (DUAL && maps.rowmap2) {
         const int r2 = maps.rowmap2[upos[p]];

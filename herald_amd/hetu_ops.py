@@ -146,6 +146,7 @@ class ParameterServerCommunicateOp:
                 # cross the fabric (PSAgent.h:537-627 / PSFhandle_embedding.cc:5-79)
                 from . import remote_store
                 versions = torch.zeros(store.local_rows, dtype=torch.int64, device=store.table.device)
+                torch.cuda.current_stream(versions.device).synchronize()
                 rstore = remote_store.ShardedStore(p.shape[0], width, store.table.device,
                                                    remote_store.LocalStore(store.table, versions),
                                                    group=store.group, a2a=store._a2a_fn)

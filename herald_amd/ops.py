@@ -642,6 +642,7 @@ class WidePlan:
         L = _lib.load()
         self.capacity, self.device = int(capacity), device
         self.ws = torch.zeros(int(L.ha_qbig_plan_bytes(self.capacity)), dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(device).synchronize()   # (the zero fill: users launch on streams of their own)
         self.buckets = int(L.ha_qbig_buckets(self.capacity))
         self.n = 0
         self._produced_on, self._view = 0, None
@@ -840,6 +841,7 @@ class QueueStepPipeline:
         self.plans = [(WidePlan if self.wide else IndexPlan)(self.capacity, self.device) for _ in range(self.NPLAN)]
         self.queue_bytes = int(L.ha_qstep_queue_bytes(self.capacity, table.shape[1]))
         self.queues = torch.zeros(self.NQUEUE * self.queue_bytes, dtype=torch.uint8, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()   # (the zero fill: the builders run on the side stream)
         # the preparation runs beside the steps: its stream may be given the LOWEST priority (HA_QSIDE_PRIO=low; =high: the highest -- A/B knobs), so that the
         # apply launches win the dispatcher whenever both have workgroups to place
         side_prio = 0

@@ -54,6 +54,7 @@ class LocalStore:
         self.versions = versions
         self._L = _lib.load()
         self._count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()   # (zero fills: the store's calls come on streams of the caller's choice)
         self._plan_ws = None
         self._plan_cap = 0
 
@@ -101,6 +102,7 @@ class HostStore(LocalStore):
         self.copy_stream = stream
         # device-side traffic counters (no host sync on the path): keys synced, rows pulled, lines pushed
         self._acc = torch.zeros(3, dtype=torch.int64, device=device)
+        torch.cuda.current_stream(torch.device(device)).synchronize()
 
     def _on_store_stream(self):
         import contextlib

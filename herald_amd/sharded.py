@@ -255,6 +255,7 @@ class HipEngine:
             fb.meta_dev = torch.zeros(2 + 2 * w, dtype=torch.int32, device=self.device)
             fb.n, fb.ids, fb.shape, fb.routed = 0, None, (0,), False
             blk.slots.append(fb)
+        torch.cuda.current_stream(self.device).synchronize()   # (the zero fills: the routing runs on a side stream)
         return blk
 
     def _frame_ptr(self, t, fb):
