@@ -102,8 +102,13 @@ __global__ __launch_bounds__(1024, 8) void apply_unique_kernel(
         if (len <= kShortRun) {
             short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, true, d2);
         } else {
-            for (int c0 = 0; c0 < width; c0 += kWave)
-                medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, true, d2);
+            if (VEC == 4 && MODE != kModeOpt) {
+                for (int c0 = 0; c0 < width; c0 += 2 * kWave)
+                    medium_pair<MODE>(dst_row, grads, width, c0 + 2 * lane, pv, len, lr, true);
+            } else {
+                for (int c0 = 0; c0 < width; c0 += kWave)
+                    medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, true, d2);
+            }
         }
     }
 }
@@ -228,14 +233,24 @@ __global__ __launch_bounds__(1024, 8) void apply_listed_kernel(
             s_off[i] = cp.meta[8 + i];
         __syncthreads();
     }
+    // Two roles.  A listed item is five dependent trips (header, list, record, occurrence indices, rows) and two barriers, a
+    // wave's keys three trips + one per key; a workgroup that did both in turn took the sum of the two (33.4-36.6 us at
+    // configs[2]'s per-GPU shape: 280 listed keys x 2 slices, 23 k keys).  Now the FIRST workgroups -- one per listed item, at
+    // most half the grid; dispatched first: the long poles -- take the listed items and nothing else, the others the keys, a wave
+    // each.  A listed workgroup fetches the records of all its items in one go and asks for the occurrence indices of the next
+    // item before the rows of the current one.  28.6-31 us in every split tried (1 / 2 / 3 items per listed workgroup, grids of
+    // 512 / 768 / 1,024: docs/EXPERIMENTS.md round 6 section 15) -- what is left is 77 MB as 512-byte reads at random places of
+    // a gradient buffer that comes from DRAM.  Which workgroup does what is a function of the plan's header alone.
+    const int G = static_cast<int>(gridDim.x);
     const long long items = (total != 0u ? static_cast<long long>(total) : L) * nslice;
-    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
-        const int j = static_cast<int>(it % nslice);
-        int li = static_cast<int>(it / nslice), ch = 0, nch = 1;
-        uint32_t q = 0;
-        if (total != 0u) {       // the listed key whose chunk range holds chunk q (offsets ascending, s_off[L] = total)
-            q = static_cast<uint32_t>(it / nslice);
-            int lo = 0, hi = static_cast<int>(L);
+    const int NL = static_cast<int>(min(items, static_cast<long long>(G / 2)));
+    const bool keys_role = static_cast<int>(blockIdx.x) >= NL;
+    if (!keys_role && total != 0u) {
+        // runs beyond kTreeChunk occurrences in chunks (ha_set_tolerance_mode(2)): item = (key, chunk, slice)
+        for (long long it = blockIdx.x; it < items; it += NL) {
+            const int j = static_cast<int>(it % nslice);
+            const uint32_t q = static_cast<uint32_t>(it / nslice);
+            int lo = 0, hi = static_cast<int>(L);      // the listed key whose chunk range holds chunk q (s_off[L] = total)
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
                 if (s_off[mid] <= q)
@@ -243,66 +258,146 @@ __global__ __launch_bounds__(1024, 8) void apply_listed_kernel(
                 else
                     hi = mid;
             }
-            li = lo;
-            ch = static_cast<int>(q - s_off[lo]);
-            nch = static_cast<int>(s_off[lo + 1] - s_off[lo]);
-        }
-        const int u = static_cast<int>(long_list[li]);
-        if (nch > 1) {           // (never with index maps or a second destination: the host leaves cp.meta null then)
+            const int li = lo, ch = static_cast<int>(q - s_off[lo]), nch = static_cast<int>(s_off[lo + 1] - s_off[lo]);
+            const int u = static_cast<int>(long_list[li]);
             const uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
-            if (row < dst_rows)
-                coop_chunk_tree<MODE>(dst + row * static_cast<uint64_t>(width), true, grads, perm, maps, n, lr, seg[u], counts[u],
-                                      width, j, w, reinterpret_cast<float *>(s_apply),
-                                      cp.part + (static_cast<size_t>(s_off[li]) * nslice + static_cast<size_t>(j) * nch) * 64,
-                                      cp.ctr + static_cast<size_t>(li) * nslice + j, ch, nch);
+            if (nch > 1) {       // (never with index maps or a second destination: the host leaves cp.meta null then)
+                if (row < dst_rows)
+                    coop_chunk_tree<MODE>(dst + row * static_cast<uint64_t>(width), true, grads, perm, maps, n, lr, seg[u],
+                                          counts[u], width, j, w, reinterpret_cast<float *>(s_apply),
+                                          cp.part + (static_cast<size_t>(s_off[li]) * nslice + static_cast<size_t>(j) * nch) * 64,
+                                          cp.ctr + static_cast<size_t>(li) * nslice + j, ch, nch);
+            } else if (row < dst_rows) {
+                Second d2{nullptr, false};
+                coop_slices<MODE, false>(dst + row * static_cast<uint64_t>(width), true, d2, grads, perm, maps, n, lr, seg[u],
+                                         counts[u], width, j, nslice, w, reinterpret_cast<float *>(s_apply));
+            }
             __syncthreads();
-            continue;
         }
-        uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(uniq[u]);
-        bool init = true;
-        if (maps.rowmap) {      // destination rows through an index map (ha_apply_mapped): -1 = no destination
-            const int r = maps.rowmap[u];
-            row = r < 0 ? ~0ull : static_cast<uint64_t>(r);
-            if (r >= 0 && maps.dst_init)
-                init = maps.dst_init[r] != 0;
+        return;
+    }
+    if (!keys_role) {
+        constexpr int kRecs = 32;      // records fetched at once (a workgroup has about three items)
+        __shared__ int s_rs[kRecs], s_rl[kRecs], s_ri[kRecs];
+        __shared__ unsigned long long s_rr[kRecs];
+        const int lane = lane_id();
+        for (long long r0 = blockIdx.x; r0 < items; r0 += static_cast<long long>(kRecs) * NL) {
+            __syncthreads();       // (the records of the round before have been read)
+            if (threadIdx.x < kRecs) {
+                const long long it = r0 + static_cast<long long>(threadIdx.x) * NL;
+                int rs = 0, rl = 0, ri = 1;
+                unsigned long long rr = ~0ull;
+                if (it < items) {
+                    const int u = static_cast<int>(long_list[it / nslice]);
+                    rs = seg[u];
+                    rl = counts[u];
+                    rr = MODE == kModeReduce ? static_cast<unsigned long long>(u) : static_cast<unsigned long long>(uniq[u]);
+                    if (maps.rowmap) {      // destination rows through an index map (ha_apply_mapped): -1 = no destination
+                        const int r = maps.rowmap[u];
+                        rr = r < 0 ? ~0ull : static_cast<unsigned long long>(r);
+                        if (r >= 0 && maps.dst_init)
+                            ri = maps.dst_init[r] != 0;
+                    }
+                }
+                s_rs[threadIdx.x] = rs;
+                s_rl[threadIdx.x] = rl;
+                s_ri[threadIdx.x] = ri;
+                s_rr[threadIdx.x] = rr;
+            }
+            __syncthreads();
+            const int cnt = static_cast<int>(min(static_cast<long long>(kRecs), (items - r0 + NL - 1) / NL));
+            // this wave's occurrence indices of the first block of 256 of item k (what coop_tree_sum asks for first)
+            auto first_indices = [&](int k) {
+                const int ks = s_rs[k], kl = s_rl[k];
+                return 16 * w < kl ? perm[min(ks + min(16 * w + (lane & 15), kl - 1), n - 1)] : 0;
+            };
+            int p_next = first_indices(0);
+            for (int k = 0; k < cnt; ++k) {
+                const int j = static_cast<int>((r0 + static_cast<long long>(k) * NL) % nslice);
+                const int ks = s_rs[k], kl = s_rl[k];
+                const uint64_t row = s_rr[k];
+                const bool init = s_ri[k] != 0;
+                const int p_cur = p_next;
+                if (k + 1 < cnt)
+                    p_next = first_indices(k + 1);
+                if (row >= dst_rows)
+                    continue;      // (uniform over the workgroup)
+                float *dst_row = dst + row * static_cast<uint64_t>(width);
+                if (MODE != kModeOpt && maps.tree_from > 0 && kl >= maps.tree_from && (width & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(dst_row) | reinterpret_cast<uintptr_t>(grads)) & 15) == 0) {
+                    // (coop_slices' own condition for the tree; ends with a barrier)
+                    coop_slice_tree<MODE>(dst_row, init, grads, perm, maps, n, lr, ks, kl, width, j, w,
+                                          reinterpret_cast<float *>(s_apply), p_cur, true);
+                } else {
+                    Second d2{nullptr, false};
+                    if (MODE == kModeOpt)
+                        opt_rows(d2, maps, row, width);
+                    coop_slices<MODE, false>(dst_row, init, d2, grads, perm, maps, n, lr, ks, kl, width, j, nslice, w,
+                                             reinterpret_cast<float *>(s_apply));
+                    __syncthreads();
+                }
+            }
         }
-        if (row < dst_rows) {
+        return;
+    }
+    // The keys below kLongRun, one wave per key, the waves striding over them.  A key costs three dependent trips (its record,
+    // its occurrence indices, the rows); a wave has several keys (22 k keys over 8,192 waves at configs[2]'s per-GPU shape), so
+    // the records of ALL the wave's keys of a round come in one trip -- lane k holds those of its k-th key -- and the
+    // occurrence indices of the next key are asked for before the rows of the current one: from the second key on a key costs
+    // the rows' trip alone.  The arithmetic per key is what it was.
+    const int U = static_cast<int>(hdr->n_unique);
+    const int lane = lane_id();
+    const int nwaves = (G - NL) * 16;
+    for (long long ub = (static_cast<int>(blockIdx.x) - NL) * 16 + w; ub < U; ub += static_cast<long long>(nwaves) * kWave) {
+        const long long uk = ub + static_cast<long long>(lane) * nwaves;
+        int m_s = 0, m_len = kLongRun, m_r = -1, m_init = 1;
+        uint32_t m_key = 0u;
+        if (uk < U) {
+            m_s = seg[uk];
+            m_len = counts[uk];
+            m_key = uniq[uk];
+            if (maps.rowmap) {
+                m_r = maps.rowmap[uk];
+                if (m_r >= 0 && maps.dst_init)
+                    m_init = maps.dst_init[m_r] != 0;
+            }
+        }
+        const int cnt = static_cast<int>(min(static_cast<long long>(kWave), (U - ub + nwaves - 1) / nwaves));
+        int pv_next = perm[min(__builtin_amdgcn_readlane(m_s, 0) + lane, n - 1)];
+        for (int k = 0; k < cnt; ++k) {
+            const int u = static_cast<int>(ub) + k * nwaves;
+            const int len = __builtin_amdgcn_readlane(m_len, k);
+            const int pv = pv_next;   // lanes 0 .. len-1: the run's occurrence indices
+            if (k + 1 < cnt)
+                pv_next = perm[min(__builtin_amdgcn_readlane(m_s, k + 1) + lane, n - 1)];
+            if (len >= kLongRun)
+                continue;
+            const uint32_t key = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m_key), k));
+            uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(key);
+            bool init = true;
+            if (maps.rowmap) {
+                const int r = __builtin_amdgcn_readlane(m_r, k);
+                row = r < 0 ? ~0ull : static_cast<uint64_t>(r);
+                if (r >= 0 && maps.dst_init)
+                    init = __builtin_amdgcn_readlane(m_init, k) != 0;
+            }
+            if (row >= dst_rows)
+                continue;  // out-of-range id / no destination: ignored
+            float *dst_row = dst + row * static_cast<uint64_t>(width);
             Second d2{nullptr, false};
             if (MODE == kModeOpt)
                 opt_rows(d2, maps, row, width);
-            coop_slices<MODE, false>(dst + row * static_cast<uint64_t>(width), init, d2, grads, perm, maps, n, lr,
-                                     seg[u], counts[u], width, j, nslice, w, reinterpret_cast<float *>(s_apply));
-        }
-        __syncthreads();
-    }
-    const int U = static_cast<int>(hdr->n_unique);
-    const int lane = lane_id();
-    const int nwaves = gridDim.x * 16;
-    for (int u = blockIdx.x * 16 + w; u < U; u += nwaves) {
-        const int s = uniform(seg[u]), len = uniform(counts[u]);
-        if (len >= kLongRun)
-            continue;
-        const uint32_t key = uniform(uniq[u]);
-        uint64_t row = MODE == kModeReduce ? static_cast<uint64_t>(u) : static_cast<uint64_t>(key);
-        bool init = true;
-        if (maps.rowmap) {
-            const int r = uniform(maps.rowmap[u]);
-            row = r < 0 ? ~0ull : static_cast<uint64_t>(r);
-            if (r >= 0 && maps.dst_init)
-                init = maps.dst_init[r] != 0;
-        }
-        if (row >= dst_rows)
-            continue;  // out-of-range id / no destination: ignored
-        float *dst_row = dst + row * static_cast<uint64_t>(width);
-        const int pv = perm[min(s + lane, n - 1)];   // lanes 0 .. len-1: the run's occurrence indices
-        Second d2{nullptr, false};
-        if (MODE == kModeOpt)
-            opt_rows(d2, maps, row, width);
-        if (len <= kShortRun) {
-            short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, init, d2);
-        } else {
-            for (int c0 = 0; c0 < width; c0 += kWave)
-                medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, init, d2);
+            if (len <= kShortRun) {
+                short_row<MODE, VEC, false>(dst_row, grads, width, pv, 0, len, lr, init, d2);
+            } else {
+                if (VEC == 4 && MODE != kModeOpt) {
+                    for (int c0 = 0; c0 < width; c0 += 2 * kWave)
+                        medium_pair<MODE>(dst_row, grads, width, c0 + 2 * lane, pv, len, lr, init);
+                } else {
+                    for (int c0 = 0; c0 < width; c0 += kWave)
+                        medium_slice<MODE, false>(dst_row, grads, width, c0 + lane, pv, 0, len, lr, init, d2);
+                }
+            }
         }
     }
 }
@@ -417,12 +512,13 @@ int apply_by_unique(float *dst, int64_t dst_rows, int64_t width, void *plan_ws, 
         // the chunked finish (plan.hip) left the list of long keys in keys_alt / header word 0
         // (grids of 448 / 384 / 256 workgroups, to leave slots to a sort running beside it on another stream:
         // 57.8 / 57.2 / 59.0 us alone against 52.5 us, and no faster together -- tools/cfgc_bench.py)
+        const dim3 grid2(1024);      // (apply_listed_kernel: up to 512 workgroups of listed items in front of 512 of keys)
         if (vec_ok)
-            hipLaunchKernelGGL((apply_listed_kernel<MODE, 4>), grid, block, cp.meta ? kListedLdsBytes : kApplyLdsBytes, stream,
+            hipLaunchKernelGGL((apply_listed_kernel<MODE, 4>), grid2, block, cp.meta ? kListedLdsBytes : kApplyLdsBytes, stream,
                                dst, (uint64_t)dst_rows, (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads,
                                lr, p.keys_alt, maps, cp);
         else
-            hipLaunchKernelGGL((apply_listed_kernel<MODE, 1>), grid, block, kApplyLdsBytes, stream, dst,
+            hipLaunchKernelGGL((apply_listed_kernel<MODE, 1>), grid2, block, kApplyLdsBytes, stream, dst,
                                (uint64_t)dst_rows, (int)width, p.hdr, p.uniq, p.seg, p.counts, p.perm, (int)n, grads,
                                lr, p.keys_alt, maps, cp);
         HA_LAUNCH_CHECK();

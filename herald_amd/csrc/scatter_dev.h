@@ -427,6 +427,51 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
     }
 }
 
+// The same for a slice of 128 columns, TWO per lane (the applies of a finished plan, whose waves take a key each): a
+// 128-float row is one pass instead of two dependent ones -- one 512-byte request per occurrence instead of two of 256 --, and
+// the destination's old value is asked for in front of the first occurrence rows instead of behind the last.  The chain per
+// column is medium_slice's.  `col` = first of the lane's two columns (even; width % 4 == 0, 8-byte aligned rows: the
+// vectorised kernels); pv: lanes 0 .. len - 1 hold the occurrence indices.  Not for kModeOpt.
+template <int MODE>
+__device__ __forceinline__ void medium_pair(float *__restrict__ dst_row, const float *__restrict__ grads, int width, int col,
+                                            int pv, int len, float lr, bool init) {
+    const bool live = col < width;
+    const int lcol = live ? col : 0;
+    float2 old{0.f, 0.f};
+    if ((MODE == kModeSgd && init) || MODE == kModePush)
+        old = *reinterpret_cast<const float2 *>(dst_row + lcol);
+    float2 g[kChunk];
+    float ax = 0.f, ay = 0.f;
+    bool first = true;
+    for (int t0 = 0; t0 < len; t0 += kChunk) {
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) {
+            const int idx = __builtin_amdgcn_readlane(pv, min(t0 + t, len - 1));
+            g[t] = *reinterpret_cast<const float2 *>(grads + static_cast<size_t>(idx) * width + lcol);
+        }
+        if (first && MODE == kModeSgd) {
+            ax = old.x;
+            ay = old.y;
+        }
+        first = false;
+        const int cnt = len - t0;
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) {
+            const float nx = step<MODE>(ax, g[t].x, lr), ny = step<MODE>(ay, g[t].y, lr);
+            ax = (t < cnt) ? nx : ax;
+            ay = (t < cnt) ? ny : ay;
+        }
+    }
+    if (live) {
+        if (MODE == kModePush) {
+            ax = __fadd_rn(old.x, ax);
+            ay = __fadd_rn(old.y, ay);
+        }
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(float2v{ax, ay}, reinterpret_cast<float2v *>(dst_row + col));
+    }
+}
+
 // ---- long runs (L >= kLongRun): the workgroups that lie wholly inside the run ---------------------
 // A compute unit pulls only ~25 GB/s from HBM and one wave keeps at most 63 loads in flight, so a run
 // of hundreds of occurrence rows is neither streamed by one wave nor by one compute unit.  The run
@@ -457,17 +502,26 @@ __device__ __forceinline__ float chain_step(float acc, float m) {
 // s_part = 16 x 64 floats.  Called by all 16 waves; needs width % 4 == 0 and 16-byte aligned rows.
 // the tree's sum over the occurrences [lo, hi) of the run at s: lr * g summed as described above, complete in every lane
 // (for its column quad).  Ends with the workgroup's partials consumed (a barrier precedes any reuse of s_part by the caller).
+// first / have_first: this wave's occurrence indices of the block at `lo`, fetched by the caller ahead of time (perm values, before
+// any valmap).
 __device__ __forceinline__ float4v coop_tree_sum(const float *__restrict__ grads, const int32_t *__restrict__ perm,
                                                  const ApplyMaps &maps, int n, float lr, int s, int lo, int hi, int width,
-                                                 int col, int w, float *s_part) {
+                                                 int col, int w, float *s_part, int first = 0, bool have_first = false) {
     const int lane = lane_id();
     const int r = lane >> 4, c4 = lane & 15;
     float4v p{0.f, 0.f, 0.f, 0.f};
+    // (the occurrence indices of the block after the current one are asked for before the current block's rows: a run of
+    // thousands costs one trip per block of 256, not two)
+    int p_next = 0;
+    if (lo + 16 * w < hi)
+        p_next = have_first ? first : perm[min(s + min(lo + 16 * w + (lane & 15), hi - 1), n - 1)];
     for (int base = lo; base < hi; base += 256) {
         const int mine = base + 16 * w;   // this wave's first occurrence of the block
         if (mine >= hi)
             break;   // wave-uniform; no barrier inside the loop
-        int pidx = perm[min(s + min(mine + (lane & 15), hi - 1), n - 1)];
+        int pidx = p_next;
+        if (mine + 256 < hi)
+            p_next = perm[min(s + min(mine + 256 + (lane & 15), hi - 1), n - 1)];
         if (maps.valmap)
             pidx = maps.valmap[pidx];
         float4v g[4];
@@ -508,7 +562,8 @@ __device__ __forceinline__ float4v coop_tree_sum(const float *__restrict__ grads
 template <int MODE>
 __device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, bool init, const float *__restrict__ grads,
                                                 const int32_t *__restrict__ perm, const ApplyMaps &maps, int n, float lr,
-                                                int s, int len, int width, int slice, int w, float *s_part) {
+                                                int s, int len, int width, int slice, int w, float *s_part, int first = 0,
+                                                bool have_first = false) {
     const int lane = lane_id();
     const int r = lane >> 4, c4 = lane & 15;
     const int col0 = slice * kWave;
@@ -517,7 +572,7 @@ __device__ __forceinline__ void coop_slice_tree(float *__restrict__ dst_row, boo
     float4v cur{0.f, 0.f, 0.f, 0.f};
     if (MODE != kModeReduce && init)
         cur = *reinterpret_cast<const float4v *>(dst_row + col);
-    const float4v total = coop_tree_sum(grads, perm, maps, n, lr, s, 0, len, width, col, w, s_part);
+    const float4v total = coop_tree_sum(grads, perm, maps, n, lr, s, 0, len, width, col, w, s_part, first, have_first);
     float4v nv;
 #pragma unroll
     for (int k = 0; k < 4; ++k)

@@ -10,14 +10,15 @@ rows, width, bs = 4_000_000, int(os.environ.get("WIDTH", "128")), 4096
 L = _lib.load()
 table = torch.zeros((rows, width), device=dev)
 plans, grads = [], []
-for b in range(8):
+NBUF = int(os.environ.get("NBUF", "8"))      # batches in rotation (8 x 54.5 MB of gradients: beyond the 256 MB Infinity Cache)
+for b in range(NBUF):
     ids = torch.from_numpy((synth.criteo_batch(bs, 100 + b).reshape(-1) % rows).astype(np.float32)).to(dev)
     plans.append(ops.IndexPlan(ids.numel(), dev).build(ids))
     grads.append(torch.randn((ids.numel(), width), device=dev))
 n = plans[0].n
 def run(reps):
     for r in range(reps):
-        p, g = plans[r % 8], grads[r % 8]
+        p, g = plans[r % NBUF], grads[r % NBUF]
         _lib.check(L.ha_push_apply_scaled_finished(ctypes.c_void_p(table.data_ptr()), rows, width, ctypes.c_void_p(p.ws.data_ptr()), n,
                                                    ctypes.c_void_p(g.data_ptr()), ctypes.c_float(-0.01), None), "push")
 for mode in (0, 1, 2):
