@@ -237,6 +237,7 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
                                             bool resolve = false) {
     const int lane = lane_id();
     Vec<VEC> acc[VB], g[kShortRun][VB], acc2[DUAL ? VB : 1];
+    Vec<VEC> cur[MODE == kModePush ? VB : 1];   // push: the destination's old value, requested in front of the occurrence rows
     int col[VB], lcol[VB];
 #pragma unroll
     for (int b = 0; b < VB; ++b) {
@@ -245,6 +246,8 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
         acc[b].zero();
         if (MODE == kModeSgd && init)  // wave-uniform
             acc[b].load(dst_row + lcol[b]);
+        if (MODE == kModePush)
+            cur[b].load(dst_row + lcol[b]);
         if (DUAL && d2.on)
             acc2[b].load(d2.row + lcol[b]);
     }
@@ -276,11 +279,9 @@ __device__ __forceinline__ void short_block(float *__restrict__ dst_row,
     for (int b = 0; b < VB; ++b) {
         if (col[b] < width) {
             if (MODE == kModePush) {
-                Vec<VEC> cur;
-                cur.load(dst_row + lcol[b]);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
-                    acc[b].set(k, __fadd_rn(cur.get(k), acc[b].get(k)));
+                    acc[b].set(k, __fadd_rn(cur[b].get(k), acc[b].get(k)));
             }
             if (DUAL == 2 && d2.push)
                 push_epilogue<VEC>(d2.push, col[b], acc[b], d2.push2);
@@ -350,9 +351,11 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
                                              uint4 pe = uint4{0, 0, 0, 0}, Fwd *fw = nullptr, bool resolve = false) {
     const bool live = col < width;
     const int lcol = live ? col : 0;
-    float acc = 0.f, acc2 = 0.f;
+    float acc = 0.f, acc2 = 0.f, old = 0.f;
     if (MODE == kModeSgd && init)
         acc = dst_row[lcol];
+    if (MODE == kModePush)      // (requested in front of the occurrence rows, not behind the last of them)
+        old = dst_row[lcol];
     if (DUAL && d2.on)
         acc2 = d2.row[lcol];
     auto load_chunk = [&](float(&g)[kChunk], int t0) {
@@ -397,7 +400,7 @@ __device__ __forceinline__ void medium_slice(float *__restrict__ dst_row,
         consume(ga, len - 2 * kChunk);
     if (live) {
         if (MODE == kModePush)
-            acc = __fadd_rn(dst_row[col], acc);
+            acc = __fadd_rn(old, acc);
         if (DUAL == 2 && d2.push) {
             float pr = __fadd_rn(d2.push[col], acc);
             if (d2.push2)
@@ -680,9 +683,11 @@ __device__ __forceinline__ void coop_slices(
         const bool chain = w < sg;
         const int ccol = (j + (g0 + (chain ? w : 0)) * workers) * kWave + lane;
         const bool clive = chain && ccol < width;
-        float acc = 0.f, acc2 = 0.f;
+        float acc = 0.f, acc2 = 0.f, old = 0.f;
         if (MODE == kModeSgd && init && chain)
             acc = dst_row[ccol < width ? ccol : 0];
+        if (MODE == kModePush && chain)      // (in front of the occurrence rows, not behind the chain)
+            old = dst_row[ccol < width ? ccol : 0];
         if (DUAL && d2.on && chain)
             acc2 = d2.row[ccol < width ? ccol : 0];
         float4v *s_wr = reinterpret_cast<float4v *>(s_m) +
@@ -723,7 +728,7 @@ __device__ __forceinline__ void coop_slices(
         // the accumulators' initial loads are older than every row request: resolve them here, or the
         // chain's first use makes the compiler drain the in-order load counter inside the loop and the
         // rows requested for the next block are waited for before the chain instead of behind it
-        asm volatile("" ::"v"(acc), "v"(acc2));
+        asm volatile("" ::"v"(acc), "v"(acc2), "v"(old));
         for (int base = 0; base < len; base += tlen) {
             if (loader) {
 #pragma unroll
@@ -770,7 +775,7 @@ __device__ __forceinline__ void coop_slices(
         }
         if (clive) {
             if (MODE == kModePush)
-                acc = __fadd_rn(dst_row[ccol], acc);
+                acc = __fadd_rn(old, acc);
             if (DUAL == 2 && d2.push) {
                 float pr = __fadd_rn(d2.push[ccol], acc);
                 if (d2.push2)
