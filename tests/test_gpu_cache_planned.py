@@ -415,3 +415,33 @@ def test_pick_side_stream_returns_a_cached_stream_of_the_priority(dev):
         x.add_(1)
     a.synchronize()
     assert float(x.sum()) == 1024.0
+
+
+@pytest.mark.parametrize("policy", ["lru", "lfuopt"])
+def test_first_planned_block_of_fresh_caches_reads_written_plans(dev, policy):
+    """Regression: the zero fill of a fresh plan workspace's header (a null-stream launch the host does not wait for) landed
+    after the first plan build on the non-blocking planning stream and wiped n_unique -- the bookkeeping of a NEW cache's first
+    block saw an empty batch, the row launches read items nobody wrote (about one new cache in eight; docs/EXPERIMENTS.md
+    round 6 section 14).  Many fresh caches, each planning its first block at once: every lookup returns the store's rows and the
+    sticky word stays clear."""
+    limit, rows, width, n = 5000, 200000, 32, 1664
+    rng = np.random.default_rng(7)
+    table = torch.from_numpy(rng.standard_normal((rows, width), dtype=np.float32)).to(dev)
+    cls = {"lru": hcache.LRUCache, "lfuopt": hcache.LFUOptCache}[policy]
+    keys = [torch.from_numpy(_draw(rng, n, rows, True).astype(np.float32)).to(dev) for _ in range(4)]
+    out = torch.empty((n, width), device=dev)
+    grad = torch.zeros((n, width), device=dev)
+    torch.cuda.synchronize()
+    for trial in range(12):
+        versions = torch.zeros(rows, dtype=torch.int64, device=dev)
+        gpu = cls(limit, rows, width, node_id=0, max_batch=n, device=dev)
+        gpu.bind_store(table, versions)
+        gpu.plan_block(keys)
+        for k in keys:
+            gpu.embedding_lookup_planned(out)
+            want = table[k.to(torch.int64)]
+            assert torch.equal(out, want), "trial %d: a planned lookup of a fresh cache" % trial
+            gpu.embedding_update_planned(grad)
+        st = gpu.state()          # (raises when a launch left its sticky word)
+        assert 0 < st["size"] <= limit
+        del gpu
