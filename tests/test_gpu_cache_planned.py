@@ -423,7 +423,8 @@ def test_first_planned_block_of_fresh_caches_reads_written_plans(dev, policy):
     after the first plan build on the non-blocking planning stream and wiped n_unique -- the bookkeeping of a NEW cache's first
     block saw an empty batch, the row launches read items nobody wrote (about one new cache in eight; docs/EXPERIMENTS.md
     round 6 section 14).  Many fresh caches, each planning its first block at once: every lookup returns the store's rows and the
-    sticky word stays clear."""
+    sticky word stays clear.  (At this size the race did not show with the wait removed -- bench.py's cache tier at 1 M rows
+    did, three runs in 28; this test holds the first block of a fresh cache, the wait is held by code review.)"""
     limit, rows, width, n = 5000, 200000, 32, 1664
     rng = np.random.default_rng(7)
     table = torch.from_numpy(rng.standard_normal((rows, width), dtype=np.float32)).to(dev)
