@@ -230,7 +230,13 @@ int ha_scale_f32(float *values, int64_t n, float scale, ha_stream_t stream);
  * A plan lives in a caller-provided device workspace of ha_plan_bytes(n) bytes
  * laid out as struct ha_plan_view describes; it is valid until the workspace is
  * reused.  n_unique is produced on the device (plan header) so that no host
- * sync is needed between plan and the kernels that consume it.               */
+ * sync is needed between plan and the kernels that consume it.
+ * The first 256 bytes of a workspace (the header: n_unique and sticky flag
+ * words) must be ZERO before its first use, and the zero fill must have
+ * COMPLETED before the first call that names the workspace on another stream:
+ * hipMemset / hipMemsetAsync on the null stream is not waited for by the host
+ * and is not ordered with non-blocking streams -- synchronise the null stream
+ * (or zero on the stream of the first call).  A late fill wipes n_unique.    */
 typedef struct {
     int64_t n;           /* number of ids */
     int64_t *n_unique;   /* device scalar (first word of the workspace) */
