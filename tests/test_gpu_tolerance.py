@@ -117,7 +117,10 @@ def test_large_batch_by_unique_key(dev, tolerance_chunked, width):
 
 
 @pytest.mark.parametrize("n,width,runs", [(40000, 128, (257, 256, 513, 3000, 64, 48, 47)), (50000, 32, (9000, 300)),
-                                          (37000, 256, (1024, 1025)), (60000, 128, ())])
+                                          (37000, 256, (1024, 1025)), (60000, 128, ()),
+                                          # medium runs (4..47: two columns per lane, 128 per pass) on rows that are not a
+                                          # multiple of a pass
+                                          (40000, 192, (47, 20, 9, 5, 4)), (38000, 96, (30, 4, 46))])
 def test_chunked_runs_of_a_finished_plan(dev, tolerance_chunked, n, width, runs):
     """The chunking rule at its edges (256 / 257 occurrences, a partial last chunk, no long run at all), sgd and push."""
     rows = 90000
