@@ -244,7 +244,12 @@ __global__ __launch_bounds__(1024, 8) void apply_listed_kernel(
     const int G = static_cast<int>(gridDim.x);
     const long long items = (total != 0u ? static_cast<long long>(total) : L) * nslice;
     const int NL = static_cast<int>(min(items, static_cast<long long>(G / 2)));
+    // (as many workgroups of keys as the chip holds at once, whatever NL is: with few listed items a second round of
+    // workgroups would pay the three leading trips twice)
+    const int NK = min(G - NL, G / 2);
     const bool keys_role = static_cast<int>(blockIdx.x) >= NL;
+    if (static_cast<int>(blockIdx.x) >= NL + NK)
+        return;
     if (!keys_role && total != 0u) {
         // runs beyond kTreeChunk occurrences in chunks (ha_set_tolerance_mode(2)): item = (key, chunk, slice)
         for (long long it = blockIdx.x; it < items; it += NL) {
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(1024, 8) void apply_listed_kernel(
     // the rows' trip alone.  The arithmetic per key is what it was.
     const int U = static_cast<int>(hdr->n_unique);
     const int lane = lane_id();
-    const int nwaves = (G - NL) * 16;
+    const int nwaves = NK * 16;
     for (long long ub = (static_cast<int>(blockIdx.x) - NL) * 16 + w; ub < U; ub += static_cast<long long>(nwaves) * kWave) {
         const long long uk = ub + static_cast<long long>(lane) * nwaves;
         int m_s = 0, m_len = kLongRun, m_r = -1, m_init = 1;

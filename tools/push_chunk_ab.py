@@ -12,7 +12,10 @@ table = torch.zeros((rows, width), device=dev)
 plans, grads = [], []
 NBUF = int(os.environ.get("NBUF", "8"))      # batches in rotation (8 x 54.5 MB of gradients: beyond the 256 MB Infinity Cache)
 for b in range(NBUF):
-    ids = torch.from_numpy((synth.criteo_batch(bs, 100 + b).reshape(-1) % rows).astype(np.float32)).to(dev)
+    if os.environ.get("UNIFORM") == "1":      # no long runs at all: every key by a wave of the keys' role
+        ids = torch.from_numpy(np.random.default_rng(b).integers(0, rows, size=bs * 26).astype(np.float32)).to(dev)
+    else:
+        ids = torch.from_numpy((synth.criteo_batch(bs, 100 + b).reshape(-1) % rows).astype(np.float32)).to(dev)
     plans.append(ops.IndexPlan(ids.numel(), dev).build(ids))
     grads.append(torch.randn((ids.numel(), width), device=dev))
 n = plans[0].n
